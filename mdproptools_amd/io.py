@@ -1,0 +1,215 @@
+"""
+LAMMPS text readers for the hot path: dump frames and thermo logs.
+
+The reference takes these from a third-party package that is not vendored
+(`pymatgen.io.lammps.outputs.parse_lammps_dumps` / `parse_lammps_log`; call
+sites /root/reference/mdproptools/structural/rdf_cn.py:176,260,
+dynamical/diffusion.py:75-77,172, dynamical/conductivity.py:87,
+dynamical/viscosity.py:211, utilities/log.py:21). No arithmetic of the hot path
+lives there, only parsing, so this module restates the observable behaviour the
+call sites rely on:
+
+* files are matched with glob and, when the pattern has a ``*``, ordered by the
+  integer the ``*`` stands for;
+* a frame starts at ``ITEM: TIMESTEP``; it carries ``timestep`` (int),
+  ``natoms`` (int), ``box`` (bounds + optional tilt) and ``data`` (a
+  ``pandas.DataFrame`` whose columns are the names after ``ITEM: ATOMS``,
+  parsed by pandas' whitespace reader so every float is the same correctly
+  rounded double the reference sees);
+* ``box.bounds[k] = [lo, hi]`` and ``box.to_lattice().lengths`` gives the edge
+  lengths (``hi - lo`` for an orthogonal box);
+* a log yields one DataFrame per ``run`` (the thermo block between the memory
+  usage line and ``Loop time of``).
+
+``read_dump_arrays`` is the fast path used by the drop-in layer when it only
+needs SoA float64 planes (it skips the DataFrame entirely).
+"""
+
+import glob
+import io as _io
+import re
+
+import numpy as np
+import pandas as pd
+
+
+class _Lattice:
+    """Minimal stand-in for the lattice object `box.to_lattice()` returns."""
+
+    def __init__(self, matrix):
+        self.matrix = np.asarray(matrix, dtype=np.float64)
+
+    @property
+    def lengths(self):
+        # |row| of the cell matrix; for a diagonal matrix sqrt(a*a) == |a| exactly.
+        return tuple(np.sqrt(np.sum(self.matrix ** 2, axis=1)).tolist())
+
+    @property
+    def volume(self):
+        return float(abs(np.linalg.det(self.matrix)))
+
+
+class LammpsBox:
+    def __init__(self, bounds, tilt=None):
+        self.bounds = [list(map(float, b)) for b in bounds]
+        self.tilt = None if tilt is None else [float(t) for t in tilt]
+
+    def to_lattice(self):
+        (xlo, xhi), (ylo, yhi), (zlo, zhi) = self.bounds
+        xy, xz, yz = self.tilt if self.tilt is not None else (0.0, 0.0, 0.0)
+        return _Lattice(
+            [[xhi - xlo, 0.0, 0.0], [xy, yhi - ylo, 0.0], [xz, yz, zhi - zlo]]
+        )
+
+    @property
+    def volume(self):
+        m = self.to_lattice().matrix
+        return float(m[0, 0] * m[1, 1] * m[2, 2])
+
+
+class LammpsDump:
+    def __init__(self, timestep, natoms, box, data):
+        self.timestep = timestep
+        self.natoms = natoms
+        self.box = box
+        self.data = data
+
+    @classmethod
+    def from_lines(cls, lines):
+        timestep = int(lines[1])
+        natoms = int(lines[3])
+        header = lines[4].split()
+        rows = [lines[5].split(), lines[6].split(), lines[7].split()]
+        triclinic = "xy" in header
+        bounds = np.array([[float(v) for v in r[:2]] for r in rows])
+        tilt = None
+        if triclinic:
+            tilt = [float(r[2]) for r in rows]
+            xy, xz, yz = tilt
+            # LAMMPS writes the bounding box of a tilted cell; undo that.
+            bounds[0, 0] -= min(0.0, xy, xz, xy + xz)
+            bounds[0, 1] -= max(0.0, xy, xz, xy + xz)
+            bounds[1, 0] -= min(0.0, yz)
+            bounds[1, 1] -= max(0.0, yz)
+        box = LammpsBox(bounds.tolist(), tilt)
+        columns = lines[8].replace("ITEM: ATOMS", "").split()
+        body = "\n".join(lines[9:])
+        data = pd.read_csv(_io.StringIO(body), names=columns, sep=r"\s+")
+        return cls(timestep, natoms, box, data)
+
+
+def _sorted_matches(file_pattern):
+    files = glob.glob(file_pattern)
+    if len(files) > 1 and "*" in file_pattern:
+        rx = re.compile(
+            ".*" + re.escape(file_pattern).replace(r"\*", "([0-9]+)")
+        )
+
+        def key(f):
+            m = rx.match(f)
+            return int(m.group(1)) if m else 0
+
+        files = sorted(files, key=key)
+    return files
+
+
+def _iter_frames(fname):
+    frame = []
+    with open(fname, "rt") as fh:
+        for line in fh:
+            if line.startswith("ITEM: TIMESTEP"):
+                if frame:
+                    yield frame
+                frame = [line.rstrip("\n")]
+            elif frame:
+                frame.append(line.rstrip("\n"))
+    if frame:
+        yield frame
+
+
+def parse_lammps_dumps(file_pattern):
+    """Generator of `LammpsDump`, one per frame, files in numeric order."""
+    for fname in _sorted_matches(file_pattern):
+        for frame in _iter_frames(fname):
+            yield LammpsDump.from_lines(frame)
+
+
+_LOG_BEGIN = ("Memory usage per processor =", "Per MPI rank memory allocation")
+_LOG_END = "Loop time of"
+
+
+def parse_lammps_log(filename="log.lammps"):
+    """List of thermo DataFrames, one per `run` found in a LAMMPS log."""
+    with open(filename, "rt") as fh:
+        lines = fh.readlines()
+    runs = []
+    start = None
+    for i, line in enumerate(lines):
+        if line.startswith(_LOG_BEGIN):
+            start = i + 1
+        elif line.startswith(_LOG_END) and start is not None:
+            runs.append((start, i))
+            start = None
+    frames = []
+    for lo, hi in runs:
+        block = [ln for ln in lines[lo:hi] if not ln.startswith("WARNING")]
+        if not block:
+            continue
+        df = pd.read_csv(_io.StringIO("".join(block)), sep=r"\s+")
+        frames.append(df)
+    return frames
+
+
+def read_dump_arrays(file_pattern, columns, sort_by_id=True):
+    """
+    Read every frame matching `file_pattern` into SoA float64 planes.
+
+    Returns (timesteps int64[F], bounds float64[F,3,2], planes float64[F,C,N])
+    with atoms ordered by ascending id in every frame (what the reference gets
+    from `sort_values("id")`, rdf_cn.py:192, diffusion.py:176). Values go
+    through pandas' reader so they are bit-identical to `parse_lammps_dumps`.
+    """
+    steps, bounds, planes = [], [], []
+    for dump in parse_lammps_dumps(file_pattern):
+        df = dump.data
+        if sort_by_id:
+            df = df.sort_values("id")
+        planes.append(
+            np.ascontiguousarray(df[list(columns)].to_numpy(dtype=np.float64).T)
+        )
+        steps.append(dump.timestep)
+        bounds.append(dump.box.bounds)
+    return (
+        np.asarray(steps, dtype=np.int64),
+        np.asarray(bounds, dtype=np.float64),
+        np.stack(planes) if planes else np.zeros((0, len(columns), 0)),
+    )
+
+
+def write_dump(path, timestep, bounds, columns, table, fmt=None):
+    """
+    Write one LAMMPS-style text frame (used by tests and the synthetic generator).
+
+    With fmt=None every float is written as its shortest round-trip decimal
+    (`repr`), so a table that was parsed from a LAMMPS dump with <= 15
+    significant digits per field is written back as the same digits and parses
+    to the same doubles again (pandas' default float reader is only correctly
+    rounded for short mantissas; longer ones can come back 1 ulp off).
+    """
+    table = np.asarray(table)
+    with open(path, "wt") as fh:
+        fh.write("ITEM: TIMESTEP\n%d\n" % int(timestep))
+        fh.write("ITEM: NUMBER OF ATOMS\n%d\n" % table.shape[0])
+        fh.write("ITEM: BOX BOUNDS pp pp pp\n")
+        for lo, hi in bounds:
+            fh.write("%.16e %.16e\n" % (lo, hi))
+        fh.write("ITEM: ATOMS " + " ".join(columns) + " \n")
+        int_cols = {"id", "mol", "type", "ix", "iy", "iz"}
+        for row in table:
+            fh.write(
+                " ".join(
+                    ("%d" % int(v)) if c in int_cols else (repr(float(v)) if fmt is None else fmt % v)
+                    for c, v in zip(columns, row)
+                )
+                + " \n"
+            )
