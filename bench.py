@@ -1,0 +1,220 @@
+#!/usr/bin/env python
+"""
+bench.py — throughput of the RDF hot path (atom-pairs/s) on N GPUs of one node.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step is one pass of `_rdf_loop` (structural/rdf_cn.py:72-97 of the reference) over one batch of
+synthetic frames that are already resident in HBM: BASELINE.json configs[1] — 10 000 atoms x 200
+frames, cubic box L = 50 A, 4 atom types, all 10 type pairs, r_cut 20 A, 400 bins. For N > 1 every
+rank owns its own 200 frames (weak scaling) and the frame-summed uint64 histograms are
+all-reduced over RCCL in every step, inside the timed region.
+
+Rank 0 prints ONE JSON line. Extra keys: `roofline` (dominant kernel, measured with HIP events on the
+launch stream inside the library), `cpu_baseline` (oracle/cpu_ref.c on the host cores, bounded
+sample), `msd` (frame-pairs/s of the single-origin MSD kernel, HBM-bound, reported beside the RDF
+number because BASELINE.json's metric names both).
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+FP64_NONFUSED_PEAK = 39.3e12  # 256 CU x 128 lanes x 2.4 GHz / 2 (FMA is forbidden by parity)
+HBM_PEAK = 8.0e12             # spec, /opt/skills/guides/MI355X_MICROARCH.md
+OPS_PER_PAIR = 18             # SURVEY.md §8d algorithmic FP64 ops per atom pair
+
+
+def cpu_baseline(cfg, types, rel, n_sample_frames):
+    """oracle/cpu_ref.c (single thread, -O2 -ffp-contract=off) on the same workload, bounded sample."""
+    from oracle import cref
+    from mdproptools_amd import synth
+
+    cref.build()
+    n = cfg["n_atoms"]
+    xyz = synth.rdf_frames(n, range(n_sample_frames), cfg["box_len"], cfg["seed_offset"])
+    L = [cfg["box_len"]] * 3
+    t0 = time.perf_counter()
+    for f in range(n_sample_frames):
+        cref.rdf_pairs(xyz[f], types, rel, L, cfg["r_cut"] ** 2, cfg["bin_size"], 400)
+    dt = time.perf_counter() - t0
+    pairs = n_sample_frames * n * (n - 1) // 2
+    return {
+        "value": pairs / dt, "unit": "atom-pairs/s", "cores": 1, "kind": "port",
+        "sample": "%d of %d frames of the same workload (cost is linear in frames), %.1f s, "
+                  "oracle/cpu_ref.c gcc -O2 single thread; host has %d cores"
+                  % (n_sample_frames, cfg["n_frames"], dt, os.cpu_count() or 0),
+    }
+
+
+def msd_leg(B, torch, device, steps):
+    """Single-origin MSD (diffusion.py:212-218) on a resident random walk: frame-pairs/s and HBM GB/s."""
+    from mdproptools_amd import synth
+
+    E, F = 50_000, 256
+    r = torch.from_numpy(synth.random_walk(E, F)).to(device)
+    pairs = [(0, t) for t in range(F)]
+    B.msd_pairs(r, pairs, [0, E], scale=1e-10)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kms = 0.0
+    for _ in range(steps):
+        B.msd_pairs(r, pairs, [0, E], scale=1e-10)
+        kms += B.default_context().last_kernel_ms()[0]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    alg_bytes = 24.0 * E * F  # 24*E bytes per frame pair (origin frame amortised)
+    return {
+        "metric": "frame-pairs/s", "value": steps * F / dt, "workload": "50k entities x 256 frames, pairs (0,t)",
+        "kernel_ms": kms / steps,
+        "roofline": {"bound": "hbm", "achieved": alg_bytes / (kms / steps * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
+                     "unit": "GB/s", "frac": alg_bytes / (kms / steps * 1e-3) / HBM_PEAK, "traffic": None},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=10)
+    ap.add_argument("--variant", type=int, default=None, help="kernel variant knob (A/B only)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0 and world == 1 and args.gpus > 1:
+            print("bench.py: --gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus),
+                  file=sys.stderr)
+            sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the hot path has no CPU fallback", file=sys.stderr)
+        sys.exit(1)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from mdproptools_amd import backend as B
+    from mdproptools_amd import synth
+    from mdproptools_amd._lib import default_context
+
+    ctx = default_context(local_rank)
+    if args.variant is not None:
+        ctx.set_option("rdf_variant", args.variant)
+
+    cfg = synth.rdf_config("C2")
+    n, F, L = cfg["n_atoms"], cfg["n_frames"], cfg["box_len"]
+    nb = int(cfg["r_cut"] / cfg["bin_size"])
+    types = synth.rdf_types(n)
+    rel = np.array(synth.ALL_PAIRS_4, dtype=np.int32)
+    box = np.full((F, 3), L)
+    frame_ids = range(rank * F, (rank + 1) * F)  # every rank its own frames: weak scaling
+    xyz = torch.from_numpy(synth.rdf_frames(n, frame_ids, L, cfg["seed_offset"])).to(device)
+    pairs_per_step = F * n * (n - 1) // 2
+
+    def step():
+        full, part, ov = B.rdf_loop(xyz, types, box, rel, cfg["r_cut"], cfg["bin_size"], nb,
+                                    per_frame=False, ctx=ctx)
+        if world > 1:
+            packed = torch.from_numpy(np.concatenate([full[None], part]).astype(np.int64)).to(device)
+            dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+            packed = packed.cpu().numpy().astype(np.uint64)
+            full, part = packed[0], packed[1:]
+        return full, part
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    kernel_ms, launches = 0.0, 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        full, part = step()
+        ms, nl = ctx.last_kernel_ms()
+        kernel_ms += ms
+        launches += nl
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # sanity inside the bench: the result of the last step is a real histogram of the right size
+    expect_in = 4.0 / 3.0 * np.pi * cfg["r_cut"] ** 3 / L ** 3
+    frac_in = float(full.sum()) / 2.0 / (world * pairs_per_step)
+    assert abs(frac_in - expect_in) < 0.01 * expect_in, (frac_in, expect_in)
+
+    if rank == 0:
+        value = world * pairs_per_step * args.steps / elapsed
+        kdur = kernel_ms / max(launches, 1) * 1e-3  # average duration of one pair_hist launch
+        alg_ops = pairs_per_step * OPS_PER_PAIR
+        out = {
+            "metric": "atom-pairs/s", "value": value, "unit": "atom-pairs/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "C2: 10k atoms x 200 frames per GPU, cubic L=50 A, 4 types, 10 type-pair "
+                                   "relations, r_cut 20 A, 400 bins, frame-summed uint64 histograms"
+                                   + (", RCCL all-reduce per step" if world > 1 else ""),
+                       "pairs_per_step_per_gpu": pairs_per_step, "kernel_variant": ctx_variant(ctx, args)},
+            "roofline": {
+                "bound": "fp64-valu (not hbm/mfma: 28 B and 18 unfused FP64 ops per atom per pair sweep)",
+                "kernel": "pair_hist_kernel<tri>", "launch_ms": kdur * 1e3,
+                "achieved": alg_ops / kdur / 1e12, "peak": FP64_NONFUSED_PEAK / 1e12, "unit": "TFLOP/s",
+                "frac": alg_ops / kdur / FP64_NONFUSED_PEAK,
+                "hbm_algorithmic_GBps": 28.0 * n * F / kdur / 1e9, "hbm_peak_GBps": HBM_PEAK / 1e9,
+                "traffic": load_traffic(),
+            },
+        }
+        try:
+            out["msd"] = msd_leg(B, torch, device, max(3, args.steps // 4))
+        except Exception as e:  # the MSD leg is informative; the RDF line must still be printed
+            out["msd"] = {"error": repr(e)}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, types, rel, args.cpu_frames)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def ctx_variant(ctx, args):
+    return 0 if args.variant is None else int(args.variant)
+
+
+def load_traffic():
+    """HBM bytes per launch from a committed rocprofv3 --pmc run of this same command (profiles/), or None."""
+    p = os.path.join(HERE, "profiles", "rdf_traffic.json")
+    if os.path.exists(p):
+        try:
+            return json.load(open(p)).get("hbm_bytes_per_launch")
+        except Exception:
+            return None
+    return None
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,218 @@
+/*
+ * mdhip.h — C ABI of libmdhip.so, the MI355X (gfx950) backend for the
+ * RDF/CN and MSD/Green-Kubo hot path of molmd/mdproptools.
+ *
+ * The reference has no plugin/FFI seam of its own: its hot path is a set of
+ * private array-in/array-out Python functions. Each entry point below replaces
+ * exactly one of them and cites it (paths under /root/reference/mdproptools/).
+ * INTEGRATION.md shows the ctypes stub a maintainer adds on the reference side.
+ *
+ * Conventions
+ *  - plain C types, caller-owned buffers, C-contiguous, float64 unless noted;
+ *  - every call returns 0 on success or a negative MDHIP_E* code; the text is
+ *    available from mdhip_last_error(); nothing throws across the boundary;
+ *  - "host|dev" inputs: the big per-frame planes may live in host memory
+ *    (the library stages them) or already in device memory (flag `on_device`);
+ *    small tables (relations, cutoffs, offsets, boxes) are always host
+ *    pointers; results are always written to host pointers;
+ *  - calls are synchronous on the context's stream: results are complete when
+ *    the call returns. One context per thread; contexts are independent;
+ *  - there is NO CPU fallback: without a usable HIP device mdhip_create fails.
+ *
+ * Integer results (histograms, counts) are exact and independent of the
+ * launch geometry. Floating-point reductions use a fixed order per launch
+ * geometry (no float atomics), so they are reproducible run to run.
+ */
+#ifndef MDHIP_H
+#define MDHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDHIP_VERSION 100 /* 0.1.0 */
+
+#define MDHIP_OK 0
+#define MDHIP_EINVAL (-1)  /* bad argument (shape, NULL, unsupported size) */
+#define MDHIP_EHIP (-2)    /* a HIP runtime call failed */
+#define MDHIP_ENOMEM (-3)  /* device or host allocation failed */
+#define MDHIP_ENODEV (-4)  /* no usable gfx950 device */
+#define MDHIP_ELIMIT (-5)  /* problem exceeds a kernel limit (e.g. LDS for the histogram rows) */
+
+typedef struct mdhip_ctx mdhip_ctx;
+
+/* ---- lifecycle ---------------------------------------------------------- */
+int mdhip_version(void);
+/* Binds `device` (ordinal), creates a stream and a growable device workspace. */
+int mdhip_create(mdhip_ctx **out, int device);
+void mdhip_destroy(mdhip_ctx *ctx);
+/* Last error text of this context (or of mdhip_create when ctx == NULL). */
+const char *mdhip_last_error(mdhip_ctx *ctx);
+/* Launch on a caller-owned hipStream_t (e.g. torch's current stream); NULL restores the own stream. */
+int mdhip_set_stream(mdhip_ctx *ctx, void *hip_stream);
+int mdhip_sync(mdhip_ctx *ctx);
+/* Device time (ms, hipEvent pair on the launch stream) of the dominant kernel of the last call,
+ * and the number of times that kernel was launched by that call. */
+double mdhip_last_kernel_ms(mdhip_ctx *ctx, int *n_launches);
+/* Writes the device name (e.g. "gfx950...") into buf. */
+int mdhip_device_name(mdhip_ctx *ctx, char *buf, int buflen);
+/* Kernel tuning knob, for A/B measurements only; results never depend on it.
+ * key: "rdf_variant" (0 = exact fp64 tiles, 1 = fp32 reject + exact fp64 confirm), "rdf_jsplit", ... */
+int mdhip_set_option(mdhip_ctx *ctx, const char *key, int value);
+
+/* ---- R2/R3 binning table ------------------------------------------------ */
+/*
+ * Exact bin edges of the reference's binning rule
+ *     bin = (int64) ( sqrt(rsq) / bin_size )           structural/rdf_cn.py:68,85
+ * edges[k] = the smallest double rsq whose bin is >= k, k = 0..nbins (edges[0] = 0).
+ * Found by bisection on the bit pattern with IEEE sqrt and divide, so that
+ * binning on the device is a pure comparison of rsq against this table and
+ * never depends on device sqrt/div rounding. `edges` has nbins+1 entries.
+ */
+int mdhip_bin_edges(double bin_size, int nbins, double *edges);
+
+/* ---- R3: _rdf_loop (+ _calc_rsq, _remove_outliers) ------------------------ */
+/*
+ * structural/rdf_cn.py:72-97 for n_frames frames at once.
+ *   xyz        host|dev [n_frames][3][n_atoms]  SoA planes, atoms sorted by id
+ *   type       host int32 [n_atoms] labels as in the dump (or altered ids, rdf_cn.py:197-215);
+ *              type_frame_stride = 0 when shared by all frames, n_atoms when per frame
+ *   box        host [n_frames][3] edge lengths lx, ly, lz (rdf_cn.py:80)
+ *   rel        host int32 [n_rel][2] = relation_matrix (rdf_cn.py:484)
+ *   r_cut_sq   the value the reference compares against, r_cut**2 (rdf_cn.py:66)
+ *   edges      host [nbins+1] from mdhip_bin_edges, or NULL to have it computed from bin_size
+ *   hist_full  host uint64 [n_frames][nbins] (per_frame=1) or [nbins] summed over frames (per_frame=0);
+ *              +2 per in-cutoff pair (rdf_cn.py:85-86)
+ *   hist_part  host uint64 [n_frames][n_rel][nbins] or [n_rel][nbins]; +1 per (head a, other b) and per
+ *              (head b, other a) (rdf_cn.py:87-96)
+ *   overflow   host uint64 [1]: in-cutoff pairs whose bin index is >= nbins. The reference indexes out of
+ *              bounds for them; here they are dropped and counted.
+ * Semantics per pair (i < j): d = head - other; one shift by -sign(d)*L iff |d| > L/2;
+ * rsq = (dx*dx + dy*dy) + dz*dz with no fused multiply-add; keep iff rsq < r_cut_sq.
+ */
+int mdhip_rdf_atomic(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *xyz,
+                     int on_device, const int32_t *type, int64_t type_frame_stride,
+                     const double *box, int n_rel, const int32_t *rel, double r_cut_sq,
+                     double bin_size, int nbins, const double *edges, int per_frame,
+                     uint64_t *hist_full, uint64_t *hist_part, uint64_t *overflow);
+
+/* ---- R4: _cn_loop --------------------------------------------------------- */
+/*
+ * structural/rdf_cn.py:100-119: cn[kl] += #pairs(rsq < r_cut_sq[kl]) with the same a/b double test;
+ * every relation has its own cutoff. cn: host uint64 [n_frames][n_rel] or [n_rel].
+ */
+int mdhip_cn_atomic(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *xyz,
+                    int on_device, const int32_t *type, int64_t type_frame_stride,
+                    const double *box, int n_rel, const int32_t *rel, const double *r_cut_sq,
+                    int per_frame, uint64_t *cn);
+
+/* ---- R5: _rdf_mol_loop / _cn_mol_loop (atoms x sites, rectangular) --------- */
+/*
+ * structural/rdf_cn.py:122-141 and 144-162. Sites are molecule centres of mass
+ * (or any second coordinate set): sites host|dev [n_frames][3][n_sites],
+ * site_type host int32 [n_sites] (molecule type labels, shared by all frames).
+ * +1 per in-cutoff (atom of type rel[kl][0], site of type rel[kl][1]); an atom's
+ * own molecule is not excluded. hist_part / cn as above (no hist_full).
+ */
+int mdhip_rdf_sites(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *xyz,
+                    int xyz_on_device, const int32_t *type, int64_t n_sites, const double *sites,
+                    int sites_on_device, const int32_t *site_type, const double *box, int n_rel,
+                    const int32_t *rel, double r_cut_sq, double bin_size, int nbins,
+                    const double *edges, int per_frame, uint64_t *hist_part, uint64_t *overflow);
+
+int mdhip_cn_sites(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *xyz,
+                   int xyz_on_device, const int32_t *type, int64_t n_sites, const double *sites,
+                   int sites_on_device, const int32_t *site_type, const double *box, int n_rel,
+                   const int32_t *rel, const double *r_cut_sq, int per_frame, uint64_t *cn);
+
+/* ---- R6 / M3: per-molecule centre of mass ---------------------------------- */
+/*
+ * structural/rdf_cn.py:218-241 (_define_mol_cols), common/com_mols.py:58-60 (calc_com),
+ * dynamical/diffusion.py:83-89: mass-weighted mean over contiguous atom runs.
+ *   attr       host|dev [n_frames][n_attr][n_atoms]
+ *   atom_mass  host [n_atoms]; atom_q host [n_atoms] or NULL
+ *   seg_off    host int64 [n_seg+1] (atoms of segment s are seg_off[s]..seg_off[s+1]-1)
+ *   out        host|dev (out_on_device) [n_frames][n_attr][n_seg]:  sum(m*a) / sum(m), each product
+ *              and sum a separate rounding, atoms added in index order
+ *   seg_mass   host [n_seg] or NULL; seg_q host [n_seg] or NULL (sum of atom_q)
+ * Floating point: sums are in a different order from pandas' Kahan group sum / BLAS dot; agreement with
+ * the reference is to ~1e-15 relative (tests use rtol 1e-13).
+ */
+int mdhip_segment_com(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, int n_attr,
+                      const double *attr, int attr_on_device, const double *atom_mass,
+                      const double *atom_q, int64_t n_seg, const int64_t *seg_off, double *out,
+                      int out_on_device, double *seg_mass, double *seg_q);
+
+/* ---- M1 / M2: frame-pair displacement reductions --------------------------- */
+/*
+ * dynamical/diffusion.py:212-218 and 225-237 as one primitive over a list of frame pairs.
+ *   r          host|dev [n_frames][3][n_ent] entity coordinates (atoms or molecule COMs)
+ *   scale      unit factor applied to every coordinate first (r*scale, diffusion.py:201-203)
+ *   pairs      host int32 [n_pairs][2] = (t0, t1); M1 is {(0,t)}, M2 is {((k-1)tao, k tao)}
+ *   group_off  host int64 [n_groups+1] contiguous entity groups (molecule types; one group for atoms)
+ *   sums       host [n_pairs][n_groups][4]: sum over the group's entities of dx2, dy2, dz2 and
+ *              (dx2+dy2)+dz2 (the caller divides by the group size: diffusion.py:218)
+ *   per_entity host|dev (pe_on_device) [n_pairs][n_ent][4] = msd_all rows, or NULL
+ * Tolerance vs the reference: rtol 1e-10 on means (fixed-order tree sums vs pandas' compensated sums).
+ */
+int mdhip_msd_pairs(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r,
+                    int on_device, double scale, int n_pairs, const int32_t *pairs, int n_groups,
+                    const int64_t *group_off, double *sums, double *per_entity, int pe_on_device);
+
+/*
+ * dynamical/diffusion.py:225-237 per entity: frames kept = 0, tao, 2 tao, ...; for every entity the
+ * sums over the n_kept-1 windows of (x_k - x_{k-1})^2 per axis and of their total.
+ *   win_sums   host [n_ent][4] (the caller applies /(n_kept-1) and, for the total, /n_kept — the
+ *              reference's NaN-row quirk)
+ */
+int mdhip_msd_windows(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r,
+                      int on_device, double scale, int tao, double *win_sums);
+
+/*
+ * Superset (not in the reference): full lag average
+ *   msd[lag][g][c] = mean over t0 in [0, n_frames-lag) and entities of group g of the squared
+ *   displacement, c = x, y, z, total; lag = 0..max_lag.   out host [max_lag+1][n_groups][4]
+ */
+int mdhip_lag_msd(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r, int on_device,
+                  double scale, int max_lag, int n_groups, const int64_t *group_off, double *out);
+
+/* ---- G1: per-frame charge flux --------------------------------------------- */
+/*
+ * dynamical/_conductivity.py:11-35: J[k][type] = sum over molecules of that type of
+ * q_mol * v_com,k with v_com = sum(m v)/sum(m), both converted to SI first.
+ *   vel        host|dev [n_frames][3][n_atoms]; atom_mass, atom_q host [n_atoms]
+ *   seg_off    host int64 [n_seg+1]; seg_type host int32 [n_seg] in 0..n_types-1
+ *   flux       host [3][n_types][n_frames] (the layout Conductivity.get_charge_flux returns)
+ */
+int mdhip_charge_flux(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *vel,
+                      int on_device, const double *atom_mass, const double *atom_q, int64_t n_seg,
+                      const int64_t *seg_off, const int32_t *seg_type, int n_types,
+                      double vel_conv, double charge_conv, double *flux);
+
+/* ---- G2 / G3: correlation functions ---------------------------------------- */
+#define MDHIP_XCORR_FFT 0    /* zero-padded length-2n FFT: conductivity.py:109-114, viscosity.py:111-115 */
+#define MDHIP_XCORR_DIRECT 1 /* direct lag sums:           viscosity.py:103-108 ("brute_force")        */
+/*
+ * out[p][k] = sum_{t=0}^{n-1-k} a_p[t+k] * b_p[t] / (n-k),  k = 0..n_lags-1, for n_pairs series pairs.
+ *   a, b       host|dev [n_pairs][n] (b == a for an autocorrelation)
+ *   out        host [n_pairs][n_lags]
+ * Tolerance vs the reference: |err| <= 1e-10 * out[p][0].
+ */
+int mdhip_xcorr(mdhip_ctx *ctx, int64_t n, int n_pairs, const double *a, const double *b,
+                int on_device, int method, int64_t n_lags, double *out);
+
+/* ---- G4: cumulative trapezoid ---------------------------------------------- */
+/*
+ * dynamical/viscosity.py:151 (cumtrapz) and conductivity.py:231 (cumulative_trapezoid):
+ * I[k] = sum_{m<k} dx*(y[m]+y[m+1])/2. y host|dev [n_series][n];
+ * out host [n_series][n-1], or [n_series][n] with a leading 0 when leading_zero != 0.
+ */
+int mdhip_cumtrapz(mdhip_ctx *ctx, int64_t n, int n_series, const double *y, int on_device,
+                   double dx, int leading_zero, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDHIP_H */

@@ -1,0 +1,185 @@
+"""
+ctypes binding of libmdhip.so (C-ABI: include/mdhip.h).
+
+This is the only place the package touches native code. There is no CPU
+fallback: if the library is missing it is built (hipcc must be present), and
+if no gfx950 device is usable `Context()` raises `MdhipError`.
+"""
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+from . import build as _build
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmdhip.so")
+
+c_dp = C.POINTER(C.c_double)
+c_ip = C.POINTER(C.c_int32)
+c_lp = C.POINTER(C.c_int64)
+c_up = C.POINTER(C.c_uint64)
+vp = C.c_void_p
+
+# name -> (restype, argtypes); every symbol include/mdhip.h declares
+PROTOTYPES = {
+    "mdhip_version": (C.c_int, []),
+    "mdhip_create": (C.c_int, [C.POINTER(vp), C.c_int]),
+    "mdhip_destroy": (None, [vp]),
+    "mdhip_last_error": (C.c_char_p, [vp]),
+    "mdhip_set_stream": (C.c_int, [vp, vp]),
+    "mdhip_sync": (C.c_int, [vp]),
+    "mdhip_last_kernel_ms": (C.c_double, [vp, C.POINTER(C.c_int)]),
+    "mdhip_device_name": (C.c_int, [vp, C.c_char_p, C.c_int]),
+    "mdhip_set_option": (C.c_int, [vp, C.c_char_p, C.c_int]),
+    "mdhip_bin_edges": (C.c_int, [C.c_double, C.c_int, c_dp]),
+    "mdhip_rdf_atomic": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, c_ip, C.c_int64, c_dp, C.c_int,
+                                   c_ip, C.c_double, C.c_double, C.c_int, c_dp, C.c_int, c_up, c_up, c_up]),
+    "mdhip_cn_atomic": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, c_ip, C.c_int64, c_dp, C.c_int,
+                                  c_ip, c_dp, C.c_int, c_up]),
+    "mdhip_rdf_sites": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, c_ip, C.c_int64, vp, C.c_int, c_ip,
+                                  c_dp, C.c_int, c_ip, C.c_double, C.c_double, C.c_int, c_dp, C.c_int, c_up,
+                                  c_up]),
+    "mdhip_cn_sites": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, c_ip, C.c_int64, vp, C.c_int, c_ip,
+                                 c_dp, C.c_int, c_ip, c_dp, C.c_int, c_up]),
+    "mdhip_segment_com": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int, vp, C.c_int, c_dp, c_dp, C.c_int64,
+                                    c_lp, vp, C.c_int, c_dp, c_dp]),
+    "mdhip_msd_pairs": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, C.c_double, C.c_int, c_ip, C.c_int,
+                                  c_lp, c_dp, vp, C.c_int]),
+    "mdhip_msd_windows": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, C.c_double, C.c_int, c_dp]),
+    "mdhip_lag_msd": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, C.c_double, C.c_int, C.c_int, c_lp,
+                                c_dp]),
+    "mdhip_charge_flux": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, c_dp, c_dp, C.c_int64, c_lp, c_ip,
+                                    C.c_int, C.c_double, C.c_double, c_dp]),
+    "mdhip_xcorr": (C.c_int, [vp, C.c_int64, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int64, c_dp]),
+    "mdhip_cumtrapz": (C.c_int, [vp, C.c_int64, C.c_int, vp, C.c_int, C.c_double, C.c_int, c_dp]),
+}
+
+
+class MdhipError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("libmdhip error %d: %s" % (code, text))
+        self.code = code
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load(build_if_missing=True):
+    """Load libmdhip.so (building it in-tree first if it is missing) and bind every prototype."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            if not build_if_missing:
+                raise MdhipError(-4, "libmdhip.so not found at %s" % LIB_PATH)
+            _build.build()
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def ptr(a, ctype=C.c_double):
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+class DevPtr:
+    """A device pointer the caller owns (e.g. torch tensor .data_ptr()); passed with on_device=1."""
+
+    def __init__(self, address, keepalive=None):
+        self.address = int(address)
+        self.keepalive = keepalive
+
+
+def as_input(a):
+    """-> (void pointer, on_device flag, keepalive) for a host ndarray, a torch tensor or a DevPtr."""
+    if isinstance(a, DevPtr):
+        return vp(a.address), 1, a
+    if hasattr(a, "data_ptr") and hasattr(a, "is_cuda"):  # torch tensor without importing torch here
+        if not a.is_contiguous() or str(a.dtype) != "torch.float64":
+            raise ValueError("device tensors must be contiguous float64")
+        if a.is_cuda:
+            return vp(a.data_ptr()), 1, a
+        a = a.numpy()
+    arr = _f64(a)
+    return vp(arr.ctypes.data), 0, arr
+
+
+class Context:
+    """One mdhip context (device + stream + workspace). Not thread-safe; use one per thread."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        h = vp()
+        rc = self.lib.mdhip_create(C.byref(h), int(device))
+        if rc != 0:
+            raise MdhipError(rc, (self.lib.mdhip_last_error(None) or b"").decode())
+        self.h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mdhip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc):
+        if rc != 0:
+            raise MdhipError(rc, (self.lib.mdhip_last_error(self.h) or b"").decode())
+
+    @property
+    def name(self):
+        buf = C.create_string_buffer(256)
+        self.check(self.lib.mdhip_device_name(self.h, buf, 256))
+        return buf.value.decode()
+
+    def set_option(self, key, value):
+        self.check(self.lib.mdhip_set_option(self.h, key.encode(), int(value)))
+
+    def set_stream(self, stream_handle):
+        self.check(self.lib.mdhip_set_stream(self.h, vp(stream_handle) if stream_handle else None))
+
+    def last_kernel_ms(self):
+        n = C.c_int(0)
+        ms = self.lib.mdhip_last_kernel_ms(self.h, C.byref(n))
+        return float(ms), int(n.value)
+
+
+_default = {}
+
+
+def default_context(device=None):
+    """Process-wide context for `device` (default: LOCAL_RANK or 0)."""
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    ctx = _default.get(device)
+    if ctx is None or ctx.h is None:
+        ctx = _default[device] = Context(device)
+    return ctx
+
+
+def bin_edges(bin_size, nbins):
+    """Exact edges of bin = trunc(sqrt(rsq)/bin_size) (host-only; no GPU needed)."""
+    lib = load()
+    out = np.empty(nbins + 1, dtype=np.float64)
+    rc = lib.mdhip_bin_edges(float(bin_size), int(nbins), ptr(out))
+    if rc != 0:
+        raise MdhipError(rc, "mdhip_bin_edges(%r, %r)" % (bin_size, nbins))
+    return out

@@ -1,0 +1,261 @@
+"""
+numpy-facing wrappers over the C-ABI, one per reference kernel (the drop-in seam).
+
+Argument meaning follows the reference's private functions
+(/root/reference/mdproptools/structural/rdf_cn.py:72-162,
+dynamical/diffusion.py:207-238, dynamical/conductivity.py:97-114,216-232,
+dynamical/viscosity.py:86-153); layouts are the SoA planes of include/mdhip.h.
+Coordinates may be host ndarrays, CUDA/HIP torch tensors (float64, contiguous)
+or `_lib.DevPtr` — device-resident inputs are used in place.
+
+Everything here runs on the GPU through libmdhip.so; there is no CPU path.
+"""
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import as_input, default_context, ptr
+
+XCORR_FFT = 0
+XCORR_DIRECT = 1
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _shape3(x, name):
+    shp = tuple(x.shape)
+    if len(shp) != 3 or shp[1] != 3:
+        raise ValueError("%s must have shape [n_frames, 3, n]" % name)
+    return shp
+
+
+def cutoff_sq(r_cut):
+    """r_cut**2 as the jitted reference evaluates it: one multiply (numba lowers `x ** 2` with a
+    literal exponent to x*x; rdf_cn.py:66). CPython's float pow differs in ~0.1% of inputs."""
+    r = float(r_cut)
+    return r * r
+
+
+def rdf_loop(xyz, types, box, relation_matrix, r_cut, ddr, nbins, per_frame=True, ctx=None, edges=None):
+    """
+    `_rdf_loop` (rdf_cn.py:72-97) for every frame of xyz [F,3,N].
+
+    Returns (rdf_full uint64 [F,nbins], rdf_part uint64 [F,R,nbins], overflow) — or the frame sums
+    [nbins] / [R,nbins] when per_frame is False.
+    """
+    ctx = ctx or default_context()
+    F, _, N = _shape3(xyz, "xyz")
+    xp, on_dev, keep = as_input(xyz)
+    ty = _i32(types)
+    stride = 0 if ty.ndim == 1 else N
+    if ty.size != (N if stride == 0 else F * N):
+        raise ValueError("types must have shape [N] or [F, N]")
+    bx = _f64(box).reshape(F, 3)
+    rel = _i32(relation_matrix).reshape(-1, 2)
+    R = len(rel)
+    lead = (F,) if per_frame else ()
+    full = np.zeros(lead + (nbins,), dtype=np.uint64)
+    part = np.zeros(lead + (R, nbins), dtype=np.uint64)
+    ov = C.c_uint64(0)
+    ed = None if edges is None else _f64(edges)
+    ctx.check(ctx.lib.mdhip_rdf_atomic(
+        ctx.h, F, N, xp, on_dev, ptr(ty, C.c_int32), stride, ptr(bx), R, ptr(rel, C.c_int32),
+        cutoff_sq(r_cut), float(ddr), int(nbins), None if ed is None else ptr(ed), int(bool(per_frame)),
+        ptr(full, C.c_uint64), ptr(part, C.c_uint64), C.byref(ov)))
+    return full, part, int(ov.value)
+
+
+def cn_loop(xyz, types, box, relation_matrix, r_cut_list, per_frame=True, ctx=None):
+    """`_cn_loop` (rdf_cn.py:100-119): raw counts uint64 [F,R] (or [R])."""
+    ctx = ctx or default_context()
+    F, _, N = _shape3(xyz, "xyz")
+    xp, on_dev, keep = as_input(xyz)
+    ty = _i32(types)
+    stride = 0 if ty.ndim == 1 else N
+    bx = _f64(box).reshape(F, 3)
+    rel = _i32(relation_matrix).reshape(-1, 2)
+    rc2 = _f64([cutoff_sq(r) for r in r_cut_list])
+    if len(rc2) != len(rel):
+        raise ValueError("one cutoff per relation is required")
+    cn = np.zeros(((F,) if per_frame else ()) + (len(rel),), dtype=np.uint64)
+    ctx.check(ctx.lib.mdhip_cn_atomic(
+        ctx.h, F, N, xp, on_dev, ptr(ty, C.c_int32), stride, ptr(bx), len(rel), ptr(rel, C.c_int32),
+        ptr(rc2), int(bool(per_frame)), ptr(cn, C.c_uint64)))
+    return cn
+
+
+def rdf_mol_loop(xyz, types, sites, site_types, box, relation_matrix, r_cut, ddr, nbins, per_frame=True,
+                 ctx=None):
+    """`_rdf_mol_loop` (rdf_cn.py:122-141): atoms [F,3,N] x sites [F,3,M] -> (rdf_part, overflow)."""
+    ctx = ctx or default_context()
+    F, _, N = _shape3(xyz, "xyz")
+    F2, _, M = _shape3(sites, "sites")
+    if F2 != F:
+        raise ValueError("xyz and sites must have the same number of frames")
+    xp, x_dev, k1 = as_input(xyz)
+    sp, s_dev, k2 = as_input(sites)
+    ty, st = _i32(types), _i32(site_types)
+    bx = _f64(box).reshape(F, 3)
+    rel = _i32(relation_matrix).reshape(-1, 2)
+    part = np.zeros(((F,) if per_frame else ()) + (len(rel), nbins), dtype=np.uint64)
+    ov = C.c_uint64(0)
+    ctx.check(ctx.lib.mdhip_rdf_sites(
+        ctx.h, F, N, xp, x_dev, ptr(ty, C.c_int32), M, sp, s_dev, ptr(st, C.c_int32), ptr(bx), len(rel),
+        ptr(rel, C.c_int32), cutoff_sq(r_cut), float(ddr), int(nbins), None, int(bool(per_frame)),
+        ptr(part, C.c_uint64), C.byref(ov)))
+    return part, int(ov.value)
+
+
+def cn_mol_loop(xyz, types, sites, site_types, box, relation_matrix, r_cut_list, per_frame=True, ctx=None):
+    """`_cn_mol_loop` (rdf_cn.py:144-162)."""
+    ctx = ctx or default_context()
+    F, _, N = _shape3(xyz, "xyz")
+    _, _, M = _shape3(sites, "sites")
+    xp, x_dev, k1 = as_input(xyz)
+    sp, s_dev, k2 = as_input(sites)
+    ty, st = _i32(types), _i32(site_types)
+    bx = _f64(box).reshape(F, 3)
+    rel = _i32(relation_matrix).reshape(-1, 2)
+    rc2 = _f64([cutoff_sq(r) for r in r_cut_list])
+    cn = np.zeros(((F,) if per_frame else ()) + (len(rel),), dtype=np.uint64)
+    ctx.check(ctx.lib.mdhip_cn_sites(
+        ctx.h, F, N, xp, x_dev, ptr(ty, C.c_int32), M, sp, s_dev, ptr(st, C.c_int32), ptr(bx), len(rel),
+        ptr(rel, C.c_int32), ptr(rc2), int(bool(per_frame)), ptr(cn, C.c_uint64)))
+    return cn
+
+
+def segment_com(attr, atom_mass, seg_off, atom_q=None, out=None, ctx=None):
+    """
+    `calc_com` / `_define_mol_cols` arithmetic (com_mols.py:58-60, rdf_cn.py:233-238):
+    attr [F,K,N] -> com [F,K,M], plus seg_mass [M] and seg_q [M] (None without atom_q).
+    `out` may be a device tensor [F,K,M] to keep the result on the GPU.
+    """
+    ctx = ctx or default_context()
+    shp = tuple(attr.shape)
+    if len(shp) != 3:
+        raise ValueError("attr must have shape [n_frames, n_attr, n_atoms]")
+    F, K, N = shp
+    ap, a_dev, keep = as_input(attr)
+    m = _f64(atom_mass)
+    off = _i64(seg_off)
+    M = len(off) - 1
+    q = None if atom_q is None else _f64(atom_q)
+    seg_mass = np.zeros(M)
+    seg_q = None if q is None else np.zeros(M)
+    if out is None:
+        res = np.zeros((F, K, M))
+        op, o_dev = C.c_void_p(res.ctypes.data), 0
+    else:
+        res = out
+        op, o_dev, _k = as_input(out)
+    ctx.check(ctx.lib.mdhip_segment_com(
+        ctx.h, F, N, K, ap, a_dev, ptr(m), None if q is None else ptr(q), M, ptr(off, C.c_int64), op,
+        o_dev, ptr(seg_mass), None if seg_q is None else ptr(seg_q)))
+    return res, seg_mass, seg_q
+
+
+def msd_pairs(r, pairs, group_off, scale=1.0, per_entity=False, ctx=None):
+    """
+    Frame-pair displacement sums (diffusion.py:212-218): r [F,3,E], pairs [P,2] ->
+    sums [P,G,4] (+ per-entity rows [P,E,4] when requested).
+    """
+    ctx = ctx or default_context()
+    F, _, E = _shape3(r, "r")
+    rp, on_dev, keep = as_input(r)
+    pr = _i32(pairs).reshape(-1, 2)
+    go = _i64(group_off)
+    G = len(go) - 1
+    sums = np.zeros((len(pr), G, 4))
+    pe = np.zeros((len(pr), E, 4)) if per_entity else None
+    ctx.check(ctx.lib.mdhip_msd_pairs(
+        ctx.h, F, E, rp, on_dev, float(scale), len(pr), ptr(pr, C.c_int32), G, ptr(go, C.c_int64),
+        ptr(sums), None if pe is None else C.c_void_p(pe.ctypes.data), 0))
+    return (sums, pe) if per_entity else sums
+
+
+def msd_windows(r, tao, scale=1.0, ctx=None):
+    """Fixed-lag window sums per entity (diffusion.py:225-237): r [F,3,E] -> [E,4]."""
+    ctx = ctx or default_context()
+    F, _, E = _shape3(r, "r")
+    rp, on_dev, keep = as_input(r)
+    out = np.zeros((E, 4))
+    ctx.check(ctx.lib.mdhip_msd_windows(ctx.h, F, E, rp, on_dev, float(scale), int(tao), ptr(out)))
+    return out
+
+
+def lag_msd(r, max_lag, group_off, scale=1.0, ctx=None):
+    """Full lag average (superset): r [F,3,E] -> [max_lag+1, G, 4]."""
+    ctx = ctx or default_context()
+    F, _, E = _shape3(r, "r")
+    rp, on_dev, keep = as_input(r)
+    go = _i64(group_off)
+    G = len(go) - 1
+    out = np.zeros((int(max_lag) + 1, G, 4))
+    ctx.check(ctx.lib.mdhip_lag_msd(ctx.h, F, E, rp, on_dev, float(scale), int(max_lag), G,
+                                    ptr(go, C.c_int64), ptr(out)))
+    return out
+
+
+def charge_flux(vel, atom_mass, atom_q, seg_off, seg_type, n_types, vel_conv, charge_conv, ctx=None):
+    """`conductivity_loop` for every frame (_conductivity.py:11-35): vel [F,3,N] -> j [3,T,F]."""
+    ctx = ctx or default_context()
+    F, _, N = _shape3(vel, "vel")
+    vp_, on_dev, keep = as_input(vel)
+    m, q = _f64(atom_mass), _f64(atom_q)
+    off = _i64(seg_off)
+    st = _i32(seg_type)
+    out = np.zeros((3, int(n_types), F))
+    ctx.check(ctx.lib.mdhip_charge_flux(
+        ctx.h, F, N, vp_, on_dev, ptr(m), ptr(q), len(off) - 1, ptr(off, C.c_int64), ptr(st, C.c_int32),
+        int(n_types), float(vel_conv), float(charge_conv), ptr(out)))
+    return out
+
+
+def xcorr(a, b=None, method=XCORR_FFT, n_lags=None, ctx=None):
+    """
+    c[p][k] = sum_t a_p[t+k] b_p[t] / (n-k) (conductivity.py:109-114, viscosity.py:103-115).
+    a, b: [n] or [P,n]; b=None gives the autocorrelation.
+    """
+    ctx = ctx or default_context()
+    single = len(a.shape) == 1
+    ap, a_dev, k1 = as_input(a)
+    shp = tuple(a.shape)
+    P, n = (1, shp[0]) if single else shp
+    if b is None:
+        bp, b_dev = ap, a_dev
+    else:
+        bp, b_dev, k2 = as_input(b)
+        if b_dev != a_dev:
+            raise ValueError("a and b must both be host arrays or both device tensors")
+    n_lags = n if n_lags is None else int(n_lags)
+    out = np.zeros((P, n_lags))
+    ctx.check(ctx.lib.mdhip_xcorr(ctx.h, n, P, ap, bp, a_dev, int(method), n_lags, ptr(out)))
+    return out[0] if single else out
+
+
+def cumtrapz(y, dx, leading_zero=False, ctx=None):
+    """Cumulative trapezoid (viscosity.py:151, conductivity.py:231): y [n] or [S,n]."""
+    ctx = ctx or default_context()
+    single = len(y.shape) == 1
+    yp, on_dev, keep = as_input(y)
+    shp = tuple(y.shape)
+    S, n = (1, shp[0]) if single else shp
+    m = n - 1 + (1 if leading_zero else 0)
+    out = np.zeros((S, max(m, 0)))
+    ctx.check(ctx.lib.mdhip_cumtrapz(ctx.h, n, S, yp, on_dev, float(dx), int(bool(leading_zero)), ptr(out)))
+    return out[0] if single else out
+
+
+bin_edges = _lib.bin_edges

@@ -1,0 +1,78 @@
+"""
+Build recipe for libmdhip.so (hand-written HIP for gfx950 behind the C-ABI of include/mdhip.h).
+
+    python -m mdproptools_amd.build            # incremental
+    python -m mdproptools_amd.build --force
+
+hipcc cross-compiles gfx950 without a GPU. The library is built IN-TREE
+(mdproptools_amd/libmdhip.so) so that it travels to the GPU box with the
+repository snapshot. -ffp-contract=off is set for every translation unit: the
+RDF/CN path needs the reference's unfused double arithmetic for bit-exact bin
+counts, and the kernels that may fuse (correlation, lag sums) call fma explicitly.
+"""
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "csrc", "_obj")
+LIB = os.path.join(HERE, "libmdhip.so")
+SOURCES = ["mdhip_ctx.hip", "pair_hist.hip", "segment_com.hip", "msd.hip", "xcorr.hip", "scan.hip"]
+HEADERS = [os.path.join(CSRC, "ctx.h"), os.path.join(os.path.dirname(HERE), "include", "mdhip.h")]
+ARCH = "gfx950"
+CFLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "--offload-arch=" + ARCH,
+          "-Wall", "-Wno-unused-function"]
+LDFLAGS = ["-shared", "-fPIC", "--offload-arch=" + ARCH, "-L/opt/rocm/lib", "-lhipfft",
+           "-Wl,-rpath,/opt/rocm/lib"]
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found; libmdhip.so cannot be built")
+    return exe
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP translation unit for gfx950 and link libmdhip.so; returns its path."""
+    os.makedirs(OBJ, exist_ok=True)
+    hipcc = _hipcc()
+    objs = []
+    procs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s] + HEADERS):
+            cmd = [hipcc] + CFLAGS + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode(errors="replace")))
+        if verbose and out:
+            print(out.decode(errors="replace"))
+    if force or procs or _stale(LIB, objs):
+        cmd = [hipcc] + objs + LDFLAGS + ["-o", LIB]
+        if verbose:
+            print(" ".join(cmd))
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n" + r.stdout.decode(errors="replace"))
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))

@@ -1,0 +1,110 @@
+// ctx.h — context, workspace and error plumbing shared by the libmdhip.so translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mdhip.h"
+
+// Workspace slots: one growable device buffer each, reused across calls.
+enum WsSlot {
+    WS_XYZ_I = 0,  // staged coordinates of set i
+    WS_XYZ_J,      // staged coordinates of set j / sites
+    WS_TYPE_I,
+    WS_TYPE_J,
+    WS_BOX,
+    WS_TABLES,  // edges + class table
+    WS_HIST,    // class histograms (slots or per-frame)
+    WS_MISC,    // overflow counters, small outputs
+    WS_OUT,     // generic device output
+    WS_PART,    // per-block partial sums
+    WS_AUX0,
+    WS_AUX1,
+    WS_AUX2,
+    WS_AUX3,
+    WS_COUNT
+};
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct mdhip_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+    DevBuf ws[WS_COUNT];
+    double last_ms = 0.0;
+    int last_launches = 0;
+    int cu_count = 256;
+    size_t lds_max = 65536;
+    char name[256] = {0};
+    // options (A/B knobs; results never depend on them)
+    int opt_rdf_variant = 0;
+    int opt_rdf_jsplit = 0;   // 0 = auto
+    int opt_rdf_slots = 16;   // replicas of the frame-summed histogram in HBM
+    int opt_xcorr_tile = 0;
+};
+
+int mdhip_fail(mdhip_ctx *ctx, int code, const char *fmt, ...);
+void *mdhip_ws(mdhip_ctx *ctx, int slot, size_t bytes);  // nullptr on failure (error set)
+
+#define MD_HIP(call)                                                                          \
+    do {                                                                                      \
+        hipError_t e__ = (call);                                                              \
+        if (e__ != hipSuccess)                                                                \
+            return mdhip_fail(ctx, MDHIP_EHIP, "%s failed: %s (%s:%d)", #call,                \
+                              hipGetErrorString(e__), __FILE__, __LINE__);                    \
+    } while (0)
+
+#define MD_REQUIRE(cond, ...)                                  \
+    do {                                                       \
+        if (!(cond)) return mdhip_fail(ctx, MDHIP_EINVAL, __VA_ARGS__); \
+    } while (0)
+
+#define MD_WS(var, type, slot, bytes)                          \
+    type *var = (type *)mdhip_ws(ctx, slot, bytes);            \
+    if (!var) return MDHIP_ENOMEM;
+
+// Stage `bytes` from a host-or-device source into workspace `slot` unless it is already on the device.
+static inline const void *mdhip_stage(mdhip_ctx *ctx, int slot, const void *src, size_t bytes,
+                                      int on_device, int *rc)
+{
+    *rc = MDHIP_OK;
+    if (on_device) return src;
+    void *d = mdhip_ws(ctx, slot, bytes);
+    if (!d) {
+        *rc = MDHIP_ENOMEM;
+        return nullptr;
+    }
+    hipError_t e = hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) {
+        *rc = mdhip_fail(ctx, MDHIP_EHIP, "H2D staging failed: %s", hipGetErrorString(e));
+        return nullptr;
+    }
+    return d;
+}
+
+struct KernelTimer {
+    mdhip_ctx *ctx;
+    explicit KernelTimer(mdhip_ctx *c, int launches = 1) : ctx(c)
+    {
+        ctx->last_launches = launches;
+        (void)hipEventRecord(ctx->ev0, ctx->stream);
+    }
+    void stop() { (void)hipEventRecord(ctx->ev1, ctx->stream); }
+    // call after the stream has been synchronised
+    void collect()
+    {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->last_ms = ms;
+    }
+};

@@ -1,0 +1,193 @@
+// mdhip_ctx.hip — lifecycle, workspace, options and the host-side bin-edge table.
+#include <cmath>
+
+#include "ctx.h"
+
+static thread_local std::string g_create_error;
+
+int mdhip_fail(mdhip_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx)
+        ctx->err = buf;
+    else
+        g_create_error = buf;
+    return code;
+}
+
+void *mdhip_ws(mdhip_ctx *ctx, int slot, size_t bytes)
+{
+    DevBuf &b = ctx->ws[slot];
+    if (bytes == 0) bytes = 16;
+    if (b.cap >= bytes) return b.p;
+    if (b.p) {
+        // the buffer may still be in use by queued work
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(b.p);
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t cap = bytes + (bytes >> 3);
+    cap = (cap + 255) & ~size_t(255);
+    hipError_t e = hipMalloc(&b.p, cap);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        mdhip_fail(ctx, MDHIP_ENOMEM, "hipMalloc(%zu) failed for workspace %d: %s", cap, slot,
+                   hipGetErrorString(e));
+        return nullptr;
+    }
+    b.cap = cap;
+    return b.p;
+}
+
+extern "C" {
+
+int mdhip_version(void) { return MDHIP_VERSION; }
+
+int mdhip_create(mdhip_ctx **out, int device)
+{
+    if (!out) return mdhip_fail(nullptr, MDHIP_EINVAL, "mdhip_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return mdhip_fail(nullptr, MDHIP_ENODEV,
+                          "mdhip_create: no HIP device (%s); libmdhip.so has no CPU fallback",
+                          e == hipSuccess ? "count is 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n)
+        return mdhip_fail(nullptr, MDHIP_EINVAL, "mdhip_create: device %d out of range [0,%d)",
+                          device, n);
+    mdhip_ctx *ctx = new mdhip_ctx();
+    ctx->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess) {
+        delete ctx;
+        return mdhip_fail(nullptr, MDHIP_EHIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        ctx->cu_count = prop.multiProcessorCount;
+        snprintf(ctx->name, sizeof ctx->name, "%s (%s)", prop.name, prop.gcnArchName);
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            std::string nm = ctx->name;
+            delete ctx;
+            return mdhip_fail(nullptr, MDHIP_ENODEV,
+                              "mdhip_create: device %d is %s; this library is built for gfx950 only",
+                              device, nm.c_str());
+        }
+        ctx->lds_max = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor
+                                                              : 65536;
+    }
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        delete ctx;
+        return mdhip_fail(nullptr, MDHIP_EHIP, "mdhip_create: stream/event creation failed");
+    }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return MDHIP_OK;
+}
+
+void mdhip_destroy(mdhip_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &b : ctx->ws)
+        if (b.p) (void)hipFree(b.p);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+const char *mdhip_last_error(mdhip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int mdhip_set_stream(mdhip_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return MDHIP_EINVAL;
+    MD_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return MDHIP_OK;
+}
+
+int mdhip_sync(mdhip_ctx *ctx)
+{
+    if (!ctx) return MDHIP_EINVAL;
+    MD_HIP(hipStreamSynchronize(ctx->stream));
+    return MDHIP_OK;
+}
+
+double mdhip_last_kernel_ms(mdhip_ctx *ctx, int *n_launches)
+{
+    if (!ctx) return 0.0;
+    if (n_launches) *n_launches = ctx->last_launches;
+    return ctx->last_ms;
+}
+
+int mdhip_device_name(mdhip_ctx *ctx, char *buf, int buflen)
+{
+    if (!ctx || !buf || buflen <= 0) return MDHIP_EINVAL;
+    snprintf(buf, (size_t)buflen, "%s", ctx->name);
+    return MDHIP_OK;
+}
+
+int mdhip_set_option(mdhip_ctx *ctx, const char *key, int value)
+{
+    if (!ctx || !key) return MDHIP_EINVAL;
+    if (!strcmp(key, "rdf_variant"))
+        ctx->opt_rdf_variant = value;
+    else if (!strcmp(key, "rdf_jsplit"))
+        ctx->opt_rdf_jsplit = value;
+    else if (!strcmp(key, "rdf_slots"))
+        ctx->opt_rdf_slots = value < 1 ? 1 : value;
+    else if (!strcmp(key, "xcorr_tile"))
+        ctx->opt_xcorr_tile = value;
+    else
+        return mdhip_fail(ctx, MDHIP_EINVAL, "mdhip_set_option: unknown key '%s'", key);
+    return MDHIP_OK;
+}
+
+// The reference's rule, evaluated on the host with IEEE sqrt and divide (structural/rdf_cn.py:68,85).
+static inline int64_t ref_bin(double rsq, double ddr) { return (int64_t)(std::sqrt(rsq) / ddr); }
+
+int mdhip_bin_edges(double bin_size, int nbins, double *edges)
+{
+    if (!(bin_size > 0.0) || nbins < 1 || !edges) return MDHIP_EINVAL;
+    edges[0] = 0.0;
+    for (int k = 1; k <= nbins; ++k) {
+        // Smallest double with ref_bin >= k: bisection on the (monotone) bit pattern of positive doubles.
+        double guess = ((double)k * bin_size) * ((double)k * bin_size);
+        uint64_t lo, hi;
+        double g_lo = guess * 0.999999, g_hi = guess * 1.000001;
+        memcpy(&lo, &g_lo, 8);
+        memcpy(&hi, &g_hi, 8);
+        double d;
+        // widen until lo is below the edge and hi is at/above it
+        for (;;) {
+            memcpy(&d, &lo, 8);
+            if (ref_bin(d, bin_size) < k) break;
+            lo -= (lo >> 20) + 1;
+        }
+        for (;;) {
+            memcpy(&d, &hi, 8);
+            if (ref_bin(d, bin_size) >= k) break;
+            hi += (hi >> 20) + 1;
+        }
+        while (hi - lo > 1) {
+            uint64_t mid = lo + ((hi - lo) >> 1);
+            memcpy(&d, &mid, 8);
+            if (ref_bin(d, bin_size) >= k)
+                hi = mid;
+            else
+                lo = mid;
+        }
+        memcpy(&edges[k], &hi, 8);
+    }
+    return MDHIP_OK;
+}
+
+}  // extern "C"

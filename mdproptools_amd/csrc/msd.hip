@@ -1,0 +1,438 @@
+// msd.hip — frame-pair displacement reductions (M1, M2) for gfx950.
+//
+// Replaces the pandas expressions at dynamical/diffusion.py:212-218 (single origin) and
+// diffusion.py:225-237 (fixed lag) of the reference.
+//
+// HBM-bound streaming kernels: a frame pair reads 2 x 24 bytes per entity (the origin frame of the
+// M1 pair list is the same for every pair and stays in L2 / Infinity Cache, so the algorithmic
+// traffic is 24*E bytes per frame pair) and does 12 flops. Coordinates are [F][3][E] planes so that
+// consecutive lanes read consecutive doubles. Reductions are fixed-order (wave shuffle tree, then
+// LDS across the 4 waves, then an ordered pass over block partials): no float atomics, results are
+// reproducible run to run.
+#include <algorithm>
+
+#include "ctx.h"
+
+namespace {
+
+constexpr int MSD_THREADS = 256;
+constexpr int MSD_PER_THREAD = 4;
+constexpr int MSD_CHUNK = MSD_THREADS * MSD_PER_THREAD;
+
+struct Chunk {
+    long long e0, e1;
+    int group;
+    int pad;
+};
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// grid (n_chunks, n_pairs). partial [n_pairs][n_chunks][4]
+__global__ __launch_bounds__(MSD_THREADS) void msd_pairs_kernel(
+    const double *__restrict__ r, long long n_ent, double scale, const int *__restrict__ pairs,
+    const Chunk *__restrict__ chunks, int n_chunks, double *__restrict__ partial,
+    double *__restrict__ per_entity)
+{
+    __shared__ double red[4][4];
+    const int p = blockIdx.y;
+    const Chunk ck = chunks[blockIdx.x];
+    const double *r0 = r + (size_t)pairs[2 * p] * 3 * n_ent;
+    const double *r1 = r + (size_t)pairs[2 * p + 1] * 3 * n_ent;
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+    for (int u = 0; u < MSD_PER_THREAD; ++u) {
+        const long long e = ck.e0 + (long long)u * MSD_THREADS + threadIdx.x;
+        if (e < ck.e1) {
+            // diffusion.py:201-203 scales first, diffusion.py:214 differences, then squares
+            const double dx = r1[e] * scale - r0[e] * scale;
+            const double dy = r1[n_ent + e] * scale - r0[n_ent + e] * scale;
+            const double dz = r1[2 * n_ent + e] * scale - r0[2 * n_ent + e] * scale;
+            const double dx2 = dx * dx, dy2 = dy * dy, dz2 = dz * dz;
+            const double tot = (dx2 + dy2) + dz2;  // diffusion.py:215
+            s0 += dx2;
+            s1 += dy2;
+            s2 += dz2;
+            s3 += tot;
+            if (per_entity) {
+                double *pe = per_entity + ((size_t)p * n_ent + e) * 4;
+                pe[0] = dx2;
+                pe[1] = dy2;
+                pe[2] = dz2;
+                pe[3] = tot;
+            }
+        }
+    }
+    s0 = wave_sum(s0);
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    s3 = wave_sum(s3);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+        red[wave][0] = s0;
+        red[wave][1] = s1;
+        red[wave][2] = s2;
+        red[wave][3] = s3;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int c = threadIdx.x;
+        partial[((size_t)p * n_chunks + blockIdx.x) * 4 + c] =
+            ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+    }
+}
+
+// sums [n_pairs][n_groups][4] from partial, chunks of one group are contiguous in the chunk list
+__global__ void msd_group_sum_kernel(const double *__restrict__ partial,
+                                     const int *__restrict__ group_chunk_off, int n_chunks,
+                                     int n_groups, int n_pairs, double *__restrict__ sums)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_pairs * n_groups * 4) return;
+    const int c = idx & 3, g = (idx >> 2) % n_groups, p = (idx >> 2) / n_groups;
+    double s = 0.0;
+    for (int k = group_chunk_off[g]; k < group_chunk_off[g + 1]; ++k)
+        s += partial[((size_t)p * n_chunks + k) * 4 + c];
+    sums[idx] = s;
+}
+
+// one lane per entity, windows walked in order with the previous kept frame in registers
+__global__ __launch_bounds__(256) void msd_windows_kernel(const double *__restrict__ r,
+                                                          long long n_ent, long long n_frames,
+                                                          double scale, int tao,
+                                                          double *__restrict__ out)
+{
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_ent) return;
+    double px = r[e] * scale, py = r[n_ent + e] * scale, pz = r[2 * n_ent + e] * scale;
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    for (long long t = tao; t < n_frames; t += tao) {
+        const double *rt = r + (size_t)t * 3 * n_ent;
+        const double x = rt[e] * scale, y = rt[n_ent + e] * scale, z = rt[2 * n_ent + e] * scale;
+        const double dx = x - px, dy = y - py, dz = z - pz;  // diffusion.py:232
+        const double dx2 = dx * dx, dy2 = dy * dy, dz2 = dz * dz;
+        s0 += dx2;
+        s1 += dy2;
+        s2 += dz2;
+        s3 += (dx2 + dy2) + dz2;  // diffusion.py:235
+        px = x;
+        py = y;
+        pz = z;
+    }
+    double *o = out + (size_t)e * 4;
+    o[0] = s0;
+    o[1] = s1;
+    o[2] = s2;
+    o[3] = s3;
+}
+
+// ---------------------------------------------------------------------------------------------
+// full lag average (superset of the reference): msd[lag] = mean_{t0, e} |r_e(t0+lag) - r_e(t0)|^2
+// ---------------------------------------------------------------------------------------------
+// FP64-bound (12 flops per entity per frame pair, F^2/2 frame pairs). The trajectory is transposed
+// once to time-major series x[c][e][t]; a block then owns (entity chunk, pair of lag tiles): for
+// every entity and axis it stages the series through LDS (transposed [i mod 8][i div 8] so that a
+// wave reads consecutive doubles) and every lane keeps 8 consecutive lags with a 16-deep sliding
+// window in registers: 8 LDS reads feed 64 (sub, fma) pairs. Sums over the chunk's entities stay in
+// registers; chunk partials are added in a fixed order afterwards.
+
+constexpr int LG_THREADS = 256;
+constexpr int LG_LPT = 8;
+constexpr int LG_KT = LG_THREADS * LG_LPT;  // 2048 lags per tile
+constexpr int LG_TT = 2048;
+constexpr int LG_AW = LG_TT + LG_KT + 8;
+constexpr int LG_ROW = LG_AW / 8 + 1;
+constexpr int LG_ECHUNK = 64;  // entities summed inside one block
+
+__global__ __launch_bounds__(256) void transpose_kernel(const double *__restrict__ in,
+                                                        double *__restrict__ out, long long rows,
+                                                        long long cols, double scale)
+{
+    // out[col][row] = in[row][col] * scale, 32x32 tiles through LDS
+    __shared__ double tile[32][33];
+    const long long c0 = (long long)blockIdx.x * 32, r0 = (long long)blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int k = ty; k < 32; k += 8) {
+        const long long rr = r0 + k, cc = c0 + tx;
+        tile[k][tx] = (rr < rows && cc < cols) ? in[rr * cols + cc] * scale : 0.0;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const long long cc = c0 + k, rr = r0 + tx;
+        if (rr < rows && cc < cols) out[cc * rows + rr] = tile[tx][k];
+    }
+}
+
+// x: [3][E][F] time-major series. partial: [n_chunks][max_lag+1][4]
+__global__ __launch_bounds__(LG_THREADS) void lag_msd_kernel(
+    const double *__restrict__ x, long long n_ent, long long n, long long n_lags,
+    const Chunk *__restrict__ chunks, int n_tiles, double *__restrict__ partial)
+{
+    __shared__ double s_a[8 * LG_ROW];
+    __shared__ __attribute__((aligned(16))) double s_b[LG_TT];
+    const int tid = threadIdx.x;
+    const Chunk ck = chunks[blockIdx.y];
+    const int pair_id = blockIdx.x;
+    for (int half = 0; half < 2; ++half) {
+        const int tile = half == 0 ? pair_id : n_tiles - 1 - pair_id;
+        if (half == 1 && tile == pair_id) break;
+        const long long K0 = (long long)tile * LG_KT;
+        if (K0 >= n_lags) continue;
+        const long long kb = K0 + (long long)tid * LG_LPT;
+        const long long lim = n - kb;  // pair (t, kb+m) is valid iff t + m < lim
+        const long long t_total = n - K0;
+        double acc[3][LG_LPT];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int m = 0; m < LG_LPT; ++m) acc[c][m] = 0.0;
+
+        for (long long e = ck.e0; e < ck.e1; ++e) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const double *xs = x + ((size_t)c * n_ent + e) * n;
+                for (long long T0 = 0; T0 < t_total; T0 += LG_TT) {
+                    __syncthreads();
+                    for (int i = tid; i < LG_TT; i += LG_THREADS) {
+                        const long long t = T0 + i;
+                        s_b[i] = t < n ? xs[t] : 0.0;
+                    }
+                    for (int i = tid; i < LG_AW; i += LG_THREADS) {
+                        const long long g = T0 + K0 + i;
+                        s_a[(i & 7) * LG_ROW + (i >> 3)] = g < n ? xs[g] : 0.0;
+                    }
+                    __syncthreads();
+                    double w[16];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) w[j] = s_a[j * LG_ROW + tid];
+                    for (int tt = 0; tt < LG_TT; tt += 8) {
+                        const int col = tid + (tt >> 3) + 1;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) w[8 + j] = s_a[j * LG_ROW + col];
+                        const long long s = lim - (T0 + tt);
+                        if (s >= 15) {
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                const double bt = s_b[tt + u];
+#pragma unroll
+                                for (int m = 0; m < LG_LPT; ++m) {
+                                    const double d = w[u + m] - bt;
+                                    acc[c][m] = __builtin_fma(d, d, acc[c][m]);
+                                }
+                            }
+                        } else if (s > 0) {
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                const double bt = s_b[tt + u];
+#pragma unroll
+                                for (int m = 0; m < LG_LPT; ++m) {
+                                    const double d = (u + m) < s ? w[u + m] - bt : 0.0;
+                                    acc[c][m] = __builtin_fma(d, d, acc[c][m]);
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) w[j] = w[8 + j];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < LG_LPT; ++m) {
+            const long long k = kb + m;
+            if (k < n_lags) {
+                double *p = partial + ((size_t)blockIdx.y * n_lags + k) * 4;
+                p[0] = acc[0][m];
+                p[1] = acc[1][m];
+                p[2] = acc[2][m];
+                p[3] = (acc[0][m] + acc[1][m]) + acc[2][m];
+            }
+        }
+    }
+}
+
+// out[lag][g][c] = sum over the group's chunks / ((n - lag) * group size)
+__global__ void lag_msd_finish_kernel(const double *__restrict__ partial,
+                                      const int *__restrict__ group_chunk_off,
+                                      const long long *__restrict__ group_off, int n_groups,
+                                      long long n, long long n_lags, double *__restrict__ out)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_lags * n_groups * 4) return;
+    const int c = (int)(idx & 3);
+    const int g = (int)((idx >> 2) % n_groups);
+    const long long k = (idx >> 2) / n_groups;
+    double s = 0.0;
+    for (int q = group_chunk_off[g]; q < group_chunk_off[g + 1]; ++q)
+        s += partial[((size_t)q * n_lags + k) * 4 + c];
+    const double cnt = (double)(n - k) * (double)(group_off[g + 1] - group_off[g]);
+    out[idx] = cnt > 0.0 ? s / cnt : 0.0;
+}
+
+int build_chunks(mdhip_ctx *ctx, int64_t n_ent, int n_groups, const int64_t *group_off,
+                 std::vector<Chunk> &chunks, std::vector<int> &gco, int64_t chunk_len = MSD_CHUNK)
+{
+    MD_REQUIRE(n_groups >= 1 && group_off, "need at least one entity group");
+    MD_REQUIRE(group_off[0] >= 0 && group_off[n_groups] <= n_ent, "group_off outside [0, n_ent]");
+    gco.assign(n_groups + 1, 0);
+    for (int g = 0; g < n_groups; ++g) {
+        MD_REQUIRE(group_off[g] <= group_off[g + 1], "group_off must be non-decreasing");
+        gco[g] = (int)chunks.size();
+        for (int64_t e = group_off[g]; e < group_off[g + 1]; e += chunk_len)
+            chunks.push_back({(long long)e, (long long)std::min<int64_t>(e + chunk_len, group_off[g + 1]), g, 0});
+    }
+    gco[n_groups] = (int)chunks.size();
+    return MDHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mdhip_msd_pairs(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r,
+                    int on_device, double scale, int n_pairs, const int32_t *pairs, int n_groups,
+                    const int64_t *group_off, double *sums, double *per_entity, int pe_on_device)
+{
+    if (!ctx) return MDHIP_EINVAL;
+    MD_REQUIRE(n_frames >= 0 && n_ent >= 0 && n_pairs >= 0, "negative sizes");
+    MD_REQUIRE(n_pairs == 0 || (pairs && sums), "NULL pairs/sums");
+    for (int p = 0; p < 2 * n_pairs; ++p)
+        MD_REQUIRE(pairs[p] >= 0 && pairs[p] < n_frames, "pair index %d out of range", pairs[p]);
+    std::vector<Chunk> chunks;
+    std::vector<int> gco;
+    int rc = build_chunks(ctx, n_ent, n_groups, group_off, chunks, gco);
+    if (rc) return rc;
+    std::fill(sums, sums + (size_t)n_pairs * n_groups * 4, 0.0);
+    if (n_pairs == 0 || chunks.empty()) return MDHIP_OK;
+    MD_REQUIRE(r != nullptr, "r is NULL");
+    MD_REQUIRE(n_pairs <= 65535, "at most 65535 frame pairs per call");
+    MD_HIP(hipSetDevice(ctx->device));
+    const double *d_r =
+        (const double *)mdhip_stage(ctx, WS_XYZ_I, r, (size_t)n_frames * 3 * n_ent * 8, on_device, &rc);
+    if (rc) return rc;
+    const int n_chunks = (int)chunks.size();
+    const size_t tab_b = (size_t)n_pairs * 8 + chunks.size() * sizeof(Chunk) + gco.size() * 4;
+    MD_WS(d_tab, unsigned char, WS_TABLES, tab_b + 64);
+    Chunk *d_chunks = reinterpret_cast<Chunk *>(d_tab);
+    int *d_pairs = reinterpret_cast<int *>(d_tab + chunks.size() * sizeof(Chunk));
+    int *d_gco = d_pairs + 2 * n_pairs;
+    MD_HIP(hipMemcpyAsync(d_chunks, chunks.data(), chunks.size() * sizeof(Chunk), hipMemcpyHostToDevice, ctx->stream));
+    MD_HIP(hipMemcpyAsync(d_pairs, pairs, (size_t)n_pairs * 8, hipMemcpyHostToDevice, ctx->stream));
+    MD_HIP(hipMemcpyAsync(d_gco, gco.data(), gco.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    MD_WS(d_partial, double, WS_PART, (size_t)n_pairs * n_chunks * 4 * 8);
+    const size_t sums_b = (size_t)n_pairs * n_groups * 4 * 8;
+    MD_WS(d_sums, double, WS_OUT, sums_b);
+    double *d_pe = nullptr;
+    const size_t pe_b = (size_t)n_pairs * n_ent * 4 * 8;
+    if (per_entity) {
+        d_pe = pe_on_device ? per_entity : (double *)mdhip_ws(ctx, WS_AUX0, pe_b);
+        if (!d_pe) return MDHIP_ENOMEM;
+    }
+    MD_HIP(hipStreamSynchronize(ctx->stream));  // host tables are stack/vector memory
+    KernelTimer timer(ctx);
+    hipLaunchKernelGGL(msd_pairs_kernel, dim3((unsigned)n_chunks, (unsigned)n_pairs),
+                       dim3(MSD_THREADS), 0, ctx->stream, d_r, (long long)n_ent, scale, d_pairs,
+                       d_chunks, n_chunks, d_partial, d_pe);
+    timer.stop();
+    MD_HIP(hipGetLastError());
+    const int tot = n_pairs * n_groups * 4;
+    hipLaunchKernelGGL(msd_group_sum_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
+                       ctx->stream, d_partial, d_gco, n_chunks, n_groups, n_pairs, d_sums);
+    MD_HIP(hipGetLastError());
+    MD_HIP(hipMemcpyAsync(sums, d_sums, sums_b, hipMemcpyDeviceToHost, ctx->stream));
+    if (per_entity && !pe_on_device)
+        MD_HIP(hipMemcpyAsync(per_entity, d_pe, pe_b, hipMemcpyDeviceToHost, ctx->stream));
+    MD_HIP(hipStreamSynchronize(ctx->stream));
+    timer.collect();
+    return MDHIP_OK;
+}
+
+int mdhip_msd_windows(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r,
+                      int on_device, double scale, int tao, double *win_sums)
+{
+    if (!ctx) return MDHIP_EINVAL;
+    MD_REQUIRE(n_frames >= 0 && n_ent >= 0 && tao >= 1, "bad sizes");
+    MD_REQUIRE(n_ent == 0 || win_sums, "win_sums is NULL");
+    if (n_ent == 0) return MDHIP_OK;
+    if (n_frames == 0) {
+        std::fill(win_sums, win_sums + (size_t)n_ent * 4, 0.0);
+        return MDHIP_OK;
+    }
+    MD_REQUIRE(r != nullptr, "r is NULL");
+    MD_HIP(hipSetDevice(ctx->device));
+    int rc;
+    const double *d_r =
+        (const double *)mdhip_stage(ctx, WS_XYZ_I, r, (size_t)n_frames * 3 * n_ent * 8, on_device, &rc);
+    if (rc) return rc;
+    MD_WS(d_out, double, WS_OUT, (size_t)n_ent * 4 * 8);
+    KernelTimer timer(ctx);
+    hipLaunchKernelGGL(msd_windows_kernel, dim3((unsigned)((n_ent + 255) / 256)), dim3(256), 0,
+                       ctx->stream, d_r, (long long)n_ent, (long long)n_frames, scale, tao, d_out);
+    timer.stop();
+    MD_HIP(hipGetLastError());
+    MD_HIP(hipMemcpyAsync(win_sums, d_out, (size_t)n_ent * 4 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    MD_HIP(hipStreamSynchronize(ctx->stream));
+    timer.collect();
+    return MDHIP_OK;
+}
+
+int mdhip_lag_msd(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r, int on_device,
+                  double scale, int max_lag, int n_groups, const int64_t *group_off, double *out)
+{
+    if (!ctx) return MDHIP_EINVAL;
+    MD_REQUIRE(n_frames >= 0 && n_ent >= 0 && max_lag >= 0, "negative sizes");
+    MD_REQUIRE(max_lag < n_frames || n_frames == 0, "max_lag must be < n_frames");
+    MD_REQUIRE(out != nullptr, "out is NULL");
+    std::vector<Chunk> chunks;
+    std::vector<int> gco;
+    int rc = build_chunks(ctx, n_ent, n_groups, group_off, chunks, gco, LG_ECHUNK);
+    if (rc) return rc;
+    const long long n_lags = (long long)max_lag + 1;
+    std::fill(out, out + (size_t)n_lags * n_groups * 4, 0.0);
+    if (n_frames == 0 || chunks.empty()) return MDHIP_OK;
+    MD_REQUIRE(r != nullptr, "r is NULL");
+    MD_REQUIRE(chunks.size() <= 65535, "too many entity chunks (%zu)", chunks.size());
+    MD_HIP(hipSetDevice(ctx->device));
+    const size_t r_b = (size_t)n_frames * 3 * n_ent * 8;
+    const double *d_r = (const double *)mdhip_stage(ctx, WS_XYZ_I, r, r_b, on_device, &rc);
+    if (rc) return rc;
+    MD_WS(d_x, double, WS_XYZ_J, r_b);
+    const int n_chunks = (int)chunks.size();
+    const size_t tab_b = chunks.size() * sizeof(Chunk) + gco.size() * 4 + (size_t)(n_groups + 1) * 8 + 64;
+    MD_WS(d_tab, unsigned char, WS_TABLES, tab_b);
+    Chunk *d_chunks = reinterpret_cast<Chunk *>(d_tab);
+    long long *d_goff = reinterpret_cast<long long *>(d_tab + chunks.size() * sizeof(Chunk));
+    int *d_gco = reinterpret_cast<int *>(d_goff + n_groups + 1);
+    MD_HIP(hipMemcpyAsync(d_chunks, chunks.data(), chunks.size() * sizeof(Chunk), hipMemcpyHostToDevice, ctx->stream));
+    MD_HIP(hipMemcpyAsync(d_goff, group_off, (size_t)(n_groups + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    MD_HIP(hipMemcpyAsync(d_gco, gco.data(), gco.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    MD_WS(d_partial, double, WS_PART, (size_t)n_chunks * n_lags * 4 * 8);
+    const size_t out_b = (size_t)n_lags * n_groups * 4 * 8;
+    MD_WS(d_out, double, WS_OUT, out_b);
+    MD_HIP(hipStreamSynchronize(ctx->stream));
+    const long long cols = 3 * n_ent;
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((cols + 31) / 32), (unsigned)((n_frames + 31) / 32)),
+                       dim3(256), 0, ctx->stream, d_r, d_x, (long long)n_frames, cols, scale);
+    MD_HIP(hipGetLastError());
+    const int n_tiles = (int)((n_lags + LG_KT - 1) / LG_KT);
+    KernelTimer timer(ctx);
+    hipLaunchKernelGGL(lag_msd_kernel, dim3((unsigned)((n_tiles + 1) / 2), (unsigned)n_chunks),
+                       dim3(LG_THREADS), 0, ctx->stream, d_x, (long long)n_ent, (long long)n_frames, n_lags,
+                       d_chunks, n_tiles, d_partial);
+    timer.stop();
+    MD_HIP(hipGetLastError());
+    const long long tot = n_lags * n_groups * 4;
+    hipLaunchKernelGGL(lag_msd_finish_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
+                       ctx->stream, d_partial, d_gco, d_goff, n_groups, (long long)n_frames, n_lags, d_out);
+    MD_HIP(hipGetLastError());
+    MD_HIP(hipMemcpyAsync(out, d_out, out_b, hipMemcpyDeviceToHost, ctx->stream));
+    MD_HIP(hipStreamSynchronize(ctx->stream));
+    timer.collect();
+    return MDHIP_OK;
+}
+
+}  // extern "C"

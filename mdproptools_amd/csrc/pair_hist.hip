@@ -1,0 +1,793 @@
+// pair_hist.hip — all-pairs minimum-image distance histogramming for gfx950 (R1-R5).
+//
+// Replaces structural/rdf_cn.py:35-162 of the reference (_calc_rsq, _remove_outliers, _rdf_loop,
+// _cn_loop, _rdf_mol_loop, _cn_mol_loop). One kernel family serves all four loops:
+//
+//   H[class(type_i, type_j)][bin(rsq)] += 1      for every in-cutoff pair, exactly once
+//
+// where `bin` is a comparison of rsq against a host-made table of exact edges and `class` is a small
+// table lookup. The reference's outputs are integer-linear in H (see derive_* below), so the kernel
+// never sees the relation list. RDF uses the edges of trunc(sqrt(rsq)/ddr); CN uses the sorted
+// distinct cutoffs^2 as edges.
+//
+// Bit-exactness: rsq is built from exactly-rounded IEEE double ops in the reference's order,
+// with contraction off for this whole translation unit:
+//   d = head - other; if |d| > L/2: d -= sign(d)*L; rsq = (dx*dx + dy*dy) + dz*dz
+// The wrap is evaluated as  a = |d|;  a' = min(a, |a - L|)  which selects the same double:
+//   |d - sign(d)L| == | |d| - L |  (rounding is sign-symmetric), and for a > L/2 the real value
+//   |a - L| < a while for a <= L/2 it is >= a; rounding to nearest is monotone and `a` is itself a
+//   double, so the comparison of the rounded value against `a` falls the same way (ties give equal
+//   values). Only a^2 enters rsq, so the lost sign is irrelevant.
+//
+// Work decomposition: a block owns one tile of 256 "i" atoms of one frame (one atom per lane, in
+// registers) and sweeps a list of 256-atom "j" tiles staged through LDS (double-buffered, one
+// barrier per tile). For the triangular (atom-atom) case the j list is the half shell
+// J = I, I+1, ..., I+nT/2 (mod nT), which covers every unordered tile pair once with equal work per
+// block; only the J == I tile needs the i<j mask. Class histograms are LDS-private per block
+// (ds_add_u32) and flushed once with 64-bit global atomics into one of `slots` replicas.
+#include <algorithm>
+
+#include "ctx.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int TILE = 256;
+constexpr double PAD_I = -1.0e300;  // padding atoms: rsq overflows to +inf, never in cutoff, never NaN
+constexpr double PAD_J = 1.0e300;
+
+struct __attribute__((aligned(16))) JAtom {
+    double x, y, z;
+    int t;
+    int pad;
+};
+
+struct PairArgs {
+    const double *xi;  // [F][3][ni]
+    const double *xj;  // [F][3][nj]
+    const int *ti;     // compact type index of i atoms
+    const int *tj;
+    const double *box;           // [F][3]
+    const unsigned char *cls;    // [n_ti][n_tj] -> class, 0xFF = not counted in this pass
+    const double *edges;         // [nbins+1]
+    unsigned long long *hist;    // [slots | F][n_cls][nbins]
+    unsigned long long *overflow;
+    long long ni, nj, ti_fs, tj_fs;
+    double rc2;
+    float gscale;  // 1/bin_size as float for the sqrt guess; 0 -> scan up from bin 0 (CN edges)
+    int n_ti, n_tj, n_cls, nbins;
+    int n_frames, nTi, nTj, jsplit, blocks_per_frame;
+    int per_frame, slots;
+};
+
+__device__ __forceinline__ double wrap_abs(double d, double L)
+{
+    double a = __builtin_fabs(d);
+    double w = __builtin_fabs(a - L);
+    return __builtin_fmin(a, w);
+}
+
+struct BinCtx {
+    const double *edges;   // LDS, nbins+2 entries, last = +inf
+    unsigned *hist;        // LDS
+    unsigned *ovf;         // LDS
+    const unsigned char *cls_row;  // LDS row of this lane's i type
+    float gscale;
+    int nbins;
+};
+
+__device__ __forceinline__ void count_pair(const BinCtx &b, double rsq, int tj)
+{
+    int k = 0;
+    if (b.gscale > 0.f) {
+        k = (int)(__builtin_amdgcn_sqrtf((float)rsq) * b.gscale);
+        k = k > b.nbins ? b.nbins : k;
+        while (rsq < b.edges[k]) --k;  // edges[0] == 0 stops it
+    }
+    while (rsq >= b.edges[k + 1]) ++k;  // edges[nbins+1] == +inf stops it
+    if (k < b.nbins) {
+        unsigned c = b.cls_row[tj];
+        if (c != 0xFFu) atomicAdd(&b.hist[c * b.nbins + k], 1u);
+    } else {
+        atomicAdd(b.ovf, 1u);
+    }
+}
+
+template <bool DIAG>
+__device__ __forceinline__ void sweep_tile(const JAtom *__restrict__ tile, double xi, double yi,
+                                           double zi, double Lx, double Ly, double Lz, double rc2,
+                                           const BinCtx &b, int lane_id)
+{
+#pragma unroll 4
+    for (int jj = 0; jj < TILE; ++jj) {
+        const JAtom pj = tile[jj];
+        const double ax = wrap_abs(xi - pj.x, Lx);
+        const double ay = wrap_abs(yi - pj.y, Ly);
+        const double az = wrap_abs(zi - pj.z, Lz);
+        const double rsq = (ax * ax + ay * ay) + az * az;
+        bool in = rsq < rc2;
+        if (DIAG) in = in && (jj > lane_id);
+        if (in) count_pair(b, rsq, pj.t);
+    }
+}
+
+__device__ __forceinline__ JAtom load_atom(const double *__restrict__ xyz, const int *__restrict__ t,
+                                           long long n, long long g, double pad)
+{
+    JAtom a;
+    if (g < n) {
+        a.x = xyz[g];
+        a.y = xyz[n + g];
+        a.z = xyz[2 * n + g];
+        a.t = t[g];
+    } else {
+        a.x = a.y = a.z = pad;
+        a.t = 0;
+    }
+    a.pad = 0;
+    return a;
+}
+
+// number of half-shell shifts owned by i-tile I when there are nT tiles
+__device__ __host__ __forceinline__ int tri_shifts(int nT, int I)
+{
+    return (nT & 1) ? (nT + 1) / 2 : nT / 2 + (I < nT / 2 ? 1 : 0);
+}
+
+template <bool TRI>
+__global__ __launch_bounds__(TILE) void pair_hist_kernel(const PairArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+
+    // ---- which frame / i-tile / slice of the j list (XCD-aware: frames are dealt to XCDs) ----
+    const long long bid = blockIdx.x;
+    const int xcd = (int)(bid & 7);
+    const long long q = bid >> 3;
+    const int f = (int)(q / a.blocks_per_frame) * 8 + xcd;
+    if (f >= a.n_frames) return;
+    const int within = (int)(q % a.blocks_per_frame);
+    const int I = within % a.nTi;
+    const int split = within / a.nTi;
+
+    int t_begin, t_end;  // range in the block's j list
+    if (TRI) {
+        const int S = tri_shifts(a.nTi, I);
+        t_begin = (int)((long long)split * S / a.jsplit);
+        t_end = (int)((long long)(split + 1) * S / a.jsplit);
+    } else {
+        t_begin = (int)((long long)split * a.nTj / a.jsplit);
+        t_end = (int)((long long)(split + 1) * a.nTj / a.jsplit);
+    }
+    if (t_begin >= t_end) return;
+
+    // ---- LDS carve-up ----
+    double *s_edges = reinterpret_cast<double *>(smem);
+    size_t off = (((size_t)(a.nbins + 2) * 8) + 15) & ~size_t(15);
+    JAtom *s_tile = reinterpret_cast<JAtom *>(smem + off);
+    off += sizeof(JAtom) * 2 * TILE;
+    unsigned *s_hist = reinterpret_cast<unsigned *>(smem + off);
+    const int hist_words = a.n_cls * a.nbins;
+    off += (size_t)hist_words * 4;
+    unsigned *s_ovf = reinterpret_cast<unsigned *>(smem + off);
+    off += 16;
+    unsigned char *s_cls = smem + off;
+
+    for (int k = tid; k <= a.nbins; k += TILE) s_edges[k] = a.edges[k];
+    if (tid == 0) {
+        s_edges[a.nbins + 1] = __builtin_inf();
+        *s_ovf = 0u;
+    }
+    for (int k = tid; k < hist_words; k += TILE) s_hist[k] = 0u;
+    for (int k = tid; k < a.n_ti * a.n_tj; k += TILE) s_cls[k] = a.cls[k];
+
+    // ---- this lane's i atom ----
+    const double *xi_f = a.xi + (long long)f * 3 * a.ni;
+    const double *xj_f = a.xj + (long long)f * 3 * a.nj;
+    const int *ti_f = a.ti + (long long)f * a.ti_fs;
+    const int *tj_f = a.tj + (long long)f * a.tj_fs;
+    const double Lx = a.box[3 * f], Ly = a.box[3 * f + 1], Lz = a.box[3 * f + 2];
+    const JAtom me = load_atom(xi_f, ti_f, a.ni, (long long)I * TILE + tid, PAD_I);
+
+    BinCtx b;
+    b.edges = s_edges;
+    b.hist = s_hist;
+    b.ovf = s_ovf;
+    b.cls_row = s_cls + me.t * a.n_tj;
+    b.gscale = a.gscale;
+    b.nbins = a.nbins;
+
+    auto tile_of = [&](int t) -> int {
+        if (TRI) {
+            int J = I + t;
+            return J >= a.nTi ? J - a.nTi : J;
+        }
+        return t;
+    };
+
+    // ---- sweep the j list, staging tiles through two LDS buffers ----
+    JAtom nxt = load_atom(xj_f, tj_f, a.nj, (long long)tile_of(t_begin) * TILE + tid, PAD_J);
+    s_tile[tid] = nxt;
+    __syncthreads();
+    for (int t = t_begin; t < t_end; ++t) {
+        const int buf = (t - t_begin) & 1;
+        if (t + 1 < t_end)
+            nxt = load_atom(xj_f, tj_f, a.nj, (long long)tile_of(t + 1) * TILE + tid, PAD_J);
+        if (TRI && t == 0)
+            sweep_tile<true>(s_tile + buf * TILE, me.x, me.y, me.z, Lx, Ly, Lz, a.rc2, b, tid);
+        else
+            sweep_tile<false>(s_tile + buf * TILE, me.x, me.y, me.z, Lx, Ly, Lz, a.rc2, b, tid);
+        if (t + 1 < t_end) s_tile[(buf ^ 1) * TILE + tid] = nxt;
+        __syncthreads();
+    }
+
+    // ---- flush: one 64-bit global atomic per non-empty LDS word ----
+    unsigned long long *g =
+        a.hist + (size_t)(a.per_frame ? f : (int)(bid % a.slots)) * (size_t)hist_words;
+    for (int k = tid; k < hist_words; k += TILE) {
+        const unsigned v = s_hist[k];
+        if (v) atomicAdd(&g[k], (unsigned long long)v);
+    }
+    if (tid == 0 && *s_ovf) atomicAdd(a.overflow, (unsigned long long)*s_ovf);
+}
+
+__global__ void reduce_slots_kernel(const unsigned long long *__restrict__ in,
+                                    unsigned long long *__restrict__ out, int words, int slots)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= words) return;
+    unsigned long long s = 0;
+    for (int r = 0; r < slots; ++r) s += in[(size_t)r * words + k];
+    out[k] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+
+struct PairProblem {
+    int64_t n_frames;
+    int64_t ni, nj;
+    const double *d_xi, *d_xj;  // device
+    const int *d_ti, *d_tj;     // device compact type index
+    int64_t ti_fs, tj_fs;
+    const double *d_box;        // device [F][3]
+    bool tri;
+    int n_ti, n_tj;
+    std::vector<unsigned char> cls;  // [n_ti][n_tj] -> class id (< n_cls)
+    int n_cls;
+    int nbins;
+    const double *edges;  // host [nbins+1]
+    double rc2;
+    float gscale;
+    int per_frame;
+};
+
+size_t lds_bytes(int nbins, int n_cls, int n_ti, int n_tj)
+{
+    size_t off = (((size_t)(nbins + 2) * 8) + 15) & ~size_t(15);
+    off += sizeof(JAtom) * 2 * TILE;
+    off += (size_t)n_cls * nbins * 4;
+    off += 16;
+    off += (size_t)n_ti * n_tj;
+    return (off + 15) & ~size_t(15);
+}
+
+// Runs the kernel (in several passes when the class rows do not fit LDS) and returns the class
+// histograms on the host: H [F|1][n_cls][nbins], overflow count.
+int pair_hist_run(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64_t> &H, uint64_t *overflow)
+{
+    const int64_t F = p.n_frames;
+    const int nTi = (int)((p.ni + TILE - 1) / TILE);
+    const int nTj = (int)((p.nj + TILE - 1) / TILE);
+    const size_t out_frames = p.per_frame ? (size_t)F : 1;
+    H.assign(out_frames * p.n_cls * p.nbins, 0);
+    *overflow = 0;
+    if (F == 0 || p.ni == 0 || p.nj == 0) return MDHIP_OK;
+
+    // classes per pass limited by LDS (keep >= 2 blocks per CU when possible)
+    const size_t lds_cap = ctx->lds_max > 0 ? ctx->lds_max : 65536;
+    const size_t fixed = lds_bytes(p.nbins, 0, p.n_ti, p.n_tj);
+    if (fixed + (size_t)p.nbins * 4 > lds_cap)
+        return mdhip_fail(ctx, MDHIP_ELIMIT, "pair_hist: %d bins do not fit LDS (%zu B)", p.nbins,
+                          lds_cap);
+    const size_t budget = lds_cap / 2 > fixed + (size_t)p.nbins * 4 ? lds_cap / 2 : lds_cap;
+    int cls_per_pass = (int)((budget - fixed) / ((size_t)p.nbins * 4));
+    if (cls_per_pass > p.n_cls) cls_per_pass = p.n_cls;
+    if (cls_per_pass > 250) cls_per_pass = 250;
+    const int n_pass = (p.n_cls + cls_per_pass - 1) / cls_per_pass;
+
+    // geometry
+    int max_list = p.tri ? tri_shifts(nTi, 0) : nTj;
+    int jsplit = ctx->opt_rdf_jsplit;
+    if (jsplit <= 0) {
+        const int64_t want = (int64_t)ctx->cu_count * 16;
+        const int64_t base = (int64_t)nTi * F;
+        jsplit = (int)((want + base - 1) / base);
+    }
+    if (jsplit > max_list) jsplit = max_list;
+    if (jsplit < 1) jsplit = 1;
+    const int blocks_per_frame = nTi * jsplit;
+    const int64_t fgroups = (F + 7) / 8;
+    const int64_t grid = fgroups * 8 * blocks_per_frame;
+    if (grid > 0x7fffffffLL)
+        return mdhip_fail(ctx, MDHIP_ELIMIT, "pair_hist: grid of %lld blocks is too large",
+                          (long long)grid);
+    int slots = p.per_frame ? 1 : ctx->opt_rdf_slots;
+
+    // device tables
+    const size_t edges_b = (size_t)(p.nbins + 1) * 8;
+    const size_t cls_b = (size_t)p.n_ti * p.n_tj;
+    MD_WS(d_tab, unsigned char, WS_TABLES, edges_b + cls_b + 64);
+    MD_HIP(hipMemcpyAsync(d_tab, p.edges, edges_b, hipMemcpyHostToDevice, ctx->stream));
+    MD_WS(d_misc, unsigned long long, WS_MISC, 64);
+    MD_HIP(hipMemsetAsync(d_misc, 0, 64, ctx->stream));
+
+    double total_ms = 0.0;
+    int launches = 0;
+    std::vector<unsigned char> cls_pass(cls_b);
+    for (int pass = 0; pass < n_pass; ++pass) {
+        const int c0 = pass * cls_per_pass;
+        const int nc = (p.n_cls - c0) < cls_per_pass ? (p.n_cls - c0) : cls_per_pass;
+        for (size_t k = 0; k < cls_b; ++k) {
+            int c = p.cls[k];
+            cls_pass[k] = (c >= c0 && c < c0 + nc) ? (unsigned char)(c - c0) : 0xFF;
+        }
+        // pageable H2D copies are staged by the runtime before the call returns, so the vector can be reused
+        MD_HIP(hipMemcpyAsync(d_tab + edges_b, cls_pass.data(), cls_b, hipMemcpyHostToDevice,
+                              ctx->stream));
+        const size_t words = (size_t)nc * p.nbins;
+        const size_t acc_frames = p.per_frame ? (size_t)F : (size_t)slots;
+        MD_WS(d_hist, unsigned long long, WS_HIST, (acc_frames + 1) * words * 8);
+        MD_HIP(hipMemsetAsync(d_hist, 0, acc_frames * words * 8, ctx->stream));
+
+        PairArgs a;
+        a.xi = p.d_xi;
+        a.xj = p.d_xj;
+        a.ti = p.d_ti;
+        a.tj = p.d_tj;
+        a.box = p.d_box;
+        a.cls = d_tab + edges_b;
+        a.edges = reinterpret_cast<const double *>(d_tab);
+        a.hist = d_hist;
+        a.overflow = d_misc;
+        a.ni = p.ni;
+        a.nj = p.nj;
+        a.ti_fs = p.ti_fs;
+        a.tj_fs = p.tj_fs;
+        a.rc2 = p.rc2;
+        a.gscale = p.gscale;
+        a.n_ti = p.n_ti;
+        a.n_tj = p.n_tj;
+        a.n_cls = nc;
+        a.nbins = p.nbins;
+        a.n_frames = (int)F;
+        a.nTi = nTi;
+        a.nTj = nTj;
+        a.jsplit = jsplit;
+        a.blocks_per_frame = blocks_per_frame;
+        a.per_frame = p.per_frame;
+        a.slots = slots;
+
+        const size_t lds = lds_bytes(p.nbins, nc, p.n_ti, p.n_tj);
+        auto kern = p.tri ? pair_hist_kernel<true> : pair_hist_kernel<false>;
+        if (lds > 65536)
+            MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        KernelTimer timer(ctx);
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(TILE), lds, ctx->stream, a);
+        timer.stop();
+        MD_HIP(hipGetLastError());
+
+        unsigned long long *d_final = d_hist;
+        if (!p.per_frame && slots > 1) {
+            d_final = d_hist + (size_t)slots * words;
+            hipLaunchKernelGGL(reduce_slots_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256),
+                               0, ctx->stream, d_hist, d_final, (int)words, slots);
+            MD_HIP(hipGetLastError());
+        }
+        // D2H into the right class rows
+        std::vector<uint64_t> tmp(out_frames * words);
+        MD_HIP(hipMemcpyAsync(tmp.data(), d_final, out_frames * words * 8, hipMemcpyDeviceToHost,
+                              ctx->stream));
+        MD_HIP(hipStreamSynchronize(ctx->stream));
+        timer.collect();
+        total_ms += ctx->last_ms;
+        ++launches;
+        for (size_t fr = 0; fr < out_frames; ++fr)
+            memcpy(&H[(fr * p.n_cls + c0) * p.nbins], &tmp[fr * words], words * 8);
+    }
+    unsigned long long ov = 0;
+    MD_HIP(hipMemcpyAsync(&ov, d_misc, 8, hipMemcpyDeviceToHost, ctx->stream));
+    MD_HIP(hipStreamSynchronize(ctx->stream));
+    // with several passes every in-cutoff overflow pair is seen once per pass
+    *overflow = ov / (uint64_t)n_pass;
+    ctx->last_ms = total_ms;
+    ctx->last_launches = launches;
+    return MDHIP_OK;
+}
+
+// labels -> compact indices 0..T-1 (sorted unique labels)
+void compact_labels(const int32_t *lab, size_t n, std::vector<int32_t> &uniq, std::vector<int32_t> &idx)
+{
+    uniq.assign(lab, lab + n);
+    std::sort(uniq.begin(), uniq.end());
+    uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+    idx.resize(n);
+    for (size_t k = 0; k < n; ++k)
+        idx[k] = (int32_t)(std::lower_bound(uniq.begin(), uniq.end(), lab[k]) - uniq.begin());
+}
+
+int find_label(const std::vector<int32_t> &uniq, int32_t lab)
+{
+    auto it = std::lower_bound(uniq.begin(), uniq.end(), lab);
+    return (it != uniq.end() && *it == lab) ? (int)(it - uniq.begin()) : -1;
+}
+
+// Relations -> classes. Triangular: unordered type pairs {a,b}; rectangular: ordered (atom type,
+// site type). rel_cls[kl] = class id, or -1 when a label does not occur in the data (the reference
+// then counts nothing); the last class collects every pair no relation asks for.
+void build_classes(bool tri, const std::vector<int32_t> &ui, const std::vector<int32_t> &uj, int n_rel,
+                   const int32_t *rel, std::vector<unsigned char> &cls, std::vector<int> &rel_cls,
+                   int &n_cls)
+{
+    const int n_ti = (int)ui.size(), n_tj = (int)uj.size();
+    std::vector<int> map((size_t)n_ti * n_tj, -1);
+    rel_cls.assign(n_rel, -1);
+    int next = 0;
+    for (int kl = 0; kl < n_rel; ++kl) {
+        const int a = find_label(ui, rel[2 * kl]);
+        const int b = find_label(uj, rel[2 * kl + 1]);
+        if (a < 0 || b < 0) continue;
+        int &slot = map[(size_t)a * n_tj + b];
+        if (slot < 0) {
+            slot = next++;
+            if (tri) map[(size_t)b * n_tj + a] = slot;
+        }
+        rel_cls[kl] = slot;
+    }
+    n_cls = next + 1;
+    cls.resize((size_t)n_ti * n_tj);
+    for (size_t k = 0; k < cls.size(); ++k) cls[k] = (unsigned char)(map[k] < 0 ? next : map[k]);
+}
+
+struct RelJob {
+    bool tri;
+    int64_t F, ni, nj;
+    const double *xi, *xj;  // host|dev
+    int xi_dev, xj_dev;
+    const int32_t *lab_i;  // host labels [ni] or [F][ni]
+    int64_t lab_i_fs;
+    const int32_t *lab_j;  // host labels [nj] (rectangular only)
+    const double *box;     // host [F][3]
+    int n_rel;
+    const int32_t *rel;
+    int nbins;
+    const double *edges;  // host [nbins+1]
+    double rc2;
+    float gscale;
+    int per_frame;
+};
+
+// Stages everything, runs the kernel and returns class histograms + the relation->class map.
+int run_job(mdhip_ctx *ctx, const RelJob &j, std::vector<uint64_t> &H, std::vector<int> &rel_cls,
+            int &n_cls, uint64_t *overflow)
+{
+    std::vector<int32_t> ui, idx_i, uj, idx_j;
+    const size_t n_lab_i = j.lab_i_fs ? (size_t)j.F * j.ni : (size_t)j.ni;
+    compact_labels(j.lab_i, n_lab_i, ui, idx_i);
+    if (!j.tri) compact_labels(j.lab_j, (size_t)j.nj, uj, idx_j);
+    const std::vector<int32_t> &ujr = j.tri ? ui : uj;
+    if (ui.size() * ujr.size() > 16384)
+        return mdhip_fail(ctx, MDHIP_ELIMIT, "too many distinct types (%zu x %zu)", ui.size(),
+                          ujr.size());
+
+    PairProblem p;
+    p.tri = j.tri;
+    build_classes(j.tri, ui, ujr, j.n_rel, j.rel, p.cls, rel_cls, n_cls);
+    p.n_cls = n_cls;
+    p.n_ti = (int)ui.size();
+    p.n_tj = (int)ujr.size();
+
+    int rc;
+    p.d_xi = (const double *)mdhip_stage(ctx, WS_XYZ_I, j.xi, (size_t)j.F * 3 * j.ni * 8, j.xi_dev, &rc);
+    if (rc) return rc;
+    MD_WS(d_ti, int, WS_TYPE_I, idx_i.size() * 4);
+    MD_HIP(hipMemcpyAsync(d_ti, idx_i.data(), idx_i.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    p.d_ti = d_ti;
+    p.ti_fs = j.lab_i_fs;
+    if (j.tri) {
+        p.d_xj = p.d_xi;
+        p.d_tj = p.d_ti;
+        p.tj_fs = p.ti_fs;
+        p.nj = j.ni;
+    } else {
+        p.d_xj = (const double *)mdhip_stage(ctx, WS_XYZ_J, j.xj, (size_t)j.F * 3 * j.nj * 8, j.xj_dev, &rc);
+        if (rc) return rc;
+        MD_WS(d_tj, int, WS_TYPE_J, idx_j.size() * 4);
+        MD_HIP(hipMemcpyAsync(d_tj, idx_j.data(), idx_j.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        p.d_tj = d_tj;
+        p.tj_fs = 0;
+        p.nj = j.nj;
+    }
+    MD_WS(d_box, double, WS_BOX, (size_t)j.F * 3 * 8);
+    MD_HIP(hipMemcpyAsync(d_box, j.box, (size_t)j.F * 3 * 8, hipMemcpyHostToDevice, ctx->stream));
+    p.d_box = d_box;
+    p.n_frames = j.F;
+    p.ni = j.ni;
+    p.nbins = j.nbins;
+    p.edges = j.edges;
+    p.rc2 = j.rc2;
+    p.gscale = j.gscale;
+    p.per_frame = j.per_frame;
+    // idx vectors must outlive the async copies: pageable copies are staged before return, but be explicit
+    MD_HIP(hipStreamSynchronize(ctx->stream));
+    return pair_hist_run(ctx, p, H, overflow);
+}
+
+// CN: edges are the sorted distinct positive cutoffs^2; rank[kl] = number of bins below relation kl's cutoff.
+void cn_edges(int n_rel, const double *rc2, std::vector<double> &edges, std::vector<int> &rank)
+{
+    std::vector<double> q;
+    for (int kl = 0; kl < n_rel; ++kl)
+        if (rc2[kl] > 0.0) q.push_back(rc2[kl]);
+    std::sort(q.begin(), q.end());
+    q.erase(std::unique(q.begin(), q.end()), q.end());
+    edges.assign(1, 0.0);
+    edges.insert(edges.end(), q.begin(), q.end());
+    rank.assign(n_rel, 0);
+    for (int kl = 0; kl < n_rel; ++kl)
+        if (rc2[kl] > 0.0)
+            rank[kl] = (int)(std::lower_bound(q.begin(), q.end(), rc2[kl]) - q.begin()) + 1;
+}
+
+int check_common(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const void *xyz, const void *type,
+                 const void *box, int n_rel, const void *rel)
+{
+    if (!ctx) return MDHIP_EINVAL;
+    MD_REQUIRE(n_frames >= 0 && n_atoms >= 0, "negative sizes");
+    MD_REQUIRE(n_frames == 0 || n_atoms == 0 || (xyz && type && box), "NULL input array");
+    MD_REQUIRE(n_rel >= 0 && (n_rel == 0 || rel), "bad relation table");
+    MD_REQUIRE(n_frames < (1LL << 31) && n_atoms < (1LL << 31), "sizes exceed 2^31");
+    return MDHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mdhip_rdf_atomic(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *xyz,
+                     int on_device, const int32_t *type, int64_t type_frame_stride,
+                     const double *box, int n_rel, const int32_t *rel, double r_cut_sq,
+                     double bin_size, int nbins, const double *edges, int per_frame,
+                     uint64_t *hist_full, uint64_t *hist_part, uint64_t *overflow)
+{
+    int rc = check_common(ctx, n_frames, n_atoms, xyz, type, box, n_rel, rel);
+    if (rc) return rc;
+    MD_REQUIRE(nbins >= 1 && bin_size > 0.0, "nbins and bin_size must be positive");
+    MD_REQUIRE(type_frame_stride == 0 || type_frame_stride == n_atoms,
+               "type_frame_stride must be 0 or n_atoms");
+    MD_REQUIRE(hist_full && (n_rel == 0 || hist_part), "NULL output");
+    MD_HIP(hipSetDevice(ctx->device));
+    const size_t out_frames = per_frame ? (size_t)n_frames : 1;
+    std::fill(hist_full, hist_full + out_frames * nbins, (uint64_t)0);
+    if (n_rel) std::fill(hist_part, hist_part + out_frames * n_rel * nbins, (uint64_t)0);
+    if (overflow) *overflow = 0;
+    if (n_frames == 0 || n_atoms < 2) return MDHIP_OK;
+
+    std::vector<double> own_edges;
+    if (!edges) {
+        own_edges.resize(nbins + 1);
+        mdhip_bin_edges(bin_size, nbins, own_edges.data());
+        edges = own_edges.data();
+    }
+    RelJob j{};
+    j.tri = true;
+    j.F = n_frames;
+    j.ni = j.nj = n_atoms;
+    j.xi = xyz;
+    j.xi_dev = on_device;
+    j.lab_i = type;
+    j.lab_i_fs = type_frame_stride;
+    j.box = box;
+    j.n_rel = n_rel;
+    j.rel = rel;
+    j.nbins = nbins;
+    j.edges = edges;
+    j.rc2 = r_cut_sq;
+    j.gscale = (float)(1.0 / bin_size);
+    j.per_frame = per_frame;
+    std::vector<uint64_t> H;
+    std::vector<int> rel_cls;
+    int n_cls = 0;
+    uint64_t ov = 0;
+    rc = run_job(ctx, j, H, rel_cls, n_cls, &ov);
+    if (rc) return rc;
+    if (overflow) *overflow = ov;
+    // rdf_full[bin] += 2 per pair (rdf_cn.py:85-86); rdf_part: +1 per unordered {a,b} pair, +2 when a == b
+    for (size_t f = 0; f < out_frames; ++f) {
+        const uint64_t *Hf = &H[f * n_cls * nbins];
+        uint64_t *full = hist_full + f * nbins;
+        for (int c = 0; c < n_cls; ++c)
+            for (int b = 0; b < nbins; ++b) full[b] += 2 * Hf[(size_t)c * nbins + b];
+        for (int kl = 0; kl < n_rel; ++kl) {
+            if (rel_cls[kl] < 0) continue;
+            const uint64_t mult = rel[2 * kl] == rel[2 * kl + 1] ? 2 : 1;
+            uint64_t *part = hist_part + (f * n_rel + kl) * nbins;
+            const uint64_t *row = Hf + (size_t)rel_cls[kl] * nbins;
+            for (int b = 0; b < nbins; ++b) part[b] = mult * row[b];
+        }
+    }
+    return MDHIP_OK;
+}
+
+int mdhip_cn_atomic(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *xyz,
+                    int on_device, const int32_t *type, int64_t type_frame_stride,
+                    const double *box, int n_rel, const int32_t *rel, const double *r_cut_sq,
+                    int per_frame, uint64_t *cn)
+{
+    int rc = check_common(ctx, n_frames, n_atoms, xyz, type, box, n_rel, rel);
+    if (rc) return rc;
+    MD_REQUIRE(n_rel == 0 || (r_cut_sq && cn), "NULL cutoff or output");
+    MD_REQUIRE(type_frame_stride == 0 || type_frame_stride == n_atoms,
+               "type_frame_stride must be 0 or n_atoms");
+    MD_HIP(hipSetDevice(ctx->device));
+    const size_t out_frames = per_frame ? (size_t)n_frames : 1;
+    std::fill(cn, cn + out_frames * n_rel, (uint64_t)0);
+    if (n_frames == 0 || n_atoms < 2 || n_rel == 0) return MDHIP_OK;
+    std::vector<double> edges;
+    std::vector<int> rank;
+    cn_edges(n_rel, r_cut_sq, edges, rank);
+    const int nbins = (int)edges.size() - 1;
+    if (nbins == 0) return MDHIP_OK;
+    RelJob j{};
+    j.tri = true;
+    j.F = n_frames;
+    j.ni = j.nj = n_atoms;
+    j.xi = xyz;
+    j.xi_dev = on_device;
+    j.lab_i = type;
+    j.lab_i_fs = type_frame_stride;
+    j.box = box;
+    j.n_rel = n_rel;
+    j.rel = rel;
+    j.nbins = nbins;
+    j.edges = edges.data();
+    j.rc2 = edges.back();
+    j.gscale = 0.f;
+    j.per_frame = per_frame;
+    std::vector<uint64_t> H;
+    std::vector<int> rel_cls;
+    int n_cls = 0;
+    uint64_t ov = 0;
+    rc = run_job(ctx, j, H, rel_cls, n_cls, &ov);
+    if (rc) return rc;
+    for (size_t f = 0; f < out_frames; ++f)
+        for (int kl = 0; kl < n_rel; ++kl) {
+            if (rel_cls[kl] < 0) continue;
+            const uint64_t mult = rel[2 * kl] == rel[2 * kl + 1] ? 2 : 1;
+            const uint64_t *row = &H[(f * n_cls + rel_cls[kl]) * nbins];
+            uint64_t s = 0;
+            for (int b = 0; b < rank[kl]; ++b) s += row[b];
+            cn[f * n_rel + kl] = mult * s;
+        }
+    return MDHIP_OK;
+}
+
+int mdhip_rdf_sites(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *xyz,
+                    int xyz_on_device, const int32_t *type, int64_t n_sites, const double *sites,
+                    int sites_on_device, const int32_t *site_type, const double *box, int n_rel,
+                    const int32_t *rel, double r_cut_sq, double bin_size, int nbins,
+                    const double *edges, int per_frame, uint64_t *hist_part, uint64_t *overflow)
+{
+    int rc = check_common(ctx, n_frames, n_atoms, xyz, type, box, n_rel, rel);
+    if (rc) return rc;
+    MD_REQUIRE(n_sites >= 0 && n_sites < (1LL << 31), "bad n_sites");
+    MD_REQUIRE(n_frames == 0 || n_sites == 0 || (sites && site_type), "NULL site arrays");
+    MD_REQUIRE(nbins >= 1 && bin_size > 0.0, "nbins and bin_size must be positive");
+    MD_REQUIRE(n_rel == 0 || hist_part, "NULL output");
+    MD_HIP(hipSetDevice(ctx->device));
+    const size_t out_frames = per_frame ? (size_t)n_frames : 1;
+    if (n_rel) std::fill(hist_part, hist_part + out_frames * n_rel * nbins, (uint64_t)0);
+    if (overflow) *overflow = 0;
+    if (n_frames == 0 || n_atoms == 0 || n_sites == 0 || n_rel == 0) return MDHIP_OK;
+    std::vector<double> own_edges;
+    if (!edges) {
+        own_edges.resize(nbins + 1);
+        mdhip_bin_edges(bin_size, nbins, own_edges.data());
+        edges = own_edges.data();
+    }
+    RelJob j{};
+    j.tri = false;
+    j.F = n_frames;
+    j.ni = n_atoms;
+    j.nj = n_sites;
+    j.xi = xyz;
+    j.xi_dev = xyz_on_device;
+    j.xj = sites;
+    j.xj_dev = sites_on_device;
+    j.lab_i = type;
+    j.lab_i_fs = 0;
+    j.lab_j = site_type;
+    j.box = box;
+    j.n_rel = n_rel;
+    j.rel = rel;
+    j.nbins = nbins;
+    j.edges = edges;
+    j.rc2 = r_cut_sq;
+    j.gscale = (float)(1.0 / bin_size);
+    j.per_frame = per_frame;
+    std::vector<uint64_t> H;
+    std::vector<int> rel_cls;
+    int n_cls = 0;
+    uint64_t ov = 0;
+    rc = run_job(ctx, j, H, rel_cls, n_cls, &ov);
+    if (rc) return rc;
+    if (overflow) *overflow = ov;
+    for (size_t f = 0; f < out_frames; ++f)
+        for (int kl = 0; kl < n_rel; ++kl) {
+            if (rel_cls[kl] < 0) continue;
+            memcpy(hist_part + (f * n_rel + kl) * nbins, &H[(f * n_cls + rel_cls[kl]) * nbins],
+                   (size_t)nbins * 8);
+        }
+    return MDHIP_OK;
+}
+
+int mdhip_cn_sites(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *xyz,
+                   int xyz_on_device, const int32_t *type, int64_t n_sites, const double *sites,
+                   int sites_on_device, const int32_t *site_type, const double *box, int n_rel,
+                   const int32_t *rel, const double *r_cut_sq, int per_frame, uint64_t *cn)
+{
+    int rc = check_common(ctx, n_frames, n_atoms, xyz, type, box, n_rel, rel);
+    if (rc) return rc;
+    MD_REQUIRE(n_sites >= 0 && n_sites < (1LL << 31), "bad n_sites");
+    MD_REQUIRE(n_frames == 0 || n_sites == 0 || (sites && site_type), "NULL site arrays");
+    MD_REQUIRE(n_rel == 0 || (r_cut_sq && cn), "NULL cutoff or output");
+    MD_HIP(hipSetDevice(ctx->device));
+    const size_t out_frames = per_frame ? (size_t)n_frames : 1;
+    std::fill(cn, cn + out_frames * n_rel, (uint64_t)0);
+    if (n_frames == 0 || n_atoms == 0 || n_sites == 0 || n_rel == 0) return MDHIP_OK;
+    std::vector<double> edges;
+    std::vector<int> rank;
+    cn_edges(n_rel, r_cut_sq, edges, rank);
+    const int nbins = (int)edges.size() - 1;
+    if (nbins == 0) return MDHIP_OK;
+    RelJob j{};
+    j.tri = false;
+    j.F = n_frames;
+    j.ni = n_atoms;
+    j.nj = n_sites;
+    j.xi = xyz;
+    j.xi_dev = xyz_on_device;
+    j.xj = sites;
+    j.xj_dev = sites_on_device;
+    j.lab_i = type;
+    j.lab_i_fs = 0;
+    j.lab_j = site_type;
+    j.box = box;
+    j.n_rel = n_rel;
+    j.rel = rel;
+    j.nbins = nbins;
+    j.edges = edges.data();
+    j.rc2 = edges.back();
+    j.gscale = 0.f;
+    j.per_frame = per_frame;
+    std::vector<uint64_t> H;
+    std::vector<int> rel_cls;
+    int n_cls = 0;
+    uint64_t ov = 0;
+    rc = run_job(ctx, j, H, rel_cls, n_cls, &ov);
+    if (rc) return rc;
+    for (size_t f = 0; f < out_frames; ++f)
+        for (int kl = 0; kl < n_rel; ++kl) {
+            if (rel_cls[kl] < 0) continue;
+            const uint64_t *row = &H[(f * n_cls + rel_cls[kl]) * nbins];
+            uint64_t s = 0;
+            for (int b = 0; b < rank[kl]; ++b) s += row[b];
+            cn[f * n_rel + kl] = s;
+        }
+    return MDHIP_OK;
+}
+
+}  // extern "C"

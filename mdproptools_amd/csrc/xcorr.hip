@@ -1,0 +1,259 @@
+// xcorr.hip — Green-Kubo correlation functions (G2, G3) for gfx950.
+//
+// Replaces dynamical/conductivity.py:97-114 (correlate), dynamical/viscosity.py:103-115
+// (autocorrelate "wkt" and "brute_force") of the reference:
+//     c[k] = sum_{t=0}^{n-1-k} a[t+k] * b[t] / (n-k)
+//
+// MDHIP_XCORR_FFT: zero-pad to 2n, real-to-complex transforms, A*conj(B), inverse, first n lags,
+// unbiased 1/(n-k). The transforms are plain library FFTs (hipFFT/rocFFT); the pointwise kernels
+// are here. HBM-bound: 3 transforms of 2n points per series pair.
+//
+// MDHIP_XCORR_DIRECT: register-blocked direct lag sums, FP64-FMA bound (n^2/2 fused multiply-adds
+// per pair). A block owns a tile of 2048 consecutive lags (8 per lane) and streams time in chunks
+// staged through LDS; a lane keeps a 16-deep sliding window of `a` in registers so that 8 LDS reads
+// feed 64 FMAs. The a-window is stored transposed in LDS ([i mod 8][i div 8]) so that the 64 lanes
+// of a wave read consecutive doubles (no bank conflicts). Lag tiles are paired (j, nT-1-j) so every
+// block has the same amount of work; time is split into slabs whose partial sums are added in a
+// fixed order by a second kernel (no float atomics).
+#include <hipfft/hipfft.h>
+
+#include <algorithm>
+#include <map>
+
+#include "ctx.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// FFT path
+// ---------------------------------------------------------------------------------------------
+
+__global__ void pad_kernel(const double *__restrict__ src, double *__restrict__ dst, long long n)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 2 * n) dst[i] = i < n ? src[i] : 0.0;
+}
+
+// A <- A * conj(B)
+__global__ void mul_conj_kernel(double2 *__restrict__ A, const double2 *__restrict__ B, long long m)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const double2 a = A[i], b = B[i];
+    A[i] = make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+
+// out[k] = c[k] / (2n) / (n-k): numpy's ifft normalisation, then conductivity.py:113 / viscosity.py:114
+__global__ void scale_unbiased_kernel(const double *__restrict__ c, double *__restrict__ out,
+                                      long long n, long long n_lags)
+{
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_lags) return;
+    out[k] = (c[k] / (double)(2 * n)) / (double)(n - k);
+}
+
+struct FftPlans {
+    hipfftHandle fwd = 0, inv = 0;
+};
+std::map<std::pair<mdhip_ctx *, long long>, FftPlans> g_plans;
+
+int get_plans(mdhip_ctx *ctx, long long n, FftPlans &out)
+{
+    auto key = std::make_pair(ctx, n);
+    auto it = g_plans.find(key);
+    if (it != g_plans.end()) {
+        out = it->second;
+        return MDHIP_OK;
+    }
+    FftPlans p;
+    if (hipfftPlan1d(&p.fwd, (int)(2 * n), HIPFFT_D2Z, 1) != HIPFFT_SUCCESS ||
+        hipfftPlan1d(&p.inv, (int)(2 * n), HIPFFT_Z2D, 1) != HIPFFT_SUCCESS)
+        return mdhip_fail(ctx, MDHIP_EHIP, "hipfftPlan1d(%lld) failed", 2 * n);
+    g_plans[key] = p;
+    out = p;
+    return MDHIP_OK;
+}
+
+int xcorr_fft(mdhip_ctx *ctx, long long n, int n_pairs, const double *d_a, const double *d_b,
+              bool same, long long n_lags, double *d_out)
+{
+    FftPlans pl;
+    int rc = get_plans(ctx, n, pl);
+    if (rc) return rc;
+    hipfftSetStream(pl.fwd, ctx->stream);
+    hipfftSetStream(pl.inv, ctx->stream);
+    const long long m = n + 1;  // complex outputs of a 2n-point real transform
+    MD_WS(d_pad, double, WS_AUX0, (size_t)2 * n * 8 + 64);
+    MD_WS(d_A, double2, WS_AUX1, (size_t)m * 16);
+    MD_WS(d_B, double2, WS_AUX2, (size_t)m * 16);
+    const unsigned gp = (unsigned)((2 * n + 255) / 256), gm = (unsigned)((m + 255) / 256);
+    for (int p = 0; p < n_pairs; ++p) {
+        hipLaunchKernelGGL(pad_kernel, dim3(gp), dim3(256), 0, ctx->stream, d_a + (size_t)p * n, d_pad, n);
+        if (hipfftExecD2Z(pl.fwd, d_pad, reinterpret_cast<hipfftDoubleComplex *>(d_A)) != HIPFFT_SUCCESS)
+            return mdhip_fail(ctx, MDHIP_EHIP, "hipfftExecD2Z failed");
+        const double2 *Bp = d_A;
+        if (!same) {
+            hipLaunchKernelGGL(pad_kernel, dim3(gp), dim3(256), 0, ctx->stream, d_b + (size_t)p * n, d_pad, n);
+            if (hipfftExecD2Z(pl.fwd, d_pad, reinterpret_cast<hipfftDoubleComplex *>(d_B)) != HIPFFT_SUCCESS)
+                return mdhip_fail(ctx, MDHIP_EHIP, "hipfftExecD2Z failed");
+            Bp = d_B;
+        }
+        hipLaunchKernelGGL(mul_conj_kernel, dim3(gm), dim3(256), 0, ctx->stream, d_A, Bp, m);
+        if (hipfftExecZ2D(pl.inv, reinterpret_cast<hipfftDoubleComplex *>(d_A), d_pad) != HIPFFT_SUCCESS)
+            return mdhip_fail(ctx, MDHIP_EHIP, "hipfftExecZ2D failed");
+        hipLaunchKernelGGL(scale_unbiased_kernel, dim3((unsigned)((n_lags + 255) / 256)), dim3(256), 0,
+                           ctx->stream, d_pad, d_out + (size_t)p * n_lags, n, n_lags);
+        MD_HIP(hipGetLastError());
+    }
+    return MDHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// direct path
+// ---------------------------------------------------------------------------------------------
+
+constexpr int DX_THREADS = 256;
+constexpr int DX_LPT = 8;                        // consecutive lags per lane
+constexpr int DX_KT = DX_THREADS * DX_LPT;       // lags per tile (2048)
+constexpr int DX_TT = 2048;                      // time steps per LDS stage (multiple of 8)
+constexpr int DX_AW = DX_TT + DX_KT + 8;         // a-window length per stage
+constexpr int DX_ROW = DX_AW / 8 + 1;            // transposed rows: 8 rows of DX_ROW doubles
+
+// partial[slab][lag] = sum over the slab's time range of a[t+lag]*b[t]
+__global__ __launch_bounds__(DX_THREADS) void xcorr_direct_kernel(
+    const double *__restrict__ a, const double *__restrict__ b, long long n, long long n_lags,
+    int n_tiles, int n_slabs, double *__restrict__ partial)
+{
+    __shared__ double s_a[8 * DX_ROW];
+    __shared__ __attribute__((aligned(16))) double s_b[DX_TT];
+    const int tid = threadIdx.x;
+    const int pair_id = blockIdx.x;  // handles lag tiles pair_id and n_tiles-1-pair_id
+    const int slab = blockIdx.y;
+
+    for (int half = 0; half < 2; ++half) {
+        const int tile = half == 0 ? pair_id : n_tiles - 1 - pair_id;
+        if (half == 1 && tile == pair_id) break;
+        const long long K0 = (long long)tile * DX_KT;
+        if (K0 >= n_lags) continue;
+        // time range of this tile: t in [0, n-K0); split evenly into n_slabs slabs (multiples of 8)
+        const long long t_total = n - K0;
+        long long per = (t_total + n_slabs - 1) / n_slabs;
+        per = (per + 7) & ~7LL;
+        const long long t_lo = (long long)slab * per;
+        const long long t_hi = t_lo + per < t_total ? t_lo + per : t_total;
+        double acc[DX_LPT];
+#pragma unroll
+        for (int m = 0; m < DX_LPT; ++m) acc[m] = 0.0;
+
+        for (long long T0 = t_lo; T0 < t_hi; T0 += DX_TT) {
+            __syncthreads();
+            // stage b[T0 .. T0+TT) and a[T0+K0 .. T0+K0+AW), zero beyond the valid range
+            for (int i = tid; i < DX_TT; i += DX_THREADS) {
+                const long long t = T0 + i;
+                s_b[i] = t < t_hi ? b[t] : 0.0;
+            }
+            for (int i = tid; i < DX_AW; i += DX_THREADS) {
+                const long long g = T0 + K0 + i;
+                s_a[(i & 7) * DX_ROW + (i >> 3)] = g < n ? a[g] : 0.0;
+            }
+            __syncthreads();
+            // lane window: w[j] = a_stage[8*tid + j + tt], element index i = 8*tid + j + tt
+            // with tt a multiple of 8 -> row (j & 7), column tid + tt/8 + (j >> 3)
+            double w[16];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j] = s_a[j * DX_ROW + tid];
+            for (int tt = 0; tt < DX_TT; tt += 8) {
+                const int col = tid + (tt >> 3) + 1;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) w[8 + j] = s_a[j * DX_ROW + col];
+                double bt[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) bt[u] = s_b[tt + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int m = 0; m < DX_LPT; ++m) acc[m] = __builtin_fma(w[u + m], bt[u], acc[m]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) w[j] = w[8 + j];
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < DX_LPT; ++m) {
+            const long long k = K0 + (long long)tid * DX_LPT + m;
+            if (k < n_lags) partial[(size_t)slab * n_lags + k] = acc[m];
+        }
+    }
+}
+
+__global__ void xcorr_finish_kernel(const double *__restrict__ partial, double *__restrict__ out,
+                                    long long n, long long n_lags, int n_slabs)
+{
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_lags) return;
+    double s = 0.0;
+    for (int r = 0; r < n_slabs; ++r) s += partial[(size_t)r * n_lags + k];
+    out[k] = s / (double)(n - k);
+}
+
+int xcorr_direct(mdhip_ctx *ctx, long long n, int n_pairs, const double *d_a, const double *d_b,
+                 long long n_lags, double *d_out)
+{
+    const int n_tiles = (int)((n_lags + DX_KT - 1) / DX_KT);
+    const int n_blocks = (n_tiles + 1) / 2;
+    int n_slabs = ctx->opt_xcorr_tile > 0 ? ctx->opt_xcorr_tile : (ctx->cu_count * 4 + n_blocks - 1) / n_blocks;
+    const long long max_slabs = (n + DX_TT - 1) / DX_TT;
+    if (n_slabs > max_slabs) n_slabs = (int)max_slabs;
+    if (n_slabs < 1) n_slabs = 1;
+    MD_WS(d_partial, double, WS_PART, (size_t)n_slabs * n_lags * 8);
+    for (int p = 0; p < n_pairs; ++p) {
+        // a slab can be empty for short tiles: start from zeros
+        MD_HIP(hipMemsetAsync(d_partial, 0, (size_t)n_slabs * n_lags * 8, ctx->stream));
+        hipLaunchKernelGGL(xcorr_direct_kernel, dim3((unsigned)n_blocks, (unsigned)n_slabs),
+                           dim3(DX_THREADS), 0, ctx->stream, d_a + (size_t)p * n, d_b + (size_t)p * n, n,
+                           n_lags, n_tiles, n_slabs, d_partial);
+        MD_HIP(hipGetLastError());
+        hipLaunchKernelGGL(xcorr_finish_kernel, dim3((unsigned)((n_lags + 255) / 256)), dim3(256), 0,
+                           ctx->stream, d_partial, d_out + (size_t)p * n_lags, n, n_lags, n_slabs);
+        MD_HIP(hipGetLastError());
+    }
+    return MDHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mdhip_xcorr(mdhip_ctx *ctx, int64_t n, int n_pairs, const double *a, const double *b,
+                int on_device, int method, int64_t n_lags, double *out)
+{
+    if (!ctx) return MDHIP_EINVAL;
+    MD_REQUIRE(n >= 0 && n_pairs >= 0 && n_lags >= 0 && n_lags <= n, "bad sizes (n_lags must be <= n)");
+    MD_REQUIRE(method == MDHIP_XCORR_FFT || method == MDHIP_XCORR_DIRECT, "unknown method %d", method);
+    if (n == 0 || n_pairs == 0 || n_lags == 0) return MDHIP_OK;
+    MD_REQUIRE(a && b && out, "NULL array");
+    MD_REQUIRE(n < (1LL << 30), "series longer than 2^30 samples are not supported");
+    MD_HIP(hipSetDevice(ctx->device));
+    int rc;
+    const size_t in_b = (size_t)n_pairs * n * 8;
+    const bool same = a == b;
+    const double *d_a = (const double *)mdhip_stage(ctx, WS_XYZ_I, a, in_b, on_device, &rc);
+    if (rc) return rc;
+    const double *d_b = d_a;
+    if (!same) {
+        d_b = (const double *)mdhip_stage(ctx, WS_XYZ_J, b, in_b, on_device, &rc);
+        if (rc) return rc;
+    }
+    const size_t out_b = (size_t)n_pairs * n_lags * 8;
+    MD_WS(d_out, double, WS_OUT, out_b);
+    KernelTimer timer(ctx, n_pairs);
+    rc = method == MDHIP_XCORR_FFT ? xcorr_fft(ctx, n, n_pairs, d_a, d_b, same, n_lags, d_out)
+                                   : xcorr_direct(ctx, n, n_pairs, d_a, d_b, n_lags, d_out);
+    timer.stop();
+    if (rc) return rc;
+    MD_HIP(hipMemcpyAsync(out, d_out, out_b, hipMemcpyDeviceToHost, ctx->stream));
+    MD_HIP(hipStreamSynchronize(ctx->stream));
+    timer.collect();
+    return MDHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,393 @@
+"""
+GPU parity tests proper: every kernel is called through the C-ABI (ctypes) and compared with the
+oracle and with the golden vectors recorded from the real reference.
+Integer work (histograms, counts) must be bit-exact; floating point within the stated tolerance.
+"""
+import numpy as np
+import pytest
+
+from conftest import sorted_frame
+from oracle import cpu_ref as O
+from oracle import cref as C
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def B():
+    from mdproptools_amd import backend
+
+    return backend
+
+
+def soa(data):
+    """[N,4] = [type,x,y,z] -> (xyz [1,3,N], types [N])."""
+    return np.ascontiguousarray(data[:, 1:4].T)[None], data[:, 0].astype(np.int32)
+
+
+# ------------------------------------------------------------------ R3 / R4: atom-atom
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_rdf_cn_golden_synth(B, g_synth, tag):
+    g = g_synth
+    data, L, rel = g[tag + "_data"], g[tag + "_lengths"], g[tag + "_rel"]
+    r_cut, ddr = float(g[tag + "_r_cut"]), float(g[tag + "_ddr"])
+    nb = int(r_cut / ddr)
+    xyz, ty = soa(data)
+    full, part, ov = B.rdf_loop(xyz, ty, L[None], rel, r_cut, ddr, nb)
+    assert ov == 0
+    np.testing.assert_array_equal(full[0].astype(np.int64), g[tag + "_full"])
+    np.testing.assert_array_equal(part[0].astype(np.int64), g[tag + "_part"])
+    cn = B.cn_loop(xyz, ty, L[None], rel, list(g[tag + "_cn_cut"]))
+    np.testing.assert_array_equal(cn[0].astype(np.int64), g[tag + "_cn"])
+
+
+def test_rdf_cn_golden_c1(B, g_c1):
+    g = g_c1
+    frames = [sorted_frame(fr) for fr in g["frames"]]
+    xyz = np.stack([np.ascontiguousarray(fr[:, 2:5].T) for fr in frames])
+    box = g["bounds"][:, :, 1] - g["bounds"][:, :, 0]
+    ty = frames[0][:, 1].astype(np.int32)
+    full, part, ov = B.rdf_loop(xyz, ty, box, g["rdf_def_rel"].T, 20, 0.05, 400)
+    assert ov == 0
+    np.testing.assert_array_equal(full.astype(np.int64), g["rdf_def_full"])
+    np.testing.assert_array_equal(part.astype(np.int64), g["rdf_def_part"])
+    assert int(full[0].sum()) == 30926986  # SURVEY.md known answer
+    cn = B.cn_loop(xyz, ty, box, g["cn_def_rel"].T, list(g["cn_def_cut"]))
+    np.testing.assert_array_equal(cn.astype(np.int64), g["cn_def_raw"])
+    # altered ids: 32 pseudo-types, 2 relations (class table 32x32)
+    alt = O.calc_atom_type(frames[0][:, 0], g["num_mols"], g["num_atoms_per_mol"]).astype(np.int32)
+    full, part, ov = B.rdf_loop(xyz, alt, box, g["rdf_alt_rel"].T, 20, 0.05, 400)
+    np.testing.assert_array_equal(full.astype(np.int64), g["rdf_alt_full"])
+    np.testing.assert_array_equal(part.astype(np.int64), g["rdf_alt_part"])
+    cn = B.cn_loop(xyz, alt, box, g["rdf_alt_rel"].T, list(g["cn_alt_cut"]))
+    np.testing.assert_array_equal(cn.astype(np.int64), g["cn_alt_raw"])
+    # frame-summed output equals the sum of the per-frame outputs
+    fsum, psum, _ = B.rdf_loop(xyz, ty, box, g["rdf_def_rel"].T, 20, 0.05, 400, per_frame=False)
+    np.testing.assert_array_equal(fsum.astype(np.int64), g["rdf_def_full"].sum(axis=0))
+    np.testing.assert_array_equal(psum.astype(np.int64), g["rdf_def_part"].sum(axis=0))
+
+
+def _random_case(rng, n, n_types, L, stray=True):
+    xyz = rng.uniform(0, 1, (3, n)) * np.asarray(L)[:, None] + 1.75
+    if stray and n > 8:
+        idx = rng.choice(n, n // 10, replace=False)
+        xyz[:, idx] += rng.integers(-2, 3, (3, len(idx))) * np.asarray(L)[:, None]
+    ty = rng.integers(1, n_types + 1, n).astype(np.int32)
+    return xyz, ty
+
+
+@pytest.mark.parametrize("n", [2, 3, 63, 255, 256, 257, 511, 513, 1025])
+def test_rdf_ragged_sizes_vs_c_oracle(B, n):
+    rng = np.random.default_rng(100 + n)
+    L = np.array([17.0, 19.5, 18.25])
+    xyz, ty = _random_case(rng, n, 3, L)
+    rel = np.array([[1, 1], [1, 2], [2, 3], [3, 3], [3, 1], [2, 2]])
+    r_cut, ddr = 8.0, 0.04
+    nb = int(r_cut / ddr)
+    full, part, ov = B.rdf_loop(xyz[None], ty, L[None], rel, r_cut, ddr, nb)
+    cf, cp, cov = C.rdf_pairs(xyz, ty, rel, L, r_cut * r_cut, ddr, nb)
+    assert ov == cov
+    np.testing.assert_array_equal(full[0], cf)
+    np.testing.assert_array_equal(part[0], cp)
+    cuts = [1.5, 2.5, 3.75, 8.0, 2.5, 0.9]
+    cn = B.cn_loop(xyz[None], ty, L[None], rel, cuts)
+    np.testing.assert_array_equal(cn[0], C.cn_pairs(xyz, ty, rel, L, [c * c for c in cuts]))
+
+
+def test_rdf_empty_and_single(B):
+    L = np.array([[10.0, 10.0, 10.0]])
+    rel = np.array([[1, 1]])
+    for n in (0, 1):
+        xyz = np.zeros((1, 3, n))
+        full, part, ov = B.rdf_loop(xyz, np.ones(n, np.int32), L, rel, 4.0, 0.1, 40)
+        assert full.sum() == 0 and part.sum() == 0 and ov == 0
+    full, part, ov = B.rdf_loop(np.zeros((0, 3, 5)), np.ones(5, np.int32), np.zeros((0, 3)), rel, 4.0, 0.1, 40)
+    assert full.shape == (0, 40)
+
+
+def test_rdf_geometry_independence(B):
+    """Integer results must not depend on launch geometry: j-splits, replica slots, variant."""
+    from mdproptools_amd._lib import Context
+
+    rng = np.random.default_rng(5)
+    L = np.array([30.0, 30.0, 30.0])
+    F, n = 5, 1500
+    xyz = np.stack([_random_case(rng, n, 4, L)[0] for _ in range(F)])
+    ty = (1 + np.arange(n) % 4).astype(np.int32)
+    rel = np.array([(a, b) for a in range(1, 5) for b in range(a, 5)])
+    box = np.tile(L, (F, 1))
+    ref = None
+    for jsplit, slots in [(0, 16), (1, 1), (2, 3), (3, 8)]:
+        ctx = Context(0)
+        ctx.set_option("rdf_jsplit", jsplit)
+        ctx.set_option("rdf_slots", slots)
+        for per_frame in (True, False):
+            full, part, ov = B.rdf_loop(xyz, ty, box, rel, 12.0, 0.05, 240, per_frame=per_frame, ctx=ctx)
+            if per_frame:
+                full, part = full.sum(axis=0), part.sum(axis=0)
+            if ref is None:
+                ref = (full, part)
+                cf = sum(C.rdf_pairs(xyz[f], ty, rel, L, 144.0, 0.05, 240)[0] for f in range(F))
+                np.testing.assert_array_equal(full, cf)
+            np.testing.assert_array_equal(full, ref[0])
+            np.testing.assert_array_equal(part, ref[1])
+        ctx.close()
+
+
+def test_rdf_overflow_bin_is_dropped_and_counted(B):
+    """a pair with rsq just below 20**2 lands in bin 400 == nbins."""
+    r = np.sqrt(np.nextafter(400.0, 0.0))
+    xyz = np.array([[[1.0, 1.0 + r]], [[1.0, 1.0]], [[1.0, 1.0]]]).reshape(1, 3, 2)
+    d = xyz[0, 0, 0] - xyz[0, 0, 1]
+    rsq = d * d
+    L = np.array([[100.0, 100.0, 100.0]])
+    full, part, ov = B.rdf_loop(xyz, np.array([1, 1], np.int32), L, np.array([[1, 1]]), 20, 0.05, 400)
+    if rsq < 400.0 and int(np.sqrt(rsq) / 0.05) == 400:
+        assert ov == 1 and full.sum() == 0
+    else:  # the constructed distance rounded elsewhere; it must then be counted normally
+        assert ov == 0
+
+
+def test_rdf_per_frame_types_and_varying_box(B):
+    rng = np.random.default_rng(11)
+    F, n = 3, 400
+    boxes = np.array([[20.0, 21.0, 22.0], [20.5, 21.5, 22.5], [19.0, 23.0, 21.0]])
+    xyz = np.stack([rng.uniform(0, 1, (3, n)) * boxes[f][:, None] for f in range(F)])
+    ty = rng.integers(1, 4, (F, n)).astype(np.int32)
+    rel = np.array([[1, 2], [3, 3], [2, 2]])
+    full, part, ov = B.rdf_loop(xyz, ty, boxes, rel, 9.0, 0.1, 90)
+    for f in range(F):
+        cf, cp, _ = C.rdf_pairs(xyz[f], ty[f], rel, boxes[f], 81.0, 0.1, 90)
+        np.testing.assert_array_equal(full[f], cf)
+        np.testing.assert_array_equal(part[f], cp)
+
+
+def test_rdf_many_relations_multi_pass(B):
+    """45 relations x 2000 bins do not fit LDS in one pass: class rows are processed in passes."""
+    rng = np.random.default_rng(12)
+    n, L = 900, np.array([24.0, 24.0, 24.0])
+    xyz = rng.uniform(0, 1, (3, n)) * L[:, None]
+    ty = rng.integers(1, 10, n).astype(np.int32)
+    rel = np.array([(a, b) for a in range(1, 10) for b in range(a, 10)])
+    full, part, ov = B.rdf_loop(xyz[None], ty, L[None], rel, 10.0, 0.005, 2000)
+    cf, cp, cov = C.rdf_pairs(xyz, ty, rel, L, 100.0, 0.005, 2000)
+    assert ov == cov
+    np.testing.assert_array_equal(full[0], cf)
+    np.testing.assert_array_equal(part[0], cp)
+
+
+# ------------------------------------------------------------------ R5 / R6: atoms x COM sites
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_rdf_cn_mol_golden_synth(B, g_synth, tag):
+    g = g_synth
+    data, mol, L, rel = g[tag + "_data"], g[tag + "_mol"], g[tag + "_lengths"], g[tag + "_mol_rel"]
+    r_cut, ddr = float(g[tag + "_r_cut"]), float(g[tag + "_ddr"])
+    nb = int(r_cut / ddr)
+    xyz, ty = soa(data)
+    sxyz, st = soa(mol)
+    part, ov = B.rdf_mol_loop(xyz, ty, sxyz, st, L[None], rel, r_cut, ddr, nb)
+    assert ov == 0
+    np.testing.assert_array_equal(part[0].astype(np.int64), g[tag + "_mol_part"])
+    cn = B.cn_mol_loop(xyz, ty, sxyz, st, L[None], rel, list(g[tag + "_mol_cn_cut"]))
+    np.testing.assert_array_equal(cn[0].astype(np.int64), g[tag + "_mol_cn"])
+
+
+def test_molecular_c1_com_and_hist(B, g_c1):
+    g = g_c1
+    fr = sorted_frame(g["frames"][0])
+    L = (g["bounds"][0][:, 1] - g["bounds"][0][:, 0])[None]
+    _, _, off, seg_type = O.molecule_layout(g["num_mols"], g["num_atoms_per_mol"])
+    amass = g["mass"][fr[:, 1].astype(np.int64) - 1]
+    xyz = np.ascontiguousarray(fr[:, 2:5].T)[None]
+    com, seg_mass, _ = B.segment_com(xyz, amass, off)
+    ref_com = g["mol_com"][0]
+    np.testing.assert_allclose(com[0].T, ref_com[:, 1:4], rtol=1e-13, atol=0)
+    ty = fr[:, 1].astype(np.int32)
+    # integer parity given the reference's own COM sites ...
+    sites = np.ascontiguousarray(ref_com[:, 1:4].T)[None]
+    part, ov = B.rdf_mol_loop(xyz, ty, sites, seg_type.astype(np.int32), L, g["mol_rel"].T, 20, 0.05, 400)
+    np.testing.assert_array_equal(part[0].astype(np.int64), g["mol_rdf_part"][0])
+    cn = B.cn_mol_loop(xyz, ty, sites, seg_type.astype(np.int32), L, g["mol_rel"].T, list(g["mol_cn_cut"]))
+    np.testing.assert_array_equal(cn[0].astype(np.int64), g["mol_cn_raw"][0])
+    # ... and with the device-computed COM (sums in another order: equal here, documented as rtol 1e-13 on COM)
+    part2, _ = B.rdf_mol_loop(xyz, ty, com, seg_type.astype(np.int32), L, g["mol_rel"].T, 20, 0.05, 400)
+    assert np.abs(part2[0].astype(np.int64) - g["mol_rdf_part"][0]).sum() <= 2
+
+
+def test_rect_ragged_vs_c_oracle(B):
+    rng = np.random.default_rng(21)
+    L = np.array([15.0, 16.0, 17.0])
+    for n, m in [(1, 1), (300, 7), (257, 513), (700, 256)]:
+        xyz, ty = _random_case(rng, n, 3, L)
+        sx, st = _random_case(rng, m, 2, L, stray=False)
+        rel = np.array([[1, 1], [2, 2], [3, 1], [1, 2], [1, 1]])
+        part, ov = B.rdf_mol_loop(xyz[None], ty, sx[None], st, L[None], rel, 7.0, 0.07, 100)
+        cp, cov = C.rdf_rect(xyz, ty, sx, st, rel, L, 49.0, 0.07, 100)
+        assert ov == cov
+        np.testing.assert_array_equal(part[0], cp)
+        cuts = [2.0, 3.0, 6.5, 1.0, 4.0]
+        cn = B.cn_mol_loop(xyz[None], ty, sx[None], st, L[None], rel, cuts)
+        np.testing.assert_array_equal(cn[0], C.cn_rect(xyz, ty, sx, st, rel, L, [c * c for c in cuts]))
+
+
+# ------------------------------------------------------------------ M1-M3, G1 on the 1146-atom golden
+def _small(g):
+    cols = list(g["columns"])
+    fr = np.stack([sorted_frame(f, cols.index("id")) for f in g["frames"]])
+    pick = lambda names: np.ascontiguousarray(  # noqa: E731
+        fr[:, :, [cols.index(c) for c in names]].transpose(0, 2, 1))
+    return cols, fr, pick
+
+
+def test_msd_allatom_golden(B, g_small):
+    g = g_small
+    cols, fr, pick = _small(g)
+    r = pick(("xu", "yu", "zu"))
+    F, _, E = r.shape
+    pairs = [(0, t) for t in range(F)]
+    sums, pe = B.msd_pairs(r, pairs, [0, E], scale=1e-10, per_entity=True)
+    np.testing.assert_allclose(pe.reshape(F * E, 4), g["aa_msd_all"][:, 2:6], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(sums[:, 0, :] / E, g["aa_msd"][:, 1:5], rtol=1e-10, atol=0)
+    win = B.msd_windows(r, 4, scale=1e-10)
+    n_kept = len(range(0, F, 4))
+    expect = g["aa_msd_int"][:, 1:5]
+    np.testing.assert_allclose(win[:, :3] / (n_kept - 1), expect[:, :3], rtol=1e-10, atol=0)
+    np.testing.assert_allclose(win[:, 3] / n_kept, expect[:, 3], rtol=1e-10, atol=0)
+
+
+def test_com_msd_and_charge_flux_golden(B, g_small):
+    g = g_small
+    cols, fr, pick = _small(g)
+    nm, na = g["num_mols"], g["num_atoms_per_mol"]
+    _, _, off, seg_type = O.molecule_layout(nm, na)
+    amass = g["mass"][fr[0][:, cols.index("type")].astype(np.int64) - 1]
+    com, seg_mass, _ = B.segment_com(pick(("xu", "yu", "zu")), amass, off)
+    ref = g["calc_com_xu"]
+    np.testing.assert_allclose(com[0].T, ref[:, 2:5], rtol=1e-13)
+    np.testing.assert_allclose(seg_mass, ref[:, 5], rtol=1e-14)
+    F, _, M = com.shape
+    goff = np.concatenate([[0], np.cumsum(nm)])
+    sums, pe = B.msd_pairs(com, [(0, t) for t in range(F)], goff, scale=1e-10, per_entity=True)
+    np.testing.assert_allclose(pe.reshape(F * M, 4), g["com_msd_all"][:, 3:7], rtol=1e-9, atol=0)
+    mean = sums / np.diff(goff)[None, :, None]
+    np.testing.assert_allclose(mean.reshape(F, -1), g["com_msd"][:, 1:], rtol=1e-9, atol=0)
+    q = fr[0][:, cols.index("q")]
+    j = B.charge_flux(pick(("vx", "vy", "vz")), amass, q, off, (seg_type - 1).astype(np.int32), 3,
+                      10 ** -10 / 10 ** -15, 1.602176634 * 10 ** -19)
+    np.testing.assert_allclose(j, g["cond_j"], rtol=1e-9, atol=1e-25)
+
+
+def test_msd_ragged_groups_vs_oracle(B):
+    rng = np.random.default_rng(31)
+    F, E = 7, 2500
+    r = np.cumsum(rng.normal(0, 0.1, (F, 3, E)), axis=0) + rng.uniform(0, 50, (1, 3, E))
+    goff = [0, 1, 1030, 1030, 2500]  # a single-entity group, an empty group, ragged chunk ends
+    pairs = [(0, 0), (0, 6), (2, 5), (6, 1)]
+    sums = B.msd_pairs(r, pairs, goff, scale=1e-10)
+    expect = C.msd_pairs(r * 1e-10, pairs, goff)
+    np.testing.assert_allclose(sums, expect, rtol=1e-12, atol=0)
+    win = B.msd_windows(r, 3, scale=1e-10)
+    kept = (r * 1e-10)[::3]
+    d2 = (kept[1:] - kept[:-1]) ** 2
+    np.testing.assert_allclose(win[:, :3], d2.sum(axis=0).T, rtol=1e-12)
+    np.testing.assert_allclose(win[:, 3], d2.sum(axis=1).sum(axis=0), rtol=1e-12)
+
+
+def test_lag_msd_vs_oracle(B):
+    rng = np.random.default_rng(32)
+    for F, E, goff in [(40, 70, [0, 30, 70]), (300, 5, [0, 5]), (2100, 3, [0, 1, 3])]:
+        r = np.cumsum(rng.normal(0, 0.1, (F, 3, E)), axis=0) + rng.uniform(0, 50, (1, 3, E))
+        out = B.lag_msd(r, F - 1, goff, scale=1.0)
+        for g in range(len(goff) - 1):
+            sub = r[:, :, goff[g]:goff[g + 1]].transpose(0, 2, 1)
+            expect = O.lag_msd_full(sub, F - 1)
+            np.testing.assert_allclose(out[:, g, :], expect, rtol=1e-10, atol=1e-12)
+
+
+# ------------------------------------------------------------------ G2-G4
+def test_xcorr_golden(B, g_acf):
+    g = g_acf
+    p = g["pressure"]
+    fft = B.xcorr(p, method=B.XCORR_FFT)
+    direct = B.xcorr(p, method=B.XCORR_DIRECT)
+    for k in range(3):
+        tol = 1e-10 * g["acf_wkt"][k][0]
+        np.testing.assert_allclose(fft[k], g["acf_wkt"][k], rtol=0, atol=tol)
+        np.testing.assert_allclose(direct[k], g["acf_brute"][k], rtol=0, atol=tol)
+    j = g["flux"]
+    c01 = B.xcorr(j[0, 0], j[0, 1], method=B.XCORR_FFT)
+    np.testing.assert_allclose(c01, g["corr_01"], rtol=0, atol=1e-10 * abs(g["corr_01"]).max())
+    d01 = B.xcorr(j[0, 0], j[0, 1], method=B.XCORR_DIRECT)
+    np.testing.assert_allclose(d01, g["corr_01"], rtol=0, atol=1e-10 * abs(g["corr_01"]).max())
+    # all 27 (i, j, k) correlations in one call, summed as correlate_charge_flux does (conductivity.py:207-213)
+    a = np.stack([j[k, i] for i in range(3) for jj in range(3) for k in range(3)])
+    b = np.stack([j[k, jj] for i in range(3) for jj in range(3) for k in range(3)])
+    c = B.xcorr(a, b, method=B.XCORR_FFT).reshape(3, 9, -1).sum(axis=1)
+    tot = np.vstack([c, c.sum(axis=0, keepdims=True)])
+    np.testing.assert_allclose(tot, g["tot_flux"], rtol=0, atol=1e-10 * abs(g["tot_flux"]).max())
+
+
+@pytest.mark.parametrize("n", [1, 2, 9, 2047, 2048, 2049, 5000, 12345])
+def test_xcorr_direct_sizes_vs_oracle(B, n):
+    rng = np.random.default_rng(n)
+    a, b = rng.standard_normal(n), rng.standard_normal(n)
+    out = B.xcorr(a, b, method=B.XCORR_DIRECT)
+    expect = C.xcorr_direct(a, b)
+    np.testing.assert_allclose(out, expect, rtol=0, atol=1e-12 * max(1.0, abs(expect).max()) * np.sqrt(n))
+    if n >= 2:
+        f = B.xcorr(a, b, method=B.XCORR_FFT)
+        np.testing.assert_allclose(f, expect, rtol=0, atol=1e-11 * max(1.0, abs(expect).max()) * np.sqrt(n))
+    half = B.xcorr(a, b, method=B.XCORR_DIRECT, n_lags=max(1, n // 2))
+    np.testing.assert_allclose(half, expect[: max(1, n // 2)], rtol=0, atol=1e-12 * max(1.0, abs(expect).max()) * np.sqrt(n))
+
+
+def test_cumtrapz_golden_and_sizes(B, g_acf):
+    g = g_acf
+    dt = g["flux_time"][1] - g["flux_time"][0]
+    out = B.cumtrapz(g["tot_flux"], dt, leading_zero=True)
+    np.testing.assert_allclose(out, g["integral"], rtol=1e-9, atol=1e-12 * abs(g["integral"]).max())
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 3, 2048, 2049, 2050, 100001):
+        y = rng.standard_normal((2, n))
+        for lead in (False, True):
+            res = B.cumtrapz(y, 0.37, leading_zero=lead)
+            for s in range(2):
+                exp = O.cumtrapz(y[s], 0.37, leading_zero=lead) if n > 1 else (np.zeros(1) if lead else np.zeros(0))
+                np.testing.assert_allclose(res[s], exp, rtol=1e-9, atol=1e-12 * max(1.0, abs(exp).max() if len(exp) else 1.0))
+
+
+# ------------------------------------------------------------------ full-size properties (BASELINE C2)
+def test_c2_full_size_properties(B):
+    """N=10 000, F=200 at full size: frame 0 against the C oracle, and size-independent identities."""
+    import torch
+    from mdproptools_amd import synth
+
+    cfg = synth.rdf_config("C2")
+    n, F, L = cfg["n_atoms"], cfg["n_frames"], cfg["box_len"]
+    xyz = synth.rdf_frames(n, range(F), L, cfg["seed_offset"])
+    ty = synth.rdf_types(n)
+    rel = np.array(synth.ALL_PAIRS_4)
+    box = np.full((F, 3), L)
+    d = torch.from_numpy(xyz).cuda()
+    full, part, ov = B.rdf_loop(d, ty, box, rel, cfg["r_cut"], cfg["bin_size"], 400)
+    cf, cp, cov = C.rdf_pairs(xyz[0], ty, rel, box[0], 400.0, 0.05, 400)
+    np.testing.assert_array_equal(full[0], cf)
+    np.testing.assert_array_equal(part[0], cp)
+    # every pair belongs to exactly one unordered type pair: sum of partials (a == b rows already doubled,
+    # a != b rows counted once per unordered pair) reproduces the full histogram
+    mult = np.array([1 if a == b else 2 for a, b in rel], dtype=np.uint64)
+    np.testing.assert_array_equal((part * mult[None, :, None]).sum(axis=1), full)
+    # frame-summed call == sum over frames of the per-frame call
+    fs, ps, ovs = B.rdf_loop(d, ty, box, rel, cfg["r_cut"], cfg["bin_size"], 400, per_frame=False)
+    np.testing.assert_array_equal(fs, full.sum(axis=0))
+    np.testing.assert_array_equal(ps, part.sum(axis=0))
+    assert ovs == ov
+    # relabelling invariance: a permutation of the atoms leaves every histogram unchanged
+    perm = np.random.default_rng(0).permutation(n)
+    f2, p2, _ = B.rdf_loop(np.ascontiguousarray(xyz[:2][:, :, perm]), ty[perm], box[:2], rel, 20.0, 0.05, 400)
+    np.testing.assert_array_equal(f2, full[:2])
+    np.testing.assert_array_equal(p2, part[:2])
+    # ideal gas: g(r) = 1 within counting noise once averaged over 200 frames (r > 2 A)
+    sv = O.shell_volume(0.05, 400)
+    gr = full.sum(axis=0) / F / (n * (n / L ** 3) * sv)
+    assert abs(gr[40:].mean() - 1.0) < 2e-3
