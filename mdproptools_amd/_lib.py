@@ -68,12 +68,26 @@ _lib = None
 _lock = threading.Lock()
 
 
+def _preload_torch_runtime():
+    """
+    PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / libhipfft.so.0. Two HIP runtimes in one
+    process cannot both own the device ("No HIP GPUs are available" from whichever initialises
+    second), so when torch is installed its runtime is loaded FIRST and libmdhip.so then binds to
+    the same copy by SONAME. Without torch the system ROCm in /opt/rocm/lib is used (RUNPATH).
+    """
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+
+
 def load(build_if_missing=True):
     """Load libmdhip.so (building it in-tree first if it is missing) and bind every prototype."""
     global _lib
     with _lock:
         if _lib is not None:
             return _lib
+        _preload_torch_runtime()
         if not os.path.exists(LIB_PATH):
             if not build_if_missing:
                 raise MdhipError(-4, "libmdhip.so not found at %s" % LIB_PATH)
