@@ -1,0 +1,204 @@
+"""
+Green-Kubo ionic conductivity from LAMMPS dumps — drop-in for
+/root/reference/mdproptools/dynamical/conductivity.py (class `Conductivity`, same method names,
+argument order, defaults and files written: conductivity.py:51-62, 98, 117, 167, 197, 216, 234, 259, 276).
+
+What runs where
+  GPU (libmdhip.so): the per-frame molecular charge flux for ALL frames in one call
+      (`conductivity_loop`, _conductivity.py:7-36 — the step the reference marks as its slowest and
+      spreads over a process pool), every flux cross-correlation (conductivity.py:97-114, batched)
+      and the running integrals (conductivity.py:216-232).
+  Host: parsing, plateau detection (pandas, conductivity.py:116-165), the final Green-Kubo factor.
+"""
+
+import glob
+import os
+
+import numpy as np
+import pandas as pd
+
+from .. import backend
+from ..common import constants
+from ..common.com_mols import atom_masses, molecule_layout
+from ..io import parse_lammps_dumps
+
+
+class Conductivity:
+    """Green-Kubo ionic conductivity (total and per molecule type) following 10.1063/1.4890741."""
+
+    def __init__(self, filename, num_mols, num_atoms_per_mol, volume, mass=None, temp=298.15, timestep=1,
+                 units="real", working_dir=None):
+        """
+        filename: dump file pattern; num_mols / num_atoms_per_mol: molecules per type and atoms per
+        molecule in dump order; volume: box volume in `units`; mass: per-atom-type masses (or None to
+        read the dump's mass column); temp [K]; timestep in `units`; working_dir: where the dumps are.
+        """
+        self.working_dir = working_dir or os.getcwd()
+        self.filename = filename
+        self.dumps = parse_lammps_dumps(f"{self.working_dir}/{self.filename}")
+        self.mass = mass
+        self.num_mols = num_mols
+        self.num_atoms_per_mol = num_atoms_per_mol
+        self.units = units
+        self.volume = volume * constants.DISTANCE_CONVERSION[self.units] ** 3  # m^3
+        self.temp = temp
+        self.timestep = timestep
+        self.time = []  # seconds, one entry per frame, filled by get_charge_flux
+
+    @staticmethod
+    def correlate(a, b):
+        """c[k] = sum_t a[t+k] b[t] / (n-k), evaluated with zero-padded FFTs on the GPU."""
+        return backend.xcorr(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64),
+                             method=backend.XCORR_FFT)
+
+    @staticmethod
+    def detect_time_range(flux, tol):
+        """
+        (start, end) indices of the longest stretch where the correlation function is flat: the series
+        is cut into blocks, the block standard deviations are scaled by their own spread, compared
+        with `tol`, smoothed with a centred rolling median and the longest run of ones is returned
+        (conductivity.py:116-165).
+        """
+        flux = pd.Series(flux, name="flux")
+        block = max(int(len(flux) / 10000), 5)
+        labels = np.arange(len(flux)) // block
+        block_std = flux.groupby(labels).transform("std")
+        spread = block_std.std()
+        flat = ((block_std / (spread if spread else 1)) < tol).astype("int").to_frame()
+        smooth = (flat.rolling(window=4 * block + 1, min_periods=3 * block + 1, center=True)
+                  .median().fillna(0)["flux"].to_numpy())
+        on = smooth == 1
+        runs, start = [], None
+        for k in range(len(smooth)):
+            if on[k] and start is None:
+                start = k
+            elif smooth[k] < 1 and start is not None:
+                runs.append((start, k))
+                start = None
+        if start is not None:
+            runs.append((start, len(smooth) - 1))
+        best, best_len = None, 0
+        for run in runs:
+            if run[1] - run[0] > best_len:
+                best, best_len = run, run[1] - run[0]
+        if best is None:
+            raise TypeError("list indices must be integers or slices, not NoneType")  # as the reference
+        return best
+
+    def get_charge_flux(self):
+        """Charge flux J[3, n_types, n_frames] in SI units; also fills `self.time` (conductivity.py:167-195)."""
+        n_expected = len(glob.glob(f"{self.working_dir}/{self.filename}"))
+        seg_off, mol_type, _ = molecule_layout(self.num_mols, self.num_atoms_per_mol)
+        vel, steps = [], []
+        m = q = None
+        for dump in self.dumps:
+            data = dump.data.sort_values(by=["id"])
+            if seg_off[-1] != len(data):
+                raise ValueError(f"Length of values ({int(seg_off[-1])}) does not match length of index "
+                                 f"({len(data)})")
+            if m is None:
+                m = atom_masses(data, self.mass)
+                q = data["q"].to_numpy(dtype=np.float64)
+            vel.append(np.ascontiguousarray(data[["vx", "vy", "vz"]].to_numpy(dtype=np.float64).T))
+            steps.append(dump.timestep * constants.TIME_CONVERSION[self.units])
+        j = np.zeros((3, len(self.num_mols), max(n_expected, len(vel))))
+        if vel:
+            flux = backend.charge_flux(np.stack(vel), m, q, seg_off, (mol_type - 1).astype(np.int32),
+                                       len(self.num_mols), constants.VELOCITY_CONVERSION[self.units],
+                                       constants.CHARGE_CONVERSION[self.units])
+            j[:, :, : len(vel)] = flux
+        for s in steps:
+            self.time.append(s * self.timestep)
+        return j
+
+    def correlate_charge_flux(self, flux):
+        """tot_flux[i] = sum_j sum_k corr(J[k,i], J[k,j]); last row = sum over i (conductivity.py:197-214)."""
+        n_types = len(self.num_mols)
+        a = np.stack([flux[k, i] for i in range(n_types) for jj in range(n_types) for k in range(flux.shape[0])])
+        b = np.stack([flux[k, jj] for i in range(n_types) for jj in range(n_types) for k in range(flux.shape[0])])
+        corr = backend.xcorr(a, b, method=backend.XCORR_FFT).reshape(n_types, n_types * flux.shape[0], -1)
+        tot_flux = np.zeros((n_types + 1, flux.shape[2]))
+        for i in range(n_types):
+            for c in corr[i]:  # same accumulation order as the reference's triple loop
+                tot_flux[i, :] += c
+                tot_flux[-1, :] += c
+        return tot_flux
+
+    def integrate_charge_flux_correlation(self, tot_flux):
+        """Running trapezoid integral of every row, first value 0 (conductivity.py:216-232)."""
+        delta = self.time[1] - self.time[0]
+        return backend.cumtrapz(np.asarray(tot_flux, dtype=np.float64), delta, leading_zero=True)
+
+    def fit_curve(self, tot_flux, integral, tol):
+        """Average of each integral over its detected plateau, and the plateau's time range."""
+        ave = np.zeros(len(integral))
+        time_range = np.zeros(len(integral), dtype=object)
+        for i in range(len(integral)):
+            lo, hi = self.detect_time_range(tot_flux[i], tol=tol)
+            ave[i] = np.average(integral[i][lo:hi])
+            time_range[i] = (self.time[lo], self.time[hi])
+        return ave, time_range
+
+    def green_kubo(self, ave):
+        """sigma = <integral> / (3 kB T V) (conductivity.py:259-274)."""
+        return np.array([a / 3 / constants.BOLTZMANN / self.temp / self.volume for a in ave])
+
+    def calc_cond(self, tol=1e-4, plot=False, save=False):
+        """
+        Whole chain: charge flux, correlation, integral, plateau average, conductivity [S/m] per molecule
+        type followed by the total. save writes charge_flux.csv, integral.csv, conductivity.csv; plot
+        writes conductivity.png, all into working_dir (conductivity.py:276-397).
+        """
+        j = self.get_charge_flux()
+        tot_flux = self.correlate_charge_flux(j)
+        integral = self.integrate_charge_flux_correlation(tot_flux)
+        ave, time_range = self.fit_curve(tot_flux, integral, tol)
+        cond = self.green_kubo(ave)
+        if plot:
+            self._plot(tot_flux, integral, time_range)
+        if save:
+            t = np.array([self.time])
+            header = "t," + ",".join(str(i + 1) for i in range(len(tot_flux) - 1)) + ",tot"
+            np.savetxt(f"{self.working_dir}/charge_flux.csv", np.append(t, tot_flux, axis=0).T, delimiter=",",
+                       header=header, comments="")
+            np.savetxt(f"{self.working_dir}/integral.csv", np.append(t, integral, axis=0).T, delimiter=",",
+                       header=header, comments="")
+            cond = np.asarray([[r[0] for r in time_range], [r[1] for r in time_range], cond])
+            np.savetxt(f"{self.working_dir}/conductivity.csv", cond.T, delimiter=",",
+                       header="start_t,end_t,cond", comments="")
+        return cond
+
+    def _plot(self, tot_flux, integral, time_range):
+        import matplotlib
+
+        matplotlib.use("Agg", force=False)
+        import matplotlib.pyplot as plt
+
+        from ..utilities.plots import set_axis
+
+        t_ns = np.array(self.time) * 10 ** 9
+        cmap = plt.get_cmap("Paired")
+        fig, (ax1, ax2) = plt.subplots(1, 2, figsize=(20, 5))
+        for i in range(len(tot_flux) - 1):
+            ax1.plot(t_ns, tot_flux[i], linewidth=2, color=cmap(i / 10))
+            ax2.plot(t_ns, integral[i], linewidth=2, color=cmap(i / 10), label=i + 1)
+        ax1.plot(t_ns, tot_flux[-1], linewidth=2, color="black")
+        ax2.plot(t_ns, integral[-1], linewidth=2, color="black", label="total")
+        ax1.set_ylabel(r"$\mathrm{\langle J(t)\cdot J(0)\rangle}$", fontsize=18)
+        ax2.set_ylabel(r"$\mathrm{\int_{0}^{t}\langle J(t')\cdot J(0)\rangle dt'}$", fontsize=18)
+        ax2.legend(fontsize=16, loc="center left", bbox_to_anchor=(1, 0.5), frameon=False)
+        for ax in (ax1, ax2):
+            set_axis(ax, axis="both")
+            for edge in time_range[-1]:
+                ax.axvline(edge * 10 ** 9, linewidth=2, color="black", linestyle="--")
+            ax.set_xscale("log")
+            ax.set_xlabel(r"$\mathrm{Time, 10^9 (s)}$", fontsize=18)
+        fig.tight_layout(pad=3)
+        fig.savefig(f"{self.working_dir}/conductivity.png", bbox_inches="tight", pad_inches=0.1)
+        plt.close(fig)
+
+    def einstein(self):
+        pass
+
+    def nernst(self):
+        pass

@@ -1,0 +1,321 @@
+"""
+Mean-square displacement and Einstein-relation diffusion coefficients — drop-in for
+/root/reference/mdproptools/dynamical/diffusion.py (class `Diffusion`, same method names,
+argument order, defaults, returned DataFrames and files written: diffusion.py:38, 101-111, 241,
+267-276, 410-412).
+
+What runs where
+  GPU (libmdhip.so): molecule centres of mass (`calc_com`), the single-origin displacement
+      reduction behind `msd` / `msd_all` (diffusion.py:212-218, `mdhip_msd_pairs`) and the
+      fixed-lag per-entity reduction behind `msd_int` (diffusion.py:225-237, `mdhip_msd_windows`).
+  Host: parsing, the per-type drift correction (small: F x n_types x 3), assembling the pandas
+      objects, the through-origin least-squares fit (closed form of what statsmodels' OLS returns).
+
+Tolerance: means are tree sums on the GPU vs pandas' compensated sums: rtol 1e-10 (observed ~1e-15).
+"""
+
+import os
+
+import numpy as np
+import pandas as pd
+
+from .. import backend
+from ..common import constants
+from ..common.com_mols import atom_masses, molecule_layout
+from ..io import parse_lammps_dumps, parse_lammps_log  # noqa: F401  (parse_lammps_log: API parity)
+from ..utilities.log import concat_log
+
+_COORDS = ["xu", "yu", "zu"]
+_DISPS = ["dx2", "dy2", "dz2"]
+
+
+class _OlsThroughOrigin:
+    """y = b t without intercept: what `sm.OLS(y, t).fit()` exposes and calc_diff reads (diffusion.py:323-329)."""
+
+    def __init__(self, y, t):
+        self.y = np.asarray(y, dtype=np.float64)
+        self.t = np.asarray(t, dtype=np.float64)
+        sxx = float(self.t @ self.t)
+        self.slope = float(self.t @ self.y) / sxx
+        resid = self.y - self.slope * self.t
+        self.rss = float(resid @ resid)
+        self.nobs = len(self.t)
+        self.bse = np.sqrt(self.rss / (self.nobs - 1) / sxx)
+        self.rsquared = 1.0 - self.rss / float(self.y @ self.y)  # uncentred: no constant in the model
+
+    def predict(self):
+        return self.slope * self.t
+
+    def summary(self):
+        return ("OLS through the origin (closed form)\n"
+                f"  observations : {self.nobs}\n  slope        : {self.slope!r}\n"
+                f"  std err      : {self.bse!r}\n  R-squared    : {self.rsquared!r} (uncentred)\n"
+                f"  residual SS  : {self.rss!r}\n")
+
+
+class Diffusion:
+    """
+    Diffusion coefficients from the mean square displacement of a LAMMPS trajectory (dumps) or from
+    msd columns of a LAMMPS log, via the Einstein relation.
+    """
+
+    def __init__(self, timestep=1, units="real", outputs_dir=None, diff_dir=None):
+        """
+        timestep: MD timestep in the units of `units`; units: LAMMPS unit style; outputs_dir: where the
+        dump/log files are; diff_dir: where results (.csv, .txt, .png) go. Both default to the cwd.
+        """
+        self.units = units
+        if self.units not in constants.SUPPORTED_UNITS:
+            raise KeyError("Unit type not supported. Supported units are: " + str(constants.SUPPORTED_UNITS))
+        self.outputs_dir = outputs_dir or os.getcwd()
+        self.diff_dir = diff_dir or os.getcwd()
+        self.timestep = timestep
+
+    # ------------------------------------------------------------------------------------------
+    @staticmethod
+    def _prepare_unwrapped_coords(dump):
+        """Make xu, yu, zu available, from x + ix*L when they were not dumped (diffusion.py:62-81)."""
+        cols = dump.data.columns
+        if "zu" not in cols:  # the reference's `"xu" and "yu" and "zu" not in ...` tests only zu
+            assert "z" in cols, "Missing wrapped and unwrapped coordinates (x y z xu yu zu)"
+            assert "iz" in cols, (
+                "Missing unwrapped coordinates (xu yu zu) and box location (ix iy iz) for converting "
+                "wrapped coordinates (x y z) into unwrapped coordinates. ")
+            for axis, (lo, hi) in zip("xyz", dump.box.bounds):
+                length = hi - lo
+                dump.data[axis + "u"] = dump.data[axis].add(dump.data["i" + axis].multiply(length))
+        return dump
+
+    def detect_linear_region():
+        pass
+
+    # ------------------------------------------------------------------------------------------
+    def _entity_frames(self, filename, msd_type, num_mols, num_atoms_per_mol, mass):
+        """Parse every frame and reduce it to entity coordinates [3, E] in LAMMPS length units."""
+        times, planes = [], []
+        ids = None
+        atom_planes, atom_mass, seg = [], None, None
+        for dump in parse_lammps_dumps(f"{self.outputs_dir}/{filename}"):
+            assert "id" in dump.data.columns, "Missing atom id's in dump file."
+            dump.data = dump.data.sort_values(by=["id"])
+            dump.data.reset_index(inplace=True)
+            dump = self._prepare_unwrapped_coords(dump)
+            xyz = np.ascontiguousarray(dump.data[_COORDS].to_numpy(dtype=np.float64).T)
+            if msd_type == "allatom":
+                if ids is None:
+                    ids = dump.data["id"].to_numpy()
+                planes.append(xyz)
+            elif msd_type == "com":
+                if seg is None:
+                    seg = molecule_layout(num_mols, num_atoms_per_mol)
+                    if seg[0][-1] != len(dump.data):
+                        raise ValueError(f"Length of values ({int(seg[0][-1])}) does not match length "
+                                         f"of index ({len(dump.data)})")
+                m = atom_masses(dump.data, mass)
+                if atom_mass is None:
+                    atom_mass = m
+                elif not np.array_equal(atom_mass, m):
+                    raise ValueError("atom masses change between frames")
+                atom_planes.append(xyz)
+            else:
+                raise ValueError("msd_type must be 'allatom' or 'com'.")
+            times.append(dump.timestep * self.timestep * constants.TIME_CONVERSION[self.units])
+        times = np.asarray(times, dtype=np.float64)
+        if msd_type == "com":
+            com, seg_mass, _ = backend.segment_com(np.stack(atom_planes), atom_mass, seg[0])
+            return times, com, dict(type=seg[1], mol_id=seg[2], mass=seg_mass)
+        return times, np.stack(planes), dict(id=ids)
+
+    def get_msd_from_dump(self, filename, msd_type="com", num_mols=None, num_atoms_per_mol=None, mass=None,
+                          com_drift=False, avg_interval=False, tao_coeff=4):
+        """
+        MSD from LAMMPS dump files; the frame at time 0 is the reference of `msd` / `msd_all`.
+
+        msd_type 'allatom' averages over atoms, 'com' over the molecules of each type (needs num_mols,
+        num_atoms_per_mol and masses from `mass` or the dump). com_drift removes the per-type
+        centre-of-mass drift first. avg_interval additionally returns `msd_int`: per atom / molecule,
+        the displacement over windows of `tao_coeff` frames averaged over the trajectory.
+
+        Returns (msd, msd_all) or (msd, msd_all, msd_int) as DataFrames laid out like the reference's.
+        """
+        times, r, meta = self._entity_frames(filename, msd_type, num_mols, num_atoms_per_mol, mass)
+        order = np.argsort(times, kind="stable")  # the reference sorts its (time, id) index
+        times, r = times[order], np.ascontiguousarray(r[order])
+        F, _, E = r.shape
+        dist = constants.DISTANCE_CONVERSION[self.units]
+        if msd_type == "allatom":
+            id_cols, id_vals = ["id"], [meta["id"]]
+            group_off = np.array([0, E], dtype=np.int64)
+            group_labels = None
+        else:
+            id_cols, id_vals = ["type", "mol_id"], [meta["type"], meta["mol_id"]]
+            counts = np.bincount(meta["type"])[1:]
+            group_off = np.concatenate(([0], np.cumsum(counts))).astype(np.int64)
+            group_labels = np.arange(1, len(counts) + 1)
+        scale = dist
+        if msd_type == "com" and com_drift:
+            r = self._remove_drift(r * dist, meta["mass"] * constants.MASS_CONVERSION[self.units], group_off)
+            scale = 1.0
+        origin = np.flatnonzero(times == 0)
+        if len(origin) == 0:
+            raise KeyError(0)  # the reference selects the time-0 rows with .xs(0, 0)
+        origin = int(origin[0])
+        pairs = np.column_stack([np.full(F, origin), np.arange(F)]).astype(np.int32)
+        sums, per_entity = backend.msd_pairs(r, pairs, group_off, scale=scale, per_entity=True)
+
+        cols_1d = _DISPS + ["msd"]
+        all_cols = {"Time (s)": np.repeat(times, E)}
+        for name, v in zip(id_cols, id_vals):
+            all_cols[name] = np.tile(v, F)
+        for k, name in enumerate(cols_1d):
+            all_cols[name] = per_entity[:, :, k].reshape(-1)
+        msd_all = pd.DataFrame(all_cols)
+
+        means = sums / np.diff(group_off)[None, :, None]
+        if msd_type == "allatom":
+            msd = pd.DataFrame({"Time (s)": times, **{c: means[:, 0, k] for k, c in enumerate(cols_1d)}})
+        else:
+            data = {"Time (s)": times}
+            for g, lab in enumerate(group_labels):  # diffusion.py:220-222: dx21 dy21 dz21 msd1 dx22 ...
+                for k, c in enumerate(cols_1d):
+                    data[f"{c}{lab}"] = means[:, g, k]
+            msd = pd.DataFrame(data)
+        if not avg_interval:
+            return msd, msd_all
+
+        kept = np.arange(F)[::tao_coeff]  # diffusion.py:226-228
+        n_kept = len(kept)
+        win = backend.msd_windows(np.ascontiguousarray(r[kept]), 1, scale=scale)
+        int_cols = {name: v for name, v in zip(id_cols, id_vals)}
+        with np.errstate(invalid="ignore", divide="ignore"):
+            for k, c in enumerate(_DISPS):
+                int_cols[c] = win[:, k] / (n_kept - 1) if n_kept > 1 else np.full(E, np.nan)
+        # the first kept frame has no predecessor: its NaN row sums to 0 and still counts in the mean
+        int_cols["msd"] = win[:, 3] / n_kept
+        msd_int = pd.DataFrame(int_cols)
+        return msd, msd_all, msd_int
+
+    @staticmethod
+    def _remove_drift(r_si, ent_mass, group_off):
+        """Per-type mass-weighted COM minus the same at the first frame, subtracted from every
+        molecule of that type (diffusion.py:83-96). r_si [F,3,E]."""
+        out = r_si.copy()
+        for g in range(len(group_off) - 1):
+            lo, hi = group_off[g], group_off[g + 1]
+            m = ent_mass[lo:hi]
+            com = (r_si[:, :, lo:hi] @ m) / m.sum()  # [F,3]
+            out[:, :, lo:hi] -= (com - com[0])[:, :, None]
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    def get_msd_from_log(self, log_pattern):
+        """msd columns of LAMMPS log file(s) in m^2 plus 'Time (s)' (diffusion.py:241-265)."""
+        full_log = concat_log(log_pattern, step=None, working_dir=self.outputs_dir)
+        msd = full_log.filter(regex="msd").copy()
+        for col in msd:
+            msd[col] = msd[col] * constants.DISTANCE_CONVERSION[self.units] ** 2
+        msd["Time (s)"] = full_log["Step"] * self.timestep * constants.TIME_CONVERSION[self.units]
+        return msd
+
+    def calc_diff(self, msd, initial_time=None, final_time=None, dimension=3, diff_names=None, save=False,
+                  plot=False):
+        """
+        D = slope / (2 * dimension) of a through-origin least-squares fit of every column whose name
+        contains 'msd' against 'Time (s)', with its standard error and R^2 (diffusion.py:267-408).
+        initial_time / final_time: dicts {column position: seconds} restricting the fit range.
+        Writes diffusion.csv (and diff_<name>.txt when save, msd.png / msd_log.png when plot).
+        """
+        initial_time = initial_time or {}
+        final_time = final_time or {}
+        t_all = msd["Time (s)"]
+        t_min, t_max = min(t_all), max(t_all)
+        names = [c for c in msd.columns if "msd" in c.lower()]
+        table = np.zeros((len(names), 3))
+        fits = []
+        for k, col in enumerate(names):
+            sel = (t_all >= initial_time.get(k, t_min)) & (t_all <= final_time.get(k, t_max))
+            fit = _OlsThroughOrigin(msd.loc[sel, col], t_all[sel])
+            fits.append((fit, sel))
+            table[k] = [fit.slope / (2 * dimension), fit.bse / (2 * dimension), fit.rsquared]
+            if save:
+                tag = diff_names[k] if diff_names else k + 1
+                with open(f"{self.diff_dir}/diff_{tag}.txt", "w") as fh:
+                    fh.write(str(fit.summary()))
+        index = diff_names or [k + 1 for k in range(len(names))]
+        diffusion = pd.DataFrame(table, columns=["diffusion (m2/s)", "std", "R2"], index=index)
+        if plot:
+            self._plot_msd(msd, names, fits, index)
+        diffusion.to_csv(f"{self.diff_dir}/diffusion.csv")
+        print("Diffusion results written to a .csv file.")
+        return diffusion
+
+    def _plot_msd(self, msd, names, fits, labels):
+        import matplotlib
+
+        matplotlib.use("Agg", force=False)
+        import matplotlib.pyplot as plt
+
+        from ..utilities.plots import set_axis
+
+        t_ns = msd["Time (s)"].to_numpy() * 10 ** 9
+        nrows = int(np.ceil(len(names) / 2))
+        for fname, logscale in (("msd.png", False), ("msd_log.png", True)):
+            fig, axes = plt.subplots(nrows, 2, figsize=(12, 8), squeeze=False)
+            cmap = plt.get_cmap("Paired")
+            for k, (ax, col) in enumerate(zip(axes.flatten(), names)):
+                fit, sel = fits[k]
+                ax.plot(t_ns, msd[col], color=cmap(k / 10), linewidth=2, label=labels[k])
+                if logscale:
+                    ref = 10 ** (np.log10(msd[col].max()) - np.log10(t_ns.max()))
+                    ax.plot(t_ns, t_ns * ref, color="k", ls="--", linewidth=2)
+                    ax.set(xscale="log", yscale="log")
+                else:
+                    ax.plot(t_ns[np.asarray(sel)], fit.predict(), color="k", ls="--", linewidth=2)
+                set_axis(ax, axis="both")
+                ax.legend(fontsize=16, frameon=False)
+                ax.set_xlabel(r"$\mathrm{Time, 10^9 (s)}$", fontsize=18)
+                ax.set_ylabel(r"$\mathrm{MSD\ (m^2)}$", fontsize=18)
+            for ax in axes.flatten()[len(names):]:
+                fig.delaxes(ax)
+            fig.tight_layout()
+            fig.savefig(f"{self.diff_dir}/{fname}", bbox_inches="tight", pad_inches=0.1)
+            plt.close(fig)
+
+    def get_diff_dist(self, msd_int, dump_freq, dimension=3, tao_coeff=4, plot=False, diff_names=None):
+        """
+        Per-entity diffusion coefficients from `msd_int`: msd / (2 * dimension * tao_coeff * delta),
+        delta = dump_freq * timestep in seconds (diffusion.py:410-516). Adds the column 'diff' and
+        returns the DataFrame; with plot=True also saves a histogram to diff_dist.png.
+        """
+        delta = dump_freq * self.timestep * constants.TIME_CONVERSION[self.units]
+        msd_int["diff"] = msd_int["msd"] / (2 * dimension * tao_coeff * delta)
+        if plot:
+            import matplotlib
+
+            matplotlib.use("Agg", force=False)
+            import matplotlib.pyplot as plt
+
+            from ..utilities.plots import set_axis
+
+            if "type" in msd_int.columns:
+                groups = list(msd_int.groupby("type"))
+                labels = diff_names or [k + 1 for k in range(len(groups))]
+                fig, axes = plt.subplots(int(np.ceil(len(groups) / 2)), 2, figsize=(12, 8), squeeze=False)
+                for ax, (key, grp) in zip(axes.flatten(), groups):
+                    ax.hist(grp["diff"] * 10 ** 9, bins="sqrt", density=True, edgecolor="k", label=labels[key - 1])
+                    ax.legend(fontsize=16, frameon=False)
+                for ax in axes.flatten()[len(groups):]:
+                    fig.delaxes(ax)
+                used = axes.flatten()[: len(groups)]
+            else:
+                fig, ax = plt.subplots(figsize=(8, 6))
+                ax.hist(msd_int["diff"] * 10 ** 9, bins="sqrt", density=True, edgecolor="k")
+                used = [ax]
+            for ax in used:
+                set_axis(ax, axis="both")
+                ax.set_xlabel(r"$\mathrm{Diffusivity, 10^{-9}\ (m^2/s)}$", fontsize=18)
+                ax.set_ylabel("Frequency", fontsize=18)
+            fig.tight_layout()
+            fig.savefig(f"{self.diff_dir}/diff_dist.png", bbox_inches="tight", pad_inches=0.1)
+            plt.close(fig)
+        return msd_int

@@ -213,3 +213,17 @@ def write_dump(path, timestep, bounds, columns, table, fmt=None):
                 )
                 + " \n"
             )
+
+
+def write_log(path, table, columns, float_fmt=None):
+    """Write a minimal LAMMPS log with one thermo block (used by tests and golden generation)."""
+    table = np.asarray(table)
+    with open(path, "wt") as fh:
+        fh.write("LAMMPS (synthetic)\nunits real\nrun %d\n" % max(0, len(table) - 1))
+        fh.write("Per MPI rank memory allocation (min/avg/max) = 1.0 | 1.0 | 1.0 Mbytes\n")
+        fh.write(" ".join(columns) + " \n")
+        for row in table:
+            fh.write(" ".join(("%d" % int(v)) if c == "Step" else
+                              (repr(float(v)) if float_fmt is None else float_fmt % v)
+                              for c, v in zip(columns, row)) + " \n")
+        fh.write("Loop time of 1.0 on 1 procs for %d steps with 1 atoms\n" % max(0, len(table) - 1))

@@ -1,0 +1,397 @@
+"""
+Radial distribution functions and coordination numbers from LAMMPS dumps —
+drop-in for /root/reference/mdproptools/structural/rdf_cn.py (same public
+functions, positional order, defaults, return types, CSV side effects and
+exception types: rdf_cn.py:385-396, 533-544, 654-665, 759-770).
+
+What runs where
+  GPU (libmdhip.so): every pair loop — `_rdf_loop`, `_cn_loop`,
+      `_rdf_mol_loop`, `_cn_mol_loop` (rdf_cn.py:72-162) — and the molecule
+      centres of mass (`_define_mol_cols`, rdf_cn.py:218-241), for all frames
+      of a batch in one call; integer histograms come back per frame.
+  Host (numpy, this file): parsing, id sorting, the altered-id remap
+      (rdf_cn.py:197-215, vectorised), densities and the per-frame
+      normalisation in the reference's operation order (rdf_cn.py:288-291,
+      312-328), the frame average and the CSV. Because the histograms are
+      exact integers and the normalisation repeats the reference's float
+      operations in order, g(r) and CN come out bit-identical.
+
+Differences, all deliberate:
+  * pairs whose bin index would be == num_bins (reachable when r_cut/bin_size
+    rounds up, e.g. 20/0.05) are dropped and reported instead of written out of
+    bounds (the numba build corrupts memory there; plain numpy raises);
+  * progress lines are printed only when `rdf_cn.VERBOSE` is true.
+"""
+
+from timeit import default_timer as timer
+
+import numpy as np
+import pandas as pd
+
+from .. import backend
+from ..io import parse_lammps_dumps
+
+CON_CONSTANT = 1.660538921  # amu/A^3 -> g/cm^3 (rdf_cn.py:30)
+VERBOSE = False
+MAX_BATCH_BYTES = 1 << 30  # coordinates staged per library call
+
+_R_LABEL = "r ($\\AA$)"
+
+
+def _say(*args):
+    if VERBOSE:
+        print(*args)
+
+
+# ------------------------------------------------------------------------------------------------
+# host-side pieces
+# ------------------------------------------------------------------------------------------------
+
+
+def _initialize(r_cut, bin_size, filename, partial_relations):
+    """Bins, radii, parsed frames and relation count (rdf_cn.py:165-180)."""
+    if isinstance(r_cut, list):
+        num_bins = [int(rc / bin_size) for rc in r_cut]
+        radii = [(np.arange(nb) + 0.5) * bin_size for nb in num_bins]
+    else:
+        num_bins = int(r_cut / bin_size)
+        radii = (np.arange(num_bins) + 0.5) * bin_size
+    dumps = list(parse_lammps_dumps(filename))
+    return dumps, num_bins, radii, len(dumps), len(partial_relations[0])
+
+
+def _calc_atom_type(ids, num_mols, num_atoms):
+    """
+    Atom id -> 1-based index of the atom inside its molecule type, offset by the atom counts of
+    the preceding molecule types (rdf_cn.py:197-215), vectorised over all atoms.
+    """
+    ids = np.asarray(ids, dtype=np.float64)
+    num_atoms = np.asarray(num_atoms)
+    upper = np.cumsum(np.multiply(num_mols, num_atoms))
+    which = np.searchsorted(upper, ids, side="left")  # first molecule type whose range holds the id
+    out = ids.copy()
+    inside = which < len(upper)
+    w = which[inside]
+    v = np.mod(ids[inside] - upper[w], num_atoms[w])  # Python-style modulo of a non-positive number
+    v[v == 0] = num_atoms[w][v == 0]
+    out[inside] = v + np.concatenate(([0], np.cumsum(num_atoms)[:-1]))[w]
+    return out
+
+
+def _molecule_layout(num_mols, num_atoms_per_mol):
+    """Segment offsets and molecule type labels implied by the sorted-id order (rdf_cn.py:222-230)."""
+    counts = np.repeat(np.asarray(num_atoms_per_mol, dtype=np.int64), np.asarray(num_mols, dtype=np.int64))
+    seg_off = np.concatenate(([0], np.cumsum(counts))).astype(np.int64)
+    seg_type = np.repeat(np.arange(1, len(num_mols) + 1), np.asarray(num_mols, dtype=np.int64))
+    return seg_off, seg_type.astype(np.int32)
+
+
+def _type_counts(labels):
+    vals, cnt = np.unique(np.asarray(labels).astype(np.int64), return_counts=True)
+    return {int(v): int(c) for v, c in zip(vals, cnt)}
+
+
+def _calc_props(box_lengths, ref_labels, obj_labels, num_types, mass, partial_relations, altered,
+                num_atoms_per_mol=None):
+    """
+    Densities and consistency checks of one frame (rdf_cn.py:244-294).
+    Returns (rho, rho_pairs, atom_types, object_types).
+    """
+    n_objects = len(obj_labels)
+    volume = np.prod(box_lengths)
+    atom_types = _type_counts(ref_labels)
+    object_types = _type_counts(obj_labels)
+    expected = np.sum(num_atoms_per_mol) if altered else num_types
+    if expected != len(atom_types):
+        raise ValueError(
+            "Consistency check failed: Number of specified atomic types is different from the "
+            f"calculated value specified= {num_atoms_per_mol if altered else num_types}, "
+            f"calculated= {len(atom_types)}")
+    # rdf_cn.py:280-282 — needs the labels 1..num_types to be present (KeyError otherwise)
+    total_mass = np.sum([float(mass[i]) * float(atom_types[i + 1]) for i in range(num_types)])
+    total_density = float((total_mass / volume) * CON_CONSTANT)
+    _say("{0:s}{1:10.8f}".format("Average density=", total_density))
+    rho = n_objects / volume
+    rho_pairs = np.zeros(len(partial_relations[1]))
+    for k, obj in enumerate(partial_relations[1]):
+        rho_pairs[k] = object_types[obj] / volume
+        if rho_pairs[k] < 1.0e-22:
+            raise ValueError("Error: Density is zero for mol type: " + str(obj))
+    return rho, rho_pairs, atom_types, object_types
+
+
+def _shell_volume(bin_size, num_bins):
+    edges3 = np.arange(1, num_bins + 1) ** 3 - np.arange(num_bins) ** 3
+    return 4 / 3 * np.pi * bin_size ** 3 * edges3  # rdf_cn.py:312-318
+
+
+def _normalize_rdf(bin_size, rho_pairs, atom_types, partial_relations, num_relations, num_bins, rdf_part,
+                   rdf_full=None, num_atoms=None, rho=None):
+    """Per-frame normalisation (rdf_cn.py:297-329); operation order kept for bit-identical g(r)."""
+    sv = _shell_volume(bin_size, num_bins)
+    if rdf_full is not None:
+        rdf_full = rdf_full / (num_atoms * rho * sv)
+    n_ref = np.array([atom_types[a] for a in partial_relations[0]]).reshape(num_relations, 1)
+    n_ref = np.tile(n_ref, num_bins)
+    rho_b = np.tile(rho_pairs.reshape(num_relations, 1), num_bins)
+    sv_m = np.tile(sv, (num_relations, 1))
+    rdf_part = rdf_part / (n_ref * rho_b * sv_m)
+    return rdf_full, rdf_part
+
+
+def _normalize_cn(atom_types, partial_relations, cn):
+    return cn / [atom_types[a] for a in partial_relations[0]]  # rdf_cn.py:332-338
+
+
+def _save_rdf(radii, relation_matrix, path_or_buf, save_mode, rdf_part_sum, rdf_full_sum=None):
+    """Same columns and CSV behaviour as rdf_cn.py:341-365."""
+    cols = [_R_LABEL] + (["g_full(r)"] if rdf_full_sum is not None else [])
+    cols += [f"g_{pair[0]}-{pair[1]}" for pair in relation_matrix]
+    blocks = (radii, rdf_full_sum, rdf_part_sum) if rdf_full_sum is not None else (radii, rdf_part_sum)
+    final_df = pd.DataFrame(np.vstack(blocks).transpose(), columns=cols)
+    if save_mode:
+        final_df.to_csv(path_or_buf, index=False)
+        _say("Results are written to pd.DataFrame and csv file")
+    else:
+        _say(final_df)
+    return final_df
+
+
+def _save_cn(relation_matrix, path_or_buff, cn_sum, save_mode):
+    cols = [f"cn_{pair[0]}-{pair[1]}" for pair in relation_matrix]
+    final_df = pd.DataFrame(np.vstack(cn_sum).transpose(), columns=cols)
+    if save_mode:
+        final_df.to_csv(path_or_buff, index=False)
+        _say("CN results are written to pd.DataFrame and csv file")
+    else:
+        _say(final_df)
+    return final_df
+
+
+# ------------------------------------------------------------------------------------------------
+# frame batching: SoA planes for the library
+# ------------------------------------------------------------------------------------------------
+
+
+class _Frame:
+    """One parsed frame reduced to what the pair loops need (rdf_cn.py:183-194)."""
+
+    __slots__ = ("timestep", "ids", "types", "xyz", "lengths")
+
+    def __init__(self, dump):
+        _say("The timestep of the current file is: " + str(dump.timestep))
+        tbl = dump.data[["id", "type", "x", "y", "z"]].sort_values("id").to_numpy(dtype=np.float64)
+        self.timestep = dump.timestep
+        self.ids = tbl[:, 0]
+        self.types = tbl[:, 1]
+        self.xyz = np.ascontiguousarray(tbl[:, 2:5].T)
+        self.lengths = dump.box.to_lattice().lengths
+
+
+def _batches(frames):
+    """Consecutive frames with the same atom count, capped at MAX_BATCH_BYTES of coordinates."""
+    start = 0
+    while start < len(frames):
+        n = frames[start].xyz.shape[1]
+        cap = max(1, MAX_BATCH_BYTES // max(1, 24 * n))
+        stop = start + 1
+        while stop < len(frames) and stop - start < cap and frames[stop].xyz.shape[1] == n:
+            stop += 1
+        yield frames[start:stop]
+        start = stop
+
+
+def _labels_for(frames, labels_per_frame):
+    """[N] when every frame carries the same labels, else [F, N]."""
+    first = labels_per_frame[0]
+    if all(np.array_equal(first, lab) for lab in labels_per_frame[1:]):
+        return first.astype(np.int32)
+    return np.stack(labels_per_frame).astype(np.int32)
+
+
+# ------------------------------------------------------------------------------------------------
+# public functions
+# ------------------------------------------------------------------------------------------------
+
+
+def calc_atomic_rdf(r_cut, bin_size, num_types, mass, partial_relations, filename, num_mols=None,
+                    num_atoms_per_mol=None, path_or_buff="rdf.csv", save_mode=True):
+    """
+    Full and partial atom-atom g(r) averaged over the frames of `filename` (rdf_cn.py:385-530).
+
+    Args follow the reference: r_cut (float), bin_size (float), num_types (int), mass (list of
+    float, one per atom type), partial_relations ([[reference types], [other types]]), filename
+    (dump file or '*' pattern), num_mols / num_atoms_per_mol (give both to use altered atom ids:
+    the index of an atom inside its molecule type), path_or_buff, save_mode.
+    Returns a DataFrame with columns r, g_full(r), g_a-b ...
+    """
+    dumps, num_bins, radii, num_files, num_relations = _initialize(r_cut, bin_size, filename, partial_relations)
+    altered = bool(num_mols and num_atoms_per_mol)
+    relation_matrix = np.asarray(partial_relations).transpose()
+    rdf_full_sum = np.zeros(num_bins)
+    rdf_part_sum = np.zeros((num_relations, num_bins))
+    frames = [_Frame(d) for d in dumps]
+    dropped = 0
+    for batch in _batches(frames):
+        start = timer()
+        labels = [(_calc_atom_type(f.ids, num_mols, num_atoms_per_mol) if altered else f.types) for f in batch]
+        props = [_calc_props(f.lengths, lab, lab, num_types, mass, partial_relations, altered,
+                             num_atoms_per_mol) for f, lab in zip(batch, labels)]
+        full, part, ov = backend.rdf_loop(np.stack([f.xyz for f in batch]), _labels_for(batch, labels),
+                                          np.array([f.lengths for f in batch]), relation_matrix, r_cut,
+                                          bin_size, num_bins, per_frame=True)
+        dropped += ov
+        for k, f in enumerate(batch):
+            rho, rho_pairs, atom_types, _ = props[k]
+            g_full, g_part = _normalize_rdf(bin_size, rho_pairs, atom_types, partial_relations, num_relations,
+                                            num_bins, part[k].astype(np.float64), full[k].astype(np.float64),
+                                            f.xyz.shape[1], rho)
+            rdf_full_sum += g_full
+            rdf_part_sum += g_part
+            _say("Finished computing RDF for timestep", f.timestep)
+        _say("Trajectory loop took:", timer() - start, "s")
+    if dropped:
+        print(f"calc_atomic_rdf: {dropped} pair(s) fell in bin index {num_bins} (== num_bins) and were dropped")
+    rdf_full_sum = rdf_full_sum / num_files
+    rdf_part_sum = rdf_part_sum / num_files
+    return _save_rdf(radii, relation_matrix, path_or_buff, save_mode, rdf_part_sum, rdf_full_sum=rdf_full_sum)
+
+
+def calc_atomic_cn(r_cut, bin_size, num_types, mass, partial_relations, filename, num_mols=None,
+                   num_atoms_per_mol=None, path_or_buff="cn.csv", save_mode=True):
+    """
+    Atom-atom coordination numbers, one cutoff per relation (rdf_cn.py:533-651). r_cut is a list.
+    Returns a one-row DataFrame with columns cn_a-b.
+    """
+    dumps, _, _, num_files, num_relations = _initialize(r_cut, bin_size, filename, partial_relations)
+    altered = bool(num_mols and num_atoms_per_mol)
+    relation_matrix = np.asarray(partial_relations).transpose()
+    cn_sum = np.zeros(num_relations)
+    frames = [_Frame(d) for d in dumps]
+    for batch in _batches(frames):
+        labels = [(_calc_atom_type(f.ids, num_mols, num_atoms_per_mol) if altered else f.types) for f in batch]
+        props = [_calc_props(f.lengths, lab, lab, num_types, mass, partial_relations, altered,
+                             num_atoms_per_mol) for f, lab in zip(batch, labels)]
+        raw = backend.cn_loop(np.stack([f.xyz for f in batch]), _labels_for(batch, labels),
+                              np.array([f.lengths for f in batch]), relation_matrix, list(r_cut),
+                              per_frame=True)
+        for k, f in enumerate(batch):
+            cn_sum += _normalize_cn(props[k][2], partial_relations, raw[k].astype(np.float64))
+            _say("Finished computing CN for timestep", f.timestep)
+    cn_sum = cn_sum / num_files
+    return _save_cn(relation_matrix, path_or_buff, cn_sum, save_mode)
+
+
+def _same_types(batch):
+    return all(np.array_equal(batch[0].types, f.types) for f in batch[1:])
+
+
+def _molecular_inputs(batch, num_mols, num_atoms_per_mol, mass):
+    """Device-side COM of wrapped coordinates for every frame of the batch (rdf_cn.py:218-241)."""
+    seg_off, seg_type = _molecule_layout(num_mols, num_atoms_per_mol)
+    n = batch[0].xyz.shape[1]
+    if seg_off[-1] != n:
+        raise ValueError(f"Length of values ({int(seg_off[-1])}) does not match length of index ({n})")
+    xyz = np.stack([f.xyz for f in batch])
+    atom_mass = np.asarray(mass, dtype=np.float64)[batch[0].types.astype(np.int64) - 1]
+    if _same_types(batch):
+        sites, _, _ = backend.segment_com(xyz, atom_mass, seg_off)
+    else:  # per-frame masses: one call per frame
+        sites = np.concatenate([
+            backend.segment_com(f.xyz[None], np.asarray(mass, dtype=np.float64)[f.types.astype(np.int64) - 1],
+                                seg_off)[0] for f in batch])
+    return xyz, sites, seg_type
+
+
+def calc_molecular_rdf(r_cut, bin_size, num_types, mass, partial_relations, filename, num_mols,
+                       num_atoms_per_mol, path_or_buff="rdf_mol.csv", save_mode=True):
+    """
+    Partial g(r) between atoms (first list of partial_relations) and molecule centres of mass
+    (second list: molecule type numbers) (rdf_cn.py:654-756).
+    """
+    dumps, num_bins, radii, num_files, num_relations = _initialize(r_cut, bin_size, filename, partial_relations)
+    relation_matrix = np.asarray(partial_relations).transpose()
+    rdf_part_sum = np.zeros((num_relations, num_bins))
+    frames = [_Frame(d) for d in dumps]
+    dropped = 0
+    for batch in _batches(frames):
+        xyz, sites, seg_type = _molecular_inputs(batch, num_mols, num_atoms_per_mol, mass)
+        props = [_calc_props(f.lengths, f.types, seg_type, num_types, mass, partial_relations, False)
+                 for f in batch]
+        if _same_types(batch):
+            part, ov = backend.rdf_mol_loop(xyz, batch[0].types.astype(np.int32), sites, seg_type,
+                                            np.array([f.lengths for f in batch]), relation_matrix, r_cut,
+                                            bin_size, num_bins, per_frame=True)
+        else:
+            part, ov = _per_frame_mol_rdf(batch, sites, seg_type, relation_matrix, r_cut, bin_size, num_bins)
+        dropped += ov
+        for k, f in enumerate(batch):
+            _, rho_pairs, atom_types, _ = props[k]
+            _, g_part = _normalize_rdf(bin_size, rho_pairs, atom_types, partial_relations, num_relations,
+                                       num_bins, part[k].astype(np.float64))
+            rdf_part_sum += g_part
+            _say("Finished computing RDF for timestep", f.timestep)
+    if dropped:
+        print(f"calc_molecular_rdf: {dropped} pair(s) fell in bin index {num_bins} (== num_bins) and were dropped")
+    rdf_part_sum = rdf_part_sum / num_files
+    return _save_rdf(radii, relation_matrix, path_or_buff, save_mode, rdf_part_sum)
+
+
+def _per_frame_mol_rdf(batch, sites, seg_type, relation_matrix, r_cut, bin_size, num_bins):
+    parts, ov = [], 0
+    for k, f in enumerate(batch):
+        p, o = backend.rdf_mol_loop(f.xyz[None], f.types.astype(np.int32), sites[k:k + 1], seg_type,
+                                    np.array([f.lengths]), relation_matrix, r_cut, bin_size, num_bins)
+        parts.append(p[0])
+        ov += o
+    return np.stack(parts), ov
+
+
+def calc_molecular_cn(r_cut, bin_size, num_types, mass, partial_relations, filename, num_mols,
+                      num_atoms_per_mol, path_or_buff="cn_mol.csv", save_mode=True):
+    """Atom - molecule-COM coordination numbers, one cutoff per relation (rdf_cn.py:759-855)."""
+    dumps, _, _, num_files, num_relations = _initialize(r_cut, bin_size, filename, partial_relations)
+    relation_matrix = np.asarray(partial_relations).transpose()
+    cn_sum = np.zeros(num_relations)
+    frames = [_Frame(d) for d in dumps]
+    for batch in _batches(frames):
+        xyz, sites, seg_type = _molecular_inputs(batch, num_mols, num_atoms_per_mol, mass)
+        props = [_calc_props(f.lengths, f.types, seg_type, num_types, mass, partial_relations, False)
+                 for f in batch]
+        if _same_types(batch):
+            raw = backend.cn_mol_loop(xyz, batch[0].types.astype(np.int32), sites, seg_type,
+                                      np.array([f.lengths for f in batch]), relation_matrix, list(r_cut))
+        else:
+            raw = np.stack([backend.cn_mol_loop(f.xyz[None], f.types.astype(np.int32), sites[k:k + 1], seg_type,
+                                                np.array([f.lengths]), relation_matrix, list(r_cut))[0]
+                            for k, f in enumerate(batch)])
+        for k, f in enumerate(batch):
+            cn_sum += _normalize_cn(props[k][2], partial_relations, raw[k].astype(np.float64))
+            _say("Finished computing CN for timestep", f.timestep)
+    cn_sum = cn_sum / num_files
+    return _save_cn(relation_matrix, path_or_buff, cn_sum, save_mode)
+
+
+def calc_intermolecular_rdf(r_cut, bin_size, num_types, mass, partial_relations, filename, num_mols,
+                            num_atoms_per_mol, path_or_buff="rdf_mol.csv", save_mode=True):
+    """
+    Molecule-COM to molecule-COM partial g(r) (rdf_cn.py:857-903; undocumented upstream, a molecule is
+    paired with itself as there). partial_relations holds molecule type numbers on both sides.
+    """
+    dumps, num_bins, radii, num_files, num_relations = _initialize(r_cut, bin_size, filename, partial_relations)
+    relation_matrix = np.asarray(partial_relations).transpose()
+    rdf_part_sum = np.zeros((num_relations, num_bins))
+    frames = [_Frame(d) for d in dumps]
+    for batch in _batches(frames):
+        _, sites, seg_type = _molecular_inputs(batch, num_mols, num_atoms_per_mol, mass)
+        props = [_calc_props(f.lengths, seg_type, seg_type, num_types, mass, partial_relations, False)
+                 for f in batch]
+        part, _ = backend.rdf_mol_loop(sites, seg_type, sites, seg_type, np.array([f.lengths for f in batch]),
+                                       relation_matrix, r_cut, bin_size, num_bins, per_frame=True)
+        for k in range(len(batch)):
+            _, rho_pairs, atom_types, _ = props[k]
+            _, g_part = _normalize_rdf(bin_size, rho_pairs, atom_types, partial_relations, num_relations,
+                                       num_bins, part[k].astype(np.float64))
+            rdf_part_sum += g_part
+    rdf_part_sum = rdf_part_sum / num_files
+    return _save_rdf(radii, relation_matrix, path_or_buff, save_mode, rdf_part_sum)

@@ -376,9 +376,71 @@ def golden_cell17():
     print("cell17:", table["reference_here"])
 
 
+# ----------------------------------------------------------------------------
+def golden_host_logic():
+    """Conductivity.detect_time_range / fit_curve / green_kubo and Viscosity.calc_avg_visc /
+    fit_avg_visc on designed inputs (host-side logic around the kernels)."""
+    rng = np.random.default_rng(20250328 + 6)
+    out = {}
+    n = 3000
+    t = np.arange(n)
+    flux = np.stack([
+        np.exp(-t / 40.0) * np.cos(t / 9.0) + 1e-3 * rng.standard_normal(n) * (t > 2400),
+        np.exp(-t / 90.0) + 2e-3 * rng.standard_normal(n) * ((t > 1500) & (t < 1700)),
+    ])
+    out["dtr_flux"] = flux
+    out["dtr_tol"] = np.asarray(1e-2)
+    out["dtr_range"] = np.array([Conductivity.detect_time_range(f, 1e-2) for f in flux])
+    c = Conductivity.__new__(Conductivity)
+    c.num_mols = [1]
+    c.time = list(t * 2e-15)
+    c.temp, c.volume = 298.15, 1.2e-25
+    integ = c.integrate_charge_flux_correlation(flux)
+    ave, rng_t = c.fit_curve(flux, integ, 1e-2)
+    out["fc_integral"], out["fc_ave"] = integ, ave
+    out["fc_time_range"] = np.array([list(r) for r in rng_t])
+    out["fc_cond"] = c.green_kubo(ave)
+    out["fc_temp"], out["fc_volume"] = np.asarray(c.temp), np.asarray(c.volume)
+    # three replicate logs -> calc_avg_visc -> fit_avg_visc
+    nlog, reps = 12000, 3
+    press = np.zeros((reps, 3, nlog))
+    for r in range(reps):
+        e = rng.standard_normal((3, nlog))
+        x = np.zeros((3, nlog))
+        for k in range(1, nlog):
+            x[:, k] = 0.9 * x[:, k - 1] + e[:, k]
+        press[r] = x * 300.0
+    out["log_press"] = press
+    out["log_step"] = np.arange(nlog) * 2
+    with tempfile.TemporaryDirectory() as tmp:
+        for r in range(reps):
+            tbl = np.column_stack([out["log_step"], press[r].T])
+            mio.write_log(os.path.join(tmp, "log.rep%d" % r), tbl, ["Step", "Pxy", "Pxz", "Pyz"])
+        v = Viscosity("log.rep*", 400, 64000.0, temp=300.0, timestep=1, acf_method="wkt", units="real",
+                      working_dir=tmp)
+        import glob as _glob
+        order = [int(os.path.basename(f)[7:]) for f in _glob.glob(os.path.join(tmp, "log.rep*"))]
+        with quiet():
+            visc_avg, visc_data, acf_data, tm = v.calc_avg_visc(output_all_data=True)
+        out["visc_rep_order"] = np.asarray(order)
+        out["visc_avg"] = np.stack(visc_avg)
+        out["visc_time"] = tm
+        out["visc_cutoff"], out["visc_volume"], out["visc_temp"] = (
+            np.asarray(400), np.asarray(64000.0), np.asarray(300.0))
+        try:
+            out["visc_fit"] = np.asarray(v.fit_avg_visc(visc_avg, initial_guess=[1e-8, 0.5, 50.0, 500.0]))
+        except Exception as exc:  # data dependent; record that the reference could not fit
+            print("fit_avg_visc failed in the reference:", repr(exc))
+            out["visc_fit"] = np.asarray(np.nan)
+    np.savez_compressed(os.path.join(OUT, "host_logic.npz"), **out)
+    print("host_logic: dtr", out["dtr_range"].tolist(), "cond", out["fc_cond"], "visc_fit", out["visc_fit"])
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["synth", "acf", "small", "c1", "cell17"]
+    which = sys.argv[1:] or ["synth", "acf", "small", "c1", "cell17", "host"]
+    if "host" in which:
+        golden_host_logic()
     if "synth" in which:
         golden_synth_rdf()
     if "acf" in which:

@@ -1,0 +1,136 @@
+"""CPU-only: the host-side logic of the drop-in layer (no kernel calls) against the golden vectors."""
+import inspect
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import load_golden
+
+
+def test_calc_atom_type_vectorised(g_synth):
+    from mdproptools_amd.structural.rdf_cn import _calc_atom_type
+
+    nm, na = g_synth["atom_type_num_mols"], g_synth["atom_type_num_atoms"]
+    ids = np.arange(1, int(np.dot(nm, na)) + 1, dtype=np.float64)
+    np.testing.assert_array_equal(_calc_atom_type(ids, nm, na), g_synth["atom_type_out"])
+    # ids beyond the last molecule type are left untouched, as in the reference loop
+    np.testing.assert_array_equal(_calc_atom_type(np.array([1000.0]), nm, na), [1000.0])
+
+
+def test_normalisation_matches_reference_frame(g_c1):
+    from mdproptools_amd.structural import rdf_cn as M
+
+    g = g_c1
+    rel = g["rdf_def_rel"].tolist()
+    gf_sum = gp_sum = 0.0
+    for f in range(2):
+        fr = g["frames"][f]
+        L = tuple((g["bounds"][f][:, 1] - g["bounds"][f][:, 0]).tolist())
+        rho, rho_pairs, atom_types, _ = M._calc_props(L, fr[:, 1], fr[:, 1], 9, g["mass"], rel, False)
+        gf, gp = M._normalize_rdf(0.05, rho_pairs, atom_types, rel, 5, 400, g["rdf_def_part"][f].astype(float),
+                                  g["rdf_def_full"][f].astype(float), len(fr), rho)
+        gf_sum, gp_sum = gf_sum + gf, gp_sum + gp
+    df = M._save_rdf((np.arange(400) + 0.5) * 0.05, np.asarray(rel).T, None, False, gp_sum / 2, gf_sum / 2)
+    np.testing.assert_array_equal(df.to_numpy(), g["rdf_def_df"])
+    assert list(df.columns) == list(g["rdf_def_df_columns"])
+
+
+def test_calc_props_errors():
+    from mdproptools_amd.structural import rdf_cn as M
+
+    types = np.array([1.0, 1.0, 2.0, 3.0])
+    with pytest.raises(ValueError):  # wrong number of atom types (rdf_cn.py:266-271)
+        M._calc_props((10.0, 10.0, 10.0), types, types, 2, [1.0, 1.0], [[1], [2]], False)
+    with pytest.raises(KeyError):  # relation names a type that does not occur
+        M._calc_props((10.0, 10.0, 10.0), types, types, 3, [1.0, 1.0, 1.0], [[1], [7]], False)
+
+
+def test_public_signatures_match_reference_surface():
+    """Names, positional order and defaults of the drop-in surface."""
+    from mdproptools_amd.dynamical.conductivity import Conductivity
+    from mdproptools_amd.dynamical.diffusion import Diffusion
+    from mdproptools_amd.dynamical.viscosity import Viscosity
+    from mdproptools_amd.structural import rdf_cn
+
+    def sig(f):
+        return [(p.name, p.default if p.default is not inspect._empty else None)
+                for p in inspect.signature(f).parameters.values()]
+
+    assert sig(rdf_cn.calc_atomic_rdf) == [
+        ("r_cut", None), ("bin_size", None), ("num_types", None), ("mass", None), ("partial_relations", None),
+        ("filename", None), ("num_mols", None), ("num_atoms_per_mol", None), ("path_or_buff", "rdf.csv"),
+        ("save_mode", True)]
+    assert sig(rdf_cn.calc_atomic_cn)[-2:] == [("path_or_buff", "cn.csv"), ("save_mode", True)]
+    assert sig(rdf_cn.calc_molecular_rdf)[6:] == [("num_mols", None), ("num_atoms_per_mol", None),
+                                                  ("path_or_buff", "rdf_mol.csv"), ("save_mode", True)]
+    assert sig(rdf_cn.calc_molecular_cn)[-2:] == [("path_or_buff", "cn_mol.csv"), ("save_mode", True)]
+    assert sig(Diffusion.__init__)[1:] == [("timestep", 1), ("units", "real"), ("outputs_dir", None),
+                                           ("diff_dir", None)]
+    assert sig(Diffusion.get_msd_from_dump)[1:] == [
+        ("filename", None), ("msd_type", "com"), ("num_mols", None), ("num_atoms_per_mol", None), ("mass", None),
+        ("com_drift", False), ("avg_interval", False), ("tao_coeff", 4)]
+    assert sig(Diffusion.calc_diff)[1:] == [("msd", None), ("initial_time", None), ("final_time", None),
+                                            ("dimension", 3), ("diff_names", None), ("save", False), ("plot", False)]
+    assert sig(Conductivity.__init__)[1:] == [
+        ("filename", None), ("num_mols", None), ("num_atoms_per_mol", None), ("volume", None), ("mass", None),
+        ("temp", 298.15), ("timestep", 1), ("units", "real"), ("working_dir", None)]
+    assert sig(Viscosity.__init__)[1:] == [
+        ("log_pattern", None), ("cutoff_time", None), ("volume", None), ("temp", 298.15), ("timestep", 1),
+        ("acf_method", "wkt"), ("units", "real"), ("working_dir", None)]
+    for name in ("correlate", "detect_time_range", "get_charge_flux", "correlate_charge_flux",
+                 "integrate_charge_flux_correlation", "fit_curve", "green_kubo", "calc_cond", "einstein", "nernst"):
+        assert hasattr(Conductivity, name)
+    for name in ("autocorrelate", "exp_func", "calc_visc", "_calc_3d_visc", "calc_avg_visc", "fit_avg_visc",
+                 "bootstrapping"):
+        assert hasattr(Viscosity, name)
+    with pytest.raises(KeyError):
+        Diffusion(units="furlongs")
+
+
+def test_detect_time_range_and_green_kubo():
+    from mdproptools_amd.dynamical.conductivity import Conductivity
+
+    g = load_golden("host_logic.npz")
+    for f, expect in zip(g["dtr_flux"], g["dtr_range"]):
+        assert tuple(Conductivity.detect_time_range(f, float(g["dtr_tol"]))) == tuple(expect)
+    c = Conductivity.__new__(Conductivity)
+    c.temp, c.volume = float(g["fc_temp"]), float(g["fc_volume"])
+    np.testing.assert_allclose(c.green_kubo(g["fc_ave"]), g["fc_cond"], rtol=1e-15)
+    with pytest.raises(TypeError):
+        Conductivity.detect_time_range(np.random.default_rng(0).standard_normal(200), 1e-9)
+
+
+def test_ols_through_origin_vs_reference_table(g_small):
+    from mdproptools_amd.dynamical.diffusion import Diffusion
+
+    g = g_small
+    msd = pd.DataFrame(g["comd_msd"], columns=list(g["comd_msd_cols"]))
+    import tempfile
+
+    d = Diffusion(diff_dir=tempfile.mkdtemp())
+    table = d.calc_diff(msd, diff_names=["dme", "tfsi", "mg"], save=True)
+    np.testing.assert_allclose(table.to_numpy(), g["comd_diff"], rtol=1e-10)
+    assert list(table.columns) == ["diffusion (m2/s)", "std", "R2"]
+    dist = d.get_diff_dist(pd.DataFrame(g["comd_msd_int"], columns=list(g["comd_msd_int_cols"])), dump_freq=50000)
+    np.testing.assert_allclose(dist.to_numpy(), g["comd_diff_dist"], rtol=1e-14)
+
+
+def test_lammps_readers_round_trip(tmp_path):
+    from mdproptools_amd import io as mio
+
+    rng = np.random.default_rng(1)
+    cols = ["id", "type", "x", "y", "z"]
+    for step in (0, 10, 200, 30):
+        tbl = np.column_stack([rng.permutation(50) + 1, rng.integers(1, 4, 50), rng.random((50, 3)).round(5) * 9])
+        mio.write_dump(tmp_path / f"d.{step}.dump", step, [[0.5, 9.5]] * 3, cols, tbl)
+    dumps = list(mio.parse_lammps_dumps(str(tmp_path / "d.*.dump")))
+    assert [d.timestep for d in dumps] == [0, 10, 30, 200]  # numeric, not lexical, order
+    assert dumps[0].natoms == 50 and list(dumps[0].data.columns) == cols
+    assert dumps[0].box.to_lattice().lengths == (9.0, 9.0, 9.0)
+    steps, bounds, planes = mio.read_dump_arrays(str(tmp_path / "d.*.dump"), ["x", "y", "z"])
+    assert planes.shape == (4, 3, 50) and np.all(np.diff(steps) > 0)
+    tab = np.column_stack([np.arange(5) * 10, rng.random((5, 2)).round(6)])  # short mantissas parse exactly
+    mio.write_log(tmp_path / "log.a", tab, ["Step", "Pxy", "msd_1"])
+    (df,) = mio.parse_lammps_log(str(tmp_path / "log.a"))
+    np.testing.assert_array_equal(df.to_numpy(), tab)

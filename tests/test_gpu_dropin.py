@@ -1,0 +1,220 @@
+"""
+GPU end-to-end: the drop-in functions/classes (same names and arguments as the reference) run on
+text dumps/logs rebuilt from the golden inputs and are compared with the DataFrames/arrays the real
+reference produced for those inputs (oracle/make_golden.py).
+"""
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+MASS = [16.000, 12.010, 1.008, 14.010, 32.060, 16.000, 12.010, 19.000, 24.305]
+
+
+def _write(tmp, g, columns=None):
+    from mdproptools_amd import io as mio
+
+    cols = list(g["columns"]) if columns is None else columns
+    for s, b, t in zip(g["steps"], g["bounds"], g["frames"]):
+        mio.write_dump(os.path.join(tmp, "dump.nvt.%d.dump" % s), s, b, cols, t)
+    return os.path.join(tmp, "dump.nvt.*.dump")
+
+
+@pytest.fixture(scope="module")
+def c1_dir(tmp_path_factory):
+    g = load_golden("c1_rdf.npz")
+    tmp = str(tmp_path_factory.mktemp("c1"))
+    return g, _write(tmp, g), tmp
+
+
+def test_calc_atomic_rdf_and_cn(c1_dir):
+    from mdproptools_amd.structural.rdf_cn import calc_atomic_cn, calc_atomic_rdf
+
+    g, pat, tmp = c1_dir
+    out = os.path.join(tmp, "rdf.csv")
+    df = calc_atomic_rdf(20, 0.05, 9, MASS, g["rdf_def_rel"].tolist(), pat, path_or_buff=out)
+    assert list(df.columns) == list(g["rdf_def_df_columns"])
+    np.testing.assert_array_equal(df.to_numpy(), g["rdf_def_df"])  # bit-identical g(r)
+    np.testing.assert_allclose(pd.read_csv(out).to_numpy(), g["rdf_def_df"], rtol=1e-15)
+    df = calc_atomic_rdf(20, 0.05, 9, MASS, g["rdf_alt_rel"].tolist(), pat, num_mols=g["num_mols"].tolist(),
+                         num_atoms_per_mol=g["num_atoms_per_mol"].tolist(), save_mode=False)
+    np.testing.assert_array_equal(df.to_numpy(), g["rdf_alt_df"])
+    assert list(df.columns)[2:] == ["g_32-17", "g_32-32"]
+    cn = calc_atomic_cn(g["cn_def_cut"].tolist(), 0.05, 9, MASS, g["cn_def_rel"].tolist(), pat, save_mode=False)
+    np.testing.assert_array_equal(cn.to_numpy(), g["cn_def_df"])
+    assert list(cn.columns) == ["cn_9-1", "cn_9-4", "cn_9-6", "cn_9-9"]
+    cn = calc_atomic_cn(g["cn_alt_cut"].tolist(), 0.05, 9, MASS, g["rdf_alt_rel"].tolist(), pat,
+                        num_mols=g["num_mols"].tolist(), num_atoms_per_mol=g["num_atoms_per_mol"].tolist(),
+                        save_mode=False)
+    np.testing.assert_array_equal(cn.to_numpy(), g["cn_alt_df"])
+
+
+def test_calc_molecular_rdf_and_cn(c1_dir):
+    from mdproptools_amd.structural.rdf_cn import calc_molecular_cn, calc_molecular_rdf
+
+    g, pat, tmp = c1_dir
+    nm, na = g["num_mols"].tolist(), g["num_atoms_per_mol"].tolist()
+    df = calc_molecular_rdf(20, 0.05, 9, MASS, g["mol_rel"].tolist(), pat, nm, na, save_mode=False)
+    # COM sums run in a different order on the GPU (rtol 1e-13 on the sites); the histograms of these
+    # frames are nevertheless identical, so g(r) is too
+    np.testing.assert_allclose(df.to_numpy(), g["mol_rdf_df"], rtol=1e-12, atol=0)
+    assert list(df.columns) == ["r ($\\AA$)", "g_9-1", "g_9-2", "g_4-3"]
+    cn = calc_molecular_cn(g["mol_cn_cut"].tolist(), 0.05, 9, MASS, g["mol_rel"].tolist(), pat, nm, na,
+                           save_mode=False)
+    np.testing.assert_allclose(cn.to_numpy(), g["mol_cn_df"], rtol=1e-12, atol=0)
+
+
+def test_rdf_errors(c1_dir):
+    from mdproptools_amd.structural.rdf_cn import calc_atomic_rdf
+
+    g, pat, tmp = c1_dir
+    with pytest.raises(ValueError):
+        calc_atomic_rdf(20, 0.05, 8, MASS[:8], [[9], [1]], pat, save_mode=False)  # wrong num_types
+
+
+@pytest.fixture(scope="module")
+def small_dir(tmp_path_factory):
+    g = load_golden("small_md.npz")
+    tmp = str(tmp_path_factory.mktemp("small"))
+    _write(tmp, g)
+    return g, tmp
+
+
+def _frame_equal(df, values, columns, rtol):
+    assert list(df.columns) == list(columns), (list(df.columns), list(columns))
+    assert df.shape == values.shape
+    np.testing.assert_allclose(df.to_numpy(dtype=np.float64), values, rtol=rtol, atol=0)
+
+
+def test_diffusion_allatom(small_dir):
+    from mdproptools_amd.dynamical.diffusion import Diffusion
+
+    g, tmp = small_dir
+    d = Diffusion(timestep=1, units="real", outputs_dir=tmp, diff_dir=tmp)
+    msd, msd_all, msd_int = d.get_msd_from_dump("dump.nvt.*.dump", msd_type="allatom", avg_interval=True,
+                                                tao_coeff=4)
+    _frame_equal(msd, g["aa_msd"], g["aa_msd_cols"], 1e-10)
+    _frame_equal(msd_all, g["aa_msd_all"], g["aa_msd_all_cols"], 1e-12)
+    _frame_equal(msd_int, g["aa_msd_int"], g["aa_msd_int_cols"], 1e-10)
+    two = d.get_msd_from_dump("dump.nvt.*.dump", msd_type="allatom")
+    assert len(two) == 2
+    with pytest.raises(ValueError):
+        d.get_msd_from_dump("dump.nvt.*.dump", msd_type="nonsense")
+
+
+@pytest.mark.parametrize("tag,drift", [("com", False), ("comd", True)])
+def test_diffusion_com(small_dir, tag, drift):
+    from mdproptools_amd.dynamical.diffusion import Diffusion
+
+    g, tmp = small_dir
+    d = Diffusion(timestep=1, units="real", outputs_dir=tmp, diff_dir=tmp)
+    msd, msd_all, msd_int = d.get_msd_from_dump(
+        "dump.nvt.*.dump", msd_type="com", num_mols=g["num_mols"].tolist(),
+        num_atoms_per_mol=g["num_atoms_per_mol"].tolist(), mass=MASS, com_drift=drift, avg_interval=True,
+        tao_coeff=4)
+    _frame_equal(msd, g[tag + "_msd"], g[tag + "_msd_cols"], 1e-9)
+    _frame_equal(msd_all, g[tag + "_msd_all"], g[tag + "_msd_all_cols"], 1e-9)
+    _frame_equal(msd_int, g[tag + "_msd_int"], g[tag + "_msd_int_cols"], 1e-9)
+    if drift:
+        table = d.calc_diff(msd, diff_names=["dme", "tfsi", "mg"])
+        np.testing.assert_allclose(table.to_numpy(), g["comd_diff"], rtol=1e-9)
+        assert os.path.exists(os.path.join(tmp, "diffusion.csv"))
+
+
+def test_calc_com_dataframe(small_dir):
+    from mdproptools_amd import io as mio
+    from mdproptools_amd.common.com_mols import calc_com
+
+    g, tmp = small_dir
+    (dump,) = list(mio.parse_lammps_dumps(os.path.join(tmp, "dump.nvt.0.dump")))
+    dump.data = dump.data.sort_values(by=["id"]).reset_index()
+    nm, na = g["num_mols"].tolist(), g["num_atoms_per_mol"].tolist()
+    com = calc_com(dump, nm, na, MASS, atom_attributes=["xu", "yu", "zu"]).reset_index()
+    _frame_equal(com, g["calc_com_xu"], g["calc_com_xu_cols"], 1e-13)
+    comv = calc_com(dump, nm, na, None, atom_attributes=["vx", "vy", "vz"], calc_charge=True).reset_index()
+    assert list(comv.columns) == list(g["calc_com_v_cols"])
+    np.testing.assert_allclose(comv.to_numpy(dtype=np.float64), g["calc_com_v"], rtol=1e-12, atol=1e-12)
+
+
+def test_conductivity_chain(small_dir):
+    from mdproptools_amd.dynamical.conductivity import Conductivity
+
+    g, tmp = small_dir
+    c = Conductivity("dump.nvt.*.dump", g["num_mols"].tolist(), g["num_atoms_per_mol"].tolist(),
+                     float(g["cond_volume"]), mass=MASS, temp=298.15, timestep=1, units="real", working_dir=tmp)
+    j = c.get_charge_flux()
+    np.testing.assert_allclose(j, g["cond_j"], rtol=1e-9, atol=1e-25)
+    np.testing.assert_allclose(c.time, g["cond_time"], rtol=1e-15)
+    tot = c.correlate_charge_flux(g["cond_j"])
+    np.testing.assert_allclose(tot, g["cond_tot_flux"], rtol=0, atol=1e-10 * abs(g["cond_tot_flux"]).max())
+    integ = c.integrate_charge_flux_correlation(g["cond_tot_flux"])
+    np.testing.assert_allclose(integ, g["cond_integral"], rtol=1e-9, atol=1e-12 * abs(g["cond_integral"]).max())
+    np.testing.assert_allclose(c.green_kubo(g["cond_integral"][:, -1]), g["cond_gk"], rtol=1e-14)
+    a, b = g["cond_j"][0, 1], g["cond_j"][0, 2]
+    ref = np.array([np.dot(a[k:], b[: len(b) - k]) / (len(a) - k) for k in range(len(a))])
+    np.testing.assert_allclose(Conductivity.correlate(a, b), ref, rtol=0, atol=1e-10 * abs(ref).max())
+
+
+def test_conductivity_fit_curve():
+    from mdproptools_amd.dynamical.conductivity import Conductivity
+
+    g = load_golden("host_logic.npz")
+    c = Conductivity.__new__(Conductivity)
+    c.num_mols = [1]
+    c.time = list(np.arange(g["dtr_flux"].shape[1]) * 2e-15)
+    c.temp, c.volume = float(g["fc_temp"]), float(g["fc_volume"])
+    integ = c.integrate_charge_flux_correlation(g["dtr_flux"])
+    np.testing.assert_allclose(integ, g["fc_integral"], rtol=1e-9, atol=1e-12 * abs(g["fc_integral"]).max())
+    ave, tr = c.fit_curve(g["dtr_flux"], integ, float(g["dtr_tol"]))
+    np.testing.assert_allclose(ave, g["fc_ave"], rtol=1e-9)
+    np.testing.assert_allclose(np.array([list(r) for r in tr]), g["fc_time_range"], rtol=1e-15)
+    np.testing.assert_allclose(c.green_kubo(ave), g["fc_cond"], rtol=1e-9)
+
+
+def test_viscosity_3d_and_replicates(tmp_path):
+    from mdproptools_amd import io as mio
+    from mdproptools_amd.dynamical.viscosity import Viscosity
+
+    g = load_golden("acf.npz")
+    p = g["pressure"]
+    v = Viscosity("log.*", 0, float(g["visc_volume"]), temp=float(g["visc_temp"]), timestep=int(g["visc_timestep"]),
+                  acf_method="wkt", units="real")
+    log_df = pd.DataFrame({"Step": g["visc_step"], "Pxy": p[0], "Pxz": p[1], "Pyz": p[2]})
+    avg, data, acf = v._calc_3d_visc(log_df)
+    scale = abs(g["visc_avg"]).max()
+    np.testing.assert_allclose(acf, g["visc_acf"], rtol=0, atol=1e-10 * g["visc_acf"].max())
+    np.testing.assert_allclose(data, g["visc_data"], rtol=1e-9, atol=1e-10 * scale)
+    np.testing.assert_allclose(avg, g["visc_avg"], rtol=1e-9, atol=1e-10 * scale)
+    v.acf_method = "brute_force"
+    avg_b, _, _ = v._calc_3d_visc(log_df)
+    np.testing.assert_allclose(avg_b, g["visc_avg_brute"], rtol=1e-9, atol=1e-10 * scale)
+    for k in range(3):
+        np.testing.assert_allclose(Viscosity.autocorrelate(p[k], "wkt"), g["acf_wkt"][k], rtol=0,
+                                   atol=1e-10 * g["acf_wkt"][k][0])
+    with pytest.raises(ValueError):
+        Viscosity.autocorrelate(p[0], "fourier")
+    with pytest.raises(KeyError):
+        Viscosity("log.*", 0, 1.0, units="furlongs")._calc_3d_visc(log_df)
+
+    h = load_golden("host_logic.npz")
+    for r in range(h["log_press"].shape[0]):
+        tbl = np.column_stack([h["log_step"], h["log_press"][r].T])
+        mio.write_log(tmp_path / ("log.rep%d" % r), tbl, ["Step", "Pxy", "Pxz", "Pyz"])
+    v = Viscosity("log.rep*", int(h["visc_cutoff"]), float(h["visc_volume"]), temp=float(h["visc_temp"]),
+                  timestep=1, acf_method="wkt", units="real", working_dir=str(tmp_path))
+    visc_avg, visc_data, acf_data, tm = v.calc_avg_visc(output_all_data=True)
+    import glob
+
+    order = [int(os.path.basename(f)[7:]) for f in glob.glob(str(tmp_path / "log.rep*"))]
+    expect = {int(o): row for o, row in zip(h["visc_rep_order"], h["visc_avg"])}
+    for o, row in zip(order, visc_avg):
+        np.testing.assert_allclose(row, expect[o], rtol=1e-8, atol=1e-10 * abs(expect[o]).max())
+    np.testing.assert_array_equal(tm, h["visc_time"])
+    fit = v.fit_avg_visc([expect[o] for o in sorted(expect)], initial_guess=[1e-8, 0.5, 50.0, 500.0])
+    ref_fit = float(h["visc_fit"])
+    assert np.isfinite(ref_fit) and abs(fit - ref_fit) <= 1e-6 * abs(ref_fit)
