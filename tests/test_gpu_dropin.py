@@ -40,7 +40,7 @@ def test_calc_atomic_rdf_and_cn(c1_dir):
     df = calc_atomic_rdf(20, 0.05, 9, MASS, g["rdf_def_rel"].tolist(), pat, path_or_buff=out)
     assert list(df.columns) == list(g["rdf_def_df_columns"])
     np.testing.assert_array_equal(df.to_numpy(), g["rdf_def_df"])  # bit-identical g(r)
-    np.testing.assert_allclose(pd.read_csv(out).to_numpy(), g["rdf_def_df"], rtol=1e-15)
+    np.testing.assert_allclose(pd.read_csv(out).to_numpy(), g["rdf_def_df"], rtol=1e-13)  # csv text round trip
     df = calc_atomic_rdf(20, 0.05, 9, MASS, g["rdf_alt_rel"].tolist(), pat, num_mols=g["num_mols"].tolist(),
                          num_atoms_per_mol=g["num_atoms_per_mol"].tolist(), save_mode=False)
     np.testing.assert_array_equal(df.to_numpy(), g["rdf_alt_df"])
