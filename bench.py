@@ -129,14 +129,15 @@ def main():
     xyz = torch.from_numpy(synth.rdf_frames(n, frame_ids, L, cfg["seed_offset"])).to(device)
     pairs_per_step = F * n * (n - 1) // 2
 
+    from mdproptools_amd import dist as D
+
+    def local_pass(x, t, b, rl, rc, dd, nbins):
+        return B.rdf_loop(x, t, b, rl, rc, dd, nbins, per_frame=False, ctx=ctx)
+
     def step():
-        full, part, ov = B.rdf_loop(xyz, types, box, rel, cfg["r_cut"], cfg["bin_size"], nb,
-                                    per_frame=False, ctx=ctx)
-        if world > 1:
-            packed = torch.from_numpy(np.concatenate([full[None], part]).astype(np.int64)).to(device)
-            dist.all_reduce(packed, op=dist.ReduceOp.SUM)
-            packed = packed.cpu().numpy().astype(np.uint64)
-            full, part = packed[0], packed[1:]
+        # N > 1: frame shards per rank, one RCCL all-reduce of the uint64 histograms (mdproptools_amd/dist.py)
+        full, part, ov = D.rdf_sharded(xyz, types, box, rel, cfg["r_cut"], cfg["bin_size"], nb,
+                                       compute=local_pass)
         return full, part
 
     def fence():

@@ -1,0 +1,234 @@
+"""
+Multi-GPU layer: one process per GPU, frames sharded across ranks, `torch.distributed` collectives
+("nccl" is RCCL over xGMI on ROCm; "gloo" on CPU for tests).
+
+The reference has no distributed code at all (its only concurrency is a process pool over frames,
+/root/reference/mdproptools/dynamical/conductivity.py:190-194). Frames are independent for every
+kernel on the path (rdf_cn.py:459; diffusion.py:174; _conductivity.py:7), so:
+
+  RDF / CN     contiguous frame blocks per rank, no data-path exchange; the frame-summed uint64
+               histograms ((1+R) x nbins words, tens of KB) are all-reduced once — exact integers, so
+               the result does not depend on the number of ranks. With a varying box the per-frame
+               integer histograms are all-gathered instead and normalised in frame order.
+  MSD          contiguous frame blocks per rank; the origin frame (24*E bytes) is broadcast from its
+               owner, every rank reduces its own frame pairs, the [F_local][G][4] sums are all-gathered.
+  charge flux  as RDF: per-frame [3][T] vectors all-gathered.
+  FFT ACF / running integrals: a single transform does not shard — replicas only.
+
+`compute` arguments exist so that the sharding/collective logic can be exercised on CPU with the
+oracle as the stand-in (tests/test_dist_gloo.py); the product default is the GPU backend.
+"""
+
+import os
+
+import numpy as np
+
+
+def _dist():
+    import torch.distributed as dist
+
+    return dist
+
+
+def is_distributed():
+    try:
+        d = _dist()
+        return d.is_available() and d.is_initialized()
+    except Exception:
+        return False
+
+
+def rank_world():
+    if is_distributed():
+        d = _dist()
+        return d.get_rank(), d.get_world_size()
+    return 0, 1
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torch.distributed.run sets them)."""
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 or dist.is_initialized():
+        return
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    kwargs = {}
+    if backend == "nccl":
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        kwargs["device_id"] = torch.device("cuda", local)
+    dist.init_process_group(backend, rank=int(os.environ["RANK"]), world_size=world, **kwargs)
+
+
+def frame_shard(n_frames, rank=None, world=None):
+    """Contiguous block [lo, hi) of frames owned by `rank`; sizes differ by at most one."""
+    if rank is None or world is None:
+        rank, world = rank_world()
+    base, extra = divmod(int(n_frames), int(world))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def _device_for_collectives():
+    import torch
+
+    d = _dist()
+    if d.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def allreduce_u64(arrays):
+    """Sum uint64 arrays over all ranks (packed into one int64 message). Exact while totals < 2^63."""
+    if not is_distributed():
+        return [np.array(a, dtype=np.uint64) for a in arrays]
+    import torch
+
+    d = _dist()
+    flat = np.concatenate([np.asarray(a, dtype=np.uint64).reshape(-1) for a in arrays]).view(np.int64)
+    t = torch.from_numpy(flat.copy()).to(_device_for_collectives())
+    d.all_reduce(t, op=d.ReduceOp.SUM)
+    out = t.cpu().numpy().view(np.uint64)
+    res, pos = [], 0
+    for a in arrays:
+        n = int(np.prod(np.shape(a)))
+        res.append(out[pos:pos + n].reshape(np.shape(a)).copy())
+        pos += n
+    return res
+
+
+def allgather_rows(local, n_total_rows):
+    """
+    Concatenate per-rank blocks of rows (frame shards, in rank order) into the full array on every rank.
+    `local` [rows_local, ...]; blocks may differ in length by one (see frame_shard).
+    """
+    local = np.ascontiguousarray(local)
+    if not is_distributed():
+        return local
+    import torch
+
+    d = _dist()
+    rank, world = rank_world()
+    row_shape = local.shape[1:]
+    row_elems = int(np.prod(row_shape)) if row_shape else 1
+    max_rows = -(-int(n_total_rows) // world)
+    pad = np.zeros((max_rows, row_elems), dtype=local.dtype)
+    pad[: local.shape[0]] = local.reshape(local.shape[0], row_elems)
+    as_i64 = local.dtype == np.uint64
+    send = torch.from_numpy(pad.view(np.int64) if as_i64 else pad).to(_device_for_collectives())
+    recv = [torch.empty_like(send) for _ in range(world)]
+    d.all_gather(recv, send)
+    blocks = []
+    for r in range(world):
+        lo, hi = frame_shard(n_total_rows, r, world)
+        blk = recv[r].cpu().numpy()[: hi - lo]
+        blocks.append(blk.view(np.uint64) if as_i64 else blk)
+    return np.concatenate(blocks).reshape((int(n_total_rows),) + row_shape)
+
+
+def broadcast_array(arr, src, shape, dtype=np.float64):
+    """Broadcast a float64 array from rank `src` (others pass arr=None)."""
+    if not is_distributed():
+        return np.asarray(arr, dtype=dtype)
+    import torch
+
+    d = _dist()
+    rank, _ = rank_world()
+    buf = np.ascontiguousarray(arr, dtype=dtype) if rank == src else np.zeros(shape, dtype=dtype)
+    t = torch.from_numpy(buf).to(_device_for_collectives())
+    d.broadcast(t, src=src)
+    return t.cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------
+# sharded hot-path calls
+# ------------------------------------------------------------------------------------------------
+
+
+def rdf_sharded(xyz_local, types, box_local, relation_matrix, r_cut, ddr, nbins, compute=None):
+    """
+    `_rdf_loop` over a frame-sharded trajectory, constant box: every rank passes ITS frames
+    [F_local,3,N]; returns the frame-summed (rdf_full [nbins], rdf_part [R,nbins], overflow) of the
+    whole trajectory on every rank. One all-reduce of (1+R)*nbins+1 uint64 words.
+    """
+    if compute is None:
+        from . import backend
+
+        def compute(x, t, b, rel, rc, dd, nb):
+            return backend.rdf_loop(x, t, b, rel, rc, dd, nb, per_frame=False)
+
+    full, part, ov = compute(xyz_local, types, box_local, relation_matrix, r_cut, ddr, nbins)
+    full, part, ovv = allreduce_u64([full, part, np.array([ov], dtype=np.uint64)])
+    return full, part, int(ovv[0])
+
+
+def rdf_sharded_per_frame(xyz_local, types, box_local, relation_matrix, r_cut, ddr, nbins, n_frames_total,
+                          compute=None):
+    """
+    Varying box (NPT): per-frame integer histograms are all-gathered in frame order so that the host can
+    normalise every frame with its own volume exactly as the reference does (rdf_cn.py:502-521).
+    Returns (rdf_full [F,nbins], rdf_part [F,R,nbins], overflow).
+    """
+    if compute is None:
+        from . import backend
+
+        def compute(x, t, b, rel, rc, dd, nb):
+            return backend.rdf_loop(x, t, b, rel, rc, dd, nb, per_frame=True)
+
+    full, part, ov = compute(xyz_local, types, box_local, relation_matrix, r_cut, ddr, nbins)
+    full = allgather_rows(np.asarray(full, dtype=np.uint64), n_frames_total)
+    part = allgather_rows(np.asarray(part, dtype=np.uint64), n_frames_total)
+    (ovv,) = allreduce_u64([np.array([ov], dtype=np.uint64)])
+    return full, part, int(ovv[0])
+
+
+def cn_sharded(xyz_local, types, box_local, relation_matrix, r_cut_list, compute=None):
+    """`_cn_loop` counts summed over all frames of all ranks (one all-reduce of R words)."""
+    if compute is None:
+        from . import backend
+
+        def compute(x, t, b, rel, cuts):
+            return backend.cn_loop(x, t, b, rel, cuts, per_frame=False)
+
+    (cn,) = allreduce_u64([compute(xyz_local, types, box_local, relation_matrix, r_cut_list)])
+    return cn
+
+
+def msd_single_origin_sharded(r_local, n_frames_total, group_off, scale=1.0, origin_frame=0, compute=None):
+    """
+    Single-origin MSD sums (diffusion.py:212-218) over a frame-sharded trajectory r_local [F_local,3,E]:
+    the origin frame is broadcast from its owner, every rank reduces its own (origin, t) pairs, the
+    [F_local,G,4] sums are all-gathered into [F,G,4] (frame order).
+    """
+    if compute is None:
+        from . import backend
+
+        def compute(r, pairs, goff, sc):
+            return backend.msd_pairs(r, pairs, goff, scale=sc)
+
+    rank, world = rank_world()
+    lo, hi = frame_shard(n_frames_total, rank, world)
+    owner = next(r for r in range(world) if frame_shard(n_frames_total, r, world)[0] <= origin_frame
+                 < frame_shard(n_frames_total, r, world)[1])
+    E = r_local.shape[2]
+    r0 = broadcast_array(r_local[origin_frame - lo] if rank == owner else None, owner, (3, E))
+    stacked = np.concatenate([r0[None], np.asarray(r_local)]) if hi > lo else r0[None]
+    pairs = np.column_stack([np.zeros(hi - lo, dtype=np.int32), 1 + np.arange(hi - lo, dtype=np.int32)])
+    sums = compute(stacked, pairs, group_off, scale) if hi > lo else np.zeros((0, len(group_off) - 1, 4))
+    return allgather_rows(sums, n_frames_total)
+
+
+def charge_flux_sharded(vel_local, n_frames_total, atom_mass, atom_q, seg_off, seg_type, n_types, vel_conv,
+                        charge_conv, compute=None):
+    """Per-frame charge flux of a frame-sharded trajectory, gathered to j [3, T, F] on every rank."""
+    if compute is None:
+        from . import backend
+
+        compute = backend.charge_flux
+    j_local = compute(vel_local, atom_mass, atom_q, seg_off, seg_type, n_types, vel_conv, charge_conv)
+    rows = np.ascontiguousarray(np.moveaxis(j_local, 2, 0))  # [F_local, 3, T]
+    return np.moveaxis(allgather_rows(rows, n_frames_total), 0, 2)
