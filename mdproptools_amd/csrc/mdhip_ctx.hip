@@ -1,5 +1,6 @@
 // mdhip_ctx.hip — lifecycle, workspace, options and the host-side bin-edge table.
 #include <cmath>
+#include <cstdlib>
 
 #include "ctx.h"
 
@@ -87,6 +88,7 @@ int mdhip_create(mdhip_ctx **out, int device)
         return mdhip_fail(nullptr, MDHIP_EHIP, "mdhip_create: stream/event creation failed");
     }
     ctx->stream = ctx->own_stream;
+    if (const char *v = getenv("MDHIP_RDF_VARIANT")) ctx->opt_rdf_variant = atoi(v);  // A/B knob
     *out = ctx;
     return MDHIP_OK;
 }

@@ -112,6 +112,64 @@ __device__ __forceinline__ void sweep_tile(const JAtom *__restrict__ tile, doubl
     }
 }
 
+// Variants 1/2: table-free binning for almost every pair.
+// g = sqrtf((float)rsq) * (float)(1/ddr) approximates G = sqrt(rsq)/ddr with relative error below
+// 2^-25 (cvt, halved by the sqrt) + 2^-23 (v_sqrt_f32, 1 ulp) + 2^-24 (rounded 1/ddr) + 2^-24 (mul)
+// < 2.7e-7, i.e. |g - G| < nbins * 2.7e-7. If g is farther than `near` = nbins*1e-6 + 1e-5 (>3.5x that
+// bound) from the nearest integer, floor(g) IS the reference's bin: the exact edge of bin k (the table
+// made by mdhip_bin_edges) lies within 1e-12 of k in G-space. Only the ~0.1 % of pairs that fall
+// inside the guard band take the exact path — a lookup in the LDS edge table, as in variant 0.
+// U pairs are processed per step with the tile reads and the exact rsq chains up front.
+// The class of a pair comes from a per-lane packed row (8 classes in 64 bits; variant 1) or from the
+// LDS table (variant 2, more than 8 j-types).
+template <bool DIAG, bool PACKED>
+__device__ __forceinline__ void sweep_tile_v2(const JAtom *__restrict__ tile, double xi, double yi,
+                                              double zi, double Lx, double Ly, double Lz, double rc2,
+                                              const BinCtx &b, unsigned long long row64, float near,
+                                              int lane_id)
+{
+    constexpr int U = 8;
+    for (int j0 = 0; j0 < TILE; j0 += U) {
+        double rsq[U];
+        int tj[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const JAtom pj = tile[j0 + u];
+            const double ax = wrap_abs(xi - pj.x, Lx);
+            const double ay = wrap_abs(yi - pj.y, Ly);
+            const double az = wrap_abs(zi - pj.z, Lz);
+            rsq[u] = (ax * ax + ay * ay) + az * az;
+            tj[u] = pj.t;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            bool in = rsq[u] < rc2;
+            if (DIAG) in = in && (j0 + u > lane_id);
+            if (in) {
+                const float g = __builtin_amdgcn_sqrtf((float)rsq[u]) * b.gscale;
+                const float fl = __builtin_floorf(g);
+                int k = (int)fl;
+                const float fr = g - fl;  // exact (Sterbenz-type: same binade or below)
+                if (__builtin_fabsf(fr - 0.5f) > 0.5f - near) {  // guard band around an integer: exact path
+                    k = k > b.nbins ? b.nbins : k;
+                    while (rsq[u] < b.edges[k]) --k;
+                    while (rsq[u] >= b.edges[k + 1]) ++k;
+                }
+                unsigned c;
+                if (PACKED)
+                    c = (unsigned)(row64 >> (8 * tj[u])) & 0xFFu;
+                else
+                    c = b.cls_row[tj[u]];
+                if (k < b.nbins) {
+                    if (c != 0xFFu) atomicAdd(&b.hist[c * b.nbins + k], 1u);
+                } else {
+                    atomicAdd(b.ovf, 1u);
+                }
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ JAtom load_atom(const double *__restrict__ xyz, const int *__restrict__ t,
                                            long long n, long long g, double pad)
 {
@@ -135,7 +193,7 @@ __device__ __host__ __forceinline__ int tri_shifts(int nT, int I)
     return (nT & 1) ? (nT + 1) / 2 : nT / 2 + (I < nT / 2 ? 1 : 0);
 }
 
-template <bool TRI>
+template <bool TRI, int VAR>
 __global__ __launch_bounds__(TILE) void pair_hist_kernel(const PairArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -197,6 +255,14 @@ __global__ __launch_bounds__(TILE) void pair_hist_kernel(const PairArgs a)
     b.cls_row = s_cls + me.t * a.n_tj;
     b.gscale = a.gscale;
     b.nbins = a.nbins;
+    // this lane's class row packed into 64 bits (used when n_tj <= 8)
+    const float near = (float)a.nbins * 1.0e-6f + 1.0e-5f;
+    unsigned long long row64 = ~0ull;
+    if (VAR == 1) {
+        row64 = 0ull;
+        for (int q = 0; q < a.n_tj && q < 8; ++q)
+            row64 |= (unsigned long long)a.cls[me.t * a.n_tj + q] << (8 * q);
+    }
 
     auto tile_of = [&](int t) -> int {
         if (TRI) {
@@ -214,10 +280,24 @@ __global__ __launch_bounds__(TILE) void pair_hist_kernel(const PairArgs a)
         const int buf = (t - t_begin) & 1;
         if (t + 1 < t_end)
             nxt = load_atom(xj_f, tj_f, a.nj, (long long)tile_of(t + 1) * TILE + tid, PAD_J);
-        if (TRI && t == 0)
-            sweep_tile<true>(s_tile + buf * TILE, me.x, me.y, me.z, Lx, Ly, Lz, a.rc2, b, tid);
-        else
-            sweep_tile<false>(s_tile + buf * TILE, me.x, me.y, me.z, Lx, Ly, Lz, a.rc2, b, tid);
+        const JAtom *cur = s_tile + buf * TILE;
+        const bool diag = TRI && t == 0;
+        if (VAR == 0) {
+            if (diag)
+                sweep_tile<true>(cur, me.x, me.y, me.z, Lx, Ly, Lz, a.rc2, b, tid);
+            else
+                sweep_tile<false>(cur, me.x, me.y, me.z, Lx, Ly, Lz, a.rc2, b, tid);
+        } else if (VAR == 1) {
+            if (diag)
+                sweep_tile_v2<true, true>(cur, me.x, me.y, me.z, Lx, Ly, Lz, a.rc2, b, row64, near, tid);
+            else
+                sweep_tile_v2<false, true>(cur, me.x, me.y, me.z, Lx, Ly, Lz, a.rc2, b, row64, near, tid);
+        } else {
+            if (diag)
+                sweep_tile_v2<true, false>(cur, me.x, me.y, me.z, Lx, Ly, Lz, a.rc2, b, row64, near, tid);
+            else
+                sweep_tile_v2<false, false>(cur, me.x, me.y, me.z, Lx, Ly, Lz, a.rc2, b, row64, near, tid);
+        }
         if (t + 1 < t_end) s_tile[(buf ^ 1) * TILE + tid] = nxt;
         __syncthreads();
     }
@@ -371,7 +451,13 @@ int pair_hist_run(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64_t> &H
         a.slots = slots;
 
         const size_t lds = lds_bytes(p.nbins, nc, p.n_ti, p.n_tj);
-        auto kern = p.tri ? pair_hist_kernel<true> : pair_hist_kernel<false>;
+        // kernel variant: 0 = reference-shaped loops (always used for CN edge tables, gscale == 0);
+        // 1/2 = straight-line predicated binning with the class row in registers / in LDS
+        int var = 0;
+        if (p.gscale > 0.f && p.nbins <= 100000 && ctx->opt_rdf_variant != 0) var = p.n_tj <= 8 ? 1 : 2;
+        void (*kern)(const PairArgs) =
+            p.tri ? (var == 0 ? pair_hist_kernel<true, 0> : var == 1 ? pair_hist_kernel<true, 1> : pair_hist_kernel<true, 2>)
+                  : (var == 0 ? pair_hist_kernel<false, 0> : var == 1 ? pair_hist_kernel<false, 1> : pair_hist_kernel<false, 2>);
         if (lds > 65536)
             MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

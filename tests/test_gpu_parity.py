@@ -117,10 +117,11 @@ def test_rdf_geometry_independence(B):
     rel = np.array([(a, b) for a in range(1, 5) for b in range(a, 5)])
     box = np.tile(L, (F, 1))
     ref = None
-    for jsplit, slots in [(0, 16), (1, 1), (2, 3), (3, 8)]:
+    for jsplit, slots, variant in [(0, 16, 0), (1, 1, 1), (2, 3, 0), (3, 8, 1), (0, 16, 1)]:
         ctx = Context(0)
         ctx.set_option("rdf_jsplit", jsplit)
         ctx.set_option("rdf_slots", slots)
+        ctx.set_option("rdf_variant", variant)
         for per_frame in (True, False):
             full, part, ov = B.rdf_loop(xyz, ty, box, rel, 12.0, 0.05, 240, per_frame=per_frame, ctx=ctx)
             if per_frame:
