@@ -112,64 +112,6 @@ __device__ __forceinline__ void sweep_tile(const JAtom *__restrict__ tile, doubl
     }
 }
 
-// Variants 1/2: table-free binning for almost every pair.
-// g = sqrtf((float)rsq) * (float)(1/ddr) approximates G = sqrt(rsq)/ddr with relative error below
-// 2^-25 (cvt, halved by the sqrt) + 2^-23 (v_sqrt_f32, 1 ulp) + 2^-24 (rounded 1/ddr) + 2^-24 (mul)
-// < 2.7e-7, i.e. |g - G| < nbins * 2.7e-7. If g is farther than `near` = nbins*1e-6 + 1e-5 (>3.5x that
-// bound) from the nearest integer, floor(g) IS the reference's bin: the exact edge of bin k (the table
-// made by mdhip_bin_edges) lies within 1e-12 of k in G-space. Only the ~0.1 % of pairs that fall
-// inside the guard band take the exact path — a lookup in the LDS edge table, as in variant 0.
-// U pairs are processed per step with the tile reads and the exact rsq chains up front.
-// The class of a pair comes from a per-lane packed row (8 classes in 64 bits; variant 1) or from the
-// LDS table (variant 2, more than 8 j-types).
-template <bool DIAG, bool PACKED>
-__device__ __forceinline__ void sweep_tile_v2(const JAtom *__restrict__ tile, double xi, double yi,
-                                              double zi, double Lx, double Ly, double Lz, double rc2,
-                                              const BinCtx &b, unsigned long long row64, float near,
-                                              int lane_id)
-{
-    constexpr int U = 8;
-    for (int j0 = 0; j0 < TILE; j0 += U) {
-        double rsq[U];
-        int tj[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const JAtom pj = tile[j0 + u];
-            const double ax = wrap_abs(xi - pj.x, Lx);
-            const double ay = wrap_abs(yi - pj.y, Ly);
-            const double az = wrap_abs(zi - pj.z, Lz);
-            rsq[u] = (ax * ax + ay * ay) + az * az;
-            tj[u] = pj.t;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            bool in = rsq[u] < rc2;
-            if (DIAG) in = in && (j0 + u > lane_id);
-            if (in) {
-                const float g = __builtin_amdgcn_sqrtf((float)rsq[u]) * b.gscale;
-                const float fl = __builtin_floorf(g);
-                int k = (int)fl;
-                const float fr = g - fl;  // exact (Sterbenz-type: same binade or below)
-                if (__builtin_fabsf(fr - 0.5f) > 0.5f - near) {  // guard band around an integer: exact path
-                    k = k > b.nbins ? b.nbins : k;
-                    while (rsq[u] < b.edges[k]) --k;
-                    while (rsq[u] >= b.edges[k + 1]) ++k;
-                }
-                unsigned c;
-                if (PACKED)
-                    c = (unsigned)(row64 >> (8 * tj[u])) & 0xFFu;
-                else
-                    c = b.cls_row[tj[u]];
-                if (k < b.nbins) {
-                    if (c != 0xFFu) atomicAdd(&b.hist[c * b.nbins + k], 1u);
-                } else {
-                    atomicAdd(b.ovf, 1u);
-                }
-            }
-        }
-    }
-}
-
 __device__ __forceinline__ JAtom load_atom(const double *__restrict__ xyz, const int *__restrict__ t,
                                            long long n, long long g, double pad)
 {
@@ -193,7 +135,7 @@ __device__ __host__ __forceinline__ int tri_shifts(int nT, int I)
     return (nT & 1) ? (nT + 1) / 2 : nT / 2 + (I < nT / 2 ? 1 : 0);
 }
 
-template <bool TRI, int VAR>
+template <bool TRI>
 __global__ __launch_bounds__(TILE) void pair_hist_kernel(const PairArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -255,15 +197,6 @@ __global__ __launch_bounds__(TILE) void pair_hist_kernel(const PairArgs a)
     b.cls_row = s_cls + me.t * a.n_tj;
     b.gscale = a.gscale;
     b.nbins = a.nbins;
-    // this lane's class row packed into 64 bits (used when n_tj <= 8)
-    const float near = (float)a.nbins * 1.0e-6f + 1.0e-5f;
-    unsigned long long row64 = ~0ull;
-    if (VAR == 1) {
-        row64 = 0ull;
-        for (int q = 0; q < a.n_tj && q < 8; ++q)
-            row64 |= (unsigned long long)a.cls[me.t * a.n_tj + q] << (8 * q);
-    }
-
     auto tile_of = [&](int t) -> int {
         if (TRI) {
             int J = I + t;
@@ -280,24 +213,10 @@ __global__ __launch_bounds__(TILE) void pair_hist_kernel(const PairArgs a)
         const int buf = (t - t_begin) & 1;
         if (t + 1 < t_end)
             nxt = load_atom(xj_f, tj_f, a.nj, (long long)tile_of(t + 1) * TILE + tid, PAD_J);
-        const JAtom *cur = s_tile + buf * TILE;
-        const bool diag = TRI && t == 0;
-        if (VAR == 0) {
-            if (diag)
-                sweep_tile<true>(cur, me.x, me.y, me.z, Lx, Ly, Lz, a.rc2, b, tid);
-            else
-                sweep_tile<false>(cur, me.x, me.y, me.z, Lx, Ly, Lz, a.rc2, b, tid);
-        } else if (VAR == 1) {
-            if (diag)
-                sweep_tile_v2<true, true>(cur, me.x, me.y, me.z, Lx, Ly, Lz, a.rc2, b, row64, near, tid);
-            else
-                sweep_tile_v2<false, true>(cur, me.x, me.y, me.z, Lx, Ly, Lz, a.rc2, b, row64, near, tid);
-        } else {
-            if (diag)
-                sweep_tile_v2<true, false>(cur, me.x, me.y, me.z, Lx, Ly, Lz, a.rc2, b, row64, near, tid);
-            else
-                sweep_tile_v2<false, false>(cur, me.x, me.y, me.z, Lx, Ly, Lz, a.rc2, b, row64, near, tid);
-        }
+        if (TRI && t == 0)
+            sweep_tile<true>(s_tile + buf * TILE, me.x, me.y, me.z, Lx, Ly, Lz, a.rc2, b, tid);
+        else
+            sweep_tile<false>(s_tile + buf * TILE, me.x, me.y, me.z, Lx, Ly, Lz, a.rc2, b, tid);
         if (t + 1 < t_end) s_tile[(buf ^ 1) * TILE + tid] = nxt;
         __syncthreads();
     }
@@ -310,6 +229,182 @@ __global__ __launch_bounds__(TILE) void pair_hist_kernel(const PairArgs a)
         if (v) atomicAdd(&g[k], (unsigned long long)v);
     }
     if (tid == 0 && *s_ovf) atomicAdd(a.overflow, (unsigned long long)*s_ovf);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fast variant (rdf_variant = 1, RDF edge tables only): same arithmetic for rsq, cheaper bookkeeping.
+//  * LDS: the class histograms sit at offset 0 as (n_cls+1) rows of (nbins+1) words. Word nbins of a
+//    row counts that class's overflow pairs (bin index == nbins), row n_cls is a bin for pairs no
+//    relation asks for in this pass — so the hot path has no "skip" and no "overflow" branch.
+//  * the byte offset of row class(ti,tj) comes from a u32 table in LDS indexed [tj][ti]: tj is
+//    wave-uniform (kept in a scalar register), so the lookup is one v_add + one ds_read_b32 and works
+//    for any number of types.
+//  * binning: table-free guess with an exact guard band (see sweep_fast below).
+//  * tiles are read as two 16-byte LDS loads per j atom (type in the 4th double).
+// ------------------------------------------------------------------------------------------------
+
+struct FastCtx {
+    unsigned *hist;               // LDS offset 0
+    const double *edges;          // LDS, nbins+2 entries, last = +inf
+    const unsigned *rowtab_me;    // LDS: &rowtab[0][ti] of the table [n_tj][n_ti] -> BYTE offset of the class row
+    float gscale, lim;            // lim = 0.5 - guard band half-width
+    int nbins;
+};
+
+template <bool DIAG>
+__device__ __forceinline__ void sweep_fast(const double4 *__restrict__ tile, double xi, double yi, double zi,
+                                           double Lx, double Ly, double Lz, double rc2, const FastCtx &c,
+                                           int lane_id)
+{
+    constexpr int U = 8;
+    for (int j0 = 0; j0 < TILE; j0 += U) {
+        double rsq[U];
+        unsigned row[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const double4 pj = tile[j0 + u];
+            const double ax = wrap_abs(xi - pj.x, Lx);
+            const double ay = wrap_abs(yi - pj.y, Ly);
+            const double az = wrap_abs(zi - pj.z, Lz);
+            rsq[u] = (ax * ax + ay * ay) + az * az;
+            // 4th double: word offset tj*n_ti into the row table; the byte offset of the class row is read
+            // here, unconditionally, so that its LDS latency is hidden behind the rsq chains
+            row[u] = c.rowtab_me[(int)__double_as_longlong(pj.w)];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            bool in = rsq[u] < rc2;
+            if (DIAG) in = in && (j0 + u > lane_id);
+            if (in) {
+                // g ~ sqrt(rsq)/ddr with |error| < nbins*2.7e-7 (cvt 2^-25 after the sqrt, v_sqrt_f32 1 ulp,
+                // rounded 1/ddr and the product 2^-24 each). Outside the guard band of half-width
+                // nbins*1e-6 + 1e-5 around an integer, trunc(g) is the reference bin; inside it (~0.1 % of
+                // pairs) the exact edge table decides.
+                const float g = __builtin_amdgcn_sqrtf((float)rsq[u]) * c.gscale;
+                int k = (int)g;
+                const float fr = __builtin_amdgcn_fractf(g);
+                if (__builtin_fabsf(fr - 0.5f) > c.lim) {
+                    k = k > c.nbins ? c.nbins : k;
+                    while (rsq[u] < c.edges[k]) --k;
+                    while (rsq[u] >= c.edges[k + 1]) ++k;
+                }
+                atomicAdd(reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(c.hist) + row[u]) + k, 1u);
+            }
+        }
+    }
+}
+
+template <bool TRI>
+__global__ __launch_bounds__(TILE) void pair_hist_fast_kernel(const PairArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const long long bid = blockIdx.x;
+    const int xcd = (int)(bid & 7);
+    const long long q = bid >> 3;
+    const int f = (int)(q / a.blocks_per_frame) * 8 + xcd;
+    if (f >= a.n_frames) return;
+    const int within = (int)(q % a.blocks_per_frame);
+    const int I = within % a.nTi;
+    const int split = within / a.nTi;
+    int t_begin, t_end;
+    if (TRI) {
+        const int S = tri_shifts(a.nTi, I);
+        t_begin = (int)((long long)split * S / a.jsplit);
+        t_end = (int)((long long)(split + 1) * S / a.jsplit);
+    } else {
+        t_begin = (int)((long long)split * a.nTj / a.jsplit);
+        t_end = (int)((long long)(split + 1) * a.nTj / a.jsplit);
+    }
+    if (t_begin >= t_end) return;
+
+    // ---- LDS carve-up: hist | edges | tiles | row table ----
+    const int row_len = a.nbins + 1;
+    const int hist_words = (a.n_cls + 1) * row_len;
+    unsigned *s_hist = reinterpret_cast<unsigned *>(smem);
+    size_t off = ((size_t)hist_words * 4 + 15) & ~size_t(15);
+    double *s_edges = reinterpret_cast<double *>(smem + off);
+    off += (((size_t)(a.nbins + 2) * 8) + 15) & ~size_t(15);
+    double4 *s_tile = reinterpret_cast<double4 *>(smem + off);
+    off += sizeof(double4) * 2 * TILE;
+    unsigned *s_row = reinterpret_cast<unsigned *>(smem + off);
+
+    for (int k = tid; k < hist_words; k += TILE) s_hist[k] = 0u;
+    for (int k = tid; k <= a.nbins; k += TILE) s_edges[k] = a.edges[k];
+    if (tid == 0) s_edges[a.nbins + 1] = __builtin_inf();
+    for (int k = tid; k < a.n_ti * a.n_tj; k += TILE) {
+        const int ti = k % a.n_ti, tj = k / a.n_ti;
+        const unsigned cl = a.cls[ti * a.n_tj + tj];
+        s_row[k] = (cl == 0xFFu ? (unsigned)a.n_cls : cl) * (unsigned)row_len * 4u;
+    }
+
+    const double *xi_f = a.xi + (long long)f * 3 * a.ni;
+    const double *xj_f = a.xj + (long long)f * 3 * a.nj;
+    const int *ti_f = a.ti + (long long)f * a.ti_fs;
+    const int *tj_f = a.tj + (long long)f * a.tj_fs;
+    const double Lx = a.box[3 * f], Ly = a.box[3 * f + 1], Lz = a.box[3 * f + 2];
+    const JAtom me = load_atom(xi_f, ti_f, a.ni, (long long)I * TILE + tid, PAD_I);
+
+    FastCtx c;
+    c.hist = s_hist;
+    c.edges = s_edges;
+    c.rowtab_me = s_row + me.t;
+    c.gscale = a.gscale;
+    c.lim = 0.5f - ((float)a.nbins * 1.0e-6f + 1.0e-5f);
+    c.nbins = a.nbins;
+
+    auto tile_of = [&](int t) -> int {
+        if (TRI) {
+            int J = I + t;
+            return J >= a.nTi ? J - a.nTi : J;
+        }
+        return t;
+    };
+    const int n_ti = a.n_ti;
+    auto pack = [n_ti](const JAtom &p) -> double4 {
+        return make_double4(p.x, p.y, p.z, __longlong_as_double((long long)p.t * n_ti));
+    };
+
+    JAtom nxt = load_atom(xj_f, tj_f, a.nj, (long long)tile_of(t_begin) * TILE + tid, PAD_J);
+    s_tile[tid] = pack(nxt);
+    __syncthreads();
+    for (int t = t_begin; t < t_end; ++t) {
+        const int buf = (t - t_begin) & 1;
+        if (t + 1 < t_end)
+            nxt = load_atom(xj_f, tj_f, a.nj, (long long)tile_of(t + 1) * TILE + tid, PAD_J);
+        const double4 *cur = s_tile + buf * TILE;
+        if (TRI && t == 0)
+            sweep_fast<true>(cur, me.x, me.y, me.z, Lx, Ly, Lz, a.rc2, c, tid);
+        else
+            sweep_fast<false>(cur, me.x, me.y, me.z, Lx, Ly, Lz, a.rc2, c, tid);
+        if (t + 1 < t_end) s_tile[(buf ^ 1) * TILE + tid] = pack(nxt);
+        __syncthreads();
+    }
+
+    // ---- flush: real classes -> global histogram rows, word nbins of every row -> overflow ----
+    const int out_words = a.n_cls * a.nbins;
+    unsigned long long *g =
+        a.hist + (size_t)(a.per_frame ? f : (int)(bid % a.slots)) * (size_t)out_words;
+    unsigned ovf = 0;
+    for (int w = tid; w < hist_words; w += TILE) {
+        const unsigned v = s_hist[w];
+        if (!v) continue;
+        const int cl = w / row_len, k = w - cl * row_len;
+        if (k == a.nbins)
+            ovf += v;
+        else if (cl < a.n_cls)
+            atomicAdd(&g[(size_t)cl * a.nbins + k], (unsigned long long)v);
+    }
+    if (ovf) atomicAdd(a.overflow, (unsigned long long)ovf);
+}
+
+size_t lds_bytes_fast(int nbins, int n_cls, int n_ti, int n_tj)
+{
+    size_t off = ((size_t)(n_cls + 1) * (nbins + 1) * 4 + 15) & ~size_t(15);
+    off += (((size_t)(nbins + 2) * 8) + 15) & ~size_t(15);
+    off += sizeof(double4) * 2 * TILE;
+    off += (size_t)n_ti * n_tj * 4;
+    return (off + 15) & ~size_t(15);
 }
 
 __global__ void reduce_slots_kernel(const unsigned long long *__restrict__ in,
@@ -366,16 +461,22 @@ int pair_hist_run(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64_t> &H
     *overflow = 0;
     if (F == 0 || p.ni == 0 || p.nj == 0) return MDHIP_OK;
 
+    // kernel variant: 0 = reference-shaped loops with an edge-table lookup per pair (always used for CN
+    // edge tables, gscale == 0); 1 = fast kernel (table-free binning with an exact guard band)
+    const bool fast = p.gscale > 0.f && p.nbins <= 100000 && ctx->opt_rdf_variant == 1;
+
     // classes per pass limited by LDS (keep >= 2 blocks per CU when possible)
     const size_t lds_cap = ctx->lds_max > 0 ? ctx->lds_max : 65536;
-    const size_t fixed = lds_bytes(p.nbins, 0, p.n_ti, p.n_tj);
-    if (fixed + (size_t)p.nbins * 4 > lds_cap)
+    const size_t fixed = fast ? lds_bytes_fast(p.nbins, 0, p.n_ti, p.n_tj) : lds_bytes(p.nbins, 0, p.n_ti, p.n_tj);
+    const size_t row_b = fast ? (size_t)(p.nbins + 1) * 4 : (size_t)p.nbins * 4;
+    if (fixed + row_b > lds_cap)
         return mdhip_fail(ctx, MDHIP_ELIMIT, "pair_hist: %d bins do not fit LDS (%zu B)", p.nbins,
                           lds_cap);
-    const size_t budget = lds_cap / 2 > fixed + (size_t)p.nbins * 4 ? lds_cap / 2 : lds_cap;
-    int cls_per_pass = (int)((budget - fixed) / ((size_t)p.nbins * 4));
+    const size_t budget = lds_cap / 2 > fixed + row_b ? lds_cap / 2 : lds_cap;
+    int cls_per_pass = (int)((budget - fixed) / row_b);
     if (cls_per_pass > p.n_cls) cls_per_pass = p.n_cls;
     if (cls_per_pass > 250) cls_per_pass = 250;
+
     const int n_pass = (p.n_cls + cls_per_pass - 1) / cls_per_pass;
 
     // geometry
@@ -450,14 +551,10 @@ int pair_hist_run(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64_t> &H
         a.per_frame = p.per_frame;
         a.slots = slots;
 
-        const size_t lds = lds_bytes(p.nbins, nc, p.n_ti, p.n_tj);
-        // kernel variant: 0 = reference-shaped loops (always used for CN edge tables, gscale == 0);
-        // 1/2 = straight-line predicated binning with the class row in registers / in LDS
-        int var = 0;
-        if (p.gscale > 0.f && p.nbins <= 100000 && ctx->opt_rdf_variant != 0) var = p.n_tj <= 8 ? 1 : 2;
+        const size_t lds = fast ? lds_bytes_fast(p.nbins, nc, p.n_ti, p.n_tj) : lds_bytes(p.nbins, nc, p.n_ti, p.n_tj);
         void (*kern)(const PairArgs) =
-            p.tri ? (var == 0 ? pair_hist_kernel<true, 0> : var == 1 ? pair_hist_kernel<true, 1> : pair_hist_kernel<true, 2>)
-                  : (var == 0 ? pair_hist_kernel<false, 0> : var == 1 ? pair_hist_kernel<false, 1> : pair_hist_kernel<false, 2>);
+            fast ? (p.tri ? pair_hist_fast_kernel<true> : pair_hist_fast_kernel<false>)
+                 : (p.tri ? pair_hist_kernel<true> : pair_hist_kernel<false>);
         if (lds > 65536)
             MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
