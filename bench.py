@@ -183,7 +183,8 @@ def main():
                        "pairs_per_step_per_gpu": pairs_per_step, "kernel_variant": ctx_variant(ctx, args)},
             "roofline": {
                 "bound": "fp64-valu (not hbm/mfma: 28 B and 18 unfused FP64 ops per atom per pair sweep)",
-                "kernel": "pair_hist_kernel<tri>", "launch_ms": kdur * 1e3,
+                "kernel": "pair_hist_fast_kernel<tri,8>" if ctx_variant(ctx, args) == 1 else "pair_hist_kernel<tri>",
+                "launch_ms": kdur * 1e3,
                 "achieved": alg_ops / kdur / 1e12, "peak": FP64_NONFUSED_PEAK / 1e12, "unit": "TFLOP/s",
                 "frac": alg_ops / kdur / FP64_NONFUSED_PEAK,
                 "hbm_algorithmic_GBps": 28.0 * n * F / kdur / 1e9, "hbm_peak_GBps": HBM_PEAK / 1e9,
@@ -203,7 +204,8 @@ def main():
 
 
 def ctx_variant(ctx, args):
-    return 0 if args.variant is None else int(args.variant)
+    """Kernel variant in use: the library default is 1 (fast kernel); --variant overrides it for A/B runs."""
+    return int(os.environ.get("MDHIP_RDF_VARIANT", "1")) if args.variant is None else int(args.variant)
 
 
 def load_traffic():

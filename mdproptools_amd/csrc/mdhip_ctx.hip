@@ -88,7 +88,9 @@ int mdhip_create(mdhip_ctx **out, int device)
         return mdhip_fail(nullptr, MDHIP_EHIP, "mdhip_create: stream/event creation failed");
     }
     ctx->stream = ctx->own_stream;
-    if (const char *v = getenv("MDHIP_RDF_VARIANT")) ctx->opt_rdf_variant = atoi(v);  // A/B knob
+    if (const char *v = getenv("MDHIP_RDF_VARIANT")) ctx->opt_rdf_variant = atoi(v);  // A/B knobs
+    if (const char *v = getenv("MDHIP_RDF_UNROLL")) ctx->opt_rdf_unroll = atoi(v);
+    if (const char *v = getenv("MDHIP_RDF_JSPLIT")) ctx->opt_rdf_jsplit = atoi(v);
     *out = ctx;
     return MDHIP_OK;
 }
@@ -142,6 +144,8 @@ int mdhip_set_option(mdhip_ctx *ctx, const char *key, int value)
     if (!ctx || !key) return MDHIP_EINVAL;
     if (!strcmp(key, "rdf_variant"))
         ctx->opt_rdf_variant = value;
+    else if (!strcmp(key, "rdf_unroll"))
+        ctx->opt_rdf_unroll = value;
     else if (!strcmp(key, "rdf_jsplit"))
         ctx->opt_rdf_jsplit = value;
     else if (!strcmp(key, "rdf_slots"))

@@ -246,17 +246,16 @@ __global__ __launch_bounds__(TILE) void pair_hist_kernel(const PairArgs a)
 struct FastCtx {
     unsigned *hist;               // LDS offset 0
     const double *edges;          // LDS, nbins+2 entries, last = +inf
-    const unsigned *rowtab_me;    // LDS: &rowtab[0][ti] of the table [n_tj][n_ti] -> BYTE offset of the class row
-    float gscale, lim;            // lim = 0.5 - guard band half-width
+    const unsigned *rowtab_me;    // LDS: &rowtab[0][ti] of the table [n_tj][n_ti] -> LDS byte address of the class row
+    float gscale, near, near2;    // guard band half-width and its double
     int nbins;
 };
 
-template <bool DIAG>
+template <bool DIAG, int U>
 __device__ __forceinline__ void sweep_fast(const double4 *__restrict__ tile, double xi, double yi, double zi,
                                            double Lx, double Ly, double Lz, double rc2, const FastCtx &c,
                                            int lane_id)
 {
-    constexpr int U = 8;
     for (int j0 = 0; j0 < TILE; j0 += U) {
         double rsq[U];
         unsigned row[U];
@@ -276,25 +275,28 @@ __device__ __forceinline__ void sweep_fast(const double4 *__restrict__ tile, dou
             bool in = rsq[u] < rc2;
             if (DIAG) in = in && (j0 + u > lane_id);
             if (in) {
-                // g ~ sqrt(rsq)/ddr with |error| < nbins*2.7e-7 (cvt 2^-25 after the sqrt, v_sqrt_f32 1 ulp,
-                // rounded 1/ddr and the product 2^-24 each). Outside the guard band of half-width
-                // nbins*1e-6 + 1e-5 around an integer, trunc(g) is the reference bin; inside it (~0.1 % of
-                // pairs) the exact edge table decides.
-                const float g = __builtin_amdgcn_sqrtf((float)rsq[u]) * c.gscale;
-                int k = (int)g;
-                const float fr = __builtin_amdgcn_fractf(g);
-                if (__builtin_fabsf(fr - 0.5f) > c.lim) {
+                // g1 = sqrt(rsq)/ddr + near, evaluated in f32: |error| < nbins*2.9e-7 (cvt 2^-25 after the
+                // sqrt, v_sqrt_f32 1 ulp, rounded 1/ddr 2^-24, the fma 2^-24). near = nbins*1e-6 + 1e-5 is
+                // > 3x that bound. If fract(g1) >= 2*near the true value is at least `near` - error away from
+                // both neighbouring integers, so trunc(g1) is the reference bin; otherwise (~0.1 % of pairs)
+                // the exact edge table decides.
+                const float g1 = __builtin_fmaf(__builtin_amdgcn_sqrtf((float)rsq[u]), c.gscale, c.near);
+                int k = (int)g1;
+                if (__builtin_amdgcn_fractf(g1) < c.near2) {
                     k = k > c.nbins ? c.nbins : k;
                     while (rsq[u] < c.edges[k]) --k;
                     while (rsq[u] >= c.edges[k + 1]) ++k;
                 }
-                atomicAdd(reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(c.hist) + row[u]) + k, 1u);
+                // one VALU op for the address (row already holds the absolute LDS byte address of the row),
+                // then the LDS increment
+                const unsigned addr = ((unsigned)k << 2) + row[u];
+                asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"(1u) : "memory");
             }
         }
     }
 }
 
-template <bool TRI>
+template <bool TRI, int U>
 __global__ __launch_bounds__(TILE) void pair_hist_fast_kernel(const PairArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -329,13 +331,16 @@ __global__ __launch_bounds__(TILE) void pair_hist_fast_kernel(const PairArgs a)
     off += sizeof(double4) * 2 * TILE;
     unsigned *s_row = reinterpret_cast<unsigned *>(smem + off);
 
+    // LDS byte address of the histogram (dynamic LDS starts after any static LDS of the kernel)
+    const unsigned lds_base =
+        (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char *)smem;
     for (int k = tid; k < hist_words; k += TILE) s_hist[k] = 0u;
     for (int k = tid; k <= a.nbins; k += TILE) s_edges[k] = a.edges[k];
     if (tid == 0) s_edges[a.nbins + 1] = __builtin_inf();
     for (int k = tid; k < a.n_ti * a.n_tj; k += TILE) {
         const int ti = k % a.n_ti, tj = k / a.n_ti;
         const unsigned cl = a.cls[ti * a.n_tj + tj];
-        s_row[k] = (cl == 0xFFu ? (unsigned)a.n_cls : cl) * (unsigned)row_len * 4u;
+        s_row[k] = lds_base + (cl == 0xFFu ? (unsigned)a.n_cls : cl) * (unsigned)row_len * 4u;
     }
 
     const double *xi_f = a.xi + (long long)f * 3 * a.ni;
@@ -350,7 +355,8 @@ __global__ __launch_bounds__(TILE) void pair_hist_fast_kernel(const PairArgs a)
     c.edges = s_edges;
     c.rowtab_me = s_row + me.t;
     c.gscale = a.gscale;
-    c.lim = 0.5f - ((float)a.nbins * 1.0e-6f + 1.0e-5f);
+    c.near = (float)a.nbins * 1.0e-6f + 1.0e-5f;
+    c.near2 = 2.0f * c.near;
     c.nbins = a.nbins;
 
     auto tile_of = [&](int t) -> int {
@@ -374,14 +380,17 @@ __global__ __launch_bounds__(TILE) void pair_hist_fast_kernel(const PairArgs a)
             nxt = load_atom(xj_f, tj_f, a.nj, (long long)tile_of(t + 1) * TILE + tid, PAD_J);
         const double4 *cur = s_tile + buf * TILE;
         if (TRI && t == 0)
-            sweep_fast<true>(cur, me.x, me.y, me.z, Lx, Ly, Lz, a.rc2, c, tid);
+            sweep_fast<true, U>(cur, me.x, me.y, me.z, Lx, Ly, Lz, a.rc2, c, tid);
         else
-            sweep_fast<false>(cur, me.x, me.y, me.z, Lx, Ly, Lz, a.rc2, c, tid);
+            sweep_fast<false, U>(cur, me.x, me.y, me.z, Lx, Ly, Lz, a.rc2, c, tid);
         if (t + 1 < t_end) s_tile[(buf ^ 1) * TILE + tid] = pack(nxt);
         __syncthreads();
     }
 
     // ---- flush: real classes -> global histogram rows, word nbins of every row -> overflow ----
+    // the LDS increments are inline asm the compiler does not count: drain them before the last barrier
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
     const int out_words = a.n_cls * a.nbins;
     unsigned long long *g =
         a.hist + (size_t)(a.per_frame ? f : (int)(bid % a.slots)) * (size_t)out_words;
@@ -483,7 +492,7 @@ int pair_hist_run(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64_t> &H
     int max_list = p.tri ? tri_shifts(nTi, 0) : nTj;
     int jsplit = ctx->opt_rdf_jsplit;
     if (jsplit <= 0) {
-        const int64_t want = (int64_t)ctx->cu_count * 16;
+        const int64_t want = (int64_t)ctx->cu_count * 48;  // ~12 blocks per CU slot: short tail
         const int64_t base = (int64_t)nTi * F;
         jsplit = (int)((want + base - 1) / base);
     }
@@ -553,7 +562,11 @@ int pair_hist_run(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64_t> &H
 
         const size_t lds = fast ? lds_bytes_fast(p.nbins, nc, p.n_ti, p.n_tj) : lds_bytes(p.nbins, nc, p.n_ti, p.n_tj);
         void (*kern)(const PairArgs) =
-            fast ? (p.tri ? pair_hist_fast_kernel<true> : pair_hist_fast_kernel<false>)
+            fast ? (ctx->opt_rdf_unroll == 4
+                        ? (p.tri ? pair_hist_fast_kernel<true, 4> : pair_hist_fast_kernel<false, 4>)
+                        : ctx->opt_rdf_unroll == 16
+                              ? (p.tri ? pair_hist_fast_kernel<true, 16> : pair_hist_fast_kernel<false, 16>)
+                              : (p.tri ? pair_hist_fast_kernel<true, 8> : pair_hist_fast_kernel<false, 8>))
                  : (p.tri ? pair_hist_kernel<true> : pair_hist_kernel<false>);
         if (lds > 65536)
             MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
