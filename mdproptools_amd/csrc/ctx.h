@@ -51,6 +51,7 @@ struct mdhip_ctx {
     int opt_rdf_variant = 1;   // 1 = fast kernel (default), 0 = table-lookup loops (A/B baseline)
     int opt_rdf_unroll = 8;   // j atoms per step of the fast kernel (4, 8, 16)
     int opt_rdf_jsplit = 0;   // 0 = auto
+    int opt_rdf_fpb = 0;      // frames per block of the fast kernel, 0 = auto
     int opt_rdf_slots = 16;   // replicas of the frame-summed histogram in HBM
     int opt_xcorr_tile = 0;
 };

@@ -140,13 +140,9 @@ __global__ __launch_bounds__(256) void msd_windows_kernel(const double *__restri
 // window in registers: 8 LDS reads feed 64 (sub, fma) pairs. Sums over the chunk's entities stay in
 // registers; chunk partials are added in a fixed order afterwards.
 
-constexpr int LG_THREADS = 256;
-constexpr int LG_LPT = 8;
-constexpr int LG_KT = LG_THREADS * LG_LPT;  // 2048 lags per tile
-constexpr int LG_TT = 2048;
-constexpr int LG_AW = LG_TT + LG_KT + 8;
-constexpr int LG_ROW = LG_AW / 8 + 1;
-constexpr int LG_ECHUNK = 64;  // entities summed inside one block
+constexpr int LG_LPT = 8;       // consecutive lags per lane
+constexpr int LG_TT = 2048;     // time steps per LDS stage
+constexpr int LG_ECHUNK = 64;   // at most this many entities are summed inside one block
 
 __global__ __launch_bounds__(256) void transpose_kernel(const double *__restrict__ in,
                                                         double *__restrict__ out, long long rows,
@@ -167,11 +163,16 @@ __global__ __launch_bounds__(256) void transpose_kernel(const double *__restrict
     }
 }
 
-// x: [3][E][F] time-major series. partial: [n_chunks][max_lag+1][4]
+// x: [3][E][F] time-major series. partial: [n_chunks][max_lag+1][4]. LG_THREADS lanes x 8 lags = one lag
+// tile; short trajectories use fewer lanes per block so that no lane owns only lags >= n.
+template <int LG_THREADS>
 __global__ __launch_bounds__(LG_THREADS) void lag_msd_kernel(
     const double *__restrict__ x, long long n_ent, long long n, long long n_lags,
     const Chunk *__restrict__ chunks, int n_tiles, double *__restrict__ partial)
 {
+    constexpr int LG_KT = LG_THREADS * LG_LPT;
+    constexpr int LG_AW = LG_TT + LG_KT + 8;
+    constexpr int LG_ROW = LG_AW / 8 + 1;
     __shared__ double s_a[8 * LG_ROW];
     __shared__ __attribute__((aligned(16))) double s_b[LG_TT];
     const int tid = threadIdx.x;
@@ -209,7 +210,10 @@ __global__ __launch_bounds__(LG_THREADS) void lag_msd_kernel(
                     double w[16];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) w[j] = s_a[j * LG_ROW + tid];
-                    for (int tt = 0; tt < LG_TT; tt += 8) {
+                    // time steps of this stage that can still pair with the tile's smallest lag
+                    const long long left = t_total - T0;
+                    const int tt_end = left < LG_TT ? (int)((left + 7) & ~7LL) : LG_TT;
+                    for (int tt = 0; tt < tt_end; tt += 8) {
                         const int col = tid + (tt >> 3) + 1;
 #pragma unroll
                         for (int j = 0; j < 8; ++j) w[8 + j] = s_a[j * LG_ROW + col];
@@ -389,9 +393,19 @@ int mdhip_lag_msd(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double 
     MD_REQUIRE(out != nullptr, "out is NULL");
     std::vector<Chunk> chunks;
     std::vector<int> gco;
-    int rc = build_chunks(ctx, n_ent, n_groups, group_off, chunks, gco, LG_ECHUNK);
-    if (rc) return rc;
     const long long n_lags = (long long)max_lag + 1;
+    // entities per block: enough blocks to fill the chip (>= ~8 per CU), at most LG_ECHUNK
+    int64_t echunk = LG_ECHUNK;
+    {
+        const int thr = n_lags <= 512 ? 64 : n_lags <= 1024 ? 128 : 256;
+        const int64_t tile_pairs = ((n_lags + thr * LG_LPT - 1) / (thr * LG_LPT) + 1) / 2;
+        const int64_t want = (int64_t)ctx->cu_count * 8;
+        echunk = n_ent * tile_pairs / want;
+        if (echunk < 1) echunk = 1;
+        if (echunk > LG_ECHUNK) echunk = LG_ECHUNK;
+    }
+    int rc = build_chunks(ctx, n_ent, n_groups, group_off, chunks, gco, echunk);
+    if (rc) return rc;
     std::fill(out, out + (size_t)n_lags * n_groups * 4, 0.0);
     if (n_frames == 0 || chunks.empty()) return MDHIP_OK;
     MD_REQUIRE(r != nullptr, "r is NULL");
@@ -418,11 +432,20 @@ int mdhip_lag_msd(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double 
     hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((cols + 31) / 32), (unsigned)((n_frames + 31) / 32)),
                        dim3(256), 0, ctx->stream, d_r, d_x, (long long)n_frames, cols, scale);
     MD_HIP(hipGetLastError());
-    const int n_tiles = (int)((n_lags + LG_KT - 1) / LG_KT);
+    const int threads = n_lags <= 512 ? 64 : n_lags <= 1024 ? 128 : 256;
+    const int kt = threads * LG_LPT;
+    const int n_tiles = (int)((n_lags + kt - 1) / kt);
+    const dim3 grid((unsigned)((n_tiles + 1) / 2), (unsigned)n_chunks);
     KernelTimer timer(ctx);
-    hipLaunchKernelGGL(lag_msd_kernel, dim3((unsigned)((n_tiles + 1) / 2), (unsigned)n_chunks),
-                       dim3(LG_THREADS), 0, ctx->stream, d_x, (long long)n_ent, (long long)n_frames, n_lags,
-                       d_chunks, n_tiles, d_partial);
+    if (threads == 64)
+        hipLaunchKernelGGL(lag_msd_kernel<64>, grid, dim3(64), 0, ctx->stream, d_x, (long long)n_ent,
+                           (long long)n_frames, n_lags, d_chunks, n_tiles, d_partial);
+    else if (threads == 128)
+        hipLaunchKernelGGL(lag_msd_kernel<128>, grid, dim3(128), 0, ctx->stream, d_x, (long long)n_ent,
+                           (long long)n_frames, n_lags, d_chunks, n_tiles, d_partial);
+    else
+        hipLaunchKernelGGL(lag_msd_kernel<256>, grid, dim3(256), 0, ctx->stream, d_x, (long long)n_ent,
+                           (long long)n_frames, n_lags, d_chunks, n_tiles, d_partial);
     timer.stop();
     MD_HIP(hipGetLastError());
     const long long tot = n_lags * n_groups * 4;

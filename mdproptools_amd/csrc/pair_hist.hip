@@ -59,6 +59,7 @@ struct PairArgs {
     int n_ti, n_tj, n_cls, nbins;
     int n_frames, nTi, nTj, jsplit, blocks_per_frame;
     int per_frame, slots;
+    int fpb;  // frames swept per block before the flush (fast kernel, frame-summed output only)
 };
 
 __device__ __forceinline__ double wrap_abs(double d, double L)
@@ -301,11 +302,12 @@ __global__ __launch_bounds__(TILE) void pair_hist_fast_kernel(const PairArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
+    // block -> (XCD, frame group, i-tile, slice of the j list); a block sweeps `fpb` frames of its XCD's
+    // share (frames f with f % 8 == xcd) before it flushes, so the merge traffic drops by fpb
     const long long bid = blockIdx.x;
     const int xcd = (int)(bid & 7);
     const long long q = bid >> 3;
-    const int f = (int)(q / a.blocks_per_frame) * 8 + xcd;
-    if (f >= a.n_frames) return;
+    const int fgroup = (int)(q / a.blocks_per_frame);
     const int within = (int)(q % a.blocks_per_frame);
     const int I = within % a.nTi;
     const int split = within / a.nTi;
@@ -319,6 +321,7 @@ __global__ __launch_bounds__(TILE) void pair_hist_fast_kernel(const PairArgs a)
         t_end = (int)((long long)(split + 1) * a.nTj / a.jsplit);
     }
     if (t_begin >= t_end) return;
+    if ((fgroup * a.fpb) * 8 + xcd >= a.n_frames) return;
 
     // ---- LDS carve-up: hist | edges | tiles | row table ----
     const int row_len = a.nbins + 1;
@@ -343,17 +346,9 @@ __global__ __launch_bounds__(TILE) void pair_hist_fast_kernel(const PairArgs a)
         s_row[k] = lds_base + (cl == 0xFFu ? (unsigned)a.n_cls : cl) * (unsigned)row_len * 4u;
     }
 
-    const double *xi_f = a.xi + (long long)f * 3 * a.ni;
-    const double *xj_f = a.xj + (long long)f * 3 * a.nj;
-    const int *ti_f = a.ti + (long long)f * a.ti_fs;
-    const int *tj_f = a.tj + (long long)f * a.tj_fs;
-    const double Lx = a.box[3 * f], Ly = a.box[3 * f + 1], Lz = a.box[3 * f + 2];
-    const JAtom me = load_atom(xi_f, ti_f, a.ni, (long long)I * TILE + tid, PAD_I);
-
     FastCtx c;
     c.hist = s_hist;
     c.edges = s_edges;
-    c.rowtab_me = s_row + me.t;
     c.gscale = a.gscale;
     c.near = (float)a.nbins * 1.0e-6f + 1.0e-5f;
     c.near2 = 2.0f * c.near;
@@ -371,20 +366,35 @@ __global__ __launch_bounds__(TILE) void pair_hist_fast_kernel(const PairArgs a)
         return make_double4(p.x, p.y, p.z, __longlong_as_double((long long)p.t * n_ti));
     };
 
-    JAtom nxt = load_atom(xj_f, tj_f, a.nj, (long long)tile_of(t_begin) * TILE + tid, PAD_J);
-    s_tile[tid] = pack(nxt);
-    __syncthreads();
-    for (int t = t_begin; t < t_end; ++t) {
-        const int buf = (t - t_begin) & 1;
-        if (t + 1 < t_end)
-            nxt = load_atom(xj_f, tj_f, a.nj, (long long)tile_of(t + 1) * TILE + tid, PAD_J);
-        const double4 *cur = s_tile + buf * TILE;
-        if (TRI && t == 0)
-            sweep_fast<true, U>(cur, me.x, me.y, me.z, Lx, Ly, Lz, a.rc2, c, tid);
-        else
-            sweep_fast<false, U>(cur, me.x, me.y, me.z, Lx, Ly, Lz, a.rc2, c, tid);
-        if (t + 1 < t_end) s_tile[(buf ^ 1) * TILE + tid] = pack(nxt);
+    int f_last = 0;
+    for (int kf = 0; kf < a.fpb; ++kf) {
+        const int f = (fgroup * a.fpb + kf) * 8 + xcd;
+        if (f >= a.n_frames) break;
+        f_last = f;
+        const double *xi_f = a.xi + (long long)f * 3 * a.ni;
+        const double *xj_f = a.xj + (long long)f * 3 * a.nj;
+        const int *ti_f = a.ti + (long long)f * a.ti_fs;
+        const int *tj_f = a.tj + (long long)f * a.tj_fs;
+        const double Lx = a.box[3 * f], Ly = a.box[3 * f + 1], Lz = a.box[3 * f + 2];
+        const JAtom me = load_atom(xi_f, ti_f, a.ni, (long long)I * TILE + tid, PAD_I);
+        c.rowtab_me = s_row + me.t;
+
+        JAtom nxt = load_atom(xj_f, tj_f, a.nj, (long long)tile_of(t_begin) * TILE + tid, PAD_J);
+        __syncthreads();  // tables ready (first frame) / previous frame's last tile fully read
+        s_tile[tid] = pack(nxt);
         __syncthreads();
+        for (int t = t_begin; t < t_end; ++t) {
+            const int buf = (t - t_begin) & 1;
+            if (t + 1 < t_end)
+                nxt = load_atom(xj_f, tj_f, a.nj, (long long)tile_of(t + 1) * TILE + tid, PAD_J);
+            const double4 *cur = s_tile + buf * TILE;
+            if (TRI && t == 0)
+                sweep_fast<true, U>(cur, me.x, me.y, me.z, Lx, Ly, Lz, a.rc2, c, tid);
+            else
+                sweep_fast<false, U>(cur, me.x, me.y, me.z, Lx, Ly, Lz, a.rc2, c, tid);
+            if (t + 1 < t_end) s_tile[(buf ^ 1) * TILE + tid] = pack(nxt);
+            __syncthreads();
+        }
     }
 
     // ---- flush: real classes -> global histogram rows, word nbins of every row -> overflow ----
@@ -393,7 +403,7 @@ __global__ __launch_bounds__(TILE) void pair_hist_fast_kernel(const PairArgs a)
     __syncthreads();
     const int out_words = a.n_cls * a.nbins;
     unsigned long long *g =
-        a.hist + (size_t)(a.per_frame ? f : (int)(bid % a.slots)) * (size_t)out_words;
+        a.hist + (size_t)(a.per_frame ? f_last : (int)(bid % a.slots)) * (size_t)out_words;
     unsigned ovf = 0;
     for (int w = tid; w < hist_words; w += TILE) {
         const unsigned v = s_hist[w];
@@ -499,7 +509,18 @@ int pair_hist_run(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64_t> &H
     if (jsplit > max_list) jsplit = max_list;
     if (jsplit < 1) jsplit = 1;
     const int blocks_per_frame = nTi * jsplit;
-    const int64_t fgroups = (F + 7) / 8;
+    // frames per block (fast kernel, frame-summed output): as many as keeps >= `want` blocks in flight
+    int fpb = 1;
+    if (fast && !p.per_frame) {
+        fpb = ctx->opt_rdf_fpb;
+        if (fpb <= 0) {
+            const int64_t want = (int64_t)ctx->cu_count * 24;
+            fpb = (int)(((int64_t)blocks_per_frame * F) / want);
+        }
+        if (fpb < 1) fpb = 1;
+        if (fpb > 64) fpb = 64;
+    }
+    const int64_t fgroups = (F + 8LL * fpb - 1) / (8LL * fpb);
     const int64_t grid = fgroups * 8 * blocks_per_frame;
     if (grid > 0x7fffffffLL)
         return mdhip_fail(ctx, MDHIP_ELIMIT, "pair_hist: grid of %lld blocks is too large",
@@ -559,6 +580,7 @@ int pair_hist_run(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64_t> &H
         a.blocks_per_frame = blocks_per_frame;
         a.per_frame = p.per_frame;
         a.slots = slots;
+        a.fpb = fpb;
 
         const size_t lds = fast ? lds_bytes_fast(p.nbins, nc, p.n_ti, p.n_tj) : lds_bytes(p.nbins, nc, p.n_ti, p.n_tj);
         void (*kern)(const PairArgs) =

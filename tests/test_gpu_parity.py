@@ -111,17 +111,19 @@ def test_rdf_geometry_independence(B):
 
     rng = np.random.default_rng(5)
     L = np.array([30.0, 30.0, 30.0])
-    F, n = 5, 1500
+    F, n = 21, 1500  # 21 frames: frame groups of 8 XCD shares with ragged ends
     xyz = np.stack([_random_case(rng, n, 4, L)[0] for _ in range(F)])
     ty = (1 + np.arange(n) % 4).astype(np.int32)
     rel = np.array([(a, b) for a in range(1, 5) for b in range(a, 5)])
     box = np.tile(L, (F, 1))
     ref = None
-    for jsplit, slots, variant in [(0, 16, 0), (1, 1, 1), (2, 3, 0), (3, 8, 1), (0, 16, 1)]:
+    for jsplit, slots, variant, fpb in [(0, 16, 0, 0), (1, 1, 1, 1), (2, 3, 0, 0), (3, 8, 1, 3), (0, 16, 1, 0),
+                                        (1, 2, 1, 64)]:
         ctx = Context(0)
         ctx.set_option("rdf_jsplit", jsplit)
         ctx.set_option("rdf_slots", slots)
         ctx.set_option("rdf_variant", variant)
+        ctx.set_option("rdf_fpb", fpb)
         for per_frame in (True, False):
             full, part, ov = B.rdf_loop(xyz, ty, box, rel, 12.0, 0.05, 240, per_frame=per_frame, ctx=ctx)
             if per_frame:
