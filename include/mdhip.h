@@ -59,7 +59,8 @@ double mdhip_last_kernel_ms(mdhip_ctx *ctx, int *n_launches);
 /* Writes the device name (e.g. "gfx950...") into buf. */
 int mdhip_device_name(mdhip_ctx *ctx, char *buf, int buflen);
 /* Kernel tuning knob, for A/B measurements only; results never depend on it.
- * key: "rdf_variant" (0 = exact fp64 tiles, 1 = fp32 reject + exact fp64 confirm), "rdf_jsplit", ... */
+ * keys: "rdf_variant" (1 = fast pair kernel, default; 0 = edge-table lookup per pair), "rdf_unroll",
+ * "rdf_jsplit", "rdf_fpb", "rdf_slots", "xcorr_tile". */
 int mdhip_set_option(mdhip_ctx *ctx, const char *key, int value);
 
 /* ---- R2/R3 binning table ------------------------------------------------ */
@@ -211,6 +212,28 @@ int mdhip_xcorr(mdhip_ctx *ctx, int64_t n, int n_pairs, const double *a, const d
  */
 int mdhip_cumtrapz(mdhip_ctx *ctx, int64_t n, int n_series, const double *y, int on_device,
                    double dx, int leading_zero, double *out);
+
+/* ---- I/O: native LAMMPS text-dump reader (host only, no GPU needed) ---------------------------- */
+/*
+ * Replaces, for the inputs of the path, the un-vendored pymatgen `parse_lammps_dumps` + pandas
+ * `read_csv` the reference uses (call sites structural/rdf_cn.py:176, dynamical/diffusion.py:172,
+ * dynamical/conductivity.py:87). A file may hold several frames. Numbers are the correctly rounded
+ * doubles of their text (identical to pandas for the <= 15 significant digits LAMMPS writes).
+ */
+typedef struct mdhip_dump mdhip_dump;
+int mdhip_dump_open(const char *path, mdhip_dump **out); /* mmap + index the frames */
+void mdhip_dump_close(mdhip_dump *d);
+const char *mdhip_dump_error(mdhip_dump *d); /* d == NULL: error of the last failed open */
+int64_t mdhip_dump_n_frames(mdhip_dump *d);
+/* Header of frame f: bounds6 = xlo xhi ylo yhi zlo zhi as written, tilt3 = xy xz yz when triclinic;
+ * columns = the names after "ITEM: ATOMS", space separated. Any output pointer may be NULL. */
+int mdhip_dump_frame_info(mdhip_dump *d, int64_t f, int64_t *timestep, int64_t *natoms, double *bounds6,
+                          double *tilt3, int *triclinic, int *n_cols, char *columns, int columns_len);
+/* Columns col_idx[0..n_sel) of frame f as SoA planes out[n_sel][natoms], rows ordered by ascending value
+ * of column sort_col (stable; e.g. the id column, as `sort_values("id")` in rdf_cn.py:192) or in file
+ * order when sort_col < 0. Parsing is split over n_threads host threads. */
+int mdhip_dump_read(mdhip_dump *d, int64_t f, int n_sel, const int32_t *col_idx, int sort_col, double *out,
+                    int n_threads);
 
 #ifdef __cplusplus
 }

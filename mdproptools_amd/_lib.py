@@ -55,6 +55,13 @@ PROTOTYPES = {
                                     C.c_int, C.c_double, C.c_double, c_dp]),
     "mdhip_xcorr": (C.c_int, [vp, C.c_int64, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int64, c_dp]),
     "mdhip_cumtrapz": (C.c_int, [vp, C.c_int64, C.c_int, vp, C.c_int, C.c_double, C.c_int, c_dp]),
+    "mdhip_dump_open": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
+    "mdhip_dump_close": (None, [vp]),
+    "mdhip_dump_error": (C.c_char_p, [vp]),
+    "mdhip_dump_n_frames": (C.c_int64, [vp]),
+    "mdhip_dump_frame_info": (C.c_int, [vp, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), c_dp, c_dp,
+                                        C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),
+    "mdhip_dump_read": (C.c_int, [vp, C.c_int64, C.c_int, c_ip, C.c_int, c_dp, C.c_int]),
 }
 
 

@@ -20,12 +20,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libmdhip.so")
-SOURCES = ["mdhip_ctx.hip", "pair_hist.hip", "segment_com.hip", "msd.hip", "xcorr.hip", "scan.hip"]
+SOURCES = ["mdhip_ctx.hip", "pair_hist.hip", "segment_com.hip", "msd.hip", "xcorr.hip", "scan.hip",
+           "dump_reader.cpp"]
 HEADERS = [os.path.join(CSRC, "ctx.h"), os.path.join(os.path.dirname(HERE), "include", "mdhip.h")]
 ARCH = "gfx950"
 CFLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "--offload-arch=" + ARCH,
           "-Wall", "-Wno-unused-function"]
-LDFLAGS = ["-shared", "-fPIC", "--offload-arch=" + ARCH, "-L/opt/rocm/lib", "-lhipfft",
+LDFLAGS = ["-shared", "-fPIC", "--offload-arch=" + ARCH, "-L/opt/rocm/lib", "-lhipfft", "-lpthread",
            "-Wl,-rpath,/opt/rocm/lib"]
 
 
@@ -51,10 +52,13 @@ def build(force=False, verbose=False):
     procs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        o = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
         objs.append(o)
         if force or _stale(o, [s] + HEADERS):
-            cmd = [hipcc] + CFLAGS + ["-c", s, "-o", o]
+            if src.endswith(".hip"):
+                cmd = [hipcc] + CFLAGS + ["-c", s, "-o", o]
+            else:  # host-only translation unit
+                cmd = ["g++", "-O3", "-std=c++17", "-fPIC", "-Wall", "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

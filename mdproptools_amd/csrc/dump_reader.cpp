@@ -1,0 +1,427 @@
+// dump_reader.cpp — native LAMMPS text-dump reader (host side of the path).
+//
+// Replaces, for the hot path's inputs, what the reference gets from the un-vendored
+// pymatgen.io.lammps.outputs.parse_lammps_dumps + pandas.read_csv (call sites
+// structural/rdf_cn.py:176, dynamical/diffusion.py:172, dynamical/conductivity.py:87): it turns the
+// text of a frame straight into the SoA float64 planes the kernels take, optionally ordered by atom id
+// (rdf_cn.py:192 `sort_values("id")`), without building a DataFrame.
+//
+// Number parsing: decimal digits are accumulated into a 64-bit integer with a power-of-ten exponent;
+// when the digit string has <= 19 digits, the integer is < 2^53 and |exponent| <= 22 the result is
+// double(m) * 10^e or double(m) / 10^e — ONE correctly rounded IEEE operation on two exact doubles
+// (Clinger's fast path), otherwise glibc strtod (also correctly rounded). Every field is therefore the
+// correctly rounded double of its text. pandas' default reader agrees with that for fields of up to
+// 15 significant digits (everything LAMMPS writes by default); for longer mantissas pandas itself can be
+// 1 ulp off the correctly rounded value, this reader is not (tests/test_dump_reader_cpu.py).
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cerrno>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/mdhip.h"
+
+namespace {
+
+struct FrameIndex {
+    int64_t timestep = 0;
+    int64_t natoms = 0;
+    double bounds[6] = {0, 0, 0, 0, 0, 0};  // xlo xhi ylo yhi zlo zhi (as written)
+    double tilt[3] = {0, 0, 0};
+    int triclinic = 0;
+    std::string columns;       // space separated
+    int n_cols = 0;
+    size_t body_begin = 0;     // offset of the first atom line
+    size_t body_end = 0;       // offset one past the last atom line
+};
+
+}  // namespace
+
+struct mdhip_dump {
+    int fd = -1;
+    const char *data = nullptr;
+    size_t size = 0;
+    std::vector<FrameIndex> frames;
+    std::string err;
+};
+
+namespace {
+
+thread_local std::string g_open_error;
+
+const double kPow10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
+                           1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+
+inline const char *skip_ws(const char *p, const char *end)
+{
+    while (p < end && (*p == ' ' || *p == '\t' || *p == '\r')) ++p;
+    return p;
+}
+
+// Parses one number starting at p (no leading whitespace); returns the position after it.
+inline const char *parse_double(const char *p, const char *end, double *out)
+{
+    const char *start = p;
+    bool neg = false;
+    if (p < end && (*p == '-' || *p == '+')) {
+        neg = *p == '-';
+        ++p;
+    }
+    uint64_t m = 0;
+    int digits = 0, frac = 0;  // significant digits held in m, digits after the decimal point held in m
+    bool any = false, dropped = false;
+    while (p < end && *p >= '0' && *p <= '9') {
+        any = true;
+        if (digits < 19) {
+            m = m * 10 + (uint64_t)(*p - '0');
+            if (m) ++digits;
+        } else {
+            dropped = true;
+        }
+        ++p;
+    }
+    if (p < end && *p == '.') {
+        ++p;
+        while (p < end && *p >= '0' && *p <= '9') {
+            any = true;
+            if (digits < 19) {
+                m = m * 10 + (uint64_t)(*p - '0');
+                if (m) ++digits;
+                ++frac;
+            } else {
+                dropped = true;
+            }
+            ++p;
+        }
+    }
+    const bool slow = dropped || !any;
+    int e10 = 0;
+    if (p < end && (*p == 'e' || *p == 'E')) {
+        const char *q = p + 1;
+        bool eneg = false;
+        if (q < end && (*q == '-' || *q == '+')) {
+            eneg = *q == '-';
+            ++q;
+        }
+        if (q < end && *q >= '0' && *q <= '9') {
+            int ev = 0;
+            while (q < end && *q >= '0' && *q <= '9') {
+                if (ev < 100000) ev = ev * 10 + (*q - '0');
+                ++q;
+            }
+            e10 = eneg ? -ev : ev;
+            p = q;
+        }
+    }
+    if (!slow) {
+        const int e = e10 - frac;
+        if (m < (1ULL << 53) && e >= -22 && e <= 22) {
+            double v = (double)m;
+            v = e < 0 ? v / kPow10[-e] : v * kPow10[e];
+            *out = neg ? -v : v;
+            return p;
+        }
+    }
+    // general case (long mantissa, huge exponent, nan/inf, garbage): glibc strtod on a bounded copy
+    char buf[96];
+    size_t len = (size_t)(p - start);
+    if (!any) {  // not a plain number: take the whole token
+        const char *q = start;
+        while (q < end && *q != ' ' && *q != '\t' && *q != '\n' && *q != '\r') ++q;
+        len = (size_t)(q - start);
+        p = q;
+    }
+    if (len >= sizeof buf) len = sizeof buf - 1;
+    memcpy(buf, start, len);
+    buf[len] = 0;
+    *out = strtod(buf, nullptr);
+    return p;
+}
+
+inline const char *line_end(const char *p, const char *end)
+{
+    const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+    return nl ? nl : end;
+}
+
+inline bool starts_with(const char *p, const char *end, const char *lit)
+{
+    const size_t n = strlen(lit);
+    return (size_t)(end - p) >= n && memcmp(p, lit, n) == 0;
+}
+
+int index_frames(mdhip_dump *d)
+{
+    const char *p = d->data, *end = d->data + d->size;
+    while (p < end) {
+        const char *le = line_end(p, end);
+        if (!starts_with(p, le, "ITEM: TIMESTEP")) {
+            p = le < end ? le + 1 : end;
+            continue;
+        }
+        FrameIndex fr;
+        auto next_line = [&](const char *&b, const char *&e) -> bool {
+            if (le >= end) return false;
+            b = le + 1;
+            e = line_end(b, end);
+            le = e;
+            return true;
+        };
+        const char *b, *e;
+        double v;
+        if (!next_line(b, e)) break;
+        parse_double(skip_ws(b, e), e, &v);
+        fr.timestep = (int64_t)v;
+        if (!next_line(b, e) || !starts_with(b, e, "ITEM: NUMBER OF ATOMS")) {
+            d->err = "dump: expected ITEM: NUMBER OF ATOMS";
+            return MDHIP_EINVAL;
+        }
+        if (!next_line(b, e)) break;
+        parse_double(skip_ws(b, e), e, &v);
+        fr.natoms = (int64_t)v;
+        if (!next_line(b, e) || !starts_with(b, e, "ITEM: BOX BOUNDS")) {
+            d->err = "dump: expected ITEM: BOX BOUNDS";
+            return MDHIP_EINVAL;
+        }
+        fr.triclinic = std::string(b, e).find(" xy ") != std::string::npos ? 1 : 0;
+        for (int ax = 0; ax < 3; ++ax) {
+            if (!next_line(b, e)) break;
+            const char *q = skip_ws(b, e);
+            q = parse_double(q, e, &fr.bounds[2 * ax]);
+            q = parse_double(skip_ws(q, e), e, &fr.bounds[2 * ax + 1]);
+            if (fr.triclinic) parse_double(skip_ws(q, e), e, &fr.tilt[ax]);
+        }
+        if (!next_line(b, e) || !starts_with(b, e, "ITEM: ATOMS")) {
+            d->err = "dump: expected ITEM: ATOMS";
+            return MDHIP_EINVAL;
+        }
+        {
+            const char *q = b + strlen("ITEM: ATOMS");
+            std::string cols;
+            int n = 0;
+            while (q < e) {
+                q = skip_ws(q, e);
+                const char *t = q;
+                while (q < e && *q != ' ' && *q != '\t' && *q != '\r') ++q;
+                if (q > t) {
+                    if (n) cols += ' ';
+                    cols.append(t, q);
+                    ++n;
+                }
+            }
+            fr.columns = cols;
+            fr.n_cols = n;
+        }
+        fr.body_begin = le < end ? (size_t)(le + 1 - d->data) : d->size;
+        // the body is exactly natoms lines
+        const char *q = d->data + fr.body_begin;
+        for (int64_t k = 0; k < fr.natoms && q < end; ++k) {
+            const char *l2 = line_end(q, end);
+            q = l2 < end ? l2 + 1 : end;
+        }
+        fr.body_end = (size_t)(q - d->data);
+        d->frames.push_back(fr);
+        p = q;
+    }
+    return MDHIP_OK;
+}
+
+// parse the lines [l0, l1) of a frame body into rows (sel columns), row-major scratch [line][n_sel (+1 key)]
+void parse_lines(const char *p, const char *end, int64_t n_lines, int n_cols, int n_sel, const int *col_idx,
+                 int key_col, double *vals, double *keys)
+{
+    std::vector<int> slot(n_cols, -1);
+    for (int s = 0; s < n_sel; ++s) slot[col_idx[s]] = s;  // a column selected twice keeps the last slot
+    for (int64_t k = 0; k < n_lines && p < end; ++k) {
+        const char *le = line_end(p, end);
+        const char *q = p;
+        for (int c = 0; c < n_cols; ++c) {
+            q = skip_ws(q, le);
+            if (q >= le) break;
+            double v;
+            q = parse_double(q, le, &v);
+            if (slot[c] >= 0) vals[k * n_sel + slot[c]] = v;
+            if (c == key_col) keys[k] = v;
+        }
+        // duplicated selections
+        for (int s = 0; s < n_sel; ++s)
+            if (slot[col_idx[s]] != s) vals[k * n_sel + s] = vals[k * n_sel + slot[col_idx[s]]];
+        p = le < end ? le + 1 : end;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mdhip_dump_open(const char *path, mdhip_dump **out)
+{
+    if (!path || !out) return MDHIP_EINVAL;
+    *out = nullptr;
+    mdhip_dump *d = new mdhip_dump();
+    d->fd = open(path, O_RDONLY);
+    if (d->fd < 0) {
+        g_open_error = std::string("cannot open ") + path + ": " + strerror(errno);
+        delete d;
+        return MDHIP_EINVAL;
+    }
+    struct stat st;
+    fstat(d->fd, &st);
+    d->size = (size_t)st.st_size;
+    if (d->size) {
+        void *m = mmap(nullptr, d->size, PROT_READ, MAP_PRIVATE, d->fd, 0);
+        if (m == MAP_FAILED) {
+            g_open_error = std::string("mmap failed for ") + path;
+            close(d->fd);
+            delete d;
+            return MDHIP_ENOMEM;
+        }
+        d->data = (const char *)m;
+        madvise(m, d->size, MADV_SEQUENTIAL);
+    }
+    int rc = index_frames(d);
+    if (rc) {
+        g_open_error = d->err;
+        mdhip_dump_close(d);
+        return rc;
+    }
+    *out = d;
+    return MDHIP_OK;
+}
+
+void mdhip_dump_close(mdhip_dump *d)
+{
+    if (!d) return;
+    if (d->data) munmap((void *)d->data, d->size);
+    if (d->fd >= 0) close(d->fd);
+    delete d;
+}
+
+const char *mdhip_dump_error(mdhip_dump *d) { return d ? d->err.c_str() : g_open_error.c_str(); }
+
+int64_t mdhip_dump_n_frames(mdhip_dump *d) { return d ? (int64_t)d->frames.size() : -1; }
+
+int mdhip_dump_frame_info(mdhip_dump *d, int64_t f, int64_t *timestep, int64_t *natoms, double *bounds6,
+                          double *tilt3, int *triclinic, int *n_cols, char *columns, int columns_len)
+{
+    if (!d || f < 0 || f >= (int64_t)d->frames.size()) return MDHIP_EINVAL;
+    const FrameIndex &fr = d->frames[f];
+    if (timestep) *timestep = fr.timestep;
+    if (natoms) *natoms = fr.natoms;
+    if (bounds6) memcpy(bounds6, fr.bounds, sizeof fr.bounds);
+    if (tilt3) memcpy(tilt3, fr.tilt, sizeof fr.tilt);
+    if (triclinic) *triclinic = fr.triclinic;
+    if (n_cols) *n_cols = fr.n_cols;
+    if (columns && columns_len > 0) {
+        strncpy(columns, fr.columns.c_str(), (size_t)columns_len - 1);
+        columns[columns_len - 1] = 0;
+    }
+    return MDHIP_OK;
+}
+
+int mdhip_dump_read(mdhip_dump *d, int64_t f, int n_sel, const int32_t *col_idx, int sort_col, double *out,
+                    int n_threads)
+{
+    if (!d || f < 0 || f >= (int64_t)d->frames.size() || n_sel < 0 || (n_sel && (!col_idx || !out)))
+        return MDHIP_EINVAL;
+    const FrameIndex &fr = d->frames[f];
+    for (int s = 0; s < n_sel; ++s)
+        if (col_idx[s] < 0 || col_idx[s] >= fr.n_cols) {
+            d->err = "mdhip_dump_read: column index out of range";
+            return MDHIP_EINVAL;
+        }
+    if (sort_col >= fr.n_cols) {
+        d->err = "mdhip_dump_read: sort column out of range";
+        return MDHIP_EINVAL;
+    }
+    const int64_t n = fr.natoms;
+    if (n == 0 || n_sel == 0) return MDHIP_OK;
+    const char *body = d->data + fr.body_begin, *body_end = d->data + fr.body_end;
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 64) n_threads = 64;
+    if (n < 4096) n_threads = 1;
+    // line offsets of the thread chunks (chunk boundaries by bytes, aligned to line starts, then counted)
+    std::vector<const char *> cstart(n_threads + 1);
+    std::vector<int64_t> cline(n_threads + 1, 0);
+    cstart[0] = body;
+    for (int t = 1; t < n_threads; ++t) {
+        const char *q = body + (size_t)((body_end - body) * (double)t / n_threads);
+        if (q < cstart[t - 1]) q = cstart[t - 1];
+        const char *le = line_end(q, body_end);
+        cstart[t] = le < body_end ? le + 1 : body_end;
+    }
+    cstart[n_threads] = body_end;
+    std::vector<int64_t> nl(n_threads, 0);
+    {
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_threads; ++t)
+            th.emplace_back([&, t] {
+                int64_t c = 0;
+                for (const char *q = cstart[t]; q < cstart[t + 1];) {
+                    const char *le = line_end(q, cstart[t + 1]);
+                    ++c;
+                    q = le < cstart[t + 1] ? le + 1 : cstart[t + 1];
+                }
+                nl[t] = c;
+            });
+        for (auto &x : th) x.join();
+    }
+    for (int t = 0; t < n_threads; ++t) cline[t + 1] = cline[t] + nl[t];
+    if (cline[n_threads] < n) {
+        d->err = "mdhip_dump_read: frame body has fewer lines than NUMBER OF ATOMS";
+        return MDHIP_EINVAL;
+    }
+    std::vector<double> vals((size_t)n * n_sel), keys(sort_col >= 0 ? (size_t)n : 0);
+    {
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_threads; ++t)
+            th.emplace_back([&, t] {
+                const int64_t l0 = cline[t], l1 = std::min<int64_t>(cline[t + 1], n);
+                if (l1 > l0)
+                    parse_lines(cstart[t], cstart[t + 1], l1 - l0, fr.n_cols, n_sel, col_idx, sort_col,
+                                vals.data() + (size_t)l0 * n_sel, sort_col >= 0 ? keys.data() + l0 : nullptr);
+            });
+        for (auto &x : th) x.join();
+    }
+    // destination row of every line: ascending key (stable), fast path when keys are a permutation of 1..n
+    std::vector<int64_t> dest(n);
+    if (sort_col < 0) {
+        for (int64_t k = 0; k < n; ++k) dest[k] = k;
+    } else {
+        bool perm = true;
+        std::vector<char> seen((size_t)n, 0);
+        for (int64_t k = 0; k < n && perm; ++k) {
+            const double v = keys[k];
+            const int64_t id = (int64_t)v;
+            if ((double)id != v || id < 1 || id > n || seen[(size_t)id - 1])
+                perm = false;
+            else {
+                seen[(size_t)id - 1] = 1;
+                dest[k] = id - 1;
+            }
+        }
+        if (!perm) {
+            std::vector<int64_t> order(n);
+            for (int64_t k = 0; k < n; ++k) order[k] = k;
+            std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return keys[a] < keys[b]; });
+            for (int64_t r = 0; r < n; ++r) dest[order[r]] = r;
+        }
+    }
+    // scatter into SoA planes out[s][row]
+    for (int64_t k = 0; k < n; ++k) {
+        const int64_t r = dest[k];
+        for (int s = 0; s < n_sel; ++s) out[(size_t)s * n + r] = vals[(size_t)k * n_sel + s];
+    }
+    return MDHIP_OK;
+}
+
+}  // extern "C"

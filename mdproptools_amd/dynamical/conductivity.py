@@ -19,7 +19,7 @@ import pandas as pd
 
 from .. import backend
 from ..common import constants
-from ..common.com_mols import atom_masses, molecule_layout
+from ..common.com_mols import molecule_layout
 from ..io import parse_lammps_dumps
 
 
@@ -89,18 +89,35 @@ class Conductivity:
         """Charge flux J[3, n_types, n_frames] in SI units; also fills `self.time` (conductivity.py:167-195)."""
         n_expected = len(glob.glob(f"{self.working_dir}/{self.filename}"))
         seg_off, mol_type, _ = molecule_layout(self.num_mols, self.num_atoms_per_mol)
+        from .. import io as mio
+
         vel, steps = [], []
         m = q = None
-        for dump in self.dumps:
-            data = dump.data.sort_values(by=["id"])
-            if seg_off[-1] != len(data):
+        if mio.USE_NATIVE_READER:
+            def wanted(names):
+                return ["vx", "vy", "vz", "q"] + (["type"] if self.mass else ["mass"])
+
+            frames = ((ts, planes[0:3], planes[3], planes[4]) for ts, _b, _l, _n, planes in
+                      mio.iter_native_frames(f"{self.working_dir}/{self.filename}", wanted, sort_by="id"))
+        else:
+            def from_pandas():
+                for dump in self.dumps:
+                    data = dump.data.sort_values(by=["id"])
+                    yield (dump.timestep,
+                           np.ascontiguousarray(data[["vx", "vy", "vz"]].to_numpy(dtype=np.float64).T),
+                           data["q"].to_numpy(dtype=np.float64),
+                           data["type" if self.mass else "mass"].to_numpy(dtype=np.float64))
+
+            frames = from_pandas()
+        for ts, v, qcol, tm in frames:
+            if seg_off[-1] != v.shape[1]:
                 raise ValueError(f"Length of values ({int(seg_off[-1])}) does not match length of index "
-                                 f"({len(data)})")
+                                 f"({v.shape[1]})")
             if m is None:
-                m = atom_masses(data, self.mass)
-                q = data["q"].to_numpy(dtype=np.float64)
-            vel.append(np.ascontiguousarray(data[["vx", "vy", "vz"]].to_numpy(dtype=np.float64).T))
-            steps.append(dump.timestep * constants.TIME_CONVERSION[self.units])
+                m = np.asarray(self.mass, dtype=np.float64)[tm.astype(np.int64) - 1] if self.mass else tm
+                q = qcol
+            vel.append(np.ascontiguousarray(v))
+            steps.append(ts * constants.TIME_CONVERSION[self.units])
         j = np.zeros((3, len(self.num_mols), max(n_expected, len(vel))))
         if vel:
             flux = backend.charge_flux(np.stack(vel), m, q, seg_off, (mol_type - 1).astype(np.int32),

@@ -92,39 +92,74 @@ class Diffusion:
     # ------------------------------------------------------------------------------------------
     def _entity_frames(self, filename, msd_type, num_mols, num_atoms_per_mol, mass):
         """Parse every frame and reduce it to entity coordinates [3, E] in LAMMPS length units."""
+        from .. import io as mio
+
+        if msd_type not in ("allatom", "com"):
+            raise ValueError("msd_type must be 'allatom' or 'com'.")
         times, planes = [], []
-        ids = None
-        atom_planes, atom_mass, seg = [], None, None
-        for dump in parse_lammps_dumps(f"{self.outputs_dir}/{filename}"):
-            assert "id" in dump.data.columns, "Missing atom id's in dump file."
-            dump.data = dump.data.sort_values(by=["id"])
-            dump.data.reset_index(inplace=True)
-            dump = self._prepare_unwrapped_coords(dump)
-            xyz = np.ascontiguousarray(dump.data[_COORDS].to_numpy(dtype=np.float64).T)
-            if msd_type == "allatom":
-                if ids is None:
-                    ids = dump.data["id"].to_numpy()
-                planes.append(xyz)
-            elif msd_type == "com":
-                if seg is None:
-                    seg = molecule_layout(num_mols, num_atoms_per_mol)
-                    if seg[0][-1] != len(dump.data):
-                        raise ValueError(f"Length of values ({int(seg[0][-1])}) does not match length "
-                                         f"of index ({len(dump.data)})")
-                m = atom_masses(dump.data, mass)
+        ids = atom_mass = None
+        for step, names, cols in self._frame_columns(f"{self.outputs_dir}/{filename}", msd_type, mass,
+                                                     mio.USE_NATIVE_READER):
+            if ids is None:
+                ids = cols["id"]
+            planes.append(np.ascontiguousarray(np.stack([cols["xu"], cols["yu"], cols["zu"]])))
+            if msd_type == "com":
+                m = cols["mass"] if not mass else np.asarray(mass, dtype=np.float64)[cols["type"].astype(np.int64) - 1]
                 if atom_mass is None:
                     atom_mass = m
                 elif not np.array_equal(atom_mass, m):
                     raise ValueError("atom masses change between frames")
-                atom_planes.append(xyz)
-            else:
-                raise ValueError("msd_type must be 'allatom' or 'com'.")
-            times.append(dump.timestep * self.timestep * constants.TIME_CONVERSION[self.units])
+            times.append(step * self.timestep * constants.TIME_CONVERSION[self.units])
         times = np.asarray(times, dtype=np.float64)
         if msd_type == "com":
-            com, seg_mass, _ = backend.segment_com(np.stack(atom_planes), atom_mass, seg[0])
+            seg = molecule_layout(num_mols, num_atoms_per_mol)
+            if planes and seg[0][-1] != planes[0].shape[1]:
+                raise ValueError(f"Length of values ({int(seg[0][-1])}) does not match length "
+                                 f"of index ({planes[0].shape[1]})")
+            com, seg_mass, _ = backend.segment_com(np.stack(planes), atom_mass, seg[0])
             return times, com, dict(type=seg[1], mol_id=seg[2], mass=seg_mass)
         return times, np.stack(planes), dict(id=ids)
+
+    def _frame_columns(self, pattern, msd_type, mass, native):
+        """Yields (timestep, column names, {name: id-sorted float64 column}) with xu, yu, zu present
+        (made from x + ix*L when they were not dumped, diffusion.py:62-81)."""
+        from .. import io as mio
+
+        def wanted(names):
+            assert "id" in names, "Missing atom id's in dump file."
+            sel = ["id"]
+            if "zu" in names:
+                sel += ["xu", "yu", "zu"]
+            else:
+                assert "z" in names, "Missing wrapped and unwrapped coordinates (x y z xu yu zu)"
+                assert "iz" in names, (
+                    "Missing unwrapped coordinates (xu yu zu) and box location (ix iy iz) for converting "
+                    "wrapped coordinates (x y z) into unwrapped coordinates. ")
+                sel += ["x", "y", "z", "ix", "iy", "iz"]
+            if msd_type == "com":
+                if not mass:
+                    assert "mass" in names, "Missing atom masses in dump file."
+                    sel.append("mass")
+                else:
+                    sel.append("type")
+            return sel
+
+        if native:
+            for ts, bounds, _lengths, names, planes in mio.iter_native_frames(pattern, wanted, sort_by="id"):
+                cols = dict(zip(wanted(names), planes))
+                if "zu" not in cols:
+                    for k, axis in enumerate("xyz"):
+                        cols[axis + "u"] = cols[axis] + cols["i" + axis] * (bounds[k][1] - bounds[k][0])
+                yield ts, names, cols
+            return
+        for dump in parse_lammps_dumps(pattern):
+            names = list(dump.data.columns)
+            sel = wanted(names)
+            dump.data = dump.data.sort_values(by=["id"])
+            dump.data.reset_index(inplace=True)
+            dump = self._prepare_unwrapped_coords(dump)
+            want = set(sel) | {"xu", "yu", "zu"}
+            yield dump.timestep, names, {c: dump.data[c].to_numpy(dtype=np.float64) for c in want}
 
     def get_msd_from_dump(self, filename, msd_type="com", num_mols=None, num_atoms_per_mol=None, mass=None,
                           com_drift=False, avg_interval=False, tao_coeff=4):

@@ -27,10 +27,14 @@ needs SoA float64 planes (it skips the DataFrame entirely).
 
 import glob
 import io as _io
+import os
 import re
 
 import numpy as np
 import pandas as pd
+
+
+USE_NATIVE_READER = True  # drop-in functions read dumps through libmdhip.so's reader (same doubles as pandas)
 
 
 class _Lattice:
@@ -158,6 +162,88 @@ def parse_lammps_log(filename="log.lammps"):
         df = pd.read_csv(_io.StringIO("".join(block)), sep=r"\s+")
         frames.append(df)
     return frames
+
+
+class NativeDumpFile:
+    """One dump file opened by the native reader of libmdhip.so (mmap + frame index, host only)."""
+
+    def __init__(self, path):
+        import ctypes as C
+
+        from . import _lib
+
+        self._C, self._lib = C, _lib.load()
+        h = C.c_void_p()
+        rc = self._lib.mdhip_dump_open(str(path).encode(), C.byref(h))
+        if rc != 0:
+            raise OSError("cannot read dump %s: %s" % (path, (self._lib.mdhip_dump_error(None) or b"").decode()))
+        self._h = h
+        self.n_frames = int(self._lib.mdhip_dump_n_frames(h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mdhip_dump_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def header(self, f):
+        """(timestep, natoms, bounds [3,2] with the tilt correction applied, tilt or None, columns)."""
+        C = self._C
+        ts, na, tri, nc = C.c_int64(), C.c_int64(), C.c_int(), C.c_int()
+        b6, t3 = (C.c_double * 6)(), (C.c_double * 3)()
+        buf = C.create_string_buffer(4096)
+        rc = self._lib.mdhip_dump_frame_info(self._h, f, C.byref(ts), C.byref(na), b6, t3, C.byref(tri),
+                                             C.byref(nc), buf, 4096)
+        if rc != 0:
+            raise IndexError("frame %d" % f)
+        bounds = np.array(list(b6)).reshape(3, 2)
+        tilt = None
+        if tri.value:
+            xy, xz, yz = tilt = list(t3)
+            bounds[0, 0] -= min(0.0, xy, xz, xy + xz)
+            bounds[0, 1] -= max(0.0, xy, xz, xy + xz)
+            bounds[1, 0] -= min(0.0, yz)
+            bounds[1, 1] -= max(0.0, yz)
+        return int(ts.value), int(na.value), bounds, tilt, buf.value.decode().split()
+
+    def read(self, f, columns, sort_by=None, n_threads=0):
+        """Columns (names) of frame f as planes [len(columns), natoms], rows ordered by `sort_by`."""
+        C = self._C
+        ts, na, bounds, tilt, names = self.header(f)
+        idx = np.array([names.index(c) for c in columns], dtype=np.int32)
+        out = np.empty((len(columns), na), dtype=np.float64)
+        sort_col = names.index(sort_by) if sort_by is not None else -1
+        rc = self._lib.mdhip_dump_read(self._h, f, len(idx), idx.ctypes.data_as(C.POINTER(C.c_int32)), sort_col,
+                                       out.ctypes.data_as(C.POINTER(C.c_double)),
+                                       int(n_threads) or min(16, os.cpu_count() or 1))
+        if rc != 0:
+            raise ValueError((self._lib.mdhip_dump_error(self._h) or b"").decode())
+        return out
+
+
+def iter_native_frames(file_pattern, columns, sort_by="id", n_threads=0):
+    """
+    Frames of every file matching `file_pattern` (same ordering rule as parse_lammps_dumps) through the
+    native reader: yields (timestep, bounds [3,2], box lengths (lx,ly,lz), columns present, planes
+    [len(columns), natoms]). `columns` is a list of names or a callable (names present -> list of names).
+    A ValueError is raised for a requested column the frame does not have.
+    """
+    for fname in _sorted_matches(file_pattern):
+        nd = NativeDumpFile(fname)
+        try:
+            for f in range(nd.n_frames):
+                ts, na, bounds, tilt, names = nd.header(f)
+                want = columns(names) if callable(columns) else columns
+                planes = nd.read(f, want, sort_by=sort_by if sort_by in names else None, n_threads=n_threads)
+                lengths = LammpsBox(bounds.tolist(), tilt).to_lattice().lengths
+                yield ts, bounds, lengths, names, planes
+        finally:
+            nd.close()
 
 
 def read_dump_arrays(file_pattern, columns, sort_by_id=True):

@@ -56,7 +56,7 @@ def _initialize(r_cut, bin_size, filename, partial_relations):
     else:
         num_bins = int(r_cut / bin_size)
         radii = (np.arange(num_bins) + 0.5) * bin_size
-    dumps = list(parse_lammps_dumps(filename))
+    dumps = _load_frames(filename)
     return dumps, num_bins, radii, len(dumps), len(partial_relations[0])
 
 
@@ -174,18 +174,32 @@ def _save_cn(relation_matrix, path_or_buff, cn_sum, save_mode):
 
 
 class _Frame:
-    """One parsed frame reduced to what the pair loops need (rdf_cn.py:183-194)."""
+    """One parsed frame reduced to what the pair loops need (rdf_cn.py:183-194): id-sorted ids, types,
+    xyz planes [3,N] and the box edge lengths."""
 
     __slots__ = ("timestep", "ids", "types", "xyz", "lengths")
 
-    def __init__(self, dump):
-        _say("The timestep of the current file is: " + str(dump.timestep))
+    def __init__(self, timestep, ids, types, xyz, lengths):
+        _say("The timestep of the current file is: " + str(timestep))
+        self.timestep, self.ids, self.types, self.xyz, self.lengths = timestep, ids, types, xyz, lengths
+
+    @classmethod
+    def from_dump(cls, dump):
         tbl = dump.data[["id", "type", "x", "y", "z"]].sort_values("id").to_numpy(dtype=np.float64)
-        self.timestep = dump.timestep
-        self.ids = tbl[:, 0]
-        self.types = tbl[:, 1]
-        self.xyz = np.ascontiguousarray(tbl[:, 2:5].T)
-        self.lengths = dump.box.to_lattice().lengths
+        return cls(dump.timestep, tbl[:, 0], tbl[:, 1], np.ascontiguousarray(tbl[:, 2:5].T),
+                   dump.box.to_lattice().lengths)
+
+
+def _load_frames(filename):
+    """Every frame of `filename` (file or '*' pattern, numeric order). The native reader of libmdhip.so
+    produces the same doubles as the pandas-based one (tests/test_dump_reader_cpu.py), ~10x faster."""
+    from .. import io as mio
+
+    if mio.USE_NATIVE_READER and (isinstance(filename, str) or hasattr(filename, "__fspath__")):
+        return [_Frame(ts, planes[0], planes[1], np.ascontiguousarray(planes[2:5]), lengths)
+                for ts, _b, lengths, _names, planes in
+                mio.iter_native_frames(str(filename), ["id", "type", "x", "y", "z"], sort_by="id")]
+    return [_Frame.from_dump(d) for d in parse_lammps_dumps(filename)]
 
 
 def _batches(frames):
@@ -230,7 +244,7 @@ def calc_atomic_rdf(r_cut, bin_size, num_types, mass, partial_relations, filenam
     relation_matrix = np.asarray(partial_relations).transpose()
     rdf_full_sum = np.zeros(num_bins)
     rdf_part_sum = np.zeros((num_relations, num_bins))
-    frames = [_Frame(d) for d in dumps]
+    frames = dumps
     dropped = 0
     for batch in _batches(frames):
         start = timer()
@@ -267,7 +281,7 @@ def calc_atomic_cn(r_cut, bin_size, num_types, mass, partial_relations, filename
     altered = bool(num_mols and num_atoms_per_mol)
     relation_matrix = np.asarray(partial_relations).transpose()
     cn_sum = np.zeros(num_relations)
-    frames = [_Frame(d) for d in dumps]
+    frames = dumps
     for batch in _batches(frames):
         labels = [(_calc_atom_type(f.ids, num_mols, num_atoms_per_mol) if altered else f.types) for f in batch]
         props = [_calc_props(f.lengths, lab, lab, num_types, mass, partial_relations, altered,
@@ -312,7 +326,7 @@ def calc_molecular_rdf(r_cut, bin_size, num_types, mass, partial_relations, file
     dumps, num_bins, radii, num_files, num_relations = _initialize(r_cut, bin_size, filename, partial_relations)
     relation_matrix = np.asarray(partial_relations).transpose()
     rdf_part_sum = np.zeros((num_relations, num_bins))
-    frames = [_Frame(d) for d in dumps]
+    frames = dumps
     dropped = 0
     for batch in _batches(frames):
         xyz, sites, seg_type = _molecular_inputs(batch, num_mols, num_atoms_per_mol, mass)
@@ -353,7 +367,7 @@ def calc_molecular_cn(r_cut, bin_size, num_types, mass, partial_relations, filen
     dumps, _, _, num_files, num_relations = _initialize(r_cut, bin_size, filename, partial_relations)
     relation_matrix = np.asarray(partial_relations).transpose()
     cn_sum = np.zeros(num_relations)
-    frames = [_Frame(d) for d in dumps]
+    frames = dumps
     for batch in _batches(frames):
         xyz, sites, seg_type = _molecular_inputs(batch, num_mols, num_atoms_per_mol, mass)
         props = [_calc_props(f.lengths, f.types, seg_type, num_types, mass, partial_relations, False)
@@ -381,7 +395,7 @@ def calc_intermolecular_rdf(r_cut, bin_size, num_types, mass, partial_relations,
     dumps, num_bins, radii, num_files, num_relations = _initialize(r_cut, bin_size, filename, partial_relations)
     relation_matrix = np.asarray(partial_relations).transpose()
     rdf_part_sum = np.zeros((num_relations, num_bins))
-    frames = [_Frame(d) for d in dumps]
+    frames = dumps
     for batch in _batches(frames):
         _, sites, seg_type = _molecular_inputs(batch, num_mols, num_atoms_per_mol, mass)
         props = [_calc_props(f.lengths, seg_type, seg_type, num_types, mass, partial_relations, False)

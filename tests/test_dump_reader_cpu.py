@@ -1,0 +1,101 @@
+"""CPU-only: the native LAMMPS dump reader of libmdhip.so against the pandas-based reader (what the
+reference sees through pymatgen) and against Python's correctly rounded float()."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from mdproptools_amd import io as mio
+
+
+def _write_golden(tmp, g):
+    cols = list(g["columns"])
+    for s, b, t in zip(g["steps"], g["bounds"], g["frames"]):
+        mio.write_dump(os.path.join(tmp, "dump.nvt.%d.dump" % s), s, b, cols, t)
+    return cols
+
+
+@pytest.mark.parametrize("name", ["small_md.npz", "c1_rdf.npz"])
+def test_native_equals_pandas_on_golden_frames(tmp_path, name):
+    g = load_golden(name)
+    cols = _write_golden(str(tmp_path), g)
+    pat = str(tmp_path / "dump.nvt.*.dump")
+    ref = list(mio.parse_lammps_dumps(pat))
+    nat = list(mio.iter_native_frames(pat, cols, sort_by="id"))
+    assert len(ref) == len(nat) == len(g["steps"])
+    for d, (ts, bounds, lengths, names, planes) in zip(ref, nat):
+        assert ts == d.timestep and names == list(d.data.columns)
+        np.testing.assert_array_equal(bounds, np.array(d.box.bounds))
+        assert lengths == d.box.to_lattice().lengths
+        expect = d.data.sort_values("id")[cols].to_numpy(dtype=np.float64).T
+        np.testing.assert_array_equal(planes, expect)  # bit-identical to what the reference parses
+
+
+def test_multi_frame_file_subset_threads_and_key_paths(tmp_path):
+    rng = np.random.default_rng(3)
+    path = tmp_path / "traj.lammpstrj"
+    cols = ["id", "type", "x", "y", "z", "vx"]
+    tables = []
+    with open(path, "wt") as fh:
+        for step, n in [(0, 5000), (10, 5000), (20, 7)]:
+            ids = rng.permutation(n) + 1
+            if step == 20:
+                ids = np.array([70, 3, 3, 11, 1000, 5, 8])  # not a permutation, with a tie -> stable sort
+            tbl = np.column_stack([ids, rng.integers(1, 4, n), rng.normal(0, 30, (n, 3)).round(4),
+                                   rng.normal(0, 1e-3, n)])
+            tables.append(tbl)
+            fh.write("ITEM: TIMESTEP\n%d\nITEM: NUMBER OF ATOMS\n%d\nITEM: BOX BOUNDS pp pp pp\n" % (step, n))
+            fh.write("-1.5e+00 2.85e1\n0 30\n0.25 30.25\nITEM: ATOMS " + " ".join(cols) + "\n")
+            for r in tbl:
+                fh.write("%d %d %.4f %.4f %.4f %.10e\n" % (r[0], r[1], r[2], r[3], r[4], r[5]))
+    nd = mio.NativeDumpFile(path)
+    assert nd.n_frames == 3
+    ts, na, bounds, tilt, names = nd.header(1)
+    assert (ts, na, names, tilt) == (10, 5000, cols, None)
+    np.testing.assert_array_equal(bounds, [[-1.5, 28.5], [0, 30], [0.25, 30.25]])
+    ref = list(mio.parse_lammps_dumps(str(path)))
+    for f in range(3):
+        want = ref[f].data.sort_values("id", kind="stable")[["vx", "x", "id", "x"]].to_numpy(dtype=np.float64).T
+        for threads in (1, 8):
+            got = nd.read(f, ["vx", "x", "id", "x"], sort_by="id", n_threads=threads)
+            np.testing.assert_array_equal(got, want)
+        unsorted = nd.read(f, ["id", "z"], sort_by=None)
+        np.testing.assert_array_equal(unsorted, ref[f].data[["id", "z"]].to_numpy(dtype=np.float64).T)
+    with pytest.raises(ValueError):
+        nd.read(0, ["nope"])
+    nd.close()
+    with pytest.raises(OSError):
+        mio.NativeDumpFile(tmp_path / "missing.dump")
+
+
+def test_numbers_are_correctly_rounded(tmp_path):
+    """Every field equals Python float() of its text, also for mantissas longer than pandas handles exactly."""
+    texts = ["0", "-0.0", "1", "5.82479", "-0.000259612", "4.0882558190751794e-01", "4.9591174418091420e+01",
+             "1e22", "1e23", "123456789012345678", "0.1234567890123456789012345", "9007199254740993",
+             "2.2250738585072014e-308", "1.7976931348623157e308", "7.2e-310", "+3.5E+2", "00012.500", ".5", "5.",
+             "6.02214076e23", "1.602176634e-19", "299792458", "3.141592653589793238462643383279"]
+    rng = np.random.default_rng(4)
+    texts += ["%.17g" % v for v in rng.normal(0, 100, 300)] + ["%.6g" % v for v in rng.normal(0, 100, 300)]
+    path = tmp_path / "n.dump"
+    with open(path, "wt") as fh:
+        fh.write("ITEM: TIMESTEP\n1\nITEM: NUMBER OF ATOMS\n%d\nITEM: BOX BOUNDS pp pp pp\n0 1\n0 1\n0 1\n" % len(texts))
+        fh.write("ITEM: ATOMS id v\n")
+        for k, t in enumerate(texts):
+            fh.write("%d %s\n" % (k + 1, t))
+    nd = mio.NativeDumpFile(path)
+    got = nd.read(0, ["v"], sort_by="id")[0]
+    want = np.array([float(t) for t in texts])
+    assert got.tobytes() == want.tobytes()
+    nd.close()
+
+
+def test_triclinic_header(tmp_path):
+    path = tmp_path / "t.dump"
+    with open(path, "wt") as fh:
+        fh.write("ITEM: TIMESTEP\n7\nITEM: NUMBER OF ATOMS\n1\nITEM: BOX BOUNDS xy xz yz pp pp pp\n"
+                 "-1.0 12.0 2.0\n0.0 10.0 -1.0\n0.0 9.0 0.5\nITEM: ATOMS id x y z\n1 0.5 0.5 0.5\n")
+    (ref,) = list(mio.parse_lammps_dumps(str(path)))
+    ((ts, bounds, lengths, names, planes),) = list(mio.iter_native_frames(str(path), ["x", "y", "z"]))
+    np.testing.assert_array_equal(bounds, np.array(ref.box.bounds))
+    assert lengths == ref.box.to_lattice().lengths and ts == 7
