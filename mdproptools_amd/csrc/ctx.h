@@ -27,6 +27,15 @@ enum WsSlot {
     WS_AUX1,
     WS_AUX2,
     WS_AUX3,
+    WS_SORT_XYZ,   // spatially sorted coordinates (culled pair path)
+    WS_SORT_TYPE,
+    WS_KEYS,
+    WS_CELLS,
+    WS_BBOX,
+    WS_LIST,
+    WS_LISTCNT,
+    WS_GSPH,
+    WS_WSPH,
     WS_COUNT
 };
 
@@ -52,6 +61,7 @@ struct mdhip_ctx {
     int opt_rdf_unroll = 8;   // j atoms per step of the fast kernel (4, 8, 16)
     int opt_rdf_jsplit = 0;   // 0 = auto
     int opt_rdf_fpb = 0;      // frames per block of the fast kernel, 0 = auto
+    int opt_rdf_cull = -1;    // spatial culling of tile pairs: -1 = auto, 0 = never, 1 = always (when applicable)
     int opt_rdf_slots = 16;   // replicas of the frame-summed histogram in HBM
     int opt_xcorr_tile = 0;
 };

@@ -92,6 +92,7 @@ int mdhip_create(mdhip_ctx **out, int device)
     if (const char *v = getenv("MDHIP_RDF_UNROLL")) ctx->opt_rdf_unroll = atoi(v);
     if (const char *v = getenv("MDHIP_RDF_JSPLIT")) ctx->opt_rdf_jsplit = atoi(v);
     if (const char *v = getenv("MDHIP_RDF_FPB")) ctx->opt_rdf_fpb = atoi(v);
+    if (const char *v = getenv("MDHIP_RDF_CULL")) ctx->opt_rdf_cull = atoi(v);
     *out = ctx;
     return MDHIP_OK;
 }
@@ -147,6 +148,8 @@ int mdhip_set_option(mdhip_ctx *ctx, const char *key, int value)
         ctx->opt_rdf_variant = value;
     else if (!strcmp(key, "rdf_unroll"))
         ctx->opt_rdf_unroll = value;
+    else if (!strcmp(key, "rdf_cull"))
+        ctx->opt_rdf_cull = value;
     else if (!strcmp(key, "rdf_fpb"))
         ctx->opt_rdf_fpb = value;
     else if (!strcmp(key, "rdf_jsplit"))

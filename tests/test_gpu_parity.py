@@ -394,3 +394,61 @@ def test_c2_full_size_properties(B):
     sv = O.shell_volume(0.05, 400)
     gr = full.sum(axis=0) / F / (n * (n / L ** 3) * sv)
     assert abs(gr[40:].mean() - 1.0) < 2e-3
+
+
+# ------------------------------------------------------------------ spatial culling (cell-list variant)
+def test_culled_path_equals_dense_and_oracle(B):
+    """Morton-sorted tiles + bounding-box culling must give the same integers as the dense sweep."""
+    from mdproptools_amd._lib import Context
+
+    rng = np.random.default_rng(77)
+    F, n = 3, 2600  # 11 tiles
+    boxes = np.array([[40.0, 42.0, 44.0], [41.0, 41.0, 41.0], [39.5, 43.0, 40.0]])
+    xyz = np.stack([rng.uniform(0, 1, (3, n)) * boxes[f][:, None] + 2.0 for f in range(F)])
+    stray = rng.choice(n, 100, replace=False)
+    xyz[:, :, stray] += (rng.integers(-2, 3, (F, 3, 100)) * boxes[:, :, None])  # atoms outside the box
+    ty = rng.integers(1, 4, (F, n)).astype(np.int32)  # per-frame types
+    rel = np.array([[1, 1], [1, 2], [2, 3], [3, 3]])
+    cuts = [3.0, 4.5, 6.0, 7.5]
+    res = {}
+    for cull in (0, 1):
+        ctx = Context(0)
+        ctx.set_option("rdf_cull", cull)
+        for jsplit in (1, 3):
+            ctx.set_option("rdf_jsplit", jsplit)
+            res[(cull, jsplit)] = (B.rdf_loop(xyz, ty, boxes, rel, 7.5, 0.05, 150, ctx=ctx),
+                                   B.rdf_loop(xyz, ty, boxes, rel, 7.5, 0.05, 150, per_frame=False, ctx=ctx),
+                                   B.cn_loop(xyz, ty, boxes, rel, cuts, ctx=ctx))
+        ctx.close()
+    ref = res[(0, 1)]
+    for f in range(F):
+        cf, cp, cov = C.rdf_pairs(xyz[f], ty[f], rel, boxes[f], 7.5 * 7.5, 0.05, 150)
+        np.testing.assert_array_equal(ref[0][0][f], cf)
+        np.testing.assert_array_equal(ref[0][1][f], cp)
+        np.testing.assert_array_equal(ref[2][f], C.cn_pairs(xyz[f], ty[f], rel, boxes[f], [c * c for c in cuts]))
+    for key, val in res.items():
+        np.testing.assert_array_equal(val[0][0], ref[0][0])
+        np.testing.assert_array_equal(val[0][1], ref[0][1])
+        assert val[0][2] == ref[0][2]
+        np.testing.assert_array_equal(val[1][0], ref[0][0].sum(axis=0))
+        np.testing.assert_array_equal(val[1][1], ref[0][1].sum(axis=0))
+        np.testing.assert_array_equal(val[2], ref[2])
+
+
+def test_culled_path_large_box_auto(B):
+    """BASELINE C3 geometry at reduced N (same density: L = 48.3 A for 10k atoms, r_cut 6.8): the
+    automatic choice takes the culled path; result against the C oracle."""
+    from mdproptools_amd import synth
+
+    n, L = 10_000, 48.27
+    xyz = synth.rdf_frames(n, range(2), L, 3)
+    ty = synth.rdf_types(n)
+    rel = np.array(synth.ALL_PAIRS_4)
+    box = np.full((2, 3), L)
+    full, part, ov = B.rdf_loop(xyz, ty, box, rel, 6.8, 0.05, 136)
+    cn = B.cn_loop(xyz, ty, box, rel, synth.cn_cutoffs(10))
+    for f in range(2):
+        cf, cp, _ = C.rdf_pairs(xyz[f], ty, rel, box[f], 6.8 * 6.8, 0.05, 136)
+        np.testing.assert_array_equal(full[f], cf)
+        np.testing.assert_array_equal(part[f], cp)
+        np.testing.assert_array_equal(cn[f], C.cn_pairs(xyz[f], ty, rel, box[f], [c * c for c in synth.cn_cutoffs(10)]))
