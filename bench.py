@@ -149,12 +149,13 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    kernel_ms, launches = 0.0, 0
+    kernel_ms, aux_ms, launches = 0.0, 0.0, 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         full, part = step()
         ms, nl = ctx.last_kernel_ms()
         kernel_ms += ms
+        aux_ms += ctx.last_aux_ms()
         launches += nl
     fence()
     elapsed = time.perf_counter() - t0
@@ -183,8 +184,9 @@ def main():
                        "pairs_per_step_per_gpu": pairs_per_step, "kernel_variant": ctx_variant(ctx, args)},
             "roofline": {
                 "bound": "fp64-valu (not hbm/mfma: 28 B and 18 unfused FP64 ops per atom per pair sweep)",
-                "kernel": "pair_hist_fast_kernel<tri,8>" if ctx_variant(ctx, args) == 1 else "pair_hist_kernel<tri>",
-                "launch_ms": kdur * 1e3,
+                "kernel": ("pair_hist_fast_kernel<true, 8, 0, %s>" % ("true" if aux_ms > 0 else "false"))
+                if ctx_variant(ctx, args) == 1 else "pair_hist_kernel<true>",
+                "launch_ms": kdur * 1e3, "prepass_ms_per_step": aux_ms / args.steps,
                 "achieved": alg_ops / kdur / 1e12, "peak": FP64_NONFUSED_PEAK / 1e12, "unit": "TFLOP/s",
                 "frac": alg_ops / kdur / FP64_NONFUSED_PEAK,
                 "hbm_algorithmic_GBps": 28.0 * n * F / kdur / 1e9, "hbm_peak_GBps": HBM_PEAK / 1e9,

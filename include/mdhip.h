@@ -56,11 +56,15 @@ int mdhip_sync(mdhip_ctx *ctx);
 /* Device time (ms, hipEvent pair on the launch stream) of the dominant kernel of the last call,
  * and the number of times that kernel was launched by that call. */
 double mdhip_last_kernel_ms(mdhip_ctx *ctx, int *n_launches);
+/* Device time (ms) of the preparation kernels of the last call that are not part of the dominant kernel
+ * (the spatial sort / tile lists of the culled pair path); 0 when there were none. */
+double mdhip_last_aux_ms(mdhip_ctx *ctx);
 /* Writes the device name (e.g. "gfx950...") into buf. */
 int mdhip_device_name(mdhip_ctx *ctx, char *buf, int buflen);
 /* Kernel tuning knob, for A/B measurements only; results never depend on it.
- * keys: "rdf_variant" (1 = fast pair kernel, default; 0 = edge-table lookup per pair), "rdf_unroll",
- * "rdf_jsplit", "rdf_fpb", "rdf_slots", "xcorr_tile". */
+ * keys: "rdf_variant" (1 = fast pair kernel, default; 0 = edge-table lookup per pair), "rdf_cull"
+ * (-1 auto, 0 dense sweep, 1 spatially culled sweep), "rdf_jsplit", "rdf_fpb", "rdf_batch", "rdf_slots",
+ * "xcorr_tile". */
 int mdhip_set_option(mdhip_ctx *ctx, const char *key, int value);
 
 /* ---- R2/R3 binning table ------------------------------------------------ */

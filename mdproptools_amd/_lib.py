@@ -32,6 +32,7 @@ PROTOTYPES = {
     "mdhip_set_stream": (C.c_int, [vp, vp]),
     "mdhip_sync": (C.c_int, [vp]),
     "mdhip_last_kernel_ms": (C.c_double, [vp, C.POINTER(C.c_int)]),
+    "mdhip_last_aux_ms": (C.c_double, [vp]),
     "mdhip_device_name": (C.c_int, [vp, C.c_char_p, C.c_int]),
     "mdhip_set_option": (C.c_int, [vp, C.c_char_p, C.c_int]),
     "mdhip_bin_edges": (C.c_int, [C.c_double, C.c_int, c_dp]),
@@ -181,6 +182,9 @@ class Context:
         n = C.c_int(0)
         ms = self.lib.mdhip_last_kernel_ms(self.h, C.byref(n))
         return float(ms), int(n.value)
+
+    def last_aux_ms(self):
+        return float(self.lib.mdhip_last_aux_ms(self.h))
 
 
 _default = {}

@@ -52,6 +52,7 @@ struct mdhip_ctx {
     std::string err;
     DevBuf ws[WS_COUNT];
     double last_ms = 0.0;
+    double last_aux_ms = 0.0;  // device time of the preparation kernels of the last call (e.g. spatial sort)
     int last_launches = 0;
     int cu_count = 256;
     size_t lds_max = 65536;
@@ -61,6 +62,7 @@ struct mdhip_ctx {
     int opt_rdf_unroll = 8;   // j atoms per step of the fast kernel (4, 8, 16)
     int opt_rdf_jsplit = 0;   // 0 = auto
     int opt_rdf_fpb = 0;      // frames per block of the fast kernel, 0 = auto
+    int opt_rdf_batch = 0;    // frames per batch of the pair path, 0 = auto (workspace-bounded)
     int opt_rdf_cull = -1;    // spatial culling of tile pairs: -1 = auto, 0 = never, 1 = always (when applicable)
     int opt_rdf_slots = 16;   // replicas of the frame-summed histogram in HBM
     int opt_xcorr_tile = 0;

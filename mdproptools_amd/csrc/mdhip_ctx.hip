@@ -134,6 +134,8 @@ double mdhip_last_kernel_ms(mdhip_ctx *ctx, int *n_launches)
     return ctx->last_ms;
 }
 
+double mdhip_last_aux_ms(mdhip_ctx *ctx) { return ctx ? ctx->last_aux_ms : 0.0; }
+
 int mdhip_device_name(mdhip_ctx *ctx, char *buf, int buflen)
 {
     if (!ctx || !buf || buflen <= 0) return MDHIP_EINVAL;
@@ -148,6 +150,8 @@ int mdhip_set_option(mdhip_ctx *ctx, const char *key, int value)
         ctx->opt_rdf_variant = value;
     else if (!strcmp(key, "rdf_unroll"))
         ctx->opt_rdf_unroll = value;
+    else if (!strcmp(key, "rdf_batch"))
+        ctx->opt_rdf_batch = value;
     else if (!strcmp(key, "rdf_cull"))
         ctx->opt_rdf_cull = value;
     else if (!strcmp(key, "rdf_fpb"))

@@ -117,13 +117,15 @@ def test_rdf_geometry_independence(B):
     rel = np.array([(a, b) for a in range(1, 5) for b in range(a, 5)])
     box = np.tile(L, (F, 1))
     ref = None
-    for jsplit, slots, variant, fpb in [(0, 16, 0, 0), (1, 1, 1, 1), (2, 3, 0, 0), (3, 8, 1, 3), (0, 16, 1, 0),
-                                        (1, 2, 1, 64)]:
+    for jsplit, slots, variant, fpb, batch in [(0, 16, 0, 0, 0), (1, 1, 1, 1, 0), (2, 3, 0, 0, 4), (3, 8, 1, 3, 0),
+                                               (0, 16, 1, 0, 5), (1, 2, 1, 64, 0)]:
         ctx = Context(0)
         ctx.set_option("rdf_jsplit", jsplit)
         ctx.set_option("rdf_slots", slots)
         ctx.set_option("rdf_variant", variant)
         ctx.set_option("rdf_fpb", fpb)
+        ctx.set_option("rdf_batch", batch)
+        ctx.set_option("rdf_cull", 0)
         for per_frame in (True, False):
             full, part, ov = B.rdf_loop(xyz, ty, box, rel, 12.0, 0.05, 240, per_frame=per_frame, ctx=ctx)
             if per_frame:
@@ -416,6 +418,7 @@ def test_culled_path_equals_dense_and_oracle(B):
         ctx.set_option("rdf_cull", cull)
         for jsplit in (1, 3):
             ctx.set_option("rdf_jsplit", jsplit)
+            ctx.set_option("rdf_batch", 2 if jsplit == 3 else 0)  # 3 frames in batches of 2 + 1
             res[(cull, jsplit)] = (B.rdf_loop(xyz, ty, boxes, rel, 7.5, 0.05, 150, ctx=ctx),
                                    B.rdf_loop(xyz, ty, boxes, rel, 7.5, 0.05, 150, per_frame=False, ctx=ctx),
                                    B.cn_loop(xyz, ty, boxes, rel, cuts, ctx=ctx))
