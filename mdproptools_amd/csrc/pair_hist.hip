@@ -726,7 +726,7 @@ __device__ __forceinline__ double interval_gap(double a0, double a1, double b0, 
     return g > 0.0 ? g : 0.0;
 }
 
-// list[f][I][*] = tiles J >= I whose boxes come within the cutoff of tile I's box; cnt[f][I]
+// list[f][I][*] = half-shell tiles J whose boxes come within the cutoff of tile I's box; cnt[f][I]
 __global__ __launch_bounds__(256) void cull_list_kernel(const double *__restrict__ bbox,
                                                         const double *__restrict__ box, int nT, double rc2_test,
                                                         unsigned short *__restrict__ list, int *__restrict__ cnt)
@@ -738,7 +738,12 @@ __global__ __launch_bounds__(256) void cull_list_kernel(const double *__restrict
     const double *bi = bbox + ((size_t)f * nT + I) * 6;
     const double Lx = box[3 * f], Ly = box[3 * f + 1], Lz = box[3 * f + 2];
     unsigned short *row = list + ((size_t)f * nT + I) * nT;
-    for (int J = I + threadIdx.x; J < nT; J += 256) {
+    // candidates = the half shell J = I, I+1, ..., I+S-1 (mod nT): every unordered tile pair belongs to
+    // exactly one row and all rows have about the same length (a plain J >= I scan would be triangular)
+    const int S = tri_shifts(nT, I);
+    for (int sft = threadIdx.x; sft < S; sft += 256) {
+        int J = I + sft;
+        J = J >= nT ? J - nT : J;
         const double *bj = bbox + ((size_t)f * nT + J) * 6;
         const double gx = interval_gap(bi[0], bi[3], bj[0], bj[3]) * Lx;
         const double gy = interval_gap(bi[1], bi[4], bj[1], bj[4]) * Ly;
