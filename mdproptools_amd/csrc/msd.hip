@@ -32,7 +32,9 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
-// grid (n_chunks, n_pairs). partial [n_pairs][n_chunks][4]
+// grid (n_chunks, n_pairs). partial [n_pairs][n_chunks][4]. VEC2: every lane handles two consecutive
+// entities with 16-byte loads (needs an even entity count and even chunk starts, checked by the host).
+template <bool VEC2>
 __global__ __launch_bounds__(MSD_THREADS) void msd_pairs_kernel(
     const double *__restrict__ r, long long n_ent, double scale, const int *__restrict__ pairs,
     const Chunk *__restrict__ chunks, int n_chunks, double *__restrict__ partial,
@@ -44,27 +46,45 @@ __global__ __launch_bounds__(MSD_THREADS) void msd_pairs_kernel(
     const double *r0 = r + (size_t)pairs[2 * p] * 3 * n_ent;
     const double *r1 = r + (size_t)pairs[2 * p + 1] * 3 * n_ent;
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    auto one = [&](long long e, double x1, double y1, double z1, double x0, double y0, double z0) {
+        // diffusion.py:201-203 scales first, diffusion.py:214 differences, then squares
+        const double dx = x1 * scale - x0 * scale;
+        const double dy = y1 * scale - y0 * scale;
+        const double dz = z1 * scale - z0 * scale;
+        const double dx2 = dx * dx, dy2 = dy * dy, dz2 = dz * dz;
+        const double tot = (dx2 + dy2) + dz2;  // diffusion.py:215
+        s0 += dx2;
+        s1 += dy2;
+        s2 += dz2;
+        s3 += tot;
+        if (per_entity) {
+            double4 *pe = reinterpret_cast<double4 *>(per_entity + ((size_t)p * n_ent + e) * 4);
+            *pe = make_double4(dx2, dy2, dz2, tot);
+        }
+    };
+    if (VEC2) {
 #pragma unroll
-    for (int u = 0; u < MSD_PER_THREAD; ++u) {
-        const long long e = ck.e0 + (long long)u * MSD_THREADS + threadIdx.x;
-        if (e < ck.e1) {
-            // diffusion.py:201-203 scales first, diffusion.py:214 differences, then squares
-            const double dx = r1[e] * scale - r0[e] * scale;
-            const double dy = r1[n_ent + e] * scale - r0[n_ent + e] * scale;
-            const double dz = r1[2 * n_ent + e] * scale - r0[2 * n_ent + e] * scale;
-            const double dx2 = dx * dx, dy2 = dy * dy, dz2 = dz * dz;
-            const double tot = (dx2 + dy2) + dz2;  // diffusion.py:215
-            s0 += dx2;
-            s1 += dy2;
-            s2 += dz2;
-            s3 += tot;
-            if (per_entity) {
-                double *pe = per_entity + ((size_t)p * n_ent + e) * 4;
-                pe[0] = dx2;
-                pe[1] = dy2;
-                pe[2] = dz2;
-                pe[3] = tot;
+        for (int u = 0; u < MSD_PER_THREAD / 2; ++u) {
+            const long long e = ck.e0 + 2 * ((long long)u * MSD_THREADS + threadIdx.x);
+            if (e + 1 < ck.e1) {
+                const double2 x1 = *reinterpret_cast<const double2 *>(r1 + e);
+                const double2 y1 = *reinterpret_cast<const double2 *>(r1 + n_ent + e);
+                const double2 z1 = *reinterpret_cast<const double2 *>(r1 + 2 * n_ent + e);
+                const double2 x0 = *reinterpret_cast<const double2 *>(r0 + e);
+                const double2 y0 = *reinterpret_cast<const double2 *>(r0 + n_ent + e);
+                const double2 z0 = *reinterpret_cast<const double2 *>(r0 + 2 * n_ent + e);
+                one(e, x1.x, y1.x, z1.x, x0.x, y0.x, z0.x);
+                one(e + 1, x1.y, y1.y, z1.y, x0.y, y0.y, z0.y);
+            } else if (e < ck.e1) {
+                one(e, r1[e], r1[n_ent + e], r1[2 * n_ent + e], r0[e], r0[n_ent + e], r0[2 * n_ent + e]);
             }
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < MSD_PER_THREAD; ++u) {
+            const long long e = ck.e0 + (long long)u * MSD_THREADS + threadIdx.x;
+            if (e < ck.e1)
+                one(e, r1[e], r1[n_ent + e], r1[2 * n_ent + e], r0[e], r0[n_ent + e], r0[2 * n_ent + e]);
         }
     }
     s0 = wave_sum(s0);
@@ -100,34 +120,51 @@ __global__ void msd_group_sum_kernel(const double *__restrict__ partial,
     sums[idx] = s;
 }
 
-// one lane per entity, windows walked in order with the previous kept frame in registers
+// one lane per (entity, slab of windows): windows are walked in order with the previous kept frame in
+// registers; blockIdx.y slabs give the chip enough lanes when there are few entities. part [slabs][E][4].
 __global__ __launch_bounds__(256) void msd_windows_kernel(const double *__restrict__ r,
-                                                          long long n_ent, long long n_frames,
-                                                          double scale, int tao,
-                                                          double *__restrict__ out)
+                                                          long long n_ent, long long n_kept,
+                                                          double scale, int tao, int n_slabs,
+                                                          double *__restrict__ part)
 {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_ent) return;
-    double px = r[e] * scale, py = r[n_ent + e] * scale, pz = r[2 * n_ent + e] * scale;
+    // kept frames k = 0..n_kept-1 are frames k*tao; window k pairs kept frame k with k-1, k = 1..n_kept-1
+    const long long n_win = n_kept - 1;
+    const long long per = (n_win + n_slabs - 1) / n_slabs;
+    const long long k0 = 1 + (long long)blockIdx.y * per;
+    long long k1 = k0 + per;
+    if (k1 > n_kept) k1 = n_kept;
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    for (long long t = tao; t < n_frames; t += tao) {
-        const double *rt = r + (size_t)t * 3 * n_ent;
-        const double x = rt[e] * scale, y = rt[n_ent + e] * scale, z = rt[2 * n_ent + e] * scale;
-        const double dx = x - px, dy = y - py, dz = z - pz;  // diffusion.py:232
-        const double dx2 = dx * dx, dy2 = dy * dy, dz2 = dz * dz;
-        s0 += dx2;
-        s1 += dy2;
-        s2 += dz2;
-        s3 += (dx2 + dy2) + dz2;  // diffusion.py:235
-        px = x;
-        py = y;
-        pz = z;
+    if (k0 < k1) {
+        const double *rp = r + (size_t)(k0 - 1) * tao * 3 * n_ent;
+        double px = rp[e] * scale, py = rp[n_ent + e] * scale, pz = rp[2 * n_ent + e] * scale;
+        for (long long k = k0; k < k1; ++k) {
+            const double *rt = r + (size_t)k * tao * 3 * n_ent;
+            const double x = rt[e] * scale, y = rt[n_ent + e] * scale, z = rt[2 * n_ent + e] * scale;
+            const double dx = x - px, dy = y - py, dz = z - pz;  // diffusion.py:232
+            const double dx2 = dx * dx, dy2 = dy * dy, dz2 = dz * dz;
+            s0 += dx2;
+            s1 += dy2;
+            s2 += dz2;
+            s3 += (dx2 + dy2) + dz2;  // diffusion.py:235
+            px = x;
+            py = y;
+            pz = z;
+        }
     }
-    double *o = out + (size_t)e * 4;
-    o[0] = s0;
-    o[1] = s1;
-    o[2] = s2;
-    o[3] = s3;
+    double4 *o = reinterpret_cast<double4 *>(part + ((size_t)blockIdx.y * n_ent + e) * 4);
+    *o = make_double4(s0, s1, s2, s3);
+}
+
+__global__ void msd_windows_sum_kernel(const double *__restrict__ part, long long n_ent, int n_slabs,
+                                       double *__restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_ent * 4) return;
+    double s = 0.0;
+    for (int k = 0; k < n_slabs; ++k) s += part[(size_t)k * n_ent * 4 + i];
+    out[i] = s;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -338,9 +375,17 @@ int mdhip_msd_pairs(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const doubl
     }
     MD_HIP(hipStreamSynchronize(ctx->stream));  // host tables are stack/vector memory
     KernelTimer timer(ctx);
-    hipLaunchKernelGGL(msd_pairs_kernel, dim3((unsigned)n_chunks, (unsigned)n_pairs),
-                       dim3(MSD_THREADS), 0, ctx->stream, d_r, (long long)n_ent, scale, d_pairs,
-                       d_chunks, n_chunks, d_partial, d_pe);
+    // 16-byte loads need 16-byte aligned planes and even chunk starts
+    bool vec2 = (n_ent % 2 == 0) && ((reinterpret_cast<uintptr_t>(d_r) & 15) == 0);
+    for (const Chunk &c : chunks) vec2 = vec2 && (c.e0 % 2 == 0);
+    if (vec2)
+        hipLaunchKernelGGL(msd_pairs_kernel<true>, dim3((unsigned)n_chunks, (unsigned)n_pairs),
+                           dim3(MSD_THREADS), 0, ctx->stream, d_r, (long long)n_ent, scale, d_pairs,
+                           d_chunks, n_chunks, d_partial, d_pe);
+    else
+        hipLaunchKernelGGL(msd_pairs_kernel<false>, dim3((unsigned)n_chunks, (unsigned)n_pairs),
+                           dim3(MSD_THREADS), 0, ctx->stream, d_r, (long long)n_ent, scale, d_pairs,
+                           d_chunks, n_chunks, d_partial, d_pe);
     timer.stop();
     MD_HIP(hipGetLastError());
     const int tot = n_pairs * n_groups * 4;
@@ -373,9 +418,18 @@ int mdhip_msd_windows(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const dou
         (const double *)mdhip_stage(ctx, WS_XYZ_I, r, (size_t)n_frames * 3 * n_ent * 8, on_device, &rc);
     if (rc) return rc;
     MD_WS(d_out, double, WS_OUT, (size_t)n_ent * 4 * 8);
+    const long long n_kept = (n_frames + tao - 1) / tao;
+    const long long n_blocks_e = (n_ent + 255) / 256;
+    long long n_slabs = ((long long)ctx->cu_count * 8 + n_blocks_e - 1) / n_blocks_e;
+    if (n_slabs > n_kept - 1) n_slabs = n_kept - 1;
+    if (n_slabs > 1024) n_slabs = 1024;
+    if (n_slabs < 1) n_slabs = 1;
+    MD_WS(d_part, double, WS_PART, (size_t)n_slabs * n_ent * 4 * 8);
     KernelTimer timer(ctx);
-    hipLaunchKernelGGL(msd_windows_kernel, dim3((unsigned)((n_ent + 255) / 256)), dim3(256), 0,
-                       ctx->stream, d_r, (long long)n_ent, (long long)n_frames, scale, tao, d_out);
+    hipLaunchKernelGGL(msd_windows_kernel, dim3((unsigned)n_blocks_e, (unsigned)n_slabs), dim3(256), 0,
+                       ctx->stream, d_r, (long long)n_ent, n_kept, scale, tao, (int)n_slabs, d_part);
+    hipLaunchKernelGGL(msd_windows_sum_kernel, dim3((unsigned)((n_ent * 4 + 255) / 256)), dim3(256), 0,
+                       ctx->stream, d_part, (long long)n_ent, (int)n_slabs, d_out);
     timer.stop();
     MD_HIP(hipGetLastError());
     MD_HIP(hipMemcpyAsync(win_sums, d_out, (size_t)n_ent * 4 * 8, hipMemcpyDeviceToHost, ctx->stream));
