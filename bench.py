@@ -105,17 +105,24 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the hot path has no CPU fallback", file=sys.stderr)
         sys.exit(1)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one process per GPU; MDHIP_DIST_BACKEND=gloo lets several ranks share one GPU (only used to exercise
+    # the N > 1 code path on a 1-GPU box; the driver's scaling runs use the default, RCCL)
+    backend = os.environ.get("MDHIP_DIST_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from mdproptools_amd import backend as B
     from mdproptools_amd import synth
     from mdproptools_amd._lib import default_context
 
-    ctx = default_context(local_rank)
+    ctx = default_context(dev_index)
     if args.variant is not None:
         ctx.set_option("rdf_variant", args.variant)
 
@@ -160,7 +167,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
