@@ -226,24 +226,42 @@ class NativeDumpFile:
         return out
 
 
-def iter_native_frames(file_pattern, columns, sort_by="id", n_threads=0):
+def _native_file_frames(fname, columns, sort_by, n_threads):
+    nd = NativeDumpFile(fname)
+    try:
+        out = []
+        for f in range(nd.n_frames):
+            ts, na, bounds, tilt, names = nd.header(f)
+            want = columns(names) if callable(columns) else columns
+            planes = nd.read(f, want, sort_by=sort_by if sort_by in names else None, n_threads=n_threads)
+            lengths = LammpsBox(bounds.tolist(), tilt).to_lattice().lengths
+            out.append((ts, bounds, lengths, names, planes))
+        return out
+    finally:
+        nd.close()
+
+
+def iter_native_frames(file_pattern, columns, sort_by="id", n_threads=0, workers=None):
     """
     Frames of every file matching `file_pattern` (same ordering rule as parse_lammps_dumps) through the
     native reader: yields (timestep, bounds [3,2], box lengths (lx,ly,lz), columns present, planes
     [len(columns), natoms]). `columns` is a list of names or a callable (names present -> list of names).
     A ValueError is raised for a requested column the frame does not have.
+    Several files are parsed concurrently by `workers` host threads (the C calls release the GIL); the
+    frames are still yielded in file order.
     """
-    for fname in _sorted_matches(file_pattern):
-        nd = NativeDumpFile(fname)
-        try:
-            for f in range(nd.n_frames):
-                ts, na, bounds, tilt, names = nd.header(f)
-                want = columns(names) if callable(columns) else columns
-                planes = nd.read(f, want, sort_by=sort_by if sort_by in names else None, n_threads=n_threads)
-                lengths = LammpsBox(bounds.tolist(), tilt).to_lattice().lengths
-                yield ts, bounds, lengths, names, planes
-        finally:
-            nd.close()
+    files = _sorted_matches(file_pattern)
+    if workers is None:
+        workers = min(len(files), max(1, (os.cpu_count() or 1) // 2), 32)
+    if workers <= 1 or len(files) <= 1:
+        for fname in files:
+            yield from _native_file_frames(fname, columns, sort_by, n_threads)
+        return
+    from concurrent.futures import ThreadPoolExecutor
+
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        for frames in pool.map(lambda fn: _native_file_frames(fn, columns, sort_by, 1), files):
+            yield from frames
 
 
 def read_dump_arrays(file_pattern, columns, sort_by_id=True):

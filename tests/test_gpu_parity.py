@@ -455,3 +455,90 @@ def test_culled_path_large_box_auto(B):
         np.testing.assert_array_equal(full[f], cf)
         np.testing.assert_array_equal(part[f], cp)
         np.testing.assert_array_equal(cn[f], C.cn_pairs(xyz[f], ty, rel, box[f], [c * c for c in synth.cn_cutoffs(10)]))
+
+
+# ------------------------------------------------------------------ full-size properties (BASELINE C3, C4, C5)
+def test_c3_geometry_properties(B):
+    """100 000 atoms, L = 104 A (BASELINE C3), 2 of its frames: the culled sweep equals the dense sweep,
+    partial histograms add up to the full one, CN equals the histogram summed below a bin-edge cutoff."""
+    import torch
+    from mdproptools_amd import synth
+    from mdproptools_amd._lib import Context
+
+    cfg = synth.rdf_config("C3")
+    n, L = cfg["n_atoms"], cfg["box_len"]
+    xyz = torch.from_numpy(synth.rdf_frames(n, range(2), L, cfg["seed_offset"])).cuda()
+    ty = synth.rdf_types(n)
+    rel = np.array(synth.ALL_PAIRS_4)
+    box = np.full((2, 3), L)
+    out = {}
+    for cull in (0, 1):
+        ctx = Context(0)
+        ctx.set_option("rdf_cull", cull)
+        out[cull] = B.rdf_loop(xyz, ty, box, rel, 20.0, 0.05, 400, ctx=ctx)
+        ctx.close()
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    full, part, ov = out[1]
+    mult = np.array([1 if a == b else 2 for a, b in rel], dtype=np.uint64)
+    np.testing.assert_array_equal((part * mult[None, :, None]).sum(axis=1), full)
+    # 8.0 A is an exact bin edge for bin_size 0.05 only if edges[160] == 64.0; use the histogram's own edge
+    e = B.bin_edges(0.05, 400)
+    cut = float(np.sqrt(e[160]))
+    if cut * cut == e[160]:
+        cn = B.cn_loop(xyz, ty, box, rel, [cut] * len(rel))
+        np.testing.assert_array_equal(cn, part[:, :, :160].sum(axis=2))
+    # ideal gas: in-cutoff fraction of all pairs
+    frac = float(full[0].sum()) / 2 / (n * (n - 1) / 2)
+    assert abs(frac - 4 / 3 * np.pi * 20.0 ** 3 / L ** 3) < 2e-4
+
+
+def test_c4_msd_properties(B):
+    """50 000 entities (BASELINE C4), 64 frames: scaling law, origin symmetry, group additivity,
+    full-lag average of a ballistic trajectory."""
+    import torch
+    from mdproptools_amd import synth
+
+    E, F = 50_000, 64
+    r = synth.random_walk(E, F)
+    d = torch.from_numpy(r).cuda()
+    pairs = [(0, t) for t in range(F)]
+    s1 = B.msd_pairs(d, pairs, [0, E], scale=1.0)
+    s3 = B.msd_pairs(d, pairs, [0, E], scale=3.0)
+    np.testing.assert_allclose(s3, 9.0 * s1, rtol=1e-12)
+    back = B.msd_pairs(d, [(t, 0) for t in range(F)], [0, E], scale=1.0)
+    np.testing.assert_allclose(back, s1, rtol=1e-13)  # (a-b)^2 == (b-a)^2
+    split = B.msd_pairs(d, pairs, [0, 12_345, 30_000, E], scale=1.0)
+    np.testing.assert_allclose(split.sum(axis=1, keepdims=True), s1, rtol=1e-12)
+    # a random walk with sigma = 0.1 per axis per frame: msd(t) ~ 3 * 0.01 * t
+    msd_last = s1[-1, 0, 3] / E
+    assert abs(msd_last / (3 * 0.01 * (F - 1)) - 1.0) < 0.02
+    win = B.msd_windows(d, 4, scale=1.0)
+    kept = r[::4]
+    np.testing.assert_allclose(win[:, 3], ((kept[1:] - kept[:-1]) ** 2).sum(axis=(0, 1)), rtol=1e-12)
+    # ballistic motion r = r0 + v t: msd[lag] = |v|^2 lag^2 exactly in expectation per entity
+    rng = np.random.default_rng(2)
+    v = rng.normal(0, 1, (3, 2000))
+    traj = rng.uniform(0, 50, (1, 3, 2000)) + v[None] * np.arange(300)[:, None, None]
+    out = B.lag_msd(traj, 299, [0, 2000])
+    expect = (v ** 2).sum(axis=0).mean() * np.arange(300) ** 2
+    np.testing.assert_allclose(out[:, 0, 3], expect, rtol=1e-9, atol=1e-9)
+
+
+def test_c5_acf_properties(B):
+    """n = 1e5 AR(1) series (BASELINE C5 at a tenth of its length): FFT and direct estimators agree,
+    acf[0] is the mean square, the cumulative trapezoid of a constant is a ramp."""
+    from mdproptools_amd import synth
+
+    p = synth.ar1_series(100_000)
+    fft = B.xcorr(p, method=B.XCORR_FFT)
+    direct = B.xcorr(p, method=B.XCORR_DIRECT)
+    for k in range(3):
+        np.testing.assert_allclose(fft[k], direct[k], rtol=0, atol=1e-10 * direct[k][0])
+        np.testing.assert_allclose(direct[k][0], np.mean(p[k] ** 2), rtol=1e-12)
+        # the last lag is the product of the two end samples
+        np.testing.assert_allclose(direct[k][-1], p[k][-1] * p[k][0], rtol=1e-9, atol=1e-9 * direct[k][0])
+    ramp = B.cumtrapz(np.full((2, 100_000), 2.5), 0.5, leading_zero=True)
+    np.testing.assert_allclose(ramp[0], 1.25 * np.arange(100_000), rtol=1e-12)
+    lin = B.cumtrapz(np.arange(100_001.0), 1.0)
+    np.testing.assert_allclose(lin, 0.5 * np.arange(1, 100_001) ** 2, rtol=1e-12)
