@@ -190,13 +190,16 @@ def main():
                                    + (", RCCL all-reduce per step" if world > 1 else ""),
                        "pairs_per_step_per_gpu": pairs_per_step, "kernel_variant": ctx_variant(ctx, args)},
             "roofline": {
-                "bound": "fp64-valu (not hbm/mfma: 28 B and 18 unfused FP64 ops per atom per pair sweep)",
+                "bound": "fp64-valu",
+                "note": "neither hbm nor mfma bounds this kernel: 28 B and 18 unfused FP64 ops per atom pair swept "
+                        "(SURVEY.md 8d); peak = 256 CU x 128 lanes x 2.4 GHz / 2; the hbm view is given beside it",
                 "kernel": ("pair_hist_fast_kernel<true, 8, 0, %s>" % ("true" if aux_ms > 0 else "false"))
                 if ctx_variant(ctx, args) == 1 else "pair_hist_kernel<true>",
                 "launch_ms": kdur * 1e3, "prepass_ms_per_step": aux_ms / args.steps,
                 "achieved": alg_ops / kdur / 1e12, "peak": FP64_NONFUSED_PEAK / 1e12, "unit": "TFLOP/s",
                 "frac": alg_ops / kdur / FP64_NONFUSED_PEAK,
-                "hbm_algorithmic_GBps": 28.0 * n * F / kdur / 1e9, "hbm_peak_GBps": HBM_PEAK / 1e9,
+                "hbm": {"achieved": 28.0 * n * F / kdur / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                        "frac": 28.0 * n * F / kdur / HBM_PEAK},
                 "traffic": load_traffic(),
             },
         }

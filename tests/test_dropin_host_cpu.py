@@ -134,3 +134,31 @@ def test_lammps_readers_round_trip(tmp_path):
     mio.write_log(tmp_path / "log.a", tab, ["Step", "Pxy", "msd_1"])
     (df,) = mio.parse_lammps_log(str(tmp_path / "log.a"))
     np.testing.assert_array_equal(df.to_numpy(), tab)
+
+
+def test_concat_log_segments(tmp_path):
+    """Restart segments: numeric order, every segment but the last drops its final (repeated) row."""
+    from mdproptools_amd import io as mio
+    from mdproptools_amd.utilities.log import concat_log
+
+    for seg, steps in [(1, [0, 10, 20]), (10, [40, 50]), (2, [20, 30, 40])]:
+        tab = np.column_stack([steps, np.asarray(steps) * 0.5])
+        mio.write_log(tmp_path / ("log.%d" % seg), tab, ["Step", "c_msd[4]"])
+    full = concat_log("log.*", working_dir=str(tmp_path))
+    assert list(full["Step"]) == [0, 10, 20, 30, 40, 50]
+    assert list(full.index) == list(range(6))
+
+
+def test_get_msd_from_log(tmp_path):
+    """diffusion.py:241-265: msd columns x DISTANCE_CONVERSION**2 and a 'Time (s)' column (host only)."""
+    from mdproptools_amd import io as mio
+    from mdproptools_amd.dynamical.diffusion import Diffusion
+
+    steps = np.arange(0, 50, 10)
+    tab = np.column_stack([steps, steps * 0.25, steps * 1.5, 300.0 + 0 * steps])
+    mio.write_log(tmp_path / "log.mixture_nvt", tab, ["Step", "c_msd1[4]", "c_msd2[4]", "Temp"])
+    d = Diffusion(timestep=2, units="real", outputs_dir=str(tmp_path), diff_dir=str(tmp_path))
+    msd = d.get_msd_from_log("log.mixture_nvt")
+    assert list(msd.columns) == ["c_msd1[4]", "c_msd2[4]", "Time (s)"]
+    np.testing.assert_allclose(msd["c_msd2[4]"], steps * 1.5 * 1e-20, rtol=1e-15)
+    np.testing.assert_allclose(msd["Time (s)"], steps * 2 * 1e-15, rtol=1e-15)
