@@ -93,6 +93,7 @@ int mdhip_create(mdhip_ctx **out, int device)
     if (const char *v = getenv("MDHIP_RDF_JSPLIT")) ctx->opt_rdf_jsplit = atoi(v);
     if (const char *v = getenv("MDHIP_RDF_FPB")) ctx->opt_rdf_fpb = atoi(v);
     if (const char *v = getenv("MDHIP_RDF_CULL")) ctx->opt_rdf_cull = atoi(v);
+    if (const char *v = getenv("MDHIP_RDF_SJ")) ctx->opt_rdf_sj = atoi(v);
     *out = ctx;
     return MDHIP_OK;
 }
@@ -150,6 +151,8 @@ int mdhip_set_option(mdhip_ctx *ctx, const char *key, int value)
         ctx->opt_rdf_variant = value;
     else if (!strcmp(key, "rdf_unroll"))
         ctx->opt_rdf_unroll = value;
+    else if (!strcmp(key, "rdf_sj"))
+        ctx->opt_rdf_sj = value;
     else if (!strcmp(key, "rdf_batch"))
         ctx->opt_rdf_batch = value;
     else if (!strcmp(key, "rdf_cull"))

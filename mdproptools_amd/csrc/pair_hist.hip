@@ -68,6 +68,7 @@ struct PairArgs {
     const float4 *gsph;          // [F][nTi*32][2] bounding box (lo, hi; w = 1 if non-empty) of every 8 sorted atoms
     const float4 *wsph;          // [F][nTi*4][2]  bounding box of every 64 sorted atoms (one wave's i atoms)
     float reach;                 // r_cut rounded up, plus slack for the f32 box test
+    const double4 *aos;          // [F][nTi*256] sorted atoms (x, y, z, bits = type * n_ti), padded with +1e300
 };
 
 __device__ __forceinline__ double wrap_abs(double d, double L)
@@ -632,7 +633,8 @@ __global__ __launch_bounds__(256) void cull_scan_kernel(unsigned *__restrict__ c
 __global__ void cull_scatter_kernel(const double *__restrict__ xyz, const int *__restrict__ type,
                                     long long type_fs, long long n, const unsigned short *__restrict__ keys,
                                     unsigned *__restrict__ cells, double *__restrict__ sxyz,
-                                    int *__restrict__ stype)
+                                    int *__restrict__ stype, double4 *__restrict__ aos, long long n_pad,
+                                    int n_ti)
 {
     const int f = blockIdx.y;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -644,7 +646,11 @@ __global__ void cull_scatter_kernel(const double *__restrict__ xyz, const int *_
     o[pos] = x[i];
     o[n + pos] = x[n + i];
     o[2 * n + pos] = x[2 * n + i];
-    stype[(size_t)f * n + pos] = type[(size_t)f * type_fs + i];
+    const int t = type[(size_t)f * type_fs + i];
+    stype[(size_t)f * n + pos] = t;
+    aos[(size_t)f * n_pad + pos] = make_double4(x[i], x[n + i], x[2 * n + i], __longlong_as_double((long long)t * n_ti));
+    // the pad records behind the last atom (never in cutoff: rsq overflows to +inf)
+    if (i < n_pad - n) aos[(size_t)f * n_pad + n + i] = make_double4(PAD_J, PAD_J, PAD_J, __longlong_as_double(0LL));
 }
 
 // bbox[f][tile][6] = min/max of the wrapped fractional coordinates of the tile's atoms
@@ -752,6 +758,200 @@ __global__ __launch_bounds__(256) void cull_list_kernel(const double *__restrict
     }
     __syncthreads();
     if (threadIdx.x == 0) cnt[(size_t)f * nT + I] = s_n;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Scalar-j kernel (culled path, rdf_variant = 1 default): the four waves of a block run independently.
+// A wave keeps one i atom per lane; the j atoms of a group are the same for all lanes, so they are read
+// with SCALAR loads (s_load_dwordx8 from the sorted record array, through the scalar cache) and used as
+// scalar operands of the rsq chain — no LDS staging of tiles, no barrier per tile, so a wave that culls
+// more groups than its neighbours never waits for them. LDS holds only the class histograms (shared by
+// the block's waves), the row table and, for CN, the few edges. Arithmetic, binning and flush are the
+// fast kernel's.
+// ------------------------------------------------------------------------------------------------
+typedef unsigned int u32x8 __attribute__((ext_vector_type(8)));
+
+// Four consecutive 32-byte records (x, y, z, w) through the scalar cache into 4 x 8 SGPRs; `p` must be
+// wave-uniform. The loads and the wait for them are ONE asm statement: hipcc knows nothing about the
+// latency of an inline-asm load and would otherwise schedule uses of the outputs in front of a separate
+// s_waitcnt (cdna_hip_programming.md §5.7). The record array is written by an earlier launch and only
+// read here, so the scalar cache is coherent.
+__device__ __forceinline__ void sload_records4(const double4 *p, u32x8 &r0, u32x8 &r1, u32x8 &r2, u32x8 &r3)
+{
+    asm volatile(
+        "s_load_dwordx8 %0, %4, 0x0\n\t"
+        "s_load_dwordx8 %1, %4, 0x20\n\t"
+        "s_load_dwordx8 %2, %4, 0x40\n\t"
+        "s_load_dwordx8 %3, %4, 0x60\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&s"(r0), "=&s"(r1), "=&s"(r2), "=&s"(r3)
+        : "s"(p)
+        : "memory");
+}
+
+template <bool DIAG, int MODE>
+__device__ __forceinline__ void sweep_group_sj(const double4 *__restrict__ grp, int local0, double xi, double yi,
+                                               double zi, double Lx, double Ly, double Lz, double rc2,
+                                               const FastCtx &c, int lane_in_tile)
+{
+    constexpr int U = 4;  // records per batch of scalar loads (4 x 8 SGPRs)
+#pragma unroll
+    for (int h = 0; h < 8 / U; ++h) {
+        u32x8 rec[U];
+        sload_records4(grp + h * U, rec[0], rec[1], rec[2], rec[3]);
+        double rsq[U];
+        unsigned row[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const double xj = __hiloint2double((int)rec[u][1], (int)rec[u][0]);
+            const double yj = __hiloint2double((int)rec[u][3], (int)rec[u][2]);
+            const double zj = __hiloint2double((int)rec[u][5], (int)rec[u][4]);
+            const double ax = wrap_abs(xi - xj, Lx);
+            const double ay = wrap_abs(yi - yj, Ly);
+            const double az = wrap_abs(zi - zj, Lz);
+            rsq[u] = (ax * ax + ay * ay) + az * az;
+            row[u] = c.rowtab_me[(int)rec[u][6]];  // low word of w = type * n_ti
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            bool in = rsq[u] < rc2;
+            if (DIAG) in = in && (local0 + h * U + u > lane_in_tile);
+            if (in) {
+                int k;
+                if (MODE == 0) {
+                    const float g1 = __builtin_fmaf(__builtin_amdgcn_sqrtf((float)rsq[u]), c.gscale, c.near);
+                    k = (int)g1;
+                    if (__builtin_amdgcn_fractf(g1) < c.near2) {
+                        k = k > c.nbins ? c.nbins : k;
+                        while (rsq[u] < c.edges[k]) --k;
+                        while (rsq[u] >= c.edges[k + 1]) ++k;
+                    }
+                } else {
+                    k = 0;
+                    for (int e = 1; e <= c.nbins; ++e) k += rsq[u] >= c.edges[e] ? 1 : 0;
+                }
+                const unsigned addr = ((unsigned)k << 2) + row[u];
+                asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"(1u) : "memory");
+            }
+        }
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(TILE) void pair_hist_sj_kernel(const PairArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const long long bid = blockIdx.x;
+    const int xcd = (int)(bid & 7);
+    const long long q = bid >> 3;
+    const int fgroup = (int)(q / a.blocks_per_frame);
+    const int within = (int)(q % a.blocks_per_frame);
+    const int I = within % a.nTi;
+    const int split = within / a.nTi;
+    if ((fgroup * a.fpb) * 8 + xcd >= a.n_frames) return;
+
+    // ---- LDS: hist | (CN edges) | row table ----
+    const int row_len = a.nbins + 1;
+    const int hist_words = (a.n_cls + 1) * row_len;
+    unsigned *s_hist = reinterpret_cast<unsigned *>(smem);
+    size_t off = ((size_t)hist_words * 4 + 15) & ~size_t(15);
+    double *s_edges = reinterpret_cast<double *>(smem + off);
+    off += MODE == 1 ? (((size_t)(a.nbins + 2) * 8 + 15) & ~size_t(15)) : 0;
+    unsigned *s_row = reinterpret_cast<unsigned *>(smem + off);
+    const unsigned lds_base =
+        (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char *)smem;
+    for (int k = tid; k < hist_words; k += TILE) s_hist[k] = 0u;
+    for (int k = tid; k < a.n_ti * a.n_tj; k += TILE) {
+        const int ti = k % a.n_ti, tj = k / a.n_ti;
+        const unsigned cl = a.cls[ti * a.n_tj + tj];
+        s_row[k] = lds_base + (cl == 0xFFu ? (unsigned)a.n_cls : cl) * (unsigned)row_len * 4u;
+    }
+    FastCtx c;
+    c.hist = s_hist;
+    c.edges = a.edges;
+    if (MODE == 1) {
+        for (int k = tid; k <= a.nbins + 1; k += TILE) s_edges[k] = a.edges[k];
+        c.edges = s_edges;
+    }
+    c.gscale = a.gscale;
+    c.near = (float)a.nbins * 1.0e-6f + 1.0e-5f;
+    c.near2 = 2.0f * c.near;
+    c.nbins = a.nbins;
+    __syncthreads();  // tables ready; from here on the waves do not synchronise until the flush
+
+    const long long n_pad = (long long)a.nTi * TILE;
+    int f_last = 0;
+    for (int kf = 0; kf < a.fpb; ++kf) {
+        const int f = (fgroup * a.fpb + kf) * 8 + xcd;
+        if (f >= a.n_frames) break;
+        f_last = f;
+        const long long rowid = (long long)f * a.nTi + I;
+        const int cnt = a.list_cnt[rowid];
+        const unsigned short *row_list = a.list + rowid * a.nTi;
+        const int t_begin = (int)((long long)split * cnt / a.jsplit);
+        const int t_end = (int)((long long)(split + 1) * cnt / a.jsplit);
+        if (t_begin >= t_end) continue;
+        const double Lx = a.box[3 * f], Ly = a.box[3 * f + 1], Lz = a.box[3 * f + 2];
+        const double4 *ats = a.aos + (long long)f * n_pad;
+        double4 me = ats[(long long)I * TILE + tid];
+        if ((long long)I * TILE + tid >= a.ni) me = make_double4(PAD_I, PAD_I, PAD_I, __longlong_as_double(0LL));
+        c.rowtab_me = s_row + (int)(__double_as_longlong(me.w) / a.n_ti);
+        const long long w = ((long long)f * a.nTi + I) * (TILE / 64) + (tid >> 6);
+        const float4 wlo = a.wsph[2 * w], whi = a.wsph[2 * w + 1];
+        const float4 *gb_f = a.gsph + (long long)f * a.nTi * (TILE / 8) * 2;
+        for (int t = t_begin; t < t_end; ++t) {
+            const int J = __builtin_amdgcn_readfirstlane((int)row_list[t]);
+            // lanes 0..31 (mirrored in 32..63) test one 8-atom group box each against this wave's box
+            const float4 glo = gb_f[((long long)J * (TILE / 8) + (tid & 31)) * 2];
+            const float4 ghi = gb_f[((long long)J * (TILE / 8) + (tid & 31)) * 2 + 1];
+            const float gx = gapf(wlo.x, whi.x, glo.x, ghi.x, (float)Lx);
+            const float gy = gapf(wlo.y, whi.y, glo.y, ghi.y, (float)Ly);
+            const float gz = gapf(wlo.z, whi.z, glo.z, ghi.z, (float)Lz);
+            const bool keep = wlo.w > 0.f && glo.w > 0.f && gx * gx + gy * gy + gz * gz < a.reach * a.reach;
+            unsigned mask = (unsigned)__builtin_amdgcn_ballot_w64(keep);
+            const double4 *tile = ats + (long long)J * TILE;
+            if (J == I) {
+                while (mask) {
+                    const int g = __builtin_ctz(mask);
+                    mask &= mask - 1;
+                    sweep_group_sj<true, MODE>(tile + g * 8, g * 8, me.x, me.y, me.z, Lx, Ly, Lz, a.rc2, c, tid);
+                }
+            } else {
+                while (mask) {
+                    const int g = __builtin_ctz(mask);
+                    mask &= mask - 1;
+                    sweep_group_sj<false, MODE>(tile + g * 8, g * 8, me.x, me.y, me.z, Lx, Ly, Lz, a.rc2, c, tid);
+                }
+            }
+        }
+    }
+
+    // ---- flush (as the fast kernel) ----
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int out_words = a.n_cls * a.nbins;
+    unsigned long long *g =
+        a.hist + (size_t)(a.per_frame ? f_last : (int)(bid % a.slots)) * (size_t)out_words;
+    unsigned ovf = 0;
+    for (int w = tid; w < hist_words; w += TILE) {
+        const unsigned v = s_hist[w];
+        if (!v) continue;
+        const int cl = w / row_len, k = w - cl * row_len;
+        if (k == a.nbins)
+            ovf += v;
+        else if (cl < a.n_cls)
+            atomicAdd(&g[(size_t)cl * a.nbins + k], (unsigned long long)v);
+    }
+    if (ovf) atomicAdd(a.overflow, (unsigned long long)ovf);
+}
+
+size_t lds_bytes_sj(int nbins, int n_cls, int n_ti, int n_tj, bool mode_cn)
+{
+    size_t off = ((size_t)(n_cls + 1) * (nbins + 1) * 4 + 15) & ~size_t(15);
+    off += mode_cn ? (((size_t)(nbins + 2) * 8 + 15) & ~size_t(15)) : 0;
+    off += (size_t)n_ti * n_tj * 4;
+    return (off + 15) & ~size_t(15);
 }
 
 __global__ void reduce_slots_kernel(const unsigned long long *__restrict__ in,
@@ -885,6 +1085,7 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
     const unsigned short *d_list = nullptr;
     const int *d_list_cnt = nullptr;
     const float4 *d_gsph = nullptr, *d_wsph = nullptr;
+    const double4 *d_aos = nullptr;
     double prep_ms = 0.0;
     if (cull) {
         const long long N = p.ni;
@@ -897,13 +1098,15 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         MD_WS(d_lc, int, WS_LISTCNT, (size_t)F * nTi * 4);
         MD_WS(d_gs, float4, WS_GSPH, (size_t)F * nTi * (TILE / 8) * 2 * sizeof(float4));
         MD_WS(d_ws, float4, WS_WSPH, (size_t)F * nTi * (TILE / 64) * 2 * sizeof(float4));
+        MD_WS(d_ao, double4, WS_SORT_AOS, (size_t)F * nTi * TILE * sizeof(double4));
         KernelTimer ptimer(ctx);
         MD_HIP(hipMemsetAsync(d_cells, 0, (size_t)F * MORTON_CELLS * 4, ctx->stream));
         const dim3 ga((unsigned)((N + 255) / 256), (unsigned)F);
         hipLaunchKernelGGL(cull_keys_kernel, ga, dim3(256), 0, ctx->stream, p.d_xi, p.d_box, N, d_keys, d_cells);
         hipLaunchKernelGGL(cull_scan_kernel, dim3((unsigned)F), dim3(256), 0, ctx->stream, d_cells);
         hipLaunchKernelGGL(cull_scatter_kernel, ga, dim3(256), 0, ctx->stream, p.d_xi, p.d_ti,
-                           (long long)p.ti_fs, N, d_keys, d_cells, d_sx, d_st);
+                           (long long)p.ti_fs, N, d_keys, d_cells, d_sx, d_st, d_ao, (long long)nTi * TILE,
+                           p.n_ti);
         hipLaunchKernelGGL(cull_bbox_kernel, dim3((unsigned)nTi, (unsigned)F), dim3(TILE), 0, ctx->stream,
                            d_sx, p.d_box, N, nTi, d_bbox);
         hipLaunchKernelGGL(cull_list_kernel, dim3((unsigned)nTi, (unsigned)F), dim3(256), 0, ctx->stream,
@@ -925,6 +1128,7 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         k_ti_fs = k_tj_fs = N;
         d_list = d_l;
         d_list_cnt = d_lc;
+        d_aos = d_ao;
     }
 
     double total_ms = 0.0;  // the pair kernel alone; the culling pre-pass is reported separately
@@ -955,6 +1159,7 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         a.gsph = d_gsph;
         a.wsph = d_wsph;
         a.reach = (float)((std::sqrt(p.rc2) + 1e-3) * 1.00001);
+        a.aos = d_aos;
         a.box = p.d_box;
         a.cls = d_tab + edges_b;
         a.edges = reinterpret_cast<const double *>(d_tab);
@@ -979,10 +1184,15 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         a.slots = slots;
         a.fpb = fpb;
 
-        const size_t lds = fast ? lds_bytes_fast(p.nbins, nc, p.n_ti, p.n_tj) : lds_bytes(p.nbins, nc, p.n_ti, p.n_tj);
+        const bool sj = cull && ctx->opt_rdf_sj != 0;  // wave-independent sweep with scalar loads of the j atoms
+        const size_t lds = sj     ? lds_bytes_sj(p.nbins, nc, p.n_ti, p.n_tj, mode_cn)
+                           : fast ? lds_bytes_fast(p.nbins, nc, p.n_ti, p.n_tj)
+                                  : lds_bytes(p.nbins, nc, p.n_ti, p.n_tj);
         void (*kern)(const PairArgs);
         if (!fast)
             kern = p.tri ? pair_hist_kernel<true> : pair_hist_kernel<false>;
+        else if (sj)
+            kern = mode_cn ? pair_hist_sj_kernel<1> : pair_hist_sj_kernel<0>;
         else if (cull)
             kern = mode_cn ? pair_hist_fast_kernel<true, 8, 1, true> : pair_hist_fast_kernel<true, 8, 0, true>;
         else if (mode_cn)
