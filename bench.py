@@ -193,8 +193,7 @@ def main():
                 "bound": "fp64-valu",
                 "note": "neither hbm nor mfma bounds this kernel: 28 B and 18 unfused FP64 ops per atom pair swept "
                         "(SURVEY.md 8d); peak = 256 CU x 128 lanes x 2.4 GHz / 2; the hbm view is given beside it",
-                "kernel": ("pair_hist_fast_kernel<true, 8, 0, %s>" % ("true" if aux_ms > 0 else "false"))
-                if ctx_variant(ctx, args) == 1 else "pair_hist_kernel<true>",
+                "kernel": ctx.last_kernel_name(),
                 "launch_ms": kdur * 1e3, "prepass_ms_per_step": aux_ms / args.steps,
                 "achieved": alg_ops / kdur / 1e12, "peak": FP64_NONFUSED_PEAK / 1e12, "unit": "TFLOP/s",
                 "frac": alg_ops / kdur / FP64_NONFUSED_PEAK,

@@ -59,6 +59,8 @@ double mdhip_last_kernel_ms(mdhip_ctx *ctx, int *n_launches);
 /* Device time (ms) of the preparation kernels of the last call that are not part of the dominant kernel
  * (the spatial sort / tile lists of the culled pair path); 0 when there were none. */
 double mdhip_last_aux_ms(mdhip_ctx *ctx);
+/* Name of the dominant kernel the last call launched (as rocprofv3 lists it, without the namespace), "" if none. */
+const char *mdhip_last_kernel_name(mdhip_ctx *ctx);
 /* Writes the device name (e.g. "gfx950...") into buf. */
 int mdhip_device_name(mdhip_ctx *ctx, char *buf, int buflen);
 /* Kernel tuning knob, for A/B measurements only; results never depend on it.

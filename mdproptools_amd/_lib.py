@@ -33,6 +33,7 @@ PROTOTYPES = {
     "mdhip_sync": (C.c_int, [vp]),
     "mdhip_last_kernel_ms": (C.c_double, [vp, C.POINTER(C.c_int)]),
     "mdhip_last_aux_ms": (C.c_double, [vp]),
+    "mdhip_last_kernel_name": (C.c_char_p, [vp]),
     "mdhip_device_name": (C.c_int, [vp, C.c_char_p, C.c_int]),
     "mdhip_set_option": (C.c_int, [vp, C.c_char_p, C.c_int]),
     "mdhip_bin_edges": (C.c_int, [C.c_double, C.c_int, c_dp]),
@@ -185,6 +186,9 @@ class Context:
 
     def last_aux_ms(self):
         return float(self.lib.mdhip_last_aux_ms(self.h))
+
+    def last_kernel_name(self):
+        return (self.lib.mdhip_last_kernel_name(self.h) or b"").decode()
 
 
 _default = {}

@@ -37,6 +37,7 @@ enum WsSlot {
     WS_GSPH,
     WS_WSPH,
     WS_SORT_AOS,   // sorted atoms as (x, y, z, row-table offset) records, padded to whole tiles
+    WS_ORIGIN,     // per-frame grid origin of the spatial sort
     WS_COUNT
 };
 
@@ -55,6 +56,7 @@ struct mdhip_ctx {
     double last_ms = 0.0;
     double last_aux_ms = 0.0;  // device time of the preparation kernels of the last call (e.g. spatial sort)
     int last_launches = 0;
+    const char *last_kernel = "";  // dominant kernel of the last call (static string)
     int cu_count = 256;
     size_t lds_max = 65536;
     char name[256] = {0};
@@ -63,7 +65,9 @@ struct mdhip_ctx {
     int opt_rdf_unroll = 8;   // j atoms per step of the fast kernel (4, 8, 16)
     int opt_rdf_jsplit = 0;   // 0 = auto
     int opt_rdf_fpb = 0;      // frames per block of the fast kernel, 0 = auto
-    int opt_rdf_sj = 1;       // culled path: 1 = scalar-j kernel (waves independent), 0 = LDS-tile kernel
+    int opt_rdf_sj = 1;       // culled path: 1 = scalar-j kernel (waves independent; persistent grid when the
+                              // output is frame-summed), 2 = scalar-j with one block per (frame, tile, slice),
+                              // 0 = LDS-tile kernel
     int opt_rdf_batch = 0;    // frames per batch of the pair path, 0 = auto (workspace-bounded)
     int opt_rdf_cull = -1;    // spatial culling of tile pairs: -1 = auto, 0 = never, 1 = always (when applicable)
     int opt_rdf_slots = 16;   // replicas of the frame-summed histogram in HBM

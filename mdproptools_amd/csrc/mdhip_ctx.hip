@@ -136,6 +136,7 @@ double mdhip_last_kernel_ms(mdhip_ctx *ctx, int *n_launches)
 }
 
 double mdhip_last_aux_ms(mdhip_ctx *ctx) { return ctx ? ctx->last_aux_ms : 0.0; }
+const char *mdhip_last_kernel_name(mdhip_ctx *ctx) { return ctx ? ctx->last_kernel : ""; }
 
 int mdhip_device_name(mdhip_ctx *ctx, char *buf, int buflen)
 {

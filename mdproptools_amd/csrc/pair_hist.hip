@@ -69,6 +69,7 @@ struct PairArgs {
     const float4 *wsph;          // [F][nTi*4][2]  bounding box of every 64 sorted atoms (one wave's i atoms)
     float reach;                 // r_cut rounded up, plus slack for the f32 box test
     const double4 *aos;          // [F][nTi*256] sorted atoms (x, y, z, bits = type * n_ti), padded with +1e300
+    unsigned *work;              // [8] per-XCD work counters of the persistent scalar-j kernel (zeroed per launch)
 };
 
 __device__ __forceinline__ double wrap_abs(double d, double L)
@@ -528,14 +529,16 @@ size_t lds_bytes_fast(int nbins, int n_cls, int n_ti, int n_tj)
 
 // ------------------------------------------------------------------------------------------------
 // Spatial culling for r_cut << L (SURVEY.md §8f "cell-list variant"): atoms are re-ordered along a Hilbert
-// curve over a 32^3 grid of the periodic cell, so that every tile of 256 consecutive atoms is a compact
-// blob; a tile pair whose axis-aligned bounding boxes (periodic, in fractional coordinates) are farther
-// apart than the cutoff cannot contain an in-cutoff pair and is never swept. The pair kernel itself and
-// its arithmetic are unchanged — the SAME exact rsq decides every pair that is swept — so the integer
+// curve over a 32^3 grid of the periodic cell (laid from the frame's smallest coordinates), so that every
+// tile of 256 consecutive atoms is a compact blob; a tile pair whose axis-aligned bounding boxes are
+// farther apart than the cutoff cannot contain an in-cutoff pair and is never swept. The pair kernel's
+// arithmetic is unchanged — the SAME exact rsq decides every pair that is swept — so the integer
 // histograms are identical to the dense path's. Conservative by construction:
-//  * the boxes are built from coordinates wrapped into [0,1) (x/L - floor(x/L)); the reference's single
-//    wrap gives a distance >= the true periodic distance, which is >= the box-to-box distance;
-//  * the box test uses r_cut^2 * (1 + 1e-9) + 1e-9 to stay clear of its own rounding.
+//  * boxes hold the coordinates AS GIVEN (no wrapping). The reference's per-axis distance after its single
+//    wrap is min(|d|, ||d| - L|) = dist(d, {0, +L, -L}); over all d = a - b with a, b in two boxes its
+//    minimum is the gap between the d interval and the nearest of those three points (interval_gap / gapf),
+//    for any coordinates, inside the cell or box lengths away from it;
+//  * f32 boxes are widened outward beyond their rounding; the tile test carries its own slack.
 // The order of atoms inside a cell depends on atomic arrival order; only sums of integers depend on it.
 // ------------------------------------------------------------------------------------------------
 
@@ -584,8 +587,40 @@ __device__ __forceinline__ unsigned hilbert3(unsigned cx, unsigned cy, unsigned 
     return key;
 }
 
+// Order-preserving map double -> u64 (for atomicMin on coordinates) and back.
+__device__ __forceinline__ unsigned long long dkey(double v)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double dkey_inv(unsigned long long k)
+{
+    const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+
+// origin[f][3] = smallest x, y, z of the frame (as dkey; the buffer starts as all ones). The grid is laid
+// from there, so that a cell [lo, lo+L) with any lo is cut at its own faces and not somewhere inside.
+__global__ __launch_bounds__(256) void cull_origin_kernel(const double *__restrict__ xyz, long long n,
+                                                          unsigned long long *__restrict__ origin)
+{
+    const int f = blockIdx.y;
+    const double *x = xyz + (size_t)f * 3 * n;
+    double lo[3] = {1e300, 1e300, 1e300};
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) lo[ax] = __builtin_fmin(lo[ax], x[ax * n + i]);
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) lo[ax] = __builtin_fmin(lo[ax], __shfl_down(lo[ax], off, 64));
+        if ((threadIdx.x & 63) == 0) atomicMin(&origin[3 * f + ax], dkey(lo[ax]));
+    }
+}
+
 // keys[f][n] and cell populations cells[f][key]
 __global__ void cull_keys_kernel(const double *__restrict__ xyz, const double *__restrict__ box, long long n,
+                                 const unsigned long long *__restrict__ origin,
                                  unsigned short *__restrict__ keys, unsigned *__restrict__ cells)
 {
     const int f = blockIdx.y;
@@ -596,7 +631,7 @@ __global__ void cull_keys_kernel(const double *__restrict__ xyz, const double *_
     unsigned c[3];
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax) {
-        int v = (int)(wrapped_frac(x[ax * n + i], box[3 * f + ax]) * G);
+        int v = (int)(wrapped_frac(x[ax * n + i] - dkey_inv(origin[3 * f + ax]), box[3 * f + ax]) * G);
         c[ax] = (unsigned)(v < 0 ? 0 : v > (1 << MORTON_BITS) - 1 ? (1 << MORTON_BITS) - 1 : v);
     }
     const unsigned key = hilbert3(c[0], c[1], c[2]);
@@ -653,9 +688,8 @@ __global__ void cull_scatter_kernel(const double *__restrict__ xyz, const int *_
     if (i < n_pad - n) aos[(size_t)f * n_pad + n + i] = make_double4(PAD_J, PAD_J, PAD_J, __longlong_as_double(0LL));
 }
 
-// bbox[f][tile][6] = min/max of the wrapped fractional coordinates of the tile's atoms
-__global__ __launch_bounds__(TILE) void cull_bbox_kernel(const double *__restrict__ sxyz,
-                                                         const double *__restrict__ box, long long n, int nT,
+// bbox[f][tile][6] = min/max of the coordinates (as given, not wrapped) of the tile's atoms
+__global__ __launch_bounds__(TILE) void cull_bbox_kernel(const double *__restrict__ sxyz, long long n, int nT,
                                                          double *__restrict__ bbox)
 {
     __shared__ double red[6][TILE / 64];
@@ -666,10 +700,10 @@ __global__ __launch_bounds__(TILE) void cull_bbox_kernel(const double *__restric
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax) {
         if (i < n) {
-            lo[ax] = hi[ax] = wrapped_frac(x[ax * n + i], box[3 * f + ax]);
+            lo[ax] = hi[ax] = x[ax * n + i];
         } else {
-            lo[ax] = 2.0;
-            hi[ax] = -1.0;
+            lo[ax] = 1e300;
+            hi[ax] = -1e300;
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
@@ -693,7 +727,7 @@ __global__ __launch_bounds__(TILE) void cull_bbox_kernel(const double *__restric
 }
 
 // Axis-aligned bounding boxes of every `group` consecutive sorted atoms (8: one step of the pair sweep;
-// 64: the i atoms of one wave) in the wrapped cell [0,L), stored in f32 and widened so that rounding can
+// 64: the i atoms of one wave) in the coordinates as given, stored in f32 and widened so that rounding can
 // only make them larger: boxes[2*g] = (lo.xyz, 1), boxes[2*g+1] = (hi.xyz, 1). Groups without atoms get
 // w = 0 (never within reach).
 __global__ void cull_box_kernel(const double *__restrict__ sxyz, const double *__restrict__ box, long long n,
@@ -710,24 +744,32 @@ __global__ void cull_box_kernel(const double *__restrict__ sxyz, const double *_
         double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
         for (long long i = i0; i < i1; ++i)
             for (int ax = 0; ax < 3; ++ax) {
-                const double p = wrapped_frac(x[ax * n + i], L[ax]) * L[ax];
+                const double p = x[ax * n + i];
                 lo[ax] = __builtin_fmin(lo[ax], p);
                 hi[ax] = __builtin_fmax(hi[ax], p);
             }
-        const double pad = 1e-5 * (L[0] + L[1] + L[2]) + 1e-6;  // >> f32 rounding of a coordinate in [0,L)
-        lo4 = make_float4((float)(lo[0] - pad), (float)(lo[1] - pad), (float)(lo[2] - pad), 1.f);
-        hi4 = make_float4((float)(hi[0] + pad), (float)(hi[1] + pad), (float)(hi[2] + pad), 1.f);
+        // >> the f32 rounding (6e-8 relative) of a bound, whatever its magnitude
+        const double pad0 = 1e-5 * (L[0] + L[1] + L[2]) + 1e-6;
+        float l[3], h[3];
+        for (int ax = 0; ax < 3; ++ax) {
+            const double pad = pad0 + 2.5e-7 * __builtin_fmax(__builtin_fabs(lo[ax]), __builtin_fabs(hi[ax]));
+            l[ax] = (float)(lo[ax] - pad);
+            h[ax] = (float)(hi[ax] + pad);
+        }
+        lo4 = make_float4(l[0], l[1], l[2], 1.f);
+        hi4 = make_float4(h[0], h[1], h[2], 1.f);
     }
     boxes[((size_t)f * n_groups + g) * 2] = lo4;
     boxes[((size_t)f * n_groups + g) * 2 + 1] = hi4;
 }
 
-// periodic gap between [a0,a1] and [b0,b1] on a circle of circumference 1
-__device__ __forceinline__ double interval_gap(double a0, double a1, double b0, double b1)
+// Lower bound of the reference's per-axis distance min(|d|, ||d| - L|) = dist(d, {0, +L, -L}) over all
+// d = a - b with a in [a0,a1], b in [b0,b1]: the gap between the d interval and the nearest of those points.
+__device__ __forceinline__ double interval_gap(double a0, double a1, double b0, double b1, double L)
 {
-    double g = __builtin_fmax(b0 - a1, a0 - b1);           // direct
-    const double g1 = __builtin_fmax(b0 + 1.0 - a1, a0 - (b1 + 1.0));  // b shifted by +1
-    const double g2 = __builtin_fmax(b0 - 1.0 - a1, a0 - (b1 - 1.0));  // b shifted by -1
+    double g = __builtin_fmax(b0 - a1, a0 - b1);                   // to d = 0
+    const double g1 = __builtin_fmax(b0 + L - a1, a0 - (b1 + L));  // to d = +L
+    const double g2 = __builtin_fmax(b0 - L - a1, a0 - (b1 - L));  // to d = -L
     g = __builtin_fmin(g, __builtin_fmin(g1, g2));
     return g > 0.0 ? g : 0.0;
 }
@@ -743,6 +785,9 @@ __global__ __launch_bounds__(256) void cull_list_kernel(const double *__restrict
     __syncthreads();
     const double *bi = bbox + ((size_t)f * nT + I) * 6;
     const double Lx = box[3 * f], Ly = box[3 * f + 1], Lz = box[3 * f + 2];
+    // slack for the roundings of the box arithmetic (the pair kernel decides every listed pair exactly)
+    const double sl = 1e-12 * (__builtin_fabs(bi[0]) + __builtin_fabs(bi[3]) + __builtin_fabs(bi[1]) +
+                               __builtin_fabs(bi[4]) + __builtin_fabs(bi[2]) + __builtin_fabs(bi[5]) + Lx + Ly + Lz);
     unsigned short *row = list + ((size_t)f * nT + I) * nT;
     // candidates = the half shell J = I, I+1, ..., I+S-1 (mod nT): every unordered tile pair belongs to
     // exactly one row and all rows have about the same length (a plain J >= I scan would be triangular)
@@ -751,9 +796,12 @@ __global__ __launch_bounds__(256) void cull_list_kernel(const double *__restrict
         int J = I + sft;
         J = J >= nT ? J - nT : J;
         const double *bj = bbox + ((size_t)f * nT + J) * 6;
-        const double gx = interval_gap(bi[0], bi[3], bj[0], bj[3]) * Lx;
-        const double gy = interval_gap(bi[1], bi[4], bj[1], bj[4]) * Ly;
-        const double gz = interval_gap(bi[2], bi[5], bj[2], bj[5]) * Lz;
+        double gx = interval_gap(bi[0], bi[3], bj[0], bj[3], Lx) - sl;
+        double gy = interval_gap(bi[1], bi[4], bj[1], bj[4], Ly) - sl;
+        double gz = interval_gap(bi[2], bi[5], bj[2], bj[5], Lz) - sl;
+        gx = gx > 0.0 ? gx : 0.0;
+        gy = gy > 0.0 ? gy : 0.0;
+        gz = gz > 0.0 ? gz : 0.0;
         if (gx * gx + gy * gy + gz * gz <= rc2_test) row[atomicAdd(&s_n, 1)] = (unsigned short)J;
     }
     __syncthreads();
@@ -766,8 +814,17 @@ __global__ __launch_bounds__(256) void cull_list_kernel(const double *__restrict
 // with SCALAR loads (s_load_dwordx8 from the sorted record array, through the scalar cache) and used as
 // scalar operands of the rsq chain — no LDS staging of tiles, no barrier per tile, so a wave that culls
 // more groups than its neighbours never waits for them. LDS holds only the class histograms (shared by
-// the block's waves), the row table and, for CN, the few edges. Arithmetic, binning and flush are the
-// fast kernel's.
+// the block's waves), the row table and, for CN, the few edges. Binning and flush are the fast kernel's.
+//
+// Wrap decisions hoisted out of the pair loop. The wave knows the bounding box of its 64 i atoms and of
+// every 8-atom j group (coordinates as given), hence the interval [dlo, dhi] that contains every
+// d = xi - xj of the 512 pairs, per axis. The reference wraps d iff d > L/2 or d < -L/2, so
+//   dlo >= -L/2 + m and dhi <= L/2 - m : no pair wraps            -> d' = d            (VAR 2: all three axes)
+//   dlo >=  L/2 + m                    : every pair takes d - L   -> d' = d + s, s = -L (VAR 1: every axis is
+//   dhi <= -L/2 - m                    : every pair takes d + L   -> d' = d + s, s = +L  one of the three)
+//   otherwise                          : per-pair decision        -> min(|d|, ||d| - L|) (VAR 0)
+// d + (-L) is the reference's d - sign(d)*L operation and d + 0 is d, so the doubles entering rsq are the
+// same in all three variants; m = 1e-4 * L/2 dwarfs the f32 rounding of the (outward widened) boxes.
 // ------------------------------------------------------------------------------------------------
 typedef unsigned int u32x8 __attribute__((ext_vector_type(8)));
 
@@ -789,10 +846,23 @@ __device__ __forceinline__ void sload_records4(const double4 *p, u32x8 &r0, u32x
         : "memory");
 }
 
-template <bool DIAG, int MODE>
+struct AxisL {
+    double Lx, Ly, Lz;  // box lengths (VAR 0)
+    double sx, sy, sz;  // wave-uniform shifts in {-L, 0, +L} (VAR 1)
+};
+
+template <int VAR>
+__device__ __forceinline__ double axis_abs(double d, double L, double sft)
+{
+    if (VAR == 0) return wrap_abs(d, L);
+    if (VAR == 1) return d + sft;
+    return d;
+}
+
+template <bool DIAG, int MODE, int VAR>
 __device__ __forceinline__ void sweep_group_sj(const double4 *__restrict__ grp, int local0, double xi, double yi,
-                                               double zi, double Lx, double Ly, double Lz, double rc2,
-                                               const FastCtx &c, int lane_in_tile)
+                                               double zi, const AxisL &L, double rc2, const FastCtx &c,
+                                               int lane_in_tile)
 {
     constexpr int U = 4;  // records per batch of scalar loads (4 x 8 SGPRs)
 #pragma unroll
@@ -806,9 +876,9 @@ __device__ __forceinline__ void sweep_group_sj(const double4 *__restrict__ grp, 
             const double xj = __hiloint2double((int)rec[u][1], (int)rec[u][0]);
             const double yj = __hiloint2double((int)rec[u][3], (int)rec[u][2]);
             const double zj = __hiloint2double((int)rec[u][5], (int)rec[u][4]);
-            const double ax = wrap_abs(xi - xj, Lx);
-            const double ay = wrap_abs(yi - yj, Ly);
-            const double az = wrap_abs(zi - zj, Lz);
+            const double ax = axis_abs<VAR>(xi - xj, L.Lx, L.sx);
+            const double ay = axis_abs<VAR>(yi - yj, L.Ly, L.sy);
+            const double az = axis_abs<VAR>(zi - zj, L.Lz, L.sz);
             rsq[u] = (ax * ax + ay * ay) + az * az;
             row[u] = c.rowtab_me[(int)rec[u][6]];  // low word of w = type * n_ti
         }
@@ -837,19 +907,111 @@ __device__ __forceinline__ void sweep_group_sj(const double4 *__restrict__ grp, 
     }
 }
 
+// per-axis wrap class of a (wave box, group box) pair: bit 0 = every pair takes d - L, bit 1 = every pair
+// takes d + L, bit 2 = undecided (per-pair decision needed); 0 = no pair wraps
+__device__ __forceinline__ unsigned wrap_class(float wlo, float whi, float glo, float ghi, float L)
+{
+    const float dlo = wlo - ghi, dhi = whi - glo;
+    const float h = 0.5f * L, m = 1.0e-4f * h;
+    if (dlo >= -(h - m) && dhi <= h - m) return 0u;
+    if (dlo >= h + m) return 1u;
+    if (dhi <= -(h + m)) return 2u;
+    return 4u;
+}
+
+// One work item of the scalar-j sweep: the 64 i atoms of wave `wq` of tile I of frame f against slice
+// `split` of the tile's neighbour list.
 template <int MODE>
+__device__ __forceinline__ void sj_item(const PairArgs &a, FastCtx &c, const unsigned *s_row, int f, int I, int wq,
+                                        int split, int lane)
+{
+    const long long n_pad = (long long)a.nTi * TILE;
+    const long long rowid = (long long)f * a.nTi + I;
+    const int cnt = a.list_cnt[rowid];
+    const unsigned short *row_list = a.list + rowid * a.nTi;
+    const int t_begin = (int)((long long)split * cnt / a.jsplit);
+    const int t_end = (int)((long long)(split + 1) * cnt / a.jsplit);
+    if (t_begin >= t_end) return;
+    AxisL L;
+    L.Lx = a.box[3 * f];
+    L.Ly = a.box[3 * f + 1];
+    L.Lz = a.box[3 * f + 2];
+    L.sx = L.sy = L.sz = 0.0;
+    const double4 *ats = a.aos + (long long)f * n_pad;
+    const int lane_in_tile = wq * 64 + lane;
+    const long long ig = (long long)I * TILE + lane_in_tile;
+    double4 me = ats[ig];
+    if (ig >= a.ni) me = make_double4(PAD_I, PAD_I, PAD_I, __longlong_as_double(0LL));
+    c.rowtab_me = s_row + (int)(__double_as_longlong(me.w) / a.n_ti);
+    const long long w = ((long long)f * a.nTi + I) * (TILE / 64) + wq;
+    const float4 wlo = a.wsph[2 * w], whi = a.wsph[2 * w + 1];
+    const float4 *gb_f = a.gsph + (long long)f * a.nTi * (TILE / 8) * 2;
+    const float fLx = (float)L.Lx, fLy = (float)L.Ly, fLz = (float)L.Lz;
+    for (int t = t_begin; t < t_end; ++t) {
+        const int J = __builtin_amdgcn_readfirstlane((int)row_list[t]);
+        // lanes 0..31 (mirrored in 32..63) test one 8-atom group box each against this wave's box
+        const float4 glo = gb_f[((long long)J * (TILE / 8) + (lane & 31)) * 2];
+        const float4 ghi = gb_f[((long long)J * (TILE / 8) + (lane & 31)) * 2 + 1];
+        const float gx = gapf(wlo.x, whi.x, glo.x, ghi.x, fLx);
+        const float gy = gapf(wlo.y, whi.y, glo.y, ghi.y, fLy);
+        const float gz = gapf(wlo.z, whi.z, glo.z, ghi.z, fLz);
+        const bool keep = wlo.w > 0.f && glo.w > 0.f && gx * gx + gy * gy + gz * gz < a.reach * a.reach;
+        const double4 *tile = ats + (long long)J * TILE;
+        if (J == I) {
+            unsigned mask = (unsigned)__builtin_amdgcn_ballot_w64(keep);
+            while (mask) {
+                const int g = __builtin_ctz(mask);
+                mask &= mask - 1;
+                sweep_group_sj<true, MODE, 0>(tile + g * 8, g * 8, me.x, me.y, me.z, L, a.rc2, c, lane_in_tile);
+            }
+            continue;
+        }
+        const unsigned cx = wrap_class(wlo.x, whi.x, glo.x, ghi.x, fLx);
+        const unsigned cy = wrap_class(wlo.y, whi.y, glo.y, ghi.y, fLy);
+        const unsigned cz = wrap_class(wlo.z, whi.z, glo.z, ghi.z, fLz);
+        const unsigned call = cx | cy | cz;
+        unsigned m0 = (unsigned)__builtin_amdgcn_ballot_w64(keep && (call & 4u));
+        unsigned m1 = (unsigned)__builtin_amdgcn_ballot_w64(keep && !(call & 4u) && call);
+        unsigned m2 = (unsigned)__builtin_amdgcn_ballot_w64(keep && !call);
+        while (m2) {
+            const int g = __builtin_ctz(m2);
+            m2 &= m2 - 1;
+            sweep_group_sj<false, MODE, 2>(tile + g * 8, g * 8, me.x, me.y, me.z, L, a.rc2, c, lane_in_tile);
+        }
+        if (m1) {
+            const unsigned xm = (unsigned)__builtin_amdgcn_ballot_w64(cx == 1u), xp = (unsigned)__builtin_amdgcn_ballot_w64(cx == 2u);
+            const unsigned ym = (unsigned)__builtin_amdgcn_ballot_w64(cy == 1u), yp = (unsigned)__builtin_amdgcn_ballot_w64(cy == 2u);
+            const unsigned zm = (unsigned)__builtin_amdgcn_ballot_w64(cz == 1u), zp = (unsigned)__builtin_amdgcn_ballot_w64(cz == 2u);
+            while (m1) {
+                const int g = __builtin_ctz(m1);
+                m1 &= m1 - 1;
+                AxisL S = L;
+                S.sx = ((xm >> g) & 1u) ? -L.Lx : ((xp >> g) & 1u) ? L.Lx : 0.0;
+                S.sy = ((ym >> g) & 1u) ? -L.Ly : ((yp >> g) & 1u) ? L.Ly : 0.0;
+                S.sz = ((zm >> g) & 1u) ? -L.Lz : ((zp >> g) & 1u) ? L.Lz : 0.0;
+                sweep_group_sj<false, MODE, 1>(tile + g * 8, g * 8, me.x, me.y, me.z, S, a.rc2, c, lane_in_tile);
+            }
+        }
+        while (m0) {
+            const int g = __builtin_ctz(m0);
+            m0 &= m0 - 1;
+            sweep_group_sj<false, MODE, 0>(tile + g * 8, g * 8, me.x, me.y, me.z, L, a.rc2, c, lane_in_tile);
+        }
+    }
+}
+
+// PERSIST = true (frame-summed output): the grid is one resident set of blocks; every WAVE draws items
+// (frame, tile, wave, list slice) from its XCD's counter — frames stay dealt to XCDs (f % 8) so a frame's
+// records live in one L2 — and the block flushes its LDS histograms once, when its four waves have run
+// dry. Every wave leaves the loop as soon as the counter passes the item count.
+// PERSIST = false (per-frame output): block = (frame, tile, list slice), one flush per block.
+template <int MODE, bool PERSIST>
 __global__ __launch_bounds__(TILE) void pair_hist_sj_kernel(const PairArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const long long bid = blockIdx.x;
     const int xcd = (int)(bid & 7);
-    const long long q = bid >> 3;
-    const int fgroup = (int)(q / a.blocks_per_frame);
-    const int within = (int)(q % a.blocks_per_frame);
-    const int I = within % a.nTi;
-    const int split = within / a.nTi;
-    if ((fgroup * a.fpb) * 8 + xcd >= a.n_frames) return;
 
     // ---- LDS: hist | (CN edges) | row table ----
     const int row_len = a.nbins + 1;
@@ -880,51 +1042,27 @@ __global__ __launch_bounds__(TILE) void pair_hist_sj_kernel(const PairArgs a)
     c.nbins = a.nbins;
     __syncthreads();  // tables ready; from here on the waves do not synchronise until the flush
 
-    const long long n_pad = (long long)a.nTi * TILE;
-    int f_last = 0;
-    for (int kf = 0; kf < a.fpb; ++kf) {
-        const int f = (fgroup * a.fpb + kf) * 8 + xcd;
-        if (f >= a.n_frames) break;
-        f_last = f;
-        const long long rowid = (long long)f * a.nTi + I;
-        const int cnt = a.list_cnt[rowid];
-        const unsigned short *row_list = a.list + rowid * a.nTi;
-        const int t_begin = (int)((long long)split * cnt / a.jsplit);
-        const int t_end = (int)((long long)(split + 1) * cnt / a.jsplit);
-        if (t_begin >= t_end) continue;
-        const double Lx = a.box[3 * f], Ly = a.box[3 * f + 1], Lz = a.box[3 * f + 2];
-        const double4 *ats = a.aos + (long long)f * n_pad;
-        double4 me = ats[(long long)I * TILE + tid];
-        if ((long long)I * TILE + tid >= a.ni) me = make_double4(PAD_I, PAD_I, PAD_I, __longlong_as_double(0LL));
-        c.rowtab_me = s_row + (int)(__double_as_longlong(me.w) / a.n_ti);
-        const long long w = ((long long)f * a.nTi + I) * (TILE / 64) + (tid >> 6);
-        const float4 wlo = a.wsph[2 * w], whi = a.wsph[2 * w + 1];
-        const float4 *gb_f = a.gsph + (long long)f * a.nTi * (TILE / 8) * 2;
-        for (int t = t_begin; t < t_end; ++t) {
-            const int J = __builtin_amdgcn_readfirstlane((int)row_list[t]);
-            // lanes 0..31 (mirrored in 32..63) test one 8-atom group box each against this wave's box
-            const float4 glo = gb_f[((long long)J * (TILE / 8) + (tid & 31)) * 2];
-            const float4 ghi = gb_f[((long long)J * (TILE / 8) + (tid & 31)) * 2 + 1];
-            const float gx = gapf(wlo.x, whi.x, glo.x, ghi.x, (float)Lx);
-            const float gy = gapf(wlo.y, whi.y, glo.y, ghi.y, (float)Ly);
-            const float gz = gapf(wlo.z, whi.z, glo.z, ghi.z, (float)Lz);
-            const bool keep = wlo.w > 0.f && glo.w > 0.f && gx * gx + gy * gy + gz * gz < a.reach * a.reach;
-            unsigned mask = (unsigned)__builtin_amdgcn_ballot_w64(keep);
-            const double4 *tile = ats + (long long)J * TILE;
-            if (J == I) {
-                while (mask) {
-                    const int g = __builtin_ctz(mask);
-                    mask &= mask - 1;
-                    sweep_group_sj<true, MODE>(tile + g * 8, g * 8, me.x, me.y, me.z, Lx, Ly, Lz, a.rc2, c, tid);
-                }
-            } else {
-                while (mask) {
-                    const int g = __builtin_ctz(mask);
-                    mask &= mask - 1;
-                    sweep_group_sj<false, MODE>(tile + g * 8, g * 8, me.x, me.y, me.z, Lx, Ly, Lz, a.rc2, c, tid);
-                }
-            }
+    const int lane = tid & 63;
+    int f_out = 0;
+    if (PERSIST) {
+        const int nfx = a.n_frames > xcd ? (a.n_frames - xcd + 7) / 8 : 0;  // frames of this XCD
+        const int ipf = a.nTi * (TILE / 64) * a.jsplit;                       // items per frame
+        const long long n_items = (long long)nfx * ipf;
+        for (;;) {
+            unsigned it = 0;
+            if (lane == 0) it = atomicAdd(&a.work[xcd], 1u);
+            it = (unsigned)__builtin_amdgcn_readfirstlane((int)it);
+            if ((long long)it >= n_items) break;
+            const int fx = (int)(it / (unsigned)ipf), r = (int)(it % (unsigned)ipf);
+            const int split = r % a.jsplit, wI = r / a.jsplit;
+            sj_item<MODE>(a, c, s_row, fx * 8 + xcd, wI >> 2, wI & 3, split, lane);
         }
+    } else {
+        const long long q = bid >> 3;
+        const int f = (int)(q / a.blocks_per_frame) * 8 + xcd;
+        const int within = (int)(q % a.blocks_per_frame);
+        f_out = f < a.n_frames ? f : 0;
+        if (f < a.n_frames) sj_item<MODE>(a, c, s_row, f, within % a.nTi, tid >> 6, within / a.nTi, lane);
     }
 
     // ---- flush (as the fast kernel) ----
@@ -932,7 +1070,7 @@ __global__ __launch_bounds__(TILE) void pair_hist_sj_kernel(const PairArgs a)
     __syncthreads();
     const int out_words = a.n_cls * a.nbins;
     unsigned long long *g =
-        a.hist + (size_t)(a.per_frame ? f_last : (int)(bid % a.slots)) * (size_t)out_words;
+        a.hist + (size_t)(a.per_frame ? f_out : (int)(bid % a.slots)) * (size_t)out_words;
     unsigned ovf = 0;
     for (int w = tid; w < hist_words; w += TILE) {
         const unsigned v = s_hist[w];
@@ -1048,6 +1186,8 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
     }
     if (jsplit > max_list) jsplit = max_list;
     if (cull && jsplit > 4) jsplit = 4;
+    // persistent scalar-j kernel: items are (frame, tile, wave, slice); 4 slices measured best at C2 and C3
+    if (cull && ctx->opt_rdf_sj == 1 && !p.per_frame && ctx->opt_rdf_jsplit <= 0) jsplit = std::min(4, max_list);
     if (jsplit < 1) jsplit = 1;
     const int blocks_per_frame = nTi * jsplit;
     // frames per block (fast kernel, frame-summed output): as many as keeps >= `want` blocks in flight
@@ -1102,13 +1242,18 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         KernelTimer ptimer(ctx);
         MD_HIP(hipMemsetAsync(d_cells, 0, (size_t)F * MORTON_CELLS * 4, ctx->stream));
         const dim3 ga((unsigned)((N + 255) / 256), (unsigned)F);
-        hipLaunchKernelGGL(cull_keys_kernel, ga, dim3(256), 0, ctx->stream, p.d_xi, p.d_box, N, d_keys, d_cells);
+        MD_WS(d_org, unsigned long long, WS_ORIGIN, (size_t)F * 3 * 8);
+        MD_HIP(hipMemsetAsync(d_org, 0xFF, (size_t)F * 3 * 8, ctx->stream));
+        const unsigned og = (unsigned)std::min<long long>((N + 255) / 256, 64);
+        hipLaunchKernelGGL(cull_origin_kernel, dim3(og, (unsigned)F), dim3(256), 0, ctx->stream, p.d_xi, N, d_org);
+        hipLaunchKernelGGL(cull_keys_kernel, ga, dim3(256), 0, ctx->stream, p.d_xi, p.d_box, N, d_org, d_keys,
+                           d_cells);
         hipLaunchKernelGGL(cull_scan_kernel, dim3((unsigned)F), dim3(256), 0, ctx->stream, d_cells);
         hipLaunchKernelGGL(cull_scatter_kernel, ga, dim3(256), 0, ctx->stream, p.d_xi, p.d_ti,
                            (long long)p.ti_fs, N, d_keys, d_cells, d_sx, d_st, d_ao, (long long)nTi * TILE,
                            p.n_ti);
         hipLaunchKernelGGL(cull_bbox_kernel, dim3((unsigned)nTi, (unsigned)F), dim3(TILE), 0, ctx->stream,
-                           d_sx, p.d_box, N, nTi, d_bbox);
+                           d_sx, N, nTi, d_bbox);
         hipLaunchKernelGGL(cull_list_kernel, dim3((unsigned)nTi, (unsigned)F), dim3(256), 0, ctx->stream,
                            d_bbox, p.d_box, nTi, p.rc2 * (1.0 + 1e-9) + 1e-9, d_l, d_lc);
         const long long nG = (long long)nTi * (TILE / 8), nW = (long long)nTi * (TILE / 64);
@@ -1185,25 +1330,51 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         a.fpb = fpb;
 
         const bool sj = cull && ctx->opt_rdf_sj != 0;  // wave-independent sweep with scalar loads of the j atoms
+        const bool persist = sj && !p.per_frame && ctx->opt_rdf_sj != 2;  // resident grid + per-XCD work counters
+        a.work = reinterpret_cast<unsigned *>(d_misc + 4);
         const size_t lds = sj     ? lds_bytes_sj(p.nbins, nc, p.n_ti, p.n_tj, mode_cn)
                            : fast ? lds_bytes_fast(p.nbins, nc, p.n_ti, p.n_tj)
                                   : lds_bytes(p.nbins, nc, p.n_ti, p.n_tj);
         void (*kern)(const PairArgs);
+#define MD_PICK(...) (ctx->last_kernel = #__VA_ARGS__, __VA_ARGS__)
         if (!fast)
-            kern = p.tri ? pair_hist_kernel<true> : pair_hist_kernel<false>;
+            kern = p.tri ? MD_PICK(pair_hist_kernel<true>) : MD_PICK(pair_hist_kernel<false>);
+        else if (persist)
+            kern = mode_cn ? MD_PICK(pair_hist_sj_kernel<1, true>) : MD_PICK(pair_hist_sj_kernel<0, true>);
         else if (sj)
-            kern = mode_cn ? pair_hist_sj_kernel<1> : pair_hist_sj_kernel<0>;
+            kern = mode_cn ? MD_PICK(pair_hist_sj_kernel<1, false>) : MD_PICK(pair_hist_sj_kernel<0, false>);
         else if (cull)
-            kern = mode_cn ? pair_hist_fast_kernel<true, 8, 1, true> : pair_hist_fast_kernel<true, 8, 0, true>;
+            kern = mode_cn ? MD_PICK(pair_hist_fast_kernel<true, 8, 1, true>)
+                           : MD_PICK(pair_hist_fast_kernel<true, 8, 0, true>);
         else if (mode_cn)
-            kern = p.tri ? pair_hist_fast_kernel<true, 8, 1, false> : pair_hist_fast_kernel<false, 8, 1, false>;
+            kern = p.tri ? MD_PICK(pair_hist_fast_kernel<true, 8, 1, false>)
+                         : MD_PICK(pair_hist_fast_kernel<false, 8, 1, false>);
         else
-            kern = p.tri ? pair_hist_fast_kernel<true, 8, 0, false> : pair_hist_fast_kernel<false, 8, 0, false>;
+            kern = p.tri ? MD_PICK(pair_hist_fast_kernel<true, 8, 0, false>)
+                         : MD_PICK(pair_hist_fast_kernel<false, 8, 0, false>);
+#undef MD_PICK
         if (lds > 65536)
             MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        long long launch_grid = grid;
+        if (sj) {
+            // the scalar-j kernel handles one frame per block visit (no fpb loop)
+            a.fpb = 1;
+            launch_grid = ((F + 7) / 8) * 8 * blocks_per_frame;
+        }
+        if (persist) {
+            int per_cu = 0;
+            MD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), TILE,
+                                                                lds));
+            if (per_cu < 1) per_cu = 1;
+            const long long items = (long long)F * nTi * (TILE / 64) * jsplit;
+            launch_grid = (long long)per_cu * ctx->cu_count;
+            launch_grid = std::min(launch_grid, (items + 3) / 4 + 8);
+            launch_grid = (launch_grid + 7) / 8 * 8;
+            MD_HIP(hipMemsetAsync(d_misc + 4, 0, 32, ctx->stream));
+        }
         KernelTimer timer(ctx);
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(TILE), lds, ctx->stream, a);
+        hipLaunchKernelGGL(kern, dim3((unsigned)launch_grid), dim3(TILE), lds, ctx->stream, a);
         timer.stop();
         MD_HIP(hipGetLastError());
 

@@ -438,6 +438,54 @@ def test_culled_path_equals_dense_and_oracle(B):
         np.testing.assert_array_equal(val[2], ref[2])
 
 
+@pytest.mark.parametrize("case", ["centred", "offset", "half_box_lattice", "long_cut", "strays"])
+def test_culled_path_wrap_variants(B, case):
+    """The scalar-j kernel hoists wrap decisions out of the pair loop per (wave box, group box): cells with
+    lo != 0, pairs at d == L/2 exactly (the reference wraps only for d > L/2), cutoffs near L/2 and atoms
+    box lengths outside the cell must all give the C oracle's integers, for every kernel organisation."""
+    from mdproptools_amd._lib import Context
+
+    rng = np.random.default_rng({"centred": 1, "offset": 2, "half_box_lattice": 3, "long_cut": 4, "strays": 5}[case])
+    n = 4200  # 17 tiles
+    L = np.array([32.0, 32.0, 32.0])
+    r_cut, nb = 7.0, 140
+    if case == "centred":
+        xyz = rng.uniform(-0.5, 0.5, (3, n)) * L[:, None]
+    elif case == "offset":
+        L = np.array([30.0, 34.0, 38.0])
+        xyz = rng.uniform(-0.3, 0.7, (3, n)) * L[:, None]
+    elif case == "half_box_lattice":
+        # multiples of L/64 = 0.5: differences hit +-L/2 = +-16 exactly, and many distances are bin edges
+        xyz = rng.integers(0, 64, (3, n)).astype(np.float64) * 0.5
+        r_cut, nb = 6.0, 120
+    elif case == "long_cut":
+        xyz = rng.uniform(0.0, 1.0, (3, n)) * L[:, None]
+        r_cut, nb = 15.5, 310  # just below L/2: nearly every group pair needs a decision
+    else:
+        xyz = rng.uniform(0.0, 1.0, (3, n)) * L[:, None]
+        idx = rng.choice(n, 300, replace=False)
+        xyz[:, idx] += rng.integers(-3, 4, (3, 300)) * L[:, None]
+    xyz = np.ascontiguousarray(xyz)[None]
+    ty = rng.integers(1, 4, n).astype(np.int32)
+    rel = np.array([[1, 1], [1, 2], [2, 3], [3, 3], [1, 3]])
+    cuts = [2.5, 3.0, 4.5, 6.0, 5.0]
+    cf, cp, cov = C.rdf_pairs(xyz[0], ty, rel, L, r_cut * r_cut, 0.05, nb)
+    ccn = C.cn_pairs(xyz[0], ty, rel, L, [c * c for c in cuts])
+    assert cf.sum() > 0
+    for cull, sj in ((0, 1), (1, 0), (1, 1), (1, 2)):
+        ctx = Context(0)
+        ctx.set_option("rdf_cull", cull)
+        ctx.set_option("rdf_sj", sj)
+        for per_frame in (True, False):
+            full, part, ov = B.rdf_loop(xyz, ty, L[None], rel, r_cut, 0.05, nb, per_frame=per_frame, ctx=ctx)
+            full, part = (full[0], part[0]) if per_frame else (full, part)
+            np.testing.assert_array_equal(full, cf, err_msg="%s cull=%d sj=%d pf=%d" % (case, cull, sj, per_frame))
+            np.testing.assert_array_equal(part, cp)
+            assert ov == cov
+        np.testing.assert_array_equal(B.cn_loop(xyz, ty, L[None], rel, cuts, ctx=ctx)[0], ccn)
+        ctx.close()
+
+
 def test_culled_path_large_box_auto(B):
     """BASELINE C3 geometry at reduced N (same density: L = 48.3 A for 10k atoms, r_cut 6.8): the
     automatic choice takes the culled path; result against the C oracle."""
