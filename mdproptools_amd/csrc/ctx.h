@@ -46,13 +46,19 @@ struct DevBuf {
     size_t cap = 0;
 };
 
+// Pinned host staging buffers (growable, owned by the context): small tables go to the device and results
+// come back through them, so that the copies are truly asynchronous and a call needs one stream sync.
+enum PinSlot { PIN_TYPES = 0, PIN_TABLES, PIN_OUT, PIN_COUNT };
+
 struct mdhip_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev2 = nullptr, ev3 = nullptr;  // second pair: preparation kernels, collected without a sync of their own
     std::string err;
     DevBuf ws[WS_COUNT];
+    DevBuf pin[PIN_COUNT];
     double last_ms = 0.0;
     double last_aux_ms = 0.0;  // device time of the preparation kernels of the last call (e.g. spatial sort)
     int last_launches = 0;
@@ -76,6 +82,7 @@ struct mdhip_ctx {
 
 int mdhip_fail(mdhip_ctx *ctx, int code, const char *fmt, ...);
 void *mdhip_ws(mdhip_ctx *ctx, int slot, size_t bytes);  // nullptr on failure (error set)
+void *mdhip_pin(mdhip_ctx *ctx, int slot, size_t bytes);  // pinned host memory; nullptr on failure (error set)
 
 #define MD_HIP(call)                                                                          \
     do {                                                                                      \
@@ -92,6 +99,10 @@ void *mdhip_ws(mdhip_ctx *ctx, int slot, size_t bytes);  // nullptr on failure (
 
 #define MD_WS(var, type, slot, bytes)                          \
     type *var = (type *)mdhip_ws(ctx, slot, bytes);            \
+    if (!var) return MDHIP_ENOMEM;
+
+#define MD_PIN(var, type, slot, bytes)                         \
+    type *var = (type *)mdhip_pin(ctx, slot, bytes);           \
     if (!var) return MDHIP_ENOMEM;
 
 // Stage `bytes` from a host-or-device source into workspace `slot` unless it is already on the device.
@@ -115,16 +126,22 @@ static inline const void *mdhip_stage(mdhip_ctx *ctx, int slot, const void *src,
 
 struct KernelTimer {
     mdhip_ctx *ctx;
-    explicit KernelTimer(mdhip_ctx *c, int launches = 1) : ctx(c)
+    hipEvent_t e0, e1;
+    // aux = true: the second event pair (preparation kernels); collect() then returns the time instead of
+    // storing it in last_ms
+    explicit KernelTimer(mdhip_ctx *c, int launches = 1, bool aux = false)
+        : ctx(c), e0(aux ? c->ev2 : c->ev0), e1(aux ? c->ev3 : c->ev1)
     {
-        ctx->last_launches = launches;
-        (void)hipEventRecord(ctx->ev0, ctx->stream);
+        if (!aux) ctx->last_launches = launches;
+        (void)hipEventRecord(e0, ctx->stream);
     }
-    void stop() { (void)hipEventRecord(ctx->ev1, ctx->stream); }
+    void stop() { (void)hipEventRecord(e1, ctx->stream); }
     // call after the stream has been synchronised
-    void collect()
+    double collect()
     {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->last_ms = ms;
+        if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return 0.0;
+        if (e0 == ctx->ev0) ctx->last_ms = ms;
+        return ms;
     }
 };

@@ -45,6 +45,30 @@ void *mdhip_ws(mdhip_ctx *ctx, int slot, size_t bytes)
     return b.p;
 }
 
+void *mdhip_pin(mdhip_ctx *ctx, int slot, size_t bytes)
+{
+    DevBuf &b = ctx->pin[slot];
+    if (bytes == 0) bytes = 16;
+    if (b.cap >= bytes) return b.p;
+    if (b.p) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipHostFree(b.p);
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t cap = bytes + (bytes >> 2);
+    cap = (cap + 4095) & ~size_t(4095);
+    hipError_t e = hipHostMalloc(&b.p, cap, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        mdhip_fail(ctx, MDHIP_ENOMEM, "hipHostMalloc(%zu) failed for staging buffer %d: %s", cap, slot,
+                   hipGetErrorString(e));
+        return nullptr;
+    }
+    b.cap = cap;
+    return b.p;
+}
+
 extern "C" {
 
 int mdhip_version(void) { return MDHIP_VERSION; }
@@ -83,7 +107,8 @@ int mdhip_create(mdhip_ctx **out, int device)
                                                               : 65536;
     }
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
+        hipEventCreate(&ctx->ev2) != hipSuccess || hipEventCreate(&ctx->ev3) != hipSuccess) {
         delete ctx;
         return mdhip_fail(nullptr, MDHIP_EHIP, "mdhip_create: stream/event creation failed");
     }
@@ -105,8 +130,12 @@ void mdhip_destroy(mdhip_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &b : ctx->ws)
         if (b.p) (void)hipFree(b.p);
+    for (auto &b : ctx->pin)
+        if (b.p) (void)hipHostFree(b.p);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
+    if (ctx->ev3) (void)hipEventDestroy(ctx->ev3);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }

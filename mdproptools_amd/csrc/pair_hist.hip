@@ -587,40 +587,39 @@ __device__ __forceinline__ unsigned hilbert3(unsigned cx, unsigned cy, unsigned 
     return key;
 }
 
-// Order-preserving map double -> u64 (for atomicMin on coordinates) and back.
-__device__ __forceinline__ unsigned long long dkey(double v)
-{
-    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
-}
-__device__ __forceinline__ double dkey_inv(unsigned long long k)
-{
-    const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
-    return __longlong_as_double((long long)b);
-}
-
-// origin[f][3] = smallest x, y, z of the frame (as dkey; the buffer starts as all ones). The grid is laid
-// from there, so that a cell [lo, lo+L) with any lo is cut at its own faces and not somewhere inside.
+// origin[f][3] ~ smallest x, y, z of the frame, from 1024 atoms spread over the id range (one block per
+// frame). The grid of the spatial sort is laid from there, so that a cell [lo, lo+L) with any lo is cut at
+// its own faces and not somewhere inside. Only the quality of the sort depends on it (an origin a little
+// inside the cell sends a thin slice of atoms to the far end of the curve), never a result.
 __global__ __launch_bounds__(256) void cull_origin_kernel(const double *__restrict__ xyz, long long n,
-                                                          unsigned long long *__restrict__ origin)
+                                                          double *__restrict__ origin)
 {
-    const int f = blockIdx.y;
+    __shared__ double red[3][4];
+    const int f = blockIdx.x;
     const double *x = xyz + (size_t)f * 3 * n;
     double lo[3] = {1e300, 1e300, 1e300};
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    const long long stride = n > 1024 ? n / 1024 : 1;
+    for (int k = threadIdx.x; k < 1024; k += 256) {
+        const long long i = (long long)k * stride;
+        if (i < n)
 #pragma unroll
-        for (int ax = 0; ax < 3; ++ax) lo[ax] = __builtin_fmin(lo[ax], x[ax * n + i]);
+            for (int ax = 0; ax < 3; ++ax) lo[ax] = __builtin_fmin(lo[ax], x[ax * n + i]);
+    }
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) lo[ax] = __builtin_fmin(lo[ax], __shfl_down(lo[ax], off, 64));
-        if ((threadIdx.x & 63) == 0) atomicMin(&origin[3 * f + ax], dkey(lo[ax]));
+        if ((threadIdx.x & 63) == 0) red[ax][threadIdx.x >> 6] = lo[ax];
     }
+    __syncthreads();
+    if (threadIdx.x < 3)
+        origin[3 * f + threadIdx.x] = __builtin_fmin(__builtin_fmin(red[threadIdx.x][0], red[threadIdx.x][1]),
+                                                     __builtin_fmin(red[threadIdx.x][2], red[threadIdx.x][3]));
 }
 
 // keys[f][n] and cell populations cells[f][key]
 __global__ void cull_keys_kernel(const double *__restrict__ xyz, const double *__restrict__ box, long long n,
-                                 const unsigned long long *__restrict__ origin,
+                                 const double *__restrict__ origin,
                                  unsigned short *__restrict__ keys, unsigned *__restrict__ cells)
 {
     const int f = blockIdx.y;
@@ -631,7 +630,7 @@ __global__ void cull_keys_kernel(const double *__restrict__ xyz, const double *_
     unsigned c[3];
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax) {
-        int v = (int)(wrapped_frac(x[ax * n + i] - dkey_inv(origin[3 * f + ax]), box[3 * f + ax]) * G);
+        int v = (int)(wrapped_frac(x[ax * n + i] - origin[3 * f + ax], box[3 * f + ax]) * G);
         c[ax] = (unsigned)(v < 0 ? 0 : v > (1 << MORTON_BITS) - 1 ? (1 << MORTON_BITS) - 1 : v);
     }
     const unsigned key = hilbert3(c[0], c[1], c[2]);
@@ -677,90 +676,90 @@ __global__ void cull_scatter_kernel(const double *__restrict__ xyz, const int *_
     const unsigned key = keys[(size_t)f * n + i];
     const unsigned pos = atomicAdd(&cells[(size_t)f * MORTON_CELLS + key], 1u);
     const double *x = xyz + (size_t)f * 3 * n;
-    double *o = sxyz + (size_t)f * 3 * n;
-    o[pos] = x[i];
-    o[n + pos] = x[n + i];
-    o[2 * n + pos] = x[2 * n + i];
+    const double px = x[i], py = x[n + i], pz = x[2 * n + i];
     const int t = type[(size_t)f * type_fs + i];
-    stype[(size_t)f * n + pos] = t;
-    aos[(size_t)f * n_pad + pos] = make_double4(x[i], x[n + i], x[2 * n + i], __longlong_as_double((long long)t * n_ti));
+    if (sxyz) {  // SoA copy: only the LDS-tile kernel reads it
+        double *o = sxyz + (size_t)f * 3 * n;
+        o[pos] = px;
+        o[n + pos] = py;
+        o[2 * n + pos] = pz;
+        stype[(size_t)f * n + pos] = t;
+    }
+    aos[(size_t)f * n_pad + pos] = make_double4(px, py, pz, __longlong_as_double((long long)t * n_ti));
     // the pad records behind the last atom (never in cutoff: rsq overflows to +inf)
     if (i < n_pad - n) aos[(size_t)f * n_pad + n + i] = make_double4(PAD_J, PAD_J, PAD_J, __longlong_as_double(0LL));
 }
 
-// bbox[f][tile][6] = min/max of the coordinates (as given, not wrapped) of the tile's atoms
-__global__ __launch_bounds__(TILE) void cull_bbox_kernel(const double *__restrict__ sxyz, long long n, int nT,
-                                                         double *__restrict__ bbox)
+// Bounding boxes of one tile of the sorted records, coordinates as given (not wrapped), all three levels
+// in one pass: bbox[f][tile][6] (doubles, min xyz / max xyz, for the tile-pair lists), and in f32, widened
+// so that rounding can only make them larger, the boxes of every 8 consecutive atoms (one step of the pair
+// sweep) and of every 64 (the i atoms of one wave): boxes[2*g] = (lo.xyz, 1), boxes[2*g+1] = (hi.xyz, 1);
+// groups without atoms get w = 0 (never within reach).
+__global__ __launch_bounds__(TILE) void cull_boxes_kernel(const double4 *__restrict__ aos,
+                                                          const double *__restrict__ box, long long n, int nT,
+                                                          double *__restrict__ bbox, float4 *__restrict__ gboxes,
+                                                          float4 *__restrict__ wboxes)
 {
     __shared__ double red[6][TILE / 64];
-    const int f = blockIdx.y, T = blockIdx.x;
-    const long long i = (long long)T * TILE + threadIdx.x;
-    const double *x = sxyz + (size_t)f * 3 * n;
-    double lo[3], hi[3];
-#pragma unroll
-    for (int ax = 0; ax < 3; ++ax) {
-        if (i < n) {
-            lo[ax] = hi[ax] = x[ax * n + i];
-        } else {
-            lo[ax] = 1e300;
-            hi[ax] = -1e300;
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            lo[ax] = __builtin_fmin(lo[ax], __shfl_down(lo[ax], off, 64));
-            hi[ax] = __builtin_fmax(hi[ax], __shfl_down(hi[ax], off, 64));
-        }
-    }
-    const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0)
-        for (int ax = 0; ax < 3; ++ax) {
-            red[ax][wave] = lo[ax];
-            red[3 + ax][wave] = hi[ax];
-        }
-    __syncthreads();
-    if (threadIdx.x < 6) {
-        double v = red[threadIdx.x][0];
-        for (int w = 1; w < TILE / 64; ++w)
-            v = threadIdx.x < 3 ? __builtin_fmin(v, red[threadIdx.x][w]) : __builtin_fmax(v, red[threadIdx.x][w]);
-        bbox[((size_t)f * nT + T) * 6 + threadIdx.x] = v;
-    }
-}
-
-// Axis-aligned bounding boxes of every `group` consecutive sorted atoms (8: one step of the pair sweep;
-// 64: the i atoms of one wave) in the coordinates as given, stored in f32 and widened so that rounding can
-// only make them larger: boxes[2*g] = (lo.xyz, 1), boxes[2*g+1] = (hi.xyz, 1). Groups without atoms get
-// w = 0 (never within reach).
-__global__ void cull_box_kernel(const double *__restrict__ sxyz, const double *__restrict__ box, long long n,
-                                int group, long long n_groups, float4 *__restrict__ boxes)
-{
-    const int f = blockIdx.y;
-    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n_groups) return;
-    const double *x = sxyz + (size_t)f * 3 * n;
-    const double L[3] = {box[3 * f], box[3 * f + 1], box[3 * f + 2]};
-    const long long i0 = g * group, i1 = i0 + group < n ? i0 + group : n;
-    float4 lo4 = make_float4(0.f, 0.f, 0.f, 0.f), hi4 = lo4;
-    if (i0 < n) {
-        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-        for (long long i = i0; i < i1; ++i)
-            for (int ax = 0; ax < 3; ++ax) {
-                const double p = x[ax * n + i];
-                lo[ax] = __builtin_fmin(lo[ax], p);
-                hi[ax] = __builtin_fmax(hi[ax], p);
-            }
-        // >> the f32 rounding (6e-8 relative) of a bound, whatever its magnitude
-        const double pad0 = 1e-5 * (L[0] + L[1] + L[2]) + 1e-6;
+    const int f = blockIdx.y, T = blockIdx.x, tid = threadIdx.x;
+    const long long i = (long long)T * TILE + tid;
+    const double4 me = aos[((size_t)f * nT + T) * TILE + tid];
+    const bool real = i < n;
+    double lo[3] = {real ? me.x : 1e300, real ? me.y : 1e300, real ? me.z : 1e300};
+    double hi[3] = {real ? me.x : -1e300, real ? me.y : -1e300, real ? me.z : -1e300};
+    // >> the f32 rounding (6e-8 relative) of a bound, whatever its magnitude
+    const double pad0 = 1e-5 * (box[3 * f] + box[3 * f + 1] + box[3 * f + 2]) + 1e-6;
+    auto widened = [&](float4 &lo4, float4 &hi4) {
         float l[3], h[3];
+#pragma unroll
         for (int ax = 0; ax < 3; ++ax) {
             const double pad = pad0 + 2.5e-7 * __builtin_fmax(__builtin_fabs(lo[ax]), __builtin_fabs(hi[ax]));
             l[ax] = (float)(lo[ax] - pad);
             h[ax] = (float)(hi[ax] + pad);
         }
-        lo4 = make_float4(l[0], l[1], l[2], 1.f);
-        hi4 = make_float4(h[0], h[1], h[2], 1.f);
+        const float w = hi[0] >= lo[0] ? 1.f : 0.f;  // no atom: lo = 1e300 > hi
+        lo4 = w > 0.f ? make_float4(l[0], l[1], l[2], 1.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+        hi4 = w > 0.f ? make_float4(h[0], h[1], h[2], 1.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto fold = [&](int m) {
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            lo[ax] = __builtin_fmin(lo[ax], __shfl_xor(lo[ax], m, 64));
+            hi[ax] = __builtin_fmax(hi[ax], __shfl_xor(hi[ax], m, 64));
+        }
+    };
+    fold(1);
+    fold(2);
+    fold(4);
+    if ((tid & 7) == 0) {
+        float4 l4, h4;
+        widened(l4, h4);
+        const size_t g = ((size_t)f * nT + T) * (TILE / 8) + (tid >> 3);
+        gboxes[2 * g] = l4;
+        gboxes[2 * g + 1] = h4;
     }
-    boxes[((size_t)f * n_groups + g) * 2] = lo4;
-    boxes[((size_t)f * n_groups + g) * 2 + 1] = hi4;
+    fold(8);
+    fold(16);
+    fold(32);
+    const int wave = tid >> 6;
+    if ((tid & 63) == 0) {
+        float4 l4, h4;
+        widened(l4, h4);
+        const size_t w = ((size_t)f * nT + T) * (TILE / 64) + wave;
+        wboxes[2 * w] = l4;
+        wboxes[2 * w + 1] = h4;
+        for (int ax = 0; ax < 3; ++ax) {
+            red[ax][wave] = lo[ax];
+            red[3 + ax][wave] = hi[ax];
+        }
+    }
+    __syncthreads();
+    if (tid < 6) {
+        double v = red[tid][0];
+        for (int w = 1; w < TILE / 64; ++w)
+            v = tid < 3 ? __builtin_fmin(v, red[tid][w]) : __builtin_fmax(v, red[tid][w]);
+        bbox[((size_t)f * nT + T) * 6 + tid] = v;
+    }
 }
 
 // Lower bound of the reference's per-axis distance min(|d|, ||d| - L|) = dist(d, {0, +L, -L}) over all
@@ -1210,11 +1209,26 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
 
     // device tables
     const size_t edges_b = (size_t)(p.nbins + 2) * 8;  // + a +inf sentinel after the last edge
-    const size_t cls_b = (size_t)p.n_ti * p.n_tj;
-    MD_WS(d_tab, unsigned char, WS_TABLES, edges_b + cls_b + 64);
-    std::vector<double> edges_s(p.edges, p.edges + p.nbins + 1);
-    edges_s.push_back(std::numeric_limits<double>::infinity());
-    MD_HIP(hipMemcpyAsync(d_tab, edges_s.data(), edges_b, hipMemcpyHostToDevice, ctx->stream));
+    const size_t cls_b = ((size_t)p.n_ti * p.n_tj + 63) & ~size_t(63);
+    // edges and the class table of every pass: one pinned staging buffer, one H2D copy
+    const size_t tab_b = edges_b + (size_t)n_pass * cls_b;
+    MD_WS(d_tab, unsigned char, WS_TABLES, tab_b);
+    MD_PIN(h_tab, unsigned char, PIN_TABLES, tab_b);
+    {
+        double *e = reinterpret_cast<double *>(h_tab);
+        std::copy(p.edges, p.edges + p.nbins + 1, e);
+        e[p.nbins + 1] = std::numeric_limits<double>::infinity();
+        for (int pass = 0; pass < n_pass; ++pass) {
+            const int c0 = pass * cls_per_pass;
+            const int nc = (p.n_cls - c0) < cls_per_pass ? (p.n_cls - c0) : cls_per_pass;
+            unsigned char *t = h_tab + edges_b + (size_t)pass * cls_b;
+            for (size_t k = 0; k < (size_t)p.n_ti * p.n_tj; ++k) {
+                const int c = p.cls[k];
+                t[k] = (c >= c0 && c < c0 + nc) ? (unsigned char)(c - c0) : 0xFF;
+            }
+        }
+    }
+    MD_HIP(hipMemcpyAsync(d_tab, h_tab, tab_b, hipMemcpyHostToDevice, ctx->stream));
     MD_WS(d_misc, unsigned long long, WS_MISC, 64);
     MD_HIP(hipMemsetAsync(d_misc, 0, 64, ctx->stream));
 
@@ -1227,10 +1241,12 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
     const float4 *d_gsph = nullptr, *d_wsph = nullptr;
     const double4 *d_aos = nullptr;
     double prep_ms = 0.0;
+    bool prep_timed = false;
     if (cull) {
         const long long N = p.ni;
-        MD_WS(d_sx, double, WS_SORT_XYZ, (size_t)F * 3 * N * 8);
-        MD_WS(d_st, int, WS_SORT_TYPE, (size_t)F * N * 4);
+        const bool want_soa = ctx->opt_rdf_sj == 0;  // only the LDS-tile kernel reads the SoA copy
+        MD_WS(d_sx, double, WS_SORT_XYZ, want_soa ? (size_t)F * 3 * N * 8 : 64);
+        MD_WS(d_st, int, WS_SORT_TYPE, want_soa ? (size_t)F * N * 4 : 64);
         MD_WS(d_keys, unsigned short, WS_KEYS, (size_t)F * N * 2);
         MD_WS(d_cells, unsigned, WS_CELLS, (size_t)F * MORTON_CELLS * 4);
         MD_WS(d_bbox, double, WS_BBOX, (size_t)F * nTi * 6 * 8);
@@ -1239,33 +1255,24 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         MD_WS(d_gs, float4, WS_GSPH, (size_t)F * nTi * (TILE / 8) * 2 * sizeof(float4));
         MD_WS(d_ws, float4, WS_WSPH, (size_t)F * nTi * (TILE / 64) * 2 * sizeof(float4));
         MD_WS(d_ao, double4, WS_SORT_AOS, (size_t)F * nTi * TILE * sizeof(double4));
-        KernelTimer ptimer(ctx);
+        KernelTimer ptimer(ctx, 1, true);  // second event pair: collected after the pair kernel's sync
         MD_HIP(hipMemsetAsync(d_cells, 0, (size_t)F * MORTON_CELLS * 4, ctx->stream));
         const dim3 ga((unsigned)((N + 255) / 256), (unsigned)F);
-        MD_WS(d_org, unsigned long long, WS_ORIGIN, (size_t)F * 3 * 8);
-        MD_HIP(hipMemsetAsync(d_org, 0xFF, (size_t)F * 3 * 8, ctx->stream));
-        const unsigned og = (unsigned)std::min<long long>((N + 255) / 256, 64);
-        hipLaunchKernelGGL(cull_origin_kernel, dim3(og, (unsigned)F), dim3(256), 0, ctx->stream, p.d_xi, N, d_org);
+        MD_WS(d_org, double, WS_ORIGIN, (size_t)F * 3 * 8);
+        hipLaunchKernelGGL(cull_origin_kernel, dim3((unsigned)F), dim3(256), 0, ctx->stream, p.d_xi, N, d_org);
         hipLaunchKernelGGL(cull_keys_kernel, ga, dim3(256), 0, ctx->stream, p.d_xi, p.d_box, N, d_org, d_keys,
                            d_cells);
         hipLaunchKernelGGL(cull_scan_kernel, dim3((unsigned)F), dim3(256), 0, ctx->stream, d_cells);
         hipLaunchKernelGGL(cull_scatter_kernel, ga, dim3(256), 0, ctx->stream, p.d_xi, p.d_ti,
-                           (long long)p.ti_fs, N, d_keys, d_cells, d_sx, d_st, d_ao, (long long)nTi * TILE,
-                           p.n_ti);
-        hipLaunchKernelGGL(cull_bbox_kernel, dim3((unsigned)nTi, (unsigned)F), dim3(TILE), 0, ctx->stream,
-                           d_sx, N, nTi, d_bbox);
+                           (long long)p.ti_fs, N, d_keys, d_cells, want_soa ? d_sx : (double *)nullptr, d_st, d_ao,
+                           (long long)nTi * TILE, p.n_ti);
+        hipLaunchKernelGGL(cull_boxes_kernel, dim3((unsigned)nTi, (unsigned)F), dim3(TILE), 0, ctx->stream,
+                           d_ao, p.d_box, N, nTi, d_bbox, d_gs, d_ws);
         hipLaunchKernelGGL(cull_list_kernel, dim3((unsigned)nTi, (unsigned)F), dim3(256), 0, ctx->stream,
                            d_bbox, p.d_box, nTi, p.rc2 * (1.0 + 1e-9) + 1e-9, d_l, d_lc);
-        const long long nG = (long long)nTi * (TILE / 8), nW = (long long)nTi * (TILE / 64);
-        hipLaunchKernelGGL(cull_box_kernel, dim3((unsigned)((nG + 255) / 256), (unsigned)F), dim3(256), 0,
-                           ctx->stream, d_sx, p.d_box, N, 8, nG, d_gs);
-        hipLaunchKernelGGL(cull_box_kernel, dim3((unsigned)((nW + 255) / 256), (unsigned)F), dim3(256), 0,
-                           ctx->stream, d_sx, p.d_box, N, 64, nW, d_ws);
         ptimer.stop();
         MD_HIP(hipGetLastError());
-        MD_HIP(hipStreamSynchronize(ctx->stream));
-        ptimer.collect();
-        prep_ms = ctx->last_ms;
+        prep_timed = true;
         d_gsph = d_gs;
         d_wsph = d_ws;
         k_xi = k_xj = d_sx;
@@ -1277,18 +1284,11 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
     }
 
     double total_ms = 0.0;  // the pair kernel alone; the culling pre-pass is reported separately
+    unsigned long long ov = 0;
     int launches = 0;
-    std::vector<unsigned char> cls_pass(cls_b);
     for (int pass = 0; pass < n_pass; ++pass) {
         const int c0 = pass * cls_per_pass;
         const int nc = (p.n_cls - c0) < cls_per_pass ? (p.n_cls - c0) : cls_per_pass;
-        for (size_t k = 0; k < cls_b; ++k) {
-            int c = p.cls[k];
-            cls_pass[k] = (c >= c0 && c < c0 + nc) ? (unsigned char)(c - c0) : 0xFF;
-        }
-        // pageable H2D copies are staged by the runtime before the call returns, so the vector can be reused
-        MD_HIP(hipMemcpyAsync(d_tab + edges_b, cls_pass.data(), cls_b, hipMemcpyHostToDevice,
-                              ctx->stream));
         const size_t words = (size_t)nc * p.nbins;
         const size_t acc_frames = p.per_frame ? (size_t)F : (size_t)slots;
         MD_WS(d_hist, unsigned long long, WS_HIST, (acc_frames + 1) * words * 8);
@@ -1306,7 +1306,7 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         a.reach = (float)((std::sqrt(p.rc2) + 1e-3) * 1.00001);
         a.aos = d_aos;
         a.box = p.d_box;
-        a.cls = d_tab + edges_b;
+        a.cls = d_tab + edges_b + (size_t)pass * cls_b;
         a.edges = reinterpret_cast<const double *>(d_tab);
         a.hist = d_hist;
         a.overflow = d_misc;
@@ -1385,20 +1385,24 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
                                0, ctx->stream, d_hist, d_final, (int)words, slots);
             MD_HIP(hipGetLastError());
         }
-        // D2H into the right class rows
-        std::vector<uint64_t> tmp(out_frames * words);
-        MD_HIP(hipMemcpyAsync(tmp.data(), d_final, out_frames * words * 8, hipMemcpyDeviceToHost,
-                              ctx->stream));
+        // D2H (pinned staging) into the right class rows; the overflow word rides along with the last pass
+        MD_PIN(tmp, uint64_t, PIN_OUT, (out_frames * words + 1) * 8);
+        MD_HIP(hipMemcpyAsync(tmp, d_final, out_frames * words * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (pass == n_pass - 1)
+            MD_HIP(hipMemcpyAsync(tmp + out_frames * words, d_misc, 8, hipMemcpyDeviceToHost, ctx->stream));
         MD_HIP(hipStreamSynchronize(ctx->stream));
+        if (pass == n_pass - 1) ov = tmp[out_frames * words];
         timer.collect();
         total_ms += ctx->last_ms;
         ++launches;
+        if (prep_timed) {  // the pre-pass ran ahead of the first pass on the same stream: its events are complete
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ctx->ev2, ctx->ev3) == hipSuccess) prep_ms = ms;
+            prep_timed = false;
+        }
         for (size_t fr = 0; fr < out_frames; ++fr)
             memcpy(&H[(fr * p.n_cls + c0) * p.nbins], &tmp[fr * words], words * 8);
     }
-    unsigned long long ov = 0;
-    MD_HIP(hipMemcpyAsync(&ov, d_misc, 8, hipMemcpyDeviceToHost, ctx->stream));
-    MD_HIP(hipStreamSynchronize(ctx->stream));
     // with several passes every in-cutoff overflow pair is seen once per pass
     *overflow = ov / (uint64_t)n_pass;
     ctx->last_ms = total_ms;
@@ -1455,10 +1459,30 @@ int pair_hist_run(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64_t> &H
 // labels -> compact indices 0..T-1 (sorted unique labels)
 void compact_labels(const int32_t *lab, size_t n, std::vector<int32_t> &uniq, std::vector<int32_t> &idx)
 {
+    idx.resize(n);
+    uniq.clear();
+    if (n == 0) return;
+    int32_t lo = lab[0], hi = lab[0];
+    for (size_t k = 1; k < n; ++k) {
+        lo = lab[k] < lo ? lab[k] : lo;
+        hi = lab[k] > hi ? lab[k] : hi;
+    }
+    const int64_t span = (int64_t)hi - (int64_t)lo + 1;
+    if (span <= (1 << 20)) {  // the usual case (LAMMPS types 1..T): one presence table, O(n)
+        std::vector<int32_t> slot((size_t)span, -1);
+        for (size_t k = 0; k < n; ++k) slot[(size_t)(lab[k] - lo)] = 0;
+        int32_t next = 0;
+        for (int64_t v = 0; v < span; ++v)
+            if (slot[(size_t)v] == 0) {
+                slot[(size_t)v] = next++;
+                uniq.push_back((int32_t)(lo + v));
+            }
+        for (size_t k = 0; k < n; ++k) idx[k] = slot[(size_t)(lab[k] - lo)];
+        return;
+    }
     uniq.assign(lab, lab + n);
     std::sort(uniq.begin(), uniq.end());
     uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
-    idx.resize(n);
     for (size_t k = 0; k < n; ++k)
         idx[k] = (int32_t)(std::lower_bound(uniq.begin(), uniq.end(), lab[k]) - uniq.begin());
 }
@@ -1537,8 +1561,16 @@ int run_job(mdhip_ctx *ctx, const RelJob &j, std::vector<uint64_t> &H, std::vect
     int rc;
     p.d_xi = (const double *)mdhip_stage(ctx, WS_XYZ_I, j.xi, (size_t)j.F * 3 * j.ni * 8, j.xi_dev, &rc);
     if (rc) return rc;
+    // compact types of both sets and the box lengths: one pinned staging buffer (owned by the context, so the
+    // asynchronous copies need no sync before this function's vectors go away)
+    const size_t ti_b = (idx_i.size() * 4 + 63) & ~size_t(63), tj_b = (idx_j.size() * 4 + 63) & ~size_t(63);
+    const size_t box_b = (size_t)j.F * 3 * 8;
+    MD_PIN(h_in, unsigned char, PIN_TYPES, ti_b + tj_b + box_b);
+    memcpy(h_in, idx_i.data(), idx_i.size() * 4);
+    memcpy(h_in + ti_b, idx_j.data(), idx_j.size() * 4);
+    memcpy(h_in + ti_b + tj_b, j.box, box_b);
     MD_WS(d_ti, int, WS_TYPE_I, idx_i.size() * 4);
-    MD_HIP(hipMemcpyAsync(d_ti, idx_i.data(), idx_i.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    MD_HIP(hipMemcpyAsync(d_ti, h_in, idx_i.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     p.d_ti = d_ti;
     p.ti_fs = j.lab_i_fs;
     if (j.tri) {
@@ -1550,13 +1582,13 @@ int run_job(mdhip_ctx *ctx, const RelJob &j, std::vector<uint64_t> &H, std::vect
         p.d_xj = (const double *)mdhip_stage(ctx, WS_XYZ_J, j.xj, (size_t)j.F * 3 * j.nj * 8, j.xj_dev, &rc);
         if (rc) return rc;
         MD_WS(d_tj, int, WS_TYPE_J, idx_j.size() * 4);
-        MD_HIP(hipMemcpyAsync(d_tj, idx_j.data(), idx_j.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        MD_HIP(hipMemcpyAsync(d_tj, h_in + ti_b, idx_j.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         p.d_tj = d_tj;
         p.tj_fs = 0;
         p.nj = j.nj;
     }
     MD_WS(d_box, double, WS_BOX, (size_t)j.F * 3 * 8);
-    MD_HIP(hipMemcpyAsync(d_box, j.box, (size_t)j.F * 3 * 8, hipMemcpyHostToDevice, ctx->stream));
+    MD_HIP(hipMemcpyAsync(d_box, h_in + ti_b + tj_b, box_b, hipMemcpyHostToDevice, ctx->stream));
     p.d_box = d_box;
     p.h_box = j.box;
     p.n_frames = j.F;
@@ -1566,8 +1598,6 @@ int run_job(mdhip_ctx *ctx, const RelJob &j, std::vector<uint64_t> &H, std::vect
     p.rc2 = j.rc2;
     p.gscale = j.gscale;
     p.per_frame = j.per_frame;
-    // idx vectors must outlive the async copies: pageable copies are staged before return, but be explicit
-    MD_HIP(hipStreamSynchronize(ctx->stream));
     return pair_hist_run(ctx, p, H, overflow);
 }
 

@@ -8,6 +8,7 @@
 // are added in index order, then one correctly rounded division by the mass sum. The reference's
 // pandas/BLAS sums use another order, so agreement is ~1e-15 relative, not bitwise.
 #include <algorithm>
+#include <vector>
 
 #include "ctx.h"
 
@@ -15,7 +16,85 @@
 
 namespace {
 
-// one lane per (segment, frame); atoms of a segment are a short contiguous run (<= tens of atoms)
+// Staged kernel (default). A block owns a run of whole segments with at most SC_CAP atoms in total and
+// loops over frames and attribute planes: the run's atoms are read with coalesced 8-byte loads,
+// multiplied by their mass and parked in LDS; then one lane per segment adds its atoms up in index
+// order from LDS and divides by the mass sum. Same operations in the same order as one lane walking
+// its segment in global memory (the fallback below, kept for segments longer than SC_CAP), but every
+// HBM byte is fetched once by a full-width load.
+struct SegBlock {
+    long long s0, s1;  // segments [s0, s1)
+};
+constexpr int SC_CAP = 2048;
+// LDS index with one pad double per 32: lanes whose segments start 4, 8, 16, ... atoms apart would otherwise
+// all hit the same banks
+__device__ __forceinline__ int sc_pad(int i) { return i + (i >> 5); }
+
+// FLUX = false: out[f][k][s] = sum(m a) / sum(m)                                   (com_mols.py:58-60)
+// FLUX = true : out[f][k][s] = (sum(m v) / sum(m) * vel_conv) * (sum(q) * charge_conv)   (_conductivity.py:21-25)
+template <bool FLUX>
+__global__ __launch_bounds__(256) void segment_staged_kernel(
+    const double *__restrict__ attr, const double *__restrict__ mass, const double *__restrict__ q,
+    const long long *__restrict__ seg_off, const SegBlock *__restrict__ blocks, double *__restrict__ out,
+    int n_attr, long long n_atoms, long long n_seg, long long n_frames, double vel_conv, double charge_conv)
+{
+    __shared__ double s_v[SC_CAP + SC_CAP / 32 + 2];
+    __shared__ double s_m[SC_CAP];
+    const int tid = threadIdx.x;
+    const SegBlock b = blocks[blockIdx.x];
+    const long long a0 = seg_off[b.s0];
+    const int na = (int)(seg_off[b.s1] - a0);
+    for (int i = tid; i < na; i += 256) s_m[i] = mass[a0 + i];
+    const long long s = b.s0 + tid;
+    const bool has = s < b.s1;
+    int lo = 0, hi = 0;
+    double msum = 0.0, q_si = 0.0;
+    if (has) {
+        lo = (int)(seg_off[s] - a0);
+        hi = (int)(seg_off[s + 1] - a0);
+    }
+    __syncthreads();
+    if (has) {
+        for (int a = lo; a < hi; ++a) msum += s_m[a];
+        if (FLUX) {
+            double qsum = 0.0;
+            for (int a = lo; a < hi; ++a) qsum += q[a0 + a];
+            q_si = qsum * charge_conv;  // _conductivity.py:25
+        }
+    }
+    for (long long f = blockIdx.y; f < n_frames; f += gridDim.y) {
+        for (int k = 0; k < n_attr; ++k) {
+            const double *p = attr + ((size_t)f * n_attr + k) * n_atoms + a0;
+            __syncthreads();  // the previous plane has been consumed
+            for (int i = tid; i < na; i += 256) s_v[sc_pad(i)] = p[i] * s_m[i];
+            __syncthreads();
+            if (has) {
+                double acc = 0.0;
+                for (int a = lo; a < hi; ++a) acc += s_v[sc_pad(a)];
+                double r = acc / msum;
+                if (FLUX) r = (r * vel_conv) * q_si;  // com_mols.py:60 then _conductivity.py:21-23
+                out[((size_t)f * n_attr + k) * n_seg + s] = r;
+            }
+        }
+    }
+}
+
+// Runs of whole segments with <= SC_CAP atoms and <= 256 segments each; false when a segment is longer.
+bool build_seg_blocks(int64_t n_seg, const int64_t *seg_off, std::vector<SegBlock> &blocks)
+{
+    blocks.clear();
+    int64_t s0 = 0;
+    while (s0 < n_seg) {
+        int64_t s1 = s0;
+        while (s1 < n_seg && s1 - s0 < 256 && seg_off[s1 + 1] - seg_off[s0] <= SC_CAP) ++s1;
+        if (s1 == s0) return false;  // segment s0 alone exceeds the LDS stage
+        blocks.push_back({(long long)s0, (long long)s1});
+        s0 = s1;
+    }
+    return true;
+}
+
+// Fallback: one lane per (segment, frame) walking global memory
 __global__ __launch_bounds__(256) void segment_com_kernel(
     const double *__restrict__ attr, const double *__restrict__ mass,
     const long long *__restrict__ seg_off, double *__restrict__ out, int n_attr, long long n_atoms,
@@ -36,7 +115,7 @@ __global__ __launch_bounds__(256) void segment_com_kernel(
     }
 }
 
-// q_mol * v_com,k in SI for every molecule: tmp [F][3][M]
+// q_mol * v_com,k in SI for every molecule: tmp [F][3][M] (fallback, as above)
 __global__ __launch_bounds__(256) void mol_flux_kernel(
     const double *__restrict__ vel, const double *__restrict__ mass, const double *__restrict__ q,
     const long long *__restrict__ seg_off, double *__restrict__ tmp, long long n_atoms,
@@ -134,11 +213,31 @@ int mdhip_segment_com(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, int n_a
         d_out = (double *)mdhip_ws(ctx, WS_OUT, out_b);
         if (!d_out) return MDHIP_ENOMEM;
     }
-    const unsigned gy = (unsigned)std::min<int64_t>(n_frames, 4096);
+    std::vector<SegBlock> blocks;
+    const bool staged = build_seg_blocks(n_seg, seg_off, blocks);
+    SegBlock *d_blocks = nullptr;
+    if (staged) {
+        d_blocks = (SegBlock *)mdhip_ws(ctx, WS_AUX3, blocks.size() * sizeof(SegBlock));
+        if (!d_blocks) return MDHIP_ENOMEM;
+        MD_HIP(hipMemcpyAsync(d_blocks, blocks.data(), blocks.size() * sizeof(SegBlock), hipMemcpyHostToDevice,
+                              ctx->stream));
+    }
     KernelTimer timer(ctx);
-    hipLaunchKernelGGL(segment_com_kernel, dim3((unsigned)((n_seg + 255) / 256), gy), dim3(256), 0,
-                       ctx->stream, d_attr, d_mass, d_off, d_out, n_attr, (long long)n_atoms,
-                       (long long)n_seg, (long long)n_frames);
+    if (staged) {
+        // enough (block, frame slice) pairs to fill the chip several times over; a block loops over its frames
+        const int64_t want = ((int64_t)ctx->cu_count * 16 + (int64_t)blocks.size() - 1) / (int64_t)blocks.size();
+        const unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_frames, std::min<int64_t>(want, 65535)));
+        ctx->last_kernel = "segment_staged_kernel<false>";
+        hipLaunchKernelGGL(segment_staged_kernel<false>, dim3((unsigned)blocks.size(), gy), dim3(256), 0,
+                           ctx->stream, d_attr, d_mass, (const double *)nullptr, d_off, d_blocks, d_out, n_attr,
+                           (long long)n_atoms, (long long)n_seg, (long long)n_frames, 1.0, 1.0);
+    } else {
+        const unsigned gy = (unsigned)std::min<int64_t>(n_frames, 4096);
+        ctx->last_kernel = "segment_com_kernel";
+        hipLaunchKernelGGL(segment_com_kernel, dim3((unsigned)((n_seg + 255) / 256), gy), dim3(256), 0,
+                           ctx->stream, d_attr, d_mass, d_off, d_out, n_attr, (long long)n_atoms,
+                           (long long)n_seg, (long long)n_frames);
+    }
     timer.stop();
     MD_HIP(hipGetLastError());
     if (!out_on_device)
@@ -186,11 +285,30 @@ int mdhip_charge_flux(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const d
     MD_WS(d_tmp, double, WS_AUX3, (size_t)n_frames * 3 * n_seg * 8);
     const size_t flux_b = (size_t)3 * n_types * n_frames * 8;
     MD_WS(d_flux, double, WS_OUT, flux_b);
-    const unsigned gy = (unsigned)std::min<int64_t>(n_frames, 4096);
+    std::vector<SegBlock> blocks;
+    const bool staged = build_seg_blocks(n_seg, seg_off, blocks);
+    SegBlock *d_blocks = nullptr;
+    if (staged) {
+        d_blocks = (SegBlock *)mdhip_ws(ctx, WS_PART, blocks.size() * sizeof(SegBlock));
+        if (!d_blocks) return MDHIP_ENOMEM;
+        MD_HIP(hipMemcpyAsync(d_blocks, blocks.data(), blocks.size() * sizeof(SegBlock), hipMemcpyHostToDevice,
+                              ctx->stream));
+    }
     KernelTimer timer(ctx);
-    hipLaunchKernelGGL(mol_flux_kernel, dim3((unsigned)((n_seg + 255) / 256), gy), dim3(256), 0,
-                       ctx->stream, d_vel, d_mq, d_mq + n_atoms, d_off, d_tmp, (long long)n_atoms,
-                       (long long)n_seg, (long long)n_frames, vel_conv, charge_conv);
+    if (staged) {
+        const int64_t want = ((int64_t)ctx->cu_count * 16 + (int64_t)blocks.size() - 1) / (int64_t)blocks.size();
+        const unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_frames, std::min<int64_t>(want, 65535)));
+        ctx->last_kernel = "segment_staged_kernel<true>";
+        hipLaunchKernelGGL(segment_staged_kernel<true>, dim3((unsigned)blocks.size(), gy), dim3(256), 0,
+                           ctx->stream, d_vel, d_mq, d_mq + n_atoms, d_off, d_blocks, d_tmp, 3,
+                           (long long)n_atoms, (long long)n_seg, (long long)n_frames, vel_conv, charge_conv);
+    } else {
+        const unsigned gy = (unsigned)std::min<int64_t>(n_frames, 4096);
+        ctx->last_kernel = "mol_flux_kernel";
+        hipLaunchKernelGGL(mol_flux_kernel, dim3((unsigned)((n_seg + 255) / 256), gy), dim3(256), 0,
+                           ctx->stream, d_vel, d_mq, d_mq + n_atoms, d_off, d_tmp, (long long)n_atoms,
+                           (long long)n_seg, (long long)n_frames, vel_conv, charge_conv);
+    }
     timer.stop();
     MD_HIP(hipGetLastError());
     for (int64_t f0 = 0; f0 < n_frames; f0 += 65535) {

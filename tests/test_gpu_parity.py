@@ -260,6 +260,31 @@ def test_msd_allatom_golden(B, g_small):
     np.testing.assert_allclose(win[:, 3] / n_kept, expect[:, 3], rtol=1e-10, atol=0)
 
 
+def test_segment_com_ragged_and_long_segments(B):
+    """Staged kernel (runs of whole segments through LDS) and the per-lane fallback (a segment longer than
+    the LDS stage) against the oracle, on ragged segment sizes 1..40, 4-atom and 16-atom molecules."""
+    rng = np.random.default_rng(9)
+    for sizes in (rng.integers(1, 41, 700), np.full(900, 4), np.full(300, 16),
+                  np.concatenate([rng.integers(1, 9, 50), [3000], rng.integers(1, 9, 50)])):
+        off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        n = int(off[-1])
+        F = 5
+        attr = rng.normal(0, 30, (F, 3, n))
+        mass = rng.uniform(1, 40, n)
+        q = rng.normal(0, 1, n)
+        com, seg_mass, seg_q = B.segment_com(attr, mass, off, atom_q=q)
+        want = np.add.reduceat(attr * mass, off[:-1], axis=2) / np.add.reduceat(mass, off[:-1])
+        np.testing.assert_allclose(com, want, rtol=1e-13, atol=1e-13)
+        np.testing.assert_allclose(seg_mass, np.add.reduceat(mass, off[:-1]), rtol=1e-14)
+        np.testing.assert_allclose(seg_q, np.add.reduceat(q, off[:-1]), rtol=1e-12, atol=1e-14)
+        M = len(sizes)
+        st = (np.arange(M) * 3 // M).astype(np.int32)
+        j = B.charge_flux(attr, mass, q, off, st, 3, 1e5, 1.6e-19)
+        jm = (want * 1e5) * (np.add.reduceat(q, off[:-1]) * 1.6e-19)  # [F,3,M]
+        jw = np.stack([np.stack([jm[:, k, st == t].sum(axis=1) for t in range(3)]) for k in range(3)])
+        np.testing.assert_allclose(j, jw, rtol=1e-9, atol=1e-25)
+
+
 def test_com_msd_and_charge_flux_golden(B, g_small):
     g = g_small
     cols, fr, pick = _small(g)
