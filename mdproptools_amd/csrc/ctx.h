@@ -78,6 +78,7 @@ struct mdhip_ctx {
     int opt_rdf_cull = -1;    // spatial culling of tile pairs: -1 = auto, 0 = never, 1 = always (when applicable)
     int opt_rdf_slots = 16;   // replicas of the frame-summed histogram in HBM
     int opt_xcorr_tile = 0;
+    int opt_lag_variant = 1;  // full-lag MSD: 1 = series-resident LDS kernel when it fits, 0 = staged kernel
 };
 
 int mdhip_fail(mdhip_ctx *ctx, int code, const char *fmt, ...);

@@ -10,6 +10,8 @@
 // LDS across the 4 waves, then an ordered pass over block partials): no float atomics, results are
 // reproducible run to run.
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 #include "ctx.h"
 
@@ -296,11 +298,141 @@ __global__ __launch_bounds__(LG_THREADS) void lag_msd_kernel(
     }
 }
 
+// Series-resident variant (default whenever one series plus its padding fits LDS, n <~ 19 000 frames).
+// The whole series of one (entity, axis) sits in LDS, transposed [i mod 8][i div 8] as above, and is
+// both the broadcast operand x[t] and the per-lane sliding window x[t + lag]. A WAVE owns a pair of
+// lag tiles of 512 lags, (j, nT-1-j), and walks each only as far as that tile's own longest valid
+// origin range (n - K0), so the idle lanes of the lag x origin triangle are confined to the last 512
+// origins of every tile and every wave of the block does the same amount of work (n + 512 origins per
+// series). Axes are the outer loop: 2 tiles x 8 lags of accumulators per lane instead of 3 x 8 per tile.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 8))) void lag_msd_lds_kernel(
+    const double *__restrict__ x, long long n_ent, int n, int n_lags, const Chunk *__restrict__ chunks,
+    int n_tiles, int row, double *__restrict__ partial)
+{
+    extern __shared__ double s_x[];  // [8][row], zero beyond n
+    constexpr int KT = 64 * LG_LPT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const Chunk ck = chunks[blockIdx.y];
+    const int pair_id = blockIdx.x * NW + wave;
+    // this wave's tiles (tile[1] < 0: none — the middle tile of an odd count is walked once)
+    int tile[2] = {pair_id, n_tiles - 1 - pair_id};
+    if (tile[1] <= tile[0]) tile[1] = -1;
+    if (tile[0] > n_tiles - 1 - pair_id) tile[0] = -1;
+    const int n_pad = 8 * (row - 1);  // entries the host sized the stage for
+    for (int c = 0; c < 3; ++c) {
+        double acc[2][LG_LPT];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int m = 0; m < LG_LPT; ++m) acc[h][m] = 0.0;
+        for (long long e = ck.e0; e < ck.e1; ++e) {
+            const double *xs = x + ((size_t)c * n_ent + e) * n;
+            __syncthreads();  // the previous series has been consumed
+            for (int base = 0; base < n_pad; base += NW * 64 * 4) {  // four loads in flight per lane
+                double v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = base + q * NW * 64 + tid;
+                    v[q] = i < n ? xs[i] : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = base + q * NW * 64 + tid;
+                    if (i < n_pad) s_x[(i & 7) * row + (i >> 3)] = v[q];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (tile[h] < 0) continue;  // wave-uniform
+                const int K0 = tile[h] * KT;
+                const int kb = K0 + lane * LG_LPT;
+                // pair (t, kb + m) is valid iff t + m < lim; lanes whose lags nobody asked for do nothing
+                const int lim = kb < n_lags ? n - kb : 0;
+                // window x[t + kb + j], j = 0..15, as two halves that swap roles every 8 origins (no moves)
+                double wa[8], wb[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) wa[j] = s_x[j * row + (kb >> 3)];  // (kb & 7) == 0
+// One step of 8 origins x 8 lags for the lanes whose whole 8 x 8 block is valid (the others are masked off:
+// their few remaining pairs are swept up after the loop). A holds x[T+kb+0..7], B is loaded with x[T+kb+8..15].
+#define LG_STEP(A, B, T)                                                                \
+    {                                                                                   \
+        const int col_ = (((T) + kb) >> 3) + 1;                                         \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) B[j] = s_x[j * row + col_];       \
+        if (lim - (T) >= 15) {                                                          \
+            _Pragma("unroll") for (int u = 0; u < 8; ++u)                               \
+            {                                                                           \
+                const double bt_ = xs[(T) + u]; /* wave-uniform: scalar load, SGPR operand */ \
+                /* differences first, then the FMAs: a dependent pair back to back leaves the FP64 pipe idle */ \
+                double d_[LG_LPT];                                                      \
+                _Pragma("unroll") for (int m = 0; m < LG_LPT; ++m)                      \
+                    d_[m] = ((u + m) < 8 ? A[(u + m) & 7] : B[(u + m) & 7]) - bt_;      \
+                __builtin_amdgcn_sched_barrier(0);                                      \
+                _Pragma("unroll") for (int m = 0; m < LG_LPT; ++m)                      \
+                    acc[h][m] = __builtin_fma(d_[m], d_[m], acc[h][m]);                 \
+                __builtin_amdgcn_sched_barrier(0);                                      \
+            }                                                                           \
+        }                                                                               \
+    }
+                const int t_wave = n - K0 - 15;  // lane 0 (smallest lag) has a whole block up to here
+                int t = 0;
+                for (; t + 8 <= t_wave; t += 16) {
+                    LG_STEP(wa, wb, t)
+                    LG_STEP(wb, wa, t + 8)
+                }
+                if (t <= t_wave) LG_STEP(wa, wb, t)
+#undef LG_STEP
+                // the pairs of the last, partial blocks of every lag: < 22 origins per lane
+                {
+                    const int t_stop = lim >= 15 ? ((lim - 15) / 8 + 1) * 8 : 0;
+                    for (int tt = t_stop; tt < lim; ++tt) {
+                        const double bt = s_x[(tt & 7) * row + (tt >> 3)];
+#pragma unroll
+                        for (int m = 0; m < LG_LPT; ++m) {
+                            const int i = tt + kb + m;
+                            const double d = s_x[(i & 7) * row + (i >> 3)] - bt;
+                            if (tt + m < lim) acc[h][m] = __builtin_fma(d, d, acc[h][m]);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (tile[h] < 0) continue;
+#pragma unroll
+            for (int m = 0; m < LG_LPT; ++m) {
+                const long long k = (long long)tile[h] * KT + lane * LG_LPT + m;
+                if (k < n_lags) partial[((size_t)blockIdx.y * n_lags + k) * 4 + c] = acc[h][m];
+            }
+        }
+    }
+}
+
+// resident blocks per CU as the runtime computes it (registers, LDS, wave slots)
+int lag_lds_blocks_per_cu(int nw, size_t lds_b)
+{
+    int n = 0;
+#define MD_OCC(NW)                                                                                               \
+    case NW:                                                                                                     \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lag_msd_lds_kernel<NW>),                        \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);                       \
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(                                                      \
+            &n, reinterpret_cast<const void *>(lag_msd_lds_kernel<NW>), NW * 64, lds_b);                         \
+        break;
+    switch (nw) {
+        MD_OCC(1) MD_OCC(2) MD_OCC(3) MD_OCC(4) MD_OCC(5) MD_OCC(6) MD_OCC(7) MD_OCC(8)
+    }
+#undef MD_OCC
+    return n;
+}
+
 // out[lag][g][c] = sum over the group's chunks / ((n - lag) * group size)
 __global__ void lag_msd_finish_kernel(const double *__restrict__ partial,
                                       const int *__restrict__ group_chunk_off,
                                       const long long *__restrict__ group_off, int n_groups,
-                                      long long n, long long n_lags, double *__restrict__ out)
+                                      long long n, long long n_lags, int axes_only, double *__restrict__ out)
 {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_lags * n_groups * 4) return;
@@ -308,8 +440,10 @@ __global__ void lag_msd_finish_kernel(const double *__restrict__ partial,
     const int g = (int)((idx >> 2) % n_groups);
     const long long k = (idx >> 2) / n_groups;
     double s = 0.0;
-    for (int q = group_chunk_off[g]; q < group_chunk_off[g + 1]; ++q)
-        s += partial[((size_t)q * n_lags + k) * 4 + c];
+    for (int q = group_chunk_off[g]; q < group_chunk_off[g + 1]; ++q) {
+        const double *p = partial + ((size_t)q * n_lags + k) * 4;
+        s += (c < 3 || !axes_only) ? p[c] : (p[0] + p[1]) + p[2];  // total column: same sum as the staged kernel
+    }
     const double cnt = (double)(n - k) * (double)(group_off[g + 1] - group_off[g]);
     out[idx] = cnt > 0.0 ? s / cnt : 0.0;
 }
@@ -448,9 +582,33 @@ int mdhip_lag_msd(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double 
     std::vector<Chunk> chunks;
     std::vector<int> gco;
     const long long n_lags = (long long)max_lag + 1;
+    // series-resident kernel: one series (+ 536 zeros so that the windows of the last tile stay inside) in LDS
+    int lds_row = (int)((n_frames + 536 + 7) / 8) + 1;
+    lds_row |= 1;  // odd row length: the 8 rows of the transposed layout start in different banks
+    const size_t lds_b = (size_t)8 * lds_row * 8;
+    const bool resident = ctx->opt_lag_variant != 0 && lds_b <= ctx->lds_max - 1024 && n_frames < (1 << 30);
+    const int r_tiles = (int)((n_lags + 64 * LG_LPT - 1) / (64 * LG_LPT));
+    const int r_pairs = (r_tiles + 1) / 2;
+    const int r_gx = (r_pairs + 7) / 8;                 // blocks per entity chunk
+    const int r_nw = (r_pairs + r_gx - 1) / r_gx;       // waves (tile pairs) per block, <= 8
     // entities per block: enough blocks to fill the chip (>= ~8 per CU), at most LG_ECHUNK
     int64_t echunk = LG_ECHUNK;
-    {
+    if (resident) {
+        // blocks that fit the chip at once (128 VGPRs: 4 waves per SIMD; LDS: one series per block), then the
+        // smallest whole number of rounds R with <= LG_ECHUNK entities per block: blocks ~ R x capacity
+        int64_t per_cu = lag_lds_blocks_per_cu(r_nw, lds_b);
+        if (per_cu < 1) per_cu = 1;
+        const int64_t capacity = std::max<int64_t>(1, per_cu * ctx->cu_count / r_gx);
+        echunk = LG_ECHUNK;
+        for (int64_t R = 1; R <= 64; ++R) {
+            const int64_t ec = (n_ent + capacity * R - 1) / (capacity * R);
+            if (ec <= LG_ECHUNK) {
+                echunk = ec;
+                break;
+            }
+        }
+        if (echunk < 1) echunk = 1;
+    } else {
         const int thr = n_lags <= 512 ? 64 : n_lags <= 1024 ? 128 : 256;
         const int64_t tile_pairs = ((n_lags + thr * LG_LPT - 1) / (thr * LG_LPT) + 1) / 2;
         const int64_t want = (int64_t)ctx->cu_count * 8;
@@ -468,7 +626,7 @@ int mdhip_lag_msd(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double 
     const size_t r_b = (size_t)n_frames * 3 * n_ent * 8;
     const double *d_r = (const double *)mdhip_stage(ctx, WS_XYZ_I, r, r_b, on_device, &rc);
     if (rc) return rc;
-    MD_WS(d_x, double, WS_XYZ_J, r_b);
+    MD_WS(d_x, double, WS_XYZ_J, r_b + 256);  // the scalar prefetch of the resident kernel reads <= 16 doubles past a series
     const int n_chunks = (int)chunks.size();
     const size_t tab_b = chunks.size() * sizeof(Chunk) + gco.size() * 4 + (size_t)(n_groups + 1) * 8 + 64;
     MD_WS(d_tab, unsigned char, WS_TABLES, tab_b);
@@ -486,25 +644,50 @@ int mdhip_lag_msd(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double 
     hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((cols + 31) / 32), (unsigned)((n_frames + 31) / 32)),
                        dim3(256), 0, ctx->stream, d_r, d_x, (long long)n_frames, cols, scale);
     MD_HIP(hipGetLastError());
-    const int threads = n_lags <= 512 ? 64 : n_lags <= 1024 ? 128 : 256;
-    const int kt = threads * LG_LPT;
-    const int n_tiles = (int)((n_lags + kt - 1) / kt);
-    const dim3 grid((unsigned)((n_tiles + 1) / 2), (unsigned)n_chunks);
     KernelTimer timer(ctx);
-    if (threads == 64)
-        hipLaunchKernelGGL(lag_msd_kernel<64>, grid, dim3(64), 0, ctx->stream, d_x, (long long)n_ent,
-                           (long long)n_frames, n_lags, d_chunks, n_tiles, d_partial);
-    else if (threads == 128)
-        hipLaunchKernelGGL(lag_msd_kernel<128>, grid, dim3(128), 0, ctx->stream, d_x, (long long)n_ent,
-                           (long long)n_frames, n_lags, d_chunks, n_tiles, d_partial);
-    else
-        hipLaunchKernelGGL(lag_msd_kernel<256>, grid, dim3(256), 0, ctx->stream, d_x, (long long)n_ent,
-                           (long long)n_frames, n_lags, d_chunks, n_tiles, d_partial);
+    if (resident) {
+        const dim3 grid((unsigned)r_gx, (unsigned)n_chunks);
+#define MD_LAG_CASE(NW)                                                                                          \
+    case NW:                                                                                                     \
+        MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(lag_msd_lds_kernel<NW>),                       \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));                     \
+        hipLaunchKernelGGL(lag_msd_lds_kernel<NW>, grid, dim3(NW * 64), lds_b, ctx->stream, d_x,                 \
+                           (long long)n_ent, (int)n_frames, (int)n_lags, d_chunks, r_tiles, lds_row, d_partial); \
+        break;
+        switch (r_nw) {
+            MD_LAG_CASE(1)
+            MD_LAG_CASE(2)
+            MD_LAG_CASE(3)
+            MD_LAG_CASE(4)
+            MD_LAG_CASE(5)
+            MD_LAG_CASE(6)
+            MD_LAG_CASE(7)
+            MD_LAG_CASE(8)
+        }
+#undef MD_LAG_CASE
+        ctx->last_kernel = "lag_msd_lds_kernel";
+    } else {
+        const int threads = n_lags <= 512 ? 64 : n_lags <= 1024 ? 128 : 256;
+        const int kt = threads * LG_LPT;
+        const int n_tiles = (int)((n_lags + kt - 1) / kt);
+        const dim3 grid((unsigned)((n_tiles + 1) / 2), (unsigned)n_chunks);
+        if (threads == 64)
+            hipLaunchKernelGGL(lag_msd_kernel<64>, grid, dim3(64), 0, ctx->stream, d_x, (long long)n_ent,
+                               (long long)n_frames, n_lags, d_chunks, n_tiles, d_partial);
+        else if (threads == 128)
+            hipLaunchKernelGGL(lag_msd_kernel<128>, grid, dim3(128), 0, ctx->stream, d_x, (long long)n_ent,
+                               (long long)n_frames, n_lags, d_chunks, n_tiles, d_partial);
+        else
+            hipLaunchKernelGGL(lag_msd_kernel<256>, grid, dim3(256), 0, ctx->stream, d_x, (long long)n_ent,
+                               (long long)n_frames, n_lags, d_chunks, n_tiles, d_partial);
+        ctx->last_kernel = "lag_msd_kernel";
+    }
     timer.stop();
     MD_HIP(hipGetLastError());
     const long long tot = n_lags * n_groups * 4;
     hipLaunchKernelGGL(lag_msd_finish_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
-                       ctx->stream, d_partial, d_gco, d_goff, n_groups, (long long)n_frames, n_lags, d_out);
+                       ctx->stream, d_partial, d_gco, d_goff, n_groups, (long long)n_frames, n_lags,
+                       resident ? 1 : 0, d_out);
     MD_HIP(hipGetLastError());
     MD_HIP(hipMemcpyAsync(out, d_out, out_b, hipMemcpyDeviceToHost, ctx->stream));
     MD_HIP(hipStreamSynchronize(ctx->stream));

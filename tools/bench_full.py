@@ -124,7 +124,7 @@ def main():
         msd_last = s1[-1, 0, 3] / E / 1e-20
         assert abs(msd_last / (3 * 0.01 * (F - 1)) - 1.0) < 0.02, msd_last
         t_lag, lag = wall(lambda: B.lag_msd(r, F - 1, [0, E], scale=1.0), sync)
-        np.testing.assert_allclose(lag[:, 0, 3] / (3 * 0.01 * np.maximum(np.arange(F), 1)), 1.0, atol=0.2)
+        np.testing.assert_allclose(lag[1:, 0, 3] / (3 * 0.01 * np.arange(1, F)), 1.0, atol=0.2)
         k_lag = ctx.last_kernel_ms()[0]
         fp_all = F * (F - 1) / 2
         # CPU: the oracle's single-origin loop on 40 frame pairs of the full 50k entities
