@@ -222,6 +222,21 @@ int mdhip_cumtrapz(mdhip_ctx *ctx, int64_t n, int n_series, const double *y, int
                    double dx, int leading_zero, double *out);
 
 /* ---- I/O: native LAMMPS text-dump reader (host only, no GPU needed) ---------------------------- */
+/* ---- neighbour-shell residence autocorrelation ---- */
+/*
+ * Replaces the two loops of ResidenceTime.calc_auto_correlation   dynamical/residence_time.py:70-146
+ * for one relation: central atoms xi [F][3][n_i], shell atoms xj [F][3][n_j], box [F][3];
+ *   h_ij(t) = (rsq > r_lo_sq) && (rsq <= r_hi_sq)                 residence_time.py:101-102
+ * with the reference's single-wrap rsq (rdf_cn.py:44-57); exclude_diagonal != 0 (a type with itself; the two
+ * sets must then be the same atoms in the same order) clears h_ii (residence_time.py:103-104).
+ *   counts[k] = sum_{i,j} sum_t h_ij(t) h_ij(t+k),  k = 0..F-1    exact integers
+ * are the numerators of the unbiased autocovariances the reference sums (residence_time.py:124-131):
+ *   corr[k] = counts[k] / (F - k) / (n_i n_j) / corr[0]. n_records (optional) = sum_t |{h_ij(t) = 1}|.
+ */
+int mdhip_shell_residence(mdhip_ctx *ctx, int64_t n_frames, int64_t n_i, const double *xi, int xi_on_device,
+                          int64_t n_j, const double *xj, int xj_on_device, const double *box, double r_lo_sq,
+                          double r_hi_sq, int exclude_diagonal, uint64_t *counts, uint64_t *n_records);
+
 /*
  * Replaces, for the inputs of the path, the un-vendored pymatgen `parse_lammps_dumps` + pandas
  * `read_csv` the reference uses (call sites structural/rdf_cn.py:176, dynamical/diffusion.py:172,

@@ -57,6 +57,8 @@ PROTOTYPES = {
                                     C.c_int, C.c_double, C.c_double, c_dp]),
     "mdhip_xcorr": (C.c_int, [vp, C.c_int64, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int64, c_dp]),
     "mdhip_cumtrapz": (C.c_int, [vp, C.c_int64, C.c_int, vp, C.c_int, C.c_double, C.c_int, c_dp]),
+    "mdhip_shell_residence": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, C.c_int64, vp, C.c_int, c_dp,
+                                        C.c_double, C.c_double, C.c_int, c_up, c_up]),
     "mdhip_dump_open": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
     "mdhip_dump_close": (None, [vp]),
     "mdhip_dump_error": (C.c_char_p, [vp]),

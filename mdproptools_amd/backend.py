@@ -259,3 +259,25 @@ def cumtrapz(y, dx, leading_zero=False, ctx=None):
 
 
 bin_edges = _lib.bin_edges
+
+
+def shell_residence(xyz_i, xyz_j, box, r_lo_sq, r_hi_sq, exclude_diagonal=False, ctx=None):
+    """
+    Numerators of the neighbour-shell autocovariance (residence_time.py:96-131): central atoms xyz_i [F,3,Ni],
+    shell atoms xyz_j [F,3,Nj] -> (counts uint64 [F], number of in-shell records).
+    counts[k] = sum_{i,j,t} h_ij(t) h_ij(t+k), h = (rsq > r_lo_sq) & (rsq <= r_hi_sq).
+    """
+    ctx = ctx or default_context()
+    F, _, Ni = _shape3(xyz_i, "xyz_i")
+    F2, _, Nj = _shape3(xyz_j, "xyz_j")
+    if F2 != F:
+        raise ValueError("xyz_i and xyz_j must have the same number of frames")
+    ip, i_dev, k1 = as_input(xyz_i)
+    jp, j_dev, k2 = as_input(xyz_j)
+    bx = _f64(box).reshape(F, 3)
+    counts = np.zeros(F, dtype=np.uint64)
+    nrec = C.c_uint64(0)
+    ctx.check(ctx.lib.mdhip_shell_residence(
+        ctx.h, F, Ni, ip, i_dev, Nj, jp, j_dev, ptr(bx), float(r_lo_sq), float(r_hi_sq),
+        int(bool(exclude_diagonal)), ptr(counts, C.c_uint64), C.byref(nrec)))
+    return counts, int(nrec.value)

@@ -630,7 +630,11 @@ __global__ void cull_keys_kernel(const double *__restrict__ xyz, const double *_
     unsigned c[3];
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax) {
-        int v = (int)(wrapped_frac(x[ax * n + i] - origin[3 * f + ax], box[3 * f + ax]) * G);
+        // the origin is a sampled minimum: an atom a little below it belongs to the first cell, not (wrapped)
+        // to the last one, where it would blow up the bounding boxes of the tiles it lands in
+        double d = x[ax * n + i] - origin[3 * f + ax];
+        if (d < 0.0 && d >= -box[3 * f + ax] * (1.0 / 64.0)) d = 0.0;
+        int v = (int)(wrapped_frac(d, box[3 * f + ax]) * G);
         c[ax] = (unsigned)(v < 0 ? 0 : v > (1 << MORTON_BITS) - 1 ? (1 << MORTON_BITS) - 1 : v);
     }
     const unsigned key = hilbert3(c[0], c[1], c[2]);

@@ -1,0 +1,250 @@
+// residence.hip — neighbour-shell residence autocorrelation.
+//
+// Replaces the two loops of dynamical/residence_time.py:70-146 of the reference
+// (ResidenceTime.calc_auto_correlation): per frame an indicator h_ij(t) = 1 when atom j sits in the shell
+// (lo, hi] around central atom i, then the mean over all (i, j) of the unbiased autocovariance of h_ij.
+// The numerators are integers,
+//
+//     counts[k] = sum_{i,j} sum_t h_ij(t) h_ij(t+k)
+//
+// and are computed exactly; the reference's FFT estimator returns them with ~1e-16 relative noise.
+//
+//  1. shell_pairs_kernel (twice: count, then fill): all central x shell atoms of every frame, the same
+//     exact single-wrap rsq as the pair histograms (rdf_cn.py:44-57, contraction off), shell atoms staged
+//     through LDS. Every hit appends one record (pair key << frame bits | frame).
+//  2. a 64-bit radix sort of the records (hipCUB) brings each pair's frames together, in time order.
+//  3. residence_lag_kernel: a wave per run of equal pair keys builds the pair's presence bit mask over the
+//     frames in LDS and adds popcount(mask & (mask >> k)) to its lag table for every lag k up to the run's
+//     span; tables are merged with 64-bit global atomics (integers: order-independent).
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <vector>
+
+#include "ctx.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int RT_TILE = 256;
+
+__device__ __forceinline__ double rt_wrap_abs(double d, double L)
+{
+    // |d - sign(d) L| if |d| > L/2 else |d|, as min(|d|, ||d| - L|): see pair_hist.hip for the equivalence
+    const double a = __builtin_fabs(d);
+    return __builtin_fmin(a, __builtin_fabs(a - L));
+}
+
+// grid (ceil(n_i / 256), F). FILL = false: total hit count into *n_rec. FILL = true: records appended.
+template <bool FILL>
+__global__ __launch_bounds__(RT_TILE) void shell_pairs_kernel(
+    const double *__restrict__ xi, long long n_i, const double *__restrict__ xj, long long n_j,
+    const double *__restrict__ box, double lo2, double hi2, int exclude_diagonal, int frame_bits,
+    unsigned long long *__restrict__ n_rec, unsigned long long *__restrict__ rec, unsigned long long cap)
+{
+    __shared__ double s_j[3][RT_TILE];
+    const int f = blockIdx.y, tid = threadIdx.x;
+    const long long i = (long long)blockIdx.x * RT_TILE + tid;
+    const double *pi = xi + (size_t)f * 3 * n_i, *pj = xj + (size_t)f * 3 * n_j;
+    const double Lx = box[3 * f], Ly = box[3 * f + 1], Lz = box[3 * f + 2];
+    double x = 0.0, y = 0.0, z = 0.0;
+    if (i < n_i) {
+        x = pi[i];
+        y = pi[n_i + i];
+        z = pi[2 * n_i + i];
+    }
+    unsigned long long mine = 0;
+    for (long long j0 = 0; j0 < n_j; j0 += RT_TILE) {
+        __syncthreads();
+        const long long jl = j0 + tid;
+        s_j[0][tid] = jl < n_j ? pj[jl] : 0.0;
+        s_j[1][tid] = jl < n_j ? pj[n_j + jl] : 0.0;
+        s_j[2][tid] = jl < n_j ? pj[2 * n_j + jl] : 0.0;
+        __syncthreads();
+        const int cnt = (int)((n_j - j0) < RT_TILE ? (n_j - j0) : RT_TILE);
+        if (i < n_i) {
+            for (int jj = 0; jj < cnt; ++jj) {
+                const double ax = rt_wrap_abs(x - s_j[0][jj], Lx);
+                const double ay = rt_wrap_abs(y - s_j[1][jj], Ly);
+                const double az = rt_wrap_abs(z - s_j[2][jj], Lz);
+                const double rsq = (ax * ax + ay * ay) + az * az;
+                const long long j = j0 + jj;
+                if (rsq > lo2 && rsq <= hi2 && !(exclude_diagonal && j == i)) {  // residence_time.py:102-104
+                    if (FILL) {
+                        const unsigned long long pos = atomicAdd(n_rec, 1ull);
+                        if (pos < cap)
+                            rec[pos] = (((unsigned long long)i * (unsigned long long)n_j + (unsigned long long)j)
+                                        << frame_bits) |
+                                       (unsigned long long)f;
+                    } else {
+                        ++mine;
+                    }
+                }
+            }
+        }
+    }
+    if (!FILL) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
+        if ((tid & 63) == 0 && mine) atomicAdd(n_rec, mine);
+    }
+}
+
+// starts[] = indices where a new pair key begins in the sorted records
+__global__ void run_starts_kernel(const unsigned long long *__restrict__ rec, unsigned long long n, int frame_bits,
+                                  unsigned long long *__restrict__ n_runs, unsigned long long *__restrict__ starts)
+{
+    const unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    if (k == 0 || (rec[k] >> frame_bits) != (rec[k - 1] >> frame_bits)) starts[atomicAdd(n_runs, 1ull)] = k;
+}
+
+// One wave per run (grid-stride over the runs). LDS: presence mask [words] + lag table [n_frames] (u64).
+__global__ __launch_bounds__(64) void residence_lag_kernel(
+    const unsigned long long *__restrict__ rec, unsigned long long n, int frame_bits,
+    const unsigned long long *__restrict__ starts, unsigned long long n_runs, int n_frames, int words,
+    unsigned long long *__restrict__ counts)
+{
+    extern __shared__ unsigned long long s_mem[];
+    unsigned long long *mask = s_mem;            // [words + 1] (one zero word behind the end)
+    unsigned long long *table = s_mem + words + 1;  // [n_frames]
+    const int lane = threadIdx.x;
+    const unsigned long long fmask = (1ull << frame_bits) - 1ull;
+    for (int k = lane; k < n_frames; k += 64) table[k] = 0ull;
+    for (unsigned long long r = blockIdx.x; r < n_runs; r += gridDim.x) {
+        for (int w = lane; w <= words; w += 64) mask[w] = 0ull;
+        __syncthreads();
+        const unsigned long long s0 = starts[r];
+        const unsigned long long key = rec[s0] >> frame_bits;
+        // records of a run are sorted by frame: walk them 64 at a time
+        int t_first = n_frames, t_last = -1;
+        for (unsigned long long p = s0 + lane;; p += 64) {
+            const bool in = p < n && (rec[p] >> frame_bits) == key;
+            if (in) {
+                const int t = (int)(rec[p] & fmask);
+                atomicOr(&mask[t >> 6], 1ull << (t & 63));
+                t_first = t < t_first ? t : t_first;
+                t_last = t > t_last ? t : t_last;
+            }
+            if (!__builtin_amdgcn_ballot_w64(in) || __builtin_amdgcn_ballot_w64(!in)) break;  // run ended in this batch
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const int a = __shfl_xor(t_first, off, 64), b = __shfl_xor(t_last, off, 64);
+            t_first = a < t_first ? a : t_first;
+            t_last = b > t_last ? b : t_last;
+        }
+        __syncthreads();
+        const int span = t_last - t_first;  // lags beyond the span see no overlap
+        const int w0 = t_first >> 6, w1 = t_last >> 6;
+        for (int lag = lane; lag <= span; lag += 64) {
+            const int q = lag >> 6, sh = lag & 63;
+            unsigned long long c = 0;
+            for (int w = w0; w + q <= w1; ++w) {
+                const unsigned long long lo = mask[w + q], hi = mask[w + q + 1];
+                const unsigned long long shifted = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+                c += (unsigned long long)__builtin_popcountll(mask[w] & shifted);
+            }
+            table[lag] += c;  // a lag belongs to one lane: no conflict
+        }
+        __syncthreads();
+    }
+    for (int k = lane; k < n_frames; k += 64)
+        if (table[k]) atomicAdd(&counts[k], table[k]);
+}
+
+}  // namespace
+
+extern "C" {
+
+int mdhip_shell_residence(mdhip_ctx *ctx, int64_t n_frames, int64_t n_i, const double *xi, int xi_on_device,
+                          int64_t n_j, const double *xj, int xj_on_device, const double *box, double r_lo_sq,
+                          double r_hi_sq, int exclude_diagonal, uint64_t *counts, uint64_t *n_records)
+{
+    if (!ctx) return MDHIP_EINVAL;
+    MD_REQUIRE(n_frames >= 0 && n_i >= 0 && n_j >= 0, "negative sizes");
+    MD_REQUIRE(n_frames == 0 || counts, "counts is NULL");
+    MD_REQUIRE(!exclude_diagonal || n_i == n_j, "exclude_diagonal needs identical sets");
+    if (n_records) *n_records = 0;
+    std::fill(counts, counts + n_frames, (uint64_t)0);
+    if (n_frames == 0 || n_i == 0 || n_j == 0) return MDHIP_OK;
+    MD_REQUIRE(xi && xj && box, "NULL input array");
+    int frame_bits = 1;
+    while ((1LL << frame_bits) < n_frames) ++frame_bits;
+    MD_REQUIRE(frame_bits <= 24, "at most 2^24 frames");
+    MD_REQUIRE((double)n_i * (double)n_j < (double)(1ull << (63 - frame_bits)), "pair key does not fit 64 bits");
+    MD_REQUIRE(n_frames <= 65535, "at most 65535 frames per call");
+    const int words = (int)((n_frames + 63) / 64);
+    const size_t lds_b = ((size_t)words + 1 + (size_t)n_frames) * 8;
+    MD_REQUIRE(lds_b <= ctx->lds_max - 512, "%lld frames exceed the LDS lag table", (long long)n_frames);
+    MD_HIP(hipSetDevice(ctx->device));
+    int rc;
+    const double *d_xi = (const double *)mdhip_stage(ctx, WS_XYZ_I, xi, (size_t)n_frames * 3 * n_i * 8, xi_on_device, &rc);
+    if (rc) return rc;
+    const double *d_xj = d_xi;
+    if (xj != xi || xj_on_device != xi_on_device) {
+        d_xj = (const double *)mdhip_stage(ctx, WS_XYZ_J, xj, (size_t)n_frames * 3 * n_j * 8, xj_on_device, &rc);
+        if (rc) return rc;
+    }
+    MD_WS(d_box, double, WS_BOX, (size_t)n_frames * 3 * 8);
+    MD_PIN(h_box, double, PIN_TYPES, (size_t)n_frames * 3 * 8);
+    memcpy(h_box, box, (size_t)n_frames * 3 * 8);
+    MD_HIP(hipMemcpyAsync(d_box, h_box, (size_t)n_frames * 3 * 8, hipMemcpyHostToDevice, ctx->stream));
+    MD_WS(d_misc, unsigned long long, WS_MISC, 64);
+    MD_HIP(hipMemsetAsync(d_misc, 0, 64, ctx->stream));
+    MD_WS(d_counts, unsigned long long, WS_OUT, (size_t)n_frames * 8);
+    MD_HIP(hipMemsetAsync(d_counts, 0, (size_t)n_frames * 8, ctx->stream));
+    MD_PIN(h_out, unsigned long long, PIN_OUT, ((size_t)n_frames + 8) * 8);
+
+    const dim3 grid((unsigned)((n_i + RT_TILE - 1) / RT_TILE), (unsigned)n_frames);
+    KernelTimer timer(ctx);
+    ctx->last_kernel = "shell_pairs_kernel";
+    hipLaunchKernelGGL(shell_pairs_kernel<false>, grid, dim3(RT_TILE), 0, ctx->stream, d_xi, (long long)n_i, d_xj,
+                       (long long)n_j, d_box, r_lo_sq, r_hi_sq, exclude_diagonal, frame_bits, d_misc,
+                       (unsigned long long *)nullptr, 0ull);
+    MD_HIP(hipGetLastError());
+    MD_HIP(hipMemcpyAsync(h_out, d_misc, 8, hipMemcpyDeviceToHost, ctx->stream));
+    MD_HIP(hipStreamSynchronize(ctx->stream));
+    const unsigned long long n_rec = h_out[0];
+    if (n_records) *n_records = n_rec;
+    if (n_rec == 0) {
+        timer.stop();
+        MD_HIP(hipStreamSynchronize(ctx->stream));
+        timer.collect();
+        return MDHIP_OK;
+    }
+    MD_WS(d_rec, unsigned long long, WS_AUX0, (size_t)n_rec * 8);
+    MD_WS(d_srt, unsigned long long, WS_AUX1, (size_t)n_rec * 8);
+    hipLaunchKernelGGL(shell_pairs_kernel<true>, grid, dim3(RT_TILE), 0, ctx->stream, d_xi, (long long)n_i, d_xj,
+                       (long long)n_j, d_box, r_lo_sq, r_hi_sq, exclude_diagonal, frame_bits, d_misc + 1, d_rec,
+                       n_rec);
+    MD_HIP(hipGetLastError());
+    size_t tmp_b = 0;
+    MD_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_b, d_rec, d_srt, (size_t)n_rec, 0, 64, ctx->stream));
+    MD_WS(d_tmp, unsigned char, WS_AUX2, tmp_b + 256);
+    MD_HIP(hipcub::DeviceRadixSort::SortKeys(d_tmp, tmp_b, d_rec, d_srt, (size_t)n_rec, 0, 64, ctx->stream));
+    // run starts (unordered list) reuse the unsorted buffer
+    unsigned long long *d_starts = d_rec;
+    hipLaunchKernelGGL(run_starts_kernel, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, ctx->stream, d_srt,
+                       n_rec, frame_bits, d_misc + 2, d_starts);
+    MD_HIP(hipGetLastError());
+    MD_HIP(hipMemcpyAsync(h_out, d_misc + 2, 8, hipMemcpyDeviceToHost, ctx->stream));
+    MD_HIP(hipStreamSynchronize(ctx->stream));
+    const unsigned long long n_runs = h_out[0];
+    if (lds_b > 65536)
+        MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(residence_lag_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+    const unsigned lag_grid = (unsigned)std::min<unsigned long long>(n_runs, (unsigned long long)ctx->cu_count * 16);
+    hipLaunchKernelGGL(residence_lag_kernel, dim3(lag_grid), dim3(64), lds_b, ctx->stream, d_srt, n_rec, frame_bits,
+                       d_starts, n_runs, (int)n_frames, words, d_counts);
+    timer.stop();
+    MD_HIP(hipGetLastError());
+    MD_HIP(hipMemcpyAsync(h_out, d_counts, (size_t)n_frames * 8, hipMemcpyDeviceToHost, ctx->stream));
+    MD_HIP(hipStreamSynchronize(ctx->stream));
+    timer.collect();
+    memcpy(counts, h_out, (size_t)n_frames * 8);
+    return MDHIP_OK;
+}
+
+}  // extern "C"

@@ -416,3 +416,42 @@ def cumtrapz(y, dx, leading_zero=False):
     inc = dx * (y[1:] + y[:-1]) / 2.0
     out = np.cumsum(inc)
     return np.concatenate(([0.0], out)) if leading_zero else out
+
+
+# ----------------------------------------------------------------------------
+# neighbour-shell residence autocorrelation
+# ----------------------------------------------------------------------------
+
+
+def shell_indicator(k_xyz, l_xyz, lengths, rc2_lo, rc2_hi, same):
+    """
+    dynamical/residence_time.py:100-106 for one frame: h[i][j] = (rsq > lo^2) & (rsq <= hi^2) with the
+    reference's single-wrap rsq (rdf_cn.py:44-57, called with num_of_ids=0); for a relation of a type with
+    itself the diagonal is cleared (residence_time.py:103-104). k_xyz [Nk,3], l_xyz [Nl,3] -> bool [Nk,Nl].
+    """
+    rsq = min_image_rsq(k_xyz[:, None, :], l_xyz[None, :, :], lengths)
+    h = (rsq > rc2_lo) & (rsq <= rc2_hi)
+    if same:
+        np.fill_diagonal(h, False)
+    return h
+
+
+def residence_counts(h_frames):
+    """
+    Exact numerators of residence_time.py:124-131: counts[k] = sum over (i, j) and t of h(t) h(t+k), the
+    quantity `acovf(column, demean=False, unbiased=True)` estimates times (n - k). h_frames: bool [F,Nk,Nl].
+    """
+    h = np.asarray(h_frames, dtype=np.int64)
+    n = h.shape[0]
+    return np.array([int((h[: n - k] * h[k:]).sum()) for k in range(n)], dtype=np.int64)
+
+
+def residence_autocorr(h_frames):
+    """
+    residence_time.py:111-136: mean over all (central atom, column) series of the unbiased autocovariance,
+    normalised by its lag-0 value. In exact arithmetic: c[k] = counts[k] / (n - k) / (Nk * Nl); corr = c / c[0].
+    """
+    counts = residence_counts(h_frames).astype(np.float64)
+    n, nk, nl = np.asarray(h_frames).shape
+    c = counts / (n - np.arange(n)) / float(nk * nl)
+    return c / c[0]

@@ -254,6 +254,53 @@ def golden_small_md():
 
 
 # ----------------------------------------------------------------------------
+def golden_residence():
+    """ResidenceTime.calc_auto_correlation / fit_auto_correlation (dynamical/residence_time.py:70-200) on the
+    1146-atom sub-system, 30 frames: Mg-O(DME), Mg-O(TFSI), a shell with a lower bound, and a same-type
+    relation; default ids and altered ids."""
+    from mdproptools.dynamical.residence_time import ResidenceTime
+
+    steps = [50000 * k for k in range(30)]
+    frames, bounds = load_real_frames(steps)
+    frames, num_mols = reduced_system(frames)
+    cols = ["id", "type", "x", "y", "z"]
+    keep = [COLS.index(c) for c in cols]
+    rng = np.random.default_rng(20250328 + 7)
+    shuffled = np.stack([fr[rng.permutation(len(fr))][:, keep] for fr in frames])
+    out = {"steps": np.asarray(steps), "bounds": bounds, "columns": np.array(cols), "frames": shuffled,
+           "num_mols": np.asarray(num_mols), "num_atoms_per_mol": np.asarray(NUM_ATOMS)}
+    # Only the altered-ids mode of the reference runs: with default ids it hands `_calc_rsq(..., num_of_ids=0)`
+    # rows of [id, x, y, z] and stops with a broadcast ValueError (residence_time.py:96-101, rdf_cn.py:43).
+    # Pseudo-types (rdf_cn.py:197-215): 1..16 DME atoms, 17..31 TFSI atoms, 32 Mg.
+    rel = [[32, 32, 32, 1, 32], [1, 19, 32, 1, 4]]
+    r_cut = [[0, 4.5], [0, 4.5], [0, 14.0], [2.0, 9.0], [2.0, 3.2]]
+    with tempfile.TemporaryDirectory() as tmp:
+        write_frames(tmp, steps, bounds, shuffled, cols)
+        with quiet():
+            rt = ResidenceTime(r_cut, rel, os.path.join(tmp, "dump.nvt.*.dump"), dt=2,
+                               num_mols=list(num_mols), num_atoms_per_mol=NUM_ATOMS, working_dir=tmp)
+            rt.calc_auto_correlation()
+        out["rel"], out["r_cut"] = np.asarray(rel), np.asarray(r_cut, dtype=np.float64)
+        out["corr"], out["corr_cols"] = rt.corr_df.to_numpy(), np.array(list(rt.corr_df.columns))
+        try:
+            with quiet():
+                ResidenceTime(r_cut[:1], [[9], [1]], os.path.join(tmp, "dump.nvt.*.dump"),
+                              working_dir=tmp).calc_auto_correlation()
+            out["default_ids_error"] = np.array("")
+        except Exception as e:  # recorded so the deliberate difference is documented by data
+            out["default_ids_error"] = np.array(type(e).__name__)
+        # the fit on a synthetic stretched-exponential table (the 30-frame correlations are too short to fit)
+        t = np.arange(200) * 0.5
+        y = ResidenceTime._stretched_exp_function(t, 0.8, 40.0, 1.5, 0.7)
+        rt.corr_df = pd.DataFrame({"Time (ps)": t, "9-1": y})
+        with quiet():
+            fit = rt.fit_auto_correlation(cut_percent=0.9, plot=False)
+        out["fit_t"], out["fit_y"], out["fit_res"] = t, y, np.asarray(fit["9-1"])
+    np.savez_compressed(os.path.join(OUT, "residence.npz"), **out)
+    print("residence:", out["corr_cols"], out["corr"][:3], out["default_ids_error"], out["fit_res"])
+
+
+# ----------------------------------------------------------------------------
 def golden_synth_rdf():
     """_rdf_loop/_cn_loop/_rdf_mol_loop/_cn_mol_loop on seeded synthetic frames with edge cases:
     non-cubic box with lo != 0, atoms outside the box by more than one box length,
@@ -438,7 +485,9 @@ def golden_host_logic():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["synth", "acf", "small", "c1", "cell17", "host"]
+    which = sys.argv[1:] or ["synth", "acf", "small", "c1", "cell17", "host", "residence"]
+    if "residence" in which:
+        golden_residence()
     if "host" in which:
         golden_host_logic()
     if "synth" in which:

@@ -162,3 +162,22 @@ def test_get_msd_from_log(tmp_path):
     assert list(msd.columns) == ["c_msd1[4]", "c_msd2[4]", "Time (s)"]
     np.testing.assert_allclose(msd["c_msd2[4]"], steps * 1.5 * 1e-20, rtol=1e-15)
     np.testing.assert_allclose(msd["Time (s)"], steps * 2 * 1e-15, rtol=1e-15)
+
+
+def test_residence_time_fit_host_logic(tmp_path):
+    """fit_auto_correlation (residence_time.py:148-200): stretched-exponential fit, table layout and CSV, on
+    the table the real reference fitted (no GPU involved)."""
+    import pandas as pd
+    from conftest import load_golden
+    from mdproptools_amd.dynamical.residence_time import ResidenceTime
+
+    g = load_golden("residence.npz")
+    rt = ResidenceTime([[0, 1]], [[9], [1]], "unused", working_dir=str(tmp_path))
+    assert rt.dt == 1e-3 and rt.relation_matrix.tolist() == [[9, 1]]
+    rt.corr_df = pd.DataFrame({"Time (ps)": g["fit_t"], "9-1": g["fit_y"]})
+    res = rt.fit_auto_correlation(cut_percent=0.9, plot=False)
+    np.testing.assert_allclose(res["9-1"], g["fit_res"], rtol=1e-6)
+    assert list(rt.res_time_df.index) == ["a", "tau_res", "tau_short", "beta", "r (ps)"]
+    assert (tmp_path / "residence_time.csv").exists()
+    y = ResidenceTime._stretched_exp_function(np.array([0.0, 1.0]), 0.8, 40.0, 1.5, 0.7)
+    assert y[0] == 1.0 and 0 < y[1] < 1

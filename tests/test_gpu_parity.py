@@ -615,3 +615,49 @@ def test_c5_acf_properties(B):
     np.testing.assert_allclose(ramp[0], 1.25 * np.arange(100_000), rtol=1e-12)
     lin = B.cumtrapz(np.arange(100_001.0), 1.0)
     np.testing.assert_allclose(lin, 0.5 * np.arange(1, 100_001) ** 2, rtol=1e-12)
+
+
+# ------------------------------------------------------------------ residence autocorrelation
+def test_shell_residence_vs_oracle(B):
+    """Exact autocovariance numerators of the shell indicator: random walkers in a periodic box, shells with
+    and without a lower bound, same-type relation (diagonal cleared), runs longer than 64 frames, an empty
+    shell; integers must equal the oracle's."""
+    rng = np.random.default_rng(41)
+    for F, ni, nj, lo, hi, same in [(30, 12, 40, 0.0, 3.0, False), (150, 7, 25, 1.5, 4.0, False),
+                                     (70, 33, 33, 0.0, 3.5, True), (10, 5, 9, 0.0, 0.01, False)]:
+        L = np.array([11.0, 12.0, 13.0])
+        n = ni if same else ni + nj
+        r = rng.uniform(0, 1, (1, 3, n)) * L[None, :, None] + np.cumsum(rng.normal(0, 0.15, (F, 3, n)), axis=0)
+        xi = np.ascontiguousarray(r[:, :, :ni])
+        xj = xi if same else np.ascontiguousarray(r[:, :, ni:])
+        box = np.tile(L, (F, 1))
+        counts, nrec = B.shell_residence(xi, xj, box, lo * lo, hi * hi, exclude_diagonal=same)
+        h = np.array([O.shell_indicator(xi[f].T, xj[f].T, L, lo * lo, hi * hi, same) for f in range(F)])
+        want = O.residence_counts(h)
+        np.testing.assert_array_equal(counts.astype(np.int64), want)
+        assert nrec == int(h.sum())
+
+
+def test_residence_time_dropin_golden(B, tmp_path):
+    """ResidenceTime.calc_auto_correlation / fit_auto_correlation against the real reference's output."""
+    from conftest import load_golden
+    from mdproptools_amd import io as mio
+    from mdproptools_amd.dynamical.residence_time import ResidenceTime
+
+    g = load_golden("residence.npz")
+    cols = [str(c) for c in g["columns"]]
+    for s, b, t in zip(g["steps"], g["bounds"], g["frames"]):
+        mio.write_dump(str(tmp_path / ("dump.nvt.%d.dump" % s)), int(s), b, cols, t)
+    rt = ResidenceTime(g["r_cut"].tolist(), g["rel"].tolist(), str(tmp_path / "dump.nvt.*.dump"), dt=2,
+                       num_mols=g["num_mols"].tolist(), num_atoms_per_mol=g["num_atoms_per_mol"].tolist(),
+                       working_dir=str(tmp_path))
+    rt.calc_auto_correlation()
+    assert list(rt.corr_df.columns) == [str(c) for c in g["corr_cols"]]
+    got, ref = rt.corr_df.to_numpy(), g["corr"]
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    np.testing.assert_allclose(got[~np.isnan(ref)], ref[~np.isnan(ref)], rtol=1e-12, atol=1e-15)
+    assert (tmp_path / "auto_correlation.csv").exists()
+    # default ids (the reference stops with a ValueError there): selection by LAMMPS type works
+    rt9 = ResidenceTime([[0, 14.0]], [[9], [9]], str(tmp_path / "dump.nvt.*.dump"), working_dir=str(tmp_path))
+    rt9.calc_auto_correlation()
+    np.testing.assert_allclose(rt9.corr_df["9-9"].to_numpy(), ref[:, 3], rtol=1e-12)  # Mg-Mg = pseudo-type 32-32

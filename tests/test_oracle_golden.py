@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, sorted_frame
+from conftest import GOLDEN, load_golden, sorted_frame
 from oracle import cpu_ref as O
 from oracle import cref as C
 
@@ -281,3 +281,30 @@ def test_cell17_oracle_chain_full_trajectory():
         assert "%.6e" % (slope / 6) == "%.6e" % tab["published"]["diffusion (m2/s)"][k]
         assert "%.6e" % (bse / 6) == "%.6e" % tab["published"]["std"][k]
         assert "%.6f" % r2 == "%.6f" % tab["published"]["R2"][k]
+
+
+# ------------------------------------------------------------------ residence autocorrelation
+def _residence_inputs(g):
+    frames = [fr[np.argsort(fr[:, 0], kind="stable")] for fr in g["frames"]]
+    labels = O.calc_atom_type(frames[0][:, 0], g["num_mols"], g["num_atoms_per_mol"])
+    xyz = np.stack([np.ascontiguousarray(fr[:, 2:5].T) for fr in frames])
+    box = g["bounds"][:, :, 1] - g["bounds"][:, :, 0]
+    return xyz, labels, box
+
+
+def test_residence_oracle_matches_reference():
+    """oracle shell indicator + exact autocovariance numerators against ResidenceTime.calc_auto_correlation of
+    the real reference (30 frames, altered ids; one relation without any neighbour gives NaN in both)."""
+    g = load_golden("residence.npz")
+    xyz, labels, box = _residence_inputs(g)
+    assert str(g["default_ids_error"]) == "ValueError"  # the reference's default-id mode does not run
+    np.testing.assert_allclose(g["corr"][:, 0], g["steps"] * 2e-3)
+    for kl, (k, l) in enumerate(g["rel"].T):
+        lo2, hi2 = g["r_cut"][kl][0] ** 2, g["r_cut"][kl][1] ** 2
+        h = np.array([O.shell_indicator(xyz[f][:, labels == k].T, xyz[f][:, labels == l].T, box[f], lo2, hi2, k == l)
+                      for f in range(len(xyz))])
+        with np.errstate(invalid="ignore"):
+            corr = O.residence_autocorr(h)
+        ref = g["corr"][:, 1 + kl]
+        assert np.array_equal(np.isnan(corr), np.isnan(ref))
+        np.testing.assert_allclose(corr[~np.isnan(ref)], ref[~np.isnan(ref)], rtol=1e-12, atol=1e-15)
