@@ -258,6 +258,25 @@ int mdhip_dump_frame_info(mdhip_dump *d, int64_t f, int64_t *timestep, int64_t *
 int mdhip_dump_read(mdhip_dump *d, int64_t f, int n_sel, const int32_t *col_idx, int sort_col, double *out,
                     int n_threads);
 
+/* ---- native LAMMPS log reader (host only) ---------------------------------------------------- */
+/*
+ * Role of pymatgen's parse_lammps_log (un-vendored; call sites dynamical/viscosity.py:211,
+ * utilities/log.py:21, dynamical/diffusion.py:241): one thermo table per `run`, between the line starting with
+ * "Memory usage per processor =" / "Per MPI rank memory allocation" and the line starting with "Loop time of";
+ * first line = column names; lines starting with "WARNING" and blank lines are skipped. Numbers are parsed as in
+ * the dump reader (correctly rounded). `regular` = 0 when some row is not one number per column (the caller then
+ * falls back to its text reader for exact pandas behaviour). mdhip_log_read fills column planes
+ * out[n_cols][n_rows]; is_int[c] = 1 when every token of column c is a plain integer (pandas makes it int64).
+ */
+typedef struct mdhip_log mdhip_log;
+int mdhip_log_open(const char *path, mdhip_log **out);
+void mdhip_log_close(mdhip_log *l);
+const char *mdhip_log_error(mdhip_log *l); /* l == NULL: error of the last failed open */
+int64_t mdhip_log_n_runs(mdhip_log *l);
+int mdhip_log_run_info(mdhip_log *l, int64_t run, int64_t *n_rows, int *n_cols, int *regular, char *names,
+                       int names_len);
+int mdhip_log_read(mdhip_log *l, int64_t run, double *out, int32_t *is_int, int n_threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,6 +66,13 @@ PROTOTYPES = {
     "mdhip_dump_frame_info": (C.c_int, [vp, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), c_dp, c_dp,
                                         C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),
     "mdhip_dump_read": (C.c_int, [vp, C.c_int64, C.c_int, c_ip, C.c_int, c_dp, C.c_int]),
+    "mdhip_log_open": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
+    "mdhip_log_close": (None, [vp]),
+    "mdhip_log_error": (C.c_char_p, [vp]),
+    "mdhip_log_n_runs": (C.c_int64, [vp]),
+    "mdhip_log_run_info": (C.c_int, [vp, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                     C.c_char_p, C.c_int]),
+    "mdhip_log_read": (C.c_int, [vp, C.c_int64, c_dp, c_ip, C.c_int]),
 }
 
 

@@ -54,6 +54,7 @@ struct mdhip_dump {
     std::string err;
 };
 
+
 namespace {
 
 thread_local std::string g_open_error;
@@ -259,6 +260,83 @@ void parse_lines(const char *p, const char *end, int64_t n_lines, int n_cols, in
     }
 }
 
+
+// ---- LAMMPS log files (thermo tables) ------------------------------------------------------------
+// Role of pymatgen's parse_lammps_log (not in the reference tree; call sites dynamical/viscosity.py:211,
+// utilities/log.py:21): a run's thermo table sits between the line that starts with "Memory usage per
+// processor =" / "Per MPI rank memory allocation" and the line that starts with "Loop time of"; its first
+// line holds the column names. Lines that start with "WARNING" and blank lines are not rows.
+struct LogRun {
+    const char *body = nullptr;  // first line after the header
+    const char *end = nullptr;   // start of the "Loop time of" line
+    std::vector<std::string> names;
+    int64_t n_rows = 0;
+    bool regular = true;  // every row has exactly one numeric token per column
+};
+
+inline bool log_row_line(const char *p, const char *le)
+{
+    const char *q = skip_ws(p, le);
+    return q < le && !starts_with(p, le, "WARNING");
+}
+
+// counts the rows of [p, end) and checks their shape
+void log_scan(const char *p, const char *end, int n_cols, int64_t *rows, bool *regular)
+{
+    int64_t n = 0;
+    bool ok = true;
+    while (p < end) {
+        const char *le = line_end(p, end);
+        if (log_row_line(p, le)) {
+            ++n;
+            int tok = 0;
+            const char *q = p;
+            for (;;) {
+                q = skip_ws(q, le);
+                if (q >= le) break;
+                const char c = *q;
+                if (!((c >= '0' && c <= '9') || c == '-' || c == '+' || c == '.')) ok = false;  // text inside the table
+                while (q < le && *q != ' ' && *q != '\t' && *q != '\r') ++q;
+                ++tok;
+            }
+            if (tok != n_cols) ok = false;
+        }
+        p = le < end ? le + 1 : end;
+    }
+    *rows = n;
+    *regular = ok;
+}
+
+// rows of [p, end) into column planes out[c * stride + row0 + k]; all_int[c] cleared when a token of column c
+// is not a plain integer
+void log_parse(const char *p, const char *end, int n_cols, int64_t row0, int64_t stride, double *out,
+               unsigned char *all_int)
+{
+    int64_t k = row0;
+    while (p < end) {
+        const char *le = line_end(p, end);
+        if (log_row_line(p, le)) {
+            const char *q = p;
+            for (int c = 0; c < n_cols; ++c) {
+                q = skip_ws(q, le);
+                if (q >= le) break;
+                const char *t0 = q;
+                double v;
+                q = parse_double(q, le, &v);
+                out[(size_t)c * stride + k] = v;
+                const char *d = t0;
+                if (d < q && (*d == '-' || *d == '+')) ++d;
+                bool is_int = d < q;
+                for (; d < q; ++d)
+                    if (*d < '0' || *d > '9') is_int = false;
+                if (!is_int) all_int[c] = 0;
+            }
+            ++k;
+        }
+        p = le < end ? le + 1 : end;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -421,6 +499,169 @@ int mdhip_dump_read(mdhip_dump *d, int64_t f, int n_sel, const int32_t *col_idx,
         const int64_t r = dest[k];
         for (int s = 0; s < n_sel; ++s) out[(size_t)s * n + r] = vals[(size_t)k * n_sel + s];
     }
+    return MDHIP_OK;
+}
+
+
+// ---- log reader C-ABI ---------------------------------------------------------------------------
+
+struct mdhip_log {
+    int fd = -1;
+    const char *data = nullptr;
+    size_t size = 0;
+    std::vector<LogRun> runs;
+    std::string err;
+};
+
+int mdhip_log_open(const char *path, mdhip_log **out)
+{
+    if (!path || !out) return MDHIP_EINVAL;
+    *out = nullptr;
+    mdhip_log *l = new mdhip_log();
+    l->fd = open(path, O_RDONLY);
+    if (l->fd < 0) {
+        g_open_error = std::string("cannot open ") + path + ": " + strerror(errno);
+        delete l;
+        return MDHIP_EINVAL;
+    }
+    struct stat st;
+    fstat(l->fd, &st);
+    l->size = (size_t)st.st_size;
+    if (l->size) {
+        void *m = mmap(nullptr, l->size, PROT_READ, MAP_PRIVATE, l->fd, 0);
+        if (m == MAP_FAILED) {
+            g_open_error = std::string("mmap failed for ") + path;
+            close(l->fd);
+            delete l;
+            return MDHIP_ENOMEM;
+        }
+        l->data = (const char *)m;
+        madvise(m, l->size, MADV_SEQUENTIAL);
+    }
+    const char *p = l->data, *end = l->data + l->size;
+    const char *begin = nullptr;
+    while (p && p < end) {
+        const char *le = line_end(p, end);
+        const char *next = le < end ? le + 1 : end;
+        if (starts_with(p, le, "Memory usage per processor =") || starts_with(p, le, "Per MPI rank memory allocation")) {
+            begin = next;
+        } else if (begin && starts_with(p, le, "Loop time of")) {
+            LogRun r;
+            // header = first row-like line of the block
+            const char *q = begin;
+            while (q < p) {
+                const char *qe = line_end(q, p);
+                if (log_row_line(q, qe)) {
+                    const char *t = q;
+                    for (;;) {
+                        t = skip_ws(t, qe);
+                        if (t >= qe) break;
+                        const char *t0 = t;
+                        while (t < qe && *t != ' ' && *t != '\t' && *t != '\r') ++t;
+                        r.names.emplace_back(t0, (size_t)(t - t0));
+                    }
+                    q = qe < p ? qe + 1 : p;
+                    break;
+                }
+                q = qe < p ? qe + 1 : p;
+            }
+            if (!r.names.empty()) {
+                r.body = q;
+                r.end = p;
+                log_scan(r.body, r.end, (int)r.names.size(), &r.n_rows, &r.regular);
+                l->runs.push_back(std::move(r));
+            }
+            begin = nullptr;
+        }
+        p = next;
+    }
+    *out = l;
+    return MDHIP_OK;
+}
+
+void mdhip_log_close(mdhip_log *l)
+{
+    if (!l) return;
+    if (l->data) munmap((void *)l->data, l->size);
+    if (l->fd >= 0) close(l->fd);
+    delete l;
+}
+
+const char *mdhip_log_error(mdhip_log *l) { return l ? l->err.c_str() : g_open_error.c_str(); }
+
+int64_t mdhip_log_n_runs(mdhip_log *l) { return l ? (int64_t)l->runs.size() : -1; }
+
+int mdhip_log_run_info(mdhip_log *l, int64_t run, int64_t *n_rows, int *n_cols, int *regular, char *names,
+                       int names_len)
+{
+    if (!l || run < 0 || run >= (int64_t)l->runs.size()) return MDHIP_EINVAL;
+    const LogRun &r = l->runs[(size_t)run];
+    if (n_rows) *n_rows = r.n_rows;
+    if (n_cols) *n_cols = (int)r.names.size();
+    if (regular) *regular = r.regular ? 1 : 0;
+    if (names && names_len > 0) {
+        std::string joined;
+        for (size_t k = 0; k < r.names.size(); ++k) joined += (k ? " " : "") + r.names[k];
+        if ((int)joined.size() >= names_len) {
+            l->err = "column names do not fit the buffer";
+            return MDHIP_ELIMIT;
+        }
+        memcpy(names, joined.c_str(), joined.size() + 1);
+    }
+    return MDHIP_OK;
+}
+
+int mdhip_log_read(mdhip_log *l, int64_t run, double *out, int32_t *is_int, int n_threads)
+{
+    if (!l || run < 0 || run >= (int64_t)l->runs.size() || !out) return MDHIP_EINVAL;
+    const LogRun &r = l->runs[(size_t)run];
+    if (!r.regular) {
+        l->err = "thermo table has rows that are not one number per column";
+        return MDHIP_EINVAL;
+    }
+    const int n_cols = (int)r.names.size();
+    const int64_t n = r.n_rows;
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 64) n_threads = 64;
+    if (n < 8192) n_threads = 1;
+    // byte ranges cut at line starts, rows counted per range, then parsed in place
+    std::vector<const char *> cut(n_threads + 1);
+    cut[0] = r.body;
+    for (int t = 1; t < n_threads; ++t) {
+        const char *q = r.body + (size_t)((r.end - r.body) * (double)t / n_threads);
+        const char *le = line_end(q, r.end);
+        cut[t] = le < r.end ? le + 1 : r.end;
+        if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
+    }
+    cut[n_threads] = r.end;
+    std::vector<int64_t> rows(n_threads, 0), row0(n_threads + 1, 0);
+    std::vector<std::vector<unsigned char>> ints(n_threads, std::vector<unsigned char>((size_t)n_cols, 1));
+    {
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_threads; ++t)
+            th.emplace_back([&, t] {
+                bool reg;
+                log_scan(cut[t], cut[t + 1], n_cols, &rows[t], &reg);
+            });
+        for (auto &x : th) x.join();
+    }
+    for (int t = 0; t < n_threads; ++t) row0[t + 1] = row0[t] + rows[t];
+    if (row0[n_threads] != n) {
+        l->err = "row count changed between index and read";
+        return MDHIP_EINVAL;
+    }
+    {
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_threads; ++t)
+            th.emplace_back([&, t] { log_parse(cut[t], cut[t + 1], n_cols, row0[t], n, out, ints[t].data()); });
+        for (auto &x : th) x.join();
+    }
+    if (is_int)
+        for (int c = 0; c < n_cols; ++c) {
+            int32_t a = 1;
+            for (int t = 0; t < n_threads; ++t) a = a && ints[t][(size_t)c];
+            is_int[c] = n > 0 ? a : 0;
+        }
     return MDHIP_OK;
 }
 

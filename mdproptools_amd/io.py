@@ -142,8 +142,8 @@ _LOG_BEGIN = ("Memory usage per processor =", "Per MPI rank memory allocation")
 _LOG_END = "Loop time of"
 
 
-def parse_lammps_log(filename="log.lammps"):
-    """List of thermo DataFrames, one per `run` found in a LAMMPS log."""
+def _parse_lammps_log_text(filename):
+    """The reference's route: lines -> blocks -> pandas.read_csv (whitespace separated)."""
     with open(filename, "rt") as fh:
         lines = fh.readlines()
     runs = []
@@ -162,6 +162,53 @@ def parse_lammps_log(filename="log.lammps"):
         df = pd.read_csv(_io.StringIO("".join(block)), sep=r"\s+")
         frames.append(df)
     return frames
+
+
+def _parse_lammps_log_native(filename):
+    """Thermo tables through the native reader of libmdhip.so (mmap, threaded number parsing, host only);
+    None when a table is not plain numbers (the text route then reproduces pandas' behaviour exactly)."""
+    import ctypes as C
+
+    from . import _lib
+
+    lib = _lib.load()
+    h = C.c_void_p()
+    if lib.mdhip_log_open(str(filename).encode(), C.byref(h)) != 0:
+        raise OSError("cannot read log %s: %s" % (filename, (lib.mdhip_log_error(None) or b"").decode()))
+    try:
+        frames = []
+        for run in range(int(lib.mdhip_log_n_runs(h))):
+            n_rows, n_cols, regular = C.c_int64(), C.c_int(), C.c_int()
+            buf = C.create_string_buffer(1 << 16)
+            if lib.mdhip_log_run_info(h, run, C.byref(n_rows), C.byref(n_cols), C.byref(regular), buf, 1 << 16) != 0:
+                return None
+            names = buf.value.decode().split()
+            if not regular.value or len(set(names)) != len(names) or n_rows.value == 0:
+                return None
+            planes = np.empty((n_cols.value, n_rows.value), dtype=np.float64)
+            is_int = np.zeros(n_cols.value, dtype=np.int32)
+            rc = lib.mdhip_log_read(h, run, planes.ctypes.data_as(C.POINTER(C.c_double)),
+                                    is_int.ctypes.data_as(C.POINTER(C.c_int32)), min(16, os.cpu_count() or 1))
+            if rc != 0:
+                return None
+            cols = {}
+            for c, name in enumerate(names):
+                col = planes[c]
+                # pandas infers int64 for a column of plain integers (e.g. Step)
+                cols[name] = col.astype(np.int64) if is_int[c] and np.all(np.abs(col) < 2 ** 62) else col
+            frames.append(pd.DataFrame(cols))
+        return frames
+    finally:
+        lib.mdhip_log_close(h)
+
+
+def parse_lammps_log(filename="log.lammps"):
+    """List of thermo DataFrames, one per `run` found in a LAMMPS log."""
+    if USE_NATIVE_READER:
+        frames = _parse_lammps_log_native(filename)
+        if frames is not None:
+            return frames
+    return _parse_lammps_log_text(filename)
 
 
 class NativeDumpFile:

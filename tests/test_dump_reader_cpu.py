@@ -99,3 +99,53 @@ def test_triclinic_header(tmp_path):
     ((ts, bounds, lengths, names, planes),) = list(mio.iter_native_frames(str(path), ["x", "y", "z"]))
     np.testing.assert_array_equal(bounds, np.array(ref.box.bounds))
     assert lengths == ref.box.to_lattice().lengths and ts == 7
+
+
+# ------------------------------------------------------------------ native log reader
+def _write_log(path, runs, junk=""):
+    with open(path, "wt") as fh:
+        fh.write("LAMMPS (synthetic)\nunits real\n")
+        for names, rows in runs:
+            fh.write("Per MPI rank memory allocation (min/avg/max) = 7.9 | 7.9 | 7.9 Mbytes\n")
+            fh.write("  ".join(names) + " \n")
+            for k, row in enumerate(rows):
+                if k == 2:
+                    fh.write("WARNING: something happened (src/fix.cpp:123)\n\n")
+                if k == 3 and junk:
+                    fh.write(junk)
+                fh.write(" ".join(row) + "\n")
+            fh.write("Loop time of 12.5 on 4 procs for %d steps with 100 atoms\n\nPerformance: 1 ns/day\n" % len(rows))
+
+
+def test_native_log_reader_equals_text_route(tmp_path):
+    """Thermo tables through the native reader (parse_lammps_log default) equal the lines -> pandas.read_csv
+    route the reference takes: values, integer columns (Step), WARNING and blank lines, several runs."""
+    import pandas as pd
+    from mdproptools_amd import io as mio
+
+    rng = np.random.default_rng(3)
+    runs = []
+    for n in (7, 20_000):  # the second table is parsed by several threads
+        steps = np.arange(n) * 10
+        vals = rng.normal(0, 1e3, (n, 4))
+        rows = [["%d" % steps[k], "%.6f" % vals[k, 0], "%.10g" % vals[k, 1], "%.3e" % vals[k, 2], "%d" % (k - 3)]
+                for k in range(n)]
+        runs.append((["Step", "Temp", "Pxy", "Pxz", "v_count"], rows))
+    path = str(tmp_path / "log.lammps")
+    _write_log(path, runs)
+    native = mio._parse_lammps_log_native(path)
+    text = mio._parse_lammps_log_text(path)
+    assert native is not None and len(native) == len(text) == 2
+    for a, b in zip(native, text):
+        pd.testing.assert_frame_equal(a, b, check_exact=True)
+        assert a["Step"].dtype == np.int64 and a["v_count"].dtype == np.int64 and a["Temp"].dtype == np.float64
+    for a, b in zip(mio.parse_lammps_log(path), text):
+        pd.testing.assert_frame_equal(a, b, check_exact=True)
+    # a table with text inside is left to the text route (same result or same exception as before)
+    bad = str(tmp_path / "log.bad")
+    _write_log(bad, runs[:1], junk="SHAKE stats (type/ave/delta) on step 30\n")
+    assert mio._parse_lammps_log_native(bad) is None
+    # a log without thermo blocks
+    empty = str(tmp_path / "log.empty")
+    open(empty, "wt").write("LAMMPS\nno runs here\n")
+    assert mio.parse_lammps_log(empty) == []
