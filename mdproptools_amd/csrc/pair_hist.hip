@@ -667,6 +667,94 @@ __global__ __launch_bounds__(256) void cull_scan_kernel(unsigned *__restrict__ c
     }
 }
 
+// Whole counting sort of one frame in ONE block (many-frame workloads: as many blocks as frames): exact
+// grid origin, keys, cell populations, scan and scatter with the 32768 cell counters in LDS — no global
+// atomics (device-scope atomics on counters spread over HBM cost several times what the arithmetic costs).
+constexpr int SORT_THREADS = 1024;
+__global__ __launch_bounds__(SORT_THREADS) void cull_sort_lds_kernel(
+    const double *__restrict__ xyz, const int *__restrict__ type, long long type_fs,
+    const double *__restrict__ box, long long n, unsigned short *__restrict__ keys, double *__restrict__ sxyz,
+    int *__restrict__ stype, double4 *__restrict__ aos, long long n_pad, int n_ti)
+{
+    extern __shared__ unsigned s_cells[];  // [MORTON_CELLS] + 3 x 16 doubles of scratch behind it
+    double *s_red = reinterpret_cast<double *>(s_cells + MORTON_CELLS);
+    __shared__ unsigned s_part[SORT_THREADS];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const double *x = xyz + (size_t)f * 3 * n;
+    const double L[3] = {box[3 * f], box[3 * f + 1], box[3 * f + 2]};
+    for (int k = tid; k < MORTON_CELLS; k += SORT_THREADS) s_cells[k] = 0u;
+    // ---- origin = exact minimum of every axis ----
+    double lo[3] = {1e300, 1e300, 1e300};
+    for (long long i = tid; i < n; i += SORT_THREADS)
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) lo[ax] = __builtin_fmin(lo[ax], x[ax * n + i]);
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) lo[ax] = __builtin_fmin(lo[ax], __shfl_down(lo[ax], off, 64));
+        if ((tid & 63) == 0) s_red[ax * 16 + (tid >> 6)] = lo[ax];
+    }
+    __syncthreads();
+    double org[3];
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        double m = s_red[ax * 16];
+        for (int w = 1; w < SORT_THREADS / 64; ++w) m = __builtin_fmin(m, s_red[ax * 16 + w]);
+        org[ax] = m;
+    }
+    // ---- keys + cell populations ----
+    const double G = (double)(1 << MORTON_BITS);
+    unsigned short *kf = keys + (size_t)f * n;
+    for (long long i = tid; i < n; i += SORT_THREADS) {
+        unsigned c[3];
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            int v = (int)(wrapped_frac(x[ax * n + i] - org[ax], L[ax]) * G);
+            c[ax] = (unsigned)(v < 0 ? 0 : v > (1 << MORTON_BITS) - 1 ? (1 << MORTON_BITS) - 1 : v);
+        }
+        const unsigned key = hilbert3(c[0], c[1], c[2]);
+        kf[i] = (unsigned short)key;
+        atomicAdd(&s_cells[key], 1u);
+    }
+    __syncthreads();
+    // ---- exclusive scan of the populations ----
+    constexpr int PER = MORTON_CELLS / SORT_THREADS;
+    const int base = tid * PER;
+    unsigned sum = 0;
+    for (int k = 0; k < PER; ++k) sum += s_cells[base + k];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int d = 1; d < SORT_THREADS; d <<= 1) {
+        const unsigned add = tid >= d ? s_part[tid - d] : 0u;
+        __syncthreads();
+        s_part[tid] += add;
+        __syncthreads();
+    }
+    unsigned run = tid ? s_part[tid - 1] : 0u;
+    for (int k = 0; k < PER; ++k) {
+        const unsigned v = s_cells[base + k];
+        s_cells[base + k] = run;
+        run += v;
+    }
+    __syncthreads();
+    // ---- scatter ----
+    for (long long i = tid; i < n; i += SORT_THREADS) {
+        const unsigned pos = atomicAdd(&s_cells[kf[i]], 1u);
+        const double px = x[i], py = x[n + i], pz = x[2 * n + i];
+        const int t = type[(size_t)f * type_fs + i];
+        if (sxyz) {
+            double *o = sxyz + (size_t)f * 3 * n;
+            o[pos] = px;
+            o[n + pos] = py;
+            o[2 * n + pos] = pz;
+            stype[(size_t)f * n + pos] = t;
+        }
+        aos[(size_t)f * n_pad + pos] = make_double4(px, py, pz, __longlong_as_double((long long)t * n_ti));
+    }
+    for (long long i = n + tid; i < n_pad; i += SORT_THREADS)
+        aos[(size_t)f * n_pad + i] = make_double4(PAD_J, PAD_J, PAD_J, __longlong_as_double(0LL));
+}
+
 // scatter atoms to their sorted position (cells[] holds running offsets)
 __global__ void cull_scatter_kernel(const double *__restrict__ xyz, const int *__restrict__ type,
                                     long long type_fs, long long n, const unsigned short *__restrict__ keys,
@@ -1260,16 +1348,29 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         MD_WS(d_ws, float4, WS_WSPH, (size_t)F * nTi * (TILE / 64) * 2 * sizeof(float4));
         MD_WS(d_ao, double4, WS_SORT_AOS, (size_t)F * nTi * TILE * sizeof(double4));
         KernelTimer ptimer(ctx, 1, true);  // second event pair: collected after the pair kernel's sync
-        MD_HIP(hipMemsetAsync(d_cells, 0, (size_t)F * MORTON_CELLS * 4, ctx->stream));
         const dim3 ga((unsigned)((N + 255) / 256), (unsigned)F);
-        MD_WS(d_org, double, WS_ORIGIN, (size_t)F * 3 * 8);
-        hipLaunchKernelGGL(cull_origin_kernel, dim3((unsigned)F), dim3(256), 0, ctx->stream, p.d_xi, N, d_org);
-        hipLaunchKernelGGL(cull_keys_kernel, ga, dim3(256), 0, ctx->stream, p.d_xi, p.d_box, N, d_org, d_keys,
-                           d_cells);
-        hipLaunchKernelGGL(cull_scan_kernel, dim3((unsigned)F), dim3(256), 0, ctx->stream, d_cells);
-        hipLaunchKernelGGL(cull_scatter_kernel, ga, dim3(256), 0, ctx->stream, p.d_xi, p.d_ti,
-                           (long long)p.ti_fs, N, d_keys, d_cells, want_soa ? d_sx : (double *)nullptr, d_st, d_ao,
-                           (long long)nTi * TILE, p.n_ti);
+        // one block per frame with the cell counters in LDS when there are frames enough to fill the chip (or the
+        // frames are small); the multi-block path with global counters otherwise
+        const size_t sort_lds = (size_t)MORTON_CELLS * 4 + 3 * 16 * 8;
+        const bool lds_sort = ctx->opt_rdf_sort != 0 && sort_lds + 8192 <= ctx->lds_max && N <= 262144 &&
+                              (ctx->opt_rdf_sort == 1 || F >= ctx->cu_count / 4 || N <= 16384);
+        if (lds_sort) {
+            MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(cull_sort_lds_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));
+            hipLaunchKernelGGL(cull_sort_lds_kernel, dim3((unsigned)F), dim3(SORT_THREADS), sort_lds, ctx->stream,
+                               p.d_xi, p.d_ti, (long long)p.ti_fs, p.d_box, N, d_keys,
+                               want_soa ? d_sx : (double *)nullptr, d_st, d_ao, (long long)nTi * TILE, p.n_ti);
+        } else {
+            MD_HIP(hipMemsetAsync(d_cells, 0, (size_t)F * MORTON_CELLS * 4, ctx->stream));
+            MD_WS(d_org, double, WS_ORIGIN, (size_t)F * 3 * 8);
+            hipLaunchKernelGGL(cull_origin_kernel, dim3((unsigned)F), dim3(256), 0, ctx->stream, p.d_xi, N, d_org);
+            hipLaunchKernelGGL(cull_keys_kernel, ga, dim3(256), 0, ctx->stream, p.d_xi, p.d_box, N, d_org, d_keys,
+                               d_cells);
+            hipLaunchKernelGGL(cull_scan_kernel, dim3((unsigned)F), dim3(256), 0, ctx->stream, d_cells);
+            hipLaunchKernelGGL(cull_scatter_kernel, ga, dim3(256), 0, ctx->stream, p.d_xi, p.d_ti,
+                               (long long)p.ti_fs, N, d_keys, d_cells, want_soa ? d_sx : (double *)nullptr, d_st, d_ao,
+                               (long long)nTi * TILE, p.n_ti);
+        }
         hipLaunchKernelGGL(cull_boxes_kernel, dim3((unsigned)nTi, (unsigned)F), dim3(TILE), 0, ctx->stream,
                            d_ao, p.d_box, N, nTi, d_bbox, d_gs, d_ws);
         hipLaunchKernelGGL(cull_list_kernel, dim3((unsigned)nTi, (unsigned)F), dim3(256), 0, ctx->stream,

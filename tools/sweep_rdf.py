@@ -43,6 +43,8 @@ def main():
         dict(rdf_jsplit=4),
         dict(rdf_slots=4),
         dict(rdf_slots=64),
+        dict(rdf_sort=0),
+        dict(rdf_sort=1),
         dict(rdf_cull=0),
     ]
     rel = np.array(synth.ALL_PAIRS_4)
