@@ -77,6 +77,7 @@ struct mdhip_ctx {
     int opt_rdf_batch = 0;    // frames per batch of the pair path, 0 = auto (workspace-bounded)
     int opt_rdf_cull = -1;    // spatial culling of tile pairs: -1 = auto, 0 = never, 1 = always (when applicable)
     int opt_rdf_slots = 16;   // replicas of the frame-summed histogram in HBM
+    int opt_rdf_rows = -1;    // scalar-j RDF: -1/1 ordered-pair rows without a row table when they fit, 0 class rows + table
     int opt_rdf_sort = -1;    // spatial sort: -1 auto, 1 one block per frame (LDS counters), 0 multi-block (global counters)
     int opt_xcorr_tile = 0;
     int opt_lag_variant = 1;  // full-lag MSD: 1 = series-resident LDS kernel when it fits, 0 = staged kernel

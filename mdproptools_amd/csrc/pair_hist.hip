@@ -70,6 +70,7 @@ struct PairArgs {
     float reach;                 // r_cut rounded up, plus slack for the f32 box test
     const double4 *aos;          // [F][nTi*256] sorted atoms (x, y, z, bits = type * n_ti), padded with +1e300
     unsigned *work;              // [8] per-XCD work counters of the persistent scalar-j kernel (zeroed per launch)
+    float near;                  // MODE 2: guard band half-width (also folded into the records' row offsets)
 };
 
 __device__ __forceinline__ double wrap_abs(double d, double L)
@@ -269,6 +270,8 @@ struct FastCtx {
     const double *edges;          // global memory, nbins+2 entries, last = +inf
     const unsigned *rowtab_me;    // LDS: &rowtab[0][ti] of the table [n_tj][n_ti] -> LDS byte address of the class row
     float gscale, near, near2;    // guard band half-width and its double
+    unsigned rowbase_me;          // MODE 2: LDS byte address of row (ti, 0) of the ordered-pair histogram
+    unsigned lds_base;            // LDS byte address of the histogram
     int nbins;
 };
 
@@ -306,9 +309,10 @@ __device__ __forceinline__ void sweep_group(const double4 *__restrict__ tile, in
                     const float g1 = __builtin_fmaf(__builtin_amdgcn_sqrtf((float)rsq[u]), c.gscale, c.near);
                     k = (int)g1;
                     if (__builtin_amdgcn_fractf(g1) < c.near2) {
+                        // g1 is within 2*near above the integer k: the true bin is k or k - 1 (|error| < near),
+                        // and the exact edge of k decides
                         k = k > c.nbins ? c.nbins : k;
-                        while (rsq[u] < c.edges[k]) --k;
-                        while (rsq[u] >= c.edges[k + 1]) ++k;
+                        k = rsq[u] < c.edges[k] ? k - 1 : k;
                     }
                 } else {
                     // CN edge tables (a few sorted cutoffs^2): count the edges at or below rsq
@@ -587,6 +591,16 @@ __device__ __forceinline__ unsigned hilbert3(unsigned cx, unsigned cy, unsigned 
     return key;
 }
 
+// 4th double of a sorted record: low word = type * n_ti (word offset into the [tj][ti] row table), high word =
+// float(near + type * row_len), the addend of the bin guess that carries the row of the ordered-pair layout
+// (MODE 2 of the scalar-j kernel; 0 otherwise).
+__device__ __forceinline__ double pack_w(int t, int n_ti, float near, int row_len)
+{
+    const unsigned lo = (unsigned)(t * n_ti);
+    const unsigned hi = row_len > 0 ? __float_as_uint(near + (float)(t * row_len)) : 0u;
+    return __hiloint2double((int)hi, (int)lo);
+}
+
 // origin[f][3] ~ smallest x, y, z of the frame, from 1024 atoms spread over the id range (one block per
 // frame). The grid of the spatial sort is laid from there, so that a cell [lo, lo+L) with any lo is cut at
 // its own faces and not somewhere inside. Only the quality of the sort depends on it (an origin a little
@@ -674,7 +688,7 @@ constexpr int SORT_THREADS = 1024;
 __global__ __launch_bounds__(SORT_THREADS) void cull_sort_lds_kernel(
     const double *__restrict__ xyz, const int *__restrict__ type, long long type_fs,
     const double *__restrict__ box, long long n, unsigned short *__restrict__ keys, double *__restrict__ sxyz,
-    int *__restrict__ stype, double4 *__restrict__ aos, long long n_pad, int n_ti)
+    int *__restrict__ stype, double4 *__restrict__ aos, long long n_pad, int n_ti, float near, int row_len)
 {
     extern __shared__ unsigned s_cells[];  // [MORTON_CELLS] + 3 x 16 doubles of scratch behind it
     double *s_red = reinterpret_cast<double *>(s_cells + MORTON_CELLS);
@@ -749,7 +763,7 @@ __global__ __launch_bounds__(SORT_THREADS) void cull_sort_lds_kernel(
             o[2 * n + pos] = pz;
             stype[(size_t)f * n + pos] = t;
         }
-        aos[(size_t)f * n_pad + pos] = make_double4(px, py, pz, __longlong_as_double((long long)t * n_ti));
+        aos[(size_t)f * n_pad + pos] = make_double4(px, py, pz, pack_w(t, n_ti, near, row_len));
     }
     for (long long i = n + tid; i < n_pad; i += SORT_THREADS)
         aos[(size_t)f * n_pad + i] = make_double4(PAD_J, PAD_J, PAD_J, __longlong_as_double(0LL));
@@ -760,7 +774,7 @@ __global__ void cull_scatter_kernel(const double *__restrict__ xyz, const int *_
                                     long long type_fs, long long n, const unsigned short *__restrict__ keys,
                                     unsigned *__restrict__ cells, double *__restrict__ sxyz,
                                     int *__restrict__ stype, double4 *__restrict__ aos, long long n_pad,
-                                    int n_ti)
+                                    int n_ti, float near, int row_len)
 {
     const int f = blockIdx.y;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -777,7 +791,7 @@ __global__ void cull_scatter_kernel(const double *__restrict__ xyz, const int *_
         o[2 * n + pos] = pz;
         stype[(size_t)f * n + pos] = t;
     }
-    aos[(size_t)f * n_pad + pos] = make_double4(px, py, pz, __longlong_as_double((long long)t * n_ti));
+    aos[(size_t)f * n_pad + pos] = make_double4(px, py, pz, pack_w(t, n_ti, near, row_len));
     // the pad records behind the last atom (never in cutoff: rsq overflows to +inf)
     if (i < n_pad - n) aos[(size_t)f * n_pad + n + i] = make_double4(PAD_J, PAD_J, PAD_J, __longlong_as_double(0LL));
 }
@@ -971,7 +985,7 @@ __device__ __forceinline__ void sweep_group_sj(const double4 *__restrict__ grp, 
             const double ay = axis_abs<VAR>(yi - yj, L.Ly, L.sy);
             const double az = axis_abs<VAR>(zi - zj, L.Lz, L.sz);
             rsq[u] = (ax * ax + ay * ay) + az * az;
-            row[u] = c.rowtab_me[(int)rec[u][6]];  // low word of w = type * n_ti
+            if (MODE != 2) row[u] = c.rowtab_me[(int)rec[u][6]];  // low word of w = type * n_ti
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -979,13 +993,33 @@ __device__ __forceinline__ void sweep_group_sj(const double4 *__restrict__ grp, 
             if (DIAG) in = in && (local0 + h * U + u > lane_in_tile);
             if (in) {
                 int k;
+                if (MODE == 2) {
+                    // ordered-pair rows: the word offset of row (., tj) rides in the addend of the bin guess
+                    // (high word of w = float(near + tj * row_len)), so no row lookup at all:
+                    // trunc(g1) = tj * row_len + bin, and fract(g1) is the same guard-band test as in MODE 0
+                    const float nearoff = __uint_as_float(rec[u][7]);
+                    const float g1 = __builtin_fmaf(__builtin_amdgcn_sqrtf((float)rsq[u]), c.gscale, nearoff);
+                    k = (int)g1;
+                    if (__builtin_amdgcn_fractf(g1) < c.near2) {
+                        // g1 is within 2*near above an integer: the true bin is that integer or the one below
+                        // (|error| < near), and the exact edge of that integer decides
+                        const int koff = (int)nearoff;  // near < 1: truncation gives tj * row_len back
+                        int kk = k - koff;
+                        kk = kk > c.nbins ? c.nbins : (kk < 0 ? 0 : kk);
+                        k = koff + (rsq[u] < c.edges[kk] ? kk - 1 : kk);
+                    }
+                    const unsigned addr2 = ((unsigned)k << 2) + c.rowbase_me;
+                    asm volatile("ds_add_u32 %0, %1" ::"v"(addr2), "v"(1u) : "memory");
+                    continue;
+                }
                 if (MODE == 0) {
                     const float g1 = __builtin_fmaf(__builtin_amdgcn_sqrtf((float)rsq[u]), c.gscale, c.near);
                     k = (int)g1;
                     if (__builtin_amdgcn_fractf(g1) < c.near2) {
+                        // g1 is within 2*near above the integer k: the true bin is k or k - 1 (|error| < near),
+                        // and the exact edge of k decides
                         k = k > c.nbins ? c.nbins : k;
-                        while (rsq[u] < c.edges[k]) --k;
-                        while (rsq[u] >= c.edges[k + 1]) ++k;
+                        k = rsq[u] < c.edges[k] ? k - 1 : k;
                     }
                 } else {
                     k = 0;
@@ -1033,7 +1067,11 @@ __device__ __forceinline__ void sj_item(const PairArgs &a, FastCtx &c, const uns
     const long long ig = (long long)I * TILE + lane_in_tile;
     double4 me = ats[ig];
     if (ig >= a.ni) me = make_double4(PAD_I, PAD_I, PAD_I, __longlong_as_double(0LL));
-    c.rowtab_me = s_row + (int)(__double_as_longlong(me.w) / a.n_ti);
+    {
+        const int ti_me = (int)((unsigned)__double_as_longlong(me.w)) / a.n_ti;  // low word of w = type * n_ti
+        c.rowtab_me = s_row + ti_me;
+        c.rowbase_me = c.lds_base + (unsigned)ti_me * (unsigned)a.n_tj * (unsigned)(a.nbins + 1) * 4u;
+    }
     const long long w = ((long long)f * a.nTi + I) * (TILE / 64) + wq;
     const float4 wlo = a.wsph[2 * w], whi = a.wsph[2 * w + 1];
     const float4 *gb_f = a.gsph + (long long)f * a.nTi * (TILE / 8) * 2;
@@ -1105,8 +1143,9 @@ __global__ __launch_bounds__(TILE) void pair_hist_sj_kernel(const PairArgs a)
     const int xcd = (int)(bid & 7);
 
     // ---- LDS: hist | (CN edges) | row table ----
+    // MODE 2: one row per ORDERED type pair (ti, tj), addressed without a table (see sweep_group_sj)
     const int row_len = a.nbins + 1;
-    const int hist_words = (a.n_cls + 1) * row_len;
+    const int hist_words = (MODE == 2 ? a.n_ti * a.n_tj : a.n_cls + 1) * row_len;
     unsigned *s_hist = reinterpret_cast<unsigned *>(smem);
     size_t off = ((size_t)hist_words * 4 + 15) & ~size_t(15);
     double *s_edges = reinterpret_cast<double *>(smem + off);
@@ -1115,11 +1154,12 @@ __global__ __launch_bounds__(TILE) void pair_hist_sj_kernel(const PairArgs a)
     const unsigned lds_base =
         (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char *)smem;
     for (int k = tid; k < hist_words; k += TILE) s_hist[k] = 0u;
-    for (int k = tid; k < a.n_ti * a.n_tj; k += TILE) {
-        const int ti = k % a.n_ti, tj = k / a.n_ti;
-        const unsigned cl = a.cls[ti * a.n_tj + tj];
-        s_row[k] = lds_base + (cl == 0xFFu ? (unsigned)a.n_cls : cl) * (unsigned)row_len * 4u;
-    }
+    if (MODE != 2)
+        for (int k = tid; k < a.n_ti * a.n_tj; k += TILE) {
+            const int ti = k % a.n_ti, tj = k / a.n_ti;
+            const unsigned cl = a.cls[ti * a.n_tj + tj];
+            s_row[k] = lds_base + (cl == 0xFFu ? (unsigned)a.n_cls : cl) * (unsigned)row_len * 4u;
+        }
     FastCtx c;
     c.hist = s_hist;
     c.edges = a.edges;
@@ -1128,9 +1168,11 @@ __global__ __launch_bounds__(TILE) void pair_hist_sj_kernel(const PairArgs a)
         c.edges = s_edges;
     }
     c.gscale = a.gscale;
-    c.near = (float)a.nbins * 1.0e-6f + 1.0e-5f;
+    c.near = MODE == 2 ? a.near : (float)a.nbins * 1.0e-6f + 1.0e-5f;
     c.near2 = 2.0f * c.near;
     c.nbins = a.nbins;
+    c.lds_base = lds_base;
+    c.rowbase_me = lds_base;
     __syncthreads();  // tables ready; from here on the waves do not synchronise until the flush
 
     const int lane = tid & 63;
@@ -1166,13 +1208,23 @@ __global__ __launch_bounds__(TILE) void pair_hist_sj_kernel(const PairArgs a)
     for (int w = tid; w < hist_words; w += TILE) {
         const unsigned v = s_hist[w];
         if (!v) continue;
-        const int cl = w / row_len, k = w - cl * row_len;
+        int cl = w / row_len;
+        const int k = w - cl * row_len;
+        if (MODE == 2) {  // row = ti * n_tj + tj -> class of the unordered pair (0xFF: no relation asks for it)
+            const unsigned c8 = a.cls[cl];
+            cl = c8 == 0xFFu ? a.n_cls : (int)c8;
+        }
         if (k == a.nbins)
             ovf += v;
         else if (cl < a.n_cls)
             atomicAdd(&g[(size_t)cl * a.nbins + k], (unsigned long long)v);
     }
     if (ovf) atomicAdd(a.overflow, (unsigned long long)ovf);
+}
+
+size_t lds_bytes_sj_ordered(int nbins, int n_ti, int n_tj)
+{
+    return (((size_t)n_ti * n_tj * (nbins + 1) * 4 + 15) & ~size_t(15)) + 16;
 }
 
 size_t lds_bytes_sj(int nbins, int n_cls, int n_ti, int n_tj, bool mode_cn)
@@ -1265,6 +1317,22 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
     if (cls_per_pass > p.n_cls) cls_per_pass = p.n_cls;
     if (cls_per_pass > 250) cls_per_pass = 250;
 
+    // Ordered-pair rows (MODE 2 of the scalar-j kernel): one LDS row per (ti, tj) addressed without a table —
+    // the row offset rides in the addend of the bin guess. Needs all n_ti^2 rows in LDS at >= 4 blocks per CU
+    // and all classes in one pass.
+    const size_t ord_b = lds_bytes_sj_ordered(p.nbins, p.n_ti, p.n_tj);
+    const bool ordered = cull && ctx->opt_rdf_sj != 0 && !mode_cn && p.tri && ctx->opt_rdf_rows != 0 &&
+                         p.n_cls <= 250 && ord_b <= lds_cap / 4 && (double)p.n_tj * (p.nbins + 1) < 65536.0;
+    float near_ord = 0.f;
+    if (ordered) {
+        cls_per_pass = p.n_cls;
+        // |error| of the f32 guess g = fma(sqrt((float)rsq), 1/ddr, near + tj*row_len): relative 2^-25 (conversion,
+        // halved by the root) + 2^-23 (v_sqrt_f32, 1 ulp) + 2^-24 (rounded 1/ddr) = 2.1e-7 of the bin number, plus
+        // half an ulp of the largest value each for the rounding of the addend and of the fma. near = 2 x that.
+        const double maxg = (double)p.n_tj * (p.nbins + 1) + 1.0;  // the addend carries tj * row_len only
+        const double ulp = std::ldexp(1.0, (int)std::floor(std::log2(maxg)) - 23);
+        near_ord = (float)(2.0 * ((double)p.nbins * 2.1e-7 + ulp) + 1.0e-5);
+    }
     const int n_pass = (p.n_cls + cls_per_pass - 1) / cls_per_pass;
 
     // geometry
@@ -1359,7 +1427,8 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));
             hipLaunchKernelGGL(cull_sort_lds_kernel, dim3((unsigned)F), dim3(SORT_THREADS), sort_lds, ctx->stream,
                                p.d_xi, p.d_ti, (long long)p.ti_fs, p.d_box, N, d_keys,
-                               want_soa ? d_sx : (double *)nullptr, d_st, d_ao, (long long)nTi * TILE, p.n_ti);
+                               want_soa ? d_sx : (double *)nullptr, d_st, d_ao, (long long)nTi * TILE, p.n_ti,
+                               ordered ? near_ord : 0.f, ordered ? p.nbins + 1 : 0);
         } else {
             MD_HIP(hipMemsetAsync(d_cells, 0, (size_t)F * MORTON_CELLS * 4, ctx->stream));
             MD_WS(d_org, double, WS_ORIGIN, (size_t)F * 3 * 8);
@@ -1369,7 +1438,7 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
             hipLaunchKernelGGL(cull_scan_kernel, dim3((unsigned)F), dim3(256), 0, ctx->stream, d_cells);
             hipLaunchKernelGGL(cull_scatter_kernel, ga, dim3(256), 0, ctx->stream, p.d_xi, p.d_ti,
                                (long long)p.ti_fs, N, d_keys, d_cells, want_soa ? d_sx : (double *)nullptr, d_st, d_ao,
-                               (long long)nTi * TILE, p.n_ti);
+                               (long long)nTi * TILE, p.n_ti, ordered ? near_ord : 0.f, ordered ? p.nbins + 1 : 0);
         }
         hipLaunchKernelGGL(cull_boxes_kernel, dim3((unsigned)nTi, (unsigned)F), dim3(TILE), 0, ctx->stream,
                            d_ao, p.d_box, N, nTi, d_bbox, d_gs, d_ws);
@@ -1434,16 +1503,20 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         a.slots = slots;
         a.fpb = fpb;
 
+        a.near = near_ord;
         const bool sj = cull && ctx->opt_rdf_sj != 0;  // wave-independent sweep with scalar loads of the j atoms
         const bool persist = sj && !p.per_frame && ctx->opt_rdf_sj != 2;  // resident grid + per-XCD work counters
         a.work = reinterpret_cast<unsigned *>(d_misc + 4);
-        const size_t lds = sj     ? lds_bytes_sj(p.nbins, nc, p.n_ti, p.n_tj, mode_cn)
+        const size_t lds = ordered ? ord_b
+                           : sj    ? lds_bytes_sj(p.nbins, nc, p.n_ti, p.n_tj, mode_cn)
                            : fast ? lds_bytes_fast(p.nbins, nc, p.n_ti, p.n_tj)
                                   : lds_bytes(p.nbins, nc, p.n_ti, p.n_tj);
         void (*kern)(const PairArgs);
 #define MD_PICK(...) (ctx->last_kernel = #__VA_ARGS__, __VA_ARGS__)
         if (!fast)
             kern = p.tri ? MD_PICK(pair_hist_kernel<true>) : MD_PICK(pair_hist_kernel<false>);
+        else if (ordered)
+            kern = persist ? MD_PICK(pair_hist_sj_kernel<2, true>) : MD_PICK(pair_hist_sj_kernel<2, false>);
         else if (persist)
             kern = mode_cn ? MD_PICK(pair_hist_sj_kernel<1, true>) : MD_PICK(pair_hist_sj_kernel<0, true>);
         else if (sj)

@@ -497,15 +497,16 @@ def test_culled_path_wrap_variants(B, case):
     cf, cp, cov = C.rdf_pairs(xyz[0], ty, rel, L, r_cut * r_cut, 0.05, nb)
     ccn = C.cn_pairs(xyz[0], ty, rel, L, [c * c for c in cuts])
     assert cf.sum() > 0
-    for cull, sj, sort in ((0, 1, -1), (1, 0, 0), (1, 1, 0), (1, 1, 1), (1, 2, 1)):
+    for cull, sj, sort, rows in ((0, 1, -1, -1), (1, 0, 0, -1), (1, 1, 0, 0), (1, 1, 1, 1), (1, 2, 1, 1), (1, 2, 0, 0)):
         ctx = Context(0)
         ctx.set_option("rdf_cull", cull)
         ctx.set_option("rdf_sj", sj)
         ctx.set_option("rdf_sort", sort)  # spatial sort with global counters / one block per frame
+        ctx.set_option("rdf_rows", rows)  # ordered-pair rows without a row table / class rows
         for per_frame in (True, False):
             full, part, ov = B.rdf_loop(xyz, ty, L[None], rel, r_cut, 0.05, nb, per_frame=per_frame, ctx=ctx)
             full, part = (full[0], part[0]) if per_frame else (full, part)
-            np.testing.assert_array_equal(full, cf, err_msg="%s cull=%d sj=%d sort=%d pf=%d" % (case, cull, sj, sort, per_frame))
+            np.testing.assert_array_equal(full, cf, err_msg="%s cull=%d sj=%d sort=%d rows=%d pf=%d" % (case, cull, sj, sort, rows, per_frame))
             np.testing.assert_array_equal(part, cp)
             assert ov == cov
         np.testing.assert_array_equal(B.cn_loop(xyz, ty, L[None], rel, cuts, ctx=ctx)[0], ccn)
