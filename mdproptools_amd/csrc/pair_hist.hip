@@ -1168,6 +1168,13 @@ __global__ __launch_bounds__(TILE) void pair_hist_sj_kernel(const PairArgs a)
         c.edges = s_edges;
     }
     c.gscale = a.gscale;
+    if (MODE == 2) {
+        // the bin guess is fma(sqrt, gscale, addend) with the addend in an SGPR (it belongs to the j atom): a VOP3
+        // may read one SGPR, so gscale has to live in a VGPR or every guess pays a v_mov
+        float gs;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(gs) : "s"(a.gscale));
+        c.gscale = gs;
+    }
     c.near = MODE == 2 ? a.near : (float)a.nbins * 1.0e-6f + 1.0e-5f;
     c.near2 = 2.0f * c.near;
     c.nbins = a.nbins;
