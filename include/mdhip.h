@@ -67,7 +67,7 @@ int mdhip_device_name(mdhip_ctx *ctx, char *buf, int buflen);
  * keys: "rdf_variant" (1 = fast pair kernel, default; 0 = edge-table lookup per pair), "rdf_cull"
  * (-1 auto, 0 dense sweep, 1 spatially culled sweep), "rdf_jsplit", "rdf_fpb", "rdf_batch", "rdf_slots",
  * "rdf_sj" (culled path: 1 scalar-j kernel, persistent grid when frame-summed; 2 scalar-j, one block per
- * (frame, tile, slice); 0 LDS-tile kernel), "rdf_rows" (scalar-j RDF: 1 ordered-pair rows, no row table; 0 class rows), "rdf_sort" (spatial sort: -1 auto, 1 one block per frame with LDS
+ * (frame, tile, slice); 0 LDS-tile kernel), "rdf_inflight" (per-frame output: frames in flight per XCD), "rdf_rows" (scalar-j RDF: 1 ordered-pair rows, no row table; 0 class rows), "rdf_sort" (spatial sort: -1 auto, 1 one block per frame with LDS
  * counters, 0 multi-block with global counters), "lag_variant" (1 series-resident full-lag kernel, 0 staged),
  * "xcorr_tile". */
 int mdhip_set_option(mdhip_ctx *ctx, const char *key, int value);

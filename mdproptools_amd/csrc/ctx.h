@@ -38,6 +38,9 @@ enum WsSlot {
     WS_WSPH,
     WS_SORT_AOS,   // sorted atoms as (x, y, z, row-table offset) records, padded to whole tiles
     WS_ORIGIN,     // per-frame grid origin of the spatial sort
+    WS_WORK,       // per-frame work counters of the scalar-j kernel
+    WS_SLICES,     // per-block histogram copies of the scalar-j kernel
+    WS_ROWS,       // their sums per output frame
     WS_COUNT
 };
 
@@ -77,6 +80,7 @@ struct mdhip_ctx {
     int opt_rdf_batch = 0;    // frames per batch of the pair path, 0 = auto (workspace-bounded)
     int opt_rdf_cull = -1;    // spatial culling of tile pairs: -1 = auto, 0 = never, 1 = always (when applicable)
     int opt_rdf_slots = 16;   // replicas of the frame-summed histogram in HBM
+    int opt_rdf_inflight = 1; // per-frame output: frames in flight per XCD (their records should stay in its L2)
     int opt_rdf_rows = -1;    // scalar-j RDF: -1/1 ordered-pair rows without a row table when they fit, 0 class rows + table
     int opt_rdf_sort = -1;    // spatial sort: -1 auto, 1 one block per frame (LDS counters), 0 multi-block (global counters)
     int opt_xcorr_tile = 0;

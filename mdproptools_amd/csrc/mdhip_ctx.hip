@@ -191,6 +191,8 @@ int mdhip_set_option(mdhip_ctx *ctx, const char *key, int value)
         ctx->opt_rdf_fpb = value;
     else if (!strcmp(key, "rdf_jsplit"))
         ctx->opt_rdf_jsplit = value;
+    else if (!strcmp(key, "rdf_inflight"))
+        ctx->opt_rdf_inflight = value < 1 ? 1 : value;
     else if (!strcmp(key, "rdf_rows"))
         ctx->opt_rdf_rows = value;
     else if (!strcmp(key, "rdf_sort"))

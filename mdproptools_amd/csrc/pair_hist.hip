@@ -69,8 +69,10 @@ struct PairArgs {
     const float4 *wsph;          // [F][nTi*4][2]  bounding box of every 64 sorted atoms (one wave's i atoms)
     float reach;                 // r_cut rounded up, plus slack for the f32 box test
     const double4 *aos;          // [F][nTi*256] sorted atoms (x, y, z, bits = type * n_ti), padded with +1e300
-    unsigned *work;              // [8] per-XCD work counters of the persistent scalar-j kernel (zeroed per launch)
+    unsigned *work;              // work counters of the scalar-j kernel, zeroed per launch: [8] per XCD
+                                 // (frame-summed output) or [F] per frame (per-frame output)
     float near;                  // MODE 2: guard band half-width (also folded into the records' row offsets)
+    unsigned *slices;            // scalar-j kernels: [blocks][LDS histogram words], every block stores its own copy
 };
 
 __device__ __forceinline__ double wrap_abs(double d, double L)
@@ -1198,35 +1200,52 @@ __global__ __launch_bounds__(TILE) void pair_hist_sj_kernel(const PairArgs a)
             sj_item<MODE>(a, c, s_row, fx * 8 + xcd, wI >> 2, wI & 3, split, lane);
         }
     } else {
-        const long long q = bid >> 3;
-        const int f = (int)(q / a.blocks_per_frame) * 8 + xcd;
-        const int within = (int)(q % a.blocks_per_frame);
+        // a.blocks_per_frame blocks share one frame and flush once each into the frame's row
+        // (frames stay dealt to XCDs, f % 8 = XCD, so that a frame's records are fetched into one L2)
+        const int f = (int)((bid >> 3) / a.blocks_per_frame) * 8 + xcd;
         f_out = f < a.n_frames ? f : 0;
-        if (f < a.n_frames) sj_item<MODE>(a, c, s_row, f, within % a.nTi, tid >> 6, within / a.nTi, lane);
+        const unsigned ipf = f < a.n_frames ? (unsigned)(a.nTi * (TILE / 64) * a.jsplit) : 0u;
+        for (;;) {  // the frame's blocks draw its wave items from the frame's counter (integer sums: any order)
+            unsigned it = 0;
+            if (ipf == 0u) break;
+            if (lane == 0) it = atomicAdd(&a.work[f], 1u);
+            it = (unsigned)__builtin_amdgcn_readfirstlane((int)it);
+            if (it >= ipf) break;
+            const int split = (int)(it % (unsigned)a.jsplit), wI = (int)(it / (unsigned)a.jsplit);
+            sj_item<MODE>(a, c, s_row, f, wI >> 2, wI & 3, split, lane);
+        }
     }
 
-    // ---- flush (as the fast kernel) ----
+    // ---- flush: the block's LDS histogram goes to its own slice with plain coalesced stores (device-scope
+    // atomics on rows spread over HBM cost ~40 ps each: 10^7 of them per launch were 6 % of the kernel);
+    // merge_slices_kernel adds the slices up afterwards ----
+    (void)f_out;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
-    const int out_words = a.n_cls * a.nbins;
-    unsigned long long *g =
-        a.hist + (size_t)(a.per_frame ? f_out : (int)(bid % a.slots)) * (size_t)out_words;
-    unsigned ovf = 0;
-    for (int w = tid; w < hist_words; w += TILE) {
-        const unsigned v = s_hist[w];
-        if (!v) continue;
-        int cl = w / row_len;
-        const int k = w - cl * row_len;
-        if (MODE == 2) {  // row = ti * n_tj + tj -> class of the unordered pair (0xFF: no relation asks for it)
-            const unsigned c8 = a.cls[cl];
-            cl = c8 == 0xFFu ? a.n_cls : (int)c8;
-        }
-        if (k == a.nbins)
-            ovf += v;
-        else if (cl < a.n_cls)
-            atomicAdd(&g[(size_t)cl * a.nbins + k], (unsigned long long)v);
+    unsigned *slice = a.slices + (size_t)bid * (size_t)hist_words;
+    for (int w = tid; w < hist_words; w += TILE) slice[w] = s_hist[w];
+}
+
+// rows[o][w] = sum of slice word w over the blocks of output o: per-frame output o = frame f, whose blocks are
+// ((f / 8) * bpf + sub) * 8 + f % 8, sub < bpf; frame-summed output: all blocks, split over gridDim.y chunks
+// whose partial sums are added with (few) 64-bit atomics into the zeroed row buffer.
+__global__ void merge_slices_kernel(const unsigned *__restrict__ slices, int hist_words, long long n_blocks,
+                                    int per_frame, int bpf, unsigned long long *__restrict__ rows)
+{
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= hist_words) return;
+    unsigned long long sum = 0;
+    if (per_frame) {
+        const long long f = blockIdx.y;
+        const long long b0 = ((f >> 3) * bpf) * 8 + (f & 7);
+        for (int sub = 0; sub < bpf; ++sub) sum += slices[(size_t)(b0 + 8LL * sub) * hist_words + w];
+        rows[(size_t)f * hist_words + w] = sum;
+    } else {
+        const long long per = (n_blocks + gridDim.y - 1) / gridDim.y;
+        const long long b1 = std::min<long long>(n_blocks, (blockIdx.y + 1) * per);
+        for (long long b = blockIdx.y * per; b < b1; ++b) sum += slices[(size_t)b * hist_words + w];
+        if (sum) atomicAdd(&rows[w], sum);
     }
-    if (ovf) atomicAdd(a.overflow, (unsigned long long)ovf);
 }
 
 size_t lds_bytes_sj_ordered(int nbins, int n_ti, int n_tj)
@@ -1543,25 +1562,82 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         long long launch_grid = grid;
         if (sj) {
-            // the scalar-j kernel handles one frame per block visit (no fpb loop)
-            a.fpb = 1;
-            launch_grid = ((F + 7) / 8) * 8 * blocks_per_frame;
-        }
-        if (persist) {
             int per_cu = 0;
             MD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), TILE,
                                                                 lds));
             if (per_cu < 1) per_cu = 1;
-            const long long items = (long long)F * nTi * (TILE / 64) * jsplit;
-            launch_grid = (long long)per_cu * ctx->cu_count;
-            launch_grid = std::min(launch_grid, (items + 3) / 4 + 8);
-            launch_grid = (launch_grid + 7) / 8 * 8;
-            MD_HIP(hipMemsetAsync(d_misc + 4, 0, 32, ctx->stream));
+            const long long capacity = (long long)per_cu * ctx->cu_count;
+            const long long block_items = (long long)nTi * jsplit;  // groups of 4 wave items per frame
+            a.fpb = 1;
+            if (persist) {
+                launch_grid = std::min(capacity, F * block_items + 8);
+                launch_grid = (launch_grid + 7) / 8 * 8;
+                MD_HIP(hipMemsetAsync(d_misc + 4, 0, 32, ctx->stream));
+            } else {
+                // per-frame output: as many blocks per frame as keeps one resident set busy, each flushing once
+                // blocks per frame: few frames in flight per XCD (their records should stay in its 4 MB L2: 32 B per
+                // atom per frame), every wave still left with a few items to draw
+                const long long cap_xcd = std::max<long long>(1, capacity / 8);
+                const long long frames_xcd = (F + 7) / 8;
+                const long long in_flight = std::max<long long>(1, std::min<long long>(frames_xcd, ctx->opt_rdf_inflight));
+                long long bpf = std::max<long long>(1, cap_xcd / in_flight);
+                bpf = std::min(bpf, std::max<long long>(1, block_items / 2));
+                a.blocks_per_frame = (int)bpf;
+                launch_grid = ((F + 7) / 8) * 8 * bpf;
+                MD_WS(d_work, unsigned, WS_WORK, (size_t)F * 4);
+                MD_HIP(hipMemsetAsync(d_work, 0, (size_t)F * 4, ctx->stream));
+                a.work = d_work;
+            }
+        }
+        // scalar-j kernels: every block stores its LDS histogram into its own slice; a merge kernel adds them up
+        const int sj_rows = ordered ? p.n_ti * p.n_tj : nc + 1;
+        const int sj_words = sj_rows * (p.nbins + 1);
+        unsigned long long *d_rows = nullptr;
+        if (sj) {
+            MD_WS(d_sl, unsigned, WS_SLICES, (size_t)launch_grid * sj_words * 4);
+            d_rows = (unsigned long long *)mdhip_ws(ctx, WS_ROWS, out_frames * (size_t)sj_words * 8);
+            if (!d_rows) return MDHIP_ENOMEM;
+            if (!p.per_frame) MD_HIP(hipMemsetAsync(d_rows, 0, (size_t)sj_words * 8, ctx->stream));
+            a.slices = d_sl;
         }
         KernelTimer timer(ctx);
         hipLaunchKernelGGL(kern, dim3((unsigned)launch_grid), dim3(TILE), lds, ctx->stream, a);
+        if (sj) {
+            const unsigned gy = p.per_frame ? (unsigned)F : (unsigned)std::min<long long>(64, launch_grid);
+            hipLaunchKernelGGL(merge_slices_kernel, dim3((unsigned)((sj_words + 255) / 256), gy), dim3(256), 0,
+                               ctx->stream, a.slices, sj_words, launch_grid, p.per_frame, a.blocks_per_frame, d_rows);
+        }
         timer.stop();
         MD_HIP(hipGetLastError());
+
+        if (sj) {
+            // D2H of the row sums (pinned staging), then rows -> classes and the overflow words on the host
+            MD_PIN(hrows, uint64_t, PIN_OUT, out_frames * (size_t)sj_words * 8);
+            MD_HIP(hipMemcpyAsync(hrows, d_rows, out_frames * (size_t)sj_words * 8, hipMemcpyDeviceToHost,
+                                  ctx->stream));
+            MD_HIP(hipStreamSynchronize(ctx->stream));
+            timer.collect();
+            total_ms += ctx->last_ms;
+            ++launches;
+            if (prep_timed) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, ctx->ev2, ctx->ev3) == hipSuccess) prep_ms = ms;
+                prep_timed = false;
+            }
+            const int row_len = p.nbins + 1;
+            for (size_t fr = 0; fr < out_frames; ++fr)
+                for (int r = 0; r < sj_rows; ++r) {
+                    const uint64_t *src = hrows + (fr * sj_rows + r) * row_len;
+                    ov += src[p.nbins];
+                    // ordered rows (ti, tj) -> class of the unordered pair; class rows of this pass -> c0 + r, the
+                    // extra row holds the pairs whose class belongs to another pass
+                    const int cl = ordered ? (int)p.cls[r] : (r < nc ? c0 + r : -1);
+                    if (cl < 0) continue;
+                    uint64_t *dst = &H[(fr * p.n_cls + cl) * p.nbins];
+                    for (int k = 0; k < p.nbins; ++k) dst[k] += src[k];
+                }
+            continue;
+        }
 
         unsigned long long *d_final = d_hist;
         if (!p.per_frame && slots > 1) {

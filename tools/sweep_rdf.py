@@ -44,6 +44,8 @@ def main():
         dict(rdf_slots=4),
         dict(rdf_slots=64),
         dict(rdf_rows=0),
+        dict(rdf_inflight=4),
+        dict(rdf_inflight=16),
         dict(rdf_sort=0),
         dict(rdf_sort=1),
         dict(rdf_cull=0),
