@@ -1582,6 +1582,8 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
                 const long long in_flight = std::max<long long>(1, std::min<long long>(frames_xcd, ctx->opt_rdf_inflight));
                 long long bpf = std::max<long long>(1, cap_xcd / in_flight);
                 bpf = std::min(bpf, std::max<long long>(1, block_items / 2));
+                // every block stores one copy of its LDS histogram: keep that workspace within ~2 GiB
+                while (bpf > 8 && (double)(((F + 7) / 8) * 8 * bpf) * (double)lds > 2147483648.0) bpf /= 2;
                 a.blocks_per_frame = (int)bpf;
                 launch_grid = ((F + 7) / 8) * 8 * bpf;
                 MD_WS(d_work, unsigned, WS_WORK, (size_t)F * 4);

@@ -11,7 +11,7 @@
 // MDHIP_XCORR_DIRECT: register-blocked direct lag sums, FP64-FMA bound (n^2/2 fused multiply-adds
 // per pair). A block owns a tile of 2048 consecutive lags (8 per lane) and streams time in chunks
 // staged through LDS; a lane keeps a 16-deep sliding window of `a` in registers so that 8 LDS reads
-// feed 64 FMAs. The a-window is stored transposed in LDS ([i mod 8][i div 8]) so that the 64 lanes
+// feed 64 FMAs, while b[t] (the same for every lane) arrives through scalar loads as an SGPR operand. The a-window is stored transposed in LDS ([i mod 8][i div 8]) so that the 64 lanes
 // of a wave read consecutive doubles (no bank conflicts). Lag tiles are paired (j, nT-1-j) so every
 // block has the same amount of work; time is split into slabs whose partial sums are added in a
 // fixed order by a second kernel (no float atomics).
@@ -125,7 +125,6 @@ __global__ __launch_bounds__(DX_THREADS) void xcorr_direct_kernel(
     int n_tiles, int n_slabs, double *__restrict__ partial)
 {
     __shared__ double s_a[8 * DX_ROW];
-    __shared__ __attribute__((aligned(16))) double s_b[DX_TT];
     const int tid = threadIdx.x;
     const int pair_id = blockIdx.x;  // handles lag tiles pair_id and n_tiles-1-pair_id
     const int slab = blockIdx.y;
@@ -147,35 +146,45 @@ __global__ __launch_bounds__(DX_THREADS) void xcorr_direct_kernel(
 
         for (long long T0 = t_lo; T0 < t_hi; T0 += DX_TT) {
             __syncthreads();
-            // stage b[T0 .. T0+TT) and a[T0+K0 .. T0+K0+AW), zero beyond the valid range
-            for (int i = tid; i < DX_TT; i += DX_THREADS) {
-                const long long t = T0 + i;
-                s_b[i] = t < t_hi ? b[t] : 0.0;
-            }
+            // stage a[T0+K0 .. T0+K0+AW), zero beyond the series (a pair whose a sample does not exist adds 0)
             for (int i = tid; i < DX_AW; i += DX_THREADS) {
                 const long long g = T0 + K0 + i;
                 s_a[(i & 7) * DX_ROW + (i >> 3)] = g < n ? a[g] : 0.0;
             }
             __syncthreads();
-            // lane window: w[j] = a_stage[8*tid + j + tt], element index i = 8*tid + j + tt
-            // with tt a multiple of 8 -> row (j & 7), column tid + tt/8 + (j >> 3)
-            double w[16];
+            // lane window a_stage[8*tid + tt + j], j = 0..15, as two halves that swap roles every 8 samples (no
+            // moves); element i = 8*tid + j + tt sits in row (j & 7), column tid + tt/8 + (j >> 3).
+            // b[t] is the same for every lane: scalar loads from global memory, SGPR operand of the FMA.
+            double wa[8], wb[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) w[j] = s_a[j * DX_ROW + tid];
-            for (int tt = 0; tt < DX_TT; tt += 8) {
-                const int col = tid + (tt >> 3) + 1;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) w[8 + j] = s_a[j * DX_ROW + col];
-                double bt[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) bt[u] = s_b[tt + u];
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-#pragma unroll
-                    for (int m = 0; m < DX_LPT; ++m) acc[m] = __builtin_fma(w[u + m], bt[u], acc[m]);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) w[j] = w[8 + j];
+            for (int j = 0; j < 8; ++j) wa[j] = s_a[j * DX_ROW + tid];
+            const double *bs = b + T0;
+            const long long left = t_hi - T0;  // samples of b that belong to this slab from T0 on
+            const int tt_full = (int)(left < DX_TT ? (left & ~7LL) : DX_TT);
+#define DX_STEP(A, B, TT, GUARD)                                                             \
+    {                                                                                        \
+        const int col_ = tid + ((TT) >> 3) + 1;                                              \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) B[j] = s_a[j * DX_ROW + col_];         \
+        _Pragma("unroll") for (int u = 0; u < 8; ++u)                                        \
+        {                                                                                    \
+            const double bt_ = (!(GUARD) || (TT) + u < left) ? bs[(TT) + u] : 0.0;           \
+            _Pragma("unroll") for (int m = 0; m < DX_LPT; ++m)                               \
+                acc[m] = __builtin_fma((u + m) < 8 ? A[(u + m) & 7] : B[(u + m) & 7], bt_, acc[m]); \
+        }                                                                                    \
+    }
+            int tt = 0;
+            for (; tt + 8 < tt_full; tt += 16) {
+                DX_STEP(wa, wb, tt, false)
+                DX_STEP(wb, wa, tt + 8, false)
             }
+            if (tt < tt_full) {
+                DX_STEP(wa, wb, tt, false)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) wa[j] = wb[j];
+                tt += 8;
+            }
+            if (tt < DX_TT && tt < left) DX_STEP(wa, wb, tt, true)  // the slab's last, partial group of 8
+#undef DX_STEP
         }
 #pragma unroll
         for (int m = 0; m < DX_LPT; ++m) {
