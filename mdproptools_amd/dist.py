@@ -130,6 +130,63 @@ def allgather_rows(local, n_total_rows):
     return np.concatenate(blocks).reshape((int(n_total_rows),) + row_shape)
 
 
+def allgather_var(local):
+    """
+    Concatenate per-rank blocks of rows of ANY length (rank order) into the full array on every rank:
+    the block lengths are gathered first, blocks are padded to the longest one. float64 or uint64 rows.
+    """
+    local = np.ascontiguousarray(local)
+    if not is_distributed():
+        return local
+    import torch
+
+    d = _dist()
+    _, world = rank_world()
+    dev = _device_for_collectives()
+    cnt = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(cnt) for _ in range(world)]
+    d.all_gather(counts, cnt)
+    counts = [int(c.item()) for c in counts]
+    row_shape = local.shape[1:]
+    row_elems = int(np.prod(row_shape)) if row_shape else 1
+    pad = np.zeros((max(max(counts), 1), row_elems), dtype=local.dtype)
+    pad[: local.shape[0]] = local.reshape(local.shape[0], row_elems)
+    as_i64 = local.dtype == np.uint64
+    send = torch.from_numpy(pad.view(np.int64) if as_i64 else pad).to(dev)
+    recv = [torch.empty_like(send) for _ in range(world)]
+    d.all_gather(recv, send)
+    blocks = []
+    for r in range(world):
+        blk = recv[r].cpu().numpy()[: counts[r]]
+        blocks.append(blk.view(np.uint64) if as_i64 else blk)
+    return np.concatenate(blocks).reshape((sum(counts),) + row_shape)
+
+
+def shard_items(items):
+    """This rank's contiguous block of a list (e.g. the dump files of a trajectory, in frame order)."""
+    rank, world = rank_world()
+    lo, hi = frame_shard(len(items), rank, world)
+    return items[lo:hi]
+
+
+def my_files(file_pattern):
+    """This rank's contiguous share of the files matching `file_pattern` (numeric order), or None when the
+    trajectory should not be split by files (single process, or fewer files than ranks)."""
+    if not is_distributed():
+        return None
+    from . import io as mio
+
+    matches = mio._sorted_matches(str(file_pattern))
+    if len(matches) < rank_world()[1]:
+        return None
+    return shard_items(matches)
+
+
+def is_writer():
+    """Rank 0 (or a single process): the one that writes result files."""
+    return rank_world()[0] == 0
+
+
 def broadcast_array(arr, src, shape, dtype=np.float64):
     """Broadcast a float64 array from rank `src` (others pass arr=None)."""
     if not is_distributed():

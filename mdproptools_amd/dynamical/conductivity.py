@@ -93,12 +93,19 @@ class Conductivity:
 
         vel, steps = [], []
         m = q = None
+        from .. import dist as D
+
+        files = None
         if mio.USE_NATIVE_READER:
             def wanted(names):
                 return ["vx", "vy", "vz", "q"] + (["type"] if self.mass else ["mass"])
 
+            # under torch.distributed every rank parses and reduces its own share of the files; the per-frame
+            # flux vectors (3 x n_types doubles) are all-gathered below
+            files = D.my_files(f"{self.working_dir}/{self.filename}")
             frames = ((ts, planes[0:3], planes[3], planes[4]) for ts, _b, _l, _n, planes in
-                      mio.iter_native_frames(f"{self.working_dir}/{self.filename}", wanted, sort_by="id"))
+                      mio.iter_native_frames(f"{self.working_dir}/{self.filename}", wanted, sort_by="id",
+                                             files=files))
         else:
             def from_pandas():
                 for dump in self.dumps:
@@ -118,12 +125,20 @@ class Conductivity:
                 q = qcol
             vel.append(np.ascontiguousarray(v))
             steps.append(ts * constants.TIME_CONVERSION[self.units])
-        j = np.zeros((3, len(self.num_mols), max(n_expected, len(vel))))
+        flux = None
         if vel:
             flux = backend.charge_flux(np.stack(vel), m, q, seg_off, (mol_type - 1).astype(np.int32),
                                        len(self.num_mols), constants.VELOCITY_CONVERSION[self.units],
                                        constants.CHARGE_CONVERSION[self.units])
-            j[:, :, : len(vel)] = flux
+        if files is not None:
+            if flux is None:
+                raise ValueError("this rank holds no frame: use at most as many ranks as there are dump files")
+            flux = np.moveaxis(D.allgather_var(np.ascontiguousarray(np.moveaxis(flux, 2, 0))), 0, 2)
+            steps = list(D.allgather_var(np.asarray(steps, dtype=np.float64)))
+        n_frames = 0 if flux is None else flux.shape[2]
+        j = np.zeros((3, len(self.num_mols), max(n_expected, n_frames)))
+        if flux is not None:
+            j[:, :, :n_frames] = flux
         for s in steps:
             self.time.append(s * self.timestep)
         return j

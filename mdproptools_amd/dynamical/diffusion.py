@@ -25,6 +25,13 @@ from ..common.com_mols import atom_masses, molecule_layout
 from ..io import parse_lammps_dumps, parse_lammps_log  # noqa: F401  (parse_lammps_log: API parity)
 from ..utilities.log import concat_log
 
+
+def _writer():
+    """Only rank 0 writes result files under torch.distributed."""
+    from .. import dist as D
+
+    return D.is_writer()
+
 _COORDS = ["xu", "yu", "zu"]
 _DISPS = ["dx2", "dy2", "dz2"]
 
@@ -96,10 +103,15 @@ class Diffusion:
 
         if msd_type not in ("allatom", "com"):
             raise ValueError("msd_type must be 'allatom' or 'com'.")
+        from .. import dist as D
+
         times, planes = [], []
         ids = atom_mass = None
-        for step, names, cols in self._frame_columns(f"{self.outputs_dir}/{filename}", msd_type, mass,
-                                                     mio.USE_NATIVE_READER):
+        pattern = f"{self.outputs_dir}/{filename}"
+        # under torch.distributed every rank parses its own share of the files (parsing is the bottleneck);
+        # the reduced frames are all-gathered below and the rest runs replicated
+        files = D.my_files(pattern) if mio.USE_NATIVE_READER else None
+        for step, names, cols in self._frame_columns(pattern, msd_type, mass, mio.USE_NATIVE_READER, files=files):
             if ids is None:
                 ids = cols["id"]
             planes.append(np.ascontiguousarray(np.stack([cols["xu"], cols["yu"], cols["zu"]])))
@@ -111,16 +123,25 @@ class Diffusion:
                     raise ValueError("atom masses change between frames")
             times.append(step * self.timestep * constants.TIME_CONVERSION[self.units])
         times = np.asarray(times, dtype=np.float64)
+        if files is not None:
+            if not planes:
+                raise ValueError("this rank holds no frame: use at most as many ranks as there are dump files")
+            times = D.allgather_var(times)
         if msd_type == "com":
             seg = molecule_layout(num_mols, num_atoms_per_mol)
             if planes and seg[0][-1] != planes[0].shape[1]:
                 raise ValueError(f"Length of values ({int(seg[0][-1])}) does not match length "
                                  f"of index ({planes[0].shape[1]})")
             com, seg_mass, _ = backend.segment_com(np.stack(planes), atom_mass, seg[0])
+            if files is not None:
+                com = D.allgather_var(com)
             return times, com, dict(type=seg[1], mol_id=seg[2], mass=seg_mass)
-        return times, np.stack(planes), dict(id=ids)
+        r = np.stack(planes)
+        if files is not None:
+            r = D.allgather_var(r)
+        return times, r, dict(id=ids)
 
-    def _frame_columns(self, pattern, msd_type, mass, native):
+    def _frame_columns(self, pattern, msd_type, mass, native, files=None):
         """Yields (timestep, column names, {name: id-sorted float64 column}) with xu, yu, zu present
         (made from x + ix*L when they were not dumped, diffusion.py:62-81)."""
         from .. import io as mio
@@ -145,7 +166,8 @@ class Diffusion:
             return sel
 
         if native:
-            for ts, bounds, _lengths, names, planes in mio.iter_native_frames(pattern, wanted, sort_by="id"):
+            for ts, bounds, _lengths, names, planes in mio.iter_native_frames(pattern, wanted, sort_by="id",
+                                                                               files=files):
                 cols = dict(zip(wanted(names), planes))
                 if "zu" not in cols:
                     for k, axis in enumerate("xyz"):
@@ -274,14 +296,15 @@ class Diffusion:
             table[k] = [fit.slope / (2 * dimension), fit.bse / (2 * dimension), fit.rsquared]
             if save:
                 tag = diff_names[k] if diff_names else k + 1
-                with open(f"{self.diff_dir}/diff_{tag}.txt", "w") as fh:
+                with open(f"{self.diff_dir}/diff_{tag}.txt" if _writer() else os.devnull, "w") as fh:
                     fh.write(str(fit.summary()))
         index = diff_names or [k + 1 for k in range(len(names))]
         diffusion = pd.DataFrame(table, columns=["diffusion (m2/s)", "std", "R2"], index=index)
         if plot:
             self._plot_msd(msd, names, fits, index)
-        diffusion.to_csv(f"{self.diff_dir}/diffusion.csv")
-        print("Diffusion results written to a .csv file.")
+        if _writer():
+            diffusion.to_csv(f"{self.diff_dir}/diffusion.csv")
+            print("Diffusion results written to a .csv file.")
         return diffusion
 
     def _plot_msd(self, msd, names, fits, labels):

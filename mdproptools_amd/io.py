@@ -288,7 +288,7 @@ def _native_file_frames(fname, columns, sort_by, n_threads):
         nd.close()
 
 
-def iter_native_frames(file_pattern, columns, sort_by="id", n_threads=0, workers=None):
+def iter_native_frames(file_pattern, columns, sort_by="id", n_threads=0, workers=None, files=None):
     """
     Frames of every file matching `file_pattern` (same ordering rule as parse_lammps_dumps) through the
     native reader: yields (timestep, bounds [3,2], box lengths (lx,ly,lz), columns present, planes
@@ -297,7 +297,8 @@ def iter_native_frames(file_pattern, columns, sort_by="id", n_threads=0, workers
     Several files are parsed concurrently by `workers` host threads (the C calls release the GIL); the
     frames are still yielded in file order.
     """
-    files = _sorted_matches(file_pattern)
+    if files is None:  # an explicit list (a rank's share of the files) takes the place of the pattern
+        files = _sorted_matches(file_pattern)
     if workers is None:
         workers = min(len(files), max(1, (os.cpu_count() or 1) // 2), 32)
     if workers <= 1 or len(files) <= 1:

@@ -56,7 +56,7 @@ def _initialize(r_cut, bin_size, filename, partial_relations):
     else:
         num_bins = int(r_cut / bin_size)
         radii = (np.arange(num_bins) + 0.5) * bin_size
-    dumps = _load_frames(filename)
+    dumps = _load_frames(filename, shard=True)
     return dumps, num_bins, radii, len(dumps), len(partial_relations[0])
 
 
@@ -190,16 +190,54 @@ class _Frame:
                    dump.box.to_lattice().lengths)
 
 
-def _load_frames(filename):
+def _load_frames(filename, shard=False):
     """Every frame of `filename` (file or '*' pattern, numeric order). The native reader of libmdhip.so
-    produces the same doubles as the pandas-based one (tests/test_dump_reader_cpu.py), ~10x faster."""
+    produces the same doubles as the pandas-based one (tests/test_dump_reader_cpu.py), ~10x faster.
+
+    shard=True under torch.distributed (one process per GPU): a rank parses and returns only ITS share of the
+    trajectory — a contiguous block of the files when there are at least as many files as ranks, else a
+    contiguous block of the frames — so that parsing, the usual bottleneck, scales with the ranks too."""
+    from .. import dist as D
     from .. import io as mio
 
+    sharded = shard and D.is_distributed()
+    files = None
+    if sharded and (isinstance(filename, str) or hasattr(filename, "__fspath__")):
+        matches = mio._sorted_matches(str(filename))
+        if len(matches) >= D.rank_world()[1]:
+            files = D.shard_items(matches)
     if mio.USE_NATIVE_READER and (isinstance(filename, str) or hasattr(filename, "__fspath__")):
-        return [_Frame(ts, planes[0], planes[1], np.ascontiguousarray(planes[2:5]), lengths)
-                for ts, _b, lengths, _names, planes in
-                mio.iter_native_frames(str(filename), ["id", "type", "x", "y", "z"], sort_by="id")]
-    return [_Frame.from_dump(d) for d in parse_lammps_dumps(filename)]
+        frames = [_Frame(ts, planes[0], planes[1], np.ascontiguousarray(planes[2:5]), lengths)
+                  for ts, _b, lengths, _names, planes in
+                  mio.iter_native_frames(str(filename), ["id", "type", "x", "y", "z"], sort_by="id", files=files)]
+    elif files is not None:
+        frames = [_Frame.from_dump(d) for fn in files for d in parse_lammps_dumps(fn)]
+    else:
+        frames = [_Frame.from_dump(d) for d in parse_lammps_dumps(filename)]
+    if sharded and files is None:
+        frames = D.shard_items(frames)
+    return frames
+
+
+def _all_frames(per_frame_rows):
+    """Per-frame result rows of every rank in frame order (identity without torch.distributed). Ranks hold
+    contiguous blocks of the trajectory, so the concatenation in rank order is the frame order, and summing
+    the gathered rows in that order gives bit for bit what one process gets."""
+    from .. import dist as D
+
+    rows = np.stack(per_frame_rows) if len(per_frame_rows) else None
+    if not D.is_distributed():
+        return [] if rows is None else rows
+    if rows is None:
+        raise ValueError("this rank holds no frame: use at most as many ranks as there are frames")
+    return D.allgather_var(rows)
+
+
+def _is_writer():
+    """Only rank 0 writes files under torch.distributed (every rank returns the same DataFrame)."""
+    from .. import dist as D
+
+    return D.rank_world()[0] == 0
 
 
 def _batches(frames):
@@ -246,6 +284,7 @@ def calc_atomic_rdf(r_cut, bin_size, num_types, mass, partial_relations, filenam
     rdf_part_sum = np.zeros((num_relations, num_bins))
     frames = dumps
     dropped = 0
+    rows = []  # normalised g(r) of every frame this process holds: [g_full | g_part]
     for batch in _batches(frames):
         start = timer()
         labels = [(_calc_atom_type(f.ids, num_mols, num_atoms_per_mol) if altered else f.types) for f in batch]
@@ -260,15 +299,20 @@ def calc_atomic_rdf(r_cut, bin_size, num_types, mass, partial_relations, filenam
             g_full, g_part = _normalize_rdf(bin_size, rho_pairs, atom_types, partial_relations, num_relations,
                                             num_bins, part[k].astype(np.float64), full[k].astype(np.float64),
                                             f.xyz.shape[1], rho)
-            rdf_full_sum += g_full
-            rdf_part_sum += g_part
+            rows.append(np.concatenate([g_full, np.ravel(g_part)]))
             _say("Finished computing RDF for timestep", f.timestep)
         _say("Trajectory loop took:", timer() - start, "s")
+    rows = _all_frames(rows)  # every rank's frames, in frame order (identity in a single process)
+    num_files = len(rows)
+    for row in rows:
+        rdf_full_sum += row[:num_bins]
+        rdf_part_sum += row[num_bins:].reshape(num_relations, num_bins)
     if dropped:
         print(f"calc_atomic_rdf: {dropped} pair(s) fell in bin index {num_bins} (== num_bins) and were dropped")
     rdf_full_sum = rdf_full_sum / num_files
     rdf_part_sum = rdf_part_sum / num_files
-    return _save_rdf(radii, relation_matrix, path_or_buff, save_mode, rdf_part_sum, rdf_full_sum=rdf_full_sum)
+    return _save_rdf(radii, relation_matrix, path_or_buff, save_mode and _is_writer(), rdf_part_sum,
+                     rdf_full_sum=rdf_full_sum)
 
 
 def calc_atomic_cn(r_cut, bin_size, num_types, mass, partial_relations, filename, num_mols=None,
@@ -282,6 +326,7 @@ def calc_atomic_cn(r_cut, bin_size, num_types, mass, partial_relations, filename
     relation_matrix = np.asarray(partial_relations).transpose()
     cn_sum = np.zeros(num_relations)
     frames = dumps
+    rows = []
     for batch in _batches(frames):
         labels = [(_calc_atom_type(f.ids, num_mols, num_atoms_per_mol) if altered else f.types) for f in batch]
         props = [_calc_props(f.lengths, lab, lab, num_types, mass, partial_relations, altered,
@@ -290,10 +335,15 @@ def calc_atomic_cn(r_cut, bin_size, num_types, mass, partial_relations, filename
                               np.array([f.lengths for f in batch]), relation_matrix, list(r_cut),
                               per_frame=True)
         for k, f in enumerate(batch):
-            cn_sum += _normalize_cn(props[k][2], partial_relations, raw[k].astype(np.float64))
+            rows.append(np.asarray(_normalize_cn(props[k][2], partial_relations, raw[k].astype(np.float64)),
+                                   dtype=np.float64))
             _say("Finished computing CN for timestep", f.timestep)
+    rows = _all_frames(rows)
+    num_files = len(rows)
+    for row in rows:
+        cn_sum += row
     cn_sum = cn_sum / num_files
-    return _save_cn(relation_matrix, path_or_buff, cn_sum, save_mode)
+    return _save_cn(relation_matrix, path_or_buff, cn_sum, save_mode and _is_writer())
 
 
 def _same_types(batch):
@@ -328,6 +378,7 @@ def calc_molecular_rdf(r_cut, bin_size, num_types, mass, partial_relations, file
     rdf_part_sum = np.zeros((num_relations, num_bins))
     frames = dumps
     dropped = 0
+    rows = []
     for batch in _batches(frames):
         xyz, sites, seg_type = _molecular_inputs(batch, num_mols, num_atoms_per_mol, mass)
         props = [_calc_props(f.lengths, f.types, seg_type, num_types, mass, partial_relations, False)
@@ -343,12 +394,16 @@ def calc_molecular_rdf(r_cut, bin_size, num_types, mass, partial_relations, file
             _, rho_pairs, atom_types, _ = props[k]
             _, g_part = _normalize_rdf(bin_size, rho_pairs, atom_types, partial_relations, num_relations,
                                        num_bins, part[k].astype(np.float64))
-            rdf_part_sum += g_part
+            rows.append(np.ravel(g_part))
             _say("Finished computing RDF for timestep", f.timestep)
+    rows = _all_frames(rows)
+    num_files = len(rows)
+    for row in rows:
+        rdf_part_sum += row.reshape(num_relations, num_bins)
     if dropped:
         print(f"calc_molecular_rdf: {dropped} pair(s) fell in bin index {num_bins} (== num_bins) and were dropped")
     rdf_part_sum = rdf_part_sum / num_files
-    return _save_rdf(radii, relation_matrix, path_or_buff, save_mode, rdf_part_sum)
+    return _save_rdf(radii, relation_matrix, path_or_buff, save_mode and _is_writer(), rdf_part_sum)
 
 
 def _per_frame_mol_rdf(batch, sites, seg_type, relation_matrix, r_cut, bin_size, num_bins):
@@ -368,6 +423,7 @@ def calc_molecular_cn(r_cut, bin_size, num_types, mass, partial_relations, filen
     relation_matrix = np.asarray(partial_relations).transpose()
     cn_sum = np.zeros(num_relations)
     frames = dumps
+    rows = []
     for batch in _batches(frames):
         xyz, sites, seg_type = _molecular_inputs(batch, num_mols, num_atoms_per_mol, mass)
         props = [_calc_props(f.lengths, f.types, seg_type, num_types, mass, partial_relations, False)
@@ -380,10 +436,15 @@ def calc_molecular_cn(r_cut, bin_size, num_types, mass, partial_relations, filen
                                                 np.array([f.lengths]), relation_matrix, list(r_cut))[0]
                             for k, f in enumerate(batch)])
         for k, f in enumerate(batch):
-            cn_sum += _normalize_cn(props[k][2], partial_relations, raw[k].astype(np.float64))
+            rows.append(np.asarray(_normalize_cn(props[k][2], partial_relations, raw[k].astype(np.float64)),
+                                   dtype=np.float64))
             _say("Finished computing CN for timestep", f.timestep)
+    rows = _all_frames(rows)
+    num_files = len(rows)
+    for row in rows:
+        cn_sum += row
     cn_sum = cn_sum / num_files
-    return _save_cn(relation_matrix, path_or_buff, cn_sum, save_mode)
+    return _save_cn(relation_matrix, path_or_buff, cn_sum, save_mode and _is_writer())
 
 
 def calc_intermolecular_rdf(r_cut, bin_size, num_types, mass, partial_relations, filename, num_mols,
@@ -396,6 +457,7 @@ def calc_intermolecular_rdf(r_cut, bin_size, num_types, mass, partial_relations,
     relation_matrix = np.asarray(partial_relations).transpose()
     rdf_part_sum = np.zeros((num_relations, num_bins))
     frames = dumps
+    rows = []
     for batch in _batches(frames):
         _, sites, seg_type = _molecular_inputs(batch, num_mols, num_atoms_per_mol, mass)
         props = [_calc_props(f.lengths, seg_type, seg_type, num_types, mass, partial_relations, False)
@@ -406,6 +468,10 @@ def calc_intermolecular_rdf(r_cut, bin_size, num_types, mass, partial_relations,
             _, rho_pairs, atom_types, _ = props[k]
             _, g_part = _normalize_rdf(bin_size, rho_pairs, atom_types, partial_relations, num_relations,
                                        num_bins, part[k].astype(np.float64))
-            rdf_part_sum += g_part
+            rows.append(np.ravel(g_part))
+    rows = _all_frames(rows)
+    num_files = len(rows)
+    for row in rows:
+        rdf_part_sum += row.reshape(num_relations, num_bins)
     rdf_part_sum = rdf_part_sum / num_files
-    return _save_rdf(radii, relation_matrix, path_or_buff, save_mode, rdf_part_sum)
+    return _save_rdf(radii, relation_matrix, path_or_buff, save_mode and _is_writer(), rdf_part_sum)

@@ -116,3 +116,169 @@ def test_sharded_paths_world2_gloo(tmp_path):
         np.testing.assert_allclose(g["sums"], sums, rtol=1e-14)
         np.testing.assert_allclose(g["sums4"], sums4, rtol=1e-14)
     assert shards == [(0, 3), (3, 5)]
+
+
+# ------------------------------------------------------------------ drop-in functions under torch.distributed
+def _oracle_backend():
+    """The four pair loops of mdproptools_amd.backend with the C oracle behind them (CPU stand-in)."""
+    from oracle import cref
+
+    def rdf_loop(xyz, types, box, rel, r_cut, ddr, nbins, per_frame=True, ctx=None, edges=None):
+        res = [cref.rdf_pairs(xyz[f], types if np.ndim(types) == 1 else types[f], rel, box[f], float(r_cut) ** 2,
+                              ddr, nbins) for f in range(len(xyz))]
+        return (np.stack([q[0] for q in res]), np.stack([q[1] for q in res]), sum(q[2] for q in res))
+
+    def cn_loop(xyz, types, box, rel, cuts, per_frame=True, ctx=None):
+        return np.stack([cref.cn_pairs(xyz[f], types if np.ndim(types) == 1 else types[f], rel, box[f],
+                                       [float(c) ** 2 for c in cuts]) for f in range(len(xyz))])
+
+    return rdf_loop, cn_loop
+
+
+def _dropin_case(tmp_dir, n_files):
+    from mdproptools_amd import io as mio
+
+    rng = np.random.default_rng(5)
+    n = 240
+    paths = []
+    for k in range(n_files):
+        L = 13.0 + 0.1 * k
+        tbl = np.column_stack([rng.permutation(n) + 1, 1 + (np.arange(n) % 3), rng.uniform(0, L, (n, 3))])
+        p = os.path.join(tmp_dir, "dump.nvt.%d.dump" % (k * 100))
+        mio.write_dump(p, k * 100, [[0, L]] * 3, ["id", "type", "x", "y", "z"], tbl)
+        paths.append(p)
+    return os.path.join(tmp_dir, "dump.nvt.*.dump")
+
+
+def _dropin_worker(rank, world, port, tmp_dir):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    from mdproptools_amd import backend
+    from mdproptools_amd.structural import rdf_cn
+
+    backend.rdf_loop, backend.cn_loop = _oracle_backend()
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    pattern = os.path.join(tmp_dir, "dump.nvt.*.dump")
+    out = os.path.join(tmp_dir, "w%d" % world)
+    os.makedirs(out, exist_ok=True)
+    g = rdf_cn.calc_atomic_rdf(5.0, 0.1, 3, [1.0, 2.0, 3.0], [[1, 1, 2], [1, 2, 3]], pattern,
+                               path_or_buff=os.path.join(out, "rdf.csv"))
+    c = rdf_cn.calc_atomic_cn([2.0, 3.0, 4.5], 0.1, 3, [1.0, 2.0, 3.0], [[1, 1, 2], [1, 2, 3]], pattern,
+                              path_or_buff=os.path.join(out, "cn.csv"))
+    np.savez(os.path.join(out, "rank%d.npz" % rank), g=g.to_numpy(), c=c.to_numpy())
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_dropin_rdf_cn_sharded_over_files_world2_gloo(tmp_path):
+    """calc_atomic_rdf / calc_atomic_cn under torch.distributed: ranks parse their own share of the dump files,
+    per-frame g(r) rows are all-gathered and summed in frame order -> bit for bit the single-process result on
+    every rank; only rank 0 writes the CSV."""
+    import torch.multiprocessing as mp
+
+    _dropin_case(str(tmp_path), 5)
+    mp.spawn(_dropin_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    mp.spawn(_dropin_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    one = np.load(tmp_path / "w1" / "rank0.npz")
+    assert np.isfinite(one["g"]).all() and one["g"][:, 1].sum() > 0
+    for rank in range(2):
+        two = np.load(tmp_path / "w2" / ("rank%d.npz" % rank))
+        np.testing.assert_array_equal(two["g"], one["g"])
+        np.testing.assert_array_equal(two["c"], one["c"])
+    assert (tmp_path / "w2" / "rdf.csv").exists() and (tmp_path / "w2" / "cn.csv").exists()
+    assert open(tmp_path / "w2" / "rdf.csv").read() == open(tmp_path / "w1" / "rdf.csv").read()
+
+
+def _numpy_dynamical_backend():
+    """segment_com / msd_pairs / msd_windows / charge_flux of mdproptools_amd.backend as plain numpy (CPU
+    stand-ins with the same signatures; only their sharding around them is under test here)."""
+
+    def segment_com(attr, atom_mass, seg_off, atom_q=None, out=None, ctx=None):
+        off = np.asarray(seg_off[:-1], dtype=np.int64)
+        mass = np.asarray(atom_mass, dtype=np.float64)
+        seg_mass = np.add.reduceat(mass, off)
+        com = np.add.reduceat(np.asarray(attr) * mass, off, axis=2) / seg_mass
+        return com, seg_mass, None if atom_q is None else np.add.reduceat(np.asarray(atom_q), off)
+
+    def msd_pairs(r, pairs, group_off, scale=1.0, per_entity=False, ctx=None):
+        r = np.asarray(r) * scale
+        pe = np.stack([np.concatenate([(r[b] - r[a]) ** 2, ((r[b] - r[a]) ** 2).sum(axis=0)[None]]).T
+                       for a, b in np.asarray(pairs)])  # [P,E,4]
+        go = np.asarray(group_off)
+        sums = np.stack([pe[:, go[g]:go[g + 1]].sum(axis=1) for g in range(len(go) - 1)], axis=1)
+        return (sums, pe) if per_entity else sums
+
+    def msd_windows(r, tao, scale=1.0, ctx=None):
+        kept = (np.asarray(r) * scale)[::tao]
+        d2 = (kept[1:] - kept[:-1]) ** 2  # [W,3,E]
+        return np.concatenate([d2.sum(axis=0), d2.sum(axis=(0, 1))[None]]).T
+
+    def charge_flux(vel, atom_mass, atom_q, seg_off, seg_type, n_types, vel_conv, charge_conv, ctx=None):
+        com, _, q = segment_com(vel, atom_mass, seg_off, atom_q=atom_q)
+        jm = (com * vel_conv) * (q * charge_conv)  # [F,3,M]
+        return np.stack([np.stack([jm[:, k, np.asarray(seg_type) == t].sum(axis=1) for t in range(n_types)])
+                         for k in range(3)])
+
+    return segment_com, msd_pairs, msd_windows, charge_flux
+
+
+def _dynamical_worker(rank, world, port, tmp_dir):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    from mdproptools_amd import backend
+    from mdproptools_amd.dynamical.conductivity import Conductivity
+    from mdproptools_amd.dynamical.diffusion import Diffusion
+
+    backend.segment_com, backend.msd_pairs, backend.msd_windows, backend.charge_flux = _numpy_dynamical_backend()
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = os.path.join(tmp_dir, "w%d" % world)
+    os.makedirs(out, exist_ok=True)
+    d = Diffusion(timestep=1, units="real", outputs_dir=tmp_dir, diff_dir=out)
+    msd, msd_all, msd_int = d.get_msd_from_dump("dyn.*.dump", msd_type="com", num_mols=[20, 10],
+                                                num_atoms_per_mol=[3, 2], mass=[1.0, 12.0], com_drift=True,
+                                                avg_interval=True, tao_coeff=2)
+    aa, _ = d.get_msd_from_dump("dyn.*.dump", msd_type="allatom")
+    c = Conductivity("dyn.*.dump", [20, 10], [3, 2], 1000.0, mass=[1.0, 12.0], temp=300.0, timestep=1,
+                     units="real", working_dir=tmp_dir)
+    j = c.get_charge_flux()
+    np.savez(os.path.join(out, "rank%d.npz" % rank), msd=msd.to_numpy(), msd_all=msd_all.to_numpy(),
+             msd_int=msd_int.to_numpy(), aa=aa.to_numpy(), j=j, time=np.asarray(c.time))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_dropin_diffusion_conductivity_sharded_parse_world2_gloo(tmp_path):
+    """Diffusion.get_msd_from_dump and Conductivity.get_charge_flux under torch.distributed: ranks parse (and, for
+    COM / flux, reduce) their own share of the files, the reduced frames are all-gathered in frame order and the
+    rest runs replicated -> the single-process result on every rank."""
+    import torch.multiprocessing as mp
+
+    from mdproptools_amd import io as mio
+
+    rng = np.random.default_rng(8)
+    n = 20 * 3 + 10 * 2
+    x0 = rng.uniform(0, 20, (n, 3))
+    cols = ["id", "type", "q", "xu", "yu", "zu", "vx", "vy", "vz"]
+    ty = np.concatenate([np.tile([1, 2, 1], 20), np.tile([2, 2], 10)])
+    q = np.concatenate([np.tile([0.5, -1.0, 0.5], 20), np.tile([1.0, 0.0], 10)])
+    for k in range(7):
+        x0 = x0 + rng.normal(0, 0.2, (n, 3))
+        perm = rng.permutation(n)
+        tbl = np.column_stack([np.arange(1, n + 1), ty, q, x0, rng.normal(0, 1e-3, (n, 3))])[perm]
+        mio.write_dump(str(tmp_path / ("dyn.%d.dump" % (k * 50))), k * 50, [[0, 20.0]] * 3, cols, tbl)
+    mp.spawn(_dynamical_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    mp.spawn(_dynamical_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    one = np.load(tmp_path / "w1" / "rank0.npz")
+    assert one["msd"].shape[0] == 7 and one["j"].shape == (3, 2, 7) and np.abs(one["j"]).max() > 0
+    for rank in range(2):
+        two = np.load(tmp_path / "w2" / ("rank%d.npz" % rank))
+        for key in ("msd", "msd_all", "msd_int", "aa", "j", "time"):
+            np.testing.assert_array_equal(two[key], one[key], err_msg=key)
