@@ -249,3 +249,63 @@ def test_native_and_pandas_readers_give_identical_results(small_dir, tmp_path):
         np.testing.assert_array_equal(a.to_numpy(), b.to_numpy())
     # the rebuilt unwrapped coordinates differ from the dumped xu only by the 6-digit rounding of the dump text
     np.testing.assert_allclose(res[True][0].to_numpy(), g["com_msd"], rtol=1e-3)
+
+
+# ------------------------------------------------------------------ drop-in under torch.distributed, on the GPU
+def _gpu_dist_worker(rank, world, port, tmp_dir):
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0")
+    import torch.distributed as dist
+
+    from mdproptools_amd.structural import rdf_cn
+
+    if world > 1:  # two ranks share the one GPU of the test box: gloo for the (host-side) collectives
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = os.path.join(tmp_dir, "w%d" % world)
+    os.makedirs(out, exist_ok=True)
+    pattern = os.path.join(tmp_dir, "dump.nvt.*.dump")
+    g = rdf_cn.calc_atomic_rdf(6.0, 0.05, 3, [1.0, 2.0, 3.0], [[1, 1, 2], [1, 2, 3]], pattern,
+                               path_or_buff=os.path.join(out, "rdf.csv"))
+    c = rdf_cn.calc_atomic_cn([2.0, 3.0, 4.5], 0.05, 3, [1.0, 2.0, 3.0], [[1, 1, 2], [1, 2, 3]], pattern,
+                              path_or_buff=os.path.join(out, "cn.csv"))
+    np.savez(os.path.join(out, "rank%d.npz" % rank), g=g.to_numpy(), c=c.to_numpy())
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_dropin_rdf_cn_two_ranks_on_gpu(tmp_path):
+    """calc_atomic_rdf / calc_atomic_cn with two processes (gloo) sharing the GPU: each parses its own files and
+    runs its own frames through libmdhip.so; both return bit for bit the single-process DataFrames."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from mdproptools_amd import io as mio
+
+    rng = np.random.default_rng(12)
+    n = 3000
+    for k in range(5):
+        L = 30.0 + 0.2 * k
+        tbl = np.column_stack([rng.permutation(n) + 1, 1 + (np.arange(n) % 3), rng.uniform(0, L, (n, 3))])
+        mio.write_dump(str(tmp_path / ("dump.nvt.%d.dump" % (k * 100))), k * 100, [[0, L]] * 3,
+                       ["id", "type", "x", "y", "z"], tbl)
+
+    def port():
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            return s.getsockname()[1]
+
+    mp.spawn(_gpu_dist_worker, args=(1, port(), str(tmp_path)), nprocs=1, join=True)
+    mp.spawn(_gpu_dist_worker, args=(2, port(), str(tmp_path)), nprocs=2, join=True)
+    one = np.load(tmp_path / "w1" / "rank0.npz")
+    assert abs(one["g"][60:, 1].mean() - 1.0) < 0.05  # ideal gas
+    for rank in range(2):
+        two = np.load(tmp_path / "w2" / ("rank%d.npz" % rank))
+        np.testing.assert_array_equal(two["g"], one["g"])
+        np.testing.assert_array_equal(two["c"], one["c"])
+    assert open(tmp_path / "w2" / "rdf.csv").read() == open(tmp_path / "w1" / "rdf.csv").read()
