@@ -1,0 +1,92 @@
+#!/usr/bin/env python
+"""
+tools/bench_e2e.py — end-to-end wall time of the drop-in API on TEXT dumps (what a user of the reference runs),
+BASELINE C2 shape by default: 200 dump files x 10 000 atoms, calc_atomic_rdf with 10 relations + calc_atomic_cn.
+
+    python tools/bench_e2e.py [n_atoms] [n_frames]
+
+Reports, as one JSON line: time to write the synthetic dumps (not part of any figure), the drop-in calls with the
+native reader (default) and with the pandas text route the reference takes (pymatgen's parser is pandas.read_csv
+per frame), the library's kernel time inside them, and — for the reference's compute side — the C oracle on a
+bounded sample of frames extrapolated linearly. The reference's own end-to-end time is text route + CPU loop.
+"""
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000
+    F = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+    from mdproptools_amd import io as mio
+    from mdproptools_amd import synth
+    from mdproptools_amd._lib import default_context
+    from mdproptools_amd.structural import rdf_cn
+    from oracle import cref
+
+    L = 50.0 * (n / 10_000) ** (1 / 3)
+    rel = [[a for a, b in synth.ALL_PAIRS_4], [b for a, b in synth.ALL_PAIRS_4]]
+    mass = [1.0, 2.0, 3.0, 4.0]
+    ty = synth.rdf_types(n)
+    with tempfile.TemporaryDirectory() as tmp:
+        t0 = time.perf_counter()
+        xyz = synth.rdf_frames(n, range(F), L, 2)
+        for f in range(F):
+            with open(os.path.join(tmp, "dump.nvt.%d.dump" % (f * 1000)), "wt") as fh:
+                fh.write("ITEM: TIMESTEP\n%d\nITEM: NUMBER OF ATOMS\n%d\nITEM: BOX BOUNDS pp pp pp\n" % (f * 1000, n))
+                fh.write(("0.0 %r\n" % L) * 3)
+                fh.write("ITEM: ATOMS id type x y z\n")
+                tbl = np.column_stack([np.arange(1, n + 1), ty, xyz[f].T])
+                np.savetxt(fh, tbl, fmt="%d %d %.6f %.6f %.6f")
+        t_write = time.perf_counter() - t0
+        pattern = os.path.join(tmp, "dump.nvt.*.dump")
+        ctx = default_context(0)
+        rdf_cn.calc_atomic_rdf(20.0, 0.05, 4, mass, rel, os.path.join(tmp, "dump.nvt.0.dump"), save_mode=False)  # warm-up
+
+        def run(native):
+            mio.USE_NATIVE_READER = native
+            t0 = time.perf_counter()
+            g = rdf_cn.calc_atomic_rdf(20.0, 0.05, 4, mass, rel, pattern, path_or_buff=os.path.join(tmp, "rdf.csv"))
+            t_rdf = time.perf_counter() - t0
+            k_rdf = ctx.last_kernel_ms()[0] + ctx.last_aux_ms()
+            t0 = time.perf_counter()
+            rdf_cn.calc_atomic_cn([2.325 + 0.5 * k for k in range(10)], 0.05, 4, mass, rel, pattern,
+                                  path_or_buff=os.path.join(tmp, "cn.csv"))
+            t_cn = time.perf_counter() - t0
+            return g, t_rdf, k_rdf, t_cn
+
+        g_nat, rdf_nat, k_rdf, cn_nat = run(True)
+        g_txt, rdf_txt, _, cn_txt = run(False)
+        assert np.array_equal(g_nat.to_numpy(), g_txt.to_numpy())  # same doubles from both readers
+        mio.USE_NATIVE_READER = True
+        t0 = time.perf_counter()
+        list(mio.iter_native_frames(pattern, ["id", "type", "x", "y", "z"]))
+        parse_nat = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for d in mio.parse_lammps_dumps(pattern):
+            d.data.sort_values("id")
+        parse_txt = time.perf_counter() - t0
+        # CPU loop of the reference (C oracle, one core) on 4 frames
+        cref.build()
+        s = min(4, F)
+        t0 = time.perf_counter()
+        for f in range(s):
+            cref.rdf_pairs(xyz[f], ty, np.array(synth.ALL_PAIRS_4), [L] * 3, 400.0, 0.05, 400)
+        cpu_loop = (time.perf_counter() - t0) / s * F
+    print(json.dumps(dict(
+        workload="%d dump files x %d atoms (id type x y z), L = %.1f A, calc_atomic_rdf (10 relations, r_cut 20, 400 bins)"
+                 " + calc_atomic_cn" % (F, n, L),
+        dropin_rdf_s=rdf_nat, dropin_cn_s=cn_nat, of_which_gpu_kernels_s=k_rdf * 1e-3, parse_native_s=parse_nat,
+        dropin_rdf_with_text_reader_s=rdf_txt, parse_text_reader_s=parse_txt,
+        reference_cpu_loop_extrapolated_s=cpu_loop, reference_end_to_end_estimate_s=parse_txt + cpu_loop,
+        end_to_end_speedup=(parse_txt + cpu_loop) / rdf_nat, host_cores=os.cpu_count(), synth_write_s=t_write)))
+
+
+if __name__ == "__main__":
+    main()
