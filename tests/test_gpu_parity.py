@@ -513,6 +513,36 @@ def test_culled_path_wrap_variants(B, case):
         ctx.close()
 
 
+@pytest.mark.parametrize("n_types,nbins,bin_size", [(1, 60, 0.1), (2, 1500, 0.004), (5, 120, 0.05), (7, 400, 0.015)])
+def test_ordered_rows_and_class_rows_agree(B, n_types, nbins, bin_size):
+    """Scalar-j kernel: ordered-pair rows addressed through the bin guess (few types) and class rows with the
+    row table (the fallback when T^2 rows do not fit LDS) against the C oracle; relations cover a == b, a != b,
+    a repeated pair and a type pair nobody asks for; many narrow bins stress the guard band."""
+    from mdproptools_amd._lib import Context
+
+    rng = np.random.default_rng(100 + n_types)
+    n, L = 2600, np.array([31.0, 29.0, 33.0])
+    xyz = (rng.uniform(0, 1, (2, 3, n)) * L[None, :, None])
+    ty = rng.integers(1, n_types + 1, n).astype(np.int32)
+    rel = np.array([[1, 1], [1, n_types], [n_types, 1], [max(1, n_types - 1), n_types]])
+    r_cut = nbins * bin_size
+    box = np.tile(L, (2, 1))
+    want = [C.rdf_pairs(xyz[f], ty, rel, L, r_cut * r_cut, bin_size, nbins) for f in range(2)]
+    for rows in (0, 1):
+        ctx = Context(0)
+        ctx.set_option("rdf_cull", 1)
+        ctx.set_option("rdf_rows", rows)
+        full, part, ov = B.rdf_loop(xyz, ty, box, rel, r_cut, bin_size, nbins, ctx=ctx)
+        for f in range(2):
+            np.testing.assert_array_equal(full[f], want[f][0], err_msg="rows=%d" % rows)
+            np.testing.assert_array_equal(part[f], want[f][1], err_msg="rows=%d" % rows)
+        assert ov == want[0][2] + want[1][2]
+        fs, ps, _ = B.rdf_loop(xyz, ty, box, rel, r_cut, bin_size, nbins, per_frame=False, ctx=ctx)
+        np.testing.assert_array_equal(fs, full.sum(axis=0))
+        np.testing.assert_array_equal(ps, part.sum(axis=0))
+        ctx.close()
+
+
 def test_culled_path_large_box_auto(B):
     """BASELINE C3 geometry at reduced N (same density: L = 48.3 A for 10k atoms, r_cut 6.8): the
     automatic choice takes the culled path; result against the C oracle."""
