@@ -39,6 +39,10 @@ enum WsSlot {
     WS_SORT_AOS,   // sorted atoms as (x, y, z, row-table offset) records, padded to whole tiles
     WS_ORIGIN,     // per-frame grid origin of the spatial sort
     WS_WORK,       // per-frame work counters of the scalar-j kernel
+    WS_SORT_AOS_J, // culled atoms x sites: sorted records and boxes of the site set
+    WS_BBOX_J,
+    WS_GSPH_J,
+    WS_WSPH_J,
     WS_SLICES,     // per-block histogram copies of the scalar-j kernel
     WS_ROWS,       // their sums per output frame
     WS_COUNT

@@ -73,6 +73,8 @@ struct PairArgs {
                                  // (frame-summed output) or [F] per frame (per-frame output)
     float near;                  // MODE 2: guard band half-width (also folded into the records' row offsets)
     unsigned *slices;            // scalar-j kernels: [blocks][LDS histogram words], every block stores its own copy
+    const double4 *aos_j;        // sorted records of the j set (== aos for atom-atom), [F][nTj*256]
+    int tri;                     // 1: atom-atom (i < j inside the diagonal tile), 0: atoms x sites
 };
 
 __device__ __forceinline__ double wrap_abs(double d, double L)
@@ -882,7 +884,10 @@ __device__ __forceinline__ double interval_gap(double a0, double a1, double b0, 
 }
 
 // list[f][I][*] = half-shell tiles J whose boxes come within the cutoff of tile I's box; cnt[f][I]
+// TRI: atom-atom, half-shell candidates of the one tile set. !TRI: every tile of the j set (bbox_j, nTj tiles).
+template <bool TRI>
 __global__ __launch_bounds__(256) void cull_list_kernel(const double *__restrict__ bbox,
+                                                        const double *__restrict__ bbox_j, int nTj,
                                                         const double *__restrict__ box, int nT, double rc2_test,
                                                         unsigned short *__restrict__ list, int *__restrict__ cnt)
 {
@@ -895,14 +900,14 @@ __global__ __launch_bounds__(256) void cull_list_kernel(const double *__restrict
     // slack for the roundings of the box arithmetic (the pair kernel decides every listed pair exactly)
     const double sl = 1e-12 * (__builtin_fabs(bi[0]) + __builtin_fabs(bi[3]) + __builtin_fabs(bi[1]) +
                                __builtin_fabs(bi[4]) + __builtin_fabs(bi[2]) + __builtin_fabs(bi[5]) + Lx + Ly + Lz);
-    unsigned short *row = list + ((size_t)f * nT + I) * nT;
-    // candidates = the half shell J = I, I+1, ..., I+S-1 (mod nT): every unordered tile pair belongs to
+    unsigned short *row = list + ((size_t)f * nT + I) * (TRI ? nT : nTj);
+    // TRI candidates = the half shell J = I, I+1, ..., I+S-1 (mod nT): every unordered tile pair belongs to
     // exactly one row and all rows have about the same length (a plain J >= I scan would be triangular)
-    const int S = tri_shifts(nT, I);
+    const int S = TRI ? tri_shifts(nT, I) : nTj;
     for (int sft = threadIdx.x; sft < S; sft += 256) {
-        int J = I + sft;
-        J = J >= nT ? J - nT : J;
-        const double *bj = bbox + ((size_t)f * nT + J) * 6;
+        int J = TRI ? I + sft : sft;
+        if (TRI) J = J >= nT ? J - nT : J;
+        const double *bj = (TRI ? bbox : bbox_j) + ((size_t)f * (TRI ? nT : nTj) + J) * 6;
         double gx = interval_gap(bi[0], bi[3], bj[0], bj[3], Lx) - sl;
         double gy = interval_gap(bi[1], bi[4], bj[1], bj[4], Ly) - sl;
         double gz = interval_gap(bi[2], bi[5], bj[2], bj[5], Lz) - sl;
@@ -1052,10 +1057,10 @@ template <int MODE>
 __device__ __forceinline__ void sj_item(const PairArgs &a, FastCtx &c, const unsigned *s_row, int f, int I, int wq,
                                         int split, int lane)
 {
-    const long long n_pad = (long long)a.nTi * TILE;
+    const long long n_pad = (long long)a.nTi * TILE, n_pad_j = (long long)a.nTj * TILE;
     const long long rowid = (long long)f * a.nTi + I;
     const int cnt = a.list_cnt[rowid];
-    const unsigned short *row_list = a.list + rowid * a.nTi;
+    const unsigned short *row_list = a.list + rowid * a.nTj;  // (nTj == nTi for atom-atom)
     const int t_begin = (int)((long long)split * cnt / a.jsplit);
     const int t_end = (int)((long long)(split + 1) * cnt / a.jsplit);
     if (t_begin >= t_end) return;
@@ -1076,7 +1081,8 @@ __device__ __forceinline__ void sj_item(const PairArgs &a, FastCtx &c, const uns
     }
     const long long w = ((long long)f * a.nTi + I) * (TILE / 64) + wq;
     const float4 wlo = a.wsph[2 * w], whi = a.wsph[2 * w + 1];
-    const float4 *gb_f = a.gsph + (long long)f * a.nTi * (TILE / 8) * 2;
+    const float4 *gb_f = a.gsph + (long long)f * a.nTj * (TILE / 8) * 2;  // group boxes of the j set
+    const double4 *ats_j = a.aos_j + (long long)f * n_pad_j;
     const float fLx = (float)L.Lx, fLy = (float)L.Ly, fLz = (float)L.Lz;
     for (int t = t_begin; t < t_end; ++t) {
         const int J = __builtin_amdgcn_readfirstlane((int)row_list[t]);
@@ -1087,8 +1093,8 @@ __device__ __forceinline__ void sj_item(const PairArgs &a, FastCtx &c, const uns
         const float gy = gapf(wlo.y, whi.y, glo.y, ghi.y, fLy);
         const float gz = gapf(wlo.z, whi.z, glo.z, ghi.z, fLz);
         const bool keep = wlo.w > 0.f && glo.w > 0.f && gx * gx + gy * gy + gz * gz < a.reach * a.reach;
-        const double4 *tile = ats + (long long)J * TILE;
-        if (J == I) {
+        const double4 *tile = ats_j + (long long)J * TILE;
+        if (a.tri && J == I) {
             unsigned mask = (unsigned)__builtin_amdgcn_ballot_w64(keep);
             while (mask) {
                 const int g = __builtin_ctz(mask);
@@ -1304,6 +1310,63 @@ size_t lds_bytes(int nbins, int n_cls, int n_ti, int n_tj)
     return (off + 15) & ~size_t(15);
 }
 
+// Spatial sort + bounding boxes of ONE atom set of a batch of frames (culled path): Hilbert-sorted records
+// `aos` [F][nT*256], tile boxes `bbox` [F][nT][6], 8-atom and 64-atom boxes `gs` / `ws`. `slot` = workspace ids of
+// {records, tile boxes, group boxes, wave boxes}; keys, cell counters and the SoA copy are shared scratch.
+struct SortedSet {
+    const double4 *aos = nullptr;
+    const double *bbox = nullptr;
+    const float4 *gs = nullptr, *ws = nullptr;
+    const double *sx = nullptr;
+    const int *st = nullptr;
+};
+
+int cull_prepare_set(mdhip_ctx *ctx, int64_t F, const double *d_x, const int *d_t, long long t_fs,
+                     const double *d_box, long long N, int nT, int n_ti, float near, int row_len, bool want_soa,
+                     const int slot[4], SortedSet &out)
+{
+    MD_WS(d_sx, double, WS_SORT_XYZ, want_soa ? (size_t)F * 3 * N * 8 : 64);
+    MD_WS(d_st, int, WS_SORT_TYPE, want_soa ? (size_t)F * N * 4 : 64);
+    MD_WS(d_keys, unsigned short, WS_KEYS, (size_t)F * N * 2);
+    MD_WS(d_cells, unsigned, WS_CELLS, (size_t)F * MORTON_CELLS * 4);
+    MD_WS(d_ao, double4, slot[0], (size_t)F * nT * TILE * sizeof(double4));
+    MD_WS(d_bbox, double, slot[1], (size_t)F * nT * 6 * 8);
+    MD_WS(d_gs, float4, slot[2], (size_t)F * nT * (TILE / 8) * 2 * sizeof(float4));
+    MD_WS(d_ws, float4, slot[3], (size_t)F * nT * (TILE / 64) * 2 * sizeof(float4));
+    const dim3 ga((unsigned)((N + 255) / 256), (unsigned)F);
+    // one block per frame with the cell counters in LDS when there are frames enough to fill the chip (or the
+    // frames are small); the multi-block path with global counters otherwise
+    const size_t sort_lds = (size_t)MORTON_CELLS * 4 + 3 * 16 * 8;
+    const bool lds_sort = ctx->opt_rdf_sort != 0 && sort_lds + 8192 <= ctx->lds_max && N <= 262144 &&
+                          (ctx->opt_rdf_sort == 1 || F >= ctx->cu_count / 4 || N <= 16384);
+    if (lds_sort) {
+        MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(cull_sort_lds_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));
+        hipLaunchKernelGGL(cull_sort_lds_kernel, dim3((unsigned)F), dim3(SORT_THREADS), sort_lds, ctx->stream, d_x,
+                           d_t, t_fs, d_box, N, d_keys, want_soa ? d_sx : (double *)nullptr, d_st, d_ao,
+                           (long long)nT * TILE, n_ti, near, row_len);
+    } else {
+        MD_HIP(hipMemsetAsync(d_cells, 0, (size_t)F * MORTON_CELLS * 4, ctx->stream));
+        MD_WS(d_org, double, WS_ORIGIN, (size_t)F * 3 * 8);
+        hipLaunchKernelGGL(cull_origin_kernel, dim3((unsigned)F), dim3(256), 0, ctx->stream, d_x, N, d_org);
+        hipLaunchKernelGGL(cull_keys_kernel, ga, dim3(256), 0, ctx->stream, d_x, d_box, N, d_org, d_keys, d_cells);
+        hipLaunchKernelGGL(cull_scan_kernel, dim3((unsigned)F), dim3(256), 0, ctx->stream, d_cells);
+        hipLaunchKernelGGL(cull_scatter_kernel, ga, dim3(256), 0, ctx->stream, d_x, d_t, t_fs, N, d_keys, d_cells,
+                           want_soa ? d_sx : (double *)nullptr, d_st, d_ao, (long long)nT * TILE, n_ti, near,
+                           row_len);
+    }
+    hipLaunchKernelGGL(cull_boxes_kernel, dim3((unsigned)nT, (unsigned)F), dim3(TILE), 0, ctx->stream, d_ao, d_box, N,
+                       nT, d_bbox, d_gs, d_ws);
+    MD_HIP(hipGetLastError());
+    out.aos = d_ao;
+    out.bbox = d_bbox;
+    out.gs = d_gs;
+    out.ws = d_ws;
+    out.sx = d_sx;
+    out.st = d_st;
+    return MDHIP_OK;
+}
+
 // Runs the kernel over one batch of frames (in several passes when the class rows do not fit LDS) and
 // returns the class histograms on the host: H [F|1][n_cls][nbins], overflow count.
 int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64_t> &H, uint64_t *overflow)
@@ -1321,11 +1384,14 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
     const bool mode_cn = !(p.gscale > 0.f);  // CN edge table: a few sorted cutoffs^2, bins found by counting
     const bool fast = ctx->opt_rdf_variant == 1 && (mode_cn ? p.nbins <= 64 : p.nbins <= 100000);
 
-    // spatial culling (atom-atom only): worth it when the cutoff sphere is a small part of the box
+    // spatial culling: worth it when the cutoff sphere is a small part of the box (atoms x sites: scalar-j
+    // kernel only)
     bool cull = false;
-    if (fast && p.tri && nTi >= 8 && nTi <= 65535 && ctx->opt_rdf_cull != 0) {
+    if (fast && nTi >= 8 && nTi <= 65535 && nTj <= 65535 && ctx->opt_rdf_cull != 0 &&
+        (p.tri || (ctx->opt_rdf_sj != 0 && nTj >= 2))) {
         const double V = p.h_box[0] * p.h_box[1] * p.h_box[2];
-        const double edge = std::cbrt((double)TILE * V / (double)p.ni);
+        const double edge = 0.5 * (std::cbrt((double)TILE * V / (double)p.ni) +
+                                   std::cbrt((double)TILE * V / (double)p.nj));
         const double reach = std::sqrt(p.rc2) + 0.8 * edge;
         const double est = 4.18879 * reach * reach * reach / V;  // share of tile pairs that survive
         cull = ctx->opt_rdf_cull == 1 || est < 1.5;  // measured: still +5 % at est = 1.08 (BASELINE C2)
@@ -1428,59 +1494,44 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
     const double4 *d_aos = nullptr;
     double prep_ms = 0.0;
     bool prep_timed = false;
+    const double4 *d_aos_j = nullptr;
     if (cull) {
         const long long N = p.ni;
-        const bool want_soa = ctx->opt_rdf_sj == 0;  // only the LDS-tile kernel reads the SoA copy
-        MD_WS(d_sx, double, WS_SORT_XYZ, want_soa ? (size_t)F * 3 * N * 8 : 64);
-        MD_WS(d_st, int, WS_SORT_TYPE, want_soa ? (size_t)F * N * 4 : 64);
-        MD_WS(d_keys, unsigned short, WS_KEYS, (size_t)F * N * 2);
-        MD_WS(d_cells, unsigned, WS_CELLS, (size_t)F * MORTON_CELLS * 4);
-        MD_WS(d_bbox, double, WS_BBOX, (size_t)F * nTi * 6 * 8);
-        MD_WS(d_l, unsigned short, WS_LIST, (size_t)F * nTi * nTi * 2);
+        const bool want_soa = ctx->opt_rdf_sj == 0;  // only the LDS-tile kernel (atom-atom) reads the SoA copy
+        MD_WS(d_l, unsigned short, WS_LIST, (size_t)F * nTi * (p.tri ? nTi : nTj) * 2);
         MD_WS(d_lc, int, WS_LISTCNT, (size_t)F * nTi * 4);
-        MD_WS(d_gs, float4, WS_GSPH, (size_t)F * nTi * (TILE / 8) * 2 * sizeof(float4));
-        MD_WS(d_ws, float4, WS_WSPH, (size_t)F * nTi * (TILE / 64) * 2 * sizeof(float4));
-        MD_WS(d_ao, double4, WS_SORT_AOS, (size_t)F * nTi * TILE * sizeof(double4));
         KernelTimer ptimer(ctx, 1, true);  // second event pair: collected after the pair kernel's sync
-        const dim3 ga((unsigned)((N + 255) / 256), (unsigned)F);
-        // one block per frame with the cell counters in LDS when there are frames enough to fill the chip (or the
-        // frames are small); the multi-block path with global counters otherwise
-        const size_t sort_lds = (size_t)MORTON_CELLS * 4 + 3 * 16 * 8;
-        const bool lds_sort = ctx->opt_rdf_sort != 0 && sort_lds + 8192 <= ctx->lds_max && N <= 262144 &&
-                              (ctx->opt_rdf_sort == 1 || F >= ctx->cu_count / 4 || N <= 16384);
-        if (lds_sort) {
-            MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(cull_sort_lds_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));
-            hipLaunchKernelGGL(cull_sort_lds_kernel, dim3((unsigned)F), dim3(SORT_THREADS), sort_lds, ctx->stream,
-                               p.d_xi, p.d_ti, (long long)p.ti_fs, p.d_box, N, d_keys,
-                               want_soa ? d_sx : (double *)nullptr, d_st, d_ao, (long long)nTi * TILE, p.n_ti,
-                               ordered ? near_ord : 0.f, ordered ? p.nbins + 1 : 0);
+        SortedSet si, sj_set;
+        const int slot_i[4] = {WS_SORT_AOS, WS_BBOX, WS_GSPH, WS_WSPH};
+        int rc = cull_prepare_set(ctx, F, p.d_xi, p.d_ti, (long long)p.ti_fs, p.d_box, N, nTi, p.n_ti,
+                                  ordered ? near_ord : 0.f, ordered ? p.nbins + 1 : 0, want_soa, slot_i, si);
+        if (rc) return rc;
+        if (p.tri) {
+            sj_set = si;
+            hipLaunchKernelGGL(cull_list_kernel<true>, dim3((unsigned)nTi, (unsigned)F), dim3(256), 0, ctx->stream,
+                               si.bbox, si.bbox, nTi, p.d_box, nTi, p.rc2 * (1.0 + 1e-9) + 1e-9, d_l, d_lc);
         } else {
-            MD_HIP(hipMemsetAsync(d_cells, 0, (size_t)F * MORTON_CELLS * 4, ctx->stream));
-            MD_WS(d_org, double, WS_ORIGIN, (size_t)F * 3 * 8);
-            hipLaunchKernelGGL(cull_origin_kernel, dim3((unsigned)F), dim3(256), 0, ctx->stream, p.d_xi, N, d_org);
-            hipLaunchKernelGGL(cull_keys_kernel, ga, dim3(256), 0, ctx->stream, p.d_xi, p.d_box, N, d_org, d_keys,
-                               d_cells);
-            hipLaunchKernelGGL(cull_scan_kernel, dim3((unsigned)F), dim3(256), 0, ctx->stream, d_cells);
-            hipLaunchKernelGGL(cull_scatter_kernel, ga, dim3(256), 0, ctx->stream, p.d_xi, p.d_ti,
-                               (long long)p.ti_fs, N, d_keys, d_cells, want_soa ? d_sx : (double *)nullptr, d_st, d_ao,
-                               (long long)nTi * TILE, p.n_ti, ordered ? near_ord : 0.f, ordered ? p.nbins + 1 : 0);
+            const int slot_j[4] = {WS_SORT_AOS_J, WS_BBOX_J, WS_GSPH_J, WS_WSPH_J};
+            rc = cull_prepare_set(ctx, F, p.d_xj, p.d_tj, (long long)p.tj_fs, p.d_box, p.nj, nTj, p.n_ti, 0.f, 0,
+                                  false, slot_j, sj_set);
+            if (rc) return rc;
+            hipLaunchKernelGGL(cull_list_kernel<false>, dim3((unsigned)nTi, (unsigned)F), dim3(256), 0, ctx->stream,
+                               si.bbox, sj_set.bbox, nTj, p.d_box, nTi, p.rc2 * (1.0 + 1e-9) + 1e-9, d_l, d_lc);
         }
-        hipLaunchKernelGGL(cull_boxes_kernel, dim3((unsigned)nTi, (unsigned)F), dim3(TILE), 0, ctx->stream,
-                           d_ao, p.d_box, N, nTi, d_bbox, d_gs, d_ws);
-        hipLaunchKernelGGL(cull_list_kernel, dim3((unsigned)nTi, (unsigned)F), dim3(256), 0, ctx->stream,
-                           d_bbox, p.d_box, nTi, p.rc2 * (1.0 + 1e-9) + 1e-9, d_l, d_lc);
         ptimer.stop();
         MD_HIP(hipGetLastError());
         prep_timed = true;
-        d_gsph = d_gs;
-        d_wsph = d_ws;
-        k_xi = k_xj = d_sx;
-        k_ti = k_tj = d_st;
-        k_ti_fs = k_tj_fs = N;
+        d_gsph = sj_set.gs;  // 8-atom boxes of the j set
+        d_wsph = si.ws;      // 64-atom boxes of the i set
+        if (want_soa) {
+            k_xi = k_xj = si.sx;
+            k_ti = k_tj = si.st;
+            k_ti_fs = k_tj_fs = N;
+        }
         d_list = d_l;
         d_list_cnt = d_lc;
-        d_aos = d_ao;
+        d_aos = si.aos;
+        d_aos_j = sj_set.aos;
     }
 
     double total_ms = 0.0;  // the pair kernel alone; the culling pre-pass is reported separately
@@ -1505,6 +1556,8 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         a.wsph = d_wsph;
         a.reach = (float)((std::sqrt(p.rc2) + 1e-3) * 1.00001);
         a.aos = d_aos;
+        a.aos_j = d_aos_j;
+        a.tri = p.tri ? 1 : 0;
         a.box = p.d_box;
         a.cls = d_tab + edges_b + (size_t)pass * cls_b;
         a.edges = reinterpret_cast<const double *>(d_tab);

@@ -543,6 +543,47 @@ def test_ordered_rows_and_class_rows_agree(B, n_types, nbins, bin_size):
         ctx.close()
 
 
+@pytest.mark.parametrize("case", ["plain", "centred_cell", "strays"])
+def test_culled_atoms_x_sites_equals_dense_and_oracle(B, case):
+    """Atoms x molecule sites (rdf_cn.py:122-162) through the spatially culled scalar-j kernel (two sorted sets,
+    rectangular tile lists) against the dense sweep and the C oracle; a site may coincide with an atom."""
+    from mdproptools_amd._lib import Context
+
+    rng = np.random.default_rng({"plain": 21, "centred_cell": 22, "strays": 23}[case])
+    F, n, m = 2, 4100, 1300
+    L = np.array([36.0, 38.0, 40.0])
+    lo = -0.5 if case == "centred_cell" else 0.0
+    xyz = (rng.uniform(lo, lo + 1, (F, 3, n)) * L[None, :, None])
+    sites = (rng.uniform(lo, lo + 1, (F, 3, m)) * L[None, :, None])
+    sites[:, :, :50] = xyz[:, :, :50]  # coincident points: rsq == 0 -> bin 0
+    if case == "strays":
+        xyz[:, :, rng.choice(n, 200, replace=False)] += (rng.integers(-2, 3, (F, 3, 200)) * L[None, :, None])
+        sites[:, :, rng.choice(m, 80, replace=False)] -= (rng.integers(-2, 3, (F, 3, 80)) * L[None, :, None])
+    ty = rng.integers(1, 5, n).astype(np.int32)
+    st = rng.integers(1, 4, m).astype(np.int32)
+    rel = np.array([[1, 1], [2, 3], [4, 2], [1, 1], [3, 3]])
+    cuts = [3.0, 5.0, 6.5, 2.0, 4.0]
+    box = np.tile(L, (F, 1))
+    want = [C.rdf_rect(xyz[f], ty, sites[f], st, rel, L, 49.0, 0.05, 140) for f in range(F)]
+    want_cn = [C.cn_rect(xyz[f], ty, sites[f], st, rel, L, [c * c for c in cuts]) for f in range(F)]
+    for cull, sort in ((0, -1), (1, 0), (1, 1)):
+        ctx = Context(0)
+        ctx.set_option("rdf_cull", cull)
+        ctx.set_option("rdf_sort", sort)
+        part, ov = B.rdf_mol_loop(xyz, ty, sites, st, box, rel, 7.0, 0.05, 140, ctx=ctx)
+        for f in range(F):
+            np.testing.assert_array_equal(part[f], want[f][0], err_msg="%s cull=%d" % (case, cull))
+        assert ov == sum(w[1] for w in want)
+        ps, _ = B.rdf_mol_loop(xyz, ty, sites, st, box, rel, 7.0, 0.05, 140, per_frame=False, ctx=ctx)
+        np.testing.assert_array_equal(ps, part.sum(axis=0))
+        cn = B.cn_mol_loop(xyz, ty, sites, st, box, rel, cuts, ctx=ctx)
+        for f in range(F):
+            np.testing.assert_array_equal(cn[f], want_cn[f])
+        if cull:
+            assert "sj_kernel" in ctx.last_kernel_name()
+        ctx.close()
+
+
 def test_culled_path_large_box_auto(B):
     """BASELINE C3 geometry at reduced N (same density: L = 48.3 A for 10k atoms, r_cut 6.8): the
     automatic choice takes the culled path; result against the C oracle."""

@@ -35,7 +35,7 @@ def main():
 
     ctx = default_context(0)
     dev = torch.device("cuda", 0)
-    which = sys.argv[1:] or ["rdf_c3", "cn_c3", "msd", "lag", "xcorr", "scan", "com"]
+    which = sys.argv[1:] or ["rdf_c3", "cn_c3", "rect", "msd", "lag", "xcorr", "scan", "com"]
     out = []
 
     if "rdf_c3" in which or "cn_c3" in which:
@@ -56,6 +56,27 @@ def main():
             out.append(dict(path="cn C3 (per-relation cutoffs 2.3-6.8 A)", call_ms=call, kernel_ms=k,
                             pairs_per_s=pairs / (k * 1e-3), fp64_frac=pairs * 18 / (k * 1e-3) / 39.3e12))
         del xyz
+
+    if "rect" in which:
+        from mdproptools_amd._lib import Context
+
+        n, m, L, F = 100_000, 10_000, 104.0, 16  # C3 geometry with 10-atom molecules
+        rng = np.random.default_rng(7)
+        xyz = torch.from_numpy(rng.random((F, 3, n)) * L).to(dev)
+        sites = torch.from_numpy(rng.random((F, 3, m)) * L).to(dev)
+        ty = synth.rdf_types(n)
+        st = (1 + np.arange(m) % 3).astype(np.int32)
+        rel = np.array([[a, b] for a in range(1, 5) for b in range(1, 4)])
+        box = np.full((F, 3), L)
+        for cull, tag in ((0, "dense"), (-1, "culled")):
+            c2 = Context(0)
+            c2.set_option("rdf_cull", cull)
+            call, k = timed(lambda: B.rdf_mol_loop(xyz, ty, sites, st, box, rel, 20.0, 0.05, 400, per_frame=False,
+                                                   ctx=c2), c2)
+            out.append(dict(path="rdf atoms x sites, %s (100k atoms x 10k sites, 16 frames, 12 relations)" % tag,
+                            call_ms=call, kernel_ms=k, pairs_per_s=F * n * m / (k * 1e-3), kernel=c2.last_kernel_name()))
+            c2.close()
+        del xyz, sites
 
     if "msd" in which or "lag" in which:
         E, F = 50_000, 1000  # C4 entities, 1000 of its 5000 frames
