@@ -56,6 +56,31 @@ def cpu_baseline(cfg, types, rel, n_sample_frames):
     }
 
 
+def cpu_baseline_all_cores(cfg, types, rel):
+    """The same loop frame-parallel over every host core (frames are independent; the reference itself only does
+    this in get_charge_flux, conductivity.py:190): one frame per core on a thread pool — the ctypes call into
+    oracle/cpu_ref.c releases the GIL — wall time of the whole pool."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import cref
+    from mdproptools_amd import synth
+
+    cores = min(os.cpu_count() or 1, 64)  # bounded sample: 64 threads, one frame each
+    n, L = cfg["n_atoms"], cfg["box_len"]
+    frames = synth.rdf_frames(n, range(cores), L, cfg["seed_offset"])
+
+    def one(f):
+        cref.rdf_pairs(frames[f], types, rel, [L] * 3, cfg["r_cut"] ** 2, cfg["bin_size"], 400)
+
+    with ThreadPoolExecutor(max_workers=cores) as pool:
+        t0 = time.perf_counter()
+        list(pool.map(one, range(cores)))
+        wall = time.perf_counter() - t0
+    return {"value": cores * (n * (n - 1) // 2) / wall, "unit": "atom-pairs/s", "cores": cores, "kind": "port",
+            "sample": "%d frames on %d threads (one each, around the C oracle; host reports %d cores), %.1f s wall"
+                      % (cores, cores, os.cpu_count() or 0, wall)}
+
+
 def msd_leg(B, torch, device, steps):
     """Single-origin MSD (diffusion.py:212-218) on a resident random walk: frame-pairs/s and HBM GB/s."""
     from mdproptools_amd import synth
@@ -208,6 +233,10 @@ def main():
             out["msd"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, types, rel, args.cpu_frames)
+            try:
+                out["cpu_baseline"]["all_cores"] = cpu_baseline_all_cores(cfg, types, rel)
+            except Exception as e:  # informative only
+                out["cpu_baseline"]["all_cores"] = {"error": repr(e)}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
