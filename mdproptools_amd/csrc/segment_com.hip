@@ -25,10 +25,12 @@ namespace {
 struct SegBlock {
     long long s0, s1;  // segments [s0, s1)
 };
-constexpr int SC_CAP = 2048;
+constexpr int SC_CAP = 1024;   // atoms per block stage
+constexpr int SC_PLANES = 3;   // attribute planes staged together (x, y, z): one barrier pair per frame
 // LDS index with one pad double per 32: lanes whose segments start 4, 8, 16, ... atoms apart would otherwise
 // all hit the same banks
 __device__ __forceinline__ int sc_pad(int i) { return i + (i >> 5); }
+constexpr int SC_STRIDE = SC_CAP + SC_CAP / 32 + 2;
 
 // FLUX = false: out[f][k][s] = sum(m a) / sum(m)                                   (com_mols.py:58-60)
 // FLUX = true : out[f][k][s] = (sum(m v) / sum(m) * vel_conv) * (sum(q) * charge_conv)   (_conductivity.py:21-25)
@@ -38,7 +40,7 @@ __global__ __launch_bounds__(256) void segment_staged_kernel(
     const long long *__restrict__ seg_off, const SegBlock *__restrict__ blocks, double *__restrict__ out,
     int n_attr, long long n_atoms, long long n_seg, long long n_frames, double vel_conv, double charge_conv)
 {
-    __shared__ double s_v[SC_CAP + SC_CAP / 32 + 2];
+    __shared__ double s_v[SC_PLANES * SC_STRIDE];
     __shared__ double s_m[SC_CAP];
     const int tid = threadIdx.x;
     const SegBlock b = blocks[blockIdx.x];
@@ -62,19 +64,50 @@ __global__ __launch_bounds__(256) void segment_staged_kernel(
             q_si = qsum * charge_conv;  // _conductivity.py:25
         }
     }
-    for (long long f = blockIdx.y; f < n_frames; f += gridDim.y) {
-        for (int k = 0; k < n_attr; ++k) {
-            const double *p = attr + ((size_t)f * n_attr + k) * n_atoms + a0;
-            __syncthreads();  // the previous plane has been consumed
-            for (int i = tid; i < na; i += 256) s_v[sc_pad(i)] = p[i] * s_m[i];
-            __syncthreads();
-            if (has) {
-                double acc = 0.0;
-                for (int a = lo; a < hi; ++a) acc += s_v[sc_pad(a)];
-                double r = acc / msum;
-                if (FLUX) r = (r * vel_conv) * q_si;  // com_mols.py:60 then _conductivity.py:21-23
-                out[((size_t)f * n_attr + k) * n_seg + s] = r;
+    // Software pipeline over (frame, plane group) steps: the values of step n+1 are loaded into registers while
+    // the segment sums of step n run out of LDS, so that HBM requests are in flight all the time.
+    constexpr int PER = SC_CAP / 256;  // atoms per lane per plane
+    const int groups = (n_attr + SC_PLANES - 1) / SC_PLANES;
+    const long long n_my = blockIdx.y < n_frames ? (n_frames - blockIdx.y + gridDim.y - 1) / gridDim.y : 0;
+    const long long steps = n_my * groups;
+    double v[SC_PLANES][PER];
+    auto fetch = [&](long long step) {
+        const long long f = blockIdx.y + (step / groups) * gridDim.y;
+        const int k0 = (int)(step % groups) * SC_PLANES;
+        const double *p = attr + ((size_t)f * n_attr + k0) * n_atoms + a0;
+#pragma unroll
+        for (int kk = 0; kk < SC_PLANES; ++kk)
+#pragma unroll
+            for (int r = 0; r < PER; ++r) {
+                const int i = tid + r * 256;
+                v[kk][r] = (k0 + kk < n_attr && i < na) ? p[(size_t)kk * n_atoms + i] : 0.0;
             }
+    };
+    if (steps > 0) fetch(0);
+    for (long long step = 0; step < steps; ++step) {
+        const long long f = blockIdx.y + (step / groups) * gridDim.y;
+        const int k0 = (int)(step % groups) * SC_PLANES;
+        const int nk = n_attr - k0 < SC_PLANES ? n_attr - k0 : SC_PLANES;
+        __syncthreads();  // the previous step's sums have been taken
+#pragma unroll
+        for (int kk = 0; kk < SC_PLANES; ++kk)
+#pragma unroll
+            for (int r = 0; r < PER; ++r) {
+                const int i = tid + r * 256;
+                if (i < na) s_v[kk * SC_STRIDE + sc_pad(i)] = v[kk][r] * s_m[i];
+            }
+        __syncthreads();
+        if (step + 1 < steps) fetch(step + 1);
+        if (has) {
+#pragma unroll
+            for (int kk = 0; kk < SC_PLANES; ++kk)
+                if (kk < nk) {
+                    double acc = 0.0;
+                    for (int a = lo; a < hi; ++a) acc += s_v[kk * SC_STRIDE + sc_pad(a)];
+                    double r = acc / msum;
+                    if (FLUX) r = (r * vel_conv) * q_si;  // com_mols.py:60 then _conductivity.py:21-23
+                    out[((size_t)f * n_attr + k0 + kk) * n_seg + s] = r;
+                }
         }
     }
 }
