@@ -934,7 +934,7 @@ __global__ __launch_bounds__(256) void cull_list_kernel(const double *__restrict
 //   dlo >= -L/2 + m and dhi <= L/2 - m : no pair wraps            -> d' = d            (VAR 2: all three axes)
 //   dlo >=  L/2 + m                    : every pair takes d - L   -> d' = d + s, s = -L (VAR 1: every axis is
 //   dhi <= -L/2 - m                    : every pair takes d + L   -> d' = d + s, s = +L  one of the three)
-//   otherwise                          : per-pair decision        -> min(|d|, ||d| - L|) (VAR 0)
+//   otherwise                          : per-pair decision        -> min(|d|, ||d| - L|) (that axis only)
 // d + (-L) is the reference's d - sign(d)*L operation and d + 0 is d, so the doubles entering rsq are the
 // same in all three variants; m = 1e-4 * L/2 dwarfs the f32 rounding of the (outward widened) boxes.
 // ------------------------------------------------------------------------------------------------
@@ -963,12 +963,14 @@ struct AxisL {
     double sx, sy, sz;  // wave-uniform shifts in {-L, 0, +L} (VAR 1)
 };
 
-template <int VAR>
+// VAR of sweep_group_sj: bits 0..2 = axes (x, y, z) that need the per-pair wrap decision, the other axes add
+// their wave-uniform shift; VAR = 8: no axis wraps at all.
+template <int VAR, int AXIS>
 __device__ __forceinline__ double axis_abs(double d, double L, double sft)
 {
-    if (VAR == 0) return wrap_abs(d, L);
-    if (VAR == 1) return d + sft;
-    return d;
+    if (VAR == 8) return d;
+    if (VAR & (1 << AXIS)) return wrap_abs(d, L);
+    return d + sft;
 }
 
 template <bool DIAG, int MODE, int VAR>
@@ -988,9 +990,9 @@ __device__ __forceinline__ void sweep_group_sj(const double4 *__restrict__ grp, 
             const double xj = __hiloint2double((int)rec[u][1], (int)rec[u][0]);
             const double yj = __hiloint2double((int)rec[u][3], (int)rec[u][2]);
             const double zj = __hiloint2double((int)rec[u][5], (int)rec[u][4]);
-            const double ax = axis_abs<VAR>(xi - xj, L.Lx, L.sx);
-            const double ay = axis_abs<VAR>(yi - yj, L.Ly, L.sy);
-            const double az = axis_abs<VAR>(zi - zj, L.Lz, L.sz);
+            const double ax = axis_abs<VAR, 0>(xi - xj, L.Lx, L.sx);
+            const double ay = axis_abs<VAR, 1>(yi - yj, L.Ly, L.sy);
+            const double az = axis_abs<VAR, 2>(zi - zj, L.Lz, L.sz);
             rsq[u] = (ax * ax + ay * ay) + az * az;
             if (MODE != 2) row[u] = c.rowtab_me[(int)rec[u][6]];  // low word of w = type * n_ti
         }
@@ -1099,41 +1101,49 @@ __device__ __forceinline__ void sj_item(const PairArgs &a, FastCtx &c, const uns
             while (mask) {
                 const int g = __builtin_ctz(mask);
                 mask &= mask - 1;
-                sweep_group_sj<true, MODE, 0>(tile + g * 8, g * 8, me.x, me.y, me.z, L, a.rc2, c, lane_in_tile);
+                sweep_group_sj<true, MODE, 7>(tile + g * 8, g * 8, me.x, me.y, me.z, L, a.rc2, c, lane_in_tile);
             }
             continue;
         }
         const unsigned cx = wrap_class(wlo.x, whi.x, glo.x, ghi.x, fLx);
         const unsigned cy = wrap_class(wlo.y, whi.y, glo.y, ghi.y, fLy);
         const unsigned cz = wrap_class(wlo.z, whi.z, glo.z, ghi.z, fLz);
-        const unsigned call = cx | cy | cz;
-        unsigned m0 = (unsigned)__builtin_amdgcn_ballot_w64(keep && (call & 4u));
-        unsigned m1 = (unsigned)__builtin_amdgcn_ballot_w64(keep && !(call & 4u) && call);
-        unsigned m2 = (unsigned)__builtin_amdgcn_ballot_w64(keep && !call);
-        while (m2) {
-            const int g = __builtin_ctz(m2);
-            m2 &= m2 - 1;
-            sweep_group_sj<false, MODE, 2>(tile + g * 8, g * 8, me.x, me.y, me.z, L, a.rc2, c, lane_in_tile);
+        // groups by the set of axes that still need the per-pair decision (bit k = axis k); the decided axes add
+        // their wave-uniform shift; groups where nothing wraps at all take the shortest chain
+        const unsigned amb = (cx >> 2) | ((cy >> 2) << 1) | ((cz >> 2) << 2);
+        const bool none = !(cx | cy | cz);
+        unsigned m8 = (unsigned)__builtin_amdgcn_ballot_w64(keep && none);
+        while (m8) {
+            const int g = __builtin_ctz(m8);
+            m8 &= m8 - 1;
+            sweep_group_sj<false, MODE, 8>(tile + g * 8, g * 8, me.x, me.y, me.z, L, a.rc2, c, lane_in_tile);
         }
-        if (m1) {
-            const unsigned xm = (unsigned)__builtin_amdgcn_ballot_w64(cx == 1u), xp = (unsigned)__builtin_amdgcn_ballot_w64(cx == 2u);
-            const unsigned ym = (unsigned)__builtin_amdgcn_ballot_w64(cy == 1u), yp = (unsigned)__builtin_amdgcn_ballot_w64(cy == 2u);
-            const unsigned zm = (unsigned)__builtin_amdgcn_ballot_w64(cz == 1u), zp = (unsigned)__builtin_amdgcn_ballot_w64(cz == 2u);
-            while (m1) {
-                const int g = __builtin_ctz(m1);
-                m1 &= m1 - 1;
-                AxisL S = L;
-                S.sx = ((xm >> g) & 1u) ? -L.Lx : ((xp >> g) & 1u) ? L.Lx : 0.0;
-                S.sy = ((ym >> g) & 1u) ? -L.Ly : ((yp >> g) & 1u) ? L.Ly : 0.0;
-                S.sz = ((zm >> g) & 1u) ? -L.Lz : ((zp >> g) & 1u) ? L.Lz : 0.0;
-                sweep_group_sj<false, MODE, 1>(tile + g * 8, g * 8, me.x, me.y, me.z, S, a.rc2, c, lane_in_tile);
-            }
-        }
-        while (m0) {
-            const int g = __builtin_ctz(m0);
-            m0 &= m0 - 1;
-            sweep_group_sj<false, MODE, 0>(tile + g * 8, g * 8, me.x, me.y, me.z, L, a.rc2, c, lane_in_tile);
-        }
+        if (!__builtin_amdgcn_ballot_w64(keep && !none)) continue;
+        const unsigned xm = (unsigned)__builtin_amdgcn_ballot_w64(cx == 1u), xp = (unsigned)__builtin_amdgcn_ballot_w64(cx == 2u);
+        const unsigned ym = (unsigned)__builtin_amdgcn_ballot_w64(cy == 1u), yp = (unsigned)__builtin_amdgcn_ballot_w64(cy == 2u);
+        const unsigned zm = (unsigned)__builtin_amdgcn_ballot_w64(cz == 1u), zp = (unsigned)__builtin_amdgcn_ballot_w64(cz == 2u);
+#define SJ_VARIANT(A)                                                                                        \
+    {                                                                                                        \
+        unsigned mk = (unsigned)__builtin_amdgcn_ballot_w64(keep && !none && amb == (A));                    \
+        while (mk) {                                                                                         \
+            const int g = __builtin_ctz(mk);                                                                 \
+            mk &= mk - 1;                                                                                    \
+            AxisL S = L;                                                                                     \
+            S.sx = ((xm >> g) & 1u) ? -L.Lx : ((xp >> g) & 1u) ? L.Lx : 0.0;                                 \
+            S.sy = ((ym >> g) & 1u) ? -L.Ly : ((yp >> g) & 1u) ? L.Ly : 0.0;                                 \
+            S.sz = ((zm >> g) & 1u) ? -L.Lz : ((zp >> g) & 1u) ? L.Lz : 0.0;                                 \
+            sweep_group_sj<false, MODE, (A)>(tile + g * 8, g * 8, me.x, me.y, me.z, S, a.rc2, c, lane_in_tile); \
+        }                                                                                                    \
+    }
+        SJ_VARIANT(0)
+        SJ_VARIANT(1)
+        SJ_VARIANT(2)
+        SJ_VARIANT(3)
+        SJ_VARIANT(4)
+        SJ_VARIANT(5)
+        SJ_VARIANT(6)
+        SJ_VARIANT(7)
+#undef SJ_VARIANT
     }
 }
 
