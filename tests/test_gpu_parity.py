@@ -584,6 +584,50 @@ def test_culled_atoms_x_sites_equals_dense_and_oracle(B, case):
         ctx.close()
 
 
+def test_culled_path_randomised_against_dense(B):
+    """40 random geometries (triclinic-free boxes of random aspect, cell origins anywhere, cutoffs from 5 % to
+    49 % of the shortest edge, clustered and uniform atoms, a few strays): the culled scalar-j sweep with its
+    hoisted wrap decisions must give the dense sweep's integers (the dense sweep itself is pinned to the oracle
+    by the tests above)."""
+    from mdproptools_amd._lib import Context
+
+    rng = np.random.default_rng(20250328)
+    dense, culled = Context(0), Context(0)
+    dense.set_option("rdf_cull", 0)
+    culled.set_option("rdf_cull", 1)
+    for trial in range(40):
+        n = int(rng.integers(2100, 5200))
+        L = rng.uniform(18.0, 60.0, 3)
+        lo = rng.uniform(-1.0, 1.0, 3) * L
+        F = int(rng.integers(1, 4))
+        if trial % 3 == 0:  # clustered: blobs around a few centres, wrapped into the cell
+            centres = rng.uniform(0, 1, (6, 3))
+            frac = (centres[rng.integers(0, 6, n)] + rng.normal(0, 0.08, (n, 3))) % 1.0
+            xyz = np.stack([(frac.T * L[:, None] + lo[:, None])] * F) + rng.normal(0, 0.05, (F, 3, n))
+        else:
+            xyz = rng.uniform(0, 1, (F, 3, n)) * L[None, :, None] + lo[None, :, None]
+        if trial % 4 == 1:
+            idx = rng.choice(n, 30, replace=False)
+            xyz[:, :, idx] += rng.integers(-2, 3, (F, 3, 30)) * L[None, :, None]
+        r_cut = float(rng.uniform(0.05, 0.49) * L.min())
+        nbins = int(r_cut / 0.05)
+        n_types = int(rng.integers(1, 6))
+        ty = rng.integers(1, n_types + 1, n).astype(np.int32)
+        rel = np.array([[1, 1], [1, n_types], [n_types, n_types]])
+        box = np.tile(L, (F, 1))
+        a = B.rdf_loop(xyz, ty, box, rel, r_cut, 0.05, nbins, ctx=dense)
+        b = B.rdf_loop(xyz, ty, box, rel, r_cut, 0.05, nbins, ctx=culled)
+        msg = "trial %d n=%d L=%s lo=%s r_cut=%.3f" % (trial, n, L, lo, r_cut)
+        np.testing.assert_array_equal(a[0], b[0], err_msg=msg)
+        np.testing.assert_array_equal(a[1], b[1], err_msg=msg)
+        assert a[2] == b[2], msg
+        cuts = [0.3 * r_cut, 0.6 * r_cut, r_cut]
+        np.testing.assert_array_equal(B.cn_loop(xyz, ty, box, rel, cuts, ctx=dense),
+                                      B.cn_loop(xyz, ty, box, rel, cuts, ctx=culled), err_msg=msg)
+    dense.close()
+    culled.close()
+
+
 def test_culled_path_large_box_auto(B):
     """BASELINE C3 geometry at reduced N (same density: L = 48.3 A for 10k atoms, r_cut 6.8): the
     automatic choice takes the culled path; result against the C oracle."""
