@@ -76,3 +76,31 @@ def test_product_never_imports_oracle():
                 hits = re.findall(r"^\s*(?:from|import)\s+oracle\b|__import__\([\"']oracle|import_module\([\"']oracle",
                                   src, flags=re.M)
                 assert not hits, (os.path.join(root, f), hits)
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/mdhip.h is the drop-in boundary: it must compile as C99 (no C++-isms, no torch / HIP types) and
+    link against libmdhip.so from a C program."""
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None:
+        pytest.skip("needs gcc")
+    src = tmp_path / "use_mdhip.c"
+    src.write_text(
+        '#include "mdhip.h"\n#include <stdio.h>\n'
+        "int main(void) {\n"
+        "  double e[5];\n"
+        "  if (mdhip_version() <= 0) return 1;\n"
+        "  if (mdhip_bin_edges(0.05, 4, e) != MDHIP_OK || e[0] != 0.0) return 2;\n"
+        '  printf("%d %.17g\\n", mdhip_version(), e[4]);\n'
+        "  return 0;\n}\n")
+    exe = tmp_path / "use_mdhip"
+    lib_dir = os.path.join(REPO, "mdproptools_amd")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(REPO, "include"),
+                        str(src), "-L", lib_dir, "-l:libmdhip.so", "-Wl,-rpath," + lib_dir, "-o", str(exe)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    run = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert run.returncode == 0, (run.stdout, run.stderr)
+    assert float(run.stdout.split()[1]) > 0.039  # edges[4] ~ (4 * 0.05)^2
