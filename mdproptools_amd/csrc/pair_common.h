@@ -1,0 +1,152 @@
+// pair_common.h — types, constants and small device helpers shared by the pair-histogram translation units
+// (pair_dense.hip: LDS-tile kernels; pair_cull.hip: spatial sort, boxes, tile lists; pair_sj.hip: scalar-j
+// kernel; pair_hist.hip: host orchestration and the C-ABI). See pair_hist.hip for the formulation.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <vector>
+
+#include "ctx.h"
+
+namespace mdpair {
+
+constexpr int TILE = 256;
+constexpr double PAD_I = -1.0e300;  // padding atoms: rsq overflows to +inf, never in cutoff, never NaN
+constexpr double PAD_J = 1.0e300;
+
+struct __attribute__((aligned(16))) JAtom {
+    double x, y, z;
+    int t;
+    int pad;
+};
+
+struct PairArgs {
+    const double *xi;  // [F][3][ni]
+    const double *xj;  // [F][3][nj]
+    const int *ti;     // compact type index of i atoms
+    const int *tj;
+    const double *box;           // [F][3]
+    const unsigned char *cls;    // [n_ti][n_tj] -> class, 0xFF = not counted in this pass
+    const double *edges;         // [nbins+1]
+    unsigned long long *hist;    // [slots | F][n_cls][nbins]
+    unsigned long long *overflow;
+    long long ni, nj, ti_fs, tj_fs;
+    double rc2;
+    float gscale;  // 1/bin_size as float for the sqrt guess; 0 -> scan up from bin 0 (CN edges)
+    int n_ti, n_tj, n_cls, nbins;
+    int n_frames, nTi, nTj, jsplit, blocks_per_frame;
+    int per_frame, slots;
+    int fpb;  // frames swept per block before the flush (fast kernel, frame-summed output only)
+    // culled path: per (frame, i-tile) the j-tiles (>= I) whose bounding boxes come within the cutoff
+    const unsigned short *list;  // [F][nTi][nTi]
+    const int *list_cnt;         // [F][nTi]
+    const float4 *gsph;          // [F][nTi*32][2] bounding box (lo, hi; w = 1 if non-empty) of every 8 sorted atoms
+    const float4 *wsph;          // [F][nTi*4][2]  bounding box of every 64 sorted atoms (one wave's i atoms)
+    float reach;                 // r_cut rounded up, plus slack for the f32 box test
+    const double4 *aos;          // [F][nTi*256] sorted atoms (x, y, z, bits = type * n_ti), padded with +1e300
+    unsigned *work;              // work counters of the scalar-j kernel, zeroed per launch: [8] per XCD
+                                 // (frame-summed output) or [F] per frame (per-frame output)
+    float near;                  // MODE 2: guard band half-width (also folded into the records' row offsets)
+    unsigned *slices;            // scalar-j kernels: [blocks][LDS histogram words], every block stores its own copy
+    const double4 *aos_j;        // sorted records of the j set (== aos for atom-atom), [F][nTj*256]
+    int tri;                     // 1: atom-atom (i < j inside the diagonal tile), 0: atoms x sites
+};
+
+__device__ __forceinline__ double wrap_abs(double d, double L)
+{
+    double a = __builtin_fabs(d);
+    double w = __builtin_fabs(a - L);
+    return __builtin_fmin(a, w);
+}
+
+// periodic gap of two intervals inside [0,L) (f32, for the in-kernel group test)
+__device__ __forceinline__ float gapf(float alo, float ahi, float blo, float bhi, float L)
+{
+    float g = __builtin_fmaxf(blo - ahi, alo - bhi);
+    const float g1 = __builtin_fmaxf(blo + L - ahi, alo - (bhi + L));
+    const float g2 = __builtin_fmaxf(blo - L - ahi, alo - (bhi - L));
+    g = __builtin_fminf(g, __builtin_fminf(g1, g2));
+    return g > 0.f ? g : 0.f;
+}
+
+__device__ __forceinline__ JAtom load_atom(const double *__restrict__ xyz, const int *__restrict__ t,
+                                           long long n, long long g, double pad)
+{
+    JAtom a;
+    if (g < n) {
+        a.x = xyz[g];
+        a.y = xyz[n + g];
+        a.z = xyz[2 * n + g];
+        a.t = t[g];
+    } else {
+        a.x = a.y = a.z = pad;
+        a.t = 0;
+    }
+    a.pad = 0;
+    return a;
+}
+
+// number of half-shell shifts owned by i-tile I when there are nT tiles
+__device__ __host__ __forceinline__ int tri_shifts(int nT, int I)
+{
+    return (nT & 1) ? (nT + 1) / 2 : nT / 2 + (I < nT / 2 ? 1 : 0);
+}
+
+struct FastCtx {
+    unsigned *hist;               // LDS offset 0
+    const double *edges;          // global memory, nbins+2 entries, last = +inf
+    const unsigned *rowtab_me;    // LDS: &rowtab[0][ti] of the table [n_tj][n_ti] -> LDS byte address of the class row
+    float gscale, near, near2;    // guard band half-width and its double
+    unsigned rowbase_me;          // MODE 2: LDS byte address of row (ti, 0) of the ordered-pair histogram
+    unsigned lds_base;            // LDS byte address of the histogram
+    int nbins;
+};
+
+// 4th double of a sorted record: low word = type * n_ti (word offset into the [tj][ti] row table), high word =
+// float(near + type * row_len), the addend of the bin guess that carries the row of the ordered-pair layout
+// (MODE 2 of the scalar-j kernel; 0 otherwise).
+__device__ __forceinline__ double pack_w(int t, int n_ti, float near, int row_len)
+{
+    const unsigned lo = (unsigned)(t * n_ti);
+    const unsigned hi = row_len > 0 ? __float_as_uint(near + (float)(t * row_len)) : 0u;
+    return __hiloint2double((int)hi, (int)lo);
+}
+
+// Spatial sort + bounding boxes of ONE atom set of a batch of frames (culled path): Hilbert-sorted records
+// `aos` [F][nT*256], tile boxes `bbox` [F][nT][6], 8-atom and 64-atom boxes `gs` / `ws`. `slot` = workspace ids of
+// {records, tile boxes, group boxes, wave boxes}; keys, cell counters and the SoA copy are shared scratch.
+struct SortedSet {
+    const double4 *aos = nullptr;
+    const double *bbox = nullptr;
+    const float4 *gs = nullptr, *ws = nullptr;
+    const double *sx = nullptr;
+    const int *st = nullptr;
+};
+
+// ---- host entry points of the kernel translation units ----
+typedef void (*PairKernel)(const PairArgs);
+
+// pair_dense.hip
+size_t lds_bytes(int nbins, int n_cls, int n_ti, int n_tj);       // edge-table kernel (rdf_variant 0)
+size_t lds_bytes_fast(int nbins, int n_cls, int n_ti, int n_tj);  // LDS-tile fast kernel
+PairKernel dense_kernel(bool fast, bool tri, bool mode_cn, bool list, const char **name);
+void launch_reduce_slots(hipStream_t stream, const unsigned long long *in, unsigned long long *out, int words, int slots);
+
+// pair_sj.hip
+size_t lds_bytes_sj(int nbins, int n_cls, int n_ti, int n_tj, bool mode_cn);
+size_t lds_bytes_sj_ordered(int nbins, int n_ti, int n_tj);
+PairKernel sj_kernel(int mode /* 0 RDF class rows, 1 CN, 2 RDF ordered-pair rows */, bool persist, const char **name);
+void launch_merge_slices(hipStream_t stream, const unsigned *slices, int hist_words, long long n_blocks, int per_frame,
+                         int bpf, unsigned grid_y, unsigned long long *rows);
+
+// pair_cull.hip
+constexpr int MORTON_BITS = 5;                       // 32 cells per axis
+constexpr int MORTON_CELLS = 1 << (3 * MORTON_BITS); // 32768
+int cull_prepare_set(mdhip_ctx *ctx, int64_t F, const double *d_x, const int *d_t, long long t_fs,
+                     const double *d_box, long long N, int nT, int n_ti, float near, int row_len, bool want_soa,
+                     const int slot[4], SortedSet &out);
+void launch_cull_lists(hipStream_t stream, bool tri, int64_t F, const double *bbox_i, const double *bbox_j, int nTi,
+                       int nTj, const double *d_box, double rc2_test, unsigned short *list, int *cnt);
+
+}  // namespace mdpair
