@@ -19,12 +19,13 @@
 //   double, so the comparison of the rounded value against `a` falls the same way (ties give equal
 //   values). Only a^2 enters rsq, so the lost sign is irrelevant.
 //
-// Work decomposition: a block owns one tile of 256 "i" atoms of one frame (one atom per lane, in
-// registers) and sweeps a list of 256-atom "j" tiles staged through LDS (double-buffered, one
-// barrier per tile). For the triangular (atom-atom) case the j list is the half shell
-// J = I, I+1, ..., I+nT/2 (mod nT), which covers every unordered tile pair once with equal work per
-// block; only the J == I tile needs the i<j mask. Class histograms are LDS-private per block
-// (ds_add_u32) and flushed once with 64-bit global atomics into one of `slots` replicas.
+// Kernels live in their own translation units (shared types: pair_common.h):
+//   pair_sj.hip     scalar-j kernel — the default of the spatially culled sweep (one i atom per lane, j atoms
+//                   through scalar loads, wrap decisions hoisted per (wave box, group box), persistent grid)
+//   pair_cull.hip   the spatial pre-pass: Hilbert sort, bounding boxes, neighbour-tile lists
+//   pair_dense.hip  LDS-tile kernels: dense half-shell sweep for small frames, the edge-table kernel of the
+//                   first commit (A/B baseline, fallback for > 64 CN cutoffs)
+// This file: relations -> classes, edge tables, batching, launch geometry, rows -> outputs, the C-ABI.
 #include "pair_common.h"
 
 using namespace mdpair;
