@@ -2,6 +2,12 @@
 // baseline and fallback for more than 64 CN cutoffs) and the fast kernel (dense half-shell sweep for frames with
 // fewer than 8 tiles, the un-culled atom x site loops, and the LDS-tile variant of the culled sweep).
 // Formulation, exactness argument and binning: pair_hist.hip.
+//
+// Work decomposition: a block owns one tile of 256 "i" atoms of one frame (one atom per lane, in registers)
+// and sweeps a list of 256-atom "j" tiles staged through LDS (double-buffered, one barrier per tile). For the
+// triangular (atom-atom) case the j list is the half shell J = I, I+1, ..., I+nT/2 (mod nT), which covers every
+// unordered tile pair once with equal work per block; only the J == I tile needs the i<j mask. Class histograms
+// are LDS-private per block (ds_add_u32) and flushed once with 64-bit global atomics into one of `slots` replicas.
 #include "pair_common.h"
 
 #pragma clang fp contract(off)
