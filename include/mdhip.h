@@ -63,13 +63,17 @@ double mdhip_last_aux_ms(mdhip_ctx *ctx);
 const char *mdhip_last_kernel_name(mdhip_ctx *ctx);
 /* Writes the device name (e.g. "gfx950...") into buf. */
 int mdhip_device_name(mdhip_ctx *ctx, char *buf, int buflen);
-/* Kernel tuning knob, for A/B measurements only; results never depend on it.
- * keys: "rdf_variant" (1 = fast pair kernel, default; 0 = edge-table lookup per pair), "rdf_cull"
- * (-1 auto, 0 dense sweep, 1 spatially culled sweep), "rdf_jsplit", "rdf_fpb", "rdf_batch", "rdf_slots",
- * "rdf_sj" (culled path: 1 scalar-j kernel, persistent grid when frame-summed; 2 scalar-j, one block per
- * (frame, tile, slice); 0 LDS-tile kernel), "rdf_inflight" (per-frame output: frames in flight per XCD), "rdf_rows" (scalar-j RDF: 1 ordered-pair rows, no row table; 0 class rows), "rdf_sort" (spatial sort: -1 auto, 1 one block per frame with LDS
- * counters, 0 multi-block with global counters), "lag_variant" (1 series-resident full-lag kernel, 0 staged),
- * "xcorr_tile". */
+/* Kernel organisation knobs, for A/B measurements only; results never depend on them. Keys:
+ *   "rdf_variant"  1 fast pair kernels (default), 0 edge-table lookup per pair
+ *   "rdf_cull"     -1 auto, 0 dense sweep, 1 spatially culled sweep (when applicable)
+ *   "rdf_sj"       culled sweep: 1 scalar-j kernel (default), 2 the same without the persistent grid,
+ *                  0 LDS-tile kernel
+ *   "rdf_rows"     scalar-j RDF: -1/1 ordered-pair rows without a class-row table when they fit LDS, 0 class rows
+ *   "rdf_sort"     spatial sort: -1 auto, 1 one block per frame (LDS counters), 0 multi-block (global counters)
+ *   "rdf_inflight" per-frame output: frames in flight per XCD
+ *   "rdf_jsplit", "rdf_fpb", "rdf_batch", "rdf_slots"  launch geometry of the pair kernels
+ *   "lag_variant"  full-lag MSD: 1 series-resident kernel (default), 0 staged kernel
+ *   "xcorr_tile"   time slabs of the direct correlation kernel */
 int mdhip_set_option(mdhip_ctx *ctx, const char *key, int value);
 
 /* ---- R2/R3 binning table ------------------------------------------------ */
