@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """
-tools/soak_cull.py [trials] [seed] — long randomised differential run of the culled scalar-j sweep against the
+tools/soak_cull.py [trials] [seed] [oracle] — long randomised differential run of the culled scalar-j sweep against the
 dense sweep (same generator as tests/test_gpu_parity.py::test_culled_path_randomised_against_dense, more trials,
 also atoms x sites). Prints the first mismatch and exits 1, or a summary.
 """
@@ -18,12 +18,17 @@ def main():
 
     trials = int(sys.argv[1]) if len(sys.argv) > 1 else 400
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    oracle = len(sys.argv) > 3 and sys.argv[3] == "oracle"  # also compare with oracle/cpu_ref.c (slow: fewer atoms)
+    if oracle:
+        from oracle import cref
+
+        cref.build()
     dense, culled = Context(0), Context(0)
     dense.set_option("rdf_cull", 0)
     culled.set_option("rdf_cull", 1)
     pairs = 0
     for trial in range(trials):
-        n = int(rng.integers(2100, 9000))
+        n = int(rng.integers(2100, 3000 if oracle else 9000))
         L = rng.uniform(15.0, 70.0, 3)
         lo = rng.uniform(-1.5, 1.5, 3) * L
         F = int(rng.integers(1, 4))
@@ -60,6 +65,13 @@ def main():
         d = B.rdf_mol_loop(xyz, ty, sites, st, box, rel2, r_cut, bin_size, nbins, per_frame=per_frame, ctx=culled)
         ok = ok and np.array_equal(c[0], d[0]) and c[1] == d[1]
         pairs += F * n * (n - 1) // 2
+        if oracle:
+            full = b[0] if per_frame else None
+            for f in range(F if per_frame else 0):
+                cf, cp, _ = cref.rdf_pairs(xyz[f], ty, rel, L, r_cut * r_cut, bin_size, nbins)
+                ok = ok and np.array_equal(full[f], cf) and np.array_equal(b[1][f], cp)
+                rp, _ = cref.rdf_rect(xyz[f], ty, sites[f], st, rel2, L, r_cut * r_cut, bin_size, nbins)
+                ok = ok and np.array_equal(d[0][f], rp)
         if not ok:
             print("MISMATCH trial %d n=%d L=%s lo=%s r_cut=%r bin=%r types=%d per_frame=%d" %
                   (trial, n, L, lo, r_cut, bin_size, n_types, per_frame))
