@@ -43,6 +43,8 @@ enum WsSlot {
     WS_BBOX_J,
     WS_GSPH_J,
     WS_WSPH_J,
+    WS_GSPH4,      // 4-atom group boxes (scalar-j kernel)
+    WS_GSPH4_J,
     WS_SLICES,     // per-block histogram copies of the scalar-j kernel
     WS_ROWS,       // their sums per output frame
     WS_COUNT

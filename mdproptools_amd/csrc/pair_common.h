@@ -12,6 +12,7 @@
 namespace mdpair {
 
 constexpr int TILE = 256;
+constexpr int SJ_GROUP = 4;  // j atoms per culling group of the scalar-j kernel (64 groups per tile: one per lane)
 constexpr double PAD_I = -1.0e300;  // padding atoms: rsq overflows to +inf, never in cutoff, never NaN
 constexpr double PAD_J = 1.0e300;
 
@@ -42,6 +43,7 @@ struct PairArgs {
     const unsigned short *list;  // [F][nTi][nTi]
     const int *list_cnt;         // [F][nTi]
     const float4 *gsph;          // [F][nTi*32][2] bounding box (lo, hi; w = 1 if non-empty) of every 8 sorted atoms
+    const float4 *gsph4;         // [F][nTj*64][2] the same for every 4 sorted atoms of the j set (scalar-j kernel)
     const float4 *wsph;          // [F][nTi*4][2]  bounding box of every 64 sorted atoms (one wave's i atoms)
     float reach;                 // r_cut rounded up, plus slack for the f32 box test
     const double4 *aos;          // [F][nTi*256] sorted atoms (x, y, z, bits = type * n_ti), padded with +1e300
@@ -119,7 +121,7 @@ __device__ __forceinline__ double pack_w(int t, int n_ti, float near, int row_le
 struct SortedSet {
     const double4 *aos = nullptr;
     const double *bbox = nullptr;
-    const float4 *gs = nullptr, *ws = nullptr;
+    const float4 *gs = nullptr, *ws = nullptr, *gs4 = nullptr;
     const double *sx = nullptr;
     const int *st = nullptr;
 };
@@ -145,7 +147,7 @@ constexpr int MORTON_BITS = 5;                       // 32 cells per axis
 constexpr int MORTON_CELLS = 1 << (3 * MORTON_BITS); // 32768
 int cull_prepare_set(mdhip_ctx *ctx, int64_t F, const double *d_x, const int *d_t, long long t_fs,
                      const double *d_box, long long N, int nT, int n_ti, float near, int row_len, bool want_soa,
-                     const int slot[4], SortedSet &out);
+                     const int slot[5], SortedSet &out);
 void launch_cull_lists(hipStream_t stream, bool tri, int64_t F, const double *bbox_i, const double *bbox_j, int nTi,
                        int nTj, const double *d_box, double rc2_test, unsigned short *list, int *cnt);
 

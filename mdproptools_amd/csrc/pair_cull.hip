@@ -260,13 +260,13 @@ __global__ void cull_scatter_kernel(const double *__restrict__ xyz, const int *_
 
 // Bounding boxes of one tile of the sorted records, coordinates as given (not wrapped), all three levels
 // in one pass: bbox[f][tile][6] (doubles, min xyz / max xyz, for the tile-pair lists), and in f32, widened
-// so that rounding can only make them larger, the boxes of every 8 consecutive atoms (one step of the pair
-// sweep) and of every 64 (the i atoms of one wave): boxes[2*g] = (lo.xyz, 1), boxes[2*g+1] = (hi.xyz, 1);
+// so that rounding can only make them larger, the boxes of every 4 and every 8 consecutive atoms (culling groups
+// of the scalar-j and of the LDS-tile kernel) and of every 64 (the i atoms of one wave): boxes[2*g] = (lo.xyz, 1), boxes[2*g+1] = (hi.xyz, 1);
 // groups without atoms get w = 0 (never within reach).
 __global__ __launch_bounds__(TILE) void cull_boxes_kernel(const double4 *__restrict__ aos,
                                                           const double *__restrict__ box, long long n, int nT,
                                                           double *__restrict__ bbox, float4 *__restrict__ gboxes,
-                                                          float4 *__restrict__ wboxes)
+                                                          float4 *__restrict__ wboxes, float4 *__restrict__ g4boxes)
 {
     __shared__ double red[6][TILE / 64];
     const int f = blockIdx.y, T = blockIdx.x, tid = threadIdx.x;
@@ -298,6 +298,13 @@ __global__ __launch_bounds__(TILE) void cull_boxes_kernel(const double4 *__restr
     };
     fold(1);
     fold(2);
+    if ((tid & 3) == 0) {  // every 4 atoms: the culling groups of the scalar-j kernel
+        float4 l4, h4;
+        widened(l4, h4);
+        const size_t g = ((size_t)f * nT + T) * (TILE / 4) + (tid >> 2);
+        g4boxes[2 * g] = l4;
+        g4boxes[2 * g + 1] = h4;
+    }
     fold(4);
     if ((tid & 7) == 0) {
         float4 l4, h4;
@@ -382,7 +389,7 @@ __global__ __launch_bounds__(256) void cull_list_kernel(const double *__restrict
 
 int cull_prepare_set(mdhip_ctx *ctx, int64_t F, const double *d_x, const int *d_t, long long t_fs,
                      const double *d_box, long long N, int nT, int n_ti, float near, int row_len, bool want_soa,
-                     const int slot[4], SortedSet &out)
+                     const int slot[5], SortedSet &out)
 {
     MD_WS(d_sx, double, WS_SORT_XYZ, want_soa ? (size_t)F * 3 * N * 8 : 64);
     MD_WS(d_st, int, WS_SORT_TYPE, want_soa ? (size_t)F * N * 4 : 64);
@@ -392,6 +399,7 @@ int cull_prepare_set(mdhip_ctx *ctx, int64_t F, const double *d_x, const int *d_
     MD_WS(d_bbox, double, slot[1], (size_t)F * nT * 6 * 8);
     MD_WS(d_gs, float4, slot[2], (size_t)F * nT * (TILE / 8) * 2 * sizeof(float4));
     MD_WS(d_ws, float4, slot[3], (size_t)F * nT * (TILE / 64) * 2 * sizeof(float4));
+    MD_WS(d_g4, float4, slot[4], (size_t)F * nT * (TILE / 4) * 2 * sizeof(float4));
     const dim3 ga((unsigned)((N + 255) / 256), (unsigned)F);
     // one block per frame with the cell counters in LDS when there are frames enough to fill the chip (or the
     // frames are small); the multi-block path with global counters otherwise
@@ -415,12 +423,13 @@ int cull_prepare_set(mdhip_ctx *ctx, int64_t F, const double *d_x, const int *d_
                            row_len);
     }
     hipLaunchKernelGGL(cull_boxes_kernel, dim3((unsigned)nT, (unsigned)F), dim3(TILE), 0, ctx->stream, d_ao, d_box, N,
-                       nT, d_bbox, d_gs, d_ws);
+                       nT, d_bbox, d_gs, d_ws, d_g4);
     MD_HIP(hipGetLastError());
     out.aos = d_ao;
     out.bbox = d_bbox;
     out.gs = d_gs;
     out.ws = d_ws;
+    out.gs4 = d_g4;
     out.sx = d_sx;
     out.st = d_st;
     return MDHIP_OK;

@@ -178,7 +178,7 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
     long long k_ti_fs = p.ti_fs, k_tj_fs = p.tj_fs;
     const unsigned short *d_list = nullptr;
     const int *d_list_cnt = nullptr;
-    const float4 *d_gsph = nullptr, *d_wsph = nullptr;
+    const float4 *d_gsph = nullptr, *d_wsph = nullptr, *d_gsph4 = nullptr;
     const double4 *d_aos = nullptr;
     double prep_ms = 0.0;
     bool prep_timed = false;
@@ -190,14 +190,14 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         MD_WS(d_lc, int, WS_LISTCNT, (size_t)F * nTi * 4);
         KernelTimer ptimer(ctx, 1, true);  // second event pair: collected after the pair kernel's sync
         SortedSet si, sj_set;
-        const int slot_i[4] = {WS_SORT_AOS, WS_BBOX, WS_GSPH, WS_WSPH};
+        const int slot_i[5] = {WS_SORT_AOS, WS_BBOX, WS_GSPH, WS_WSPH, WS_GSPH4};
         int rc = cull_prepare_set(ctx, F, p.d_xi, p.d_ti, (long long)p.ti_fs, p.d_box, N, nTi, p.n_ti,
                                   ordered ? near_ord : 0.f, ordered ? p.nbins + 1 : 0, want_soa, slot_i, si);
         if (rc) return rc;
         if (p.tri) {
             sj_set = si;
         } else {
-            const int slot_j[4] = {WS_SORT_AOS_J, WS_BBOX_J, WS_GSPH_J, WS_WSPH_J};
+            const int slot_j[5] = {WS_SORT_AOS_J, WS_BBOX_J, WS_GSPH_J, WS_WSPH_J, WS_GSPH4_J};
             rc = cull_prepare_set(ctx, F, p.d_xj, p.d_tj, (long long)p.tj_fs, p.d_box, p.nj, nTj, p.n_ti, 0.f, 0,
                                   false, slot_j, sj_set);
             if (rc) return rc;
@@ -207,7 +207,8 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         ptimer.stop();
         MD_HIP(hipGetLastError());
         prep_timed = true;
-        d_gsph = sj_set.gs;  // 8-atom boxes of the j set
+        d_gsph = sj_set.gs;    // 8-atom boxes of the j set (LDS-tile kernel)
+        d_gsph4 = sj_set.gs4;  // 4-atom boxes of the j set (scalar-j kernel)
         d_wsph = si.ws;      // 64-atom boxes of the i set
         if (want_soa) {
             k_xi = k_xj = si.sx;
@@ -239,6 +240,7 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         a.list = d_list;
         a.list_cnt = d_list_cnt;
         a.gsph = d_gsph;
+        a.gsph4 = d_gsph4;
         a.wsph = d_wsph;
         a.reach = (float)((std::sqrt(p.rc2) + 1e-3) * 1.00001);
         a.aos = d_aos;

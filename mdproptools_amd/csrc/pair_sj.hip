@@ -67,7 +67,7 @@ __device__ __forceinline__ void sweep_group_sj(const double4 *__restrict__ grp, 
 {
     constexpr int U = 4;  // records per batch of scalar loads (4 x 8 SGPRs)
 #pragma unroll
-    for (int h = 0; h < 8 / U; ++h) {
+    for (int h = 0; h < SJ_GROUP / U; ++h) {
         u32x8 rec[U];
         sload_records4(grp + h * U, rec[0], rec[1], rec[2], rec[3]);
         double rsq[U];
@@ -170,25 +170,25 @@ __device__ __forceinline__ void sj_item(const PairArgs &a, FastCtx &c, const uns
     }
     const long long w = ((long long)f * a.nTi + I) * (TILE / 64) + wq;
     const float4 wlo = a.wsph[2 * w], whi = a.wsph[2 * w + 1];
-    const float4 *gb_f = a.gsph + (long long)f * a.nTj * (TILE / 8) * 2;  // group boxes of the j set
+    const float4 *gb_f = a.gsph4 + (long long)f * a.nTj * (TILE / SJ_GROUP) * 2;  // group boxes of the j set
     const double4 *ats_j = a.aos_j + (long long)f * n_pad_j;
     const float fLx = (float)L.Lx, fLy = (float)L.Ly, fLz = (float)L.Lz;
     for (int t = t_begin; t < t_end; ++t) {
         const int J = __builtin_amdgcn_readfirstlane((int)row_list[t]);
-        // lanes 0..31 (mirrored in 32..63) test one 8-atom group box each against this wave's box
-        const float4 glo = gb_f[((long long)J * (TILE / 8) + (lane & 31)) * 2];
-        const float4 ghi = gb_f[((long long)J * (TILE / 8) + (lane & 31)) * 2 + 1];
+        // every lane tests one 4-atom group box of the tile against this wave's box
+        const float4 glo = gb_f[((long long)J * (TILE / SJ_GROUP) + lane) * 2];
+        const float4 ghi = gb_f[((long long)J * (TILE / SJ_GROUP) + lane) * 2 + 1];
         const float gx = gapf(wlo.x, whi.x, glo.x, ghi.x, fLx);
         const float gy = gapf(wlo.y, whi.y, glo.y, ghi.y, fLy);
         const float gz = gapf(wlo.z, whi.z, glo.z, ghi.z, fLz);
         const bool keep = wlo.w > 0.f && glo.w > 0.f && gx * gx + gy * gy + gz * gz < a.reach * a.reach;
         const double4 *tile = ats_j + (long long)J * TILE;
         if (a.tri && J == I) {
-            unsigned mask = (unsigned)__builtin_amdgcn_ballot_w64(keep);
+            unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
             while (mask) {
-                const int g = __builtin_ctz(mask);
+                const int g = __builtin_ctzll(mask);
                 mask &= mask - 1;
-                sweep_group_sj<true, MODE, 7>(tile + g * 8, g * 8, me.x, me.y, me.z, L, a.rc2, c, lane_in_tile);
+                sweep_group_sj<true, MODE, 7>(tile + g * SJ_GROUP, g * SJ_GROUP, me.x, me.y, me.z, L, a.rc2, c, lane_in_tile);
             }
             continue;
         }
@@ -199,27 +199,27 @@ __device__ __forceinline__ void sj_item(const PairArgs &a, FastCtx &c, const uns
         // their wave-uniform shift; groups where nothing wraps at all take the shortest chain
         const unsigned amb = (cx >> 2) | ((cy >> 2) << 1) | ((cz >> 2) << 2);
         const bool none = !(cx | cy | cz);
-        unsigned m8 = (unsigned)__builtin_amdgcn_ballot_w64(keep && none);
+        unsigned long long m8 = __builtin_amdgcn_ballot_w64(keep && none);
         while (m8) {
-            const int g = __builtin_ctz(m8);
+            const int g = __builtin_ctzll(m8);
             m8 &= m8 - 1;
-            sweep_group_sj<false, MODE, 8>(tile + g * 8, g * 8, me.x, me.y, me.z, L, a.rc2, c, lane_in_tile);
+            sweep_group_sj<false, MODE, 8>(tile + g * SJ_GROUP, g * SJ_GROUP, me.x, me.y, me.z, L, a.rc2, c, lane_in_tile);
         }
         if (!__builtin_amdgcn_ballot_w64(keep && !none)) continue;
-        const unsigned xm = (unsigned)__builtin_amdgcn_ballot_w64(cx == 1u), xp = (unsigned)__builtin_amdgcn_ballot_w64(cx == 2u);
-        const unsigned ym = (unsigned)__builtin_amdgcn_ballot_w64(cy == 1u), yp = (unsigned)__builtin_amdgcn_ballot_w64(cy == 2u);
-        const unsigned zm = (unsigned)__builtin_amdgcn_ballot_w64(cz == 1u), zp = (unsigned)__builtin_amdgcn_ballot_w64(cz == 2u);
+        const unsigned long long xm = __builtin_amdgcn_ballot_w64(cx == 1u), xp = __builtin_amdgcn_ballot_w64(cx == 2u);
+        const unsigned long long ym = __builtin_amdgcn_ballot_w64(cy == 1u), yp = __builtin_amdgcn_ballot_w64(cy == 2u);
+        const unsigned long long zm = __builtin_amdgcn_ballot_w64(cz == 1u), zp = __builtin_amdgcn_ballot_w64(cz == 2u);
 #define SJ_VARIANT(A)                                                                                        \
     {                                                                                                        \
-        unsigned mk = (unsigned)__builtin_amdgcn_ballot_w64(keep && !none && amb == (A));                    \
+        unsigned long long mk = __builtin_amdgcn_ballot_w64(keep && !none && amb == (A));                    \
         while (mk) {                                                                                         \
-            const int g = __builtin_ctz(mk);                                                                 \
+            const int g = __builtin_ctzll(mk);                                                               \
             mk &= mk - 1;                                                                                    \
             AxisL S = L;                                                                                     \
-            S.sx = ((xm >> g) & 1u) ? -L.Lx : ((xp >> g) & 1u) ? L.Lx : 0.0;                                 \
-            S.sy = ((ym >> g) & 1u) ? -L.Ly : ((yp >> g) & 1u) ? L.Ly : 0.0;                                 \
-            S.sz = ((zm >> g) & 1u) ? -L.Lz : ((zp >> g) & 1u) ? L.Lz : 0.0;                                 \
-            sweep_group_sj<false, MODE, (A)>(tile + g * 8, g * 8, me.x, me.y, me.z, S, a.rc2, c, lane_in_tile); \
+            S.sx = ((xm >> g) & 1ull) ? -L.Lx : ((xp >> g) & 1ull) ? L.Lx : 0.0;                                 \
+            S.sy = ((ym >> g) & 1ull) ? -L.Ly : ((yp >> g) & 1ull) ? L.Ly : 0.0;                                 \
+            S.sz = ((zm >> g) & 1ull) ? -L.Lz : ((zp >> g) & 1ull) ? L.Lz : 0.0;                                 \
+            sweep_group_sj<false, MODE, (A)>(tile + g * SJ_GROUP, g * SJ_GROUP, me.x, me.y, me.z, S, a.rc2, c, lane_in_tile); \
         }                                                                                                    \
     }
         SJ_VARIANT(0)
