@@ -35,7 +35,7 @@ def main():
 
     ctx = default_context(0)
     dev = torch.device("cuda", 0)
-    which = sys.argv[1:] or ["rdf_c3", "cn_c3", "rect", "msd", "lag", "xcorr", "scan", "com"]
+    which = sys.argv[1:] or ["rdf_c3", "cn_c3", "rect", "residence", "msd", "lag", "xcorr", "scan", "com"]
     out = []
 
     if "rdf_c3" in which or "cn_c3" in which:
@@ -77,6 +77,18 @@ def main():
                             call_ms=call, kernel_ms=k, pairs_per_s=F * n * m / (k * 1e-3), kernel=c2.last_kernel_name()))
             c2.close()
         del xyz, sites
+
+    if "residence" in which:
+        ni, nj, F, L = 2000, 20_000, 500, 60.0  # e.g. 2000 cations against 20 000 solvent oxygens
+        rng = np.random.default_rng(9)
+        xi = rng.random((1, 3, ni)) * L + np.cumsum(rng.normal(0, 0.05, (F, 3, ni)), axis=0)
+        xj = rng.random((1, 3, nj)) * L + np.cumsum(rng.normal(0, 0.05, (F, 3, nj)), axis=0)
+        di, dj = torch.from_numpy(xi).to(dev), torch.from_numpy(xj).to(dev)
+        box = np.full((F, 3), L)
+        call, k = timed(lambda: B.shell_residence(di, dj, box, 0.0, 3.0 ** 2), ctx)
+        counts, nrec = B.shell_residence(di, dj, box, 0.0, 9.0)
+        out.append(dict(path="residence autocorrelation (2000 x 20000 atoms, 500 frames, shell 0-3 A)", call_ms=call,
+                        kernel_ms=k, pair_tests_per_s=F * ni * nj / (k * 1e-3), records=nrec))
 
     if "msd" in which or "lag" in which:
         E, F = 50_000, 1000  # C4 entities, 1000 of its 5000 frames
