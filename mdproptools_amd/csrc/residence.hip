@@ -113,13 +113,31 @@ __global__ __launch_bounds__(RT_TILE) void shell_pairs_kernel(
     }
 }
 
-// starts[] = indices where a new pair key begins in the sorted records
-__global__ void run_starts_kernel(const unsigned long long *__restrict__ rec, unsigned long long n, int frame_bits,
-                                  unsigned long long *__restrict__ n_runs, unsigned long long *__restrict__ starts)
+// starts[] = indices where a new pair key begins in the sorted records (any order); a block reserves its
+// slots with ONE global atomic
+__global__ __launch_bounds__(256) void run_starts_kernel(const unsigned long long *__restrict__ rec,
+                                                         unsigned long long n, int frame_bits,
+                                                         unsigned long long *__restrict__ n_runs,
+                                                         unsigned long long *__restrict__ starts)
 {
+    __shared__ unsigned s_wave[4];
+    __shared__ unsigned long long s_base;
     const unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    if (k == 0 || (rec[k] >> frame_bits) != (rec[k - 1] >> frame_bits)) starts[atomicAdd(n_runs, 1ull)] = k;
+    const bool is_start = k < n && (k == 0 || (rec[k] >> frame_bits) != (rec[k - 1] >> frame_bits));
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(is_start);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) s_wave[wave] = (unsigned)__builtin_popcountll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned tot = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        s_base = tot ? atomicAdd(n_runs, (unsigned long long)tot) : 0ull;
+    }
+    __syncthreads();
+    if (is_start) {
+        unsigned off = (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wave; ++w) off += s_wave[w];
+        starts[s_base + off] = k;
+    }
 }
 
 // One wave per run (grid-stride over the runs). LDS: presence mask [words] + lag table [n_frames] (u64).
