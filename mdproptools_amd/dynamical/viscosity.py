@@ -83,8 +83,16 @@ class Viscosity:
 
     def calc_avg_visc(self, output_all_data=False):
         """Viscosity of every replicate log after `cutoff_time` (viscosity.py:193-237)."""
-        logs = [parse_lammps_log(f)[0] for f in glob.glob(f"{self.working_dir}/{self.log_pattern}")]
-        first = logs[0]
+        from .. import dist as D
+
+        files = glob.glob(f"{self.working_dir}/{self.log_pattern}")
+        # under torch.distributed the replicates (independent logs) are dealt to the ranks: every rank parses
+        # and correlates its share — plus the first log, which fixes the cutoff row and the time axis —
+        # and the per-replicate arrays are all-gathered in file order
+        sharded = D.is_distributed() and len(files) >= D.rank_world()[1]
+        mine = D.shard_items(files) if sharded else files
+        first = parse_lammps_log(files[0])[0]
+        logs = [first if f == files[0] else parse_lammps_log(f)[0] for f in mine]
         start = first.index.get_loc(first[first["Step"] == self.cutoff_time].index[0])
         visc_avg, visc_data, acf_data = [], [], []
         for k, log_df in enumerate(logs):
@@ -93,6 +101,10 @@ class Viscosity:
             visc_avg.append(avg)
             visc_data.append(data)
             acf_data.append(acf)
+        if sharded:
+            visc_avg = list(D.allgather_var(np.stack(visc_avg)))
+            visc_data = list(D.allgather_var(np.stack(visc_data)))
+            acf_data = list(D.allgather_var(np.stack(acf_data)))
         self.time = np.array(first["Step"][: len(visc_avg[0]) - 1]) * self.timestep
         if output_all_data:
             return visc_avg, visc_data, acf_data, self.time

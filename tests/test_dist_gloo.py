@@ -282,3 +282,54 @@ def test_dropin_diffusion_conductivity_sharded_parse_world2_gloo(tmp_path):
         two = np.load(tmp_path / "w2" / ("rank%d.npz" % rank))
         for key in ("msd", "msd_all", "msd_int", "aa", "j", "time"):
             np.testing.assert_array_equal(two[key], one[key], err_msg=key)
+
+
+def _visc_worker(rank, world, port, tmp_dir):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    from mdproptools_amd import backend
+    from mdproptools_amd.dynamical.viscosity import Viscosity
+    from oracle import cpu_ref as O
+
+    def xcorr(a, b=None, method=0, n_lags=None, ctx=None):
+        return np.stack([O.xcorr_fft(row, row) for row in np.atleast_2d(a)])
+
+    def cumtrapz(y, dx, leading_zero=False, ctx=None):
+        return np.stack([O.cumtrapz(row, dx, leading_zero) for row in np.atleast_2d(y)])
+
+    backend.xcorr, backend.cumtrapz = xcorr, cumtrapz
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    v = Viscosity("log.rep*", cutoff_time=20, volume=1000.0, temp=300.0, timestep=1, working_dir=tmp_dir)
+    avg, data, acf, t = v.calc_avg_visc(output_all_data=True)
+    np.savez(os.path.join(tmp_dir, "visc_w%d_r%d.npz" % (world, rank)), avg=np.stack(avg), data=np.stack(data),
+             acf=np.stack(acf), t=t)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_dropin_viscosity_replicates_sharded_world2_gloo(tmp_path):
+    """Viscosity.calc_avg_visc under torch.distributed: the replicate logs are dealt to the ranks, every rank returns
+    all replicates in file order, equal to the single-process result."""
+    import glob
+
+    import torch.multiprocessing as mp
+
+    from mdproptools_amd import io as mio
+
+    rng = np.random.default_rng(4)
+    for k in range(5):
+        n = 300
+        tbl = np.column_stack([np.arange(n) * 10, rng.normal(0, 50, (n, 3))])
+        mio.write_log(str(tmp_path / ("log.rep%d" % k)), tbl, ["Step", "Pxy", "Pxz", "Pyz"])
+    mp.spawn(_visc_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    mp.spawn(_visc_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    one = np.load(tmp_path / "visc_w1_r0.npz")
+    assert one["avg"].shape[0] == len(glob.glob(str(tmp_path / "log.rep*"))) == 5
+    for rank in range(2):
+        two = np.load(tmp_path / ("visc_w2_r%d.npz" % rank))
+        for key in ("avg", "data", "acf", "t"):
+            np.testing.assert_array_equal(two[key], one[key], err_msg=key)
