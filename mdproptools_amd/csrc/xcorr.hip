@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <map>
+#include <tuple>
 
 #include "ctx.h"
 
@@ -28,47 +29,53 @@ namespace {
 // FFT path
 // ---------------------------------------------------------------------------------------------
 
+// dst[p][i] = i < n ? src[p][i] : 0 for the 2n-point padded copies of `batch` series (grid.y = batch)
 __global__ void pad_kernel(const double *__restrict__ src, double *__restrict__ dst, long long n)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 2 * n) dst[i] = i < n ? src[i] : 0.0;
+    const long long p = blockIdx.y;
+    if (i < 2 * n) dst[p * 2 * n + i] = i < n ? src[p * n + i] : 0.0;
 }
 
-// A <- A * conj(B)
+// A <- A * conj(B), m complex values per series
 __global__ void mul_conj_kernel(double2 *__restrict__ A, const double2 *__restrict__ B, long long m)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
-    const double2 a = A[i], b = B[i];
-    A[i] = make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+    const size_t k = (size_t)blockIdx.y * m + i;
+    const double2 a = A[k], b = B[k];
+    A[k] = make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
 }
 
-// out[k] = c[k] / (2n) / (n-k): numpy's ifft normalisation, then conductivity.py:113 / viscosity.py:114
+// out[p][k] = c[p][k] / (2n) / (n-k): numpy's ifft normalisation, then conductivity.py:113 / viscosity.py:114
 __global__ void scale_unbiased_kernel(const double *__restrict__ c, double *__restrict__ out,
                                       long long n, long long n_lags)
 {
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_lags) return;
-    out[k] = (c[k] / (double)(2 * n)) / (double)(n - k);
+    const long long p = blockIdx.y;
+    out[p * n_lags + k] = (c[p * 2 * n + k] / (double)(2 * n)) / (double)(n - k);
 }
 
 struct FftPlans {
     hipfftHandle fwd = 0, inv = 0;
 };
-std::map<std::pair<mdhip_ctx *, long long>, FftPlans> g_plans;
+std::map<std::tuple<mdhip_ctx *, long long, int>, FftPlans> g_plans;
 
-int get_plans(mdhip_ctx *ctx, long long n, FftPlans &out)
+// batched 2n-point real transforms (one launch sequence for all series pairs of a chunk)
+int get_plans(mdhip_ctx *ctx, long long n, int batch, FftPlans &out)
 {
-    auto key = std::make_pair(ctx, n);
+    auto key = std::make_tuple(ctx, n, batch);
     auto it = g_plans.find(key);
     if (it != g_plans.end()) {
         out = it->second;
         return MDHIP_OK;
     }
     FftPlans p;
-    if (hipfftPlan1d(&p.fwd, (int)(2 * n), HIPFFT_D2Z, 1) != HIPFFT_SUCCESS ||
-        hipfftPlan1d(&p.inv, (int)(2 * n), HIPFFT_Z2D, 1) != HIPFFT_SUCCESS)
-        return mdhip_fail(ctx, MDHIP_EHIP, "hipfftPlan1d(%lld) failed", 2 * n);
+    int len = (int)(2 * n);
+    if (hipfftPlanMany(&p.fwd, 1, &len, nullptr, 1, len, nullptr, 1, len / 2 + 1, HIPFFT_D2Z, batch) != HIPFFT_SUCCESS ||
+        hipfftPlanMany(&p.inv, 1, &len, nullptr, 1, len / 2 + 1, nullptr, 1, len, HIPFFT_Z2D, batch) != HIPFFT_SUCCESS)
+        return mdhip_fail(ctx, MDHIP_EHIP, "hipfftPlanMany(%lld x %d) failed", 2 * n, batch);
     g_plans[key] = p;
     out = p;
     return MDHIP_OK;
@@ -77,32 +84,35 @@ int get_plans(mdhip_ctx *ctx, long long n, FftPlans &out)
 int xcorr_fft(mdhip_ctx *ctx, long long n, int n_pairs, const double *d_a, const double *d_b,
               bool same, long long n_lags, double *d_out)
 {
-    FftPlans pl;
-    int rc = get_plans(ctx, n, pl);
-    if (rc) return rc;
-    hipfftSetStream(pl.fwd, ctx->stream);
-    hipfftSetStream(pl.inv, ctx->stream);
     const long long m = n + 1;  // complex outputs of a 2n-point real transform
-    MD_WS(d_pad, double, WS_AUX0, (size_t)2 * n * 8 + 64);
-    MD_WS(d_A, double2, WS_AUX1, (size_t)m * 16);
-    MD_WS(d_B, double2, WS_AUX2, (size_t)m * 16);
-    const unsigned gp = (unsigned)((2 * n + 255) / 256), gm = (unsigned)((m + 255) / 256);
-    for (int p = 0; p < n_pairs; ++p) {
-        hipLaunchKernelGGL(pad_kernel, dim3(gp), dim3(256), 0, ctx->stream, d_a + (size_t)p * n, d_pad, n);
+    // series pairs per chunk: all of them while the padded copies stay below ~1 GiB
+    int chunk = (int)std::max<long long>(1, std::min<long long>(n_pairs, (1LL << 30) / (2 * n * 8 * 3)));
+    MD_WS(d_pad, double, WS_AUX0, (size_t)chunk * 2 * n * 8 + 64);
+    MD_WS(d_A, double2, WS_AUX1, (size_t)chunk * m * 16);
+    MD_WS(d_B, double2, WS_AUX2, (size_t)(same ? 1 : chunk) * m * 16);
+    for (int p0 = 0; p0 < n_pairs; p0 += chunk) {
+        const int nb = std::min(chunk, n_pairs - p0);
+        FftPlans pl;
+        int rc = get_plans(ctx, n, nb, pl);
+        if (rc) return rc;
+        hipfftSetStream(pl.fwd, ctx->stream);
+        hipfftSetStream(pl.inv, ctx->stream);
+        const dim3 gp((unsigned)((2 * n + 255) / 256), (unsigned)nb), gm((unsigned)((m + 255) / 256), (unsigned)nb);
+        hipLaunchKernelGGL(pad_kernel, gp, dim3(256), 0, ctx->stream, d_a + (size_t)p0 * n, d_pad, n);
         if (hipfftExecD2Z(pl.fwd, d_pad, reinterpret_cast<hipfftDoubleComplex *>(d_A)) != HIPFFT_SUCCESS)
             return mdhip_fail(ctx, MDHIP_EHIP, "hipfftExecD2Z failed");
         const double2 *Bp = d_A;
         if (!same) {
-            hipLaunchKernelGGL(pad_kernel, dim3(gp), dim3(256), 0, ctx->stream, d_b + (size_t)p * n, d_pad, n);
+            hipLaunchKernelGGL(pad_kernel, gp, dim3(256), 0, ctx->stream, d_b + (size_t)p0 * n, d_pad, n);
             if (hipfftExecD2Z(pl.fwd, d_pad, reinterpret_cast<hipfftDoubleComplex *>(d_B)) != HIPFFT_SUCCESS)
                 return mdhip_fail(ctx, MDHIP_EHIP, "hipfftExecD2Z failed");
             Bp = d_B;
         }
-        hipLaunchKernelGGL(mul_conj_kernel, dim3(gm), dim3(256), 0, ctx->stream, d_A, Bp, m);
+        hipLaunchKernelGGL(mul_conj_kernel, gm, dim3(256), 0, ctx->stream, d_A, Bp, m);
         if (hipfftExecZ2D(pl.inv, reinterpret_cast<hipfftDoubleComplex *>(d_A), d_pad) != HIPFFT_SUCCESS)
             return mdhip_fail(ctx, MDHIP_EHIP, "hipfftExecZ2D failed");
-        hipLaunchKernelGGL(scale_unbiased_kernel, dim3((unsigned)((n_lags + 255) / 256)), dim3(256), 0,
-                           ctx->stream, d_pad, d_out + (size_t)p * n_lags, n, n_lags);
+        hipLaunchKernelGGL(scale_unbiased_kernel, dim3((unsigned)((n_lags + 255) / 256), (unsigned)nb), dim3(256), 0,
+                           ctx->stream, d_pad, d_out + (size_t)p0 * n_lags, n, n_lags);
         MD_HIP(hipGetLastError());
     }
     return MDHIP_OK;
