@@ -1,9 +1,9 @@
 #!/usr/bin/env python
 """
-tools/bench_e2e.py — end-to-end wall time of the drop-in API on TEXT dumps (what a user of the reference runs),
+tests/bench/bench_e2e.py — end-to-end wall time of the drop-in API on TEXT dumps (what a user of the reference runs),
 BASELINE C2 shape by default: 200 dump files x 10 000 atoms, calc_atomic_rdf with 10 relations + calc_atomic_cn.
 
-    python tools/bench_e2e.py [n_atoms] [n_frames]
+    python tests/bench/bench_e2e.py [n_atoms] [n_frames]
 
 Reports, as one JSON line: time to write the synthetic dumps (not part of any figure), the drop-in calls with the
 native reader (default) and with the pandas text route the reference takes (pymatgen's parser is pandas.read_csv
@@ -18,7 +18,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 
 def main():

@@ -1,11 +1,11 @@
 #!/usr/bin/env python
 """
-tools/bench_full.py — the BASELINE.json configurations at FULL size on one MI355X, wall time of every
+tests/bench/bench_full.py — the BASELINE.json configurations at FULL size on one MI355X, wall time of every
 library call with the inputs resident in HBM, next to the CPU oracle (oracle/cpu_ref.c, one core) timed
 on a bounded sample of the same workload and extrapolated linearly (every one of these costs is linear in
 the number of frames / frame pairs).
 
-    python tools/bench_full.py [c3] [c4] [c5]
+    python tests/bench/bench_full.py [c3] [c4] [c5]
 
 C3: 100 000 atoms x 1000 frames, L = 104 A: RDF (10 relations, r_cut 20 A, 400 bins) + CN.
 C4: 50 000 atoms x 5000 frames random walk: single-origin MSD (allatom), fixed-lag MSD (tao = 4), molecule
@@ -20,7 +20,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 
 def wall(fn, sync, reps=2):

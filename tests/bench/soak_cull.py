@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """
-tools/soak_cull.py [trials] [seed] [oracle] — long randomised differential run of the culled scalar-j sweep against the
+tests/bench/soak_cull.py [trials] [seed] [oracle] — long randomised differential run of the culled scalar-j sweep against the
 dense sweep (same generator as tests/test_gpu_parity.py::test_culled_path_randomised_against_dense, more trials,
 also atoms x sites). Prints the first mismatch and exits 1, or a summary.
 """
@@ -9,7 +9,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 
 def main():

@@ -76,6 +76,16 @@ def test_product_never_imports_oracle():
                 hits = re.findall(r"^\s*(?:from|import)\s+oracle\b|__import__\([\"']oracle|import_module\([\"']oracle",
                                   src, flags=re.M)
                 assert not hits, (os.path.join(root, f), hits)
+    # tools/ holds product-side measurement scripts: no oracle there either (oracle-based ones live in tests/bench/)
+    for f in os.listdir(os.path.join(REPO, "tools")):
+        if f.endswith(".py"):
+            src = open(os.path.join(REPO, "tools", f)).read()
+            assert not re.findall(r"^\s*(?:from|import)\s+oracle\b", src, flags=re.M), f
+    # bench.py: only inside the cpu_baseline functions
+    src = open(os.path.join(REPO, "bench.py")).read()
+    for m in re.finditer(r"^\s*(?:from|import)\s+oracle\b", src, flags=re.M):
+        enclosing = re.findall(r"^def (\w+)\(", src[: m.start()], flags=re.M)[-1]
+        assert enclosing.startswith("cpu_baseline"), enclosing
 
 
 def test_header_is_plain_c(tmp_path):
