@@ -77,7 +77,6 @@ struct mdhip_ctx {
     char name[256] = {0};
     // options (A/B knobs; results never depend on them)
     int opt_rdf_variant = 1;   // 1 = fast kernel (default), 0 = table-lookup loops (A/B baseline)
-    int opt_rdf_unroll = 8;   // j atoms per step of the fast kernel (4, 8, 16)
     int opt_rdf_jsplit = 0;   // 0 = auto
     int opt_rdf_fpb = 0;      // frames per block of the fast kernel, 0 = auto
     int opt_rdf_sj = 1;       // culled path: 1 = scalar-j kernel (waves independent; persistent grid when the

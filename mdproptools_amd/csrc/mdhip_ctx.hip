@@ -114,7 +114,6 @@ int mdhip_create(mdhip_ctx **out, int device)
     }
     ctx->stream = ctx->own_stream;
     if (const char *v = getenv("MDHIP_RDF_VARIANT")) ctx->opt_rdf_variant = atoi(v);  // A/B knobs
-    if (const char *v = getenv("MDHIP_RDF_UNROLL")) ctx->opt_rdf_unroll = atoi(v);
     if (const char *v = getenv("MDHIP_RDF_JSPLIT")) ctx->opt_rdf_jsplit = atoi(v);
     if (const char *v = getenv("MDHIP_RDF_FPB")) ctx->opt_rdf_fpb = atoi(v);
     if (const char *v = getenv("MDHIP_RDF_CULL")) ctx->opt_rdf_cull = atoi(v);
@@ -179,8 +178,6 @@ int mdhip_set_option(mdhip_ctx *ctx, const char *key, int value)
     if (!ctx || !key) return MDHIP_EINVAL;
     if (!strcmp(key, "rdf_variant"))
         ctx->opt_rdf_variant = value;
-    else if (!strcmp(key, "rdf_unroll"))
-        ctx->opt_rdf_unroll = value;
     else if (!strcmp(key, "rdf_sj"))
         ctx->opt_rdf_sj = value;
     else if (!strcmp(key, "rdf_batch"))
