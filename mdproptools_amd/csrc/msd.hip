@@ -356,18 +356,19 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 8)))
                 for (int j = 0; j < 8; ++j) wa[j] = s_x[j * row + (kb >> 3)];  // (kb & 7) == 0
 // One step of 8 origins x 8 lags for the lanes whose whole 8 x 8 block is valid (the others are masked off:
 // their few remaining pairs are swept up after the loop). A holds x[T+kb+0..7], B is loaded with x[T+kb+8..15].
-#define LG_STEP(A, B, T)                                                                \
+#define LG_STEP(A, B, T, BC, BN)                                                        \
     {                                                                                   \
         const int col_ = (((T) + kb) >> 3) + 1;                                         \
+        /* x[T+8 .. T+15] for the NEXT step: wave-uniform scalar loads, in flight during this step */ \
+        _Pragma("unroll") for (int u = 0; u < 8; ++u) BN[u] = xs[(T) + 8 + u];          \
         _Pragma("unroll") for (int j = 0; j < 8; ++j) B[j] = s_x[j * row + col_];       \
         if (lim - (T) >= 15) {                                                          \
             _Pragma("unroll") for (int u = 0; u < 8; ++u)                               \
             {                                                                           \
-                const double bt_ = xs[(T) + u]; /* wave-uniform: scalar load, SGPR operand */ \
                 /* differences first, then the FMAs: a dependent pair back to back leaves the FP64 pipe idle */ \
                 double d_[LG_LPT];                                                      \
                 _Pragma("unroll") for (int m = 0; m < LG_LPT; ++m)                      \
-                    d_[m] = ((u + m) < 8 ? A[(u + m) & 7] : B[(u + m) & 7]) - bt_;      \
+                    d_[m] = ((u + m) < 8 ? A[(u + m) & 7] : B[(u + m) & 7]) - BC[u];    \
                 __builtin_amdgcn_sched_barrier(0);                                      \
                 _Pragma("unroll") for (int m = 0; m < LG_LPT; ++m)                      \
                     acc[h][m] = __builtin_fma(d_[m], d_[m], acc[h][m]);                 \
@@ -376,12 +377,15 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 8)))
         }                                                                               \
     }
                 const int t_wave = n - K0 - 15;  // lane 0 (smallest lag) has a whole block up to here
+                double b0[8], b1[8];             // x[t .. t+7] of the current / next step, SGPRs (ping-pong)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) b0[u] = xs[u];
                 int t = 0;
                 for (; t + 8 <= t_wave; t += 16) {
-                    LG_STEP(wa, wb, t)
-                    LG_STEP(wb, wa, t + 8)
+                    LG_STEP(wa, wb, t, b0, b1)
+                    LG_STEP(wb, wa, t + 8, b1, b0)
                 }
-                if (t <= t_wave) LG_STEP(wa, wb, t)
+                if (t <= t_wave) LG_STEP(wa, wb, t, b0, b1)
 #undef LG_STEP
                 // the pairs of the last, partial blocks of every lag: < 22 origins per lane
                 {
