@@ -175,6 +175,25 @@ def golden_c1_rdf():
 
 
 # ----------------------------------------------------------------------------
+def golden_inter_rdf():
+    """calc_intermolecular_rdf (rdf_cn.py:857-903) on the two frames of c1_rdf.npz: molecule-COM to molecule-COM
+    g(r); inputs are c1_rdf.npz's frames, only the outputs are stored here."""
+    steps = [0, 50000]
+    frames, bounds = load_real_frames(steps)
+    keep = [COLS.index(c) for c in ("id", "type", "x", "y", "z")]
+    rel = [[1, 2, 3, 3], [1, 3, 3, 1]]
+    with tempfile.TemporaryDirectory() as tmp:
+        write_frames(tmp, steps, bounds, frames[:, :, keep], ["id", "type", "x", "y", "z"])
+        with quiet(), Recorder(ref_rdf, "_rdf_mol_loop") as rec:
+            df = ref_rdf.calc_intermolecular_rdf(20, 0.05, 3, MASS, rel,
+                                                 os.path.join(tmp, "dump.nvt.*.dump"), NUM_MOLS, NUM_ATOMS,
+                                                 save_mode=False)
+    np.savez_compressed(os.path.join(OUT, "inter_rdf.npz"), rel=np.asarray(rel), df=df.to_numpy(),
+                        columns=np.array(list(df.columns)), part=np.stack([c[0] for c in rec.calls]).astype(np.int64))
+    print("inter_rdf:", list(df.columns), df.to_numpy()[100:103])
+
+
+# ----------------------------------------------------------------------------
 def reduced_system(frames, n_keep=(60, 12, 6)):
     """First n_keep molecules of each type, re-numbered 1..n in type-major order."""
     sel, off = [], 0
@@ -485,9 +504,11 @@ def golden_host_logic():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["synth", "acf", "small", "c1", "cell17", "host", "residence"]
+    which = sys.argv[1:] or ["synth", "acf", "small", "c1", "cell17", "host", "residence", "inter"]
     if "residence" in which:
         golden_residence()
+    if "inter" in which:
+        golden_inter_rdf()
     if "host" in which:
         golden_host_logic()
     if "synth" in which:
