@@ -167,10 +167,10 @@ def main():
         return B.rdf_loop(x, t, b, rl, rc, dd, nbins, per_frame=False, ctx=ctx)
 
     def step():
-        # N > 1: frame shards per rank, one RCCL all-reduce of the uint64 histograms (mdproptools_amd/dist.py)
-        full, part, ov = D.rdf_sharded(xyz, types, box, rel, cfg["r_cut"], cfg["bin_size"], nb,
-                                       compute=local_pass)
-        return full, part
+        # N > 1: frame shards per rank, one RCCL all-reduce of the uint64 histograms per step
+        # (mdproptools_amd/dist.py). The collective of step k is left in flight while step k+1 computes and is
+        # waited for right after: every step's sums are complete inside the timed region.
+        return D.rdf_sharded_async(xyz, types, box, rel, cfg["r_cut"], cfg["bin_size"], nb, compute=local_pass)
 
     def fence():
         torch.cuda.synchronize()
@@ -179,16 +179,21 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
+        step().wait()
     fence()
     kernel_ms, aux_ms, launches = 0.0, 0.0, 0
+    pending = None
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        full, part = step()
+        handle = step()
         ms, nl = ctx.last_kernel_ms()
         kernel_ms += ms
         aux_ms += ctx.last_aux_ms()
         launches += nl
+        if pending is not None:
+            pending.wait()
+        pending = handle
+    full, part, _ov = pending.wait()
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:

@@ -101,6 +101,40 @@ def allreduce_u64(arrays):
     return res
 
 
+class _PendingSum:
+    """Handle of an all-reduce in flight (allreduce_u64_async): wait() returns the summed arrays."""
+
+    def __init__(self, work, tensor, shapes):
+        self._work, self._t, self._shapes = work, tensor, shapes
+        self._out = None
+
+    def wait(self):
+        if self._out is None:
+            if self._work is not None:
+                self._work.wait()
+            flat = self._t.cpu().numpy().view(np.uint64)
+            self._out, pos = [], 0
+            for shp in self._shapes:
+                n = int(np.prod(shp))
+                self._out.append(flat[pos:pos + n].reshape(shp).copy())
+                pos += n
+        return self._out
+
+
+def allreduce_u64_async(arrays):
+    """allreduce_u64 without waiting: the collective runs while the caller goes on (e.g. with the next batch of
+    frames); `.wait()` on the returned handle gives the sums."""
+    shapes = [np.shape(a) for a in arrays]
+    flat = np.concatenate([np.asarray(a, dtype=np.uint64).reshape(-1) for a in arrays]).view(np.int64)
+    import torch
+
+    if not is_distributed():
+        return _PendingSum(None, torch.from_numpy(flat.copy()), shapes)
+    d = _dist()
+    t = torch.from_numpy(flat.copy()).to(_device_for_collectives())
+    return _PendingSum(d.all_reduce(t, op=d.ReduceOp.SUM, async_op=True), t, shapes)
+
+
 def allgather_rows(local, n_total_rows):
     """
     Concatenate per-rank blocks of rows (frame shards, in rank order) into the full array on every rank.
@@ -221,6 +255,19 @@ def rdf_sharded(xyz_local, types, box_local, relation_matrix, r_cut, ddr, nbins,
     full, part, ov = compute(xyz_local, types, box_local, relation_matrix, r_cut, ddr, nbins)
     full, part, ovv = allreduce_u64([full, part, np.array([ov], dtype=np.uint64)])
     return full, part, int(ovv[0])
+
+
+def rdf_sharded_async(xyz_local, types, box_local, relation_matrix, r_cut, ddr, nbins, compute=None):
+    """rdf_sharded with the all-reduce left in flight: returns a handle whose wait() gives
+    [rdf_full, rdf_part, [overflow]] — for pipelines that start the next batch of frames meanwhile."""
+    if compute is None:
+        from . import backend
+
+        def compute(x, t, b, rel, rc, dd, nb):
+            return backend.rdf_loop(x, t, b, rel, rc, dd, nb, per_frame=False)
+
+    full, part, ov = compute(xyz_local, types, box_local, relation_matrix, r_cut, ddr, nbins)
+    return allreduce_u64_async([full, part, np.array([ov], dtype=np.uint64)])
 
 
 def rdf_sharded_per_frame(xyz_local, types, box_local, relation_matrix, r_cut, ddr, nbins, n_frames_total,
