@@ -221,8 +221,11 @@ def main():
                        "pairs_per_step_per_gpu": pairs_per_step, "kernel_variant": ctx_variant(ctx, args)},
             "roofline": {
                 "bound": "fp64-valu",
-                "note": "neither hbm nor mfma bounds this kernel: 28 B and 18 unfused FP64 ops per atom pair swept "
-                        "(SURVEY.md 8d); peak = 256 CU x 128 lanes x 2.4 GHz / 2; the hbm view is given beside it",
+                "note": "neither hbm nor mfma bounds this kernel: 28 B and 18 unfused FP64 ops per atom pair the "
+                        "reference evaluates (SURVEY.md 8d); peak = 256 CU x 128 lanes x 2.4 GHz / 2; the hbm view is "
+                        "given beside it. achieved counts ALGORITHMIC ops: the spatially culled sweep skips ~15 % of "
+                        "the pairs and hoists wrap decisions, so frac can exceed 1 while the VALU issue slots are "
+                        "the actual limit (profiles/r01_pmc_summary.txt)",
                 "kernel": ctx.last_kernel_name(),
                 "launch_ms": kdur * 1e3, "prepass_ms_per_step": aux_ms / args.steps,
                 "achieved": alg_ops / kdur / 1e12, "peak": FP64_NONFUSED_PEAK / 1e12, "unit": "TFLOP/s",
