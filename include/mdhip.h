@@ -61,6 +61,9 @@ double mdhip_last_kernel_ms(mdhip_ctx *ctx, int *n_launches);
 double mdhip_last_aux_ms(mdhip_ctx *ctx);
 /* Name of the dominant kernel the last call launched (as rocprofv3 lists it, without the namespace), "" if none. */
 const char *mdhip_last_kernel_name(mdhip_ctx *ctx);
+/* Estimated relative rounding-error bound of the last mdhip_lag_msd call when it was answered by the FFT
+ * path (lag_variant 2 or 3); 0 when the exact-difference kernel answered. */
+double mdhip_last_rel_bound(mdhip_ctx *ctx);
 /* Writes the device name (e.g. "gfx950...") into buf. */
 int mdhip_device_name(mdhip_ctx *ctx, char *buf, int buflen);
 /* Kernel organisation knobs, for A/B measurements only; results never depend on them. Keys:
@@ -72,7 +75,9 @@ int mdhip_device_name(mdhip_ctx *ctx, char *buf, int buflen);
  *   "rdf_sort"     spatial sort: -1 auto, 1 one block per frame (LDS counters), 0 multi-block (global counters)
  *   "rdf_inflight" per-frame output: frames in flight per XCD
  *   "rdf_jsplit", "rdf_fpb", "rdf_batch", "rdf_slots"  launch geometry of the pair kernels
- *   "lag_variant"  full-lag MSD: 1 series-resident kernel (default), 0 staged kernel
+ *   "lag_variant"  full-lag MSD: 1 series-resident kernel (default), 0 staged kernel; 2 = autocorrelation
+ *                  theorem through batched FFTs (O(F log F); the one knob that changes results, within the
+ *                  bound mdhip_last_rel_bound reports), 3 = 2 when that bound is <= 1e-10, else 1
  *   "xcorr_tile"   time slabs of the direct correlation kernel */
 int mdhip_set_option(mdhip_ctx *ctx, const char *key, int value);
 

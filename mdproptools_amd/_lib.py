@@ -34,6 +34,7 @@ PROTOTYPES = {
     "mdhip_last_kernel_ms": (C.c_double, [vp, C.POINTER(C.c_int)]),
     "mdhip_last_aux_ms": (C.c_double, [vp]),
     "mdhip_last_kernel_name": (C.c_char_p, [vp]),
+    "mdhip_last_rel_bound": (C.c_double, [vp]),
     "mdhip_device_name": (C.c_int, [vp, C.c_char_p, C.c_int]),
     "mdhip_set_option": (C.c_int, [vp, C.c_char_p, C.c_int]),
     "mdhip_bin_edges": (C.c_int, [C.c_double, C.c_int, c_dp]),
@@ -143,6 +144,11 @@ def as_input(a):
         if not a.is_contiguous() or str(a.dtype) != "torch.float64":
             raise ValueError("device tensors must be contiguous float64")
         if a.is_cuda:
+            # the context launches on its own non-blocking stream: whatever torch still has queued to produce
+            # this tensor must have finished first
+            import torch
+
+            torch.cuda.current_stream(a.device).synchronize()
             return vp(a.data_ptr()), 1, a
         a = a.numpy()
     arr = _f64(a)
@@ -198,6 +204,9 @@ class Context:
 
     def last_kernel_name(self):
         return (self.lib.mdhip_last_kernel_name(self.h) or b"").decode()
+
+    def last_rel_bound(self):
+        return float(self.lib.mdhip_last_rel_bound(self.h))
 
 
 _default = {}

@@ -89,10 +89,16 @@ struct mdhip_ctx {
     int opt_rdf_rows = -1;    // scalar-j RDF: -1/1 ordered-pair rows without a row table when they fit, 0 class rows + table
     int opt_rdf_sort = -1;    // spatial sort: -1 auto, 1 one block per frame (LDS counters), 0 multi-block (global counters)
     int opt_xcorr_tile = 0;
-    int opt_lag_variant = 1;  // full-lag MSD: 1 = series-resident LDS kernel when it fits, 0 = staged kernel
+    int opt_lag_variant = 1;  // full-lag MSD: 1 = series-resident LDS kernel when it fits, 0 = staged kernel,
+                              // 2 = autocorrelation theorem (batched FFT, msd_fft.hip), 3 = 2 when its error
+                              // bound stays below 1e-10, else 1
+    double last_rel_bound = 0.0;  // error bound reported by the FFT MSD path of the last mdhip_lag_msd call (0: exact path)
 };
 
 int mdhip_fail(mdhip_ctx *ctx, int code, const char *fmt, ...);
+// msd_fft.hip: full-lag MSD through batched FFTs; d_r device [F][3][E], out host [max_lag+1][G][4]
+int mdhip_lag_msd_fft(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *d_r, double scale,
+                      int max_lag, int n_groups, const int64_t *group_off, double *out, double *rel_bound);
 void *mdhip_ws(mdhip_ctx *ctx, int slot, size_t bytes);  // nullptr on failure (error set)
 void *mdhip_pin(mdhip_ctx *ctx, int slot, size_t bytes);  // pinned host memory; nullptr on failure (error set)
 

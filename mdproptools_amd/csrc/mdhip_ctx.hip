@@ -165,6 +165,7 @@ double mdhip_last_kernel_ms(mdhip_ctx *ctx, int *n_launches)
 
 double mdhip_last_aux_ms(mdhip_ctx *ctx) { return ctx ? ctx->last_aux_ms : 0.0; }
 const char *mdhip_last_kernel_name(mdhip_ctx *ctx) { return ctx ? ctx->last_kernel : ""; }
+double mdhip_last_rel_bound(mdhip_ctx *ctx) { return ctx ? ctx->last_rel_bound : 0.0; }
 
 int mdhip_device_name(mdhip_ctx *ctx, char *buf, int buflen)
 {

@@ -630,6 +630,15 @@ int mdhip_lag_msd(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double 
     const size_t r_b = (size_t)n_frames * 3 * n_ent * 8;
     const double *d_r = (const double *)mdhip_stage(ctx, WS_XYZ_I, r, r_b, on_device, &rc);
     if (rc) return rc;
+    ctx->last_rel_bound = 0.0;
+    if (ctx->opt_lag_variant >= 2 && ctx->opt_lag_variant <= 4) {
+        double bound = 0.0;
+        rc = mdhip_lag_msd_fft(ctx, n_frames, n_ent, d_r, scale, max_lag, n_groups, group_off, out, &bound);
+        if (rc) return rc;
+        ctx->last_rel_bound = bound;
+        if (ctx->opt_lag_variant != 3 || bound <= 1e-10) return MDHIP_OK;
+        ctx->last_rel_bound = 0.0;  // bound too loose for this data: the exact-difference kernel below answers
+    }
     MD_WS(d_x, double, WS_XYZ_J, r_b + 256);  // the scalar prefetch of the resident kernel reads <= 16 doubles past a series
     const int n_chunks = (int)chunks.size();
     const size_t tab_b = chunks.size() * sizeof(Chunk) + gco.size() * 4 + (size_t)(n_groups + 1) * 8 + 64;

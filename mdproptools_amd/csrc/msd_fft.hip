@@ -1,0 +1,728 @@
+// Full lag x origin MSD through the autocorrelation theorem (the O(F log F) alternative to the
+// lag-tile kernel of msd.hip; `lag_variant` 2 / 3).
+//
+//   sum_t0 |x(t0+k) - x(t0)|^2 = S1(k) - 2 S2(k)
+//   S1(k) = sum_{t<F-k} x(t)^2 + sum_{t>=k} x(t)^2        (prefix sums of the per-frame squares)
+//   S2(k) = sum_t0 x(t0) x(t0+k)                          (inverse transform of the power spectrum)
+//
+// Both sums are linear in the series, so the power spectra of all series of one (axis, entity group) are
+// added BEFORE the inverse transform: one batched forward D2Z over every series, one column reduction of
+// |X|^2, and a 3 x n_groups inverse transform. Every series is centred on its own mean first (the MSD does
+// not see a constant offset), which keeps S1 as small as the data allow: the result carries an absolute
+// rounding error of a few eps * log2(L) * S1(k) per lag, i.e. a relative error that grows with
+// <x^2> / MSD(k). The caller gets that bound back and (variant 3) falls back to the exact-difference kernel
+// when it exceeds its tolerance.
+//
+// Layout: r [F][3][E] as handed in (frame-major) -> padded series [batch][L] (L = smooth length >= F +
+// max_lag, zeros behind F) -> spectra [batch][L/2+1]. The series are processed in batches of <= ~4 GiB of
+// workspace. All reductions have a fixed order (no floating-point atomics): results are reproducible.
+#include <hip/hip_runtime.h>
+#include <hipfft/hipfft.h>
+
+#include <algorithm>
+#include <cmath>
+#include <map>
+#include <tuple>
+#include <vector>
+
+#include "ctx.h"
+
+namespace {
+
+constexpr int MF_SLABS = 16;    // frame slabs of the column-mean pass
+constexpr int MF_SPLITS = 32;   // row splits of the power-spectrum column reduction
+
+// partial[slab][c] = sum over the slab's frames of r[t][c]   (c = axis * E + entity)
+__global__ __launch_bounds__(256) void col_sum_kernel(const double *__restrict__ r, long long F,
+                                                      long long cols, double *__restrict__ partial)
+{
+    const long long c = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    const long long t0 = F * blockIdx.y / gridDim.y, t1 = F * (blockIdx.y + 1) / gridDim.y;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    long long t = t0;
+    for (; t + 4 <= t1; t += 4) {
+        s0 += r[t * cols + c];
+        s1 += r[(t + 1) * cols + c];
+        s2 += r[(t + 2) * cols + c];
+        s3 += r[(t + 3) * cols + c];
+    }
+    for (; t < t1; ++t) s0 += r[t * cols + c];
+    partial[(size_t)blockIdx.y * cols + c] = (s0 + s1) + (s2 + s3);
+}
+
+// mean[c] = scale * sum_slabs partial / F
+__global__ void col_mean_kernel(const double *__restrict__ partial, int slabs, long long F, long long cols,
+                                double scale, double *__restrict__ mean)
+{
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    double s = 0.0;
+    for (int k = 0; k < slabs; ++k) s += partial[(size_t)k * cols + c];
+    mean[c] = scale * s / (double)F;
+}
+
+__device__ inline double block_sum_256(double v, double *red)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// Q[(a * G + g)][t] = sum over the group's entities of (r[t][a][e] * scale - mean[a][e])^2
+__global__ __launch_bounds__(256) void frame_sq_kernel(const double *__restrict__ r,
+                                                       const double *__restrict__ mean, long long E,
+                                                       double scale, const long long *__restrict__ goff,
+                                                       int G, long long F, double *__restrict__ Q)
+{
+    __shared__ double red[4];
+    const long long t = blockIdx.x;
+    const int a = blockIdx.y;
+    const double *row = r + ((size_t)t * 3 + a) * E;
+    const double *m = mean + (size_t)a * E;
+    for (int g = 0; g < G; ++g) {
+        double s = 0.0;
+        for (long long e = goff[g] + threadIdx.x; e < goff[g + 1]; e += 256) {
+            const double v = row[e] * scale - m[e];
+            s += v * v;
+        }
+        s = block_sum_256(s, red);
+        if (threadIdx.x == 0) Q[((size_t)a * G + g) * F + t] = s;
+    }
+}
+
+// pad[c - c_first][t] = t < F ? r[t][c] * scale - mean[c] : 0 for the nb series from c_first, t < L
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const double *__restrict__ r,
+                                                            const double *__restrict__ mean, long long F,
+                                                            long long cols, long long c_first, long long nb,
+                                                            long long L, double scale,
+                                                            double *__restrict__ pad)
+{
+    __shared__ double tile[32][33];
+    const long long c0 = c_first + (long long)blockIdx.x * 32, t0 = (long long)blockIdx.y * 32;
+    const long long c_end = c_first + nb;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    if (t0 < F) {
+        for (int k = ty; k < 32; k += 8) {
+            const long long tt = t0 + k, cc = c0 + tx;
+            tile[k][tx] = (tt < F && cc < c_end) ? r[tt * cols + cc] * scale - mean[cc] : 0.0;
+        }
+        __syncthreads();
+    }
+    for (int k = ty; k < 32; k += 8) {
+        const long long cc = c0 + k, tt = t0 + tx;
+        if (tt < L && cc < c_end) pad[(size_t)(cc - c_first) * L + tt] = t0 < F ? tile[tx][k] : 0.0;
+    }
+}
+
+// partial[split][k] = sum over the split's rows of |spec[row][k]|^2
+__global__ __launch_bounds__(256) void power_rows_kernel(const double2 *__restrict__ spec, long long K,
+                                                         long long row0, long long row1,
+                                                         double *__restrict__ partial)
+{
+    const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    const long long n = row1 - row0;
+    const long long ra = row0 + n * blockIdx.y / gridDim.y, rb = row0 + n * (blockIdx.y + 1) / gridDim.y;
+    double s0 = 0.0, s1 = 0.0;
+    long long q = ra;
+    for (; q + 2 <= rb; q += 2) {
+        const double2 z0 = spec[(size_t)q * K + k], z1 = spec[(size_t)(q + 1) * K + k];
+        s0 += z0.x * z0.x + z0.y * z0.y;
+        s1 += z1.x * z1.x + z1.y * z1.y;
+    }
+    if (q < rb) {
+        const double2 z = spec[(size_t)q * K + k];
+        s0 += z.x * z.x + z.y * z.y;
+    }
+    partial[(size_t)blockIdx.y * K + k] = s0 + s1;
+}
+
+// P[k] += sum over the splits of partial[split][k]
+__global__ void power_fold_kernel(const double *__restrict__ partial, int splits, long long K,
+                                  double *__restrict__ P)
+{
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    double s = 0.0;
+    for (int q = 0; q < splits; ++q) s += partial[(size_t)q * K + k];
+    P[k] += s;
+}
+
+__global__ void real_to_complex_kernel(const double *__restrict__ P, long long n, double2 *__restrict__ Z)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) Z[i] = make_double2(P[i], 0.0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused path (L <= 16384): the whole padded series lives in LDS. One block per CU walks a contiguous range
+// of series of one (axis, group) segment; per series it loads the F samples (coalesced, from the
+// time-major copy), removes the mean, adds the squares into per-lane accumulators (S1), runs an in-place
+// radix-8 decimation-in-frequency transform of the L/2-point complex packing x[2n] + i x[2n+1], untangles
+// the real spectrum and adds |X_k|^2 into per-lane accumulators. Nothing but the two partial sums per block
+// goes back to HBM: the spectra never exist in memory.
+//
+// LDS layout: re[] and im[] as separate double arrays, logical index i stored at i + (i >> 4) so that the
+// stride-2 / stride-16 passes stay at <= 2-way bank conflicts. Twiddles come from a two-level table
+// w^i = A[i >> 7] * B[i & 127] (4 KiB) and w^2..w^7 by multiplication.
+// ---------------------------------------------------------------------------------------------
+
+constexpr int FT_THREADS = 512;                 // 2 waves per SIMD, 256 VGPRs each: the accumulators stay in registers
+constexpr int FT_MAX_M = 13;                  // N = L/2 <= 8192 complex points
+constexpr int FT_PREGS = 17;                  // k = 0..N: <= 17 per lane
+
+struct FftItem {
+    long long c_lo, c_hi;  // series range [c_lo, c_hi) of one segment
+};
+
+__device__ __forceinline__ int ft_skew(int i) { return i + (i >> 4); }
+
+struct Cx {
+    double x, y;
+};
+__device__ __forceinline__ Cx cx_mul(Cx a, Cx b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+__device__ __forceinline__ Cx cx_add(Cx a, Cx b) { return {a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ Cx cx_sub(Cx a, Cx b) { return {a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ Cx cx_mul_mi(Cx a) { return {a.y, -a.x}; }  // a * (-i)
+
+// w_L^i = exp(-2 pi i / L), 0 <= i < L
+__device__ __forceinline__ Cx ft_tw(const double2 *tabA, const double2 *tabB, int i)
+{
+    const double2 a = tabA[i >> 7], b = tabB[i & 127];
+    return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+}
+
+// position of frequency k after the in-place passes (radix 8 ... 8, then 2^rem)
+__device__ __forceinline__ int ft_pos(int k, int m)
+{
+    int p = 0, bits = m;
+    while (bits >= 3) {
+        bits -= 3;
+        p += (k & 7) << bits;
+        k >>= 3;
+    }
+    return p + k;  // the last digit (rem bits) lands at stride 1
+}
+
+__device__ __forceinline__ void dft4(Cx c0, Cx c1, Cx c2, Cx c3, Cx &z0, Cx &z1, Cx &z2, Cx &z3)
+{
+    const Cx d0 = cx_add(c0, c2), d1 = cx_sub(c0, c2), d2 = cx_add(c1, c3), d3 = cx_mul_mi(cx_sub(c1, c3));
+    z0 = cx_add(d0, d2);
+    z2 = cx_sub(d0, d2);
+    z1 = cx_add(d1, d3);
+    z3 = cx_sub(d1, d3);
+}
+
+// In-place DIF transform of the N = 2^m points in re/im (skewed indexing); every thread of the block calls it.
+// tw_shift: twiddle table index of w_N^1 relative to the table's base root (1 for a table of w_{2N}).
+__device__ void ft_transform(double *re, double *im, int m, const double2 *tabA, const double2 *tabB)
+{
+    const int N = 1 << m;
+    int lb = m;  // log2 of the current sub-transform length
+    while (lb >= 3) {
+        const int ls = lb - 3, s = 1 << ls;  // butterfly stride
+        for (int b = threadIdx.x; b < (N >> 3); b += FT_THREADS) {
+            const int j = b & (s - 1), base = (b >> ls) << lb;
+            int idx[8];
+            Cx a[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                idx[q] = ft_skew(base + j + (q << ls));
+                a[q] = {re[idx[q]], im[idx[q]]};
+            }
+            const Cx b0 = cx_add(a[0], a[4]), b4 = cx_sub(a[0], a[4]);
+            const Cx b1 = cx_add(a[1], a[5]), t5 = cx_sub(a[1], a[5]);
+            const Cx b2 = cx_add(a[2], a[6]), t6 = cx_sub(a[2], a[6]);
+            const Cx b3 = cx_add(a[3], a[7]), t7 = cx_sub(a[3], a[7]);
+            constexpr double H = 0.70710678118654752440;
+            const Cx b5 = {(t5.x + t5.y) * H, (t5.y - t5.x) * H};   // t5 * (1 - i)/sqrt2
+            const Cx b6 = cx_mul_mi(t6);                            // t6 * (-i)
+            const Cx b7 = {(t7.y - t7.x) * H, -(t7.x + t7.y) * H};  // t7 * (-1 - i)/sqrt2
+            Cx y[8];
+            dft4(b0, b1, b2, b3, y[0], y[2], y[4], y[6]);
+            dft4(b4, b5, b6, b7, y[1], y[3], y[5], y[7]);
+            if (ls > 0) {
+                // w_len^(j p) = w_L^(j p L / len), L = 2N: table index of p = 1 is j << (m + 1 - lb)
+                const Cx w1 = ft_tw(tabA, tabB, j << (m + 1 - lb));
+                const Cx w2 = cx_mul(w1, w1), w3 = cx_mul(w2, w1), w4 = cx_mul(w2, w2);
+                const Cx w5 = cx_mul(w4, w1), w6 = cx_mul(w4, w2), w7 = cx_mul(w4, w3);
+                y[1] = cx_mul(y[1], w1);
+                y[2] = cx_mul(y[2], w2);
+                y[3] = cx_mul(y[3], w3);
+                y[4] = cx_mul(y[4], w4);
+                y[5] = cx_mul(y[5], w5);
+                y[6] = cx_mul(y[6], w6);
+                y[7] = cx_mul(y[7], w7);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                re[idx[q]] = y[q].x;
+                im[idx[q]] = y[q].y;
+            }
+        }
+        __syncthreads();
+        lb -= 3;
+    }
+    if (lb == 2) {  // contiguous groups of four
+        for (int b = threadIdx.x; b < (N >> 2); b += FT_THREADS) {
+            int idx[4];
+            Cx a[4], y[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                idx[q] = ft_skew(4 * b + q);
+                a[q] = {re[idx[q]], im[idx[q]]};
+            }
+            dft4(a[0], a[1], a[2], a[3], y[0], y[1], y[2], y[3]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                re[idx[q]] = y[q].x;
+                im[idx[q]] = y[q].y;
+            }
+        }
+        __syncthreads();
+    } else if (lb == 1) {
+        for (int b = threadIdx.x; b < (N >> 1); b += FT_THREADS) {
+            const int i0 = ft_skew(2 * b), i1 = ft_skew(2 * b + 1);
+            const Cx a0 = {re[i0], im[i0]}, a1 = {re[i1], im[i1]};
+            re[i0] = a0.x + a1.x;
+            im[i0] = a0.y + a1.y;
+            re[i1] = a0.x - a1.x;
+            im[i1] = a0.y - a1.y;
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ double ft_block_sum(double v, double *red)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < FT_THREADS / 64; ++w) s += red[w];
+    return s;
+}
+
+// LDS bytes of the two fused kernels for N = 2^m
+size_t ft_lds_bytes(int m)
+{
+    const size_t np = ((size_t)1 << m) + ((size_t)1 << m >> 4) + 2;
+    return 2 * np * 8 + 256 * 16 + 32 * 8;
+}
+
+// x: time-major series [cols][F] (already scaled). Qpart [items][F], Ppart [items][N + 1].
+template <int QR>
+__global__ __launch_bounds__(FT_THREADS) void msd_power_lds_kernel(
+    const double *__restrict__ x, int F, int m, const FftItem *__restrict__ items,
+    const double2 *__restrict__ tab, double *__restrict__ Qpart, double *__restrict__ Ppart)
+{
+    extern __shared__ double ft_lds[];
+    const int N = 1 << m, np = N + (N >> 4) + 2;
+    double *re = ft_lds, *im = ft_lds + np;
+    double2 *tabA = reinterpret_cast<double2 *>(im + np), *tabB = tabA + 128;
+    double *red = reinterpret_cast<double *>(tabB + 128);
+    const int tid = threadIdx.x;
+    if (tid < 256) tabA[tid] = tab[tid];
+    const FftItem it = items[blockIdx.x];
+    double qacc[QR], pacc[FT_PREGS];
+#pragma unroll
+    for (int i = 0; i < QR; ++i) qacc[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < FT_PREGS; ++i) pacc[i] = 0.0;
+    const int half = (F + 1) >> 1;  // packed points that hold data
+    for (long long c = it.c_lo; c < it.c_hi; ++c) {
+        const double *row = x + (size_t)c * F;
+        double v[QR];
+        double sum = 0.0;
+#pragma unroll
+        for (int i = 0; i < QR; ++i) {
+            const int t = tid + i * FT_THREADS;
+            v[i] = t < F ? row[t] : 0.0;
+            sum += v[i];
+        }
+        const double mean = ft_block_sum(sum, red) / (double)F;  // (also orders the previous untangle reads)
+#pragma unroll
+        for (int i = 0; i < QR; ++i) {
+            const int t = tid + i * FT_THREADS;
+            if (t < F) {
+                const double d = v[i] - mean;
+                qacc[i] += d * d;
+                const int n = ft_skew(t >> 1);
+                if (t & 1)
+                    im[n] = d;
+                else {
+                    re[n] = d;
+                    if (t == F - 1) im[n] = 0.0;
+                }
+            }
+        }
+        for (int n = half + tid; n < N; n += FT_THREADS) {
+            const int p = ft_skew(n);
+            re[p] = 0.0;
+            im[p] = 0.0;
+        }
+        __syncthreads();
+        ft_transform(re, im, m, tabA, tabB);
+#pragma unroll
+        for (int i = 0; i < FT_PREGS; ++i) {
+            const int k = tid + i * FT_THREADS;
+            if (k <= N) {
+                const int ia = ft_skew(ft_pos(k & (N - 1), m)), ib = ft_skew(ft_pos((N - k) & (N - 1), m));
+                const Cx zk = {re[ia], im[ia]}, zn = {re[ib], im[ib]};
+                const Cx e = {0.5 * (zk.x + zn.x), 0.5 * (zk.y - zn.y)};
+                const Cx o = {0.5 * (zk.y + zn.y), -0.5 * (zk.x - zn.x)};
+                const Cx w = ft_tw(tabA, tabB, k);
+                const Cx xk = cx_add(e, cx_mul(w, o));
+                pacc[i] += xk.x * xk.x + xk.y * xk.y;
+            }
+        }
+        // the next series' block sum has two barriers before LDS is written again
+    }
+    double *q = Qpart + (size_t)blockIdx.x * F, *p = Ppart + (size_t)blockIdx.x * (N + 1);
+#pragma unroll
+    for (int i = 0; i < QR; ++i) {
+        const int t = tid + i * FT_THREADS;
+        if (t < F) q[t] = qacc[i];
+    }
+#pragma unroll
+    for (int i = 0; i < FT_PREGS; ++i) {
+        const int k = tid + i * FT_THREADS;
+        if (k <= N) p[k] = pacc[i];
+    }
+}
+
+// out[s][i] = sum over the items of segment s of part[item][i]
+__global__ void fold_items_kernel(const double *__restrict__ part, const int *__restrict__ seg_item_off,
+                                  long long width, double *__restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= width) return;
+    const int s = blockIdx.y;
+    double acc = 0.0;
+    for (int q = seg_item_off[s]; q < seg_item_off[s + 1]; ++q) acc += part[(size_t)q * width + i];
+    out[(size_t)s * width + i] = acc;
+}
+
+// corr[s][k] = sum_t x(t) x(t+k) summed over the segment = inverse real transform of P[s][0..N], k < n_lags
+__global__ __launch_bounds__(FT_THREADS) void msd_inverse_lds_kernel(const double *__restrict__ P, int m,
+                                                                     const double2 *__restrict__ tab,
+                                                                     int n_lags, double *__restrict__ corr)
+{
+    extern __shared__ double ft_lds[];
+    const int N = 1 << m, np = N + (N >> 4) + 2;
+    double *re = ft_lds, *im = ft_lds + np;
+    double2 *tabA = reinterpret_cast<double2 *>(im + np), *tabB = tabA + 128;
+    const int tid = threadIdx.x;
+    if (tid < 256) tabA[tid] = tab[tid];
+    __syncthreads();
+    const double *p = P + (size_t)blockIdx.x * (N + 1);
+    // packed half-length spectrum of the real, even sequence: conj(Z_k), Z_k = E_k + i O_k
+    for (int k = tid; k < N; k += FT_THREADS) {
+        const double pk = p[k], pn = p[N - k];
+        const double e = 0.5 * (pk + pn), d = 0.5 * (pk - pn);
+        const Cx w = ft_tw(tabA, tabB, k);  // (cos, -sin)
+        const int n = ft_skew(k);
+        re[n] = e + d * w.y;
+        im[n] = -d * w.x;
+    }
+    __syncthreads();
+    ft_transform(re, im, m, tabA, tabB);
+    const double inv = 1.0 / (double)N;
+    double *out = corr + (size_t)blockIdx.x * n_lags;
+    for (int k = tid; k < n_lags; k += FT_THREADS) {
+        const int n = ft_skew(ft_pos(k >> 1, m));
+        out[k] = (k & 1) ? -im[n] * inv : re[n] * inv;
+    }
+}
+
+__global__ __launch_bounds__(256) void transpose_scale_kernel(const double *__restrict__ in,
+                                                              double *__restrict__ out, long long rows,
+                                                              long long cols, double scale)
+{
+    // out[col][row] = in[row][col] * scale, 32x32 tiles through LDS
+    __shared__ double tile[32][33];
+    const long long c0 = (long long)blockIdx.x * 32, r0 = (long long)blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int k = ty; k < 32; k += 8) {
+        const long long rr = r0 + k, cc = c0 + tx;
+        tile[k][tx] = (rr < rows && cc < cols) ? in[rr * cols + cc] * scale : 0.0;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const long long cc = c0 + k, rr = r0 + tx;
+        if (rr < rows && cc < cols) out[cc * rows + rr] = tile[tx][k];
+    }
+}
+
+struct MsdPlans {
+    hipfftHandle h = 0;
+};
+std::map<std::tuple<mdhip_ctx *, long long, long long, int>, MsdPlans> g_msd_plans;
+
+int get_plan(mdhip_ctx *ctx, long long L, long long batch, bool forward, hipfftHandle &out)
+{
+    auto key = std::make_tuple(ctx, L, batch, forward ? 1 : 0);
+    auto it = g_msd_plans.find(key);
+    if (it != g_msd_plans.end()) {
+        out = it->second.h;
+        return MDHIP_OK;
+    }
+    MsdPlans p;
+    int len = (int)L;
+    const int K = len / 2 + 1;
+    hipfftResult rc = forward
+                          ? hipfftPlanMany(&p.h, 1, &len, nullptr, 1, len, nullptr, 1, K, HIPFFT_D2Z, (int)batch)
+                          : hipfftPlanMany(&p.h, 1, &len, nullptr, 1, K, nullptr, 1, len, HIPFFT_Z2D, (int)batch);
+    if (rc != HIPFFT_SUCCESS)
+        return mdhip_fail(ctx, MDHIP_EHIP, "hipfftPlanMany(%lld x %lld) failed (%d)", L, batch, (int)rc);
+    g_msd_plans[key] = p;
+    out = p.h;
+    return MDHIP_OK;
+}
+
+// smallest 2^a 3^b 5^c 7^d >= n
+long long smooth_length(long long n)
+{
+    for (long long m = std::max<long long>(n, 2);; ++m) {
+        long long q = m;
+        for (int p : {2, 3, 5, 7})
+            while (q % p == 0) q /= p;
+        if (q == 1) return m;
+    }
+}
+
+// host: prefix sums of Q, S1 - 2 S2, normalisation as lag_msd_finish_kernel; returns the error bound.
+// corr[s][k] * corr_scale = S2(k) of segment s = axis * G + group; row length corr_row.
+double finish_on_host(long long F, long long G, long long n_lags, const int64_t *group_off, const double *Q,
+                      const double *corr, long long corr_row, double corr_scale, long long L, double *out)
+{
+    const double eps_l = 4.0 * 2.220446049250313e-16 * std::log2((double)L);
+    double worst = 0.0;
+    std::vector<long double> pre((size_t)F + 1);
+    for (long long g = 0; g < G; ++g) {
+        const double n_g = (double)(group_off[g + 1] - group_off[g]);
+        for (int a = 0; a < 3; ++a) {
+            const size_t s = (size_t)a * G + g;
+            pre[0] = 0.0L;
+            for (long long t = 0; t < F; ++t) pre[t + 1] = pre[t] + (long double)Q[s * F + t];
+            for (long long k = 0; k < n_lags; ++k) {
+                const long double s1 = pre[F - k] + (pre[F] - pre[k]);
+                const long double s2 = (long double)corr[s * corr_row + k] * (long double)corr_scale;
+                const double cnt = (double)(F - k) * n_g;
+                double v = (double)(s1 - 2.0L * s2);
+                if (k == 0) v = 0.0;  // exactly, as the difference form gives
+                out[((size_t)k * G + g) * 4 + a] = cnt > 0.0 ? v / cnt : 0.0;
+                if (k > 0 && v != 0.0) worst = std::max(worst, eps_l * (double)s1 / std::fabs(v));
+            }
+        }
+        for (long long k = 0; k < n_lags; ++k) {
+            double *o = out + ((size_t)k * G + g) * 4;
+            o[3] = (o[0] + o[1]) + o[2];
+        }
+    }
+    return worst;
+}
+
+// The fused LDS path: L = 2^(m+1) <= 16384.
+int lag_msd_fft_fused(mdhip_ctx *ctx, long long F, long long E, const double *d_r, double scale, int max_lag,
+                      long long G, const int64_t *group_off, int m, double *out, double *rel_bound)
+{
+    const long long n_lags = (long long)max_lag + 1, cols = 3 * E, S = 3 * G;
+    const long long N = 1LL << m, L = 2 * N;
+    // work items: every non-empty segment gets a share of ~one block per CU, each a contiguous series range
+    std::vector<FftItem> items;
+    std::vector<int> seg_off((size_t)S + 1, 0);
+    for (long long s = 0; s < S; ++s) {
+        const long long a = s / G, g = s % G;
+        const long long lo = a * E + group_off[g], hi = a * E + group_off[g + 1], n = hi - lo;
+        seg_off[s] = (int)items.size();
+        if (n <= 0) continue;
+        long long k = (n * ctx->cu_count + cols / 2) / cols;
+        k = std::max<long long>(1, std::min(k, n));
+        for (long long q = 0; q < k; ++q) items.push_back({lo + n * q / k, lo + n * (q + 1) / k});
+    }
+    seg_off[S] = (int)items.size();
+    const long long n_items = (long long)items.size();
+
+    // twiddle table of w_L: A[i] = w^(128 i), B[i] = w^i
+    std::vector<double> tab(512);
+    const long double step = -2.0L * 3.14159265358979323846264338327950288L / (long double)L;
+    for (int i = 0; i < 128; ++i) {
+        const long long ia = (128LL * i) % L;
+        tab[2 * i] = (double)cosl(step * ia);
+        tab[2 * i + 1] = (double)sinl(step * ia);
+        tab[256 + 2 * i] = (double)cosl(step * (i % L));
+        tab[256 + 2 * i + 1] = (double)sinl(step * (i % L));
+    }
+
+    MD_WS(d_x, double, WS_AUX1, (size_t)cols * F * 8 + 256);
+    const size_t qp_b = (size_t)n_items * F * 8, pp_b = (size_t)n_items * (N + 1) * 8;
+    MD_WS(d_part, double, WS_PART, qp_b + pp_b);
+    double *d_Qpart = d_part, *d_Ppart = d_part + (size_t)n_items * F;
+    const size_t q_b = (size_t)S * F * 8, p_b = (size_t)S * (N + 1) * 8, c_b = (size_t)S * n_lags * 8;
+    const size_t it_b = (size_t)n_items * sizeof(FftItem), so_b = ((size_t)S + 1) * 4;
+    MD_WS(d_small, unsigned char, WS_AUX3, q_b + p_b + c_b + 4096 + it_b + so_b + 64);
+    double *d_Q = reinterpret_cast<double *>(d_small);
+    double *d_P = reinterpret_cast<double *>(d_small + q_b);
+    double *d_corr = reinterpret_cast<double *>(d_small + q_b + p_b);
+    double2 *d_tab = reinterpret_cast<double2 *>(d_small + q_b + p_b + c_b);
+    FftItem *d_items = reinterpret_cast<FftItem *>(d_small + q_b + p_b + c_b + 4096);
+    int *d_seg_off = reinterpret_cast<int *>(d_small + q_b + p_b + c_b + 4096 + it_b);
+    MD_HIP(hipMemcpyAsync(d_tab, tab.data(), 4096, hipMemcpyHostToDevice, ctx->stream));
+    MD_HIP(hipMemcpyAsync(d_items, items.data(), it_b, hipMemcpyHostToDevice, ctx->stream));
+    MD_HIP(hipMemcpyAsync(d_seg_off, seg_off.data(), so_b, hipMemcpyHostToDevice, ctx->stream));
+    MD_HIP(hipStreamSynchronize(ctx->stream));  // the tables above are locals
+
+    const size_t lds_b = ft_lds_bytes(m);
+    KernelTimer timer(ctx);
+    hipLaunchKernelGGL(transpose_scale_kernel, dim3((unsigned)((cols + 31) / 32), (unsigned)((F + 31) / 32)), dim3(256),
+                       0, ctx->stream, d_r, d_x, F, cols, scale);
+    MD_HIP(hipGetLastError());
+    const int qr = (int)((F + FT_THREADS - 1) / FT_THREADS);
+#define MD_FT_CASE(QR)                                                                                         \
+    {                                                                                                          \
+        MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msd_power_lds_kernel<QR>),                   \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));                   \
+        hipLaunchKernelGGL(msd_power_lds_kernel<QR>, dim3((unsigned)n_items), dim3(FT_THREADS), lds_b,         \
+                           ctx->stream, d_x, (int)F, m, d_items, d_tab, d_Qpart, d_Ppart);                     \
+    }
+    if (qr <= 1) MD_FT_CASE(1)
+    else if (qr <= 2) MD_FT_CASE(2)
+    else if (qr <= 4) MD_FT_CASE(4)
+    else if (qr <= 8) MD_FT_CASE(8)
+    else if (qr <= 10) MD_FT_CASE(10)
+    else if (qr <= 12) MD_FT_CASE(12)
+    else if (qr <= 16) MD_FT_CASE(16)
+    else if (qr <= 24) MD_FT_CASE(24)
+    else MD_FT_CASE(32)
+#undef MD_FT_CASE
+    MD_HIP(hipGetLastError());
+    hipLaunchKernelGGL(fold_items_kernel, dim3((unsigned)((F + 255) / 256), (unsigned)S), dim3(256), 0, ctx->stream,
+                       d_Qpart, d_seg_off, F, d_Q);
+    hipLaunchKernelGGL(fold_items_kernel, dim3((unsigned)((N + 1 + 255) / 256), (unsigned)S), dim3(256), 0,
+                       ctx->stream, d_Ppart, d_seg_off, N + 1, d_P);
+    MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msd_inverse_lds_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+    hipLaunchKernelGGL(msd_inverse_lds_kernel, dim3((unsigned)S), dim3(FT_THREADS), lds_b, ctx->stream, d_P, m, d_tab,
+                       (int)n_lags, d_corr);
+    MD_HIP(hipGetLastError());
+    timer.stop();
+    ctx->last_kernel = "msd_power_lds_kernel";
+
+    std::vector<double> Q((size_t)S * F), corr((size_t)S * n_lags);
+    MD_HIP(hipMemcpyAsync(Q.data(), d_Q, q_b, hipMemcpyDeviceToHost, ctx->stream));
+    MD_HIP(hipMemcpyAsync(corr.data(), d_corr, c_b, hipMemcpyDeviceToHost, ctx->stream));
+    MD_HIP(hipStreamSynchronize(ctx->stream));
+    timer.collect();
+    const double worst = finish_on_host(F, G, n_lags, group_off, Q.data(), corr.data(), n_lags, 1.0, L, out);
+    if (rel_bound) *rel_bound = worst;
+    return MDHIP_OK;
+}
+
+}  // namespace
+
+// d_r: device [F][3][E]. out: host [max_lag+1][G][4] means as mdhip_lag_msd. *rel_bound: the largest
+// estimated relative rounding error over all (lag >= 1, group, axis) entries with a non-zero value.
+int mdhip_lag_msd_fft(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *d_r, double scale,
+                      int max_lag, int n_groups, const int64_t *group_off, double *out, double *rel_bound)
+{
+    const long long F = n_frames, E = n_ent, G = n_groups;
+    const long long n_lags = (long long)max_lag + 1;
+    const long long cols = 3 * E;
+    if (ctx->opt_lag_variant != 4) {
+        // fused LDS path when the padded series fits: L = power of two >= max(16, F + max_lag)
+        int m = 3;
+        while ((2LL << m) < F + max_lag) ++m;
+        if (m <= FT_MAX_M && ft_lds_bytes(m) <= ctx->lds_max)
+            return lag_msd_fft_fused(ctx, F, E, d_r, scale, max_lag, G, group_off, m, out, rel_bound);
+    }
+    const long long L = smooth_length(F + max_lag);
+    MD_REQUIRE(L < (1LL << 30), "series too long for the FFT path (%lld)", L);
+    const long long K = L / 2 + 1;
+    const long long S = 3 * G;  // (axis, group) segments
+
+    // batches of whole series: padded copy + spectrum <= ~4 GiB
+    const long long per_series = L * 8 + K * 16;
+    const long long nb_max = std::max<long long>(1, std::min<long long>((4LL << 30) / per_series, (1LL << 31) / K));
+    const long long n_batches = (cols + nb_max - 1) / nb_max;
+    const long long nb0 = (cols + n_batches - 1) / n_batches;
+
+    MD_WS(d_mean, double, WS_AUX0, (size_t)(MF_SLABS + 1) * cols * 8);
+    double *d_msum = d_mean + cols;
+    MD_WS(d_pad, double, WS_AUX1, (size_t)nb0 * L * 8);
+    MD_WS(d_spec, double2, WS_AUX2, (size_t)nb0 * K * 16);
+    // Q [S][F] | P [S][K] | complex P [S][K] | correlations [S][L] | group offsets
+    const size_t q_b = (size_t)S * F * 8, p_b = (size_t)S * K * 8, z_b = (size_t)S * K * 16, c_b = (size_t)S * L * 8;
+    MD_WS(d_small, unsigned char, WS_AUX3, q_b + p_b + z_b + c_b + (size_t)(G + 1) * 8 + 256);
+    double *d_Q = reinterpret_cast<double *>(d_small);
+    double *d_P = reinterpret_cast<double *>(d_small + q_b);
+    double2 *d_Z = reinterpret_cast<double2 *>(d_small + q_b + p_b);
+    double *d_corr = reinterpret_cast<double *>(d_small + q_b + p_b + z_b);
+    long long *d_goff = reinterpret_cast<long long *>(d_small + q_b + p_b + z_b + c_b);
+    MD_WS(d_part, double, WS_PART, (size_t)MF_SPLITS * K * 8);
+
+    MD_HIP(hipMemcpyAsync(d_goff, group_off, (size_t)(G + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    MD_HIP(hipMemsetAsync(d_P, 0, p_b, ctx->stream));
+    MD_HIP(hipStreamSynchronize(ctx->stream));  // group_off is the caller's memory
+
+    KernelTimer timer(ctx);
+    hipLaunchKernelGGL(col_sum_kernel, dim3((unsigned)((cols + 255) / 256), MF_SLABS), dim3(256), 0, ctx->stream,
+                       d_r, F, cols, d_msum);
+    hipLaunchKernelGGL(col_mean_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, ctx->stream, d_msum,
+                       MF_SLABS, F, cols, scale, d_mean);
+    hipLaunchKernelGGL(frame_sq_kernel, dim3((unsigned)F, 3), dim3(256), 0, ctx->stream, d_r, d_mean, E, scale,
+                       d_goff, (int)G, F, d_Q);
+    MD_HIP(hipGetLastError());
+
+    for (long long c_first = 0; c_first < cols; c_first += nb0) {
+        const long long nb = std::min(nb0, cols - c_first);
+        hipfftHandle fwd;
+        int rc = get_plan(ctx, L, nb, true, fwd);
+        if (rc) return rc;
+        hipfftSetStream(fwd, ctx->stream);
+        hipLaunchKernelGGL(transpose_pad_kernel, dim3((unsigned)((nb + 31) / 32), (unsigned)((L + 31) / 32)),
+                           dim3(256), 0, ctx->stream, d_r, d_mean, F, cols, c_first, nb, L, scale, d_pad);
+        MD_HIP(hipGetLastError());
+        if (hipfftExecD2Z(fwd, d_pad, reinterpret_cast<hipfftDoubleComplex *>(d_spec)) != HIPFFT_SUCCESS)
+            return mdhip_fail(ctx, MDHIP_EHIP, "hipfftExecD2Z failed");
+        // the (axis, group) segments this batch touches
+        for (long long s = 0; s < S; ++s) {
+            const long long a = s / G, g = s % G;
+            const long long lo = std::max(c_first, a * E + (long long)group_off[g]);
+            const long long hi = std::min(c_first + nb, a * E + (long long)group_off[g + 1]);
+            if (lo >= hi) continue;
+            const int splits = (int)std::min<long long>(MF_SPLITS, hi - lo);
+            hipLaunchKernelGGL(power_rows_kernel, dim3((unsigned)((K + 255) / 256), (unsigned)splits), dim3(256), 0,
+                               ctx->stream, d_spec, K, lo - c_first, hi - c_first, d_part);
+            hipLaunchKernelGGL(power_fold_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, ctx->stream,
+                               d_part, splits, K, d_P + (size_t)s * K);
+        }
+        MD_HIP(hipGetLastError());
+    }
+    hipfftHandle inv;
+    int rc = get_plan(ctx, L, S, false, inv);
+    if (rc) return rc;
+    hipfftSetStream(inv, ctx->stream);
+    hipLaunchKernelGGL(real_to_complex_kernel, dim3((unsigned)((S * K + 255) / 256)), dim3(256), 0, ctx->stream, d_P,
+                       S * K, d_Z);
+    if (hipfftExecZ2D(inv, reinterpret_cast<hipfftDoubleComplex *>(d_Z), d_corr) != HIPFFT_SUCCESS)
+        return mdhip_fail(ctx, MDHIP_EHIP, "hipfftExecZ2D failed");
+    timer.stop();
+    ctx->last_kernel = "lag_msd_fft";
+
+    std::vector<double> Q((size_t)S * F), corr((size_t)S * L);
+    MD_HIP(hipMemcpyAsync(Q.data(), d_Q, q_b, hipMemcpyDeviceToHost, ctx->stream));
+    MD_HIP(hipMemcpyAsync(corr.data(), d_corr, c_b, hipMemcpyDeviceToHost, ctx->stream));
+    MD_HIP(hipStreamSynchronize(ctx->stream));
+    timer.collect();
+
+    const double worst = finish_on_host(F, G, n_lags, group_off, Q.data(), corr.data(), L, 1.0 / (double)L, L, out);
+    if (rel_bound) *rel_bound = worst;
+    return MDHIP_OK;
+}

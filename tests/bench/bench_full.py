@@ -127,6 +127,11 @@ def main():
         np.testing.assert_allclose(lag[1:, 0, 3] / (3 * 0.01 * np.arange(1, F)), 1.0, atol=0.2)
         k_lag = ctx.last_kernel_ms()[0]
         fp_all = F * (F - 1) / 2
+        ctx.set_option("lag_variant", 2)
+        t_lagf, lagf = wall(lambda: B.lag_msd(r, F - 1, [0, E], scale=1.0), sync)
+        k_lagf, bound = ctx.last_kernel_ms()[0], ctx.last_rel_bound()
+        ctx.set_option("lag_variant", 1)
+        fft_err = float(np.max(np.abs(lagf[1:] - lag[1:]) / lag[1:]))
         # CPU: the oracle's single-origin loop on 40 frame pairs of the full 50k entities
         rs = r[:41].cpu().numpy()
         tc0 = time.perf_counter()
@@ -146,6 +151,8 @@ def main():
              fp64_TFLOPs_kernel=12.0 * E * fp_all / (k_lag * 1e-3) / 1e12,
              fp64_frac_kernel=12.0 * E * fp_all / (k_lag * 1e-3) / 78.6e12,
              cpu_extrapolated_s=cpu_msd * fp_all)
+        emit(config="C4 full lag x origin msd, FFT variant", gpu_wall_s=t_lagf, device_s=k_lagf * 1e-3,
+             frame_pairs_per_s=fp_all / t_lagf, max_rel_diff_vs_difference_kernel=fft_err, reported_bound=bound)
         del r, com_d
         torch.cuda.empty_cache()
 

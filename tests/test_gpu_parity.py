@@ -334,6 +334,57 @@ def test_lag_msd_vs_oracle(B):
             np.testing.assert_allclose(out[:, g, :], expect, rtol=1e-10, atol=1e-12)
 
 
+def test_lag_msd_fft_variant(B):
+    """The autocorrelation-theorem path (lag_variant 2) against the oracle and the difference kernel: random
+    walks far from the origin with ragged / empty / single-entity groups, a scale factor, max_lag < F - 1;
+    agreement within the bound the library reports (and within 1e-9 here). Variant 3 hands a ballistic
+    trajectory, whose bound is too loose, back to the difference kernel."""
+    ctx = B.default_context()
+    rng = np.random.default_rng(33)
+    try:
+        for F, E, goff, max_lag in [(40, 70, [0, 30, 30, 70], 39), (300, 5, [0, 5], 299), (2100, 3, [0, 1, 3], 2099),
+                                    (1000, 400, [0, 150, 400], 250), (17, 1, [0, 1], 16), (5, 3, [0, 3], 4),
+                                    (2, 2, [0, 2], 1), (100, 9, [0, 9], 0), (6000, 2, [0, 2], 5999),
+                                    (9000, 2, [0, 1, 2], 7000), (700, 20, [0, 20], 300), (130, 6, [0, 6], 120)]:
+            r = np.cumsum(rng.normal(0, 0.1, (F, 3, E)), axis=0) + rng.uniform(-500, 500, (1, 3, E))
+            ctx.set_option("lag_variant", 1)
+            exact = B.lag_msd(r, max_lag, goff, scale=0.5)
+            assert ctx.last_rel_bound() == 0.0
+            for variant in (2, 4):   # fused LDS transform / hipFFT batches
+                ctx.set_option("lag_variant", variant)
+                fft = B.lag_msd(r, max_lag, goff, scale=0.5)
+                bound = ctx.last_rel_bound()
+                assert (ctx.last_kernel_name() == "lag_msd_fft") == (variant == 4)
+                assert ctx.last_kernel_name() in ("lag_msd_fft", "msd_power_lds_kernel") and (bound > 0.0) == (max_lag > 0) and bound < 1e-9, (F, bound)
+                assert fft.shape == exact.shape and (fft[0] == 0.0).all()
+                nz = exact > 0
+                rel = np.abs(fft[nz] - exact[nz]) / exact[nz]
+                assert not nz.any() or rel.max() <= max(bound, 1e-13), (F, rel.max(), bound)
+                assert (fft[~nz] == 0.0).all()          # the empty group and lag 0
+                for g in range(len(goff) - 1):
+                    if goff[g + 1] > goff[g]:
+                        sub = 0.5 * r[:, :, goff[g]:goff[g + 1]].transpose(0, 2, 1)
+                        np.testing.assert_allclose(fft[:, g, :], O.lag_msd_full(sub, max_lag), rtol=1e-9, atol=1e-12)
+        # ballistic: <x^2> / MSD(1) ~ F^2, the bound exceeds 1e-10 and variant 3 falls back
+        v = rng.normal(0, 1, (3, 50))
+        traj = rng.uniform(0, 50, (1, 3, 50)) + v[None] * np.arange(4000)[:, None, None]
+        ctx.set_option("lag_variant", 2)
+        B.lag_msd(traj, 3999, [0, 50])
+        assert ctx.last_rel_bound() > 1e-10
+        ctx.set_option("lag_variant", 3)
+        out3 = B.lag_msd(traj, 3999, [0, 50])
+        assert ctx.last_rel_bound() == 0.0 and ctx.last_kernel_name().startswith("lag_msd_")
+        ctx.set_option("lag_variant", 1)
+        np.testing.assert_array_equal(out3, B.lag_msd(traj, 3999, [0, 50]))
+        # diffusive data: variant 3 keeps the FFT answer
+        r = np.cumsum(rng.normal(0, 0.1, (500, 3, 64)), axis=0)
+        ctx.set_option("lag_variant", 3)
+        B.lag_msd(r, 499, [0, 64])
+        assert ctx.last_kernel_name() == "msd_power_lds_kernel" and 0.0 < ctx.last_rel_bound() <= 1e-10
+    finally:
+        ctx.set_option("lag_variant", 1)
+
+
 # ------------------------------------------------------------------ G2-G4
 def test_xcorr_golden(B, g_acf):
     g = g_acf
