@@ -47,6 +47,8 @@ enum WsSlot {
     WS_GSPH4_J,
     WS_SLICES,     // per-block histogram copies of the scalar-j kernel
     WS_ROWS,       // their sums per output frame
+    WS_REL,        // packed-f32 tile-relative records (scalar-j MODE 3)
+    WS_CEN,        // tile centres + half extents
     WS_COUNT
 };
 
@@ -87,6 +89,8 @@ struct mdhip_ctx {
     int opt_rdf_slots = 16;   // replicas of the frame-summed histogram in HBM
     int opt_rdf_inflight = 1; // per-frame output: frames in flight per XCD (their records should stay in its L2)
     int opt_rdf_rows = -1;    // scalar-j RDF: -1/1 ordered-pair rows without a row table when they fit, 0 class rows + table
+    int opt_rdf_pk = -1;      // scalar-j RDF with ordered rows: -1/1 packed-f32 classification sweep with the exact
+                              // deferred resolver (MODE 3) when its error bound allows, 0 the all-f64 sweep (MODE 2)
     int opt_rdf_sort = -1;    // spatial sort: -1 auto, 1 one block per frame (LDS counters), 0 multi-block (global counters)
     int opt_xcorr_tile = 0;
     int opt_lag_variant = 1;  // full-lag MSD: 1 = series-resident LDS kernel when it fits, 0 = staged kernel,

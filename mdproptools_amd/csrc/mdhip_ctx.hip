@@ -195,6 +195,8 @@ int mdhip_set_option(mdhip_ctx *ctx, const char *key, int value)
         ctx->opt_rdf_rows = value;
     else if (!strcmp(key, "rdf_sort"))
         ctx->opt_rdf_sort = value;
+    else if (!strcmp(key, "rdf_pk"))
+        ctx->opt_rdf_pk = value;
     else if (!strcmp(key, "lag_variant"))
         ctx->opt_lag_variant = value;
     else if (!strcmp(key, "rdf_slots"))

@@ -53,6 +53,12 @@ struct PairArgs {
     unsigned *slices;            // scalar-j kernels: [blocks][LDS histogram words], every block stores its own copy
     const double4 *aos_j;        // sorted records of the j set (== aos for atom-atom), [F][nTj*256]
     int tri;                     // 1: atom-atom (i < j inside the diagonal tile), 0: atoms x sites
+    // packed-f32 classification sweep (MODE 3 of the scalar-j kernel, pair_sj.hip)
+    const float *rel;            // [F][nTj*128][8] f32 records of the j set relative to their tile's centre, two atoms
+                                 // per record: (x0, x1, y0, y1, z0, z1, w0, w1), w = the bin-guess addend of pack_w
+    const double *cen;           // [F][nTj][8] tile centre (x, y, z) and half extents (hx, hy, hz) of the sorted tiles
+    float s_cap;                 // largest |relative coordinate| sum (i + j, per axis) the error bound `near` covers
+    float rc2hi;                 // f32 pre-filter: every in-cutoff pair has rsq32 < rc2hi (see pk_error_bound)
 };
 
 __device__ __forceinline__ double wrap_abs(double d, double L)
@@ -119,6 +125,8 @@ __device__ __forceinline__ double pack_w(int t, int n_ti, float near, int row_le
 // `aos` [F][nT*256], tile boxes `bbox` [F][nT][6], 8-atom and 64-atom boxes `gs` / `ws`. `slot` = workspace ids of
 // {records, tile boxes, group boxes, wave boxes}; keys, cell counters and the SoA copy are shared scratch.
 struct SortedSet {
+    const float *rel = nullptr;   // packed-f32 records (tile-relative), see PairArgs::rel
+    const double *cen = nullptr;  // tile centres and half extents
     const double4 *aos = nullptr;
     const double *bbox = nullptr;
     const float4 *gs = nullptr, *ws = nullptr, *gs4 = nullptr;
@@ -138,7 +146,11 @@ void launch_reduce_slots(hipStream_t stream, const unsigned long long *in, unsig
 // pair_sj.hip
 size_t lds_bytes_sj(int nbins, int n_cls, int n_ti, int n_tj, bool mode_cn);
 size_t lds_bytes_sj_ordered(int nbins, int n_ti, int n_tj);
-PairKernel sj_kernel(int mode /* 0 RDF class rows, 1 CN, 2 RDF ordered-pair rows */, bool persist, const char **name);
+size_t lds_bytes_sj_pk(int nbins, int n_ti, int n_tj);
+PairKernel sj_kernel(int mode /* 0 RDF class rows, 1 CN, 2 RDF ordered-pair rows, 3 = 2 with the packed-f32 sweep */,
+                     bool persist, const char **name);
+// error bound (in bins) of the packed-f32 bin guess for |relative coordinates| <= s_cap per axis pair sum; 0 = not usable
+double pk_error_bound(double r_cut, double bin_size, int nbins, int n_tj, double s_cap, double l_max);
 void launch_merge_slices(hipStream_t stream, const unsigned *slices, int hist_words, long long n_blocks, int per_frame,
                          int bpf, unsigned grid_y, unsigned long long *rows);
 
@@ -147,7 +159,7 @@ constexpr int MORTON_BITS = 5;                       // 32 cells per axis
 constexpr int MORTON_CELLS = 1 << (3 * MORTON_BITS); // 32768
 int cull_prepare_set(mdhip_ctx *ctx, int64_t F, const double *d_x, const int *d_t, long long t_fs,
                      const double *d_box, long long N, int nT, int n_ti, float near, int row_len, bool want_soa,
-                     const int slot[5], SortedSet &out);
+                     bool want_rel, const int slot[5], SortedSet &out);
 void launch_cull_lists(hipStream_t stream, bool tri, int64_t F, const double *bbox_i, const double *bbox_j, int nTi,
                        int nTj, const double *d_box, double rc2_test, unsigned short *list, int *cnt);
 

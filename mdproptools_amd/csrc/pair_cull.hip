@@ -266,7 +266,8 @@ __global__ void cull_scatter_kernel(const double *__restrict__ xyz, const int *_
 __global__ __launch_bounds__(TILE) void cull_boxes_kernel(const double4 *__restrict__ aos,
                                                           const double *__restrict__ box, long long n, int nT,
                                                           double *__restrict__ bbox, float4 *__restrict__ gboxes,
-                                                          float4 *__restrict__ wboxes, float4 *__restrict__ g4boxes)
+                                                          float4 *__restrict__ wboxes, float4 *__restrict__ g4boxes,
+                                                          double *__restrict__ cen, float *__restrict__ rel)
 {
     __shared__ double red[6][TILE / 64];
     const int f = blockIdx.y, T = blockIdx.x, tid = threadIdx.x;
@@ -335,6 +336,33 @@ __global__ __launch_bounds__(TILE) void cull_boxes_kernel(const double4 *__restr
             v = tid < 3 ? __builtin_fmin(v, red[tid][w]) : __builtin_fmax(v, red[tid][w]);
         bbox[((size_t)f * nT + T) * 6 + tid] = v;
     }
+    if (rel) {
+        // packed-f32 sweep (pair_sj.hip MODE 3): the tile's atoms relative to the centre c of its box, rounded to
+        // f32 — |x - c| <= half extent, so the rounding error is 2^-24 of a few Angstrom instead of 2^-24 of the
+        // coordinate. c and the half extents go to cen[f][T][8]; every thread derives the same doubles.
+        double c[3], hext[3];
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            double l = red[ax][0], h = red[3 + ax][0];
+            for (int w = 1; w < TILE / 64; ++w) {
+                l = __builtin_fmin(l, red[ax][w]);
+                h = __builtin_fmax(h, red[3 + ax][w]);
+            }
+            c[ax] = 0.5 * (l + h);
+            hext[ax] = __builtin_fmax(h - c[ax], c[ax] - l);
+        }
+        if (tid < 3) {
+            cen[((size_t)f * nT + T) * 8 + tid] = c[tid];
+            cen[((size_t)f * nT + T) * 8 + 3 + tid] = hext[tid];
+        }
+        // two atoms per 32-byte record: (x0, x1, y0, y1, z0, z1, w0, w1); pad atoms sit 1e18 away (rsq32 = 3e36:
+        // finite, never in cutoff)
+        float *o = rel + (((size_t)f * nT + T) * (TILE / 2) + (tid >> 1)) * 8 + (tid & 1);
+        o[0] = real ? (float)(me.x - c[0]) : 1.0e18f;
+        o[2] = real ? (float)(me.y - c[1]) : 1.0e18f;
+        o[4] = real ? (float)(me.z - c[2]) : 1.0e18f;
+        o[6] = __int_as_float(__double2hiint(me.w));
+    }
 }
 
 // Lower bound of the reference's per-axis distance min(|d|, ||d| - L|) = dist(d, {0, +L, -L}) over all
@@ -389,8 +417,10 @@ __global__ __launch_bounds__(256) void cull_list_kernel(const double *__restrict
 
 int cull_prepare_set(mdhip_ctx *ctx, int64_t F, const double *d_x, const int *d_t, long long t_fs,
                      const double *d_box, long long N, int nT, int n_ti, float near, int row_len, bool want_soa,
-                     const int slot[5], SortedSet &out)
+                     bool want_rel, const int slot[5], SortedSet &out)
 {
+    MD_WS(d_rel, float, WS_REL, want_rel ? (size_t)F * nT * TILE * 16 : 64);
+    MD_WS(d_cen, double, WS_CEN, want_rel ? (size_t)F * nT * 64 : 64);
     MD_WS(d_sx, double, WS_SORT_XYZ, want_soa ? (size_t)F * 3 * N * 8 : 64);
     MD_WS(d_st, int, WS_SORT_TYPE, want_soa ? (size_t)F * N * 4 : 64);
     MD_WS(d_keys, unsigned short, WS_KEYS, (size_t)F * N * 2);
@@ -423,8 +453,11 @@ int cull_prepare_set(mdhip_ctx *ctx, int64_t F, const double *d_x, const int *d_
                            row_len);
     }
     hipLaunchKernelGGL(cull_boxes_kernel, dim3((unsigned)nT, (unsigned)F), dim3(TILE), 0, ctx->stream, d_ao, d_box, N,
-                       nT, d_bbox, d_gs, d_ws, d_g4);
+                       nT, d_bbox, d_gs, d_ws, d_g4, want_rel ? d_cen : (double *)nullptr,
+                       want_rel ? d_rel : (float *)nullptr);
     MD_HIP(hipGetLastError());
+    out.rel = want_rel ? d_rel : nullptr;
+    out.cen = want_rel ? d_cen : nullptr;
     out.aos = d_ao;
     out.bbox = d_bbox;
     out.gs = d_gs;

@@ -26,6 +26,9 @@
 //   pair_dense.hip  LDS-tile kernels: dense half-shell sweep for small frames, the edge-table kernel of the
 //                   first commit (A/B baseline, fallback for > 64 CN cutoffs)
 // This file: relations -> classes, edge tables, batching, launch geometry, rows -> outputs, the C-ABI.
+#include <cstdio>
+#include <cstdlib>
+
 #include "pair_common.h"
 
 using namespace mdpair;
@@ -52,6 +55,7 @@ struct PairProblem {
     const double *edges;  // host [nbins+1]
     double rc2;
     float gscale;
+    double bin_size;  // RDF: the reference's bin_size (0 for CN edge tables)
     int per_frame;
 };
 
@@ -112,6 +116,37 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         const double maxg = (double)p.n_tj * (p.nbins + 1) + 1.0;  // the addend carries tj * row_len only
         const double ulp = std::ldexp(1.0, (int)std::floor(std::log2(maxg)) - 23);
         near_ord = (float)(2.0 * ((double)p.nbins * 2.1e-7 + ulp) + 1.0e-5);
+    }
+    // Packed-f32 classification (MODE 3 of the scalar-j kernel, header in pair_sj.hip): usable when the cutoff sits
+    // on a bin edge (then the band of that edge also decides in/out of the cutoff) and the error band is narrow.
+    bool pk = false;
+    float s_cap = 0.f, rc2hi = 0.f;
+    if (ordered && ctx->opt_rdf_pk != 0 && p.bin_size > 0.0) {
+        const double r_cut = std::sqrt(p.rc2);
+        const double cpos = r_cut / p.bin_size, K = std::floor(cpos + 0.5);
+        double l_max = 0.0, v_max = 0.0;
+        for (int64_t f = 0; f < F; ++f) {
+            const double *b = p.h_box + 3 * f;
+            l_max = std::max(l_max, std::max(b[0], std::max(b[1], b[2])));
+            v_max = std::max(v_max, b[0] * b[1] * b[2]);
+        }
+        const double edge = std::cbrt((double)TILE * v_max / (double)p.ni);
+        const double cap = r_cut + 3.5 * edge;
+        const double err = pk_error_bound(r_cut, p.bin_size, p.nbins, p.n_tj, cap, l_max);
+        const double u = std::ldexp(1.0, -24);
+        const double near_pk = 2.0 * err + 4.5 * u * (p.nbins + 1) + 2.0e-5;
+        if (std::getenv("MDHIP_PK_DEBUG"))
+            fprintf(stderr, "pk: cpos %.9f K %.0f nbins %d err %.3e near %.3e cap %.2f lmax %.2f lds %zu\n", cpos, K,
+                    p.nbins, err, near_pk, cap, l_max, lds_bytes_sj_pk(p.nbins, p.n_ti, p.n_tj));
+        if (std::fabs(cpos - K) <= 1e-6 && (K == (double)p.nbins || K == (double)p.nbins + 1.0) &&
+            near_pk <= 0.02 && lds_bytes_sj_pk(p.nbins, p.n_ti, p.n_tj) <= lds_cap / 4 && std::isfinite(l_max)) {
+            pk = true;
+            near_ord = std::max(near_ord, (float)near_pk);
+            s_cap = (float)cap;
+            // every pair with rsq < r_cut^2 has sqrt(rsq32) <= r_cut + err * bin_size
+            const double r_hi = r_cut + err * p.bin_size;
+            rc2hi = std::nextafterf((float)(r_hi * r_hi * (1.0 + 2.0 * u)), std::numeric_limits<float>::infinity());
+        }
     }
     const int n_pass = (p.n_cls + cls_per_pass - 1) / cls_per_pass;
 
@@ -183,6 +218,8 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
     double prep_ms = 0.0;
     bool prep_timed = false;
     const double4 *d_aos_j = nullptr;
+    const float *d_rel = nullptr;
+    const double *d_cen = nullptr;
     if (cull) {
         const long long N = p.ni;
         const bool want_soa = ctx->opt_rdf_sj == 0;  // only the LDS-tile kernel (atom-atom) reads the SoA copy
@@ -192,14 +229,14 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         SortedSet si, sj_set;
         const int slot_i[5] = {WS_SORT_AOS, WS_BBOX, WS_GSPH, WS_WSPH, WS_GSPH4};
         int rc = cull_prepare_set(ctx, F, p.d_xi, p.d_ti, (long long)p.ti_fs, p.d_box, N, nTi, p.n_ti,
-                                  ordered ? near_ord : 0.f, ordered ? p.nbins + 1 : 0, want_soa, slot_i, si);
+                                  ordered ? near_ord : 0.f, ordered ? p.nbins + 1 : 0, want_soa, pk, slot_i, si);
         if (rc) return rc;
         if (p.tri) {
             sj_set = si;
         } else {
             const int slot_j[5] = {WS_SORT_AOS_J, WS_BBOX_J, WS_GSPH_J, WS_WSPH_J, WS_GSPH4_J};
             rc = cull_prepare_set(ctx, F, p.d_xj, p.d_tj, (long long)p.tj_fs, p.d_box, p.nj, nTj, p.n_ti, 0.f, 0,
-                                  false, slot_j, sj_set);
+                                  false, false, slot_j, sj_set);
             if (rc) return rc;
         }
         launch_cull_lists(ctx->stream, p.tri, F, si.bbox, sj_set.bbox, nTi, nTj, p.d_box,
@@ -219,6 +256,8 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         d_list_cnt = d_lc;
         d_aos = si.aos;
         d_aos_j = sj_set.aos;
+        d_rel = si.rel;
+        d_cen = si.cen;
     }
 
     double total_ms = 0.0;  // the pair kernel alone; the culling pre-pass is reported separately
@@ -271,15 +310,20 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         a.fpb = fpb;
 
         a.near = near_ord;
+        a.rel = d_rel;
+        a.cen = d_cen;
+        a.s_cap = s_cap;
+        a.rc2hi = rc2hi;
         const bool sj = cull && ctx->opt_rdf_sj != 0;  // wave-independent sweep with scalar loads of the j atoms
         const bool persist = sj && !p.per_frame && ctx->opt_rdf_sj != 2;  // resident grid + per-XCD work counters
         a.work = reinterpret_cast<unsigned *>(d_misc + 4);
-        const size_t lds = ordered ? ord_b
+        const size_t lds = pk      ? lds_bytes_sj_pk(p.nbins, p.n_ti, p.n_tj)
+                           : ordered ? ord_b
                            : sj    ? lds_bytes_sj(p.nbins, nc, p.n_ti, p.n_tj, mode_cn)
                            : fast ? lds_bytes_fast(p.nbins, nc, p.n_ti, p.n_tj)
                                   : lds_bytes(p.nbins, nc, p.n_ti, p.n_tj);
         const char *kname = "";
-        PairKernel kern = sj ? sj_kernel(ordered ? 2 : mode_cn ? 1 : 0, persist, &kname)
+        PairKernel kern = sj ? sj_kernel(pk && ctx->opt_rdf_pk != 2 ? 3 : ordered ? 2 : mode_cn ? 1 : 0, persist, &kname)
                              : dense_kernel(fast, p.tri, mode_cn, fast && cull, &kname);
         ctx->last_kernel = kname;
         if (lds > 65536)
@@ -339,10 +383,15 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
 
         if (sj) {
             // D2H of the row sums (pinned staging), then rows -> classes and the overflow words on the host
-            MD_PIN(hrows, uint64_t, PIN_OUT, out_frames * (size_t)sj_words * 8);
+            MD_PIN(hrows, uint64_t, PIN_OUT, (out_frames * (size_t)sj_words + 2) * 8);
             MD_HIP(hipMemcpyAsync(hrows, d_rows, out_frames * (size_t)sj_words * 8, hipMemcpyDeviceToHost,
                                   ctx->stream));
+            uint64_t *hlost = hrows + out_frames * (size_t)sj_words;  // [0] queue overflow, [1] work-loop assertion
+            MD_HIP(hipMemcpyAsync(hlost, d_misc + 1, 16, hipMemcpyDeviceToHost, ctx->stream));
             MD_HIP(hipStreamSynchronize(ctx->stream));
+            if (hlost[0] || hlost[1])
+                return mdhip_fail(ctx, MDHIP_EHIP, "pair_hist: internal check failed (%llu deferred pairs lost, work loop %llu)",
+                                  (unsigned long long)hlost[0], (unsigned long long)hlost[1]);
             timer.collect();
             total_ms += ctx->last_ms;
             ++launches;
@@ -404,7 +453,7 @@ int pair_hist_run(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64_t> &H
 {
     const int64_t F = p.n_frames;
     const int64_t nT = (p.ni + TILE - 1) / TILE;
-    const double per_frame_b = 38.0 * (double)p.ni + 4.0 * MORTON_CELLS + 2.0 * (double)nT * (double)nT + 1024.0;
+    const double per_frame_b = 54.0 * (double)p.ni + 4.0 * MORTON_CELLS + 2.0 * (double)nT * (double)nT + 1024.0;
     int64_t batch = (int64_t)(2147483648.0 / per_frame_b);
     if (batch < 1) batch = 1;
     if (batch > 32768) batch = 32768;
@@ -522,6 +571,7 @@ struct RelJob {
     const double *edges;  // host [nbins+1]
     double rc2;
     float gscale;
+    double bin_size;
     int per_frame;
 };
 
@@ -584,6 +634,7 @@ int run_job(mdhip_ctx *ctx, const RelJob &j, std::vector<uint64_t> &H, std::vect
     p.edges = j.edges;
     p.rc2 = j.rc2;
     p.gscale = j.gscale;
+    p.bin_size = j.bin_size;
     p.per_frame = j.per_frame;
     return pair_hist_run(ctx, p, H, overflow);
 }
@@ -659,6 +710,7 @@ int mdhip_rdf_atomic(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const do
     j.edges = edges;
     j.rc2 = r_cut_sq;
     j.gscale = (float)(1.0 / bin_size);
+    j.bin_size = bin_size;
     j.per_frame = per_frame;
     std::vector<uint64_t> H;
     std::vector<int> rel_cls;
@@ -779,6 +831,7 @@ int mdhip_rdf_sites(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const dou
     j.edges = edges;
     j.rc2 = r_cut_sq;
     j.gscale = (float)(1.0 / bin_size);
+    j.bin_size = bin_size;
     j.per_frame = per_frame;
     std::vector<uint64_t> H;
     std::vector<int> rel_cls;

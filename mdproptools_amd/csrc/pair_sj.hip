@@ -234,6 +234,296 @@ __device__ __forceinline__ void sj_item(const PairArgs &a, FastCtx &c, const uns
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// MODE 3: packed-f32 classification with an exact deferred resolver (ordered-pair rows, as MODE 2).
+//
+// Only the BIN of a pair enters the result, not its rsq. The sweep therefore evaluates rsq in f32 with the
+// packed instructions of gfx950 (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: two pairs per VALU issue slot, the
+// j operands as SGPR pairs): 3 slots per 2 pairs instead of 8-15 f64 slots per pair. The f32 value differs
+// from the reference's f64 rsq by a BOUNDED amount (pk_error_bound below, in bins: `err`); the bin guess
+//   g = fma(v_sqrt_f32(rsq32), 1/ddr, near + tj*row_len),   near = 2*err + slack
+// is trusted only when fract(g) >= 2*near, i.e. when the true sqrt(rsq)/ddr is provably farther than `err` from
+// every integer — then trunc(g) IS the reference's bin. Every other pair (~0.2 %, the band around each bin edge;
+// the cutoff sits on such an edge by the host's choice of when to use this mode) is not binned here: its (i, j)
+// indices go to a per-wave queue in LDS, and the queue is drained 64 entries at a time by the EXACT chain of
+// MODE 2 (f64 coordinates re-read from the sorted records, the reference's operations in the reference's
+// order, exact cutoff test, exact edge table). So the integers are the reference's; only who computes which
+// pair changes. Lane-parallel draining makes the exact chain cost ~1/64 of what an inline fallback would.
+//
+// Keeping the f32 error small: coordinates are taken relative to the centre c_J of the j tile's box.
+//   xr_j = f32(x_j - c_J)            (pre-pass, |xr_j| <= half extent of the tile)
+//   xr_i = f32((x_i - c_J) + s)      (per lane and neighbour tile; s in {0, -L, +L} is the wave-uniform shift of
+//                                     the hoisted wrap decision, so |xr_i| <= cutoff + extents)
+// Per axis and group the hoisted wrap class (wrap_class) against the shift s the tile was given decides:
+//   class == class of s          -> d' = xr_i - xr_j                        (no further operation)
+//   s == 0, class != "none"      -> d' = min(|d|, ||d| - L|) in f32         (== the reference's wrap for every d)
+//   otherwise                    -> the group is swept by the exact f64 chain (rare: tiles across a cell face)
+// A (wave, tile) whose relative coordinates exceed what `near` was computed for (s_cap) is swept in f64 as well.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int PK_QCAP = 320;     // queue entries per wave: drained above 64, one group of 4 j atoms adds at most 256
+constexpr int PK_QSTRIDE = 324;  // words per wave: the entries, then the entry counter
+
+struct PkCtx {
+    f32x2 x2, y2, z2;     // this lane's i atom relative to the j tile's centre (+ shift), both halves equal
+    f32x2 Lx2, Ly2, Lz2;  // box lengths (f32) for the axes that still need the per-pair wrap
+    float rc2hi;          // pre-filter: every pair with rsq < r_cut^2 has rsq32 < rc2hi
+    unsigned *queue;      // this wave's queue (LDS); queue[PK_QCAP] = number of entries
+    unsigned long long *lost;  // device counter of entries that did not fit the queue (must stay 0)
+    // what the resolver needs
+    const double4 *ats_i;  // sorted f64 records of the i atoms of this wave (64 consecutive)
+    const double4 *ats_j;  // sorted f64 records of the frame's j set
+    double Lx, Ly, Lz, rc2;
+    int n_ti, n_tj;
+};
+
+// min(|d|, ||d| - L|) on both halves
+__device__ __forceinline__ f32x2 wrap_abs_pk(f32x2 d, f32x2 L)
+{
+    const f32x2 a = __builtin_elementwise_max(d, -d);
+    const f32x2 b = a - L;
+    return __builtin_elementwise_min(a, __builtin_elementwise_max(b, -b));
+}
+
+// Two records = four j atoms through the scalar cache (see sload_records4)
+__device__ __forceinline__ void sload_rel4(const float *p, u32x8 &r0, u32x8 &r1)
+{
+    asm volatile(
+        "s_load_dwordx8 %0, %2, 0x0\n\t"
+        "s_load_dwordx8 %1, %2, 0x20\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&s"(r0), "=&s"(r1)
+        : "s"(p)
+        : "memory");
+}
+
+// The exact chain for the n queued pairs: entry = (j index in the frame << 6) | lane of the i atom.
+__device__ __forceinline__ void pk_drain(const PkCtx &p, const FastCtx &c, int n, int lane)
+{
+    if (n > PK_QCAP) n = PK_QCAP;
+    for (int b = 0; b < n; b += 64) {
+        if (b + lane < n) {
+            const unsigned e = p.queue[b + lane];
+            const double4 ri = p.ats_i[e & 63u];
+            const double4 rj = p.ats_j[e >> 6];
+            const double ax = wrap_abs(ri.x - rj.x, p.Lx);
+            const double ay = wrap_abs(ri.y - rj.y, p.Ly);
+            const double az = wrap_abs(ri.z - rj.z, p.Lz);
+            const double rsq = (ax * ax + ay * ay) + az * az;
+            if (rsq < p.rc2) {
+                const int ti = (int)((unsigned)__double2loint(ri.w)) / p.n_ti;  // low word of w = type * n_ti
+                const unsigned rowbase = c.lds_base + (unsigned)ti * (unsigned)p.n_tj * (unsigned)(c.nbins + 1) * 4u;
+                const float nearoff = __int_as_float(__double2hiint(rj.w));
+                const float g1 = __builtin_fmaf(__builtin_amdgcn_sqrtf((float)rsq), c.gscale, nearoff);
+                int k = (int)g1;
+                if (__builtin_amdgcn_fractf(g1) < c.near2) {
+                    const int koff = (int)nearoff;
+                    int kk = k - koff;
+                    kk = kk > c.nbins ? c.nbins : (kk < 0 ? 0 : kk);
+                    k = koff + (rsq < c.edges[kk] ? kk - 1 : kk);
+                }
+                const unsigned addr = ((unsigned)k << 2) + rowbase;
+                asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"(1u) : "memory");
+            }
+        }
+    }
+    if (lane == 0) p.queue[PK_QCAP] = 0u;
+}
+
+// The four j atoms of one group (two records, already in SGPRs) against the wave's 64 i atoms.
+// VAR: bit k = axis k takes the per-pair f32 wrap. jidx0 = index of the group's first atom in the frame's j set.
+template <bool DIAG, int VAR>
+__device__ __forceinline__ void sweep_group_pk(const u32x8 &rec0, const u32x8 &rec1, int jidx0, int local0,
+                                               const PkCtx &p, const FastCtx &c, int lane_in_tile, int lane)
+{
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const u32x8 &rec = h ? rec1 : rec0;
+        const f32x2 xj = {__uint_as_float(rec[0]), __uint_as_float(rec[1])};
+        const f32x2 yj = {__uint_as_float(rec[2]), __uint_as_float(rec[3])};
+        const f32x2 zj = {__uint_as_float(rec[4]), __uint_as_float(rec[5])};
+        f32x2 dx = p.x2 - xj, dy = p.y2 - yj, dz = p.z2 - zj;
+        if (VAR & 1) dx = wrap_abs_pk(dx, p.Lx2);
+        if (VAR & 2) dy = wrap_abs_pk(dy, p.Ly2);
+        if (VAR & 4) dz = wrap_abs_pk(dz, p.Lz2);
+        f32x2 rsq = dx * dx;
+        rsq = __builtin_elementwise_fma(dy, dy, rsq);
+        rsq = __builtin_elementwise_fma(dz, dz, rsq);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            bool in = rsq[u] < p.rc2hi;
+            if (DIAG) in = in && (local0 + 2 * h + u > lane_in_tile);
+            if (in) {
+                const float nearoff = __uint_as_float(rec[6 + u]);
+                const float g1 = __builtin_fmaf(__builtin_amdgcn_sqrtf(rsq[u]), c.gscale, nearoff);
+                if (__builtin_amdgcn_fractf(g1) >= c.near2) {
+                    const unsigned addr = ((unsigned)(int)g1 << 2) + c.rowbase_me;
+                    asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"(1u) : "memory");
+                } else {
+                    // inside the error band of a bin edge (or of the cutoff): the exact chain decides, later
+                    const unsigned pos = atomicAdd(p.queue + PK_QCAP, 1u);
+                    if (pos < (unsigned)PK_QCAP)
+                        p.queue[pos] = ((unsigned)(jidx0 + 2 * h + u) << 6) | (unsigned)lane;
+                    else  // cannot happen (drained above 64, a group adds <= 256); the host turns this into an error
+                        atomicAdd(p.lost, 1ull);
+                }
+            }
+        }
+    }
+}
+
+// One work item of the packed-f32 sweep (atom-atom, ordered-pair rows): as sj_item, with the tile-relative f32
+// records for the pair chain and the f64 chain (sweep_group_sj<., 2, 7>: the general wrap on all axes, valid for
+// every d) for the groups and tiles the f32 bound does not cover.
+__device__ __forceinline__ void sj_item_pk(const PairArgs &a, FastCtx &c, unsigned *queue, int f, int I, int wq,
+                                           int split, int lane)
+{
+    const long long n_pad = (long long)a.nTi * TILE;
+    const long long rowid = (long long)f * a.nTi + I;
+    const int cnt = a.list_cnt[rowid];
+    const unsigned short *row_list = a.list + rowid * a.nTj;
+    const int t_begin = (int)((long long)split * cnt / a.jsplit);
+    const int t_end = (int)((long long)(split + 1) * cnt / a.jsplit);
+    AxisL L;
+    L.Lx = a.box[3 * f];
+    L.Ly = a.box[3 * f + 1];
+    L.Lz = a.box[3 * f + 2];
+    L.sx = L.sy = L.sz = 0.0;
+    const double4 *ats = a.aos + (long long)f * n_pad;
+    const int lane_in_tile = wq * 64 + lane;
+    const long long ig = (long long)I * TILE + lane_in_tile;
+    double4 me = ats[ig];
+    const bool real_i = ig < a.ni;
+    if (!real_i) me = make_double4(PAD_I, PAD_I, PAD_I, __longlong_as_double(0LL));
+    {
+        const int ti_me = (int)((unsigned)__double_as_longlong(me.w)) / a.n_ti;
+        c.rowtab_me = nullptr;
+        c.rowbase_me = c.lds_base + (unsigned)ti_me * (unsigned)a.n_tj * (unsigned)(a.nbins + 1) * 4u;
+    }
+    const long long w = ((long long)f * a.nTi + I) * (TILE / 64) + wq;
+    const float4 wlo = a.wsph[2 * w], whi = a.wsph[2 * w + 1];
+    const float4 *gb_f = a.gsph4 + (long long)f * a.nTj * (TILE / SJ_GROUP) * 2;
+    const float fLx = (float)L.Lx, fLy = (float)L.Ly, fLz = (float)L.Lz;
+    PkCtx p;
+    p.Lx2 = f32x2{fLx, fLx};
+    p.Ly2 = f32x2{fLy, fLy};
+    p.Lz2 = f32x2{fLz, fLz};
+    p.rc2hi = a.rc2hi;
+    p.queue = queue;
+    p.lost = a.overflow + 1;
+    p.ats_i = ats + (long long)I * TILE + wq * 64;
+    p.ats_j = ats;
+    p.Lx = L.Lx;
+    p.Ly = L.Ly;
+    p.Lz = L.Lz;
+    p.rc2 = a.rc2;
+    p.n_ti = a.n_ti;
+    p.n_tj = a.n_tj;
+    const float *rel_f = a.rel + (long long)f * n_pad * 4;  // 4 floats per atom
+    const double *cen_f = a.cen + (long long)f * a.nTj * 8;
+    unsigned qn_v = 0u;  // the queue's entry count as of the end of the previous group (read back from LDS)
+    for (int t = t_begin; t < t_end; ++t) {
+        const int J = __builtin_amdgcn_readfirstlane((int)row_list[t]);
+        const float4 glo = gb_f[((long long)J * (TILE / SJ_GROUP) + lane) * 2];
+        const float4 ghi = gb_f[((long long)J * (TILE / SJ_GROUP) + lane) * 2 + 1];
+        const float gx = gapf(wlo.x, whi.x, glo.x, ghi.x, fLx);
+        const float gy = gapf(wlo.y, whi.y, glo.y, ghi.y, fLy);
+        const float gz = gapf(wlo.z, whi.z, glo.z, ghi.z, fLz);
+        const bool keep = wlo.w > 0.f && glo.w > 0.f && gx * gx + gy * gy + gz * gz < a.reach * a.reach;
+        const unsigned long long km = __builtin_amdgcn_ballot_w64(keep);
+        if (!km) continue;
+        const double4 *tile = ats + (long long)J * TILE;
+        const float *rtile = rel_f + (long long)J * TILE * 4;
+        const bool diag = J == I;
+        // hoisted wrap classes of the groups and the shift of the tile: the class of the first kept group
+        const unsigned cx = wrap_class(wlo.x, whi.x, glo.x, ghi.x, fLx);
+        const unsigned cy = wrap_class(wlo.y, whi.y, glo.y, ghi.y, fLy);
+        const unsigned cz = wrap_class(wlo.z, whi.z, glo.z, ghi.z, fLz);
+        const int g0 = __builtin_ctzll(km);
+        unsigned sx = (unsigned)__builtin_amdgcn_readlane((int)cx, g0);
+        unsigned sy = (unsigned)__builtin_amdgcn_readlane((int)cy, g0);
+        unsigned sz = (unsigned)__builtin_amdgcn_readlane((int)cz, g0);
+        if (diag || sx > 2u) sx = 0u;
+        if (diag || sy > 2u) sy = 0u;
+        if (diag || sz > 2u) sz = 0u;
+        const double shx = sx == 1u ? -L.Lx : sx == 2u ? L.Lx : 0.0;
+        const double shy = sy == 1u ? -L.Ly : sy == 2u ? L.Ly : 0.0;
+        const double shz = sz == 1u ? -L.Lz : sz == 2u ? L.Lz : 0.0;
+        const double ccx = cen_f[J * 8], ccy = cen_f[J * 8 + 1], ccz = cen_f[J * 8 + 2];
+        // does the error bound cover this (wave, tile)? largest |xr_i| + |xr_j| per axis against s_cap
+        const float ox = (float)(shx - ccx), oy = (float)(shy - ccy), oz = (float)(shz - ccz);
+        const float mix = __builtin_fmaxf(__builtin_fabsf(wlo.x + ox), __builtin_fabsf(whi.x + ox)) + (float)cen_f[J * 8 + 3];
+        const float miy = __builtin_fmaxf(__builtin_fabsf(wlo.y + oy), __builtin_fabsf(whi.y + oy)) + (float)cen_f[J * 8 + 4];
+        const float miz = __builtin_fmaxf(__builtin_fabsf(wlo.z + oz), __builtin_fabsf(whi.z + oz)) + (float)cen_f[J * 8 + 5];
+        const bool covered = __builtin_fmaxf(mix, __builtin_fmaxf(miy, miz)) * 1.0001f < a.s_cap;
+        // per axis: 0 = plain difference, 1 = per-pair f32 wrap, 2 = not expressible with this tile's shift
+        const unsigned mx = cx == sx ? 0u : (sx == 0u ? 1u : 2u);
+        const unsigned my = cy == sy ? 0u : (sy == 0u ? 1u : 2u);
+        const unsigned mz = cz == sz ? 0u : (sz == 0u ? 1u : 2u);
+        const bool exact = !__builtin_amdgcn_readfirstlane((int)covered) || (!diag && ((mx | my | mz) & 2u));
+        {  // groups (or the whole tile) the f32 bound does not cover: the f64 chain, general wrap on every axis
+            unsigned long long mk = __builtin_amdgcn_ballot_w64(keep && exact);
+            while (mk) {
+                const int g = __builtin_ctzll(mk);
+                mk &= mk - 1;
+                if (diag)
+                    sweep_group_sj<true, 2, 7>(tile + g * SJ_GROUP, g * SJ_GROUP, me.x, me.y, me.z, L, a.rc2, c, lane_in_tile);
+                else
+                    sweep_group_sj<false, 2, 7>(tile + g * SJ_GROUP, g * SJ_GROUP, me.x, me.y, me.z, L, a.rc2, c, lane_in_tile);
+            }
+        }
+        if (!__builtin_amdgcn_ballot_w64(keep && !exact)) continue;
+        {
+            const float xr = real_i ? (float)((me.x - ccx) + shx) : -1.0e18f;
+            const float yr = real_i ? (float)((me.y - ccy) + shy) : -1.0e18f;
+            const float zr = real_i ? (float)((me.z - ccz) + shz) : -1.0e18f;
+            p.x2 = f32x2{xr, xr};
+            p.y2 = f32x2{yr, yr};
+            p.z2 = f32x2{zr, zr};
+        }
+        const int jbase = J * TILE;
+        // variant of a group: the set of axes with the per-pair wrap (the diagonal tile: all three, no shift)
+        const unsigned var = diag ? 8u : (mx & 1u) | ((my & 1u) << 1) | ((mz & 1u) << 2);
+        for (unsigned A = diag ? 8u : 0u; A <= (diag ? 8u : 7u); ++A) {
+            unsigned long long mk = __builtin_amdgcn_ballot_w64(keep && !exact && var == A);
+            while (mk) {
+                const int g = __builtin_ctzll(mk);
+                mk &= mk - 1;
+                u32x8 r0, r1;
+                sload_rel4(rtile + g * SJ_GROUP * 4, r0, r1);
+                // (the wait of the scalar loads also covers the read-back of the entry count)
+                if (__builtin_amdgcn_readfirstlane((int)qn_v) > 64) pk_drain(p, c, __builtin_amdgcn_readfirstlane((int)qn_v), lane);
+                const int j0 = jbase + g * SJ_GROUP, l0 = g * SJ_GROUP;
+                switch (A) {
+                case 0: sweep_group_pk<false, 0>(r0, r1, j0, l0, p, c, lane_in_tile, lane); break;
+                case 1: sweep_group_pk<false, 1>(r0, r1, j0, l0, p, c, lane_in_tile, lane); break;
+                case 2: sweep_group_pk<false, 2>(r0, r1, j0, l0, p, c, lane_in_tile, lane); break;
+                case 3: sweep_group_pk<false, 3>(r0, r1, j0, l0, p, c, lane_in_tile, lane); break;
+                case 4: sweep_group_pk<false, 4>(r0, r1, j0, l0, p, c, lane_in_tile, lane); break;
+                case 5: sweep_group_pk<false, 5>(r0, r1, j0, l0, p, c, lane_in_tile, lane); break;
+                case 6: sweep_group_pk<false, 6>(r0, r1, j0, l0, p, c, lane_in_tile, lane); break;
+                case 7: sweep_group_pk<false, 7>(r0, r1, j0, l0, p, c, lane_in_tile, lane); break;
+                default: sweep_group_pk<true, 7>(r0, r1, j0, l0, p, c, lane_in_tile, lane); break;
+                }
+                qn_v = queue[PK_QCAP];
+            }
+        }
+    }
+    const int n_left = __builtin_amdgcn_readfirstlane((int)queue[PK_QCAP]);
+    if (n_left > 0) pk_drain(p, c, n_left, lane);
+}
+
+// Assertion at the top of every work-loop iteration: the whole wave is here (the item index is drawn by lane 0
+// and broadcast) and the wave has not drawn more items than exist. A violation would make the wave spin on
+// item 0; it is recorded in overflow[2] and ends the loop, and the host turns it into an error.
+__device__ __forceinline__ bool work_loop_sane(const PairArgs &a, long long iter, long long n_items)
+{
+    if (__builtin_amdgcn_ballot_w64(true) == ~0ull && iter <= n_items + 1) return true;
+    atomicOr(a.overflow + 2, __builtin_amdgcn_ballot_w64(true) == ~0ull ? 2ull : 1ull);
+    return false;
+}
+
 // PERSIST = true (frame-summed output): the grid is one resident set of blocks; every WAVE draws items
 // (frame, tile, wave, list slice) from its XCD's counter — frames stay dealt to XCDs (f % 8) so a frame's
 // records live in one L2 — and the block flushes its LDS histograms once, when its four waves have run
@@ -250,16 +540,17 @@ __global__ __launch_bounds__(TILE) void pair_hist_sj_kernel(const PairArgs a)
     // ---- LDS: hist | (CN edges) | row table ----
     // MODE 2: one row per ORDERED type pair (ti, tj), addressed without a table (see sweep_group_sj)
     const int row_len = a.nbins + 1;
-    const int hist_words = (MODE == 2 ? a.n_ti * a.n_tj : a.n_cls + 1) * row_len;
+    const int hist_words = (MODE >= 2 ? a.n_ti * a.n_tj : a.n_cls + 1) * row_len;
     unsigned *s_hist = reinterpret_cast<unsigned *>(smem);
     size_t off = ((size_t)hist_words * 4 + 15) & ~size_t(15);
     double *s_edges = reinterpret_cast<double *>(smem + off);
     off += MODE == 1 ? (((size_t)(a.nbins + 2) * 8 + 15) & ~size_t(15)) : 0;
-    unsigned *s_row = reinterpret_cast<unsigned *>(smem + off);
+    unsigned *s_row = reinterpret_cast<unsigned *>(smem + off);  // MODE 3: the waves' queues of deferred pairs instead
     const unsigned lds_base =
         (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char *)smem;
     for (int k = tid; k < hist_words; k += TILE) s_hist[k] = 0u;
-    if (MODE != 2)
+    if (MODE == 3 && tid < TILE / 64) s_row[tid * PK_QSTRIDE + PK_QCAP] = 0u;  // the waves' queues start empty
+    if (MODE < 2)
         for (int k = tid; k < a.n_ti * a.n_tj; k += TILE) {
             const int ti = k % a.n_ti, tj = k / a.n_ti;
             const unsigned cl = a.cls[ti * a.n_tj + tj];
@@ -273,14 +564,14 @@ __global__ __launch_bounds__(TILE) void pair_hist_sj_kernel(const PairArgs a)
         c.edges = s_edges;
     }
     c.gscale = a.gscale;
-    if (MODE == 2) {
+    if (MODE >= 2) {
         // the bin guess is fma(sqrt, gscale, addend) with the addend in an SGPR (it belongs to the j atom): a VOP3
         // may read one SGPR, so gscale has to live in a VGPR or every guess pays a v_mov
         float gs;
         asm volatile("v_mov_b32 %0, %1" : "=v"(gs) : "s"(a.gscale));
         c.gscale = gs;
     }
-    c.near = MODE == 2 ? a.near : (float)a.nbins * 1.0e-6f + 1.0e-5f;
+    c.near = MODE >= 2 ? a.near : (float)a.nbins * 1.0e-6f + 1.0e-5f;
     c.near2 = 2.0f * c.near;
     c.nbins = a.nbins;
     c.lds_base = lds_base;
@@ -293,14 +584,19 @@ __global__ __launch_bounds__(TILE) void pair_hist_sj_kernel(const PairArgs a)
         const int nfx = a.n_frames > xcd ? (a.n_frames - xcd + 7) / 8 : 0;  // frames of this XCD
         const int ipf = a.nTi * (TILE / 64) * a.jsplit;                       // items per frame
         const long long n_items = (long long)nfx * ipf;
+        long long guard = 0;
         for (;;) {
             unsigned it = 0;
+            if (!work_loop_sane(a, ++guard, n_items)) break;
             if (lane == 0) it = atomicAdd(&a.work[xcd], 1u);
             it = (unsigned)__builtin_amdgcn_readfirstlane((int)it);
             if ((long long)it >= n_items) break;
             const int fx = (int)(it / (unsigned)ipf), r = (int)(it % (unsigned)ipf);
             const int split = r % a.jsplit, wI = r / a.jsplit;
-            sj_item<MODE>(a, c, s_row, fx * 8 + xcd, wI >> 2, wI & 3, split, lane);
+            if (MODE == 3)
+                sj_item_pk(a, c, s_row + (tid >> 6) * PK_QSTRIDE, fx * 8 + xcd, wI >> 2, wI & 3, split, lane);
+            else
+                sj_item<MODE == 3 ? 2 : MODE>(a, c, s_row, fx * 8 + xcd, wI >> 2, wI & 3, split, lane);
         }
     } else {
         // a.blocks_per_frame blocks share one frame and flush once each into the frame's row
@@ -308,14 +604,19 @@ __global__ __launch_bounds__(TILE) void pair_hist_sj_kernel(const PairArgs a)
         const int f = (int)((bid >> 3) / a.blocks_per_frame) * 8 + xcd;
         f_out = f < a.n_frames ? f : 0;
         const unsigned ipf = f < a.n_frames ? (unsigned)(a.nTi * (TILE / 64) * a.jsplit) : 0u;
+        int guard = 0;
         for (;;) {  // the frame's blocks draw its wave items from the frame's counter (integer sums: any order)
             unsigned it = 0;
             if (ipf == 0u) break;
+            if (!work_loop_sane(a, ++guard, ipf)) break;
             if (lane == 0) it = atomicAdd(&a.work[f], 1u);
             it = (unsigned)__builtin_amdgcn_readfirstlane((int)it);
             if (it >= ipf) break;
             const int split = (int)(it % (unsigned)a.jsplit), wI = (int)(it / (unsigned)a.jsplit);
-            sj_item<MODE>(a, c, s_row, f, wI >> 2, wI & 3, split, lane);
+            if (MODE == 3)
+                sj_item_pk(a, c, s_row + (tid >> 6) * PK_QSTRIDE, f, wI >> 2, wI & 3, split, lane);
+            else
+                sj_item<MODE == 3 ? 2 : MODE>(a, c, s_row, f, wI >> 2, wI & 3, split, lane);
         }
     }
 
@@ -358,6 +659,33 @@ size_t lds_bytes_sj_ordered(int nbins, int n_ti, int n_tj)
     return (((size_t)n_ti * n_tj * (nbins + 1) * 4 + 15) & ~size_t(15)) + 16;
 }
 
+size_t lds_bytes_sj_pk(int nbins, int n_ti, int n_tj)
+{
+    return (((size_t)n_ti * n_tj * (nbins + 1) * 4 + 15) & ~size_t(15)) + (size_t)(TILE / 64) * PK_QSTRIDE * 4;
+}
+
+// Error bound of the packed-f32 bin guess, in bins (see the MODE 3 header). u = 2^-24 (f32 round to nearest).
+//   per axis   d32 = fl(xr_i - xr_j): the two inputs carry u |xr_i| + u |xr_j| <= u s_cap, the subtraction adds
+//              u |d'| <= u s_cap (|d'| <= |xr_i| + |xr_j|)
+//              f32 wrap of an axis: 1-Lipschitz in d'; adds |L32 - L| <= u L and u |result|
+//   rsq32      one rounded product and two fused multiply-adds: relative 3u
+//   r32        v_sqrt_f32 (1 ulp = 2u): relative 1.5u + 2u
+//   => |r32 - sqrt(rsq_ref)| <= sqrt(3) u (2 s_cap + l_max) + 5.5 u r   (the three axes add in quadrature; r <= the
+//      cutoff for every pair whose bin matters; the reference's own f64 roundings are 2^-29 of these terms)
+//   g          1/ddr rounded to f32 (u nbins), the addend near + tj*row_len and the fma each rounded at the size of
+//              the largest guess (half an ulp each)
+// 5 % head room on top; the caller uses near = 2 err + slack (one err for the guess, one for the f32 pre-filter
+// rsq32 < rc2hi, which has to let every in-cutoff pair through and still keep the rejected ones inside the band of
+// the cutoff's edge).
+double pk_error_bound(double r_cut, double bin_size, int nbins, int n_tj, double s_cap, double l_max)
+{
+    const double u = std::ldexp(1.0, -24);
+    const double e_r = std::sqrt(3.0) * u * (2.0 * s_cap + l_max) + 5.5 * u * r_cut;
+    const double maxg = (double)n_tj * (nbins + 1) + 2.0;
+    const double ulp = std::ldexp(1.0, (int)std::floor(std::log2(maxg)) - 23);
+    return 1.05 * (e_r / bin_size + u * (double)(nbins + 1)) + ulp;
+}
+
 size_t lds_bytes_sj(int nbins, int n_cls, int n_ti, int n_tj, bool mode_cn)
 {
     size_t off = ((size_t)(n_cls + 1) * (nbins + 1) * 4 + 15) & ~size_t(15);
@@ -369,6 +697,7 @@ size_t lds_bytes_sj(int nbins, int n_cls, int n_ti, int n_tj, bool mode_cn)
 PairKernel sj_kernel(int mode, bool persist, const char **name)
 {
 #define MD_PICK(...) (*name = #__VA_ARGS__, __VA_ARGS__)
+    if (mode == 3) return persist ? MD_PICK(pair_hist_sj_kernel<3, true>) : MD_PICK(pair_hist_sj_kernel<3, false>);
     if (mode == 2) return persist ? MD_PICK(pair_hist_sj_kernel<2, true>) : MD_PICK(pair_hist_sj_kernel<2, false>);
     if (mode == 1) return persist ? MD_PICK(pair_hist_sj_kernel<1, true>) : MD_PICK(pair_hist_sj_kernel<1, false>);
     return persist ? MD_PICK(pair_hist_sj_kernel<0, true>) : MD_PICK(pair_hist_sj_kernel<0, false>);
