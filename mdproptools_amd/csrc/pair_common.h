@@ -54,9 +54,11 @@ struct PairArgs {
     const double4 *aos_j;        // sorted records of the j set (== aos for atom-atom), [F][nTj*256]
     int tri;                     // 1: atom-atom (i < j inside the diagonal tile), 0: atoms x sites
     // packed-f32 classification sweep (MODE 3 of the scalar-j kernel, pair_sj.hip)
-    const float *rel;            // [F][nTj*128][8] f32 records of the j set relative to their tile's centre, two atoms
-                                 // per record: (x0, x1, y0, y1, z0, z1, w0, w1), w = the bin-guess addend of pack_w
-    const double *cen;           // [F][nTj][8] tile centre (x, y, z) and half extents (hx, hy, hz) of the sorted tiles
+    const float *rel;            // [F][nTj*128][8] f32 records of the j set relative to the centre of their block (64
+                                 // or 256 sorted atoms), two atoms per record: (x0, x1, y0, y1, z0, z1, w0, w1),
+                                 // w = the bin-guess addend of pack_w
+    const double *cen;           // [F][nTj * blocks][8] block centre (x, y, z) and half extents (hx, hy, hz)
+    int cen_shift;               // log2(groups of 4 atoms per centre block): 4 = 64 atoms, 6 = the whole tile
     float s_cap;                 // largest |relative coordinate| sum (i + j, per axis) the error bound `near` covers
     float rc2hi;                 // f32 pre-filter: every in-cutoff pair has rsq32 < rc2hi (see pk_error_bound)
 };
@@ -147,6 +149,7 @@ void launch_reduce_slots(hipStream_t stream, const unsigned long long *in, unsig
 size_t lds_bytes_sj(int nbins, int n_cls, int n_ti, int n_tj, bool mode_cn);
 size_t lds_bytes_sj_ordered(int nbins, int n_ti, int n_tj);
 size_t lds_bytes_sj_pk(int nbins, int n_ti, int n_tj);
+int sj_block_threads(int mode);  // threads per block of the scalar-j kernels (mode as sj_kernel)
 PairKernel sj_kernel(int mode /* 0 RDF class rows, 1 CN, 2 RDF ordered-pair rows, 3 = 2 with the packed-f32 sweep */,
                      bool persist, const char **name);
 // error bound (in bins) of the packed-f32 bin guess for |relative coordinates| <= s_cap per axis pair sum; 0 = not usable
@@ -159,7 +162,8 @@ constexpr int MORTON_BITS = 5;                       // 32 cells per axis
 constexpr int MORTON_CELLS = 1 << (3 * MORTON_BITS); // 32768
 int cull_prepare_set(mdhip_ctx *ctx, int64_t F, const double *d_x, const int *d_t, long long t_fs,
                      const double *d_box, long long N, int nT, int n_ti, float near, int row_len, bool want_soa,
-                     bool want_rel, const int slot[5], SortedSet &out);
+                     int rel_block /* 0 = no f32 records, else atoms per centre block: 64 or 256 */, const int slot[5],
+                     SortedSet &out);
 void launch_cull_lists(hipStream_t stream, bool tri, int64_t F, const double *bbox_i, const double *bbox_j, int nTi,
                        int nTj, const double *d_box, double rc2_test, unsigned short *list, int *cnt);
 

@@ -26,9 +26,6 @@
 //   pair_dense.hip  LDS-tile kernels: dense half-shell sweep for small frames, the edge-table kernel of the
 //                   first commit (A/B baseline, fallback for > 64 CN cutoffs)
 // This file: relations -> classes, edge tables, batching, launch geometry, rows -> outputs, the C-ABI.
-#include <cstdio>
-#include <cstdlib>
-
 #include "pair_common.h"
 
 using namespace mdpair;
@@ -121,6 +118,7 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
     // on a bin edge (then the band of that edge also decides in/out of the cutoff) and the error band is narrow.
     bool pk = false;
     float s_cap = 0.f, rc2hi = 0.f;
+    int rel_block = 0;  // atoms per centre block of the f32 records (0: none)
     if (ordered && ctx->opt_rdf_pk != 0 && p.bin_size > 0.0) {
         const double r_cut = std::sqrt(p.rc2);
         const double cpos = r_cut / p.bin_size, K = std::floor(cpos + 0.5);
@@ -135,12 +133,11 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         const double err = pk_error_bound(r_cut, p.bin_size, p.nbins, p.n_tj, cap, l_max);
         const double u = std::ldexp(1.0, -24);
         const double near_pk = 2.0 * err + 4.5 * u * (p.nbins + 1) + 2.0e-5;
-        if (std::getenv("MDHIP_PK_DEBUG"))
-            fprintf(stderr, "pk: cpos %.9f K %.0f nbins %d err %.3e near %.3e cap %.2f lmax %.2f lds %zu\n", cpos, K,
-                    p.nbins, err, near_pk, cap, l_max, lds_bytes_sj_pk(p.nbins, p.n_ti, p.n_tj));
         if (std::fabs(cpos - K) <= 1e-6 && (K == (double)p.nbins || K == (double)p.nbins + 1.0) &&
             near_pk <= 0.02 && lds_bytes_sj_pk(p.nbins, p.n_ti, p.n_tj) <= lds_cap / 4 && std::isfinite(l_max)) {
             pk = true;
+            // centre blocks: whole tiles (64-atom blocks only buy a little f32 precision for 4x the per-block work)
+            rel_block = TILE;
             near_ord = std::max(near_ord, (float)near_pk);
             s_cap = (float)cap;
             // every pair with rsq < r_cut^2 has sqrt(rsq32) <= r_cut + err * bin_size
@@ -229,14 +226,14 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         SortedSet si, sj_set;
         const int slot_i[5] = {WS_SORT_AOS, WS_BBOX, WS_GSPH, WS_WSPH, WS_GSPH4};
         int rc = cull_prepare_set(ctx, F, p.d_xi, p.d_ti, (long long)p.ti_fs, p.d_box, N, nTi, p.n_ti,
-                                  ordered ? near_ord : 0.f, ordered ? p.nbins + 1 : 0, want_soa, pk, slot_i, si);
+                                  ordered ? near_ord : 0.f, ordered ? p.nbins + 1 : 0, want_soa, pk ? rel_block : 0, slot_i, si);
         if (rc) return rc;
         if (p.tri) {
             sj_set = si;
         } else {
             const int slot_j[5] = {WS_SORT_AOS_J, WS_BBOX_J, WS_GSPH_J, WS_WSPH_J, WS_GSPH4_J};
             rc = cull_prepare_set(ctx, F, p.d_xj, p.d_tj, (long long)p.tj_fs, p.d_box, p.nj, nTj, p.n_ti, 0.f, 0,
-                                  false, false, slot_j, sj_set);
+                                  false, 0, slot_j, sj_set);
             if (rc) return rc;
         }
         launch_cull_lists(ctx->stream, p.tri, F, si.bbox, sj_set.bbox, nTi, nTj, p.d_box,
@@ -313,6 +310,7 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         a.rel = d_rel;
         a.cen = d_cen;
         a.s_cap = s_cap;
+        a.cen_shift = rel_block == 64 ? 4 : 6;
         a.rc2hi = rc2hi;
         const bool sj = cull && ctx->opt_rdf_sj != 0;  // wave-independent sweep with scalar loads of the j atoms
         const bool persist = sj && !p.per_frame && ctx->opt_rdf_sj != 2;  // resident grid + per-XCD work counters
@@ -323,7 +321,10 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
                            : fast ? lds_bytes_fast(p.nbins, nc, p.n_ti, p.n_tj)
                                   : lds_bytes(p.nbins, nc, p.n_ti, p.n_tj);
         const char *kname = "";
-        PairKernel kern = sj ? sj_kernel(pk && ctx->opt_rdf_pk != 2 ? 3 : ordered ? 2 : mode_cn ? 1 : 0, persist, &kname)
+        const int sj_mode = pk && ctx->opt_rdf_pk != 2 ? 3 : ordered ? 2 : mode_cn ? 1 : 0;
+        const int bs = sj ? sj_block_threads(sj_mode) : TILE;  // threads per block
+        const int wpb = bs / 64;                                // independent waves per block (scalar-j kernels)
+        PairKernel kern = sj ? sj_kernel(sj_mode, persist, &kname)
                              : dense_kernel(fast, p.tri, mode_cn, fast && cull, &kname);
         ctx->last_kernel = kname;
         if (lds > 65536)
@@ -332,11 +333,12 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         long long launch_grid = grid;
         if (sj) {
             int per_cu = 0;
-            MD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), TILE,
+            MD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), bs,
                                                                 lds));
             if (per_cu < 1) per_cu = 1;
             const long long capacity = (long long)per_cu * ctx->cu_count;
-            const long long block_items = (long long)nTi * jsplit;  // groups of 4 wave items per frame
+            // blocks' worth of wave items per frame (a frame has nTi * 4 * jsplit wave items)
+            const long long block_items = ((long long)nTi * 4 * jsplit + wpb - 1) / wpb;
             a.fpb = 1;
             if (persist) {
                 launch_grid = std::min(capacity, F * block_items + 8);
@@ -372,7 +374,7 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
             a.slices = d_sl;
         }
         KernelTimer timer(ctx);
-        hipLaunchKernelGGL(kern, dim3((unsigned)launch_grid), dim3(TILE), lds, ctx->stream, a);
+        hipLaunchKernelGGL(kern, dim3((unsigned)launch_grid), dim3(bs), lds, ctx->stream, a);
         if (sj) {
             const unsigned gy = p.per_frame ? (unsigned)F : (unsigned)std::min<long long>(64, launch_grid);
             launch_merge_slices(ctx->stream, a.slices, sj_words, launch_grid, p.per_frame, a.blocks_per_frame, gy,

@@ -250,26 +250,40 @@ __device__ __forceinline__ void sj_item(const PairArgs &a, FastCtx &c, const uns
 // order, exact cutoff test, exact edge table). So the integers are the reference's; only who computes which
 // pair changes. Lane-parallel draining makes the exact chain cost ~1/64 of what an inline fallback would.
 //
-// Keeping the f32 error small: coordinates are taken relative to the centre c_J of the j tile's box.
-//   xr_j = f32(x_j - c_J)            (pre-pass, |xr_j| <= half extent of the tile)
-//   xr_i = f32((x_i - c_J) + s)      (per lane and neighbour tile; s in {0, -L, +L} is the wave-uniform shift of
-//                                     the hoisted wrap decision, so |xr_i| <= cutoff + extents)
-// Per axis and group the hoisted wrap class (wrap_class) against the shift s the tile was given decides:
-//   class == class of s          -> d' = xr_i - xr_j                        (no further operation)
-//   s == 0, class != "none"      -> d' = min(|d|, ||d| - L|) in f32         (== the reference's wrap for every d)
-//   otherwise                    -> the group is swept by the exact f64 chain (rare: tiles across a cell face)
-// A (wave, tile) whose relative coordinates exceed what `near` was computed for (s_cap) is swept in f64 as well.
+// Keeping the f32 error small, and the wrap out of the pair loop: the j atoms are stored relative to the centre c
+// of the box of their BLOCK (64 or 256 sorted atoms, cen_shift), and every lane moves its own i atom to the
+// periodic image nearest to that centre, once per block:
+//   xr_j = f32(x_j - c)                          (pre-pass, |xr_j| <= half extent h of the block)
+//   q    = x_i - c;  xr_i = f32(q - L rint(q/L)) (f64 per lane and block, |xr_i| <= L/2)
+// so that d' = xr_i - xr_j is d = x_i - x_j moved by a whole number of box lengths, |d'| <= L/2 + e (e = how far
+// the group's atoms reach from c). With |d| < 1.5 L the reference's single wrap yields the nearest image of d, and
+//   |d'| <= L/2            : d' IS that nearest image;
+//   L/2 < |d'| <= L/2 + e  : the nearest image is L - |d'| away.
+// So wherever |d'| <= L - r_cut - margin the plain difference is enough: either d' is the nearest image, or both d'
+// and the nearest image exceed the cutoff on that axis alone and the pair counts nowhere either way. The wave tests
+// this per (wave box, group box) and axis, lane-parallel over the groups of a tile: when all its lanes sit at the
+// same image n (the wave box does not straddle a wrap boundary of this centre), d' ranges over
+// [wlo' - ghi', whi' - glo'] (primed = relative to c, the wave box moved by n L). Only groups where that interval
+// reaches beyond L - r_cut (cutoffs close to L/2: the far corner of a neighbour at the edge of the cutoff) take the
+// per-pair f32 wrap d' - L rint(d'/L) on that axis (VAR bit). Blocks that the bound does not cover — some
+// |x_i - x_j| >= 1.5 L (atoms box lengths outside the cell, where the reference's single wrap is not the nearest
+// image) or |xr_i| + h beyond s_cap — are swept by the exact f64 chain (sweep_group_sj<., 2, 7>: general wrap,
+// valid for every d).
 // ------------------------------------------------------------------------------------------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int PK_QCAP = 320;     // queue entries per wave: drained above 64, one group of 4 j atoms adds at most 256
-constexpr int PK_QSTRIDE = 324;  // words per wave: the entries, then the entry counter
+constexpr int PK_QSTRIDE = 320;  // words per wave
+constexpr int PK_THREADS = 512;  // threads per block of the MODE 3 kernel (8 independent waves, one LDS histogram)
+constexpr int PK_BLOCKS_PER_CU = 8;  // (HIP: the second launch-bound is waves per SIMD) register budget for 6 waves per SIMD: <= 80 VGPRs
 
 struct PkCtx {
     f32x2 x2, y2, z2;     // this lane's i atom relative to the j tile's centre (+ shift), both halves equal
     f32x2 Lx2, Ly2, Lz2;  // box lengths (f32) for the axes that still need the per-pair wrap
+    f32x2 iLx2, iLy2, iLz2;  // and their reciprocals
     float rc2hi;          // pre-filter: every pair with rsq < r_cut^2 has rsq32 < rc2hi
-    unsigned *queue;      // this wave's queue (LDS); queue[PK_QCAP] = number of entries
+    unsigned *queue;      // this wave's queue (LDS)
+    int qn;               // entries queued (wave-uniform: kept in an SGPR)
     unsigned long long *lost;  // device counter of entries that did not fit the queue (must stay 0)
     // what the resolver needs
     const double4 *ats_i;  // sorted f64 records of the i atoms of this wave (64 consecutive)
@@ -278,30 +292,19 @@ struct PkCtx {
     int n_ti, n_tj;
 };
 
-// min(|d|, ||d| - L|) on both halves
-__device__ __forceinline__ f32x2 wrap_abs_pk(f32x2 d, f32x2 L)
+// d - L rint(d / L) on both halves: the image of d nearest to zero (|d| < 1.5 L). One rounding in the fma; the
+// rint may fall either way within rounding of |d| = L/2, where both images have the same magnitude.
+__device__ __forceinline__ f32x2 wrap_pk(f32x2 d, f32x2 L, f32x2 iL)
 {
-    const f32x2 a = __builtin_elementwise_max(d, -d);
-    const f32x2 b = a - L;
-    return __builtin_elementwise_min(a, __builtin_elementwise_max(b, -b));
-}
-
-// Two records = four j atoms through the scalar cache (see sload_records4)
-__device__ __forceinline__ void sload_rel4(const float *p, u32x8 &r0, u32x8 &r1)
-{
-    asm volatile(
-        "s_load_dwordx8 %0, %2, 0x0\n\t"
-        "s_load_dwordx8 %1, %2, 0x20\n\t"
-        "s_waitcnt lgkmcnt(0)"
-        : "=&s"(r0), "=&s"(r1)
-        : "s"(p)
-        : "memory");
+    const f32x2 t = d * iL;
+    const f32x2 n = {__builtin_rintf(t[0]), __builtin_rintf(t[1])};
+    return __builtin_elementwise_fma(-n, L, d);
 }
 
 // The exact chain for the n queued pairs: entry = (j index in the frame << 6) | lane of the i atom.
-__device__ __forceinline__ void pk_drain(const PkCtx &p, const FastCtx &c, int n, int lane)
+__device__ __forceinline__ void pk_drain(PkCtx &p, const FastCtx &c, int lane)
 {
-    if (n > PK_QCAP) n = PK_QCAP;
+    const int n = p.qn < PK_QCAP ? p.qn : PK_QCAP;
     for (int b = 0; b < n; b += 64) {
         if (b + lane < n) {
             const unsigned e = p.queue[b + lane];
@@ -328,54 +331,134 @@ __device__ __forceinline__ void pk_drain(const PkCtx &p, const FastCtx &c, int n
             }
         }
     }
-    if (lane == 0) p.queue[PK_QCAP] = 0u;
+    p.qn = 0;
 }
 
-// The four j atoms of one group (two records, already in SGPRs) against the wave's 64 i atoms.
+// The f32 records of one group: four j atoms as two packed records (x0, x1, y0, y1 | z0, z1, w0, w1) each. Loaded
+// with plain (compiler-visible) loads from a wave-uniform address, so that the compiler tracks their latency and
+// the load of the NEXT group can be in flight while the current one is swept.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+struct RelQ {
+    f32x4 a, b, c, d;
+};
+__device__ __forceinline__ RelQ load_relq(const float *__restrict__ p)
+{
+    // constant address space: the records were written by an earlier launch and are only read here, and the address
+    // is wave-uniform, so these become scalar loads (s_load_dwordx4/x8 into SGPRs through the scalar cache) — vector
+    // loads of one address by 64 lanes would cost the texture path 16 cycles each
+    typedef const __attribute__((address_space(4))) f32x4 *cptr;
+    const cptr q = (cptr)(unsigned long long)p;
+    RelQ r;
+    r.a = q[0];
+    r.b = q[1];
+    r.c = q[2];
+    r.d = q[3];
+    return r;
+}
+
+// One pair slot of the packed sweep, hand-scheduled: cutoff pre-filter, bin guess, guard-band test and the LDS
+// add for the lanes whose guess is safe, in 7 VALU + 5 SALU + 1 branch (the compiler's structurised version of the
+// same C++ spends 9 SALU and 3-4 branches on the exec-mask bookkeeping, and this kernel is bound by issue slots).
+// Returns the mask of lanes whose pair lies inside the error band (to be queued for the exact chain).
+// exec is restored before the block ends; v_sqrt_f32 needs one wait state before its result is read.
+__device__ __forceinline__ unsigned long long bin_pair(float rsq, float rc2hi, float gscale, float nearoff, float near2,
+                                                       unsigned rowbase)
+{
+    unsigned long long amb, save;
+    float t, fr;
+    asm volatile(
+        "v_cmp_gt_f32 vcc, %[rc2], %[rsq]\n\t"
+        "s_mov_b64 %[amb], 0\n\t"
+        "s_and_saveexec_b64 %[save], vcc\n\t"
+        "s_cbranch_execz 1f\n\t"
+        "v_sqrt_f32 %[t], %[rsq]\n\t"
+        "s_nop 0\n\t"
+        "v_fma_f32 %[t], %[t], %[gs], %[no]\n\t"
+        "v_fract_f32 %[fr], %[t]\n\t"
+        "v_cvt_i32_f32 %[t], %[t]\n\t"
+        "v_cmp_ge_f32 vcc, %[fr], %[n2]\n\t"
+        "v_lshl_add_u32 %[t], %[t], 2, %[rb]\n\t"
+        "s_andn2_b64 %[amb], exec, vcc\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"
+        "ds_add_u32 %[t], %[one]\n\t"
+        "1:\n\t"
+        "s_mov_b64 exec, %[save]"
+        : [amb] "=&s"(amb), [save] "=&s"(save), [t] "=&v"(t), [fr] "=&v"(fr)
+        : [rc2] "s"(rc2hi), [rsq] "v"(rsq), [gs] "v"(gscale), [no] "s"(nearoff), [n2] "v"(near2), [rb] "v"(rowbase),
+          [one] "v"(1u)
+        : "vcc", "scc", "memory");
+    return amb;
+}
+
+// The four j atoms of one group against the wave's 64 i atoms.
 // VAR: bit k = axis k takes the per-pair f32 wrap. jidx0 = index of the group's first atom in the frame's j set.
-template <bool DIAG, int VAR>
-__device__ __forceinline__ void sweep_group_pk(const u32x8 &rec0, const u32x8 &rec1, int jidx0, int local0,
-                                               const PkCtx &p, const FastCtx &c, int lane_in_tile, int lane)
+// PF: load the records at `next_p` into `next` (the group swept after this one) once the first operation on this
+// group's records has been issued. Scalar loads return out of order, so the compiler can only wait for ALL of
+// them (lgkmcnt(0)) before the first use of `rq`: that wait has to come before the prefetch is issued — the two
+// empty asm statements pin that order (the first depends on dx, i.e. on a use of rq) — and is free, because rq was
+// itself prefetched during the previous sweep.
+template <bool DIAG, int VAR, bool PF>
+__device__ __forceinline__ void sweep_group_pk(const RelQ &rq, int jidx0, int local0, PkCtx &p, const FastCtx &c,
+                                               int lane_in_tile, int lane, const float *next_p, RelQ &next)
 {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const u32x8 &rec = h ? rec1 : rec0;
-        const f32x2 xj = {__uint_as_float(rec[0]), __uint_as_float(rec[1])};
-        const f32x2 yj = {__uint_as_float(rec[2]), __uint_as_float(rec[3])};
-        const f32x2 zj = {__uint_as_float(rec[4]), __uint_as_float(rec[5])};
-        f32x2 dx = p.x2 - xj, dy = p.y2 - yj, dz = p.z2 - zj;
-        if (VAR & 1) dx = wrap_abs_pk(dx, p.Lx2);
-        if (VAR & 2) dy = wrap_abs_pk(dy, p.Ly2);
-        if (VAR & 4) dz = wrap_abs_pk(dz, p.Lz2);
+        const f32x4 ra = h ? rq.c : rq.a, rb = h ? rq.d : rq.b;
+        const f32x2 xj = {ra[0], ra[1]};
+        const f32x2 yj = {ra[2], ra[3]};
+        const f32x2 zj = {rb[0], rb[1]};
+        f32x2 dx = p.x2 - xj;
+        if (PF && h == 0) {
+            asm volatile("" ::"v"(dx) : "memory");
+            next = load_relq(next_p);
+            asm volatile("" ::: "memory");
+        }
+        f32x2 dy = p.y2 - yj, dz = p.z2 - zj;
+        if (VAR & 1) dx = wrap_pk(dx, p.Lx2, p.iLx2);
+        if (VAR & 2) dy = wrap_pk(dy, p.Ly2, p.iLy2);
+        if (VAR & 4) dz = wrap_pk(dz, p.Lz2, p.iLz2);
         f32x2 rsq = dx * dx;
         rsq = __builtin_elementwise_fma(dy, dy, rsq);
         rsq = __builtin_elementwise_fma(dz, dz, rsq);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            bool in = rsq[u] < p.rc2hi;
-            if (DIAG) in = in && (local0 + 2 * h + u > lane_in_tile);
-            if (in) {
-                const float nearoff = __uint_as_float(rec[6 + u]);
-                const float g1 = __builtin_fmaf(__builtin_amdgcn_sqrtf(rsq[u]), c.gscale, nearoff);
-                if (__builtin_amdgcn_fractf(g1) >= c.near2) {
-                    const unsigned addr = ((unsigned)(int)g1 << 2) + c.rowbase_me;
-                    asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"(1u) : "memory");
-                } else {
-                    // inside the error band of a bin edge (or of the cutoff): the exact chain decides, later
-                    const unsigned pos = atomicAdd(p.queue + PK_QCAP, 1u);
-                    if (pos < (unsigned)PK_QCAP)
+            const float nearoff = u ? rb[3] : rb[2];
+            float r2 = rsq[u];
+            if (DIAG) r2 = local0 + 2 * h + u > lane_in_tile ? r2 : 3.0e38f;  // i < j inside the diagonal tile
+            const unsigned long long amb = bin_pair(r2, p.rc2hi, c.gscale, nearoff, c.near2, c.rowbase_me);
+            if (amb) {  // wave-uniform, rare: some lane's pair is inside the error band -> the exact chain, later
+                // (the copy through a volatile asm keeps the per-lane test inside this branch: the compiler would
+                // otherwise fold both conditions into one divergent branch and pay 3 VALU per pair for it)
+                unsigned long long amb_in;
+                asm volatile("s_mov_b64 %0, %1" : "=s"(amb_in) : "s"(amb));
+                if ((amb_in >> lane) & 1ull) {
+                    const int pos = p.qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(amb_in >> 32),
+                                                                          __builtin_amdgcn_mbcnt_lo((unsigned)amb_in, 0u));
+                    if (pos < PK_QCAP)
                         p.queue[pos] = ((unsigned)(jidx0 + 2 * h + u) << 6) | (unsigned)lane;
-                    else  // cannot happen (drained above 64, a group adds <= 256); the host turns this into an error
+                    else  // cannot happen (drained above 64, a group adds <= 256); the host reports it
                         atomicAdd(p.lost, 1ull);
                 }
+                p.qn += __builtin_popcountll(amb_in);
             }
         }
     }
 }
 
-// One work item of the packed-f32 sweep (atom-atom, ordered-pair rows): as sj_item, with the tile-relative f32
-// records for the pair chain and the f64 chain (sweep_group_sj<., 2, 7>: the general wrap on all axes, valid for
-// every d) for the groups and tiles the f32 bound does not cover.
+// Does the plain difference d' = xr_i - xr_j suffice on this axis for every pair of (wave box, group box)?
+// All lanes of the wave must sit at the same image n relative to the centre c — the rint of both ends of the box
+// agree, with 1e-3 of slack so that every lane's own f64 rint agrees too — and |d'| must stay within th.
+__device__ __forceinline__ bool axis_plain(float wlo, float whi, float glo, float ghi, float c, float L, float iL,
+                                           float th)
+{
+    const float n0 = __builtin_rintf((wlo - c) * iL - 1.0e-3f), n1 = __builtin_rintf((whi - c) * iL + 1.0e-3f);
+    const float lo = (wlo - c) - n0 * L, hi = (whi - c) - n0 * L;
+    const float dmax = __builtin_fmaxf(__builtin_fabsf(lo - (ghi - c)), __builtin_fabsf(hi - (glo - c)));
+    return n0 == n1 && dmax <= th;
+}
+
+// One work item of the packed-f32 sweep (atom-atom, ordered-pair rows): the 64 i atoms of wave `wq` of tile I of
+// frame f against slice `split` of the tile's neighbour list.
 __device__ __forceinline__ void sj_item_pk(const PairArgs &a, FastCtx &c, unsigned *queue, int f, int I, int wq,
                                            int split, int lane)
 {
@@ -390,14 +473,13 @@ __device__ __forceinline__ void sj_item_pk(const PairArgs &a, FastCtx &c, unsign
     L.Ly = a.box[3 * f + 1];
     L.Lz = a.box[3 * f + 2];
     L.sx = L.sy = L.sz = 0.0;
+    const double iLx = 1.0 / L.Lx, iLy = 1.0 / L.Ly, iLz = 1.0 / L.Lz;
     const double4 *ats = a.aos + (long long)f * n_pad;
     const int lane_in_tile = wq * 64 + lane;
     const long long ig = (long long)I * TILE + lane_in_tile;
-    double4 me = ats[ig];
     const bool real_i = ig < a.ni;
-    if (!real_i) me = make_double4(PAD_I, PAD_I, PAD_I, __longlong_as_double(0LL));
     {
-        const int ti_me = (int)((unsigned)__double_as_longlong(me.w)) / a.n_ti;
+        const int ti_me = (int)((unsigned)__double_as_longlong(ats[ig].w)) / a.n_ti;  // (pad records: type 0)
         c.rowtab_me = nullptr;
         c.rowbase_me = c.lds_base + (unsigned)ti_me * (unsigned)a.n_tj * (unsigned)(a.nbins + 1) * 4u;
     }
@@ -405,12 +487,22 @@ __device__ __forceinline__ void sj_item_pk(const PairArgs &a, FastCtx &c, unsign
     const float4 wlo = a.wsph[2 * w], whi = a.wsph[2 * w + 1];
     const float4 *gb_f = a.gsph4 + (long long)f * a.nTj * (TILE / SJ_GROUP) * 2;
     const float fLx = (float)L.Lx, fLy = (float)L.Ly, fLz = (float)L.Lz;
+    const float r_cut = __builtin_sqrtf((float)a.rc2);
+    // |d'| up to here needs no per-pair wrap on that axis (see above); the margin covers the f32 box arithmetic
+    const float thx = fLx - r_cut - (1.0e-3f * fLx + 1.0e-3f);
+    const float thy = fLy - r_cut - (1.0e-3f * fLy + 1.0e-3f);
+    const float thz = fLz - r_cut - (1.0e-3f * fLz + 1.0e-3f);
+    const float fiLx = (float)iLx, fiLy = (float)iLy, fiLz = (float)iLz;
     PkCtx p;
     p.Lx2 = f32x2{fLx, fLx};
     p.Ly2 = f32x2{fLy, fLy};
     p.Lz2 = f32x2{fLz, fLz};
+    p.iLx2 = f32x2{(float)iLx, (float)iLx};
+    p.iLy2 = f32x2{(float)iLy, (float)iLy};
+    p.iLz2 = f32x2{(float)iLz, (float)iLz};
     p.rc2hi = a.rc2hi;
     p.queue = queue;
+    p.qn = 0;
     p.lost = a.overflow + 1;
     p.ats_i = ats + (long long)I * TILE + wq * 64;
     p.ats_j = ats;
@@ -421,10 +513,12 @@ __device__ __forceinline__ void sj_item_pk(const PairArgs &a, FastCtx &c, unsign
     p.n_ti = a.n_ti;
     p.n_tj = a.n_tj;
     const float *rel_f = a.rel + (long long)f * n_pad * 4;  // 4 floats per atom
-    const double *cen_f = a.cen + (long long)f * a.nTj * 8;
-    unsigned qn_v = 0u;  // the queue's entry count as of the end of the previous group (read back from LDS)
+    const int gpb = 1 << a.cen_shift;                        // groups per centre block
+    const int nblk = (TILE / SJ_GROUP) >> a.cen_shift;       // centre blocks per tile
+    const double *cen_f = a.cen + (long long)f * a.nTj * nblk * 8;
     for (int t = t_begin; t < t_end; ++t) {
         const int J = __builtin_amdgcn_readfirstlane((int)row_list[t]);
+        // every lane tests one 4-atom group box of the tile against this wave's box
         const float4 glo = gb_f[((long long)J * (TILE / SJ_GROUP) + lane) * 2];
         const float4 ghi = gb_f[((long long)J * (TILE / SJ_GROUP) + lane) * 2 + 1];
         const float gx = gapf(wlo.x, whi.x, glo.x, ghi.x, fLx);
@@ -436,82 +530,109 @@ __device__ __forceinline__ void sj_item_pk(const PairArgs &a, FastCtx &c, unsign
         const double4 *tile = ats + (long long)J * TILE;
         const float *rtile = rel_f + (long long)J * TILE * 4;
         const bool diag = J == I;
-        // hoisted wrap classes of the groups and the shift of the tile: the class of the first kept group
-        const unsigned cx = wrap_class(wlo.x, whi.x, glo.x, ghi.x, fLx);
-        const unsigned cy = wrap_class(wlo.y, whi.y, glo.y, ghi.y, fLy);
-        const unsigned cz = wrap_class(wlo.z, whi.z, glo.z, ghi.z, fLz);
-        const int g0 = __builtin_ctzll(km);
-        unsigned sx = (unsigned)__builtin_amdgcn_readlane((int)cx, g0);
-        unsigned sy = (unsigned)__builtin_amdgcn_readlane((int)cy, g0);
-        unsigned sz = (unsigned)__builtin_amdgcn_readlane((int)cz, g0);
-        if (diag || sx > 2u) sx = 0u;
-        if (diag || sy > 2u) sy = 0u;
-        if (diag || sz > 2u) sz = 0u;
-        const double shx = sx == 1u ? -L.Lx : sx == 2u ? L.Lx : 0.0;
-        const double shy = sy == 1u ? -L.Ly : sy == 2u ? L.Ly : 0.0;
-        const double shz = sz == 1u ? -L.Lz : sz == 2u ? L.Lz : 0.0;
-        const double ccx = cen_f[J * 8], ccy = cen_f[J * 8 + 1], ccz = cen_f[J * 8 + 2];
-        // does the error bound cover this (wave, tile)? largest |xr_i| + |xr_j| per axis against s_cap
-        const float ox = (float)(shx - ccx), oy = (float)(shy - ccy), oz = (float)(shz - ccz);
-        const float mix = __builtin_fmaxf(__builtin_fabsf(wlo.x + ox), __builtin_fabsf(whi.x + ox)) + (float)cen_f[J * 8 + 3];
-        const float miy = __builtin_fmaxf(__builtin_fabsf(wlo.y + oy), __builtin_fabsf(whi.y + oy)) + (float)cen_f[J * 8 + 4];
-        const float miz = __builtin_fmaxf(__builtin_fabsf(wlo.z + oz), __builtin_fabsf(whi.z + oz)) + (float)cen_f[J * 8 + 5];
-        const bool covered = __builtin_fmaxf(mix, __builtin_fmaxf(miy, miz)) * 1.0001f < a.s_cap;
-        // per axis: 0 = plain difference, 1 = per-pair f32 wrap, 2 = not expressible with this tile's shift
-        const unsigned mx = cx == sx ? 0u : (sx == 0u ? 1u : 2u);
-        const unsigned my = cy == sy ? 0u : (sy == 0u ? 1u : 2u);
-        const unsigned mz = cz == sz ? 0u : (sz == 0u ? 1u : 2u);
-        const bool exact = !__builtin_amdgcn_readfirstlane((int)covered) || (!diag && ((mx | my | mz) & 2u));
-        {  // groups (or the whole tile) the f32 bound does not cover: the f64 chain, general wrap on every axis
-            unsigned long long mk = __builtin_amdgcn_ballot_w64(keep && exact);
-            while (mk) {
-                const int g = __builtin_ctzll(mk);
-                mk &= mk - 1;
-                if (diag)
-                    sweep_group_sj<true, 2, 7>(tile + g * SJ_GROUP, g * SJ_GROUP, me.x, me.y, me.z, L, a.rc2, c, lane_in_tile);
-                else
-                    sweep_group_sj<false, 2, 7>(tile + g * SJ_GROUP, g * SJ_GROUP, me.x, me.y, me.z, L, a.rc2, c, lane_in_tile);
-            }
-        }
-        if (!__builtin_amdgcn_ballot_w64(keep && !exact)) continue;
+        // variant of this lane's group: the axes on which some |d'| may exceed L - r_cut (per-pair wrap needed)
+        unsigned var;
         {
-            const float xr = real_i ? (float)((me.x - ccx) + shx) : -1.0e18f;
-            const float yr = real_i ? (float)((me.y - ccy) + shy) : -1.0e18f;
-            const float zr = real_i ? (float)((me.z - ccz) + shz) : -1.0e18f;
-            p.x2 = f32x2{xr, xr};
-            p.y2 = f32x2{yr, yr};
-            p.z2 = f32x2{zr, zr};
+            const double *cg = cen_f + ((long long)J * nblk + (lane >> a.cen_shift)) * 8;
+            var = (axis_plain(wlo.x, whi.x, glo.x, ghi.x, (float)cg[0], fLx, fiLx, thx) ? 0u : 1u) |
+                  (axis_plain(wlo.y, whi.y, glo.y, ghi.y, (float)cg[1], fLy, fiLy, thy) ? 0u : 2u) |
+                  (axis_plain(wlo.z, whi.z, glo.z, ghi.z, (float)cg[2], fLz, fiLz, thz) ? 0u : 4u);
+            if (diag) var = 8u;  // the diagonal tile: one instantiation (wrap on all axes, i < j inside the tile)
         }
-        const int jbase = J * TILE;
-        // variant of a group: the set of axes with the per-pair wrap (the diagonal tile: all three, no shift)
-        const unsigned var = diag ? 8u : (mx & 1u) | ((my & 1u) << 1) | ((mz & 1u) << 2);
-        for (unsigned A = diag ? 8u : 0u; A <= (diag ? 8u : 7u); ++A) {
-            unsigned long long mk = __builtin_amdgcn_ballot_w64(keep && !exact && var == A);
-            while (mk) {
-                const int g = __builtin_ctzll(mk);
-                mk &= mk - 1;
-                u32x8 r0, r1;
-                sload_rel4(rtile + g * SJ_GROUP * 4, r0, r1);
-                // (the wait of the scalar loads also covers the read-back of the entry count)
-                if (__builtin_amdgcn_readfirstlane((int)qn_v) > 64) pk_drain(p, c, __builtin_amdgcn_readfirstlane((int)qn_v), lane);
-                const int j0 = jbase + g * SJ_GROUP, l0 = g * SJ_GROUP;
-                switch (A) {
-                case 0: sweep_group_pk<false, 0>(r0, r1, j0, l0, p, c, lane_in_tile, lane); break;
-                case 1: sweep_group_pk<false, 1>(r0, r1, j0, l0, p, c, lane_in_tile, lane); break;
-                case 2: sweep_group_pk<false, 2>(r0, r1, j0, l0, p, c, lane_in_tile, lane); break;
-                case 3: sweep_group_pk<false, 3>(r0, r1, j0, l0, p, c, lane_in_tile, lane); break;
-                case 4: sweep_group_pk<false, 4>(r0, r1, j0, l0, p, c, lane_in_tile, lane); break;
-                case 5: sweep_group_pk<false, 5>(r0, r1, j0, l0, p, c, lane_in_tile, lane); break;
-                case 6: sweep_group_pk<false, 6>(r0, r1, j0, l0, p, c, lane_in_tile, lane); break;
-                case 7: sweep_group_pk<false, 7>(r0, r1, j0, l0, p, c, lane_in_tile, lane); break;
-                default: sweep_group_pk<true, 7>(r0, r1, j0, l0, p, c, lane_in_tile, lane); break;
+        for (int b = 0; b < nblk; ++b) {
+            const unsigned long long bm = nblk == 1 ? ~0ull : ((1ull << gpb) - 1ull) << (b * gpb);
+            if (!(km & bm)) continue;
+            // this lane's i atom at the periodic image nearest to the block's centre
+            const double *cb = cen_f + ((long long)J * nblk + b) * 8;
+            // (the i atom is re-read per block rather than kept live through the pair loop: 8 VGPRs)
+            double4 me = ats[ig];
+            if (!real_i) me = make_double4(PAD_I, PAD_I, PAD_I, __longlong_as_double(0LL));
+            const double ccx = cb[0], ccy = cb[1], ccz = cb[2];
+            const double hx = cb[3], hy = cb[4], hz = cb[5];
+            const double qx = me.x - ccx, qy = me.y - ccy, qz = me.z - ccz;
+            const double wx = __builtin_fma(-__builtin_rint(qx * iLx), L.Lx, qx);
+            const double wy = __builtin_fma(-__builtin_rint(qy * iLy), L.Ly, qy);
+            const double wz = __builtin_fma(-__builtin_rint(qz * iLz), L.Lz, qz);
+            // covered: every |x_i - x_j| < 1.5 L (single wrap = nearest image), |xr_i| + |xr_j| within the error
+            // bound's s_cap, blocks much smaller than the cell
+            const bool ok = (__builtin_fabs(qx) + hx < 1.49 * L.Lx) && (__builtin_fabs(qy) + hy < 1.49 * L.Ly) &&
+                            (__builtin_fabs(qz) + hz < 1.49 * L.Lz) &&
+                            (__builtin_fabs(wx) + hx < (double)a.s_cap) && (__builtin_fabs(wy) + hy < (double)a.s_cap) &&
+                            (__builtin_fabs(wz) + hz < (double)a.s_cap) && hx < 0.45 * L.Lx && hy < 0.45 * L.Ly &&
+                            hz < 0.45 * L.Lz;
+            if (__builtin_amdgcn_ballot_w64(real_i && !ok)) {
+                unsigned long long mk = km & bm;
+                while (mk) {
+                    const int g = __builtin_ctzll(mk);
+                    mk &= mk - 1;
+                    if (diag)
+                        sweep_group_sj<true, 2, 7>(tile + g * SJ_GROUP, g * SJ_GROUP, me.x, me.y, me.z, L, a.rc2, c, lane_in_tile);
+                    else
+                        sweep_group_sj<false, 2, 7>(tile + g * SJ_GROUP, g * SJ_GROUP, me.x, me.y, me.z, L, a.rc2, c, lane_in_tile);
                 }
-                qn_v = queue[PK_QCAP];
+                continue;
             }
+            {
+                const float xr = real_i ? (float)wx : -1.0e18f;
+                const float yr = real_i ? (float)wy : -1.0e18f;
+                const float zr = real_i ? (float)wz : -1.0e18f;
+                p.x2 = f32x2{xr, xr};
+                p.y2 = f32x2{yr, yr};
+                p.z2 = f32x2{zr, zr};
+            }
+            const int jbase = J * TILE;
+#define PK_DRAIN_CHECK() \
+    if (p.qn > 64) pk_drain(p, c, lane)
+            if (!diag) {
+                // the common variant (no per-pair wrap), software-pipelined: the records of the next group are
+                // loaded while the current group is swept; two buffers, loop unrolled by two (no register copies)
+                unsigned long long mk = __builtin_amdgcn_ballot_w64(keep && var == 0u) & bm;
+                if (mk) {
+                    int gA = __builtin_ctzll(mk);
+                    mk &= mk - 1;
+                    RelQ qA = load_relq(rtile + gA * SJ_GROUP * 4), qB;
+                    for (;;) {
+                        PK_DRAIN_CHECK();
+                        const bool moreB = mk != 0;
+                        const int gB = moreB ? __builtin_ctzll(mk) : gA;
+                        mk &= mk - 1;
+                        sweep_group_pk<false, 0, true>(qA, jbase + gA * SJ_GROUP, gA * SJ_GROUP, p, c, lane_in_tile, lane,
+                                                       rtile + gB * SJ_GROUP * 4, qB);
+                        if (!moreB) break;
+                        PK_DRAIN_CHECK();
+                        const bool moreA = mk != 0;
+                        gA = moreA ? __builtin_ctzll(mk) : gB;
+                        mk &= mk - 1;
+                        sweep_group_pk<false, 0, true>(qB, jbase + gB * SJ_GROUP, gB * SJ_GROUP, p, c, lane_in_tile, lane,
+                                                       rtile + gA * SJ_GROUP * 4, qA);
+                        if (!moreA) break;
+                    }
+                }
+            }
+            for (unsigned A = diag ? 8u : 1u; A <= (diag ? 8u : 7u); ++A) {
+                unsigned long long mk = __builtin_amdgcn_ballot_w64(keep && var == A) & bm;
+                while (mk) {
+                    const int g = __builtin_ctzll(mk);
+                    mk &= mk - 1;
+                    RelQ q = load_relq(rtile + g * SJ_GROUP * 4), qnone;
+                    PK_DRAIN_CHECK();
+                    const int j0 = jbase + g * SJ_GROUP, l0 = g * SJ_GROUP;
+                    switch (A) {
+                    case 1: sweep_group_pk<false, 1, false>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
+                    case 2: sweep_group_pk<false, 2, false>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
+                    case 3: sweep_group_pk<false, 3, false>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
+                    case 4: sweep_group_pk<false, 4, false>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
+                    case 5: sweep_group_pk<false, 5, false>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
+                    case 6: sweep_group_pk<false, 6, false>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
+                    case 7: sweep_group_pk<false, 7, false>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
+                    default: sweep_group_pk<true, 7, false>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
+                    }
+                }
+            }
+#undef PK_DRAIN_CHECK
         }
     }
-    const int n_left = __builtin_amdgcn_readfirstlane((int)queue[PK_QCAP]);
-    if (n_left > 0) pk_drain(p, c, n_left, lane);
+    if (p.qn > 0) pk_drain(p, c, lane);
 }
 
 // Assertion at the top of every work-loop iteration: the whole wave is here (the item index is drawn by lane 0
@@ -530,8 +651,12 @@ __device__ __forceinline__ bool work_loop_sane(const PairArgs &a, long long iter
 // dry. Every wave leaves the loop as soon as the counter passes the item count.
 // PERSIST = false (per-frame output): block = (frame, tile, list slice), one flush per block.
 template <int MODE, bool PERSIST>
-__global__ __launch_bounds__(TILE) void pair_hist_sj_kernel(const PairArgs a)
+__global__ __launch_bounds__(MODE == 3 ? PK_THREADS : TILE, MODE == 3 ? PK_BLOCKS_PER_CU : 1) void pair_hist_sj_kernel(const PairArgs a)
 {
+    // threads per block: the waves are independent (they share only the LDS histogram), so the block size is free.
+    // MODE 3 runs 8 waves per block: LDS (one histogram per block) then allows 6 waves per SIMD instead of 5, which
+    // this latency-bound sweep (scalar record loads from L2) converts into VALU utilisation.
+    constexpr int BS = MODE == 3 ? PK_THREADS : TILE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const long long bid = blockIdx.x;
@@ -548,10 +673,9 @@ __global__ __launch_bounds__(TILE) void pair_hist_sj_kernel(const PairArgs a)
     unsigned *s_row = reinterpret_cast<unsigned *>(smem + off);  // MODE 3: the waves' queues of deferred pairs instead
     const unsigned lds_base =
         (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char *)smem;
-    for (int k = tid; k < hist_words; k += TILE) s_hist[k] = 0u;
-    if (MODE == 3 && tid < TILE / 64) s_row[tid * PK_QSTRIDE + PK_QCAP] = 0u;  // the waves' queues start empty
+    for (int k = tid; k < hist_words; k += BS) s_hist[k] = 0u;
     if (MODE < 2)
-        for (int k = tid; k < a.n_ti * a.n_tj; k += TILE) {
+        for (int k = tid; k < a.n_ti * a.n_tj; k += BS) {
             const int ti = k % a.n_ti, tj = k / a.n_ti;
             const unsigned cl = a.cls[ti * a.n_tj + tj];
             s_row[k] = lds_base + (cl == 0xFFu ? (unsigned)a.n_cls : cl) * (unsigned)row_len * 4u;
@@ -560,7 +684,7 @@ __global__ __launch_bounds__(TILE) void pair_hist_sj_kernel(const PairArgs a)
     c.hist = s_hist;
     c.edges = a.edges;
     if (MODE == 1) {
-        for (int k = tid; k <= a.nbins + 1; k += TILE) s_edges[k] = a.edges[k];
+        for (int k = tid; k <= a.nbins + 1; k += BS) s_edges[k] = a.edges[k];
         c.edges = s_edges;
     }
     c.gscale = a.gscale;
@@ -627,7 +751,7 @@ __global__ __launch_bounds__(TILE) void pair_hist_sj_kernel(const PairArgs a)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
     unsigned *slice = a.slices + (size_t)bid * (size_t)hist_words;
-    for (int w = tid; w < hist_words; w += TILE) slice[w] = s_hist[w];
+    for (int w = tid; w < hist_words; w += BS) slice[w] = s_hist[w];
 }
 
 // rows[o][w] = sum of slice word w over the blocks of output o: per-frame output o = frame f, whose blocks are
@@ -659,9 +783,11 @@ size_t lds_bytes_sj_ordered(int nbins, int n_ti, int n_tj)
     return (((size_t)n_ti * n_tj * (nbins + 1) * 4 + 15) & ~size_t(15)) + 16;
 }
 
+int sj_block_threads(int mode) { return mode == 3 ? PK_THREADS : TILE; }
+
 size_t lds_bytes_sj_pk(int nbins, int n_ti, int n_tj)
 {
-    return (((size_t)n_ti * n_tj * (nbins + 1) * 4 + 15) & ~size_t(15)) + (size_t)(TILE / 64) * PK_QSTRIDE * 4;
+    return (((size_t)n_ti * n_tj * (nbins + 1) * 4 + 15) & ~size_t(15)) + (size_t)(PK_THREADS / 64) * PK_QSTRIDE * 4;
 }
 
 // Error bound of the packed-f32 bin guess, in bins (see the MODE 3 header). u = 2^-24 (f32 round to nearest).

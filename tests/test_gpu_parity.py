@@ -679,6 +679,99 @@ def test_culled_path_randomised_against_dense(B):
     culled.close()
 
 
+# ------------------------------------------------------------------ packed-f32 classification sweep (rdf_pk)
+def _pk_case(rng, trial):
+    """A geometry that stresses the packed-f32 sweep: the cutoff on a bin edge (its precondition), lattices whose
+    distances sit exactly ON bin edges, cutoffs up to L/2, cell origins anywhere, strays box lengths outside."""
+    n = int(rng.integers(2100, 6000))
+    bin_size = float(rng.choice([0.05, 0.1, 0.025]))
+    L = rng.uniform(20.0, 64.0, 3)
+    if trial % 5 == 0:
+        L[:] = L[0]  # cubic
+    lo = rng.uniform(-1.0, 1.0, 3) * L
+    F = int(rng.integers(1, 4))
+    nbins = int(rng.uniform(0.06, 0.4999) * L.min() / bin_size)
+    r_cut = nbins * bin_size  # on a bin edge, as in every RDF call that divides its cutoff into whole bins
+    kind = trial % 4
+    if kind == 0:  # a lattice with spacing = a whole number of bins: most distances are exactly on edges
+        g = int(round(n ** (1 / 3))) + 1
+        a = bin_size * max(1, int(L.min() / g / bin_size))
+        idx = rng.choice(g ** 3, n, replace=False)
+        cell = np.stack([idx % g, (idx // g) % g, idx // (g * g)]).astype(np.float64)
+        xyz = np.stack([cell * a + lo[:, None]] * F)
+    elif kind == 1:  # blobs
+        centres = rng.uniform(0, 1, (6, 3))
+        frac = (centres[rng.integers(0, 6, n)] + rng.normal(0, 0.07, (n, 3))) % 1.0
+        xyz = np.stack([(frac.T * L[:, None] + lo[:, None])] * F) + rng.normal(0, 0.05, (F, 3, n))
+    else:
+        xyz = rng.uniform(0, 1, (F, 3, n)) * L[None, :, None] + lo[None, :, None]
+    if trial % 3 == 1:
+        idx = rng.choice(n, 25, replace=False)
+        xyz[:, :, idx] += rng.integers(-2, 3, (F, 3, 25)) * L[None, :, None]
+    box = np.tile(L, (F, 1))
+    if trial % 7 == 3:
+        box = box * (1.0 + 0.01 * np.arange(F))[:, None]  # NPT: another box every frame
+    n_types = int(rng.integers(1, 5))
+    ty = rng.integers(1, n_types + 1, n).astype(np.int32)
+    rel = np.array([[1, 1], [1, n_types], [n_types, n_types]])
+    return xyz, ty, box, rel, r_cut, bin_size, nbins
+
+
+def test_packed_f32_sweep_equals_f64_sweep(B):
+    """rdf_pk: pairs are classified with packed f32 arithmetic and every pair inside the error band of a bin edge
+    or of the cutoff is resolved by the exact f64 chain — the integers must be those of the all-f64 sweep (itself
+    pinned to the oracle and the goldens above), per frame and frame-summed."""
+    from mdproptools_amd._lib import Context
+
+    rng = np.random.default_rng(77001)
+    f64, pk = Context(0), Context(0)
+    for ctx, v in ((f64, 0), (pk, 1)):
+        ctx.set_option("rdf_cull", 1)
+        ctx.set_option("rdf_pk", v)
+    engaged = 0
+    for trial in range(36):
+        xyz, ty, box, rel, r_cut, bin_size, nbins = _pk_case(rng, trial)
+        per_frame = bool(trial % 2)
+        a = B.rdf_loop(xyz, ty, box, rel, r_cut, bin_size, nbins, per_frame=per_frame, ctx=f64)
+        b = B.rdf_loop(xyz, ty, box, rel, r_cut, bin_size, nbins, per_frame=per_frame, ctx=pk)
+        engaged += "<3," in pk.last_kernel_name()
+        msg = "trial %d n=%d box=%s r_cut=%.4f bin=%.3f kernel=%s" % (trial, xyz.shape[2], box[0], r_cut, bin_size,
+                                                                     pk.last_kernel_name())
+        np.testing.assert_array_equal(a[0], b[0], err_msg=msg)
+        np.testing.assert_array_equal(a[1], b[1], err_msg=msg)
+        assert a[2] == b[2], msg
+    assert engaged >= 24, "the packed-f32 kernel ran in only %d of 36 cases" % engaged
+    f64.close()
+    pk.close()
+
+
+def test_packed_f32_sweep_against_oracle(B):
+    """The default path of a C2-shaped call (packed-f32 sweep) against the C oracle, and the cases where the mode
+    must NOT engage (cutoff inside a bin) still right."""
+    from mdproptools_amd import synth
+    from mdproptools_amd._lib import Context
+
+    n, L = 4000, 36.8
+    xyz = synth.rdf_frames(n, range(2), L, 9)
+    ty = synth.rdf_types(n)
+    rel = np.array(synth.ALL_PAIRS_4)
+    box = np.full((2, 3), L)
+    ctx = Context(0)
+    ctx.set_option("rdf_cull", 1)
+    for r_cut, bin_size, nbins in ((12.0, 0.05, 240), (12.02, 0.05, 240), (18.0, 0.1, 180), (18.3, 0.1, 183)):
+        full, part, ov = B.rdf_loop(xyz, ty, box, rel, r_cut, bin_size, nbins, ctx=ctx)
+        on_edge = abs(r_cut / bin_size - round(r_cut / bin_size)) < 1e-6
+        assert ("<3," in ctx.last_kernel_name()) == on_edge, (r_cut, ctx.last_kernel_name())
+        ovs = 0
+        for f in range(2):
+            cf, cp, cov = C.rdf_pairs(xyz[f], ty, rel, box[f], r_cut * r_cut, bin_size, nbins)
+            np.testing.assert_array_equal(full[f], cf)
+            np.testing.assert_array_equal(part[f], cp)
+            ovs += cov
+        assert ov == ovs
+    ctx.close()
+
+
 def test_culled_path_large_box_auto(B):
     """BASELINE C3 geometry at reduced N (same density: L = 48.3 A for 10k atoms, r_cut 6.8): the
     automatic choice takes the culled path; result against the C oracle."""

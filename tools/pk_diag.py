@@ -20,8 +20,9 @@ res = {}
 for v in (0, pk):
     ctx = Context(0)
     ctx.set_option("rdf_pk", v)
-    res[v] = B.rdf_loop(xyz, ty, box, rel, 20.0, 0.05, 400, per_frame=per_frame, ctx=ctx)
-    print("rdf_pk", v, "kernel", ctx.last_kernel_name(), "ms", ctx.last_kernel_ms(), "sum", int(res[v][0].sum()), flush=True)
+    for rep in range(3):
+        res[v] = B.rdf_loop(xyz, ty, box, rel, 20.0, 0.05, 400, per_frame=per_frame, ctx=ctx)
+        print("rdf_pk", v, "rep", rep, "kernel", ctx.last_kernel_name(), "ms", ctx.last_kernel_ms(), "sum", int(res[v][0].sum()), flush=True)
 same = all(np.array_equal(a, b) for a, b in zip(res[0][:2], res[pk][:2])) and res[0][2] == res[pk][2]
 print("identical:", same)
 if not same:
