@@ -275,7 +275,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int PK_QCAP = 320;     // queue entries per wave: drained above 64, one group of 4 j atoms adds at most 256
 constexpr int PK_QSTRIDE = 320;  // words per wave
 constexpr int PK_THREADS = 512;  // threads per block of the MODE 3 kernel (8 independent waves, one LDS histogram)
-constexpr int PK_BLOCKS_PER_CU = 8;  // (HIP: the second launch-bound is waves per SIMD) register budget for 6 waves per SIMD: <= 80 VGPRs
+constexpr int PK_BLOCKS_PER_CU = 6;  // (HIP: the second launch-bound is waves per SIMD) register budget for 6 waves per SIMD: <= 80 VGPRs
 
 struct PkCtx {
     f32x2 x2, y2, z2;     // this lane's i atom relative to the j tile's centre (+ shift), both halves equal
@@ -484,7 +484,11 @@ __device__ __forceinline__ void sj_item_pk(const PairArgs &a, FastCtx &c, unsign
         c.rowbase_me = c.lds_base + (unsigned)ti_me * (unsigned)a.n_tj * (unsigned)(a.nbins + 1) * 4u;
     }
     const long long w = ((long long)f * a.nTi + I) * (TILE / 64) + wq;
-    const float4 wlo = a.wsph[2 * w], whi = a.wsph[2 * w + 1];
+    // (wave-uniform: through the constant address space, so that the box lives in SGPRs, not in 8 VGPRs)
+    typedef const __attribute__((address_space(4))) f32x4 *cbox;
+    const cbox wb = (cbox)(unsigned long long)(a.wsph + 2 * w);
+    const f32x4 wlo4 = wb[0], whi4 = wb[1];
+    const float4 wlo = make_float4(wlo4[0], wlo4[1], wlo4[2], wlo4[3]), whi = make_float4(whi4[0], whi4[1], whi4[2], whi4[3]);
     const float4 *gb_f = a.gsph4 + (long long)f * a.nTj * (TILE / SJ_GROUP) * 2;
     const float fLx = (float)L.Lx, fLy = (float)L.Ly, fLz = (float)L.Lz;
     const float r_cut = __builtin_sqrtf((float)a.rc2);
