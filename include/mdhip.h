@@ -94,6 +94,14 @@ int mdhip_set_option(mdhip_ctx *ctx, const char *key, int value);
  * never depends on device sqrt/div rounding. `edges` has nbins+1 entries.
  */
 int mdhip_bin_edges(double bin_size, int nbins, double *edges);
+/*
+ * Bound (in bins) on |g32 - sqrt(rsq_ref)/bin_size - addend| of the packed-f32 bin guess the pair kernel uses to
+ * classify pairs: coordinates relative to a tile centre with |xr_i| + |xr_j| <= s_cap per axis, boxes up
+ * to l_max, n_rows histogram rows of nbins+1 words riding in the guess. Pairs whose guess is within twice this bound
+ * (plus slack) of an integer are resolved by the exact f64 chain instead. Exposed so that the bound can be checked
+ * against an emulation of the f32 chain (tests/test_abi_cpu.py); a pure function, no device needed.
+ */
+double mdhip_pk_error_bound(double r_cut, double bin_size, int nbins, int n_rows, double s_cap, double l_max);
 
 /* ---- R3: _rdf_loop (+ _calc_rsq, _remove_outliers) ------------------------ */
 /*

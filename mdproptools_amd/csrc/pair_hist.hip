@@ -672,6 +672,11 @@ int check_common(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const void *
 
 extern "C" {
 
+double mdhip_pk_error_bound(double r_cut, double bin_size, int nbins, int n_rows, double s_cap, double l_max)
+{
+    return pk_error_bound(r_cut, bin_size, nbins, n_rows, s_cap, l_max);
+}
+
 int mdhip_rdf_atomic(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *xyz,
                      int on_device, const int32_t *type, int64_t type_frame_stride,
                      const double *box, int n_rel, const int32_t *rel, double r_cut_sq,

@@ -114,3 +114,75 @@ def test_header_is_plain_c(tmp_path):
     run = subprocess.run([str(exe)], capture_output=True, text=True)
     assert run.returncode == 0, (run.stdout, run.stderr)
     assert float(run.stdout.split()[1]) > 0.039  # edges[4] ~ (4 * 0.05)^2
+
+
+def _f32_guess_emulation(rng, n, L, r_cut, bin_size, s_cap, wrap):
+    """Emulates, pair by pair in IEEE float32, what pair_hist_sj_kernel<3> computes for the bin guess (DESIGN.md
+    4.1b): tile-relative coordinates rounded to f32, the packed difference / product / two fused multiply-adds,
+    an (exactly rounded) square root, 1/ddr rounded to f32 and the final fma — next to the reference's f64 value."""
+    f32 = np.float32
+    Lv = np.array(L, dtype=np.float64)
+    c = rng.uniform(0, 1, 3) * Lv                               # tile centre
+    xj = c + rng.uniform(-1, 1, (n, 3)) * 0.25 * (s_cap - r_cut)  # j atoms around the centre
+    # i atoms anywhere within reach of the j atoms, possibly across the periodic boundary
+    u = rng.normal(size=(n, 3))
+    u /= np.linalg.norm(u, axis=1)[:, None]
+    xi = xj + u * rng.uniform(0, 1.02 * r_cut, (n, 1)) + rng.integers(-1, 2, (n, 3)) * Lv
+    # the reference (rdf_cn.py:35-69): single wrap, f64
+    d = xi - xj
+    d = np.where(np.abs(d) > Lv / 2, d - np.sign(d) * Lv, d)
+    rsq_ref = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+    g_ref = np.sqrt(rsq_ref) / bin_size
+    # the device chain; it only covers lanes with |x_i - c| + h < 1.49 L (the reference's single wrap is the nearest
+    # image there) — anything else is swept by the f64 chain
+    q = xi - c
+    h = np.abs(xj - c).max(axis=0)
+    cov = np.all(np.abs(q) + h < 1.49 * Lv, axis=1)
+    xi, xj, q, g_ref, rsq_ref = xi[cov], xj[cov], q[cov], g_ref[cov], rsq_ref[cov]
+    xr_i = (q - Lv * np.rint(q / Lv)).astype(f32)               # f64 per lane, then one rounding to f32
+    xr_j = (xj - c).astype(f32)
+    dd = xr_i - xr_j                                            # f32 subtraction
+    if wrap:
+        L32, iL32 = Lv.astype(f32), (1.0 / Lv).astype(f32)
+        nn = np.rint(dd * iL32)                                 # f32 product, round to even
+        dd = (dd.astype(np.float64) - nn.astype(np.float64) * L32.astype(np.float64)).astype(f32)  # one fma rounding
+    else:
+        # where the kernel takes the plain difference: |d'| <= L - r_cut - margin on every axis (axis_plain)
+        margin = 1.0e-3 * Lv + 1.0e-3
+        keep = np.all(np.abs(dd.astype(np.float64)) <= Lv - r_cut - margin, axis=1)
+        dd, g_ref, rsq_ref = dd[keep], g_ref[keep], rsq_ref[keep]
+        # d' is the nearest image unless some |d'| > L/2 — and then BOTH d' and the nearest image are beyond the
+        # cutoff on that axis alone, so the pair is out of the cutoff for the reference and for the f32 chain alike
+        far = np.any(np.abs(dd.astype(np.float64)) > Lv / 2, axis=1)
+        assert np.all(rsq_ref[far] > r_cut * r_cut * (1 + 1e-6))
+        assert np.all(np.max(np.abs(dd[far].astype(np.float64)), axis=1) > r_cut * (1 + 1e-6))
+        dd, g_ref, rsq_ref = dd[~far], g_ref[~far], rsq_ref[~far]
+    r = dd[:, 0] * dd[:, 0]                                     # f32 product
+    r = (dd[:, 1].astype(np.float64) ** 2 + r.astype(np.float64)).astype(f32)  # fma: exact in f64, one rounding
+    r = (dd[:, 2].astype(np.float64) ** 2 + r.astype(np.float64)).astype(f32)
+    s = np.sqrt(r.astype(np.float64)).astype(f32)               # <= 0.5 ulp; the bound allows 1 ulp (v_sqrt_f32)
+    gs = f32(1.0 / bin_size)
+    g32 = (s.astype(np.float64) * np.float64(gs)).astype(f32)   # fma with a zero addend
+    inside = rsq_ref < (1.02 * r_cut) ** 2
+    return np.abs(g32.astype(np.float64) - g_ref)[inside]
+
+
+@pytest.mark.parametrize("L,r_cut,bin_size", [((50.0, 50.0, 50.0), 20.0, 0.05), ((104.0, 104.0, 104.0), 20.0, 0.05),
+                                              ((31.0, 44.0, 37.5), 15.4, 0.1), ((26.0, 26.0, 26.0), 12.5, 0.025)])
+def test_packed_f32_error_bound_covers_emulation(L, r_cut, bin_size):
+    """The exactness of the packed-f32 sweep rests on mdhip_pk_error_bound: every pair whose f32 guess is farther
+    than that from an integer is binned without the f64 chain. Emulate the device's f32 operations on 400k random
+    pairs per case (with and without the per-pair wrap) and compare the worst observed deviation with the bound."""
+    lib = _lib.load()
+    nbins = int(round(r_cut / bin_size))
+    edge = (256 * L[0] * L[1] * L[2] / 10000.0) ** (1 / 3)
+    s_cap = r_cut + 3.5 * edge
+    bound = lib.mdhip_pk_error_bound(r_cut, bin_size, nbins, 1, s_cap, max(L))
+    assert 0 < bound < 0.01
+    rng = np.random.default_rng(4242)
+    for wrap in (False, True):
+        err = _f32_guess_emulation(rng, 400_000, L, r_cut, bin_size, s_cap, wrap)
+        assert len(err) > 100_000
+        # the emulated chain has an exactly rounded sqrt (the device: 1 ulp), so it must sit well inside
+        assert err.max() < 0.8 * bound, (wrap, err.max(), bound)
+        assert err.max() > 0.02 * bound, "the bound is vacuous"
