@@ -541,7 +541,8 @@ __device__ __forceinline__ void sj_item_pk(const PairArgs &a, FastCtx &c, unsign
             var = (axis_plain(wlo.x, whi.x, glo.x, ghi.x, (float)cg[0], fLx, fiLx, thx) ? 0u : 1u) |
                   (axis_plain(wlo.y, whi.y, glo.y, ghi.y, (float)cg[1], fLy, fiLy, thy) ? 0u : 2u) |
                   (axis_plain(wlo.z, whi.z, glo.z, ghi.z, (float)cg[2], fLz, fiLz, thz) ? 0u : 4u);
-            if (diag) var = 8u;  // the diagonal tile: one instantiation (wrap on all axes, i < j inside the tile)
+            // the diagonal tile (i < j inside the tile): plain where every axis qualifies, else the wrap on all axes
+            if (diag) var = var == 0u ? 9u : 8u;
         }
         for (int b = 0; b < nblk; ++b) {
             const unsigned long long bm = nblk == 1 ? ~0ull : ((1ull << gpb) - 1ull) << (b * gpb);
@@ -613,7 +614,7 @@ __device__ __forceinline__ void sj_item_pk(const PairArgs &a, FastCtx &c, unsign
                     }
                 }
             }
-            for (unsigned A = diag ? 8u : 1u; A <= (diag ? 8u : 7u); ++A) {
+            for (unsigned A = diag ? 8u : 1u; A <= (diag ? 9u : 7u); ++A) {
                 unsigned long long mk = __builtin_amdgcn_ballot_w64(keep && var == A) & bm;
                 while (mk) {
                     const int g = __builtin_ctzll(mk);
@@ -629,6 +630,7 @@ __device__ __forceinline__ void sj_item_pk(const PairArgs &a, FastCtx &c, unsign
                     case 5: sweep_group_pk<false, 5, false>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
                     case 6: sweep_group_pk<false, 6, false>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
                     case 7: sweep_group_pk<false, 7, false>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
+                    case 9: sweep_group_pk<true, 0, false>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
                     default: sweep_group_pk<true, 7, false>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
                     }
                 }
