@@ -98,28 +98,20 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
     if (cls_per_pass > p.n_cls) cls_per_pass = p.n_cls;
     if (cls_per_pass > 250) cls_per_pass = 250;
 
-    // Ordered-pair rows (MODE 2 of the scalar-j kernel): one LDS row per (ti, tj) addressed without a table —
-    // the row offset rides in the addend of the bin guess. Needs all n_ti^2 rows in LDS at >= 4 blocks per CU
-    // and all classes in one pass.
+    // Ordered-pair rows (MODE 2 / 3 of the scalar-j kernel): one LDS row per (ti, tj) addressed without a table —
+    // the row offset rides in the addend of the bin guess. Needs all n_ti^2 rows in LDS and all classes in one pass:
+    // at >= 4 blocks of 4 waves per CU for the all-f64 sweep, at 3 blocks of 8 waves (6 waves per SIMD) for the
+    // packed-f32 sweep, whose blocks share one histogram among 8 waves.
     const size_t ord_b = lds_bytes_sj_ordered(p.nbins, p.n_ti, p.n_tj);
-    const bool ordered = cull && ctx->opt_rdf_sj != 0 && !mode_cn && p.tri && ctx->opt_rdf_rows != 0 &&
-                         p.n_cls <= 250 && ord_b <= lds_cap / 4 && (double)p.n_tj * (p.nbins + 1) < 65536.0;
-    float near_ord = 0.f;
-    if (ordered) {
-        cls_per_pass = p.n_cls;
-        // |error| of the f32 guess g = fma(sqrt((float)rsq), 1/ddr, near + tj*row_len): relative 2^-25 (conversion,
-        // halved by the root) + 2^-23 (v_sqrt_f32, 1 ulp) + 2^-24 (rounded 1/ddr) = 2.1e-7 of the bin number, plus
-        // half an ulp of the largest value each for the rounding of the addend and of the fma. near = 2 x that.
-        const double maxg = (double)p.n_tj * (p.nbins + 1) + 1.0;  // the addend carries tj * row_len only
-        const double ulp = std::ldexp(1.0, (int)std::floor(std::log2(maxg)) - 23);
-        near_ord = (float)(2.0 * ((double)p.nbins * 2.1e-7 + ulp) + 1.0e-5);
-    }
+    const bool ord_base = cull && ctx->opt_rdf_sj != 0 && !mode_cn && p.tri && ctx->opt_rdf_rows != 0 &&
+                          p.n_cls <= 250 && (double)p.n_tj * (p.nbins + 1) < 65536.0;
+    bool ordered = ord_base && ord_b <= lds_cap / 4;
     // Packed-f32 classification (MODE 3 of the scalar-j kernel, header in pair_sj.hip): usable when the cutoff sits
     // on a bin edge (then the band of that edge also decides in/out of the cutoff) and the error band is narrow.
     bool pk = false;
-    float s_cap = 0.f, rc2hi = 0.f;
+    float s_cap = 0.f, rc2hi = 0.f, near_pk_f = 0.f;
     int rel_block = 0;  // atoms per centre block of the f32 records (0: none)
-    if (ordered && ctx->opt_rdf_pk != 0 && p.bin_size > 0.0) {
+    if (ord_base && ctx->opt_rdf_pk != 0 && p.bin_size > 0.0) {
         const double r_cut = std::sqrt(p.rc2);
         const double cpos = r_cut / p.bin_size, K = std::floor(cpos + 0.5);
         double l_max = 0.0, v_max = 0.0;
@@ -134,16 +126,28 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         const double u = std::ldexp(1.0, -24);
         const double near_pk = 2.0 * err + 4.5 * u * (p.nbins + 1) + 2.0e-5;
         if (std::fabs(cpos - K) <= 1e-6 && (K == (double)p.nbins || K == (double)p.nbins + 1.0) &&
-            near_pk <= 0.02 && lds_bytes_sj_pk(p.nbins, p.n_ti, p.n_tj) <= lds_cap / 4 && std::isfinite(l_max)) {
+            near_pk <= 0.02 && lds_bytes_sj_pk(p.nbins, p.n_ti, p.n_tj) <= lds_cap / 3 - 512 && std::isfinite(l_max)) {
             pk = true;
+            ordered = true;
             // centre blocks: whole tiles (64-atom blocks only buy a little f32 precision for 4x the per-block work)
             rel_block = TILE;
-            near_ord = std::max(near_ord, (float)near_pk);
+            near_pk_f = (float)near_pk;
             s_cap = (float)cap;
             // every pair with rsq < r_cut^2 has sqrt(rsq32) <= r_cut + err * bin_size
             const double r_hi = r_cut + err * p.bin_size;
             rc2hi = std::nextafterf((float)(r_hi * r_hi * (1.0 + 2.0 * u)), std::numeric_limits<float>::infinity());
         }
+    }
+    float near_ord = 0.f;
+    if (ordered) {
+        cls_per_pass = p.n_cls;
+        // |error| of the f32 guess g = fma(sqrt((float)rsq), 1/ddr, near + tj*row_len): relative 2^-25 (conversion,
+        // halved by the root) + 2^-23 (v_sqrt_f32, 1 ulp) + 2^-24 (rounded 1/ddr) = 2.1e-7 of the bin number, plus
+        // half an ulp of the largest value each for the rounding of the addend and of the fma. near = 2 x that.
+        const double maxg = (double)p.n_tj * (p.nbins + 1) + 1.0;  // the addend carries tj * row_len only
+        const double ulp = std::ldexp(1.0, (int)std::floor(std::log2(maxg)) - 23);
+        near_ord = (float)(2.0 * ((double)p.nbins * 2.1e-7 + ulp) + 1.0e-5);
+        near_ord = std::max(near_ord, near_pk_f);  // one band for the f32 guess of either sweep
     }
     const int n_pass = (p.n_cls + cls_per_pass - 1) / cls_per_pass;
 

@@ -772,6 +772,36 @@ def test_packed_f32_sweep_against_oracle(B):
     ctx.close()
 
 
+def test_packed_f32_sweep_more_types(B):
+    """5 types at 400 bins (25 ordered rows, 50 KB of LDS per 8-wave block) and 7 types at 200 bins still take the
+    packed-f32 sweep; 8 types at 400 bins do not fit and fall back. All against the all-f64 sweep and the C oracle."""
+    from mdproptools_amd._lib import Context
+
+    rng = np.random.default_rng(515)
+    n, L, F = 4200, 37.0, 2
+    xyz = rng.uniform(0, L, (F, 3, n))
+    box = np.full((F, 3), L)
+    f64, pk = Context(0), Context(0)
+    for ctx, v in ((f64, 0), (pk, 1)):
+        ctx.set_option("rdf_cull", 1)
+        ctx.set_option("rdf_pk", v)
+    for n_types, nbins, bin_size, expect_pk in ((5, 400, 0.04, True), (7, 200, 0.08, True), (8, 400, 0.04, False)):
+        ty = rng.integers(1, n_types + 1, n).astype(np.int32)
+        rel = np.array([[a, b] for a in range(1, n_types + 1) for b in range(a, n_types + 1)][:12])
+        r_cut = nbins * bin_size
+        a = B.rdf_loop(xyz, ty, box, rel, r_cut, bin_size, nbins, ctx=f64)
+        b = B.rdf_loop(xyz, ty, box, rel, r_cut, bin_size, nbins, ctx=pk)
+        assert ("<3," in pk.last_kernel_name()) == expect_pk, (n_types, nbins, pk.last_kernel_name())
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[1], b[1])
+        assert a[2] == b[2]
+        cf, cp, _ = C.rdf_pairs(xyz[0], ty, rel, box[0], r_cut * r_cut, bin_size, nbins)
+        np.testing.assert_array_equal(b[0][0], cf)
+        np.testing.assert_array_equal(b[1][0], cp)
+    f64.close()
+    pk.close()
+
+
 def test_culled_path_large_box_auto(B):
     """BASELINE C3 geometry at reduced N (same density: L = 48.3 A for 10k atoms, r_cut 6.8): the
     automatic choice takes the culled path; result against the C oracle."""
