@@ -161,8 +161,9 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
     }
     if (jsplit > max_list) jsplit = max_list;
     if (cull && jsplit > 4) jsplit = 4;
-    // persistent scalar-j kernel: items are (frame, tile, wave, slice); 4 slices measured best at C2 and C3
-    if (cull && ctx->opt_rdf_sj == 1 && !p.per_frame && ctx->opt_rdf_jsplit <= 0) jsplit = std::min(4, max_list);
+    // scalar-j kernels: items are (frame, tile, wave, slice); 4 slices measured best at C2 and C3, for the persistent
+    // grid and for per-frame output alike (with one slice a 100k-atom frame has only two items per resident wave)
+    if (cull && ctx->opt_rdf_sj != 0 && ctx->opt_rdf_jsplit <= 0) jsplit = std::min(4, max_list);
     if (jsplit < 1) jsplit = 1;
     const int blocks_per_frame = nTi * jsplit;
     // frames per block (fast kernel, frame-summed output): as many as keeps >= `want` blocks in flight
