@@ -536,14 +536,40 @@ int find_label(const std::vector<int32_t> &uniq, int32_t lab)
     return (it != uniq.end() && *it == lab) ? (int)(it - uniq.begin()) : -1;
 }
 
+// Only labels that some relation names need histogram rows of their own: every other label shares ONE index (its
+// pairs all belong to the class "no relation asks for this"). Shrinks the type count the kernels see — e.g. a
+// 9-type electrolyte with relations over 3 types runs with 4 — which is what decides whether the table-free
+// ordered-row layout (and with it the packed-f32 sweep) fits LDS. `col` = the relation column that refers to this
+// atom set (-1: both, the triangular case). uniq: sorted distinct labels (in) -> named labels (out); idx: remapped.
+int merge_unnamed_labels(std::vector<int32_t> &uniq, std::vector<int32_t> &idx, int n_rel, const int32_t *rel, int col)
+{
+    std::vector<int32_t> named;
+    std::vector<int32_t> rank(uniq.size(), -1);
+    for (size_t k = 0; k < uniq.size(); ++k) {
+        bool hit = false;
+        for (int kl = 0; kl < n_rel && !hit; ++kl)
+            hit = (col != 1 && rel[2 * kl] == uniq[k]) || (col != 0 && rel[2 * kl + 1] == uniq[k]);
+        if (hit) {
+            rank[k] = (int32_t)named.size();
+            named.push_back(uniq[k]);
+        }
+    }
+    const int32_t other = (int32_t)named.size();
+    const bool has_other = named.size() < uniq.size();
+    for (auto &v : idx) v = rank[(size_t)v] >= 0 ? rank[(size_t)v] : other;
+    uniq.swap(named);
+    return (int)uniq.size() + (has_other ? 1 : 0);
+}
+
 // Relations -> classes. Triangular: unordered type pairs {a,b}; rectangular: ordered (atom type,
 // site type). rel_cls[kl] = class id, or -1 when a label does not occur in the data (the reference
 // then counts nothing); the last class collects every pair no relation asks for.
-void build_classes(bool tri, const std::vector<int32_t> &ui, const std::vector<int32_t> &uj, int n_rel,
-                   const int32_t *rel, std::vector<unsigned char> &cls, std::vector<int> &rel_cls,
+// ui / uj hold the labels that have an index of their own (0 .. size-1); n_ti / n_tj may be one larger: the
+// index shared by all labels no relation names (merge_unnamed_labels).
+void build_classes(bool tri, const std::vector<int32_t> &ui, const std::vector<int32_t> &uj, int n_ti, int n_tj,
+                   int n_rel, const int32_t *rel, std::vector<unsigned char> &cls, std::vector<int> &rel_cls,
                    int &n_cls)
 {
-    const int n_ti = (int)ui.size(), n_tj = (int)uj.size();
     std::vector<int> map((size_t)n_ti * n_tj, -1);
     rel_cls.assign(n_rel, -1);
     int next = 0;
@@ -590,17 +616,18 @@ int run_job(mdhip_ctx *ctx, const RelJob &j, std::vector<uint64_t> &H, std::vect
     const size_t n_lab_i = j.lab_i_fs ? (size_t)j.F * j.ni : (size_t)j.ni;
     compact_labels(j.lab_i, n_lab_i, ui, idx_i);
     if (!j.tri) compact_labels(j.lab_j, (size_t)j.nj, uj, idx_j);
+    const int n_ti = merge_unnamed_labels(ui, idx_i, j.n_rel, j.rel, j.tri ? -1 : 0);
+    const int n_tj = j.tri ? n_ti : merge_unnamed_labels(uj, idx_j, j.n_rel, j.rel, 1);
     const std::vector<int32_t> &ujr = j.tri ? ui : uj;
-    if (ui.size() * ujr.size() > 16384)
-        return mdhip_fail(ctx, MDHIP_ELIMIT, "too many distinct types (%zu x %zu)", ui.size(),
-                          ujr.size());
+    if ((size_t)n_ti * (size_t)n_tj > 16384)
+        return mdhip_fail(ctx, MDHIP_ELIMIT, "too many distinct types named by relations (%d x %d)", n_ti, n_tj);
 
     PairProblem p;
     p.tri = j.tri;
-    build_classes(j.tri, ui, ujr, j.n_rel, j.rel, p.cls, rel_cls, n_cls);
+    build_classes(j.tri, ui, ujr, n_ti, n_tj, j.n_rel, j.rel, p.cls, rel_cls, n_cls);
     p.n_cls = n_cls;
-    p.n_ti = (int)ui.size();
-    p.n_tj = (int)ujr.size();
+    p.n_ti = n_ti;
+    p.n_tj = n_tj;
 
     int rc;
     p.d_xi = (const double *)mdhip_stage(ctx, WS_XYZ_I, j.xi, (size_t)j.F * 3 * j.ni * 8, j.xi_dev, &rc);

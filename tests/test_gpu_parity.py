@@ -785,9 +785,13 @@ def test_packed_f32_sweep_more_types(B):
     for ctx, v in ((f64, 0), (pk, 1)):
         ctx.set_option("rdf_cull", 1)
         ctx.set_option("rdf_pk", v)
-    for n_types, nbins, bin_size, expect_pk in ((5, 400, 0.04, True), (7, 200, 0.08, True), (8, 400, 0.04, False)):
+    # (the last case: 9 types of which the relations name 3 — the other 6 share one index, so 4 types reach the kernel)
+    for n_types, nbins, bin_size, expect_pk in ((5, 400, 0.04, True), (7, 200, 0.08, True), (8, 400, 0.04, False),
+                                                (9, 400, 0.04, True)):
         ty = rng.integers(1, n_types + 1, n).astype(np.int32)
         rel = np.array([[a, b] for a in range(1, n_types + 1) for b in range(a, n_types + 1)][:12])
+        if n_types == 9:
+            rel = np.array([[2, 2], [2, 7], [7, 4], [4, 4]])
         r_cut = nbins * bin_size
         a = B.rdf_loop(xyz, ty, box, rel, r_cut, bin_size, nbins, ctx=f64)
         b = B.rdf_loop(xyz, ty, box, rel, r_cut, bin_size, nbins, ctx=pk)
