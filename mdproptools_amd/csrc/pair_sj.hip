@@ -454,7 +454,9 @@ __device__ __forceinline__ bool axis_plain(float wlo, float whi, float glo, floa
     const float n0 = __builtin_rintf((wlo - c) * iL - 1.0e-3f), n1 = __builtin_rintf((whi - c) * iL + 1.0e-3f);
     const float lo = (wlo - c) - n0 * L, hi = (whi - c) - n0 * L;
     const float dmax = __builtin_fmaxf(__builtin_fabsf(lo - (ghi - c)), __builtin_fabsf(hi - (glo - c)));
-    return n0 == n1 && dmax <= th;
+    // (c is rounded to f32 here: 2^-24 |c| on each difference — nothing next to the margin inside th for coordinates
+    // within a few box lengths of the origin, but subtracted so that the test stays conservative for any offset)
+    return n0 == n1 && dmax <= th - 1.0e-6f * __builtin_fabsf(c);
 }
 
 // One work item of the packed-f32 sweep (atom-atom, ordered-pair rows): the 64 i atoms of wave `wq` of tile I of

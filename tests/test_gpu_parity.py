@@ -806,6 +806,37 @@ def test_packed_f32_sweep_more_types(B):
     pk.close()
 
 
+def test_packed_f32_sweep_far_from_origin(B):
+    """A cell 1e5 A away from the origin: the f32 boxes and tile centres lose ~0.01 A there, the tile-relative f32
+    coordinates of the pair chain do not. Against the all-f64 sweep and the C oracle."""
+    from mdproptools_amd._lib import Context
+
+    rng = np.random.default_rng(99)
+    n, F = 3600, 2
+    L = np.array([38.0, 41.0, 36.5])
+    lo = np.array([3.0e4, -7.0e4, 1.0e5])
+    xyz = rng.uniform(0, 1, (F, 3, n)) * L[None, :, None] + lo[None, :, None]
+    ty = rng.integers(1, 4, n).astype(np.int32)
+    rel = np.array([[1, 1], [1, 2], [2, 3], [3, 3]])
+    box = np.tile(L, (F, 1))
+    f64, pk = Context(0), Context(0)
+    for ctx, v in ((f64, 0), (pk, 1)):
+        ctx.set_option("rdf_cull", 1)
+        ctx.set_option("rdf_pk", v)
+    for r_cut, bin_size, nbins in ((12.0, 0.05, 240), (18.0, 0.05, 360)):
+        a = B.rdf_loop(xyz, ty, box, rel, r_cut, bin_size, nbins, ctx=f64)
+        b = B.rdf_loop(xyz, ty, box, rel, r_cut, bin_size, nbins, ctx=pk)
+        assert "<3," in pk.last_kernel_name()
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[1], b[1])
+        assert a[2] == b[2]
+        cf, cp, _ = C.rdf_pairs(xyz[0], ty, rel, box[0], r_cut * r_cut, bin_size, nbins)
+        np.testing.assert_array_equal(b[0][0], cf)
+        np.testing.assert_array_equal(b[1][0], cp)
+    f64.close()
+    pk.close()
+
+
 def test_culled_path_large_box_auto(B):
     """BASELINE C3 geometry at reduced N (same density: L = 48.3 A for 10k atoms, r_cut 6.8): the
     automatic choice takes the culled path; result against the C oracle."""
