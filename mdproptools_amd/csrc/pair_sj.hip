@@ -239,7 +239,7 @@ __device__ __forceinline__ void sj_item(const PairArgs &a, FastCtx &c, const uns
 //
 // Only the BIN of a pair enters the result, not its rsq. The sweep therefore evaluates rsq in f32 with the
 // packed instructions of gfx950 (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: two pairs per VALU issue slot, the
-// j operands as SGPR pairs): 3 slots per 2 pairs instead of 8-15 f64 slots per pair. The f32 value differs
+// j operands as SGPR pairs): 3 slots per pair instead of 8-15 f64 slots. The f32 value differs
 // from the reference's f64 rsq by a BOUNDED amount (pk_error_bound below, in bins: `err`); the bin guess
 //   g = fma(v_sqrt_f32(rsq32), 1/ddr, near + tj*row_len),   near = 2*err + slack
 // is trusted only when fract(g) >= 2*near, i.e. when the true sqrt(rsq)/ddr is provably farther than `err` from
@@ -251,8 +251,8 @@ __device__ __forceinline__ void sj_item(const PairArgs &a, FastCtx &c, const uns
 // pair changes. Lane-parallel draining makes the exact chain cost ~1/64 of what an inline fallback would.
 //
 // Keeping the f32 error small, and the wrap out of the pair loop: the j atoms are stored relative to the centre c
-// of the box of their BLOCK (64 or 256 sorted atoms, cen_shift), and every lane moves its own i atom to the
-// periodic image nearest to that centre, once per block:
+// of the box of their BLOCK (the tile of 256 sorted atoms; 64-atom blocks are supported through cen_shift but were
+// slower), and every lane moves its own i atom to the periodic image nearest to that centre, once per block:
 //   xr_j = f32(x_j - c)                          (pre-pass, |xr_j| <= half extent h of the block)
 //   q    = x_i - c;  xr_i = f32(q - L rint(q/L)) (f64 per lane and block, |xr_i| <= L/2)
 // so that d' = xr_i - xr_j is d = x_i - x_j moved by a whole number of box lengths, |d'| <= L/2 + e (e = how far
@@ -275,10 +275,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int PK_QCAP = 320;     // queue entries per wave: drained above 64, one group of 4 j atoms adds at most 256
 constexpr int PK_QSTRIDE = 320;  // words per wave
 constexpr int PK_THREADS = 512;  // threads per block of the MODE 3 kernel (8 independent waves, one LDS histogram)
-constexpr int PK_BLOCKS_PER_CU = 6;  // (HIP: the second launch-bound is waves per SIMD) register budget for 6 waves per SIMD: <= 80 VGPRs
+constexpr int PK_WAVES_PER_SIMD = 6;  // HIP's second launch bound: the register budget (<= 80 VGPRs) for 3 such blocks per CU
 
 struct PkCtx {
-    f32x2 x2, y2, z2;     // this lane's i atom relative to the j tile's centre (+ shift), both halves equal
+    f32x2 x2, y2, z2;     // this lane's i atom (its image nearest to the j block's centre) relative to that centre,
+                          // both halves equal
     f32x2 Lx2, Ly2, Lz2;  // box lengths (f32) for the axes that still need the per-pair wrap
     f32x2 iLx2, iLy2, iLz2;  // and their reciprocals
     float rc2hi;          // pre-filter: every pair with rsq < r_cut^2 has rsq32 < rc2hi
@@ -659,7 +660,7 @@ __device__ __forceinline__ bool work_loop_sane(const PairArgs &a, long long iter
 // dry. Every wave leaves the loop as soon as the counter passes the item count.
 // PERSIST = false (per-frame output): block = (frame, tile, list slice), one flush per block.
 template <int MODE, bool PERSIST>
-__global__ __launch_bounds__(MODE == 3 ? PK_THREADS : TILE, MODE == 3 ? PK_BLOCKS_PER_CU : 1) void pair_hist_sj_kernel(const PairArgs a)
+__global__ __launch_bounds__(MODE == 3 ? PK_THREADS : TILE, MODE == 3 ? PK_WAVES_PER_SIMD : 1) void pair_hist_sj_kernel(const PairArgs a)
 {
     // threads per block: the waves are independent (they share only the LDS histogram), so the block size is free.
     // MODE 3 runs 8 waves per block: LDS (one histogram per block) then allows 6 waves per SIMD instead of 5, which
