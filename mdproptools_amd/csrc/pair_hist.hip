@@ -103,7 +103,7 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
     // at >= 4 blocks of 4 waves per CU for the all-f64 sweep, at 3 blocks of 8 waves (6 waves per SIMD) for the
     // packed-f32 sweep, whose blocks share one histogram among 8 waves.
     const size_t ord_b = lds_bytes_sj_ordered(p.nbins, p.n_ti, p.n_tj);
-    const bool ord_base = cull && ctx->opt_rdf_sj != 0 && !mode_cn && p.tri && ctx->opt_rdf_rows != 0 &&
+    const bool ord_base = cull && ctx->opt_rdf_sj != 0 && !mode_cn && ctx->opt_rdf_rows != 0 &&
                           p.n_cls <= 250 && (double)p.n_tj * (p.nbins + 1) < 65536.0;
     bool ordered = ord_base && ord_b <= lds_cap / 4;
     // Packed-f32 classification (MODE 3 of the scalar-j kernel, header in pair_sj.hip): usable when the cutoff sits
@@ -120,7 +120,8 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
             l_max = std::max(l_max, std::max(b[0], std::max(b[1], b[2])));
             v_max = std::max(v_max, b[0] * b[1] * b[2]);
         }
-        const double edge = std::cbrt((double)TILE * v_max / (double)p.ni);
+        // tile edge of the sparser of the two sets (atoms x sites: the sites)
+        const double edge = std::cbrt((double)TILE * v_max / (double)std::min(p.ni, p.nj));
         const double cap = r_cut + 3.5 * edge;
         const double err = pk_error_bound(r_cut, p.bin_size, p.nbins, p.n_tj, cap, l_max);
         const double u = std::ldexp(1.0, -24);
@@ -230,15 +231,18 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         KernelTimer ptimer(ctx, 1, true);  // second event pair: collected after the pair kernel's sync
         SortedSet si, sj_set;
         const int slot_i[5] = {WS_SORT_AOS, WS_BBOX, WS_GSPH, WS_WSPH, WS_GSPH4};
+        // (the bin-guess addend near + type * row_len and the tile-relative f32 records belong to the j set)
         int rc = cull_prepare_set(ctx, F, p.d_xi, p.d_ti, (long long)p.ti_fs, p.d_box, N, nTi, p.n_ti,
-                                  ordered ? near_ord : 0.f, ordered ? p.nbins + 1 : 0, want_soa, pk ? rel_block : 0, slot_i, si);
+                                  ordered ? near_ord : 0.f, ordered ? p.nbins + 1 : 0, want_soa,
+                                  pk && p.tri ? rel_block : 0, slot_i, si);
         if (rc) return rc;
         if (p.tri) {
             sj_set = si;
         } else {
             const int slot_j[5] = {WS_SORT_AOS_J, WS_BBOX_J, WS_GSPH_J, WS_WSPH_J, WS_GSPH4_J};
-            rc = cull_prepare_set(ctx, F, p.d_xj, p.d_tj, (long long)p.tj_fs, p.d_box, p.nj, nTj, p.n_ti, 0.f, 0,
-                                  false, 0, slot_j, sj_set);
+            rc = cull_prepare_set(ctx, F, p.d_xj, p.d_tj, (long long)p.tj_fs, p.d_box, p.nj, nTj, p.n_ti,
+                                  ordered ? near_ord : 0.f, ordered ? p.nbins + 1 : 0, false, pk ? rel_block : 0, slot_j,
+                                  sj_set);
             if (rc) return rc;
         }
         launch_cull_lists(ctx->stream, p.tri, F, si.bbox, sj_set.bbox, nTi, nTj, p.d_box,
@@ -258,8 +262,8 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         d_list_cnt = d_lc;
         d_aos = si.aos;
         d_aos_j = sj_set.aos;
-        d_rel = si.rel;
-        d_cen = si.cen;
+        d_rel = sj_set.rel;
+        d_cen = sj_set.cen;
     }
 
     double total_ms = 0.0;  // the pair kernel alone; the culling pre-pass is reported separately

@@ -460,12 +460,12 @@ __device__ __forceinline__ bool axis_plain(float wlo, float whi, float glo, floa
     return n0 == n1 && dmax <= th - 1.0e-6f * __builtin_fabsf(c);
 }
 
-// One work item of the packed-f32 sweep (atom-atom, ordered-pair rows): the 64 i atoms of wave `wq` of tile I of
+// One work item of the packed-f32 sweep (ordered-pair rows; atom-atom or atoms x sites): the 64 i atoms of wave `wq` of tile I of
 // frame f against slice `split` of the tile's neighbour list.
 __device__ __forceinline__ void sj_item_pk(const PairArgs &a, FastCtx &c, unsigned *queue, int f, int I, int wq,
                                            int split, int lane)
 {
-    const long long n_pad = (long long)a.nTi * TILE;
+    const long long n_pad = (long long)a.nTi * TILE, n_pad_j = (long long)a.nTj * TILE;
     const long long rowid = (long long)f * a.nTi + I;
     const int cnt = a.list_cnt[rowid];
     const unsigned short *row_list = a.list + rowid * a.nTj;
@@ -477,7 +477,8 @@ __device__ __forceinline__ void sj_item_pk(const PairArgs &a, FastCtx &c, unsign
     L.Lz = a.box[3 * f + 2];
     L.sx = L.sy = L.sz = 0.0;
     const double iLx = 1.0 / L.Lx, iLy = 1.0 / L.Ly, iLz = 1.0 / L.Lz;
-    const double4 *ats = a.aos + (long long)f * n_pad;
+    const double4 *ats = a.aos + (long long)f * n_pad;        // the i set (== the j set for atom-atom)
+    const double4 *ats_j = a.aos_j + (long long)f * n_pad_j;  // the j set (atoms x sites: the sites)
     const int lane_in_tile = wq * 64 + lane;
     const long long ig = (long long)I * TILE + lane_in_tile;
     const bool real_i = ig < a.ni;
@@ -512,14 +513,14 @@ __device__ __forceinline__ void sj_item_pk(const PairArgs &a, FastCtx &c, unsign
     p.qn = 0;
     p.lost = a.overflow + 1;
     p.ats_i = ats + (long long)I * TILE + wq * 64;
-    p.ats_j = ats;
+    p.ats_j = ats_j;
     p.Lx = L.Lx;
     p.Ly = L.Ly;
     p.Lz = L.Lz;
     p.rc2 = a.rc2;
     p.n_ti = a.n_ti;
     p.n_tj = a.n_tj;
-    const float *rel_f = a.rel + (long long)f * n_pad * 4;  // 4 floats per atom
+    const float *rel_f = a.rel + (long long)f * n_pad_j * 4;  // 4 floats per j atom
     const int gpb = 1 << a.cen_shift;                        // groups per centre block
     const int nblk = (TILE / SJ_GROUP) >> a.cen_shift;       // centre blocks per tile
     const double *cen_f = a.cen + (long long)f * a.nTj * nblk * 8;
@@ -534,9 +535,9 @@ __device__ __forceinline__ void sj_item_pk(const PairArgs &a, FastCtx &c, unsign
         const bool keep = wlo.w > 0.f && glo.w > 0.f && gx * gx + gy * gy + gz * gz < a.reach * a.reach;
         const unsigned long long km = __builtin_amdgcn_ballot_w64(keep);
         if (!km) continue;
-        const double4 *tile = ats + (long long)J * TILE;
+        const double4 *tile = ats_j + (long long)J * TILE;
         const float *rtile = rel_f + (long long)J * TILE * 4;
-        const bool diag = J == I;
+        const bool diag = a.tri && J == I;
         // variant of this lane's group: the axes on which some |d'| may exceed L - r_cut (per-pair wrap needed)
         unsigned var;
         {
@@ -562,12 +563,12 @@ __device__ __forceinline__ void sj_item_pk(const PairArgs &a, FastCtx &c, unsign
             const double wy = __builtin_fma(-__builtin_rint(qy * iLy), L.Ly, qy);
             const double wz = __builtin_fma(-__builtin_rint(qz * iLz), L.Lz, qz);
             // covered: every |x_i - x_j| < 1.5 L (single wrap = nearest image), |xr_i| + |xr_j| within the error
-            // bound's s_cap, blocks much smaller than the cell
+            // bound's s_cap, |d'| <= L/2 + h < 1.5 L for the per-pair wrap
             const bool ok = (__builtin_fabs(qx) + hx < 1.49 * L.Lx) && (__builtin_fabs(qy) + hy < 1.49 * L.Ly) &&
                             (__builtin_fabs(qz) + hz < 1.49 * L.Lz) &&
                             (__builtin_fabs(wx) + hx < (double)a.s_cap) && (__builtin_fabs(wy) + hy < (double)a.s_cap) &&
-                            (__builtin_fabs(wz) + hz < (double)a.s_cap) && hx < 0.45 * L.Lx && hy < 0.45 * L.Ly &&
-                            hz < 0.45 * L.Lz;
+                            (__builtin_fabs(wz) + hz < (double)a.s_cap) && hx < 0.9 * L.Lx && hy < 0.9 * L.Ly &&
+                            hz < 0.9 * L.Lz;
             if (__builtin_amdgcn_ballot_w64(real_i && !ok)) {
                 unsigned long long mk = km & bm;
                 while (mk) {

@@ -837,6 +837,41 @@ def test_packed_f32_sweep_far_from_origin(B):
     pk.close()
 
 
+def test_packed_f32_sweep_atoms_x_sites(B):
+    """Atoms x sites (R5) through the ordered-row layout and the packed-f32 sweep: against the all-f64 sweep, the
+    class-row layout and the C oracle; sites coincide with atoms, strays on both sides, a cutoff close to L/2."""
+    from mdproptools_amd._lib import Context
+
+    rng = np.random.default_rng(808)
+    F, n, m = 2, 5200, 2300
+    L = np.array([33.0, 35.0, 34.0])
+    xyz = rng.uniform(0, 1, (F, 3, n)) * L[None, :, None]
+    sites = rng.uniform(0, 1, (F, 3, m)) * L[None, :, None]
+    sites[:, :, :40] = xyz[:, :, :40]
+    xyz[:, :, rng.choice(n, 60, replace=False)] += rng.integers(-2, 3, (F, 3, 60)) * L[None, :, None]
+    sites[:, :, rng.choice(m, 30, replace=False)] -= rng.integers(-1, 2, (F, 3, 30)) * L[None, :, None]
+    ty = rng.integers(1, 6, n).astype(np.int32)
+    st = rng.integers(1, 4, m).astype(np.int32)
+    rel = np.array([[1, 1], [2, 3], [4, 2], [3, 3]])
+    box = np.tile(L, (F, 1))
+    res = {}
+    for r_cut, bin_size, nbins in ((7.0, 0.05, 140), (16.4, 0.1, 164)):
+        for tag, opts in (("pk", {"rdf_pk": 1}), ("f64", {"rdf_pk": 0}), ("rows", {"rdf_pk": 0, "rdf_rows": 0})):
+            ctx = Context(0)
+            ctx.set_option("rdf_cull", 1)
+            for k, v in opts.items():
+                ctx.set_option(k, v)
+            res[tag] = B.rdf_mol_loop(xyz, ty, sites, st, box, rel, r_cut, bin_size, nbins, ctx=ctx)
+            name = ctx.last_kernel_name()
+            assert ("<3," in name) == (tag == "pk") and ("<2," in name) == (tag == "f64"), (tag, name)
+            ctx.close()
+        for tag in ("f64", "rows"):
+            np.testing.assert_array_equal(res["pk"][0], res[tag][0], err_msg=tag)
+            assert res["pk"][1] == res[tag][1]
+        want = C.rdf_rect(xyz[0], ty, sites[0], st, rel, L, r_cut * r_cut, bin_size, nbins)
+        np.testing.assert_array_equal(res["pk"][0][0], want[0])
+
+
 def test_culled_path_large_box_auto(B):
     """BASELINE C3 geometry at reduced N (same density: L = 48.3 A for 10k atoms, r_cut 6.8): the
     automatic choice takes the culled path; result against the C oracle."""
