@@ -535,7 +535,6 @@ __device__ __forceinline__ void sj_item_pk(const PairArgs &a, FastCtx &c, unsign
         const bool keep = wlo.w > 0.f && glo.w > 0.f && gx * gx + gy * gy + gz * gz < a.reach * a.reach;
         const unsigned long long km = __builtin_amdgcn_ballot_w64(keep);
         if (!km) continue;
-        const double4 *tile = ats_j + (long long)J * TILE;
         const float *rtile = rel_f + (long long)J * TILE * 4;
         const bool diag = a.tri && J == I;
         // variant of this lane's group: the axes on which some |d'| may exceed L - r_cut (per-pair wrap needed)
@@ -554,8 +553,7 @@ __device__ __forceinline__ void sj_item_pk(const PairArgs &a, FastCtx &c, unsign
             // this lane's i atom at the periodic image nearest to the block's centre
             const double *cb = cen_f + ((long long)J * nblk + b) * 8;
             // (the i atom is re-read per block rather than kept live through the pair loop: 8 VGPRs)
-            double4 me = ats[ig];
-            if (!real_i) me = make_double4(PAD_I, PAD_I, PAD_I, __longlong_as_double(0LL));
+            const double4 me = ats[ig];
             const double ccx = cb[0], ccy = cb[1], ccz = cb[2];
             const double hx = cb[3], hy = cb[4], hz = cb[5];
             const double qx = me.x - ccx, qy = me.y - ccy, qz = me.z - ccz;
@@ -570,14 +568,23 @@ __device__ __forceinline__ void sj_item_pk(const PairArgs &a, FastCtx &c, unsign
                             (__builtin_fabs(wz) + hz < (double)a.s_cap) && hx < 0.9 * L.Lx && hy < 0.9 * L.Ly &&
                             hz < 0.9 * L.Lz;
             if (__builtin_amdgcn_ballot_w64(real_i && !ok)) {
+                // not covered (rare: atoms box lengths outside the cell): every pair of the kept groups goes to the
+                // queue, i.e. to the exact f64 chain with the general wrap (valid for every d)
                 unsigned long long mk = km & bm;
                 while (mk) {
                     const int g = __builtin_ctzll(mk);
                     mk &= mk - 1;
-                    if (diag)
-                        sweep_group_sj<true, 2, 7>(tile + g * SJ_GROUP, g * SJ_GROUP, me.x, me.y, me.z, L, a.rc2, c, lane_in_tile);
-                    else
-                        sweep_group_sj<false, 2, 7>(tile + g * SJ_GROUP, g * SJ_GROUP, me.x, me.y, me.z, L, a.rc2, c, lane_in_tile);
+#pragma unroll 1
+                    for (int u = 0; u < SJ_GROUP; ++u) {
+                        if (p.qn > 64) pk_drain(p, c, lane);
+                        const bool want = real_i && (!diag || g * SJ_GROUP + u > lane_in_tile);
+                        const unsigned long long wm = __builtin_amdgcn_ballot_w64(want);
+                        if (want)
+                            p.queue[p.qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(wm >> 32),
+                                                                           __builtin_amdgcn_mbcnt_lo((unsigned)wm, 0u))] =
+                                ((unsigned)(J * TILE + g * SJ_GROUP + u) << 6) | (unsigned)lane;
+                        p.qn += __builtin_popcountll(wm);
+                    }
                 }
                 continue;
             }
