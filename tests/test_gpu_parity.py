@@ -474,6 +474,43 @@ def test_c2_full_size_properties(B):
     assert abs(gr[40:].mean() - 1.0) < 2e-3
 
 
+def test_c3_geometry_full_atoms_properties(B):
+    """BASELINE C3 geometry at full N (100 000 atoms, L = 104 A, r_cut 20 A, 400 bins), 6 frames: the packed-f32
+    sweep against the all-f64 sweep, and the size-independent identities (sum of partials = full, frame-summed =
+    sum of per-frame, ideal gas g(r) = 1)."""
+    import torch
+    from mdproptools_amd import synth
+    from mdproptools_amd._lib import Context
+
+    cfg = synth.rdf_config("C3")
+    n, L, F = cfg["n_atoms"], cfg["box_len"], 6
+    xyz = synth.rdf_frames(n, range(F), L, cfg["seed_offset"])
+    ty = synth.rdf_types(n)
+    rel = np.array(synth.ALL_PAIRS_4)
+    box = np.full((F, 3), L)
+    d = torch.from_numpy(xyz).cuda()
+    out = {}
+    for v in (0, 1):
+        ctx = Context(0)
+        ctx.set_option("rdf_pk", v)
+        out[v] = B.rdf_loop(d, ty, box, rel, cfg["r_cut"], cfg["bin_size"], 400, ctx=ctx)
+        assert ("<3," in ctx.last_kernel_name()) == bool(v)
+        if v:
+            fs, ps, ovs = B.rdf_loop(d, ty, box, rel, cfg["r_cut"], cfg["bin_size"], 400, per_frame=False, ctx=ctx)
+        ctx.close()
+    full, part, ov = out[1]
+    np.testing.assert_array_equal(full, out[0][0])
+    np.testing.assert_array_equal(part, out[0][1])
+    assert ov == out[0][2] == ovs
+    np.testing.assert_array_equal(fs, full.sum(axis=0))
+    np.testing.assert_array_equal(ps, part.sum(axis=0))
+    mult = np.array([1 if a == b else 2 for a, b in rel], dtype=np.uint64)
+    np.testing.assert_array_equal((part * mult[None, :, None]).sum(axis=1), full)
+    sv = O.shell_volume(0.05, 400)
+    gr = full.sum(axis=0) / F / (n * (n / L ** 3) * sv)
+    assert abs(gr[40:].mean() - 1.0) < 2e-3
+
+
 # ------------------------------------------------------------------ spatial culling (cell-list variant)
 def test_culled_path_equals_dense_and_oracle(B):
     """Morton-sorted tiles + bounding-box culling must give the same integers as the dense sweep."""
