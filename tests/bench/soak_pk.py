@@ -1,9 +1,10 @@
 #!/usr/bin/env python
 """
-tests/bench/soak_pk.py [trials] [seed] — long randomised differential run of the packed-f32 classification sweep
+tests/bench/soak_pk.py [trials] [seed] [oracle] — long randomised differential run of the packed-f32 classification sweep
 (rdf_pk = 1) against the all-f64 sweep (rdf_pk = 0): the generator of
 tests/test_gpu_parity.py::test_packed_f32_sweep_equals_f64_sweep with more trials and larger frames. Prints the first
-mismatch and exits 1, or a summary (cases, how often the packed kernel engaged, atom pairs compared).
+mismatch and exits 1, or a summary (cases, how often the packed kernel engaged, atom pairs compared). With `oracle`
+frame 0 of every case is also compared with oracle/cpu_ref.c (slow: use a few hundred trials).
 """
 import os
 import sys
@@ -22,6 +23,11 @@ def main():
 
     trials = int(sys.argv[1]) if len(sys.argv) > 1 else 400
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    oracle = len(sys.argv) > 3 and sys.argv[3] == "oracle"
+    if oracle:
+        from oracle import cref
+
+        cref.build()
     f64, pk = Context(0), Context(0)
     for ctx, v in ((f64, 0), (pk, 1)):
         ctx.set_option("rdf_cull", 1)
@@ -40,6 +46,13 @@ def main():
             print("MISMATCH trial %d n=%d box=%s r_cut=%.4f bin=%.3f kernel=%s: %d words differ, sum %d, overflow %d vs %d"
                   % (trial, n, box[0], r_cut, bin_size, pk.last_kernel_name(), np.count_nonzero(d), d.sum(), a[2], b[2]))
             sys.exit(1)
+        if oracle:
+            f0 = 0
+            cf, cp, _ = cref.rdf_pairs(xyz[f0], ty, rel, box[f0], r_cut * r_cut, bin_size, nbins)
+            bf = b[0][f0] if per_frame else None
+            if per_frame and not (np.array_equal(bf, cf) and np.array_equal(b[1][f0], cp)):
+                print("ORACLE MISMATCH trial %d n=%d box=%s r_cut=%.4f bin=%.3f" % (trial, n, box[0], r_cut, bin_size))
+                sys.exit(1)
         if trial % 50 == 49:
             print("trial %d ok (%d with the packed kernel, %.3g atom pairs so far)" % (trial + 1, engaged, pairs), flush=True)
     print("soak_pk: %d cases identical, packed kernel in %d, %.4g atom pairs" % (trials, engaged, pairs))
