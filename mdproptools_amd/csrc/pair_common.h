@@ -60,6 +60,7 @@ struct PairArgs {
     const double *cen;           // [F][nTj * blocks][8] block centre (x, y, z) and half extents (hx, hy, hz)
     int cen_shift;               // log2(groups of 4 atoms per centre block): 4 = 64 atoms, 6 = the whole tile
     float s_cap;                 // largest |relative coordinate| sum (i + j, per axis) the error bound `near` covers
+    float cut_lo;                // MODE 4 (cutoff inside a bin): sqrt(rsq32) >= cut_lo may lie beyond the cutoff
     float rc2hi;                 // f32 pre-filter: every in-cutoff pair has rsq32 < rc2hi (see pk_error_bound)
 };
 
@@ -150,7 +151,8 @@ size_t lds_bytes_sj(int nbins, int n_cls, int n_ti, int n_tj, bool mode_cn);
 size_t lds_bytes_sj_ordered(int nbins, int n_ti, int n_tj);
 size_t lds_bytes_sj_pk(int nbins, int n_ti, int n_tj);
 int sj_block_threads(int mode);  // threads per block of the scalar-j kernels (mode as sj_kernel)
-PairKernel sj_kernel(int mode /* 0 RDF class rows, 1 CN, 2 RDF ordered-pair rows, 3 = 2 with the packed-f32 sweep */,
+PairKernel sj_kernel(int mode /* 0 RDF class rows, 1 CN, 2 RDF ordered-pair rows, 3 = 2 with the packed-f32 sweep,
+                                 4 = 3 with the cutoff guard (cutoff inside a bin) */,
                      bool persist, const char **name);
 // error bound (in bins) of the packed-f32 bin guess for |relative coordinates| <= s_cap per axis pair sum; 0 = not usable
 double pk_error_bound(double r_cut, double bin_size, int nbins, int n_tj, double s_cap, double l_max);

@@ -71,7 +71,11 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
     // kernel variant: 0 = reference-shaped loops with an edge-table lookup per pair (always used for CN
     // edge tables, gscale == 0); 1 = fast kernel (table-free binning with an exact guard band)
     const bool mode_cn = !(p.gscale > 0.f);  // CN edge table: a few sorted cutoffs^2, bins found by counting
-    const bool fast = ctx->opt_rdf_variant == 1 && (mode_cn ? p.nbins <= 64 : p.nbins <= 100000);
+    // The table-free bin guess of the fast kernels indexes a row of nbins + 1 words: that is enough exactly when
+    // nbins = int(r_cut / bin_size) as the reference computes it (rdf_cn.py:169); a caller that passes fewer bins
+    // gets the edge-table kernel, which clamps.
+    const bool bins_ok = mode_cn || !(p.bin_size > 0.0) || std::sqrt(p.rc2) / p.bin_size < (double)p.nbins + 1.0 - 1e-9;
+    const bool fast = ctx->opt_rdf_variant == 1 && bins_ok && (mode_cn ? p.nbins <= 64 : p.nbins <= 100000);
 
     // spatial culling: worth it when the cutoff sphere is a small part of the box (atoms x sites: scalar-j
     // kernel only)
@@ -109,7 +113,8 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
     // Packed-f32 classification (MODE 3 of the scalar-j kernel, header in pair_sj.hip): usable when the cutoff sits
     // on a bin edge (then the band of that edge also decides in/out of the cutoff) and the error band is narrow.
     bool pk = false;
-    float s_cap = 0.f, rc2hi = 0.f, near_pk_f = 0.f;
+    float s_cap = 0.f, rc2hi = 0.f, near_pk_f = 0.f, cut_lo = 0.f;
+    bool cut_guard = false;  // the cutoff lies inside a bin: its own error band is tested per pair (MODE 4)
     int rel_block = 0;  // atoms per centre block of the f32 records (0: none)
     if (ord_base && ctx->opt_rdf_pk != 0 && p.bin_size > 0.0) {
         const double r_cut = std::sqrt(p.rc2);
@@ -126,9 +131,13 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         const double err = pk_error_bound(r_cut, p.bin_size, p.nbins, p.n_tj, cap, l_max);
         const double u = std::ldexp(1.0, -24);
         const double near_pk = 2.0 * err + 4.5 * u * (p.nbins + 1) + 2.0e-5;
-        if (std::fabs(cpos - K) <= 1e-6 && (K == (double)p.nbins || K == (double)p.nbins + 1.0) &&
-            near_pk <= 0.02 && lds_bytes_sj_pk(p.nbins, p.n_ti, p.n_tj) <= lds_cap / 3 - 512 && std::isfinite(l_max)) {
+        const bool on_edge = std::fabs(cpos - K) <= 1e-6 && (K == (double)p.nbins || K == (double)p.nbins + 1.0);
+        if ((on_edge || std::floor(cpos) == (double)p.nbins) && near_pk <= 0.02 &&
+            lds_bytes_sj_pk(p.nbins, p.n_ti, p.n_tj) <= lds_cap / 3 - 512 && std::isfinite(l_max)) {
             pk = true;
+            cut_guard = !on_edge;
+            // sqrt(rsq32) < cut_lo  =>  sqrt(rsq) < cut_lo + err * bin_size < r_cut: inside the cutoff for certain
+            cut_lo = std::nextafterf((float)(r_cut - 1.1 * err * p.bin_size), 0.f);
             ordered = true;
             // centre blocks: whole tiles (64-atom blocks only buy a little f32 precision for 4x the per-block work)
             rel_block = TILE;
@@ -321,6 +330,7 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         a.s_cap = s_cap;
         a.cen_shift = rel_block == 64 ? 4 : 6;
         a.rc2hi = rc2hi;
+        a.cut_lo = cut_lo;
         const bool sj = cull && ctx->opt_rdf_sj != 0;  // wave-independent sweep with scalar loads of the j atoms
         const bool persist = sj && !p.per_frame && ctx->opt_rdf_sj != 2;  // resident grid + per-XCD work counters
         a.work = reinterpret_cast<unsigned *>(d_misc + 4);
@@ -330,7 +340,7 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
                            : fast ? lds_bytes_fast(p.nbins, nc, p.n_ti, p.n_tj)
                                   : lds_bytes(p.nbins, nc, p.n_ti, p.n_tj);
         const char *kname = "";
-        const int sj_mode = pk && ctx->opt_rdf_pk != 2 ? 3 : ordered ? 2 : mode_cn ? 1 : 0;
+        const int sj_mode = pk && ctx->opt_rdf_pk != 2 ? (cut_guard ? 4 : 3) : ordered ? 2 : mode_cn ? 1 : 0;
         const int bs = sj ? sj_block_threads(sj_mode) : TILE;  // threads per block
         const int wpb = bs / 64;                                // independent waves per block (scalar-j kernels)
         PairKernel kern = sj ? sj_kernel(sj_mode, persist, &kname)

@@ -283,6 +283,7 @@ struct PkCtx {
     f32x2 Lx2, Ly2, Lz2;  // box lengths (f32) for the axes that still need the per-pair wrap
     f32x2 iLx2, iLy2, iLz2;  // and their reciprocals
     float rc2hi;          // pre-filter: every pair with rsq < r_cut^2 has rsq32 < rc2hi
+    float cut_lo;         // CUTG: sqrt(rsq32) >= cut_lo may be beyond the cutoff (pk_cut_lo)
     unsigned *queue;      // this wave's queue (LDS)
     int qn;               // entries queued (wave-uniform: kept in an SGPR)
     unsigned long long *lost;  // device counter of entries that did not fit the queue (must stay 0)
@@ -362,11 +363,41 @@ __device__ __forceinline__ RelQ load_relq(const float *__restrict__ p)
 // same C++ spends 9 SALU and 3-4 branches on the exec-mask bookkeeping, and this kernel is bound by issue slots).
 // Returns the mask of lanes whose pair lies inside the error band (to be queued for the exact chain).
 // exec is restored before the block ends; v_sqrt_f32 needs one wait state before its result is read.
+// CUTG: the cutoff does not sit on a bin edge, so the band of an edge does not decide in/out of the cutoff: lanes whose
+// f32 distance reaches the cutoff's own error band (sqrt(rsq32) >= cut_lo) are ambiguous too (+1 VALU, +1 SALU).
+template <bool CUTG>
 __device__ __forceinline__ unsigned long long bin_pair(float rsq, float rc2hi, float gscale, float nearoff, float near2,
-                                                       unsigned rowbase)
+                                                       unsigned rowbase, float cut_lo)
 {
     unsigned long long amb, save;
     float t, fr;
+    if (CUTG) {
+        unsigned long long m2;
+        asm volatile(
+            "v_cmp_gt_f32 vcc, %[rc2], %[rsq]\n\t"
+            "s_mov_b64 %[amb], 0\n\t"
+            "s_and_saveexec_b64 %[save], vcc\n\t"
+            "s_cbranch_execz 1f\n\t"
+            "v_sqrt_f32 %[t], %[rsq]\n\t"
+            "s_nop 0\n\t"
+            "v_cmp_ge_f32 %[m2], %[t], %[cl]\n\t"
+            "v_fma_f32 %[t], %[t], %[gs], %[no]\n\t"
+            "v_fract_f32 %[fr], %[t]\n\t"
+            "v_cvt_i32_f32 %[t], %[t]\n\t"
+            "v_cmp_ge_f32 vcc, %[fr], %[n2]\n\t"
+            "v_lshl_add_u32 %[t], %[t], 2, %[rb]\n\t"
+            "s_andn2_b64 vcc, vcc, %[m2]\n\t"
+            "s_andn2_b64 %[amb], exec, vcc\n\t"
+            "s_and_b64 exec, exec, vcc\n\t"
+            "ds_add_u32 %[t], %[one]\n\t"
+            "1:\n\t"
+            "s_mov_b64 exec, %[save]"
+            : [amb] "=&s"(amb), [save] "=&s"(save), [m2] "=&s"(m2), [t] "=&v"(t), [fr] "=&v"(fr)
+            : [rc2] "s"(rc2hi), [rsq] "v"(rsq), [gs] "v"(gscale), [no] "s"(nearoff), [n2] "v"(near2), [rb] "v"(rowbase),
+              [one] "v"(1u), [cl] "v"(cut_lo)
+            : "vcc", "scc", "memory");
+        return amb;
+    }
     asm volatile(
         "v_cmp_gt_f32 vcc, %[rc2], %[rsq]\n\t"
         "s_mov_b64 %[amb], 0\n\t"
@@ -398,7 +429,7 @@ __device__ __forceinline__ unsigned long long bin_pair(float rsq, float rc2hi, f
 // them (lgkmcnt(0)) before the first use of `rq`: that wait has to come before the prefetch is issued — the two
 // empty asm statements pin that order (the first depends on dx, i.e. on a use of rq) — and is free, because rq was
 // itself prefetched during the previous sweep.
-template <bool DIAG, int VAR, bool PF>
+template <bool DIAG, int VAR, bool PF, bool CUTG>
 __device__ __forceinline__ void sweep_group_pk(const RelQ &rq, int jidx0, int local0, PkCtx &p, const FastCtx &c,
                                                int lane_in_tile, int lane, const float *next_p, RelQ &next)
 {
@@ -426,7 +457,7 @@ __device__ __forceinline__ void sweep_group_pk(const RelQ &rq, int jidx0, int lo
             const float nearoff = u ? rb[3] : rb[2];
             float r2 = rsq[u];
             if (DIAG) r2 = local0 + 2 * h + u > lane_in_tile ? r2 : 3.0e38f;  // i < j inside the diagonal tile
-            const unsigned long long amb = bin_pair(r2, p.rc2hi, c.gscale, nearoff, c.near2, c.rowbase_me);
+            const unsigned long long amb = bin_pair<CUTG>(r2, p.rc2hi, c.gscale, nearoff, c.near2, c.rowbase_me, p.cut_lo);
             if (amb) {  // wave-uniform, rare: some lane's pair is inside the error band -> the exact chain, later
                 // (the copy through a volatile asm keeps the per-lane test inside this branch: the compiler would
                 // otherwise fold both conditions into one divergent branch and pay 3 VALU per pair for it)
@@ -462,6 +493,7 @@ __device__ __forceinline__ bool axis_plain(float wlo, float whi, float glo, floa
 
 // One work item of the packed-f32 sweep (ordered-pair rows; atom-atom or atoms x sites): the 64 i atoms of wave `wq` of tile I of
 // frame f against slice `split` of the tile's neighbour list.
+template <bool CUTG>
 __device__ __forceinline__ void sj_item_pk(const PairArgs &a, FastCtx &c, unsigned *queue, int f, int I, int wq,
                                            int split, int lane)
 {
@@ -509,6 +541,7 @@ __device__ __forceinline__ void sj_item_pk(const PairArgs &a, FastCtx &c, unsign
     p.iLy2 = f32x2{(float)iLy, (float)iLy};
     p.iLz2 = f32x2{(float)iLz, (float)iLz};
     p.rc2hi = a.rc2hi;
+    p.cut_lo = a.cut_lo;
     p.queue = queue;
     p.qn = 0;
     p.lost = a.overflow + 1;
@@ -612,14 +645,14 @@ __device__ __forceinline__ void sj_item_pk(const PairArgs &a, FastCtx &c, unsign
                         const bool moreB = mk != 0;
                         const int gB = moreB ? __builtin_ctzll(mk) : gA;
                         mk &= mk - 1;
-                        sweep_group_pk<false, 0, true>(qA, jbase + gA * SJ_GROUP, gA * SJ_GROUP, p, c, lane_in_tile, lane,
+                        sweep_group_pk<false, 0, true, CUTG>(qA, jbase + gA * SJ_GROUP, gA * SJ_GROUP, p, c, lane_in_tile, lane,
                                                        rtile + gB * SJ_GROUP * 4, qB);
                         if (!moreB) break;
                         PK_DRAIN_CHECK();
                         const bool moreA = mk != 0;
                         gA = moreA ? __builtin_ctzll(mk) : gB;
                         mk &= mk - 1;
-                        sweep_group_pk<false, 0, true>(qB, jbase + gB * SJ_GROUP, gB * SJ_GROUP, p, c, lane_in_tile, lane,
+                        sweep_group_pk<false, 0, true, CUTG>(qB, jbase + gB * SJ_GROUP, gB * SJ_GROUP, p, c, lane_in_tile, lane,
                                                        rtile + gA * SJ_GROUP * 4, qA);
                         if (!moreA) break;
                     }
@@ -634,15 +667,15 @@ __device__ __forceinline__ void sj_item_pk(const PairArgs &a, FastCtx &c, unsign
                     PK_DRAIN_CHECK();
                     const int j0 = jbase + g * SJ_GROUP, l0 = g * SJ_GROUP;
                     switch (A) {
-                    case 1: sweep_group_pk<false, 1, false>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
-                    case 2: sweep_group_pk<false, 2, false>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
-                    case 3: sweep_group_pk<false, 3, false>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
-                    case 4: sweep_group_pk<false, 4, false>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
-                    case 5: sweep_group_pk<false, 5, false>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
-                    case 6: sweep_group_pk<false, 6, false>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
-                    case 7: sweep_group_pk<false, 7, false>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
-                    case 9: sweep_group_pk<true, 0, false>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
-                    default: sweep_group_pk<true, 7, false>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
+                    case 1: sweep_group_pk<false, 1, false, CUTG>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
+                    case 2: sweep_group_pk<false, 2, false, CUTG>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
+                    case 3: sweep_group_pk<false, 3, false, CUTG>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
+                    case 4: sweep_group_pk<false, 4, false, CUTG>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
+                    case 5: sweep_group_pk<false, 5, false, CUTG>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
+                    case 6: sweep_group_pk<false, 6, false, CUTG>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
+                    case 7: sweep_group_pk<false, 7, false, CUTG>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
+                    case 9: sweep_group_pk<true, 0, false, CUTG>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
+                    default: sweep_group_pk<true, 7, false, CUTG>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
                     }
                 }
             }
@@ -668,12 +701,12 @@ __device__ __forceinline__ bool work_loop_sane(const PairArgs &a, long long iter
 // dry. Every wave leaves the loop as soon as the counter passes the item count.
 // PERSIST = false (per-frame output): block = (frame, tile, list slice), one flush per block.
 template <int MODE, bool PERSIST>
-__global__ __launch_bounds__(MODE == 3 ? PK_THREADS : TILE, MODE == 3 ? PK_WAVES_PER_SIMD : 1) void pair_hist_sj_kernel(const PairArgs a)
+__global__ __launch_bounds__(MODE >= 3 ? PK_THREADS : TILE, MODE >= 3 ? PK_WAVES_PER_SIMD : 1) void pair_hist_sj_kernel(const PairArgs a)
 {
     // threads per block: the waves are independent (they share only the LDS histogram), so the block size is free.
     // MODE 3 runs 8 waves per block: LDS (one histogram per block) then allows 6 waves per SIMD instead of 5, which
     // this latency-bound sweep (scalar record loads from L2) converts into VALU utilisation.
-    constexpr int BS = MODE == 3 ? PK_THREADS : TILE;
+    constexpr int BS = MODE >= 3 ? PK_THREADS : TILE;  // MODE 4 = MODE 3 with the cutoff guard (CUTG)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const long long bid = blockIdx.x;
@@ -734,10 +767,10 @@ __global__ __launch_bounds__(MODE == 3 ? PK_THREADS : TILE, MODE == 3 ? PK_WAVES
             if ((long long)it >= n_items) break;
             const int fx = (int)(it / (unsigned)ipf), r = (int)(it % (unsigned)ipf);
             const int split = r % a.jsplit, wI = r / a.jsplit;
-            if (MODE == 3)
-                sj_item_pk(a, c, s_row + (tid >> 6) * PK_QSTRIDE, fx * 8 + xcd, wI >> 2, wI & 3, split, lane);
+            if (MODE >= 3)
+                sj_item_pk<MODE == 4>(a, c, s_row + (tid >> 6) * PK_QSTRIDE, fx * 8 + xcd, wI >> 2, wI & 3, split, lane);
             else
-                sj_item<MODE == 3 ? 2 : MODE>(a, c, s_row, fx * 8 + xcd, wI >> 2, wI & 3, split, lane);
+                sj_item<MODE >= 3 ? 2 : MODE>(a, c, s_row, fx * 8 + xcd, wI >> 2, wI & 3, split, lane);
         }
     } else {
         // a.blocks_per_frame blocks share one frame and flush once each into the frame's row
@@ -754,10 +787,10 @@ __global__ __launch_bounds__(MODE == 3 ? PK_THREADS : TILE, MODE == 3 ? PK_WAVES
             it = (unsigned)__builtin_amdgcn_readfirstlane((int)it);
             if (it >= ipf) break;
             const int split = (int)(it % (unsigned)a.jsplit), wI = (int)(it / (unsigned)a.jsplit);
-            if (MODE == 3)
-                sj_item_pk(a, c, s_row + (tid >> 6) * PK_QSTRIDE, f, wI >> 2, wI & 3, split, lane);
+            if (MODE >= 3)
+                sj_item_pk<MODE == 4>(a, c, s_row + (tid >> 6) * PK_QSTRIDE, f, wI >> 2, wI & 3, split, lane);
             else
-                sj_item<MODE == 3 ? 2 : MODE>(a, c, s_row, f, wI >> 2, wI & 3, split, lane);
+                sj_item<MODE >= 3 ? 2 : MODE>(a, c, s_row, f, wI >> 2, wI & 3, split, lane);
         }
     }
 
@@ -800,7 +833,7 @@ size_t lds_bytes_sj_ordered(int nbins, int n_ti, int n_tj)
     return (((size_t)n_ti * n_tj * (nbins + 1) * 4 + 15) & ~size_t(15)) + 16;
 }
 
-int sj_block_threads(int mode) { return mode == 3 ? PK_THREADS : TILE; }
+int sj_block_threads(int mode) { return mode >= 3 ? PK_THREADS : TILE; }
 
 size_t lds_bytes_sj_pk(int nbins, int n_ti, int n_tj)
 {
@@ -840,6 +873,7 @@ size_t lds_bytes_sj(int nbins, int n_cls, int n_ti, int n_tj, bool mode_cn)
 PairKernel sj_kernel(int mode, bool persist, const char **name)
 {
 #define MD_PICK(...) (*name = #__VA_ARGS__, __VA_ARGS__)
+    if (mode == 4) return persist ? MD_PICK(pair_hist_sj_kernel<4, true>) : MD_PICK(pair_hist_sj_kernel<4, false>);
     if (mode == 3) return persist ? MD_PICK(pair_hist_sj_kernel<3, true>) : MD_PICK(pair_hist_sj_kernel<3, false>);
     if (mode == 2) return persist ? MD_PICK(pair_hist_sj_kernel<2, true>) : MD_PICK(pair_hist_sj_kernel<2, false>);
     if (mode == 1) return persist ? MD_PICK(pair_hist_sj_kernel<1, true>) : MD_PICK(pair_hist_sj_kernel<1, false>);

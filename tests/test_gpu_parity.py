@@ -729,6 +729,9 @@ def _pk_case(rng, trial):
     F = int(rng.integers(1, 4))
     nbins = int(rng.uniform(0.06, 0.4999) * L.min() / bin_size)
     r_cut = nbins * bin_size  # on a bin edge, as in every RDF call that divides its cutoff into whole bins
+    if trial % 6 == 5:        # ... or inside the last bin: the sweep then guards the cutoff's own error band too
+        r_cut = min((nbins + float(rng.uniform(0.03, 0.97))) * bin_size, 0.4999 * float(L.min()))
+        nbins = int(r_cut / bin_size)
     kind = trial % 4
     if kind == 0:  # a lattice with spacing = a whole number of bins: most distances are exactly on edges
         g = int(round(n ** (1 / 3))) + 1
@@ -771,7 +774,7 @@ def test_packed_f32_sweep_equals_f64_sweep(B):
         per_frame = bool(trial % 2)
         a = B.rdf_loop(xyz, ty, box, rel, r_cut, bin_size, nbins, per_frame=per_frame, ctx=f64)
         b = B.rdf_loop(xyz, ty, box, rel, r_cut, bin_size, nbins, per_frame=per_frame, ctx=pk)
-        engaged += "<3," in pk.last_kernel_name()
+        engaged += ("<3," in pk.last_kernel_name()) or ("<4," in pk.last_kernel_name())
         msg = "trial %d n=%d box=%s r_cut=%.4f bin=%.3f kernel=%s" % (trial, xyz.shape[2], box[0], r_cut, bin_size,
                                                                      pk.last_kernel_name())
         np.testing.assert_array_equal(a[0], b[0], err_msg=msg)
@@ -783,8 +786,8 @@ def test_packed_f32_sweep_equals_f64_sweep(B):
 
 
 def test_packed_f32_sweep_against_oracle(B):
-    """The default path of a C2-shaped call (packed-f32 sweep) against the C oracle, and the cases where the mode
-    must NOT engage (cutoff inside a bin) still right."""
+    """The default path of a C2-shaped call (packed-f32 sweep) against the C oracle: cutoff on a bin edge (<3, .>)
+    and inside the last bin (<4, .>: the cutoff's own error band is guarded per pair)."""
     from mdproptools_amd import synth
     from mdproptools_amd._lib import Context
 
@@ -798,7 +801,7 @@ def test_packed_f32_sweep_against_oracle(B):
     for r_cut, bin_size, nbins in ((12.0, 0.05, 240), (12.02, 0.05, 240), (18.0, 0.1, 180), (18.3, 0.1, 183)):
         full, part, ov = B.rdf_loop(xyz, ty, box, rel, r_cut, bin_size, nbins, ctx=ctx)
         on_edge = abs(r_cut / bin_size - round(r_cut / bin_size)) < 1e-6
-        assert ("<3," in ctx.last_kernel_name()) == on_edge, (r_cut, ctx.last_kernel_name())
+        assert ("<3," if on_edge else "<4,") in ctx.last_kernel_name(), (r_cut, ctx.last_kernel_name())
         ovs = 0
         for f in range(2):
             cf, cp, cov = C.rdf_pairs(xyz[f], ty, rel, box[f], r_cut * r_cut, bin_size, nbins)
@@ -907,6 +910,29 @@ def test_packed_f32_sweep_atoms_x_sites(B):
             assert res["pk"][1] == res[tag][1]
         want = C.rdf_rect(xyz[0], ty, sites[0], st, rel, L, r_cut * r_cut, bin_size, nbins)
         np.testing.assert_array_equal(res["pk"][0][0], want[0])
+
+
+def test_fewer_bins_than_the_cutoff_spans(B):
+    """A caller of the C-ABI may pass fewer bins than int(r_cut / bin_size): every in-cutoff pair beyond the last
+    bin is then overflow (as in the oracle), and the table-free fast kernels — whose rows have nbins + 1 words —
+    must not be used."""
+    from mdproptools_amd._lib import Context
+
+    rng = np.random.default_rng(31)
+    n, L = 3000, 32.0
+    xyz = rng.uniform(0, L, (1, 3, n))
+    ty = rng.integers(1, 4, n).astype(np.int32)
+    rel = np.array([[1, 1], [1, 2], [3, 3]])
+    box = np.full((1, 3), L)
+    for cull in (0, 1):
+        ctx = Context(0)
+        ctx.set_option("rdf_cull", cull)
+        full, part, ov = B.rdf_loop(xyz, ty, box, rel, 12.0, 0.05, 150, ctx=ctx)  # int(12 / 0.05) = 240 bins
+        cf, cp, cov = C.rdf_pairs(xyz[0], ty, rel, box[0], 144.0, 0.05, 150)
+        np.testing.assert_array_equal(full[0], cf)
+        np.testing.assert_array_equal(part[0], cp)
+        assert ov == cov and cov > 0
+        ctx.close()
 
 
 def test_culled_path_large_box_auto(B):
