@@ -74,8 +74,8 @@ int mdhip_device_name(mdhip_ctx *ctx, char *buf, int buflen);
  *   "rdf_rows"     scalar-j RDF: -1/1 ordered-pair rows without a class-row table when they fit LDS, 0 class rows
  *   "rdf_pk"       scalar-j RDF with ordered rows: -1/1 packed-f32 classification of the pairs (two per VALU
  *                  instruction) with every pair inside the error band of a bin edge or of the cutoff resolved by
- *                  the exact f64 chain (default when the ordered rows fit LDS and the band is narrow enough),
- *                  0 all-f64 sweep
+ *                  the exact f64 chain (default whenever the band is narrow enough; ordered rows when they fit LDS,
+ *                  else class rows with their row table), 0 all-f64 sweep
  *   "rdf_sort"     spatial sort: -1 auto, 1 one block per frame (LDS counters), 0 multi-block (global counters)
  *   "rdf_inflight" per-frame output: frames in flight per XCD
  *   "rdf_jsplit", "rdf_fpb", "rdf_batch", "rdf_slots"  launch geometry of the pair kernels

@@ -150,9 +150,10 @@ void launch_reduce_slots(hipStream_t stream, const unsigned long long *in, unsig
 size_t lds_bytes_sj(int nbins, int n_cls, int n_ti, int n_tj, bool mode_cn);
 size_t lds_bytes_sj_ordered(int nbins, int n_ti, int n_tj);
 size_t lds_bytes_sj_pk(int nbins, int n_ti, int n_tj);
+size_t lds_bytes_sj_pk_rows(int nbins, int n_cls, int n_ti, int n_tj);  // class rows + row table + queues
 int sj_block_threads(int mode);  // threads per block of the scalar-j kernels (mode as sj_kernel)
 PairKernel sj_kernel(int mode /* 0 RDF class rows, 1 CN, 2 RDF ordered-pair rows, 3 = 2 with the packed-f32 sweep,
-                                 4 = 3 with the cutoff guard (cutoff inside a bin) */,
+                                 4 = 3 with the cutoff guard (cutoff inside a bin), 5 / 6 = 3 / 4 with class rows */,
                      bool persist, const char **name);
 // error bound (in bins) of the packed-f32 bin guess for |relative coordinates| <= s_cap per axis pair sum; 0 = not usable
 double pk_error_bound(double r_cut, double bin_size, int nbins, int n_tj, double s_cap, double l_max);
@@ -164,7 +165,8 @@ constexpr int MORTON_BITS = 5;                       // 32 cells per axis
 constexpr int MORTON_CELLS = 1 << (3 * MORTON_BITS); // 32768
 int cull_prepare_set(mdhip_ctx *ctx, int64_t F, const double *d_x, const int *d_t, long long t_fs,
                      const double *d_box, long long N, int nT, int n_ti, float near, int row_len, bool want_soa,
-                     int rel_block /* 0 = no f32 records, else atoms per centre block: 64 or 256 */, const int slot[5],
+                     int rel_block /* 0 = no f32 records, else atoms per centre block: 64 or 256 */,
+                     int rel_w_type /* w of the f32 records: 0 bin-guess addend, 1 row-table offset */, const int slot[5],
                      SortedSet &out);
 void launch_cull_lists(hipStream_t stream, bool tri, int64_t F, const double *bbox_i, const double *bbox_j, int nTi,
                        int nTj, const double *d_box, double rc2_test, unsigned short *list, int *cnt);

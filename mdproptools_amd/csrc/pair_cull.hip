@@ -268,7 +268,7 @@ __global__ __launch_bounds__(TILE) void cull_boxes_kernel(const double4 *__restr
                                                           double *__restrict__ bbox, float4 *__restrict__ gboxes,
                                                           float4 *__restrict__ wboxes, float4 *__restrict__ g4boxes,
                                                           double *__restrict__ cen, float *__restrict__ rel,
-                                                          int rel_block)
+                                                          int rel_block, int rel_w_type)
 {
     __shared__ double red[6][TILE / 64];
     const int f = blockIdx.y, T = blockIdx.x, tid = threadIdx.x;
@@ -372,7 +372,8 @@ __global__ __launch_bounds__(TILE) void cull_boxes_kernel(const double4 *__restr
         o[0] = real ? (float)(me.x - c[0]) : 1.0e18f;
         o[2] = real ? (float)(me.y - c[1]) : 1.0e18f;
         o[4] = real ? (float)(me.z - c[2]) : 1.0e18f;
-        o[6] = __int_as_float(__double2hiint(me.w));
+        // w: the bin-guess addend near + type * row_len (ordered rows) or the row-table offset type * n_ti (class rows)
+        o[6] = __int_as_float(rel_w_type ? __double2loint(me.w) : __double2hiint(me.w));
     }
 }
 
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(256) void cull_list_kernel(const double *__restrict
 
 int cull_prepare_set(mdhip_ctx *ctx, int64_t F, const double *d_x, const int *d_t, long long t_fs,
                      const double *d_box, long long N, int nT, int n_ti, float near, int row_len, bool want_soa,
-                     int rel_block, const int slot[5], SortedSet &out)
+                     int rel_block, int rel_w_type, const int slot[5], SortedSet &out)
 {
     const bool want_rel = rel_block != 0;
     MD_WS(d_rel, float, WS_REL, want_rel ? (size_t)F * nT * TILE * 16 : 64);
@@ -466,7 +467,7 @@ int cull_prepare_set(mdhip_ctx *ctx, int64_t F, const double *d_x, const int *d_
     }
     hipLaunchKernelGGL(cull_boxes_kernel, dim3((unsigned)nT, (unsigned)F), dim3(TILE), 0, ctx->stream, d_ao, d_box, N,
                        nT, d_bbox, d_gs, d_ws, d_g4, want_rel ? d_cen : (double *)nullptr,
-                       want_rel ? d_rel : (float *)nullptr, want_rel ? rel_block : TILE);
+                       want_rel ? d_rel : (float *)nullptr, want_rel ? rel_block : TILE, rel_w_type);
     MD_HIP(hipGetLastError());
     out.rel = want_rel ? d_rel : nullptr;
     out.cen = want_rel ? d_cen : nullptr;

@@ -110,13 +110,17 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
     const bool ord_base = cull && ctx->opt_rdf_sj != 0 && !mode_cn && ctx->opt_rdf_rows != 0 &&
                           p.n_cls <= 250 && (double)p.n_tj * (p.nbins + 1) < 65536.0;
     bool ordered = ord_base && ord_b <= lds_cap / 4;
-    // Packed-f32 classification (MODE 3 of the scalar-j kernel, header in pair_sj.hip): usable when the cutoff sits
-    // on a bin edge (then the band of that edge also decides in/out of the cutoff) and the error band is narrow.
-    bool pk = false;
+    // Packed-f32 classification (MODE 3-6 of the scalar-j kernel, header in pair_sj.hip) when the error band is
+    // narrow: with the ordered rows when they fit a third of LDS (3 blocks of 8 waves per CU), else with class rows
+    // and their row table (any number of types). The cutoff on a bin edge lets the band of that edge decide in/out
+    // of the cutoff; a cutoff inside the last bin has its own band tested per pair (cut_guard).
+    bool pk = false, pk_rows = false;
     float s_cap = 0.f, rc2hi = 0.f, near_pk_f = 0.f, cut_lo = 0.f;
-    bool cut_guard = false;  // the cutoff lies inside a bin: its own error band is tested per pair (MODE 4)
+    bool cut_guard = false;
     int rel_block = 0;  // atoms per centre block of the f32 records (0: none)
-    if (ord_base && ctx->opt_rdf_pk != 0 && p.bin_size > 0.0) {
+    if (cull && ctx->opt_rdf_sj != 0 && !mode_cn && p.n_cls <= 250 && ctx->opt_rdf_pk != 0 && p.bin_size > 0.0) {
+        const bool fits_ordered = ord_base && lds_bytes_sj_pk(p.nbins, p.n_ti, p.n_tj) <= lds_cap / 3 - 512;
+        const bool fits_rows = lds_bytes_sj_pk_rows(p.nbins, p.n_cls, p.n_ti, p.n_tj) <= lds_cap / 3 - 512;
         const double r_cut = std::sqrt(p.rc2);
         const double cpos = r_cut / p.bin_size, K = std::floor(cpos + 0.5);
         double l_max = 0.0, v_max = 0.0;
@@ -128,17 +132,19 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         // tile edge of the sparser of the two sets (atoms x sites: the sites)
         const double edge = std::cbrt((double)TILE * v_max / (double)std::min(p.ni, p.nj));
         const double cap = r_cut + 3.5 * edge;
-        const double err = pk_error_bound(r_cut, p.bin_size, p.nbins, p.n_tj, cap, l_max);
+        // (the guess carries tj * row_len with ordered rows, nothing with class rows)
+        const double err = pk_error_bound(r_cut, p.bin_size, p.nbins, fits_ordered ? p.n_tj : 1, cap, l_max);
         const double u = std::ldexp(1.0, -24);
         const double near_pk = 2.0 * err + 4.5 * u * (p.nbins + 1) + 2.0e-5;
         const bool on_edge = std::fabs(cpos - K) <= 1e-6 && (K == (double)p.nbins || K == (double)p.nbins + 1.0);
-        if ((on_edge || std::floor(cpos) == (double)p.nbins) && near_pk <= 0.02 &&
-            lds_bytes_sj_pk(p.nbins, p.n_ti, p.n_tj) <= lds_cap / 3 - 512 && std::isfinite(l_max)) {
+        if ((fits_ordered || fits_rows) && (on_edge || std::floor(cpos) == (double)p.nbins) && near_pk <= 0.02 &&
+            std::isfinite(l_max)) {
             pk = true;
+            pk_rows = !fits_ordered;
+            ordered = fits_ordered;
             cut_guard = !on_edge;
             // sqrt(rsq32) < cut_lo  =>  sqrt(rsq) < cut_lo + err * bin_size < r_cut: inside the cutoff for certain
             cut_lo = std::nextafterf((float)(r_cut - 1.1 * err * p.bin_size), 0.f);
-            ordered = true;
             // centre blocks: whole tiles (64-atom blocks only buy a little f32 precision for 4x the per-block work)
             rel_block = TILE;
             near_pk_f = (float)near_pk;
@@ -146,6 +152,7 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
             // every pair with rsq < r_cut^2 has sqrt(rsq32) <= r_cut + err * bin_size
             const double r_hi = r_cut + err * p.bin_size;
             rc2hi = std::nextafterf((float)(r_hi * r_hi * (1.0 + 2.0 * u)), std::numeric_limits<float>::infinity());
+            if (pk_rows) cls_per_pass = p.n_cls;  // all classes in one pass (they fit: fits_rows)
         }
     }
     float near_ord = 0.f;
@@ -243,15 +250,15 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         // (the bin-guess addend near + type * row_len and the tile-relative f32 records belong to the j set)
         int rc = cull_prepare_set(ctx, F, p.d_xi, p.d_ti, (long long)p.ti_fs, p.d_box, N, nTi, p.n_ti,
                                   ordered ? near_ord : 0.f, ordered ? p.nbins + 1 : 0, want_soa,
-                                  pk && p.tri ? rel_block : 0, slot_i, si);
+                                  pk && p.tri ? rel_block : 0, pk_rows ? 1 : 0, slot_i, si);
         if (rc) return rc;
         if (p.tri) {
             sj_set = si;
         } else {
             const int slot_j[5] = {WS_SORT_AOS_J, WS_BBOX_J, WS_GSPH_J, WS_WSPH_J, WS_GSPH4_J};
             rc = cull_prepare_set(ctx, F, p.d_xj, p.d_tj, (long long)p.tj_fs, p.d_box, p.nj, nTj, p.n_ti,
-                                  ordered ? near_ord : 0.f, ordered ? p.nbins + 1 : 0, false, pk ? rel_block : 0, slot_j,
-                                  sj_set);
+                                  ordered ? near_ord : 0.f, ordered ? p.nbins + 1 : 0, false, pk ? rel_block : 0,
+                                  pk_rows ? 1 : 0, slot_j, sj_set);
             if (rc) return rc;
         }
         launch_cull_lists(ctx->stream, p.tri, F, si.bbox, sj_set.bbox, nTi, nTj, p.d_box,
@@ -324,7 +331,7 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         a.slots = slots;
         a.fpb = fpb;
 
-        a.near = near_ord;
+        a.near = pk_rows ? near_pk_f : near_ord;
         a.rel = d_rel;
         a.cen = d_cen;
         a.s_cap = s_cap;
@@ -334,13 +341,14 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         const bool sj = cull && ctx->opt_rdf_sj != 0;  // wave-independent sweep with scalar loads of the j atoms
         const bool persist = sj && !p.per_frame && ctx->opt_rdf_sj != 2;  // resident grid + per-XCD work counters
         a.work = reinterpret_cast<unsigned *>(d_misc + 4);
-        const size_t lds = pk      ? lds_bytes_sj_pk(p.nbins, p.n_ti, p.n_tj)
+        const size_t lds = pk_rows ? lds_bytes_sj_pk_rows(p.nbins, nc, p.n_ti, p.n_tj)
+                           : pk    ? lds_bytes_sj_pk(p.nbins, p.n_ti, p.n_tj)
                            : ordered ? ord_b
                            : sj    ? lds_bytes_sj(p.nbins, nc, p.n_ti, p.n_tj, mode_cn)
                            : fast ? lds_bytes_fast(p.nbins, nc, p.n_ti, p.n_tj)
                                   : lds_bytes(p.nbins, nc, p.n_ti, p.n_tj);
         const char *kname = "";
-        const int sj_mode = pk && ctx->opt_rdf_pk != 2 ? (cut_guard ? 4 : 3) : ordered ? 2 : mode_cn ? 1 : 0;
+        const int sj_mode = pk && ctx->opt_rdf_pk != 2 ? (pk_rows ? 5 : 3) + (cut_guard ? 1 : 0) : ordered ? 2 : mode_cn ? 1 : 0;
         const int bs = sj ? sj_block_threads(sj_mode) : TILE;  // threads per block
         const int wpb = bs / 64;                                // independent waves per block (scalar-j kernels)
         PairKernel kern = sj ? sj_kernel(sj_mode, persist, &kname)

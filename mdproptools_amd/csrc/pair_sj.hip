@@ -284,6 +284,7 @@ struct PkCtx {
     f32x2 iLx2, iLy2, iLz2;  // and their reciprocals
     float rc2hi;          // pre-filter: every pair with rsq < r_cut^2 has rsq32 < rc2hi
     float cut_lo;         // CUTG: sqrt(rsq32) >= cut_lo may be beyond the cutoff (pk_cut_lo)
+    const unsigned *rowtab;  // ROWS: the class-row table [n_tj][n_ti] of LDS byte addresses (nullptr: ordered rows)
     unsigned *queue;      // this wave's queue (LDS)
     int qn;               // entries queued (wave-uniform: kept in an SGPR)
     unsigned long long *lost;  // device counter of entries that did not fit the queue (must stay 0)
@@ -318,8 +319,10 @@ __device__ __forceinline__ void pk_drain(PkCtx &p, const FastCtx &c, int lane)
             const double rsq = (ax * ax + ay * ay) + az * az;
             if (rsq < p.rc2) {
                 const int ti = (int)((unsigned)__double2loint(ri.w)) / p.n_ti;  // low word of w = type * n_ti
-                const unsigned rowbase = c.lds_base + (unsigned)ti * (unsigned)p.n_tj * (unsigned)(c.nbins + 1) * 4u;
-                const float nearoff = __int_as_float(__double2hiint(rj.w));
+                // ordered rows: row (ti, .) + the offset of tj in the addend; class rows: table[tj][ti], addend near
+                const unsigned rowbase = p.rowtab ? p.rowtab[__double2loint(rj.w) + ti]
+                                                  : c.lds_base + (unsigned)ti * (unsigned)p.n_tj * (unsigned)(c.nbins + 1) * 4u;
+                const float nearoff = p.rowtab ? c.near : __int_as_float(__double2hiint(rj.w));
                 const float g1 = __builtin_fmaf(__builtin_amdgcn_sqrtf((float)rsq), c.gscale, nearoff);
                 int k = (int)g1;
                 if (__builtin_amdgcn_fractf(g1) < c.near2) {
@@ -429,10 +432,11 @@ __device__ __forceinline__ unsigned long long bin_pair(float rsq, float rc2hi, f
 // them (lgkmcnt(0)) before the first use of `rq`: that wait has to come before the prefetch is issued — the two
 // empty asm statements pin that order (the first depends on dx, i.e. on a use of rq) — and is free, because rq was
 // itself prefetched during the previous sweep.
-template <bool DIAG, int VAR, bool PF, bool CUTG>
+template <bool DIAG, int VAR, bool PF, bool CUTG, bool ROWS>
 __device__ __forceinline__ void sweep_group_pk(const RelQ &rq, int jidx0, int local0, PkCtx &p, const FastCtx &c,
                                                int lane_in_tile, int lane, const float *next_p, RelQ &next)
 {
+    unsigned row[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const f32x4 ra = h ? rq.c : rq.a, rb = h ? rq.d : rq.b;
@@ -440,6 +444,16 @@ __device__ __forceinline__ void sweep_group_pk(const RelQ &rq, int jidx0, int lo
         const f32x2 yj = {ra[2], ra[3]};
         const f32x2 zj = {rb[0], rb[1]};
         f32x2 dx = p.x2 - xj;
+        if (ROWS && h == 0) {
+            // class rows: the LDS address of the row of (ti, tj) from the table, for the four j atoms at once; the
+            // lookups (and the wait for them, which the asm operands force here) come before the prefetch is issued,
+            // because scalar loads and LDS share the lgkmcnt counter
+            row[0] = c.rowtab_me[__float_as_uint(rq.b[2])];
+            row[1] = c.rowtab_me[__float_as_uint(rq.b[3])];
+            row[2] = c.rowtab_me[__float_as_uint(rq.d[2])];
+            row[3] = c.rowtab_me[__float_as_uint(rq.d[3])];
+            asm volatile("" : "+v"(row[0]), "+v"(row[1]), "+v"(row[2]), "+v"(row[3])::"memory");
+        }
         if (PF && h == 0) {
             asm volatile("" ::"v"(dx) : "memory");
             next = load_relq(next_p);
@@ -454,10 +468,12 @@ __device__ __forceinline__ void sweep_group_pk(const RelQ &rq, int jidx0, int lo
         rsq = __builtin_elementwise_fma(dz, dz, rsq);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const float nearoff = u ? rb[3] : rb[2];
+            // ordered rows: w = the bin-guess addend near + tj * row_len; class rows: w = the table offset of tj
+            const float nearoff = ROWS ? c.near : (u ? rb[3] : rb[2]);
+            const unsigned rowbase = ROWS ? row[2 * h + u] : c.rowbase_me;
             float r2 = rsq[u];
             if (DIAG) r2 = local0 + 2 * h + u > lane_in_tile ? r2 : 3.0e38f;  // i < j inside the diagonal tile
-            const unsigned long long amb = bin_pair<CUTG>(r2, p.rc2hi, c.gscale, nearoff, c.near2, c.rowbase_me, p.cut_lo);
+            const unsigned long long amb = bin_pair<CUTG>(r2, p.rc2hi, c.gscale, nearoff, c.near2, rowbase, p.cut_lo);
             if (amb) {  // wave-uniform, rare: some lane's pair is inside the error band -> the exact chain, later
                 // (the copy through a volatile asm keeps the per-lane test inside this branch: the compiler would
                 // otherwise fold both conditions into one divergent branch and pay 3 VALU per pair for it)
@@ -493,8 +509,9 @@ __device__ __forceinline__ bool axis_plain(float wlo, float whi, float glo, floa
 
 // One work item of the packed-f32 sweep (ordered-pair rows; atom-atom or atoms x sites): the 64 i atoms of wave `wq` of tile I of
 // frame f against slice `split` of the tile's neighbour list.
-template <bool CUTG>
-__device__ __forceinline__ void sj_item_pk(const PairArgs &a, FastCtx &c, unsigned *queue, int f, int I, int wq,
+template <bool CUTG, bool ROWS>
+__device__ __forceinline__ void sj_item_pk(const PairArgs &a, FastCtx &c, const unsigned *s_row, unsigned *queue, int f,
+                                           int I, int wq,
                                            int split, int lane)
 {
     const long long n_pad = (long long)a.nTi * TILE, n_pad_j = (long long)a.nTj * TILE;
@@ -516,7 +533,7 @@ __device__ __forceinline__ void sj_item_pk(const PairArgs &a, FastCtx &c, unsign
     const bool real_i = ig < a.ni;
     {
         const int ti_me = (int)((unsigned)__double_as_longlong(ats[ig].w)) / a.n_ti;  // (pad records: type 0)
-        c.rowtab_me = nullptr;
+        c.rowtab_me = ROWS ? s_row + ti_me : nullptr;
         c.rowbase_me = c.lds_base + (unsigned)ti_me * (unsigned)a.n_tj * (unsigned)(a.nbins + 1) * 4u;
     }
     const long long w = ((long long)f * a.nTi + I) * (TILE / 64) + wq;
@@ -542,6 +559,7 @@ __device__ __forceinline__ void sj_item_pk(const PairArgs &a, FastCtx &c, unsign
     p.iLz2 = f32x2{(float)iLz, (float)iLz};
     p.rc2hi = a.rc2hi;
     p.cut_lo = a.cut_lo;
+    p.rowtab = ROWS ? s_row : nullptr;
     p.queue = queue;
     p.qn = 0;
     p.lost = a.overflow + 1;
@@ -645,14 +663,14 @@ __device__ __forceinline__ void sj_item_pk(const PairArgs &a, FastCtx &c, unsign
                         const bool moreB = mk != 0;
                         const int gB = moreB ? __builtin_ctzll(mk) : gA;
                         mk &= mk - 1;
-                        sweep_group_pk<false, 0, true, CUTG>(qA, jbase + gA * SJ_GROUP, gA * SJ_GROUP, p, c, lane_in_tile, lane,
+                        sweep_group_pk<false, 0, true, CUTG, ROWS>(qA, jbase + gA * SJ_GROUP, gA * SJ_GROUP, p, c, lane_in_tile, lane,
                                                        rtile + gB * SJ_GROUP * 4, qB);
                         if (!moreB) break;
                         PK_DRAIN_CHECK();
                         const bool moreA = mk != 0;
                         gA = moreA ? __builtin_ctzll(mk) : gB;
                         mk &= mk - 1;
-                        sweep_group_pk<false, 0, true, CUTG>(qB, jbase + gB * SJ_GROUP, gB * SJ_GROUP, p, c, lane_in_tile, lane,
+                        sweep_group_pk<false, 0, true, CUTG, ROWS>(qB, jbase + gB * SJ_GROUP, gB * SJ_GROUP, p, c, lane_in_tile, lane,
                                                        rtile + gA * SJ_GROUP * 4, qA);
                         if (!moreA) break;
                     }
@@ -667,15 +685,15 @@ __device__ __forceinline__ void sj_item_pk(const PairArgs &a, FastCtx &c, unsign
                     PK_DRAIN_CHECK();
                     const int j0 = jbase + g * SJ_GROUP, l0 = g * SJ_GROUP;
                     switch (A) {
-                    case 1: sweep_group_pk<false, 1, false, CUTG>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
-                    case 2: sweep_group_pk<false, 2, false, CUTG>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
-                    case 3: sweep_group_pk<false, 3, false, CUTG>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
-                    case 4: sweep_group_pk<false, 4, false, CUTG>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
-                    case 5: sweep_group_pk<false, 5, false, CUTG>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
-                    case 6: sweep_group_pk<false, 6, false, CUTG>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
-                    case 7: sweep_group_pk<false, 7, false, CUTG>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
-                    case 9: sweep_group_pk<true, 0, false, CUTG>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
-                    default: sweep_group_pk<true, 7, false, CUTG>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
+                    case 1: sweep_group_pk<false, 1, false, CUTG, ROWS>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
+                    case 2: sweep_group_pk<false, 2, false, CUTG, ROWS>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
+                    case 3: sweep_group_pk<false, 3, false, CUTG, ROWS>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
+                    case 4: sweep_group_pk<false, 4, false, CUTG, ROWS>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
+                    case 5: sweep_group_pk<false, 5, false, CUTG, ROWS>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
+                    case 6: sweep_group_pk<false, 6, false, CUTG, ROWS>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
+                    case 7: sweep_group_pk<false, 7, false, CUTG, ROWS>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
+                    case 9: sweep_group_pk<true, 0, false, CUTG, ROWS>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
+                    default: sweep_group_pk<true, 7, false, CUTG, ROWS>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
                     }
                 }
             }
@@ -706,7 +724,10 @@ __global__ __launch_bounds__(MODE >= 3 ? PK_THREADS : TILE, MODE >= 3 ? PK_WAVES
     // threads per block: the waves are independent (they share only the LDS histogram), so the block size is free.
     // MODE 3 runs 8 waves per block: LDS (one histogram per block) then allows 6 waves per SIMD instead of 5, which
     // this latency-bound sweep (scalar record loads from L2) converts into VALU utilisation.
-    constexpr int BS = MODE >= 3 ? PK_THREADS : TILE;  // MODE 4 = MODE 3 with the cutoff guard (CUTG)
+    constexpr int BS = MODE >= 3 ? PK_THREADS : TILE;
+    // packed-f32 modes: 3 ordered rows, 4 = 3 with the cutoff guard (CUTG), 5 class rows + row table, 6 = 5 with CUTG
+    constexpr bool ORDERED = MODE >= 2 && MODE <= 4;
+    constexpr bool PK_ROWS = MODE >= 5;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const long long bid = blockIdx.x;
@@ -715,16 +736,18 @@ __global__ __launch_bounds__(MODE >= 3 ? PK_THREADS : TILE, MODE >= 3 ? PK_WAVES
     // ---- LDS: hist | (CN edges) | row table ----
     // MODE 2: one row per ORDERED type pair (ti, tj), addressed without a table (see sweep_group_sj)
     const int row_len = a.nbins + 1;
-    const int hist_words = (MODE >= 2 ? a.n_ti * a.n_tj : a.n_cls + 1) * row_len;
+    const int hist_words = (ORDERED ? a.n_ti * a.n_tj : a.n_cls + 1) * row_len;
     unsigned *s_hist = reinterpret_cast<unsigned *>(smem);
     size_t off = ((size_t)hist_words * 4 + 15) & ~size_t(15);
     double *s_edges = reinterpret_cast<double *>(smem + off);
     off += MODE == 1 ? (((size_t)(a.nbins + 2) * 8 + 15) & ~size_t(15)) : 0;
-    unsigned *s_row = reinterpret_cast<unsigned *>(smem + off);  // MODE 3: the waves' queues of deferred pairs instead
+    unsigned *s_row = reinterpret_cast<unsigned *>(smem + off);  // class rows: the row table [n_tj][n_ti]
+    // packed-f32 modes: the waves' queues of deferred pairs, behind the row table when there is one
+    unsigned *s_queue = s_row + (PK_ROWS ? (a.n_ti * a.n_tj + 3) / 4 * 4 : 0);
     const unsigned lds_base =
         (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char *)smem;
     for (int k = tid; k < hist_words; k += BS) s_hist[k] = 0u;
-    if (MODE < 2)
+    if (!ORDERED)
         for (int k = tid; k < a.n_ti * a.n_tj; k += BS) {
             const int ti = k % a.n_ti, tj = k / a.n_ti;
             const unsigned cl = a.cls[ti * a.n_tj + tj];
@@ -768,7 +791,8 @@ __global__ __launch_bounds__(MODE >= 3 ? PK_THREADS : TILE, MODE >= 3 ? PK_WAVES
             const int fx = (int)(it / (unsigned)ipf), r = (int)(it % (unsigned)ipf);
             const int split = r % a.jsplit, wI = r / a.jsplit;
             if (MODE >= 3)
-                sj_item_pk<MODE == 4>(a, c, s_row + (tid >> 6) * PK_QSTRIDE, fx * 8 + xcd, wI >> 2, wI & 3, split, lane);
+                sj_item_pk<MODE == 4 || MODE == 6, PK_ROWS>(a, c, s_row, s_queue + (tid >> 6) * PK_QSTRIDE, fx * 8 + xcd, wI >> 2,
+                                                            wI & 3, split, lane);
             else
                 sj_item<MODE >= 3 ? 2 : MODE>(a, c, s_row, fx * 8 + xcd, wI >> 2, wI & 3, split, lane);
         }
@@ -788,7 +812,8 @@ __global__ __launch_bounds__(MODE >= 3 ? PK_THREADS : TILE, MODE >= 3 ? PK_WAVES
             if (it >= ipf) break;
             const int split = (int)(it % (unsigned)a.jsplit), wI = (int)(it / (unsigned)a.jsplit);
             if (MODE >= 3)
-                sj_item_pk<MODE == 4>(a, c, s_row + (tid >> 6) * PK_QSTRIDE, f, wI >> 2, wI & 3, split, lane);
+                sj_item_pk<MODE == 4 || MODE == 6, PK_ROWS>(a, c, s_row, s_queue + (tid >> 6) * PK_QSTRIDE, f, wI >> 2, wI & 3, split,
+                                                            lane);
             else
                 sj_item<MODE >= 3 ? 2 : MODE>(a, c, s_row, f, wI >> 2, wI & 3, split, lane);
         }
@@ -835,6 +860,12 @@ size_t lds_bytes_sj_ordered(int nbins, int n_ti, int n_tj)
 
 int sj_block_threads(int mode) { return mode >= 3 ? PK_THREADS : TILE; }
 
+size_t lds_bytes_sj_pk_rows(int nbins, int n_cls, int n_ti, int n_tj)
+{
+    const size_t hist = ((size_t)(n_cls + 1) * (nbins + 1) * 4 + 15) & ~size_t(15);
+    return hist + (size_t)((n_ti * n_tj + 3) / 4 * 4) * 4 + (size_t)(PK_THREADS / 64) * PK_QSTRIDE * 4;
+}
+
 size_t lds_bytes_sj_pk(int nbins, int n_ti, int n_tj)
 {
     return (((size_t)n_ti * n_tj * (nbins + 1) * 4 + 15) & ~size_t(15)) + (size_t)(PK_THREADS / 64) * PK_QSTRIDE * 4;
@@ -873,6 +904,8 @@ size_t lds_bytes_sj(int nbins, int n_cls, int n_ti, int n_tj, bool mode_cn)
 PairKernel sj_kernel(int mode, bool persist, const char **name)
 {
 #define MD_PICK(...) (*name = #__VA_ARGS__, __VA_ARGS__)
+    if (mode == 6) return persist ? MD_PICK(pair_hist_sj_kernel<6, true>) : MD_PICK(pair_hist_sj_kernel<6, false>);
+    if (mode == 5) return persist ? MD_PICK(pair_hist_sj_kernel<5, true>) : MD_PICK(pair_hist_sj_kernel<5, false>);
     if (mode == 4) return persist ? MD_PICK(pair_hist_sj_kernel<4, true>) : MD_PICK(pair_hist_sj_kernel<4, false>);
     if (mode == 3) return persist ? MD_PICK(pair_hist_sj_kernel<3, true>) : MD_PICK(pair_hist_sj_kernel<3, false>);
     if (mode == 2) return persist ? MD_PICK(pair_hist_sj_kernel<2, true>) : MD_PICK(pair_hist_sj_kernel<2, false>);

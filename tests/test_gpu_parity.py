@@ -752,8 +752,11 @@ def _pk_case(rng, trial):
     if trial % 7 == 3:
         box = box * (1.0 + 0.01 * np.arange(F))[:, None]  # NPT: another box every frame
     n_types = int(rng.integers(1, 5))
-    ty = rng.integers(1, n_types + 1, n).astype(np.int32)
     rel = np.array([[1, 1], [1, n_types], [n_types, n_types]])
+    if trial % 5 == 4:  # many types, all of them named: the T^2 ordered rows do not fit LDS -> class rows + row table
+        n_types = int(rng.integers(6, 10))
+        rel = np.array([[a, b] for a in range(1, n_types + 1) for b in range(a, n_types + 1)])[::3][:14]
+    ty = rng.integers(1, n_types + 1, n).astype(np.int32)
     return xyz, ty, box, rel, r_cut, bin_size, nbins
 
 
@@ -774,7 +777,7 @@ def test_packed_f32_sweep_equals_f64_sweep(B):
         per_frame = bool(trial % 2)
         a = B.rdf_loop(xyz, ty, box, rel, r_cut, bin_size, nbins, per_frame=per_frame, ctx=f64)
         b = B.rdf_loop(xyz, ty, box, rel, r_cut, bin_size, nbins, per_frame=per_frame, ctx=pk)
-        engaged += ("<3," in pk.last_kernel_name()) or ("<4," in pk.last_kernel_name())
+        engaged += any(t in pk.last_kernel_name() for t in ("<3,", "<4,", "<5,", "<6,"))
         msg = "trial %d n=%d box=%s r_cut=%.4f bin=%.3f kernel=%s" % (trial, xyz.shape[2], box[0], r_cut, bin_size,
                                                                      pk.last_kernel_name())
         np.testing.assert_array_equal(a[0], b[0], err_msg=msg)
@@ -933,6 +936,39 @@ def test_fewer_bins_than_the_cutoff_spans(B):
         np.testing.assert_array_equal(part[0], cp)
         assert ov == cov and cov > 0
         ctx.close()
+
+
+def test_packed_f32_sweep_class_rows(B):
+    """9 atom types, all named by relations: the 81 ordered rows do not fit LDS, so the packed-f32 sweep runs on the
+    class-row layout with its LDS row table (<5, .>; <6, .> with the cutoff inside a bin). Against the all-f64 sweep
+    (class rows, MODE 0) and the C oracle."""
+    from mdproptools_amd._lib import Context
+
+    rng = np.random.default_rng(606)
+    n, L, F = 4300, 37.5, 2
+    xyz = rng.uniform(0, L, (F, 3, n))
+    xyz[:, :, rng.choice(n, 40, replace=False)] += rng.integers(-2, 3, (F, 3, 40)) * L
+    box = np.full((F, 3), L)
+    ty = rng.integers(1, 10, n).astype(np.int32)
+    rel = np.array([[a, b] for a in range(1, 10) for b in range(a, 10)])[::4]  # 12 relations over all 9 types
+    f64, pk = Context(0), Context(0)
+    for ctx, v in ((f64, 0), (pk, 1)):
+        ctx.set_option("rdf_cull", 1)
+        ctx.set_option("rdf_pk", v)
+    for r_cut, bin_size, nbins, tag in ((16.0, 0.04, 400, "<5,"), (16.03, 0.04, 400, "<6,"), (18.7, 0.1, 187, "<5,")):
+        for per_frame in (True, False):
+            a = B.rdf_loop(xyz, ty, box, rel, r_cut, bin_size, nbins, per_frame=per_frame, ctx=f64)
+            b = B.rdf_loop(xyz, ty, box, rel, r_cut, bin_size, nbins, per_frame=per_frame, ctx=pk)
+            assert tag in pk.last_kernel_name() and "<0," in f64.last_kernel_name(), (pk.last_kernel_name(), f64.last_kernel_name())
+            np.testing.assert_array_equal(a[0], b[0])
+            np.testing.assert_array_equal(a[1], b[1])
+            assert a[2] == b[2]
+            if per_frame:
+                cf, cp, _ = C.rdf_pairs(xyz[0], ty, rel, box[0], r_cut * r_cut, bin_size, nbins)
+                np.testing.assert_array_equal(b[0][0], cf)
+                np.testing.assert_array_equal(b[1][0], cp)
+    f64.close()
+    pk.close()
 
 
 def test_culled_path_large_box_auto(B):

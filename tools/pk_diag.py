@@ -1,4 +1,5 @@
-"""Diagnostic for the packed-f32 sweep: python tools/pk_diag.py <rdf_pk value> <n_atoms> <n_frames> [per_frame]"""
+"""Diagnostic for the packed-f32 sweep: python tools/pk_diag.py <rdf_pk value> <n_atoms> <n_frames> [per_frame] [n_types]
+(more than 5 types: every 4th type pair as a relation, all types named -> class rows)"""
 import os
 import sys
 
@@ -13,8 +14,11 @@ per_frame = len(sys.argv) < 5 or sys.argv[4] != "0"
 rng = np.random.default_rng(5)
 L = 50.0 * (n / 1e4) ** (1 / 3)
 xyz = rng.uniform(0, L, (F, 3, n))
-ty = (1 + np.arange(n) % 4).astype(np.int32)
-rel = np.array([[a, b] for a in range(1, 5) for b in range(a, 5)])
+nt = int(sys.argv[5]) if len(sys.argv) > 5 else 4
+ty = (1 + np.arange(n) % nt).astype(np.int32)
+rel = np.array([[a, b] for a in range(1, nt + 1) for b in range(a, nt + 1)])
+if nt > 5:
+    rel = rel[::4]
 box = np.full((F, 3), L)
 res = {}
 for v in (0, pk):
