@@ -3,24 +3,37 @@
 bench.py — throughput of the RDF hot path (atom-pairs/s) on N GPUs of one node.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 4                       # starts 4 fresh ranks itself (torch.distributed.run), see spawn()
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A step is one pass of `_rdf_loop` (structural/rdf_cn.py:72-97 of the reference) over one batch of
-synthetic frames that are already resident in HBM: BASELINE.json configs[1] — 10 000 atoms x 200
-frames, cubic box L = 50 A, 4 atom types, all 10 type pairs, r_cut 20 A, 400 bins. For N > 1 every
-rank owns its own 200 frames (weak scaling) and the frame-summed uint64 histograms are
-all-reduced over RCCL in every step, inside the timed region.
+synthetic frames that are already resident in HBM.
 
-Rank 0 prints ONE JSON line. Extra keys: `roofline` (dominant kernel, measured with HIP events on the
-launch stream inside the library), `cpu_baseline` (oracle/cpu_ref.c on the host cores, bounded
-sample), `msd` (frame-pairs/s of the single-origin MSD kernel, HBM-bound, reported beside the RDF
-number because BASELINE.json's metric names both).
+  --scaling weak (default)  BASELINE.json configs[1], C2 — 10 000 atoms x 200 frames, cubic box L = 50 A, 4 atom
+                            types, all 10 type pairs, r_cut 20 A, 400 bins — on EVERY rank (its own frames);
+  --scaling strong          BASELINE.json configs[2], C3 — 100 000 atoms x 1000 frames, L = 104 A — split
+                            contiguously over the ranks (1000/N frames each).
+For N > 1 the frame-summed uint64 histograms are all-reduced over RCCL in every step, inside the timed region.
+
+Rank 0 prints ONE JSON line. Beside the contract's keys it carries (N = 1 only, all measured in this run):
+  roofline        the dominant kernel against the VALU-issue roof MEASURED for its instruction mix
+                  (profiles/r02_ubench_valu.json), HBM traffic from the committed PMC run
+  parity_checked  the timed histograms == the sum of a per-frame run, whose frames are compared bit for bit with
+                  the C oracle (as many frames as the all-cores CPU leg computes anyway)
+  f64_only        the same step with the all-f64 sweep (the reference's arithmetic type end to end)
+  h2d_inclusive   the same step with the coordinates in host memory (pageable and pinned)
+  c3, c4, c5      BASELINE.json configs[2..4] at FULL size on this GPU, each with its roofline and a bounded
+                  cpu_baseline sample
+  cpu_baseline    oracle/cpu_ref.c on the host cores (bounded sample), the checker — never the thing measured
 """
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,12 +42,122 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
-FP64_NONFUSED_PEAK = 39.3e12  # 256 CU x 128 lanes x 2.4 GHz / 2 (SURVEY.md §8d; FMA is forbidden by parity)
-HBM_PEAK = 8.0e12             # spec, /opt/skills/guides/MI355X_MICROARCH.md
-OPS_PER_PAIR = 18             # SURVEY.md §8d algorithmic FP64 ops per atom pair
+FP64_NONFUSED_PEAK = 39.3e12  # 256 CU x 128 lanes x 2.4 GHz / 2 (SURVEY.md 8d; FMA is forbidden by parity)
+FP64_FMA_PEAK = 78.6e12       # FP64 vector FMA, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK = 8.0e12             # spec, same guide
+OPS_PER_PAIR = 18             # SURVEY.md 8d algorithmic FP64 ops per atom pair
+N_SIMD = 256 * 4
+PAIR_SOURCES = ["pair_sj.hip", "pair_common.h", "pair_hist.hip", "pair_cull.hip"]
 
 
-def cpu_baseline(cfg, types, rel, n_sample_frames):
+# ------------------------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: start the ranks ourselves, before anything touches the GPU
+# ------------------------------------------------------------------------------------------------------------------
+def spawn(args):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: run N fresh child ranks under
+    torch.distributed.run (this process has made no HIP call, and makes none) and pass rank 0's line through."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if line:
+        print(line[-1], flush=True)
+    else:
+        sys.stdout.write(r.stdout)
+    sys.exit(r.returncode if r.returncode else (0 if line else 3))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# committed measurements the roofline is priced against
+# ------------------------------------------------------------------------------------------------------------------
+def source_hash():
+    """Hash of the pair-kernel sources: a PMC instruction count is only used when it was taken from this code."""
+    h = hashlib.sha256()
+    for name in PAIR_SOURCES:
+        with open(os.path.join(HERE, "mdproptools_amd", "csrc", name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def load_json(*parts):
+    try:
+        with open(os.path.join(HERE, *parts)) as fh:
+            return json.load(fh)
+    except Exception:
+        return None
+
+
+def ubench_rate(inst, waves):
+    """Measured issue rate (G wave-instructions/s per SIMD) of `inst` at `waves` per SIMD, tools/ubench_valu.hip."""
+    ub = load_json("profiles", "r02_ubench_valu.json")
+    if not ub:
+        return None
+    for r in ub["results"]:
+        if r["inst"] == inst and r["waves_per_simd"] == waves:
+            return r["ginst_per_s_per_simd"]
+    return None
+
+
+def pmc_entry(kernel, workload):
+    """The committed rocprofv3 --pmc summary of `kernel` on `workload` (profiles/pmc_kernels.json, written by
+    tools/pmc_summarize.py), or (None, reason) when there is none or it was taken from other kernel sources."""
+    db = load_json("profiles", "pmc_kernels.json")
+    if not db:
+        return None, "profiles/pmc_kernels.json missing"
+    e = db.get("%s|%s" % (kernel, workload))
+    if not e:
+        return None, "no PMC run of %s on %s" % (kernel, workload)
+    if e.get("source_hash") != source_hash():
+        return None, "stale: PMC run was taken from other pair-kernel sources (hash %s, now %s)" % (
+            e.get("source_hash"), source_hash())
+    return e, None
+
+
+def valu_roofline(kernel, workload, kdur, mix, waves, alg_pairs, alg_bytes):
+    """
+    Roofline object of a pair kernel. The kernel is bound by VALU issue (neither HBM nor MFMA: 28 B and <= 18 vector
+    ops per atom pair), so:
+      achieved = VALU wave-instructions per launch (rocprofv3 SQ_INSTS_VALU of this kernel on this workload, from
+                 the committed PMC run; used only when that run was made from the present kernel sources)
+                 / the launch duration measured live with HIP events;
+      peak     = the issue rate tools/ubench_valu.hip measures on this GPU for the kernel's own instruction mix at
+                 the kernel's occupancy (`mix` / `waves`), x 1024 SIMDs.
+    """
+    rate = ubench_rate(mix, waves)
+    e, why = pmc_entry(kernel, workload)
+    out = {"bound": "valu-issue", "kernel": kernel, "launch_ms": kdur * 1e3, "unit": "G wave-instructions/s",
+           "achieved": None, "peak": None if rate is None else rate * N_SIMD, "frac": None,
+           "peak_source": "profiles/r02_ubench_valu.json '%s' at %d waves/SIMD x %d SIMDs" % (mix, waves, N_SIMD),
+           "traffic": None,
+           "algorithmic_vs_fp64_nonfused": alg_pairs * OPS_PER_PAIR / kdur / FP64_NONFUSED_PEAK,
+           "hbm": {"achieved": alg_bytes / kdur / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                   "frac": alg_bytes / kdur / HBM_PEAK, "algorithmic_bytes": alg_bytes}}
+    if e is None:
+        out["note"] = why
+        return out
+    insts = float(e["SQ_INSTS_VALU"])
+    out["achieved"] = insts / kdur / 1e9
+    out["instructions_per_launch"] = insts
+    out["instruction_source"] = "profiles/pmc_kernels.json (%s)" % e.get("tag", "")
+    out["traffic"] = e.get("hbm_bytes_per_launch")
+    if rate is not None:
+        out["frac"] = insts / kdur / (rate * 1e9 * N_SIMD)
+    for k in ("valu_busy", "wait_inst_any_over_wave_cycles"):
+        if k in e:
+            out[k] = e[k]
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# CPU side (the oracle as the checker and as the reported baseline)
+# ------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(cfg, types, rel, nb, n_sample_frames):
     """oracle/cpu_ref.c (single thread, -O2 -ffp-contract=off) on the same workload, bounded sample."""
     from oracle import cref
     from mdproptools_amd import synth
@@ -45,7 +168,7 @@ def cpu_baseline(cfg, types, rel, n_sample_frames):
     L = [cfg["box_len"]] * 3
     t0 = time.perf_counter()
     for f in range(n_sample_frames):
-        cref.rdf_pairs(xyz[f], types, rel, L, cfg["r_cut"] ** 2, cfg["bin_size"], 400)
+        cref.rdf_pairs(xyz[f], types, rel, L, cfg["r_cut"] ** 2, cfg["bin_size"], nb)
     dt = time.perf_counter() - t0
     pairs = n_sample_frames * n * (n - 1) // 2
     return {
@@ -56,65 +179,388 @@ def cpu_baseline(cfg, types, rel, n_sample_frames):
     }
 
 
-def cpu_baseline_all_cores(cfg, types, rel):
-    """The same loop frame-parallel over every host core (frames are independent; the reference itself only does
-    this in get_charge_flux, conductivity.py:190): one frame per core on a thread pool — the ctypes call into
-    oracle/cpu_ref.c releases the GIL — wall time of the whole pool."""
+def cpu_baseline_all_cores(cfg, types, rel, nb):
+    """The same loop frame-parallel over the host cores (frames are independent; the reference itself only does
+    this in get_charge_flux, conductivity.py:190): one frame per thread — the ctypes call into oracle/cpu_ref.c
+    releases the GIL. Returns (report, per-frame histograms) — the histograms are the parity check's oracle."""
     from concurrent.futures import ThreadPoolExecutor
 
     from oracle import cref
     from mdproptools_amd import synth
 
-    cores = min(os.cpu_count() or 1, 64)  # bounded sample: 64 threads, one frame each
+    cores = min(os.cpu_count() or 1, 64)  # bounded sample: at most 64 threads, one frame each
     n, L = cfg["n_atoms"], cfg["box_len"]
     frames = synth.rdf_frames(n, range(cores), L, cfg["seed_offset"])
 
     def one(f):
-        cref.rdf_pairs(frames[f], types, rel, [L] * 3, cfg["r_cut"] ** 2, cfg["bin_size"], 400)
+        return cref.rdf_pairs(frames[f], types, rel, [L] * 3, cfg["r_cut"] ** 2, cfg["bin_size"], nb)
 
     with ThreadPoolExecutor(max_workers=cores) as pool:
         t0 = time.perf_counter()
-        list(pool.map(one, range(cores)))
+        res = list(pool.map(one, range(cores)))
         wall = time.perf_counter() - t0
-    return {"value": cores * (n * (n - 1) // 2) / wall, "unit": "atom-pairs/s", "cores": cores, "kind": "port",
-            "sample": "%d frames on %d threads (one each, around the C oracle; host reports %d cores), %.1f s wall"
-                      % (cores, cores, os.cpu_count() or 0, wall)}
+    rep = {"value": cores * (n * (n - 1) // 2) / wall, "unit": "atom-pairs/s", "cores": cores, "kind": "port",
+           "sample": "%d frames on %d threads (one each, around the C oracle; host reports %d cores), %.1f s wall"
+                     % (cores, cores, os.cpu_count() or 0, wall)}
+    return rep, res
 
 
-def msd_leg(B, torch, device, steps):
-    """Single-origin MSD (diffusion.py:212-218) on a resident random walk: frame-pairs/s and HBM GB/s."""
-    from mdproptools_amd import synth
+def cpu_check_frame(x0, types, rel, L, cfg, nb):
+    """One frame through oracle/cpu_ref.c (the parity leg's checker when the all-cores leg did not run)."""
+    from oracle import cref
 
-    E, F = 50_000, 256
-    r = torch.from_numpy(synth.random_walk(E, F)).to(device)
-    pairs = [(0, t) for t in range(F)]
-    B.msd_pairs(r, pairs, [0, E], scale=1e-10)
-    torch.cuda.synchronize()
+    return cref.rdf_pairs(x0, types, rel, [L] * 3, cfg["r_cut"] ** 2, cfg["bin_size"], nb)
+
+
+def cpu_check_c3(x0, ty, rel, L, cfg, nb, cuts):
+    """C3 frame 0 at full size: the whole frame on the host cores (head rows dealt to threads) as the parity oracle,
+    and its first head rows on ONE core as the bounded single-core sample (RDF and CN)."""
+    from oracle import cref
+
+    n = x0.shape[1]
+    threads = min(os.cpu_count() or 1, 64)
+    tc = time.perf_counter()
+    cf, cp, _ = cref.rdf_pairs_threaded(x0, ty, rel, [L] * 3, cfg["r_cut"] ** 2, cfg["bin_size"], nb, threads)
+    cpu_wall = time.perf_counter() - tc
+    rows = 3000
+    spairs = rows * n - rows * (rows + 1) // 2
+    tc = time.perf_counter()
+    cref.rdf_pairs(x0, ty, rel, [L] * 3, cfg["r_cut"] ** 2, cfg["bin_size"], nb, rows=(0, rows))
+    c1 = time.perf_counter() - tc
+    tc = time.perf_counter()
+    cref.cn_pairs(x0, ty, rel, [L] * 3, [c * c for c in cuts], rows=(0, rows))
+    c2 = time.perf_counter() - tc
+    return dict(full=cf, part=cp, threads=threads, wall=cpu_wall, rows=rows, spairs=spairs, rdf_s=c1, cn_s=c2)
+
+
+def cpu_check_c4(rs, rsub, lags, E, esub):
+    """C4: single-origin sums of the first frame pairs (all entities) and the lag x origin means of an entity subset."""
+    from oracle import cref
+
+    npairs = rs.shape[0]
+    tc = time.perf_counter()
+    cs = cref.msd_pairs(rs, [(0, t) for t in range(npairs)], [0, E])
+    cpu_pair = (time.perf_counter() - tc) / npairs
+    tc = time.perf_counter()
+    cl = cref.lag_msd(rsub, lags, [0, esub])
+    return dict(single=np.asarray(cs), per_pair_s=cpu_pair, lag=cl, lag_s=time.perf_counter() - tc)
+
+
+def cpu_check_c5(ph, nl):
+    """C5: numpy's FFT estimator on the full series (what the reference calls) and the direct estimator on nl lags."""
+    from oracle import cref
+
+    n = ph.shape[1]
+    tc = time.perf_counter()
+    for k in range(3):
+        fa = np.fft.fft(ph[k], 2 * n)
+        ref = np.fft.ifft(fa * np.conj(fa))[:n].real / (n - np.arange(n))
+    cpu_fft = time.perf_counter() - tc
+    tc = time.perf_counter()
+    cd = cref.xcorr_direct(ph[0], ph[0], n_lags=nl)
+    cpu_dir = (time.perf_counter() - tc) / (nl * n - nl * (nl - 1) / 2)
+    return dict(fft_last=ref, fft_s=cpu_fft, direct=cd, per_pair_s=cpu_dir)
+
+
+def timed(fn, sync, reps):
+    """Mean wall time of `reps` calls after one untimed call."""
+    fn()
+    sync()
     t0 = time.perf_counter()
-    kms = 0.0
-    for _ in range(steps):
-        B.msd_pairs(r, pairs, [0, E], scale=1e-10)
-        kms += B.default_context().last_kernel_ms()[0]
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    alg_bytes = 24.0 * E * F  # SURVEY.md §8d: 24*E bytes per frame pair (origin frame amortised)
-    return {
-        "metric": "frame-pairs/s", "value": steps * F / dt, "workload": "50k entities x 256 frames, pairs (0,t)",
-        "kernel_ms": kms / steps,
-        "roofline": {"bound": "hbm", "achieved": alg_bytes / (kms / steps * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
-                     "unit": "GB/s", "frac": alg_bytes / (kms / steps * 1e-3) / HBM_PEAK, "traffic": None},
-    }
+    for _ in range(reps):
+        out = fn()
+    sync()
+    return (time.perf_counter() - t0) / reps, out
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# legs
+# ------------------------------------------------------------------------------------------------------------------
+def leg_parity(B, ctx, xyz, types, box, rel, cfg, nb, full, part, oracle_frames):
+    """The timed (frame-summed) histograms against a per-frame run of the same frames, and that run's first frames
+    against the C oracle, bit for bit."""
+    pf_full, pf_part, _ = B.rdf_loop(xyz, types, box, rel, cfg["r_cut"], cfg["bin_size"], nb, per_frame=True, ctx=ctx)
+    pf_kernel = ctx.last_kernel_name()
+    if not (np.array_equal(pf_full.sum(axis=0), full) and np.array_equal(pf_part.sum(axis=0), part)):
+        raise AssertionError("frame-summed histograms differ from the sum of the per-frame histograms")
+    for f, (cf, cp, _ov) in enumerate(oracle_frames):
+        if not (np.array_equal(pf_full[f], cf) and np.array_equal(pf_part[f], cp)):
+            raise AssertionError("frame %d differs from oracle/cpu_ref.c" % f)
+    return {"frames_against_oracle": len(oracle_frames), "summed_equals_per_frame_sum": True,
+            "per_frame_kernel": pf_kernel}
+
+
+def leg_f64_only(B, ctx, xyz, types, box, rel, cfg, nb, steps, pairs_per_step, full_ref, sync):
+    """The like-for-like line: every pair through the reference's f64 chain (rdf_pk = 0)."""
+    ctx.set_option("rdf_pk", 0)
+    try:
+        kms = []
+
+        def call():
+            out = B.rdf_loop(xyz, types, box, rel, cfg["r_cut"], cfg["bin_size"], nb, per_frame=False, ctx=ctx)
+            kms.append(ctx.last_kernel_ms()[0])
+            return out
+
+        dt, (full, _p, _o) = timed(call, sync, steps)
+        kernel = ctx.last_kernel_name()
+    finally:
+        ctx.set_option("rdf_pk", -1)
+    if not np.array_equal(full, full_ref):
+        raise AssertionError("all-f64 sweep and default sweep disagree")
+    kdur = float(np.mean(kms[1:])) * 1e-3
+    n, F = cfg["n_atoms"], xyz.shape[0]
+    return {"value": pairs_per_step / dt, "unit": "atom-pairs/s", "dtype": "f64", "ms_per_step": dt * 1e3,
+            "identical_to_default": True,
+            "roofline": valu_roofline(kernel, "C2", kdur, "v_add_f64", 4, pairs_per_step, 28.0 * n * F)}
+
+
+def leg_h2d(B, ctx, torch, xyz_host, types, box, rel, cfg, nb, steps, pairs_per_step, sync):
+    """the library call on host arrays, staging included (never `value`)."""
+    out = {}
+    pinned = torch.empty(xyz_host.shape, dtype=torch.float64, pin_memory=True)
+    pinned.numpy()[...] = xyz_host
+    for name, arr in (("pageable", xyz_host), ("pinned", pinned.numpy())):
+        dt, _ = timed(lambda: B.rdf_loop(arr, types, box, rel, cfg["r_cut"], cfg["bin_size"], nb, per_frame=False,
+                                         ctx=ctx), sync, steps)
+        out[name] = {"value": pairs_per_step / dt, "unit": "atom-pairs/s", "ms_per_step": dt * 1e3,
+                     "h2d_GBps_if_serial": xyz_host.nbytes / dt / 1e9}
+    out["bytes_per_step"] = int(xyz_host.nbytes)
+    return out
+
+
+def leg_c3(B, ctx, torch, device, synth, sync):
+    """BASELINE.json configs[2] on ONE GPU: 100k atoms x 1000 frames, RDF (10 relations, 400 bins) + CN."""
+    cfg = synth.rdf_config("C3")
+    n, L, F = cfg["n_atoms"], cfg["box_len"], cfg["n_frames"]
+    nb = int(cfg["r_cut"] / cfg["bin_size"])
+    xyz = torch.empty((F, 3, n), dtype=torch.float64, device=device)
+    for f0 in range(0, F, 50):
+        xyz[f0:f0 + 50] = torch.from_numpy(synth.rdf_frames(n, range(f0, min(F, f0 + 50)), L,
+                                                            cfg["seed_offset"])).to(device)
+    ty = synth.rdf_types(n)
+    rel = np.array(synth.ALL_PAIRS_4, dtype=np.int32)
+    box = np.full((F, 3), L)
+    cuts = synth.cn_cutoffs(len(rel))
+    pairs = F * n * (n - 1) // 2
+    km = {}
+
+    def rdf():
+        o = B.rdf_loop(xyz, ty, box, rel, cfg["r_cut"], cfg["bin_size"], nb, per_frame=False, ctx=ctx)
+        km["rdf"] = (ctx.last_kernel_ms()[0], ctx.last_aux_ms(), ctx.last_kernel_name())
+        return o
+
+    def cn():
+        o = B.cn_loop(xyz, ty, box, rel, cuts, per_frame=False, ctx=ctx)
+        km["cn"] = (ctx.last_kernel_ms()[0], ctx.last_aux_ms(), ctx.last_kernel_name())
+        return o
+
+    t_rdf, (full, part, _ov) = timed(rdf, sync, 2)
+    t_cn, cnt = timed(cn, sync, 2)
+    out = {"workload": "C3: 100k atoms x 1000 frames, L=104 A, 4 types, 10 relations, r_cut 20 A, 400 bins; "
+                       "CN cutoffs 2.325 + 0.5 kl A; one GPU, frames resident",
+           "pairs": pairs}
+    if hasattr(B, "rdf_cn_loop"):
+        def both():
+            o = B.rdf_cn_loop(xyz, ty, box, rel, cfg["r_cut"], cfg["bin_size"], nb, cuts, per_frame=False, ctx=ctx)
+            km["both"] = (ctx.last_kernel_ms()[0], ctx.last_aux_ms(), ctx.last_kernel_name())
+            return o
+
+        t_both, (full2, part2, _o2, cnt2) = timed(both, sync, 2)
+        if not (np.array_equal(full2, full) and np.array_equal(part2, part) and np.array_equal(cnt2, cnt)):
+            raise AssertionError("fused RDF+CN sweep differs from the separate calls")
+        out["rdf_cn_one_sweep"] = {"wall_s": t_both, "kernel_s": km["both"][0] * 1e-3, "kernel": km["both"][2],
+                                   "value": pairs / t_both, "unit": "atom-pairs/s",
+                                   "over_rdf_alone": t_both / t_rdf}
+    # frame 0 at full size against the oracle (the frame split over the host cores by head rows)
+    chk = cpu_check_c3(xyz[0].cpu().numpy(), ty, rel, L, cfg, nb, cuts)
+    f0, p0, _ = B.rdf_loop(xyz[:1], ty, box[:1], rel, cfg["r_cut"], cfg["bin_size"], nb, ctx=ctx)
+    if not (np.array_equal(f0[0], chk["full"]) and np.array_equal(p0[0], chk["part"])):
+        raise AssertionError("C3 frame 0 differs from oracle/cpu_ref.c")
+    rows, spairs, c1, c2, threads, cpu_wall = (chk[k] for k in ("rows", "spairs", "rdf_s", "cn_s", "threads", "wall"))
+    frac_in = float(full.sum()) / 2.0 / pairs
+    expect = 4.0 / 3.0 * np.pi * cfg["r_cut"] ** 3 / L ** 3
+    if abs(frac_in - expect) > 1e-4:
+        raise AssertionError((frac_in, expect))
+    out["rdf"] = {"wall_s": t_rdf, "kernel_s": km["rdf"][0] * 1e-3, "prepass_s": km["rdf"][1] * 1e-3,
+                  "value": pairs / t_rdf, "unit": "atom-pairs/s",
+                  "roofline": valu_roofline(km["rdf"][2], "C3", km["rdf"][0] * 1e-3, "mix bin 11/16", 6, pairs,
+                                            28.0 * n * F)}
+    out["cn"] = {"wall_s": t_cn, "kernel_s": km["cn"][0] * 1e-3, "value": pairs / t_cn, "unit": "atom-pairs/s",
+                 "roofline": valu_roofline(km["cn"][2], "C3", km["cn"][0] * 1e-3, "v_add_f64", 4, pairs,
+                                           28.0 * n * F)}
+    out["rdf_plus_cn_wall_s"] = out.get("rdf_cn_one_sweep", {}).get("wall_s", t_rdf + t_cn)
+    out["parity_checked"] = "frame 0 (5.0e9 pairs) == oracle/cpu_ref.c, bit-exact"
+    out["cpu_baseline"] = {
+        "value": spairs / c1, "unit": "atom-pairs/s", "cores": 1, "kind": "port",
+        "sample": "head rows 0..%d of frame 0 at full N (%.2e pairs): RDF %.1f s, CN %.1f s (%.3g pairs/s); "
+                  "whole frame 0 on %d threads: %.1f s wall" % (rows, spairs, c1, c2, spairs / c2, threads, cpu_wall),
+        "extrapolated_rdf_plus_cn_s": pairs / (spairs / c1) + pairs / (spairs / c2)}
+    out["speedup_vs_one_core"] = out["cpu_baseline"]["extrapolated_rdf_plus_cn_s"] / out["rdf_plus_cn_wall_s"]
+    del xyz
+    torch.cuda.empty_cache()
+    return out
+
+
+def leg_c4(B, ctx, torch, device, synth, sync):
+    """BASELINE.json configs[3] at full size: 50k atoms x 5000 frames, MSD (single origin, fixed lag, COM, full lag)."""
+    E, F = 50_000, 5000
+    g = torch.Generator(device=device)
+    g.manual_seed(synth.BASE_SEED + 4)
+    r = torch.empty((F, 3, E), dtype=torch.float64, device=device)
+    r[0] = torch.rand((3, E), generator=g, device=device, dtype=torch.float64) * 82.8
+    for f0 in range(1, F, 250):
+        f1 = min(F, f0 + 250)
+        st = torch.randn((f1 - f0, 3, E), generator=g, device=device, dtype=torch.float64) * 0.1
+        r[f0:f1] = r[f0 - 1] + torch.cumsum(st, dim=0)
+        del st
+    pairs = [(0, t) for t in range(F)]
+    km = {}
+
+    def rec(key, fn):
+        def run():
+            o = fn()
+            km[key] = (ctx.last_kernel_ms()[0], ctx.last_kernel_name())
+            return o
+        return run
+
+    t_msd, s1 = timed(rec("msd", lambda: B.msd_pairs(r, pairs, [0, E], scale=1e-10, ctx=ctx)), sync, 3)
+    t_win, _w = timed(rec("win", lambda: B.msd_windows(r, 4, scale=1e-10, ctx=ctx)), sync, 3)
+    off = np.concatenate([np.arange(0, 40_000, 16), np.arange(40_000, 50_001, 4)]).astype(np.int64)
+    mass = np.where(np.arange(E) < 40_000, 2.0, 3.0)
+    M = len(off) - 1
+    com_d = torch.empty((F, 3, M), dtype=torch.float64, device=device)
+    t_com, _c = timed(rec("com", lambda: B.segment_com(r, mass, off, out=com_d, ctx=ctx)), sync, 3)
+    t_lag, lag = timed(rec("lag", lambda: B.lag_msd(r, F - 1, [0, E], scale=1.0, ctx=ctx)), sync, 1)
+    bound = ctx.last_rel_bound()
+    ctx.set_option("lag_variant", 1)
+    try:
+        t_lagd, lagd = timed(rec("lagd", lambda: B.lag_msd(r, F - 1, [0, E], scale=1.0, ctx=ctx)), sync, 1)
+    finally:
+        ctx.set_option("lag_variant", -1)
+    lag_err = float(np.max(np.abs(lag[1:] - lagd[1:]) / lagd[1:]))
+    msd_last = s1[-1, 0, 3] / E / 1e-20
+    if abs(msd_last / (3 * 0.01 * (F - 1)) - 1.0) > 0.02:
+        raise AssertionError(msd_last)
+    # CPU: the single-origin loop on 200 frame pairs of all 50k entities; the lag x origin sum on 64 entities, 40 lags
+    nsub = 200
+    esub, lags = 64, np.linspace(1, F - 1, 40).astype(np.int32)
+    rsub = r[:, :, :esub].contiguous().cpu().numpy()
+    chk = cpu_check_c4(r[:nsub + 1].cpu().numpy(), rsub, lags, E, esub)
+    cpu_pair, cl, cpu_lag = chk["per_pair_s"], chk["lag"], chk["lag_s"]
+    np.testing.assert_allclose(s1[:nsub + 1, 0, :] / 1e-20, chk["single"][:, 0, :], rtol=1e-10)
+    fp_sub = float(np.sum(F - lags)) * esub
+    gl = B.lag_msd(rsub, F - 1, [0, esub], scale=1.0, ctx=ctx)
+    np.testing.assert_allclose(gl[lags, 0, :], cl[:, 0, :], rtol=1e-10)
+    fp_all = F * (F - 1) / 2
+    out = {"workload": "C4: 50k atoms x 5000 frames unwrapped random walk (6 GB resident), molecules 2500x16 + 2500x4",
+           "msd_single_origin": {
+               "wall_s": t_msd, "kernel_s": km["msd"][0] * 1e-3, "kernel": km["msd"][1], "value": F / t_msd,
+               "unit": "frame-pairs/s",
+               "roofline": {"bound": "hbm", "achieved": 24.0 * E * F / (km["msd"][0] * 1e-3) / 1e9,
+                            "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                            "frac": 24.0 * E * F / (km["msd"][0] * 1e-3) / HBM_PEAK, "traffic": None}},
+           "msd_fixed_lag_tao4": {
+               "wall_s": t_win, "kernel_s": km["win"][0] * 1e-3, "kernel": km["win"][1],
+               "roofline": {"bound": "hbm", "achieved": 24.0 * E * (F // 4 + 1) / (km["win"][0] * 1e-3) / 1e9,
+                            "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                            "frac": 24.0 * E * (F // 4 + 1) / (km["win"][0] * 1e-3) / HBM_PEAK, "traffic": None}},
+           "com": {
+               "wall_s": t_com, "kernel_s": km["com"][0] * 1e-3, "kernel": km["com"][1],
+               "roofline": {"bound": "hbm", "achieved": (24.0 * E + 24.0 * M) * F / (km["com"][0] * 1e-3) / 1e9,
+                            "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                            "frac": (24.0 * E + 24.0 * M) * F / (km["com"][0] * 1e-3) / HBM_PEAK, "traffic": None}},
+           "lag_msd": {
+               "wall_s": t_lag, "kernel_s": km["lag"][0] * 1e-3, "kernel": km["lag"][1], "frame_pairs": fp_all,
+               "value": fp_all / t_lag, "unit": "frame-pairs/s", "reported_rel_bound": bound,
+               "max_rel_diff_vs_difference_kernel": lag_err,
+               "roofline": {"bound": "hbm", "achieved": 24.0 * E * F / (km["lag"][0] * 1e-3) / 1e9,
+                            "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                            "frac": 24.0 * E * F / (km["lag"][0] * 1e-3) / HBM_PEAK, "traffic": None,
+                            "note": "autocorrelation-theorem path: compulsory traffic 24*E*F bytes; the transform "
+                                    "runs out of LDS, which is what binds it"}},
+           "lag_msd_difference_kernel": {
+               "wall_s": t_lagd, "kernel_s": km["lagd"][0] * 1e-3, "kernel": km["lagd"][1],
+               "value": fp_all / t_lagd, "unit": "frame-pairs/s",
+               "roofline": {"bound": "fp64-fma", "achieved": 12.0 * E * fp_all / (km["lagd"][0] * 1e-3) / 1e12,
+                            "peak": FP64_FMA_PEAK / 1e12, "unit": "TFLOP/s",
+                            "frac": 12.0 * E * fp_all / (km["lagd"][0] * 1e-3) / FP64_FMA_PEAK, "traffic": None}},
+           "parity_checked": "single origin: 201 frame pairs x 50k entities vs oracle (rtol 1e-10); full lag: 40 lags "
+                             "x 64 entities x 5000 frames vs oracle (rtol 1e-10); FFT path vs difference kernel above",
+           "cpu_baseline": {"value": 1.0 / cpu_pair, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
+                            "sample": "single origin: 201 of 5000 frame pairs, all 50k entities; full lag: 64 of 50k "
+                                      "entities x 40 of 4999 lags in %.2f s -> %.3g s extrapolated for all"
+                                      % (cpu_lag, cpu_lag / fp_sub * fp_all * E),
+                            "lag_msd_extrapolated_s": cpu_lag / fp_sub * fp_all * E}}
+    del r, com_d
+    torch.cuda.empty_cache()
+    return out
+
+
+def leg_c5(B, ctx, torch, device, synth, sync):
+    """BASELINE.json configs[4]: 1e6-sample pressure-tensor series x 3, Green-Kubo ACF by FFT and direct, integral."""
+    n = 1_000_000
+    ph = synth.ar1_series(n)
+    p = torch.from_numpy(ph).to(device)
+    km = {}
+
+    def rec(key, fn):
+        def run():
+            o = fn()
+            km[key] = (ctx.last_kernel_ms()[0], ctx.last_kernel_name())
+            return o
+        return run
+
+    t_fft, a_fft = timed(rec("fft", lambda: B.xcorr(p, method=B.XCORR_FFT, ctx=ctx)), sync, 3)
+    t_dir, a_dir = timed(rec("dir", lambda: B.xcorr(p, method=B.XCORR_DIRECT, ctx=ctx)), sync, 1)
+    t_int, _i = timed(rec("int", lambda: B.cumtrapz(a_fft, 1e-15, ctx=ctx)), sync, 3)
+    err_half = max(float(np.max(np.abs(a_fft[k][:n // 2] - a_dir[k][:n // 2]))) / float(a_dir[k][0]) for k in range(3))
+    if err_half > 1e-10:
+        raise AssertionError(err_half)
+    nl = 200
+    chk = cpu_check_c5(ph, nl)
+    ref, cpu_fft, cd, cpu_dir = chk["fft_last"], chk["fft_s"], chk["direct"], chk["per_pair_s"]
+    e_np = float(np.max(np.abs(ref[:n // 2] - a_fft[2][:n // 2]))) / float(ref[0])
+    np.testing.assert_allclose(a_dir[0][:nl], cd, rtol=0, atol=1e-10 * cd[0])
+    sp = 3 * n * (n + 1) / 2
+    fft_bytes = 3 * 2 * 16.0 * 2 * n * 3  # SURVEY.md 8d: 2 (r+w) x 16 B x 2n x 3 transforms per series pair
+    return {"workload": "C5: 3 series x 1e6 samples (AR(1) phi 0.99 x100), unbiased ACF k = 0..n-1",
+            "acf_fft": {"wall_s": t_fft, "kernel_s": km["fft"][0] * 1e-3, "kernel": km["fft"][1],
+                        "value": 3 * n / t_fft, "unit": "lags/s",
+                        "roofline": {"bound": "hbm", "achieved": fft_bytes / max(km["fft"][0], 1e-9) / 1e6,
+                                     "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                     "frac": fft_bytes / max(km["fft"][0] * 1e-3, 1e-12) / HBM_PEAK, "traffic": None}},
+            "acf_direct": {"wall_s": t_dir, "kernel_s": km["dir"][0] * 1e-3, "kernel": km["dir"][1],
+                           "value": sp / t_dir, "unit": "sample-pairs/s",
+                           "roofline": {"bound": "fp64-fma", "achieved": 2 * sp / (km["dir"][0] * 1e-3) / 1e12,
+                                        "peak": FP64_FMA_PEAK / 1e12, "unit": "TFLOP/s",
+                                        "frac": 2 * sp / (km["dir"][0] * 1e-3) / FP64_FMA_PEAK, "traffic": None}},
+            "cumtrapz": {"wall_s": t_int, "kernel_s": km["int"][0] * 1e-3},
+            "parity_checked": "FFT vs direct, first n/2 lags: %.1e acf[0]; FFT vs numpy FFT estimator %.1e acf[0]; "
+                              "direct vs oracle on %d lags (atol 1e-10 acf[0])" % (err_half, e_np, nl),
+            "cpu_baseline": {"value": 3 * n / cpu_fft, "unit": "lags/s", "cores": 1, "kind": "port",
+                             "sample": "numpy FFT estimator (viscosity.py:111-115) on all 3 x 1e6 samples: %.2f s; direct "
+                                       "estimator: %d of 1e6 lags of one series -> %.3g s extrapolated for all"
+                                       % (cpu_fft, nl, cpu_dir * sp),
+                             "direct_extrapolated_s": cpu_dir * sp}}
+
+
+# ------------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="headline only (profiling runs)")
+    ap.add_argument("--legs", default="parity,f64,h2d,c3,c4,c5")
     ap.add_argument("--cpu-frames", type=int, default=10)
     ap.add_argument("--variant", type=int, default=None, help="kernel variant knob (A/B only)")
+    ap.add_argument("--option", action="append", default=[], help="library option key=value (A/B only)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn(args)
 
     import torch
     import torch.distributed as dist
@@ -122,11 +568,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if rank == 0 and world == 1 and args.gpus > 1:
-            print("bench.py: --gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus),
-                  file=sys.stderr)
-            sys.exit(2)
+    if world != args.gpus and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the hot path has no CPU fallback", file=sys.stderr)
         sys.exit(1)
@@ -144,33 +587,46 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     from mdproptools_amd import backend as B
+    from mdproptools_amd import dist as D
     from mdproptools_amd import synth
     from mdproptools_amd._lib import default_context
 
     ctx = default_context(dev_index)
     if args.variant is not None:
         ctx.set_option("rdf_variant", args.variant)
+    for kv in args.option:
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
 
-    cfg = synth.rdf_config("C2")
-    n, F, L = cfg["n_atoms"], cfg["n_frames"], cfg["box_len"]
+    strong = args.scaling == "strong"
+    cfg = synth.rdf_config("C3" if strong else "C2")
+    n, L = cfg["n_atoms"], cfg["box_len"]
     nb = int(cfg["r_cut"] / cfg["bin_size"])
     types = synth.rdf_types(n)
     rel = np.array(synth.ALL_PAIRS_4, dtype=np.int32)
+    if strong:  # C3's frames split contiguously over the ranks
+        lo, hi = D.frame_shard(cfg["n_frames"], rank, world)
+        frame_ids = range(lo, hi)
+    else:       # every rank its own C2: weak scaling
+        frame_ids = range(rank * cfg["n_frames"], (rank + 1) * cfg["n_frames"])
+    F = len(frame_ids)
     box = np.full((F, 3), L)
-    frame_ids = range(rank * F, (rank + 1) * F)  # every rank its own frames: weak scaling
-    xyz = torch.from_numpy(synth.rdf_frames(n, frame_ids, L, cfg["seed_offset"])).to(device)
-    pairs_per_step = F * n * (n - 1) // 2
-
-    from mdproptools_amd import dist as D
-
-    def local_pass(x, t, b, rl, rc, dd, nbins):
-        return B.rdf_loop(x, t, b, rl, rc, dd, nbins, per_frame=False, ctx=ctx)
+    xyz = torch.empty((F, 3, n), dtype=torch.float64, device=device)
+    xyz_host = None
+    for f0 in range(0, F, 50):
+        blk = synth.rdf_frames(n, frame_ids[f0:f0 + 50], L, cfg["seed_offset"])
+        xyz[f0:f0 + 50] = torch.from_numpy(blk).to(device)
+        if not strong and world == 1:
+            xyz_host = blk if xyz_host is None else np.concatenate([xyz_host, blk])
+    pairs_per_frame = n * (n - 1) // 2
+    pairs_local = F * pairs_per_frame
+    pairs_job = (cfg["n_frames"] if strong else world * F) * pairs_per_frame
 
     def step():
         # N > 1: frame shards per rank, one RCCL all-reduce of the uint64 histograms per step
         # (mdproptools_amd/dist.py). The collective of step k is left in flight while step k+1 computes and is
         # waited for right after: every step's sums are complete inside the timed region.
-        return D.rdf_sharded_async(xyz, types, box, rel, cfg["r_cut"], cfg["bin_size"], nb, compute=local_pass)
+        return D.rdf_sharded_async(xyz, types, box, rel, cfg["r_cut"], cfg["bin_size"], nb, ctx=ctx)
 
     def fence():
         torch.cuda.synchronize()
@@ -196,6 +652,7 @@ def main():
     full, part, _ov = pending.wait()
     fence()
     elapsed = time.perf_counter() - t0
+    kernel_name = ctx.last_kernel_name()
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -203,85 +660,76 @@ def main():
 
     # sanity inside the bench: the result of the last step is a real histogram of the right size
     expect_in = 4.0 / 3.0 * np.pi * cfg["r_cut"] ** 3 / L ** 3
-    frac_in = float(full.sum()) / 2.0 / (world * pairs_per_step)
+    frac_in = float(full.sum()) / 2.0 / pairs_job
     assert abs(frac_in - expect_in) < 0.01 * expect_in, (frac_in, expect_in)
 
     if rank == 0:
-        value = world * pairs_per_step * args.steps / elapsed
+        value = pairs_job * args.steps / elapsed
         kdur = kernel_ms / max(launches, 1) * 1e-3  # average duration of one pair_hist launch
-        alg_ops = pairs_per_step * OPS_PER_PAIR
+        wl = ("C3: 100k atoms x 1000 frames split over %d GPU(s), cubic L=104 A" % world) if strong else \
+             "C2: 10k atoms x 200 frames per GPU, cubic L=50 A"
         out = {
             "metric": "atom-pairs/s", "value": value, "unit": "atom-pairs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32/f64",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32/f64",
             "data": "synthetic",
-            "config": {"workload": "C2: 10k atoms x 200 frames per GPU, cubic L=50 A, 4 types, 10 type-pair "
-                                   "relations, r_cut 20 A, 400 bins, frame-summed uint64 histograms"
-                                   + (", RCCL all-reduce per step" if world > 1 else ""),
-                       "pairs_per_step_per_gpu": pairs_per_step, "kernel_variant": ctx_variant(ctx, args)},
-            "roofline": {
-                "bound": "fp64-valu",
-                "note": "neither hbm nor mfma bounds this kernel: 28 B and 18 unfused FP64 ops per atom pair the "
-                        "reference evaluates (SURVEY.md 8d); peak = 256 CU x 128 lanes x 2.4 GHz / 2; the hbm view is "
-                        "given beside it. achieved counts ALGORITHMIC ops: the sweep culls ~15 % of the pairs "
-                        "spatially and classifies the rest with packed f32 arithmetic (two pairs per VALU slot; the "
-                        "~0.2 % of pairs inside the error band of a bin edge are resolved by the exact f64 chain, so "
-                        "the integers are the reference's), hence frac > 1 against the unfused-FP64 roof. What binds "
-                        "is VALU issue: see valu_issue (instruction count from profiles/r01_pmc_summary.txt)",
-                "kernel": ctx.last_kernel_name(),
-                "launch_ms": kdur * 1e3, "prepass_ms_per_step": aux_ms / args.steps,
-                "achieved": alg_ops / kdur / 1e12, "peak": FP64_NONFUSED_PEAK / 1e12, "unit": "TFLOP/s",
-                "frac": alg_ops / kdur / FP64_NONFUSED_PEAK,
-                "hbm": {"achieved": 28.0 * n * F / kdur / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                        "frac": 28.0 * n * F / kdur / HBM_PEAK},
-                "traffic": load_traffic(),
-                "valu_issue": valu_issue(kdur),
-            },
+            "config": {"workload": wl + ", 4 types, 10 type-pair relations, r_cut 20 A, 400 bins, frame-summed uint64 "
+                                      "histograms" + (", %s all-reduce per step" % ("RCCL" if backend == "nccl" else backend) if world > 1 else ""),
+                       "pairs_per_step": pairs_job, "frames_per_gpu": F, "kernel": kernel_name,
+                       "arithmetic": "packed-f32 classification, every pair within the error band of a bin edge or "
+                                     "of the cutoff resolved by the reference's f64 chain (integers identical to the "
+                                     "all-f64 sweep: see f64_only)" if "<3" in kernel_name or "<4" in kernel_name
+                                     or "<5" in kernel_name or "<6" in kernel_name else "f64"},
+            "roofline": valu_roofline(kernel_name, "C3" if strong else "C2", kdur, "mix bin 11/16", 6,
+                                      pairs_local, 28.0 * n * F),
         }
-        try:
-            out["msd"] = msd_leg(B, torch, device, max(3, args.steps // 4))
-        except Exception as e:  # the MSD leg is informative; the RDF line must still be printed
-            out["msd"] = {"error": repr(e)}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, types, rel, args.cpu_frames)
+        out["roofline"]["prepass_ms_per_step"] = aux_ms / args.steps
+        legs = [] if (args.no_legs or world > 1 or strong) else args.legs.split(",")
+        sync = torch.cuda.synchronize
+        oracle_frames = []
+        if world == 1 and not strong and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, types, rel, nb, args.cpu_frames)
             try:
-                out["cpu_baseline"]["all_cores"] = cpu_baseline_all_cores(cfg, types, rel)
+                rep, oracle_frames = cpu_baseline_all_cores(cfg, types, rel, nb)
+                out["cpu_baseline"]["all_cores"] = rep
             except Exception as e:  # informative only
                 out["cpu_baseline"]["all_cores"] = {"error": repr(e)}
+
+        def run_leg(key, fn):
+            try:
+                out[key] = fn()
+            except Exception as e:  # a leg must not lose the headline line; its failure is part of the record
+                out[key] = {"error": repr(e)}
+
+        if "parity" in legs:
+            if not oracle_frames:
+                oracle_frames = [cpu_check_frame(xyz_host[0], types, rel, L, cfg, nb)]
+            try:
+                out["parity"] = leg_parity(B, ctx, xyz, types, box, rel, cfg, nb, full, part, oracle_frames)
+                out["parity_checked"] = True
+            except Exception as e:
+                out["parity"] = {"error": repr(e)}
+                out["parity_checked"] = False
+                print(json.dumps(out))
+                sys.exit(4)  # a fast kernel whose results differ from the reference's is not done
+        if "f64" in legs:
+            run_leg("f64_only", lambda: leg_f64_only(B, ctx, xyz, types, box, rel, cfg, nb, max(5, args.steps // 2),
+                                                     pairs_local, full, sync))
+        if "h2d" in legs:
+            run_leg("h2d_inclusive", lambda: leg_h2d(B, ctx, torch, xyz_host, types, box, rel, cfg, nb,
+                                                     max(5, args.steps // 2), pairs_local, sync))
+        del xyz
+        torch.cuda.empty_cache()
+        if "c3" in legs:
+            run_leg("c3", lambda: leg_c3(B, ctx, torch, device, synth, sync))
+        if "c4" in legs:
+            run_leg("c4", lambda: leg_c4(B, ctx, torch, device, synth, sync))
+        if "c5" in legs:
+            run_leg("c5", lambda: leg_c5(B, ctx, torch, device, synth, sync))
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-
-
-def ctx_variant(ctx, args):
-    """Kernel variant in use: the library default is 1 (fast kernel); --variant overrides it for A/B runs."""
-    return int(os.environ.get("MDHIP_RDF_VARIANT", "1")) if args.variant is None else int(args.variant)
-
-
-def valu_issue(kdur):
-    """VALU issue-slot view of the pair kernel: wave-instructions per launch (a constant of this workload, from the
-    committed rocprofv3 --pmc run, profiles/rdf_traffic.json) over the live launch duration, against one VALU
-    instruction per SIMD every 4 cycles (256 CU x 4 SIMD x 2.4 GHz / 4)."""
-    p = os.path.join(HERE, "profiles", "rdf_traffic.json")
-    try:
-        insts = float(json.load(open(p))["valu_wave_instructions_per_launch"])
-    except Exception:
-        return None
-    peak = 256 * 4 * 2.4e9 / 4
-    return {"achieved": insts / kdur / 1e9, "peak": peak / 1e9, "unit": "G wave-instructions/s",
-            "frac": insts / kdur / peak}
-
-
-def load_traffic():
-    """HBM bytes per launch from a committed rocprofv3 --pmc run of this same command (profiles/), or None."""
-    p = os.path.join(HERE, "profiles", "rdf_traffic.json")
-    if os.path.exists(p):
-        try:
-            return json.load(open(p)).get("hbm_bytes_per_launch")
-        except Exception:
-            return None
-    return None
 
 
 if __name__ == "__main__":

@@ -79,9 +79,10 @@ int mdhip_device_name(mdhip_ctx *ctx, char *buf, int buflen);
  *   "rdf_sort"     spatial sort: -1 auto, 1 one block per frame (LDS counters), 0 multi-block (global counters)
  *   "rdf_inflight" per-frame output: frames in flight per XCD
  *   "rdf_jsplit", "rdf_fpb", "rdf_batch", "rdf_slots"  launch geometry of the pair kernels
- *   "lag_variant"  full-lag MSD: 1 series-resident kernel (default), 0 staged kernel; 2 = autocorrelation
- *                  theorem through batched FFTs (O(F log F); the one knob that changes results, within the
- *                  bound mdhip_last_rel_bound reports), 3 = 2 when that bound is <= 1e-10, else 1
+ *   "lag_variant"  full-lag MSD: 3 / -1 (default) = autocorrelation theorem (O(F log F)) when the relative error
+ *                  bound it computes for the data (mdhip_last_rel_bound) is <= 1e-10, else the exact-difference
+ *                  kernel; 1 = always the series-resident difference kernel, 0 = staged difference kernel,
+ *                  2 = always the autocorrelation theorem (the one knob that changes results, within that bound)
  *   "xcorr_tile"   time slabs of the direct correlation kernel */
 int mdhip_set_option(mdhip_ctx *ctx, const char *key, int value);
 
@@ -128,6 +129,18 @@ int mdhip_rdf_atomic(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const do
                      const double *box, int n_rel, const int32_t *rel, double r_cut_sq,
                      double bin_size, int nbins, const double *edges, int per_frame,
                      uint64_t *hist_full, uint64_t *hist_part, uint64_t *overflow);
+
+/*
+ * The frame-summed form of mdhip_rdf_atomic (per_frame = 0) with the sums left ON THE DEVICE, for the multi-GPU
+ * path: frames shard over one process per GPU and the (1 + n_rel) * nbins + 1 words are all-reduced over RCCL
+ * straight from this buffer (mdproptools_amd/dist.py), no host round trip.
+ *   out_dev    DEVICE uint64 [(1 + n_rel) * nbins + 1] = hist_full | hist_part | overflow (overwritten)
+ * Complete (stream synchronised) on return, like every other call.
+ */
+int mdhip_rdf_atomic_dev(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *xyz, int on_device,
+                         const int32_t *type, int64_t type_frame_stride, const double *box, int n_rel,
+                         const int32_t *rel, double r_cut_sq, double bin_size, int nbins, const double *edges,
+                         uint64_t *out_dev);
 
 /* ---- R4: _cn_loop --------------------------------------------------------- */
 /*
@@ -205,6 +218,10 @@ int mdhip_msd_windows(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const dou
  * Superset (not in the reference): full lag average
  *   msd[lag][g][c] = mean over t0 in [0, n_frames-lag) and entities of group g of the squared
  *   displacement, c = x, y, z, total; lag = 0..max_lag.   out host [max_lag+1][n_groups][4]
+ * Tolerance: rtol 1e-10 against the plain double sum. The default evaluates S1(k) - 2 S2(k) with S2 from the power
+ * spectrum (O(F log F)) whenever the rounding bound it computes for the data is <= 1e-10 relative to the MSD
+ * (mdhip_last_rel_bound reports it); otherwise — e.g. coordinates far from the origin against a small displacement —
+ * the difference kernel sums (r(t0+k) - r(t0))^2 directly.
  */
 int mdhip_lag_msd(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r, int on_device,
                   double scale, int max_lag, int n_groups, const int64_t *group_off, double *out);
@@ -233,6 +250,14 @@ int mdhip_charge_flux(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const d
  */
 int mdhip_xcorr(mdhip_ctx *ctx, int64_t n, int n_pairs, const double *a, const double *b,
                 int on_device, int method, int64_t n_lags, double *out);
+
+/*
+ * The lags lag_begin .. lag_begin + n_lags - 1 only (out host [n_pairs][n_lags]): the unit of the multi-GPU split of
+ * the direct estimator, whose cost per lag k is n - k products — every GPU owns a lag range and needs the whole
+ * series (mdproptools_amd/dist.py: xcorr_direct_sharded). Direct method only unless lag_begin == 0.
+ */
+int mdhip_xcorr_lags(mdhip_ctx *ctx, int64_t n, int n_pairs, const double *a, const double *b, int on_device,
+                     int method, int64_t lag_begin, int64_t n_lags, double *out);
 
 /* ---- G4: cumulative trapezoid ---------------------------------------------- */
 /*

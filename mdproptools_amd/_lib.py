@@ -41,6 +41,8 @@ PROTOTYPES = {
     "mdhip_pk_error_bound": (C.c_double, [C.c_double, C.c_double, C.c_int, C.c_int, C.c_double, C.c_double]),
     "mdhip_rdf_atomic": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, c_ip, C.c_int64, c_dp, C.c_int,
                                    c_ip, C.c_double, C.c_double, C.c_int, c_dp, C.c_int, c_up, c_up, c_up]),
+    "mdhip_rdf_atomic_dev": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, c_ip, C.c_int64, c_dp, C.c_int,
+                                       c_ip, C.c_double, C.c_double, C.c_int, c_dp, vp]),
     "mdhip_cn_atomic": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, c_ip, C.c_int64, c_dp, C.c_int,
                                   c_ip, c_dp, C.c_int, c_up]),
     "mdhip_rdf_sites": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, c_ip, C.c_int64, vp, C.c_int, c_ip,
@@ -58,6 +60,7 @@ PROTOTYPES = {
     "mdhip_charge_flux": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, c_dp, c_dp, C.c_int64, c_lp, c_ip,
                                     C.c_int, C.c_double, C.c_double, c_dp]),
     "mdhip_xcorr": (C.c_int, [vp, C.c_int64, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int64, c_dp]),
+    "mdhip_xcorr_lags": (C.c_int, [vp, C.c_int64, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int64, C.c_int64, c_dp]),
     "mdhip_cumtrapz": (C.c_int, [vp, C.c_int64, C.c_int, vp, C.c_int, C.c_double, C.c_int, c_dp]),
     "mdhip_shell_residence": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, C.c_int64, vp, C.c_int, c_dp,
                                         C.c_double, C.c_double, C.c_int, c_up, c_up]),
@@ -137,14 +140,19 @@ class DevPtr:
         self.keepalive = keepalive
 
 
-def as_input(a):
-    """-> (void pointer, on_device flag, keepalive) for a host ndarray, a torch tensor or a DevPtr."""
+def as_input(a, ctx=None):
+    """-> (void pointer, on_device flag, keepalive) for a host ndarray, a torch tensor or a DevPtr.
+    With `ctx`, a CUDA tensor that lives on another device than the context's is refused (its pointer would be
+    dereferenced on the wrong GPU)."""
     if isinstance(a, DevPtr):
         return vp(a.address), 1, a
     if hasattr(a, "data_ptr") and hasattr(a, "is_cuda"):  # torch tensor without importing torch here
         if not a.is_contiguous() or str(a.dtype) != "torch.float64":
             raise ValueError("device tensors must be contiguous float64")
         if a.is_cuda:
+            if ctx is not None and a.device.index is not None and a.device.index != ctx.device:
+                raise ValueError("tensor lives on cuda:%d but the mdhip context is bound to device %d"
+                                 % (a.device.index, ctx.device))
             # the context launches on its own non-blocking stream: whatever torch still has queued to produce
             # this tensor must have finished first
             import torch
@@ -217,6 +225,14 @@ def default_context(device=None):
     """Process-wide context for `device` (default: LOCAL_RANK or 0)."""
     if device is None:
         device = int(os.environ.get("LOCAL_RANK", "0"))
+        try:  # more ranks than GPUs (several ranks sharing a card): wrap around instead of "device out of range"
+            import torch
+
+            n_dev = torch.cuda.device_count()
+            if n_dev > 0:
+                device %= n_dev
+        except Exception:
+            pass
     ctx = _default.get(device)
     if ctx is None or ctx.h is None:
         ctx = _default[device] = Context(device)

@@ -57,7 +57,7 @@ def rdf_loop(xyz, types, box, relation_matrix, r_cut, ddr, nbins, per_frame=True
     """
     ctx = ctx or default_context()
     F, _, N = _shape3(xyz, "xyz")
-    xp, on_dev, keep = as_input(xyz)
+    xp, on_dev, keep = as_input(xyz, ctx)
     ty = _i32(types)
     stride = 0 if ty.ndim == 1 else N
     if ty.size != (N if stride == 0 else F * N):
@@ -77,11 +77,36 @@ def rdf_loop(xyz, types, box, relation_matrix, r_cut, ddr, nbins, per_frame=True
     return full, part, int(ov.value)
 
 
+def rdf_loop_dev(xyz, types, box, relation_matrix, r_cut, ddr, nbins, out, ctx=None):
+    """
+    Frame-summed `_rdf_loop` with the sums left on the device: `out` = contiguous int64 CUDA tensor of
+    (1 + R) * nbins + 1 words (rdf_full | rdf_part | overflow; the bit patterns are the uint64 counts), overwritten.
+    Used by the multi-GPU layer so that the all-reduce reads the buffer the kernels wrote.
+    """
+    ctx = ctx or default_context()
+    F, _, N = _shape3(xyz, "xyz")
+    xp, on_dev, keep = as_input(xyz, ctx)
+    ty = _i32(types)
+    stride = 0 if ty.ndim == 1 else N
+    if ty.size != (N if stride == 0 else F * N):
+        raise ValueError("types must have shape [N] or [F, N]")
+    bx = _f64(box).reshape(F, 3)
+    rel = _i32(relation_matrix).reshape(-1, 2)
+    words = (1 + len(rel)) * int(nbins) + 1
+    if not (getattr(out, "is_cuda", False) and out.is_contiguous() and str(out.dtype) == "torch.int64"
+            and out.numel() == words):
+        raise ValueError("out must be a contiguous int64 CUDA tensor of %d words" % words)
+    ctx.check(ctx.lib.mdhip_rdf_atomic_dev(
+        ctx.h, F, N, xp, on_dev, ptr(ty, C.c_int32), stride, ptr(bx), len(rel), ptr(rel, C.c_int32),
+        cutoff_sq(r_cut), float(ddr), int(nbins), None, C.c_void_p(out.data_ptr())))
+    return out
+
+
 def cn_loop(xyz, types, box, relation_matrix, r_cut_list, per_frame=True, ctx=None):
     """`_cn_loop` (rdf_cn.py:100-119): raw counts uint64 [F,R] (or [R])."""
     ctx = ctx or default_context()
     F, _, N = _shape3(xyz, "xyz")
-    xp, on_dev, keep = as_input(xyz)
+    xp, on_dev, keep = as_input(xyz, ctx)
     ty = _i32(types)
     stride = 0 if ty.ndim == 1 else N
     bx = _f64(box).reshape(F, 3)
@@ -104,8 +129,8 @@ def rdf_mol_loop(xyz, types, sites, site_types, box, relation_matrix, r_cut, ddr
     F2, _, M = _shape3(sites, "sites")
     if F2 != F:
         raise ValueError("xyz and sites must have the same number of frames")
-    xp, x_dev, k1 = as_input(xyz)
-    sp, s_dev, k2 = as_input(sites)
+    xp, x_dev, k1 = as_input(xyz, ctx)
+    sp, s_dev, k2 = as_input(sites, ctx)
     ty, st = _i32(types), _i32(site_types)
     bx = _f64(box).reshape(F, 3)
     rel = _i32(relation_matrix).reshape(-1, 2)
@@ -123,8 +148,8 @@ def cn_mol_loop(xyz, types, sites, site_types, box, relation_matrix, r_cut_list,
     ctx = ctx or default_context()
     F, _, N = _shape3(xyz, "xyz")
     _, _, M = _shape3(sites, "sites")
-    xp, x_dev, k1 = as_input(xyz)
-    sp, s_dev, k2 = as_input(sites)
+    xp, x_dev, k1 = as_input(xyz, ctx)
+    sp, s_dev, k2 = as_input(sites, ctx)
     ty, st = _i32(types), _i32(site_types)
     bx = _f64(box).reshape(F, 3)
     rel = _i32(relation_matrix).reshape(-1, 2)
@@ -147,7 +172,7 @@ def segment_com(attr, atom_mass, seg_off, atom_q=None, out=None, ctx=None):
     if len(shp) != 3:
         raise ValueError("attr must have shape [n_frames, n_attr, n_atoms]")
     F, K, N = shp
-    ap, a_dev, keep = as_input(attr)
+    ap, a_dev, keep = as_input(attr, ctx)
     m = _f64(atom_mass)
     off = _i64(seg_off)
     M = len(off) - 1
@@ -159,7 +184,7 @@ def segment_com(attr, atom_mass, seg_off, atom_q=None, out=None, ctx=None):
         op, o_dev = C.c_void_p(res.ctypes.data), 0
     else:
         res = out
-        op, o_dev, _k = as_input(out)
+        op, o_dev, _k = as_input(out, ctx)
     ctx.check(ctx.lib.mdhip_segment_com(
         ctx.h, F, N, K, ap, a_dev, ptr(m), None if q is None else ptr(q), M, ptr(off, C.c_int64), op,
         o_dev, ptr(seg_mass), None if seg_q is None else ptr(seg_q)))
@@ -173,7 +198,7 @@ def msd_pairs(r, pairs, group_off, scale=1.0, per_entity=False, ctx=None):
     """
     ctx = ctx or default_context()
     F, _, E = _shape3(r, "r")
-    rp, on_dev, keep = as_input(r)
+    rp, on_dev, keep = as_input(r, ctx)
     pr = _i32(pairs).reshape(-1, 2)
     go = _i64(group_off)
     G = len(go) - 1
@@ -189,7 +214,7 @@ def msd_windows(r, tao, scale=1.0, ctx=None):
     """Fixed-lag window sums per entity (diffusion.py:225-237): r [F,3,E] -> [E,4]."""
     ctx = ctx or default_context()
     F, _, E = _shape3(r, "r")
-    rp, on_dev, keep = as_input(r)
+    rp, on_dev, keep = as_input(r, ctx)
     out = np.zeros((E, 4))
     ctx.check(ctx.lib.mdhip_msd_windows(ctx.h, F, E, rp, on_dev, float(scale), int(tao), ptr(out)))
     return out
@@ -199,7 +224,7 @@ def lag_msd(r, max_lag, group_off, scale=1.0, ctx=None):
     """Full lag average (superset): r [F,3,E] -> [max_lag+1, G, 4]."""
     ctx = ctx or default_context()
     F, _, E = _shape3(r, "r")
-    rp, on_dev, keep = as_input(r)
+    rp, on_dev, keep = as_input(r, ctx)
     go = _i64(group_off)
     G = len(go) - 1
     out = np.zeros((int(max_lag) + 1, G, 4))
@@ -212,7 +237,7 @@ def charge_flux(vel, atom_mass, atom_q, seg_off, seg_type, n_types, vel_conv, ch
     """`conductivity_loop` for every frame (_conductivity.py:11-35): vel [F,3,N] -> j [3,T,F]."""
     ctx = ctx or default_context()
     F, _, N = _shape3(vel, "vel")
-    vp_, on_dev, keep = as_input(vel)
+    vp_, on_dev, keep = as_input(vel, ctx)
     m, q = _f64(atom_mass), _f64(atom_q)
     off = _i64(seg_off)
     st = _i32(seg_type)
@@ -223,25 +248,26 @@ def charge_flux(vel, atom_mass, atom_q, seg_off, seg_type, n_types, vel_conv, ch
     return out
 
 
-def xcorr(a, b=None, method=XCORR_FFT, n_lags=None, ctx=None):
+def xcorr(a, b=None, method=XCORR_FFT, n_lags=None, ctx=None, lag_begin=0):
     """
     c[p][k] = sum_t a_p[t+k] b_p[t] / (n-k) (conductivity.py:109-114, viscosity.py:103-115).
-    a, b: [n] or [P,n]; b=None gives the autocorrelation.
+    a, b: [n] or [P,n]; b=None gives the autocorrelation. lag_begin > 0 (direct method): the lags
+    lag_begin .. lag_begin + n_lags - 1 only.
     """
     ctx = ctx or default_context()
     single = len(a.shape) == 1
-    ap, a_dev, k1 = as_input(a)
+    ap, a_dev, k1 = as_input(a, ctx)
     shp = tuple(a.shape)
     P, n = (1, shp[0]) if single else shp
     if b is None:
         bp, b_dev = ap, a_dev
     else:
-        bp, b_dev, k2 = as_input(b)
+        bp, b_dev, k2 = as_input(b, ctx)
         if b_dev != a_dev:
             raise ValueError("a and b must both be host arrays or both device tensors")
-    n_lags = n if n_lags is None else int(n_lags)
+    n_lags = n - int(lag_begin) if n_lags is None else int(n_lags)
     out = np.zeros((P, n_lags))
-    ctx.check(ctx.lib.mdhip_xcorr(ctx.h, n, P, ap, bp, a_dev, int(method), n_lags, ptr(out)))
+    ctx.check(ctx.lib.mdhip_xcorr_lags(ctx.h, n, P, ap, bp, a_dev, int(method), int(lag_begin), n_lags, ptr(out)))
     return out[0] if single else out
 
 
@@ -249,7 +275,7 @@ def cumtrapz(y, dx, leading_zero=False, ctx=None):
     """Cumulative trapezoid (viscosity.py:151, conductivity.py:231): y [n] or [S,n]."""
     ctx = ctx or default_context()
     single = len(y.shape) == 1
-    yp, on_dev, keep = as_input(y)
+    yp, on_dev, keep = as_input(y, ctx)
     shp = tuple(y.shape)
     S, n = (1, shp[0]) if single else shp
     m = n - 1 + (1 if leading_zero else 0)
@@ -272,8 +298,8 @@ def shell_residence(xyz_i, xyz_j, box, r_lo_sq, r_hi_sq, exclude_diagonal=False,
     F2, _, Nj = _shape3(xyz_j, "xyz_j")
     if F2 != F:
         raise ValueError("xyz_i and xyz_j must have the same number of frames")
-    ip, i_dev, k1 = as_input(xyz_i)
-    jp, j_dev, k2 = as_input(xyz_j)
+    ip, i_dev, k1 = as_input(xyz_i, ctx)
+    jp, j_dev, k2 = as_input(xyz_j, ctx)
     bx = _f64(box).reshape(F, 3)
     counts = np.zeros(F, dtype=np.uint64)
     nrec = C.c_uint64(0)

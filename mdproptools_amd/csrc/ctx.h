@@ -93,9 +93,10 @@ struct mdhip_ctx {
                               // deferred resolver (MODE 3) when its error bound allows, 0 the all-f64 sweep (MODE 2)
     int opt_rdf_sort = -1;    // spatial sort: -1 auto, 1 one block per frame (LDS counters), 0 multi-block (global counters)
     int opt_xcorr_tile = 0;
-    int opt_lag_variant = 1;  // full-lag MSD: 1 = series-resident LDS kernel when it fits, 0 = staged kernel,
-                              // 2 = autocorrelation theorem (batched FFT, msd_fft.hip), 3 = 2 when its error
-                              // bound stays below 1e-10, else 1
+    int opt_lag_variant = 3;  // full-lag MSD: 3 (default) = autocorrelation theorem (msd_fft.hip) when its error bound
+                              // stays below 1e-10, else the exact-difference kernel; 1 = series-resident LDS
+                              // difference kernel when it fits, 0 = staged difference kernel, 2 = always the
+                              // autocorrelation theorem, 4 = 2 through batched hipFFT
     double last_rel_bound = 0.0;  // error bound reported by the FFT MSD path of the last mdhip_lag_msd call (0: exact path)
 };
 

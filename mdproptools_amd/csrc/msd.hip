@@ -513,6 +513,7 @@ int mdhip_msd_pairs(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const doubl
     }
     MD_HIP(hipStreamSynchronize(ctx->stream));  // host tables are stack/vector memory
     KernelTimer timer(ctx);
+    ctx->last_kernel = "msd_pairs_kernel";
     // 16-byte loads need 16-byte aligned planes and even chunk starts
     bool vec2 = (n_ent % 2 == 0) && ((reinterpret_cast<uintptr_t>(d_r) & 15) == 0);
     for (const Chunk &c : chunks) vec2 = vec2 && (c.e0 % 2 == 0);
@@ -564,6 +565,7 @@ int mdhip_msd_windows(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const dou
     if (n_slabs < 1) n_slabs = 1;
     MD_WS(d_part, double, WS_PART, (size_t)n_slabs * n_ent * 4 * 8);
     KernelTimer timer(ctx);
+    ctx->last_kernel = "msd_windows_kernel";
     hipLaunchKernelGGL(msd_windows_kernel, dim3((unsigned)n_blocks_e, (unsigned)n_slabs), dim3(256), 0,
                        ctx->stream, d_r, (long long)n_ent, n_kept, scale, tao, (int)n_slabs, d_part);
     hipLaunchKernelGGL(msd_windows_sum_kernel, dim3((unsigned)((n_ent * 4 + 255) / 256)), dim3(256), 0,

@@ -46,7 +46,7 @@ struct PairProblem {
     const double *h_box;        // host   [F][3]
     bool tri;
     int n_ti, n_tj;
-    std::vector<unsigned char> cls;  // [n_ti][n_tj] -> class id (< n_cls)
+    std::vector<int> cls;  // [n_ti][n_tj] -> class id (< n_cls; any number of classes: the device sees pass-local bytes)
     int n_cls;
     int nbins;
     const double *edges;  // host [nbins+1]
@@ -54,6 +54,13 @@ struct PairProblem {
     float gscale;
     double bin_size;  // RDF: the reference's bin_size (0 for CN edge tables)
     int per_frame;
+    // frame-summed RDF outputs kept on the device (mdhip_rdf_atomic_dev): full | part | overflow, accumulated by
+    // derive_rdf_kernel straight from the row sums when the batch runs as one scalar-j pass; otherwise the batch
+    // comes back as host class histograms like every other call and the caller adds them in
+    unsigned long long *dev_out = nullptr;
+    int n_rel = 0;
+    const int *rel_cls = nullptr;   // host [n_rel]
+    const int *rel_mult = nullptr;  // host [n_rel]
 };
 
 // Runs the kernel over one batch of frames (in several passes when the class rows do not fit LDS) and
@@ -217,7 +224,7 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
             const int nc = (p.n_cls - c0) < cls_per_pass ? (p.n_cls - c0) : cls_per_pass;
             unsigned char *t = h_tab + edges_b + (size_t)pass * cls_b;
             for (size_t k = 0; k < (size_t)p.n_ti * p.n_tj; ++k) {
-                const int c = p.cls[k];
+                const int c = p.cls[k];  // (pass-local ids are < 250: they fit the byte, 0xFF = other pass)
                 t[k] = (c >= c0 && c < c0 + nc) ? (unsigned char)(c - c0) : 0xFF;
             }
         }
@@ -410,6 +417,36 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         timer.stop();
         MD_HIP(hipGetLastError());
 
+        if (sj && p.dev_out && n_pass == 1 && !p.per_frame) {
+            // outputs stay on the device: rows -> full | part | overflow by derive_rdf_kernel (added to dev_out)
+            const size_t tb = ((size_t)sj_rows + 2 * (size_t)p.n_rel) * 4;
+            MD_PIN(h_map, int, PIN_OUT, tb + 16);
+            for (int r = 0; r < sj_rows; ++r) h_map[r] = ordered ? p.cls[r] : (r < nc ? c0 + r : -1);
+            for (int kl = 0; kl < p.n_rel; ++kl) {
+                h_map[sj_rows + kl] = p.rel_cls[kl];
+                h_map[sj_rows + p.n_rel + kl] = p.rel_mult[kl];
+            }
+            MD_WS(d_map, int, WS_AUX3, tb);
+            MD_HIP(hipMemcpyAsync(d_map, h_map, tb, hipMemcpyHostToDevice, ctx->stream));
+            launch_derive_rdf(ctx->stream, d_rows, sj_rows, p.nbins, d_map, p.n_rel, d_map + sj_rows,
+                              d_map + sj_rows + p.n_rel, p.dev_out);
+            MD_HIP(hipGetLastError());
+            uint64_t *hlost = reinterpret_cast<uint64_t *>(reinterpret_cast<unsigned char *>(h_map) + ((tb + 7) & ~size_t(7)));
+            MD_HIP(hipMemcpyAsync(hlost, d_misc + 1, 16, hipMemcpyDeviceToHost, ctx->stream));
+            MD_HIP(hipStreamSynchronize(ctx->stream));
+            if (hlost[0] || hlost[1])
+                return mdhip_fail(ctx, MDHIP_EHIP, "pair_hist: internal check failed (%llu deferred pairs lost, work loop %llu)",
+                                  (unsigned long long)hlost[0], (unsigned long long)hlost[1]);
+            timer.collect();
+            total_ms += ctx->last_ms;
+            ++launches;
+            if (prep_timed) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, ctx->ev2, ctx->ev3) == hipSuccess) prep_ms = ms;
+                prep_timed = false;
+            }
+            continue;
+        }
         if (sj) {
             // D2H of the row sums (pinned staging), then rows -> classes and the overflow words on the host
             MD_PIN(hrows, uint64_t, PIN_OUT, (out_frames * (size_t)sj_words + 2) * 8);
@@ -589,7 +626,7 @@ int merge_unnamed_labels(std::vector<int32_t> &uniq, std::vector<int32_t> &idx, 
 // ui / uj hold the labels that have an index of their own (0 .. size-1); n_ti / n_tj may be one larger: the
 // index shared by all labels no relation names (merge_unnamed_labels).
 void build_classes(bool tri, const std::vector<int32_t> &ui, const std::vector<int32_t> &uj, int n_ti, int n_tj,
-                   int n_rel, const int32_t *rel, std::vector<unsigned char> &cls, std::vector<int> &rel_cls,
+                   int n_rel, const int32_t *rel, std::vector<int> &cls, std::vector<int> &rel_cls,
                    int &n_cls)
 {
     std::vector<int> map((size_t)n_ti * n_tj, -1);
@@ -608,7 +645,7 @@ void build_classes(bool tri, const std::vector<int32_t> &ui, const std::vector<i
     }
     n_cls = next + 1;
     cls.resize((size_t)n_ti * n_tj);
-    for (size_t k = 0; k < cls.size(); ++k) cls[k] = (unsigned char)(map[k] < 0 ? next : map[k]);
+    for (size_t k = 0; k < cls.size(); ++k) cls[k] = map[k] < 0 ? next : map[k];
 }
 
 struct RelJob {
@@ -628,6 +665,7 @@ struct RelJob {
     float gscale;
     double bin_size;
     int per_frame;
+    unsigned long long *dev_out = nullptr;  // see PairProblem::dev_out
 };
 
 // Stages everything, runs the kernel and returns class histograms + the relation->class map.
@@ -648,6 +686,14 @@ int run_job(mdhip_ctx *ctx, const RelJob &j, std::vector<uint64_t> &H, std::vect
     p.tri = j.tri;
     build_classes(j.tri, ui, ujr, n_ti, n_tj, j.n_rel, j.rel, p.cls, rel_cls, n_cls);
     p.n_cls = n_cls;
+    std::vector<int> rel_mult(j.n_rel, 1);
+    if (j.dev_out) {
+        for (int kl = 0; kl < j.n_rel; ++kl) rel_mult[kl] = (j.tri && j.rel[2 * kl] == j.rel[2 * kl + 1]) ? 2 : 1;
+        p.dev_out = j.dev_out;
+        p.n_rel = j.n_rel;
+        p.rel_cls = rel_cls.data();
+        p.rel_mult = rel_mult.data();
+    }
     p.n_ti = n_ti;
     p.n_tj = n_tj;
 
@@ -793,6 +839,75 @@ int mdhip_rdf_atomic(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const do
             const uint64_t *row = Hf + (size_t)rel_cls[kl] * nbins;
             for (int b = 0; b < nbins; ++b) part[b] = mult * row[b];
         }
+    }
+    return MDHIP_OK;
+}
+
+int mdhip_rdf_atomic_dev(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *xyz, int on_device,
+                         const int32_t *type, int64_t type_frame_stride, const double *box, int n_rel,
+                         const int32_t *rel, double r_cut_sq, double bin_size, int nbins, const double *edges,
+                         uint64_t *out_dev)
+{
+    int rc = check_common(ctx, n_frames, n_atoms, xyz, type, box, n_rel, rel);
+    if (rc) return rc;
+    MD_REQUIRE(nbins >= 1 && bin_size > 0.0, "nbins and bin_size must be positive");
+    MD_REQUIRE(type_frame_stride == 0 || type_frame_stride == n_atoms, "type_frame_stride must be 0 or n_atoms");
+    MD_REQUIRE(out_dev, "NULL output");
+    MD_HIP(hipSetDevice(ctx->device));
+    const size_t words = (size_t)(1 + n_rel) * nbins + 1;
+    MD_HIP(hipMemsetAsync(out_dev, 0, words * 8, ctx->stream));
+    if (n_frames == 0 || n_atoms < 2) {
+        MD_HIP(hipStreamSynchronize(ctx->stream));
+        return MDHIP_OK;
+    }
+    std::vector<double> own_edges;
+    if (!edges) {
+        own_edges.resize(nbins + 1);
+        mdhip_bin_edges(bin_size, nbins, own_edges.data());
+        edges = own_edges.data();
+    }
+    RelJob j{};
+    j.tri = true;
+    j.F = n_frames;
+    j.ni = j.nj = n_atoms;
+    j.xi = xyz;
+    j.xi_dev = on_device;
+    j.lab_i = type;
+    j.lab_i_fs = type_frame_stride;
+    j.box = box;
+    j.n_rel = n_rel;
+    j.rel = rel;
+    j.nbins = nbins;
+    j.edges = edges;
+    j.rc2 = r_cut_sq;
+    j.gscale = (float)(1.0 / bin_size);
+    j.bin_size = bin_size;
+    j.per_frame = 0;
+    j.dev_out = reinterpret_cast<unsigned long long *>(out_dev);
+    std::vector<uint64_t> H;
+    std::vector<int> rel_cls;
+    int n_cls = 0;
+    uint64_t ov = 0;
+    rc = run_job(ctx, j, H, rel_cls, n_cls, &ov);
+    if (rc) return rc;
+    // batches that did not run as one scalar-j pass (small frames, class passes) came back as host class histograms:
+    // add them in (rare path; a D2H / H2D round trip of the output words)
+    bool any = ov != 0;
+    for (size_t k = 0; k < H.size() && !any; ++k) any = H[k] != 0;
+    if (any) {
+        std::vector<uint64_t> out(words);
+        MD_HIP(hipMemcpyAsync(out.data(), out_dev, words * 8, hipMemcpyDeviceToHost, ctx->stream));
+        MD_HIP(hipStreamSynchronize(ctx->stream));
+        for (int c = 0; c < n_cls; ++c)
+            for (int b = 0; b < nbins; ++b) out[b] += 2 * H[(size_t)c * nbins + b];
+        for (int kl = 0; kl < n_rel; ++kl) {
+            if (rel_cls[kl] < 0) continue;
+            const uint64_t mult = rel[2 * kl] == rel[2 * kl + 1] ? 2 : 1;
+            for (int b = 0; b < nbins; ++b) out[(size_t)(1 + kl) * nbins + b] += mult * H[(size_t)rel_cls[kl] * nbins + b];
+        }
+        out[words - 1] += ov;
+        MD_HIP(hipMemcpyAsync(out_dev, out.data(), words * 8, hipMemcpyHostToDevice, ctx->stream));
+        MD_HIP(hipStreamSynchronize(ctx->stream));
     }
     return MDHIP_OK;
 }

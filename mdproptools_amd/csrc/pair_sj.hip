@@ -851,7 +851,49 @@ __global__ void merge_slices_kernel(const unsigned *__restrict__ slices, int his
     }
 }
 
+// Row sums -> the reference's outputs, on the device (frame-summed RDF for collectives without a host round trip):
+// out = full [nbins] | part [n_rel][nbins] | overflow [1], ADDED to what is there (batches of frames accumulate).
+//   full[b]     += 2 * sum over counted rows            (rdf_cn.py:85-86)
+//   part[kl][b] += mult[kl] * sum over the rows of relation kl's class   (rdf_cn.py:87-96; mult 2 when a == b)
+// blockIdx.y = 0: full, 1..n_rel: part, n_rel + 1: overflow. rowcls[r] = class of row r (-1: not counted).
+__global__ void derive_rdf_kernel(const unsigned long long *__restrict__ rows, int n_rows, int nbins,
+                                  const int *__restrict__ rowcls, int n_rel, const int *__restrict__ relcls,
+                                  const int *__restrict__ relmult, unsigned long long *__restrict__ out)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    const int row_len = nbins + 1;
+    if (y == n_rel + 1) {
+        if (b == 0) {
+            unsigned long long ov = 0;
+            for (int r = 0; r < n_rows; ++r) ov += rows[(size_t)r * row_len + nbins];
+            out[(size_t)(1 + n_rel) * nbins] += ov;
+        }
+        return;
+    }
+    if (b >= nbins) return;
+    unsigned long long sum = 0;
+    if (y == 0) {
+        for (int r = 0; r < n_rows; ++r)
+            if (rowcls[r] >= 0) sum += rows[(size_t)r * row_len + b];
+        out[b] += 2ull * sum;
+    } else {
+        const int want = relcls[y - 1];
+        if (want < 0) return;
+        for (int r = 0; r < n_rows; ++r)
+            if (rowcls[r] == want) sum += rows[(size_t)r * row_len + b];
+        out[(size_t)y * nbins + b] += (unsigned long long)relmult[y - 1] * sum;
+    }
+}
+
 }  // namespace
+
+void launch_derive_rdf(hipStream_t stream, const unsigned long long *rows, int n_rows, int nbins, const int *rowcls,
+                       int n_rel, const int *relcls, const int *relmult, unsigned long long *out)
+{
+    hipLaunchKernelGGL(derive_rdf_kernel, dim3((unsigned)((nbins + 127) / 128), (unsigned)(n_rel + 2)), dim3(128), 0,
+                       stream, rows, n_rows, nbins, rowcls, n_rel, relcls, relmult, out);
+}
 
 size_t lds_bytes_sj_ordered(int nbins, int n_ti, int n_tj)
 {

@@ -124,6 +124,7 @@ int mdhip_cumtrapz(mdhip_ctx *ctx, int64_t n, int n_series, const double *y, int
     MD_WS(d_out, double, WS_OUT, out_b);
     MD_WS(d_tot, double, WS_PART, (size_t)n_series * n_blocks * 8);
     KernelTimer timer(ctx);
+    ctx->last_kernel = "trap_scan_local_kernel";
     hipLaunchKernelGGL(trap_scan_local_kernel, dim3((unsigned)n_blocks, (unsigned)n_series),
                        dim3(SC_THREADS), 0, ctx->stream, d_y, d_out, d_tot, (long long)n,
                        (long long)out_stride, lead, dx, n_blocks);

@@ -129,9 +129,10 @@ constexpr int DX_TT = 2048;                      // time steps per LDS stage (mu
 constexpr int DX_AW = DX_TT + DX_KT + 8;         // a-window length per stage
 constexpr int DX_ROW = DX_AW / 8 + 1;            // transposed rows: 8 rows of DX_ROW doubles
 
-// partial[slab][lag] = sum over the slab's time range of a[t+lag]*b[t]
+// partial[slab][q] = sum over the slab's time range of a[t+lag]*b[t], lag = lag0 + q, q < n_lags
+// (lag0 > 0: a lag range of the whole function, the unit of the multi-GPU split by lags)
 __global__ __launch_bounds__(DX_THREADS) void xcorr_direct_kernel(
-    const double *__restrict__ a, const double *__restrict__ b, long long n, long long n_lags,
+    const double *__restrict__ a, const double *__restrict__ b, long long n, long long lag0, long long n_lags,
     int n_tiles, int n_slabs, double *__restrict__ partial)
 {
     __shared__ double s_a[8 * DX_ROW];
@@ -142,8 +143,9 @@ __global__ __launch_bounds__(DX_THREADS) void xcorr_direct_kernel(
     for (int half = 0; half < 2; ++half) {
         const int tile = half == 0 ? pair_id : n_tiles - 1 - pair_id;
         if (half == 1 && tile == pair_id) break;
-        const long long K0 = (long long)tile * DX_KT;
-        if (K0 >= n_lags) continue;
+        const long long Q0 = (long long)tile * DX_KT;  // first lag of the tile, relative to lag0
+        if (Q0 >= n_lags) continue;
+        const long long K0 = lag0 + Q0;
         // time range of this tile: t in [0, n-K0); split evenly into n_slabs slabs (multiples of 8)
         const long long t_total = n - K0;
         long long per = (t_total + n_slabs - 1) / n_slabs;
@@ -198,29 +200,29 @@ __global__ __launch_bounds__(DX_THREADS) void xcorr_direct_kernel(
         }
 #pragma unroll
         for (int m = 0; m < DX_LPT; ++m) {
-            const long long k = K0 + (long long)tid * DX_LPT + m;
-            if (k < n_lags) partial[(size_t)slab * n_lags + k] = acc[m];
+            const long long q = Q0 + (long long)tid * DX_LPT + m;
+            if (q < n_lags) partial[(size_t)slab * n_lags + q] = acc[m];
         }
     }
 }
 
 __global__ void xcorr_finish_kernel(const double *__restrict__ partial, double *__restrict__ out,
-                                    long long n, long long n_lags, int n_slabs)
+                                    long long n, long long lag0, long long n_lags, int n_slabs)
 {
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_lags) return;
     double s = 0.0;
     for (int r = 0; r < n_slabs; ++r) s += partial[(size_t)r * n_lags + k];
-    out[k] = s / (double)(n - k);
+    out[k] = s / (double)(n - (lag0 + k));
 }
 
 int xcorr_direct(mdhip_ctx *ctx, long long n, int n_pairs, const double *d_a, const double *d_b,
-                 long long n_lags, double *d_out)
+                 long long lag0, long long n_lags, double *d_out)
 {
     const int n_tiles = (int)((n_lags + DX_KT - 1) / DX_KT);
     const int n_blocks = (n_tiles + 1) / 2;
     int n_slabs = ctx->opt_xcorr_tile > 0 ? ctx->opt_xcorr_tile : (ctx->cu_count * 4 + n_blocks - 1) / n_blocks;
-    const long long max_slabs = (n + DX_TT - 1) / DX_TT;
+    const long long max_slabs = (n - lag0 + DX_TT - 1) / DX_TT;
     if (n_slabs > max_slabs) n_slabs = (int)max_slabs;
     if (n_slabs < 1) n_slabs = 1;
     MD_WS(d_partial, double, WS_PART, (size_t)n_slabs * n_lags * 8);
@@ -229,10 +231,10 @@ int xcorr_direct(mdhip_ctx *ctx, long long n, int n_pairs, const double *d_a, co
         MD_HIP(hipMemsetAsync(d_partial, 0, (size_t)n_slabs * n_lags * 8, ctx->stream));
         hipLaunchKernelGGL(xcorr_direct_kernel, dim3((unsigned)n_blocks, (unsigned)n_slabs),
                            dim3(DX_THREADS), 0, ctx->stream, d_a + (size_t)p * n, d_b + (size_t)p * n, n,
-                           n_lags, n_tiles, n_slabs, d_partial);
+                           lag0, n_lags, n_tiles, n_slabs, d_partial);
         MD_HIP(hipGetLastError());
         hipLaunchKernelGGL(xcorr_finish_kernel, dim3((unsigned)((n_lags + 255) / 256)), dim3(256), 0,
-                           ctx->stream, d_partial, d_out + (size_t)p * n_lags, n, n_lags, n_slabs);
+                           ctx->stream, d_partial, d_out + (size_t)p * n_lags, n, lag0, n_lags, n_slabs);
         MD_HIP(hipGetLastError());
     }
     return MDHIP_OK;
@@ -245,9 +247,17 @@ extern "C" {
 int mdhip_xcorr(mdhip_ctx *ctx, int64_t n, int n_pairs, const double *a, const double *b,
                 int on_device, int method, int64_t n_lags, double *out)
 {
+    return mdhip_xcorr_lags(ctx, n, n_pairs, a, b, on_device, method, 0, n_lags, out);
+}
+
+int mdhip_xcorr_lags(mdhip_ctx *ctx, int64_t n, int n_pairs, const double *a, const double *b, int on_device,
+                     int method, int64_t lag_begin, int64_t n_lags, double *out)
+{
     if (!ctx) return MDHIP_EINVAL;
-    MD_REQUIRE(n >= 0 && n_pairs >= 0 && n_lags >= 0 && n_lags <= n, "bad sizes (n_lags must be <= n)");
+    MD_REQUIRE(n >= 0 && n_pairs >= 0 && n_lags >= 0 && lag_begin >= 0 && lag_begin + n_lags <= n,
+               "bad sizes (lag_begin + n_lags must be <= n)");
     MD_REQUIRE(method == MDHIP_XCORR_FFT || method == MDHIP_XCORR_DIRECT, "unknown method %d", method);
+    MD_REQUIRE(lag_begin == 0 || method == MDHIP_XCORR_DIRECT, "a lag range needs the direct method");
     if (n == 0 || n_pairs == 0 || n_lags == 0) return MDHIP_OK;
     MD_REQUIRE(a && b && out, "NULL array");
     MD_REQUIRE(n < (1LL << 30), "series longer than 2^30 samples are not supported");
@@ -265,8 +275,9 @@ int mdhip_xcorr(mdhip_ctx *ctx, int64_t n, int n_pairs, const double *a, const d
     const size_t out_b = (size_t)n_pairs * n_lags * 8;
     MD_WS(d_out, double, WS_OUT, out_b);
     KernelTimer timer(ctx, n_pairs);
+    ctx->last_kernel = method == MDHIP_XCORR_FFT ? "hipfft D2Z/Z2D + pad/mul_conj/scale kernels" : "xcorr_direct_kernel";
     rc = method == MDHIP_XCORR_FFT ? xcorr_fft(ctx, n, n_pairs, d_a, d_b, same, n_lags, d_out)
-                                   : xcorr_direct(ctx, n, n_pairs, d_a, d_b, n_lags, d_out);
+                                   : xcorr_direct(ctx, n, n_pairs, d_a, d_b, lag_begin, n_lags, d_out);
     timer.stop();
     if (rc) return rc;
     MD_HIP(hipMemcpyAsync(out, d_out, out_b, hipMemcpyDeviceToHost, ctx->stream));

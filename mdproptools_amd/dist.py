@@ -10,8 +10,15 @@ kernel on the path (rdf_cn.py:459; diffusion.py:174; _conductivity.py:7), so:
                histograms ((1+R) x nbins words, tens of KB) are all-reduced once — exact integers, so
                the result does not depend on the number of ranks. With a varying box the per-frame
                integer histograms are all-gathered instead and normalised in frame order.
+               On RCCL the sums never leave the GPU before the collective: the kernels' row sums are turned
+               into rdf_full | rdf_part | overflow on the device (mdhip_rdf_atomic_dev) and that buffer is
+               what all_reduce reads.
   MSD          contiguous frame blocks per rank; the origin frame (24*E bytes) is broadcast from its
                owner, every rank reduces its own frame pairs, the [F_local][G][4] sums are all-gathered.
+  full-lag MSD the compute-bound lag x origin average shards by ENTITIES (no exchange in): every rank
+               reduces its entity slice over all lags, the per-lag sums are all-reduced (double).
+  direct ACF   the n^2/2 estimator shards by LAG RANGE (every rank holds the whole series, 8 MB at
+               n = 1e6): ranges of equal work (lag k costs n - k products), slices all-gathered.
   charge flux  as RDF: per-frame [3][T] vectors all-gathered.
   FFT ACF / running integrals: a single transform does not shard — replicas only.
 
@@ -240,34 +247,66 @@ def broadcast_array(arr, src, shape, dtype=np.float64):
 # ------------------------------------------------------------------------------------------------
 
 
-def rdf_sharded(xyz_local, types, box_local, relation_matrix, r_cut, ddr, nbins, compute=None):
+def _on_rccl(x):
+    """True when the collective can read device memory directly: RCCL backend and a CUDA tensor input."""
+    return is_distributed() and _dist().get_backend() == "nccl" and bool(getattr(x, "is_cuda", False))
+
+
+class _PendingDev:
+    """All-reduce in flight on the device buffer the kernels wrote (rdf_full | rdf_part | overflow)."""
+
+    def __init__(self, work, tensor, n_rel, nbins):
+        self._work, self._t, self._R, self._nb = work, tensor, n_rel, nbins
+        self._out = None
+
+    def wait(self):
+        if self._out is None:
+            if self._work is not None:
+                self._work.wait()
+            flat = self._t.cpu().numpy().view(np.uint64)
+            nb, R = self._nb, self._R
+            self._out = [flat[:nb].copy(), flat[nb:(1 + R) * nb].reshape(R, nb).copy(), flat[(1 + R) * nb:].copy()]
+        return self._out
+
+
+def _rdf_local_dev(xyz_local, types, box_local, relation_matrix, r_cut, ddr, nbins, ctx):
+    import torch
+
+    from . import backend
+
+    R = len(np.asarray(relation_matrix).reshape(-1, 2))
+    out = torch.empty((1 + R) * int(nbins) + 1, dtype=torch.int64, device=xyz_local.device)
+    backend.rdf_loop_dev(xyz_local, types, box_local, relation_matrix, r_cut, ddr, nbins, out, ctx=ctx)
+    return out, R
+
+
+def rdf_sharded_async(xyz_local, types, box_local, relation_matrix, r_cut, ddr, nbins, compute=None, ctx=None):
     """
-    `_rdf_loop` over a frame-sharded trajectory, constant box: every rank passes ITS frames
-    [F_local,3,N]; returns the frame-summed (rdf_full [nbins], rdf_part [R,nbins], overflow) of the
-    whole trajectory on every rank. One all-reduce of (1+R)*nbins+1 uint64 words.
+    `_rdf_loop` over a frame-sharded trajectory, constant box: every rank passes ITS frames [F_local,3,N]; returns a
+    handle whose wait() gives [rdf_full [nbins], rdf_part [R,nbins], [overflow]] of the whole trajectory on every
+    rank — one all-reduce of (1+R)*nbins+1 uint64 words, left in flight so that a pipeline can start the next
+    batch of frames meanwhile. On RCCL with device-resident frames the words go from the kernels to the collective
+    without touching the host.
     """
+    if compute is None and _on_rccl(xyz_local):
+        out, R = _rdf_local_dev(xyz_local, types, box_local, relation_matrix, r_cut, ddr, nbins, ctx)
+        d = _dist()
+        return _PendingDev(d.all_reduce(out, op=d.ReduceOp.SUM, async_op=True), out, R, int(nbins))
     if compute is None:
         from . import backend
 
         def compute(x, t, b, rel, rc, dd, nb):
-            return backend.rdf_loop(x, t, b, rel, rc, dd, nb, per_frame=False)
-
-    full, part, ov = compute(xyz_local, types, box_local, relation_matrix, r_cut, ddr, nbins)
-    full, part, ovv = allreduce_u64([full, part, np.array([ov], dtype=np.uint64)])
-    return full, part, int(ovv[0])
-
-
-def rdf_sharded_async(xyz_local, types, box_local, relation_matrix, r_cut, ddr, nbins, compute=None):
-    """rdf_sharded with the all-reduce left in flight: returns a handle whose wait() gives
-    [rdf_full, rdf_part, [overflow]] — for pipelines that start the next batch of frames meanwhile."""
-    if compute is None:
-        from . import backend
-
-        def compute(x, t, b, rel, rc, dd, nb):
-            return backend.rdf_loop(x, t, b, rel, rc, dd, nb, per_frame=False)
+            return backend.rdf_loop(x, t, b, rel, rc, dd, nb, per_frame=False, ctx=ctx)
 
     full, part, ov = compute(xyz_local, types, box_local, relation_matrix, r_cut, ddr, nbins)
     return allreduce_u64_async([full, part, np.array([ov], dtype=np.uint64)])
+
+
+def rdf_sharded(xyz_local, types, box_local, relation_matrix, r_cut, ddr, nbins, compute=None, ctx=None):
+    """rdf_sharded_async, waited for: (rdf_full [nbins], rdf_part [R,nbins], overflow) on every rank."""
+    full, part, ovv = rdf_sharded_async(xyz_local, types, box_local, relation_matrix, r_cut, ddr, nbins,
+                                        compute=compute, ctx=ctx).wait()
+    return full, part, int(ovv[0])
 
 
 def rdf_sharded_per_frame(xyz_local, types, box_local, relation_matrix, r_cut, ddr, nbins, n_frames_total,
@@ -336,3 +375,101 @@ def charge_flux_sharded(vel_local, n_frames_total, atom_mass, atom_q, seg_off, s
     j_local = compute(vel_local, atom_mass, atom_q, seg_off, seg_type, n_types, vel_conv, charge_conv)
     rows = np.ascontiguousarray(np.moveaxis(j_local, 2, 0))  # [F_local, 3, T]
     return np.moveaxis(allgather_rows(rows, n_frames_total), 0, 2)
+
+
+def lag_msd_sharded(r_local, entity_range, max_lag, group_off, scale=1.0, compute=None, ctx=None):
+    """
+    Full lag x origin MSD (mdhip_lag_msd; the compute-bound superset of diffusion.py:225-238) with the ENTITIES
+    sharded: this rank holds r_local [F,3,E_local], the entities entity_range = (e_lo, e_hi) of the global order;
+    group_off [G+1] are the global contiguous groups. Every rank reduces its slice over all lags (no exchange in),
+    the per-(lag, group) SUMS are all-reduced (double: the order of the ranks' partial sums differs from the single-
+    GPU order in the last bits, inside the rtol 1e-10 bar) and divided by the global counts.
+    Returns msd [max_lag+1, G, 4] on every rank. entity_shard(E) gives the contiguous split.
+    """
+    if compute is None:
+        from . import backend
+
+        def compute(r, ml, goff, sc):
+            return backend.lag_msd(r, ml, goff, scale=sc, ctx=ctx)
+
+    e_lo, e_hi = int(entity_range[0]), int(entity_range[1])
+    goff = np.asarray(group_off, dtype=np.int64)
+    G = len(goff) - 1
+    F = int(r_local.shape[0])
+    n_lags = int(max_lag) + 1
+    # this rank's part of every group, as local offsets; groups it holds nothing of are left out of the call
+    lo = np.clip(goff[:-1], e_lo, e_hi) - e_lo
+    hi = np.clip(goff[1:], e_lo, e_hi) - e_lo
+    held = [g for g in range(G) if hi[g] > lo[g]]
+    sums = np.zeros((n_lags, G, 4))
+    if held and F > 0:
+        # the held groups are contiguous in the slice (groups are contiguous globally)
+        loc_off = np.array([lo[held[0]]] + [hi[g] for g in held], dtype=np.int64)
+        x = r_local[:, :, int(loc_off[0]):int(loc_off[-1])]
+        if hasattr(x, "contiguous"):
+            x = x.contiguous()
+        means = np.asarray(compute(x, int(max_lag), loc_off - loc_off[0], scale))
+        origins = (F - np.arange(n_lags)).astype(np.float64)[:, None]
+        for k, g in enumerate(held):
+            sums[:, g, :] = means[:, k, :] * (origins * float(hi[g] - lo[g]))
+    if is_distributed():
+        import torch
+
+        d = _dist()
+        t = torch.from_numpy(sums).to(_device_for_collectives())
+        d.all_reduce(t, op=d.ReduceOp.SUM)
+        sums = t.cpu().numpy()
+    counts = (F - np.arange(n_lags)).astype(np.float64)[:, None] * (goff[1:] - goff[:-1]).astype(np.float64)[None, :]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        out = np.where(counts[:, :, None] > 0, sums / counts[:, :, None], 0.0)
+    return out
+
+
+def entity_shard(n_entities, rank=None, world=None):
+    """Contiguous block [lo, hi) of entities owned by `rank` (lag_msd_sharded); sizes differ by at most one."""
+    return frame_shard(n_entities, rank, world)
+
+
+def lag_ranges(n, n_lags, world):
+    """Boundaries k_0 = 0 < k_1 < ... <= k_world = n_lags of lag ranges of equal work for the direct correlation
+    estimator: lag k costs n - k products, so the cumulative work up to lag k is k (2n - k + 1) / 2."""
+    n, n_lags, world = int(n), int(n_lags), int(world)
+    total = n_lags * (2.0 * n - n_lags + 1.0) / 2.0
+    b = [0]
+    for r in range(1, world):
+        w = total * r / world
+        # smallest k with k (2n - k + 1) / 2 >= w
+        k = int(np.ceil(((2.0 * n + 1.0) - np.sqrt(max((2.0 * n + 1.0) ** 2 - 8.0 * w, 0.0))) / 2.0))
+        b.append(min(max(k, b[-1]), n_lags))
+    b.append(n_lags)
+    return b
+
+
+def xcorr_direct_sharded(a, b=None, n_lags=None, compute=None, ctx=None):
+    """
+    Direct ("brute_force", viscosity.py:103-108) correlation with the LAGS sharded: every rank holds the whole
+    series a, b [n] or [P,n] (b=None: autocorrelation), computes the lags of its range (equal work per rank, see
+    lag_ranges) and the slices are all-gathered: c [n_lags] or [P,n_lags] on every rank, identical to the
+    single-GPU result (each lag is computed by exactly one rank with the same kernel).
+    """
+    if compute is None:
+        from . import backend
+
+        def compute(aa, bb, k0, nl):
+            return backend.xcorr(aa, bb, method=backend.XCORR_DIRECT, n_lags=nl, ctx=ctx, lag_begin=k0)
+
+    single = len(a.shape) == 1
+    n = int(a.shape[-1])
+    P = 1 if single else int(a.shape[0])
+    n_lags = n if n_lags is None else int(n_lags)
+    rank, world = rank_world()
+    bounds = lag_ranges(n, n_lags, world)
+    k0, k1 = bounds[rank], bounds[rank + 1]
+    mine = np.asarray(compute(a, b, k0, k1 - k0)).reshape(P, k1 - k0) if k1 > k0 else np.zeros((P, 0))
+    if not is_distributed():
+        out = mine
+    else:
+        # rows = lags (so that allgather_var concatenates along the lag axis)
+        out = allgather_var(np.ascontiguousarray(mine.T)).T
+    out = np.ascontiguousarray(out)
+    return out[0] if single else out

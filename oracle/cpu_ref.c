@@ -43,13 +43,17 @@ static inline double pair_rsq(double xi, double yi, double zi, double xj, double
  * full[bin] += 2; part[kl][bin] += 1 per (head a, other b) and per (head b, other a).
  * bin = trunc(sqrt(rsq)/ddr) (rdf_cn.py:68,85). bin == nbins is dropped and counted.
  */
-void oracle_rdf_pairs(int64_t n, const double *xyz, const int32_t *type, int n_rel,
-                      const int32_t *rel, const double *lengths, double rc2, double ddr,
-                      int nbins, uint64_t *full, uint64_t *part, uint64_t *overflow)
+/* Head rows i0 <= i < i1 only (the reference's outer loop, rdf_cn.py:82, restricted): a bounded sample of a
+ * large frame for bench.py's cpu_baseline, and what lets tests split a frame over host threads. */
+void oracle_rdf_pairs_rows(int64_t n, int64_t i0, int64_t i1, const double *xyz, const int32_t *type, int n_rel,
+                           const int32_t *rel, const double *lengths, double rc2, double ddr,
+                           int nbins, uint64_t *full, uint64_t *part, uint64_t *overflow)
 {
     const double *x = xyz, *y = xyz + n, *z = xyz + 2 * n;
     double H[3] = {lengths[0] / 2, lengths[1] / 2, lengths[2] / 2};
-    for (int64_t i = 0; i + 1 < n; ++i) {
+    if (i1 > n - 1)
+        i1 = n - 1;
+    for (int64_t i = i0 < 0 ? 0 : i0; i < i1; ++i) {
         const double xi = x[i], yi = y[i], zi = z[i];
         const int32_t ti = type[i];
         for (int64_t j = i + 1; j < n; ++j) {
@@ -74,9 +78,16 @@ void oracle_rdf_pairs(int64_t n, const double *xyz, const int32_t *type, int n_r
     }
 }
 
-/* structural/rdf_cn.py:100-119 (_cn_loop): per-relation cutoff rc2[kl]. */
-void oracle_cn_pairs(int64_t n, const double *xyz, const int32_t *type, int n_rel,
-                     const int32_t *rel, const double *lengths, const double *rc2, uint64_t *cn)
+void oracle_rdf_pairs(int64_t n, const double *xyz, const int32_t *type, int n_rel,
+                      const int32_t *rel, const double *lengths, double rc2, double ddr,
+                      int nbins, uint64_t *full, uint64_t *part, uint64_t *overflow)
+{
+    oracle_rdf_pairs_rows(n, 0, n - 1, xyz, type, n_rel, rel, lengths, rc2, ddr, nbins, full, part, overflow);
+}
+
+/* structural/rdf_cn.py:100-119 (_cn_loop): per-relation cutoff rc2[kl]; head rows i0 <= i < i1. */
+void oracle_cn_pairs_rows(int64_t n, int64_t i0, int64_t i1, const double *xyz, const int32_t *type, int n_rel,
+                          const int32_t *rel, const double *lengths, const double *rc2, uint64_t *cn)
 {
     const double *x = xyz, *y = xyz + n, *z = xyz + 2 * n;
     double H[3] = {lengths[0] / 2, lengths[1] / 2, lengths[2] / 2};
@@ -84,7 +95,9 @@ void oracle_cn_pairs(int64_t n, const double *xyz, const int32_t *type, int n_re
     for (int kl = 0; kl < n_rel; ++kl)
         if (rc2[kl] > rcmax)
             rcmax = rc2[kl];
-    for (int64_t i = 0; i + 1 < n; ++i) {
+    if (i1 > n - 1)
+        i1 = n - 1;
+    for (int64_t i = i0 < 0 ? 0 : i0; i < i1; ++i) {
         const double xi = x[i], yi = y[i], zi = z[i];
         const int32_t ti = type[i];
         for (int64_t j = i + 1; j < n; ++j) {
@@ -103,6 +116,12 @@ void oracle_cn_pairs(int64_t n, const double *xyz, const int32_t *type, int n_re
             }
         }
     }
+}
+
+void oracle_cn_pairs(int64_t n, const double *xyz, const int32_t *type, int n_rel,
+                     const int32_t *rel, const double *lengths, const double *rc2, uint64_t *cn)
+{
+    oracle_cn_pairs_rows(n, 0, n - 1, xyz, type, n_rel, rel, lengths, rc2, cn);
 }
 
 /* structural/rdf_cn.py:122-141 (_rdf_mol_loop): atoms x sites, +1 when (atom a, site b). */
@@ -186,5 +205,36 @@ void oracle_xcorr_direct(int64_t n, const double *a, const double *b, int64_t n_
         for (int64_t t = 0; t + k < n; ++t)
             s += a[t + k] * b[t];
         out[k] = s / (double)(n - k);
+    }
+}
+
+/*
+ * Full lag x origin MSD (superset of dynamical/diffusion.py:225-238, which keeps one lag): for lag k = 0..max_lag
+ * the mean over origins t0 < F - k and over the entities of each group of (r(t0+k) - r(t0))^2 per axis and of
+ * (dx2+dy2)+dz2. r: [F][3][E]; lags: the n_lags lags to evaluate (any subset); out [n_lags][G][4].
+ */
+void oracle_lag_msd(int64_t n_frames, int64_t n_ent, const double *r, int n_lags, const int32_t *lags,
+                    int n_groups, const int64_t *group_off, double *out)
+{
+    for (int q = 0; q < n_lags; ++q) {
+        const int64_t k = lags[q];
+        for (int g = 0; g < n_groups; ++g) {
+            double s[4] = {0, 0, 0, 0};
+            for (int64_t t0 = 0; t0 + k < n_frames; ++t0) {
+                const double *a = r + t0 * 3 * n_ent, *b = r + (t0 + k) * 3 * n_ent;
+                for (int64_t e = group_off[g]; e < group_off[g + 1]; ++e) {
+                    double dx = b[e] - a[e], dy = b[n_ent + e] - a[n_ent + e],
+                           dz = b[2 * n_ent + e] - a[2 * n_ent + e];
+                    double dx2 = dx * dx, dy2 = dy * dy, dz2 = dz * dz;
+                    s[0] += dx2;
+                    s[1] += dy2;
+                    s[2] += dz2;
+                    s[3] += (dx2 + dy2) + dz2;
+                }
+            }
+            const double cnt = (double)(n_frames - k) * (double)(group_off[g + 1] - group_off[g]);
+            for (int c = 0; c < 4; ++c)
+                out[((int64_t)q * n_groups + g) * 4 + c] = cnt > 0 ? s[c] / cnt : 0.0;
+        }
     }
 }

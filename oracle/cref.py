@@ -45,27 +45,29 @@ def _prep(xyz_soa, types, rel):
     return xyz, ty, rl
 
 
-def rdf_pairs(xyz_soa, types, rel, lengths, rc2, ddr, nbins):
-    """xyz_soa [3,N]; returns (full u64[nb], part u64[R,nb], overflow)."""
+def rdf_pairs(xyz_soa, types, rel, lengths, rc2, ddr, nbins, rows=None):
+    """xyz_soa [3,N]; returns (full u64[nb], part u64[R,nb], overflow). rows=(i0, i1): head rows i0 <= i < i1 only."""
     xyz, ty, rl = _prep(xyz_soa, types, rel)
     L = np.ascontiguousarray(lengths, dtype=np.float64)
     full = np.zeros(nbins, dtype=np.uint64)
     part = np.zeros((len(rl), nbins), dtype=np.uint64)
     ov = C.c_uint64(0)
-    lib().oracle_rdf_pairs(
-        C.c_int64(xyz.shape[1]), _p(xyz, C.c_double), _p(ty, C.c_int32), C.c_int(len(rl)),
+    i0, i1 = (0, xyz.shape[1]) if rows is None else rows
+    lib().oracle_rdf_pairs_rows(
+        C.c_int64(xyz.shape[1]), C.c_int64(i0), C.c_int64(i1), _p(xyz, C.c_double), _p(ty, C.c_int32), C.c_int(len(rl)),
         _p(rl, C.c_int32), _p(L, C.c_double), C.c_double(rc2), C.c_double(ddr), C.c_int(nbins),
         _p(full, C.c_uint64), _p(part, C.c_uint64), C.byref(ov))
     return full, part, ov.value
 
 
-def cn_pairs(xyz_soa, types, rel, lengths, rc2_list):
+def cn_pairs(xyz_soa, types, rel, lengths, rc2_list, rows=None):
     xyz, ty, rl = _prep(xyz_soa, types, rel)
     L = np.ascontiguousarray(lengths, dtype=np.float64)
     rc2 = np.ascontiguousarray(rc2_list, dtype=np.float64)
     cn = np.zeros(len(rl), dtype=np.uint64)
-    lib().oracle_cn_pairs(
-        C.c_int64(xyz.shape[1]), _p(xyz, C.c_double), _p(ty, C.c_int32), C.c_int(len(rl)),
+    i0, i1 = (0, xyz.shape[1]) if rows is None else rows
+    lib().oracle_cn_pairs_rows(
+        C.c_int64(xyz.shape[1]), C.c_int64(i0), C.c_int64(i1), _p(xyz, C.c_double), _p(ty, C.c_int32), C.c_int(len(rl)),
         _p(rl, C.c_int32), _p(L, C.c_double), _p(rc2, C.c_double), _p(cn, C.c_uint64))
     return cn
 
@@ -119,3 +121,33 @@ def xcorr_direct(a, b, n_lags=None):
     lib().oracle_xcorr_direct(C.c_int64(len(a)), _p(a, C.c_double), _p(b, C.c_double),
                               C.c_int64(n_lags), _p(out, C.c_double))
     return out
+
+
+def lag_msd(r_soa, lags, group_off):
+    """r_soa [F,3,E]; lags: the lags to evaluate -> means [len(lags), G, 4] over origins and entities."""
+    r = np.ascontiguousarray(r_soa, dtype=np.float64)
+    lg = np.ascontiguousarray(lags, dtype=np.int32)
+    go = np.ascontiguousarray(group_off, dtype=np.int64)
+    out = np.zeros((len(lg), len(go) - 1, 4))
+    lib().oracle_lag_msd(C.c_int64(r.shape[0]), C.c_int64(r.shape[2]), _p(r, C.c_double), C.c_int(len(lg)),
+                         _p(lg, C.c_int32), C.c_int(len(go) - 1), _p(go, C.c_int64), _p(out, C.c_double))
+    return out
+
+
+def rdf_pairs_threaded(xyz_soa, types, rel, lengths, rc2, ddr, nbins, n_threads):
+    """One frame split over host threads by head rows (row i costs N-1-i pairs: rows are dealt so that every thread
+    gets about the same number of pairs); the ctypes calls release the GIL. Integer sums: same result as rdf_pairs."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    n = np.asarray(xyz_soa).shape[1]
+    # boundaries b_k with equal pair counts: pairs above row b = (n-b)(n-b-1)/2
+    total = n * (n - 1) / 2.0
+    bounds = [0]
+    for k in range(1, n_threads):
+        rem = total * (1.0 - k / n_threads)
+        bounds.append(int(n - (1.0 + np.sqrt(1.0 + 8.0 * rem)) / 2.0))
+    bounds.append(n)
+    with ThreadPoolExecutor(max_workers=n_threads) as pool:
+        parts = list(pool.map(lambda k: rdf_pairs(xyz_soa, types, rel, lengths, rc2, ddr, nbins,
+                                                  rows=(bounds[k], bounds[k + 1])), range(n_threads)))
+    return (sum(p[0] for p in parts), sum(p[1] for p in parts), sum(p[2] for p in parts))

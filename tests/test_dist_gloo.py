@@ -71,8 +71,26 @@ def _worker(rank, world, port, out_dir):
     cn = D.cn_sharded(xyz[lo:hi], ty, box[lo:hi], rel, [2.0, 3.0, 4.0, 5.5], compute=cn_sum)
     sums = D.msd_single_origin_sharded(r[lo:hi], F, [0, 100, n], scale=1e-10, origin_frame=0, compute=msd)
     sums4 = D.msd_single_origin_sharded(r[lo:hi], F, [0, 100, n], scale=1e-10, origin_frame=4, compute=msd)
+    # compute-bound paths: full-lag MSD sharded by entities (groups straddle the rank boundary: 100 | 200 entities
+    # against slices of 150 + 150), direct ACF sharded by lag ranges of equal work
+    e_lo, e_hi = D.entity_shard(n)
+
+    def lag(rr, ml, goff, sc):
+        return cref.lag_msd(np.asarray(rr) * sc, np.arange(ml + 1), goff)
+
+    lagm = D.lag_msd_sharded(r[:, :, e_lo:e_hi], (e_lo, e_hi), F - 1, [0, 100, n], scale=2.0, compute=lag)
+    series = np.cumsum(np.random.default_rng(5).normal(size=(2, 400)), axis=1)
+
+    def xc(aa, bb, k0, nl):
+        bb = aa if bb is None else bb
+        return np.stack([cref.xcorr_direct(aa[p], bb[p], n_lags=k0 + nl)[k0:] for p in range(len(aa))])
+
+    acf = D.xcorr_direct_sharded(series, None, compute=xc)
+    ccf = D.xcorr_direct_sharded(series[0], series[1], n_lags=300,
+                                 compute=lambda aa, bb, k0, nl: cref.xcorr_direct(aa, bb, n_lags=k0 + nl)[k0:])
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), full=full, part=part, ov=ov, pf=pf, pp=pp, cn=cn,
-             sums=sums, sums4=sums4, shard=np.array([lo, hi]))
+             sums=sums, sums4=sums4, shard=np.array([lo, hi]), lagm=lagm, acf=acf, ccf=ccf,
+             eshard=np.array([e_lo, e_hi]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -87,6 +105,18 @@ def test_frame_shard_partition():
             assert all(blocks[i][1] == blocks[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in blocks]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_lag_ranges_balance_the_work():
+    from mdproptools_amd.dist import lag_ranges
+
+    for n, n_lags, world in ((1000, 1000, 2), (1000, 1000, 8), (10 ** 6, 10 ** 6, 8), (500, 37, 3), (10, 10, 16)):
+        b = lag_ranges(n, n_lags, world)
+        assert b[0] == 0 and b[-1] == n_lags and len(b) == world + 1 and all(x <= y for x, y in zip(b, b[1:]))
+        work = [sum(n - k for k in range(b[r], b[r + 1])) if n <= 1000 else
+                (b[r + 1] - b[r]) * (2 * n - b[r] - b[r + 1] + 1) / 2 for r in range(world)]
+        if n_lags >= 100 * world:
+            assert max(work) <= 1.02 * sum(work) / world
 
 
 def test_sharded_paths_world2_gloo(tmp_path):
@@ -107,10 +137,18 @@ def test_sharded_paths_world2_gloo(tmp_path):
     cn = sum(cref.cn_pairs(xyz[f], ty, rel, box[f], [4.0, 9.0, 16.0, 30.25]) for f in range(F))
     sums = cref.msd_pairs(r * 1e-10, [(0, t) for t in range(F)], [0, 100, n])
     sums4 = cref.msd_pairs(r * 1e-10, [(4, t) for t in range(F)], [0, 100, n])
+    lagm = cref.lag_msd(r * 2.0, np.arange(F), [0, 100, n])
+    series = np.cumsum(np.random.default_rng(5).normal(size=(2, 400)), axis=1)
+    acf = np.stack([cref.xcorr_direct(series[p], series[p]) for p in range(2)])
+    ccf = cref.xcorr_direct(series[0], series[1], n_lags=300)
     shards = []
     for rank in range(2):
         g = np.load(tmp_path / ("rank%d.npz" % rank))
         shards.append(tuple(g["shard"]))
+        assert tuple(g["eshard"]) == ((0, 150), (150, 300))[rank]
+        np.testing.assert_allclose(g["lagm"], lagm, rtol=1e-12)
+        np.testing.assert_array_equal(g["acf"], acf)  # every lag comes from exactly one rank: identical
+        np.testing.assert_array_equal(g["ccf"], ccf)
         np.testing.assert_array_equal(g["full"], full)
         np.testing.assert_array_equal(g["part"], part)
         np.testing.assert_array_equal(g["pf"], np.stack([q[0] for q in per]))

@@ -1,9 +1,11 @@
 #!/bin/bash
-# tools/pmc.sh <tag> [bench args...] — rocprofv3 PMC passes over bench.py on the GPU box (one counter
-# group per run, --kernel-trace only, as gpurun requires). Output: gpurun_out/pmc/<tag>_pN_*.csv and a
-# per-kernel summary gpurun_out/pmc/<tag>_summary.txt (means over the pair_hist dispatches).
+# tools/pmc.sh <tag> <workload C2|C3> [bench args...] — rocprofv3 PMC passes over bench.py's headline loop on the GPU
+# box (one counter group per run, --kernel-trace only, as gpurun requires; separate passes for FETCH_SIZE and
+# WRITE_SIZE as MI355X_MICROARCH.md prescribes). Output: gpurun_out/pmc/<tag>_pN_*.csv, a per-kernel summary
+# gpurun_out/pmc/<tag>_summary.txt and the entries tools/pmc_summarize.py merges into profiles/pmc_kernels.json.
 set -u
 TAG=$1; shift
+WL=$1; shift
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/pmc
 mkdir -p $OUT
@@ -13,25 +15,10 @@ P2="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK
 P3="GRBM_GUI_ACTIVE GRBM_COUNT SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_LDS_ATOMIC SQ_INSTS_BRANCH"
 P4="FETCH_SIZE"
 P5="WRITE_SIZE"
+P6="SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"
 i=0
-for P in "$P1" "$P2" "$P3" "$P4" "$P5"; do
+for P in "$P1" "$P2" "$P3" "$P4" "$P5" "$P6"; do
   i=$((i+1))
-  rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT -o ${TAG}_p$i -- python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 "$@" > $OUT/${TAG}_p$i.log 2>&1
+  rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT -o ${TAG}_p$i -- python3 $R/bench.py --no-cpu-baseline --no-legs --steps 3 --warmup 1 "$@" > $OUT/${TAG}_p$i.log 2>&1
 done
-python3 - "$OUT" "$TAG" <<'PY'
-import csv, glob, sys, collections
-out, tag = sys.argv[1], sys.argv[2]
-acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in sorted(glob.glob(f"{out}/{tag}_p*_counter_collection.csv")):
-    for row in csv.DictReader(open(f)):
-        k = row["Kernel_Name"]
-        short = "pair_hist" if "pair_hist" in k else ("msd_pairs" if "msd_pairs" in k else None)
-        if short:
-            acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
-with open(f"{out}/{tag}_summary.txt", "w") as fh:
-    for k, d in acc.items():
-        fh.write(f"[{k}] mean per dispatch over {max(len(v) for v in d.values())} dispatches\n")
-        for c, v in sorted(d.items()):
-            fh.write(f"  {c:28s} {sum(v)/len(v):.6g}\n")
-print(open(f"{out}/{tag}_summary.txt").read())
-PY
+python3 $R/tools/pmc_summarize.py $OUT $TAG $WL
