@@ -346,12 +346,12 @@ def leg_c3(B, ctx, torch, device, synth, sync):
 
     def rdf():
         o = B.rdf_loop(xyz, ty, box, rel, cfg["r_cut"], cfg["bin_size"], nb, per_frame=False, ctx=ctx)
-        km["rdf"] = (ctx.last_kernel_ms()[0], ctx.last_aux_ms(), ctx.last_kernel_name())
+        km["rdf"] = (ctx.last_kernel_ms()[0], ctx.last_aux_ms(), ctx.last_kernel_name(), ctx.last_kernel_ms()[1])
         return o
 
     def cn():
         o = B.cn_loop(xyz, ty, box, rel, cuts, per_frame=False, ctx=ctx)
-        km["cn"] = (ctx.last_kernel_ms()[0], ctx.last_aux_ms(), ctx.last_kernel_name())
+        km["cn"] = (ctx.last_kernel_ms()[0], ctx.last_aux_ms(), ctx.last_kernel_name(), ctx.last_kernel_ms()[1])
         return o
 
     t_rdf, (full, part, _ov) = timed(rdf, sync, 2)
@@ -383,11 +383,13 @@ def leg_c3(B, ctx, torch, device, synth, sync):
         raise AssertionError((frac_in, expect))
     out["rdf"] = {"wall_s": t_rdf, "kernel_s": km["rdf"][0] * 1e-3, "prepass_s": km["rdf"][1] * 1e-3,
                   "value": pairs / t_rdf, "unit": "atom-pairs/s",
-                  "roofline": valu_roofline(km["rdf"][2], "C3", km["rdf"][0] * 1e-3, "mix bin 11/16", 6, pairs,
-                                            28.0 * n * F)}
+                  "launches": km["rdf"][3],  # frame batches (workspace-bounded); the roofline is per launch
+                  "roofline": valu_roofline(km["rdf"][2], "C3", km["rdf"][0] * 1e-3 / km["rdf"][3], "mix bin 11/16", 6,
+                                            pairs / km["rdf"][3], 28.0 * n * F / km["rdf"][3])}
     out["cn"] = {"wall_s": t_cn, "kernel_s": km["cn"][0] * 1e-3, "value": pairs / t_cn, "unit": "atom-pairs/s",
-                 "roofline": valu_roofline(km["cn"][2], "C3", km["cn"][0] * 1e-3, "v_add_f64", 4, pairs,
-                                           28.0 * n * F)}
+                 "launches": km["cn"][3],
+                 "roofline": valu_roofline(km["cn"][2], "C3", km["cn"][0] * 1e-3 / km["cn"][3], "v_add_f64", 4,
+                                           pairs / km["cn"][3], 28.0 * n * F / km["cn"][3])}
     out["rdf_plus_cn_wall_s"] = out.get("rdf_cn_one_sweep", {}).get("wall_s", t_rdf + t_cn)
     out["parity_checked"] = "frame 0 (5.0e9 pairs) == oracle/cpu_ref.c, bit-exact"
     out["cpu_baseline"] = {

@@ -449,8 +449,9 @@ def xcorr_direct_sharded(a, b=None, n_lags=None, compute=None, ctx=None):
     """
     Direct ("brute_force", viscosity.py:103-108) correlation with the LAGS sharded: every rank holds the whole
     series a, b [n] or [P,n] (b=None: autocorrelation), computes the lags of its range (equal work per rank, see
-    lag_ranges) and the slices are all-gathered: c [n_lags] or [P,n_lags] on every rank, identical to the
-    single-GPU result (each lag is computed by exactly one rank with the same kernel).
+    lag_ranges) and the slices are all-gathered: c [n_lags] or [P,n_lags] on every rank. Every lag is computed by
+    exactly one rank with the same kernel; the time slabs of a launch depend on its lag range, so the result equals
+    the single-GPU one to rounding (~1e-14 relative), well inside the 1e-10 acf[0] bar.
     """
     if compute is None:
         from . import backend

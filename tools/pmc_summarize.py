@@ -34,9 +34,9 @@ def source_hash():
 def short_name(k):
     """'void mdpair::(anonymous namespace)::pair_hist_sj_kernel<3, true>(mdpair::PairArgs)' -> the name the
     library reports (mdhip_last_kernel_name)."""
-    k = re.sub(r"\(.*\)$", "", k.strip())           # argument list
+    k = k.strip().replace("(anonymous namespace)::", "")
+    k = re.sub(r"\(.*\)$", "", k)                   # argument list
     k = re.sub(r"^void\s+", "", k)
-    k = k.replace("(anonymous namespace)::", "")
     k = re.sub(r"^(\w+::)+", "", k)
     return k.replace(" [clone .kd]", "").replace(".kd", "")
 
