@@ -152,6 +152,21 @@ int mdhip_cn_atomic(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const dou
                     const double *box, int n_rel, const int32_t *rel, const double *r_cut_sq,
                     int per_frame, uint64_t *cn);
 
+/* ---- R3 + R4 in one sweep ------------------------------------------------------------------ */
+/*
+ * calc_atomic_rdf and calc_atomic_cn walk the same pairs of the same frames (structural/rdf_cn.py:385-530 and
+ * 533-651; BASELINE config 3 asks for both): this call returns the outputs of mdhip_rdf_atomic AND of mdhip_cn_atomic
+ * from ONE sweep. The packed-f32 sweep sends every pair that can lie inside the largest coordination cutoff to the
+ * exact f64 chain, which bins it and counts it below the cutoffs it is below — the integers are those of the two
+ * separate calls. cn_r_cut_sq host [n_rel] (each <= r_cut_sq for the single sweep; otherwise, and for geometries the
+ * packed sweep does not cover, the two sweeps run one after the other inside this call).
+ */
+int mdhip_rdf_cn_atomic(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *xyz, int on_device,
+                        const int32_t *type, int64_t type_frame_stride, const double *box, int n_rel,
+                        const int32_t *rel, double r_cut_sq, double bin_size, int nbins, const double *edges,
+                        const double *cn_r_cut_sq, int per_frame, uint64_t *hist_full, uint64_t *hist_part,
+                        uint64_t *overflow, uint64_t *cn);
+
 /* ---- R5: _rdf_mol_loop / _cn_mol_loop (atoms x sites, rectangular) --------- */
 /*
  * structural/rdf_cn.py:122-141 and 144-162. Sites are molecule centres of mass

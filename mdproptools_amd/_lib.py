@@ -43,6 +43,9 @@ PROTOTYPES = {
                                    c_ip, C.c_double, C.c_double, C.c_int, c_dp, C.c_int, c_up, c_up, c_up]),
     "mdhip_rdf_atomic_dev": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, c_ip, C.c_int64, c_dp, C.c_int,
                                        c_ip, C.c_double, C.c_double, C.c_int, c_dp, vp]),
+    "mdhip_rdf_cn_atomic": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, c_ip, C.c_int64, c_dp, C.c_int,
+                                      c_ip, C.c_double, C.c_double, C.c_int, c_dp, c_dp, C.c_int, c_up, c_up, c_up,
+                                      c_up]),
     "mdhip_cn_atomic": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, c_ip, C.c_int64, c_dp, C.c_int,
                                   c_ip, c_dp, C.c_int, c_up]),
     "mdhip_rdf_sites": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, c_ip, C.c_int64, vp, C.c_int, c_ip,

@@ -102,6 +102,36 @@ def rdf_loop_dev(xyz, types, box, relation_matrix, r_cut, ddr, nbins, out, ctx=N
     return out
 
 
+def rdf_cn_loop(xyz, types, box, relation_matrix, r_cut, ddr, nbins, cn_cut_list, per_frame=True, ctx=None):
+    """
+    `_rdf_loop` and `_cn_loop` (rdf_cn.py:72-119) from ONE sweep over the pairs: returns
+    (rdf_full, rdf_part, overflow, cn) — the integers of rdf_loop(...) and cn_loop(..., cn_cut_list).
+    """
+    ctx = ctx or default_context()
+    F, _, N = _shape3(xyz, "xyz")
+    xp, on_dev, keep = as_input(xyz, ctx)
+    ty = _i32(types)
+    stride = 0 if ty.ndim == 1 else N
+    if ty.size != (N if stride == 0 else F * N):
+        raise ValueError("types must have shape [N] or [F, N]")
+    bx = _f64(box).reshape(F, 3)
+    rel = _i32(relation_matrix).reshape(-1, 2)
+    R = len(rel)
+    rc2 = _f64([cutoff_sq(r) for r in cn_cut_list])
+    if len(rc2) != R:
+        raise ValueError("one coordination cutoff per relation is required")
+    lead = (F,) if per_frame else ()
+    full = np.zeros(lead + (nbins,), dtype=np.uint64)
+    part = np.zeros(lead + (R, nbins), dtype=np.uint64)
+    cn = np.zeros(lead + (R,), dtype=np.uint64)
+    ov = C.c_uint64(0)
+    ctx.check(ctx.lib.mdhip_rdf_cn_atomic(
+        ctx.h, F, N, xp, on_dev, ptr(ty, C.c_int32), stride, ptr(bx), R, ptr(rel, C.c_int32),
+        cutoff_sq(r_cut), float(ddr), int(nbins), None, ptr(rc2), int(bool(per_frame)),
+        ptr(full, C.c_uint64), ptr(part, C.c_uint64), C.byref(ov), ptr(cn, C.c_uint64)))
+    return full, part, int(ov.value), cn
+
+
 def cn_loop(xyz, types, box, relation_matrix, r_cut_list, per_frame=True, ctx=None):
     """`_cn_loop` (rdf_cn.py:100-119): raw counts uint64 [F,R] (or [R])."""
     ctx = ctx or default_context()

@@ -62,6 +62,10 @@ struct PairArgs {
     float s_cap;                 // largest |relative coordinate| sum (i + j, per axis) the error bound `near` covers
     float cut_lo;                // MODE 4 (cutoff inside a bin): sqrt(rsq32) >= cut_lo may lie beyond the cutoff
     float rc2hi;                 // f32 pre-filter: every in-cutoff pair has rsq32 < rc2hi (see pk_error_bound)
+    // coordination numbers from the RDF sweep (pair_hist_sj_kernel<., ., true>)
+    int n_cn;                    // distinct coordination cutoffs (0: none)
+    const double *cn_edges;      // their squares, ascending, [n_cn]
+    float cn_hi;                 // f32 distance below which a pair may lie inside the largest of them
 };
 
 __device__ __forceinline__ double wrap_abs(double d, double L)
@@ -149,12 +153,12 @@ void launch_reduce_slots(hipStream_t stream, const unsigned long long *in, unsig
 // pair_sj.hip
 size_t lds_bytes_sj(int nbins, int n_cls, int n_ti, int n_tj, bool mode_cn);
 size_t lds_bytes_sj_ordered(int nbins, int n_ti, int n_tj);
-size_t lds_bytes_sj_pk(int nbins, int n_ti, int n_tj);
-size_t lds_bytes_sj_pk_rows(int nbins, int n_cls, int n_ti, int n_tj);  // class rows + row table + queues
+size_t lds_bytes_sj_pk(int nbins, int n_ti, int n_tj, int n_cn = 0);
+size_t lds_bytes_sj_pk_rows(int nbins, int n_cls, int n_ti, int n_tj, int n_cn = 0);  // class rows + row table + queues
 int sj_block_threads(int mode);  // threads per block of the scalar-j kernels (mode as sj_kernel)
 PairKernel sj_kernel(int mode /* 0 RDF class rows, 1 CN, 2 RDF ordered-pair rows, 3 = 2 with the packed-f32 sweep,
                                  4 = 3 with the cutoff guard (cutoff inside a bin), 5 / 6 = 3 / 4 with class rows */,
-                     bool persist, const char **name);
+                     bool persist, bool cn, const char **name);
 // error bound (in bins) of the packed-f32 bin guess for |relative coordinates| <= s_cap per axis pair sum; 0 = not usable
 double pk_error_bound(double r_cut, double bin_size, int nbins, int n_tj, double s_cap, double l_max);
 void launch_derive_rdf(hipStream_t stream, const unsigned long long *rows, int n_rows, int nbins, const int *rowcls,

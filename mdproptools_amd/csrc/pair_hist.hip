@@ -61,7 +61,13 @@ struct PairProblem {
     int n_rel = 0;
     const int *rel_cls = nullptr;   // host [n_rel]
     const int *rel_mult = nullptr;  // host [n_rel]
+    // coordination numbers from the same sweep (mdhip_rdf_cn_atomic): the distinct cutoffs^2, ascending; only the
+    // packed-f32 sweep carries them — a batch that cannot run it returns CN_UNFUSED and the caller runs a CN job
+    int n_cn = 0;
+    const double *cn_edges = nullptr;      // host [n_cn]
+    std::vector<uint64_t> *Hcn = nullptr;  // out: [F|1][n_cls][n_cn] pairs per class between consecutive cutoffs
 };
+constexpr int CN_UNFUSED = 1;  // (positive: not an error code of the ABI)
 
 // Runs the kernel over one batch of frames (in several passes when the class rows do not fit LDS) and
 // returns the class histograms on the host: H [F|1][n_cls][nbins], overflow count.
@@ -72,6 +78,7 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
     const int nTj = (int)((p.nj + TILE - 1) / TILE);
     const size_t out_frames = p.per_frame ? (size_t)F : 1;
     H.assign(out_frames * p.n_cls * p.nbins, 0);
+    if (p.Hcn) p.Hcn->assign(out_frames * p.n_cls * p.n_cn, 0);
     *overflow = 0;
     if (F == 0 || p.ni == 0 || p.nj == 0) return MDHIP_OK;
 
@@ -124,10 +131,11 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
     bool pk = false, pk_rows = false;
     float s_cap = 0.f, rc2hi = 0.f, near_pk_f = 0.f, cut_lo = 0.f;
     bool cut_guard = false;
+    double pk_err = 0.0;  // error bound of the f32 distance, in bins
     int rel_block = 0;  // atoms per centre block of the f32 records (0: none)
     if (cull && ctx->opt_rdf_sj != 0 && !mode_cn && p.n_cls <= 250 && ctx->opt_rdf_pk != 0 && p.bin_size > 0.0) {
-        const bool fits_ordered = ord_base && lds_bytes_sj_pk(p.nbins, p.n_ti, p.n_tj) <= lds_cap / 3 - 512;
-        const bool fits_rows = lds_bytes_sj_pk_rows(p.nbins, p.n_cls, p.n_ti, p.n_tj) <= lds_cap / 3 - 512;
+        const bool fits_ordered = ord_base && lds_bytes_sj_pk(p.nbins, p.n_ti, p.n_tj, p.n_cn) <= lds_cap / 3 - 512;
+        const bool fits_rows = lds_bytes_sj_pk_rows(p.nbins, p.n_cls, p.n_ti, p.n_tj, p.n_cn) <= lds_cap / 3 - 512;
         const double r_cut = std::sqrt(p.rc2);
         const double cpos = r_cut / p.bin_size, K = std::floor(cpos + 0.5);
         double l_max = 0.0, v_max = 0.0;
@@ -147,6 +155,7 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         if ((fits_ordered || fits_rows) && (on_edge || std::floor(cpos) == (double)p.nbins) && near_pk <= 0.02 &&
             std::isfinite(l_max)) {
             pk = true;
+            pk_err = err;
             pk_rows = !fits_ordered;
             ordered = fits_ordered;
             cut_guard = !on_edge;
@@ -161,6 +170,14 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
             rc2hi = std::nextafterf((float)(r_hi * r_hi * (1.0 + 2.0 * u)), std::numeric_limits<float>::infinity());
             if (pk_rows) cls_per_pass = p.n_cls;  // all classes in one pass (they fit: fits_rows)
         }
+    }
+    float cn_hi = 0.f;
+    if (p.n_cn > 0) {
+        if (!pk || ctx->opt_rdf_pk == 2) return CN_UNFUSED;
+        // every pair with rsq < c_max^2 has sqrt(rsq32) < c_max + err * bin_size (err in bins, as for cut_lo)
+        const double c_max = std::sqrt(p.cn_edges[p.n_cn - 1]);
+        cn_hi = std::nextafterf((float)(c_max + 1.1 * pk_err * p.bin_size + 1e-6 * c_max),
+                                std::numeric_limits<float>::infinity());
     }
     float near_ord = 0.f;
     if (ordered) {
@@ -209,7 +226,7 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
     int slots = p.per_frame ? 1 : ctx->opt_rdf_slots;
 
     // device tables
-    const size_t edges_b = (size_t)(p.nbins + 2) * 8;  // + a +inf sentinel after the last edge
+    const size_t edges_b = (size_t)(p.nbins + 2 + p.n_cn) * 8;  // + a +inf sentinel after the last edge, + the CN cutoffs^2
     const size_t cls_b = ((size_t)p.n_ti * p.n_tj + 63) & ~size_t(63);
     // edges and the class table of every pass: one pinned staging buffer, one H2D copy
     const size_t tab_b = edges_b + (size_t)n_pass * cls_b;
@@ -219,6 +236,7 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         double *e = reinterpret_cast<double *>(h_tab);
         std::copy(p.edges, p.edges + p.nbins + 1, e);
         e[p.nbins + 1] = std::numeric_limits<double>::infinity();
+        for (int k = 0; k < p.n_cn; ++k) e[p.nbins + 2 + k] = p.cn_edges[k];
         for (int pass = 0; pass < n_pass; ++pass) {
             const int c0 = pass * cls_per_pass;
             const int nc = (p.n_cls - c0) < cls_per_pass ? (p.n_cls - c0) : cls_per_pass;
@@ -345,11 +363,14 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         a.cen_shift = rel_block == 64 ? 4 : 6;
         a.rc2hi = rc2hi;
         a.cut_lo = cut_lo;
+        a.n_cn = p.n_cn;
+        a.cn_edges = reinterpret_cast<const double *>(d_tab) + p.nbins + 2;
+        a.cn_hi = cn_hi;
         const bool sj = cull && ctx->opt_rdf_sj != 0;  // wave-independent sweep with scalar loads of the j atoms
         const bool persist = sj && !p.per_frame && ctx->opt_rdf_sj != 2;  // resident grid + per-XCD work counters
         a.work = reinterpret_cast<unsigned *>(d_misc + 4);
-        const size_t lds = pk_rows ? lds_bytes_sj_pk_rows(p.nbins, nc, p.n_ti, p.n_tj)
-                           : pk    ? lds_bytes_sj_pk(p.nbins, p.n_ti, p.n_tj)
+        const size_t lds = pk_rows ? lds_bytes_sj_pk_rows(p.nbins, nc, p.n_ti, p.n_tj, p.n_cn)
+                           : pk    ? lds_bytes_sj_pk(p.nbins, p.n_ti, p.n_tj, p.n_cn)
                            : ordered ? ord_b
                            : sj    ? lds_bytes_sj(p.nbins, nc, p.n_ti, p.n_tj, mode_cn)
                            : fast ? lds_bytes_fast(p.nbins, nc, p.n_ti, p.n_tj)
@@ -358,7 +379,7 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         const int sj_mode = pk && ctx->opt_rdf_pk != 2 ? (pk_rows ? 5 : 3) + (cut_guard ? 1 : 0) : ordered ? 2 : mode_cn ? 1 : 0;
         const int bs = sj ? sj_block_threads(sj_mode) : TILE;  // threads per block
         const int wpb = bs / 64;                                // independent waves per block (scalar-j kernels)
-        PairKernel kern = sj ? sj_kernel(sj_mode, persist, &kname)
+        PairKernel kern = sj ? sj_kernel(sj_mode, persist, p.n_cn > 0, &kname)
                              : dense_kernel(fast, p.tri, mode_cn, fast && cull, &kname);
         ctx->last_kernel = kname;
         if (lds > 65536)
@@ -398,7 +419,8 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         }
         // scalar-j kernels: every block stores its LDS histogram into its own slice; a merge kernel adds them up
         const int sj_rows = ordered ? p.n_ti * p.n_tj : nc + 1;
-        const int sj_words = sj_rows * (p.nbins + 1);
+        const int cn_len = p.n_cn > 0 ? p.n_cn + 1 : 0;  // CN counters per row, behind all histogram rows
+        const int sj_words = sj_rows * (p.nbins + 1 + cn_len);
         unsigned long long *d_rows = nullptr;
         if (sj) {
             MD_WS(d_sl, unsigned, WS_SLICES, (size_t)launch_grid * sj_words * 4);
@@ -467,9 +489,17 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
                 prep_timed = false;
             }
             const int row_len = p.nbins + 1;
+            for (size_t fr = 0; fr < out_frames && cn_len; ++fr)
+                for (int r = 0; r < sj_rows; ++r) {
+                    const uint64_t *src = hrows + fr * (size_t)sj_words + (size_t)sj_rows * row_len + (size_t)r * cn_len;
+                    const int cl = ordered ? p.cls[r] : (r < nc ? c0 + r : -1);
+                    if (cl < 0) continue;
+                    uint64_t *dst = &(*p.Hcn)[(fr * p.n_cls + cl) * p.n_cn];
+                    for (int k = 0; k < p.n_cn; ++k) dst[k] += src[k];
+                }
             for (size_t fr = 0; fr < out_frames; ++fr)
                 for (int r = 0; r < sj_rows; ++r) {
-                    const uint64_t *src = hrows + (fr * sj_rows + r) * row_len;
+                    const uint64_t *src = hrows + fr * (size_t)sj_words + (size_t)r * row_len;
                     ov += src[p.nbins];
                     // ordered rows (ti, tj) -> class of the unordered pair; class rows of this pass -> c0 + r, the
                     // extra row holds the pairs whose class belongs to another pass
@@ -527,12 +557,15 @@ int pair_hist_run(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64_t> &H
     if (F <= batch) return pair_hist_run_batch(ctx, p, H, overflow);
     const size_t row = (size_t)p.n_cls * p.nbins;
     H.assign((p.per_frame ? (size_t)F : 1) * row, 0);
+    const size_t row_cn = (size_t)p.n_cls * p.n_cn;
+    if (p.Hcn) p.Hcn->assign((p.per_frame ? (size_t)F : 1) * row_cn, 0);
     *overflow = 0;
     double ms = 0.0, aux = 0.0;
     int launches = 0;
-    std::vector<uint64_t> part;
+    std::vector<uint64_t> part, part_cn;
     for (int64_t f0 = 0; f0 < F; f0 += batch) {
         PairProblem q = p;
+        if (p.Hcn) q.Hcn = &part_cn;
         q.n_frames = std::min<int64_t>(batch, F - f0);
         q.d_xi = p.d_xi + (size_t)f0 * 3 * p.ni;
         q.d_xj = p.d_xj + (size_t)f0 * 3 * p.nj;
@@ -551,6 +584,12 @@ int pair_hist_run(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64_t> &H
             std::copy(part.begin(), part.end(), H.begin() + (size_t)f0 * row);
         else
             for (size_t k = 0; k < row; ++k) H[k] += part[k];
+        if (p.Hcn) {
+            if (p.per_frame)
+                std::copy(part_cn.begin(), part_cn.end(), p.Hcn->begin() + (size_t)f0 * row_cn);
+            else
+                for (size_t k = 0; k < row_cn; ++k) (*p.Hcn)[k] += part_cn[k];
+        }
     }
     ctx->last_ms = ms;
     ctx->last_aux_ms = aux;
@@ -666,6 +705,9 @@ struct RelJob {
     double bin_size;
     int per_frame;
     unsigned long long *dev_out = nullptr;  // see PairProblem::dev_out
+    int n_cn = 0;                           // see PairProblem::n_cn
+    const double *cn_edges = nullptr;
+    std::vector<uint64_t> *Hcn = nullptr;
 };
 
 // Stages everything, runs the kernel and returns class histograms + the relation->class map.
@@ -738,6 +780,9 @@ int run_job(mdhip_ctx *ctx, const RelJob &j, std::vector<uint64_t> &H, std::vect
     p.gscale = j.gscale;
     p.bin_size = j.bin_size;
     p.per_frame = j.per_frame;
+    p.n_cn = j.n_cn;
+    p.cn_edges = j.cn_edges;
+    p.Hcn = j.Hcn;
     return pair_hist_run(ctx, p, H, overflow);
 }
 
@@ -910,6 +955,92 @@ int mdhip_rdf_atomic_dev(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, cons
         MD_HIP(hipStreamSynchronize(ctx->stream));
     }
     return MDHIP_OK;
+}
+
+int mdhip_rdf_cn_atomic(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *xyz, int on_device,
+                        const int32_t *type, int64_t type_frame_stride, const double *box, int n_rel,
+                        const int32_t *rel, double r_cut_sq, double bin_size, int nbins, const double *edges,
+                        const double *cn_r_cut_sq, int per_frame, uint64_t *hist_full, uint64_t *hist_part,
+                        uint64_t *overflow, uint64_t *cn)
+{
+    int rc = check_common(ctx, n_frames, n_atoms, xyz, type, box, n_rel, rel);
+    if (rc) return rc;
+    MD_REQUIRE(nbins >= 1 && bin_size > 0.0, "nbins and bin_size must be positive");
+    MD_REQUIRE(type_frame_stride == 0 || type_frame_stride == n_atoms, "type_frame_stride must be 0 or n_atoms");
+    MD_REQUIRE(hist_full && (n_rel == 0 || (hist_part && cn_r_cut_sq && cn)), "NULL output or cutoff array");
+    std::vector<double> cedges;
+    std::vector<int> rank;
+    cn_edges(n_rel, cn_r_cut_sq, cedges, rank);
+    const int n_cn = (int)cedges.size() - 1;
+    bool fused = n_cn >= 1 && n_cn <= 64 && cedges.back() <= r_cut_sq && n_frames > 0 && n_atoms >= 2;
+    if (fused) {
+        MD_HIP(hipSetDevice(ctx->device));
+        const size_t out_frames = per_frame ? (size_t)n_frames : 1;
+        std::vector<double> own_edges;
+        const double *use_edges = edges;
+        if (!use_edges) {
+            own_edges.resize(nbins + 1);
+            mdhip_bin_edges(bin_size, nbins, own_edges.data());
+            use_edges = own_edges.data();
+        }
+        RelJob j{};
+        j.tri = true;
+        j.F = n_frames;
+        j.ni = j.nj = n_atoms;
+        j.xi = xyz;
+        j.xi_dev = on_device;
+        j.lab_i = type;
+        j.lab_i_fs = type_frame_stride;
+        j.box = box;
+        j.n_rel = n_rel;
+        j.rel = rel;
+        j.nbins = nbins;
+        j.edges = use_edges;
+        j.rc2 = r_cut_sq;
+        j.gscale = (float)(1.0 / bin_size);
+        j.bin_size = bin_size;
+        j.per_frame = per_frame;
+        std::vector<uint64_t> H, Hcn;
+        j.n_cn = n_cn;
+        j.cn_edges = cedges.data() + 1;
+        j.Hcn = &Hcn;
+        std::vector<int> rel_cls;
+        int n_cls = 0;
+        uint64_t ov = 0;
+        rc = run_job(ctx, j, H, rel_cls, n_cls, &ov);
+        if (rc < 0) return rc;
+        if (rc == MDHIP_OK) {
+            if (overflow) *overflow = ov;
+            std::fill(hist_full, hist_full + out_frames * nbins, (uint64_t)0);
+            for (size_t f = 0; f < out_frames; ++f) {
+                const uint64_t *Hf = &H[f * n_cls * nbins];
+                uint64_t *full = hist_full + f * nbins;
+                for (int c = 0; c < n_cls; ++c)
+                    for (int b = 0; b < nbins; ++b) full[b] += 2 * Hf[(size_t)c * nbins + b];
+                for (int kl = 0; kl < n_rel; ++kl) {
+                    uint64_t *part = hist_part + (f * n_rel + kl) * nbins;
+                    uint64_t s = 0;
+                    const uint64_t mult = rel[2 * kl] == rel[2 * kl + 1] ? 2 : 1;
+                    if (rel_cls[kl] < 0) {
+                        std::fill(part, part + nbins, (uint64_t)0);
+                    } else {
+                        const uint64_t *row = Hf + (size_t)rel_cls[kl] * nbins;
+                        for (int b = 0; b < nbins; ++b) part[b] = mult * row[b];
+                        const uint64_t *crow = &Hcn[(f * n_cls + rel_cls[kl]) * n_cn];
+                        for (int b = 0; b < rank[kl]; ++b) s += crow[b];
+                    }
+                    cn[f * n_rel + kl] = mult * s;
+                }
+            }
+            return MDHIP_OK;
+        }
+        // CN_UNFUSED: this geometry does not run the packed-f32 sweep — two sweeps, same integers
+    }
+    rc = mdhip_rdf_atomic(ctx, n_frames, n_atoms, xyz, on_device, type, type_frame_stride, box, n_rel, rel, r_cut_sq,
+                          bin_size, nbins, edges, per_frame, hist_full, hist_part, overflow);
+    if (rc) return rc;
+    return mdhip_cn_atomic(ctx, n_frames, n_atoms, xyz, on_device, type, type_frame_stride, box, n_rel, rel,
+                           cn_r_cut_sq, per_frame, cn);
 }
 
 int mdhip_cn_atomic(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *xyz,

@@ -293,6 +293,13 @@ struct PkCtx {
     const double4 *ats_j;  // sorted f64 records of the frame's j set
     double Lx, Ly, Lz, rc2;
     int n_ti, n_tj;
+    // CN in the same sweep (CNG): every pair whose f32 distance is below cn_hi — i.e. every pair that can lie inside
+    // the largest coordination cutoff — goes to the queue, and the exact chain counts it below the cutoffs it is below
+    float cn_hi;
+    int n_cn;                 // number of distinct cutoffs
+    const double *cn_edges;   // their squares, ascending (global memory)
+    unsigned cn_base;         // LDS byte address of the CN counters [row][n_cn + 1]
+    int row_len;              // words per histogram row (nbins + 1)
 };
 
 // d - L rint(d / L) on both halves: the image of d nearest to zero (|d| < 1.5 L). One rounding in the fma; the
@@ -305,6 +312,10 @@ __device__ __forceinline__ f32x2 wrap_pk(f32x2 d, f32x2 L, f32x2 iL)
 }
 
 // The exact chain for the n queued pairs: entry = (j index in the frame << 6) | lane of the i atom.
+// CNG: pairs below the largest coordination cutoff are also counted in the CN counters of their row:
+// word k = number of cutoffs^2 <= rsq (rdf_cn.py:100-119 is a strict rsq < cutoff^2 per relation; the host sums the
+// words below a relation's own cutoff).
+template <bool CNG>
 __device__ __forceinline__ void pk_drain(PkCtx &p, const FastCtx &c, int lane)
 {
     const int n = p.qn < PK_QCAP ? p.qn : PK_QCAP;
@@ -333,6 +344,16 @@ __device__ __forceinline__ void pk_drain(PkCtx &p, const FastCtx &c, int lane)
                 }
                 const unsigned addr = ((unsigned)k << 2) + rowbase;
                 asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"(1u) : "memory");
+                if (CNG && rsq < p.cn_edges[p.n_cn - 1]) {
+                    int kc = 0;
+                    for (int e = 0; e < p.n_cn; ++e) kc += rsq >= p.cn_edges[e] ? 1 : 0;
+                    // row index: ordered rows (ti, tj); class rows: the class of the pair from its row address
+                    const unsigned row = p.rowtab ? (rowbase - c.lds_base) / ((unsigned)p.row_len * 4u)
+                                                  : (unsigned)ti * (unsigned)p.n_tj +
+                                                        (unsigned)__double2loint(rj.w) / (unsigned)p.n_ti;
+                    const unsigned caddr = p.cn_base + (row * (unsigned)(p.n_cn + 1) + (unsigned)kc) * 4u;
+                    asm volatile("ds_add_u32 %0, %1" ::"v"(caddr), "v"(1u) : "memory");
+                }
             }
         }
     }
@@ -368,62 +389,75 @@ __device__ __forceinline__ RelQ load_relq(const float *__restrict__ p)
 // exec is restored before the block ends; v_sqrt_f32 needs one wait state before its result is read.
 // CUTG: the cutoff does not sit on a bin edge, so the band of an edge does not decide in/out of the cutoff: lanes whose
 // f32 distance reaches the cutoff's own error band (sqrt(rsq32) >= cut_lo) are ambiguous too (+1 VALU, +1 SALU).
-template <bool CUTG>
+// CNG: coordination numbers ride on the same sweep: lanes whose f32 distance is below cn_hi (the largest coordination
+// cutoff plus the error bound) are ambiguous as well — the exact chain bins them AND counts them (+1 VALU, +1 SALU).
+#define BP_HEAD                                      \
+    "v_cmp_gt_f32 vcc, %[rc2], %[rsq]\n\t"           \
+    "s_mov_b64 %[amb], 0\n\t"                        \
+    "s_and_saveexec_b64 %[save], vcc\n\t"            \
+    "s_cbranch_execz 1f\n\t"                         \
+    "v_sqrt_f32 %[t], %[rsq]\n\t"                    \
+    "s_nop 0\n\t"
+#define BP_CUT "v_cmp_ge_f32 %[m2], %[t], %[cl]\n\t"
+#define BP_CN "v_cmp_lt_f32 %[m3], %[t], %[ch]\n\t"
+#define BP_MID                                       \
+    "v_fma_f32 %[t], %[t], %[gs], %[no]\n\t"         \
+    "v_fract_f32 %[fr], %[t]\n\t"                    \
+    "v_cvt_i32_f32 %[t], %[t]\n\t"                   \
+    "v_cmp_ge_f32 vcc, %[fr], %[n2]\n\t"             \
+    "v_lshl_add_u32 %[t], %[t], 2, %[rb]\n\t"
+#define BP_TAIL                                      \
+    "s_andn2_b64 %[amb], exec, vcc\n\t"              \
+    "s_and_b64 exec, exec, vcc\n\t"                  \
+    "ds_add_u32 %[t], %[one]\n\t"                    \
+    "1:\n\t"                                         \
+    "s_mov_b64 exec, %[save]"
+template <bool CUTG, bool CNG>
 __device__ __forceinline__ unsigned long long bin_pair(float rsq, float rc2hi, float gscale, float nearoff, float near2,
-                                                       unsigned rowbase, float cut_lo)
+                                                       unsigned rowbase, float cut_lo, float cn_hi)
 {
     unsigned long long amb, save;
     float t, fr;
-    if (CUTG) {
-        unsigned long long m2;
-        asm volatile(
-            "v_cmp_gt_f32 vcc, %[rc2], %[rsq]\n\t"
-            "s_mov_b64 %[amb], 0\n\t"
-            "s_and_saveexec_b64 %[save], vcc\n\t"
-            "s_cbranch_execz 1f\n\t"
-            "v_sqrt_f32 %[t], %[rsq]\n\t"
-            "s_nop 0\n\t"
-            "v_cmp_ge_f32 %[m2], %[t], %[cl]\n\t"
-            "v_fma_f32 %[t], %[t], %[gs], %[no]\n\t"
-            "v_fract_f32 %[fr], %[t]\n\t"
-            "v_cvt_i32_f32 %[t], %[t]\n\t"
-            "v_cmp_ge_f32 vcc, %[fr], %[n2]\n\t"
-            "v_lshl_add_u32 %[t], %[t], 2, %[rb]\n\t"
-            "s_andn2_b64 vcc, vcc, %[m2]\n\t"
-            "s_andn2_b64 %[amb], exec, vcc\n\t"
-            "s_and_b64 exec, exec, vcc\n\t"
-            "ds_add_u32 %[t], %[one]\n\t"
-            "1:\n\t"
-            "s_mov_b64 exec, %[save]"
-            : [amb] "=&s"(amb), [save] "=&s"(save), [m2] "=&s"(m2), [t] "=&v"(t), [fr] "=&v"(fr)
-            : [rc2] "s"(rc2hi), [rsq] "v"(rsq), [gs] "v"(gscale), [no] "s"(nearoff), [n2] "v"(near2), [rb] "v"(rowbase),
-              [one] "v"(1u), [cl] "v"(cut_lo)
-            : "vcc", "scc", "memory");
+    if (CUTG && CNG) {
+        unsigned long long m2, m3;
+        asm volatile(BP_HEAD BP_CUT BP_CN BP_MID "s_andn2_b64 vcc, vcc, %[m2]\n\t"
+                                                 "s_andn2_b64 vcc, vcc, %[m3]\n\t" BP_TAIL
+                     : [amb] "=&s"(amb), [save] "=&s"(save), [m2] "=&s"(m2), [m3] "=&s"(m3), [t] "=&v"(t), [fr] "=&v"(fr)
+                     : [rc2] "s"(rc2hi), [rsq] "v"(rsq), [gs] "v"(gscale), [no] "s"(nearoff), [n2] "v"(near2),
+                       [rb] "v"(rowbase), [one] "v"(1u), [cl] "v"(cut_lo), [ch] "v"(cn_hi)
+                     : "vcc", "scc", "memory");
         return amb;
     }
-    asm volatile(
-        "v_cmp_gt_f32 vcc, %[rc2], %[rsq]\n\t"
-        "s_mov_b64 %[amb], 0\n\t"
-        "s_and_saveexec_b64 %[save], vcc\n\t"
-        "s_cbranch_execz 1f\n\t"
-        "v_sqrt_f32 %[t], %[rsq]\n\t"
-        "s_nop 0\n\t"
-        "v_fma_f32 %[t], %[t], %[gs], %[no]\n\t"
-        "v_fract_f32 %[fr], %[t]\n\t"
-        "v_cvt_i32_f32 %[t], %[t]\n\t"
-        "v_cmp_ge_f32 vcc, %[fr], %[n2]\n\t"
-        "v_lshl_add_u32 %[t], %[t], 2, %[rb]\n\t"
-        "s_andn2_b64 %[amb], exec, vcc\n\t"
-        "s_and_b64 exec, exec, vcc\n\t"
-        "ds_add_u32 %[t], %[one]\n\t"
-        "1:\n\t"
-        "s_mov_b64 exec, %[save]"
-        : [amb] "=&s"(amb), [save] "=&s"(save), [t] "=&v"(t), [fr] "=&v"(fr)
-        : [rc2] "s"(rc2hi), [rsq] "v"(rsq), [gs] "v"(gscale), [no] "s"(nearoff), [n2] "v"(near2), [rb] "v"(rowbase),
-          [one] "v"(1u)
-        : "vcc", "scc", "memory");
+    if (CUTG) {
+        unsigned long long m2;
+        asm volatile(BP_HEAD BP_CUT BP_MID "s_andn2_b64 vcc, vcc, %[m2]\n\t" BP_TAIL
+                     : [amb] "=&s"(amb), [save] "=&s"(save), [m2] "=&s"(m2), [t] "=&v"(t), [fr] "=&v"(fr)
+                     : [rc2] "s"(rc2hi), [rsq] "v"(rsq), [gs] "v"(gscale), [no] "s"(nearoff), [n2] "v"(near2),
+                       [rb] "v"(rowbase), [one] "v"(1u), [cl] "v"(cut_lo)
+                     : "vcc", "scc", "memory");
+        return amb;
+    }
+    if (CNG) {
+        unsigned long long m3;
+        asm volatile(BP_HEAD BP_CN BP_MID "s_andn2_b64 vcc, vcc, %[m3]\n\t" BP_TAIL
+                     : [amb] "=&s"(amb), [save] "=&s"(save), [m3] "=&s"(m3), [t] "=&v"(t), [fr] "=&v"(fr)
+                     : [rc2] "s"(rc2hi), [rsq] "v"(rsq), [gs] "v"(gscale), [no] "s"(nearoff), [n2] "v"(near2),
+                       [rb] "v"(rowbase), [one] "v"(1u), [ch] "v"(cn_hi)
+                     : "vcc", "scc", "memory");
+        return amb;
+    }
+    asm volatile(BP_HEAD BP_MID BP_TAIL
+                 : [amb] "=&s"(amb), [save] "=&s"(save), [t] "=&v"(t), [fr] "=&v"(fr)
+                 : [rc2] "s"(rc2hi), [rsq] "v"(rsq), [gs] "v"(gscale), [no] "s"(nearoff), [n2] "v"(near2), [rb] "v"(rowbase),
+                   [one] "v"(1u)
+                 : "vcc", "scc", "memory");
     return amb;
 }
+#undef BP_HEAD
+#undef BP_CUT
+#undef BP_CN
+#undef BP_MID
+#undef BP_TAIL
 
 // The four j atoms of one group against the wave's 64 i atoms.
 // VAR: bit k = axis k takes the per-pair f32 wrap. jidx0 = index of the group's first atom in the frame's j set.
@@ -432,7 +466,7 @@ __device__ __forceinline__ unsigned long long bin_pair(float rsq, float rc2hi, f
 // them (lgkmcnt(0)) before the first use of `rq`: that wait has to come before the prefetch is issued — the two
 // empty asm statements pin that order (the first depends on dx, i.e. on a use of rq) — and is free, because rq was
 // itself prefetched during the previous sweep.
-template <bool DIAG, int VAR, bool PF, bool CUTG, bool ROWS>
+template <bool DIAG, int VAR, bool PF, bool CUTG, bool ROWS, bool CNG>
 __device__ __forceinline__ void sweep_group_pk(const RelQ &rq, int jidx0, int local0, PkCtx &p, const FastCtx &c,
                                                int lane_in_tile, int lane, const float *next_p, RelQ &next)
 {
@@ -473,7 +507,7 @@ __device__ __forceinline__ void sweep_group_pk(const RelQ &rq, int jidx0, int lo
             const unsigned rowbase = ROWS ? row[2 * h + u] : c.rowbase_me;
             float r2 = rsq[u];
             if (DIAG) r2 = local0 + 2 * h + u > lane_in_tile ? r2 : 3.0e38f;  // i < j inside the diagonal tile
-            const unsigned long long amb = bin_pair<CUTG>(r2, p.rc2hi, c.gscale, nearoff, c.near2, rowbase, p.cut_lo);
+            const unsigned long long amb = bin_pair<CUTG, CNG>(r2, p.rc2hi, c.gscale, nearoff, c.near2, rowbase, p.cut_lo, p.cn_hi);
             if (amb) {  // wave-uniform, rare: some lane's pair is inside the error band -> the exact chain, later
                 // (the copy through a volatile asm keeps the per-lane test inside this branch: the compiler would
                 // otherwise fold both conditions into one divergent branch and pay 3 VALU per pair for it)
@@ -509,7 +543,7 @@ __device__ __forceinline__ bool axis_plain(float wlo, float whi, float glo, floa
 
 // One work item of the packed-f32 sweep (ordered-pair rows; atom-atom or atoms x sites): the 64 i atoms of wave `wq` of tile I of
 // frame f against slice `split` of the tile's neighbour list.
-template <bool CUTG, bool ROWS>
+template <bool CUTG, bool ROWS, bool CNG>
 __device__ __forceinline__ void sj_item_pk(const PairArgs &a, FastCtx &c, const unsigned *s_row, unsigned *queue, int f,
                                            int I, int wq,
                                            int split, int lane)
@@ -571,6 +605,11 @@ __device__ __forceinline__ void sj_item_pk(const PairArgs &a, FastCtx &c, const 
     p.rc2 = a.rc2;
     p.n_ti = a.n_ti;
     p.n_tj = a.n_tj;
+    p.cn_hi = a.cn_hi;
+    p.n_cn = a.n_cn;
+    p.cn_edges = a.cn_edges;
+    p.cn_base = c.lds_base + (unsigned)((ROWS ? a.n_cls + 1 : a.n_ti * a.n_tj) * (a.nbins + 1)) * 4u;
+    p.row_len = a.nbins + 1;
     const float *rel_f = a.rel + (long long)f * n_pad_j * 4;  // 4 floats per j atom
     const int gpb = 1 << a.cen_shift;                        // groups per centre block
     const int nblk = (TILE / SJ_GROUP) >> a.cen_shift;       // centre blocks per tile
@@ -627,7 +666,7 @@ __device__ __forceinline__ void sj_item_pk(const PairArgs &a, FastCtx &c, const 
                     mk &= mk - 1;
 #pragma unroll 1
                     for (int u = 0; u < SJ_GROUP; ++u) {
-                        if (p.qn > 64) pk_drain(p, c, lane);
+                        if (p.qn > 64) pk_drain<CNG>(p, c, lane);
                         const bool want = real_i && (!diag || g * SJ_GROUP + u > lane_in_tile);
                         const unsigned long long wm = __builtin_amdgcn_ballot_w64(want);
                         if (want)
@@ -649,7 +688,7 @@ __device__ __forceinline__ void sj_item_pk(const PairArgs &a, FastCtx &c, const 
             }
             const int jbase = J * TILE;
 #define PK_DRAIN_CHECK() \
-    if (p.qn > 64) pk_drain(p, c, lane)
+    if (p.qn > 64) pk_drain<CNG>(p, c, lane)
             if (!diag) {
                 // the common variant (no per-pair wrap), software-pipelined: the records of the next group are
                 // loaded while the current group is swept; two buffers, loop unrolled by two (no register copies)
@@ -663,14 +702,14 @@ __device__ __forceinline__ void sj_item_pk(const PairArgs &a, FastCtx &c, const 
                         const bool moreB = mk != 0;
                         const int gB = moreB ? __builtin_ctzll(mk) : gA;
                         mk &= mk - 1;
-                        sweep_group_pk<false, 0, true, CUTG, ROWS>(qA, jbase + gA * SJ_GROUP, gA * SJ_GROUP, p, c, lane_in_tile, lane,
+                        sweep_group_pk<false, 0, true, CUTG, ROWS, CNG>(qA, jbase + gA * SJ_GROUP, gA * SJ_GROUP, p, c, lane_in_tile, lane,
                                                        rtile + gB * SJ_GROUP * 4, qB);
                         if (!moreB) break;
                         PK_DRAIN_CHECK();
                         const bool moreA = mk != 0;
                         gA = moreA ? __builtin_ctzll(mk) : gB;
                         mk &= mk - 1;
-                        sweep_group_pk<false, 0, true, CUTG, ROWS>(qB, jbase + gB * SJ_GROUP, gB * SJ_GROUP, p, c, lane_in_tile, lane,
+                        sweep_group_pk<false, 0, true, CUTG, ROWS, CNG>(qB, jbase + gB * SJ_GROUP, gB * SJ_GROUP, p, c, lane_in_tile, lane,
                                                        rtile + gA * SJ_GROUP * 4, qA);
                         if (!moreA) break;
                     }
@@ -685,22 +724,22 @@ __device__ __forceinline__ void sj_item_pk(const PairArgs &a, FastCtx &c, const 
                     PK_DRAIN_CHECK();
                     const int j0 = jbase + g * SJ_GROUP, l0 = g * SJ_GROUP;
                     switch (A) {
-                    case 1: sweep_group_pk<false, 1, false, CUTG, ROWS>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
-                    case 2: sweep_group_pk<false, 2, false, CUTG, ROWS>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
-                    case 3: sweep_group_pk<false, 3, false, CUTG, ROWS>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
-                    case 4: sweep_group_pk<false, 4, false, CUTG, ROWS>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
-                    case 5: sweep_group_pk<false, 5, false, CUTG, ROWS>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
-                    case 6: sweep_group_pk<false, 6, false, CUTG, ROWS>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
-                    case 7: sweep_group_pk<false, 7, false, CUTG, ROWS>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
-                    case 9: sweep_group_pk<true, 0, false, CUTG, ROWS>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
-                    default: sweep_group_pk<true, 7, false, CUTG, ROWS>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
+                    case 1: sweep_group_pk<false, 1, false, CUTG, ROWS, CNG>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
+                    case 2: sweep_group_pk<false, 2, false, CUTG, ROWS, CNG>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
+                    case 3: sweep_group_pk<false, 3, false, CUTG, ROWS, CNG>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
+                    case 4: sweep_group_pk<false, 4, false, CUTG, ROWS, CNG>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
+                    case 5: sweep_group_pk<false, 5, false, CUTG, ROWS, CNG>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
+                    case 6: sweep_group_pk<false, 6, false, CUTG, ROWS, CNG>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
+                    case 7: sweep_group_pk<false, 7, false, CUTG, ROWS, CNG>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
+                    case 9: sweep_group_pk<true, 0, false, CUTG, ROWS, CNG>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
+                    default: sweep_group_pk<true, 7, false, CUTG, ROWS, CNG>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
                     }
                 }
             }
 #undef PK_DRAIN_CHECK
         }
     }
-    if (p.qn > 0) pk_drain(p, c, lane);
+    if (p.qn > 0) pk_drain<CNG>(p, c, lane);
 }
 
 // Assertion at the top of every work-loop iteration: the whole wave is here (the item index is drawn by lane 0
@@ -718,7 +757,9 @@ __device__ __forceinline__ bool work_loop_sane(const PairArgs &a, long long iter
 // records live in one L2 — and the block flushes its LDS histograms once, when its four waves have run
 // dry. Every wave leaves the loop as soon as the counter passes the item count.
 // PERSIST = false (per-frame output): block = (frame, tile, list slice), one flush per block.
-template <int MODE, bool PERSIST>
+// CNG (packed-f32 modes only): coordination numbers from the same sweep; the CN counters [rows][n_cn + 1] sit right
+// behind the histogram rows in LDS and travel with them through the slices.
+template <int MODE, bool PERSIST, bool CNG = false>
 __global__ __launch_bounds__(MODE >= 3 ? PK_THREADS : TILE, MODE >= 3 ? PK_WAVES_PER_SIMD : 1) void pair_hist_sj_kernel(const PairArgs a)
 {
     // threads per block: the waves are independent (they share only the LDS histogram), so the block size is free.
@@ -736,7 +777,7 @@ __global__ __launch_bounds__(MODE >= 3 ? PK_THREADS : TILE, MODE >= 3 ? PK_WAVES
     // ---- LDS: hist | (CN edges) | row table ----
     // MODE 2: one row per ORDERED type pair (ti, tj), addressed without a table (see sweep_group_sj)
     const int row_len = a.nbins + 1;
-    const int hist_words = (ORDERED ? a.n_ti * a.n_tj : a.n_cls + 1) * row_len;
+    const int hist_words = (ORDERED ? a.n_ti * a.n_tj : a.n_cls + 1) * (row_len + (CNG ? a.n_cn + 1 : 0));
     unsigned *s_hist = reinterpret_cast<unsigned *>(smem);
     size_t off = ((size_t)hist_words * 4 + 15) & ~size_t(15);
     double *s_edges = reinterpret_cast<double *>(smem + off);
@@ -791,7 +832,7 @@ __global__ __launch_bounds__(MODE >= 3 ? PK_THREADS : TILE, MODE >= 3 ? PK_WAVES
             const int fx = (int)(it / (unsigned)ipf), r = (int)(it % (unsigned)ipf);
             const int split = r % a.jsplit, wI = r / a.jsplit;
             if (MODE >= 3)
-                sj_item_pk<MODE == 4 || MODE == 6, PK_ROWS>(a, c, s_row, s_queue + (tid >> 6) * PK_QSTRIDE, fx * 8 + xcd, wI >> 2,
+                sj_item_pk<MODE == 4 || MODE == 6, PK_ROWS, CNG>(a, c, s_row, s_queue + (tid >> 6) * PK_QSTRIDE, fx * 8 + xcd, wI >> 2,
                                                             wI & 3, split, lane);
             else
                 sj_item<MODE >= 3 ? 2 : MODE>(a, c, s_row, fx * 8 + xcd, wI >> 2, wI & 3, split, lane);
@@ -812,7 +853,7 @@ __global__ __launch_bounds__(MODE >= 3 ? PK_THREADS : TILE, MODE >= 3 ? PK_WAVES
             if (it >= ipf) break;
             const int split = (int)(it % (unsigned)a.jsplit), wI = (int)(it / (unsigned)a.jsplit);
             if (MODE >= 3)
-                sj_item_pk<MODE == 4 || MODE == 6, PK_ROWS>(a, c, s_row, s_queue + (tid >> 6) * PK_QSTRIDE, f, wI >> 2, wI & 3, split,
+                sj_item_pk<MODE == 4 || MODE == 6, PK_ROWS, CNG>(a, c, s_row, s_queue + (tid >> 6) * PK_QSTRIDE, f, wI >> 2, wI & 3, split,
                                                             lane);
             else
                 sj_item<MODE >= 3 ? 2 : MODE>(a, c, s_row, f, wI >> 2, wI & 3, split, lane);
@@ -902,15 +943,16 @@ size_t lds_bytes_sj_ordered(int nbins, int n_ti, int n_tj)
 
 int sj_block_threads(int mode) { return mode >= 3 ? PK_THREADS : TILE; }
 
-size_t lds_bytes_sj_pk_rows(int nbins, int n_cls, int n_ti, int n_tj)
+size_t lds_bytes_sj_pk_rows(int nbins, int n_cls, int n_ti, int n_tj, int n_cn)
 {
-    const size_t hist = ((size_t)(n_cls + 1) * (nbins + 1) * 4 + 15) & ~size_t(15);
+    const size_t hist = ((size_t)(n_cls + 1) * (nbins + 1 + (n_cn ? n_cn + 1 : 0)) * 4 + 15) & ~size_t(15);
     return hist + (size_t)((n_ti * n_tj + 3) / 4 * 4) * 4 + (size_t)(PK_THREADS / 64) * PK_QSTRIDE * 4;
 }
 
-size_t lds_bytes_sj_pk(int nbins, int n_ti, int n_tj)
+size_t lds_bytes_sj_pk(int nbins, int n_ti, int n_tj, int n_cn)
 {
-    return (((size_t)n_ti * n_tj * (nbins + 1) * 4 + 15) & ~size_t(15)) + (size_t)(PK_THREADS / 64) * PK_QSTRIDE * 4;
+    return (((size_t)n_ti * n_tj * (nbins + 1 + (n_cn ? n_cn + 1 : 0)) * 4 + 15) & ~size_t(15)) +
+           (size_t)(PK_THREADS / 64) * PK_QSTRIDE * 4;
 }
 
 // Error bound of the packed-f32 bin guess, in bins (see the MODE 3 header). u = 2^-24 (f32 round to nearest).
@@ -943,9 +985,13 @@ size_t lds_bytes_sj(int nbins, int n_cls, int n_ti, int n_tj, bool mode_cn)
     return (off + 15) & ~size_t(15);
 }
 
-PairKernel sj_kernel(int mode, bool persist, const char **name)
+PairKernel sj_kernel(int mode, bool persist, bool cn, const char **name)
 {
 #define MD_PICK(...) (*name = #__VA_ARGS__, __VA_ARGS__)
+    if (cn && mode == 6) return persist ? MD_PICK(pair_hist_sj_kernel<6, true, true>) : MD_PICK(pair_hist_sj_kernel<6, false, true>);
+    if (cn && mode == 5) return persist ? MD_PICK(pair_hist_sj_kernel<5, true, true>) : MD_PICK(pair_hist_sj_kernel<5, false, true>);
+    if (cn && mode == 4) return persist ? MD_PICK(pair_hist_sj_kernel<4, true, true>) : MD_PICK(pair_hist_sj_kernel<4, false, true>);
+    if (cn && mode == 3) return persist ? MD_PICK(pair_hist_sj_kernel<3, true, true>) : MD_PICK(pair_hist_sj_kernel<3, false, true>);
     if (mode == 6) return persist ? MD_PICK(pair_hist_sj_kernel<6, true>) : MD_PICK(pair_hist_sj_kernel<6, false>);
     if (mode == 5) return persist ? MD_PICK(pair_hist_sj_kernel<5, true>) : MD_PICK(pair_hist_sj_kernel<5, false>);
     if (mode == 4) return persist ? MD_PICK(pair_hist_sj_kernel<4, true>) : MD_PICK(pair_hist_sj_kernel<4, false>);

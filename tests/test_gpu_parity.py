@@ -788,6 +788,61 @@ def test_packed_f32_sweep_equals_f64_sweep(B):
     pk.close()
 
 
+def test_rdf_and_cn_from_one_sweep(B):
+    """mdhip_rdf_cn_atomic: RDF histograms and coordination counts from ONE sweep equal the two separate calls on
+    every geometry of the packed-sweep stress set (lattices on bin edges, blobs, NPT boxes, strays box lengths
+    outside the cell, ordered rows and class rows, cutoff on and inside a bin), with coordination cutoffs on bin
+    edges, between them, equal for several relations, zero, and — for the fallback inside the call — beyond r_cut."""
+    from mdproptools_amd._lib import Context
+
+    rng = np.random.default_rng(4242)
+    ctx = Context(0)
+    ctx.set_option("rdf_cull", 1)
+    fused = 0
+    for trial in range(24):
+        xyz, ty, box, rel, r_cut, bin_size, nbins = _pk_case(rng, trial)
+        R = len(rel)
+        cuts = list(rng.uniform(0.1, 0.95, R) * r_cut)
+        if trial % 3 == 0:
+            cuts[0] = bin_size * int(0.5 * nbins)          # exactly a bin edge
+        if trial % 4 == 1 and R > 1:
+            cuts[1] = cuts[0]                               # two relations share a cutoff
+        if trial % 5 == 2:
+            cuts[-1] = 0.0                                  # a relation that counts nothing
+        if trial % 8 == 7:
+            cuts[0] = 1.2 * r_cut                           # beyond the RDF cutoff: two sweeps inside the call
+        per_frame = bool(trial % 2)
+        a = B.rdf_loop(xyz, ty, box, rel, r_cut, bin_size, nbins, per_frame=per_frame, ctx=ctx)
+        cn = B.cn_loop(xyz, ty, box, rel, cuts, per_frame=per_frame, ctx=ctx)
+        f, p_, ov, cn2 = B.rdf_cn_loop(xyz, ty, box, rel, r_cut, bin_size, nbins, cuts, per_frame=per_frame, ctx=ctx)
+        name = ctx.last_kernel_name()
+        fused += "true>" in name and name.count(",") == 2 and name.endswith(", true>")
+        msg = "trial %d n=%d r_cut=%.4f bin=%.3f cuts=%s kernel=%s" % (trial, xyz.shape[2], r_cut, bin_size, cuts, name)
+        np.testing.assert_array_equal(f, a[0], err_msg=msg)
+        np.testing.assert_array_equal(p_, a[1], err_msg=msg)
+        assert ov == a[2], msg
+        np.testing.assert_array_equal(cn2, cn, err_msg=msg)
+    assert fused >= 12, "the one-sweep kernel ran in only %d of 24 cases" % fused
+    # and against the oracle directly, C2-like shape
+    from mdproptools_amd import synth
+
+    n, L = 4000, 36.8
+    xyz = synth.rdf_frames(n, range(2), L, 9)
+    ty = synth.rdf_types(n)
+    rel = np.array(synth.ALL_PAIRS_4)
+    box = np.full((2, 3), L)
+    cuts = synth.cn_cutoffs(len(rel))
+    for r_cut, bin_size, nbins in ((12.0, 0.05, 240), (12.02, 0.05, 240)):
+        f, p_, ov, cn = B.rdf_cn_loop(xyz, ty, box, rel, r_cut, bin_size, nbins, cuts, ctx=ctx)
+        assert ctx.last_kernel_name().endswith(", true>"), ctx.last_kernel_name()
+        for fr in range(2):
+            cf, cp, _ = C.rdf_pairs(xyz[fr], ty, rel, box[fr], r_cut * r_cut, bin_size, nbins)
+            np.testing.assert_array_equal(f[fr], cf)
+            np.testing.assert_array_equal(p_[fr], cp)
+            np.testing.assert_array_equal(cn[fr], C.cn_pairs(xyz[fr], ty, rel, box[fr], [c * c for c in cuts]))
+    ctx.close()
+
+
 def test_packed_f32_sweep_against_oracle(B):
     """The default path of a C2-shaped call (packed-f32 sweep) against the C oracle: cutoff on a bin edge (<3, .>)
     and inside the last bin (<4, .>: the cutoff's own error band is guarded per pair)."""
