@@ -63,9 +63,9 @@ struct PairArgs {
     float cut_lo;                // MODE 4 (cutoff inside a bin): sqrt(rsq32) >= cut_lo may lie beyond the cutoff
     float rc2hi;                 // f32 pre-filter: every in-cutoff pair has rsq32 < rc2hi (see pk_error_bound)
     // coordination numbers from the RDF sweep (pair_hist_sj_kernel<., ., true>)
-    int n_cn;                    // distinct coordination cutoffs (0: none)
-    const double *cn_edges;      // their squares, ascending, [n_cn]
-    float cn_hi;                 // f32 distance below which a pair may lie inside the largest of them
+    int n_cn;                    // != 0: on
+    const unsigned *cn_tab;      // word index of every row's split bin (-1: none; padded to 8 bytes) | cutoff^2 per row
+    float cn_reach;              // groups whose box is farther than this from the wave's box hold no split-bin pair
 };
 
 __device__ __forceinline__ double wrap_abs(double d, double L)

@@ -61,11 +61,13 @@ struct PairProblem {
     int n_rel = 0;
     const int *rel_cls = nullptr;   // host [n_rel]
     const int *rel_mult = nullptr;  // host [n_rel]
-    // coordination numbers from the same sweep (mdhip_rdf_cn_atomic): the distinct cutoffs^2, ascending; only the
-    // packed-f32 sweep carries them — a batch that cannot run it returns CN_UNFUSED and the caller runs a CN job
-    int n_cn = 0;
-    const double *cn_edges = nullptr;      // host [n_cn]
-    std::vector<uint64_t> *Hcn = nullptr;  // out: [F|1][n_cls][n_cn] pairs per class between consecutive cutoffs
+    // coordination numbers from the same sweep (mdhip_rdf_cn_atomic): one cutoff^2 per class (0: none). The bins of
+    // the histogram are exact, so only the pairs of the bin that holds a class's cutoff (its split bin) need the exact
+    // comparison: Hsplit counts those that are inside. Only the packed-f32 sweep does this — a batch that cannot run
+    // it returns CN_UNFUSED and the caller runs a separate CN job
+    int n_cn = 0;                             // != 0: on
+    const double *cn_c2_cls = nullptr;        // host [n_cls]
+    std::vector<uint64_t> *Hsplit = nullptr;  // out: [F|1][n_cls] pairs of the split bin with rsq < cutoff^2
 };
 constexpr int CN_UNFUSED = 1;  // (positive: not an error code of the ABI)
 
@@ -78,7 +80,7 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
     const int nTj = (int)((p.nj + TILE - 1) / TILE);
     const size_t out_frames = p.per_frame ? (size_t)F : 1;
     H.assign(out_frames * p.n_cls * p.nbins, 0);
-    if (p.Hcn) p.Hcn->assign(out_frames * p.n_cls * p.n_cn, 0);
+    if (p.Hsplit) p.Hsplit->assign(out_frames * p.n_cls, 0);
     *overflow = 0;
     if (F == 0 || p.ni == 0 || p.nj == 0) return MDHIP_OK;
 
@@ -171,14 +173,7 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
             if (pk_rows) cls_per_pass = p.n_cls;  // all classes in one pass (they fit: fits_rows)
         }
     }
-    float cn_hi = 0.f;
-    if (p.n_cn > 0) {
-        if (!pk || ctx->opt_rdf_pk == 2) return CN_UNFUSED;
-        // every pair with rsq < c_max^2 has sqrt(rsq32) < c_max + err * bin_size (err in bins, as for cut_lo)
-        const double c_max = std::sqrt(p.cn_edges[p.n_cn - 1]);
-        cn_hi = std::nextafterf((float)(c_max + 1.1 * pk_err * p.bin_size + 1e-6 * c_max),
-                                std::numeric_limits<float>::infinity());
-    }
+    if (p.n_cn > 0 && (!pk || ctx->opt_rdf_pk == 2)) return CN_UNFUSED;
     float near_ord = 0.f;
     if (ordered) {
         cls_per_pass = p.n_cls;
@@ -226,17 +221,40 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
     int slots = p.per_frame ? 1 : ctx->opt_rdf_slots;
 
     // device tables
-    const size_t edges_b = (size_t)(p.nbins + 2 + p.n_cn) * 8;  // + a +inf sentinel after the last edge, + the CN cutoffs^2
+    const size_t edges_b = (size_t)(p.nbins + 2) * 8;  // + a +inf sentinel after the last edge
+    // CN tables of the scalar-j rows (one pass, all rows): word index of every row's split bin | cutoff^2 per row
+    const int cn_rows = p.n_cn ? (ordered ? p.n_ti * p.n_tj : p.n_cls + 1) : 0;
+    const size_t cn_fw = ((size_t)cn_rows + 1) & ~size_t(1);
+    const size_t cn_b = p.n_cn ? (cn_fw + 2 * (size_t)cn_rows) * 4 : 0;
+    float cn_reach = 0.f;
     const size_t cls_b = ((size_t)p.n_ti * p.n_tj + 63) & ~size_t(63);
     // edges and the class table of every pass: one pinned staging buffer, one H2D copy
-    const size_t tab_b = edges_b + (size_t)n_pass * cls_b;
+    const size_t tab_b = edges_b + (size_t)n_pass * cls_b + cn_b + 8;
     MD_WS(d_tab, unsigned char, WS_TABLES, tab_b);
     MD_PIN(h_tab, unsigned char, PIN_TABLES, tab_b);
     {
         double *e = reinterpret_cast<double *>(h_tab);
         std::copy(p.edges, p.edges + p.nbins + 1, e);
         e[p.nbins + 1] = std::numeric_limits<double>::infinity();
-        for (int k = 0; k < p.n_cn; ++k) e[p.nbins + 2 + k] = p.cn_edges[k];
+        if (p.n_cn) {
+            int *fl = reinterpret_cast<int *>(h_tab + edges_b + (size_t)n_pass * cls_b);
+            double *c2r = reinterpret_cast<double *>(fl + cn_fw);
+            std::fill(fl, fl + cn_fw, -1);
+            double reach = 0.0;
+            for (int r = 0; r < cn_rows; ++r) {
+                const int cl = ordered ? p.cls[r] : (r < p.n_cls ? r : -1);
+                const double c2 = cl >= 0 ? p.cn_c2_cls[cl] : 0.0;
+                c2r[r] = c2;
+                if (!(c2 > 0.0)) continue;
+                // split bin kc: edges[kc] <= c2 < edges[kc + 1]; none when the cutoff sits exactly on an edge
+                const int kc = (int)(std::upper_bound(p.edges, p.edges + p.nbins + 1, c2) - p.edges) - 1;
+                if (p.edges[kc] == c2) continue;
+                fl[r] = r * (p.nbins + 1) + kc;
+                const double top = kc + 1 <= p.nbins ? std::sqrt(p.edges[kc + 1]) : std::sqrt(p.rc2);
+                reach = std::max(reach, std::min(top, std::sqrt(p.rc2)));
+            }
+            cn_reach = (float)((reach + 1e-3) * 1.00001);
+        }
         for (int pass = 0; pass < n_pass; ++pass) {
             const int c0 = pass * cls_per_pass;
             const int nc = (p.n_cls - c0) < cls_per_pass ? (p.n_cls - c0) : cls_per_pass;
@@ -364,8 +382,8 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         a.rc2hi = rc2hi;
         a.cut_lo = cut_lo;
         a.n_cn = p.n_cn;
-        a.cn_edges = reinterpret_cast<const double *>(d_tab) + p.nbins + 2;
-        a.cn_hi = cn_hi;
+        a.cn_tab = reinterpret_cast<const unsigned *>(d_tab + edges_b + (size_t)n_pass * cls_b);
+        a.cn_reach = cn_reach;
         const bool sj = cull && ctx->opt_rdf_sj != 0;  // wave-independent sweep with scalar loads of the j atoms
         const bool persist = sj && !p.per_frame && ctx->opt_rdf_sj != 2;  // resident grid + per-XCD work counters
         a.work = reinterpret_cast<unsigned *>(d_misc + 4);
@@ -419,7 +437,7 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         }
         // scalar-j kernels: every block stores its LDS histogram into its own slice; a merge kernel adds them up
         const int sj_rows = ordered ? p.n_ti * p.n_tj : nc + 1;
-        const int cn_len = p.n_cn > 0 ? p.n_cn + 1 : 0;  // CN counters per row, behind all histogram rows
+        const int cn_len = p.n_cn ? 1 : 0;  // one split counter per row, behind all histogram rows
         const int sj_words = sj_rows * (p.nbins + 1 + cn_len);
         unsigned long long *d_rows = nullptr;
         if (sj) {
@@ -491,11 +509,9 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
             const int row_len = p.nbins + 1;
             for (size_t fr = 0; fr < out_frames && cn_len; ++fr)
                 for (int r = 0; r < sj_rows; ++r) {
-                    const uint64_t *src = hrows + fr * (size_t)sj_words + (size_t)sj_rows * row_len + (size_t)r * cn_len;
+                    const uint64_t *src = hrows + fr * (size_t)sj_words + (size_t)sj_rows * row_len + (size_t)r;
                     const int cl = ordered ? p.cls[r] : (r < nc ? c0 + r : -1);
-                    if (cl < 0) continue;
-                    uint64_t *dst = &(*p.Hcn)[(fr * p.n_cls + cl) * p.n_cn];
-                    for (int k = 0; k < p.n_cn; ++k) dst[k] += src[k];
+                    if (cl >= 0) (*p.Hsplit)[fr * p.n_cls + cl] += src[0];
                 }
             for (size_t fr = 0; fr < out_frames; ++fr)
                 for (int r = 0; r < sj_rows; ++r) {
@@ -557,15 +573,15 @@ int pair_hist_run(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64_t> &H
     if (F <= batch) return pair_hist_run_batch(ctx, p, H, overflow);
     const size_t row = (size_t)p.n_cls * p.nbins;
     H.assign((p.per_frame ? (size_t)F : 1) * row, 0);
-    const size_t row_cn = (size_t)p.n_cls * p.n_cn;
-    if (p.Hcn) p.Hcn->assign((p.per_frame ? (size_t)F : 1) * row_cn, 0);
+    const size_t row_cn = (size_t)p.n_cls;
+    if (p.Hsplit) p.Hsplit->assign((p.per_frame ? (size_t)F : 1) * row_cn, 0);
     *overflow = 0;
     double ms = 0.0, aux = 0.0;
     int launches = 0;
     std::vector<uint64_t> part, part_cn;
     for (int64_t f0 = 0; f0 < F; f0 += batch) {
         PairProblem q = p;
-        if (p.Hcn) q.Hcn = &part_cn;
+        if (p.Hsplit) q.Hsplit = &part_cn;
         q.n_frames = std::min<int64_t>(batch, F - f0);
         q.d_xi = p.d_xi + (size_t)f0 * 3 * p.ni;
         q.d_xj = p.d_xj + (size_t)f0 * 3 * p.nj;
@@ -584,11 +600,11 @@ int pair_hist_run(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64_t> &H
             std::copy(part.begin(), part.end(), H.begin() + (size_t)f0 * row);
         else
             for (size_t k = 0; k < row; ++k) H[k] += part[k];
-        if (p.Hcn) {
+        if (p.Hsplit) {
             if (p.per_frame)
-                std::copy(part_cn.begin(), part_cn.end(), p.Hcn->begin() + (size_t)f0 * row_cn);
+                std::copy(part_cn.begin(), part_cn.end(), p.Hsplit->begin() + (size_t)f0 * row_cn);
             else
-                for (size_t k = 0; k < row_cn; ++k) (*p.Hcn)[k] += part_cn[k];
+                for (size_t k = 0; k < row_cn; ++k) (*p.Hsplit)[k] += part_cn[k];
         }
     }
     ctx->last_ms = ms;
@@ -705,9 +721,9 @@ struct RelJob {
     double bin_size;
     int per_frame;
     unsigned long long *dev_out = nullptr;  // see PairProblem::dev_out
-    int n_cn = 0;                           // see PairProblem::n_cn
-    const double *cn_edges = nullptr;
-    std::vector<uint64_t> *Hcn = nullptr;
+    const double *cn_rc2 = nullptr;           // mdhip_rdf_cn_atomic: coordination cutoff^2 per relation, host [n_rel]
+    std::vector<uint64_t> *Hsplit = nullptr;  // see PairProblem::Hsplit
+    std::vector<double> *cn_c2_cls = nullptr; // out: the cutoff^2 of every class
 };
 
 // Stages everything, runs the kernel and returns class histograms + the relation->class map.
@@ -780,9 +796,23 @@ int run_job(mdhip_ctx *ctx, const RelJob &j, std::vector<uint64_t> &H, std::vect
     p.gscale = j.gscale;
     p.bin_size = j.bin_size;
     p.per_frame = j.per_frame;
-    p.n_cn = j.n_cn;
-    p.cn_edges = j.cn_edges;
-    p.Hcn = j.Hcn;
+    if (j.cn_rc2) {
+        // one cutoff per class: relations that name the same pair of types with different cutoffs take two sweeps
+        std::vector<double> &c2 = *j.cn_c2_cls;
+        c2.assign(n_cls, 0.0);
+        std::vector<char> seen(n_cls, 0);
+        for (int kl = 0; kl < j.n_rel; ++kl) {
+            const int cl = rel_cls[kl];
+            if (cl < 0) continue;
+            const double v = j.cn_rc2[kl] > 0.0 ? j.cn_rc2[kl] : 0.0;
+            if (seen[cl] && c2[cl] != v) return CN_UNFUSED;
+            seen[cl] = 1;
+            c2[cl] = v;
+        }
+        p.n_cn = 1;
+        p.cn_c2_cls = c2.data();
+        p.Hsplit = j.Hsplit;
+    }
     return pair_hist_run(ctx, p, H, overflow);
 }
 
@@ -968,11 +998,8 @@ int mdhip_rdf_cn_atomic(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const
     MD_REQUIRE(nbins >= 1 && bin_size > 0.0, "nbins and bin_size must be positive");
     MD_REQUIRE(type_frame_stride == 0 || type_frame_stride == n_atoms, "type_frame_stride must be 0 or n_atoms");
     MD_REQUIRE(hist_full && (n_rel == 0 || (hist_part && cn_r_cut_sq && cn)), "NULL output or cutoff array");
-    std::vector<double> cedges;
-    std::vector<int> rank;
-    cn_edges(n_rel, cn_r_cut_sq, cedges, rank);
-    const int n_cn = (int)cedges.size() - 1;
-    bool fused = n_cn >= 1 && n_cn <= 64 && cedges.back() <= r_cut_sq && n_frames > 0 && n_atoms >= 2;
+    bool fused = n_rel > 0 && n_frames > 0 && n_atoms >= 2;
+    for (int kl = 0; kl < n_rel && fused; ++kl) fused = !(cn_r_cut_sq[kl] > r_cut_sq);
     if (fused) {
         MD_HIP(hipSetDevice(ctx->device));
         const size_t out_frames = per_frame ? (size_t)n_frames : 1;
@@ -1000,10 +1027,11 @@ int mdhip_rdf_cn_atomic(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const
         j.gscale = (float)(1.0 / bin_size);
         j.bin_size = bin_size;
         j.per_frame = per_frame;
-        std::vector<uint64_t> H, Hcn;
-        j.n_cn = n_cn;
-        j.cn_edges = cedges.data() + 1;
-        j.Hcn = &Hcn;
+        std::vector<uint64_t> H, Hsplit;
+        std::vector<double> c2_cls;
+        j.cn_rc2 = cn_r_cut_sq;
+        j.Hsplit = &Hsplit;
+        j.cn_c2_cls = &c2_cls;
         std::vector<int> rel_cls;
         int n_cls = 0;
         uint64_t ov = 0;
@@ -1024,10 +1052,18 @@ int mdhip_rdf_cn_atomic(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const
                     if (rel_cls[kl] < 0) {
                         std::fill(part, part + nbins, (uint64_t)0);
                     } else {
-                        const uint64_t *row = Hf + (size_t)rel_cls[kl] * nbins;
+                        const int cl = rel_cls[kl];
+                        const uint64_t *row = Hf + (size_t)cl * nbins;
                         for (int b = 0; b < nbins; ++b) part[b] = mult * row[b];
-                        const uint64_t *crow = &Hcn[(f * n_cls + rel_cls[kl]) * n_cn];
-                        for (int b = 0; b < rank[kl]; ++b) s += crow[b];
+                        const double c2 = c2_cls[cl];
+                        if (c2 > 0.0) {
+                            // bins below the split bin are inside the cutoff (exact edges); the split bin's share was
+                            // counted by the exact chain (a cutoff inside the overflow bin, index nbins: all bins plus
+                            // the overflow pairs below the cutoff)
+                            const int kc = (int)(std::upper_bound(use_edges, use_edges + nbins + 1, c2) - use_edges) - 1;
+                            for (int b = 0; b < kc && b < nbins; ++b) s += row[b];
+                            s += Hsplit[f * n_cls + cl];
+                        }
                     }
                     cn[f * n_rel + kl] = mult * s;
                 }

@@ -293,14 +293,19 @@ struct PkCtx {
     const double4 *ats_j;  // sorted f64 records of the frame's j set
     double Lx, Ly, Lz, rc2;
     int n_ti, n_tj;
-    // CN in the same sweep (CNG): every pair whose f32 distance is below cn_hi — i.e. every pair that can lie inside
-    // the largest coordination cutoff — goes to the queue, and the exact chain counts it below the cutoffs it is below
-    float cn_hi;
-    int n_cn;                 // number of distinct cutoffs
-    const double *cn_edges;   // their squares, ascending (global memory)
-    unsigned cn_base;         // LDS byte address of the CN counters [row][n_cn + 1]
-    int row_len;              // words per histogram row (nbins + 1)
+    // CN in the same sweep (CNG). The histogram bins are exact, so a pair in a bin below the one that holds its
+    // class's coordination cutoff is inside that cutoff and a pair in a bin above it is not: only the pairs of that one
+    // SPLIT bin need the exact comparison rsq < cutoff^2. Their histogram words are flagged (one bit per word); a
+    // pair that the sweep has binned into a flagged word is queued as a "CN only" entry, and the exact chain counts it
+    // in its row's split counter when it is inside the cutoff. The host adds the bins below the split bin.
+    const unsigned *cn_kc;     // LDS: per histogram row the LDS byte address of its split-bin word (~0u: none), [rows]
+    const unsigned *cn_kc_me;  // this lane's part of it: ordered rows &cn_kc[ti * n_tj] (index tj); class rows: the table
+                               // [n_tj][n_ti] of split-word addresses beside the row table, &tab[ti] (index = rowtab's)
+    const double *cn_c2;       // LDS: cutoff^2 of the row's class (0: none), [rows]
+    unsigned cn_base;          // LDS byte address of the split counters [rows]
+    float inv_row_len;         // 1 / (nbins + 1)
 };
+constexpr unsigned PK_CN_ONLY = 0x80000000u;  // queue entry: already binned by the sweep, count the split bin only
 
 // d - L rint(d / L) on both halves: the image of d nearest to zero (|d| < 1.5 L). One rounding in the fma; the
 // rint may fall either way within rounding of |d| = L/2, where both images have the same magnitude.
@@ -312,9 +317,8 @@ __device__ __forceinline__ f32x2 wrap_pk(f32x2 d, f32x2 L, f32x2 iL)
 }
 
 // The exact chain for the n queued pairs: entry = (j index in the frame << 6) | lane of the i atom.
-// CNG: pairs below the largest coordination cutoff are also counted in the CN counters of their row:
-// word k = number of cutoffs^2 <= rsq (rdf_cn.py:100-119 is a strict rsq < cutoff^2 per relation; the host sums the
-// words below a relation's own cutoff).
+// CNG: a resolved pair that lands in a flagged (split) word is counted in its row's split counter when
+// rsq < cutoff^2 of the row's class (rdf_cn.py:100-119: strict); PK_CN_ONLY entries were binned by the sweep already.
 template <bool CNG>
 __device__ __forceinline__ void pk_drain(PkCtx &p, const FastCtx &c, int lane)
 {
@@ -323,7 +327,7 @@ __device__ __forceinline__ void pk_drain(PkCtx &p, const FastCtx &c, int lane)
         if (b + lane < n) {
             const unsigned e = p.queue[b + lane];
             const double4 ri = p.ats_i[e & 63u];
-            const double4 rj = p.ats_j[e >> 6];
+            const double4 rj = p.ats_j[(e & ~PK_CN_ONLY) >> 6];
             const double ax = wrap_abs(ri.x - rj.x, p.Lx);
             const double ay = wrap_abs(ri.y - rj.y, p.Ly);
             const double az = wrap_abs(ri.z - rj.z, p.Lz);
@@ -343,16 +347,16 @@ __device__ __forceinline__ void pk_drain(PkCtx &p, const FastCtx &c, int lane)
                     k = koff + (rsq < c.edges[kk] ? kk - 1 : kk);
                 }
                 const unsigned addr = ((unsigned)k << 2) + rowbase;
-                asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"(1u) : "memory");
-                if (CNG && rsq < p.cn_edges[p.n_cn - 1]) {
-                    int kc = 0;
-                    for (int e = 0; e < p.n_cn; ++e) kc += rsq >= p.cn_edges[e] ? 1 : 0;
-                    // row index: ordered rows (ti, tj); class rows: the class of the pair from its row address
-                    const unsigned row = p.rowtab ? (rowbase - c.lds_base) / ((unsigned)p.row_len * 4u)
-                                                  : (unsigned)ti * (unsigned)p.n_tj +
-                                                        (unsigned)__double2loint(rj.w) / (unsigned)p.n_ti;
-                    const unsigned caddr = p.cn_base + (row * (unsigned)(p.n_cn + 1) + (unsigned)kc) * 4u;
-                    asm volatile("ds_add_u32 %0, %1" ::"v"(caddr), "v"(1u) : "memory");
+                if (!CNG || !(e & PK_CN_ONLY)) asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"(1u) : "memory");
+                if (CNG) {
+                    // row = word / row_len without a division (word < 2^20, the product is within 1e-3 of the quotient:
+                    // truncation after adding half a word is exact)
+                    const unsigned w = (addr - c.lds_base) >> 2;
+                    const unsigned row = (unsigned)(((float)w + 0.5f) * p.inv_row_len);
+                    if (p.cn_kc[row] == addr && rsq < p.cn_c2[row]) {
+                        const unsigned caddr = p.cn_base + row * 4u;
+                        asm volatile("ds_add_u32 %0, %1" ::"v"(caddr), "v"(1u) : "memory");
+                    }
                 }
             }
         }
@@ -389,8 +393,8 @@ __device__ __forceinline__ RelQ load_relq(const float *__restrict__ p)
 // exec is restored before the block ends; v_sqrt_f32 needs one wait state before its result is read.
 // CUTG: the cutoff does not sit on a bin edge, so the band of an edge does not decide in/out of the cutoff: lanes whose
 // f32 distance reaches the cutoff's own error band (sqrt(rsq32) >= cut_lo) are ambiguous too (+1 VALU, +1 SALU).
-// CNG: coordination numbers ride on the same sweep: lanes whose f32 distance is below cn_hi (the largest coordination
-// cutoff plus the error bound) are ambiguous as well — the exact chain bins them AND counts them (+1 VALU, +1 SALU).
+// RET: also hand back the LDS address every lane computed and the mask of the lanes that added there (the CN check of
+// the groups near the wave looks those words up in the flag bits: +1 SALU).
 #define BP_HEAD                                      \
     "v_cmp_gt_f32 vcc, %[rc2], %[rsq]\n\t"           \
     "s_mov_b64 %[amb], 0\n\t"                        \
@@ -399,7 +403,6 @@ __device__ __forceinline__ RelQ load_relq(const float *__restrict__ p)
     "v_sqrt_f32 %[t], %[rsq]\n\t"                    \
     "s_nop 0\n\t"
 #define BP_CUT "v_cmp_ge_f32 %[m2], %[t], %[cl]\n\t"
-#define BP_CN "v_cmp_lt_f32 %[m3], %[t], %[ch]\n\t"
 #define BP_MID                                       \
     "v_fma_f32 %[t], %[t], %[gs], %[no]\n\t"         \
     "v_fract_f32 %[fr], %[t]\n\t"                    \
@@ -409,44 +412,48 @@ __device__ __forceinline__ RelQ load_relq(const float *__restrict__ p)
 #define BP_TAIL                                      \
     "s_andn2_b64 %[amb], exec, vcc\n\t"              \
     "s_and_b64 exec, exec, vcc\n\t"                  \
-    "ds_add_u32 %[t], %[one]\n\t"                    \
-    "1:\n\t"                                         \
+    "ds_add_u32 %[t], %[one]\n\t"
+#define BP_END       \
+    "1:\n\t"         \
     "s_mov_b64 exec, %[save]"
-template <bool CUTG, bool CNG>
+template <bool CUTG, bool RET>
 __device__ __forceinline__ unsigned long long bin_pair(float rsq, float rc2hi, float gscale, float nearoff, float near2,
-                                                       unsigned rowbase, float cut_lo, float cn_hi)
+                                                       unsigned rowbase, float cut_lo, unsigned long long &done,
+                                                       unsigned &addr)
 {
     unsigned long long amb, save;
     float t, fr;
-    if (CUTG && CNG) {
-        unsigned long long m2, m3;
-        asm volatile(BP_HEAD BP_CUT BP_CN BP_MID "s_andn2_b64 vcc, vcc, %[m2]\n\t"
-                                                 "s_andn2_b64 vcc, vcc, %[m3]\n\t" BP_TAIL
-                     : [amb] "=&s"(amb), [save] "=&s"(save), [m2] "=&s"(m2), [m3] "=&s"(m3), [t] "=&v"(t), [fr] "=&v"(fr)
-                     : [rc2] "s"(rc2hi), [rsq] "v"(rsq), [gs] "v"(gscale), [no] "s"(nearoff), [n2] "v"(near2),
-                       [rb] "v"(rowbase), [one] "v"(1u), [cl] "v"(cut_lo), [ch] "v"(cn_hi)
-                     : "vcc", "scc", "memory");
+    if (RET) {
+        unsigned long long dn;
+        if (CUTG) {
+            unsigned long long m2;
+            asm volatile("s_mov_b64 %[dn], 0\n\t" BP_HEAD BP_CUT BP_MID "s_andn2_b64 vcc, vcc, %[m2]\n\t" BP_TAIL
+                         "s_mov_b64 %[dn], exec\n\t" BP_END
+                         : [amb] "=&s"(amb), [save] "=&s"(save), [m2] "=&s"(m2), [dn] "=&s"(dn), [t] "=&v"(t), [fr] "=&v"(fr)
+                         : [rc2] "s"(rc2hi), [rsq] "v"(rsq), [gs] "v"(gscale), [no] "s"(nearoff), [n2] "v"(near2),
+                           [rb] "v"(rowbase), [one] "v"(1u), [cl] "v"(cut_lo)
+                         : "vcc", "scc", "memory");
+        } else {
+            asm volatile("s_mov_b64 %[dn], 0\n\t" BP_HEAD BP_MID BP_TAIL "s_mov_b64 %[dn], exec\n\t" BP_END
+                         : [amb] "=&s"(amb), [save] "=&s"(save), [dn] "=&s"(dn), [t] "=&v"(t), [fr] "=&v"(fr)
+                         : [rc2] "s"(rc2hi), [rsq] "v"(rsq), [gs] "v"(gscale), [no] "s"(nearoff), [n2] "v"(near2),
+                           [rb] "v"(rowbase), [one] "v"(1u)
+                         : "vcc", "scc", "memory");
+        }
+        done = dn;
+        addr = __float_as_uint(t);
         return amb;
     }
     if (CUTG) {
         unsigned long long m2;
-        asm volatile(BP_HEAD BP_CUT BP_MID "s_andn2_b64 vcc, vcc, %[m2]\n\t" BP_TAIL
+        asm volatile(BP_HEAD BP_CUT BP_MID "s_andn2_b64 vcc, vcc, %[m2]\n\t" BP_TAIL BP_END
                      : [amb] "=&s"(amb), [save] "=&s"(save), [m2] "=&s"(m2), [t] "=&v"(t), [fr] "=&v"(fr)
                      : [rc2] "s"(rc2hi), [rsq] "v"(rsq), [gs] "v"(gscale), [no] "s"(nearoff), [n2] "v"(near2),
                        [rb] "v"(rowbase), [one] "v"(1u), [cl] "v"(cut_lo)
                      : "vcc", "scc", "memory");
         return amb;
     }
-    if (CNG) {
-        unsigned long long m3;
-        asm volatile(BP_HEAD BP_CN BP_MID "s_andn2_b64 vcc, vcc, %[m3]\n\t" BP_TAIL
-                     : [amb] "=&s"(amb), [save] "=&s"(save), [m3] "=&s"(m3), [t] "=&v"(t), [fr] "=&v"(fr)
-                     : [rc2] "s"(rc2hi), [rsq] "v"(rsq), [gs] "v"(gscale), [no] "s"(nearoff), [n2] "v"(near2),
-                       [rb] "v"(rowbase), [one] "v"(1u), [ch] "v"(cn_hi)
-                     : "vcc", "scc", "memory");
-        return amb;
-    }
-    asm volatile(BP_HEAD BP_MID BP_TAIL
+    asm volatile(BP_HEAD BP_MID BP_TAIL BP_END
                  : [amb] "=&s"(amb), [save] "=&s"(save), [t] "=&v"(t), [fr] "=&v"(fr)
                  : [rc2] "s"(rc2hi), [rsq] "v"(rsq), [gs] "v"(gscale), [no] "s"(nearoff), [n2] "v"(near2), [rb] "v"(rowbase),
                    [one] "v"(1u)
@@ -455,9 +462,9 @@ __device__ __forceinline__ unsigned long long bin_pair(float rsq, float rc2hi, f
 }
 #undef BP_HEAD
 #undef BP_CUT
-#undef BP_CN
 #undef BP_MID
 #undef BP_TAIL
+#undef BP_END
 
 // The four j atoms of one group against the wave's 64 i atoms.
 // VAR: bit k = axis k takes the per-pair f32 wrap. jidx0 = index of the group's first atom in the frame's j set.
@@ -466,6 +473,8 @@ __device__ __forceinline__ unsigned long long bin_pair(float rsq, float rc2hi, f
 // them (lgkmcnt(0)) before the first use of `rq`: that wait has to come before the prefetch is issued — the two
 // empty asm statements pin that order (the first depends on dx, i.e. on a use of rq) — and is free, because rq was
 // itself prefetched during the previous sweep.
+// CNG: the group is near enough to the wave to hold pairs of a CN split bin: every pair the sweep bins is looked up in
+// the flag bits, and the ones in a flagged word are queued as PK_CN_ONLY entries.
 template <bool DIAG, int VAR, bool PF, bool CUTG, bool ROWS, bool CNG>
 __device__ __forceinline__ void sweep_group_pk(const RelQ &rq, int jidx0, int local0, PkCtx &p, const FastCtx &c,
                                                int lane_in_tile, int lane, const float *next_p, RelQ &next)
@@ -507,7 +516,32 @@ __device__ __forceinline__ void sweep_group_pk(const RelQ &rq, int jidx0, int lo
             const unsigned rowbase = ROWS ? row[2 * h + u] : c.rowbase_me;
             float r2 = rsq[u];
             if (DIAG) r2 = local0 + 2 * h + u > lane_in_tile ? r2 : 3.0e38f;  // i < j inside the diagonal tile
-            const unsigned long long amb = bin_pair<CUTG, CNG>(r2, p.rc2hi, c.gscale, nearoff, c.near2, rowbase, p.cut_lo, p.cn_hi);
+            unsigned long long done = 0;
+            unsigned addr = 0, kaddr = 0;
+            if (CNG) {
+                // the split-bin word of the row (ti of this lane, tj of this j atom), looked up BEFORE the pair block so
+                // that the LDS read runs under it. Ordered rows: tj from the addend near + tj * row_len (near < 1: the
+                // truncated quotient is tj); class rows: the row table's own index. (Hoisting the four lookups of a
+                // group costs 4 VGPRs, which the 80-register budget pays for with spills: measured slower.)
+                kaddr = ROWS ? p.cn_kc_me[__float_as_uint(u ? rb[3] : rb[2])]
+                             : p.cn_kc_me[(int)(nearoff * p.inv_row_len)];
+            }
+            const unsigned long long amb = bin_pair<CUTG, CNG>(r2, p.rc2hi, c.gscale, nearoff, c.near2, rowbase, p.cut_lo, done, addr);
+            if (CNG && done) {  // wave-uniform
+                const unsigned long long hm = __builtin_amdgcn_ballot_w64(addr == kaddr) & done;
+                if (hm) {
+                    const bool hit = (hm >> lane) & 1ull;
+                    if (hit) {
+                        const int pos = p.qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32),
+                                                                              __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0u));
+                        if (pos < PK_QCAP)
+                            p.queue[pos] = PK_CN_ONLY | ((unsigned)(jidx0 + 2 * h + u) << 6) | (unsigned)lane;
+                        else
+                            atomicAdd(p.lost, 1ull);
+                    }
+                    p.qn += __builtin_popcountll(hm);
+                }
+            }
             if (amb) {  // wave-uniform, rare: some lane's pair is inside the error band -> the exact chain, later
                 // (the copy through a volatile asm keeps the per-lane test inside this branch: the compiler would
                 // otherwise fold both conditions into one divergent branch and pay 3 VALU per pair for it)
@@ -544,9 +578,8 @@ __device__ __forceinline__ bool axis_plain(float wlo, float whi, float glo, floa
 // One work item of the packed-f32 sweep (ordered-pair rows; atom-atom or atoms x sites): the 64 i atoms of wave `wq` of tile I of
 // frame f against slice `split` of the tile's neighbour list.
 template <bool CUTG, bool ROWS, bool CNG>
-__device__ __forceinline__ void sj_item_pk(const PairArgs &a, FastCtx &c, const unsigned *s_row, unsigned *queue, int f,
-                                           int I, int wq,
-                                           int split, int lane)
+__device__ __forceinline__ void sj_item_pk(const PairArgs &a, FastCtx &c, const unsigned *s_row, unsigned *queue,
+                                           const unsigned *cn_lds, int f, int I, int wq, int split, int lane)
 {
     const long long n_pad = (long long)a.nTi * TILE, n_pad_j = (long long)a.nTj * TILE;
     const long long rowid = (long long)f * a.nTi + I;
@@ -605,11 +638,16 @@ __device__ __forceinline__ void sj_item_pk(const PairArgs &a, FastCtx &c, const 
     p.rc2 = a.rc2;
     p.n_ti = a.n_ti;
     p.n_tj = a.n_tj;
-    p.cn_hi = a.cn_hi;
-    p.n_cn = a.n_cn;
-    p.cn_edges = a.cn_edges;
-    p.cn_base = c.lds_base + (unsigned)((ROWS ? a.n_cls + 1 : a.n_ti * a.n_tj) * (a.nbins + 1)) * 4u;
-    p.row_len = a.nbins + 1;
+    if (CNG) {
+        // LDS behind the queues: split-word address per row | cutoff^2 per row | (class rows) split-word address [tj][ti]
+        const int rows = ROWS ? a.n_cls + 1 : a.n_ti * a.n_tj;
+        const int ti_me = (int)((unsigned)__double_as_longlong(ats[ig].w)) / a.n_ti;
+        p.cn_kc = cn_lds;
+        p.cn_c2 = reinterpret_cast<const double *>(cn_lds + ((rows + 1) & ~1));
+        p.cn_kc_me = ROWS ? cn_lds + ((rows + 1) & ~1) + 2 * rows + ti_me : cn_lds + ti_me * a.n_tj;
+        p.cn_base = c.lds_base + (unsigned)(rows * (a.nbins + 1)) * 4u;
+    }
+    p.inv_row_len = 1.0f / (float)(a.nbins + 1);
     const float *rel_f = a.rel + (long long)f * n_pad_j * 4;  // 4 floats per j atom
     const int gpb = 1 << a.cen_shift;                        // groups per centre block
     const int nblk = (TILE / SJ_GROUP) >> a.cen_shift;       // centre blocks per tile
@@ -625,6 +663,8 @@ __device__ __forceinline__ void sj_item_pk(const PairArgs &a, FastCtx &c, const 
         const bool keep = wlo.w > 0.f && glo.w > 0.f && gx * gx + gy * gy + gz * gz < a.reach * a.reach;
         const unsigned long long km = __builtin_amdgcn_ballot_w64(keep);
         if (!km) continue;
+        // CNG: groups whose box comes within the largest split bin of the wave's box are swept with the flag check
+        const bool nearg = CNG && gx * gx + gy * gy + gz * gz < a.cn_reach * a.cn_reach;
         const float *rtile = rel_f + (long long)J * TILE * 4;
         const bool diag = a.tri && J == I;
         // variant of this lane's group: the axes on which some |d'| may exceed L - r_cut (per-pair wrap needed)
@@ -692,7 +732,7 @@ __device__ __forceinline__ void sj_item_pk(const PairArgs &a, FastCtx &c, const 
             if (!diag) {
                 // the common variant (no per-pair wrap), software-pipelined: the records of the next group are
                 // loaded while the current group is swept; two buffers, loop unrolled by two (no register copies)
-                unsigned long long mk = __builtin_amdgcn_ballot_w64(keep && var == 0u) & bm;
+                unsigned long long mk = __builtin_amdgcn_ballot_w64(keep && var == 0u && !nearg) & bm;
                 if (mk) {
                     int gA = __builtin_ctzll(mk);
                     mk &= mk - 1;
@@ -702,40 +742,56 @@ __device__ __forceinline__ void sj_item_pk(const PairArgs &a, FastCtx &c, const 
                         const bool moreB = mk != 0;
                         const int gB = moreB ? __builtin_ctzll(mk) : gA;
                         mk &= mk - 1;
-                        sweep_group_pk<false, 0, true, CUTG, ROWS, CNG>(qA, jbase + gA * SJ_GROUP, gA * SJ_GROUP, p, c, lane_in_tile, lane,
+                        sweep_group_pk<false, 0, true, CUTG, ROWS, false>(qA, jbase + gA * SJ_GROUP, gA * SJ_GROUP, p, c, lane_in_tile, lane,
                                                        rtile + gB * SJ_GROUP * 4, qB);
                         if (!moreB) break;
                         PK_DRAIN_CHECK();
                         const bool moreA = mk != 0;
                         gA = moreA ? __builtin_ctzll(mk) : gB;
                         mk &= mk - 1;
-                        sweep_group_pk<false, 0, true, CUTG, ROWS, CNG>(qB, jbase + gB * SJ_GROUP, gB * SJ_GROUP, p, c, lane_in_tile, lane,
+                        sweep_group_pk<false, 0, true, CUTG, ROWS, false>(qB, jbase + gB * SJ_GROUP, gB * SJ_GROUP, p, c, lane_in_tile, lane,
                                                        rtile + gA * SJ_GROUP * 4, qA);
                         if (!moreA) break;
                     }
                 }
             }
-            for (unsigned A = diag ? 8u : 1u; A <= (diag ? 9u : 7u); ++A) {
-                unsigned long long mk = __builtin_amdgcn_ballot_w64(keep && var == A) & bm;
+            // the other variants (per-pair wrap on some axis, the diagonal tile) and, with CNG, the groups near the
+            // wave (plain variant included): not pipelined
+#define PK_SWEEP_CASES(CN)                                                                                             \
+    switch (A) {                                                                                                       \
+    case 1: sweep_group_pk<false, 1, false, CUTG, ROWS, CN>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break; \
+    case 2: sweep_group_pk<false, 2, false, CUTG, ROWS, CN>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break; \
+    case 3: sweep_group_pk<false, 3, false, CUTG, ROWS, CN>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break; \
+    case 4: sweep_group_pk<false, 4, false, CUTG, ROWS, CN>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break; \
+    case 5: sweep_group_pk<false, 5, false, CUTG, ROWS, CN>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break; \
+    case 6: sweep_group_pk<false, 6, false, CUTG, ROWS, CN>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break; \
+    case 7: sweep_group_pk<false, 7, false, CUTG, ROWS, CN>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break; \
+    case 9: sweep_group_pk<true, 0, false, CUTG, ROWS, CN>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;  \
+    case 8: sweep_group_pk<true, 7, false, CUTG, ROWS, CN>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;  \
+    default: break;                                                                                                    \
+    }
+            const unsigned long long nm = CNG ? __builtin_amdgcn_ballot_w64(nearg) : 0ull;
+            for (unsigned A = diag ? 8u : (CNG ? 0u : 1u); A <= (diag ? 9u : 7u); ++A) {
+                unsigned long long mk = __builtin_amdgcn_ballot_w64(keep && var == A && (A != 0u || nearg)) & bm;
                 while (mk) {
                     const int g = __builtin_ctzll(mk);
                     mk &= mk - 1;
                     RelQ q = load_relq(rtile + g * SJ_GROUP * 4), qnone;
                     PK_DRAIN_CHECK();
                     const int j0 = jbase + g * SJ_GROUP, l0 = g * SJ_GROUP;
-                    switch (A) {
-                    case 1: sweep_group_pk<false, 1, false, CUTG, ROWS, CNG>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
-                    case 2: sweep_group_pk<false, 2, false, CUTG, ROWS, CNG>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
-                    case 3: sweep_group_pk<false, 3, false, CUTG, ROWS, CNG>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
-                    case 4: sweep_group_pk<false, 4, false, CUTG, ROWS, CNG>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
-                    case 5: sweep_group_pk<false, 5, false, CUTG, ROWS, CNG>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
-                    case 6: sweep_group_pk<false, 6, false, CUTG, ROWS, CNG>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
-                    case 7: sweep_group_pk<false, 7, false, CUTG, ROWS, CNG>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
-                    case 9: sweep_group_pk<true, 0, false, CUTG, ROWS, CNG>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
-                    default: sweep_group_pk<true, 7, false, CUTG, ROWS, CNG>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;
+                    if constexpr (CNG) {
+                        if ((nm >> g) & 1ull) {
+                            if (A == 0u)
+                                sweep_group_pk<false, 0, false, CUTG, ROWS, true>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone);
+                            else
+                                PK_SWEEP_CASES(true)
+                            continue;
+                        }
                     }
+                    PK_SWEEP_CASES(false)
                 }
             }
+#undef PK_SWEEP_CASES
 #undef PK_DRAIN_CHECK
         }
     }
@@ -757,8 +813,8 @@ __device__ __forceinline__ bool work_loop_sane(const PairArgs &a, long long iter
 // records live in one L2 — and the block flushes its LDS histograms once, when its four waves have run
 // dry. Every wave leaves the loop as soon as the counter passes the item count.
 // PERSIST = false (per-frame output): block = (frame, tile, list slice), one flush per block.
-// CNG (packed-f32 modes only): coordination numbers from the same sweep; the CN counters [rows][n_cn + 1] sit right
-// behind the histogram rows in LDS and travel with them through the slices.
+// CNG (packed-f32 modes only): coordination numbers from the same sweep; one split counter per row sits right behind
+// the histogram rows in LDS and travels with them through the slices.
 template <int MODE, bool PERSIST, bool CNG = false>
 __global__ __launch_bounds__(MODE >= 3 ? PK_THREADS : TILE, MODE >= 3 ? PK_WAVES_PER_SIMD : 1) void pair_hist_sj_kernel(const PairArgs a)
 {
@@ -777,7 +833,8 @@ __global__ __launch_bounds__(MODE >= 3 ? PK_THREADS : TILE, MODE >= 3 ? PK_WAVES
     // ---- LDS: hist | (CN edges) | row table ----
     // MODE 2: one row per ORDERED type pair (ti, tj), addressed without a table (see sweep_group_sj)
     const int row_len = a.nbins + 1;
-    const int hist_words = (ORDERED ? a.n_ti * a.n_tj : a.n_cls + 1) * (row_len + (CNG ? a.n_cn + 1 : 0));
+    const int n_rows = ORDERED ? a.n_ti * a.n_tj : a.n_cls + 1;
+    const int hist_words = n_rows * (row_len + (CNG ? 1 : 0));  // CNG: + one split counter per row, behind the rows
     unsigned *s_hist = reinterpret_cast<unsigned *>(smem);
     size_t off = ((size_t)hist_words * 4 + 15) & ~size_t(15);
     double *s_edges = reinterpret_cast<double *>(smem + off);
@@ -785,6 +842,9 @@ __global__ __launch_bounds__(MODE >= 3 ? PK_THREADS : TILE, MODE >= 3 ? PK_WAVES
     unsigned *s_row = reinterpret_cast<unsigned *>(smem + off);  // class rows: the row table [n_tj][n_ti]
     // packed-f32 modes: the waves' queues of deferred pairs, behind the row table when there is one
     unsigned *s_queue = s_row + (PK_ROWS ? (a.n_ti * a.n_tj + 3) / 4 * 4 : 0);
+    // CNG, behind the queues: the LDS address of every row's split-bin word (the host gives word indices; -1: none),
+    // the rows' cutoffs^2 (8-byte aligned) and, for class rows, the split-word addresses as a table [n_tj][n_ti]
+    unsigned *s_cn = s_queue + (MODE >= 3 ? (BS / 64) * PK_QSTRIDE : 0);
     const unsigned lds_base =
         (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char *)smem;
     for (int k = tid; k < hist_words; k += BS) s_hist[k] = 0u;
@@ -814,6 +874,21 @@ __global__ __launch_bounds__(MODE >= 3 ? PK_THREADS : TILE, MODE >= 3 ? PK_WAVES
     c.nbins = a.nbins;
     c.lds_base = lds_base;
     c.rowbase_me = lds_base;
+    if (CNG) {
+        const int pad = (n_rows + 1) & ~1;
+        for (int k = tid; k < n_rows; k += BS) {
+            const int w = (int)a.cn_tab[k];
+            s_cn[k] = w < 0 ? ~0u : lds_base + (unsigned)w * 4u;
+        }
+        for (int k = tid; k < 2 * n_rows; k += BS) s_cn[pad + k] = a.cn_tab[pad + k];
+        if (PK_ROWS)
+            for (int k = tid; k < a.n_ti * a.n_tj; k += BS) {
+                const int ti = k % a.n_ti, tj = k / a.n_ti;
+                const unsigned cl = a.cls[ti * a.n_tj + tj];
+                const int w = (int)a.cn_tab[cl == 0xFFu ? a.n_cls : (int)cl];
+                s_cn[pad + 2 * n_rows + k] = w < 0 ? ~0u : lds_base + (unsigned)w * 4u;
+            }
+    }
     __syncthreads();  // tables ready; from here on the waves do not synchronise until the flush
 
     const int lane = tid & 63;
@@ -832,8 +907,8 @@ __global__ __launch_bounds__(MODE >= 3 ? PK_THREADS : TILE, MODE >= 3 ? PK_WAVES
             const int fx = (int)(it / (unsigned)ipf), r = (int)(it % (unsigned)ipf);
             const int split = r % a.jsplit, wI = r / a.jsplit;
             if (MODE >= 3)
-                sj_item_pk<MODE == 4 || MODE == 6, PK_ROWS, CNG>(a, c, s_row, s_queue + (tid >> 6) * PK_QSTRIDE, fx * 8 + xcd, wI >> 2,
-                                                            wI & 3, split, lane);
+                sj_item_pk<MODE == 4 || MODE == 6, PK_ROWS, CNG>(a, c, s_row, s_queue + (tid >> 6) * PK_QSTRIDE, s_cn, fx * 8 + xcd,
+                                                                 wI >> 2, wI & 3, split, lane);
             else
                 sj_item<MODE >= 3 ? 2 : MODE>(a, c, s_row, fx * 8 + xcd, wI >> 2, wI & 3, split, lane);
         }
@@ -853,8 +928,8 @@ __global__ __launch_bounds__(MODE >= 3 ? PK_THREADS : TILE, MODE >= 3 ? PK_WAVES
             if (it >= ipf) break;
             const int split = (int)(it % (unsigned)a.jsplit), wI = (int)(it / (unsigned)a.jsplit);
             if (MODE >= 3)
-                sj_item_pk<MODE == 4 || MODE == 6, PK_ROWS, CNG>(a, c, s_row, s_queue + (tid >> 6) * PK_QSTRIDE, f, wI >> 2, wI & 3, split,
-                                                            lane);
+                sj_item_pk<MODE == 4 || MODE == 6, PK_ROWS, CNG>(a, c, s_row, s_queue + (tid >> 6) * PK_QSTRIDE, s_cn, f, wI >> 2, wI & 3,
+                                                                 split, lane);
             else
                 sj_item<MODE >= 3 ? 2 : MODE>(a, c, s_row, f, wI >> 2, wI & 3, split, lane);
         }
@@ -943,16 +1018,24 @@ size_t lds_bytes_sj_ordered(int nbins, int n_ti, int n_tj)
 
 int sj_block_threads(int mode) { return mode >= 3 ? PK_THREADS : TILE; }
 
+// CN tables behind the queues: split-word address per row (padded to 8 bytes) + one double per row + (class rows)
+// the split-word addresses as a table [n_tj][n_ti]
+static size_t cn_table_bytes(int rows, int n_tab)
+{
+    return ((((size_t)rows + 1) & ~size_t(1)) + 2 * (size_t)rows + (size_t)n_tab) * 4;
+}
+
 size_t lds_bytes_sj_pk_rows(int nbins, int n_cls, int n_ti, int n_tj, int n_cn)
 {
-    const size_t hist = ((size_t)(n_cls + 1) * (nbins + 1 + (n_cn ? n_cn + 1 : 0)) * 4 + 15) & ~size_t(15);
-    return hist + (size_t)((n_ti * n_tj + 3) / 4 * 4) * 4 + (size_t)(PK_THREADS / 64) * PK_QSTRIDE * 4;
+    const size_t hist = ((size_t)(n_cls + 1) * (nbins + 1 + (n_cn ? 1 : 0)) * 4 + 15) & ~size_t(15);
+    return hist + (size_t)((n_ti * n_tj + 3) / 4 * 4) * 4 + (size_t)(PK_THREADS / 64) * PK_QSTRIDE * 4 +
+           (n_cn ? cn_table_bytes(n_cls + 1, n_ti * n_tj) : 0);
 }
 
 size_t lds_bytes_sj_pk(int nbins, int n_ti, int n_tj, int n_cn)
 {
-    return (((size_t)n_ti * n_tj * (nbins + 1 + (n_cn ? n_cn + 1 : 0)) * 4 + 15) & ~size_t(15)) +
-           (size_t)(PK_THREADS / 64) * PK_QSTRIDE * 4;
+    return (((size_t)n_ti * n_tj * (nbins + 1 + (n_cn ? 1 : 0)) * 4 + 15) & ~size_t(15)) +
+           (size_t)(PK_THREADS / 64) * PK_QSTRIDE * 4 + (n_cn ? cn_table_bytes(n_ti * n_tj, 0) : 0);
 }
 
 // Error bound of the packed-f32 bin guess, in bins (see the MODE 3 header). u = 2^-24 (f32 round to nearest).
