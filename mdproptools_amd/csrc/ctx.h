@@ -92,6 +92,8 @@ struct mdhip_ctx {
     int opt_rdf_pk = -1;      // scalar-j RDF with ordered rows: -1/1 packed-f32 classification sweep with the exact
                               // deferred resolver (MODE 3) when its error bound allows, 0 the all-f64 sweep (MODE 2)
     int opt_rdf_sort = -1;    // spatial sort: -1 auto, 1 one block per frame (LDS counters), 0 multi-block (global counters)
+    int opt_rdf_guard = 0;    // overflow guard of the 32-bit LDS histogram words: neighbour tiles a block may sweep
+                              // per launch (0 = the real bound, 2^32 / (64 * 256) with margin; tests lower it)
     int opt_xcorr_tile = 0;
     int opt_lag_variant = 3;  // full-lag MSD: 3 (default) = autocorrelation theorem (msd_fft.hip) when its error bound
                               // stays below 1e-10, else the exact-difference kernel; 1 = series-resident LDS

@@ -199,6 +199,8 @@ int mdhip_set_option(mdhip_ctx *ctx, const char *key, int value)
         ctx->opt_rdf_pk = value;
     else if (!strcmp(key, "lag_variant"))
         ctx->opt_lag_variant = value < 0 ? 3 : value;  // -1 restores the default
+    else if (!strcmp(key, "rdf_guard"))
+        ctx->opt_rdf_guard = value < 0 ? 0 : value;
     else if (!strcmp(key, "rdf_slots"))
         ctx->opt_rdf_slots = value < 1 ? 1 : value;
     else if (!strcmp(key, "xcorr_tile"))

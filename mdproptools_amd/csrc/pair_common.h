@@ -65,7 +65,9 @@ struct PairArgs {
     // coordination numbers from the RDF sweep (pair_hist_sj_kernel<., ., true>)
     int n_cn;                    // != 0: on
     const unsigned *cn_tab;      // word index of every row's split bin (-1: none; padded to 8 bytes) | cutoff^2 per row
-    float cn_reach;              // groups whose box is farther than this from the wave's box hold no split-bin pair
+    float cn_reach;              // groups whose box is farther than this from the wave's box hold no split-bin pair    // overflow guard of the per-block 32-bit histogram words (scalar-j kernels)
+    unsigned guard_off;          // LDS byte offset of the block's tile counter (behind everything else)
+    unsigned guard_tiles;        // a block that swept more neighbour tiles than this may have wrapped a word
 };
 
 __device__ __forceinline__ double wrap_abs(double d, double L)
@@ -162,7 +164,8 @@ PairKernel sj_kernel(int mode /* 0 RDF class rows, 1 CN, 2 RDF ordered-pair rows
 // error bound (in bins) of the packed-f32 bin guess for |relative coordinates| <= s_cap per axis pair sum; 0 = not usable
 double pk_error_bound(double r_cut, double bin_size, int nbins, int n_tj, double s_cap, double l_max);
 void launch_derive_rdf(hipStream_t stream, const unsigned long long *rows, int n_rows, int nbins, const int *rowcls,
-                       int n_rel, const int *relcls, const int *relmult, unsigned long long *out);
+                       int n_rel, const int *relcls, const int *relmult, const unsigned long long *guard,
+                       unsigned long long *out);
 void launch_merge_slices(hipStream_t stream, const unsigned *slices, int hist_words, long long n_blocks, int per_frame,
                          int bpf, unsigned grid_y, unsigned long long *rows);
 

@@ -70,6 +70,7 @@ struct PairProblem {
     std::vector<uint64_t> *Hsplit = nullptr;  // out: [F|1][n_cls] pairs of the split bin with rsq < cutoff^2
 };
 constexpr int CN_UNFUSED = 1;  // (positive: not an error code of the ABI)
+constexpr int SPLIT_BATCH = 2;  // a block may have wrapped a 32-bit LDS word: run the batch again in halves
 
 // Runs the kernel over one batch of frames (in several passes when the class rows do not fit LDS) and
 // returns the class histograms on the host: H [F|1][n_cls][nbins], overflow count.
@@ -393,6 +394,12 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
                            : sj    ? lds_bytes_sj(p.nbins, nc, p.n_ti, p.n_tj, mode_cn)
                            : fast ? lds_bytes_fast(p.nbins, nc, p.n_ti, p.n_tj)
                                   : lds_bytes(p.nbins, nc, p.n_ti, p.n_tj);
+        if (sj) {
+            a.guard_off = (unsigned)((lds + 15) & ~size_t(15));
+            // one neighbour tile adds at most 64 x 256 to any one word of a block: 2^32 / 2^14 tiles, with margin
+            a.guard_tiles = ctx->opt_rdf_guard > 0 ? (unsigned)ctx->opt_rdf_guard : 250000u;
+        }
+        const size_t lds_launch = sj ? ((lds + 15) & ~size_t(15)) + 16 : lds;
         const char *kname = "";
         const int sj_mode = pk && ctx->opt_rdf_pk != 2 ? (pk_rows ? 5 : 3) + (cut_guard ? 1 : 0) : ordered ? 2 : mode_cn ? 1 : 0;
         const int bs = sj ? sj_block_threads(sj_mode) : TILE;  // threads per block
@@ -400,14 +407,14 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         PairKernel kern = sj ? sj_kernel(sj_mode, persist, p.n_cn > 0, &kname)
                              : dense_kernel(fast, p.tri, mode_cn, fast && cull, &kname);
         ctx->last_kernel = kname;
-        if (lds > 65536)
+        if (lds_launch > 65536)
             MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_launch));
         long long launch_grid = grid;
         if (sj) {
             int per_cu = 0;
             MD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), bs,
-                                                                lds));
+                                                                lds_launch));
             if (per_cu < 1) per_cu = 1;
             const long long capacity = (long long)per_cu * ctx->cu_count;
             // blocks' worth of wave items per frame (a frame has nTi * 4 * jsplit wave items)
@@ -448,7 +455,7 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
             a.slices = d_sl;
         }
         KernelTimer timer(ctx);
-        hipLaunchKernelGGL(kern, dim3((unsigned)launch_grid), dim3(bs), lds, ctx->stream, a);
+        hipLaunchKernelGGL(kern, dim3((unsigned)launch_grid), dim3(bs), lds_launch, ctx->stream, a);
         if (sj) {
             const unsigned gy = p.per_frame ? (unsigned)F : (unsigned)std::min<long long>(64, launch_grid);
             launch_merge_slices(ctx->stream, a.slices, sj_words, launch_grid, p.per_frame, a.blocks_per_frame, gy,
@@ -460,7 +467,7 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         if (sj && p.dev_out && n_pass == 1 && !p.per_frame) {
             // outputs stay on the device: rows -> full | part | overflow by derive_rdf_kernel (added to dev_out)
             const size_t tb = ((size_t)sj_rows + 2 * (size_t)p.n_rel) * 4;
-            MD_PIN(h_map, int, PIN_OUT, tb + 16);
+            MD_PIN(h_map, int, PIN_OUT, tb + 32);
             for (int r = 0; r < sj_rows; ++r) h_map[r] = ordered ? p.cls[r] : (r < nc ? c0 + r : -1);
             for (int kl = 0; kl < p.n_rel; ++kl) {
                 h_map[sj_rows + kl] = p.rel_cls[kl];
@@ -469,11 +476,12 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
             MD_WS(d_map, int, WS_AUX3, tb);
             MD_HIP(hipMemcpyAsync(d_map, h_map, tb, hipMemcpyHostToDevice, ctx->stream));
             launch_derive_rdf(ctx->stream, d_rows, sj_rows, p.nbins, d_map, p.n_rel, d_map + sj_rows,
-                              d_map + sj_rows + p.n_rel, p.dev_out);
+                              d_map + sj_rows + p.n_rel, d_misc + 3, p.dev_out);
             MD_HIP(hipGetLastError());
             uint64_t *hlost = reinterpret_cast<uint64_t *>(reinterpret_cast<unsigned char *>(h_map) + ((tb + 7) & ~size_t(7)));
-            MD_HIP(hipMemcpyAsync(hlost, d_misc + 1, 16, hipMemcpyDeviceToHost, ctx->stream));
+            MD_HIP(hipMemcpyAsync(hlost, d_misc + 1, 24, hipMemcpyDeviceToHost, ctx->stream));
             MD_HIP(hipStreamSynchronize(ctx->stream));
+            if (hlost[2]) return SPLIT_BATCH;
             if (hlost[0] || hlost[1])
                 return mdhip_fail(ctx, MDHIP_EHIP, "pair_hist: internal check failed (%llu deferred pairs lost, work loop %llu)",
                                   (unsigned long long)hlost[0], (unsigned long long)hlost[1]);
@@ -489,12 +497,13 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         }
         if (sj) {
             // D2H of the row sums (pinned staging), then rows -> classes and the overflow words on the host
-            MD_PIN(hrows, uint64_t, PIN_OUT, (out_frames * (size_t)sj_words + 2) * 8);
+            MD_PIN(hrows, uint64_t, PIN_OUT, (out_frames * (size_t)sj_words + 3) * 8);
             MD_HIP(hipMemcpyAsync(hrows, d_rows, out_frames * (size_t)sj_words * 8, hipMemcpyDeviceToHost,
                                   ctx->stream));
             uint64_t *hlost = hrows + out_frames * (size_t)sj_words;  // [0] queue overflow, [1] work-loop assertion
-            MD_HIP(hipMemcpyAsync(hlost, d_misc + 1, 16, hipMemcpyDeviceToHost, ctx->stream));
+            MD_HIP(hipMemcpyAsync(hlost, d_misc + 1, 24, hipMemcpyDeviceToHost, ctx->stream));
             MD_HIP(hipStreamSynchronize(ctx->stream));
+            if (hlost[2]) return SPLIT_BATCH;
             if (hlost[0] || hlost[1])
                 return mdhip_fail(ctx, MDHIP_EHIP, "pair_hist: internal check failed (%llu deferred pairs lost, work loop %llu)",
                                   (unsigned long long)hlost[0], (unsigned long long)hlost[1]);
@@ -570,7 +579,14 @@ int pair_hist_run(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64_t> &H
     if (batch < 1) batch = 1;
     if (batch > 32768) batch = 32768;
     if (ctx->opt_rdf_batch > 0) batch = ctx->opt_rdf_batch;
-    if (F <= batch) return pair_hist_run_batch(ctx, p, H, overflow);
+    if (F <= batch) {
+        const int rc1 = pair_hist_run_batch(ctx, p, H, overflow);
+        if (rc1 != SPLIT_BATCH) return rc1;
+        if (F == 1)
+            return mdhip_fail(ctx, MDHIP_ELIMIT, "pair_hist: one frame can overflow the 32-bit block histograms "
+                                                  "(%lld x %lld atoms)", (long long)p.ni, (long long)p.nj);
+        batch = (F + 1) / 2;
+    }
     const size_t row = (size_t)p.n_cls * p.nbins;
     H.assign((p.per_frame ? (size_t)F : 1) * row, 0);
     const size_t row_cn = (size_t)p.n_cls;
@@ -590,7 +606,7 @@ int pair_hist_run(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64_t> &H
         q.d_box = p.d_box + (size_t)f0 * 3;
         q.h_box = p.h_box + (size_t)f0 * 3;
         uint64_t ov = 0;
-        int rc = pair_hist_run_batch(ctx, q, part, &ov);
+        int rc = pair_hist_run(ctx, q, part, &ov);  // (recursion: a batch whose blocks may wrap a word is halved again)
         if (rc) return rc;
         *overflow += ov;
         ms += ctx->last_ms;

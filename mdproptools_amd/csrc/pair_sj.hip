@@ -142,9 +142,10 @@ __device__ __forceinline__ unsigned wrap_class(float wlo, float whi, float glo, 
 
 // One work item of the scalar-j sweep: the 64 i atoms of wave `wq` of tile I of frame f against slice
 // `split` of the tile's neighbour list.
+// Returns the number of neighbour tiles of the slice (the overflow guard of the 32-bit LDS words counts them).
 template <int MODE>
-__device__ __forceinline__ void sj_item(const PairArgs &a, FastCtx &c, const unsigned *s_row, int f, int I, int wq,
-                                        int split, int lane)
+__device__ __forceinline__ int sj_item(const PairArgs &a, FastCtx &c, const unsigned *s_row, int f, int I, int wq,
+                                       int split, int lane)
 {
     const long long n_pad = (long long)a.nTi * TILE, n_pad_j = (long long)a.nTj * TILE;
     const long long rowid = (long long)f * a.nTi + I;
@@ -152,7 +153,7 @@ __device__ __forceinline__ void sj_item(const PairArgs &a, FastCtx &c, const uns
     const unsigned short *row_list = a.list + rowid * a.nTj;  // (nTj == nTi for atom-atom)
     const int t_begin = (int)((long long)split * cnt / a.jsplit);
     const int t_end = (int)((long long)(split + 1) * cnt / a.jsplit);
-    if (t_begin >= t_end) return;
+    if (t_begin >= t_end) return 0;
     AxisL L;
     L.Lx = a.box[3 * f];
     L.Ly = a.box[3 * f + 1];
@@ -232,6 +233,7 @@ __device__ __forceinline__ void sj_item(const PairArgs &a, FastCtx &c, const uns
         SJ_VARIANT(7)
 #undef SJ_VARIANT
     }
+    return t_end - t_begin;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -578,7 +580,7 @@ __device__ __forceinline__ bool axis_plain(float wlo, float whi, float glo, floa
 // One work item of the packed-f32 sweep (ordered-pair rows; atom-atom or atoms x sites): the 64 i atoms of wave `wq` of tile I of
 // frame f against slice `split` of the tile's neighbour list.
 template <bool CUTG, bool ROWS, bool CNG>
-__device__ __forceinline__ void sj_item_pk(const PairArgs &a, FastCtx &c, const unsigned *s_row, unsigned *queue,
+__device__ __forceinline__ int sj_item_pk(const PairArgs &a, FastCtx &c, const unsigned *s_row, unsigned *queue,
                                            const unsigned *cn_lds, int f, int I, int wq, int split, int lane)
 {
     const long long n_pad = (long long)a.nTi * TILE, n_pad_j = (long long)a.nTj * TILE;
@@ -796,6 +798,7 @@ __device__ __forceinline__ void sj_item_pk(const PairArgs &a, FastCtx &c, const 
         }
     }
     if (p.qn > 0) pk_drain<CNG>(p, c, lane);
+    return t_end > t_begin ? t_end - t_begin : 0;
 }
 
 // Assertion at the top of every work-loop iteration: the whole wave is here (the item index is drawn by lane 0
@@ -847,6 +850,10 @@ __global__ __launch_bounds__(MODE >= 3 ? PK_THREADS : TILE, MODE >= 3 ? PK_WAVES
     unsigned *s_cn = s_queue + (MODE >= 3 ? (BS / 64) * PK_QSTRIDE : 0);
     const unsigned lds_base =
         (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char *)smem;
+    // Overflow guard of the 32-bit histogram words: the block counts the neighbour tiles its waves sweep (one tile = at
+    // most 64 x 256 increments of any one word); past a.guard_tiles it raises overflow[3] and the host splits the batch.
+    unsigned *s_guard = reinterpret_cast<unsigned *>(smem + a.guard_off);
+    if (tid == 0) *s_guard = 0u;
     for (int k = tid; k < hist_words; k += BS) s_hist[k] = 0u;
     if (!ORDERED)
         for (int k = tid; k < a.n_ti * a.n_tj; k += BS) {
@@ -906,11 +913,13 @@ __global__ __launch_bounds__(MODE >= 3 ? PK_THREADS : TILE, MODE >= 3 ? PK_WAVES
             if ((long long)it >= n_items) break;
             const int fx = (int)(it / (unsigned)ipf), r = (int)(it % (unsigned)ipf);
             const int split = r % a.jsplit, wI = r / a.jsplit;
+            int tiles;
             if (MODE >= 3)
-                sj_item_pk<MODE == 4 || MODE == 6, PK_ROWS, CNG>(a, c, s_row, s_queue + (tid >> 6) * PK_QSTRIDE, s_cn, fx * 8 + xcd,
-                                                                 wI >> 2, wI & 3, split, lane);
+                tiles = sj_item_pk<MODE == 4 || MODE == 6, PK_ROWS, CNG>(a, c, s_row, s_queue + (tid >> 6) * PK_QSTRIDE, s_cn,
+                                                                         fx * 8 + xcd, wI >> 2, wI & 3, split, lane);
             else
-                sj_item<MODE >= 3 ? 2 : MODE>(a, c, s_row, fx * 8 + xcd, wI >> 2, wI & 3, split, lane);
+                tiles = sj_item<MODE >= 3 ? 2 : MODE>(a, c, s_row, fx * 8 + xcd, wI >> 2, wI & 3, split, lane);
+            if (lane == 0) atomicAdd(s_guard, (unsigned)tiles);
         }
     } else {
         // a.blocks_per_frame blocks share one frame and flush once each into the frame's row
@@ -927,11 +936,13 @@ __global__ __launch_bounds__(MODE >= 3 ? PK_THREADS : TILE, MODE >= 3 ? PK_WAVES
             it = (unsigned)__builtin_amdgcn_readfirstlane((int)it);
             if (it >= ipf) break;
             const int split = (int)(it % (unsigned)a.jsplit), wI = (int)(it / (unsigned)a.jsplit);
+            int tiles;
             if (MODE >= 3)
-                sj_item_pk<MODE == 4 || MODE == 6, PK_ROWS, CNG>(a, c, s_row, s_queue + (tid >> 6) * PK_QSTRIDE, s_cn, f, wI >> 2, wI & 3,
-                                                                 split, lane);
+                tiles = sj_item_pk<MODE == 4 || MODE == 6, PK_ROWS, CNG>(a, c, s_row, s_queue + (tid >> 6) * PK_QSTRIDE, s_cn, f, wI >> 2,
+                                                                         wI & 3, split, lane);
             else
-                sj_item<MODE >= 3 ? 2 : MODE>(a, c, s_row, f, wI >> 2, wI & 3, split, lane);
+                tiles = sj_item<MODE >= 3 ? 2 : MODE>(a, c, s_row, f, wI >> 2, wI & 3, split, lane);
+            if (lane == 0) atomicAdd(s_guard, (unsigned)tiles);
         }
     }
 
@@ -941,6 +952,7 @@ __global__ __launch_bounds__(MODE >= 3 ? PK_THREADS : TILE, MODE >= 3 ? PK_WAVES
     (void)f_out;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
+    if (tid == 0 && *s_guard > a.guard_tiles) atomicOr(a.overflow + 3, 1ull);
     unsigned *slice = a.slices + (size_t)bid * (size_t)hist_words;
     for (int w = tid; w < hist_words; w += BS) slice[w] = s_hist[w];
 }
@@ -974,8 +986,10 @@ __global__ void merge_slices_kernel(const unsigned *__restrict__ slices, int his
 // blockIdx.y = 0: full, 1..n_rel: part, n_rel + 1: overflow. rowcls[r] = class of row r (-1: not counted).
 __global__ void derive_rdf_kernel(const unsigned long long *__restrict__ rows, int n_rows, int nbins,
                                   const int *__restrict__ rowcls, int n_rel, const int *__restrict__ relcls,
-                                  const int *__restrict__ relmult, unsigned long long *__restrict__ out)
+                                  const int *__restrict__ relmult, const unsigned long long *__restrict__ guard,
+                                  unsigned long long *__restrict__ out)
 {
+    if (*guard) return;  // a block may have wrapped a 32-bit word: the host runs this batch again in halves
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     const int row_len = nbins + 1;
@@ -1005,10 +1019,11 @@ __global__ void derive_rdf_kernel(const unsigned long long *__restrict__ rows, i
 }  // namespace
 
 void launch_derive_rdf(hipStream_t stream, const unsigned long long *rows, int n_rows, int nbins, const int *rowcls,
-                       int n_rel, const int *relcls, const int *relmult, unsigned long long *out)
+                       int n_rel, const int *relcls, const int *relmult, const unsigned long long *guard,
+                       unsigned long long *out)
 {
     hipLaunchKernelGGL(derive_rdf_kernel, dim3((unsigned)((nbins + 127) / 128), (unsigned)(n_rel + 2)), dim3(128), 0,
-                       stream, rows, n_rows, nbins, rowcls, n_rel, relcls, relmult, out);
+                       stream, rows, n_rows, nbins, rowcls, n_rel, relcls, relmult, guard, out);
 }
 
 size_t lds_bytes_sj_ordered(int nbins, int n_ti, int n_tj)

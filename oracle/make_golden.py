@@ -41,7 +41,7 @@ from mdproptools.common.com_mols import calc_com  # noqa: E402
 
 from mdproptools_amd import io as mio  # noqa: E402
 
-OUT = os.path.join(REPO, "tests", "golden")
+OUT = os.environ.get("MDHIP_GOLDEN_OUT") or os.path.join(REPO, "tests", "golden")  # (override: regenerate elsewhere and compare)
 DATA = os.path.join(REF, "data", "mg_tfsi_dme")
 MASS = [16.000, 12.010, 1.008, 14.010, 32.060, 16.000, 12.010, 19.000, 24.305]
 NUM_MOLS = [591, 66, 33]
@@ -83,10 +83,28 @@ def write_frames(tmp, steps, bounds, tables, columns):
 
 
 def load_real_frames(steps):
+    """The reference's own dump files through the INDEPENDENT pandas route of oracle/shims (what the reference reads
+    when this script runs it); the product's readers — pandas route and native mmap route — must return the very same
+    doubles for the same files, or this script stops: golden inputs are never 'parsed by the code under test'."""
+    from pymatgen.io.lammps.outputs import parse_lammps_dumps as shim_parse  # oracle/shims, no product import
+
     frames, bounds = [], []
     for s in steps:
-        (d,) = list(mio.parse_lammps_dumps(os.path.join(DATA, "dump.nvt.%d.dump" % s)))
-        frames.append(d.data[COLS].to_numpy(dtype=np.float64))
+        path = os.path.join(DATA, "dump.nvt.%d.dump" % s)
+        (d,) = list(shim_parse(path))
+        arr = d.data[COLS].to_numpy(dtype=np.float64)
+        (own,) = list(mio.parse_lammps_dumps(path))
+        assert own.timestep == d.timestep and own.natoms == d.natoms
+        assert np.array_equal(np.asarray(own.box.bounds), np.asarray(d.box.bounds))
+        assert list(own.data.columns) == list(d.data.columns)
+        assert np.array_equal(own.data[COLS].to_numpy(dtype=np.float64), arr), "product pandas route differs"
+        by_id = d.data.sort_values("id")[COLS].to_numpy(dtype=np.float64).T
+        ((ts, nb, _len, _names, planes),) = list(mio.iter_native_frames(path, COLS, sort_by="id"))
+        assert ts == d.timestep and np.array_equal(np.asarray(nb), np.asarray(d.box.bounds))
+        assert np.array_equal(np.asarray(planes), by_id), "product native route differs"
+        _st, _bd, pl = mio.read_dump_arrays(path, COLS)
+        assert np.array_equal(pl[0], by_id)
+        frames.append(arr)
         bounds.append(d.box.bounds)
     return np.stack(frames), np.asarray(bounds)
 

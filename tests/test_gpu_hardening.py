@@ -1,0 +1,247 @@
+"""
+Round-2 hardening of the pin and of the boundary (GPU side):
+  * the ctypes stub of INTEGRATION.md section 2 is executed VERBATIM — in a fresh interpreter that imports neither this
+    package nor torch — and its `_rdf_loop` must reproduce the reference's integers on the mg_tfsi_dme golden frame;
+  * more than 255 histogram classes (ids no longer fit a byte anywhere on the host);
+  * the packed-f32 sweep on adversarial inputs at C2 scale: a lattice whose distances sit exactly ON bin edges and on
+    the cutoff, all atoms coincident (every pair in bin 0: the fullest LDS words a frame can produce), and a slice
+    of the soak generator (tests/bench/soak_pk.py) inside the suite.
+"""
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, REPO
+from oracle import cref as C
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def B():
+    from mdproptools_amd import backend
+
+    return backend
+
+
+def test_integration_md_stub_verbatim(tmp_path):
+    text = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    sec = text[text.index("## 2."):text.index("## 3.")]
+    (stub,) = re.findall(r"```python\n(.*?)```", sec, flags=re.S)
+    assert "mdhip_rdf_atomic" in stub and "def _rdf_loop" in stub and "mdproptools_amd" not in stub
+    driver = '''
+import sys, json, numpy as np
+STUB = open(sys.argv[1]).read()
+exec(compile(STUB, "INTEGRATION.md#2", "exec"))
+assert "torch" not in sys.modules and "mdproptools_amd" not in sys.modules
+g = np.load(sys.argv[2])
+fr = g["frames"][0]
+fr = fr[np.argsort(fr[:, 0], kind="stable")]                       # rdf_cn.py:192 sort_values("id")
+data = np.ascontiguousarray(fr[:, 1:5])                             # [type, x, y, z] as _rdf_loop receives it
+lengths = g["bounds"][0][:, 1] - g["bounds"][0][:, 0]
+rel = np.ascontiguousarray(g["rdf_def_rel"].T)                      # relation_matrix rows (a, b)
+rdf_full = np.zeros(400); rdf_part = np.zeros((len(rel), 400))
+_rdf_loop(data, rel, len(rel), lengths, 20.0, 0.05, rdf_full, rdf_part)
+ok = bool(np.array_equal(rdf_full, g["rdf_def_full"][0]) and np.array_equal(rdf_part, g["rdf_def_part"][0]))
+print(json.dumps({"ok": ok, "sum": int(rdf_full.sum())}))
+'''
+    (tmp_path / "stub.py").write_text(stub)
+    (tmp_path / "driver.py").write_text(driver)
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = os.path.join(REPO, "mdproptools_amd") + ":" + env.get("LD_LIBRARY_PATH", "")
+    env.pop("PYTHONPATH", None)
+    r = subprocess.run([sys.executable, str(tmp_path / "driver.py"), str(tmp_path / "stub.py"),
+                        os.path.join(GOLDEN, "c1_rdf.npz")], env=env, cwd=str(tmp_path), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res == {"ok": True, "sum": 30926986}  # SURVEY.md's known answer for frame 0
+
+
+def test_more_than_255_classes(B):
+    """24 atom types, all 300 unordered type pairs as relations (301 classes with 'other'): several class passes,
+    class ids beyond a byte. Against the C oracle, per relation."""
+    rng = np.random.default_rng(255)
+    n, L, T = 2600, 30.0, 24
+    xyz = rng.uniform(0, L, (2, 3, n))
+    ty = rng.integers(1, T + 1, n).astype(np.int32)
+    rel = np.array([[a, b] for a in range(1, T + 1) for b in range(a, T + 1)], dtype=np.int32)
+    assert len(rel) == 300
+    box = np.full((2, 3), L)
+    full, part, ov = B.rdf_loop(xyz, ty, box, rel, 9.0, 0.1, 90)
+    cuts = list(2.0 + 6.5 * rng.random(len(rel)))
+    cn = B.cn_loop(xyz, ty, box, rel, cuts)
+    for f in range(2):
+        cf, cp, cov = C.rdf_pairs(xyz[f], ty, rel, box[f], 81.0, 0.1, 90)
+        np.testing.assert_array_equal(full[f], cf)
+        np.testing.assert_array_equal(part[f], cp)
+        np.testing.assert_array_equal(cn[f], C.cn_pairs(xyz[f], ty, rel, box[f], [c * c for c in cuts]))
+    # a frame large enough for the culled sweep (>= 8 tiles) with the same 300 relations
+    n2 = 4200
+    x2 = rng.uniform(0, 40.0, (1, 3, n2))
+    t2 = rng.integers(1, T + 1, n2).astype(np.int32)
+    f2, p2, _ = B.rdf_loop(x2, t2, np.full((1, 3), 40.0), rel, 9.0, 0.1, 90)
+    cf, cp, _ = C.rdf_pairs(x2[0], t2, rel, [40.0] * 3, 81.0, 0.1, 90)
+    np.testing.assert_array_equal(f2[0], cf)
+    np.testing.assert_array_equal(p2[0], cp)
+
+
+def test_lattice_on_bin_edges_at_c2_scale(B):
+    """10 000 atoms on a simple cubic lattice whose spacing is a whole number of bins (2.5 A = 50 bins of 0.05): a
+    large share of all distances sits exactly ON a bin edge, and lattice vectors such as (8,0,0) a = 20 A sit exactly
+    on the cutoff. C2's cutoff, bin size and type pattern; packed-f32 sweep == all-f64 sweep == C oracle (frame 0)."""
+    from mdproptools_amd import synth
+    from mdproptools_amd._lib import Context
+
+    g, a = 22, 2.5
+    L = g * a  # 55 A
+    rng = np.random.default_rng(20)
+    frames = []
+    for _ in range(3):
+        idx = rng.choice(g ** 3, 10_000, replace=False)
+        cell = np.stack([idx % g, (idx // g) % g, idx // (g * g)]).astype(np.float64)
+        frames.append(cell * a)
+    xyz = np.stack(frames)
+    ty = synth.rdf_types(10_000)
+    rel = np.array(synth.ALL_PAIRS_4)
+    box = np.full((3, 3), L)
+    pk, f64 = Context(0), Context(0)
+    f64.set_option("rdf_pk", 0)
+    a_ = B.rdf_loop(xyz, ty, box, rel, 20.0, 0.05, 400, ctx=pk)
+    assert "<3," in pk.last_kernel_name(), pk.last_kernel_name()
+    b_ = B.rdf_loop(xyz, ty, box, rel, 20.0, 0.05, 400, ctx=f64)
+    assert "<2," in f64.last_kernel_name()
+    np.testing.assert_array_equal(a_[0], b_[0])
+    np.testing.assert_array_equal(a_[1], b_[1])
+    cf, cp, cov = C.rdf_pairs_threaded(xyz[0], ty, rel, box[0], 400.0, 0.05, 400, 16)
+    np.testing.assert_array_equal(a_[0][0], cf)
+    np.testing.assert_array_equal(a_[1][0], cp)
+    # nearly every populated bin is a multiple of the lattice's sqrt(k) pattern: the edge-sitting pairs are many
+    on_edge = sum(int(cf[int(round(np.sqrt(k) * a / 0.05))]) for k in (1, 4, 9, 16, 25, 36, 49)
+                  if abs(np.sqrt(k) * a / 0.05 - round(np.sqrt(k) * a / 0.05)) < 1e-9)
+    assert on_edge > 100_000
+    # the coordination counts from the same sweep, cutoffs ON lattice distances (2.5, 5.0 A ...) and between them
+    cuts = [2.5, 5.0, 7.5, 3.0, 3.5355339059327378, 4.330127018922194, 6.0, 2.5, 10.0, 12.5]
+    f_, p_, ov, cn = B.rdf_cn_loop(xyz, ty, box, rel, 20.0, 0.05, 400, cuts, ctx=pk)
+    np.testing.assert_array_equal(f_, a_[0])
+    np.testing.assert_array_equal(cn[0], C.cn_pairs(xyz[0], ty, rel, box[0], [c * c for c in cuts]))
+    np.testing.assert_array_equal(cn, B.cn_loop(xyz, ty, box, rel, cuts, ctx=f64))
+    pk.close()
+    f64.close()
+
+
+def test_all_atoms_coincident_many_frames(B):
+    """Degenerate input: every atom of every frame at one point, so that every pair of a frame lands in ONE histogram
+    word (bin 0). 4096 atoms x 600 frames = 5.0e9 increments of a single counter overall — more than 2^32: the
+    per-block 32-bit LDS words must be flushed before they wrap (the library bounds the frames a block may sum)."""
+    import torch
+
+    n, F = 4096, 600
+    xyz = torch.full((F, 3, n), 7.25, dtype=torch.float64, device="cuda")
+    ty = np.ones(n, dtype=np.int32)
+    rel = np.array([[1, 1]])
+    box = np.full((F, 3), 30.0)
+    pairs = n * (n - 1) // 2
+    full, part, ov = B.rdf_loop(xyz, ty, box, rel, 10.0, 0.05, 200, per_frame=False)
+    assert int(full[0]) == 2 * pairs * F and int(full[1:].sum()) == 0 and ov == 0
+    assert int(part[0, 0]) == 2 * pairs * F
+    assert 2 * pairs * F > 2 ** 32
+    pf, pp, _ = B.rdf_loop(xyz[:3], ty, box[:3], rel, 10.0, 0.05, 200, per_frame=True)
+    assert [int(v) for v in pf[:, 0]] == [2 * pairs] * 3
+    cn = B.cn_loop(xyz, ty, box, rel, [1.0], per_frame=False)
+    assert int(cn[0]) == 2 * pairs * F
+
+
+def test_soak_slice_packed_vs_f64_and_oracle(B):
+    """300 cases of the soak generator (tests/bench/soak_pk.py, the first of its seeded stream) inside the suite:
+    packed-f32 sweep == all-f64 sweep everywhere, and every 10th case also == the C oracle on frame 0."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from test_gpu_parity import _pk_case
+    from mdproptools_amd._lib import Context
+
+    rng = np.random.default_rng(20250328)
+    f64, pk = Context(0), Context(0)
+    for ctx, v in ((f64, 0), (pk, 1)):
+        ctx.set_option("rdf_cull", 1)
+        ctx.set_option("rdf_pk", v)
+    engaged = 0
+    for trial in range(300):
+        xyz, ty, box, rel, r_cut, bin_size, nbins = _pk_case(rng, trial)
+        xyz = xyz[:2]
+        box = box[:2]
+        per_frame = bool(trial % 2) or trial % 10 == 0
+        a = B.rdf_loop(xyz, ty, box, rel, r_cut, bin_size, nbins, per_frame=per_frame, ctx=f64)
+        b = B.rdf_loop(xyz, ty, box, rel, r_cut, bin_size, nbins, per_frame=per_frame, ctx=pk)
+        engaged += any(t in pk.last_kernel_name() for t in ("<3,", "<4,", "<5,", "<6,"))
+        msg = "trial %d kernel %s" % (trial, pk.last_kernel_name())
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2], msg
+        if trial % 10 == 0:
+            cf, cp, _ = C.rdf_pairs(xyz[0], ty, rel, box[0], r_cut * r_cut, bin_size, nbins)
+            assert np.array_equal(b[0][0], cf) and np.array_equal(b[1][0], cp), msg
+    assert engaged >= 200
+    f64.close()
+    pk.close()
+
+
+def test_overflow_guard_splits_the_batch(B):
+    """The guard of the 32-bit LDS words: with its threshold lowered (rdf_guard) a persistent block that swept more
+    neighbour tiles than allowed raises the flag, the host halves the batch until every launch passes, and the sums
+    are what the unguarded run gives — frame-summed, per frame, with device-resident sums and with CN riding along."""
+    import torch
+
+    from mdproptools_amd import synth
+    from mdproptools_amd._lib import Context
+
+    n, L, F = 6000, 42.0, 24
+    xyz = synth.rdf_frames(n, range(F), L, 11)
+    ty = synth.rdf_types(n)
+    rel = np.array(synth.ALL_PAIRS_4)
+    box = np.full((F, 3), L)
+    ref = B.rdf_loop(xyz, ty, box, rel, 12.0, 0.05, 240, per_frame=False)
+    refp = B.rdf_loop(xyz, ty, box, rel, 12.0, 0.05, 240, per_frame=True)
+    ctx = Context(0)
+    # lower the number of neighbour tiles a block may sweep per launch until the 24-frame batch has to be halved
+    # (a threshold even one frame exceeds gives a clean error instead, see the end of the test)
+    split_at = None
+    for guard in (256, 128, 96, 64, 48, 32, 24, 16, 12, 8, 6, 4):
+        ctx.set_option("rdf_guard", guard)
+        try:
+            a = B.rdf_loop(xyz, ty, box, rel, 12.0, 0.05, 240, per_frame=False, ctx=ctx)
+        except Exception as e:
+            assert "overflow the 32-bit" in str(e)
+            break
+        np.testing.assert_array_equal(a[0], ref[0])
+        np.testing.assert_array_equal(a[1], ref[1])
+        if ctx.last_kernel_ms()[1] > 1:
+            split_at = guard
+    assert split_at is not None, "no threshold made the host split the batch"
+    # per-frame output: a frame's blocks share its items, so a block sweeps more tiles than in the persistent grid —
+    # the first threshold that passes must still give the right rows
+    for k in (1, 2, 4, 8, 16, 64):
+        ctx.set_option("rdf_guard", split_at * k)
+        try:
+            b = B.rdf_loop(xyz, ty, box, rel, 12.0, 0.05, 240, per_frame=True, ctx=ctx)
+        except Exception as e:
+            assert "overflow the 32-bit" in str(e)
+            continue
+        np.testing.assert_array_equal(b[0], refp[0])
+        break
+    else:
+        raise AssertionError("per-frame output never passed the guard")
+    ctx.set_option("rdf_guard", split_at)
+    out = torch.empty(11 * 240 + 1, dtype=torch.int64, device="cuda")
+    B.rdf_loop_dev(torch.from_numpy(xyz).cuda(), ty, box, rel, 12.0, 0.05, 240, out, ctx=ctx)
+    np.testing.assert_array_equal(out.cpu().numpy().view(np.uint64)[:240], ref[0])
+    cuts = synth.cn_cutoffs(len(rel))
+    f_, p_, ov, cn = B.rdf_cn_loop(xyz, ty, box, rel, 12.0, 0.05, 240, cuts, per_frame=False, ctx=ctx)
+    np.testing.assert_array_equal(f_, ref[0])
+    np.testing.assert_array_equal(cn, B.cn_loop(xyz, ty, box, rel, cuts, per_frame=False))
+    ctx.set_option("rdf_guard", 1)  # not even one frame passes: a clean error, not wrong sums
+    with pytest.raises(Exception, match="overflow the 32-bit"):
+        B.rdf_loop(xyz, ty, box, rel, 12.0, 0.05, 240, per_frame=False, ctx=ctx)
+    ctx.close()

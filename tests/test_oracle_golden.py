@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, load_golden, sorted_frame
+from conftest import GOLDEN, REPO, load_golden, sorted_frame
 from oracle import cpu_ref as O
 from oracle import cref as C
 
@@ -308,3 +308,27 @@ def test_residence_oracle_matches_reference():
         ref = g["corr"][:, 1 + kl]
         assert np.array_equal(np.isnan(corr), np.isnan(ref))
         np.testing.assert_allclose(corr[~np.isnan(ref)], ref[~np.isnan(ref)], rtol=1e-12, atol=1e-15)
+
+
+def test_acovf_shim_equals_its_definition():
+    """oracle/shims/statsmodels acovf (the stand-in the reference's ResidenceTime ran on when the goldens were made,
+    residence_time.py:128-130) against the direct-sum definition it claims, sum_t x[t] x[t+k] / (n - k): 0/1 indicator
+    series as the reference feeds it, and real-valued ones."""
+    import importlib.util
+
+    path = os.path.join(REPO, "oracle", "shims", "statsmodels", "tsa", "stattools.py")
+    spec = importlib.util.spec_from_file_location("_acovf_shim", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 7, 30, 101, 256):
+        for x in (rng.integers(0, 2, n).astype(float), rng.normal(size=n)):
+            direct = np.array([np.dot(x[k:], x[: n - k]) / (n - k) for k in range(n)])
+            got = mod.acovf(x, demean=False, unbiased=True, fft=True)
+            np.testing.assert_allclose(got, direct, rtol=0, atol=1e-12 * max(1.0, abs(direct).max()))
+            np.testing.assert_allclose(mod.acovf(x, demean=False, unbiased=True, fft=False), direct, rtol=1e-13,
+                                       atol=1e-15)
+        # indicator series: numerators are integers, so the FFT route must round to them exactly
+        h = rng.integers(0, 2, n).astype(float)
+        num = mod.acovf(h, demean=False, unbiased=True, fft=True) * (n - np.arange(n))
+        assert np.array_equal(np.rint(num), [np.dot(h[k:], h[: n - k]) for k in range(n)])
