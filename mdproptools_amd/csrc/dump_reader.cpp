@@ -24,6 +24,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -181,6 +182,10 @@ int index_frames(mdhip_dump *d)
         double v;
         if (!next_line(b, e)) break;
         parse_double(skip_ws(b, e), e, &v);
+        if (!(std::fabs(v) < 9.2e18)) {  // (also NaN: the cast below would be undefined)
+            d->err = "dump: TIMESTEP is not an integer";
+            return MDHIP_EINVAL;
+        }
         fr.timestep = (int64_t)v;
         if (!next_line(b, e) || !starts_with(b, e, "ITEM: NUMBER OF ATOMS")) {
             d->err = "dump: expected ITEM: NUMBER OF ATOMS";
@@ -188,6 +193,10 @@ int index_frames(mdhip_dump *d)
         }
         if (!next_line(b, e)) break;
         parse_double(skip_ws(b, e), e, &v);
+        if (!(v >= 0.0 && v <= (double)d->size)) {  // negative, NaN, or more atoms than the file has bytes
+            d->err = "dump: bad NUMBER OF ATOMS";
+            return MDHIP_EINVAL;
+        }
         fr.natoms = (int64_t)v;
         if (!next_line(b, e) || !starts_with(b, e, "ITEM: BOX BOUNDS")) {
             d->err = "dump: expected ITEM: BOX BOUNDS";
@@ -237,9 +246,12 @@ int index_frames(mdhip_dump *d)
 }
 
 // parse the lines [l0, l1) of a frame body into rows (sel columns), row-major scratch [line][n_sel (+1 key)]
-void parse_lines(const char *p, const char *end, int64_t n_lines, int n_cols, int n_sel, const int *col_idx,
-                 int key_col, double *vals, double *keys)
+// Returns the number of malformed rows: fewer than n_cols tokens, or a token that is not a number (pandas would give
+// NaN / object columns and pymatgen's callers would fail later; here the read fails loudly instead of filling zeros).
+int64_t parse_lines(const char *p, const char *end, int64_t n_lines, int n_cols, int n_sel, const int *col_idx,
+                    int key_col, double *vals, double *keys)
 {
+    int64_t bad = 0;
     std::vector<int> slot(n_cols, -1);
     for (int s = 0; s < n_sel; ++s) slot[col_idx[s]] = s;  // a column selected twice keeps the last slot
     for (int64_t k = 0; k < n_lines && p < end; ++k) {
@@ -247,7 +259,14 @@ void parse_lines(const char *p, const char *end, int64_t n_lines, int n_cols, in
         const char *q = p;
         for (int c = 0; c < n_cols; ++c) {
             q = skip_ws(q, le);
-            if (q >= le) break;
+            if (q >= le) {
+                ++bad;
+                break;
+            }
+            const char ch = *q;
+            if (!((ch >= '0' && ch <= '9') || ch == '-' || ch == '+' || ch == '.' || ch == 'n' || ch == 'N' || ch == 'i' ||
+                  ch == 'I'))
+                ++bad;
             double v;
             q = parse_double(q, le, &v);
             if (slot[c] >= 0) vals[k * n_sel + slot[c]] = v;
@@ -258,6 +277,7 @@ void parse_lines(const char *p, const char *end, int64_t n_lines, int n_cols, in
             if (slot[col_idx[s]] != s) vals[k * n_sel + s] = vals[k * n_sel + slot[col_idx[s]]];
         p = le < end ? le + 1 : end;
     }
+    return bad;
 }
 
 
@@ -337,11 +357,24 @@ void log_parse(const char *p, const char *end, int n_cols, int64_t row0, int64_t
     }
 }
 
+// nothing may unwind across the C boundary
+template <typename F>
+static int guarded(F f)
+{
+    try {
+        return f();
+    } catch (const std::bad_alloc &) {
+        return MDHIP_ENOMEM;
+    } catch (...) {
+        return MDHIP_EINVAL;
+    }
+}
+
 }  // namespace
 
 extern "C" {
 
-int mdhip_dump_open(const char *path, mdhip_dump **out)
+static int dump_open_impl(const char *path, mdhip_dump **out)
 {
     if (!path || !out) return MDHIP_EINVAL;
     *out = nullptr;
@@ -406,8 +439,8 @@ int mdhip_dump_frame_info(mdhip_dump *d, int64_t f, int64_t *timestep, int64_t *
     return MDHIP_OK;
 }
 
-int mdhip_dump_read(mdhip_dump *d, int64_t f, int n_sel, const int32_t *col_idx, int sort_col, double *out,
-                    int n_threads)
+static int dump_read_impl(mdhip_dump *d, int64_t f, int n_sel, const int32_t *col_idx, int sort_col, double *out,
+                          int n_threads)
 {
     if (!d || f < 0 || f >= (int64_t)d->frames.size() || n_sel < 0 || (n_sel && (!col_idx || !out)))
         return MDHIP_EINVAL;
@@ -459,17 +492,23 @@ int mdhip_dump_read(mdhip_dump *d, int64_t f, int n_sel, const int32_t *col_idx,
         return MDHIP_EINVAL;
     }
     std::vector<double> vals((size_t)n * n_sel), keys(sort_col >= 0 ? (size_t)n : 0);
+    std::vector<int64_t> bad(n_threads, 0);
     {
         std::vector<std::thread> th;
         for (int t = 0; t < n_threads; ++t)
             th.emplace_back([&, t] {
                 const int64_t l0 = cline[t], l1 = std::min<int64_t>(cline[t + 1], n);
                 if (l1 > l0)
-                    parse_lines(cstart[t], cstart[t + 1], l1 - l0, fr.n_cols, n_sel, col_idx, sort_col,
-                                vals.data() + (size_t)l0 * n_sel, sort_col >= 0 ? keys.data() + l0 : nullptr);
+                    bad[t] = parse_lines(cstart[t], cstart[t + 1], l1 - l0, fr.n_cols, n_sel, col_idx, sort_col,
+                                         vals.data() + (size_t)l0 * n_sel, sort_col >= 0 ? keys.data() + l0 : nullptr);
             });
         for (auto &x : th) x.join();
     }
+    for (int t = 0; t < n_threads; ++t)
+        if (bad[t]) {
+            d->err = "mdhip_dump_read: a row has fewer values than columns or a value that is not a number";
+            return MDHIP_EINVAL;
+        }
     // destination row of every line: ascending key (stable), fast path when keys are a permutation of 1..n
     std::vector<int64_t> dest(n);
     if (sort_col < 0) {
@@ -479,8 +518,8 @@ int mdhip_dump_read(mdhip_dump *d, int64_t f, int n_sel, const int32_t *col_idx,
         std::vector<char> seen((size_t)n, 0);
         for (int64_t k = 0; k < n && perm; ++k) {
             const double v = keys[k];
-            const int64_t id = (int64_t)v;
-            if ((double)id != v || id < 1 || id > n || seen[(size_t)id - 1])
+            const int64_t id = (v >= 1.0 && v <= (double)n) ? (int64_t)v : 0;  // (range first: the cast of NaN is undefined)
+            if (id < 1 || (double)id != v || seen[(size_t)id - 1])
                 perm = false;
             else {
                 seen[(size_t)id - 1] = 1;
@@ -513,7 +552,7 @@ struct mdhip_log {
     std::string err;
 };
 
-int mdhip_log_open(const char *path, mdhip_log **out)
+static int log_open_impl(const char *path, mdhip_log **out)
 {
     if (!path || !out) return MDHIP_EINVAL;
     *out = nullptr;
@@ -611,7 +650,7 @@ int mdhip_log_run_info(mdhip_log *l, int64_t run, int64_t *n_rows, int *n_cols, 
     return MDHIP_OK;
 }
 
-int mdhip_log_read(mdhip_log *l, int64_t run, double *out, int32_t *is_int, int n_threads)
+static int log_read_impl(mdhip_log *l, int64_t run, double *out, int32_t *is_int, int n_threads)
 {
     if (!l || run < 0 || run >= (int64_t)l->runs.size() || !out) return MDHIP_EINVAL;
     const LogRun &r = l->runs[(size_t)run];
@@ -663,6 +702,28 @@ int mdhip_log_read(mdhip_log *l, int64_t run, double *out, int32_t *is_int, int 
             is_int[c] = n > 0 ? a : 0;
         }
     return MDHIP_OK;
+}
+
+// ---- exception barriers: nothing may unwind across the C boundary (a std::bad_alloc from a vector sized by a
+// corrupt header would otherwise call std::terminate in the caller's process) ---------------------------------------
+int mdhip_dump_open(const char *path, mdhip_dump **out)
+{
+    return guarded([&] { return dump_open_impl(path, out); });
+}
+
+int mdhip_dump_read(mdhip_dump *d, int64_t f, int n_sel, const int32_t *col_idx, int sort_col, double *out, int n_threads)
+{
+    return guarded([&] { return dump_read_impl(d, f, n_sel, col_idx, sort_col, out, n_threads); });
+}
+
+int mdhip_log_open(const char *path, mdhip_log **out)
+{
+    return guarded([&] { return log_open_impl(path, out); });
+}
+
+int mdhip_log_read(mdhip_log *l, int64_t run, double *out, int32_t *is_int, int n_threads)
+{
+    return guarded([&] { return log_read_impl(l, run, out, is_int, n_threads); });
 }
 
 }  // extern "C"

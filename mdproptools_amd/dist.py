@@ -203,6 +203,25 @@ def allgather_var(local):
     return np.concatenate(blocks).reshape((sum(counts),) + row_shape)
 
 
+def require_all_nonempty(n_local, what="frame"):
+    """Collective check that every rank holds at least one item: the counts are all-gathered FIRST, so that all ranks
+    raise together — a rank that raised alone would leave the others waiting in the next collective until the
+    process-group timeout."""
+    if not is_distributed():
+        return
+    import torch
+
+    d = _dist()
+    _, world = rank_world()
+    dev = _device_for_collectives()
+    cnt = torch.tensor([int(n_local)], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(cnt) for _ in range(world)]
+    d.all_gather(counts, cnt)
+    empty = [r for r, c in enumerate(counts) if int(c.item()) == 0]
+    if empty:
+        raise ValueError("rank(s) %s hold no %s: use at most as many ranks as there are %ss" % (empty, what, what))
+
+
 def shard_items(items):
     """This rank's contiguous block of a list (e.g. the dump files of a trajectory, in frame order)."""
     rank, world = rank_world()

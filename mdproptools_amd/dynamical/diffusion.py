@@ -124,8 +124,7 @@ class Diffusion:
             times.append(step * self.timestep * constants.TIME_CONVERSION[self.units])
         times = np.asarray(times, dtype=np.float64)
         if files is not None:
-            if not planes:
-                raise ValueError("this rank holds no frame: use at most as many ranks as there are dump files")
+            D.require_all_nonempty(len(planes), "dump file")  # every rank raises, or none
             times = D.allgather_var(times)
         if msd_type == "com":
             seg = molecule_layout(num_mols, num_atoms_per_mol)

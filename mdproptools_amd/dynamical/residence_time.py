@@ -35,6 +35,13 @@ def _say(*args):
         print(*args)
 
 
+def _is_writer():
+    """Only rank 0 writes files under torch.distributed (every rank computes the same tables)."""
+    from .. import dist as D
+
+    return D.is_writer()
+
+
 class ResidenceTime:
     def __init__(self, r_cut, partial_relations, filename, dt=1, num_mols=None, num_atoms_per_mol=None,
                  working_dir=None):
@@ -99,7 +106,8 @@ class ResidenceTime:
                 corr = corr / corr[0]                                           # residence_time.py:142
             correlation[atom_pair] = corr
         self.corr_df = pd.DataFrame.from_dict(correlation)
-        self.corr_df.to_csv(self.working_dir + "/auto_correlation.csv")
+        if _is_writer():
+            self.corr_df.to_csv(self.working_dir + "/auto_correlation.csv")
 
     def fit_auto_correlation(self, cut_percent=0.9, plot=True):
         residence_time = {}
@@ -118,7 +126,8 @@ class ResidenceTime:
         print("Finished computing residence time")
         self.res_time_df = pd.DataFrame(residence_time)
         self.res_time_df.index = ["a", "tau_res", "tau_short", "beta", "r (ps)"]
-        self.res_time_df.to_csv(self.working_dir + "/residence_time.csv")
+        if _is_writer():
+            self.res_time_df.to_csv(self.working_dir + "/residence_time.csv")
         return residence_time
 
     def _plot_fit(self, corr_data, col, popt):
@@ -137,5 +146,6 @@ class ResidenceTime:
         ax.legend(frameon=False, fontsize=20)
         ax.set_xlabel("Time (ps)", fontsize=20)
         ax.set_ylabel("C(t)", fontsize=20)
-        fig.savefig(self.working_dir + f"/{col}_fit.png", bbox_inches="tight", pad_inches=0.1)
+        if _is_writer():
+            fig.savefig(self.working_dir + f"/{col}_fit.png", bbox_inches="tight", pad_inches=0.1)
         plt.close()

@@ -117,9 +117,18 @@ def _sorted_matches(file_pattern):
     return files
 
 
+def _open_text(fname):
+    """Plain or gzip-compressed text (pymatgen's zopen accepts both; the mmap reader takes plain text only)."""
+    if str(fname).endswith(".gz"):
+        import gzip
+
+        return gzip.open(fname, "rt")
+    return open(fname, "rt")
+
+
 def _iter_frames(fname):
     frame = []
-    with open(fname, "rt") as fh:
+    with _open_text(fname) as fh:
         for line in fh:
             if line.startswith("ITEM: TIMESTEP"):
                 if frame:
@@ -273,14 +282,34 @@ class NativeDumpFile:
         return out
 
 
+def _pandas_file_frames(fname, columns, sort_by):
+    """The frames of one file through the pandas route, in the tuple form of the native route (compressed files,
+    and files whose rows the native reader refuses: pandas' behaviour for them is then the reference's)."""
+    out = []
+    for frame in _iter_frames(fname):
+        d = LammpsDump.from_lines(frame)
+        names = list(d.data.columns)
+        want = columns(names) if callable(columns) else columns
+        df = d.data
+        if sort_by is not None:
+            df = df.sort_values(sort_by)  # KeyError when the column is absent, as in the reference (rdf_cn.py:192)
+        planes = np.ascontiguousarray(df[list(want)].to_numpy(dtype=np.float64).T)
+        out.append((d.timestep, np.asarray(d.box.bounds, dtype=np.float64), d.box.to_lattice().lengths, names, planes))
+    return out
+
+
 def _native_file_frames(fname, columns, sort_by, n_threads):
+    if str(fname).endswith(".gz"):
+        return _pandas_file_frames(fname, columns, sort_by)
     nd = NativeDumpFile(fname)
     try:
         out = []
         for f in range(nd.n_frames):
             ts, na, bounds, tilt, names = nd.header(f)
             want = columns(names) if callable(columns) else columns
-            planes = nd.read(f, want, sort_by=sort_by if sort_by in names else None, n_threads=n_threads)
+            if sort_by is not None and sort_by not in names:
+                raise KeyError(sort_by)  # pandas' sort_values on a missing column, as in the reference (rdf_cn.py:192)
+            planes = nd.read(f, want, sort_by=sort_by, n_threads=n_threads)
             lengths = LammpsBox(bounds.tolist(), tilt).to_lattice().lengths
             out.append((ts, bounds, lengths, names, planes))
         return out

@@ -228,8 +228,7 @@ def _all_frames(per_frame_rows):
     rows = np.stack(per_frame_rows) if len(per_frame_rows) else None
     if not D.is_distributed():
         return [] if rows is None else rows
-    if rows is None:
-        raise ValueError("this rank holds no frame: use at most as many ranks as there are frames")
+    D.require_all_nonempty(0 if rows is None else len(rows), "frame")  # every rank raises, or none
     return D.allgather_var(rows)
 
 

@@ -149,3 +149,78 @@ def test_native_log_reader_equals_text_route(tmp_path):
     empty = str(tmp_path / "log.empty")
     open(empty, "wt").write("LAMMPS\nno runs here\n")
     assert mio.parse_lammps_log(empty) == []
+
+
+# ---------------------------------------------------------------- malformed input (round-2 hardening)
+def _write(path, natoms_line, rows, cols="id type x y z"):
+    with open(path, "w") as fh:
+        fh.write("ITEM: TIMESTEP\n100\nITEM: NUMBER OF ATOMS\n%s\nITEM: BOX BOUNDS pp pp pp\n0 10\n0 10\n0 10\n" % natoms_line)
+        fh.write("ITEM: ATOMS %s\n" % cols)
+        fh.write("\n".join(rows) + "\n")
+
+
+def test_native_reader_refuses_malformed_rows(tmp_path):
+    """Short rows, blank body lines and non-numeric tokens make the read FAIL (pandas would give NaN / object
+    columns); nothing is silently filled with zeros."""
+    from mdproptools_amd import io as mio
+
+    good = ["1 1 0.5 0.5 0.5", "2 2 1.5 1.5 1.5", "3 1 2.5 2.5 2.5"]
+    for bad_rows in (["1 1 0.5 0.5 0.5", "2 2 1.5 1.5", "3 1 2.5 2.5 2.5"],       # short row
+                     ["1 1 0.5 0.5 0.5", "", "3 1 2.5 2.5 2.5"],                  # blank line inside the body
+                     ["1 1 0.5 0.5 0.5", "2 2 abc 1.5 1.5", "3 1 2.5 2.5 2.5"]):  # not a number
+        p = str(tmp_path / "bad.dump")
+        _write(p, "3", bad_rows)
+        nd = mio.NativeDumpFile(p)
+        with pytest.raises(ValueError, match="fewer values|not a number"):
+            nd.read(0, ["id", "x"], sort_by="id")
+        nd.close()
+    p = str(tmp_path / "ok.dump")
+    _write(p, "3", good)
+    nd = mio.NativeDumpFile(p)
+    np.testing.assert_array_equal(nd.read(0, ["id", "x"], sort_by="id"), [[1, 2, 3], [0.5, 1.5, 2.5]])
+    nd.close()
+    # nan / inf ARE numbers (pandas parses them): accepted, and a NaN id falls back to the stable key sort
+    _write(p, "3", ["2 1 nan 0.5 0.5", "1 2 inf 1.5 1.5", "3 1 -inf 2.5 2.5"])
+    nd = mio.NativeDumpFile(p)
+    got = nd.read(0, ["id", "x"], sort_by="id")
+    assert np.array_equal(got[0], [1, 2, 3]) and np.isinf(got[1][0]) and np.isnan(got[1][1])
+    nd.close()
+
+
+def test_native_reader_refuses_bad_headers(tmp_path):
+    from mdproptools_amd import io as mio
+
+    for natoms in ("-5", "nan", "1e30"):
+        p = str(tmp_path / "hdr.dump")
+        _write(p, natoms, ["1 1 0.5 0.5 0.5"])
+        with pytest.raises(OSError, match="NUMBER OF ATOMS"):
+            mio.NativeDumpFile(p)
+
+
+def test_gz_dumps_and_missing_sort_column(tmp_path):
+    """A gzip-compressed dump (pymatgen's zopen reads those) goes through the pandas route with the same result; a
+    dump without the `id` column raises KeyError as pandas' sort_values does in the reference (rdf_cn.py:192)."""
+    import gzip
+
+    from mdproptools_amd import io as mio
+
+    rng = np.random.default_rng(8)
+    # (6 decimals, as LAMMPS writes: for texts of more than 15 significant digits pandas' default parser, which the
+    # reference goes through, is not correctly rounded, while the native reader is)
+    tbl = np.column_stack([rng.permutation(50) + 1, 1 + np.arange(50) % 3, np.round(rng.uniform(0, 10, (50, 3)), 6)])
+    plain = str(tmp_path / "dump.nvt.0.dump")
+    mio.write_dump(plain, 0, [[0, 10]] * 3, ["id", "type", "x", "y", "z"], tbl)
+    with open(plain, "rb") as src, gzip.open(str(tmp_path / "z.nvt.0.dump.gz"), "wb") as dst:
+        dst.write(src.read())
+    (a,) = list(mio.iter_native_frames(plain, ["id", "type", "x", "y", "z"]))
+    (b,) = list(mio.iter_native_frames(str(tmp_path / "z.nvt.0.dump.gz"), ["id", "type", "x", "y", "z"]))
+    assert a[0] == b[0] and a[3] == b[3]
+    np.testing.assert_array_equal(a[4], b[4])
+    (d,) = list(mio.parse_lammps_dumps(str(tmp_path / "z.nvt.0.dump.gz")))
+    assert len(d.data) == 50
+    noid = str(tmp_path / "noid.dump")
+    mio.write_dump(noid, 0, [[0, 10]] * 3, ["type", "x", "y", "z"], tbl[:, 1:])
+    with pytest.raises(KeyError):
+        list(mio.iter_native_frames(noid, ["type", "x"], sort_by="id"))
+    (c,) = list(mio.iter_native_frames(noid, ["type", "x"], sort_by=None))
+    np.testing.assert_array_equal(c[4][1], tbl[:, 2])
