@@ -199,6 +199,12 @@ int mdhip_set_option(mdhip_ctx *ctx, const char *key, int value)
         ctx->opt_rdf_pk = value;
     else if (!strcmp(key, "lag_variant"))
         ctx->opt_lag_variant = value < 0 ? 3 : value;  // -1 restores the default
+    else if (!strcmp(key, "seg_cap"))
+        ctx->opt_seg_cap = value;
+    else if (!strcmp(key, "seg_vec"))
+        ctx->opt_seg_vec = value;
+    else if (!strcmp(key, "seg_gy"))
+        ctx->opt_seg_gy = value;
     else if (!strcmp(key, "rdf_guard"))
         ctx->opt_rdf_guard = value < 0 ? 0 : value;
     else if (!strcmp(key, "rdf_slots"))

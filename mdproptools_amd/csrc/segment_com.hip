@@ -25,21 +25,22 @@ namespace {
 struct SegBlock {
     long long s0, s1;  // segments [s0, s1)
 };
-constexpr int SC_CAP = 1024;   // atoms per block stage
+constexpr int SC_CAP_MAX = 1024;   // atoms per block stage (CAP of the kernel: 1024 or 512)
 constexpr int SC_PLANES = 3;   // attribute planes staged together (x, y, z): one barrier pair per frame
 // LDS index with one pad double per 32: lanes whose segments start 4, 8, 16, ... atoms apart would otherwise
 // all hit the same banks
 __device__ __forceinline__ int sc_pad(int i) { return i + (i >> 5); }
-constexpr int SC_STRIDE = SC_CAP + SC_CAP / 32 + 2;
+constexpr int sc_stride(int cap) { return cap + cap / 32 + 2; }
 
 // FLUX = false: out[f][k][s] = sum(m a) / sum(m)                                   (com_mols.py:58-60)
 // FLUX = true : out[f][k][s] = (sum(m v) / sum(m) * vel_conv) * (sum(q) * charge_conv)   (_conductivity.py:21-25)
-template <bool FLUX>
+template <bool FLUX, int SC_CAP>
 __global__ __launch_bounds__(256) void segment_staged_kernel(
     const double *__restrict__ attr, const double *__restrict__ mass, const double *__restrict__ q,
     const long long *__restrict__ seg_off, const SegBlock *__restrict__ blocks, double *__restrict__ out,
-    int n_attr, long long n_atoms, long long n_seg, long long n_frames, double vel_conv, double charge_conv)
+    int n_attr, long long n_atoms, long long n_seg, long long n_frames, double vel_conv, double charge_conv, int use_vec)
 {
+    constexpr int SC_STRIDE = sc_stride(SC_CAP);
     __shared__ double s_v[SC_PLANES * SC_STRIDE];
     __shared__ double s_m[SC_CAP];
     const int tid = threadIdx.x;
@@ -47,21 +48,34 @@ __global__ __launch_bounds__(256) void segment_staged_kernel(
     const long long a0 = seg_off[b.s0];
     const int na = (int)(seg_off[b.s1] - a0);
     for (int i = tid; i < na; i += 256) s_m[i] = mass[a0 + i];
-    const long long s = b.s0 + tid;
-    const bool has = s < b.s1;
-    int lo = 0, hi = 0;
-    double msum = 0.0, q_si = 0.0;
-    if (has) {
-        lo = (int)(seg_off[s] - a0);
-        hi = (int)(seg_off[s + 1] - a0);
-    }
+    // Sum tasks: (segment, plane) pairs of the block, dealt plane-major over the 256 lanes — consecutive lanes take
+    // consecutive segments of one plane (coalesced stores, spread LDS banks), and a block of 64 sixteen-atom molecules
+    // keeps 192 lanes busy in the sum phase instead of 64 (SC_TPL tasks per lane cover 256 segments x 3 planes).
+    constexpr int SC_TPL = SC_PLANES;
+    const int nseg = (int)(b.s1 - b.s0);
+    int t_lo[SC_TPL], t_hi[SC_TPL], t_kk[SC_TPL], t_seg[SC_TPL];
+    double t_msum[SC_TPL], t_qsi[SC_TPL];
     __syncthreads();
-    if (has) {
-        for (int a = lo; a < hi; ++a) msum += s_m[a];
-        if (FLUX) {
-            double qsum = 0.0;
-            for (int a = lo; a < hi; ++a) qsum += q[a0 + a];
-            q_si = qsum * charge_conv;  // _conductivity.py:25
+#pragma unroll
+    for (int j = 0; j < SC_TPL; ++j) {
+        const int t = tid + j * 256;
+        const int kk = t / nseg, sg = t - kk * nseg;
+        t_kk[j] = kk < SC_PLANES ? kk : -1;
+        t_seg[j] = sg;
+        t_lo[j] = t_hi[j] = 0;
+        t_msum[j] = 1.0;
+        t_qsi[j] = 0.0;
+        if (t_kk[j] >= 0) {
+            t_lo[j] = (int)(seg_off[b.s0 + sg] - a0);
+            t_hi[j] = (int)(seg_off[b.s0 + sg + 1] - a0);
+            double msum = 0.0;
+            for (int a = t_lo[j]; a < t_hi[j]; ++a) msum += s_m[a];
+            t_msum[j] = msum;
+            if (FLUX) {
+                double qsum = 0.0;
+                for (int a = t_lo[j]; a < t_hi[j]; ++a) qsum += q[a0 + a];
+                t_qsi[j] = qsum * charge_conv;  // _conductivity.py:25
+            }
         }
     }
     // Software pipeline over (frame, plane group) steps: the values of step n+1 are loaded into registers while
@@ -70,7 +84,12 @@ __global__ __launch_bounds__(256) void segment_staged_kernel(
     const int groups = (n_attr + SC_PLANES - 1) / SC_PLANES;
     const long long n_my = blockIdx.y < n_frames ? (n_frames - blockIdx.y + gridDim.y - 1) / gridDim.y : 0;
     const long long steps = n_my * groups;
+    // The loads of step n+1 are issued right after the barrier that ends the LDS writes of step n and land while
+    // its sums run. (A second register set, fetching at the very top of the step, measured slower: 102 VGPRs.)
+    // A lane owns the atoms (2 tid, 2 tid + 1) + 512 r: 16-byte loads when the planes allow it (even atom count and
+    // block start, 16-byte aligned base) — half the load instructions of 8-byte loads.
     double v[SC_PLANES][PER];
+    const bool vec2 = use_vec && ((n_atoms | a0) & 1LL) == 0 && ((reinterpret_cast<unsigned long long>(attr) & 15ULL) == 0);
     auto fetch = [&](long long step) {
         const long long f = blockIdx.y + (step / groups) * gridDim.y;
         const int k0 = (int)(step % groups) * SC_PLANES;
@@ -78,13 +97,26 @@ __global__ __launch_bounds__(256) void segment_staged_kernel(
 #pragma unroll
         for (int kk = 0; kk < SC_PLANES; ++kk)
 #pragma unroll
-            for (int r = 0; r < PER; ++r) {
-                const int i = tid + r * 256;
-                v[kk][r] = (k0 + kk < n_attr && i < na) ? p[(size_t)kk * n_atoms + i] : 0.0;
+            for (int r = 0; r < PER / 2; ++r) {
+                const int i = 2 * tid + r * 512;
+                const bool ok = k0 + kk < n_attr;
+                if (!use_vec) {  // A/B: the 8-byte layout (lane owns tid + 256 r)
+                    const int i0 = tid + (2 * r) * 256, i1 = tid + (2 * r + 1) * 256;
+                    v[kk][2 * r] = (ok && i0 < na) ? p[(size_t)kk * n_atoms + i0] : 0.0;
+                    v[kk][2 * r + 1] = (ok && i1 < na) ? p[(size_t)kk * n_atoms + i1] : 0.0;
+                    continue;
+                }
+                if (vec2 && ok && i + 1 < na) {
+                    const double2 t2 = *reinterpret_cast<const double2 *>(p + (size_t)kk * n_atoms + i);
+                    v[kk][2 * r] = t2.x;
+                    v[kk][2 * r + 1] = t2.y;
+                } else {
+                    v[kk][2 * r] = (ok && i < na) ? p[(size_t)kk * n_atoms + i] : 0.0;
+                    v[kk][2 * r + 1] = (ok && i + 1 < na) ? p[(size_t)kk * n_atoms + i + 1] : 0.0;
+                }
             }
     };
-    if (steps > 0) fetch(0);
-    for (long long step = 0; step < steps; ++step) {
+    auto process = [&](long long step) {
         const long long f = blockIdx.y + (step / groups) * gridDim.y;
         const int k0 = (int)(step % groups) * SC_PLANES;
         const int nk = n_attr - k0 < SC_PLANES ? n_attr - k0 : SC_PLANES;
@@ -93,27 +125,41 @@ __global__ __launch_bounds__(256) void segment_staged_kernel(
         for (int kk = 0; kk < SC_PLANES; ++kk)
 #pragma unroll
             for (int r = 0; r < PER; ++r) {
-                const int i = tid + r * 256;
+                const int i = use_vec ? 2 * tid + (r >> 1) * 512 + (r & 1) : tid + r * 256;
                 if (i < na) s_v[kk * SC_STRIDE + sc_pad(i)] = v[kk][r] * s_m[i];
             }
         __syncthreads();
         if (step + 1 < steps) fetch(step + 1);
-        if (has) {
 #pragma unroll
-            for (int kk = 0; kk < SC_PLANES; ++kk)
-                if (kk < nk) {
-                    double acc = 0.0;
-                    for (int a = lo; a < hi; ++a) acc += s_v[kk * SC_STRIDE + sc_pad(a)];
-                    double r = acc / msum;
-                    if (FLUX) r = (r * vel_conv) * q_si;  // com_mols.py:60 then _conductivity.py:21-23
-                    out[((size_t)f * n_attr + k0 + kk) * n_seg + s] = r;
+        for (int j = 0; j < SC_TPL; ++j) {
+            const int kk = t_kk[j];
+            if (kk >= 0 && kk < nk) {
+                // atoms added in index order (one rounding per addition, as a lane walking the segment would);
+                // four LDS reads are issued before their additions so that the reads overlap
+                const double *row = s_v + kk * SC_STRIDE;
+                double acc = 0.0;
+                int a = t_lo[j];
+                for (; a + 4 <= t_hi[j]; a += 4) {
+                    const double x0 = row[sc_pad(a)], x1 = row[sc_pad(a + 1)], x2 = row[sc_pad(a + 2)],
+                                 x3 = row[sc_pad(a + 3)];
+                    acc += x0;
+                    acc += x1;
+                    acc += x2;
+                    acc += x3;
                 }
+                for (; a < t_hi[j]; ++a) acc += row[sc_pad(a)];
+                double r = acc / t_msum[j];
+                if (FLUX) r = (r * vel_conv) * t_qsi[j];  // com_mols.py:60 then _conductivity.py:21-23
+                out[((size_t)f * n_attr + k0 + kk) * n_seg + b.s0 + t_seg[j]] = r;
+            }
         }
-    }
+    };
+    if (steps > 0) fetch(0);
+    for (long long step = 0; step < steps; ++step) process(step);
 }
 
 // Runs of whole segments with <= SC_CAP atoms and <= 256 segments each; false when a segment is longer.
-bool build_seg_blocks(int64_t n_seg, const int64_t *seg_off, std::vector<SegBlock> &blocks)
+bool build_seg_blocks(int64_t n_seg, const int64_t *seg_off, std::vector<SegBlock> &blocks, int SC_CAP = SC_CAP_MAX)
 {
     blocks.clear();
     int64_t s0 = 0;
@@ -247,7 +293,8 @@ int mdhip_segment_com(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, int n_a
         if (!d_out) return MDHIP_ENOMEM;
     }
     std::vector<SegBlock> blocks;
-    const bool staged = build_seg_blocks(n_seg, seg_off, blocks);
+    const int cap = ctx->opt_seg_cap == 512 ? 512 : SC_CAP_MAX;
+    const bool staged = build_seg_blocks(n_seg, seg_off, blocks, cap);
     SegBlock *d_blocks = nullptr;
     if (staged) {
         d_blocks = (SegBlock *)mdhip_ws(ctx, WS_AUX3, blocks.size() * sizeof(SegBlock));
@@ -258,12 +305,21 @@ int mdhip_segment_com(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, int n_a
     KernelTimer timer(ctx);
     if (staged) {
         // enough (block, frame slice) pairs to fill the chip several times over; a block loops over its frames
-        const int64_t want = ((int64_t)ctx->cu_count * 16 + (int64_t)blocks.size() - 1) / (int64_t)blocks.size();
-        const unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_frames, std::min<int64_t>(want, 65535)));
+        // frame slices: at least enough (block, slice) pairs to fill the chip several times over, and short runs of
+        // ~10 frames per block (measured at C4 shape: 82 slices 0.57 of HBM spec, 512 slices 0.63, 1250 slices 0.60)
+        int64_t want = ((int64_t)ctx->cu_count * 16 + (int64_t)blocks.size() - 1) / (int64_t)blocks.size();
+        want = std::max<int64_t>(want, n_frames / 10);
+        unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_frames, std::min<int64_t>(want, 65535)));
+        if (ctx->opt_seg_gy > 0) gy = (unsigned)std::min<int64_t>(n_frames, ctx->opt_seg_gy);
         ctx->last_kernel = "segment_staged_kernel<false>";
-        hipLaunchKernelGGL(segment_staged_kernel<false>, dim3((unsigned)blocks.size(), gy), dim3(256), 0,
-                           ctx->stream, d_attr, d_mass, (const double *)nullptr, d_off, d_blocks, d_out, n_attr,
-                           (long long)n_atoms, (long long)n_seg, (long long)n_frames, 1.0, 1.0);
+        if (cap == 512)
+            hipLaunchKernelGGL((segment_staged_kernel<false, 512>), dim3((unsigned)blocks.size(), gy), dim3(256), 0,
+                               ctx->stream, d_attr, d_mass, (const double *)nullptr, d_off, d_blocks, d_out, n_attr,
+                               (long long)n_atoms, (long long)n_seg, (long long)n_frames, 1.0, 1.0, ctx->opt_seg_vec);
+        else
+            hipLaunchKernelGGL((segment_staged_kernel<false, 1024>), dim3((unsigned)blocks.size(), gy), dim3(256), 0,
+                               ctx->stream, d_attr, d_mass, (const double *)nullptr, d_off, d_blocks, d_out, n_attr,
+                               (long long)n_atoms, (long long)n_seg, (long long)n_frames, 1.0, 1.0, ctx->opt_seg_vec);
     } else {
         const unsigned gy = (unsigned)std::min<int64_t>(n_frames, 4096);
         ctx->last_kernel = "segment_com_kernel";
@@ -319,7 +375,8 @@ int mdhip_charge_flux(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const d
     const size_t flux_b = (size_t)3 * n_types * n_frames * 8;
     MD_WS(d_flux, double, WS_OUT, flux_b);
     std::vector<SegBlock> blocks;
-    const bool staged = build_seg_blocks(n_seg, seg_off, blocks);
+    const int cap = ctx->opt_seg_cap == 512 ? 512 : SC_CAP_MAX;
+    const bool staged = build_seg_blocks(n_seg, seg_off, blocks, cap);
     SegBlock *d_blocks = nullptr;
     if (staged) {
         d_blocks = (SegBlock *)mdhip_ws(ctx, WS_PART, blocks.size() * sizeof(SegBlock));
@@ -329,12 +386,18 @@ int mdhip_charge_flux(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const d
     }
     KernelTimer timer(ctx);
     if (staged) {
-        const int64_t want = ((int64_t)ctx->cu_count * 16 + (int64_t)blocks.size() - 1) / (int64_t)blocks.size();
+        int64_t want = ((int64_t)ctx->cu_count * 16 + (int64_t)blocks.size() - 1) / (int64_t)blocks.size();
+        want = std::max<int64_t>(want, n_frames / 10);
         const unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_frames, std::min<int64_t>(want, 65535)));
         ctx->last_kernel = "segment_staged_kernel<true>";
-        hipLaunchKernelGGL(segment_staged_kernel<true>, dim3((unsigned)blocks.size(), gy), dim3(256), 0,
-                           ctx->stream, d_vel, d_mq, d_mq + n_atoms, d_off, d_blocks, d_tmp, 3,
-                           (long long)n_atoms, (long long)n_seg, (long long)n_frames, vel_conv, charge_conv);
+        if (cap == 512)
+            hipLaunchKernelGGL((segment_staged_kernel<true, 512>), dim3((unsigned)blocks.size(), gy), dim3(256), 0,
+                               ctx->stream, d_vel, d_mq, d_mq + n_atoms, d_off, d_blocks, d_tmp, 3, (long long)n_atoms,
+                               (long long)n_seg, (long long)n_frames, vel_conv, charge_conv, ctx->opt_seg_vec);
+        else
+            hipLaunchKernelGGL((segment_staged_kernel<true, 1024>), dim3((unsigned)blocks.size(), gy), dim3(256), 0,
+                               ctx->stream, d_vel, d_mq, d_mq + n_atoms, d_off, d_blocks, d_tmp, 3, (long long)n_atoms,
+                               (long long)n_seg, (long long)n_frames, vel_conv, charge_conv, ctx->opt_seg_vec);
     } else {
         const unsigned gy = (unsigned)std::min<int64_t>(n_frames, 4096);
         ctx->last_kernel = "mol_flux_kernel";
