@@ -26,6 +26,7 @@
 #ifndef MDHIP_H
 #define MDHIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -283,6 +284,15 @@ int mdhip_xcorr_lags(mdhip_ctx *ctx, int64_t n, int n_pairs, const double *a, co
 int mdhip_cumtrapz(mdhip_ctx *ctx, int64_t n, int n_series, const double *y, int on_device,
                    double dx, int leading_zero, double *out);
 
+/* ---- pinned host staging memory (reader -> pinned buffers -> H2D) -------- */
+/*
+ * Page-locked host memory for the frame batches a caller parses into (mdproptools_amd/stream.py): host|dev inputs
+ * that live in it are copied by DMA at the PCIe rate, asynchronously to the host, instead of through the driver's
+ * bounce buffers. MDHIP_ENODEV without a usable HIP runtime.
+ */
+int mdhip_host_alloc(size_t bytes, void **out);
+void mdhip_host_free(void *p);
+
 /* ---- I/O: native LAMMPS text-dump reader (host only, no GPU needed) ---------------------------- */
 /* ---- neighbour-shell residence autocorrelation ---- */
 /*
@@ -319,6 +329,12 @@ int mdhip_dump_frame_info(mdhip_dump *d, int64_t f, int64_t *timestep, int64_t *
  * order when sort_col < 0. Parsing is split over n_threads host threads. */
 int mdhip_dump_read(mdhip_dump *d, int64_t f, int n_sel, const int32_t *col_idx, int sort_col, double *out,
                     int n_threads);
+
+/* As mdhip_dump_read, with one destination plane [natoms] per selected column: outs[s] may point anywhere — the
+ * streaming layer parses x, y, z straight into a slot of a page-locked batch buffer (mdhip_host_alloc) and the ids
+ * and types into arrays of their own, so that no copy stands between the text and the H2D transfer. */
+int mdhip_dump_read_cols(mdhip_dump *d, int64_t f, int n_sel, const int32_t *col_idx, int sort_col,
+                         double *const *outs, int n_threads);
 
 /* ---- native LAMMPS log reader (host only) ---------------------------------------------------- */
 /*

@@ -36,6 +36,8 @@ PROTOTYPES = {
     "mdhip_last_kernel_name": (C.c_char_p, [vp]),
     "mdhip_last_rel_bound": (C.c_double, [vp]),
     "mdhip_device_name": (C.c_int, [vp, C.c_char_p, C.c_int]),
+    "mdhip_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(vp)]),
+    "mdhip_host_free": (None, [vp]),
     "mdhip_set_option": (C.c_int, [vp, C.c_char_p, C.c_int]),
     "mdhip_bin_edges": (C.c_int, [C.c_double, C.c_int, c_dp]),
     "mdhip_pk_error_bound": (C.c_double, [C.c_double, C.c_double, C.c_int, C.c_int, C.c_double, C.c_double]),
@@ -74,6 +76,7 @@ PROTOTYPES = {
     "mdhip_dump_frame_info": (C.c_int, [vp, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), c_dp, c_dp,
                                         C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),
     "mdhip_dump_read": (C.c_int, [vp, C.c_int64, C.c_int, c_ip, C.c_int, c_dp, C.c_int]),
+    "mdhip_dump_read_cols": (C.c_int, [vp, C.c_int64, C.c_int, c_ip, C.c_int, C.POINTER(c_dp), C.c_int]),
     "mdhip_log_open": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
     "mdhip_log_close": (None, [vp]),
     "mdhip_log_error": (C.c_char_p, [vp]),

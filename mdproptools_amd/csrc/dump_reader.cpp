@@ -439,11 +439,15 @@ int mdhip_dump_frame_info(mdhip_dump *d, int64_t f, int64_t *timestep, int64_t *
     return MDHIP_OK;
 }
 
-static int dump_read_impl(mdhip_dump *d, int64_t f, int n_sel, const int32_t *col_idx, int sort_col, double *out,
-                          int n_threads)
+// outs[s] = destination plane [natoms] of selected column s (mdhip_dump_read: consecutive planes of one buffer;
+// mdhip_dump_read_cols: anywhere, e.g. x, y, z straight into a page-locked staging slot)
+static int dump_read_impl(mdhip_dump *d, int64_t f, int n_sel, const int32_t *col_idx, int sort_col,
+                          double *const *outs, int n_threads)
 {
-    if (!d || f < 0 || f >= (int64_t)d->frames.size() || n_sel < 0 || (n_sel && (!col_idx || !out)))
+    if (!d || f < 0 || f >= (int64_t)d->frames.size() || n_sel < 0 || (n_sel && (!col_idx || !outs)))
         return MDHIP_EINVAL;
+    for (int s = 0; s < n_sel; ++s)
+        if (!outs[s]) return MDHIP_EINVAL;
     const FrameIndex &fr = d->frames[f];
     for (int s = 0; s < n_sel; ++s)
         if (col_idx[s] < 0 || col_idx[s] >= fr.n_cols) {
@@ -536,7 +540,7 @@ static int dump_read_impl(mdhip_dump *d, int64_t f, int n_sel, const int32_t *co
     // scatter into SoA planes out[s][row]
     for (int64_t k = 0; k < n; ++k) {
         const int64_t r = dest[k];
-        for (int s = 0; s < n_sel; ++s) out[(size_t)s * n + r] = vals[(size_t)k * n_sel + s];
+        for (int s = 0; s < n_sel; ++s) outs[s][r] = vals[(size_t)k * n_sel + s];
     }
     return MDHIP_OK;
 }
@@ -713,7 +717,18 @@ int mdhip_dump_open(const char *path, mdhip_dump **out)
 
 int mdhip_dump_read(mdhip_dump *d, int64_t f, int n_sel, const int32_t *col_idx, int sort_col, double *out, int n_threads)
 {
-    return guarded([&] { return dump_read_impl(d, f, n_sel, col_idx, sort_col, out, n_threads); });
+    return guarded([&] {
+        if (!d || f < 0 || f >= (int64_t)d->frames.size() || n_sel < 0 || (n_sel && !out)) return (int)MDHIP_EINVAL;
+        std::vector<double *> outs((size_t)n_sel);
+        for (int s = 0; s < n_sel; ++s) outs[s] = out + (size_t)s * (size_t)d->frames[f].natoms;
+        return dump_read_impl(d, f, n_sel, col_idx, sort_col, outs.data(), n_threads);
+    });
+}
+
+int mdhip_dump_read_cols(mdhip_dump *d, int64_t f, int n_sel, const int32_t *col_idx, int sort_col, double *const *outs,
+                         int n_threads)
+{
+    return guarded([&] { return dump_read_impl(d, f, n_sel, col_idx, sort_col, outs, n_threads); });
 }
 
 int mdhip_log_open(const char *path, mdhip_log **out)

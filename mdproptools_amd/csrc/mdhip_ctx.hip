@@ -167,6 +167,29 @@ double mdhip_last_aux_ms(mdhip_ctx *ctx) { return ctx ? ctx->last_aux_ms : 0.0; 
 const char *mdhip_last_kernel_name(mdhip_ctx *ctx) { return ctx ? ctx->last_kernel : ""; }
 double mdhip_last_rel_bound(mdhip_ctx *ctx) { return ctx ? ctx->last_rel_bound : 0.0; }
 
+int mdhip_host_alloc(size_t bytes, void **out)
+{
+    if (!out) return MDHIP_EINVAL;
+    *out = nullptr;
+    if (bytes == 0) return MDHIP_OK;
+    void *p = nullptr;
+    // non-coherent = ordinary cached host memory that is page-locked: the reader threads scatter 8-byte values into
+    // it (fine-grained coherent host memory is uncached for the CPU on this platform: that scatter ran 4x slower), and
+    // the only consumer is an explicit hipMemcpyAsync, which needs no CPU/GPU coherence
+    const hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocNonCoherent);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return e == hipErrorOutOfMemory ? MDHIP_ENOMEM : MDHIP_ENODEV;
+    }
+    *out = p;
+    return MDHIP_OK;
+}
+
+void mdhip_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
 int mdhip_device_name(mdhip_ctx *ctx, char *buf, int buflen)
 {
     if (!ctx || !buf || buflen <= 0) return MDHIP_EINVAL;

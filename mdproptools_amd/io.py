@@ -298,6 +298,20 @@ def _pandas_file_frames(fname, columns, sort_by):
     return out
 
 
+def native_read_into(nd, f, names, columns, dests, sort_by="id", n_threads=1):
+    """Columns `columns` of frame f of the open NativeDumpFile `nd`, parsed straight into the float64 arrays `dests`
+    (one [natoms] array per column, each contiguous; they may be slices of a page-locked staging buffer)."""
+    C = nd._C
+    if sort_by is not None and sort_by not in names:
+        raise KeyError(sort_by)
+    idx = np.array([names.index(c) for c in columns], dtype=np.int32)
+    ptrs = (C.POINTER(C.c_double) * len(dests))(*[d.ctypes.data_as(C.POINTER(C.c_double)) for d in dests])
+    rc = nd._lib.mdhip_dump_read_cols(nd._h, f, len(idx), idx.ctypes.data_as(C.POINTER(C.c_int32)),
+                                      names.index(sort_by) if sort_by is not None else -1, ptrs, int(n_threads))
+    if rc != 0:
+        raise ValueError((nd._lib.mdhip_dump_error(nd._h) or b"").decode())
+
+
 def _native_file_frames(fname, columns, sort_by, n_threads):
     if str(fname).endswith(".gz"):
         return _pandas_file_frames(fname, columns, sort_by)

@@ -34,6 +34,8 @@ from ..io import parse_lammps_dumps
 CON_CONSTANT = 1.660538921  # amu/A^3 -> g/cm^3 (rdf_cn.py:30)
 VERBOSE = False
 MAX_BATCH_BYTES = 1 << 30  # coordinates staged per library call
+STREAM = True  # parse the next batch of frames (into page-locked staging buffers) while the GPU runs the current one;
+               # the frames of a trajectory are then never all resident on the host (mdproptools_amd/stream.py)
 
 _R_LABEL = "r ($\\AA$)"
 
@@ -56,8 +58,9 @@ def _initialize(r_cut, bin_size, filename, partial_relations):
     else:
         num_bins = int(r_cut / bin_size)
         radii = (np.arange(num_bins) + 0.5) * bin_size
-    dumps = _load_frames(filename, shard=True)
-    return dumps, num_bins, radii, len(dumps), len(partial_relations[0])
+    dumps = _load_frames(filename, shard=True, stream=STREAM)
+    n_known = len(dumps) if hasattr(dumps, "__len__") else None  # (a stream knows its length only at its end)
+    return dumps, num_bins, radii, n_known, len(partial_relations[0])
 
 
 def _calc_atom_type(ids, num_mols, num_atoms):
@@ -184,15 +187,26 @@ class _Frame:
         self.timestep, self.ids, self.types, self.xyz, self.lengths = timestep, ids, types, xyz, lengths
 
     @classmethod
+    def view(cls, fr):
+        """A frame of a streamed batch (views into the staging buffer; no message: the stream printed it)."""
+        self = cls.__new__(cls)
+        self.timestep, self.ids, self.types, self.xyz, self.lengths = fr.timestep, fr.ids, fr.types, fr.xyz, fr.lengths
+        return self
+
+    @classmethod
     def from_dump(cls, dump):
         tbl = dump.data[["id", "type", "x", "y", "z"]].sort_values("id").to_numpy(dtype=np.float64)
         return cls(dump.timestep, tbl[:, 0], tbl[:, 1], np.ascontiguousarray(tbl[:, 2:5].T),
                    dump.box.to_lattice().lengths)
 
 
-def _load_frames(filename, shard=False):
+def _load_frames(filename, shard=False, stream=False):
     """Every frame of `filename` (file or '*' pattern, numeric order). The native reader of libmdhip.so
     produces the same doubles as the pandas-based one (tests/test_dump_reader_cpu.py), ~10x faster.
+
+    stream=True (what the public functions ask for): a `stream.FrameStream` instead of a list — `_batches` then
+    yields batches as the producer thread finishes parsing them, the frames of the trajectory are never all
+    resident on the host (the reference builds the whole list first, rdf_cn.py:176).
 
     shard=True under torch.distributed (one process per GPU): a rank parses and returns only ITS share of the
     trajectory — a contiguous block of the files when there are at least as many files as ranks, else a
@@ -206,7 +220,13 @@ def _load_frames(filename, shard=False):
         matches = mio._sorted_matches(str(filename))
         if len(matches) >= D.rank_world()[1]:
             files = D.shard_items(matches)
-    if mio.USE_NATIVE_READER and (isinstance(filename, str) or hasattr(filename, "__fspath__")):
+    is_path = isinstance(filename, str) or hasattr(filename, "__fspath__")
+    if stream and mio.USE_NATIVE_READER and is_path and (not sharded or files is not None):
+        from ..stream import FrameStream
+
+        return FrameStream(str(filename), files=files,
+                           on_frame=lambda ts: _say("The timestep of the current file is: " + str(ts)))
+    if mio.USE_NATIVE_READER and is_path:
         frames = [_Frame(ts, planes[0], planes[1], np.ascontiguousarray(planes[2:5]), lengths)
                   for ts, _b, lengths, _names, planes in
                   mio.iter_native_frames(str(filename), ["id", "type", "x", "y", "z"], sort_by="id", files=files)]
@@ -239,8 +259,27 @@ def _is_writer():
     return D.rank_world()[0] == 0
 
 
+class _Batch(list):
+    """The frames of one library call; `block` = their coordinates as ONE array [B,3,N] when they already sit in a
+    staging buffer (streamed batches), else None."""
+
+    block = None
+
+
+def _xyz_block(batch):
+    return batch.block if getattr(batch, "block", None) is not None else np.stack([f.xyz for f in batch])
+
+
 def _batches(frames):
-    """Consecutive frames with the same atom count, capped at MAX_BATCH_BYTES of coordinates."""
+    """Consecutive frames with the same atom count, capped at MAX_BATCH_BYTES of coordinates. A FrameStream
+    yields its own batches (the staging buffer goes back to the producer when the loop asks for the next one:
+    everything a caller keeps from a batch must be a copy)."""
+    if not isinstance(frames, list):
+        for sb in frames:
+            b = _Batch(_Frame.view(fr) for fr in sb)
+            b.block = sb.xyz
+            yield b
+        return
     start = 0
     while start < len(frames):
         n = frames[start].xyz.shape[1]
@@ -289,7 +328,7 @@ def calc_atomic_rdf(r_cut, bin_size, num_types, mass, partial_relations, filenam
         labels = [(_calc_atom_type(f.ids, num_mols, num_atoms_per_mol) if altered else f.types) for f in batch]
         props = [_calc_props(f.lengths, lab, lab, num_types, mass, partial_relations, altered,
                              num_atoms_per_mol) for f, lab in zip(batch, labels)]
-        full, part, ov = backend.rdf_loop(np.stack([f.xyz for f in batch]), _labels_for(batch, labels),
+        full, part, ov = backend.rdf_loop(_xyz_block(batch), _labels_for(batch, labels),
                                           np.array([f.lengths for f in batch]), relation_matrix, r_cut,
                                           bin_size, num_bins, per_frame=True)
         dropped += ov
@@ -330,7 +369,7 @@ def calc_atomic_cn(r_cut, bin_size, num_types, mass, partial_relations, filename
         labels = [(_calc_atom_type(f.ids, num_mols, num_atoms_per_mol) if altered else f.types) for f in batch]
         props = [_calc_props(f.lengths, lab, lab, num_types, mass, partial_relations, altered,
                              num_atoms_per_mol) for f, lab in zip(batch, labels)]
-        raw = backend.cn_loop(np.stack([f.xyz for f in batch]), _labels_for(batch, labels),
+        raw = backend.cn_loop(_xyz_block(batch), _labels_for(batch, labels),
                               np.array([f.lengths for f in batch]), relation_matrix, list(r_cut),
                               per_frame=True)
         for k, f in enumerate(batch):
@@ -355,7 +394,7 @@ def _molecular_inputs(batch, num_mols, num_atoms_per_mol, mass):
     n = batch[0].xyz.shape[1]
     if seg_off[-1] != n:
         raise ValueError(f"Length of values ({int(seg_off[-1])}) does not match length of index ({n})")
-    xyz = np.stack([f.xyz for f in batch])
+    xyz = _xyz_block(batch)
     atom_mass = np.asarray(mass, dtype=np.float64)[batch[0].types.astype(np.int64) - 1]
     if _same_types(batch):
         sites, _, _ = backend.segment_com(xyz, atom_mass, seg_off)

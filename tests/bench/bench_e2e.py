@@ -9,6 +9,15 @@ Reports, as one JSON line: time to write the synthetic dumps (not part of any fi
 native reader (default) and with the pandas text route the reference takes (pymatgen's parser is pandas.read_csv
 per frame), the library's kernel time inside them, and — for the reference's compute side — the C oracle on a
 bounded sample of frames extrapolated linearly. The reference's own end-to-end time is text route + CPU loop.
+
+Round 2: the streamed pipeline (reader -> page-locked staging buffers -> H2D -> kernels, mdproptools_amd/stream.py)
+against the load-everything-first route, with the parse / copy / kernel split of the streamed call:
+  parse      producer thread busy parsing text (runs beside the GPU work)
+  lib_calls  wall time inside the library calls of the consumer (H2D of the pinned batch + pre-pass + pair kernel +
+             D2H of the histograms); device = the kernels' own time; copy = lib_calls - device
+  host_rest  per-frame normalisation, DataFrame, CSV
+
+    python tests/bench/bench_e2e.py 100000 100      # 100 frames of BASELINE C3 size
 """
 import json
 import os
@@ -49,39 +58,103 @@ def main():
         ctx = default_context(0)
         rdf_cn.calc_atomic_rdf(20.0, 0.05, 4, mass, rel, os.path.join(tmp, "dump.nvt.0.dump"), save_mode=False)  # warm-up
 
+        from mdproptools_amd import backend as Bk
+
+        calls = {"wall": 0.0, "device_ms": 0.0, "n": 0}
+        orig_rdf_loop = Bk.rdf_loop
+
+        def timed_rdf_loop(*a, **kw):
+            t0 = time.perf_counter()
+            out = orig_rdf_loop(*a, **kw)
+            calls["wall"] += time.perf_counter() - t0
+            calls["device_ms"] += ctx.last_kernel_ms()[0] + ctx.last_aux_ms()
+            calls["n"] += 1
+            return out
+
+        Bk.rdf_loop = timed_rdf_loop
+
+        def run_streamed(on):
+            import mdproptools_amd.stream as S
+
+            rdf_cn.STREAM = on
+            calls.update(wall=0.0, device_ms=0.0, n=0)
+            made = []
+            orig_init = S.FrameStream.__init__
+
+            def spy(self, *a, **kw):
+                orig_init(self, *a, **kw)
+                made.append(self)
+
+            S.FrameStream.__init__ = spy
+            try:
+                t0 = time.perf_counter()
+                g = rdf_cn.calc_atomic_rdf(20.0, 0.05, 4, mass, rel, pattern, path_or_buff=os.path.join(tmp, "rdf.csv"))
+                wall = time.perf_counter() - t0
+            finally:
+                S.FrameStream.__init__ = orig_init
+                rdf_cn.STREAM = True
+            st = made[0].stats if made else {}
+            return g, dict(wall_s=wall, lib_calls_s=calls["wall"], device_s=calls["device_ms"] * 1e-3,
+                           copy_s=calls["wall"] - calls["device_ms"] * 1e-3, library_calls=calls["n"],
+                           parse_s=st.get("parse_s"), consumer_waited_for_parser_s=st.get("consumer_wait_s"),
+                           pinned=st.get("pinned"), batches=st.get("batches"),
+                           host_rest_s=wall - calls["wall"] - (st.get("consumer_wait_s") or 0.0))
+
         def run(native):
             mio.USE_NATIVE_READER = native
             t0 = time.perf_counter()
             g = rdf_cn.calc_atomic_rdf(20.0, 0.05, 4, mass, rel, pattern, path_or_buff=os.path.join(tmp, "rdf.csv"))
             t_rdf = time.perf_counter() - t0
-            k_rdf = ctx.last_kernel_ms()[0] + ctx.last_aux_ms()
+            k_rdf = calls["device_ms"]
             t0 = time.perf_counter()
             rdf_cn.calc_atomic_cn([2.325 + 0.5 * k for k in range(10)], 0.05, 4, mass, rel, pattern,
                                   path_or_buff=os.path.join(tmp, "cn.csv"))
             t_cn = time.perf_counter() - t0
             return g, t_rdf, k_rdf, t_cn
 
+        # the first read of freshly written files pays the page-table population of their mappings (5-20x the
+        # steady-state parse time): one untimed pass first, then each route twice, the better of the two reported
+        list(mio.iter_native_frames(pattern, ["id", "type", "x", "y", "z"]))
+        best = {}
+        for rep in range(2):
+            for on in (True, False):
+                g, rec = run_streamed(on)
+                if on not in best or rec["wall_s"] < best[on][1]["wall_s"]:
+                    best[on] = (g, rec)
+        (g_st, streamed), (g_ls, listed) = best[True], best[False]
+        assert np.array_equal(g_st.to_numpy(), g_ls.to_numpy())
+        calls.update(wall=0.0, device_ms=0.0, n=0)
         g_nat, rdf_nat, k_rdf, cn_nat = run(True)
-        g_txt, rdf_txt, _, cn_txt = run(False)
-        assert np.array_equal(g_nat.to_numpy(), g_txt.to_numpy())  # same doubles from both readers
+        if n * F <= 4_000_000:
+            g_txt, rdf_txt, _, cn_txt = run(False)
+            assert np.array_equal(g_nat.to_numpy(), g_txt.to_numpy())  # same doubles from both readers
+        else:
+            rdf_txt = float("nan")
         mio.USE_NATIVE_READER = True
         t0 = time.perf_counter()
         list(mio.iter_native_frames(pattern, ["id", "type", "x", "y", "z"]))
         parse_nat = time.perf_counter() - t0
         t0 = time.perf_counter()
+        n_txt = 0
         for d in mio.parse_lammps_dumps(pattern):
             d.data.sort_values("id")
-        parse_txt = time.perf_counter() - t0
+            n_txt += 1
+            if n_txt * n >= 2_000_000:
+                break
+        parse_txt = (time.perf_counter() - t0) * F / n_txt
         # CPU loop of the reference (C oracle, one core) on 4 frames
         cref.build()
         s = min(4, F)
         t0 = time.perf_counter()
+        rows = n if n <= 20_000 else 2000  # large frames: the first head rows only (cost is linear in the pairs)
+        pairs_s = rows * n - rows * (rows + 1) // 2
         for f in range(s):
-            cref.rdf_pairs(xyz[f], ty, np.array(synth.ALL_PAIRS_4), [L] * 3, 400.0, 0.05, 400)
-        cpu_loop = (time.perf_counter() - t0) / s * F
+            cref.rdf_pairs(xyz[f], ty, np.array(synth.ALL_PAIRS_4), [L] * 3, 400.0, 0.05, 400, rows=(0, rows))
+        cpu_loop = (time.perf_counter() - t0) / s * F * (n * (n - 1) / 2) / pairs_s
     print(json.dumps(dict(
         workload="%d dump files x %d atoms (id type x y z), L = %.1f A, calc_atomic_rdf (10 relations, r_cut 20, 400 bins)"
                  " + calc_atomic_cn" % (F, n, L),
+        streamed=streamed, load_all_first=listed,
         dropin_rdf_s=rdf_nat, dropin_cn_s=cn_nat, of_which_gpu_kernels_s=k_rdf * 1e-3, parse_native_s=parse_nat,
         dropin_rdf_with_text_reader_s=rdf_txt, parse_text_reader_s=parse_txt,
         reference_cpu_loop_extrapolated_s=cpu_loop, reference_end_to_end_estimate_s=parse_txt + cpu_loop,
