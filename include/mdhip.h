@@ -256,7 +256,7 @@ int mdhip_charge_flux(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const d
                       double vel_conv, double charge_conv, double *flux);
 
 /* ---- G2 / G3: correlation functions ---------------------------------------- */
-#define MDHIP_XCORR_FFT 0    /* zero-padded length-2n FFT: conductivity.py:109-114, viscosity.py:111-115 */
+#define MDHIP_XCORR_FFT 0    /* zero-padded FFT (reference: length 2n; here the next power of two >= 2n, same linear correlation): conductivity.py:109-114, viscosity.py:111-115 */
 #define MDHIP_XCORR_DIRECT 1 /* direct lag sums:           viscosity.py:103-108 ("brute_force")        */
 /*
  * out[p][k] = sum_{t=0}^{n-1-k} a_p[t+k] * b_p[t] / (n-k),  k = 0..n_lags-1, for n_pairs series pairs.

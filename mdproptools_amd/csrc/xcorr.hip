@@ -29,12 +29,12 @@ namespace {
 // FFT path
 // ---------------------------------------------------------------------------------------------
 
-// dst[p][i] = i < n ? src[p][i] : 0 for the 2n-point padded copies of `batch` series (grid.y = batch)
-__global__ void pad_kernel(const double *__restrict__ src, double *__restrict__ dst, long long n)
+// dst[p][i] = i < n ? src[p][i] : 0 for the L-point padded copies of `batch` series (grid.y = batch), L >= 2n
+__global__ void pad_kernel(const double *__restrict__ src, double *__restrict__ dst, long long n, long long L)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long p = blockIdx.y;
-    if (i < 2 * n) dst[p * 2 * n + i] = i < n ? src[p * n + i] : 0.0;
+    if (i < L) dst[p * L + i] = i < n ? src[p * n + i] : 0.0;
 }
 
 // A <- A * conj(B), m complex values per series
@@ -47,14 +47,14 @@ __global__ void mul_conj_kernel(double2 *__restrict__ A, const double2 *__restri
     A[k] = make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
 }
 
-// out[p][k] = c[p][k] / (2n) / (n-k): numpy's ifft normalisation, then conductivity.py:113 / viscosity.py:114
+// out[p][k] = c[p][k] / L / (n-k): the inverse transform's normalisation, then conductivity.py:113 / viscosity.py:114
 __global__ void scale_unbiased_kernel(const double *__restrict__ c, double *__restrict__ out,
-                                      long long n, long long n_lags)
+                                      long long n, long long L, long long n_lags)
 {
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_lags) return;
     const long long p = blockIdx.y;
-    out[p * n_lags + k] = (c[p * 2 * n + k] / (double)(2 * n)) / (double)(n - k);
+    out[p * n_lags + k] = (c[p * L + k] / (double)L) / (double)(n - k);
 }
 
 struct FftPlans {
@@ -62,20 +62,31 @@ struct FftPlans {
 };
 std::map<std::tuple<mdhip_ctx *, long long, int>, FftPlans> g_plans;
 
-// batched 2n-point real transforms (one launch sequence for all series pairs of a chunk)
-int get_plans(mdhip_ctx *ctx, long long n, int batch, FftPlans &out)
+// Transform length: the reference pads to 2n (conductivity.py:111, viscosity.py:112); any length >= 2n - 1 gives the
+// same linear correlation. rocFFT compiles its kernels at run time for every NEW length (1.4-1.8 s each, measured),
+// so the length is rounded up to a power of two: series of similar lengths share one plan, and a process pays for
+// at most ~20 distinct lengths instead of one per series length. The result moves by rounding only (tests: 1e-10 acf[0]).
+long long fft_length(long long n)
 {
-    auto key = std::make_tuple(ctx, n, batch);
+    long long L = 2;
+    while (L < 2 * n) L <<= 1;
+    return L;
+}
+
+// batched L-point real transforms (one launch sequence for all series pairs of a chunk)
+int get_plans(mdhip_ctx *ctx, long long L, int batch, FftPlans &out)
+{
+    auto key = std::make_tuple(ctx, L, batch);
     auto it = g_plans.find(key);
     if (it != g_plans.end()) {
         out = it->second;
         return MDHIP_OK;
     }
     FftPlans p;
-    int len = (int)(2 * n);
+    int len = (int)L;
     if (hipfftPlanMany(&p.fwd, 1, &len, nullptr, 1, len, nullptr, 1, len / 2 + 1, HIPFFT_D2Z, batch) != HIPFFT_SUCCESS ||
         hipfftPlanMany(&p.inv, 1, &len, nullptr, 1, len / 2 + 1, nullptr, 1, len, HIPFFT_Z2D, batch) != HIPFFT_SUCCESS)
-        return mdhip_fail(ctx, MDHIP_EHIP, "hipfftPlanMany(%lld x %d) failed", 2 * n, batch);
+        return mdhip_fail(ctx, MDHIP_EHIP, "hipfftPlanMany(%lld x %d) failed", L, batch);
     g_plans[key] = p;
     out = p;
     return MDHIP_OK;
@@ -84,26 +95,27 @@ int get_plans(mdhip_ctx *ctx, long long n, int batch, FftPlans &out)
 int xcorr_fft(mdhip_ctx *ctx, long long n, int n_pairs, const double *d_a, const double *d_b,
               bool same, long long n_lags, double *d_out)
 {
-    const long long m = n + 1;  // complex outputs of a 2n-point real transform
+    const long long L = fft_length(n);
+    const long long m = L / 2 + 1;  // complex outputs of an L-point real transform
     // series pairs per chunk: all of them while the padded copies stay below ~1 GiB
-    int chunk = (int)std::max<long long>(1, std::min<long long>(n_pairs, (1LL << 30) / (2 * n * 8 * 3)));
-    MD_WS(d_pad, double, WS_AUX0, (size_t)chunk * 2 * n * 8 + 64);
+    int chunk = (int)std::max<long long>(1, std::min<long long>(n_pairs, (1LL << 30) / (L * 8 * 3)));
+    MD_WS(d_pad, double, WS_AUX0, (size_t)chunk * L * 8 + 64);
     MD_WS(d_A, double2, WS_AUX1, (size_t)chunk * m * 16);
     MD_WS(d_B, double2, WS_AUX2, (size_t)(same ? 1 : chunk) * m * 16);
     for (int p0 = 0; p0 < n_pairs; p0 += chunk) {
         const int nb = std::min(chunk, n_pairs - p0);
         FftPlans pl;
-        int rc = get_plans(ctx, n, nb, pl);
+        int rc = get_plans(ctx, L, nb, pl);
         if (rc) return rc;
         hipfftSetStream(pl.fwd, ctx->stream);
         hipfftSetStream(pl.inv, ctx->stream);
-        const dim3 gp((unsigned)((2 * n + 255) / 256), (unsigned)nb), gm((unsigned)((m + 255) / 256), (unsigned)nb);
-        hipLaunchKernelGGL(pad_kernel, gp, dim3(256), 0, ctx->stream, d_a + (size_t)p0 * n, d_pad, n);
+        const dim3 gp((unsigned)((L + 255) / 256), (unsigned)nb), gm((unsigned)((m + 255) / 256), (unsigned)nb);
+        hipLaunchKernelGGL(pad_kernel, gp, dim3(256), 0, ctx->stream, d_a + (size_t)p0 * n, d_pad, n, L);
         if (hipfftExecD2Z(pl.fwd, d_pad, reinterpret_cast<hipfftDoubleComplex *>(d_A)) != HIPFFT_SUCCESS)
             return mdhip_fail(ctx, MDHIP_EHIP, "hipfftExecD2Z failed");
         const double2 *Bp = d_A;
         if (!same) {
-            hipLaunchKernelGGL(pad_kernel, gp, dim3(256), 0, ctx->stream, d_b + (size_t)p0 * n, d_pad, n);
+            hipLaunchKernelGGL(pad_kernel, gp, dim3(256), 0, ctx->stream, d_b + (size_t)p0 * n, d_pad, n, L);
             if (hipfftExecD2Z(pl.fwd, d_pad, reinterpret_cast<hipfftDoubleComplex *>(d_B)) != HIPFFT_SUCCESS)
                 return mdhip_fail(ctx, MDHIP_EHIP, "hipfftExecD2Z failed");
             Bp = d_B;
@@ -112,7 +124,7 @@ int xcorr_fft(mdhip_ctx *ctx, long long n, int n_pairs, const double *d_a, const
         if (hipfftExecZ2D(pl.inv, reinterpret_cast<hipfftDoubleComplex *>(d_A), d_pad) != HIPFFT_SUCCESS)
             return mdhip_fail(ctx, MDHIP_EHIP, "hipfftExecZ2D failed");
         hipLaunchKernelGGL(scale_unbiased_kernel, dim3((unsigned)((n_lags + 255) / 256), (unsigned)nb), dim3(256), 0,
-                           ctx->stream, d_pad, d_out + (size_t)p0 * n_lags, n, n_lags);
+                           ctx->stream, d_pad, d_out + (size_t)p0 * n_lags, n, L, n_lags);
         MD_HIP(hipGetLastError());
     }
     return MDHIP_OK;
@@ -260,7 +272,7 @@ int mdhip_xcorr_lags(mdhip_ctx *ctx, int64_t n, int n_pairs, const double *a, co
     MD_REQUIRE(lag_begin == 0 || method == MDHIP_XCORR_DIRECT, "a lag range needs the direct method");
     if (n == 0 || n_pairs == 0 || n_lags == 0) return MDHIP_OK;
     MD_REQUIRE(a && b && out, "NULL array");
-    MD_REQUIRE(n < (1LL << 30), "series longer than 2^30 samples are not supported");
+    MD_REQUIRE(n < (1LL << 29), "series longer than 2^29 samples are not supported");
     MD_HIP(hipSetDevice(ctx->device));
     int rc;
     const size_t in_b = (size_t)n_pairs * n * 8;
