@@ -311,6 +311,28 @@ def test_dropin_rdf_cn_two_ranks_on_gpu(tmp_path):
     assert open(tmp_path / "w2" / "rdf.csv").read() == open(tmp_path / "w1" / "rdf.csv").read()
 
 
+def test_calc_atomic_rdf_cn_one_pass(c1_dir, tmp_path):
+    """calc_atomic_rdf_cn == (calc_atomic_rdf, calc_atomic_cn) on the mg_tfsi_dme frames, DataFrames bit for bit,
+    default and altered ids; the two CSV files are the ones the separate calls write."""
+    from mdproptools_amd.structural.rdf_cn import calc_atomic_cn, calc_atomic_rdf, calc_atomic_rdf_cn
+
+    g, pat, tmp = c1_dir
+    rel = [[9, 9, 9, 9, 1], [1, 4, 6, 9, 3]]
+    cuts = [2.3, 2.3, 3.1, 6.0, 1.5]
+    for kw in ({}, dict(num_mols=g["num_mols"].tolist(), num_atoms_per_mol=g["num_atoms_per_mol"].tolist())):
+        r = rel if not kw else [[32, 32], [17, 32]]
+        c = cuts if not kw else [2.4, 5.5]
+        a = calc_atomic_rdf(20, 0.05, 9, MASS, r, pat, path_or_buff=str(tmp_path / "a.csv"), **kw)
+        b = calc_atomic_cn(c, 0.05, 9, MASS, r, pat, path_or_buff=str(tmp_path / "b.csv"), **kw)
+        g2, c2 = calc_atomic_rdf_cn(20, c, 0.05, 9, MASS, r, pat, rdf_path_or_buff=str(tmp_path / "g.csv"),
+                                    cn_path_or_buff=str(tmp_path / "c.csv"), **kw)
+        assert list(g2.columns) == list(a.columns) and list(c2.columns) == list(b.columns)
+        np.testing.assert_array_equal(g2.to_numpy(), a.to_numpy())
+        np.testing.assert_array_equal(c2.to_numpy(), b.to_numpy())
+        assert open(tmp_path / "g.csv").read() == open(tmp_path / "a.csv").read()
+        assert open(tmp_path / "c.csv").read() == open(tmp_path / "b.csv").read()
+
+
 def test_calc_intermolecular_rdf(c1_dir):
     """Molecule-COM to molecule-COM g(r) (rdf_cn.py:857-903) against the real reference on two mg_tfsi_dme
     frames: num_types counts molecule types there while `mass` still lists atom masses."""
