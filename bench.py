@@ -314,17 +314,20 @@ def leg_f64_only(B, ctx, xyz, types, box, rel, cfg, nb, steps, pairs_per_step, f
             "roofline": valu_roofline(kernel, "C2", kdur, "v_add_f64", 4, pairs_per_step, 28.0 * n * F)}
 
 
-def leg_h2d(B, ctx, torch, xyz_host, types, box, rel, cfg, nb, steps, pairs_per_step, sync):
+def leg_h2d(B, ctx, torch, xyz_host, types, box, rel, cfg, nb, steps, pairs_per_step, sync, resident_ms):
     """the library call on host arrays, staging included (never `value`)."""
-    out = {}
+    out = {"resident_ms_per_step": resident_ms}
     pinned = torch.empty(xyz_host.shape, dtype=torch.float64, pin_memory=True)
     pinned.numpy()[...] = xyz_host
     for name, arr in (("pageable", xyz_host), ("pinned", pinned.numpy())):
         dt, _ = timed(lambda: B.rdf_loop(arr, types, box, rel, cfg["r_cut"], cfg["bin_size"], nb, per_frame=False,
                                          ctx=ctx), sync, steps)
-        out[name] = {"value": pairs_per_step / dt, "unit": "atom-pairs/s", "ms_per_step": dt * 1e3,
-                     "h2d_GBps_if_serial": xyz_host.nbytes / dt / 1e9}
+        out[name] = {"value": pairs_per_step / dt, "unit": "atom-pairs/s", "ms_per_step": dt * 1e3}
     out["bytes_per_step"] = int(xyz_host.nbytes)
+    for name in ("pageable", "pinned"):  # what the staging costs on top of the resident step, as a copy rate
+        extra = out[name]["ms_per_step"] - resident_ms
+        out[name]["h2d_ms_per_step"] = extra
+        out[name]["h2d_GBps"] = xyz_host.nbytes / (extra * 1e-3) / 1e9 if extra > 0 else None
     return out
 
 
@@ -362,14 +365,18 @@ def leg_c3(B, ctx, torch, device, synth, sync):
     if hasattr(B, "rdf_cn_loop"):
         def both():
             o = B.rdf_cn_loop(xyz, ty, box, rel, cfg["r_cut"], cfg["bin_size"], nb, cuts, per_frame=False, ctx=ctx)
-            km["both"] = (ctx.last_kernel_ms()[0], ctx.last_aux_ms(), ctx.last_kernel_name())
+            km["both"] = (ctx.last_kernel_ms()[0], ctx.last_aux_ms(), ctx.last_kernel_name(), ctx.last_kernel_ms()[1])
             return o
 
         t_both, (full2, part2, _o2, cnt2) = timed(both, sync, 2)
         same = bool(np.array_equal(full2, full) and np.array_equal(part2, part) and np.array_equal(cnt2, cnt))
         out["rdf_cn_one_sweep"] = {"wall_s": t_both, "kernel_s": km["both"][0] * 1e-3, "kernel": km["both"][2],
                                    "value": pairs / t_both, "unit": "atom-pairs/s",
-                                   "over_rdf_alone": t_both / t_rdf, "identical_to_separate_calls": same}
+                                   "over_rdf_alone": t_both / t_rdf, "identical_to_separate_calls": same,
+                                   "launches": km["both"][3],
+                                   "roofline": valu_roofline(km["both"][2], "C3", km["both"][0] * 1e-3 / km["both"][3],
+                                                             "mix bin 11/16", 6, pairs / km["both"][3],
+                                                             28.0 * n * F / km["both"][3])}
         if not same:
             t_both = t_rdf + t_cn  # a sweep whose integers differ is not counted
     # frame 0 at full size against the oracle (the frame split over the host cores by head rows)
@@ -560,6 +567,8 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=10)
     ap.add_argument("--variant", type=int, default=None, help="kernel variant knob (A/B only)")
     ap.add_argument("--option", action="append", default=[], help="library option key=value (A/B only)")
+    ap.add_argument("--op", choices=["rdf", "cn", "rdf_cn"], default="rdf",
+                    help="what the headline loop calls (profiling runs of the CN and the one-sweep kernels; N = 1)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -625,10 +634,24 @@ def main():
     pairs_local = F * pairs_per_frame
     pairs_job = (cfg["n_frames"] if strong else world * F) * pairs_per_frame
 
+    class _Done:  # (profiling ops: the same handle protocol as the sharded RDF call)
+        def __init__(self, res):
+            self.res = res
+
+        def wait(self):
+            return self.res
+
     def step():
         # N > 1: frame shards per rank, one RCCL all-reduce of the uint64 histograms per step
         # (mdproptools_amd/dist.py). The collective of step k is left in flight while step k+1 computes and is
         # waited for right after: every step's sums are complete inside the timed region.
+        if args.op == "cn":
+            B.cn_loop(xyz, types, box, rel, synth.cn_cutoffs(len(rel)), per_frame=False, ctx=ctx)
+            return _Done(None)
+        if args.op == "rdf_cn":
+            f_, p_, o_, _cn = B.rdf_cn_loop(xyz, types, box, rel, cfg["r_cut"], cfg["bin_size"], nb,
+                                            synth.cn_cutoffs(len(rel)), per_frame=False, ctx=ctx)
+            return _Done((f_, p_, [o_]))
         return D.rdf_sharded_async(xyz, types, box, rel, cfg["r_cut"], cfg["bin_size"], nb, ctx=ctx)
 
     def fence():
@@ -652,7 +675,7 @@ def main():
         if pending is not None:
             pending.wait()
         pending = handle
-    full, part, _ov = pending.wait()
+    last = pending.wait()
     fence()
     elapsed = time.perf_counter() - t0
     kernel_name = ctx.last_kernel_name()
@@ -662,9 +685,13 @@ def main():
         elapsed = float(tmax.item())
 
     # sanity inside the bench: the result of the last step is a real histogram of the right size
-    expect_in = 4.0 / 3.0 * np.pi * cfg["r_cut"] ** 3 / L ** 3
-    frac_in = float(full.sum()) / 2.0 / pairs_job
-    assert abs(frac_in - expect_in) < 0.01 * expect_in, (frac_in, expect_in)
+    if last is not None:
+        full, part, _ov = last
+        expect_in = 4.0 / 3.0 * np.pi * cfg["r_cut"] ** 3 / L ** 3
+        frac_in = float(full.sum()) / 2.0 / pairs_job
+        assert abs(frac_in - expect_in) < 0.01 * expect_in, (frac_in, expect_in)
+    if args.op != "rdf":
+        args.no_legs = True  # a profiling run
 
     if rank == 0:
         value = pairs_job * args.steps / elapsed
@@ -720,7 +747,8 @@ def main():
                                                      pairs_local, full, sync))
         if "h2d" in legs:
             run_leg("h2d_inclusive", lambda: leg_h2d(B, ctx, torch, xyz_host, types, box, rel, cfg, nb,
-                                                     max(5, args.steps // 2), pairs_local, sync))
+                                                     max(5, args.steps // 2), pairs_local, sync,
+                                                     elapsed / args.steps * 1e3))
         del xyz
         torch.cuda.empty_cache()
         if "c3" in legs:

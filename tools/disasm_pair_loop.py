@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """
 tools/disasm_pair_loop.py [kernel-substring] — opcode histogram of the hot loop of the packed-f32 pair kernel
-(pair_hist_sj_kernel<3, true>), from the compiler's own assembly of mdproptools_amd/csrc/pair_sj.hip (hipcc -S, the
+(pair_hist_sj_kernel<3, true, false>), from the compiler's own assembly of mdproptools_amd/csrc/pair_sj.hip (hipcc -S, the
 flags of mdproptools_amd/build.py; no GPU needed).
 
 The hot loop is the software-pipelined sweep of the common variant (no per-pair wrap): two unrolled copies of
