@@ -94,7 +94,7 @@ struct mdhip_ctx {
     int opt_rdf_sort = -1;    // spatial sort: -1 auto, 1 one block per frame (LDS counters), 0 multi-block (global counters)
     int opt_rdf_guard = 0;    // overflow guard of the 32-bit LDS histogram words: neighbour tiles a block may sweep
                               // per launch (0 = the real bound, 2^32 / (64 * 256) with margin; tests lower it)
-    int opt_seg_cap = 0;      // segment kernels: atoms per block stage, 1024 (default) or 512 (A/B)
+    int opt_seg_cap = 0;      // segment kernels: atoms per block stage, 1024 (default), 512, or 256 = one wave per block (A/B)
     int opt_seg_vec = 1;      // segment kernels: 16-byte loads when alignment allows (default), 0 = 8-byte loads (A/B)
     int opt_seg_gy = 0;       // segment kernels: frame slices per block run (0 = auto)
     int opt_xcorr_tile = 0;

@@ -34,8 +34,11 @@ constexpr int sc_stride(int cap) { return cap + cap / 32 + 2; }
 
 // FLUX = false: out[f][k][s] = sum(m a) / sum(m)                                   (com_mols.py:58-60)
 // FLUX = true : out[f][k][s] = (sum(m v) / sum(m) * vel_conv) * (sum(q) * charge_conv)   (_conductivity.py:21-25)
-template <bool FLUX, int SC_CAP>
-__global__ __launch_bounds__(256) void segment_staged_kernel(
+// NT = threads per block: 256 (four waves share a stage of SC_CAP atoms, two block barriers per step) or 64 — ONE wave
+// per block with a stage of 256 atoms: the barriers then cost nothing and every wave runs its own pipeline, decoupled
+// from its neighbours (the wave-private form; default whenever no segment is longer than 256 atoms).
+template <bool FLUX, int SC_CAP, int NT>
+__global__ __launch_bounds__(NT) void segment_staged_kernel(
     const double *__restrict__ attr, const double *__restrict__ mass, const double *__restrict__ q,
     const long long *__restrict__ seg_off, const SegBlock *__restrict__ blocks, double *__restrict__ out,
     int n_attr, long long n_atoms, long long n_seg, long long n_frames, double vel_conv, double charge_conv, int use_vec)
@@ -47,7 +50,7 @@ __global__ __launch_bounds__(256) void segment_staged_kernel(
     const SegBlock b = blocks[blockIdx.x];
     const long long a0 = seg_off[b.s0];
     const int na = (int)(seg_off[b.s1] - a0);
-    for (int i = tid; i < na; i += 256) s_m[i] = mass[a0 + i];
+    for (int i = tid; i < na; i += NT) s_m[i] = mass[a0 + i];
     // Sum tasks: (segment, plane) pairs of the block, dealt plane-major over the 256 lanes — consecutive lanes take
     // consecutive segments of one plane (coalesced stores, spread LDS banks), and a block of 64 sixteen-atom molecules
     // keeps 192 lanes busy in the sum phase instead of 64 (SC_TPL tasks per lane cover 256 segments x 3 planes).
@@ -58,7 +61,7 @@ __global__ __launch_bounds__(256) void segment_staged_kernel(
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < SC_TPL; ++j) {
-        const int t = tid + j * 256;
+        const int t = tid + j * NT;
         const int kk = t / nseg, sg = t - kk * nseg;
         t_kk[j] = kk < SC_PLANES ? kk : -1;
         t_seg[j] = sg;
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(256) void segment_staged_kernel(
     }
     // Software pipeline over (frame, plane group) steps: the values of step n+1 are loaded into registers while
     // the segment sums of step n run out of LDS, so that HBM requests are in flight all the time.
-    constexpr int PER = SC_CAP / 256;  // atoms per lane per plane
+    constexpr int PER = SC_CAP / NT;  // atoms per lane per plane
     const int groups = (n_attr + SC_PLANES - 1) / SC_PLANES;
     const long long n_my = blockIdx.y < n_frames ? (n_frames - blockIdx.y + gridDim.y - 1) / gridDim.y : 0;
     const long long steps = n_my * groups;
@@ -98,10 +101,10 @@ __global__ __launch_bounds__(256) void segment_staged_kernel(
         for (int kk = 0; kk < SC_PLANES; ++kk)
 #pragma unroll
             for (int r = 0; r < PER / 2; ++r) {
-                const int i = 2 * tid + r * 512;
+                const int i = 2 * tid + r * (2 * NT);
                 const bool ok = k0 + kk < n_attr;
                 if (!use_vec) {  // A/B: the 8-byte layout (lane owns tid + 256 r)
-                    const int i0 = tid + (2 * r) * 256, i1 = tid + (2 * r + 1) * 256;
+                    const int i0 = tid + (2 * r) * NT, i1 = tid + (2 * r + 1) * NT;
                     v[kk][2 * r] = (ok && i0 < na) ? p[(size_t)kk * n_atoms + i0] : 0.0;
                     v[kk][2 * r + 1] = (ok && i1 < na) ? p[(size_t)kk * n_atoms + i1] : 0.0;
                     continue;
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(256) void segment_staged_kernel(
         for (int kk = 0; kk < SC_PLANES; ++kk)
 #pragma unroll
             for (int r = 0; r < PER; ++r) {
-                const int i = use_vec ? 2 * tid + (r >> 1) * 512 + (r & 1) : tid + r * 256;
+                const int i = use_vec ? 2 * tid + (r >> 1) * (2 * NT) + (r & 1) : tid + r * NT;
                 if (i < na) s_v[kk * SC_STRIDE + sc_pad(i)] = v[kk][r] * s_m[i];
             }
         __syncthreads();
@@ -159,13 +162,14 @@ __global__ __launch_bounds__(256) void segment_staged_kernel(
 }
 
 // Runs of whole segments with <= SC_CAP atoms and <= 256 segments each; false when a segment is longer.
-bool build_seg_blocks(int64_t n_seg, const int64_t *seg_off, std::vector<SegBlock> &blocks, int SC_CAP = SC_CAP_MAX)
+bool build_seg_blocks(int64_t n_seg, const int64_t *seg_off, std::vector<SegBlock> &blocks, int SC_CAP = SC_CAP_MAX,
+                      int max_segs = 256)
 {
     blocks.clear();
     int64_t s0 = 0;
     while (s0 < n_seg) {
         int64_t s1 = s0;
-        while (s1 < n_seg && s1 - s0 < 256 && seg_off[s1 + 1] - seg_off[s0] <= SC_CAP) ++s1;
+        while (s1 < n_seg && s1 - s0 < max_segs && seg_off[s1 + 1] - seg_off[s0] <= SC_CAP) ++s1;
         if (s1 == s0) return false;  // segment s0 alone exceeds the LDS stage
         blocks.push_back({(long long)s0, (long long)s1});
         s0 = s1;
@@ -293,8 +297,15 @@ int mdhip_segment_com(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, int n_a
         if (!d_out) return MDHIP_ENOMEM;
     }
     std::vector<SegBlock> blocks;
-    const int cap = ctx->opt_seg_cap == 512 ? 512 : SC_CAP_MAX;
-    const bool staged = build_seg_blocks(n_seg, seg_off, blocks, cap);
+    // default: four waves share a 1024-atom stage; seg_cap = 256 selects the wave-private form (one wave per block,
+    // 256-atom stage, no block barrier that costs anything) — measured 0.61 against 0.635 of HBM spec at C4 shape, so
+    // the two barriers per step are not what limits this kernel
+    int cap = ctx->opt_seg_cap == 512 ? 512 : ctx->opt_seg_cap == 256 ? 256 : SC_CAP_MAX;
+    bool staged = build_seg_blocks(n_seg, seg_off, blocks, cap, cap == 256 ? 64 : 256);
+    if (!staged && cap != SC_CAP_MAX) {
+        cap = SC_CAP_MAX;
+        staged = build_seg_blocks(n_seg, seg_off, blocks, cap, 256);
+    }
     SegBlock *d_blocks = nullptr;
     if (staged) {
         d_blocks = (SegBlock *)mdhip_ws(ctx, WS_AUX3, blocks.size() * sizeof(SegBlock));
@@ -311,13 +322,18 @@ int mdhip_segment_com(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, int n_a
         want = std::max<int64_t>(want, n_frames / 10);
         unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_frames, std::min<int64_t>(want, 65535)));
         if (ctx->opt_seg_gy > 0) gy = (unsigned)std::min<int64_t>(n_frames, ctx->opt_seg_gy);
-        ctx->last_kernel = "segment_staged_kernel<false>";
-        if (cap == 512)
-            hipLaunchKernelGGL((segment_staged_kernel<false, 512>), dim3((unsigned)blocks.size(), gy), dim3(256), 0,
+        ctx->last_kernel = cap == 512 ? "segment_staged_kernel<false, 512, 256>" : "segment_staged_kernel<false, 1024, 256>";
+        if (cap == 256) {
+            ctx->last_kernel = "segment_staged_kernel<false, 256, 64>";
+            hipLaunchKernelGGL((segment_staged_kernel<false, 256, 64>), dim3((unsigned)blocks.size(), gy), dim3(64), 0,
+                               ctx->stream, d_attr, d_mass, (const double *)nullptr, d_off, d_blocks, d_out, n_attr,
+                               (long long)n_atoms, (long long)n_seg, (long long)n_frames, 1.0, 1.0, ctx->opt_seg_vec);
+        } else if (cap == 512)
+            hipLaunchKernelGGL((segment_staged_kernel<false, 512, 256>), dim3((unsigned)blocks.size(), gy), dim3(256), 0,
                                ctx->stream, d_attr, d_mass, (const double *)nullptr, d_off, d_blocks, d_out, n_attr,
                                (long long)n_atoms, (long long)n_seg, (long long)n_frames, 1.0, 1.0, ctx->opt_seg_vec);
         else
-            hipLaunchKernelGGL((segment_staged_kernel<false, 1024>), dim3((unsigned)blocks.size(), gy), dim3(256), 0,
+            hipLaunchKernelGGL((segment_staged_kernel<false, 1024, 256>), dim3((unsigned)blocks.size(), gy), dim3(256), 0,
                                ctx->stream, d_attr, d_mass, (const double *)nullptr, d_off, d_blocks, d_out, n_attr,
                                (long long)n_atoms, (long long)n_seg, (long long)n_frames, 1.0, 1.0, ctx->opt_seg_vec);
     } else {
@@ -375,8 +391,15 @@ int mdhip_charge_flux(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const d
     const size_t flux_b = (size_t)3 * n_types * n_frames * 8;
     MD_WS(d_flux, double, WS_OUT, flux_b);
     std::vector<SegBlock> blocks;
-    const int cap = ctx->opt_seg_cap == 512 ? 512 : SC_CAP_MAX;
-    const bool staged = build_seg_blocks(n_seg, seg_off, blocks, cap);
+    // default: four waves share a 1024-atom stage; seg_cap = 256 selects the wave-private form (one wave per block,
+    // 256-atom stage, no block barrier that costs anything) — measured 0.61 against 0.635 of HBM spec at C4 shape, so
+    // the two barriers per step are not what limits this kernel
+    int cap = ctx->opt_seg_cap == 512 ? 512 : ctx->opt_seg_cap == 256 ? 256 : SC_CAP_MAX;
+    bool staged = build_seg_blocks(n_seg, seg_off, blocks, cap, cap == 256 ? 64 : 256);
+    if (!staged && cap != SC_CAP_MAX) {
+        cap = SC_CAP_MAX;
+        staged = build_seg_blocks(n_seg, seg_off, blocks, cap, 256);
+    }
     SegBlock *d_blocks = nullptr;
     if (staged) {
         d_blocks = (SegBlock *)mdhip_ws(ctx, WS_PART, blocks.size() * sizeof(SegBlock));
@@ -389,13 +412,18 @@ int mdhip_charge_flux(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const d
         int64_t want = ((int64_t)ctx->cu_count * 16 + (int64_t)blocks.size() - 1) / (int64_t)blocks.size();
         want = std::max<int64_t>(want, n_frames / 10);
         const unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_frames, std::min<int64_t>(want, 65535)));
-        ctx->last_kernel = "segment_staged_kernel<true>";
-        if (cap == 512)
-            hipLaunchKernelGGL((segment_staged_kernel<true, 512>), dim3((unsigned)blocks.size(), gy), dim3(256), 0,
+        ctx->last_kernel = cap == 512 ? "segment_staged_kernel<true, 512, 256>" : "segment_staged_kernel<true, 1024, 256>";
+        if (cap == 256) {
+            ctx->last_kernel = "segment_staged_kernel<true, 256, 64>";
+            hipLaunchKernelGGL((segment_staged_kernel<true, 256, 64>), dim3((unsigned)blocks.size(), gy), dim3(64), 0,
+                               ctx->stream, d_vel, d_mq, d_mq + n_atoms, d_off, d_blocks, d_tmp, 3, (long long)n_atoms,
+                               (long long)n_seg, (long long)n_frames, vel_conv, charge_conv, ctx->opt_seg_vec);
+        } else if (cap == 512)
+            hipLaunchKernelGGL((segment_staged_kernel<true, 512, 256>), dim3((unsigned)blocks.size(), gy), dim3(256), 0,
                                ctx->stream, d_vel, d_mq, d_mq + n_atoms, d_off, d_blocks, d_tmp, 3, (long long)n_atoms,
                                (long long)n_seg, (long long)n_frames, vel_conv, charge_conv, ctx->opt_seg_vec);
         else
-            hipLaunchKernelGGL((segment_staged_kernel<true, 1024>), dim3((unsigned)blocks.size(), gy), dim3(256), 0,
+            hipLaunchKernelGGL((segment_staged_kernel<true, 1024, 256>), dim3((unsigned)blocks.size(), gy), dim3(256), 0,
                                ctx->stream, d_vel, d_mq, d_mq + n_atoms, d_off, d_blocks, d_tmp, 3, (long long)n_atoms,
                                (long long)n_seg, (long long)n_frames, vel_conv, charge_conv, ctx->opt_seg_vec);
     } else {

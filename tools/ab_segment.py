@@ -21,8 +21,7 @@ mass = np.where(np.arange(E) < 40_000, 2.0, 3.0)
 M = len(off) - 1
 out = torch.empty((F, 3, M), dtype=torch.float64, device="cuda")
 byt = (24.0 * E + 24.0 * M) * F
-for cap, vec, gy in ((1024, 1, 0), (1024, 1, 128), (1024, 1, 256), (1024, 1, 512), (1024, 1, 1250), (1024, 1, 5000),
-                     (512, 1, 128), (512, 1, 256), (512, 1, 512), (512, 1, 1250), (512, 1, 5000)):
+for cap, vec, gy in ((0, 1, 0), (256, 1, 0), (512, 1, 0), (0, 0, 0), (0, 1, 128), (0, 1, 1250)):
     ctx.set_option("seg_cap", cap)
     ctx.set_option("seg_vec", vec)
     ctx.set_option("seg_gy", gy)
