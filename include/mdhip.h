@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MDHIP_VERSION 100 /* 0.1.0 */
+#define MDHIP_VERSION 200 /* 0.2.0: + mdhip_rdf_cn_atomic, mdhip_rdf_atomic_dev, mdhip_xcorr_lags, mdhip_host_alloc/free, mdhip_dump_read_cols */
 
 #define MDHIP_OK 0
 #define MDHIP_EINVAL (-1)  /* bad argument (shape, NULL, unsupported size) */
