@@ -468,56 +468,6 @@ __device__ __forceinline__ unsigned long long bin_pair(float rsq, float rc2hi, f
 #undef BP_TAIL
 #undef BP_END
 
-// Two pair slots (the two j atoms of one packed result) in ONE block with their instructions interleaved: every
-// dependent VALU pair (sqrt -> fma -> fract/cvt -> compare/address) is separated by the other slot's independent
-// instruction, and the bin guess runs unmasked on all lanes (a VALU instruction costs the same whatever exec is) —
-// exec is narrowed only around the two LDS adds. Entered when either slot has a lane inside the cutoff. Plain variant
-// (cutoff on a bin edge, no CN); the other variants keep one bin_pair block per slot.
-__device__ __forceinline__ void bin_pair2(float rsqA, float rsqB, float rc2hi, float gscale, float noA, float noB,
-                                          float near2, unsigned rbA, unsigned rbB, unsigned long long &ambA,
-                                          unsigned long long &ambB)
-{
-    unsigned long long aA, aB, inA, inB, mB, save;
-    float tA, tB, fA, fB;
-    asm volatile(
-        "v_cmp_gt_f32 %[inA], %[rc2], %[rA]\n\t"
-        "v_cmp_gt_f32 %[inB], %[rc2], %[rB]\n\t"
-        "s_mov_b64 %[aA], 0\n\t"
-        "s_mov_b64 %[aB], 0\n\t"
-        "s_or_b64 %[save], %[inA], %[inB]\n\t"
-        "s_cbranch_scc0 1f\n\t"
-        "v_sqrt_f32 %[tA], %[rA]\n\t"
-        "v_sqrt_f32 %[tB], %[rB]\n\t"
-        "s_mov_b64 %[save], exec\n\t"
-        "v_fma_f32 %[tA], %[tA], %[gs], %[noA]\n\t"
-        "v_fma_f32 %[tB], %[tB], %[gs], %[noB]\n\t"
-        "v_fract_f32 %[fA], %[tA]\n\t"
-        "v_fract_f32 %[fB], %[tB]\n\t"
-        "v_cvt_i32_f32 %[tA], %[tA]\n\t"
-        "v_cvt_i32_f32 %[tB], %[tB]\n\t"
-        "v_cmp_ge_f32 vcc, %[fA], %[n2]\n\t"
-        "v_cmp_ge_f32 %[mB], %[fB], %[n2]\n\t"
-        "v_lshl_add_u32 %[tA], %[tA], 2, %[rbA]\n\t"
-        "v_lshl_add_u32 %[tB], %[tB], 2, %[rbB]\n\t"
-        "s_andn2_b64 %[aA], %[inA], vcc\n\t"
-        "s_and_b64 %[inA], %[inA], vcc\n\t"
-        "s_andn2_b64 %[aB], %[inB], %[mB]\n\t"
-        "s_and_b64 %[inB], %[inB], %[mB]\n\t"
-        "s_and_b64 exec, %[save], %[inA]\n\t"
-        "ds_add_u32 %[tA], %[one]\n\t"
-        "s_and_b64 exec, %[save], %[inB]\n\t"
-        "ds_add_u32 %[tB], %[one]\n\t"
-        "s_mov_b64 exec, %[save]\n\t"
-        "1:"
-        : [aA] "=&s"(aA), [aB] "=&s"(aB), [inA] "=&s"(inA), [inB] "=&s"(inB), [mB] "=&s"(mB), [save] "=&s"(save),
-          [tA] "=&v"(tA), [tB] "=&v"(tB), [fA] "=&v"(fA), [fB] "=&v"(fB)
-        : [rc2] "s"(rc2hi), [rA] "v"(rsqA), [rB] "v"(rsqB), [gs] "v"(gscale), [noA] "s"(noA), [noB] "s"(noB),
-          [n2] "v"(near2), [rbA] "v"(rbA), [rbB] "v"(rbB), [one] "v"(1u)
-        : "vcc", "scc", "memory");
-    ambA = aA;
-    ambB = aB;
-}
-
 // The four j atoms of one group against the wave's 64 i atoms.
 // VAR: bit k = axis k takes the per-pair f32 wrap. jidx0 = index of the group's first atom in the frame's j set.
 // PF: load the records at `next_p` into `next` (the group swept after this one) once the first operation on this
@@ -561,17 +511,6 @@ __device__ __forceinline__ void sweep_group_pk(const RelQ &rq, int jidx0, int lo
         f32x2 rsq = dx * dx;
         rsq = __builtin_elementwise_fma(dy, dy, rsq);
         rsq = __builtin_elementwise_fma(dz, dz, rsq);
-        unsigned long long amb2[2] = {0ull, 0ull};
-        constexpr bool pair2 = !CUTG && !CNG;  // (measured in one process, rdf_pair2 A/B: C2 3.92 -> 3.73 ms, C3 -5.3 %)
-        if (pair2) {
-            float rA = rsq[0], rB = rsq[1];
-            if (DIAG) {
-                rA = local0 + 2 * h > lane_in_tile ? rA : 3.0e38f;
-                rB = local0 + 2 * h + 1 > lane_in_tile ? rB : 3.0e38f;
-            }
-            bin_pair2(rA, rB, p.rc2hi, c.gscale, ROWS ? c.near : rb[2], ROWS ? c.near : rb[3], c.near2,
-                      ROWS ? row[2 * h] : c.rowbase_me, ROWS ? row[2 * h + 1] : c.rowbase_me, amb2[0], amb2[1]);
-        }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             // ordered rows: w = the bin-guess addend near + tj * row_len; class rows: w = the table offset of tj
@@ -589,9 +528,7 @@ __device__ __forceinline__ void sweep_group_pk(const RelQ &rq, int jidx0, int lo
                 kaddr = ROWS ? p.cn_kc_me[__float_as_uint(u ? rb[3] : rb[2])]
                              : p.cn_kc_me[(int)(nearoff * p.inv_row_len)];
             }
-            const unsigned long long amb = pair2
-                                               ? amb2[u]
-                                               : bin_pair<CUTG, CNG>(r2, p.rc2hi, c.gscale, nearoff, c.near2, rowbase, p.cut_lo, done, addr);
+            const unsigned long long amb = bin_pair<CUTG, CNG>(r2, p.rc2hi, c.gscale, nearoff, c.near2, rowbase, p.cut_lo, done, addr);
             if (CNG && done) {  // wave-uniform
                 const unsigned long long hm = __builtin_amdgcn_ballot_w64(addr == kaddr) & done;
                 if (hm) {

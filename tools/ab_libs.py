@@ -1,8 +1,6 @@
 #!/usr/bin/env python
-"""tools/ab_pair.py KEY=V1,V2,... [C2|C3] — A/B of one library OPTION on the pair kernel inside ONE process (boxes differ
-by ~10 %, runs inside a process by ~1 %): kernel time (min / median of 8 launches) per value, results asserted equal.
-For two code variants use tools/ab_libs.py with two BUILDS: a kernel that carries both variants behind a run-time flag
-is not either of them (the two-slot pair block looked 5 % faster that way and was 2 % slower build against build)."""
+"""tools/ab_libs.py LIB_A.so LIB_B.so [C2|C3] — A/B of two BUILDS of libmdhip.so inside one process (boxes differ by
+~10 %): the C2 (or 64 frames of C3) RDF call alternately through each library, kernel time min / median, results equal."""
 import os
 import sys
 
@@ -11,13 +9,20 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
+from mdproptools_amd import _lib  # noqa: E402
 from mdproptools_amd import backend as B  # noqa: E402
 from mdproptools_amd import synth  # noqa: E402
-from mdproptools_amd._lib import default_context  # noqa: E402
 
-key, vals = sys.argv[1].split("=")
-vals = [int(v) for v in vals.split(",")]
-which = sys.argv[2] if len(sys.argv) > 2 else "C2"
+
+def ctx_of(path):
+    _lib._lib = None
+    _lib.LIB_PATH = os.path.abspath(path)
+    return _lib.Context(0)
+
+
+libs = sys.argv[1:3]
+which = sys.argv[3] if len(sys.argv) > 3 else "C2"
+ctxs = [ctx_of(p) for p in libs]
 cfg = synth.rdf_config(which)
 n, L = cfg["n_atoms"], cfg["box_len"]
 F = cfg["n_frames"] if which == "C2" else 64
@@ -25,11 +30,9 @@ xyz = torch.from_numpy(synth.rdf_frames(n, range(F), L, cfg["seed_offset"])).cud
 ty = synth.rdf_types(n)
 rel = np.array(synth.ALL_PAIRS_4)
 box = np.full((F, 3), L)
-ctx = default_context(0)
 ref = None
-for rnd in range(2):
-    for v in vals:
-        ctx.set_option(key, v)
+for rnd in range(3):
+    for p, ctx in zip(libs, ctxs):
         ms = []
         for _ in range(8):
             out = B.rdf_loop(xyz, ty, box, rel, 20.0, 0.05, 400, per_frame=False, ctx=ctx)
@@ -38,4 +41,4 @@ for rnd in range(2):
             ref = out
         assert np.array_equal(out[0], ref[0]) and np.array_equal(out[1], ref[1])
         ms = np.array(ms[2:])
-        print("%s %s=%d  %s  min %.4f ms  median %.4f ms" % (which, key, v, ctx.last_kernel_name(), ms.min(), np.median(ms)))
+        print("%s %-28s min %.4f ms  median %.4f ms" % (which, os.path.basename(p), ms.min(), np.median(ms)))
