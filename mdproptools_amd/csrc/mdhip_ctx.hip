@@ -228,6 +228,8 @@ int mdhip_set_option(mdhip_ctx *ctx, const char *key, int value)
         ctx->opt_seg_vec = value;
     else if (!strcmp(key, "seg_gy"))
         ctx->opt_seg_gy = value;
+    else if (!strcmp(key, "cn_pk"))
+        ctx->opt_cn_pk = value;
     else if (!strcmp(key, "rdf_guard"))
         ctx->opt_rdf_guard = value < 0 ? 0 : value;
     else if (!strcmp(key, "rdf_slots"))

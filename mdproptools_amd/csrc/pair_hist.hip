@@ -1003,6 +1003,91 @@ int mdhip_rdf_atomic_dev(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, cons
     return MDHIP_OK;
 }
 
+// One sweep for the histograms AND the coordination counts. hist_full / hist_part / overflow may be
+// NULL (coordination counts only: mdhip_cn_atomic runs its cutoffs through here with a coarse 64-bin histogram whose
+// cutoff is the largest coordination cutoff). Returns MDHIP_OK, an error, or CN_UNFUSED when this call has to take the
+// two-sweep route (a cutoff beyond r_cut, two cutoffs for one class, a geometry the packed sweep does not take).
+static int fused_rdf_cn(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *xyz, int on_device,
+                        const int32_t *type, int64_t type_frame_stride, const double *box, int n_rel,
+                        const int32_t *rel, double r_cut_sq, double bin_size, int nbins, const double *edges,
+                        const double *cn_r_cut_sq, int per_frame, uint64_t *hist_full, uint64_t *hist_part,
+                        uint64_t *overflow, uint64_t *cn)
+{
+    bool fused = n_rel > 0 && n_frames > 0 && n_atoms >= 2;
+    for (int kl = 0; kl < n_rel && fused; ++kl) fused = !(cn_r_cut_sq[kl] > r_cut_sq);
+    if (!fused) return CN_UNFUSED;
+    MD_HIP(hipSetDevice(ctx->device));
+    const size_t out_frames = per_frame ? (size_t)n_frames : 1;
+    std::vector<double> own_edges;
+    const double *use_edges = edges;
+    if (!use_edges) {
+        own_edges.resize(nbins + 1);
+        mdhip_bin_edges(bin_size, nbins, own_edges.data());
+        use_edges = own_edges.data();
+    }
+    RelJob j{};
+    j.tri = true;
+    j.F = n_frames;
+    j.ni = j.nj = n_atoms;
+    j.xi = xyz;
+    j.xi_dev = on_device;
+    j.lab_i = type;
+    j.lab_i_fs = type_frame_stride;
+    j.box = box;
+    j.n_rel = n_rel;
+    j.rel = rel;
+    j.nbins = nbins;
+    j.edges = use_edges;
+    j.rc2 = r_cut_sq;
+    j.gscale = (float)(1.0 / bin_size);
+    j.bin_size = bin_size;
+    j.per_frame = per_frame;
+    std::vector<uint64_t> H, Hsplit;
+    std::vector<double> c2_cls;
+    j.cn_rc2 = cn_r_cut_sq;
+    j.Hsplit = &Hsplit;
+    j.cn_c2_cls = &c2_cls;
+    std::vector<int> rel_cls;
+    int n_cls = 0;
+    uint64_t ov = 0;
+    const int rc = run_job(ctx, j, H, rel_cls, n_cls, &ov);
+    if (rc != MDHIP_OK) return rc;  // an error, or CN_UNFUSED
+    if (overflow) *overflow = ov;
+    if (hist_full) std::fill(hist_full, hist_full + out_frames * nbins, (uint64_t)0);
+    for (size_t f = 0; f < out_frames; ++f) {
+        const uint64_t *Hf = &H[f * n_cls * nbins];
+        if (hist_full) {
+            uint64_t *full = hist_full + f * nbins;
+            for (int c = 0; c < n_cls; ++c)
+                for (int b = 0; b < nbins; ++b) full[b] += 2 * Hf[(size_t)c * nbins + b];
+        }
+        for (int kl = 0; kl < n_rel; ++kl) {
+            uint64_t *part = hist_part ? hist_part + (f * n_rel + kl) * nbins : nullptr;
+            uint64_t s = 0;
+            const uint64_t mult = rel[2 * kl] == rel[2 * kl + 1] ? 2 : 1;
+            if (rel_cls[kl] < 0) {
+                if (part) std::fill(part, part + nbins, (uint64_t)0);
+            } else {
+                const int cl = rel_cls[kl];
+                const uint64_t *row = Hf + (size_t)cl * nbins;
+                if (part)
+                    for (int b = 0; b < nbins; ++b) part[b] = mult * row[b];
+                const double c2 = c2_cls[cl];
+                if (c2 > 0.0) {
+                    // bins below the split bin are inside the cutoff (exact edges); the split bin's share was
+                    // counted by the exact chain (a cutoff inside the overflow bin, index nbins: all bins plus
+                    // the overflow pairs below the cutoff)
+                    const int kc = (int)(std::upper_bound(use_edges, use_edges + nbins + 1, c2) - use_edges) - 1;
+                    for (int b = 0; b < kc && b < nbins; ++b) s += row[b];
+                    s += Hsplit[f * n_cls + cl];
+                }
+            }
+            cn[f * n_rel + kl] = mult * s;
+        }
+    }
+    return MDHIP_OK;
+}
+
 int mdhip_rdf_cn_atomic(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *xyz, int on_device,
                         const int32_t *type, int64_t type_frame_stride, const double *box, int n_rel,
                         const int32_t *rel, double r_cut_sq, double bin_size, int nbins, const double *edges,
@@ -1014,80 +1099,10 @@ int mdhip_rdf_cn_atomic(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const
     MD_REQUIRE(nbins >= 1 && bin_size > 0.0, "nbins and bin_size must be positive");
     MD_REQUIRE(type_frame_stride == 0 || type_frame_stride == n_atoms, "type_frame_stride must be 0 or n_atoms");
     MD_REQUIRE(hist_full && (n_rel == 0 || (hist_part && cn_r_cut_sq && cn)), "NULL output or cutoff array");
-    bool fused = n_rel > 0 && n_frames > 0 && n_atoms >= 2;
-    for (int kl = 0; kl < n_rel && fused; ++kl) fused = !(cn_r_cut_sq[kl] > r_cut_sq);
-    if (fused) {
-        MD_HIP(hipSetDevice(ctx->device));
-        const size_t out_frames = per_frame ? (size_t)n_frames : 1;
-        std::vector<double> own_edges;
-        const double *use_edges = edges;
-        if (!use_edges) {
-            own_edges.resize(nbins + 1);
-            mdhip_bin_edges(bin_size, nbins, own_edges.data());
-            use_edges = own_edges.data();
-        }
-        RelJob j{};
-        j.tri = true;
-        j.F = n_frames;
-        j.ni = j.nj = n_atoms;
-        j.xi = xyz;
-        j.xi_dev = on_device;
-        j.lab_i = type;
-        j.lab_i_fs = type_frame_stride;
-        j.box = box;
-        j.n_rel = n_rel;
-        j.rel = rel;
-        j.nbins = nbins;
-        j.edges = use_edges;
-        j.rc2 = r_cut_sq;
-        j.gscale = (float)(1.0 / bin_size);
-        j.bin_size = bin_size;
-        j.per_frame = per_frame;
-        std::vector<uint64_t> H, Hsplit;
-        std::vector<double> c2_cls;
-        j.cn_rc2 = cn_r_cut_sq;
-        j.Hsplit = &Hsplit;
-        j.cn_c2_cls = &c2_cls;
-        std::vector<int> rel_cls;
-        int n_cls = 0;
-        uint64_t ov = 0;
-        rc = run_job(ctx, j, H, rel_cls, n_cls, &ov);
-        if (rc < 0) return rc;
-        if (rc == MDHIP_OK) {
-            if (overflow) *overflow = ov;
-            std::fill(hist_full, hist_full + out_frames * nbins, (uint64_t)0);
-            for (size_t f = 0; f < out_frames; ++f) {
-                const uint64_t *Hf = &H[f * n_cls * nbins];
-                uint64_t *full = hist_full + f * nbins;
-                for (int c = 0; c < n_cls; ++c)
-                    for (int b = 0; b < nbins; ++b) full[b] += 2 * Hf[(size_t)c * nbins + b];
-                for (int kl = 0; kl < n_rel; ++kl) {
-                    uint64_t *part = hist_part + (f * n_rel + kl) * nbins;
-                    uint64_t s = 0;
-                    const uint64_t mult = rel[2 * kl] == rel[2 * kl + 1] ? 2 : 1;
-                    if (rel_cls[kl] < 0) {
-                        std::fill(part, part + nbins, (uint64_t)0);
-                    } else {
-                        const int cl = rel_cls[kl];
-                        const uint64_t *row = Hf + (size_t)cl * nbins;
-                        for (int b = 0; b < nbins; ++b) part[b] = mult * row[b];
-                        const double c2 = c2_cls[cl];
-                        if (c2 > 0.0) {
-                            // bins below the split bin are inside the cutoff (exact edges); the split bin's share was
-                            // counted by the exact chain (a cutoff inside the overflow bin, index nbins: all bins plus
-                            // the overflow pairs below the cutoff)
-                            const int kc = (int)(std::upper_bound(use_edges, use_edges + nbins + 1, c2) - use_edges) - 1;
-                            for (int b = 0; b < kc && b < nbins; ++b) s += row[b];
-                            s += Hsplit[f * n_cls + cl];
-                        }
-                    }
-                    cn[f * n_rel + kl] = mult * s;
-                }
-            }
-            return MDHIP_OK;
-        }
-        // CN_UNFUSED: this geometry does not run the packed-f32 sweep — two sweeps, same integers
-    }
+    rc = fused_rdf_cn(ctx, n_frames, n_atoms, xyz, on_device, type, type_frame_stride, box, n_rel, rel, r_cut_sq,
+                      bin_size, nbins, edges, cn_r_cut_sq, per_frame, hist_full, hist_part, overflow, cn);
+    if (rc != CN_UNFUSED) return rc;
+    // this call does not run as one packed sweep — two sweeps, same integers
     rc = mdhip_rdf_atomic(ctx, n_frames, n_atoms, xyz, on_device, type, type_frame_stride, box, n_rel, rel, r_cut_sq,
                           bin_size, nbins, edges, per_frame, hist_full, hist_part, overflow);
     if (rc) return rc;
@@ -1114,6 +1129,18 @@ int mdhip_cn_atomic(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const dou
     cn_edges(n_rel, r_cut_sq, edges, rank);
     const int nbins = (int)edges.size() - 1;
     if (nbins == 0) return MDHIP_OK;
+    if (ctx->opt_cn_pk != 0) {
+        // Option cn_pk: the packed-f32 sweep with a coarse histogram whose cutoff is the largest coordination cutoff;
+        // the counts are the exact bins below each class's split bin plus the split-bin pairs the exact chain finds
+        // inside — the same integers as the f64 edge-table kernel below, which is the default and
+        // the route for everything the packed sweep does not take (small frames, two cutoffs for one class, ...).
+        const double c_max = std::sqrt(edges.back());
+        const int nb = 64;
+        rc = fused_rdf_cn(ctx, n_frames, n_atoms, xyz, on_device, type, type_frame_stride, box, n_rel, rel,
+                          edges.back(), c_max / nb, nb, nullptr, r_cut_sq, per_frame, nullptr, nullptr, nullptr, cn);
+        if (rc != CN_UNFUSED) return rc;
+        std::fill(cn, cn + out_frames * n_rel, (uint64_t)0);
+    }
     RelJob j{};
     j.tri = true;
     j.F = n_frames;

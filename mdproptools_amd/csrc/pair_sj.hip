@@ -731,34 +731,41 @@ __device__ __forceinline__ int sj_item_pk(const PairArgs &a, FastCtx &c, const u
             const int jbase = J * TILE;
 #define PK_DRAIN_CHECK() \
     if (p.qn > 64) pk_drain<CNG>(p, c, lane)
+            // the common variant (no per-pair wrap), software-pipelined: the records of the next group are loaded
+            // while the current group is swept; two buffers, loop unrolled by two (no register copies). With CNG the
+            // groups near the wave run the same pipeline in its split-bin-checking form (an unpipelined near loop
+            // exposed every group's record load: a near slot then cost ~2.5 slots).
+#define PK_PIPELINED(MASK, CN)                                                                                          \
+    {                                                                                                                   \
+        unsigned long long mk = (MASK);                                                                                 \
+        if (mk) {                                                                                                       \
+            int gA = __builtin_ctzll(mk);                                                                               \
+            mk &= mk - 1;                                                                                               \
+            RelQ qA = load_relq(rtile + gA * SJ_GROUP * 4), qB;                                                         \
+            for (;;) {                                                                                                  \
+                PK_DRAIN_CHECK();                                                                                       \
+                const bool moreB = mk != 0;                                                                             \
+                const int gB = moreB ? __builtin_ctzll(mk) : gA;                                                        \
+                mk &= mk - 1;                                                                                           \
+                sweep_group_pk<false, 0, true, CUTG, ROWS, CN>(qA, jbase + gA * SJ_GROUP, gA * SJ_GROUP, p, c,          \
+                                                               lane_in_tile, lane, rtile + gB * SJ_GROUP * 4, qB);      \
+                if (!moreB) break;                                                                                      \
+                PK_DRAIN_CHECK();                                                                                       \
+                const bool moreA = mk != 0;                                                                             \
+                gA = moreA ? __builtin_ctzll(mk) : gB;                                                                  \
+                mk &= mk - 1;                                                                                           \
+                sweep_group_pk<false, 0, true, CUTG, ROWS, CN>(qB, jbase + gB * SJ_GROUP, gB * SJ_GROUP, p, c,          \
+                                                               lane_in_tile, lane, rtile + gA * SJ_GROUP * 4, qA);      \
+                if (!moreA) break;                                                                                      \
+            }                                                                                                           \
+        }                                                                                                               \
+    }
             if (!diag) {
-                // the common variant (no per-pair wrap), software-pipelined: the records of the next group are
-                // loaded while the current group is swept; two buffers, loop unrolled by two (no register copies)
-                unsigned long long mk = __builtin_amdgcn_ballot_w64(keep && var == 0u && !nearg) & bm;
-                if (mk) {
-                    int gA = __builtin_ctzll(mk);
-                    mk &= mk - 1;
-                    RelQ qA = load_relq(rtile + gA * SJ_GROUP * 4), qB;
-                    for (;;) {
-                        PK_DRAIN_CHECK();
-                        const bool moreB = mk != 0;
-                        const int gB = moreB ? __builtin_ctzll(mk) : gA;
-                        mk &= mk - 1;
-                        sweep_group_pk<false, 0, true, CUTG, ROWS, false>(qA, jbase + gA * SJ_GROUP, gA * SJ_GROUP, p, c, lane_in_tile, lane,
-                                                       rtile + gB * SJ_GROUP * 4, qB);
-                        if (!moreB) break;
-                        PK_DRAIN_CHECK();
-                        const bool moreA = mk != 0;
-                        gA = moreA ? __builtin_ctzll(mk) : gB;
-                        mk &= mk - 1;
-                        sweep_group_pk<false, 0, true, CUTG, ROWS, false>(qB, jbase + gB * SJ_GROUP, gB * SJ_GROUP, p, c, lane_in_tile, lane,
-                                                       rtile + gA * SJ_GROUP * 4, qA);
-                        if (!moreA) break;
-                    }
-                }
+                PK_PIPELINED(__builtin_amdgcn_ballot_w64(keep && var == 0u && !nearg) & bm, false)
+                if constexpr (CNG) PK_PIPELINED(__builtin_amdgcn_ballot_w64(keep && var == 0u && nearg) & bm, true)
             }
-            // the other variants (per-pair wrap on some axis, the diagonal tile) and, with CNG, the groups near the
-            // wave (plain variant included): not pipelined
+#undef PK_PIPELINED
+            // the other variants (per-pair wrap on some axis, the diagonal tile): not pipelined
 #define PK_SWEEP_CASES(CN)                                                                                             \
     switch (A) {                                                                                                       \
     case 1: sweep_group_pk<false, 1, false, CUTG, ROWS, CN>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break; \
@@ -773,8 +780,8 @@ __device__ __forceinline__ int sj_item_pk(const PairArgs &a, FastCtx &c, const u
     default: break;                                                                                                    \
     }
             const unsigned long long nm = CNG ? __builtin_amdgcn_ballot_w64(nearg) : 0ull;
-            for (unsigned A = diag ? 8u : (CNG ? 0u : 1u); A <= (diag ? 9u : 7u); ++A) {
-                unsigned long long mk = __builtin_amdgcn_ballot_w64(keep && var == A && (A != 0u || nearg)) & bm;
+            for (unsigned A = diag ? 8u : 1u; A <= (diag ? 9u : 7u); ++A) {
+                unsigned long long mk = __builtin_amdgcn_ballot_w64(keep && var == A) & bm;
                 while (mk) {
                     const int g = __builtin_ctzll(mk);
                     mk &= mk - 1;
@@ -783,10 +790,7 @@ __device__ __forceinline__ int sj_item_pk(const PairArgs &a, FastCtx &c, const u
                     const int j0 = jbase + g * SJ_GROUP, l0 = g * SJ_GROUP;
                     if constexpr (CNG) {
                         if ((nm >> g) & 1ull) {
-                            if (A == 0u)
-                                sweep_group_pk<false, 0, false, CUTG, ROWS, true>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone);
-                            else
-                                PK_SWEEP_CASES(true)
+                            PK_SWEEP_CASES(true)
                             continue;
                         }
                     }

@@ -31,6 +31,10 @@ def main():
         cref.build()
     ctx = Context(0)
     ctx.set_option("rdf_cull", 1)
+    ctx.set_option("cn_pk", 1)
+    edge_table = Context(0)  # mdhip_cn_atomic on its f64 edge-table kernel: the independent side of the comparison
+    edge_table.set_option("rdf_cull", 1)
+    edge_table.set_option("cn_pk", 0)
     fused, pairs = 0, 0
     for trial in range(trials):
         xyz, ty, box, rel, r_cut, bin_size, nbins = _pk_case(rng, trial)
@@ -48,7 +52,11 @@ def main():
             cuts[0] = 1.2 * r_cut                                  # beyond it: two sweeps inside the call
         per_frame = bool(trial % 2)
         a = B.rdf_loop(xyz, ty, box, rel, r_cut, bin_size, nbins, per_frame=per_frame, ctx=ctx)
-        cn = B.cn_loop(xyz, ty, box, rel, cuts, per_frame=per_frame, ctx=ctx)
+        cn = B.cn_loop(xyz, ty, box, rel, cuts, per_frame=per_frame, ctx=edge_table)
+        cn_pk = B.cn_loop(xyz, ty, box, rel, cuts, per_frame=per_frame, ctx=ctx)  # coarse histogram + split bins
+        if not np.array_equal(cn_pk, cn):
+            print("MISMATCH (cn through the packed sweep) trial %d cuts=%s\n edge table %s\n packed %s" % (trial, cuts, cn, cn_pk))
+            sys.exit(1)
         f, p_, ov, cn2 = B.rdf_cn_loop(xyz, ty, box, rel, r_cut, bin_size, nbins, cuts, per_frame=per_frame, ctx=ctx)
         name = ctx.last_kernel_name()
         fused += name.endswith(", true>")

@@ -130,7 +130,9 @@ def test_lattice_on_bin_edges_at_c2_scale(B):
     f_, p_, ov, cn = B.rdf_cn_loop(xyz, ty, box, rel, 20.0, 0.05, 400, cuts, ctx=pk)
     np.testing.assert_array_equal(f_, a_[0])
     np.testing.assert_array_equal(cn[0], C.cn_pairs(xyz[0], ty, rel, box[0], [c * c for c in cuts]))
+    pk.set_option("cn_pk", 1)  # mdhip_cn_atomic through the packed sweep (coarse histogram + split bins)
     np.testing.assert_array_equal(cn, B.cn_loop(xyz, ty, box, rel, cuts, ctx=f64))
+    np.testing.assert_array_equal(cn, B.cn_loop(xyz, ty, box, rel, cuts, ctx=pk))  # coarse histogram + split bins
     pk.close()
     f64.close()
 

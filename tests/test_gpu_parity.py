@@ -798,6 +798,10 @@ def test_rdf_and_cn_from_one_sweep(B):
     rng = np.random.default_rng(4242)
     ctx = Context(0)
     ctx.set_option("rdf_cull", 1)
+    ctx.set_option("cn_pk", 1)  # mdhip_cn_atomic through the packed sweep as well (an option, not the default)
+    edge_table = Context(0)  # the f64 edge-table CN kernel (mdhip_cn_atomic itself now prefers the packed sweep too)
+    edge_table.set_option("rdf_cull", 1)
+    edge_table.set_option("cn_pk", 0)
     fused = 0
     for trial in range(24):
         xyz, ty, box, rel, r_cut, bin_size, nbins = _pk_case(rng, trial)
@@ -813,7 +817,11 @@ def test_rdf_and_cn_from_one_sweep(B):
             cuts[0] = 1.2 * r_cut                           # beyond the RDF cutoff: two sweeps inside the call
         per_frame = bool(trial % 2)
         a = B.rdf_loop(xyz, ty, box, rel, r_cut, bin_size, nbins, per_frame=per_frame, ctx=ctx)
-        cn = B.cn_loop(xyz, ty, box, rel, cuts, per_frame=per_frame, ctx=ctx)
+        cn = B.cn_loop(xyz, ty, box, rel, cuts, per_frame=per_frame, ctx=edge_table)
+        assert "<1," in edge_table.last_kernel_name() or "pair_hist_kernel" in edge_table.last_kernel_name() \
+            or "fast" in edge_table.last_kernel_name(), edge_table.last_kernel_name()
+        cn_pk = B.cn_loop(xyz, ty, box, rel, cuts, per_frame=per_frame, ctx=ctx)  # coarse histogram + split bins
+        np.testing.assert_array_equal(cn_pk, cn, err_msg="cn through the packed sweep, trial %d" % trial)
         f, p_, ov, cn2 = B.rdf_cn_loop(xyz, ty, box, rel, r_cut, bin_size, nbins, cuts, per_frame=per_frame, ctx=ctx)
         name = ctx.last_kernel_name()
         fused += "true>" in name and name.count(",") == 2 and name.endswith(", true>")
@@ -841,6 +849,7 @@ def test_rdf_and_cn_from_one_sweep(B):
             np.testing.assert_array_equal(p_[fr], cp)
             np.testing.assert_array_equal(cn[fr], C.cn_pairs(xyz[fr], ty, rel, box[fr], [c * c for c in cuts]))
     ctx.close()
+    edge_table.close()
 
 
 def test_packed_f32_sweep_against_oracle(B):

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""tools/ab_libs.py LIB_A.so LIB_B.so [C2|C3] — A/B of two BUILDS of libmdhip.so inside one process (boxes differ by
-~10 %): the C2 (or 64 frames of C3) RDF call alternately through each library, kernel time min / median, results equal."""
+"""tools/ab_libs.py LIB_A.so LIB_B.so [C2|C3] [rdf|cn|rdf_cn] — A/B of two BUILDS of libmdhip.so inside one process (boxes
+differ by ~10 %): the C2 (or 64 frames of C3) call alternately through each library, kernel time min / median, results
+equal."""
 import os
 import sys
 
@@ -22,6 +23,7 @@ def ctx_of(path):
 
 libs = sys.argv[1:3]
 which = sys.argv[3] if len(sys.argv) > 3 else "C2"
+op = sys.argv[4] if len(sys.argv) > 4 else "rdf"
 ctxs = [ctx_of(p) for p in libs]
 cfg = synth.rdf_config(which)
 n, L = cfg["n_atoms"], cfg["box_len"]
@@ -35,10 +37,16 @@ for rnd in range(3):
     for p, ctx in zip(libs, ctxs):
         ms = []
         for _ in range(8):
-            out = B.rdf_loop(xyz, ty, box, rel, 20.0, 0.05, 400, per_frame=False, ctx=ctx)
+            if op == "rdf":
+                out = B.rdf_loop(xyz, ty, box, rel, 20.0, 0.05, 400, per_frame=False, ctx=ctx)
+            elif op == "cn":
+                out = (B.cn_loop(xyz, ty, box, rel, synth.cn_cutoffs(len(rel)), per_frame=False, ctx=ctx),) * 2
+            else:
+                o = B.rdf_cn_loop(xyz, ty, box, rel, 20.0, 0.05, 400, synth.cn_cutoffs(len(rel)), per_frame=False, ctx=ctx)
+                out = (o[0], o[3])
             ms.append(ctx.last_kernel_ms()[0])
         if ref is None:
             ref = out
         assert np.array_equal(out[0], ref[0]) and np.array_equal(out[1], ref[1])
         ms = np.array(ms[2:])
-        print("%s %-28s min %.4f ms  median %.4f ms" % (which, os.path.basename(p), ms.min(), np.median(ms)))
+        print("%s %s %-28s min %.4f ms  median %.4f ms" % (which, op, os.path.basename(p), ms.min(), np.median(ms)))
