@@ -199,7 +199,8 @@ def test_overflow_guard_splits_the_batch(B):
     from mdproptools_amd import synth
     from mdproptools_amd._lib import Context
 
-    n, L, F = 6000, 42.0, 24
+    n, L, F = 6000, 42.0, 96  # (many frames: a block's tile count at 96 frames is far above its count at one frame,
+    #                            so that there is a wide range of thresholds that split the batch and still pass)
     xyz = synth.rdf_frames(n, range(F), L, 11)
     ty = synth.rdf_types(n)
     rel = np.array(synth.ALL_PAIRS_4)
@@ -207,10 +208,10 @@ def test_overflow_guard_splits_the_batch(B):
     ref = B.rdf_loop(xyz, ty, box, rel, 12.0, 0.05, 240, per_frame=False)
     refp = B.rdf_loop(xyz, ty, box, rel, 12.0, 0.05, 240, per_frame=True)
     ctx = Context(0)
-    # lower the number of neighbour tiles a block may sweep per launch until the 24-frame batch has to be halved
+    # lower the number of neighbour tiles a block may sweep per launch until the 96-frame batch has to be halved
     # (a threshold even one frame exceeds gives a clean error instead, see the end of the test)
     split_at = None
-    for guard in (256, 128, 96, 64, 48, 32, 24, 16, 12, 8, 6, 4):
+    for guard in (2048, 1024, 768, 512, 384, 256, 192, 128, 96, 64, 48, 32, 24, 16, 12, 8, 6, 4):
         ctx.set_option("rdf_guard", guard)
         try:
             a = B.rdf_loop(xyz, ty, box, rel, 12.0, 0.05, 240, per_frame=False, ctx=ctx)
