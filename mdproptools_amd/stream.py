@@ -175,12 +175,17 @@ class FrameStream:
                     heads = [nd.header(f) for f in range(nd.n_frames)]
                     return nd, heads, time.perf_counter() - t0
 
-                def parse(nd, f, names, dests, last_of_file):
+                def parse(nd, f, names, dests, pending):
+                    # `pending` = [frames of this file still to be parsed, lock]: the frames of a multi-frame file are
+                    # parsed concurrently, whoever finishes LAST closes the mapping
                     t0 = time.perf_counter()
                     try:
                         mio.native_read_into(nd, f, names, self.columns, dests, sort_by="id", n_threads=1)
                     finally:
-                        if last_of_file:
+                        with pending[1]:
+                            pending[0] -= 1
+                            last = pending[0] == 0
+                        if last:
                             nd.close()
                     return time.perf_counter() - t0
 
@@ -216,6 +221,7 @@ class FrameStream:
                     nd, heads, t_open = opens.pop(0).result()
                     self.stats["parse_s"] += t_open
                     top_up()
+                    pending = [len(heads), threading.Lock()]
                     for f, (ts, n, bounds, tilt, names) in enumerate(heads):
                         if cur is not None and (cur[1] != n or len(cur[6]) >= cur[2]):
                             flush()
@@ -232,8 +238,7 @@ class FrameStream:
                         cur[4].append(types)
                         cur[5].append(mio.LammpsBox(bounds.tolist(), tilt).to_lattice().lengths)
                         cur[6].append(ts)
-                        cur[7].append(pool.submit(parse, nd, f, names, [ids, types, slot[0], slot[1], slot[2]],
-                                                  f == len(heads) - 1))
+                        cur[7].append(pool.submit(parse, nd, f, names, [ids, types, slot[0], slot[1], slot[2]], pending))
                         self.stats["frames"] += 1
                     if not heads:
                         nd.close()

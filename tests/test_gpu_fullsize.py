@@ -259,3 +259,58 @@ def test_bench_launches_its_own_ranks():
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["frames_per_gpu"] == 500
     assert line["config"]["pairs_per_step"] == 1000 * 100_000 * 99_999 // 2
     assert line["value"] > 1e12
+
+
+# ------------------------------------------------------------------ compute-bound paths sharded over two ranks
+def _sharded_worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0")
+    import torch.distributed as dist
+
+    from mdproptools_amd import dist as D
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # two ranks share the one GPU of the test box
+    rng = np.random.default_rng(31)
+    F, E = 600, 3000
+    r = np.cumsum(rng.normal(0, 0.1, (F, 3, E)), axis=0) + rng.uniform(0, 40, (1, 3, E))
+    goff = [0, 1000, 1900, E]  # group 1 straddles the rank boundary at entity 1500
+    lo, hi = D.entity_shard(E)
+    lag = D.lag_msd_sharded(r[:, :, lo:hi], (lo, hi), F - 1, goff, scale=1.0)
+    series = np.cumsum(rng.normal(size=(3, 40_000)), axis=1)
+    acf = D.xcorr_direct_sharded(series)
+    ccf = D.xcorr_direct_sharded(series[0], series[1], n_lags=25_000)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), lag=lag, acf=acf, ccf=ccf)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_lag_msd_and_direct_acf_sharded_two_ranks(B, tmp_path):
+    """lag_msd_sharded (entities split, a group straddling the boundary) and xcorr_direct_sharded (lag ranges of equal
+    work) with the real kernels, two ranks sharing the GPU over gloo, against the single-process calls."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from mdproptools_amd._lib import Context
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_sharded_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    rng = np.random.default_rng(31)
+    F, E = 600, 3000
+    r = np.cumsum(rng.normal(0, 0.1, (F, 3, E)), axis=0) + rng.uniform(0, 40, (1, 3, E))
+    ctx = Context(0)
+    ctx.set_option("lag_variant", 1)  # the exact-difference kernel as the reference
+    one = B.lag_msd(r, F - 1, [0, 1000, 1900, E], ctx=ctx)
+    ctx.close()
+    series = np.cumsum(rng.normal(size=(3, 40_000)), axis=1)
+    acf = B.xcorr(series, method=B.XCORR_DIRECT)
+    ccf = B.xcorr(series[0], series[1], method=B.XCORR_DIRECT, n_lags=25_000)
+    for rank in range(2):
+        g = np.load(tmp_path / ("rank%d.npz" % rank))
+        np.testing.assert_allclose(g["lag"][1:], one[1:], rtol=1e-10)
+        assert np.all(g["lag"][0] == 0.0)
+        np.testing.assert_allclose(g["acf"], acf, rtol=0, atol=1e-12 * abs(acf[:, 0]).max())
+        np.testing.assert_allclose(g["ccf"], ccf, rtol=0, atol=1e-12 * abs(acf[:, 0]).max())

@@ -69,3 +69,29 @@ def test_stream_explicit_files_and_errors(tmp_path):
         break
     st.close()
     assert not st._thread.is_alive()
+
+
+def test_stream_multi_frame_files(tmp_path):
+    """Files that hold several frames: their frames are parsed concurrently (the file's mapping is closed by whichever
+    parse finishes last) and still come out in order, across batch boundaries."""
+    rng = np.random.default_rng(6)
+    tables, k = [], 0
+    for fidx in range(3):
+        text = []
+        for _ in range(4):  # four frames per file
+            n = 35
+            tbl = np.column_stack([rng.permutation(n) + 1, 1 + np.arange(n) % 2, np.round(rng.uniform(0, 8, (n, 3)), 5)])
+            p = tmp_path / "one.dump"
+            mio.write_dump(str(p), k * 10, [[0, 8]] * 3, ["id", "type", "x", "y", "z"], tbl)
+            text.append(p.read_text())
+            tables.append(tbl[np.argsort(tbl[:, 0])])
+            k += 1
+        (tmp_path / ("traj.%d.dump" % fidx)).write_text("".join(text))
+    (tmp_path / "one.dump").unlink()
+    got = []
+    for batch in FrameStream(str(tmp_path / "traj.*.dump"), batch_bytes=5 * 24 * 35, depth=2):
+        for fr in batch:
+            got.append((fr.timestep, fr.xyz.copy()))
+    assert [g[0] for g in got] == [10 * i for i in range(12)]
+    for (ts, xyz), tbl in zip(got, tables):
+        np.testing.assert_array_equal(xyz, tbl[:, 2:5].T)
