@@ -90,8 +90,29 @@ def _molecule_layout(num_mols, num_atoms_per_mol):
 
 
 def _type_counts(labels):
-    vals, cnt = np.unique(np.asarray(labels).astype(np.int64), return_counts=True)
+    """{label: number of atoms} — what `np.unique(..., return_counts=True)` gives (rdf_cn.py:253-256), by a counting
+    pass when the labels are small non-negative integers (always, for LAMMPS types and altered ids): O(n), no sort."""
+    lab = np.asarray(labels).astype(np.int64)
+    if lab.size and lab.min() >= 0 and lab.max() < (1 << 20):
+        cnt = np.bincount(lab)
+        vals = np.flatnonzero(cnt)
+        return {int(v): int(cnt[v]) for v in vals}
+    vals, cnt = np.unique(lab, return_counts=True)
     return {int(v): int(c) for v, c in zip(vals, cnt)}
+
+
+_COUNTS_MEMO = {"lab": None, "counts": None}
+
+
+def _type_counts_memo(labels):
+    """_type_counts with a one-entry memo: the frames of a trajectory nearly always carry the same labels, and the
+    comparison (a memcmp) is several times cheaper than the count."""
+    m = _COUNTS_MEMO
+    lab = np.asarray(labels)
+    if m["lab"] is not None and m["lab"].shape == lab.shape and np.array_equal(m["lab"], lab):
+        return m["counts"]
+    m["lab"], m["counts"] = lab.copy(), _type_counts(lab)
+    return m["counts"]
 
 
 def _calc_props(box_lengths, ref_labels, obj_labels, num_types, mass, partial_relations, altered,
@@ -102,8 +123,8 @@ def _calc_props(box_lengths, ref_labels, obj_labels, num_types, mass, partial_re
     """
     n_objects = len(obj_labels)
     volume = np.prod(box_lengths)
-    atom_types = _type_counts(ref_labels)
-    object_types = _type_counts(obj_labels)
+    atom_types = _type_counts_memo(ref_labels)
+    object_types = atom_types if obj_labels is ref_labels else _type_counts(obj_labels)
     expected = np.sum(num_atoms_per_mol) if altered else num_types
     if expected != len(atom_types):
         raise ValueError(
