@@ -222,6 +222,17 @@ int mdhip_msd_pairs(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const doubl
                     const int64_t *group_off, double *sums, double *per_entity, int pe_on_device);
 
 /*
+ * The same reduction with the per-entity values stored as COLUMNS: dx2, dy2, dz2, msd, each [n_pairs][n_ent],
+ * column k at cols + k * col_stride (col_stride >= n_pairs * n_ent, in doubles). These are the column blocks the
+ * `msd_all` DataFrame (diffusion.py:212-217, 222) is made of, so the caller wraps them without a transpose.
+ *   cols       host|dev (cols_on_device)
+ */
+int mdhip_msd_pairs_cols(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r,
+                         int on_device, double scale, int n_pairs, const int32_t *pairs, int n_groups,
+                         const int64_t *group_off, double *sums, double *cols, int64_t col_stride,
+                         int cols_on_device);
+
+/*
  * dynamical/diffusion.py:225-237 per entity: frames kept = 0, tao, 2 tao, ...; for every entity the
  * sums over the n_kept-1 windows of (x_k - x_{k-1})^2 per axis and of their total.
  *   win_sums   host [n_ent][4] (the caller applies /(n_kept-1) and, for the total, /n_kept — the

@@ -59,6 +59,8 @@ PROTOTYPES = {
                                     c_lp, vp, C.c_int, c_dp, c_dp]),
     "mdhip_msd_pairs": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, C.c_double, C.c_int, c_ip, C.c_int,
                                   c_lp, c_dp, vp, C.c_int]),
+    "mdhip_msd_pairs_cols": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, C.c_double, C.c_int, c_ip, C.c_int,
+                                       c_lp, c_dp, vp, C.c_int64, C.c_int]),
     "mdhip_msd_windows": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, C.c_double, C.c_int, c_dp]),
     "mdhip_lag_msd": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, C.c_double, C.c_int, C.c_int, c_lp,
                                 c_dp]),

@@ -240,6 +240,28 @@ def msd_pairs(r, pairs, group_off, scale=1.0, per_entity=False, ctx=None):
     return (sums, pe) if per_entity else sums
 
 
+def msd_pairs_cols(r, pairs, group_off, cols, scale=1.0, ctx=None):
+    """
+    `msd_pairs` with the per-entity values written as the four COLUMNS dx2, dy2, dz2, msd of `cols` — a host float64
+    array [4, P*E] whose rows are contiguous (they may be rows of a larger C-ordered block: the block a DataFrame
+    wraps without copying). Returns sums [P,G,4].
+    """
+    ctx = ctx or default_context()
+    F, _, E = _shape3(r, "r")
+    rp, on_dev, keep = as_input(r, ctx)
+    pr = _i32(pairs).reshape(-1, 2)
+    go = _i64(group_off)
+    G = len(go) - 1
+    if not (isinstance(cols, np.ndarray) and cols.dtype == np.float64 and cols.shape == (4, len(pr) * E)
+            and cols.strides[1] == 8 and cols.strides[0] % 8 == 0 and cols.strides[0] >= 8 * len(pr) * E):
+        raise ValueError("cols must be a float64 array [4, n_pairs * n_ent] with contiguous rows")
+    sums = np.zeros((len(pr), G, 4))
+    ctx.check(ctx.lib.mdhip_msd_pairs_cols(
+        ctx.h, F, E, rp, on_dev, float(scale), len(pr), ptr(pr, C.c_int32), G, ptr(go, C.c_int64),
+        ptr(sums), C.c_void_p(cols.ctypes.data), cols.strides[0] // 8, 0))
+    return sums
+
+
 def msd_windows(r, tao, scale=1.0, ctx=None):
     """Fixed-lag window sums per entity (diffusion.py:225-237): r [F,3,E] -> [E,4]."""
     ctx = ctx or default_context()

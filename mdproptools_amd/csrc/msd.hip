@@ -40,8 +40,10 @@ template <bool VEC2>
 __global__ __launch_bounds__(MSD_THREADS) void msd_pairs_kernel(
     const double *__restrict__ r, long long n_ent, double scale, const int *__restrict__ pairs,
     const Chunk *__restrict__ chunks, int n_chunks, double *__restrict__ partial,
-    double *__restrict__ per_entity)
+    double *__restrict__ per_entity, long long pe_stride)
 {
+    // per_entity: pe_stride == 0 -> rows [n_pairs][n_ent][4]; otherwise four columns, column k at k * pe_stride,
+    // each [n_pairs][n_ent] (the column blocks a DataFrame is made of, stored without a host-side transpose)
     __shared__ double red[4][4];
     const int p = blockIdx.y;
     const Chunk ck = chunks[blockIdx.x];
@@ -60,8 +62,16 @@ __global__ __launch_bounds__(MSD_THREADS) void msd_pairs_kernel(
         s2 += dz2;
         s3 += tot;
         if (per_entity) {
-            double4 *pe = reinterpret_cast<double4 *>(per_entity + ((size_t)p * n_ent + e) * 4);
-            *pe = make_double4(dx2, dy2, dz2, tot);
+            if (pe_stride) {
+                double *pe = per_entity + (size_t)p * n_ent + e;
+                __builtin_nontemporal_store(dx2, pe);
+                __builtin_nontemporal_store(dy2, pe + pe_stride);
+                __builtin_nontemporal_store(dz2, pe + 2 * pe_stride);
+                __builtin_nontemporal_store(tot, pe + 3 * pe_stride);
+            } else {
+                double4 *pe = reinterpret_cast<double4 *>(per_entity + ((size_t)p * n_ent + e) * 4);
+                *pe = make_double4(dx2, dy2, dz2, tot);
+            }
         }
     };
     if (VEC2) {
@@ -468,13 +478,11 @@ int build_chunks(mdhip_ctx *ctx, int64_t n_ent, int n_groups, const int64_t *gro
     return MDHIP_OK;
 }
 
-}  // namespace
-
-extern "C" {
-
-int mdhip_msd_pairs(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r,
-                    int on_device, double scale, int n_pairs, const int32_t *pairs, int n_groups,
-                    const int64_t *group_off, double *sums, double *per_entity, int pe_on_device)
+// per_entity layouts: col_stride == 0 -> rows [n_pairs][n_ent][4]; > 0 -> four columns [n_pairs * n_ent] that lie
+// col_stride doubles apart at the destination (packed on the device, copied column by column)
+int msd_pairs_impl(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r, int on_device, double scale,
+                   int n_pairs, const int32_t *pairs, int n_groups, const int64_t *group_off, double *sums,
+                   double *per_entity, int pe_on_device, int64_t col_stride)
 {
     if (!ctx) return MDHIP_EINVAL;
     MD_REQUIRE(n_frames >= 0 && n_ent >= 0 && n_pairs >= 0, "negative sizes");
@@ -511,6 +519,8 @@ int mdhip_msd_pairs(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const doubl
         d_pe = pe_on_device ? per_entity : (double *)mdhip_ws(ctx, WS_AUX0, pe_b);
         if (!d_pe) return MDHIP_ENOMEM;
     }
+    const long long col_len = (long long)n_pairs * n_ent;
+    const long long d_stride = col_stride ? (pe_on_device ? (long long)col_stride : col_len) : 0;
     MD_HIP(hipStreamSynchronize(ctx->stream));  // host tables are stack/vector memory
     KernelTimer timer(ctx);
     ctx->last_kernel = "msd_pairs_kernel";
@@ -520,11 +530,11 @@ int mdhip_msd_pairs(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const doubl
     if (vec2)
         hipLaunchKernelGGL(msd_pairs_kernel<true>, dim3((unsigned)n_chunks, (unsigned)n_pairs),
                            dim3(MSD_THREADS), 0, ctx->stream, d_r, (long long)n_ent, scale, d_pairs,
-                           d_chunks, n_chunks, d_partial, d_pe);
+                           d_chunks, n_chunks, d_partial, d_pe, d_stride);
     else
         hipLaunchKernelGGL(msd_pairs_kernel<false>, dim3((unsigned)n_chunks, (unsigned)n_pairs),
                            dim3(MSD_THREADS), 0, ctx->stream, d_r, (long long)n_ent, scale, d_pairs,
-                           d_chunks, n_chunks, d_partial, d_pe);
+                           d_chunks, n_chunks, d_partial, d_pe, d_stride);
     timer.stop();
     MD_HIP(hipGetLastError());
     const int tot = n_pairs * n_groups * 4;
@@ -532,11 +542,42 @@ int mdhip_msd_pairs(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const doubl
                        ctx->stream, d_partial, d_gco, n_chunks, n_groups, n_pairs, d_sums);
     MD_HIP(hipGetLastError());
     MD_HIP(hipMemcpyAsync(sums, d_sums, sums_b, hipMemcpyDeviceToHost, ctx->stream));
-    if (per_entity && !pe_on_device)
-        MD_HIP(hipMemcpyAsync(per_entity, d_pe, pe_b, hipMemcpyDeviceToHost, ctx->stream));
+    if (per_entity && !pe_on_device) {
+        if (!col_stride || col_stride == col_len) {
+            MD_HIP(hipMemcpyAsync(per_entity, d_pe, pe_b, hipMemcpyDeviceToHost, ctx->stream));
+        } else {
+            for (int k = 0; k < 4; ++k)
+                MD_HIP(hipMemcpyAsync(per_entity + (size_t)k * col_stride, d_pe + (size_t)k * col_len,
+                                      (size_t)col_len * 8, hipMemcpyDeviceToHost, ctx->stream));
+        }
+    }
     MD_HIP(hipStreamSynchronize(ctx->stream));
     timer.collect();
     return MDHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mdhip_msd_pairs(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r,
+                    int on_device, double scale, int n_pairs, const int32_t *pairs, int n_groups,
+                    const int64_t *group_off, double *sums, double *per_entity, int pe_on_device)
+{
+    return msd_pairs_impl(ctx, n_frames, n_ent, r, on_device, scale, n_pairs, pairs, n_groups, group_off, sums,
+                          per_entity, pe_on_device, 0);
+}
+
+int mdhip_msd_pairs_cols(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r,
+                         int on_device, double scale, int n_pairs, const int32_t *pairs, int n_groups,
+                         const int64_t *group_off, double *sums, double *cols, int64_t col_stride,
+                         int cols_on_device)
+{
+    if (!ctx) return MDHIP_EINVAL;
+    MD_REQUIRE(cols != nullptr || (int64_t)n_pairs * n_ent == 0, "cols is NULL");
+    MD_REQUIRE(col_stride >= (int64_t)n_pairs * n_ent, "col_stride is shorter than one column");
+    return msd_pairs_impl(ctx, n_frames, n_ent, r, on_device, scale, n_pairs, pairs, n_groups, group_off, sums, cols,
+                          cols_on_device, col_stride ? col_stride : 1);
 }
 
 int mdhip_msd_windows(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r,

@@ -35,6 +35,25 @@ def _writer():
 _COORDS = ["xu", "yu", "zu"]
 _DISPS = ["dx2", "dy2", "dz2"]
 
+# True: get_msd_from_dump parses into page-locked staging buffers and moves every batch of frames to the GPU while
+# the next one is being parsed (mdproptools_amd/stream.py); the trajectory is never stacked on the host and the
+# reductions read ONE device copy. False: every frame is parsed first (round-1 route).
+STREAM = True
+STREAM_BATCH_BYTES = None  # coordinates per staging batch (None: stream.DEFAULT_BATCH_BYTES)
+
+
+def _is_device(r):
+    return hasattr(r, "is_cuda")
+
+
+def _take_frames(r, idx):
+    """r[idx] as a contiguous block, host array or device tensor alike."""
+    if _is_device(r):
+        import torch
+
+        return r[torch.as_tensor(np.asarray(idx), device=r.device)].contiguous()
+    return np.ascontiguousarray(r[idx])
+
 
 class _OlsThroughOrigin:
     """y = b t without intercept: what `sm.OLS(y, t).fit()` exposes and calc_diff reads (diffusion.py:323-329)."""
@@ -111,6 +130,10 @@ class Diffusion:
         # under torch.distributed every rank parses its own share of the files (parsing is the bottleneck);
         # the reduced frames are all-gathered below and the rest runs replicated
         files = D.my_files(pattern) if mio.USE_NATIVE_READER else None
+        if STREAM and mio.USE_NATIVE_READER:
+            got = self._entity_frames_streamed(pattern, files, msd_type, num_mols, num_atoms_per_mol, mass)
+            if got is not None:
+                return got
         for step, names, cols in self._frame_columns(pattern, msd_type, mass, mio.USE_NATIVE_READER, files=files):
             if ids is None:
                 ids = cols["id"]
@@ -138,7 +161,72 @@ class Diffusion:
         r = np.stack(planes)
         if files is not None:
             r = D.allgather_var(r)
-        return times, r, dict(id=ids)
+        return times, r, dict(id=np.asarray(ids).astype(np.int64))  # an integer column, as the reference's parser reads it
+
+    def _entity_frames_streamed(self, pattern, files, msd_type, num_mols, num_atoms_per_mol, mass):
+        """The same (times, r [F,3,E], meta) with r a DEVICE tensor: frames go text -> page-locked batch -> GPU while
+        the next batch is parsed; 'com' reduces every batch to molecule centres on the way (`mdhip_segment_com` with a
+        device destination), so only [F,3,M] stays. None when the dumps need the general route (wrapped coordinates
+        to unwrap, compressed text, a column missing — whose error the general route raises in the reference's
+        words)."""
+        import torch
+
+        from .. import dist as D
+        from .. import io as mio
+        from .. import stream as S
+        from .._lib import default_context
+
+        mine = files if files is not None else mio._sorted_matches(pattern)
+        if not mine or any(str(f).endswith(".gz") for f in mine):
+            return None
+        nd = mio.NativeDumpFile(mine[0])
+        try:
+            names = nd.header(0)[4] if nd.n_frames else []
+        finally:
+            nd.close()
+        # the staging batch carries id, ONE per-atom attribute and the three coordinate planes
+        second = "id" if msd_type == "allatom" else ("type" if mass else "mass")
+        if not {"id", "xu", "yu", "zu", second} <= set(names):
+            return None
+        ctx = default_context()
+        dev = torch.device("cuda", ctx.device)
+        seg = molecule_layout(num_mols, num_atoms_per_mol) if msd_type == "com" else None
+        times, blocks = [], []
+        ids = atom_mass = seg_mass = None
+        stream = S.FrameStream(pattern, files=mine, columns=("id", second, "xu", "yu", "zu"),
+                               batch_bytes=STREAM_BATCH_BYTES or S.DEFAULT_BATCH_BYTES)
+        for batch in stream:
+            B, _, n = batch.xyz.shape
+            if ids is None:
+                ids = batch.ids[0].copy()
+            if msd_type == "com":
+                if seg[0][-1] != n:
+                    raise ValueError(f"Length of values ({int(seg[0][-1])}) does not match length of index ({n})")
+                m = batch.types if not mass else np.asarray(mass, dtype=np.float64)[batch.types.astype(np.int64) - 1]
+                if atom_mass is None:
+                    atom_mass = m[0].copy()
+                if not (m == atom_mass).all():
+                    raise ValueError("atom masses change between frames")
+                out = torch.empty((B, 3, len(seg[0]) - 1), dtype=torch.float64, device=dev)
+                _, seg_mass, _ = backend.segment_com(batch.xyz, atom_mass, seg[0], out=out, ctx=ctx)
+            else:
+                out = torch.empty((B, 3, n), dtype=torch.float64, device=dev)
+                out.copy_(torch.from_numpy(batch.xyz))  # synchronous DMA from the page-locked batch
+            blocks.append(out)
+            times.extend(batch.timesteps.tolist())
+        times = np.asarray(times, dtype=np.float64) * self.timestep * constants.TIME_CONVERSION[self.units]
+        if files is not None:
+            D.require_all_nonempty(len(times), "dump file")  # every rank raises, or none
+        elif not blocks:
+            return None
+        r = torch.cat(blocks) if len(blocks) > 1 else blocks[0]
+        del blocks
+        if files is not None and D.is_distributed():
+            times = D.allgather_var(times)
+            r = torch.from_numpy(D.allgather_var(r.cpu().numpy())).to(dev)
+        if msd_type == "com":
+            return times, r, dict(type=seg[1], mol_id=seg[2], mass=seg_mass)
+        return times, r, dict(id=ids.astype(np.int64))  # an integer column, as the reference's parser reads it
 
     def _frame_columns(self, pattern, msd_type, mass, native, files=None):
         """Yields (timestep, column names, {name: id-sorted float64 column}) with xu, yu, zu present
@@ -196,7 +284,8 @@ class Diffusion:
         """
         times, r, meta = self._entity_frames(filename, msd_type, num_mols, num_atoms_per_mol, mass)
         order = np.argsort(times, kind="stable")  # the reference sorts its (time, id) index
-        times, r = times[order], np.ascontiguousarray(r[order])
+        if not np.array_equal(order, np.arange(len(order))):
+            times, r = times[order], _take_frames(r, order)
         F, _, E = r.shape
         dist = constants.DISTANCE_CONVERSION[self.units]
         if msd_type == "allatom":
@@ -210,6 +299,8 @@ class Diffusion:
             group_labels = np.arange(1, len(counts) + 1)
         scale = dist
         if msd_type == "com" and com_drift:
+            if _is_device(r):  # small ([F,3,M]) and host arithmetic: same doubles as the load-everything route
+                r = r.cpu().numpy()
             r = self._remove_drift(r * dist, meta["mass"] * constants.MASS_CONVERSION[self.units], group_off)
             scale = 1.0
         origin = np.flatnonzero(times == 0)
@@ -217,15 +308,17 @@ class Diffusion:
             raise KeyError(0)  # the reference selects the time-0 rows with .xs(0, 0)
         origin = int(origin[0])
         pairs = np.column_stack([np.full(F, origin), np.arange(F)]).astype(np.int32)
-        sums, per_entity = backend.msd_pairs(r, pairs, group_off, scale=scale, per_entity=True)
-
+        # the per-entity values come back as the four COLUMNS of msd_all (one contiguous block each); the frame wraps
+        # them, the time column and the tiled id columns without consolidating them into a second copy
         cols_1d = _DISPS + ["msd"]
+        col_block = np.empty((4, F * E))
+        sums = backend.msd_pairs_cols(r, pairs, group_off, col_block, scale=scale)
         all_cols = {"Time (s)": np.repeat(times, E)}
         for name, v in zip(id_cols, id_vals):
             all_cols[name] = np.tile(v, F)
         for k, name in enumerate(cols_1d):
-            all_cols[name] = per_entity[:, :, k].reshape(-1)
-        msd_all = pd.DataFrame(all_cols)
+            all_cols[name] = col_block[k]
+        msd_all = pd.DataFrame(all_cols, copy=False)
 
         means = sums / np.diff(group_off)[None, :, None]
         if msd_type == "allatom":
@@ -241,7 +334,7 @@ class Diffusion:
 
         kept = np.arange(F)[::tao_coeff]  # diffusion.py:226-228
         n_kept = len(kept)
-        win = backend.msd_windows(np.ascontiguousarray(r[kept]), 1, scale=scale)
+        win = backend.msd_windows(_take_frames(r, kept), 1, scale=scale)
         int_cols = {name: v for name, v in zip(id_cols, id_vals)}
         with np.errstate(invalid="ignore", divide="ignore"):
             for k, c in enumerate(_DISPS):

@@ -198,22 +198,22 @@ class FrameStream:
                         opens.append(pool.submit(open_file, files[nxt]))
                         nxt += 1
 
-                cur = None  # [buf, n, cap, ids, types, lengths, steps, parse futures]
+                cur = None  # [buf, n, cap, ids [cap,n], types [cap,n], lengths, steps, parse futures]
 
                 def flush():
+                    # the batch goes to the consumer WITH its parse futures still running (the consumer waits for them):
+                    # the producer moves on to place the frames of the next batches, so up to `depth` batches of
+                    # frames are being parsed at once
                     nonlocal cur
                     if cur is None:
                         return
                     buf, n, _cap, ids, types, lengths, steps, futs = cur
-                    for fu in futs:
-                        self.stats["parse_s"] += fu.result()  # (summed over the pool's threads)
-                    self._ready.put(Batch(self, buf, len(steps), n, np.stack(ids), np.stack(types), np.array(lengths),
-                                          np.array(steps, dtype=np.int64)))
+                    B = len(steps)
+                    self._ready.put((Batch(self, buf, B, n, ids[:B], types[:B], np.array(lengths),
+                                           np.array(steps, dtype=np.int64)), futs))
                     self.stats["batches"] += 1
-                    self.stats.setdefault("batch_ready_at_s", []).append(time.perf_counter() - t_start)
                     cur = None
 
-                t_start = time.perf_counter()
                 top_up()
                 while opens:
                     if self._closed:
@@ -230,12 +230,10 @@ class FrameStream:
                             buf = self._get_buffer(cap * 3 * n)
                             if buf is None:
                                 return
-                            cur = [buf, n, cap, [], [], [], [], []]
+                            cur = [buf, n, cap, np.empty((cap, n)), np.empty((cap, n)), [], [], []]
                         k = len(cur[6])
                         slot = cur[0].array[k * 3 * n:(k + 1) * 3 * n].reshape(3, n)
-                        ids, types = np.empty(n), np.empty(n)
-                        cur[3].append(ids)
-                        cur[4].append(types)
+                        ids, types = cur[3][k], cur[4][k]
                         cur[5].append(mio.LammpsBox(bounds.tolist(), tilt).to_lattice().lengths)
                         cur[6].append(ts)
                         cur[7].append(pool.submit(parse, nd, f, names, [ids, types, slot[0], slot[1], slot[2]], pending))
@@ -259,8 +257,8 @@ class FrameStream:
                 if cur is None:
                     return
                 buf, n, _cap, ids, types, lengths, steps = cur
-                self._ready.put(Batch(self, buf, len(steps), n, np.stack(ids), np.stack(types), np.array(lengths),
-                                      np.array(steps, dtype=np.int64)))
+                self._ready.put((Batch(self, buf, len(steps), n, np.stack(ids), np.stack(types), np.array(lengths),
+                                       np.array(steps, dtype=np.int64)), []))
                 self.stats["batches"] += 1
                 cur = None
 
@@ -300,10 +298,14 @@ class FrameStream:
         try:
             while True:
                 t0 = time.perf_counter()
-                batch = self._ready.get()
-                self.stats["consumer_wait_s"] += time.perf_counter() - t0
-                if batch is None:
+                item = self._ready.get()
+                if item is None:
+                    self.stats["consumer_wait_s"] += time.perf_counter() - t0
                     break
+                batch, futs = item
+                for fu in futs:
+                    self.stats["parse_s"] += fu.result()  # (summed over the pool's threads)
+                self.stats["consumer_wait_s"] += time.perf_counter() - t0
                 if self.on_frame is not None:
                     for ts in batch.timesteps:
                         self.on_frame(int(ts))
@@ -317,15 +319,18 @@ class FrameStream:
     def close(self):
         self._closed = True
         self._free.put(None)
-        try:  # unblock a producer waiting on a full ready queue
-            while True:
-                b = self._ready.get_nowait()
-                if b is None:
-                    break
-        except queue.Empty:
-            pass
-        if self._thread is not None:
-            self._thread.join(timeout=30)
+        deadline = time.perf_counter() + 30.0
+        while True:  # keep the ready queue drained until the producer (and its parse tasks) are gone
+            try:
+                while self._ready.get_nowait() is not None:
+                    pass
+            except queue.Empty:
+                pass
+            if self._thread is None:
+                break
+            self._thread.join(timeout=0.05)
+            if not self._thread.is_alive() or time.perf_counter() > deadline:
+                break
         for b in self._bufs:
             _give_back(b)
         self._bufs = []

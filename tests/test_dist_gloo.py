@@ -253,6 +253,11 @@ def _numpy_dynamical_backend():
         sums = np.stack([pe[:, go[g]:go[g + 1]].sum(axis=1) for g in range(len(go) - 1)], axis=1)
         return (sums, pe) if per_entity else sums
 
+    def msd_pairs_cols(r, pairs, group_off, cols, scale=1.0, ctx=None):
+        sums, pe = msd_pairs(r, pairs, group_off, scale=scale, per_entity=True)
+        cols[:] = pe.reshape(-1, 4).T
+        return sums
+
     def msd_windows(r, tao, scale=1.0, ctx=None):
         kept = (np.asarray(r) * scale)[::tao]
         d2 = (kept[1:] - kept[:-1]) ** 2  # [W,3,E]
@@ -264,7 +269,7 @@ def _numpy_dynamical_backend():
         return np.stack([np.stack([jm[:, k, np.asarray(seg_type) == t].sum(axis=1) for t in range(n_types)])
                          for k in range(3)])
 
-    return segment_com, msd_pairs, msd_windows, charge_flux
+    return segment_com, msd_pairs, msd_pairs_cols, msd_windows, charge_flux
 
 
 def _dynamical_worker(rank, world, port, tmp_dir):
@@ -276,7 +281,11 @@ def _dynamical_worker(rank, world, port, tmp_dir):
     from mdproptools_amd.dynamical.conductivity import Conductivity
     from mdproptools_amd.dynamical.diffusion import Diffusion
 
-    backend.segment_com, backend.msd_pairs, backend.msd_windows, backend.charge_flux = _numpy_dynamical_backend()
+    (backend.segment_com, backend.msd_pairs, backend.msd_pairs_cols, backend.msd_windows,
+     backend.charge_flux) = _numpy_dynamical_backend()
+    from mdproptools_amd.dynamical import diffusion as dm
+
+    dm.STREAM = False  # the streamed route keeps the trajectory on the GPU; its two-rank run is tests/test_gpu_dropin.py
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     out = os.path.join(tmp_dir, "w%d" % world)

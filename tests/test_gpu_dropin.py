@@ -101,6 +101,7 @@ def test_diffusion_allatom(small_dir):
     _frame_equal(msd, g["aa_msd"], g["aa_msd_cols"], 1e-10)
     _frame_equal(msd_all, g["aa_msd_all"], g["aa_msd_all_cols"], 1e-12)
     _frame_equal(msd_int, g["aa_msd_int"], g["aa_msd_int_cols"], 1e-10)
+    assert msd_all["id"].dtype == np.int64 and msd_int["id"].dtype == np.int64  # as the reference's parser reads ids
     two = d.get_msd_from_dump("dump.nvt.*.dump", msd_type="allatom")
     assert len(two) == 2
     with pytest.raises(ValueError):
@@ -124,6 +125,42 @@ def test_diffusion_com(small_dir, tag, drift):
         table = d.calc_diff(msd, diff_names=["dme", "tfsi", "mg"])
         np.testing.assert_allclose(table.to_numpy(), g["comd_diff"], rtol=1e-9)
         assert os.path.exists(os.path.join(tmp, "diffusion.csv"))
+
+
+@pytest.mark.parametrize("kw", [dict(msd_type="allatom"), dict(msd_type="com", mass=MASS),
+                                dict(msd_type="com", mass=None), dict(msd_type="com", mass=MASS, com_drift=True)])
+def test_diffusion_streamed_equals_load_all(small_dir, kw, monkeypatch):
+    """get_msd_from_dump on the frame stream (text -> page-locked batches -> device-resident trajectory, several
+    batches here) returns the same DataFrames, bit for bit, as the load-everything-first route."""
+    from mdproptools_amd.dynamical import diffusion as dm
+
+    g, tmp = small_dir
+    if kw["msd_type"] == "com":
+        kw = dict(kw, num_mols=g["num_mols"].tolist(), num_atoms_per_mol=g["num_atoms_per_mol"].tolist())
+    d = dm.Diffusion(timestep=1, units="real", outputs_dir=tmp, diff_dir=tmp)
+    n = g["frames"][0].shape[0]
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(dm, "STREAM", on)
+        monkeypatch.setattr(dm, "STREAM_BATCH_BYTES", 2 * 24 * n)  # two frames per batch
+        made = []
+        orig = dm.Diffusion._entity_frames_streamed
+
+        def spy(self, *a, **k):
+            out = orig(self, *a, **k)
+            made.append(out)
+            return out
+
+        monkeypatch.setattr(dm.Diffusion, "_entity_frames_streamed", spy)
+        res[on] = d.get_msd_from_dump("dump.nvt.*.dump", avg_interval=True, tao_coeff=3, **kw)
+        monkeypatch.setattr(dm.Diffusion, "_entity_frames_streamed", orig)
+        if on:
+            assert made and made[0] is not None and made[0][1].is_cuda  # the device-resident route was taken
+        else:
+            assert not made
+    for a, b in zip(res[True], res[False]):
+        assert list(a.columns) == list(b.columns)
+        np.testing.assert_array_equal(a.to_numpy(), b.to_numpy())
 
 
 def test_calc_com_dataframe(small_dir):
@@ -272,7 +309,15 @@ def _gpu_dist_worker(rank, world, port, tmp_dir):
                                path_or_buff=os.path.join(out, "rdf.csv"))
     c = rdf_cn.calc_atomic_cn([2.0, 3.0, 4.5], 0.05, 3, [1.0, 2.0, 3.0], [[1, 1, 2], [1, 2, 3]], pattern,
                               path_or_buff=os.path.join(out, "cn.csv"))
-    np.savez(os.path.join(out, "rank%d.npz" % rank), g=g.to_numpy(), c=c.to_numpy())
+    # the streamed Diffusion route (device-resident trajectory; the ranks' blocks are all-gathered)
+    from mdproptools_amd.dynamical.diffusion import Diffusion
+
+    d = Diffusion(timestep=1, units="real", outputs_dir=tmp_dir, diff_dir=out)
+    aa = d.get_msd_from_dump("msd.*.dump", msd_type="allatom", avg_interval=True, tao_coeff=2)
+    cm = d.get_msd_from_dump("msd.*.dump", msd_type="com", num_mols=[500, 500], num_atoms_per_mol=[4, 2],
+                             mass=[1.0, 2.0, 3.0], avg_interval=True, tao_coeff=2)
+    np.savez(os.path.join(out, "rank%d.npz" % rank), g=g.to_numpy(), c=c.to_numpy(),
+             **{"aa%d" % k: v.to_numpy() for k, v in enumerate(aa)}, **{"cm%d" % k: v.to_numpy() for k, v in enumerate(cm)})
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -294,6 +339,13 @@ def test_dropin_rdf_cn_two_ranks_on_gpu(tmp_path):
         tbl = np.column_stack([rng.permutation(n) + 1, 1 + (np.arange(n) % 3), rng.uniform(0, L, (n, 3))])
         mio.write_dump(str(tmp_path / ("dump.nvt.%d.dump" % (k * 100))), k * 100, [[0, L]] * 3,
                        ["id", "type", "x", "y", "z"], tbl)
+    walk = rng.uniform(0, 30, (n, 3))
+    for k in range(7):  # unwrapped coordinates of a random walk, one frame per file, seven files over two ranks
+        perm = rng.permutation(n)  # rows in a different order in every file; an atom keeps its id, type and walk
+        tbl = np.column_stack([perm + 1, 1 + (perm % 3), walk[perm]])
+        mio.write_dump(str(tmp_path / ("msd.%d.dump" % (k * 100))), k * 100, [[0, 30.0]] * 3,
+                       ["id", "type", "xu", "yu", "zu"], tbl)
+        walk = walk + rng.normal(0, 0.3, (n, 3))
 
     def port():
         with socket.socket() as s:
@@ -308,6 +360,9 @@ def test_dropin_rdf_cn_two_ranks_on_gpu(tmp_path):
         two = np.load(tmp_path / "w2" / ("rank%d.npz" % rank))
         np.testing.assert_array_equal(two["g"], one["g"])
         np.testing.assert_array_equal(two["c"], one["c"])
+        for key in ("aa0", "aa1", "aa2", "cm0", "cm1", "cm2"):
+            np.testing.assert_array_equal(two[key], one[key])
+    assert one["aa0"][-1, 4] > 0
     assert open(tmp_path / "w2" / "rdf.csv").read() == open(tmp_path / "w1" / "rdf.csv").read()
 
 

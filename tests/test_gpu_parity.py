@@ -260,6 +260,29 @@ def test_msd_allatom_golden(B, g_small):
     np.testing.assert_allclose(win[:, 3] / n_kept, expect[:, 3], rtol=1e-10, atol=0)
 
 
+@pytest.mark.parametrize("E", [1, 777, 4096])
+def test_msd_pairs_column_layout_equals_row_layout(B, E):
+    """mdhip_msd_pairs_cols (the four per-entity values as column blocks, here rows of a wider block) stores the same
+    doubles as the row layout of mdhip_msd_pairs, with the same sums; odd and even entity counts, groups."""
+    rng = np.random.default_rng(E)
+    F = 6
+    r = rng.normal(0, 20, (F, 3, E))
+    pairs = [(0, t) for t in range(F)] + [(3, 1)]
+    goff = [0, E] if E < 10 else [0, E // 3, E]
+    sums, pe = B.msd_pairs(r, pairs, goff, scale=1e-10, per_entity=True)
+    block = np.full((6, len(pairs) * E + 5), -1.0)
+    cols = block[1:5, :len(pairs) * E]
+    sums_c = B.msd_pairs_cols(r, pairs, goff, cols, scale=1e-10)
+    np.testing.assert_array_equal(sums_c, sums)
+    np.testing.assert_array_equal(cols, pe.reshape(-1, 4).T)
+    assert (block[0] == -1).all() and (block[5] == -1).all() and (block[:, len(pairs) * E:] == -1).all()
+    tight = np.empty((4, len(pairs) * E))
+    B.msd_pairs_cols(r, pairs, goff, tight, scale=1e-10)
+    np.testing.assert_array_equal(tight, cols)
+    with pytest.raises(ValueError):
+        B.msd_pairs_cols(r, pairs, goff, np.empty((4, 3)), scale=1.0)
+
+
 def test_segment_com_ragged_and_long_segments(B):
     """Staged kernel (runs of whole segments through LDS) and the per-lane fallback (a segment longer than
     the LDS stage) against the oracle, on ragged segment sizes 1..40, 4-atom and 16-atom molecules."""

@@ -42,6 +42,5 @@ for n, F in ((100_000, 60),):
             for b in st:
                 nb += len(b)
             t_stream = time.perf_counter() - t0
-            print("workers", w, "batches ready at", ["%.3f" % t for t in st.stats.get("batch_ready_at_s", [])])
             print("n=%d F=%d  one-shot %.4f s   stream %.4f s (%d frames, pinned=%s, parse_s(sum)=%.3f, buffer waits %.3f)"
                   % (n, F, t_list, t_stream, nb, st.stats["pinned"], st.stats["parse_s"], st.stats["wait_for_buffer_s"]))
