@@ -101,7 +101,7 @@ _lock = threading.Lock()
 
 def _preload_torch_runtime():
     """
-    PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / libhipfft.so.0. Two HIP runtimes in one
+    PyTorch-ROCm wheels bundle their own libamdhip64.so.7. Two HIP runtimes in one
     process cannot both own the device ("No HIP GPUs are available" from whichever initialises
     second), so when torch is installed its runtime is loaded FIRST and libmdhip.so then binds to
     the same copy by SONAME. Without torch the system ROCm in /opt/rocm/lib is used (RUNPATH).

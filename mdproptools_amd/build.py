@@ -20,13 +20,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libmdhip.so")
-SOURCES = ["mdhip_ctx.hip", "pair_hist.hip", "pair_dense.hip", "pair_cull.hip", "pair_sj.hip", "segment_com.hip", "msd.hip", "msd_fft.hip", "xcorr.hip", "scan.hip", "residence.hip",
+SOURCES = ["mdhip_ctx.hip", "pair_hist.hip", "pair_dense.hip", "pair_cull.hip", "pair_sj.hip", "segment_com.hip", "msd.hip", "msd_fft.hip", "xcorr.hip", "fft_pow2.hip", "scan.hip", "residence.hip",
            "dump_reader.cpp"]
 HEADERS = [os.path.join(CSRC, "ctx.h"), os.path.join(CSRC, "pair_common.h"), os.path.join(os.path.dirname(HERE), "include", "mdhip.h")]
 ARCH = "gfx950"
 CFLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "--offload-arch=" + ARCH,
           "-Wall", "-Wno-unused-function"]
-LDFLAGS = ["-shared", "-fPIC", "--offload-arch=" + ARCH, "-L/opt/rocm/lib", "-lhipfft", "-lpthread",
+LDFLAGS = ["-shared", "-fPIC", "--offload-arch=" + ARCH, "-L/opt/rocm/lib", "-lpthread",
            "-Wl,-rpath,/opt/rocm/lib"]
 
 

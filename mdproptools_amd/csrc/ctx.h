@@ -49,6 +49,7 @@ enum WsSlot {
     WS_ROWS,       // their sums per output frame
     WS_REL,        // packed-f32 tile-relative records (scalar-j MODE 3)
     WS_CEN,        // tile centres + half extents
+    WS_FFT_TMP,    // second transform buffer of fft_pow2.hip for the large-lag MSD path
     WS_COUNT
 };
 
@@ -105,12 +106,17 @@ struct mdhip_ctx {
     int opt_lag_variant = 3;  // full-lag MSD: 3 (default) = autocorrelation theorem (msd_fft.hip) when its error bound
                               // stays below 1e-10, else the exact-difference kernel; 1 = series-resident LDS
                               // difference kernel when it fits, 0 = staged difference kernel, 2 = always the
-                              // autocorrelation theorem, 4 = 2 through batched hipFFT
+                              // autocorrelation theorem, 4 = 2 through batched global transforms (fft_pow2.hip)
     double last_rel_bound = 0.0;  // error bound reported by the FFT MSD path of the last mdhip_lag_msd call (0: exact path)
 };
 
 int mdhip_fail(mdhip_ctx *ctx, int code, const char *fmt, ...);
 // msd_fft.hip: full-lag MSD through batched FFTs; d_r device [F][3][E], out host [max_lag+1][G][4]
+// fft_pow2.hip: batched power-of-two FP64 real transforms (half spectra [batch][L/2+1]); d_tmp holds batch * L/2
+// complex points; r2c overwrites its input, c2r is the unnormalised inverse
+int mdhip_fft_r2c(mdhip_ctx *ctx, double *d_real, double2 *d_tmp, double2 *d_spec, long long L, int batch);
+int mdhip_fft_c2r(mdhip_ctx *ctx, const double2 *d_spec, double2 *d_tmp, double *d_real, long long L, int batch);
+
 int mdhip_lag_msd_fft(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *d_r, double scale,
                       int max_lag, int n_groups, const int64_t *group_off, double *out, double *rel_bound);
 void *mdhip_ws(mdhip_ctx *ctx, int slot, size_t bytes);  // nullptr on failure (error set)

@@ -1,0 +1,269 @@
+// fft_pow2.hip — batched power-of-two FP64 transforms for the correlation paths (G2/G3 of SURVEY §8a:
+// dynamical/conductivity.py:97-114 `correlate`, dynamical/viscosity.py:103-115 `autocorrelate`), written for gfx950.
+//
+// Why not the library FFT: rocFFT compiles its kernels at run time for every new length — 1.4-1.8 s on the first
+// transform of a process, three orders of magnitude more than the transform itself — and a correlation call is
+// usually made ONCE per process. These kernels are compiled with the library; the first call costs what every call
+// costs.
+//
+// Layout of the work (L real samples, H = L/2 complex points, both powers of two):
+//   real -> spectrum   the L reals ARE H complex points z[j] = x[2j] + i x[2j+1] (no repacking); Z = FFT_H(z);
+//                      X(k) = E(k) + e^{-2 pi i k/L} O(k), E/O from Z(k) and conj Z(H-k)       (r2c_post_kernel)
+//   spectrum -> real   Y(k) = [S(k) + conj S(H-k)] + i e^{+2 pi i k/L} [S(k) - conj S(H-k)];     (c2r_pre_kernel)
+//                      y = IFFT_H(Y) = conj FFT_H(conj Y); c[2j] = Re y[j], c[2j+1] = Im y[j]  (unnormalised)
+//   FFT_H              Stockham autosort, decimation in frequency, 1-4 passes of radix R = 2^1..2^8:
+//                      pass (n, s) with n*s = H reads column c of the [R][H/R] view of its input, does the R-point
+//                      DFT, multiplies output j by e^{-2 pi i j p/n} (p = c div s) and stores it at
+//                      (c mod s) + s*(R*p + j); then n /= R, s *= R. Natural order in, natural order out.
+//
+// fft_pass_kernel: a workgroup of 256 lanes owns a tile of C = 16 neighbouring columns (256-byte runs in HBM for the
+// loads of every pass and for the stores of every pass but the first, whose stores are runs of R points): the
+// R x C tile sits in LDS (64 KB at R = 256), the DFT is an in-place Gentleman-Sande radix-2 network over the rows
+// (lanes walk the columns: consecutive 16-byte LDS words, no bank conflicts) with the R/2 roots of unity in an LDS
+// table made once per workgroup by sincospi of an EXACT argument (k/R, dyadic), and the bit-reversed row order is
+// undone by the store loop. The per-pass twiddle e^{-2 pi i jp/n} is again sincospi of an exact dyadic argument
+// (jp < n <= 2^29 fits an integer, n is a power of two), so twiddle error is the ~1 ulp of ocml's sincospi and does
+// not grow with the length. HBM-bound: 32 B per point per pass.
+#include <algorithm>
+
+#include "ctx.h"
+
+namespace {
+
+constexpr int FFT_THREADS = 256;
+constexpr int FFT_MAX_LOGR = 8;  // R <= 256
+constexpr int FFT_LOGC = 4;      // C = 16 columns per tile
+constexpr int FFT_MAX_BATCH = 32768;  // series per launch (grid.y)
+
+__device__ __forceinline__ double2 cmul(double2 a, double2 b)
+{
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// e^{-2 pi i num/den}, den a power of two, 0 <= num: the argument 2*num/den is exact in double
+__device__ __forceinline__ double2 root_of_unity(long long num, long long den)
+{
+    double s, c;
+    sincospi(-2.0 * (double)num / (double)den, &s, &c);
+    return make_double2(c, s);
+}
+
+__device__ __forceinline__ unsigned bit_reverse(unsigned r, int bits) { return bits ? __brev(r) >> (32 - bits) : 0u; }
+
+// grid (H/R/C tiles, batch). in/out [batch][H]. CONJ_IN: conjugate every point on load; CONJ_OUT: on store.
+template <bool CONJ_IN, bool CONJ_OUT>
+__global__ __launch_bounds__(FFT_THREADS) void fft_pass_kernel(const double2 *__restrict__ in,
+                                                               double2 *__restrict__ out, long long H, int logR,
+                                                               int logC, int logS, long long n)
+{
+    const long long s = 1LL << logS;
+    extern __shared__ double2 lds[];
+    const int R = 1 << logR, C = 1 << logC;
+    double2 *buf = lds;              // [R][C]
+    double2 *tw = lds + (R << logC);  // [R/2]
+    const long long cols = H >> logR;
+    const long long c0 = (long long)blockIdx.x << logC;
+    in += (size_t)blockIdx.y * H;
+    out += (size_t)blockIdx.y * H;
+    for (int idx = threadIdx.x; idx < (R << logC); idx += FFT_THREADS) {
+        const int k = idx >> logC, cc = idx & (C - 1);
+        double2 v = in[c0 + cc + (long long)k * cols];
+        if (CONJ_IN) v.y = -v.y;
+        buf[idx] = v;
+    }
+    for (int t = threadIdx.x; t < (R >> 1); t += FFT_THREADS) tw[t] = root_of_unity(t, R);
+    __syncthreads();
+    for (int st = 0; st < logR; ++st) {
+        const int lh = logR - 1 - st;  // log2 of the half-span
+        const int half = 1 << lh;
+        for (int b = threadIdx.x; b < (R >> 1 << logC); b += FFT_THREADS) {
+            const int cc = b & (C - 1), pr = b >> logC;
+            const int i = pr & (half - 1);
+            const int top = ((pr >> lh) << (lh + 1)) + i;
+            double2 *pa = buf + (top << logC) + cc, *pb = pa + (half << logC);
+            const double2 a = *pa, bb = *pb;
+            *pa = make_double2(a.x + bb.x, a.y + bb.y);
+            *pb = cmul(make_double2(a.x - bb.x, a.y - bb.y), tw[i << st]);
+        }
+        __syncthreads();
+    }
+    const bool last = n == R;  // p = 0 for every column: no twiddle
+    // store order: columns fastest when a tile's columns share their p (s >= C: runs of C points), output index
+    // fastest otherwise (first pass, s = 1: the tile's outputs are one contiguous block of R*C points)
+    const bool col_fast = s >= C;
+    for (int idx = threadIdx.x; idx < (R << logC); idx += FFT_THREADS) {
+        int cc, j;
+        if (col_fast) {
+            cc = idx & (C - 1);
+            j = idx >> logC;
+        } else {
+            j = idx & (R - 1);
+            cc = idx >> logR;
+        }
+        const int r = (int)bit_reverse((unsigned)j, logR);
+        double2 v = buf[(r << logC) + cc];
+        const long long c = c0 + cc;
+        const long long p = c >> logS, q = c & (s - 1);
+        if (!last && j != 0 && p != 0) v = cmul(v, root_of_unity((long long)j * p, n));
+        if (CONJ_OUT) v.y = -v.y;
+        out[q + s * (((long long)p << logR) + j)] = v;
+    }
+}
+
+// spec[b][k], k = 0..H, from Z = FFT_H of the reals read as complex pairs. grid (ceil((H/2+1)/256), batch)
+__global__ void r2c_post_kernel(const double2 *__restrict__ Z, double2 *__restrict__ spec, long long H)
+{
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > H / 2) return;
+    Z += (size_t)blockIdx.y * H;
+    spec += (size_t)blockIdx.y * (H + 1);
+    const long long kk = (H - k) & (H - 1);
+    const double2 zk = Z[k], zh = Z[kk];
+    const double2 E = make_double2(0.5 * (zk.x + zh.x), 0.5 * (zk.y - zh.y));
+    const double2 O = make_double2(0.5 * (zk.y + zh.y), -0.5 * (zk.x - zh.x));  // (zk - conj zh) / (2i)
+    const double2 w = root_of_unity(k, 2 * H);
+    const double2 wo = cmul(w, O);
+    spec[k] = make_double2(E.x + wo.x, E.y + wo.y);
+    spec[H - k] = make_double2(E.x - wo.x, -(E.y - wo.y));  // X(H-k) = conj(E - w O); k = 0 -> X(H)
+}
+
+// W = conj Y (the input of the forward transform that stands for the inverse one) from the Hermitian half spectrum
+// S[b][0..H]. grid (ceil((H/2+1)/256), batch)
+__global__ void c2r_pre_kernel(const double2 *__restrict__ S, double2 *__restrict__ W, long long H)
+{
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > H / 2) return;
+    S += (size_t)blockIdx.y * (H + 1);
+    W += (size_t)blockIdx.y * H;
+    const double2 sk = S[k], sh = S[H - k];
+    const double2 w = root_of_unity(k, 2 * H);                       // e^{-2 pi i k/L}
+    const double2 se = make_double2(sk.x + sh.x, sk.y - sh.y);       // S(k) + conj S(H-k)
+    const double2 sd = make_double2(sk.x - sh.x, sk.y + sh.y);       // S(k) - conj S(H-k)
+    const double2 t = cmul(make_double2(w.x, -w.y), sd);             // e^{+2 pi i k/L} sd
+    const double2 yk = make_double2(se.x - t.y, se.y + t.x);         // se + i t
+    W[k] = make_double2(yk.x, -yk.y);
+    if (k != 0 && 2 * k != H) {
+        // Y(H-k) = conj(se) - i w (S(H-k) - conj S(k)) = conj(se) + i w conj(sd)
+        const double2 u = cmul(w, make_double2(sd.x, -sd.y));
+        const double2 yh = make_double2(se.x - u.y, -se.y + u.x);
+        W[H - k] = make_double2(yh.x, -yh.y);
+    }
+}
+
+__global__ void conj_copy_kernel(const double2 *__restrict__ in, double2 *__restrict__ out, long long count)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = make_double2(in[i].x, -in[i].y);
+}
+
+struct PassPlan {
+    int n_pass = 0;
+    int logR[4] = {0, 0, 0, 0};
+};
+
+PassPlan plan_passes(long long H)
+{
+    int logH = 0;
+    while ((1LL << logH) < H) ++logH;
+    PassPlan p;
+    p.n_pass = (logH + FFT_MAX_LOGR - 1) / FFT_MAX_LOGR;
+    for (int i = 0, left = logH; i < p.n_pass; ++i) {
+        p.logR[i] = (left + (p.n_pass - i) - 1) / (p.n_pass - i);  // as even as possible, larger radices first
+        left -= p.logR[i];
+    }
+    return p;
+}
+
+template <bool CI, bool CO>
+void launch_pass(mdhip_ctx *ctx, const double2 *in, double2 *out, long long H, int batch, int logR, int logS)
+{
+    const long long cols = H >> logR;
+    int logC = FFT_LOGC;
+    while ((1LL << logC) > cols) --logC;
+    const size_t lds = ((size_t)(1 << logR << logC) + (size_t)(1 << logR >> 1)) * sizeof(double2);
+    const dim3 grid((unsigned)(cols >> logC), (unsigned)batch);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fft_pass_kernel<CI, CO>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((fft_pass_kernel<CI, CO>), grid, dim3(FFT_THREADS), lds, ctx->stream, in, out, H, logR, logC,
+                       logS, H >> logS);
+}
+
+// FFT_H of `batch` series, conj on the way in and/or out. The passes alternate between the two buffers; returns the
+// buffer that holds the result (x after an even number of passes, y after an odd one). x is overwritten.
+double2 *fft_forward(mdhip_ctx *ctx, double2 *x, double2 *y, long long H, int batch, bool conj_in, bool conj_out)
+{
+    const PassPlan p = plan_passes(H);
+    if (p.n_pass == 0) {  // H = 1: the transform is the identity
+        if (conj_in != conj_out)
+            hipLaunchKernelGGL(conj_copy_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, ctx->stream, x, y,
+                               (long long)batch);
+        return conj_in != conj_out ? y : x;
+    }
+    double2 *src = x, *dst = y;
+    int s = 0;  // log2 of the product of the radices done
+    for (int i = 0; i < p.n_pass; ++i) {
+        const bool ci = conj_in && i == 0, co = conj_out && i == p.n_pass - 1;
+        if (ci && co) launch_pass<true, true>(ctx, src, dst, H, batch, p.logR[i], s);
+        else if (ci) launch_pass<true, false>(ctx, src, dst, H, batch, p.logR[i], s);
+        else if (co) launch_pass<false, true>(ctx, src, dst, H, batch, p.logR[i], s);
+        else launch_pass<false, false>(ctx, src, dst, H, batch, p.logR[i], s);
+        s += p.logR[i];
+        std::swap(src, dst);
+    }
+    return src;
+}
+
+}  // namespace
+
+// ---- interface used by xcorr.hip / msd_fft.hip (declared in ctx.h) ------------------------------------------------
+
+// Half spectra X[b][0..L/2] of `batch` real series x[b][0..L-1], L a power of two >= 2.
+// d_real is overwritten (it is one of the two transform buffers); d_tmp holds batch * L/2 complex points.
+int mdhip_fft_r2c(mdhip_ctx *ctx, double *d_real, double2 *d_tmp, double2 *d_spec, long long L, int batch)
+{
+    MD_REQUIRE(L >= 2 && (L & (L - 1)) == 0, "transform length %lld is not a power of two", L);
+    const long long H = L / 2;
+    if (batch > FFT_MAX_BATCH) {  // grid.y
+        for (int b0 = 0; b0 < batch; b0 += FFT_MAX_BATCH) {
+            const int rc = mdhip_fft_r2c(ctx, d_real + (size_t)b0 * L, d_tmp + (size_t)b0 * H,
+                                         d_spec + (size_t)b0 * (H + 1), L, std::min(FFT_MAX_BATCH, batch - b0));
+            if (rc) return rc;
+        }
+        return MDHIP_OK;
+    }
+    double2 *Z = fft_forward(ctx, reinterpret_cast<double2 *>(d_real), d_tmp, H, batch, false, false);
+    hipLaunchKernelGGL(r2c_post_kernel, dim3((unsigned)((H / 2 + 1 + 255) / 256), (unsigned)batch), dim3(256), 0,
+                       ctx->stream, Z, d_spec, H);
+    MD_HIP(hipGetLastError());
+    return MDHIP_OK;
+}
+
+// Unnormalised inverse: c[b][t] = sum_{k=0}^{L-1} S[b][k] e^{+2 pi i k t/L} (S Hermitian, given for k = 0..L/2) into
+// d_real [batch][L]. d_spec is left as it is; d_tmp holds batch * L/2 complex points.
+int mdhip_fft_c2r(mdhip_ctx *ctx, const double2 *d_spec, double2 *d_tmp, double *d_real, long long L, int batch)
+{
+    MD_REQUIRE(L >= 2 && (L & (L - 1)) == 0, "transform length %lld is not a power of two", L);
+    const long long H = L / 2;
+    if (batch > FFT_MAX_BATCH) {  // grid.y
+        for (int b0 = 0; b0 < batch; b0 += FFT_MAX_BATCH) {
+            const int rc = mdhip_fft_c2r(ctx, d_spec + (size_t)b0 * (H + 1), d_tmp + (size_t)b0 * H,
+                                         d_real + (size_t)b0 * L, L, std::min(FFT_MAX_BATCH, batch - b0));
+            if (rc) return rc;
+        }
+        return MDHIP_OK;
+    }
+    const PassPlan p = plan_passes(H);
+    // the result must land in d_real: start in d_real for an even number of buffer hops, in d_tmp for an odd one
+    // (H = 1: one hop, the conjugating copy)
+    const int hops = p.n_pass == 0 ? 1 : p.n_pass;
+    double2 *real_c = reinterpret_cast<double2 *>(d_real);
+    double2 *first = hops % 2 == 0 ? real_c : d_tmp, *second = hops % 2 == 0 ? d_tmp : real_c;
+    hipLaunchKernelGGL(c2r_pre_kernel, dim3((unsigned)((H / 2 + 1 + 255) / 256), (unsigned)batch), dim3(256), 0,
+                       ctx->stream, d_spec, first, H);
+    // W = conj Y went in; y = conj FFT(W): conjugate on the way out. c[2j] = Re y[j], c[2j+1] = Im y[j]: the complex
+    // result read as reals IS the series.
+    double2 *res = fft_forward(ctx, first, second, H, batch, false, true);
+    MD_HIP(hipGetLastError());
+    if (res != real_c) return mdhip_fail(ctx, MDHIP_EHIP, "internal: inverse transform landed in the wrong buffer");
+    return MDHIP_OK;
+}

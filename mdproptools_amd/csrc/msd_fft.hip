@@ -6,23 +6,20 @@
 //   S2(k) = sum_t0 x(t0) x(t0+k)                          (inverse transform of the power spectrum)
 //
 // Both sums are linear in the series, so the power spectra of all series of one (axis, entity group) are
-// added BEFORE the inverse transform: one batched forward D2Z over every series, one column reduction of
+// added BEFORE the inverse transform: one batched forward real transform (fft_pow2.hip) over every series, one column reduction of
 // |X|^2, and a 3 x n_groups inverse transform. Every series is centred on its own mean first (the MSD does
 // not see a constant offset), which keeps S1 as small as the data allow: the result carries an absolute
 // rounding error of a few eps * log2(L) * S1(k) per lag, i.e. a relative error that grows with
 // <x^2> / MSD(k). The caller gets that bound back and (variant 3) falls back to the exact-difference kernel
 // when it exceeds its tolerance.
 //
-// Layout: r [F][3][E] as handed in (frame-major) -> padded series [batch][L] (L = smooth length >= F +
+// Layout: r [F][3][E] as handed in (frame-major) -> padded series [batch][L] (L = power of two >= F +
 // max_lag, zeros behind F) -> spectra [batch][L/2+1]. The series are processed in batches of <= ~4 GiB of
 // workspace. All reductions have a fixed order (no floating-point atomics): results are reproducible.
 #include <hip/hip_runtime.h>
-#include <hipfft/hipfft.h>
 
 #include <algorithm>
 #include <cmath>
-#include <map>
-#include <tuple>
 #include <vector>
 
 #include "ctx.h"
@@ -460,41 +457,12 @@ __global__ __launch_bounds__(256) void transpose_scale_kernel(const double *__re
     }
 }
 
-struct MsdPlans {
-    hipfftHandle h = 0;
-};
-std::map<std::tuple<mdhip_ctx *, long long, long long, int>, MsdPlans> g_msd_plans;
-
-int get_plan(mdhip_ctx *ctx, long long L, long long batch, bool forward, hipfftHandle &out)
+// transform length of the large-lag path: the next power of two (fft_pow2.hip)
+long long pow2_length(long long n)
 {
-    auto key = std::make_tuple(ctx, L, batch, forward ? 1 : 0);
-    auto it = g_msd_plans.find(key);
-    if (it != g_msd_plans.end()) {
-        out = it->second.h;
-        return MDHIP_OK;
-    }
-    MsdPlans p;
-    int len = (int)L;
-    const int K = len / 2 + 1;
-    hipfftResult rc = forward
-                          ? hipfftPlanMany(&p.h, 1, &len, nullptr, 1, len, nullptr, 1, K, HIPFFT_D2Z, (int)batch)
-                          : hipfftPlanMany(&p.h, 1, &len, nullptr, 1, K, nullptr, 1, len, HIPFFT_Z2D, (int)batch);
-    if (rc != HIPFFT_SUCCESS)
-        return mdhip_fail(ctx, MDHIP_EHIP, "hipfftPlanMany(%lld x %lld) failed (%d)", L, batch, (int)rc);
-    g_msd_plans[key] = p;
-    out = p.h;
-    return MDHIP_OK;
-}
-
-// smallest 2^a 3^b 5^c 7^d >= n
-long long smooth_length(long long n)
-{
-    for (long long m = std::max<long long>(n, 2);; ++m) {
-        long long q = m;
-        for (int p : {2, 3, 5, 7})
-            while (q % p == 0) q /= p;
-        if (q == 1) return m;
-    }
+    long long L = 2;
+    while (L < n) L <<= 1;
+    return L;
 }
 
 // host: prefix sums of Q, S1 - 2 S2, normalisation as lag_msd_finish_kernel; returns the error bound.
@@ -642,13 +610,13 @@ int mdhip_lag_msd_fft(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const dou
         if (m <= FT_MAX_M && ft_lds_bytes(m) <= ctx->lds_max)
             return lag_msd_fft_fused(ctx, F, E, d_r, scale, max_lag, G, group_off, m, out, rel_bound);
     }
-    const long long L = smooth_length(F + max_lag);
+    const long long L = pow2_length(F + max_lag);
     MD_REQUIRE(L < (1LL << 30), "series too long for the FFT path (%lld)", L);
     const long long K = L / 2 + 1;
     const long long S = 3 * G;  // (axis, group) segments
 
-    // batches of whole series: padded copy + spectrum <= ~4 GiB
-    const long long per_series = L * 8 + K * 16;
+    // batches of whole series: padded copy + second transform buffer + spectrum <= ~4 GiB
+    const long long per_series = 2 * L * 8 + K * 16;
     const long long nb_max = std::max<long long>(1, std::min<long long>((4LL << 30) / per_series, (1LL << 31) / K));
     const long long n_batches = (cols + nb_max - 1) / nb_max;
     const long long nb0 = (cols + n_batches - 1) / n_batches;
@@ -657,6 +625,7 @@ int mdhip_lag_msd_fft(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const dou
     double *d_msum = d_mean + cols;
     MD_WS(d_pad, double, WS_AUX1, (size_t)nb0 * L * 8);
     MD_WS(d_spec, double2, WS_AUX2, (size_t)nb0 * K * 16);
+    MD_WS(d_tmp, double2, WS_FFT_TMP, (size_t)std::max(nb0, S) * L * 8 + 64);
     // Q [S][F] | P [S][K] | complex P [S][K] | correlations [S][L] | group offsets
     const size_t q_b = (size_t)S * F * 8, p_b = (size_t)S * K * 8, z_b = (size_t)S * K * 16, c_b = (size_t)S * L * 8;
     MD_WS(d_small, unsigned char, WS_AUX3, q_b + p_b + z_b + c_b + (size_t)(G + 1) * 8 + 256);
@@ -682,15 +651,11 @@ int mdhip_lag_msd_fft(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const dou
 
     for (long long c_first = 0; c_first < cols; c_first += nb0) {
         const long long nb = std::min(nb0, cols - c_first);
-        hipfftHandle fwd;
-        int rc = get_plan(ctx, L, nb, true, fwd);
-        if (rc) return rc;
-        hipfftSetStream(fwd, ctx->stream);
         hipLaunchKernelGGL(transpose_pad_kernel, dim3((unsigned)((nb + 31) / 32), (unsigned)((L + 31) / 32)),
                            dim3(256), 0, ctx->stream, d_r, d_mean, F, cols, c_first, nb, L, scale, d_pad);
         MD_HIP(hipGetLastError());
-        if (hipfftExecD2Z(fwd, d_pad, reinterpret_cast<hipfftDoubleComplex *>(d_spec)) != HIPFFT_SUCCESS)
-            return mdhip_fail(ctx, MDHIP_EHIP, "hipfftExecD2Z failed");
+        int rc = mdhip_fft_r2c(ctx, d_pad, d_tmp, d_spec, L, (int)nb);
+        if (rc) return rc;
         // the (axis, group) segments this batch touches
         for (long long s = 0; s < S; ++s) {
             const long long a = s / G, g = s % G;
@@ -705,14 +670,10 @@ int mdhip_lag_msd_fft(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const dou
         }
         MD_HIP(hipGetLastError());
     }
-    hipfftHandle inv;
-    int rc = get_plan(ctx, L, S, false, inv);
-    if (rc) return rc;
-    hipfftSetStream(inv, ctx->stream);
     hipLaunchKernelGGL(real_to_complex_kernel, dim3((unsigned)((S * K + 255) / 256)), dim3(256), 0, ctx->stream, d_P,
                        S * K, d_Z);
-    if (hipfftExecZ2D(inv, reinterpret_cast<hipfftDoubleComplex *>(d_Z), d_corr) != HIPFFT_SUCCESS)
-        return mdhip_fail(ctx, MDHIP_EHIP, "hipfftExecZ2D failed");
+    int rc = mdhip_fft_c2r(ctx, d_Z, d_tmp, d_corr, L, (int)S);
+    if (rc) return rc;
     timer.stop();
     ctx->last_kernel = "lag_msd_fft";
 

@@ -4,9 +4,10 @@
 // (autocorrelate "wkt" and "brute_force") of the reference:
 //     c[k] = sum_{t=0}^{n-1-k} a[t+k] * b[t] / (n-k)
 //
-// MDHIP_XCORR_FFT: zero-pad to 2n, real-to-complex transforms, A*conj(B), inverse, first n lags,
-// unbiased 1/(n-k). The transforms are plain library FFTs (hipFFT/rocFFT); the pointwise kernels
-// are here. HBM-bound: 3 transforms of 2n points per series pair.
+// MDHIP_XCORR_FFT: zero-pad to a power of two >= 2n, real-to-complex transforms, A*conj(B), inverse, first n lags,
+// unbiased 1/(n-k). The transforms are the library's own (fft_pow2.hip: no run-time kernel compilation, so the
+// first call of a process costs what every call costs); the pointwise kernels are here. HBM-bound: 3 transforms
+// per series pair.
 //
 // MDHIP_XCORR_DIRECT: register-blocked direct lag sums, FP64-FMA bound (n^2/2 fused multiply-adds
 // per pair). A block owns a tile of 2048 consecutive lags (8 per lane) and streams time in chunks
@@ -15,11 +16,7 @@
 // of a wave read consecutive doubles (no bank conflicts). Lag tiles are paired (j, nT-1-j) so every
 // block has the same amount of work; time is split into slabs whose partial sums are added in a
 // fixed order by a second kernel (no float atomics).
-#include <hipfft/hipfft.h>
-
 #include <algorithm>
-#include <map>
-#include <tuple>
 
 #include "ctx.h"
 
@@ -57,15 +54,9 @@ __global__ void scale_unbiased_kernel(const double *__restrict__ c, double *__re
     out[p * n_lags + k] = (c[p * L + k] / (double)L) / (double)(n - k);
 }
 
-struct FftPlans {
-    hipfftHandle fwd = 0, inv = 0;
-};
-std::map<std::tuple<mdhip_ctx *, long long, int>, FftPlans> g_plans;
-
 // Transform length: the reference pads to 2n (conductivity.py:111, viscosity.py:112); any length >= 2n - 1 gives the
-// same linear correlation. rocFFT compiles its kernels at run time for every NEW length (1.4-1.8 s each, measured),
-// so the length is rounded up to a power of two: series of similar lengths share one plan, and a process pays for
-// at most ~20 distinct lengths instead of one per series length. The result moves by rounding only (tests: 1e-10 acf[0]).
+// same linear correlation: the next power of two, the lengths fft_pow2.hip transforms. Against the 2n-point transform
+// the result moves by rounding only (tests: 1e-10 acf[0]).
 long long fft_length(long long n)
 {
     long long L = 2;
@@ -73,56 +64,33 @@ long long fft_length(long long n)
     return L;
 }
 
-// batched L-point real transforms (one launch sequence for all series pairs of a chunk)
-int get_plans(mdhip_ctx *ctx, long long L, int batch, FftPlans &out)
-{
-    auto key = std::make_tuple(ctx, L, batch);
-    auto it = g_plans.find(key);
-    if (it != g_plans.end()) {
-        out = it->second;
-        return MDHIP_OK;
-    }
-    FftPlans p;
-    int len = (int)L;
-    if (hipfftPlanMany(&p.fwd, 1, &len, nullptr, 1, len, nullptr, 1, len / 2 + 1, HIPFFT_D2Z, batch) != HIPFFT_SUCCESS ||
-        hipfftPlanMany(&p.inv, 1, &len, nullptr, 1, len / 2 + 1, nullptr, 1, len, HIPFFT_Z2D, batch) != HIPFFT_SUCCESS)
-        return mdhip_fail(ctx, MDHIP_EHIP, "hipfftPlanMany(%lld x %d) failed", L, batch);
-    g_plans[key] = p;
-    out = p;
-    return MDHIP_OK;
-}
-
 int xcorr_fft(mdhip_ctx *ctx, long long n, int n_pairs, const double *d_a, const double *d_b,
               bool same, long long n_lags, double *d_out)
 {
     const long long L = fft_length(n);
     const long long m = L / 2 + 1;  // complex outputs of an L-point real transform
-    // series pairs per chunk: all of them while the padded copies stay below ~1 GiB
-    int chunk = (int)std::max<long long>(1, std::min<long long>(n_pairs, (1LL << 30) / (L * 8 * 3)));
+    // series pairs per chunk: all of them while the padded copies stay below ~1 GiB (and the batch fits grid.y)
+    int chunk = (int)std::max<long long>(1, std::min<long long>(std::min(n_pairs, 65535), (1LL << 30) / (L * 8 * 4)));
     MD_WS(d_pad, double, WS_AUX0, (size_t)chunk * L * 8 + 64);
     MD_WS(d_A, double2, WS_AUX1, (size_t)chunk * m * 16);
     MD_WS(d_B, double2, WS_AUX2, (size_t)(same ? 1 : chunk) * m * 16);
+    MD_WS(d_tmp, double2, WS_AUX3, (size_t)chunk * L * 8 + 64);
     for (int p0 = 0; p0 < n_pairs; p0 += chunk) {
         const int nb = std::min(chunk, n_pairs - p0);
-        FftPlans pl;
-        int rc = get_plans(ctx, L, nb, pl);
-        if (rc) return rc;
-        hipfftSetStream(pl.fwd, ctx->stream);
-        hipfftSetStream(pl.inv, ctx->stream);
         const dim3 gp((unsigned)((L + 255) / 256), (unsigned)nb), gm((unsigned)((m + 255) / 256), (unsigned)nb);
         hipLaunchKernelGGL(pad_kernel, gp, dim3(256), 0, ctx->stream, d_a + (size_t)p0 * n, d_pad, n, L);
-        if (hipfftExecD2Z(pl.fwd, d_pad, reinterpret_cast<hipfftDoubleComplex *>(d_A)) != HIPFFT_SUCCESS)
-            return mdhip_fail(ctx, MDHIP_EHIP, "hipfftExecD2Z failed");
+        int rc = mdhip_fft_r2c(ctx, d_pad, d_tmp, d_A, L, nb);
+        if (rc) return rc;
         const double2 *Bp = d_A;
         if (!same) {
             hipLaunchKernelGGL(pad_kernel, gp, dim3(256), 0, ctx->stream, d_b + (size_t)p0 * n, d_pad, n, L);
-            if (hipfftExecD2Z(pl.fwd, d_pad, reinterpret_cast<hipfftDoubleComplex *>(d_B)) != HIPFFT_SUCCESS)
-                return mdhip_fail(ctx, MDHIP_EHIP, "hipfftExecD2Z failed");
+            rc = mdhip_fft_r2c(ctx, d_pad, d_tmp, d_B, L, nb);
+            if (rc) return rc;
             Bp = d_B;
         }
         hipLaunchKernelGGL(mul_conj_kernel, gm, dim3(256), 0, ctx->stream, d_A, Bp, m);
-        if (hipfftExecZ2D(pl.inv, reinterpret_cast<hipfftDoubleComplex *>(d_A), d_pad) != HIPFFT_SUCCESS)
-            return mdhip_fail(ctx, MDHIP_EHIP, "hipfftExecZ2D failed");
+        rc = mdhip_fft_c2r(ctx, d_A, d_tmp, d_pad, L, nb);
+        if (rc) return rc;
         hipLaunchKernelGGL(scale_unbiased_kernel, dim3((unsigned)((n_lags + 255) / 256), (unsigned)nb), dim3(256), 0,
                            ctx->stream, d_pad, d_out + (size_t)p0 * n_lags, n, L, n_lags);
         MD_HIP(hipGetLastError());
@@ -287,7 +255,7 @@ int mdhip_xcorr_lags(mdhip_ctx *ctx, int64_t n, int n_pairs, const double *a, co
     const size_t out_b = (size_t)n_pairs * n_lags * 8;
     MD_WS(d_out, double, WS_OUT, out_b);
     KernelTimer timer(ctx, n_pairs);
-    ctx->last_kernel = method == MDHIP_XCORR_FFT ? "hipfft D2Z/Z2D + pad/mul_conj/scale kernels" : "xcorr_direct_kernel";
+    ctx->last_kernel = method == MDHIP_XCORR_FFT ? "fft_pass_kernel<false, false>" : "xcorr_direct_kernel";
     rc = method == MDHIP_XCORR_FFT ? xcorr_fft(ctx, n, n_pairs, d_a, d_b, same, n_lags, d_out)
                                    : xcorr_direct(ctx, n, n_pairs, d_a, d_b, lag_begin, n_lags, d_out);
     timer.stop();

@@ -373,7 +373,7 @@ def test_lag_msd_fft_variant(B):
             ctx.set_option("lag_variant", 1)
             exact = B.lag_msd(r, max_lag, goff, scale=0.5)
             assert ctx.last_rel_bound() == 0.0
-            for variant in (2, 4):   # fused LDS transform / hipFFT batches
+            for variant in (2, 4):   # fused LDS transform / batched global transforms (fft_pow2.hip)
                 ctx.set_option("lag_variant", variant)
                 fft = B.lag_msd(r, max_lag, goff, scale=0.5)
                 bound = ctx.last_rel_bound()
@@ -438,9 +438,8 @@ def test_xcorr_direct_sizes_vs_oracle(B, n):
     out = B.xcorr(a, b, method=B.XCORR_DIRECT)
     expect = C.xcorr_direct(a, b)
     np.testing.assert_allclose(out, expect, rtol=0, atol=1e-12 * max(1.0, abs(expect).max()) * np.sqrt(n))
-    if n >= 2:
-        f = B.xcorr(a, b, method=B.XCORR_FFT)
-        np.testing.assert_allclose(f, expect, rtol=0, atol=1e-11 * max(1.0, abs(expect).max()) * np.sqrt(n))
+    f = B.xcorr(a, b, method=B.XCORR_FFT)
+    np.testing.assert_allclose(f, expect, rtol=0, atol=1e-11 * max(1.0, abs(expect).max()) * np.sqrt(n))
     half = B.xcorr(a, b, method=B.XCORR_DIRECT, n_lags=max(1, n // 2))
     np.testing.assert_allclose(half, expect[: max(1, n // 2)], rtol=0, atol=1e-12 * max(1.0, abs(expect).max()) * np.sqrt(n))
 
@@ -1143,6 +1142,34 @@ def test_c4_msd_properties(B):
     out = B.lag_msd(traj, 299, [0, 2000])
     expect = (v ** 2).sum(axis=0).mean() * np.arange(300) ** 2
     np.testing.assert_allclose(out[:, 0, 3], expect, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 16, 17, 255, 256, 257, 4096, 4097, 40_000, 70_000, 1_100_000])
+def test_xcorr_fft_all_pass_plans(B, n):
+    """The library's own power-of-two transforms (csrc/fft_pow2.hip) behind MDHIP_XCORR_FFT: every shape of the pass
+    plan (no pass at H = 1, one short pass, tiles narrower than 16 columns, two, three passes, radices 2..256),
+    cross- and auto-correlation, batches, against numpy's FFT of the same zero-padded series. The sums
+    c[k] (n - k) are compared with 1e-13 |a| |b| (their Cauchy-Schwarz bound), i.e. rounding level at every lag."""
+    rng = np.random.default_rng(n)
+    nb = 3 if n <= 70_000 else 1
+    a = rng.standard_normal((nb, n)) * np.array([1.0, 1e3, 1e-4])[:nb, None]
+    b = rng.standard_normal((nb, n)) + 0.5
+    L = 2
+    while L < 2 * n:
+        L *= 2
+    w = n - np.arange(n)
+
+    def ref(x, y):
+        return np.fft.irfft(np.fft.rfft(x, L) * np.conj(np.fft.rfft(y, L)), L)[..., :n]
+
+    got = B.xcorr(a, b, method=B.XCORR_FFT)
+    scale = np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1)
+    assert (np.abs(got * w - ref(a, b)).max(axis=1) <= 1e-13 * scale).all()
+    auto = B.xcorr(a, method=B.XCORR_FFT)
+    assert (np.abs(auto * w - ref(a, a)).max(axis=1) <= 1e-13 * np.linalg.norm(a, axis=1) ** 2).all()
+    np.testing.assert_allclose(auto[:, 0], (a * a).mean(axis=1), rtol=1e-12)
+    few = B.xcorr(a, b, method=B.XCORR_FFT, n_lags=max(1, n // 3))
+    np.testing.assert_array_equal(few, got[:, :max(1, n // 3)])
 
 
 def test_c5_acf_properties(B):
