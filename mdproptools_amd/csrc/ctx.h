@@ -101,6 +101,8 @@ struct mdhip_ctx {
                               // per launch (0 = the real bound, 2^32 / (64 * 256) with margin; tests lower it)
     int opt_seg_cap = 0;      // segment kernels: atoms per block stage, 1024 (default), 512, or 256 = one wave per block (A/B)
     int opt_seg_vec = 1;      // segment kernels: 16-byte loads when alignment allows (default), 0 = 8-byte loads (A/B)
+    int opt_fft_logr = 8;     // fft_pow2.hip: largest radix of a pass (log2, 4..10)
+    int opt_fft_logc = 3;     // fft_pow2.hip: columns per tile (log2); 8 columns = 128-byte runs measured best (tools/ab_fft.py)
     int opt_seg_gy = 0;       // segment kernels: frame slices per block run (0 = auto)
     int opt_xcorr_tile = 0;
     int opt_lag_variant = 3;  // full-lag MSD: 3 (default) = autocorrelation theorem (msd_fft.hip) when its error bound
@@ -116,6 +118,9 @@ int mdhip_fail(mdhip_ctx *ctx, int code, const char *fmt, ...);
 // complex points; r2c overwrites its input, c2r is the unnormalised inverse
 int mdhip_fft_r2c(mdhip_ctx *ctx, double *d_real, double2 *d_tmp, double2 *d_spec, long long L, int batch);
 int mdhip_fft_c2r(mdhip_ctx *ctx, const double2 *d_spec, double2 *d_tmp, double *d_real, long long L, int batch);
+// the fused FFT estimator of xcorr.hip: series in, scaled lags out; buf0..3 hold batch * L/2 complex points each
+int mdhip_fft_xcorr(mdhip_ctx *ctx, const double *d_a, const double *d_b, long long n, long long L, int batch,
+                    double2 *buf0, double2 *buf1, double2 *buf2, double2 *buf3, long long n_lags, double *d_lags);
 
 int mdhip_lag_msd_fft(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *d_r, double scale,
                       int max_lag, int n_groups, const int64_t *group_off, double *out, double *rel_bound);

@@ -11,7 +11,7 @@
 //                      X(k) = E(k) + e^{-2 pi i k/L} O(k), E/O from Z(k) and conj Z(H-k)       (r2c_post_kernel)
 //   spectrum -> real   Y(k) = [S(k) + conj S(H-k)] + i e^{+2 pi i k/L} [S(k) - conj S(H-k)];     (c2r_pre_kernel)
 //                      y = IFFT_H(Y) = conj FFT_H(conj Y); c[2j] = Re y[j], c[2j+1] = Im y[j]  (unnormalised)
-//   FFT_H              Stockham autosort, decimation in frequency, 1-4 passes of radix R = 2^1..2^8:
+//   FFT_H              Stockham autosort, decimation in frequency, passes of radix R = 2^1..2^8 (option fft_logr):
 //                      pass (n, s) with n*s = H reads column c of the [R][H/R] view of its input, does the R-point
 //                      DFT, multiplies output j by e^{-2 pi i j p/n} (p = c div s) and stores it at
 //                      (c mod s) + s*(R*p + j); then n /= R, s *= R. Natural order in, natural order out.
@@ -50,11 +50,23 @@ __device__ __forceinline__ double2 root_of_unity(long long num, long long den)
 
 __device__ __forceinline__ unsigned bit_reverse(unsigned r, int bits) { return bits ? __brev(r) >> (32 - bits) : 0u; }
 
-// grid (H/R/C tiles, batch). in/out [batch][H]. CONJ_IN: conjugate every point on load; CONJ_OUT: on store.
-template <bool CONJ_IN, bool CONJ_OUT>
+enum { IN_PLAIN = 0, IN_PAD = 1 };
+enum { OUT_PLAIN = 0, OUT_CONJ = 1, OUT_LAGS = 2 };
+
+// what the first / last pass of the fused correlation pipeline reads / writes instead of a complex buffer
+struct PassIo {
+    const double *series;  // IN_PAD: [batch][n] real samples; the transform input is the zero-padded series read
+    long long n;           //         as complex pairs (x[2e], x[2e+1])
+    double *lags;          // OUT_LAGS: [batch][n_lags]; the complex result y = conj(v) holds c[2o] = Re, c[2o+1] = Im,
+    long long n_lags;      //           lags[t] = (c[t] / L) / (n - t) for t < n_lags
+    double L;
+};
+
+// grid (H/R/C tiles, batch). in/out [batch][H].
+template <int IN, int OUT>
 __global__ __launch_bounds__(FFT_THREADS) void fft_pass_kernel(const double2 *__restrict__ in,
                                                                double2 *__restrict__ out, long long H, int logR,
-                                                               int logC, int logS, long long n)
+                                                               int logC, int logS, long long n, PassIo io)
 {
     const long long s = 1LL << logS;
     extern __shared__ double2 lds[];
@@ -63,13 +75,24 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass_kernel(const double2 *__
     double2 *tw = lds + (R << logC);  // [R/2]
     const long long cols = H >> logR;
     const long long c0 = (long long)blockIdx.x << logC;
-    in += (size_t)blockIdx.y * H;
-    out += (size_t)blockIdx.y * H;
-    for (int idx = threadIdx.x; idx < (R << logC); idx += FFT_THREADS) {
-        const int k = idx >> logC, cc = idx & (C - 1);
-        double2 v = in[c0 + cc + (long long)k * cols];
-        if (CONJ_IN) v.y = -v.y;
-        buf[idx] = v;
+    if (IN == IN_PAD) {
+        const double *x = io.series + (size_t)blockIdx.y * io.n;
+        for (int idx = threadIdx.x; idx < (R << logC); idx += FFT_THREADS) {
+            const int k = idx >> logC, cc = idx & (C - 1);
+            const long long e = 2 * (c0 + cc + (long long)k * cols);
+            double2 v = make_double2(0.0, 0.0);
+            if (e < io.n) {  // (rows k >= R/2 lie in the zero padding: L >= 2n)
+                v.x = x[e];
+                if (e + 1 < io.n) v.y = x[e + 1];
+            }
+            buf[idx] = v;
+        }
+    } else {
+        in += (size_t)blockIdx.y * H;
+        for (int idx = threadIdx.x; idx < (R << logC); idx += FFT_THREADS) {
+            const int k = idx >> logC, cc = idx & (C - 1);
+            buf[idx] = in[c0 + cc + (long long)k * cols];
+        }
     }
     for (int t = threadIdx.x; t < (R >> 1); t += FFT_THREADS) tw[t] = root_of_unity(t, R);
     __syncthreads();
@@ -91,6 +114,8 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass_kernel(const double2 *__
     // store order: columns fastest when a tile's columns share their p (s >= C: runs of C points), output index
     // fastest otherwise (first pass, s = 1: the tile's outputs are one contiguous block of R*C points)
     const bool col_fast = s >= C;
+    out += (size_t)blockIdx.y * H;
+    double *lags = OUT == OUT_LAGS ? io.lags + (size_t)blockIdx.y * io.n_lags : nullptr;
     for (int idx = threadIdx.x; idx < (R << logC); idx += FFT_THREADS) {
         int cc, j;
         if (col_fast) {
@@ -105,8 +130,15 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass_kernel(const double2 *__
         const long long c = c0 + cc;
         const long long p = c >> logS, q = c & (s - 1);
         if (!last && j != 0 && p != 0) v = cmul(v, root_of_unity((long long)j * p, n));
-        if (CONJ_OUT) v.y = -v.y;
-        out[q + s * (((long long)p << logR) + j)] = v;
+        const long long o = q + s * (((long long)p << logR) + j);
+        if (OUT == OUT_LAGS) {
+            const long long t = 2 * o;
+            if (t < io.n_lags) lags[t] = (v.x / io.L) / (double)(io.n - t);
+            if (t + 1 < io.n_lags) lags[t + 1] = (-v.y / io.L) / (double)(io.n - t - 1);
+        } else {
+            if (OUT == OUT_CONJ) v.y = -v.y;
+            out[o] = v;
+        }
     }
 }
 
@@ -150,6 +182,45 @@ __global__ void c2r_pre_kernel(const double2 *__restrict__ S, double2 *__restric
     }
 }
 
+// The correlation pipeline's one pointwise step, in place: Za, Zb = FFT_H of the two zero-padded series read as
+// complex pairs  ->  half spectra A, B (as r2c_post_kernel)  ->  S = A conj(B)  ->  W = conj Y (as c2r_pre_kernel),
+// written over Za (thread k owns the points k and H-k of both inputs and of the output). SAME: Zb is Za.
+template <bool SAME>
+__global__ void xcorr_spectrum_kernel(double2 *__restrict__ Za, const double2 *__restrict__ Zb, long long H)
+{
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > H / 2) return;
+    Za += (size_t)blockIdx.y * H;
+    Zb += (size_t)blockIdx.y * H;
+    const long long kk = (H - k) & (H - 1);
+    const double2 w = root_of_unity(k, 2 * H);  // e^{-2 pi i k/L}
+    auto half_spectrum = [&](const double2 zk, const double2 zh, double2 &xk, double2 &xh) {
+        const double2 E = make_double2(0.5 * (zk.x + zh.x), 0.5 * (zk.y - zh.y));
+        const double2 O = make_double2(0.5 * (zk.y + zh.y), -0.5 * (zk.x - zh.x));
+        const double2 wo = cmul(w, O);
+        xk = make_double2(E.x + wo.x, E.y + wo.y);     // X(k)
+        xh = make_double2(E.x - wo.x, -(E.y - wo.y));  // X(H-k)
+    };
+    double2 ak, ah, bk, bh;
+    half_spectrum(Za[k], Za[kk], ak, ah);
+    if (SAME) {
+        bk = ak;
+        bh = ah;
+    } else {
+        half_spectrum(Zb[k], Zb[kk], bk, bh);
+    }
+    const double2 sk = make_double2(ak.x * bk.x + ak.y * bk.y, ak.y * bk.x - ak.x * bk.y);  // A conj(B), as mul_conj
+    const double2 sh = make_double2(ah.x * bh.x + ah.y * bh.y, ah.y * bh.x - ah.x * bh.y);
+    const double2 se = make_double2(sk.x + sh.x, sk.y - sh.y);
+    const double2 sd = make_double2(sk.x - sh.x, sk.y + sh.y);
+    const double2 t = cmul(make_double2(w.x, -w.y), sd);
+    Za[k] = make_double2(se.x - t.y, -(se.y + t.x));
+    if (k != 0 && 2 * k != H) {
+        const double2 u = cmul(w, make_double2(sd.x, -sd.y));
+        Za[kk] = make_double2(se.x - u.y, -(-se.y + u.x));
+    }
+}
+
 __global__ void conj_copy_kernel(const double2 *__restrict__ in, double2 *__restrict__ out, long long count)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -158,15 +229,16 @@ __global__ void conj_copy_kernel(const double2 *__restrict__ in, double2 *__rest
 
 struct PassPlan {
     int n_pass = 0;
-    int logR[4] = {0, 0, 0, 0};
+    int logR[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
-PassPlan plan_passes(long long H)
+PassPlan plan_passes(const mdhip_ctx *ctx, long long H)
 {
     int logH = 0;
     while ((1LL << logH) < H) ++logH;
+    const int max_logr = std::min(std::max(ctx->opt_fft_logr, 4), 10);
     PassPlan p;
-    p.n_pass = (logH + FFT_MAX_LOGR - 1) / FFT_MAX_LOGR;
+    p.n_pass = (logH + max_logr - 1) / max_logr;
     for (int i = 0, left = logH; i < p.n_pass; ++i) {
         p.logR[i] = (left + (p.n_pass - i) - 1) / (p.n_pass - i);  // as even as possible, larger radices first
         left -= p.logR[i];
@@ -174,39 +246,44 @@ PassPlan plan_passes(long long H)
     return p;
 }
 
-template <bool CI, bool CO>
-void launch_pass(mdhip_ctx *ctx, const double2 *in, double2 *out, long long H, int batch, int logR, int logS)
+template <int IN, int OUT>
+void launch_pass(mdhip_ctx *ctx, const double2 *in, double2 *out, long long H, int batch, int logR, int logS,
+                 const PassIo &io)
 {
     const long long cols = H >> logR;
-    int logC = FFT_LOGC;
+    // 16 columns per tile (256-byte runs) while the tile fits 64 KB of LDS, fewer for the larger radices
+    int logC = std::min(std::max(ctx->opt_fft_logc, 0), 6);
+    while (logC > 0 && ((size_t)16 << logR << logC) > (size_t)128 * 1024) --logC;
     while ((1LL << logC) > cols) --logC;
     const size_t lds = ((size_t)(1 << logR << logC) + (size_t)(1 << logR >> 1)) * sizeof(double2);
     const dim3 grid((unsigned)(cols >> logC), (unsigned)batch);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fft_pass_kernel<CI, CO>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fft_pass_kernel<IN, OUT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((fft_pass_kernel<CI, CO>), grid, dim3(FFT_THREADS), lds, ctx->stream, in, out, H, logR, logC,
-                       logS, H >> logS);
+    hipLaunchKernelGGL((fft_pass_kernel<IN, OUT>), grid, dim3(FFT_THREADS), lds, ctx->stream, in, out, H, logR, logC,
+                       logS, H >> logS, io);
 }
 
-// FFT_H of `batch` series, conj on the way in and/or out. The passes alternate between the two buffers; returns the
-// buffer that holds the result (x after an even number of passes, y after an odd one). x is overwritten.
-double2 *fft_forward(mdhip_ctx *ctx, double2 *x, double2 *y, long long H, int batch, bool conj_in, bool conj_out)
+// FFT_H of `batch` series. The passes alternate between the two buffers; returns the buffer that holds the result
+// (x after an even number of passes, y after an odd one). x is overwritten. in_mode IN_PAD: the first pass reads
+// io.series instead of x; out_mode OUT_LAGS: the last pass writes io.lags instead of a buffer.
+double2 *fft_forward(mdhip_ctx *ctx, double2 *x, double2 *y, long long H, int batch, int in_mode, int out_mode,
+                     const PassIo &io)
 {
-    const PassPlan p = plan_passes(H);
-    if (p.n_pass == 0) {  // H = 1: the transform is the identity
-        if (conj_in != conj_out)
+    const PassPlan p = plan_passes(ctx, H);
+    if (p.n_pass == 0) {  // H = 1: the transform is the identity (plain buffers only)
+        if (out_mode == OUT_CONJ)
             hipLaunchKernelGGL(conj_copy_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, ctx->stream, x, y,
                                (long long)batch);
-        return conj_in != conj_out ? y : x;
+        return out_mode == OUT_CONJ ? y : x;
     }
     double2 *src = x, *dst = y;
     int s = 0;  // log2 of the product of the radices done
     for (int i = 0; i < p.n_pass; ++i) {
-        const bool ci = conj_in && i == 0, co = conj_out && i == p.n_pass - 1;
-        if (ci && co) launch_pass<true, true>(ctx, src, dst, H, batch, p.logR[i], s);
-        else if (ci) launch_pass<true, false>(ctx, src, dst, H, batch, p.logR[i], s);
-        else if (co) launch_pass<false, true>(ctx, src, dst, H, batch, p.logR[i], s);
-        else launch_pass<false, false>(ctx, src, dst, H, batch, p.logR[i], s);
+        const int im = i == 0 ? in_mode : IN_PLAIN, om = i == p.n_pass - 1 ? out_mode : OUT_PLAIN;
+        if (im == IN_PAD && om == OUT_PLAIN) launch_pass<IN_PAD, OUT_PLAIN>(ctx, src, dst, H, batch, p.logR[i], s, io);
+        else if (im == IN_PLAIN && om == OUT_LAGS) launch_pass<IN_PLAIN, OUT_LAGS>(ctx, src, dst, H, batch, p.logR[i], s, io);
+        else if (im == IN_PLAIN && om == OUT_CONJ) launch_pass<IN_PLAIN, OUT_CONJ>(ctx, src, dst, H, batch, p.logR[i], s, io);
+        else launch_pass<IN_PLAIN, OUT_PLAIN>(ctx, src, dst, H, batch, p.logR[i], s, io);
         s += p.logR[i];
         std::swap(src, dst);
     }
@@ -231,7 +308,7 @@ int mdhip_fft_r2c(mdhip_ctx *ctx, double *d_real, double2 *d_tmp, double2 *d_spe
         }
         return MDHIP_OK;
     }
-    double2 *Z = fft_forward(ctx, reinterpret_cast<double2 *>(d_real), d_tmp, H, batch, false, false);
+    double2 *Z = fft_forward(ctx, reinterpret_cast<double2 *>(d_real), d_tmp, H, batch, IN_PLAIN, OUT_PLAIN, PassIo{});
     hipLaunchKernelGGL(r2c_post_kernel, dim3((unsigned)((H / 2 + 1 + 255) / 256), (unsigned)batch), dim3(256), 0,
                        ctx->stream, Z, d_spec, H);
     MD_HIP(hipGetLastError());
@@ -252,7 +329,7 @@ int mdhip_fft_c2r(mdhip_ctx *ctx, const double2 *d_spec, double2 *d_tmp, double 
         }
         return MDHIP_OK;
     }
-    const PassPlan p = plan_passes(H);
+    const PassPlan p = plan_passes(ctx, H);
     // the result must land in d_real: start in d_real for an even number of buffer hops, in d_tmp for an odd one
     // (H = 1: one hop, the conjugating copy)
     const int hops = p.n_pass == 0 ? 1 : p.n_pass;
@@ -262,8 +339,42 @@ int mdhip_fft_c2r(mdhip_ctx *ctx, const double2 *d_spec, double2 *d_tmp, double 
                        ctx->stream, d_spec, first, H);
     // W = conj Y went in; y = conj FFT(W): conjugate on the way out. c[2j] = Re y[j], c[2j+1] = Im y[j]: the complex
     // result read as reals IS the series.
-    double2 *res = fft_forward(ctx, first, second, H, batch, false, true);
+    double2 *res = fft_forward(ctx, first, second, H, batch, IN_PLAIN, OUT_CONJ, PassIo{});
     MD_HIP(hipGetLastError());
     if (res != real_c) return mdhip_fail(ctx, MDHIP_EHIP, "internal: inverse transform landed in the wrong buffer");
+    return MDHIP_OK;
+}
+
+// The whole FFT estimator of `batch` series pairs (xcorr.hip): lags[b][t] = sum_u a[b][u+t] b[b][u] / (n - t),
+// t < n_lags, through L-point transforms (L a power of two >= 2n, n >= 2). Five kinds of launches: the forward passes
+// of a (the first reads the series and pads on the fly), the same for b unless d_b == d_a, one pointwise kernel
+// (half spectra, product, inverse-transform input), the inverse passes (the last writes the scaled lags).
+// buf0..buf3 hold batch * L/2 complex points each (buf2, buf3 unused for an autocorrelation).
+int mdhip_fft_xcorr(mdhip_ctx *ctx, const double *d_a, const double *d_b, long long n, long long L, int batch,
+                    double2 *buf0, double2 *buf1, double2 *buf2, double2 *buf3, long long n_lags, double *d_lags)
+{
+    MD_REQUIRE(L >= 4 && (L & (L - 1)) == 0 && L >= 2 * n, "bad transform length %lld for %lld samples", L, n);
+    MD_REQUIRE(batch <= 65535, "more than 65535 series per launch");
+    const long long H = L / 2;
+    PassIo io{};
+    io.n = n;
+    io.series = d_a;
+    double2 *Za = fft_forward(ctx, buf0, buf1, H, batch, IN_PAD, OUT_PLAIN, io);
+    double2 *Zb = Za;
+    const bool same = d_a == d_b;
+    if (!same) {
+        io.series = d_b;
+        Zb = fft_forward(ctx, buf2, buf3, H, batch, IN_PAD, OUT_PLAIN, io);
+    }
+    const dim3 grid((unsigned)((H / 2 + 1 + 255) / 256), (unsigned)batch);
+    if (same)
+        hipLaunchKernelGGL(xcorr_spectrum_kernel<true>, grid, dim3(256), 0, ctx->stream, Za, Zb, H);
+    else
+        hipLaunchKernelGGL(xcorr_spectrum_kernel<false>, grid, dim3(256), 0, ctx->stream, Za, Zb, H);
+    io.lags = d_lags;
+    io.n_lags = n_lags;
+    io.L = (double)L;
+    (void)fft_forward(ctx, Za, Za == buf0 ? buf1 : buf0, H, batch, IN_PLAIN, OUT_LAGS, io);
+    MD_HIP(hipGetLastError());
     return MDHIP_OK;
 }

@@ -226,6 +226,10 @@ int mdhip_set_option(mdhip_ctx *ctx, const char *key, int value)
         ctx->opt_seg_cap = value;
     else if (!strcmp(key, "seg_vec"))
         ctx->opt_seg_vec = value;
+    else if (!strcmp(key, "fft_logr"))
+        ctx->opt_fft_logr = value;
+    else if (!strcmp(key, "fft_logc"))
+        ctx->opt_fft_logc = value;
     else if (!strcmp(key, "seg_gy"))
         ctx->opt_seg_gy = value;
     else if (!strcmp(key, "cn_pk"))

@@ -6,8 +6,8 @@
 //
 // MDHIP_XCORR_FFT: zero-pad to a power of two >= 2n, real-to-complex transforms, A*conj(B), inverse, first n lags,
 // unbiased 1/(n-k). The transforms are the library's own (fft_pow2.hip: no run-time kernel compilation, so the
-// first call of a process costs what every call costs); the pointwise kernels are here. HBM-bound: 3 transforms
-// per series pair.
+// first call of a process costs what every call costs), with the padding, the spectrum product and the 1/(n-k)
+// scaling fused into their first / pointwise / last kernels (mdhip_fft_xcorr). HBM-bound.
 //
 // MDHIP_XCORR_DIRECT: register-blocked direct lag sums, FP64-FMA bound (n^2/2 fused multiply-adds
 // per pair). A block owns a tile of 2048 consecutive lags (8 per lane) and streams time in chunks
@@ -26,34 +26,6 @@ namespace {
 // FFT path
 // ---------------------------------------------------------------------------------------------
 
-// dst[p][i] = i < n ? src[p][i] : 0 for the L-point padded copies of `batch` series (grid.y = batch), L >= 2n
-__global__ void pad_kernel(const double *__restrict__ src, double *__restrict__ dst, long long n, long long L)
-{
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long p = blockIdx.y;
-    if (i < L) dst[p * L + i] = i < n ? src[p * n + i] : 0.0;
-}
-
-// A <- A * conj(B), m complex values per series
-__global__ void mul_conj_kernel(double2 *__restrict__ A, const double2 *__restrict__ B, long long m)
-{
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    const size_t k = (size_t)blockIdx.y * m + i;
-    const double2 a = A[k], b = B[k];
-    A[k] = make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
-}
-
-// out[p][k] = c[p][k] / L / (n-k): the inverse transform's normalisation, then conductivity.py:113 / viscosity.py:114
-__global__ void scale_unbiased_kernel(const double *__restrict__ c, double *__restrict__ out,
-                                      long long n, long long L, long long n_lags)
-{
-    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_lags) return;
-    const long long p = blockIdx.y;
-    out[p * n_lags + k] = (c[p * L + k] / (double)L) / (double)(n - k);
-}
-
 // Transform length: the reference pads to 2n (conductivity.py:111, viscosity.py:112); any length >= 2n - 1 gives the
 // same linear correlation: the next power of two, the lengths fft_pow2.hip transforms. Against the 2n-point transform
 // the result moves by rounding only (tests: 1e-10 acf[0]).
@@ -68,32 +40,20 @@ int xcorr_fft(mdhip_ctx *ctx, long long n, int n_pairs, const double *d_a, const
               bool same, long long n_lags, double *d_out)
 {
     const long long L = fft_length(n);
-    const long long m = L / 2 + 1;  // complex outputs of an L-point real transform
-    // series pairs per chunk: all of them while the padded copies stay below ~1 GiB (and the batch fits grid.y)
+    const long long H = L / 2;
+    // series pairs per chunk: all of them while the four transform buffers stay below ~1 GiB (and fit grid.y)
     int chunk = (int)std::max<long long>(1, std::min<long long>(std::min(n_pairs, 65535), (1LL << 30) / (L * 8 * 4)));
-    MD_WS(d_pad, double, WS_AUX0, (size_t)chunk * L * 8 + 64);
-    MD_WS(d_A, double2, WS_AUX1, (size_t)chunk * m * 16);
-    MD_WS(d_B, double2, WS_AUX2, (size_t)(same ? 1 : chunk) * m * 16);
-    MD_WS(d_tmp, double2, WS_AUX3, (size_t)chunk * L * 8 + 64);
+    const size_t buf_b = (size_t)chunk * H * 16 + 64;
+    MD_WS(buf0, double2, WS_AUX0, buf_b);
+    MD_WS(buf1, double2, WS_AUX1, buf_b);
+    MD_WS(buf2, double2, WS_AUX2, same ? 64 : buf_b);
+    MD_WS(buf3, double2, WS_AUX3, same ? 64 : buf_b);
     for (int p0 = 0; p0 < n_pairs; p0 += chunk) {
         const int nb = std::min(chunk, n_pairs - p0);
-        const dim3 gp((unsigned)((L + 255) / 256), (unsigned)nb), gm((unsigned)((m + 255) / 256), (unsigned)nb);
-        hipLaunchKernelGGL(pad_kernel, gp, dim3(256), 0, ctx->stream, d_a + (size_t)p0 * n, d_pad, n, L);
-        int rc = mdhip_fft_r2c(ctx, d_pad, d_tmp, d_A, L, nb);
+        const double *pa = d_a + (size_t)p0 * n;
+        const int rc = mdhip_fft_xcorr(ctx, pa, same ? pa : d_b + (size_t)p0 * n, n, L, nb, buf0, buf1, buf2, buf3,
+                                       n_lags, d_out + (size_t)p0 * n_lags);
         if (rc) return rc;
-        const double2 *Bp = d_A;
-        if (!same) {
-            hipLaunchKernelGGL(pad_kernel, gp, dim3(256), 0, ctx->stream, d_b + (size_t)p0 * n, d_pad, n, L);
-            rc = mdhip_fft_r2c(ctx, d_pad, d_tmp, d_B, L, nb);
-            if (rc) return rc;
-            Bp = d_B;
-        }
-        hipLaunchKernelGGL(mul_conj_kernel, gm, dim3(256), 0, ctx->stream, d_A, Bp, m);
-        rc = mdhip_fft_c2r(ctx, d_A, d_tmp, d_pad, L, nb);
-        if (rc) return rc;
-        hipLaunchKernelGGL(scale_unbiased_kernel, dim3((unsigned)((n_lags + 255) / 256), (unsigned)nb), dim3(256), 0,
-                           ctx->stream, d_pad, d_out + (size_t)p0 * n_lags, n, L, n_lags);
-        MD_HIP(hipGetLastError());
     }
     return MDHIP_OK;
 }
@@ -255,7 +215,8 @@ int mdhip_xcorr_lags(mdhip_ctx *ctx, int64_t n, int n_pairs, const double *a, co
     const size_t out_b = (size_t)n_pairs * n_lags * 8;
     MD_WS(d_out, double, WS_OUT, out_b);
     KernelTimer timer(ctx, n_pairs);
-    ctx->last_kernel = method == MDHIP_XCORR_FFT ? "fft_pass_kernel<false, false>" : "xcorr_direct_kernel";
+    if (method == MDHIP_XCORR_FFT && n == 1) method = MDHIP_XCORR_DIRECT;  // one sample: the product itself
+    ctx->last_kernel = method == MDHIP_XCORR_FFT ? "fft_pass_kernel<0, 0>" : "xcorr_direct_kernel";
     rc = method == MDHIP_XCORR_FFT ? xcorr_fft(ctx, n, n_pairs, d_a, d_b, same, n_lags, d_out)
                                    : xcorr_direct(ctx, n, n_pairs, d_a, d_b, lag_begin, n_lags, d_out);
     timer.stop();

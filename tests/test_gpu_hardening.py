@@ -220,7 +220,9 @@ def test_overflow_guard_splits_the_batch(B):
             break
         np.testing.assert_array_equal(a[0], ref[0])
         np.testing.assert_array_equal(a[1], ref[1])
-        if ctx.last_kernel_ms()[1] > 1:
+        if ctx.last_kernel_ms()[1] > 1 and split_at is None:
+            # the LARGEST threshold that splits: the blocks' tile counts vary from run to run with the work queue, so
+            # the calls below need the margin the smaller thresholds do not have
             split_at = guard
     assert split_at is not None, "no threshold made the host split the batch"
     # per-frame output: a frame's blocks share its items, so a block sweeps more tiles than in the persistent grid —
