@@ -11,8 +11,9 @@
 //
 // MDHIP_XCORR_DIRECT: register-blocked direct lag sums, FP64-FMA bound (n^2/2 fused multiply-adds
 // per pair). A block owns a tile of 2048 consecutive lags (8 per lane) and streams time in chunks
-// staged through LDS; a lane keeps a 16-deep sliding window of `a` in registers so that 8 LDS reads
-// feed 64 FMAs, while b[t] (the same for every lane) arrives through scalar loads as an SGPR operand. The a-window is stored transposed in LDS ([i mod 8][i div 8]) so that the 64 lanes
+// staged through LDS; a lane keeps three groups of 8 window entries in registers so that 8 LDS reads feed 64 FMAs, every
+// read issued a whole group before its first use, while b[t] (the same for every lane) arrives through scalar loads,
+// also a group ahead, as the SGPR operand of the FMA. The a-window is stored transposed in LDS ([i mod 8][i div 8]) so that the 64 lanes
 // of a wave read consecutive doubles (no bank conflicts). Lag tiles are paired (j, nT-1-j) so every
 // block has the same amount of work; time is split into slabs whose partial sums are added in a
 // fixed order by a second kernel (no float atomics).
@@ -65,9 +66,10 @@ int xcorr_fft(mdhip_ctx *ctx, long long n, int n_pairs, const double *d_a, const
 constexpr int DX_THREADS = 256;
 constexpr int DX_LPT = 8;                        // consecutive lags per lane
 constexpr int DX_KT = DX_THREADS * DX_LPT;       // lags per tile (2048)
-constexpr int DX_TT = 2048;                      // time steps per LDS stage (multiple of 8)
-constexpr int DX_AW = DX_TT + DX_KT + 8;         // a-window length per stage
-constexpr int DX_ROW = DX_AW / 8 + 1;            // transposed rows: 8 rows of DX_ROW doubles
+constexpr int DX_TT = 2016;                      // time steps per LDS stage (42 trips of 48 steps)
+constexpr int DX_AW = DX_TT + DX_KT + 8 + 16;    // a-window length per stage (+ two groups of prefetch)
+constexpr int DX_ROW = DX_AW / 8 + 3;            // transposed rows: 8 rows of DX_ROW doubles (514: rows 4112 B apart,
+                                                 // the 8 rows a staging store walks fall into different banks)
 
 // partial[slab][q] = sum over the slab's time range of a[t+lag]*b[t], lag = lag0 + q, q < n_lags
 // (lag0 > 0: a lag range of the whole function, the unit of the multi-GPU split by lags)
@@ -79,6 +81,9 @@ __global__ __launch_bounds__(DX_THREADS) void xcorr_direct_kernel(
     const int tid = threadIdx.x;
     const int pair_id = blockIdx.x;  // handles lag tiles pair_id and n_tiles-1-pair_id
     const int slab = blockIdx.y;
+    a += (size_t)blockIdx.z * n;  // series pair of this block
+    b += (size_t)blockIdx.z * n;
+    partial += (size_t)blockIdx.z * n_slabs * n_lags;
 
     for (int half = 0; half < 2; ++half) {
         const int tile = half == 0 ? pair_id : n_tiles - 1 - pair_id;
@@ -104,39 +109,66 @@ __global__ __launch_bounds__(DX_THREADS) void xcorr_direct_kernel(
                 s_a[(i & 7) * DX_ROW + (i >> 3)] = g < n ? a[g] : 0.0;
             }
             __syncthreads();
-            // lane window a_stage[8*tid + tt + j], j = 0..15, as two halves that swap roles every 8 samples (no
-            // moves); element i = 8*tid + j + tt sits in row (j & 7), column tid + tt/8 + (j >> 3).
-            // b[t] is the same for every lane: scalar loads from global memory, SGPR operand of the FMA.
-            double wa[8], wb[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) wa[j] = s_a[j * DX_ROW + tid];
+            const long long left = t_hi - T0;  // time steps of this slab from T0 on
+            const int tt_count = (int)(left < DX_TT ? left : DX_TT);
+            // Lane window a_stage[8*tid + t + m], m = 0..7, held as groups of 8 consecutive entries: group g of a
+            // trip needs the entries of groups g and g+1 (X, Y) and b[8g..8g+7]. Everything a group needs is requested
+            // one whole group (64 FMAs, ~280 cycles) earlier: at the top of group g the 8 LDS reads of group g+2's
+            // entries (Z; one address register, immediate offsets) and the scalar load of group g+1's b are issued,
+            // then come the 64 FMAs on registers that are already complete — the only wait is the one at the group
+            // top (lgkmcnt(0), for requests a group old). X, Y, Z rotate and the two b buffers alternate: six groups
+            // (48 steps, 384 FMAs) per trip, no register moves. The fast trips stop where a prefetch of b would leave
+            // the series; the steps behind them (the last stage of a slab only) are done one by one.
             const double *bs = b + T0;
-            const long long left = t_hi - T0;  // samples of b that belong to this slab from T0 on
-            const int tt_full = (int)(left < DX_TT ? (left & ~7LL) : DX_TT);
-#define DX_STEP(A, B, TT, GUARD)                                                             \
-    {                                                                                        \
-        const int col_ = tid + ((TT) >> 3) + 1;                                              \
-        _Pragma("unroll") for (int j = 0; j < 8; ++j) B[j] = s_a[j * DX_ROW + col_];         \
-        _Pragma("unroll") for (int u = 0; u < 8; ++u)                                        \
-        {                                                                                    \
-            const double bt_ = (!(GUARD) || (TT) + u < left) ? bs[(TT) + u] : 0.0;           \
-            _Pragma("unroll") for (int m = 0; m < DX_LPT; ++m)                               \
-                acc[m] = __builtin_fma((u + m) < 8 ? A[(u + m) & 7] : B[(u + m) & 7], bt_, acc[m]); \
-        }                                                                                    \
-    }
             int tt = 0;
-            for (; tt + 8 < tt_full; tt += 16) {
-                DX_STEP(wa, wb, tt, false)
-                DX_STEP(wb, wa, tt + 8, false)
-            }
-            if (tt < tt_full) {
-                DX_STEP(wa, wb, tt, false)
+            const long long room = n - T0 - 56;  // a trip at tt reads b up to T0 + tt + 55
+            int fast_end = 0;
+            if (room >= 0) fast_end = (int)std::min<long long>((tt_count / 48) * 48, (room / 48 + 1) * 48);
+            if (fast_end >= 48) {
+                double wx[8], wy[8], wz[8], b0[8], b1[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) wa[j] = wb[j];
-                tt += 8;
+                for (int j = 0; j < 8; ++j) {
+                    wx[j] = s_a[j * DX_ROW + tid];
+                    wy[j] = s_a[j * DX_ROW + tid + 1];
+                    b0[j] = bs[j];
+                }
+#define DX_FMAS(X, Y, BC, U0, U1)                                                                           \
+    _Pragma("unroll") for (int u = (U0); u < (U1); ++u)                                                     \
+    {                                                                                                       \
+        _Pragma("unroll") for (int m = 0; m < DX_LPT; ++m)                                                  \
+            acc[m] = __builtin_fma((u + m) < 8 ? X[(u + m) & 7] : Y[(u + m) & 7], BC[u], acc[m]);           \
+    }
+// (the first step's FMAs come BEFORE the requests: they need this group's b, whose scalar load can only be waited for
+// with lgkmcnt(0) — placed behind the new requests that wait would drain them too)
+#define DX_GROUP(X, Y, Z, BC, BN, G)                                                                        \
+    {                                                                                                       \
+        DX_FMAS(X, Y, BC, 0, 1)                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) BN[j] = bp[8 * ((G) + 1) + j];                        \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) Z[j] = row[j * DX_ROW + (G) + 2];                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        DX_FMAS(X, Y, BC, 1, 8)                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+    }
+                for (; tt < fast_end; tt += 48) {
+                    const double *bp = bs + tt;
+                    const double *row = s_a + tid + (tt >> 3);
+                    DX_GROUP(wx, wy, wz, b0, b1, 0)
+                    DX_GROUP(wy, wz, wx, b1, b0, 1)
+                    DX_GROUP(wz, wx, wy, b0, b1, 2)
+                    DX_GROUP(wx, wy, wz, b1, b0, 3)
+                    DX_GROUP(wy, wz, wx, b0, b1, 4)
+                    DX_GROUP(wz, wx, wy, b1, b0, 5)
+                }
+#undef DX_GROUP
+#undef DX_FMAS
             }
-            if (tt < DX_TT && tt < left) DX_STEP(wa, wb, tt, true)  // the slab's last, partial group of 8
-#undef DX_STEP
+            for (; tt < tt_count; ++tt) {
+                const double bt = bs[tt];
+#pragma unroll
+                for (int m = 0; m < DX_LPT; ++m)
+                    acc[m] = __builtin_fma(s_a[((tt + m) & 7) * DX_ROW + tid + ((tt + m) >> 3)], bt, acc[m]);
+            }
         }
 #pragma unroll
         for (int m = 0; m < DX_LPT; ++m) {
@@ -151,9 +183,10 @@ __global__ void xcorr_finish_kernel(const double *__restrict__ partial, double *
 {
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_lags) return;
+    partial += (size_t)blockIdx.y * n_slabs * n_lags;
     double s = 0.0;
     for (int r = 0; r < n_slabs; ++r) s += partial[(size_t)r * n_lags + k];
-    out[k] = s / (double)(n - (lag0 + k));
+    out[(size_t)blockIdx.y * n_lags + k] = s / (double)(n - (lag0 + k));
 }
 
 int xcorr_direct(mdhip_ctx *ctx, long long n, int n_pairs, const double *d_a, const double *d_b,
@@ -161,20 +194,31 @@ int xcorr_direct(mdhip_ctx *ctx, long long n, int n_pairs, const double *d_a, co
 {
     const int n_tiles = (int)((n_lags + DX_KT - 1) / DX_KT);
     const int n_blocks = (n_tiles + 1) / 2;
-    int n_slabs = ctx->opt_xcorr_tile > 0 ? ctx->opt_xcorr_tile : (ctx->cu_count * 4 + n_blocks - 1) / n_blocks;
+    // Time slabs: every block of a launch has the same amount of work (tiles are paired), so the launch ends with a
+    // partly filled last round of blocks: ~6 rounds of the 4 resident blocks per CU keep that below a few percent
+    // (C5, one series: 5 slabs = 1.2 rounds 46.5 TFLOP/s, 25 slabs = 6 rounds 54.3; tools/ab_xcorr_direct.py). All
+    // series pairs of a call share one launch (grid.z) while the slab sums fit ~1 GiB.
     const long long max_slabs = (n - lag0 + DX_TT - 1) / DX_TT;
+    const size_t slab_b = (size_t)n_lags * 8;
+    int group = (int)std::max<long long>(1, std::min<long long>(std::min(n_pairs, 65535), (1LL << 30) / (slab_b * 8)));
+    int n_slabs = ctx->opt_xcorr_tile > 0
+                      ? ctx->opt_xcorr_tile
+                      : (int)((6LL * ctx->cu_count * 4 + (long long)n_blocks * group - 1) / ((long long)n_blocks * group));
     if (n_slabs > max_slabs) n_slabs = (int)max_slabs;
+    if (n_slabs > 65535) n_slabs = 65535;
     if (n_slabs < 1) n_slabs = 1;
-    MD_WS(d_partial, double, WS_PART, (size_t)n_slabs * n_lags * 8);
-    for (int p = 0; p < n_pairs; ++p) {
+    group = (int)std::max<long long>(1, std::min<long long>(group, (1LL << 30) / (slab_b * n_slabs)));
+    MD_WS(d_partial, double, WS_PART, (size_t)group * n_slabs * slab_b);
+    for (int p0 = 0; p0 < n_pairs; p0 += group) {
+        const int np = std::min(group, n_pairs - p0);
         // a slab can be empty for short tiles: start from zeros
-        MD_HIP(hipMemsetAsync(d_partial, 0, (size_t)n_slabs * n_lags * 8, ctx->stream));
-        hipLaunchKernelGGL(xcorr_direct_kernel, dim3((unsigned)n_blocks, (unsigned)n_slabs),
-                           dim3(DX_THREADS), 0, ctx->stream, d_a + (size_t)p * n, d_b + (size_t)p * n, n,
+        MD_HIP(hipMemsetAsync(d_partial, 0, (size_t)np * n_slabs * slab_b, ctx->stream));
+        hipLaunchKernelGGL(xcorr_direct_kernel, dim3((unsigned)n_blocks, (unsigned)n_slabs, (unsigned)np),
+                           dim3(DX_THREADS), 0, ctx->stream, d_a + (size_t)p0 * n, d_b + (size_t)p0 * n, n,
                            lag0, n_lags, n_tiles, n_slabs, d_partial);
         MD_HIP(hipGetLastError());
-        hipLaunchKernelGGL(xcorr_finish_kernel, dim3((unsigned)((n_lags + 255) / 256)), dim3(256), 0,
-                           ctx->stream, d_partial, d_out + (size_t)p * n_lags, n, lag0, n_lags, n_slabs);
+        hipLaunchKernelGGL(xcorr_finish_kernel, dim3((unsigned)((n_lags + 255) / 256), (unsigned)np), dim3(256), 0,
+                           ctx->stream, d_partial, d_out + (size_t)p0 * n_lags, n, lag0, n_lags, n_slabs);
         MD_HIP(hipGetLastError());
     }
     return MDHIP_OK;
