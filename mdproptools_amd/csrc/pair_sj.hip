@@ -286,6 +286,7 @@ struct PkCtx {
     f32x2 iLx2, iLy2, iLz2;  // and their reciprocals
     float rc2hi;          // pre-filter: every pair with rsq < r_cut^2 has rsq32 < rc2hi
     float cut_lo;         // CUTG: sqrt(rsq32) >= cut_lo may be beyond the cutoff (pk_cut_lo)
+    unsigned long long full;  // the exec mask of the sweep (the pair block narrows exec and puts this back)
     const unsigned *rowtab;  // ROWS: the class-row table [n_tj][n_ti] of LDS byte addresses (nullptr: ordered rows)
     unsigned *queue;      // this wave's queue (LDS)
     int qn;               // entries queued (wave-uniform: kept in an SGPR)
@@ -388,85 +389,123 @@ __device__ __forceinline__ RelQ load_relq(const float *__restrict__ p)
     return r;
 }
 
-// One pair slot of the packed sweep, hand-scheduled: cutoff pre-filter, bin guess, guard-band test and the LDS
-// add for the lanes whose guess is safe, in 7 VALU + 5 SALU + 1 branch (the compiler's structurised version of the
-// same C++ spends 9 SALU and 3-4 branches on the exec-mask bookkeeping, and this kernel is bound by issue slots).
-// Returns the mask of lanes whose pair lies inside the error band (to be queued for the exact chain).
-// exec is restored before the block ends; v_sqrt_f32 needs one wait state before its result is read.
+// Two pair slots of the packed sweep (the two halves of one packed rsq), hand-scheduled. The kernel is bound by ISSUE
+// slots, and a scalar instruction costs a SIMD as much issue time as a vector one (tools/ubench_salu.hip: 16 s_add_u32
+// 31 ns, 16 v_pk_fma_f32 33 ns per trip at 6 waves; interleaved 1:1 36 ns, 2:1 62 ns), so the exec-mask bookkeeping is
+// written with the compares that write exec themselves:
+//     v_cmpx_gt  c = exec = lanes inside the cutoff pre-filter      (was v_cmp + s_mov amb,0 + s_and_saveexec)
+//     s_cbranch_execz                                               (no lane inside: skip the bin guess)
+//     sqrt, fma, fract, cvt, lshl_add                               (bin guess + LDS address)
+//     v_cmpx_ge  d = exec = lanes whose guess is safe               (was v_cmp + s_andn2 amb + s_and exec)
+//     ds_add_u32
+//     s_andn2    amb = c & ~d  (c = 0 on the skipped path)          (the lanes inside the error band of an edge)
+//     s_mov      exec = full
+// = 8 VALU + 2 SALU + 1 branch per slot (round 1: 7 VALU + 5 SALU + 1 branch, and a compare + branch on amb per slot
+// behind it; the caller now tests amb0 | amb1 once). `full` is the exec mask of the sweep (read once per item).
+// v_sqrt_f32 needs one wait state before its result is read.
 // CUTG: the cutoff does not sit on a bin edge, so the band of an edge does not decide in/out of the cutoff: lanes whose
-// f32 distance reaches the cutoff's own error band (sqrt(rsq32) >= cut_lo) are ambiguous too (+1 VALU, +1 SALU).
+// f32 distance reaches the cutoff's own error band (sqrt(rsq32) >= cut_lo) are ambiguous too: one more v_cmpx (t < cl).
 // RET: also hand back the LDS address every lane computed and the mask of the lanes that added there (the CN check of
-// the groups near the wave looks those words up in the flag bits: +1 SALU).
-#define BP_HEAD                                      \
-    "v_cmp_gt_f32 vcc, %[rc2], %[rsq]\n\t"           \
-    "s_mov_b64 %[amb], 0\n\t"                        \
-    "s_and_saveexec_b64 %[save], vcc\n\t"            \
-    "s_cbranch_execz 1f\n\t"                         \
-    "v_sqrt_f32 %[t], %[rsq]\n\t"                    \
+// the groups near the wave looks those words up in the flag bits: +1 SALU per slot).
+#define BP_SLOT(K, L)                                                \
+    "v_cmpx_gt_f32_e64 %[c" K "], %[rc2], %[rsq" K "]\n\t"            \
+    "s_cbranch_execz " L "f\n\t"                                     \
+    "v_sqrt_f32 %[t" K "], %[rsq" K "]\n\t"                           \
     "s_nop 0\n\t"
-#define BP_CUT "v_cmp_ge_f32 %[m2], %[t], %[cl]\n\t"
-#define BP_MID                                       \
-    "v_fma_f32 %[t], %[t], %[gs], %[no]\n\t"         \
-    "v_fract_f32 %[fr], %[t]\n\t"                    \
-    "v_cvt_i32_f32 %[t], %[t]\n\t"                   \
-    "v_cmp_ge_f32 vcc, %[fr], %[n2]\n\t"             \
-    "v_lshl_add_u32 %[t], %[t], 2, %[rb]\n\t"
-#define BP_TAIL                                      \
-    "s_andn2_b64 %[amb], exec, vcc\n\t"              \
-    "s_and_b64 exec, exec, vcc\n\t"                  \
-    "ds_add_u32 %[t], %[one]\n\t"
-#define BP_END       \
-    "1:\n\t"         \
-    "s_mov_b64 exec, %[save]"
+#define BP_SLOT_CUT(K) "v_cmpx_lt_f32_e64 %[d" K "], %[t" K "], %[cl]\n\t"
+#define BP_SLOT_MID(K)                                               \
+    "v_fma_f32 %[t" K "], %[t" K "], %[gs], %[no" K "]\n\t"           \
+    "v_fract_f32 %[fr], %[t" K "]\n\t"                               \
+    "v_cvt_i32_f32 %[t" K "], %[t" K "]\n\t"                          \
+    "v_lshl_add_u32 %[t" K "], %[t" K "], 2, %[rb" K "]\n\t"          \
+    "v_cmpx_ge_f32_e64 %[d" K "], %[fr], %[n2]\n\t"                  \
+    "ds_add_u32 %[t" K "], %[one]\n\t"
+#define BP_SLOT_END(K, L)                                            \
+    L ":\n\t"                                                       \
+    "s_andn2_b64 %[c" K "], %[c" K "], %[d" K "]\n\t"                 \
+    "s_mov_b64 exec, %[full]\n\t"
+// RET: the lanes that added = c & d (c = 0 when the slot was skipped), before c becomes amb
+#define BP_SLOT_DONE(K, L) L ":\n\t" "s_and_b64 %[dn" K "], %[c" K "], %[d" K "]\n\t"
+struct PairOut {
+    unsigned long long amb0, amb1;    // lanes whose pair lies inside the error band (to be queued for the exact chain)
+    unsigned long long done0, done1;  // RET: lanes that added to the histogram
+    unsigned addr0, addr1;            // RET: the LDS address every lane computed
+};
+// Returns whether any lane of either slot is ambiguous (one test for both slots; leaving the asm through an
+// `asm goto` exit on the s_or's scc would save the compare, but callbr with outputs crashes this compiler's ISel).
 template <bool CUTG, bool RET>
-__device__ __forceinline__ unsigned long long bin_pair(float rsq, float rc2hi, float gscale, float nearoff, float near2,
-                                                       unsigned rowbase, float cut_lo, unsigned long long &done,
-                                                       unsigned &addr)
+__device__ __forceinline__ bool bin_pair2(float rsq0, float rsq1, float rc2hi, float gscale, float nearoff0, float nearoff1,
+                                          float near2, unsigned rowbase0, unsigned rowbase1, float cut_lo,
+                                          unsigned long long full, PairOut &o)
 {
-    unsigned long long amb, save;
-    float t, fr;
+    unsigned long long c0, c1, d0, d1;
+    float t0, t1, fr;
+#define BP_OUT [c0] "=&s"(c0), [c1] "=&s"(c1), [d0] "=&s"(d0), [d1] "=&s"(d1), [t0] "=&v"(t0), [t1] "=&v"(t1), [fr] "=&v"(fr)
+#define BP_IN                                                                                                          \
+    [rc2] "s"(rc2hi), [rsq0] "v"(rsq0), [rsq1] "v"(rsq1), [gs] "v"(gscale), [no0] "s"(nearoff0), [no1] "s"(nearoff1),   \
+        [n2] "v"(near2), [rb0] "v"(rowbase0), [rb1] "v"(rowbase1), [one] "v"(1u), [full] "s"(full)
     if (RET) {
-        unsigned long long dn;
-        if (CUTG) {
-            unsigned long long m2;
-            asm volatile("s_mov_b64 %[dn], 0\n\t" BP_HEAD BP_CUT BP_MID "s_andn2_b64 vcc, vcc, %[m2]\n\t" BP_TAIL
-                         "s_mov_b64 %[dn], exec\n\t" BP_END
-                         : [amb] "=&s"(amb), [save] "=&s"(save), [m2] "=&s"(m2), [dn] "=&s"(dn), [t] "=&v"(t), [fr] "=&v"(fr)
-                         : [rc2] "s"(rc2hi), [rsq] "v"(rsq), [gs] "v"(gscale), [no] "s"(nearoff), [n2] "v"(near2),
-                           [rb] "v"(rowbase), [one] "v"(1u), [cl] "v"(cut_lo)
+        unsigned long long dn0, dn1;
+        if (CUTG)
+            asm volatile(BP_SLOT("0", "1") BP_SLOT_CUT("0") BP_SLOT_MID("0") BP_SLOT_DONE("0", "1")
+                             "s_andn2_b64 %[c0], %[c0], %[d0]\n\ts_mov_b64 exec, %[full]\n\t"
+                         BP_SLOT("1", "2") BP_SLOT_CUT("1") BP_SLOT_MID("1") BP_SLOT_DONE("1", "2")
+                             "s_andn2_b64 %[c1], %[c1], %[d1]\n\ts_mov_b64 exec, %[full]"
+                         : BP_OUT, [dn0] "=&s"(dn0), [dn1] "=&s"(dn1)
+                         : BP_IN, [cl] "v"(cut_lo)
                          : "vcc", "scc", "memory");
-        } else {
-            asm volatile("s_mov_b64 %[dn], 0\n\t" BP_HEAD BP_MID BP_TAIL "s_mov_b64 %[dn], exec\n\t" BP_END
-                         : [amb] "=&s"(amb), [save] "=&s"(save), [dn] "=&s"(dn), [t] "=&v"(t), [fr] "=&v"(fr)
-                         : [rc2] "s"(rc2hi), [rsq] "v"(rsq), [gs] "v"(gscale), [no] "s"(nearoff), [n2] "v"(near2),
-                           [rb] "v"(rowbase), [one] "v"(1u)
+        else
+            asm volatile(BP_SLOT("0", "1") BP_SLOT_MID("0") BP_SLOT_DONE("0", "1")
+                             "s_andn2_b64 %[c0], %[c0], %[d0]\n\ts_mov_b64 exec, %[full]\n\t"
+                         BP_SLOT("1", "2") BP_SLOT_MID("1") BP_SLOT_DONE("1", "2")
+                             "s_andn2_b64 %[c1], %[c1], %[d1]\n\ts_mov_b64 exec, %[full]"
+                         : BP_OUT, [dn0] "=&s"(dn0), [dn1] "=&s"(dn1)
+                         : BP_IN
                          : "vcc", "scc", "memory");
-        }
-        done = dn;
-        addr = __float_as_uint(t);
-        return amb;
+        o.done0 = dn0;
+        o.done1 = dn1;
+        o.addr0 = __float_as_uint(t0);
+        o.addr1 = __float_as_uint(t1);
+        o.amb0 = c0;
+        o.amb1 = c1;
+        return (c0 | c1) != 0;
     }
     if (CUTG) {
-        unsigned long long m2;
-        asm volatile(BP_HEAD BP_CUT BP_MID "s_andn2_b64 vcc, vcc, %[m2]\n\t" BP_TAIL BP_END
-                     : [amb] "=&s"(amb), [save] "=&s"(save), [m2] "=&s"(m2), [t] "=&v"(t), [fr] "=&v"(fr)
-                     : [rc2] "s"(rc2hi), [rsq] "v"(rsq), [gs] "v"(gscale), [no] "s"(nearoff), [n2] "v"(near2),
-                       [rb] "v"(rowbase), [one] "v"(1u), [cl] "v"(cut_lo)
+        asm volatile(BP_SLOT("0", "1") BP_SLOT_CUT("0") BP_SLOT_MID("0") BP_SLOT_END("0", "1")
+                     BP_SLOT("1", "2") BP_SLOT_CUT("1") BP_SLOT_MID("1") BP_SLOT_END("1", "2")
+                     : BP_OUT
+                     : BP_IN, [cl] "v"(cut_lo)
                      : "vcc", "scc", "memory");
-        return amb;
+    } else {
+        asm volatile(BP_SLOT("0", "1") BP_SLOT_MID("0") BP_SLOT_END("0", "1")
+                     BP_SLOT("1", "2") BP_SLOT_MID("1") BP_SLOT_END("1", "2")
+                     : BP_OUT
+                     : BP_IN
+                     : "vcc", "scc", "memory");
     }
-    asm volatile(BP_HEAD BP_MID BP_TAIL BP_END
-                 : [amb] "=&s"(amb), [save] "=&s"(save), [t] "=&v"(t), [fr] "=&v"(fr)
-                 : [rc2] "s"(rc2hi), [rsq] "v"(rsq), [gs] "v"(gscale), [no] "s"(nearoff), [n2] "v"(near2), [rb] "v"(rowbase),
-                   [one] "v"(1u)
-                 : "vcc", "scc", "memory");
-    return amb;
+    o.amb0 = c0;
+    o.amb1 = c1;
+    return (c0 | c1) != 0;
+#undef BP_OUT
+#undef BP_IN
 }
-#undef BP_HEAD
-#undef BP_CUT
-#undef BP_MID
-#undef BP_TAIL
-#undef BP_END
+#undef BP_SLOT
+#undef BP_SLOT_CUT
+#undef BP_SLOT_MID
+#undef BP_SLOT_END
+#undef BP_SLOT_DONE
+
+// jbase + 4 g of a group, computed where it is needed (the rare queue pushes): the opaque copy keeps the compiler from
+// hoisting the two scalar instructions into every group's sweep (the kernel is bound by issue slots, scalar ones too)
+struct GroupIdx {
+    int jbase, g;
+};
+__device__ __forceinline__ int jidx_here(GroupIdx k)
+{
+    int g = k.g;
+    asm volatile("" : "+s"(g));
+    return k.jbase + g * SJ_GROUP;
+}
 
 // The four j atoms of one group against the wave's 64 i atoms.
 // VAR: bit k = axis k takes the per-pair f32 wrap. jidx0 = index of the group's first atom in the frame's j set.
@@ -478,7 +517,7 @@ __device__ __forceinline__ unsigned long long bin_pair(float rsq, float rc2hi, f
 // CNG: the group is near enough to the wave to hold pairs of a CN split bin: every pair the sweep bins is looked up in
 // the flag bits, and the ones in a flagged word are queued as PK_CN_ONLY entries.
 template <bool DIAG, int VAR, bool PF, bool CUTG, bool ROWS, bool CNG>
-__device__ __forceinline__ void sweep_group_pk(const RelQ &rq, int jidx0, int local0, PkCtx &p, const FastCtx &c,
+__device__ __forceinline__ void sweep_group_pk(const RelQ &rq, GroupIdx jidx0, int local0, PkCtx &p, const FastCtx &c,
                                                int lane_in_tile, int lane, const float *next_p, RelQ &next)
 {
     unsigned row[4] = {0u, 0u, 0u, 0u};
@@ -511,53 +550,63 @@ __device__ __forceinline__ void sweep_group_pk(const RelQ &rq, int jidx0, int lo
         f32x2 rsq = dx * dx;
         rsq = __builtin_elementwise_fma(dy, dy, rsq);
         rsq = __builtin_elementwise_fma(dz, dz, rsq);
+        // ordered rows: w = the bin-guess addend near + tj * row_len; class rows: w = the table offset of tj
+        const float nearoff0 = ROWS ? c.near : rb[2], nearoff1 = ROWS ? c.near : rb[3];
+        const unsigned rowbase0 = ROWS ? row[2 * h] : c.rowbase_me, rowbase1 = ROWS ? row[2 * h + 1] : c.rowbase_me;
+        float r2a = rsq[0], r2b = rsq[1];
+        if (DIAG) {  // i < j inside the diagonal tile
+            r2a = local0 + 2 * h > lane_in_tile ? r2a : 3.0e38f;
+            r2b = local0 + 2 * h + 1 > lane_in_tile ? r2b : 3.0e38f;
+        }
+        unsigned kaddr0 = 0, kaddr1 = 0;
+        if (CNG) {
+            // the split-bin word of the row (ti of this lane, tj of this j atom), looked up BEFORE the pair block so
+            // that the LDS read runs under it. Ordered rows: tj from the addend near + tj * row_len (near < 1: the
+            // truncated quotient is tj); class rows: the row table's own index. (Hoisting the four lookups of a
+            // group costs 4 VGPRs, which the 80-register budget pays for with spills: measured slower.)
+            kaddr0 = ROWS ? p.cn_kc_me[__float_as_uint(rb[2])] : p.cn_kc_me[(int)(nearoff0 * p.inv_row_len)];
+            kaddr1 = ROWS ? p.cn_kc_me[__float_as_uint(rb[3])] : p.cn_kc_me[(int)(nearoff1 * p.inv_row_len)];
+        }
+        PairOut o;
+        const bool any_amb = bin_pair2<CUTG, CNG>(r2a, r2b, p.rc2hi, c.gscale, nearoff0, nearoff1, c.near2, rowbase0,
+                                                  rowbase1, p.cut_lo, p.full, o);
+        if (CNG && (o.done0 | o.done1)) {  // wave-uniform
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            // ordered rows: w = the bin-guess addend near + tj * row_len; class rows: w = the table offset of tj
-            const float nearoff = ROWS ? c.near : (u ? rb[3] : rb[2]);
-            const unsigned rowbase = ROWS ? row[2 * h + u] : c.rowbase_me;
-            float r2 = rsq[u];
-            if (DIAG) r2 = local0 + 2 * h + u > lane_in_tile ? r2 : 3.0e38f;  // i < j inside the diagonal tile
-            unsigned long long done = 0;
-            unsigned addr = 0, kaddr = 0;
-            if (CNG) {
-                // the split-bin word of the row (ti of this lane, tj of this j atom), looked up BEFORE the pair block so
-                // that the LDS read runs under it. Ordered rows: tj from the addend near + tj * row_len (near < 1: the
-                // truncated quotient is tj); class rows: the row table's own index. (Hoisting the four lookups of a
-                // group costs 4 VGPRs, which the 80-register budget pays for with spills: measured slower.)
-                kaddr = ROWS ? p.cn_kc_me[__float_as_uint(u ? rb[3] : rb[2])]
-                             : p.cn_kc_me[(int)(nearoff * p.inv_row_len)];
-            }
-            const unsigned long long amb = bin_pair<CUTG, CNG>(r2, p.rc2hi, c.gscale, nearoff, c.near2, rowbase, p.cut_lo, done, addr);
-            if (CNG && done) {  // wave-uniform
-                const unsigned long long hm = __builtin_amdgcn_ballot_w64(addr == kaddr) & done;
+            for (int u = 0; u < 2; ++u) {
+                const unsigned long long done = u ? o.done1 : o.done0;
+                const unsigned long long hm = __builtin_amdgcn_ballot_w64((u ? o.addr1 : o.addr0) == (u ? kaddr1 : kaddr0)) & done;
                 if (hm) {
                     const bool hit = (hm >> lane) & 1ull;
                     if (hit) {
                         const int pos = p.qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32),
                                                                               __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0u));
                         if (pos < PK_QCAP)
-                            p.queue[pos] = PK_CN_ONLY | ((unsigned)(jidx0 + 2 * h + u) << 6) | (unsigned)lane;
+                            p.queue[pos] = PK_CN_ONLY | ((unsigned)(jidx_here(jidx0) + 2 * h + u) << 6) | (unsigned)lane;
                         else
                             atomicAdd(p.lost, 1ull);
                     }
                     p.qn += __builtin_popcountll(hm);
                 }
             }
-            if (amb) {  // wave-uniform, rare: some lane's pair is inside the error band -> the exact chain, later
+        }
+        if (any_amb) {  // wave-uniform, rare: some lane's pair is inside the error band -> the exact chain, later
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
                 // (the copy through a volatile asm keeps the per-lane test inside this branch: the compiler would
                 // otherwise fold both conditions into one divergent branch and pay 3 VALU per pair for it)
                 unsigned long long amb_in;
-                asm volatile("s_mov_b64 %0, %1" : "=s"(amb_in) : "s"(amb));
-                if ((amb_in >> lane) & 1ull) {
-                    const int pos = p.qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(amb_in >> 32),
-                                                                          __builtin_amdgcn_mbcnt_lo((unsigned)amb_in, 0u));
-                    if (pos < PK_QCAP)
-                        p.queue[pos] = ((unsigned)(jidx0 + 2 * h + u) << 6) | (unsigned)lane;
-                    else  // cannot happen (drained above 64, a group adds <= 256); the host reports it
-                        atomicAdd(p.lost, 1ull);
+                asm volatile("s_mov_b64 %0, %1" : "=s"(amb_in) : "s"(u ? o.amb1 : o.amb0));
+                if (amb_in) {
+                    if ((amb_in >> lane) & 1ull) {
+                        const int pos = p.qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(amb_in >> 32),
+                                                                              __builtin_amdgcn_mbcnt_lo((unsigned)amb_in, 0u));
+                        if (pos < PK_QCAP)
+                            p.queue[pos] = ((unsigned)(jidx_here(jidx0) + 2 * h + u) << 6) | (unsigned)lane;
+                        else  // cannot happen (drained above 64, a group adds <= 256); the host reports it
+                            atomicAdd(p.lost, 1ull);
+                    }
+                    p.qn += __builtin_popcountll(amb_in);
                 }
-                p.qn += __builtin_popcountll(amb_in);
             }
         }
     }
@@ -628,6 +677,7 @@ __device__ __forceinline__ int sj_item_pk(const PairArgs &a, FastCtx &c, const u
     p.iLz2 = f32x2{(float)iLz, (float)iLz};
     p.rc2hi = a.rc2hi;
     p.cut_lo = a.cut_lo;
+    asm volatile("s_mov_b64 %0, exec" : "=s"(p.full));
     p.rowtab = ROWS ? s_row : nullptr;
     p.queue = queue;
     p.qn = 0;
@@ -735,27 +785,35 @@ __device__ __forceinline__ int sj_item_pk(const PairArgs &a, FastCtx &c, const u
             // while the current group is swept; two buffers, loop unrolled by two (no register copies). With CNG the
             // groups near the wave run the same pipeline in its split-bin-checking form (an unpipelined near loop
             // exposed every group's record load: a near slot then cost ~2.5 slots).
+// (mask walk in scalar instructions that exist: s_ff1 gives -1 for an empty mask, & 63 turns that into a group whose
+// records are merely prefetched and never swept; s_bitset0 clears the bit in one instruction instead of the three of
+// mk &= mk - 1; the record address is 32-bit offset arithmetic)
+#define PK_NEXT(G)                                                                                                      \
+    {                                                                                                                   \
+        asm("s_ff1_i32_b64 %0, %1" : "=s"(G) : "s"(mk));                                                                \
+        G &= 63;                                                                                                        \
+        asm("s_bitset0_b64 %0, %1" : "+s"(mk) : "s"(G));                                                                \
+    }
+#define PK_REC(G) (const float *)((const char *)rtile + ((unsigned)(G) << 6))
 #define PK_PIPELINED(MASK, CN)                                                                                          \
     {                                                                                                                   \
         unsigned long long mk = (MASK);                                                                                 \
         if (mk) {                                                                                                       \
-            int gA = __builtin_ctzll(mk);                                                                               \
-            mk &= mk - 1;                                                                                               \
-            RelQ qA = load_relq(rtile + gA * SJ_GROUP * 4), qB;                                                         \
+            int gA, gB;                                                                                                 \
+            PK_NEXT(gA)                                                                                                 \
+            RelQ qA = load_relq(PK_REC(gA)), qB;                                                                        \
             for (;;) {                                                                                                  \
                 PK_DRAIN_CHECK();                                                                                       \
                 const bool moreB = mk != 0;                                                                             \
-                const int gB = moreB ? __builtin_ctzll(mk) : gA;                                                        \
-                mk &= mk - 1;                                                                                           \
-                sweep_group_pk<false, 0, true, CUTG, ROWS, CN>(qA, jbase + gA * SJ_GROUP, gA * SJ_GROUP, p, c,          \
-                                                               lane_in_tile, lane, rtile + gB * SJ_GROUP * 4, qB);      \
+                PK_NEXT(gB)                                                                                             \
+                sweep_group_pk<false, 0, true, CUTG, ROWS, CN>(qA, GroupIdx{jbase, gA}, gA * SJ_GROUP, p, c,            \
+                                                               lane_in_tile, lane, PK_REC(gB), qB);                     \
                 if (!moreB) break;                                                                                      \
                 PK_DRAIN_CHECK();                                                                                       \
                 const bool moreA = mk != 0;                                                                             \
-                gA = moreA ? __builtin_ctzll(mk) : gB;                                                                  \
-                mk &= mk - 1;                                                                                           \
-                sweep_group_pk<false, 0, true, CUTG, ROWS, CN>(qB, jbase + gB * SJ_GROUP, gB * SJ_GROUP, p, c,          \
-                                                               lane_in_tile, lane, rtile + gA * SJ_GROUP * 4, qA);      \
+                PK_NEXT(gA)                                                                                             \
+                sweep_group_pk<false, 0, true, CUTG, ROWS, CN>(qB, GroupIdx{jbase, gB}, gB * SJ_GROUP, p, c,            \
+                                                               lane_in_tile, lane, PK_REC(gA), qA);                     \
                 if (!moreA) break;                                                                                      \
             }                                                                                                           \
         }                                                                                                               \
@@ -765,6 +823,8 @@ __device__ __forceinline__ int sj_item_pk(const PairArgs &a, FastCtx &c, const u
                 if constexpr (CNG) PK_PIPELINED(__builtin_amdgcn_ballot_w64(keep && var == 0u && nearg) & bm, true)
             }
 #undef PK_PIPELINED
+#undef PK_NEXT
+#undef PK_REC
             // the other variants (per-pair wrap on some axis, the diagonal tile): not pipelined
 #define PK_SWEEP_CASES(CN)                                                                                             \
     switch (A) {                                                                                                       \
@@ -787,7 +847,8 @@ __device__ __forceinline__ int sj_item_pk(const PairArgs &a, FastCtx &c, const u
                     mk &= mk - 1;
                     RelQ q = load_relq(rtile + g * SJ_GROUP * 4), qnone;
                     PK_DRAIN_CHECK();
-                    const int j0 = jbase + g * SJ_GROUP, l0 = g * SJ_GROUP;
+                    const GroupIdx j0{jbase, g};
+                    const int l0 = g * SJ_GROUP;
                     if constexpr (CNG) {
                         if ((nm >> g) & 1ull) {
                             PK_SWEEP_CASES(true)
