@@ -98,9 +98,10 @@ def main():
     # nowhere else in the loop, so their counts per pair slot can be read off the histogram. Everything else in the
     # loop's address range is the wave-uniformly skipped ambiguous-pair code (queue push: v_mbcnt, ds_write; lost-entry
     # atomics), the queue-drain check and the loop control / prefetch.
-    sig_uncond = ["v_pk_add_f32", "v_pk_mul_f32", "v_pk_fma_f32", "v_cmp_gt_f32"]
-    sig_cond = ["v_sqrt_f32", "v_fma_f32", "v_fract_f32", "v_cvt_i32_f32", "v_cmp_ge_f32", "v_lshl_add_u32"]
-    sig_other = ["ds_add_u32", "s_and_saveexec_b64", "s_cbranch_execz", "s_load_dwordx16", "s_load_dwordx8", "s_load_dwordx4"]
+    sig_uncond = ["v_pk_add_f32", "v_pk_mul_f32", "v_pk_fma_f32", "v_cmpx_gt_f32_e64"]
+    sig_cond = ["v_sqrt_f32", "v_fma_f32", "v_fract_f32", "v_cvt_i32_f32", "v_cmpx_ge_f32_e64", "v_lshl_add_u32"]
+    sig_other = ["ds_add_u32", "s_andn2_b64", "s_mov_b64", "s_and_saveexec_b64", "s_cbranch_execz", "s_ff1_i32_b64", "s_bitset0_b64",
+                 "s_load_dwordx16", "s_load_dwordx8", "s_load_dwordx4"]
     print("\npair path, per trip and per pair slot (64 pairs):")
     u = c = 0
     for k in sig_uncond:

@@ -130,20 +130,22 @@ K32S(k_cmp_f32_s, OP_CMP_F32_S)
     "v_pk_mul_f32 v[40:41], v[40:41], v[40:41]\n\t"                     \
     "v_pk_fma_f32 v[40:41], v[42:43], v[42:43], v[40:41]\n\t"           \
     "v_pk_fma_f32 v[40:41], v[44:45], v[44:45], v[40:41]\n\t"
-#define MIX_CMP(R) "v_cmp_gt_f32 vcc, %[rc], " R "\n\t"
+// (the pair block masks with v_cmpx, VOP3 with an SGPR-pair destination; here the compares are always true — rc = +inf,
+// n2 = -1 — so that exec stays whole without a restoring scalar instruction)
+#define MIX_CMP(R) "v_cmpx_gt_f32_e64 s[60:61], %[rc], " R "\n\t"
 #define MIX_BIN(R)                              \
     "v_sqrt_f32 v46, " R "\n\t"                 \
     "s_nop 0\n\t"                               \
     "v_fma_f32 v46, v46, %[gs], %[no]\n\t"      \
     "v_fract_f32 v47, v46\n\t"                  \
     "v_cvt_i32_f32 v46, v46\n\t"                \
-    "v_cmp_ge_f32 vcc, v47, %[n2]\n\t"          \
-    "v_lshl_add_u32 %[acc], v46, 2, %[acc]\n\t"
+    "v_lshl_add_u32 %[acc], v46, 2, %[acc]\n\t" \
+    "v_cmpx_ge_f32_e64 s[62:63], v47, %[n2]\n\t"
 #define MIX_OPERANDS                                                                                                  \
     [acc] "+v"(acc)                                                                                                   \
         : [x2] "v"(x2), [y2] "v"(y2), [z2] "v"(z2), [sx] "s"(sx), [sy] "s"(sy), [sz] "s"(sz), [rc] "s"(rc), [gs] "v"(gs), \
           [no] "s"(no), [n2] "v"(n2)                                                                                  \
-        : "vcc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47"
+        : "vcc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "s60", "s61", "s62", "s63"
 
 // NB = how many of the 16 pair slots of an iteration (8 half groups) run the bin guess: 0, 11 (= 0.69, the C2 share) or 16
 template <int NB>
@@ -152,8 +154,8 @@ __global__ __launch_bounds__(256) void k_mix(Stamp *out, double a, double b, uns
     extern __shared__ unsigned char lds[];
     f32x2 x2 = INIT_P(a + threadIdx.x), y2 = INIT_P(a + 1.0 + threadIdx.x), z2 = INIT_P(a + 2.0 + threadIdx.x);
     const unsigned long long sx = sb, sy = sb + 0x0000100000001000ull, sz = sb + 0x0000200000002000ull;
-    const unsigned rc = 0x43c80000u, no = 0x3f000000u;  // 400.0f, 0.5f as SGPR operands
-    float gs = (float)b, n2 = 0.001f;
+    const unsigned rc = 0x7f800000u, no = 0x3f000000u;  // +inf, 0.5f as SGPR operands
+    float gs = (float)b, n2 = -1.0f;
     unsigned acc = threadIdx.x;
     unsigned long long c0, r0, c1, r1;
     stamp(c0, r0);
