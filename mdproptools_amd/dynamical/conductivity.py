@@ -22,6 +22,10 @@ from ..common import constants
 from ..common.com_mols import molecule_layout
 from ..io import parse_lammps_dumps
 
+# True: get_charge_flux parses into page-locked staging batches and runs the fused flux kernel on each while the next
+# one is being parsed (mdproptools_amd/stream.py). False: every frame is parsed first (round-1 route).
+STREAM = True
+
 
 class Conductivity:
     """Green-Kubo ionic conductivity (total and per molecule type) following 10.1063/1.4890741."""
@@ -96,6 +100,13 @@ class Conductivity:
         from .. import dist as D
 
         files = None
+        if mio.USE_NATIVE_READER and STREAM:
+            # text -> page-locked batches -> fused flux kernel, the next batch being parsed meanwhile (stream.py)
+            files = D.my_files(f"{self.working_dir}/{self.filename}")
+            got = self._flux_streamed(files, seg_off, mol_type)
+            if got is not None:
+                flux, steps = got
+                return self._finish_flux(flux, steps, files, n_expected)
         if mio.USE_NATIVE_READER:
             def wanted(names):
                 return ["vx", "vy", "vz", "q"] + (["type"] if self.mass else ["mass"])
@@ -130,6 +141,48 @@ class Conductivity:
             flux = backend.charge_flux(np.stack(vel), m, q, seg_off, (mol_type - 1).astype(np.int32),
                                        len(self.num_mols), constants.VELOCITY_CONVERSION[self.units],
                                        constants.CHARGE_CONVERSION[self.units])
+        return self._finish_flux(flux, steps, files, n_expected)
+
+    def _flux_streamed(self, files, seg_off, mol_type):
+        """(flux [3, n_types, F_local] or None, steps) through the frame stream; None when the dumps need the general
+        route (compressed text, a column missing: the general route raises the reference's message)."""
+        from .. import io as mio
+        from .. import stream as S
+
+        pattern = f"{self.working_dir}/{self.filename}"
+        mine = files if files is not None else mio._sorted_matches(pattern)
+        if not mine or any(str(f).endswith(".gz") for f in mine):
+            return None
+        nd = mio.NativeDumpFile(mine[0])
+        try:
+            names = nd.header(0)[4] if nd.n_frames else []
+        finally:
+            nd.close()
+        second = "type" if self.mass else "mass"
+        if not {"id", "q", second, "vx", "vy", "vz"} <= set(names):
+            return None
+        m = q = None
+        parts, steps = [], []
+        # the staging batch carries the charge, ONE more per-atom attribute and the three velocity planes
+        for batch in S.FrameStream(pattern, files=mine, columns=("q", second, "vx", "vy", "vz")):
+            n = batch.xyz.shape[2]
+            if seg_off[-1] != n:
+                raise ValueError(f"Length of values ({int(seg_off[-1])}) does not match length of index ({n})")
+            if m is None:  # masses and charges of the first frame, as the general route takes them
+                tm = batch.types[0]
+                m = np.asarray(self.mass, dtype=np.float64)[tm.astype(np.int64) - 1] if self.mass else tm.copy()
+                q = batch.ids[0].copy()
+            parts.append(backend.charge_flux(batch.xyz, m, q, seg_off, (mol_type - 1).astype(np.int32),
+                                             len(self.num_mols), constants.VELOCITY_CONVERSION[self.units],
+                                             constants.CHARGE_CONVERSION[self.units]))
+            steps.extend((batch.timesteps * constants.TIME_CONVERSION[self.units]).tolist())
+        if not parts:
+            return None if files is None else (None, steps)
+        return np.concatenate(parts, axis=2), steps
+
+    def _finish_flux(self, flux, steps, files, n_expected):
+        from .. import dist as D
+
         if files is not None:
             if flux is None:
                 raise ValueError("this rank holds no frame: use at most as many ranks as there are dump files")

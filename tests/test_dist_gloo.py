@@ -286,6 +286,9 @@ def _dynamical_worker(rank, world, port, tmp_dir):
     from mdproptools_amd.dynamical import diffusion as dm
 
     dm.STREAM = False  # the streamed route keeps the trajectory on the GPU; its two-rank run is tests/test_gpu_dropin.py
+    from mdproptools_amd.dynamical import conductivity as cm
+
+    cm.STREAM = True  # (host-side batches through the stand-in flux function: runs on the CPU too)
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     out = os.path.join(tmp_dir, "w%d" % world)

@@ -197,6 +197,35 @@ def test_conductivity_chain(small_dir):
     np.testing.assert_allclose(Conductivity.correlate(a, b), ref, rtol=0, atol=1e-10 * abs(ref).max())
 
 
+def test_conductivity_flux_streamed_equals_load_all(small_dir, monkeypatch):
+    """get_charge_flux on the frame stream (several batches) == the load-everything-first route, bit for bit."""
+    from mdproptools_amd import stream as S
+    from mdproptools_amd.dynamical import conductivity as cm
+
+    g, tmp = small_dir
+    n = g["frames"][0].shape[0]
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(cm, "STREAM", on)
+        monkeypatch.setattr(S, "DEFAULT_BATCH_BYTES", 2 * 24 * n)
+        orig = S.FrameStream.__init__
+
+        def small_batches(self, *a, **k):
+            k["batch_bytes"] = 2 * 24 * n  # two frames per batch
+            orig(self, *a, **k)
+
+        monkeypatch.setattr(S.FrameStream, "__init__", small_batches)
+        for mass in (MASS, None):
+            c = cm.Conductivity("dump.nvt.*.dump", g["num_mols"].tolist(), g["num_atoms_per_mol"].tolist(), 1000.0,
+                                mass=mass, temp=300.0, timestep=1, units="real", working_dir=tmp)
+            res[(on, mass is None)] = (c.get_charge_flux(), np.asarray(c.time))
+        monkeypatch.setattr(S.FrameStream, "__init__", orig)
+    for key in (False, True):
+        np.testing.assert_array_equal(res[(True, key)][0], res[(False, key)][0])
+        np.testing.assert_array_equal(res[(True, key)][1], res[(False, key)][1])
+    assert np.abs(res[(True, False)][0]).max() > 0
+
+
 def test_conductivity_fit_curve():
     from mdproptools_amd.dynamical.conductivity import Conductivity
 
