@@ -374,7 +374,7 @@ def leg_c3(B, ctx, torch, device, synth, sync):
                                    "value": pairs / t_both, "unit": "atom-pairs/s",
                                    "over_rdf_alone": t_both / t_rdf, "identical_to_separate_calls": same,
                                    "launches": km["both"][3],
-                                   "roofline": valu_roofline(km["both"][2], "C3", km["both"][0] * 1e-3 / km["both"][3],
+                                   "roofline": valu_roofline(km["both"][2], "C3/rdf_cn", km["both"][0] * 1e-3 / km["both"][3],
                                                              "mix bin 11/16", 6, pairs / km["both"][3],
                                                              28.0 * n * F / km["both"][3])}
         if not same:
@@ -396,7 +396,7 @@ def leg_c3(B, ctx, torch, device, synth, sync):
                                             pairs / km["rdf"][3], 28.0 * n * F / km["rdf"][3])}
     out["cn"] = {"wall_s": t_cn, "kernel_s": km["cn"][0] * 1e-3, "value": pairs / t_cn, "unit": "atom-pairs/s",
                  "launches": km["cn"][3],
-                 "roofline": valu_roofline(km["cn"][2], "C3", km["cn"][0] * 1e-3 / km["cn"][3], "v_add_f64", 4,
+                 "roofline": valu_roofline(km["cn"][2], "C3/cn", km["cn"][0] * 1e-3 / km["cn"][3], "mix bin 11/16", 6,
                                            pairs / km["cn"][3], 28.0 * n * F / km["cn"][3])}
     out["rdf_plus_cn_wall_s"] = t_both if "rdf_cn_one_sweep" in out else t_rdf + t_cn
     out["parity_checked"] = "frame 0 (5.0e9 pairs) == oracle/cpu_ref.c, bit-exact"
@@ -710,8 +710,8 @@ def main():
                                      "of the cutoff resolved by the reference's f64 chain (integers identical to the "
                                      "all-f64 sweep: see f64_only)" if "<3" in kernel_name or "<4" in kernel_name
                                      or "<5" in kernel_name or "<6" in kernel_name else "f64"},
-            "roofline": valu_roofline(kernel_name, "C3" if strong else "C2", kdur, "mix bin 11/16", 6,
-                                      pairs_local, 28.0 * n * F),
+            "roofline": valu_roofline(kernel_name, ("C3" if strong else "C2") + ("" if args.op == "rdf" else "/" + args.op),
+                                      kdur, "mix bin 11/16", 6, pairs_local, 28.0 * n * F),
         }
         out["roofline"]["prepass_ms_per_step"] = aux_ms / args.steps
         legs = [] if (args.no_legs or world > 1 or strong) else args.legs.split(",")

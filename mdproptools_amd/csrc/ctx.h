@@ -93,10 +93,11 @@ struct mdhip_ctx {
     int opt_rdf_pk = -1;      // scalar-j RDF with ordered rows: -1/1 packed-f32 classification sweep with the exact
                               // deferred resolver (MODE 3) when its error bound allows, 0 the all-f64 sweep (MODE 2)
     int opt_rdf_sort = -1;    // spatial sort: -1 auto, 1 one block per frame (LDS counters), 0 multi-block (global counters)
-    int opt_cn_pk = 0;        // mdhip_cn_atomic: 1 = through the packed-f32 sweep (coarse 64-bin histogram up to the largest
-                              // cutoff + split bins) when the geometry allows, 0 (default) = the f64 edge-table kernel.
-                              // Same integers; measured at C3: 0.081 s against 0.086 s — with so short a reach the
-                              // per-tile latencies (group boxes, tile centre, queue drain) dominate either way
+    int opt_cn_pk = 1;        // mdhip_cn_atomic: 1 (default since the scalar-stream cut of the packed sweep) =
+                              // through the packed-f32 sweep (coarse 64-bin histogram up to the largest cutoff + split
+                              // bins) when the geometry allows, 0 = the f64 edge-table kernel (also the fallback).
+                              // Same integers (soaked against each other and the oracle); C3: 4.78 against 5.11 ms per
+                              // 64 frames, C2 1.60 against 1.70 ms
     int opt_rdf_guard = 0;    // overflow guard of the 32-bit LDS histogram words: neighbour tiles a block may sweep
                               // per launch (0 = the real bound, 2^32 / (64 * 256) with margin; tests lower it)
     int opt_seg_cap = 0;      // segment kernels: atoms per block stage, 1024 (default), 512, or 256 = one wave per block (A/B)

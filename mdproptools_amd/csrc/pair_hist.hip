@@ -1130,10 +1130,10 @@ int mdhip_cn_atomic(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const dou
     const int nbins = (int)edges.size() - 1;
     if (nbins == 0) return MDHIP_OK;
     if (ctx->opt_cn_pk != 0) {
-        // Option cn_pk: the packed-f32 sweep with a coarse histogram whose cutoff is the largest coordination cutoff;
-        // the counts are the exact bins below each class's split bin plus the split-bin pairs the exact chain finds
-        // inside — the same integers as the f64 edge-table kernel below, which is the default and
-        // the route for everything the packed sweep does not take (small frames, two cutoffs for one class, ...).
+        // Option cn_pk (default): the packed-f32 sweep with a coarse histogram whose cutoff is the largest coordination
+        // cutoff; the counts are the exact bins below each class's split bin plus the split-bin pairs the exact chain
+        // finds inside — the same integers as the f64 edge-table kernel below, which is the route for
+        // everything the packed sweep does not take (small frames, two cutoffs for one class, ...) and for cn_pk = 0.
         const double c_max = std::sqrt(edges.back());
         const int nb = 64;
         rc = fused_rdf_cn(ctx, n_frames, n_atoms, xyz, on_device, type, type_frame_stride, box, n_rel, rel,

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""tools/ab_pair.py KEY=V1,V2,... [C2|C3] — A/B of one library OPTION on the pair kernel inside ONE process (boxes differ
+"""tools/ab_pair.py KEY=V1,V2,... [C2|C3] [rdf|cn] — A/B of one library OPTION on the pair kernel inside ONE process (boxes differ
 by ~10 %, runs inside a process by ~1 %): kernel time (min / median of 8 launches) per value, results asserted equal.
 For two code variants use tools/ab_libs.py with two BUILDS: a kernel that carries both variants behind a run-time flag
 is not either of them (the two-slot pair block looked 5 % faster that way and was 2 % slower build against build)."""
@@ -18,6 +18,7 @@ from mdproptools_amd._lib import default_context  # noqa: E402
 key, vals = sys.argv[1].split("=")
 vals = [int(v) for v in vals.split(",")]
 which = sys.argv[2] if len(sys.argv) > 2 else "C2"
+op = sys.argv[3] if len(sys.argv) > 3 else "rdf"  # rdf | cn
 cfg = synth.rdf_config(which)
 n, L = cfg["n_atoms"], cfg["box_len"]
 F = cfg["n_frames"] if which == "C2" else 64
@@ -32,7 +33,10 @@ for rnd in range(2):
         ctx.set_option(key, v)
         ms = []
         for _ in range(8):
-            out = B.rdf_loop(xyz, ty, box, rel, 20.0, 0.05, 400, per_frame=False, ctx=ctx)
+            if op == "cn":
+                out = (B.cn_loop(xyz, ty, box, rel, synth.cn_cutoffs(len(rel)), per_frame=False, ctx=ctx),) * 2
+            else:
+                out = B.rdf_loop(xyz, ty, box, rel, 20.0, 0.05, 400, per_frame=False, ctx=ctx)
             ms.append(ctx.last_kernel_ms()[0])
         if ref is None:
             ref = out

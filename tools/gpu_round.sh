@@ -18,8 +18,8 @@ for s in "$@"; do
     pmc_c2) timeout -k 10 900 bash tools/pmc.sh r02_c2 C2 > $O/pmc_c2.log 2>&1; echo "pmc rc=$?" ;;
     pmc_c2_f64) timeout -k 10 900 bash tools/pmc.sh r02_c2_f64 C2 --option rdf_pk=0 > $O/pmc_c2_f64.log 2>&1; echo "pmc rc=$?" ;;
     pmc_c3) timeout -k 10 900 bash tools/pmc.sh r02_c3 C3 --scaling strong > $O/pmc_c3.log 2>&1; echo "pmc rc=$?" ;;
-    pmc_c3_cn) timeout -k 10 900 bash tools/pmc.sh r02_c3_cn C3 --scaling strong --op cn > $O/pmc_c3_cn.log 2>&1; echo "pmc rc=$?" ;;
-    pmc_c3_both) timeout -k 10 900 bash tools/pmc.sh r02_c3_both C3 --scaling strong --op rdf_cn > $O/pmc_c3_both.log 2>&1; echo "pmc rc=$?" ;;
+    pmc_c3_cn) timeout -k 10 900 bash tools/pmc.sh r02_c3_cn C3/cn --scaling strong --op cn > $O/pmc_c3_cn.log 2>&1; echo "pmc rc=$?" ;;
+    pmc_c3_both) timeout -k 10 900 bash tools/pmc.sh r02_c3_both C3/rdf_cn --scaling strong --op rdf_cn > $O/pmc_c3_both.log 2>&1; echo "pmc rc=$?" ;;
     stats) (cd /tmp && export TMPDIR=/tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o r02_bench -- python3 $R/bench.py --no-cpu-baseline --no-legs > $O/bench_line_rocprof.json 2> $O/rocprof_err.log); echo "stats rc=$?" ;;
     *) echo "unknown step $s" ;;
   esac
