@@ -309,7 +309,7 @@ __global__ __launch_bounds__(LG_THREADS) void lag_msd_kernel(
 }
 
 // Series-resident variant (default whenever one series plus its padding fits LDS, n <~ 19 000 frames).
-// The whole series of one (entity, axis) sits in LDS, transposed [i mod 8][i div 8] as above, and is
+// The whole series of one (entity, axis) sits in LDS (padded natural order, see LX below), and is
 // both the broadcast operand x[t] and the per-lane sliding window x[t + lag]. A WAVE owns a pair of
 // lag tiles of 512 lags, (j, nT-1-j), and walks each only as far as that tile's own longest valid
 // origin range (n - K0), so the idle lanes of the lag x origin triangle are confined to the last 512
@@ -320,7 +320,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 8)))
     const double *__restrict__ x, long long n_ent, int n, int n_lags, const Chunk *__restrict__ chunks,
     int n_tiles, int row, double *__restrict__ partial)
 {
-    extern __shared__ double s_x[];  // [8][row], zero beyond n
+    // the series, zero beyond n, one pad double behind every 8 entries: entry i at LX(i) = i + (i >> 3). The lanes of a
+    // wave read entries 8 apart (9 doubles apart in LDS: no bank conflicts) and a lane's own entries follow each other
+    // at offsets that are compile-time constants from ONE address register (kb and the trip's t are multiples of 8);
+    // the round-1 layout [i mod 8][i div 8] needed a register per row — the row length depends on the series — and
+    // the compiler spilled them
+    extern __shared__ double s_x[];
+#define LX(i) ((i) + ((i) >> 3))
     constexpr int KT = 64 * LG_LPT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const Chunk ck = chunks[blockIdx.y];
@@ -349,7 +355,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int i = base + q * NW * 64 + tid;
-                    if (i < n_pad) s_x[(i & 7) * row + (i >> 3)] = v[q];
+                    if (i < n_pad) s_x[LX(i)] = v[q];
                 }
             }
             __syncthreads();
@@ -361,17 +367,19 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 8)))
                 // pair (t, kb + m) is valid iff t + m < lim; lanes whose lags nobody asked for do nothing
                 const int lim = kb < n_lags ? n - kb : 0;
                 // window x[t + kb + j], j = 0..15, as two halves that swap roles every 8 origins (no moves)
-                double wa[8], wb[8];
+                double w[16];  // the ring; wa / wb name its halves for the finishing steps (t is a multiple of 16 there)
+#define wa (w)
+#define wb (w + 8)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) wa[j] = s_x[j * row + (kb >> 3)];  // (kb & 7) == 0
+                for (int j = 0; j < 8; ++j) wa[j] = s_x[LX(kb) + j];  // (kb & 7) == 0
 // One step of 8 origins x 8 lags for the lanes whose whole 8 x 8 block is valid (the others are masked off:
 // their few remaining pairs are swept up after the loop). A holds x[T+kb+0..7], B is loaded with x[T+kb+8..15].
 #define LG_STEP(A, B, T, BC, BN)                                                        \
     {                                                                                   \
-        const int col_ = (((T) + kb) >> 3) + 1;                                         \
+        const double *next_ = s_x + LX((T) + kb) + 9;  /* entry T + kb + 8 */          \
         /* x[T+8 .. T+15] for the NEXT step: wave-uniform scalar loads, in flight during this step */ \
         _Pragma("unroll") for (int u = 0; u < 8; ++u) BN[u] = xs[(T) + 8 + u];          \
-        _Pragma("unroll") for (int j = 0; j < 8; ++j) B[j] = s_x[j * row + col_];       \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) B[j] = next_[j];                  \
         if (lim - (T) >= 15) {                                                          \
             _Pragma("unroll") for (int u = 0; u < 8; ++u)                               \
             {                                                                           \
@@ -391,21 +399,76 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 #pragma unroll
                 for (int u = 0; u < 8; ++u) b0[u] = xs[u];
                 int t = 0;
+                // Fast trips (round 2; cf. xcorr_direct_kernel). The window is a ring of 16 registers, w[i & 15] =
+                // x[kb + i]: origin o of a trip uses w[o .. o+7], after which w[o] is dead and takes the entry 16
+                // further on (one address register, immediate offsets) — 8 origins, ~550 cycles, before
+                // its first use. The operations of a half trip's FIRST origin come before its scalar request (b of
+                // the next half): they need this half's b, whose scalar load can only be waited for with lgkmcnt(0),
+                // and that wait then meets requests that are 8 origins old plus the ring reads of the origin before.
+                // (The round-1 step requested b and its 8 window entries at the top and needed them within the same
+                // step: every step paid a scalar-load latency. Three rotating window groups, as in xcorr_direct,
+                // spill here: 32 accumulators are live.)
+// (the ring loads are asm: written as plain loads the compiler gathers a half's eight reads behind its first origin
+// and waits for them on the spot. The wait for them is the one at the top of the next half — the wait asm names the
+// registers, so no use of a new value can be moved above it.)
+#define LG_WAIT8(B0)                                                                    \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                 \
+                 : "+v"(w[(B0) + 0]), "+v"(w[(B0) + 1]), "+v"(w[(B0) + 2]), "+v"(w[(B0) + 3]), "+v"(w[(B0) + 4]), \
+                   "+v"(w[(B0) + 5]), "+v"(w[(B0) + 6]), "+v"(w[(B0) + 7]))
+#define LG_HALF(O0, BC, BN, T, BNOFF)                                                   \
+    {                                                                                   \
+        LG_WAIT8(8 - (O0)); /* the reads issued during the previous half */             \
+        _Pragma("unroll") for (int o = (O0); o < (O0) + 8; ++o)                         \
+        {                                                                               \
+            double d_[LG_LPT];                                                          \
+            _Pragma("unroll") for (int m = 0; m < LG_LPT; ++m) d_[m] = w[(o + m) & 15] - BC[o - (O0)]; \
+            __builtin_amdgcn_sched_barrier(0);                                          \
+            _Pragma("unroll") for (int m = 0; m < LG_LPT; ++m)                          \
+                acc[h][m] = __builtin_fma(d_[m], d_[m], acc[h][m]);                     \
+            __builtin_amdgcn_sched_barrier(0);                                          \
+            if (o == (O0)) {                                                            \
+                _Pragma("unroll") for (int u = 0; u < 8; ++u) BN[u] = xs[(T) + (BNOFF) + u]; \
+            }                                                                           \
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(w[o]) : "v"(wt), "n"(LX(o + 16) * 8)); \
+            __builtin_amdgcn_sched_barrier(0);                                          \
+        }                                                                               \
+    }
+                {
+                    const double *wrow = s_x + LX(kb);  // LX(kb + e) = LX(kb) + LX(e): kb is a multiple of 8
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) wb[j] = wrow[9 + j];
+                    // while EVERY lane of the wave has whole 8 x 8 blocks (the lane with the largest lag runs out
+                    // first) the trips run without exec masking — the lanes whose lags nobody asked for compute on the
+                    // zero padding and are never stored; the masked steps below walk the remaining diagonal band
+                    const int t_all = n - (K0 + 63 * LG_LPT) - 15;
+                    const unsigned wrow_lds = (unsigned)(unsigned long long)wrow;  // LDS byte address
+                    for (; t + 8 <= t_all; t += 16) {
+                        const unsigned wt = wrow_lds + 144u * (unsigned)(t >> 4);  // + LX(t) * 8: t is a multiple of 16
+                        LG_HALF(0, b0, b1, t, 8)
+                        LG_HALF(8, b1, b0, t, 16)
+                    }
+                    LG_WAIT8(0);
+                    LG_WAIT8(8);
+                }
+#undef LG_WAIT8
+#undef LG_HALF
                 for (; t + 8 <= t_wave; t += 16) {
                     LG_STEP(wa, wb, t, b0, b1)
                     LG_STEP(wb, wa, t + 8, b1, b0)
                 }
                 if (t <= t_wave) LG_STEP(wa, wb, t, b0, b1)
 #undef LG_STEP
+#undef wa
+#undef wb
                 // the pairs of the last, partial blocks of every lag: < 22 origins per lane
                 {
                     const int t_stop = lim >= 15 ? ((lim - 15) / 8 + 1) * 8 : 0;
                     for (int tt = t_stop; tt < lim; ++tt) {
-                        const double bt = s_x[(tt & 7) * row + (tt >> 3)];
+                        const double bt = s_x[LX(tt)];
 #pragma unroll
                         for (int m = 0; m < LG_LPT; ++m) {
                             const int i = tt + kb + m;
-                            const double d = s_x[(i & 7) * row + (i >> 3)] - bt;
+                            const double d = s_x[LX(i)] - bt;
                             if (tt + m < lim) acc[h][m] = __builtin_fma(d, d, acc[h][m]);
                         }
                     }
@@ -423,6 +486,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 8)))
         }
     }
 }
+
+#undef LX
 
 // resident blocks per CU as the runtime computes it (registers, LDS, wave slots)
 int lag_lds_blocks_per_cu(int nw, size_t lds_b)
@@ -632,7 +697,7 @@ int mdhip_lag_msd(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double 
     // series-resident kernel: one series (+ 536 zeros so that the windows of the last tile stay inside) in LDS
     int lds_row = (int)((n_frames + 536 + 7) / 8) + 1;
     lds_row |= 1;  // odd row length: the 8 rows of the transposed layout start in different banks
-    const size_t lds_b = (size_t)8 * lds_row * 8;
+    const size_t lds_b = (size_t)(9 * lds_row + 8) * 8;  // 8 lds_row entries + one pad double per 8
     const bool resident = ctx->opt_lag_variant != 0 && lds_b <= ctx->lds_max - 1024 && n_frames < (1 << 30);
     const int r_tiles = (int)((n_lags + 64 * LG_LPT - 1) / (64 * LG_LPT));
     const int r_pairs = (r_tiles + 1) / 2;
