@@ -79,9 +79,12 @@ __global__ __launch_bounds__(MSD_THREADS) void msd_pairs_kernel(
         for (int u = 0; u < MSD_PER_THREAD / 2; ++u) {
             const long long e = ck.e0 + 2 * ((long long)u * MSD_THREADS + threadIdx.x);
             if (e + 1 < ck.e1) {
-                const double2 x1 = *reinterpret_cast<const double2 *>(r1 + e);
-                const double2 y1 = *reinterpret_cast<const double2 *>(r1 + n_ent + e);
-                const double2 z1 = *reinterpret_cast<const double2 *>(r1 + 2 * n_ent + e);
+                typedef double d2_t __attribute__((ext_vector_type(2)));
+                const d2_t x1v = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(r1 + e));
+                const d2_t y1v = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(r1 + n_ent + e));
+                const d2_t z1v = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(r1 + 2 * n_ent + e));
+                const double2 x1 = make_double2(x1v[0], x1v[1]), y1 = make_double2(y1v[0], y1v[1]),
+                              z1 = make_double2(z1v[0], z1v[1]);
                 const double2 x0 = *reinterpret_cast<const double2 *>(r0 + e);
                 const double2 y0 = *reinterpret_cast<const double2 *>(r0 + n_ent + e);
                 const double2 z0 = *reinterpret_cast<const double2 *>(r0 + 2 * n_ent + e);
@@ -153,7 +156,9 @@ __global__ __launch_bounds__(256) void msd_windows_kernel(const double *__restri
         double px = rp[e] * scale, py = rp[n_ent + e] * scale, pz = rp[2 * n_ent + e] * scale;
         for (long long k = k0; k < k1; ++k) {
             const double *rt = r + (size_t)k * tao * 3 * n_ent;
-            const double x = rt[e] * scale, y = rt[n_ent + e] * scale, z = rt[2 * n_ent + e] * scale;
+            // (streamed once: nontemporal loads, +5 % on msd_pairs_kernel build against build, tools/ab_libs_msd.py)
+            const double x = __builtin_nontemporal_load(rt + e) * scale, y = __builtin_nontemporal_load(rt + n_ent + e) * scale,
+                         z = __builtin_nontemporal_load(rt + 2 * n_ent + e) * scale;
             const double dx = x - px, dy = y - py, dz = z - pz;  // diffusion.py:232
             const double dx2 = dx * dx, dy2 = dy * dy, dz2 = dz * dz;
             s0 += dx2;

@@ -110,9 +110,10 @@ __global__ __launch_bounds__(NT) void segment_staged_kernel(
                     continue;
                 }
                 if (vec2 && ok && i + 1 < na) {
-                    const double2 t2 = *reinterpret_cast<const double2 *>(p + (size_t)kk * n_atoms + i);
-                    v[kk][2 * r] = t2.x;
-                    v[kk][2 * r + 1] = t2.y;
+                    typedef double d2_t __attribute__((ext_vector_type(2)));
+                    const d2_t t2 = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(p + (size_t)kk * n_atoms + i));
+                    v[kk][2 * r] = t2[0];
+                    v[kk][2 * r + 1] = t2[1];
                 } else {
                     v[kk][2 * r] = (ok && i < na) ? p[(size_t)kk * n_atoms + i] : 0.0;
                     v[kk][2 * r + 1] = (ok && i + 1 < na) ? p[(size_t)kk * n_atoms + i + 1] : 0.0;
