@@ -820,7 +820,7 @@ def test_rdf_and_cn_from_one_sweep(B):
     rng = np.random.default_rng(4242)
     ctx = Context(0)
     ctx.set_option("rdf_cull", 1)
-    ctx.set_option("cn_pk", 1)  # mdhip_cn_atomic through the packed sweep as well (an option, not the default)
+    ctx.set_option("cn_pk", 1)  # mdhip_cn_atomic through the packed sweep as well (the default since round 2)
     edge_table = Context(0)  # the f64 edge-table CN kernel (mdhip_cn_atomic itself now prefers the packed sweep too)
     edge_table.set_option("rdf_cull", 1)
     edge_table.set_option("cn_pk", 0)
