@@ -18,7 +18,8 @@
 //
 // fft_pass_kernel: a workgroup of 256 lanes owns a tile of C = 16 neighbouring columns (256-byte runs in HBM for the
 // loads of every pass and for the stores of every pass but the first, whose stores are runs of R points): the
-// R x C tile sits in LDS (64 KB at R = 256), the DFT is an in-place Gentleman-Sande radix-2 network over the rows
+// R x C tile sits in LDS (64 KB at R = 256), the DFT is an in-place Gentleman-Sande network over the rows, radix-4
+// butterflies in registers = two radix-2 stages per LDS round trip
 // (lanes walk the columns: consecutive 16-byte LDS words, no bank conflicts) with the R/2 roots of unity in an LDS
 // table made once per workgroup by sincospi of an EXACT argument (k/R, dyadic), and the bit-reversed row order is
 // undone by the store loop. The per-pass twiddle e^{-2 pi i jp/n} is again sincospi of an exact dyadic argument
@@ -96,17 +97,42 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass_kernel(const double2 *__
     }
     for (int t = threadIdx.x; t < (R >> 1); t += FFT_THREADS) tw[t] = root_of_unity(t, R);
     __syncthreads();
-    for (int st = 0; st < logR; ++st) {
-        const int lh = logR - 1 - st;  // log2 of the half-span
-        const int half = 1 << lh;
+    // Gentleman-Sande network over the rows, two radix-2 stages per LDS round trip (a radix-4 butterfly in registers:
+    // the same operations in the same order as the two stages one after the other, half the LDS traffic and barriers);
+    // an odd log2 R starts with one radix-2 stage.
+    int st = 0;
+    if (logR & 1) {
+        const int lh = logR - 1, half = 1 << lh;
         for (int b = threadIdx.x; b < (R >> 1 << logC); b += FFT_THREADS) {
-            const int cc = b & (C - 1), pr = b >> logC;
-            const int i = pr & (half - 1);
-            const int top = ((pr >> lh) << (lh + 1)) + i;
-            double2 *pa = buf + (top << logC) + cc, *pb = pa + (half << logC);
+            const int cc = b & (C - 1), i = b >> logC;
+            double2 *pa = buf + (i << logC) + cc, *pb = pa + (half << logC);
             const double2 a = *pa, bb = *pb;
             *pa = make_double2(a.x + bb.x, a.y + bb.y);
-            *pb = cmul(make_double2(a.x - bb.x, a.y - bb.y), tw[i << st]);
+            *pb = cmul(make_double2(a.x - bb.x, a.y - bb.y), tw[i]);
+        }
+        __syncthreads();
+        st = 1;
+    }
+    for (; st < logR; st += 2) {
+        const int lq = logR - 2 - st;  // log2 of the quarter-span q
+        const int q = 1 << lq;
+        for (int b = threadIdx.x; b < (R >> 2 << logC); b += FFT_THREADS) {
+            const int cc = b & (C - 1), pr = b >> logC;
+            const int i = pr & (q - 1);
+            const int i0 = ((pr >> lq) << (lq + 2)) + i;
+            double2 *p0 = buf + (i0 << logC) + cc, *p1 = p0 + (q << logC), *p2 = p1 + (q << logC), *p3 = p2 + (q << logC);
+            const double2 x0 = *p0, x1 = *p1, x2 = *p2, x3 = *p3;
+            // stage st (half-span 2q): (x0, x2) with W_4q^i, (x1, x3) with W_4q^(i+q)
+            const double2 a0 = make_double2(x0.x + x2.x, x0.y + x2.y);
+            const double2 a2 = cmul(make_double2(x0.x - x2.x, x0.y - x2.y), tw[i << st]);
+            const double2 a1 = make_double2(x1.x + x3.x, x1.y + x3.y);
+            const double2 a3 = cmul(make_double2(x1.x - x3.x, x1.y - x3.y), tw[(i + q) << st]);
+            // stage st + 1 (half-span q): (a0, a1) and (a2, a3), both with W_2q^i
+            const double2 w2 = tw[i << (st + 1)];
+            *p0 = make_double2(a0.x + a1.x, a0.y + a1.y);
+            *p1 = cmul(make_double2(a0.x - a1.x, a0.y - a1.y), w2);
+            *p2 = make_double2(a2.x + a3.x, a2.y + a3.y);
+            *p3 = cmul(make_double2(a2.x - a3.x, a2.y - a3.y), w2);
         }
         __syncthreads();
     }
