@@ -281,6 +281,27 @@ def test_msd_pairs_column_layout_equals_row_layout(B, E):
     np.testing.assert_array_equal(tight, cols)
     with pytest.raises(ValueError):
         B.msd_pairs_cols(r, pairs, goff, np.empty((4, 3)), scale=1.0)
+    # device-resident columns with a stride (the C-ABI's cols_on_device form), device-resident input
+    import ctypes as C
+
+    import torch
+
+    from mdproptools_amd._lib import default_context, ptr
+
+    ctx = default_context()
+    n_col = len(pairs) * E
+    dcols = torch.full((4, n_col + 3), -1.0, dtype=torch.float64, device="cuda")
+    rd = torch.from_numpy(r).cuda()
+    pr = np.asarray(pairs, dtype=np.int32)
+    go = np.asarray(goff, dtype=np.int64)
+    sums_d = np.zeros((len(pairs), len(goff) - 1, 4))
+    ctx.check(ctx.lib.mdhip_msd_pairs_cols(ctx.h, F, E, C.c_void_p(rd.data_ptr()), 1, 1e-10, len(pairs), ptr(pr, C.c_int32),
+                                           len(goff) - 1, ptr(go, C.c_int64), ptr(sums_d), C.c_void_p(dcols.data_ptr()),
+                                           n_col + 3, 1))
+    np.testing.assert_array_equal(sums_d, sums)
+    got = dcols.cpu().numpy()
+    np.testing.assert_array_equal(got[:, :n_col], cols)
+    assert (got[:, n_col:] == -1).all()
 
 
 def test_segment_com_ragged_and_long_segments(B):
