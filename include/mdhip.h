@@ -302,6 +302,9 @@ int mdhip_cumtrapz(mdhip_ctx *ctx, int64_t n, int n_series, const double *y, int
  * bounce buffers. MDHIP_ENODEV without a usable HIP runtime.
  */
 int mdhip_host_alloc(size_t bytes, void **out);
+/* The same from a thread that has made no HIP call yet (a reader thread): `device` is made the thread's current device
+ * first, so that a rank bound to GPU k does not open a context on GPU 0; device < 0 = whatever is current. */
+int mdhip_host_alloc_on(int device, size_t bytes, void **out);
 void mdhip_host_free(void *p);
 
 /* ---- I/O: native LAMMPS text-dump reader (host only, no GPU needed) ---------------------------- */

@@ -37,6 +37,7 @@ PROTOTYPES = {
     "mdhip_last_rel_bound": (C.c_double, [vp]),
     "mdhip_device_name": (C.c_int, [vp, C.c_char_p, C.c_int]),
     "mdhip_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(vp)]),
+    "mdhip_host_alloc_on": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(vp)]),
     "mdhip_host_free": (None, [vp]),
     "mdhip_set_option": (C.c_int, [vp, C.c_char_p, C.c_int]),
     "mdhip_bin_edges": (C.c_int, [C.c_double, C.c_int, c_dp]),

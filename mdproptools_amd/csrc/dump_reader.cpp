@@ -263,6 +263,12 @@ int64_t parse_lines(const char *p, const char *end, int64_t n_lines, int n_cols,
                 ++bad;
                 break;
             }
+            if (slot[c] < 0 && c != key_col) {
+                // a column nobody asked for may hold text (`element`, pandas reads it as an object column and the
+                // reference never touches it): skip the token, numeric or not
+                while (q < le && *q != ' ' && *q != '\t' && *q != '\r') ++q;
+                continue;
+            }
             const char ch = *q;
             if (!((ch >= '0' && ch <= '9') || ch == '-' || ch == '+' || ch == '.' || ch == 'n' || ch == 'N' || ch == 'i' ||
                   ch == 'I'))

@@ -32,7 +32,8 @@
 namespace {
 
 constexpr int FFT_THREADS = 256;
-constexpr int FFT_MAX_LOGR = 8;  // R <= 256
+constexpr int FFT_MAX_LOGR = 10;   // largest radix of a pass the `fft_logr` knob may ask for (default 8: R <= 256, 64 KB tiles)
+constexpr int FFT_MAX_PASSES = 8;  // PassPlan::logR slots: H <= 2^32 at the smallest allowed radix, 2^4
 constexpr int FFT_LOGC = 4;      // C = 16 columns per tile
 constexpr int FFT_MAX_BATCH = 32768;  // series per launch (grid.y)
 
@@ -255,16 +256,22 @@ __global__ void conj_copy_kernel(const double2 *__restrict__ in, double2 *__rest
 
 struct PassPlan {
     int n_pass = 0;
-    int logR[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int logR[FFT_MAX_PASSES] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 PassPlan plan_passes(const mdhip_ctx *ctx, long long H)
 {
     int logH = 0;
     while ((1LL << logH) < H) ++logH;
-    const int max_logr = std::min(std::max(ctx->opt_fft_logr, 4), 10);
+    int max_logr = std::min(std::max(ctx->opt_fft_logr, 4), FFT_MAX_LOGR);
+    // a one-column tile of the radix (R + R/2 complex points) must fit the CU's LDS
+    while (max_logr > 4 && ((size_t)24 << max_logr) > ctx->lds_max) --max_logr;
     PassPlan p;
     p.n_pass = (logH + max_logr - 1) / max_logr;
+    if (p.n_pass > FFT_MAX_PASSES) {  // H > 2^32 at radix 16: no caller gets here (xcorr caps n at 2^29)
+        p.n_pass = -1;
+        return p;
+    }
     for (int i = 0, left = logH; i < p.n_pass; ++i) {
         p.logR[i] = (left + (p.n_pass - i) - 1) / (p.n_pass - i);  // as even as possible, larger radices first
         left -= p.logR[i];
@@ -273,7 +280,7 @@ PassPlan plan_passes(const mdhip_ctx *ctx, long long H)
 }
 
 template <int IN, int OUT>
-void launch_pass(mdhip_ctx *ctx, const double2 *in, double2 *out, long long H, int batch, int logR, int logS,
+bool launch_pass(mdhip_ctx *ctx, const double2 *in, double2 *out, long long H, int batch, int logR, int logS,
                  const PassIo &io)
 {
     const long long cols = H >> logR;
@@ -283,19 +290,29 @@ void launch_pass(mdhip_ctx *ctx, const double2 *in, double2 *out, long long H, i
     while ((1LL << logC) > cols) --logC;
     const size_t lds = ((size_t)(1 << logR << logC) + (size_t)(1 << logR >> 1)) * sizeof(double2);
     const dim3 grid((unsigned)(cols >> logC), (unsigned)batch);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fft_pass_kernel<IN, OUT>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fft_pass_kernel<IN, OUT>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+        mdhip_fail(ctx, MDHIP_EHIP, "fft pass of radix 2^%d needs %zu bytes of LDS: %s", logR, lds, hipGetErrorString(e));
+        return false;
+    }
     hipLaunchKernelGGL((fft_pass_kernel<IN, OUT>), grid, dim3(FFT_THREADS), lds, ctx->stream, in, out, H, logR, logC,
                        logS, H >> logS, io);
+    return true;
 }
 
 // FFT_H of `batch` series. The passes alternate between the two buffers; returns the buffer that holds the result
-// (x after an even number of passes, y after an odd one). x is overwritten. in_mode IN_PAD: the first pass reads
-// io.series instead of x; out_mode OUT_LAGS: the last pass writes io.lags instead of a buffer.
+// (x after an even number of passes, y after an odd one), nullptr when a pass could not be launched (error set).
+// x is overwritten. in_mode IN_PAD: the first pass reads io.series instead of x; out_mode OUT_LAGS: the last pass
+// writes io.lags instead of a buffer.
 double2 *fft_forward(mdhip_ctx *ctx, double2 *x, double2 *y, long long H, int batch, int in_mode, int out_mode,
                      const PassIo &io)
 {
     const PassPlan p = plan_passes(ctx, H);
+    if (p.n_pass < 0) {
+        mdhip_fail(ctx, MDHIP_ELIMIT, "transform of %lld complex points needs more than %d passes", H, FFT_MAX_PASSES);
+        return nullptr;
+    }
     if (p.n_pass == 0) {  // H = 1: the transform is the identity (plain buffers only)
         if (out_mode == OUT_CONJ)
             hipLaunchKernelGGL(conj_copy_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, ctx->stream, x, y,
@@ -306,10 +323,12 @@ double2 *fft_forward(mdhip_ctx *ctx, double2 *x, double2 *y, long long H, int ba
     int s = 0;  // log2 of the product of the radices done
     for (int i = 0; i < p.n_pass; ++i) {
         const int im = i == 0 ? in_mode : IN_PLAIN, om = i == p.n_pass - 1 ? out_mode : OUT_PLAIN;
-        if (im == IN_PAD && om == OUT_PLAIN) launch_pass<IN_PAD, OUT_PLAIN>(ctx, src, dst, H, batch, p.logR[i], s, io);
-        else if (im == IN_PLAIN && om == OUT_LAGS) launch_pass<IN_PLAIN, OUT_LAGS>(ctx, src, dst, H, batch, p.logR[i], s, io);
-        else if (im == IN_PLAIN && om == OUT_CONJ) launch_pass<IN_PLAIN, OUT_CONJ>(ctx, src, dst, H, batch, p.logR[i], s, io);
-        else launch_pass<IN_PLAIN, OUT_PLAIN>(ctx, src, dst, H, batch, p.logR[i], s, io);
+        bool ok;
+        if (im == IN_PAD && om == OUT_PLAIN) ok = launch_pass<IN_PAD, OUT_PLAIN>(ctx, src, dst, H, batch, p.logR[i], s, io);
+        else if (im == IN_PLAIN && om == OUT_LAGS) ok = launch_pass<IN_PLAIN, OUT_LAGS>(ctx, src, dst, H, batch, p.logR[i], s, io);
+        else if (im == IN_PLAIN && om == OUT_CONJ) ok = launch_pass<IN_PLAIN, OUT_CONJ>(ctx, src, dst, H, batch, p.logR[i], s, io);
+        else ok = launch_pass<IN_PLAIN, OUT_PLAIN>(ctx, src, dst, H, batch, p.logR[i], s, io);
+        if (!ok) return nullptr;
         s += p.logR[i];
         std::swap(src, dst);
     }
@@ -335,6 +354,7 @@ int mdhip_fft_r2c(mdhip_ctx *ctx, double *d_real, double2 *d_tmp, double2 *d_spe
         return MDHIP_OK;
     }
     double2 *Z = fft_forward(ctx, reinterpret_cast<double2 *>(d_real), d_tmp, H, batch, IN_PLAIN, OUT_PLAIN, PassIo{});
+    if (!Z) return MDHIP_EHIP;
     hipLaunchKernelGGL(r2c_post_kernel, dim3((unsigned)((H / 2 + 1 + 255) / 256), (unsigned)batch), dim3(256), 0,
                        ctx->stream, Z, d_spec, H);
     MD_HIP(hipGetLastError());
@@ -356,6 +376,7 @@ int mdhip_fft_c2r(mdhip_ctx *ctx, const double2 *d_spec, double2 *d_tmp, double 
         return MDHIP_OK;
     }
     const PassPlan p = plan_passes(ctx, H);
+    MD_REQUIRE(p.n_pass >= 0, "transform length %lld needs more than %d passes", L, FFT_MAX_PASSES);
     // the result must land in d_real: start in d_real for an even number of buffer hops, in d_tmp for an odd one
     // (H = 1: one hop, the conjugating copy)
     const int hops = p.n_pass == 0 ? 1 : p.n_pass;
@@ -366,6 +387,7 @@ int mdhip_fft_c2r(mdhip_ctx *ctx, const double2 *d_spec, double2 *d_tmp, double 
     // W = conj Y went in; y = conj FFT(W): conjugate on the way out. c[2j] = Re y[j], c[2j+1] = Im y[j]: the complex
     // result read as reals IS the series.
     double2 *res = fft_forward(ctx, first, second, H, batch, IN_PLAIN, OUT_CONJ, PassIo{});
+    if (!res) return MDHIP_EHIP;
     MD_HIP(hipGetLastError());
     if (res != real_c) return mdhip_fail(ctx, MDHIP_EHIP, "internal: inverse transform landed in the wrong buffer");
     return MDHIP_OK;
@@ -386,11 +408,13 @@ int mdhip_fft_xcorr(mdhip_ctx *ctx, const double *d_a, const double *d_b, long l
     io.n = n;
     io.series = d_a;
     double2 *Za = fft_forward(ctx, buf0, buf1, H, batch, IN_PAD, OUT_PLAIN, io);
+    if (!Za) return MDHIP_EHIP;
     double2 *Zb = Za;
     const bool same = d_a == d_b;
     if (!same) {
         io.series = d_b;
         Zb = fft_forward(ctx, buf2, buf3, H, batch, IN_PAD, OUT_PLAIN, io);
+        if (!Zb) return MDHIP_EHIP;
     }
     const dim3 grid((unsigned)((H / 2 + 1 + 255) / 256), (unsigned)batch);
     if (same)
@@ -400,7 +424,7 @@ int mdhip_fft_xcorr(mdhip_ctx *ctx, const double *d_a, const double *d_b, long l
     io.lags = d_lags;
     io.n_lags = n_lags;
     io.L = (double)L;
-    (void)fft_forward(ctx, Za, Za == buf0 ? buf1 : buf0, H, batch, IN_PLAIN, OUT_LAGS, io);
+    if (!fft_forward(ctx, Za, Za == buf0 ? buf1 : buf0, H, batch, IN_PLAIN, OUT_LAGS, io)) return MDHIP_EHIP;
     MD_HIP(hipGetLastError());
     return MDHIP_OK;
 }

@@ -167,16 +167,23 @@ double mdhip_last_aux_ms(mdhip_ctx *ctx) { return ctx ? ctx->last_aux_ms : 0.0; 
 const char *mdhip_last_kernel_name(mdhip_ctx *ctx) { return ctx ? ctx->last_kernel : ""; }
 double mdhip_last_rel_bound(mdhip_ctx *ctx) { return ctx ? ctx->last_rel_bound : 0.0; }
 
-int mdhip_host_alloc(size_t bytes, void **out)
+int mdhip_host_alloc_on(int device, size_t bytes, void **out)
 {
     if (!out) return MDHIP_EINVAL;
     *out = nullptr;
     if (bytes == 0) return MDHIP_OK;
+    // the calling thread may be a reader thread that never touched HIP: its current device would be 0 whatever GPU
+    // the process (one rank per GPU) works on, and the allocation would open a context there
+    if (device >= 0 && hipSetDevice(device) != hipSuccess) {
+        (void)hipGetLastError();
+        return MDHIP_ENODEV;
+    }
     void *p = nullptr;
     // non-coherent = ordinary cached host memory that is page-locked: the reader threads scatter 8-byte values into
     // it (fine-grained coherent host memory is uncached for the CPU on this platform: that scatter ran 4x slower), and
-    // the only consumer is an explicit hipMemcpyAsync, which needs no CPU/GPU coherence
-    const hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocNonCoherent);
+    // the only consumer is an explicit hipMemcpyAsync, which needs no CPU/GPU coherence. Portable: page-locked for
+    // every device of the process, not only for the one that was current at the time.
+    const hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocNonCoherent | hipHostMallocPortable);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         return e == hipErrorOutOfMemory ? MDHIP_ENOMEM : MDHIP_ENODEV;
@@ -184,6 +191,8 @@ int mdhip_host_alloc(size_t bytes, void **out)
     *out = p;
     return MDHIP_OK;
 }
+
+int mdhip_host_alloc(size_t bytes, void **out) { return mdhip_host_alloc_on(-1, bytes, out); }
 
 void mdhip_host_free(void *p)
 {

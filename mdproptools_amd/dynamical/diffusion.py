@@ -169,7 +169,10 @@ class Diffusion:
         device destination), so only [F,3,M] stays. None when the dumps need the general route (wrapped coordinates
         to unwrap, compressed text, a column missing — whose error the general route raises in the reference's
         words)."""
-        import torch
+        try:
+            import torch
+        except ImportError:  # libmdhip.so runs on the system ROCm runtime without torch (_lib.py): general route
+            return None
 
         from .. import dist as D
         from .. import io as mio

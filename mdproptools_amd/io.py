@@ -283,8 +283,9 @@ class NativeDumpFile:
 
 
 def _pandas_file_frames(fname, columns, sort_by):
-    """The frames of one file through the pandas route, in the tuple form of the native route (compressed files,
-    and files whose rows the native reader refuses: pandas' behaviour for them is then the reference's)."""
+    """The frames of one file through the pandas route, in the tuple form of the native route (compressed files).
+    Rows the native reader refuses — short, blank, or a non-numeric token in a REQUESTED column — are an error there,
+    not a reason to come here; text in columns nobody asked for (`element`) is skipped by the native reader."""
     out = []
     for frame in _iter_frames(fname):
         d = LammpsDump.from_lines(frame)

@@ -30,10 +30,27 @@ DEFAULT_BATCH_BYTES = 24 << 20  # coordinates per batch (100 frames of 10k atoms
 DEFAULT_DEPTH = 3               # staging buffers in the ring
 
 
+def _rank_device():
+    """The GPU this process works on (one rank per GPU: LOCAL_RANK, wrapped when ranks share a card). The staging
+    buffers are allocated from reader threads, whose current HIP device would otherwise be 0 on every rank."""
+    import os
+
+    dev = int(os.environ.get("LOCAL_RANK", "0"))
+    try:
+        import torch
+
+        n = torch.cuda.device_count()
+        if n > 0:
+            dev %= n
+    except Exception:
+        pass
+    return dev
+
+
 class _Pinned:
     """A page-locked float64 buffer from libmdhip.so (falls back to pageable numpy memory without a HIP runtime)."""
 
-    def __init__(self, n_doubles):
+    def __init__(self, n_doubles, device=None):
         self.ptr = None
         self.lib = None
         self.array = None
@@ -42,7 +59,8 @@ class _Pinned:
 
             lib = _lib.load()
             p = C.c_void_p()
-            if lib.mdhip_host_alloc(C.c_size_t(n_doubles * 8), C.byref(p)) == 0 and p.value:
+            dev = _rank_device() if device is None else int(device)
+            if lib.mdhip_host_alloc_on(dev, C.c_size_t(n_doubles * 8), C.byref(p)) == 0 and p.value:
                 self.ptr, self.lib = p, lib
                 self.array = np.ctypeslib.as_array((C.c_double * n_doubles).from_address(p.value))
         except Exception:
@@ -331,6 +349,12 @@ class FrameStream:
             self._thread.join(timeout=0.05)
             if not self._thread.is_alive() or time.perf_counter() > deadline:
                 break
+        if self._thread is not None and self._thread.is_alive():
+            # parse tasks that were already submitted may still be scattering values into the staging buffers (a
+            # slow file system, very large frames): the buffers are LEAKED — neither unpinned nor handed to the next
+            # stream — rather than freed under a writer
+            self._bufs = []
+            return
         for b in self._bufs:
             _give_back(b)
         self._bufs = []
