@@ -16,6 +16,15 @@ synthetic frames that are already resident in HBM.
                             contiguously over the ranks (1000/N frames each).
 For N > 1 the frame-summed uint64 histograms are all-reduced over RCCL in every step, inside the timed region.
 
+  --workload c4             BASELINE.json configs[3], C4 — 50 000 entities x 5000 frames of an unwrapped random walk —
+                            as the headline, in frame-pairs/s, STRONG scaling: the 5000 frames are dealt to the ranks
+                            for the reference's single-origin MSD (origin frame broadcast, [F_local][G][4] all-gathered;
+                            dynamical/diffusion.py:212-218) and its fixed-lag windows (one-frame halo, [E][4] all-reduced;
+                            diffusion.py:225-237), the 50 000 entities for the full lag x origin average (no exchange in,
+                            [F][G][4] all-reduced). Every collective runs on device buffers, inside the timed region.
+The default line carries the same measurement as the object `msd` (fewer steps), so that one run per N gives both halves
+of BASELINE.json's metric: atom-pairs/s (RDF) and frame-pairs/s (MSD).
+
 Rank 0 prints ONE JSON line. Beside the contract's keys it carries (N = 1 only, all measured in this run):
   roofline        the dominant kernel against the VALU-issue roof MEASURED for its instruction mix
                   (profiles/r02_ubench_valu.json), HBM traffic from the committed PMC run
@@ -554,13 +563,148 @@ def leg_c5(B, ctx, torch, device, synth, sync):
                              "direct_extrapolated_s": cpu_dir * sp}}
 
 
+def lib_build_id(ctx):
+    """Which code produced the numbers: the id compiled into the shipped libmdhip.so (hash of the sources it was built
+    from) next to the hash of the sources present, and whether they agree."""
+    from mdproptools_amd import build as bld
+
+    try:
+        lib = (ctx.lib.mdhip_build_id() or b"").decode()
+    except Exception:
+        lib = "unknown"
+    src = bld.source_id()
+    return {"library": lib, "sources": src, "match": lib == src}
+
+
+def c4_shards(torch, device, synth, rank, world, D, E=50_000, F=5000, block=250):
+    """BASELINE C4 (unwrapped random walk, sigma 0.1 A per frame, r(0) uniform in L = 82.8 A) as this rank's two
+    shards of ONE trajectory: its contiguous frames [F_local,3,E] and its contiguous entities [F,3,E_local]. Every rank
+    generates the whole walk block by block from the same per-block seeds on its own GPU (identical bits on identical
+    GPUs) and keeps what is its own, so the problem does not depend on the number of ranks."""
+    lo, hi = D.frame_shard(F, rank, world)
+    e_lo, e_hi = D.entity_shard(E, rank, world)
+    r_f = torch.empty((hi - lo, 3, E), dtype=torch.float64, device=device)
+    r_e = torch.empty((F, 3, e_hi - e_lo), dtype=torch.float64, device=device)
+    g = torch.Generator(device=device)
+    g.manual_seed(synth.BASE_SEED + 4)
+    last = torch.rand((3, E), generator=g, device=device, dtype=torch.float64) * 82.8
+    for f0 in range(0, F, block):
+        f1 = min(F, f0 + block)
+        g.manual_seed(synth.BASE_SEED + 4 + 1000 * (1 + f0 // block))
+        st = torch.randn((f1 - f0, 3, E), generator=g, device=device, dtype=torch.float64) * 0.1
+        if f0 == 0:
+            st[0] = 0.0  # frame 0 is r(0) itself
+        blk = last + torch.cumsum(st, dim=0)
+        del st
+        last = blk[-1].clone()
+        r_e[f0:f1] = blk[:, :, e_lo:e_hi]
+        a, b = max(f0, lo), min(f1, hi)
+        if b > a:
+            r_f[a - lo:b - lo] = blk[a - f0:b - f0]
+        del blk
+    return r_f, r_e, (lo, hi), (e_lo, e_hi)
+
+
+def msd_sharded(torch, dist, D, B, ctx, device, synth, rank, world, backend, steps, warmup, fence):
+    """
+    BASELINE.json configs[3] on `world` GPUs, strong scaling. One step =
+      single origin   (diffusion.py:212-218) frames dealt to the ranks: origin frame broadcast (24 E bytes), every rank
+                      reduces its (origin, t) pairs (msd_pairs_kernel), [F_local][G][4] all-gathered     F frame pairs
+      fixed lag tao=4 (diffusion.py:225-237) the same frames: one-frame halo from the rank below (all-gather of one
+                      frame per rank), msd_windows_kernel, [E][4] all-reduced                            F/4 frame pairs
+      full lag        (superset) ENTITIES dealt to the ranks: every rank all lags of its entities (default path:
+                      autocorrelation theorem, msd_power_lds_kernel), [F][G][4] sums all-reduced         F(F-1)/2 frame pairs
+    The collectives run on the device buffers the kernels wrote (RCCL; gloo stages through the host) and are inside
+    the timed region; every call returns its result to the host (one small D2H each).
+    """
+    E, F, tao = 50_000, 5000, 4
+    r_f, r_e, (lo, hi), (e_lo, e_hi) = c4_shards(torch, device, synth, rank, world, D, E, F)
+    goff = [0, E]
+    res, t_part, k_ms = {}, {"single": 0.0, "fixed": 0.0, "lag": 0.0}, {"single": [], "fixed": [], "lag": []}
+
+    def one_step(timed):
+        t0 = time.perf_counter()
+        res["single"] = D.msd_single_origin_sharded(r_f, F, goff, scale=1e-10, origin_frame=0, ctx=ctx)
+        k1 = ctx.last_kernel_ms()[0]
+        t1 = time.perf_counter()
+        res["fixed"] = D.msd_windows_sharded(r_f, F, tao, scale=1e-10, ctx=ctx)
+        k2 = ctx.last_kernel_ms()[0]
+        t2 = time.perf_counter()
+        res["lag"] = D.lag_msd_sharded(r_e, (e_lo, e_hi), F - 1, goff, scale=1.0, ctx=ctx)
+        k3 = ctx.last_kernel_ms()[0]
+        t3 = time.perf_counter()
+        if timed:
+            for key, dt, km in (("single", t1 - t0, k1), ("fixed", t2 - t1, k2), ("lag", t3 - t2, k3)):
+                t_part[key] += dt
+                k_ms[key].append(km)
+
+    for _ in range(max(1, warmup)):
+        one_step(False)
+    lag_kernel = ctx.last_kernel_name()
+    bound = ctx.last_rel_bound()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    parts = [t_part["single"], t_part["fixed"], t_part["lag"], elapsed]
+    if world > 1:  # max over ranks, of the step and of its three parts
+        tmax = torch.tensor(parts, dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        parts = [float(v) for v in tmax.tolist()]
+    t_single, t_fixed, t_lag, elapsed = parts
+    # sanity inside the bench: a random walk's MSD is 3 sigma^2 t; the longest lag has ONE origin, frame 0, so the
+    # full-lag path (entity shards, all-reduce) and the single-origin path (frame shards, all-gather) must agree on it
+    msd_last = res["single"][-1, 0, 3] / E / 1e-20
+    assert abs(msd_last / (3 * 0.01 * (F - 1)) - 1.0) < 0.02, msd_last
+    np.testing.assert_allclose(res["lag"][F - 1, 0, :], res["single"][F - 1, 0, :] / E / 1e-20, rtol=1e-9)
+    n_kept = len(range(0, F, tao))
+    np.testing.assert_allclose(res["fixed"][:, 3].mean() / (n_kept - 1) / 1e-20, 3 * 0.01 * tao, rtol=0.02)
+    fp_single, fp_fixed, fp_lag = float(F), float(n_kept - 1), F * (F - 1) / 2.0
+    k_single = float(np.mean(k_ms["single"])) * 1e-3
+    out = {
+        "value": (fp_single + fp_fixed + fp_lag) * steps / elapsed, "unit": "frame-pairs/s",
+        "ms_per_step": elapsed / steps * 1e3, "steps": steps, "scaling": "strong",
+        "single_origin": {"frame_pairs": fp_single, "ms": t_single / steps * 1e3, "value": fp_single * steps / t_single,
+                          "unit": "frame-pairs/s", "kernel_ms_rank0": k_single * 1e3},
+        "fixed_lag_tao4": {"frame_pairs": fp_fixed, "ms": t_fixed / steps * 1e3, "value": fp_fixed * steps / t_fixed,
+                           "unit": "frame-pairs/s", "kernel_ms_rank0": float(np.mean(k_ms["fixed"]))},
+        "full_lag": {"frame_pairs": fp_lag, "ms": t_lag / steps * 1e3, "value": fp_lag * steps / t_lag,
+                     "unit": "frame-pairs/s", "kernel": lag_kernel, "kernel_ms_rank0": float(np.mean(k_ms["lag"])),
+                     "reported_rel_bound": bound},
+        "checks": "MSD(t_last) = 3 sigma^2 t within 2 %; full-lag(F-1) == single-origin(F-1) (rtol 1e-9) across the two "
+                  "shardings; fixed-lag mean = 3 sigma^2 tao within 2 %",
+        "config": {"workload": "C4: 50k entities x 5000 frames unwrapped random walk, ONE trajectory on %d GPU(s): frames "
+                               "dealt to the ranks for single-origin + fixed-lag (tao 4) MSD, entities for the full "
+                               "lag x origin average" % world,
+                   "frames_per_gpu": hi - lo, "entities_per_gpu": e_hi - e_lo,
+                   "frame_pairs_per_step": fp_single + fp_fixed + fp_lag},
+        "collectives": {"backend": dist.get_backend() if world > 1 else None,
+                        "world_size": dist.get_world_size() if world > 1 else 1,
+                        "per_step": "broadcast 24 E B; all_gather [F_local,1,4] f64; all_gather 1 frame per rank; "
+                                    "all_reduce [E,4] f64; all_reduce [F,1,4] f64 — all on device buffers"},
+        # the HBM-bound kernel of the step, this rank's launch: 24 E bytes per frame pair (SURVEY.md 8d)
+        "roofline": {"bound": "hbm", "kernel": "msd_pairs_kernel", "achieved": 24.0 * E * (hi - lo) / k_single / 1e9,
+                     "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": 24.0 * E * (hi - lo) / k_single / HBM_PEAK,
+                     "traffic": None, "launch_ms": k_single * 1e3},
+    }
+    del r_f, r_e
+    torch.cuda.empty_cache()
+    return out
+
+
 # ------------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="rdf: weak (default) = C2 on every rank, strong = C3 split; c4 is always strong")
+    ap.add_argument("--workload", choices=["rdf", "c4"], default="rdf",
+                    help="rdf: the pair histogram (atom-pairs/s); c4: sharded MSD of BASELINE configs[3] (frame-pairs/s)")
+    ap.add_argument("--msd-steps", type=int, default=5, help="timed steps of the `msd` object of the default line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="headline only (profiling runs)")
     ap.add_argument("--legs", default="parity,f64,h2d,c3,c4,c5")
@@ -570,6 +714,10 @@ def main():
     ap.add_argument("--op", choices=["rdf", "cn", "rdf_cn"], default="rdf",
                     help="what the headline loop calls (profiling runs of the CN and the one-sweep kernels; N = 1)")
     args = ap.parse_args()
+    if args.scaling is None:
+        args.scaling = "strong" if args.workload == "c4" else "weak"
+    if args.workload == "c4" and args.scaling != "strong":
+        ap.error("--workload c4 is a strong-scaling workload (BASELINE configs[3]: one C4 trajectory on 1..8 GPUs)")
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn(args)
@@ -609,6 +757,28 @@ def main():
     for kv in args.option:
         k, v = kv.split("=")
         ctx.set_option(k, int(v))
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.workload == "c4":
+        m = msd_sharded(torch, dist, D, B, ctx, device, synth, rank, world, backend, args.steps, args.warmup, fence)
+        if rank == 0:
+            out = {"metric": "frame-pairs/s", "value": m["value"], "unit": "frame-pairs/s", "n_gpus": world,
+                   "steps": args.steps, "warmup": args.warmup, "ms_per_step": m["ms_per_step"],
+                   "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+                   "data": "synthetic", "config": m.pop("config"), "lib_build_id": lib_build_id(ctx)}
+            out["config"]["collectives"] = m.pop("collectives")
+            out["roofline"] = m.pop("roofline")
+            out["msd"] = m
+            print(json.dumps(out))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     strong = args.scaling == "strong"
     cfg = synth.rdf_config("C3" if strong else "C2")
@@ -654,12 +824,6 @@ def main():
             return _Done((f_, p_, [o_]))
         return D.rdf_sharded_async(xyz, types, box, rel, cfg["r_cut"], cfg["bin_size"], nb, ctx=ctx)
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for _ in range(args.warmup):
         step().wait()
     fence()
@@ -692,6 +856,13 @@ def main():
         assert abs(frac_in - expect_in) < 0.01 * expect_in, (frac_in, expect_in)
     if args.op != "rdf":
         args.no_legs = True  # a profiling run
+    msd_obj = None
+    if args.op == "rdf" and not args.no_legs and args.msd_steps > 0:
+        # the MSD half of BASELINE.json's metric, same sharding at every N (every rank takes part: before rank 0 goes on alone)
+        try:
+            msd_obj = msd_sharded(torch, dist, D, B, ctx, device, synth, rank, world, backend, args.msd_steps, 1, fence)
+        except Exception as e:  # must not lose the headline
+            msd_obj = {"error": repr(e)}
 
     if rank == 0:
         value = pairs_job * args.steps / elapsed
@@ -714,6 +885,11 @@ def main():
                                       kdur, "mix bin 11/16", 6, pairs_local, 28.0 * n * F),
         }
         out["roofline"]["prepass_ms_per_step"] = aux_ms / args.steps
+        out["lib_build_id"] = lib_build_id(ctx)
+        if world > 1:
+            out["config"]["collectives"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size()}
+        if msd_obj is not None:
+            out["msd"] = msd_obj
         legs = [] if (args.no_legs or world > 1 or strong) else args.legs.split(",")
         sync = torch.cuda.synchronize
         oracle_frames = []
@@ -745,6 +921,7 @@ def main():
         if "f64" in legs:
             run_leg("f64_only", lambda: leg_f64_only(B, ctx, xyz, types, box, rel, cfg, nb, max(5, args.steps // 2),
                                                      pairs_local, full, sync))
+            out["f64_value"] = out["f64_only"].get("value")  # (short top-level key: survives a truncated tail)
         if "h2d" in legs:
             run_leg("h2d_inclusive", lambda: leg_h2d(B, ctx, torch, xyz_host, types, box, rel, cfg, nb,
                                                      max(5, args.steps // 2), pairs_local, sync,

@@ -14,7 +14,9 @@
  *  - "host|dev" inputs: the big per-frame planes may live in host memory
  *    (the library stages them) or already in device memory (flag `on_device`);
  *    small tables (relations, cutoffs, offsets, boxes) are always host
- *    pointers; results are always written to host pointers;
+ *    pointers; results are written to host pointers, except by the entry points
+ *    named *_dev, which write the same values to a DEVICE buffer of the caller
+ *    (one process per GPU: the multi-GPU layer hands that buffer to RCCL);
  *  - calls are synchronous on the context's stream: results are complete when
  *    the call returns. One context per thread; contexts are independent;
  *  - there is NO CPU fallback: without a usable HIP device mdhip_create fails.
@@ -33,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MDHIP_VERSION 200 /* 0.2.0: + mdhip_rdf_cn_atomic, mdhip_rdf_atomic_dev, mdhip_xcorr_lags, mdhip_host_alloc/free, mdhip_dump_read_cols */
+#define MDHIP_VERSION 300 /* 0.3.0: + the *_dev result variants of the sharded paths (cn, msd_pairs, msd_windows, lag_msd, charge_flux, xcorr_lags), mdhip_host_alloc_on, mdhip_build_id */
 
 #define MDHIP_OK 0
 #define MDHIP_EINVAL (-1)  /* bad argument (shape, NULL, unsupported size) */
@@ -65,6 +67,9 @@ const char *mdhip_last_kernel_name(mdhip_ctx *ctx);
 /* Estimated relative rounding-error bound of the last mdhip_lag_msd call when it was answered by the FFT
  * path (lag_variant 2 or 3); 0 when the exact-difference kernel answered. */
 double mdhip_last_rel_bound(mdhip_ctx *ctx);
+/* Identity of the BUILD: sha256 (first 16 hex digits) of the sources the library was compiled from, as the build
+ * recipe computed it (mdproptools_amd/build.py); "unknown" for a library built by other means. bench.py prints it. */
+const char *mdhip_build_id(void);
 /* Writes the device name (e.g. "gfx950...") into buf. */
 int mdhip_device_name(mdhip_ctx *ctx, char *buf, int buflen);
 /* Kernel organisation knobs, for A/B measurements only; results never depend on them. Keys:
@@ -153,6 +158,12 @@ int mdhip_cn_atomic(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const dou
                     const double *box, int n_rel, const int32_t *rel, const double *r_cut_sq,
                     int per_frame, uint64_t *cn);
 
+/* mdhip_cn_atomic with per_frame = 0 and the n_rel counts written to a DEVICE buffer (all-reduced over RCCL by
+ * mdproptools_amd/dist.py: cn_sharded). cn_dev: device uint64 [n_rel]. */
+int mdhip_cn_atomic_dev(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *xyz, int on_device,
+                        const int32_t *type, int64_t type_frame_stride, const double *box, int n_rel,
+                        const int32_t *rel, const double *r_cut_sq, uint64_t *cn_dev);
+
 /* ---- R3 + R4 in one sweep ------------------------------------------------------------------ */
 /*
  * calc_atomic_rdf and calc_atomic_cn walk the same pairs of the same frames (structural/rdf_cn.py:385-530 and
@@ -222,6 +233,25 @@ int mdhip_msd_pairs(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const doubl
                     const int64_t *group_off, double *sums, double *per_entity, int pe_on_device);
 
 /*
+ * M1 for a FRAME SHARD (dynamical/diffusion.py:212-218 when the frames are dealt to one process per GPU): every frame
+ * t of r against ONE origin frame that need not be among them — the frame at time 0, broadcast by the rank that owns
+ * it — i.e. the frame pairs {(origin, t)}, t = 0..n_frames-1.
+ *   origin     host|dev (origin_on_device) [3][n_ent]
+ *   sums       host|dev (sums_on_device) [n_frames][n_groups][4]
+ *   cols       NULL, or host|dev (cols_on_device) the four per-entity columns as in mdhip_msd_pairs_cols
+ */
+int mdhip_msd_origin(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r, int on_device,
+                     const double *origin, int origin_on_device, double scale, int n_groups,
+                     const int64_t *group_off, double *sums, int sums_on_device, double *cols, int64_t col_stride,
+                     int cols_on_device);
+
+/* mdhip_msd_pairs without per-entity rows and with the sums left in a DEVICE buffer [n_pairs][n_groups][4]: a rank's
+ * frame shard of the single-origin MSD, all-gathered over RCCL from there (dist.py: msd_single_origin_sharded;
+ * reference: dynamical/diffusion.py:212-218). */
+int mdhip_msd_pairs_dev(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r, int on_device, double scale,
+                        int n_pairs, const int32_t *pairs, int n_groups, const int64_t *group_off, double *sums_dev);
+
+/*
  * The same reduction with the per-entity values stored as COLUMNS: dx2, dy2, dz2, msd, each [n_pairs][n_ent],
  * column k at cols + k * col_stride (col_stride >= n_pairs * n_ent, in doubles). These are the column blocks the
  * `msd_all` DataFrame (diffusion.py:212-217, 222) is made of, so the caller wraps them without a transpose.
@@ -241,6 +271,10 @@ int mdhip_msd_pairs_cols(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const 
 int mdhip_msd_windows(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r,
                       int on_device, double scale, int tao, double *win_sums);
 
+/* The same with win_sums in a DEVICE buffer [n_ent][4] (a rank's windows of the fixed-lag MSD, all-reduced over RCCL). */
+int mdhip_msd_windows_dev(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r, int on_device,
+                          double scale, int tao, double *win_sums_dev);
+
 /*
  * Superset (not in the reference): full lag average
  *   msd[lag][g][c] = mean over t0 in [0, n_frames-lag) and entities of group g of the squared
@@ -252,6 +286,11 @@ int mdhip_msd_windows(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const dou
  */
 int mdhip_lag_msd(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r, int on_device,
                   double scale, int max_lag, int n_groups, const int64_t *group_off, double *out);
+
+/* The same with the means in a DEVICE buffer [max_lag+1][n_groups][4] (a rank's entity slice; dist.py: lag_msd_sharded
+ * turns them into sums on the device and all-reduces them). */
+int mdhip_lag_msd_dev(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r, int on_device,
+                      double scale, int max_lag, int n_groups, const int64_t *group_off, double *out_dev);
 
 /* ---- G1: per-frame charge flux --------------------------------------------- */
 /*
@@ -265,6 +304,13 @@ int mdhip_charge_flux(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const d
                       int on_device, const double *atom_mass, const double *atom_q, int64_t n_seg,
                       const int64_t *seg_off, const int32_t *seg_type, int n_types,
                       double vel_conv, double charge_conv, double *flux);
+
+/* The same with flux in a DEVICE buffer [3][n_types][n_frames] (a rank's frames; all-gathered over RCCL — the reference's
+ * only frame-parallel gather, dynamical/conductivity.py:190-194). */
+int mdhip_charge_flux_dev(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *vel,
+                          int on_device, const double *atom_mass, const double *atom_q, int64_t n_seg,
+                          const int64_t *seg_off, const int32_t *seg_type, int n_types,
+                          double vel_conv, double charge_conv, double *flux_dev);
 
 /* ---- G2 / G3: correlation functions ---------------------------------------- */
 #define MDHIP_XCORR_FFT 0    /* zero-padded FFT (reference: length 2n; here the next power of two >= 2n, same linear correlation): conductivity.py:109-114, viscosity.py:111-115 */
@@ -285,6 +331,10 @@ int mdhip_xcorr(mdhip_ctx *ctx, int64_t n, int n_pairs, const double *a, const d
  */
 int mdhip_xcorr_lags(mdhip_ctx *ctx, int64_t n, int n_pairs, const double *a, const double *b, int on_device,
                      int method, int64_t lag_begin, int64_t n_lags, double *out);
+
+/* The same with out in a DEVICE buffer [n_pairs][n_lags] (a rank's lag range, all-gathered over RCCL). */
+int mdhip_xcorr_lags_dev(mdhip_ctx *ctx, int64_t n, int n_pairs, const double *a, const double *b, int on_device,
+                         int method, int64_t lag_begin, int64_t n_lags, double *out_dev);
 
 /* ---- G4: cumulative trapezoid ---------------------------------------------- */
 /*

@@ -35,6 +35,7 @@ PROTOTYPES = {
     "mdhip_last_aux_ms": (C.c_double, [vp]),
     "mdhip_last_kernel_name": (C.c_char_p, [vp]),
     "mdhip_last_rel_bound": (C.c_double, [vp]),
+    "mdhip_build_id": (C.c_char_p, []),
     "mdhip_device_name": (C.c_int, [vp, C.c_char_p, C.c_int]),
     "mdhip_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(vp)]),
     "mdhip_host_alloc_on": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(vp)]),
@@ -51,6 +52,8 @@ PROTOTYPES = {
                                       c_up]),
     "mdhip_cn_atomic": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, c_ip, C.c_int64, c_dp, C.c_int,
                                   c_ip, c_dp, C.c_int, c_up]),
+    "mdhip_cn_atomic_dev": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, c_ip, C.c_int64, c_dp, C.c_int,
+                                      c_ip, c_dp, vp]),
     "mdhip_rdf_sites": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, c_ip, C.c_int64, vp, C.c_int, c_ip,
                                   c_dp, C.c_int, c_ip, C.c_double, C.c_double, C.c_int, c_dp, C.c_int, c_up,
                                   c_up]),
@@ -62,7 +65,17 @@ PROTOTYPES = {
                                   c_lp, c_dp, vp, C.c_int]),
     "mdhip_msd_pairs_cols": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, C.c_double, C.c_int, c_ip, C.c_int,
                                        c_lp, c_dp, vp, C.c_int64, C.c_int]),
+    "mdhip_msd_origin": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, vp, C.c_int, C.c_double, C.c_int, c_lp,
+                                   vp, C.c_int, vp, C.c_int64, C.c_int]),
+    "mdhip_msd_pairs_dev": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, C.c_double, C.c_int, c_ip, C.c_int,
+                                      c_lp, vp]),
     "mdhip_msd_windows": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, C.c_double, C.c_int, c_dp]),
+    "mdhip_msd_windows_dev": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, C.c_double, C.c_int, vp]),
+    "mdhip_lag_msd_dev": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, C.c_double, C.c_int, C.c_int, c_lp,
+                                    vp]),
+    "mdhip_charge_flux_dev": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, c_dp, c_dp, C.c_int64, c_lp, c_ip,
+                                        C.c_int, C.c_double, C.c_double, vp]),
+    "mdhip_xcorr_lags_dev": (C.c_int, [vp, C.c_int64, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int64, C.c_int64, vp]),
     "mdhip_lag_msd": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, C.c_double, C.c_int, C.c_int, c_lp,
                                 c_dp]),
     "mdhip_charge_flux": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, c_dp, c_dp, C.c_int64, c_lp, c_ip,

@@ -34,6 +34,14 @@ def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
 
+def _dev_out(out, shape, dtype="torch.float64"):
+    """Checks a device result buffer (`out=`): contiguous CUDA tensor of `shape` and `dtype`; returns its address."""
+    if not (getattr(out, "is_cuda", False) and out.is_contiguous() and str(out.dtype) == dtype
+            and tuple(out.shape) == tuple(shape)):
+        raise ValueError("out must be a contiguous %s CUDA tensor of shape %s" % (dtype, tuple(shape)))
+    return C.c_void_p(out.data_ptr())
+
+
 def _shape3(x, name):
     shp = tuple(x.shape)
     if len(shp) != 3 or shp[1] != 3:
@@ -132,8 +140,9 @@ def rdf_cn_loop(xyz, types, box, relation_matrix, r_cut, ddr, nbins, cn_cut_list
     return full, part, int(ov.value), cn
 
 
-def cn_loop(xyz, types, box, relation_matrix, r_cut_list, per_frame=True, ctx=None):
-    """`_cn_loop` (rdf_cn.py:100-119): raw counts uint64 [F,R] (or [R])."""
+def cn_loop(xyz, types, box, relation_matrix, r_cut_list, per_frame=True, ctx=None, out=None):
+    """`_cn_loop` (rdf_cn.py:100-119): raw counts uint64 [F,R] (or [R]). `out` (frame-summed only): an int64 CUDA
+    tensor [R] that receives the counts on the device (their bit patterns; the multi-GPU layer all-reduces it)."""
     ctx = ctx or default_context()
     F, _, N = _shape3(xyz, "xyz")
     xp, on_dev, keep = as_input(xyz, ctx)
@@ -144,6 +153,13 @@ def cn_loop(xyz, types, box, relation_matrix, r_cut_list, per_frame=True, ctx=No
     rc2 = _f64([cutoff_sq(r) for r in r_cut_list])
     if len(rc2) != len(rel):
         raise ValueError("one cutoff per relation is required")
+    if out is not None:
+        if per_frame:
+            raise ValueError("a device result buffer holds the frame-summed counts: pass per_frame=False")
+        ctx.check(ctx.lib.mdhip_cn_atomic_dev(
+            ctx.h, F, N, xp, on_dev, ptr(ty, C.c_int32), stride, ptr(bx), len(rel), ptr(rel, C.c_int32),
+            ptr(rc2), _dev_out(out, (len(rel),), "torch.int64")))
+        return out
     cn = np.zeros(((F,) if per_frame else ()) + (len(rel),), dtype=np.uint64)
     ctx.check(ctx.lib.mdhip_cn_atomic(
         ctx.h, F, N, xp, on_dev, ptr(ty, C.c_int32), stride, ptr(bx), len(rel), ptr(rel, C.c_int32),
@@ -221,10 +237,11 @@ def segment_com(attr, atom_mass, seg_off, atom_q=None, out=None, ctx=None):
     return res, seg_mass, seg_q
 
 
-def msd_pairs(r, pairs, group_off, scale=1.0, per_entity=False, ctx=None):
+def msd_pairs(r, pairs, group_off, scale=1.0, per_entity=False, ctx=None, out=None):
     """
     Frame-pair displacement sums (diffusion.py:212-218): r [F,3,E], pairs [P,2] ->
-    sums [P,G,4] (+ per-entity rows [P,E,4] when requested).
+    sums [P,G,4] (+ per-entity rows [P,E,4] when requested). `out`: a float64 CUDA tensor [P,G,4] that receives the
+    sums on the device (no per-entity rows then).
     """
     ctx = ctx or default_context()
     F, _, E = _shape3(r, "r")
@@ -232,12 +249,54 @@ def msd_pairs(r, pairs, group_off, scale=1.0, per_entity=False, ctx=None):
     pr = _i32(pairs).reshape(-1, 2)
     go = _i64(group_off)
     G = len(go) - 1
+    if out is not None:
+        if per_entity:
+            raise ValueError("per-entity rows are not available with a device result buffer")
+        ctx.check(ctx.lib.mdhip_msd_pairs_dev(
+            ctx.h, F, E, rp, on_dev, float(scale), len(pr), ptr(pr, C.c_int32), G, ptr(go, C.c_int64),
+            _dev_out(out, (len(pr), G, 4))))
+        return out
     sums = np.zeros((len(pr), G, 4))
     pe = np.zeros((len(pr), E, 4)) if per_entity else None
     ctx.check(ctx.lib.mdhip_msd_pairs(
         ctx.h, F, E, rp, on_dev, float(scale), len(pr), ptr(pr, C.c_int32), G, ptr(go, C.c_int64),
         ptr(sums), None if pe is None else C.c_void_p(pe.ctypes.data), 0))
     return (sums, pe) if per_entity else sums
+
+
+def msd_origin(r, origin, group_off, scale=1.0, cols=None, out=None, ctx=None):
+    """
+    Single-origin MSD of a FRAME SHARD (diffusion.py:212-218 with the frames dealt to one process per GPU): every
+    frame of r [F,3,E] against `origin` [3,E] (host array or CUDA tensor — the time-0 frame, broadcast by its owner).
+    Returns sums [F,G,4]: a host array, or `out` (float64 CUDA tensor [F,G,4]) when given. `cols`: the per-entity
+    columns dx2, dy2, dz2, msd, each [F*E] — a host float64 array [4, F*E] with contiguous rows or a CUDA tensor.
+    """
+    ctx = ctx or default_context()
+    F, _, E = _shape3(r, "r")
+    rp, on_dev, keep = as_input(r, ctx)
+    if tuple(origin.shape) != (3, E):
+        raise ValueError("origin must have shape [3, n_ent]")
+    op, o_dev, keep2 = as_input(origin, ctx)
+    go = _i64(group_off)
+    G = len(go) - 1
+    if out is None:
+        sums = np.zeros((F, G, 4))
+        sp, s_dev = C.c_void_p(sums.ctypes.data), 0
+    else:
+        sums, sp, s_dev = out, _dev_out(out, (F, G, 4)), 1
+    cp, c_dev, stride = None, 0, 0
+    if cols is not None:
+        if getattr(cols, "is_cuda", False):
+            cp, c_dev, stride = _dev_out(cols, (4, F * E)), 1, F * E
+        else:
+            if not (isinstance(cols, np.ndarray) and cols.dtype == np.float64 and cols.shape == (4, F * E)
+                    and (F * E == 0 or (cols.strides[1] == 8 and cols.strides[0] % 8 == 0
+                                        and cols.strides[0] >= 8 * F * E))):
+                raise ValueError("cols must be a float64 array [4, n_frames * n_ent] with contiguous rows")
+            cp, stride = C.c_void_p(cols.ctypes.data), (cols.strides[0] // 8 if F * E else 0)
+    ctx.check(ctx.lib.mdhip_msd_origin(ctx.h, F, E, rp, on_dev, op, o_dev, float(scale), G, ptr(go, C.c_int64),
+                                       sp, s_dev, cp, stride, c_dev))
+    return sums
 
 
 def msd_pairs_cols(r, pairs, group_off, cols, scale=1.0, ctx=None):
@@ -262,37 +321,50 @@ def msd_pairs_cols(r, pairs, group_off, cols, scale=1.0, ctx=None):
     return sums
 
 
-def msd_windows(r, tao, scale=1.0, ctx=None):
-    """Fixed-lag window sums per entity (diffusion.py:225-237): r [F,3,E] -> [E,4]."""
+def msd_windows(r, tao, scale=1.0, ctx=None, out=None):
+    """Fixed-lag window sums per entity (diffusion.py:225-237): r [F,3,E] -> [E,4] (`out`: float64 CUDA tensor [E,4])."""
     ctx = ctx or default_context()
     F, _, E = _shape3(r, "r")
     rp, on_dev, keep = as_input(r, ctx)
+    if out is not None:
+        ctx.check(ctx.lib.mdhip_msd_windows_dev(ctx.h, F, E, rp, on_dev, float(scale), int(tao), _dev_out(out, (E, 4))))
+        return out
     out = np.zeros((E, 4))
     ctx.check(ctx.lib.mdhip_msd_windows(ctx.h, F, E, rp, on_dev, float(scale), int(tao), ptr(out)))
     return out
 
 
-def lag_msd(r, max_lag, group_off, scale=1.0, ctx=None):
-    """Full lag average (superset): r [F,3,E] -> [max_lag+1, G, 4]."""
+def lag_msd(r, max_lag, group_off, scale=1.0, ctx=None, out=None):
+    """Full lag average (superset): r [F,3,E] -> [max_lag+1, G, 4] (`out`: float64 CUDA tensor of that shape)."""
     ctx = ctx or default_context()
     F, _, E = _shape3(r, "r")
     rp, on_dev, keep = as_input(r, ctx)
     go = _i64(group_off)
     G = len(go) - 1
+    if out is not None:
+        ctx.check(ctx.lib.mdhip_lag_msd_dev(ctx.h, F, E, rp, on_dev, float(scale), int(max_lag), G,
+                                            ptr(go, C.c_int64), _dev_out(out, (int(max_lag) + 1, G, 4))))
+        return out
     out = np.zeros((int(max_lag) + 1, G, 4))
     ctx.check(ctx.lib.mdhip_lag_msd(ctx.h, F, E, rp, on_dev, float(scale), int(max_lag), G,
                                     ptr(go, C.c_int64), ptr(out)))
     return out
 
 
-def charge_flux(vel, atom_mass, atom_q, seg_off, seg_type, n_types, vel_conv, charge_conv, ctx=None):
-    """`conductivity_loop` for every frame (_conductivity.py:11-35): vel [F,3,N] -> j [3,T,F]."""
+def charge_flux(vel, atom_mass, atom_q, seg_off, seg_type, n_types, vel_conv, charge_conv, ctx=None, out=None):
+    """`conductivity_loop` for every frame (_conductivity.py:11-35): vel [F,3,N] -> j [3,T,F] (`out`: float64 CUDA
+    tensor of that shape)."""
     ctx = ctx or default_context()
     F, _, N = _shape3(vel, "vel")
     vp_, on_dev, keep = as_input(vel, ctx)
     m, q = _f64(atom_mass), _f64(atom_q)
     off = _i64(seg_off)
     st = _i32(seg_type)
+    if out is not None:
+        ctx.check(ctx.lib.mdhip_charge_flux_dev(
+            ctx.h, F, N, vp_, on_dev, ptr(m), ptr(q), len(off) - 1, ptr(off, C.c_int64), ptr(st, C.c_int32),
+            int(n_types), float(vel_conv), float(charge_conv), _dev_out(out, (3, int(n_types), F))))
+        return out
     out = np.zeros((3, int(n_types), F))
     ctx.check(ctx.lib.mdhip_charge_flux(
         ctx.h, F, N, vp_, on_dev, ptr(m), ptr(q), len(off) - 1, ptr(off, C.c_int64), ptr(st, C.c_int32),
@@ -300,11 +372,12 @@ def charge_flux(vel, atom_mass, atom_q, seg_off, seg_type, n_types, vel_conv, ch
     return out
 
 
-def xcorr(a, b=None, method=XCORR_FFT, n_lags=None, ctx=None, lag_begin=0):
+def xcorr(a, b=None, method=XCORR_FFT, n_lags=None, ctx=None, lag_begin=0, out=None):
     """
     c[p][k] = sum_t a_p[t+k] b_p[t] / (n-k) (conductivity.py:109-114, viscosity.py:103-115).
     a, b: [n] or [P,n]; b=None gives the autocorrelation. lag_begin > 0 (direct method): the lags
-    lag_begin .. lag_begin + n_lags - 1 only.
+    lag_begin .. lag_begin + n_lags - 1 only. `out`: float64 CUDA tensor [P, n_lags] that receives the lags on the
+    device (returned as it is).
     """
     ctx = ctx or default_context()
     single = len(a.shape) == 1
@@ -318,6 +391,10 @@ def xcorr(a, b=None, method=XCORR_FFT, n_lags=None, ctx=None, lag_begin=0):
         if b_dev != a_dev:
             raise ValueError("a and b must both be host arrays or both device tensors")
     n_lags = n - int(lag_begin) if n_lags is None else int(n_lags)
+    if out is not None:
+        ctx.check(ctx.lib.mdhip_xcorr_lags_dev(ctx.h, n, P, ap, bp, a_dev, int(method), int(lag_begin), n_lags,
+                                               _dev_out(out, (P, n_lags))))
+        return out
     out = np.zeros((P, n_lags))
     ctx.check(ctx.lib.mdhip_xcorr_lags(ctx.h, n, P, ap, bp, a_dev, int(method), int(lag_begin), n_lags, ptr(out)))
     return out[0] if single else out

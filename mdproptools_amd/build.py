@@ -37,6 +37,20 @@ def _hipcc():
     return exe
 
 
+def source_id():
+    """sha256 (16 hex digits) over every source the library is compiled from, in a fixed order: what
+    `mdhip_build_id()` of a library built by this recipe returns. bench.py prints both, so that a number can be tied
+    to the code that produced it even though the shipped .so is prebuilt."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for path in [os.path.join(CSRC, s) for s in SOURCES] + HEADERS:
+        with open(path, "rb") as fh:
+            h.update(os.path.basename(path).encode() + b"\0")
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -50,13 +64,21 @@ def build(force=False, verbose=False):
     hipcc = _hipcc()
     objs = []
     procs = []
+    build_id = source_id()
+    id_file = os.path.join(OBJ, "build_id.txt")
+    try:
+        with open(id_file) as fh:
+            id_stale = fh.read().strip() != build_id
+    except OSError:
+        id_stale = True
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
         objs.append(o)
-        if force or _stale(o, [s] + HEADERS):
+        carries_id = src == "mdhip_ctx.hip"  # the one unit that holds the build id: rebuilt whenever any source changed
+        if force or _stale(o, [s] + HEADERS) or (carries_id and id_stale):
             if src.endswith(".hip"):
-                cmd = [hipcc] + CFLAGS + ["-c", s, "-o", o]
+                cmd = [hipcc] + CFLAGS + (['-DMDHIP_BUILD_ID="%s"' % build_id] if carries_id else []) + ["-c", s, "-o", o]
             else:  # host-only translation unit
                 cmd = ["g++", "-O3", "-std=c++17", "-fPIC", "-Wall", "-c", s, "-o", o]
             if verbose:
@@ -75,6 +97,8 @@ def build(force=False, verbose=False):
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stdout.decode(errors="replace"))
+    with open(id_file, "w") as fh:
+        fh.write(build_id + "\n")
     return LIB
 
 

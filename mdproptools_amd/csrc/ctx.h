@@ -168,6 +168,29 @@ static inline const void *mdhip_stage(mdhip_ctx *ctx, int slot, const void *src,
     return d;
 }
 
+// Results: device workspace -> the caller's buffer, which is host memory for the plain entry points and device
+// memory for the *_dev ones (the multi-GPU layer hands those buffers to RCCL without a host round trip).
+static inline hipError_t mdhip_deliver(mdhip_ctx *ctx, void *dst, const void *d_src, size_t bytes, int dst_on_device)
+{
+    if (bytes == 0) return hipSuccess;
+    return hipMemcpyAsync(dst, d_src, bytes, dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                          ctx->stream);
+}
+
+// Zeroes a result buffer (host: at once; device: on the stream, complete on return).
+static inline int mdhip_zero_result(mdhip_ctx *ctx, void *dst, size_t bytes, int dst_on_device)
+{
+    if (bytes == 0 || !dst) return MDHIP_OK;
+    if (!dst_on_device) {
+        memset(dst, 0, bytes);
+        return MDHIP_OK;
+    }
+    hipError_t e = hipMemsetAsync(dst, 0, bytes, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return mdhip_fail(ctx, MDHIP_EHIP, "zeroing a device result failed: %s", hipGetErrorString(e));
+    return MDHIP_OK;
+}
+
 struct KernelTimer {
     mdhip_ctx *ctx;
     hipEvent_t e0, e1;

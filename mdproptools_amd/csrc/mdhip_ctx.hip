@@ -73,6 +73,11 @@ extern "C" {
 
 int mdhip_version(void) { return MDHIP_VERSION; }
 
+#ifndef MDHIP_BUILD_ID
+#define MDHIP_BUILD_ID "unknown"
+#endif
+const char *mdhip_build_id(void) { return MDHIP_BUILD_ID; }
+
 int mdhip_create(mdhip_ctx **out, int device)
 {
     if (!out) return mdhip_fail(nullptr, MDHIP_EINVAL, "mdhip_create: out is NULL");

@@ -40,14 +40,16 @@ template <bool VEC2>
 __global__ __launch_bounds__(MSD_THREADS) void msd_pairs_kernel(
     const double *__restrict__ r, long long n_ent, double scale, const int *__restrict__ pairs,
     const Chunk *__restrict__ chunks, int n_chunks, double *__restrict__ partial,
-    double *__restrict__ per_entity, long long pe_stride)
+    double *__restrict__ per_entity, long long pe_stride, const double *__restrict__ origin)
 {
     // per_entity: pe_stride == 0 -> rows [n_pairs][n_ent][4]; otherwise four columns, column k at k * pe_stride,
     // each [n_pairs][n_ent] (the column blocks a DataFrame is made of, stored without a host-side transpose)
     __shared__ double red[4][4];
     const int p = blockIdx.y;
     const Chunk ck = chunks[blockIdx.x];
-    const double *r0 = r + (size_t)pairs[2 * p] * 3 * n_ent;
+    // t0 < 0: the separate origin frame (a frame shard of the single-origin MSD: the origin was broadcast by its owner)
+    const int t0 = pairs[2 * p];
+    const double *r0 = t0 < 0 ? origin : r + (size_t)t0 * 3 * n_ent;
     const double *r1 = r + (size_t)pairs[2 * p + 1] * 3 * n_ent;
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
     auto one = [&](long long e, double x1, double y1, double z1, double x0, double y0, double z0) {
@@ -552,25 +554,33 @@ int build_chunks(mdhip_ctx *ctx, int64_t n_ent, int n_groups, const int64_t *gro
 // col_stride doubles apart at the destination (packed on the device, copied column by column)
 int msd_pairs_impl(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r, int on_device, double scale,
                    int n_pairs, const int32_t *pairs, int n_groups, const int64_t *group_off, double *sums,
-                   double *per_entity, int pe_on_device, int64_t col_stride)
+                   double *per_entity, int pe_on_device, int64_t col_stride, int sums_on_device = 0,
+                   const double *origin = nullptr, int origin_on_device = 0)
 {
     if (!ctx) return MDHIP_EINVAL;
     MD_REQUIRE(n_frames >= 0 && n_ent >= 0 && n_pairs >= 0, "negative sizes");
     MD_REQUIRE(n_pairs == 0 || (pairs && sums), "NULL pairs/sums");
     for (int p = 0; p < 2 * n_pairs; ++p)
-        MD_REQUIRE(pairs[p] >= 0 && pairs[p] < n_frames, "pair index %d out of range", pairs[p]);
+        MD_REQUIRE((pairs[p] >= 0 && pairs[p] < n_frames) || (origin && p % 2 == 0 && pairs[p] == -1),
+                   "pair index %d out of range", pairs[p]);
     std::vector<Chunk> chunks;
     std::vector<int> gco;
     int rc = build_chunks(ctx, n_ent, n_groups, group_off, chunks, gco);
     if (rc) return rc;
-    std::fill(sums, sums + (size_t)n_pairs * n_groups * 4, 0.0);
+    MD_HIP(hipSetDevice(ctx->device));
+    rc = mdhip_zero_result(ctx, sums, (size_t)n_pairs * n_groups * 4 * 8, sums_on_device);
+    if (rc) return rc;
     if (n_pairs == 0 || chunks.empty()) return MDHIP_OK;
     MD_REQUIRE(r != nullptr, "r is NULL");
     MD_REQUIRE(n_pairs <= 65535, "at most 65535 frame pairs per call");
-    MD_HIP(hipSetDevice(ctx->device));
     const double *d_r =
         (const double *)mdhip_stage(ctx, WS_XYZ_I, r, (size_t)n_frames * 3 * n_ent * 8, on_device, &rc);
     if (rc) return rc;
+    const double *d_origin = nullptr;
+    if (origin) {
+        d_origin = (const double *)mdhip_stage(ctx, WS_XYZ_J, origin, (size_t)3 * n_ent * 8, origin_on_device, &rc);
+        if (rc) return rc;
+    }
     const int n_chunks = (int)chunks.size();
     const size_t tab_b = (size_t)n_pairs * 8 + chunks.size() * sizeof(Chunk) + gco.size() * 4;
     MD_WS(d_tab, unsigned char, WS_TABLES, tab_b + 64);
@@ -595,23 +605,24 @@ int msd_pairs_impl(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double
     KernelTimer timer(ctx);
     ctx->last_kernel = "msd_pairs_kernel";
     // 16-byte loads need 16-byte aligned planes and even chunk starts
-    bool vec2 = (n_ent % 2 == 0) && ((reinterpret_cast<uintptr_t>(d_r) & 15) == 0);
+    bool vec2 = (n_ent % 2 == 0) && ((reinterpret_cast<uintptr_t>(d_r) & 15) == 0) &&
+                ((reinterpret_cast<uintptr_t>(d_origin) & 15) == 0);
     for (const Chunk &c : chunks) vec2 = vec2 && (c.e0 % 2 == 0);
     if (vec2)
         hipLaunchKernelGGL(msd_pairs_kernel<true>, dim3((unsigned)n_chunks, (unsigned)n_pairs),
                            dim3(MSD_THREADS), 0, ctx->stream, d_r, (long long)n_ent, scale, d_pairs,
-                           d_chunks, n_chunks, d_partial, d_pe, d_stride);
+                           d_chunks, n_chunks, d_partial, d_pe, d_stride, d_origin);
     else
         hipLaunchKernelGGL(msd_pairs_kernel<false>, dim3((unsigned)n_chunks, (unsigned)n_pairs),
                            dim3(MSD_THREADS), 0, ctx->stream, d_r, (long long)n_ent, scale, d_pairs,
-                           d_chunks, n_chunks, d_partial, d_pe, d_stride);
+                           d_chunks, n_chunks, d_partial, d_pe, d_stride, d_origin);
     timer.stop();
     MD_HIP(hipGetLastError());
     const int tot = n_pairs * n_groups * 4;
     hipLaunchKernelGGL(msd_group_sum_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
                        ctx->stream, d_partial, d_gco, n_chunks, n_groups, n_pairs, d_sums);
     MD_HIP(hipGetLastError());
-    MD_HIP(hipMemcpyAsync(sums, d_sums, sums_b, hipMemcpyDeviceToHost, ctx->stream));
+    MD_HIP(mdhip_deliver(ctx, sums, d_sums, sums_b, sums_on_device));
     if (per_entity && !pe_on_device) {
         if (!col_stride || col_stride == col_len) {
             MD_HIP(hipMemcpyAsync(per_entity, d_pe, pe_b, hipMemcpyDeviceToHost, ctx->stream));
@@ -650,20 +661,17 @@ int mdhip_msd_pairs_cols(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const 
                           cols_on_device, col_stride ? col_stride : 1);
 }
 
-int mdhip_msd_windows(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r,
-                      int on_device, double scale, int tao, double *win_sums)
+static int msd_windows_impl(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r, int on_device,
+                            double scale, int tao, double *win_sums, int out_on_device)
 {
     if (!ctx) return MDHIP_EINVAL;
     MD_REQUIRE(n_frames >= 0 && n_ent >= 0 && tao >= 1, "bad sizes");
     MD_REQUIRE(n_ent == 0 || win_sums, "win_sums is NULL");
     if (n_ent == 0) return MDHIP_OK;
-    if (n_frames == 0) {
-        std::fill(win_sums, win_sums + (size_t)n_ent * 4, 0.0);
-        return MDHIP_OK;
-    }
-    MD_REQUIRE(r != nullptr, "r is NULL");
     MD_HIP(hipSetDevice(ctx->device));
     int rc;
+    if (n_frames == 0) return mdhip_zero_result(ctx, win_sums, (size_t)n_ent * 4 * 8, out_on_device);
+    MD_REQUIRE(r != nullptr, "r is NULL");
     const double *d_r =
         (const double *)mdhip_stage(ctx, WS_XYZ_I, r, (size_t)n_frames * 3 * n_ent * 8, on_device, &rc);
     if (rc) return rc;
@@ -683,14 +691,56 @@ int mdhip_msd_windows(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const dou
                        ctx->stream, d_part, (long long)n_ent, (int)n_slabs, d_out);
     timer.stop();
     MD_HIP(hipGetLastError());
-    MD_HIP(hipMemcpyAsync(win_sums, d_out, (size_t)n_ent * 4 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    MD_HIP(mdhip_deliver(ctx, win_sums, d_out, (size_t)n_ent * 4 * 8, out_on_device));
     MD_HIP(hipStreamSynchronize(ctx->stream));
     timer.collect();
     return MDHIP_OK;
 }
 
-int mdhip_lag_msd(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r, int on_device,
-                  double scale, int max_lag, int n_groups, const int64_t *group_off, double *out)
+int mdhip_msd_windows(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r,
+                      int on_device, double scale, int tao, double *win_sums)
+{
+    return msd_windows_impl(ctx, n_frames, n_ent, r, on_device, scale, tao, win_sums, 0);
+}
+
+int mdhip_msd_windows_dev(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r, int on_device,
+                          double scale, int tao, double *win_sums_dev)
+{
+    return msd_windows_impl(ctx, n_frames, n_ent, r, on_device, scale, tao, win_sums_dev, 1);
+}
+
+int mdhip_msd_origin(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r, int on_device,
+                     const double *origin, int origin_on_device, double scale, int n_groups,
+                     const int64_t *group_off, double *sums, int sums_on_device, double *cols, int64_t col_stride,
+                     int cols_on_device)
+{
+    if (!ctx) return MDHIP_EINVAL;
+    MD_REQUIRE(n_frames >= 0 && n_frames <= 65535, "1..65535 frames per call");
+    MD_REQUIRE(origin != nullptr || n_ent == 0 || n_frames == 0, "origin is NULL");
+    MD_REQUIRE(sums != nullptr || n_frames == 0, "sums is NULL");
+    MD_REQUIRE(!cols || col_stride >= n_frames * n_ent, "col_stride is shorter than one column");
+    std::vector<int32_t> pairs((size_t)2 * n_frames);
+    for (int64_t t = 0; t < n_frames; ++t) {
+        pairs[2 * t] = -1;
+        pairs[2 * t + 1] = (int32_t)t;
+    }
+    return msd_pairs_impl(ctx, n_frames, n_ent, r, on_device, scale, (int)n_frames, pairs.data(), n_groups, group_off,
+                          sums, cols, cols_on_device, cols ? (col_stride ? col_stride : 1) : 0, sums_on_device, origin,
+                          origin_on_device);
+}
+
+int mdhip_msd_pairs_dev(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r, int on_device, double scale,
+                        int n_pairs, const int32_t *pairs, int n_groups, const int64_t *group_off, double *sums_dev)
+{
+    if (!ctx) return MDHIP_EINVAL;
+    MD_REQUIRE(sums_dev != nullptr || n_pairs == 0, "sums_dev is NULL");
+    return msd_pairs_impl(ctx, n_frames, n_ent, r, on_device, scale, n_pairs, pairs, n_groups, group_off, sums_dev,
+                          nullptr, 0, 0, 1);
+}
+
+static int lag_msd_impl(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r, int on_device,
+                        double scale, int max_lag, int n_groups, const int64_t *group_off, double *out,
+                        int out_on_device)
 {
     if (!ctx) return MDHIP_EINVAL;
     MD_REQUIRE(n_frames >= 0 && n_ent >= 0 && max_lag >= 0, "negative sizes");
@@ -735,21 +785,34 @@ int mdhip_lag_msd(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double 
     }
     int rc = build_chunks(ctx, n_ent, n_groups, group_off, chunks, gco, echunk);
     if (rc) return rc;
-    std::fill(out, out + (size_t)n_lags * n_groups * 4, 0.0);
+    MD_HIP(hipSetDevice(ctx->device));
+    const size_t res_b = (size_t)n_lags * n_groups * 4 * 8;
+    rc = mdhip_zero_result(ctx, out, res_b, out_on_device);
+    if (rc) return rc;
     if (n_frames == 0 || chunks.empty()) return MDHIP_OK;
     MD_REQUIRE(r != nullptr, "r is NULL");
     MD_REQUIRE(chunks.size() <= 65535, "too many entity chunks (%zu)", chunks.size());
-    MD_HIP(hipSetDevice(ctx->device));
     const size_t r_b = (size_t)n_frames * 3 * n_ent * 8;
     const double *d_r = (const double *)mdhip_stage(ctx, WS_XYZ_I, r, r_b, on_device, &rc);
     if (rc) return rc;
     ctx->last_rel_bound = 0.0;
     if (ctx->opt_lag_variant >= 2 && ctx->opt_lag_variant <= 4) {
         double bound = 0.0;
-        rc = mdhip_lag_msd_fft(ctx, n_frames, n_ent, d_r, scale, max_lag, n_groups, group_off, out, &bound);
+        // the spectral path finishes on the host (prefix sums of the squares, S1 - 2 S2, division by the counts, in
+        // long-hand double arithmetic over [n_lags][n_groups][4] values); a device destination gets those values copied in
+        std::vector<double> host_out;
+        if (out_on_device) host_out.assign((size_t)n_lags * n_groups * 4, 0.0);
+        rc = mdhip_lag_msd_fft(ctx, n_frames, n_ent, d_r, scale, max_lag, n_groups, group_off,
+                               out_on_device ? host_out.data() : out, &bound);
         if (rc) return rc;
         ctx->last_rel_bound = bound;
-        if (ctx->opt_lag_variant != 3 || bound <= 1e-10) return MDHIP_OK;
+        if (ctx->opt_lag_variant != 3 || bound <= 1e-10) {
+            if (out_on_device) {
+                MD_HIP(hipMemcpyAsync(out, host_out.data(), res_b, hipMemcpyHostToDevice, ctx->stream));
+                MD_HIP(hipStreamSynchronize(ctx->stream));
+            }
+            return MDHIP_OK;
+        }
         ctx->last_rel_bound = 0.0;  // bound too loose for this data: the exact-difference kernel below answers
     }
     MD_WS(d_x, double, WS_XYZ_J, r_b + 256);  // the scalar prefetch of the resident kernel reads <= 16 doubles past a series
@@ -815,10 +878,22 @@ int mdhip_lag_msd(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double 
                        ctx->stream, d_partial, d_gco, d_goff, n_groups, (long long)n_frames, n_lags,
                        resident ? 1 : 0, d_out);
     MD_HIP(hipGetLastError());
-    MD_HIP(hipMemcpyAsync(out, d_out, out_b, hipMemcpyDeviceToHost, ctx->stream));
+    MD_HIP(mdhip_deliver(ctx, out, d_out, out_b, out_on_device));
     MD_HIP(hipStreamSynchronize(ctx->stream));
     timer.collect();
     return MDHIP_OK;
+}
+
+int mdhip_lag_msd(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r, int on_device,
+                  double scale, int max_lag, int n_groups, const int64_t *group_off, double *out)
+{
+    return lag_msd_impl(ctx, n_frames, n_ent, r, on_device, scale, max_lag, n_groups, group_off, out, 0);
+}
+
+int mdhip_lag_msd_dev(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r, int on_device,
+                      double scale, int max_lag, int n_groups, const int64_t *group_off, double *out_dev)
+{
+    return lag_msd_impl(ctx, n_frames, n_ent, r, on_device, scale, max_lag, n_groups, group_off, out_dev, 1);
 }
 
 }  // extern "C"

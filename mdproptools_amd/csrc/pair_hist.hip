@@ -1175,6 +1175,26 @@ int mdhip_cn_atomic(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const dou
     return MDHIP_OK;
 }
 
+int mdhip_cn_atomic_dev(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *xyz, int on_device,
+                        const int32_t *type, int64_t type_frame_stride, const double *box, int n_rel,
+                        const int32_t *rel, const double *r_cut_sq, uint64_t *cn_dev)
+{
+    if (!ctx) return MDHIP_EINVAL;
+    MD_REQUIRE(n_rel == 0 || cn_dev, "NULL output");
+    // the n_rel count words are folded from the class rows on the host (prefix sums over a few bins per relation);
+    // they go to the caller's device buffer from there
+    std::vector<uint64_t> cn((size_t)std::max(n_rel, 1), 0);
+    const int rc = mdhip_cn_atomic(ctx, n_frames, n_atoms, xyz, on_device, type, type_frame_stride, box, n_rel, rel,
+                                   r_cut_sq, 0, cn.data());
+    if (rc) return rc;
+    if (n_rel > 0) {
+        MD_HIP(hipSetDevice(ctx->device));
+        MD_HIP(hipMemcpyAsync(cn_dev, cn.data(), (size_t)n_rel * 8, hipMemcpyHostToDevice, ctx->stream));
+        MD_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return MDHIP_OK;
+}
+
 int mdhip_rdf_sites(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *xyz,
                     int xyz_on_device, const int32_t *type, int64_t n_sites, const double *sites,
                     int sites_on_device, const int32_t *site_type, const double *box, int n_rel,

@@ -353,10 +353,10 @@ int mdhip_segment_com(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, int n_a
     return MDHIP_OK;
 }
 
-int mdhip_charge_flux(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *vel,
-                      int on_device, const double *atom_mass, const double *atom_q, int64_t n_seg,
-                      const int64_t *seg_off, const int32_t *seg_type, int n_types,
-                      double vel_conv, double charge_conv, double *flux)
+static int charge_flux_impl(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *vel,
+                            int on_device, const double *atom_mass, const double *atom_q, int64_t n_seg,
+                            const int64_t *seg_off, const int32_t *seg_type, int n_types,
+                            double vel_conv, double charge_conv, double *flux, int flux_on_device)
 {
     if (!ctx) return MDHIP_EINVAL;
     MD_REQUIRE(n_frames >= 0 && n_atoms >= 0 && n_types >= 0, "negative sizes");
@@ -444,10 +444,28 @@ int mdhip_charge_flux(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const d
                            (long long)n_seg, (long long)n_frames, n_types);
         MD_HIP(hipGetLastError());
     }
-    MD_HIP(hipMemcpyAsync(flux, d_flux, flux_b, hipMemcpyDeviceToHost, ctx->stream));
+    MD_HIP(mdhip_deliver(ctx, flux, d_flux, flux_b, flux_on_device));
     MD_HIP(hipStreamSynchronize(ctx->stream));
     timer.collect();
     return MDHIP_OK;
+}
+
+int mdhip_charge_flux(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *vel,
+                      int on_device, const double *atom_mass, const double *atom_q, int64_t n_seg,
+                      const int64_t *seg_off, const int32_t *seg_type, int n_types,
+                      double vel_conv, double charge_conv, double *flux)
+{
+    return charge_flux_impl(ctx, n_frames, n_atoms, vel, on_device, atom_mass, atom_q, n_seg, seg_off, seg_type,
+                            n_types, vel_conv, charge_conv, flux, 0);
+}
+
+int mdhip_charge_flux_dev(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *vel,
+                          int on_device, const double *atom_mass, const double *atom_q, int64_t n_seg,
+                          const int64_t *seg_off, const int32_t *seg_type, int n_types,
+                          double vel_conv, double charge_conv, double *flux_dev)
+{
+    return charge_flux_impl(ctx, n_frames, n_atoms, vel, on_device, atom_mass, atom_q, n_seg, seg_off, seg_type,
+                            n_types, vel_conv, charge_conv, flux_dev, 1);
 }
 
 }  // extern "C"

@@ -234,8 +234,8 @@ int mdhip_xcorr(mdhip_ctx *ctx, int64_t n, int n_pairs, const double *a, const d
     return mdhip_xcorr_lags(ctx, n, n_pairs, a, b, on_device, method, 0, n_lags, out);
 }
 
-int mdhip_xcorr_lags(mdhip_ctx *ctx, int64_t n, int n_pairs, const double *a, const double *b, int on_device,
-                     int method, int64_t lag_begin, int64_t n_lags, double *out)
+static int xcorr_lags_impl(mdhip_ctx *ctx, int64_t n, int n_pairs, const double *a, const double *b, int on_device,
+                           int method, int64_t lag_begin, int64_t n_lags, double *out, int out_on_device)
 {
     if (!ctx) return MDHIP_EINVAL;
     MD_REQUIRE(n >= 0 && n_pairs >= 0 && n_lags >= 0 && lag_begin >= 0 && lag_begin + n_lags <= n,
@@ -265,10 +265,22 @@ int mdhip_xcorr_lags(mdhip_ctx *ctx, int64_t n, int n_pairs, const double *a, co
                                    : xcorr_direct(ctx, n, n_pairs, d_a, d_b, lag_begin, n_lags, d_out);
     timer.stop();
     if (rc) return rc;
-    MD_HIP(hipMemcpyAsync(out, d_out, out_b, hipMemcpyDeviceToHost, ctx->stream));
+    MD_HIP(mdhip_deliver(ctx, out, d_out, out_b, out_on_device));
     MD_HIP(hipStreamSynchronize(ctx->stream));
     timer.collect();
     return MDHIP_OK;
+}
+
+int mdhip_xcorr_lags(mdhip_ctx *ctx, int64_t n, int n_pairs, const double *a, const double *b, int on_device,
+                     int method, int64_t lag_begin, int64_t n_lags, double *out)
+{
+    return xcorr_lags_impl(ctx, n, n_pairs, a, b, on_device, method, lag_begin, n_lags, out, 0);
+}
+
+int mdhip_xcorr_lags_dev(mdhip_ctx *ctx, int64_t n, int n_pairs, const double *a, const double *b, int on_device,
+                         int method, int64_t lag_begin, int64_t n_lags, double *out_dev)
+{
+    return xcorr_lags_impl(ctx, n, n_pairs, a, b, on_device, method, lag_begin, n_lags, out_dev, 1);
 }
 
 }  // extern "C"

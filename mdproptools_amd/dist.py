@@ -22,6 +22,13 @@ kernel on the path (rdf_cn.py:459; diffusion.py:174; _conductivity.py:7), so:
   charge flux  as RDF: per-frame [3][T] vectors all-gathered.
   FFT ACF / running integrals: a single transform does not shard — replicas only.
 
+Device residency. Every sharded call below takes its shard as a host array or as a CUDA tensor. With a CUDA tensor the
+kernels write their (small) results into device buffers (the *_dev entry points of include/mdhip.h) and the
+collective reads those buffers: on RCCL nothing touches the host between the kernel and the collective, and the caller
+gets ONE device-to-host copy of the reduced / gathered result (or the device tensor itself, `return_device=True`).
+With gloo (tests: several ranks sharing one GPU, or CPU only) the same code stages the collective's operands through
+host memory, since gloo gathers only host tensors.
+
 `compute` arguments exist so that the sharding/collective logic can be exercised on CPU with the
 oracle as the stand-in (tests/test_dist_gloo.py); the product default is the GPU backend.
 """
@@ -142,65 +149,87 @@ def allreduce_u64_async(arrays):
     return _PendingSum(d.all_reduce(t, op=d.ReduceOp.SUM, async_op=True), t, shapes)
 
 
-def allgather_rows(local, n_total_rows):
-    """
-    Concatenate per-rank blocks of rows (frame shards, in rank order) into the full array on every rank.
-    `local` [rows_local, ...]; blocks may differ in length by one (see frame_shard).
-    """
-    local = np.ascontiguousarray(local)
-    if not is_distributed():
-        return local
+def _is_tensor(x):
+    return hasattr(x, "is_cuda") and hasattr(x, "data_ptr")
+
+
+def _coll_tensor(x):
+    """(tensor on the device the backend's collectives take, came_as_tensor, home device, uint64 flag)."""
     import torch
 
-    d = _dist()
-    rank, world = rank_world()
-    row_shape = local.shape[1:]
-    row_elems = int(np.prod(row_shape)) if row_shape else 1
-    max_rows = -(-int(n_total_rows) // world)
-    pad = np.zeros((max_rows, row_elems), dtype=local.dtype)
-    pad[: local.shape[0]] = local.reshape(local.shape[0], row_elems)
-    as_i64 = local.dtype == np.uint64
-    send = torch.from_numpy(pad.view(np.int64) if as_i64 else pad).to(_device_for_collectives())
-    recv = [torch.empty_like(send) for _ in range(world)]
-    d.all_gather(recv, send)
-    blocks = []
-    for r in range(world):
-        lo, hi = frame_shard(n_total_rows, r, world)
-        blk = recv[r].cpu().numpy()[: hi - lo]
-        blocks.append(blk.view(np.uint64) if as_i64 else blk)
-    return np.concatenate(blocks).reshape((int(n_total_rows),) + row_shape)
+    if _is_tensor(x):
+        return x.contiguous().to(_device_for_collectives()), True, x.device, False
+    x = np.ascontiguousarray(x)
+    as_u64 = x.dtype == np.uint64
+    return torch.from_numpy(x.view(np.int64) if as_u64 else x).to(_device_for_collectives()), False, None, as_u64
 
 
-def allgather_var(local):
-    """
-    Concatenate per-rank blocks of rows of ANY length (rank order) into the full array on every rank:
-    the block lengths are gathered first, blocks are padded to the longest one. float64 or uint64 rows.
-    """
-    local = np.ascontiguousarray(local)
-    if not is_distributed():
-        return local
+def _coll_result(t, came_as_tensor, home, as_u64):
+    if came_as_tensor:
+        return t.to(home)
+    a = t.cpu().numpy()
+    return a.view(np.uint64) if as_u64 else a
+
+
+def _gather_blocks(local, counts):
+    """Per-rank blocks of rows (counts[r] rows from rank r) concatenated in rank order on every rank. `local` is a host
+    array (float64 / int64 / uint64) or a tensor; the result has the same kind (a CUDA tensor stays on the GPU: on
+    RCCL the gather reads and writes device memory only)."""
     import torch
 
     d = _dist()
     _, world = rank_world()
-    dev = _device_for_collectives()
-    cnt = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
-    counts = [torch.zeros_like(cnt) for _ in range(world)]
-    d.all_gather(counts, cnt)
-    counts = [int(c.item()) for c in counts]
-    row_shape = local.shape[1:]
-    row_elems = int(np.prod(row_shape)) if row_shape else 1
-    pad = np.zeros((max(max(counts), 1), row_elems), dtype=local.dtype)
-    pad[: local.shape[0]] = local.reshape(local.shape[0], row_elems)
-    as_i64 = local.dtype == np.uint64
-    send = torch.from_numpy(pad.view(np.int64) if as_i64 else pad).to(dev)
+    t, was_t, home, as_u64 = _coll_tensor(local)
+    row_shape = tuple(t.shape[1:])
+    longest = max(max(counts), 1)
+    if all(c == longest for c in counts):
+        send = t
+    else:
+        send = torch.zeros((longest,) + row_shape, dtype=t.dtype, device=t.device)
+        send[: t.shape[0]] = t
     recv = [torch.empty_like(send) for _ in range(world)]
     d.all_gather(recv, send)
-    blocks = []
-    for r in range(world):
-        blk = recv[r].cpu().numpy()[: counts[r]]
-        blocks.append(blk.view(np.uint64) if as_i64 else blk)
-    return np.concatenate(blocks).reshape((sum(counts),) + row_shape)
+    out = torch.cat([recv[r][: counts[r]] for r in range(world)]) if world > 1 else recv[0][: counts[0]]
+    return _coll_result(out, was_t, home, as_u64)
+
+
+def allgather_rows(local, n_total_rows):
+    """
+    Concatenate per-rank blocks of rows (frame shards, in rank order) into the full array on every rank.
+    `local` [rows_local, ...] — host array or tensor (see _gather_blocks); blocks may differ in length by one
+    (see frame_shard).
+    """
+    if not is_distributed():
+        return local if _is_tensor(local) else np.ascontiguousarray(local)
+    _, world = rank_world()
+    counts = [frame_shard(n_total_rows, r, world)[1] - frame_shard(n_total_rows, r, world)[0] for r in range(world)]
+    return _gather_blocks(local, counts)
+
+
+def allgather_counts(n_local):
+    """The number of rows every rank holds, in rank order (one small all-gather)."""
+    if not is_distributed():
+        return [int(n_local)]
+    import torch
+
+    d = _dist()
+    _, world = rank_world()
+    cnt = torch.tensor([int(n_local)], dtype=torch.int64, device=_device_for_collectives())
+    counts = [torch.zeros_like(cnt) for _ in range(world)]
+    d.all_gather(counts, cnt)
+    return [int(c.item()) for c in counts]
+
+
+def allgather_var(local, counts=None):
+    """
+    Concatenate per-rank blocks of rows of ANY length (rank order) into the full array on every rank: the block lengths
+    are gathered first (unless the caller has them), blocks are padded to the longest one. Host array or tensor.
+    """
+    if not is_distributed():
+        return local if _is_tensor(local) else np.ascontiguousarray(local)
+    if counts is None:
+        counts = allgather_counts(local.shape[0])
+    return _gather_blocks(local, counts)
 
 
 def require_all_nonempty(n_local, what="frame"):
@@ -247,18 +276,38 @@ def is_writer():
     return rank_world()[0] == 0
 
 
-def broadcast_array(arr, src, shape, dtype=np.float64):
-    """Broadcast a float64 array from rank `src` (others pass arr=None)."""
-    if not is_distributed():
-        return np.asarray(arr, dtype=dtype)
+def broadcast_array(arr, src, shape, dtype=np.float64, like=None):
+    """Broadcast a float64 array from rank `src` (others pass arr=None). `like`: a CUDA tensor of this rank — the
+    result is then a tensor on its device, and on RCCL the broadcast goes device to device."""
     import torch
 
+    if like is not None and _is_tensor(like):
+        if not is_distributed():
+            return arr
+        d = _dist()
+        rank, _ = rank_world()
+        dev = _device_for_collectives()
+        t = arr.contiguous().to(dev) if rank == src else torch.empty(tuple(shape), dtype=like.dtype, device=dev)
+        d.broadcast(t, src=src)
+        return t.to(like.device)
+    if not is_distributed():
+        return np.asarray(arr, dtype=dtype)
     d = _dist()
     rank, _ = rank_world()
     buf = np.ascontiguousarray(arr, dtype=dtype) if rank == src else np.zeros(shape, dtype=dtype)
     t = torch.from_numpy(buf).to(_device_for_collectives())
     d.broadcast(t, src=src)
     return t.cpu().numpy()
+
+
+def allreduce_tensor(t):
+    """Sum a tensor over all ranks; returns a tensor on t's device (on RCCL: t itself, reduced in place)."""
+    if not is_distributed():
+        return t
+    d = _dist()
+    c = t.contiguous().to(_device_for_collectives())
+    d.all_reduce(c, op=d.ReduceOp.SUM)
+    return c.to(t.device)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -348,49 +397,181 @@ def rdf_sharded_per_frame(xyz_local, types, box_local, relation_matrix, r_cut, d
     return full, part, int(ovv[0])
 
 
-def cn_sharded(xyz_local, types, box_local, relation_matrix, r_cut_list, compute=None):
-    """`_cn_loop` counts summed over all frames of all ranks (one all-reduce of R words)."""
+def cn_sharded(xyz_local, types, box_local, relation_matrix, r_cut_list, compute=None, ctx=None):
+    """`_cn_loop` counts summed over all frames of all ranks (one all-reduce of R words). With device-resident frames
+    the counts go from the library's device buffer to the collective (mdhip_cn_atomic_dev)."""
+    if compute is None and _is_tensor(xyz_local) and xyz_local.is_cuda:
+        import torch
+
+        from . import backend
+
+        R = len(np.asarray(relation_matrix).reshape(-1, 2))
+        out = torch.empty(R, dtype=torch.int64, device=xyz_local.device)
+        backend.cn_loop(xyz_local, types, box_local, relation_matrix, r_cut_list, per_frame=False, ctx=ctx, out=out)
+        return allreduce_tensor(out).cpu().numpy().view(np.uint64)
     if compute is None:
         from . import backend
 
         def compute(x, t, b, rel, cuts):
-            return backend.cn_loop(x, t, b, rel, cuts, per_frame=False)
+            return backend.cn_loop(x, t, b, rel, cuts, per_frame=False, ctx=ctx)
 
     (cn,) = allreduce_u64([compute(xyz_local, types, box_local, relation_matrix, r_cut_list)])
     return cn
 
 
-def msd_single_origin_sharded(r_local, n_frames_total, group_off, scale=1.0, origin_frame=0, compute=None):
+def frame_blocks(n_frames_total, counts=None, world=None):
+    """[(lo, hi)] per rank of a trajectory dealt to the ranks in contiguous blocks: frame_shard's even split, or the
+    given per-rank frame counts (ranks that parsed whole files hold what their files held)."""
+    if world is None:
+        world = rank_world()[1]
+    if counts is None:
+        return [frame_shard(n_frames_total, r, world) for r in range(world)]
+    if len(counts) != world or sum(counts) != int(n_frames_total):
+        raise ValueError("counts must give one frame count per rank, adding up to n_frames_total")
+    edges = np.concatenate(([0], np.cumsum(counts))).astype(np.int64)
+    return [(int(edges[r]), int(edges[r + 1])) for r in range(world)]
+
+
+def frame_owner(n_frames_total, frame, world=None, counts=None):
+    """The rank whose contiguous frame block holds `frame`."""
+    blocks = frame_blocks(n_frames_total, counts, world)
+    return next(r for r, (lo, hi) in enumerate(blocks) if lo <= frame < hi)
+
+
+def msd_single_origin_sharded(r_local, n_frames_total, group_off, scale=1.0, origin_frame=0, compute=None, ctx=None,
+                              return_device=False, counts=None, cols=None):
     """
     Single-origin MSD sums (diffusion.py:212-218) over a frame-sharded trajectory r_local [F_local,3,E]:
-    the origin frame is broadcast from its owner, every rank reduces its own (origin, t) pairs, the
+    the origin frame is broadcast from its owner (24 E bytes), every rank reduces its own (origin, t) pairs, the
     [F_local,G,4] sums are all-gathered into [F,G,4] (frame order).
+    r_local as a CUDA tensor: the broadcast, the reduction (mdhip_msd_origin: the origin frame is a separate device
+    buffer, the shard is not copied) and the gather all work on device memory; the result comes back as a host array,
+    or as the device tensor with return_device. `cols`: receives the per-entity columns of THIS rank's frames
+    (backend.msd_origin); `counts`: per-rank frame counts when the split is not frame_shard's.
     """
+    rank, world = rank_world()
+    blocks = frame_blocks(n_frames_total, counts, world)
+    lo, hi = blocks[rank]
+    owner = frame_owner(n_frames_total, origin_frame, world, counts)
+    cnts = [b - a for a, b in blocks]
+    E = r_local.shape[2]
+    G = len(group_off) - 1
+    if int(r_local.shape[0]) != hi - lo:
+        raise ValueError("this rank holds %d frames, its block is [%d, %d)" % (int(r_local.shape[0]), lo, hi))
+    if compute is None and _is_tensor(r_local) and r_local.is_cuda:
+        import torch
+
+        from . import backend
+
+        r0 = broadcast_array(r_local[origin_frame - lo] if rank == owner else None, owner, (3, E), like=r_local)
+        sums = torch.empty((hi - lo, G, 4), dtype=torch.float64, device=r_local.device)
+        if hi > lo:
+            backend.msd_origin(r_local, r0, group_off, scale=scale, out=sums, cols=cols, ctx=ctx)
+        full = _gather_blocks(sums, cnts) if is_distributed() else sums
+        return full if return_device else full.cpu().numpy()
+    r_np = np.asarray(r_local.cpu() if _is_tensor(r_local) else r_local)
+    r0 = broadcast_array(r_np[origin_frame - lo] if rank == owner else None, owner, (3, E))
     if compute is None:
         from . import backend
 
-        def compute(r, pairs, goff, sc):
-            return backend.msd_pairs(r, pairs, goff, scale=sc)
+        sums = backend.msd_origin(r_np, r0, group_off, scale=scale, cols=cols, ctx=ctx) if hi > lo \
+            else np.zeros((0, G, 4))
+    else:
+        stacked = np.concatenate([r0[None], r_np]) if hi > lo else r0[None]
+        pairs = np.column_stack([np.zeros(hi - lo, dtype=np.int32), 1 + np.arange(hi - lo, dtype=np.int32)])
+        sums = compute(stacked, pairs, group_off, scale) if hi > lo else np.zeros((0, G, 4))
+    return _gather_blocks(sums, cnts) if is_distributed() else sums
 
+
+def msd_windows_sharded(r_local, n_frames_total, tao, scale=1.0, compute=None, ctx=None, return_device=False,
+                        counts=None):
+    """
+    Fixed-lag per-entity window sums (diffusion.py:225-237; mdhip_msd_windows) over a frame-sharded trajectory:
+    frames kept = 0, tao, 2 tao, ... of the GLOBAL order; a window (k-1, k) belongs to the rank that holds kept frame
+    k. Every rank therefore needs ONE frame from before its block — the last kept frame of the ranks below it — and
+    gets it from an all-gather of "my last kept frame" (24 E bytes per rank). The per-entity sums [E,4] of the ranks
+    are added by an all-reduce (double: the windows are summed rank by rank instead of in one sequence, so the last
+    bits may differ from a single-GPU run; inside the rtol 1e-10 bar by orders of magnitude).
+    """
     rank, world = rank_world()
-    lo, hi = frame_shard(n_frames_total, rank, world)
-    owner = next(r for r in range(world) if frame_shard(n_frames_total, r, world)[0] <= origin_frame
-                 < frame_shard(n_frames_total, r, world)[1])
-    E = r_local.shape[2]
-    r0 = broadcast_array(r_local[origin_frame - lo] if rank == owner else None, owner, (3, E))
-    stacked = np.concatenate([r0[None], np.asarray(r_local)]) if hi > lo else r0[None]
-    pairs = np.column_stack([np.zeros(hi - lo, dtype=np.int32), 1 + np.arange(hi - lo, dtype=np.int32)])
-    sums = compute(stacked, pairs, group_off, scale) if hi > lo else np.zeros((0, len(group_off) - 1, 4))
-    return allgather_rows(sums, n_frames_total)
+    blocks = frame_blocks(n_frames_total, counts, world)
+    lo, hi = blocks[rank]
+    E = int(r_local.shape[2])
+    tao = int(tao)
+
+    def kept_of(a, b):  # global indices of the kept frames inside [a, b)
+        return np.arange(-(-a // tao) * tao, b, tao)
+
+    kept_local = kept_of(lo, hi) - lo
+    dev = _is_tensor(r_local) and r_local.is_cuda and compute is None
+    if compute is None:
+        from . import backend
+
+        def compute(r, sc):
+            return backend.msd_windows(r, 1, scale=sc, ctx=ctx)
+
+    if dev:
+        import torch
+
+        zero = torch.zeros((1, 3, E), dtype=torch.float64, device=r_local.device)
+        mine = r_local[int(kept_local[-1])][None] if len(kept_local) else zero
+        lasts = allgather_var(mine, counts=[1] * world) if world > 1 else mine
+    else:
+        r_np = np.asarray(r_local.cpu() if _is_tensor(r_local) else r_local)
+        mine = r_np[int(kept_local[-1])][None] if len(kept_local) else np.zeros((1, 3, E))
+        lasts = allgather_var(mine, counts=[1] * world) if world > 1 else mine
+        kept = r_np[kept_local]
+    # the halo: the last kept frame of the nearest rank below that has one
+    halo = None
+    for q in range(rank - 1, -1, -1):
+        if len(kept_of(*blocks[q])):
+            halo = lasts[q]
+            break
+    if dev:
+        from . import backend
+
+        sums = torch.zeros((E, 4), dtype=torch.float64, device=r_local.device)
+        if len(kept_local):
+            # my kept frames lie tao apart from the first one on: the kernel strides over them where they are (no
+            # gathered copy of every tao-th frame) ...
+            k0 = int(kept_local[0])
+            backend.msd_windows(r_local[k0:], tao, scale=scale, ctx=ctx, out=sums)
+            if halo is not None:
+                # ... and the one window that reaches back to the rank below is three planes of arithmetic
+                # (the kernel's operations: scale, subtract, square, (dx2 + dy2) + dz2)
+                d2 = (r_local[k0] * scale - halo * scale) ** 2
+                sums += torch.stack([d2[0], d2[1], d2[2], (d2[0] + d2[1]) + d2[2]], dim=1)
+        sums = allreduce_tensor(sums)
+        return sums if return_device else sums.cpu().numpy()
+    block = kept if halo is None else np.concatenate([halo[None], kept])
+    sums = np.asarray(compute(np.ascontiguousarray(block), scale)) if block.shape[0] > 1 else np.zeros((E, 4))
+    if is_distributed():
+        import torch
+
+        sums = allreduce_tensor(torch.from_numpy(np.ascontiguousarray(sums))).numpy()
+    return sums
 
 
 def charge_flux_sharded(vel_local, n_frames_total, atom_mass, atom_q, seg_off, seg_type, n_types, vel_conv,
-                        charge_conv, compute=None):
-    """Per-frame charge flux of a frame-sharded trajectory, gathered to j [3, T, F] on every rank."""
+                        charge_conv, compute=None, ctx=None):
+    """Per-frame charge flux of a frame-sharded trajectory, gathered to j [3, T, F] on every rank (the reference's
+    only frame-parallel gather, conductivity.py:190-194). Device-resident velocities: the [3,T,F_local] block stays
+    on the GPU (mdhip_charge_flux_dev) until it has been gathered."""
+    if compute is None and _is_tensor(vel_local) and vel_local.is_cuda:
+        import torch
+
+        from . import backend
+
+        j_local = torch.empty((3, int(n_types), int(vel_local.shape[0])), dtype=torch.float64, device=vel_local.device)
+        backend.charge_flux(vel_local, atom_mass, atom_q, seg_off, seg_type, n_types, vel_conv, charge_conv, ctx=ctx,
+                            out=j_local)
+        rows = j_local.permute(2, 0, 1).contiguous()  # [F_local, 3, T]
+        return allgather_rows(rows, n_frames_total).permute(1, 2, 0).contiguous().cpu().numpy()
     if compute is None:
         from . import backend
 
-        compute = backend.charge_flux
+        def compute(*a):
+            return backend.charge_flux(*a, ctx=ctx)
     j_local = compute(vel_local, atom_mass, atom_q, seg_off, seg_type, n_types, vel_conv, charge_conv)
     rows = np.ascontiguousarray(np.moveaxis(j_local, 2, 0))  # [F_local, 3, T]
     return np.moveaxis(allgather_rows(rows, n_frames_total), 0, 2)
@@ -404,7 +585,10 @@ def lag_msd_sharded(r_local, entity_range, max_lag, group_off, scale=1.0, comput
     the per-(lag, group) SUMS are all-reduced (double: the order of the ranks' partial sums differs from the single-
     GPU order in the last bits, inside the rtol 1e-10 bar) and divided by the global counts.
     Returns msd [max_lag+1, G, 4] on every rank. entity_shard(E) gives the contiguous split.
+    r_local as a CUDA tensor: means -> sums -> all-reduce -> means all on the device (mdhip_lag_msd_dev), one copy to
+    the host at the end.
     """
+    dev = compute is None and _is_tensor(r_local) and r_local.is_cuda
     if compute is None:
         from . import backend
 
@@ -420,6 +604,25 @@ def lag_msd_sharded(r_local, entity_range, max_lag, group_off, scale=1.0, comput
     lo = np.clip(goff[:-1], e_lo, e_hi) - e_lo
     hi = np.clip(goff[1:], e_lo, e_hi) - e_lo
     held = [g for g in range(G) if hi[g] > lo[g]]
+    counts = (F - np.arange(n_lags)).astype(np.float64)[:, None] * (goff[1:] - goff[:-1]).astype(np.float64)[None, :]
+    origins = (F - np.arange(n_lags)).astype(np.float64)[:, None]
+    if dev:
+        import torch
+
+        from . import backend
+
+        sums = torch.zeros((n_lags, G, 4), dtype=torch.float64, device=r_local.device)
+        if held and F > 0:
+            loc_off = np.array([lo[held[0]]] + [hi[g] for g in held], dtype=np.int64)
+            x = r_local[:, :, int(loc_off[0]):int(loc_off[-1])].contiguous()
+            means = torch.empty((n_lags, len(held), 4), dtype=torch.float64, device=r_local.device)
+            backend.lag_msd(x, int(max_lag), loc_off - loc_off[0], scale=scale, ctx=ctx, out=means)
+            w = torch.from_numpy(origins * (hi[held] - lo[held]).astype(np.float64)[None, :]).to(r_local.device)
+            sums[:, torch.as_tensor(held, device=r_local.device), :] = means * w[:, :, None]
+        sums = allreduce_tensor(sums)
+        cnt = torch.from_numpy(counts).to(r_local.device)[:, :, None]
+        out = torch.where(cnt > 0, sums / torch.clamp(cnt, min=1.0), torch.zeros_like(sums))
+        return out.cpu().numpy()
     sums = np.zeros((n_lags, G, 4))
     if held and F > 0:
         # the held groups are contiguous in the slice (groups are contiguous globally)
@@ -428,17 +631,12 @@ def lag_msd_sharded(r_local, entity_range, max_lag, group_off, scale=1.0, comput
         if hasattr(x, "contiguous"):
             x = x.contiguous()
         means = np.asarray(compute(x, int(max_lag), loc_off - loc_off[0], scale))
-        origins = (F - np.arange(n_lags)).astype(np.float64)[:, None]
         for k, g in enumerate(held):
             sums[:, g, :] = means[:, k, :] * (origins * float(hi[g] - lo[g]))
     if is_distributed():
         import torch
 
-        d = _dist()
-        t = torch.from_numpy(sums).to(_device_for_collectives())
-        d.all_reduce(t, op=d.ReduceOp.SUM)
-        sums = t.cpu().numpy()
-    counts = (F - np.arange(n_lags)).astype(np.float64)[:, None] * (goff[1:] - goff[:-1]).astype(np.float64)[None, :]
+        sums = allreduce_tensor(torch.from_numpy(sums)).numpy()
     with np.errstate(invalid="ignore", divide="ignore"):
         out = np.where(counts[:, :, None] > 0, sums / counts[:, :, None], 0.0)
     return out
@@ -471,7 +669,10 @@ def xcorr_direct_sharded(a, b=None, n_lags=None, compute=None, ctx=None):
     lag_ranges) and the slices are all-gathered: c [n_lags] or [P,n_lags] on every rank. Every lag is computed by
     exactly one rank with the same kernel; the time slabs of a launch depend on its lag range, so the result equals
     the single-GPU one to rounding (~1e-14 relative), well inside the 1e-10 acf[0] bar.
+    Series as CUDA tensors: a rank's slice [P, k1-k0] is written to a device buffer (mdhip_xcorr_lags_dev) and gathered
+    from there (8 MB per series at n = 1e6); one copy to the host at the end.
     """
+    dev = compute is None and _is_tensor(a) and a.is_cuda
     if compute is None:
         from . import backend
 
@@ -485,11 +686,22 @@ def xcorr_direct_sharded(a, b=None, n_lags=None, compute=None, ctx=None):
     rank, world = rank_world()
     bounds = lag_ranges(n, n_lags, world)
     k0, k1 = bounds[rank], bounds[rank + 1]
+    widths = [bounds[r + 1] - bounds[r] for r in range(world)]
+    if dev:
+        import torch
+
+        from . import backend
+
+        mine = torch.empty((P, k1 - k0), dtype=torch.float64, device=a.device)
+        if k1 > k0:
+            backend.xcorr(a, b, method=backend.XCORR_DIRECT, n_lags=k1 - k0, ctx=ctx, lag_begin=k0, out=mine)
+        rows = mine.t().contiguous()  # rows = lags, so that the gather concatenates along the lag axis
+        out = (allgather_var(rows, counts=widths) if is_distributed() else rows).t().contiguous().cpu().numpy()
+        return out[0] if single else out
     mine = np.asarray(compute(a, b, k0, k1 - k0)).reshape(P, k1 - k0) if k1 > k0 else np.zeros((P, 0))
     if not is_distributed():
         out = mine
     else:
-        # rows = lags (so that allgather_var concatenates along the lag axis)
-        out = allgather_var(np.ascontiguousarray(mine.T)).T
+        out = allgather_var(np.ascontiguousarray(mine.T), counts=widths).T
     out = np.ascontiguousarray(out)
     return out[0] if single else out

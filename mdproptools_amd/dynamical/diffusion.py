@@ -40,6 +40,9 @@ _DISPS = ["dx2", "dy2", "dz2"]
 # reductions read ONE device copy. False: every frame is parsed first (round-1 route).
 STREAM = True
 STREAM_BATCH_BYTES = None  # coordinates per staging batch (None: stream.DEFAULT_BATCH_BYTES)
+# Under torch.distributed: True = every rank returns the whole `msd_all` (its F x E value columns are gathered, device to
+# device on RCCL) — the frame one process would return; False = every rank returns the rows of ITS frames only.
+MSD_ALL_ON_EVERY_RANK = True
 
 
 def _is_device(r):
@@ -117,7 +120,9 @@ class Diffusion:
 
     # ------------------------------------------------------------------------------------------
     def _entity_frames(self, filename, msd_type, num_mols, num_atoms_per_mol, mass):
-        """Parse every frame and reduce it to entity coordinates [3, E] in LAMMPS length units."""
+        """Parse this process's frames and reduce them to entity coordinates [F_local, 3, E] in LAMMPS length units.
+        Returns (times, r, meta, sharded): under torch.distributed every rank parses ITS share of the files and
+        `sharded` is True — r then holds only those frames (get_msd_from_dump reduces them where they are)."""
         from .. import io as mio
 
         if msd_type not in ("allatom", "com"):
@@ -146,22 +151,19 @@ class Diffusion:
                     raise ValueError("atom masses change between frames")
             times.append(step * self.timestep * constants.TIME_CONVERSION[self.units])
         times = np.asarray(times, dtype=np.float64)
+        sharded = files is not None and D.is_distributed()
         if files is not None:
             D.require_all_nonempty(len(planes), "dump file")  # every rank raises, or none
-            times = D.allgather_var(times)
         if msd_type == "com":
             seg = molecule_layout(num_mols, num_atoms_per_mol)
             if planes and seg[0][-1] != planes[0].shape[1]:
                 raise ValueError(f"Length of values ({int(seg[0][-1])}) does not match length "
                                  f"of index ({planes[0].shape[1]})")
             com, seg_mass, _ = backend.segment_com(np.stack(planes), atom_mass, seg[0])
-            if files is not None:
-                com = D.allgather_var(com)
-            return times, com, dict(type=seg[1], mol_id=seg[2], mass=seg_mass)
+            return times, com, dict(type=seg[1], mol_id=seg[2], mass=seg_mass), sharded
         r = np.stack(planes)
-        if files is not None:
-            r = D.allgather_var(r)
-        return times, r, dict(id=np.asarray(ids).astype(np.int64))  # an integer column, as the reference's parser reads it
+        # (id: an integer column, as the reference's parser reads it)
+        return times, r, dict(id=np.asarray(ids).astype(np.int64)), sharded
 
     def _entity_frames_streamed(self, pattern, files, msd_type, num_mols, num_atoms_per_mol, mass):
         """The same (times, r [F,3,E], meta) with r a DEVICE tensor: frames go text -> page-locked batch -> GPU while
@@ -224,12 +226,10 @@ class Diffusion:
             return None
         r = torch.cat(blocks) if len(blocks) > 1 else blocks[0]
         del blocks
-        if files is not None and D.is_distributed():
-            times = D.allgather_var(times)
-            r = torch.from_numpy(D.allgather_var(r.cpu().numpy())).to(dev)
+        sharded = files is not None and D.is_distributed()
         if msd_type == "com":
-            return times, r, dict(type=seg[1], mol_id=seg[2], mass=seg_mass)
-        return times, r, dict(id=ids.astype(np.int64))  # an integer column, as the reference's parser reads it
+            return times, r, dict(type=seg[1], mol_id=seg[2], mass=seg_mass), sharded
+        return times, r, dict(id=ids.astype(np.int64)), sharded  # an integer column, as the reference's parser reads it
 
     def _frame_columns(self, pattern, msd_type, mass, native, files=None):
         """Yields (timestep, column names, {name: id-sorted float64 column}) with xu, yu, zu present
@@ -285,21 +285,23 @@ class Diffusion:
 
         Returns (msd, msd_all) or (msd, msd_all, msd_int) as DataFrames laid out like the reference's.
         """
-        times, r, meta = self._entity_frames(filename, msd_type, num_mols, num_atoms_per_mol, mass)
+        times, r, meta, sharded = self._entity_frames(filename, msd_type, num_mols, num_atoms_per_mol, mass)
+        if sharded:
+            got = self._msd_frame_sharded(times, r, meta, msd_type, com_drift, avg_interval, tao_coeff)
+            if got is not None:
+                return got
+            # frames out of time order ACROSS ranks: the blocks cannot be reduced where they are; gather them (device
+            # to device on RCCL) and go on as one process would
+            from .. import dist as D
+
+            counts = D.allgather_counts(len(times))
+            times, r = D.allgather_var(times, counts), D.allgather_var(r, counts)
         order = np.argsort(times, kind="stable")  # the reference sorts its (time, id) index
         if not np.array_equal(order, np.arange(len(order))):
             times, r = times[order], _take_frames(r, order)
         F, _, E = r.shape
+        id_cols, id_vals, group_off, group_labels = self._groups(meta, msd_type, E)
         dist = constants.DISTANCE_CONVERSION[self.units]
-        if msd_type == "allatom":
-            id_cols, id_vals = ["id"], [meta["id"]]
-            group_off = np.array([0, E], dtype=np.int64)
-            group_labels = None
-        else:
-            id_cols, id_vals = ["type", "mol_id"], [meta["type"], meta["mol_id"]]
-            counts = np.bincount(meta["type"])[1:]
-            group_off = np.concatenate(([0], np.cumsum(counts))).astype(np.int64)
-            group_labels = np.arange(1, len(counts) + 1)
         scale = dist
         if msd_type == "com" and com_drift:
             if _is_device(r):  # small ([F,3,M]) and host arithmetic: same doubles as the load-everything route
@@ -313,39 +315,137 @@ class Diffusion:
         pairs = np.column_stack([np.full(F, origin), np.arange(F)]).astype(np.int32)
         # the per-entity values come back as the four COLUMNS of msd_all (one contiguous block each); the frame wraps
         # them, the time column and the tiled id columns without consolidating them into a second copy
-        cols_1d = _DISPS + ["msd"]
         col_block = np.empty((4, F * E))
         sums = backend.msd_pairs_cols(r, pairs, group_off, col_block, scale=scale)
-        all_cols = {"Time (s)": np.repeat(times, E)}
-        for name, v in zip(id_cols, id_vals):
-            all_cols[name] = np.tile(v, F)
-        for k, name in enumerate(cols_1d):
-            all_cols[name] = col_block[k]
-        msd_all = pd.DataFrame(all_cols, copy=False)
-
-        means = sums / np.diff(group_off)[None, :, None]
-        if msd_type == "allatom":
-            msd = pd.DataFrame({"Time (s)": times, **{c: means[:, 0, k] for k, c in enumerate(cols_1d)}})
-        else:
-            data = {"Time (s)": times}
-            for g, lab in enumerate(group_labels):  # diffusion.py:220-222: dx21 dy21 dz21 msd1 dx22 ...
-                for k, c in enumerate(cols_1d):
-                    data[f"{c}{lab}"] = means[:, g, k]
-            msd = pd.DataFrame(data)
+        msd_all = self._msd_all_frame(times, E, id_cols, id_vals, col_block)
+        msd = self._msd_frame(times, sums, group_off, group_labels, msd_type)
         if not avg_interval:
             return msd, msd_all
 
-        kept = np.arange(F)[::tao_coeff]  # diffusion.py:226-228
-        n_kept = len(kept)
-        win = backend.msd_windows(_take_frames(r, kept), 1, scale=scale)
+        n_kept = len(np.arange(F)[::tao_coeff])  # diffusion.py:226-228: every tao-th time is kept
+        win = backend.msd_windows(r, tao_coeff, scale=scale)  # (the kernel strides over the kept frames in place)
+        return msd, msd_all, self._msd_int_frame(win, n_kept, E, id_cols, id_vals)
+
+    # ------------------------------------------------------------------------------------------
+    @staticmethod
+    def _groups(meta, msd_type, E):
+        if msd_type == "allatom":
+            return ["id"], [meta["id"]], np.array([0, E], dtype=np.int64), None
+        counts = np.bincount(meta["type"])[1:]
+        group_off = np.concatenate(([0], np.cumsum(counts))).astype(np.int64)
+        return ["type", "mol_id"], [meta["type"], meta["mol_id"]], group_off, np.arange(1, len(counts) + 1)
+
+    @staticmethod
+    def _msd_all_frame(times, E, id_cols, id_vals, col_block):
+        all_cols = {"Time (s)": np.repeat(times, E)}
+        for name, v in zip(id_cols, id_vals):
+            all_cols[name] = np.tile(v, len(times))
+        for k, name in enumerate(_DISPS + ["msd"]):
+            all_cols[name] = col_block[k]
+        return pd.DataFrame(all_cols, copy=False)
+
+    @staticmethod
+    def _msd_frame(times, sums, group_off, group_labels, msd_type):
+        cols_1d = _DISPS + ["msd"]
+        means = sums / np.diff(group_off)[None, :, None]
+        if msd_type == "allatom":
+            return pd.DataFrame({"Time (s)": times, **{c: means[:, 0, k] for k, c in enumerate(cols_1d)}})
+        data = {"Time (s)": times}
+        for g, lab in enumerate(group_labels):  # diffusion.py:220-222: dx21 dy21 dz21 msd1 dx22 ...
+            for k, c in enumerate(cols_1d):
+                data[f"{c}{lab}"] = means[:, g, k]
+        return pd.DataFrame(data)
+
+    @staticmethod
+    def _msd_int_frame(win, n_kept, E, id_cols, id_vals):
         int_cols = {name: v for name, v in zip(id_cols, id_vals)}
         with np.errstate(invalid="ignore", divide="ignore"):
             for k, c in enumerate(_DISPS):
                 int_cols[c] = win[:, k] / (n_kept - 1) if n_kept > 1 else np.full(E, np.nan)
         # the first kept frame has no predecessor: its NaN row sums to 0 and still counts in the mean
         int_cols["msd"] = win[:, 3] / n_kept
-        msd_int = pd.DataFrame(int_cols)
-        return msd, msd_all, msd_int
+        return pd.DataFrame(int_cols)
+
+    def _msd_frame_sharded(self, times_l, r_l, meta, msd_type, com_drift, avg_interval, tao_coeff):
+        """
+        get_msd_from_dump with the FRAMES where their ranks parsed them (torch.distributed): the frame
+        at time 0 is broadcast by its owner (24 E bytes), every rank reduces its own frames against it
+        (mdhip_msd_origin) and the [F_local, G, 4] sums are all-gathered; the fixed-lag windows need one frame from
+        the rank below (dist.msd_windows_sharded) and an all-reduce of [E, 4]. The trajectory itself never moves.
+        `msd_all` is F x E rows whatever is done: its four value columns are gathered (device to device on RCCL) so
+        that every rank returns the frame one process would — MSD_ALL_ON_EVERY_RANK = False keeps each rank's own
+        rows instead and skips that gather.
+        Returns None when the ranks' blocks are not in time order one after the other (the caller then gathers the
+        frames and reduces them as one process).
+        """
+        from .. import dist as D
+
+        rank, world = D.rank_world()
+        counts = D.allgather_counts(len(times_l))
+        times = D.allgather_var(np.asarray(times_l, dtype=np.float64), counts)
+        if np.any(np.diff(times) < 0):
+            return None
+        F, F_l, E = int(sum(counts)), int(r_l.shape[0]), int(r_l.shape[2])
+        lo = int(sum(counts[:rank]))
+        id_cols, id_vals, group_off, group_labels = self._groups(meta, msd_type, E)
+        dist = constants.DISTANCE_CONVERSION[self.units]
+        scale = dist
+        if msd_type == "com" and com_drift:
+            # per-type drift: this rank's frames against the per-type centre of the FIRST frame (rank 0's first)
+            if _is_device(r_l):
+                r_l = r_l.cpu().numpy()
+            ent_mass = meta["mass"] * constants.MASS_CONVERSION[self.units]
+            r_si = r_l * dist
+            com_l = self._type_com(r_si, ent_mass, group_off)  # [F_l, 3, G]
+            com0 = D.broadcast_array(com_l[0] if rank == 0 else None, 0, (3, len(group_off) - 1))
+            r_l = self._subtract_drift(r_si, com_l - com0[None], group_off)
+            scale = 1.0
+        origin = np.flatnonzero(times == 0)
+        if len(origin) == 0:
+            raise KeyError(0)  # the reference selects the time-0 rows with .xs(0, 0)
+        origin = int(origin[0])
+        on_dev = _is_device(r_l)
+        if on_dev:
+            import torch
+
+            cols_l = torch.empty((4, F_l * E), dtype=torch.float64, device=r_l.device)
+        else:
+            cols_l = np.empty((4, F_l * E))
+        sums = D.msd_single_origin_sharded(r_l, F, group_off, scale=scale, origin_frame=origin, counts=counts,
+                                           cols=cols_l)
+        if MSD_ALL_ON_EVERY_RANK:
+            col_block = np.empty((4, F * E))
+            for k in range(4):  # column k of every rank's frames, in rank (= time) order
+                g = D.allgather_var(cols_l[k].reshape(F_l, E), counts)
+                col_block[k] = (g.cpu().numpy() if on_dev else g).reshape(-1)
+            msd_all = self._msd_all_frame(times, E, id_cols, id_vals, col_block)
+        else:
+            col_block = cols_l.cpu().numpy() if on_dev else cols_l
+            msd_all = self._msd_all_frame(times[lo:lo + F_l], E, id_cols, id_vals, col_block)
+        del cols_l
+        msd = self._msd_frame(times, sums, group_off, group_labels, msd_type)
+        if not avg_interval:
+            return msd, msd_all
+        n_kept = len(np.arange(F)[::tao_coeff])
+        win = D.msd_windows_sharded(r_l, F, tao_coeff, scale=scale, counts=counts)
+        return msd, msd_all, self._msd_int_frame(win, n_kept, E, id_cols, id_vals)
+
+    @staticmethod
+    def _type_com(r_si, ent_mass, group_off):
+        """Per-type mass-weighted centre [F, 3, G] of r_si [F, 3, E] (diffusion.py:83-89)."""
+        out = np.empty(r_si.shape[:2] + (len(group_off) - 1,))
+        for g in range(len(group_off) - 1):
+            lo, hi = group_off[g], group_off[g + 1]
+            m = ent_mass[lo:hi]
+            out[:, :, g] = (r_si[:, :, lo:hi] @ m) / m.sum()
+        return out
+
+    @staticmethod
+    def _subtract_drift(r_si, drift, group_off):
+        out = r_si.copy()
+        for g in range(len(group_off) - 1):
+            out[:, :, group_off[g]:group_off[g + 1]] -= drift[:, :, g][:, :, None]
+        return out
 
     @staticmethod
     def _remove_drift(r_si, ent_mass, group_off):

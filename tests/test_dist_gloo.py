@@ -31,6 +31,18 @@ def _make_case():
     return F, n, L, xyz, ty, rel, box, r
 
 
+def _walk(F, n):
+    return np.cumsum(np.random.default_rng(1000 + F).normal(0, 0.1, (F, 3, n)), axis=0)
+
+
+def _np_windows(r, scale):
+    """mdhip_msd_windows(r, tao=1) in numpy: per entity, the sums over consecutive frames of the squared steps
+    (diffusion.py:225-237)."""
+    d = np.diff(np.asarray(r) * scale, axis=0) ** 2  # [F-1,3,E]
+    s = d.sum(axis=0)
+    return np.column_stack([s[0], s[1], s[2], ((d[:, 0] + d[:, 1]) + d[:, 2]).sum(axis=0)])
+
+
 def _worker(rank, world, port, out_dir):
     sys.path.insert(0, REPO)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -88,9 +100,15 @@ def _worker(rank, world, port, out_dir):
     acf = D.xcorr_direct_sharded(series, None, compute=xc)
     ccf = D.xcorr_direct_sharded(series[0], series[1], n_lags=300,
                                  compute=lambda aa, bb, k0, nl: cref.xcorr_direct(aa, bb, n_lags=k0 + nl)[k0:])
+    # fixed-lag windows by frames with a one-frame halo: tao 2 over shards (3, 2) and tao 3 / 5 over 11 frames (6, 5)
+    wins = {}
+    for F2, tao in ((F, 2), (11, 3), (11, 5), (11, 7), (2, 1)):
+        rw = _walk(F2, n)
+        l2, h2 = D.frame_shard(F2)
+        wins["win_%d_%d" % (F2, tao)] = D.msd_windows_sharded(rw[l2:h2], F2, tao, scale=3.0, compute=_np_windows)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), full=full, part=part, ov=ov, pf=pf, pp=pp, cn=cn,
              sums=sums, sums4=sums4, shard=np.array([lo, hi]), lagm=lagm, acf=acf, ccf=ccf,
-             eshard=np.array([e_lo, e_hi]))
+             eshard=np.array([e_lo, e_hi]), **wins)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -156,6 +174,8 @@ def test_sharded_paths_world2_gloo(tmp_path):
         np.testing.assert_array_equal(g["cn"], cn)
         np.testing.assert_allclose(g["sums"], sums, rtol=1e-14)
         np.testing.assert_allclose(g["sums4"], sums4, rtol=1e-14)
+        for F2, tao in ((F, 2), (11, 3), (11, 5), (11, 7), (2, 1)):
+            np.testing.assert_allclose(g["win_%d_%d" % (F2, tao)], _np_windows(_walk(F2, n)[::tao], 3.0), rtol=1e-13)
     assert shards == [(0, 3), (3, 5)]
 
 
@@ -258,7 +278,15 @@ def _numpy_dynamical_backend():
         cols[:] = pe.reshape(-1, 4).T
         return sums
 
-    def msd_windows(r, tao, scale=1.0, ctx=None):
+    def msd_origin(r, origin, group_off, scale=1.0, cols=None, out=None, ctx=None):
+        stacked = np.concatenate([np.asarray(origin)[None], np.asarray(r)])
+        pairs = [(0, 1 + t) for t in range(len(r))]
+        sums, pe = msd_pairs(stacked, pairs, group_off, scale=scale, per_entity=True)
+        if cols is not None:
+            cols[:] = pe.reshape(-1, 4).T
+        return sums
+
+    def msd_windows(r, tao, scale=1.0, ctx=None, out=None):
         kept = (np.asarray(r) * scale)[::tao]
         d2 = (kept[1:] - kept[:-1]) ** 2  # [W,3,E]
         return np.concatenate([d2.sum(axis=0), d2.sum(axis=(0, 1))[None]]).T
@@ -269,7 +297,7 @@ def _numpy_dynamical_backend():
         return np.stack([np.stack([jm[:, k, np.asarray(seg_type) == t].sum(axis=1) for t in range(n_types)])
                          for k in range(3)])
 
-    return segment_com, msd_pairs, msd_pairs_cols, msd_windows, charge_flux
+    return segment_com, msd_pairs, msd_pairs_cols, msd_windows, charge_flux, msd_origin
 
 
 def _dynamical_worker(rank, world, port, tmp_dir):
@@ -282,7 +310,7 @@ def _dynamical_worker(rank, world, port, tmp_dir):
     from mdproptools_amd.dynamical.diffusion import Diffusion
 
     (backend.segment_com, backend.msd_pairs, backend.msd_pairs_cols, backend.msd_windows,
-     backend.charge_flux) = _numpy_dynamical_backend()
+     backend.charge_flux, backend.msd_origin) = _numpy_dynamical_backend()
     from mdproptools_amd.dynamical import diffusion as dm
 
     dm.STREAM = False  # the streamed route keeps the trajectory on the GPU; its two-rank run is tests/test_gpu_dropin.py
@@ -309,9 +337,10 @@ def _dynamical_worker(rank, world, port, tmp_dir):
 
 
 def test_dropin_diffusion_conductivity_sharded_parse_world2_gloo(tmp_path):
-    """Diffusion.get_msd_from_dump and Conductivity.get_charge_flux under torch.distributed: ranks parse (and, for
-    COM / flux, reduce) their own share of the files, the reduced frames are all-gathered in frame order and the
-    rest runs replicated -> the single-process result on every rank."""
+    """Diffusion.get_msd_from_dump and Conductivity.get_charge_flux under torch.distributed: ranks parse their own
+    share of the files and REDUCE their own frames (MSD: origin frame broadcast, per-frame sums and per-entity columns
+    gathered, fixed-lag windows through a one-frame halo and an all-reduce; flux: per-frame vectors gathered) -> the
+    single-process result on every rank (msd_int to rounding: its windows are summed rank by rank)."""
     import torch.multiprocessing as mp
 
     from mdproptools_amd import io as mio
@@ -333,8 +362,9 @@ def test_dropin_diffusion_conductivity_sharded_parse_world2_gloo(tmp_path):
     assert one["msd"].shape[0] == 7 and one["j"].shape == (3, 2, 7) and np.abs(one["j"]).max() > 0
     for rank in range(2):
         two = np.load(tmp_path / "w2" / ("rank%d.npz" % rank))
-        for key in ("msd", "msd_all", "msd_int", "aa", "j", "time"):
+        for key in ("msd", "msd_all", "aa", "j", "time"):
             np.testing.assert_array_equal(two[key], one[key], err_msg=key)
+        np.testing.assert_allclose(two["msd_int"], one["msd_int"], rtol=1e-13)
 
 
 def _visc_worker(rank, world, port, tmp_dir):

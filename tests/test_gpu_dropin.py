@@ -370,8 +370,18 @@ def _gpu_dist_worker(rank, world, port, tmp_dir):
     aa = d.get_msd_from_dump("msd.*.dump", msd_type="allatom", avg_interval=True, tao_coeff=2)
     cm = d.get_msd_from_dump("msd.*.dump", msd_type="com", num_mols=[500, 500], num_atoms_per_mol=[4, 2],
                              mass=[1.0, 2.0, 3.0], avg_interval=True, tao_coeff=2)
-    np.savez(os.path.join(out, "rank%d.npz" % rank), g=g.to_numpy(), c=c.to_numpy(),
-             **{"aa%d" % k: v.to_numpy() for k, v in enumerate(aa)}, **{"cm%d" % k: v.to_numpy() for k, v in enumerate(cm)})
+    cd = d.get_msd_from_dump("msd.*.dump", msd_type="com", num_mols=[500, 500], num_atoms_per_mol=[4, 2],
+                             mass=[1.0, 2.0, 3.0], com_drift=True, avg_interval=True, tao_coeff=3)
+    from mdproptools_amd.dynamical import diffusion as dmod
+
+    dmod.MSD_ALL_ON_EVERY_RANK = False  # every rank keeps the msd_all rows of ITS frames
+    try:
+        own = d.get_msd_from_dump("msd.*.dump", msd_type="allatom")[1]
+    finally:
+        dmod.MSD_ALL_ON_EVERY_RANK = True
+    np.savez(os.path.join(out, "rank%d.npz" % rank), g=g.to_numpy(), c=c.to_numpy(), own_all=own.to_numpy(),
+             **{"aa%d" % k: v.to_numpy() for k, v in enumerate(aa)}, **{"cm%d" % k: v.to_numpy() for k, v in enumerate(cm)},
+             **{"cd%d" % k: v.to_numpy() for k, v in enumerate(cd)})
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -414,8 +424,14 @@ def test_dropin_rdf_cn_two_ranks_on_gpu(tmp_path):
         two = np.load(tmp_path / "w2" / ("rank%d.npz" % rank))
         np.testing.assert_array_equal(two["g"], one["g"])
         np.testing.assert_array_equal(two["c"], one["c"])
-        for key in ("aa0", "aa1", "aa2", "cm0", "cm1", "cm2"):
+        # Diffusion under torch.distributed reduces every rank's frames where they are (origin broadcast, sums
+        # gathered): msd and msd_all are the single-process frames bit for bit; msd_int's windows are summed rank by
+        # rank (one all-reduce), so its last bits may differ
+        for key in ("aa0", "aa1", "cm0", "cm1", "cd0", "cd1"):
             np.testing.assert_array_equal(two[key], one[key])
+        for key in ("aa2", "cm2", "cd2"):
+            np.testing.assert_allclose(two[key], one[key], rtol=1e-12)
+        np.testing.assert_array_equal(two["own_all"], one["aa1"][{0: slice(0, 4 * 3000), 1: slice(4 * 3000, None)}[rank]])
     assert one["aa0"][-1, 4] > 0
     assert open(tmp_path / "w2" / "rdf.csv").read() == open(tmp_path / "w1" / "rdf.csv").read()
 

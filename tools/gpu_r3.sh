@@ -1,0 +1,20 @@
+#!/bin/bash
+# tools/gpu_r3.sh [steps...] — round-3 GPU-box sequences; every step writes under gpurun_out/.
+set -u
+R=${GRAFT_REPO_ROOT:-$PWD}
+O=$R/gpurun_out
+mkdir -p $O
+cd $R
+for s in "$@"; do
+  echo "== $s $(date +%T)"
+  case $s in
+    tests) timeout -k 10 1100 python -m pytest tests -m gpu -x -q > $O/gpu_tests.log 2>&1; rc=$?; echo "tests rc=$rc"; tail -5 $O/gpu_tests.log; [ $rc -eq 0 ] || exit 1 ;;
+    tests_dist) timeout -k 10 900 python -m pytest tests/test_gpu_fullsize.py tests/test_gpu_dropin.py -m gpu -x -q -k "two_ranks or sharded or bench" > $O/gpu_tests_dist.log 2>&1; rc=$?; echo "tests_dist rc=$rc"; tail -15 $O/gpu_tests_dist.log; [ $rc -eq 0 ] || exit 1 ;;
+    bench) timeout -k 10 900 python bench.py > $O/bench_line.json 2> $O/bench_err.log; echo "bench rc=$?"; tail -3 $O/bench_err.log ;;
+    bench_head) timeout -k 10 300 python bench.py --no-legs > $O/bench_head.json 2> $O/bench_head_err.log; echo "bench rc=$?"; tail -3 $O/bench_head_err.log ;;
+    bench_c4) timeout -k 10 600 python bench.py --workload c4 --steps 10 --warmup 2 > $O/bench_c4_n1.json 2> $O/bench_c4_n1_err.log; echo "c4 rc=$?"; tail -3 $O/bench_c4_n1_err.log; cat $O/bench_c4_n1.json ;;
+    bench_c4_2) MDHIP_DIST_BACKEND=gloo timeout -k 10 600 python bench.py --gpus 2 --workload c4 --steps 5 --warmup 1 > $O/bench_c4_gloo2.json 2> $O/bench_c4_gloo2_err.log; echo "c4x2 rc=$?"; tail -3 $O/bench_c4_gloo2_err.log; cat $O/bench_c4_gloo2.json ;;
+    bench2) MDHIP_DIST_BACKEND=gloo timeout -k 10 600 python bench.py --gpus 2 --steps 5 --warmup 1 > $O/bench_gpus2_gloo.json 2> $O/bench_gpus2_err.log; echo "bench2 rc=$?"; tail -3 $O/bench_gpus2_err.log; cat $O/bench_gpus2_gloo.json ;;
+    *) echo "unknown step $s" ;;
+  esac
+done
