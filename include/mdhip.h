@@ -400,6 +400,21 @@ int mdhip_dump_read(mdhip_dump *d, int64_t f, int n_sel, const int32_t *col_idx,
 int mdhip_dump_read_cols(mdhip_dump *d, int64_t f, int n_sel, const int32_t *col_idx, int sort_col,
                          double *const *outs, int n_threads);
 
+/*
+ * MANY single-frame dump files in one call (the per-timestep files LAMMPS writes; the reference's glob pattern,
+ * rdf_cn.py:176): file k is opened, indexed and parsed by one of n_threads host threads, column s of its atoms going to
+ * dst[s] + k * dst_stride[s] (doubles), rows ordered by ascending sort_name (NULL: file order) — e.g. x, y, z straight
+ * into frame slot k of a page-locked batch buffer [n_files][3][n_atoms] and the ids into a table of their own. Columns
+ * are found by NAME in every file. timesteps [n_files], bounds6 [n_files][6] (as written), tilt3 [n_files][3],
+ * triclinic [n_files]: headers, any may be NULL. Returns MDHIP_OK; a negative MDHIP_E* code with the first failure's
+ * text in err; or 1 when some file is not ONE frame of n_atoms atoms with all the requested columns (err says which):
+ * the caller then reads that batch frame by frame (mdhip_dump_open / mdhip_dump_read_cols).
+ */
+int mdhip_dump_read_files(const char *const *paths, int n_files, int n_sel, const char *const *col_names,
+                          const char *sort_name, int64_t n_atoms, double *const *dst, const int64_t *dst_stride,
+                          int64_t *timesteps, double *bounds6, double *tilt3, int32_t *triclinic, int n_threads,
+                          char *err, int err_len);
+
 /* ---- native LAMMPS log reader (host only) ---------------------------------------------------- */
 /*
  * Role of pymatgen's parse_lammps_log (un-vendored; call sites dynamical/viscosity.py:211,

@@ -68,6 +68,11 @@ struct mdhip_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev2 = nullptr, ev3 = nullptr;  // second pair: preparation kernels, collected without a sync of their own
+    // host-resident pair inputs: the frames of batch k+1 are copied on this stream while batch k is swept (created on
+    // first use); one event per batch in flight
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t copy_ev[2] = {nullptr, nullptr};
+    int opt_h2d_overlap = 1;  // 1 (default): overlapped staging of host-resident pair inputs, 0: one copy up front (A/B)
     std::string err;
     DevBuf ws[WS_COUNT];
     DevBuf pin[PIN_COUNT];

@@ -19,11 +19,13 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -51,6 +53,7 @@ struct mdhip_dump {
     int fd = -1;
     const char *data = nullptr;
     size_t size = 0;
+    bool mapped = true;  // data is an mmap of fd (false: a caller-owned buffer, nothing to unmap)
     std::vector<FrameIndex> frames;
     std::string err;
 };
@@ -287,6 +290,70 @@ int64_t parse_lines(const char *p, const char *end, int64_t n_lines, int n_cols,
 }
 
 
+// One pass over a frame body with DIRECT placement: every line's selected tokens are parsed into a small local row and
+// stored at their destination row at once — the row of the line itself (key_col < 0) or id - 1 when the key column holds
+// a permutation of 1..n (atom ids: what sort_values("id") of the reference amounts to, rdf_cn.py:192) — so that no
+// scratch table, no second (scatter) pass and no line-count pass is needed. `seen` [n] must be zeroed by the caller.
+// Returns 0 ok, 1 malformed row (fewer values than columns, a non-numeric token in a wanted column, fewer lines than
+// atoms), 2 the keys are not a permutation of 1..n (the caller takes the general route: stable sort by key).
+int parse_frame_direct(const char *p, const char *end, int64_t n, int n_cols, int n_sel, const int *col_idx, int key_col,
+                       double *const *outs, unsigned char *seen)
+{
+    constexpr int MAXC = 64;
+    if (n_cols > MAXC) return 2;
+    int want[MAXC];  // 0: skip the token, 1: parse it
+    for (int c = 0; c < n_cols; ++c) want[c] = c == key_col ? 1 : 0;
+    int last = key_col;
+    for (int s = 0; s < n_sel; ++s) {
+        want[col_idx[s]] = 1;
+        last = col_idx[s] > last ? col_idx[s] : last;
+    }
+    double tok[MAXC];
+    for (int64_t k = 0; k < n; ++k) {
+        if (p >= end) return 1;
+        const char *le = line_end(p, end);
+        const char *q = p;
+        for (int c = 0; c < n_cols; ++c) {
+            q = skip_ws(q, le);
+            if (q >= le) return 1;
+            if (!want[c]) {
+                if (c > last) break;  // nothing wanted behind this column: the rest of the line is only counted below
+                while (q < le && *q != ' ' && *q != '\t' && *q != '\r') ++q;
+                continue;
+            }
+            const char ch = *q;
+            if (!((ch >= '0' && ch <= '9') || ch == '-' || ch == '+' || ch == '.' || ch == 'n' || ch == 'N' || ch == 'i' ||
+                  ch == 'I'))
+                return 1;
+            q = parse_double(q, le, &tok[c]);
+        }
+        if (last + 1 < n_cols) {
+            // the columns behind the last wanted one must still be there (a short row is malformed)
+            int c = last + 1;
+            // (q stands behind token `last`, or at the start of token last + 1 when that one was reached above)
+            for (;;) {
+                q = skip_ws(q, le);
+                if (q >= le) break;
+                while (q < le && *q != ' ' && *q != '\t' && *q != '\r') ++q;
+                ++c;
+            }
+            if (c < n_cols) return 1;
+        }
+        int64_t r = k;
+        if (key_col >= 0) {
+            const double v = tok[key_col];
+            const int64_t id = (v >= 1.0 && v <= (double)n) ? (int64_t)v : 0;  // (range first: the cast of NaN is undefined)
+            if (id < 1 || (double)id != v || seen[(size_t)id - 1]) return 2;
+            seen[(size_t)id - 1] = 1;
+            r = id - 1;
+        }
+        for (int s = 0; s < n_sel; ++s) outs[s][r] = tok[col_idx[s]];
+        p = le < end ? le + 1 : end;
+    }
+    return 0;
+}
+
+
 // ---- LAMMPS log files (thermo tables) ------------------------------------------------------------
 // Role of pymatgen's parse_lammps_log (not in the reference tree; call sites dynamical/viscosity.py:211,
 // utilities/log.py:21): a run's thermo table sits between the line that starts with "Memory usage per
@@ -380,7 +447,11 @@ static int guarded(F f)
 
 extern "C" {
 
-static int dump_open_impl(const char *path, mdhip_dump **out)
+// `into` != nullptr: the file is READ into that (reusable, thread-owned) buffer instead of being mapped. A worker that
+// walks through hundreds of small files pays mmap + page faults + munmap per file otherwise, all of them serialised on
+// the process's address-space lock: with 8 threads the batch reader ran SLOWER than with one; a pread from the page
+// cache into a warm buffer touches no page table.
+static int dump_open_impl(const char *path, mdhip_dump **out, std::vector<char> *into = nullptr)
 {
     if (!path || !out) return MDHIP_EINVAL;
     *out = nullptr;
@@ -394,7 +465,24 @@ static int dump_open_impl(const char *path, mdhip_dump **out)
     struct stat st;
     fstat(d->fd, &st);
     d->size = (size_t)st.st_size;
-    if (d->size) {
+    if (into) {
+        d->mapped = false;
+        if (into->size() < d->size) into->resize(d->size + d->size / 4 + 4096);
+        size_t got = 0;
+        while (got < d->size) {
+            const ssize_t r = pread(d->fd, into->data() + got, d->size - got, (off_t)got);
+            if (r < 0 && errno == EINTR) continue;
+            if (r <= 0) break;
+            got += (size_t)r;
+        }
+        if (got != d->size) {
+            g_open_error = std::string("short read of ") + path;
+            close(d->fd);
+            delete d;
+            return MDHIP_EINVAL;
+        }
+        d->data = into->data();
+    } else if (d->size) {
         void *m = mmap(nullptr, d->size, PROT_READ, MAP_PRIVATE, d->fd, 0);
         if (m == MAP_FAILED) {
             g_open_error = std::string("mmap failed for ") + path;
@@ -418,7 +506,7 @@ static int dump_open_impl(const char *path, mdhip_dump **out)
 void mdhip_dump_close(mdhip_dump *d)
 {
     if (!d) return;
-    if (d->data) munmap((void *)d->data, d->size);
+    if (d->data && d->mapped) munmap((void *)d->data, d->size);
     if (d->fd >= 0) close(d->fd);
     delete d;
 }
@@ -470,6 +558,26 @@ static int dump_read_impl(mdhip_dump *d, int64_t f, int n_sel, const int32_t *co
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 64) n_threads = 64;
     if (n < 4096) n_threads = 1;
+    if (n_threads == 1) {
+        // one thread: a single pass with direct placement (no scratch table, no thread start-up)
+        std::vector<unsigned char> seen(sort_col >= 0 ? (size_t)n : 0, 0);
+        std::vector<int> ci(col_idx, col_idx + n_sel);
+        const int st = parse_frame_direct(body, body_end, n, fr.n_cols, n_sel, ci.data(), sort_col, outs, seen.data());
+        if (st == 0) return MDHIP_OK;
+        if (st == 1) {
+            // which of the two messages: fewer lines than atoms, or a bad row
+            int64_t lines = 0;
+            for (const char *q = body; q < body_end;) {
+                const char *le = line_end(q, body_end);
+                ++lines;
+                q = le < body_end ? le + 1 : body_end;
+            }
+            d->err = lines < n ? "mdhip_dump_read: frame body has fewer lines than NUMBER OF ATOMS"
+                               : "mdhip_dump_read: a row has fewer values than columns or a value that is not a number";
+            return MDHIP_EINVAL;
+        }
+        // st == 2: keys that are not a permutation of 1..n -> the general route below (stable sort by key)
+    }
     // line offsets of the thread chunks (chunk boundaries by bytes, aligned to line starts, then counted)
     std::vector<const char *> cstart(n_threads + 1);
     std::vector<int64_t> cline(n_threads + 1, 0);
@@ -735,6 +843,130 @@ int mdhip_dump_read_cols(mdhip_dump *d, int64_t f, int n_sel, const int32_t *col
                          int n_threads)
 {
     return guarded([&] { return dump_read_impl(d, f, n_sel, col_idx, sort_col, outs, n_threads); });
+}
+
+// ---- many single-frame files in one call --------------------------------------------------------------
+static int split_names(const std::string &cols, std::vector<std::string> &out)
+{
+    out.clear();
+    size_t i = 0;
+    while (i < cols.size()) {
+        size_t j = cols.find(' ', i);
+        if (j == std::string::npos) j = cols.size();
+        if (j > i) out.emplace_back(cols.substr(i, j - i));
+        i = j + 1;
+    }
+    return (int)out.size();
+}
+
+static int dump_read_files_impl(const char *const *paths, int n_files, int n_sel, const char *const *col_names,
+                                const char *sort_name, int64_t n_atoms, double *const *dst, const int64_t *dst_stride,
+                                int64_t *timesteps, double *bounds6, double *tilt3, int32_t *triclinic, int n_threads,
+                                char *err, int err_len)
+{
+    if (err && err_len > 0) err[0] = 0;
+    if (n_files < 0 || n_sel < 0 || n_atoms < 0 || (n_files && !paths) || (n_sel && (!col_names || !dst || !dst_stride)))
+        return MDHIP_EINVAL;
+    if (n_files == 0) return MDHIP_OK;
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > n_files) n_threads = n_files;
+    if (n_threads > 64) n_threads = 64;
+    std::atomic<int> next{0};
+    std::atomic<int> status{MDHIP_OK};  // first failure wins
+    std::string first_error;
+    std::mutex err_mu;
+    auto fail = [&](int code, const std::string &msg) {
+        int expect = MDHIP_OK;
+        if (status.compare_exchange_strong(expect, code)) {
+            std::lock_guard<std::mutex> g(err_mu);
+            first_error = msg;
+        }
+    };
+    auto work = [&] {
+        std::vector<unsigned char> seen;
+        std::vector<std::string> names;
+        std::vector<int> ci((size_t)n_sel);
+        std::vector<double *> outs((size_t)n_sel);
+        std::vector<char> text;  // this worker's file buffer, reused from file to file
+        for (;;) {
+            const int k = next.fetch_add(1);
+            if (k >= n_files || status.load() != MDHIP_OK) return;
+            mdhip_dump *d = nullptr;
+            const int rc = dump_open_impl(paths[k], &d, &text);
+            if (rc) {
+                fail(rc, g_open_error);
+                return;
+            }
+            struct Closer {
+                mdhip_dump *d;
+                ~Closer() { mdhip_dump_close(d); }
+            } closer{d};
+            if (d->frames.size() != 1 || d->frames[0].natoms != n_atoms) {
+                fail(1, std::string(paths[k]) + ": not one frame of the expected atom count");
+                return;
+            }
+            const FrameIndex &fr = d->frames[0];
+            split_names(fr.columns, names);
+            int key = -1;
+            bool ok = true;
+            for (int s = 0; s < n_sel && ok; ++s) {
+                ci[s] = -1;
+                for (int c = 0; c < (int)names.size(); ++c)
+                    if (names[c] == col_names[s]) ci[s] = c;
+                ok = ci[s] >= 0;
+                outs[s] = dst[s] + (size_t)k * (size_t)dst_stride[s];
+            }
+            if (ok && sort_name) {
+                for (int c = 0; c < (int)names.size(); ++c)
+                    if (names[c] == sort_name) key = c;
+                ok = key >= 0;
+            }
+            if (!ok) {
+                fail(1, std::string(paths[k]) + ": a requested column is missing");
+                return;
+            }
+            if (timesteps) timesteps[k] = fr.timestep;
+            if (bounds6) memcpy(bounds6 + (size_t)k * 6, fr.bounds, 48);
+            if (tilt3) memcpy(tilt3 + (size_t)k * 3, fr.tilt, 24);
+            if (triclinic) triclinic[k] = fr.triclinic;
+            if (n_atoms == 0 || n_sel == 0) continue;
+            seen.assign(key >= 0 ? (size_t)n_atoms : 0, 0);
+            const char *body = d->data + fr.body_begin, *body_end = d->data + fr.body_end;
+            int st = parse_frame_direct(body, body_end, n_atoms, fr.n_cols, n_sel, ci.data(), key, outs.data(), seen.data());
+            if (st == 2) {  // ids that are not a permutation of 1..n: the general route (stable sort by key)
+                std::vector<int32_t> ci32(ci.begin(), ci.end());
+                st = dump_read_impl(d, 0, n_sel, ci32.data(), key, outs.data(), 1) == MDHIP_OK ? 0 : 1;
+            }
+            if (st) {
+                fail(MDHIP_EINVAL, std::string(paths[k]) + ": " + (d->err.empty() ? "a row has fewer values than columns or a value that is not a number" : d->err));
+                return;
+            }
+        }
+    };
+    if (n_threads == 1) {
+        work();
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_threads; ++t) th.emplace_back(work);
+        for (auto &x : th) x.join();
+    }
+    const int rc = status.load();
+    if (rc != MDHIP_OK && err && err_len > 0) {
+        strncpy(err, first_error.c_str(), (size_t)err_len - 1);
+        err[err_len - 1] = 0;
+    }
+    return rc;
+}
+
+int mdhip_dump_read_files(const char *const *paths, int n_files, int n_sel, const char *const *col_names,
+                          const char *sort_name, int64_t n_atoms, double *const *dst, const int64_t *dst_stride,
+                          int64_t *timesteps, double *bounds6, double *tilt3, int32_t *triclinic, int n_threads,
+                          char *err, int err_len)
+{
+    return guarded([&] {
+        return dump_read_files_impl(paths, n_files, n_sel, col_names, sort_name, n_atoms, dst, dst_stride, timesteps,
+                                    bounds6, tilt3, triclinic, n_threads, err, err_len);
+    });
 }
 
 int mdhip_log_open(const char *path, mdhip_log **out)

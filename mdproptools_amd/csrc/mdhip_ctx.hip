@@ -138,6 +138,12 @@ void mdhip_destroy(mdhip_ctx *ctx)
         if (b.p) (void)hipHostFree(b.p);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->copy_stream) {
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        (void)hipStreamDestroy(ctx->copy_stream);
+    }
+    for (auto &e : ctx->copy_ev)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
     if (ctx->ev3) (void)hipEventDestroy(ctx->ev3);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -254,6 +260,8 @@ int mdhip_set_option(mdhip_ctx *ctx, const char *key, int value)
         ctx->opt_rdf_slots = value < 1 ? 1 : value;
     else if (!strcmp(key, "xcorr_tile"))
         ctx->opt_xcorr_tile = value;
+    else if (!strcmp(key, "h2d_overlap"))
+        ctx->opt_h2d_overlap = value;
     else
         return mdhip_fail(ctx, MDHIP_EINVAL, "mdhip_set_option: unknown key '%s'", key);
     return MDHIP_OK;

@@ -68,6 +68,10 @@ struct PairProblem {
     int n_cn = 0;                             // != 0: on
     const double *cn_c2_cls = nullptr;        // host [n_cls]
     std::vector<uint64_t> *Hsplit = nullptr;  // out: [F|1][n_cls] pairs of the split bin with rsq < cutoff^2
+    // Host-resident coordinates staged batch by batch (pair_hist_run): h_xi / h_xj are the caller's arrays, d_xi / d_xj
+    // the (still empty) device buffers for all frames; the copy of batch k+1 runs on ctx->copy_stream while batch k is
+    // swept. nullptr: the coordinates are on the device already.
+    const double *h_xi = nullptr, *h_xj = nullptr;
 };
 constexpr int CN_UNFUSED = 1;  // (positive: not an error code of the ABI)
 constexpr int SPLIT_BATCH = 2;  // a block may have wrapped a 32-bit LDS word: run the batch again in halves
@@ -568,8 +572,29 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
     return MDHIP_OK;
 }
 
+// Copies the frames [f0, f0 + n) of the host-resident inputs of `p` to their device buffers on the copy stream and
+// records `ev` behind them.
+static int stage_batch_async(mdhip_ctx *ctx, const PairProblem &p, int64_t f0, int64_t n, hipEvent_t ev)
+{
+    if (p.h_xi)
+        MD_HIP(hipMemcpyAsync(const_cast<double *>(p.d_xi) + (size_t)f0 * 3 * p.ni, p.h_xi + (size_t)f0 * 3 * p.ni,
+                              (size_t)n * 3 * p.ni * 8, hipMemcpyHostToDevice, ctx->copy_stream));
+    if (p.h_xj)
+        MD_HIP(hipMemcpyAsync(const_cast<double *>(p.d_xj) + (size_t)f0 * 3 * p.nj, p.h_xj + (size_t)f0 * 3 * p.nj,
+                              (size_t)n * 3 * p.nj * 8, hipMemcpyHostToDevice, ctx->copy_stream));
+    MD_HIP(hipEventRecord(ev, ctx->copy_stream));
+    return MDHIP_OK;
+}
+
+static int pair_hist_run_range(mdhip_ctx *ctx, const PairProblem &p, int64_t f0, int64_t n, std::vector<uint64_t> &H,
+                               uint64_t *overflow, std::vector<uint64_t> *Hsplit);
+
 // Splits the frames into batches so that the culled path's workspace (sorted copy, keys, cell counts, boxes,
 // neighbour-tile lists) stays within ~2 GiB and a launch's grid.y within 65535, and merges the batches.
+// Host-resident coordinates (p.h_xi): the batches are also the unit of the host-to-device staging — the copy of batch
+// k + 1 is issued on the copy stream before batch k is swept, so that it runs under that sweep (page-locked sources:
+// a DMA the host does not wait for; pageable sources: the runtime stages them synchronously, so the copy simply comes
+// first, as without this scheme). A shorter first batch lets the sweep start early.
 int pair_hist_run(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64_t> &H, uint64_t *overflow)
 {
     const int64_t F = p.n_frames;
@@ -579,34 +604,49 @@ int pair_hist_run(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64_t> &H
     if (batch < 1) batch = 1;
     if (batch > 32768) batch = 32768;
     if (ctx->opt_rdf_batch > 0) batch = ctx->opt_rdf_batch;
-    if (F <= batch) {
-        const int rc1 = pair_hist_run_batch(ctx, p, H, overflow);
-        if (rc1 != SPLIT_BATCH) return rc1;
-        if (F == 1)
-            return mdhip_fail(ctx, MDHIP_ELIMIT, "pair_hist: one frame can overflow the 32-bit block histograms "
-                                                  "(%lld x %lld atoms)", (long long)p.ni, (long long)p.nj);
-        batch = (F + 1) / 2;
+    const bool staged = p.h_xi || p.h_xj;
+    // the batches: [f0, f0 + n)
+    std::vector<std::pair<int64_t, int64_t>> parts;
+    {
+        int64_t f0 = 0;
+        if (staged && F >= 32) {
+            // first batch: a quarter of the frames (whole multiples of 8: frames are dealt to the 8 XCDs). Its sweep has
+            // to last as long as the copy of the rest — the sweep consumes frames ~3.7x slower than PCIe delivers them
+            // at C2 and at C3 size (61 against 230 frames per ms at 10k atoms) — or the second sweep waits for data
+            // (a sixth measured 3.94 ms per C2 step with a 0.18 ms stall)
+            int64_t b0 = std::max<int64_t>(8, (F / 4) / 8 * 8);
+            b0 = std::min(b0, batch);
+            parts.emplace_back(0, b0);
+            f0 = b0;
+        }
+        for (; f0 < F; f0 += batch) parts.emplace_back(f0, std::min<int64_t>(batch, F - f0));
     }
     const size_t row = (size_t)p.n_cls * p.nbins;
-    H.assign((p.per_frame ? (size_t)F : 1) * row, 0);
     const size_t row_cn = (size_t)p.n_cls;
+    if (staged) {
+        const int rc = stage_batch_async(ctx, p, parts[0].first, parts[0].second, ctx->copy_ev[0]);
+        if (rc) return rc;
+    }
+    if (parts.size() == 1 && !staged) return pair_hist_run_range(ctx, p, 0, F, H, overflow, p.Hsplit);
+    H.assign((p.per_frame ? (size_t)F : 1) * row, 0);
     if (p.Hsplit) p.Hsplit->assign((p.per_frame ? (size_t)F : 1) * row_cn, 0);
     *overflow = 0;
     double ms = 0.0, aux = 0.0;
     int launches = 0;
     std::vector<uint64_t> part, part_cn;
-    for (int64_t f0 = 0; f0 < F; f0 += batch) {
-        PairProblem q = p;
-        if (p.Hsplit) q.Hsplit = &part_cn;
-        q.n_frames = std::min<int64_t>(batch, F - f0);
-        q.d_xi = p.d_xi + (size_t)f0 * 3 * p.ni;
-        q.d_xj = p.d_xj + (size_t)f0 * 3 * p.nj;
-        q.d_ti = p.d_ti + (size_t)f0 * p.ti_fs;
-        q.d_tj = p.d_tj + (size_t)f0 * p.tj_fs;
-        q.d_box = p.d_box + (size_t)f0 * 3;
-        q.h_box = p.h_box + (size_t)f0 * 3;
+    for (size_t k = 0; k < parts.size(); ++k) {
+        const int64_t f0 = parts[k].first, n = parts[k].second;
+        if (staged) {
+            // this batch's frames must have landed before the launch stream touches them; the next batch's copy goes
+            // out now, ahead of this batch's kernels
+            MD_HIP(hipStreamWaitEvent(ctx->stream, ctx->copy_ev[k & 1], 0));
+            if (k + 1 < parts.size()) {
+                const int rc = stage_batch_async(ctx, p, parts[k + 1].first, parts[k + 1].second, ctx->copy_ev[(k + 1) & 1]);
+                if (rc) return rc;
+            }
+        }
         uint64_t ov = 0;
-        int rc = pair_hist_run(ctx, q, part, &ov);  // (recursion: a batch whose blocks may wrap a word is halved again)
+        const int rc = pair_hist_run_range(ctx, p, f0, n, part, &ov, p.Hsplit ? &part_cn : nullptr);
         if (rc) return rc;
         *overflow += ov;
         ms += ctx->last_ms;
@@ -615,12 +655,67 @@ int pair_hist_run(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64_t> &H
         if (p.per_frame)
             std::copy(part.begin(), part.end(), H.begin() + (size_t)f0 * row);
         else
-            for (size_t k = 0; k < row; ++k) H[k] += part[k];
+            for (size_t q = 0; q < row; ++q) H[q] += part[q];
         if (p.Hsplit) {
             if (p.per_frame)
                 std::copy(part_cn.begin(), part_cn.end(), p.Hsplit->begin() + (size_t)f0 * row_cn);
             else
-                for (size_t k = 0; k < row_cn; ++k) (*p.Hsplit)[k] += part_cn[k];
+                for (size_t q = 0; q < row_cn; ++q) (*p.Hsplit)[q] += part_cn[q];
+        }
+    }
+    ctx->last_ms = ms;
+    ctx->last_aux_ms = aux;
+    ctx->last_launches = launches;
+    return MDHIP_OK;
+}
+
+// The frames [f0, f0 + n) of `p` (their coordinates are on the device): one batch, or — when a block's 32-bit histogram
+// words might wrap — halves of it, recursively. Results as pair_hist_run_batch's.
+static int pair_hist_run_range(mdhip_ctx *ctx, const PairProblem &p, int64_t f0, int64_t n, std::vector<uint64_t> &H,
+                               uint64_t *overflow, std::vector<uint64_t> *Hsplit)
+{
+    PairProblem q = p;
+    q.h_xi = q.h_xj = nullptr;
+    q.Hsplit = Hsplit;
+    q.n_frames = n;
+    q.d_xi = p.d_xi + (size_t)f0 * 3 * p.ni;
+    q.d_xj = p.d_xj + (size_t)f0 * 3 * p.nj;
+    q.d_ti = p.d_ti + (size_t)f0 * p.ti_fs;
+    q.d_tj = p.d_tj + (size_t)f0 * p.tj_fs;
+    q.d_box = p.d_box + (size_t)f0 * 3;
+    q.h_box = p.h_box + (size_t)f0 * 3;
+    const int rc1 = pair_hist_run_batch(ctx, q, H, overflow);
+    if (rc1 != SPLIT_BATCH) return rc1;
+    if (n == 1)
+        return mdhip_fail(ctx, MDHIP_ELIMIT, "pair_hist: one frame can overflow the 32-bit block histograms "
+                                              "(%lld x %lld atoms)", (long long)p.ni, (long long)p.nj);
+    // (device-resident sums, dev_out, are left untouched by a flagged launch)
+    const size_t row = (size_t)p.n_cls * p.nbins, row_cn = (size_t)p.n_cls;
+    H.assign((p.per_frame ? (size_t)n : 1) * row, 0);
+    if (Hsplit) Hsplit->assign((p.per_frame ? (size_t)n : 1) * row_cn, 0);
+    *overflow = 0;
+    double ms = 0.0, aux = 0.0;
+    int launches = 0;
+    std::vector<uint64_t> part, part_cn;
+    const int64_t half = (n + 1) / 2;
+    for (int64_t h0 = 0; h0 < n; h0 += half) {
+        uint64_t ov = 0;
+        const int rc = pair_hist_run_range(ctx, p, f0 + h0, std::min<int64_t>(half, n - h0), part, &ov,
+                                           Hsplit ? &part_cn : nullptr);
+        if (rc) return rc;
+        *overflow += ov;
+        ms += ctx->last_ms;
+        aux += ctx->last_aux_ms;
+        launches += ctx->last_launches;
+        if (p.per_frame)
+            std::copy(part.begin(), part.end(), H.begin() + (size_t)h0 * row);
+        else
+            for (size_t k = 0; k < row; ++k) H[k] += part[k];
+        if (Hsplit) {
+            if (p.per_frame)
+                std::copy(part_cn.begin(), part_cn.end(), Hsplit->begin() + (size_t)h0 * row_cn);
+            else
+                for (size_t k = 0; k < row_cn; ++k) (*Hsplit)[k] += part_cn[k];
         }
     }
     ctx->last_ms = ms;
@@ -772,8 +867,30 @@ int run_job(mdhip_ctx *ctx, const RelJob &j, std::vector<uint64_t> &H, std::vect
     p.n_tj = n_tj;
 
     int rc;
-    p.d_xi = (const double *)mdhip_stage(ctx, WS_XYZ_I, j.xi, (size_t)j.F * 3 * j.ni * 8, j.xi_dev, &rc);
-    if (rc) return rc;
+    // Host-resident coordinates are staged batch by batch under the sweeps (pair_hist_run); the guard drains the copy
+    // stream on every way out, so that no copy still reads the caller's arrays after this call has returned.
+    struct CopyGuard {
+        mdhip_ctx *c;
+        ~CopyGuard()
+        {
+            if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+        }
+    } copy_guard{ctx};
+    const bool overlap = ctx->opt_h2d_overlap != 0 && (!j.xi_dev || (!j.tri && !j.xj_dev));
+    if (overlap && !ctx->copy_stream) {
+        MD_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        MD_HIP(hipEventCreateWithFlags(&ctx->copy_ev[0], hipEventDisableTiming));
+        MD_HIP(hipEventCreateWithFlags(&ctx->copy_ev[1], hipEventDisableTiming));
+    }
+    if (overlap && !j.xi_dev) {
+        MD_WS(d_x, double, WS_XYZ_I, (size_t)j.F * 3 * j.ni * 8);
+        // (a workspace buffer that was just re-allocated may still be read by nothing: mdhip_ws synchronised the stream)
+        p.d_xi = d_x;
+        p.h_xi = j.xi;
+    } else {
+        p.d_xi = (const double *)mdhip_stage(ctx, WS_XYZ_I, j.xi, (size_t)j.F * 3 * j.ni * 8, j.xi_dev, &rc);
+        if (rc) return rc;
+    }
     // compact types of both sets and the box lengths: one pinned staging buffer (owned by the context, so the
     // asynchronous copies need no sync before this function's vectors go away)
     const size_t ti_b = (idx_i.size() * 4 + 63) & ~size_t(63), tj_b = (idx_j.size() * 4 + 63) & ~size_t(63);
@@ -792,8 +909,14 @@ int run_job(mdhip_ctx *ctx, const RelJob &j, std::vector<uint64_t> &H, std::vect
         p.tj_fs = p.ti_fs;
         p.nj = j.ni;
     } else {
-        p.d_xj = (const double *)mdhip_stage(ctx, WS_XYZ_J, j.xj, (size_t)j.F * 3 * j.nj * 8, j.xj_dev, &rc);
-        if (rc) return rc;
+        if (overlap && !j.xj_dev) {
+            MD_WS(d_xjw, double, WS_XYZ_J, (size_t)j.F * 3 * j.nj * 8);
+            p.d_xj = d_xjw;
+            p.h_xj = j.xj;
+        } else {
+            p.d_xj = (const double *)mdhip_stage(ctx, WS_XYZ_J, j.xj, (size_t)j.F * 3 * j.nj * 8, j.xj_dev, &rc);
+            if (rc) return rc;
+        }
         MD_WS(d_tj, int, WS_TYPE_J, idx_j.size() * 4);
         MD_HIP(hipMemcpyAsync(d_tj, h_in + ti_b, idx_j.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         p.d_tj = d_tj;

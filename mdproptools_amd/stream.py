@@ -184,6 +184,10 @@ class FrameStream:
             return self._produce_by_copy()  # compressed text goes through the pandas route
         try:
             files = self.files if self.files is not None else mio._sorted_matches(self.pattern)
+            done = self._produce_whole_files(files)
+            if done is None:
+                return
+            files = files[done:]  # (what the batch reader did not take: multi-frame files, changing atom counts)
             workers = int(os.environ.get("MDHIP_STREAM_WORKERS", "0")) or min(max(1, (os.cpu_count() or 1) // 2), 32)
             ahead = 2 * workers  # files opened (indexed) ahead of the one being placed
             with ThreadPoolExecutor(max_workers=workers) as pool:
@@ -263,6 +267,82 @@ class FrameStream:
             self._error = e
         finally:
             self._ready.put(None)
+
+    def _produce_whole_files(self, files):
+        """The common trajectory — one frame per file, the same atoms in every file — a BATCH of files per library
+        call (mdhip_dump_read_files): the library's own threads open, index and parse the files of a batch and place
+        x, y, z straight into the frame slots of the page-locked buffer, ids and types into their tables; Python does
+        per-batch work only (per-file Python — open, header, a future per frame — cost ~0.2 ms a file: as much as the
+        parsing itself for 10 000-atom frames). Returns the number of files consumed (the caller's per-frame route takes
+        the rest: multi-frame files, a changing atom count, a missing column), or None when the stream was closed."""
+        import ctypes as C
+        import os
+
+        if not files:
+            return 0
+        try:
+            from . import _lib
+
+            lib = _lib.load()
+        except Exception:
+            return 0
+        threads = int(os.environ.get("MDHIP_STREAM_WORKERS", "0")) or min(max(1, (os.cpu_count() or 1) // 2), 32)
+        done = 0
+        n = None
+        cols = (C.c_char_p * len(self.columns))(*[c.encode() for c in self.columns])
+        while done < len(files):
+            if self._closed:
+                return None
+            if n is None:
+                nd = mio.NativeDumpFile(files[done])
+                try:
+                    if nd.n_frames != 1:
+                        return done
+                    n = nd.header(0)[1]
+                finally:
+                    nd.close()
+                if n < 1:
+                    return done
+            cap = max(1, self.batch_bytes // max(1, 24 * n))
+            chunk = files[done:done + cap]
+            B = len(chunk)
+            buf = self._get_buffer(cap * 3 * n)
+            if buf is None:
+                return None
+            ids, types = np.empty((B, n)), np.empty((B, n))
+            steps = np.empty(B, dtype=np.int64)
+            bounds, tilt = np.empty((B, 6)), np.empty((B, 3))
+            tri = np.zeros(B, dtype=np.int32)
+            base = buf.array.ctypes.data
+            dptr = C.POINTER(C.c_double)
+            dst = (dptr * 5)(C.cast(ids.ctypes.data, dptr), C.cast(types.ctypes.data, dptr), C.cast(base, dptr),
+                             C.cast(base + 8 * n, dptr), C.cast(base + 16 * n, dptr))
+            stride = (C.c_int64 * 5)(n, n, 3 * n, 3 * n, 3 * n)
+            paths = (C.c_char_p * B)(*[str(f).encode() for f in chunk])
+            err = C.create_string_buffer(512)
+            t0 = time.perf_counter()
+            rc = lib.mdhip_dump_read_files(paths, B, 5, cols, b"id", n, dst, stride,
+                                           steps.ctypes.data_as(C.POINTER(C.c_int64)),
+                                           bounds.ctypes.data_as(dptr), tilt.ctypes.data_as(dptr),
+                                           tri.ctypes.data_as(C.POINTER(C.c_int32)), threads, err, 512)
+            self.stats["parse_s"] += (time.perf_counter() - t0) * min(threads, B)  # (upper bound: wall x threads)
+            if rc == 1 or (rc == 0 and tri.any()):
+                # some file of the chunk is not a plain single frame of n atoms in an orthogonal box: the per-frame
+                # route from here (it applies the tilt correction of the bounds)
+                self._free.put(buf)
+                return done
+            if rc != 0:
+                self._free.put(buf)
+                raise ValueError(err.value.decode() or "mdhip_dump_read_files failed (%d)" % rc)
+            # orthogonal cell: |row| of the diagonal cell matrix = hi - lo, as LammpsBox.to_lattice().lengths computes it
+            # (sqrt(a * a) == |a| exactly)
+            lengths = np.abs(np.column_stack([bounds[:, 1] - bounds[:, 0], bounds[:, 3] - bounds[:, 2],
+                                              bounds[:, 5] - bounds[:, 4]]))
+            self._ready.put((Batch(self, buf, B, n, ids, types, lengths, steps), []))
+            self.stats["batches"] += 1
+            self.stats["frames"] += B
+            done += B
+        return done
 
     def _produce_by_copy(self):
         """Fallback producer (compressed dumps): frames from the generic reader, copied into the staging slots."""

@@ -163,6 +163,77 @@ def _normalize_rdf(bin_size, rho_pairs, atom_types, partial_relations, num_relat
     return rdf_full, rdf_part
 
 
+def _normalize_rdf_batch(bin_size, props, partial_relations, num_relations, num_bins, part, full=None, num_atoms=None):
+    """`_normalize_rdf` for all B frames of a batch in ONE numpy expression per output, each element through the
+    reference's operations in the reference's order (rdf_cn.py:312-328):
+        g_full[k][b]    = h / ((num_atoms_k * rho_k) * shell[b])
+        g_part[k][r][b] = h / ((n_ref[k][r] * rho_pair[k][r]) * shell[b])
+    (the reference tiles n_ref, rho_pair and the shell volumes to [R, nb] and multiplies left to right: the same two
+    products per element, so the doubles are the same). part uint64 [B,R,nb], full uint64 [B,nb] or None.
+    Returns rows [B, (1 + R) * nb] (or [B, R * nb] without `full`): g_full | g_part, as the per-frame code stacked them."""
+    B = len(props)
+    sv = _shell_volume(bin_size, num_bins)
+    n_ref = np.array([[p[2][a] for a in partial_relations[0]] for p in props]).reshape(B, num_relations)
+    rho_b = np.stack([p[1] for p in props]).reshape(B, num_relations)
+    g_part = np.asarray(part).astype(np.float64) / ((n_ref * rho_b)[:, :, None] * sv[None, None, :])
+    if full is None:
+        return g_part.reshape(B, num_relations * num_bins)
+    na_rho = np.array([n * p[0] for n, p in zip(num_atoms, props)])
+    g_full = np.asarray(full).astype(np.float64) / (na_rho[:, None] * sv[None, :])
+    return np.concatenate([g_full, g_part.reshape(B, num_relations * num_bins)], axis=1)
+
+
+def _sum_frames(rows):
+    """Sum of the per-frame rows in FRAME ORDER, one addition per frame and element as the reference's
+    `rdf_full_sum += ...` loop (rdf_cn.py:514-515; numpy's own sum would add pairwise: other roundings)."""
+    acc = np.zeros(rows.shape[1])
+    for row in rows:
+        acc += row
+    return acc
+
+
+_PROPS_MEMO = {"key": None, "val": None}
+
+
+def _calc_props_memo(box_lengths, ref_labels, obj_labels, num_types, mass, partial_relations, altered,
+                     num_atoms_per_mol=None):
+    """_calc_props, computed once for consecutive frames with the same box and the same labels (NVT trajectories:
+    every frame): the densities are functions of exactly those. Not used with VERBOSE (the density line is printed
+    per frame there, as the reference does)."""
+    if VERBOSE:
+        return _calc_props(box_lengths, ref_labels, obj_labels, num_types, mass, partial_relations, altered,
+                           num_atoms_per_mol)
+    m = _PROPS_MEMO
+    key = (tuple(float(x) for x in box_lengths), num_types, tuple(float(x) for x in mass),
+           tuple(map(tuple, partial_relations)), altered, None if num_atoms_per_mol is None else tuple(num_atoms_per_mol))
+    same_labels = (m["key"] is not None and m["key"][0] == key and m["key"][1].shape == np.shape(ref_labels)
+                   and np.array_equal(m["key"][1], ref_labels)
+                   and (obj_labels is ref_labels or (m["key"][2] is not None and np.array_equal(m["key"][2], obj_labels))))
+    if same_labels:
+        return m["val"]
+    val = _calc_props(box_lengths, ref_labels, obj_labels, num_types, mass, partial_relations, altered, num_atoms_per_mol)
+    m["key"] = (key, np.array(ref_labels, copy=True), None if obj_labels is ref_labels else np.array(obj_labels, copy=True))
+    m["val"] = val
+    return val
+
+
+def _write_csv(df, path_or_buf):
+    """`df.to_csv(path_or_buf, index=False)` — byte for byte — for the all-float64 frames these functions write,
+    without pandas' per-cell formatting machinery (20 ms for 400 x 12 values, a quarter of a C2-size call): pandas
+    writes the shortest round-trip decimal of every double, which is Python's repr, and an empty field for NaN."""
+    simple = (isinstance(path_or_buf, (str, bytes)) or hasattr(path_or_buf, "__fspath__")) and \
+        all(str(t) == "float64" for t in df.dtypes) and \
+        not any(ch in str(c) for c in df.columns for ch in ',"\n\r')
+    if not simple:
+        df.to_csv(path_or_buf, index=False)
+        return
+    lines = [",".join(str(c) for c in df.columns)]
+    for row in df.to_numpy().tolist():
+        lines.append(",".join("" if v != v else repr(v) for v in row))
+    with open(path_or_buf, "w", newline="") as fh:
+        fh.write("\n".join(lines) + "\n")
+
+
 def _normalize_cn(atom_types, partial_relations, cn):
     return cn / [atom_types[a] for a in partial_relations[0]]  # rdf_cn.py:332-338
 
@@ -174,7 +245,7 @@ def _save_rdf(radii, relation_matrix, path_or_buf, save_mode, rdf_part_sum, rdf_
     blocks = (radii, rdf_full_sum, rdf_part_sum) if rdf_full_sum is not None else (radii, rdf_part_sum)
     final_df = pd.DataFrame(np.vstack(blocks).transpose(), columns=cols)
     if save_mode:
-        final_df.to_csv(path_or_buf, index=False)
+        _write_csv(final_df, path_or_buf)
         _say("Results are written to pd.DataFrame and csv file")
     else:
         _say(final_df)
@@ -185,7 +256,7 @@ def _save_cn(relation_matrix, path_or_buff, cn_sum, save_mode):
     cols = [f"cn_{pair[0]}-{pair[1]}" for pair in relation_matrix]
     final_df = pd.DataFrame(np.vstack(cn_sum).transpose(), columns=cols)
     if save_mode:
-        final_df.to_csv(path_or_buff, index=False)
+        _write_csv(final_df, path_or_buff)
         _say("CN results are written to pd.DataFrame and csv file")
     else:
         _say(final_df)
@@ -266,7 +337,10 @@ def _all_frames(per_frame_rows):
     the gathered rows in that order gives bit for bit what one process gets."""
     from .. import dist as D
 
-    rows = np.stack(per_frame_rows) if len(per_frame_rows) else None
+    if len(per_frame_rows) and np.ndim(per_frame_rows[0]) == 2:  # per-batch blocks [B, W]
+        rows = np.concatenate(per_frame_rows)
+    else:
+        rows = np.stack(per_frame_rows) if len(per_frame_rows) else None
     if not D.is_distributed():
         return [] if rows is None else rows
     D.require_all_nonempty(0 if rows is None else len(rows), "frame")  # every rank raises, or none
@@ -347,25 +421,24 @@ def calc_atomic_rdf(r_cut, bin_size, num_types, mass, partial_relations, filenam
     for batch in _batches(frames):
         start = timer()
         labels = [(_calc_atom_type(f.ids, num_mols, num_atoms_per_mol) if altered else f.types) for f in batch]
-        props = [_calc_props(f.lengths, lab, lab, num_types, mass, partial_relations, altered,
-                             num_atoms_per_mol) for f, lab in zip(batch, labels)]
+        props = [_calc_props_memo(f.lengths, lab, lab, num_types, mass, partial_relations, altered,
+                                  num_atoms_per_mol) for f, lab in zip(batch, labels)]
         full, part, ov = backend.rdf_loop(_xyz_block(batch), _labels_for(batch, labels),
                                           np.array([f.lengths for f in batch]), relation_matrix, r_cut,
                                           bin_size, num_bins, per_frame=True)
         dropped += ov
-        for k, f in enumerate(batch):
-            rho, rho_pairs, atom_types, _ = props[k]
-            g_full, g_part = _normalize_rdf(bin_size, rho_pairs, atom_types, partial_relations, num_relations,
-                                            num_bins, part[k].astype(np.float64), full[k].astype(np.float64),
-                                            f.xyz.shape[1], rho)
-            rows.append(np.concatenate([g_full, np.ravel(g_part)]))
-            _say("Finished computing RDF for timestep", f.timestep)
+        # every frame normalised with ITS box and densities (rdf_cn.py:502-513), all frames of the batch at once
+        rows.append(_normalize_rdf_batch(bin_size, props, partial_relations, num_relations, num_bins, part, full,
+                                         [f.xyz.shape[1] for f in batch]))
+        if VERBOSE:
+            for f in batch:
+                _say("Finished computing RDF for timestep", f.timestep)
         _say("Trajectory loop took:", timer() - start, "s")
     rows = _all_frames(rows)  # every rank's frames, in frame order (identity in a single process)
     num_files = len(rows)
-    for row in rows:
-        rdf_full_sum += row[:num_bins]
-        rdf_part_sum += row[num_bins:].reshape(num_relations, num_bins)
+    if num_files:
+        acc = _sum_frames(rows)
+        rdf_full_sum, rdf_part_sum = acc[:num_bins], acc[num_bins:].reshape(num_relations, num_bins)
     if dropped:
         print(f"calc_atomic_rdf: {dropped} pair(s) fell in bin index {num_bins} (== num_bins) and were dropped")
     rdf_full_sum = rdf_full_sum / num_files
@@ -423,31 +496,23 @@ def calc_atomic_rdf_cn(r_cut, cn_r_cut, bin_size, num_types, mass, partial_relat
     rows, cn_rows = [], []
     for batch in _batches(dumps):
         labels = [(_calc_atom_type(f.ids, num_mols, num_atoms_per_mol) if altered else f.types) for f in batch]
-        props = [_calc_props(f.lengths, lab, lab, num_types, mass, partial_relations, altered,
-                             num_atoms_per_mol) for f, lab in zip(batch, labels)]
+        props = [_calc_props_memo(f.lengths, lab, lab, num_types, mass, partial_relations, altered,
+                                  num_atoms_per_mol) for f, lab in zip(batch, labels)]
         full, part, ov, raw = backend.rdf_cn_loop(_xyz_block(batch), _labels_for(batch, labels),
                                                   np.array([f.lengths for f in batch]), relation_matrix, r_cut,
                                                   bin_size, num_bins, list(cn_r_cut), per_frame=True)
         dropped += ov
+        rows.append(_normalize_rdf_batch(bin_size, props, partial_relations, num_relations, num_bins, part, full,
+                                         [f.xyz.shape[1] for f in batch]))
         for k, f in enumerate(batch):
-            rho, rho_pairs, atom_types, _ = props[k]
-            g_full, g_part = _normalize_rdf(bin_size, rho_pairs, atom_types, partial_relations, num_relations,
-                                            num_bins, part[k].astype(np.float64), full[k].astype(np.float64),
-                                            f.xyz.shape[1], rho)
-            rows.append(np.concatenate([g_full, np.ravel(g_part)]))
-            cn_rows.append(np.asarray(_normalize_cn(atom_types, partial_relations, raw[k].astype(np.float64)),
+            cn_rows.append(np.asarray(_normalize_cn(props[k][2], partial_relations, raw[k].astype(np.float64)),
                                       dtype=np.float64))
             _say("Finished computing RDF and CN for timestep", f.timestep)
     rows, cn_rows = _all_frames(rows), _all_frames(cn_rows)
     n_frames = len(rows)
-    rdf_full_sum = np.zeros(num_bins)
-    rdf_part_sum = np.zeros((num_relations, num_bins))
-    cn_sum = np.zeros(num_relations)
-    for row in rows:
-        rdf_full_sum += row[:num_bins]
-        rdf_part_sum += row[num_bins:].reshape(num_relations, num_bins)
-    for row in cn_rows:
-        cn_sum += row
+    acc = _sum_frames(rows) if n_frames else np.zeros((1 + num_relations) * num_bins)
+    rdf_full_sum, rdf_part_sum = acc[:num_bins], acc[num_bins:].reshape(num_relations, num_bins)
+    cn_sum = _sum_frames(cn_rows) if n_frames else np.zeros(num_relations)
     if dropped:
         print(f"calc_atomic_rdf_cn: {dropped} pair(s) fell in bin index {num_bins} (== num_bins) and were dropped")
     g = _save_rdf(radii, relation_matrix, rdf_path_or_buff, save_mode and _is_writer(), rdf_part_sum / n_frames,

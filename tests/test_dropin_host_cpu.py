@@ -190,3 +190,47 @@ def test_residence_time_fit_host_logic(tmp_path):
     assert (tmp_path / "residence_time.csv").exists()
     y = ResidenceTime._stretched_exp_function(np.array([0.0, 1.0]), 0.8, 40.0, 1.5, 0.7)
     assert y[0] == 1.0 and 0 < y[1] < 1
+
+
+def test_batch_normalisation_sum_and_csv_are_the_per_frame_code_bit_for_bit(tmp_path):
+    """Round 3 host-share cut: the per-frame normalisation of a batch in one expression, the frame-ordered sum and the
+    hand-written CSV writer give exactly what the per-frame code / pandas gave (rdf_cn.py:297-329, 502-521, 341-365)."""
+    import pandas as pd
+
+    from mdproptools_amd.structural import rdf_cn as R
+
+    rng = np.random.default_rng(3)
+    B, nb, rel = 7, 160, [[1, 1, 2, 3], [1, 2, 3, 3]]
+    n = 3000
+    full = rng.integers(0, 50_000, (B, nb)).astype(np.uint64)
+    part = rng.integers(0, 50_000, (B, 4, nb)).astype(np.uint64)
+    ty = (1 + np.arange(n) % 3).astype(np.float64)
+    props = [R._calc_props((30.0 + 0.1 * k, 31.0, 32.0 - 0.05 * k), ty, ty, 3, [1.0, 2.0, 3.0], rel, False) for k in range(B)]
+    memo = [R._calc_props_memo((30.0 + 0.1 * (k // 2), 31.0, 32.0), ty, ty, 3, [1.0, 2.0, 3.0], rel, False) for k in range(B)]
+    for k in range(B):  # the memo returns what a fresh call returns (boxes repeat in pairs here)
+        fresh = R._calc_props((30.0 + 0.1 * (k // 2), 31.0, 32.0), ty, ty, 3, [1.0, 2.0, 3.0], rel, False)
+        assert fresh[0] == memo[k][0] and np.array_equal(fresh[1], memo[k][1]) and fresh[2] == memo[k][2]
+    rows = R._normalize_rdf_batch(0.05, props, rel, 4, nb, part, full, [n] * B)
+    want = []
+    for k in range(B):
+        gf, gp = R._normalize_rdf(0.05, props[k][1], props[k][2], rel, 4, nb, part[k].astype(np.float64),
+                                  full[k].astype(np.float64), n, props[k][0])
+        want.append(np.concatenate([gf, np.ravel(gp)]))
+    np.testing.assert_array_equal(rows, np.stack(want))
+    only_part = R._normalize_rdf_batch(0.05, props, rel, 4, nb, part)
+    np.testing.assert_array_equal(only_part, np.stack(want)[:, nb:])
+    acc = np.zeros(rows.shape[1])
+    for r in want:
+        acc += r
+    np.testing.assert_array_equal(R._sum_frames(rows), acc)
+    vals = np.column_stack([(np.arange(nb) + 0.5) * 0.05, acc[:nb] / B, (acc[nb:].reshape(4, nb) / B).T])
+    vals[3, 2], vals[5, 3], vals[6, 1], vals[7, 4] = np.nan, np.inf, 1e-300, 1e22
+    df = pd.DataFrame(vals, columns=[R._R_LABEL, "g_full(r)"] + ["g_%d-%d" % (a, b) for a, b in zip(*rel)])
+    R._write_csv(df, str(tmp_path / "fast.csv"))
+    df.to_csv(str(tmp_path / "pandas.csv"), index=False)
+    assert open(tmp_path / "fast.csv", "rb").read() == open(tmp_path / "pandas.csv", "rb").read()
+    import io
+
+    buf = io.StringIO()  # not a path: pandas writes it
+    R._write_csv(df, buf)
+    assert buf.getvalue() == open(tmp_path / "pandas.csv").read()

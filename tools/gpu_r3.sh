@@ -18,6 +18,12 @@ for s in "$@"; do
     pmc2) timeout -k 10 1100 bash tools/pmc_secondary.sh r03 > $O/pmc2.log 2>&1; echo "pmc2 rc=$?"; tail -5 $O/pmc2.log ;;
     stats_legs) (cd /tmp && export TMPDIR=/tmp && timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o r03_bench_legs -- python3 $R/bench.py --no-cpu-baseline > $O/bench_line_rocprof_legs.json 2> $O/rocprof_legs_err.log); echo "stats_legs rc=$?"; tail -2 $O/rocprof_legs_err.log ;;
     stats) (cd /tmp && export TMPDIR=/tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o r03_bench -- python3 $R/bench.py --no-cpu-baseline --no-legs > $O/bench_line_rocprof.json 2> $O/rocprof_err.log); echo "stats rc=$?" ;;
+    mem) free -g; nproc; df -h /tmp | tail -1 ;;
+    tests_dropin) timeout -k 10 900 python -m pytest tests/test_gpu_dropin.py -m gpu -x -q > $O/gpu_tests_dropin.log 2>&1; rc=$?; echo "tests_dropin rc=$rc"; tail -5 $O/gpu_tests_dropin.log; [ $rc -eq 0 ] || exit 1 ;;
+    e2e_c2) timeout -k 10 600 python tests/bench/bench_e2e.py 10000 200 > $O/bench_e2e_c2.txt 2> $O/bench_e2e_err.log; echo "e2e_c2 rc=$?"; tail -2 $O/bench_e2e_err.log; cat $O/bench_e2e_c2.txt ;;
+    e2e_c3) timeout -k 10 1100 python tests/bench/bench_e2e.py 100000 1000 > $O/bench_e2e_c3_full.txt 2> $O/bench_e2e_c3_err.log; echo "e2e_c3 rc=$?"; tail -2 $O/bench_e2e_c3_err.log; cat $O/bench_e2e_c3_full.txt ;;
+    e2e_c4) timeout -k 10 1100 python tests/bench/bench_e2e_msd.py 50000 5000 allatom > $O/bench_e2e_c4_full.txt 2> $O/bench_e2e_c4_err.log; echo "e2e_c4 rc=$?"; tail -2 $O/bench_e2e_c4_err.log; cat $O/bench_e2e_c4_full.txt ;;
+    e2e_c4com) timeout -k 10 1100 python tests/bench/bench_e2e_msd.py 50000 5000 com > $O/bench_e2e_c4com_full.txt 2> $O/bench_e2e_c4com_err.log; echo "e2e_c4com rc=$?"; tail -2 $O/bench_e2e_c4com_err.log; cat $O/bench_e2e_c4com_full.txt ;;
     *) echo "unknown step $s" ;;
   esac
 done
