@@ -50,6 +50,7 @@ enum WsSlot {
     WS_REL,        // packed-f32 tile-relative records (scalar-j MODE 3)
     WS_CEN,        // tile centres + half extents
     WS_FFT_TMP,    // second transform buffer of fft_pow2.hip for the large-lag MSD path
+    WS_FFT_TW,     // two-level table of the roots of unity of order L (fft_pow2.hip), kept from call to call
     WS_COUNT
 };
 
@@ -115,6 +116,8 @@ struct mdhip_ctx {
                               // stays below 1e-10, else the exact-difference kernel; 1 = series-resident LDS
                               // difference kernel when it fits, 0 = staged difference kernel, 2 = always the
                               // autocorrelation theorem, 4 = 2 through batched global transforms (fft_pow2.hip)
+    int fft_tw_logL = -1;         // length the table in WS_FFT_TW was built for (-1: none)
+    const void *fft_tw_ptr = nullptr;
     double last_rel_bound = 0.0;  // error bound reported by the FFT MSD path of the last mdhip_lag_msd call (0: exact path)
 };
 

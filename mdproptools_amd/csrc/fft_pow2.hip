@@ -50,6 +50,31 @@ __device__ __forceinline__ double2 root_of_unity(long long num, long long den)
     return make_double2(c, s);
 }
 
+// Roots of unity from a two-level table instead of sincospi per point (round 3: the per-output twiddle of a pass was
+// ~50 of the ~150 FP64 instructions a point costs, and the passes were as VALU-busy (58 %) as HBM-busy (60 %)):
+//   e^{-2 pi i m / 2^logn} = A[idx >> 10] * B[idx & 1023],  idx = m << (logL - logn)  (a root of order n is a root of order L)
+//   A[k] = e^{-2 pi i k 2^10 / L}, k < L / 2^10 (one entry for L <= 2^10);  B[k] = e^{-2 pi i k / L}, k < min(L, 2^10)
+// Every entry is sincospi of an exact dyadic argument (~1 ulp); the product adds ~2 ulp: the twiddle error still does
+// not grow with the length. The table (<= 16 MB at L = 2^30, 48 KB at L = 2^21: L2-resident) is built once per length
+// and context (fft_twiddle_table).
+struct TwTab {
+    const double2 *A, *B;
+    int logL;
+};
+
+__device__ __forceinline__ double2 tw_lookup(const TwTab &t, unsigned long long m, int logn)
+{
+    const unsigned long long idx = m << (t.logL - logn);
+    return cmul(t.A[idx >> 10], t.B[idx & 1023ull]);
+}
+
+__global__ void fft_twiddle_table_kernel(double2 *A, long long nA, double2 *B, long long nB, long long L)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nA) A[i] = root_of_unity(i << 10, L);
+    if (i < nB) B[i] = root_of_unity(i, L);
+}
+
 __device__ __forceinline__ unsigned bit_reverse(unsigned r, int bits) { return bits ? __brev(r) >> (32 - bits) : 0u; }
 
 enum { IN_PLAIN = 0, IN_PAD = 1 };
@@ -68,7 +93,7 @@ struct PassIo {
 template <int IN, int OUT>
 __global__ __launch_bounds__(FFT_THREADS) void fft_pass_kernel(const double2 *__restrict__ in,
                                                                double2 *__restrict__ out, long long H, int logR,
-                                                               int logC, int logS, long long n, PassIo io)
+                                                               int logC, int logS, long long n, PassIo io, TwTab tt)
 {
     const long long s = 1LL << logS;
     extern __shared__ double2 lds[];
@@ -96,7 +121,7 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass_kernel(const double2 *__
             buf[idx] = in[c0 + cc + (long long)k * cols];
         }
     }
-    for (int t = threadIdx.x; t < (R >> 1); t += FFT_THREADS) tw[t] = root_of_unity(t, R);
+    for (int t = threadIdx.x; t < (R >> 1); t += FFT_THREADS) tw[t] = tw_lookup(tt, (unsigned long long)t, logR);
     __syncthreads();
     // Gentleman-Sande network over the rows, two radix-2 stages per LDS round trip (a radix-4 butterfly in registers:
     // the same operations in the same order as the two stages one after the other, half the LDS traffic and barriers);
@@ -138,6 +163,7 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass_kernel(const double2 *__
         __syncthreads();
     }
     const bool last = n == R;  // p = 0 for every column: no twiddle
+    const int logn = 63 - __builtin_clzll((unsigned long long)n);
     // store order: columns fastest when a tile's columns share their p (s >= C: runs of C points), output index
     // fastest otherwise (first pass, s = 1: the tile's outputs are one contiguous block of R*C points)
     const bool col_fast = s >= C;
@@ -156,7 +182,7 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass_kernel(const double2 *__
         double2 v = buf[(r << logC) + cc];
         const long long c = c0 + cc;
         const long long p = c >> logS, q = c & (s - 1);
-        if (!last && j != 0 && p != 0) v = cmul(v, root_of_unity((long long)j * p, n));
+        if (!last && j != 0 && p != 0) v = cmul(v, tw_lookup(tt, (unsigned long long)j * (unsigned long long)p, logn));
         const long long o = q + s * (((long long)p << logR) + j);
         if (OUT == OUT_LAGS) {
             const long long t = 2 * o;
@@ -170,7 +196,7 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass_kernel(const double2 *__
 }
 
 // spec[b][k], k = 0..H, from Z = FFT_H of the reals read as complex pairs. grid (ceil((H/2+1)/256), batch)
-__global__ void r2c_post_kernel(const double2 *__restrict__ Z, double2 *__restrict__ spec, long long H)
+__global__ void r2c_post_kernel(const double2 *__restrict__ Z, double2 *__restrict__ spec, long long H, TwTab tt)
 {
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k > H / 2) return;
@@ -180,7 +206,7 @@ __global__ void r2c_post_kernel(const double2 *__restrict__ Z, double2 *__restri
     const double2 zk = Z[k], zh = Z[kk];
     const double2 E = make_double2(0.5 * (zk.x + zh.x), 0.5 * (zk.y - zh.y));
     const double2 O = make_double2(0.5 * (zk.y + zh.y), -0.5 * (zk.x - zh.x));  // (zk - conj zh) / (2i)
-    const double2 w = root_of_unity(k, 2 * H);
+    const double2 w = tw_lookup(tt, (unsigned long long)k, tt.logL);
     const double2 wo = cmul(w, O);
     spec[k] = make_double2(E.x + wo.x, E.y + wo.y);
     spec[H - k] = make_double2(E.x - wo.x, -(E.y - wo.y));  // X(H-k) = conj(E - w O); k = 0 -> X(H)
@@ -188,14 +214,14 @@ __global__ void r2c_post_kernel(const double2 *__restrict__ Z, double2 *__restri
 
 // W = conj Y (the input of the forward transform that stands for the inverse one) from the Hermitian half spectrum
 // S[b][0..H]. grid (ceil((H/2+1)/256), batch)
-__global__ void c2r_pre_kernel(const double2 *__restrict__ S, double2 *__restrict__ W, long long H)
+__global__ void c2r_pre_kernel(const double2 *__restrict__ S, double2 *__restrict__ W, long long H, TwTab tt)
 {
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k > H / 2) return;
     S += (size_t)blockIdx.y * (H + 1);
     W += (size_t)blockIdx.y * H;
     const double2 sk = S[k], sh = S[H - k];
-    const double2 w = root_of_unity(k, 2 * H);                       // e^{-2 pi i k/L}
+    const double2 w = tw_lookup(tt, (unsigned long long)k, tt.logL);  // e^{-2 pi i k/L}
     const double2 se = make_double2(sk.x + sh.x, sk.y - sh.y);       // S(k) + conj S(H-k)
     const double2 sd = make_double2(sk.x - sh.x, sk.y + sh.y);       // S(k) - conj S(H-k)
     const double2 t = cmul(make_double2(w.x, -w.y), sd);             // e^{+2 pi i k/L} sd
@@ -213,14 +239,14 @@ __global__ void c2r_pre_kernel(const double2 *__restrict__ S, double2 *__restric
 // complex pairs  ->  half spectra A, B (as r2c_post_kernel)  ->  S = A conj(B)  ->  W = conj Y (as c2r_pre_kernel),
 // written over Za (thread k owns the points k and H-k of both inputs and of the output). SAME: Zb is Za.
 template <bool SAME>
-__global__ void xcorr_spectrum_kernel(double2 *__restrict__ Za, const double2 *__restrict__ Zb, long long H)
+__global__ void xcorr_spectrum_kernel(double2 *__restrict__ Za, const double2 *__restrict__ Zb, long long H, TwTab tt)
 {
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k > H / 2) return;
     Za += (size_t)blockIdx.y * H;
     Zb += (size_t)blockIdx.y * H;
     const long long kk = (H - k) & (H - 1);
-    const double2 w = root_of_unity(k, 2 * H);  // e^{-2 pi i k/L}
+    const double2 w = tw_lookup(tt, (unsigned long long)k, tt.logL);  // e^{-2 pi i k/L}
     auto half_spectrum = [&](const double2 zk, const double2 zh, double2 &xk, double2 &xh) {
         const double2 E = make_double2(0.5 * (zk.x + zh.x), 0.5 * (zk.y - zh.y));
         const double2 O = make_double2(0.5 * (zk.y + zh.y), -0.5 * (zk.x - zh.x));
@@ -254,6 +280,28 @@ __global__ void conj_copy_kernel(const double2 *__restrict__ in, double2 *__rest
     if (i < count) out[i] = make_double2(in[i].x, -in[i].y);
 }
 
+// The table of roots of order L = 2 H for this context (built on the launch stream when the length changes).
+bool fft_twiddle_table(mdhip_ctx *ctx, long long H, TwTab &tt)
+{
+    const long long L = 2 * H;
+    int logL = 0;
+    while ((1LL << logL) < L) ++logL;
+    const long long nA = L > 1024 ? L >> 10 : 1, nB = L > 1024 ? 1024 : L;
+    double2 *tab = (double2 *)mdhip_ws(ctx, WS_FFT_TW, (size_t)(nA + nB) * sizeof(double2));
+    if (!tab) return false;
+    tt.A = tab;
+    tt.B = tab + nA;
+    tt.logL = logL;
+    if (ctx->fft_tw_logL != logL || ctx->fft_tw_ptr != tab) {
+        const long long m = std::max(nA, nB);
+        hipLaunchKernelGGL(fft_twiddle_table_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, tab,
+                           nA, tab + nA, nB, L);
+        ctx->fft_tw_logL = logL;
+        ctx->fft_tw_ptr = tab;
+    }
+    return true;
+}
+
 struct PassPlan {
     int n_pass = 0;
     int logR[FFT_MAX_PASSES] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -281,7 +329,7 @@ PassPlan plan_passes(const mdhip_ctx *ctx, long long H)
 
 template <int IN, int OUT>
 bool launch_pass(mdhip_ctx *ctx, const double2 *in, double2 *out, long long H, int batch, int logR, int logS,
-                 const PassIo &io)
+                 const PassIo &io, const TwTab &tt)
 {
     const long long cols = H >> logR;
     // 16 columns per tile (256-byte runs) while the tile fits 64 KB of LDS, fewer for the larger radices
@@ -297,7 +345,7 @@ bool launch_pass(mdhip_ctx *ctx, const double2 *in, double2 *out, long long H, i
         return false;
     }
     hipLaunchKernelGGL((fft_pass_kernel<IN, OUT>), grid, dim3(FFT_THREADS), lds, ctx->stream, in, out, H, logR, logC,
-                       logS, H >> logS, io);
+                       logS, H >> logS, io, tt);
     return true;
 }
 
@@ -306,7 +354,7 @@ bool launch_pass(mdhip_ctx *ctx, const double2 *in, double2 *out, long long H, i
 // x is overwritten. in_mode IN_PAD: the first pass reads io.series instead of x; out_mode OUT_LAGS: the last pass
 // writes io.lags instead of a buffer.
 double2 *fft_forward(mdhip_ctx *ctx, double2 *x, double2 *y, long long H, int batch, int in_mode, int out_mode,
-                     const PassIo &io)
+                     const PassIo &io, const TwTab &tt)
 {
     const PassPlan p = plan_passes(ctx, H);
     if (p.n_pass < 0) {
@@ -324,10 +372,10 @@ double2 *fft_forward(mdhip_ctx *ctx, double2 *x, double2 *y, long long H, int ba
     for (int i = 0; i < p.n_pass; ++i) {
         const int im = i == 0 ? in_mode : IN_PLAIN, om = i == p.n_pass - 1 ? out_mode : OUT_PLAIN;
         bool ok;
-        if (im == IN_PAD && om == OUT_PLAIN) ok = launch_pass<IN_PAD, OUT_PLAIN>(ctx, src, dst, H, batch, p.logR[i], s, io);
-        else if (im == IN_PLAIN && om == OUT_LAGS) ok = launch_pass<IN_PLAIN, OUT_LAGS>(ctx, src, dst, H, batch, p.logR[i], s, io);
-        else if (im == IN_PLAIN && om == OUT_CONJ) ok = launch_pass<IN_PLAIN, OUT_CONJ>(ctx, src, dst, H, batch, p.logR[i], s, io);
-        else ok = launch_pass<IN_PLAIN, OUT_PLAIN>(ctx, src, dst, H, batch, p.logR[i], s, io);
+        if (im == IN_PAD && om == OUT_PLAIN) ok = launch_pass<IN_PAD, OUT_PLAIN>(ctx, src, dst, H, batch, p.logR[i], s, io, tt);
+        else if (im == IN_PLAIN && om == OUT_LAGS) ok = launch_pass<IN_PLAIN, OUT_LAGS>(ctx, src, dst, H, batch, p.logR[i], s, io, tt);
+        else if (im == IN_PLAIN && om == OUT_CONJ) ok = launch_pass<IN_PLAIN, OUT_CONJ>(ctx, src, dst, H, batch, p.logR[i], s, io, tt);
+        else ok = launch_pass<IN_PLAIN, OUT_PLAIN>(ctx, src, dst, H, batch, p.logR[i], s, io, tt);
         if (!ok) return nullptr;
         s += p.logR[i];
         std::swap(src, dst);
@@ -353,10 +401,12 @@ int mdhip_fft_r2c(mdhip_ctx *ctx, double *d_real, double2 *d_tmp, double2 *d_spe
         }
         return MDHIP_OK;
     }
-    double2 *Z = fft_forward(ctx, reinterpret_cast<double2 *>(d_real), d_tmp, H, batch, IN_PLAIN, OUT_PLAIN, PassIo{});
+    TwTab tt;
+    if (!fft_twiddle_table(ctx, H, tt)) return MDHIP_ENOMEM;
+    double2 *Z = fft_forward(ctx, reinterpret_cast<double2 *>(d_real), d_tmp, H, batch, IN_PLAIN, OUT_PLAIN, PassIo{}, tt);
     if (!Z) return MDHIP_EHIP;
     hipLaunchKernelGGL(r2c_post_kernel, dim3((unsigned)((H / 2 + 1 + 255) / 256), (unsigned)batch), dim3(256), 0,
-                       ctx->stream, Z, d_spec, H);
+                       ctx->stream, Z, d_spec, H, tt);
     MD_HIP(hipGetLastError());
     return MDHIP_OK;
 }
@@ -382,11 +432,13 @@ int mdhip_fft_c2r(mdhip_ctx *ctx, const double2 *d_spec, double2 *d_tmp, double 
     const int hops = p.n_pass == 0 ? 1 : p.n_pass;
     double2 *real_c = reinterpret_cast<double2 *>(d_real);
     double2 *first = hops % 2 == 0 ? real_c : d_tmp, *second = hops % 2 == 0 ? d_tmp : real_c;
+    TwTab tt;
+    if (!fft_twiddle_table(ctx, H, tt)) return MDHIP_ENOMEM;
     hipLaunchKernelGGL(c2r_pre_kernel, dim3((unsigned)((H / 2 + 1 + 255) / 256), (unsigned)batch), dim3(256), 0,
-                       ctx->stream, d_spec, first, H);
+                       ctx->stream, d_spec, first, H, tt);
     // W = conj Y went in; y = conj FFT(W): conjugate on the way out. c[2j] = Re y[j], c[2j+1] = Im y[j]: the complex
     // result read as reals IS the series.
-    double2 *res = fft_forward(ctx, first, second, H, batch, IN_PLAIN, OUT_CONJ, PassIo{});
+    double2 *res = fft_forward(ctx, first, second, H, batch, IN_PLAIN, OUT_CONJ, PassIo{}, tt);
     if (!res) return MDHIP_EHIP;
     MD_HIP(hipGetLastError());
     if (res != real_c) return mdhip_fail(ctx, MDHIP_EHIP, "internal: inverse transform landed in the wrong buffer");
@@ -407,24 +459,26 @@ int mdhip_fft_xcorr(mdhip_ctx *ctx, const double *d_a, const double *d_b, long l
     PassIo io{};
     io.n = n;
     io.series = d_a;
-    double2 *Za = fft_forward(ctx, buf0, buf1, H, batch, IN_PAD, OUT_PLAIN, io);
+    TwTab tt;
+    if (!fft_twiddle_table(ctx, H, tt)) return MDHIP_ENOMEM;
+    double2 *Za = fft_forward(ctx, buf0, buf1, H, batch, IN_PAD, OUT_PLAIN, io, tt);
     if (!Za) return MDHIP_EHIP;
     double2 *Zb = Za;
     const bool same = d_a == d_b;
     if (!same) {
         io.series = d_b;
-        Zb = fft_forward(ctx, buf2, buf3, H, batch, IN_PAD, OUT_PLAIN, io);
+        Zb = fft_forward(ctx, buf2, buf3, H, batch, IN_PAD, OUT_PLAIN, io, tt);
         if (!Zb) return MDHIP_EHIP;
     }
     const dim3 grid((unsigned)((H / 2 + 1 + 255) / 256), (unsigned)batch);
     if (same)
-        hipLaunchKernelGGL(xcorr_spectrum_kernel<true>, grid, dim3(256), 0, ctx->stream, Za, Zb, H);
+        hipLaunchKernelGGL(xcorr_spectrum_kernel<true>, grid, dim3(256), 0, ctx->stream, Za, Zb, H, tt);
     else
-        hipLaunchKernelGGL(xcorr_spectrum_kernel<false>, grid, dim3(256), 0, ctx->stream, Za, Zb, H);
+        hipLaunchKernelGGL(xcorr_spectrum_kernel<false>, grid, dim3(256), 0, ctx->stream, Za, Zb, H, tt);
     io.lags = d_lags;
     io.n_lags = n_lags;
     io.L = (double)L;
-    if (!fft_forward(ctx, Za, Za == buf0 ? buf1 : buf0, H, batch, IN_PLAIN, OUT_LAGS, io)) return MDHIP_EHIP;
+    if (!fft_forward(ctx, Za, Za == buf0 ? buf1 : buf0, H, batch, IN_PLAIN, OUT_LAGS, io, tt)) return MDHIP_EHIP;
     MD_HIP(hipGetLastError());
     return MDHIP_OK;
 }

@@ -199,7 +199,7 @@ class Diffusion:
         times, blocks = [], []
         ids = atom_mass = seg_mass = None
         stream = S.FrameStream(pattern, files=mine, columns=("id", second, "xu", "yu", "zu"),
-                               batch_bytes=STREAM_BATCH_BYTES or S.DEFAULT_BATCH_BYTES)
+                               batch_bytes=STREAM_BATCH_BYTES)
         for batch in stream:
             B, _, n = batch.xyz.shape
             if ids is None:
