@@ -409,11 +409,14 @@ int mdhip_dump_read_cols(mdhip_dump *d, int64_t f, int n_sel, const int32_t *col
  * triclinic [n_files]: headers, any may be NULL. Returns MDHIP_OK; a negative MDHIP_E* code with the first failure's
  * text in err; or 1 when some file is not ONE frame of n_atoms atoms with all the requested columns (err says which):
  * the caller then reads that batch frame by frame (mdhip_dump_open / mdhip_dump_read_cols).
+ * cmp_equal (may be NULL) [n_files]: 1 where column cmp_sel of the file equals, bit for bit, cmp_ref [n_atoms] — or
+ * the same column of the FIRST file when cmp_ref is NULL. The reference re-derives the atom types of every frame
+ * (rdf_cn.py:462-470); a caller that knows they did not change skips that per-frame work.
  */
 int mdhip_dump_read_files(const char *const *paths, int n_files, int n_sel, const char *const *col_names,
                           const char *sort_name, int64_t n_atoms, double *const *dst, const int64_t *dst_stride,
                           int64_t *timesteps, double *bounds6, double *tilt3, int32_t *triclinic, int n_threads,
-                          char *err, int err_len);
+                          char *err, int err_len, int cmp_sel, const double *cmp_ref, int32_t *cmp_equal);
 
 /* ---- native LAMMPS log reader (host only) ---------------------------------------------------- */
 /*

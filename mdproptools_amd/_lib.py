@@ -95,7 +95,7 @@ PROTOTYPES = {
     "mdhip_dump_read_cols": (C.c_int, [vp, C.c_int64, C.c_int, c_ip, C.c_int, C.POINTER(c_dp), C.c_int]),
     "mdhip_dump_read_files": (C.c_int, [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.POINTER(C.c_char_p), C.c_char_p,
                                         C.c_int64, C.POINTER(c_dp), c_lp, c_lp, c_dp, c_dp, c_ip, C.c_int, C.c_char_p,
-                                        C.c_int]),
+                                        C.c_int, C.c_int, c_dp, c_ip]),
     "mdhip_log_open": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
     "mdhip_log_close": (None, [vp]),
     "mdhip_log_error": (C.c_char_p, [vp]),

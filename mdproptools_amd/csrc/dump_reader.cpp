@@ -862,7 +862,7 @@ static int split_names(const std::string &cols, std::vector<std::string> &out)
 static int dump_read_files_impl(const char *const *paths, int n_files, int n_sel, const char *const *col_names,
                                 const char *sort_name, int64_t n_atoms, double *const *dst, const int64_t *dst_stride,
                                 int64_t *timesteps, double *bounds6, double *tilt3, int32_t *triclinic, int n_threads,
-                                char *err, int err_len)
+                                char *err, int err_len, int cmp_sel, const double *cmp_ref, int32_t *cmp_equal)
 {
     if (err && err_len > 0) err[0] = 0;
     if (n_files < 0 || n_sel < 0 || n_atoms < 0 || (n_files && !paths) || (n_sel && (!col_names || !dst || !dst_stride)))
@@ -941,6 +941,10 @@ static int dump_read_files_impl(const char *const *paths, int n_files, int n_sel
                 fail(MDHIP_EINVAL, std::string(paths[k]) + ": " + (d->err.empty() ? "a row has fewer values than columns or a value that is not a number" : d->err));
                 return;
             }
+            // (the plane is still in this core's cache: the comparison the caller would otherwise make in numpy, one
+            // file at a time on one thread, costs nothing here)
+            if (cmp_equal && cmp_ref && cmp_sel >= 0 && cmp_sel < n_sel)
+                cmp_equal[k] = memcmp(outs[cmp_sel], cmp_ref, (size_t)n_atoms * 8) == 0 ? 1 : 0;
         }
     };
     if (n_threads == 1) {
@@ -955,17 +959,37 @@ static int dump_read_files_impl(const char *const *paths, int n_files, int n_sel
         strncpy(err, first_error.c_str(), (size_t)err_len - 1);
         err[err_len - 1] = 0;
     }
+    if (rc == MDHIP_OK && cmp_equal && !cmp_ref && cmp_sel >= 0 && cmp_sel < n_sel) {
+        // no reference given: every file against the first one of this call
+        const double *first = dst[cmp_sel];
+        cmp_equal[0] = 1;
+        std::atomic<int> nk{1};
+        auto cmp = [&] {
+            for (;;) {
+                const int k = nk.fetch_add(1);
+                if (k >= n_files) return;
+                cmp_equal[k] = memcmp(dst[cmp_sel] + (size_t)k * (size_t)dst_stride[cmp_sel], first, (size_t)n_atoms * 8) == 0;
+            }
+        };
+        if (n_threads == 1 || n_files < 4) {
+            cmp();
+        } else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < n_threads; ++t) th.emplace_back(cmp);
+            for (auto &x : th) x.join();
+        }
+    }
     return rc;
 }
 
 int mdhip_dump_read_files(const char *const *paths, int n_files, int n_sel, const char *const *col_names,
                           const char *sort_name, int64_t n_atoms, double *const *dst, const int64_t *dst_stride,
                           int64_t *timesteps, double *bounds6, double *tilt3, int32_t *triclinic, int n_threads,
-                          char *err, int err_len)
+                          char *err, int err_len, int cmp_sel, const double *cmp_ref, int32_t *cmp_equal)
 {
     return guarded([&] {
         return dump_read_files_impl(paths, n_files, n_sel, col_names, sort_name, n_atoms, dst, dst_stride, timesteps,
-                                    bounds6, tilt3, triclinic, n_threads, err, err_len);
+                                    bounds6, tilt3, triclinic, n_threads, err, err_len, cmp_sel, cmp_ref, cmp_equal);
     });
 }
 

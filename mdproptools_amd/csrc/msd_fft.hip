@@ -178,6 +178,9 @@ struct FftItem {
 
 __device__ __forceinline__ int ft_skew(int i) { return i + (i >> 4); }
 
+// From here on the arithmetic may fuse multiply-adds (the library is built with -ffp-contract=off for the pair
+// kernels' bit-exactness; this path is tolerance parity and returns a computed rounding bound).
+#pragma clang fp contract(fast)
 struct Cx {
     double x, y;
 };
@@ -394,6 +397,386 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Round 3: the fused kernel re-organised around what its counters said (profiles/r03_pmc_secondary_summary.txt: the
+// LDS array busy half of the time, 47 % of those cycles bank conflicts; 2 waves per SIMD waiting 64 % of their cycles).
+//
+//  * Layout: logical point i at i + (i >> 5) (one pad double per 32). Every access of every phase then touches 32
+//    different banks per 32-lane group: lanes that walk CONSECUTIVE points (the load, the passes with butterfly
+//    stride >= 32, the accumulation's own point) stay inside one aligned run of 32; the in-register radix-16 tail,
+//    where lane b owns the 16 points from 16 b, reads 16 b + e + (b >> 1) — for a fixed e the 32 lanes of a group cover
+//    e .. e + 31; the one pass with butterfly stride 16 deals its 128-point blocks to the two halves of a lane group
+//    four blocks apart (a bit swap of the block index: pad shift 16). The old i + (i >> 4) skew made the tail and the
+//    stride-16 pass conflict-free but cost every run of consecutive points one 2-way conflict, and the real-spectrum
+//    pass, which walked FREQUENCIES (digit-reversed positions), ran 8-way.
+//  * Passes: 2^m = [2 | 4] x 8 x ... x 8 x 16 — radix-8 passes through LDS down to blocks of 16 consecutive points,
+//    which one lane then transforms in registers: 4 LDS round trips at m = 13 instead of 5.
+//  * The spectrum is accumulated BILINEARLY, per position and not per frequency. With Z the packed transform, X the
+//    real spectrum, w = e^{-2 pi i k/L}:   |X_k|^2 = (|Z_k|^2 + |Z_{N-k}|^2)/2 + Im(w) (|Z_k|^2 - |Z_{N-k}|^2)/2 + Re(w) Im(Z_k Z_{N-k}),
+//    so a lane only adds |Z_p|^2 and Im(Z_p Z_p') for its own positions p (p' holds the frequency N - k: a fixed
+//    position per lane, read with few conflicts because the digit reversal maps a run of positions onto a run of
+//    partners) — 4 fused multiply-adds per point instead of the ~30 operations + table lookups of the untangling —
+//    and the frequencies are sorted out ONCE per block, after its last series.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int f2_skew(int i) { return i + (i >> 5); }
+
+struct F2Plan {
+    int n_pass;      // LDS passes before the in-register tail
+    int lr[6];       // log2 radix of pass q (1, 2 or 3)
+    int ls[6];       // log2 butterfly stride of pass q
+};
+
+__host__ __device__ inline F2Plan f2_plan(int m)
+{
+    F2Plan p{};
+    int lb = m, q = 0;
+    const int r0 = (m - 4) % 3;
+    if (r0) {
+        p.lr[q] = r0;
+        p.ls[q] = lb - r0;
+        lb -= r0;
+        ++q;
+    }
+    while (lb > 4) {
+        p.lr[q] = 3;
+        p.ls[q] = lb - 3;
+        lb -= 3;
+        ++q;
+    }
+    p.n_pass = q;
+    return p;
+}
+
+// position of frequency k after the in-place passes + tail (and back): every pass peels the lowest remaining
+// frequency digit and leaves it at its butterfly stride; the tail's 16-point DFT (two radix-4 stages) leaves
+// frequency f0 + 4 f1 at local index 4 f0 + f1
+__device__ __forceinline__ int f2_pos(int k, const F2Plan &pl)
+{
+    int p = 0;
+    for (int q = 0; q < pl.n_pass; ++q) {
+        p += (k & ((1 << pl.lr[q]) - 1)) << pl.ls[q];
+        k >>= pl.lr[q];
+    }
+    return p + 4 * (k & 3) + (k >> 2);
+}
+
+__device__ __forceinline__ int f2_freq(int p, const F2Plan &pl)
+{
+    int k = 0, w = 0;
+    for (int q = 0; q < pl.n_pass; ++q) {
+        k += ((p >> pl.ls[q]) & ((1 << pl.lr[q]) - 1)) << w;
+        w += pl.lr[q];
+    }
+    const int t = p & 15;
+    return k + (((t >> 2) + 4 * (t & 3)) << w);
+}
+
+// One radix-8 DIF butterfly on a[0..7] (elements j + q s of a sub-transform of length 8 s), outputs in a[] with
+// output digit d at a[d], twiddled by w1^d (w1 = w_len^j); first = no twiddle (s == 1 never happens here: the tail
+// takes the last 16 points)
+__device__ __forceinline__ void f2_bfly8(Cx *a, Cx w1, bool twiddle)
+{
+    const Cx b0 = cx_add(a[0], a[4]), b4 = cx_sub(a[0], a[4]);
+    const Cx b1 = cx_add(a[1], a[5]), t5 = cx_sub(a[1], a[5]);
+    const Cx b2 = cx_add(a[2], a[6]), t6 = cx_sub(a[2], a[6]);
+    const Cx b3 = cx_add(a[3], a[7]), t7 = cx_sub(a[3], a[7]);
+    constexpr double H = 0.70710678118654752440;
+    const Cx b5 = {(t5.x + t5.y) * H, (t5.y - t5.x) * H};
+    const Cx b6 = cx_mul_mi(t6);
+    const Cx b7 = {(t7.y - t7.x) * H, -(t7.x + t7.y) * H};
+    Cx y[8];
+    dft4(b0, b1, b2, b3, y[0], y[2], y[4], y[6]);
+    dft4(b4, b5, b6, b7, y[1], y[3], y[5], y[7]);
+    if (twiddle) {
+        const Cx w2 = cx_mul(w1, w1), w3 = cx_mul(w2, w1), w4 = cx_mul(w2, w2);
+        const Cx w5 = cx_mul(w4, w1), w6 = cx_mul(w4, w2), w7 = cx_mul(w4, w3);
+        y[1] = cx_mul(y[1], w1);
+        y[2] = cx_mul(y[2], w2);
+        y[3] = cx_mul(y[3], w3);
+        y[4] = cx_mul(y[4], w4);
+        y[5] = cx_mul(y[5], w5);
+        y[6] = cx_mul(y[6], w6);
+        y[7] = cx_mul(y[7], w7);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a[q] = y[q];
+}
+
+// 16-point DFT in registers, DIF as two radix-4 stages; output frequency f0 + 4 f1 ends up in x[4 f0 + f1]
+__device__ __forceinline__ void f2_dft16(Cx *x)
+{
+    constexpr double C1 = 0.92387953251128675613, S1 = 0.38268343236508977173, H = 0.70710678118654752440;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        Cx y0, y1, y2, y3;
+        dft4(x[e], x[e + 4], x[e + 8], x[e + 12], y0, y1, y2, y3);
+        // twiddle w16^(e d), d = output digit
+        if (e == 1) {
+            y1 = cx_mul(y1, Cx{C1, -S1});
+            y2 = Cx{(y2.x + y2.y) * H, (y2.y - y2.x) * H};
+            y3 = cx_mul(y3, Cx{S1, -C1});
+        } else if (e == 2) {
+            y1 = Cx{(y1.x + y1.y) * H, (y1.y - y1.x) * H};
+            y2 = cx_mul_mi(y2);
+            y3 = Cx{(y3.y - y3.x) * H, -(y3.x + y3.y) * H};
+        } else if (e == 3) {
+            y1 = cx_mul(y1, Cx{S1, -C1});
+            y2 = Cx{(y2.y - y2.x) * H, -(y2.x + y2.y) * H};
+            y3 = cx_mul(y3, Cx{-C1, S1});  // w16^9 = -w16^1
+        }
+        x[e] = y0;
+        x[e + 4] = y1;
+        x[e + 8] = y2;
+        x[e + 12] = y3;
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        Cx y0, y1, y2, y3;
+        dft4(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3], y0, y1, y2, y3);
+        x[4 * g] = y0;
+        x[4 * g + 1] = y1;
+        x[4 * g + 2] = y2;
+        x[4 * g + 3] = y3;
+    }
+}
+
+// Every pass's first twiddles w_len^j come from a per-pass LDS table walked by consecutive lanes (`twp`; the two-level
+// table is walked with strides of 2^k entries there: 2- to 8-way bank conflicts). Variant for A/B builds
+// (tools/build_variant.sh): F2V_PREFETCH = the next series' samples fetched into registers under the transform
+// (measured 6 % SLOWER at C4: 20 more live registers at a budget the accumulators already fill).
+// the LDS passes + the tail, in place on re/im (f2_skew layout); every thread of the block calls it
+template <int NT>
+__device__ void f2_transform(double *re, double *im, int m, const F2Plan &pl, const double2 *tabA, const double2 *tabB,
+                             const double2 *twp)
+{
+    const int N = 1 << m;
+    int off = 0;
+    for (int q = 0; q < pl.n_pass; ++q) {
+        const int lr = pl.lr[q], ls = pl.ls[q], lb = ls + lr, s = 1 << ls;
+        const int nbf = N >> lr;  // butterflies of this pass
+        // the stride-16 pass: the two 16-lane halves of a lane group take blocks 4 apart (pad shift 16), when the
+        // transform has at least 8 such blocks
+        const bool swz = ls == 4 && (N >> lb) >= 8;
+        for (int b = threadIdx.x; b < nbf; b += NT) {
+            const int j = b & (s - 1);
+            int blk = b >> ls;
+            if (swz) blk = (blk & ~5) | ((blk & 1) << 2) | ((blk >> 2) & 1);
+            const int base = (blk << lb) + j;
+            const double2 wv = twp[off + j];  // w_len^j = w_L^(j L / len), L = 2 N
+            const Cx w1 = {wv.x, wv.y};
+            if (lr == 3) {
+                int idx[8];
+                Cx a[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    idx[e] = f2_skew(base + (e << ls));
+                    a[e] = {re[idx[e]], im[idx[e]]};
+                }
+                f2_bfly8(a, w1, true);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    re[idx[e]] = a[e].x;
+                    im[idx[e]] = a[e].y;
+                }
+            } else if (lr == 2) {
+                int idx[4];
+                Cx a[4], y[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    idx[e] = f2_skew(base + (e << ls));
+                    a[e] = {re[idx[e]], im[idx[e]]};
+                }
+                dft4(a[0], a[1], a[2], a[3], y[0], y[1], y[2], y[3]);
+                const Cx w2 = cx_mul(w1, w1), w3 = cx_mul(w2, w1);
+                y[1] = cx_mul(y[1], w1);
+                y[2] = cx_mul(y[2], w2);
+                y[3] = cx_mul(y[3], w3);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    re[idx[e]] = y[e].x;
+                    im[idx[e]] = y[e].y;
+                }
+            } else {
+                const int i0 = f2_skew(base), i1 = f2_skew(base + s);
+                const Cx a0 = {re[i0], im[i0]}, a1 = {re[i1], im[i1]};
+                const Cx d = cx_mul(cx_sub(a0, a1), w1);
+                re[i0] = a0.x + a1.x;
+                im[i0] = a0.y + a1.y;
+                re[i1] = d.x;
+                im[i1] = d.y;
+            }
+        }
+        off += s;
+        __syncthreads();
+    }
+    for (int b = threadIdx.x; b < (N >> 4); b += NT) {
+        const int p0 = f2_skew(16 * b);  // 16 consecutive points never cross a pad (pads sit at multiples of 32)
+        Cx x[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) x[e] = {re[p0 + e], im[p0 + e]};
+        f2_dft16(x);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            re[p0 + e] = x[e].x;
+            im[p0 + e] = x[e].y;
+        }
+    }
+    __syncthreads();
+}
+// LDS bytes of the round-3 kernel for N = 2^m: data planes + the two-level twiddle table (+ the per-pass tables)
+size_t f2_lds_bytes(int m)
+{
+    const size_t np = ((size_t)1 << m) + ((size_t)1 << m >> 5) + 2;
+    size_t tw = 0;
+    const F2Plan pl = f2_plan(m);
+    for (int q = 0; q < pl.n_pass; ++q) tw += (size_t)1 << pl.ls[q];
+    return 2 * np * 8 + 256 * 16 + 32 * 8 + tw * 16;
+}
+
+// x: time-major series [cols][F] (already scaled). Qpart [items][F], Ppart [items][N + 1] as msd_power_lds_kernel.
+// PR = positions per lane = N / FT_THREADS (16 at N = 8192); QR2 = sample PAIRS per lane that can hold data.
+template <int QR2, int PR>
+__global__ __launch_bounds__(FT_THREADS) void msd_power_lds2_kernel(
+    const double *__restrict__ x, int F, int m, const FftItem *__restrict__ items,
+    const double2 *__restrict__ tab, double *__restrict__ Qpart, double *__restrict__ Ppart)
+{
+    extern __shared__ double ft_lds[];
+    const int N = 1 << m, np = N + (N >> 5) + 2;
+    double *re = ft_lds, *im = ft_lds + np;
+    double2 *tabA = reinterpret_cast<double2 *>(im + np), *tabB = tabA + 128;
+    double *red = reinterpret_cast<double *>(tabB + 128);
+    double2 *twp = reinterpret_cast<double2 *>(red + 32);
+    const int tid = threadIdx.x;
+    if (tid < 256) tabA[tid] = tab[tid];
+    const F2Plan pl = f2_plan(m);
+    const FftItem it = items[blockIdx.x];
+    __syncthreads();
+    {
+        int off = 0;
+        for (int q = 0; q < pl.n_pass; ++q) {
+            const int ls = pl.ls[q], lb = ls + pl.lr[q], s = 1 << ls;
+            for (int j = tid; j < s; j += FT_THREADS) {
+                const Cx w = ft_tw(tabA, tabB, j << (m + 1 - lb));
+                twp[off + j] = make_double2(w.x, w.y);
+            }
+            off += s;
+        }
+    }
+    // this lane's positions p = tid + i FT_THREADS and the position of each one's partner frequency N - k
+    int partner[PR];
+#pragma unroll
+    for (int i = 0; i < PR; ++i) {
+        const int p = tid + i * FT_THREADS;
+        partner[i] = p < N ? f2_skew(f2_pos((N - f2_freq(p, pl)) & (N - 1), pl)) : 0;
+    }
+    double qa[QR2], qb[QR2], sacc[PR], tacc[PR];
+#pragma unroll
+    for (int i = 0; i < QR2; ++i) qa[i] = qb[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < PR; ++i) sacc[i] = tacc[i] = 0.0;
+    const int half = (F + 1) >> 1;  // packed points that hold data
+    double va[QR2], vb[QR2];
+    auto fetch = [&](long long c) {
+        const double *row = x + (size_t)c * F;
+        const bool al16 = (reinterpret_cast<unsigned long long>(row) & 15ull) == 0ull;
+#pragma unroll
+        for (int i = 0; i < QR2; ++i) {
+            const int n = tid + i * FT_THREADS;  // packed point: samples 2 n, 2 n + 1
+            va[i] = vb[i] = 0.0;
+            if (2 * n + 1 < F) {
+                if (al16) {
+                    typedef double d2_t __attribute__((ext_vector_type(2)));
+                    const d2_t v = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(row + 2 * n));
+                    va[i] = v[0];
+                    vb[i] = v[1];
+                } else {
+                    va[i] = row[2 * n];
+                    vb[i] = row[2 * n + 1];
+                }
+            } else if (2 * n < F) {
+                va[i] = row[2 * n];
+            }
+        }
+    };
+#ifdef F2V_PREFETCH
+    if (it.c_lo < it.c_hi) fetch(it.c_lo);
+#endif
+    for (long long c = it.c_lo; c < it.c_hi; ++c) {
+#ifndef F2V_PREFETCH
+        fetch(c);
+#endif
+        double sum = 0.0;
+#pragma unroll
+        for (int i = 0; i < QR2; ++i) sum += va[i] + vb[i];
+        const double mean = ft_block_sum(sum, red) / (double)F;  // (its barriers also order the previous series' reads)
+#pragma unroll
+        for (int i = 0; i < QR2; ++i) {
+            const int n = tid + i * FT_THREADS;
+            if (n < half) {
+                const double da = va[i] - mean;
+                const double db = 2 * n + 1 < F ? vb[i] - mean : 0.0;
+                qa[i] += da * da;
+                qb[i] += db * db;
+                const int q = f2_skew(n);
+                re[q] = da;
+                im[q] = db;
+            }
+        }
+        for (int n = half + tid; n < N; n += FT_THREADS) {
+            const int q = f2_skew(n);
+            re[q] = 0.0;
+            im[q] = 0.0;
+        }
+#ifdef F2V_PREFETCH
+        if (c + 1 < it.c_hi) fetch(c + 1);  // in flight under the transform
+#endif
+        __syncthreads();
+        f2_transform<FT_THREADS>(re, im, m, pl, tabA, tabB, twp);
+#pragma unroll
+        for (int i = 0; i < PR; ++i) {
+            const int p = tid + i * FT_THREADS;
+            if (p < N) {
+                const int q = f2_skew(p);
+                const double ax = re[q], ay = im[q];
+                const double cx = re[partner[i]], cy = im[partner[i]];
+                sacc[i] = __builtin_fma(ax, ax, sacc[i]);
+                sacc[i] = __builtin_fma(ay, ay, sacc[i]);
+                tacc[i] = __builtin_fma(ax, cy, tacc[i]);
+                tacc[i] = __builtin_fma(ay, cx, tacc[i]);
+            }
+        }
+        // the next series' block sum has two barriers before LDS is written again
+    }
+    double *q = Qpart + (size_t)blockIdx.x * F, *pp = Ppart + (size_t)blockIdx.x * (N + 1);
+#pragma unroll
+    for (int i = 0; i < QR2; ++i) {
+        const int n = tid + i * FT_THREADS;
+        if (2 * n < F) q[2 * n] = qa[i];
+        if (2 * n + 1 < F) q[2 * n + 1] = qb[i];
+    }
+    // frequencies, once per block: S of the partner frequency through LDS, then
+    //   P_k = (S_k + S_{N-k})/2 + Im(w) (S_k - S_{N-k})/2 + Re(w) T_k,   w = e^{-2 pi i k/L};   P_N = S_0 - T_0
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PR; ++i) {
+        const int p = tid + i * FT_THREADS;
+        if (p < N) re[f2_skew(p)] = sacc[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PR; ++i) {
+        const int p = tid + i * FT_THREADS;
+        if (p < N) {
+            const int k = f2_freq(p, pl);
+            const double sk = sacc[i], sn = re[partner[i]];
+            const Cx w = ft_tw(tabA, tabB, k);  // (cos, -sin) of 2 pi k / L
+            pp[k] = 0.5 * (sk + sn) + w.y * (0.5 * (sk - sn)) + w.x * tacc[i];
+            if (k == 0) pp[N] = sk - tacc[i];
+        }
+    }
+}
+
 // out[s][i] = sum over the items of segment s of part[item][i]
 __global__ void fold_items_kernel(const double *__restrict__ part, const int *__restrict__ seg_item_off,
                                   long long width, double *__restrict__ out)
@@ -548,11 +931,33 @@ int lag_msd_fft_fused(mdhip_ctx *ctx, long long F, long long E, const double *d_
     MD_HIP(hipStreamSynchronize(ctx->stream));  // the tables above are locals
 
     const size_t lds_b = ft_lds_bytes(m);
+    // round-3 kernel (conflict-free layout, bilinear spectrum accumulation): N = 2^m a multiple of the block size
+    const bool v2 = ctx->opt_lag_fft_kernel != 0 && m >= 9 && f2_lds_bytes(m) <= ctx->lds_max;
     KernelTimer timer(ctx);
     hipLaunchKernelGGL(transpose_scale_kernel, dim3((unsigned)((cols + 31) / 32), (unsigned)((F + 31) / 32)), dim3(256),
                        0, ctx->stream, d_r, d_x, F, cols, scale);
     MD_HIP(hipGetLastError());
     const int qr = (int)((F + FT_THREADS - 1) / FT_THREADS);
+    if (v2) {
+        const size_t lds2 = f2_lds_bytes(m);
+        const int qr2 = (int)(((F + 1) / 2 + FT_THREADS - 1) / FT_THREADS);  // sample pairs per lane, <= N / 512
+#define MD_F2_LAUNCH(QR2, PR)                                                                                  \
+    {                                                                                                          \
+        MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msd_power_lds2_kernel<QR2, PR>),             \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));                    \
+        hipLaunchKernelGGL((msd_power_lds2_kernel<QR2, PR>), dim3((unsigned)n_items), dim3(FT_THREADS), lds2,  \
+                           ctx->stream, d_x, (int)F, m, d_items, d_tab, d_Qpart, d_Ppart);                     \
+    }
+        // PR = N / 512 positions per lane; QR2 <= PR / 2 + 1 pairs hold data (F <= L/2 + ...): instantiate per m
+        switch (m) {  // (second argument: PR = N / 512 positions per lane)
+        case 9: MD_F2_LAUNCH(1, 1) break;
+        case 10: MD_F2_LAUNCH(2, 2) break;
+        case 11: if (qr2 <= 2) MD_F2_LAUNCH(2, 4) else MD_F2_LAUNCH(4, 4) break;
+        case 12: if (qr2 <= 3) MD_F2_LAUNCH(3, 8) else MD_F2_LAUNCH(8, 8) break;
+        default: if (qr2 <= 5) MD_F2_LAUNCH(5, 16) else if (qr2 <= 8) MD_F2_LAUNCH(8, 16) else MD_F2_LAUNCH(16, 16) break;
+        }
+#undef MD_F2_LAUNCH
+    } else {
 #define MD_FT_CASE(QR)                                                                                         \
     {                                                                                                          \
         MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msd_power_lds_kernel<QR>),                   \
@@ -570,6 +975,7 @@ int lag_msd_fft_fused(mdhip_ctx *ctx, long long F, long long E, const double *d_
     else if (qr <= 24) MD_FT_CASE(24)
     else MD_FT_CASE(32)
 #undef MD_FT_CASE
+    }
     MD_HIP(hipGetLastError());
     hipLaunchKernelGGL(fold_items_kernel, dim3((unsigned)((F + 255) / 256), (unsigned)S), dim3(256), 0, ctx->stream,
                        d_Qpart, d_seg_off, F, d_Q);

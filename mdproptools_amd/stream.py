@@ -128,6 +128,11 @@ class Batch:
     """Consecutive frames with the same atom count: xyz [B,3,N] (one contiguous, page-locked block), ids / types
     [B,N], lengths [B,3], timesteps [B]. Iterating yields `Frame` views."""
 
+    # True when the library's reader threads found the second column (types) of EVERY frame of this batch bit-identical
+    # to that of the stream's first frame (`types_ref`): callers then derive labels, counts and densities once
+    uniform_types = False
+    types_ref = None
+
     def __init__(self, stream, buf, n_frames, n_atoms, ids, types, lengths, timesteps):
         self._stream, self._buf = stream, buf
         self.xyz = buf.array[: n_frames * 3 * n_atoms].reshape(n_frames, 3, n_atoms)
@@ -334,11 +339,17 @@ class FrameStream:
             stride = (C.c_int64 * 5)(n, n, 3 * n, 3 * n, 3 * n)
             paths = (C.c_char_p * B)(*[str(f).encode() for f in chunk])
             err = C.create_string_buffer(512)
+            same = np.zeros(B, dtype=np.int32)
+            ref = getattr(self, "_types_ref", None)
+            if ref is not None and ref.shape[0] != n:
+                ref = None
             t0 = time.perf_counter()
             rc = lib.mdhip_dump_read_files(paths, B, 5, cols, b"id", n, dst, stride,
                                            steps.ctypes.data_as(C.POINTER(C.c_int64)),
                                            bounds.ctypes.data_as(dptr), tilt.ctypes.data_as(dptr),
-                                           tri.ctypes.data_as(C.POINTER(C.c_int32)), threads, err, 512)
+                                           tri.ctypes.data_as(C.POINTER(C.c_int32)), threads, err, 512, 1,
+                                           None if ref is None else ref.ctypes.data_as(dptr),
+                                           same.ctypes.data_as(C.POINTER(C.c_int32)))
             self.stats["parse_s"] += (time.perf_counter() - t0) * min(threads, B)  # (upper bound: wall x threads)
             if rc == 1 or (rc == 0 and tri.any()):
                 # some file of the chunk is not a plain single frame of n atoms in an orthogonal box: the per-frame
@@ -352,7 +363,11 @@ class FrameStream:
             # (sqrt(a * a) == |a| exactly)
             lengths = np.abs(np.column_stack([bounds[:, 1] - bounds[:, 0], bounds[:, 3] - bounds[:, 2],
                                               bounds[:, 5] - bounds[:, 4]]))
-            self._ready.put((Batch(self, buf, B, n, ids, types, lengths, steps), []))
+            if ref is None:
+                ref = self._types_ref = types[0].copy()
+            b = Batch(self, buf, B, n, ids, types, lengths, steps)
+            b.uniform_types, b.types_ref = bool(same.all()), ref
+            self._ready.put((b, []))
             self.stats["batches"] += 1
             self.stats["frames"] += B
             done += B

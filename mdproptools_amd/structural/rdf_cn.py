@@ -206,15 +206,40 @@ def _calc_props_memo(box_lengths, ref_labels, obj_labels, num_types, mass, parti
     m = _PROPS_MEMO
     key = (tuple(float(x) for x in box_lengths), num_types, tuple(float(x) for x in mass),
            tuple(map(tuple, partial_relations)), altered, None if num_atoms_per_mol is None else tuple(num_atoms_per_mol))
-    same_labels = (m["key"] is not None and m["key"][0] == key and m["key"][1].shape == np.shape(ref_labels)
-                   and np.array_equal(m["key"][1], ref_labels)
+    # (the SAME array object as last time — the stream hands `types_ref` to every batch whose frames the reader threads
+    # found unchanged — needs no comparison; another array is compared value by value)
+    same_labels = (m["key"] is not None and m["key"][0] == key
+                   and (m.get("obj") is ref_labels
+                        or (m["key"][1].shape == np.shape(ref_labels) and np.array_equal(m["key"][1], ref_labels)))
                    and (obj_labels is ref_labels or (m["key"][2] is not None and np.array_equal(m["key"][2], obj_labels))))
     if same_labels:
         return m["val"]
     val = _calc_props(box_lengths, ref_labels, obj_labels, num_types, mass, partial_relations, altered, num_atoms_per_mol)
     m["key"] = (key, np.array(ref_labels, copy=True), None if obj_labels is ref_labels else np.array(obj_labels, copy=True))
+    m["obj"] = ref_labels
     m["val"] = val
     return val
+
+
+_I32_MEMO = {"obj": None, "val": None}
+
+
+def _labels_and_props(batch, altered, num_mols, num_atoms_per_mol, num_types, mass, partial_relations):
+    """(labels for the library — int32 [N], or [F, N] when they change —, the per-frame `_calc_props` tuples) of one
+    batch (rdf_cn.py:462-482). A streamed batch whose frames all carry the first frame's types (the reader threads
+    compared them while the text was in their caches) takes one label array and, with a constant box, one set of
+    densities for all its frames."""
+    if not altered and getattr(batch, "uniform_types", False) and batch.types_ref is not None:
+        lab = batch.types_ref
+        props = [_calc_props_memo(f.lengths, lab, lab, num_types, mass, partial_relations, altered, num_atoms_per_mol)
+                 for f in batch]
+        if _I32_MEMO["obj"] is not lab:
+            _I32_MEMO["obj"], _I32_MEMO["val"] = lab, lab.astype(np.int32)
+        return _I32_MEMO["val"], props
+    labels = [(_calc_atom_type(f.ids, num_mols, num_atoms_per_mol) if altered else f.types) for f in batch]
+    props = [_calc_props_memo(f.lengths, lab, lab, num_types, mass, partial_relations, altered, num_atoms_per_mol)
+             for f, lab in zip(batch, labels)]
+    return _labels_for(batch, labels), props
 
 
 def _write_csv(df, path_or_buf):
@@ -359,6 +384,14 @@ class _Batch(list):
     staging buffer (streamed batches), else None."""
 
     block = None
+    uniform_types = False
+    types_ref = None
+    lengths_block = None
+
+
+def _lengths_block(batch):
+    lb = getattr(batch, "lengths_block", None)
+    return lb if lb is not None else np.array([f.lengths for f in batch])
 
 
 def _xyz_block(batch):
@@ -373,6 +406,8 @@ def _batches(frames):
         for sb in frames:
             b = _Batch(_Frame.view(fr) for fr in sb)
             b.block = sb.xyz
+            b.uniform_types, b.types_ref = getattr(sb, "uniform_types", False), getattr(sb, "types_ref", None)
+            b.lengths_block = np.asarray(sb.lengths, dtype=np.float64)
             yield b
         return
     start = 0
@@ -420,11 +455,9 @@ def calc_atomic_rdf(r_cut, bin_size, num_types, mass, partial_relations, filenam
     rows = []  # normalised g(r) of every frame this process holds: [g_full | g_part]
     for batch in _batches(frames):
         start = timer()
-        labels = [(_calc_atom_type(f.ids, num_mols, num_atoms_per_mol) if altered else f.types) for f in batch]
-        props = [_calc_props_memo(f.lengths, lab, lab, num_types, mass, partial_relations, altered,
-                                  num_atoms_per_mol) for f, lab in zip(batch, labels)]
-        full, part, ov = backend.rdf_loop(_xyz_block(batch), _labels_for(batch, labels),
-                                          np.array([f.lengths for f in batch]), relation_matrix, r_cut,
+        lab_arg, props = _labels_and_props(batch, altered, num_mols, num_atoms_per_mol, num_types, mass,
+                                           partial_relations)
+        full, part, ov = backend.rdf_loop(_xyz_block(batch), lab_arg, _lengths_block(batch), relation_matrix, r_cut,
                                           bin_size, num_bins, per_frame=True)
         dropped += ov
         # every frame normalised with ITS box and densities (rdf_cn.py:502-513), all frames of the batch at once
@@ -460,11 +493,9 @@ def calc_atomic_cn(r_cut, bin_size, num_types, mass, partial_relations, filename
     frames = dumps
     rows = []
     for batch in _batches(frames):
-        labels = [(_calc_atom_type(f.ids, num_mols, num_atoms_per_mol) if altered else f.types) for f in batch]
-        props = [_calc_props(f.lengths, lab, lab, num_types, mass, partial_relations, altered,
-                             num_atoms_per_mol) for f, lab in zip(batch, labels)]
-        raw = backend.cn_loop(_xyz_block(batch), _labels_for(batch, labels),
-                              np.array([f.lengths for f in batch]), relation_matrix, list(r_cut),
+        lab_arg, props = _labels_and_props(batch, altered, num_mols, num_atoms_per_mol, num_types, mass,
+                                           partial_relations)
+        raw = backend.cn_loop(_xyz_block(batch), lab_arg, _lengths_block(batch), relation_matrix, list(r_cut),
                               per_frame=True)
         for k, f in enumerate(batch):
             rows.append(np.asarray(_normalize_cn(props[k][2], partial_relations, raw[k].astype(np.float64)),
@@ -495,12 +526,10 @@ def calc_atomic_rdf_cn(r_cut, cn_r_cut, bin_size, num_types, mass, partial_relat
     dropped = 0
     rows, cn_rows = [], []
     for batch in _batches(dumps):
-        labels = [(_calc_atom_type(f.ids, num_mols, num_atoms_per_mol) if altered else f.types) for f in batch]
-        props = [_calc_props_memo(f.lengths, lab, lab, num_types, mass, partial_relations, altered,
-                                  num_atoms_per_mol) for f, lab in zip(batch, labels)]
-        full, part, ov, raw = backend.rdf_cn_loop(_xyz_block(batch), _labels_for(batch, labels),
-                                                  np.array([f.lengths for f in batch]), relation_matrix, r_cut,
-                                                  bin_size, num_bins, list(cn_r_cut), per_frame=True)
+        lab_arg, props = _labels_and_props(batch, altered, num_mols, num_atoms_per_mol, num_types, mass,
+                                           partial_relations)
+        full, part, ov, raw = backend.rdf_cn_loop(_xyz_block(batch), lab_arg, _lengths_block(batch), relation_matrix,
+                                                  r_cut, bin_size, num_bins, list(cn_r_cut), per_frame=True)
         dropped += ov
         rows.append(_normalize_rdf_batch(bin_size, props, partial_relations, num_relations, num_bins, part, full,
                                          [f.xyz.shape[1] for f in batch]))

@@ -24,6 +24,9 @@ for s in "$@"; do
     e2e_c3) timeout -k 10 1100 python tests/bench/bench_e2e.py 100000 1000 > $O/bench_e2e_c3_full.txt 2> $O/bench_e2e_c3_err.log; echo "e2e_c3 rc=$?"; tail -2 $O/bench_e2e_c3_err.log; cat $O/bench_e2e_c3_full.txt ;;
     e2e_c4) timeout -k 10 1100 python tests/bench/bench_e2e_msd.py 50000 5000 allatom > $O/bench_e2e_c4_full.txt 2> $O/bench_e2e_c4_err.log; echo "e2e_c4 rc=$?"; tail -2 $O/bench_e2e_c4_err.log; cat $O/bench_e2e_c4_full.txt ;;
     e2e_c4com) timeout -k 10 1100 python tests/bench/bench_e2e_msd.py 50000 5000 com > $O/bench_e2e_c4com_full.txt 2> $O/bench_e2e_c4com_err.log; echo "e2e_c4com rc=$?"; tail -2 $O/bench_e2e_c4com_err.log; cat $O/bench_e2e_c4com_full.txt ;;
+    tests_fft) timeout -k 10 900 python -m pytest tests -m gpu -x -q -k "xcorr or fft or lag or c5 or c4 or viscos or conduct" > $O/gpu_tests_fft.log 2>&1; rc=$?; echo "tests_fft rc=$rc"; tail -5 $O/gpu_tests_fft.log; [ $rc -eq 0 ] || exit 1 ;;
+    soak_fft) timeout -k 10 900 python tests/bench/soak_fft.py > $O/soak_fft.log 2>&1; echo "soak_fft rc=$?"; tail -4 $O/soak_fft.log ;;
+    sec_fft) for w in acf_fft lag_fft; do timeout -k 10 300 python tools/run_secondary.py $w 5 2>&1 | tail -3; done ;;
     *) echo "unknown step $s" ;;
   esac
 done
