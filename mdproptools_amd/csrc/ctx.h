@@ -73,6 +73,7 @@ struct mdhip_ctx {
     // first use); one event per batch in flight
     hipStream_t copy_stream = nullptr;
     hipEvent_t copy_ev[2] = {nullptr, nullptr};
+    int opt_rdf_relblock = 0;  // packed sweep: atoms per centre block of the f32 records, 0 / 256 = whole tiles, 64 (A/B)
     int opt_h2d_overlap = 1;  // 1 (default): overlapped staging of host-resident pair inputs, 0: one copy up front (A/B)
     std::string err;
     DevBuf ws[WS_COUNT];

@@ -260,6 +260,8 @@ int mdhip_set_option(mdhip_ctx *ctx, const char *key, int value)
         ctx->opt_rdf_slots = value < 1 ? 1 : value;
     else if (!strcmp(key, "xcorr_tile"))
         ctx->opt_xcorr_tile = value;
+    else if (!strcmp(key, "rdf_relblock"))
+        ctx->opt_rdf_relblock = value;
     else if (!strcmp(key, "lag_fft_kernel"))
         ctx->opt_lag_fft_kernel = value;
     else if (!strcmp(key, "h2d_overlap"))

@@ -825,18 +825,22 @@ __global__ __launch_bounds__(256) void transpose_scale_kernel(const double *__re
                                                               double *__restrict__ out, long long rows,
                                                               long long cols, double scale)
 {
-    // out[col][row] = in[row][col] * scale, 32x32 tiles through LDS
-    __shared__ double tile[32][33];
-    const long long c0 = (long long)blockIdx.x * 32, r0 = (long long)blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int k = ty; k < 32; k += 8) {
+    // out[col][row] = in[row][col] * scale, 64 x 64 tiles through LDS: a wave reads and writes runs of 64 doubles
+    // (512 B; the 32 x 32 tiles of round 2 moved 256-byte runs: 4.2 TB/s of read + write at C4), every element is
+    // touched once in each direction: nontemporal
+    __shared__ double tile[64][65];
+    const long long c0 = (long long)blockIdx.x * 64, r0 = (long long)blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+#pragma unroll 4
+    for (int k = ty; k < 64; k += 4) {
         const long long rr = r0 + k, cc = c0 + tx;
-        tile[k][tx] = (rr < rows && cc < cols) ? in[rr * cols + cc] * scale : 0.0;
+        tile[k][tx] = (rr < rows && cc < cols) ? __builtin_nontemporal_load(in + rr * cols + cc) * scale : 0.0;
     }
     __syncthreads();
-    for (int k = ty; k < 32; k += 8) {
+#pragma unroll 4
+    for (int k = ty; k < 64; k += 4) {
         const long long cc = c0 + k, rr = r0 + tx;
-        if (rr < rows && cc < cols) out[cc * rows + rr] = tile[tx][k];
+        if (rr < rows && cc < cols) __builtin_nontemporal_store(tile[tx][k], out + cc * rows + rr);
     }
 }
 
@@ -934,7 +938,7 @@ int lag_msd_fft_fused(mdhip_ctx *ctx, long long F, long long E, const double *d_
     // round-3 kernel (conflict-free layout, bilinear spectrum accumulation): N = 2^m a multiple of the block size
     const bool v2 = ctx->opt_lag_fft_kernel != 0 && m >= 9 && f2_lds_bytes(m) <= ctx->lds_max;
     KernelTimer timer(ctx);
-    hipLaunchKernelGGL(transpose_scale_kernel, dim3((unsigned)((cols + 31) / 32), (unsigned)((F + 31) / 32)), dim3(256),
+    hipLaunchKernelGGL(transpose_scale_kernel, dim3((unsigned)((cols + 63) / 64), (unsigned)((F + 63) / 64)), dim3(256),
                        0, ctx->stream, d_r, d_x, F, cols, scale);
     MD_HIP(hipGetLastError());
     const int qr = (int)((F + FT_THREADS - 1) / FT_THREADS);

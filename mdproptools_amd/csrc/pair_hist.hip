@@ -169,7 +169,7 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
             // sqrt(rsq32) < cut_lo  =>  sqrt(rsq) < cut_lo + err * bin_size < r_cut: inside the cutoff for certain
             cut_lo = std::nextafterf((float)(r_cut - 1.1 * err * p.bin_size), 0.f);
             // centre blocks: whole tiles (64-atom blocks only buy a little f32 precision for 4x the per-block work)
-            rel_block = TILE;
+            rel_block = ctx->opt_rdf_relblock == 64 ? 64 : TILE;
             near_pk_f = (float)near_pk;
             s_cap = (float)cap;
             // every pair with rsq < r_cut^2 has sqrt(rsq32) <= r_cut + err * bin_size

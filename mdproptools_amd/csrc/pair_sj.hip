@@ -289,6 +289,7 @@ struct PkCtx {
     unsigned long long full;  // the exec mask of the sweep (the pair block narrows exec and puts this back)
     const unsigned *rowtab;  // ROWS: the class-row table [n_tj][n_ti] of LDS byte addresses (nullptr: ordered rows)
     unsigned *queue;      // this wave's queue (LDS)
+    unsigned qaddr;       // its LDS byte address (wave-uniform)
     int qn;               // entries queued (wave-uniform: kept in an SGPR)
     unsigned long long *lost;  // device counter of entries that did not fit the queue (must stay 0)
     // what the resolver needs
@@ -507,6 +508,33 @@ __device__ __forceinline__ int jidx_here(GroupIdx k)
     return k.jbase + g * SJ_GROUP;
 }
 
+// Appends one queue entry per lane of `mask` (wave-uniform, non-zero): (tag | lane) at queue[qn + rank of the lane in
+// the mask]. The exec mask itself selects the lanes — v_mbcnt ranks them, one LDS store — and is put back to the sweep's
+// mask (p.full: every call sits in wave-uniform control flow with the sweep's lanes live, as bin_pair2 requires):
+// 4 VALU + 1 LDS + 3 SALU, where the compiler's form of `if ((mask >> lane) & 1) queue[pos] = ...` with its capacity test
+// took ~9 VALU + ~12 SALU + 4 branches per ambiguous slot (6 % of the slots at C2 take this path). No capacity test:
+// the queue is drained above 64 entries before every group and a group appends at most 4 x 64 (PK_QCAP = 320).
+// Measured build against build (tools/ab_libs.py): C2 -2.0 %, C3 RDF -2.3 %, one-sweep RDF+CN -4.3 %; integers identical
+// (soak_pk 1500 + soak_cn 800 against the oracle).
+__device__ __forceinline__ void pk_push(PkCtx &p, unsigned long long mask, unsigned tag, int lane)
+{
+    unsigned rank, addr;
+    const unsigned qa = p.qaddr + 4u * (unsigned)p.qn;
+    asm volatile(
+        "s_mov_b64 exec, %[m]\n\t"
+        "v_mbcnt_lo_u32_b32 %[r], %[mlo], 0\n\t"
+        "v_mbcnt_hi_u32_b32 %[r], %[mhi], %[r]\n\t"
+        "v_lshl_add_u32 %[a], %[r], 2, %[qa]\n\t"
+        "v_or_b32 %[r], %[tag], %[lane]\n\t"
+        "ds_write_b32 %[a], %[r]\n\t"
+        "s_mov_b64 exec, %[full]"
+        : [r] "=&v"(rank), [a] "=&v"(addr)
+        : [m] "s"(mask), [mlo] "s"((unsigned)mask), [mhi] "s"((unsigned)(mask >> 32)), [qa] "s"(qa), [tag] "s"(tag),
+          [lane] "v"(lane), [full] "s"(p.full)
+        : "memory");
+    p.qn += __builtin_popcountll(mask);
+}
+
 // The four j atoms of one group against the wave's 64 i atoms.
 // VAR: bit k = axis k takes the per-pair f32 wrap. jidx0 = index of the group's first atom in the frame's j set.
 // PF: load the records at `next_p` into `next` (the group swept after this one) once the first operation on this
@@ -575,18 +603,7 @@ __device__ __forceinline__ void sweep_group_pk(const RelQ &rq, GroupIdx jidx0, i
             for (int u = 0; u < 2; ++u) {
                 const unsigned long long done = u ? o.done1 : o.done0;
                 const unsigned long long hm = __builtin_amdgcn_ballot_w64((u ? o.addr1 : o.addr0) == (u ? kaddr1 : kaddr0)) & done;
-                if (hm) {
-                    const bool hit = (hm >> lane) & 1ull;
-                    if (hit) {
-                        const int pos = p.qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32),
-                                                                              __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0u));
-                        if (pos < PK_QCAP)
-                            p.queue[pos] = PK_CN_ONLY | ((unsigned)(jidx_here(jidx0) + 2 * h + u) << 6) | (unsigned)lane;
-                        else
-                            atomicAdd(p.lost, 1ull);
-                    }
-                    p.qn += __builtin_popcountll(hm);
-                }
+                if (hm) pk_push(p, hm, PK_CN_ONLY | ((unsigned)(jidx_here(jidx0) + 2 * h + u) << 6), lane);
             }
         }
         if (any_amb) {  // wave-uniform, rare: some lane's pair is inside the error band -> the exact chain, later
@@ -596,17 +613,7 @@ __device__ __forceinline__ void sweep_group_pk(const RelQ &rq, GroupIdx jidx0, i
                 // otherwise fold both conditions into one divergent branch and pay 3 VALU per pair for it)
                 unsigned long long amb_in;
                 asm volatile("s_mov_b64 %0, %1" : "=s"(amb_in) : "s"(u ? o.amb1 : o.amb0));
-                if (amb_in) {
-                    if ((amb_in >> lane) & 1ull) {
-                        const int pos = p.qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(amb_in >> 32),
-                                                                              __builtin_amdgcn_mbcnt_lo((unsigned)amb_in, 0u));
-                        if (pos < PK_QCAP)
-                            p.queue[pos] = ((unsigned)(jidx_here(jidx0) + 2 * h + u) << 6) | (unsigned)lane;
-                        else  // cannot happen (drained above 64, a group adds <= 256); the host reports it
-                            atomicAdd(p.lost, 1ull);
-                    }
-                    p.qn += __builtin_popcountll(amb_in);
-                }
+                if (amb_in) pk_push(p, amb_in, (unsigned)(jidx_here(jidx0) + 2 * h + u) << 6, lane);
             }
         }
     }
@@ -680,6 +687,8 @@ __device__ __forceinline__ int sj_item_pk(const PairArgs &a, FastCtx &c, const u
     asm volatile("s_mov_b64 %0, exec" : "=s"(p.full));
     p.rowtab = ROWS ? s_row : nullptr;
     p.queue = queue;
+    p.qaddr = (unsigned)__builtin_amdgcn_readfirstlane(
+        (int)(unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned *)queue);
     p.qn = 0;
     p.lost = a.overflow + 1;
     p.ats_i = ats + (long long)I * TILE + wq * 64;
@@ -795,7 +804,7 @@ __device__ __forceinline__ int sj_item_pk(const PairArgs &a, FastCtx &c, const u
         asm("s_bitset0_b64 %0, %1" : "+s"(mk) : "s"(G));                                                                \
     }
 #define PK_REC(G) (const float *)((const char *)rtile + ((unsigned)(G) << 6))
-#define PK_PIPELINED(MASK, CN)                                                                                          \
+#define PK_PIPELINED(MASK, CN, VAR)                                                                                     \
     {                                                                                                                   \
         unsigned long long mk = (MASK);                                                                                 \
         if (mk) {                                                                                                       \
@@ -806,26 +815,38 @@ __device__ __forceinline__ int sj_item_pk(const PairArgs &a, FastCtx &c, const u
                 PK_DRAIN_CHECK();                                                                                       \
                 const bool moreB = mk != 0;                                                                             \
                 PK_NEXT(gB)                                                                                             \
-                sweep_group_pk<false, 0, true, CUTG, ROWS, CN>(qA, GroupIdx{jbase, gA}, gA * SJ_GROUP, p, c,            \
-                                                               lane_in_tile, lane, PK_REC(gB), qB);                     \
+                sweep_group_pk<false, VAR, true, CUTG, ROWS, CN>(qA, GroupIdx{jbase, gA}, gA * SJ_GROUP, p, c,          \
+                                                                 lane_in_tile, lane, PK_REC(gB), qB);                   \
                 if (!moreB) break;                                                                                      \
                 PK_DRAIN_CHECK();                                                                                       \
                 const bool moreA = mk != 0;                                                                             \
                 PK_NEXT(gA)                                                                                             \
-                sweep_group_pk<false, 0, true, CUTG, ROWS, CN>(qB, GroupIdx{jbase, gB}, gB * SJ_GROUP, p, c,            \
-                                                               lane_in_tile, lane, PK_REC(gA), qA);                     \
+                sweep_group_pk<false, VAR, true, CUTG, ROWS, CN>(qB, GroupIdx{jbase, gB}, gB * SJ_GROUP, p, c,          \
+                                                                 lane_in_tile, lane, PK_REC(gA), qA);                   \
                 if (!moreA) break;                                                                                      \
             }                                                                                                           \
         }                                                                                                               \
     }
             if (!diag) {
-                PK_PIPELINED(__builtin_amdgcn_ballot_w64(keep && var == 0u && !nearg) & bm, false)
-                if constexpr (CNG) PK_PIPELINED(__builtin_amdgcn_ballot_w64(keep && var == 0u && nearg) & bm, true)
+                PK_PIPELINED(__builtin_amdgcn_ballot_w64(keep && var == 0u && !nearg) & bm, false, 0)
+                if constexpr (CNG) PK_PIPELINED(__builtin_amdgcn_ballot_w64(keep && var == 0u && nearg) & bm, true, 0)
+                // the groups that take the per-pair wrap on some axis run the same software pipeline, variant by variant
+                // (round 3: their records were loaded and waited for group by group before — at C2, where a third of the
+                // swept groups wrap on some axis, 3.04 -> 2.82 ms build against build; C3, which has none, -0.9 %)
+                if (__builtin_amdgcn_ballot_w64(keep && var != 0u && !nearg)) {
+                    PK_PIPELINED(__builtin_amdgcn_ballot_w64(keep && var == 1u && !nearg) & bm, false, 1)
+                    PK_PIPELINED(__builtin_amdgcn_ballot_w64(keep && var == 2u && !nearg) & bm, false, 2)
+                    PK_PIPELINED(__builtin_amdgcn_ballot_w64(keep && var == 4u && !nearg) & bm, false, 4)
+                    PK_PIPELINED(__builtin_amdgcn_ballot_w64(keep && var == 3u && !nearg) & bm, false, 3)
+                    PK_PIPELINED(__builtin_amdgcn_ballot_w64(keep && var == 5u && !nearg) & bm, false, 5)
+                    PK_PIPELINED(__builtin_amdgcn_ballot_w64(keep && var == 6u && !nearg) & bm, false, 6)
+                    PK_PIPELINED(__builtin_amdgcn_ballot_w64(keep && var == 7u && !nearg) & bm, false, 7)
+                }
             }
 #undef PK_PIPELINED
 #undef PK_NEXT
 #undef PK_REC
-            // the other variants (per-pair wrap on some axis, the diagonal tile): not pipelined
+            // what is left — the diagonal tile, and wrapping groups the CN check walks —: not pipelined
 #define PK_SWEEP_CASES(CN)                                                                                             \
     switch (A) {                                                                                                       \
     case 1: sweep_group_pk<false, 1, false, CUTG, ROWS, CN>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break; \
@@ -841,7 +862,7 @@ __device__ __forceinline__ int sj_item_pk(const PairArgs &a, FastCtx &c, const u
     }
             const unsigned long long nm = CNG ? __builtin_amdgcn_ballot_w64(nearg) : 0ull;
             for (unsigned A = diag ? 8u : 1u; A <= (diag ? 9u : 7u); ++A) {
-                unsigned long long mk = __builtin_amdgcn_ballot_w64(keep && var == A) & bm;
+                unsigned long long mk = __builtin_amdgcn_ballot_w64(keep && var == A && (diag || nearg)) & bm;
                 while (mk) {
                     const int g = __builtin_ctzll(mk);
                     mk &= mk - 1;

@@ -47,6 +47,7 @@ for rnd in range(3):
             ms.append(ctx.last_kernel_ms()[0])
         if ref is None:
             ref = out
-        assert np.array_equal(out[0], ref[0]) and np.array_equal(out[1], ref[1])
+        same = np.array_equal(out[0], ref[0]) and np.array_equal(out[1], ref[1])
+        assert same or os.environ.get("AB_ALLOW_DIFFERENT"), "results differ"
         ms = np.array(ms[2:])
-        print("%s %s %-28s min %.4f ms  median %.4f ms" % (which, op, os.path.basename(p), ms.min(), np.median(ms)))
+        print("%s %s %-28s min %.4f ms  median %.4f ms%s" % (which, op, os.path.basename(p), ms.min(), np.median(ms), "" if same else "  DIFFERENT RESULTS (timing experiment)"))

@@ -27,6 +27,11 @@ for s in "$@"; do
     tests_fft) timeout -k 10 900 python -m pytest tests -m gpu -x -q -k "xcorr or fft or lag or c5 or c4 or viscos or conduct" > $O/gpu_tests_fft.log 2>&1; rc=$?; echo "tests_fft rc=$rc"; tail -5 $O/gpu_tests_fft.log; [ $rc -eq 0 ] || exit 1 ;;
     soak_fft) timeout -k 10 900 python tests/bench/soak_fft.py > $O/soak_fft.log 2>&1; echo "soak_fft rc=$?"; tail -4 $O/soak_fft.log ;;
     sec_fft) for w in acf_fft lag_fft; do timeout -k 10 300 python tools/run_secondary.py $w 5 2>&1 | tail -3; done ;;
+    tests_pair) timeout -k 10 1000 python -m pytest tests/test_gpu_parity.py tests/test_gpu_hardening.py tests/test_gpu_fullsize.py -m gpu -x -q -k "not bench and not two_ranks and not c4 and not c5 and not xcorr and not msd" > $O/gpu_tests_pair.log 2>&1; rc=$?; echo "tests_pair rc=$rc"; tail -4 $O/gpu_tests_pair.log; [ $rc -eq 0 ] || exit 1 ;;
+    soak_pk) timeout -k 10 900 python tests/bench/soak_pk.py 1500 31 oracle > $O/soak_pk.log 2>&1; echo "soak_pk rc=$?"; tail -3 $O/soak_pk.log ;;
+    soak_cn) timeout -k 10 900 python tests/bench/soak_cn.py 800 5 oracle > $O/soak_cn.log 2>&1; echo "soak_cn rc=$?"; tail -3 $O/soak_cn.log ;;
+    soak_cull) timeout -k 10 900 python tests/bench/soak_cull.py 600 > $O/soak_cull.log 2>&1; echo "soak_cull rc=$?"; tail -3 $O/soak_cull.log ;;
+    ab_pair) for w in C2 C3; do for op in rdf cn rdf_cn; do timeout -k 10 300 python tools/ab_libs.py tools/_bin/libmdhip_cur.so mdproptools_amd/libmdhip.so $w $op 2>&1 | grep -v amdgpu | tail -2; done; done ;;
     *) echo "unknown step $s" ;;
   esac
 done
