@@ -403,6 +403,12 @@ __device__ __forceinline__ RelQ load_relq(const float *__restrict__ p)
 //     s_mov      exec = full
 // = 8 VALU + 2 SALU + 1 branch per slot (round 1: 7 VALU + 5 SALU + 1 branch, and a compare + branch on amb per slot
 // behind it; the caller now tests amb0 | amb1 once). `full` is the exec mask of the sweep (read once per item).
+// INVARIANT (also pk_push): these blocks rewrite exec and put `full` back, and the compiler does not know — every call
+// must sit in wave-uniform control flow with exactly the lanes of `full` live (sj_item_pk reads it at its top; every
+// branch between there and the sweeps is on a wave-uniform value: ballots, scalar masks, readfirstlane'd indices).
+// A call placed under a divergent branch would silently re-enable lanes. work_loop_sane() checks at the top of every
+// work item that all 64 lanes are present, so `full` is ~0 for every sweep; reading exec inside the block instead
+// would cost one more scalar instruction per two slots in a loop that is bound by issue slots, scalar ones included.
 // v_sqrt_f32 needs one wait state before its result is read.
 // CUTG: the cutoff does not sit on a bin edge, so the band of an edge does not decide in/out of the cutoff: lanes whose
 // f32 distance reaches the cutoff's own error band (sqrt(rsq32) >= cut_lo) are ambiguous too: one more v_cmpx (t < cl).

@@ -250,3 +250,21 @@ def test_overflow_guard_splits_the_batch(B):
     with pytest.raises(Exception, match="overflow the 32-bit"):
         B.rdf_loop(xyz, ty, box, rel, 12.0, 0.05, 240, per_frame=False, ctx=ctx)
     ctx.close()
+
+
+def test_soak_slices_inside_the_suite():
+    """A slice of the long differential runs (tests/bench/soak_pk.py, soak_cn.py) inside `-m gpu`, behind a time budget of
+    about a minute: 700 cases of the packed-f32 sweep against the all-f64 sweep (fresh seed: not the stream of
+    test_soak_slice_packed_vs_f64_and_oracle) and 400 cases of the one-sweep RDF + CN call against the two calls, every
+    fifth one also against oracle/cpu_ref.c. The full soaks (12 000 + 3000 cases) are run by hand per round and
+    logged under profiles/."""
+    import subprocess
+    import time
+
+    t0 = time.perf_counter()
+    for script, args in (("soak_pk.py", ["700", "909"]), ("soak_cn.py", ["400", "17", "oracle"])):
+        r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "bench", script)] + args, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True, timeout=600)
+        tail = "\n".join(r.stdout.splitlines()[-5:])
+        assert r.returncode == 0 and "identical" in tail, tail
+    assert time.perf_counter() - t0 < 300.0

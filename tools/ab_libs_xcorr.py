@@ -14,6 +14,7 @@ from mdproptools_amd import backend as B  # noqa: E402
 
 libs = [a for a in sys.argv[1:] if a.endswith(".so")]
 n = next((int(a) for a in sys.argv[1:] if a.isdigit()), 1_000_000)
+METHOD = B.XCORR_FFT if "fft" in sys.argv[1:] else B.XCORR_DIRECT  # `fft`: the FFT estimator (kernel time of the whole pipeline)
 
 
 def ctx_of(path):
@@ -28,10 +29,10 @@ ref = None
 for rnd in range(2):
     for p, ctx in zip(libs, ctxs):
         best = 1e9
-        for rep in range(3):
-            out = B.xcorr(x, method=B.XCORR_DIRECT, ctx=ctx)
+        for rep in range(3 if METHOD == B.XCORR_DIRECT else 10):
+            out = B.xcorr(x, method=METHOD, ctx=ctx)
             best = min(best, ctx.last_kernel_ms()[0])
         if ref is None:
             ref = out
         err = float(np.max(np.abs(out[:, : n // 2] - ref[:, : n // 2])) / ref[0, 0])
-        print("%-28s %.2f ms  %.1f TFLOP/s  (diff to first %.1e acf0)" % (os.path.basename(p), best, 3 * n * (n + 1.0) / best * 1e-9, err), flush=True)
+        print("%-28s %.4f ms  %.1f TFLOP/s  (diff to first %.1e acf0)" % (os.path.basename(p), best, 3 * n * (n + 1.0) / best * 1e-9, err), flush=True)
