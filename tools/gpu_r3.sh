@@ -32,6 +32,11 @@ for s in "$@"; do
     soak_cn) timeout -k 10 900 python tests/bench/soak_cn.py 800 5 oracle > $O/soak_cn.log 2>&1; echo "soak_cn rc=$?"; tail -3 $O/soak_cn.log ;;
     soak_cull) timeout -k 10 900 python tests/bench/soak_cull.py 600 > $O/soak_cull.log 2>&1; echo "soak_cull rc=$?"; tail -3 $O/soak_cull.log ;;
     ab_pair) for w in C2 C3; do for op in rdf cn rdf_cn; do timeout -k 10 300 python tools/ab_libs.py tools/_bin/libmdhip_cur.so mdproptools_amd/libmdhip.so $w $op 2>&1 | grep -v amdgpu | tail -2; done; done ;;
+    pmc_c2) timeout -k 10 900 bash tools/pmc.sh r03_c2 C2 > $O/pmc_c2.log 2>&1; echo "pmc rc=$?" ;;
+    pmc_c2_f64) timeout -k 10 900 bash tools/pmc.sh r03_c2_f64 C2 --option rdf_pk=0 > $O/pmc_c2_f64.log 2>&1; echo "pmc rc=$?" ;;
+    pmc_c3) timeout -k 10 900 bash tools/pmc.sh r03_c3 C3 --scaling strong > $O/pmc_c3.log 2>&1; echo "pmc rc=$?" ;;
+    pmc_c3_cn) timeout -k 10 900 bash tools/pmc.sh r03_c3_cn C3/cn --scaling strong --op cn > $O/pmc_c3_cn.log 2>&1; echo "pmc rc=$?" ;;
+    pmc_c3_both) timeout -k 10 900 bash tools/pmc.sh r03_c3_both C3/rdf_cn --scaling strong --op rdf_cn > $O/pmc_c3_both.log 2>&1; echo "pmc rc=$?" ;;
     *) echo "unknown step $s" ;;
   esac
 done
