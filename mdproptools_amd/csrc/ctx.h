@@ -119,8 +119,10 @@ struct mdhip_ctx {
                               // autocorrelation theorem, 4 = 2 through batched global transforms (fft_pow2.hip)
     int fft_tw_logL = -1;         // length the table in WS_FFT_TW was built for (-1: none)
     const void *fft_tw_ptr = nullptr;
-    int opt_lag_fft_kernel = 1;   // fused full-lag MSD path: 1 (default) = round-3 kernel (conflict-free LDS layout, bilinear
-                                  // spectrum sums), 0 = the round-2 kernel (A/B; also what short series fall back to)
+    int opt_lag_fft_kernel = 2;   // fused full-lag MSD path: 2 (default) = first pass from registers + wave-private
+                                  // sub-transforms where the series is long enough (msd_power_lds3_kernel), else as 1;
+                                  // 1 = conflict-free LDS layout, bilinear spectrum sums (msd_power_lds2_kernel);
+                                  // 0 = the round-2 kernel (A/B; also what short series fall back to)
     double last_rel_bound = 0.0;  // error bound reported by the FFT MSD path of the last mdhip_lag_msd call (0: exact path)
 };
 

@@ -472,6 +472,13 @@ __device__ __forceinline__ int f2_freq(int p, const F2Plan &pl)
     return k + (((t >> 2) + 4 * (t & 3)) << w);
 }
 
+// position (in a tail block) of the tail digit (16 - d) mod 16, d the digit position t holds
+__device__ __forceinline__ constexpr int f2_tail_neg(int t)
+{
+    const int d = (t >> 2) + 4 * (t & 3), e = (16 - d) & 15;
+    return 4 * (e & 3) + (e >> 2);
+}
+
 // One radix-8 DIF butterfly on a[0..7] (elements j + q s of a sub-transform of length 8 s), outputs in a[] with
 // output digit d at a[d], twiddled by w1^d (w1 = w_len^j); first = no twiddle (s == 1 never happens here: the tail
 // takes the last 16 points)
@@ -545,16 +552,20 @@ __device__ __forceinline__ void f2_dft16(Cx *x)
 // table is walked with strides of 2^k entries there: 2- to 8-way bank conflicts). Variant for A/B builds
 // (tools/build_variant.sh): F2V_PREFETCH = the next series' samples fetched into registers under the transform
 // (measured 6 % SLOWER at C4: 20 more live registers at a budget the accumulators already fill).
-// the LDS passes + the tail, in place on re/im (f2_skew layout); every thread of the block calls it
+// The LDS passes, in place on re/im (f2_skew layout); every thread of the block calls it. The in-register radix-16
+// tail is the caller's (it accumulates the spectrum sums from the registers the tail leaves). `half` = packed points
+// that hold data: the rest of the input is the zero padding, which the FIRST pass neither needs in LDS (nobody
+// writes it) nor reads — a butterfly input at or beyond `half` is a zero in a register; with F = 5000 in L = 16384
+// five of the eight inputs of every first-pass butterfly are.
 template <int NT>
-__device__ void f2_transform(double *re, double *im, int m, const F2Plan &pl, const double2 *tabA, const double2 *tabB,
-                             const double2 *twp)
+__device__ __forceinline__ void f2_passes(double *re, double *im, int m, int half, const F2Plan &pl, const double2 *twp)
 {
     const int N = 1 << m;
     int off = 0;
     for (int q = 0; q < pl.n_pass; ++q) {
         const int lr = pl.lr[q], ls = pl.ls[q], lb = ls + lr, s = 1 << ls;
         const int nbf = N >> lr;  // butterflies of this pass
+        const int lim = q == 0 ? half : N;  // inputs at or beyond it are zeros (first pass: one block, base = j)
         // the stride-16 pass: the two 16-lane halves of a lane group take blocks 4 apart (pad shift 16), when the
         // transform has at least 8 such blocks
         const bool swz = ls == 4 && (N >> lb) >= 8;
@@ -571,7 +582,11 @@ __device__ void f2_transform(double *re, double *im, int m, const F2Plan &pl, co
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     idx[e] = f2_skew(base + (e << ls));
-                    a[e] = {re[idx[e]], im[idx[e]]};
+                    if ((e << ls) < lim) {  // (wave-uniform: whole rows of the zero padding are not read at all)
+                        a[e] = base + (e << ls) < lim ? Cx{re[idx[e]], im[idx[e]]} : Cx{0.0, 0.0};
+                    } else {
+                        a[e] = Cx{0.0, 0.0};
+                    }
                 }
                 f2_bfly8(a, w1, true);
 #pragma unroll
@@ -585,7 +600,7 @@ __device__ void f2_transform(double *re, double *im, int m, const F2Plan &pl, co
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     idx[e] = f2_skew(base + (e << ls));
-                    a[e] = {re[idx[e]], im[idx[e]]};
+                    a[e] = base + (e << ls) < lim ? Cx{re[idx[e]], im[idx[e]]} : Cx{0.0, 0.0};
                 }
                 dft4(a[0], a[1], a[2], a[3], y[0], y[1], y[2], y[3]);
                 const Cx w2 = cx_mul(w1, w1), w3 = cx_mul(w2, w1);
@@ -599,7 +614,8 @@ __device__ void f2_transform(double *re, double *im, int m, const F2Plan &pl, co
                 }
             } else {
                 const int i0 = f2_skew(base), i1 = f2_skew(base + s);
-                const Cx a0 = {re[i0], im[i0]}, a1 = {re[i1], im[i1]};
+                const Cx a0 = base < lim ? Cx{re[i0], im[i0]} : Cx{0.0, 0.0};
+                const Cx a1 = base + s < lim ? Cx{re[i1], im[i1]} : Cx{0.0, 0.0};
                 const Cx d = cx_mul(cx_sub(a0, a1), w1);
                 re[i0] = a0.x + a1.x;
                 im[i0] = a0.y + a1.y;
@@ -610,20 +626,8 @@ __device__ void f2_transform(double *re, double *im, int m, const F2Plan &pl, co
         off += s;
         __syncthreads();
     }
-    for (int b = threadIdx.x; b < (N >> 4); b += NT) {
-        const int p0 = f2_skew(16 * b);  // 16 consecutive points never cross a pad (pads sit at multiples of 32)
-        Cx x[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) x[e] = {re[p0 + e], im[p0 + e]};
-        f2_dft16(x);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            re[p0 + e] = x[e].x;
-            im[p0 + e] = x[e].y;
-        }
-    }
-    __syncthreads();
 }
+
 // LDS bytes of the round-3 kernel for N = 2^m: data planes + the two-level twiddle table (+ the per-pass tables)
 size_t f2_lds_bytes(int m)
 {
@@ -635,12 +639,17 @@ size_t f2_lds_bytes(int m)
 }
 
 // x: time-major series [cols][F] (already scaled). Qpart [items][F], Ppart [items][N + 1] as msd_power_lds_kernel.
-// PR = positions per lane = N / FT_THREADS (16 at N = 8192); QR2 = sample PAIRS per lane that can hold data.
-template <int QR2, int PR>
+// QR2 = sample PAIRS per lane that can hold data. Lane b < N / 16 owns the 16 consecutive positions of tail block b
+// (N <= 8192 = 16 x FT_THREADS): the in-register radix-16 leaves their transform values in its registers, and the
+// spectrum sums are taken from there — |Z|^2 without touching LDS again, Im(Z Z') against the partner frequencies, which
+// for the 16 positions of one block all lie in ONE other block (N - k flips the low digits together and reverses the
+// tail digit), read as 16 consecutive points.
+template <int QR2>
 __global__ __launch_bounds__(FT_THREADS) void msd_power_lds2_kernel(
     const double *__restrict__ x, int F, int m, const FftItem *__restrict__ items,
     const double2 *__restrict__ tab, double *__restrict__ Qpart, double *__restrict__ Ppart)
 {
+    constexpr int PR = 16;
     extern __shared__ double ft_lds[];
     const int N = 1 << m, np = N + (N >> 5) + 2;
     double *re = ft_lds, *im = ft_lds + np;
@@ -663,18 +672,24 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds2_kernel(
             off += s;
         }
     }
-    // this lane's positions p = tid + i FT_THREADS and the position of each one's partner frequency N - k
-    int partner[PR];
-#pragma unroll
-    for (int i = 0; i < PR; ++i) {
-        const int p = tid + i * FT_THREADS;
-        partner[i] = p < N ? f2_skew(f2_pos((N - f2_freq(p, pl)) & (N - 1), pl)) : 0;
-    }
-    double qa[QR2], qb[QR2], sacc[PR], tacc[PR];
+    // this lane's positions p = 16 tid + t and the position of each one's partner frequency N - k
+    const bool owner = tid < (N >> 4);
+    const int p0 = f2_skew(16 * tid);  // 16 consecutive points never cross a pad (pads sit at multiples of 32)
+    // position 16 b + t holds frequency K_b + t N/16 (K_b < N/16: the digits of the LDS passes); its partner N - k is
+    // K' + (15 - t) N/16 with K' = N/16 - K_b, all in the block that holds K' — except K_b = 0 (lane 0), whose partners
+    // stay in its own block, at the position of tail digit (16 - d) mod 16 (a position t holds tail digit
+    // d = (t >> 2) + 4 (t & 3), so 15 - d sits at 15 - t)
+    const int kb = owner ? f2_freq(16 * tid, pl) : 0;
+    const int pb = owner ? f2_skew(f2_pos(((N >> 4) - kb) & ((N >> 4) - 1), pl)) : 0;
+    const bool kb0 = kb == 0;
+#define F2_PARTNER(t) (pb + (kb0 ? f2_tail_neg(t) : 15 - (t)))
+    double qa[QR2], qb[QR2], sacc[PR], tacc[9];
 #pragma unroll
     for (int i = 0; i < QR2; ++i) qa[i] = qb[i] = 0.0;
 #pragma unroll
-    for (int i = 0; i < PR; ++i) sacc[i] = tacc[i] = 0.0;
+    for (int t = 0; t < PR; ++t) sacc[t] = 0.0;
+#pragma unroll
+    for (int u = 0; u < 9; ++u) tacc[u] = 0.0;
     const int half = (F + 1) >> 1;  // packed points that hold data
     double va[QR2], vb[QR2];
     auto fetch = [&](long long c) {
@@ -699,13 +714,8 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds2_kernel(
             }
         }
     };
-#ifdef F2V_PREFETCH
-    if (it.c_lo < it.c_hi) fetch(it.c_lo);
-#endif
     for (long long c = it.c_lo; c < it.c_hi; ++c) {
-#ifndef F2V_PREFETCH
         fetch(c);
-#endif
         double sum = 0.0;
 #pragma unroll
         for (int i = 0; i < QR2; ++i) sum += va[i] + vb[i];
@@ -723,27 +733,51 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds2_kernel(
                 im[q] = db;
             }
         }
-        for (int n = half + tid; n < N; n += FT_THREADS) {
-            const int q = f2_skew(n);
-            re[q] = 0.0;
-            im[q] = 0.0;
+        if (pl.n_pass == 0) {  // (no LDS pass prunes the padding: N = 16, the tail reads all of it)
+            for (int n = half + tid; n < N; n += FT_THREADS) {
+                const int q = f2_skew(n);
+                re[q] = 0.0;
+                im[q] = 0.0;
+            }
         }
-#ifdef F2V_PREFETCH
-        if (c + 1 < it.c_hi) fetch(c + 1);  // in flight under the transform
-#endif
         __syncthreads();
-        f2_transform<FT_THREADS>(re, im, m, pl, tabA, tabB, twp);
+        f2_passes<FT_THREADS>(re, im, m, half, pl, twp);
+        Cx z[PR];
+        if (owner) {
 #pragma unroll
-        for (int i = 0; i < PR; ++i) {
-            const int p = tid + i * FT_THREADS;
-            if (p < N) {
-                const int q = f2_skew(p);
-                const double ax = re[q], ay = im[q];
-                const double cx = re[partner[i]], cy = im[partner[i]];
-                sacc[i] = __builtin_fma(ax, ax, sacc[i]);
-                sacc[i] = __builtin_fma(ay, ay, sacc[i]);
-                tacc[i] = __builtin_fma(ax, cy, tacc[i]);
-                tacc[i] = __builtin_fma(ay, cx, tacc[i]);
+            for (int e = 0; e < PR; ++e) z[e] = {re[p0 + e], im[p0 + e]};
+            f2_dft16(z);
+#pragma unroll
+            for (int e = 0; e < PR; ++e) {
+                re[p0 + e] = z[e].x;
+                im[p0 + e] = z[e].y;
+            }
+        }
+        if (owner) {
+#pragma unroll
+            for (int t = 0; t < PR; ++t) {
+                sacc[t] = __builtin_fma(z[t].x, z[t].x, sacc[t]);
+                sacc[t] = __builtin_fma(z[t].y, z[t].y, sacc[t]);
+            }
+        }
+        __syncthreads();
+        if (owner) {
+            // T is the same number at a position and at its partner: a lane takes it for 8 of its 16 positions, the
+            // partner block's lane for the other 8 (lane 0, its own partner block, for one position of each of its 9
+            // pairs: slot 8)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t0 = u < 3 ? u : u + 1;  // lane 0: 0 1 2 4 5 6 7 8
+                const double zx = kb0 ? z[t0].x : z[u].x, zy = kb0 ? z[t0].y : z[u].y;
+                const int pt = pb + (kb0 ? f2_tail_neg(t0) : 15 - u);
+                const double cx = re[pt], cy = im[pt];
+                tacc[u] = __builtin_fma(zx, cy, tacc[u]);
+                tacc[u] = __builtin_fma(zy, cx, tacc[u]);
+            }
+            if (kb0) {
+                const int pt = pb + f2_tail_neg(9);
+                tacc[8] = __builtin_fma(z[9].x, im[pt], tacc[8]);
+                tacc[8] = __builtin_fma(z[9].y, re[pt], tacc[8]);
             }
         }
         // the next series' block sum has two barriers before LDS is written again
@@ -758,23 +792,432 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds2_kernel(
     // frequencies, once per block: S of the partner frequency through LDS, then
     //   P_k = (S_k + S_{N-k})/2 + Im(w) (S_k - S_{N-k})/2 + Re(w) T_k,   w = e^{-2 pi i k/L};   P_N = S_0 - T_0
     __syncthreads();
+    if (owner) {
 #pragma unroll
-    for (int i = 0; i < PR; ++i) {
-        const int p = tid + i * FT_THREADS;
-        if (p < N) re[f2_skew(p)] = sacc[i];
+        for (int t = 0; t < PR; ++t) re[p0 + t] = sacc[t];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) im[p0 + (kb0 ? (u < 3 ? u : u + 1) : u)] = tacc[u];
+        if (kb0) im[p0 + 9] = tacc[8];
     }
     __syncthreads();
+    if (owner) {
 #pragma unroll
-    for (int i = 0; i < PR; ++i) {
-        const int p = tid + i * FT_THREADS;
-        if (p < N) {
-            const int k = f2_freq(p, pl);
-            const double sk = sacc[i], sn = re[partner[i]];
+        for (int t = 0; t < PR; ++t) {
+            const int k = f2_freq(16 * tid + t, pl);
+            const bool mine = kb0 ? (t != 3 && t < 10) : t < 8;  // T taken at this position, else at its partner
+            const double sk = sacc[t], sn = re[F2_PARTNER(t)], tk = im[mine ? p0 + t : F2_PARTNER(t)];
             const Cx w = ft_tw(tabA, tabB, k);  // (cos, -sin) of 2 pi k / L
-            pp[k] = 0.5 * (sk + sn) + w.y * (0.5 * (sk - sn)) + w.x * tacc[i];
-            if (k == 0) pp[N] = sk - tacc[i];
+            pp[k] = 0.5 * (sk + sn) + w.y * (0.5 * (sk - sn)) + w.x * tk;
+            if (k == 0) pp[N] = sk - tk;
         }
     }
+#undef F2_PARTNER
+}
+
+// ---------------------------------------------------------------------------------------------
+// Round 3, second step: the same transform with the block barriers taken out of its middle. The counters of the kernel
+// above (profiles/r03_pmc_secondary_summary.txt) showed the LDS array busy 41 % and the f64 pipes ~30 % of the time,
+// one after the other: with one 512-thread block per CU (the data planes fill LDS) every pass was "all waves read, all
+// waves compute, all waves write, barrier", so neither unit ever worked under the other.
+//
+//  * First pass from REGISTERS. It is always radix 8 at stride N/8, and lane `tid` loads exactly the samples its own
+//    butterflies j = tid (+ 512) need: packed points j + e N/8. The series never goes to LDS untransformed — no input
+//    store, no first-pass reads, and the zero padding (e >= QE) is a literal zero that prunes half the butterfly.
+//  * After it the transform is 8 independent sub-transforms of N/8 points: wave w takes sub-transform w through
+//    all remaining LDS passes and the in-register radix-16 tail with NO block barrier (LDS serves one wave's
+//    accesses in order), so the eight waves drift apart and one wave's LDS phase runs under another's arithmetic.
+//    Three block barriers per series are left: first-pass writes -> sub-transforms, tail write-back -> partner reads,
+//    partner reads -> the next series' first-pass writes.
+//  * The next series' samples are fetched right after the first pass has consumed the current ones (the registers
+//    are free again), land during the sub-transforms, and their block sum rides on the second barrier.
+// Plan: 2^m = 8 x [4 x [4]] x 8 ... x 16 (f3_plan); positions/frequencies through f2_pos / f2_freq as above.
+// ---------------------------------------------------------------------------------------------
+#ifndef F3_MIN_M
+#define F3_MIN_M 12  // smallest log2 N the kernel below is used for (it is correct from 9; A/B builds lower this)
+#endif
+__host__ __device__ inline F2Plan f3_plan(int m)  // m >= 8
+{
+    F2Plan p{};
+    int q = 0, lb = m;
+    p.lr[q] = 3;
+    p.ls[q] = lb - 3;
+    lb -= 3;
+    ++q;
+    int rem = lb - 4;
+    while (rem % 3 != 0) {
+        const int r = rem >= 2 ? 2 : 1;
+        p.lr[q] = r;
+        p.ls[q] = lb - r;
+        lb -= r;
+        rem -= r;
+        ++q;
+    }
+    while (rem > 0) {
+        p.lr[q] = 3;
+        p.ls[q] = lb - 3;
+        lb -= 3;
+        rem -= 3;
+        ++q;
+    }
+    p.n_pass = q;
+    return p;
+}
+
+size_t f3_lds_bytes(int m)
+{
+    const size_t np = ((size_t)1 << m) + ((size_t)1 << m >> 5) + 2;
+    size_t tw = 0;
+    const F2Plan pl = f3_plan(m);
+    for (int q = 0; q < pl.n_pass; ++q) tw += (size_t)1 << pl.ls[q];
+    return 2 * np * 8 + 256 * 16 + 32 * 8 + tw * 16;
+}
+
+// dft4 with a zero fourth input
+__device__ __forceinline__ void dft4_3(Cx c0, Cx c1, Cx c2, Cx &z0, Cx &z1, Cx &z2, Cx &z3)
+{
+    const Cx d0 = cx_add(c0, c2), d1 = cx_sub(c0, c2), d3 = cx_mul_mi(c1);
+    z0 = cx_add(d0, c1);
+    z2 = cx_sub(d0, c1);
+    z1 = cx_add(d1, d3);
+    z3 = cx_sub(d1, d3);
+}
+
+// The radix-8 butterfly of the first pass with inputs a[0 .. QE) and zeros beyond; y[d] = output digit d, twiddled by
+// w1^d. QE <= 4: the first stage (a_e +- a_{e+4}) is the identity.
+template <int QE>
+__device__ __forceinline__ void f3_head8(const Cx *a, Cx w1, Cx *y)
+{
+    if constexpr (QE <= 4) {
+        constexpr double H = 0.70710678118654752440;
+        const Cx b5 = {(a[1].x + a[1].y) * H, (a[1].y - a[1].x) * H};
+        const Cx b6 = cx_mul_mi(a[2]);
+        if constexpr (QE <= 3) {
+            dft4_3(a[0], a[1], a[2], y[0], y[2], y[4], y[6]);
+            dft4_3(a[0], b5, b6, y[1], y[3], y[5], y[7]);
+        } else {
+            const Cx b7 = {(a[3].y - a[3].x) * H, -(a[3].x + a[3].y) * H};
+            dft4(a[0], a[1], a[2], a[3], y[0], y[2], y[4], y[6]);
+            dft4(a[0], b5, b6, b7, y[1], y[3], y[5], y[7]);
+        }
+        const Cx w2 = cx_mul(w1, w1), w3 = cx_mul(w2, w1), w4 = cx_mul(w2, w2);
+        const Cx w5 = cx_mul(w4, w1), w6 = cx_mul(w4, w2), w7 = cx_mul(w4, w3);
+        y[1] = cx_mul(y[1], w1);
+        y[2] = cx_mul(y[2], w2);
+        y[3] = cx_mul(y[3], w3);
+        y[4] = cx_mul(y[4], w4);
+        y[5] = cx_mul(y[5], w5);
+        y[6] = cx_mul(y[6], w6);
+        y[7] = cx_mul(y[7], w7);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = e < QE ? a[e] : Cx{0.0, 0.0};
+        f2_bfly8(y, w1, true);
+    }
+}
+
+// One LDS pass (radix 2^LR at stride 2^LS) over the `len` points from `org` that ONE wave owns; no block barrier. The
+// elements of a butterfly sit at fixed distances in the padded layout (e 2^LS + (e 2^LS >> 5): the butterfly's first
+// point is at a multiple of 32 plus j, and j < 16 when the stride is 16), immediates of the LDS instructions.
+template <int LR>
+__device__ __forceinline__ void f3_bfly(Cx *a, Cx w1)
+{
+    if constexpr (LR == 3) {
+        f2_bfly8(a, w1, true);
+    } else {
+        Cx y0, y1, y2, y3;
+        dft4(a[0], a[1], a[2], a[3], y0, y1, y2, y3);
+        const Cx w2 = cx_mul(w1, w1), w3 = cx_mul(w2, w1);
+        a[0] = y0;
+        a[1] = cx_mul(y1, w1);
+        a[2] = cx_mul(y2, w2);
+        a[3] = cx_mul(y3, w3);
+    }
+}
+
+#ifndef F3_PAIR
+#define F3_PAIR 0  // 1: both butterflies of a lane in flight together where a pass has two. Measured at C4 with the
+                   // prefetch on: 9.24 ms against 7.47 ms for the call — the second butterfly's 32 registers spill,
+                   // and a scratch reload waits for the prefetched samples like any other vector-memory load.
+#endif
+#ifndef F3_PREFETCH
+#define F3_PREFETCH 1  // the next series' samples fetched under the sub-transforms (0: at the top of each series)
+#endif
+template <int LR, int LS>
+__device__ __forceinline__ void f3_wave_pass(double *re, double *im, int org, int len, const double2 *tw, int lane)
+{
+    constexpr int R = 1 << LR, lb = LS + LR, s = 1 << LS;
+    const int nb = len >> LR;
+    const bool swz = LS == 4 && (len >> lb) >= 8;  // stride 16: the halves of a lane group take blocks 4 apart
+    auto first = [&](int b) {
+        const int j = b & (s - 1);
+        int blk = b >> LS;
+        if (swz) blk = (blk & ~5) | ((blk & 1) << 2) | ((blk >> 2) & 1);
+        return f2_skew(org + (blk << lb) + j);
+    };
+#define F3_AT(i0, e) ((i0) + ((e) << LS) + (((e) << LS) >> 5))
+    if (F3_PAIR && nb == 128) {
+        // the second butterfly's reads are in flight under the first one's arithmetic, the first one's writes under
+        // the second one's
+        const int iA = first(lane), iB = first(lane + 64);
+        const double2 wa = tw[lane & (s - 1)], wb = tw[(lane + 64) & (s - 1)];
+        Cx a[R], c[R];
+#pragma unroll
+        for (int e = 0; e < R; ++e) a[e] = {re[F3_AT(iA, e)], im[F3_AT(iA, e)]};
+#pragma unroll
+        for (int e = 0; e < R; ++e) c[e] = {re[F3_AT(iB, e)], im[F3_AT(iB, e)]};
+        f3_bfly<LR>(a, Cx{wa.x, wa.y});
+#pragma unroll
+        for (int e = 0; e < R; ++e) {
+            re[F3_AT(iA, e)] = a[e].x;
+            im[F3_AT(iA, e)] = a[e].y;
+        }
+        f3_bfly<LR>(c, Cx{wb.x, wb.y});
+#pragma unroll
+        for (int e = 0; e < R; ++e) {
+            re[F3_AT(iB, e)] = c[e].x;
+            im[F3_AT(iB, e)] = c[e].y;
+        }
+    } else {
+        for (int b = lane; b < nb; b += 64) {
+            const int i0 = first(b);
+            const double2 wv = tw[b & (s - 1)];
+            Cx a[R];
+#pragma unroll
+            for (int e = 0; e < R; ++e) a[e] = {re[F3_AT(i0, e)], im[F3_AT(i0, e)]};
+            f3_bfly<LR>(a, Cx{wv.x, wv.y});
+#pragma unroll
+            for (int e = 0; e < R; ++e) {
+                re[F3_AT(i0, e)] = a[e].x;
+                im[F3_AT(i0, e)] = a[e].y;
+            }
+        }
+    }
+#undef F3_AT
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// x, Qpart, Ppart as msd_power_lds2_kernel. JJ = first-pass butterflies per lane (N/8 / 512, at least 1), QE = inputs
+// of a first-pass butterfly that can hold data (ceil(ceil(F / 2) / (N/8)) <= 8).
+template <int JJ, int QE>
+__global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
+    const double *__restrict__ x, int F, int m, const FftItem *__restrict__ items,
+    const double2 *__restrict__ tab, double *__restrict__ Qpart, double *__restrict__ Ppart)
+{
+    constexpr int PR = 16;
+    extern __shared__ double ft_lds[];
+    const int N = 1 << m, np = N + (N >> 5) + 2;
+    double *re = ft_lds, *im = ft_lds + np;
+    double2 *tabA = reinterpret_cast<double2 *>(im + np), *tabB = tabA + 128;
+    double *red = reinterpret_cast<double *>(tabB + 128);
+    double2 *twp = reinterpret_cast<double2 *>(red + 32);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid < 256) tabA[tid] = tab[tid];
+    const F2Plan pl = f3_plan(m);
+    const FftItem it = items[blockIdx.x];
+    __syncthreads();
+    {
+        int off = 0;
+        for (int q = 0; q < pl.n_pass; ++q) {
+            const int ls = pl.ls[q], lb = ls + pl.lr[q], s = 1 << ls;
+            for (int j = tid; j < s; j += FT_THREADS) {
+                const Cx w = ft_tw(tabA, tabB, j << (m + 1 - lb));
+                twp[off + j] = make_double2(w.x, w.y);
+            }
+            off += s;
+        }
+    }
+    // first-pass stride = points per wave afterwards; two first-pass butterflies per lane only at N = 8192
+    const int ls0 = JJ == 2 ? 10 : m - 3, s0 = 1 << ls0;
+    // lane < s0 / 16 of wave wv owns the 16 positions of tail block `lane` of its sub-transform
+    const bool owner = lane < (s0 >> 4);
+    const int pidx = owner ? wv * s0 + 16 * lane : 0;
+    const int p0 = f2_skew(pidx);
+    const int kb = f2_freq(pidx, pl);
+    const int pb = f2_skew(f2_pos(((N >> 4) - kb) & ((N >> 4) - 1), pl));
+    const bool kb0 = kb == 0;
+#define F3_PARTNER(t) (pb + (kb0 ? f2_tail_neg(t) : 15 - (t)))
+    double qa[JJ][QE], qb[JJ][QE], sacc[PR], tacc[9];
+#pragma unroll
+    for (int jj = 0; jj < JJ; ++jj)
+#pragma unroll
+        for (int e = 0; e < QE; ++e) qa[jj][e] = qb[jj][e] = 0.0;
+#pragma unroll
+    for (int t = 0; t < PR; ++t) sacc[t] = 0.0;
+#pragma unroll
+    for (int u = 0; u < 9; ++u) tacc[u] = 0.0;
+    const int half = (F + 1) >> 1;  // packed points that hold data
+    double va[JJ][QE], vb[JJ][QE];
+    auto fetch = [&](long long c) {
+        const double *row = x + (size_t)c * F;
+        const bool al16 = (reinterpret_cast<unsigned long long>(row) & 15ull) == 0ull;
+#pragma unroll
+        for (int jj = 0; jj < JJ; ++jj) {
+#pragma unroll
+            for (int e = 0; e < QE; ++e) {
+                const int j = tid + jj * FT_THREADS, n = j + (e << ls0);  // packed point: samples 2 n, 2 n + 1
+                va[jj][e] = vb[jj][e] = 0.0;
+                if (j < s0 && 2 * n + 1 < F) {
+                    if (al16) {
+                        typedef double d2_t __attribute__((ext_vector_type(2)));
+                        const d2_t v = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(row + 2 * n));
+                        va[jj][e] = v[0];
+                        vb[jj][e] = v[1];
+                    } else {
+                        va[jj][e] = row[2 * n];
+                        vb[jj][e] = row[2 * n + 1];
+                    }
+                } else if (j < s0 && 2 * n < F) {
+                    va[jj][e] = row[2 * n];
+                }
+            }
+        }
+    };
+    auto lane_sum = [&]() {
+        double sum = 0.0;
+#pragma unroll
+        for (int jj = 0; jj < JJ; ++jj)
+#pragma unroll
+            for (int e = 0; e < QE; ++e) sum += va[jj][e] + vb[jj][e];
+        return sum;
+    };
+    fetch(it.c_lo);
+    double mean = ft_block_sum(lane_sum(), red) / (double)F;
+    for (long long c = it.c_lo; c < it.c_hi; ++c) {
+        // first pass, from the registers (the previous series' partner reads are behind the barrier that ended it)
+#pragma unroll
+        for (int jj = 0; jj < JJ; ++jj) {
+            const int j = tid + jj * FT_THREADS;
+            if (j < s0) {
+                Cx a[QE], y[8];
+#pragma unroll
+                for (int e = 0; e < QE; ++e) {
+                    const int n = j + (e << ls0);
+                    double da = 0.0, db = 0.0;
+                    if (n < half) {
+                        da = va[jj][e] - mean;
+                        db = 2 * n + 1 < F ? vb[jj][e] - mean : 0.0;
+                    }
+                    qa[jj][e] = __builtin_fma(da, da, qa[jj][e]);
+                    qb[jj][e] = __builtin_fma(db, db, qb[jj][e]);
+                    a[e] = {da, db};
+                }
+                const double2 wv1 = twp[j];
+                f3_head8<QE>(a, Cx{wv1.x, wv1.y}, y);
+                const int i0 = f2_skew(j), st = s0 + (s0 >> 5);  // (s0 is a multiple of 32)
+#pragma unroll
+                for (int d = 0; d < 8; ++d) {
+                    re[i0 + d * st] = y[d].x;
+                    im[i0 + d * st] = y[d].y;
+                }
+            }
+        }
+        const bool more = F3_PREFETCH && c + 1 < it.c_hi;
+        if (more) fetch(c + 1);
+        __syncthreads();
+        // this wave's sub-transform: the remaining LDS passes, then the tail in registers
+        {
+            // the (radix, stride) pairs f3_plan makes, spelled out per m: a plan array indexed at run time would
+            // live in scratch memory, and a scratch load waits for the prefetch above like any other vector load
+            const int org = wv * s0;
+            const double2 *tw1 = twp + s0;
+            if (JJ == 2 || m == 13) {
+                f3_wave_pass<3, 7>(re, im, org, s0, tw1, lane);
+                f3_wave_pass<3, 4>(re, im, org, s0, tw1 + 128, lane);
+            } else if (m == 12) {
+                f3_wave_pass<2, 7>(re, im, org, s0, tw1, lane);
+                f3_wave_pass<3, 4>(re, im, org, s0, tw1 + 128, lane);
+            } else if (m == 11) {
+                f3_wave_pass<2, 6>(re, im, org, s0, tw1, lane);
+                f3_wave_pass<2, 4>(re, im, org, s0, tw1 + 64, lane);
+            } else if (m == 10) {
+                f3_wave_pass<3, 4>(re, im, org, s0, tw1, lane);
+            } else {
+                f3_wave_pass<2, 4>(re, im, org, s0, tw1, lane);
+            }
+        }
+        Cx z[PR];
+        if (owner) {
+#pragma unroll
+            for (int e = 0; e < PR; ++e) z[e] = {re[p0 + e], im[p0 + e]};
+            f2_dft16(z);
+#pragma unroll
+            for (int e = 0; e < PR; ++e) {
+                re[p0 + e] = z[e].x;
+                im[p0 + e] = z[e].y;
+            }
+#pragma unroll
+            for (int t = 0; t < PR; ++t) {
+                sacc[t] = __builtin_fma(z[t].x, z[t].x, sacc[t]);
+                sacc[t] = __builtin_fma(z[t].y, z[t].y, sacc[t]);
+            }
+        }
+        if (more) {  // the next series' block sum rides on the barrier below
+            double v = lane_sum();
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+            if (lane == 0) red[8 + wv] = v;
+        }
+        __syncthreads();
+        if (owner) {
+            // T at 8 of the 16 positions, the partner block's lane has the other 8 (see msd_power_lds2_kernel)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t0 = u < 3 ? u : u + 1;  // lane 0: 0 1 2 4 5 6 7 8
+                const double zx = kb0 ? z[t0].x : z[u].x, zy = kb0 ? z[t0].y : z[u].y;
+                const int pt = pb + (kb0 ? f2_tail_neg(t0) : 15 - u);
+                const double cx = re[pt], cy = im[pt];
+                tacc[u] = __builtin_fma(zx, cy, tacc[u]);
+                tacc[u] = __builtin_fma(zy, cx, tacc[u]);
+            }
+            if (kb0) {
+                const int pt = pb + f2_tail_neg(9);
+                tacc[8] = __builtin_fma(z[9].x, im[pt], tacc[8]);
+                tacc[8] = __builtin_fma(z[9].y, re[pt], tacc[8]);
+            }
+        }
+        if (more) {
+            double sum = 0.0;
+#pragma unroll
+            for (int w = 0; w < FT_THREADS / 64; ++w) sum += red[8 + w];
+            mean = sum / (double)F;
+        }
+        __syncthreads();
+        if (!F3_PREFETCH && c + 1 < it.c_hi) {
+            fetch(c + 1);
+            mean = ft_block_sum(lane_sum(), red) / (double)F;
+        }
+    }
+    double *q = Qpart + (size_t)blockIdx.x * F, *pp = Ppart + (size_t)blockIdx.x * (N + 1);
+#pragma unroll
+    for (int jj = 0; jj < JJ; ++jj) {
+#pragma unroll
+        for (int e = 0; e < QE; ++e) {
+            const int j = tid + jj * FT_THREADS, n = j + (e << ls0);
+            if (j < s0 && 2 * n < F) q[2 * n] = qa[jj][e];
+            if (j < s0 && 2 * n + 1 < F) q[2 * n + 1] = qb[jj][e];
+        }
+    }
+    // frequencies, once per block (the loop ended on a barrier): as msd_power_lds2_kernel
+    if (owner) {
+#pragma unroll
+        for (int t = 0; t < PR; ++t) re[p0 + t] = sacc[t];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) im[p0 + (kb0 ? (u < 3 ? u : u + 1) : u)] = tacc[u];
+        if (kb0) im[p0 + 9] = tacc[8];
+    }
+    __syncthreads();
+    if (owner) {
+#pragma unroll
+        for (int t = 0; t < PR; ++t) {
+            const int k = f2_freq(pidx + t, pl);
+            const bool mine = kb0 ? (t != 3 && t < 10) : t < 8;
+            const double sk = sacc[t], sn = re[F3_PARTNER(t)], tk = im[mine ? p0 + t : F3_PARTNER(t)];
+            const Cx w = ft_tw(tabA, tabB, k);  // (cos, -sin) of 2 pi k / L
+            pp[k] = 0.5 * (sk + sn) + w.y * (0.5 * (sk - sn)) + w.x * tk;
+            if (k == 0) pp[N] = sk - tk;
+        }
+    }
+#undef F3_PARTNER
 }
 
 // out[s][i] = sum over the items of segment s of part[item][i]
@@ -873,7 +1316,9 @@ double finish_on_host(long long F, long long G, long long n_lags, const int64_t 
                 double v = (double)(s1 - 2.0L * s2);
                 if (k == 0) v = 0.0;  // exactly, as the difference form gives
                 out[((size_t)k * G + g) * 4 + a] = cnt > 0.0 ? v / cnt : 0.0;
-                if (k > 0 && v != 0.0) worst = std::max(worst, eps_l * (double)s1 / std::fabs(v));
+                // the transform's rounding error in S2(k) scales with the energy of the WHOLE series at every lag
+                // (2 pre[F] >= S1(k), equal at small lags), not with the few samples S1 still holds at large ones
+                if (k > 0 && v != 0.0) worst = std::max(worst, eps_l * (double)(2.0L * pre[F]) / std::fabs(v));
             }
         }
         for (long long k = 0; k < n_lags; ++k) {
@@ -942,24 +1387,46 @@ int lag_msd_fft_fused(mdhip_ctx *ctx, long long F, long long E, const double *d_
                        0, ctx->stream, d_r, d_x, F, cols, scale);
     MD_HIP(hipGetLastError());
     const int qr = (int)((F + FT_THREADS - 1) / FT_THREADS);
-    if (v2) {
-        const size_t lds2 = f2_lds_bytes(m);
-        const int qr2 = (int)(((F + 1) / 2 + FT_THREADS - 1) / FT_THREADS);  // sample pairs per lane, <= N / 512
-#define MD_F2_LAUNCH(QR2, PR)                                                                                  \
+    // second step of round 3 (first pass from registers, wave-private sub-transforms): lag_fft_kernel >= 2
+    const bool v3 = ctx->opt_lag_fft_kernel >= 2 && m >= F3_MIN_M && f3_lds_bytes(m) <= ctx->lds_max;
+    if (v3) {
+        const size_t lds3 = f3_lds_bytes(m);
+        const long long s0 = N >> 3;
+        const int qe = (int)(((F + 1) / 2 + s0 - 1) / s0);  // <= 8
+#define MD_F3_LAUNCH(JJ, QE)                                                                                   \
     {                                                                                                          \
-        MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msd_power_lds2_kernel<QR2, PR>),             \
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));                    \
-        hipLaunchKernelGGL((msd_power_lds2_kernel<QR2, PR>), dim3((unsigned)n_items), dim3(FT_THREADS), lds2,  \
+        MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msd_power_lds3_kernel<JJ, QE>),              \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));                    \
+        hipLaunchKernelGGL((msd_power_lds3_kernel<JJ, QE>), dim3((unsigned)n_items), dim3(FT_THREADS), lds3,   \
                            ctx->stream, d_x, (int)F, m, d_items, d_tab, d_Qpart, d_Ppart);                     \
     }
-        // PR = N / 512 positions per lane; QR2 <= PR / 2 + 1 pairs hold data (F <= L/2 + ...): instantiate per m
-        switch (m) {  // (second argument: PR = N / 512 positions per lane)
-        case 9: MD_F2_LAUNCH(1, 1) break;
-        case 10: MD_F2_LAUNCH(2, 2) break;
-        case 11: if (qr2 <= 2) MD_F2_LAUNCH(2, 4) else MD_F2_LAUNCH(4, 4) break;
-        case 12: if (qr2 <= 3) MD_F2_LAUNCH(3, 8) else MD_F2_LAUNCH(8, 8) break;
-        default: if (qr2 <= 5) MD_F2_LAUNCH(5, 16) else if (qr2 <= 8) MD_F2_LAUNCH(8, 16) else MD_F2_LAUNCH(16, 16) break;
+        if (s0 > FT_THREADS) {
+            if (qe <= 3) MD_F3_LAUNCH(2, 3)
+            else if (qe <= 4) MD_F3_LAUNCH(2, 4)
+            else MD_F3_LAUNCH(2, 8)
+        } else {
+            if (qe <= 3) MD_F3_LAUNCH(1, 3)
+            else if (qe <= 4) MD_F3_LAUNCH(1, 4)
+            else MD_F3_LAUNCH(1, 8)
         }
+#undef MD_F3_LAUNCH
+    } else if (v2) {
+        const size_t lds2 = f2_lds_bytes(m);
+        const int qr2 = (int)(((F + 1) / 2 + FT_THREADS - 1) / FT_THREADS);  // sample pairs per lane, <= N / 512
+#define MD_F2_LAUNCH(QR2)                                                                                      \
+    {                                                                                                          \
+        MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msd_power_lds2_kernel<QR2>),                 \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));                    \
+        hipLaunchKernelGGL((msd_power_lds2_kernel<QR2>), dim3((unsigned)n_items), dim3(FT_THREADS), lds2,      \
+                           ctx->stream, d_x, (int)F, m, d_items, d_tab, d_Qpart, d_Ppart);                     \
+    }
+        // QR2 = sample pairs per lane: ceil(ceil(F / 2) / 512) <= N / 512 = 16
+        if (qr2 <= 1) MD_F2_LAUNCH(1)
+        else if (qr2 <= 2) MD_F2_LAUNCH(2)
+        else if (qr2 <= 3) MD_F2_LAUNCH(3)
+        else if (qr2 <= 5) MD_F2_LAUNCH(5)
+        else if (qr2 <= 8) MD_F2_LAUNCH(8)
+        else MD_F2_LAUNCH(16)  // (F > N: only with max_lag < F - 1)
 #undef MD_F2_LAUNCH
     } else {
 #define MD_FT_CASE(QR)                                                                                         \

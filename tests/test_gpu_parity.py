@@ -429,6 +429,42 @@ def test_lag_msd_fft_variant(B):
         ctx.set_option("lag_variant", 1)
 
 
+def test_lag_msd_fft_every_transform_size(B):
+    """The fused kernels (lag_fft_kernel 2 = first pass from registers + wave-private sub-transforms where it applies,
+    1 = block-wide passes, 0 = round-2 kernel) over series lengths on both sides of every transform size 2^9 .. 2^13,
+    full and truncated lag ranges (F > N only happens with those), tiny and empty groups: each within the bound the
+    library reports against the difference kernel (hence within twice that of each other)."""
+    ctx = B.default_context()
+    rng = np.random.default_rng(5)
+    cases = [(F, F - 1) for F in (257, 511, 513, 1024, 1025, 2047, 2049, 3000, 4096, 4097, 5000, 8191, 8192)]
+    cases += [(9000, 7000), (12000, 4000), (16000, 300), (6000, 2100), (1000, 20)]
+    try:
+        for F, max_lag in cases:
+            E = int(rng.integers(3, 24))
+            cut = int(rng.integers(0, E + 1))
+            goff = [0, cut, cut, E]
+            r = np.cumsum(rng.normal(0, 0.1, (F, 3, E)), axis=0) + rng.uniform(-500, 500, (1, 3, E))
+            ctx.set_option("lag_variant", 1)
+            exact = B.lag_msd(r, max_lag, goff, scale=0.5)
+            ctx.set_option("lag_variant", 2)
+            nz = exact > 0
+            outs = []
+            for kern in (2, 1, 0):
+                ctx.set_option("lag_fft_kernel", kern)
+                fft = B.lag_msd(r, max_lag, goff, scale=0.5)
+                bound = ctx.last_rel_bound()
+                assert ctx.last_kernel_name() == "msd_power_lds_kernel" and bound > 0.0
+                assert (fft[0] == 0.0).all()
+                rel = np.abs(fft[nz] - exact[nz]) / exact[nz]
+                assert rel.max() <= bound, (F, max_lag, kern, rel.max(), bound)
+                outs.append((fft, bound))
+            for o, b in outs[1:]:
+                assert (np.abs(o[nz] - outs[0][0][nz]) / exact[nz]).max() <= b + outs[0][1], (F, max_lag)
+    finally:
+        ctx.set_option("lag_variant", 1)
+        ctx.set_option("lag_fft_kernel", 2)
+
+
 # ------------------------------------------------------------------ G2-G4
 def test_xcorr_golden(B, g_acf):
     g = g_acf
