@@ -935,9 +935,16 @@ __device__ __forceinline__ void f3_bfly(Cx *a, Cx w1)
 }
 
 #ifndef F3_PAIR
-#define F3_PAIR 0  // 1: both butterflies of a lane in flight together where a pass has two. Measured at C4 with the
-                   // prefetch on: 9.24 ms against 7.47 ms for the call — the second butterfly's 32 registers spill,
-                   // and a scratch reload waits for the prefetched samples like any other vector-memory load.
+#define F3_PAIR 0  // 1: both butterflies of a lane in flight together where a pass has two. Measured at C4: 8.5 ms
+                   // against 7.1 ms for the call (9.2 against 7.5 while the pair still spilled 50 registers: a scratch
+                   // reload waits for the prefetched samples like any other vector-memory load) - eight waves a CU already
+                   // keep the LDS queue full, a second butterfly per wave only lengthens every wave's wait for its data.
+#endif
+#ifndef F3_PRIO
+#define F3_PRIO 0
+#endif
+#ifndef F3_SKIP
+#define F3_SKIP 0  // timing experiments only (wrong results): 2 = no wave passes, 4 = no tail arithmetic, 8 = no partner reads
 #endif
 #ifndef F3_PREFETCH
 #define F3_PREFETCH 1  // the next series' samples fetched under the sub-transforms (0: at the top of each series)
@@ -1012,6 +1019,11 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
     double *red = reinterpret_cast<double *>(tabB + 128);
     double2 *twp = reinterpret_cast<double2 *>(red + 32);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+#if F3_PRIO
+    // one of the two waves of every SIMD issues first whenever both can: its LDS reads are served first, it computes
+    // while the other's are served, and the two stay half a phase apart instead of meeting at every LDS queue
+    if (wv < 4) __builtin_amdgcn_s_setprio(F3_PRIO);
+#endif
     if (tid < 256) tabA[tid] = tab[tid];
     const F2Plan pl = f3_plan(m);
     const FftItem it = items[blockIdx.x];
@@ -1121,7 +1133,11 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
             // live in scratch memory, and a scratch load waits for the prefetch above like any other vector load
             const int org = wv * s0;
             const double2 *tw1 = twp + s0;
+#if F3_SKIP & 2
+            if (F == 1) {
+#else
             if (JJ == 2 || m == 13) {
+#endif
                 f3_wave_pass<3, 7>(re, im, org, s0, tw1, lane);
                 f3_wave_pass<3, 4>(re, im, org, s0, tw1 + 128, lane);
             } else if (m == 12) {
@@ -1140,9 +1156,13 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
         if (owner) {
 #pragma unroll
             for (int e = 0; e < PR; ++e) z[e] = {re[p0 + e], im[p0 + e]};
+#if !(F3_SKIP & 4)
             f2_dft16(z);
+#endif
+            // only positions 8 .. 15 go back to LDS: they are what the partner block's lane reads (its 15 - u,
+            // u < 8); lane 0 of wave 0 pairs inside its own block and takes its partners from the registers
 #pragma unroll
-            for (int e = 0; e < PR; ++e) {
+            for (int e = 8; e < PR; ++e) {
                 re[p0 + e] = z[e].x;
                 im[p0 + e] = z[e].y;
             }
@@ -1152,27 +1172,33 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
                 sacc[t] = __builtin_fma(z[t].y, z[t].y, sacc[t]);
             }
         }
+        if (owner && kb0) {  // (one lane of the block) T for its 9 pairs, all inside its own block
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t0 = u < 3 ? u : u + 1;  // 0 1 2 4 5 6 7 8
+                tacc[u] = __builtin_fma(z[t0].x, z[f2_tail_neg(t0)].y, tacc[u]);
+                tacc[u] = __builtin_fma(z[t0].y, z[f2_tail_neg(t0)].x, tacc[u]);
+            }
+            tacc[8] = __builtin_fma(z[9].x, z[f2_tail_neg(9)].y, tacc[8]);
+            tacc[8] = __builtin_fma(z[9].y, z[f2_tail_neg(9)].x, tacc[8]);
+        }
         if (more) {  // the next series' block sum rides on the barrier below
             double v = lane_sum();
             for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
             if (lane == 0) red[8 + wv] = v;
         }
         __syncthreads();
-        if (owner) {
+#if F3_SKIP & 8
+        if (owner && F == 1) {
+#else
+        if (owner && !kb0) {
+#endif
             // T at 8 of the 16 positions, the partner block's lane has the other 8 (see msd_power_lds2_kernel)
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int t0 = u < 3 ? u : u + 1;  // lane 0: 0 1 2 4 5 6 7 8
-                const double zx = kb0 ? z[t0].x : z[u].x, zy = kb0 ? z[t0].y : z[u].y;
-                const int pt = pb + (kb0 ? f2_tail_neg(t0) : 15 - u);
-                const double cx = re[pt], cy = im[pt];
-                tacc[u] = __builtin_fma(zx, cy, tacc[u]);
-                tacc[u] = __builtin_fma(zy, cx, tacc[u]);
-            }
-            if (kb0) {
-                const int pt = pb + f2_tail_neg(9);
-                tacc[8] = __builtin_fma(z[9].x, im[pt], tacc[8]);
-                tacc[8] = __builtin_fma(z[9].y, re[pt], tacc[8]);
+                const double cx = re[pb + 15 - u], cy = im[pb + 15 - u];
+                tacc[u] = __builtin_fma(z[u].x, cy, tacc[u]);
+                tacc[u] = __builtin_fma(z[u].y, cx, tacc[u]);
             }
         }
         if (more) {
