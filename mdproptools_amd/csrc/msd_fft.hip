@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <utility>
 #include <vector>
 
 #include "ctx.h"
@@ -918,6 +919,62 @@ __device__ __forceinline__ void f3_head8(const Cx *a, Cx w1, Cx *y)
 // One LDS pass (radix 2^LR at stride 2^LS) over the `len` points from `org` that ONE wave owns; no block barrier. The
 // elements of a butterfly sit at fixed distances in the padded layout (e 2^LS + (e 2^LS >> 5): the butterfly's first
 // point is at a multiple of 32 plus j, and j < 16 when the stride is 16), immediates of the LDS instructions.
+// 8-byte LDS reads the compiler cannot pair: `ds_read2_b64` moves 16 bytes per lane in 8 LDS cycles, two `ds_read_b64`
+// the same bytes in 4 (MI355X_MICROARCH.md, LDS table), and the backend pairs every two reads whose offsets allow it —
+// all of the stride-16 pass, the tail and the partner reads. Hand-issued instead: f3_rd<byte offset>(LDS byte address),
+// then ONE f3_wait_*() through which every loaded value passes (the dependency keeps their uses behind the wait; the
+// compiler's own lgkmcnt bookkeeping does not know these reads, which only makes its waits stricter than needed).
+// F3_NO_READ2 = 0 builds the plain C++ reads for A/B.
+#ifndef F3_NO_READ2
+#define F3_NO_READ2 1
+#endif
+__device__ __forceinline__ unsigned f3_lds_addr(const double *p) { return (unsigned)reinterpret_cast<size_t>(p); }
+
+template <int OFF>
+__device__ __forceinline__ double f3_rd(unsigned a)
+{
+    double v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF) : "memory");
+    return v;
+}
+
+__device__ __forceinline__ void f3_wait_4(Cx *a)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0].x), "+v"(a[0].y), "+v"(a[1].x), "+v"(a[1].y), "+v"(a[2].x), "+v"(a[2].y), "+v"(a[3].x),
+                   "+v"(a[3].y)::"memory");
+}
+
+__device__ __forceinline__ void f3_pass_8(Cx *a)  // (no instruction: the values of a[0 .. 7] pass through)
+{
+    asm volatile(""
+                 : "+v"(a[0].x), "+v"(a[0].y), "+v"(a[1].x), "+v"(a[1].y), "+v"(a[2].x), "+v"(a[2].y), "+v"(a[3].x),
+                   "+v"(a[3].y), "+v"(a[4].x), "+v"(a[4].y), "+v"(a[5].x), "+v"(a[5].y), "+v"(a[6].x), "+v"(a[6].y),
+                   "+v"(a[7].x), "+v"(a[7].y)::"memory");
+}
+
+__device__ __forceinline__ void f3_wait_8(Cx *a)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0].x), "+v"(a[0].y), "+v"(a[1].x), "+v"(a[1].y), "+v"(a[2].x), "+v"(a[2].y), "+v"(a[3].x),
+                   "+v"(a[3].y), "+v"(a[4].x), "+v"(a[4].y), "+v"(a[5].x), "+v"(a[5].y), "+v"(a[6].x), "+v"(a[6].y),
+                   "+v"(a[7].x), "+v"(a[7].y)::"memory");
+}
+
+// a[e] = point (first + e 2^LS) of a butterfly: ar / ai = LDS byte addresses of its first point in the two planes
+template <int LS, int... E>
+__device__ __forceinline__ void f3_rd_bfly(Cx *a, unsigned ar, unsigned ai, std::integer_sequence<int, E...>)
+{
+    ((a[E].x = f3_rd<8 * ((E << LS) + ((E << LS) >> 5))>(ar), a[E].y = f3_rd<8 * ((E << LS) + ((E << LS) >> 5))>(ai)), ...);
+}
+
+// a[e] = the 8-byte words at word offsets D0 + S e from ar / ai (S may be negative)
+template <int D0, int S, int... E>
+__device__ __forceinline__ void f3_rd_run(Cx *a, unsigned ar, unsigned ai, std::integer_sequence<int, E...>)
+{
+    ((a[E].x = f3_rd<8 * (D0 + S * E)>(ar), a[E].y = f3_rd<8 * (D0 + S * E)>(ai)), ...);
+}
+
 template <int LR>
 __device__ __forceinline__ void f3_bfly(Cx *a, Cx w1)
 {
@@ -989,8 +1046,14 @@ __device__ __forceinline__ void f3_wave_pass(double *re, double *im, int org, in
             const int i0 = first(b);
             const double2 wv = tw[b & (s - 1)];
             Cx a[R];
+#if F3_NO_READ2
+            f3_rd_bfly<LS>(a, f3_lds_addr(re + i0), f3_lds_addr(im + i0), std::make_integer_sequence<int, R>{});
+            if constexpr (LR == 3) f3_wait_8(a);
+            else f3_wait_4(a);
+#else
 #pragma unroll
             for (int e = 0; e < R; ++e) a[e] = {re[F3_AT(i0, e)], im[F3_AT(i0, e)]};
+#endif
             f3_bfly<LR>(a, Cx{wv.x, wv.y});
 #pragma unroll
             for (int e = 0; e < R; ++e) {
@@ -1154,8 +1217,14 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
         }
         Cx z[PR];
         if (owner) {
+#if F3_NO_READ2
+            f3_rd_run<0, 1>(z, f3_lds_addr(re + p0), f3_lds_addr(im + p0), std::make_integer_sequence<int, PR>{});
+            f3_wait_8(z);
+            f3_pass_8(z + 8);
+#else
 #pragma unroll
             for (int e = 0; e < PR; ++e) z[e] = {re[p0 + e], im[p0 + e]};
+#endif
 #if !(F3_SKIP & 4)
             f2_dft16(z);
 #endif
@@ -1194,11 +1263,18 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
         if (owner && !kb0) {
 #endif
             // T at 8 of the 16 positions, the partner block's lane has the other 8 (see msd_power_lds2_kernel)
+            Cx pz[8];  // pz[u] = the partner block's position 15 - u
+#if F3_NO_READ2
+            f3_rd_run<15, -1>(pz, f3_lds_addr(re + pb), f3_lds_addr(im + pb), std::make_integer_sequence<int, 8>{});
+            f3_wait_8(pz);
+#else
+#pragma unroll
+            for (int u = 0; u < 8; ++u) pz[u] = {re[pb + 15 - u], im[pb + 15 - u]};
+#endif
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const double cx = re[pb + 15 - u], cy = im[pb + 15 - u];
-                tacc[u] = __builtin_fma(z[u].x, cy, tacc[u]);
-                tacc[u] = __builtin_fma(z[u].y, cx, tacc[u]);
+                tacc[u] = __builtin_fma(z[u].x, pz[u].y, tacc[u]);
+                tacc[u] = __builtin_fma(z[u].y, pz[u].x, tacc[u]);
             }
         }
         if (more) {
