@@ -169,40 +169,64 @@ def pmc_traffic(workload):
     return None if e is None else e["per_call"].get("hbm_bytes")
 
 
+LDS_WRITE_PEAK = 45e12  # ds_write_b32 ... b128 aggregate: 38-51 TB/s in the same table (a store's cycles are set by
+                        # the transfer of its address + data registers to the LDS, ~85 B/clk/CU for ds_write_b64)
+
+
+def _lag_fft_lds_sweeps(m):
+    """(reads, writes) of the N = 2^m packed points per series, in sweeps of N points, of the kernel
+    mdhip_lag_msd picks for that size (csrc/msd_fft.hip: f3_plan / f2_plan and the kernels under them)."""
+    if m >= 12:    # msd_power_lds3_kernel: first pass from registers (writes only), wave-private passes, tail reads all /
+        rest = m - 7              # writes back the half its partner reads, partner reads half
+        n_pass = 1 + (2 if rest in (4, 5, 6) else 1)
+        return (n_pass - 1) + 1.0 + 0.5, 1.0 + (n_pass - 1) + 0.5
+    if m >= 9:     # msd_power_lds2_kernel: load store, block-wide passes, tail, partner reads
+        n_pass = (1 if (m - 4) % 3 else 0) + (m - 4) // 3
+        return n_pass + 1.0 + 0.5, 1.0 + n_pass + 1.0
+    passes = m // 3 + (1 if m % 3 else 0)   # round-2 kernel: load, in-place passes, real-spectrum pass
+    return passes + 2.0, 1.0 + passes
+
+
 def lds_roofline_lag_fft(E, F, kernel_s):
     """
-    Roofline of the default full-lag MSD path (msd_power_lds_kernel, csrc/msd_fft.hip): every series is transformed inside
-    LDS and only sums leave the CU, so the call is bound by the LDS, not by HBM (compulsory 24 E F bytes = 5 % of the HBM
-    rate) and not by FP64 issue. achieved = ALGORITHMIC bytes through LDS per call / kernel time: per series of padded
-    length L (N = L/2 packed complex points of 16 bytes) the load writes N points, each of the ceil(log2(N) / 3) in-place
-    radix-8 passes (+ the radix-2/4 tail) reads and writes N points, the real-spectrum pass reads 2 N points
-    -> 16 N (3 + 2 passes) bytes, twiddle tables not counted. peak = the guide's ds_read_b64 aggregate, 150 TB/s
-    (stores run at a third of that, so the mix's own ceiling is lower: frac is a lower bound on how busy the LDS is;
-    the counters' view — LDS-array busy share and the bank-conflict share of it — rides along from the PMC run).
+    Roofline of the default full-lag MSD path (csrc/msd_fft.hip): every series is transformed inside LDS and only sums
+    leave the CU, so the call is bound by the LDS, not by HBM (compulsory 24 E F bytes = 5 % of the HBM rate) and not by
+    FP64 issue. achieved = ALGORITHMIC bytes through LDS per call / kernel time of the WHOLE call (transpose included):
+    per series of padded length L (N = L/2 packed complex points of 16 bytes) the sweeps _lag_fft_lds_sweeps counts,
+    twiddle tables not counted. peak = the guide's ds_read_b64 aggregate, 150 TB/s; stores run at 38-51 TB/s, so the
+    mix's own ceiling (`mix_ceiling`: bytes / (reads / 150 + writes / 45 TB/s)) is what the kernel can approach, and
+    `frac_of_mix_ceiling` the honest fraction. The counters' view — LDS-array busy share and the bank-conflict share of
+    it, for the power kernel alone — rides along from the PMC run.
     """
     L = 1
     while L < 2 * F - 1:
         L *= 2
     N = L // 2
     m = N.bit_length() - 1
-    passes = m // 3 + (1 if m % 3 else 0)
-    lds_bytes = 3.0 * E * 16.0 * N * (3 + 2 * passes)
+    rd, wr = _lag_fft_lds_sweeps(m)
+    rd_b, wr_b = 3.0 * E * 16.0 * N * rd, 3.0 * E * 16.0 * N * wr
+    lds_bytes = rd_b + wr_b
+    ceiling = lds_bytes / (rd_b / LDS_READ_PEAK + wr_b / LDS_WRITE_PEAK)
     e, why = secondary_pmc("lag_fft")
-    out = {"bound": "lds", "kernel": "msd_power_lds_kernel", "achieved": lds_bytes / kernel_s / 1e12,
+    out = {"bound": "lds", "kernel": "msd_power_lds3_kernel" if m >= 12 else "msd_power_lds2_kernel" if m >= 9
+           else "msd_power_lds_kernel", "achieved": lds_bytes / kernel_s / 1e12,
            "peak": LDS_READ_PEAK / 1e12, "unit": "TB/s", "frac": lds_bytes / kernel_s / LDS_READ_PEAK,
-           "algorithmic_lds_bytes": lds_bytes, "padded_length": L, "in_place_passes": passes,
+           "mix_ceiling": ceiling / 1e12, "frac_of_mix_ceiling": lds_bytes / kernel_s / ceiling,
+           "algorithmic_lds_bytes": lds_bytes, "read_sweeps": rd, "write_sweeps": wr, "padded_length": L,
            "hbm": {"algorithmic_bytes": 24.0 * E * F, "achieved": 24.0 * E * F / kernel_s / 1e9, "unit": "GB/s",
                    "frac": 24.0 * E * F / kernel_s / HBM_PEAK},
            "traffic": None if e is None else e["per_call"].get("hbm_bytes")}
     if e is None:
         out["note"] = why
         return out
-    k = next((v for name, v in e["kernels"].items() if name.startswith("msd_power_lds_kernel")), None)
+    k = next((v for name, v in e["kernels"].items() if name.startswith("msd_power_lds")), None)
     if k and "SQ_LDS_IDX_ACTIVE" in k and "GRBM_GUI_ACTIVE" in k:
         # SQ_LDS_IDX_ACTIVE: LDS-array cycles summed over the CUs; GRBM_GUI_ACTIVE: chip cycles summed over the 8 XCDs
         cu_cycles = k["GRBM_GUI_ACTIVE"] / 8.0 * 256.0
         out["lds_array_busy"] = k["SQ_LDS_IDX_ACTIVE"] / cu_cycles
         out["bank_conflict_share_of_lds_cycles"] = k.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(k["SQ_LDS_IDX_ACTIVE"], 1.0)
+        if "avg_us" in k:
+            out["power_kernel_s_in_pmc_run"] = k["avg_us"] * 1e-6
         out["counters_source"] = "profiles/pmc_secondary.json (%s/lag_fft)" % e.get("tag", "")
     return out
 
