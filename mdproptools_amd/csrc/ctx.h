@@ -112,6 +112,8 @@ struct mdhip_ctx {
     int opt_fft_logr = 8;     // fft_pow2.hip: largest radix of a pass (log2, 4..10)
     int opt_fft_logc = 3;     // fft_pow2.hip: columns per tile (log2); 8 columns = 128-byte runs measured best (tools/ab_fft.py)
     int opt_seg_gy = 0;       // segment kernels: frame slices per block run (0 = auto)
+    int opt_seg_frame = 1;    // mdhip_segment_com: one (run, frame) per block, nothing carried between frames (A/B: 0 =
+                              // the software-pipelined staged kernel)
     int opt_xcorr_tile = 0;
     int opt_lag_variant = 3;  // full-lag MSD: 3 (default) = autocorrelation theorem (msd_fft.hip) when its error bound
                               // stays below 1e-10, else the exact-difference kernel; 1 = series-resident LDS

@@ -162,6 +162,118 @@ __global__ __launch_bounds__(NT) void segment_staged_kernel(
     for (long long step = 0; step < steps; ++step) process(step);
 }
 
+// One (run of segments, frame, plane group) per block and nothing carried between frames (round 3; option seg_frame):
+// the run's table entry holds its atom range, the per-segment mass sums come from the host's index-order sums
+// (mdhip_segment_com computes them anyway), the masses are re-read per block (L2 hits: 8 B per atom against 24 B of
+// coordinates from HBM). No software pipeline, no register double buffer: the loads of many small blocks overlap
+// instead, as in msd_pairs_kernel. Same products, same additions in the same order, one division.
+struct SegRun {
+    long long s0, s1, a0;
+    int na, pad_;
+};
+
+// (88 / 100 VGPRs: 5 / 4 blocks per CU where LDS would hold 6; forcing 80 registers spills 3 / 11 of them and measured
+// 5 % / 20 % slower.)
+template <bool FLUX, int SC_CAP>
+__global__ __launch_bounds__(256) void segment_frame_kernel(
+    const double *__restrict__ attr, const double *__restrict__ mass, const double *__restrict__ seg_msum,
+    const double *__restrict__ seg_qsi, const long long *__restrict__ seg_off, const SegRun *__restrict__ runs,
+    double *__restrict__ out, int n_attr, long long n_atoms, long long n_seg, long long n_steps, double vel_conv)
+{
+    constexpr int NT = 256, SC_STRIDE = sc_stride(SC_CAP), PER = SC_CAP / NT;
+    __shared__ double s_v[SC_PLANES * SC_STRIDE];
+    const int tid = threadIdx.x;
+    const SegRun b = runs[blockIdx.x];
+    const int na = b.na, nseg = (int)(b.s1 - b.s0);
+    const int groups = (n_attr + SC_PLANES - 1) / SC_PLANES;
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    const bool vec2 = ((n_atoms | b.a0) & 1LL) == 0 &&
+                      ((reinterpret_cast<unsigned long long>(attr) | reinterpret_cast<unsigned long long>(mass)) & 15ULL) == 0;
+    for (long long step = blockIdx.y; step < n_steps; step += gridDim.y) {
+        const long long f = step / groups;
+        const int k0 = (int)(step % groups) * SC_PLANES;
+        const int nk = n_attr - k0 < SC_PLANES ? n_attr - k0 : SC_PLANES;
+        const double *p = attr + ((size_t)f * n_attr + k0) * n_atoms + b.a0;
+        double v[SC_PLANES][PER], mm[PER];
+#pragma unroll
+        for (int r = 0; r < PER / 2; ++r) {
+            const int i = 2 * tid + r * (2 * NT);
+#pragma unroll
+            for (int kk = 0; kk < SC_PLANES; ++kk) {
+                v[kk][2 * r] = v[kk][2 * r + 1] = 0.0;
+                if (kk < nk) {
+                    if (vec2 && i + 1 < na) {
+                        const d2_t t2 = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(p + (size_t)kk * n_atoms + i));
+                        v[kk][2 * r] = t2[0];
+                        v[kk][2 * r + 1] = t2[1];
+                    } else {
+                        if (i < na) v[kk][2 * r] = p[(size_t)kk * n_atoms + i];
+                        if (i + 1 < na) v[kk][2 * r + 1] = p[(size_t)kk * n_atoms + i + 1];
+                    }
+                }
+            }
+            mm[2 * r] = mm[2 * r + 1] = 0.0;
+            if (vec2 && i + 1 < na) {
+                const d2_t t2 = *reinterpret_cast<const d2_t *>(mass + b.a0 + i);
+                mm[2 * r] = t2[0];
+                mm[2 * r + 1] = t2[1];
+            } else {
+                if (i < na) mm[2 * r] = mass[b.a0 + i];
+                if (i + 1 < na) mm[2 * r + 1] = mass[b.a0 + i + 1];
+            }
+        }
+        // the (segment, plane) sum tasks of this lane, plane-major over the lanes as in segment_staged_kernel
+        int t_lo[SC_PLANES], t_hi[SC_PLANES], t_kk[SC_PLANES], t_seg[SC_PLANES];
+        double t_msum[SC_PLANES], t_qsi[SC_PLANES];
+#pragma unroll
+        for (int j = 0; j < SC_PLANES; ++j) {
+            const int t = tid + j * NT;
+            const int kk = t / nseg, sg = t - kk * nseg;
+            t_kk[j] = kk < nk ? kk : -1;
+            t_seg[j] = sg;
+            t_lo[j] = t_hi[j] = 0;
+            t_msum[j] = 1.0;
+            t_qsi[j] = 0.0;
+            if (t_kk[j] >= 0) {
+                t_lo[j] = (int)(seg_off[b.s0 + sg] - b.a0);
+                t_hi[j] = (int)(seg_off[b.s0 + sg + 1] - b.a0);
+                t_msum[j] = seg_msum[b.s0 + sg];
+                if (FLUX) t_qsi[j] = seg_qsi[b.s0 + sg];
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < SC_PLANES; ++kk)
+#pragma unroll
+            for (int r = 0; r < PER; ++r) {
+                const int i = 2 * tid + (r >> 1) * (2 * NT) + (r & 1);
+                if (i < na) s_v[kk * SC_STRIDE + sc_pad(i)] = v[kk][r] * mm[r];
+            }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < SC_PLANES; ++j) {
+            const int kk = t_kk[j];
+            if (kk >= 0) {
+                const double *row = s_v + kk * SC_STRIDE;
+                double acc = 0.0;
+                int a = t_lo[j];
+                for (; a + 4 <= t_hi[j]; a += 4) {
+                    const double x0 = row[sc_pad(a)], x1 = row[sc_pad(a + 1)], x2 = row[sc_pad(a + 2)],
+                                 x3 = row[sc_pad(a + 3)];
+                    acc += x0;
+                    acc += x1;
+                    acc += x2;
+                    acc += x3;
+                }
+                for (; a < t_hi[j]; ++a) acc += row[sc_pad(a)];
+                double r = acc / t_msum[j];
+                if (FLUX) r = (r * vel_conv) * t_qsi[j];
+                out[((size_t)f * n_attr + k0 + kk) * n_seg + b.s0 + t_seg[j]] = r;
+            }
+        }
+        if (step + gridDim.y < n_steps) __syncthreads();  // (only when the grid could not hold every step)
+    }
+}
+
 // Runs of whole segments with <= SC_CAP atoms and <= 256 segments each; false when a segment is longer.
 bool build_seg_blocks(int64_t n_seg, const int64_t *seg_off, std::vector<SegBlock> &blocks, int SC_CAP = SC_CAP_MAX,
                       int max_segs = 256)
@@ -271,12 +383,14 @@ int mdhip_segment_com(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, int n_a
     int rc = check_segments(ctx, n_atoms, n_seg, seg_off);
     if (rc) return rc;
     // sums that do not depend on the frame are done on the host, in index order
+    std::vector<double> msum_h((size_t)n_seg);
     for (int64_t s = 0; s < n_seg; ++s) {
         double m = 0.0, q = 0.0;
         for (int64_t a = seg_off[s]; a < seg_off[s + 1]; ++a) {
             m += atom_mass[a];
             if (atom_q) q += atom_q[a];
         }
+        msum_h[s] = m;
         if (seg_mass) seg_mass[s] = m;
         if (seg_q && atom_q) seg_q[s] = q;
     }
@@ -308,14 +422,38 @@ int mdhip_segment_com(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, int n_a
         staged = build_seg_blocks(n_seg, seg_off, blocks, cap, 256);
     }
     SegBlock *d_blocks = nullptr;
-    if (staged) {
+    const bool by_frame = staged && ctx->opt_seg_frame != 0 && cap == SC_CAP_MAX;
+    std::vector<SegRun> runs;
+    SegRun *d_runs = nullptr;
+    double *d_msum = nullptr;
+    if (by_frame) {
+        runs.resize(blocks.size());
+        for (size_t i = 0; i < blocks.size(); ++i)
+            runs[i] = {blocks[i].s0, blocks[i].s1, (long long)seg_off[blocks[i].s0],
+                       (int)(seg_off[blocks[i].s1] - seg_off[blocks[i].s0]), 0};
+        const size_t rb = runs.size() * sizeof(SegRun);
+        unsigned char *d_tab = (unsigned char *)mdhip_ws(ctx, WS_AUX3, rb + (size_t)n_seg * 8);
+        if (!d_tab) return MDHIP_ENOMEM;
+        d_runs = reinterpret_cast<SegRun *>(d_tab);
+        d_msum = reinterpret_cast<double *>(d_tab + rb);
+        MD_HIP(hipMemcpyAsync(d_runs, runs.data(), rb, hipMemcpyHostToDevice, ctx->stream));
+        MD_HIP(hipMemcpyAsync(d_msum, msum_h.data(), (size_t)n_seg * 8, hipMemcpyHostToDevice, ctx->stream));
+        MD_HIP(hipStreamSynchronize(ctx->stream));  // the tables are locals
+    } else if (staged) {
         d_blocks = (SegBlock *)mdhip_ws(ctx, WS_AUX3, blocks.size() * sizeof(SegBlock));
         if (!d_blocks) return MDHIP_ENOMEM;
         MD_HIP(hipMemcpyAsync(d_blocks, blocks.data(), blocks.size() * sizeof(SegBlock), hipMemcpyHostToDevice,
                               ctx->stream));
     }
     KernelTimer timer(ctx);
-    if (staged) {
+    if (by_frame) {
+        const long long n_steps = (long long)n_frames * ((n_attr + SC_PLANES - 1) / SC_PLANES);
+        const unsigned gy = (unsigned)std::min<long long>(n_steps, 65535);
+        ctx->last_kernel = "segment_frame_kernel<false, 1024>";
+        hipLaunchKernelGGL((segment_frame_kernel<false, 1024>), dim3((unsigned)runs.size(), gy), dim3(256), 0,
+                           ctx->stream, d_attr, d_mass, d_msum, (const double *)nullptr, d_off, d_runs, d_out, n_attr,
+                           (long long)n_atoms, (long long)n_seg, n_steps, 1.0);
+    } else if (staged) {
         // enough (block, frame slice) pairs to fill the chip several times over; a block loops over its frames
         // frame slices: at least enough (block, slice) pairs to fill the chip several times over, and short runs of
         // ~10 frames per block (measured at C4 shape: 82 slices 0.57 of HBM spec, 512 slices 0.63, 1250 slices 0.60)
@@ -403,13 +541,45 @@ static int charge_flux_impl(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, c
     }
     SegBlock *d_blocks = nullptr;
     if (staged) {
-        d_blocks = (SegBlock *)mdhip_ws(ctx, WS_PART, blocks.size() * sizeof(SegBlock));
+        d_blocks = (SegBlock *)mdhip_ws(ctx, WS_PART, blocks.size() * sizeof(SegBlock) +
+                                                          (ctx->opt_seg_frame ? blocks.size() * sizeof(SegRun) + (size_t)n_seg * 16 : 0));
         if (!d_blocks) return MDHIP_ENOMEM;
         MD_HIP(hipMemcpyAsync(d_blocks, blocks.data(), blocks.size() * sizeof(SegBlock), hipMemcpyHostToDevice,
                               ctx->stream));
     }
+    const bool by_frame = staged && ctx->opt_seg_frame != 0 && cap == SC_CAP_MAX;
+    SegRun *d_runs = nullptr;
+    double *d_msq = nullptr;  // per segment: mass sum, then (charge sum) x charge_conv — the host's index-order sums
+    if (by_frame) {
+        std::vector<SegRun> runs(blocks.size());
+        for (size_t i = 0; i < blocks.size(); ++i)
+            runs[i] = {blocks[i].s0, blocks[i].s1, (long long)seg_off[blocks[i].s0],
+                       (int)(seg_off[blocks[i].s1] - seg_off[blocks[i].s0]), 0};
+        std::vector<double> msq((size_t)n_seg * 2);
+        for (int64_t sg = 0; sg < n_seg; ++sg) {
+            double m = 0.0, q = 0.0;
+            for (int64_t a = seg_off[sg]; a < seg_off[sg + 1]; ++a) {
+                m += atom_mass[a];
+                q += atom_q[a];
+            }
+            msq[sg] = m;
+            msq[n_seg + sg] = q * charge_conv;  // _conductivity.py:25
+        }
+        d_runs = reinterpret_cast<SegRun *>(d_blocks + blocks.size());
+        d_msq = reinterpret_cast<double *>(d_runs + runs.size());
+        MD_HIP(hipMemcpyAsync(d_runs, runs.data(), runs.size() * sizeof(SegRun), hipMemcpyHostToDevice, ctx->stream));
+        MD_HIP(hipMemcpyAsync(d_msq, msq.data(), msq.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        MD_HIP(hipStreamSynchronize(ctx->stream));  // the tables are locals
+    }
     KernelTimer timer(ctx);
-    if (staged) {
+    if (by_frame) {
+        const long long n_steps = (long long)n_frames;
+        const unsigned gy = (unsigned)std::min<long long>(n_steps, 65535);
+        ctx->last_kernel = "segment_frame_kernel<true, 1024>";
+        hipLaunchKernelGGL((segment_frame_kernel<true, 1024>), dim3((unsigned)blocks.size(), gy), dim3(256), 0,
+                           ctx->stream, d_vel, d_mq, d_msq, d_msq + n_seg, d_off, d_runs, d_tmp, 3, (long long)n_atoms,
+                           (long long)n_seg, n_steps, vel_conv);
+    } else if (staged) {
         int64_t want = ((int64_t)ctx->cu_count * 16 + (int64_t)blocks.size() - 1) / (int64_t)blocks.size();
         want = std::max<int64_t>(want, n_frames / 10);
         const unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_frames, std::min<int64_t>(want, 65535)));

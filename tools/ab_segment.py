@@ -21,7 +21,10 @@ mass = np.where(np.arange(E) < 40_000, 2.0, 3.0)
 M = len(off) - 1
 out = torch.empty((F, 3, M), dtype=torch.float64, device="cuda")
 byt = (24.0 * E + 24.0 * M) * F
-for cap, vec, gy in ((0, 1, 0), (256, 1, 0), (512, 1, 0), (0, 0, 0), (0, 1, 128), (0, 1, 1250)):
+ref = None
+for frame, cap, vec, gy in ((1, 0, 1, 0), (0, 0, 1, 0), (1, 0, 1, 0), (0, 256, 1, 0), (0, 512, 1, 0), (0, 0, 0, 0), (0, 0, 1, 128),
+                            (0, 0, 1, 1250)):
+    ctx.set_option("seg_frame", frame)
     ctx.set_option("seg_cap", cap)
     ctx.set_option("seg_vec", vec)
     ctx.set_option("seg_gy", gy)
@@ -30,5 +33,8 @@ for cap, vec, gy in ((0, 1, 0), (256, 1, 0), (512, 1, 0), (0, 0, 0), (0, 1, 128)
         B.segment_com(r, mass, off, out=out, ctx=ctx)
         ms.append(ctx.last_kernel_ms()[0])
     ms = np.array(ms[2:])
-    print("cap %4d vec %d gy %3d  min %.4f ms  median %.4f ms  -> %.0f GB/s (%.3f of 8 TB/s)" % (
-        cap, vec, gy, ms.min(), np.median(ms), byt / np.median(ms) / 1e6, byt / np.median(ms) / 1e-3 / 8e12))
+    if ref is None:
+        ref = out.clone()
+    assert torch.equal(out, ref), "results differ"
+    print("%-40s frame %d cap %4d vec %d gy %3d  min %.4f ms  median %.4f ms  -> %.0f GB/s (%.3f of 8 TB/s)" % (
+        ctx.last_kernel_name(), frame, cap, vec, gy, ms.min(), np.median(ms), byt / np.median(ms) / 1e6, byt / np.median(ms) / 1e-3 / 8e12))
