@@ -755,7 +755,7 @@ def msd_sharded(torch, dist, D, B, ctx, device, synth, rank, world, backend, ste
     fence()
     elapsed = time.perf_counter() - t0
     parts = [t_part["single"], t_part["fixed"], t_part["lag"], elapsed]
-    if world > 1:  # max over ranks, of the step and of its three parts
+    if dist.is_initialized():  # max over ranks, of the step and of its three parts
         tmax = torch.tensor(parts, dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         parts = [float(v) for v in tmax.tolist()]
@@ -786,8 +786,8 @@ def msd_sharded(torch, dist, D, B, ctx, device, synth, rank, world, backend, ste
                                "lag x origin average" % world,
                    "frames_per_gpu": hi - lo, "entities_per_gpu": e_hi - e_lo,
                    "frame_pairs_per_step": fp_single + fp_fixed + fp_lag},
-        "collectives": {"backend": dist.get_backend() if world > 1 else None,
-                        "world_size": dist.get_world_size() if world > 1 else 1,
+        "collectives": {"backend": dist.get_backend() if dist.is_initialized() else None,
+                        "world_size": dist.get_world_size() if dist.is_initialized() else 1,
                         "per_step": "broadcast 24 E B; all_gather [F_local,1,4] f64; all_gather 1 frame per rank; "
                                     "all_reduce [E,4] f64; all_reduce [F,1,4] f64 — all on device buffers"},
         # the HBM-bound kernel of the step, this rank's launch: 24 E bytes per frame pair
@@ -846,8 +846,11 @@ def main():
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
+    # MDHIP_BENCH_FORCE_DIST=1: a process group even for ONE rank, so that a 1-GPU box runs every collective of the
+    # N > 1 path through RCCL itself (tests/test_gpu_fullsize.py; two ranks cannot share a GPU under RCCL)
+    if world > 1 or os.environ.get("MDHIP_BENCH_FORCE_DIST") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
@@ -867,7 +870,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -882,7 +885,7 @@ def main():
             out["roofline"] = m.pop("roofline")
             out["msd"] = m
             print(json.dumps(out))
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -950,7 +953,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     kernel_name = ctx.last_kernel_name()
-    if world > 1:
+    if dist.is_initialized():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -993,7 +996,7 @@ def main():
         }
         out["roofline"]["prepass_ms_per_step"] = aux_ms / args.steps
         out["lib_build_id"] = lib_build_id(ctx)
-        if world > 1:
+        if dist.is_initialized():
             out["config"]["collectives"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size()}
         if msd_obj is not None:
             out["msd"] = msd_obj
@@ -1042,7 +1045,7 @@ def main():
         if "c5" in legs:
             run_leg("c5", lambda: leg_c5(B, ctx, torch, device, synth, sync))
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

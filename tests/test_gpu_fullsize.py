@@ -281,6 +281,27 @@ def test_bench_c4_workload_two_ranks():
     assert line["lib_build_id"]["match"] is True
 
 
+def test_bench_through_rccl_with_one_rank():
+    """Both bench workloads with a ONE-rank RCCL process group (MDHIP_BENCH_FORCE_DIST=1): every collective of the
+    N > 1 path — histogram all-reduce on the device buffer, origin broadcast, row all-gathers, halo all-gather, the
+    entity-sharded all-reduce, the max-over-ranks timing — goes through RCCL itself on device tensors (two ranks
+    cannot share one GPU under RCCL; the two-rank tests above use gloo)."""
+    env = dict(os.environ, MDHIP_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MDHIP_DIST_BACKEND"):
+        env.pop(k, None)
+    for port, extra in ((29541, ["--workload", "c4"]), (29542, ["--legs", "parity", "--no-cpu-baseline", "--msd-steps", "1"])):
+        env["MASTER_PORT"] = str(port)
+        r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "2", "--warmup", "1"] + extra,
+                           env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        coll = line["config"]["collectives"]
+        assert coll["backend"] == "nccl" and coll["world_size"] == 1 and line["n_gpus"] == 1
+        assert line["msd"]["value"] > 1e8 and line["value"] > 1e8
+        if "--workload" not in extra:
+            assert line["metric"] == "atom-pairs/s" and line["parity_checked"] is True
+
+
 # ------------------------------------------------------------------ compute-bound paths sharded over two ranks
 def _sharded_worker(rank, world, port, out_dir):
     sys.path.insert(0, REPO)
