@@ -1436,6 +1436,7 @@ double finish_on_host(long long F, long long G, long long n_lags, const int64_t 
             const size_t s = (size_t)a * G + g;
             pre[0] = 0.0L;
             for (long long t = 0; t < F; ++t) pre[t + 1] = pre[t] + (long double)Q[s * F + t];
+            double v_min = 0.0;  // smallest non-zero |S1 - 2 S2| over the lags k > 0
             for (long long k = 0; k < n_lags; ++k) {
                 const long double s1 = pre[F - k] + (pre[F] - pre[k]);
                 const long double s2 = (long double)corr[s * corr_row + k] * (long double)corr_scale;
@@ -1443,10 +1444,13 @@ double finish_on_host(long long F, long long G, long long n_lags, const int64_t 
                 double v = (double)(s1 - 2.0L * s2);
                 if (k == 0) v = 0.0;  // exactly, as the difference form gives
                 out[((size_t)k * G + g) * 4 + a] = cnt > 0.0 ? v / cnt : 0.0;
-                // the transform's rounding error in S2(k) scales with the energy of the WHOLE series at every lag
-                // (2 pre[F] >= S1(k), equal at small lags), not with the few samples S1 still holds at large ones
-                if (k > 0 && v != 0.0) worst = std::max(worst, eps_l * (double)(2.0L * pre[F]) / std::fabs(v));
+                const double av = std::fabs(v);
+                if (k > 0 && av != 0.0 && (v_min == 0.0 || av < v_min)) v_min = av;
             }
+            // the transform's rounding error in S2(k) scales with the energy of the WHOLE series at every lag
+            // (2 pre[F] >= S1(k), equal at small lags), not with the few samples S1 still holds at large ones:
+            // the worst relative error is at the lag with the smallest |v|
+            if (v_min > 0.0) worst = std::max(worst, eps_l * (double)(2.0L * pre[F]) / v_min);
         }
         for (long long k = 0; k < n_lags; ++k) {
             double *o = out + ((size_t)k * G + g) * 4;

@@ -3,7 +3,7 @@
 // Replaces scipy's cumulative trapezoid as called at dynamical/viscosity.py:151 and
 // dynamical/conductivity.py:231 of the reference: inc[m] = dx*(y[m]+y[m+1])/2, I[k] = sum_{m<k} inc[m].
 // HBM-bound (16 bytes per sample). Three-phase scan: per-block inclusive scan of 2048 increments
-// (8 per lane sequentially, then a wave/LDS scan of the lane totals), an ordered scan of the block
+// (8 per lane sequentially, then a wave-shuffle scan of the lane totals), a scan of the block
 // totals, then the offsets are added. The summation order differs from scipy's sequential cumsum,
 // so agreement is to rounding (tests: rtol 1e-9 with an absolute floor of 1e-12*max|I|).
 #include <algorithm>
@@ -18,61 +18,97 @@ constexpr int SC_THREADS = 256;
 constexpr int SC_PER = 8;
 constexpr int SC_BLOCK = SC_THREADS * SC_PER;
 
-__device__ __forceinline__ double trap_inc(const double *__restrict__ y, long long m, double dx)
-{
-    return dx * (y[m + 1] + y[m]) / 2.0;  // scipy: d * (y[1:] + y[:-1]) / 2.0
-}
+// LDS index of sample / result i of a block: one pad double per 8, so that a lane walking ITS 8 consecutive entries
+// (stride 9 between lanes) and the block walking consecutive entries (coalesced global side) both spread over the banks
+__device__ __forceinline__ int sc_pad(int i) { return i + (i >> 3); }
 
 // n_inc = n-1 increments per series. out_series points at the first integral value (after the
 // optional leading zero). block_tot [n_series][n_blocks].
+// Round 3: the samples of a block come in through coalesced loads into LDS (the lane that owns increments 8 t .. 8 t + 7
+// used to read its 9 samples straight from global memory: 64-byte strides between lanes, eight partial sweeps of the
+// same lines), the lane totals are scanned with wave shuffles (six steps, no barrier) and the four wave totals in
+// order, and the results leave through LDS again, coalesced: three barriers per block instead of seventeen.
 __global__ __launch_bounds__(SC_THREADS) void trap_scan_local_kernel(
     const double *__restrict__ y, double *__restrict__ out, double *__restrict__ block_tot,
     long long n, long long out_stride, int lead, double dx, int n_blocks)
 {
-    __shared__ double s_tot[SC_THREADS];
-    const int series = blockIdx.y;
+    __shared__ double s_v[SC_BLOCK + SC_BLOCK / 8 + 2];
+    __shared__ double s_w[SC_THREADS / 64];
+    const int series = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const double *ys = y + (size_t)series * n;
     double *os = out + (size_t)series * out_stride + lead;
     const long long n_inc = n - 1;
-    const long long base = (long long)blockIdx.x * SC_BLOCK + (long long)threadIdx.x * SC_PER;
+    const long long blk0 = (long long)blockIdx.x * SC_BLOCK;
+    // samples blk0 .. blk0 + 2048 (one more than increments)
+#pragma unroll
+    for (int u = 0; u < SC_PER; ++u) {
+        const int i = u * SC_THREADS + tid;
+        s_v[sc_pad(i)] = blk0 + i < n ? ys[blk0 + i] : 0.0;
+    }
+    if (tid == 0) s_v[sc_pad(SC_BLOCK)] = blk0 + SC_BLOCK < n ? ys[blk0 + SC_BLOCK] : 0.0;
+    __syncthreads();
     double v[SC_PER];
     double run = 0.0;
+    {
+        const int i0 = tid * SC_PER;
+        double y0 = s_v[sc_pad(i0)];
 #pragma unroll
-    for (int u = 0; u < SC_PER; ++u) {
-        const long long m = base + u;
-        const double inc = m < n_inc ? trap_inc(ys, m, dx) : 0.0;
-        run += inc;
-        v[u] = run;
+        for (int u = 0; u < SC_PER; ++u) {
+            const double y1 = s_v[sc_pad(i0 + u + 1)];
+            const double inc = blk0 + i0 + u < n_inc ? dx * (y1 + y0) / 2.0 : 0.0;  // scipy: d * (y[1:] + y[:-1]) / 2.0
+            run += inc;
+            v[u] = run;
+            y0 = y1;
+        }
     }
-    s_tot[threadIdx.x] = run;
+    // inclusive scan of the lane totals inside the wave, then the wave totals in order
+    double incl = run;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double up = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += up;
+    }
+    if (lane == 63) s_w[wv] = incl;
+    __syncthreads();  // (also: every lane has read its samples, s_v can take the results)
+    double before = incl - run;
+    for (int w = 0; w < wv; ++w) before += s_w[w];
+#pragma unroll
+    for (int u = 0; u < SC_PER; ++u) s_v[sc_pad(tid * SC_PER + u)] = before + v[u];
+    if (tid == SC_THREADS - 1) block_tot[(size_t)series * n_blocks + blockIdx.x] = before + run;
     __syncthreads();
-    // Hillis-Steele inclusive scan of the 256 lane totals
-    for (int d = 1; d < SC_THREADS; d <<= 1) {
-        const double add = (int)threadIdx.x >= d ? s_tot[threadIdx.x - d] : 0.0;
-        __syncthreads();
-        s_tot[threadIdx.x] += add;
-        __syncthreads();
-    }
-    const double before = threadIdx.x ? s_tot[threadIdx.x - 1] : 0.0;
 #pragma unroll
     for (int u = 0; u < SC_PER; ++u) {
-        const long long m = base + u;
-        if (m < n_inc) os[m] = before + v[u];
+        const int i = u * SC_THREADS + tid;
+        if (blk0 + i < n_inc) os[blk0 + i] = s_v[sc_pad(i)];
     }
-    if (threadIdx.x == SC_THREADS - 1) block_tot[(size_t)series * n_blocks + blockIdx.x] = s_tot[SC_THREADS - 1];
 }
 
-// exclusive scan of the block totals, one lane per series (n_blocks is small: n/2048)
-__global__ void trap_scan_blocks_kernel(double *__restrict__ block_tot, int n_blocks, int n_series)
+// exclusive scan of the block totals of one series per block: every lane takes a contiguous share in order, the 256
+// share totals are scanned (wave shuffles, then the four wave totals in order). (Round 2: ONE lane per series walked
+// the totals through dependent global loads: 64 us for 489 blocks.)
+__global__ __launch_bounds__(SC_THREADS) void trap_scan_blocks_kernel(double *__restrict__ block_tot, int n_blocks)
 {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_series) return;
+    __shared__ double s_w[SC_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double *p = block_tot + (size_t)blockIdx.x * n_blocks;
+    const int share = (n_blocks + SC_THREADS - 1) / SC_THREADS;
+    const int lo = min(tid * share, n_blocks), hi = min(lo + share, n_blocks);
     double run = 0.0;
-    double *p = block_tot + (size_t)s * n_blocks;
-    for (int b = 0; b < n_blocks; ++b) {
+    for (int b = lo; b < hi; ++b) run += p[b];
+    double incl = run;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double up = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += up;
+    }
+    if (lane == 63) s_w[wv] = incl;
+    __syncthreads();
+    double acc = incl - run;
+    for (int w = 0; w < wv; ++w) acc += s_w[w];
+    for (int b = lo; b < hi; ++b) {
         const double t = p[b];
-        p[b] = run;
-        run += t;
+        p[b] = acc;
+        acc += t;
     }
 }
 
@@ -128,8 +164,8 @@ int mdhip_cumtrapz(mdhip_ctx *ctx, int64_t n, int n_series, const double *y, int
     hipLaunchKernelGGL(trap_scan_local_kernel, dim3((unsigned)n_blocks, (unsigned)n_series),
                        dim3(SC_THREADS), 0, ctx->stream, d_y, d_out, d_tot, (long long)n,
                        (long long)out_stride, lead, dx, n_blocks);
-    hipLaunchKernelGGL(trap_scan_blocks_kernel, dim3((unsigned)((n_series + 63) / 64)), dim3(64), 0,
-                       ctx->stream, d_tot, n_blocks, n_series);
+    hipLaunchKernelGGL(trap_scan_blocks_kernel, dim3((unsigned)n_series), dim3(SC_THREADS), 0, ctx->stream, d_tot,
+                       n_blocks);
     hipLaunchKernelGGL(trap_scan_add_kernel, dim3((unsigned)n_blocks, (unsigned)n_series),
                        dim3(SC_THREADS), 0, ctx->stream, d_out, d_tot, (long long)n,
                        (long long)out_stride, lead, n_blocks);
