@@ -279,6 +279,13 @@ constexpr int PK_QSTRIDE = 320;  // words per wave
 constexpr int PK_THREADS = 512;  // threads per block of the MODE 3 kernel (8 independent waves, one LDS histogram)
 constexpr int PK_WAVES_PER_SIMD = 6;  // HIP's second launch bound: the register budget (<= 80 VGPRs) for 3 such blocks per CU
 
+#ifndef PK_INLINE_PUSH
+#define PK_INLINE_PUSH 0  // 1 = queue pushes inside the hand-written pair block (bin_pair2q, A/B builds). Measured build
+                          // against build (tools/ab_libs.py, integers identical): push in line behind a taken branch
+                          // C2 +1.1 %, C3 +2.3 %; push out of line (no taken branch on the common path, 0.5 scalar
+                          // issues fewer per slot, no spills) C2 +0.5 %, C3 +1.5 %, CN -1 % — fewer instructions, not
+                          // less time: the masks-out form stays
+#endif
 struct PkCtx {
     f32x2 x2, y2, z2;     // this lane's i atom (its image nearest to the j block's centre) relative to that centre,
                           // both halves equal
@@ -496,6 +503,74 @@ __device__ __forceinline__ bool bin_pair2(float rsq0, float rsq1, float rc2hi, f
 #undef BP_OUT
 #undef BP_IN
 }
+// bin_pair2 with the queue push of the ambiguous lanes INSIDE the block (round 3; the plain variant without the CN flag
+// check): `s_andn2 amb = c & ~d` leaves SCC = (amb != 0), so the block branches on it where it stands instead of handing
+// the masks out for an s_or + s_cmp + s_cbranch per two slots and a compare + branch per slot behind those; the rare
+// path is pk_push's own seven instructions + the tag ((jbase + 4 g + KOFF + slot) << 6, from scalars that are live
+// anyway) + the count. Per slot on the common path: execz branch, andn2, scc branch, exec restore = 4 scalar issues
+// (4.5 before), and the C++ around the block has no control flow left for the compiler to structurize.
+// The push sits OUT OF LINE (subsection 1 of the kernel's text section, behind the function): on the common path both
+// branches of a slot fall through — a taken branch costs several issue cycles, and the first form of this block, with
+// the push in line behind an `s_cbranch_scc0` that was taken on every unambiguous slot, measured 1-2 % SLOWER than
+// the masks-out form it replaced. L = the slot's skip / return label, R = the label of its out-of-line push.
+#define BQ_PUSH(K, L, R)                                               \
+    "s_andn2_b64 %[c" K "], %[c" K "], %[d" K "]\n\t"                  \
+    "s_cbranch_scc1 " R "f\n\t"                                        \
+    L ":\n\t"                                                         \
+    "s_mov_b64 exec, %[full]\n\t"                                      \
+    ".subsection 1\n\t"                                                \
+    R ":\n\t"                                                         \
+    "s_mov_b64 exec, %[c" K "]\n\t"                                    \
+    "v_mbcnt_lo_u32_b32 %[fr], exec_lo, 0\n\t"                         \
+    "v_mbcnt_hi_u32_b32 %[fr], exec_hi, %[fr]\n\t"                     \
+    "s_lshl2_add_u32 %[st], %[qn], %[qaddr]\n\t"                       \
+    "v_lshl_add_u32 %[t" K "], %[fr], 2, %[st]\n\t"                    \
+    "s_lshl2_add_u32 %[st], %[g], %[jbase]\n\t"                        \
+    "s_add_i32 %[st], %[st], %[ko" K "]\n\t"                           \
+    "s_lshl_b32 %[st], %[st], 6\n\t"                                   \
+    "v_or_b32 %[fr], %[st], %[lane]\n\t"                               \
+    "ds_write_b32 %[t" K "], %[fr]\n\t"                                \
+    "s_bcnt1_i32_b64 %[st], exec\n\t"                                  \
+    "s_add_i32 %[qn], %[qn], %[st]\n\t"                                \
+    "s_branch " L "b\n\t"                                              \
+    ".subsection 0\n\t"
+template <bool CUTG, int KOFF>
+__device__ __forceinline__ void bin_pair2q(float rsq0, float rsq1, float rc2hi, float gscale, float nearoff0, float nearoff1,
+                                           float near2, unsigned rowbase0, unsigned rowbase1, float cut_lo,
+                                           unsigned long long full, int &qn, unsigned qaddr, int jbase, int g, int lane)
+{
+    unsigned long long c0, c1, d0, d1;
+    float t0, t1, fr;
+    unsigned st;
+    // (the count travels through the block as a tied scalar operand; the readfirstlane tells the compiler's
+    // uniformity analysis what it cannot see through an asm with vector outputs — it folds to nothing)
+    int qn_io = __builtin_amdgcn_readfirstlane(qn);
+#define BQ_OUT                                                                                                         \
+    [c0] "=&s"(c0), [c1] "=&s"(c1), [d0] "=&s"(d0), [d1] "=&s"(d1), [t0] "=&v"(t0), [t1] "=&v"(t1), [fr] "=&v"(fr),    \
+        [st] "=&s"(st), [qn] "+s"(qn_io)
+#define BQ_IN                                                                                                          \
+    [rc2] "s"(rc2hi), [rsq0] "v"(rsq0), [rsq1] "v"(rsq1), [gs] "v"(gscale), [no0] "s"(nearoff0), [no1] "s"(nearoff1),   \
+        [n2] "v"(near2), [rb0] "v"(rowbase0), [rb1] "v"(rowbase1), [one] "v"(1u), [full] "s"(full), [qaddr] "s"(qaddr), \
+        [jbase] "s"(jbase), [g] "s"(g), [lane] "v"(lane), [ko0] "n"(KOFF), [ko1] "n"(KOFF + 1)
+    // (a slot with no lane inside the cutoff jumps over its bin guess AND its push: labels 1 / 2)
+    if (CUTG) {
+        asm volatile(BP_SLOT("0", "1") BP_SLOT_CUT("0") BP_SLOT_MID("0") BQ_PUSH("0", "1", "3")
+                     BP_SLOT("1", "2") BP_SLOT_CUT("1") BP_SLOT_MID("1") BQ_PUSH("1", "2", "4")
+                     : BQ_OUT
+                     : BQ_IN, [cl] "v"(cut_lo)
+                     : "vcc", "scc", "memory");
+    } else {
+        asm volatile(BP_SLOT("0", "1") BP_SLOT_MID("0") BQ_PUSH("0", "1", "3")
+                     BP_SLOT("1", "2") BP_SLOT_MID("1") BQ_PUSH("1", "2", "4")
+                     : BQ_OUT
+                     : BQ_IN
+                     : "vcc", "scc", "memory");
+    }
+    qn = qn_io;
+#undef BQ_OUT
+#undef BQ_IN
+}
+#undef BQ_PUSH
 #undef BP_SLOT
 #undef BP_SLOT_CUT
 #undef BP_SLOT_MID
@@ -600,6 +675,15 @@ __device__ __forceinline__ void sweep_group_pk(const RelQ &rq, GroupIdx jidx0, i
             // group costs 4 VGPRs, which the 80-register budget pays for with spills: measured slower.)
             kaddr0 = ROWS ? p.cn_kc_me[__float_as_uint(rb[2])] : p.cn_kc_me[(int)(nearoff0 * p.inv_row_len)];
             kaddr1 = ROWS ? p.cn_kc_me[__float_as_uint(rb[3])] : p.cn_kc_me[(int)(nearoff1 * p.inv_row_len)];
+        }
+        if constexpr (!CNG && PK_INLINE_PUSH) {
+            if (h == 0)
+                bin_pair2q<CUTG, 0>(r2a, r2b, p.rc2hi, c.gscale, nearoff0, nearoff1, c.near2, rowbase0, rowbase1, p.cut_lo,
+                                    p.full, p.qn, p.qaddr, jidx0.jbase, jidx0.g, lane);
+            else
+                bin_pair2q<CUTG, 2>(r2a, r2b, p.rc2hi, c.gscale, nearoff0, nearoff1, c.near2, rowbase0, rowbase1, p.cut_lo,
+                                    p.full, p.qn, p.qaddr, jidx0.jbase, jidx0.g, lane);
+            continue;
         }
         PairOut o;
         const bool any_amb = bin_pair2<CUTG, CNG>(r2a, r2b, p.rc2hi, c.gscale, nearoff0, nearoff1, c.near2, rowbase0,
