@@ -147,18 +147,22 @@ __global__ __launch_bounds__(256) void cull_scan_kernel(unsigned *__restrict__ c
 // grid origin, keys, cell populations, scan and scatter with the 32768 cell counters in LDS — no global
 // atomics (device-scope atomics on counters spread over HBM cost several times what the arithmetic costs).
 constexpr int SORT_THREADS = 1024;
+// LDS word of cell k: one pad word per 32 cells. The scan hands every lane a run of 32 consecutive cells; without the pad
+// all 64 lanes of a wave walk the same bank (32-way conflicts on both scan loops).
+__device__ __forceinline__ unsigned sort_cell(unsigned k) { return k + (k >> 5); }
+constexpr size_t SORT_CELL_WORDS = MORTON_CELLS + MORTON_CELLS / 32;
 __global__ __launch_bounds__(SORT_THREADS) void cull_sort_lds_kernel(
     const double *__restrict__ xyz, const int *__restrict__ type, long long type_fs,
     const double *__restrict__ box, long long n, unsigned short *__restrict__ keys, double *__restrict__ sxyz,
     int *__restrict__ stype, double4 *__restrict__ aos, long long n_pad, int n_ti, float near, int row_len)
 {
-    extern __shared__ unsigned s_cells[];  // [MORTON_CELLS] + 3 x 16 doubles of scratch behind it
-    double *s_red = reinterpret_cast<double *>(s_cells + MORTON_CELLS);
-    __shared__ unsigned s_part[SORT_THREADS];
-    const int f = blockIdx.x, tid = threadIdx.x;
+    extern __shared__ unsigned s_cells[];  // [SORT_CELL_WORDS] + 3 x 16 doubles of scratch behind it
+    double *s_red = reinterpret_cast<double *>(s_cells + SORT_CELL_WORDS);
+    __shared__ unsigned s_part[SORT_THREADS / 64];
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const double *x = xyz + (size_t)f * 3 * n;
     const double L[3] = {box[3 * f], box[3 * f + 1], box[3 * f + 2]};
-    for (int k = tid; k < MORTON_CELLS; k += SORT_THREADS) s_cells[k] = 0u;
+    for (int k = tid; k < (int)SORT_CELL_WORDS; k += SORT_THREADS) s_cells[k] = 0u;
     // ---- origin = exact minimum of every axis ----
     double lo[3] = {1e300, 1e300, 1e300};
     for (long long i = tid; i < n; i += SORT_THREADS)
@@ -190,23 +194,26 @@ __global__ __launch_bounds__(SORT_THREADS) void cull_sort_lds_kernel(
         }
         const unsigned key = hilbert3(c[0], c[1], c[2]);
         kf[i] = (unsigned short)key;
-        atomicAdd(&s_cells[key], 1u);
+        atomicAdd(&s_cells[sort_cell(key)], 1u);
     }
     __syncthreads();
-    // ---- exclusive scan of the populations ----
+    // ---- exclusive scan of the populations: 32 consecutive cells per lane (stride 33 words between lanes), the lane
+    // totals through wave shuffles, the 16 wave totals in order (round 3: two barriers instead of twenty-one) ----
     constexpr int PER = MORTON_CELLS / SORT_THREADS;
-    const int base = tid * PER;
+    static_assert(PER == 32, "one pad word per lane run");
+    const int base = tid * (PER + 1);
     unsigned sum = 0;
     for (int k = 0; k < PER; ++k) sum += s_cells[base + k];
-    s_part[tid] = sum;
-    __syncthreads();
-    for (int d = 1; d < SORT_THREADS; d <<= 1) {
-        const unsigned add = tid >= d ? s_part[tid - d] : 0u;
-        __syncthreads();
-        s_part[tid] += add;
-        __syncthreads();
+    unsigned incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned up = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += up;
     }
-    unsigned run = tid ? s_part[tid - 1] : 0u;
+    if (lane == 63) s_part[wv] = incl;
+    __syncthreads();
+    unsigned run = incl - sum;
+    for (int w = 0; w < wv; ++w) run += s_part[w];
     for (int k = 0; k < PER; ++k) {
         const unsigned v = s_cells[base + k];
         s_cells[base + k] = run;
@@ -215,7 +222,7 @@ __global__ __launch_bounds__(SORT_THREADS) void cull_sort_lds_kernel(
     __syncthreads();
     // ---- scatter ----
     for (long long i = tid; i < n; i += SORT_THREADS) {
-        const unsigned pos = atomicAdd(&s_cells[kf[i]], 1u);
+        const unsigned pos = atomicAdd(&s_cells[sort_cell(kf[i])], 1u);
         const double px = x[i], py = x[n + i], pz = x[2 * n + i];
         const int t = type[(size_t)f * type_fs + i];
         if (sxyz) {
@@ -446,7 +453,7 @@ int cull_prepare_set(mdhip_ctx *ctx, int64_t F, const double *d_x, const int *d_
     const dim3 ga((unsigned)((N + 255) / 256), (unsigned)F);
     // one block per frame with the cell counters in LDS when there are frames enough to fill the chip (or the
     // frames are small); the multi-block path with global counters otherwise
-    const size_t sort_lds = (size_t)MORTON_CELLS * 4 + 3 * 16 * 8;
+    const size_t sort_lds = SORT_CELL_WORDS * 4 + 3 * 16 * 8;
     const bool lds_sort = ctx->opt_rdf_sort != 0 && sort_lds + 8192 <= ctx->lds_max && N <= 262144 &&
                           (ctx->opt_rdf_sort == 1 || F >= ctx->cu_count / 4 || N <= 16384);
     if (lds_sort) {

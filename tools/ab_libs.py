@@ -35,7 +35,7 @@ box = np.full((F, 3), L)
 ref = None
 for rnd in range(3):
     for p, ctx in zip(libs, ctxs):
-        ms = []
+        ms, aux = [], []
         for _ in range(8):
             if op == "rdf":
                 out = B.rdf_loop(xyz, ty, box, rel, 20.0, 0.05, 400, per_frame=False, ctx=ctx)
@@ -45,9 +45,10 @@ for rnd in range(3):
                 o = B.rdf_cn_loop(xyz, ty, box, rel, 20.0, 0.05, 400, synth.cn_cutoffs(len(rel)), per_frame=False, ctx=ctx)
                 out = (o[0], o[3])
             ms.append(ctx.last_kernel_ms()[0])
+            aux.append(ctx.last_aux_ms())
         if ref is None:
             ref = out
         same = np.array_equal(out[0], ref[0]) and np.array_equal(out[1], ref[1])
         assert same or os.environ.get("AB_ALLOW_DIFFERENT"), "results differ"
         ms = np.array(ms[2:])
-        print("%s %s %-28s min %.4f ms  median %.4f ms%s" % (which, op, os.path.basename(p), ms.min(), np.median(ms), "" if same else "  DIFFERENT RESULTS (timing experiment)"))
+        print("%s %s %-28s min %.4f ms  median %.4f ms  pre-pass %.4f ms%s" % (which, op, os.path.basename(p), ms.min(), np.median(ms), float(np.median(aux[2:])), "" if same else "  DIFFERENT RESULTS (timing experiment)"))
