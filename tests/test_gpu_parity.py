@@ -329,6 +329,41 @@ def test_segment_com_ragged_and_long_segments(B):
         np.testing.assert_allclose(j, jw, rtol=1e-9, atol=1e-25)
 
 
+def test_segment_kernels_agree_for_any_plane_count(B):
+    """The one-(run, frame)-per-block kernel (seg_frame 1, default) and the software-pipelined staged kernel (0) do the
+    same products and additions in the same order: bit-identical centres and fluxes, for 1 .. 7 attribute planes (plane
+    groups of three, the last one partial), odd and even atom counts (the 16-byte load path needs even ones), many
+    frames (more steps than one grid row holds is not reachable here; the loop is covered by the frame count)."""
+    ctx = B.default_context()
+    rng = np.random.default_rng(19)
+    try:
+        for sizes in (rng.integers(1, 30, 400), np.full(257, 4), np.concatenate([np.full(130, 16), [3]])):
+            off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+            n, M = int(off[-1]), len(sizes)
+            mass = rng.uniform(1, 40, n)
+            q = rng.normal(0, 1, n)
+            st = (np.arange(M) * 2 // M).astype(np.int32)
+            for K in (1, 2, 3, 4, 7):
+                attr = rng.normal(0, 30, (9, K, n))
+                got = {}
+                for mode in (1, 0):
+                    ctx.set_option("seg_frame", mode)
+                    com, _, _ = B.segment_com(attr, mass, off)
+                    assert ctx.last_kernel_name().startswith("segment_frame_kernel" if mode else "segment_staged_kernel")
+                    got[mode] = com
+                np.testing.assert_array_equal(got[1], got[0])
+                want = np.add.reduceat(attr * mass, off[:-1], axis=2) / np.add.reduceat(mass, off[:-1])
+                np.testing.assert_allclose(got[1], want, rtol=1e-13, atol=1e-13)
+            vel = rng.normal(0, 5, (9, 3, n))
+            flux = {}
+            for mode in (1, 0):
+                ctx.set_option("seg_frame", mode)
+                flux[mode] = B.charge_flux(vel, mass, q, off, st, 2, 1e5, 1.6e-19)
+            np.testing.assert_array_equal(flux[1], flux[0])
+    finally:
+        ctx.set_option("seg_frame", 1)
+
+
 def test_com_msd_and_charge_flux_golden(B, g_small):
     g = g_small
     cols, fr, pick = _small(g)
