@@ -577,6 +577,9 @@ def charge_flux_sharded(vel_local, n_frames_total, atom_mass, atom_q, seg_off, s
     return np.moveaxis(allgather_rows(rows, n_frames_total), 0, 2)
 
 
+_LAG_CONST = {}  # lag_msd_sharded: device-resident weights per (device, shapes)
+
+
 def lag_msd_sharded(r_local, entity_range, max_lag, group_off, scale=1.0, compute=None, ctx=None):
     """
     Full lag x origin MSD (mdhip_lag_msd; the compute-bound superset of diffusion.py:225-238) with the ENTITIES
@@ -617,12 +620,22 @@ def lag_msd_sharded(r_local, entity_range, max_lag, group_off, scale=1.0, comput
             x = r_local[:, :, int(loc_off[0]):int(loc_off[-1])].contiguous()
             means = torch.empty((n_lags, len(held), 4), dtype=torch.float64, device=r_local.device)
             backend.lag_msd(x, int(max_lag), loc_off - loc_off[0], scale=scale, ctx=ctx, out=means)
-            w = torch.from_numpy(origins * (hi[held] - lo[held]).astype(np.float64)[None, :]).to(r_local.device)
-            sums[:, torch.as_tensor(held, device=r_local.device), :] = means * w[:, :, None]
-        sums = allreduce_tensor(sums)
-        cnt = torch.from_numpy(counts).to(r_local.device)[:, :, None]
-        out = torch.where(cnt > 0, sums / torch.clamp(cnt, min=1.0), torch.zeros_like(sums))
-        return out.cpu().numpy()
+            # (the weights and the index of the held groups depend on the shapes only: kept on the device between calls)
+            key = (str(r_local.device), F, n_lags, tuple(int(v) for v in (hi[held] - lo[held])), tuple(held))
+            cached = _LAG_CONST.get(key)
+            if cached is None:
+                w = torch.from_numpy(origins * (hi[held] - lo[held]).astype(np.float64)[None, :]).to(r_local.device)
+                cached = (w[:, :, None].contiguous(), torch.as_tensor(held, device=r_local.device))
+                if len(_LAG_CONST) > 8:
+                    _LAG_CONST.clear()
+                _LAG_CONST[key] = cached
+            if len(held) == G:
+                sums = means * cached[0]
+            else:
+                sums[:, cached[1], :] = means * cached[0]
+        sums = allreduce_tensor(sums).cpu().numpy()
+        with np.errstate(invalid="ignore", divide="ignore"):
+            return np.where(counts[:, :, None] > 0, sums / np.maximum(counts, 1.0)[:, :, None], 0.0)
     sums = np.zeros((n_lags, G, 4))
     if held and F > 0:
         # the held groups are contiguous in the slice (groups are contiguous globally)
