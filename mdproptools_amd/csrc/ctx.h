@@ -109,7 +109,9 @@ struct mdhip_ctx {
                               // per launch (0 = the real bound, 2^32 / (64 * 256) with margin; tests lower it)
     int opt_seg_cap = 0;      // segment kernels: atoms per block stage, 1024 (default), 512, or 256 = one wave per block (A/B)
     int opt_seg_vec = 1;      // segment kernels: 16-byte loads when alignment allows (default), 0 = 8-byte loads (A/B)
-    int opt_fft_logr = 8;     // fft_pow2.hip: largest radix of a pass (log2, 4..10)
+    int opt_fft_logr = 10;    // fft_pow2.hip: largest radix of a pass (log2, 4..10); passes of radix >= 2^9 run the radix-8
+                              // network (fft_pass8_kernel), so that 2^20 points take two passes (round 2: 8 = three passes)
+    int opt_fft_net8 = 1;     // 0: radix-4 network for every radix (A/B)
     int opt_fft_logc = 3;     // fft_pow2.hip: columns per tile (log2); 8 columns = 128-byte runs measured best (tools/ab_fft.py)
     int opt_seg_gy = 0;       // segment kernels: frame slices per block run (0 = auto)
     int opt_seg_frame = 1;    // mdhip_segment_com: one (run, frame) per block, nothing carried between frames (A/B: 0 =

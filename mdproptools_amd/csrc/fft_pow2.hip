@@ -195,6 +195,257 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass_kernel(const double2 *__
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Round 3: the same pass with a radix-8 network, for the large radices (R = 2^9 .. 2^11) that let a transform of 2^20
+// points run in TWO passes instead of three (C5: 144 MB per series through HBM instead of 208). The radix-4 network above
+// needs log2(R)/2 LDS round trips with a block barrier each and 256 lanes — at R = 1024 five of them over an 8192-point
+// tile, which is why two passes measured slower than three. Here a lane does a whole radix-8 butterfly in
+// registers per round (the butterflies of msd_fft.hip's in-LDS transform), R·C/8 lanes per workgroup, the last round is a
+// 16-, 8- or 4-point transform without twiddles: 1024 = 8 x 8 x 16 in three rounds. Rows sit C points apart with C
+// points of padding per final sub-transform, so that the last round — a lane walks 16 consecutive rows — spreads over
+// the banks. Decimation in frequency, output row of frequency j by digit reversal (net8_row).
+constexpr int NET8_MIN_LOGR = 9;  // passes of radix >= 2^9 take the radix-8 network (fft_net8 = 0: the radix-4 one, A/B)
+struct Net8Plan {
+    int n8;  // rounds of radix 8 (with twiddles)
+    int lf;  // log2 of the last round's transform (1 .. 4), without twiddles
+};
+
+__host__ __device__ inline Net8Plan net8_plan(int logR)
+{
+    Net8Plan p{0, logR};
+    while (p.lf > 4) {
+        ++p.n8;
+        p.lf -= 3;
+    }
+    return p;
+}
+
+__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ double2 cmul_mi(double2 a) { return make_double2(a.y, -a.x); }  // a * (-i)
+
+__device__ __forceinline__ void net_dft4(double2 c0, double2 c1, double2 c2, double2 c3, double2 &z0, double2 &z1,
+                                         double2 &z2, double2 &z3)
+{
+    const double2 d0 = cadd(c0, c2), d1 = csub(c0, c2), d2 = cadd(c1, c3), d3 = cmul_mi(csub(c1, c3));
+    z0 = cadd(d0, d2);
+    z2 = csub(d0, d2);
+    z1 = cadd(d1, d3);
+    z3 = csub(d1, d3);
+}
+
+// 8-point DFT of a[0..7] (elements i + e·stride of a sub-transform), output digit d left in a[d]
+__device__ __forceinline__ void net_dft8(double2 *a)
+{
+    constexpr double H = 0.70710678118654752440;
+    const double2 b0 = cadd(a[0], a[4]), b4 = csub(a[0], a[4]);
+    const double2 b1 = cadd(a[1], a[5]), t5 = csub(a[1], a[5]);
+    const double2 b2 = cadd(a[2], a[6]), t6 = csub(a[2], a[6]);
+    const double2 b3 = cadd(a[3], a[7]), t7 = csub(a[3], a[7]);
+    const double2 b5 = make_double2((t5.x + t5.y) * H, (t5.y - t5.x) * H);
+    const double2 b6 = cmul_mi(t6);
+    const double2 b7 = make_double2((t7.y - t7.x) * H, -(t7.x + t7.y) * H);
+    net_dft4(b0, b1, b2, b3, a[0], a[2], a[4], a[6]);
+    net_dft4(b4, b5, b6, b7, a[1], a[3], a[5], a[7]);
+}
+
+// 16-point DFT, two radix-4 stages; frequency f0 + 4 f1 ends up in x[4 f0 + f1]
+__device__ __forceinline__ void net_dft16(double2 *x)
+{
+    constexpr double C1 = 0.92387953251128675613, S1 = 0.38268343236508977173, H = 0.70710678118654752440;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        double2 y0, y1, y2, y3;
+        net_dft4(x[e], x[e + 4], x[e + 8], x[e + 12], y0, y1, y2, y3);
+        if (e == 1) {
+            y1 = cmul(y1, make_double2(C1, -S1));
+            y2 = make_double2((y2.x + y2.y) * H, (y2.y - y2.x) * H);
+            y3 = cmul(y3, make_double2(S1, -C1));
+        } else if (e == 2) {
+            y1 = make_double2((y1.x + y1.y) * H, (y1.y - y1.x) * H);
+            y2 = cmul_mi(y2);
+            y3 = make_double2((y3.y - y3.x) * H, -(y3.x + y3.y) * H);
+        } else if (e == 3) {
+            y1 = cmul(y1, make_double2(S1, -C1));
+            y2 = make_double2((y2.y - y2.x) * H, -(y2.x + y2.y) * H);
+            y3 = cmul(y3, make_double2(-C1, S1));
+        }
+        x[e] = y0;
+        x[e + 4] = y1;
+        x[e + 8] = y2;
+        x[e + 12] = y3;
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        double2 y0, y1, y2, y3;
+        net_dft4(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3], y0, y1, y2, y3);
+        x[4 * g] = y0;
+        x[4 * g + 1] = y1;
+        x[4 * g + 2] = y2;
+        x[4 * g + 3] = y3;
+    }
+}
+
+// row that holds frequency j after the rounds of `pl`
+__device__ __forceinline__ int net8_row(int j, int logR, const Net8Plan &pl)
+{
+    int row = 0, left = logR;
+    for (int q = 0; q < pl.n8; ++q) {
+        left -= 3;
+        row += (j & 7) << left;
+        j >>= 3;
+    }
+    // the 16-point transform leaves frequency f0 + 4 f1 at local index 4 f0 + f1, the smaller ones digit d at d
+    return pl.lf == 4 ? row + 4 * (j & 3) + (j >> 2) : row + j;
+}
+
+// W_R^m for 0 <= m < R from the table of the first R/2 powers
+__device__ __forceinline__ double2 net8_root(const double2 *tw, int m, int half)
+{
+    const double2 w = tw[m & (half - 1)];
+    return m & half ? make_double2(-w.x, -w.y) : w;
+}
+
+// grid (H/R/C tiles, batch), R·C/8 lanes (at most 1024). in/out [batch][H]. LDS: (R·C + (R >> lf)·C) points + R/2 roots.
+template <int IN, int OUT>
+__global__ __launch_bounds__(1024) void fft_pass8_kernel(const double2 *__restrict__ in, double2 *__restrict__ out,
+                                                         long long H, int logR, int logC, int logS, long long n,
+                                                         PassIo io, TwTab tt)
+{
+    const long long s = 1LL << logS;
+    extern __shared__ double2 lds[];
+    const int R = 1 << logR, C = 1 << logC, NT = blockDim.x;
+    const Net8Plan pl = net8_plan(logR);
+    const int lf = pl.lf;
+    double2 *buf = lds;                                        // point (row k, column cc) at P(k, cc)
+    double2 *tw = lds + (R << logC) + ((R >> lf) << logC);     // [R/2]
+#define NET8_P(k, cc) ((((k) + ((k) >> lf)) << logC) + (cc))
+    const long long cols = H >> logR;
+    // Tiles narrower than a 128-byte line (C = 4 points) share every line with a neighbour: workgroups are dealt to the
+    // XCDs round robin, so the neighbours are given to the SAME XCD, one dispatch round apart (w = 8 m + x -> tile
+    // (m & 1) + 2 x + 16 (m >> 1)); dealt in launch order the two halves of a line were fetched by two L2s (FETCH_SIZE
+    // twice the algorithmic bytes).
+    long long tile = blockIdx.x;
+    if ((gridDim.x & 15u) == 0u) {
+        const unsigned m = blockIdx.x >> 3, xc = blockIdx.x & 7u;
+        tile = (long long)((m & 1u) + 2u * xc) + 16LL * (m >> 1);
+    }
+    const long long c0 = tile << logC;
+    if (IN == IN_PAD) {
+        const double *x = io.series + (size_t)blockIdx.y * io.n;
+        for (int idx = threadIdx.x; idx < (R << logC); idx += NT) {
+            const int k = idx >> logC, cc = idx & (C - 1);
+            const long long e = 2 * (c0 + cc + (long long)k * cols);
+            double2 v = make_double2(0.0, 0.0);
+            if (e < io.n) {
+                v.x = x[e];
+                if (e + 1 < io.n) v.y = x[e + 1];
+            }
+            buf[NET8_P(k, cc)] = v;
+        }
+    } else {
+        in += (size_t)blockIdx.y * H;
+        for (int idx = threadIdx.x; idx < (R << logC); idx += NT) {
+            const int k = idx >> logC, cc = idx & (C - 1);
+            buf[NET8_P(k, cc)] = in[c0 + cc + (long long)k * cols];
+        }
+    }
+    for (int t = threadIdx.x; t < (R >> 1); t += NT) tw[t] = tw_lookup(tt, (unsigned long long)t, logR);
+    __syncthreads();
+    // ---- rounds with twiddles: radix 8 ----
+    int logn = logR;  // log2 of the current sub-transform length
+    for (int q = 0; q < pl.n8; ++q) {
+        const int lst = logn - 3;  // log2 of the butterfly stride (rows)
+        for (int b = threadIdx.x; b < (R >> 3 << logC); b += NT) {
+            const int cc = b & (C - 1), bf = b >> logC;
+            const int i = bf & ((1 << lst) - 1), blk = bf >> lst;
+            const int row0 = (blk << logn) + i;
+            double2 a[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] = buf[NET8_P(row0 + (e << lst), cc)];
+            net_dft8(a);
+            // output digit d times W_len^(i d) = W_R^(i d R/len): the powers 1, 2, 4 from the table, the others products
+            const int sh = logR - logn;
+            const double2 w1 = net8_root(tw, i << sh, R >> 1), w2 = net8_root(tw, (2 * i) << sh, R >> 1),
+                          w4 = net8_root(tw, (4 * i) << sh, R >> 1);
+            const double2 w3 = cmul(w1, w2), w5 = cmul(w4, w1), w6 = cmul(w4, w2), w7 = cmul(w4, w3);
+            a[1] = cmul(a[1], w1);
+            a[2] = cmul(a[2], w2);
+            a[3] = cmul(a[3], w3);
+            a[4] = cmul(a[4], w4);
+            a[5] = cmul(a[5], w5);
+            a[6] = cmul(a[6], w6);
+            a[7] = cmul(a[7], w7);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) buf[NET8_P(row0 + (e << lst), cc)] = a[e];
+        }
+        __syncthreads();
+        logn -= 3;
+    }
+    // ---- last round: 2^lf consecutive rows per lane, no twiddles ----
+    for (int b = threadIdx.x; b < (R >> lf << logC); b += NT) {
+        const int cc = b & (C - 1), row0 = (b >> logC) << lf;
+        if (lf == 4) {
+            double2 x[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) x[e] = buf[NET8_P(row0 + e, cc)];
+            net_dft16(x);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) buf[NET8_P(row0 + e, cc)] = x[e];
+        } else if (lf == 3) {
+            double2 x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = buf[NET8_P(row0 + e, cc)];
+            net_dft8(x);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) buf[NET8_P(row0 + e, cc)] = x[e];
+        } else if (lf == 2) {
+            double2 y0, y1, y2, y3;
+            net_dft4(buf[NET8_P(row0, cc)], buf[NET8_P(row0 + 1, cc)], buf[NET8_P(row0 + 2, cc)], buf[NET8_P(row0 + 3, cc)],
+                     y0, y1, y2, y3);
+            buf[NET8_P(row0, cc)] = y0;
+            buf[NET8_P(row0 + 1, cc)] = y1;
+            buf[NET8_P(row0 + 2, cc)] = y2;
+            buf[NET8_P(row0 + 3, cc)] = y3;
+        } else {
+            const double2 u = buf[NET8_P(row0, cc)], v = buf[NET8_P(row0 + 1, cc)];
+            buf[NET8_P(row0, cc)] = cadd(u, v);
+            buf[NET8_P(row0 + 1, cc)] = csub(u, v);
+        }
+    }
+    __syncthreads();
+    const bool last = n == R;  // p = 0 for every column: no twiddle
+    const int logn_p = 63 - __builtin_clzll((unsigned long long)n);
+    const bool col_fast = s >= C;
+    out += (size_t)blockIdx.y * H;
+    double *lags = OUT == OUT_LAGS ? io.lags + (size_t)blockIdx.y * io.n_lags : nullptr;
+    for (int idx = threadIdx.x; idx < (R << logC); idx += NT) {
+        int cc, j;
+        if (col_fast) {
+            cc = idx & (C - 1);
+            j = idx >> logC;
+        } else {
+            j = idx & (R - 1);
+            cc = idx >> logR;
+        }
+        const int r = net8_row(j, logR, pl);
+        double2 v = buf[NET8_P(r, cc)];
+        const long long c = c0 + cc;
+        const long long p = c >> logS, q = c & (s - 1);
+        if (!last && j != 0 && p != 0) v = cmul(v, tw_lookup(tt, (unsigned long long)j * (unsigned long long)p, logn_p));
+        const long long o = q + s * (((long long)p << logR) + j);
+        if (OUT == OUT_LAGS) {
+            const long long t = 2 * o;
+            if (t < io.n_lags) lags[t] = (v.x / io.L) / (double)(io.n - t);
+            if (t + 1 < io.n_lags) lags[t + 1] = (-v.y / io.L) / (double)(io.n - t - 1);
+        } else {
+            if (OUT == OUT_CONJ) v.y = -v.y;
+            out[o] = v;
+        }
+    }
+#undef NET8_P
+}
+
 // spec[b][k], k = 0..H, from Z = FFT_H of the reals read as complex pairs. grid (ceil((H/2+1)/256), batch)
 __global__ void r2c_post_kernel(const double2 *__restrict__ Z, double2 *__restrict__ spec, long long H, TwTab tt)
 {
@@ -307,13 +558,20 @@ struct PassPlan {
     int logR[FFT_MAX_PASSES] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
-PassPlan plan_passes(const mdhip_ctx *ctx, long long H)
+PassPlan plan_passes(const mdhip_ctx *ctx, long long H, int batch)
 {
     int logH = 0;
     while ((1LL << logH) < H) ++logH;
     int max_logr = std::min(std::max(ctx->opt_fft_logr, 4), FFT_MAX_LOGR);
     // a one-column tile of the radix (R + R/2 complex points) must fit the CU's LDS
     while (max_logr > 4 && ((size_t)24 << max_logr) > ctx->lds_max) --max_logr;
+    if (max_logr > 8 && logH > 0) {
+        // the large radices save a pass over HBM only while their tiles (>= 64 KB, 4 columns) still fill the chip:
+        // 3 x 2^17 points as 9 + 8 put 96 workgroups on 256 CUs and measured 0.050 ms against 0.044 ms for three passes
+        const int np = (logH + max_logr - 1) / max_logr;
+        const int lr0 = (logH + np - 1) / np;
+        if (lr0 > 8 && ((H >> lr0) >> 2) * (long long)std::max(batch, 1) < (long long)ctx->cu_count) max_logr = 8;
+    }
     PassPlan p;
     p.n_pass = (logH + max_logr - 1) / max_logr;
     if (p.n_pass > FFT_MAX_PASSES) {  // H > 2^32 at radix 16: no caller gets here (xcorr caps n at 2^29)
@@ -332,6 +590,30 @@ bool launch_pass(mdhip_ctx *ctx, const double2 *in, double2 *out, long long H, i
                  const PassIo &io, const TwTab &tt)
 {
     const long long cols = H >> logR;
+    if (logR >= NET8_MIN_LOGR && ctx->opt_fft_net8 != 0) {
+        // radix-8 network: two workgroups per CU (their loads, transforms and stores overlap), i.e. <= 78 KB of LDS each
+        const int lf = net8_plan(logR).lf;
+        int logC = 5;
+        auto bytes = [&](int lc) {
+            return (((size_t)1 << logR) + ((size_t)1 << logR >> lf) << lc) * sizeof(double2) + ((size_t)1 << logR >> 1) * sizeof(double2);
+        };
+        const size_t cap = ctx->opt_fft_net8 == 2 ? ctx->lds_max : (size_t)78 * 1024;  // (2: one workgroup per CU, A/B)
+        while (logC > 0 && (bytes(logC) > cap || (1LL << logC) > cols)) --logC;
+        const size_t lds = bytes(logC);
+        if (lds <= ctx->lds_max) {
+            const int threads = (int)std::min<long long>(1024, std::max<long long>(64, ((1LL << logR) << logC) >> 3));
+            const dim3 grid((unsigned)(cols >> logC), (unsigned)batch);
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fft_pass8_kernel<IN, OUT>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) {
+                mdhip_fail(ctx, MDHIP_EHIP, "fft pass of radix 2^%d needs %zu bytes of LDS: %s", logR, lds, hipGetErrorString(e));
+                return false;
+            }
+            hipLaunchKernelGGL((fft_pass8_kernel<IN, OUT>), grid, dim3((unsigned)threads), lds, ctx->stream, in, out, H, logR,
+                               logC, logS, H >> logS, io, tt);
+            return true;
+        }
+    }
     // 16 columns per tile (256-byte runs) while the tile fits 64 KB of LDS, fewer for the larger radices
     int logC = std::min(std::max(ctx->opt_fft_logc, 0), 6);
     while (logC > 0 && ((size_t)16 << logR << logC) > (size_t)128 * 1024) --logC;
@@ -356,7 +638,7 @@ bool launch_pass(mdhip_ctx *ctx, const double2 *in, double2 *out, long long H, i
 double2 *fft_forward(mdhip_ctx *ctx, double2 *x, double2 *y, long long H, int batch, int in_mode, int out_mode,
                      const PassIo &io, const TwTab &tt)
 {
-    const PassPlan p = plan_passes(ctx, H);
+    const PassPlan p = plan_passes(ctx, H, batch);
     if (p.n_pass < 0) {
         mdhip_fail(ctx, MDHIP_ELIMIT, "transform of %lld complex points needs more than %d passes", H, FFT_MAX_PASSES);
         return nullptr;
@@ -425,7 +707,7 @@ int mdhip_fft_c2r(mdhip_ctx *ctx, const double2 *d_spec, double2 *d_tmp, double 
         }
         return MDHIP_OK;
     }
-    const PassPlan p = plan_passes(ctx, H);
+    const PassPlan p = plan_passes(ctx, H, batch);
     MD_REQUIRE(p.n_pass >= 0, "transform length %lld needs more than %d passes", L, FFT_MAX_PASSES);
     // the result must land in d_real: start in d_real for an even number of buffer hops, in d_tmp for an odd one
     // (H = 1: one hop, the conjugating copy)

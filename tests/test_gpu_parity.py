@@ -1264,6 +1264,58 @@ def test_xcorr_fft_all_pass_plans(B, n):
     np.testing.assert_array_equal(few, got[:, :max(1, n // 3)])
 
 
+def test_lag_msd_batched_transforms_with_a_large_radix_pass(B):
+    """Full-lag MSD of a 70 000-frame trajectory: padded length 2^18, the batched global transforms
+    (mdhip_fft_r2c / mdhip_fft_c2r, lag_variant 4) plan 2^17 points as a radix-2^9 pass (radix-8 network) + a radix-2^8
+    pass (radix-4 network) over a batch of 60 series; against the difference kernel within the reported bound."""
+    ctx = B.default_context()
+    rng = np.random.default_rng(77)
+    F, E = 70_000, 20
+    r = np.cumsum(rng.normal(0, 0.1, (F, 3, E)), axis=0) + rng.uniform(-50, 50, (1, 3, E))
+    lags = 3000
+    try:
+        ctx.set_option("lag_variant", 1)
+        exact = B.lag_msd(r, lags, [0, 12, E])
+        ctx.set_option("lag_variant", 4)
+        fft = B.lag_msd(r, lags, [0, 12, E])
+        bound = ctx.last_rel_bound()
+        assert ctx.last_kernel_name() == "lag_msd_fft" and 0.0 < bound < 1e-8
+        nz = exact > 0
+        assert (np.abs(fft[nz] - exact[nz]) / exact[nz]).max() <= bound
+    finally:
+        ctx.set_option("lag_variant", 1)
+
+
+@pytest.mark.parametrize("n", [140_000, 300_000, 1_000_000])
+def test_xcorr_fft_large_radix_passes(B, n):
+    """Two-pass plans (radix 2^9 and 2^10 through the radix-8 network, fft_pass8_kernel: last rounds of 8 and of 16
+    points, 4- and 8-column tiles, the XCD-paired tile order) against numpy's FFT at rounding level, and against the
+    three-pass plan of the radix-4 network (fft_logr 8) and the radix-4 network at the large radices (fft_net8 0):
+    every plan within 1e-13 |a| |b| of the reference at every lag."""
+    ctx = B.default_context()
+    rng = np.random.default_rng(n)
+    a = rng.standard_normal((3, n)) * np.array([1.0, 1e3, 1e-4])[:, None]
+    b = rng.standard_normal((3, n)) + 0.5
+    L = 2
+    while L < 2 * n:
+        L *= 2
+    w = n - np.arange(n)
+    ref_ab = np.fft.irfft(np.fft.rfft(a, L) * np.conj(np.fft.rfft(b, L)), L)[..., :n]
+    ref_aa = np.fft.irfft(np.abs(np.fft.rfft(a, L)) ** 2, L)[..., :n]
+    na, nb_ = np.linalg.norm(a, axis=1), np.linalg.norm(b, axis=1)
+    try:
+        for opts in ({}, {"fft_logr": 8}, {"fft_net8": 0}, {"fft_net8": 2}):
+            ctx.set_option("fft_logr", opts.get("fft_logr", 10))
+            ctx.set_option("fft_net8", opts.get("fft_net8", 1))
+            got = B.xcorr(a, b, method=B.XCORR_FFT)
+            assert (np.abs(got * w - ref_ab).max(axis=1) <= 1e-13 * na * nb_).all(), opts
+            auto = B.xcorr(a, method=B.XCORR_FFT, n_lags=n // 2)
+            assert (np.abs(auto * w[: n // 2] - ref_aa[:, : n // 2]).max(axis=1) <= 1e-13 * na * na).all(), opts
+    finally:
+        ctx.set_option("fft_logr", 10)
+        ctx.set_option("fft_net8", 1)
+
+
 def test_c5_acf_properties(B):
     """n = 1e5 AR(1) series (BASELINE C5 at a tenth of its length): FFT and direct estimators agree,
     acf[0] is the mean square, the cumulative trapezoid of a constant is a ramp."""
