@@ -204,7 +204,12 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass_kernel(const double2 *__
 // 16-, 8- or 4-point transform without twiddles: 1024 = 8 x 8 x 16 in three rounds. Rows sit C points apart with C
 // points of padding per final sub-transform, so that the last round — a lane walks 16 consecutive rows — spreads over
 // the banks. Decimation in frequency, output row of frequency j by digit reversal (net8_row).
-constexpr int NET8_MIN_LOGR = 9;  // passes of radix >= 2^9 take the radix-8 network (fft_net8 = 0: the radix-4 one, A/B)
+#ifndef NET8_MIN_LOGR
+#define NET8_MIN_LOGR 9  // passes of radix >= 2^9 take the radix-8 network (fft_net8 = 0: the radix-4 one, A/B)
+#endif
+#ifndef NET8_MAX_LOGC
+#define NET8_MAX_LOGC 5
+#endif
 struct Net8Plan {
     int n8;  // rounds of radix 8 (with twiddles)
     int lf;  // log2 of the last round's transform (1 .. 4), without twiddles
@@ -593,7 +598,7 @@ bool launch_pass(mdhip_ctx *ctx, const double2 *in, double2 *out, long long H, i
     if (logR >= NET8_MIN_LOGR && ctx->opt_fft_net8 != 0) {
         // radix-8 network: two workgroups per CU (their loads, transforms and stores overlap), i.e. <= 78 KB of LDS each
         const int lf = net8_plan(logR).lf;
-        int logC = 5;
+        int logC = NET8_MAX_LOGC;
         auto bytes = [&](int lc) {
             return (((size_t)1 << logR) + ((size_t)1 << logR >> lf) << lc) * sizeof(double2) + ((size_t)1 << logR >> 1) * sizeof(double2);
         };
