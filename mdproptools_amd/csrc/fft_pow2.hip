@@ -77,7 +77,7 @@ __global__ void fft_twiddle_table_kernel(double2 *A, long long nA, double2 *B, l
 
 __device__ __forceinline__ unsigned bit_reverse(unsigned r, int bits) { return bits ? __brev(r) >> (32 - bits) : 0u; }
 
-enum { IN_PLAIN = 0, IN_PAD = 1 };
+enum { IN_PLAIN = 0, IN_PAD = 1, IN_SPEC = 2 };  // IN_SPEC (fft_pass8_kernel only): see spec_input
 enum { OUT_PLAIN = 0, OUT_CONJ = 1, OUT_LAGS = 2 };
 
 // what the first / last pass of the fused correlation pipeline reads / writes instead of a complex buffer
@@ -87,6 +87,7 @@ struct PassIo {
     double *lags;          // OUT_LAGS: [batch][n_lags]; the complex result y = conj(v) holds c[2o] = Re, c[2o+1] = Im,
     long long n_lags;      //           lags[t] = (c[t] / L) / (n - t) for t < n_lags
     double L;
+    const double2 *zb;     // IN_SPEC: the second series' transform [batch][H] (nullptr: autocorrelation, Zb = Za = `in`)
 };
 
 // grid (H/R/C tiles, batch). in/out [batch][H].
@@ -311,6 +312,45 @@ __device__ __forceinline__ double2 net8_root(const double2 *tw, int m, int half)
     return m & half ? make_double2(-w.x, -w.y) : w;
 }
 
+// IN_SPEC: the inverse transform's first pass computes its own input — what xcorr_spectrum_kernel writes in place, W(o) =
+// conj Y(o) from the half spectra of Za, Zb (the zero-padded series' transforms read as complex pairs) — from Z(o) and
+// Z(H - o) of both series, so that the spectrum never makes a round trip through HBM: 32 MB read instead of 16 read +
+// 16 written + 16 read per 10^6-sample series. Same operations in the same order as that kernel (thread k of it owns
+// the points k and H - k; here every point is computed by the lane that loads it).
+__device__ __forceinline__ double2 spec_input(const double2 *__restrict__ Za, const double2 *__restrict__ Zb, long long o,
+                                              long long H, const TwTab &tt)
+{
+    const long long om = (H - o) & (H - 1);
+    const bool upper = o > om;              // o = H - k with k < H/2: the mirror point of the pair
+    const long long k = upper ? om : o, kk = upper ? o : om;
+    const double2 w = tw_lookup(tt, (unsigned long long)k, tt.logL);  // e^{-2 pi i k/L}
+    auto half_spectrum = [&](const double2 zk, const double2 zh, double2 &xk, double2 &xh) {
+        const double2 E = make_double2(0.5 * (zk.x + zh.x), 0.5 * (zk.y - zh.y));
+        const double2 O = make_double2(0.5 * (zk.y + zh.y), -0.5 * (zk.x - zh.x));
+        const double2 wo = cmul(w, O);
+        xk = make_double2(E.x + wo.x, E.y + wo.y);
+        xh = make_double2(E.x - wo.x, -(E.y - wo.y));
+    };
+    double2 ak, ah, bk, bh;
+    half_spectrum(Za[k], Za[kk], ak, ah);
+    if (Zb == Za) {
+        bk = ak;
+        bh = ah;
+    } else {
+        half_spectrum(Zb[k], Zb[kk], bk, bh);
+    }
+    const double2 sk = make_double2(ak.x * bk.x + ak.y * bk.y, ak.y * bk.x - ak.x * bk.y);
+    const double2 sh = make_double2(ah.x * bh.x + ah.y * bh.y, ah.y * bh.x - ah.x * bh.y);
+    const double2 se = make_double2(sk.x + sh.x, sk.y - sh.y);
+    const double2 sd = make_double2(sk.x - sh.x, sk.y + sh.y);
+    if (!upper) {
+        const double2 t = cmul(make_double2(w.x, -w.y), sd);
+        return make_double2(se.x - t.y, -(se.y + t.x));
+    }
+    const double2 u = cmul(w, make_double2(sd.x, -sd.y));
+    return make_double2(se.x - u.y, -(-se.y + u.x));
+}
+
 // grid (H/R/C tiles, batch), R·C/8 lanes (at most 1024). in/out [batch][H]. LDS: (R·C + (R >> lf)·C) points + R/2 roots.
 template <int IN, int OUT>
 __global__ __launch_bounds__(1024) void fft_pass8_kernel(const double2 *__restrict__ in, double2 *__restrict__ out,
@@ -347,6 +387,13 @@ __global__ __launch_bounds__(1024) void fft_pass8_kernel(const double2 *__restri
                 if (e + 1 < io.n) v.y = x[e + 1];
             }
             buf[NET8_P(k, cc)] = v;
+        }
+    } else if (IN == IN_SPEC) {
+        const double2 *za = in + (size_t)blockIdx.y * H;
+        const double2 *zb = io.zb ? io.zb + (size_t)blockIdx.y * H : za;
+        for (int idx = threadIdx.x; idx < (R << logC); idx += NT) {
+            const int k = idx >> logC, cc = idx & (C - 1);
+            buf[NET8_P(k, cc)] = spec_input(za, zb, c0 + cc + (long long)k * cols, H, tt);
         }
     } else {
         in += (size_t)blockIdx.y * H;
@@ -590,22 +637,33 @@ PassPlan plan_passes(const mdhip_ctx *ctx, long long H, int batch)
     return p;
 }
 
+// Tile width (log2 columns) and LDS bytes of a radix-2^logR pass through the radix-8 network; false when that pass runs the
+// radix-4 network instead (small radix, switched off, or no tile fits)
+bool net8_tile(const mdhip_ctx *ctx, long long H, int logR, int &logC, size_t &lds)
+{
+    if (logR < NET8_MIN_LOGR || ctx->opt_fft_net8 == 0) return false;
+    const long long cols = H >> logR;
+    const int lf = net8_plan(logR).lf;
+    auto bytes = [&](int lc) {
+        return (((size_t)1 << logR) + ((size_t)1 << logR >> lf) << lc) * sizeof(double2) + ((size_t)1 << logR >> 1) * sizeof(double2);
+    };
+    // two workgroups per CU (their loads, transforms and stores overlap), i.e. <= 78 KB of LDS each
+    const size_t cap = ctx->opt_fft_net8 == 2 ? ctx->lds_max : (size_t)78 * 1024;  // (2: one workgroup per CU, A/B)
+    logC = NET8_MAX_LOGC;
+    while (logC > 0 && (bytes(logC) > cap || (1LL << logC) > cols)) --logC;
+    lds = bytes(logC);
+    return lds <= ctx->lds_max;
+}
+
 template <int IN, int OUT>
 bool launch_pass(mdhip_ctx *ctx, const double2 *in, double2 *out, long long H, int batch, int logR, int logS,
                  const PassIo &io, const TwTab &tt)
 {
     const long long cols = H >> logR;
-    if (logR >= NET8_MIN_LOGR && ctx->opt_fft_net8 != 0) {
-        // radix-8 network: two workgroups per CU (their loads, transforms and stores overlap), i.e. <= 78 KB of LDS each
-        const int lf = net8_plan(logR).lf;
-        int logC = NET8_MAX_LOGC;
-        auto bytes = [&](int lc) {
-            return (((size_t)1 << logR) + ((size_t)1 << logR >> lf) << lc) * sizeof(double2) + ((size_t)1 << logR >> 1) * sizeof(double2);
-        };
-        const size_t cap = ctx->opt_fft_net8 == 2 ? ctx->lds_max : (size_t)78 * 1024;  // (2: one workgroup per CU, A/B)
-        while (logC > 0 && (bytes(logC) > cap || (1LL << logC) > cols)) --logC;
-        const size_t lds = bytes(logC);
-        if (lds <= ctx->lds_max) {
+    {
+        int logC;
+        size_t lds;
+        if (net8_tile(ctx, H, logR, logC, lds)) {
             const int threads = (int)std::min<long long>(1024, std::max<long long>(64, ((1LL << logR) << logC) >> 3));
             const dim3 grid((unsigned)(cols >> logC), (unsigned)batch);
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fft_pass8_kernel<IN, OUT>),
@@ -618,6 +676,10 @@ bool launch_pass(mdhip_ctx *ctx, const double2 *in, double2 *out, long long H, i
                                logC, logS, H >> logS, io, tt);
             return true;
         }
+    }
+    if (IN == IN_SPEC) {  // (callers ask for the fused spectrum input only when net8_tile says the first pass takes it)
+        mdhip_fail(ctx, MDHIP_EHIP, "internal: spectrum-input pass of radix 2^%d has no radix-8 tile", logR);
+        return false;
     }
     // 16 columns per tile (256-byte runs) while the tile fits 64 KB of LDS, fewer for the larger radices
     int logC = std::min(std::max(ctx->opt_fft_logc, 0), 6);
@@ -659,7 +721,9 @@ double2 *fft_forward(mdhip_ctx *ctx, double2 *x, double2 *y, long long H, int ba
     for (int i = 0; i < p.n_pass; ++i) {
         const int im = i == 0 ? in_mode : IN_PLAIN, om = i == p.n_pass - 1 ? out_mode : OUT_PLAIN;
         bool ok;
-        if (im == IN_PAD && om == OUT_PLAIN) ok = launch_pass<IN_PAD, OUT_PLAIN>(ctx, src, dst, H, batch, p.logR[i], s, io, tt);
+        if (im == IN_SPEC && om == OUT_PLAIN) ok = launch_pass<IN_SPEC, OUT_PLAIN>(ctx, src, dst, H, batch, p.logR[i], s, io, tt);
+        else if (im == IN_SPEC && om == OUT_LAGS) ok = launch_pass<IN_SPEC, OUT_LAGS>(ctx, src, dst, H, batch, p.logR[i], s, io, tt);
+        else if (im == IN_PAD && om == OUT_PLAIN) ok = launch_pass<IN_PAD, OUT_PLAIN>(ctx, src, dst, H, batch, p.logR[i], s, io, tt);
         else if (im == IN_PLAIN && om == OUT_LAGS) ok = launch_pass<IN_PLAIN, OUT_LAGS>(ctx, src, dst, H, batch, p.logR[i], s, io, tt);
         else if (im == IN_PLAIN && om == OUT_CONJ) ok = launch_pass<IN_PLAIN, OUT_CONJ>(ctx, src, dst, H, batch, p.logR[i], s, io, tt);
         else ok = launch_pass<IN_PLAIN, OUT_PLAIN>(ctx, src, dst, H, batch, p.logR[i], s, io, tt);
@@ -757,15 +821,24 @@ int mdhip_fft_xcorr(mdhip_ctx *ctx, const double *d_a, const double *d_b, long l
         Zb = fft_forward(ctx, buf2, buf3, H, batch, IN_PAD, OUT_PLAIN, io, tt);
         if (!Zb) return MDHIP_EHIP;
     }
-    const dim3 grid((unsigned)((H / 2 + 1 + 255) / 256), (unsigned)batch);
-    if (same)
-        hipLaunchKernelGGL(xcorr_spectrum_kernel<true>, grid, dim3(256), 0, ctx->stream, Za, Zb, H, tt);
-    else
-        hipLaunchKernelGGL(xcorr_spectrum_kernel<false>, grid, dim3(256), 0, ctx->stream, Za, Zb, H, tt);
+    // the pointwise step (half spectra, product, inverse-transform input) rides on the inverse transform's first pass when
+    // that pass runs the radix-8 network (IN_SPEC); else it is a kernel of its own, in place
+    const PassPlan ip = plan_passes(ctx, H, batch);
+    int lc_;
+    size_t lds_;
+    const bool fuse = ctx->opt_fft_specfuse != 0 && ip.n_pass >= 1 && net8_tile(ctx, H, ip.logR[0], lc_, lds_);
+    if (!fuse) {
+        const dim3 grid((unsigned)((H / 2 + 1 + 255) / 256), (unsigned)batch);
+        if (same)
+            hipLaunchKernelGGL(xcorr_spectrum_kernel<true>, grid, dim3(256), 0, ctx->stream, Za, Zb, H, tt);
+        else
+            hipLaunchKernelGGL(xcorr_spectrum_kernel<false>, grid, dim3(256), 0, ctx->stream, Za, Zb, H, tt);
+    }
     io.lags = d_lags;
     io.n_lags = n_lags;
     io.L = (double)L;
-    if (!fft_forward(ctx, Za, Za == buf0 ? buf1 : buf0, H, batch, IN_PLAIN, OUT_LAGS, io, tt)) return MDHIP_EHIP;
+    io.zb = same ? nullptr : Zb;
+    if (!fft_forward(ctx, Za, Za == buf0 ? buf1 : buf0, H, batch, fuse ? IN_SPEC : IN_PLAIN, OUT_LAGS, io, tt)) return MDHIP_EHIP;
     MD_HIP(hipGetLastError());
     return MDHIP_OK;
 }

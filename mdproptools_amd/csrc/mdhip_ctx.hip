@@ -252,6 +252,8 @@ int mdhip_set_option(mdhip_ctx *ctx, const char *key, int value)
         ctx->opt_fft_logc = value;
     else if (!strcmp(key, "seg_gy"))
         ctx->opt_seg_gy = value;
+    else if (!strcmp(key, "fft_specfuse"))
+        ctx->opt_fft_specfuse = value;
     else if (!strcmp(key, "fft_net8"))
         ctx->opt_fft_net8 = value;
     else if (!strcmp(key, "seg_frame"))

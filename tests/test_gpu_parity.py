@@ -1290,8 +1290,9 @@ def test_lag_msd_batched_transforms_with_a_large_radix_pass(B):
 def test_xcorr_fft_large_radix_passes(B, n):
     """Two-pass plans (radix 2^9 and 2^10 through the radix-8 network, fft_pass8_kernel: last rounds of 8 and of 16
     points, 4- and 8-column tiles, the XCD-paired tile order) against numpy's FFT at rounding level, and against the
-    three-pass plan of the radix-4 network (fft_logr 8) and the radix-4 network at the large radices (fft_net8 0):
-    every plan within 1e-13 |a| |b| of the reference at every lag."""
+    three-pass plan of the radix-4 network (fft_logr 8) and the radix-4 network at the large radices (fft_net8 0), with
+    the spectrum step inside the inverse's first pass (default) and as its own kernel (fft_specfuse 0), cross- and
+    autocorrelation: every plan within 1e-13 |a| |b| of the reference at every lag."""
     ctx = B.default_context()
     rng = np.random.default_rng(n)
     a = rng.standard_normal((3, n)) * np.array([1.0, 1e3, 1e-4])[:, None]
@@ -1304,9 +1305,10 @@ def test_xcorr_fft_large_radix_passes(B, n):
     ref_aa = np.fft.irfft(np.abs(np.fft.rfft(a, L)) ** 2, L)[..., :n]
     na, nb_ = np.linalg.norm(a, axis=1), np.linalg.norm(b, axis=1)
     try:
-        for opts in ({}, {"fft_logr": 8}, {"fft_net8": 0}, {"fft_net8": 2}):
+        for opts in ({}, {"fft_specfuse": 0}, {"fft_logr": 8}, {"fft_net8": 0}, {"fft_net8": 2}):
             ctx.set_option("fft_logr", opts.get("fft_logr", 10))
             ctx.set_option("fft_net8", opts.get("fft_net8", 1))
+            ctx.set_option("fft_specfuse", opts.get("fft_specfuse", 1))
             got = B.xcorr(a, b, method=B.XCORR_FFT)
             assert (np.abs(got * w - ref_ab).max(axis=1) <= 1e-13 * na * nb_).all(), opts
             auto = B.xcorr(a, method=B.XCORR_FFT, n_lags=n // 2)
@@ -1314,6 +1316,7 @@ def test_xcorr_fft_large_radix_passes(B, n):
     finally:
         ctx.set_option("fft_logr", 10)
         ctx.set_option("fft_net8", 1)
+        ctx.set_option("fft_specfuse", 1)
 
 
 def test_c5_acf_properties(B):

@@ -37,7 +37,7 @@ for s in "$@"; do
     tests_rccl1) timeout -k 10 900 python -m pytest tests/test_gpu_fullsize.py -m gpu -x -q -k "rccl" > $O/gpu_tests_rccl1.log 2>&1; rc=$?; echo "tests_rccl1 rc=$rc"; tail -15 $O/gpu_tests_rccl1.log; [ $rc -eq 0 ] || exit 1 ;;
     overhead) timeout -k 10 300 python tools/call_overhead.py 2>&1 | grep -v amdgpu | tail -8 ;;
     ab_scan) timeout -k 10 300 python tools/ab_libs_scan.py $(ls tools/_bin/libmdhip_scan*.so) mdproptools_amd/libmdhip.so 2>&1 | grep -v amdgpu | tail -20 ;;
-    ab_fft) L=mdproptools_amd/libmdhip.so; for n in 2000000 1000000 100000 10000; do timeout -k 10 300 python tools/ab_libs_xcorr.py $L $(ls tools/_bin/libmdhip_n8*.so) fft $n 2>&1 | grep -v amdgpu | tail -4; done ;;
+    ab_fft) L=mdproptools_amd/libmdhip.so; for n in 1000000 300000; do timeout -k 10 300 python tools/ab_libs_xcorr.py $L:fft_logr=8 $L:fft_specfuse=0 $L fft $n 2>&1 | grep -v amdgpu | tail -3; done ;;
     ab_seg) timeout -k 10 300 python tools/ab_libs_seg.py $(ls tools/_bin/libmdhip_seg*.so) mdproptools_amd/libmdhip.so 2>&1 | grep -v amdgpu | tail -16 ;;
     ab_lag) timeout -k 10 300 python tools/ab_libs_lag.py $(ls tools/_bin/libmdhip_f3*.so) mdproptools_amd/libmdhip.so 2>&1 | grep -v amdgpu | tail -12 ;;
     ab_pair) for w in C2 C3; do for op in rdf cn rdf_cn; do timeout -k 10 300 python tools/ab_libs.py tools/_bin/libmdhip_cur.so mdproptools_amd/libmdhip.so $w $op 2>&1 | grep -v amdgpu | tail -2; done; done ;;
