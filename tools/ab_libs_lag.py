@@ -14,8 +14,10 @@ from mdproptools_amd import _lib  # noqa: E402
 from mdproptools_amd import backend as B  # noqa: E402
 from mdproptools_amd import synth  # noqa: E402
 
-libs = [a for a in sys.argv[1:] if a.endswith(".so")]
-opts = [a.split("=") for a in sys.argv[1:] if "=" in a]
+libs = [a.split(":")[0] for a in sys.argv[1:] if a.split(":")[0].endswith(".so")]
+lib_opts = [dict(kv.split("=") for kv in a.split(":")[1].split(",")) if ":" in a else {} for a in sys.argv[1:]
+            if a.split(":")[0].endswith(".so")]  # LIB.so:key=value,key=value
+opts = [a.split("=") for a in sys.argv[1:] if "=" in a and ".so" not in a]
 E, F = 50_000, 5000
 
 
@@ -29,6 +31,9 @@ def ctx_of(path):
 
 
 ctxs = [ctx_of(p) for p in libs]
+for c_, o_ in zip(ctxs, lib_opts):
+    for k_, v_ in o_.items():
+        c_.set_option(k_, int(v_))
 g = torch.Generator(device="cuda")
 g.manual_seed(synth.BASE_SEED + 4)
 r = torch.empty((F, 3, E), dtype=torch.float64, device="cuda")
@@ -38,7 +43,7 @@ for f0 in range(1, F, 250):
     r[f0:f1] = r[f0 - 1] + torch.cumsum(torch.randn((f1 - f0, 3, E), generator=g, device="cuda", dtype=torch.float64) * 0.1, dim=0)
 ref = None
 for rnd in range(2):
-    for p, ctx in zip(libs, ctxs):
+    for k_lib, (p, ctx) in enumerate(zip(libs, ctxs)):
         ms = []
         for _ in range(4):
             out = B.lag_msd(r, F - 1, [0, E], scale=1.0, ctx=ctx)
@@ -47,5 +52,5 @@ for rnd in range(2):
             ref = out
         err = float(np.max(np.abs(out[1:] - ref[1:]) / ref[1:]))
         print("%-34s %-22s min %.3f ms  median %.3f ms  max rel diff vs first %.2e  bound %.2e" % (
-            os.path.basename(p), ctx.last_kernel_name(), min(ms[1:]), float(np.median(ms[1:])), err, ctx.last_rel_bound()),
+            os.path.basename(p) + " " + ",".join("%s=%s" % kv for kv in lib_opts[k_lib].items()), ctx.last_kernel_name(), min(ms[1:]), float(np.median(ms[1:])), err, ctx.last_rel_bound()),
             flush=True)

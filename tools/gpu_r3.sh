@@ -39,7 +39,7 @@ for s in "$@"; do
     ab_scan) timeout -k 10 300 python tools/ab_libs_scan.py $(ls tools/_bin/libmdhip_scan*.so) mdproptools_amd/libmdhip.so 2>&1 | grep -v amdgpu | tail -20 ;;
     ab_fft) L=mdproptools_amd/libmdhip.so; for n in 1000000 300000; do timeout -k 10 300 python tools/ab_libs_xcorr.py $L:fft_logr=8 $L:fft_specfuse=0 $L fft $n 2>&1 | grep -v amdgpu | tail -3; done ;;
     ab_seg) timeout -k 10 300 python tools/ab_libs_seg.py $(ls tools/_bin/libmdhip_seg*.so) mdproptools_amd/libmdhip.so 2>&1 | grep -v amdgpu | tail -16 ;;
-    ab_lag) timeout -k 10 300 python tools/ab_libs_lag.py $(ls tools/_bin/libmdhip_f3*.so) mdproptools_amd/libmdhip.so 2>&1 | grep -v amdgpu | tail -12 ;;
+    ab_lag) timeout -k 10 300 python tools/ab_libs_lag.py mdproptools_amd/libmdhip.so:lag_fft_kernel=1 mdproptools_amd/libmdhip.so:lag_fft_kernel=2 2>&1 | grep -v amdgpu | tail -12 ;;
     ab_pair) for w in C2 C3; do for op in rdf cn rdf_cn; do timeout -k 10 300 python tools/ab_libs.py tools/_bin/libmdhip_cur.so mdproptools_amd/libmdhip.so $w $op 2>&1 | grep -v amdgpu | tail -2; done; done ;;
     pmc_c2) timeout -k 10 900 bash tools/pmc.sh r03_c2 C2 > $O/pmc_c2.log 2>&1; echo "pmc rc=$?" ;;
     pmc_c2_f64) timeout -k 10 900 bash tools/pmc.sh r03_c2_f64 C2 --option rdf_pk=0 > $O/pmc_c2_f64.log 2>&1; echo "pmc rc=$?" ;;
