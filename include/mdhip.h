@@ -89,7 +89,16 @@ int mdhip_device_name(mdhip_ctx *ctx, char *buf, int buflen);
  *                  bound it computes for the data (mdhip_last_rel_bound) is <= 1e-10, else the exact-difference
  *                  kernel; 1 = always the series-resident difference kernel, 0 = staged difference kernel,
  *                  2 = always the autocorrelation theorem (the one knob that changes results, within that bound)
- *   "xcorr_tile"   time slabs of the direct correlation kernel */
+ *   "lag_fft_kernel" fused full-lag MSD kernel: 2 (default) first pass from registers + wave-private sub-transforms where
+ *                  the series is long enough, 1 block-wide passes, 0 the round-2 kernel (results agree within the bound)
+ *   "xcorr_tile"   time slabs of the direct correlation kernel
+ *   "fft_logr", "fft_logc"  FFT correlation: largest radix of a pass (log2, default 10) and columns per tile of the
+ *                  radix-4 network; "fft_net8" 1 (default) radix-8 network for passes of radix >= 2^9, 0 off, 2 one
+ *                  workgroup per CU; "fft_specfuse" 1 (default) spectrum step inside the inverse's first pass
+ *   "seg_frame"    segment COM / flux: 1 (default) one (run, frame) per block, 0 the software-pipelined staged kernel;
+ *                  "seg_cap", "seg_vec", "seg_gy" geometry of the staged kernel
+ *   "h2d_overlap"  host-resident frames: 1 (default) staged batch by batch under the sweeps, 0 copied first
+ *   "rdf_relblock", "rdf_guard", "cn_pk"  record blocks / overflow guard / coordination counts through the packed sweep */
 int mdhip_set_option(mdhip_ctx *ctx, const char *key, int value);
 
 /* ---- R2/R3 binning table ------------------------------------------------ */
