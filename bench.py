@@ -724,7 +724,20 @@ def msd_sharded(torch, dist, D, B, ctx, device, synth, rank, world, backend, ste
     the timed region; every call returns its result to the host (one small D2H each).
     """
     E, F, tao = 50_000, 5000, 4
-    r_f, r_e, (lo, hi), (e_lo, e_hi) = c4_shards(torch, device, synth, rank, world, D, E, F)
+    # the shards are the one place where a rank can fail alone (memory): the ranks agree before anyone enters a collective
+    shards, err = None, None
+    try:
+        shards = c4_shards(torch, device, synth, rank, world, D, E, F)
+    except Exception as e:  # noqa: BLE001
+        err = e
+    if dist.is_initialized():
+        ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            raise RuntimeError("a rank could not build its C4 shards: %r" % (err,))
+    elif err is not None:
+        raise err
+    r_f, r_e, (lo, hi), (e_lo, e_hi) = shards
     goff = [0, E]
     res, t_part, k_ms = {}, {"single": 0.0, "fixed": 0.0, "lag": 0.0}, {"single": [], "fixed": [], "lag": []}
 
