@@ -18,7 +18,10 @@
  *    named *_dev, which write the same values to a DEVICE buffer of the caller
  *    (one process per GPU: the multi-GPU layer hands that buffer to RCCL);
  *  - calls are synchronous on the context's stream: results are complete when
- *    the call returns. One context per thread; contexts are independent;
+ *    the call returns — except for the entry points named *_async (SURVEY.md
+ *    8b: "an _async variant + mdhip_sync"), which return with their work queued
+ *    on the stream; see "asynchronous calls" below. One context per thread;
+ *    contexts are independent;
  *  - there is NO CPU fallback: without a usable HIP device mdhip_create fails.
  *
  * Integer results (histograms, counts) are exact and independent of the
@@ -35,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MDHIP_VERSION 300 /* 0.3.0: + the *_dev result variants of the sharded paths (cn, msd_pairs, msd_windows, lag_msd, charge_flux, xcorr_lags), mdhip_host_alloc_on, mdhip_build_id */
+#define MDHIP_VERSION 400 /* 0.4.0: + the *_async entry points with mdhip_sync / mdhip_wait / mdhip_call_stats, mdhip_green_kubo (correlation -> unit factor -> running integral on the device), mdhip_cumtrapz_dev */
 
 #define MDHIP_OK 0
 #define MDHIP_EINVAL (-1)  /* bad argument (shape, NULL, unsupported size) */
@@ -55,7 +58,38 @@ void mdhip_destroy(mdhip_ctx *ctx);
 const char *mdhip_last_error(mdhip_ctx *ctx);
 /* Launch on a caller-owned hipStream_t (e.g. torch's current stream); NULL restores the own stream. */
 int mdhip_set_stream(mdhip_ctx *ctx, void *hip_stream);
+/*
+ * ---- asynchronous calls ----------------------------------------------------
+ * A *_async entry point takes the arguments of its synchronous twin (a trailing `*_on_device` flag where the twin
+ * comes as a host / _dev pair), queues ALL of its device work — staging of the small tables, kernels, the copy of
+ * the results into page-locked staging — on the context's stream and returns. The call COMPLETES later, inside
+ * mdhip_sync or mdhip_wait, in issue order: only then are host results in the caller's arrays, device results final
+ * (a rare internal re-run may rewrite them at completion), and the error code of the call known — mdhip_sync /
+ * mdhip_wait return the first error of the calls they completed (text: mdhip_last_error). Until then every array
+ * passed to the call — inputs and outputs, host and device, the small tables too — must stay valid and unchanged.
+ * Several calls may be in flight; their kernels run back to back on the stream with no host round trip between
+ * them, which is the point: a step of k calls costs its kernels plus ONE wait (reference callers are plain
+ * synchronous Python, e.g. dynamical/viscosity.py:178-190, so the overlap has to come from here). Inputs the
+ * asynchronous path does not take (frames in pageable host memory, class passes, the edge-table kernels) are
+ * handled by completing that part of the work before the call returns: correct, just not overlapped.
+ * A synchronous call completes everything issued before it first. mdhip_destroy completes what is still in flight.
+ */
+/* Completes every call in flight, then waits for the stream. Returns the first error among them, 0 if none. */
 int mdhip_sync(mdhip_ctx *ctx);
+/* Completes the calls in flight in issue order until at most `keep_in_flight` remain (double buffering: issue step
+ * k + 1, then mdhip_wait(ctx, 1) for the results of step k while k + 1 runs). */
+int mdhip_wait(mdhip_ctx *ctx, int keep_in_flight);
+/* Number of asynchronous calls issued and not yet completed. */
+int mdhip_pending(mdhip_ctx *ctx);
+/* Kernel time / preparation time / launches / dominant kernel of the call completed `back` calls ago (0 = the last
+ * one, as mdhip_last_kernel_ms reports; the last 64 are remembered). Any output pointer may be NULL. */
+int mdhip_call_stats(mdhip_ctx *ctx, int back, double *kernel_ms, double *aux_ms, int *n_launches, const char **kernel);
+/* The number of the entry-point call issued last on this context (1, 2, ...; calls made by the library itself while it
+ * completes another one are not counted), and the same statistics looked up by that number once the call has
+ * completed — how a caller with several calls in flight finds the times of each. */
+long long mdhip_last_ticket(mdhip_ctx *ctx);
+int mdhip_ticket_stats(mdhip_ctx *ctx, long long ticket, double *kernel_ms, double *aux_ms, int *n_launches,
+                       const char **kernel);
 /* Device time (ms, hipEvent pair on the launch stream) of the dominant kernel of the last call,
  * and the number of times that kernel was launched by that call. */
 double mdhip_last_kernel_ms(mdhip_ctx *ctx, int *n_launches);
@@ -98,7 +132,9 @@ int mdhip_device_name(mdhip_ctx *ctx, char *buf, int buflen);
  *   "seg_frame"    segment COM / flux: 1 (default) one (run, frame) per block, 0 the software-pipelined staged kernel;
  *                  "seg_cap", "seg_vec", "seg_gy" geometry of the staged kernel
  *   "h2d_overlap"  host-resident frames: 1 (default) staged batch by batch under the sweeps, 0 copied first
- *   "rdf_relblock", "rdf_guard", "cn_pk"  record blocks / overflow guard / coordination counts through the packed sweep */
+ *   "rdf_relblock", "rdf_guard", "cn_pk"  record blocks / overflow guard / coordination counts through the packed sweep
+ *   "sync_spin"    waiting for device work: 1 (default) poll the completion event (no interrupt wake-up latency; turns
+ *                  into a blocking wait after 100 ms), 0 block at once */
 int mdhip_set_option(mdhip_ctx *ctx, const char *key, int value);
 
 /* ---- R2/R3 binning table ------------------------------------------------ */
@@ -157,6 +193,15 @@ int mdhip_rdf_atomic_dev(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, cons
                          const int32_t *rel, double r_cut_sq, double bin_size, int nbins, const double *edges,
                          uint64_t *out_dev);
 
+int mdhip_rdf_atomic_async(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *xyz, int on_device,
+                           const int32_t *type, int64_t type_frame_stride, const double *box, int n_rel,
+                           const int32_t *rel, double r_cut_sq, double bin_size, int nbins, const double *edges,
+                           int per_frame, uint64_t *hist_full, uint64_t *hist_part, uint64_t *overflow);
+int mdhip_rdf_atomic_dev_async(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *xyz, int on_device,
+                               const int32_t *type, int64_t type_frame_stride, const double *box, int n_rel,
+                               const int32_t *rel, double r_cut_sq, double bin_size, int nbins, const double *edges,
+                               uint64_t *out_dev);
+
 /* ---- R4: _cn_loop --------------------------------------------------------- */
 /*
  * structural/rdf_cn.py:100-119: cn[kl] += #pairs(rsq < r_cut_sq[kl]) with the same a/b double test;
@@ -173,6 +218,11 @@ int mdhip_cn_atomic_dev(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const
                         const int32_t *type, int64_t type_frame_stride, const double *box, int n_rel,
                         const int32_t *rel, const double *r_cut_sq, uint64_t *cn_dev);
 
+/* cn: host [n_frames][n_rel] / [n_rel], or (cn_on_device, per_frame = 0) device [n_rel]. */
+int mdhip_cn_atomic_async(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *xyz, int on_device,
+                          const int32_t *type, int64_t type_frame_stride, const double *box, int n_rel,
+                          const int32_t *rel, const double *r_cut_sq, int per_frame, uint64_t *cn, int cn_on_device);
+
 /* ---- R3 + R4 in one sweep ------------------------------------------------------------------ */
 /*
  * calc_atomic_rdf and calc_atomic_cn walk the same pairs of the same frames (structural/rdf_cn.py:385-530 and
@@ -187,6 +237,12 @@ int mdhip_rdf_cn_atomic(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const
                         const int32_t *rel, double r_cut_sq, double bin_size, int nbins, const double *edges,
                         const double *cn_r_cut_sq, int per_frame, uint64_t *hist_full, uint64_t *hist_part,
                         uint64_t *overflow, uint64_t *cn);
+
+int mdhip_rdf_cn_atomic_async(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *xyz, int on_device,
+                              const int32_t *type, int64_t type_frame_stride, const double *box, int n_rel,
+                              const int32_t *rel, double r_cut_sq, double bin_size, int nbins, const double *edges,
+                              const double *cn_r_cut_sq, int per_frame, uint64_t *hist_full, uint64_t *hist_part,
+                              uint64_t *overflow, uint64_t *cn);
 
 /* ---- R5: _rdf_mol_loop / _cn_mol_loop (atoms x sites, rectangular) --------- */
 /*
@@ -224,6 +280,10 @@ int mdhip_segment_com(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, int n_a
                       const double *attr, int attr_on_device, const double *atom_mass,
                       const double *atom_q, int64_t n_seg, const int64_t *seg_off, double *out,
                       int out_on_device, double *seg_mass, double *seg_q);
+
+int mdhip_segment_com_async(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, int n_attr, const double *attr,
+                            int attr_on_device, const double *atom_mass, const double *atom_q, int64_t n_seg,
+                            const int64_t *seg_off, double *out, int out_on_device, double *seg_mass, double *seg_q);
 
 /* ---- M1 / M2: frame-pair displacement reductions --------------------------- */
 /*
@@ -301,6 +361,21 @@ int mdhip_lag_msd(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double 
 int mdhip_lag_msd_dev(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r, int on_device,
                       double scale, int max_lag, int n_groups, const int64_t *group_off, double *out_dev);
 
+/* Asynchronous twins of the MSD calls of a sharded step (dist.py issues them back to back and waits once):
+ * mdhip_msd_origin, mdhip_msd_pairs_dev, mdhip_msd_windows[_dev] (out_on_device), mdhip_lag_msd[_dev] (out_on_device;
+ * the spectral path's bound check and its fallback to the difference kernel happen at completion). */
+int mdhip_msd_origin_async(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r, int on_device,
+                           const double *origin, int origin_on_device, double scale, int n_groups,
+                           const int64_t *group_off, double *sums, int sums_on_device, double *cols, int64_t col_stride,
+                           int cols_on_device);
+int mdhip_msd_pairs_dev_async(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r, int on_device,
+                              double scale, int n_pairs, const int32_t *pairs, int n_groups, const int64_t *group_off,
+                              double *sums_dev);
+int mdhip_msd_windows_async(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r, int on_device,
+                            double scale, int tao, double *win_sums, int out_on_device);
+int mdhip_lag_msd_async(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r, int on_device, double scale,
+                        int max_lag, int n_groups, const int64_t *group_off, double *out, int out_on_device);
+
 /* ---- G1: per-frame charge flux --------------------------------------------- */
 /*
  * dynamical/_conductivity.py:11-35: J[k][type] = sum over molecules of that type of
@@ -320,6 +395,11 @@ int mdhip_charge_flux_dev(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, con
                           int on_device, const double *atom_mass, const double *atom_q, int64_t n_seg,
                           const int64_t *seg_off, const int32_t *seg_type, int n_types,
                           double vel_conv, double charge_conv, double *flux_dev);
+
+int mdhip_charge_flux_async(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *vel, int on_device,
+                            const double *atom_mass, const double *atom_q, int64_t n_seg, const int64_t *seg_off,
+                            const int32_t *seg_type, int n_types, double vel_conv, double charge_conv, double *flux,
+                            int flux_on_device);
 
 /* ---- G2 / G3: correlation functions ---------------------------------------- */
 #define MDHIP_XCORR_FFT 0    /* zero-padded FFT (reference: length 2n; here the next power of two >= 2n, same linear correlation): conductivity.py:109-114, viscosity.py:111-115 */
@@ -345,6 +425,11 @@ int mdhip_xcorr_lags(mdhip_ctx *ctx, int64_t n, int n_pairs, const double *a, co
 int mdhip_xcorr_lags_dev(mdhip_ctx *ctx, int64_t n, int n_pairs, const double *a, const double *b, int on_device,
                          int method, int64_t lag_begin, int64_t n_lags, double *out_dev);
 
+int mdhip_xcorr_async(mdhip_ctx *ctx, int64_t n, int n_pairs, const double *a, const double *b, int on_device,
+                      int method, int64_t n_lags, double *out);
+int mdhip_xcorr_lags_dev_async(mdhip_ctx *ctx, int64_t n, int n_pairs, const double *a, const double *b, int on_device,
+                               int method, int64_t lag_begin, int64_t n_lags, double *out_dev);
+
 /* ---- G4: cumulative trapezoid ---------------------------------------------- */
 /*
  * dynamical/viscosity.py:151 (cumtrapz) and conductivity.py:231 (cumulative_trapezoid):
@@ -353,6 +438,33 @@ int mdhip_xcorr_lags_dev(mdhip_ctx *ctx, int64_t n, int n_pairs, const double *a
  */
 int mdhip_cumtrapz(mdhip_ctx *ctx, int64_t n, int n_series, const double *y, int on_device,
                    double dx, int leading_zero, double *out);
+
+/* The same with out in a DEVICE buffer [n_series][n-1 (+1)] (the running integral stays on the GPU). */
+int mdhip_cumtrapz_dev(mdhip_ctx *ctx, int64_t n, int n_series, const double *y, int on_device, double dx,
+                       int leading_zero, double *out_dev);
+int mdhip_cumtrapz_async(mdhip_ctx *ctx, int64_t n, int n_series, const double *y, int on_device, double dx,
+                         int leading_zero, double *out);
+int mdhip_cumtrapz_dev_async(mdhip_ctx *ctx, int64_t n, int n_series, const double *y, int on_device, double dx,
+                             int leading_zero, double *out_dev);
+
+/* ---- G3 -> G4 in one call: the Green-Kubo chain without leaving the device ------------------------------------ */
+/*
+ * dynamical/viscosity.py:178-190 (_calc_3d_visc: autocorrelate, times PRESSURE_CONVERSION**2, calc_visc = V/(kB T) x
+ * cumtrapz, mean over the three tensor components) and dynamical/conductivity.py:109-114 + 229-231 as ONE call: the
+ * series go to the device once, the correlation functions never come back to be sent again.
+ *   acf[p][k]       = ( sum_t a_p[t+k] b_p[t] / (n-k) ) * acf_scale,  k = 0..n-1     host [n_series][n], or NULL
+ *   integral[p][k]  = integral_scale * cumtrapz(acf[p], dx)                          host [n_series][n-1 (+1 with leading_zero)]
+ *   integral_mean   = mean over p of integral[p] (numpy's order: ((i0 + i1) + i2 ...) / n_series)   host [n-1 (+1)], or NULL
+ * Each factor is applied as one multiplication of the finished value — the roundings of `acf * c**2` and
+ * `np.multiply(c, integral)` on the host; 1.0 leaves values untouched. a, b host|dev [n_series][n] (b == a:
+ * autocorrelation). Destinations in page-locked memory (mdhip_host_alloc) are written by DMA.
+ */
+int mdhip_green_kubo(mdhip_ctx *ctx, int64_t n, int n_series, const double *a, const double *b, int on_device,
+                     int method, double acf_scale, double dx, double integral_scale, int leading_zero, double *acf,
+                     double *integral, double *integral_mean);
+int mdhip_green_kubo_async(mdhip_ctx *ctx, int64_t n, int n_series, const double *a, const double *b, int on_device,
+                           int method, double acf_scale, double dx, double integral_scale, int leading_zero, double *acf,
+                           double *integral, double *integral_mean);
 
 /* ---- pinned host staging memory (reader -> pinned buffers -> H2D) -------- */
 /*

@@ -31,6 +31,11 @@ PROTOTYPES = {
     "mdhip_last_error": (C.c_char_p, [vp]),
     "mdhip_set_stream": (C.c_int, [vp, vp]),
     "mdhip_sync": (C.c_int, [vp]),
+    "mdhip_wait": (C.c_int, [vp, C.c_int]),
+    "mdhip_pending": (C.c_int, [vp]),
+    "mdhip_call_stats": (C.c_int, [vp, C.c_int, c_dp, c_dp, C.POINTER(C.c_int), C.POINTER(C.c_char_p)]),
+    "mdhip_last_ticket": (C.c_longlong, [vp]),
+    "mdhip_ticket_stats": (C.c_int, [vp, C.c_longlong, c_dp, c_dp, C.POINTER(C.c_int), C.POINTER(C.c_char_p)]),
     "mdhip_last_kernel_ms": (C.c_double, [vp, C.POINTER(C.c_int)]),
     "mdhip_last_aux_ms": (C.c_double, [vp]),
     "mdhip_last_kernel_name": (C.c_char_p, [vp]),
@@ -83,6 +88,36 @@ PROTOTYPES = {
     "mdhip_xcorr": (C.c_int, [vp, C.c_int64, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int64, c_dp]),
     "mdhip_xcorr_lags": (C.c_int, [vp, C.c_int64, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int64, C.c_int64, c_dp]),
     "mdhip_cumtrapz": (C.c_int, [vp, C.c_int64, C.c_int, vp, C.c_int, C.c_double, C.c_int, c_dp]),
+    "mdhip_cumtrapz_dev": (C.c_int, [vp, C.c_int64, C.c_int, vp, C.c_int, C.c_double, C.c_int, vp]),
+    "mdhip_cumtrapz_async": (C.c_int, [vp, C.c_int64, C.c_int, vp, C.c_int, C.c_double, C.c_int, c_dp]),
+    "mdhip_cumtrapz_dev_async": (C.c_int, [vp, C.c_int64, C.c_int, vp, C.c_int, C.c_double, C.c_int, vp]),
+    "mdhip_green_kubo": (C.c_int, [vp, C.c_int64, C.c_int, vp, vp, C.c_int, C.c_int, C.c_double, C.c_double,
+                                   C.c_double, C.c_int, c_dp, c_dp, c_dp]),
+    "mdhip_green_kubo_async": (C.c_int, [vp, C.c_int64, C.c_int, vp, vp, C.c_int, C.c_int, C.c_double, C.c_double,
+                                         C.c_double, C.c_int, c_dp, c_dp, c_dp]),
+    "mdhip_rdf_atomic_async": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, c_ip, C.c_int64, c_dp, C.c_int,
+                                         c_ip, C.c_double, C.c_double, C.c_int, c_dp, C.c_int, c_up, c_up, c_up]),
+    "mdhip_rdf_atomic_dev_async": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, c_ip, C.c_int64, c_dp, C.c_int,
+                                             c_ip, C.c_double, C.c_double, C.c_int, c_dp, vp]),
+    "mdhip_rdf_cn_atomic_async": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, c_ip, C.c_int64, c_dp, C.c_int,
+                                            c_ip, C.c_double, C.c_double, C.c_int, c_dp, c_dp, C.c_int, c_up, c_up, c_up,
+                                            c_up]),
+    "mdhip_cn_atomic_async": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, c_ip, C.c_int64, c_dp, C.c_int,
+                                        c_ip, c_dp, C.c_int, vp, C.c_int]),
+    "mdhip_segment_com_async": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int, vp, C.c_int, c_dp, c_dp, C.c_int64,
+                                          c_lp, vp, C.c_int, c_dp, c_dp]),
+    "mdhip_msd_origin_async": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, vp, C.c_int, C.c_double, C.c_int, c_lp,
+                                         vp, C.c_int, vp, C.c_int64, C.c_int]),
+    "mdhip_msd_pairs_dev_async": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, C.c_double, C.c_int, c_ip, C.c_int,
+                                            c_lp, vp]),
+    "mdhip_msd_windows_async": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, C.c_double, C.c_int, vp, C.c_int]),
+    "mdhip_lag_msd_async": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, C.c_double, C.c_int, C.c_int, c_lp,
+                                      vp, C.c_int]),
+    "mdhip_charge_flux_async": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, c_dp, c_dp, C.c_int64, c_lp, c_ip,
+                                          C.c_int, C.c_double, C.c_double, vp, C.c_int]),
+    "mdhip_xcorr_async": (C.c_int, [vp, C.c_int64, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int64, c_dp]),
+    "mdhip_xcorr_lags_dev_async": (C.c_int, [vp, C.c_int64, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int64, C.c_int64,
+                                             vp]),
     "mdhip_shell_residence": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, C.c_int64, vp, C.c_int, c_dp,
                                         C.c_double, C.c_double, C.c_int, c_up, c_up]),
     "mdhip_dump_open": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
@@ -182,11 +217,119 @@ def as_input(a, ctx=None):
             # this tensor must have finished first
             import torch
 
-            torch.cuda.current_stream(a.device).synchronize()
+            cur = torch.cuda.current_stream(a.device)
+            if ctx is None or getattr(ctx, "_stream", None) != cur.cuda_stream:
+                cur.synchronize()  # (a context that launches on that very stream is ordered behind it anyway)
             return vp(a.data_ptr()), 1, a
         a = a.numpy()
     arr = _f64(a)
     return vp(arr.ctypes.data), 0, arr
+
+
+class PinnedPool:
+    """
+    Page-locked host arrays for LARGE results (include/mdhip.h: a destination in page-locked memory is written by DMA at
+    the PCIe rate; a pageable one goes through the runtime's bounce buffers at a third of it and blocks the host). The
+    memory comes from mdhip_host_alloc_on and goes back to a free list when the last array that views it dies, so a
+    caller who asks for the same result shape again and again (replicates of a Green-Kubo run) pays the page-locking
+    once. At most `max_keep` bytes are kept for reuse.
+    """
+
+    GRAIN = 1 << 20
+
+    def __init__(self, max_keep=1 << 30):
+        self.free = {}
+        self.kept = 0
+        self.max_keep = max_keep
+        self.lock = threading.Lock()
+
+    def empty(self, shape, dtype=np.float64, device=-1):
+        import weakref
+
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        cap = max(self.GRAIN, -(-n // self.GRAIN) * self.GRAIN)
+        with self.lock:
+            lst = self.free.get(cap)
+            ptr = lst.pop() if lst else None
+            if ptr is not None:
+                self.kept -= cap
+        if ptr is None:
+            out = vp()
+            rc = load().mdhip_host_alloc_on(int(device), cap, C.byref(out))
+            if rc != 0 or not out.value:
+                return np.empty(shape, dtype=dtype)  # (no page-locked memory to be had: an ordinary array works too)
+            ptr = out.value
+        buf = (C.c_char * cap).from_address(ptr)
+        weakref.finalize(buf, self._release, ptr, cap)
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def _release(self, ptr, cap):
+        with self.lock:
+            if self.kept + cap <= self.max_keep:
+                self.free.setdefault(cap, []).append(ptr)
+                self.kept += cap
+                return
+        try:
+            load().mdhip_host_free(vp(ptr))
+        except Exception:
+            pass
+
+
+PINNED = PinnedPool()
+PIN_RESULTS_FROM = 4 << 20  # results of at least this many bytes are given page-locked arrays (= MD_STAGE_MAX of ctx.h)
+
+
+def result_array(shape, dtype=np.float64, device=-1, zero=False):
+    """A host array for a library result: page-locked when it is large (see PinnedPool), numpy's own otherwise."""
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    if n >= PIN_RESULTS_FROM:
+        a = PINNED.empty(shape, dtype, device)
+        if zero:
+            a[...] = 0
+        return a
+    return np.zeros(shape, dtype=dtype) if zero else np.empty(shape, dtype=dtype)
+
+
+class Pending:
+    """
+    Handle of an asynchronous library call (the *_async entry points of include/mdhip.h): the call's device work is
+    queued, `wait()` completes it — and every call of the context issued before it — and returns what the synchronous
+    wrapper would have returned. The handle keeps the call's arrays alive until then.
+    """
+
+    def __init__(self, ctx, result, keep=None, finish=None):
+        self.ctx, self._result, self._keep, self._finish = ctx, result, keep, finish
+        ctx._issued += 1
+        self._seq = ctx._issued
+        self._done = False
+        self.ticket = ctx.last_ticket()
+
+    def wait(self):
+        if not self._done:
+            keep = self.ctx._issued - self._seq
+            if self.ctx.pending() > keep:
+                self.ctx.wait(keep)
+            self._done = True
+            self._keep = None
+            if self._finish is not None:
+                self._result = self._finish(self._result)
+                self._finish = None
+        return self._result
+
+    def stats(self):
+        """(kernel ms, preparation ms, launches, dominant kernel) of this call, once it has completed."""
+        return self.ctx.ticket_stats(self.ticket)
+
+
+class Ready:
+    """The same protocol for a result that is already there."""
+
+    def __init__(self, result):
+        self._result = result
+
+    def wait(self):
+        return self._result
 
 
 class Context:
@@ -200,6 +343,8 @@ class Context:
             raise MdhipError(rc, (self.lib.mdhip_last_error(None) or b"").decode())
         self.h = h
         self.device = int(device)
+        self._issued = 0       # asynchronous calls issued so far (Pending handles count from here)
+        self._stream = None    # None: the context's own stream; else the hipStream_t handle it launches on
 
     def close(self):
         if getattr(self, "h", None):
@@ -226,7 +371,36 @@ class Context:
         self.check(self.lib.mdhip_set_option(self.h, key.encode(), int(value)))
 
     def set_stream(self, stream_handle):
+        """Launch on a caller-owned hipStream_t (e.g. torch.cuda.Stream.cuda_stream); None / 0 restores the own stream.
+        Completes what is in flight first."""
         self.check(self.lib.mdhip_set_stream(self.h, vp(stream_handle) if stream_handle else None))
+        self._stream = int(stream_handle) if stream_handle else None
+
+    def sync(self):
+        """Completes every asynchronous call in flight (their results are then in place) and waits for the stream;
+        raises the first error among them."""
+        self.check(self.lib.mdhip_sync(self.h))
+
+    def wait(self, keep_in_flight=0):
+        """Completes the asynchronous calls in flight, oldest first, until at most `keep_in_flight` remain."""
+        self.check(self.lib.mdhip_wait(self.h, int(keep_in_flight)))
+
+    def pending(self):
+        return int(self.lib.mdhip_pending(self.h))
+
+    def call_stats(self, back=0):
+        """(kernel ms, preparation ms, launches, dominant kernel) of the call completed `back` calls ago."""
+        ms, aux, n, name = C.c_double(0), C.c_double(0), C.c_int(0), C.c_char_p()
+        self.check(self.lib.mdhip_call_stats(self.h, int(back), C.byref(ms), C.byref(aux), C.byref(n), C.byref(name)))
+        return float(ms.value), float(aux.value), int(n.value), (name.value or b"").decode()
+
+    def last_ticket(self):
+        return int(self.lib.mdhip_last_ticket(self.h))
+
+    def ticket_stats(self, ticket):
+        ms, aux, n, name = C.c_double(0), C.c_double(0), C.c_int(0), C.c_char_p()
+        self.check(self.lib.mdhip_ticket_stats(self.h, int(ticket), C.byref(ms), C.byref(aux), C.byref(n), C.byref(name)))
+        return float(ms.value), float(aux.value), int(n.value), (name.value or b"").decode()
 
     def last_kernel_ms(self):
         n = C.c_int(0)

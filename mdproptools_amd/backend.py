@@ -9,6 +9,11 @@ Coordinates may be host ndarrays, CUDA/HIP torch tensors (float64, contiguous)
 or `_lib.DevPtr` — device-resident inputs are used in place.
 
 Everything here runs on the GPU through libmdhip.so; there is no CPU path.
+
+`async_=True` (where offered) issues the call through its *_async entry point: the device work is queued on the
+context's stream and a `_lib.Pending` handle comes back at once; `handle.wait()` completes the call (and every call
+issued before it) and returns what the synchronous form returns. Calls issued back to back run back to back on the
+GPU, with no host round trip in between.
 """
 
 import ctypes as C
@@ -16,7 +21,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import as_input, default_context, ptr
+from ._lib import Pending, as_input, default_context, ptr, result_array
 
 XCORR_FFT = 0
 XCORR_DIRECT = 1
@@ -34,11 +39,22 @@ def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
 
-def _dev_out(out, shape, dtype="torch.float64"):
-    """Checks a device result buffer (`out=`): contiguous CUDA tensor of `shape` and `dtype`; returns its address."""
+def _dev_out(out, shape, dtype="torch.float64", ctx=None):
+    """Checks a device result buffer (`out=`): contiguous CUDA tensor of `shape` and `dtype` on the context's device;
+    whatever torch still has queued on that tensor's stream (its allocation's fill, say) is waited for, since the
+    context writes it from a stream of its own. Returns its address."""
     if not (getattr(out, "is_cuda", False) and out.is_contiguous() and str(out.dtype) == dtype
             and tuple(out.shape) == tuple(shape)):
         raise ValueError("out must be a contiguous %s CUDA tensor of shape %s" % (dtype, tuple(shape)))
+    if ctx is not None:
+        if out.device.index is not None and out.device.index != ctx.device:
+            raise ValueError("out lives on cuda:%d but the mdhip context is bound to device %d"
+                             % (out.device.index, ctx.device))
+        import torch
+
+        cur = torch.cuda.current_stream(out.device)
+        if getattr(ctx, "_stream", None) != cur.cuda_stream:
+            cur.synchronize()
     return C.c_void_p(out.data_ptr())
 
 
@@ -56,7 +72,7 @@ def cutoff_sq(r_cut):
     return r * r
 
 
-def rdf_loop(xyz, types, box, relation_matrix, r_cut, ddr, nbins, per_frame=True, ctx=None, edges=None):
+def rdf_loop(xyz, types, box, relation_matrix, r_cut, ddr, nbins, per_frame=True, ctx=None, edges=None, async_=False):
     """
     `_rdf_loop` (rdf_cn.py:72-97) for every frame of xyz [F,3,N].
 
@@ -78,14 +94,17 @@ def rdf_loop(xyz, types, box, relation_matrix, r_cut, ddr, nbins, per_frame=True
     part = np.zeros(lead + (R, nbins), dtype=np.uint64)
     ov = C.c_uint64(0)
     ed = None if edges is None else _f64(edges)
-    ctx.check(ctx.lib.mdhip_rdf_atomic(
+    fn = ctx.lib.mdhip_rdf_atomic_async if async_ else ctx.lib.mdhip_rdf_atomic
+    ctx.check(fn(
         ctx.h, F, N, xp, on_dev, ptr(ty, C.c_int32), stride, ptr(bx), R, ptr(rel, C.c_int32),
         cutoff_sq(r_cut), float(ddr), int(nbins), None if ed is None else ptr(ed), int(bool(per_frame)),
         ptr(full, C.c_uint64), ptr(part, C.c_uint64), C.byref(ov)))
+    if async_:
+        return Pending(ctx, (full, part, ov), keep=(keep, ty, bx, rel, ed), finish=lambda r: (r[0], r[1], int(r[2].value)))
     return full, part, int(ov.value)
 
 
-def rdf_loop_dev(xyz, types, box, relation_matrix, r_cut, ddr, nbins, out, ctx=None):
+def rdf_loop_dev(xyz, types, box, relation_matrix, r_cut, ddr, nbins, out, ctx=None, async_=False):
     """
     Frame-summed `_rdf_loop` with the sums left on the device: `out` = contiguous int64 CUDA tensor of
     (1 + R) * nbins + 1 words (rdf_full | rdf_part | overflow; the bit patterns are the uint64 counts), overwritten.
@@ -104,13 +123,18 @@ def rdf_loop_dev(xyz, types, box, relation_matrix, r_cut, ddr, nbins, out, ctx=N
     if not (getattr(out, "is_cuda", False) and out.is_contiguous() and str(out.dtype) == "torch.int64"
             and out.numel() == words):
         raise ValueError("out must be a contiguous int64 CUDA tensor of %d words" % words)
-    ctx.check(ctx.lib.mdhip_rdf_atomic_dev(
+    op = _dev_out(out, out.shape, "torch.int64", ctx)
+    fn = ctx.lib.mdhip_rdf_atomic_dev_async if async_ else ctx.lib.mdhip_rdf_atomic_dev
+    ctx.check(fn(
         ctx.h, F, N, xp, on_dev, ptr(ty, C.c_int32), stride, ptr(bx), len(rel), ptr(rel, C.c_int32),
-        cutoff_sq(r_cut), float(ddr), int(nbins), None, C.c_void_p(out.data_ptr())))
+        cutoff_sq(r_cut), float(ddr), int(nbins), None, op))
+    if async_:
+        return Pending(ctx, out, keep=(keep, ty, bx, rel))
     return out
 
 
-def rdf_cn_loop(xyz, types, box, relation_matrix, r_cut, ddr, nbins, cn_cut_list, per_frame=True, ctx=None):
+def rdf_cn_loop(xyz, types, box, relation_matrix, r_cut, ddr, nbins, cn_cut_list, per_frame=True, ctx=None,
+                async_=False):
     """
     `_rdf_loop` and `_cn_loop` (rdf_cn.py:72-119) from ONE sweep over the pairs: returns
     (rdf_full, rdf_part, overflow, cn) — the integers of rdf_loop(...) and cn_loop(..., cn_cut_list).
@@ -133,14 +157,18 @@ def rdf_cn_loop(xyz, types, box, relation_matrix, r_cut, ddr, nbins, cn_cut_list
     part = np.zeros(lead + (R, nbins), dtype=np.uint64)
     cn = np.zeros(lead + (R,), dtype=np.uint64)
     ov = C.c_uint64(0)
-    ctx.check(ctx.lib.mdhip_rdf_cn_atomic(
+    fn = ctx.lib.mdhip_rdf_cn_atomic_async if async_ else ctx.lib.mdhip_rdf_cn_atomic
+    ctx.check(fn(
         ctx.h, F, N, xp, on_dev, ptr(ty, C.c_int32), stride, ptr(bx), R, ptr(rel, C.c_int32),
         cutoff_sq(r_cut), float(ddr), int(nbins), None, ptr(rc2), int(bool(per_frame)),
         ptr(full, C.c_uint64), ptr(part, C.c_uint64), C.byref(ov), ptr(cn, C.c_uint64)))
+    if async_:
+        return Pending(ctx, (full, part, ov, cn), keep=(keep, ty, bx, rel, rc2),
+                       finish=lambda r: (r[0], r[1], int(r[2].value), r[3]))
     return full, part, int(ov.value), cn
 
 
-def cn_loop(xyz, types, box, relation_matrix, r_cut_list, per_frame=True, ctx=None, out=None):
+def cn_loop(xyz, types, box, relation_matrix, r_cut_list, per_frame=True, ctx=None, out=None, async_=False):
     """`_cn_loop` (rdf_cn.py:100-119): raw counts uint64 [F,R] (or [R]). `out` (frame-summed only): an int64 CUDA
     tensor [R] that receives the counts on the device (their bit patterns; the multi-GPU layer all-reduces it)."""
     ctx = ctx or default_context()
@@ -156,11 +184,22 @@ def cn_loop(xyz, types, box, relation_matrix, r_cut_list, per_frame=True, ctx=No
     if out is not None:
         if per_frame:
             raise ValueError("a device result buffer holds the frame-summed counts: pass per_frame=False")
+        op = _dev_out(out, (len(rel),), "torch.int64", ctx)
+        if async_:
+            ctx.check(ctx.lib.mdhip_cn_atomic_async(
+                ctx.h, F, N, xp, on_dev, ptr(ty, C.c_int32), stride, ptr(bx), len(rel), ptr(rel, C.c_int32),
+                ptr(rc2), 0, op, 1))
+            return Pending(ctx, out, keep=(keep, ty, bx, rel, rc2))
         ctx.check(ctx.lib.mdhip_cn_atomic_dev(
             ctx.h, F, N, xp, on_dev, ptr(ty, C.c_int32), stride, ptr(bx), len(rel), ptr(rel, C.c_int32),
-            ptr(rc2), _dev_out(out, (len(rel),), "torch.int64")))
+            ptr(rc2), op))
         return out
     cn = np.zeros(((F,) if per_frame else ()) + (len(rel),), dtype=np.uint64)
+    if async_:
+        ctx.check(ctx.lib.mdhip_cn_atomic_async(
+            ctx.h, F, N, xp, on_dev, ptr(ty, C.c_int32), stride, ptr(bx), len(rel), ptr(rel, C.c_int32),
+            ptr(rc2), int(bool(per_frame)), C.c_void_p(cn.ctypes.data), 0))
+        return Pending(ctx, cn, keep=(keep, ty, bx, rel, rc2))
     ctx.check(ctx.lib.mdhip_cn_atomic(
         ctx.h, F, N, xp, on_dev, ptr(ty, C.c_int32), stride, ptr(bx), len(rel), ptr(rel, C.c_int32),
         ptr(rc2), int(bool(per_frame)), ptr(cn, C.c_uint64)))
@@ -207,7 +246,7 @@ def cn_mol_loop(xyz, types, sites, site_types, box, relation_matrix, r_cut_list,
     return cn
 
 
-def segment_com(attr, atom_mass, seg_off, atom_q=None, out=None, ctx=None):
+def segment_com(attr, atom_mass, seg_off, atom_q=None, out=None, ctx=None, async_=False):
     """
     `calc_com` / `_define_mol_cols` arithmetic (com_mols.py:58-60, rdf_cn.py:233-238):
     attr [F,K,N] -> com [F,K,M], plus seg_mass [M] and seg_q [M] (None without atom_q).
@@ -226,14 +265,17 @@ def segment_com(attr, atom_mass, seg_off, atom_q=None, out=None, ctx=None):
     seg_mass = np.zeros(M)
     seg_q = None if q is None else np.zeros(M)
     if out is None:
-        res = np.zeros((F, K, M))
+        res = result_array((F, K, M), device=ctx.device, zero=True)
         op, o_dev = C.c_void_p(res.ctypes.data), 0
     else:
         res = out
         op, o_dev, _k = as_input(out, ctx)
-    ctx.check(ctx.lib.mdhip_segment_com(
+    fn = ctx.lib.mdhip_segment_com_async if async_ else ctx.lib.mdhip_segment_com
+    ctx.check(fn(
         ctx.h, F, N, K, ap, a_dev, ptr(m), None if q is None else ptr(q), M, ptr(off, C.c_int64), op,
         o_dev, ptr(seg_mass), None if seg_q is None else ptr(seg_q)))
+    if async_:
+        return Pending(ctx, (res, seg_mass, seg_q), keep=(keep, m, off, q))
     return res, seg_mass, seg_q
 
 
@@ -264,7 +306,7 @@ def msd_pairs(r, pairs, group_off, scale=1.0, per_entity=False, ctx=None, out=No
     return (sums, pe) if per_entity else sums
 
 
-def msd_origin(r, origin, group_off, scale=1.0, cols=None, out=None, ctx=None):
+def msd_origin(r, origin, group_off, scale=1.0, cols=None, out=None, ctx=None, async_=False):
     """
     Single-origin MSD of a FRAME SHARD (diffusion.py:212-218 with the frames dealt to one process per GPU): every
     frame of r [F,3,E] against `origin` [3,E] (host array or CUDA tensor — the time-0 frame, broadcast by its owner).
@@ -283,19 +325,21 @@ def msd_origin(r, origin, group_off, scale=1.0, cols=None, out=None, ctx=None):
         sums = np.zeros((F, G, 4))
         sp, s_dev = C.c_void_p(sums.ctypes.data), 0
     else:
-        sums, sp, s_dev = out, _dev_out(out, (F, G, 4)), 1
+        sums, sp, s_dev = out, _dev_out(out, (F, G, 4), ctx=ctx), 1
     cp, c_dev, stride = None, 0, 0
     if cols is not None:
         if getattr(cols, "is_cuda", False):
-            cp, c_dev, stride = _dev_out(cols, (4, F * E)), 1, F * E
+            cp, c_dev, stride = _dev_out(cols, (4, F * E), ctx=ctx), 1, F * E
         else:
             if not (isinstance(cols, np.ndarray) and cols.dtype == np.float64 and cols.shape == (4, F * E)
                     and (F * E == 0 or (cols.strides[1] == 8 and cols.strides[0] % 8 == 0
                                         and cols.strides[0] >= 8 * F * E))):
                 raise ValueError("cols must be a float64 array [4, n_frames * n_ent] with contiguous rows")
             cp, stride = C.c_void_p(cols.ctypes.data), (cols.strides[0] // 8 if F * E else 0)
-    ctx.check(ctx.lib.mdhip_msd_origin(ctx.h, F, E, rp, on_dev, op, o_dev, float(scale), G, ptr(go, C.c_int64),
-                                       sp, s_dev, cp, stride, c_dev))
+    fn = ctx.lib.mdhip_msd_origin_async if async_ else ctx.lib.mdhip_msd_origin
+    ctx.check(fn(ctx.h, F, E, rp, on_dev, op, o_dev, float(scale), G, ptr(go, C.c_int64), sp, s_dev, cp, stride, c_dev))
+    if async_:
+        return Pending(ctx, sums, keep=(keep, keep2, go, cols))
     return sums
 
 
@@ -321,20 +365,28 @@ def msd_pairs_cols(r, pairs, group_off, cols, scale=1.0, ctx=None):
     return sums
 
 
-def msd_windows(r, tao, scale=1.0, ctx=None, out=None):
+def msd_windows(r, tao, scale=1.0, ctx=None, out=None, async_=False):
     """Fixed-lag window sums per entity (diffusion.py:225-237): r [F,3,E] -> [E,4] (`out`: float64 CUDA tensor [E,4])."""
     ctx = ctx or default_context()
     F, _, E = _shape3(r, "r")
     rp, on_dev, keep = as_input(r, ctx)
     if out is not None:
-        ctx.check(ctx.lib.mdhip_msd_windows_dev(ctx.h, F, E, rp, on_dev, float(scale), int(tao), _dev_out(out, (E, 4))))
+        op = _dev_out(out, (E, 4), ctx=ctx)
+        if async_:
+            ctx.check(ctx.lib.mdhip_msd_windows_async(ctx.h, F, E, rp, on_dev, float(scale), int(tao), op, 1))
+            return Pending(ctx, out, keep=keep)
+        ctx.check(ctx.lib.mdhip_msd_windows_dev(ctx.h, F, E, rp, on_dev, float(scale), int(tao), op))
         return out
     out = np.zeros((E, 4))
+    if async_:
+        ctx.check(ctx.lib.mdhip_msd_windows_async(ctx.h, F, E, rp, on_dev, float(scale), int(tao),
+                                                  C.c_void_p(out.ctypes.data), 0))
+        return Pending(ctx, out, keep=keep)
     ctx.check(ctx.lib.mdhip_msd_windows(ctx.h, F, E, rp, on_dev, float(scale), int(tao), ptr(out)))
     return out
 
 
-def lag_msd(r, max_lag, group_off, scale=1.0, ctx=None, out=None):
+def lag_msd(r, max_lag, group_off, scale=1.0, ctx=None, out=None, async_=False):
     """Full lag average (superset): r [F,3,E] -> [max_lag+1, G, 4] (`out`: float64 CUDA tensor of that shape)."""
     ctx = ctx or default_context()
     F, _, E = _shape3(r, "r")
@@ -342,16 +394,26 @@ def lag_msd(r, max_lag, group_off, scale=1.0, ctx=None, out=None):
     go = _i64(group_off)
     G = len(go) - 1
     if out is not None:
+        op = _dev_out(out, (int(max_lag) + 1, G, 4), ctx=ctx)
+        if async_:
+            ctx.check(ctx.lib.mdhip_lag_msd_async(ctx.h, F, E, rp, on_dev, float(scale), int(max_lag), G,
+                                                  ptr(go, C.c_int64), op, 1))
+            return Pending(ctx, out, keep=(keep, go))
         ctx.check(ctx.lib.mdhip_lag_msd_dev(ctx.h, F, E, rp, on_dev, float(scale), int(max_lag), G,
-                                            ptr(go, C.c_int64), _dev_out(out, (int(max_lag) + 1, G, 4))))
+                                            ptr(go, C.c_int64), op))
         return out
     out = np.zeros((int(max_lag) + 1, G, 4))
+    if async_:
+        ctx.check(ctx.lib.mdhip_lag_msd_async(ctx.h, F, E, rp, on_dev, float(scale), int(max_lag), G,
+                                              ptr(go, C.c_int64), C.c_void_p(out.ctypes.data), 0))
+        return Pending(ctx, out, keep=(keep, go))
     ctx.check(ctx.lib.mdhip_lag_msd(ctx.h, F, E, rp, on_dev, float(scale), int(max_lag), G,
                                     ptr(go, C.c_int64), ptr(out)))
     return out
 
 
-def charge_flux(vel, atom_mass, atom_q, seg_off, seg_type, n_types, vel_conv, charge_conv, ctx=None, out=None):
+def charge_flux(vel, atom_mass, atom_q, seg_off, seg_type, n_types, vel_conv, charge_conv, ctx=None, out=None,
+                async_=False):
     """`conductivity_loop` for every frame (_conductivity.py:11-35): vel [F,3,N] -> j [3,T,F] (`out`: float64 CUDA
     tensor of that shape)."""
     ctx = ctx or default_context()
@@ -360,19 +422,29 @@ def charge_flux(vel, atom_mass, atom_q, seg_off, seg_type, n_types, vel_conv, ch
     m, q = _f64(atom_mass), _f64(atom_q)
     off = _i64(seg_off)
     st = _i32(seg_type)
-    if out is not None:
+    dev = out is not None
+    if dev:
+        op = _dev_out(out, (3, int(n_types), F), ctx=ctx)
+    else:
+        out = np.zeros((3, int(n_types), F))
+        op = C.c_void_p(out.ctypes.data)
+    if async_:
+        ctx.check(ctx.lib.mdhip_charge_flux_async(
+            ctx.h, F, N, vp_, on_dev, ptr(m), ptr(q), len(off) - 1, ptr(off, C.c_int64), ptr(st, C.c_int32),
+            int(n_types), float(vel_conv), float(charge_conv), op, int(dev)))
+        return Pending(ctx, out, keep=(keep, m, q, off, st))
+    if dev:
         ctx.check(ctx.lib.mdhip_charge_flux_dev(
             ctx.h, F, N, vp_, on_dev, ptr(m), ptr(q), len(off) - 1, ptr(off, C.c_int64), ptr(st, C.c_int32),
-            int(n_types), float(vel_conv), float(charge_conv), _dev_out(out, (3, int(n_types), F))))
+            int(n_types), float(vel_conv), float(charge_conv), op))
         return out
-    out = np.zeros((3, int(n_types), F))
     ctx.check(ctx.lib.mdhip_charge_flux(
         ctx.h, F, N, vp_, on_dev, ptr(m), ptr(q), len(off) - 1, ptr(off, C.c_int64), ptr(st, C.c_int32),
         int(n_types), float(vel_conv), float(charge_conv), ptr(out)))
     return out
 
 
-def xcorr(a, b=None, method=XCORR_FFT, n_lags=None, ctx=None, lag_begin=0, out=None):
+def xcorr(a, b=None, method=XCORR_FFT, n_lags=None, ctx=None, lag_begin=0, out=None, async_=False):
     """
     c[p][k] = sum_t a_p[t+k] b_p[t] / (n-k) (conductivity.py:109-114, viscosity.py:103-115).
     a, b: [n] or [P,n]; b=None gives the autocorrelation. lag_begin > 0 (direct method): the lags
@@ -392,25 +464,68 @@ def xcorr(a, b=None, method=XCORR_FFT, n_lags=None, ctx=None, lag_begin=0, out=N
             raise ValueError("a and b must both be host arrays or both device tensors")
     n_lags = n - int(lag_begin) if n_lags is None else int(n_lags)
     if out is not None:
-        ctx.check(ctx.lib.mdhip_xcorr_lags_dev(ctx.h, n, P, ap, bp, a_dev, int(method), int(lag_begin), n_lags,
-                                               _dev_out(out, (P, n_lags))))
-        return out
-    out = np.zeros((P, n_lags))
+        fn = ctx.lib.mdhip_xcorr_lags_dev_async if async_ else ctx.lib.mdhip_xcorr_lags_dev
+        ctx.check(fn(ctx.h, n, P, ap, bp, a_dev, int(method), int(lag_begin), n_lags, _dev_out(out, (P, n_lags), ctx=ctx)))
+        return Pending(ctx, out, keep=(a, b)) if async_ else out
+    out = result_array((P, n_lags), device=ctx.device, zero=True)
+    if async_:
+        if lag_begin:
+            raise ValueError("a lag range is asynchronous only with a device result buffer")
+        ctx.check(ctx.lib.mdhip_xcorr_async(ctx.h, n, P, ap, bp, a_dev, int(method), n_lags, ptr(out)))
+        return Pending(ctx, out[0] if single else out, keep=(a, b, k1))
     ctx.check(ctx.lib.mdhip_xcorr_lags(ctx.h, n, P, ap, bp, a_dev, int(method), int(lag_begin), n_lags, ptr(out)))
     return out[0] if single else out
 
 
-def cumtrapz(y, dx, leading_zero=False, ctx=None):
-    """Cumulative trapezoid (viscosity.py:151, conductivity.py:231): y [n] or [S,n]."""
+def cumtrapz(y, dx, leading_zero=False, ctx=None, out=None, async_=False):
+    """Cumulative trapezoid (viscosity.py:151, conductivity.py:231): y [n] or [S,n] (`out`: float64 CUDA tensor
+    [S, n-1 (+1)] that receives the integrals on the device)."""
     ctx = ctx or default_context()
     single = len(y.shape) == 1
     yp, on_dev, keep = as_input(y, ctx)
     shp = tuple(y.shape)
     S, n = (1, shp[0]) if single else shp
     m = n - 1 + (1 if leading_zero else 0)
-    out = np.zeros((S, max(m, 0)))
-    ctx.check(ctx.lib.mdhip_cumtrapz(ctx.h, n, S, yp, on_dev, float(dx), int(bool(leading_zero)), ptr(out)))
-    return out[0] if single else out
+    if out is not None:
+        fn = ctx.lib.mdhip_cumtrapz_dev_async if async_ else ctx.lib.mdhip_cumtrapz_dev
+        ctx.check(fn(ctx.h, n, S, yp, on_dev, float(dx), int(bool(leading_zero)), _dev_out(out, (S, max(m, 0)), ctx=ctx)))
+        return Pending(ctx, out, keep=keep) if async_ else out
+    out = result_array((S, max(m, 0)), device=ctx.device, zero=True)
+    fn = ctx.lib.mdhip_cumtrapz_async if async_ else ctx.lib.mdhip_cumtrapz
+    ctx.check(fn(ctx.h, n, S, yp, on_dev, float(dx), int(bool(leading_zero)), ptr(out)))
+    res = out[0] if single else out
+    return Pending(ctx, res, keep=keep) if async_ else res
+
+
+def green_kubo(a, b=None, method=XCORR_FFT, acf_scale=1.0, dx=1.0, integral_scale=1.0, leading_zero=False,
+               want_acf=True, want_mean=False, ctx=None, async_=False):
+    """
+    The Green-Kubo chain in ONE call, nothing but the results crossing the bus (mdhip_green_kubo):
+      acf      = xcorr(a, b) * acf_scale                      viscosity.py:178-184, conductivity.py:109-114
+      integral = integral_scale * cumtrapz(acf, dx)           viscosity.py:151-152, conductivity.py:229-231
+      mean     = integral.mean(axis=0)                        viscosity.py:189
+    a, b: [S, n] host arrays or CUDA tensors (b=None: autocorrelation). Returns (acf [S,n] or None, integral
+    [S, n-1 (+1)], mean [n-1 (+1)] or None); large results are page-locked arrays (written by DMA).
+    """
+    ctx = ctx or default_context()
+    ap, a_dev, k1 = as_input(a, ctx)
+    S, n = tuple(a.shape)
+    if b is None:
+        bp, k2 = ap, None
+    else:
+        bp, b_dev, k2 = as_input(b, ctx)
+        if b_dev != a_dev:
+            raise ValueError("a and b must both be host arrays or both device tensors")
+    m = n - 1 + (1 if leading_zero else 0)
+    acf = result_array((S, n), device=ctx.device) if want_acf else None
+    integral = result_array((S, max(m, 0)), device=ctx.device)
+    mean = result_array((max(m, 0),), device=ctx.device) if want_mean else None
+    fn = ctx.lib.mdhip_green_kubo_async if async_ else ctx.lib.mdhip_green_kubo
+    ctx.check(fn(ctx.h, n, S, ap, bp, a_dev, int(method), float(acf_scale), float(dx), float(integral_scale),
+                 int(bool(leading_zero)), None if acf is None else ptr(acf), ptr(integral),
+                 None if mean is None else ptr(mean)))
+    res = (acf, integral, mean)
+    return Pending(ctx, res, keep=(k1, k2)) if async_ else res
 
 
 bin_edges = _lib.bin_edges

@@ -6,7 +6,11 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <deque>
+#include <functional>
+#include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/mdhip.h"
@@ -51,6 +55,8 @@ enum WsSlot {
     WS_CEN,        // tile centres + half extents
     WS_FFT_TMP,    // second transform buffer of fft_pow2.hip for the large-lag MSD path
     WS_FFT_TW,     // two-level table of the roots of unity of order L (fft_pow2.hip), kept from call to call
+    WS_OUT2,       // second / third device result of a chained call (mdhip_green_kubo: running integrals, their mean)
+    WS_OUT3,
     WS_COUNT
 };
 
@@ -59,16 +65,55 @@ struct DevBuf {
     size_t cap = 0;
 };
 
-// Pinned host staging buffers (growable, owned by the context): small tables go to the device and results
-// come back through them, so that the copies are truly asynchronous and a call needs one stream sync.
-enum PinSlot { PIN_TYPES = 0, PIN_TABLES, PIN_OUT, PIN_COUNT };
+// Pinned host staging memory: blocks of a pool owned by the context. A call takes the blocks it needs (small tables on
+// their way to the device, results on their way back) and gives them back when it has COMPLETED — which for an
+// asynchronous call is later than its return, so the copies are truly asynchronous and nothing a queued copy still
+// reads is ever reused or freed under it.
+struct PinBlock {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+// What a completed call reports (mdhip_last_kernel_ms and friends; mdhip_call_stats for the calls before the last).
+struct CallStats {
+    double ms = 0.0, aux_ms = 0.0, rel_bound = 0.0;
+    int launches = 0;
+    const char *kernel = "";
+    long long ticket = 0;  // the call's number (mdhip_last_ticket)
+};
+
+// One invocation of an entry point. Everything it enqueues goes to the context's stream; what is left to do on the
+// host once that work has run (timer read-out, folding row sums, copying out of pinned staging, a rare re-run) is a list
+// of completion steps. A synchronous call completes before it returns; an asynchronous one (the *_async entry points)
+// returns with its work queued and completes inside mdhip_sync / mdhip_wait — in issue order.
+struct mdhip_call {
+    bool async = false;
+    bool ended = false;
+    mdhip_call *parent = nullptr;  // a call made from inside another one (always synchronous)
+    std::vector<PinBlock> pins;
+    std::vector<hipEvent_t> events;            // timing events, back to the pool at completion
+    std::vector<std::function<int()>> steps;   // run in order once `done` has fired; the first error ends the list
+    hipEvent_t done = nullptr;
+    CallStats stats;                           // kernel name / launches as set while the call was issued
+};
 
 struct mdhip_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    hipEvent_t ev2 = nullptr, ev3 = nullptr;  // second pair: preparation kernels, collected without a sync of their own
+    // calls (see mdhip_call): the one being issued, those issued asynchronously and not yet completed, and the pools
+    mdhip_call *cur = nullptr;
+    std::deque<mdhip_call *> inflight;
+    std::vector<PinBlock> pin_free;
+    std::vector<hipEvent_t> ev_free, done_free;
+    std::deque<CallStats> history;  // completed calls, newest first (bounded)
+    long long tickets = 0;          // top-level calls issued so far; the last one's number is mdhip_last_ticket
+    bool want_async = false;        // set by an *_async entry point for the call it is about to make
+    int completing = 0;             // > 0 while completion steps run (they may issue calls of their own)
+    int deferred_rc = 0;            // first error of an asynchronous call that was completed on behalf of a later one
+    std::string deferred_err;
+    int opt_sync_spin = 1;          // waiting for the stream: 1 poll the completion event (no interrupt wake-up latency)
+                                    // for up to 100 ms, then block; 0 block at once (A/B)
     // host-resident pair inputs: the frames of batch k+1 are copied on this stream while batch k is swept (created on
     // first use); one event per batch in flight
     hipStream_t copy_stream = nullptr;
@@ -77,7 +122,6 @@ struct mdhip_ctx {
     int opt_h2d_overlap = 1;  // 1 (default): overlapped staging of host-resident pair inputs, 0: one copy up front (A/B)
     std::string err;
     DevBuf ws[WS_COUNT];
-    DevBuf pin[PIN_COUNT];
     double last_ms = 0.0;
     double last_aux_ms = 0.0;  // device time of the preparation kernels of the last call (e.g. spatial sort)
     int last_launches = 0;
@@ -140,12 +184,21 @@ int mdhip_fft_r2c(mdhip_ctx *ctx, double *d_real, double2 *d_tmp, double2 *d_spe
 int mdhip_fft_c2r(mdhip_ctx *ctx, const double2 *d_spec, double2 *d_tmp, double *d_real, long long L, int batch);
 // the fused FFT estimator of xcorr.hip: series in, scaled lags out; buf0..3 hold batch * L/2 complex points each
 int mdhip_fft_xcorr(mdhip_ctx *ctx, const double *d_a, const double *d_b, long long n, long long L, int batch,
-                    double2 *buf0, double2 *buf1, double2 *buf2, double2 *buf3, long long n_lags, double *d_lags);
+                    double2 *buf0, double2 *buf1, double2 *buf2, double2 *buf3, long long n_lags, double *d_lags,
+                    double out_scale);
+// scan.hip: cumulative trapezoid of device series y [n_series][n] into d_out [n_series][n - 1 + lead], on the stream
+int mdhip_cumtrapz_enqueue(mdhip_ctx *ctx, int64_t n, int n_series, const double *d_y, double dx, int lead, double *d_out);
 
-int mdhip_lag_msd_fft(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *d_r, double scale,
-                      int max_lag, int n_groups, const int64_t *group_off, double *out, double *rel_bound);
 void *mdhip_ws(mdhip_ctx *ctx, int slot, size_t bytes);  // nullptr on failure (error set)
-void *mdhip_pin(mdhip_ctx *ctx, int slot, size_t bytes);  // pinned host memory; nullptr on failure (error set)
+// pinned host memory that belongs to the call being issued (ctx->cur) until it completes; nullptr on failure (error set)
+void *mdhip_pin(mdhip_ctx *ctx, size_t bytes);
+hipEvent_t mdhip_timer_event(mdhip_ctx *ctx);  // a timing event that belongs to the call being issued; nullptr on failure
+// Waits until everything queued on the context's stream so far has run (polling or blocking: opt_sync_spin).
+hipError_t mdhip_stream_wait(mdhip_ctx *ctx);
+mdhip_call *mdhip_call_begin(mdhip_ctx *ctx);
+int mdhip_call_end(mdhip_ctx *ctx, mdhip_call *call);      // see CallScope::end
+void mdhip_call_abandon(mdhip_ctx *ctx, mdhip_call *call);  // an error return: drain the stream, drop the steps
+int mdhip_complete_inflight(mdhip_ctx *ctx, size_t keep);  // completes all but the newest `keep` asynchronous calls
 
 #define MD_HIP(call)                                                                          \
     do {                                                                                      \
@@ -164,9 +217,98 @@ void *mdhip_pin(mdhip_ctx *ctx, int slot, size_t bytes);  // pinned host memory;
     type *var = (type *)mdhip_ws(ctx, slot, bytes);            \
     if (!var) return MDHIP_ENOMEM;
 
-#define MD_PIN(var, type, slot, bytes)                         \
-    type *var = (type *)mdhip_pin(ctx, slot, bytes);           \
+#define MD_PIN(var, type, bytes)                               \
+    type *var = (type *)mdhip_pin(ctx, bytes);                 \
     if (!var) return MDHIP_ENOMEM;
+
+// Scope of one entry-point invocation (see mdhip_call). Construct it first thing; `return cs.end()` on the way out
+// with success; every other return (MD_HIP / MD_REQUIRE failures) abandons the call in the destructor.
+struct CallScope {
+    mdhip_ctx *ctx;
+    mdhip_call *call;
+    explicit CallScope(mdhip_ctx *c) : ctx(c), call(c ? mdhip_call_begin(c) : nullptr) {}
+    CallScope(const CallScope &) = delete;
+    CallScope &operator=(const CallScope &) = delete;
+    ~CallScope()
+    {
+        if (call) mdhip_call_abandon(ctx, call);  // (never reached end(): an error return)
+    }
+    bool async() const { return call && call->async; }
+    bool ended() const { return call == nullptr; }
+    // host work to do once the queued device work has run: fn() -> MDHIP_* code
+    template <class F>
+    void defer(F &&fn)
+    {
+        call->steps.emplace_back(std::forward<F>(fn));
+    }
+    // Synchronous call: waits for the stream, runs the completion steps, returns the first error. Asynchronous call:
+    // leaves the call in flight and returns MDHIP_OK.
+    int end()
+    {
+        mdhip_call *c = call;
+        if (!c) return MDHIP_EINVAL;
+        call = nullptr;  // (the call object belongs to the context from here on: it may be gone when this returns)
+        return mdhip_call_end(ctx, c);
+    }
+};
+
+// What an *_async entry point does before it runs the body it shares with its synchronous twin: the next top-level
+// call of this context is issued asynchronously. Cleared on the way out whatever happened.
+struct AsyncCall {
+    mdhip_ctx *ctx;
+    explicit AsyncCall(mdhip_ctx *c) : ctx(c) { c->want_async = true; }
+    ~AsyncCall() { ctx->want_async = false; }
+};
+
+// msd_fft.hip: full-lag MSD through the autocorrelation theorem. d_r device [F][3][E]. Enqueues the transforms and
+// defers the long-hand finish: once the call has completed, res->out [max_lag+1][G][4] holds the means (as
+// mdhip_lag_msd) and res->bound the largest estimated relative rounding error over all (lag >= 1, group, axis) entries.
+struct LagFftResult {
+    std::vector<double> out;
+    std::vector<int64_t> group_off;
+    double bound = 0.0;
+};
+int mdhip_lag_msd_fft(CallScope &cs, int64_t n_frames, int64_t n_ent, const double *d_r, double scale, int max_lag,
+                      int n_groups, const int64_t *group_off, const std::shared_ptr<LagFftResult> &res);
+
+// A small host table on its way to device memory: through pinned staging of the call, so that the copy is asynchronous
+// and the caller's (or this function's) memory may go away at once.
+static inline int mdhip_h2d_small(mdhip_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes)
+{
+    if (bytes == 0) return MDHIP_OK;
+    void *h = mdhip_pin(ctx, bytes);
+    if (!h) return MDHIP_ENOMEM;
+    memcpy(h, src_host, bytes);
+    MD_HIP(hipMemcpyAsync(dst_dev, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return MDHIP_OK;
+}
+
+// A result on its way to the caller. Device destination: a device-to-device copy on the stream. Host destination: up to
+// MD_STAGE_MAX bytes go through pinned staging of the call (asynchronous copy now, memcpy in a completion step);
+// larger results are copied straight into the caller's memory (a DMA when that memory is page-locked, else the
+// runtime's own staged copy, which blocks the host until it is done — correct either way).
+constexpr size_t MD_STAGE_MAX = (size_t)4 << 20;
+static inline int mdhip_result(CallScope &cs, void *dst, const void *d_src, size_t bytes, int dst_on_device)
+{
+    mdhip_ctx *ctx = cs.ctx;
+    if (bytes == 0) return MDHIP_OK;
+    if (dst_on_device) {
+        MD_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        return MDHIP_OK;
+    }
+    if (bytes > MD_STAGE_MAX) {
+        MD_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        return MDHIP_OK;
+    }
+    void *h = mdhip_pin(ctx, bytes);
+    if (!h) return MDHIP_ENOMEM;
+    MD_HIP(hipMemcpyAsync(h, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    cs.defer([dst, h, bytes]() {
+        memcpy(dst, h, bytes);
+        return MDHIP_OK;
+    });
+    return MDHIP_OK;
+}
 
 // Stage `bytes` from a host-or-device source into workspace `slot` unless it is already on the device.
 static inline const void *mdhip_stage(mdhip_ctx *ctx, int slot, const void *src, size_t bytes,
@@ -196,7 +338,7 @@ static inline hipError_t mdhip_deliver(mdhip_ctx *ctx, void *dst, const void *d_
                           ctx->stream);
 }
 
-// Zeroes a result buffer (host: at once; device: on the stream, complete on return).
+// Zeroes a result buffer (host: at once; device: on the stream — complete when the call is).
 static inline int mdhip_zero_result(mdhip_ctx *ctx, void *dst, size_t bytes, int dst_on_device)
 {
     if (bytes == 0 || !dst) return MDHIP_OK;
@@ -204,30 +346,32 @@ static inline int mdhip_zero_result(mdhip_ctx *ctx, void *dst, size_t bytes, int
         memset(dst, 0, bytes);
         return MDHIP_OK;
     }
-    hipError_t e = hipMemsetAsync(dst, 0, bytes, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    const hipError_t e = hipMemsetAsync(dst, 0, bytes, ctx->stream);
     if (e != hipSuccess) return mdhip_fail(ctx, MDHIP_EHIP, "zeroing a device result failed: %s", hipGetErrorString(e));
     return MDHIP_OK;
 }
 
+// Device time of a run of launches: an event pair of the call being issued. collect() belongs in a completion step
+// (the events have fired by then); the main timer's value becomes the call's `ms`, an `aux` timer's is returned only.
 struct KernelTimer {
     mdhip_ctx *ctx;
     hipEvent_t e0, e1;
-    // aux = true: the second event pair (preparation kernels); collect() then returns the time instead of
-    // storing it in last_ms
-    explicit KernelTimer(mdhip_ctx *c, int launches = 1, bool aux = false)
-        : ctx(c), e0(aux ? c->ev2 : c->ev0), e1(aux ? c->ev3 : c->ev1)
+    bool aux;
+    explicit KernelTimer(mdhip_ctx *c, int launches = 1, bool aux_ = false)
+        : ctx(c), e0(mdhip_timer_event(c)), e1(mdhip_timer_event(c)), aux(aux_)
     {
         if (!aux) ctx->last_launches = launches;
-        (void)hipEventRecord(e0, ctx->stream);
+        if (e0) (void)hipEventRecord(e0, ctx->stream);
     }
-    void stop() { (void)hipEventRecord(e1, ctx->stream); }
-    // call after the stream has been synchronised
-    double collect()
+    void stop()
+    {
+        if (e1) (void)hipEventRecord(e1, ctx->stream);
+    }
+    double collect() const
     {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return 0.0;
-        if (e0 == ctx->ev0) ctx->last_ms = ms;
+        if (!e0 || !e1 || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return 0.0;
+        if (!aux) ctx->last_ms = ms;
         return ms;
     }
 };

@@ -87,6 +87,8 @@ struct PassIo {
     double *lags;          // OUT_LAGS: [batch][n_lags]; the complex result y = conj(v) holds c[2o] = Re, c[2o+1] = Im,
     long long n_lags;      //           lags[t] = (c[t] / L) / (n - t) for t < n_lags
     double L;
+    double scale;          //           ... times `scale` (a unit factor of the caller: one more rounding, as a multiplication
+                           //           of the finished array would be; 1.0 leaves every value as it is)
     const double2 *zb;     // IN_SPEC: the second series' transform [batch][H] (nullptr: autocorrelation, Zb = Za = `in`)
 };
 
@@ -187,8 +189,8 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass_kernel(const double2 *__
         const long long o = q + s * (((long long)p << logR) + j);
         if (OUT == OUT_LAGS) {
             const long long t = 2 * o;
-            if (t < io.n_lags) lags[t] = (v.x / io.L) / (double)(io.n - t);
-            if (t + 1 < io.n_lags) lags[t + 1] = (-v.y / io.L) / (double)(io.n - t - 1);
+            if (t < io.n_lags) lags[t] = ((v.x / io.L) / (double)(io.n - t)) * io.scale;
+            if (t + 1 < io.n_lags) lags[t + 1] = ((-v.y / io.L) / (double)(io.n - t - 1)) * io.scale;
         } else {
             if (OUT == OUT_CONJ) v.y = -v.y;
             out[o] = v;
@@ -488,8 +490,8 @@ __global__ __launch_bounds__(1024) void fft_pass8_kernel(const double2 *__restri
         const long long o = q + s * (((long long)p << logR) + j);
         if (OUT == OUT_LAGS) {
             const long long t = 2 * o;
-            if (t < io.n_lags) lags[t] = (v.x / io.L) / (double)(io.n - t);
-            if (t + 1 < io.n_lags) lags[t + 1] = (-v.y / io.L) / (double)(io.n - t - 1);
+            if (t < io.n_lags) lags[t] = ((v.x / io.L) / (double)(io.n - t)) * io.scale;
+            if (t + 1 < io.n_lags) lags[t + 1] = ((-v.y / io.L) / (double)(io.n - t - 1)) * io.scale;
         } else {
             if (OUT == OUT_CONJ) v.y = -v.y;
             out[o] = v;
@@ -802,7 +804,8 @@ int mdhip_fft_c2r(mdhip_ctx *ctx, const double2 *d_spec, double2 *d_tmp, double 
 // (half spectra, product, inverse-transform input), the inverse passes (the last writes the scaled lags).
 // buf0..buf3 hold batch * L/2 complex points each (buf2, buf3 unused for an autocorrelation).
 int mdhip_fft_xcorr(mdhip_ctx *ctx, const double *d_a, const double *d_b, long long n, long long L, int batch,
-                    double2 *buf0, double2 *buf1, double2 *buf2, double2 *buf3, long long n_lags, double *d_lags)
+                    double2 *buf0, double2 *buf1, double2 *buf2, double2 *buf3, long long n_lags, double *d_lags,
+                    double out_scale)
 {
     MD_REQUIRE(L >= 4 && (L & (L - 1)) == 0 && L >= 2 * n, "bad transform length %lld for %lld samples", L, n);
     MD_REQUIRE(batch <= 65535, "more than 65535 series per launch");
@@ -837,6 +840,7 @@ int mdhip_fft_xcorr(mdhip_ctx *ctx, const double *d_a, const double *d_b, long l
     io.lags = d_lags;
     io.n_lags = n_lags;
     io.L = (double)L;
+    io.scale = out_scale;
     io.zb = same ? nullptr : Zb;
     if (!fft_forward(ctx, Za, Za == buf0 ? buf1 : buf0, H, batch, fuse ? IN_SPEC : IN_PLAIN, OUT_LAGS, io, tt)) return MDHIP_EHIP;
     MD_HIP(hipGetLastError());

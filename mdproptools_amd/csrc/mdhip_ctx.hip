@@ -1,6 +1,7 @@
 // mdhip_ctx.hip — lifecycle, workspace, options and the host-side bin-edge table.
 #include <cmath>
 #include <cstdlib>
+#include <ctime>
 
 #include "ctx.h"
 
@@ -45,28 +46,212 @@ void *mdhip_ws(mdhip_ctx *ctx, int slot, size_t bytes)
     return b.p;
 }
 
-void *mdhip_pin(mdhip_ctx *ctx, int slot, size_t bytes)
+void *mdhip_pin(mdhip_ctx *ctx, size_t bytes)
 {
-    DevBuf &b = ctx->pin[slot];
-    if (bytes == 0) bytes = 16;
-    if (b.cap >= bytes) return b.p;
-    if (b.p) {
-        (void)hipStreamSynchronize(ctx->stream);
-        (void)hipHostFree(b.p);
-        b.p = nullptr;
-        b.cap = 0;
-    }
-    size_t cap = bytes + (bytes >> 2);
-    cap = (cap + 4095) & ~size_t(4095);
-    hipError_t e = hipHostMalloc(&b.p, cap, hipHostMallocDefault);
-    if (e != hipSuccess) {
-        b.p = nullptr;
-        mdhip_fail(ctx, MDHIP_ENOMEM, "hipHostMalloc(%zu) failed for staging buffer %d: %s", cap, slot,
-                   hipGetErrorString(e));
+    if (!ctx->cur) {
+        mdhip_fail(ctx, MDHIP_EINVAL, "internal: pinned staging requested outside a call");
         return nullptr;
     }
-    b.cap = cap;
+    if (bytes == 0) bytes = 16;
+    // the smallest free block that is large enough
+    int best = -1;
+    for (size_t k = 0; k < ctx->pin_free.size(); ++k)
+        if (ctx->pin_free[k].cap >= bytes && (best < 0 || ctx->pin_free[k].cap < ctx->pin_free[(size_t)best].cap))
+            best = (int)k;
+    PinBlock b;
+    if (best >= 0) {
+        b = ctx->pin_free[(size_t)best];
+        ctx->pin_free.erase(ctx->pin_free.begin() + best);
+    } else {
+        size_t cap = bytes + (bytes >> 2);
+        if (cap < 65536) cap = 65536;
+        cap = (cap + 4095) & ~size_t(4095);
+        const hipError_t e = hipHostMalloc(&b.p, cap, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            mdhip_fail(ctx, MDHIP_ENOMEM, "hipHostMalloc(%zu) failed for a staging block: %s", cap, hipGetErrorString(e));
+            return nullptr;
+        }
+        b.cap = cap;
+    }
+    ctx->cur->pins.push_back(b);
     return b.p;
+}
+
+hipEvent_t mdhip_timer_event(mdhip_ctx *ctx)
+{
+    hipEvent_t e = nullptr;
+    if (!ctx->ev_free.empty()) {
+        e = ctx->ev_free.back();
+        ctx->ev_free.pop_back();
+    } else if (hipEventCreate(&e) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    if (ctx->cur)
+        ctx->cur->events.push_back(e);
+    else
+        ctx->ev_free.push_back(e);  // (no call to own it: usable at once, never collected)
+    return e;
+}
+
+static inline void cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#endif
+}
+
+// Polls `ev` (already recorded) instead of sleeping on it: a blocked host thread is woken by an interrupt and pays the
+// scheduler's latency on top — tens of microseconds on a quiet host, milliseconds on a busy one — and the calls of this
+// library are a few milliseconds long. After 100 ms of polling the wait turns into a blocking one.
+static hipError_t wait_event(mdhip_ctx *ctx, hipEvent_t ev)
+{
+    if (ctx->opt_sync_spin) {
+        timespec t0;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (unsigned it = 0;; ++it) {
+            const hipError_t q = hipEventQuery(ev);
+            if (q != hipErrorNotReady) return q;
+            for (int k = 0; k < 32; ++k) cpu_relax();
+            if ((it & 63) == 63) {
+                timespec t1;
+                clock_gettime(CLOCK_MONOTONIC, &t1);
+                if ((t1.tv_sec - t0.tv_sec) * 1000000000LL + (t1.tv_nsec - t0.tv_nsec) > 100000000LL) break;
+            }
+        }
+    }
+    return hipEventSynchronize(ev);
+}
+
+static hipEvent_t take_done_event(mdhip_ctx *ctx)
+{
+    hipEvent_t e = nullptr;
+    if (!ctx->done_free.empty()) {
+        e = ctx->done_free.back();
+        ctx->done_free.pop_back();
+        return e;
+    }
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return e;
+}
+
+hipError_t mdhip_stream_wait(mdhip_ctx *ctx)
+{
+    if (!ctx->opt_sync_spin) return hipStreamSynchronize(ctx->stream);
+    hipEvent_t e = take_done_event(ctx);
+    if (!e) return hipStreamSynchronize(ctx->stream);
+    hipError_t rc = hipEventRecord(e, ctx->stream);
+    if (rc == hipSuccess) rc = wait_event(ctx, e);
+    ctx->done_free.push_back(e);
+    return rc;
+}
+
+mdhip_call *mdhip_call_begin(mdhip_ctx *ctx)
+{
+    mdhip_call *c = new mdhip_call();
+    c->parent = ctx->cur;
+    c->async = ctx->want_async && ctx->cur == nullptr && ctx->completing == 0;
+    ctx->want_async = false;
+    if (!c->parent && ctx->completing == 0) c->stats.ticket = ++ctx->tickets;
+    ctx->cur = c;
+    // the registers a call reports through start from nothing: what is in them when the call has been issued is its own
+    ctx->last_ms = 0.0;
+    ctx->last_aux_ms = 0.0;
+    ctx->last_launches = 0;
+    ctx->last_kernel = "";
+    return c;
+}
+
+static void release_call(mdhip_ctx *ctx, mdhip_call *c)
+{
+    for (const PinBlock &b : c->pins) ctx->pin_free.push_back(b);
+    for (hipEvent_t e : c->events) ctx->ev_free.push_back(e);
+    if (c->done) ctx->done_free.push_back(c->done);
+    delete c;
+}
+
+// The call's queued work has to be over: waits for its `done` event, runs the completion steps, records the stats.
+static int complete_call(mdhip_ctx *ctx, mdhip_call *c)
+{
+    int rc = MDHIP_OK;
+    hipError_t e = c->done ? wait_event(ctx, c->done) : mdhip_stream_wait(ctx);
+    if (e != hipSuccess) rc = mdhip_fail(ctx, MDHIP_EHIP, "waiting for a call's device work failed: %s", hipGetErrorString(e));
+    // the registers the steps work on start from what the call set while it was issued (a part of the work that
+    // completed inside the call has its times there already)
+    ctx->last_ms = c->stats.ms;
+    ctx->last_aux_ms = c->stats.aux_ms;
+    ctx->last_kernel = c->stats.kernel;
+    ctx->last_launches = c->stats.launches;
+    ctx->last_rel_bound = c->stats.rel_bound;
+    ++ctx->completing;
+    for (size_t k = 0; k < c->steps.size() && rc == MDHIP_OK; ++k) rc = c->steps[k]();
+    --ctx->completing;
+    CallStats st;
+    st.ticket = c->stats.ticket;
+    st.ms = ctx->last_ms;
+    st.aux_ms = ctx->last_aux_ms;
+    st.launches = ctx->last_launches;
+    st.kernel = ctx->last_kernel;
+    st.rel_bound = ctx->last_rel_bound;
+    ctx->history.push_front(st);
+    if (ctx->history.size() > 64) ctx->history.pop_back();
+    release_call(ctx, c);
+    return rc;
+}
+
+int mdhip_complete_inflight(mdhip_ctx *ctx, size_t keep)
+{
+    int first = MDHIP_OK;
+    while (ctx->inflight.size() > keep) {
+        mdhip_call *c = ctx->inflight.front();
+        ctx->inflight.pop_front();
+        const int rc = complete_call(ctx, c);
+        if (rc != MDHIP_OK && first == MDHIP_OK) {
+            first = rc;
+            ctx->deferred_err = ctx->err;
+        }
+    }
+    return first;
+}
+
+int mdhip_call_end(mdhip_ctx *ctx, mdhip_call *c)
+{
+    c->ended = true;
+    ctx->cur = c->parent;
+    c->stats.ms = ctx->last_ms;
+    c->stats.aux_ms = ctx->last_aux_ms;
+    c->stats.kernel = ctx->last_kernel;
+    c->stats.launches = ctx->last_launches;
+    c->stats.rel_bound = ctx->last_rel_bound;
+    c->done = take_done_event(ctx);
+    if (c->done && hipEventRecord(c->done, ctx->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->done_free.push_back(c->done);
+        c->done = nullptr;  // complete_call then drains the stream instead
+    }
+    if (c->async) {
+        ctx->inflight.push_back(c);
+        return MDHIP_OK;
+    }
+    // a synchronous call: everything issued before it completes first (stream order) — unless this call was made from
+    // inside a completion step, which only answers for itself
+    if (!c->parent && ctx->completing == 0) {
+        const int prev = mdhip_complete_inflight(ctx, 0);
+        if (prev != MDHIP_OK && ctx->deferred_rc == MDHIP_OK) ctx->deferred_rc = prev;
+    }
+    return complete_call(ctx, c);
+}
+
+void mdhip_call_abandon(mdhip_ctx *ctx, mdhip_call *c)
+{
+    // queued copies may still read the call's staging blocks
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipGetLastError();
+    ctx->cur = c->parent;
+    release_call(ctx, c);
 }
 
 extern "C" {
@@ -111,11 +296,9 @@ int mdhip_create(mdhip_ctx **out, int device)
         ctx->lds_max = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor
                                                               : 65536;
     }
-    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
-        hipEventCreate(&ctx->ev2) != hipSuccess || hipEventCreate(&ctx->ev3) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
-        return mdhip_fail(nullptr, MDHIP_EHIP, "mdhip_create: stream/event creation failed");
+        return mdhip_fail(nullptr, MDHIP_EHIP, "mdhip_create: stream creation failed");
     }
     ctx->stream = ctx->own_stream;
     if (const char *v = getenv("MDHIP_RDF_VARIANT")) ctx->opt_rdf_variant = atoi(v);  // A/B knobs
@@ -131,47 +314,102 @@ void mdhip_destroy(mdhip_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    (void)mdhip_complete_inflight(ctx, 0);  // (results of calls nobody waited for still reach their destinations)
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &b : ctx->ws)
         if (b.p) (void)hipFree(b.p);
-    for (auto &b : ctx->pin)
+    for (auto &b : ctx->pin_free)
         if (b.p) (void)hipHostFree(b.p);
-    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
-    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (hipEvent_t e : ctx->ev_free) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->done_free) (void)hipEventDestroy(e);
     if (ctx->copy_stream) {
         (void)hipStreamSynchronize(ctx->copy_stream);
         (void)hipStreamDestroy(ctx->copy_stream);
     }
     for (auto &e : ctx->copy_ev)
         if (e) (void)hipEventDestroy(e);
-    if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
-    if (ctx->ev3) (void)hipEventDestroy(ctx->ev3);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
 
 const char *mdhip_last_error(mdhip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
+// first error of the asynchronous calls completed so far that nobody has been told about, then `rc`
+static int take_deferred(mdhip_ctx *ctx, int rc)
+{
+    if (ctx->deferred_rc != MDHIP_OK) {
+        const int d = ctx->deferred_rc;
+        ctx->deferred_rc = MDHIP_OK;
+        if (!ctx->deferred_err.empty()) ctx->err = ctx->deferred_err;
+        ctx->deferred_err.clear();
+        return d;
+    }
+    if (rc != MDHIP_OK && !ctx->deferred_err.empty()) {
+        ctx->err = ctx->deferred_err;
+        ctx->deferred_err.clear();
+    }
+    return rc;
+}
+
 int mdhip_set_stream(mdhip_ctx *ctx, void *hip_stream)
 {
     if (!ctx) return MDHIP_EINVAL;
+    MD_HIP(hipSetDevice(ctx->device));
+    const int rc = mdhip_complete_inflight(ctx, 0);
     MD_HIP(hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
-    return MDHIP_OK;
+    return take_deferred(ctx, rc);
 }
 
 int mdhip_sync(mdhip_ctx *ctx)
 {
     if (!ctx) return MDHIP_EINVAL;
-    MD_HIP(hipStreamSynchronize(ctx->stream));
-    return MDHIP_OK;
+    MD_HIP(hipSetDevice(ctx->device));
+    const int rc = mdhip_complete_inflight(ctx, 0);
+    const hipError_t e = mdhip_stream_wait(ctx);
+    if (e != hipSuccess && rc == MDHIP_OK && ctx->deferred_rc == MDHIP_OK)
+        return mdhip_fail(ctx, MDHIP_EHIP, "mdhip_sync: %s", hipGetErrorString(e));
+    return take_deferred(ctx, rc);
 }
+
+int mdhip_wait(mdhip_ctx *ctx, int keep_in_flight)
+{
+    if (!ctx) return MDHIP_EINVAL;
+    MD_HIP(hipSetDevice(ctx->device));
+    return take_deferred(ctx, mdhip_complete_inflight(ctx, keep_in_flight > 0 ? (size_t)keep_in_flight : 0));
+}
+
+int mdhip_pending(mdhip_ctx *ctx) { return ctx ? (int)ctx->inflight.size() : 0; }
 
 double mdhip_last_kernel_ms(mdhip_ctx *ctx, int *n_launches)
 {
     if (!ctx) return 0.0;
     if (n_launches) *n_launches = ctx->last_launches;
     return ctx->last_ms;
+}
+
+long long mdhip_last_ticket(mdhip_ctx *ctx) { return ctx ? ctx->tickets : 0; }
+
+int mdhip_ticket_stats(mdhip_ctx *ctx, long long ticket, double *kernel_ms, double *aux_ms, int *n_launches,
+                       const char **kernel)
+{
+    if (!ctx) return MDHIP_EINVAL;
+    for (size_t k = 0; k < ctx->history.size(); ++k)
+        if (ctx->history[k].ticket == ticket && ticket > 0) return mdhip_call_stats(ctx, (int)k, kernel_ms, aux_ms, n_launches, kernel);
+    return mdhip_fail(ctx, MDHIP_EINVAL, "mdhip_ticket_stats: call %lld has not completed, or more than 64 calls ago", ticket);
+}
+
+int mdhip_call_stats(mdhip_ctx *ctx, int back, double *kernel_ms, double *aux_ms, int *n_launches, const char **kernel)
+{
+    if (!ctx) return MDHIP_EINVAL;
+    if (back < 0 || (size_t)back >= ctx->history.size())
+        return mdhip_fail(ctx, MDHIP_EINVAL, "mdhip_call_stats: only %zu completed calls are remembered", ctx->history.size());
+    const CallStats &st = ctx->history[(size_t)back];
+    if (kernel_ms) *kernel_ms = st.ms;
+    if (aux_ms) *aux_ms = st.aux_ms;
+    if (n_launches) *n_launches = st.launches;
+    if (kernel) *kernel = st.kernel;
+    return MDHIP_OK;
 }
 
 double mdhip_last_aux_ms(mdhip_ctx *ctx) { return ctx ? ctx->last_aux_ms : 0.0; }
@@ -272,6 +510,8 @@ int mdhip_set_option(mdhip_ctx *ctx, const char *key, int value)
         ctx->opt_lag_fft_kernel = value;
     else if (!strcmp(key, "h2d_overlap"))
         ctx->opt_h2d_overlap = value;
+    else if (!strcmp(key, "sync_spin"))
+        ctx->opt_sync_spin = value;
     else
         return mdhip_fail(ctx, MDHIP_EINVAL, "mdhip_set_option: unknown key '%s'", key);
     return MDHIP_OK;

@@ -558,6 +558,7 @@ int msd_pairs_impl(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double
                    const double *origin = nullptr, int origin_on_device = 0)
 {
     if (!ctx) return MDHIP_EINVAL;
+    CallScope cs(ctx);
     MD_REQUIRE(n_frames >= 0 && n_ent >= 0 && n_pairs >= 0, "negative sizes");
     MD_REQUIRE(n_pairs == 0 || (pairs && sums), "NULL pairs/sums");
     for (int p = 0; p < 2 * n_pairs; ++p)
@@ -570,7 +571,7 @@ int msd_pairs_impl(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double
     MD_HIP(hipSetDevice(ctx->device));
     rc = mdhip_zero_result(ctx, sums, (size_t)n_pairs * n_groups * 4 * 8, sums_on_device);
     if (rc) return rc;
-    if (n_pairs == 0 || chunks.empty()) return MDHIP_OK;
+    if (n_pairs == 0 || chunks.empty()) return cs.end();
     MD_REQUIRE(r != nullptr, "r is NULL");
     MD_REQUIRE(n_pairs <= 65535, "at most 65535 frame pairs per call");
     const double *d_r =
@@ -582,17 +583,25 @@ int msd_pairs_impl(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double
         if (rc) return rc;
     }
     const int n_chunks = (int)chunks.size();
-    const size_t tab_b = (size_t)n_pairs * 8 + chunks.size() * sizeof(Chunk) + gco.size() * 4;
+    // chunks | pairs | group -> chunk offsets: one pinned staging block, one copy
+    const size_t ch_b = chunks.size() * sizeof(Chunk), pr_b = (size_t)n_pairs * 8, gc_b = gco.size() * 4;
+    const size_t tab_b = ch_b + pr_b + gc_b;
     MD_WS(d_tab, unsigned char, WS_TABLES, tab_b + 64);
+    MD_PIN(h_tab, unsigned char, tab_b);
+    memcpy(h_tab, chunks.data(), ch_b);
+    memcpy(h_tab + ch_b, pairs, pr_b);
+    memcpy(h_tab + ch_b + pr_b, gco.data(), gc_b);
+    MD_HIP(hipMemcpyAsync(d_tab, h_tab, tab_b, hipMemcpyHostToDevice, ctx->stream));
     Chunk *d_chunks = reinterpret_cast<Chunk *>(d_tab);
-    int *d_pairs = reinterpret_cast<int *>(d_tab + chunks.size() * sizeof(Chunk));
+    int *d_pairs = reinterpret_cast<int *>(d_tab + ch_b);
     int *d_gco = d_pairs + 2 * n_pairs;
-    MD_HIP(hipMemcpyAsync(d_chunks, chunks.data(), chunks.size() * sizeof(Chunk), hipMemcpyHostToDevice, ctx->stream));
-    MD_HIP(hipMemcpyAsync(d_pairs, pairs, (size_t)n_pairs * 8, hipMemcpyHostToDevice, ctx->stream));
-    MD_HIP(hipMemcpyAsync(d_gco, gco.data(), gco.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     MD_WS(d_partial, double, WS_PART, (size_t)n_pairs * n_chunks * 4 * 8);
     const size_t sums_b = (size_t)n_pairs * n_groups * 4 * 8;
-    MD_WS(d_sums, double, WS_OUT, sums_b);
+    double *d_sums = sums;
+    if (!sums_on_device) {
+        d_sums = (double *)mdhip_ws(ctx, WS_OUT, sums_b);
+        if (!d_sums) return MDHIP_ENOMEM;
+    }
     double *d_pe = nullptr;
     const size_t pe_b = (size_t)n_pairs * n_ent * 4 * 8;
     if (per_entity) {
@@ -601,7 +610,6 @@ int msd_pairs_impl(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double
     }
     const long long col_len = (long long)n_pairs * n_ent;
     const long long d_stride = col_stride ? (pe_on_device ? (long long)col_stride : col_len) : 0;
-    MD_HIP(hipStreamSynchronize(ctx->stream));  // host tables are stack/vector memory
     KernelTimer timer(ctx);
     ctx->last_kernel = "msd_pairs_kernel";
     // 16-byte loads need 16-byte aligned planes and even chunk starts
@@ -622,8 +630,12 @@ int msd_pairs_impl(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double
     hipLaunchKernelGGL(msd_group_sum_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0,
                        ctx->stream, d_partial, d_gco, n_chunks, n_groups, n_pairs, d_sums);
     MD_HIP(hipGetLastError());
-    MD_HIP(mdhip_deliver(ctx, sums, d_sums, sums_b, sums_on_device));
+    if (!sums_on_device) {
+        rc = mdhip_result(cs, sums, d_sums, sums_b, 0);
+        if (rc) return rc;
+    }
     if (per_entity && !pe_on_device) {
+        // (F x E x 4 values: straight into the caller's memory, see mdhip_result)
         if (!col_stride || col_stride == col_len) {
             MD_HIP(hipMemcpyAsync(per_entity, d_pe, pe_b, hipMemcpyDeviceToHost, ctx->stream));
         } else {
@@ -632,9 +644,11 @@ int msd_pairs_impl(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double
                                       (size_t)col_len * 8, hipMemcpyDeviceToHost, ctx->stream));
         }
     }
-    MD_HIP(hipStreamSynchronize(ctx->stream));
-    timer.collect();
-    return MDHIP_OK;
+    cs.defer([timer]() {
+        timer.collect();
+        return MDHIP_OK;
+    });
+    return cs.end();
 }
 
 }  // namespace
@@ -665,17 +679,25 @@ static int msd_windows_impl(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, con
                             double scale, int tao, double *win_sums, int out_on_device)
 {
     if (!ctx) return MDHIP_EINVAL;
+    CallScope cs(ctx);
     MD_REQUIRE(n_frames >= 0 && n_ent >= 0 && tao >= 1, "bad sizes");
     MD_REQUIRE(n_ent == 0 || win_sums, "win_sums is NULL");
-    if (n_ent == 0) return MDHIP_OK;
+    if (n_ent == 0) return cs.end();
     MD_HIP(hipSetDevice(ctx->device));
     int rc;
-    if (n_frames == 0) return mdhip_zero_result(ctx, win_sums, (size_t)n_ent * 4 * 8, out_on_device);
+    if (n_frames == 0) {
+        rc = mdhip_zero_result(ctx, win_sums, (size_t)n_ent * 4 * 8, out_on_device);
+        return rc ? rc : cs.end();
+    }
     MD_REQUIRE(r != nullptr, "r is NULL");
     const double *d_r =
         (const double *)mdhip_stage(ctx, WS_XYZ_I, r, (size_t)n_frames * 3 * n_ent * 8, on_device, &rc);
     if (rc) return rc;
-    MD_WS(d_out, double, WS_OUT, (size_t)n_ent * 4 * 8);
+    double *d_out = win_sums;
+    if (!out_on_device) {
+        d_out = (double *)mdhip_ws(ctx, WS_OUT, (size_t)n_ent * 4 * 8);
+        if (!d_out) return MDHIP_ENOMEM;
+    }
     const long long n_kept = (n_frames + tao - 1) / tao;
     const long long n_blocks_e = (n_ent + 255) / 256;
     long long n_slabs = ((long long)ctx->cu_count * 8 + n_blocks_e - 1) / n_blocks_e;
@@ -691,10 +713,15 @@ static int msd_windows_impl(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, con
                        ctx->stream, d_part, (long long)n_ent, (int)n_slabs, d_out);
     timer.stop();
     MD_HIP(hipGetLastError());
-    MD_HIP(mdhip_deliver(ctx, win_sums, d_out, (size_t)n_ent * 4 * 8, out_on_device));
-    MD_HIP(hipStreamSynchronize(ctx->stream));
-    timer.collect();
-    return MDHIP_OK;
+    if (!out_on_device) {
+        rc = mdhip_result(cs, win_sums, d_out, (size_t)n_ent * 4 * 8, 0);
+        if (rc) return rc;
+    }
+    cs.defer([timer]() {
+        timer.collect();
+        return MDHIP_OK;
+    });
+    return cs.end();
 }
 
 int mdhip_msd_windows(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r,
@@ -738,11 +765,28 @@ int mdhip_msd_pairs_dev(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const d
                           nullptr, 0, 0, 1);
 }
 
+// A host result [n_lags][G][4] that is ready in `src` goes to the caller: host memory at once, device memory through a
+// copy of its own (a small call inside the completion step that runs this).
+static int deliver_host_values(mdhip_ctx *ctx, const double *src, size_t bytes, double *dst, int dst_on_device)
+{
+    if (!dst_on_device) {
+        memcpy(dst, src, bytes);
+        return MDHIP_OK;
+    }
+    CallScope cs(ctx);
+    const int rc = mdhip_h2d_small(ctx, dst, src, bytes);
+    if (rc) return rc;
+    return cs.end();
+}
+
+// force_variant >= 0: that lag_variant instead of the context's option (the fallback of the spectral path)
 static int lag_msd_impl(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r, int on_device,
                         double scale, int max_lag, int n_groups, const int64_t *group_off, double *out,
-                        int out_on_device)
+                        int out_on_device, int force_variant = -1)
 {
     if (!ctx) return MDHIP_EINVAL;
+    CallScope cs(ctx);
+    const int variant = force_variant >= 0 ? force_variant : ctx->opt_lag_variant;
     MD_REQUIRE(n_frames >= 0 && n_ent >= 0 && max_lag >= 0, "negative sizes");
     MD_REQUIRE(max_lag < n_frames || n_frames == 0, "max_lag must be < n_frames");
     MD_REQUIRE(out != nullptr, "out is NULL");
@@ -753,7 +797,7 @@ static int lag_msd_impl(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const d
     int lds_row = (int)((n_frames + 536 + 7) / 8) + 1;
     lds_row |= 1;  // odd row length: the 8 rows of the transposed layout start in different banks
     const size_t lds_b = (size_t)(9 * lds_row + 8) * 8;  // 8 lds_row entries + one pad double per 8
-    const bool resident = ctx->opt_lag_variant != 0 && lds_b <= ctx->lds_max - 1024 && n_frames < (1 << 30);
+    const bool resident = variant != 0 && lds_b <= ctx->lds_max - 1024 && n_frames < (1 << 30);
     const int r_tiles = (int)((n_lags + 64 * LG_LPT - 1) / (64 * LG_LPT));
     const int r_pairs = (r_tiles + 1) / 2;
     const int r_gx = (r_pairs + 7) / 8;                 // blocks per entity chunk
@@ -789,46 +833,52 @@ static int lag_msd_impl(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const d
     const size_t res_b = (size_t)n_lags * n_groups * 4 * 8;
     rc = mdhip_zero_result(ctx, out, res_b, out_on_device);
     if (rc) return rc;
-    if (n_frames == 0 || chunks.empty()) return MDHIP_OK;
+    if (n_frames == 0 || chunks.empty()) return cs.end();
     MD_REQUIRE(r != nullptr, "r is NULL");
     MD_REQUIRE(chunks.size() <= 65535, "too many entity chunks (%zu)", chunks.size());
     const size_t r_b = (size_t)n_frames * 3 * n_ent * 8;
     const double *d_r = (const double *)mdhip_stage(ctx, WS_XYZ_I, r, r_b, on_device, &rc);
     if (rc) return rc;
     ctx->last_rel_bound = 0.0;
-    if (ctx->opt_lag_variant >= 2 && ctx->opt_lag_variant <= 4) {
-        double bound = 0.0;
+    if (variant >= 2 && variant <= 4) {
         // the spectral path finishes on the host (prefix sums of the squares, S1 - 2 S2, division by the counts, in
-        // long-hand double arithmetic over [n_lags][n_groups][4] values); a device destination gets those values copied in
-        std::vector<double> host_out;
-        if (out_on_device) host_out.assign((size_t)n_lags * n_groups * 4, 0.0);
-        rc = mdhip_lag_msd_fft(ctx, n_frames, n_ent, d_r, scale, max_lag, n_groups, group_off,
-                               out_on_device ? host_out.data() : out, &bound);
+        // long-hand arithmetic over [n_lags][n_groups][4] values) in a completion step; that step also decides whether
+        // the bound it finds is good enough — if not, the exact-difference kernel answers, from inside the step
+        auto res = std::make_shared<LagFftResult>();
+        rc = mdhip_lag_msd_fft(cs, n_frames, n_ent, d_r, scale, max_lag, n_groups, group_off, res);
         if (rc) return rc;
-        ctx->last_rel_bound = bound;
-        if (ctx->opt_lag_variant != 3 || bound <= 1e-10) {
-            if (out_on_device) {
-                MD_HIP(hipMemcpyAsync(out, host_out.data(), res_b, hipMemcpyHostToDevice, ctx->stream));
-                MD_HIP(hipStreamSynchronize(ctx->stream));
-            }
-            return MDHIP_OK;
-        }
-        ctx->last_rel_bound = 0.0;  // bound too loose for this data: the exact-difference kernel below answers
+        cs.defer([=]() {
+            ctx->last_rel_bound = res->bound;
+            if (variant != 3 || res->bound <= 1e-10)
+                return deliver_host_values(ctx, res->out.data(), res_b, out, out_on_device);
+            // bound too loose for this data (r and group_off are the caller's: valid until the call has completed)
+            const int rc2 = lag_msd_impl(ctx, n_frames, n_ent, r, on_device, scale, max_lag, n_groups,
+                                         res->group_off.data(), out, out_on_device, 1);
+            ctx->last_rel_bound = 0.0;
+            return rc2;
+        });
+        return cs.end();
     }
     MD_WS(d_x, double, WS_XYZ_J, r_b + 256);  // the scalar prefetch of the resident kernel reads <= 16 doubles past a series
     const int n_chunks = (int)chunks.size();
-    const size_t tab_b = chunks.size() * sizeof(Chunk) + gco.size() * 4 + (size_t)(n_groups + 1) * 8 + 64;
-    MD_WS(d_tab, unsigned char, WS_TABLES, tab_b);
+    const size_t ch_b = chunks.size() * sizeof(Chunk), go_b = (size_t)(n_groups + 1) * 8, gc_b = gco.size() * 4;
+    const size_t tab_b = ch_b + go_b + gc_b;
+    MD_WS(d_tab, unsigned char, WS_TABLES, tab_b + 64);
+    MD_PIN(h_tab, unsigned char, tab_b);
+    memcpy(h_tab, chunks.data(), ch_b);
+    memcpy(h_tab + ch_b, group_off, go_b);
+    memcpy(h_tab + ch_b + go_b, gco.data(), gc_b);
+    MD_HIP(hipMemcpyAsync(d_tab, h_tab, tab_b, hipMemcpyHostToDevice, ctx->stream));
     Chunk *d_chunks = reinterpret_cast<Chunk *>(d_tab);
-    long long *d_goff = reinterpret_cast<long long *>(d_tab + chunks.size() * sizeof(Chunk));
+    long long *d_goff = reinterpret_cast<long long *>(d_tab + ch_b);
     int *d_gco = reinterpret_cast<int *>(d_goff + n_groups + 1);
-    MD_HIP(hipMemcpyAsync(d_chunks, chunks.data(), chunks.size() * sizeof(Chunk), hipMemcpyHostToDevice, ctx->stream));
-    MD_HIP(hipMemcpyAsync(d_goff, group_off, (size_t)(n_groups + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    MD_HIP(hipMemcpyAsync(d_gco, gco.data(), gco.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     MD_WS(d_partial, double, WS_PART, (size_t)n_chunks * n_lags * 4 * 8);
     const size_t out_b = (size_t)n_lags * n_groups * 4 * 8;
-    MD_WS(d_out, double, WS_OUT, out_b);
-    MD_HIP(hipStreamSynchronize(ctx->stream));
+    double *d_out = out;
+    if (!out_on_device) {
+        d_out = (double *)mdhip_ws(ctx, WS_OUT, out_b);
+        if (!d_out) return MDHIP_ENOMEM;
+    }
     const long long cols = 3 * n_ent;
     hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((cols + 31) / 32), (unsigned)((n_frames + 31) / 32)),
                        dim3(256), 0, ctx->stream, d_r, d_x, (long long)n_frames, cols, scale);
@@ -878,10 +928,15 @@ static int lag_msd_impl(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const d
                        ctx->stream, d_partial, d_gco, d_goff, n_groups, (long long)n_frames, n_lags,
                        resident ? 1 : 0, d_out);
     MD_HIP(hipGetLastError());
-    MD_HIP(mdhip_deliver(ctx, out, d_out, out_b, out_on_device));
-    MD_HIP(hipStreamSynchronize(ctx->stream));
-    timer.collect();
-    return MDHIP_OK;
+    if (!out_on_device) {
+        rc = mdhip_result(cs, out, d_out, out_b, 0);
+        if (rc) return rc;
+    }
+    cs.defer([timer]() {
+        timer.collect();
+        return MDHIP_OK;
+    });
+    return cs.end();
 }
 
 int mdhip_lag_msd(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r, int on_device,
@@ -894,6 +949,44 @@ int mdhip_lag_msd_dev(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const dou
                       double scale, int max_lag, int n_groups, const int64_t *group_off, double *out_dev)
 {
     return lag_msd_impl(ctx, n_frames, n_ent, r, on_device, scale, max_lag, n_groups, group_off, out_dev, 1);
+}
+
+/* ---- asynchronous twins: the work is queued on the context's stream, results are complete after mdhip_sync / mdhip_wait ---- */
+int mdhip_msd_origin_async(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r, int on_device,
+                           const double *origin, int origin_on_device, double scale, int n_groups,
+                           const int64_t *group_off, double *sums, int sums_on_device, double *cols, int64_t col_stride,
+                           int cols_on_device)
+{
+    if (!ctx) return MDHIP_EINVAL;
+    AsyncCall mark(ctx);
+    return mdhip_msd_origin(ctx, n_frames, n_ent, r, on_device, origin, origin_on_device, scale, n_groups, group_off, sums,
+                            sums_on_device, cols, col_stride, cols_on_device);
+}
+
+int mdhip_msd_pairs_dev_async(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r, int on_device,
+                              double scale, int n_pairs, const int32_t *pairs, int n_groups, const int64_t *group_off,
+                              double *sums_dev)
+{
+    if (!ctx) return MDHIP_EINVAL;
+    AsyncCall mark(ctx);
+    return mdhip_msd_pairs_dev(ctx, n_frames, n_ent, r, on_device, scale, n_pairs, pairs, n_groups, group_off, sums_dev);
+}
+
+int mdhip_msd_windows_async(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r, int on_device,
+                            double scale, int tao, double *win_sums, int out_on_device)
+{
+    if (!ctx) return MDHIP_EINVAL;
+    AsyncCall mark(ctx);
+    return msd_windows_impl(ctx, n_frames, n_ent, r, on_device, scale, tao, win_sums, out_on_device ? 1 : 0);
+}
+
+int mdhip_lag_msd_async(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r, int on_device, double scale,
+                        int max_lag, int n_groups, const int64_t *group_off, double *out, int out_on_device)
+{
+    if (!ctx) return MDHIP_EINVAL;
+    AsyncCall mark(ctx);
+    return lag_msd_impl(ctx, n_frames, n_ent, r, on_device, scale, max_lag, n_groups, group_off, out,
+                        out_on_device ? 1 : 0);
 }
 
 }  // extern "C"

@@ -1461,9 +1461,10 @@ double finish_on_host(long long F, long long G, long long n_lags, const int64_t 
 }
 
 // The fused LDS path: L = 2^(m+1) <= 16384.
-int lag_msd_fft_fused(mdhip_ctx *ctx, long long F, long long E, const double *d_r, double scale, int max_lag,
-                      long long G, const int64_t *group_off, int m, double *out, double *rel_bound)
+int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r, double scale, int max_lag,
+                      long long G, const int64_t *group_off, int m, const std::shared_ptr<LagFftResult> &res)
 {
+    mdhip_ctx *ctx = cs.ctx;
     const long long n_lags = (long long)max_lag + 1, cols = 3 * E, S = 3 * G;
     const long long N = 1LL << m, L = 2 * N;
     // work items: every non-empty segment gets a share of ~one block per CU, each a contiguous series range
@@ -1505,10 +1506,14 @@ int lag_msd_fft_fused(mdhip_ctx *ctx, long long F, long long E, const double *d_
     double2 *d_tab = reinterpret_cast<double2 *>(d_small + q_b + p_b + c_b);
     FftItem *d_items = reinterpret_cast<FftItem *>(d_small + q_b + p_b + c_b + 4096);
     int *d_seg_off = reinterpret_cast<int *>(d_small + q_b + p_b + c_b + 4096 + it_b);
-    MD_HIP(hipMemcpyAsync(d_tab, tab.data(), 4096, hipMemcpyHostToDevice, ctx->stream));
-    MD_HIP(hipMemcpyAsync(d_items, items.data(), it_b, hipMemcpyHostToDevice, ctx->stream));
-    MD_HIP(hipMemcpyAsync(d_seg_off, seg_off.data(), so_b, hipMemcpyHostToDevice, ctx->stream));
-    MD_HIP(hipStreamSynchronize(ctx->stream));  // the tables above are locals
+    {
+        // twiddles | items | segment offsets: one pinned staging block (the vectors above are locals), one copy
+        MD_PIN(h_tab, unsigned char, 4096 + it_b + so_b);
+        memcpy(h_tab, tab.data(), 4096);
+        memcpy(h_tab + 4096, items.data(), it_b);
+        memcpy(h_tab + 4096 + it_b, seg_off.data(), so_b);
+        MD_HIP(hipMemcpyAsync(d_tab, h_tab, 4096 + it_b + so_b, hipMemcpyHostToDevice, ctx->stream));
+    }
 
     const size_t lds_b = ft_lds_bytes(m);
     // round-3 kernel (conflict-free layout, bilinear spectrum accumulation): N = 2^m a multiple of the block size
@@ -1591,13 +1596,17 @@ int lag_msd_fft_fused(mdhip_ctx *ctx, long long F, long long E, const double *d_
     timer.stop();
     ctx->last_kernel = "msd_power_lds_kernel";
 
-    std::vector<double> Q((size_t)S * F), corr((size_t)S * n_lags);
-    MD_HIP(hipMemcpyAsync(Q.data(), d_Q, q_b, hipMemcpyDeviceToHost, ctx->stream));
-    MD_HIP(hipMemcpyAsync(corr.data(), d_corr, c_b, hipMemcpyDeviceToHost, ctx->stream));
-    MD_HIP(hipStreamSynchronize(ctx->stream));
-    timer.collect();
-    const double worst = finish_on_host(F, G, n_lags, group_off, Q.data(), corr.data(), n_lags, 1.0, L, out);
-    if (rel_bound) *rel_bound = worst;
+    // Q and the correlations come back through pinned staging (d_Q | d_P | d_corr are one buffer: Q and corr are
+    // fetched separately, P stays); the long-hand finish runs on the host once they are there
+    MD_PIN(h_Q, double, q_b);
+    MD_PIN(h_corr, double, c_b);
+    MD_HIP(hipMemcpyAsync(h_Q, d_Q, q_b, hipMemcpyDeviceToHost, ctx->stream));
+    MD_HIP(hipMemcpyAsync(h_corr, d_corr, c_b, hipMemcpyDeviceToHost, ctx->stream));
+    cs.defer([timer, res, h_Q, h_corr, F, G, n_lags, L]() {
+        timer.collect();
+        res->bound = finish_on_host(F, G, n_lags, res->group_off.data(), h_Q, h_corr, n_lags, 1.0, L, res->out.data());
+        return MDHIP_OK;
+    });
     return MDHIP_OK;
 }
 
@@ -1605,10 +1614,14 @@ int lag_msd_fft_fused(mdhip_ctx *ctx, long long F, long long E, const double *d_
 
 // d_r: device [F][3][E]. out: host [max_lag+1][G][4] means as mdhip_lag_msd. *rel_bound: the largest
 // estimated relative rounding error over all (lag >= 1, group, axis) entries with a non-zero value.
-int mdhip_lag_msd_fft(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *d_r, double scale,
-                      int max_lag, int n_groups, const int64_t *group_off, double *out, double *rel_bound)
+int mdhip_lag_msd_fft(CallScope &cs, int64_t n_frames, int64_t n_ent, const double *d_r, double scale,
+                      int max_lag, int n_groups, const int64_t *group_off, const std::shared_ptr<LagFftResult> &res)
 {
+    mdhip_ctx *ctx = cs.ctx;
     const long long F = n_frames, E = n_ent, G = n_groups;
+    res->group_off.assign(group_off, group_off + n_groups + 1);
+    res->out.assign((size_t)(max_lag + 1) * n_groups * 4, 0.0);
+    res->bound = 0.0;
     const long long n_lags = (long long)max_lag + 1;
     const long long cols = 3 * E;
     if (ctx->opt_lag_variant != 4) {
@@ -1616,7 +1629,7 @@ int mdhip_lag_msd_fft(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const dou
         int m = 3;
         while ((2LL << m) < F + max_lag) ++m;
         if (m <= FT_MAX_M && ft_lds_bytes(m) <= ctx->lds_max)
-            return lag_msd_fft_fused(ctx, F, E, d_r, scale, max_lag, G, group_off, m, out, rel_bound);
+            return lag_msd_fft_fused(cs, F, E, d_r, scale, max_lag, G, group_off, m, res);
     }
     const long long L = pow2_length(F + max_lag);
     MD_REQUIRE(L < (1LL << 30), "series too long for the FFT path (%lld)", L);
@@ -1644,9 +1657,11 @@ int mdhip_lag_msd_fft(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const dou
     long long *d_goff = reinterpret_cast<long long *>(d_small + q_b + p_b + z_b + c_b);
     MD_WS(d_part, double, WS_PART, (size_t)MF_SPLITS * K * 8);
 
-    MD_HIP(hipMemcpyAsync(d_goff, group_off, (size_t)(G + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    {
+        const int rc0 = mdhip_h2d_small(ctx, d_goff, group_off, (size_t)(G + 1) * 8);  // (the caller's memory)
+        if (rc0) return rc0;
+    }
     MD_HIP(hipMemsetAsync(d_P, 0, p_b, ctx->stream));
-    MD_HIP(hipStreamSynchronize(ctx->stream));  // group_off is the caller's memory
 
     KernelTimer timer(ctx);
     hipLaunchKernelGGL(col_sum_kernel, dim3((unsigned)((cols + 255) / 256), MF_SLABS), dim3(256), 0, ctx->stream,
@@ -1685,13 +1700,15 @@ int mdhip_lag_msd_fft(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const dou
     timer.stop();
     ctx->last_kernel = "lag_msd_fft";
 
-    std::vector<double> Q((size_t)S * F), corr((size_t)S * L);
-    MD_HIP(hipMemcpyAsync(Q.data(), d_Q, q_b, hipMemcpyDeviceToHost, ctx->stream));
-    MD_HIP(hipMemcpyAsync(corr.data(), d_corr, c_b, hipMemcpyDeviceToHost, ctx->stream));
-    MD_HIP(hipStreamSynchronize(ctx->stream));
-    timer.collect();
-
-    const double worst = finish_on_host(F, G, n_lags, group_off, Q.data(), corr.data(), L, 1.0 / (double)L, L, out);
-    if (rel_bound) *rel_bound = worst;
+    MD_PIN(h_Q, double, q_b);
+    MD_PIN(h_corr, double, c_b);
+    MD_HIP(hipMemcpyAsync(h_Q, d_Q, q_b, hipMemcpyDeviceToHost, ctx->stream));
+    MD_HIP(hipMemcpyAsync(h_corr, d_corr, c_b, hipMemcpyDeviceToHost, ctx->stream));
+    cs.defer([timer, res, h_Q, h_corr, F, G, n_lags, L]() {
+        timer.collect();
+        res->bound = finish_on_host(F, G, n_lags, res->group_off.data(), h_Q, h_corr, L, 1.0 / (double)L, L,
+                                    res->out.data());
+        return MDHIP_OK;
+    });
     return MDHIP_OK;
 }

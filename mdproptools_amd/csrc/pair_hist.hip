@@ -78,7 +78,13 @@ constexpr int SPLIT_BATCH = 2;  // a block may have wrapped a 32-bit LDS word: r
 
 // Runs the kernel over one batch of frames (in several passes when the class rows do not fit LDS) and
 // returns the class histograms on the host: H [F|1][n_cls][nbins], overflow count.
-int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64_t> &H, uint64_t *overflow)
+// `defer` (an asynchronous call's scope, or nullptr): when the batch runs as ONE scalar-j pass, its host half — flag
+// check, timer read-out, folding the row sums into H — is left as a completion step of that call instead of being done
+// behind a stream sync here; H, *overflow, p.Hsplit and *redo must then outlive the call (they are parts of the entry
+// point's heap state). A launch that raised the overflow guard sets *redo there (nothing else is touched) instead of
+// returning SPLIT_BATCH. Everything else (class passes, the dense kernels) completes inside, as before.
+int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64_t> &H, uint64_t *overflow,
+                        CallScope *defer = nullptr, bool *redo = nullptr)
 {
     const int64_t F = p.n_frames;
     const int nTi = (int)((p.ni + TILE - 1) / TILE);
@@ -236,7 +242,7 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
     // edges and the class table of every pass: one pinned staging buffer, one H2D copy
     const size_t tab_b = edges_b + (size_t)n_pass * cls_b + cn_b + 8;
     MD_WS(d_tab, unsigned char, WS_TABLES, tab_b);
-    MD_PIN(h_tab, unsigned char, PIN_TABLES, tab_b);
+    MD_PIN(h_tab, unsigned char, tab_b);
     {
         double *e = reinterpret_cast<double *>(h_tab);
         std::copy(p.edges, p.edges + p.nbins + 1, e);
@@ -282,8 +288,16 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
     const int *d_list_cnt = nullptr;
     const float4 *d_gsph = nullptr, *d_wsph = nullptr, *d_gsph4 = nullptr;
     const double4 *d_aos = nullptr;
-    double prep_ms = 0.0;
-    bool prep_timed = false;
+    // what the host half of the passes accumulates (shared with the completion step of a deferred batch)
+    struct BatchAcc {
+        double total_ms = 0.0, prep_ms = 0.0;
+        int launches = 0;
+        unsigned long long ov = 0;
+        bool prep_timed = false;
+        KernelTimer prep;
+        explicit BatchAcc(const KernelTimer &t) : prep(t) {}
+    };
+    std::shared_ptr<BatchAcc> acc;
     const double4 *d_aos_j = nullptr;
     const float *d_rel = nullptr;
     const double *d_cen = nullptr;
@@ -292,7 +306,7 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         const bool want_soa = ctx->opt_rdf_sj == 0;  // only the LDS-tile kernel (atom-atom) reads the SoA copy
         MD_WS(d_l, unsigned short, WS_LIST, (size_t)F * nTi * (p.tri ? nTi : nTj) * 2);
         MD_WS(d_lc, int, WS_LISTCNT, (size_t)F * nTi * 4);
-        KernelTimer ptimer(ctx, 1, true);  // second event pair: collected after the pair kernel's sync
+        KernelTimer ptimer(ctx, 1, true);  // second event pair: collected with the pair kernel's
         SortedSet si, sj_set;
         const int slot_i[5] = {WS_SORT_AOS, WS_BBOX, WS_GSPH, WS_WSPH, WS_GSPH4};
         // (the bin-guess addend near + type * row_len and the tile-relative f32 records belong to the j set)
@@ -313,7 +327,8 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
                           p.rc2 * (1.0 + 1e-9) + 1e-9, d_l, d_lc);
         ptimer.stop();
         MD_HIP(hipGetLastError());
-        prep_timed = true;
+        acc = std::make_shared<BatchAcc>(ptimer);
+        acc->prep_timed = true;
         d_gsph = sj_set.gs;    // 8-atom boxes of the j set (LDS-tile kernel)
         d_gsph4 = sj_set.gs4;  // 4-atom boxes of the j set (scalar-j kernel)
         d_wsph = si.ws;      // 64-atom boxes of the i set
@@ -330,9 +345,19 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         d_cen = sj_set.cen;
     }
 
-    double total_ms = 0.0;  // the pair kernel alone; the culling pre-pass is reported separately
-    unsigned long long ov = 0;
-    int launches = 0;
+    // (total_ms: the pair kernel alone; the culling pre-pass is reported separately)
+    if (!acc) acc = std::make_shared<BatchAcc>(KernelTimer(ctx, 1, true));
+    const int n_cls_all = p.n_cls, nbins_all = p.nbins;
+    // the end of the batch: what the passes found goes to the caller and to the context's registers
+    auto finalize = [ctx, acc, overflow, n_pass]() {
+        // with several passes every in-cutoff overflow pair is seen once per pass
+        *overflow = acc->ov / (uint64_t)n_pass;
+        ctx->last_ms = acc->total_ms;
+        ctx->last_launches = acc->launches;
+        ctx->last_aux_ms = acc->prep_ms;
+        return MDHIP_OK;
+    };
+    bool deferred = false;
     for (int pass = 0; pass < n_pass; ++pass) {
         const int c0 = pass * cls_per_pass;
         const int nc = (p.n_cls - c0) < cls_per_pass ? (p.n_cls - c0) : cls_per_pass;
@@ -468,10 +493,27 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         timer.stop();
         MD_HIP(hipGetLastError());
 
+        const bool can_defer = defer != nullptr && sj && n_pass == 1;
+        // the launch's flags (pinned): [0] deferred pairs lost, [1] work-loop assertion, [2] overflow guard
+        auto check_flags = [ctx](const uint64_t *hlost) {
+            if (hlost[2]) return SPLIT_BATCH;
+            if (hlost[0] || hlost[1])
+                return mdhip_fail(ctx, MDHIP_EHIP, "pair_hist: internal check failed (%llu deferred pairs lost, work loop %llu)",
+                                  (unsigned long long)hlost[0], (unsigned long long)hlost[1]);
+            return MDHIP_OK;
+        };
+        auto collect_times = [acc, timer]() {
+            acc->total_ms += timer.collect();
+            ++acc->launches;
+            if (acc->prep_timed) {  // the pre-pass ran ahead of the first pass on the same stream: its events are complete
+                acc->prep_ms = acc->prep.collect();
+                acc->prep_timed = false;
+            }
+        };
         if (sj && p.dev_out && n_pass == 1 && !p.per_frame) {
             // outputs stay on the device: rows -> full | part | overflow by derive_rdf_kernel (added to dev_out)
             const size_t tb = ((size_t)sj_rows + 2 * (size_t)p.n_rel) * 4;
-            MD_PIN(h_map, int, PIN_OUT, tb + 32);
+            MD_PIN(h_map, int, tb + 32);
             for (int r = 0; r < sj_rows; ++r) h_map[r] = ordered ? p.cls[r] : (r < nc ? c0 + r : -1);
             for (int kl = 0; kl < p.n_rel; ++kl) {
                 h_map[sj_rows + kl] = p.rel_cls[kl];
@@ -484,59 +526,77 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
             MD_HIP(hipGetLastError());
             uint64_t *hlost = reinterpret_cast<uint64_t *>(reinterpret_cast<unsigned char *>(h_map) + ((tb + 7) & ~size_t(7)));
             MD_HIP(hipMemcpyAsync(hlost, d_misc + 1, 24, hipMemcpyDeviceToHost, ctx->stream));
-            MD_HIP(hipStreamSynchronize(ctx->stream));
-            if (hlost[2]) return SPLIT_BATCH;
-            if (hlost[0] || hlost[1])
-                return mdhip_fail(ctx, MDHIP_EHIP, "pair_hist: internal check failed (%llu deferred pairs lost, work loop %llu)",
-                                  (unsigned long long)hlost[0], (unsigned long long)hlost[1]);
-            timer.collect();
-            total_ms += ctx->last_ms;
-            ++launches;
-            if (prep_timed) {
-                float ms = 0.f;
-                if (hipEventElapsedTime(&ms, ctx->ev2, ctx->ev3) == hipSuccess) prep_ms = ms;
-                prep_timed = false;
+            auto fin = [check_flags, collect_times, hlost]() {
+                const int rcf = check_flags(hlost);
+                if (rcf) return rcf;
+                collect_times();
+                return (int)MDHIP_OK;
+            };
+            if (can_defer) {
+                defer->defer([fin, finalize, redo]() {
+                    const int rcf = fin();
+                    if (rcf == SPLIT_BATCH) {
+                        *redo = true;
+                        return (int)MDHIP_OK;
+                    }
+                    return rcf ? rcf : finalize();
+                });
+                deferred = true;
+                continue;
             }
+            MD_HIP(mdhip_stream_wait(ctx));
+            const int rcf = fin();
+            if (rcf) return rcf;
             continue;
         }
         if (sj) {
             // D2H of the row sums (pinned staging), then rows -> classes and the overflow words on the host
-            MD_PIN(hrows, uint64_t, PIN_OUT, (out_frames * (size_t)sj_words + 3) * 8);
+            MD_PIN(hrows, uint64_t, (out_frames * (size_t)sj_words + 3) * 8);
             MD_HIP(hipMemcpyAsync(hrows, d_rows, out_frames * (size_t)sj_words * 8, hipMemcpyDeviceToHost,
                                   ctx->stream));
             uint64_t *hlost = hrows + out_frames * (size_t)sj_words;  // [0] queue overflow, [1] work-loop assertion
             MD_HIP(hipMemcpyAsync(hlost, d_misc + 1, 24, hipMemcpyDeviceToHost, ctx->stream));
-            MD_HIP(hipStreamSynchronize(ctx->stream));
-            if (hlost[2]) return SPLIT_BATCH;
-            if (hlost[0] || hlost[1])
-                return mdhip_fail(ctx, MDHIP_EHIP, "pair_hist: internal check failed (%llu deferred pairs lost, work loop %llu)",
-                                  (unsigned long long)hlost[0], (unsigned long long)hlost[1]);
-            timer.collect();
-            total_ms += ctx->last_ms;
-            ++launches;
-            if (prep_timed) {
-                float ms = 0.f;
-                if (hipEventElapsedTime(&ms, ctx->ev2, ctx->ev3) == hipSuccess) prep_ms = ms;
-                prep_timed = false;
+            std::vector<uint64_t> *Hp = &H, *Hsplit = p.Hsplit;
+            auto fin = [check_flags, collect_times, acc, hrows, hlost, Hp, Hsplit, out_frames, sj_words, sj_rows, cn_len,
+                        ordered, nc, c0, n_cls_all, nbins_all, cls = ordered ? p.cls : std::vector<int>()]() {
+                const int rcf = check_flags(hlost);
+                if (rcf) return rcf;
+                collect_times();
+                const int row_len = nbins_all + 1;
+                for (size_t fr = 0; fr < out_frames && cn_len; ++fr)
+                    for (int r = 0; r < sj_rows; ++r) {
+                        const uint64_t *src = hrows + fr * (size_t)sj_words + (size_t)sj_rows * row_len + (size_t)r;
+                        const int cl = ordered ? cls[r] : (r < nc ? c0 + r : -1);
+                        if (cl >= 0) (*Hsplit)[fr * n_cls_all + cl] += src[0];
+                    }
+                for (size_t fr = 0; fr < out_frames; ++fr)
+                    for (int r = 0; r < sj_rows; ++r) {
+                        const uint64_t *src = hrows + fr * (size_t)sj_words + (size_t)r * row_len;
+                        acc->ov += src[nbins_all];
+                        // ordered rows (ti, tj) -> class of the unordered pair; class rows of this pass -> c0 + r, the
+                        // extra row holds the pairs whose class belongs to another pass
+                        const int cl = ordered ? (int)cls[r] : (r < nc ? c0 + r : -1);
+                        if (cl < 0) continue;
+                        uint64_t *dst = &(*Hp)[(fr * n_cls_all + cl) * nbins_all];
+                        for (int k = 0; k < nbins_all; ++k) dst[k] += src[k];
+                    }
+                return (int)MDHIP_OK;
+            };
+            if (can_defer) {
+                defer->defer([fin, finalize, redo]() {
+                    const int rcf = fin();
+                    if (rcf == SPLIT_BATCH) {
+                        *redo = true;
+                        return (int)MDHIP_OK;
+                    }
+                    return rcf ? rcf : finalize();
+                });
+                deferred = true;
+                continue;
             }
-            const int row_len = p.nbins + 1;
-            for (size_t fr = 0; fr < out_frames && cn_len; ++fr)
-                for (int r = 0; r < sj_rows; ++r) {
-                    const uint64_t *src = hrows + fr * (size_t)sj_words + (size_t)sj_rows * row_len + (size_t)r;
-                    const int cl = ordered ? p.cls[r] : (r < nc ? c0 + r : -1);
-                    if (cl >= 0) (*p.Hsplit)[fr * p.n_cls + cl] += src[0];
-                }
-            for (size_t fr = 0; fr < out_frames; ++fr)
-                for (int r = 0; r < sj_rows; ++r) {
-                    const uint64_t *src = hrows + fr * (size_t)sj_words + (size_t)r * row_len;
-                    ov += src[p.nbins];
-                    // ordered rows (ti, tj) -> class of the unordered pair; class rows of this pass -> c0 + r, the
-                    // extra row holds the pairs whose class belongs to another pass
-                    const int cl = ordered ? (int)p.cls[r] : (r < nc ? c0 + r : -1);
-                    if (cl < 0) continue;
-                    uint64_t *dst = &H[(fr * p.n_cls + cl) * p.nbins];
-                    for (int k = 0; k < p.nbins; ++k) dst[k] += src[k];
-                }
+            MD_HIP(mdhip_stream_wait(ctx));
+            const int rcf = fin();
+            if (rcf) return rcf;
             continue;
         }
 
@@ -547,29 +607,18 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
             MD_HIP(hipGetLastError());
         }
         // D2H (pinned staging) into the right class rows; the overflow word rides along with the last pass
-        MD_PIN(tmp, uint64_t, PIN_OUT, (out_frames * words + 1) * 8);
+        MD_PIN(tmp, uint64_t, (out_frames * words + 1) * 8);
         MD_HIP(hipMemcpyAsync(tmp, d_final, out_frames * words * 8, hipMemcpyDeviceToHost, ctx->stream));
         if (pass == n_pass - 1)
             MD_HIP(hipMemcpyAsync(tmp + out_frames * words, d_misc, 8, hipMemcpyDeviceToHost, ctx->stream));
-        MD_HIP(hipStreamSynchronize(ctx->stream));
-        if (pass == n_pass - 1) ov = tmp[out_frames * words];
-        timer.collect();
-        total_ms += ctx->last_ms;
-        ++launches;
-        if (prep_timed) {  // the pre-pass ran ahead of the first pass on the same stream: its events are complete
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, ctx->ev2, ctx->ev3) == hipSuccess) prep_ms = ms;
-            prep_timed = false;
-        }
+        MD_HIP(mdhip_stream_wait(ctx));
+        if (pass == n_pass - 1) acc->ov = tmp[out_frames * words];  // (d_misc[0] accumulates over the passes)
+        collect_times();
         for (size_t fr = 0; fr < out_frames; ++fr)
             memcpy(&H[(fr * p.n_cls + c0) * p.nbins], &tmp[fr * words], words * 8);
     }
-    // with several passes every in-cutoff overflow pair is seen once per pass
-    *overflow = ov / (uint64_t)n_pass;
-    ctx->last_ms = total_ms;
-    ctx->last_launches = launches;
-    ctx->last_aux_ms = prep_ms;
-    return MDHIP_OK;
+    if (deferred) return MDHIP_OK;
+    return finalize();
 }
 
 // Copies the frames [f0, f0 + n) of the host-resident inputs of `p` to their device buffers on the copy stream and
@@ -587,7 +636,8 @@ static int stage_batch_async(mdhip_ctx *ctx, const PairProblem &p, int64_t f0, i
 }
 
 static int pair_hist_run_range(mdhip_ctx *ctx, const PairProblem &p, int64_t f0, int64_t n, std::vector<uint64_t> &H,
-                               uint64_t *overflow, std::vector<uint64_t> *Hsplit);
+                               uint64_t *overflow, std::vector<uint64_t> *Hsplit, CallScope *defer = nullptr,
+                               bool *redo = nullptr);
 
 // Splits the frames into batches so that the culled path's workspace (sorted copy, keys, cell counts, boxes,
 // neighbour-tile lists) stays within ~2 GiB and a launch's grid.y within 65535, and merges the batches.
@@ -595,7 +645,9 @@ static int pair_hist_run_range(mdhip_ctx *ctx, const PairProblem &p, int64_t f0,
 // k + 1 is issued on the copy stream before batch k is swept, so that it runs under that sweep (page-locked sources:
 // a DMA the host does not wait for; pageable sources: the runtime stages them synchronously, so the copy simply comes
 // first, as without this scheme). A shorter first batch lets the sweep start early.
-int pair_hist_run(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64_t> &H, uint64_t *overflow)
+// `defer` / `redo`: see pair_hist_run_batch — used when the frames are ONE batch whose coordinates are on the device.
+int pair_hist_run(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64_t> &H, uint64_t *overflow,
+                  CallScope *defer = nullptr, bool *redo = nullptr)
 {
     const int64_t F = p.n_frames;
     const int64_t nT = (p.ni + TILE - 1) / TILE;
@@ -627,7 +679,7 @@ int pair_hist_run(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64_t> &H
         const int rc = stage_batch_async(ctx, p, parts[0].first, parts[0].second, ctx->copy_ev[0]);
         if (rc) return rc;
     }
-    if (parts.size() == 1 && !staged) return pair_hist_run_range(ctx, p, 0, F, H, overflow, p.Hsplit);
+    if (parts.size() == 1 && !staged) return pair_hist_run_range(ctx, p, 0, F, H, overflow, p.Hsplit, defer, redo);
     H.assign((p.per_frame ? (size_t)F : 1) * row, 0);
     if (p.Hsplit) p.Hsplit->assign((p.per_frame ? (size_t)F : 1) * row_cn, 0);
     *overflow = 0;
@@ -672,7 +724,7 @@ int pair_hist_run(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64_t> &H
 // The frames [f0, f0 + n) of `p` (their coordinates are on the device): one batch, or — when a block's 32-bit histogram
 // words might wrap — halves of it, recursively. Results as pair_hist_run_batch's.
 static int pair_hist_run_range(mdhip_ctx *ctx, const PairProblem &p, int64_t f0, int64_t n, std::vector<uint64_t> &H,
-                               uint64_t *overflow, std::vector<uint64_t> *Hsplit)
+                               uint64_t *overflow, std::vector<uint64_t> *Hsplit, CallScope *defer, bool *redo)
 {
     PairProblem q = p;
     q.h_xi = q.h_xj = nullptr;
@@ -684,7 +736,7 @@ static int pair_hist_run_range(mdhip_ctx *ctx, const PairProblem &p, int64_t f0,
     q.d_tj = p.d_tj + (size_t)f0 * p.tj_fs;
     q.d_box = p.d_box + (size_t)f0 * 3;
     q.h_box = p.h_box + (size_t)f0 * 3;
-    const int rc1 = pair_hist_run_batch(ctx, q, H, overflow);
+    const int rc1 = pair_hist_run_batch(ctx, q, H, overflow, defer, redo);
     if (rc1 != SPLIT_BATCH) return rc1;
     if (n == 1)
         return mdhip_fail(ctx, MDHIP_ELIMIT, "pair_hist: one frame can overflow the 32-bit block histograms "
@@ -838,8 +890,10 @@ struct RelJob {
 };
 
 // Stages everything, runs the kernel and returns class histograms + the relation->class map.
+// `defer` / `redo`: see pair_hist_run_batch (H, rel_cls, *overflow, j.Hsplit and *redo then live in the entry point's
+// heap state; what a deferred step needs from this function's locals is copied into it).
 int run_job(mdhip_ctx *ctx, const RelJob &j, std::vector<uint64_t> &H, std::vector<int> &rel_cls,
-            int &n_cls, uint64_t *overflow)
+            int &n_cls, uint64_t *overflow, CallScope *defer = nullptr, bool *redo = nullptr)
 {
     std::vector<int32_t> ui, idx_i, uj, idx_j;
     const size_t n_lab_i = j.lab_i_fs ? (size_t)j.F * j.ni : (size_t)j.ni;
@@ -895,7 +949,7 @@ int run_job(mdhip_ctx *ctx, const RelJob &j, std::vector<uint64_t> &H, std::vect
     // asynchronous copies need no sync before this function's vectors go away)
     const size_t ti_b = (idx_i.size() * 4 + 63) & ~size_t(63), tj_b = (idx_j.size() * 4 + 63) & ~size_t(63);
     const size_t box_b = (size_t)j.F * 3 * 8;
-    MD_PIN(h_in, unsigned char, PIN_TYPES, ti_b + tj_b + box_b);
+    MD_PIN(h_in, unsigned char, ti_b + tj_b + box_b);
     memcpy(h_in, idx_i.data(), idx_i.size() * 4);
     memcpy(h_in + ti_b, idx_j.data(), idx_j.size() * 4);
     memcpy(h_in + ti_b + tj_b, j.box, box_b);
@@ -952,7 +1006,7 @@ int run_job(mdhip_ctx *ctx, const RelJob &j, std::vector<uint64_t> &H, std::vect
         p.cn_c2_cls = c2.data();
         p.Hsplit = j.Hsplit;
     }
-    return pair_hist_run(ctx, p, H, overflow);
+    return pair_hist_run(ctx, p, H, overflow, defer, redo);
 }
 
 // CN: edges are the sorted distinct positive cutoffs^2; rank[kl] = number of bins below relation kl's cutoff.
@@ -991,12 +1045,60 @@ double mdhip_pk_error_bound(double r_cut, double bin_size, int nbins, int n_rows
     return pk_error_bound(r_cut, bin_size, nbins, n_rows, s_cap, l_max);
 }
 
+// What an atom-atom entry point keeps on the heap while its batch may still be in flight (asynchronous calls): the
+// class histograms the batch's completion step fills, and what the entry point's own step needs to turn them into the
+// reference's outputs.
+struct PairState {
+    std::vector<uint64_t> H, Hsplit;
+    std::vector<int> rel_cls;
+    std::vector<double> c2_cls, edges;
+    std::vector<int32_t> rel;
+    int n_cls = 0;
+    uint64_t ov = 0;
+    bool redo = false;  // the launch raised the overflow guard of the 32-bit block histograms: run again, synchronously
+};
+
+static const double *state_edges(PairState &st, const double *edges, double bin_size, int nbins)
+{
+    if (edges) {
+        st.edges.assign(edges, edges + nbins + 1);
+    } else {
+        st.edges.resize((size_t)nbins + 1);
+        mdhip_bin_edges(bin_size, nbins, st.edges.data());
+    }
+    return st.edges.data();
+}
+
+static void atomic_job(RelJob &j, int64_t n_frames, int64_t n_atoms, const double *xyz, int on_device, const int32_t *type,
+                       int64_t type_frame_stride, const double *box, int n_rel, const int32_t *rel, double r_cut_sq,
+                       double bin_size, int nbins, const double *edges, int per_frame)
+{
+    j.tri = true;
+    j.F = n_frames;
+    j.ni = j.nj = n_atoms;
+    j.xi = xyz;
+    j.xi_dev = on_device;
+    j.lab_i = type;
+    j.lab_i_fs = type_frame_stride;
+    j.box = box;
+    j.n_rel = n_rel;
+    j.rel = rel;
+    j.nbins = nbins;
+    j.edges = edges;
+    j.rc2 = r_cut_sq;
+    j.gscale = bin_size > 0.0 ? (float)(1.0 / bin_size) : 0.f;
+    j.bin_size = bin_size;
+    j.per_frame = per_frame;
+}
+
 int mdhip_rdf_atomic(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *xyz,
                      int on_device, const int32_t *type, int64_t type_frame_stride,
                      const double *box, int n_rel, const int32_t *rel, double r_cut_sq,
                      double bin_size, int nbins, const double *edges, int per_frame,
                      uint64_t *hist_full, uint64_t *hist_part, uint64_t *overflow)
 {
+    if (!ctx) return MDHIP_EINVAL;
+    CallScope cs(ctx);
     int rc = check_common(ctx, n_frames, n_atoms, xyz, type, box, n_rel, rel);
     if (rc) return rc;
     MD_REQUIRE(nbins >= 1 && bin_size > 0.0, "nbins and bin_size must be positive");
@@ -1008,53 +1110,40 @@ int mdhip_rdf_atomic(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const do
     std::fill(hist_full, hist_full + out_frames * nbins, (uint64_t)0);
     if (n_rel) std::fill(hist_part, hist_part + out_frames * n_rel * nbins, (uint64_t)0);
     if (overflow) *overflow = 0;
-    if (n_frames == 0 || n_atoms < 2) return MDHIP_OK;
+    if (n_frames == 0 || n_atoms < 2) return cs.end();
 
-    std::vector<double> own_edges;
-    if (!edges) {
-        own_edges.resize(nbins + 1);
-        mdhip_bin_edges(bin_size, nbins, own_edges.data());
-        edges = own_edges.data();
-    }
+    auto st = std::make_shared<PairState>();
     RelJob j{};
-    j.tri = true;
-    j.F = n_frames;
-    j.ni = j.nj = n_atoms;
-    j.xi = xyz;
-    j.xi_dev = on_device;
-    j.lab_i = type;
-    j.lab_i_fs = type_frame_stride;
-    j.box = box;
-    j.n_rel = n_rel;
-    j.rel = rel;
-    j.nbins = nbins;
-    j.edges = edges;
-    j.rc2 = r_cut_sq;
-    j.gscale = (float)(1.0 / bin_size);
-    j.bin_size = bin_size;
-    j.per_frame = per_frame;
-    std::vector<uint64_t> H;
-    std::vector<int> rel_cls;
-    int n_cls = 0;
-    uint64_t ov = 0;
-    rc = run_job(ctx, j, H, rel_cls, n_cls, &ov);
+    atomic_job(j, n_frames, n_atoms, xyz, on_device, type, type_frame_stride, box, n_rel, rel, r_cut_sq, bin_size, nbins,
+               state_edges(*st, edges, bin_size, nbins), per_frame);
+    st->rel.assign(rel, rel + 2 * (size_t)n_rel);
+    rc = run_job(ctx, j, st->H, st->rel_cls, st->n_cls, &st->ov, cs.async() ? &cs : nullptr, &st->redo);
     if (rc) return rc;
-    if (overflow) *overflow = ov;
-    // rdf_full[bin] += 2 per pair (rdf_cn.py:85-86); rdf_part: +1 per unordered {a,b} pair, +2 when a == b
-    for (size_t f = 0; f < out_frames; ++f) {
-        const uint64_t *Hf = &H[f * n_cls * nbins];
-        uint64_t *full = hist_full + f * nbins;
-        for (int c = 0; c < n_cls; ++c)
-            for (int b = 0; b < nbins; ++b) full[b] += 2 * Hf[(size_t)c * nbins + b];
-        for (int kl = 0; kl < n_rel; ++kl) {
-            if (rel_cls[kl] < 0) continue;
-            const uint64_t mult = rel[2 * kl] == rel[2 * kl + 1] ? 2 : 1;
-            uint64_t *part = hist_part + (f * n_rel + kl) * nbins;
-            const uint64_t *row = Hf + (size_t)rel_cls[kl] * nbins;
-            for (int b = 0; b < nbins; ++b) part[b] = mult * row[b];
+    cs.defer([=]() {
+        if (st->redo)  // (xyz, type, box are the caller's: valid and unchanged until the call has completed)
+            return mdhip_rdf_atomic(ctx, n_frames, n_atoms, xyz, on_device, type, type_frame_stride, box, n_rel,
+                                    st->rel.data(), r_cut_sq, bin_size, nbins, st->edges.data(), per_frame, hist_full,
+                                    hist_part, overflow);
+        if (overflow) *overflow = st->ov;
+        const int n_cls = st->n_cls;
+        const int32_t *rl = st->rel.data();
+        // rdf_full[bin] += 2 per pair (rdf_cn.py:85-86); rdf_part: +1 per unordered {a,b} pair, +2 when a == b
+        for (size_t f = 0; f < out_frames; ++f) {
+            const uint64_t *Hf = &st->H[f * n_cls * nbins];
+            uint64_t *full = hist_full + f * nbins;
+            for (int c = 0; c < n_cls; ++c)
+                for (int b = 0; b < nbins; ++b) full[b] += 2 * Hf[(size_t)c * nbins + b];
+            for (int kl = 0; kl < n_rel; ++kl) {
+                if (st->rel_cls[kl] < 0) continue;
+                const uint64_t mult = rl[2 * kl] == rl[2 * kl + 1] ? 2 : 1;
+                uint64_t *part = hist_part + (f * n_rel + kl) * nbins;
+                const uint64_t *row = Hf + (size_t)st->rel_cls[kl] * nbins;
+                for (int b = 0; b < nbins; ++b) part[b] = mult * row[b];
+            }
         }
-    }
-    return MDHIP_OK;
+        return (int)MDHIP_OK;
+    });
+    return cs.end();
 }
 
 int mdhip_rdf_atomic_dev(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *xyz, int on_device,
@@ -1062,6 +1151,8 @@ int mdhip_rdf_atomic_dev(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, cons
                          const int32_t *rel, double r_cut_sq, double bin_size, int nbins, const double *edges,
                          uint64_t *out_dev)
 {
+    if (!ctx) return MDHIP_EINVAL;
+    CallScope cs(ctx);
     int rc = check_common(ctx, n_frames, n_atoms, xyz, type, box, n_rel, rel);
     if (rc) return rc;
     MD_REQUIRE(nbins >= 1 && bin_size > 0.0, "nbins and bin_size must be positive");
@@ -1070,146 +1161,146 @@ int mdhip_rdf_atomic_dev(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, cons
     MD_HIP(hipSetDevice(ctx->device));
     const size_t words = (size_t)(1 + n_rel) * nbins + 1;
     MD_HIP(hipMemsetAsync(out_dev, 0, words * 8, ctx->stream));
-    if (n_frames == 0 || n_atoms < 2) {
-        MD_HIP(hipStreamSynchronize(ctx->stream));
-        return MDHIP_OK;
-    }
-    std::vector<double> own_edges;
-    if (!edges) {
-        own_edges.resize(nbins + 1);
-        mdhip_bin_edges(bin_size, nbins, own_edges.data());
-        edges = own_edges.data();
-    }
+    if (n_frames == 0 || n_atoms < 2) return cs.end();
+    auto st = std::make_shared<PairState>();
     RelJob j{};
-    j.tri = true;
-    j.F = n_frames;
-    j.ni = j.nj = n_atoms;
-    j.xi = xyz;
-    j.xi_dev = on_device;
-    j.lab_i = type;
-    j.lab_i_fs = type_frame_stride;
-    j.box = box;
-    j.n_rel = n_rel;
-    j.rel = rel;
-    j.nbins = nbins;
-    j.edges = edges;
-    j.rc2 = r_cut_sq;
-    j.gscale = (float)(1.0 / bin_size);
-    j.bin_size = bin_size;
-    j.per_frame = 0;
+    atomic_job(j, n_frames, n_atoms, xyz, on_device, type, type_frame_stride, box, n_rel, rel, r_cut_sq, bin_size, nbins,
+               state_edges(*st, edges, bin_size, nbins), 0);
     j.dev_out = reinterpret_cast<unsigned long long *>(out_dev);
-    std::vector<uint64_t> H;
-    std::vector<int> rel_cls;
-    int n_cls = 0;
-    uint64_t ov = 0;
-    rc = run_job(ctx, j, H, rel_cls, n_cls, &ov);
+    st->rel.assign(rel, rel + 2 * (size_t)n_rel);
+    rc = run_job(ctx, j, st->H, st->rel_cls, st->n_cls, &st->ov, cs.async() ? &cs : nullptr, &st->redo);
     if (rc) return rc;
-    // batches that did not run as one scalar-j pass (small frames, class passes) came back as host class histograms:
-    // add them in (rare path; a D2H / H2D round trip of the output words)
-    bool any = ov != 0;
-    for (size_t k = 0; k < H.size() && !any; ++k) any = H[k] != 0;
-    if (any) {
-        std::vector<uint64_t> out(words);
-        MD_HIP(hipMemcpyAsync(out.data(), out_dev, words * 8, hipMemcpyDeviceToHost, ctx->stream));
-        MD_HIP(hipStreamSynchronize(ctx->stream));
+    cs.defer([=]() {
+        if (st->redo)  // (device-resident sums are left untouched by a flagged launch)
+            return mdhip_rdf_atomic_dev(ctx, n_frames, n_atoms, xyz, on_device, type, type_frame_stride, box, n_rel,
+                                        st->rel.data(), r_cut_sq, bin_size, nbins, st->edges.data(), out_dev);
+        // batches that did not run as one scalar-j pass (small frames, class passes) came back as host class
+        // histograms: add them in (rare path; a D2H / H2D round trip of the output words)
+        const std::vector<uint64_t> &H = st->H;
+        bool any = st->ov != 0;
+        for (size_t k = 0; k < H.size() && !any; ++k) any = H[k] != 0;
+        if (!any) return (int)MDHIP_OK;
+        CallScope fix(ctx);
+        const int n_cls = st->n_cls;
+        const int32_t *rl = st->rel.data();
+        MD_PIN(out, uint64_t, words * 8);
+        MD_HIP(hipMemcpyAsync(out, out_dev, words * 8, hipMemcpyDeviceToHost, ctx->stream));
+        MD_HIP(mdhip_stream_wait(ctx));
         for (int c = 0; c < n_cls; ++c)
             for (int b = 0; b < nbins; ++b) out[b] += 2 * H[(size_t)c * nbins + b];
         for (int kl = 0; kl < n_rel; ++kl) {
-            if (rel_cls[kl] < 0) continue;
-            const uint64_t mult = rel[2 * kl] == rel[2 * kl + 1] ? 2 : 1;
-            for (int b = 0; b < nbins; ++b) out[(size_t)(1 + kl) * nbins + b] += mult * H[(size_t)rel_cls[kl] * nbins + b];
+            if (st->rel_cls[kl] < 0) continue;
+            const uint64_t mult = rl[2 * kl] == rl[2 * kl + 1] ? 2 : 1;
+            for (int b = 0; b < nbins; ++b)
+                out[(size_t)(1 + kl) * nbins + b] += mult * H[(size_t)st->rel_cls[kl] * nbins + b];
         }
-        out[words - 1] += ov;
-        MD_HIP(hipMemcpyAsync(out_dev, out.data(), words * 8, hipMemcpyHostToDevice, ctx->stream));
-        MD_HIP(hipStreamSynchronize(ctx->stream));
+        out[words - 1] += st->ov;
+        MD_HIP(hipMemcpyAsync(out_dev, out, words * 8, hipMemcpyHostToDevice, ctx->stream));
+        return fix.end();
+    });
+    return cs.end();
+}
+
+// A finished array of counts goes to the caller: host memory at once, device memory through a copy of its own.
+static int deliver_counts(mdhip_ctx *ctx, const uint64_t *src, size_t n, uint64_t *dst, int dst_on_device)
+{
+    if (!dst_on_device) {
+        if (dst != src) memcpy(dst, src, n * 8);
+        return MDHIP_OK;
     }
-    return MDHIP_OK;
+    CallScope cs(ctx);
+    const int rc = mdhip_h2d_small(ctx, dst, src, n * 8);
+    if (rc) return rc;
+    return cs.end();
 }
 
 // One sweep for the histograms AND the coordination counts. hist_full / hist_part / overflow may be
 // NULL (coordination counts only: mdhip_cn_atomic runs its cutoffs through here with a coarse 64-bin histogram whose
 // cutoff is the largest coordination cutoff). Returns MDHIP_OK, an error, or CN_UNFUSED when this call has to take the
 // two-sweep route (a cutoff beyond r_cut, two cutoffs for one class, a geometry the packed sweep does not take).
-static int fused_rdf_cn(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *xyz, int on_device,
+// The work is issued into the caller's scope `cs`; its host half is a completion step of that call. cn: host, or
+// device memory (cn_on_device; frame-summed only).
+static int fused_rdf_cn(CallScope &cs, int64_t n_frames, int64_t n_atoms, const double *xyz, int on_device,
                         const int32_t *type, int64_t type_frame_stride, const double *box, int n_rel,
                         const int32_t *rel, double r_cut_sq, double bin_size, int nbins, const double *edges,
                         const double *cn_r_cut_sq, int per_frame, uint64_t *hist_full, uint64_t *hist_part,
-                        uint64_t *overflow, uint64_t *cn)
+                        uint64_t *overflow, uint64_t *cn, int cn_on_device)
 {
+    mdhip_ctx *ctx = cs.ctx;
     bool fused = n_rel > 0 && n_frames > 0 && n_atoms >= 2;
     for (int kl = 0; kl < n_rel && fused; ++kl) fused = !(cn_r_cut_sq[kl] > r_cut_sq);
     if (!fused) return CN_UNFUSED;
     MD_HIP(hipSetDevice(ctx->device));
     const size_t out_frames = per_frame ? (size_t)n_frames : 1;
-    std::vector<double> own_edges;
-    const double *use_edges = edges;
-    if (!use_edges) {
-        own_edges.resize(nbins + 1);
-        mdhip_bin_edges(bin_size, nbins, own_edges.data());
-        use_edges = own_edges.data();
-    }
+    auto st = std::make_shared<PairState>();
     RelJob j{};
-    j.tri = true;
-    j.F = n_frames;
-    j.ni = j.nj = n_atoms;
-    j.xi = xyz;
-    j.xi_dev = on_device;
-    j.lab_i = type;
-    j.lab_i_fs = type_frame_stride;
-    j.box = box;
-    j.n_rel = n_rel;
-    j.rel = rel;
-    j.nbins = nbins;
-    j.edges = use_edges;
-    j.rc2 = r_cut_sq;
-    j.gscale = (float)(1.0 / bin_size);
-    j.bin_size = bin_size;
-    j.per_frame = per_frame;
-    std::vector<uint64_t> H, Hsplit;
-    std::vector<double> c2_cls;
-    j.cn_rc2 = cn_r_cut_sq;
-    j.Hsplit = &Hsplit;
-    j.cn_c2_cls = &c2_cls;
-    std::vector<int> rel_cls;
-    int n_cls = 0;
-    uint64_t ov = 0;
-    const int rc = run_job(ctx, j, H, rel_cls, n_cls, &ov);
+    atomic_job(j, n_frames, n_atoms, xyz, on_device, type, type_frame_stride, box, n_rel, rel, r_cut_sq, bin_size, nbins,
+               state_edges(*st, edges, bin_size, nbins), per_frame);
+    st->rel.assign(rel, rel + 2 * (size_t)n_rel);
+    auto cuts = std::make_shared<std::vector<double>>(cn_r_cut_sq, cn_r_cut_sq + n_rel);
+    j.cn_rc2 = cuts->data();
+    j.Hsplit = &st->Hsplit;
+    j.cn_c2_cls = &st->c2_cls;
+    const int rc = run_job(ctx, j, st->H, st->rel_cls, st->n_cls, &st->ov, cs.async() ? &cs : nullptr, &st->redo);
     if (rc != MDHIP_OK) return rc;  // an error, or CN_UNFUSED
-    if (overflow) *overflow = ov;
-    if (hist_full) std::fill(hist_full, hist_full + out_frames * nbins, (uint64_t)0);
-    for (size_t f = 0; f < out_frames; ++f) {
-        const uint64_t *Hf = &H[f * n_cls * nbins];
-        if (hist_full) {
-            uint64_t *full = hist_full + f * nbins;
-            for (int c = 0; c < n_cls; ++c)
-                for (int b = 0; b < nbins; ++b) full[b] += 2 * Hf[(size_t)c * nbins + b];
+    cs.defer([=]() {
+        if (st->redo) {
+            // the same sweep again, inside a synchronous call of its own (which halves the batch where it has to)
+            CallScope again(ctx);
+            const int rc2 = fused_rdf_cn(again, n_frames, n_atoms, xyz, on_device, type, type_frame_stride, box, n_rel,
+                                         st->rel.data(), r_cut_sq, bin_size, nbins, st->edges.data(), cuts->data(),
+                                         per_frame, hist_full, hist_part, overflow, cn, cn_on_device);
+            if (rc2 != MDHIP_OK)
+                return rc2 == CN_UNFUSED ? mdhip_fail(ctx, MDHIP_EHIP, "pair_hist: the one-sweep path refused its own re-run") : rc2;
+            return again.end();
         }
-        for (int kl = 0; kl < n_rel; ++kl) {
-            uint64_t *part = hist_part ? hist_part + (f * n_rel + kl) * nbins : nullptr;
-            uint64_t s = 0;
-            const uint64_t mult = rel[2 * kl] == rel[2 * kl + 1] ? 2 : 1;
-            if (rel_cls[kl] < 0) {
-                if (part) std::fill(part, part + nbins, (uint64_t)0);
-            } else {
-                const int cl = rel_cls[kl];
-                const uint64_t *row = Hf + (size_t)cl * nbins;
-                if (part)
-                    for (int b = 0; b < nbins; ++b) part[b] = mult * row[b];
-                const double c2 = c2_cls[cl];
-                if (c2 > 0.0) {
-                    // bins below the split bin are inside the cutoff (exact edges); the split bin's share was
-                    // counted by the exact chain (a cutoff inside the overflow bin, index nbins: all bins plus
-                    // the overflow pairs below the cutoff)
-                    const int kc = (int)(std::upper_bound(use_edges, use_edges + nbins + 1, c2) - use_edges) - 1;
-                    for (int b = 0; b < kc && b < nbins; ++b) s += row[b];
-                    s += Hsplit[f * n_cls + cl];
-                }
+        const std::vector<uint64_t> &H = st->H, &Hsplit = st->Hsplit;
+        const double *use_edges = st->edges.data();
+        const int32_t *rl = st->rel.data();
+        const int n_cls = st->n_cls;
+        if (overflow) *overflow = st->ov;
+        if (hist_full) std::fill(hist_full, hist_full + out_frames * nbins, (uint64_t)0);
+        std::vector<uint64_t> cn_host(cn_on_device ? out_frames * (size_t)n_rel : 0);
+        uint64_t *cn_out = cn_on_device ? cn_host.data() : cn;
+        for (size_t f = 0; f < out_frames; ++f) {
+            const uint64_t *Hf = &H[f * n_cls * nbins];
+            if (hist_full) {
+                uint64_t *full = hist_full + f * nbins;
+                for (int c = 0; c < n_cls; ++c)
+                    for (int b = 0; b < nbins; ++b) full[b] += 2 * Hf[(size_t)c * nbins + b];
             }
-            cn[f * n_rel + kl] = mult * s;
+            for (int kl = 0; kl < n_rel; ++kl) {
+                uint64_t *part = hist_part ? hist_part + (f * n_rel + kl) * nbins : nullptr;
+                uint64_t s = 0;
+                const uint64_t mult = rl[2 * kl] == rl[2 * kl + 1] ? 2 : 1;
+                if (st->rel_cls[kl] < 0) {
+                    if (part) std::fill(part, part + nbins, (uint64_t)0);
+                } else {
+                    const int cl = st->rel_cls[kl];
+                    const uint64_t *row = Hf + (size_t)cl * nbins;
+                    if (part)
+                        for (int b = 0; b < nbins; ++b) part[b] = mult * row[b];
+                    const double c2 = st->c2_cls[cl];
+                    if (c2 > 0.0) {
+                        // bins below the split bin are inside the cutoff (exact edges); the split bin's share was
+                        // counted by the exact chain (a cutoff inside the overflow bin, index nbins: all bins plus
+                        // the overflow pairs below the cutoff)
+                        const int kc = (int)(std::upper_bound(use_edges, use_edges + nbins + 1, c2) - use_edges) - 1;
+                        for (int b = 0; b < kc && b < nbins; ++b) s += row[b];
+                        s += Hsplit[f * n_cls + cl];
+                    }
+                }
+                cn_out[f * n_rel + kl] = mult * s;
+            }
         }
-    }
+        return deliver_counts(ctx, cn_out, out_frames * (size_t)n_rel, cn, cn_on_device);
+    });
     return MDHIP_OK;
 }
+
+static int cn_atomic_impl(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *xyz, int on_device,
+                          const int32_t *type, int64_t type_frame_stride, const double *box, int n_rel,
+                          const int32_t *rel, const double *r_cut_sq, int per_frame, uint64_t *cn, int cn_on_device);
 
 int mdhip_rdf_cn_atomic(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *xyz, int on_device,
                         const int32_t *type, int64_t type_frame_stride, const double *box, int n_rel,
@@ -1217,41 +1308,49 @@ int mdhip_rdf_cn_atomic(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const
                         const double *cn_r_cut_sq, int per_frame, uint64_t *hist_full, uint64_t *hist_part,
                         uint64_t *overflow, uint64_t *cn)
 {
+    if (!ctx) return MDHIP_EINVAL;
+    CallScope cs(ctx);
     int rc = check_common(ctx, n_frames, n_atoms, xyz, type, box, n_rel, rel);
     if (rc) return rc;
     MD_REQUIRE(nbins >= 1 && bin_size > 0.0, "nbins and bin_size must be positive");
     MD_REQUIRE(type_frame_stride == 0 || type_frame_stride == n_atoms, "type_frame_stride must be 0 or n_atoms");
     MD_REQUIRE(hist_full && (n_rel == 0 || (hist_part && cn_r_cut_sq && cn)), "NULL output or cutoff array");
-    rc = fused_rdf_cn(ctx, n_frames, n_atoms, xyz, on_device, type, type_frame_stride, box, n_rel, rel, r_cut_sq,
-                      bin_size, nbins, edges, cn_r_cut_sq, per_frame, hist_full, hist_part, overflow, cn);
+    rc = fused_rdf_cn(cs, n_frames, n_atoms, xyz, on_device, type, type_frame_stride, box, n_rel, rel, r_cut_sq,
+                      bin_size, nbins, edges, cn_r_cut_sq, per_frame, hist_full, hist_part, overflow, cn, 0);
+    if (rc == MDHIP_OK) return cs.end();
     if (rc != CN_UNFUSED) return rc;
-    // this call does not run as one packed sweep — two sweeps, same integers
+    // this call does not run as one packed sweep — two sweeps (calls of their own, complete on return), same integers
     rc = mdhip_rdf_atomic(ctx, n_frames, n_atoms, xyz, on_device, type, type_frame_stride, box, n_rel, rel, r_cut_sq,
                           bin_size, nbins, edges, per_frame, hist_full, hist_part, overflow);
     if (rc) return rc;
-    return mdhip_cn_atomic(ctx, n_frames, n_atoms, xyz, on_device, type, type_frame_stride, box, n_rel, rel,
-                           cn_r_cut_sq, per_frame, cn);
+    rc = cn_atomic_impl(ctx, n_frames, n_atoms, xyz, on_device, type, type_frame_stride, box, n_rel, rel,
+                        cn_r_cut_sq, per_frame, cn, 0);
+    if (rc) return rc;
+    return cs.end();
 }
 
-int mdhip_cn_atomic(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *xyz,
-                    int on_device, const int32_t *type, int64_t type_frame_stride,
-                    const double *box, int n_rel, const int32_t *rel, const double *r_cut_sq,
-                    int per_frame, uint64_t *cn)
+static int cn_atomic_impl(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *xyz, int on_device,
+                          const int32_t *type, int64_t type_frame_stride, const double *box, int n_rel,
+                          const int32_t *rel, const double *r_cut_sq, int per_frame, uint64_t *cn, int cn_on_device)
 {
+    if (!ctx) return MDHIP_EINVAL;
+    CallScope cs(ctx);
     int rc = check_common(ctx, n_frames, n_atoms, xyz, type, box, n_rel, rel);
     if (rc) return rc;
     MD_REQUIRE(n_rel == 0 || (r_cut_sq && cn), "NULL cutoff or output");
     MD_REQUIRE(type_frame_stride == 0 || type_frame_stride == n_atoms,
                "type_frame_stride must be 0 or n_atoms");
+    MD_REQUIRE(!cn_on_device || !per_frame, "a device result buffer holds the frame-summed counts");
     MD_HIP(hipSetDevice(ctx->device));
     const size_t out_frames = per_frame ? (size_t)n_frames : 1;
-    std::fill(cn, cn + out_frames * n_rel, (uint64_t)0);
-    if (n_frames == 0 || n_atoms < 2 || n_rel == 0) return MDHIP_OK;
+    rc = mdhip_zero_result(ctx, cn, out_frames * (size_t)n_rel * 8, cn_on_device);
+    if (rc) return rc;
+    if (n_frames == 0 || n_atoms < 2 || n_rel == 0) return cs.end();
     std::vector<double> edges;
     std::vector<int> rank;
     cn_edges(n_rel, r_cut_sq, edges, rank);
     const int nbins = (int)edges.size() - 1;
-    if (nbins == 0) return MDHIP_OK;
+    if (nbins == 0) return cs.end();
     if (ctx->opt_cn_pk != 0) {
         // Option cn_pk (default): the packed-f32 sweep with a coarse histogram whose cutoff is the largest coordination
         // cutoff; the counts are the exact bins below each class's split bin plus the split-bin pairs the exact chain
@@ -1259,33 +1358,22 @@ int mdhip_cn_atomic(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const dou
         // everything the packed sweep does not take (small frames, two cutoffs for one class, ...) and for cn_pk = 0.
         const double c_max = std::sqrt(edges.back());
         const int nb = 64;
-        rc = fused_rdf_cn(ctx, n_frames, n_atoms, xyz, on_device, type, type_frame_stride, box, n_rel, rel,
-                          edges.back(), c_max / nb, nb, nullptr, r_cut_sq, per_frame, nullptr, nullptr, nullptr, cn);
+        rc = fused_rdf_cn(cs, n_frames, n_atoms, xyz, on_device, type, type_frame_stride, box, n_rel, rel,
+                          edges.back(), c_max / nb, nb, nullptr, r_cut_sq, per_frame, nullptr, nullptr, nullptr, cn,
+                          cn_on_device);
+        if (rc == MDHIP_OK) return cs.end();
         if (rc != CN_UNFUSED) return rc;
-        std::fill(cn, cn + out_frames * n_rel, (uint64_t)0);
     }
     RelJob j{};
-    j.tri = true;
-    j.F = n_frames;
-    j.ni = j.nj = n_atoms;
-    j.xi = xyz;
-    j.xi_dev = on_device;
-    j.lab_i = type;
-    j.lab_i_fs = type_frame_stride;
-    j.box = box;
-    j.n_rel = n_rel;
-    j.rel = rel;
-    j.nbins = nbins;
-    j.edges = edges.data();
-    j.rc2 = edges.back();
-    j.gscale = 0.f;
-    j.per_frame = per_frame;
+    atomic_job(j, n_frames, n_atoms, xyz, on_device, type, type_frame_stride, box, n_rel, rel, edges.back(), 0.0, nbins,
+               edges.data(), per_frame);
     std::vector<uint64_t> H;
     std::vector<int> rel_cls;
     int n_cls = 0;
     uint64_t ov = 0;
-    rc = run_job(ctx, j, H, rel_cls, n_cls, &ov);
+    rc = run_job(ctx, j, H, rel_cls, n_cls, &ov);  // (edge-table kernel: completes inside)
     if (rc) return rc;
+    std::vector<uint64_t> cn_host(out_frames * (size_t)n_rel, 0);
     for (size_t f = 0; f < out_frames; ++f)
         for (int kl = 0; kl < n_rel; ++kl) {
             if (rel_cls[kl] < 0) continue;
@@ -1293,9 +1381,24 @@ int mdhip_cn_atomic(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const dou
             const uint64_t *row = &H[(f * n_cls + rel_cls[kl]) * nbins];
             uint64_t s = 0;
             for (int b = 0; b < rank[kl]; ++b) s += row[b];
-            cn[f * n_rel + kl] = mult * s;
+            cn_host[f * n_rel + kl] = mult * s;
         }
-    return MDHIP_OK;
+    if (cn_on_device) {
+        rc = mdhip_h2d_small(ctx, cn, cn_host.data(), cn_host.size() * 8);
+        if (rc) return rc;
+    } else {
+        memcpy(cn, cn_host.data(), cn_host.size() * 8);
+    }
+    return cs.end();
+}
+
+int mdhip_cn_atomic(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *xyz,
+                    int on_device, const int32_t *type, int64_t type_frame_stride,
+                    const double *box, int n_rel, const int32_t *rel, const double *r_cut_sq,
+                    int per_frame, uint64_t *cn)
+{
+    return cn_atomic_impl(ctx, n_frames, n_atoms, xyz, on_device, type, type_frame_stride, box, n_rel, rel, r_cut_sq,
+                          per_frame, cn, 0);
 }
 
 int mdhip_cn_atomic_dev(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *xyz, int on_device,
@@ -1304,18 +1407,53 @@ int mdhip_cn_atomic_dev(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const
 {
     if (!ctx) return MDHIP_EINVAL;
     MD_REQUIRE(n_rel == 0 || cn_dev, "NULL output");
-    // the n_rel count words are folded from the class rows on the host (prefix sums over a few bins per relation);
-    // they go to the caller's device buffer from there
-    std::vector<uint64_t> cn((size_t)std::max(n_rel, 1), 0);
-    const int rc = mdhip_cn_atomic(ctx, n_frames, n_atoms, xyz, on_device, type, type_frame_stride, box, n_rel, rel,
-                                   r_cut_sq, 0, cn.data());
-    if (rc) return rc;
-    if (n_rel > 0) {
-        MD_HIP(hipSetDevice(ctx->device));
-        MD_HIP(hipMemcpyAsync(cn_dev, cn.data(), (size_t)n_rel * 8, hipMemcpyHostToDevice, ctx->stream));
-        MD_HIP(hipStreamSynchronize(ctx->stream));
-    }
-    return MDHIP_OK;
+    return cn_atomic_impl(ctx, n_frames, n_atoms, xyz, on_device, type, type_frame_stride, box, n_rel, rel, r_cut_sq, 0,
+                          cn_dev, 1);
+}
+
+/* ---- asynchronous twins (results complete after mdhip_sync / mdhip_wait; inputs must stay valid until then) ---- */
+int mdhip_rdf_atomic_async(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *xyz, int on_device,
+                           const int32_t *type, int64_t type_frame_stride, const double *box, int n_rel,
+                           const int32_t *rel, double r_cut_sq, double bin_size, int nbins, const double *edges,
+                           int per_frame, uint64_t *hist_full, uint64_t *hist_part, uint64_t *overflow)
+{
+    if (!ctx) return MDHIP_EINVAL;
+    AsyncCall mark(ctx);
+    return mdhip_rdf_atomic(ctx, n_frames, n_atoms, xyz, on_device, type, type_frame_stride, box, n_rel, rel, r_cut_sq,
+                            bin_size, nbins, edges, per_frame, hist_full, hist_part, overflow);
+}
+
+int mdhip_rdf_atomic_dev_async(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *xyz, int on_device,
+                               const int32_t *type, int64_t type_frame_stride, const double *box, int n_rel,
+                               const int32_t *rel, double r_cut_sq, double bin_size, int nbins, const double *edges,
+                               uint64_t *out_dev)
+{
+    if (!ctx) return MDHIP_EINVAL;
+    AsyncCall mark(ctx);
+    return mdhip_rdf_atomic_dev(ctx, n_frames, n_atoms, xyz, on_device, type, type_frame_stride, box, n_rel, rel, r_cut_sq,
+                                bin_size, nbins, edges, out_dev);
+}
+
+int mdhip_rdf_cn_atomic_async(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *xyz, int on_device,
+                              const int32_t *type, int64_t type_frame_stride, const double *box, int n_rel,
+                              const int32_t *rel, double r_cut_sq, double bin_size, int nbins, const double *edges,
+                              const double *cn_r_cut_sq, int per_frame, uint64_t *hist_full, uint64_t *hist_part,
+                              uint64_t *overflow, uint64_t *cn)
+{
+    if (!ctx) return MDHIP_EINVAL;
+    AsyncCall mark(ctx);
+    return mdhip_rdf_cn_atomic(ctx, n_frames, n_atoms, xyz, on_device, type, type_frame_stride, box, n_rel, rel, r_cut_sq,
+                               bin_size, nbins, edges, cn_r_cut_sq, per_frame, hist_full, hist_part, overflow, cn);
+}
+
+int mdhip_cn_atomic_async(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *xyz, int on_device,
+                          const int32_t *type, int64_t type_frame_stride, const double *box, int n_rel,
+                          const int32_t *rel, const double *r_cut_sq, int per_frame, uint64_t *cn, int cn_on_device)
+{
+    if (!ctx) return MDHIP_EINVAL;
+    AsyncCall mark(ctx);
+    return cn_atomic_impl(ctx, n_frames, n_atoms, xyz, on_device, type, type_frame_stride, box, n_rel, rel, r_cut_sq,
+                          per_frame, cn, cn_on_device ? 1 : 0);
 }
 
 int mdhip_rdf_sites(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *xyz,
@@ -1324,6 +1462,8 @@ int mdhip_rdf_sites(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const dou
                     const int32_t *rel, double r_cut_sq, double bin_size, int nbins,
                     const double *edges, int per_frame, uint64_t *hist_part, uint64_t *overflow)
 {
+    if (!ctx) return MDHIP_EINVAL;
+    CallScope cs(ctx);  // (atoms x sites: completes inside)
     int rc = check_common(ctx, n_frames, n_atoms, xyz, type, box, n_rel, rel);
     if (rc) return rc;
     MD_REQUIRE(n_sites >= 0 && n_sites < (1LL << 31), "bad n_sites");
@@ -1334,7 +1474,7 @@ int mdhip_rdf_sites(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const dou
     const size_t out_frames = per_frame ? (size_t)n_frames : 1;
     if (n_rel) std::fill(hist_part, hist_part + out_frames * n_rel * nbins, (uint64_t)0);
     if (overflow) *overflow = 0;
-    if (n_frames == 0 || n_atoms == 0 || n_sites == 0 || n_rel == 0) return MDHIP_OK;
+    if (n_frames == 0 || n_atoms == 0 || n_sites == 0 || n_rel == 0) return cs.end();
     std::vector<double> own_edges;
     if (!edges) {
         own_edges.resize(nbins + 1);
@@ -1375,7 +1515,7 @@ int mdhip_rdf_sites(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const dou
             memcpy(hist_part + (f * n_rel + kl) * nbins, &H[(f * n_cls + rel_cls[kl]) * nbins],
                    (size_t)nbins * 8);
         }
-    return MDHIP_OK;
+    return cs.end();
 }
 
 int mdhip_cn_sites(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *xyz,
@@ -1383,6 +1523,8 @@ int mdhip_cn_sites(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const doub
                    int sites_on_device, const int32_t *site_type, const double *box, int n_rel,
                    const int32_t *rel, const double *r_cut_sq, int per_frame, uint64_t *cn)
 {
+    if (!ctx) return MDHIP_EINVAL;
+    CallScope cs(ctx);  // (atoms x sites: completes inside)
     int rc = check_common(ctx, n_frames, n_atoms, xyz, type, box, n_rel, rel);
     if (rc) return rc;
     MD_REQUIRE(n_sites >= 0 && n_sites < (1LL << 31), "bad n_sites");
@@ -1391,12 +1533,12 @@ int mdhip_cn_sites(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const doub
     MD_HIP(hipSetDevice(ctx->device));
     const size_t out_frames = per_frame ? (size_t)n_frames : 1;
     std::fill(cn, cn + out_frames * n_rel, (uint64_t)0);
-    if (n_frames == 0 || n_atoms == 0 || n_sites == 0 || n_rel == 0) return MDHIP_OK;
+    if (n_frames == 0 || n_atoms == 0 || n_sites == 0 || n_rel == 0) return cs.end();
     std::vector<double> edges;
     std::vector<int> rank;
     cn_edges(n_rel, r_cut_sq, edges, rank);
     const int nbins = (int)edges.size() - 1;
-    if (nbins == 0) return MDHIP_OK;
+    if (nbins == 0) return cs.end();
     RelJob j{};
     j.tri = false;
     j.F = n_frames;
@@ -1431,7 +1573,7 @@ int mdhip_cn_sites(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const doub
             for (int b = 0; b < rank[kl]; ++b) s += row[b];
             cn[f * n_rel + kl] = s;
         }
-    return MDHIP_OK;
+    return cs.end();
 }
 
 }  // extern "C"

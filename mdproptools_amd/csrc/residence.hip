@@ -203,12 +203,13 @@ int mdhip_shell_residence(mdhip_ctx *ctx, int64_t n_frames, int64_t n_i, const d
                           double r_hi_sq, int exclude_diagonal, uint64_t *counts, uint64_t *n_records)
 {
     if (!ctx) return MDHIP_EINVAL;
+    CallScope cs(ctx);  // (synchronous throughout: the record and run counts steer the launches that follow)
     MD_REQUIRE(n_frames >= 0 && n_i >= 0 && n_j >= 0, "negative sizes");
     MD_REQUIRE(n_frames == 0 || counts, "counts is NULL");
     MD_REQUIRE(!exclude_diagonal || n_i == n_j, "exclude_diagonal needs identical sets");
     if (n_records) *n_records = 0;
     std::fill(counts, counts + n_frames, (uint64_t)0);
-    if (n_frames == 0 || n_i == 0 || n_j == 0) return MDHIP_OK;
+    if (n_frames == 0 || n_i == 0 || n_j == 0) return cs.end();
     MD_REQUIRE(xi && xj && box, "NULL input array");
     int frame_bits = 1;
     while ((1LL << frame_bits) < n_frames) ++frame_bits;
@@ -228,14 +229,14 @@ int mdhip_shell_residence(mdhip_ctx *ctx, int64_t n_frames, int64_t n_i, const d
         if (rc) return rc;
     }
     MD_WS(d_box, double, WS_BOX, (size_t)n_frames * 3 * 8);
-    MD_PIN(h_box, double, PIN_TYPES, (size_t)n_frames * 3 * 8);
+    MD_PIN(h_box, double, (size_t)n_frames * 3 * 8);
     memcpy(h_box, box, (size_t)n_frames * 3 * 8);
     MD_HIP(hipMemcpyAsync(d_box, h_box, (size_t)n_frames * 3 * 8, hipMemcpyHostToDevice, ctx->stream));
     MD_WS(d_misc, unsigned long long, WS_MISC, 64);
     MD_HIP(hipMemsetAsync(d_misc, 0, 64, ctx->stream));
     MD_WS(d_counts, unsigned long long, WS_OUT, (size_t)n_frames * 8);
     MD_HIP(hipMemsetAsync(d_counts, 0, (size_t)n_frames * 8, ctx->stream));
-    MD_PIN(h_out, unsigned long long, PIN_OUT, ((size_t)n_frames + 8) * 8);
+    MD_PIN(h_out, unsigned long long, ((size_t)n_frames + 8) * 8);
 
     const dim3 grid((unsigned)((n_i + RT_TILE - 1) / RT_TILE), (unsigned)n_frames);
     KernelTimer timer(ctx);
@@ -245,14 +246,18 @@ int mdhip_shell_residence(mdhip_ctx *ctx, int64_t n_frames, int64_t n_i, const d
                        (unsigned long long *)nullptr, 0ull);
     MD_HIP(hipGetLastError());
     MD_HIP(hipMemcpyAsync(h_out, d_misc, 8, hipMemcpyDeviceToHost, ctx->stream));
-    MD_HIP(hipStreamSynchronize(ctx->stream));
+    MD_HIP(mdhip_stream_wait(ctx));
     const unsigned long long n_rec = h_out[0];
     if (n_records) *n_records = n_rec;
     if (n_rec == 0) {
         timer.stop();
-        MD_HIP(hipStreamSynchronize(ctx->stream));
-        timer.collect();
-        return MDHIP_OK;
+        MD_HIP(mdhip_stream_wait(ctx));
+        const double ms0 = timer.collect();
+        cs.defer([ctx, ms0]() {
+            ctx->last_ms = ms0;
+            return MDHIP_OK;
+        });
+        return cs.end();
     }
     MD_WS(d_rec, unsigned long long, WS_AUX0, (size_t)n_rec * 8);
     MD_WS(d_srt, unsigned long long, WS_AUX1, (size_t)n_rec * 8);
@@ -270,7 +275,7 @@ int mdhip_shell_residence(mdhip_ctx *ctx, int64_t n_frames, int64_t n_i, const d
                        n_rec, frame_bits, d_misc + 2, d_starts);
     MD_HIP(hipGetLastError());
     MD_HIP(hipMemcpyAsync(h_out, d_misc + 2, 8, hipMemcpyDeviceToHost, ctx->stream));
-    MD_HIP(hipStreamSynchronize(ctx->stream));
+    MD_HIP(mdhip_stream_wait(ctx));
     const unsigned long long n_runs = h_out[0];
     if (lds_b > 65536)
         MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(residence_lag_kernel),
@@ -281,10 +286,14 @@ int mdhip_shell_residence(mdhip_ctx *ctx, int64_t n_frames, int64_t n_i, const d
     timer.stop();
     MD_HIP(hipGetLastError());
     MD_HIP(hipMemcpyAsync(h_out, d_counts, (size_t)n_frames * 8, hipMemcpyDeviceToHost, ctx->stream));
-    MD_HIP(hipStreamSynchronize(ctx->stream));
-    timer.collect();
+    MD_HIP(mdhip_stream_wait(ctx));
+    const double ms = timer.collect();
     memcpy(counts, h_out, (size_t)n_frames * 8);
-    return MDHIP_OK;
+    cs.defer([ctx, ms]() {
+        ctx->last_ms = ms;
+        return MDHIP_OK;
+    });
+    return cs.end();
 }
 
 }  // extern "C"

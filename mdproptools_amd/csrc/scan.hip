@@ -134,33 +134,12 @@ __global__ __launch_bounds__(SC_THREADS) void trap_scan_add_kernel(
 
 }  // namespace
 
-extern "C" {
-
-int mdhip_cumtrapz(mdhip_ctx *ctx, int64_t n, int n_series, const double *y, int on_device,
-                   double dx, int leading_zero, double *out)
+// y device [n_series][n] -> d_out device [n_series][n - 1 + lead]; everything on the context's stream
+int mdhip_cumtrapz_enqueue(mdhip_ctx *ctx, int64_t n, int n_series, const double *d_y, double dx, int lead, double *d_out)
 {
-    if (!ctx) return MDHIP_EINVAL;
-    MD_REQUIRE(n >= 0 && n_series >= 0, "negative sizes");
-    if (n_series == 0 || n == 0) return MDHIP_OK;
-    MD_REQUIRE(y && out, "NULL array");
-    MD_REQUIRE(n_series <= 65535, "at most 65535 series per call");
-    const int lead = leading_zero ? 1 : 0;
     const int64_t out_stride = n - 1 + lead;
-    if (n == 1) {
-        if (lead)
-            for (int s = 0; s < n_series; ++s) out[s] = 0.0;
-        return MDHIP_OK;
-    }
-    MD_HIP(hipSetDevice(ctx->device));
-    int rc;
-    const double *d_y = (const double *)mdhip_stage(ctx, WS_XYZ_I, y, (size_t)n_series * n * 8, on_device, &rc);
-    if (rc) return rc;
     const int n_blocks = (int)((n - 1 + SC_BLOCK - 1) / SC_BLOCK);
-    const size_t out_b = (size_t)n_series * out_stride * 8;
-    MD_WS(d_out, double, WS_OUT, out_b);
     MD_WS(d_tot, double, WS_PART, (size_t)n_series * n_blocks * 8);
-    KernelTimer timer(ctx);
-    ctx->last_kernel = "trap_scan_local_kernel";
     hipLaunchKernelGGL(trap_scan_local_kernel, dim3((unsigned)n_blocks, (unsigned)n_series),
                        dim3(SC_THREADS), 0, ctx->stream, d_y, d_out, d_tot, (long long)n,
                        (long long)out_stride, lead, dx, n_blocks);
@@ -169,12 +148,82 @@ int mdhip_cumtrapz(mdhip_ctx *ctx, int64_t n, int n_series, const double *y, int
     hipLaunchKernelGGL(trap_scan_add_kernel, dim3((unsigned)n_blocks, (unsigned)n_series),
                        dim3(SC_THREADS), 0, ctx->stream, d_out, d_tot, (long long)n,
                        (long long)out_stride, lead, n_blocks);
-    timer.stop();
     MD_HIP(hipGetLastError());
-    MD_HIP(hipMemcpyAsync(out, d_out, out_b, hipMemcpyDeviceToHost, ctx->stream));
-    MD_HIP(hipStreamSynchronize(ctx->stream));
-    timer.collect();
     return MDHIP_OK;
+}
+
+static int cumtrapz_impl(mdhip_ctx *ctx, int64_t n, int n_series, const double *y, int on_device, double dx,
+                         int leading_zero, double *out, int out_on_device)
+{
+    if (!ctx) return MDHIP_EINVAL;
+    CallScope cs(ctx);
+    MD_REQUIRE(n >= 0 && n_series >= 0, "negative sizes");
+    if (n_series == 0 || n == 0) return cs.end();
+    MD_REQUIRE(y && out, "NULL array");
+    MD_REQUIRE(n_series <= 65535, "at most 65535 series per call");
+    const int lead = leading_zero ? 1 : 0;
+    const int64_t out_stride = n - 1 + lead;
+    MD_HIP(hipSetDevice(ctx->device));
+    if (n == 1) {
+        if (lead) {
+            const int rc0 = mdhip_zero_result(ctx, out, (size_t)n_series * 8, out_on_device);
+            if (rc0) return rc0;
+        }
+        return cs.end();
+    }
+    int rc;
+    const double *d_y = (const double *)mdhip_stage(ctx, WS_XYZ_I, y, (size_t)n_series * n * 8, on_device, &rc);
+    if (rc) return rc;
+    const size_t out_b = (size_t)n_series * out_stride * 8;
+    double *d_out = out;
+    if (!out_on_device) {
+        d_out = (double *)mdhip_ws(ctx, WS_OUT, out_b);
+        if (!d_out) return MDHIP_ENOMEM;
+    }
+    KernelTimer timer(ctx);
+    ctx->last_kernel = "trap_scan_local_kernel";
+    rc = mdhip_cumtrapz_enqueue(ctx, n, n_series, d_y, dx, lead, d_out);
+    if (rc) return rc;
+    timer.stop();
+    if (!out_on_device) {
+        rc = mdhip_result(cs, out, d_out, out_b, 0);
+        if (rc) return rc;
+    }
+    cs.defer([timer]() {
+        timer.collect();
+        return MDHIP_OK;
+    });
+    return cs.end();
+}
+
+extern "C" {
+
+int mdhip_cumtrapz(mdhip_ctx *ctx, int64_t n, int n_series, const double *y, int on_device,
+                   double dx, int leading_zero, double *out)
+{
+    return cumtrapz_impl(ctx, n, n_series, y, on_device, dx, leading_zero, out, 0);
+}
+
+int mdhip_cumtrapz_dev(mdhip_ctx *ctx, int64_t n, int n_series, const double *y, int on_device, double dx,
+                       int leading_zero, double *out_dev)
+{
+    return cumtrapz_impl(ctx, n, n_series, y, on_device, dx, leading_zero, out_dev, 1);
+}
+
+int mdhip_cumtrapz_async(mdhip_ctx *ctx, int64_t n, int n_series, const double *y, int on_device, double dx,
+                         int leading_zero, double *out)
+{
+    if (!ctx) return MDHIP_EINVAL;
+    AsyncCall mark(ctx);
+    return cumtrapz_impl(ctx, n, n_series, y, on_device, dx, leading_zero, out, 0);
+}
+
+int mdhip_cumtrapz_dev_async(mdhip_ctx *ctx, int64_t n, int n_series, const double *y, int on_device, double dx,
+                             int leading_zero, double *out_dev)
+{
+    if (!ctx) return MDHIP_EINVAL;
+    AsyncCall mark(ctx);
+    return cumtrapz_impl(ctx, n, n_series, y, on_device, dx, leading_zero, out_dev, 1);
 }
 
 }  // extern "C"

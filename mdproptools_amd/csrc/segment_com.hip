@@ -378,6 +378,7 @@ int mdhip_segment_com(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, int n_a
                       int out_on_device, double *seg_mass, double *seg_q)
 {
     if (!ctx) return MDHIP_EINVAL;
+    CallScope cs(ctx);
     MD_REQUIRE(n_frames >= 0 && n_atoms >= 0 && n_attr >= 0, "negative sizes");
     MD_REQUIRE(atom_mass || n_atoms == 0, "atom_mass is NULL");
     int rc = check_segments(ctx, n_atoms, n_seg, seg_off);
@@ -394,7 +395,7 @@ int mdhip_segment_com(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, int n_a
         if (seg_mass) seg_mass[s] = m;
         if (seg_q && atom_q) seg_q[s] = q;
     }
-    if (n_frames == 0 || n_seg == 0 || n_attr == 0) return MDHIP_OK;
+    if (n_frames == 0 || n_seg == 0 || n_attr == 0) return cs.end();
     MD_REQUIRE(attr && out, "NULL attr/out");
     MD_HIP(hipSetDevice(ctx->device));
     const double *d_attr = (const double *)mdhip_stage(ctx, WS_AUX0, attr,
@@ -402,9 +403,11 @@ int mdhip_segment_com(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, int n_a
                                                        attr_on_device, &rc);
     if (rc) return rc;
     MD_WS(d_mass, double, WS_AUX1, (size_t)n_atoms * 8);
-    MD_HIP(hipMemcpyAsync(d_mass, atom_mass, (size_t)n_atoms * 8, hipMemcpyHostToDevice, ctx->stream));
+    rc = mdhip_h2d_small(ctx, d_mass, atom_mass, (size_t)n_atoms * 8);
+    if (rc) return rc;
     MD_WS(d_off, long long, WS_AUX2, (size_t)(n_seg + 1) * 8);
-    MD_HIP(hipMemcpyAsync(d_off, seg_off, (size_t)(n_seg + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    rc = mdhip_h2d_small(ctx, d_off, seg_off, (size_t)(n_seg + 1) * 8);
+    if (rc) return rc;
     const size_t out_b = (size_t)n_frames * n_attr * n_seg * 8;
     double *d_out = out;
     if (!out_on_device) {
@@ -436,14 +439,16 @@ int mdhip_segment_com(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, int n_a
         if (!d_tab) return MDHIP_ENOMEM;
         d_runs = reinterpret_cast<SegRun *>(d_tab);
         d_msum = reinterpret_cast<double *>(d_tab + rb);
-        MD_HIP(hipMemcpyAsync(d_runs, runs.data(), rb, hipMemcpyHostToDevice, ctx->stream));
-        MD_HIP(hipMemcpyAsync(d_msum, msum_h.data(), (size_t)n_seg * 8, hipMemcpyHostToDevice, ctx->stream));
-        MD_HIP(hipStreamSynchronize(ctx->stream));  // the tables are locals
+        // (the tables are locals: through pinned staging of the call)
+        rc = mdhip_h2d_small(ctx, d_runs, runs.data(), rb);
+        if (rc) return rc;
+        rc = mdhip_h2d_small(ctx, d_msum, msum_h.data(), (size_t)n_seg * 8);
+        if (rc) return rc;
     } else if (staged) {
         d_blocks = (SegBlock *)mdhip_ws(ctx, WS_AUX3, blocks.size() * sizeof(SegBlock));
         if (!d_blocks) return MDHIP_ENOMEM;
-        MD_HIP(hipMemcpyAsync(d_blocks, blocks.data(), blocks.size() * sizeof(SegBlock), hipMemcpyHostToDevice,
-                              ctx->stream));
+        rc = mdhip_h2d_small(ctx, d_blocks, blocks.data(), blocks.size() * sizeof(SegBlock));
+        if (rc) return rc;
     }
     KernelTimer timer(ctx);
     if (by_frame) {
@@ -484,11 +489,15 @@ int mdhip_segment_com(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, int n_a
     }
     timer.stop();
     MD_HIP(hipGetLastError());
-    if (!out_on_device)
-        MD_HIP(hipMemcpyAsync(out, d_out, out_b, hipMemcpyDeviceToHost, ctx->stream));
-    MD_HIP(hipStreamSynchronize(ctx->stream));
-    timer.collect();
-    return MDHIP_OK;
+    if (!out_on_device) {
+        rc = mdhip_result(cs, out, d_out, out_b, 0);
+        if (rc) return rc;
+    }
+    cs.defer([timer]() {
+        timer.collect();
+        return MDHIP_OK;
+    });
+    return cs.end();
 }
 
 static int charge_flux_impl(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *vel,
@@ -497,12 +506,13 @@ static int charge_flux_impl(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, c
                             double vel_conv, double charge_conv, double *flux, int flux_on_device)
 {
     if (!ctx) return MDHIP_EINVAL;
+    CallScope cs(ctx);
     MD_REQUIRE(n_frames >= 0 && n_atoms >= 0 && n_types >= 0, "negative sizes");
     MD_REQUIRE(n_frames < 65536LL * 65536LL, "too many frames");
     int rc = check_segments(ctx, n_atoms, n_seg, seg_off);
     if (rc) return rc;
     MD_REQUIRE(flux || n_frames == 0 || n_types == 0, "flux is NULL");
-    if (n_frames == 0 || n_types == 0) return MDHIP_OK;
+    if (n_frames == 0 || n_types == 0) return cs.end();
     MD_REQUIRE(vel && atom_mass && atom_q && seg_type, "NULL input");
     // molecules of one type must be contiguous (they are: ids are type-major, com_mols.py:31-42)
     std::vector<long long> type_off(n_types + 1, 0);
@@ -520,15 +530,27 @@ static int charge_flux_impl(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, c
                                                       on_device, &rc);
     if (rc) return rc;
     MD_WS(d_mq, double, WS_AUX1, (size_t)n_atoms * 16);
-    MD_HIP(hipMemcpyAsync(d_mq, atom_mass, (size_t)n_atoms * 8, hipMemcpyHostToDevice, ctx->stream));
-    MD_HIP(hipMemcpyAsync(d_mq + n_atoms, atom_q, (size_t)n_atoms * 8, hipMemcpyHostToDevice, ctx->stream));
+    {
+        // masses | charges and segment offsets | type offsets: pinned staging of the call, one copy each
+        MD_PIN(h_mq, double, (size_t)n_atoms * 16);
+        memcpy(h_mq, atom_mass, (size_t)n_atoms * 8);
+        memcpy(h_mq + n_atoms, atom_q, (size_t)n_atoms * 8);
+        MD_HIP(hipMemcpyAsync(d_mq, h_mq, (size_t)n_atoms * 16, hipMemcpyHostToDevice, ctx->stream));
+    }
     MD_WS(d_off, long long, WS_AUX2, (size_t)(n_seg + 1 + n_types + 1) * 8);
-    MD_HIP(hipMemcpyAsync(d_off, seg_off, (size_t)(n_seg + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    MD_HIP(hipMemcpyAsync(d_off + n_seg + 1, type_off.data(), (size_t)(n_types + 1) * 8,
-                          hipMemcpyHostToDevice, ctx->stream));
+    {
+        MD_PIN(h_off, long long, (size_t)(n_seg + 1 + n_types + 1) * 8);
+        memcpy(h_off, seg_off, (size_t)(n_seg + 1) * 8);
+        memcpy(h_off + n_seg + 1, type_off.data(), (size_t)(n_types + 1) * 8);
+        MD_HIP(hipMemcpyAsync(d_off, h_off, (size_t)(n_seg + 1 + n_types + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
     MD_WS(d_tmp, double, WS_AUX3, (size_t)n_frames * 3 * n_seg * 8);
     const size_t flux_b = (size_t)3 * n_types * n_frames * 8;
-    MD_WS(d_flux, double, WS_OUT, flux_b);
+    double *d_flux = flux;
+    if (!flux_on_device) {
+        d_flux = (double *)mdhip_ws(ctx, WS_OUT, flux_b);
+        if (!d_flux) return MDHIP_ENOMEM;
+    }
     std::vector<SegBlock> blocks;
     // default: four waves share a 1024-atom stage; seg_cap = 256 selects the wave-private form (one wave per block,
     // 256-atom stage, no block barrier that costs anything) — measured 0.61 against 0.635 of HBM spec at C4 shape, so
@@ -544,8 +566,8 @@ static int charge_flux_impl(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, c
         d_blocks = (SegBlock *)mdhip_ws(ctx, WS_PART, blocks.size() * sizeof(SegBlock) +
                                                           (ctx->opt_seg_frame ? blocks.size() * sizeof(SegRun) + (size_t)n_seg * 16 : 0));
         if (!d_blocks) return MDHIP_ENOMEM;
-        MD_HIP(hipMemcpyAsync(d_blocks, blocks.data(), blocks.size() * sizeof(SegBlock), hipMemcpyHostToDevice,
-                              ctx->stream));
+        rc = mdhip_h2d_small(ctx, d_blocks, blocks.data(), blocks.size() * sizeof(SegBlock));
+        if (rc) return rc;
     }
     const bool by_frame = staged && ctx->opt_seg_frame != 0 && cap == SC_CAP_MAX;
     SegRun *d_runs = nullptr;
@@ -567,9 +589,10 @@ static int charge_flux_impl(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, c
         }
         d_runs = reinterpret_cast<SegRun *>(d_blocks + blocks.size());
         d_msq = reinterpret_cast<double *>(d_runs + runs.size());
-        MD_HIP(hipMemcpyAsync(d_runs, runs.data(), runs.size() * sizeof(SegRun), hipMemcpyHostToDevice, ctx->stream));
-        MD_HIP(hipMemcpyAsync(d_msq, msq.data(), msq.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-        MD_HIP(hipStreamSynchronize(ctx->stream));  // the tables are locals
+        rc = mdhip_h2d_small(ctx, d_runs, runs.data(), runs.size() * sizeof(SegRun));  // (the tables are locals)
+        if (rc) return rc;
+        rc = mdhip_h2d_small(ctx, d_msq, msq.data(), msq.size() * 8);
+        if (rc) return rc;
     }
     KernelTimer timer(ctx);
     if (by_frame) {
@@ -614,10 +637,15 @@ static int charge_flux_impl(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, c
                            (long long)n_seg, (long long)n_frames, n_types);
         MD_HIP(hipGetLastError());
     }
-    MD_HIP(mdhip_deliver(ctx, flux, d_flux, flux_b, flux_on_device));
-    MD_HIP(hipStreamSynchronize(ctx->stream));
-    timer.collect();
-    return MDHIP_OK;
+    if (!flux_on_device) {
+        rc = mdhip_result(cs, flux, d_flux, flux_b, 0);
+        if (rc) return rc;
+    }
+    cs.defer([timer]() {
+        timer.collect();
+        return MDHIP_OK;
+    });
+    return cs.end();
 }
 
 int mdhip_charge_flux(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *vel,
@@ -636,6 +664,27 @@ int mdhip_charge_flux_dev(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, con
 {
     return charge_flux_impl(ctx, n_frames, n_atoms, vel, on_device, atom_mass, atom_q, n_seg, seg_off, seg_type,
                             n_types, vel_conv, charge_conv, flux_dev, 1);
+}
+
+int mdhip_charge_flux_async(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, const double *vel, int on_device,
+                            const double *atom_mass, const double *atom_q, int64_t n_seg, const int64_t *seg_off,
+                            const int32_t *seg_type, int n_types, double vel_conv, double charge_conv, double *flux,
+                            int flux_on_device)
+{
+    if (!ctx) return MDHIP_EINVAL;
+    AsyncCall mark(ctx);
+    return charge_flux_impl(ctx, n_frames, n_atoms, vel, on_device, atom_mass, atom_q, n_seg, seg_off, seg_type, n_types,
+                            vel_conv, charge_conv, flux, flux_on_device ? 1 : 0);
+}
+
+int mdhip_segment_com_async(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, int n_attr, const double *attr,
+                            int attr_on_device, const double *atom_mass, const double *atom_q, int64_t n_seg,
+                            const int64_t *seg_off, double *out, int out_on_device, double *seg_mass, double *seg_q)
+{
+    if (!ctx) return MDHIP_EINVAL;
+    AsyncCall mark(ctx);
+    return mdhip_segment_com(ctx, n_frames, n_atoms, n_attr, attr, attr_on_device, atom_mass, atom_q, n_seg, seg_off, out,
+                             out_on_device, seg_mass, seg_q);
 }
 
 }  // extern "C"

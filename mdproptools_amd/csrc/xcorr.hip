@@ -38,7 +38,7 @@ long long fft_length(long long n)
 }
 
 int xcorr_fft(mdhip_ctx *ctx, long long n, int n_pairs, const double *d_a, const double *d_b,
-              bool same, long long n_lags, double *d_out)
+              bool same, long long n_lags, double *d_out, double out_scale)
 {
     const long long L = fft_length(n);
     const long long H = L / 2;
@@ -53,7 +53,7 @@ int xcorr_fft(mdhip_ctx *ctx, long long n, int n_pairs, const double *d_a, const
         const int nb = std::min(chunk, n_pairs - p0);
         const double *pa = d_a + (size_t)p0 * n;
         const int rc = mdhip_fft_xcorr(ctx, pa, same ? pa : d_b + (size_t)p0 * n, n, L, nb, buf0, buf1, buf2, buf3,
-                                       n_lags, d_out + (size_t)p0 * n_lags);
+                                       n_lags, d_out + (size_t)p0 * n_lags, out_scale);
         if (rc) return rc;
     }
     return MDHIP_OK;
@@ -224,25 +224,57 @@ int xcorr_direct(mdhip_ctx *ctx, long long n, int n_pairs, const double *d_a, co
     return MDHIP_OK;
 }
 
-}  // namespace
-
-extern "C" {
-
-int mdhip_xcorr(mdhip_ctx *ctx, int64_t n, int n_pairs, const double *a, const double *b,
-                int on_device, int method, int64_t n_lags, double *out)
+// out[p][k] *= scale (direct estimator; the FFT path scales in its last pass)
+__global__ void scale_kernel(double *__restrict__ x, long long n, double scale)
 {
-    return mdhip_xcorr_lags(ctx, n, n_pairs, a, b, on_device, method, 0, n_lags, out);
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] *= scale;
 }
 
-static int xcorr_lags_impl(mdhip_ctx *ctx, int64_t n, int n_pairs, const double *a, const double *b, int on_device,
-                           int method, int64_t lag_begin, int64_t n_lags, double *out, int out_on_device)
+// mean over the series of [n_series][m], numpy's order: ((x0 + x1) + x2 ...) / n_series
+__global__ void series_mean_kernel(const double *__restrict__ x, int n_series, long long m, double *__restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    double s = x[i];
+    for (int p = 1; p < n_series; ++p) s += x[(size_t)p * m + i];
+    out[i] = s / (double)n_series;
+}
+
+__global__ void scale_rows_kernel(double *__restrict__ x, long long n, double scale)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = scale * x[i];
+}
+
+// the correlation of device series into a device buffer, on the stream; `scale` multiplies every finished value
+int xcorr_enqueue(mdhip_ctx *ctx, int64_t n, int n_pairs, const double *d_a, const double *d_b, int method,
+                  int64_t lag_begin, int64_t n_lags, double scale, double *d_out)
+{
+    const bool same = d_a == d_b;
+    if (method == MDHIP_XCORR_FFT && n == 1) method = MDHIP_XCORR_DIRECT;  // one sample: the product itself
+    ctx->last_kernel = method == MDHIP_XCORR_FFT ? "fft_pass_kernel<0, 0>" : "xcorr_direct_kernel";
+    if (method == MDHIP_XCORR_FFT) return xcorr_fft(ctx, n, n_pairs, d_a, d_b, same, n_lags, d_out, scale);
+    const int rc = xcorr_direct(ctx, n, n_pairs, d_a, d_b, lag_begin, n_lags, d_out);
+    if (rc) return rc;
+    if (scale != 1.0) {
+        const long long tot = (long long)n_pairs * n_lags;
+        hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, d_out, tot, scale);
+        MD_HIP(hipGetLastError());
+    }
+    return MDHIP_OK;
+}
+
+int xcorr_lags_impl(mdhip_ctx *ctx, int64_t n, int n_pairs, const double *a, const double *b, int on_device,
+                    int method, int64_t lag_begin, int64_t n_lags, double *out, int out_on_device)
 {
     if (!ctx) return MDHIP_EINVAL;
+    CallScope cs(ctx);
     MD_REQUIRE(n >= 0 && n_pairs >= 0 && n_lags >= 0 && lag_begin >= 0 && lag_begin + n_lags <= n,
                "bad sizes (lag_begin + n_lags must be <= n)");
     MD_REQUIRE(method == MDHIP_XCORR_FFT || method == MDHIP_XCORR_DIRECT, "unknown method %d", method);
     MD_REQUIRE(lag_begin == 0 || method == MDHIP_XCORR_DIRECT, "a lag range needs the direct method");
-    if (n == 0 || n_pairs == 0 || n_lags == 0) return MDHIP_OK;
+    if (n == 0 || n_pairs == 0 || n_lags == 0) return cs.end();
     MD_REQUIRE(a && b && out, "NULL array");
     MD_REQUIRE(n < (1LL << 29), "series longer than 2^29 samples are not supported");
     MD_HIP(hipSetDevice(ctx->device));
@@ -257,18 +289,42 @@ static int xcorr_lags_impl(mdhip_ctx *ctx, int64_t n, int n_pairs, const double 
         if (rc) return rc;
     }
     const size_t out_b = (size_t)n_pairs * n_lags * 8;
-    MD_WS(d_out, double, WS_OUT, out_b);
+    double *d_out = out;
+    if (!out_on_device) {
+        d_out = (double *)mdhip_ws(ctx, WS_OUT, out_b);
+        if (!d_out) return MDHIP_ENOMEM;
+    }
     KernelTimer timer(ctx, n_pairs);
-    if (method == MDHIP_XCORR_FFT && n == 1) method = MDHIP_XCORR_DIRECT;  // one sample: the product itself
-    ctx->last_kernel = method == MDHIP_XCORR_FFT ? "fft_pass_kernel<0, 0>" : "xcorr_direct_kernel";
-    rc = method == MDHIP_XCORR_FFT ? xcorr_fft(ctx, n, n_pairs, d_a, d_b, same, n_lags, d_out)
-                                   : xcorr_direct(ctx, n, n_pairs, d_a, d_b, lag_begin, n_lags, d_out);
+    rc = xcorr_enqueue(ctx, n, n_pairs, d_a, d_b, method, lag_begin, n_lags, 1.0, d_out);
     timer.stop();
     if (rc) return rc;
-    MD_HIP(mdhip_deliver(ctx, out, d_out, out_b, out_on_device));
-    MD_HIP(hipStreamSynchronize(ctx->stream));
-    timer.collect();
-    return MDHIP_OK;
+    if (!out_on_device) {
+        rc = mdhip_result(cs, out, d_out, out_b, 0);
+        if (rc) return rc;
+    }
+    cs.defer([timer]() {
+        timer.collect();
+        return MDHIP_OK;
+    });
+    return cs.end();
+}
+
+}  // namespace
+
+extern "C" {
+
+int mdhip_xcorr(mdhip_ctx *ctx, int64_t n, int n_pairs, const double *a, const double *b,
+                int on_device, int method, int64_t n_lags, double *out)
+{
+    return xcorr_lags_impl(ctx, n, n_pairs, a, b, on_device, method, 0, n_lags, out, 0);
+}
+
+int mdhip_xcorr_async(mdhip_ctx *ctx, int64_t n, int n_pairs, const double *a, const double *b,
+                      int on_device, int method, int64_t n_lags, double *out)
+{
+    if (!ctx) return MDHIP_EINVAL;
+    AsyncCall mark(ctx);
+    return xcorr_lags_impl(ctx, n, n_pairs, a, b, on_device, method, 0, n_lags, out, 0);
 }
 
 int mdhip_xcorr_lags(mdhip_ctx *ctx, int64_t n, int n_pairs, const double *a, const double *b, int on_device,
@@ -281,6 +337,91 @@ int mdhip_xcorr_lags_dev(mdhip_ctx *ctx, int64_t n, int n_pairs, const double *a
                          int method, int64_t lag_begin, int64_t n_lags, double *out_dev)
 {
     return xcorr_lags_impl(ctx, n, n_pairs, a, b, on_device, method, lag_begin, n_lags, out_dev, 1);
+}
+
+int mdhip_xcorr_lags_dev_async(mdhip_ctx *ctx, int64_t n, int n_pairs, const double *a, const double *b, int on_device,
+                               int method, int64_t lag_begin, int64_t n_lags, double *out_dev)
+{
+    if (!ctx) return MDHIP_EINVAL;
+    AsyncCall mark(ctx);
+    return xcorr_lags_impl(ctx, n, n_pairs, a, b, on_device, method, lag_begin, n_lags, out_dev, 1);
+}
+
+// G3 -> unit factor -> G4 (-> mean over the series) without leaving the device: see include/mdhip.h
+int mdhip_green_kubo(mdhip_ctx *ctx, int64_t n, int n_series, const double *a, const double *b, int on_device,
+                     int method, double acf_scale, double dx, double integral_scale, int leading_zero, double *acf,
+                     double *integral, double *integral_mean)
+{
+    if (!ctx) return MDHIP_EINVAL;
+    CallScope cs(ctx);
+    MD_REQUIRE(n >= 0 && n_series >= 0, "negative sizes");
+    MD_REQUIRE(method == MDHIP_XCORR_FFT || method == MDHIP_XCORR_DIRECT, "unknown method %d", method);
+    if (n == 0 || n_series == 0) return cs.end();
+    MD_REQUIRE(a && b && integral, "NULL array");
+    MD_REQUIRE(n >= 2 && n < (1LL << 29), "series of 2 .. 2^29 samples are supported");
+    MD_REQUIRE(n_series <= 65535, "at most 65535 series per call");
+    MD_HIP(hipSetDevice(ctx->device));
+    int rc;
+    const size_t in_b = (size_t)n_series * n * 8;
+    const bool same = a == b;
+    const double *d_a = (const double *)mdhip_stage(ctx, WS_XYZ_I, a, in_b, on_device, &rc);
+    if (rc) return rc;
+    const double *d_b = d_a;
+    if (!same) {
+        d_b = (const double *)mdhip_stage(ctx, WS_XYZ_J, b, in_b, on_device, &rc);
+        if (rc) return rc;
+    }
+    const int lead = leading_zero ? 1 : 0;
+    const int64_t m = n - 1 + lead;
+    const size_t acf_b = in_b, int_b = (size_t)n_series * m * 8;
+    MD_WS(d_acf, double, WS_OUT, acf_b);
+    MD_WS(d_int, double, WS_OUT2, int_b);
+    KernelTimer timer(ctx, n_series);
+    rc = xcorr_enqueue(ctx, n, n_series, d_a, d_b, method, 0, n, acf_scale, d_acf);
+    if (rc) return rc;
+    // the correlation functions start their way to the host while the integrals are still being formed
+    if (acf) {
+        rc = mdhip_result(cs, acf, d_acf, acf_b, 0);
+        if (rc) return rc;
+    }
+    rc = mdhip_cumtrapz_enqueue(ctx, n, n_series, d_acf, dx, lead, d_int);
+    if (rc) return rc;
+    const long long tot = (long long)n_series * m;
+    if (integral_scale != 1.0) {
+        hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, d_int, tot,
+                           integral_scale);
+        MD_HIP(hipGetLastError());
+    }
+    double *d_mean = nullptr;
+    if (integral_mean) {
+        d_mean = (double *)mdhip_ws(ctx, WS_OUT3, (size_t)m * 8);
+        if (!d_mean) return MDHIP_ENOMEM;
+        hipLaunchKernelGGL(series_mean_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, d_int,
+                           n_series, (long long)m, d_mean);
+        MD_HIP(hipGetLastError());
+    }
+    timer.stop();
+    rc = mdhip_result(cs, integral, d_int, int_b, 0);
+    if (rc) return rc;
+    if (integral_mean) {
+        rc = mdhip_result(cs, integral_mean, d_mean, (size_t)m * 8, 0);
+        if (rc) return rc;
+    }
+    cs.defer([timer]() {
+        timer.collect();
+        return MDHIP_OK;
+    });
+    return cs.end();
+}
+
+int mdhip_green_kubo_async(mdhip_ctx *ctx, int64_t n, int n_series, const double *a, const double *b, int on_device,
+                           int method, double acf_scale, double dx, double integral_scale, int leading_zero, double *acf,
+                           double *integral, double *integral_mean)
+{
+    if (!ctx) return MDHIP_EINVAL;
+    AsyncCall mark(ctx);
+    return mdhip_green_kubo(ctx, n, n_series, a, b, on_device, method, acf_scale, dx, integral_scale, leading_zero, acf,
+                            integral, integral_mean);
 }
 
 }  // extern "C"

@@ -320,54 +320,84 @@ def _on_rccl(x):
     return is_distributed() and _dist().get_backend() == "nccl" and bool(getattr(x, "is_cuda", False))
 
 
-class _PendingDev:
-    """All-reduce in flight on the device buffer the kernels wrote (rdf_full | rdf_part | overflow)."""
+class _PendingRdf:
+    """
+    One sharded `_rdf_loop` step in flight, in two stages:
+      reduce()  completes the LOCAL library call (mdhip_wait: its kernels have run, its flags are checked) and issues
+                the all-reduce of the uint64 words, asynchronously — on RCCL straight from the device buffer the kernels
+                wrote;
+      wait()    (reduce() first if it has not happened) waits for the collective and returns
+                [rdf_full [nbins], rdf_part [R, nbins], [overflow]] of the whole trajectory.
+    A pipeline calls reduce() of step k right after it has ISSUED step k + 1 and wait() of step k one step later: the
+    GPU always has the next step's kernels queued while the host waits, and the collective of step k — which gets no
+    compute unit before the persistent pair kernel of step k + 1 lets go of some — has a whole step to finish.
+    """
 
-    def __init__(self, work, tensor, n_rel, nbins):
-        self._work, self._t, self._R, self._nb = work, tensor, n_rel, nbins
-        self._out = None
+    def __init__(self, local, n_rel, nbins, on_device):
+        self._local, self._R, self._nb, self._dev = local, n_rel, nbins, on_device
+        self._work, self._t, self._out = None, None, None
+        self.stats = None
+
+    def reduce(self):
+        if self._t is not None or self._out is not None:
+            return self
+        import torch
+
+        res = self._local.wait()
+        self.stats = self._local.stats() if hasattr(self._local, "stats") else None
+        if self._dev:
+            self._t = res  # int64 CUDA tensor: full | part | overflow
+        else:
+            full, part, ov = res
+            flat = np.concatenate([full.reshape(-1), part.reshape(-1), np.array([ov], dtype=np.uint64)]).view(np.int64)
+            self._t = torch.from_numpy(flat)
+        if is_distributed():
+            d = _dist()
+            if not self._dev:
+                self._t = self._t.to(_device_for_collectives())
+            self._work = d.all_reduce(self._t, op=d.ReduceOp.SUM, async_op=True)
+        return self
 
     def wait(self):
         if self._out is None:
+            self.reduce()
             if self._work is not None:
                 self._work.wait()
             flat = self._t.cpu().numpy().view(np.uint64)
             nb, R = self._nb, self._R
             self._out = [flat[:nb].copy(), flat[nb:(1 + R) * nb].reshape(R, nb).copy(), flat[(1 + R) * nb:].copy()]
+            self._t = self._local = None
         return self._out
-
-
-def _rdf_local_dev(xyz_local, types, box_local, relation_matrix, r_cut, ddr, nbins, ctx):
-    import torch
-
-    from . import backend
-
-    R = len(np.asarray(relation_matrix).reshape(-1, 2))
-    out = torch.empty((1 + R) * int(nbins) + 1, dtype=torch.int64, device=xyz_local.device)
-    backend.rdf_loop_dev(xyz_local, types, box_local, relation_matrix, r_cut, ddr, nbins, out, ctx=ctx)
-    return out, R
 
 
 def rdf_sharded_async(xyz_local, types, box_local, relation_matrix, r_cut, ddr, nbins, compute=None, ctx=None):
     """
     `_rdf_loop` over a frame-sharded trajectory, constant box: every rank passes ITS frames [F_local,3,N]; returns a
-    handle whose wait() gives [rdf_full [nbins], rdf_part [R,nbins], [overflow]] of the whole trajectory on every
-    rank — one all-reduce of (1+R)*nbins+1 uint64 words, left in flight so that a pipeline can start the next
-    batch of frames meanwhile. On RCCL with device-resident frames the words go from the kernels to the collective
-    without touching the host.
+    handle (see _PendingRdf: reduce(), wait()) whose wait() gives [rdf_full [nbins], rdf_part [R,nbins], [overflow]] of
+    the whole trajectory on every rank — one all-reduce of (1+R)*nbins+1 uint64 words. The local sweep is issued through
+    the library's *_async entry points: this call returns with the kernels queued, so that a pipeline can issue the next
+    batch of frames before it waits for this one. On RCCL with device-resident frames the words go from the kernels to
+    the collective without touching the host.
     """
+    R = len(np.asarray(relation_matrix).reshape(-1, 2))
     if compute is None and _on_rccl(xyz_local):
-        out, R = _rdf_local_dev(xyz_local, types, box_local, relation_matrix, r_cut, ddr, nbins, ctx)
-        d = _dist()
-        return _PendingDev(d.all_reduce(out, op=d.ReduceOp.SUM, async_op=True), out, R, int(nbins))
+        import torch
+
+        from . import backend
+
+        out = torch.empty((1 + R) * int(nbins) + 1, dtype=torch.int64, device=xyz_local.device)
+        local = backend.rdf_loop_dev(xyz_local, types, box_local, relation_matrix, r_cut, ddr, nbins, out, ctx=ctx,
+                                     async_=True)
+        return _PendingRdf(local, R, int(nbins), True)
     if compute is None:
         from . import backend
 
-        def compute(x, t, b, rel, rc, dd, nb):
-            return backend.rdf_loop(x, t, b, rel, rc, dd, nb, per_frame=False, ctx=ctx)
+        local = backend.rdf_loop(xyz_local, types, box_local, relation_matrix, r_cut, ddr, nbins, per_frame=False,
+                                 ctx=ctx, async_=True)
+        return _PendingRdf(local, R, int(nbins), False)
+    from ._lib import Ready
 
-    full, part, ov = compute(xyz_local, types, box_local, relation_matrix, r_cut, ddr, nbins)
-    return allreduce_u64_async([full, part, np.array([ov], dtype=np.uint64)])
+    return _PendingRdf(Ready(compute(xyz_local, types, box_local, relation_matrix, r_cut, ddr, nbins)), R, int(nbins), False)
 
 
 def rdf_sharded(xyz_local, types, box_local, relation_matrix, r_cut, ddr, nbins, compute=None, ctx=None):

@@ -76,10 +76,13 @@ class Viscosity:
         how = {"wkt": backend.XCORR_FFT, "brute_force": backend.XCORR_DIRECT}.get(self.acf_method)
         if how is None:
             raise ValueError("Method string input not recognized")
-        acf_data = backend.xcorr(series, method=how) * constants.PRESSURE_CONVERSION[self.units] ** 2
-        integral = backend.cumtrapz(acf_data, delta_t)
-        viscosity_data = np.multiply(self.volume / (constants.BOLTZMANN * self.temp), integral)
-        return np.mean(viscosity_data, axis=0), viscosity_data, acf_data
+        # one library call: the series go to the GPU once, acf -> x conv^2 -> cumtrapz -> x V/(kB T) -> mean over
+        # the three components happen there (each factor one multiplication of the finished value, as upstream's
+        # `acf * conv ** 2` and `np.multiply(V / (kB T), integral)`: viscosity.py:152, 182), three arrays come back
+        acf_data, viscosity_data, viscosity_average = backend.green_kubo(
+            series, method=how, acf_scale=constants.PRESSURE_CONVERSION[self.units] ** 2, dx=delta_t,
+            integral_scale=self.volume / (constants.BOLTZMANN * self.temp), want_mean=True)
+        return viscosity_average, viscosity_data, acf_data
 
     def calc_avg_visc(self, output_all_data=False):
         """Viscosity of every replicate log after `cutoff_time` (viscosity.py:193-237)."""

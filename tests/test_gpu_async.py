@@ -1,0 +1,328 @@
+"""
+The asynchronous entry points (include/mdhip.h "asynchronous calls"; SURVEY.md 8b: "an _async variant + mdhip_sync"):
+every *_async call must leave, once it has completed, exactly what its synchronous twin leaves — bit for bit, since
+both run the same kernels in the same order — whatever is in flight around it, and errors must surface at the wait.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+
+    from mdproptools_amd import backend, synth
+    from mdproptools_amd._lib import Context
+
+    ctx = Context(0)
+    yield backend, synth, torch, ctx
+    ctx.close()
+
+
+def _frames(synth, torch, n, F, L, seed, device=True):
+    x = synth.rdf_frames(n, range(F), L, seed)
+    return torch.from_numpy(x).cuda() if device else x
+
+
+def test_rdf_cn_async_equals_sync_with_several_calls_in_flight(env):
+    B, synth, torch, ctx = env
+    n, F, L = 6000, 24, 42.0
+    ty = synth.rdf_types(n)
+    rel = np.array(synth.ALL_PAIRS_4)
+    box = np.full((F, 3), L)
+    cuts = synth.cn_cutoffs(len(rel))
+    xs = [_frames(synth, torch, n, F, L, 40 + k) for k in range(3)]
+    for per_frame in (False, True):
+        ref = [B.rdf_loop(x, ty, box, rel, 12.0, 0.05, 240, per_frame=per_frame, ctx=ctx) for x in xs]
+        ref_cn = [B.cn_loop(x, ty, box, rel, cuts, per_frame=per_frame, ctx=ctx) for x in xs]
+        ref_both = B.rdf_cn_loop(xs[0], ty, box, rel, 12.0, 0.05, 240, cuts, per_frame=per_frame, ctx=ctx)
+        # three histogram calls, three CN calls and a one-sweep call queued behind each other, then ONE wait
+        hs = [B.rdf_loop(x, ty, box, rel, 12.0, 0.05, 240, per_frame=per_frame, ctx=ctx, async_=True) for x in xs]
+        hc = [B.cn_loop(x, ty, box, rel, cuts, per_frame=per_frame, ctx=ctx, async_=True) for x in xs]
+        hb = B.rdf_cn_loop(xs[0], ty, box, rel, 12.0, 0.05, 240, cuts, per_frame=per_frame, ctx=ctx, async_=True)
+        assert ctx.pending() == 7
+        got_b = hb.wait()  # completes everything issued before it too
+        assert ctx.pending() == 0
+        for h, r in zip(hs, ref):
+            g = h.wait()
+            np.testing.assert_array_equal(g[0], r[0])
+            np.testing.assert_array_equal(g[1], r[1])
+            assert g[2] == r[2]
+        for h, r in zip(hc, ref_cn):
+            np.testing.assert_array_equal(h.wait(), r)
+        for a, b in zip(got_b, ref_both):
+            np.testing.assert_array_equal(a, b)
+    # the stats of the calls completed last are remembered, newest first: the one-sweep kernel, then a CN sweep
+    ms, aux, launches, name = ctx.call_stats(0)
+    assert ms > 0 and launches >= 1 and "pair_hist" in name
+    assert ctx.call_stats(1)[0] > 0
+
+
+def test_double_buffered_steps_and_device_results(env):
+    """The bench's pattern: issue step k + 1, then wait for step k (mdhip_wait(ctx, 1)) — with host results and with
+    the sums left in a device buffer (the multi-GPU path's form)."""
+    B, synth, torch, ctx = env
+    n, F, L = 5000, 16, 40.0
+    ty = synth.rdf_types(n)
+    rel = np.array(synth.ALL_PAIRS_4)
+    box = np.full((F, 3), L)
+    xs = [_frames(synth, torch, n, F, L, 60 + k) for k in range(5)]
+    ref = [B.rdf_loop(x, ty, box, rel, 10.0, 0.05, 200, per_frame=False, ctx=ctx) for x in xs]
+    pending, got = None, []
+    for x in xs:
+        h = B.rdf_loop(x, ty, box, rel, 10.0, 0.05, 200, per_frame=False, ctx=ctx, async_=True)
+        if pending is not None:
+            got.append(pending.wait())
+            assert ctx.pending() == 1
+        pending = h
+    got.append(pending.wait())
+    for g, r in zip(got, ref):
+        np.testing.assert_array_equal(g[0], r[0])
+        np.testing.assert_array_equal(g[1], r[1])
+    words = (1 + len(rel)) * 200 + 1
+    outs = [torch.empty(words, dtype=torch.int64, device="cuda") for _ in xs]
+    hs = [B.rdf_loop_dev(x, ty, box, rel, 10.0, 0.05, 200, o, ctx=ctx, async_=True) for x, o in zip(xs, outs)]
+    ctx.sync()
+    for h, o, r in zip(hs, outs, ref):
+        flat = h.wait().cpu().numpy().view(np.uint64)
+        np.testing.assert_array_equal(flat[:200], r[0])
+        np.testing.assert_array_equal(flat[200:-1].reshape(len(rel), 200), r[1])
+        assert int(flat[-1]) == r[2]
+    cn_ref = B.cn_loop(xs[0], ty, box, rel, synth.cn_cutoffs(len(rel)), per_frame=False, ctx=ctx)
+    cn_dev = torch.empty(len(rel), dtype=torch.int64, device="cuda")
+    B.cn_loop(xs[0], ty, box, rel, synth.cn_cutoffs(len(rel)), per_frame=False, ctx=ctx, out=cn_dev, async_=True).wait()
+    np.testing.assert_array_equal(cn_dev.cpu().numpy().view(np.uint64), cn_ref)
+
+
+def test_overflow_guard_rerun_inside_an_async_call(env):
+    """A launch that raises the overflow guard of the 32-bit block histograms cannot be fixed while it is in flight:
+    its completion step runs the batch again, synchronously, in halves. Same integers, host and device results."""
+    B, synth, torch, ctx = env
+    from mdproptools_amd._lib import Context
+
+    n, F, L = 6000, 96, 42.0
+    x = _frames(synth, torch, n, F, L, 11)
+    ty = synth.rdf_types(n)
+    rel = np.array(synth.ALL_PAIRS_4)
+    box = np.full((F, 3), L)
+    ref = B.rdf_loop(x, ty, box, rel, 12.0, 0.05, 240, per_frame=False, ctx=ctx)
+    c2 = Context(0)
+    try:
+        hit = False
+        for guard in (1024, 512, 256, 128, 64, 32):
+            c2.set_option("rdf_guard", guard)
+            try:
+                g = B.rdf_loop(x, ty, box, rel, 12.0, 0.05, 240, per_frame=False, ctx=c2, async_=True).wait()
+            except Exception as e:  # a threshold even one frame exceeds: the clean error, delivered by the wait
+                assert "overflow the 32-bit" in str(e)
+                break
+            np.testing.assert_array_equal(g[0], ref[0])
+            np.testing.assert_array_equal(g[1], ref[1])
+            if c2.last_kernel_ms()[1] > 1:  # the re-run needed more than one launch
+                hit = True
+                out = torch.empty((1 + len(rel)) * 240 + 1, dtype=torch.int64, device="cuda")
+                B.rdf_loop_dev(x, ty, box, rel, 12.0, 0.05, 240, out, ctx=c2, async_=True).wait()
+                flat = out.cpu().numpy().view(np.uint64)
+                np.testing.assert_array_equal(flat[:240], ref[0])
+                np.testing.assert_array_equal(flat[240:-1].reshape(len(rel), 240), ref[1])
+                break
+        assert hit, "no threshold made the asynchronous call re-run its batch"
+    finally:
+        c2.close()
+
+
+def test_inputs_the_async_path_does_not_take(env):
+    """Frames in host memory (staged batch by batch), frames too small for the culled sweep (dense kernels), many
+    classes (class passes): the *_async entry point completes that work before it returns — same results."""
+    B, synth, torch, ctx = env
+    rng = np.random.default_rng(5)
+    cases = []
+    n, F, L = 5000, 40, 40.0
+    cases.append((synth.rdf_frames(n, range(F), L, 3), synth.rdf_types(n), np.array(synth.ALL_PAIRS_4), L, 10.0, 200))
+    n = 700  # fewer than 8 tiles: dense LDS-tile kernel
+    cases.append((torch.from_numpy(rng.uniform(0, 20.0, (6, 3, n))).cuda(), (1 + np.arange(n) % 3).astype(np.int32),
+                  np.array([[1, 1], [1, 2], [2, 3]]), 20.0, 8.0, 160))
+    n, T = 2600, 24  # 301 classes: several class passes
+    rel24 = np.array([[a, b] for a in range(1, T + 1) for b in range(a, T + 1)], dtype=np.int32)
+    cases.append((torch.from_numpy(rng.uniform(0, 30.0, (2, 3, n))).cuda(), rng.integers(1, T + 1, n).astype(np.int32),
+                  rel24, 30.0, 9.0, 90))
+    for x, ty, rel, L, rc, nb in cases:
+        F = x.shape[0]
+        box = np.full((F, 3), L)
+        for per_frame in (False, True):
+            r = B.rdf_loop(x, ty, box, rel, rc, rc / nb, nb, per_frame=per_frame, ctx=ctx)
+            g = B.rdf_loop(x, ty, box, rel, rc, rc / nb, nb, per_frame=per_frame, ctx=ctx, async_=True).wait()
+            np.testing.assert_array_equal(g[0], r[0])
+            np.testing.assert_array_equal(g[1], r[1])
+            assert g[2] == r[2]
+
+
+def test_msd_step_async_equals_sync(env):
+    """The three MSD calls of a C4 step, host and device results, queued back to back and waited for once."""
+    B, synth, torch, ctx = env
+    F, E = 400, 3000
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    r = torch.cumsum(torch.randn((F, 3, E), generator=g, device="cuda", dtype=torch.float64) * 0.1, dim=0)
+    goff = [0, 1000, E]
+    ref_o = B.msd_origin(r[1:], r[0], goff, scale=1e-10, ctx=ctx)
+    ref_w = B.msd_windows(r, 4, scale=1e-10, ctx=ctx)
+    ref_l = B.lag_msd(r, F - 1, goff, scale=1.0, ctx=ctx)
+    bound = ctx.last_rel_bound()
+    assert 0.0 < bound <= 1e-10
+    for dev in (False, True):
+        o = torch.empty((F - 1, 2, 4), dtype=torch.float64, device="cuda") if dev else None
+        w = torch.empty((E, 4), dtype=torch.float64, device="cuda") if dev else None
+        lg = torch.empty((F, 2, 4), dtype=torch.float64, device="cuda") if dev else None
+        h1 = B.msd_origin(r[1:], r[0], goff, scale=1e-10, out=o, ctx=ctx, async_=True)
+        h2 = B.msd_windows(r, 4, scale=1e-10, out=w, ctx=ctx, async_=True)
+        h3 = B.lag_msd(r, F - 1, goff, scale=1.0, out=lg, ctx=ctx, async_=True)
+        assert ctx.pending() == 3
+        ctx.sync()
+        assert ctx.last_rel_bound() == bound  # (the spectral path's bound, checked at completion)
+        got = [h.wait() for h in (h1, h2, h3)]
+        got = [t.cpu().numpy() if dev else t for t in got]
+        np.testing.assert_array_equal(got[0], ref_o)
+        np.testing.assert_array_equal(got[1], ref_w)
+        np.testing.assert_array_equal(got[2], ref_l)
+    # a trajectory whose bound is too loose for the spectral path (ballistic motion): the fallback to the difference
+    # kernel happens inside the completion step
+    t = torch.arange(F, device="cuda", dtype=torch.float64)[:, None, None]
+    rb = (t * torch.rand((1, 3, E), generator=g, device="cuda", dtype=torch.float64) + 500.0).contiguous()
+    ref_b = B.lag_msd(rb, F - 1, goff, scale=1.0, ctx=ctx)
+    assert ctx.last_rel_bound() == 0.0 and "lag_msd" in ctx.last_kernel_name()
+    got_b = B.lag_msd(rb, F - 1, goff, scale=1.0, ctx=ctx, async_=True).wait()
+    np.testing.assert_array_equal(got_b, ref_b)
+    assert ctx.last_rel_bound() == 0.0
+
+
+def test_flux_com_xcorr_cumtrapz_async_equal_sync(env):
+    B, synth, torch, ctx = env
+    rng = np.random.default_rng(9)
+    F, M, per = 50, 600, 5
+    N = M * per
+    vel = torch.from_numpy(rng.standard_normal((F, 3, N))).cuda()
+    mass = 1.0 + rng.random(N)
+    q = rng.standard_normal(N)
+    off = np.arange(0, N + 1, per)
+    st = (np.arange(M) >= 200).astype(np.int32) + (np.arange(M) >= 400).astype(np.int32)
+    ref_f = B.charge_flux(vel, mass, q, off, st, 3, 1e-5, 1.6e-19, ctx=ctx)
+    ref_c = B.segment_com(vel, mass, off, atom_q=q, ctx=ctx)
+    s = torch.from_numpy(rng.standard_normal((3, 20000))).cuda()
+    ref_x = B.xcorr(s, method=B.XCORR_FFT, ctx=ctx)
+    ref_d = B.xcorr(s, method=B.XCORR_DIRECT, ctx=ctx)
+    ref_i = B.cumtrapz(ref_x, 2e-15, ctx=ctx)
+    hf = B.charge_flux(vel, mass, q, off, st, 3, 1e-5, 1.6e-19, ctx=ctx, async_=True)
+    hc = B.segment_com(vel, mass, off, atom_q=q, ctx=ctx, async_=True)
+    hx = B.xcorr(s, method=B.XCORR_FFT, ctx=ctx, async_=True)
+    hd = B.xcorr(s, method=B.XCORR_DIRECT, ctx=ctx, async_=True)
+    hi = B.cumtrapz(ref_x, 2e-15, ctx=ctx, async_=True)
+    fdev = torch.empty((3, 3, F), dtype=torch.float64, device="cuda")
+    hfd = B.charge_flux(vel, mass, q, off, st, 3, 1e-5, 1.6e-19, ctx=ctx, out=fdev, async_=True)
+    assert ctx.pending() == 6
+    ctx.sync()
+    np.testing.assert_array_equal(hf.wait(), ref_f)
+    np.testing.assert_array_equal(hfd.wait().cpu().numpy(), ref_f)
+    for a, b in zip(hc.wait(), ref_c):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(hx.wait(), ref_x)
+    np.testing.assert_array_equal(hd.wait(), ref_d)
+    np.testing.assert_array_equal(hi.wait(), ref_i)
+
+
+def test_green_kubo_chain_equals_the_separate_calls(env, g_acf):
+    """mdhip_green_kubo = xcorr -> x c^2 -> cumtrapz -> x V/(kB T) -> mean, every factor one rounding as on the host:
+    bit-identical to the separate calls + numpy, both estimators, with and without the leading zero, large (page-locked
+    results, DMA) and small; and the reference's own viscosity chain on the golden series."""
+    B, synth, torch, ctx = env
+    rng = np.random.default_rng(21)
+    c2, dx, vk = 101325.0 ** 2, 2e-15, 3.7e9
+    for n, method in ((300000, B.XCORR_FFT), (5000, B.XCORR_FFT), (5000, B.XCORR_DIRECT)):
+        s = rng.standard_normal((3, n)) * 100.0
+        for lead in (False, True):
+            acf_ref = B.xcorr(s, method=method, ctx=ctx) * c2
+            int_ref = np.multiply(vk, B.cumtrapz(acf_ref, dx, leading_zero=lead, ctx=ctx))
+            mean_ref = np.mean(int_ref, axis=0)
+            for dev in (False, True):
+                a = torch.from_numpy(s).cuda() if dev else s
+                acf, integral, mean = B.green_kubo(a, method=method, acf_scale=c2, dx=dx, integral_scale=vk,
+                                                   leading_zero=lead, want_mean=True, ctx=ctx)
+                np.testing.assert_array_equal(acf, acf_ref)
+                np.testing.assert_array_equal(integral, int_ref)
+                np.testing.assert_array_equal(mean, mean_ref)
+        h = B.green_kubo(s, method=method, acf_scale=c2, dx=dx, integral_scale=vk, want_acf=False, ctx=ctx, async_=True)
+        acf, integral, mean = h.wait()
+        assert acf is None and mean is None
+        np.testing.assert_array_equal(integral, np.multiply(vk, B.cumtrapz(B.xcorr(s, method=method, ctx=ctx) * c2, dx, ctx=ctx)))
+    # cross-correlation with b != a (the conductivity chain's form)
+    a, b = rng.standard_normal((4, 3000)), rng.standard_normal((4, 3000))
+    acf, integral, _ = B.green_kubo(a, b, acf_scale=1.0, dx=1e-15, leading_zero=True, ctx=ctx)
+    np.testing.assert_array_equal(acf, B.xcorr(a, b, ctx=ctx))
+    np.testing.assert_array_equal(integral, B.cumtrapz(acf, 1e-15, leading_zero=True, ctx=ctx))
+    # the reference's numbers (tests/golden/acf.npz: Viscosity._calc_3d_visc on the AR(1) series, units "real")
+    from mdproptools_amd.common import constants as K
+
+    ser = np.ascontiguousarray(g_acf["pressure"])
+    dt = float(g_acf["visc_step"][1] - g_acf["visc_step"][0]) * float(g_acf["visc_timestep"]) * K.TIME_CONVERSION["real"]
+    pre = float(g_acf["visc_volume"]) * K.DISTANCE_CONVERSION["real"] ** 3 / (K.BOLTZMANN * float(g_acf["visc_temp"]))
+    acf, integral, mean = B.green_kubo(ser, acf_scale=K.PRESSURE_CONVERSION["real"] ** 2, dx=dt, integral_scale=pre,
+                                       want_mean=True, ctx=ctx)
+    np.testing.assert_allclose(acf, g_acf["visc_acf"], rtol=0, atol=1e-10 * g_acf["visc_acf"].max())
+    scale = np.abs(g_acf["visc_data"]).max()
+    np.testing.assert_allclose(integral, g_acf["visc_data"], rtol=1e-9, atol=1e-10 * scale)
+    np.testing.assert_allclose(mean, g_acf["visc_avg"], rtol=1e-9, atol=1e-10 * scale)
+
+
+def test_errors_and_mixing_sync_with_async(env):
+    B, synth, torch, ctx = env
+    n, F, L = 5000, 8, 40.0
+    x = _frames(synth, torch, n, F, L, 77)
+    ty = synth.rdf_types(n)
+    rel = np.array(synth.ALL_PAIRS_4)
+    box = np.full((F, 3), L)
+    ref = B.rdf_loop(x, ty, box, rel, 10.0, 0.05, 200, per_frame=False, ctx=ctx)
+    # an argument error is reported by the call itself and leaves nothing in flight
+    with pytest.raises(Exception):
+        B.rdf_loop(x, ty, box, rel, 10.0, -0.05, 200, per_frame=False, ctx=ctx, async_=True)
+    assert ctx.pending() == 0
+    # a synchronous call completes what was issued before it
+    h = B.rdf_loop(x, ty, box, rel, 10.0, 0.05, 200, per_frame=False, ctx=ctx, async_=True)
+    s = B.rdf_loop(x, ty, box, rel, 10.0, 0.05, 200, per_frame=True, ctx=ctx)
+    assert ctx.pending() == 0
+    g = h.wait()
+    np.testing.assert_array_equal(g[0], ref[0])
+    np.testing.assert_array_equal(s[0].sum(axis=0), ref[0])
+    # an error found at completion (a single frame that cannot pass the lowered guard) comes out of the wait
+    from mdproptools_amd._lib import Context, MdhipError
+
+    c2 = Context(0)
+    try:
+        c2.set_option("rdf_guard", 1)
+        h = B.rdf_loop(x, ty, box, rel, 10.0, 0.05, 200, per_frame=False, ctx=c2, async_=True)
+        with pytest.raises(MdhipError, match="overflow the 32-bit"):
+            h.wait()
+        c2.set_option("rdf_guard", 0)
+        g = B.rdf_loop(x, ty, box, rel, 10.0, 0.05, 200, per_frame=False, ctx=c2, async_=True).wait()
+        np.testing.assert_array_equal(g[0], ref[0])
+    finally:
+        c2.close()
+
+
+def test_blocking_wait_option_gives_the_same_results(env):
+    B, synth, torch, ctx = env
+    n, F, L = 5000, 8, 40.0
+    x = _frames(synth, torch, n, F, L, 78)
+    ty = synth.rdf_types(n)
+    rel = np.array(synth.ALL_PAIRS_4)
+    box = np.full((F, 3), L)
+    ref = B.rdf_loop(x, ty, box, rel, 10.0, 0.05, 200, per_frame=False, ctx=ctx)
+    ctx.set_option("sync_spin", 0)
+    try:
+        a = B.rdf_loop(x, ty, box, rel, 10.0, 0.05, 200, per_frame=False, ctx=ctx)
+        b = B.rdf_loop(x, ty, box, rel, 10.0, 0.05, 200, per_frame=False, ctx=ctx, async_=True).wait()
+    finally:
+        ctx.set_option("sync_spin", 1)
+    np.testing.assert_array_equal(a[0], ref[0])
+    np.testing.assert_array_equal(b[1], ref[1])

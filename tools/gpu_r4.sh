@@ -1,0 +1,24 @@
+#!/bin/bash
+# tools/gpu_r4.sh [steps...] — round-4 GPU-box sequences; every step writes under gpurun_out/.
+set -u
+R=${GRAFT_REPO_ROOT:-$PWD}
+O=$R/gpurun_out
+mkdir -p $O
+cd $R
+TAG=${TAG:-x}
+for s in "$@"; do
+  echo "== $s $(date +%T)"
+  case $s in
+    tests) timeout -k 10 1100 python -m pytest tests -m gpu -x -q > $O/gpu_tests.log 2>&1; rc=$?; echo "tests rc=$rc"; tail -5 $O/gpu_tests.log; [ $rc -eq 0 ] || exit 1 ;;
+    # the driver's own command, three times on one lease (the first is the cold one), headline only
+    head3) for k in 1 2 3; do timeout -k 10 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-legs --no-cpu-baseline > $O/head_${TAG}_$k.json 2> $O/head_${TAG}_$k.err; echo "head $k rc=$?"; python3 tools/show_steps.py $O/head_${TAG}_$k.json; done ;;
+    # the same under a concurrent rocm-smi poll (the driver samples the GPU every ~5 s while bench.py runs; here every 0.3 s)
+    head_smi) ( while true; do rocm-smi --showuse --showmemuse --showpower --json > /dev/null 2>&1; sleep 0.3; done ) & SMI=$!
+      for k in 1 2 3 4; do timeout -k 10 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-legs --no-cpu-baseline > $O/headsmi_${TAG}_$k.json 2> $O/headsmi_${TAG}_$k.err; echo "head_smi $k rc=$?"; python3 tools/show_steps.py $O/headsmi_${TAG}_$k.json; done
+      kill $SMI; wait $SMI 2>/dev/null; which rocm-smi amd-smi; ( time rocm-smi --showuse --json ) 2>&1 | tail -5 ;;
+    bench) timeout -k 10 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_line_${TAG}.json 2> $O/bench_err_${TAG}.log; echo "bench rc=$?"; tail -3 $O/bench_err_${TAG}.log; python3 tools/show_steps.py $O/bench_line_${TAG}.json ;;
+    tests_async) timeout -k 10 900 python -m pytest tests/test_gpu_async.py -m gpu -x -q > $O/gpu_tests_async.log 2>&1; rc=$?; echo "tests_async rc=$rc"; tail -30 $O/gpu_tests_async.log; [ $rc -eq 0 ] || exit 1 ;;
+    overhead) timeout -k 10 300 python tools/call_overhead.py 2>&1 | grep -v amdgpu | tail -8 ;;
+    *) echo "unknown step $s" ;;
+  esac
+done
