@@ -95,6 +95,8 @@ struct mdhip_call {
     std::vector<std::function<int()>> steps;   // run in order once `done` has fired; the first error ends the list
     hipEvent_t done = nullptr;
     CallStats stats;                           // kernel name / launches as set while the call was issued
+    bool inner = false;                        // made from inside another call or from a completion step
+    CallStats outer;                           // ... the registers of the call around it, as they were
 };
 
 struct mdhip_ctx {

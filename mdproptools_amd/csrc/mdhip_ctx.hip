@@ -155,7 +155,15 @@ mdhip_call *mdhip_call_begin(mdhip_ctx *ctx)
     c->parent = ctx->cur;
     c->async = ctx->want_async && ctx->cur == nullptr && ctx->completing == 0;
     ctx->want_async = false;
-    if (!c->parent && ctx->completing == 0) c->stats.ticket = ++ctx->tickets;
+    if (!c->parent && ctx->completing == 0) {
+        c->stats.ticket = ++ctx->tickets;
+    } else {
+        c->inner = true;
+        c->outer.ms = ctx->last_ms;
+        c->outer.aux_ms = ctx->last_aux_ms;
+        c->outer.launches = ctx->last_launches;
+        c->outer.kernel = ctx->last_kernel;
+    }
     ctx->cur = c;
     // the registers a call reports through start from nothing: what is in them when the call has been issued is its own
     ctx->last_ms = 0.0;
@@ -196,8 +204,19 @@ static int complete_call(mdhip_ctx *ctx, mdhip_call *c)
     st.launches = ctx->last_launches;
     st.kernel = ctx->last_kernel;
     st.rel_bound = ctx->last_rel_bound;
-    ctx->history.push_front(st);
-    if (ctx->history.size() > 64) ctx->history.pop_back();
+    if (c->inner) {
+        // a helper call (a copy of finished values, say) reports nothing of its own: the call around it keeps its numbers;
+        // a re-run of the work replaces them
+        if (st.ms == 0.0 && st.aux_ms == 0.0) {
+            ctx->last_ms = c->outer.ms;
+            ctx->last_aux_ms = c->outer.aux_ms;
+            ctx->last_launches = c->outer.launches;
+            ctx->last_kernel = c->outer.kernel;
+        }
+    } else {
+        ctx->history.push_front(st);
+        if (ctx->history.size() > 64) ctx->history.pop_back();
+    }
     release_call(ctx, c);
     return rc;
 }

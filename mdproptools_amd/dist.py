@@ -685,6 +685,218 @@ def lag_msd_sharded(r_local, entity_range, max_lag, group_off, scale=1.0, comput
     return out
 
 
+_STEP_STREAM = {}  # msd_step_sharded: (device index, context) -> torch stream the context launches on
+
+
+def _step_stream(device, ctx, post=False):
+    """The stream a fused step is ISSUED on: the context's kernels and torch's own work before them (the pre-exchange,
+    the zero fill of the result buffer) are queued on ONE stream, so that their order needs no host wait in between.
+    `post`: the second stream of the pair, for what follows the kernels of a step that has been waited for."""
+    import torch
+
+    key = (device.index, id(ctx), bool(post))
+    s = _STEP_STREAM.get(key)
+    if s is None:
+        s = torch.cuda.Stream(device=device)
+        _STEP_STREAM[key] = s
+    if not post and getattr(ctx, "_stream", None) != s.cuda_stream:
+        ctx.set_stream(s.cuda_stream)
+    return s
+
+
+def _allreduce_inplace(t):
+    """Sum `t` (a CUDA tensor) over the ranks, in place: RCCL on the tensor itself, gloo through a host copy."""
+    d = _dist()
+    if d.get_backend() == "nccl":
+        d.all_reduce(t, op=d.ReduceOp.SUM)
+        return
+    c = t.cpu()
+    d.all_reduce(c, op=d.ReduceOp.SUM)
+    t.copy_(c)
+
+
+def _allgather_equal(t):
+    """[world, ...] of every rank's `t` (same shape everywhere; CUDA tensor in, CUDA tensor out)."""
+    import torch
+
+    d = _dist()
+    _, world = rank_world()
+    if d.get_backend() == "nccl":
+        out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        d.all_gather_into_tensor(out, t.contiguous())
+        return out
+    c = t.cpu()
+    recv = [torch.empty_like(c) for _ in range(world)]
+    d.all_gather(recv, c)
+    return torch.stack(recv).to(t.device)
+
+
+def msd_step_sharded_async(r_f, r_e, n_frames_total, entity_range, group_off, tao, scale=1.0, lag_scale=1.0, origin_frame=0,
+                     ctx=None, counts=None, compute=None):
+    """
+    The three MSD reductions of one trajectory as ONE step (BASELINE configs[3]; what `bench.py --workload c4` times):
+      single origin  (diffusion.py:212-218)  frames dealt to the ranks, r_f [F_local,3,E]     -> sums  [F,G,4]
+      fixed lag tao  (diffusion.py:225-237)  the same frames                                   -> sums  [E,4]
+      full lag x origin average (superset)   ENTITIES dealt to the ranks, r_e [F,3,E_local]   -> means [F,G,4]
+    Returns a handle: wait() -> (single, windows, lag) as host arrays, the same on every rank, plus the per-call kernel
+    times. The library calls are ISSUED when this function returns (their kernels queued behind the all-gather); what
+    has to wait for them — the host finish of the spectral lag path, the all-reduce, the copy to the host — happens in
+    wait(). A pipeline issues step k + 1 before it waits for step k, so that the GPU never idles while the host works.
+
+    What crosses between the ranks is coalesced into ONE collective before the kernels and ONE after them:
+      before  an all-gather of two frames per rank — the origin frame (zeros from every rank but its owner) and the rank's
+              last kept frame (the one-frame halo of the fixed-lag windows);
+      after   an all-reduce of ONE buffer: the single-origin rows at their global offsets in a zero array (a row is
+              non-zero on exactly one rank: the sum IS the gather, exactly), the window sums, the lag sums.
+    The three library calls are issued through their *_async entry points on the stream the collectives are ordered
+    with; the host waits twice per step: once for the calls to complete (the spectral lag path finishes on the host,
+    include/mdhip.h) and once for the reduced buffer. With one process it is three queued calls and one wait.
+    `compute` (tests: the exchange logic on CPU over gloo, with the oracle as the stand-in): a dict of
+    "origin"(r [f,3,E], r0 [3,E], goff, scale) -> [f,G,4], "windows"(r [f,3,E], tao, scale) -> [E,4] (windows between the
+    frames 0, tao, 2 tao ... of r) and "lag"(x [F,3,e], max_lag, loc_off, scale) -> means [F,g,4] on numpy arrays.
+    """
+    import contextlib
+
+    import torch
+
+    rank, world = rank_world()
+    on_gpu = compute is None
+    if on_gpu:
+        from . import backend
+        from ._lib import default_context
+
+        ctx = ctx or default_context()
+    else:
+        r_f = torch.as_tensor(np.ascontiguousarray(r_f))
+        r_e = torch.as_tensor(np.ascontiguousarray(r_e))
+    F = int(n_frames_total)
+    blocks = frame_blocks(F, counts, world)
+    lo, hi = blocks[rank]
+    E = int(r_f.shape[2])
+    goff = np.asarray(group_off, dtype=np.int64)
+    G = len(goff) - 1
+    tao = int(tao)
+    max_lag = F - 1
+    n_lags = F
+    e_lo, e_hi = int(entity_range[0]), int(entity_range[1])
+    if int(r_f.shape[0]) != hi - lo or int(r_e.shape[0]) != F or int(r_e.shape[2]) != e_hi - e_lo:
+        raise ValueError("shard shapes do not match the frame block / entity range of this rank")
+    # this rank's part of every group of the entity shard (as lag_msd_sharded)
+    g_lo = np.clip(goff[:-1], e_lo, e_hi) - e_lo
+    g_hi = np.clip(goff[1:], e_lo, e_hi) - e_lo
+    held = [g for g in range(G) if g_hi[g] > g_lo[g]]
+    lag_counts = (F - np.arange(n_lags)).astype(np.float64)[:, None] * (goff[1:] - goff[:-1]).astype(np.float64)[None, :]
+    origins = (F - np.arange(n_lags)).astype(np.float64)[:, None]
+
+    def kept_of(a, b):  # global indices of the kept frames inside [a, b)
+        return np.arange(-(-a // tao) * tao, b, tao)
+
+    kept_local = kept_of(lo, hi) - lo
+    stats = {}
+    if not is_distributed() and on_gpu:
+        h1 = backend.msd_origin(r_f, r_f[origin_frame], goff, scale=scale, ctx=ctx, async_=True)
+        h2 = backend.msd_windows(r_f, tao, scale=scale, ctx=ctx, async_=True)
+        h3 = backend.lag_msd(r_e, max_lag, goff, scale=lag_scale, ctx=ctx, async_=True)
+
+        def finish_local():
+            out = (h1.wait(), h2.wait(), h3.wait())  # (h1 first: the waits complete the calls in issue order)
+            for key, h in (("single", h1), ("fixed", h2), ("lag", h3)):
+                stats[key] = h.stats()
+            return out + (stats,)
+
+        return _Deferred(finish_local)
+    dev = r_f.device
+    owner = frame_owner(F, origin_frame, world, counts)
+    nS, nW, nL = F * G * 4, E * 4, n_lags * G * 4
+    with (torch.cuda.stream(_step_stream(dev, ctx)) if on_gpu else contextlib.nullcontext()):
+        zero = torch.zeros((3, E), dtype=torch.float64, device=dev)
+        mine = torch.stack([r_f[origin_frame - lo] if rank == owner else zero,
+                            r_f[int(kept_local[-1])] if len(kept_local) else zero])
+        allf = _allgather_equal(mine) if world > 1 else mine[None]  # [world, 2, 3, E]
+        r0 = allf[owner, 0].contiguous()
+        halo = None
+        for q in range(rank - 1, -1, -1):
+            if len(kept_of(*blocks[q])):
+                halo = allf[q, 1]
+                break
+        res = torch.zeros(nS + nW + nL, dtype=torch.float64, device=dev)
+        single = res[:nS].view(F, G, 4)
+        win = res[nS:nS + nW].view(E, 4)
+        lagsum = res[nS + nW:].view(n_lags, G, 4)
+        hs = {}
+        k0 = int(kept_local[0]) if len(kept_local) else 0
+        means, x, loc_off = None, None, None
+        if held and F > 0:
+            loc_off = np.array([g_lo[held[0]]] + [g_hi[g] for g in held], dtype=np.int64)
+            x = r_e[:, :, int(loc_off[0]):int(loc_off[-1])].contiguous()
+        if on_gpu:
+            if hi > lo:
+                hs["single"] = backend.msd_origin(r_f, r0, goff, scale=scale, out=single[lo:hi], ctx=ctx, async_=True)
+            if len(kept_local):
+                hs["fixed"] = backend.msd_windows(r_f[k0:], tao, scale=scale, out=win, ctx=ctx, async_=True)
+            if x is not None:
+                means = torch.empty((n_lags, len(held), 4), dtype=torch.float64, device=dev)
+                hs["lag"] = backend.lag_msd(x, max_lag, loc_off - loc_off[0], scale=lag_scale, out=means, ctx=ctx,
+                                            async_=True)
+        else:
+            if hi > lo:
+                single[lo:hi] = torch.as_tensor(compute["origin"](r_f.numpy(), r0.numpy(), goff, scale))
+            if len(kept_local) > 1:
+                win.copy_(torch.as_tensor(compute["windows"](r_f[k0:].numpy(), tao, scale)))
+            if x is not None:
+                means = torch.as_tensor(np.asarray(compute["lag"](x.numpy(), max_lag, loc_off - loc_off[0], lag_scale)))
+    keep = (r_f, r_e, allf, r0, x)  # what the queued kernels read stays alive until the step has been waited for
+
+    def finish():
+        # On a stream of its own: the next step's kernels may already be queued on the issue stream, and nothing
+        # here has to wait for them (what it reads is complete: the calls are waited for first).
+        with (torch.cuda.stream(_step_stream(dev, ctx, post=True)) if on_gpu else contextlib.nullcontext()):
+            for key, h in hs.items():
+                h.wait()  # the calls have completed: `means` is in place (the spectral path's host finish ran here)
+                stats[key] = h.stats()
+            if len(kept_local) and halo is not None:
+                # the one window that reaches back to the rank below: three planes of arithmetic (the kernel's
+                # operations: scale, subtract, square, (dx2 + dy2) + dz2)
+                d2 = (r_f[k0] * scale - halo * scale) ** 2
+                win.add_(torch.stack([d2[0], d2[1], d2[2], (d2[0] + d2[1]) + d2[2]], dim=1))
+            if means is not None:
+                w = torch.from_numpy(origins * (g_hi[held] - g_lo[held]).astype(np.float64)[None, :]).to(dev)
+                if len(held) == G:
+                    lagsum.copy_(means * w[:, :, None])
+                else:
+                    lagsum[:, torch.as_tensor(held, device=dev), :] = means * w[:, :, None]
+            if world > 1:
+                _allreduce_inplace(res)
+            flat = res.cpu().numpy()
+        assert keep is not None
+        single_h = flat[:nS].reshape(F, G, 4)
+        win_h = flat[nS:nS + nW].reshape(E, 4)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            lag_h = np.where(lag_counts[:, :, None] > 0,
+                             flat[nS + nW:].reshape(n_lags, G, 4) / np.maximum(lag_counts, 1.0)[:, :, None], 0.0)
+        return single_h, win_h, lag_h, stats
+
+    return _Deferred(finish)
+
+
+def msd_step_sharded(*args, **kwargs):
+    """msd_step_sharded_async, waited for: (single [F,G,4], windows [E,4], lag [F,G,4], per-call kernel times)."""
+    return msd_step_sharded_async(*args, **kwargs).wait()
+
+
+class _Deferred:
+    """Handle of a step whose calls have been issued: wait() runs what is left (once) and returns the result."""
+
+    def __init__(self, finish):
+        self._finish, self._out = finish, None
+
+    def wait(self):
+        if self._finish is not None:
+            self._out = self._finish()
+            self._finish = None
+        return self._out
+
+
 def entity_shard(n_entities, rank=None, world=None):
     """Contiguous block [lo, hi) of entities owned by `rank` (lag_msd_sharded); sizes differ by at most one."""
     return frame_shard(n_entities, rank, world)

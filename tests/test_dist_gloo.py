@@ -106,9 +106,27 @@ def _worker(rank, world, port, out_dir):
         rw = _walk(F2, n)
         l2, h2 = D.frame_shard(F2)
         wins["win_%d_%d" % (F2, tao)] = D.msd_windows_sharded(rw[l2:h2], F2, tao, scale=3.0, compute=_np_windows)
+    # the fused MSD step (one all-gather before the kernels, ONE all-reduce after them): 11 frames in shards of 6 + 5,
+    # the origin in either shard, tao 1 / 3 / 7 (7: the upper shard's only kept frame reaches back across the boundary)
+    steps = {}
+    F3 = 11
+    rs = _walk(F3, n)
+    l3, h3 = D.frame_shard(F3)
+    stand_in = {
+        "origin": lambda rr, r0, goff, sc: cref.msd_pairs(np.concatenate([r0[None], rr]) * sc,
+                                                          [(0, 1 + t) for t in range(len(rr))], goff),
+        "windows": lambda rr, tao, sc: _np_windows(rr[::tao], sc),
+        "lag": lambda x, ml, goff, sc: cref.lag_msd(np.asarray(x) * sc, np.arange(ml + 1), goff),
+    }
+    for origin, tao in ((0, 1), (7, 3), (2, 7)):
+        a, b, c, _st = D.msd_step_sharded(rs[l3:h3], rs[:, :, e_lo:e_hi], F3, (e_lo, e_hi), [0, 100, n], tao, scale=1e-10,
+                                          lag_scale=2.0, origin_frame=origin, compute=stand_in)
+        steps["step_%d_%d_single" % (origin, tao)] = a
+        steps["step_%d_%d_win" % (origin, tao)] = b
+        steps["step_%d_%d_lag" % (origin, tao)] = c
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), full=full, part=part, ov=ov, pf=pf, pp=pp, cn=cn,
              sums=sums, sums4=sums4, shard=np.array([lo, hi]), lagm=lagm, acf=acf, ccf=ccf,
-             eshard=np.array([e_lo, e_hi]), **wins)
+             eshard=np.array([e_lo, e_hi]), **wins, **steps)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -176,6 +194,13 @@ def test_sharded_paths_world2_gloo(tmp_path):
         np.testing.assert_allclose(g["sums4"], sums4, rtol=1e-14)
         for F2, tao in ((F, 2), (11, 3), (11, 5), (11, 7), (2, 1)):
             np.testing.assert_allclose(g["win_%d_%d" % (F2, tao)], _np_windows(_walk(F2, n)[::tao], 3.0), rtol=1e-13)
+        rs = _walk(11, n)
+        for origin, tao in ((0, 1), (7, 3), (2, 7)):
+            key = "step_%d_%d_" % (origin, tao)
+            np.testing.assert_allclose(g[key + "single"], cref.msd_pairs(rs * 1e-10, [(origin, t) for t in range(11)],
+                                                                         [0, 100, n]), rtol=1e-14)
+            np.testing.assert_allclose(g[key + "win"], _np_windows(rs[::tao], 1e-10), rtol=1e-13)
+            np.testing.assert_allclose(g[key + "lag"], cref.lag_msd(rs * 2.0, np.arange(11), [0, 100, n]), rtol=1e-12)
     assert shards == [(0, 3), (3, 5)]
 
 
@@ -382,7 +407,13 @@ def _visc_worker(rank, world, port, tmp_dir):
     def cumtrapz(y, dx, leading_zero=False, ctx=None):
         return np.stack([O.cumtrapz(row, dx, leading_zero) for row in np.atleast_2d(y)])
 
-    backend.xcorr, backend.cumtrapz = xcorr, cumtrapz
+    def green_kubo(a, b=None, method=0, acf_scale=1.0, dx=1.0, integral_scale=1.0, leading_zero=False, want_acf=True,
+                   want_mean=False, ctx=None):
+        acf = xcorr(a) * acf_scale
+        integral = np.multiply(integral_scale, cumtrapz(acf, dx, leading_zero))
+        return (acf if want_acf else None), integral, (np.mean(integral, axis=0) if want_mean else None)
+
+    backend.xcorr, backend.cumtrapz, backend.green_kubo = xcorr, cumtrapz, green_kubo
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     v = Viscosity("log.rep*", cutoff_time=20, volume=1000.0, temp=300.0, timestep=1, working_dir=tmp_dir)

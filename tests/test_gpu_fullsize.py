@@ -273,11 +273,12 @@ def test_bench_c4_workload_two_ranks():
                        text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["metric"] == "frame-pairs/s" and line["unit"] == "frame-pairs/s" and line["n_gpus"] == 2
+    assert line["metric"] == "frame-pairs/s" and line["unit"].startswith("effective frame-pairs/s") and line["n_gpus"] == 2
     assert line["scaling"] == "strong" and line["config"]["frames_per_gpu"] == 2500
     assert line["config"]["entities_per_gpu"] == 25_000
     assert line["config"]["collectives"]["world_size"] == 2 and line["config"]["collectives"]["backend"] == "gloo"
-    assert line["value"] > 1e6 and line["msd"]["single_origin"]["value"] > 1e4
+    assert line["value"] > 1e6 and line["msd"]["single_origin"]["value_at_kernel_time"] > 1e4
+    assert line["msd"]["kernel_ms_per_step"] > 0 and len(line["msd"]["step_ms"]["raw"]) == 2
     assert line["lib_build_id"]["match"] is True
 
 

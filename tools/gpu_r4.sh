@@ -18,6 +18,11 @@ for s in "$@"; do
       kill $SMI; wait $SMI 2>/dev/null; which rocm-smi amd-smi; ( time rocm-smi --showuse --json ) 2>&1 | tail -5 ;;
     bench) timeout -k 10 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_line_${TAG}.json 2> $O/bench_err_${TAG}.log; echo "bench rc=$?"; tail -3 $O/bench_err_${TAG}.log; python3 tools/show_steps.py $O/bench_line_${TAG}.json ;;
     tests_async) timeout -k 10 900 python -m pytest tests/test_gpu_async.py -m gpu -x -q > $O/gpu_tests_async.log 2>&1; rc=$?; echo "tests_async rc=$rc"; tail -30 $O/gpu_tests_async.log; [ $rc -eq 0 ] || exit 1 ;;
+    bench_c4) timeout -k 10 600 python bench.py --workload c4 --steps 10 --warmup 2 > $O/bench_c4_n1_${TAG}.json 2> $O/bench_c4_n1_err.log; echo "c4 rc=$?"; tail -3 $O/bench_c4_n1_err.log; python3 -c "
+import json,sys; d=json.loads(open('$O/bench_c4_n1_${TAG}.json').read().strip().splitlines()[-1]); m=d['msd']; print('c4 value %.4g ms/step %.3f kernels %.3f ratio %.3f' % (d['value'], d['ms_per_step'], m['kernel_ms_per_step'], m['step_over_kernels'])); print(m['step_ms']['raw']); print({k:m[k]['kernel_ms'] for k in ('single_origin','fixed_lag_tao4','full_lag')})" ;;
+    bench_c4_2) MDHIP_DIST_BACKEND=gloo timeout -k 10 600 python bench.py --gpus 2 --workload c4 --steps 5 --warmup 1 > $O/bench_c4_gloo2_${TAG}.json 2> $O/bench_c4_gloo2_err.log; echo "c4x2 rc=$?"; tail -3 $O/bench_c4_gloo2_err.log ;;
+    bench_c4_rccl1) MDHIP_BENCH_FORCE_DIST=1 timeout -k 10 600 python bench.py --workload c4 --steps 10 --warmup 2 > $O/bench_c4_rccl1_${TAG}.json 2> $O/bench_c4_rccl1_err.log; echo "c4 rccl1 rc=$?"; tail -3 $O/bench_c4_rccl1_err.log; python3 -c "
+import json,sys; d=json.loads(open('$O/bench_c4_rccl1_${TAG}.json').read().strip().splitlines()[-1]); m=d['msd']; print('c4 rccl1 value %.4g ms/step %.3f kernels %.3f ratio %.3f' % (d['value'], d['ms_per_step'], m['kernel_ms_per_step'], m['step_over_kernels'])); print(m['step_ms']['raw'])" ;;
     overhead) timeout -k 10 300 python tools/call_overhead.py 2>&1 | grep -v amdgpu | tail -8 ;;
     *) echo "unknown step $s" ;;
   esac
