@@ -265,7 +265,7 @@ def segment_com(attr, atom_mass, seg_off, atom_q=None, out=None, ctx=None, async
     seg_mass = np.zeros(M)
     seg_q = None if q is None else np.zeros(M)
     if out is None:
-        res = result_array((F, K, M), device=ctx.device, zero=True)
+        res = result_array((F, K, M), device=ctx.device)
         op, o_dev = C.c_void_p(res.ctypes.data), 0
     else:
         res = out
@@ -467,7 +467,7 @@ def xcorr(a, b=None, method=XCORR_FFT, n_lags=None, ctx=None, lag_begin=0, out=N
         fn = ctx.lib.mdhip_xcorr_lags_dev_async if async_ else ctx.lib.mdhip_xcorr_lags_dev
         ctx.check(fn(ctx.h, n, P, ap, bp, a_dev, int(method), int(lag_begin), n_lags, _dev_out(out, (P, n_lags), ctx=ctx)))
         return Pending(ctx, out, keep=(a, b)) if async_ else out
-    out = result_array((P, n_lags), device=ctx.device, zero=True)
+    out = result_array((P, n_lags), device=ctx.device)
     if async_:
         if lag_begin:
             raise ValueError("a lag range is asynchronous only with a device result buffer")
@@ -490,7 +490,7 @@ def cumtrapz(y, dx, leading_zero=False, ctx=None, out=None, async_=False):
         fn = ctx.lib.mdhip_cumtrapz_dev_async if async_ else ctx.lib.mdhip_cumtrapz_dev
         ctx.check(fn(ctx.h, n, S, yp, on_dev, float(dx), int(bool(leading_zero)), _dev_out(out, (S, max(m, 0)), ctx=ctx)))
         return Pending(ctx, out, keep=keep) if async_ else out
-    out = result_array((S, max(m, 0)), device=ctx.device, zero=True)
+    out = result_array((S, max(m, 0)), device=ctx.device)
     fn = ctx.lib.mdhip_cumtrapz_async if async_ else ctx.lib.mdhip_cumtrapz
     ctx.check(fn(ctx.h, n, S, yp, on_dev, float(dx), int(bool(leading_zero)), ptr(out)))
     res = out[0] if single else out

@@ -57,6 +57,7 @@ enum WsSlot {
     WS_FFT_TW,     // two-level table of the roots of unity of order L (fft_pow2.hip), kept from call to call
     WS_OUT2,       // second / third device result of a chained call (mdhip_green_kubo: running integrals, their mean)
     WS_OUT3,
+    WS_XYZ_I2,     // second staging buffer of host-resident coordinates (asynchronous pair calls alternate between the two)
     WS_COUNT
 };
 
@@ -120,6 +121,12 @@ struct mdhip_ctx {
     // first use); one event per batch in flight
     hipStream_t copy_stream = nullptr;
     hipEvent_t copy_ev[2] = {nullptr, nullptr};
+    // asynchronous pair calls on host-resident frames: the whole trajectory of call k + 1 is copied (copy stream) into
+    // the staging buffer call k does NOT use, while call k's kernels run; stage_ev[b]: recorded on the launch stream
+    // behind the last kernels that read buffer b
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    bool stage_used[2] = {false, false};
+    int stage_flip = 0;
     int opt_rdf_relblock = 0;  // packed sweep: atoms per centre block of the f32 records, 0 / 256 = whole tiles, 64 (A/B)
     int opt_h2d_overlap = 1;  // 1 (default): overlapped staging of host-resident pair inputs, 0: one copy up front (A/B)
     std::string err;

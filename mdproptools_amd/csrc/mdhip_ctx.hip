@@ -151,10 +151,18 @@ hipError_t mdhip_stream_wait(mdhip_ctx *ctx)
 
 mdhip_call *mdhip_call_begin(mdhip_ctx *ctx)
 {
+    const bool top = ctx->cur == nullptr && ctx->completing == 0;
+    const bool async = ctx->want_async && top;
+    ctx->want_async = false;
+    if (top && !async && !ctx->inflight.empty()) {
+        // a synchronous call drains what is in flight BEFORE it issues anything: its own staging (copy stream, the
+        // batch-by-batch path of host-resident frames) is not ordered behind the kernels of the calls before it
+        const int prev = mdhip_complete_inflight(ctx, 0);
+        if (prev != MDHIP_OK && ctx->deferred_rc == MDHIP_OK) ctx->deferred_rc = prev;
+    }
     mdhip_call *c = new mdhip_call();
     c->parent = ctx->cur;
-    c->async = ctx->want_async && ctx->cur == nullptr && ctx->completing == 0;
-    ctx->want_async = false;
+    c->async = async;
     if (!c->parent && ctx->completing == 0) {
         c->stats.ticket = ++ctx->tickets;
     } else {
@@ -266,8 +274,9 @@ int mdhip_call_end(mdhip_ctx *ctx, mdhip_call *c)
 
 void mdhip_call_abandon(mdhip_ctx *ctx, mdhip_call *c)
 {
-    // queued copies may still read the call's staging blocks
+    // queued copies may still read the call's staging blocks (or, on the copy stream, the caller's arrays)
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
     (void)hipGetLastError();
     ctx->cur = c->parent;
     release_call(ctx, c);
@@ -346,6 +355,8 @@ void mdhip_destroy(mdhip_ctx *ctx)
         (void)hipStreamDestroy(ctx->copy_stream);
     }
     for (auto &e : ctx->copy_ev)
+        if (e) (void)hipEventDestroy(e);
+    for (auto &e : ctx->stage_ev)
         if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;

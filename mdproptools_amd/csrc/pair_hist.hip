@@ -925,9 +925,10 @@ int run_job(mdhip_ctx *ctx, const RelJob &j, std::vector<uint64_t> &H, std::vect
     // stream on every way out, so that no copy still reads the caller's arrays after this call has returned.
     struct CopyGuard {
         mdhip_ctx *c;
+        bool on = true;
         ~CopyGuard()
         {
-            if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+            if (on && c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
         }
     } copy_guard{ctx};
     const bool overlap = ctx->opt_h2d_overlap != 0 && (!j.xi_dev || (!j.tri && !j.xj_dev));
@@ -935,8 +936,29 @@ int run_job(mdhip_ctx *ctx, const RelJob &j, std::vector<uint64_t> &H, std::vect
         MD_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
         MD_HIP(hipEventCreateWithFlags(&ctx->copy_ev[0], hipEventDisableTiming));
         MD_HIP(hipEventCreateWithFlags(&ctx->copy_ev[1], hipEventDisableTiming));
+        MD_HIP(hipEventCreateWithFlags(&ctx->stage_ev[0], hipEventDisableTiming));
+        MD_HIP(hipEventCreateWithFlags(&ctx->stage_ev[1], hipEventDisableTiming));
     }
-    if (overlap && !j.xi_dev) {
+    // An ASYNCHRONOUS atom-atom call on host-resident frames: the whole trajectory is copied on the copy stream into the
+    // staging buffer the call before this one does not use — i.e. under that call's kernels — and the sweep then runs as
+    // on resident frames (one batch, its host half deferred). The caller's array is read until the call completes (the
+    // contract of the *_async entry points; a pageable source is staged by the runtime before hipMemcpyAsync returns).
+    int stage_buf = -1;
+    if (ctx->completing > 0 && (!j.xi_dev || (!j.tri && !j.xj_dev)))
+        MD_HIP(mdhip_stream_wait(ctx));  // a re-run from a completion step: the staging buffers may feed queued kernels
+    if (overlap && !j.xi_dev && j.tri && defer != nullptr) {
+        stage_buf = ctx->stage_flip;
+        ctx->stage_flip ^= 1;
+        const size_t xb = (size_t)j.F * 3 * j.ni * 8;
+        double *d_x = (double *)mdhip_ws(ctx, stage_buf ? WS_XYZ_I2 : WS_XYZ_I, xb);
+        if (!d_x) return MDHIP_ENOMEM;
+        if (ctx->stage_used[stage_buf]) MD_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->stage_ev[stage_buf], 0));
+        MD_HIP(hipMemcpyAsync(d_x, j.xi, xb, hipMemcpyHostToDevice, ctx->copy_stream));
+        MD_HIP(hipEventRecord(ctx->copy_ev[0], ctx->copy_stream));
+        MD_HIP(hipStreamWaitEvent(ctx->stream, ctx->copy_ev[0], 0));
+        p.d_xi = d_x;
+        copy_guard.on = false;
+    } else if (overlap && !j.xi_dev) {
         MD_WS(d_x, double, WS_XYZ_I, (size_t)j.F * 3 * j.ni * 8);
         // (a workspace buffer that was just re-allocated may still be read by nothing: mdhip_ws synchronised the stream)
         p.d_xi = d_x;
@@ -1006,7 +1028,12 @@ int run_job(mdhip_ctx *ctx, const RelJob &j, std::vector<uint64_t> &H, std::vect
         p.cn_c2_cls = c2.data();
         p.Hsplit = j.Hsplit;
     }
-    return pair_hist_run(ctx, p, H, overflow, defer, redo);
+    rc = pair_hist_run(ctx, p, H, overflow, defer, redo);
+    if (stage_buf >= 0 && (rc == MDHIP_OK || rc == CN_UNFUSED)) {
+        MD_HIP(hipEventRecord(ctx->stage_ev[stage_buf], ctx->stream));  // behind the last kernels that read the buffer
+        ctx->stage_used[stage_buf] = true;
+    }
+    return rc;
 }
 
 // CN: edges are the sorted distinct positive cutoffs^2; rank[kl] = number of bins below relation kl's cutoff.

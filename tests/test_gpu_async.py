@@ -326,3 +326,37 @@ def test_blocking_wait_option_gives_the_same_results(env):
         ctx.set_option("sync_spin", 1)
     np.testing.assert_array_equal(a[0], ref[0])
     np.testing.assert_array_equal(b[1], ref[1])
+
+
+def test_host_resident_frames_pipelined(env):
+    """Asynchronous calls on frames in (page-locked or pageable) HOST memory: the copy of call k + 1 goes into the
+    staging buffer call k does not use and runs under call k's kernels. Different data every call, several in flight,
+    a synchronous call in between — every result equals the synchronous one."""
+    B, synth, torch, ctx = env
+    n, F, L = 5000, 16, 40.0
+    ty = synth.rdf_types(n)
+    rel = np.array(synth.ALL_PAIRS_4)
+    box = np.full((F, 3), L)
+    cuts = synth.cn_cutoffs(len(rel))
+    hosts = []
+    for k in range(6):
+        x = synth.rdf_frames(n, range(F), L, 90 + k)
+        if k % 2 == 0:  # page-locked
+            t = torch.empty(x.shape, dtype=torch.float64, pin_memory=True)
+            t.numpy()[...] = x
+            hosts.append(t.numpy())
+        else:
+            hosts.append(x)
+    ref = [B.rdf_loop(torch.from_numpy(np.ascontiguousarray(x)).cuda(), ty, box, rel, 10.0, 0.05, 200, per_frame=False,
+                      ctx=ctx) for x in hosts]
+    hs = [B.rdf_loop(x, ty, box, rel, 10.0, 0.05, 200, per_frame=False, ctx=ctx, async_=True) for x in hosts[:4]]
+    mid = B.rdf_loop(hosts[4], ty, box, rel, 10.0, 0.05, 200, per_frame=True, ctx=ctx)  # synchronous: drains first
+    assert ctx.pending() == 0
+    hs += [B.rdf_loop(x, ty, box, rel, 10.0, 0.05, 200, per_frame=False, ctx=ctx, async_=True) for x in hosts[4:]]
+    hc = B.cn_loop(hosts[5], ty, box, rel, cuts, per_frame=False, ctx=ctx, async_=True)
+    for h, r in zip(hs, ref):
+        g = h.wait()
+        np.testing.assert_array_equal(g[0], r[0])
+        np.testing.assert_array_equal(g[1], r[1])
+    np.testing.assert_array_equal(mid[0].sum(axis=0), ref[4][0])
+    np.testing.assert_array_equal(hc.wait(), B.cn_loop(hosts[5], ty, box, rel, cuts, per_frame=False, ctx=ctx))
