@@ -389,9 +389,10 @@ def step_stats(step_ms, kernel_ms, aux_ms, call_ms):
                     "closing fence); value and ms_per_step are the contract's: steps / total elapsed"}
 
 
-def timed(fn, sync, reps):
-    """Mean wall time of `reps` calls after one untimed call."""
-    fn()
+def timed(fn, sync, reps, warm=1):
+    """Mean wall time of `reps` calls after `warm` untimed ones."""
+    for _ in range(warm):
+        fn()
     sync()
     t0 = time.perf_counter()
     for _ in range(reps):
@@ -680,16 +681,17 @@ def leg_c5(B, ctx, torch, device, synth, sync):
             return o
         return run
 
-    t_fft, a_fft = timed(rec("fft", lambda: B.xcorr(p, method=B.XCORR_FFT, ctx=ctx)), sync, 3)
+    # (three untimed calls: large results come back in page-locked arrays that are recycled from the third call on)
+    t_fft, a_fft = timed(rec("fft", lambda: B.xcorr(p, method=B.XCORR_FFT, ctx=ctx)), sync, 5, warm=3)
     t_dir, a_dir = timed(rec("dir", lambda: B.xcorr(p, method=B.XCORR_DIRECT, ctx=ctx)), sync, 1)
-    t_int, _i = timed(rec("int", lambda: B.cumtrapz(a_fft, 1e-15, ctx=ctx)), sync, 3)
+    t_int, _i = timed(rec("int", lambda: B.cumtrapz(a_fft, 1e-15, ctx=ctx)), sync, 5, warm=3)
     # the Green-Kubo chain of Viscosity._calc_3d_visc (viscosity.py:178-190) as ONE library call on the resident series:
     # acf -> x conv^2 -> cumtrapz -> x V/(kB T) -> mean over the components; only the three results cross the bus
     conv2, vk = 101325.0 ** 2, 118969.0e-30 / (1.380649e-23 * 298.15)
     t_gk, gk = timed(rec("gk", lambda: B.green_kubo(p, method=B.XCORR_FFT, acf_scale=conv2, dx=1e-15, integral_scale=vk,
-                                                    want_mean=True, ctx=ctx)), sync, 3)
+                                                    want_mean=True, ctx=ctx)), sync, 5, warm=3)
     t_gk2, gk2 = timed(rec("gk2", lambda: B.green_kubo(p, method=B.XCORR_FFT, acf_scale=conv2, dx=1e-15,
-                                                       integral_scale=vk, want_acf=False, ctx=ctx)), sync, 3)
+                                                       integral_scale=vk, want_acf=False, ctx=ctx)), sync, 5, warm=3)
     sep_acf = a_fft * conv2
     sep_int = np.multiply(vk, B.cumtrapz(sep_acf, 1e-15, ctx=ctx))
     if not (np.array_equal(gk[0], sep_acf) and np.array_equal(gk[1], sep_int) and np.array_equal(gk2[1], sep_int)

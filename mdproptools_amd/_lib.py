@@ -233,14 +233,22 @@ class PinnedPool:
     memory comes from mdhip_host_alloc_on and goes back to a free list when the last array that views it dies, so a
     caller who asks for the same result shape again and again (replicates of a Green-Kubo run) pays the page-locking
     once. At most `max_keep` bytes are kept for reuse.
+
+    Page-locking is not free (tools/pin_cost.py, MI355X host: hipHostMalloc of 24 MB 1.6 ms and as much again to free it,
+    against 1.3 ms for the runtime's staged copy into fresh pageable pages and 0.46 ms for the DMA into locked ones), so it
+    pays only for memory that comes BACK: at most `max_live` blocks per size are handed out at a time (six: two calls'
+    worth of a three-array result) — a caller that keeps every result (replicate lists) gets ordinary arrays after that,
+    a caller that drops them (a loop over trajectories, the bench) keeps getting the same locked blocks.
     """
 
     GRAIN = 1 << 20
 
-    def __init__(self, max_keep=1 << 30):
+    def __init__(self, max_keep=1 << 30, max_live=6):
         self.free = {}
+        self.live = {}
         self.kept = 0
         self.max_keep = max_keep
+        self.max_live = max_live
         self.lock = threading.Lock()
 
     def empty(self, shape, dtype=np.float64, device=-1):
@@ -254,10 +262,15 @@ class PinnedPool:
             ptr = lst.pop() if lst else None
             if ptr is not None:
                 self.kept -= cap
+            elif self.live.get(cap, 0) >= self.max_live:
+                return np.empty(shape, dtype=dtype)
+            self.live[cap] = self.live.get(cap, 0) + 1
         if ptr is None:
             out = vp()
             rc = load().mdhip_host_alloc_on(int(device), cap, C.byref(out))
             if rc != 0 or not out.value:
+                with self.lock:
+                    self.live[cap] -= 1
                 return np.empty(shape, dtype=dtype)  # (no page-locked memory to be had: an ordinary array works too)
             ptr = out.value
         buf = (C.c_char * cap).from_address(ptr)
@@ -266,6 +279,7 @@ class PinnedPool:
 
     def _release(self, ptr, cap):
         with self.lock:
+            self.live[cap] = max(0, self.live.get(cap, 0) - 1)
             if self.kept + cap <= self.max_keep:
                 self.free.setdefault(cap, []).append(ptr)
                 self.kept += cap

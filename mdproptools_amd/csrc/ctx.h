@@ -57,6 +57,7 @@ enum WsSlot {
     WS_FFT_TW,     // two-level table of the roots of unity of order L (fft_pow2.hip), kept from call to call
     WS_OUT2,       // second / third device result of a chained call (mdhip_green_kubo: running integrals, their mean)
     WS_OUT3,
+    WS_SCAN,       // one-pass scan (scan.hip): block totals | flags | ticket counter, kept from call to call
     WS_XYZ_I2,     // second staging buffer of host-resident coordinates (asynchronous pair calls alternate between the two)
     WS_COUNT
 };
@@ -176,6 +177,7 @@ struct mdhip_ctx {
                               // stays below 1e-10, else the exact-difference kernel; 1 = series-resident LDS
                               // difference kernel when it fits, 0 = staged difference kernel, 2 = always the
                               // autocorrelation theorem, 4 = 2 through batched global transforms (fft_pow2.hip)
+    int scan_capacity = 0;     // scan.hip: blocks of the one-pass scan the chip holds at once (occupancy calculator, once)
     int fft_tw_logL = -1;         // length the table in WS_FFT_TW was built for (-1: none)
     const void *fft_tw_ptr = nullptr;
     int opt_lag_fft_kernel = 2;   // fused full-lag MSD path: 2 (default) = first pass from registers + wave-private
@@ -196,7 +198,9 @@ int mdhip_fft_xcorr(mdhip_ctx *ctx, const double *d_a, const double *d_b, long l
                     double2 *buf0, double2 *buf1, double2 *buf2, double2 *buf3, long long n_lags, double *d_lags,
                     double out_scale);
 // scan.hip: cumulative trapezoid of device series y [n_series][n] into d_out [n_series][n - 1 + lead], on the stream
-int mdhip_cumtrapz_enqueue(mdhip_ctx *ctx, int64_t n, int n_series, const double *d_y, double dx, int lead, double *d_out);
+// (every finished value times post_scale: one more rounding, as a multiplication of the finished array)
+int mdhip_cumtrapz_enqueue(mdhip_ctx *ctx, int64_t n, int n_series, const double *d_y, double dx, int lead, double *d_out,
+                           double post_scale);
 
 void *mdhip_ws(mdhip_ctx *ctx, int slot, size_t bytes);  // nullptr on failure (error set)
 // pinned host memory that belongs to the call being issued (ctx->cur) until it completes; nullptr on failure (error set)

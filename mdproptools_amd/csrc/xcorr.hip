@@ -241,12 +241,6 @@ __global__ void series_mean_kernel(const double *__restrict__ x, int n_series, l
     out[i] = s / (double)n_series;
 }
 
-__global__ void scale_rows_kernel(double *__restrict__ x, long long n, double scale)
-{
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) x[i] = scale * x[i];
-}
-
 // the correlation of device series into a device buffer, on the stream; `scale` multiplies every finished value
 int xcorr_enqueue(mdhip_ctx *ctx, int64_t n, int n_pairs, const double *d_a, const double *d_b, int method,
                   int64_t lag_begin, int64_t n_lags, double scale, double *d_out)
@@ -384,14 +378,9 @@ int mdhip_green_kubo(mdhip_ctx *ctx, int64_t n, int n_series, const double *a, c
         rc = mdhip_result(cs, acf, d_acf, acf_b, 0);
         if (rc) return rc;
     }
-    rc = mdhip_cumtrapz_enqueue(ctx, n, n_series, d_acf, dx, lead, d_int);
+    // (integral_scale rides in the scan's store: finished value times scale, the rounding of np.multiply on the host)
+    rc = mdhip_cumtrapz_enqueue(ctx, n, n_series, d_acf, dx, lead, d_int, integral_scale);
     if (rc) return rc;
-    const long long tot = (long long)n_series * m;
-    if (integral_scale != 1.0) {
-        hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, d_int, tot,
-                           integral_scale);
-        MD_HIP(hipGetLastError());
-    }
     double *d_mean = nullptr;
     if (integral_mean) {
         d_mean = (double *)mdhip_ws(ctx, WS_OUT3, (size_t)m * 8);
