@@ -540,6 +540,8 @@ int mdhip_set_option(mdhip_ctx *ctx, const char *key, int value)
         ctx->opt_lag_fft_kernel = value;
     else if (!strcmp(key, "h2d_overlap"))
         ctx->opt_h2d_overlap = value;
+    else if (!strcmp(key, "lag_direct"))
+        ctx->opt_lag_direct = value;
     else if (!strcmp(key, "sync_spin"))
         ctx->opt_sync_spin = value;
     else

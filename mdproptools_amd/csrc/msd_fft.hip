@@ -174,7 +174,9 @@ constexpr int FT_MAX_M = 13;                  // N = L/2 <= 8192 complex points
 constexpr int FT_PREGS = 17;                  // k = 0..N: <= 17 per lane
 
 struct FftItem {
-    long long c_lo, c_hi;  // series range [c_lo, c_hi) of one segment
+    long long c_lo, c_hi;  // series c_lo, c_lo + step, ... < c_hi of one segment
+    int step;              // 1: a contiguous range; 16: one column of every 16-column tile (the direct-read kernel)
+    int row;               // row of Qpart / Ppart the block writes (rows of one segment are consecutive)
 };
 
 __device__ __forceinline__ int ft_skew(int i) { return i + (i >> 4); }
@@ -1069,10 +1071,18 @@ __device__ __forceinline__ void f3_wave_pass(double *re, double *im, int org, in
 
 // x, Qpart, Ppart as msd_power_lds2_kernel. JJ = first-pass butterflies per lane (N/8 / 512, at least 1), QE = inputs
 // of a first-pass butterfly that can hold data (ceil(ceil(F / 2) / (N/8)) <= 8).
-template <int JJ, int QE>
+// DIRECT (round 4): x is the caller's trajectory itself, [F][cols] (= [F][3][E]), times `scale`: sample t of series c is
+// x[t cols + c] — no transposed copy is made (rounds 2-3: transpose_scale_kernel wrote one and this kernel read it
+// back: two thirds of the call's HBM traffic). A lane's samples then sit in lines of their own (a row is cols * 8
+// bytes long), 8 useful bytes per 128-byte line — so the blocks are dealt series in CLUSTERS: the 16 blocks that the
+// hardware places on one XCD one dispatch round after another (block b runs on XCD b % 8) take the 16 columns of one
+// aligned tile, member k column 16 T + k, tile after tile (FftItem::step 16); they do the same work per series and stay
+// within a fraction of an iteration of each other, so the line one of them brings into the XCD's L2 serves the other
+// fifteen. Nothing but the hit rate depends on that placement or on the blocks keeping step: no barrier, no flag.
+template <int JJ, int QE, bool DIRECT>
 __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
     const double *__restrict__ x, int F, int m, const FftItem *__restrict__ items,
-    const double2 *__restrict__ tab, double *__restrict__ Qpart, double *__restrict__ Ppart)
+    const double2 *__restrict__ tab, double *__restrict__ Qpart, double *__restrict__ Ppart, long long cols, double scale)
 {
     constexpr int PR = 16;
     extern __shared__ double ft_lds[];
@@ -1124,6 +1134,20 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
     const int half = (F + 1) >> 1;  // packed points that hold data
     double va[JJ][QE], vb[JJ][QE];
     auto fetch = [&](long long c) {
+        if constexpr (DIRECT) {
+            const double *col = x + c;
+#pragma unroll
+            for (int jj = 0; jj < JJ; ++jj) {
+#pragma unroll
+                for (int e = 0; e < QE; ++e) {
+                    const int j = tid + jj * FT_THREADS, n = j + (e << ls0);  // packed point: samples 2 n, 2 n + 1
+                    va[jj][e] = vb[jj][e] = 0.0;
+                    if (j < s0 && 2 * n < F) va[jj][e] = col[(size_t)(2 * n) * (size_t)cols] * scale;
+                    if (j < s0 && 2 * n + 1 < F) vb[jj][e] = col[(size_t)(2 * n + 1) * (size_t)cols] * scale;
+                }
+            }
+            return;
+        }
         const double *row = x + (size_t)c * F;
         const bool al16 = (reinterpret_cast<unsigned long long>(row) & 15ull) == 0ull;
 #pragma unroll
@@ -1156,9 +1180,13 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
             for (int e = 0; e < QE; ++e) sum += va[jj][e] + vb[jj][e];
         return sum;
     };
-    fetch(it.c_lo);
-    double mean = ft_block_sum(lane_sum(), red) / (double)F;
-    for (long long c = it.c_lo; c < it.c_hi; ++c) {
+    double mean = 0.0;
+    if (it.c_lo < it.c_hi) {  // (a cluster member whose column lies outside the segment has nothing to do)
+        fetch(it.c_lo);
+        mean = ft_block_sum(lane_sum(), red) / (double)F;
+    }
+    const int cstep = it.step;
+    for (long long c = it.c_lo; c < it.c_hi; c += cstep) {
         // first pass, from the registers (the previous series' partner reads are behind the barrier that ended it)
 #pragma unroll
         for (int jj = 0; jj < JJ; ++jj) {
@@ -1187,8 +1215,8 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
                 }
             }
         }
-        const bool more = F3_PREFETCH && c + 1 < it.c_hi;
-        if (more) fetch(c + 1);
+        const bool more = F3_PREFETCH && c + cstep < it.c_hi;
+        if (more) fetch(c + cstep);
         __syncthreads();
         // this wave's sub-transform: the remaining LDS passes, then the tail in registers
         {
@@ -1284,12 +1312,12 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
             mean = sum / (double)F;
         }
         __syncthreads();
-        if (!F3_PREFETCH && c + 1 < it.c_hi) {
-            fetch(c + 1);
+        if (!F3_PREFETCH && c + cstep < it.c_hi) {
+            fetch(c + cstep);
             mean = ft_block_sum(lane_sum(), red) / (double)F;
         }
     }
-    double *q = Qpart + (size_t)blockIdx.x * F, *pp = Ppart + (size_t)blockIdx.x * (N + 1);
+    double *q = Qpart + (size_t)it.row * F, *pp = Ppart + (size_t)it.row * (N + 1);
 #pragma unroll
     for (int jj = 0; jj < JJ; ++jj) {
 #pragma unroll
@@ -1467,19 +1495,102 @@ int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r
     mdhip_ctx *ctx = cs.ctx;
     const long long n_lags = (long long)max_lag + 1, cols = 3 * E, S = 3 * G;
     const long long N = 1LL << m, L = 2 * N;
-    // work items: every non-empty segment gets a share of ~one block per CU, each a contiguous series range
+    const size_t lds_b = ft_lds_bytes(m);
+    // round-3 kernel (conflict-free layout, bilinear spectrum accumulation): N = 2^m a multiple of the block size
+    const bool v2 = ctx->opt_lag_fft_kernel != 0 && m >= 9 && f2_lds_bytes(m) <= ctx->lds_max;
+    // second step of round 3 (first pass from registers, wave-private sub-transforms): lag_fft_kernel >= 2
+    const bool v3 = ctx->opt_lag_fft_kernel >= 2 && m >= F3_MIN_M && f3_lds_bytes(m) <= ctx->lds_max;
+    // round 4, option `lag_direct` (off by default: measured slower, see ctx.h): that kernel reads the trajectory as it
+    // is, [F][3 E], no transposed copy (see msd_power_lds3_kernel). Needs the blocks in whole clusters of 16 per XCD:
+    // 128 | cu_count.
+    const int n_clusters = ctx->cu_count / 16;
+    const bool direct = v3 && ctx->opt_lag_direct != 0 && ctx->cu_count % 128 == 0 && cols >= 16 * (long long)n_clusters;
+    // work items: every non-empty segment gets a share of ~one block per CU, each a contiguous series range — or, for
+    // the direct-read kernel, whole clusters of 16 blocks that walk the segment's 16-column tiles (aligned to 16 columns
+    // of the [F][cols] matrix = one 128-byte line per row), member k taking column 16 T + k
     std::vector<FftItem> items;
     std::vector<int> seg_off((size_t)S + 1, 0);
-    for (long long s = 0; s < S; ++s) {
-        const long long a = s / G, g = s % G;
-        const long long lo = a * E + group_off[g], hi = a * E + group_off[g + 1], n = hi - lo;
-        seg_off[s] = (int)items.size();
-        if (n <= 0) continue;
-        long long k = (n * ctx->cu_count + cols / 2) / cols;
-        k = std::max<long long>(1, std::min(k, n));
-        for (long long q = 0; q < k; ++q) items.push_back({lo + n * q / k, lo + n * (q + 1) / k});
+    if (!direct) {
+        for (long long s = 0; s < S; ++s) {
+            const long long a = s / G, g = s % G;
+            const long long lo = a * E + group_off[g], hi = a * E + group_off[g + 1], n = hi - lo;
+            seg_off[s] = (int)items.size();
+            if (n <= 0) continue;
+            long long k = (n * ctx->cu_count + cols / 2) / cols;
+            k = std::max<long long>(1, std::min(k, n));
+            for (long long q = 0; q < k; ++q)
+                items.push_back({lo + n * q / k, lo + n * (q + 1) / k, 1, (int)items.size()});
+        }
+        seg_off[S] = (int)items.size();
+    } else {
+        // clusters per segment by largest remainder (every non-empty segment at least one while clusters last)
+        std::vector<long long> seg_n((size_t)S), seg_lo((size_t)S);
+        std::vector<int> seg_c((size_t)S, 0);
+        int nonempty = 0, given = 0;
+        for (long long s = 0; s < S; ++s) {
+            const long long a = s / G, g = s % G;
+            seg_lo[s] = a * E + group_off[g];
+            seg_n[s] = group_off[g + 1] - group_off[g];
+            if (seg_n[s] > 0) ++nonempty;
+        }
+        const bool enough = nonempty <= n_clusters;
+        for (long long s = 0; s < S && enough; ++s)
+            if (seg_n[s] > 0) {
+                seg_c[s] = std::max<int>(1, (int)(seg_n[s] * n_clusters / cols));
+                given += seg_c[s];
+            }
+        while (enough && given > n_clusters) {  // (the floor of 1 can overshoot when many segments are tiny)
+            long long best = -1;
+            for (long long s = 0; s < S; ++s)
+                if (seg_c[s] > 1 && (best < 0 || seg_n[s] * seg_c[best] < seg_n[best] * seg_c[s])) best = s;
+            if (best < 0) break;
+            --seg_c[best];
+            --given;
+        }
+        while (enough && given < n_clusters) {  // the segment with the most columns per cluster takes the next one
+            long long best = -1;
+            for (long long s = 0; s < S; ++s)
+                if (seg_n[s] > 0 && (best < 0 || seg_n[s] * seg_c[best] > seg_n[best] * seg_c[s])) best = s;
+            ++seg_c[best];
+            ++given;
+        }
+        if (!enough || given != n_clusters) {
+            // more non-empty segments than clusters: this shape keeps the transposed path (re-enter without `direct`)
+            const int keep = ctx->opt_lag_direct;
+            ctx->opt_lag_direct = 0;
+            const int rc = lag_msd_fft_fused(cs, F, E, d_r, scale, max_lag, G, group_off, m, res);
+            ctx->opt_lag_direct = keep;
+            return rc;
+        }
+        // rows (= Qpart / Ppart rows, consecutive per segment): cluster q, member k -> row 16 q + k
+        std::vector<FftItem> rows;
+        for (long long s = 0; s < S; ++s) {
+            seg_off[s] = (int)rows.size();
+            if (seg_c[s] == 0) continue;
+            const long long lo = seg_lo[s], hi = lo + seg_n[s];
+            const long long t0 = lo / 16, t1 = (hi + 15) / 16, nt = t1 - t0;
+            for (int q = 0; q < seg_c[s]; ++q) {
+                const long long ta = t0 + nt * q / seg_c[s], tb = t0 + nt * (q + 1) / seg_c[s];
+                for (int k = 0; k < 16; ++k) {
+                    long long c0 = 16 * ta + k, c1 = 16 * tb;  // columns 16 T + k, ta <= T < tb, inside [lo, hi)
+                    while (c0 < lo) c0 += 16;
+                    c1 = std::min(c1, hi);
+                    rows.push_back({c0, std::max(c0, c1), 16, (int)rows.size()});
+                }
+            }
+        }
+        seg_off[S] = (int)rows.size();
+        // block b runs on XCD b % 8, dispatch round b / 8: the 16 members of a cluster are the blocks of one XCD in 16
+        // consecutive rounds
+        const int per_xcd = ctx->cu_count / 8;  // dispatch rounds = blocks per XCD
+        items.resize(rows.size());
+        for (int b = 0; b < (int)rows.size(); ++b) {
+            const int xcd = b % 8, round = b / 8;
+            const int q = (round / 16) * 8 + xcd, k = round % 16;
+            (void)per_xcd;
+            items[(size_t)b] = rows[(size_t)q * 16 + k];
+        }
     }
-    seg_off[S] = (int)items.size();
     const long long n_items = (long long)items.size();
 
     // twiddle table of w_L: A[i] = w^(128 i), B[i] = w^i
@@ -1493,7 +1604,11 @@ int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r
         tab[256 + 2 * i + 1] = (double)sinl(step * (i % L));
     }
 
-    MD_WS(d_x, double, WS_AUX1, (size_t)cols * F * 8 + 256);
+    double *d_x = nullptr;  // the transposed, scaled copy [cols][F] (not made for the direct-read kernel)
+    if (!direct) {
+        d_x = (double *)mdhip_ws(ctx, WS_AUX1, (size_t)cols * F * 8 + 256);
+        if (!d_x) return MDHIP_ENOMEM;
+    }
     const size_t qp_b = (size_t)n_items * F * 8, pp_b = (size_t)n_items * (N + 1) * 8;
     MD_WS(d_part, double, WS_PART, qp_b + pp_b);
     double *d_Qpart = d_part, *d_Ppart = d_part + (size_t)n_items * F;
@@ -1515,26 +1630,30 @@ int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r
         MD_HIP(hipMemcpyAsync(d_tab, h_tab, 4096 + it_b + so_b, hipMemcpyHostToDevice, ctx->stream));
     }
 
-    const size_t lds_b = ft_lds_bytes(m);
-    // round-3 kernel (conflict-free layout, bilinear spectrum accumulation): N = 2^m a multiple of the block size
-    const bool v2 = ctx->opt_lag_fft_kernel != 0 && m >= 9 && f2_lds_bytes(m) <= ctx->lds_max;
     KernelTimer timer(ctx);
-    hipLaunchKernelGGL(transpose_scale_kernel, dim3((unsigned)((cols + 63) / 64), (unsigned)((F + 63) / 64)), dim3(256),
-                       0, ctx->stream, d_r, d_x, F, cols, scale);
-    MD_HIP(hipGetLastError());
+    if (!direct) {
+        hipLaunchKernelGGL(transpose_scale_kernel, dim3((unsigned)((cols + 63) / 64), (unsigned)((F + 63) / 64)), dim3(256),
+                           0, ctx->stream, d_r, d_x, F, cols, scale);
+        MD_HIP(hipGetLastError());
+    }
     const int qr = (int)((F + FT_THREADS - 1) / FT_THREADS);
-    // second step of round 3 (first pass from registers, wave-private sub-transforms): lag_fft_kernel >= 2
-    const bool v3 = ctx->opt_lag_fft_kernel >= 2 && m >= F3_MIN_M && f3_lds_bytes(m) <= ctx->lds_max;
     if (v3) {
         const size_t lds3 = f3_lds_bytes(m);
         const long long s0 = N >> 3;
         const int qe = (int)(((F + 1) / 2 + s0 - 1) / s0);  // <= 8
 #define MD_F3_LAUNCH(JJ, QE)                                                                                   \
     {                                                                                                          \
-        MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msd_power_lds3_kernel<JJ, QE>),              \
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));                    \
-        hipLaunchKernelGGL((msd_power_lds3_kernel<JJ, QE>), dim3((unsigned)n_items), dim3(FT_THREADS), lds3,   \
-                           ctx->stream, d_x, (int)F, m, d_items, d_tab, d_Qpart, d_Ppart);                     \
+        if (direct) {                                                                                          \
+            MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msd_power_lds3_kernel<JJ, QE, true>),    \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));                \
+            hipLaunchKernelGGL((msd_power_lds3_kernel<JJ, QE, true>), dim3((unsigned)n_items), dim3(FT_THREADS), lds3, \
+                               ctx->stream, d_r, (int)F, m, d_items, d_tab, d_Qpart, d_Ppart, cols, scale);    \
+        } else {                                                                                               \
+            MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msd_power_lds3_kernel<JJ, QE, false>),   \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));                \
+            hipLaunchKernelGGL((msd_power_lds3_kernel<JJ, QE, false>), dim3((unsigned)n_items), dim3(FT_THREADS), lds3, \
+                               ctx->stream, d_x, (int)F, m, d_items, d_tab, d_Qpart, d_Ppart, cols, 1.0);      \
+        }                                                                                                      \
     }
         if (s0 > FT_THREADS) {
             if (qe <= 3) MD_F3_LAUNCH(2, 3)
