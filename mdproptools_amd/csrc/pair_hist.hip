@@ -210,7 +210,18 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
     if (cull && jsplit > 4) jsplit = 4;
     // scalar-j kernels: items are (frame, tile, wave, slice); 4 slices measured best at C2 and C3, for the persistent
     // grid and for per-frame output alike (with one slice a 100k-atom frame has only two items per resident wave)
-    if (cull && ctx->opt_rdf_sj != 0 && ctx->opt_rdf_jsplit <= 0) jsplit = std::min(4, max_list);
+    if (cull && ctx->opt_rdf_sj != 0 && ctx->opt_rdf_jsplit <= 0) {
+        // ... when the lists are long. A short reach (coordination cutoffs: a handful of neighbour tiles per tile) leaves
+        // a slice one tile or none, and every item pays its set-up (counter, boxes, context) for it: round 4 measured
+        // 4.72 -> 2.93 ms per 64 C3 frames for CN alone with ONE slice (tools/ab_pair.py rdf_jsplit=4,2,1 C3 cn).
+        // Expected list length: the share of tile pairs within reach (as for the culling decision above) x tiles / 2.
+        const double V = p.h_box[0] * p.h_box[1] * p.h_box[2];
+        const double edge = 0.5 * (std::cbrt((double)TILE * V / (double)p.ni) + std::cbrt((double)TILE * V / (double)p.nj));
+        const double reach = std::sqrt(p.rc2) + 0.8 * edge;
+        const double share = std::min(1.0, 4.18879 * reach * reach * reach / V);
+        const double list_est = share * (double)nTj * (p.tri ? 0.5 : 1.0);
+        jsplit = std::min(list_est >= 12.0 ? 4 : list_est >= 6.0 ? 2 : 1, max_list);
+    }
     if (jsplit < 1) jsplit = 1;
     const int blocks_per_frame = nTi * jsplit;
     // frames per block (fast kernel, frame-summed output): as many as keeps >= `want` blocks in flight

@@ -333,6 +333,15 @@ __device__ __forceinline__ f32x2 wrap_pk(f32x2 d, f32x2 L, f32x2 iL)
 template <bool CNG>
 __device__ __forceinline__ void pk_drain(PkCtx &p, const FastCtx &c, int lane)
 {
+    // The pushes carry no capacity test (pk_push): a wave drains above 64 entries before every group and a group adds at
+    // most 4 x 64, so qn <= PK_QCAP here — by construction. Should a later variant break that, entries beyond the queue
+    // have overwritten the next wave's queue or the tables behind it: nothing can repair that, but it must not pass
+    // silently — the count goes to the `lost` word, which the host turns into an error (checked on this, the rare, path
+    // only: the hot loop is bound by scalar issue slots too).
+    if (p.qn > PK_QCAP) {
+        if (lane == 0) atomicAdd(p.lost, (unsigned long long)(p.qn - PK_QCAP));
+        p.qn = PK_QCAP;
+    }
     const int n = p.qn < PK_QCAP ? p.qn : PK_QCAP;
     for (int b = 0; b < n; b += 64) {
         if (b + lane < n) {

@@ -251,6 +251,26 @@ def require_all_nonempty(n_local, what="frame"):
         raise ValueError("rank(s) %s hold no %s: use at most as many ranks as there are %ss" % (empty, what, what))
 
 
+def raise_together(err, what="its share of the work"):
+    """
+    Collective agreement on rank-local failures: every rank passes the exception its local work raised (None: it went
+    through). If any rank failed, ALL ranks raise here — the failing ones their own exception, the others a RuntimeError
+    that names them — instead of one rank raising alone and the rest waiting in the next collective until the process
+    group times out. A no-op for a single process (the exception is re-raised as it is).
+    """
+    if not is_distributed():
+        if err is not None:
+            raise err
+        return
+    flags = allgather_counts(0 if err is None else 1)
+    if not any(flags):
+        return
+    if err is not None:
+        raise err
+    failed = [r for r, f in enumerate(flags) if f]
+    raise RuntimeError("rank(s) %s failed on %s; this rank stops with them" % (failed, what))
+
+
 def shard_items(items):
     """This rank's contiguous block of a list (e.g. the dump files of a trajectory, in frame order)."""
     rank, world = rank_world()

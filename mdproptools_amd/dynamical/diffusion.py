@@ -139,17 +139,25 @@ class Diffusion:
             got = self._entity_frames_streamed(pattern, files, msd_type, num_mols, num_atoms_per_mol, mass)
             if got is not None:
                 return got
-        for step, names, cols in self._frame_columns(pattern, msd_type, mass, mio.USE_NATIVE_READER, files=files):
-            if ids is None:
-                ids = cols["id"]
-            planes.append(np.ascontiguousarray(np.stack([cols["xu"], cols["yu"], cols["zu"]])))
-            if msd_type == "com":
-                m = cols["mass"] if not mass else np.asarray(mass, dtype=np.float64)[cols["type"].astype(np.int64) - 1]
-                if atom_mass is None:
-                    atom_mass = m
-                elif not np.array_equal(atom_mass, m):
-                    raise ValueError("atom masses change between frames")
-            times.append(step * self.timestep * constants.TIME_CONVERSION[self.units])
+        err = None
+        try:
+            for step, names, cols in self._frame_columns(pattern, msd_type, mass, mio.USE_NATIVE_READER, files=files):
+                if ids is None:
+                    ids = cols["id"]
+                planes.append(np.ascontiguousarray(np.stack([cols["xu"], cols["yu"], cols["zu"]])))
+                if msd_type == "com":
+                    m = cols["mass"] if not mass else np.asarray(mass, dtype=np.float64)[cols["type"].astype(np.int64) - 1]
+                    if atom_mass is None:
+                        atom_mass = m
+                    elif not np.array_equal(atom_mass, m):
+                        raise ValueError("atom masses change between frames")
+                times.append(step * self.timestep * constants.TIME_CONVERSION[self.units])
+        except Exception as e:  # noqa: BLE001
+            if files is None:
+                raise
+            err = e  # (a rank's own parse error: the ranks agree on it before anyone enters a collective)
+        if files is not None:
+            D.raise_together(err, "parsing its dump files")
         times = np.asarray(times, dtype=np.float64)
         sharded = files is not None and D.is_distributed()
         if files is not None:
@@ -198,27 +206,35 @@ class Diffusion:
         seg = molecule_layout(num_mols, num_atoms_per_mol) if msd_type == "com" else None
         times, blocks = [], []
         ids = atom_mass = seg_mass = None
-        stream = S.FrameStream(pattern, files=mine, columns=("id", second, "xu", "yu", "zu"),
-                               batch_bytes=STREAM_BATCH_BYTES)
-        for batch in stream:
-            B, _, n = batch.xyz.shape
-            if ids is None:
-                ids = batch.ids[0].copy()
-            if msd_type == "com":
-                if seg[0][-1] != n:
-                    raise ValueError(f"Length of values ({int(seg[0][-1])}) does not match length of index ({n})")
-                m = batch.types if not mass else np.asarray(mass, dtype=np.float64)[batch.types.astype(np.int64) - 1]
-                if atom_mass is None:
-                    atom_mass = m[0].copy()
-                if not (m == atom_mass).all():
-                    raise ValueError("atom masses change between frames")
-                out = torch.empty((B, 3, len(seg[0]) - 1), dtype=torch.float64, device=dev)
-                _, seg_mass, _ = backend.segment_com(batch.xyz, atom_mass, seg[0], out=out, ctx=ctx)
-            else:
-                out = torch.empty((B, 3, n), dtype=torch.float64, device=dev)
-                out.copy_(torch.from_numpy(batch.xyz))  # synchronous DMA from the page-locked batch
-            blocks.append(out)
-            times.extend(batch.timesteps.tolist())
+        err = None
+        try:
+            stream = S.FrameStream(pattern, files=mine, columns=("id", second, "xu", "yu", "zu"),
+                                   batch_bytes=STREAM_BATCH_BYTES)
+            for batch in stream:
+                B, _, n = batch.xyz.shape
+                if ids is None:
+                    ids = batch.ids[0].copy()
+                if msd_type == "com":
+                    if seg[0][-1] != n:
+                        raise ValueError(f"Length of values ({int(seg[0][-1])}) does not match length of index ({n})")
+                    m = batch.types if not mass else np.asarray(mass, dtype=np.float64)[batch.types.astype(np.int64) - 1]
+                    if atom_mass is None:
+                        atom_mass = m[0].copy()
+                    if not (m == atom_mass).all():
+                        raise ValueError("atom masses change between frames")
+                    out = torch.empty((B, 3, len(seg[0]) - 1), dtype=torch.float64, device=dev)
+                    _, seg_mass, _ = backend.segment_com(batch.xyz, atom_mass, seg[0], out=out, ctx=ctx)
+                else:
+                    out = torch.empty((B, 3, n), dtype=torch.float64, device=dev)
+                    out.copy_(torch.from_numpy(batch.xyz))  # synchronous DMA from the page-locked batch
+                blocks.append(out)
+                times.extend(batch.timesteps.tolist())
+        except Exception as e:  # noqa: BLE001
+            if files is None:
+                raise
+            err = e  # (this rank's own parse / reduce error: agreed on below, before the first collective)
+        if files is not None:
+            D.raise_together(err, "streaming its dump files")
         times = np.asarray(times, dtype=np.float64) * self.timestep * constants.TIME_CONVERSION[self.units]
         if files is not None:
             D.require_all_nonempty(len(times), "dump file")  # every rank raises, or none
@@ -373,8 +389,8 @@ class Diffusion:
         (mdhip_msd_origin) and the [F_local, G, 4] sums are all-gathered; the fixed-lag windows need one frame from
         the rank below (dist.msd_windows_sharded) and an all-reduce of [E, 4]. The trajectory itself never moves.
         `msd_all` is F x E rows whatever is done: its four value columns are gathered (device to device on RCCL) so
-        that every rank returns the frame one process would — MSD_ALL_ON_EVERY_RANK = False keeps each rank's own
-        rows instead and skips that gather.
+        that every rank returns the frame one process would — MSD_ALL_ON_EVERY_RANK = False makes every rank return
+        the rows of ITS OWN frames instead and skips that gather.
         Returns None when the ranks' blocks are not in time order one after the other (the caller then gathers the
         frames and reduces them as one process).
         """

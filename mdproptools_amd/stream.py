@@ -299,6 +299,10 @@ class FrameStream:
 
         if not files:
             return 0
+        # the batch call below places exactly FIVE columns (id, one per-atom attribute, three planes) and orders rows by
+        # "id": any other column set takes the per-frame route, which is general
+        if len(self.columns) != 5 or self.columns[0] != "id":
+            return 0
         try:
             from . import _lib
 

@@ -447,3 +447,38 @@ def test_dropin_viscosity_replicates_sharded_world2_gloo(tmp_path):
         two = np.load(tmp_path / ("visc_w2_r%d.npz" % rank))
         for key in ("avg", "data", "acf", "t"):
             np.testing.assert_array_equal(two[key], one[key], err_msg=key)
+
+
+# ------------------------------------------------------------------ rank-local failures are agreed on collectively
+def _raise_worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    from mdproptools_amd import dist as D
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    D.raise_together(None)  # nobody failed: goes through
+    got = "none"
+    try:
+        D.raise_together(ValueError("atom masses change between frames") if rank == 1 else None, "parsing")
+    except ValueError as e:
+        got = "own:" + str(e)
+    except RuntimeError as e:
+        got = "other:" + str(e)
+    # both ranks are still in step: the next collective completes
+    counts = D.allgather_counts(rank + 5)
+    with open(os.path.join(out_dir, "raise%d.txt" % rank), "w") as fh:
+        fh.write(got + "|" + ",".join(map(str, counts)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rank_local_failure_makes_every_rank_raise(tmp_path):
+    import torch.multiprocessing as mp
+
+    mp.spawn(_raise_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0 = (tmp_path / "raise0.txt").read_text()
+    r1 = (tmp_path / "raise1.txt").read_text()
+    assert r0.startswith("other:rank(s) [1] failed on parsing") and r0.endswith("|5,6")
+    assert r1 == "own:atom masses change between frames|5,6"
