@@ -23,6 +23,12 @@ import json,sys; d=json.loads(open('$O/bench_c4_n1_${TAG}.json').read().strip().
     bench_c4_2) MDHIP_DIST_BACKEND=gloo timeout -k 10 600 python bench.py --gpus 2 --workload c4 --steps 5 --warmup 1 > $O/bench_c4_gloo2_${TAG}.json 2> $O/bench_c4_gloo2_err.log; echo "c4x2 rc=$?"; tail -3 $O/bench_c4_gloo2_err.log ;;
     bench_c4_rccl1) MDHIP_BENCH_FORCE_DIST=1 timeout -k 10 600 python bench.py --workload c4 --steps 10 --warmup 2 > $O/bench_c4_rccl1_${TAG}.json 2> $O/bench_c4_rccl1_err.log; echo "c4 rccl1 rc=$?"; tail -3 $O/bench_c4_rccl1_err.log; python3 -c "
 import json,sys; d=json.loads(open('$O/bench_c4_rccl1_${TAG}.json').read().strip().splitlines()[-1]); m=d['msd']; print('c4 rccl1 value %.4g ms/step %.3f kernels %.3f ratio %.3f' % (d['value'], d['ms_per_step'], m['kernel_ms_per_step'], m['step_over_kernels'])); print(m['step_ms']['raw'])" ;;
+    pmc_c2) timeout -k 10 900 bash tools/pmc.sh r04_c2 C2 > $O/pmc_c2.log 2>&1; echo "pmc rc=$?"; tail -3 $O/pmc_c2.log ;;
+    pmc_c2_f64) timeout -k 10 900 bash tools/pmc.sh r04_c2_f64 C2 --option rdf_pk=0 > $O/pmc_c2_f64.log 2>&1; echo "pmc rc=$?" ;;
+    pmc_c3) timeout -k 10 900 bash tools/pmc.sh r04_c3 C3 --scaling strong > $O/pmc_c3.log 2>&1; echo "pmc rc=$?" ;;
+    pmc_c3_cn) timeout -k 10 900 bash tools/pmc.sh r04_c3_cn C3/cn --scaling strong --op cn > $O/pmc_c3_cn.log 2>&1; echo "pmc rc=$?" ;;
+    pmc_c3_both) timeout -k 10 900 bash tools/pmc.sh r04_c3_both C3/rdf_cn --scaling strong --op rdf_cn > $O/pmc_c3_both.log 2>&1; echo "pmc rc=$?" ;;
+    pmc2) timeout -k 10 1100 bash tools/pmc_secondary.sh r04 > $O/pmc2.log 2>&1; echo "pmc2 rc=$?"; tail -5 $O/pmc2.log ;;
     overhead) timeout -k 10 300 python tools/call_overhead.py 2>&1 | grep -v amdgpu | tail -8 ;;
     *) echo "unknown step $s" ;;
   esac
