@@ -334,14 +334,18 @@ template <bool CNG>
 __device__ __forceinline__ void pk_drain(PkCtx &p, const FastCtx &c, int lane)
 {
     // The pushes carry no capacity test (pk_push): a wave drains above 64 entries before every group and a group adds at
-    // most 4 x 64, so qn <= PK_QCAP here — by construction. Should a later variant break that, entries beyond the queue
-    // have overwritten the next wave's queue or the tables behind it: nothing can repair that, but it must not pass
-    // silently — the count goes to the `lost` word, which the host turns into an error (checked on this, the rare, path
-    // only: the hot loop is bound by scalar issue slots too).
+    // most 4 x 64, so qn <= PK_QCAP here — by construction. A check even on this rare path is not free (round 4, build
+    // against build: +1.1 % at C2, +2.2 % at C3 — the function is inlined at every drain point and the extra live
+    // values move the whole kernel's allocation), so it is a DEBUG build's: -DPK_CAPCHECK counts entries beyond the
+    // queue in the `lost` word, which the host turns into an error. The invariant itself is exercised at its limit by
+    // tests/test_gpu_hardening.py::test_every_pair_ambiguous_fills_the_queues (every pair of every group ambiguous:
+    // 64 + 256 entries per wave, against the oracle).
+#ifdef PK_CAPCHECK
     if (p.qn > PK_QCAP) {
         if (lane == 0) atomicAdd(p.lost, (unsigned long long)(p.qn - PK_QCAP));
         p.qn = PK_QCAP;
     }
+#endif
     const int n = p.qn < PK_QCAP ? p.qn : PK_QCAP;
     for (int b = 0; b < n; b += 64) {
         if (b + lane < n) {

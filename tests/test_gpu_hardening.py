@@ -268,3 +268,45 @@ def test_soak_slices_inside_the_suite():
         tail = "\n".join(r.stdout.splitlines()[-5:])
         assert r.returncode == 0 and "identical" in tail, tail
     assert time.perf_counter() - t0 < 300.0
+
+
+def test_every_pair_ambiguous_fills_the_queues(B):
+    """The deferred-pair queues at their limit (the push has no capacity test). Atoms sit on TWO points a
+    whole number of bins apart: every pair is either at distance 0 or exactly on a bin edge, i.e. inside the guard band of
+    the packed-f32 guess — every lane of every group pushes, 4 x 64 entries on top of whatever a wave still holds. If an
+    entry ever landed beyond a wave's 320 words it would overwrite the next wave's queue or the CN tables and these counts
+    could not all be right: histogram, coordination counts (cutoffs on and off the distance) and the one-sweep call
+    against the C oracle, packed sweep against the all-f64 sweep."""
+    n, L = 8192, 30.0
+    rng = np.random.default_rng(8)
+    side = rng.integers(0, 2, n)
+    xyz = np.empty((2, 3, n))
+    for f, d in enumerate((4.0, 6.35)):  # 80 and 127 bins of 0.05
+        xyz[f, 0] = 10.0 + d * side
+        xyz[f, 1] = 11.0
+        xyz[f, 2] = 12.0
+    ty = (1 + np.arange(n) % 3).astype(np.int32)
+    rel = np.array([[1, 1], [1, 2], [2, 3], [3, 3]])
+    box = np.full((2, 3), L)
+    ctx = B.default_context()
+    full, part, ov = B.rdf_loop(xyz, ty, box, rel, 10.0, 0.05, 200, ctx=ctx)
+    assert "<3" in ctx.last_kernel_name() or "<4" in ctx.last_kernel_name()  # the packed sweep took it
+    cuts = [4.0, 6.35, 3.9999, 9.0]
+    cn = B.cn_loop(xyz, ty, box, rel, cuts, ctx=ctx)
+    f2, p2, o2, cn2 = B.rdf_cn_loop(xyz, ty, box, rel, 10.0, 0.05, 200, cuts, ctx=ctx)
+    ctx.set_option("rdf_pk", 0)
+    try:
+        f64 = B.rdf_loop(xyz, ty, box, rel, 10.0, 0.05, 200, ctx=ctx)
+    finally:
+        ctx.set_option("rdf_pk", -1)
+    for f in range(2):
+        cf, cp, cov = C.rdf_pairs(xyz[f], ty, rel, box[f], 100.0, 0.05, 200)
+        np.testing.assert_array_equal(full[f], cf)
+        np.testing.assert_array_equal(part[f], cp)
+        np.testing.assert_array_equal(cn[f], C.cn_pairs(xyz[f], ty, rel, box[f], [c * c for c in cuts]))
+    assert int(full.sum()) == 2 * 2 * (n * (n - 1) // 2) and ov == 0
+    np.testing.assert_array_equal(f2, full)
+    np.testing.assert_array_equal(p2, part)
+    np.testing.assert_array_equal(cn2, cn)
+    np.testing.assert_array_equal(f64[0], full)
+    np.testing.assert_array_equal(f64[1], part)
