@@ -38,7 +38,7 @@ import json,sys; d=json.loads(open('$O/bench_c4_rccl1_${TAG}.json').read().strip
       timeout -k 10 120 python tools/pin_cost.py 2>&1 | grep -v amdgpu > $O/r04_pin_cost.txt
       timeout -k 10 120 python tools/h2d_pipe.py 16 2>&1 | grep -v amdgpu > $O/r04_h2d_pipe.txt
       ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $O/trace_h2d -- python3 $R/tools/h2d_pipe.py 8 > /dev/null 2>&1 ); python3 tools/trace_overlap.py $O/trace_h2d >> $O/r04_h2d_pipe.txt
-      tail -3 $O/r04_ab_scan.txt $O/r04_ab_lag_direct.txt $O/r04_gk_diag.txt ;;
+      for f in r04_ab_scan r04_ab_lag_direct r04_gk_diag; do tail -n 3 $O/$f.txt; done ;;
     stats) (cd /tmp && export TMPDIR=/tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o r04_bench -- python3 $R/bench.py --no-cpu-baseline --no-legs > $O/bench_line_rocprof.json 2> $O/rocprof_err.log); echo "stats rc=$?" ;;
     stats_legs) (cd /tmp && export TMPDIR=/tmp && timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o r04_bench_legs -- python3 $R/bench.py --no-cpu-baseline > $O/bench_line_rocprof_legs.json 2> $O/rocprof_legs_err.log); echo "stats_legs rc=$?"; tail -2 $O/rocprof_legs_err.log ;;
     overhead) timeout -k 10 300 python tools/call_overhead.py 2>&1 | grep -v amdgpu | tail -8 ;;
