@@ -236,14 +236,14 @@ class PinnedPool:
 
     Page-locking is not free (tools/pin_cost.py, MI355X host: hipHostMalloc of 24 MB 1.6 ms and as much again to free it,
     against 1.3 ms for the runtime's staged copy into fresh pageable pages and 0.46 ms for the DMA into locked ones), so it
-    pays only for memory that comes BACK: at most `max_live` blocks per size are handed out at a time (six: two calls'
-    worth of a three-array result) — a caller that keeps every result (replicate lists) gets ordinary arrays after that,
+    pays only for memory that comes BACK: at most `max_live` blocks per size are handed out at a time (eight: two calls'
+    worth of a three-array result and a couple of inputs kept around) — a caller that keeps every result (replicate lists) gets ordinary arrays after that,
     a caller that drops them (a loop over trajectories, the bench) keeps getting the same locked blocks.
     """
 
     GRAIN = 1 << 20
 
-    def __init__(self, max_keep=1 << 30, max_live=6):
+    def __init__(self, max_keep=1 << 30, max_live=8):
         self.free = {}
         self.live = {}
         self.kept = 0

@@ -289,6 +289,12 @@ struct LagFftResult {
 int mdhip_lag_msd_fft(CallScope &cs, int64_t n_frames, int64_t n_ent, const double *d_r, double scale, int max_lag,
                       int n_groups, const int64_t *group_off, const std::shared_ptr<LagFftResult> &res);
 
+// Finished values (host memory) on their way to a DEVICE result buffer from inside a completion step. The copy runs on
+// the context's copy stream, not on the launch stream: a later call's kernels may already be queued there (calls are
+// issued ahead of the completion of the ones before them), and a copy behind them would make this completion — and
+// with it the caller's next issue — wait for kernels it has nothing to do with. Complete when this returns.
+int mdhip_deliver_to_device(mdhip_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+
 // A small host table on its way to device memory: through pinned staging of the call, so that the copy is asynchronous
 // and the caller's (or this function's) memory may go away at once.
 static inline int mdhip_h2d_small(mdhip_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes)

@@ -1,4 +1,5 @@
 // mdhip_ctx.hip — lifecycle, workspace, options and the host-side bin-edge table.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <ctime>
@@ -280,6 +281,38 @@ void mdhip_call_abandon(mdhip_ctx *ctx, mdhip_call *c)
     (void)hipGetLastError();
     ctx->cur = c->parent;
     release_call(ctx, c);
+}
+
+int mdhip_deliver_to_device(mdhip_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes)
+{
+    if (bytes == 0) return MDHIP_OK;
+    if (!ctx->copy_stream) {
+        MD_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        MD_HIP(hipEventCreateWithFlags(&ctx->copy_ev[0], hipEventDisableTiming));
+        MD_HIP(hipEventCreateWithFlags(&ctx->copy_ev[1], hipEventDisableTiming));
+        MD_HIP(hipEventCreateWithFlags(&ctx->stage_ev[0], hipEventDisableTiming));
+        MD_HIP(hipEventCreateWithFlags(&ctx->stage_ev[1], hipEventDisableTiming));
+    }
+    // a staging block of its own for the length of the copy (this runs outside any call's issue phase)
+    int best = -1;
+    for (size_t k = 0; k < ctx->pin_free.size(); ++k)
+        if (ctx->pin_free[k].cap >= bytes && (best < 0 || ctx->pin_free[k].cap < ctx->pin_free[(size_t)best].cap)) best = (int)k;
+    PinBlock b;
+    if (best >= 0) {
+        b = ctx->pin_free[(size_t)best];
+        ctx->pin_free.erase(ctx->pin_free.begin() + best);
+    } else {
+        size_t cap = std::max<size_t>(65536, (bytes + 4095) & ~size_t(4095));
+        if (hipHostMalloc(&b.p, cap, hipHostMallocDefault) != hipSuccess)
+            return mdhip_fail(ctx, MDHIP_ENOMEM, "hipHostMalloc(%zu) failed for a staging block", cap);
+        b.cap = cap;
+    }
+    memcpy(b.p, src_host, bytes);
+    hipError_t e = hipMemcpyAsync(dst_dev, b.p, bytes, hipMemcpyHostToDevice, ctx->copy_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->copy_stream);
+    ctx->pin_free.push_back(b);
+    if (e != hipSuccess) return mdhip_fail(ctx, MDHIP_EHIP, "copy of finished values to the device failed: %s", hipGetErrorString(e));
+    return MDHIP_OK;
 }
 
 extern "C" {

@@ -773,10 +773,7 @@ static int deliver_host_values(mdhip_ctx *ctx, const double *src, size_t bytes, 
         memcpy(dst, src, bytes);
         return MDHIP_OK;
     }
-    CallScope cs(ctx);
-    const int rc = mdhip_h2d_small(ctx, dst, src, bytes);
-    if (rc) return rc;
-    return cs.end();
+    return mdhip_deliver_to_device(ctx, dst, src, bytes);
 }
 
 // force_variant >= 0: that lag_variant instead of the context's option (the fallback of the spectral path)

@@ -1246,10 +1246,7 @@ static int deliver_counts(mdhip_ctx *ctx, const uint64_t *src, size_t n, uint64_
         if (dst != src) memcpy(dst, src, n * 8);
         return MDHIP_OK;
     }
-    CallScope cs(ctx);
-    const int rc = mdhip_h2d_small(ctx, dst, src, n * 8);
-    if (rc) return rc;
-    return cs.end();
+    return mdhip_deliver_to_device(ctx, dst, src, n * 8);
 }
 
 // One sweep for the histograms AND the coordination counts. hist_full / hist_part / overflow may be
