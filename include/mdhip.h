@@ -132,7 +132,8 @@ int mdhip_device_name(mdhip_ctx *ctx, char *buf, int buflen);
  *   "seg_frame"    segment COM / flux: 1 (default) one (run, frame) per block, 0 the software-pipelined staged kernel;
  *                  "seg_cap", "seg_vec", "seg_gy" geometry of the staged kernel
  *   "h2d_overlap"  host-resident frames: 1 (default) staged batch by batch under the sweeps, 0 copied first
- *   "rdf_relblock", "rdf_guard", "cn_pk"  record blocks / overflow guard / coordination counts through the packed sweep
+ *   "rdf_guard", "cn_pk"  overflow guard / coordination counts through the packed sweep ("rdf_relblock": retired in
+ *                  round 4, accepted and ignored — the f32 records are relative to their whole tile's centre)
  *   "sync_spin"    waiting for device work: 1 (default) poll the completion event (no interrupt wake-up latency; turns
  *                  into a blocking wait after 100 ms), 0 block at once */
 int mdhip_set_option(mdhip_ctx *ctx, const char *key, int value);

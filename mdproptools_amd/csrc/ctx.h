@@ -128,7 +128,7 @@ struct mdhip_ctx {
     hipEvent_t stage_ev[2] = {nullptr, nullptr};
     bool stage_used[2] = {false, false};
     int stage_flip = 0;
-    int opt_rdf_relblock = 0;  // packed sweep: atoms per centre block of the f32 records, 0 / 256 = whole tiles, 64 (A/B)
+    int opt_rdf_relblock = 0;  // (retired: the f32 records are relative to their whole tile's centre; accepted, ignored)
     int opt_h2d_overlap = 1;  // 1 (default): overlapped staging of host-resident pair inputs, 0: one copy up front (A/B)
     std::string err;
     DevBuf ws[WS_COUNT];

@@ -45,6 +45,7 @@ struct PairArgs {
     const float4 *gsph;          // [F][nTi*32][2] bounding box (lo, hi; w = 1 if non-empty) of every 8 sorted atoms
     const float4 *gsph4;         // [F][nTj*64][2] the same for every 4 sorted atoms of the j set (scalar-j kernel)
     const float4 *wsph;          // [F][nTi*4][2]  bounding box of every 64 sorted atoms (one wave's i atoms)
+                                 // (packed-f32 sweep: both as (centre, half extents), see cull_boxes_kernel)
     float reach;                 // r_cut rounded up, plus slack for the f32 box test
     const double4 *aos;          // [F][nTi*256] sorted atoms (x, y, z, bits = type * n_ti), padded with +1e300
     unsigned *work;              // work counters of the scalar-j kernel, zeroed per launch: [8] per XCD
@@ -57,8 +58,7 @@ struct PairArgs {
     const float *rel;            // [F][nTj*128][8] f32 records of the j set relative to the centre of their block (64
                                  // or 256 sorted atoms), two atoms per record: (x0, x1, y0, y1, z0, z1, w0, w1),
                                  // w = the bin-guess addend of pack_w
-    const double *cen;           // [F][nTj * blocks][8] block centre (x, y, z) and half extents (hx, hy, hz)
-    int cen_shift;               // log2(groups of 4 atoms per centre block): 4 = 64 atoms, 6 = the whole tile
+    const double *cen;           // [F][nTj][8] tile centre (x, y, z) and half extents (hx, hy, hz)
     float s_cap;                 // largest |relative coordinate| sum (i + j, per axis) the error bound `near` covers
     float cut_lo;                // MODE 4 (cutoff inside a bin): sqrt(rsq32) >= cut_lo may lie beyond the cutoff
     float rc2hi;                 // f32 pre-filter: every in-cutoff pair has rsq32 < rc2hi (see pk_error_bound)
@@ -175,8 +175,9 @@ constexpr int MORTON_CELLS = 1 << (3 * MORTON_BITS); // 32768
 int cull_prepare_set(mdhip_ctx *ctx, int64_t F, const double *d_x, const int *d_t, long long t_fs,
                      const double *d_box, long long N, int nT, int n_ti, float near, int row_len, bool want_soa,
                      int rel_block /* 0 = no f32 records, else atoms per centre block: 64 or 256 */,
-                     int rel_w_type /* w of the f32 records: 0 bin-guess addend, 1 row-table offset */, const int slot[5],
-                     SortedSet &out);
+                     int rel_w_type /* w of the f32 records: 0 bin-guess addend, 1 row-table offset */,
+                     int cbox /* 1: 4-atom and 64-atom boxes as (centre, half extents): packed-f32 sweep */,
+                     const int slot[5], SortedSet &out);
 void launch_cull_lists(hipStream_t stream, bool tri, int64_t F, const double *bbox_i, const double *bbox_j, int nTi,
                        int nTj, const double *d_box, double rc2_test, unsigned short *list, int *cnt);
 

@@ -275,7 +275,7 @@ __global__ __launch_bounds__(TILE) void cull_boxes_kernel(const double4 *__restr
                                                           double *__restrict__ bbox, float4 *__restrict__ gboxes,
                                                           float4 *__restrict__ wboxes, float4 *__restrict__ g4boxes,
                                                           double *__restrict__ cen, float *__restrict__ rel,
-                                                          int rel_block, int rel_w_type)
+                                                          int rel_block, int rel_w_type, int cbox)
 {
     __shared__ double red[6][TILE / 64];
     const int f = blockIdx.y, T = blockIdx.x, tid = threadIdx.x;
@@ -298,6 +298,24 @@ __global__ __launch_bounds__(TILE) void cull_boxes_kernel(const double4 *__restr
         lo4 = w > 0.f ? make_float4(l[0], l[1], l[2], 1.f) : make_float4(0.f, 0.f, 0.f, 0.f);
         hi4 = w > 0.f ? make_float4(h[0], h[1], h[2], 1.f) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
+    // cbox (packed-f32 sweep): the 4-atom and 64-atom boxes as (centre, half extents) instead — the sweep's group test
+    // is then |nearest image of (c_wave - c_group)| - (h_wave + h_group) per axis, and its plain-difference test
+    // |c_wave - n L - c_group| + (h_wave + h_group): a third of the instructions of the same tests on (lo, hi) pairs.
+    // The centre is rounded to f32 first and the half extents taken around THAT value, widened as above (the padding
+    // also covers the roundings of the sweep's own arithmetic: it grows with the coordinates like they do). A box
+    // without atoms gets half extents of -1e18: its gap to anything is 1e18.
+    auto centred = [&](float4 &c4, float4 &h4) {
+        float cc[3], hh[3];
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            const double pad = pad0 + 2.5e-7 * __builtin_fmax(__builtin_fabs(lo[ax]), __builtin_fabs(hi[ax]));
+            cc[ax] = (float)(0.5 * (lo[ax] + hi[ax]));
+            hh[ax] = (float)(__builtin_fmax(hi[ax] - (double)cc[ax], (double)cc[ax] - lo[ax]) + pad);
+        }
+        const bool any = hi[0] >= lo[0];
+        c4 = any ? make_float4(cc[0], cc[1], cc[2], 1.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+        h4 = any ? make_float4(hh[0], hh[1], hh[2], 1.f) : make_float4(-1.0e18f, -1.0e18f, -1.0e18f, 0.f);
+    };
     auto fold = [&](int m) {
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) {
@@ -309,7 +327,8 @@ __global__ __launch_bounds__(TILE) void cull_boxes_kernel(const double4 *__restr
     fold(2);
     if ((tid & 3) == 0) {  // every 4 atoms: the culling groups of the scalar-j kernel
         float4 l4, h4;
-        widened(l4, h4);
+        if (cbox) centred(l4, h4);
+        else widened(l4, h4);
         const size_t g = ((size_t)f * nT + T) * (TILE / 4) + (tid >> 2);
         g4boxes[2 * g] = l4;
         g4boxes[2 * g + 1] = h4;
@@ -329,7 +348,8 @@ __global__ __launch_bounds__(TILE) void cull_boxes_kernel(const double4 *__restr
     const double wl[3] = {lo[0], lo[1], lo[2]}, wh[3] = {hi[0], hi[1], hi[2]};  // box of this wave's 64 atoms
     if ((tid & 63) == 0) {
         float4 l4, h4;
-        widened(l4, h4);
+        if (cbox) centred(l4, h4);
+        else widened(l4, h4);
         const size_t w = ((size_t)f * nT + T) * (TILE / 64) + wave;
         wboxes[2 * w] = l4;
         wboxes[2 * w + 1] = h4;
@@ -436,7 +456,7 @@ __global__ __launch_bounds__(256) void cull_list_kernel(const double *__restrict
 
 int cull_prepare_set(mdhip_ctx *ctx, int64_t F, const double *d_x, const int *d_t, long long t_fs,
                      const double *d_box, long long N, int nT, int n_ti, float near, int row_len, bool want_soa,
-                     int rel_block, int rel_w_type, const int slot[5], SortedSet &out)
+                     int rel_block, int rel_w_type, int cbox, const int slot[5], SortedSet &out)
 {
     const bool want_rel = rel_block != 0;
     MD_WS(d_rel, float, WS_REL, want_rel ? (size_t)F * nT * TILE * 16 : 64);
@@ -474,7 +494,7 @@ int cull_prepare_set(mdhip_ctx *ctx, int64_t F, const double *d_x, const int *d_
     }
     hipLaunchKernelGGL(cull_boxes_kernel, dim3((unsigned)nT, (unsigned)F), dim3(TILE), 0, ctx->stream, d_ao, d_box, N,
                        nT, d_bbox, d_gs, d_ws, d_g4, want_rel ? d_cen : (double *)nullptr,
-                       want_rel ? d_rel : (float *)nullptr, want_rel ? rel_block : TILE, rel_w_type);
+                       want_rel ? d_rel : (float *)nullptr, want_rel ? rel_block : TILE, rel_w_type, cbox);
     MD_HIP(hipGetLastError());
     out.rel = want_rel ? d_rel : nullptr;
     out.cen = want_rel ? d_cen : nullptr;

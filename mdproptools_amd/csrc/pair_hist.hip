@@ -174,8 +174,9 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
             cut_guard = !on_edge;
             // sqrt(rsq32) < cut_lo  =>  sqrt(rsq) < cut_lo + err * bin_size < r_cut: inside the cutoff for certain
             cut_lo = std::nextafterf((float)(r_cut - 1.1 * err * p.bin_size), 0.f);
-            // centre blocks: whole tiles (64-atom blocks only buy a little f32 precision for 4x the per-block work)
-            rel_block = ctx->opt_rdf_relblock == 64 ? 64 : TILE;
+            // the f32 records are relative to the centre of their whole tile (64-atom blocks bought a little f32
+            // precision for 4x the per-block work: measured slower in round 2, retired in round 4)
+            rel_block = TILE;
             near_pk_f = (float)near_pk;
             s_cap = (float)cap;
             // every pair with rsq < r_cut^2 has sqrt(rsq32) <= r_cut + err * bin_size
@@ -323,7 +324,7 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         // (the bin-guess addend near + type * row_len and the tile-relative f32 records belong to the j set)
         int rc = cull_prepare_set(ctx, F, p.d_xi, p.d_ti, (long long)p.ti_fs, p.d_box, N, nTi, p.n_ti,
                                   ordered ? near_ord : 0.f, ordered ? p.nbins + 1 : 0, want_soa,
-                                  pk && p.tri ? rel_block : 0, pk_rows ? 1 : 0, slot_i, si);
+                                  pk && p.tri ? rel_block : 0, pk_rows ? 1 : 0, pk ? 1 : 0, slot_i, si);
         if (rc) return rc;
         if (p.tri) {
             sj_set = si;
@@ -331,7 +332,7 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
             const int slot_j[5] = {WS_SORT_AOS_J, WS_BBOX_J, WS_GSPH_J, WS_WSPH_J, WS_GSPH4_J};
             rc = cull_prepare_set(ctx, F, p.d_xj, p.d_tj, (long long)p.tj_fs, p.d_box, p.nj, nTj, p.n_ti,
                                   ordered ? near_ord : 0.f, ordered ? p.nbins + 1 : 0, false, pk ? rel_block : 0,
-                                  pk_rows ? 1 : 0, slot_j, sj_set);
+                                  pk_rows ? 1 : 0, pk ? 1 : 0, slot_j, sj_set);
             if (rc) return rc;
         }
         launch_cull_lists(ctx->stream, p.tri, F, si.bbox, sj_set.bbox, nTi, nTj, p.d_box,
@@ -419,7 +420,6 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         a.rel = d_rel;
         a.cen = d_cen;
         a.s_cap = s_cap;
-        a.cen_shift = rel_block == 64 ? 4 : 6;
         a.rc2hi = rc2hi;
         a.cut_lo = cut_lo;
         a.n_cn = p.n_cn;

@@ -253,8 +253,8 @@ __device__ __forceinline__ int sj_item(const PairArgs &a, FastCtx &c, const unsi
 // pair changes. Lane-parallel draining makes the exact chain cost ~1/64 of what an inline fallback would.
 //
 // Keeping the f32 error small, and the wrap out of the pair loop: the j atoms are stored relative to the centre c
-// of the box of their BLOCK (the tile of 256 sorted atoms; 64-atom blocks are supported through cen_shift but were
-// slower), and every lane moves its own i atom to the periodic image nearest to that centre, once per block:
+// of the box of their tile of 256 sorted atoms (64-atom blocks were slower: retired in round 4), and every lane moves
+// its own i atom to the periodic image nearest to that centre, once per neighbour tile:
 //   xr_j = f32(x_j - c)                          (pre-pass, |xr_j| <= half extent h of the block)
 //   q    = x_i - c;  xr_i = f32(q - L rint(q/L)) (f64 per lane and block, |xr_i| <= L/2)
 // so that d' = xr_i - xr_j is d = x_i - x_j moved by a whole number of box lengths, |d'| <= L/2 + e (e = how far
@@ -765,19 +765,25 @@ __device__ __forceinline__ int sj_item_pk(const PairArgs &a, FastCtx &c, const u
         c.rowbase_me = c.lds_base + (unsigned)ti_me * (unsigned)a.n_tj * (unsigned)(a.nbins + 1) * 4u;
     }
     const long long w = ((long long)f * a.nTi + I) * (TILE / 64) + wq;
-    // (wave-uniform: through the constant address space, so that the box lives in SGPRs, not in 8 VGPRs)
+    // The wave's box and the group boxes as (centre, half extents; cull_boxes_kernel, cbox). The wave's:
+    // wave-uniform, through the constant address space, so that it lives in SGPRs, not in 8 VGPRs.
     typedef const __attribute__((address_space(4))) f32x4 *cbox;
     const cbox wb = (cbox)(unsigned long long)(a.wsph + 2 * w);
-    const f32x4 wlo4 = wb[0], whi4 = wb[1];
-    const float4 wlo = make_float4(wlo4[0], wlo4[1], wlo4[2], wlo4[3]), whi = make_float4(whi4[0], whi4[1], whi4[2], whi4[3]);
+    const f32x4 wc = wb[0], wh = wb[1];
     const float4 *gb_f = a.gsph4 + (long long)f * a.nTj * (TILE / SJ_GROUP) * 2;
     const float fLx = (float)L.Lx, fLy = (float)L.Ly, fLz = (float)L.Lz;
     const float r_cut = __builtin_sqrtf((float)a.rc2);
-    // |d'| up to here needs no per-pair wrap on that axis (see above); the margin covers the f32 box arithmetic
-    const float thx = fLx - r_cut - (1.0e-3f * fLx + 1.0e-3f);
-    const float thy = fLy - r_cut - (1.0e-3f * fLy + 1.0e-3f);
-    const float thz = fLz - r_cut - (1.0e-3f * fLz + 1.0e-3f);
     const float fiLx = (float)iLx, fiLy = (float)iLy, fiLz = (float)iLz;
+    // What depends on (wave box, tile centre) only is computed ONCE per neighbour tile, lanes 0 .. 2 taking one axis
+    // each (round 3 computed it in every lane, per group: two thirds of the axis tests' instructions), and handed to
+    // the wave through v_readlane. Per-axis constants of this lane's axis:
+    const int ax = lane < 3 ? lane : 0;
+    const float L_a = (float)a.box[3 * f + ax], iL_a = (float)(1.0 / a.box[3 * f + ax]);
+    // |d'| up to here needs no per-pair wrap on that axis (see above); the margin covers the f32 box arithmetic
+    const float th_a = L_a - r_cut - (1.0e-3f * L_a + 1.0e-3f);
+    const float cw_a = reinterpret_cast<const float *>(a.wsph + 2 * w)[ax];
+    const float hw_a = reinterpret_cast<const float *>(a.wsph + 2 * w)[4 + ax];
+    const float cap_a = a.s_cap * (1.0f - 1.0e-6f);
     PkCtx p;
     p.Lx2 = f32x2{fLx, fLx};
     p.Ly2 = f32x2{fLy, fLy};
@@ -813,58 +819,68 @@ __device__ __forceinline__ int sj_item_pk(const PairArgs &a, FastCtx &c, const u
     }
     p.inv_row_len = 1.0f / (float)(a.nbins + 1);
     const float *rel_f = a.rel + (long long)f * n_pad_j * 4;  // 4 floats per j atom
-    const int gpb = 1 << a.cen_shift;                        // groups per centre block
-    const int nblk = (TILE / SJ_GROUP) >> a.cen_shift;       // centre blocks per tile
-    const double *cen_f = a.cen + (long long)f * a.nTj * nblk * 8;
+    const double *cen_f = a.cen + (long long)f * a.nTj * 8;
+    const int I_u = __builtin_amdgcn_readfirstlane(I);  // (uniform anyway; this tells the compiler: masks are selected on it)
+    const float reach2 = a.reach * a.reach, cn_reach2 = a.cn_reach * a.cn_reach;
     for (int t = t_begin; t < t_end; ++t) {
         const int J = __builtin_amdgcn_readfirstlane((int)row_list[t]);
-        // every lane tests one 4-atom group box of the tile against this wave's box
-        const float4 glo = gb_f[((long long)J * (TILE / SJ_GROUP) + lane) * 2];
-        const float4 ghi = gb_f[((long long)J * (TILE / SJ_GROUP) + lane) * 2 + 1];
-        const float gx = gapf(wlo.x, whi.x, glo.x, ghi.x, fLx);
-        const float gy = gapf(wlo.y, whi.y, glo.y, ghi.y, fLy);
-        const float gz = gapf(wlo.z, whi.z, glo.z, ghi.z, fLz);
-        const bool keep = wlo.w > 0.f && glo.w > 0.f && gx * gx + gy * gy + gz * gz < a.reach * a.reach;
-        const unsigned long long km = __builtin_amdgcn_ballot_w64(keep);
+        // every lane tests one 4-atom group box of the tile against this wave's box: per axis the distance of the
+        // centres at the nearest image minus the half extents (a lower bound of the reference's per-axis distance
+        // min(|d|, ||d| - L|): the nearest image is never farther than the single wrap's)
+        const float4 gc = gb_f[((long long)J * (TILE / SJ_GROUP) + lane) * 2];
+        const float4 gh = gb_f[((long long)J * (TILE / SJ_GROUP) + lane) * 2 + 1];
+        const double *cb = cen_f + (long long)J * 8;
+        const double cd_a = cb[ax], hd_a = cb[3 + ax];  // (lanes 0 .. 2: the tile's centre and half extent on their axis)
+        const float sx = wh[0] + gh.x, sy = wh[1] + gh.y, sz = wh[2] + gh.z;
+        const float dx = wc[0] - gc.x, dy = wc[1] - gc.y, dz = wc[2] - gc.z;
+        const float gx = __builtin_fmaxf(__builtin_fabsf(__builtin_fmaf(-__builtin_rintf(dx * fiLx), fLx, dx)) - sx, 0.f);
+        const float gy = __builtin_fmaxf(__builtin_fabsf(__builtin_fmaf(-__builtin_rintf(dy * fiLy), fLy, dy)) - sy, 0.f);
+        const float gz = __builtin_fmaxf(__builtin_fabsf(__builtin_fmaf(-__builtin_rintf(dz * fiLz), fLz, dz)) - sz, 0.f);
+        const float g2 = gx * gx + gy * gy + gz * gz;
+        const unsigned long long km = __builtin_amdgcn_ballot_w64(g2 < reach2);  // (a box without atoms: g2 ~ 1e36)
         if (!km) continue;
         // CNG: groups whose box comes within the largest split bin of the wave's box are swept with the flag check
-        const bool nearg = CNG && gx * gx + gy * gy + gz * gz < a.cn_reach * a.cn_reach;
+        const unsigned long long nm = CNG ? __builtin_amdgcn_ballot_w64(g2 < cn_reach2) : 0ull;
         const float *rtile = rel_f + (long long)J * TILE * 4;
-        const bool diag = a.tri && J == I;
-        // variant of this lane's group: the axes on which some |d'| may exceed L - r_cut (per-pair wrap needed)
-        unsigned var;
+        const bool diag = a.tri && J == I_u;
+        // (wave box, tile centre c), one axis per lane: do all lanes of the wave sit at the same image n relative to c
+        // — the rint of both ends of the box agree, with 1e-3 of slack so that every lane's own f64 rint agrees too —,
+        // the wave's centre moved there, the threshold for |d'| (-1 = no group is plain on this axis), and whether
+        // the error bound covers the tile: every |x_i - x_j| < 1.5 L (single wrap = nearest image), |xr_i| + |xr_j|
+        // within s_cap, |d'| <= L/2 + h < 1.5 L for the per-pair wrap.
+        const float c_a = (float)cd_a, he_a = (float)hd_a;
+        const float rel_a = cw_a - c_a;
+        const float n0 = __builtin_rintf(__builtin_fmaf(rel_a - hw_a, iL_a, -1.0e-3f));
+        const float n1 = __builtin_rintf(__builtin_fmaf(rel_a + hw_a, iL_a, 1.0e-3f));
+        const bool same = n0 == n1;
+        const float cwn_a = __builtin_fmaf(-n0, L_a, cw_a);
+        // (c is rounded to f32 here: 2^-24 |c| on each difference — nothing next to the margin inside th for
+        // coordinates within a few box lengths of the origin, but subtracted so that the test stays conservative)
+        const float thc_a = same ? __builtin_fmaf(-1.0e-6f, __builtin_fabsf(c_a), th_a) : -1.0f;
+        // the largest |xr_i| of the wave: its box at image n0, or L/2 when the wave straddles a wrap boundary
+        const float wmax_a = same ? __builtin_fabsf(__builtin_fmaf(-n0, L_a, rel_a)) + hw_a : 0.5000001f * L_a;
+        const bool ok_a = (__builtin_fabsf(rel_a) + hw_a + he_a < 1.49f * L_a) && (wmax_a + he_a < cap_a) &&
+                          (he_a < 0.9f * L_a);
+        const bool covered = (__builtin_amdgcn_ballot_w64(ok_a) & 7ull) == 7ull;
+#define PK_LANE(V, K) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(V), K))
+        const float cwnx = PK_LANE(cwn_a, 0), cwny = PK_LANE(cwn_a, 1), cwnz = PK_LANE(cwn_a, 2);
+        const float thcx = PK_LANE(thc_a, 0), thcy = PK_LANE(thc_a, 1), thcz = PK_LANE(thc_a, 2);
+#undef PK_LANE
+        // per group and axis: does the plain difference d' = xr_i - xr_j suffice for every pair of (wave box, group
+        // box)? |d'| <= |c_wave - n L - c_group| + h_wave + h_group must stay within th. The axes that fail take the
+        // per-pair wrap (variant bits 1 / 2 / 4); the masks of the groups per variant are scalar arithmetic from here.
+        const unsigned long long mx = __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(cwnx - gc.x) + sx <= thcx));
+        const unsigned long long my = __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(cwny - gc.y) + sy <= thcy));
+        const unsigned long long mz = __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(cwnz - gc.z) + sz <= thcz));
+        const unsigned long long wrapm = mx | my | mz;
+        auto variant = [&](unsigned A) {
+            return km & ((A & 1u) ? mx : ~mx) & ((A & 2u) ? my : ~my) & ((A & 4u) ? mz : ~mz);
+        };
         {
-            const double *cg = cen_f + ((long long)J * nblk + (lane >> a.cen_shift)) * 8;
-            var = (axis_plain(wlo.x, whi.x, glo.x, ghi.x, (float)cg[0], fLx, fiLx, thx) ? 0u : 1u) |
-                  (axis_plain(wlo.y, whi.y, glo.y, ghi.y, (float)cg[1], fLy, fiLy, thy) ? 0u : 2u) |
-                  (axis_plain(wlo.z, whi.z, glo.z, ghi.z, (float)cg[2], fLz, fiLz, thz) ? 0u : 4u);
-            // the diagonal tile (i < j inside the tile): plain where every axis qualifies, else the wrap on all axes
-            if (diag) var = var == 0u ? 9u : 8u;
-        }
-        for (int b = 0; b < nblk; ++b) {
-            const unsigned long long bm = nblk == 1 ? ~0ull : ((1ull << gpb) - 1ull) << (b * gpb);
-            if (!(km & bm)) continue;
-            // this lane's i atom at the periodic image nearest to the block's centre
-            const double *cb = cen_f + ((long long)J * nblk + b) * 8;
-            // (the i atom is re-read per block rather than kept live through the pair loop: 8 VGPRs)
-            const double4 me = ats[ig];
-            const double ccx = cb[0], ccy = cb[1], ccz = cb[2];
-            const double hx = cb[3], hy = cb[4], hz = cb[5];
-            const double qx = me.x - ccx, qy = me.y - ccy, qz = me.z - ccz;
-            const double wx = __builtin_fma(-__builtin_rint(qx * iLx), L.Lx, qx);
-            const double wy = __builtin_fma(-__builtin_rint(qy * iLy), L.Ly, qy);
-            const double wz = __builtin_fma(-__builtin_rint(qz * iLz), L.Lz, qz);
-            // covered: every |x_i - x_j| < 1.5 L (single wrap = nearest image), |xr_i| + |xr_j| within the error
-            // bound's s_cap, |d'| <= L/2 + h < 1.5 L for the per-pair wrap
-            const bool ok = (__builtin_fabs(qx) + hx < 1.49 * L.Lx) && (__builtin_fabs(qy) + hy < 1.49 * L.Ly) &&
-                            (__builtin_fabs(qz) + hz < 1.49 * L.Lz) &&
-                            (__builtin_fabs(wx) + hx < (double)a.s_cap) && (__builtin_fabs(wy) + hy < (double)a.s_cap) &&
-                            (__builtin_fabs(wz) + hz < (double)a.s_cap) && hx < 0.9 * L.Lx && hy < 0.9 * L.Ly &&
-                            hz < 0.9 * L.Lz;
-            if (__builtin_amdgcn_ballot_w64(real_i && !ok)) {
+            if (!covered) {
                 // not covered (rare: atoms box lengths outside the cell): every pair of the kept groups goes to the
                 // queue, i.e. to the exact f64 chain with the general wrap (valid for every d)
-                unsigned long long mk = km & bm;
+                unsigned long long mk = km;
                 while (mk) {
                     const int g = __builtin_ctzll(mk);
                     mk &= mk - 1;
@@ -882,6 +898,13 @@ __device__ __forceinline__ int sj_item_pk(const PairArgs &a, FastCtx &c, const u
                 }
                 continue;
             }
+            // this lane's i atom at the periodic image nearest to the tile's centre
+            // (the i atom is re-read per tile rather than kept live through the pair loop: 8 VGPRs)
+            const double4 me = ats[ig];
+            const double qx = me.x - cb[0], qy = me.y - cb[1], qz = me.z - cb[2];
+            const double wx = __builtin_fma(-__builtin_rint(qx * iLx), L.Lx, qx);
+            const double wy = __builtin_fma(-__builtin_rint(qy * iLy), L.Ly, qy);
+            const double wz = __builtin_fma(-__builtin_rint(qz * iLz), L.Lz, qz);
             {
                 const float xr = real_i ? (float)wx : -1.0e18f;
                 const float yr = real_i ? (float)wy : -1.0e18f;
@@ -931,19 +954,19 @@ __device__ __forceinline__ int sj_item_pk(const PairArgs &a, FastCtx &c, const u
         }                                                                                                               \
     }
             if (!diag) {
-                PK_PIPELINED(__builtin_amdgcn_ballot_w64(keep && var == 0u && !nearg) & bm, false, 0)
-                if constexpr (CNG) PK_PIPELINED(__builtin_amdgcn_ballot_w64(keep && var == 0u && nearg) & bm, true, 0)
+                PK_PIPELINED(km & ~wrapm & ~nm, false, 0)
+                if constexpr (CNG) PK_PIPELINED(km & ~wrapm & nm, true, 0)
                 // the groups that take the per-pair wrap on some axis run the same software pipeline, variant by variant
                 // (round 3: their records were loaded and waited for group by group before — at C2, where a third of the
                 // swept groups wrap on some axis, 3.04 -> 2.82 ms build against build; C3, which has none, -0.9 %)
-                if (__builtin_amdgcn_ballot_w64(keep && var != 0u && !nearg)) {
-                    PK_PIPELINED(__builtin_amdgcn_ballot_w64(keep && var == 1u && !nearg) & bm, false, 1)
-                    PK_PIPELINED(__builtin_amdgcn_ballot_w64(keep && var == 2u && !nearg) & bm, false, 2)
-                    PK_PIPELINED(__builtin_amdgcn_ballot_w64(keep && var == 4u && !nearg) & bm, false, 4)
-                    PK_PIPELINED(__builtin_amdgcn_ballot_w64(keep && var == 3u && !nearg) & bm, false, 3)
-                    PK_PIPELINED(__builtin_amdgcn_ballot_w64(keep && var == 5u && !nearg) & bm, false, 5)
-                    PK_PIPELINED(__builtin_amdgcn_ballot_w64(keep && var == 6u && !nearg) & bm, false, 6)
-                    PK_PIPELINED(__builtin_amdgcn_ballot_w64(keep && var == 7u && !nearg) & bm, false, 7)
+                if (km & wrapm & ~nm) {
+                    PK_PIPELINED(variant(1u) & ~nm, false, 1)
+                    PK_PIPELINED(variant(2u) & ~nm, false, 2)
+                    PK_PIPELINED(variant(4u) & ~nm, false, 4)
+                    PK_PIPELINED(variant(3u) & ~nm, false, 3)
+                    PK_PIPELINED(variant(5u) & ~nm, false, 5)
+                    PK_PIPELINED(variant(6u) & ~nm, false, 6)
+                    PK_PIPELINED(variant(7u) & ~nm, false, 7)
                 }
             }
 #undef PK_PIPELINED
@@ -963,11 +986,12 @@ __device__ __forceinline__ int sj_item_pk(const PairArgs &a, FastCtx &c, const u
     case 8: sweep_group_pk<true, 7, false, CUTG, ROWS, CN>(q, j0, l0, p, c, lane_in_tile, lane, nullptr, qnone); break;  \
     default: break;                                                                                                    \
     }
-            const unsigned long long nm = CNG ? __builtin_amdgcn_ballot_w64(nearg) : 0ull;
+            // (the diagonal tile, i < j inside the tile: 9 = plain where every axis qualifies, 8 = the wrap on all axes)
+            if (!diag && !(CNG && (km & wrapm & nm))) continue;
             for (unsigned A = diag ? 8u : 1u; A <= (diag ? 9u : 7u); ++A) {
-                unsigned long long mk = __builtin_amdgcn_ballot_w64(keep && var == A && (diag || nearg)) & bm;
+                unsigned long long mk = diag ? (A == 9u ? km & ~wrapm : km & wrapm) : variant(A) & nm;
                 while (mk) {
-                    const int g = __builtin_ctzll(mk);
+                    const int g = __builtin_amdgcn_readfirstlane(__builtin_ctzll(mk));
                     mk &= mk - 1;
                     RelQ q = load_relq(rtile + g * SJ_GROUP * 4), qnone;
                     PK_DRAIN_CHECK();
