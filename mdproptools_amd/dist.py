@@ -428,23 +428,44 @@ def rdf_sharded(xyz_local, types, box_local, relation_matrix, r_cut, ddr, nbins,
 
 
 def rdf_sharded_per_frame(xyz_local, types, box_local, relation_matrix, r_cut, ddr, nbins, n_frames_total,
-                          compute=None):
+                          compute=None, ctx=None):
     """
     Varying box (NPT): per-frame integer histograms are all-gathered in frame order so that the host can
     normalise every frame with its own volume exactly as the reference does (rdf_cn.py:502-521).
     Returns (rdf_full [F,nbins], rdf_part [F,R,nbins], overflow).
+
+    ONE collective: a rank's rows travel as [frames_local, (1 + R) * nbins + 1] words — totals | partials | the rank's
+    overflow count in the last column of its first row (zeros below) — so the gathered last column sums to the
+    job's overflow. With device-resident frames the packed rows are gathered as a device tensor (RCCL reads and writes
+    device memory; gloo takes the same tensor through the host), and `ctx` is the context the sweep runs in.
     """
     if compute is None:
         from . import backend
 
         def compute(x, t, b, rel, rc, dd, nb):
-            return backend.rdf_loop(x, t, b, rel, rc, dd, nb, per_frame=True)
+            return backend.rdf_loop(x, t, b, rel, rc, dd, nb, per_frame=True, ctx=ctx)
 
     full, part, ov = compute(xyz_local, types, box_local, relation_matrix, r_cut, ddr, nbins)
-    full = allgather_rows(np.asarray(full, dtype=np.uint64), n_frames_total)
-    part = allgather_rows(np.asarray(part, dtype=np.uint64), n_frames_total)
-    (ovv,) = allreduce_u64([np.array([ov], dtype=np.uint64)])
-    return full, part, int(ovv[0])
+    full = np.asarray(full, dtype=np.uint64)
+    part = np.asarray(part, dtype=np.uint64)
+    fl, R = full.shape[0], part.shape[1]
+    packed = np.zeros((fl, (1 + R) * int(nbins) + 1), dtype=np.uint64)
+    packed[:, :nbins] = full
+    packed[:, nbins:-1] = part.reshape(fl, R * int(nbins))
+    if fl:
+        packed[0, -1] = np.uint64(ov)
+    if _is_tensor(xyz_local) and xyz_local.is_cuda and is_distributed():
+        import torch
+
+        dev = torch.from_numpy(packed.view(np.int64)).to(xyz_local.device, non_blocking=True)
+        rows = allgather_rows(dev, n_frames_total).cpu().numpy().view(np.uint64)
+    else:
+        rows = allgather_rows(packed, n_frames_total)
+    if not is_distributed() and fl == 0:
+        return full, part, int(ov)
+    return (np.ascontiguousarray(rows[:, :nbins]),
+            np.ascontiguousarray(rows[:, nbins:-1]).reshape(rows.shape[0], R, int(nbins)),
+            int(rows[:, -1].sum()))
 
 
 def cn_sharded(xyz_local, types, box_local, relation_matrix, r_cut_list, compute=None, ctx=None):

@@ -79,7 +79,8 @@ def _worker(rank, world, port, out_dir):
     pending = D.rdf_sharded_async(xyz[lo:hi], ty, box[lo:hi], rel, 6.0, 0.05, 120, compute=rdf_sum)
     afull, apart, aov = pending.wait()  # the in-flight variant gives the same sums
     assert np.array_equal(afull, full) and np.array_equal(apart, part) and int(aov[0]) == ov
-    pf, pp, _ = D.rdf_sharded_per_frame(xyz[lo:hi], ty, box[lo:hi], rel, 6.0, 0.05, 120, F, compute=rdf_frames)
+    pf, pp, pov = D.rdf_sharded_per_frame(xyz[lo:hi], ty, box[lo:hi], rel, 6.0, 0.05, 120, F, compute=rdf_frames)
+    assert pov == ov  # (one collective: the overflow count rides in the packed rows' last column)
     cn = D.cn_sharded(xyz[lo:hi], ty, box[lo:hi], rel, [2.0, 3.0, 4.0, 5.5], compute=cn_sum)
     sums = D.msd_single_origin_sharded(r[lo:hi], F, [0, 100, n], scale=1e-10, origin_frame=0, compute=msd)
     sums4 = D.msd_single_origin_sharded(r[lo:hi], F, [0, 100, n], scale=1e-10, origin_frame=4, compute=msd)

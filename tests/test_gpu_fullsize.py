@@ -400,7 +400,8 @@ def _frame_sharded_worker(rank, world, port, out_dir):
         res["w2_" + tag] = D.msd_windows_sharded(w_l, F, 2, scale=1e-10)
         res["w3_" + tag] = D.msd_windows_sharded(w_l, F, 3, scale=1e-10)
         res["j_" + tag] = D.charge_flux_sharded(v_l, F, mass, q, seg_off, seg_type, 2, 1e5, 1.602e-19)
-    pf, pp, ov = D.rdf_sharded_per_frame(xyz[lo:hi], ty, box[lo:hi], rel, 8.0, 0.05, 160, F)
+    # (device-resident frames: the packed per-frame rows are gathered as a device tensor)
+    pf, pp, ov = D.rdf_sharded_per_frame(torch.from_numpy(xyz[lo:hi]).to(dev), ty, box[lo:hi], rel, 8.0, 0.05, 160, F)
     full, part, ovs = D.rdf_sharded(torch.from_numpy(xyz[lo:hi]).to(dev), ty, box[lo:hi], rel, 8.0, 0.05, 160)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), pf=pf, pp=pp, ov=ov, full=full, part=part, **res)
     dist.barrier()
