@@ -184,7 +184,7 @@ struct mdhip_ctx {
                                   // sub-transforms where the series is long enough (msd_power_lds3_kernel), else as 1;
                                   // 1 = conflict-free LDS layout, bilinear spectrum sums (msd_power_lds2_kernel);
                                   // 0 = the round-2 kernel (A/B; also what short series fall back to)
-    int opt_lag_direct = 0;       // fused full-lag MSD path: 0 (default) a transposed copy [3 E][F] is made first; 1 = the power
+    int opt_lag_direct = -1;      // fused full-lag MSD path (-1: the default, msd_fft.hip): 0 a transposed copy [3 E][F] is made first; 1 = the power
                                   // kernel reads the trajectory [F][3][E] as it is, its blocks in XCD clusters of 16 that share
                                   // every line they fetch (round 4: no transposed copy and a third of the HBM traffic, but
                                   // 9.4 ms against 6.5 ms per C4 call: a lane's 8 bytes cost the vector-memory path a whole

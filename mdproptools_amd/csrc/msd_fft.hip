@@ -179,6 +179,21 @@ struct FftItem {
     int row;               // row of Qpart / Ppart the block writes (rows of one segment are consecutive)
 };
 
+// SRC == 2 of msd_power_lds3_kernel (round 4: a cluster of 16 blocks transposes its tiles itself): what a member needs
+// beside its FftItem, whose c_lo / c_hi are the cluster's range of 16-column TILES there
+struct FftStage {
+    long long lo, hi;  // the segment's columns [lo, hi): a member whose column 16 T + k lies outside transforms zeros
+    int k, cluster;    // member 0 .. 15: column 16 T + k of every tile; rows [k Fc, (k + 1) Fc) are its staging share
+};
+constexpr int ST_AHEAD = 4;  // tile i + ST_AHEAD is staged while tile i is transformed
+constexpr int ST_BUF = 8;    // ring of staged tiles per cluster (3 ST_AHEAD - 4 can be live at once)
+constexpr int ST_UNITS = 5;  // 16-byte units a lane moves per tile: rows per member Fc <= 64 ST_UNITS
+constexpr int ST_FLAG_STRIDE = 32;  // words between two ready counters (a 128-byte line each)
+#ifndef ST_SKIP
+#define ST_SKIP 0  // timing experiments only (wrong results): 1 = no polls, 2 = no staging loads / stores inside the series loop,
+                   // 4 = no wait + signal, 16 = no ring stores, 32 = no staging loads
+#endif
+
 __device__ __forceinline__ int ft_skew(int i) { return i + (i >> 4); }
 
 // From here on the arithmetic may fuse multiply-adds (the library is built with -ffp-contract=off for the pair
@@ -1008,8 +1023,11 @@ __device__ __forceinline__ void f3_bfly(Cx *a, Cx w1)
 #ifndef F3_PREFETCH
 #define F3_PREFETCH 1  // the next series' samples fetched under the sub-transforms (0: at the top of each series)
 #endif
+// `b_lo`, `b_hi`: the lane's butterflies b_lo + lane, b_lo + lane + 64, ... < b_hi of the pass (all of them by default;
+// the SRC == 2 kernel runs a pass in two halves with a staging unit moved in between)
 template <int LR, int LS>
-__device__ __forceinline__ void f3_wave_pass(double *re, double *im, int org, int len, const double2 *tw, int lane)
+__device__ __forceinline__ void f3_wave_pass(double *re, double *im, int org, int len, const double2 *tw, int lane,
+                                             int b_lo = 0, int b_hi = 1 << 30)
 {
     constexpr int R = 1 << LR, lb = LS + LR, s = 1 << LS;
     const int nb = len >> LR;
@@ -1044,7 +1062,7 @@ __device__ __forceinline__ void f3_wave_pass(double *re, double *im, int org, in
             im[F3_AT(iB, e)] = c[e].y;
         }
     } else {
-        for (int b = lane; b < nb; b += 64) {
+        for (int b = b_lo + lane; b < nb && b < b_hi; b += 64) {
             const int i0 = first(b);
             const double2 wv = tw[b & (s - 1)];
             Cx a[R];
@@ -1079,11 +1097,28 @@ __device__ __forceinline__ void f3_wave_pass(double *re, double *im, int org, in
 // aligned tile, member k column 16 T + k, tile after tile (FftItem::step 16); they do the same work per series and stay
 // within a fraction of an iteration of each other, so the line one of them brings into the XCD's L2 serves the other
 // fifteen. Nothing but the hit rate depends on that placement or on the blocks keeping step: no barrier, no flag.
-template <int JJ, int QE, bool DIRECT>
+// SRC == 2 (round 4, the default where the shape allows it): x is the caller's trajectory as for SRC == 1, and the
+// transposition happens INSIDE this kernel, spread over the transforms: the 16 blocks of a cluster walk the same
+// 16-column tiles (one 128-byte line per row); member k copies rows [k Fc, (k + 1) Fc) of tile i + ST_AHEAD — whole
+// lines, every line of the trajectory fetched once, by one block — into a scratch ring [cluster][tile % 8][16][16 Fc],
+// time-major and scaled, a 16-byte load and two 8-byte stores per lane at five points of every series' iteration, and
+// reads column k of tile i + 1 from there, 40 KB contiguous, as it read the transposed copy before. What rounds 2-4
+// paid for the copy — a 2.2 ms pass at C4, and 6 GB of workspace — is gone; the ring is 16 x 8 x 16 x 16 Fc doubles (84 MB).
+// Hand-off between blocks (MI355X_MICROARCH.md, "inter-workgroup visibility", first row of the measured table): the
+// scratch is written and read with device-scope (sc1) accesses only — __hip_atomic_store / _load, relaxed, agent —;
+// every wave waits for its stores (s_waitcnt vmcnt(0)) in front of a block barrier, behind which ONE lane adds to the
+// tile's ready counter (agent-scope atomic); a consumer wave polls that counter itself with sc1 loads and reads the
+// column only after its own poll has seen all 16 members. No placement assumption: any 16 co-resident blocks work.
+// Every block must be resident (the grid is one block per CU, as the LDS footprint allows one): a poll that does not
+// complete within ~2 s gives up, raises `stall` and the block runs to its end on whatever it reads (the host then
+// takes the transposed path).
+template <int JJ, int QE, int SRC>
 __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
     const double *__restrict__ x, int F, int m, const FftItem *__restrict__ items,
-    const double2 *__restrict__ tab, double *__restrict__ Qpart, double *__restrict__ Ppart, long long cols, double scale)
+    const double2 *__restrict__ tab, double *__restrict__ Qpart, double *__restrict__ Ppart, long long cols, double scale,
+    const FftStage *__restrict__ stg, double *__restrict__ scratch, unsigned *__restrict__ ready, int Fc)
 {
+    constexpr bool DIRECT = SRC == 1;
     constexpr int PR = 16;
     extern __shared__ double ft_lds[];
     const int N = 1 << m, np = N + (N >> 5) + 2;
@@ -1133,7 +1168,120 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
     for (int u = 0; u < 9; ++u) tacc[u] = 0.0;
     const int half = (F + 1) >> 1;  // packed points that hold data
     double va[JJ][QE], vb[JJ][QE];
+    // ---- SRC == 2: the cluster's staging ring ----
+    typedef double st2_t __attribute__((ext_vector_type(2)));
+    FftStage sg{};
+    if constexpr (SRC == 2) sg = stg[blockIdx.x];
+    const long long Fs = 16LL * Fc, nt = it.c_hi - it.c_lo;  // column stride of the ring; tiles of this cluster
+    st2_t sv = {0.0, 0.0};                                   // the unit in flight
+    // unit r of tile i (relative to c_lo): 64 rows x 128 bytes per round of the block. Wave w takes 16 of the rows
+    // (w >> 1) and half of every line (w & 1); lanes l, l + 16, l + 32, l + 48 sit side by side in one row (64 bytes),
+    // lanes l and l ^ 1 in consecutive rows: a load instruction touches 16 half lines (lane = row would touch 64 lines
+    // for the same bytes: the vector-memory path works per line), and after the lane-pair swap below a store
+    // instruction writes whole lines. What a lane needs per unit is kept to four registers beside the data (the kernel
+    // has none to spare: a spilled register's reload waits for whatever load is in flight): its pointer into the
+    // trajectory, its byte offset in the ring, and how many rounds it takes part in; the rest is scalar arithmetic.
+    const int st_rr = (wv >> 1) * 16 + (lane & 15), st_p = (wv & 1) * 4 + (lane >> 4);
+    // Nothing here branches: a lane that has no part in a unit (rows beyond the member's share or the series' end, tiles
+    // beyond the cluster's last, columns beyond the matrix) addresses the buffer beyond its end, where the hardware
+    // returns zeros and drops stores. Branch-free matters for more than the branch: the compiler counts vector-memory
+    // operations to place its waits, operations inside conditions count as "maybe not issued", and every wait behind
+    // one turns into "wait for everything" — the unit just requested included (measured: 0.6 ms of the call).
+    int st_lim = 0, st_lim2 = 0;  // unit r: this lane loads iff 64 r < st_lim, its pair stores iff 64 r < st_lim2
+    unsigned st_vi = 0u, st_vo = 0u;  // the lane's byte offsets: in its member's rows of the trajectory, in the ring
+    constexpr unsigned ST_OOB = 0xFFFFF000u;
+    typedef unsigned st4_t __attribute__((ext_vector_type(4)));
+    if constexpr (SRC == 2) {
+        const int row = sg.k * Fc + st_rr, row2 = row & ~1;
+        st_lim = Fc - st_rr < F - row ? Fc - st_rr : F - row;
+        st_lim2 = Fc - (st_rr & ~1) < F - row2 ? Fc - (st_rr & ~1) : F - row2;
+        st_vi = (unsigned)(((size_t)st_rr * (size_t)cols + 2 * st_p) * 8);
+        st_vo = (unsigned)(((size_t)(2 * st_p + (lane & 1)) * (size_t)Fs + (size_t)row2) * 8);
+    }
+    // the member's rows of the trajectory, [k Fc, (k + 1) Fc) x cols doubles (the host checks: below 4 GB), and the ring of
+    // this cluster, as buffer resources. The ring takes 16-byte device-scope (sc1) accesses — buffer_load / buffer_store
+    // dwordx4 with the sc1 bit (aux 16) —, which the 8-byte __hip_atomic forms cannot give (an 8-byte sc1 store is a
+    // fabric write of its own: the first version of this kernel, 8.8 ms per C4 call, was bound by 750 M of them).
+    // (SRC != 2: scratch is null and the resources are never used)
+    const long long st_rows = (long long)F - (long long)sg.k * Fc < Fc ? (long long)F - (long long)sg.k * Fc : (long long)Fc;
+    const __amdgpu_buffer_rsrc_t traj = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double *>(x) + (size_t)sg.k * (size_t)Fc * (size_t)cols, 0,
+        (int)(unsigned)((size_t)(st_rows > 0 ? st_rows : 0) * (size_t)cols * 8), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ring = __builtin_amdgcn_make_buffer_rsrc(
+        scratch + (size_t)sg.cluster * ST_BUF * 16 * (size_t)Fs, 0, (int)((size_t)ST_BUF * 16 * (size_t)Fs * 8), 0x00020000);
+    constexpr int SC1 = 16, NT_HINT = 2;
+    bool st_on = true;  // (ST_SKIP & 2: off inside the series loop)
+    auto stage_load = [&](long long i, int r, st2_t &sv) {
+        const long long T = it.c_lo + i;
+        // (cols is even and x 16-byte aligned — the host's condition for this kernel; only the matrix's last tile can reach
+        // beyond a row's end, where the next row's first columns must not be taken for this tile's)
+        const bool in = st_on && i < nt && 64 * r < st_lim && !(ST_SKIP & 32) &&
+                        (16 * T + 16 <= cols || 16 * T + 2 * st_p + 1 < cols);
+        const unsigned soff = (unsigned)(((size_t)(64 * r) * (size_t)cols + (size_t)(16 * T)) * 8);
+        sv = __builtin_bit_cast(st2_t, __builtin_amdgcn_raw_buffer_load_b128(traj, in ? st_vi : ST_OOB, in ? soff : 0u, NT_HINT));
+    };
+    // Two lanes hold rows t, t + 1 (t even) of a column pair (a, b): they swap one value, so that the even lane has
+    // (a[t], a[t + 1]) and the odd one (b[t], b[t + 1]) — 16 bytes of ONE column each, and a store instruction writes
+    // whole 128-byte lines (eight lanes per line)
+    auto stage_store = [&](long long i, int r, const st2_t &sv) {
+        const bool odd = lane & 1;
+        const double a = sv[0] * scale, b = sv[1] * scale;
+        const double send = odd ? a : b;
+        const int lo = __builtin_amdgcn_mov_dpp(__double2loint(send), 0xB1, 0xF, 0xF, true);  // quad_perm [1, 0, 3, 2]
+        const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(send), 0xB1, 0xF, 0xF, true);
+        const double recv = __hiloint2double(hi, lo);
+        const bool in = st_on && i < nt && 64 * r < st_lim2 && !(ST_SKIP & 16);
+        const st2_t out = odd ? st2_t{recv, b} : st2_t{a, recv};
+        const unsigned soff = (unsigned)(((size_t)(i & (ST_BUF - 1)) * 16 * (size_t)Fs + (size_t)(64 * r)) * 8);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(st4_t, out), ring, in ? st_vo : ST_OOB, in ? soff : 0u, SC1);
+    };
+    auto st_flag = [&](long long i) { return ready + ((size_t)sg.cluster * ST_BUF + (size_t)(i & (ST_BUF - 1))) * ST_FLAG_STRIDE; };
+    // (behind a block barrier that every wave entered after its own s_waitcnt vmcnt(0))
+    auto st_signal = [&](long long i) {
+        if (tid == 0 && i >= 0 && i < nt) __hip_atomic_fetch_add(st_flag(i), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    bool stalled = false;  // (wave-uniform) a poll gave up, here or in another block: no more waiting in this launch
+    auto st_wait = [&](long long i) {
+        const unsigned need = 16u * (unsigned)((i >> 3) + 1);
+        if (stalled || (ST_SKIP & 1)) return;
+        const unsigned *w = st_flag(i);
+        unsigned *stall = ready + (size_t)(gridDim.x / 16) * ST_BUF * ST_FLAG_STRIDE;
+        for (int spin = 1; __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need; ++spin) {
+            __builtin_amdgcn_s_sleep(8);
+            if ((spin & 255) == 0 && __hip_atomic_load(stall, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                stalled = true;
+                break;
+            }
+            if (spin > (1 << 19)) {  // ~1 s: a member is not running
+                __hip_atomic_store(stall, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                stalled = true;
+                break;
+            }
+        }
+    };
     auto fetch = [&](long long c) {
+        if constexpr (SRC == 2) {
+            // c = the tile; this member's column of it, from the ring (device-scope loads, after this wave's own poll)
+            const long long i = c - it.c_lo, col = 16 * c + sg.k;
+            const bool valid = col >= sg.lo && col < sg.hi;
+            st_wait(i);
+            const unsigned row = (unsigned)((((size_t)(i & (ST_BUF - 1))) * 16 + sg.k) * (size_t)Fs * 8);  // (scalar)
+#pragma unroll
+            for (int jj = 0; jj < JJ; ++jj) {
+#pragma unroll
+                for (int e = 0; e < QE; ++e) {
+                    const int j = tid + jj * FT_THREADS, n = j + (e << ls0);  // packed point: samples 2 n, 2 n + 1
+                    // (beyond the series, or a column outside the segment: zeros from beyond the buffer's end; row F of
+                    // the ring holds a zero where F is odd: the pair store wrote it)
+                    const bool in = valid && j < s0 && 2 * n < F;
+                    const st2_t v = __builtin_bit_cast(
+                        st2_t, __builtin_amdgcn_raw_buffer_load_b128(ring, in ? (unsigned)n * 16u : ST_OOB, in ? row : 0u, SC1));
+                    va[jj][e] = v[0];
+                    vb[jj][e] = v[1];
+                }
+            }
+            return;
+        }
         if constexpr (DIRECT) {
             const double *col = x + c;
 #pragma unroll
@@ -1181,12 +1329,33 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
         return sum;
     };
     double mean = 0.0;
+    if constexpr (SRC == 2) {
+        // the first ST_AHEAD tiles, before anything is transformed
+        for (int i = 0; i < ST_AHEAD; ++i)
+            for (int r = 0; r < ST_UNITS; ++r) {
+                stage_load(i, r, sv);
+                stage_store(i, r, sv);
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int i = 0; i < ST_AHEAD; ++i) st_signal(i);
+    }
     if (it.c_lo < it.c_hi) {  // (a cluster member whose column lies outside the segment has nothing to do)
         fetch(it.c_lo);
         mean = ft_block_sum(lane_sum(), red) / (double)F;
     }
-    const int cstep = it.step;
+    const int cstep = SRC == 2 ? 1 : it.step;
+    if (ST_SKIP & 2) st_on = false;
     for (long long c = it.c_lo; c < it.c_hi; c += cstep) {
+        // SRC == 2: tile st_i is staged under this series, ONE 16-byte unit in flight per lane (there are no registers for
+        // two: a spilled register's reload waits for whatever load is in flight, which cost this kernel 2 ms), loaded at
+        // one point of the iteration and stored at the next: A here, B behind the first pass, C and D in the middle of the
+        // two wave passes, E behind them; the fifth unit crosses the series boundary (E -> A)
+        const long long st_i = c - it.c_lo + ST_AHEAD;
+        if constexpr (SRC == 2) {
+            if (c > it.c_lo) stage_store(st_i - 1, 4, sv);
+            stage_load(st_i, 0, sv);
+        }
         // first pass, from the registers (the previous series' partner reads are behind the barrier that ended it)
 #pragma unroll
         for (int jj = 0; jj < JJ; ++jj) {
@@ -1216,7 +1385,9 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
             }
         }
         const bool more = F3_PREFETCH && c + cstep < it.c_hi;
+        if constexpr (SRC == 2) stage_store(st_i, 0, sv);
         if (more) fetch(c + cstep);
+        if constexpr (SRC == 2) stage_load(st_i, 1, sv);
         __syncthreads();
         // this wave's sub-transform: the remaining LDS passes, then the tail in registers
         {
@@ -1224,24 +1395,68 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
             // live in scratch memory, and a scratch load waits for the prefetch above like any other vector load
             const int org = wv * s0;
             const double2 *tw1 = twp + s0;
+            // SRC == 2: points C and D of the staging schedule sit in the middle of the wave passes where a lane has two
+            // butterflies per pass (N = 8192), which puts the five points 2100 - 4100 cycles apart
+            auto pc = [&]() {
+                if constexpr (SRC == 2) {
+                    stage_store(st_i, 1, sv);
+                    stage_load(st_i, 2, sv);
+                }
+            };
+            auto pd = [&]() {
+                if constexpr (SRC == 2) {
+                    // what this wave stored for the tile staged under the PREVIOUS series (its last unit at A) has long
+                    // been issued: waiting for everything in flight here is free (the youngest operation is a wave pass
+                    // old), and lets the second barrier below carry the signal for that tile
+                    if (!(ST_SKIP & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    stage_store(st_i, 2, sv);
+                    stage_load(st_i, 3, sv);
+                }
+            };
 #if F3_SKIP & 2
             if (F == 1) {
 #else
             if (JJ == 2 || m == 13) {
 #endif
-                f3_wave_pass<3, 7>(re, im, org, s0, tw1, lane);
-                f3_wave_pass<3, 4>(re, im, org, s0, tw1 + 128, lane);
+                if constexpr (SRC == 2) {
+                    // (two butterflies per lane and pass: the halves of a pass touch different points, no barrier between)
+                    // (the bound is opaque: with trip counts it can see, the compiler unrolls the halves into one
+                    // schedule with both butterflies' reads in flight — 120 spilled registers, as F3_PAIR found)
+                    int h64 = 64;
+                    asm volatile("" : "+s"(h64));
+                    f3_wave_pass<3, 7>(re, im, org, s0, tw1, lane, 0, h64);
+                    pc();
+                    f3_wave_pass<3, 7>(re, im, org, s0, tw1, lane, h64);
+                    f3_wave_pass<3, 4>(re, im, org, s0, tw1 + 128, lane, 0, h64);
+                    pd();
+                    f3_wave_pass<3, 4>(re, im, org, s0, tw1 + 128, lane, h64);
+                } else {
+                    f3_wave_pass<3, 7>(re, im, org, s0, tw1, lane);
+                    f3_wave_pass<3, 4>(re, im, org, s0, tw1 + 128, lane);
+                }
             } else if (m == 12) {
                 f3_wave_pass<2, 7>(re, im, org, s0, tw1, lane);
+                pc();
                 f3_wave_pass<3, 4>(re, im, org, s0, tw1 + 128, lane);
+                pd();
             } else if (m == 11) {
                 f3_wave_pass<2, 6>(re, im, org, s0, tw1, lane);
+                pc();
                 f3_wave_pass<2, 4>(re, im, org, s0, tw1 + 64, lane);
+                pd();
             } else if (m == 10) {
                 f3_wave_pass<3, 4>(re, im, org, s0, tw1, lane);
+                pc();
+                pd();
             } else {
                 f3_wave_pass<2, 4>(re, im, org, s0, tw1, lane);
+                pc();
+                pd();
             }
+        }
+        if constexpr (SRC == 2) {
+            stage_store(st_i, 3, sv);
+            stage_load(st_i, 4, sv);
         }
         Cx z[PR];
         if (owner) {
@@ -1285,6 +1500,9 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
             if (lane == 0) red[8 + wv] = v;
         }
         __syncthreads();
+        if constexpr (SRC == 2) {
+            if (c > it.c_lo && !(ST_SKIP & 4)) st_signal(st_i - 1);  // (the prologue signalled its own tiles)
+        }
 #if F3_SKIP & 8
         if (owner && F == 1) {
 #else
@@ -1490,7 +1708,8 @@ double finish_on_host(long long F, long long G, long long n_lags, const int64_t 
 
 // The fused LDS path: L = 2^(m+1) <= 16384.
 int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r, double scale, int max_lag,
-                      long long G, const int64_t *group_off, int m, const std::shared_ptr<LagFftResult> &res)
+                      long long G, const int64_t *group_off, int m, const std::shared_ptr<LagFftResult> &res,
+                      int src_want = -1 /* -1: the context's option lag_direct */)
 {
     mdhip_ctx *ctx = cs.ctx;
     const long long n_lags = (long long)max_lag + 1, cols = 3 * E, S = 3 * G;
@@ -1503,12 +1722,25 @@ int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r
     // round 4, option `lag_direct` (off by default: measured slower, see ctx.h): that kernel reads the trajectory as it
     // is, [F][3 E], no transposed copy (see msd_power_lds3_kernel). Needs the blocks in whole clusters of 16 per XCD:
     // 128 | cu_count.
+    // round 4, option `lag_direct` = 2 (default): no transposed copy either, the clusters of 16 blocks transpose their own
+    // tiles inside the kernel through a small ring (SRC == 2 of msd_power_lds3_kernel): any 16 blocks, rows per member
+    // Fc = F / 16 rounded up to whole 128-byte lines, at most 64 ST_UNITS.
     const int n_clusters = ctx->cu_count / 16;
-    const bool direct = v3 && ctx->opt_lag_direct != 0 && ctx->cu_count % 128 == 0 && cols >= 16 * (long long)n_clusters;
+#ifndef LAG_DIRECT_DEFAULT
+#define LAG_DIRECT_DEFAULT 0
+#endif
+    const int src_opt = src_want >= 0 ? src_want : ctx->opt_lag_direct >= 0 ? ctx->opt_lag_direct : LAG_DIRECT_DEFAULT;
+    const int Fc = (int)((((F + 15) / 16) + 15) / 16 * 16);
+    const bool staged = v3 && src_opt == 2 && ctx->cu_count % 16 == 0 && n_clusters >= 1 && Fc <= 64 * ST_UNITS &&
+                        cols >= 16 * (long long)n_clusters && (cols & 1LL) == 0 &&
+                        (unsigned long long)Fc * (unsigned long long)cols * 8ull < 0xFFFFF000ull &&  // (a member's rows: one buffer)
+                        (reinterpret_cast<unsigned long long>(d_r) & 15ull) == 0ull;  // (16-byte loads of column pairs)
+    const bool direct = staged || (v3 && src_opt == 1 && ctx->cu_count % 128 == 0 && cols >= 16 * (long long)n_clusters);
     // work items: every non-empty segment gets a share of ~one block per CU, each a contiguous series range — or, for
     // the direct-read kernel, whole clusters of 16 blocks that walk the segment's 16-column tiles (aligned to 16 columns
     // of the [F][cols] matrix = one 128-byte line per row), member k taking column 16 T + k
     std::vector<FftItem> items;
+    std::vector<FftStage> stages;
     std::vector<int> seg_off((size_t)S + 1, 0);
     if (!direct) {
         for (long long s = 0; s < S; ++s) {
@@ -1556,14 +1788,28 @@ int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r
         }
         if (!enough || given != n_clusters) {
             // more non-empty segments than clusters: this shape keeps the transposed path (re-enter without `direct`)
-            const int keep = ctx->opt_lag_direct;
-            ctx->opt_lag_direct = 0;
-            const int rc = lag_msd_fft_fused(cs, F, E, d_r, scale, max_lag, G, group_off, m, res);
-            ctx->opt_lag_direct = keep;
-            return rc;
+            return lag_msd_fft_fused(cs, F, E, d_r, scale, max_lag, G, group_off, m, res, 0);
         }
         // rows (= Qpart / Ppart rows, consecutive per segment): cluster q, member k -> row 16 q + k
         std::vector<FftItem> rows;
+        if (staged) {
+            // block 16 q + k = member k of cluster q (no placement assumption); c_lo / c_hi = the cluster's tiles
+            for (long long s = 0; s < S; ++s) {
+                seg_off[s] = (int)rows.size();
+                if (seg_c[s] == 0) continue;
+                const long long lo = seg_lo[s], hi = lo + seg_n[s];
+                const long long t0 = lo / 16, t1 = (hi + 15) / 16, nt = t1 - t0;
+                for (int q = 0; q < seg_c[s]; ++q) {
+                    const long long ta = t0 + nt * q / seg_c[s], tb = t0 + nt * (q + 1) / seg_c[s];
+                    for (int k = 0; k < 16; ++k) {
+                        stages.push_back({lo, hi, k, (int)(rows.size() / 16)});
+                        rows.push_back({ta, tb, 1, (int)rows.size()});
+                    }
+                }
+            }
+            seg_off[S] = (int)rows.size();
+            items = rows;
+        } else {
         for (long long s = 0; s < S; ++s) {
             seg_off[s] = (int)rows.size();
             if (seg_c[s] == 0) continue;
@@ -1590,6 +1836,7 @@ int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r
             (void)per_xcd;
             items[(size_t)b] = rows[(size_t)q * 16 + k];
         }
+        }
     }
     const long long n_items = (long long)items.size();
 
@@ -1604,30 +1851,44 @@ int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r
         tab[256 + 2 * i + 1] = (double)sinl(step * (i % L));
     }
 
-    double *d_x = nullptr;  // the transposed, scaled copy [cols][F] (not made for the direct-read kernel)
+    double *d_x = nullptr;  // the transposed, scaled copy [cols][F] (not made for the direct-read kernels)
     if (!direct) {
         d_x = (double *)mdhip_ws(ctx, WS_AUX1, (size_t)cols * F * 8 + 256);
         if (!d_x) return MDHIP_ENOMEM;
+    }
+    double *d_ring = nullptr;  // SRC == 2: the clusters' staging rings [cluster][ST_BUF][16][16 Fc]
+    if (staged) {
+        d_ring = (double *)mdhip_ws(ctx, WS_AUX1, (size_t)n_clusters * ST_BUF * 16 * 16 * (size_t)Fc * 8 + 256);
+        if (!d_ring) return MDHIP_ENOMEM;
     }
     const size_t qp_b = (size_t)n_items * F * 8, pp_b = (size_t)n_items * (N + 1) * 8;
     MD_WS(d_part, double, WS_PART, qp_b + pp_b);
     double *d_Qpart = d_part, *d_Ppart = d_part + (size_t)n_items * F;
     const size_t q_b = (size_t)S * F * 8, p_b = (size_t)S * (N + 1) * 8, c_b = (size_t)S * n_lags * 8;
-    const size_t it_b = (size_t)n_items * sizeof(FftItem), so_b = ((size_t)S + 1) * 4;
-    MD_WS(d_small, unsigned char, WS_AUX3, q_b + p_b + c_b + 4096 + it_b + so_b + 64);
+    const size_t it_b = (size_t)n_items * sizeof(FftItem), so_b = (((size_t)S + 1) * 4 + 7) / 8 * 8;
+    const size_t sg_b = stages.size() * sizeof(FftStage);
+    // ready counters of the rings, a 128-byte line each, and the stall word behind them
+    const size_t rd_b = staged ? ((size_t)n_clusters * ST_BUF * ST_FLAG_STRIDE + ST_FLAG_STRIDE) * 4 : 0;
+    MD_WS(d_small, unsigned char, WS_AUX3, q_b + p_b + c_b + 4096 + it_b + so_b + sg_b + rd_b + 256);
     double *d_Q = reinterpret_cast<double *>(d_small);
     double *d_P = reinterpret_cast<double *>(d_small + q_b);
     double *d_corr = reinterpret_cast<double *>(d_small + q_b + p_b);
     double2 *d_tab = reinterpret_cast<double2 *>(d_small + q_b + p_b + c_b);
     FftItem *d_items = reinterpret_cast<FftItem *>(d_small + q_b + p_b + c_b + 4096);
     int *d_seg_off = reinterpret_cast<int *>(d_small + q_b + p_b + c_b + 4096 + it_b);
+    FftStage *d_stages = reinterpret_cast<FftStage *>(d_small + q_b + p_b + c_b + 4096 + it_b + so_b);
+    // (on a 128-byte boundary: d_small is, and so is everything in front once rounded up)
+    const size_t rd_off = (q_b + p_b + c_b + 4096 + it_b + so_b + sg_b + 127) / 128 * 128;
+    unsigned *d_ready = reinterpret_cast<unsigned *>(d_small + rd_off);
     {
-        // twiddles | items | segment offsets: one pinned staging block (the vectors above are locals), one copy
-        MD_PIN(h_tab, unsigned char, 4096 + it_b + so_b);
+        // twiddles | items | segment offsets | stages: one pinned staging block (the vectors above are locals), one copy
+        MD_PIN(h_tab, unsigned char, 4096 + it_b + so_b + sg_b);
         memcpy(h_tab, tab.data(), 4096);
         memcpy(h_tab + 4096, items.data(), it_b);
-        memcpy(h_tab + 4096 + it_b, seg_off.data(), so_b);
-        MD_HIP(hipMemcpyAsync(d_tab, h_tab, 4096 + it_b + so_b, hipMemcpyHostToDevice, ctx->stream));
+        memcpy(h_tab + 4096 + it_b, seg_off.data(), ((size_t)S + 1) * 4);
+        if (sg_b) memcpy(h_tab + 4096 + it_b + so_b, stages.data(), sg_b);
+        MD_HIP(hipMemcpyAsync(d_tab, h_tab, 4096 + it_b + so_b + sg_b, hipMemcpyHostToDevice, ctx->stream));
+        if (staged) MD_HIP(hipMemsetAsync(d_ready, 0, rd_b, ctx->stream));
     }
 
     KernelTimer timer(ctx);
@@ -1641,19 +1902,19 @@ int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r
         const size_t lds3 = f3_lds_bytes(m);
         const long long s0 = N >> 3;
         const int qe = (int)(((F + 1) / 2 + s0 - 1) / s0);  // <= 8
+#define MD_F3_GO(JJ, QE, SRC, X, SC)                                                                           \
+    {                                                                                                          \
+        MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msd_power_lds3_kernel<JJ, QE, SRC>),         \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));                    \
+        hipLaunchKernelGGL((msd_power_lds3_kernel<JJ, QE, SRC>), dim3((unsigned)n_items), dim3(FT_THREADS), lds3, \
+                           ctx->stream, X, (int)F, m, d_items, d_tab, d_Qpart, d_Ppart, cols, SC, d_stages,    \
+                           d_ring, d_ready, Fc);                                                               \
+    }
 #define MD_F3_LAUNCH(JJ, QE)                                                                                   \
     {                                                                                                          \
-        if (direct) {                                                                                          \
-            MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msd_power_lds3_kernel<JJ, QE, true>),    \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));                \
-            hipLaunchKernelGGL((msd_power_lds3_kernel<JJ, QE, true>), dim3((unsigned)n_items), dim3(FT_THREADS), lds3, \
-                               ctx->stream, d_r, (int)F, m, d_items, d_tab, d_Qpart, d_Ppart, cols, scale);    \
-        } else {                                                                                               \
-            MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msd_power_lds3_kernel<JJ, QE, false>),   \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));                \
-            hipLaunchKernelGGL((msd_power_lds3_kernel<JJ, QE, false>), dim3((unsigned)n_items), dim3(FT_THREADS), lds3, \
-                               ctx->stream, d_x, (int)F, m, d_items, d_tab, d_Qpart, d_Ppart, cols, 1.0);      \
-        }                                                                                                      \
+        if (staged) MD_F3_GO(JJ, QE, 2, d_r, scale)                                                            \
+        else if (direct) MD_F3_GO(JJ, QE, 1, d_r, scale)                                                       \
+        else MD_F3_GO(JJ, QE, 0, d_x, 1.0)                                                                     \
     }
         if (s0 > FT_THREADS) {
             if (qe <= 3) MD_F3_LAUNCH(2, 3)
@@ -1665,6 +1926,7 @@ int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r
             else MD_F3_LAUNCH(1, 8)
         }
 #undef MD_F3_LAUNCH
+#undef MD_F3_GO
     } else if (v2) {
         const size_t lds2 = f2_lds_bytes(m);
         const int qr2 = (int)(((F + 1) / 2 + FT_THREADS - 1) / FT_THREADS);  // sample pairs per lane, <= N / 512
@@ -1719,10 +1981,23 @@ int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r
     // fetched separately, P stays); the long-hand finish runs on the host once they are there
     MD_PIN(h_Q, double, q_b);
     MD_PIN(h_corr, double, c_b);
+    MD_PIN(h_stall, unsigned, 4);
+    *h_stall = 0u;
     MD_HIP(hipMemcpyAsync(h_Q, d_Q, q_b, hipMemcpyDeviceToHost, ctx->stream));
     MD_HIP(hipMemcpyAsync(h_corr, d_corr, c_b, hipMemcpyDeviceToHost, ctx->stream));
-    cs.defer([timer, res, h_Q, h_corr, F, G, n_lags, L]() {
+    if (staged)
+        MD_HIP(hipMemcpyAsync(h_stall, d_ready + (size_t)n_clusters * ST_BUF * ST_FLAG_STRIDE, 4, hipMemcpyDeviceToHost,
+                              ctx->stream));
+    cs.defer([=]() {
         timer.collect();
+        if (*h_stall) {
+            // a cluster member never ran (the grid was not resident as a whole): the same call over the transposed copy,
+            // inside a synchronous call of its own (d_r is the caller's, or the call's staging: valid until completion)
+            CallScope again(ctx);
+            const int rc2 = lag_msd_fft_fused(again, F, E, d_r, scale, max_lag, G, res->group_off.data(), m, res, 0);
+            if (rc2 != MDHIP_OK) return rc2;
+            return again.end();
+        }
         res->bound = finish_on_host(F, G, n_lags, res->group_off.data(), h_Q, h_corr, n_lags, 1.0, L, res->out.data());
         return MDHIP_OK;
     });

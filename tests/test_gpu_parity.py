@@ -500,16 +500,19 @@ def test_lag_msd_fft_every_transform_size(B):
         ctx.set_option("lag_fft_kernel", 2)
 
 
-def test_lag_msd_direct_read_option(B):
+@pytest.mark.parametrize("mode", [1, 2])
+def test_lag_msd_direct_read_option(B, mode):
     """`lag_direct` 1: the power kernel reads [F][3][E] itself (clusters of 16 blocks on adjacent columns, no transposed
-    copy). Kept as an option (it measured slower); its results must sit within the reported bound of the
-    exact-difference kernel like the default's — groups that start and end off the 16-column tiles, a group smaller than
-    a tile, an empty group, more groups than clusters (falls back to the transposed path)."""
+    copy; kept as an option, it measured slower). `lag_direct` 2: the clusters transpose their tiles
+    inside the kernel through a ring in device memory, handed from block to block (device-scope stores, per-tile ready
+    counters). Either way the results must sit within the reported bound of the exact-difference kernel like the
+    transposed path's — groups that start and end off the 16-column tiles, a group smaller than a tile, an empty group,
+    more groups than clusters (falls back to the transposed path), entity counts off the tile width, odd column counts."""
     ctx = B.default_context()
     rng = np.random.default_rng(15)
     try:
         for F, E, goff in ((4500, 700, [0, 700]), (5000, 333, [0, 5, 5, 141, 333]), (4100, 64, [0, 1, 64]),
-                           (4200, 90, list(range(0, 91, 3)))):
+                           (4200, 90, list(range(0, 91, 3))), (5120, 171, [0, 100, 171]), (2100, 257, [0, 257])):
             r = np.cumsum(rng.normal(0, 0.1, (F, 3, E)), axis=0) + rng.uniform(-100, 100, (1, 3, E))
             ctx.set_option("lag_variant", 1)
             exact = B.lag_msd(r, F - 1, goff, scale=0.7)
@@ -517,16 +520,18 @@ def test_lag_msd_direct_read_option(B):
             ctx.set_option("lag_direct", 0)
             ref = B.lag_msd(r, F - 1, goff, scale=0.7)
             b0 = ctx.last_rel_bound()
-            ctx.set_option("lag_direct", 1)
+            ctx.set_option("lag_direct", mode)
             got = B.lag_msd(r, F - 1, goff, scale=0.7)
             b1 = ctx.last_rel_bound()
+            again = B.lag_msd(r, F - 1, goff, scale=0.7)
             nz = exact > 0
             assert (np.abs(got[nz] - exact[nz]) / exact[nz]).max() <= b1, (F, E)
             assert (np.abs(got[nz] - ref[nz]) / exact[nz]).max() <= b0 + b1, (F, E)
             assert (got[0] == 0.0).all()
+            assert np.array_equal(got, again), (F, E)  # (the hand-off between blocks leaves nothing to chance)
     finally:
         ctx.set_option("lag_variant", -1)
-        ctx.set_option("lag_direct", 0)
+        ctx.set_option("lag_direct", -1)
 
 
 # ------------------------------------------------------------------ G2-G4
