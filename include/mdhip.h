@@ -134,6 +134,9 @@ int mdhip_device_name(mdhip_ctx *ctx, char *buf, int buflen);
  *   "h2d_overlap"  host-resident frames: 1 (default) staged batch by batch under the sweeps, 0 copied first
  *   "rdf_guard", "cn_pk"  overflow guard / coordination counts through the packed sweep ("rdf_relblock": retired in
  *                  round 4, accepted and ignored — the f32 records are relative to their whole tile's centre)
+ *   "lag_direct"   fused full-lag MSD path: -1 default (= 2), 0 transposed copy made by a pass of its own, 1 the kernel reads
+ *                  the trajectory in place, 2 clusters of 16 workgroups transpose their tiles inside the kernel (results of
+ *                  the three agree within the reported bound)
  *   "sync_spin"    waiting for device work: 1 (default) poll the completion event (no interrupt wake-up latency; turns
  *                  into a blocking wait after 100 ms), 0 block at once */
 int mdhip_set_option(mdhip_ctx *ctx, const char *key, int value);

@@ -184,11 +184,13 @@ struct mdhip_ctx {
                                   // sub-transforms where the series is long enough (msd_power_lds3_kernel), else as 1;
                                   // 1 = conflict-free LDS layout, bilinear spectrum sums (msd_power_lds2_kernel);
                                   // 0 = the round-2 kernel (A/B; also what short series fall back to)
-    int opt_lag_direct = -1;      // fused full-lag MSD path (-1: the default, msd_fft.hip): 0 a transposed copy [3 E][F] is made first; 1 = the power
-                                  // kernel reads the trajectory [F][3][E] as it is, its blocks in XCD clusters of 16 that share
-                                  // every line they fetch (round 4: no transposed copy and a third of the HBM traffic, but
-                                  // 9.4 ms against 6.5 ms per C4 call: a lane's 8 bytes cost the vector-memory path a whole
-                                  // 128-byte line, 6144 of them per series and CU — DESIGN.md 4.4)
+    int opt_lag_direct = -1;      // fused full-lag MSD path, where the power kernel gets its time series from (-1: the default,
+                                  // LAG_DIRECT_DEFAULT in msd_fft.hip = 2): 0 = a transposed copy [3 E][F] made by a pass
+                                  // of its own (rounds 2-3: 2.2 of the call's 6.8 ms at C4, 6 GB of workspace); 1 = the
+                                  // trajectory [F][3][E] itself, blocks in XCD clusters of 16 that share every line they fetch
+                                  // (a third of the traffic, but 9.4 ms: a lane's 8 bytes cost the vector-memory path a whole
+                                  // line); 2 = clusters of 16 blocks transpose their tiles inside the kernel through a ring in
+                                  // device memory, handed from block to block (5.0 ms; shapes it does not take fall back to 0)
     double last_rel_bound = 0.0;  // error bound reported by the FFT MSD path of the last mdhip_lag_msd call (0: exact path)
 };
 

@@ -1173,7 +1173,7 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
     FftStage sg{};
     if constexpr (SRC == 2) sg = stg[blockIdx.x];
     const long long Fs = 16LL * Fc, nt = it.c_hi - it.c_lo;  // column stride of the ring; tiles of this cluster
-    st2_t sv = {0.0, 0.0};                                   // the unit in flight
+    st2_t sx = {0.0, 0.0}, sy = {0.0, 0.0};                  // the units in flight
     // unit r of tile i (relative to c_lo): 64 rows x 128 bytes per round of the block. Wave w takes 16 of the rows
     // (w >> 1) and half of every line (w & 1); lanes l, l + 16, l + 32, l + 48 sit side by side in one row (64 bytes),
     // lanes l and l ^ 1 in consecutive rows: a load instruction touches 16 half lines (lane = row would touch 64 lines
@@ -1183,7 +1183,9 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
     // trajectory, its byte offset in the ring, and how many rounds it takes part in; the rest is scalar arithmetic.
     const int st_rr = (wv >> 1) * 16 + (lane & 15), st_p = (wv & 1) * 4 + (lane >> 4);
     // Nothing here branches: a lane that has no part in a unit (rows beyond the member's share or the series' end, tiles
-    // beyond the cluster's last, columns beyond the matrix) addresses the buffer beyond its end, where the hardware
+    // beyond the cluster's last, columns beyond the matrix) addresses the buffer beyond its end — in the per-lane offset,
+    // which is what the hardware's range check looks at; the scalar offset stays the same for all lanes (a per-lane
+    // "scalar" operand makes the compiler wrap the instruction in a loop over its distinct values) —, where the hardware
     // returns zeros and drops stores. Branch-free matters for more than the branch: the compiler counts vector-memory
     // operations to place its waits, operations inside conditions count as "maybe not issued", and every wait behind
     // one turns into "wait for everything" — the unit just requested included (measured: 0.6 ms of the call).
@@ -1218,7 +1220,7 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
         const bool in = st_on && i < nt && 64 * r < st_lim && !(ST_SKIP & 32) &&
                         (16 * T + 16 <= cols || 16 * T + 2 * st_p + 1 < cols);
         const unsigned soff = (unsigned)(((size_t)(64 * r) * (size_t)cols + (size_t)(16 * T)) * 8);
-        sv = __builtin_bit_cast(st2_t, __builtin_amdgcn_raw_buffer_load_b128(traj, in ? st_vi : ST_OOB, in ? soff : 0u, NT_HINT));
+        sv = __builtin_bit_cast(st2_t, __builtin_amdgcn_raw_buffer_load_b128(traj, in ? st_vi : ST_OOB, soff, NT_HINT));
     };
     // Two lanes hold rows t, t + 1 (t even) of a column pair (a, b): they swap one value, so that the even lane has
     // (a[t], a[t + 1]) and the odd one (b[t], b[t + 1]) — 16 bytes of ONE column each, and a store instruction writes
@@ -1233,7 +1235,7 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
         const bool in = st_on && i < nt && 64 * r < st_lim2 && !(ST_SKIP & 16);
         const st2_t out = odd ? st2_t{recv, b} : st2_t{a, recv};
         const unsigned soff = (unsigned)(((size_t)(i & (ST_BUF - 1)) * 16 * (size_t)Fs + (size_t)(64 * r)) * 8);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(st4_t, out), ring, in ? st_vo : ST_OOB, in ? soff : 0u, SC1);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(st4_t, out), ring, in ? st_vo : ST_OOB, soff, SC1);
     };
     auto st_flag = [&](long long i) { return ready + ((size_t)sg.cluster * ST_BUF + (size_t)(i & (ST_BUF - 1))) * ST_FLAG_STRIDE; };
     // (behind a block barrier that every wave entered after its own s_waitcnt vmcnt(0))
@@ -1241,9 +1243,13 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
         if (tid == 0 && i >= 0 && i < nt) __hip_atomic_fetch_add(st_flag(i), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     bool stalled = false;  // (wave-uniform) a poll gave up, here or in another block: no more waiting in this launch
-    auto st_wait = [&](long long i) {
+    // (`seen` = an earlier look at the counter, requested a wave pass ago: the common case costs no round trip here)
+    auto st_peek = [&](long long i) {
+        return __hip_atomic_load(st_flag(i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto st_wait = [&](long long i, unsigned seen) {
         const unsigned need = 16u * (unsigned)((i >> 3) + 1);
-        if (stalled || (ST_SKIP & 1)) return;
+        if (stalled || seen >= need || (ST_SKIP & 1)) return;
         const unsigned *w = st_flag(i);
         unsigned *stall = ready + (size_t)(gridDim.x / 16) * ST_BUF * ST_FLAG_STRIDE;
         for (int spin = 1; __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need; ++spin) {
@@ -1259,12 +1265,12 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
             }
         }
     };
-    auto fetch = [&](long long c) {
+    auto fetch = [&](long long c, unsigned seen = 0u) {
         if constexpr (SRC == 2) {
             // c = the tile; this member's column of it, from the ring (device-scope loads, after this wave's own poll)
             const long long i = c - it.c_lo, col = 16 * c + sg.k;
             const bool valid = col >= sg.lo && col < sg.hi;
-            st_wait(i);
+            st_wait(i, seen);
             const unsigned row = (unsigned)((((size_t)(i & (ST_BUF - 1))) * 16 + sg.k) * (size_t)Fs * 8);  // (scalar)
 #pragma unroll
             for (int jj = 0; jj < JJ; ++jj) {
@@ -1275,7 +1281,7 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
                     // the ring holds a zero where F is odd: the pair store wrote it)
                     const bool in = valid && j < s0 && 2 * n < F;
                     const st2_t v = __builtin_bit_cast(
-                        st2_t, __builtin_amdgcn_raw_buffer_load_b128(ring, in ? (unsigned)n * 16u : ST_OOB, in ? row : 0u, SC1));
+                        st2_t, __builtin_amdgcn_raw_buffer_load_b128(ring, in ? (unsigned)n * 16u : ST_OOB, row, SC1));
                     va[jj][e] = v[0];
                     vb[jj][e] = v[1];
                 }
@@ -1333,8 +1339,8 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
         // the first ST_AHEAD tiles, before anything is transformed
         for (int i = 0; i < ST_AHEAD; ++i)
             for (int r = 0; r < ST_UNITS; ++r) {
-                stage_load(i, r, sv);
-                stage_store(i, r, sv);
+                stage_load(i, r, sx);
+                stage_store(i, r, sx);
             }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -1347,14 +1353,17 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
     const int cstep = SRC == 2 ? 1 : it.step;
     if (ST_SKIP & 2) st_on = false;
     for (long long c = it.c_lo; c < it.c_hi; c += cstep) {
-        // SRC == 2: tile st_i is staged under this series, ONE 16-byte unit in flight per lane (there are no registers for
-        // two: a spilled register's reload waits for whatever load is in flight, which cost this kernel 2 ms), loaded at
-        // one point of the iteration and stored at the next: A here, B behind the first pass, C and D in the middle of the
-        // two wave passes, E behind them; the fifth unit crosses the series boundary (E -> A)
+        // SRC == 2: tile st_i is staged under this series, five 16-byte units per lane, each stored TWO points of the
+        // iteration after it was requested (4100 - 6500 cycles: a load from HBM takes ~2500 here, and with one point
+        // between request and use the kernel stalled at every one of them): requests at A (here), B (behind the first
+        // pass), C (middle of the first wave pass), C2 (between the wave passes), D (middle of the second); stores at
+        // C, C2, D, E (behind the wave passes) and A. Two units in flight from B to E, one elsewhere — the registers for
+        // the second come from the next series' samples, which this variant requests at E, behind the wave passes,
+        // instead of at B (their block sum then rides on the THIRD barrier).
         const long long st_i = c - it.c_lo + ST_AHEAD;
         if constexpr (SRC == 2) {
-            if (c > it.c_lo) stage_store(st_i - 1, 4, sv);
-            stage_load(st_i, 0, sv);
+            if (c > it.c_lo) stage_store(st_i - 1, 4, sx);
+            stage_load(st_i, 0, sx);
         }
         // first pass, from the registers (the previous series' partner reads are behind the barrier that ended it)
 #pragma unroll
@@ -1384,10 +1393,9 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
                 }
             }
         }
-        const bool more = F3_PREFETCH && c + cstep < it.c_hi;
-        if constexpr (SRC == 2) stage_store(st_i, 0, sv);
-        if (more) fetch(c + cstep);
-        if constexpr (SRC == 2) stage_load(st_i, 1, sv);
+        const bool more = (F3_PREFETCH || SRC == 2) && c + cstep < it.c_hi;
+        if constexpr (SRC == 2) stage_load(st_i, 1, sy);
+        else if (more) fetch(c + cstep);
         __syncthreads();
         // this wave's sub-transform: the remaining LDS passes, then the tail in registers
         {
@@ -1395,22 +1403,28 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
             // live in scratch memory, and a scratch load waits for the prefetch above like any other vector load
             const int org = wv * s0;
             const double2 *tw1 = twp + s0;
-            // SRC == 2: points C and D of the staging schedule sit in the middle of the wave passes where a lane has two
-            // butterflies per pass (N = 8192), which puts the five points 2100 - 4100 cycles apart
+            unsigned seen = 0u;
             auto pc = [&]() {
                 if constexpr (SRC == 2) {
-                    stage_store(st_i, 1, sv);
-                    stage_load(st_i, 2, sv);
+                    // what this wave stored for the tile staged under the PREVIOUS series (its last unit at A) has long
+                    // been issued: waiting for everything in flight here is free (the youngest request is a phase old),
+                    // and lets the second barrier below carry the signal for that tile
+                    if (!(ST_SKIP & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    stage_store(st_i, 0, sx);
+                    stage_load(st_i, 2, sx);
+                }
+            };
+            auto pc2 = [&]() {
+                if constexpr (SRC == 2) {
+                    if (more) seen = st_peek(c + cstep - it.c_lo);
+                    stage_store(st_i, 1, sy);
+                    stage_load(st_i, 3, sy);
                 }
             };
             auto pd = [&]() {
                 if constexpr (SRC == 2) {
-                    // what this wave stored for the tile staged under the PREVIOUS series (its last unit at A) has long
-                    // been issued: waiting for everything in flight here is free (the youngest operation is a wave pass
-                    // old), and lets the second barrier below carry the signal for that tile
-                    if (!(ST_SKIP & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    stage_store(st_i, 2, sv);
-                    stage_load(st_i, 3, sv);
+                    stage_store(st_i, 2, sx);
+                    stage_load(st_i, 4, sx);
                 }
             };
 #if F3_SKIP & 2
@@ -1427,6 +1441,7 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
                     f3_wave_pass<3, 7>(re, im, org, s0, tw1, lane, 0, h64);
                     pc();
                     f3_wave_pass<3, 7>(re, im, org, s0, tw1, lane, h64);
+                    pc2();
                     f3_wave_pass<3, 4>(re, im, org, s0, tw1 + 128, lane, 0, h64);
                     pd();
                     f3_wave_pass<3, 4>(re, im, org, s0, tw1 + 128, lane, h64);
@@ -1437,26 +1452,30 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
             } else if (m == 12) {
                 f3_wave_pass<2, 7>(re, im, org, s0, tw1, lane);
                 pc();
+                pc2();
                 f3_wave_pass<3, 4>(re, im, org, s0, tw1 + 128, lane);
                 pd();
             } else if (m == 11) {
                 f3_wave_pass<2, 6>(re, im, org, s0, tw1, lane);
                 pc();
+                pc2();
                 f3_wave_pass<2, 4>(re, im, org, s0, tw1 + 64, lane);
                 pd();
             } else if (m == 10) {
                 f3_wave_pass<3, 4>(re, im, org, s0, tw1, lane);
                 pc();
+                pc2();
                 pd();
             } else {
                 f3_wave_pass<2, 4>(re, im, org, s0, tw1, lane);
                 pc();
+                pc2();
                 pd();
             }
-        }
-        if constexpr (SRC == 2) {
-            stage_store(st_i, 3, sv);
-            stage_load(st_i, 4, sv);
+            if constexpr (SRC == 2) {
+                stage_store(st_i, 3, sy);
+                if (more) fetch(c + cstep, seen);
+            }
         }
         Cx z[PR];
         if (owner) {
@@ -1494,7 +1513,7 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
             tacc[8] = __builtin_fma(z[9].x, z[f2_tail_neg(9)].y, tacc[8]);
             tacc[8] = __builtin_fma(z[9].y, z[f2_tail_neg(9)].x, tacc[8]);
         }
-        if (more) {  // the next series' block sum rides on the barrier below
+        if (more && SRC != 2) {  // the next series' block sum rides on the barrier below
             double v = lane_sum();
             for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
             if (lane == 0) red[8 + wv] = v;
@@ -1523,14 +1542,27 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
                 tacc[u] = __builtin_fma(z[u].y, pz[u].x, tacc[u]);
             }
         }
-        if (more) {
+        if (more && SRC != 2) {
             double sum = 0.0;
 #pragma unroll
             for (int w = 0; w < FT_THREADS / 64; ++w) sum += red[8 + w];
             mean = sum / (double)F;
         }
+        if (more && SRC == 2) {  // (requested behind the wave passes: its block sum rides on this last barrier)
+            double v = lane_sum();
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+            if (lane == 0) red[8 + wv] = v;
+        }
         __syncthreads();
-        if (!F3_PREFETCH && c + cstep < it.c_hi) {
+        if (more && SRC == 2) {
+            // (nobody writes red[8 ...] again before the first barrier of the next series, which this wave joins
+            // after these reads)
+            double sum = 0.0;
+#pragma unroll
+            for (int w = 0; w < FT_THREADS / 64; ++w) sum += red[8 + w];
+            mean = sum / (double)F;
+        }
+        if (!F3_PREFETCH && SRC != 2 && c + cstep < it.c_hi) {
             fetch(c + cstep);
             mean = ft_block_sum(lane_sum(), red) / (double)F;
         }
@@ -1727,7 +1759,7 @@ int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r
     // Fc = F / 16 rounded up to whole 128-byte lines, at most 64 ST_UNITS.
     const int n_clusters = ctx->cu_count / 16;
 #ifndef LAG_DIRECT_DEFAULT
-#define LAG_DIRECT_DEFAULT 0
+#define LAG_DIRECT_DEFAULT 2
 #endif
     const int src_opt = src_want >= 0 ? src_want : ctx->opt_lag_direct >= 0 ? ctx->opt_lag_direct : LAG_DIRECT_DEFAULT;
     const int Fc = (int)((((F + 15) / 16) + 15) / 16 * 16);
