@@ -1116,9 +1116,13 @@ template <int JJ, int QE, int SRC>
 __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
     const double *__restrict__ x, int F, int m, const FftItem *__restrict__ items,
     const double2 *__restrict__ tab, double *__restrict__ Qpart, double *__restrict__ Ppart, long long cols, double scale,
-    const FftStage *__restrict__ stg, double *__restrict__ scratch, unsigned *__restrict__ ready, int Fc)
+    const FftStage *__restrict__ stg, double *__restrict__ scratch, unsigned *__restrict__ ready, int Fc_arg)
 {
     constexpr bool DIRECT = SRC == 1;
+    // (a negative Fc is the test suite's request that ONE member withholds its signals: the polls then run out and
+    // the host's repeat over the transposed copy is exercised — option lag_direct 3)
+    const int Fc = Fc_arg < 0 ? -Fc_arg : Fc_arg;
+    const bool withhold = Fc_arg < 0 && blockIdx.x == 0;
     constexpr int PR = 16;
     extern __shared__ double ft_lds[];
     const int N = 1 << m, np = N + (N >> 5) + 2;
@@ -1240,7 +1244,8 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
     auto st_flag = [&](long long i) { return ready + ((size_t)sg.cluster * ST_BUF + (size_t)(i & (ST_BUF - 1))) * ST_FLAG_STRIDE; };
     // (behind a block barrier that every wave entered after its own s_waitcnt vmcnt(0))
     auto st_signal = [&](long long i) {
-        if (tid == 0 && i >= 0 && i < nt) __hip_atomic_fetch_add(st_flag(i), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0 && i >= 0 && i < nt && !(withhold && i >= ST_AHEAD))
+            __hip_atomic_fetch_add(st_flag(i), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     bool stalled = false;  // (wave-uniform) a poll gave up, here or in another block: no more waiting in this launch
     // (`seen` = an earlier look at the counter, requested a wave pass ago: the common case costs no round trip here)
@@ -1763,7 +1768,7 @@ int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r
 #endif
     const int src_opt = src_want >= 0 ? src_want : ctx->opt_lag_direct >= 0 ? ctx->opt_lag_direct : LAG_DIRECT_DEFAULT;
     const int Fc = (int)((((F + 15) / 16) + 15) / 16 * 16);
-    const bool staged = v3 && src_opt == 2 && ctx->cu_count % 16 == 0 && n_clusters >= 1 && Fc <= 64 * ST_UNITS &&
+    const bool staged = v3 && (src_opt == 2 || src_opt == 3) && ctx->cu_count % 16 == 0 && n_clusters >= 1 && Fc <= 64 * ST_UNITS &&
                         cols >= 16 * (long long)n_clusters && (cols & 1LL) == 0 &&
                         (unsigned long long)Fc * (unsigned long long)cols * 8ull < 0xFFFFF000ull &&  // (a member's rows: one buffer)
                         (reinterpret_cast<unsigned long long>(d_r) & 15ull) == 0ull;  // (16-byte loads of column pairs)
@@ -1940,7 +1945,7 @@ int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));                    \
         hipLaunchKernelGGL((msd_power_lds3_kernel<JJ, QE, SRC>), dim3((unsigned)n_items), dim3(FT_THREADS), lds3, \
                            ctx->stream, X, (int)F, m, d_items, d_tab, d_Qpart, d_Ppart, cols, SC, d_stages,    \
-                           d_ring, d_ready, Fc);                                                               \
+                           d_ring, d_ready, src_opt == 3 ? -Fc : Fc);                                          \
     }
 #define MD_F3_LAUNCH(JJ, QE)                                                                                   \
     {                                                                                                          \

@@ -534,6 +534,28 @@ def test_lag_msd_direct_read_option(B, mode):
         ctx.set_option("lag_direct", -1)
 
 
+def test_lag_msd_cluster_stall_falls_back(B):
+    """`lag_direct` 3 = the in-kernel transposition with ONE cluster member withholding its signals (what a grid that is
+    not resident as a whole looks like to the others): the polls run out (~1 s), the kernel raises its stall word and
+    runs to its end, and the host repeats the call over the transposed copy — same numbers as `lag_direct` 0."""
+    ctx = B.default_context()
+    rng = np.random.default_rng(16)
+    F, E = 4300, 900
+    r = np.cumsum(rng.normal(0, 0.1, (F, 3, E)), axis=0)
+    try:
+        ctx.set_option("lag_variant", 2)
+        ctx.set_option("lag_direct", 0)
+        ref = B.lag_msd(r, F - 1, [0, 400, E], scale=1.0)
+        ctx.set_option("lag_direct", 3)
+        got = B.lag_msd(r, F - 1, [0, 400, E], scale=1.0)
+        assert np.array_equal(got, ref)
+        pend = B.lag_msd(r, F - 1, [0, 400, E], scale=1.0, async_=True)  # (the repeat runs inside the completion step)
+        assert np.array_equal(pend.wait(), ref)
+    finally:
+        ctx.set_option("lag_variant", -1)
+        ctx.set_option("lag_direct", -1)
+
+
 # ------------------------------------------------------------------ G2-G4
 def test_xcorr_golden(B, g_acf):
     g = g_acf
