@@ -2033,7 +2033,9 @@ int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r
             CallScope again(ctx);
             const int rc2 = lag_msd_fft_fused(again, F, E, d_r, scale, max_lag, G, res->group_off.data(), m, res, 0);
             if (rc2 != MDHIP_OK) return rc2;
-            return again.end();
+            const int rc3 = again.end();
+            ctx->last_kernel = "msd_power_lds_kernel (repeated over the transposed copy: a cluster member did not run)";
+            return rc3;
         }
         res->bound = finish_on_host(F, G, n_lags, res->group_off.data(), h_Q, h_corr, n_lags, 1.0, L, res->out.data());
         return MDHIP_OK;

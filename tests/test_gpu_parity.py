@@ -549,6 +549,7 @@ def test_lag_msd_cluster_stall_falls_back(B):
         ctx.set_option("lag_direct", 3)
         got = B.lag_msd(r, F - 1, [0, 400, E], scale=1.0)
         assert np.array_equal(got, ref)
+        assert "repeated over the transposed copy" in ctx.last_kernel_name()
         pend = B.lag_msd(r, F - 1, [0, 400, E], scale=1.0, async_=True)  # (the repeat runs inside the completion step)
         assert np.array_equal(pend.wait(), ref)
     finally:
