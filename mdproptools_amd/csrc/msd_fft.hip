@@ -1196,6 +1196,7 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
     int st_lim = 0, st_lim2 = 0;  // unit r: this lane loads iff 64 r < st_lim, its pair stores iff 64 r < st_lim2
     unsigned st_vi = 0u, st_vo = 0u;  // the lane's byte offsets: in its member's rows of the trajectory, in the ring
     constexpr unsigned ST_OOB = 0xFFFFF000u;
+    const bool odd_cols = (cols & 1LL) != 0;  // (uniform: one of two forms of the staging load for the whole launch)
     typedef unsigned st4_t __attribute__((ext_vector_type(4)));
     if constexpr (SRC == 2) {
         const int row = sg.k * Fc + st_rr, row2 = row & ~1;
@@ -1217,14 +1218,26 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
         scratch + (size_t)sg.cluster * ST_BUF * 16 * (size_t)Fs, 0, (int)((size_t)ST_BUF * 16 * (size_t)Fs * 8), 0x00020000);
     constexpr int SC1 = 16, NT_HINT = 2;
     bool st_on = true;  // (ST_SKIP & 2: off inside the series loop)
+#ifndef ST_LOAD8
+#define ST_LOAD8 0
+#endif
     auto stage_load = [&](long long i, int r, st2_t &sv) {
         const long long T = it.c_lo + i;
-        // (cols is even and x 16-byte aligned — the host's condition for this kernel; only the matrix's last tile can reach
-        // beyond a row's end, where the next row's first columns must not be taken for this tile's)
-        const bool in = st_on && i < nt && 64 * r < st_lim && !(ST_SKIP & 32) &&
-                        (16 * T + 16 <= cols || 16 * T + 2 * st_p + 1 < cols);
+        const bool row_in = st_on && i < nt && 64 * r < st_lim && !(ST_SKIP & 32);
         const unsigned soff = (unsigned)(((size_t)(64 * r) * (size_t)cols + (size_t)(16 * T)) * 8);
-        sv = __builtin_bit_cast(st2_t, __builtin_amdgcn_raw_buffer_load_b128(traj, in ? st_vi : ST_OOB, soff, NT_HINT));
+        if (ST_LOAD8 || odd_cols) {
+            // an odd number of columns: rows start on odd multiples of 8 bytes and the matrix's last column has no
+            // partner — two 8-byte loads, each with its own range test (only the matrix's last tile can reach beyond a
+            // row's end, where the next row's first columns must not be taken for this tile's)
+            typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+            const bool in0 = row_in && 16 * T + 2 * st_p < cols, in1 = row_in && 16 * T + 2 * st_p + 1 < cols;
+            const u2_t a = __builtin_amdgcn_raw_buffer_load_b64(traj, in0 ? st_vi : ST_OOB, soff, NT_HINT);
+            const u2_t b = __builtin_amdgcn_raw_buffer_load_b64(traj, in1 ? st_vi + 8u : ST_OOB, soff, NT_HINT);
+            sv = st2_t{__builtin_bit_cast(double, a), __builtin_bit_cast(double, b)};
+        } else {
+            const bool in = row_in && (16 * T + 16 <= cols || 16 * T + 2 * st_p + 1 < cols);
+            sv = __builtin_bit_cast(st2_t, __builtin_amdgcn_raw_buffer_load_b128(traj, in ? st_vi : ST_OOB, soff, NT_HINT));
+        }
     };
     // Two lanes hold rows t, t + 1 (t even) of a column pair (a, b): they swap one value, so that the even lane has
     // (a[t], a[t + 1]) and the odd one (b[t], b[t + 1]) — 16 bytes of ONE column each, and a store instruction writes
@@ -1769,9 +1782,10 @@ int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r
     const int src_opt = src_want >= 0 ? src_want : ctx->opt_lag_direct >= 0 ? ctx->opt_lag_direct : LAG_DIRECT_DEFAULT;
     const int Fc = (int)((((F + 15) / 16) + 15) / 16 * 16);
     const bool staged = v3 && (src_opt == 2 || src_opt == 3) && ctx->cu_count % 16 == 0 && n_clusters >= 1 && Fc <= 64 * ST_UNITS &&
-                        cols >= 16 * (long long)n_clusters && (cols & 1LL) == 0 &&
+                        cols >= 16 * (long long)n_clusters &&
                         (unsigned long long)Fc * (unsigned long long)cols * 8ull < 0xFFFFF000ull &&  // (a member's rows: one buffer)
-                        (reinterpret_cast<unsigned long long>(d_r) & 15ull) == 0ull;  // (16-byte loads of column pairs)
+                        (reinterpret_cast<unsigned long long>(d_r) & 15ull) == 0ull;  // (16-byte loads of column pairs
+                                                                                     // where the column count is even)
     const bool direct = staged || (v3 && src_opt == 1 && ctx->cu_count % 128 == 0 && cols >= 16 * (long long)n_clusters);
     // work items: every non-empty segment gets a share of ~one block per CU, each a contiguous series range — or, for
     // the direct-read kernel, whole clusters of 16 blocks that walk the segment's 16-column tiles (aligned to 16 columns
