@@ -191,7 +191,8 @@ def lds_roofline_lag_fft(E, F, kernel_s):
     """
     Roofline of the default full-lag MSD path (csrc/msd_fft.hip): every series is transformed inside LDS and only sums
     leave the CU, so the call is bound by the LDS, not by HBM (compulsory 24 E F bytes = 5 % of the HBM rate) and not by
-    FP64 issue. achieved = ALGORITHMIC bytes through LDS per call / kernel time of the WHOLE call (transpose included):
+    FP64 issue. achieved = ALGORITHMIC bytes through LDS per call / kernel time of the WHOLE call (round 4: the power
+    kernel transposes its tiles itself — the staging of the trajectory into time-major rings rides inside that time):
     per series of padded length L (N = L/2 packed complex points of 16 bytes) the sweeps _lag_fft_lds_sweeps counts,
     twiddle tables not counted. peak = the guide's ds_read_b64 aggregate, 150 TB/s; stores run at 38-51 TB/s, so the
     mix's own ceiling (`mix_ceiling`: bytes / (reads / 150 + writes / 45 TB/s)) is what the kernel can approach, and
