@@ -842,7 +842,9 @@ __device__ __forceinline__ int sj_item_pk(const PairArgs &a, FastCtx &c, const u
         const float gy = __builtin_fmaxf(__builtin_fabsf(__builtin_fmaf(-__builtin_rintf(dy * fiLy), fLy, dy)) - sy, 0.f);
         const float gz = __builtin_fmaxf(__builtin_fabsf(__builtin_fmaf(-__builtin_rintf(dz * fiLz), fLz, dz)) - sz, 0.f);
         const float g2 = gx * gx + gy * gy + gz * gz;
-        const unsigned long long km = __builtin_amdgcn_ballot_w64(g2 < reach2);  // (a box without atoms: g2 ~ 1e36)
+        unsigned long long km = __builtin_amdgcn_ballot_w64(g2 < reach2);  // (a box without atoms: g2 ~ 1e36)
+        // the diagonal tile counts i < j: the groups below this wave's first atom hold no such pair
+        if (a.tri && J == I_u) km &= ~0ull << (wq * (64 / SJ_GROUP));
         if (!km) continue;
         // CNG: groups whose box comes within the largest split bin of the wave's box are swept with the flag check
         const unsigned long long nm = CNG ? __builtin_amdgcn_ballot_w64(g2 < cn_reach2) : 0ull;
@@ -935,7 +937,7 @@ __device__ __forceinline__ int sj_item_pk(const PairArgs &a, FastCtx &c, const u
         asm("s_bitset0_b64 %0, %1" : "+s"(mk) : "s"(G));                                                                \
     }
 #define PK_REC(G) (const float *)((const char *)rtile + ((unsigned)(G) << 6))
-#define PK_PIPELINED(MASK, CN, VAR)                                                                                     \
+#define PK_PIPELINED(MASK, CN, VAR, DG)                                                                                 \
     {                                                                                                                   \
         unsigned long long mk = (MASK);                                                                                 \
         if (mk) {                                                                                                       \
@@ -946,32 +948,36 @@ __device__ __forceinline__ int sj_item_pk(const PairArgs &a, FastCtx &c, const u
                 PK_DRAIN_CHECK();                                                                                       \
                 const bool moreB = mk != 0;                                                                             \
                 PK_NEXT(gB)                                                                                             \
-                sweep_group_pk<false, VAR, true, CUTG, ROWS, CN>(qA, GroupIdx{jbase, gA}, gA * SJ_GROUP, p, c,          \
+                sweep_group_pk<DG, VAR, true, CUTG, ROWS, CN>(qA, GroupIdx{jbase, gA}, gA * SJ_GROUP, p, c,             \
                                                                  lane_in_tile, lane, PK_REC(gB), qB);                   \
                 if (!moreB) break;                                                                                      \
                 PK_DRAIN_CHECK();                                                                                       \
                 const bool moreA = mk != 0;                                                                             \
                 PK_NEXT(gA)                                                                                             \
-                sweep_group_pk<false, VAR, true, CUTG, ROWS, CN>(qB, GroupIdx{jbase, gB}, gB * SJ_GROUP, p, c,          \
+                sweep_group_pk<DG, VAR, true, CUTG, ROWS, CN>(qB, GroupIdx{jbase, gB}, gB * SJ_GROUP, p, c,             \
                                                                  lane_in_tile, lane, PK_REC(gA), qA);                   \
                 if (!moreA) break;                                                                                      \
             }                                                                                                           \
         }                                                                                                               \
     }
-            if (!diag) {
-                PK_PIPELINED(km & ~wrapm & ~nm, false, 0)
-                if constexpr (CNG) PK_PIPELINED(km & ~wrapm & nm, true, 0)
+            if (diag) {
+                // the diagonal tile (i < j inside the tile): its plain groups through the same pipeline (round 4; they
+                // were swept one by one with their record loads exposed)
+                PK_PIPELINED(km & ~wrapm & ~nm, false, 0, true)
+            } else {
+                PK_PIPELINED(km & ~wrapm & ~nm, false, 0, false)
+                if constexpr (CNG) PK_PIPELINED(km & ~wrapm & nm, true, 0, false)
                 // the groups that take the per-pair wrap on some axis run the same software pipeline, variant by variant
                 // (round 3: their records were loaded and waited for group by group before — at C2, where a third of the
                 // swept groups wrap on some axis, 3.04 -> 2.82 ms build against build; C3, which has none, -0.9 %)
                 if (km & wrapm & ~nm) {
-                    PK_PIPELINED(variant(1u) & ~nm, false, 1)
-                    PK_PIPELINED(variant(2u) & ~nm, false, 2)
-                    PK_PIPELINED(variant(4u) & ~nm, false, 4)
-                    PK_PIPELINED(variant(3u) & ~nm, false, 3)
-                    PK_PIPELINED(variant(5u) & ~nm, false, 5)
-                    PK_PIPELINED(variant(6u) & ~nm, false, 6)
-                    PK_PIPELINED(variant(7u) & ~nm, false, 7)
+                    PK_PIPELINED(variant(1u) & ~nm, false, 1, false)
+                    PK_PIPELINED(variant(2u) & ~nm, false, 2, false)
+                    PK_PIPELINED(variant(4u) & ~nm, false, 4, false)
+                    PK_PIPELINED(variant(3u) & ~nm, false, 3, false)
+                    PK_PIPELINED(variant(5u) & ~nm, false, 5, false)
+                    PK_PIPELINED(variant(6u) & ~nm, false, 6, false)
+                    PK_PIPELINED(variant(7u) & ~nm, false, 7, false)
                 }
             }
 #undef PK_PIPELINED
@@ -994,7 +1000,7 @@ __device__ __forceinline__ int sj_item_pk(const PairArgs &a, FastCtx &c, const u
             // (the diagonal tile, i < j inside the tile: 9 = plain where every axis qualifies, 8 = the wrap on all axes)
             if (!diag && !(CNG && (km & wrapm & nm))) continue;
             for (unsigned A = diag ? 8u : 1u; A <= (diag ? 9u : 7u); ++A) {
-                unsigned long long mk = diag ? (A == 9u ? km & ~wrapm : km & wrapm) : variant(A) & nm;
+                unsigned long long mk = diag ? (A == 9u ? km & ~wrapm & nm : km & wrapm) : variant(A) & nm;
                 while (mk) {
                     const int g = __builtin_amdgcn_readfirstlane(__builtin_ctzll(mk));
                     mk &= mk - 1;
