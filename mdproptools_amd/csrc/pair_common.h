@@ -174,7 +174,7 @@ constexpr int MORTON_BITS = 5;                       // 32 cells per axis
 constexpr int MORTON_CELLS = 1 << (3 * MORTON_BITS); // 32768
 int cull_prepare_set(mdhip_ctx *ctx, int64_t F, const double *d_x, const int *d_t, long long t_fs,
                      const double *d_box, long long N, int nT, int n_ti, float near, int row_len, bool want_soa,
-                     int rel_block /* 0 = no f32 records, else atoms per centre block: 64 or 256 */,
+                     int want_rel /* != 0: the tile-relative f32 records of the packed sweep and their tiles' centres */,
                      int rel_w_type /* w of the f32 records: 0 bin-guess addend, 1 row-table offset */,
                      int cbox /* 1: 4-atom and 64-atom boxes as (centre, half extents): packed-f32 sweep */,
                      const int slot[5], SortedSet &out);

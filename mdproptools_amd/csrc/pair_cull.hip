@@ -275,7 +275,7 @@ __global__ __launch_bounds__(TILE) void cull_boxes_kernel(const double4 *__restr
                                                           double *__restrict__ bbox, float4 *__restrict__ gboxes,
                                                           float4 *__restrict__ wboxes, float4 *__restrict__ g4boxes,
                                                           double *__restrict__ cen, float *__restrict__ rel,
-                                                          int rel_block, int rel_w_type, int cbox)
+                                                          int rel_w_type, int cbox)
 {
     __shared__ double red[6][TILE / 64];
     const int f = blockIdx.y, T = blockIdx.x, tid = threadIdx.x;
@@ -345,7 +345,6 @@ __global__ __launch_bounds__(TILE) void cull_boxes_kernel(const double4 *__restr
     fold(16);
     fold(32);
     const int wave = tid >> 6;
-    const double wl[3] = {lo[0], lo[1], lo[2]}, wh[3] = {hi[0], hi[1], hi[2]};  // box of this wave's 64 atoms
     if ((tid & 63) == 0) {
         float4 l4, h4;
         if (cbox) centred(l4, h4);
@@ -366,32 +365,25 @@ __global__ __launch_bounds__(TILE) void cull_boxes_kernel(const double4 *__restr
         bbox[((size_t)f * nT + T) * 6 + tid] = v;
     }
     if (rel) {
-        // packed-f32 sweep (pair_sj.hip MODE 3): the atoms relative to the centre c of the box of their block of
-        // rel_block (64 or 256) sorted atoms, rounded to f32 — |x - c| <= half extent, so the rounding error is
-        // 2^-24 of a few Angstrom instead of 2^-24 of the coordinate. c and the half extents go to
-        // cen[f][T * blocks + b][8]; every thread of a block derives the same doubles.
+        // packed-f32 sweep (pair_sj.hip MODE 3): the atoms relative to the centre c of their tile's box, rounded to f32
+        // — |x - c| <= half extent, so the rounding error is 2^-24 of a few Angstrom instead of 2^-24 of the coordinate.
+        // c and the half extents go to cen[f][T][8]; every thread of the block derives the same doubles.
         double c[3], hext[3];
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) {
-            double l = wl[ax], h = wh[ax];
-            if (rel_block == TILE) {
-                l = red[ax][0];
-                h = red[3 + ax][0];
-                for (int w = 1; w < TILE / 64; ++w) {
-                    l = __builtin_fmin(l, red[ax][w]);
-                    h = __builtin_fmax(h, red[3 + ax][w]);
-                }
+            double l = red[ax][0], h = red[3 + ax][0];
+            for (int w = 1; w < TILE / 64; ++w) {
+                l = __builtin_fmin(l, red[ax][w]);
+                h = __builtin_fmax(h, red[3 + ax][w]);
             }
-            const bool any = h >= l;  // a block of pad atoms only: lo = 1e300 > hi
+            const bool any = h >= l;  // a tile of pad atoms only: lo = 1e300 > hi
             c[ax] = any ? 0.5 * (l + h) : 0.0;
             hext[ax] = any ? __builtin_fmax(h - c[ax], c[ax] - l) : 0.0;
         }
-        const int nblk = TILE / rel_block, blk = rel_block == TILE ? 0 : wave;
-        if ((tid & (rel_block - 1)) < 3) {
-            const int ax = tid & (rel_block - 1);
-            double *o = cen + (((size_t)f * nT + T) * nblk + blk) * 8;
-            o[ax] = c[ax];
-            o[3 + ax] = hext[ax];
+        if (tid < 3) {
+            double *o = cen + ((size_t)f * nT + T) * 8;
+            o[tid] = c[tid];
+            o[3 + tid] = hext[tid];
         }
         // two atoms per 32-byte record: (x0, x1, y0, y1, z0, z1, w0, w1); pad atoms sit 1e18 away (rsq32 = 3e36:
         // finite, never in cutoff)
@@ -456,11 +448,11 @@ __global__ __launch_bounds__(256) void cull_list_kernel(const double *__restrict
 
 int cull_prepare_set(mdhip_ctx *ctx, int64_t F, const double *d_x, const int *d_t, long long t_fs,
                      const double *d_box, long long N, int nT, int n_ti, float near, int row_len, bool want_soa,
-                     int rel_block, int rel_w_type, int cbox, const int slot[5], SortedSet &out)
+                     int want_rel_i, int rel_w_type, int cbox, const int slot[5], SortedSet &out)
 {
-    const bool want_rel = rel_block != 0;
+    const bool want_rel = want_rel_i != 0;
     MD_WS(d_rel, float, WS_REL, want_rel ? (size_t)F * nT * TILE * 16 : 64);
-    MD_WS(d_cen, double, WS_CEN, want_rel ? (size_t)F * nT * (TILE / rel_block) * 64 : 64);
+    MD_WS(d_cen, double, WS_CEN, want_rel ? (size_t)F * nT * 64 : 64);
     MD_WS(d_sx, double, WS_SORT_XYZ, want_soa ? (size_t)F * 3 * N * 8 : 64);
     MD_WS(d_st, int, WS_SORT_TYPE, want_soa ? (size_t)F * N * 4 : 64);
     MD_WS(d_keys, unsigned short, WS_KEYS, (size_t)F * N * 2);
@@ -494,7 +486,7 @@ int cull_prepare_set(mdhip_ctx *ctx, int64_t F, const double *d_x, const int *d_
     }
     hipLaunchKernelGGL(cull_boxes_kernel, dim3((unsigned)nT, (unsigned)F), dim3(TILE), 0, ctx->stream, d_ao, d_box, N,
                        nT, d_bbox, d_gs, d_ws, d_g4, want_rel ? d_cen : (double *)nullptr,
-                       want_rel ? d_rel : (float *)nullptr, want_rel ? rel_block : TILE, rel_w_type, cbox);
+                       want_rel ? d_rel : (float *)nullptr, rel_w_type, cbox);
     MD_HIP(hipGetLastError());
     out.rel = want_rel ? d_rel : nullptr;
     out.cen = want_rel ? d_cen : nullptr;

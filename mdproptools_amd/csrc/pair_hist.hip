@@ -145,7 +145,7 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
     float s_cap = 0.f, rc2hi = 0.f, near_pk_f = 0.f, cut_lo = 0.f;
     bool cut_guard = false;
     double pk_err = 0.0;  // error bound of the f32 distance, in bins
-    int rel_block = 0;  // atoms per centre block of the f32 records (0: none)
+    int rel_block = 0;  // != 0: the packed sweep's f32 records are wanted (relative to their tile's centre)
     if (cull && ctx->opt_rdf_sj != 0 && !mode_cn && p.n_cls <= 250 && ctx->opt_rdf_pk != 0 && p.bin_size > 0.0) {
         const bool fits_ordered = ord_base && lds_bytes_sj_pk(p.nbins, p.n_ti, p.n_tj, p.n_cn) <= lds_cap / 3 - 512;
         const bool fits_rows = lds_bytes_sj_pk_rows(p.nbins, p.n_cls, p.n_ti, p.n_tj, p.n_cn) <= lds_cap / 3 - 512;
@@ -666,6 +666,9 @@ int pair_hist_run(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64_t> &H
     int64_t batch = (int64_t)(2147483648.0 / per_frame_b);
     if (batch < 1) batch = 1;
     if (batch > 32768) batch = 32768;
+    // whole rounds of the spatial sort, which runs one block per frame and CU (its cell counters fill the LDS): 367 C3
+    // frames a batch sorted in two rounds of 1.1 ms where 256 take one
+    if (batch > ctx->cu_count && ctx->cu_count > 0) batch = batch / ctx->cu_count * ctx->cu_count;
     if (ctx->opt_rdf_batch > 0) batch = ctx->opt_rdf_batch;
     const bool staged = p.h_xi || p.h_xj;
     // the batches: [f0, f0 + n)
