@@ -270,6 +270,19 @@ def test_soak_slices_inside_the_suite():
     assert time.perf_counter() - t0 < 300.0
 
 
+def test_soak_slice_full_lag_sources():
+    """A slice of tests/bench/soak_lag.py inside `-m gpu`: ten random shapes (frames 2049 .. 5120, entities 1 .. 1500, odd
+    and even column counts, up to six groups with empty ones) through the transposed-copy, read-in-place and in-kernel
+    transposition forms of the fused full-lag MSD kernel — agreement within the reported bounds, every call reproducible
+    bit for bit (the in-kernel form hands tiles from block to block)."""
+    import subprocess
+
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "bench", "soak_lag.py"), "10", "77"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    tail = "\n".join(r.stdout.splitlines()[-5:])
+    assert r.returncode == 0 and "agree within their bounds" in tail, tail
+
+
 def test_every_pair_ambiguous_fills_the_queues(B):
     """The deferred-pair queues at their limit (the push has no capacity test). Atoms sit on TWO points a
     whole number of bins apart: every pair is either at distance 0 or exactly on a bin edge, i.e. inside the guard band of
