@@ -187,7 +187,8 @@ struct FftStage {
 };
 constexpr int ST_AHEAD = 4;  // tile i + ST_AHEAD is staged while tile i is transformed
 constexpr int ST_BUF = 8;    // ring of staged tiles per cluster (3 ST_AHEAD - 4 can be live at once)
-constexpr int ST_UNITS = 5;  // 16-byte units a lane moves per tile: rows per member Fc <= 64 ST_UNITS
+constexpr int ST_UNITS = 8;  // 16-byte units a lane moves per tile at most (template parameter UN: 5 for rows per member
+                             // Fc <= 320, i.e. F <= 5120; 8 beyond)
 constexpr int ST_FLAG_STRIDE = 32;  // words between two ready counters (a 128-byte line each)
 #ifndef ST_SKIP
 #define ST_SKIP 0  // timing experiments only (wrong results): 1 = no polls, 2 = no staging loads / stores inside the series loop,
@@ -1112,7 +1113,7 @@ __device__ __forceinline__ void f3_wave_pass(double *re, double *im, int org, in
 // Every block must be resident (the grid is one block per CU, as the LDS footprint allows one): a poll that does not
 // complete within ~2 s gives up, raises `stall` and the block runs to its end on whatever it reads (the host then
 // takes the transposed path).
-template <int JJ, int QE, int SRC>
+template <int JJ, int QE, int SRC, int UN = 5>
 __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
     const double *__restrict__ x, int F, int m, const FftItem *__restrict__ items,
     const double2 *__restrict__ tab, double *__restrict__ Qpart, double *__restrict__ Ppart, long long cols, double scale,
@@ -1356,7 +1357,7 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
     if constexpr (SRC == 2) {
         // the first ST_AHEAD tiles, before anything is transformed
         for (int i = 0; i < ST_AHEAD; ++i)
-            for (int r = 0; r < ST_UNITS; ++r) {
+            for (int r = 0; r < UN; ++r) {
                 stage_load(i, r, sx);
                 stage_store(i, r, sx);
             }
@@ -1379,13 +1380,30 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
         // the second come from the next series' samples, which this variant requests at E, behind the wave passes,
         // instead of at B (their block sum then rides on the THIRD barrier).
         const long long st_i = c - it.c_lo + ST_AHEAD;
-        if constexpr (SRC == 2) {
-            if (c > it.c_lo) stage_store(st_i - 1, 4, sx);
-            stage_load(st_i, 0, sx);
-        }
+        // Point P of the iteration (NP points: A, [A2,] B, C, C2, D, E [, G]; the bracketed ones only with UN = 8 units,
+        // F > 5120): the unit requested two points ago is stored — P - 2 of this tile, or P - 2 + NP of the tile staged
+        // under the previous series — and unit P is requested, units alternating between the two register pairs
+        constexpr int NP = UN == 5 ? 6 : 8;
+        constexpr int P_A = 0, P_A2 = UN == 5 ? -1 : 1, P_B = UN == 5 ? 1 : 2, P_C = P_B + 1, P_C2 = P_B + 2, P_D = P_B + 3,
+                      P_E = P_B + 4, P_G = UN == 5 ? -1 : 7;
+        auto point = [&](auto pk) {
+            constexpr int P = decltype(pk)::value;
+            if constexpr (SRC == 2 && P >= 0) {
+                st2_t &reg = (P & 1) ? sy : sx;
+                if constexpr (P >= 2) {
+                    if constexpr (P - 2 < UN) stage_store(st_i, P - 2, reg);
+                } else if constexpr (P - 2 + NP < UN) {
+                    if (c > it.c_lo) stage_store(st_i - 1, P - 2 + NP, reg);
+                }
+                if constexpr (P < UN) stage_load(st_i, P, reg);
+            }
+        };
+#define ST_POINT(P) point(std::integral_constant<int, (P)>())
+        ST_POINT(P_A);
         // first pass, from the registers (the previous series' partner reads are behind the barrier that ended it)
 #pragma unroll
         for (int jj = 0; jj < JJ; ++jj) {
+            if (jj == 1) ST_POINT(P_A2);
             const int j = tid + jj * FT_THREADS;
             if (j < s0) {
                 Cx a[QE], y[8];
@@ -1412,7 +1430,7 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
             }
         }
         const bool more = (F3_PREFETCH || SRC == 2) && c + cstep < it.c_hi;
-        if constexpr (SRC == 2) stage_load(st_i, 1, sy);
+        if constexpr (SRC == 2) ST_POINT(P_B);
         else if (more) fetch(c + cstep);
         __syncthreads();
         // this wave's sub-transform: the remaining LDS passes, then the tail in registers
@@ -1424,27 +1442,20 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
             unsigned seen = 0u;
             auto pc = [&]() {
                 if constexpr (SRC == 2) {
-                    // what this wave stored for the tile staged under the PREVIOUS series (its last unit at A) has long
-                    // been issued: waiting for everything in flight here is free (the youngest request is a phase old),
-                    // and lets the second barrier below carry the signal for that tile
+                    // what this wave stored for the tile staged under the PREVIOUS series (its last units at A / A2) has
+                    // long been issued: waiting for everything in flight here is free (the youngest request is a phase
+                    // old), and lets the second barrier below carry the signal for that tile
                     if (!(ST_SKIP & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    stage_store(st_i, 0, sx);
-                    stage_load(st_i, 2, sx);
+                    ST_POINT(P_C);
                 }
             };
             auto pc2 = [&]() {
                 if constexpr (SRC == 2) {
                     if (more) seen = st_peek(c + cstep - it.c_lo);
-                    stage_store(st_i, 1, sy);
-                    stage_load(st_i, 3, sy);
+                    ST_POINT(P_C2);
                 }
             };
-            auto pd = [&]() {
-                if constexpr (SRC == 2) {
-                    stage_store(st_i, 2, sx);
-                    stage_load(st_i, 4, sx);
-                }
-            };
+            auto pd = [&]() { ST_POINT(P_D); };
 #if F3_SKIP & 2
             if (F == 1) {
 #else
@@ -1491,7 +1502,7 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
                 pd();
             }
             if constexpr (SRC == 2) {
-                stage_store(st_i, 3, sy);
+                ST_POINT(P_E);
                 if (more) fetch(c + cstep, seen);
             }
         }
@@ -1539,6 +1550,7 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
         __syncthreads();
         if constexpr (SRC == 2) {
             if (c > it.c_lo && !(ST_SKIP & 4)) st_signal(st_i - 1);  // (the prologue signalled its own tiles)
+            ST_POINT(P_G);
         }
 #if F3_SKIP & 8
         if (owner && F == 1) {
@@ -1585,6 +1597,7 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
             mean = ft_block_sum(lane_sum(), red) / (double)F;
         }
     }
+#undef ST_POINT
     double *q = Qpart + (size_t)it.row * F, *pp = Ppart + (size_t)it.row * (N + 1);
 #pragma unroll
     for (int jj = 0; jj < JJ; ++jj) {
@@ -1782,6 +1795,7 @@ int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r
     const int src_opt = src_want >= 0 ? src_want : ctx->opt_lag_direct >= 0 ? ctx->opt_lag_direct : LAG_DIRECT_DEFAULT;
     const int Fc = (int)((((F + 15) / 16) + 15) / 16 * 16);
     const bool staged = v3 && (src_opt == 2 || src_opt == 3) && ctx->cu_count % 16 == 0 && n_clusters >= 1 && Fc <= 64 * ST_UNITS &&
+                        (Fc <= 64 * 5 || (m == 13 && F <= 8192)) &&  // (eight units: the N = 8192 kernels only)
                         cols >= 16 * (long long)n_clusters &&
                         (unsigned long long)Fc * (unsigned long long)cols * 8ull < 0xFFFFF000ull &&  // (a member's rows: one buffer)
                         (reinterpret_cast<unsigned long long>(d_r) & 15ull) == 0ull;  // (16-byte loads of column pairs
@@ -1967,7 +1981,19 @@ int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r
         else if (direct) MD_F3_GO(JJ, QE, 1, d_r, scale)                                                       \
         else MD_F3_GO(JJ, QE, 0, d_x, 1.0)                                                                     \
     }
-        if (s0 > FT_THREADS) {
+// (eight staging units per lane and tile: rows per member beyond 320, F > 5120)
+#define MD_F3_GO8(QE)                                                                                          \
+    {                                                                                                          \
+        MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msd_power_lds3_kernel<2, QE, 2, 8>),         \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));                    \
+        hipLaunchKernelGGL((msd_power_lds3_kernel<2, QE, 2, 8>), dim3((unsigned)n_items), dim3(FT_THREADS), lds3, \
+                           ctx->stream, d_r, (int)F, m, d_items, d_tab, d_Qpart, d_Ppart, cols, scale, d_stages, \
+                           d_ring, d_ready, src_opt == 3 ? -Fc : Fc);                                          \
+    }
+        if (staged && Fc > 64 * 5) {
+            if (qe <= 3) MD_F3_GO8(3)
+            else MD_F3_GO8(4)
+        } else if (s0 > FT_THREADS) {
             if (qe <= 3) MD_F3_LAUNCH(2, 3)
             else if (qe <= 4) MD_F3_LAUNCH(2, 4)
             else MD_F3_LAUNCH(2, 8)
@@ -1977,6 +2003,7 @@ int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r
             else MD_F3_LAUNCH(1, 8)
         }
 #undef MD_F3_LAUNCH
+#undef MD_F3_GO8
 #undef MD_F3_GO
     } else if (v2) {
         const size_t lds2 = f2_lds_bytes(m);

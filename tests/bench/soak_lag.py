@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """tests/bench/soak_lag.py [trials] [seed] — random shapes through the three sources of the fused full-lag MSD kernel
 (`lag_direct` 0: transposed copy, 1: read in place, 2: clusters transposing their tiles inside the kernel): frames
-2049 .. 5120 (the range the in-kernel form takes), entities 1 .. 1500 (odd and even column counts, fewer columns than
+2049 .. 8192 (the range the in-kernel form takes: five staging units per lane up to 5120 frames, eight beyond), entities 1 .. 1500 (odd and even column counts, fewer columns than
 clusters), one to six groups with empty and one-entity ones, random scale. Every result must agree with the transposed
 path within the sum of the two reported bounds, and a second call must reproduce the first bit for bit."""
 import os
@@ -19,7 +19,7 @@ ctx.set_option("lag_variant", 2)
 took = {0: 0, 1: 0, 2: 0}
 try:
     for t in range(trials):
-        F = int(rng.integers(2049, 5121))
+        F = int(rng.integers(2049, 8193))
         E = int(rng.choice([1, 2, 5, 16, 17, 85, 86, 300, 333, 1024, 1500, int(rng.integers(1, 1500))]))
         G = int(rng.integers(1, 7))
         cuts = np.sort(rng.integers(0, E + 1, G - 1)) if G > 1 else np.array([], dtype=np.int64)

@@ -271,7 +271,7 @@ def test_soak_slices_inside_the_suite():
 
 
 def test_soak_slice_full_lag_sources():
-    """A slice of tests/bench/soak_lag.py inside `-m gpu`: ten random shapes (frames 2049 .. 5120, entities 1 .. 1500, odd
+    """A slice of tests/bench/soak_lag.py inside `-m gpu`: ten random shapes (frames 2049 .. 8192, entities 1 .. 1500, odd
     and even column counts, up to six groups with empty ones) through the transposed-copy, read-in-place and in-kernel
     transposition forms of the fused full-lag MSD kernel — agreement within the reported bounds, every call reproducible
     bit for bit (the in-kernel form hands tiles from block to block)."""

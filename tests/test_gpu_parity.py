@@ -507,12 +507,14 @@ def test_lag_msd_direct_read_option(B, mode):
     inside the kernel through a ring in device memory, handed from block to block (device-scope stores, per-tile ready
     counters). Either way the results must sit within the reported bound of the exact-difference kernel like the
     transposed path's — groups that start and end off the 16-column tiles, a group smaller than a tile, an empty group,
-    more groups than clusters (falls back to the transposed path), entity counts off the tile width, odd column counts."""
+    more groups than clusters (falls back to the transposed path), entity counts off the tile width, odd column counts,
+    trajectories beyond 5120 frames (eight staging units per lane and tile instead of five)."""
     ctx = B.default_context()
     rng = np.random.default_rng(15)
     try:
         for F, E, goff in ((4500, 700, [0, 700]), (5000, 333, [0, 5, 5, 141, 333]), (4100, 64, [0, 1, 64]),
-                           (4200, 90, list(range(0, 91, 3))), (5120, 171, [0, 100, 171]), (2100, 257, [0, 257])):
+                           (4200, 90, list(range(0, 91, 3))), (5120, 171, [0, 100, 171]), (2100, 257, [0, 257]),
+                           (6001, 120, [0, 120]), (8192, 70, [0, 33, 70]), (7000, 45, [0, 45])):
             r = np.cumsum(rng.normal(0, 0.1, (F, 3, E)), axis=0) + rng.uniform(-100, 100, (1, 3, E))
             ctx.set_option("lag_variant", 1)
             exact = B.lag_msd(r, F - 1, goff, scale=0.7)

@@ -18,7 +18,7 @@ libs = [a.split(":")[0] for a in sys.argv[1:] if a.split(":")[0].endswith(".so")
 lib_opts = [dict(kv.split("=") for kv in a.split(":")[1].split(",")) if ":" in a else {} for a in sys.argv[1:]
             if a.split(":")[0].endswith(".so")]  # LIB.so:key=value,key=value
 opts = [a.split("=") for a in sys.argv[1:] if "=" in a and ".so" not in a]
-E, F = 50_000, 5000
+E, F = int(os.environ.get("LAG_E", 50_000)), int(os.environ.get("LAG_F", 5000))  # (other shapes: LAG_E=30000 LAG_F=8000)
 
 
 def ctx_of(path):
