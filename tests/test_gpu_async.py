@@ -198,6 +198,27 @@ def test_msd_step_async_equals_sync(env):
     assert ctx.last_rel_bound() == 0.0
 
 
+def test_full_lag_in_kernel_transposition_pipelined(env):
+    """Trajectories long enough for the kernel that transposes its tiles itself (clusters of workgroups handing tiles to
+    each other through a ring in device memory and per-tile counters that every call resets): four calls in flight on
+    two different trajectories — ring, counters and result staging are shared by the calls and ordered by the stream —
+    equal the synchronous calls bit for bit."""
+    B, synth, torch, ctx = env
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    trajs = []
+    for F, E, goff in ((2300, 500, [0, 200, 500]), (4100, 333, [0, 333])):
+        r = torch.cumsum(torch.randn((F, 3, E), generator=g, device="cuda", dtype=torch.float64) * 0.1, dim=0)
+        ref = B.lag_msd(r, F - 1, goff, scale=1.0, ctx=ctx)
+        assert "msd_power_lds" in ctx.last_kernel_name() and "repeated" not in ctx.last_kernel_name()
+        trajs.append((r, F, goff, ref))
+    hs = [B.lag_msd(r, F - 1, goff, scale=1.0, ctx=ctx, async_=True) for _ in range(2) for r, F, goff, _ in trajs]
+    assert ctx.pending() == 4
+    got = [h.wait() for h in hs]
+    for k, out in enumerate(got):
+        np.testing.assert_array_equal(out, trajs[k % 2][3])
+
+
 def test_flux_com_xcorr_cumtrapz_async_equal_sync(env):
     B, synth, torch, ctx = env
     rng = np.random.default_rng(9)
