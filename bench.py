@@ -286,9 +286,9 @@ def cpu_baseline(cfg, types, rel, nb, n_sample_frames):
     pairs = n_sample_frames * n * (n - 1) // 2
     return {
         "value": pairs / dt, "unit": "atom-pairs/s", "cores": 1, "kind": "port",
-        "sample": "%d of %d frames of the same workload (cost is linear in frames), %.1f s, "
-                  "oracle/cpu_ref.c gcc -O2 single thread; host has %d cores"
+        "sample": "%d of %d frames of the same workload, %.1f s, oracle/cpu_ref.c gcc -O2, 1 thread; host has %d cores"
                   % (n_sample_frames, cfg["n_frames"], dt, os.cpu_count() or 0),
+        "host_cores": os.cpu_count() or 0, "sample_frames": n_sample_frames, "sample_seconds": dt,
     }
 
 
@@ -734,38 +734,87 @@ def leg_c5(B, ctx, torch, device, synth, sync):
                              "direct_extrapolated_s": cpu_dir * sp}}
 
 
-def summary_scalars(out):
-    """The judge-relevant scalars of the legs, repeated inside `config` (the driver's record keeps `config`, `roofline`
-    and `cpu_baseline` whole and reduces every other key to its name)."""
-    def get(d, *path):
-        for k in path:
-            if not isinstance(d, dict) or k not in d:
-                return None
-            d = d[k]
-        return d
+def _get(d, *path):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return None
+        d = d[k]
+    return d
 
-    return {
-        "f64_only_pairs_per_s": get(out, "f64_only", "value"),
-        "f64_only_ms_per_step": get(out, "f64_only", "ms_per_step"),
-        "f64_only_roofline_frac": get(out, "f64_only", "roofline", "frac"),
-        "h2d_pinned_ms_per_step": get(out, "h2d_inclusive", "pinned_pipelined", "ms_per_step"),
-        "h2d_pinned_pairs_per_s": get(out, "h2d_inclusive", "pinned_pipelined", "value"),
-        "h2d_pinned_over_resident": get(out, "h2d_inclusive", "pinned_pipelined", "over_resident"),
-        "h2d_pinned_one_call_at_a_time_ms": get(out, "h2d_inclusive", "pinned", "ms_per_step"),
-        "msd_frame_pairs_per_s": get(out, "msd", "value"),
-        "msd_ms_per_step": get(out, "msd", "ms_per_step"),
-        "msd_kernel_ms_per_step": get(out, "msd", "kernel_ms_per_step"),
-        "parity_checked": get(out, "parity_checked"),
-        "lib_build_match": get(out, "lib_build_id", "match"),
-        "lib_build_id": get(out, "lib_build_id", "library"),
-        "c3_rdf_kernel_s": get(out, "c3", "rdf", "kernel_s"), "c3_cn_kernel_s": get(out, "c3", "cn", "kernel_s"),
-        "c3_rdf_cn_one_sweep_wall_s": get(out, "c3", "rdf_cn_one_sweep", "wall_s"),
-        "c4_lag_msd_kernel_s": get(out, "c4", "lag_msd", "kernel_s"),
-        "c4_lag_msd_traffic": get(out, "c4", "lag_msd", "roofline", "traffic"),
-        "c5_acf_fft_wall_s": get(out, "c5", "acf_fft", "wall_s"), "c5_acf_fft_kernel_s": get(out, "c5", "acf_fft", "kernel_s"),
-        "c5_cumtrapz_kernel_s": get(out, "c5", "cumtrapz", "kernel_s"),
-        "c5_green_kubo_chain_wall_s": get(out, "c5", "green_kubo_chain", "wall_s"),
+
+def driver_filter(line):
+    """A model of what the round driver's record keeps of the JSON line ("What the driver keeps"):
+    the contract's top-level scalars, and of `config`, `roofline` and `cpu_baseline` the FLAT scalars only (numbers,
+    booleans, None; strings cut at 128 characters) — nested dicts and lists are dropped, every other top-level key is
+    reduced to its name. tests/test_bench_line_cpu.py asserts that every judge-relevant figure survives this."""
+    keep_top = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data")
+    out = {k: line[k] for k in keep_top if k in line}
+    for sec in ("config", "roofline", "cpu_baseline"):
+        if isinstance(line.get(sec), dict):
+            out[sec] = {k: (v[:128] if isinstance(v, str) else v) for k, v in line[sec].items()
+                        if v is None or isinstance(v, (int, float, bool, str))}
+    out["extra_keys"] = sorted(k for k in line if k not in keep_top and k not in ("config", "roofline", "cpu_baseline"))
+    return out
+
+
+# every key the VERDICT asked to see in the driver's record (flat, inside `roofline` / `config`)
+FLAT_ROOFLINE_KEYS = (
+    "step_ms_min", "step_ms_median", "step_ms_p90", "step_ms_max", "median_over_kernel_plus_prepass",
+    "f64_only_pairs_per_s", "f64_only_ms_per_step", "f64_only_frac", "msd_frame_pairs_per_s", "msd_ms_per_step",
+    "msd_kernel_ms_per_step", "msd_single_origin_hbm_frac", "lag_msd_kernel_ms", "lag_msd_lds_frac_of_ceiling",
+    "lag_msd_traffic_over_algorithmic", "c3_rdf_cn_wall_s", "c3_pairs_per_s", "h2d_pinned_over_resident",
+    "h2d_pageable_over_resident", "hbm_frac")
+FLAT_CONFIG_KEYS = ("lib_build_match", "lib_build_id", "parity_checked")
+
+
+def flat_scalars(out):
+    """Flat copies of the legs' judge-relevant scalars: -> (roofline additions, config additions). The driver's record
+    keeps only flat scalars of `roofline` / `config` / `cpu_baseline` (driver_filter above), so the f64-only rate, the
+    MSD half of BASELINE's metric and the step distribution ride there under flat names."""
+    st = _get(out, "roofline", "step_ms") or {}
+    lag = _get(out, "c4", "lag_msd") or {}
+    lag_alg = _get(lag, "roofline", "hbm", "algorithmic_bytes")
+    lag_tr = _get(lag, "roofline", "traffic")
+    c3_pairs = _get(out, "c3", "pairs")
+    c3_wall = _get(out, "c3", "rdf_cn_one_sweep", "wall_s")
+    traffic = _get(out, "roofline", "traffic")
+    launch_ms = _get(out, "roofline", "launch_ms")
+    roof = {
+        "step_ms_min": st.get("min"), "step_ms_median": st.get("median"), "step_ms_p90": st.get("p90"),
+        "step_ms_max": st.get("max"), "median_over_kernel_plus_prepass": st.get("median_over_kernel_plus_prepass"),
+        "f64_only_pairs_per_s": _get(out, "f64_only", "value"),
+        "f64_only_ms_per_step": _get(out, "f64_only", "ms_per_step"),
+        "f64_only_frac": _get(out, "f64_only", "roofline", "frac"),
+        "msd_frame_pairs_per_s": _get(out, "msd", "value"), "msd_ms_per_step": _get(out, "msd", "ms_per_step"),
+        "msd_kernel_ms_per_step": _get(out, "msd", "kernel_ms_per_step"),
+        "msd_single_origin_hbm_frac": _get(out, "msd", "roofline", "frac"),
+        "lag_msd_kernel_ms": None if lag.get("kernel_s") is None else lag["kernel_s"] * 1e3,
+        "lag_msd_lds_frac_of_ceiling": _get(lag, "roofline", "frac_of_mix_ceiling"),
+        "lag_msd_lds_array_busy": _get(lag, "roofline", "lds_array_busy"),
+        "lag_msd_valu_issue_frac": _get(lag, "roofline", "valu_issue_frac"),
+        "lag_msd_hbm_frac": _get(lag, "roofline", "hbm", "frac"),
+        "lag_msd_traffic_over_algorithmic": None if not lag_tr or not lag_alg else lag_tr / lag_alg,
+        "lag_msd_rel_bound": lag.get("reported_rel_bound"),
+        "lag_msd_max_rel_diff_vs_difference_kernel": lag.get("max_rel_diff_vs_difference_kernel"),
+        "c3_rdf_cn_wall_s": c3_wall, "c3_rdf_kernel_s": _get(out, "c3", "rdf", "kernel_s"),
+        "c3_cn_kernel_s": _get(out, "c3", "cn", "kernel_s"),
+        "c3_pairs_per_s": None if not c3_pairs or not c3_wall else c3_pairs / c3_wall,
+        "h2d_pinned_over_resident": _get(out, "h2d_inclusive", "pinned_pipelined", "over_resident"),
+        "h2d_pinned_pairs_per_s": _get(out, "h2d_inclusive", "pinned_pipelined", "value"),
+        "h2d_pageable_over_resident": _get(out, "h2d_inclusive", "pageable_pipelined", "over_resident"),
+        "hbm_frac": None if not traffic or not launch_ms else traffic / (launch_ms * 1e-3) / HBM_PEAK,
+        "c4_com_hbm_frac": _get(out, "c4", "com", "roofline", "frac"),
+        "c4_msd_windows_hbm_frac": _get(out, "c4", "msd_fixed_lag_tao4", "roofline", "frac"),
+        "c5_acf_fft_kernel_s": _get(out, "c5", "acf_fft", "kernel_s"),
+        "c5_acf_fft_hbm_frac": _get(out, "c5", "acf_fft", "roofline", "frac"),
+        "c5_acf_direct_fp64_frac": _get(out, "c5", "acf_direct", "roofline", "frac"),
+        "c5_cumtrapz_kernel_s": _get(out, "c5", "cumtrapz", "kernel_s"),
+        "c5_green_kubo_chain_wall_s": _get(out, "c5", "green_kubo_chain", "wall_s"),
     }
+    conf = {"lib_build_match": _get(out, "lib_build_id", "match"), "lib_build_id": _get(out, "lib_build_id", "library"),
+            "parity_checked": _get(out, "parity_checked")}
+    return roof, conf
 
 
 def lib_build_id(ctx):
@@ -1142,20 +1191,20 @@ def main():
     if rank == 0:
         value = pairs_job * args.steps / elapsed
         kdur = max(kernel_ms / max(launches, 1) * 1e-3, 1e-9)  # average duration of one pair_hist launch
-        wl = ("C3: 100k atoms x 1000 frames split over %d GPU(s), cubic L=104 A" % world) if strong else \
-             "C2: 10k atoms x 200 frames per GPU, cubic L=50 A"
+        wl = ("C3: 100k atoms x 1000 frames over %d GPU(s), L=104 A" % world) if strong else \
+             "C2: 10k atoms x 200 frames per GPU, L=50 A"
+        packed = any(t in kernel_name for t in ("<3", "<4", "<5", "<6"))
         out = {
             "metric": "atom-pairs/s", "value": value, "unit": "atom-pairs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32/f64",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32/f64" if packed else "f64",
             "data": "synthetic",
-            "config": {"workload": wl + ", 4 types, 10 type-pair relations, r_cut 20 A, 400 bins, frame-summed uint64 "
-                                      "histograms" + (", %s all-reduce per step" % ("RCCL" if backend == "nccl" else backend) if world > 1 else ""),
+            # strings below stay under 128 characters: the driver's record cuts longer ones
+            "config": {"workload": wl + ", 4 types, 10 relations, r_cut 20 A, 400 bins, uint64 sums"
+                                      + (", %s all-reduce" % ("RCCL" if backend == "nccl" else backend) if world > 1 else ""),
                        "pairs_per_step": pairs_job, "frames_per_gpu": F, "kernel": kernel_name,
-                       "arithmetic": "packed-f32 classification, every pair within the error band of a bin edge or "
-                                     "of the cutoff resolved by the reference's f64 chain (integers identical to the "
-                                     "all-f64 sweep: see f64_only)" if "<3" in kernel_name or "<4" in kernel_name
-                                     or "<5" in kernel_name or "<6" in kernel_name else "f64"},
+                       "arithmetic": "packed-f32 classification + exact f64 resolution near edges; integers == all-f64 "
+                                     "sweep (roofline.f64_only_*)" if packed else "f64"},
             "roofline": valu_roofline(kernel_name, ("C3" if strong else "C2") + ("" if args.op == "rdf" else "/" + args.op),
                                       kdur, "mix bin 11/16", 6, pairs_local, 28.0 * n * F),
         }
@@ -1178,6 +1227,8 @@ def main():
             try:
                 rep, oracle_frames = cpu_baseline_all_cores(cfg, types, rel, nb)
                 out["cpu_baseline"]["all_cores"] = rep
+                out["cpu_baseline"]["all_cores_value"] = rep["value"]  # (flat: the driver's record keeps scalars)
+                out["cpu_baseline"]["all_cores_threads"] = rep["cores"]
             except Exception as e:  # informative only
                 out["cpu_baseline"]["all_cores"] = {"error": repr(e)}
 
@@ -1214,7 +1265,9 @@ def main():
             run_leg("c4", lambda: leg_c4(B, ctx, torch, device, synth, sync))
         if "c5" in legs:
             run_leg("c5", lambda: leg_c5(B, ctx, torch, device, synth, sync))
-        out["config"]["summary"] = summary_scalars(out)
+        roof_flat, conf_flat = flat_scalars(out)
+        out["roofline"].update(roof_flat)  # flat scalars: what the driver's record keeps (driver_filter)
+        out["config"].update(conf_flat)
         print(json.dumps(out))
     if dist.is_initialized():
         dist.barrier()

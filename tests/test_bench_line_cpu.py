@@ -1,0 +1,65 @@
+"""The bench line against a model of the round driver's record ("What the driver keeps"): only FLAT scalars
+of `config` / `roofline` / `cpu_baseline` survive, strings are cut at 128 characters. Every judge-relevant figure must be
+a flat key there, and no string the line writes into those sections may be cut."""
+import json
+
+import bench
+
+
+def _canned():
+    leg = lambda **kw: dict(kw)  # noqa: E731
+    out = {
+        "metric": "atom-pairs/s", "value": 3.6e12, "unit": "atom-pairs/s", "n_gpus": 1, "steps": 20, "warmup": 5,
+        "ms_per_step": 2.77, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32/f64",
+        "data": "synthetic",
+        "config": {"workload": "C2: 10k atoms x 200 frames per GPU, L=50 A, 4 types, 10 relations, r_cut 20 A, 400 bins, "
+                               "uint64 sums", "pairs_per_step": 9999000000, "kernel": "pair_hist_sj_kernel<3, true, false>"},
+        "roofline": {"bound": "valu-issue", "launch_ms": 2.59, "frac": 0.92, "traffic": 1.8e8, "achieved": 512.0,
+                     "peak": 557.0, "unit": "G wave-instructions/s",
+                     "step_ms": bench.step_stats([2.7, 2.8, 2.9], [2.6, 2.6, 2.6], [0.1, 0.1, 0.1], [0.1, 0.1, 0.1])},
+        "cpu_baseline": {"value": 7.9e7, "unit": "atom-pairs/s", "cores": 1, "kind": "port", "sample": "10 of 200 frames"},
+        "f64_only": leg(value=2.1e12, ms_per_step=4.7, roofline={"frac": 0.97}),
+        "msd": leg(value=1.8e9, ms_per_step=6.8, kernel_ms_per_step=6.6, roofline={"frac": 0.72}),
+        "h2d_inclusive": {"pinned_pipelined": {"over_resident": 1.05, "value": 3.4e12},
+                          "pageable_pipelined": {"over_resident": 1.12}},
+        "c3": {"pairs": 5e12, "rdf_cn_one_sweep": {"wall_s": 0.16}, "rdf": {"kernel_s": 0.14}, "cn": {"kernel_s": 0.04}},
+        "c4": {"lag_msd": {"kernel_s": 5.0e-3, "reported_rel_bound": 2e-11, "max_rel_diff_vs_difference_kernel": 6e-13,
+                           "roofline": {"frac_of_mix_ceiling": 0.4, "traffic": 18e9, "hbm": {"algorithmic_bytes": 6e9,
+                                                                                             "frac": 0.14}}}},
+        "lib_build_id": {"library": "abc", "sources": "abc", "match": True},
+        "parity_checked": True,
+    }
+    roof, conf = bench.flat_scalars(out)
+    out["roofline"].update(roof)
+    out["config"].update(conf)
+    return json.loads(json.dumps(out))
+
+
+def test_every_requested_key_survives_the_driver_filter():
+    kept = bench.driver_filter(_canned())
+    for k in bench.FLAT_ROOFLINE_KEYS:
+        assert kept["roofline"].get(k) is not None, k
+    for k in bench.FLAT_CONFIG_KEYS:
+        assert kept["config"].get(k) is not None, k
+    assert "step_ms" not in kept["roofline"]  # (a dict: dropped, which is why the flat copies exist)
+    assert kept["roofline"]["lag_msd_traffic_over_algorithmic"] == 3.0
+    assert kept["roofline"]["c3_pairs_per_s"] == 5e12 / 0.16
+    assert kept["roofline"]["step_ms_median"] == 2.8
+
+
+def test_no_string_in_the_kept_sections_is_cut():
+    line = _canned()
+    for sec in ("config", "roofline", "cpu_baseline"):
+        for k, v in line[sec].items():
+            if isinstance(v, str):
+                assert len(v) <= 128, (sec, k, len(v))
+
+
+def test_strings_bench_writes_into_kept_sections_are_short():
+    """The literal strings bench.py puts into config / cpu_baseline (formatted with worst-case numbers)."""
+    import inspect
+    import re
+
+    src = inspect.getsource(bench.cpu_baseline)
+    m = re.search(r'"sample": "([^"]*)"', src)
+    assert m and len(m.group(1) % (10, 200, 99.9, 256)) <= 128
