@@ -46,6 +46,7 @@ extern "C" {
 #define MDHIP_ENOMEM (-3)  /* device or host allocation failed */
 #define MDHIP_ENODEV (-4)  /* no usable gfx950 device */
 #define MDHIP_ELIMIT (-5)  /* problem exceeds a kernel limit (e.g. LDS for the histogram rows) */
+#define MDHIP_EPENDING (-6) /* mdhip_ticket_status: the call is still in flight */
 
 typedef struct mdhip_ctx mdhip_ctx;
 
@@ -90,6 +91,16 @@ int mdhip_call_stats(mdhip_ctx *ctx, int back, double *kernel_ms, double *aux_ms
 long long mdhip_last_ticket(mdhip_ctx *ctx);
 int mdhip_ticket_stats(mdhip_ctx *ctx, long long ticket, double *kernel_ms, double *aux_ms, int *n_launches,
                        const char **kernel);
+/* What the COMPLETION of call `ticket` returned: 0, or the negative code of its failure (text: mdhip_last_error) —
+ * whoever completed it (its own mdhip_wait, a later mdhip_sync, a synchronous call that drained it). MDHIP_EPENDING
+ * while it is in flight, MDHIP_EINVAL for a number more than 64 completed calls old. An error handed out here is no
+ * longer reported by a later mdhip_sync / mdhip_wait. *n_fallbacks (may be NULL): slow-path repeats the call took —
+ * the staged full-lag MSD kernel's ring timed out (grid not resident as a whole: a co-tenant on the GPU) and the
+ * call was repeated over a transposed copy — results are the same, the call took seconds instead of milliseconds.
+ * The wrapper warns when it is non-zero. */
+int mdhip_ticket_status(mdhip_ctx *ctx, long long ticket, int *n_fallbacks);
+/* Slow-path repeats (see mdhip_ticket_status) since the context was created. */
+long long mdhip_fallbacks(mdhip_ctx *ctx);
 /* Device time (ms, hipEvent pair on the launch stream) of the dominant kernel of the last call,
  * and the number of times that kernel was launched by that call. */
 double mdhip_last_kernel_ms(mdhip_ctx *ctx, int *n_launches);

@@ -36,6 +36,8 @@ PROTOTYPES = {
     "mdhip_call_stats": (C.c_int, [vp, C.c_int, c_dp, c_dp, C.POINTER(C.c_int), C.POINTER(C.c_char_p)]),
     "mdhip_last_ticket": (C.c_longlong, [vp]),
     "mdhip_ticket_stats": (C.c_int, [vp, C.c_longlong, c_dp, c_dp, C.POINTER(C.c_int), C.POINTER(C.c_char_p)]),
+    "mdhip_ticket_status": (C.c_int, [vp, C.c_longlong, C.POINTER(C.c_int)]),
+    "mdhip_fallbacks": (C.c_longlong, [vp]),
     "mdhip_last_kernel_ms": (C.c_double, [vp, C.POINTER(C.c_int)]),
     "mdhip_last_aux_ms": (C.c_double, [vp]),
     "mdhip_last_kernel_name": (C.c_char_p, [vp]),
@@ -309,23 +311,46 @@ class Pending:
     """
     Handle of an asynchronous library call (the *_async entry points of include/mdhip.h): the call's device work is
     queued, `wait()` completes it — and every call of the context issued before it — and returns what the synchronous
-    wrapper would have returned. The handle keeps the call's arrays alive until then.
+    wrapper would have returned, or raises what the completion of THIS call returned (mdhip_ticket_status), whoever
+    completed it. The call's arrays (results and converted inputs) belong to the CONTEXT until the call has completed:
+    a handle that is dropped un-waited leaves nothing dangling — the library still writes that call's results when a
+    later wait / sync / close completes it, into memory the context keeps alive.
     """
 
     def __init__(self, ctx, result, keep=None, finish=None):
-        self.ctx, self._result, self._keep, self._finish = ctx, result, keep, finish
+        self.ctx, self._result, self._finish = ctx, result, finish
         ctx._issued += 1
         self._seq = ctx._issued
         self._done = False
         self.ticket = ctx.last_ticket()
+        if len(ctx._live) >= 32:  # handles dropped un-waited and completed by synchronous calls since
+            ctx._completed_upto(ctx._issued - 1 - ctx.pending())
+        ctx._live[self._seq] = (self.ticket, result, keep)
 
     def wait(self):
         if not self._done:
-            keep = self.ctx._issued - self._seq
-            if self.ctx.pending() > keep:
-                self.ctx.wait(keep)
+            ctx = self.ctx
+            keep = ctx._issued - self._seq
+            rc = 0
+            if ctx.pending() > keep:
+                rc = ctx.lib.mdhip_wait(ctx.h, int(keep))
             self._done = True
-            self._keep = None
+            ctx._completed_upto(self._seq)
+            nfb = C.c_int(0)
+            st = ctx.lib.mdhip_ticket_status(ctx.h, int(self.ticket), C.byref(nfb))
+            if st == -6:  # (cannot happen: the wait above completed it)
+                raise MdhipError(st, "call %d still in flight after its wait" % self.ticket)
+            if st != 0 and st != -1:
+                raise MdhipError(st, (ctx.lib.mdhip_last_error(ctx.h) or b"").decode())
+            if st == -1 and rc != 0:  # more than 64 calls ago: all that is known is what the wait returned
+                ctx.check(rc)
+            if nfb.value:
+                ctx._warn_fallback(self.ticket, nfb.value)
+                ctx._fallbacks_seen = max(ctx._fallbacks_seen, ctx.fallbacks())
+            # rc != 0 with this call fine: the error belongs to an earlier call — its own handle raises it (its status
+            # is remembered by ticket); a handle that was dropped cannot, so say it here once
+            if rc != 0 and st == 0:
+                ctx._orphan_error(rc)
             if self._finish is not None:
                 self._result = self._finish(self._result)
                 self._finish = None
@@ -359,11 +384,47 @@ class Context:
         self.device = int(device)
         self._issued = 0       # asynchronous calls issued so far (Pending handles count from here)
         self._stream = None    # None: the context's own stream; else the hipStream_t handle it launches on
+        self._live = {}        # seq -> (ticket, results, keep-alive inputs) of the calls not known to have completed
+        self._fallbacks_seen = 0
 
     def close(self):
         if getattr(self, "h", None):
-            self.lib.mdhip_destroy(self.h)
+            self.lib.mdhip_destroy(self.h)  # completes what is in flight: the arrays in _live are still there
             self.h = None
+        self._live = {}
+
+    def _completed_upto(self, seq):
+        """Calls complete in issue order: everything up to `seq` has, its arrays go back to their handles' owners."""
+        for k in [k for k in self._live if k <= seq]:
+            del self._live[k]
+
+    def _orphan_error(self, rc):
+        """A wait completed a FAILED call on behalf of a later one. If that call's handle is still alive it raises from
+        its own wait(); otherwise nobody would ever hear of it."""
+        import warnings
+
+        text = (self.lib.mdhip_last_error(self.h) or b"").decode()
+        warnings.warn("an earlier asynchronous mdhip call failed at completion (%d: %s); its handle raises this from "
+                      "wait() — if it was dropped, this warning is the only report" % (rc, text), RuntimeWarning,
+                      stacklevel=3)
+
+    def _warn_fallback(self, ticket, n):
+        import warnings
+
+        warnings.warn("mdhip call %d took %d slow-path repeat(s) (the staged full-lag MSD kernel's grid was not resident "
+                      "as a whole — another process on this GPU?): results are the same, the call took "
+                      "seconds instead of milliseconds" % (ticket, n), RuntimeWarning, stacklevel=3)
+
+    def note_fallbacks(self):
+        """After a synchronous call: warn when it took a slow-path repeat (see mdhip_ticket_status)."""
+        n = self.fallbacks()
+        if n > self._fallbacks_seen:
+            self._warn_fallback(self.last_ticket(), n - self._fallbacks_seen)
+        self._fallbacks_seen = n
+
+    def fallbacks(self):
+        """Slow-path repeats since the context was created (mdhip_fallbacks)."""
+        return int(self.lib.mdhip_fallbacks(self.h))
 
     def __del__(self):
         try:
@@ -393,11 +454,15 @@ class Context:
     def sync(self):
         """Completes every asynchronous call in flight (their results are then in place) and waits for the stream;
         raises the first error among them."""
-        self.check(self.lib.mdhip_sync(self.h))
+        rc = self.lib.mdhip_sync(self.h)
+        self._completed_upto(self._issued)
+        self.check(rc)
 
     def wait(self, keep_in_flight=0):
         """Completes the asynchronous calls in flight, oldest first, until at most `keep_in_flight` remain."""
-        self.check(self.lib.mdhip_wait(self.h, int(keep_in_flight)))
+        rc = self.lib.mdhip_wait(self.h, int(keep_in_flight))
+        self._completed_upto(self._issued - self.pending())
+        self.check(rc)
 
     def pending(self):
         return int(self.lib.mdhip_pending(self.h))

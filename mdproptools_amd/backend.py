@@ -401,6 +401,7 @@ def lag_msd(r, max_lag, group_off, scale=1.0, ctx=None, out=None, async_=False):
             return Pending(ctx, out, keep=(keep, go))
         ctx.check(ctx.lib.mdhip_lag_msd_dev(ctx.h, F, E, rp, on_dev, float(scale), int(max_lag), G,
                                             ptr(go, C.c_int64), op))
+        ctx.note_fallbacks()
         return out
     out = np.zeros((int(max_lag) + 1, G, 4))
     if async_:
@@ -409,6 +410,7 @@ def lag_msd(r, max_lag, group_off, scale=1.0, ctx=None, out=None, async_=False):
         return Pending(ctx, out, keep=(keep, go))
     ctx.check(ctx.lib.mdhip_lag_msd(ctx.h, F, E, rp, on_dev, float(scale), int(max_lag), G,
                                     ptr(go, C.c_int64), ptr(out)))
+    ctx.note_fallbacks()
     return out
 
 
@@ -454,6 +456,7 @@ def xcorr(a, b=None, method=XCORR_FFT, n_lags=None, ctx=None, lag_begin=0, out=N
     ctx = ctx or default_context()
     single = len(a.shape) == 1
     ap, a_dev, k1 = as_input(a, ctx)
+    k2 = None  # (the converted copies as_input hands the library must live until the call has completed)
     shp = tuple(a.shape)
     P, n = (1, shp[0]) if single else shp
     if b is None:
@@ -466,13 +469,13 @@ def xcorr(a, b=None, method=XCORR_FFT, n_lags=None, ctx=None, lag_begin=0, out=N
     if out is not None:
         fn = ctx.lib.mdhip_xcorr_lags_dev_async if async_ else ctx.lib.mdhip_xcorr_lags_dev
         ctx.check(fn(ctx.h, n, P, ap, bp, a_dev, int(method), int(lag_begin), n_lags, _dev_out(out, (P, n_lags), ctx=ctx)))
-        return Pending(ctx, out, keep=(a, b)) if async_ else out
+        return Pending(ctx, out, keep=(a, b, k1, k2)) if async_ else out
     out = result_array((P, n_lags), device=ctx.device)
     if async_:
         if lag_begin:
             raise ValueError("a lag range is asynchronous only with a device result buffer")
         ctx.check(ctx.lib.mdhip_xcorr_async(ctx.h, n, P, ap, bp, a_dev, int(method), n_lags, ptr(out)))
-        return Pending(ctx, out[0] if single else out, keep=(a, b, k1))
+        return Pending(ctx, out[0] if single else out, keep=(a, b, k1, k2))
     ctx.check(ctx.lib.mdhip_xcorr_lags(ctx.h, n, P, ap, bp, a_dev, int(method), int(lag_begin), n_lags, ptr(out)))
     return out[0] if single else out
 

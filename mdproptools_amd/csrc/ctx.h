@@ -82,6 +82,9 @@ struct CallStats {
     int launches = 0;
     const char *kernel = "";
     long long ticket = 0;  // the call's number (mdhip_last_ticket)
+    int rc = 0;            // what the call's completion returned (mdhip_ticket_status), with its text
+    std::string err;
+    int fallbacks = 0;     // slow-path repeats the call took (the staged full-lag kernel's stalled ring, a guard re-run)
 };
 
 // One invocation of an entry point. Everything it enqueues goes to the context's stream; what is left to do on the
@@ -116,6 +119,9 @@ struct mdhip_ctx {
     int completing = 0;             // > 0 while completion steps run (they may issue calls of their own)
     int deferred_rc = 0;            // first error of an asynchronous call that was completed on behalf of a later one
     std::string deferred_err;
+    long long deferred_ticket = 0;  // ... and the call it belongs to (mdhip_ticket_status hands it to its owner)
+    int cur_fallbacks = 0;          // slow-path repeats of the call being issued / completed (CallStats::fallbacks)
+    long long fallbacks_total = 0;  // ... since the context was created (mdhip_fallbacks)
     int opt_sync_spin = 1;          // waiting for the stream: 1 poll the completion event (no interrupt wake-up latency)
                                     // for up to 100 ms, then block; 0 block at once (A/B)
     // host-resident pair inputs: the frames of batch k+1 are copied on this stream while batch k is swept (created on
@@ -177,7 +183,8 @@ struct mdhip_ctx {
                               // stays below 1e-10, else the exact-difference kernel; 1 = series-resident LDS
                               // difference kernel when it fits, 0 = staged difference kernel, 2 = always the
                               // autocorrelation theorem, 4 = 2 through batched global transforms (fft_pow2.hip)
-    int scan_capacity = 0;     // scan.hip: blocks of the one-pass scan the chip holds at once (occupancy calculator, once)
+    int scan_capacity = 0;     // scan.hip: tiles per launch of the one-pass scan; 0: its words have to be filled (first use, after a stall)
+    int scan_parity = 0;       // ... which of the two sets of totals the next launch publishes into
     int fft_tw_logL = -1;         // length the table in WS_FFT_TW was built for (-1: none)
     const void *fft_tw_ptr = nullptr;
     int opt_lag_fft_kernel = 2;   // fused full-lag MSD path: 2 (default) = first pass from registers + wave-private

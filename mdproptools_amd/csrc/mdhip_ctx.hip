@@ -213,6 +213,12 @@ static int complete_call(mdhip_ctx *ctx, mdhip_call *c)
     st.launches = ctx->last_launches;
     st.kernel = ctx->last_kernel;
     st.rel_bound = ctx->last_rel_bound;
+    st.rc = rc;
+    if (rc != MDHIP_OK) st.err = ctx->err;
+    if (!c->inner) {
+        st.fallbacks = ctx->cur_fallbacks;
+        ctx->cur_fallbacks = 0;
+    }
     if (c->inner) {
         // a helper call (a copy of finished values, say) reports nothing of its own: the call around it keeps its numbers;
         // a re-run of the work replaces them
@@ -239,7 +245,10 @@ int mdhip_complete_inflight(mdhip_ctx *ctx, size_t keep)
         const int rc = complete_call(ctx, c);
         if (rc != MDHIP_OK && first == MDHIP_OK) {
             first = rc;
-            ctx->deferred_err = ctx->err;
+            if (ctx->deferred_rc == MDHIP_OK) {
+                ctx->deferred_err = ctx->err;
+                ctx->deferred_ticket = ctx->history.empty() ? 0 : ctx->history.front().ticket;
+            }
         }
     }
     return first;
@@ -403,6 +412,7 @@ static int take_deferred(mdhip_ctx *ctx, int rc)
     if (ctx->deferred_rc != MDHIP_OK) {
         const int d = ctx->deferred_rc;
         ctx->deferred_rc = MDHIP_OK;
+        ctx->deferred_ticket = 0;
         if (!ctx->deferred_err.empty()) ctx->err = ctx->deferred_err;
         ctx->deferred_err.clear();
         return d;
@@ -452,6 +462,31 @@ double mdhip_last_kernel_ms(mdhip_ctx *ctx, int *n_launches)
 }
 
 long long mdhip_last_ticket(mdhip_ctx *ctx) { return ctx ? ctx->tickets : 0; }
+
+int mdhip_ticket_status(mdhip_ctx *ctx, long long ticket, int *n_fallbacks)
+{
+    if (!ctx) return MDHIP_EINVAL;
+    if (n_fallbacks) *n_fallbacks = 0;
+    for (size_t k = 0; k < ctx->history.size(); ++k) {
+        const CallStats &st = ctx->history[k];
+        if (st.ticket != ticket || ticket <= 0) continue;
+        if (n_fallbacks) *n_fallbacks = st.fallbacks;
+        if (st.rc != MDHIP_OK) {
+            ctx->err = st.err;
+            if (ctx->deferred_ticket == ticket) {  // its owner has been told: not parked for a later mdhip_sync any more
+                ctx->deferred_rc = MDHIP_OK;
+                ctx->deferred_err.clear();
+                ctx->deferred_ticket = 0;
+            }
+        }
+        return st.rc;
+    }
+    for (const mdhip_call *c : ctx->inflight)
+        if (c->stats.ticket == ticket) return MDHIP_EPENDING;
+    return mdhip_fail(ctx, MDHIP_EINVAL, "mdhip_ticket_status: call %lld is unknown (more than 64 calls ago?)", ticket);
+}
+
+long long mdhip_fallbacks(mdhip_ctx *ctx) { return ctx ? ctx->fallbacks_total : 0; }
 
 int mdhip_ticket_stats(mdhip_ctx *ctx, long long ticket, double *kernel_ms, double *aux_ms, int *n_launches,
                        const char **kernel)

@@ -2071,6 +2071,8 @@ int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r
         if (*h_stall) {
             // a cluster member never ran (the grid was not resident as a whole): the same call over the transposed copy,
             // inside a synchronous call of its own (d_r is the caller's, or the call's staging: valid until completion)
+            ++ctx->cur_fallbacks;  // visible: mdhip_ticket_status / mdhip_fallbacks (the 2 s poll is otherwise silent)
+            ++ctx->fallbacks_total;
             CallScope again(ctx);
             const int rc2 = lag_msd_fft_fused(again, F, E, d_r, scale, max_lag, G, res->group_off.data(), m, res, 0);
             if (rc2 != MDHIP_OK) return rc2;

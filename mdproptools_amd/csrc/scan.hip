@@ -25,27 +25,27 @@ constexpr int SC_BLOCK = SC_THREADS * SC_PER;
 __device__ __forceinline__ int sc_pad(int i) { return i + (i >> 3); }
 
 // The one-pass form. Tile t = series * n_blocks + block of 2048 increments; a launch covers the tiles [t0, t0 + grid),
-// ONE per block, and the grid is at most what the chip holds at once (mdhip_cumtrapz_enqueue asks the occupancy
-// calculator; longer inputs take several launches, a per-series carry goes from one to the next). Every block scans
-// its tile in registers and publishes the tile's total; the block of the FIRST tile a series has in the launch then
-// waits for the totals of that series' tiles in the launch, scans them — every lane a contiguous share in order, the
-// 256 share totals by wave shuffles, the four wave sums in order: a fixed order, the result does not depend on timing —
-// and publishes every tile's offset; a block waits for ITS offset (one lane polls one word), adds it and writes.
-// Nobody waits before having published and the scanners wait for totals only: no cycle.
-// How the words travel between the CUs. A total and an offset are ONE 64-bit word each, empty = SC_EMPTY (a NaN pattern
-// no arithmetic produces; NaN results are stored as the canonical quiet NaN), written and polled with relaxed
-// device-scope atomics — no flag beside the value, hence no release / acquire fence: on this GPU a device-scope fence
-// writes back and invalidates the XCD's whole L2, and two of them per block made a first version of this kernel four
-// times SLOWER than the three launches it replaces. Every block empties its two words again once it has its offset
-// (the scanner has read every total before it publishes the first offset), so the next launch finds them empty;
-// trap_scan_fill_kernel runs once per buffer.
-// Measured build against build in one process (tools/ab_libs_scan.py, 3 x 1e6 samples): 25.8 us against 24.7 us for the
-// three launches — the same time for half the bytes (PMC: profiles/pmc_secondary.json): what is left is the load phase,
-// two device-scope hops of ~1.5 us each (total -> scanner -> offset) and the store phase, one after the other in every
-// block of the launch at once; a tile-per-XCD mapping with L2-scope hops would shorten the hops but would make the
-// RESULT depend on how blocks are dealt to XCDs, which this library does not rely on.
+// ONE per block. Every block scans its tile in registers, publishes the tile's total, then adds up the totals of the
+// tiles of ITS series that come BEFORE it in the launch — every lane a contiguous share in order, the 256 share sums by
+// wave shuffles, the four wave sums in order: a fixed order, the result does not depend on timing — adds that offset
+// and writes. Waits go BACKWARDS only (round 5): a block waits for blocks with a smaller index, never for a
+// later one, so the launch needs no co-residency — with blocks dispatched in index order (what the hardware does; HIP
+// does not promise it) the lowest unfinished block never waits, and by induction everything drains, whatever else
+// shares the GPU (a second context or process, a CU mask). Round 4's form (the first tile of a series scanned the
+// totals of the LATER tiles and handed out offsets) was correct only with the whole grid resident. Should the dispatch
+// order ever differ, a poll gives up after ~2 s, raises the stall word, every block runs out, and the host fails the
+// call (MDHIP_EHIP) instead of hanging the GPU.
+// How the words travel between the CUs. A total is ONE 64-bit word, empty = SC_EMPTY (a NaN pattern no arithmetic
+// produces; NaN results are stored as the canonical quiet NaN), written and polled with relaxed device-scope atomics —
+// no flag beside the value, hence no release / acquire fence: on this GPU a device-scope fence writes back and
+// invalidates the XCD's whole L2, and two of them per block made a first version of this kernel four times SLOWER than
+// the three launches it replaced. A total is read by every later block of its series, so nobody can empty it inside the
+// launch: there are TWO sets of words, launches alternate between them, and the blocks of a launch empty the set the
+// launch BEFORE them used (complete by stream order) — block b the words b, b + grid, b + 2 grid, ...; a fill kernel
+// runs once per buffer (and after a stall).
 // The samples of a tile come in through coalesced loads into LDS, the results leave through LDS again, coalesced.
 constexpr unsigned long long SC_EMPTY = 0x7ff4dead5ca1ab1eULL;
+constexpr unsigned SC_SPIN_MAX = 1u << 21;  // polls of ~1 us each before a block gives up
 
 __device__ __forceinline__ void sc_publish(double *slot, double v)
 {
@@ -54,12 +54,21 @@ __device__ __forceinline__ void sc_publish(double *slot, double v)
     __hip_atomic_store(reinterpret_cast<unsigned long long *>(slot), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__device__ __forceinline__ double sc_await(const double *slot)
+// -> the word once it is there; gives up (-> 0, *stall raised) after SC_SPIN_MAX polls or when another block has
+__device__ __forceinline__ double sc_await(const double *slot, unsigned *stall)
 {
     unsigned long long bits;
+    unsigned spin = 0;
     while ((bits = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(slot), __ATOMIC_RELAXED,
-                                     __HIP_MEMORY_SCOPE_AGENT)) == SC_EMPTY)
+                                     __HIP_MEMORY_SCOPE_AGENT)) == SC_EMPTY) {
         __builtin_amdgcn_s_sleep(2);
+        ++spin;
+        if ((spin & 1023u) == 0u && __hip_atomic_load(stall, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return 0.0;
+        if (spin >= SC_SPIN_MAX) {
+            __hip_atomic_store(stall, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return 0.0;
+        }
+    }
     return __longlong_as_double((long long)bits);
 }
 
@@ -70,16 +79,19 @@ __global__ void trap_scan_fill_kernel(unsigned long long *__restrict__ w, unsign
 }
 
 __global__ __launch_bounds__(SC_THREADS) void trap_scan_onepass_kernel(
-    const double *__restrict__ y, double *__restrict__ out, double *__restrict__ totals, double *__restrict__ offsets,
-    double *__restrict__ carry, unsigned t0, unsigned t_end, long long n, long long out_stride, int lead, double dx,
-    int n_blocks, double post_scale)
+    const double *__restrict__ y, double *__restrict__ out, double *__restrict__ totals, double *__restrict__ other,
+    unsigned n_words, double *__restrict__ carry, unsigned *__restrict__ stall, unsigned t0, unsigned t_end, long long n,
+    long long out_stride, int lead, double dx, int n_blocks, double post_scale)
 {
     __shared__ double s_v[SC_BLOCK + SC_BLOCK / 8 + 2];
     __shared__ double s_w[SC_THREADS / 64];
-    __shared__ double s_off;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const long long n_inc = n - 1;
     const unsigned t = t0 + blockIdx.x, slot = blockIdx.x;
+    // the words the launch before this one used: empty again for the launch after this one
+    for (unsigned w = slot * SC_THREADS + tid; w < n_words; w += gridDim.x * SC_THREADS)
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(other) + w, SC_EMPTY, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
     if (t >= t_end) return;
     const int series = (int)(t / (unsigned)n_blocks), bid = (int)(t % (unsigned)n_blocks);
     const double *ys = y + (size_t)series * n;
@@ -118,50 +130,35 @@ __global__ __launch_bounds__(SC_THREADS) void trap_scan_onepass_kernel(
     __syncthreads();  // (also: every lane has read its samples, s_v can take the results)
     double before = incl - run;
     for (int w = 0; w < wv; ++w) before += s_w[w];
-    if (tid == SC_THREADS - 1) sc_publish(&totals[slot], before + run);
+    double tile_total = 0.0;
+    if (tid == SC_THREADS - 1) {
+        tile_total = before + run;
+        sc_publish(&totals[slot], tile_total);
+    }
     __syncthreads();  // (s_w is free)
-    if (bid == 0 || t == t0) {
-        // this block scans the totals of its series' tiles in this launch: slots lo .. lo + m
-        const unsigned hi_t = min(t_end, (unsigned)(series + 1) * (unsigned)n_blocks);
-        const unsigned lo = slot;
-        const int m = (int)(hi_t - t);
-        const int share = (m + SC_THREADS - 1) / SC_THREADS;
-        const int a = min(tid * share, m), e = min(a + share, m);
-        double tot[SC_PER];  // (m <= the launch's blocks <= 8 per lane: scan_capacity is at most 8 blocks per CU x 256)
-        double mine = 0.0;
+    // the tiles of this series before this one in the launch: slots lo .. slot - 1
+    const unsigned first_t = max(t0, (unsigned)series * (unsigned)n_blocks);
+    const unsigned lo = first_t - t0;
+    const int m = (int)(t - first_t);  // < the launch's blocks <= SC_PER * SC_THREADS
+    const int share = (m + SC_THREADS - 1) / SC_THREADS;
+    const int a = min(tid * share, m), e = min(a + share, m);
+    double mine = 0.0;
 #pragma unroll
-        for (int q = 0; q < SC_PER; ++q) {
-            tot[q] = a + q < e ? sc_await(&totals[lo + a + q]) : 0.0;
-            mine += tot[q];
-        }
-        double sc = mine;
+    for (int q = 0; q < SC_PER; ++q)
+        if (a + q < e) mine += sc_await(&totals[lo + a + q], stall);
+    double sc = mine;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const double up = __shfl_up(sc, d, 64);
-            if (lane >= d) sc += up;
-        }
-        if (lane == 63) s_w[wv] = sc;
-        __syncthreads();
-        // what came before this launch (the first tile of the series: nothing)
-        double acc = bid == 0 ? 0.0 : carry[series];
-        acc += sc - mine;
-        for (int w = 0; w < wv; ++w) acc += s_w[w];
-#pragma unroll
-        for (int q = 0; q < SC_PER; ++q) {
-            if (a + q < e) sc_publish(&offsets[lo + a + q], acc);
-            acc += tot[q];
-        }
-        if (tid == SC_THREADS - 1) carry[series] = acc;  // (read by the next launch of this call, behind this one)
+    for (int d = 1; d < 64; d <<= 1) {
+        const double up = __shfl_up(sc, d, 64);
+        if (lane >= d) sc += up;
     }
-    if (tid == 0) {
-        s_off = sc_await(&offsets[slot]);
-        __hip_atomic_store(reinterpret_cast<unsigned long long *>(&offsets[slot]), SC_EMPTY, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(reinterpret_cast<unsigned long long *>(&totals[slot]), SC_EMPTY, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (lane == 63) s_w[wv] = sc;
     __syncthreads();
-    const double off = s_off;
+    // what came before this launch (a series that starts inside it: nothing), then the four wave sums in order
+    double off = first_t > (unsigned)series * (unsigned)n_blocks ? carry[series] : 0.0;
+    for (int w = 0; w < SC_THREADS / 64; ++w) off += s_w[w];
+    // (the launch's last tile: what the next launch of this call starts its series from — behind this one on the stream)
+    if (t == t_end - 1 && tid == SC_THREADS - 1) carry[series] = off + tile_total;
 #pragma unroll
     for (int u = 0; u < SC_PER; ++u) s_v[sc_pad(tid * SC_PER + u)] = (off + (before + v[u])) * post_scale;
     __syncthreads();
@@ -175,7 +172,8 @@ __global__ __launch_bounds__(SC_THREADS) void trap_scan_onepass_kernel(
 
 }  // namespace
 
-// y device [n_series][n] -> d_out device [n_series][n - 1 + lead]; everything on the context's stream
+// y device [n_series][n] -> d_out device [n_series][n - 1 + lead]; everything on the context's stream. Must run inside a
+// call (ctx->cur): the stall word comes back through the call's pinned staging and is looked at when it completes.
 int mdhip_cumtrapz_enqueue(mdhip_ctx *ctx, int64_t n, int n_series, const double *d_y, double dx, int lead, double *d_out,
                            double post_scale)
 {
@@ -183,32 +181,44 @@ int mdhip_cumtrapz_enqueue(mdhip_ctx *ctx, int64_t n, int n_series, const double
     const int n_blocks = (int)((n - 1 + SC_BLOCK - 1) / SC_BLOCK);
     const size_t total = (size_t)n_series * n_blocks;
     MD_REQUIRE(total < (1u << 30), "too many scan tiles (%zu)", total);
-    // every block of a launch must be resident (see the kernel): at most what the occupancy calculator says the chip holds
-    if (ctx->scan_capacity <= 0) {
-        int per_cu = 0;
-        MD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(trap_scan_onepass_kernel),
-                                                            SC_THREADS, 0));
-        ctx->scan_capacity = std::max(1, per_cu) * ctx->cu_count;
-    }
-    MD_REQUIRE(ctx->scan_capacity <= SC_PER * SC_THREADS, "internal: scan launches of more than %d blocks", SC_PER * SC_THREADS);
-    const size_t cap = (size_t)ctx->scan_capacity;
-    // per launch: totals | offsets, one word per block (empty between launches: the blocks see to that); carry: one
-    // double per series, behind them (a buffer that has to grow for more series is emptied again)
-    const bool fresh = ctx->ws[WS_SCAN].cap < (2 * cap + (size_t)n_series) * 8;
-    MD_WS(d_ws, double, WS_SCAN, (2 * cap + (size_t)std::max(n_series, 64)) * 8);
-    double *d_tot = d_ws, *d_off = d_ws + cap, *d_carry = d_ws + 2 * cap;
+    // tiles per launch: a block adds up at most SC_PER totals per lane (no residency condition: the waits go backwards)
+    const size_t cap = (size_t)SC_PER * SC_THREADS;
+    // two sets of totals (launches alternate, see the kernel) | stall word (a line of its own) | carry: one double per
+    // series (a buffer that has to grow for more series is emptied again)
+    const size_t words = 2 * cap + 16 + (size_t)std::max(n_series, 64);
+    const bool fresh = ctx->ws[WS_SCAN].cap < words * 8 || ctx->scan_capacity <= 0;
+    MD_WS(d_ws, double, WS_SCAN, words * 8);
+    double *d_set[2] = {d_ws, d_ws + cap};
+    unsigned *d_stall = reinterpret_cast<unsigned *>(d_ws + 2 * cap);
+    double *d_carry = d_ws + 2 * cap + 16;
     if (fresh) {
         hipLaunchKernelGGL(trap_scan_fill_kernel, dim3((unsigned)((2 * cap + 255) / 256)), dim3(256), 0, ctx->stream,
                            reinterpret_cast<unsigned long long *>(d_ws), (unsigned)(2 * cap));
+        MD_HIP(hipMemsetAsync(d_stall, 0, 128, ctx->stream));
+        ctx->scan_capacity = (int)cap;
+        ctx->scan_parity = 0;
     }
     for (size_t t0 = 0; t0 < total; t0 += cap) {
         const size_t t1 = std::min(total, t0 + cap);
         const unsigned g = (unsigned)(t1 - t0);
-        hipLaunchKernelGGL(trap_scan_onepass_kernel, dim3(g), dim3(SC_THREADS), 0, ctx->stream, d_y, d_out, d_tot, d_off,
-                           d_carry, (unsigned)t0, (unsigned)t1, (long long)n, (long long)out_stride, lead, dx, n_blocks,
-                           post_scale);
+        const int par = ctx->scan_parity;
+        ctx->scan_parity ^= 1;
+        hipLaunchKernelGGL(trap_scan_onepass_kernel, dim3(g), dim3(SC_THREADS), 0, ctx->stream, d_y, d_out, d_set[par],
+                           d_set[par ^ 1], (unsigned)cap, d_carry, d_stall, (unsigned)t0, (unsigned)t1, (long long)n,
+                           (long long)out_stride, lead, dx, n_blocks, post_scale);
     }
     MD_HIP(hipGetLastError());
+    if (ctx->cur) {
+        MD_PIN(h_stall, unsigned, 4);
+        *h_stall = 0u;
+        MD_HIP(hipMemcpyAsync(h_stall, d_stall, 4, hipMemcpyDeviceToHost, ctx->stream));
+        ctx->cur->steps.emplace_back([ctx, h_stall]() {
+            if (*h_stall == 0u) return (int)MDHIP_OK;
+            ctx->scan_capacity = 0;  // the words are in an unknown state: filled again by the next call
+            return mdhip_fail(ctx, MDHIP_EHIP, "cumtrapz: a block of the one-pass scan waited ~2 s for an earlier block's "
+                                               "total (blocks not dispatched in index order?); results are not valid");
+        });
+    }
     return MDHIP_OK;
 }
 

@@ -726,23 +726,38 @@ def lag_msd_sharded(r_local, entity_range, max_lag, group_off, scale=1.0, comput
     return out
 
 
-_STEP_STREAM = {}  # msd_step_sharded: (device index, context) -> torch stream the context launches on
+import weakref
+
+# msd_step_sharded: context -> {(device index, post): torch stream}. Keyed on the Context OBJECT (weakly): an id() can be
+# reused by a new context once the old one has been collected, and would hand it a stream it never bound.
+_STEP_STREAM = weakref.WeakKeyDictionary()
 
 
 def _step_stream(device, ctx, post=False):
     """The stream a fused step is ISSUED on: the context's kernels and torch's own work before them (the pre-exchange,
     the zero fill of the result buffer) are queued on ONE stream, so that their order needs no host wait in between.
-    `post`: the second stream of the pair, for what follows the kernels of a step that has been waited for."""
+    `post`: the second stream of the pair, for what follows the kernels of a step that has been waited for.
+    NOTE: the context STAYS bound to that stream after the step (steps are pipelined: step k + 1 is issued before step k
+    is waited for, so there is no point at which a step could hand the old stream back); `release_step_stream(ctx)`
+    restores the context's own stream when the caller is done with sharded steps."""
     import torch
 
-    key = (device.index, id(ctx), bool(post))
-    s = _STEP_STREAM.get(key)
+    per_ctx = _STEP_STREAM.setdefault(ctx, {})
+    key = (device.index, bool(post))
+    s = per_ctx.get(key)
     if s is None:
         s = torch.cuda.Stream(device=device)
-        _STEP_STREAM[key] = s
+        per_ctx[key] = s
     if not post and getattr(ctx, "_stream", None) != s.cuda_stream:
         ctx.set_stream(s.cuda_stream)
     return s
+
+
+def release_step_stream(ctx):
+    """Undo what msd_step_sharded_async did to `ctx`: complete what is in flight and launch on the context's own stream
+    again."""
+    if _STEP_STREAM.pop(ctx, None) is not None:
+        ctx.set_stream(None)
 
 
 def _allreduce_inplace(t):
@@ -860,10 +875,12 @@ def msd_step_sharded_async(r_f, r_e, n_frames_total, entity_range, group_off, ta
             if len(kept_of(*blocks[q])):
                 halo = allf[q, 1]
                 break
-        res = torch.zeros(nS + nW + nL, dtype=torch.float64, device=dev)
+        # (+ 1: the last element is a failure flag — a rank whose local calls raised still takes part in the all-reduce
+        # and every rank raises after it, instead of the others waiting in the collective until it times out)
+        res = torch.zeros(nS + nW + nL + 1, dtype=torch.float64, device=dev)
         single = res[:nS].view(F, G, 4)
         win = res[nS:nS + nW].view(E, 4)
-        lagsum = res[nS + nW:].view(n_lags, G, 4)
+        lagsum = res[nS + nW:nS + nW + nL].view(n_lags, G, 4)
         hs = {}
         k0 = int(kept_local[0]) if len(kept_local) else 0
         means, x, loc_off = None, None, None
@@ -892,29 +909,40 @@ def msd_step_sharded_async(r_f, r_e, n_frames_total, entity_range, group_off, ta
         # On a stream of its own: the next step's kernels may already be queued on the issue stream, and nothing
         # here has to wait for them (what it reads is complete: the calls are waited for first).
         with (torch.cuda.stream(_step_stream(dev, ctx, post=True)) if on_gpu else contextlib.nullcontext()):
-            for key, h in hs.items():
-                h.wait()  # the calls have completed: `means` is in place (the spectral path's host finish ran here)
-                stats[key] = h.stats()
-            if len(kept_local) and halo is not None:
-                # the one window that reaches back to the rank below: three planes of arithmetic (the kernel's
-                # operations: scale, subtract, square, (dx2 + dy2) + dz2)
-                d2 = (r_f[k0] * scale - halo * scale) ** 2
-                win.add_(torch.stack([d2[0], d2[1], d2[2], (d2[0] + d2[1]) + d2[2]], dim=1))
-            if means is not None:
-                w = torch.from_numpy(origins * (g_hi[held] - g_lo[held]).astype(np.float64)[None, :]).to(dev)
-                if len(held) == G:
-                    lagsum.copy_(means * w[:, :, None])
-                else:
-                    lagsum[:, torch.as_tensor(held, device=dev), :] = means * w[:, :, None]
+            err = None
+            try:
+                for key, h in hs.items():
+                    h.wait()  # the calls have completed: `means` is in place (the spectral path's finish ran here)
+                    stats[key] = h.stats()
+                if len(kept_local) and halo is not None:
+                    # the one window that reaches back to the rank below: three planes of arithmetic (the kernel's
+                    # operations: scale, subtract, square, (dx2 + dy2) + dz2)
+                    d2 = (r_f[k0] * scale - halo * scale) ** 2
+                    win.add_(torch.stack([d2[0], d2[1], d2[2], (d2[0] + d2[1]) + d2[2]], dim=1))
+                if means is not None:
+                    w = torch.from_numpy(origins * (g_hi[held] - g_lo[held]).astype(np.float64)[None, :]).to(dev)
+                    if len(held) == G:
+                        lagsum.copy_(means * w[:, :, None])
+                    else:
+                        lagsum[:, torch.as_tensor(held, device=dev), :] = means * w[:, :, None]
+            except Exception as e:  # agreed on THROUGH the all-reduce (no collective of its own)
+                err = e
+                res[-1] = 1.0
             if world > 1:
                 _allreduce_inplace(res)
             flat = res.cpu().numpy()
+            if err is not None:
+                raise err
+            if flat[-1] != 0.0:
+                raise RuntimeError("%d rank(s) failed on their share of the MSD step; this rank stops with them"
+                                   % int(round(flat[-1])))
         assert keep is not None
         single_h = flat[:nS].reshape(F, G, 4)
         win_h = flat[nS:nS + nW].reshape(E, 4)
         with np.errstate(invalid="ignore", divide="ignore"):
             lag_h = np.where(lag_counts[:, :, None] > 0,
-                             flat[nS + nW:].reshape(n_lags, G, 4) / np.maximum(lag_counts, 1.0)[:, :, None], 0.0)
+                             flat[nS + nW:nS + nW + nL].reshape(n_lags, G, 4) / np.maximum(lag_counts, 1.0)[:, :, None],
+                             0.0)
         return single_h, win_h, lag_h, stats
 
     return _Deferred(finish)

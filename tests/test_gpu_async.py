@@ -381,3 +381,85 @@ def test_host_resident_frames_pipelined(env):
         np.testing.assert_array_equal(g[1], r[1])
     np.testing.assert_array_equal(mid[0].sum(axis=0), ref[4][0])
     np.testing.assert_array_equal(hc.wait(), B.cn_loop(hosts[5], ty, box, rel, cuts, per_frame=False, ctx=ctx))
+
+
+def test_completion_error_goes_to_its_own_handle_whoever_completed_the_call(env):
+    """a FAILED asynchronous call completed on behalf of a later one (a synchronous call that drains it, the
+    wait of a later handle) is reported by ITS handle's wait() — not returned as zero-filled arrays — and the handle whose
+    call went through returns its result. (The failing call: a pair sweep whose single frames cannot pass a lowered
+    overflow guard — found at completion; the calls around it: cumulative trapezoids, which have no such guard.)"""
+    import warnings
+
+    B, synth, torch, _ctx = env
+    from mdproptools_amd._lib import Context, MdhipError
+
+    n, F, L = 5000, 8, 40.0
+    x = _frames(synth, torch, n, F, L, 79)
+    ty = synth.rdf_types(n)
+    rel = np.array(synth.ALL_PAIRS_4)
+    box = np.full((F, 3), L)
+    y = np.random.default_rng(3).normal(size=(2, 50_000))
+    c2 = Context(0)
+    try:
+        ref = B.cumtrapz(y, 0.5, ctx=c2)
+        c2.set_option("rdf_guard", 1)
+        # (a) drained by a synchronous call
+        bad = B.rdf_loop(x, ty, box, rel, 10.0, 0.05, 200, per_frame=False, ctx=c2, async_=True)
+        good = B.cumtrapz(y, 0.5, ctx=c2)  # completes `bad` first
+        assert c2.pending() == 0
+        np.testing.assert_array_equal(good, ref)
+        with pytest.raises(MdhipError, match="overflow the 32-bit"):
+            bad.wait()
+        c2.sync()  # its owner has been told: not reported a second time
+        # (b) completed by the wait of a LATER handle
+        bad = B.rdf_loop(x, ty, box, rel, 10.0, 0.05, 200, per_frame=False, ctx=c2, async_=True)
+        later = B.cumtrapz(y, 0.5, ctx=c2, async_=True)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            g = later.wait()
+        np.testing.assert_array_equal(g, ref)
+        assert any("earlier asynchronous mdhip call failed" in str(m.message) for m in w)
+        with pytest.raises(MdhipError, match="overflow the 32-bit"):
+            bad.wait()
+        # (c) nobody holds the failed call's handle: the next sync reports it
+        B.rdf_loop(x, ty, box, rel, 10.0, 0.05, 200, per_frame=False, ctx=c2, async_=True)
+        with pytest.raises(MdhipError, match="overflow the 32-bit"):
+            c2.sync()
+        c2.set_option("rdf_guard", 0)
+        np.testing.assert_array_equal(B.cumtrapz(y, 0.5, ctx=c2, async_=True).wait(), ref)
+    finally:
+        c2.close()
+
+
+def test_dropped_handles_leave_nothing_dangling(env):
+    """the arrays of an un-waited call belong to the context until the call has completed — dropping the
+    handle and then completing the call through sync(), a later wait or close() writes into memory that is still there."""
+    import gc
+
+    B, synth, torch, _ctx = env
+    from mdproptools_amd._lib import Context
+
+    n, F, L = 5000, 8, 40.0
+    x = _frames(synth, torch, n, F, L, 80)
+    ty = synth.rdf_types(n)
+    rel = np.array(synth.ALL_PAIRS_4)
+    box = np.full((F, 3), L)
+    c2 = Context(0)
+    try:
+        ref = B.rdf_loop(x, ty, box, rel, 10.0, 0.05, 200, per_frame=False, ctx=c2)
+        for _ in range(3):
+            B.rdf_loop(x, ty, box, rel, 10.0, 0.05, 200, per_frame=False, ctx=c2, async_=True)  # handle dropped
+        gc.collect()
+        assert len(c2._live) == 3 and c2.pending() == 3
+        junk = [np.full(200 * 11, 7, dtype=np.uint64) for _ in range(16)]  # (whatever freed result memory would be reused for)
+        c2.sync()
+        assert len(c2._live) == 0
+        assert all(int(j.min()) == 7 and int(j.max()) == 7 for j in junk)
+        h1 = B.rdf_loop(x, ty, box, rel, 10.0, 0.05, 200, per_frame=False, ctx=c2, async_=True)
+        B.rdf_loop(x, ty, box, rel, 10.0, 0.05, 200, per_frame=False, ctx=c2, async_=True)  # dropped, behind h1
+        gc.collect()
+        np.testing.assert_array_equal(h1.wait()[0], ref[0])
+        assert len(c2._live) == 1
+    finally:
+        c2.close()  # completes the dropped call into arrays the context still holds
+    assert c2._live == {}
