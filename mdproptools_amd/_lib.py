@@ -173,11 +173,12 @@ def load(build_if_missing=True):
         if _lib is not None:
             return _lib
         _preload_torch_runtime()
-        if not os.path.exists(LIB_PATH):
-            if not build_if_missing:
-                raise MdhipError(-4, "libmdhip.so not found at %s" % LIB_PATH)
+        path = os.environ.get("MDHIP_LIB") or LIB_PATH  # (MDHIP_LIB: another BUILD of this library — build.build_variant)
+        if not os.path.exists(path):
+            if not build_if_missing or path != LIB_PATH:
+                raise MdhipError(-4, "libmdhip.so not found at %s" % path)
             _build.build()
-        lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(path)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
             fn.restype = res

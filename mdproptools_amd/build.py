@@ -102,5 +102,37 @@ def build(force=False, verbose=False):
     return LIB
 
 
+VARIANT_DIR = os.path.join(os.path.dirname(HERE), "tools", "_bin")
+
+
+def build_variant(name, src, extra_flags, force=False):
+    """A variant BUILD of the library — `src` recompiled with `extra_flags`, every other object taken from the regular
+    build — as tools/_bin/libmdhip_<name>.so (git-ignored; travels to the GPU box with the snapshot). Load it with
+    MDHIP_LIB=<path> (mdproptools_amd/_lib.py). Used for A/B measurements and for the debug build the GPU suite runs
+    (-DPK_CAPCHECK: the packed sweep's queue-capacity check, tests/test_gpu_hardening.py)."""
+    build()
+    os.makedirs(os.path.join(VARIANT_DIR, "obj_" + name), exist_ok=True)
+    s = os.path.join(CSRC, src)
+    o = os.path.join(VARIANT_DIR, "obj_" + name, os.path.splitext(src)[0] + ".o")
+    lib = os.path.join(VARIANT_DIR, "libmdhip_%s.so" % name)
+    hipcc = _hipcc()
+    if force or _stale(o, [s] + HEADERS):
+        r = subprocess.run([hipcc] + CFLAGS + list(extra_flags) + ["-c", s, "-o", o], stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed on %s (%s):\n%s" % (src, name, r.stdout.decode(errors="replace")))
+    objs = [o if src_k == src else os.path.join(OBJ, os.path.splitext(src_k)[0] + ".o") for src_k in SOURCES]
+    if force or _stale(lib, objs):
+        r = subprocess.run([hipcc] + objs + LDFLAGS + ["-o", lib], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        if r.returncode != 0:
+            raise RuntimeError("link failed (%s):\n%s" % (name, r.stdout.decode(errors="replace")))
+    return lib
+
+
+def build_capcheck():
+    """The debug build with the packed sweep's queue-capacity check compiled in (pair_sj.hip, PK_CAPCHECK)."""
+    return build_variant("capcheck", "pair_sj.hip", ["-DPK_CAPCHECK"])
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))

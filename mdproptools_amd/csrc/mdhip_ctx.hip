@@ -420,6 +420,7 @@ static int take_deferred(mdhip_ctx *ctx, int rc)
     if (rc != MDHIP_OK && !ctx->deferred_err.empty()) {
         ctx->err = ctx->deferred_err;
         ctx->deferred_err.clear();
+        ctx->deferred_ticket = 0;
     }
     return rc;
 }

@@ -323,3 +323,34 @@ def test_every_pair_ambiguous_fills_the_queues(B):
     np.testing.assert_array_equal(cn2, cn)
     np.testing.assert_array_equal(f64[0], full)
     np.testing.assert_array_equal(f64[1], part)
+
+
+def test_queue_limit_cases_through_the_capacity_check_build():
+    """the packed sweep's pushes carry no capacity test in the shipped build (+1-2 % for
+    a check that cannot fire); the invariant `a wave never holds more than PK_QCAP entries` is checked by the DEBUG build
+    (-DPK_CAPCHECK, mdproptools_amd/build.py:build_capcheck — entries beyond the queue are counted and the call fails).
+    Through that build, in a fresh interpreter: the every-pair-ambiguous case above (queues at their limit) and a slice of
+    the randomised packed-vs-f64 soak. Both must pass with the check armed."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "tools", "_bin", "libmdhip_capcheck.so")
+    if not os.path.exists(lib):
+        from mdproptools_amd import build as bld
+
+        lib = bld.build_capcheck()
+    env = dict(os.environ, MDHIP_LIB=lib)
+    chk = ("import ctypes, os; from mdproptools_amd import _lib; h = _lib.load(); "
+           "assert os.path.realpath(h._name) == os.path.realpath(os.environ['MDHIP_LIB']), h._name")
+    r = subprocess.run([sys.executable, "-c", chk], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stdout
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        "tests/test_gpu_hardening.py::test_every_pair_ambiguous_fills_the_queues"], cwd=root, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "bench", "soak_pk.py"), "60", "17"], cwd=root, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
