@@ -17,6 +17,7 @@ from mdproptools_amd import synth  # noqa: E402
 
 def ctx_of(path):
     _lib._lib = None
+    _lib.STRICT = False
     _lib.LIB_PATH = os.path.abspath(path)
     return _lib.Context(0)
 

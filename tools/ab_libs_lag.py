@@ -23,6 +23,7 @@ E, F = int(os.environ.get("LAG_E", 50_000)), int(os.environ.get("LAG_F", 5000)) 
 
 def ctx_of(path):
     _lib._lib = None
+    _lib.STRICT = False
     _lib.LIB_PATH = os.path.abspath(path)
     c = _lib.Context(0)
     for k, v in opts:

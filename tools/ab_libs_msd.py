@@ -18,6 +18,7 @@ E, F = 50_000, 2000
 
 def ctx_of(path):
     _lib._lib = None
+    _lib.STRICT = False
     _lib.LIB_PATH = os.path.abspath(path)
     return _lib.Context(0)
 

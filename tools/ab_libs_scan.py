@@ -18,6 +18,7 @@ libs = [a for a in sys.argv[1:] if a.endswith(".so")]
 
 def ctx_of(path):
     _lib._lib = None
+    _lib.STRICT = False
     _lib.LIB_PATH = os.path.abspath(path)
     return _lib.Context(0)
 

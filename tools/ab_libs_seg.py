@@ -20,6 +20,7 @@ E, F = 50_000, 5000
 
 def ctx_of(path):
     _lib._lib = None
+    _lib.STRICT = False
     _lib.LIB_PATH = os.path.abspath(path)
     c = _lib.Context(0)
     for k, v in opts:

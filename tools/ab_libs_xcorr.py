@@ -20,6 +20,7 @@ METHOD = B.XCORR_FFT if "fft" in sys.argv[1:] else B.XCORR_DIRECT  # `fft`: the 
 
 def ctx_of(path):
     _lib._lib = None
+    _lib.STRICT = False
     _lib.LIB_PATH = os.path.abspath(path)
     return _lib.Context(0)
 

@@ -1,0 +1,25 @@
+#!/bin/bash
+# tools/gpu_r5.sh [steps...] — round-5 GPU-box sequences; every step writes under gpurun_out/.
+set -u
+R=${GRAFT_REPO_ROOT:-$PWD}
+O=$R/gpurun_out
+mkdir -p $O
+cd $R
+TAG=${TAG:-x}
+L=mdproptools_amd/libmdhip.so
+L4=tools/_bin/libmdhip_r4.so
+for s in "$@"; do
+  echo "== $s $(date +%T)"
+  case $s in
+    tests) timeout -k 10 1100 python -m pytest tests -m gpu -x -q > $O/gpu_tests.log 2>&1; rc=$?; echo "tests rc=$rc"; tail -5 $O/gpu_tests.log; [ $rc -eq 0 ] || exit 1 ;;
+    tests_new) timeout -k 10 900 python -m pytest -m gpu -x -q tests/test_gpu_async.py tests/test_gpu_hardening.py "tests/test_gpu_parity.py::test_cumtrapz_golden_and_sizes" > $O/gpu_tests_new.log 2>&1; rc=$?; echo "tests_new rc=$rc"; tail -15 $O/gpu_tests_new.log; [ $rc -eq 0 ] || exit 1 ;;
+    ab_scan) timeout -k 10 300 python tools/ab_libs_scan.py $L4 $L 2>&1 | grep -v amdgpu > $O/r05_ab_scan.txt; cat $O/r05_ab_scan.txt ;;
+    bench) timeout -k 10 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_line_${TAG}.json 2> $O/bench_err_${TAG}.log; echo "bench rc=$?"; tail -3 $O/bench_err_${TAG}.log; python3 tools/show_steps.py $O/bench_line_${TAG}.json ;;
+    head1) timeout -k 10 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-legs --no-cpu-baseline > $O/fresh_${TAG}.json 2> $O/fresh_${TAG}.err; echo "head rc=$?"; python3 tools/show_steps.py $O/fresh_${TAG}.json ;;
+    bench_c4) timeout -k 10 600 python bench.py --workload c4 --steps 10 --warmup 2 > $O/bench_c4_n1_${TAG}.json 2> $O/bench_c4_n1_err.log; echo "c4 rc=$?"; tail -3 $O/bench_c4_n1_err.log ;;
+    ab_lag) timeout -k 10 400 python tools/ab_libs_lag.py $L4 $L 2>&1 | grep -v amdgpu > $O/r05_ab_lag_${TAG}.txt; cat $O/r05_ab_lag_${TAG}.txt ;;
+    stats) (cd /tmp && export TMPDIR=/tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o r05_bench -- python3 $R/bench.py --no-cpu-baseline --no-legs > $O/bench_line_rocprof.json 2> $O/rocprof_err.log); echo "stats rc=$?" ;;
+    stats_legs) (cd /tmp && export TMPDIR=/tmp && timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o r05_bench_legs -- python3 $R/bench.py --no-cpu-baseline > $O/bench_line_rocprof_legs.json 2> $O/rocprof_legs_err.log); echo "stats_legs rc=$?"; tail -2 $O/rocprof_legs_err.log ;;
+    *) if [ -f "$s" ]; then timeout -k 10 600 python "$s" > $O/$(basename $s .py)_${TAG}.txt 2>&1; echo "$s rc=$?"; tail -40 $O/$(basename $s .py)_${TAG}.txt; else echo "unknown step $s"; fi ;;
+  esac
+done
