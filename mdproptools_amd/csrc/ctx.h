@@ -187,7 +187,9 @@ struct mdhip_ctx {
     int scan_parity = 0;       // ... which of the two sets of totals the next launch publishes into
     int fft_tw_logL = -1;         // length the table in WS_FFT_TW was built for (-1: none)
     const void *fft_tw_ptr = nullptr;
-    int opt_lag_fft_kernel = 2;   // fused full-lag MSD path: 2 (default) = first pass from registers + wave-private
+    int opt_lag_fft_kernel = 3;   // fused full-lag MSD path: 3 (default, round 5) = as 2, and padded length 12288 = 12 x 1024
+                                  // (twelve waves, register-resident 512-point sub-transforms: msd_fft_w12.h) where the
+                                  // next power of two would be 16384; 2 = first pass from registers + wave-private
                                   // sub-transforms where the series is long enough (msd_power_lds3_kernel), else as 1;
                                   // 1 = conflict-free LDS layout, bilinear spectrum sums (msd_power_lds2_kernel);
                                   // 0 = the round-2 kernel (A/B; also what short series fall back to)

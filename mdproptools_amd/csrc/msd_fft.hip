@@ -1631,6 +1631,8 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
 #undef F3_PARTNER
 }
 
+#include "msd_fft_w12.h"
+
 // out[s][i] = sum over the items of segment s of part[item][i]
 __global__ void fold_items_kernel(const double *__restrict__ part, const int *__restrict__ seg_item_off,
                                   long long width, double *__restrict__ out)
@@ -1770,18 +1772,19 @@ double finish_on_host(long long F, long long G, long long n_lags, const int64_t 
 }
 
 // The fused LDS path: L = 2^(m+1) <= 16384.
+// w12 (round 5): N = 6144 = 12 x 512, L = 12288 (msd_fft_w12.h) instead of N = 2^m; `m` is ignored then.
 int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r, double scale, int max_lag,
                       long long G, const int64_t *group_off, int m, const std::shared_ptr<LagFftResult> &res,
-                      int src_want = -1 /* -1: the context's option lag_direct */)
+                      int src_want = -1 /* -1: the context's option lag_direct */, bool w12 = false)
 {
     mdhip_ctx *ctx = cs.ctx;
     const long long n_lags = (long long)max_lag + 1, cols = 3 * E, S = 3 * G;
-    const long long N = 1LL << m, L = 2 * N;
-    const size_t lds_b = ft_lds_bytes(m);
+    const long long N = w12 ? (long long)W12_N : 1LL << m, L = 2 * N;
+    const size_t lds_b = w12 ? (size_t)W12_N * 16 + 256 * 16 : ft_lds_bytes(m);
     // round-3 kernel (conflict-free layout, bilinear spectrum accumulation): N = 2^m a multiple of the block size
-    const bool v2 = ctx->opt_lag_fft_kernel != 0 && m >= 9 && f2_lds_bytes(m) <= ctx->lds_max;
+    const bool v2 = !w12 && ctx->opt_lag_fft_kernel != 0 && m >= 9 && f2_lds_bytes(m) <= ctx->lds_max;
     // second step of round 3 (first pass from registers, wave-private sub-transforms): lag_fft_kernel >= 2
-    const bool v3 = ctx->opt_lag_fft_kernel >= 2 && m >= F3_MIN_M && f3_lds_bytes(m) <= ctx->lds_max;
+    const bool v3 = !w12 && ctx->opt_lag_fft_kernel >= 2 && m >= F3_MIN_M && f3_lds_bytes(m) <= ctx->lds_max;
     // round 4, option `lag_direct` (off by default: measured slower, see ctx.h): that kernel reads the trajectory as it
     // is, [F][3 E], no transposed copy (see msd_power_lds3_kernel). Needs the blocks in whole clusters of 16 per XCD:
     // 128 | cu_count.
@@ -1794,8 +1797,9 @@ int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r
 #endif
     const int src_opt = src_want >= 0 ? src_want : ctx->opt_lag_direct >= 0 ? ctx->opt_lag_direct : LAG_DIRECT_DEFAULT;
     const int Fc = (int)((((F + 15) / 16) + 15) / 16 * 16);
-    const bool staged = v3 && (src_opt == 2 || src_opt == 3) && ctx->cu_count % 16 == 0 && n_clusters >= 1 && Fc <= 64 * ST_UNITS &&
-                        (Fc <= 64 * 5 || (m == 13 && F <= 8192)) &&  // (eight units: the N = 8192 kernels only)
+    const bool staged = (v3 || w12) && (src_opt == 2 || src_opt == 3) && ctx->cu_count % 16 == 0 && n_clusters >= 1 &&
+                        (w12 ? Fc <= 16 * (W12_NW / 2) * W12_UN
+                             : Fc <= 64 * ST_UNITS && (Fc <= 64 * 5 || (m == 13 && F <= 8192))) &&  // (eight units: the N = 8192 kernels only)
                         cols >= 16 * (long long)n_clusters &&
                         (unsigned long long)Fc * (unsigned long long)cols * 8ull < 0xFFFFF000ull &&  // (a member's rows: one buffer)
                         (reinterpret_cast<unsigned long long>(d_r) & 15ull) == 0ull;  // (16-byte loads of column pairs
@@ -1853,7 +1857,7 @@ int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r
         }
         if (!enough || given != n_clusters) {
             // more non-empty segments than clusters: this shape keeps the transposed path (re-enter without `direct`)
-            return lag_msd_fft_fused(cs, F, E, d_r, scale, max_lag, G, group_off, m, res, 0);
+            return lag_msd_fft_fused(cs, F, E, d_r, scale, max_lag, G, group_off, m, res, 0, w12);
         }
         // rows (= Qpart / Ppart rows, consecutive per segment): cluster q, member k -> row 16 q + k
         std::vector<FftItem> rows;
@@ -1963,7 +1967,28 @@ int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r
         MD_HIP(hipGetLastError());
     }
     const int qr = (int)((F + FT_THREADS - 1) / FT_THREADS);
-    if (v3) {
+    if (w12) {
+        const int qe = std::max(4, (int)(((F + 1) / 2 + W12_SUB - 1) / W12_SUB));  // first-pass inputs that hold data: 4 .. 6
+        const size_t ldsw = w12_lds_bytes(qe);
+#define MD_W12_GO(QE, SRC, X, SC)                                                                              \
+    {                                                                                                          \
+        MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msd_power_w12_kernel<QE, SRC>),              \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw));                    \
+        hipLaunchKernelGGL((msd_power_w12_kernel<QE, SRC>), dim3((unsigned)n_items), dim3(W12_THREADS), ldsw,  \
+                           ctx->stream, X, (int)F, d_items, d_tab, d_Qpart, d_Ppart, cols, SC, d_stages, d_ring, \
+                           d_ready, src_opt == 3 ? -Fc : Fc);                                                  \
+    }
+#define MD_W12_LAUNCH(QE)                                                                                      \
+    {                                                                                                          \
+        if (staged) MD_W12_GO(QE, 2, d_r, scale)                                                               \
+        else MD_W12_GO(QE, 0, d_x, 1.0)                                                                        \
+    }
+        if (qe <= 4) MD_W12_LAUNCH(4)
+        else if (qe == 5) MD_W12_LAUNCH(5)
+        else MD_W12_LAUNCH(6)
+#undef MD_W12_LAUNCH
+#undef MD_W12_GO
+    } else if (v3) {
         const size_t lds3 = f3_lds_bytes(m);
         const long long s0 = N >> 3;
         const int qe = (int)(((F + 1) / 2 + s0 - 1) / s0);  // <= 8
@@ -2047,13 +2072,20 @@ int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r
                        d_Qpart, d_seg_off, F, d_Q);
     hipLaunchKernelGGL(fold_items_kernel, dim3((unsigned)((N + 1 + 255) / 256), (unsigned)S), dim3(256), 0,
                        ctx->stream, d_Ppart, d_seg_off, N + 1, d_P);
-    MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msd_inverse_lds_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
-    hipLaunchKernelGGL(msd_inverse_lds_kernel, dim3((unsigned)S), dim3(FT_THREADS), lds_b, ctx->stream, d_P, m, d_tab,
-                       (int)n_lags, d_corr);
+    if (w12) {
+        MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msd_inverse_w12_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+        hipLaunchKernelGGL(msd_inverse_w12_kernel, dim3((unsigned)S), dim3(512), lds_b, ctx->stream, d_P, d_tab,
+                           (int)n_lags, d_corr);
+    } else {
+        MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msd_inverse_lds_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+        hipLaunchKernelGGL(msd_inverse_lds_kernel, dim3((unsigned)S), dim3(FT_THREADS), lds_b, ctx->stream, d_P, m, d_tab,
+                           (int)n_lags, d_corr);
+    }
     MD_HIP(hipGetLastError());
     timer.stop();
-    ctx->last_kernel = "msd_power_lds_kernel";
+    ctx->last_kernel = w12 ? "msd_power_w12_kernel" : "msd_power_lds_kernel";
 
     // Q and the correlations come back through pinned staging (d_Q | d_P | d_corr are one buffer: Q and corr are
     // fetched separately, P stays); the long-hand finish runs on the host once they are there
@@ -2074,10 +2106,11 @@ int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r
             ++ctx->cur_fallbacks;  // visible: mdhip_ticket_status / mdhip_fallbacks (the 2 s poll is otherwise silent)
             ++ctx->fallbacks_total;
             CallScope again(ctx);
-            const int rc2 = lag_msd_fft_fused(again, F, E, d_r, scale, max_lag, G, res->group_off.data(), m, res, 0);
+            const int rc2 = lag_msd_fft_fused(again, F, E, d_r, scale, max_lag, G, res->group_off.data(), m, res, 0, w12);
             if (rc2 != MDHIP_OK) return rc2;
             const int rc3 = again.end();
-            ctx->last_kernel = "msd_power_lds_kernel (repeated over the transposed copy: a cluster member did not run)";
+            ctx->last_kernel = w12 ? "msd_power_w12_kernel (repeated over the transposed copy: a cluster member did not run)"
+                                   : "msd_power_lds_kernel (repeated over the transposed copy: a cluster member did not run)";
             return rc3;
         }
         res->bound = finish_on_host(F, G, n_lags, res->group_off.data(), h_Q, h_corr, n_lags, 1.0, L, res->out.data());
@@ -2104,6 +2137,10 @@ int mdhip_lag_msd_fft(CallScope &cs, int64_t n_frames, int64_t n_ent, const doub
         // fused LDS path when the padded series fits: L = power of two >= max(16, F + max_lag)
         int m = 3;
         while ((2LL << m) < F + max_lag) ++m;
+        // round 5: padded length 12288 = 3 * 2^12 where 16384 would be the next power of two (msd_fft_w12.h)
+        if (ctx->opt_lag_fft_kernel >= 3 && m == 13 && F + max_lag <= 2 * W12_N && (F + 1) / 2 <= 6 * W12_SUB &&
+            w12_lds_bytes(6) <= ctx->lds_max)
+            return lag_msd_fft_fused(cs, F, E, d_r, scale, max_lag, G, group_off, m, res, -1, true);
         if (m <= FT_MAX_M && ft_lds_bytes(m) <= ctx->lds_max)
             return lag_msd_fft_fused(cs, F, E, d_r, scale, max_lag, G, group_off, m, res);
     }
