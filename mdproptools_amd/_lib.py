@@ -428,6 +428,8 @@ class Context:
 
     def fallbacks(self):
         """Slow-path repeats since the context was created (mdhip_fallbacks)."""
+        if not STRICT and not hasattr(self.lib, "mdhip_fallbacks"):
+            return 0  # (an older build loaded by an A/B tool)
         return int(self.lib.mdhip_fallbacks(self.h))
 
     def __del__(self):

@@ -2138,7 +2138,7 @@ int mdhip_lag_msd_fft(CallScope &cs, int64_t n_frames, int64_t n_ent, const doub
         int m = 3;
         while ((2LL << m) < F + max_lag) ++m;
         // round 5: padded length 12288 = 3 * 2^12 where 16384 would be the next power of two (msd_fft_w12.h)
-        if (ctx->opt_lag_fft_kernel >= 3 && m == 13 && F + max_lag <= 2 * W12_N && (F + 1) / 2 <= 6 * W12_SUB &&
+        if (ctx->opt_lag_fft_kernel >= 3 && m == 13 && F + max_lag <= 2 * W12_N && (F + 1) / 2 <= 6 * W12_SUB && F >= 6 * W12_SUB &&
             w12_lds_bytes(6) <= ctx->lds_max)
             return lag_msd_fft_fused(cs, F, E, d_r, scale, max_lag, G, group_off, m, res, -1, true);
         if (m <= FT_MAX_M && ft_lds_bytes(m) <= ctx->lds_max)

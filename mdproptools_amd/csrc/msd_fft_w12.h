@@ -34,6 +34,12 @@ constexpr int W12_SUB = 512;                // points per sub-transform
 constexpr int W12_N = W12_NW * W12_SUB;     // 6144
 constexpr int W12_RS = 520;                 // points between two regions (the second exchange uses 8 x 65)
 constexpr int W12_UN = 4;                   // staging units per lane and tile (96 rows a round: rows per member <= 384)
+#ifndef W12_EXP
+#define W12_EXP 0  // timing experiments only (WRONG results): 1 no first barrier, 2 no second, 4 no third, 8 no partner phase,
+                   // 16 no exchanges (LDS writes + reads of the register passes), 32 no butterfly arithmetic in the passes,
+                   // 64 no first-pass arithmetic, 128 no staging (SRC == 2: loads, stores)
+#endif
+#define W12_BARRIER(bit) do { if (!(W12_EXP & (bit))) __syncthreads(); } while (0)
 
 // LDS: regions | raw plane (QE x 512 points) | two-level twiddle table | b table [12][8] | w_512^lane [64] | w_64^n0 [8] | red
 inline size_t w12_lds_bytes(int qe)
@@ -132,30 +138,34 @@ __global__ __launch_bounds__(W12_THREADS) void msd_power_w12_kernel(
     for (int i = 0; i < 5; ++i) tacc[i] = 0.0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) qa[i] = qb[i] = 0.0;
-    const int half = (F + 1) >> 1;  // packed points that hold data
     typedef double st2_t __attribute__((ext_vector_type(2)));
     st2_t v[4];  // the next series' samples: packed points tid + 768 r
 
-    // ---- SRC == 2: the cluster's staging ring (msd_power_lds3_kernel's, 96 rows per round) ----
+    // ---- SRC == 2: the cluster's staging ring (msd_power_lds3_kernel's protocol and ring layout [slot][column][time]) ----
+    // What differs is how a unit is moved. There a lane loads 16 bytes of ONE row (two columns) and swaps a value with its
+    // neighbour lane so that it can store 16 bytes of one column: 2 multiplications + 2 DPP moves + 6 selects per unit,
+    // and a second form of the load for odd column counts. Here a lane loads the SAME column of TWO consecutive rows with
+    // two 8-byte loads — lane (pair sp = 8 (wave / 2) + lane / 8, column sc = 8 (wave % 2) + lane % 8): a load instruction
+    // touches 8 half lines, as there — and stores the 16 bytes as they are: no swap, no odd-column form (8-byte loads do
+    // not care about the rows' alignment), whole 128-byte lines per column in the ring (the 8 lanes of a column hold 16
+    // consecutive rows). 8 vector instructions per unit instead of ~26: the staging was 0.93 of the call's 4.5 ms.
     FftStage sg{};
     if constexpr (SRC == 2) sg = stg[blockIdx.x];
     const long long Fs = 16LL * Fc, nt = it.c_hi - it.c_lo;
     st2_t sx = {0.0, 0.0}, sy = {0.0, 0.0};
     constexpr int RPR = 16 * (W12_NW / 2);  // rows per round of the block
-    const int st_rr = (wv >> 1) * 16 + (lane & 15), st_p = (wv & 1) * 4 + (lane >> 4);
-    int st_lim = 0, st_lim2 = 0;
-    unsigned st_vi = 0u, st_vo = 0u;
+    const int st_sp = (wv >> 1) * 8 + (lane >> 3), st_sc = (wv & 1) * 8 + (lane & 7);
     constexpr unsigned ST_OOB = 0xFFFFF000u;
-    const bool odd_cols = (cols & 1LL) != 0;
-    typedef unsigned st4_t __attribute__((ext_vector_type(4)));
-    if constexpr (SRC == 2) {
-        const int row = sg.k * Fc + st_rr, row2 = row & ~1;
-        st_lim = Fc - st_rr < F - row ? Fc - st_rr : F - row;
-        st_lim2 = Fc - (st_rr & ~1) < F - row2 ? Fc - (st_rr & ~1) : F - row2;
-        st_vi = (unsigned)(((size_t)st_rr * (size_t)cols + 2 * st_p) * 8);
-        st_vo = (unsigned)(((size_t)(2 * st_p + (lane & 1)) * (size_t)Fs + (size_t)row2) * 8);
-    }
+    // rows of this member's share [k Fc, k Fc + st_rows) that lie at or behind the lane's first row 2 sp: unit r moves the
+    // pair (96 r + 2 sp, + 1) iff 96 r < st_have (the second row of a pair may be the one behind the series' end, F odd:
+    // it reads as zero — beyond the buffer — and the ring's row F holds that zero)
     const long long st_rows = (long long)F - (long long)sg.k * Fc < Fc ? (long long)F - (long long)sg.k * Fc : (long long)Fc;
+    const int st_have = (int)(st_rows > 0 ? st_rows : 0) - 2 * st_sp;
+    unsigned st_vi = 0u, st_vo = 0u;
+    if constexpr (SRC == 2) {
+        st_vi = (unsigned)(((size_t)(2 * st_sp) * (size_t)cols + (size_t)st_sc) * 8);
+        st_vo = (unsigned)(((size_t)st_sc * (size_t)Fs + (size_t)sg.k * Fc + 2 * st_sp) * 8);
+    }
     const __amdgpu_buffer_rsrc_t traj = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<double *>(x) + (SRC == 2 ? (size_t)sg.k * (size_t)Fc * (size_t)cols : 0), 0,
         SRC == 2 ? (int)(unsigned)((size_t)(st_rows > 0 ? st_rows : 0) * (size_t)cols * 8) : 0, 0x00020000);
@@ -163,32 +173,28 @@ __global__ __launch_bounds__(W12_THREADS) void msd_power_w12_kernel(
         scratch + (SRC == 2 ? (size_t)sg.cluster * ST_BUF * 16 * (size_t)Fs : 0), 0,
         SRC == 2 ? (int)((size_t)ST_BUF * 16 * (size_t)Fs * 8) : 0, 0x00020000);
     constexpr int SC1 = 16, NT_HINT = 2;
-    auto stage_load = [&](long long i, int r, st2_t &sv) {
+    typedef unsigned st2u_t __attribute__((ext_vector_type(2)));
+    typedef unsigned st4_t __attribute__((ext_vector_type(4)));
+    // (per tile, wave-uniform but for the column test of the matrix's last tile) rows this lane may move of tile i: 0
+    // for a tile behind the cluster's last one or a column beyond the matrix
+    auto st_lim_of = [&](long long i) {
         const long long T = it.c_lo + i;
-        const bool row_in = i < nt && RPR * r < st_lim;
-        const unsigned soff = (unsigned)(((size_t)(RPR * r) * (size_t)cols + (size_t)(16 * T)) * 8);
-        if (odd_cols) {
-            typedef unsigned u2_t __attribute__((ext_vector_type(2)));
-            const bool in0 = row_in && 16 * T + 2 * st_p < cols, in1 = row_in && 16 * T + 2 * st_p + 1 < cols;
-            const u2_t a = __builtin_amdgcn_raw_buffer_load_b64(traj, in0 ? st_vi : ST_OOB, soff, NT_HINT);
-            const u2_t b = __builtin_amdgcn_raw_buffer_load_b64(traj, in1 ? st_vi + 8u : ST_OOB, soff, NT_HINT);
-            sv = st2_t{__builtin_bit_cast(double, a), __builtin_bit_cast(double, b)};
-        } else {
-            const bool in = row_in && (16 * T + 16 <= cols || 16 * T + 2 * st_p + 1 < cols);
-            sv = __builtin_bit_cast(st2_t, __builtin_amdgcn_raw_buffer_load_b128(traj, in ? st_vi : ST_OOB, soff, NT_HINT));
-        }
+        return (i < nt && 16 * T + st_sc < cols) ? st_have : 0;
     };
-    auto stage_store = [&](long long i, int r, const st2_t &sv) {
-        const bool odd = lane & 1;
-        const double a = sv[0] * scale, b = sv[1] * scale;
-        const double send = odd ? a : b;
-        const int lo = __builtin_amdgcn_mov_dpp(__double2loint(send), 0xB1, 0xF, 0xF, true);  // quad_perm [1, 0, 3, 2]
-        const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(send), 0xB1, 0xF, 0xF, true);
-        const double recv = __hiloint2double(hi, lo);
-        const bool in = i < nt && RPR * r < st_lim2;
-        const st2_t out = odd ? st2_t{recv, b} : st2_t{a, recv};
+    // Nothing here branches (see msd_power_lds3_kernel): a lane without a part addresses the buffer beyond its end in its
+    // PER-LANE offset, which is what the hardware's range check looks at; loads return zeros there, stores are dropped.
+    auto stage_load = [&](long long i, int r, int lim, st2_t &sv) {
+        const long long T = it.c_lo + i;
+        const unsigned soff = (unsigned)(((size_t)(RPR * r) * (size_t)cols + (size_t)(16 * T)) * 8);
+        const st2u_t a = __builtin_amdgcn_raw_buffer_load_b64(traj, RPR * r < lim ? st_vi : ST_OOB, soff, NT_HINT);
+        const st2u_t b = __builtin_amdgcn_raw_buffer_load_b64(traj, RPR * r + 1 < lim ? st_vi : ST_OOB,
+                                                             soff + (unsigned)((size_t)cols * 8), NT_HINT);
+        sv = st2_t{__builtin_bit_cast(double, a), __builtin_bit_cast(double, b)};
+    };
+    auto stage_store = [&](long long i, int r, int lim, const st2_t &sv) {
+        const st2_t out = st2_t{sv[0] * scale, sv[1] * scale};
         const unsigned soff = (unsigned)(((size_t)(i & (ST_BUF - 1)) * 16 * (size_t)Fs + (size_t)(RPR * r)) * 8);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(st4_t, out), ring, in ? st_vo : ST_OOB, soff, SC1);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(st4_t, out), ring, RPR * r < lim ? st_vo : ST_OOB, soff, SC1);
     };
     auto st_flag = [&](long long i) { return ready + ((size_t)sg.cluster * ST_BUF + (size_t)(i & (ST_BUF - 1))) * ST_FLAG_STRIDE; };
     auto st_signal = [&](long long i) {
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(W12_THREADS) void msd_power_w12_kernel(
                 const int n = tid + W12_THREADS * r;
                 // (beyond the series, or a column outside the segment: zeros from beyond the buffer's end; row F of the
                 // ring holds a zero where F is odd: the pair store wrote it)
-                const bool in = valid && 2 * n < F;
+                const bool in = valid && (r < 2 || 2 * n < F);  // (F >= 3072: the host's condition for this kernel)
                 v[r] = __builtin_bit_cast(
                     st2_t, __builtin_amdgcn_raw_buffer_load_b128(ring, in ? (unsigned)n * 16u : ST_OOB, row, SC1));
             }
@@ -269,9 +275,10 @@ __global__ __launch_bounds__(W12_THREADS) void msd_power_w12_kernel(
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int n = tid + W12_THREADS * r;
-            if (n < QE * W12_SUB) {
-                const double da = 2 * n < F ? v[r][0] - mean : 0.0;
-                const double db = 2 * n + 1 < F ? v[r][1] - mean : 0.0;
+            if (r < 3 || n < QE * W12_SUB) {  // (QE >= 4: the first three units always lie inside the raw plane)
+                // (F >= 3072, the host's condition for this kernel: the first two units hold data in every lane)
+                const double da = (r < 2 || 2 * n < F) ? v[r][0] - mean : 0.0;
+                const double db = (r < 2 || 2 * n + 1 < F) ? v[r][1] - mean : 0.0;
                 qa[r] = __builtin_fma(da, da, qa[r]);
                 qb[r] = __builtin_fma(db, db, qb[r]);
                 raw[n] = make_double2(da, db);
@@ -281,23 +288,57 @@ __global__ __launch_bounds__(W12_THREADS) void msd_power_w12_kernel(
 
     if constexpr (SRC == 2) {
         // the first ST_AHEAD tiles, before anything is transformed
-        for (int i = 0; i < ST_AHEAD; ++i)
-            for (int r = 0; r < W12_UN; ++r) {
-                stage_load(i, r, sx);
-                stage_store(i, r, sx);
-            }
+        // (one unit at a time, each waited for: the unrolled, software-pipelined form the compiler makes of this loop — eight
+        // loads in flight, stores between them — delivered wrong rows in its fifth load; it runs once per block)
+        int n_ahead = ST_AHEAD * W12_UN;
+        asm volatile("" : "+s"(n_ahead));  // (opaque trip count: no unrolling)
+        for (int u = 0; u < n_ahead; ++u) {
+            const int i = u / W12_UN, r = u % W12_UN;
+            const int lim = st_lim_of(i);
+            const long long T = it.c_lo + i;
+            const unsigned soff = (unsigned)(((size_t)(RPR * r) * (size_t)cols + (size_t)(16 * T)) * 8);
+            const st2u_t a = __builtin_amdgcn_raw_buffer_load_b64(traj, RPR * r < lim ? st_vi : ST_OOB, soff, NT_HINT);
+            const st2u_t b = __builtin_amdgcn_raw_buffer_load_b64(traj, RPR * r + 1 < lim ? st_vi : ST_OOB,
+                                                                 soff + (unsigned)((size_t)cols * 8), NT_HINT);
+            sx = st2_t{__builtin_bit_cast(double, a), __builtin_bit_cast(double, b)};
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(sx)::"memory");
+            const st2_t out = st2_t{sx[0] * scale, sx[1] * scale};
+            const unsigned soff2 = (unsigned)(((size_t)(i & (ST_BUF - 1)) * 16 * (size_t)Fs + (size_t)(RPR * r)) * 8);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(st4_t, out), ring, RPR * r < lim ? st_vo : ST_OOB, soff2, SC1);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         for (int i = 0; i < ST_AHEAD; ++i) st_signal(i);
     }
     if (it.c_lo < it.c_hi) {  // (a cluster member whose column lies outside the segment transforms zeros)
         fetch(it.c_lo);
+#ifdef W12_VERIFY
+        if constexpr (SRC == 2) {
+            const long long coln = 16 * it.c_lo + sg.k;
+            if (coln >= sg.lo && coln < sg.hi) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = tid + W12_THREADS * r;
+                    for (int h = 0; h < 2; ++h) {
+                        const int t = 2 * n + h;
+                        if (t < F && v[r][h] != 16384.0 * (double)coln + (double)t)
+                            printf("BAD0 block %d k %d tile %lld t %d got %.1f want %.1f\n", (int)blockIdx.x, sg.k, it.c_lo, t,
+                                   v[r][h], 16384.0 * (double)coln + (double)t);
+                    }
+                }
+            }
+        }
+#endif
         wave_sum(0);
         __syncthreads();
         centre_store(0);
     }
     __syncthreads();
     const int cstep = SRC == 2 ? 1 : it.step;
+#ifdef W12_VERIFY
+    double vfirst = 0.0;
+    int vfirst_set = 0;
+#endif
     const int c3 = wv % 3, g4 = wv / 3;  // first pass: this wave's residue c = d mod 3 and its quarter of the positions j
     double2 *myR = R + wv * RS;
     const double2 *pR = R + pw * RS;
@@ -305,12 +346,14 @@ __global__ __launch_bounds__(W12_THREADS) void msd_power_w12_kernel(
         const long long st_i = c - it.c_lo + ST_AHEAD;
         // Staging points 0 .. 5 of the iteration: point P stores the unit requested two points ago (P - 2) and requests
         // unit P (< W12_UN), units alternating between the two register pairs (msd_power_lds3_kernel's scheme)
+        int st_lim = 0;
+        if constexpr (SRC == 2) st_lim = st_lim_of(st_i);
         auto point = [&](auto pk) {
             constexpr int P = decltype(pk)::value;
-            if constexpr (SRC == 2) {
+            if constexpr (SRC == 2 && !(W12_EXP & 128)) {
                 st2_t &reg = (P & 1) ? sy : sx;
-                if constexpr (P >= 2 && P - 2 < W12_UN) stage_store(st_i, P - 2, reg);
-                if constexpr (P < W12_UN) stage_load(st_i, P, reg);
+                if constexpr (P >= 2 && P - 2 < W12_UN) stage_store(st_i, P - 2, st_lim, reg);
+                if constexpr (P < W12_UN) stage_load(st_i, P, st_lim, reg);
             }
         };
 #define W12_POINT(P) point(std::integral_constant<int, (P)>())
@@ -327,26 +370,29 @@ __global__ __launch_bounds__(W12_THREADS) void msd_power_w12_kernel(
             Cx z[QE], o[4];
 #pragma unroll
             for (int e = 0; e < QE; ++e) z[e] = w12_ld(raw + j + W12_SUB * e);
-            if (c3 == 0) w12_head<QE, 0>(z, o);
+            if (W12_EXP & 64) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = z[q];
+            } else if (c3 == 0) w12_head<QE, 0>(z, o);
             else if (c3 == 1) w12_head<QE, 1>(z, o);
             else w12_head<QE, 2>(z, o);
 #pragma unroll
             for (int q = 0; q < 4; ++q) w12_st(R + (c3 + 3 * q) * RS + j, o[q]);
         }
         W12_POINT(1);
-        __syncthreads();
+        W12_BARRIER(1);
         // the raw plane is free: the next series' samples are requested into registers and land under the passes
         if (more) fetch(c + cstep, seen);
         // ---- this wave's 512-point sub-transform, in registers ----
         Cx a[8];
 #pragma unroll
         for (int n2 = 0; n2 < 8; ++n2) a[n2] = w12_ld(myR + lane + 64 * n2);
-        if (wv != 0) {
+        if (wv != 0 && !(W12_EXP & 32)) {
 #pragma unroll
             for (int n2 = 1; n2 < 8; ++n2) a[n2] = cx_mul(a[n2], w12_ld(btab + wv * 8 + n2));
         }
-        f2_bfly8(a, Cx{1.0, 0.0}, false);
-        {
+        if (!(W12_EXP & 32)) f2_bfly8(a, Cx{1.0, 0.0}, false);
+        if (!(W12_EXP & 32)) {
             const Cx tw_1 = w12_ld(t1tab + lane);
             Cx t = tw_a;  // w_N^(lane d) w_512^(lane k2), k2 = 0..7
             a[0] = cx_mul(a[0], t);
@@ -359,12 +405,14 @@ __global__ __launch_bounds__(W12_THREADS) void msd_power_w12_kernel(
         // exchange 1: (n0, n1 | k2) -> (n0, k2 | n1): point n0 + 8 k2 + 64 n1
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        if (!(W12_EXP & 16)) {
 #pragma unroll
         for (int k2 = 0; k2 < 8; ++k2) w12_st(myR + (lane & 7) + 8 * k2 + 64 * (lane >> 3), a[k2]);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int n1 = 0; n1 < 8; ++n1) a[n1] = w12_ld(myR + lane + 64 * n1);
+        }
         if constexpr (SRC == 2) {
             // what this wave stored for the tile staged under the PREVIOUS series has long been issued, and the youngest
             // request in flight (the next series' samples) is a pass old: waiting for everything here is cheap and lets
@@ -372,8 +420,8 @@ __global__ __launch_bounds__(W12_THREADS) void msd_power_w12_kernel(
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         W12_POINT(2);
-        f2_bfly8(a, Cx{1.0, 0.0}, false);
-        {
+        if (!(W12_EXP & 32)) f2_bfly8(a, Cx{1.0, 0.0}, false);
+        if (!(W12_EXP & 32)) {
             const Cx tw_2 = w12_ld(t2tab + (lane & 7));
             Cx t = tw_2;  // w_64^(n0 k1)
             a[1] = cx_mul(a[1], t);
@@ -386,14 +434,16 @@ __global__ __launch_bounds__(W12_THREADS) void msd_power_w12_kernel(
         // exchange 2: (n0, k2 | k1) -> (k1, k2 | n0): point k1 + 8 k2 + 65 n0
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        if (!(W12_EXP & 16)) {
 #pragma unroll
         for (int k1 = 0; k1 < 8; ++k1) w12_st(myR + k1 + 8 * (lane >> 3) + 65 * (lane & 7), a[k1]);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int n0 = 0; n0 < 8; ++n0) a[n0] = w12_ld(myR + lane + 65 * n0);
+        }
         W12_POINT(3);
-        f2_bfly8(a, Cx{1.0, 0.0}, false);
+        if (!(W12_EXP & 32)) f2_bfly8(a, Cx{1.0, 0.0}, false);
         // a[k0] = Z at frequency d + 12 (k2 + 8 k1 + 64 k0), lane = k1 + 8 k2
 #pragma unroll
         for (int k0 = 0; k0 < 8; ++k0) {
@@ -417,11 +467,11 @@ __global__ __launch_bounds__(W12_THREADS) void msd_power_w12_kernel(
         }
         W12_POINT(4);
         if (more) wave_sum(0);
-        __syncthreads();
+        W12_BARRIER(2);
         if constexpr (SRC == 2) {
             if (c > it.c_lo) st_signal(st_i - 1);  // (the prologue signalled its own tiles)
         }
-        if (!self0) {
+        if (!self0 && !(W12_EXP & 8)) {
             Cx pz[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) pz[u] = w12_ld(pR + plane + 64 * (3 - u));  // the partner's register 7 - u
@@ -433,7 +483,7 @@ __global__ __launch_bounds__(W12_THREADS) void msd_power_w12_kernel(
         }
         W12_POINT(5);
         if (more) centre_store(0);
-        __syncthreads();
+        W12_BARRIER(4);
 #undef W12_POINT
     }
     if constexpr (SRC == 2) {

@@ -434,7 +434,7 @@ def test_lag_msd_fft_variant(B):
                 fft = B.lag_msd(r, max_lag, goff, scale=0.5)
                 bound = ctx.last_rel_bound()
                 assert (ctx.last_kernel_name() == "lag_msd_fft") == (variant == 4)
-                assert ctx.last_kernel_name() in ("lag_msd_fft", "msd_power_lds_kernel") and (bound > 0.0) == (max_lag > 0) and bound < 1e-9, (F, bound)
+                assert ctx.last_kernel_name() in ("lag_msd_fft", "msd_power_lds_kernel", "msd_power_w12_kernel") and (bound > 0.0) == (max_lag > 0) and bound < 1e-9, (F, bound)
                 assert fft.shape == exact.shape and (fft[0] == 0.0).all()
                 nz = exact > 0
                 rel = np.abs(fft[nz] - exact[nz]) / exact[nz]
@@ -465,14 +465,16 @@ def test_lag_msd_fft_variant(B):
 
 
 def test_lag_msd_fft_every_transform_size(B):
-    """The fused kernels (lag_fft_kernel 2 = first pass from registers + wave-private sub-transforms where it applies,
-    1 = block-wide passes, 0 = round-2 kernel) over series lengths on both sides of every transform size 2^9 .. 2^13,
-    full and truncated lag ranges (F > N only happens with those), tiny and empty groups: each within the bound the
-    library reports against the difference kernel (hence within twice that of each other)."""
+    """The fused kernels (lag_fft_kernel 3 = the round-5 kernel for padded length 12288 where it applies (F + max_lag in
+    (8192, 12288]), else as 2 = first pass from registers + wave-private sub-transforms where that applies, 1 = block-wide
+    passes, 0 = round-2 kernel) over series lengths on both sides of every transform size 2^9 .. 2^13 and 3 * 2^12, full and
+    truncated lag ranges (F > N only happens with those), tiny and empty groups: each within the bound the library reports
+    against the difference kernel (hence within twice that of each other)."""
     ctx = B.default_context()
     rng = np.random.default_rng(5)
-    cases = [(F, F - 1) for F in (257, 511, 513, 1024, 1025, 2047, 2049, 3000, 4096, 4097, 5000, 8191, 8192)]
-    cases += [(9000, 7000), (12000, 4000), (16000, 300), (6000, 2100), (1000, 20)]
+    cases = [(F, F - 1) for F in (257, 511, 513, 1024, 1025, 2047, 2049, 3000, 4096, 4097, 5000, 5121, 6143, 6144, 6145,
+                                  8191, 8192)]
+    cases += [(9000, 7000), (12000, 4000), (16000, 300), (6000, 2100), (1000, 20), (6200, 6000), (8000, 4288), (4200, 4100)]
     try:
         for F, max_lag in cases:
             E = int(rng.integers(3, 24))
@@ -484,11 +486,12 @@ def test_lag_msd_fft_every_transform_size(B):
             ctx.set_option("lag_variant", 2)
             nz = exact > 0
             outs = []
-            for kern in (2, 1, 0):
+            for kern in (3, 2, 1, 0):
                 ctx.set_option("lag_fft_kernel", kern)
                 fft = B.lag_msd(r, max_lag, goff, scale=0.5)
                 bound = ctx.last_rel_bound()
-                assert ctx.last_kernel_name() == "msd_power_lds_kernel" and bound > 0.0
+                w12 = kern == 3 and 8192 < F + max_lag <= 12288 and (F + 1) // 2 <= 3072
+                assert ctx.last_kernel_name() == ("msd_power_w12_kernel" if w12 else "msd_power_lds_kernel") and bound > 0.0
                 assert (fft[0] == 0.0).all()
                 rel = np.abs(fft[nz] - exact[nz]) / exact[nz]
                 assert rel.max() <= bound, (F, max_lag, kern, rel.max(), bound)
@@ -497,7 +500,7 @@ def test_lag_msd_fft_every_transform_size(B):
                 assert (np.abs(o[nz] - outs[0][0][nz]) / exact[nz]).max() <= b + outs[0][1], (F, max_lag)
     finally:
         ctx.set_option("lag_variant", 1)
-        ctx.set_option("lag_fft_kernel", 2)
+        ctx.set_option("lag_fft_kernel", 3)
 
 
 @pytest.mark.parametrize("mode", [1, 2])
