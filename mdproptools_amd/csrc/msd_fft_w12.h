@@ -288,23 +288,22 @@ __global__ __launch_bounds__(W12_THREADS) void msd_power_w12_kernel(
 
     if constexpr (SRC == 2) {
         // the first ST_AHEAD tiles, before anything is transformed
-        // (one unit at a time, each waited for: the unrolled, software-pipelined form the compiler makes of this loop — eight
-        // loads in flight, stores between them — delivered wrong rows in its fifth load; it runs once per block)
-        int n_ahead = ST_AHEAD * W12_UN;
-        asm volatile("" : "+s"(n_ahead));  // (opaque trip count: no unrolling)
-        for (int u = 0; u < n_ahead; ++u) {
-            const int i = u / W12_UN, r = u % W12_UN;
+        // (a tile at a time: its eight loads, ONE wait for all of them, then its four stores. The form the compiler makes
+        // of the plain loop — units software-pipelined, stores issued between loads still in flight and `s_waitcnt
+        // vmcnt(N)` counting across both — delivered wrong rows in the fifth load of eight on this GPU (every second
+        // 8-lane group got the first group's rows; found with the -DW12_VERIFY build on an integer ramp, never seen in
+        // the series loop, where a wait for everything sits between a unit's loads and the stores behind them): the
+        // prologue runs once per block and simply does not mix the two.)
+        int n_ahead = ST_AHEAD;
+        asm volatile("" : "+s"(n_ahead));  // (opaque trip count: no unrolling across tiles)
+        for (int i = 0; i < n_ahead; ++i) {
             const int lim = st_lim_of(i);
-            const long long T = it.c_lo + i;
-            const unsigned soff = (unsigned)(((size_t)(RPR * r) * (size_t)cols + (size_t)(16 * T)) * 8);
-            const st2u_t a = __builtin_amdgcn_raw_buffer_load_b64(traj, RPR * r < lim ? st_vi : ST_OOB, soff, NT_HINT);
-            const st2u_t b = __builtin_amdgcn_raw_buffer_load_b64(traj, RPR * r + 1 < lim ? st_vi : ST_OOB,
-                                                                 soff + (unsigned)((size_t)cols * 8), NT_HINT);
-            sx = st2_t{__builtin_bit_cast(double, a), __builtin_bit_cast(double, b)};
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(sx)::"memory");
-            const st2_t out = st2_t{sx[0] * scale, sx[1] * scale};
-            const unsigned soff2 = (unsigned)(((size_t)(i & (ST_BUF - 1)) * 16 * (size_t)Fs + (size_t)(RPR * r)) * 8);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(st4_t, out), ring, RPR * r < lim ? st_vo : ST_OOB, soff2, SC1);
+            st2_t u[W12_UN];
+#pragma unroll
+            for (int r = 0; r < W12_UN; ++r) stage_load(i, r, lim, u[r]);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3])::"memory");
+#pragma unroll
+            for (int r = 0; r < W12_UN; ++r) stage_store(i, r, lim, u[r]);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();

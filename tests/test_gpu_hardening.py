@@ -354,3 +354,37 @@ def test_queue_limit_cases_through_the_capacity_check_build():
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "bench", "soak_pk.py"), "60", "17"], cwd=root, env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:]
+
+
+def test_lag_msd_staged_integer_ramp_exact_and_reproducible():
+    """The in-kernel transposition of the round-5 full-lag kernel (msd_fft_w12.h: clusters of workgroups stage their tiles
+    through a ring in device memory) on an input where every wrong sample shows: x[t][column] = 16384 column + t — integers,
+    so every series' mean and every centred sample is exact, MSD(k) = k^2 for every series, and a sample taken from another
+    row or column moves the result by orders of magnitude more than rounding. (A pipelined form of the staging prologue
+    delivered wrong rows on this GPU: found this way.) Against the transposed-copy source, against k^2, and bit-identical
+    from call to call."""
+    import torch
+
+    from mdproptools_amd import backend as B
+    from mdproptools_amd._lib import Context
+
+    ctx = Context(0)
+    try:
+        for F, E in ((5000, 4096), (6144, 1024), (4097, 2048)):
+            t = torch.arange(F, dtype=torch.float64, device="cuda")[:, None, None]
+            c = torch.arange(3 * E, dtype=torch.float64, device="cuda").reshape(1, 3, E)
+            r = (16384.0 * c + t).contiguous()
+            ctx.set_option("lag_variant", 2)
+            ctx.set_option("lag_direct", 0)
+            ref = B.lag_msd(r, F - 1, [0, E], scale=1.0, ctx=ctx)
+            assert ctx.last_kernel_name() == "msd_power_w12_kernel"
+            ctx.set_option("lag_direct", 2)
+            outs = [B.lag_msd(r, F - 1, [0, E], scale=1.0, ctx=ctx) for _ in range(4)]
+            assert ctx.last_kernel_name() == "msd_power_w12_kernel" and ctx.fallbacks() == 0
+            k2 = np.arange(F, dtype=np.float64) ** 2
+            for o in outs:
+                np.testing.assert_array_equal(o, outs[0])
+                np.testing.assert_allclose(o[1:, 0, :3], ref[1:, 0, :3], rtol=5e-12)
+                np.testing.assert_allclose(o[1:, 0, 0], k2[1:], rtol=1e-9)
+    finally:
+        ctx.close()
