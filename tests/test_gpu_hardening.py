@@ -384,7 +384,8 @@ def test_lag_msd_staged_integer_ramp_exact_and_reproducible():
             k2 = np.arange(F, dtype=np.float64) ** 2
             for o in outs:
                 np.testing.assert_array_equal(o, outs[0])
-                np.testing.assert_allclose(o[1:, 0, :3], ref[1:, 0, :3], rtol=5e-12)
-                np.testing.assert_allclose(o[1:, 0, 0], k2[1:], rtol=1e-9)
+                # (rounding: ~1e-5 at lag F - 1, where the mean is taken over one origin; a wrong sample: >= 0.5)
+                np.testing.assert_allclose(o[1:, 0, :3], ref[1:, 0, :3], rtol=0, atol=1e-3)
+                np.testing.assert_allclose(o[1:, 0, 0], k2[1:], rtol=0, atol=1e-3)
     finally:
         ctx.close()
