@@ -104,7 +104,7 @@ def load_json(*parts):
 
 def ubench_rate(inst, waves):
     """Measured issue rate (G wave-instructions/s per SIMD) of `inst` at `waves` per SIMD, tools/ubench_valu.hip."""
-    ub = load_json("profiles", "r02_ubench_valu.json")
+    ub = load_json("profiles", "r05_ubench_valu.json") or load_json("profiles", "r02_ubench_valu.json")
     if not ub:
         return None
     for r in ub["results"]:
@@ -128,7 +128,7 @@ def pmc_entry(kernel, workload):
     return e, None
 
 
-SECONDARY_SOURCES = ["msd.hip", "msd_fft.hip", "segment_com.hip", "xcorr.hip", "fft_pow2.hip", "scan.hip"]
+SECONDARY_SOURCES = ["msd.hip", "msd_fft.hip", "msd_fft_w12.h", "segment_com.hip", "xcorr.hip", "fft_pow2.hip", "scan.hip"]
 LDS_READ_PEAK = 150e12  # ds_read_b64 / b128 aggregate with every CU streaming, MI355X_MICROARCH.md (LDS section)
 
 
@@ -187,40 +187,63 @@ def _lag_fft_lds_sweeps(m):
     return passes + 2.0, 1.0 + passes
 
 
-def lds_roofline_lag_fft(E, F, kernel_s):
-    """
-    Roofline of the default full-lag MSD path (csrc/msd_fft.hip): every series is transformed inside LDS and only sums
-    leave the CU, so the call is bound by the LDS, not by HBM (compulsory 24 E F bytes = 5 % of the HBM rate) and not by
-    FP64 issue. achieved = ALGORITHMIC bytes through LDS per call / kernel time of the WHOLE call (round 4: the power
-    kernel transposes its tiles itself — the staging of the trajectory into time-major rings rides inside that time):
-    per series of padded length L (N = L/2 packed complex points of 16 bytes) the sweeps _lag_fft_lds_sweeps counts,
-    twiddle tables not counted. peak = the guide's ds_read_b64 aggregate, 150 TB/s; stores run at 38-51 TB/s, so the
-    mix's own ceiling (`mix_ceiling`: bytes / (reads / 150 + writes / 45 TB/s)) is what the kernel can approach, and
-    `frac_of_mix_ceiling` the honest fraction. The counters' view — LDS-array busy share and the bank-conflict share of
-    it, for the power kernel alone — rides along from the PMC run.
-    """
-    L = 1
-    while L < 2 * F - 1:
+def lag_fft_plan(F, max_lag=None):
+    """(padded length L, packed points N, kernel) of the fused full-lag path for F frames with lags up to max_lag
+    (mdproptools_amd/csrc/msd_fft.hip: mdhip_lag_msd_fft)."""
+    max_lag = F - 1 if max_lag is None else max_lag
+    L = 16
+    while L < F + max_lag:
         L *= 2
+    if L == 16384 and F + max_lag <= 12288 and 3072 <= F and (F + 1) // 2 <= 3072:
+        return 12288, 6144, "msd_power_w12_kernel"
     N = L // 2
     m = N.bit_length() - 1
-    rd, wr = _lag_fft_lds_sweeps(m)
+    return L, N, "msd_power_lds3_kernel" if m >= 12 else "msd_power_lds2_kernel" if m >= 9 else "msd_power_lds_kernel"
+
+
+def lds_roofline_lag_fft(E, F, kernel_s):
+    """
+    Roofline of the default full-lag MSD path (csrc/msd_fft.hip): every series is transformed inside the CU and only
+    sums leave it (compulsory 24 E F bytes = a few % of the HBM rate).
+    Round 5 (msd_power_w12_kernel, padded length 12288): what binds the kernel is f64 vector ISSUE at its occupancy —
+    three waves per SIMD — so the line is priced as the pair kernels are:
+      achieved = VALU wave-instructions per call (rocprofv3 SQ_INSTS_VALU of the committed PMC run of this call,
+                 used only when it was taken from the present kernel sources) / the call's kernel time, live;
+      peak     = the issue rate tools/ubench_valu.hip measures on this GPU at 3 waves per SIMD for the kernel's own
+                 instruction mix (the counters' f64 add / mul / fma shares, the rest priced as v_lshl_add_u32), x 1024.
+    The LDS view rides along (`lds_*`: algorithmic bytes through LDS per call against the guide's 150 TB/s read peak and
+    against the read/write-mix ceiling bytes / (reads / 150 + writes / 45 TB/s); the counters' LDS-array busy share).
+    Rounds 3-4 (msd_power_lds3_kernel, L = 16384 and the other powers of two): the LDS view is the roofline, as before.
+    """
+    L, N, kernel = lag_fft_plan(F)
+    if kernel == "msd_power_w12_kernel":
+        # per series: the first pass (raw plane: 1 write, 3 reads of the F/2 points that hold data; regions: 1 write, 1
+        # read of N), two register-pass exchanges (1 write + 1 read of N each), partner (N/2 each way)
+        held = (F + 1) // 2
+        rd, wr = 3.0 * held / N + 3.5, 1.0 * held / N + 3.5
+    else:
+        rd, wr = _lag_fft_lds_sweeps(N.bit_length() - 1)
     rd_b, wr_b = 3.0 * E * 16.0 * N * rd, 3.0 * E * 16.0 * N * wr
     lds_bytes = rd_b + wr_b
     ceiling = lds_bytes / (rd_b / LDS_READ_PEAK + wr_b / LDS_WRITE_PEAK)
     e, why = secondary_pmc("lag_fft")
-    out = {"bound": "lds", "kernel": "msd_power_lds3_kernel" if m >= 12 else "msd_power_lds2_kernel" if m >= 9
-           else "msd_power_lds_kernel", "achieved": lds_bytes / kernel_s / 1e12,
-           "peak": LDS_READ_PEAK / 1e12, "unit": "TB/s", "frac": lds_bytes / kernel_s / LDS_READ_PEAK,
+    hbm = {"algorithmic_bytes": 24.0 * E * F, "achieved": 24.0 * E * F / kernel_s / 1e9, "unit": "GB/s",
+           "frac": 24.0 * E * F / kernel_s / HBM_PEAK}
+    lds = {"lds_achieved_tb_s": lds_bytes / kernel_s / 1e12, "lds_frac_of_read_peak": lds_bytes / kernel_s / LDS_READ_PEAK,
            "mix_ceiling": ceiling / 1e12, "frac_of_mix_ceiling": lds_bytes / kernel_s / ceiling,
-           "algorithmic_lds_bytes": lds_bytes, "read_sweeps": rd, "write_sweeps": wr, "padded_length": L,
-           "hbm": {"algorithmic_bytes": 24.0 * E * F, "achieved": 24.0 * E * F / kernel_s / 1e9, "unit": "GB/s",
-                   "frac": 24.0 * E * F / kernel_s / HBM_PEAK},
-           "traffic": None if e is None else e["per_call"].get("hbm_bytes")}
+           "algorithmic_lds_bytes": lds_bytes, "read_sweeps": rd, "write_sweeps": wr, "padded_length": L}
+    if kernel != "msd_power_w12_kernel":
+        out = dict({"bound": "lds", "kernel": kernel, "achieved": lds_bytes / kernel_s / 1e12, "peak": LDS_READ_PEAK / 1e12,
+                    "unit": "TB/s", "frac": lds_bytes / kernel_s / LDS_READ_PEAK}, **lds)
+    else:
+        out = dict({"bound": "valu-issue (f64, 3 waves/SIMD)", "kernel": kernel, "achieved": None, "peak": None,
+                    "unit": "G wave-instructions/s", "frac": None}, **lds)
+    out["hbm"] = hbm
+    out["traffic"] = None if e is None else e["per_call"].get("hbm_bytes")
     if e is None:
         out["note"] = why
         return out
-    k = next((v for name, v in e["kernels"].items() if name.startswith("msd_power_lds")), None)
+    k = next((v for name, v in e["kernels"].items() if name.startswith("msd_power_")), None)
     if k and "SQ_LDS_IDX_ACTIVE" in k and "GRBM_GUI_ACTIVE" in k:
         # SQ_LDS_IDX_ACTIVE: LDS-array cycles summed over the CUs; GRBM_GUI_ACTIVE: chip cycles summed over the 8 XCDs
         cu_cycles = k["GRBM_GUI_ACTIVE"] / 8.0 * 256.0
@@ -229,6 +252,24 @@ def lds_roofline_lag_fft(E, F, kernel_s):
         if "avg_us" in k:
             out["power_kernel_s_in_pmc_run"] = k["avg_us"] * 1e-6
         out["counters_source"] = "profiles/pmc_secondary.json (%s/lag_fft)" % e.get("tag", "")
+    if kernel == "msd_power_w12_kernel" and k and "SQ_INSTS_VALU" in k:
+        insts = float(k["SQ_INSTS_VALU"])
+        n_add, n_mul, n_fma = (float(k.get("SQ_INSTS_VALU_%s_F64" % t, 0.0)) for t in ("ADD", "MUL", "FMA"))
+        rates = {t: ubench_rate(t, 3) for t in ("v_add_f64", "v_mul_f64", "v_fma_f64", "v_lshl_add_u32")}
+        out["instructions_per_call"] = insts
+        out["f64_share_of_valu"] = (n_add + n_mul + n_fma) / insts if insts else None
+        out["achieved"] = insts / kernel_s / 1e9
+        if all(rates.values()):
+            t_simd = (n_add / rates["v_add_f64"] + n_mul / rates["v_mul_f64"] + n_fma / rates["v_fma_f64"]
+                      + max(insts - n_add - n_mul - n_fma, 0.0) / rates["v_lshl_add_u32"])  # G-inst / (G-inst/s) = seconds x SIMDs
+            peak = insts / t_simd * N_SIMD
+            out["peak"] = peak
+            out["frac"] = insts / kernel_s / 1e9 / peak
+            out["valu_issue_frac"] = out["frac"]
+            out["peak_source"] = ("profiles/r05_ubench_valu.json: v_add_f64 / v_mul_f64 / v_fma_f64 / v_lshl_add_u32 at 3 "
+                                  "waves/SIMD, weighted by the counters' instruction shares, x %d SIMDs" % N_SIMD)
+        else:
+            out["note"] = "no issue rates at 3 waves/SIMD (profiles/r05_ubench_valu.json missing)"
     return out
 
 

@@ -1,5 +1,5 @@
 // tools/ubench_valu.hip — issue cost (shader cycles per wave64 instruction per SIMD) of the VALU ops the pair
-// kernels are made of, at 1, 2, 4, 6 and 8 resident waves per SIMD, measured on the box:
+// kernels are made of, at 1, 2, 3, 4, 6 and 8 resident waves per SIMD, measured on the box:
 //
 //   hipcc --offload-arch=gfx950 -O3 -o /tmp/ub tools/ubench_valu.hip && /tmp/ub [json-path]
 //
@@ -232,7 +232,7 @@ int main(int argc, char **argv)
     double *d_sink;
     (void)hipMalloc(&d_out, sizeof(Stamp) * 256 * 8 * 4);
     (void)hipMalloc(&d_sink, 64);
-    const int occ[5] = {1, 2, 4, 6, 8};
+    const int occ[6] = {1, 2, 3, 4, 6, 8};  // (3: the round-5 full-lag MSD kernel, twelve waves per CU)
     std::vector<Result> all;
 #define RUN(K, NAME)                                                  \
     for (int k : occ) all.push_back(run(K, NAME, k, 16.0, d_out, d_sink));
