@@ -293,12 +293,14 @@ struct AsyncCall {
 // defers the long-hand finish: once the call has completed, res->out [max_lag+1][G][4] holds the means (as
 // mdhip_lag_msd) and res->bound the largest estimated relative rounding error over all (lag >= 1, group, axis) entries.
 struct LagFftResult {
-    std::vector<double> out;
+    std::vector<double> out;       // the means, when the path finished on the host (!delivered)
     std::vector<int64_t> group_off;
     double bound = 0.0;
+    bool delivered = false;        // the fused path: finished on the device and copied to the caller's buffer on the stream
 };
 int mdhip_lag_msd_fft(CallScope &cs, int64_t n_frames, int64_t n_ent, const double *d_r, double scale, int max_lag,
-                      int n_groups, const int64_t *group_off, const std::shared_ptr<LagFftResult> &res);
+                      int n_groups, const int64_t *group_off, const std::shared_ptr<LagFftResult> &res, double *out,
+                      int out_on_device);
 
 // Finished values (host memory) on their way to a DEVICE result buffer from inside a completion step. The copy runs on
 // the context's copy stream, not on the launch stream: a later call's kernels may already be queued there (calls are

@@ -838,16 +838,17 @@ static int lag_msd_impl(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const d
     if (rc) return rc;
     ctx->last_rel_bound = 0.0;
     if (variant >= 2 && variant <= 4) {
-        // the spectral path finishes on the host (prefix sums of the squares, S1 - 2 S2, division by the counts, in
-        // long-hand arithmetic over [n_lags][n_groups][4] values) in a completion step; that step also decides whether
-        // the bound it finds is good enough — if not, the exact-difference kernel answers, from inside the step
+        // the spectral path: the fused kernels finish on the device (round 5: prefix sums of the squares, S1 - 2 S2, division
+        // by the counts in double-double arithmetic, msd_fft.hip) and the means are on their way to `out` when this
+        // returns; only the batched path for long series still finishes on the host. The completion step decides
+        // whether the bound is good enough — if not, the exact-difference kernel answers, from inside the step
         auto res = std::make_shared<LagFftResult>();
-        rc = mdhip_lag_msd_fft(cs, n_frames, n_ent, d_r, scale, max_lag, n_groups, group_off, res);
+        rc = mdhip_lag_msd_fft(cs, n_frames, n_ent, d_r, scale, max_lag, n_groups, group_off, res, out, out_on_device);
         if (rc) return rc;
         cs.defer([=]() {
             ctx->last_rel_bound = res->bound;
             if (variant != 3 || res->bound <= 1e-10)
-                return deliver_host_values(ctx, res->out.data(), res_b, out, out_on_device);
+                return res->delivered ? MDHIP_OK : deliver_host_values(ctx, res->out.data(), res_b, out, out_on_device);
             // bound too loose for this data (r and group_off are the caller's: valid until the call has completed)
             const int rc2 = lag_msd_impl(ctx, n_frames, n_ent, r, on_device, scale, max_lag, n_groups,
                                          res->group_off.data(), out, out_on_device, 1);

@@ -1771,11 +1771,128 @@ double finish_on_host(long long F, long long G, long long n_lags, const int64_t 
     return worst;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 5: the finish of the fused path ON THE DEVICE (rounds 2-4: finish_on_host below, in long double, behind a
+// device-to-host copy of Q and the correlations and a host wait in the middle of every call — 0.8 of the 1.03 ms a C4
+// step took on the shard one of eight ranks holds). What the host did with a 64-bit mantissa is done here in
+// double-double (two-sum arithmetic, ~106 bits): prefix sums of the per-frame squares Q, S1(k) = pre[F - k] + (pre[F] -
+// pre[k]), v = S1 - 2 S2, the means v / ((F - k) n_g) and their total (x + y) + z, and the same error bound,
+// eps_l * 2 pre[F] / min |v|. One block per group, the three axes one after the other; pre (hi, lo) in a workspace.
+// -ffp-contract / the pragma above only fuse multiply-adds: the two-sums below hold nothing but additions.
+// ---------------------------------------------------------------------------------------------
+struct DD {
+    double hi, lo;
+};
+__device__ __forceinline__ DD dd_two_sum(double a, double b)
+{
+    const double s = a + b, bb = s - a;
+    return {s, (a - (s - bb)) + (b - bb)};
+}
+__device__ __forceinline__ DD dd_add(DD a, DD b)
+{
+    DD s = dd_two_sum(a.hi, b.hi);
+    const DD t = dd_two_sum(a.lo, b.lo);
+    s.lo += t.hi;
+    s = dd_two_sum(s.hi, s.lo);  // (fast two-sum would do: |hi| >= |lo|)
+    s.lo += t.lo;
+    return dd_two_sum(s.hi, s.lo);
+}
+__device__ __forceinline__ DD dd_add_d(DD a, double b)
+{
+    DD s = dd_two_sum(a.hi, b);
+    s.lo += a.lo;
+    return dd_two_sum(s.hi, s.lo);
+}
+__device__ __forceinline__ DD dd_neg(DD a) { return {-a.hi, -a.lo}; }
+
+// Q [3 G][F], corr [3 G][corr_row] (S2(k) = corr * corr_scale), n_g [G] entities per group -> out [n_lags][G][4] (device:
+// components 0..2 here, their total by lag_total_kernel), bound [3 G]; pre: workspace [3 G][F + 1] of DD.
+// One block per (axis, group) segment.
+__global__ __launch_bounds__(256) void lag_finish_dd_kernel(const double *__restrict__ Q, const double *__restrict__ corr,
+                                                           long long corr_row, double corr_scale, long long F, long long n_lags,
+                                                           int G, const double *__restrict__ n_g, double eps_l,
+                                                           DD *__restrict__ pre_ws, double *__restrict__ out,
+                                                           double *__restrict__ bound)
+{
+    __shared__ DD wtot[4];
+    __shared__ double vmin_s[4];
+    const int s = blockIdx.x, a = s / G, g = s % G, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const double ng = n_g[g];
+    const long long chunk = (F + 255) / 256;
+    const double *q = Q + (size_t)s * F;
+    DD *pre = pre_ws + (size_t)s * (F + 1);
+    const long long i0 = (long long)tid * chunk, i1 = i0 + chunk < F ? i0 + chunk : F;
+    DD acc = {0.0, 0.0};
+    for (long long i = i0; i < i1; ++i) acc = dd_add_d(acc, q[i]);
+    // inclusive scan of the 256 chunk sums: inside the wave by shuffles, the four wave totals in order
+    DD incl = acc;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const DD up = {__shfl_up(incl.hi, d, 64), __shfl_up(incl.lo, d, 64)};
+        if (lane >= d) incl = dd_add(up, incl);
+    }
+    if (lane == 63) wtot[wv] = incl;
+    __syncthreads();
+    DD before = {0.0, 0.0};
+    for (int w = 0; w < wv; ++w) before = dd_add(before, wtot[w]);
+    DD tot = before;
+    for (int w = wv; w < 4; ++w) tot = dd_add(tot, wtot[w]);
+    // exclusive prefix of this thread's chunk = before + (incl - acc): recomputed as before + (sum of the lanes below)
+    DD run = before;
+    {
+        const DD below = {__shfl_up(incl.hi, 1, 64), __shfl_up(incl.lo, 1, 64)};
+        if (lane > 0) run = dd_add(before, below);
+    }
+    for (long long i = i0; i < i1; ++i) {
+        pre[i] = run;
+        run = dd_add_d(run, q[i]);
+    }
+    if (tid == 255) pre[F] = tot;
+    __threadfence_block();
+    __syncthreads();
+    double vmin = 0.0;  // smallest non-zero |S1 - 2 S2| over the lags k > 0
+    for (long long k = tid; k < n_lags; k += 256) {
+        const DD s1 = dd_add(pre[F - k], dd_add(tot, dd_neg(pre[k])));
+        const double s2 = corr[(size_t)s * corr_row + k] * corr_scale;
+        const DD vd = dd_add_d(s1, -2.0 * s2);
+        double v = vd.hi + vd.lo;
+        if (k == 0) v = 0.0;  // exactly, as the difference form gives
+        const double cnt = (double)(F - k) * ng;
+        out[((size_t)k * G + g) * 4 + a] = cnt > 0.0 ? v / cnt : 0.0;
+        const double av = fabs(v);
+        if (k > 0 && av != 0.0 && (vmin == 0.0 || av < vmin)) vmin = av;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const double other = __shfl_down(vmin, o, 64);
+        if (other != 0.0 && (vmin == 0.0 || other < vmin)) vmin = other;
+    }
+    if (lane == 0) vmin_s[wv] = vmin;
+    __syncthreads();
+    if (tid == 0) {
+        double m = 0.0;
+        for (int w = 0; w < 4; ++w)
+            if (vmin_s[w] != 0.0 && (m == 0.0 || vmin_s[w] < m)) m = vmin_s[w];
+        // the transform's rounding error in S2(k) scales with the energy of the WHOLE series at every lag: the worst
+        // relative error is at the lag with the smallest |v| (see finish_on_host)
+        bound[s] = m > 0.0 ? eps_l * (2.0 * (tot.hi + tot.lo)) / m : 0.0;
+    }
+}
+
+// out[k][g][3] = (x + y) + z
+__global__ void lag_total_kernel(double *__restrict__ out, long long n)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[4 * i + 3] = (out[4 * i] + out[4 * i + 1]) + out[4 * i + 2];
+}
+
 // The fused LDS path: L = 2^(m+1) <= 16384.
 // w12 (round 5): N = 6144 = 12 x 512, L = 12288 (msd_fft_w12.h) instead of N = 2^m; `m` is ignored then.
+// The means go to `out` (host or device memory) from here: finished on the device, copied on the stream; res->bound is
+// known when the call has completed.
 int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r, double scale, int max_lag,
                       long long G, const int64_t *group_off, int m, const std::shared_ptr<LagFftResult> &res,
-                      int src_want = -1 /* -1: the context's option lag_direct */, bool w12 = false)
+                      double *out, int out_on_device, int src_want = -1 /* -1: the context's option lag_direct */,
+                      bool w12 = false)
 {
     mdhip_ctx *ctx = cs.ctx;
     const long long n_lags = (long long)max_lag + 1, cols = 3 * E, S = 3 * G;
@@ -1857,7 +1974,7 @@ int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r
         }
         if (!enough || given != n_clusters) {
             // more non-empty segments than clusters: this shape keeps the transposed path (re-enter without `direct`)
-            return lag_msd_fft_fused(cs, F, E, d_r, scale, max_lag, G, group_off, m, res, 0, w12);
+            return lag_msd_fft_fused(cs, F, E, d_r, scale, max_lag, G, group_off, m, res, out, out_on_device, 0, w12);
         }
         // rows (= Qpart / Ppart rows, consecutive per segment): cluster q, member k -> row 16 q + k
         std::vector<FftItem> rows;
@@ -1935,10 +2052,10 @@ int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r
     double *d_Qpart = d_part, *d_Ppart = d_part + (size_t)n_items * F;
     const size_t q_b = (size_t)S * F * 8, p_b = (size_t)S * (N + 1) * 8, c_b = (size_t)S * n_lags * 8;
     const size_t it_b = (size_t)n_items * sizeof(FftItem), so_b = (((size_t)S + 1) * 4 + 7) / 8 * 8;
-    const size_t sg_b = stages.size() * sizeof(FftStage);
+    const size_t sg_b = (stages.size() * sizeof(FftStage) + 7) / 8 * 8, ng_b = (size_t)G * 8;
     // ready counters of the rings, a 128-byte line each, and the stall word behind them
     const size_t rd_b = staged ? ((size_t)n_clusters * ST_BUF * ST_FLAG_STRIDE + ST_FLAG_STRIDE) * 4 : 0;
-    MD_WS(d_small, unsigned char, WS_AUX3, q_b + p_b + c_b + 4096 + it_b + so_b + sg_b + rd_b + 256);
+    MD_WS(d_small, unsigned char, WS_AUX3, q_b + p_b + c_b + 4096 + it_b + so_b + sg_b + ng_b + rd_b + 256);
     double *d_Q = reinterpret_cast<double *>(d_small);
     double *d_P = reinterpret_cast<double *>(d_small + q_b);
     double *d_corr = reinterpret_cast<double *>(d_small + q_b + p_b);
@@ -1946,17 +2063,20 @@ int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r
     FftItem *d_items = reinterpret_cast<FftItem *>(d_small + q_b + p_b + c_b + 4096);
     int *d_seg_off = reinterpret_cast<int *>(d_small + q_b + p_b + c_b + 4096 + it_b);
     FftStage *d_stages = reinterpret_cast<FftStage *>(d_small + q_b + p_b + c_b + 4096 + it_b + so_b);
+    double *d_ng = reinterpret_cast<double *>(d_small + q_b + p_b + c_b + 4096 + it_b + so_b + sg_b);  // entities per group
     // (on a 128-byte boundary: d_small is, and so is everything in front once rounded up)
-    const size_t rd_off = (q_b + p_b + c_b + 4096 + it_b + so_b + sg_b + 127) / 128 * 128;
+    const size_t rd_off = (q_b + p_b + c_b + 4096 + it_b + so_b + sg_b + ng_b + 127) / 128 * 128;
     unsigned *d_ready = reinterpret_cast<unsigned *>(d_small + rd_off);
     {
         // twiddles | items | segment offsets | stages: one pinned staging block (the vectors above are locals), one copy
-        MD_PIN(h_tab, unsigned char, 4096 + it_b + so_b + sg_b);
+        MD_PIN(h_tab, unsigned char, 4096 + it_b + so_b + sg_b + ng_b);
         memcpy(h_tab, tab.data(), 4096);
         memcpy(h_tab + 4096, items.data(), it_b);
         memcpy(h_tab + 4096 + it_b, seg_off.data(), ((size_t)S + 1) * 4);
-        if (sg_b) memcpy(h_tab + 4096 + it_b + so_b, stages.data(), sg_b);
-        MD_HIP(hipMemcpyAsync(d_tab, h_tab, 4096 + it_b + so_b + sg_b, hipMemcpyHostToDevice, ctx->stream));
+        if (!stages.empty()) memcpy(h_tab + 4096 + it_b + so_b, stages.data(), stages.size() * sizeof(FftStage));
+        double *h_ng = reinterpret_cast<double *>(h_tab + 4096 + it_b + so_b + sg_b);
+        for (long long g = 0; g < G; ++g) h_ng[g] = (double)(group_off[g + 1] - group_off[g]);
+        MD_HIP(hipMemcpyAsync(d_tab, h_tab, 4096 + it_b + so_b + sg_b + ng_b, hipMemcpyHostToDevice, ctx->stream));
         if (staged) MD_HIP(hipMemsetAsync(d_ready, 0, rd_b, ctx->stream));
     }
 
@@ -2087,14 +2207,26 @@ int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r
     timer.stop();
     ctx->last_kernel = w12 ? "msd_power_w12_kernel" : "msd_power_lds_kernel";
 
-    // Q and the correlations come back through pinned staging (d_Q | d_P | d_corr are one buffer: Q and corr are
-    // fetched separately, P stays); the long-hand finish runs on the host once they are there
-    MD_PIN(h_Q, double, q_b);
-    MD_PIN(h_corr, double, c_b);
-    MD_PIN(h_stall, unsigned, 4);
+    // the finish, on the device (lag_finish_dd_kernel): means into `d_fin`, from there to the caller's buffer on the
+    // stream; only the bound of every group (and the ring's stall word) comes back for the completion step
+    const size_t fin_b = (size_t)n_lags * G * 4 * 8;
+    MD_WS(d_fin_ws, unsigned char, WS_OUT3, fin_b + (size_t)S * 8 + (size_t)S * (F + 1) * sizeof(DD) + 64);
+    double *d_fin = reinterpret_cast<double *>(d_fin_ws), *d_bound = d_fin + (size_t)n_lags * G * 4;
+    DD *d_pre = reinterpret_cast<DD *>(d_bound + S);
+    const double eps_l = 4.0 * 2.220446049250313e-16 * std::log2((double)L);
+    hipLaunchKernelGGL(lag_finish_dd_kernel, dim3((unsigned)S), dim3(256), 0, ctx->stream, d_Q, d_corr, n_lags, 1.0, F, n_lags,
+                       (int)G, d_ng, eps_l, d_pre, d_fin, d_bound);
+    hipLaunchKernelGGL(lag_total_kernel, dim3((unsigned)((n_lags * G + 255) / 256)), dim3(256), 0, ctx->stream, d_fin,
+                       n_lags * G);
+    MD_HIP(hipGetLastError());
+    {
+        const int rcr = mdhip_result(cs, out, d_fin, fin_b, out_on_device);
+        if (rcr) return rcr;
+    }
+    MD_PIN(h_bound, double, (size_t)S * 8 + 8);
+    unsigned *h_stall = reinterpret_cast<unsigned *>(h_bound + S);
     *h_stall = 0u;
-    MD_HIP(hipMemcpyAsync(h_Q, d_Q, q_b, hipMemcpyDeviceToHost, ctx->stream));
-    MD_HIP(hipMemcpyAsync(h_corr, d_corr, c_b, hipMemcpyDeviceToHost, ctx->stream));
+    MD_HIP(hipMemcpyAsync(h_bound, d_bound, (size_t)S * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (staged)
         MD_HIP(hipMemcpyAsync(h_stall, d_ready + (size_t)n_clusters * ST_BUF * ST_FLAG_STRIDE, 4, hipMemcpyDeviceToHost,
                               ctx->stream));
@@ -2102,18 +2234,22 @@ int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r
         timer.collect();
         if (*h_stall) {
             // a cluster member never ran (the grid was not resident as a whole): the same call over the transposed copy,
-            // inside a synchronous call of its own (d_r is the caller's, or the call's staging: valid until completion)
+            // inside a synchronous call of its own (d_r is the caller's, or the call's staging: valid until completion);
+            // it writes `out` again
             ++ctx->cur_fallbacks;  // visible: mdhip_ticket_status / mdhip_fallbacks (the 2 s poll is otherwise silent)
             ++ctx->fallbacks_total;
             CallScope again(ctx);
-            const int rc2 = lag_msd_fft_fused(again, F, E, d_r, scale, max_lag, G, res->group_off.data(), m, res, 0, w12);
+            const int rc2 = lag_msd_fft_fused(again, F, E, d_r, scale, max_lag, G, res->group_off.data(), m, res, out,
+                                              out_on_device, 0, w12);
             if (rc2 != MDHIP_OK) return rc2;
             const int rc3 = again.end();
             ctx->last_kernel = w12 ? "msd_power_w12_kernel (repeated over the transposed copy: a cluster member did not run)"
                                    : "msd_power_lds_kernel (repeated over the transposed copy: a cluster member did not run)";
             return rc3;
         }
-        res->bound = finish_on_host(F, G, n_lags, res->group_off.data(), h_Q, h_corr, n_lags, 1.0, L, res->out.data());
+        double worst = 0.0;
+        for (long long q = 0; q < S; ++q) worst = std::max(worst, h_bound[q]);
+        res->bound = worst;
         return MDHIP_OK;
     });
     return MDHIP_OK;
@@ -2123,13 +2259,16 @@ int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r
 
 // d_r: device [F][3][E]. out: host [max_lag+1][G][4] means as mdhip_lag_msd. *rel_bound: the largest
 // estimated relative rounding error over all (lag >= 1, group, axis) entries with a non-zero value.
+// The fused path (padded length <= 16384) delivers the means itself (res->delivered); the batched path below finishes
+// on the host and leaves them in res->out for the caller to deliver.
 int mdhip_lag_msd_fft(CallScope &cs, int64_t n_frames, int64_t n_ent, const double *d_r, double scale,
-                      int max_lag, int n_groups, const int64_t *group_off, const std::shared_ptr<LagFftResult> &res)
+                      int max_lag, int n_groups, const int64_t *group_off, const std::shared_ptr<LagFftResult> &res,
+                      double *out, int out_on_device)
 {
     mdhip_ctx *ctx = cs.ctx;
     const long long F = n_frames, E = n_ent, G = n_groups;
     res->group_off.assign(group_off, group_off + n_groups + 1);
-    res->out.assign((size_t)(max_lag + 1) * n_groups * 4, 0.0);
+    res->out.clear();
     res->bound = 0.0;
     const long long n_lags = (long long)max_lag + 1;
     const long long cols = 3 * E;
@@ -2139,13 +2278,18 @@ int mdhip_lag_msd_fft(CallScope &cs, int64_t n_frames, int64_t n_ent, const doub
         while ((2LL << m) < F + max_lag) ++m;
         // round 5: padded length 12288 = 3 * 2^12 where 16384 would be the next power of two (msd_fft_w12.h)
         if (ctx->opt_lag_fft_kernel >= 3 && m == 13 && F + max_lag <= 2 * W12_N && (F + 1) / 2 <= 6 * W12_SUB && F >= 6 * W12_SUB &&
-            w12_lds_bytes(6) <= ctx->lds_max)
-            return lag_msd_fft_fused(cs, F, E, d_r, scale, max_lag, G, group_off, m, res, -1, true);
-        if (m <= FT_MAX_M && ft_lds_bytes(m) <= ctx->lds_max)
-            return lag_msd_fft_fused(cs, F, E, d_r, scale, max_lag, G, group_off, m, res);
+            w12_lds_bytes(6) <= ctx->lds_max) {
+            res->delivered = true;
+            return lag_msd_fft_fused(cs, F, E, d_r, scale, max_lag, G, group_off, m, res, out, out_on_device, -1, true);
+        }
+        if (m <= FT_MAX_M && ft_lds_bytes(m) <= ctx->lds_max) {
+            res->delivered = true;
+            return lag_msd_fft_fused(cs, F, E, d_r, scale, max_lag, G, group_off, m, res, out, out_on_device);
+        }
     }
     const long long L = pow2_length(F + max_lag);
     MD_REQUIRE(L < (1LL << 30), "series too long for the FFT path (%lld)", L);
+    res->out.assign((size_t)(max_lag + 1) * n_groups * 4, 0.0);  // (this path finishes on the host)
     const long long K = L / 2 + 1;
     const long long S = 3 * G;  // (axis, group) segments
 
