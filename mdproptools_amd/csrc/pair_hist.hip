@@ -253,8 +253,19 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
     const size_t cls_b = ((size_t)p.n_ti * p.n_tj + 63) & ~size_t(63);
     // edges and the class table of every pass: one pinned staging buffer, one H2D copy
     const size_t tab_b = edges_b + (size_t)n_pass * cls_b + cn_b + 8;
-    MD_WS(d_tab, unsigned char, WS_TABLES, tab_b);
-    MD_PIN(h_tab, unsigned char, tab_b);
+    // The common case of the scalar-j sweep — one class pass, frame-summed rows — needs two more small things that a
+    // C2 step paid a copy / a fill of their own for (round 5: ~12 us each with the gaps around them): the row map of
+    // derive_rdf_kernel (results left on the device) rides behind the tables in the same copy, and the row sums sit
+    // behind the flag words so that ONE fill empties both.
+    const bool sj_path = cull && ctx->opt_rdf_sj != 0;
+    const bool one_sum = sj_path && n_pass == 1 && !p.per_frame;
+    const int sj_rows1 = ordered ? p.n_ti * p.n_tj : p.n_cls + 1;
+    const size_t rows1_b = one_sum ? (size_t)sj_rows1 * (size_t)(p.nbins + 1 + (p.n_cn ? 1 : 0)) * 8 : 0;
+    const bool map_rides = one_sum && p.dev_out != nullptr;
+    const size_t tab_al = (tab_b + 15) & ~size_t(15);
+    const size_t map_b = map_rides ? ((size_t)sj_rows1 + 2 * (size_t)p.n_rel) * 4 : 0;
+    MD_WS(d_tab, unsigned char, WS_TABLES, tab_al + map_b);
+    MD_PIN(h_tab, unsigned char, tab_al + map_b + 32);
     {
         double *e = reinterpret_cast<double *>(h_tab);
         std::copy(p.edges, p.edges + p.nbins + 1, e);
@@ -288,9 +299,17 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
             }
         }
     }
-    MD_HIP(hipMemcpyAsync(d_tab, h_tab, tab_b, hipMemcpyHostToDevice, ctx->stream));
-    MD_WS(d_misc, unsigned long long, WS_MISC, 64);
-    MD_HIP(hipMemsetAsync(d_misc, 0, 64, ctx->stream));
+    if (map_rides) {
+        int *h_map = reinterpret_cast<int *>(h_tab + tab_al);
+        for (int r = 0; r < sj_rows1; ++r) h_map[r] = ordered ? p.cls[r] : (r < p.n_cls ? r : -1);
+        for (int kl = 0; kl < p.n_rel; ++kl) {
+            h_map[sj_rows1 + kl] = p.rel_cls[kl];
+            h_map[sj_rows1 + p.n_rel + kl] = p.rel_mult[kl];
+        }
+    }
+    MD_HIP(hipMemcpyAsync(d_tab, h_tab, tab_al + map_b, hipMemcpyHostToDevice, ctx->stream));
+    MD_WS(d_misc, unsigned long long, WS_MISC, 64 + rows1_b);
+    MD_HIP(hipMemsetAsync(d_misc, 0, 64 + rows1_b, ctx->stream));
 
     // ---- culled path: Morton sort, tile boxes, neighbour-tile lists (once, shared by all class passes) ----
     const double *k_xi = p.d_xi, *k_xj = p.d_xj;
@@ -376,7 +395,9 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         const size_t words = (size_t)nc * p.nbins;
         const size_t acc_frames = p.per_frame ? (size_t)F : (size_t)slots;
         MD_WS(d_hist, unsigned long long, WS_HIST, (acc_frames + 1) * words * 8);
-        MD_HIP(hipMemsetAsync(d_hist, 0, acc_frames * words * 8, ctx->stream));
+        // (the scalar-j kernels keep their histograms in LDS and store them to their own slices: nothing of theirs is
+        // added to d_hist, so it need not be emptied for them — one fill less per call)
+        if (!(cull && ctx->opt_rdf_sj != 0)) MD_HIP(hipMemsetAsync(d_hist, 0, acc_frames * words * 8, ctx->stream));
 
         PairArgs a;
         a.xi = k_xi;
@@ -463,7 +484,8 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
             if (persist) {
                 launch_grid = std::min(capacity, F * block_items + 8);
                 launch_grid = (launch_grid + 7) / 8 * 8;
-                MD_HIP(hipMemsetAsync(d_misc + 4, 0, 32, ctx->stream));
+                // (the work counters: the first pass finds them empty, d_misc was zeroed whole at the top of the batch)
+                if (pass > 0) MD_HIP(hipMemsetAsync(d_misc + 4, 0, 32, ctx->stream));
             } else {
                 // per-frame output: as many blocks per frame as keeps one resident set busy, each flushing once
                 // blocks per frame: few frames in flight per XCD (their records should stay in its 4 MB L2: 32 B per
@@ -489,9 +511,13 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         unsigned long long *d_rows = nullptr;
         if (sj) {
             MD_WS(d_sl, unsigned, WS_SLICES, (size_t)launch_grid * sj_words * 4);
-            d_rows = (unsigned long long *)mdhip_ws(ctx, WS_ROWS, out_frames * (size_t)sj_words * 8);
-            if (!d_rows) return MDHIP_ENOMEM;
-            if (!p.per_frame) MD_HIP(hipMemsetAsync(d_rows, 0, (size_t)sj_words * 8, ctx->stream));
+            if (one_sum && rows1_b == (size_t)sj_words * 8) {
+                d_rows = d_misc + 8;  // (emptied with the flag words at the top of the batch)
+            } else {
+                d_rows = (unsigned long long *)mdhip_ws(ctx, WS_ROWS, out_frames * (size_t)sj_words * 8);
+                if (!d_rows) return MDHIP_ENOMEM;
+                if (!p.per_frame) MD_HIP(hipMemsetAsync(d_rows, 0, (size_t)sj_words * 8, ctx->stream));
+            }
             a.slices = d_sl;
         }
         KernelTimer timer(ctx);
@@ -523,19 +549,14 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         };
         if (sj && p.dev_out && n_pass == 1 && !p.per_frame) {
             // outputs stay on the device: rows -> full | part | overflow by derive_rdf_kernel (added to dev_out)
-            const size_t tb = ((size_t)sj_rows + 2 * (size_t)p.n_rel) * 4;
-            MD_PIN(h_map, int, tb + 32);
-            for (int r = 0; r < sj_rows; ++r) h_map[r] = ordered ? p.cls[r] : (r < nc ? c0 + r : -1);
-            for (int kl = 0; kl < p.n_rel; ++kl) {
-                h_map[sj_rows + kl] = p.rel_cls[kl];
-                h_map[sj_rows + p.n_rel + kl] = p.rel_mult[kl];
-            }
-            MD_WS(d_map, int, WS_AUX3, tb);
-            MD_HIP(hipMemcpyAsync(d_map, h_map, tb, hipMemcpyHostToDevice, ctx->stream));
+            // (the row map came with the tables, in the copy at the top of the batch: map_rides)
+            if (!map_rides || sj_rows != sj_rows1)
+                return mdhip_fail(ctx, MDHIP_EHIP, "pair_hist: internal: the row map of the device-resident path is missing");
+            const int *d_map = reinterpret_cast<const int *>(d_tab + tab_al);
             launch_derive_rdf(ctx->stream, d_rows, sj_rows, p.nbins, d_map, p.n_rel, d_map + sj_rows,
                               d_map + sj_rows + p.n_rel, d_misc + 3, p.dev_out);
             MD_HIP(hipGetLastError());
-            uint64_t *hlost = reinterpret_cast<uint64_t *>(reinterpret_cast<unsigned char *>(h_map) + ((tb + 7) & ~size_t(7)));
+            uint64_t *hlost = reinterpret_cast<uint64_t *>(h_tab + tab_al + ((map_b + 7) & ~size_t(7)));
             MD_HIP(hipMemcpyAsync(hlost, d_misc + 1, 24, hipMemcpyDeviceToHost, ctx->stream));
             auto fin = [check_flags, collect_times, hlost]() {
                 const int rcf = check_flags(hlost);
@@ -989,8 +1010,11 @@ int run_job(mdhip_ctx *ctx, const RelJob &j, std::vector<uint64_t> &H, std::vect
     memcpy(h_in, idx_i.data(), idx_i.size() * 4);
     memcpy(h_in + ti_b, idx_j.data(), idx_j.size() * 4);
     memcpy(h_in + ti_b + tj_b, j.box, box_b);
-    MD_WS(d_ti, int, WS_TYPE_I, idx_i.size() * 4);
-    MD_HIP(hipMemcpyAsync(d_ti, h_in, idx_i.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    // ONE copy for the three tables (round 5: three copies cost a C2 step ~12 us each, the gaps between a copy and the
+    // kernels around it included): types of set i | types of set j | box lengths, behind each other in one buffer
+    MD_WS(d_in, unsigned char, WS_TYPE_I, ti_b + tj_b + box_b);
+    MD_HIP(hipMemcpyAsync(d_in, h_in, ti_b + tj_b + box_b, hipMemcpyHostToDevice, ctx->stream));
+    int *d_ti = reinterpret_cast<int *>(d_in);
     p.d_ti = d_ti;
     p.ti_fs = j.lab_i_fs;
     if (j.tri) {
@@ -1007,15 +1031,11 @@ int run_job(mdhip_ctx *ctx, const RelJob &j, std::vector<uint64_t> &H, std::vect
             p.d_xj = (const double *)mdhip_stage(ctx, WS_XYZ_J, j.xj, (size_t)j.F * 3 * j.nj * 8, j.xj_dev, &rc);
             if (rc) return rc;
         }
-        MD_WS(d_tj, int, WS_TYPE_J, idx_j.size() * 4);
-        MD_HIP(hipMemcpyAsync(d_tj, h_in + ti_b, idx_j.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-        p.d_tj = d_tj;
+        p.d_tj = reinterpret_cast<int *>(d_in + ti_b);
         p.tj_fs = 0;
         p.nj = j.nj;
     }
-    MD_WS(d_box, double, WS_BOX, (size_t)j.F * 3 * 8);
-    MD_HIP(hipMemcpyAsync(d_box, h_in + ti_b + tj_b, box_b, hipMemcpyHostToDevice, ctx->stream));
-    p.d_box = d_box;
+    p.d_box = reinterpret_cast<double *>(d_in + ti_b + tj_b);
     p.h_box = j.box;
     p.n_frames = j.F;
     p.ni = j.ni;
