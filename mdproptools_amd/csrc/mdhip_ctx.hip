@@ -4,6 +4,10 @@
 #include <cstdlib>
 #include <ctime>
 
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+
 #include "ctx.h"
 
 static thread_local std::string g_create_error;
@@ -324,6 +328,133 @@ int mdhip_deliver_to_device(mdhip_ctx *ctx, void *dst_dev, const void *src_host,
     return MDHIP_OK;
 }
 
+// ---- mdhip_h2d_any: pageable sources through a page-locked ring, copied there by a few helper threads ----
+struct CopyPool {
+    static constexpr int N = 4;
+    struct Job {
+        char *dst = nullptr;
+        const char *src = nullptr;
+        size_t n = 0;
+    };
+    std::thread th[N];
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    Job job[N];
+    unsigned long long gen = 0;
+    int left = 0;
+    bool quit = false;
+    CopyPool()
+    {
+        for (int k = 0; k < N; ++k) th[k] = std::thread([this, k]() { run(k); });
+    }
+    ~CopyPool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            quit = true;
+            ++gen;
+        }
+        cv_go.notify_all();
+        for (auto &t : th) t.join();
+    }
+    void run(int k)
+    {
+        unsigned long long seen = 0;
+        for (;;) {
+            Job j;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_go.wait(lk, [&]() { return gen != seen; });
+                seen = gen;
+                if (quit) return;
+                j = job[k];
+            }
+            if (j.n) memcpy(j.dst, j.src, j.n);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (--left == 0) cv_done.notify_one();
+            }
+        }
+    }
+    // dst[0, n) = src[0, n), split over the helpers; returns when done
+    void copy(void *dst, const void *src, size_t n)
+    {
+        const size_t per = ((n + N - 1) / N + 63) & ~size_t(63);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (int k = 0; k < N; ++k) {
+                const size_t o = std::min(n, per * k), e = std::min(n, per * (k + 1));
+                job[k] = {static_cast<char *>(dst) + o, static_cast<const char *>(src) + o, e - o};
+            }
+            left = N;
+            ++gen;
+        }
+        cv_go.notify_all();
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&]() { return left == 0; });
+    }
+};
+
+static void copy_pool_destroy(mdhip_ctx *ctx)
+{
+    delete ctx->copy_pool;
+    ctx->copy_pool = nullptr;
+    for (int k = 0; k < 2; ++k) {
+        if (ctx->h2d_ring[k]) (void)hipHostFree(ctx->h2d_ring[k]);
+        if (ctx->h2d_ring_ev[k]) (void)hipEventDestroy(ctx->h2d_ring_ev[k]);
+        ctx->h2d_ring[k] = nullptr;
+        ctx->h2d_ring_ev[k] = nullptr;
+    }
+}
+
+int mdhip_h2d_any(mdhip_ctx *ctx, void *dst_dev, const void *src, size_t bytes, hipStream_t stream, int slot)
+{
+    if (bytes == 0) return MDHIP_OK;
+    bool pageable = false;
+    if (ctx->opt_h2d_ring) {
+        hipPointerAttribute_t at;
+        const hipError_t e = hipPointerGetAttributes(&at, src);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();  // (memory the runtime has never seen: ordinary pageable memory)
+            pageable = true;
+        } else {
+            pageable = at.type == hipMemoryTypeUnregistered;
+        }
+    }
+    if (!pageable) {
+        MD_HIP(hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyHostToDevice, stream));
+        return MDHIP_OK;
+    }
+    slot &= 1;
+    if (!ctx->copy_pool) ctx->copy_pool = new CopyPool();
+    if (!ctx->h2d_ring_ev[slot]) MD_HIP(hipEventCreateWithFlags(&ctx->h2d_ring_ev[slot], hipEventDisableTiming));
+    if (ctx->h2d_ring_used[slot]) MD_HIP(hipEventSynchronize(ctx->h2d_ring_ev[slot]));  // (the half's last DMA: long over)
+    if (ctx->h2d_ring_cap[slot] < bytes) {
+        if (ctx->h2d_ring[slot]) MD_HIP(hipHostFree(ctx->h2d_ring[slot]));
+        ctx->h2d_ring[slot] = nullptr;
+        ctx->h2d_ring_cap[slot] = 0;
+        const size_t cap = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+        if (hipHostMalloc(&ctx->h2d_ring[slot], cap, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->h2d_ring[slot] = nullptr;
+            MD_HIP(hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyHostToDevice, stream));  // (no page-locked memory to be had)
+            return MDHIP_OK;
+        }
+        ctx->h2d_ring_cap[slot] = cap;
+    }
+    // chunks of 8 MB: the DMA of chunk c runs while the helpers copy chunk c + 1
+    const size_t chunk = (size_t)8 << 20;
+    char *ring = static_cast<char *>(ctx->h2d_ring[slot]);
+    for (size_t o = 0; o < bytes; o += chunk) {
+        const size_t n = std::min(chunk, bytes - o);
+        ctx->copy_pool->copy(ring + o, static_cast<const char *>(src) + o, n);
+        MD_HIP(hipMemcpyAsync(static_cast<char *>(dst_dev) + o, ring + o, n, hipMemcpyHostToDevice, stream));
+    }
+    MD_HIP(hipEventRecord(ctx->h2d_ring_ev[slot], stream));
+    ctx->h2d_ring_used[slot] = true;
+    return MDHIP_OK;
+}
+
 extern "C" {
 
 int mdhip_version(void) { return MDHIP_VERSION; }
@@ -396,6 +527,7 @@ void mdhip_destroy(mdhip_ctx *ctx)
         (void)hipStreamSynchronize(ctx->copy_stream);
         (void)hipStreamDestroy(ctx->copy_stream);
     }
+    copy_pool_destroy(ctx);
     for (auto &e : ctx->copy_ev)
         if (e) (void)hipEventDestroy(e);
     for (auto &e : ctx->stage_ev)
@@ -609,6 +741,8 @@ int mdhip_set_option(mdhip_ctx *ctx, const char *key, int value)
         ctx->opt_lag_fft_kernel = value;
     else if (!strcmp(key, "h2d_overlap"))
         ctx->opt_h2d_overlap = value;
+    else if (!strcmp(key, "h2d_ring"))
+        ctx->opt_h2d_ring = value;
     else if (!strcmp(key, "lag_direct"))
         ctx->opt_lag_direct = value;
     else if (!strcmp(key, "sync_spin"))

@@ -657,12 +657,18 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
 // records `ev` behind them.
 static int stage_batch_async(mdhip_ctx *ctx, const PairProblem &p, int64_t f0, int64_t n, hipEvent_t ev)
 {
-    if (p.h_xi)
-        MD_HIP(hipMemcpyAsync(const_cast<double *>(p.d_xi) + (size_t)f0 * 3 * p.ni, p.h_xi + (size_t)f0 * 3 * p.ni,
-                              (size_t)n * 3 * p.ni * 8, hipMemcpyHostToDevice, ctx->copy_stream));
-    if (p.h_xj)
-        MD_HIP(hipMemcpyAsync(const_cast<double *>(p.d_xj) + (size_t)f0 * 3 * p.nj, p.h_xj + (size_t)f0 * 3 * p.nj,
-                              (size_t)n * 3 * p.nj * 8, hipMemcpyHostToDevice, ctx->copy_stream));
+    // (pageable sources through the context's page-locked ring: mdhip_h2d_any — the halves alternate with the batches)
+    const int half = ev == ctx->copy_ev[1] ? 1 : 0;
+    if (p.h_xi) {
+        const int rc = mdhip_h2d_any(ctx, const_cast<double *>(p.d_xi) + (size_t)f0 * 3 * p.ni, p.h_xi + (size_t)f0 * 3 * p.ni,
+                                     (size_t)n * 3 * p.ni * 8, ctx->copy_stream, half);
+        if (rc) return rc;
+    }
+    if (p.h_xj) {
+        const int rc = mdhip_h2d_any(ctx, const_cast<double *>(p.d_xj) + (size_t)f0 * 3 * p.nj, p.h_xj + (size_t)f0 * 3 * p.nj,
+                                     (size_t)n * 3 * p.nj * 8, ctx->copy_stream, half);
+        if (rc) return rc;
+    }
     MD_HIP(hipEventRecord(ev, ctx->copy_stream));
     return MDHIP_OK;
 }
@@ -988,7 +994,10 @@ int run_job(mdhip_ctx *ctx, const RelJob &j, std::vector<uint64_t> &H, std::vect
         double *d_x = (double *)mdhip_ws(ctx, stage_buf ? WS_XYZ_I2 : WS_XYZ_I, xb);
         if (!d_x) return MDHIP_ENOMEM;
         if (ctx->stage_used[stage_buf]) MD_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->stage_ev[stage_buf], 0));
-        MD_HIP(hipMemcpyAsync(d_x, j.xi, xb, hipMemcpyHostToDevice, ctx->copy_stream));
+        {
+            const int rch = mdhip_h2d_any(ctx, d_x, j.xi, xb, ctx->copy_stream, stage_buf);
+            if (rch) return rch;
+        }
         MD_HIP(hipEventRecord(ctx->copy_ev[0], ctx->copy_stream));
         MD_HIP(hipStreamWaitEvent(ctx->stream, ctx->copy_ev[0], 0));
         p.d_xi = d_x;
