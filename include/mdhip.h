@@ -390,6 +390,14 @@ int mdhip_msd_windows_async(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, con
                             double scale, int tao, double *win_sums, int out_on_device);
 int mdhip_lag_msd_async(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r, int on_device, double scale,
                         int max_lag, int n_groups, const int64_t *group_off, double *out, int out_on_device);
+/* The STATUS of the mdhip_lag_msd* call issued last on this context, as one number in DEVICE memory, copied to
+ * *dst_dev on the context's stream (behind that call's kernels, no host wait): the relative error bound of the spectral
+ * path (what mdhip_last_rel_bound returns once the call has completed), +infinity when the in-kernel transposition of
+ * that path did not complete (its result is then rewritten when the call completes), 0 when the exact-difference
+ * kernel answered. The multi-GPU step adds this word to the buffer it all-reduces: every rank then knows, from the
+ * reduced value alone, whether the lag sums have to be redone — without a host wait between the kernels and the
+ * collective (mdproptools_amd/dist.py: msd_step_sharded_async). */
+int mdhip_lag_msd_status_dev(mdhip_ctx *ctx, double *dst_dev);
 
 /* ---- G1: per-frame charge flux --------------------------------------------- */
 /*

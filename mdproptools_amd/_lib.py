@@ -115,6 +115,7 @@ PROTOTYPES = {
     "mdhip_msd_windows_async": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, C.c_double, C.c_int, vp, C.c_int]),
     "mdhip_lag_msd_async": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, C.c_double, C.c_int, C.c_int, c_lp,
                                       vp, C.c_int]),
+    "mdhip_lag_msd_status_dev": (C.c_int, [vp, vp]),
     "mdhip_charge_flux_async": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, c_dp, c_dp, C.c_int64, c_lp, c_ip,
                                           C.c_int, C.c_double, C.c_double, vp, C.c_int]),
     "mdhip_xcorr_async": (C.c_int, [vp, C.c_int64, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int64, c_dp]),

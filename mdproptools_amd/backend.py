@@ -386,8 +386,11 @@ def msd_windows(r, tao, scale=1.0, ctx=None, out=None, async_=False):
     return out
 
 
-def lag_msd(r, max_lag, group_off, scale=1.0, ctx=None, out=None, async_=False):
-    """Full lag average (superset): r [F,3,E] -> [max_lag+1, G, 4] (`out`: float64 CUDA tensor of that shape)."""
+def lag_msd(r, max_lag, group_off, scale=1.0, ctx=None, out=None, async_=False, status_out=None):
+    """Full lag average (superset): r [F,3,E] -> [max_lag+1, G, 4] (`out`: float64 CUDA tensor of that shape).
+    `status_out` (asynchronous call with a device result only): a float64 CUDA tensor whose first element receives the
+    call's status on the device, behind its kernels (mdhip_lag_msd_status_dev: the spectral path's error bound, +inf
+    when its result will be rewritten at completion, 0 for the exact path)."""
     ctx = ctx or default_context()
     F, _, E = _shape3(r, "r")
     rp, on_dev, keep = as_input(r, ctx)
@@ -398,7 +401,10 @@ def lag_msd(r, max_lag, group_off, scale=1.0, ctx=None, out=None, async_=False):
         if async_:
             ctx.check(ctx.lib.mdhip_lag_msd_async(ctx.h, F, E, rp, on_dev, float(scale), int(max_lag), G,
                                                   ptr(go, C.c_int64), op, 1))
-            return Pending(ctx, out, keep=(keep, go))
+            pend = Pending(ctx, out, keep=(keep, go, status_out))
+            if status_out is not None:
+                ctx.check(ctx.lib.mdhip_lag_msd_status_dev(ctx.h, _dev_out(status_out, tuple(status_out.shape), ctx=ctx)))
+            return pend
         ctx.check(ctx.lib.mdhip_lag_msd_dev(ctx.h, F, E, rp, on_dev, float(scale), int(max_lag), G,
                                             ptr(go, C.c_int64), op))
         ctx.note_fallbacks()

@@ -209,6 +209,8 @@ struct mdhip_ctx {
                                   // line); 2 = clusters of 16 blocks transpose their tiles inside the kernel through a ring in
                                   // device memory, handed from block to block (5.0 ms; shapes it does not take fall back to 0)
     double last_rel_bound = 0.0;  // error bound reported by the FFT MSD path of the last mdhip_lag_msd call (0: exact path)
+    const double *lag_status_dev = nullptr;  // device word of the last mdhip_lag_msd call issued: its error bound, +inf when
+                                             // the staged kernel's ring stalled; nullptr when the exact path answered
 };
 
 int mdhip_fail(mdhip_ctx *ctx, int code, const char *fmt, ...);

@@ -837,6 +837,7 @@ static int lag_msd_impl(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const d
     const double *d_r = (const double *)mdhip_stage(ctx, WS_XYZ_I, r, r_b, on_device, &rc);
     if (rc) return rc;
     ctx->last_rel_bound = 0.0;
+    ctx->lag_status_dev = nullptr;
     if (variant >= 2 && variant <= 4) {
         // the spectral path: the fused kernels finish on the device (round 5: prefix sums of the squares, S1 - 2 S2, division
         // by the counts in double-double arithmetic, msd_fft.hip) and the means are on their way to `out` when this
@@ -976,6 +977,17 @@ int mdhip_msd_windows_async(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, con
     if (!ctx) return MDHIP_EINVAL;
     AsyncCall mark(ctx);
     return msd_windows_impl(ctx, n_frames, n_ent, r, on_device, scale, tao, win_sums, out_on_device ? 1 : 0);
+}
+
+int mdhip_lag_msd_status_dev(mdhip_ctx *ctx, double *dst_dev)
+{
+    if (!ctx || !dst_dev) return MDHIP_EINVAL;
+    MD_HIP(hipSetDevice(ctx->device));
+    if (ctx->lag_status_dev)
+        MD_HIP(hipMemcpyAsync(dst_dev, ctx->lag_status_dev, 8, hipMemcpyDeviceToDevice, ctx->stream));
+    else
+        MD_HIP(hipMemsetAsync(dst_dev, 0, 8, ctx->stream));
+    return MDHIP_OK;
 }
 
 int mdhip_lag_msd_async(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r, int on_device, double scale,

@@ -1878,11 +1878,20 @@ __global__ __launch_bounds__(256) void lag_finish_dd_kernel(const double *__rest
     }
 }
 
-// out[k][g][3] = (x + y) + z
-__global__ void lag_total_kernel(double *__restrict__ out, long long n)
+// out[k][g][3] = (x + y) + z; bound[S] = the largest of the S segment bounds, or +infinity when the staging ring of the
+// power kernel stalled (`stall` non-null and set): the call's STATUS as one device-resident number, which the multi-GPU
+// step passes through its all-reduce so that every rank learns of a result that must be redone without a host wait
+__global__ void lag_total_kernel(double *__restrict__ out, long long n, double *__restrict__ bound, int S,
+                                 const unsigned *__restrict__ stall)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[4 * i + 3] = (out[4 * i] + out[4 * i + 1]) + out[4 * i + 2];
+    if (i == 0) {
+        double m = 0.0;
+        for (int q = 0; q < S; ++q) m = fmax(m, bound[q]);
+        if (stall && *stall) m = __longlong_as_double(0x7ff0000000000000LL);
+        bound[S] = m;
+    }
 }
 
 // The fused LDS path: L = 2^(m+1) <= 16384.
@@ -2210,14 +2219,16 @@ int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r
     // the finish, on the device (lag_finish_dd_kernel): means into `d_fin`, from there to the caller's buffer on the
     // stream; only the bound of every group (and the ring's stall word) comes back for the completion step
     const size_t fin_b = (size_t)n_lags * G * 4 * 8;
-    MD_WS(d_fin_ws, unsigned char, WS_OUT3, fin_b + (size_t)S * 8 + (size_t)S * (F + 1) * sizeof(DD) + 64);
+    MD_WS(d_fin_ws, unsigned char, WS_OUT3, fin_b + (size_t)(S + 2) * 8 + (size_t)S * (F + 1) * sizeof(DD) + 64);
     double *d_fin = reinterpret_cast<double *>(d_fin_ws), *d_bound = d_fin + (size_t)n_lags * G * 4;
-    DD *d_pre = reinterpret_cast<DD *>(d_bound + S);
+    DD *d_pre = reinterpret_cast<DD *>(d_bound + S + 2);
     const double eps_l = 4.0 * 2.220446049250313e-16 * std::log2((double)L);
     hipLaunchKernelGGL(lag_finish_dd_kernel, dim3((unsigned)S), dim3(256), 0, ctx->stream, d_Q, d_corr, n_lags, 1.0, F, n_lags,
                        (int)G, d_ng, eps_l, d_pre, d_fin, d_bound);
     hipLaunchKernelGGL(lag_total_kernel, dim3((unsigned)((n_lags * G + 255) / 256)), dim3(256), 0, ctx->stream, d_fin,
-                       n_lags * G);
+                       n_lags * G, d_bound, (int)S,
+                       staged ? d_ready + (size_t)n_clusters * ST_BUF * ST_FLAG_STRIDE : (const unsigned *)nullptr);
+    ctx->lag_status_dev = d_bound + S;  // (mdhip_lag_msd_status_dev: valid until the next call that uses WS_OUT3)
     MD_HIP(hipGetLastError());
     {
         const int rcr = mdhip_result(cs, out, d_fin, fin_b, out_on_device);

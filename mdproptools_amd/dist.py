@@ -760,14 +760,62 @@ def release_step_stream(ctx):
         ctx.set_stream(None)
 
 
-def _allreduce_inplace(t):
+_LAGW = {}
+
+
+def _lag_weights(origins, g_hi, g_lo, held, dev):
+    """[n_lags, len(held)] origins x entities of this rank's part of every held group, on the device (kept from step to
+    step: a fresh tensor would be a synchronous copy from pageable memory in every step)."""
+    key = (dev.index, len(origins), tuple(int(g_hi[g] - g_lo[g]) for g in held))
+    w = _LAGW.get(key)
+    if w is None:
+        if len(_LAGW) > 16:
+            _LAGW.clear()
+        w = _LAGW[key] = torch_from(origins * (g_hi[held] - g_lo[held]).astype(np.float64)[None, :], dev)
+    return w
+
+
+def torch_from(a, dev):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _pinned_like(t):
+    """A page-locked host tensor of t's size (torch's caching host allocator: recycled once the step's results — numpy
+    views that keep the tensor alive — are dropped) and its numpy view. Page-locked as TORCH knows it: a non_blocking
+    copy into memory torch does not know to be page-locked is a synchronous one."""
+    import torch
+
+    ht = torch.empty(int(t.numel()), dtype=t.dtype, pin_memory=True)
+    return ht.numpy(), ht
+
+
+_POST_GROUP = {}
+
+
+def _post_group():
+    """A second communicator for the all-reduce that ENDS a fused step. Collectives of one communicator run in the order
+    they were issued; a step's all-reduce is issued (queued behind the step's kernels) before the next step's all-gather,
+    so on ONE communicator the next step's pre-exchange — and with it the next step's kernels — would wait for this
+    step's kernels, post-processing and collective: no pipelining (measured on the shard of 8: 1.25 ms per step against
+    0.95). Created collectively by the first fused step of every rank."""
+    d = _dist()
+    key = id(d.group.WORLD)
+    g = _POST_GROUP.get(key)
+    if g is None:
+        g = _POST_GROUP[key] = d.new_group(backend=d.get_backend())
+    return g
+
+
+def _allreduce_inplace(t, group=None):
     """Sum `t` (a CUDA tensor) over the ranks, in place: RCCL on the tensor itself, gloo through a host copy."""
     d = _dist()
     if d.get_backend() == "nccl":
-        d.all_reduce(t, op=d.ReduceOp.SUM)
+        d.all_reduce(t, op=d.ReduceOp.SUM, group=group)
         return
     c = t.cpu()
-    d.all_reduce(c, op=d.ReduceOp.SUM)
+    d.all_reduce(c, op=d.ReduceOp.SUM, group=group)
     t.copy_(c)
 
 
@@ -875,9 +923,12 @@ def msd_step_sharded_async(r_f, r_e, n_frames_total, entity_range, group_off, ta
             if len(kept_of(*blocks[q])):
                 halo = allf[q, 1]
                 break
-        # (+ 1: the last element is a failure flag — a rank whose local calls raised still takes part in the all-reduce
-        # and every rank raises after it, instead of the others waiting in the collective until it times out)
-        res = torch.zeros(nS + nW + nL + 1, dtype=torch.float64, device=dev)
+        # (+ 2: a failure flag — a rank whose local calls raised still takes part in the all-reduce and every rank raises
+        # after it, instead of the others waiting in the collective until it times out — and the STATUS of the lag call
+        # (mdhip_lag_msd_status_dev: its error bound, +inf when its result will be rewritten at completion), which
+        # every rank reads from the reduced buffer: whether the lag sums must be redone is agreed on without a host
+        # wait between the kernels and the collective)
+        res = torch.zeros(nS + nW + nL + 2, dtype=torch.float64, device=dev)
         single = res[:nS].view(F, G, 4)
         win = res[nS:nS + nW].view(E, 4)
         lagsum = res[nS + nW:nS + nW + nL].view(n_lags, G, 4)
@@ -887,15 +938,35 @@ def msd_step_sharded_async(r_f, r_e, n_frames_total, entity_range, group_off, ta
         if held and F > 0:
             loc_off = np.array([g_lo[held[0]]] + [g_hi[g] for g in held], dtype=np.int64)
             x = r_e[:, :, int(loc_off[0]):int(loc_off[-1])].contiguous()
+        # One host wait per step (round 5): the fused spectral lag path finishes on the device, so everything behind the
+        # three calls — the halo window, the weighting of the lag means, the all-reduce, the copy to the host — is QUEUED
+        # here, at issue time, and finish() only waits for the copy. (Series too long for the fused path, F + max_lag >
+        # 16384, still finish on the host: the round-4 order, two waits.)
+        # Measured on ONE GPU with the shards one of eight / four ranks holds, both orders in the same process (tools/
+        # c4_shard_cost.py, C4_ORDER=two|one, profiles/r05_c4_shard.txt): 1.17 against 1.16 ms per step at 8, 2.01 against
+        # 1.83 at 4 — boxes differ by more than that between leases, so orders are compared inside one run. On a
+        # multi-GPU node the single wait also covers the collective's wire time. MDHIP_STEP_ONE_WAIT=0 restores round 4's order.
+        one_wait = on_gpu and F + max_lag <= 16384 and os.environ.get("MDHIP_STEP_ONE_WAIT", "1") != "0"
+        issue_err = None
         if on_gpu:
-            if hi > lo:
-                hs["single"] = backend.msd_origin(r_f, r0, goff, scale=scale, out=single[lo:hi], ctx=ctx, async_=True)
-            if len(kept_local):
-                hs["fixed"] = backend.msd_windows(r_f[k0:], tao, scale=scale, out=win, ctx=ctx, async_=True)
-            if x is not None:
-                means = torch.empty((n_lags, len(held), 4), dtype=torch.float64, device=dev)
-                hs["lag"] = backend.lag_msd(x, max_lag, loc_off - loc_off[0], scale=lag_scale, out=means, ctx=ctx,
-                                            async_=True)
+            try:
+                if hi > lo:
+                    hs["single"] = backend.msd_origin(r_f, r0, goff, scale=scale, out=single[lo:hi], ctx=ctx, async_=True)
+                if len(kept_local):
+                    hs["fixed"] = backend.msd_windows(r_f[k0:], tao, scale=scale, out=win, ctx=ctx, async_=True)
+                if x is not None:
+                    means = torch.empty((n_lags, len(held), 4), dtype=torch.float64, device=dev)
+                    if one_wait:
+                        ctx.set_option("lag_variant", 2)  # (the spectral path, no host-side fallback: the status word decides)
+                    try:
+                        hs["lag"] = backend.lag_msd(x, max_lag, loc_off - loc_off[0], scale=lag_scale, out=means, ctx=ctx,
+                                                    async_=True, status_out=res[nS + nW + nL + 1:] if one_wait else None)
+                    finally:
+                        if one_wait:
+                            ctx.set_option("lag_variant", -1)
+            except Exception as e:  # (this rank still takes part in the all-reduce; every rank raises behind it)
+                issue_err = e
+                res[nS + nW + nL] = 1.0
         else:
             if hi > lo:
                 single[lo:hi] = torch.as_tensor(compute["origin"](r_f.numpy(), r0.numpy(), goff, scale))
@@ -903,39 +974,102 @@ def msd_step_sharded_async(r_f, r_e, n_frames_total, entity_range, group_off, ta
                 win.copy_(torch.as_tensor(compute["windows"](r_f[k0:].numpy(), tao, scale)))
             if x is not None:
                 means = torch.as_tensor(np.asarray(compute["lag"](x.numpy(), max_lag, loc_off - loc_off[0], lag_scale)))
-    keep = (r_f, r_e, allf, r0, x)  # what the queued kernels read stays alive until the step has been waited for
+
+        def post_ops():
+            """What follows the kernels on the device: the halo window, the lag sums (stream-ordered behind the calls)."""
+            if len(kept_local) and halo is not None:
+                # the one window that reaches back to the rank below: three planes of arithmetic (the kernel's
+                # operations: scale, subtract, square, (dx2 + dy2) + dz2)
+                d2 = (r_f[k0] * scale - halo * scale) ** 2
+                win.add_(torch.stack([d2[0], d2[1], d2[2], (d2[0] + d2[1]) + d2[2]], dim=1))
+            if means is not None:
+                w = _lag_weights(origins, g_hi, g_lo, held, dev)
+                if len(held) == G:
+                    lagsum.copy_(means * w[:, :, None])
+                else:
+                    lagsum[:, torch.as_tensor(held, device=dev), :] = means * w[:, :, None]
+
+        ev_done, flat_t, flat_np = None, None, None
+        if one_wait:
+            ev_k = torch.cuda.Event()
+            ev_k.record(torch.cuda.current_stream(dev))
+            s2 = _step_stream(dev, ctx, post=True)
+            s2.wait_event(ev_k)
+            # (on the second stream: the next step's kernels queue behind this step's KERNELS only, not behind its dozen
+            # small operations and its collective; everything these read is held by this step until finish())
+            with torch.cuda.stream(s2):
+                if issue_err is None:
+                    post_ops()
+                if world > 1:
+                    _allreduce_inplace(res, _post_group())
+                flat_np, flat_t = _pinned_like(res)
+                flat_t.copy_(res, non_blocking=True)
+                ev_done = torch.cuda.Event()
+                ev_done.record(s2)
+    keep = (r_f, r_e, allf, r0, x, means)  # what the queued kernels read stays alive until the step has been waited for
 
     def finish():
-        # On a stream of its own: the next step's kernels may already be queued on the issue stream, and nothing
-        # here has to wait for them (what it reads is complete: the calls are waited for first).
-        with (torch.cuda.stream(_step_stream(dev, ctx, post=True)) if on_gpu else contextlib.nullcontext()):
-            err = None
+        if one_wait:
+            ev_done.synchronize()  # THE host wait of the step
+            flat = flat_np
+            err = issue_err
             try:
                 for key, h in hs.items():
-                    h.wait()  # the calls have completed: `means` is in place (the spectral path's finish ran here)
+                    h.wait()  # (complete: the status of each call, its times)
                     stats[key] = h.stats()
-                if len(kept_local) and halo is not None:
-                    # the one window that reaches back to the rank below: three planes of arithmetic (the kernel's
-                    # operations: scale, subtract, square, (dx2 + dy2) + dz2)
-                    d2 = (r_f[k0] * scale - halo * scale) ** 2
-                    win.add_(torch.stack([d2[0], d2[1], d2[2], (d2[0] + d2[1]) + d2[2]], dim=1))
-                if means is not None:
-                    w = torch.from_numpy(origins * (g_hi[held] - g_lo[held]).astype(np.float64)[None, :]).to(dev)
-                    if len(held) == G:
-                        lagsum.copy_(means * w[:, :, None])
-                    else:
-                        lagsum[:, torch.as_tensor(held, device=dev), :] = means * w[:, :, None]
-            except Exception as e:  # agreed on THROUGH the all-reduce (no collective of its own)
-                err = e
-                res[-1] = 1.0
-            if world > 1:
-                _allreduce_inplace(res)
-            flat = res.cpu().numpy()
+            except Exception as e:
+                err = err or e
             if err is not None:
                 raise err
-            if flat[-1] != 0.0:
+            if flat[nS + nW + nL] != 0.0:
                 raise RuntimeError("%d rank(s) failed on their share of the MSD step; this rank stops with them"
-                                   % int(round(flat[-1])))
+                                   % int(round(flat[nS + nW + nL])))
+            status = flat[nS + nW + nL + 1]  # (the SUM of the ranks' bounds: at least the largest of them)
+            if not (status <= 1e-10):
+                # some rank's spectral result is not good enough (or was rewritten at completion): every rank sees the same
+                # reduced status, so every rank repeats the lag part with the exact-difference kernel, together
+                flat = flat.copy()
+                lag_part = torch.zeros(nL, dtype=torch.float64, device=dev)
+                with torch.cuda.stream(_step_stream(dev, ctx, post=True)):
+                    if x is not None:
+                        ctx.set_option("lag_variant", 1)
+                        try:
+                            m2 = torch.empty((n_lags, len(held), 4), dtype=torch.float64, device=dev)
+                            backend.lag_msd(x, max_lag, loc_off - loc_off[0], scale=lag_scale, out=m2, ctx=ctx)
+                        finally:
+                            ctx.set_option("lag_variant", -1)
+                        w = _lag_weights(origins, g_hi, g_lo, held, dev)
+                        lv = lag_part.view(n_lags, G, 4)
+                        if len(held) == G:
+                            lv.copy_(m2 * w[:, :, None])
+                        else:
+                            lv[:, torch.as_tensor(held, device=dev), :] = m2 * w[:, :, None]
+                    if world > 1:
+                        _allreduce_inplace(lag_part)
+                    flat[nS + nW:nS + nW + nL] = lag_part.cpu().numpy()
+                stats["lag_redone"] = float(status)
+        else:
+            # On a stream of its own: the next step's kernels may already be queued on the issue stream, and nothing
+            # here has to wait for them (what it reads is complete: the calls are waited for first).
+            with (torch.cuda.stream(_step_stream(dev, ctx, post=True)) if on_gpu else contextlib.nullcontext()):
+                err = issue_err
+                try:
+                    if err is None:
+                        for key, h in hs.items():
+                            h.wait()  # the calls have completed: `means` is in place (the batched path's finish ran here)
+                            stats[key] = h.stats()
+                        post_ops()
+                except Exception as e:  # agreed on THROUGH the all-reduce (no collective of its own)
+                    err = e
+                    res[nS + nW + nL] = 1.0
+                if world > 1:
+                    _allreduce_inplace(res)
+                flat = res.cpu().numpy()
+                if err is not None:
+                    raise err
+                if flat[nS + nW + nL] != 0.0:
+                    raise RuntimeError("%d rank(s) failed on their share of the MSD step; this rank stops with them"
+                                       % int(round(flat[nS + nW + nL])))
         assert keep is not None
         single_h = flat[:nS].reshape(F, G, 4)
         win_h = flat[nS:nS + nW].reshape(E, 4)
