@@ -463,3 +463,69 @@ def test_dropped_handles_leave_nothing_dangling(env):
     finally:
         c2.close()  # completes the dropped call into arrays the context still holds
     assert c2._live == {}
+
+
+def test_lag_status_word_on_the_device(env):
+    """mdhip_lag_msd_status_dev: the status of the lag call issued last, as a number in device memory behind the call's
+    kernels — the spectral path's bound for diffusive data, a bound above the tolerance for ballistic data (where the
+    library itself then answers with the exact kernel at completion), 0 when the exact kernel was asked for."""
+    B, synth, torch, ctx = env
+    F, E = 400, 3000
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    r = torch.cumsum(torch.randn((F, 3, E), generator=g, device="cuda", dtype=torch.float64) * 0.1, dim=0)
+    t = torch.arange(F, device="cuda", dtype=torch.float64)[:, None, None]
+    rb = (t * torch.rand((1, 3, E), generator=g, device="cuda", dtype=torch.float64) + 500.0).contiguous()
+    out = torch.empty((F, 1, 4), dtype=torch.float64, device="cuda")
+    st = torch.full((1,), -1.0, dtype=torch.float64, device="cuda")
+    B.lag_msd(r, F - 1, [0, E], out=out, ctx=ctx, async_=True, status_out=st).wait()
+    assert float(st.cpu()[0]) == ctx.last_rel_bound() and 0.0 < ctx.last_rel_bound() <= 1e-10
+    B.lag_msd(rb, F - 1, [0, E], out=out, ctx=ctx, async_=True, status_out=st).wait()
+    assert float(st.cpu()[0]) > 1e-10 and ctx.last_rel_bound() == 0.0  # (the exact kernel answered at completion)
+    ctx.set_option("lag_variant", 1)
+    try:
+        B.lag_msd(r, F - 1, [0, E], out=out, ctx=ctx, async_=True, status_out=st).wait()
+    finally:
+        ctx.set_option("lag_variant", -1)
+    assert float(st.cpu()[0]) == 0.0
+
+
+def test_fused_step_redoes_the_lag_part_together_when_the_status_says_so():
+    """dist.msd_step_sharded_async (one host wait): the lag call's status word travels through the all-reduce; a bound
+    above the tolerance (ballistic motion) makes every rank repeat the lag part with the exact-difference kernel. One rank
+    behind a real process group, in a process of its own; against the plain library calls."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import os, sys
+import numpy as np
+import torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from mdproptools_amd import backend as B, dist as D
+from mdproptools_amd._lib import default_context
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29631")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+ctx = default_context(0)
+F, E = 400, 3000
+g = torch.Generator(device="cuda"); g.manual_seed(3)
+walk = torch.cumsum(torch.randn((F, 3, E), generator=g, device="cuda", dtype=torch.float64) * 0.1, dim=0)
+t = torch.arange(F, device="cuda", dtype=torch.float64)[:, None, None]
+ball = (t * torch.rand((1, 3, E), generator=g, device="cuda", dtype=torch.float64) + 500.0).contiguous()
+goff = [0, 1000, E]
+for name, r in (("walk", walk), ("ballistic", ball)):
+    ref_l = B.lag_msd(r, F - 1, goff, scale=1.0, ctx=ctx)
+    ref_o = B.msd_origin(r, r[0], goff, scale=1e-10, ctx=ctx)
+    single, win, lag, stats = D.msd_step_sharded(r, r, F, (0, E), goff, 4, scale=1e-10, lag_scale=1.0, ctx=ctx)
+    assert ("lag_redone" in stats) == (name == "ballistic"), (name, stats.keys())
+    np.testing.assert_allclose(single, ref_o, rtol=1e-12)
+    np.testing.assert_allclose(lag, ref_l, rtol=1e-9 if name == "walk" else 1e-12, atol=0)
+print("STEP OK")
+dist.destroy_process_group()
+''' % root
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "STEP OK" in r.stdout, r.stdout[-3000:]
