@@ -344,7 +344,13 @@ __global__ __launch_bounds__(W12_THREADS) void msd_power_w12_kernel(
     for (long long c = it.c_lo; c < it.c_hi; c += cstep) {
         const long long st_i = c - it.c_lo + ST_AHEAD;
         // Staging points 0 .. 5 of the iteration: point P stores the unit requested two points ago (P - 2) and requests
-        // unit P (< W12_UN), units alternating between the two register pairs (msd_power_lds3_kernel's scheme)
+        // unit P (< W12_UN), units alternating between the two register pairs (msd_power_lds3_kernel's scheme).
+        // Two other schedules were measured against this one in one process (tools/w12_exp.py, C4 call, 4.23-4.28 ms
+        // here; 3.52 ms with no staging at all): every unit stored FOUR points after its request (four units, 16
+        // registers, live throughout; the signal two series later) 4.33-4.37 ms; all four units requested at the end of
+        // the series before and stored together behind the first register pass 4.72 ms. The staging's cost is not the
+        // distance between request and use: with it the call moves 18 GB through the fabric port (trajectory in, ring
+        // out, ring in: profiles/pmc_secondary.json) in ~4.2 ms.
         int st_lim = 0;
         if constexpr (SRC == 2) st_lim = st_lim_of(st_i);
         auto point = [&](auto pk) {
