@@ -41,10 +41,11 @@ constexpr int W12_UN = 4;                   // staging units per lane and tile (
 #endif
 #define W12_BARRIER(bit) do { if (!(W12_EXP & (bit))) __syncthreads(); } while (0)
 
-// LDS: regions | raw plane (QE x 512 points) | two-level twiddle table | b table [12][8] | w_512^lane [64] | w_64^n0 [8] | red
+// LDS: regions | raw plane (QE x 512 points) | two-level twiddle table | b table [12][8] | w_512^lane [64] |
+// w_64^(n0 k1) [8][9] | red
 inline size_t w12_lds_bytes(int qe)
 {
-    return (size_t)W12_NW * W12_RS * 16 + (size_t)qe * W12_SUB * 16 + 256 * 16 + (size_t)W12_NW * 8 * 16 + 72 * 16 + 32 * 8;
+    return (size_t)W12_NW * W12_RS * 16 + (size_t)qe * W12_SUB * 16 + 256 * 16 + (size_t)W12_NW * 8 * 16 + (64 + 72) * 16 + 32 * 8;
 }
 
 template <int K12>
@@ -100,8 +101,9 @@ __global__ __launch_bounds__(W12_THREADS) void msd_power_w12_kernel(
     double2 *tabA = raw + QE * W12_SUB, *tabB = tabA + 128;  // w_L^(128 i), w_L^i
     double2 *btab = tabB + 128;                              // [d][n2] = w_N^(64 d n2)
     double2 *t1tab = btab + W12_NW * 8;                      // [lane] = w_512^lane (the twiddle step of the first register pass)
-    double2 *t2tab = t1tab + 64;                             // [n0] = w_64^n0 (of the second)
-    double *red = reinterpret_cast<double *>(t2tab + 8);
+    double2 *t2tab = t1tab + 64;                             // [9 n0 + k1] = w_64^(n0 k1): the twiddles of the second, ready made
+                                                             // (rows of 9: the 8 rows a read touches start 36 banks apart)
+    double *red = reinterpret_cast<double *>(t2tab + 72);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid < 256) tabA[tid] = tab[tid];
     const FftItem it = items[blockIdx.x];
@@ -111,9 +113,10 @@ __global__ __launch_bounds__(W12_THREADS) void msd_power_w12_kernel(
         const Cx w = ft_tw(tabA, tabB, (128 * d * n2) % (2 * N));  // w_N^(64 d n2) = w_L^(128 d n2)
         btab[tid] = make_double2(w.x, w.y);
     }
-    if (tid >= 128 && tid < 200) {
+    if (tid >= 128 && tid < 128 + 64 + 72) {
         const int i = tid - 128;
-        const Cx w = ft_tw(tabA, tabB, i < 64 ? 24 * i : 192 * (i - 64));
+        const int q = i - 64;  // (second table: row n0 = q / 9, column k1 = q % 9; column 8 is padding)
+        const Cx w = ft_tw(tabA, tabB, i < 64 ? 24 * i : (192 * (q / 9) * (q % 9)) % (2 * N));
         t1tab[i] = make_double2(w.x, w.y);
     }
     // per-lane constants of the three register passes: lane = n0 + 8 n1 (pass 1) = n0 + 8 k2 (pass 2) = k1 + 8 k2 (pass 3).
@@ -427,14 +430,11 @@ __global__ __launch_bounds__(W12_THREADS) void msd_power_w12_kernel(
         W12_POINT(2);
         if (!(W12_EXP & 32)) f2_bfly8(a, Cx{1.0, 0.0}, false);
         if (!(W12_EXP & 32)) {
-            const Cx tw_2 = w12_ld(t2tab + (lane & 7));
-            Cx t = tw_2;  // w_64^(n0 k1)
-            a[1] = cx_mul(a[1], t);
+            // w_64^(n0 k1) from the table (7 reads of 16 bytes, the 8 lanes of an n0 reading one address) instead of six
+            // chained complex products: the kernel is short of vector issue, not of LDS reads
+            const double2 *t2 = t2tab + 9 * (lane & 7);
 #pragma unroll
-            for (int k1 = 2; k1 < 8; ++k1) {
-                t = cx_mul(t, tw_2);
-                a[k1] = cx_mul(a[k1], t);
-            }
+            for (int k1 = 1; k1 < 8; ++k1) a[k1] = cx_mul(a[k1], w12_ld(t2 + k1));
         }
         // exchange 2: (n0, k2 | k1) -> (k1, k2 | n0): point k1 + 8 k2 + 65 n0
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

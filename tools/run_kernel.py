@@ -27,6 +27,16 @@ def main():
         for _ in range(3):
             B.lag_msd(r, F - 1, [0, E])
             print(ctx.last_kernel_name(), ctx.last_kernel_ms()[0])
+    elif what == "c2":
+        cfg = synth.rdf_config("C2")
+        n, L, F = cfg["n_atoms"], cfg["box_len"], cfg["n_frames"]
+        xyz = torch.from_numpy(synth.rdf_frames(n, range(F), L, cfg["seed_offset"])).cuda()
+        ty = synth.rdf_types(n)
+        rel = np.array(synth.ALL_PAIRS_4)
+        box = np.full((F, 3), L)
+        for _ in range(4):
+            B.rdf_loop(xyz, ty, box, rel, cfg["r_cut"], cfg["bin_size"], int(cfg["r_cut"] / cfg["bin_size"]), per_frame=False, ctx=ctx)
+            print(ctx.last_kernel_name(), ctx.last_kernel_ms()[0], ctx.last_aux_ms())
     elif what == "xcorr":
         n = int(sys.argv[2]) if len(sys.argv) > 2 else 100_000
         p = torch.from_numpy(synth.ar1_series(n)).cuda()
