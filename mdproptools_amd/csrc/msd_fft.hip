@@ -1254,6 +1254,7 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
         const st2_t out = odd ? st2_t{recv, b} : st2_t{a, recv};
         const unsigned soff = (unsigned)(((size_t)(i & (ST_BUF - 1)) * 16 * (size_t)Fs + (size_t)(64 * r)) * 8);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(st4_t, out), ring, in ? st_vo : ST_OOB, soff, SC1);
+        asm volatile("s_nop 1" ::"v"(out));  // (the store's data registers stay untouched for two cycles: see W12_STORE_GUARD)
     };
     auto st_flag = [&](long long i) { return ready + ((size_t)sg.cluster * ST_BUF + (size_t)(i & (ST_BUF - 1))) * ST_FLAG_STRIDE; };
     // (behind a block barrier that every wave entered after its own s_waitcnt vmcnt(0))

@@ -39,6 +39,16 @@ constexpr int W12_UN = 4;                   // staging units per lane and tile (
                    // 16 no exchanges (LDS writes + reads of the register passes), 32 no butterfly arithmetic in the passes,
                    // 64 no first-pass arithmetic, 128 no staging (SRC == 2: loads, stores)
 #endif
+// A 16-byte buffer store hands its data registers to the memory pipeline over more than one cycle: a vector instruction
+// that WRITES one of them in the cycle behind the store changes what some lanes store. The compiler knows the hazard
+// (one or two idle cycles behind stores of more than 8 bytes) but not for buffer stores whose scalar offset is a
+// register — the form every staging store here has — and the QE = 6 instance of this kernel came out with
+//     buffer_store_dwordx4 v[86:89], v114, s[56:59], s74 offen sc1
+//     v_cndmask_b32_e32 v86, v148, v126, vcc        (the next unit's load offset, into the store's first data register)
+// which stored that offset as the low word of one sample in every second 8-lane group (integer-ramp input: MSD(1) =
+// 1.013 instead of 1; tools/w12_probe.py). The guard keeps the data registers live across two idle cycles behind the
+// store; tests/test_codegen_cpu.py scans the compiled kernels for the pattern.
+#define W12_STORE_GUARD(v) asm volatile("s_nop 1" ::"v"(v))
 #define W12_BARRIER(bit) do { if (!(W12_EXP & (bit))) __syncthreads(); } while (0)
 
 // LDS: regions | raw plane (QE x 512 points) | two-level twiddle table | b table [12][8] | w_512^lane [64] |
@@ -198,6 +208,7 @@ __global__ __launch_bounds__(W12_THREADS) void msd_power_w12_kernel(
         const st2_t out = st2_t{sv[0] * scale, sv[1] * scale};
         const unsigned soff = (unsigned)(((size_t)(i & (ST_BUF - 1)) * 16 * (size_t)Fs + (size_t)(RPR * r)) * 8);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(st4_t, out), ring, RPR * r < lim ? st_vo : ST_OOB, soff, SC1);
+        W12_STORE_GUARD(out);
     };
     auto st_flag = [&](long long i) { return ready + ((size_t)sg.cluster * ST_BUF + (size_t)(i & (ST_BUF - 1))) * ST_FLAG_STRIDE; };
     auto st_signal = [&](long long i) {
@@ -291,12 +302,11 @@ __global__ __launch_bounds__(W12_THREADS) void msd_power_w12_kernel(
 
     if constexpr (SRC == 2) {
         // the first ST_AHEAD tiles, before anything is transformed
-        // (a tile at a time: its eight loads, ONE wait for all of them, then its four stores. The form the compiler makes
-        // of the plain loop — units software-pipelined, stores issued between loads still in flight and `s_waitcnt
-        // vmcnt(N)` counting across both — delivered wrong rows in the fifth load of eight on this GPU (every second
-        // 8-lane group got the first group's rows; found with the -DW12_VERIFY build on an integer ramp, never seen in
-        // the series loop, where a wait for everything sits between a unit's loads and the stores behind them): the
-        // prologue runs once per block and simply does not mix the two.)
+        // (a tile at a time: its eight loads, one wait for all of them, then its four stores. The software-pipelined form
+        // the compiler makes of the plain loop stored wrong values in every second 8-lane group; the cause, found later
+        // in the series loop of the QE = 6 instance, is the one W12_STORE_GUARD describes — a store's data register
+        // rewritten in the cycle behind it — and the guard covers these stores too. The prologue runs once per block:
+        // the simple form stays.)
         int n_ahead = ST_AHEAD;
         asm volatile("" : "+s"(n_ahead));  // (opaque trip count: no unrolling across tiles)
         for (int i = 0; i < n_ahead; ++i) {

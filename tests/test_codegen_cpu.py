@@ -151,3 +151,59 @@ def test_resource_budgets_of_the_headline_kernels(pair_sj):
     # the all-f64 sweep (f64_only leg)
     _, meta = _find(pair_sj, "pair_hist_sj_kernelILi2ELb1ELb0EE")
     assert int(meta["vgpr_spill_count"]) == 0 and int(meta["private_segment_fixed_size"]) == 0, meta
+
+
+def _regs(tok):
+    """'v86' -> {86}; 'v[86:89]' -> {86..89}; anything else -> empty."""
+    m = re.match(r"^v(\d+)$", tok)
+    if m:
+        return {int(m.group(1))}
+    m = re.match(r"^v\[(\d+):(\d+)\]$", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    return set()
+
+
+def wide_store_hazards(body, idle=2):
+    """(store, writer) pairs: a buffer store of more than 8 bytes and a vector-ALU instruction that writes one of its DATA
+    registers fewer than `idle` cycles behind it (every instruction is one cycle, `s_nop k` is k + 1)."""
+    ops = list(_ops(body))
+    out = []
+    for i, (op, s) in enumerate(ops):
+        if not re.match(r"buffer_store_(dwordx[34]|format_xyzw?)", op):
+            continue
+        data = _regs(s.split()[1].rstrip(","))
+        gap = 0
+        for op2, s2 in ops[i + 1:]:
+            if gap >= idle:
+                break
+            if op2.startswith("v_") and not op2.startswith(("v_cmp", "v_readlane", "v_readfirstlane")):
+                dst = _regs(s2.split()[1].rstrip(","))
+                if op2.startswith("v_swap"):
+                    dst |= _regs(s2.split()[2].rstrip(","))
+                if dst & data:
+                    out.append((s, s2))
+            m = re.match(r"s_nop\s+(\d+)", s2)
+            gap += int(m.group(1)) + 1 if m else 1
+    return out
+
+
+def test_scanner_sees_the_pattern_that_went_wrong():
+    bad = ["k:", "\tbuffer_store_dwordx4 v[86:89], v114, s[56:59], s74 offen sc1", "\tv_cndmask_b32_e32 v86, v148, v126, vcc"]
+    assert len(wide_store_hazards(bad)) == 1
+    ok = [bad[0], bad[1], "\ts_nop 1", bad[2]]
+    assert wide_store_hazards(ok) == []
+    ok2 = [bad[0], bad[1], "\ts_mov_b32 s55, s59", "\tv_add_f64 v[90:91], v[86:87], v[88:89]", bad[2]]
+    assert wide_store_hazards(ok2) == []
+
+
+def test_staging_stores_keep_their_data_registers_for_two_cycles():
+    """The full-lag MSD kernels' staging stores (16 bytes, scalar offset in a register): the compiler does not guard
+    that form against a vector write of the data registers in the next cycle, and on gfx950 such a write changes what
+    some lanes store (msd_fft_w12.h, W12_STORE_GUARD: found on an integer ramp at 5120 < F <= 6144). Every kernel of
+    msd_fft.hip is scanned."""
+    kern = _kernels(_asm("msd_fft.hip"))
+    assert any("msd_power_w12_kernel" in k for k in kern)
+    found = {k: wide_store_hazards(body) for k, (body, _) in kern.items()}
+    found = {k: v for k, v in found.items() if v}
+    assert found == {}, found
