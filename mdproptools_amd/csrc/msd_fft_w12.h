@@ -37,7 +37,7 @@ constexpr int W12_UN = 4;                   // staging units per lane and tile (
 #ifndef W12_EXP
 #define W12_EXP 0  // timing experiments only (WRONG results): 1 no first barrier, 2 no second, 4 no third, 8 no partner phase,
                    // 16 no exchanges (LDS writes + reads of the register passes), 32 no butterfly arithmetic in the passes,
-                   // 64 no first-pass arithmetic, 128 no staging (SRC == 2: loads, stores)
+                   // 64 no first-pass arithmetic, 128 no staging (SRC == 2: loads, stores), 256 no staging loads, 512 no staging stores
 #endif
 // A 16-byte buffer store hands its data registers to the memory pipeline over more than one cycle: a vector instruction
 // that WRITES one of them in the cycle behind the store changes what some lanes store. The compiler knows the hazard
@@ -207,7 +207,8 @@ __global__ __launch_bounds__(W12_THREADS) void msd_power_w12_kernel(
     auto stage_store = [&](long long i, int r, int lim, const st2_t &sv) {
         const st2_t out = st2_t{sv[0] * scale, sv[1] * scale};
         const unsigned soff = (unsigned)(((size_t)(i & (ST_BUF - 1)) * 16 * (size_t)Fs + (size_t)(RPR * r)) * 8);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(st4_t, out), ring, RPR * r < lim ? st_vo : ST_OOB, soff, SC1);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(st4_t, out), ring, RPR * r < lim ? st_vo : ST_OOB, soff,
+                                               (W12_EXP & 1024) ? 0 : SC1);  // (timing: a store that ends in this XCD's L2)
         W12_STORE_GUARD(out);
     };
     auto st_flag = [&](long long i) { return ready + ((size_t)sg.cluster * ST_BUF + (size_t)(i & (ST_BUF - 1))) * ST_FLAG_STRIDE; };
@@ -364,14 +365,31 @@ __global__ __launch_bounds__(W12_THREADS) void msd_power_w12_kernel(
         // the series before and stored together behind the first register pass 4.72 ms. The staging's cost is not the
         // distance between request and use: with it the call moves 18 GB through the fabric port (trajectory in, ring
         // out, ring in: profiles/pmc_secondary.json) in ~4.2 ms.
+        // What it is, from timing builds in one process (W12_EXP 256 / 512 / 128 / 1024; the full kernel 4.11-4.16 ms):
+        // no trajectory loads (zeros stored, ring read back) 3.53 ms; loads but no ring stores 3.75 ms; neither 3.56 ms;
+        // ring stores without sc1 4.07-4.17 ms (no change). The stores alone are free, the loads alone cost 0.2 ms, both
+        // 0.57 ms: the price follows the BYTES through the fabric port — 6 GB (ring in) 3.56 ms, 12 GB 3.5-3.75 ms,
+        // 18 GB 4.1 ms = 4.4 TB/s of mixed reads and writes, the rate this kernel's traffic is served at — and below
+        // ~12 GB the arithmetic and LDS time of the series (3.5 ms) hides it. Under 4.0 ms needs fewer bytes (a ring
+        // that stays inside an XCD's 4 MB L2 does not fit two clusters' live tiles), not a better schedule.
+        // Nor is it the instruction count at the margin (same process, 4.20 ms): the mean by a reciprocal made once
+        // instead of a division per series (-12 vector instructions of ~640) 4.20 ms; the two multiplications per unit
+        // skipped behind a wave-uniform test of scale == 1.0 4.51-4.54 ms (the branches cut the schedule the compiler
+        // makes of the points). Neither is kept.
         int st_lim = 0;
         if constexpr (SRC == 2) st_lim = st_lim_of(st_i);
         auto point = [&](auto pk) {
             constexpr int P = decltype(pk)::value;
             if constexpr (SRC == 2 && !(W12_EXP & 128)) {
                 st2_t &reg = (P & 1) ? sy : sx;
-                if constexpr (P >= 2 && P - 2 < W12_UN) stage_store(st_i, P - 2, st_lim, reg);
-                if constexpr (P < W12_UN) stage_load(st_i, P, st_lim, reg);
+                if constexpr (P >= 2 && P - 2 < W12_UN) {
+                    if constexpr (W12_EXP & 512) asm volatile("" ::"v"(reg));  // (timing: the unit is loaded, not stored)
+                    else stage_store(st_i, P - 2, st_lim, reg);
+                }
+                if constexpr (P < W12_UN) {
+                    if constexpr (W12_EXP & 256) reg = st2_t{0.0, 0.0};  // (timing: nothing is loaded, zeros are stored)
+                    else stage_load(st_i, P, st_lim, reg);
+                }
             }
         };
 #define W12_POINT(P) point(std::integral_constant<int, (P)>())
@@ -433,8 +451,10 @@ __global__ __launch_bounds__(W12_THREADS) void msd_power_w12_kernel(
         }
         if constexpr (SRC == 2) {
             // what this wave stored for the tile staged under the PREVIOUS series has long been issued, and the youngest
-            // request in flight (the next series' samples) is a pass old: waiting for everything here is cheap and lets
-            // the second barrier below carry the signal for that tile
+            // request in flight (the next series' samples) is a pass old: waiting for everything here lets the second
+            // barrier below carry the signal for that tile. (A counted wait that leaves the eight loads issued behind
+            // those stores in flight — memory operations complete in issue order — measured the same, 4.18-4.29 against
+            // 4.22-4.24 ms in one process: not kept.)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         W12_POINT(2);
