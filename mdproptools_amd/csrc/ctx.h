@@ -136,6 +136,10 @@ struct mdhip_ctx {
     int stage_flip = 0;
     int opt_rdf_relblock = 0;  // (retired: the f32 records are relative to their whole tile's centre; accepted, ignored)
     int opt_h2d_overlap = 1;  // 1 (default): overlapped staging of host-resident pair inputs, 0: one copy up front (A/B)
+    int opt_small_copy = 1;   // 1 (default): copies of up to MD_SMALL_COPY_MAX bytes between page-locked host memory and the
+                              // device are made by a KERNEL on the launch stream (mdhip_copy_small) instead of
+                              // hipMemcpyAsync: the runtime's copies run as blit kernels on another hardware queue,
+                              // and every hand-over between the queues cost a C2 step ~17 us of idle GPU (round 5)
     int opt_h2d_ring = 1;     // 1 (default): pageable sources go through the context's page-locked ring (mdhip_h2d_any),
                               // 0: handed to hipMemcpyAsync as they are (A/B)
     // the ring: two halves, each with the event recorded behind its last DMA (a half is reused once that has fired)
@@ -327,6 +331,11 @@ int mdhip_lag_msd_fft(CallScope &cs, int64_t n_frames, int64_t n_ent, const doub
 // with it the caller's next issue — wait for kernels it has nothing to do with. Complete when this returns.
 int mdhip_deliver_to_device(mdhip_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 
+// dst <- src, `bytes` bytes, either side page-locked host memory (device-accessible at the same address) or device
+// memory, as ONE kernel on the launch stream when the copy is small (see opt_small_copy), else hipMemcpyAsync of `kind`.
+constexpr size_t MD_SMALL_COPY_MAX = (size_t)256 << 10;
+int mdhip_copy_small(mdhip_ctx *ctx, void *dst, const void *src, size_t bytes, hipMemcpyKind kind);
+
 // A small host table on its way to device memory: through pinned staging of the call, so that the copy is asynchronous
 // and the caller's (or this function's) memory may go away at once.
 static inline int mdhip_h2d_small(mdhip_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes)
@@ -335,8 +344,7 @@ static inline int mdhip_h2d_small(mdhip_ctx *ctx, void *dst_dev, const void *src
     void *h = mdhip_pin(ctx, bytes);
     if (!h) return MDHIP_ENOMEM;
     memcpy(h, src_host, bytes);
-    MD_HIP(hipMemcpyAsync(dst_dev, h, bytes, hipMemcpyHostToDevice, ctx->stream));
-    return MDHIP_OK;
+    return mdhip_copy_small(ctx, dst_dev, h, bytes, hipMemcpyHostToDevice);
 }
 
 // A result on its way to the caller. Device destination: a device-to-device copy on the stream. Host destination: up to
@@ -358,7 +366,10 @@ static inline int mdhip_result(CallScope &cs, void *dst, const void *d_src, size
     }
     void *h = mdhip_pin(ctx, bytes);
     if (!h) return MDHIP_ENOMEM;
-    MD_HIP(hipMemcpyAsync(h, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    {
+        const int rcc = mdhip_copy_small(ctx, h, d_src, bytes, hipMemcpyDeviceToHost);
+        if (rcc) return rcc;
+    }
     cs.defer([dst, h, bytes]() {
         memcpy(dst, h, bytes);
         return MDHIP_OK;

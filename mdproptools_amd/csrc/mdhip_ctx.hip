@@ -296,6 +296,42 @@ void mdhip_call_abandon(mdhip_ctx *ctx, mdhip_call *c)
     release_call(ctx, c);
 }
 
+// 16 bytes per lane where both sides allow it, the tail (and unaligned copies) byte by byte
+__global__ __launch_bounds__(256) void copy_small_kernel(unsigned char *__restrict__ dst, const unsigned char *__restrict__ src,
+                                                         size_t n16, size_t bytes)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) reinterpret_cast<uint4 *>(dst)[i] = reinterpret_cast<const uint4 *>(src)[i];
+    const size_t t = n16 * 16 + i;
+    if (i < 16 && t < bytes) dst[t] = src[t];
+}
+__global__ __launch_bounds__(256) void copy_bytes_kernel(unsigned char *__restrict__ dst, const unsigned char *__restrict__ src,
+                                                         size_t bytes)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < bytes) dst[i] = src[i];
+}
+
+int mdhip_copy_small(mdhip_ctx *ctx, void *dst, const void *src, size_t bytes, hipMemcpyKind kind)
+{
+    if (bytes == 0) return MDHIP_OK;
+    if (!ctx->opt_small_copy || bytes > MD_SMALL_COPY_MAX) {
+        MD_HIP(hipMemcpyAsync(dst, src, bytes, kind, ctx->stream));
+        return MDHIP_OK;
+    }
+    const bool al = ((reinterpret_cast<unsigned long long>(dst) | reinterpret_cast<unsigned long long>(src)) & 15ull) == 0ull;
+    if (al) {
+        const size_t n16 = bytes / 16, n = n16 > 16 ? n16 : 16;
+        hipLaunchKernelGGL(copy_small_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (unsigned char *)dst, (const unsigned char *)src, n16, bytes);
+    } else {
+        hipLaunchKernelGGL(copy_bytes_kernel, dim3((unsigned)((bytes + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (unsigned char *)dst, (const unsigned char *)src, bytes);
+    }
+    MD_HIP(hipGetLastError());
+    return MDHIP_OK;
+}
+
 int mdhip_deliver_to_device(mdhip_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes)
 {
     if (bytes == 0) return MDHIP_OK;
@@ -741,6 +777,8 @@ int mdhip_set_option(mdhip_ctx *ctx, const char *key, int value)
         ctx->opt_lag_fft_kernel = value;
     else if (!strcmp(key, "h2d_overlap"))
         ctx->opt_h2d_overlap = value;
+    else if (!strcmp(key, "small_copy"))
+        ctx->opt_small_copy = value;
     else if (!strcmp(key, "h2d_ring"))
         ctx->opt_h2d_ring = value;
     else if (!strcmp(key, "lag_direct"))

@@ -307,7 +307,10 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
             h_map[sj_rows1 + p.n_rel + kl] = p.rel_mult[kl];
         }
     }
-    MD_HIP(hipMemcpyAsync(d_tab, h_tab, tab_al + map_b, hipMemcpyHostToDevice, ctx->stream));
+    {
+        const int rcc = mdhip_copy_small(ctx, d_tab, h_tab, tab_al + map_b, hipMemcpyHostToDevice);
+        if (rcc) return rcc;
+    }
     MD_WS(d_misc, unsigned long long, WS_MISC, 64 + rows1_b);
     MD_HIP(hipMemsetAsync(d_misc, 0, 64 + rows1_b, ctx->stream));
 
@@ -557,7 +560,10 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
                               d_map + sj_rows + p.n_rel, d_misc + 3, p.dev_out);
             MD_HIP(hipGetLastError());
             uint64_t *hlost = reinterpret_cast<uint64_t *>(h_tab + tab_al + ((map_b + 7) & ~size_t(7)));
-            MD_HIP(hipMemcpyAsync(hlost, d_misc + 1, 24, hipMemcpyDeviceToHost, ctx->stream));
+            {
+                const int rcc = mdhip_copy_small(ctx, hlost, d_misc + 1, 24, hipMemcpyDeviceToHost);
+                if (rcc) return rcc;
+            }
             auto fin = [check_flags, collect_times, hlost]() {
                 const int rcf = check_flags(hlost);
                 if (rcf) return rcf;
@@ -583,11 +589,19 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         }
         if (sj) {
             // D2H of the row sums (pinned staging), then rows -> classes and the overflow words on the host
-            MD_PIN(hrows, uint64_t, (out_frames * (size_t)sj_words + 3) * 8);
-            MD_HIP(hipMemcpyAsync(hrows, d_rows, out_frames * (size_t)sj_words * 8, hipMemcpyDeviceToHost,
-                                  ctx->stream));
+            MD_PIN(hall, uint64_t, (out_frames * (size_t)sj_words + 16) * 8);
+            uint64_t *hrows = hall + 8;
             uint64_t *hlost = hrows + out_frames * (size_t)sj_words;  // [0] queue overflow, [1] work-loop assertion
-            MD_HIP(hipMemcpyAsync(hlost, d_misc + 1, 24, hipMemcpyDeviceToHost, ctx->stream));
+            if (d_rows == d_misc + 8 && out_frames == 1) {
+                // the row sums sit behind the flag words (one_sum): flags and rows leave in ONE copy
+                hlost = hall + 1;
+                const int rcc = mdhip_copy_small(ctx, hall, d_misc, (8 + (size_t)sj_words) * 8, hipMemcpyDeviceToHost);
+                if (rcc) return rcc;
+            } else {
+                int rcc = mdhip_copy_small(ctx, hrows, d_rows, out_frames * (size_t)sj_words * 8, hipMemcpyDeviceToHost);
+                if (!rcc) rcc = mdhip_copy_small(ctx, hlost, d_misc + 1, 24, hipMemcpyDeviceToHost);
+                if (rcc) return rcc;
+            }
             std::vector<uint64_t> *Hp = &H, *Hsplit = p.Hsplit;
             auto fin = [check_flags, collect_times, acc, hrows, hlost, Hp, Hsplit, out_frames, sj_words, sj_rows, cn_len,
                         ordered, nc, c0, n_cls_all, nbins_all, cls = ordered ? p.cls : std::vector<int>()]() {
@@ -1022,7 +1036,10 @@ int run_job(mdhip_ctx *ctx, const RelJob &j, std::vector<uint64_t> &H, std::vect
     // ONE copy for the three tables (round 5: three copies cost a C2 step ~12 us each, the gaps between a copy and the
     // kernels around it included): types of set i | types of set j | box lengths, behind each other in one buffer
     MD_WS(d_in, unsigned char, WS_TYPE_I, ti_b + tj_b + box_b);
-    MD_HIP(hipMemcpyAsync(d_in, h_in, ti_b + tj_b + box_b, hipMemcpyHostToDevice, ctx->stream));
+    {
+        const int rcc = mdhip_copy_small(ctx, d_in, h_in, ti_b + tj_b + box_b, hipMemcpyHostToDevice);
+        if (rcc) return rcc;
+    }
     int *d_ti = reinterpret_cast<int *>(d_in);
     p.d_ti = d_ti;
     p.ti_fs = j.lab_i_fs;
