@@ -171,7 +171,8 @@ struct mdhip_ctx {
     int opt_rdf_rows = -1;    // scalar-j RDF: -1/1 ordered-pair rows without a row table when they fit, 0 class rows + table
     int opt_rdf_pk = -1;      // scalar-j RDF with ordered rows: -1/1 packed-f32 classification sweep with the exact
                               // deferred resolver (MODE 3) when its error bound allows, 0 the all-f64 sweep (MODE 2)
-    int opt_rdf_sort = -1;    // spatial sort: -1 auto, 1 one block per frame (LDS counters), 0 multi-block (global counters)
+    int opt_rdf_sort = -1;    // spatial sort: -1 auto, 1 one block per frame (LDS counters), 0 multi-block (global counters),
+                              // 3 as auto but without the read-once form for frames of <= 12288 atoms (A/B)
     int opt_cn_pk = 1;        // mdhip_cn_atomic: 1 (default since the scalar-stream cut of the packed sweep) =
                               // through the packed-f32 sweep (coarse 64-bin histogram up to the largest cutoff + split
                               // bins) when the geometry allows, 0 = the f64 edge-table kernel (also the fallback).

@@ -2,6 +2,9 @@
 // neighbour-tile lists (SURVEY.md 8f "cell-list variant").
 #include "pair_common.h"
 
+#ifndef SORT_EXP
+#define SORT_EXP 0  // timing experiments of cull_sort_reg_kernel: 1 no division, 2 no Hilbert arithmetic (a plain key)
+#endif
 namespace mdpair {
 namespace {
 
@@ -238,6 +241,137 @@ __global__ __launch_bounds__(SORT_THREADS) void cull_sort_lds_kernel(
         aos[(size_t)f * n_pad + i] = make_double4(PAD_J, PAD_J, PAD_J, __longlong_as_double(0LL));
 }
 
+// The same sort for frames of up to ITEMS x 1024 atoms, every atom read ONCE (round 5): the kernel above walks the frame
+// three times (minimum, keys, scatter) in loops whose every trip waits for its own loads — one block per CU has nothing
+// else to run meanwhile — and took 69 us for the 10k atoms of a C2 frame, a third of it arithmetic. Here a thread's
+// ITEMS atoms (coordinates and type) are requested at the top, all at once, and stay in registers through the three
+// phases; the keys never leave the registers either. 59 us (pre-pass of a C2 step 101 -> 92 us). What is left is not
+// arithmetic (timing builds, -DSORT_EXP: a multiplication for the division of wrapped_frac 0 us, a plain key instead
+// of the Hilbert arithmetic -8 us): the 200 blocks move 56 MB in and 64 MB out in lockstep — all read, all compute,
+// all write — so the memory system idles through the middle of every block's life.
+template <int ITEMS>
+__global__ __launch_bounds__(SORT_THREADS) void cull_sort_reg_kernel(
+    const double *__restrict__ xyz, const int *__restrict__ type, long long type_fs, const double *__restrict__ box,
+    long long n, double *__restrict__ sxyz, int *__restrict__ stype, double4 *__restrict__ aos, long long n_pad, int n_ti,
+    float near, int row_len)
+{
+    extern __shared__ unsigned s_cells[];  // [SORT_CELL_WORDS] + 3 x 16 doubles of scratch behind it
+    double *s_red = reinterpret_cast<double *>(s_cells + SORT_CELL_WORDS);
+    __shared__ unsigned s_part[SORT_THREADS / 64];
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const double *x = xyz + (size_t)f * 3 * n;
+    const int *tf = type + (size_t)f * type_fs;
+    double px[ITEMS], py[ITEMS], pz[ITEMS];
+    int tp[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        const long long i = tid + (long long)k * SORT_THREADS;
+        px[k] = py[k] = pz[k] = 1e300;
+        tp[k] = 0;
+        if (i < n) {
+            px[k] = x[i];
+            py[k] = x[n + i];
+            pz[k] = x[2 * n + i];
+            tp[k] = tf[i];
+        }
+    }
+    const double L[3] = {box[3 * f], box[3 * f + 1], box[3 * f + 2]};
+    for (int k = tid; k < (int)SORT_CELL_WORDS; k += SORT_THREADS) s_cells[k] = 0u;
+    // ---- origin = exact minimum of every axis ----
+    double lo[3] = {1e300, 1e300, 1e300};
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        lo[0] = __builtin_fmin(lo[0], px[k]);
+        lo[1] = __builtin_fmin(lo[1], py[k]);
+        lo[2] = __builtin_fmin(lo[2], pz[k]);
+    }
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) lo[ax] = __builtin_fmin(lo[ax], __shfl_down(lo[ax], off, 64));
+        if (lane == 0) s_red[ax * 16 + wv] = lo[ax];
+    }
+    __syncthreads();
+    double org[3];
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        double m = s_red[ax * 16];
+        for (int w = 1; w < SORT_THREADS / 64; ++w) m = __builtin_fmin(m, s_red[ax * 16 + w]);
+        org[ax] = m;
+    }
+    // ---- keys + cell populations ----
+    const double G = (double)(1 << MORTON_BITS);
+    unsigned key[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        const long long i = tid + (long long)k * SORT_THREADS;
+        key[k] = 0u;
+        if (i < n) {
+            const double p[3] = {px[k], py[k], pz[k]};
+            unsigned c[3];
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+#if SORT_EXP & 1
+                const double sfr = (p[ax] - org[ax]) * (1.0 / L[ax]);
+                double fr = sfr - __builtin_floor(sfr);
+                fr = fr < 1.0 ? fr : 0.0;
+                int v = (int)(fr * G);
+#else
+                int v = (int)(wrapped_frac(p[ax] - org[ax], L[ax]) * G);
+#endif
+                c[ax] = (unsigned)(v < 0 ? 0 : v > (1 << MORTON_BITS) - 1 ? (1 << MORTON_BITS) - 1 : v);
+            }
+#if SORT_EXP & 2
+            key[k] = (c[0] | (c[1] << 5) | (c[2] << 10)) & 0xFFFFu;
+#else
+            key[k] = hilbert3(c[0], c[1], c[2]) & 0xFFFFu;  // (the other kernel keeps its keys in 16 bits)
+#endif
+            atomicAdd(&s_cells[sort_cell(key[k])], 1u);
+        }
+    }
+    __syncthreads();
+    // ---- exclusive scan of the populations (as above) ----
+    constexpr int PER = MORTON_CELLS / SORT_THREADS;
+    static_assert(PER == 32, "one pad word per lane run");
+    const int base = tid * (PER + 1);
+    unsigned sum = 0;
+    for (int k = 0; k < PER; ++k) sum += s_cells[base + k];
+    unsigned incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned up = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += up;
+    }
+    if (lane == 63) s_part[wv] = incl;
+    __syncthreads();
+    unsigned run = incl - sum;
+    for (int w = 0; w < wv; ++w) run += s_part[w];
+    for (int k = 0; k < PER; ++k) {
+        const unsigned v = s_cells[base + k];
+        s_cells[base + k] = run;
+        run += v;
+    }
+    __syncthreads();
+    // ---- scatter ----
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        const long long i = tid + (long long)k * SORT_THREADS;
+        if (i < n) {
+            const unsigned pos = atomicAdd(&s_cells[sort_cell(key[k])], 1u);
+            if (sxyz) {
+                double *o = sxyz + (size_t)f * 3 * n;
+                o[pos] = px[k];
+                o[n + pos] = py[k];
+                o[2 * n + pos] = pz[k];
+                stype[(size_t)f * n + pos] = tp[k];
+            }
+            aos[(size_t)f * n_pad + pos] = make_double4(px[k], py[k], pz[k], pack_w(tp[k], n_ti, near, row_len));
+        }
+    }
+    for (long long i = n + tid; i < n_pad; i += SORT_THREADS)
+        aos[(size_t)f * n_pad + i] = make_double4(PAD_J, PAD_J, PAD_J, __longlong_as_double(0LL));
+}
+
 // scatter atoms to their sorted position (cells[] holds running offsets)
 __global__ void cull_scatter_kernel(const double *__restrict__ xyz, const int *__restrict__ type,
                                     long long type_fs, long long n, const unsigned short *__restrict__ keys,
@@ -468,7 +602,25 @@ int cull_prepare_set(mdhip_ctx *ctx, int64_t F, const double *d_x, const int *d_
     const size_t sort_lds = SORT_CELL_WORDS * 4 + 3 * 16 * 8;
     const bool lds_sort = ctx->opt_rdf_sort != 0 && sort_lds + 8192 <= ctx->lds_max && N <= 262144 &&
                           (ctx->opt_rdf_sort == 1 || F >= ctx->cu_count / 4 || N <= 16384);
-    if (lds_sort) {
+    const int sort_items = (int)((N + SORT_THREADS - 1) / SORT_THREADS);
+    if (lds_sort && sort_items <= 12 && ctx->opt_rdf_sort != 3) {
+        // (frames of up to 12288 atoms: every atom read once, kept in registers — cull_sort_reg_kernel)
+#define MD_SORT_REG(I)                                                                                              \
+    {                                                                                                               \
+        MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(cull_sort_reg_kernel<I>),                         \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));                     \
+        hipLaunchKernelGGL(cull_sort_reg_kernel<I>, dim3((unsigned)F), dim3(SORT_THREADS), sort_lds, ctx->stream,   \
+                           d_x, d_t, t_fs, d_box, N, want_soa ? d_sx : (double *)nullptr, d_st, d_ao,               \
+                           (long long)nT * TILE, n_ti, near, row_len);                                              \
+    }
+        if (sort_items <= 2) MD_SORT_REG(2)
+        else if (sort_items <= 4) MD_SORT_REG(4)
+        else if (sort_items <= 6) MD_SORT_REG(6)
+        else if (sort_items <= 8) MD_SORT_REG(8)
+        else if (sort_items <= 10) MD_SORT_REG(10)
+        else MD_SORT_REG(12)
+#undef MD_SORT_REG
+    } else if (lds_sort) {
         MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(cull_sort_lds_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));
         hipLaunchKernelGGL(cull_sort_lds_kernel, dim3((unsigned)F), dim3(SORT_THREADS), sort_lds, ctx->stream, d_x,
