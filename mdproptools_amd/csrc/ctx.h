@@ -187,6 +187,8 @@ struct mdhip_ctx {
     int opt_fft_net8 = 1;     // 0: radix-4 network for every radix (A/B)
     int opt_fft_specfuse = 1; // mdhip_fft_xcorr: the spectrum step inside the inverse transform's first pass when that pass
                               // runs the radix-8 network (0: a kernel of its own, A/B)
+    int opt_fft_mid = 1;      // mdhip_fft_xcorr, autocorrelation through a two-pass transform: 1 (default) three launches
+                              // (fft_mid_acf_kernel: second pass + spectrum + inverse's first pass in one), 0 four
     int opt_fft_logc = 3;     // fft_pow2.hip: columns per tile (log2); 8 columns = 128-byte runs measured best (tools/ab_fft.py)
     int opt_seg_gy = 0;       // segment kernels: frame slices per block run (0 = auto)
     int opt_seg_frame = 1;    // mdhip_segment_com: one (run, frame) per block, nothing carried between frames (A/B: 0 =

@@ -78,7 +78,13 @@ __global__ void fft_twiddle_table_kernel(double2 *A, long long nA, double2 *B, l
 __device__ __forceinline__ unsigned bit_reverse(unsigned r, int bits) { return bits ? __brev(r) >> (32 - bits) : 0u; }
 
 enum { IN_PLAIN = 0, IN_PAD = 1, IN_SPEC = 2 };  // IN_SPEC (fft_pass8_kernel only): see spec_input
-enum { OUT_PLAIN = 0, OUT_CONJ = 1, OUT_LAGS = 2 };
+enum { OUT_PLAIN = 0, OUT_CONJ = 1, OUT_LAGS = 2, OUT_PERM = 3 };  // OUT_PERM (fft_pass8_kernel, first of two passes): pair_phys
+
+// The order in which the first pass of a two-pass autocorrelation leaves the R outputs of a column (fft_mid_acf_kernel):
+// j and R - j next to each other — 0, R/2, 1, R-1, 2, R-2, ... — so that the frequencies k and H - k, which the
+// spectrum step combines, sit in NEIGHBOURING columns of the second pass and every tile of >= 2 columns holds whole pairs.
+__host__ __device__ inline int pair_phys(int j, int R) { return j == 0 ? 0 : j == R / 2 ? 1 : j < R / 2 ? 2 * j : 2 * (R - j) + 1; }
+__host__ __device__ inline int pair_logical(int x, int R) { return (x & 1) ? (x == 1 ? R / 2 : R - (x >> 1)) : (x >> 1); }
 
 // what the first / last pass of the fused correlation pipeline reads / writes instead of a complex buffer
 struct PassIo {
@@ -473,6 +479,18 @@ __global__ __launch_bounds__(1024) void fft_pass8_kernel(const double2 *__restri
     const bool col_fast = s >= C;
     out += (size_t)blockIdx.y * H;
     double *lags = OUT == OUT_LAGS ? io.lags + (size_t)blockIdx.y * io.n_lags : nullptr;
+    if (OUT == OUT_PERM) {
+        // (s = 1, the host's condition: a column's R outputs are one run of R points; lanes walk its POSITIONS)
+        for (int idx = threadIdx.x; idx < (R << logC); idx += NT) {
+            const int x = idx & (R - 1), cc = idx >> logR;
+            const int j = pair_logical(x, R);
+            double2 v = buf[NET8_P(net8_row(j, logR, pl), cc)];
+            const long long c = c0 + cc;
+            if (!last && j != 0 && c != 0) v = cmul(v, tw_lookup(tt, (unsigned long long)j * (unsigned long long)c, logn_p));
+            out[(c << logR) + x] = v;
+        }
+        return;
+    }
     for (int idx = threadIdx.x; idx < (R << logC); idx += NT) {
         int cc, j;
         if (col_fast) {
@@ -496,6 +514,182 @@ __global__ __launch_bounds__(1024) void fft_pass8_kernel(const double2 *__restri
             if (OUT == OUT_CONJ) v.y = -v.y;
             out[o] = v;
         }
+    }
+#undef NET8_P
+}
+
+// Round 5: the middle of a TWO-pass autocorrelation in one launch — the forward transform's second pass, the spectrum
+// step and the inverse transform's first pass — so that the pipeline is three launches and the spectrum never leaves
+// the CU: 8 + 16 | 16 + 16 | 16 + 8 MB per 10^6-sample series through HBM instead of 8 + 16 | 16 + 16 | 32 + 16 | 16 + 8.
+// H = Ra Rb. The first pass (radix Ra, OUT_PERM) left in[Ra r + pair_phys(j)] = output j of column r; this kernel's
+// tile is C neighbouring positions x of every row r < Rb: the columns c = pair_logical(x) of the second pass, whose
+// outputs are the frequencies k = c + Ra j. H - k = (Ra - c) + Ra (Rb - 1 - j) (c > 0) lies in the column next door,
+// Ra (Rb - j) (c = 0) in the same one: the spectrum step (xcorr_spectrum_kernel's operations, SAME) works in place on
+// the tile, each pair by the lane that owns its lower frequency. The forward network (decimation in frequency, as
+// fft_pass8_kernel) leaves frequency j in row net8_row(j); the inverse runs the TRANSPOSED network — the rounds in
+// reverse order, twiddles before the butterflies — which takes exactly that order and ends in natural order (F = P A
+// is symmetric, so F w' = A^T P^T w', and P^T undoes the digit reversal the data already carries): no reordering
+// between the two. Output as the inverse's first pass (n = H, s = 1): out[Rb c + j], times e^{-2 pi i j c / H}.
+// grid (Ra / C tiles, batch), Rb C / 8 lanes; LDS as fft_pass8_kernel at radix Rb.
+__global__ __launch_bounds__(1024) void fft_mid_acf_kernel(const double2 *__restrict__ in, double2 *__restrict__ out,
+                                                           long long H, int logRa, int logR, int logC, TwTab tt)
+{
+    extern __shared__ double2 lds[];
+    const int R = 1 << logR, C = 1 << logC, NT = blockDim.x, Ra = 1 << logRa;
+    const Net8Plan pl = net8_plan(logR);
+    const int lf = pl.lf;
+    double2 *buf = lds;
+    double2 *tw = lds + (R << logC) + ((R >> lf) << logC);
+#define NET8_P(k, cc) ((((k) + ((k) >> lf)) << logC) + (cc))
+    long long tile = blockIdx.x;
+    if ((gridDim.x & 15u) == 0u) {  // (half-line tiles: the two halves of a line to the same XCD, as fft_pass8_kernel)
+        const unsigned m = blockIdx.x >> 3, xc = blockIdx.x & 7u;
+        tile = (long long)((m & 1u) + 2u * xc) + 16LL * (m >> 1);
+    }
+    const int x0 = (int)(tile << logC);
+    in += (size_t)blockIdx.y * H;
+    out += (size_t)blockIdx.y * H;
+    for (int idx = threadIdx.x; idx < (R << logC); idx += NT) {
+        const int k = idx >> logC, cc = idx & (C - 1);
+        buf[NET8_P(k, cc)] = in[x0 + cc + (long long)k * Ra];
+    }
+    for (int t = threadIdx.x; t < (R >> 1); t += NT) tw[t] = tw_lookup(tt, (unsigned long long)t, logR);
+    __syncthreads();
+    // ---- forward: radix-8 rounds with twiddles, then the last round (fft_pass8_kernel) ----
+    int logn = logR;
+    for (int q = 0; q < pl.n8; ++q) {
+        const int lst = logn - 3;
+        for (int b = threadIdx.x; b < (R >> 3 << logC); b += NT) {
+            const int cc = b & (C - 1), bf = b >> logC;
+            const int i = bf & ((1 << lst) - 1), blk = bf >> lst;
+            const int row0 = (blk << logn) + i;
+            double2 a[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] = buf[NET8_P(row0 + (e << lst), cc)];
+            net_dft8(a);
+            const int sh = logR - logn;
+            const double2 w1 = net8_root(tw, i << sh, R >> 1), w2 = net8_root(tw, (2 * i) << sh, R >> 1),
+                          w4 = net8_root(tw, (4 * i) << sh, R >> 1);
+            const double2 w3 = cmul(w1, w2), w5 = cmul(w4, w1), w6 = cmul(w4, w2), w7 = cmul(w4, w3);
+            a[1] = cmul(a[1], w1);
+            a[2] = cmul(a[2], w2);
+            a[3] = cmul(a[3], w3);
+            a[4] = cmul(a[4], w4);
+            a[5] = cmul(a[5], w5);
+            a[6] = cmul(a[6], w6);
+            a[7] = cmul(a[7], w7);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) buf[NET8_P(row0 + (e << lst), cc)] = a[e];
+        }
+        __syncthreads();
+        logn -= 3;
+    }
+    // the last round and its transpose: net_dft16 leaves frequency f0 + 4 f1 at 4 f0 + f1 (sg16: that digit swap), the
+    // smaller ones are in natural order. PRE: the rows are permuted on the way in, POST: on the way out.
+    auto last_round = [&](bool transposed) {
+        for (int b = threadIdx.x; b < (R >> lf << logC); b += NT) {
+            const int cc = b & (C - 1), row0 = (b >> logC) << lf;
+            if (lf == 4) {
+                double2 x[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) x[e] = buf[NET8_P(row0 + (transposed ? 4 * (e & 3) + (e >> 2) : e), cc)];
+                net_dft16(x);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) buf[NET8_P(row0 + e, cc)] = x[transposed ? 4 * (e & 3) + (e >> 2) : e];
+            } else if (lf == 3) {
+                double2 x[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = buf[NET8_P(row0 + e, cc)];
+                net_dft8(x);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) buf[NET8_P(row0 + e, cc)] = x[e];
+            } else if (lf == 2) {
+                double2 y0, y1, y2, y3;
+                net_dft4(buf[NET8_P(row0, cc)], buf[NET8_P(row0 + 1, cc)], buf[NET8_P(row0 + 2, cc)], buf[NET8_P(row0 + 3, cc)],
+                         y0, y1, y2, y3);
+                buf[NET8_P(row0, cc)] = y0;
+                buf[NET8_P(row0 + 1, cc)] = y1;
+                buf[NET8_P(row0 + 2, cc)] = y2;
+                buf[NET8_P(row0 + 3, cc)] = y3;
+            } else {
+                const double2 u = buf[NET8_P(row0, cc)], v = buf[NET8_P(row0 + 1, cc)];
+                buf[NET8_P(row0, cc)] = cadd(u, v);
+                buf[NET8_P(row0 + 1, cc)] = csub(u, v);
+            }
+        }
+    };
+    last_round(false);
+    __syncthreads();
+    // ---- spectrum step, in place (xcorr_spectrum_kernel<true>, pair by pair) ----
+    // (k = c + Ra j <= H / 2 exactly for j < Rb / 2, whatever the column — and for the one point H / 2 itself, c = 0,
+    // j = Rb / 2, which rides as one more item of the tile that holds column 0: every item is a pair to do)
+    const int n_items = (R >> 1 << logC) + (x0 == 0 ? 1 : 0);
+    for (int idx = threadIdx.x; idx < n_items; idx += NT) {
+        const bool mid_point = idx == (R >> 1 << logC);
+        const int cc = mid_point ? 0 : idx & (C - 1), j = mid_point ? R >> 1 : idx >> logC;
+        const int x = x0 + cc, c = pair_logical(x, Ra);
+        const long long k = (long long)c + (long long)Ra * j;
+        const int ccp = (x < 2 ? x : x ^ 1) - x0;
+        const int jp = c == 0 ? (R - j) & (R - 1) : R - 1 - j;
+        const int pos = NET8_P(net8_row(j, logR, pl), cc), posp = NET8_P(net8_row(jp, logR, pl), ccp);
+        const double2 zk = buf[pos], zh = buf[posp];
+        const double2 w = tw_lookup(tt, (unsigned long long)k, tt.logL);  // e^{-2 pi i k/L}
+        const double2 E = make_double2(0.5 * (zk.x + zh.x), 0.5 * (zk.y - zh.y));
+        const double2 O = make_double2(0.5 * (zk.y + zh.y), -0.5 * (zk.x - zh.x));
+        const double2 wo = cmul(w, O);
+        const double2 ak = make_double2(E.x + wo.x, E.y + wo.y);     // X(k)
+        const double2 ah = make_double2(E.x - wo.x, -(E.y - wo.y));  // X(H-k)
+        const double2 sk = make_double2(ak.x * ak.x + ak.y * ak.y, ak.y * ak.x - ak.x * ak.y);  // A conj(A), as mul_conj
+        const double2 sh = make_double2(ah.x * ah.x + ah.y * ah.y, ah.y * ah.x - ah.x * ah.y);
+        const double2 se = make_double2(sk.x + sh.x, sk.y - sh.y);
+        const double2 sd = make_double2(sk.x - sh.x, sk.y + sh.y);
+        const double2 t = cmul(make_double2(w.x, -w.y), sd);
+        buf[pos] = make_double2(se.x - t.y, -(se.y + t.x));
+        if (k != 0 && 2 * k != H) {
+            const double2 u = cmul(w, make_double2(sd.x, -sd.y));
+            buf[posp] = make_double2(se.x - u.y, -(-se.y + u.x));
+        }
+    }
+    __syncthreads();
+    // ---- inverse: the transposed network — last round first, then the radix-8 rounds, twiddles BEFORE the butterflies ----
+    last_round(true);
+    __syncthreads();
+    for (int q = pl.n8 - 1; q >= 0; --q) {
+        logn = logR - 3 * q;
+        const int lst = logn - 3;
+        for (int b = threadIdx.x; b < (R >> 3 << logC); b += NT) {
+            const int cc = b & (C - 1), bf = b >> logC;
+            const int i = bf & ((1 << lst) - 1), blk = bf >> lst;
+            const int row0 = (blk << logn) + i;
+            double2 a[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] = buf[NET8_P(row0 + (e << lst), cc)];
+            const int sh = logR - logn;
+            const double2 w1 = net8_root(tw, i << sh, R >> 1), w2 = net8_root(tw, (2 * i) << sh, R >> 1),
+                          w4 = net8_root(tw, (4 * i) << sh, R >> 1);
+            const double2 w3 = cmul(w1, w2), w5 = cmul(w4, w1), w6 = cmul(w4, w2), w7 = cmul(w4, w3);
+            a[1] = cmul(a[1], w1);
+            a[2] = cmul(a[2], w2);
+            a[3] = cmul(a[3], w3);
+            a[4] = cmul(a[4], w4);
+            a[5] = cmul(a[5], w5);
+            a[6] = cmul(a[6], w6);
+            a[7] = cmul(a[7], w7);
+            net_dft8(a);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) buf[NET8_P(row0 + (e << lst), cc)] = a[e];
+        }
+        __syncthreads();
+    }
+    // ---- the inverse's first pass ends: twiddle e^{-2 pi i j c / H}, a column's outputs one run of Rb points ----
+    int logH = 0;
+    while ((1LL << logH) < H) ++logH;
+    for (int idx = threadIdx.x; idx < (R << logC); idx += NT) {
+        const int j = idx & (R - 1), cc = idx >> logR;
+        const int c = pair_logical(x0 + cc, Ra);
+        double2 v = buf[NET8_P(j, cc)];
+        if (j != 0 && c != 0) v = cmul(v, tw_lookup(tt, (unsigned long long)j * (unsigned long long)c, logH));
+        out[((long long)c << logR) + j] = v;
     }
 #undef NET8_P
 }
@@ -815,10 +1009,40 @@ int mdhip_fft_xcorr(mdhip_ctx *ctx, const double *d_a, const double *d_b, long l
     io.series = d_a;
     TwTab tt;
     if (!fft_twiddle_table(ctx, H, tt)) return MDHIP_ENOMEM;
+    const bool same = d_a == d_b;
+    {
+        // Autocorrelation in THREE launches where the transform runs in two passes of the radix-8 network (round 5,
+        // fft_mid_acf_kernel): first pass (pairs next to each other) | second pass + spectrum + inverse's first | last
+        const PassPlan fp = plan_passes(ctx, H, batch);
+        int lc1 = 0, lcm = 0;
+        size_t lds1 = 0, ldsm = 0;
+        if (same && ctx->opt_fft_mid != 0 && fp.n_pass == 2 && net8_tile(ctx, H, fp.logR[0], lc1, lds1) &&
+            net8_tile(ctx, H, fp.logR[1], lcm, ldsm) && lcm >= 1) {
+            const int logRa = fp.logR[0], logRb = fp.logR[1];
+            if (ctx->opt_fft_mid == 2 && lcm > 1) {  // (A/B: tiles half as wide, more workgroups per CU)
+                --lcm;
+                ldsm = ((((size_t)1 << logRb) + ((size_t)1 << logRb >> net8_plan(logRb).lf)) << lcm) * sizeof(double2) +
+                       ((size_t)1 << logRb >> 1) * sizeof(double2);
+            }
+            if (!launch_pass<IN_PAD, OUT_PERM>(ctx, buf0, buf1, H, batch, logRa, 0, io, tt)) return MDHIP_EHIP;
+            const int threads = (int)std::min<long long>(1024, std::max<long long>(64, ((1LL << logRb) << lcm) >> 3));
+            MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fft_mid_acf_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm));
+            hipLaunchKernelGGL(fft_mid_acf_kernel, dim3((unsigned)((1LL << logRa) >> lcm), (unsigned)batch),
+                               dim3((unsigned)threads), ldsm, ctx->stream, buf1, buf0, H, logRa, logRb, lcm, tt);
+            io.lags = d_lags;
+            io.n_lags = n_lags;
+            io.L = (double)L;
+            io.scale = out_scale;
+            io.zb = nullptr;
+            if (!launch_pass<IN_PLAIN, OUT_LAGS>(ctx, buf0, buf1, H, batch, logRa, logRb, io, tt)) return MDHIP_EHIP;
+            MD_HIP(hipGetLastError());
+            return MDHIP_OK;
+        }
+    }
     double2 *Za = fft_forward(ctx, buf0, buf1, H, batch, IN_PAD, OUT_PLAIN, io, tt);
     if (!Za) return MDHIP_EHIP;
     double2 *Zb = Za;
-    const bool same = d_a == d_b;
     if (!same) {
         io.series = d_b;
         Zb = fft_forward(ctx, buf2, buf3, H, batch, IN_PAD, OUT_PLAIN, io, tt);

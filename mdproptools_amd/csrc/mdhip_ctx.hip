@@ -777,6 +777,8 @@ int mdhip_set_option(mdhip_ctx *ctx, const char *key, int value)
         ctx->opt_lag_fft_kernel = value;
     else if (!strcmp(key, "h2d_overlap"))
         ctx->opt_h2d_overlap = value;
+    else if (!strcmp(key, "fft_mid"))
+        ctx->opt_fft_mid = value;
     else if (!strcmp(key, "small_copy"))
         ctx->opt_small_copy = value;
     else if (!strcmp(key, "h2d_ring"))

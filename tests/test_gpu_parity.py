@@ -1351,7 +1351,7 @@ def test_lag_msd_batched_transforms_with_a_large_radix_pass(B):
 
 @pytest.mark.parametrize("n", [140_000, 300_000, 1_000_000])
 def test_xcorr_fft_large_radix_passes(B, n):
-    """Two-pass plans (radix 2^9 and 2^10 through the radix-8 network, fft_pass8_kernel: last rounds of 8 and of 16
+    """Two-pass plans (radix 2^9 and 2^10 through the radix-8 network, fft_pass8_kernel / fft_mid_acf_kernel: last rounds of 8 and of 16
     points, 4- and 8-column tiles, the XCD-paired tile order) against numpy's FFT at rounding level, and against the
     three-pass plan of the radix-4 network (fft_logr 8) and the radix-4 network at the large radices (fft_net8 0), with
     the spectrum step inside the inverse's first pass (default) and as its own kernel (fft_specfuse 0), cross- and
@@ -1368,7 +1368,12 @@ def test_xcorr_fft_large_radix_passes(B, n):
     ref_aa = np.fft.irfft(np.abs(np.fft.rfft(a, L)) ** 2, L)[..., :n]
     na, nb_ = np.linalg.norm(a, axis=1), np.linalg.norm(b, axis=1)
     try:
-        for opts in ({}, {"fft_specfuse": 0}, {"fft_logr": 8}, {"fft_net8": 0}, {"fft_net8": 2}):
+        # ({}: the autocorrelation runs in THREE launches, round 5 — fft_mid_acf_kernel: the forward transform's second
+        # pass, the spectrum step and the inverse's first pass on one tile, the inverse through the transposed network;
+        # fft_mid 0 the four launches it replaces, 2 its narrower tiles)
+        for opts in ({}, {"fft_mid": 0}, {"fft_mid": 2}, {"fft_specfuse": 0, "fft_mid": 0}, {"fft_logr": 8}, {"fft_net8": 0},
+                     {"fft_net8": 2}):
+            ctx.set_option("fft_mid", opts.get("fft_mid", 1))
             ctx.set_option("fft_logr", opts.get("fft_logr", 10))
             ctx.set_option("fft_net8", opts.get("fft_net8", 1))
             ctx.set_option("fft_specfuse", opts.get("fft_specfuse", 1))
@@ -1380,6 +1385,7 @@ def test_xcorr_fft_large_radix_passes(B, n):
         ctx.set_option("fft_logr", 10)
         ctx.set_option("fft_net8", 1)
         ctx.set_option("fft_specfuse", 1)
+        ctx.set_option("fft_mid", 1)
 
 
 def test_c5_acf_properties(B):
