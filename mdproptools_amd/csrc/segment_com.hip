@@ -267,7 +267,9 @@ __global__ __launch_bounds__(256) void segment_frame_kernel(
                 for (; a < t_hi[j]; ++a) acc += row[sc_pad(a)];
                 double r = acc / t_msum[j];
                 if (FLUX) r = (r * vel_conv) * t_qsi[j];
-                out[((size_t)f * n_attr + k0 + kk) * n_seg + b.s0 + t_seg[j]] = r;
+                // (non-temporal: a write stream of a tenth of the bytes read costs a plain read stream a quarter of its
+                // rate with ordinary stores and a sixth with these — tools/ubench_hbm.hip, 0.65 against 0.75 of 8 TB/s)
+                __builtin_nontemporal_store(r, out + ((size_t)f * n_attr + k0 + kk) * n_seg + b.s0 + t_seg[j]);
             }
         }
         if (step + gridDim.y < n_steps) __syncthreads();  // (only when the grid could not hold every step)
