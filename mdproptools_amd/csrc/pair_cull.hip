@@ -248,7 +248,9 @@ __global__ __launch_bounds__(SORT_THREADS) void cull_sort_lds_kernel(
 // phases; the keys never leave the registers either. 59 us (pre-pass of a C2 step 101 -> 92 us). What is left is not
 // arithmetic (timing builds, -DSORT_EXP: a multiplication for the division of wrapped_frac 0 us, a plain key instead
 // of the Hilbert arithmetic -8 us): the 200 blocks move 56 MB in and 64 MB out in lockstep — all read, all compute,
-// all write — so the memory system idles through the middle of every block's life.
+// all write — so the memory system idles through the middle of every block's life. (Non-temporal stores of the
+// scattered records: 92 -> 204 us, they lose the L2's write combining; of cull_boxes_kernel's f32 records: the
+// pre-pass the same, the sweep that reads them +17 us. Neither kept.)
 template <int ITEMS>
 __global__ __launch_bounds__(SORT_THREADS) void cull_sort_reg_kernel(
     const double *__restrict__ xyz, const int *__restrict__ type, long long type_fs, const double *__restrict__ box,
