@@ -31,6 +31,18 @@
 
 namespace {
 
+#ifndef FFT_NT_STORE
+#define FFT_NT_STORE 0  // (A/B build) 1: the passes' complex outputs leave with non-temporal stores
+#endif
+__device__ __forceinline__ void fft_store(double2 *p, double2 v)
+{
+#if FFT_NT_STORE
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    __builtin_nontemporal_store(d2_t{v.x, v.y}, reinterpret_cast<d2_t *>(p));
+#else
+    *p = v;
+#endif
+}
 constexpr int FFT_THREADS = 256;
 constexpr int FFT_MAX_LOGR = 10;   // largest radix of a pass the `fft_logr` knob may ask for (default 8: R <= 256, 64 KB tiles)
 constexpr int FFT_MAX_PASSES = 8;  // PassPlan::logR slots: H <= 2^32 at the smallest allowed radix, 2^4
@@ -199,7 +211,7 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_pass_kernel(const double2 *__
             if (t + 1 < io.n_lags) lags[t + 1] = ((-v.y / io.L) / (double)(io.n - t - 1)) * io.scale;
         } else {
             if (OUT == OUT_CONJ) v.y = -v.y;
-            out[o] = v;
+            fft_store(out + o, v);
         }
     }
 }
@@ -487,7 +499,7 @@ __global__ __launch_bounds__(1024) void fft_pass8_kernel(const double2 *__restri
             double2 v = buf[NET8_P(net8_row(j, logR, pl), cc)];
             const long long c = c0 + cc;
             if (!last && j != 0 && c != 0) v = cmul(v, tw_lookup(tt, (unsigned long long)j * (unsigned long long)c, logn_p));
-            out[(c << logR) + x] = v;
+            fft_store(out + (c << logR) + x, v);
         }
         return;
     }
@@ -512,7 +524,7 @@ __global__ __launch_bounds__(1024) void fft_pass8_kernel(const double2 *__restri
             if (t + 1 < io.n_lags) lags[t + 1] = ((-v.y / io.L) / (double)(io.n - t - 1)) * io.scale;
         } else {
             if (OUT == OUT_CONJ) v.y = -v.y;
-            out[o] = v;
+            fft_store(out + o, v);
         }
     }
 #undef NET8_P
@@ -689,7 +701,7 @@ __global__ __launch_bounds__(1024) void fft_mid_acf_kernel(const double2 *__rest
         const int c = pair_logical(x0 + cc, Ra);
         double2 v = buf[NET8_P(j, cc)];
         if (j != 0 && c != 0) v = cmul(v, tw_lookup(tt, (unsigned long long)j * (unsigned long long)c, logH));
-        out[((long long)c << logR) + j] = v;
+        fft_store(out + ((long long)c << logR) + j, v);
     }
 #undef NET8_P
 }
