@@ -127,22 +127,30 @@ int mdhip_device_name(mdhip_ctx *ctx, char *buf, int buflen);
  *                  instruction) with every pair inside the error band of a bin edge or of the cutoff resolved by
  *                  the exact f64 chain (default whenever the band is narrow enough; ordered rows when they fit LDS,
  *                  else class rows with their row table), 0 all-f64 sweep
- *   "rdf_sort"     spatial sort: -1 auto, 1 one block per frame (LDS counters), 0 multi-block (global counters)
+ *   "rdf_sort"     spatial sort: -1 auto, 1 one block per frame (LDS counters), 0 multi-block (global counters), 3 as
+ *                  auto without the read-once form for frames of <= 12288 atoms
  *   "rdf_inflight" per-frame output: frames in flight per XCD
  *   "rdf_jsplit", "rdf_fpb", "rdf_batch", "rdf_slots"  launch geometry of the pair kernels
  *   "lag_variant"  full-lag MSD: 3 / -1 (default) = autocorrelation theorem (O(F log F)) when the relative error
  *                  bound it computes for the data (mdhip_last_rel_bound) is <= 1e-10, else the exact-difference
  *                  kernel; 1 = always the series-resident difference kernel, 0 = staged difference kernel,
  *                  2 = always the autocorrelation theorem (the one knob that changes results, within that bound)
- *   "lag_fft_kernel" fused full-lag MSD kernel: 2 (default) first pass from registers + wave-private sub-transforms where
- *                  the series is long enough, 1 block-wide passes, 0 the round-2 kernel (results agree within the bound)
+ *   "lag_fft_kernel" fused full-lag MSD kernel: 3 (default) the 12288-point kernel (radix-12 first pass, twelve waves each a
+ *                  512-point transform in registers) where 3072 <= F and F + max_lag <= 12288, else as 2; 2 first pass
+ *                  from registers + wave-private sub-transforms of a power-of-two length where the series is long
+ *                  enough, 1 block-wide passes, 0 the round-2 kernel (results agree within the bound)
  *   "xcorr_tile"   time slabs of the direct correlation kernel
  *   "fft_logr", "fft_logc"  FFT correlation: largest radix of a pass (log2, default 10) and columns per tile of the
  *                  radix-4 network; "fft_net8" 1 (default) radix-8 network for passes of radix >= 2^9, 0 off, 2 one
- *                  workgroup per CU; "fft_specfuse" 1 (default) spectrum step inside the inverse's first pass
+ *                  workgroup per CU; "fft_specfuse" 1 (default) spectrum step inside the inverse's first pass;
+ *                  "fft_mid" 1 (default) an autocorrelation through a two-pass transform runs in three launches (second
+ *                  pass + spectrum step + inverse's first pass in one), 0 four, 2 three with narrower tiles
  *   "seg_frame"    segment COM / flux: 1 (default) one (run, frame) per block, 0 the software-pipelined staged kernel;
  *                  "seg_cap", "seg_vec", "seg_gy" geometry of the staged kernel
- *   "h2d_overlap"  host-resident frames: 1 (default) staged batch by batch under the sweeps, 0 copied first
+ *   "h2d_overlap"  host-resident frames: 1 (default) staged batch by batch under the sweeps, 0 copied first;
+ *                  "h2d_ring" 1 (default) pageable sources go through a page-locked ring filled by helper threads
+ *   "small_copy"   1 (default) copies of <= 256 KB between page-locked host memory and the device are made by a kernel
+ *                  on the launch stream, 0 by hipMemcpyAsync (a blit on another hardware queue)
  *   "rdf_guard", "cn_pk"  overflow guard / coordination counts through the packed sweep ("rdf_relblock": retired in
  *                  round 4, accepted and ignored — the f32 records are relative to their whole tile's centre)
  *   "lag_direct"   fused full-lag MSD path: -1 default (= 2), 0 transposed copy made by a pass of its own, 1 the kernel reads
