@@ -372,6 +372,7 @@ __global__ __launch_bounds__(W12_THREADS) void msd_power_w12_kernel(
         // 18 GB 4.1 ms = 4.4 TB/s of mixed reads and writes, the rate this kernel's traffic is served at — and below
         // ~12 GB the arithmetic and LDS time of the series (3.5 ms) hides it. Under 4.0 ms needs fewer bytes (a ring
         // that stays inside an XCD's 4 MB L2 does not fit two clusters' live tiles), not a better schedule.
+        // (The non-temporal hint on the ring's stores, its loads or both: 4.26 / 4.11 / 4.21 ms against 4.14-4.19 — nothing.)
         // Nor is it the instruction count at the margin (same process, 4.20 ms): the mean by a reciprocal made once
         // instead of a division per series (-12 vector instructions of ~640) 4.20 ms; the two multiplications per unit
         // skipped behind a wave-uniform test of scale == 1.0 4.51-4.54 ms (the branches cut the schedule the compiler

@@ -913,7 +913,7 @@ def msd_step_sharded_async(r_f, r_e, n_frames_total, entity_range, group_off, ta
     owner = frame_owner(F, origin_frame, world, counts)
     nS, nW, nL = F * G * 4, E * 4, n_lags * G * 4
     with (torch.cuda.stream(_step_stream(dev, ctx)) if on_gpu else contextlib.nullcontext()):
-        zero = torch.zeros((3, E), dtype=torch.float64, device=dev)
+        zero = None if (rank == owner and len(kept_local)) else torch.zeros((3, E), dtype=torch.float64, device=dev)
         mine = torch.stack([r_f[origin_frame - lo] if rank == owner else zero,
                             r_f[int(kept_local[-1])] if len(kept_local) else zero])
         allf = _allgather_equal(mine) if world > 1 else mine[None]  # [world, 2, 3, E]
@@ -928,10 +928,22 @@ def msd_step_sharded_async(r_f, r_e, n_frames_total, entity_range, group_off, ta
         # (mdhip_lag_msd_status_dev: its error bound, +inf when its result will be rewritten at completion), which
         # every rank reads from the reduced buffer: whether the lag sums must be redone is agreed on without a host
         # wait between the kernels and the collective)
-        res = torch.zeros(nS + nW + nL + 2, dtype=torch.float64, device=dev)
+        # (only what no kernel of this rank writes is zeroed: the other ranks' single-origin rows, the lag sums of groups
+        # held elsewhere, the two flag words — the window sums, most of the buffer, are written whole by their kernel; a
+        # fill of all 1.9 MB cost the shard-of-8 step 37 us of its ~1 ms)
+        on_dev_fill = on_gpu
+        res = (torch.empty if on_dev_fill else torch.zeros)(nS + nW + nL + 2, dtype=torch.float64, device=dev)
         single = res[:nS].view(F, G, 4)
         win = res[nS:nS + nW].view(E, 4)
         lagsum = res[nS + nW:nS + nW + nL].view(n_lags, G, 4)
+        if on_dev_fill:
+            if lo > 0:
+                single[:lo].zero_()
+            if hi < F:
+                single[hi:].zero_()
+            if not (len(kept_local) and on_gpu):
+                win.zero_()
+            res[nS + nW:].zero_()
         hs = {}
         k0 = int(kept_local[0]) if len(kept_local) else 0
         means, x, loc_off = None, None, None
