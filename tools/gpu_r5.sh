@@ -34,9 +34,9 @@ for s in "$@"; do
     w12_check) timeout -k 10 400 python tools/w12_check.py 2>&1 | grep -v amdgpu > $O/r05_w12_check.txt; tail -12 $O/r05_w12_check.txt ;;
     w12_exp) timeout -k 10 400 python tools/w12_exp.py $L tools/_bin/libmdhip_w12e256.so tools/_bin/libmdhip_w12e512.so tools/_bin/libmdhip_w12e128.so tools/_bin/libmdhip_w12e1024.so $L 2>&1 | grep -v amdgpu > $O/r05_w12_exp.txt; cat $O/r05_w12_exp.txt ;;
     fft_mid) timeout -k 10 400 python tools/fft_mid_check.py 2>&1 | grep -v amdgpu > $O/r05_fft_mid.txt; cat $O/r05_fft_mid.txt ;;
-    ab_small_copy) bash tools/ab_opt.sh small_copy 1 0 "rdf_golden" > $O/r05_ab_small_copy.txt 2>&1; cat $O/r05_ab_small_copy.txt ;;
-    ab_sort) bash tools/ab_opt.sh rdf_sort -1 3 "rdf_golden" > $O/r05_ab_sort.txt 2>&1; cat $O/r05_ab_sort.txt ;;
-    c4_shard) ( for n in 8 4; do for o in two one; do C4_ORDER=$o timeout -k 10 300 python tools/c4_shard_cost.py $n 2>&1 | grep -v amdgpu | tail -3; done; done ) > $O/r05_c4_shard.txt 2>&1; cat $O/r05_c4_shard.txt ;;
+    ab_small_copy) bash tools/ab_opt.sh small_copy 1 0 "golden" > $O/r05_ab_small_copy.txt 2>&1; cat $O/r05_ab_small_copy.txt ;;
+    ab_sort) bash tools/ab_opt.sh rdf_sort -1 3 "golden" > $O/r05_ab_sort.txt 2>&1; cat $O/r05_ab_sort.txt ;;
+    c4_shard) ( for rep in 1 2 3; do for n in 8 4; do for o in two one; do C4_ORDER=$o timeout -k 10 300 python tools/c4_shard_cost.py $n 2>&1 | grep -v amdgpu | tail -3; done; done; done ) > $O/r05_c4_shard.txt 2>&1; cat $O/r05_c4_shard.txt ;;
     ab_msd) timeout -k 10 400 python tools/ab_libs_msd.py $L4 $L 2>&1 | grep -v amdgpu > $O/r05_ab_msd.txt; cat $O/r05_ab_msd.txt ;;
     ubench_hbm) timeout -k 10 300 tools/_bin/ubench_hbm $O/r05_ubench_hbm.json > $O/r05_ubench_hbm.txt 2>&1; cat $O/r05_ubench_hbm.txt ;;
     *) if [ -f "$s" ]; then timeout -k 10 600 python "$s" > $O/$(basename $s .py)_${TAG}.txt 2>&1; echo "$s rc=$?"; tail -40 $O/$(basename $s .py)_${TAG}.txt; else echo "unknown step $s"; fi ;;
