@@ -1642,7 +1642,18 @@ __global__ void fold_items_kernel(const double *__restrict__ part, const int *__
     if (i >= width) return;
     const int s = blockIdx.y;
     double acc = 0.0;
-    for (int q = seg_item_off[s]; q < seg_item_off[s + 1]; ++q) acc += part[(size_t)q * width + i];
+    // (eight rows requested before the first is added — the additions keep their order: same bits — instead of a load
+    // and a wait per row: the grid is only (width / 256) x segments blocks, 60 at C4, and took 26 + 30 us per call)
+    int q = seg_item_off[s];
+    const int q1 = seg_item_off[s + 1];
+    for (; q + 8 <= q1; q += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(part + (size_t)(q + u) * width + i);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; q < q1; ++q) acc += part[(size_t)q * width + i];
     out[(size_t)s * width + i] = acc;
 }
 

@@ -389,3 +389,40 @@ def test_lag_msd_staged_integer_ramp_exact_and_reproducible():
                 np.testing.assert_allclose(o[1:, 0, 0], k2[1:], rtol=0, atol=1e-3)
     finally:
         ctx.close()
+
+
+def test_read_once_sort_every_instance_and_small_copy_paths(B):
+    """Round 5's pre-pass changes, against the forms they replace: the spatial sort that keeps a frame's atoms in
+    registers (cull_sort_reg_kernel<2..12>: one instance per 2048 atoms, frames of up to 12288; beyond that the loop
+    form) against the multi-block sort (rdf_sort 0) and the loop form (rdf_sort 3), and the small host<->device copies
+    made by a kernel (small_copy 1) against hipMemcpyAsync (0) — frame-summed and per-frame results, host and the
+    one-sweep RDF+CN: the integers must be identical, whatever order the atoms of a cell end up in."""
+    from mdproptools_amd._lib import Context
+
+    rng = np.random.default_rng(5)
+    ref_ctx, new_ctx = Context(0), Context(0)
+    ref_ctx.set_option("rdf_sort", 0)
+    ref_ctx.set_option("small_copy", 0)
+    for c in (ref_ctx, new_ctx):
+        c.set_option("rdf_cull", 1)
+    try:
+        for n in (700, 2048, 2049, 4100, 6200, 8191, 10000, 12288, 12289, 13000):
+            F, L = 3, 46.0
+            xyz = rng.uniform(-3.0, L + 3.0, (F, 3, n))  # (atoms outside the cell too: the sort wraps, the sweep does not)
+            ty = rng.integers(1, 4, n).astype(np.int32)
+            box = np.full((F, 3), L)
+            rel = np.array([[1, 1], [1, 2], [2, 3], [3, 3]])
+            for per_frame in (False, True):
+                a = B.rdf_loop(xyz, ty, box, rel, 9.0, 0.05, 180, per_frame=per_frame, ctx=ref_ctx)
+                b = B.rdf_loop(xyz, ty, box, rel, 9.0, 0.05, 180, per_frame=per_frame, ctx=new_ctx)
+                assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2], (n, per_frame)
+            new_ctx.set_option("rdf_sort", 3)
+            c = B.rdf_loop(xyz, ty, box, rel, 9.0, 0.05, 180, per_frame=False, ctx=new_ctx)
+            new_ctx.set_option("rdf_sort", -1)
+            assert np.array_equal(a[0].sum(axis=0) if a[0].ndim > 1 else a[0], c[0]), n
+            ra = B.rdf_cn_loop(xyz, ty, box, rel, 9.0, 0.05, 180, [3.1, 4.0, 5.5, 2.2], per_frame=False, ctx=ref_ctx)
+            rb = B.rdf_cn_loop(xyz, ty, box, rel, 9.0, 0.05, 180, [3.1, 4.0, 5.5, 2.2], per_frame=False, ctx=new_ctx)
+            assert all(np.array_equal(u, v) for u, v in zip(ra[:2], rb[:2])) and np.array_equal(ra[2], rb[2]), n
+    finally:
+        ref_ctx.close()
+        new_ctx.close()
