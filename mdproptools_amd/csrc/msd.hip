@@ -605,7 +605,8 @@ int msd_pairs_impl(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double
     memcpy(h_tab, chunks.data(), ch_b);
     memcpy(h_tab + ch_b, pairs, pr_b);
     memcpy(h_tab + ch_b + pr_b, gco.data(), gc_b);
-    MD_HIP(hipMemcpyAsync(d_tab, h_tab, tab_b, hipMemcpyHostToDevice, ctx->stream));
+    rc = mdhip_copy_small(ctx, d_tab, h_tab, tab_b, hipMemcpyHostToDevice);
+    if (rc) return rc;
     Chunk *d_chunks = reinterpret_cast<Chunk *>(d_tab);
     int *d_pairs = reinterpret_cast<int *>(d_tab + ch_b);
     int *d_gco = d_pairs + 2 * n_pairs;
@@ -881,7 +882,8 @@ static int lag_msd_impl(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const d
     memcpy(h_tab, chunks.data(), ch_b);
     memcpy(h_tab + ch_b, group_off, go_b);
     memcpy(h_tab + ch_b + go_b, gco.data(), gc_b);
-    MD_HIP(hipMemcpyAsync(d_tab, h_tab, tab_b, hipMemcpyHostToDevice, ctx->stream));
+    rc = mdhip_copy_small(ctx, d_tab, h_tab, tab_b, hipMemcpyHostToDevice);
+    if (rc) return rc;
     Chunk *d_chunks = reinterpret_cast<Chunk *>(d_tab);
     long long *d_goff = reinterpret_cast<long long *>(d_tab + ch_b);
     int *d_gco = reinterpret_cast<int *>(d_goff + n_groups + 1);
@@ -998,7 +1000,7 @@ int mdhip_lag_msd_status_dev(mdhip_ctx *ctx, double *dst_dev)
     if (!ctx || !dst_dev) return MDHIP_EINVAL;
     MD_HIP(hipSetDevice(ctx->device));
     if (ctx->lag_status_dev)
-        MD_HIP(hipMemcpyAsync(dst_dev, ctx->lag_status_dev, 8, hipMemcpyDeviceToDevice, ctx->stream));
+        return mdhip_copy_small(ctx, dst_dev, ctx->lag_status_dev, 8, hipMemcpyDeviceToDevice);
     else
         MD_HIP(hipMemsetAsync(dst_dev, 0, 8, ctx->stream));
     return MDHIP_OK;

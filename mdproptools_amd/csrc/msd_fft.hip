@@ -2097,7 +2097,10 @@ int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r
         if (!stages.empty()) memcpy(h_tab + 4096 + it_b + so_b, stages.data(), stages.size() * sizeof(FftStage));
         double *h_ng = reinterpret_cast<double *>(h_tab + 4096 + it_b + so_b + sg_b);
         for (long long g = 0; g < G; ++g) h_ng[g] = (double)(group_off[g + 1] - group_off[g]);
-        MD_HIP(hipMemcpyAsync(d_tab, h_tab, 4096 + it_b + so_b + sg_b + ng_b, hipMemcpyHostToDevice, ctx->stream));
+        {  // (a kernel on the launch stream, not a copy engine's job: no hand-over between queues — mdhip_copy_small)
+            const int rcc = mdhip_copy_small(ctx, d_tab, h_tab, 4096 + it_b + so_b + sg_b + ng_b, hipMemcpyHostToDevice);
+            if (rcc) return rcc;
+        }
         if (staged) MD_HIP(hipMemsetAsync(d_ready, 0, rd_b, ctx->stream));
     }
 
@@ -2249,10 +2252,15 @@ int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r
     MD_PIN(h_bound, double, (size_t)S * 8 + 8);
     unsigned *h_stall = reinterpret_cast<unsigned *>(h_bound + S);
     *h_stall = 0u;
-    MD_HIP(hipMemcpyAsync(h_bound, d_bound, (size_t)S * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (staged)
-        MD_HIP(hipMemcpyAsync(h_stall, d_ready + (size_t)n_clusters * ST_BUF * ST_FLAG_STRIDE, 4, hipMemcpyDeviceToHost,
-                              ctx->stream));
+    {
+        const int rcc = mdhip_copy_small(ctx, h_bound, d_bound, (size_t)S * 8, hipMemcpyDeviceToHost);
+        if (rcc) return rcc;
+    }
+    if (staged) {
+        const int rcc = mdhip_copy_small(ctx, h_stall, d_ready + (size_t)n_clusters * ST_BUF * ST_FLAG_STRIDE, 4,
+                                         hipMemcpyDeviceToHost);
+        if (rcc) return rcc;
+    }
     cs.defer([=]() {
         timer.collect();
         if (*h_stall) {
