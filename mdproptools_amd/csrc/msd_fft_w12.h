@@ -370,8 +370,11 @@ __global__ __launch_bounds__(W12_THREADS) void msd_power_w12_kernel(
         // ring stores without sc1 4.07-4.17 ms (no change). The stores alone are free, the loads alone cost 0.2 ms, both
         // 0.57 ms: the price follows the BYTES through the fabric port — 6 GB (ring in) 3.56 ms, 12 GB 3.5-3.75 ms,
         // 18 GB 4.1 ms = 4.4 TB/s of mixed reads and writes, the rate this kernel's traffic is served at — and below
-        // ~12 GB the arithmetic and LDS time of the series (3.5 ms) hides it. Under 4.0 ms needs fewer bytes (a ring
-        // that stays inside an XCD's 4 MB L2 does not fit two clusters' live tiles), not a better schedule.
+        // ~12 GB the arithmetic and LDS time of the series (3.5 ms) hides it. Under 4.0 ms needs fewer bytes, not a
+        // better schedule — and not simply a ring next door: with every cluster's 16 members dealt to ONE XCD (block b
+        // runs on XCD b % 8) and the ring going through that XCD's L2 (plain stores, plain or sc0 loads; a timing build,
+        // right only by luck) the call took 4.16-4.23 ms against 4.14-4.20: two clusters' live tiles (8 x 655 KB each)
+        // do not fit 4 MB of L2 beside the trajectory streaming through it. (With an L1 invalidate per series: 15 ms.)
         // (The non-temporal hint on the ring's stores, its loads or both: 4.26 / 4.11 / 4.21 ms against 4.14-4.19 — nothing.)
         // Nor is it the instruction count at the margin (same process, 4.20 ms): the mean by a reciprocal made once
         // instead of a division per series (-12 vector instructions of ~640) 4.20 ms; the two multiplications per unit
