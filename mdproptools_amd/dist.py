@@ -799,7 +799,8 @@ def _post_group():
     they were issued; a step's all-reduce is issued (queued behind the step's kernels) before the next step's all-gather,
     so on ONE communicator the next step's pre-exchange — and with it the next step's kernels — would wait for this
     step's kernels, post-processing and collective: no pipelining (measured on the shard of 8: 1.25 ms per step against
-    0.95). Created collectively by the first fused step of every rank."""
+    0.95, a one-rank RCCL group). Created collectively by the first fused step of every rank. OPT-IN
+    (MDHIP_STEP_POST_GROUP=1): see the call site."""
     d = _dist()
     key = id(d.group.WORLD)
     g = _POST_GROUP.get(key)
@@ -1013,7 +1014,11 @@ def msd_step_sharded_async(r_f, r_e, n_frames_total, entity_range, group_off, ta
                 if issue_err is None:
                     post_ops()
                 if world > 1:
-                    _allreduce_inplace(res, _post_group())
+                    # (the second communicator is opt-in, MDHIP_STEP_POST_GROUP=1: collectives of two communicators in
+                    # flight at once have not been run on more than one GPU here — a one-rank RCCL group and gloo pairs
+                    # are what this box allows — and a hang would cost a whole multi-GPU run; on the default group the
+                    # next step's all-gather queues behind this all-reduce, which is slower but cannot interleave)
+                    _allreduce_inplace(res, _post_group() if os.environ.get("MDHIP_STEP_POST_GROUP", "0") == "1" else None)
                 flat_np, flat_t = _pinned_like(res)
                 flat_t.copy_(res, non_blocking=True)
                 ev_done = torch.cuda.Event()
