@@ -39,7 +39,9 @@ __device__ __forceinline__ double wave_sum(double v)
 // pair, from L2. A block that keeps the origin's values in registers and walks 8 pairs, or requests 4 pairs' frames at
 // once, took 0.65 / 0.72 ms against 0.40 ms for 2000 pairs at C4 shape: what this kernel lives on is a quarter of a
 // million small independent blocks in flight, which the longer blocks give up. msd_windows_kernel with two entities
-// per lane and four windows' frames requested together: 0.119 against 0.117 ms, no change.)
+// per lane and four windows' frames requested together: 0.119 against 0.117 ms, no change. The four wave sums through
+// DPP lanes (row_shr 1-8, row_bcast15 / 31: no LDS instruction) instead of 48 ds_bpermute per wave: 0.405 against
+// 0.408 ms — the epilogue is not what holds the kernel either.)
 // grid (n_chunks, n_pairs). partial [n_pairs][n_chunks][4]. VEC2: every lane handles two consecutive
 // entities with 16-byte loads (needs an even entity count and even chunk starts, checked by the host).
 template <bool VEC2>
