@@ -998,7 +998,7 @@ def msd_step_sharded_async(r_f, r_e, n_frames_total, entity_range, group_off, ta
             if means is not None:
                 w = _lag_weights(origins, g_hi, g_lo, held, dev)
                 if len(held) == G:
-                    lagsum.copy_(means * w[:, :, None])
+                    torch.mul(means, w[:, :, None], out=lagsum)  # (one kernel: the product lands in the reduced buffer)
                 else:
                     lagsum[:, torch.as_tensor(held, device=dev), :] = means * w[:, :, None]
 
