@@ -420,14 +420,17 @@ int mdhip_segment_com(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, int n_a
     // default: four waves share a 1024-atom stage; seg_cap = 256 selects the wave-private form (one wave per block,
     // 256-atom stage, no block barrier that costs anything) — measured 0.61 against 0.635 of HBM spec at C4 shape, so
     // the two barriers per step are not what limits this kernel
-    int cap = ctx->opt_seg_cap == 512 ? 512 : ctx->opt_seg_cap == 256 ? 256 : SC_CAP_MAX;
+    // round 5: the by-frame kernel with a 512-atom stage by default (seg_cap 1024: the round-3 stage) — half the LDS and
+    // registers per block, more blocks per CU: 0.516 -> 0.486 ms at C4 shape / 2000 frames in one process, same bits
+    int cap = ctx->opt_seg_cap == 1024 ? SC_CAP_MAX : ctx->opt_seg_cap == 256 ? 256 : 512;
+    if (ctx->opt_seg_frame == 0 && ctx->opt_seg_cap == 0) cap = SC_CAP_MAX;  // (the staged kernel's default is unchanged)
     bool staged = build_seg_blocks(n_seg, seg_off, blocks, cap, cap == 256 ? 64 : 256);
     if (!staged && cap != SC_CAP_MAX) {
         cap = SC_CAP_MAX;
         staged = build_seg_blocks(n_seg, seg_off, blocks, cap, 256);
     }
     SegBlock *d_blocks = nullptr;
-    const bool by_frame = staged && ctx->opt_seg_frame != 0 && cap == SC_CAP_MAX;
+    const bool by_frame = staged && ctx->opt_seg_frame != 0 && (cap == SC_CAP_MAX || cap == 512);
     std::vector<SegRun> runs;
     SegRun *d_runs = nullptr;
     double *d_msum = nullptr;
@@ -456,10 +459,17 @@ int mdhip_segment_com(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, int n_a
     if (by_frame) {
         const long long n_steps = (long long)n_frames * ((n_attr + SC_PLANES - 1) / SC_PLANES);
         const unsigned gy = (unsigned)std::min<long long>(n_steps, 65535);
+        if (cap == 512) {
+            ctx->last_kernel = "segment_frame_kernel<false, 512>";
+            hipLaunchKernelGGL((segment_frame_kernel<false, 512>), dim3((unsigned)runs.size(), gy), dim3(256), 0,
+                               ctx->stream, d_attr, d_mass, d_msum, (const double *)nullptr, d_off, d_runs, d_out, n_attr,
+                               (long long)n_atoms, (long long)n_seg, n_steps, 1.0);
+        } else {
         ctx->last_kernel = "segment_frame_kernel<false, 1024>";
         hipLaunchKernelGGL((segment_frame_kernel<false, 1024>), dim3((unsigned)runs.size(), gy), dim3(256), 0,
                            ctx->stream, d_attr, d_mass, d_msum, (const double *)nullptr, d_off, d_runs, d_out, n_attr,
                            (long long)n_atoms, (long long)n_seg, n_steps, 1.0);
+        }
     } else if (staged) {
         // enough (block, frame slice) pairs to fill the chip several times over; a block loops over its frames
         // frame slices: at least enough (block, slice) pairs to fill the chip several times over, and short runs of
@@ -557,7 +567,8 @@ static int charge_flux_impl(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, c
     // default: four waves share a 1024-atom stage; seg_cap = 256 selects the wave-private form (one wave per block,
     // 256-atom stage, no block barrier that costs anything) — measured 0.61 against 0.635 of HBM spec at C4 shape, so
     // the two barriers per step are not what limits this kernel
-    int cap = ctx->opt_seg_cap == 512 ? 512 : ctx->opt_seg_cap == 256 ? 256 : SC_CAP_MAX;
+    int cap = ctx->opt_seg_cap == 1024 ? SC_CAP_MAX : ctx->opt_seg_cap == 256 ? 256 : 512;  // (as mdhip_segment_com)
+    if (ctx->opt_seg_frame == 0 && ctx->opt_seg_cap == 0) cap = SC_CAP_MAX;
     bool staged = build_seg_blocks(n_seg, seg_off, blocks, cap, cap == 256 ? 64 : 256);
     if (!staged && cap != SC_CAP_MAX) {
         cap = SC_CAP_MAX;
@@ -571,7 +582,7 @@ static int charge_flux_impl(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, c
         rc = mdhip_h2d_small(ctx, d_blocks, blocks.data(), blocks.size() * sizeof(SegBlock));
         if (rc) return rc;
     }
-    const bool by_frame = staged && ctx->opt_seg_frame != 0 && cap == SC_CAP_MAX;
+    const bool by_frame = staged && ctx->opt_seg_frame != 0 && (cap == SC_CAP_MAX || cap == 512);
     SegRun *d_runs = nullptr;
     double *d_msq = nullptr;  // per segment: mass sum, then (charge sum) x charge_conv — the host's index-order sums
     if (by_frame) {
@@ -600,10 +611,17 @@ static int charge_flux_impl(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, c
     if (by_frame) {
         const long long n_steps = (long long)n_frames;
         const unsigned gy = (unsigned)std::min<long long>(n_steps, 65535);
-        ctx->last_kernel = "segment_frame_kernel<true, 1024>";
-        hipLaunchKernelGGL((segment_frame_kernel<true, 1024>), dim3((unsigned)blocks.size(), gy), dim3(256), 0,
-                           ctx->stream, d_vel, d_mq, d_msq, d_msq + n_seg, d_off, d_runs, d_tmp, 3, (long long)n_atoms,
-                           (long long)n_seg, n_steps, vel_conv);
+        if (cap == 512) {
+            ctx->last_kernel = "segment_frame_kernel<true, 512>";
+            hipLaunchKernelGGL((segment_frame_kernel<true, 512>), dim3((unsigned)blocks.size(), gy), dim3(256), 0,
+                               ctx->stream, d_vel, d_mq, d_msq, d_msq + n_seg, d_off, d_runs, d_tmp, 3, (long long)n_atoms,
+                               (long long)n_seg, n_steps, vel_conv);
+        } else {
+            ctx->last_kernel = "segment_frame_kernel<true, 1024>";
+            hipLaunchKernelGGL((segment_frame_kernel<true, 1024>), dim3((unsigned)blocks.size(), gy), dim3(256), 0,
+                               ctx->stream, d_vel, d_mq, d_msq, d_msq + n_seg, d_off, d_runs, d_tmp, 3, (long long)n_atoms,
+                               (long long)n_seg, n_steps, vel_conv);
+        }
     } else if (staged) {
         int64_t want = ((int64_t)ctx->cu_count * 16 + (int64_t)blocks.size() - 1) / (int64_t)blocks.size();
         want = std::max<int64_t>(want, n_frames / 10);
