@@ -180,8 +180,8 @@ struct mdhip_ctx {
                               // 64 frames, C2 1.60 against 1.70 ms
     int opt_rdf_guard = 0;    // overflow guard of the 32-bit LDS histogram words: neighbour tiles a block may sweep
                               // per launch (0 = the real bound, 2^32 / (64 * 256) with margin; tests lower it)
-    int opt_seg_cap = 0;      // segment kernels: atoms per block stage: 0 = 512 for the by-frame kernel (round 5), 1024 for the
-                              // staged one; 1024, 512, or 256 = one wave per block (A/B)
+    int opt_seg_cap = 0;      // segment kernels: atoms per block stage: 0 = 1024 or 512 by the shape of the segment table (by-frame
+                              // kernel, pick_seg_cap), 1024 for the staged one; 1024, 512, or 256 = one wave per block (A/B)
     int opt_seg_vec = 1;      // segment kernels: 16-byte loads when alignment allows (default), 0 = 8-byte loads (A/B)
     int opt_fft_logr = 10;    // fft_pow2.hip: largest radix of a pass (log2, 4..10); passes of radix >= 2^9 run the radix-8
                               // network (fft_pass8_kernel), so that 2^20 points take two passes (round 2: 8 = three passes)

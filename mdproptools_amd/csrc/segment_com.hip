@@ -10,6 +10,8 @@
 #include <algorithm>
 #include <vector>
 
+#include <cmath>
+
 #include "ctx.h"
 
 #pragma clang fp contract(off)
@@ -292,6 +294,34 @@ bool build_seg_blocks(int64_t n_seg, const int64_t *seg_off, std::vector<SegBloc
     return true;
 }
 
+// Stage size of the by-frame kernel for a segment table (round 5; measured at C4 size, tools/ab_seg_cap.py): 1024 atoms per
+// block unless that leaves the block's second phase — one lane per (segment, plane) sum, 256 lanes a round — mostly idle
+// rounds (10-atom molecules: 102 segments x 3 planes = 306 sums = two rounds for 1.2 rounds' worth: 0.515 -> 0.478 ms with
+// 512-atom stages) or the stage mostly empty (3-atom molecules: the 256-segment limit fills 768 of 1024: 0.722 -> 0.69).
+// Molecules of 4, 16, 40 atoms and mixes of them keep 1024 (512: 2-7 % slower).
+int pick_seg_cap(int64_t n_seg, const int64_t *seg_off, int n_attr, std::vector<SegBlock> &blocks)
+{
+    if (!build_seg_blocks(n_seg, seg_off, blocks, SC_CAP_MAX, 256)) {
+        blocks.clear();  // (a segment longer than the stage: the caller takes the one-lane-per-segment kernel)
+        return SC_CAP_MAX;
+    }
+    const int planes = n_attr < SC_PLANES ? n_attr : SC_PLANES;
+    double rounds = 0.0, tasks = 0.0, atoms = 0.0;
+    for (const SegBlock &b : blocks) {
+        const double t = (double)planes * (double)(b.s1 - b.s0);
+        rounds += std::ceil(t / 256.0);
+        tasks += t;
+        atoms += (double)(seg_off[b.s1] - seg_off[b.s0]);
+    }
+    const bool idle_rounds = rounds > (double)blocks.size() && rounds * 256.0 > 1.5 * tasks;
+    const bool empty_stage = atoms < 0.85 * (double)SC_CAP_MAX * (double)blocks.size() && blocks.size() > 1;
+    if (!(idle_rounds || empty_stage)) return SC_CAP_MAX;
+    std::vector<SegBlock> half;
+    if (!build_seg_blocks(n_seg, seg_off, half, 512, 256)) return SC_CAP_MAX;
+    blocks.swap(half);
+    return 512;
+}
+
 // Fallback: one lane per (segment, frame) walking global memory
 __global__ __launch_bounds__(256) void segment_com_kernel(
     const double *__restrict__ attr, const double *__restrict__ mass,
@@ -420,14 +450,17 @@ int mdhip_segment_com(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, int n_a
     // default: four waves share a 1024-atom stage; seg_cap = 256 selects the wave-private form (one wave per block,
     // 256-atom stage, no block barrier that costs anything) — measured 0.61 against 0.635 of HBM spec at C4 shape, so
     // the two barriers per step are not what limits this kernel
-    // round 5: the by-frame kernel with a 512-atom stage by default (seg_cap 1024: the round-3 stage) — half the LDS and
-    // registers per block, more blocks per CU: 0.516 -> 0.486 ms at C4 shape / 2000 frames in one process, same bits
-    int cap = ctx->opt_seg_cap == 1024 ? SC_CAP_MAX : ctx->opt_seg_cap == 256 ? 256 : 512;
-    if (ctx->opt_seg_frame == 0 && ctx->opt_seg_cap == 0) cap = SC_CAP_MAX;  // (the staged kernel's default is unchanged)
-    bool staged = build_seg_blocks(n_seg, seg_off, blocks, cap, cap == 256 ? 64 : 256);
-    if (!staged && cap != SC_CAP_MAX) {
-        cap = SC_CAP_MAX;
-        staged = build_seg_blocks(n_seg, seg_off, blocks, cap, 256);
+    int cap = ctx->opt_seg_cap == 512 ? 512 : ctx->opt_seg_cap == 256 ? 256 : SC_CAP_MAX;
+    bool staged;
+    if (ctx->opt_seg_cap == 0 && ctx->opt_seg_frame != 0) {  // (default: by the shape of the segment table, pick_seg_cap)
+        cap = pick_seg_cap(n_seg, seg_off, n_attr, blocks);
+        staged = !blocks.empty();
+    } else {
+        staged = build_seg_blocks(n_seg, seg_off, blocks, cap, cap == 256 ? 64 : 256);
+        if (!staged && cap != SC_CAP_MAX) {
+            cap = SC_CAP_MAX;
+            staged = build_seg_blocks(n_seg, seg_off, blocks, cap, 256);
+        }
     }
     SegBlock *d_blocks = nullptr;
     const bool by_frame = staged && ctx->opt_seg_frame != 0 && (cap == SC_CAP_MAX || cap == 512);
@@ -567,12 +600,17 @@ static int charge_flux_impl(mdhip_ctx *ctx, int64_t n_frames, int64_t n_atoms, c
     // default: four waves share a 1024-atom stage; seg_cap = 256 selects the wave-private form (one wave per block,
     // 256-atom stage, no block barrier that costs anything) — measured 0.61 against 0.635 of HBM spec at C4 shape, so
     // the two barriers per step are not what limits this kernel
-    int cap = ctx->opt_seg_cap == 1024 ? SC_CAP_MAX : ctx->opt_seg_cap == 256 ? 256 : 512;  // (as mdhip_segment_com)
-    if (ctx->opt_seg_frame == 0 && ctx->opt_seg_cap == 0) cap = SC_CAP_MAX;
-    bool staged = build_seg_blocks(n_seg, seg_off, blocks, cap, cap == 256 ? 64 : 256);
-    if (!staged && cap != SC_CAP_MAX) {
-        cap = SC_CAP_MAX;
-        staged = build_seg_blocks(n_seg, seg_off, blocks, cap, 256);
+    int cap = ctx->opt_seg_cap == 512 ? 512 : ctx->opt_seg_cap == 256 ? 256 : SC_CAP_MAX;
+    bool staged;
+    if (ctx->opt_seg_cap == 0 && ctx->opt_seg_frame != 0) {  // (as mdhip_segment_com)
+        cap = pick_seg_cap(n_seg, seg_off, 3, blocks);
+        staged = !blocks.empty();
+    } else {
+        staged = build_seg_blocks(n_seg, seg_off, blocks, cap, cap == 256 ? 64 : 256);
+        if (!staged && cap != SC_CAP_MAX) {
+            cap = SC_CAP_MAX;
+            staged = build_seg_blocks(n_seg, seg_off, blocks, cap, 256);
+        }
     }
     SegBlock *d_blocks = nullptr;
     if (staged) {
