@@ -80,7 +80,8 @@ __global__ void trap_scan_fill_kernel(unsigned long long *__restrict__ w, unsign
 
 __global__ __launch_bounds__(SC_THREADS) void trap_scan_onepass_kernel(
     const double *__restrict__ y, double *__restrict__ out, double *__restrict__ totals, double *__restrict__ other,
-    unsigned n_words, double *__restrict__ carry, unsigned *__restrict__ stall, unsigned t0, unsigned t_end, long long n,
+    unsigned n_words, const double *__restrict__ carry_in, double *__restrict__ carry_out, unsigned *__restrict__ stall,
+    unsigned t0, unsigned t_end, long long n,
     long long out_stride, int lead, double dx, int n_blocks, double post_scale)
 {
     __shared__ double s_v[SC_BLOCK + SC_BLOCK / 8 + 2];
@@ -155,10 +156,13 @@ __global__ __launch_bounds__(SC_THREADS) void trap_scan_onepass_kernel(
     if (lane == 63) s_w[wv] = sc;
     __syncthreads();
     // what came before this launch (a series that starts inside it: nothing), then the four wave sums in order
-    double off = first_t > (unsigned)series * (unsigned)n_blocks ? carry[series] : 0.0;
+    // (round 6, ADVICE r05: the carry words alternate by launch parity like the totals — this launch READS what the launch
+    // before it wrote and WRITES the other set; with one set the last tile's store below raced with these loads whenever a
+    // continued series filled the whole launch)
+    double off = first_t > (unsigned)series * (unsigned)n_blocks ? carry_in[series] : 0.0;
     for (int w = 0; w < SC_THREADS / 64; ++w) off += s_w[w];
     // (the launch's last tile: what the next launch of this call starts its series from — behind this one on the stream)
-    if (t == t_end - 1 && tid == SC_THREADS - 1) carry[series] = off + tile_total;
+    if (t == t_end - 1 && tid == SC_THREADS - 1) carry_out[series] = off + tile_total;
 #pragma unroll
     for (int u = 0; u < SC_PER; ++u) s_v[sc_pad(tid * SC_PER + u)] = (off + (before + v[u])) * post_scale;
     __syncthreads();
@@ -183,14 +187,15 @@ int mdhip_cumtrapz_enqueue(mdhip_ctx *ctx, int64_t n, int n_series, const double
     MD_REQUIRE(total < (1u << 30), "too many scan tiles (%zu)", total);
     // tiles per launch: a block adds up at most SC_PER totals per lane (no residency condition: the waits go backwards)
     const size_t cap = (size_t)SC_PER * SC_THREADS;
-    // two sets of totals (launches alternate, see the kernel) | stall word (a line of its own) | carry: one double per
-    // series (a buffer that has to grow for more series is emptied again)
-    const size_t words = 2 * cap + 16 + (size_t)std::max(n_series, 64);
+    // two sets of totals (launches alternate, see the kernel) | stall word (a line of its own) | carry: two sets of one
+    // double per series, alternating with the totals (a buffer that has to grow for more series is emptied again)
+    const size_t n_carry = (size_t)std::max(n_series, 64);
+    const size_t words = 2 * cap + 16 + 2 * n_carry;
     const bool fresh = ctx->ws[WS_SCAN].cap < words * 8 || ctx->scan_capacity <= 0;
     MD_WS(d_ws, double, WS_SCAN, words * 8);
     double *d_set[2] = {d_ws, d_ws + cap};
     unsigned *d_stall = reinterpret_cast<unsigned *>(d_ws + 2 * cap);
-    double *d_carry = d_ws + 2 * cap + 16;
+    double *d_carry[2] = {d_ws + 2 * cap + 16, d_ws + 2 * cap + 16 + n_carry};
     if (fresh) {
         hipLaunchKernelGGL(trap_scan_fill_kernel, dim3((unsigned)((2 * cap + 255) / 256)), dim3(256), 0, ctx->stream,
                            reinterpret_cast<unsigned long long *>(d_ws), (unsigned)(2 * cap));
@@ -204,7 +209,8 @@ int mdhip_cumtrapz_enqueue(mdhip_ctx *ctx, int64_t n, int n_series, const double
         const int par = ctx->scan_parity;
         ctx->scan_parity ^= 1;
         hipLaunchKernelGGL(trap_scan_onepass_kernel, dim3(g), dim3(SC_THREADS), 0, ctx->stream, d_y, d_out, d_set[par],
-                           d_set[par ^ 1], (unsigned)cap, d_carry, d_stall, (unsigned)t0, (unsigned)t1, (long long)n,
+                           d_set[par ^ 1], (unsigned)cap, d_carry[par ^ 1], d_carry[par], d_stall, (unsigned)t0, (unsigned)t1,
+                           (long long)n,
                            (long long)out_stride, lead, dx, n_blocks, post_scale);
     }
     MD_HIP(hipGetLastError());

@@ -613,6 +613,33 @@ def test_cumtrapz_golden_and_sizes(B, g_acf):
                 np.testing.assert_allclose(res[s], exp, rtol=1e-9, atol=1e-12 * max(1.0, abs(exp).max() if len(exp) else 1.0))
 
 
+@pytest.mark.parametrize("shape", [(5, 1_000_001), (1, 9_000_000), (3, 4_196_000)])
+def test_cumtrapz_across_launch_boundaries(B, shape):
+    """More than 2048 tiles: the scan takes several launches, a series continues from the launch before it through the
+    carry words and the two sets of totals alternate (with one set of carry words the last tile's store
+    raced with the other tiles' loads whenever a continued series filled a whole launch). Integer-valued samples whose
+    partial sums stay below 2^53 make every summation order exact: the result must equal numpy's cumsum bit for bit,
+    and repeats must be bit-identical."""
+    s, n = shape
+    rng = np.random.default_rng(17 + n % 97)
+    y = rng.integers(-1000, 1001, size=(s, n)).astype(np.float64)
+    inc = y[:, 1:] + y[:, :-1]  # dx = 2: inc = 2 * (y0 + y1) / 2, exact
+    exp = np.cumsum(inc, axis=1)
+    first = B.cumtrapz(y, 2.0)
+    np.testing.assert_array_equal(first, exp)
+    for rep in range(3):
+        np.testing.assert_array_equal(B.cumtrapz(y, 2.0), first)
+    lead = B.cumtrapz(y, 2.0, leading_zero=True)
+    np.testing.assert_array_equal(lead[:, 1:], exp)
+    assert not lead[:, 0].any()
+    # and a float case against the oracle to rounding
+    z = rng.standard_normal((s, n))
+    got = B.cumtrapz(z, 0.37)
+    for k in range(s):
+        e = O.cumtrapz(z[k], 0.37)
+        np.testing.assert_allclose(got[k], e, rtol=1e-9, atol=1e-12 * max(1.0, abs(e).max()))
+
+
 # ------------------------------------------------------------------ full-size properties (BASELINE C2)
 def test_c2_full_size_properties(B):
     """N=10 000, F=200 at full size: frame 0 against the C oracle, and size-independent identities."""
