@@ -484,6 +484,54 @@ def leg_f64_only(B, ctx, xyz, types, box, rel, cfg, nb, steps, pairs_per_step, f
             "roofline": valu_roofline(kernel, "C2", kdur, "v_add_f64", 4, pairs_per_step, 28.0 * n * F)}
 
 
+def leg_c1(B, ctx, torch, device, synth, sync, steps, c2_kernel_ns_per_kpair, alt):
+    """The reference's own workload shape (BASELINE configs[0]) on the fast path: N = 10 479 at the example's
+    density, the nine atom types with the example's populations and the notebook's five relations (alt: the 32
+    pseudo-types of the altered-id mode and its two relations), r_cut 20 A, 400 bins, synthetic positions, 200 frames
+    per launch like C2 so that the per-pair cost compares with the headline's. Frame 0 against the C oracle."""
+    cfg = synth.rdf_config("C1")
+    n, L, F = cfg["n_atoms"], cfg["box_len"], cfg["n_frames"]
+    nb = int(cfg["r_cut"] / cfg["bin_size"])
+    xyz = torch.empty((F, 3, n), dtype=torch.float64, device=device)
+    for f0 in range(0, F, 50):
+        xyz[f0:f0 + 50] = torch.from_numpy(synth.rdf_frames(n, range(f0, min(F, f0 + 50)), L, cfg["seed_offset"])).to(device)
+    ty = synth.c1_types(alt)
+    rel = np.array(synth.C1_ALT_RELATIONS if alt else synth.C1_RELATIONS, dtype=np.int32)
+    box = np.full((F, 3), L)
+    pairs = F * n * (n - 1) // 2
+    stats = []
+
+    def issue():
+        h = B.rdf_loop(xyz, ty, box, rel, cfg["r_cut"], cfg["bin_size"], nb, per_frame=False, ctx=ctx, async_=True)
+        stats.append(h)
+        return h
+
+    dt, (full, part, _ov) = timed_pipelined(issue, sync, steps)
+    kernel = ctx.last_kernel_name()
+    ks = [h.stats() for h in stats[-steps:]]
+    kdur = float(np.mean([k[0] / max(k[2], 1) for k in ks])) * 1e-3
+    aux = float(np.mean([k[1] for k in ks]))
+    f0, p0, _ = B.rdf_loop(xyz[:1], ty, box[:1], rel, cfg["r_cut"], cfg["bin_size"], nb, ctx=ctx)
+    cf, cp, _ = cpu_check_frame(xyz[0].cpu().numpy(), ty, rel, L, cfg, nb)
+    if not (np.array_equal(f0[0], cf) and np.array_equal(p0[0], cp)):
+        raise AssertionError("C1-shaped frame 0 differs from oracle/cpu_ref.c")
+    pf = B.rdf_loop(xyz[:8], ty, box[:8], rel, cfg["r_cut"], cfg["bin_size"], nb, per_frame=True, ctx=ctx)
+    s8 = B.rdf_loop(xyz[:8], ty, box[:8], rel, cfg["r_cut"], cfg["bin_size"], nb, per_frame=False, ctx=ctx)
+    if not (np.array_equal(pf[0].sum(axis=0), s8[0]) and np.array_equal(pf[1].sum(axis=0), s8[1])):
+        raise AssertionError("C1 shape: frame-summed histograms differ from the sum of the per-frame ones")
+    ns_per_kpair = kdur * 1e9 / (pairs / 1e3)
+    tag = "C1alt" if alt else "C1"
+    return {"workload": "%s: 10 479 atoms x 200 frames, L=49.18 A, %s, r_cut 20 A, 400 bins, synthetic positions"
+                        % (tag, "32 pseudo-types (altered ids), relations 32-17, 32-32" if alt
+                           else "9 types (example populations), relations 9-1, 9-4, 9-6, 9-9, 1-3"),
+            "value": pairs / dt, "unit": "atom-pairs/s", "ms_per_step": dt * 1e3, "kernel": kernel,
+            "kernel_ms": kdur * 1e3, "prepass_ms": aux, "pairs_per_step": pairs,
+            "kernel_ns_per_kpair": ns_per_kpair,
+            "cost_per_pair_over_c2": None if not c2_kernel_ns_per_kpair else ns_per_kpair / c2_kernel_ns_per_kpair,
+            "parity_checked": "frame 0 == oracle/cpu_ref.c; sum of 8 per-frame histograms == their frame-summed call",
+            "roofline": valu_roofline(kernel, tag, kdur, "mix bin 11/16", 6, pairs, 28.0 * n * F)}
+
+
 def timed_pipelined(issue, sync, reps):
     """Mean wall time per call of `reps` asynchronous calls, each issued before the one before it is waited for (the
     headline loop's pattern), after eight untimed ones in the same pattern (staging blocks of every call in flight exist
@@ -1062,12 +1110,15 @@ def main():
     ap.add_argument("--msd-steps", type=int, default=5, help="timed steps of the `msd` object of the default line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="headline only (profiling runs)")
-    ap.add_argument("--legs", default="parity,f64,h2d,c3,c4,c5")
+    ap.add_argument("--legs", default="parity,f64,h2d,c1,c3,c4,c5")
     ap.add_argument("--cpu-frames", type=int, default=10)
     ap.add_argument("--variant", type=int, default=None, help="kernel variant knob (A/B only)")
     ap.add_argument("--option", action="append", default=[], help="library option key=value (A/B only)")
     ap.add_argument("--op", choices=["rdf", "cn", "rdf_cn"], default="rdf",
                     help="what the headline loop calls (profiling runs of the CN and the one-sweep kernels; N = 1)")
+    ap.add_argument("--shape", choices=("C1", "C1alt"), default=None,
+                    help="profiling runs only (implies --no-legs): the headline loop on the reference's own workload shape "
+                         "(leg_c1's inputs) instead of C2")
     args = ap.parse_args()
     if args.scaling is None:
         args.scaling = "strong" if args.workload == "c4" else "weak"
@@ -1144,6 +1195,12 @@ def main():
     nb = int(cfg["r_cut"] / cfg["bin_size"])
     types = synth.rdf_types(n)
     rel = np.array(synth.ALL_PAIRS_4, dtype=np.int32)
+    if args.shape:  # (a profiling run: the C1 legs' inputs through the headline loop)
+        cfg = synth.rdf_config("C1")
+        n, L = cfg["n_atoms"], cfg["box_len"]
+        types = synth.c1_types(args.shape == "C1alt")
+        rel = np.array(synth.C1_ALT_RELATIONS if args.shape == "C1alt" else synth.C1_RELATIONS, dtype=np.int32)
+        args.no_legs = True
     if strong:  # C3's frames split contiguously over the ranks
         lo, hi = D.frame_shard(cfg["n_frames"], rank, world)
         frame_ids = range(lo, hi)
@@ -1261,6 +1318,8 @@ def main():
         kdur = max(kernel_ms / max(launches, 1) * 1e-3, 1e-9)  # average duration of one pair_hist launch
         wl = ("C3: 100k atoms x 1000 frames over %d GPU(s), L=104 A" % world) if strong else \
              "C2: 10k atoms x 200 frames per GPU, L=50 A"
+        if args.shape:
+            wl = "%s (profiling run): 10 479 atoms x 200 frames, L=49.18 A" % args.shape
         packed = any(t in kernel_name for t in ("<3", "<4", "<5", "<6"))
         out = {
             "metric": "atom-pairs/s", "value": value, "unit": "atom-pairs/s", "n_gpus": world,
@@ -1268,12 +1327,12 @@ def main():
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32/f64" if packed else "f64",
             "data": "synthetic",
             # strings below stay under 128 characters: the driver's record cuts longer ones
-            "config": {"workload": wl + ", 4 types, 10 relations, r_cut 20 A, 400 bins, uint64 sums"
+            "config": {"workload": wl + ("" if args.shape else ", 4 types, 10 relations") + ", r_cut 20 A, 400 bins, uint64 sums"
                                       + (", %s all-reduce" % ("RCCL" if backend == "nccl" else backend) if world > 1 else ""),
                        "pairs_per_step": pairs_job, "frames_per_gpu": F, "kernel": kernel_name,
                        "arithmetic": "packed-f32 classification + exact f64 resolution near edges; integers == all-f64 "
                                      "sweep (roofline.f64_only_*)" if packed else "f64"},
-            "roofline": valu_roofline(kernel_name, ("C3" if strong else "C2") + ("" if args.op == "rdf" else "/" + args.op),
+            "roofline": valu_roofline(kernel_name, (args.shape or ("C3" if strong else "C2")) + ("" if args.op == "rdf" else "/" + args.op),
                                       kdur, "mix bin 11/16", 6, pairs_local, 28.0 * n * F),
         }
         out["roofline"]["prepass_ms_per_step"] = aux_ms / args.steps
@@ -1327,6 +1386,10 @@ def main():
                                                      elapsed / args.steps * 1e3))
         del xyz
         torch.cuda.empty_cache()
+        c2_ns = kdur * 1e9 / (pairs_local / 1e3)
+        if "c1" in legs:
+            run_leg("c1", lambda: leg_c1(B, ctx, torch, device, synth, sync, max(5, args.steps // 2), c2_ns, False))
+            run_leg("c1_alt", lambda: leg_c1(B, ctx, torch, device, synth, sync, max(5, args.steps // 2), c2_ns, True))
         if "c3" in legs:
             run_leg("c3", lambda: leg_c3(B, ctx, torch, device, synth, sync))
         if "c4" in legs:

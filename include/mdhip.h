@@ -179,6 +179,17 @@ int mdhip_bin_edges(double bin_size, int nbins, double *edges);
  */
 double mdhip_pk_error_bound(double r_cut, double bin_size, int nbins, int n_rows, double s_cap, double l_max);
 
+/*
+ * Row layout of the table-free ("ordered rows") sweep when the plain n_ti x n_tj rows do not fit LDS:
+ * integers a[n_ti], b[n_tj] such that row(ti, tj) = a[ti] + b[tj] never holds two type pairs of different classes
+ * (cls[ti * n_tj + tj] >= 0: the class of the ordered pair), with *n_rows = max a + max b + 1 < n_ti * n_tj rows and
+ * row_cls[row] the class of every row (-1: unused; at least n_ti * n_tj entries). *n_rows = 0: no layout with fewer
+ * rows than the plain one was found (a, b, row_cls untouched). Exposed so that the layout's defining property can be
+ * checked without a device (tests/test_abi_cpu.py); a pure function, deterministic.
+ */
+int mdhip_row_displacement(int n_ti, int n_tj, const int32_t *cls, int32_t *a, int32_t *b, int32_t *row_cls,
+                           int *n_rows);
+
 /* ---- R3: _rdf_loop (+ _calc_rsq, _remove_outliers) ------------------------ */
 /*
  * structural/rdf_cn.py:72-97 for n_frames frames at once.

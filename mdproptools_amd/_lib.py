@@ -50,6 +50,7 @@ PROTOTYPES = {
     "mdhip_set_option": (C.c_int, [vp, C.c_char_p, C.c_int]),
     "mdhip_bin_edges": (C.c_int, [C.c_double, C.c_int, c_dp]),
     "mdhip_pk_error_bound": (C.c_double, [C.c_double, C.c_double, C.c_int, C.c_int, C.c_double, C.c_double]),
+    "mdhip_row_displacement": (C.c_int, [C.c_int, C.c_int, c_ip, c_ip, c_ip, c_ip, C.POINTER(C.c_int)]),
     "mdhip_rdf_atomic": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, c_ip, C.c_int64, c_dp, C.c_int,
                                    c_ip, C.c_double, C.c_double, C.c_int, c_dp, C.c_int, c_up, c_up, c_up]),
     "mdhip_rdf_atomic_dev": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_int, c_ip, C.c_int64, c_dp, C.c_int,

@@ -36,6 +36,11 @@ struct PairArgs {
     double rc2;
     float gscale;  // 1/bin_size as float for the sqrt guess; 0 -> scan up from bin 0 (CN edges)
     int n_ti, n_tj, n_cls, nbins;
+    // ordered-pair rows (MODE 2-4 of the scalar-j kernel): row of (ti, tj) = A[ti] + B[tj] with host-chosen integers
+    // (pair_hist.hip, row displacement); the records carry A[t] * n_ti in the low word of w and near + B[t] * row_len
+    // in the high word. The plain layout is A[t] = t * n_tj, B[t] = t (row_mul = n_tj with A[t] = t in the record).
+    int row_mul;     // lane row base = (low word / n_ti) * row_mul rows
+    int n_rows_ord;  // rows of the ordered layout: max A + max B + 1
     int n_frames, nTi, nTj, jsplit, blocks_per_frame;
     int per_frame, slots;
     int fpb;  // frames swept per block before the flush (fast kernel, frame-summed output only)
@@ -122,11 +127,17 @@ struct FastCtx {
 
 // 4th double of a sorted record: low word = type * n_ti (word offset into the [tj][ti] row table), high word =
 // float(near + type * row_len), the addend of the bin guess that carries the row of the ordered-pair layout
-// (MODE 2 of the scalar-j kernel; 0 otherwise).
-__device__ __forceinline__ double pack_w(int t, int n_ti, float near, int row_len)
+// (MODE 2 of the scalar-j kernel; 0 otherwise). With displaced rows (`disp` != nullptr: [2][n_types] = A | B, see
+// PairArgs::row_mul) the low word carries A[t] * n_ti and the addend B[t] * row_len.
+struct RowDisp {
+    const int *lo = nullptr;  // device: A[t] (i role) — nullptr: t
+    const int *hi = nullptr;  // device: B[t] (j role) — nullptr: t
+};
+__device__ __forceinline__ double pack_w(int t, int n_ti, float near, int row_len, const RowDisp &d)
 {
-    const unsigned lo = (unsigned)(t * n_ti);
-    const unsigned hi = row_len > 0 ? __float_as_uint(near + (float)(t * row_len)) : 0u;
+    const int tl = d.lo ? d.lo[t] : t, th = d.hi ? d.hi[t] : t;
+    const unsigned lo = (unsigned)(tl * n_ti);
+    const unsigned hi = row_len > 0 ? __float_as_uint(near + (float)(th * row_len)) : 0u;
     return __hiloint2double((int)hi, (int)lo);
 }
 
@@ -154,8 +165,8 @@ void launch_reduce_slots(hipStream_t stream, const unsigned long long *in, unsig
 
 // pair_sj.hip
 size_t lds_bytes_sj(int nbins, int n_cls, int n_ti, int n_tj, bool mode_cn);
-size_t lds_bytes_sj_ordered(int nbins, int n_ti, int n_tj);
-size_t lds_bytes_sj_pk(int nbins, int n_ti, int n_tj, int n_cn = 0);
+size_t lds_bytes_sj_ordered(int nbins, int n_rows);
+size_t lds_bytes_sj_pk(int nbins, int n_rows, int n_cn = 0);
 size_t lds_bytes_sj_pk_rows(int nbins, int n_cls, int n_ti, int n_tj, int n_cn = 0);  // class rows + row table + queues
 int sj_block_threads(int mode);  // threads per block of the scalar-j kernels (mode as sj_kernel)
 PairKernel sj_kernel(int mode /* 0 RDF class rows, 1 CN, 2 RDF ordered-pair rows, 3 = 2 with the packed-f32 sweep,
@@ -173,8 +184,8 @@ void launch_merge_slices(hipStream_t stream, const unsigned *slices, int hist_wo
 constexpr int MORTON_BITS = 5;                       // 32 cells per axis
 constexpr int MORTON_CELLS = 1 << (3 * MORTON_BITS); // 32768
 int cull_prepare_set(mdhip_ctx *ctx, int64_t F, const double *d_x, const int *d_t, long long t_fs,
-                     const double *d_box, long long N, int nT, int n_ti, float near, int row_len, bool want_soa,
-                     int want_rel /* != 0: the tile-relative f32 records of the packed sweep and their tiles' centres */,
+                     const double *d_box, long long N, int nT, int n_ti, float near, int row_len, RowDisp disp,
+                     bool want_soa, int want_rel /* != 0: the tile-relative f32 records of the packed sweep and their tiles' centres */,
                      int rel_w_type /* w of the f32 records: 0 bin-guess addend, 1 row-table offset */,
                      int cbox /* 1: 4-atom and 64-atom boxes as (centre, half extents): packed-f32 sweep */,
                      const int slot[5], SortedSet &out);

@@ -157,7 +157,7 @@ constexpr size_t SORT_CELL_WORDS = MORTON_CELLS + MORTON_CELLS / 32;
 __global__ __launch_bounds__(SORT_THREADS) void cull_sort_lds_kernel(
     const double *__restrict__ xyz, const int *__restrict__ type, long long type_fs,
     const double *__restrict__ box, long long n, unsigned short *__restrict__ keys, double *__restrict__ sxyz,
-    int *__restrict__ stype, double4 *__restrict__ aos, long long n_pad, int n_ti, float near, int row_len)
+    int *__restrict__ stype, double4 *__restrict__ aos, long long n_pad, int n_ti, float near, int row_len, RowDisp disp)
 {
     extern __shared__ unsigned s_cells[];  // [SORT_CELL_WORDS] + 3 x 16 doubles of scratch behind it
     double *s_red = reinterpret_cast<double *>(s_cells + SORT_CELL_WORDS);
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(SORT_THREADS) void cull_sort_lds_kernel(
             o[2 * n + pos] = pz;
             stype[(size_t)f * n + pos] = t;
         }
-        aos[(size_t)f * n_pad + pos] = make_double4(px, py, pz, pack_w(t, n_ti, near, row_len));
+        aos[(size_t)f * n_pad + pos] = make_double4(px, py, pz, pack_w(t, n_ti, near, row_len, disp));
     }
     for (long long i = n + tid; i < n_pad; i += SORT_THREADS)
         aos[(size_t)f * n_pad + i] = make_double4(PAD_J, PAD_J, PAD_J, __longlong_as_double(0LL));
@@ -255,7 +255,7 @@ template <int ITEMS>
 __global__ __launch_bounds__(SORT_THREADS) void cull_sort_reg_kernel(
     const double *__restrict__ xyz, const int *__restrict__ type, long long type_fs, const double *__restrict__ box,
     long long n, double *__restrict__ sxyz, int *__restrict__ stype, double4 *__restrict__ aos, long long n_pad, int n_ti,
-    float near, int row_len)
+    float near, int row_len, RowDisp disp)
 {
     extern __shared__ unsigned s_cells[];  // [SORT_CELL_WORDS] + 3 x 16 doubles of scratch behind it
     double *s_red = reinterpret_cast<double *>(s_cells + SORT_CELL_WORDS);
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(SORT_THREADS) void cull_sort_reg_kernel(
                 o[2 * n + pos] = pz[k];
                 stype[(size_t)f * n + pos] = tp[k];
             }
-            aos[(size_t)f * n_pad + pos] = make_double4(px[k], py[k], pz[k], pack_w(tp[k], n_ti, near, row_len));
+            aos[(size_t)f * n_pad + pos] = make_double4(px[k], py[k], pz[k], pack_w(tp[k], n_ti, near, row_len, disp));
         }
     }
     for (long long i = n + tid; i < n_pad; i += SORT_THREADS)
@@ -379,7 +379,7 @@ __global__ void cull_scatter_kernel(const double *__restrict__ xyz, const int *_
                                     long long type_fs, long long n, const unsigned short *__restrict__ keys,
                                     unsigned *__restrict__ cells, double *__restrict__ sxyz,
                                     int *__restrict__ stype, double4 *__restrict__ aos, long long n_pad,
-                                    int n_ti, float near, int row_len)
+                                    int n_ti, float near, int row_len, RowDisp disp)
 {
     const int f = blockIdx.y;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -396,7 +396,7 @@ __global__ void cull_scatter_kernel(const double *__restrict__ xyz, const int *_
         o[2 * n + pos] = pz;
         stype[(size_t)f * n + pos] = t;
     }
-    aos[(size_t)f * n_pad + pos] = make_double4(px, py, pz, pack_w(t, n_ti, near, row_len));
+    aos[(size_t)f * n_pad + pos] = make_double4(px, py, pz, pack_w(t, n_ti, near, row_len, disp));
     // the pad records behind the last atom (never in cutoff: rsq overflows to +inf)
     if (i < n_pad - n) aos[(size_t)f * n_pad + n + i] = make_double4(PAD_J, PAD_J, PAD_J, __longlong_as_double(0LL));
 }
@@ -583,8 +583,8 @@ __global__ __launch_bounds__(256) void cull_list_kernel(const double *__restrict
 }  // namespace
 
 int cull_prepare_set(mdhip_ctx *ctx, int64_t F, const double *d_x, const int *d_t, long long t_fs,
-                     const double *d_box, long long N, int nT, int n_ti, float near, int row_len, bool want_soa,
-                     int want_rel_i, int rel_w_type, int cbox, const int slot[5], SortedSet &out)
+                     const double *d_box, long long N, int nT, int n_ti, float near, int row_len, RowDisp disp,
+                     bool want_soa, int want_rel_i, int rel_w_type, int cbox, const int slot[5], SortedSet &out)
 {
     const bool want_rel = want_rel_i != 0;
     MD_WS(d_rel, float, WS_REL, want_rel ? (size_t)F * nT * TILE * 16 : 64);
@@ -613,7 +613,7 @@ int cull_prepare_set(mdhip_ctx *ctx, int64_t F, const double *d_x, const int *d_
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));                     \
         hipLaunchKernelGGL(cull_sort_reg_kernel<I>, dim3((unsigned)F), dim3(SORT_THREADS), sort_lds, ctx->stream,   \
                            d_x, d_t, t_fs, d_box, N, want_soa ? d_sx : (double *)nullptr, d_st, d_ao,               \
-                           (long long)nT * TILE, n_ti, near, row_len);                                              \
+                           (long long)nT * TILE, n_ti, near, row_len, disp);                                        \
     }
         if (sort_items <= 2) MD_SORT_REG(2)
         else if (sort_items <= 4) MD_SORT_REG(4)
@@ -627,7 +627,7 @@ int cull_prepare_set(mdhip_ctx *ctx, int64_t F, const double *d_x, const int *d_
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));
         hipLaunchKernelGGL(cull_sort_lds_kernel, dim3((unsigned)F), dim3(SORT_THREADS), sort_lds, ctx->stream, d_x,
                            d_t, t_fs, d_box, N, d_keys, want_soa ? d_sx : (double *)nullptr, d_st, d_ao,
-                           (long long)nT * TILE, n_ti, near, row_len);
+                           (long long)nT * TILE, n_ti, near, row_len, disp);
     } else {
         MD_HIP(hipMemsetAsync(d_cells, 0, (size_t)F * MORTON_CELLS * 4, ctx->stream));
         MD_WS(d_org, double, WS_ORIGIN, (size_t)F * 3 * 8);
@@ -636,7 +636,7 @@ int cull_prepare_set(mdhip_ctx *ctx, int64_t F, const double *d_x, const int *d_
         hipLaunchKernelGGL(cull_scan_kernel, dim3((unsigned)F), dim3(256), 0, ctx->stream, d_cells);
         hipLaunchKernelGGL(cull_scatter_kernel, ga, dim3(256), 0, ctx->stream, d_x, d_t, t_fs, N, d_keys, d_cells,
                            want_soa ? d_sx : (double *)nullptr, d_st, d_ao, (long long)nT * TILE, n_ti, near,
-                           row_len);
+                           row_len, disp);
     }
     hipLaunchKernelGGL(cull_boxes_kernel, dim3((unsigned)nT, (unsigned)F), dim3(TILE), 0, ctx->stream, d_ao, d_box, N,
                        nT, d_bbox, d_gs, d_ws, d_g4, want_rel ? d_cen : (double *)nullptr,

@@ -26,6 +26,10 @@
 //   pair_dense.hip  LDS-tile kernels: dense half-shell sweep for small frames, the edge-table kernel of the
 //                   first commit (A/B baseline, fallback for > 64 CN cutoffs)
 // This file: relations -> classes, edge tables, batching, launch geometry, rows -> outputs, the C-ABI.
+#include <chrono>
+#include <map>
+#include <mutex>
+
 #include "pair_common.h"
 
 using namespace mdpair;
@@ -48,6 +52,9 @@ struct PairProblem {
     int n_ti, n_tj;
     std::vector<int> cls;  // [n_ti][n_tj] -> class id (< n_cls; any number of classes: the device sees pass-local bytes)
     int n_cls;
+    // displaced ordered rows (displace_rows below): row of (ti, tj) = disp_a[ti] + disp_b[tj]; disp_rows == 0: none found
+    std::vector<int> disp_a, disp_b, disp_cls;  // disp_cls[row] -> class id (-1: no type pair lands there)
+    int disp_rows = 0;
     int nbins;
     const double *edges;  // host [nbins+1]
     double rc2;
@@ -75,6 +82,152 @@ struct PairProblem {
 };
 constexpr int CN_UNFUSED = 1;  // (positive: not an error code of the ABI)
 constexpr int SPLIT_BATCH = 2;  // a block may have wrapped a 32-bit LDS word: run the batch again in halves
+
+// Row displacement for the ordered-pair rows. The table-free sweep adds to word A[ti] + B[tj] + bin — the lane holds
+// A[ti] rows as its base, the j atom's record carries B[tj] rows in the addend of the bin guess — and the plain layout
+// A = ti * n_tj, B = tj needs n_ti * n_tj rows: 36 rows x 401 words for the reference's own example (9 atom types, five
+// relations naming five of them -> 6 type indices), which does not fit the third of LDS a block may use, and sent
+// that shape to the class-row kernels (a row-table lookup per pair: 1.47x per pair). But rows only
+// have to be distinct where CLASSES are: two ordered type pairs may share a row whenever they belong to the same class
+// (their counts are added up at the flush anyway) — above all the many pairs that no relation names. So: find
+// integers A, B with  A[i] + B[j] == A[k] + B[l]  =>  cls(i, j) == cls(k, l),  minimising max A + max B + 1. Greedy,
+// type by type (A[k] and B[k] together, smallest resulting row count first), over a few orders; 15 rows instead of 36
+// for the example above. The kernels are unchanged: they see A and B through the records (pack_w) and row_mul.
+// Cached per class table (the search costs ~1 ms; a drop-in run repeats the same relations for every batch).
+struct DispKey {
+    int n_ti, n_tj;
+    std::vector<int> cls;
+    bool operator<(const DispKey &o) const
+    {
+        if (n_ti != o.n_ti) return n_ti < o.n_ti;
+        if (n_tj != o.n_tj) return n_tj < o.n_tj;
+        return cls < o.cls;
+    }
+};
+struct DispVal {
+    std::vector<int> a, b, row_cls;
+    int rows = 0;
+};
+
+static int displace_greedy(int n_ti, int n_tj, const std::vector<int> &cls, const std::vector<int> &order, int give_up,
+                           std::vector<int> &A, std::vector<int> &B, std::vector<int> &row_cls)
+{
+    const int n = std::max(n_ti, n_tj);
+    A.assign(n_ti, -1);
+    B.assign(n_tj, -1);
+    row_cls.assign((size_t)2 * give_up + 2, -1);
+    std::vector<int> done;  // type indices placed so far
+    int max_a = 0, max_b = 0;
+    std::vector<int> touched;
+    for (int step = 0; step < n; ++step) {
+        const int k = order[step];
+        const bool has_a = k < n_ti, has_b = k < n_tj;
+        int best_r = 1 << 30, best_s = 0, best_a = -1, best_b = -1;
+        const int lim = give_up;
+        for (int ai = 0; ai < (has_a ? lim : 1); ++ai) {
+            for (int bi = 0; bi < (has_b ? lim : 1); ++bi) {
+                const int ma = has_a ? std::max(max_a, ai) : max_a, mb = has_b ? std::max(max_b, bi) : max_b;
+                const int r = ma + mb + 1, sc = ai + bi;
+                if (r >= give_up) break;  // (bi only grows)
+                if (r > best_r || (r == best_r && sc >= best_s)) continue;
+                // consistent with every row written so far, and with itself?
+                bool ok = true;
+                touched.clear();
+                auto put = [&](int row, int c) {
+                    if (row_cls[row] >= 0) {
+                        if (row_cls[row] != c) ok = false;
+                    } else {
+                        row_cls[row] = c;
+                        touched.push_back(row);
+                    }
+                };
+                if (has_a && has_b) put(ai + bi, cls[(size_t)k * n_tj + k]);
+                for (size_t q = 0; q < done.size() && ok; ++q) {
+                    const int u = done[q];
+                    if (has_a && u < n_tj) put(ai + B[u], cls[(size_t)k * n_tj + u]);
+                    if (ok && has_b && u < n_ti) put(A[u] + bi, cls[(size_t)u * n_tj + k]);
+                }
+                for (int row : touched) row_cls[row] = -1;
+                if (!ok) continue;
+                best_r = r;
+                best_s = sc;
+                best_a = ai;
+                best_b = bi;
+            }
+        }
+        if (best_r >= give_up) return 0;
+        if (has_a) {
+            A[k] = best_a;
+            max_a = std::max(max_a, best_a);
+        }
+        if (has_b) {
+            B[k] = best_b;
+            max_b = std::max(max_b, best_b);
+        }
+        if (has_a && has_b) row_cls[best_a + best_b] = cls[(size_t)k * n_tj + k];
+        for (int u : done) {
+            if (has_a && u < n_tj) row_cls[best_a + B[u]] = cls[(size_t)k * n_tj + u];
+            if (has_b && u < n_ti) row_cls[A[u] + best_b] = cls[(size_t)u * n_tj + k];
+        }
+        done.push_back(k);
+    }
+    const int rows = max_a + max_b + 1;
+    row_cls.resize(rows);
+    return rows;
+}
+
+// -> rows of the best displaced layout found (0: none with fewer rows than the plain layout, or too many types to try)
+static int displace_rows(int n_ti, int n_tj, const std::vector<int> &cls, std::vector<int> &A, std::vector<int> &B,
+                         std::vector<int> &row_cls)
+{
+    static std::mutex mu;
+    static std::map<DispKey, DispVal> cache;
+    const int plain = n_ti * n_tj;
+    if (plain <= 4 || n_ti > 24 || n_tj > 24) return 0;
+    DispKey key{n_ti, n_tj, cls};
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = cache.find(key);
+        if (it != cache.end()) {
+            A = it->second.a;
+            B = it->second.b;
+            row_cls = it->second.row_cls;
+            return it->second.rows;
+        }
+    }
+    const int n = std::max(n_ti, n_tj);
+    DispVal best;
+    std::vector<int> order(n), a, b, rc;
+    for (int k = 0; k < n; ++k) order[k] = k;
+    uint64_t lcg = 0x9E3779B97F4A7C15ull;
+    const auto t_start = std::chrono::steady_clock::now();
+    for (int attempt = 0; attempt < 400; ++attempt) {
+        if (attempt == 1) std::reverse(order.begin(), order.end());
+        if (attempt >= 2)
+            for (int k = n - 1; k > 0; --k) {  // a fixed pseudo-random shuffle: the same layout on every rank and run
+                lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+                std::swap(order[k], order[(size_t)((lcg >> 33) % (uint64_t)(k + 1))]);
+            }
+        const int give_up = best.rows ? best.rows : plain;  // only strictly better layouts
+        const int rows = displace_greedy(n_ti, n_tj, cls, order, give_up, a, b, rc);
+        if (rows > 0 && (best.rows == 0 || rows < best.rows)) {
+            best.rows = rows;
+            best.a = a;
+            best.b = b;
+            best.row_cls = rc;
+        }
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > 0.02) break;
+    }
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (cache.size() > 256) cache.clear();
+        cache[key] = best;
+    }
+    A = best.a;
+    B = best.b;
+    row_cls = best.row_cls;
+    return best.rows;
+}
 
 // Runs the kernel over one batch of frames (in several passes when the class rows do not fit LDS) and
 // returns the class histograms on the host: H [F|1][n_cls][nbins], overflow count.
@@ -133,9 +286,21 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
     // the row offset rides in the addend of the bin guess. Needs all n_ti^2 rows in LDS and all classes in one pass:
     // at >= 4 blocks of 4 waves per CU for the all-f64 sweep, at 3 blocks of 8 waves (6 waves per SIMD) for the
     // packed-f32 sweep, whose blocks share one histogram among 8 waves.
-    const size_t ord_b = lds_bytes_sj_ordered(p.nbins, p.n_ti, p.n_tj);
+    // Row layout of the ordered modes: plain (row = ti * n_tj + tj) unless that does not fit the packed sweep's third of
+    // LDS and the displaced layout of displace_rows (row = A[ti] + B[tj], classes never mixed in a row) does.
+    int ord_rows = p.n_ti * p.n_tj, ord_maxb = p.n_tj - 1;
+    bool displaced = false;
+    if (p.disp_rows > 0 && p.disp_rows < ord_rows && ctx->opt_rdf_disp != 0 &&
+        (ctx->opt_rdf_disp == 2 || (lds_bytes_sj_pk(p.nbins, ord_rows, p.n_cn) > lds_cap / 3 - 512 &&
+                                    lds_bytes_sj_pk(p.nbins, p.disp_rows, p.n_cn) <= lds_cap / 3 - 512))) {
+        displaced = true;
+        ord_rows = p.disp_rows;
+        ord_maxb = *std::max_element(p.disp_b.begin(), p.disp_b.end());
+    }
+    const std::vector<int> &row_cls = displaced ? p.disp_cls : p.cls;  // ordered row -> class
+    const size_t ord_b = lds_bytes_sj_ordered(p.nbins, ord_rows);
     const bool ord_base = cull && ctx->opt_rdf_sj != 0 && !mode_cn && ctx->opt_rdf_rows != 0 &&
-                          p.n_cls <= 250 && (double)p.n_tj * (p.nbins + 1) < 65536.0;
+                          p.n_cls <= 250 && (double)(ord_maxb + 1) * (p.nbins + 1) < 65536.0;
     bool ordered = ord_base && ord_b <= lds_cap / 4;
     // Packed-f32 classification (MODE 3-6 of the scalar-j kernel, header in pair_sj.hip) when the error band is
     // narrow: with the ordered rows when they fit a third of LDS (3 blocks of 8 waves per CU), else with class rows
@@ -147,7 +312,7 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
     double pk_err = 0.0;  // error bound of the f32 distance, in bins
     int rel_block = 0;  // != 0: the packed sweep's f32 records are wanted (relative to their tile's centre)
     if (cull && ctx->opt_rdf_sj != 0 && !mode_cn && p.n_cls <= 250 && ctx->opt_rdf_pk != 0 && p.bin_size > 0.0) {
-        const bool fits_ordered = ord_base && lds_bytes_sj_pk(p.nbins, p.n_ti, p.n_tj, p.n_cn) <= lds_cap / 3 - 512;
+        const bool fits_ordered = ord_base && lds_bytes_sj_pk(p.nbins, ord_rows, p.n_cn) <= lds_cap / 3 - 512;
         const bool fits_rows = lds_bytes_sj_pk_rows(p.nbins, p.n_cls, p.n_ti, p.n_tj, p.n_cn) <= lds_cap / 3 - 512;
         const double r_cut = std::sqrt(p.rc2);
         const double cpos = r_cut / p.bin_size, K = std::floor(cpos + 0.5);
@@ -161,7 +326,7 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         const double edge = std::cbrt((double)TILE * v_max / (double)std::min(p.ni, p.nj));
         const double cap = r_cut + 3.5 * edge;
         // (the guess carries tj * row_len with ordered rows, nothing with class rows)
-        const double err = pk_error_bound(r_cut, p.bin_size, p.nbins, fits_ordered ? p.n_tj : 1, cap, l_max);
+        const double err = pk_error_bound(r_cut, p.bin_size, p.nbins, fits_ordered ? ord_maxb + 1 : 1, cap, l_max);
         const double u = std::ldexp(1.0, -24);
         const double near_pk = 2.0 * err + 4.5 * u * (p.nbins + 1) + 2.0e-5;
         const bool on_edge = std::fabs(cpos - K) <= 1e-6 && (K == (double)p.nbins || K == (double)p.nbins + 1.0);
@@ -192,7 +357,7 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         // |error| of the f32 guess g = fma(sqrt((float)rsq), 1/ddr, near + tj*row_len): relative 2^-25 (conversion,
         // halved by the root) + 2^-23 (v_sqrt_f32, 1 ulp) + 2^-24 (rounded 1/ddr) = 2.1e-7 of the bin number, plus
         // half an ulp of the largest value each for the rounding of the addend and of the fma. near = 2 x that.
-        const double maxg = (double)p.n_tj * (p.nbins + 1) + 1.0;  // the addend carries tj * row_len only
+        const double maxg = (double)(ord_maxb + 1) * (p.nbins + 1) + 1.0;  // the addend carries B[tj] * row_len only
         const double ulp = std::ldexp(1.0, (int)std::floor(std::log2(maxg)) - 23);
         near_ord = (float)(2.0 * ((double)p.nbins * 2.1e-7 + ulp) + 1.0e-5);
         near_ord = std::max(near_ord, near_pk_f);  // one band for the f32 guess of either sweep
@@ -246,20 +411,23 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
     // device tables
     const size_t edges_b = (size_t)(p.nbins + 2) * 8;  // + a +inf sentinel after the last edge
     // CN tables of the scalar-j rows (one pass, all rows): word index of every row's split bin | cutoff^2 per row
-    const int cn_rows = p.n_cn ? (ordered ? p.n_ti * p.n_tj : p.n_cls + 1) : 0;
+    const int cn_rows = p.n_cn ? (ordered ? ord_rows : p.n_cls + 1) : 0;
     const size_t cn_fw = ((size_t)cn_rows + 1) & ~size_t(1);
     const size_t cn_b = p.n_cn ? (cn_fw + 2 * (size_t)cn_rows) * 4 : 0;
     float cn_reach = 0.f;
     const size_t cls_b = ((size_t)p.n_ti * p.n_tj + 63) & ~size_t(63);
     // edges and the class table of every pass: one pinned staging buffer, one H2D copy
-    const size_t tab_b = edges_b + (size_t)n_pass * cls_b + cn_b + 8;
+    // (displaced rows: A | B as ints behind the CN tables, for pack_w of the sort pre-pass)
+    const size_t disp_off = (edges_b + (size_t)n_pass * cls_b + cn_b + 7) & ~size_t(7);
+    const size_t disp_b = ordered && displaced ? ((size_t)p.n_ti + p.n_tj) * 4 : 0;
+    const size_t tab_b = disp_off + disp_b + 8;
     // The common case of the scalar-j sweep — one class pass, frame-summed rows — needs two more small things that a
     // C2 step paid a copy / a fill of their own for (round 5: ~12 us each with the gaps around them): the row map of
     // derive_rdf_kernel (results left on the device) rides behind the tables in the same copy, and the row sums sit
     // behind the flag words so that ONE fill empties both.
     const bool sj_path = cull && ctx->opt_rdf_sj != 0;
     const bool one_sum = sj_path && n_pass == 1 && !p.per_frame;
-    const int sj_rows1 = ordered ? p.n_ti * p.n_tj : p.n_cls + 1;
+    const int sj_rows1 = ordered ? ord_rows : p.n_cls + 1;
     const size_t rows1_b = one_sum ? (size_t)sj_rows1 * (size_t)(p.nbins + 1 + (p.n_cn ? 1 : 0)) * 8 : 0;
     const bool map_rides = one_sum && p.dev_out != nullptr;
     const size_t tab_al = (tab_b + 15) & ~size_t(15);
@@ -276,7 +444,7 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
             std::fill(fl, fl + cn_fw, -1);
             double reach = 0.0;
             for (int r = 0; r < cn_rows; ++r) {
-                const int cl = ordered ? p.cls[r] : (r < p.n_cls ? r : -1);
+                const int cl = ordered ? row_cls[r] : (r < p.n_cls ? r : -1);
                 const double c2 = cl >= 0 ? p.cn_c2_cls[cl] : 0.0;
                 c2r[r] = c2;
                 if (!(c2 > 0.0)) continue;
@@ -299,9 +467,21 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
             }
         }
     }
+    RowDisp disp_i, disp_j;
+    if (disp_b) {
+        int *h_d = reinterpret_cast<int *>(h_tab + disp_off);
+        std::copy(p.disp_a.begin(), p.disp_a.end(), h_d);
+        std::copy(p.disp_b.begin(), p.disp_b.end(), h_d + p.n_ti);
+        const int *d_d = reinterpret_cast<const int *>(d_tab + disp_off);
+        // atom-atom: one sorted set plays both roles (low word A, addend B); atoms x sites: the i set's addend and the j
+        // set's low word are never read
+        disp_i.lo = d_d;
+        disp_i.hi = p.tri ? d_d + p.n_ti : d_d;
+        disp_j.lo = disp_j.hi = d_d + p.n_ti;
+    }
     if (map_rides) {
         int *h_map = reinterpret_cast<int *>(h_tab + tab_al);
-        for (int r = 0; r < sj_rows1; ++r) h_map[r] = ordered ? p.cls[r] : (r < p.n_cls ? r : -1);
+        for (int r = 0; r < sj_rows1; ++r) h_map[r] = ordered ? row_cls[r] : (r < p.n_cls ? r : -1);
         for (int kl = 0; kl < p.n_rel; ++kl) {
             h_map[sj_rows1 + kl] = p.rel_cls[kl];
             h_map[sj_rows1 + p.n_rel + kl] = p.rel_mult[kl];
@@ -345,7 +525,7 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         const int slot_i[5] = {WS_SORT_AOS, WS_BBOX, WS_GSPH, WS_WSPH, WS_GSPH4};
         // (the bin-guess addend near + type * row_len and the tile-relative f32 records belong to the j set)
         int rc = cull_prepare_set(ctx, F, p.d_xi, p.d_ti, (long long)p.ti_fs, p.d_box, N, nTi, p.n_ti,
-                                  ordered ? near_ord : 0.f, ordered ? p.nbins + 1 : 0, want_soa,
+                                  ordered ? near_ord : 0.f, ordered ? p.nbins + 1 : 0, disp_i, want_soa,
                                   pk && p.tri ? rel_block : 0, pk_rows ? 1 : 0, pk ? 1 : 0, slot_i, si);
         if (rc) return rc;
         if (p.tri) {
@@ -353,7 +533,7 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         } else {
             const int slot_j[5] = {WS_SORT_AOS_J, WS_BBOX_J, WS_GSPH_J, WS_WSPH_J, WS_GSPH4_J};
             rc = cull_prepare_set(ctx, F, p.d_xj, p.d_tj, (long long)p.tj_fs, p.d_box, p.nj, nTj, p.n_ti,
-                                  ordered ? near_ord : 0.f, ordered ? p.nbins + 1 : 0, false, pk ? rel_block : 0,
+                                  ordered ? near_ord : 0.f, ordered ? p.nbins + 1 : 0, disp_j, false, pk ? rel_block : 0,
                                   pk_rows ? 1 : 0, pk ? 1 : 0, slot_j, sj_set);
             if (rc) return rc;
         }
@@ -429,6 +609,8 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         a.gscale = p.gscale;
         a.n_ti = p.n_ti;
         a.n_tj = p.n_tj;
+        a.row_mul = ordered && displaced ? 1 : p.n_tj;
+        a.n_rows_ord = ord_rows;
         a.n_cls = nc;
         a.nbins = p.nbins;
         a.n_frames = (int)F;
@@ -453,7 +635,7 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         const bool persist = sj && !p.per_frame && ctx->opt_rdf_sj != 2;  // resident grid + per-XCD work counters
         a.work = reinterpret_cast<unsigned *>(d_misc + 4);
         const size_t lds = pk_rows ? lds_bytes_sj_pk_rows(p.nbins, nc, p.n_ti, p.n_tj, p.n_cn)
-                           : pk    ? lds_bytes_sj_pk(p.nbins, p.n_ti, p.n_tj, p.n_cn)
+                           : pk    ? lds_bytes_sj_pk(p.nbins, ord_rows, p.n_cn)
                            : ordered ? ord_b
                            : sj    ? lds_bytes_sj(p.nbins, nc, p.n_ti, p.n_tj, mode_cn)
                            : fast ? lds_bytes_fast(p.nbins, nc, p.n_ti, p.n_tj)
@@ -508,7 +690,7 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
             }
         }
         // scalar-j kernels: every block stores its LDS histogram into its own slice; a merge kernel adds them up
-        const int sj_rows = ordered ? p.n_ti * p.n_tj : nc + 1;
+        const int sj_rows = ordered ? ord_rows : nc + 1;
         const int cn_len = p.n_cn ? 1 : 0;  // one split counter per row, behind all histogram rows
         const int sj_words = sj_rows * (p.nbins + 1 + cn_len);
         unsigned long long *d_rows = nullptr;
@@ -604,7 +786,7 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
             }
             std::vector<uint64_t> *Hp = &H, *Hsplit = p.Hsplit;
             auto fin = [check_flags, collect_times, acc, hrows, hlost, Hp, Hsplit, out_frames, sj_words, sj_rows, cn_len,
-                        ordered, nc, c0, n_cls_all, nbins_all, cls = ordered ? p.cls : std::vector<int>()]() {
+                        ordered, nc, c0, n_cls_all, nbins_all, cls = ordered ? row_cls : std::vector<int>()]() {
                 const int rcf = check_flags(hlost);
                 if (rcf) return rcf;
                 collect_times();
@@ -974,6 +1156,7 @@ int run_job(mdhip_ctx *ctx, const RelJob &j, std::vector<uint64_t> &H, std::vect
     }
     p.n_ti = n_ti;
     p.n_tj = n_tj;
+    if (ctx->opt_rdf_disp != 0) p.disp_rows = displace_rows(n_ti, n_tj, p.cls, p.disp_a, p.disp_b, p.disp_cls);
 
     int rc;
     // Host-resident coordinates are staged batch by batch under the sweeps (pair_hist_run); the guard drains the copy
@@ -1130,6 +1313,22 @@ extern "C" {
 double mdhip_pk_error_bound(double r_cut, double bin_size, int nbins, int n_rows, double s_cap, double l_max)
 {
     return pk_error_bound(r_cut, bin_size, nbins, n_rows, s_cap, l_max);
+}
+
+int mdhip_row_displacement(int n_ti, int n_tj, const int32_t *cls, int32_t *a, int32_t *b, int32_t *row_cls, int *n_rows)
+{
+    if (n_ti < 1 || n_tj < 1 || !cls || !a || !b || !row_cls || !n_rows) return MDHIP_EINVAL;
+    std::vector<int> c(cls, cls + (size_t)n_ti * n_tj), va, vb, vr;
+    for (int v : c)
+        if (v < 0) return MDHIP_EINVAL;
+    const int rows = displace_rows(n_ti, n_tj, c, va, vb, vr);
+    *n_rows = rows;
+    if (rows > 0) {
+        std::copy(va.begin(), va.end(), a);
+        std::copy(vb.begin(), vb.end(), b);
+        std::copy(vr.begin(), vr.end(), row_cls);
+    }
+    return MDHIP_OK;
 }
 
 // What an atom-atom entry point keeps on the heap while its batch may still be in flight (asynchronous calls): the

@@ -167,7 +167,7 @@ __device__ __forceinline__ int sj_item(const PairArgs &a, FastCtx &c, const unsi
     {
         const int ti_me = (int)((unsigned)__double_as_longlong(me.w)) / a.n_ti;  // low word of w = type * n_ti
         c.rowtab_me = s_row + ti_me;
-        c.rowbase_me = c.lds_base + (unsigned)ti_me * (unsigned)a.n_tj * (unsigned)(a.nbins + 1) * 4u;
+        c.rowbase_me = c.lds_base + (unsigned)ti_me * (unsigned)a.row_mul * (unsigned)(a.nbins + 1) * 4u;
     }
     const long long w = ((long long)f * a.nTi + I) * (TILE / 64) + wq;
     const float4 wlo = a.wsph[2 * w], whi = a.wsph[2 * w + 1];
@@ -303,7 +303,7 @@ struct PkCtx {
     const double4 *ats_i;  // sorted f64 records of the i atoms of this wave (64 consecutive)
     const double4 *ats_j;  // sorted f64 records of the frame's j set
     double Lx, Ly, Lz, rc2;
-    int n_ti, n_tj;
+    int n_ti, row_mul;
     // CN in the same sweep (CNG). The histogram bins are exact, so a pair in a bin below the one that holds its
     // class's coordination cutoff is inside that cutoff and a pair in a bin above it is not: only the pairs of that one
     // SPLIT bin need the exact comparison rsq < cutoff^2. Their histogram words are flagged (one bit per word); a
@@ -365,7 +365,7 @@ __device__ __forceinline__ void pk_drain(PkCtx &p, const FastCtx &c, int lane)
                 const int ti = (int)((unsigned)__double2loint(ri.w)) / p.n_ti;  // low word of w = type * n_ti
                 // ordered rows: row (ti, .) + the offset of tj in the addend; class rows: table[tj][ti], addend near
                 const unsigned rowbase = p.rowtab ? p.rowtab[__double2loint(rj.w) + ti]
-                                                  : c.lds_base + (unsigned)ti * (unsigned)p.n_tj * (unsigned)(c.nbins + 1) * 4u;
+                                                  : c.lds_base + (unsigned)ti * (unsigned)p.row_mul * (unsigned)(c.nbins + 1) * 4u;
                 const float nearoff = p.rowtab ? c.near : __int_as_float(__double2hiint(rj.w));
                 const float g1 = __builtin_fmaf(__builtin_amdgcn_sqrtf((float)rsq), c.gscale, nearoff);
                 int k = (int)g1;
@@ -767,7 +767,7 @@ __device__ __forceinline__ int sj_item_pk(const PairArgs &a, FastCtx &c, const u
     {
         const int ti_me = (int)((unsigned)__double_as_longlong(ats[ig].w)) / a.n_ti;  // (pad records: type 0)
         c.rowtab_me = ROWS ? s_row + ti_me : nullptr;
-        c.rowbase_me = c.lds_base + (unsigned)ti_me * (unsigned)a.n_tj * (unsigned)(a.nbins + 1) * 4u;
+        c.rowbase_me = c.lds_base + (unsigned)ti_me * (unsigned)a.row_mul * (unsigned)(a.nbins + 1) * 4u;
     }
     const long long w = ((long long)f * a.nTi + I) * (TILE / 64) + wq;
     // The wave's box and the group boxes as (centre, half extents; cull_boxes_kernel, cbox). The wave's:
@@ -812,14 +812,14 @@ __device__ __forceinline__ int sj_item_pk(const PairArgs &a, FastCtx &c, const u
     p.Lz = L.Lz;
     p.rc2 = a.rc2;
     p.n_ti = a.n_ti;
-    p.n_tj = a.n_tj;
+    p.row_mul = a.row_mul;
     if (CNG) {
         // LDS behind the queues: split-word address per row | cutoff^2 per row | (class rows) split-word address [tj][ti]
-        const int rows = ROWS ? a.n_cls + 1 : a.n_ti * a.n_tj;
+        const int rows = ROWS ? a.n_cls + 1 : a.n_rows_ord;
         const int ti_me = (int)((unsigned)__double_as_longlong(ats[ig].w)) / a.n_ti;
         p.cn_kc = cn_lds;
         p.cn_c2 = reinterpret_cast<const double *>(cn_lds + ((rows + 1) & ~1));
-        p.cn_kc_me = ROWS ? cn_lds + ((rows + 1) & ~1) + 2 * rows + ti_me : cn_lds + ti_me * a.n_tj;
+        p.cn_kc_me = ROWS ? cn_lds + ((rows + 1) & ~1) + 2 * rows + ti_me : cn_lds + ti_me * a.row_mul;
         p.cn_base = c.lds_base + (unsigned)(rows * (a.nbins + 1)) * 4u;
     }
     p.inv_row_len = 1.0f / (float)(a.nbins + 1);
@@ -1061,7 +1061,7 @@ __global__ __launch_bounds__(MODE >= 3 ? PK_THREADS : TILE, MODE >= 3 ? PK_WAVES
     // ---- LDS: hist | (CN edges) | row table ----
     // MODE 2: one row per ORDERED type pair (ti, tj), addressed without a table (see sweep_group_sj)
     const int row_len = a.nbins + 1;
-    const int n_rows = ORDERED ? a.n_ti * a.n_tj : a.n_cls + 1;
+    const int n_rows = ORDERED ? a.n_rows_ord : a.n_cls + 1;
     const int hist_words = n_rows * (row_len + (CNG ? 1 : 0));  // CNG: + one split counter per row, behind the rows
     unsigned *s_hist = reinterpret_cast<unsigned *>(smem);
     size_t off = ((size_t)hist_words * 4 + 15) & ~size_t(15);
@@ -1251,9 +1251,9 @@ void launch_derive_rdf(hipStream_t stream, const unsigned long long *rows, int n
                        stream, rows, n_rows, nbins, rowcls, n_rel, relcls, relmult, guard, out);
 }
 
-size_t lds_bytes_sj_ordered(int nbins, int n_ti, int n_tj)
+size_t lds_bytes_sj_ordered(int nbins, int n_rows)
 {
-    return (((size_t)n_ti * n_tj * (nbins + 1) * 4 + 15) & ~size_t(15)) + 16;
+    return (((size_t)n_rows * (nbins + 1) * 4 + 15) & ~size_t(15)) + 16;
 }
 
 int sj_block_threads(int mode) { return mode >= 3 ? PK_THREADS : TILE; }
@@ -1272,10 +1272,10 @@ size_t lds_bytes_sj_pk_rows(int nbins, int n_cls, int n_ti, int n_tj, int n_cn)
            (n_cn ? cn_table_bytes(n_cls + 1, n_ti * n_tj) : 0);
 }
 
-size_t lds_bytes_sj_pk(int nbins, int n_ti, int n_tj, int n_cn)
+size_t lds_bytes_sj_pk(int nbins, int n_rows, int n_cn)
 {
-    return (((size_t)n_ti * n_tj * (nbins + 1 + (n_cn ? 1 : 0)) * 4 + 15) & ~size_t(15)) +
-           (size_t)(PK_THREADS / 64) * PK_QSTRIDE * 4 + (n_cn ? cn_table_bytes(n_ti * n_tj, 0) : 0);
+    return (((size_t)n_rows * (nbins + 1 + (n_cn ? 1 : 0)) * 4 + 15) & ~size_t(15)) +
+           (size_t)(PK_THREADS / 64) * PK_QSTRIDE * 4 + (n_cn ? cn_table_bytes(n_rows, 0) : 0);
 }
 
 // Error bound of the packed-f32 bin guess, in bins (see the MODE 3 header). u = 2^-24 (f32 round to nearest).

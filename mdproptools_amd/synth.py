@@ -21,6 +21,26 @@ def rdf_types(n_atoms, n_types=4):
     return (1 + (np.arange(n_atoms) % n_types)).astype(np.int32)
 
 
+# The reference's own example (data/mg_tfsi_dme): 591 DME x 16 atoms, 66 TFSI x 15 atoms, 33 Mg in a cubic box.
+C1_ATOMS, C1_BOX = 10_479, 49.182348836183905
+C1_TYPE_COUNTS = {1: 1182, 2: 2364, 3: 5910, 4: 66, 5: 132, 6: 264, 7: 132, 8: 396, 9: 33}
+C1_RELATIONS = [(9, 1), (9, 4), (9, 6), (9, 9), (1, 3)]  # the relations of the example notebook
+C1_MOLS, C1_ATOMS_PER_MOL = [591, 66, 33], [16, 15, 1]
+C1_ALT_RELATIONS = [(32, 17), (32, 32)]                   # altered ids (rdf_cn.py:197-215): Mg - first TFSI atom, Mg - Mg
+
+
+def c1_types(alt=False):
+    """Type column of a C1-shaped frame: the nine atom types with the example's populations, or (alt) the 32 pseudo-types
+    of the altered-id mode — the index of an atom inside its molecule type, offset by the preceding types' atoms."""
+    if not alt:
+        return np.concatenate([np.full(c, t, np.int32) for t, c in C1_TYPE_COUNTS.items()])
+    out, first = [], 1
+    for mols, per in zip(C1_MOLS, C1_ATOMS_PER_MOL):
+        out.append(np.tile(np.arange(first, first + per, dtype=np.int32), mols))
+        first += per
+    return np.concatenate(out)
+
+
 def rdf_frames(n_atoms, frame_ids, box_len, seed_offset=2, dtype=np.float64):
     """Ideal-gas frames [len(frame_ids), 3, n_atoms] in [0, L)."""
     out = np.empty((len(frame_ids), 3, n_atoms), dtype=dtype)
@@ -33,6 +53,8 @@ def rdf_frames(n_atoms, frame_ids, box_len, seed_offset=2, dtype=np.float64):
 def rdf_config(name):
     if name == "C2":
         return dict(n_atoms=10_000, n_frames=200, box_len=50.0, r_cut=20.0, bin_size=0.05, seed_offset=2)
+    if name == "C1":  # synthetic positions at the example's size and density (the real frames: tests/golden)
+        return dict(n_atoms=C1_ATOMS, n_frames=200, box_len=C1_BOX, r_cut=20.0, bin_size=0.05, seed_offset=1)
     if name == "C3":
         return dict(n_atoms=100_000, n_frames=1000, box_len=104.0, r_cut=20.0, bin_size=0.05, seed_offset=3)
     raise KeyError(name)

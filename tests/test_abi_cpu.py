@@ -187,3 +187,72 @@ def test_packed_f32_error_bound_covers_emulation(L, r_cut, bin_size):
         # the emulated chain has an exactly rounded sqrt (the device: 1 ulp), so it must sit well inside
         assert err.max() < 0.8 * bound, (wrap, err.max(), bound)
         assert err.max() > 0.02 * bound, "the bound is vacuous"
+
+
+def _displace(cls):
+    import ctypes as C
+
+    lib = _lib.load()
+    cls = np.ascontiguousarray(cls, dtype=np.int32)
+    n_ti, n_tj = cls.shape
+    a = np.full(n_ti, -1, np.int32)
+    b = np.full(n_tj, -1, np.int32)
+    rc = np.full(n_ti * n_tj + 8, -7, np.int32)
+    rows = C.c_int(-1)
+    ip = lambda v: v.ctypes.data_as(C.POINTER(C.c_int32))  # noqa: E731
+    assert lib.mdhip_row_displacement(n_ti, n_tj, ip(cls), ip(a), ip(b), ip(rc), C.byref(rows)) == 0
+    return rows.value, a, b, rc
+
+
+def _tri_classes(n, rels):
+    cls = np.full((n, n), len(rels), np.int32)
+    for k, (x, y) in enumerate(rels):
+        cls[x, y] = cls[y, x] = k
+    return cls
+
+
+def test_row_displacement_never_mixes_classes():
+    """mdhip_row_displacement: row(ti, tj) = a[ti] + b[tj] may merge type pairs only within one class, every
+    row's class is what row_cls says, fewer rows than n_ti * n_tj — for the reference's own example (nine atom types, the
+    five relations 9-1, 9-4, 9-6, 9-9, 1-3 -> six type indices, 36 plain rows), star-shaped and random relation sets,
+    and rectangular (atoms x sites) tables."""
+    rng = np.random.default_rng(5)
+    cases = [_tri_classes(6, [(4, 0), (4, 2), (4, 3), (4, 4), (0, 1)]),  # C1: indices of 1, 3, 4, 6, 9, other
+             _tri_classes(3, [(1, 0), (1, 1)]),                            # altered ids: 32-17, 32-32
+             _tri_classes(10, [(9, j) for j in range(1, 10)]),
+             _tri_classes(9, [(i, j) for i in range(9) for j in range(i, 9)])]  # every pair named: nothing to gain
+    for _ in range(30):
+        n = int(rng.integers(3, 13))
+        pairs = [(i, j) for i in range(n) for j in range(i, n)]
+        pick = rng.permutation(len(pairs))[: int(rng.integers(1, min(len(pairs), 12) + 1))]
+        cases.append(_tri_classes(n, [pairs[k] for k in pick]))
+    for _ in range(10):  # rectangular: ordered (atom type, site type) classes
+        n_ti, n_tj = int(rng.integers(2, 9)), int(rng.integers(2, 6))
+        cls = np.full((n_ti, n_tj), 0, np.int32)
+        k = int(rng.integers(1, 6))
+        cls[:] = k
+        for c in range(k):
+            cls[rng.integers(0, n_ti), rng.integers(0, n_tj)] = c
+        cases.append(cls)
+    gained = 0
+    for cls in cases:
+        rows, a, b, rc = _displace(cls)
+        n_ti, n_tj = cls.shape
+        if rows == 0:
+            continue
+        gained += 1
+        assert 0 < rows < n_ti * n_tj
+        assert a.min() >= 0 and b.min() >= 0 and a.max() + b.max() + 1 == rows
+        seen = {}
+        for i in range(n_ti):
+            for j in range(n_tj):
+                r = int(a[i] + b[j])
+                assert rc[r] == cls[i, j], (cls, a, b, i, j)
+                seen[r] = True
+        assert all(rc[r] == -1 for r in range(rows) if r not in seen)
+        again = _displace(cls)
+        assert again[0] == rows and np.array_equal(again[1], a) and np.array_equal(again[2], b)  # deterministic
+    rows_c1 = _displace(cases[0])[0]
+    assert 0 < rows_c1 <= 18, rows_c1  # 36 plain rows; <= 33 needed to fit a third of LDS at 400 bins
+    assert _displace(cases[3])[0] == 0
+    assert gained >= 20

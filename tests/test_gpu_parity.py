@@ -1116,6 +1116,79 @@ def test_packed_f32_sweep_more_types(B):
     pk.close()
 
 
+def test_displaced_rows_reference_shape_and_random_relations(B):
+    """Displaced ordered rows (row = A[ti] + B[tj]): the reference's own shape — nine atom types, the
+    relations 9-1, 9-4, 9-6, 9-9, 1-3 of the example notebook: six type indices, 36 plain rows that do not fit — takes
+    the packed table-free sweep `<3, .>` instead of the class-row kernel `<5, .>`, and random relation sets over 5-12
+    types give the same integers with displacement off (class rows), forced on, the all-f64 sweep and the C oracle;
+    per-frame and frame-summed; RDF + CN from one sweep; atoms x sites."""
+    from mdproptools_amd._lib import Context
+
+    rng = np.random.default_rng(20251004)
+    n, L, F = 4300, 36.0, 3
+    xyz = rng.uniform(0, L, (F, 3, n))
+    box = np.full((F, 3), L)
+    ctxs = {}
+    for tag, opts in (("auto", {}), ("off", {"rdf_disp": 0}), ("force", {"rdf_disp": 2}), ("f64", {"rdf_pk": 0})):
+        c = ctxs[tag] = Context(0)
+        c.set_option("rdf_cull", 1)
+        for k, v in opts.items():
+            c.set_option(k, v)
+    nbins, bin_size = 400, 0.04
+    r_cut = nbins * bin_size
+    cases = [(9, np.array([[9, 1], [9, 4], [9, 6], [9, 9], [1, 3]]))]
+    for _ in range(9):
+        T = int(rng.integers(5, 13))
+        pairs = [(a, b) for a in range(1, T + 1) for b in range(a, T + 1)]
+        pick = rng.permutation(len(pairs))[: int(rng.integers(2, 8))]
+        cases.append((T, np.array([pairs[k] if rng.random() < 0.5 else pairs[k][::-1] for k in pick])))
+    took_disp = 0
+    for k, (T, rel) in enumerate(cases):
+        ty = rng.integers(1, T + 1, n).astype(np.int32)
+        per_frame = bool(k % 2)
+        res = {}
+        for tag, c in ctxs.items():
+            res[tag] = B.rdf_loop(xyz, ty, box, rel, r_cut, bin_size, nbins, per_frame=per_frame, ctx=c)
+            res[tag + "_kernel"] = c.last_kernel_name()
+        if k == 0:
+            assert "<3," in res["auto_kernel"], res["auto_kernel"]
+            assert "<5," in res["off_kernel"], res["off_kernel"]
+        took_disp += ("<3," in res["auto_kernel"]) and ("<5," in res["off_kernel"])
+        for tag in ("off", "force", "f64"):
+            msg = "case %d T=%d rel=%s %s vs auto (%s / %s)" % (k, T, rel.tolist(), tag, res[tag + "_kernel"], res["auto_kernel"])
+            np.testing.assert_array_equal(res[tag][0], res["auto"][0], err_msg=msg)
+            np.testing.assert_array_equal(res[tag][1], res["auto"][1], err_msg=msg)
+            assert res[tag][2] == res["auto"][2], msg
+        cf, cp, _ = C.rdf_pairs(xyz[0], ty, rel, box[0], r_cut * r_cut, bin_size, nbins)
+        if per_frame:
+            np.testing.assert_array_equal(res["auto"][0][0], cf)
+            np.testing.assert_array_equal(res["auto"][1][0], cp)
+        # RDF + CN from one sweep on the displaced rows
+        cuts = list(rng.uniform(0.1, 0.9, len(rel)) * r_cut)
+        cuts[0] = bin_size * 137
+        f, p_, ov, cn = B.rdf_cn_loop(xyz, ty, box, rel, r_cut, bin_size, nbins, cuts, per_frame=per_frame, ctx=ctxs["auto"])
+        np.testing.assert_array_equal(f, res["auto"][0])
+        np.testing.assert_array_equal(p_, res["auto"][1])
+        cn_ref = B.cn_loop(xyz, ty, box, rel, cuts, per_frame=per_frame, ctx=ctxs["off"])
+        np.testing.assert_array_equal(cn, cn_ref, err_msg="one-sweep CN, case %d (%s)" % (k, ctxs["auto"].last_kernel_name()))
+        if per_frame:
+            np.testing.assert_array_equal(cn[0], C.cn_pairs(xyz[0], ty, rel, box[0], [c * c for c in cuts]))
+    assert took_disp >= 4, took_disp
+    # atoms x sites: ordered (atom type, site type) classes, 9 x 5 types, four relations
+    m = 2300
+    sites = rng.uniform(0, L, (F, 3, m))
+    ty = rng.integers(1, 10, n).astype(np.int32)
+    st = rng.integers(1, 6, m).astype(np.int32)
+    rel = np.array([[9, 1], [9, 4], [2, 4], [7, 5]])
+    parts = {tag: B.rdf_mol_loop(xyz, ty, sites, st, box, rel, r_cut, bin_size, nbins, ctx=c) for tag, c in ctxs.items()}
+    for tag in ("off", "force", "f64"):
+        np.testing.assert_array_equal(parts[tag][0], parts["auto"][0], err_msg=tag)
+    cp, _ = C.rdf_rect(xyz[0], ty, sites[0], st, rel, box[0], r_cut * r_cut, bin_size, nbins)
+    np.testing.assert_array_equal(parts["auto"][0][0], cp)
+    for c in ctxs.values():
+        c.close()
+
+
 def test_packed_f32_sweep_far_from_origin(B):
     """A cell 1e5 A away from the origin: the f32 boxes and tile centres lose ~0.01 A there, the tile-relative f32
     coordinates of the pair chain do not. Against the all-f64 sweep and the C oracle."""
