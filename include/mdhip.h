@@ -47,6 +47,7 @@ extern "C" {
 #define MDHIP_ENODEV (-4)  /* no usable gfx950 device */
 #define MDHIP_ELIMIT (-5)  /* problem exceeds a kernel limit (e.g. LDS for the histogram rows) */
 #define MDHIP_EPENDING (-6) /* mdhip_ticket_status: the call is still in flight */
+#define MDHIP_EUNKNOWN (-7) /* mdhip_ticket_status: no such call is remembered (more than 64 completed calls ago) */
 
 typedef struct mdhip_ctx mdhip_ctx;
 
@@ -93,7 +94,8 @@ int mdhip_ticket_stats(mdhip_ctx *ctx, long long ticket, double *kernel_ms, doub
                        const char **kernel);
 /* What the COMPLETION of call `ticket` returned: 0, or the negative code of its failure (text: mdhip_last_error) —
  * whoever completed it (its own mdhip_wait, a later mdhip_sync, a synchronous call that drained it). MDHIP_EPENDING
- * while it is in flight, MDHIP_EINVAL for a number more than 64 completed calls old. An error handed out here is no
+ * while it is in flight, MDHIP_EUNKNOWN for a number more than 64 completed calls old (the context's error text is left as it is: MDHIP_EINVAL
+ * can be the completion status of the call itself). An error handed out here is no
  * longer reported by a later mdhip_sync / mdhip_wait. *n_fallbacks (may be NULL): slow-path repeats the call took —
  * the staged full-lag MSD kernel's ring timed out (grid not resident as a whole: a co-tenant on the GPU) and the
  * call was repeated over a transposed copy — results are the same, the call took seconds instead of milliseconds.

@@ -346,9 +346,9 @@ class Pending:
             st = ctx.lib.mdhip_ticket_status(ctx.h, int(self.ticket), C.byref(nfb))
             if st == -6:  # (cannot happen: the wait above completed it)
                 raise MdhipError(st, "call %d still in flight after its wait" % self.ticket)
-            if st != 0 and st != -1:
+            if st != 0 and st != -7:
                 raise MdhipError(st, (ctx.lib.mdhip_last_error(ctx.h) or b"").decode())
-            if st == -1 and rc != 0:  # more than 64 calls ago: all that is known is what the wait returned
+            if st == -7 and rc != 0:  # MDHIP_EUNKNOWN, more than 64 calls ago: all that is known is what the wait returned
                 ctx.check(rc)
             if nfb.value:
                 ctx._warn_fallback(self.ticket, nfb.value)
@@ -452,6 +452,11 @@ class Context:
 
     def set_option(self, key, value):
         self.check(self.lib.mdhip_set_option(self.h, key.encode(), int(value)))
+        self.__dict__.setdefault("_options", {})[key] = int(value)
+
+    def get_option(self, key, default=-1):
+        """What set_option last set for `key` through THIS object (`default`: never set — the library's own default)."""
+        return self.__dict__.get("_options", {}).get(key, default)
 
     def set_stream(self, stream_handle):
         """Launch on a caller-owned hipStream_t (e.g. torch.cuda.Stream.cuda_stream); None / 0 restores the own stream.

@@ -652,7 +652,9 @@ int mdhip_ticket_status(mdhip_ctx *ctx, long long ticket, int *n_fallbacks)
     }
     for (const mdhip_call *c : ctx->inflight)
         if (c->stats.ticket == ticket) return MDHIP_EPENDING;
-    return mdhip_fail(ctx, MDHIP_EINVAL, "mdhip_ticket_status: call %lld is unknown (more than 64 calls ago?)", ticket);
+    // (a code of its own, and ctx->err untouched: MDHIP_EINVAL is a legitimate completion status of a call — a
+    // requirement failing inside a deferred re-run — and the error text belongs to whoever checks the wait's code next)
+    return MDHIP_EUNKNOWN;
 }
 
 long long mdhip_fallbacks(mdhip_ctx *ctx) { return ctx ? ctx->fallbacks_total : 0; }

@@ -969,6 +969,8 @@ def msd_step_sharded_async(r_f, r_e, n_frames_total, entity_range, group_off, ta
                     hs["fixed"] = backend.msd_windows(r_f[k0:], tao, scale=scale, out=win, ctx=ctx, async_=True)
                 if x is not None:
                     means = torch.empty((n_lags, len(held), 4), dtype=torch.float64, device=dev)
+                    # (the caller's own lag_variant is put back afterwards: ADVICE r05 — resetting to the default lost it)
+                    user_variant = ctx.get_option("lag_variant", -1)
                     if one_wait:
                         ctx.set_option("lag_variant", 2)  # (the spectral path, no host-side fallback: the status word decides)
                     try:
@@ -976,7 +978,7 @@ def msd_step_sharded_async(r_f, r_e, n_frames_total, entity_range, group_off, ta
                                                     async_=True, status_out=res[nS + nW + nL + 1:] if one_wait else None)
                     finally:
                         if one_wait:
-                            ctx.set_option("lag_variant", -1)
+                            ctx.set_option("lag_variant", user_variant)
             except Exception as e:  # (this rank still takes part in the all-reduce; every rank raises behind it)
                 issue_err = e
                 res[nS + nW + nL] = 1.0
@@ -1036,6 +1038,18 @@ def msd_step_sharded_async(r_f, r_e, n_frames_total, entity_range, group_off, ta
                     stats[key] = h.stats()
             except Exception as e:
                 err = err or e
+            if world > 1:
+                # Errors that only show at COMPLETION (a call's deferred re-run failing, EHIP) are not on the reduced
+                # failure flag — that all-reduce ran before the host knew. The ranks agree on them here, before anyone
+                # raises or enters another collective (the redo below, the next step's exchange): one word, summed.
+                # (a rank raising alone left the others waiting in their next collective until it timed out.)
+                agree = torch.tensor([0.0 if err is None else 1.0], dtype=torch.float64, device=dev)
+                with torch.cuda.stream(_step_stream(dev, ctx, post=True)):
+                    _allreduce_inplace(agree, _post_group() if os.environ.get("MDHIP_STEP_POST_GROUP", "0") == "1" else None)
+                    n_failed = int(round(float(agree.item())))
+                if n_failed and err is None:
+                    err = RuntimeError("%d rank(s) failed completing their share of the MSD step; this rank stops with them"
+                                       % n_failed)
             if err is not None:
                 raise err
             if flat[nS + nW + nL] != 0.0:
@@ -1049,12 +1063,13 @@ def msd_step_sharded_async(r_f, r_e, n_frames_total, entity_range, group_off, ta
                 lag_part = torch.zeros(nL, dtype=torch.float64, device=dev)
                 with torch.cuda.stream(_step_stream(dev, ctx, post=True)):
                     if x is not None:
+                        user_variant = ctx.get_option("lag_variant", -1)
                         ctx.set_option("lag_variant", 1)
                         try:
                             m2 = torch.empty((n_lags, len(held), 4), dtype=torch.float64, device=dev)
                             backend.lag_msd(x, max_lag, loc_off - loc_off[0], scale=lag_scale, out=m2, ctx=ctx)
                         finally:
-                            ctx.set_option("lag_variant", -1)
+                            ctx.set_option("lag_variant", user_variant)
                         w = _lag_weights(origins, g_hi, g_lo, held, dev)
                         lv = lag_part.view(n_lags, G, 4)
                         if len(held) == G:
@@ -1080,7 +1095,9 @@ def msd_step_sharded_async(r_f, r_e, n_frames_total, entity_range, group_off, ta
                     err = e
                     res[nS + nW + nL] = 1.0
                 if world > 1:
-                    _allreduce_inplace(res)
+                    # (MDHIP_STEP_POST_GROUP=1: the closing all-reduce on the second communicator, as in the one-wait order
+                    # above — also on this path so that the two-communicator pattern runs under gloo in the CPU suite)
+                    _allreduce_inplace(res, _post_group() if os.environ.get("MDHIP_STEP_POST_GROUP", "0") == "1" else None)
                 flat = res.cpu().numpy()
                 if err is not None:
                     raise err

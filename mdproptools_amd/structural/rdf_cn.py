@@ -368,8 +368,16 @@ def _all_frames(per_frame_rows):
         rows = np.stack(per_frame_rows) if len(per_frame_rows) else None
     if not D.is_distributed():
         return [] if rows is None else rows
-    D.require_all_nonempty(0 if rows is None else len(rows), "frame")  # every rank raises, or none
-    return D.allgather_var(rows)
+    # Fewer frames than ranks: the ranks without a frame contribute no rows (round 6; they used to make every rank raise).
+    # The row width of an empty rank comes from the others, with the counts, in one small all-gather.
+    mine = (0, 0) if rows is None else (int(rows.shape[0]), int(rows.shape[1]))
+    both = D.allgather_var(np.array([mine], dtype=np.int64), counts=[1] * D.rank_world()[1])
+    counts, width = [int(c) for c in both[:, 0]], int(both[:, 1].max())
+    if sum(counts) == 0:
+        return []
+    if rows is None:
+        rows = np.zeros((0, width))
+    return D.allgather_var(rows, counts=counts)
 
 
 def _is_writer():

@@ -1,5 +1,5 @@
 """
-CPU, world_size 2, gloo: the frame-sharding and collective logic of mdproptools_amd.dist with the
+CPU, world_size 2 / 3 / 8, gloo: the frame-sharding and collective logic of mdproptools_amd.dist with the
 oracle standing in for the GPU kernels. Results must equal the single-process oracle exactly for
 integer work, and to rounding for the gathered floating-point rows.
 """
@@ -65,12 +65,15 @@ def _worker(rank, world, port, out_dir):
         return full, part, ov
 
     def rdf_frames(x, t, b, rl, rc, dd, nb):
+        if len(x) == 0:  # (a rank without frames, F < world: what backend.rdf_loop returns for F = 0)
+            return np.zeros((0, nb), np.uint64), np.zeros((0, len(rl), nb), np.uint64), 0
         res = [cref.rdf_pairs(x[f], t, rl, b[f], rc * rc, dd, nb) for f in range(len(x))]
         return (np.stack([q[0] for q in res]).reshape(len(x), nb),
                 np.stack([q[1] for q in res]).reshape(len(x), len(rl), nb), sum(q[2] for q in res))
 
     def cn_sum(x, t, b, rl, cuts):
-        return sum(cref.cn_pairs(x[f], t, rl, b[f], [c * c for c in cuts]) for f in range(len(x)))
+        return sum((cref.cn_pairs(x[f], t, rl, b[f], [c * c for c in cuts]) for f in range(len(x))),
+                   np.zeros(len(rl), np.uint64))
 
     def msd(rr, pairs, goff, sc):
         return cref.msd_pairs(np.asarray(rr) * sc, pairs, goff)
@@ -125,8 +128,24 @@ def _worker(rank, world, port, out_dir):
         steps["step_%d_%d_single" % (origin, tao)] = a
         steps["step_%d_%d_win" % (origin, tao)] = b
         steps["step_%d_%d_lag" % (origin, tao)] = c
+    # fewer frames than ranks at world 8 (ranks without a frame contribute zeros): 5 frames, origin in the last
+    # non-empty rank, tao 2 (kept frames 0, 2, 4: every window crosses a rank boundary at world >= 3)
+    F4 = 5
+    r4 = _walk(F4, n)
+    l4, h4 = D.frame_shard(F4)
+    a, b, c, _st = D.msd_step_sharded(r4[l4:h4], r4[:, :, e_lo:e_hi], F4, (e_lo, e_hi), [0, 100, n], 2, scale=1e-10,
+                                      lag_scale=2.0, origin_frame=F4 - 1, compute=stand_in)
+    steps["step5_single"], steps["step5_win"], steps["step5_lag"] = a, b, c
+    sums_last = D.msd_single_origin_sharded(r[lo:hi], F, [0, 100, n], scale=1e-10, origin_frame=F - 1, compute=msd)
+    # per-frame charge flux gathered in frame order (the reference's only frame-parallel gather, conductivity.py:190-194)
+    vel = np.random.default_rng(77).normal(0, 1e-3, (F, 3, n))
+    seg_off = np.arange(0, n + 1, 3)
+    seg_type = np.arange(len(seg_off) - 1) % 2
+    q_atom = np.tile([0.5, -1.0, 0.25], n // 3)
+    flux_fn = _numpy_dynamical_backend()[4]
+    flux = D.charge_flux_sharded(vel[lo:hi], F, np.ones(n), q_atom, seg_off, seg_type, 2, 1e5, 1.6e-19, compute=flux_fn)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), full=full, part=part, ov=ov, pf=pf, pp=pp, cn=cn,
-             sums=sums, sums4=sums4, shard=np.array([lo, hi]), lagm=lagm, acf=acf, ccf=ccf,
+             sums=sums, sums4=sums4, sums_last=sums_last, flux=flux, shard=np.array([lo, hi]), lagm=lagm, acf=acf, ccf=ccf,
              eshard=np.array([e_lo, e_hi]), **wins, **steps)
     dist.barrier()
     dist.destroy_process_group()
@@ -156,13 +175,18 @@ def test_lag_ranges_balance_the_work():
             assert max(work) <= 1.02 * sum(work) / world
 
 
-def test_sharded_paths_world2_gloo(tmp_path):
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharded_paths_gloo(tmp_path, world):
+    """Every sharded path at 2, 3 and 8 ranks (the target machine has 8): frame counts that do not divide
+    (5 and 11 frames), FEWER frames than ranks at 8 (ranks without a frame contribute zeros), the origin in the last
+    non-empty rank, tao values that do not divide the shards, groups that straddle several entity-shard boundaries."""
     import torch.multiprocessing as mp
 
+    from mdproptools_amd.dist import entity_shard, frame_shard
     from oracle import cref
 
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     F, n, L, xyz, ty, rel, box, r = _make_case()
     full = np.zeros(120, np.uint64)
     part = np.zeros((4, 120), np.uint64)
@@ -179,10 +203,24 @@ def test_sharded_paths_world2_gloo(tmp_path):
     acf = np.stack([cref.xcorr_direct(series[p], series[p]) for p in range(2)])
     ccf = cref.xcorr_direct(series[0], series[1], n_lags=300)
     shards = []
-    for rank in range(2):
+    sums_last = cref.msd_pairs(r * 1e-10, [(F - 1, t) for t in range(F)], [0, 100, n])
+    vel = np.random.default_rng(77).normal(0, 1e-3, (F, 3, n))
+    seg_off = np.arange(0, n + 1, 3)
+    flux = _numpy_dynamical_backend()[4](vel, np.ones(n), np.tile([0.5, -1.0, 0.25], n // 3), seg_off,
+                                          np.arange(len(seg_off) - 1) % 2, 2, 1e5, 1.6e-19)
+    r4 = _walk(5, n)
+    for rank in range(world):
         g = np.load(tmp_path / ("rank%d.npz" % rank))
         shards.append(tuple(g["shard"]))
-        assert tuple(g["eshard"]) == ((0, 150), (150, 300))[rank]
+        assert tuple(g["eshard"]) == entity_shard(n, rank, world)
+        np.testing.assert_allclose(g["sums_last"], sums_last, rtol=1e-14)
+        # (every frame's vector comes from exactly one rank; numpy's stand-in sums a shard's block in an order that depends
+        # on the block's shape, hence to rounding — the device kernel's per-frame order does not: tests/test_gpu_fullsize.py)
+        np.testing.assert_allclose(g["flux"], flux, rtol=1e-12, atol=1e-40)
+        np.testing.assert_allclose(g["step5_single"], cref.msd_pairs(r4 * 1e-10, [(4, t) for t in range(5)], [0, 100, n]),
+                                   rtol=1e-14)
+        np.testing.assert_allclose(g["step5_win"], _np_windows(r4[::2], 1e-10), rtol=1e-13)
+        np.testing.assert_allclose(g["step5_lag"], cref.lag_msd(r4 * 2.0, np.arange(5), [0, 100, n]), rtol=1e-12)
         np.testing.assert_allclose(g["lagm"], lagm, rtol=1e-12)
         np.testing.assert_array_equal(g["acf"], acf)  # every lag comes from exactly one rank: identical
         np.testing.assert_array_equal(g["ccf"], ccf)
@@ -202,7 +240,67 @@ def test_sharded_paths_world2_gloo(tmp_path):
                                                                          [0, 100, n]), rtol=1e-14)
             np.testing.assert_allclose(g[key + "win"], _np_windows(rs[::tao], 1e-10), rtol=1e-13)
             np.testing.assert_allclose(g[key + "lag"], cref.lag_msd(rs * 2.0, np.arange(11), [0, 100, n]), rtol=1e-12)
-    assert shards == [(0, 3), (3, 5)]
+    assert shards == [frame_shard(F, rank, world) for rank in range(world)]
+    if world == 2:
+        assert shards == [(0, 3), (3, 5)]
+    if world == 8:
+        assert shards[5:] == [(5, 5)] * 3  # three ranks hold no frame of the 5
+
+
+def _post_group_worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      MDHIP_STEP_POST_GROUP="1")
+    import torch.distributed as dist
+
+    from mdproptools_amd import dist as D
+    from oracle import cref
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, F = 120, 9
+    stand_in = {
+        "origin": lambda rr, r0, goff, sc: cref.msd_pairs(np.concatenate([r0[None], rr]) * sc,
+                                                          [(0, 1 + t) for t in range(len(rr))], goff),
+        "windows": lambda rr, tao, sc: _np_windows(rr[::tao], sc),
+        "lag": lambda x, ml, goff, sc: cref.lag_msd(np.asarray(x) * sc, np.arange(ml + 1), goff),
+    }
+    lo, hi = D.frame_shard(F)
+    e_lo, e_hi = D.entity_shard(n)
+    walks = [np.cumsum(np.random.default_rng(300 + k).normal(0, 0.1, (F, 3, n)), axis=0) for k in range(4)]
+    # a pipeline as bench.py --workload c4 runs it: step k + 1 is ISSUED (its all-gather on the default communicator)
+    # before step k is waited for (its all-reduce on the second communicator)
+    inflight, out = [], []
+    for k, rw in enumerate(walks):
+        inflight.append(D.msd_step_sharded_async(rw[lo:hi], rw[:, :, e_lo:e_hi], F, (e_lo, e_hi), [0, 50, n], 2,
+                                                 scale=1e-10, lag_scale=2.0, origin_frame=k, compute=stand_in))
+        if len(inflight) > 1:
+            out.append(inflight.pop(0).wait())
+    out.append(inflight.pop(0).wait())
+    assert len(D._POST_GROUP) == 1  # the second communicator exists and was used
+    np.savez(os.path.join(out_dir, "post%d.npz" % rank), **{"s%d_%d" % (k, j): o[j] for k, o in enumerate(out) for j in range(3)})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_fused_step_with_the_second_communicator_gloo(tmp_path, world):
+    """MDHIP_STEP_POST_GROUP=1 (the opt-in that lets step k + 1's all-gather overtake step k's all-reduce): the closing
+    all-reduce of every step runs on a second communicator while the next step's pre-exchange is already issued on the
+    default one — four pipelined steps, results equal to the oracle's on every rank."""
+    import torch.multiprocessing as mp
+
+    from oracle import cref
+
+    mp.spawn(_post_group_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    n, F = 120, 9
+    for k in range(4):
+        rw = np.cumsum(np.random.default_rng(300 + k).normal(0, 0.1, (F, 3, n)), axis=0)
+        for rank in range(world):
+            g = np.load(tmp_path / ("post%d.npz" % rank))
+            np.testing.assert_allclose(g["s%d_0" % k], cref.msd_pairs(rw * 1e-10, [(k, t) for t in range(F)], [0, 50, n]),
+                                       rtol=1e-14)
+            np.testing.assert_allclose(g["s%d_1" % k], _np_windows(rw[::2], 1e-10), rtol=1e-13)
+            np.testing.assert_allclose(g["s%d_2" % k], cref.lag_msd(rw * 2.0, np.arange(F), [0, 50, n]), rtol=1e-12)
 
 
 # ------------------------------------------------------------------ drop-in functions under torch.distributed
@@ -278,6 +376,21 @@ def test_dropin_rdf_cn_sharded_over_files_world2_gloo(tmp_path):
         np.testing.assert_array_equal(two["c"], one["c"])
     assert (tmp_path / "w2" / "rdf.csv").exists() and (tmp_path / "w2" / "cn.csv").exists()
     assert open(tmp_path / "w2" / "rdf.csv").read() == open(tmp_path / "w1" / "rdf.csv").read()
+
+
+def test_dropin_rdf_cn_fewer_frames_than_ranks_gloo(tmp_path):
+    """Two dump files, three ranks: the trajectory is not split by files (every rank parses both and takes its share of
+    the frames), rank 2 holds no frame and contributes no rows — the result is the single-process one on every rank."""
+    import torch.multiprocessing as mp
+
+    _dropin_case(str(tmp_path), 2)
+    mp.spawn(_dropin_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    mp.spawn(_dropin_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+    one = np.load(tmp_path / "w1" / "rank0.npz")
+    for rank in range(3):
+        three = np.load(tmp_path / "w3" / ("rank%d.npz" % rank))
+        np.testing.assert_array_equal(three["g"], one["g"])
+        np.testing.assert_array_equal(three["c"], one["c"])
 
 
 def _numpy_dynamical_backend():
