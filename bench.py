@@ -532,6 +532,56 @@ def leg_c1(B, ctx, torch, device, synth, sync, steps, c2_kernel_ns_per_kpair, al
             "roofline": valu_roofline(kernel, tag, kdur, "mix bin 11/16", 6, pairs, 28.0 * n * F)}
 
 
+def leg_residence(B, ctx, torch, device, synth, sync):
+    """SURVEY 8f rank 4 (residence_time.py:70-148) at C3's size and density: 100 000 atoms in L = 104 A of which the
+    example's share are central atoms (Mg: 315) and shell atoms (ether O: 11 280), unwrapped random walks (0.1 A per
+    frame) over 1000 frames, shell (0, 2.325 A] — the example's Mg-O coordination cutoff. One call = every central x
+    shell pair of every frame through the exact f64 distance chain (the sweep is dense: n_i x n_j x F pairs), records
+    sorted by pair, presence masks correlated over all lags. The first frames' indicator against the oracle."""
+    from oracle import cpu_ref as O
+
+    F, L, n_i, n_j = 1000, 104.0, 315, 11_280
+    rng = np.random.default_rng(synth.BASE_SEED + 7)
+    start = rng.random((3, n_i + n_j)) * L
+    r = np.empty((F, 3, n_i + n_j))
+    r[0] = start
+    for f0 in range(1, F, 100):
+        steps = rng.normal(0.0, 0.1, (min(F, f0 + 100) - f0, 3, n_i + n_j))
+        np.cumsum(steps, axis=0, out=steps)
+        r[f0:f0 + len(steps)] = r[f0 - 1] + steps
+    xi = torch.from_numpy(np.ascontiguousarray(r[:, :, :n_i])).to(device)
+    xj = torch.from_numpy(np.ascontiguousarray(r[:, :, n_i:])).to(device)
+    box = np.full((F, 3), L)
+    lo2, hi2 = 0.0, 2.325 ** 2
+    km = []
+
+    def call():
+        out = B.shell_residence(xi, xj, box, lo2, hi2, ctx=ctx)
+        km.append(ctx.last_kernel_ms()[0])
+        return out
+
+    dt, (counts, nrec) = timed(call, sync, 5)
+    kdur = float(np.mean(km[1:])) * 1e-3
+    # parity: the integer lag counts of the first 40 frames against the oracle's indicator + correlation
+    Fc = 40
+    c40, n40 = B.shell_residence(xi[:Fc], xj[:Fc], box[:Fc], lo2, hi2, ctx=ctx)
+    h = np.array([O.shell_indicator(r[f, :, :n_i].T, r[f, :, n_i:].T, np.full(3, L), lo2, hi2, False) for f in range(Fc)])
+    if not (np.array_equal(c40.astype(np.int64), O.residence_counts(h)) and int(n40) == int(h.sum())):
+        raise AssertionError("residence counts differ from the oracle")
+    pairs = float(F) * n_i * n_j
+    return {"workload": "residence: 315 central x 11 280 shell atoms (the example's Mg / ether-O shares of 100k atoms), "
+                        "L=104 A, 1000 frames of a 0.1 A random walk, shell (0, 2.325 A]",
+            "value": pairs / dt, "unit": "atom-pairs/s (dense central x shell sweep, every frame)", "wall_s": dt,
+            "kernel_s": kdur, "records": int(nrec), "counts_lag0": int(counts[0]), "pairs_per_call": pairs,
+            "parity_checked": "40 frames: integer lag counts == oracle (indicator + exact autocovariance numerators)",
+            # the sweep dominates: 15 unfused f64 operations per pair (3 sub, 3 x (abs-sub, min), 3 mul, 2 add, 2 compares)
+            "roofline": {"bound": "fp64-valu (non-fused)", "achieved": pairs * 17.0 / kdur / 1e12,
+                         "peak": FP64_NONFUSED_PEAK / 1e12, "unit": "T op/s", "frac": pairs * 17.0 / kdur / FP64_NONFUSED_PEAK,
+                         "ops_per_pair": 17, "traffic": pmc_traffic("residence"),
+                         "hbm_algorithmic_bytes": 24.0 * F * (n_i + n_j) + 16.0 * float(nrec),
+                         "note": "3 sub + 3 x (|a - L|, min) + 3 mul + 2 add + 2 compares per pair, exact chain (rdf_cn.py:44-57)"}}
+
+
 def timed_pipelined(issue, sync, reps):
     """Mean wall time per call of `reps` asynchronous calls, each issued before the one before it is waited for (the
     headline loop's pattern), after eight untimed ones in the same pattern (staging blocks of every call in flight exist
@@ -925,6 +975,8 @@ def flat_scalars(out):
         "c5_cumtrapz_kernel_s": _get(out, "c5", "cumtrapz", "kernel_s"),
         "c5_green_kubo_chain_wall_s": _get(out, "c5", "green_kubo_chain", "wall_s"),
         "c1_pairs_per_s": _get(out, "c1", "value"), "c1_alt_pairs_per_s": _get(out, "c1_alt", "value"),
+        "residence_pairs_per_s": _get(out, "residence", "value"), "residence_kernel_s": _get(out, "residence", "kernel_s"),
+        "residence_fp64_nonfused_frac": _get(out, "residence", "roofline", "frac"),
         "c1_ns_per_kpair_over_c2": _get(out, "c1", "cost_per_pair_over_c2"),
         "c1_alt_ns_per_kpair_over_c2": _get(out, "c1_alt", "cost_per_pair_over_c2"),
     }
@@ -1110,7 +1162,7 @@ def main():
     ap.add_argument("--msd-steps", type=int, default=5, help="timed steps of the `msd` object of the default line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="headline only (profiling runs)")
-    ap.add_argument("--legs", default="parity,f64,h2d,c1,c3,c4,c5")
+    ap.add_argument("--legs", default="parity,f64,h2d,c1,residence,c3,c4,c5")
     ap.add_argument("--cpu-frames", type=int, default=10)
     ap.add_argument("--variant", type=int, default=None, help="kernel variant knob (A/B only)")
     ap.add_argument("--option", action="append", default=[], help="library option key=value (A/B only)")
@@ -1390,6 +1442,8 @@ def main():
         if "c1" in legs:
             run_leg("c1", lambda: leg_c1(B, ctx, torch, device, synth, sync, max(5, args.steps // 2), c2_ns, False))
             run_leg("c1_alt", lambda: leg_c1(B, ctx, torch, device, synth, sync, max(5, args.steps // 2), c2_ns, True))
+        if "residence" in legs:
+            run_leg("residence", lambda: leg_residence(B, ctx, torch, device, synth, sync))
         if "c3" in legs:
             run_leg("c3", lambda: leg_c3(B, ctx, torch, device, synth, sync))
         if "c4" in legs:

@@ -19,6 +19,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <cmath>
 #include <vector>
 
 #include "ctx.h"
@@ -241,13 +242,35 @@ int mdhip_shell_residence(mdhip_ctx *ctx, int64_t n_frames, int64_t n_i, const d
     const dim3 grid((unsigned)((n_i + RT_TILE - 1) / RT_TILE), (unsigned)n_frames);
     KernelTimer timer(ctx);
     ctx->last_kernel = "shell_pairs_kernel";
-    hipLaunchKernelGGL(shell_pairs_kernel<false>, grid, dim3(RT_TILE), 0, ctx->stream, d_xi, (long long)n_i, d_xj,
-                       (long long)n_j, d_box, r_lo_sq, r_hi_sq, exclude_diagonal, frame_bits, d_misc,
-                       (unsigned long long *)nullptr, 0ull);
-    MD_HIP(hipGetLastError());
-    MD_HIP(hipMemcpyAsync(h_out, d_misc, 8, hipMemcpyDeviceToHost, ctx->stream));
-    MD_HIP(mdhip_stream_wait(ctx));
-    const unsigned long long n_rec = h_out[0];
+    // ONE sweep over the pairs in the common case (round 6; rounds 1-5 swept twice, count then fill): the record list is
+    // sized from the shell's share of the box — expected records x 1.5 + slack — and the fill sweep counts every hit
+    // whether it fits or not; only a call whose shells are denser than that (a clustered system) sweeps again with
+    // the exact size. The sweep is the call's cost (n_i x n_j x F exact f64 distance chains), the list a few MB.
+    unsigned long long cap;
+    {
+        const double pi43 = 4.18879020478639;
+        const double vol = box[0] * box[1] * box[2];
+        const double r_hi = std::sqrt(std::max(r_hi_sq, 0.0)), r_lo = std::sqrt(std::max(r_lo_sq, 0.0));
+        const double share = vol > 0.0 ? std::min(1.0, pi43 * (r_hi * r_hi * r_hi - r_lo * r_lo * r_lo) / vol) : 1.0;
+        const double est = (double)n_i * (double)n_j * (double)n_frames * share * 1.5 + 262144.0;
+        cap = (unsigned long long)std::min(est, 2.5e8);  // (<= 4 GB for the list and its sorted copy)
+        if (ctx->opt_residence_cap > 0) cap = (unsigned long long)ctx->opt_residence_cap;  // (tests: force the second sweep)
+    }
+    unsigned long long n_rec = 0;
+    unsigned long long *d_rec = nullptr;
+    for (int sweep = 0; sweep < 2; ++sweep) {
+        d_rec = (unsigned long long *)mdhip_ws(ctx, WS_AUX0, (size_t)cap * 8);
+        if (!d_rec) return MDHIP_ENOMEM;
+        hipLaunchKernelGGL(shell_pairs_kernel<true>, grid, dim3(RT_TILE), 0, ctx->stream, d_xi, (long long)n_i, d_xj,
+                           (long long)n_j, d_box, r_lo_sq, r_hi_sq, exclude_diagonal, frame_bits, d_misc + sweep, d_rec, cap);
+        MD_HIP(hipGetLastError());
+        MD_HIP(hipMemcpyAsync(h_out, d_misc + sweep, 8, hipMemcpyDeviceToHost, ctx->stream));
+        MD_HIP(mdhip_stream_wait(ctx));
+        n_rec = h_out[0];
+        if (n_rec <= cap) break;
+        MD_REQUIRE(sweep == 0, "residence: the record count changed between two sweeps of the same frames");
+        cap = n_rec;  // exact now
+    }
     if (n_records) *n_records = n_rec;
     if (n_rec == 0) {
         timer.stop();
@@ -259,12 +282,7 @@ int mdhip_shell_residence(mdhip_ctx *ctx, int64_t n_frames, int64_t n_i, const d
         });
         return cs.end();
     }
-    MD_WS(d_rec, unsigned long long, WS_AUX0, (size_t)n_rec * 8);
     MD_WS(d_srt, unsigned long long, WS_AUX1, (size_t)n_rec * 8);
-    hipLaunchKernelGGL(shell_pairs_kernel<true>, grid, dim3(RT_TILE), 0, ctx->stream, d_xi, (long long)n_i, d_xj,
-                       (long long)n_j, d_box, r_lo_sq, r_hi_sq, exclude_diagonal, frame_bits, d_misc + 1, d_rec,
-                       n_rec);
-    MD_HIP(hipGetLastError());
     size_t tmp_b = 0;
     MD_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_b, d_rec, d_srt, (size_t)n_rec, 0, 64, ctx->stream));
     MD_WS(d_tmp, unsigned char, WS_AUX2, tmp_b + 256);

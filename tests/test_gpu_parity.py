@@ -1295,6 +1295,7 @@ def test_packed_f32_sweep_class_rows(B):
     for ctx, v in ((f64, 0), (pk, 1)):
         ctx.set_option("rdf_cull", 1)
         ctx.set_option("rdf_pk", v)
+        ctx.set_option("rdf_disp", 0)  # (round 6: displaced rows would fit these 12 relations into the table-free sweep)
     for r_cut, bin_size, nbins, tag in ((16.0, 0.04, 400, "<5,"), (16.03, 0.04, 400, "<6,"), (18.7, 0.1, 187, "<5,")):
         for per_frame in (True, False):
             a = B.rdf_loop(xyz, ty, box, rel, r_cut, bin_size, nbins, per_frame=per_frame, ctx=f64)
@@ -1526,6 +1527,16 @@ def test_shell_residence_vs_oracle(B):
         want = O.residence_counts(h)
         np.testing.assert_array_equal(counts.astype(np.int64), want)
         assert nrec == int(h.sum())
+        # the record list is sized from an estimate and filled in ONE sweep (round 6); a list that turns out too small is
+        # swept again with the exact size: forced here with a capacity of 5 records
+        ctx = B.default_context()
+        ctx.set_option("residence_cap", 5)
+        try:
+            c2, n2 = B.shell_residence(xi, xj, box, lo * lo, hi * hi, exclude_diagonal=same)
+        finally:
+            ctx.set_option("residence_cap", 0)
+        np.testing.assert_array_equal(c2, counts)
+        assert n2 == nrec
 
 
 def test_residence_time_dropin_golden(B, tmp_path):
