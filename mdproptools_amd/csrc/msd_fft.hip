@@ -1745,46 +1745,8 @@ long long pow2_length(long long n)
     return L;
 }
 
-// host: prefix sums of Q, S1 - 2 S2, normalisation as lag_msd_finish_kernel; returns the error bound.
-// corr[s][k] * corr_scale = S2(k) of segment s = axis * G + group; row length corr_row.
-double finish_on_host(long long F, long long G, long long n_lags, const int64_t *group_off, const double *Q,
-                      const double *corr, long long corr_row, double corr_scale, long long L, double *out)
-{
-    const double eps_l = 4.0 * 2.220446049250313e-16 * std::log2((double)L);
-    double worst = 0.0;
-    std::vector<long double> pre((size_t)F + 1);
-    for (long long g = 0; g < G; ++g) {
-        const double n_g = (double)(group_off[g + 1] - group_off[g]);
-        for (int a = 0; a < 3; ++a) {
-            const size_t s = (size_t)a * G + g;
-            pre[0] = 0.0L;
-            for (long long t = 0; t < F; ++t) pre[t + 1] = pre[t] + (long double)Q[s * F + t];
-            double v_min = 0.0;  // smallest non-zero |S1 - 2 S2| over the lags k > 0
-            for (long long k = 0; k < n_lags; ++k) {
-                const long double s1 = pre[F - k] + (pre[F] - pre[k]);
-                const long double s2 = (long double)corr[s * corr_row + k] * (long double)corr_scale;
-                const double cnt = (double)(F - k) * n_g;
-                double v = (double)(s1 - 2.0L * s2);
-                if (k == 0) v = 0.0;  // exactly, as the difference form gives
-                out[((size_t)k * G + g) * 4 + a] = cnt > 0.0 ? v / cnt : 0.0;
-                const double av = std::fabs(v);
-                if (k > 0 && av != 0.0 && (v_min == 0.0 || av < v_min)) v_min = av;
-            }
-            // the transform's rounding error in S2(k) scales with the energy of the WHOLE series at every lag
-            // (2 pre[F] >= S1(k), equal at small lags), not with the few samples S1 still holds at large ones:
-            // the worst relative error is at the lag with the smallest |v|
-            if (v_min > 0.0) worst = std::max(worst, eps_l * (double)(2.0L * pre[F]) / v_min);
-        }
-        for (long long k = 0; k < n_lags; ++k) {
-            double *o = out + ((size_t)k * G + g) * 4;
-            o[3] = (o[0] + o[1]) + o[2];
-        }
-    }
-    return worst;
-}
-
 // ---------------------------------------------------------------------------------------------
-// Round 5: the finish of the fused path ON THE DEVICE (rounds 2-4: finish_on_host below, in long double, behind a
+// Round 5: the finish of the fused path ON THE DEVICE (rounds 2-4: a host pass in long double behind a
 // device-to-host copy of Q and the correlations and a host wait in the middle of every call — 0.8 of the 1.03 ms a C4
 // step took on the shard one of eight ranks holds). What the host did with a 64-bit mantissa is done here in
 // double-double (two-sum arithmetic, ~106 bits): prefix sums of the per-frame squares Q, S1(k) = pre[F - k] + (pre[F] -
@@ -1885,7 +1847,7 @@ __global__ __launch_bounds__(256) void lag_finish_dd_kernel(const double *__rest
         for (int w = 0; w < 4; ++w)
             if (vmin_s[w] != 0.0 && (m == 0.0 || vmin_s[w] < m)) m = vmin_s[w];
         // the transform's rounding error in S2(k) scales with the energy of the WHOLE series at every lag: the worst
-        // relative error is at the lag with the smallest |v| (see finish_on_host)
+        // relative error is at the lag with the smallest |v| (2 pre[F] >= S1(k), equal at small lags)
         bound[s] = m > 0.0 ? eps_l * (2.0 * (tot.hi + tot.lo)) / m : 0.0;
     }
 }
@@ -2290,8 +2252,8 @@ int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r
 
 // d_r: device [F][3][E]. out: host [max_lag+1][G][4] means as mdhip_lag_msd. *rel_bound: the largest
 // estimated relative rounding error over all (lag >= 1, group, axis) entries with a non-zero value.
-// The fused path (padded length <= 16384) delivers the means itself (res->delivered); the batched path below finishes
-// on the host and leaves them in res->out for the caller to deliver.
+// Both paths — the fused kernels (padded length <= 16384) and the batched transforms below — finish on the device and
+// deliver the means themselves (res->delivered).
 int mdhip_lag_msd_fft(CallScope &cs, int64_t n_frames, int64_t n_ent, const double *d_r, double scale,
                       int max_lag, int n_groups, const int64_t *group_off, const std::shared_ptr<LagFftResult> &res,
                       double *out, int out_on_device)
@@ -2320,7 +2282,10 @@ int mdhip_lag_msd_fft(CallScope &cs, int64_t n_frames, int64_t n_ent, const doub
     }
     const long long L = pow2_length(F + max_lag);
     MD_REQUIRE(L < (1LL << 30), "series too long for the FFT path (%lld)", L);
-    res->out.assign((size_t)(max_lag + 1) * n_groups * 4, 0.0);  // (this path finishes on the host)
+    // (round 6: this path finishes on the device as well — lag_finish_dd_kernel on Q and the correlations where they are —
+    // so that series of more than 16 384 padded points, trajectories of 10^4+ frames, no longer cost two device-to-host
+    // copies and a host pass in long double, and carry the same device status word as the fused kernels)
+    res->delivered = true;
     const long long K = L / 2 + 1;
     const long long S = 3 * G;  // (axis, group) segments
 
@@ -2337,16 +2302,22 @@ int mdhip_lag_msd_fft(CallScope &cs, int64_t n_frames, int64_t n_ent, const doub
     MD_WS(d_tmp, double2, WS_FFT_TMP, (size_t)std::max(nb0, S) * L * 8 + 64);
     // Q [S][F] | P [S][K] | complex P [S][K] | correlations [S][L] | group offsets
     const size_t q_b = (size_t)S * F * 8, p_b = (size_t)S * K * 8, z_b = (size_t)S * K * 16, c_b = (size_t)S * L * 8;
-    MD_WS(d_small, unsigned char, WS_AUX3, q_b + p_b + z_b + c_b + (size_t)(G + 1) * 8 + 256);
+    MD_WS(d_small, unsigned char, WS_AUX3, q_b + p_b + z_b + c_b + (size_t)(G + 1) * 8 + (size_t)G * 8 + 256);
     double *d_Q = reinterpret_cast<double *>(d_small);
     double *d_P = reinterpret_cast<double *>(d_small + q_b);
     double2 *d_Z = reinterpret_cast<double2 *>(d_small + q_b + p_b);
     double *d_corr = reinterpret_cast<double *>(d_small + q_b + p_b + z_b);
     long long *d_goff = reinterpret_cast<long long *>(d_small + q_b + p_b + z_b + c_b);
+    double *d_ng = reinterpret_cast<double *>(d_goff + G + 1);  // entities per group (lag_finish_dd_kernel)
     MD_WS(d_part, double, WS_PART, (size_t)MF_SPLITS * K * 8);
 
     {
-        const int rc0 = mdhip_h2d_small(ctx, d_goff, group_off, (size_t)(G + 1) * 8);  // (the caller's memory)
+        // group offsets | entities per group: one pinned block, one copy on the launch stream
+        MD_PIN(h_g, unsigned char, (size_t)(2 * G + 1) * 8);
+        memcpy(h_g, group_off, (size_t)(G + 1) * 8);
+        double *h_ng = reinterpret_cast<double *>(h_g + (size_t)(G + 1) * 8);
+        for (long long g = 0; g < G; ++g) h_ng[g] = (double)(group_off[g + 1] - group_off[g]);
+        const int rc0 = mdhip_copy_small(ctx, d_goff, h_g, (size_t)(2 * G + 1) * 8, hipMemcpyHostToDevice);
         if (rc0) return rc0;
     }
     MD_HIP(hipMemsetAsync(d_P, 0, p_b, ctx->stream));
@@ -2388,14 +2359,33 @@ int mdhip_lag_msd_fft(CallScope &cs, int64_t n_frames, int64_t n_ent, const doub
     timer.stop();
     ctx->last_kernel = "lag_msd_fft";
 
-    MD_PIN(h_Q, double, q_b);
-    MD_PIN(h_corr, double, c_b);
-    MD_HIP(hipMemcpyAsync(h_Q, d_Q, q_b, hipMemcpyDeviceToHost, ctx->stream));
-    MD_HIP(hipMemcpyAsync(h_corr, d_corr, c_b, hipMemcpyDeviceToHost, ctx->stream));
-    cs.defer([timer, res, h_Q, h_corr, F, G, n_lags, L]() {
+    // the finish, on the device: means into `d_fin`, from there to the caller's buffer on the stream; only the segments'
+    // bounds come back for the completion step (as lag_msd_fft_fused)
+    const size_t fin_b = (size_t)n_lags * G * 4 * 8;
+    MD_WS(d_fin_ws, unsigned char, WS_OUT3, fin_b + (size_t)(S + 2) * 8 + (size_t)S * (F + 1) * sizeof(DD) + 64);
+    double *d_fin = reinterpret_cast<double *>(d_fin_ws), *d_bound = d_fin + (size_t)n_lags * G * 4;
+    DD *d_pre = reinterpret_cast<DD *>(d_bound + S + 2);
+    const double eps_l = 4.0 * 2.220446049250313e-16 * std::log2((double)L);
+    hipLaunchKernelGGL(lag_finish_dd_kernel, dim3((unsigned)S), dim3(256), 0, ctx->stream, d_Q, d_corr, L, 1.0 / (double)L, F,
+                       n_lags, (int)G, d_ng, eps_l, d_pre, d_fin, d_bound);
+    hipLaunchKernelGGL(lag_total_kernel, dim3((unsigned)((n_lags * G + 255) / 256)), dim3(256), 0, ctx->stream, d_fin,
+                       n_lags * G, d_bound, (int)S, (const unsigned *)nullptr);
+    ctx->lag_status_dev = d_bound + S;  // (mdhip_lag_msd_status_dev: valid until the next call that uses WS_OUT3)
+    MD_HIP(hipGetLastError());
+    {
+        const int rcr = mdhip_result(cs, out, d_fin, fin_b, out_on_device);
+        if (rcr) return rcr;
+    }
+    MD_PIN(h_bound, double, (size_t)S * 8);
+    {
+        const int rcc = mdhip_copy_small(ctx, h_bound, d_bound, (size_t)S * 8, hipMemcpyDeviceToHost);
+        if (rcc) return rcc;
+    }
+    cs.defer([timer, res, h_bound, S]() {
         timer.collect();
-        res->bound = finish_on_host(F, G, n_lags, res->group_off.data(), h_Q, h_corr, L, 1.0 / (double)L, L,
-                                    res->out.data());
+        double worst = 0.0;
+        for (long long q = 0; q < S; ++q) worst = std::max(worst, h_bound[q]);
+        res->bound = worst;
         return MDHIP_OK;
     });
     return MDHIP_OK;

@@ -953,13 +953,13 @@ def msd_step_sharded_async(r_f, r_e, n_frames_total, entity_range, group_off, ta
             x = r_e[:, :, int(loc_off[0]):int(loc_off[-1])].contiguous()
         # One host wait per step (round 5): the fused spectral lag path finishes on the device, so everything behind the
         # three calls — the halo window, the weighting of the lag means, the all-reduce, the copy to the host — is QUEUED
-        # here, at issue time, and finish() only waits for the copy. (Series too long for the fused path, F + max_lag >
-        # 16384, still finish on the host: the round-4 order, two waits.)
+        # here, at issue time, and finish() only waits for the copy. (Round 6: the batched path for series of more than
+        # 16 384 padded points finishes on the device too, so the one-wait order holds for every length.)
         # Measured on ONE GPU with the shards one of eight / four ranks holds, both orders in the same process (tools/
         # c4_shard_cost.py, C4_ORDER=two|one, profiles/r05_c4_shard.txt): 1.17 against 1.16 ms per step at 8, 2.01 against
         # 1.83 at 4 — boxes differ by more than that between leases, so orders are compared inside one run. On a
         # multi-GPU node the single wait also covers the collective's wire time. MDHIP_STEP_ONE_WAIT=0 restores round 4's order.
-        one_wait = on_gpu and F + max_lag <= 16384 and os.environ.get("MDHIP_STEP_ONE_WAIT", "1") != "0"
+        one_wait = on_gpu and os.environ.get("MDHIP_STEP_ONE_WAIT", "1") != "0"
         issue_err = None
         if on_gpu:
             try:

@@ -503,6 +503,46 @@ def test_lag_msd_fft_every_transform_size(B):
         ctx.set_option("lag_fft_kernel", 3)
 
 
+def test_lag_msd_long_series_finish_on_the_device(B):
+    """Series beyond the fused kernels (F + max_lag > 16 384: trajectories of 10^4+ frames, diffusion.py:207-238) run the
+    batched transforms and — round 6 — finish on the device like the fused kernels: the means equal the exact-difference
+    kernel's within the reported bound and the C oracle's at rtol 1e-9, a device result with its status word equals the
+    host result bit for bit, the asynchronous twin equals the synchronous call, no device-to-host copy of Q / the
+    correlations is left (the call reports the bound through the same status word the multi-GPU step all-reduces)."""
+    import torch
+
+    ctx = B.default_context()
+    rng = np.random.default_rng(77)
+    try:
+        for F, max_lag, E in ((9001, 9000, 7), (12000, 8000, 5), (20000, 19999, 3)):
+            goff = [0, 2, 2, E]
+            r = np.cumsum(rng.normal(0, 0.1, (F, 3, E)), axis=0) + rng.uniform(-50, 50, (1, 3, E))
+            ctx.set_option("lag_variant", 1)
+            exact = B.lag_msd(r, max_lag, goff, scale=0.5)
+            ctx.set_option("lag_variant", 2)
+            fft = B.lag_msd(r, max_lag, goff, scale=0.5)
+            bound = ctx.last_rel_bound()
+            assert ctx.last_kernel_name() == "lag_msd_fft" and 0.0 < bound < 1e-9, (ctx.last_kernel_name(), bound)
+            assert (fft[0] == 0.0).all()
+            nz = exact > 0
+            rel = np.abs(fft[nz] - exact[nz]) / exact[nz]
+            assert rel.max() <= bound, (F, max_lag, rel.max(), bound)
+            lags = np.unique(np.concatenate([np.arange(0, 40), rng.integers(0, max_lag + 1, 60), [max_lag]]))
+            want = C.lag_msd(r * 0.5, lags, goff)
+            np.testing.assert_allclose(fft[lags], want, rtol=1e-9, atol=0)
+            dev_r = torch.from_numpy(r).cuda()
+            out = torch.empty((max_lag + 1, 3, 4), dtype=torch.float64, device="cuda")
+            st = torch.full((1,), -1.0, dtype=torch.float64, device="cuda")
+            B.lag_msd(dev_r, max_lag, goff, scale=0.5, out=out, async_=True, status_out=st).wait()
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(out.cpu().numpy(), fft)
+            assert float(st.item()) == bound
+            again = B.lag_msd(r, max_lag, goff, scale=0.5, async_=True).wait()
+            np.testing.assert_array_equal(again, fft)
+    finally:
+        ctx.set_option("lag_variant", 1)
+
+
 @pytest.mark.parametrize("mode", [1, 2])
 def test_lag_msd_direct_read_option(B, mode):
     """`lag_direct` 1: the power kernel reads [F][3][E] itself (clusters of 16 blocks on adjacent columns, no transposed
