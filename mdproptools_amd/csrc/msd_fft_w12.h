@@ -46,7 +46,7 @@ constexpr int W12_UN = 4;                   // staging units per lane and tile (
 //     buffer_store_dwordx4 v[86:89], v114, s[56:59], s74 offen sc1
 //     v_cndmask_b32_e32 v86, v148, v126, vcc        (the next unit's load offset, into the store's first data register)
 // which stored that offset as the low word of one sample in every second 8-lane group (integer-ramp input: MSD(1) =
-// 1.013 instead of 1; tools/w12_probe.py). The guard keeps the data registers live across two idle cycles behind the
+// 1.013 instead of 1; tools/w12.py ramp). The guard keeps the data registers live across two idle cycles behind the
 // store; tests/test_codegen_cpu.py scans the compiled kernels for the pattern.
 #define W12_STORE_GUARD(v) asm volatile("s_nop 1" ::"v"(v))
 #define W12_BARRIER(bit) do { if (!(W12_EXP & (bit))) __syncthreads(); } while (0)
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(W12_THREADS) void msd_power_w12_kernel(
         const long long st_i = c - it.c_lo + ST_AHEAD;
         // Staging points 0 .. 5 of the iteration: point P stores the unit requested two points ago (P - 2) and requests
         // unit P (< W12_UN), units alternating between the two register pairs (msd_power_lds3_kernel's scheme).
-        // Two other schedules were measured against this one in one process (tools/w12_exp.py, C4 call, 4.23-4.28 ms
+        // Two other schedules were measured against this one in one process (tools/w12.py exp, C4 call, 4.23-4.28 ms
         // here; 3.52 ms with no staging at all): every unit stored FOUR points after its request (four units, 16
         // registers, live throughout; the signal two series later) 4.33-4.37 ms; all four units requested at the end of
         // the series before and stored together behind the first register pass 4.72 ms. The staging's cost is not the

@@ -37,80 +37,77 @@ __device__ __forceinline__ double rt_wrap_abs(double d, double L)
     return __builtin_fmin(a, __builtin_fabs(a - L));
 }
 
-// grid (ceil(n_i / 256), F). FILL = false: total hit count into *n_rec. FILL = true: records appended; a block
-// collects its hits in LDS and reserves space in the global list once per j tile (one global atomic per flush
-// instead of one per hit on a single counter, which serialises: 10^7 hits took 100 ms that way).
+// grid (ceil(n_lane / 256), F): a lane holds one atom of the LARGER set (round 6: with the central atoms always on the
+// lanes, 315 Mg against 11 280 O filled 315 of 512 lanes), the atoms of the other set are staged through LDS 256 at a time
+// and read as broadcasts. SWAP: the lanes hold the shell atoms j, the loop walks the central atoms i (the record key is
+// i * n_j + j either way). Records are appended to the list; a block collects its hits in LDS and reserves space in the
+// global list once per staged tile (one global atomic per flush instead of one per hit on a single counter, which
+// serialises: 10^7 hits took 100 ms that way). *n_rec counts every hit, also those beyond `cap` (the host sweeps again
+// with the exact size then).
 constexpr int RT_STAGE = 2048;
-template <bool FILL>
+template <bool SWAP>
 __global__ __launch_bounds__(RT_TILE) void shell_pairs_kernel(
     const double *__restrict__ xi, long long n_i, const double *__restrict__ xj, long long n_j,
     const double *__restrict__ box, double lo2, double hi2, int exclude_diagonal, int frame_bits,
     unsigned long long *__restrict__ n_rec, unsigned long long *__restrict__ rec, unsigned long long cap)
 {
-    __shared__ double s_j[3][RT_TILE];
-    __shared__ unsigned long long s_rec[FILL ? RT_STAGE : 1];
+    __shared__ double s_b[3][RT_TILE];
+    __shared__ unsigned long long s_rec[RT_STAGE];
     __shared__ unsigned s_n;
     __shared__ unsigned long long s_base;
     const int f = blockIdx.y, tid = threadIdx.x;
-    const long long i = (long long)blockIdx.x * RT_TILE + tid;
-    const double *pi = xi + (size_t)f * 3 * n_i, *pj = xj + (size_t)f * 3 * n_j;
+    // lane set a, looped set b
+    const long long n_a = SWAP ? n_j : n_i, n_b = SWAP ? n_i : n_j;
+    const double *pa = (SWAP ? xj : xi) + (size_t)f * 3 * n_a, *pb = (SWAP ? xi : xj) + (size_t)f * 3 * n_b;
+    const long long la = (long long)blockIdx.x * RT_TILE + tid;
     const double Lx = box[3 * f], Ly = box[3 * f + 1], Lz = box[3 * f + 2];
     double x = 0.0, y = 0.0, z = 0.0;
-    if (i < n_i) {
-        x = pi[i];
-        y = pi[n_i + i];
-        z = pi[2 * n_i + i];
+    if (la < n_a) {
+        x = pa[la];
+        y = pa[n_a + la];
+        z = pa[2 * n_a + la];
     }
     if (tid == 0) s_n = 0u;
-    unsigned long long mine = 0;
-    for (long long j0 = 0; j0 < n_j; j0 += RT_TILE) {
+    for (long long b0 = 0; b0 < n_b; b0 += RT_TILE) {
         __syncthreads();
-        const long long jl = j0 + tid;
-        s_j[0][tid] = jl < n_j ? pj[jl] : 0.0;
-        s_j[1][tid] = jl < n_j ? pj[n_j + jl] : 0.0;
-        s_j[2][tid] = jl < n_j ? pj[2 * n_j + jl] : 0.0;
+        const long long bl = b0 + tid;
+        s_b[0][tid] = bl < n_b ? pb[bl] : 0.0;
+        s_b[1][tid] = bl < n_b ? pb[n_b + bl] : 0.0;
+        s_b[2][tid] = bl < n_b ? pb[2 * n_b + bl] : 0.0;
         __syncthreads();
-        const int cnt = (int)((n_j - j0) < RT_TILE ? (n_j - j0) : RT_TILE);
-        if (i < n_i) {
-            for (int jj = 0; jj < cnt; ++jj) {
-                const double ax = rt_wrap_abs(x - s_j[0][jj], Lx);
-                const double ay = rt_wrap_abs(y - s_j[1][jj], Ly);
-                const double az = rt_wrap_abs(z - s_j[2][jj], Lz);
+        const int cnt = (int)((n_b - b0) < RT_TILE ? (n_b - b0) : RT_TILE);
+        if (la < n_a) {
+            for (int bb = 0; bb < cnt; ++bb) {
+                // head - other (rdf_cn.py:44-57): the central atom is the head row; |d| is what enters, so the order of
+                // the subtraction is immaterial to the bits (rounding is sign-symmetric)
+                const double ax = rt_wrap_abs(x - s_b[0][bb], Lx);
+                const double ay = rt_wrap_abs(y - s_b[1][bb], Ly);
+                const double az = rt_wrap_abs(z - s_b[2][bb], Lz);
                 const double rsq = (ax * ax + ay * ay) + az * az;
-                const long long j = j0 + jj;
+                const long long i = SWAP ? b0 + bb : la, j = SWAP ? la : b0 + bb;
                 if (rsq > lo2 && rsq <= hi2 && !(exclude_diagonal && j == i)) {  // residence_time.py:102-104
-                    if (FILL) {
-                        const unsigned long long r =
-                            (((unsigned long long)i * (unsigned long long)n_j + (unsigned long long)j) << frame_bits) |
-                            (unsigned long long)f;
-                        const unsigned k = atomicAdd(&s_n, 1u);
-                        if (k < (unsigned)RT_STAGE) {
-                            s_rec[k] = r;
-                        } else {  // stage full (a very dense shell): straight to the global list
-                            const unsigned long long pos = atomicAdd(n_rec, 1ull);
-                            if (pos < cap) rec[pos] = r;
-                        }
-                    } else {
-                        ++mine;
+                    const unsigned long long r =
+                        (((unsigned long long)i * (unsigned long long)n_j + (unsigned long long)j) << frame_bits) |
+                        (unsigned long long)f;
+                    const unsigned k = atomicAdd(&s_n, 1u);
+                    if (k < (unsigned)RT_STAGE) {
+                        s_rec[k] = r;
+                    } else {  // stage full (a very dense shell): straight to the global list
+                        const unsigned long long pos = atomicAdd(n_rec, 1ull);
+                        if (pos < cap) rec[pos] = r;
                     }
                 }
             }
         }
-        if (FILL) {  // flush the stage
-            __syncthreads();
-            const unsigned staged = s_n < (unsigned)RT_STAGE ? s_n : (unsigned)RT_STAGE;
-            if (tid == 0 && staged) s_base = atomicAdd(n_rec, (unsigned long long)staged);
-            __syncthreads();
-            for (unsigned k = tid; k < staged; k += RT_TILE)
-                if (s_base + k < cap) rec[s_base + k] = s_rec[k];
-            __syncthreads();
-            if (tid == 0) s_n = 0u;
-        }
-    }
-    if (!FILL) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
-        if ((tid & 63) == 0 && mine) atomicAdd(n_rec, mine);
+        // flush the stage
+        __syncthreads();
+        const unsigned staged = s_n < (unsigned)RT_STAGE ? s_n : (unsigned)RT_STAGE;
+        if (tid == 0 && staged) s_base = atomicAdd(n_rec, (unsigned long long)staged);
+        __syncthreads();
+        for (unsigned k = tid; k < staged; k += RT_TILE)
+            if (s_base + k < cap) rec[s_base + k] = s_rec[k];
+        __syncthreads();
+        if (tid == 0) s_n = 0u;
     }
 }
 
@@ -239,7 +236,8 @@ int mdhip_shell_residence(mdhip_ctx *ctx, int64_t n_frames, int64_t n_i, const d
     MD_HIP(hipMemsetAsync(d_counts, 0, (size_t)n_frames * 8, ctx->stream));
     MD_PIN(h_out, unsigned long long, ((size_t)n_frames + 8) * 8);
 
-    const dim3 grid((unsigned)((n_i + RT_TILE - 1) / RT_TILE), (unsigned)n_frames);
+    const bool swap = n_j > n_i;  // the larger set on the lanes
+    const dim3 grid((unsigned)(((swap ? n_j : n_i) + RT_TILE - 1) / RT_TILE), (unsigned)n_frames);
     KernelTimer timer(ctx);
     ctx->last_kernel = "shell_pairs_kernel";
     // ONE sweep over the pairs in the common case (round 6; rounds 1-5 swept twice, count then fill): the record list is
@@ -261,8 +259,12 @@ int mdhip_shell_residence(mdhip_ctx *ctx, int64_t n_frames, int64_t n_i, const d
     for (int sweep = 0; sweep < 2; ++sweep) {
         d_rec = (unsigned long long *)mdhip_ws(ctx, WS_AUX0, (size_t)cap * 8);
         if (!d_rec) return MDHIP_ENOMEM;
-        hipLaunchKernelGGL(shell_pairs_kernel<true>, grid, dim3(RT_TILE), 0, ctx->stream, d_xi, (long long)n_i, d_xj,
-                           (long long)n_j, d_box, r_lo_sq, r_hi_sq, exclude_diagonal, frame_bits, d_misc + sweep, d_rec, cap);
+        if (swap)
+            hipLaunchKernelGGL(shell_pairs_kernel<true>, grid, dim3(RT_TILE), 0, ctx->stream, d_xi, (long long)n_i, d_xj,
+                               (long long)n_j, d_box, r_lo_sq, r_hi_sq, exclude_diagonal, frame_bits, d_misc + sweep, d_rec, cap);
+        else
+            hipLaunchKernelGGL(shell_pairs_kernel<false>, grid, dim3(RT_TILE), 0, ctx->stream, d_xi, (long long)n_i, d_xj,
+                               (long long)n_j, d_box, r_lo_sq, r_hi_sq, exclude_diagonal, frame_bits, d_misc + sweep, d_rec, cap);
         MD_HIP(hipGetLastError());
         MD_HIP(hipMemcpyAsync(h_out, d_misc + sweep, 8, hipMemcpyDeviceToHost, ctx->stream));
         MD_HIP(mdhip_stream_wait(ctx));

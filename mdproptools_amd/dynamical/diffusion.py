@@ -115,6 +115,28 @@ class Diffusion:
                 dump.data[axis + "u"] = dump.data[axis].add(dump.data["i" + axis].multiply(length))
         return dump
 
+    def _calculate_type_com(self, df, ind):
+        """Mass-weighted mean of xu, yu, zu per group of `ind` (index levels or columns of `df`): a DataFrame indexed by
+        `ind` with the three coordinate columns (diffusion.py:83-89). The product path computes the same per-type centres
+        on its arrays (`_type_com`, mdhip_segment_com); this host form exists for callers that subclass and call it — the
+        sums run per group in pandas' order instead of a BLAS dot, so it agrees with the reference to rounding."""
+        cols = ["xu", "yu", "zu"]
+        weighted = df[["mass"]].copy()
+        weighted[cols] = df[cols].to_numpy() * df["mass"].to_numpy()[:, None]
+        sums = weighted.groupby(ind).sum()
+        return sums[cols].div(sums["mass"], axis=0)
+
+    def _modify_dump_coordinates(self, msd_df):
+        """Subtract from every molecule the drift of its TYPE's centre of mass since time 0 (diffusion.py:91-96);
+        `msd_df` is indexed by ("Time (s)", "type", "mol_id") with columns mass, xu, yu, zu."""
+        cols = ["xu", "yu", "zu"]
+        ref_com = self._calculate_type_com(msd_df.xs(0, level=0), ["type"])
+        com = self._calculate_type_com(msd_df, ["Time (s)", "type"])
+        drift = com.sub(ref_com.reindex(com.index.get_level_values("type")).to_numpy())
+        rows = pd.MultiIndex.from_arrays([msd_df.index.get_level_values("Time (s)"), msd_df.index.get_level_values("type")])
+        msd_df.loc[:, cols] = msd_df[cols].to_numpy() - drift.reindex(rows).to_numpy()
+        return msd_df
+
     def detect_linear_region():
         pass
 

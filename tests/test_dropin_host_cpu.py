@@ -234,3 +234,37 @@ def test_batch_normalisation_sum_and_csv_are_the_per_frame_code_bit_for_bit(tmp_
     buf = io.StringIO()  # not a path: pandas writes it
     R._write_csv(df, buf)
     assert buf.getvalue() == open(tmp_path / "pandas.csv").read()
+
+
+def test_diffusion_private_drift_helpers_match_the_array_path():
+    """Diffusion._calculate_type_com / _modify_dump_coordinates (the reference's private helpers, diffusion.py:83-96, kept
+    for callers that subclass): on a (Time, type, mol_id)-indexed frame they remove the same per-type drift as the array
+    path the product runs (`_remove_drift`), to rounding."""
+    import pandas as pd
+
+    from mdproptools_amd.dynamical.diffusion import Diffusion
+
+    rng = np.random.default_rng(12)
+    F, counts = 6, [5, 3, 4]
+    E = sum(counts)
+    types = np.repeat([1, 2, 3], counts)
+    mol_id = np.concatenate([np.arange(1, c + 1) for c in counts])
+    mass = rng.uniform(1.0, 30.0, E)
+    r = rng.normal(0, 1, (1, 3, E)) + np.cumsum(rng.normal(0, 0.3, (F, 3, E)), axis=0)
+    times = np.arange(F) * 2.0e-15
+    rows = []
+    for f in range(F):
+        rows.append(pd.DataFrame({"Time (s)": times[f], "type": types, "mol_id": mol_id, "mass": mass,
+                                  "xu": r[f, 0], "yu": r[f, 1], "zu": r[f, 2]}))
+    msd_df = pd.concat(rows).set_index(["Time (s)", "type", "mol_id"]).sort_index()
+    d = Diffusion()
+    com = d._calculate_type_com(msd_df, ["Time (s)", "type"])
+    assert list(com.columns) == ["xu", "yu", "zu"] and com.index.names == ["Time (s)", "type"]
+    goff = np.concatenate([[0], np.cumsum(counts)])
+    want_com = Diffusion._type_com(r, mass, goff)  # [F,3,G]
+    np.testing.assert_allclose(com.to_numpy().reshape(F, 3, 3).transpose(0, 2, 1), want_com, rtol=1e-13)
+    out = d._modify_dump_coordinates(msd_df.copy())
+    want = Diffusion._remove_drift(r, mass, goff)
+    got = out[["xu", "yu", "zu"]].to_numpy().reshape(F, E, 3).transpose(0, 2, 1)
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-13)
+    np.testing.assert_array_equal(got[0], r[0])  # time 0 is the reference: no drift there

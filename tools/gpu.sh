@@ -37,6 +37,8 @@ for s in "$@"; do
     stats_legs) (cd /tmp && export TMPDIR=/tmp && timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o ${ROUND}_bench_legs -- python3 $R/bench.py --no-cpu-baseline > $O/bench_line_rocprof_legs.json 2> $O/rocprof_legs_err.log); echo "stats_legs rc=$?"; tail -2 $O/rocprof_legs_err.log ;;
     ab_lag) timeout -k 10 400 python tools/ab_libs_lag.py $LP $L 2>&1 | grep -v amdgpu > $O/${ROUND}_ab_lag_${TAG}.txt; cat $O/${ROUND}_ab_lag_${TAG}.txt ;;
     ab_pair) timeout -k 10 400 python tools/ab_libs.py $LP $L 2>&1 | grep -v amdgpu > $O/${ROUND}_ab_pair_${TAG}.txt; cat $O/${ROUND}_ab_pair_${TAG}.txt ;;
+    w12_check) timeout -k 10 400 python tools/w12.py check 2>&1 | grep -v amdgpu > $O/${ROUND}_w12_check.txt; tail -12 $O/${ROUND}_w12_check.txt ;;
+    w12_exp=*) timeout -k 10 400 python tools/w12.py exp $L ${s#w12_exp=} $L 2>&1 | grep -v amdgpu > $O/${ROUND}_w12_exp_${TAG}.txt; cat $O/${ROUND}_w12_exp_${TAG}.txt ;;
     lag_sizes) timeout -k 10 900 python tools/lag_sizes.py 2>&1 | grep -v amdgpu > $O/${ROUND}_lag_sizes.txt; cat $O/${ROUND}_lag_sizes.txt ;;
     c4_shard) ( for rep in 1 2 3; do for n in 8 4; do for o in two one; do C4_ORDER=$o timeout -k 10 300 python tools/c4_shard_cost.py $n 2>&1 | grep -v amdgpu | tail -3; done; done; done ) > $O/${ROUND}_c4_shard.txt 2>&1; cat $O/${ROUND}_c4_shard.txt ;;
     *) if [ -f "$s" ]; then timeout -k 10 600 python "$s" > $O/$(basename $s .py)_${TAG}.txt 2>&1; echo "$s rc=$?"; tail -40 $O/$(basename $s .py)_${TAG}.txt; else echo "unknown step $s"; fi ;;
