@@ -393,6 +393,15 @@ def cpu_check_frame(x0, types, rel, L, cfg, nb):
     return cref.rdf_pairs(x0, types, rel, [L] * 3, cfg["r_cut"] ** 2, cfg["bin_size"], nb)
 
 
+def cpu_check_residence(r, n_i, L, lo2, hi2):
+    """The residence leg's checker: the oracle's shell indicator of every frame of r [F,3,n_i+n_j] and its exact lag
+    counts -> (counts [F], number of in-shell records)."""
+    from oracle import cpu_ref as O
+
+    h = np.array([O.shell_indicator(r[f, :, :n_i].T, r[f, :, n_i:].T, np.full(3, L), lo2, hi2, False) for f in range(len(r))])
+    return O.residence_counts(h), int(h.sum())
+
+
 def cpu_check_c3(x0, ty, rel, L, cfg, nb, cuts):
     """C3 frame 0 at full size: the whole frame on the host cores (head rows dealt to threads) as the parity oracle,
     and its first head rows on ONE core as the bounded single-core sample (RDF and CN)."""
@@ -565,8 +574,6 @@ def leg_residence(B, ctx, torch, device, synth, sync):
     frame) over 1000 frames, shell (0, 2.325 A] — the example's Mg-O coordination cutoff. One call = every central x
     shell pair of every frame through the exact f64 distance chain (the sweep is dense: n_i x n_j x F pairs), records
     sorted by pair, presence masks correlated over all lags. The first frames' indicator against the oracle."""
-    from oracle import cpu_ref as O
-
     F, L, n_i, n_j = 1000, 104.0, 315, 11_280
     rng = np.random.default_rng(synth.BASE_SEED + 7)
     start = rng.random((3, n_i + n_j)) * L
@@ -592,8 +599,8 @@ def leg_residence(B, ctx, torch, device, synth, sync):
     # parity: the integer lag counts of the first 40 frames against the oracle's indicator + correlation
     Fc = 40
     c40, n40 = B.shell_residence(xi[:Fc], xj[:Fc], box[:Fc], lo2, hi2, ctx=ctx)
-    h = np.array([O.shell_indicator(r[f, :, :n_i].T, r[f, :, n_i:].T, np.full(3, L), lo2, hi2, False) for f in range(Fc)])
-    if not (np.array_equal(c40.astype(np.int64), O.residence_counts(h)) and int(n40) == int(h.sum())):
+    want, n_want = cpu_check_residence(r[:Fc], n_i, L, lo2, hi2)
+    if not (np.array_equal(c40.astype(np.int64), want) and int(n40) == n_want):
         raise AssertionError("residence counts differ from the oracle")
     pairs = float(F) * n_i * n_j
     return {"workload": "residence: 315 central x 11 280 shell atoms (the example's Mg / ether-O shares of 100k atoms), "
