@@ -128,7 +128,8 @@ def pmc_entry(kernel, workload):
     return e, None
 
 
-SECONDARY_SOURCES = ["msd.hip", "msd_fft.hip", "msd_fft_w12.h", "segment_com.hip", "xcorr.hip", "fft_pow2.hip", "scan.hip"]
+SECONDARY_SOURCES = ["msd.hip", "msd_fft.hip", "msd_fft_w12.h", "segment_com.hip", "xcorr.hip", "fft_pow2.hip", "scan.hip",
+                     "residence.hip"]
 LDS_READ_PEAK = 150e12  # ds_read_b64 / b128 aggregate with every CU streaming, MI355X_MICROARCH.md (LDS section)
 
 
@@ -575,16 +576,10 @@ def leg_residence(B, ctx, torch, device, synth, sync):
     shell pair of every frame through the exact f64 distance chain (the sweep is dense: n_i x n_j x F pairs), records
     sorted by pair, presence masks correlated over all lags. The first frames' indicator against the oracle."""
     F, L, n_i, n_j = 1000, 104.0, 315, 11_280
-    rng = np.random.default_rng(synth.BASE_SEED + 7)
-    start = rng.random((3, n_i + n_j)) * L
-    r = np.empty((F, 3, n_i + n_j))
-    r[0] = start
-    for f0 in range(1, F, 100):
-        steps = rng.normal(0.0, 0.1, (min(F, f0 + 100) - f0, 3, n_i + n_j))
-        np.cumsum(steps, axis=0, out=steps)
-        r[f0:f0 + len(steps)] = r[f0 - 1] + steps
-    xi = torch.from_numpy(np.ascontiguousarray(r[:, :, :n_i])).to(device)
-    xj = torch.from_numpy(np.ascontiguousarray(r[:, :, n_i:])).to(device)
+    ri, rj = synth.residence_walk(F, n_i, n_j, L)
+    r = np.concatenate([ri, rj], axis=2)
+    xi = torch.from_numpy(ri).to(device)
+    xj = torch.from_numpy(rj).to(device)
     box = np.full((F, 3), L)
     lo2, hi2 = 0.0, 2.325 ** 2
     km = []

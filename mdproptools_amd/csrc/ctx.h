@@ -143,10 +143,13 @@ struct mdhip_ctx {
     int opt_h2d_ring = 1;     // 1 (default): pageable sources go through the context's page-locked ring (mdhip_h2d_any),
                               // 0: handed to hipMemcpyAsync as they are (A/B)
     // the ring: two halves, each with the event recorded behind its last DMA (a half is reused once that has fired)
+    // (round 6, ADVICE r05: each half is H2D_RING_CHUNKS chunks of 8 MB cycled through with an event per chunk — a half
+    // sized to the whole copy pinned up to twice the trajectory, ~4.8 GB at C3, until mdhip_destroy)
+    static constexpr int H2D_RING_CHUNKS = 4;
     void *h2d_ring[2] = {nullptr, nullptr};
-    size_t h2d_ring_cap[2] = {0, 0};
-    hipEvent_t h2d_ring_ev[2] = {nullptr, nullptr};
-    bool h2d_ring_used[2] = {false, false};
+    hipEvent_t h2d_chunk_ev[2][H2D_RING_CHUNKS] = {};
+    bool h2d_chunk_used[2][H2D_RING_CHUNKS] = {};
+    int h2d_chunk_next[2] = {0, 0};
     struct CopyPool *copy_pool = nullptr;  // helper threads of mdhip_h2d_any (created on first use)
     std::string err;
     DevBuf ws[WS_COUNT];

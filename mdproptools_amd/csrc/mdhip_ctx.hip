@@ -437,9 +437,12 @@ static void copy_pool_destroy(mdhip_ctx *ctx)
     ctx->copy_pool = nullptr;
     for (int k = 0; k < 2; ++k) {
         if (ctx->h2d_ring[k]) (void)hipHostFree(ctx->h2d_ring[k]);
-        if (ctx->h2d_ring_ev[k]) (void)hipEventDestroy(ctx->h2d_ring_ev[k]);
         ctx->h2d_ring[k] = nullptr;
-        ctx->h2d_ring_ev[k] = nullptr;
+        for (int c = 0; c < mdhip_ctx::H2D_RING_CHUNKS; ++c) {
+            if (ctx->h2d_chunk_ev[k][c]) (void)hipEventDestroy(ctx->h2d_chunk_ev[k][c]);
+            ctx->h2d_chunk_ev[k][c] = nullptr;
+            ctx->h2d_chunk_used[k][c] = false;
+        }
     }
 }
 
@@ -463,31 +466,32 @@ int mdhip_h2d_any(mdhip_ctx *ctx, void *dst_dev, const void *src, size_t bytes, 
     }
     slot &= 1;
     if (!ctx->copy_pool) ctx->copy_pool = new CopyPool();
-    if (!ctx->h2d_ring_ev[slot]) MD_HIP(hipEventCreateWithFlags(&ctx->h2d_ring_ev[slot], hipEventDisableTiming));
-    if (ctx->h2d_ring_used[slot]) MD_HIP(hipEventSynchronize(ctx->h2d_ring_ev[slot]));  // (the half's last DMA: long over)
-    if (ctx->h2d_ring_cap[slot] < bytes) {
-        if (ctx->h2d_ring[slot]) MD_HIP(hipHostFree(ctx->h2d_ring[slot]));
-        ctx->h2d_ring[slot] = nullptr;
-        ctx->h2d_ring_cap[slot] = 0;
-        const size_t cap = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
-        if (hipHostMalloc(&ctx->h2d_ring[slot], cap, hipHostMallocDefault) != hipSuccess) {
+    // A ring of a few 8 MB chunks per half, cycled through with an event per chunk: the DMA of chunk c runs while the helper
+    // threads fill chunk c + 1, and a chunk is written again only when the DMA that last read it is over. The pinned memory
+    // is bounded (2 x 4 x 8 MB) whatever the copy's size; two copies into the same half (xi, then xj) wait for single
+    // chunks, not for each other's whole transfer.
+    constexpr int NC = mdhip_ctx::H2D_RING_CHUNKS;
+    const size_t chunk = (size_t)8 << 20;
+    if (!ctx->h2d_ring[slot]) {
+        if (hipHostMalloc(&ctx->h2d_ring[slot], chunk * NC, hipHostMallocDefault) != hipSuccess) {
             (void)hipGetLastError();
             ctx->h2d_ring[slot] = nullptr;
             MD_HIP(hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyHostToDevice, stream));  // (no page-locked memory to be had)
             return MDHIP_OK;
         }
-        ctx->h2d_ring_cap[slot] = cap;
     }
-    // chunks of 8 MB: the DMA of chunk c runs while the helpers copy chunk c + 1
-    const size_t chunk = (size_t)8 << 20;
     char *ring = static_cast<char *>(ctx->h2d_ring[slot]);
     for (size_t o = 0; o < bytes; o += chunk) {
         const size_t n = std::min(chunk, bytes - o);
-        ctx->copy_pool->copy(ring + o, static_cast<const char *>(src) + o, n);
-        MD_HIP(hipMemcpyAsync(static_cast<char *>(dst_dev) + o, ring + o, n, hipMemcpyHostToDevice, stream));
+        const int c = ctx->h2d_chunk_next[slot];
+        ctx->h2d_chunk_next[slot] = (c + 1) % NC;
+        if (!ctx->h2d_chunk_ev[slot][c]) MD_HIP(hipEventCreateWithFlags(&ctx->h2d_chunk_ev[slot][c], hipEventDisableTiming));
+        if (ctx->h2d_chunk_used[slot][c]) MD_HIP(hipEventSynchronize(ctx->h2d_chunk_ev[slot][c]));  // (NC - 1 chunks ago)
+        ctx->copy_pool->copy(ring + (size_t)c * chunk, static_cast<const char *>(src) + o, n);
+        MD_HIP(hipMemcpyAsync(static_cast<char *>(dst_dev) + o, ring + (size_t)c * chunk, n, hipMemcpyHostToDevice, stream));
+        MD_HIP(hipEventRecord(ctx->h2d_chunk_ev[slot][c], stream));
+        ctx->h2d_chunk_used[slot][c] = true;
     }
-    MD_HIP(hipEventRecord(ctx->h2d_ring_ev[slot], stream));
-    ctx->h2d_ring_used[slot] = true;
     return MDHIP_OK;
 }
 

@@ -439,9 +439,17 @@ __device__ __forceinline__ RelQ load_relq(const float *__restrict__ p)
 // f32 distance reaches the cutoff's own error band (sqrt(rsq32) >= cut_lo) are ambiguous too: one more v_cmpx (t < cl).
 // RET: also hand back the LDS address every lane computed and the mask of the lanes that added there (the CN check of
 // the groups near the wave looks those words up in the flag bits: +1 SALU per slot).
+// (-DPK_NO_EXECZ, an A/B build only, round 6: the slot without its skip — a slot none of whose lanes is inside the
+// cutoff then issues its six bin-guess instructions with an empty exec mask instead of one taken branch. Measured
+// against the shipped form in one process: profiles/r06_ab_execz.txt.)
+#ifdef PK_NO_EXECZ
+#define BP_SKIP(L) ""
+#else
+#define BP_SKIP(L) "s_cbranch_execz " L "f\n\t"
+#endif
 #define BP_SLOT(K, L)                                                \
     "v_cmpx_gt_f32_e64 %[c" K "], %[rc2], %[rsq" K "]\n\t"            \
-    "s_cbranch_execz " L "f\n\t"                                     \
+    BP_SKIP(L)                                                       \
     "v_sqrt_f32 %[t" K "], %[rsq" K "]\n\t"                           \
     "s_nop 0\n\t"
 #define BP_SLOT_CUT(K) "v_cmpx_lt_f32_e64 %[d" K "], %[t" K "], %[cl]\n\t"

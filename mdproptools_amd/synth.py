@@ -84,3 +84,17 @@ def ar1_series(n, n_series=3, phi=0.99, scale=100.0, seed_offset=5):
     rng = np.random.default_rng(BASE_SEED + seed_offset)
     e = rng.standard_normal((n_series, n))
     return lfilter([1.0], [1.0, -phi], e, axis=1) * scale
+
+
+def residence_walk(n_frames=1000, n_central=315, n_shell=11_280, box_len=104.0, sigma=0.1, seed_offset=7):
+    """The residence leg's trajectory (bench.py, tools/run_secondary.py): the example's shares of central (Mg) and shell
+    (ether O) atoms of 100 000 atoms at C3's density, unwrapped random walks; -> (central [F,3,n_c], shell [F,3,n_s])."""
+    rng = np.random.default_rng(BASE_SEED + seed_offset)
+    n = n_central + n_shell
+    r = np.empty((n_frames, 3, n))
+    r[0] = rng.random((3, n)) * box_len
+    for f0 in range(1, n_frames, 100):
+        steps = rng.normal(0.0, sigma, (min(n_frames, f0 + 100) - f0, 3, n))
+        np.cumsum(steps, axis=0, out=steps)
+        r[f0:f0 + len(steps)] = r[f0 - 1] + steps
+    return np.ascontiguousarray(r[:, :, :n_central]), np.ascontiguousarray(r[:, :, n_central:])

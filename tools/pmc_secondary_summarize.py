@@ -22,11 +22,12 @@ import sys
 
 KEEP = ("msd_", "segment_", "type_sum", "mol_flux", "fft_", "xcorr_", "lag_msd", "transpose", "cumtrapz", "scan",
         "r2c_", "c2r_", "conj_copy", "spectrum", "col_sum", "col_mean", "frame_sq", "power_", "fold_items",
-        "real_to_complex", "trapz")
+        "real_to_complex", "trapz", "shell_pairs", "run_starts", "residence_lag", "DeviceRadixSort", "rocprim")
 
 
 HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SECONDARY_SOURCES = ["msd.hip", "msd_fft.hip", "msd_fft_w12.h", "segment_com.hip", "xcorr.hip", "fft_pow2.hip", "scan.hip"]
+SECONDARY_SOURCES = ["msd.hip", "msd_fft.hip", "msd_fft_w12.h", "segment_com.hip", "xcorr.hip", "fft_pow2.hip", "scan.hip",
+                     "residence.hip"]
 
 
 def source_hash():
@@ -43,6 +44,7 @@ def source_hash():
 
 def ours(raw):
     """libmdhip kernels only: torch's generators, copies and scans (at::native::...) are dropped."""
+    # (the residence call's sort is the one vendor-library kernel family in the product: kept, so that its share shows)
     return "at::" not in raw and "tensor_kernel" not in raw and "rocclr" not in raw and any(s in raw for s in KEEP)
 
 

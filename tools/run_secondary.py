@@ -13,6 +13,7 @@ call (tools/pmc_secondary.sh). Prints one line per repetition: dominant kernel, 
   acf_fft      3 x 1e6-sample autocorrelation by FFT                         (fft_pass_kernel<...>, xcorr_spectrum)
   acf_direct   the same by direct lag sums                                   (xcorr_direct_kernel)
   cumtrapz     running integral of 3 x 1e6 samples                           (scan kernels)
+  residence    shell residence counts, 315 x 11 280 atoms x 1000 frames      (shell_pairs_kernel, sort, residence_lag_kernel)
 """
 import os
 import sys
@@ -69,6 +70,11 @@ def main():
     elif what == "lag_diff":
         ctx.set_option("lag_variant", 1)
         call = lambda: B.lag_msd(r, F - 1, [0, E], scale=1.0, ctx=ctx)
+    elif what == "residence":
+        ri, rj = synth.residence_walk()
+        xi, xj = torch.from_numpy(ri).to(dev), torch.from_numpy(rj).to(dev)
+        bx = np.full((len(ri), 3), 104.0)
+        call = lambda: B.shell_residence(xi, xj, bx, 0.0, 2.325 ** 2, ctx=ctx)
     elif what in ("acf_fft", "acf_direct", "cumtrapz"):
         p = torch.from_numpy(synth.ar1_series(1_000_000)).to(dev)
         if what == "acf_fft":
