@@ -202,6 +202,8 @@ struct mdhip_ctx {
     int opt_seg_frame = 1;    // mdhip_segment_com: one (run, frame) per block, nothing carried between frames (A/B: 0 =
                               // the software-pipelined staged kernel)
     int opt_xcorr_tile = 0;
+    int opt_lag_w12_min_f = 1536;  // full-lag MSD with 2048 < F + max_lag <= 8192: from this many frames on the 12288-point
+                                   // kernel (msd_fft_w12.h) instead of the 8192-point one; 0 = never, >= 1536
     int opt_lag_variant = 3;  // full-lag MSD: 3 (default) = autocorrelation theorem (msd_fft.hip) when its error bound
                               // stays below 1e-10, else the exact-difference kernel; 1 = series-resident LDS
                               // difference kernel when it fits, 0 = staged difference kernel, 2 = always the

@@ -2076,22 +2076,23 @@ int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r
     if (w12) {
         const int qe = std::max(4, (int)(((F + 1) / 2 + W12_SUB - 1) / W12_SUB));  // first-pass inputs that hold data: 4 .. 6
         const size_t ldsw = w12_lds_bytes(qe);
-#define MD_W12_GO(QE, SRC, X, SC)                                                                              \
+#define MD_W12_GO(QE, SRC, SH, X, SC)                                                                          \
     {                                                                                                          \
-        MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msd_power_w12_kernel<QE, SRC>),              \
+        MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msd_power_w12_kernel<QE, SRC, SH>),          \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw));                    \
-        hipLaunchKernelGGL((msd_power_w12_kernel<QE, SRC>), dim3((unsigned)n_items), dim3(W12_THREADS), ldsw,  \
+        hipLaunchKernelGGL((msd_power_w12_kernel<QE, SRC, SH>), dim3((unsigned)n_items), dim3(W12_THREADS), ldsw, \
                            ctx->stream, X, (int)F, d_items, d_tab, d_Qpart, d_Ppart, cols, SC, d_stages, d_ring, \
                            d_ready, src_opt == 3 ? -Fc : Fc);                                                  \
     }
-#define MD_W12_LAUNCH(QE)                                                                                      \
+#define MD_W12_LAUNCH(QE, SH)                                                                                  \
     {                                                                                                          \
-        if (staged) MD_W12_GO(QE, 2, d_r, scale)                                                               \
-        else MD_W12_GO(QE, 0, d_x, 1.0)                                                                        \
+        if (staged) MD_W12_GO(QE, 2, SH, d_r, scale)                                                           \
+        else MD_W12_GO(QE, 0, SH, d_x, 1.0)                                                                    \
     }
-        if (qe <= 4) MD_W12_LAUNCH(4)
-        else if (qe == 5) MD_W12_LAUNCH(5)
-        else MD_W12_LAUNCH(6)
+        if (F < 6 * W12_SUB) MD_W12_LAUNCH(4, true)  // (1536 <= F < 3072: the host's condition, mdhip_lag_msd_fft)
+        else if (qe <= 4) MD_W12_LAUNCH(4, false)
+        else if (qe == 5) MD_W12_LAUNCH(5, false)
+        else MD_W12_LAUNCH(6, false)
 #undef MD_W12_LAUNCH
 #undef MD_W12_GO
     } else if (v3) {
@@ -2270,7 +2271,14 @@ int mdhip_lag_msd_fft(CallScope &cs, int64_t n_frames, int64_t n_ent, const doub
         int m = 3;
         while ((2LL << m) < F + max_lag) ++m;
         // round 5: padded length 12288 = 3 * 2^12 where 16384 would be the next power of two (msd_fft_w12.h)
-        if (ctx->opt_lag_fft_kernel >= 3 && m == 13 && F + max_lag <= 2 * W12_N && (F + 1) / 2 <= 6 * W12_SUB && F >= 6 * W12_SUB &&
+        // round 6: the same kernel for 2048 < F + max_lag <= 8192 (m == 11, 12) from `lag_w12_min_f` frames on (default 1536,
+        // the SHORT instance's lower limit): its twelve register-resident 512-point sub-transforms cost less per series than
+        // the power-of-two kernels' 2048- and 4096-point transforms through LDS although it transforms 1.5-3 x the points
+        // (tools/lag_sizes.py, profiles/r06_lag_sizes_ab.txt: E = 50 000, full lag, F = 1536 3.77 vs 3.78 ms, 2048 3.62 vs
+        // 4.06, 3000 3.79 vs 5.43, 4096 4.02 vs 7.01)
+        const bool w12_long = m == 13 && F >= 6 * W12_SUB;
+        const bool w12_short = (m == 12 || m == 11) && F >= std::max(3 * W12_SUB, ctx->opt_lag_w12_min_f) && ctx->opt_lag_w12_min_f > 0;
+        if (ctx->opt_lag_fft_kernel >= 3 && (w12_long || w12_short) && F + max_lag <= 2 * W12_N && (F + 1) / 2 <= 6 * W12_SUB &&
             w12_lds_bytes(6) <= ctx->lds_max) {
             res->delivered = true;
             return lag_msd_fft_fused(cs, F, E, d_r, scale, max_lag, G, group_off, m, res, out, out_on_device, -1, true);

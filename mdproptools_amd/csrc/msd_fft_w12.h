@@ -96,13 +96,16 @@ __device__ __forceinline__ void w12_st(double2 *p, Cx v) { *p = make_double2(v.x
 
 // x: SRC == 0 the time-major copy [cols][F] (scaled), SRC == 2 the trajectory [F][cols] (see msd_power_lds3_kernel).
 // Qpart [rows][F], Ppart [rows][N + 1] as the other fused kernels (N = 6144).
-template <int QE, int SRC>
+// SHORT (round 6): trajectories of 1536 <= F < 3072 frames (QE = 4): only the first of a lane's four sample units is
+// known to hold data in every lane (the instances for F >= 3072 skip the test for the first two).
+template <int QE, int SRC, bool SHORT = false>
 __global__ __launch_bounds__(W12_THREADS) void msd_power_w12_kernel(
     const double *__restrict__ x, int F, const FftItem *__restrict__ items, const double2 *__restrict__ tab,
     double *__restrict__ Qpart, double *__restrict__ Ppart, long long cols, double scale, const FftStage *__restrict__ stg,
     double *__restrict__ scratch, unsigned *__restrict__ ready, int Fc_arg)
 {
     constexpr int N = W12_N, RS = W12_RS;
+    constexpr int RFULL = SHORT ? 1 : 2;  // units r < RFULL hold data in every lane
     const int Fc = Fc_arg < 0 ? -Fc_arg : Fc_arg;
     const bool withhold = Fc_arg < 0 && blockIdx.x == 0;
     extern __shared__ double ft_lds[];
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(W12_THREADS) void msd_power_w12_kernel(
                 const int n = tid + W12_THREADS * r;
                 // (beyond the series, or a column outside the segment: zeros from beyond the buffer's end; row F of the
                 // ring holds a zero where F is odd: the pair store wrote it)
-                const bool in = valid && (r < 2 || 2 * n < F);  // (F >= 3072: the host's condition for this kernel)
+                const bool in = valid && (r < RFULL || 2 * n < F);  // (F >= 1536 RFULL: the host's condition for this kernel)
                 v[r] = __builtin_bit_cast(
                     st2_t, __builtin_amdgcn_raw_buffer_load_b128(ring, in ? (unsigned)n * 16u : ST_OOB, row, SC1));
             }
@@ -290,10 +293,13 @@ __global__ __launch_bounds__(W12_THREADS) void msd_power_w12_kernel(
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int n = tid + W12_THREADS * r;
-            if (r < 3 || n < QE * W12_SUB) {  // (QE >= 4: the first three units always lie inside the raw plane)
+            // (QE >= 5: the first three units always lie inside the raw plane; QE = 4 — never instantiated before round 6,
+            // whose shorter trajectories found it — holds 2048 points: the third unit reaches 2303 and would run over the
+            // twiddle table behind the plane)
+            if (r < (QE >= 5 ? 3 : 2) || n < QE * W12_SUB) {
                 // (F >= 3072, the host's condition for this kernel: the first two units hold data in every lane)
-                const double da = (r < 2 || 2 * n < F) ? v[r][0] - mean : 0.0;
-                const double db = (r < 2 || 2 * n + 1 < F) ? v[r][1] - mean : 0.0;
+                const double da = (r < RFULL || 2 * n < F) ? v[r][0] - mean : 0.0;
+                const double db = (r < RFULL || 2 * n + 1 < F) ? v[r][1] - mean : 0.0;
                 qa[r] = __builtin_fma(da, da, qa[r]);
                 qb[r] = __builtin_fma(db, db, qb[r]);
                 raw[n] = make_double2(da, db);

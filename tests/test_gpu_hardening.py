@@ -370,7 +370,8 @@ def test_lag_msd_staged_integer_ramp_exact_and_reproducible():
 
     ctx = Context(0)
     try:
-        for F, E in ((5000, 4096), (6144, 1024), (4097, 2048)):
+        # (2500, 3071: the SHORT instance of round 6, 1536 <= F < 3072 with F + max_lag in (4096, 8192])
+        for F, E in ((5000, 4096), (6144, 1024), (4097, 2048), (2500, 2048), (3071, 1024)):
             t = torch.arange(F, dtype=torch.float64, device="cuda")[:, None, None]
             c = torch.arange(3 * E, dtype=torch.float64, device="cuda").reshape(1, 3, E)
             r = (16384.0 * c + t).contiguous()

@@ -49,6 +49,9 @@ def test_rdf_cn_golden_c1(B, g_c1):
     ty = frames[0][:, 1].astype(np.int32)
     full, part, ov = B.rdf_loop(xyz, ty, box, g["rdf_def_rel"].T, 20, 0.05, 400)
     assert ov == 0
+    # (round 6: the example's nine types / five relations run on the table-free packed sweep through displaced rows —
+    # 15 rows instead of 36 — not on the class-row kernel `<5, .>`)
+    assert "<3," in B.default_context().last_kernel_name(), B.default_context().last_kernel_name()
     np.testing.assert_array_equal(full.astype(np.int64), g["rdf_def_full"])
     np.testing.assert_array_equal(part.astype(np.int64), g["rdf_def_part"])
     assert int(full[0].sum()) == 30926986  # SURVEY.md known answer
@@ -475,6 +478,8 @@ def test_lag_msd_fft_every_transform_size(B):
     cases = [(F, F - 1) for F in (257, 511, 513, 1024, 1025, 2047, 2049, 3000, 4096, 4097, 5000, 5121, 6143, 6144, 6145,
                                   8191, 8192)]
     cases += [(9000, 7000), (12000, 4000), (16000, 300), (6000, 2100), (1000, 20), (6200, 6000), (8000, 4288), (4200, 4100)]
+    cases += [(2050, 2049), (2500, 2499), (3071, 3070), (3072, 3071), (3073, 3072), (2600, 1800), (1536, 1535), (1537, 600),
+              (1535, 1534), (1800, 400)]  # the 12288-point kernel's short range and its lower edge
     try:
         for F, max_lag in cases:
             E = int(rng.integers(3, 24))
@@ -490,7 +495,9 @@ def test_lag_msd_fft_every_transform_size(B):
                 ctx.set_option("lag_fft_kernel", kern)
                 fft = B.lag_msd(r, max_lag, goff, scale=0.5)
                 bound = ctx.last_rel_bound()
-                w12 = kern == 3 and 8192 < F + max_lag <= 12288 and (F + 1) // 2 <= 3072
+                # (round 6: also from 1536 frames on where F + max_lag lies in (2048, 8192] — the SHORT instance below 3072)
+                w12 = kern == 3 and (F + 1) // 2 <= 3072 and ((8192 < F + max_lag <= 12288 and F >= 3072) or
+                                                              (2048 < F + max_lag <= 8192 and F >= 1536))
                 assert ctx.last_kernel_name() == ("msd_power_w12_kernel" if w12 else "msd_power_lds_kernel") and bound > 0.0
                 assert (fft[0] == 0.0).all()
                 rel = np.abs(fft[nz] - exact[nz]) / exact[nz]

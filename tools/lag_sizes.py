@@ -16,8 +16,11 @@ from mdproptools_amd import backend as B  # noqa: E402
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 50_000
 ctx = B.default_context()
 ctx.set_option("lag_variant", 2)
+if len(sys.argv) > 2:  # A/B: from how many frames on the 12288-point kernel takes series of F + max_lag <= 8192 (0: never)
+    ctx.set_option("lag_w12_min_f", int(sys.argv[2]))
+    print("lag_w12_min_f =", sys.argv[2])
 rows = []
-for F in (1000, 3000, 5000, 6144, 8192, 10_000, 20_000):
+for F in (1000, 1536, 1800, 2048, 2500, 3000, 4096, 5000, 6144, 8192, 10_000, 20_000):
     g = torch.Generator(device="cuda").manual_seed(100 + F)
     r = torch.empty((F, 3, E), dtype=torch.float64, device="cuda")
     for f0 in range(0, F, 500):
