@@ -13,6 +13,7 @@ call (tools/pmc_secondary.sh). Prints one line per repetition: dominant kernel, 
   acf_fft      3 x 1e6-sample autocorrelation by FFT                         (fft_pass_kernel<...>, xcorr_spectrum)
   acf_direct   the same by direct lag sums                                   (xcorr_direct_kernel)
   cumtrapz     running integral of 3 x 1e6 samples                           (scan kernels)
+  lag_long     full lag x origin MSD of 10 000 frames x 50k entities         (the batched path: transforms in HBM, fft_pow2.hip)
   residence    shell residence counts, 315 x 11 280 atoms x 1000 frames      (shell_pairs_kernel, sort, residence_lag_kernel)
 """
 import os
@@ -51,7 +52,9 @@ def main():
     off = np.concatenate([np.arange(0, 40_000, 16), np.arange(40_000, 50_001, 4)]).astype(np.int64)
     mass = np.where(np.arange(E) < 40_000, 2.0, 3.0)
     M = len(off) - 1
-    if what in ("msd_pairs", "msd_windows", "com", "flux", "lag_fft", "lag_diff"):
+    if what == "lag_long":
+        F = 10_000
+    if what in ("msd_pairs", "msd_windows", "com", "flux", "lag_fft", "lag_diff", "lag_long"):
         r = c4_walk(torch, dev, synth, E, F)
     if what == "msd_pairs":
         pairs = [(0, t) for t in range(F)]
@@ -65,7 +68,8 @@ def main():
         q = np.where(np.arange(E) < 40_000, 0.125, -0.25)
         st = np.concatenate([np.zeros(2500, np.int32), np.ones(2500, np.int32)])
         call = lambda: B.charge_flux(r, mass, q, off, st, 2, 1e5, 1.602e-19, ctx=ctx)
-    elif what == "lag_fft":
+    elif what in ("lag_fft", "lag_long"):
+        ctx.set_option("lag_variant", 2)
         call = lambda: B.lag_msd(r, F - 1, [0, E], scale=1.0, ctx=ctx)
     elif what == "lag_diff":
         ctx.set_option("lag_variant", 1)
