@@ -294,6 +294,26 @@ def shares_rate(e):
                                    "weighted by the counters' shares (f64 %.2f)" % (waves, sum(n.values()) / insts))
 
 
+def lag_diff_roofline(E, frame_pairs, kernel_s):
+    """The exact-difference full-lag kernel (lag_msd_lds_kernel): 12 flop per entity and frame pair against the
+    FP64-FMA peak — and beside that fraction the ceiling its arithmetic allows: a pair is ONE subtraction and ONE fma per
+    axis, 3 flops in 2 issue slots (all-fma peak x 0.75), issued at the f64 rate of its occupancy (the counters' SQ_WAVES;
+    the 50 KB series per 5-wave block caps it at 3.75 waves per SIMD -> the measured rate at 4)."""
+    flops = 12.0 * E * frame_pairs
+    out = {"bound": "fp64-fma", "achieved": flops / kernel_s / 1e12, "peak": FP64_FMA_PEAK / 1e12, "unit": "TFLOP/s",
+           "frac": flops / kernel_s / FP64_FMA_PEAK, "traffic": pmc_traffic("lag_diff")}
+    r_add, r_fma = ubench_rate("v_add_f64", 4), ubench_rate("v_fma_f64", 4)
+    if r_add and r_fma:
+        # one add + one fma per axis pair: seconds per SIMD for a pair of instructions, 1024 SIMDs, 64 lanes, 3 flops
+        t_pair = 1.0 / (r_add * 1e9) + 1.0 / (r_fma * 1e9)
+        ceiling = 3.0 * 64.0 * N_SIMD / t_pair
+        out["issue_ceiling_tflops"] = ceiling / 1e12
+        out["issue_ceiling_over_fma_peak"] = ceiling / FP64_FMA_PEAK
+        out["frac_of_issue_ceiling"] = flops / kernel_s / ceiling
+        out["ceiling_source"] = "sub + fma per axis pair at the measured v_add_f64 / v_fma_f64 rates, 4 waves/SIMD (r05_ubench_valu.json)"
+    return out
+
+
 def valu_roofline(kernel, workload, kdur, mix, waves, alg_pairs, alg_bytes, shares=False):
     """
     Roofline object of a pair kernel. The kernel is bound by VALU issue (neither HBM nor MFMA: 28 B and <= 18 vector
@@ -828,10 +848,7 @@ def leg_c4(B, ctx, torch, device, synth, sync):
            "lag_msd_difference_kernel": {
                "wall_s": t_lagd, "kernel_s": km["lagd"][0] * 1e-3, "kernel": km["lagd"][1],
                "value": fp_all / t_lagd, "unit": "frame-pairs/s",
-               "roofline": {"bound": "fp64-fma", "achieved": 12.0 * E * fp_all / (km["lagd"][0] * 1e-3) / 1e12,
-                            "peak": FP64_FMA_PEAK / 1e12, "unit": "TFLOP/s",
-                            "frac": 12.0 * E * fp_all / (km["lagd"][0] * 1e-3) / FP64_FMA_PEAK,
-                            "traffic": pmc_traffic("lag_diff")}},
+               "roofline": lag_diff_roofline(E, fp_all, km["lagd"][0] * 1e-3)},
            "parity_checked": "single origin: 201 frame pairs x 50k entities vs oracle (rtol 1e-10); full lag: 40 lags "
                              "x 64 entities x 5000 frames vs oracle (rtol 1e-10); FFT path vs difference kernel above",
            "cpu_baseline": {"value": 1.0 / cpu_pair, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
@@ -1004,6 +1021,10 @@ def flat_scalars(out):
         "c5_cumtrapz_kernel_s": _get(out, "c5", "cumtrapz", "kernel_s"),
         "c5_green_kubo_chain_wall_s": _get(out, "c5", "green_kubo_chain", "wall_s"),
         "c1_pairs_per_s": _get(out, "c1", "value"), "c1_alt_pairs_per_s": _get(out, "c1_alt", "value"),
+        "lag_diff_kernel_ms": None if _get(out, "c4", "lag_msd_difference_kernel", "kernel_s") is None
+        else _get(out, "c4", "lag_msd_difference_kernel", "kernel_s") * 1e3,
+        "lag_diff_fp64_fma_frac": _get(out, "c4", "lag_msd_difference_kernel", "roofline", "frac"),
+        "lag_diff_frac_of_issue_ceiling": _get(out, "c4", "lag_msd_difference_kernel", "roofline", "frac_of_issue_ceiling"),
         "residence_pairs_per_s": _get(out, "residence", "value"), "residence_kernel_s": _get(out, "residence", "kernel_s"),
         "residence_fp64_nonfused_frac": _get(out, "residence", "roofline", "frac"),
         "c1_ns_per_kpair_over_c2": _get(out, "c1", "cost_per_pair_over_c2"),
