@@ -723,6 +723,42 @@ __global__ void r2c_post_kernel(const double2 *__restrict__ Z, double2 *__restri
     spec[H - k] = make_double2(E.x - wo.x, -(E.y - wo.y));  // X(H-k) = conj(E - w O); k = 0 -> X(H)
 }
 
+// r2c_post_kernel and the column sums of |X_k|^2 in one pass over Z (round 6: the full-lag MSD of series too long for the
+// fused kernels wrote the half spectra only to read them once): partial[split][k], k = 0..H, = the sum over the split's
+// rows of |X_row(k)|^2, X from Z exactly as r2c_post_kernel makes it (the same operations in the same order, the rows
+// added alternately into two sums as power_rows_kernel of msd_fft.hip did: bit-identical results).
+// grid (ceil((H/2+1)/256), splits); rows [row0, row1) of Z [.][H].
+__global__ __launch_bounds__(256) void r2c_power_rows_kernel(const double2 *__restrict__ Z, long long H, long long row0,
+                                                             long long row1, double *__restrict__ partial, TwTab tt)
+{
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > H / 2) return;
+    const long long n = row1 - row0;
+    const long long ra = row0 + n * blockIdx.y / gridDim.y, rb = row0 + n * (blockIdx.y + 1) / gridDim.y;
+    const long long kk = (H - k) & (H - 1);
+    const double2 w = tw_lookup(tt, (unsigned long long)k, tt.logL);
+    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;  // |X_k|^2 and |X_(H-k)|^2, even / odd rows
+    for (long long q = ra; q < rb; ++q) {
+        const double2 zk = Z[(size_t)q * H + k], zh = Z[(size_t)q * H + kk];
+        const double2 E = make_double2(0.5 * (zk.x + zh.x), 0.5 * (zk.y - zh.y));
+        const double2 O = make_double2(0.5 * (zk.y + zh.y), -0.5 * (zk.x - zh.x));
+        const double2 wo = cmul(w, O);
+        const double2 xk = make_double2(E.x + wo.x, E.y + wo.y);
+        const double2 xh = make_double2(E.x - wo.x, -(E.y - wo.y));
+        const double pk = xk.x * xk.x + xk.y * xk.y, ph = xh.x * xh.x + xh.y * xh.y;
+        if ((q - ra) & 1) {
+            a1 += pk;
+            b1 += ph;
+        } else {
+            a0 += pk;
+            b0 += ph;
+        }
+    }
+    double *p = partial + (size_t)blockIdx.y * (H + 1);
+    p[k] = a0 + a1;
+    if (H - k != k) p[H - k] = b0 + b1;  // (k = 0 -> X(H))
+}
+
 // W = conj Y (the input of the forward transform that stands for the inverse one) from the Hermitian half spectrum
 // S[b][0..H]. grid (ceil((H/2+1)/256), batch)
 __global__ void c2r_pre_kernel(const double2 *__restrict__ S, double2 *__restrict__ W, long long H, TwTab tt)
@@ -966,6 +1002,45 @@ int mdhip_fft_r2c(mdhip_ctx *ctx, double *d_real, double2 *d_tmp, double2 *d_spe
     if (!Z) return MDHIP_EHIP;
     hipLaunchKernelGGL(r2c_post_kernel, dim3((unsigned)((H / 2 + 1 + 255) / 256), (unsigned)batch), dim3(256), 0,
                        ctx->stream, Z, d_spec, H, tt);
+    MD_HIP(hipGetLastError());
+    return MDHIP_OK;
+}
+
+// Z[b][0..L/2) = FFT_(L/2) of the zero-padded real series d_series[b][0..n) read as complex pairs — the transform WITHOUT
+// the half-spectrum post pass, for a caller that reduces |X_k|^2 over many series itself (mdhip_fft_power_rows): the first
+// pass reads the n samples where they are (no padded copy: the padding is implicit), *Z_out is whichever of the two
+// buffers (batch * L/2 complex points each) holds the result.
+int mdhip_fft_r2c_packed(mdhip_ctx *ctx, const double *d_series, long long n, double2 *d_buf0, double2 *d_buf1, long long L,
+                         int batch, const double2 **Z_out)
+{
+    MD_REQUIRE(L >= 4 && (L & (L - 1)) == 0 && n <= L, "transform length %lld is not a power of two >= the series", L);
+    const long long H = L / 2;
+    TwTab tt;
+    if (!fft_twiddle_table(ctx, H, tt)) return MDHIP_ENOMEM;
+    const double2 *Z = nullptr;
+    for (int b0 = 0; b0 < batch; b0 += FFT_MAX_BATCH) {  // (grid.y)
+        PassIo io{};
+        io.series = d_series + (size_t)b0 * n;
+        io.n = n;
+        double2 *z = fft_forward(ctx, d_buf0 + (size_t)b0 * H, d_buf1 + (size_t)b0 * H, H, std::min(FFT_MAX_BATCH, batch - b0),
+                                 IN_PAD, OUT_PLAIN, io, tt);
+        if (!z) return MDHIP_EHIP;
+        if (b0 == 0) Z = z - (size_t)b0 * H;  // (the same number of passes for every part: the same buffer)
+    }
+    *Z_out = Z;
+    MD_HIP(hipGetLastError());
+    return MDHIP_OK;
+}
+
+// partial[split][0..L/2] = sum over the rows [row0, row1) of Z (mdhip_fft_r2c_packed) of |X_row(k)|^2, in `splits` parts
+int mdhip_fft_power_rows(mdhip_ctx *ctx, const double2 *Z, long long L, long long row0, long long row1, int splits,
+                         double *d_partial)
+{
+    const long long H = L / 2;
+    TwTab tt;
+    if (!fft_twiddle_table(ctx, H, tt)) return MDHIP_ENOMEM;
+    hipLaunchKernelGGL(r2c_power_rows_kernel, dim3((unsigned)((H / 2 + 1 + 255) / 256), (unsigned)splits), dim3(256), 0,
+                       ctx->stream, Z, H, row0, row1, d_partial, tt);
     MD_HIP(hipGetLastError());
     return MDHIP_OK;
 }

@@ -116,6 +116,34 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const double *__rest
     }
 }
 
+// ser[c - c_first][t] = r[t][c] * scale - mean[c], t < F, for the nb series from c_first: the same values as
+// transpose_pad_kernel writes below F, through 64 x 64 tiles (runs of 64 doubles in both directions, every element
+// touched once: non-temporal) instead of 32 x 32 — round 6, for the batched full-lag path whose first transform pass
+// reads the series where this kernel leaves them (0.31 -> 0.17 ms per batch of 5357 series x 10 000 frames).
+__global__ __launch_bounds__(256) void transpose_centre64_kernel(const double *__restrict__ r,
+                                                                 const double *__restrict__ mean, long long F,
+                                                                 long long cols, long long c_first, long long nb,
+                                                                 double scale, double *__restrict__ ser)
+{
+    __shared__ double tile[64][65];
+    const long long c0 = c_first + (long long)blockIdx.x * 64, t0 = (long long)blockIdx.y * 64;
+    const long long c_end = c_first + nb;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+    const long long cc_in = c0 + tx;
+    const double m = cc_in < c_end ? mean[cc_in] : 0.0;
+#pragma unroll 4
+    for (int k = ty; k < 64; k += 4) {
+        const long long tt = t0 + k;
+        tile[k][tx] = (tt < F && cc_in < c_end) ? __builtin_nontemporal_load(r + tt * cols + cc_in) * scale - m : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int k = ty; k < 64; k += 4) {
+        const long long cc = c0 + k, tt = t0 + tx;
+        if (tt < F && cc < c_end) __builtin_nontemporal_store(tile[tx][k], ser + (size_t)(cc - c_first) * F + tt);
+    }
+}
+
 // partial[split][k] = sum over the split's rows of |spec[row][k]|^2
 __global__ __launch_bounds__(256) void power_rows_kernel(const double2 *__restrict__ spec, long long K,
                                                          long long row0, long long row1,
@@ -2297,16 +2325,21 @@ int mdhip_lag_msd_fft(CallScope &cs, int64_t n_frames, int64_t n_ent, const doub
     const long long K = L / 2 + 1;
     const long long S = 3 * G;  // (axis, group) segments
 
-    // batches of whole series: padded copy + second transform buffer + spectrum <= ~4 GiB
-    const long long per_series = 2 * L * 8 + K * 16;
+    // Round 6 (`lag_batched_fuse`, default): the first transform pass reads the centred series [nb][F] where the transposition
+    // left them (implicit zero padding: no padded copy is written or read) and the column sums of |X_k|^2 are taken straight
+    // from the packed transform (r2c_power_rows_kernel: the half spectra are never written) — 2.1 -> 1.3 MB of HBM traffic per
+    // series at F = 10 000 (profiles/r06_lag_long_kernel_stats.csv before, r06_lag_sizes.txt after). 0: the round-2 sequence.
+    const bool fuse = ctx->opt_lag_batched_fuse != 0;
+    // batches of whole series: (padded copy | centred series) + the transform buffers (+ spectrum) <= ~4 GiB
+    const long long per_series = fuse ? F * 8 + 2 * L * 8 : 2 * L * 8 + K * 16;
     const long long nb_max = std::max<long long>(1, std::min<long long>((4LL << 30) / per_series, (1LL << 31) / K));
     const long long n_batches = (cols + nb_max - 1) / nb_max;
     const long long nb0 = (cols + n_batches - 1) / n_batches;
 
     MD_WS(d_mean, double, WS_AUX0, (size_t)(MF_SLABS + 1) * cols * 8);
     double *d_msum = d_mean + cols;
-    MD_WS(d_pad, double, WS_AUX1, (size_t)nb0 * L * 8);
-    MD_WS(d_spec, double2, WS_AUX2, (size_t)nb0 * K * 16);
+    MD_WS(d_pad, double, WS_AUX1, (size_t)nb0 * (fuse ? F : L) * 8);                 // fuse: the centred series [nb][F]
+    MD_WS(d_spec, double2, WS_AUX2, fuse ? (size_t)nb0 * L * 8 : (size_t)nb0 * K * 16);  // fuse: the first transform buffer
     MD_WS(d_tmp, double2, WS_FFT_TMP, (size_t)std::max(nb0, S) * L * 8 + 64);
     // Q [S][F] | P [S][K] | complex P [S][K] | correlations [S][L] | group offsets
     const size_t q_b = (size_t)S * F * 8, p_b = (size_t)S * K * 8, z_b = (size_t)S * K * 16, c_b = (size_t)S * L * 8;
@@ -2341,10 +2374,16 @@ int mdhip_lag_msd_fft(CallScope &cs, int64_t n_frames, int64_t n_ent, const doub
 
     for (long long c_first = 0; c_first < cols; c_first += nb0) {
         const long long nb = std::min(nb0, cols - c_first);
-        hipLaunchKernelGGL(transpose_pad_kernel, dim3((unsigned)((nb + 31) / 32), (unsigned)((L + 31) / 32)),
-                           dim3(256), 0, ctx->stream, d_r, d_mean, F, cols, c_first, nb, L, scale, d_pad);
+        if (fuse)
+            hipLaunchKernelGGL(transpose_centre64_kernel, dim3((unsigned)((nb + 63) / 64), (unsigned)((F + 63) / 64)),
+                               dim3(256), 0, ctx->stream, d_r, d_mean, F, cols, c_first, nb, scale, d_pad);
+        else
+            hipLaunchKernelGGL(transpose_pad_kernel, dim3((unsigned)((nb + 31) / 32), (unsigned)((L + 31) / 32)),
+                               dim3(256), 0, ctx->stream, d_r, d_mean, F, cols, c_first, nb, L, scale, d_pad);
         MD_HIP(hipGetLastError());
-        int rc = mdhip_fft_r2c(ctx, d_pad, d_tmp, d_spec, L, (int)nb);
+        const double2 *d_Zp = nullptr;  // fuse: the packed transform of the batch
+        int rc = fuse ? mdhip_fft_r2c_packed(ctx, d_pad, F, d_spec, d_tmp, L, (int)nb, &d_Zp)
+                      : mdhip_fft_r2c(ctx, d_pad, d_tmp, d_spec, L, (int)nb);
         if (rc) return rc;
         // the (axis, group) segments this batch touches
         for (long long s = 0; s < S; ++s) {
@@ -2353,8 +2392,13 @@ int mdhip_lag_msd_fft(CallScope &cs, int64_t n_frames, int64_t n_ent, const doub
             const long long hi = std::min(c_first + nb, a * E + (long long)group_off[g + 1]);
             if (lo >= hi) continue;
             const int splits = (int)std::min<long long>(MF_SPLITS, hi - lo);
-            hipLaunchKernelGGL(power_rows_kernel, dim3((unsigned)((K + 255) / 256), (unsigned)splits), dim3(256), 0,
-                               ctx->stream, d_spec, K, lo - c_first, hi - c_first, d_part);
+            if (fuse) {
+                const int rcp = mdhip_fft_power_rows(ctx, d_Zp, L, lo - c_first, hi - c_first, splits, d_part);
+                if (rcp) return rcp;
+            } else {
+                hipLaunchKernelGGL(power_rows_kernel, dim3((unsigned)((K + 255) / 256), (unsigned)splits), dim3(256), 0,
+                                   ctx->stream, d_spec, K, lo - c_first, hi - c_first, d_part);
+            }
             hipLaunchKernelGGL(power_fold_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, ctx->stream,
                                d_part, splits, K, d_P + (size_t)s * K);
         }

@@ -550,6 +550,14 @@ def test_lag_msd_long_series_finish_on_the_device(B):
             assert float(st.item()) == bound
             again = B.lag_msd(r, max_lag, goff, scale=0.5, async_=True).wait()
             np.testing.assert_array_equal(again, fft)
+            # round 6: the first pass reads the series in place and |X|^2 is reduced from the packed transform — the same
+            # operations in the same order as the padded copy + half spectra of round 2 (`lag_batched_fuse` 0): identical bits
+            ctx.set_option("lag_batched_fuse", 0)
+            try:
+                old = B.lag_msd(r, max_lag, goff, scale=0.5)
+            finally:
+                ctx.set_option("lag_batched_fuse", 1)
+            np.testing.assert_array_equal(old, fft)
     finally:
         ctx.set_option("lag_variant", 1)
 
