@@ -1218,7 +1218,7 @@ def main():
     ap.add_argument("--option", action="append", default=[], help="library option key=value (A/B only)")
     ap.add_argument("--op", choices=["rdf", "cn", "rdf_cn"], default="rdf",
                     help="what the headline loop calls (profiling runs of the CN and the one-sweep kernels; N = 1)")
-    ap.add_argument("--shape", choices=("C1", "C1alt"), default=None,
+    ap.add_argument("--shape", choices=("C1", "C1alt", "C1full"), default=None,
                     help="profiling runs only (implies --no-legs): the headline loop on the reference's own workload shape "
                          "(leg_c1's inputs) instead of C2")
     args = ap.parse_args()
@@ -1302,6 +1302,8 @@ def main():
         n, L = cfg["n_atoms"], cfg["box_len"]
         types = synth.c1_types(args.shape == "C1alt")
         rel = np.array(synth.C1_ALT_RELATIONS if args.shape == "C1alt" else synth.C1_RELATIONS, dtype=np.int32)
+        if args.shape == "C1full":  # every unordered pair of the nine types: 45 relations, nothing for displaced rows to merge
+            rel = np.array([(a, b) for a in range(1, 10) for b in range(a, 10)], dtype=np.int32)
         args.no_legs = True
     if strong:  # C3's frames split contiguously over the ranks
         lo, hi = D.frame_shard(cfg["n_frames"], rank, world)
