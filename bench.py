@@ -552,8 +552,12 @@ def leg_c1(B, ctx, torch, device, synth, sync, steps, c2_kernel_ns_per_kpair, al
     xyz = torch.empty((F, 3, n), dtype=torch.float64, device=device)
     for f0 in range(0, F, 50):
         xyz[f0:f0 + 50] = torch.from_numpy(synth.rdf_frames(n, range(f0, min(F, f0 + 50)), L, cfg["seed_offset"])).to(device)
+    full_rel = alt == "full"  # every unordered pair of the nine types: 45 classes, the packed class rows in two passes
+    alt = alt is True
     ty = synth.c1_types(alt)
     rel = np.array(synth.C1_ALT_RELATIONS if alt else synth.C1_RELATIONS, dtype=np.int32)
+    if full_rel:
+        rel = np.array([(a, b) for a in range(1, 10) for b in range(a, 10)], dtype=np.int32)
     box = np.full((F, 3), L)
     pairs = F * n * (n - 1) // 2
     stats = []
@@ -566,7 +570,7 @@ def leg_c1(B, ctx, torch, device, synth, sync, steps, c2_kernel_ns_per_kpair, al
     dt, (full, part, _ov) = timed_pipelined(issue, sync, steps)
     kernel = ctx.last_kernel_name()
     ks = [h.stats() for h in stats[-steps:]]
-    kdur = float(np.mean([k[0] / max(k[2], 1) for k in ks])) * 1e-3
+    kdur = float(np.mean([k[0] for k in ks])) * 1e-3  # (all launches of a call: one, or the passes of the class-row sweep)
     aux = float(np.mean([k[1] for k in ks]))
     f0, p0, _ = B.rdf_loop(xyz[:1], ty, box[:1], rel, cfg["r_cut"], cfg["bin_size"], nb, ctx=ctx)
     cf, cp, _ = cpu_check_frame(xyz[0].cpu().numpy(), ty, rel, L, cfg, nb)
@@ -577,10 +581,12 @@ def leg_c1(B, ctx, torch, device, synth, sync, steps, c2_kernel_ns_per_kpair, al
     if not (np.array_equal(pf[0].sum(axis=0), s8[0]) and np.array_equal(pf[1].sum(axis=0), s8[1])):
         raise AssertionError("C1 shape: frame-summed histograms differ from the sum of the per-frame ones")
     ns_per_kpair = kdur * 1e9 / (pairs / 1e3)
-    tag = "C1alt" if alt else "C1"
+    tag = "C1alt" if alt else "C1full" if full_rel else "C1"
     return {"workload": "%s: 10 479 atoms x 200 frames, L=49.18 A, %s, r_cut 20 A, 400 bins, synthetic positions"
                         % (tag, "32 pseudo-types (altered ids), relations 32-17, 32-32" if alt
+                           else "9 types, all 45 unordered pairs as relations" if full_rel
                            else "9 types (example populations), relations 9-1, 9-4, 9-6, 9-9, 1-3"),
+            "launches_per_call": int(ks[-1][2]),
             "value": pairs / dt, "unit": "atom-pairs/s", "ms_per_step": dt * 1e3, "kernel": kernel,
             "kernel_ms": kdur * 1e3, "prepass_ms": aux, "pairs_per_step": pairs,
             "kernel_ns_per_kpair": ns_per_kpair,
@@ -1027,6 +1033,8 @@ def flat_scalars(out):
         "lag_diff_frac_of_issue_ceiling": _get(out, "c4", "lag_msd_difference_kernel", "roofline", "frac_of_issue_ceiling"),
         "residence_pairs_per_s": _get(out, "residence", "value"), "residence_kernel_s": _get(out, "residence", "kernel_s"),
         "residence_fp64_nonfused_frac": _get(out, "residence", "roofline", "frac"),
+        "c1_full_pairs_per_s": _get(out, "c1_full", "value"),
+        "c1_full_ns_per_kpair_over_c2": _get(out, "c1_full", "cost_per_pair_over_c2"),
         "c1_ns_per_kpair_over_c2": _get(out, "c1", "cost_per_pair_over_c2"),
         "c1_alt_ns_per_kpair_over_c2": _get(out, "c1_alt", "cost_per_pair_over_c2"),
     }
@@ -1494,6 +1502,7 @@ def main():
         if "c1" in legs:
             run_leg("c1", lambda: leg_c1(B, ctx, torch, device, synth, sync, max(5, args.steps // 2), c2_ns, False))
             run_leg("c1_alt", lambda: leg_c1(B, ctx, torch, device, synth, sync, max(5, args.steps // 2), c2_ns, True))
+            run_leg("c1_full", lambda: leg_c1(B, ctx, torch, device, synth, sync, max(5, args.steps // 2), c2_ns, "full"))
         if "residence" in legs:
             run_leg("residence", lambda: leg_residence(B, ctx, torch, device, synth, sync))
         if "c3" in legs:

@@ -313,7 +313,18 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
     int rel_block = 0;  // != 0: the packed sweep's f32 records are wanted (relative to their tile's centre)
     if (cull && ctx->opt_rdf_sj != 0 && !mode_cn && p.n_cls <= 250 && ctx->opt_rdf_pk != 0 && p.bin_size > 0.0) {
         const bool fits_ordered = ord_base && lds_bytes_sj_pk(p.nbins, ord_rows, p.n_cn) <= lds_cap / 3 - 512;
-        const bool fits_rows = lds_bytes_sj_pk_rows(p.nbins, p.n_cls, p.n_ti, p.n_tj, p.n_cn) <= lds_cap / 3 - 512;
+        // class rows: as many classes per pass as fit a third of LDS. Round 6: when they do not all fit (every pair of nine
+        // types named: 45 classes x 401 words = 72 KB) the packed sweep runs in SEVERAL passes over the pairs instead of
+        // leaving the call to the all-f64 class-row kernel — C1's atoms with all 45 relations: 14.5 -> 6.3 ms per 200 frames
+        // (`bench.py --shape C1full`); coordination numbers from the same sweep need one pass (else: two sweeps, as before)
+        int pk_cls_fit = 0;
+        for (int nc = std::min(p.n_cls, 250); nc >= 1; --nc)
+            if (lds_bytes_sj_pk_rows(p.nbins, nc, p.n_ti, p.n_tj, p.n_cn) <= lds_cap / 3 - 512) {
+                pk_cls_fit = nc;
+                break;
+            }
+        // (at least 8 classes per pass: with rows so long that fewer fit, the f64 kernel's half-of-LDS passes are as few)
+        const bool fits_rows = pk_cls_fit >= p.n_cls || (pk_cls_fit >= 8 && p.n_cn == 0 && ctx->opt_rdf_pk_passes != 0);
         const double r_cut = std::sqrt(p.rc2);
         const double cpos = r_cut / p.bin_size, K = std::floor(cpos + 0.5);
         double l_max = 0.0, v_max = 0.0;
@@ -347,7 +358,10 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
             // every pair with rsq < r_cut^2 has sqrt(rsq32) <= r_cut + err * bin_size
             const double r_hi = r_cut + err * p.bin_size;
             rc2hi = std::nextafterf((float)(r_hi * r_hi * (1.0 + 2.0 * u)), std::numeric_limits<float>::infinity());
-            if (pk_rows) cls_per_pass = p.n_cls;  // all classes in one pass (they fit: fits_rows)
+            if (pk_rows) {  // all classes in one pass when they fit, else balanced passes of at most pk_cls_fit classes
+                const int np = (p.n_cls + pk_cls_fit - 1) / pk_cls_fit;
+                cls_per_pass = (p.n_cls + np - 1) / np;
+            }
         }
     }
     if (p.n_cn > 0 && (!pk || ctx->opt_rdf_pk == 2)) return CN_UNFUSED;

@@ -1371,6 +1371,45 @@ def test_packed_f32_sweep_class_rows(B):
     pk.close()
 
 
+def test_packed_class_rows_in_several_passes(B):
+    """Every unordered pair of nine types named (45 relations, the "all partial RDFs" call on the reference's example):
+    the class rows do not fit LDS at once — 45 x 401 words — and there is nothing for displaced rows to merge. Round 6
+    runs the packed class-row sweep in several passes (two here) instead of handing the call to the all-f64 kernel;
+    12 types / 78 relations take four. Against the all-f64 sweep, the single-pass-only setting and the C oracle,
+    per-frame and frame-summed; the overflow count (pairs beyond the last bin edge) is not multiplied by the passes."""
+    from mdproptools_amd._lib import Context
+
+    rng = np.random.default_rng(909)
+    n, L, F = 4300, 37.5, 2
+    xyz = rng.uniform(0, L, (F, 3, n))
+    box = np.full((F, 3), L)
+    ctxs = {}
+    for tag, opts in (("pk", {}), ("one", {"rdf_pk_passes": 0}), ("f64", {"rdf_pk": 0})):
+        c = ctxs[tag] = Context(0)
+        c.set_option("rdf_cull", 1)
+        for k, v in opts.items():
+            c.set_option(k, v)
+    for T, r_cut, bin_size, nbins in ((9, 16.0, 0.04, 400), (12, 16.03, 0.04, 400), (9, 15.99, 0.04, 399)):
+        ty = rng.integers(1, T + 1, n).astype(np.int32)
+        rel = np.array([[a, b] for a in range(1, T + 1) for b in range(a, T + 1)])
+        for per_frame in (True, False):
+            res = {tag: B.rdf_loop(xyz, ty, box, rel, r_cut, bin_size, nbins, per_frame=per_frame, ctx=c)
+                   for tag, c in ctxs.items()}
+            names = {tag: c.last_kernel_name() for tag, c in ctxs.items()}
+            assert ("<5," in names["pk"] or "<6," in names["pk"]) and "<0," in names["one"] and "<0," in names["f64"], names
+            assert ctxs["pk"].last_kernel_ms()[1] >= 2, ctxs["pk"].last_kernel_ms()  # launches of the pair kernel
+            for tag in ("one", "f64"):
+                np.testing.assert_array_equal(res[tag][0], res["pk"][0], err_msg=tag)
+                np.testing.assert_array_equal(res[tag][1], res["pk"][1], err_msg=tag)
+                assert res[tag][2] == res["pk"][2], (tag, res[tag][2], res["pk"][2])
+            if per_frame:
+                cf, cp, cov = C.rdf_pairs(xyz[0], ty, rel, box[0], r_cut * r_cut, bin_size, nbins)
+                np.testing.assert_array_equal(res["pk"][0][0], cf)
+                np.testing.assert_array_equal(res["pk"][1][0], cp)
+    for c in ctxs.values():
+        c.close()
+
+
 def test_culled_path_large_box_auto(B):
     """BASELINE C3 geometry at reduced N (same density: L = 48.3 A for 10k atoms, r_cut 6.8): the
     automatic choice takes the culled path; result against the C oracle."""

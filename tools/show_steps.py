@@ -22,7 +22,7 @@ for path in sys.argv[1:]:
         print("  kernel", " ".join("%.2f" % v for v in st["kernel_plus_prepass_ms"]))
         print("  call  ", " ".join("%.2f" % v for v in st["call_ms"]))
     print("  kernel:", d.get("config", {}).get("kernel"), "| workload:", d.get("config", {}).get("workload"))
-    for leg in ("c1", "c1_alt", "residence"):
+    for leg in ("c1", "c1_alt", "c1_full", "residence"):
         v = d.get(leg)
         if isinstance(v, dict):
             print("  %s:" % leg, {k: v.get(k) for k in ("error", "value", "kernel", "kernel_ms", "prepass_ms", "ms_per_step",
