@@ -175,6 +175,8 @@ struct mdhip_ctx {
     int opt_rdf_disp = -1;    // ordered rows: -1/1 displaced rows (row = A[ti] + B[tj], pair_hist.hip) when the plain
                               // n_ti x n_tj layout does not fit LDS and the displaced one does, 0 never, 2 whenever
                               // it has fewer rows (A/B)
+    int opt_rdf_big = -1;      // ordered rows that fit neither a third of LDS nor a displaced layout: -1/1 ONE 16-wave block per
+                               // CU with the whole LDS (pair_hist_sj_kernel<., ., false, true>), 0 class rows in passes (A/B)
     int opt_rdf_pk_passes = 1; // packed class-row sweep in several passes when the classes do not fit LDS at once (round 6);
                                // 0: such calls take the all-f64 class-row kernel as before (A/B)
     int opt_residence_cap = 0; // mdhip_shell_residence: > 0 = capacity of the first sweep's record list (tests: forces the re-sweep)

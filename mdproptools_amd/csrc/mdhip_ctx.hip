@@ -747,6 +747,8 @@ int mdhip_set_option(mdhip_ctx *ctx, const char *key, int value)
         ctx->opt_rdf_inflight = value < 1 ? 1 : value;
     else if (!strcmp(key, "rdf_rows"))
         ctx->opt_rdf_rows = value;
+    else if (!strcmp(key, "rdf_big"))
+        ctx->opt_rdf_big = value;
     else if (!strcmp(key, "rdf_pk_passes"))
         ctx->opt_rdf_pk_passes = value < 0 ? 1 : value;
     else if (!strcmp(key, "residence_cap"))

@@ -166,12 +166,12 @@ void launch_reduce_slots(hipStream_t stream, const unsigned long long *in, unsig
 // pair_sj.hip
 size_t lds_bytes_sj(int nbins, int n_cls, int n_ti, int n_tj, bool mode_cn);
 size_t lds_bytes_sj_ordered(int nbins, int n_rows);
-size_t lds_bytes_sj_pk(int nbins, int n_rows, int n_cn = 0);
+size_t lds_bytes_sj_pk(int nbins, int n_rows, int n_cn = 0, bool big = false);  // big: 16 waves' queues
 size_t lds_bytes_sj_pk_rows(int nbins, int n_cls, int n_ti, int n_tj, int n_cn = 0);  // class rows + row table + queues
-int sj_block_threads(int mode);  // threads per block of the scalar-j kernels (mode as sj_kernel)
+int sj_block_threads(int mode, bool big = false);  // threads per block of the scalar-j kernels (mode as sj_kernel)
 PairKernel sj_kernel(int mode /* 0 RDF class rows, 1 CN, 2 RDF ordered-pair rows, 3 = 2 with the packed-f32 sweep,
                                  4 = 3 with the cutoff guard (cutoff inside a bin), 5 / 6 = 3 / 4 with class rows */,
-                     bool persist, bool cn, const char **name);
+                     bool persist, bool cn, bool big /* modes 3, 4 without cn: one 16-wave block per CU */, const char **name);
 // error bound (in bins) of the packed-f32 bin guess for |relative coordinates| <= s_cap per axis pair sum; 0 = not usable
 double pk_error_bound(double r_cut, double bin_size, int nbins, int n_tj, double s_cap, double l_max);
 void launch_derive_rdf(hipStream_t stream, const unsigned long long *rows, int n_rows, int nbins, const int *rowcls,

@@ -288,14 +288,38 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
     // packed-f32 sweep, whose blocks share one histogram among 8 waves.
     // Row layout of the ordered modes: plain (row = ti * n_tj + tj) unless that does not fit the packed sweep's third of
     // LDS and the displaced layout of displace_rows (row = A[ti] + B[tj], classes never mixed in a row) does.
+    // (class rows of the packed sweep: as many classes per pass as fit a third of LDS)
+    int pk_cls_fit = 0;
+    for (int nc = std::min(p.n_cls, 250); nc >= 1; --nc)
+        if (lds_bytes_sj_pk_rows(p.nbins, nc, p.n_ti, p.n_tj, p.n_cn) <= lds_cap / 3 - 512) {
+            pk_cls_fit = nc;
+            break;
+        }
     int ord_rows = p.n_ti * p.n_tj, ord_maxb = p.n_tj - 1;
-    bool displaced = false;
-    if (p.disp_rows > 0 && p.disp_rows < ord_rows && ctx->opt_rdf_disp != 0 &&
-        (ctx->opt_rdf_disp == 2 || (lds_bytes_sj_pk(p.nbins, ord_rows, p.n_cn) > lds_cap / 3 - 512 &&
-                                    lds_bytes_sj_pk(p.nbins, p.disp_rows, p.n_cn) <= lds_cap / 3 - 512))) {
-        displaced = true;
-        ord_rows = p.disp_rows;
-        ord_maxb = *std::max_element(p.disp_b.begin(), p.disp_b.end());
+    bool displaced = false, big = false;
+    {
+        const size_t third = lds_cap / 3 - 512, whole = lds_cap - 1024;
+        const bool have_disp = p.disp_rows > 0 && p.disp_rows < ord_rows && ctx->opt_rdf_disp != 0;
+        auto use_disp = [&]() {
+            displaced = true;
+            ord_rows = p.disp_rows;
+            ord_maxb = *std::max_element(p.disp_b.begin(), p.disp_b.end());
+        };
+        if (lds_bytes_sj_pk(p.nbins, ord_rows, p.n_cn) <= third) {
+            if (have_disp && ctx->opt_rdf_disp == 2) use_disp();  // (A/B: whenever it has fewer rows)
+        } else if (have_disp && lds_bytes_sj_pk(p.nbins, p.disp_rows, p.n_cn) <= third) {
+            use_disp();
+        } else if (p.n_cn == 0 && ctx->opt_rdf_big != 0 && lds_cap >= 160 * 1024 && pk_cls_fit < p.n_cls) {
+            // neither fits a third of LDS, and the class rows would need several passes (all classes in ONE pass of class rows
+            // measured faster than this: 3.12 against 3.37 ms at C1's shape): ONE 16-wave block per CU with the whole LDS for
+            // its histogram (BIG, pair_sj.hip) — every pair of nine types named is 81 rows, 130 KB — on whichever layout has
+            // fewer rows
+            const int rows_small = have_disp ? p.disp_rows : ord_rows;
+            if (lds_bytes_sj_pk(p.nbins, rows_small, 0, true) <= whole) {
+                big = true;
+                if (have_disp) use_disp();
+            }
+        }
     }
     const std::vector<int> &row_cls = displaced ? p.disp_cls : p.cls;  // ordered row -> class
     const size_t ord_b = lds_bytes_sj_ordered(p.nbins, ord_rows);
@@ -312,17 +336,11 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
     double pk_err = 0.0;  // error bound of the f32 distance, in bins
     int rel_block = 0;  // != 0: the packed sweep's f32 records are wanted (relative to their tile's centre)
     if (cull && ctx->opt_rdf_sj != 0 && !mode_cn && p.n_cls <= 250 && ctx->opt_rdf_pk != 0 && p.bin_size > 0.0) {
-        const bool fits_ordered = ord_base && lds_bytes_sj_pk(p.nbins, ord_rows, p.n_cn) <= lds_cap / 3 - 512;
+        const bool fits_ordered = ord_base && (big || lds_bytes_sj_pk(p.nbins, ord_rows, p.n_cn) <= lds_cap / 3 - 512);
         // class rows: as many classes per pass as fit a third of LDS. Round 6: when they do not all fit (every pair of nine
         // types named: 45 classes x 401 words = 72 KB) the packed sweep runs in SEVERAL passes over the pairs instead of
         // leaving the call to the all-f64 class-row kernel — C1's atoms with all 45 relations: 14.5 -> 6.3 ms per 200 frames
         // (`bench.py --shape C1full`); coordination numbers from the same sweep need one pass (else: two sweeps, as before)
-        int pk_cls_fit = 0;
-        for (int nc = std::min(p.n_cls, 250); nc >= 1; --nc)
-            if (lds_bytes_sj_pk_rows(p.nbins, nc, p.n_ti, p.n_tj, p.n_cn) <= lds_cap / 3 - 512) {
-                pk_cls_fit = nc;
-                break;
-            }
         // (at least 8 classes per pass: with rows so long that fewer fit, the f64 kernel's half-of-LDS passes are as few)
         const bool fits_rows = pk_cls_fit >= p.n_cls || (pk_cls_fit >= 8 && p.n_cn == 0 && ctx->opt_rdf_pk_passes != 0);
         const double r_cut = std::sqrt(p.rc2);
@@ -364,6 +382,7 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
             }
         }
     }
+    big = big && pk && ordered && ctx->opt_rdf_pk != 2;  // (only the packed ordered sweep has the 16-wave instance)
     if (p.n_cn > 0 && (!pk || ctx->opt_rdf_pk == 2)) return CN_UNFUSED;
     float near_ord = 0.f;
     if (ordered) {
@@ -649,7 +668,7 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         const bool persist = sj && !p.per_frame && ctx->opt_rdf_sj != 2;  // resident grid + per-XCD work counters
         a.work = reinterpret_cast<unsigned *>(d_misc + 4);
         const size_t lds = pk_rows ? lds_bytes_sj_pk_rows(p.nbins, nc, p.n_ti, p.n_tj, p.n_cn)
-                           : pk    ? lds_bytes_sj_pk(p.nbins, ord_rows, p.n_cn)
+                           : pk    ? lds_bytes_sj_pk(p.nbins, ord_rows, p.n_cn, big)
                            : ordered ? ord_b
                            : sj    ? lds_bytes_sj(p.nbins, nc, p.n_ti, p.n_tj, mode_cn)
                            : fast ? lds_bytes_fast(p.nbins, nc, p.n_ti, p.n_tj)
@@ -662,9 +681,10 @@ int pair_hist_run_batch(mdhip_ctx *ctx, const PairProblem &p, std::vector<uint64
         const size_t lds_launch = sj ? ((lds + 15) & ~size_t(15)) + 16 : lds;
         const char *kname = "";
         const int sj_mode = pk && ctx->opt_rdf_pk != 2 ? (pk_rows ? 5 : 3) + (cut_guard ? 1 : 0) : ordered ? 2 : mode_cn ? 1 : 0;
-        const int bs = sj ? sj_block_threads(sj_mode) : TILE;  // threads per block
+        const bool big_launch = big && sj_mode >= 3 && sj_mode <= 4;
+        const int bs = sj ? sj_block_threads(sj_mode, big_launch) : TILE;  // threads per block
         const int wpb = bs / 64;                                // independent waves per block (scalar-j kernels)
-        PairKernel kern = sj ? sj_kernel(sj_mode, persist, p.n_cn > 0, &kname)
+        PairKernel kern = sj ? sj_kernel(sj_mode, persist, p.n_cn > 0, big_launch, &kname)
                              : dense_kernel(fast, p.tri, mode_cn, fast && cull, &kname);
         ctx->last_kernel = kname;
         if (lds_launch > 65536)

@@ -278,6 +278,10 @@ constexpr int PK_QCAP = 320;     // queue entries per wave: drained above 64, on
 constexpr int PK_QSTRIDE = 320;  // words per wave
 constexpr int PK_THREADS = 512;  // threads per block of the MODE 3 kernel (8 independent waves, one LDS histogram)
 constexpr int PK_WAVES_PER_SIMD = 6;  // HIP's second launch bound: the register budget (<= 80 VGPRs) for 3 such blocks per CU
+// BIG (round 6): ONE block of 16 waves per CU sharing one histogram of up to ~140 KB — ordered rows that fit neither a third of
+// LDS nor a displaced layout (every pair of nine types named: 81 rows x 401 words = 130 KB) stay on the table-free sweep,
+// at 4 waves per SIMD (128 registers: no spills) instead of 6, rather than going through the class rows in two passes
+constexpr int PK_BIG_THREADS = 1024;
 
 #ifndef PK_INLINE_PUSH
 #define PK_INLINE_PUSH 0  // 1 = queue pushes inside the hand-written pair block (bin_pair2q, A/B builds). Measured build
@@ -1051,13 +1055,14 @@ __device__ __forceinline__ bool work_loop_sane(const PairArgs &a, long long iter
 // CNG (packed-f32 modes only): coordination numbers from the same sweep; one split counter per row sits right behind
 // the histogram rows in LDS and travels with them through the slices. (Register budget as the plain variant, 6 waves per
 // SIMD: the CNG variant then spills 18 dwords; a 5-wave budget without spills measured 1.40x RDF alone instead of 1.15x.)
-template <int MODE, bool PERSIST, bool CNG = false>
-__global__ __launch_bounds__(MODE >= 3 ? PK_THREADS : TILE, MODE >= 3 ? PK_WAVES_PER_SIMD : 1) void pair_hist_sj_kernel(const PairArgs a)
+template <int MODE, bool PERSIST, bool CNG = false, bool BIG = false>
+__global__ __launch_bounds__(BIG ? PK_BIG_THREADS : MODE >= 3 ? PK_THREADS : TILE, BIG ? 4 : MODE >= 3 ? PK_WAVES_PER_SIMD : 1) void
+pair_hist_sj_kernel(const PairArgs a)
 {
     // threads per block: the waves are independent (they share only the LDS histogram), so the block size is free.
     // MODE 3 runs 8 waves per block: LDS (one histogram per block) then allows 6 waves per SIMD instead of 5, which
     // this latency-bound sweep (scalar record loads from L2) converts into VALU utilisation.
-    constexpr int BS = MODE >= 3 ? PK_THREADS : TILE;
+    constexpr int BS = BIG ? PK_BIG_THREADS : MODE >= 3 ? PK_THREADS : TILE;
     // packed-f32 modes: 3 ordered rows, 4 = 3 with the cutoff guard (CUTG), 5 class rows + row table, 6 = 5 with CUTG
     constexpr bool ORDERED = MODE >= 2 && MODE <= 4;
     constexpr bool PK_ROWS = MODE >= 5;
@@ -1264,7 +1269,7 @@ size_t lds_bytes_sj_ordered(int nbins, int n_rows)
     return (((size_t)n_rows * (nbins + 1) * 4 + 15) & ~size_t(15)) + 16;
 }
 
-int sj_block_threads(int mode) { return mode >= 3 ? PK_THREADS : TILE; }
+int sj_block_threads(int mode, bool big) { return big ? PK_BIG_THREADS : mode >= 3 ? PK_THREADS : TILE; }
 
 // CN tables behind the queues: split-word address per row (padded to 8 bytes) + one double per row + (class rows)
 // the split-word addresses as a table [n_tj][n_ti]
@@ -1280,10 +1285,10 @@ size_t lds_bytes_sj_pk_rows(int nbins, int n_cls, int n_ti, int n_tj, int n_cn)
            (n_cn ? cn_table_bytes(n_cls + 1, n_ti * n_tj) : 0);
 }
 
-size_t lds_bytes_sj_pk(int nbins, int n_rows, int n_cn)
+size_t lds_bytes_sj_pk(int nbins, int n_rows, int n_cn, bool big)
 {
     return (((size_t)n_rows * (nbins + 1 + (n_cn ? 1 : 0)) * 4 + 15) & ~size_t(15)) +
-           (size_t)(PK_THREADS / 64) * PK_QSTRIDE * 4 + (n_cn ? cn_table_bytes(n_rows, 0) : 0);
+           (size_t)((big ? PK_BIG_THREADS : PK_THREADS) / 64) * PK_QSTRIDE * 4 + (n_cn ? cn_table_bytes(n_rows, 0) : 0);
 }
 
 // Error bound of the packed-f32 bin guess, in bins (see the MODE 3 header). u = 2^-24 (f32 round to nearest).
@@ -1316,9 +1321,11 @@ size_t lds_bytes_sj(int nbins, int n_cls, int n_ti, int n_tj, bool mode_cn)
     return (off + 15) & ~size_t(15);
 }
 
-PairKernel sj_kernel(int mode, bool persist, bool cn, const char **name)
+PairKernel sj_kernel(int mode, bool persist, bool cn, bool big, const char **name)
 {
 #define MD_PICK(...) (*name = #__VA_ARGS__, __VA_ARGS__)
+    if (big && !cn && mode == 4) return persist ? MD_PICK(pair_hist_sj_kernel<4, true, false, true>) : MD_PICK(pair_hist_sj_kernel<4, false, false, true>);
+    if (big && !cn && mode == 3) return persist ? MD_PICK(pair_hist_sj_kernel<3, true, false, true>) : MD_PICK(pair_hist_sj_kernel<3, false, false, true>);
     if (cn && mode == 6) return persist ? MD_PICK(pair_hist_sj_kernel<6, true, true>) : MD_PICK(pair_hist_sj_kernel<6, false, true>);
     if (cn && mode == 5) return persist ? MD_PICK(pair_hist_sj_kernel<5, true, true>) : MD_PICK(pair_hist_sj_kernel<5, false, true>);
     if (cn && mode == 4) return persist ? MD_PICK(pair_hist_sj_kernel<4, true, true>) : MD_PICK(pair_hist_sj_kernel<4, false, true>);

@@ -75,7 +75,7 @@ def test_reference_f64_chain_is_not_fused(pair_sj):
     """pair_hist_sj_kernel<2, ., false> is the all-f64 sweep: d = xi - xj, the single +-L wrap, (dx2 + dy2) + dz2, the
     edge-table compare — the reference's operations one by one. Not one fused multiply-add may appear in it."""
     for rows in ("Lb1", "Lb0"):
-        body, meta = _find(pair_sj, "pair_hist_sj_kernelILi2E%sELb0EE" % rows)
+        body, meta = _find(pair_sj, "pair_hist_sj_kernelILi2E%sELb0ELb0EE" % rows)
         fused = [s for op, s in _ops(body) if re.match(r"v_(fma|fmac|mad)_f64", op)]
         assert fused == [], fused[:3]
         assert any(op == "v_mul_f64" for op, _ in _ops(body)) and any(op == "v_add_f64" for op, _ in _ops(body))
@@ -89,7 +89,7 @@ def test_packed_kernels_f64_fma_count_is_the_sqrt_and_division_expansions(pair_s
     for mode in (3, 4, 5, 6):
         for rows in ("Lb1", "Lb0"):
             for cn in ("Lb0", "Lb1"):
-                body, _ = _find(pair_sj, "pair_hist_sj_kernelILi%dE%sE%sEE" % (mode, rows, cn))
+                body, _ = _find(pair_sj, "pair_hist_sj_kernelILi%dE%sE%sELb0EE" % (mode, rows, cn))
                 n = sum(1 for op, _ in _ops(body) if re.match(r"v_(fma|fmac|mad)_f64", op))
                 assert 0 < n <= 23, (mode, rows, cn, n)
 
@@ -141,15 +141,20 @@ def test_resource_budgets_of_the_headline_kernels(pair_sj):
     (6 waves per SIMD: profiles/r02_ubench_valu.json's roof is priced at 6) with at most a few spilled registers outside
     the sweep (ROCm 7.2: 2 registers, 12 bytes of scratch)."""
     for mode in (3, 4):
-        _, meta = _find(pair_sj, "pair_hist_sj_kernelILi%dELb1ELb0EE" % mode)
+        _, meta = _find(pair_sj, "pair_hist_sj_kernelILi%dELb1ELb0ELb0EE" % mode)
         assert int(meta["vgpr_count"]) <= 80, meta
         assert int(meta["vgpr_spill_count"]) <= 3, meta
         assert int(meta["private_segment_fixed_size"]) <= 16, meta
     # the one-sweep RDF + CN kernel keeps the same occupancy (a few spilled registers in its rare CN-check path)
-    _, meta = _find(pair_sj, "pair_hist_sj_kernelILi3ELb1ELb1EE")
+    _, meta = _find(pair_sj, "pair_hist_sj_kernelILi3ELb1ELb1ELb0EE")
     assert int(meta["vgpr_count"]) <= 80 and int(meta["private_segment_fixed_size"]) <= 32, meta
+    # round 6: the 16-wave instance (one block per CU, the whole LDS for one histogram) at <= 128 VGPRs — 4 waves per SIMD —
+    # and without a single spilled register
+    for mode in (3, 4):
+        _, meta = _find(pair_sj, "pair_hist_sj_kernelILi%dELb1ELb0ELb1EE" % mode)
+        assert int(meta["vgpr_count"]) <= 128 and int(meta["vgpr_spill_count"]) == 0, meta
     # the all-f64 sweep (f64_only leg)
-    _, meta = _find(pair_sj, "pair_hist_sj_kernelILi2ELb1ELb0EE")
+    _, meta = _find(pair_sj, "pair_hist_sj_kernelILi2ELb1ELb0ELb0EE")
     assert int(meta["vgpr_spill_count"]) == 0 and int(meta["private_segment_fixed_size"]) == 0, meta
 
 

@@ -1188,7 +1188,9 @@ def test_displaced_rows_reference_shape_and_random_relations(B):
     xyz = rng.uniform(0, L, (F, 3, n))
     box = np.full((F, 3), L)
     ctxs = {}
-    for tag, opts in (("auto", {}), ("off", {"rdf_disp": 0}), ("force", {"rdf_disp": 2}), ("f64", {"rdf_pk": 0})):
+    # ("big": no displacement, but the plain 36+ rows in one 16-wave block per CU — the second new layout of round 6)
+    for tag, opts in (("auto", {}), ("off", {"rdf_disp": 0, "rdf_big": 0}), ("force", {"rdf_disp": 2}), ("f64", {"rdf_pk": 0}),
+                      ("big", {"rdf_disp": 0})):
         c = ctxs[tag] = Context(0)
         c.set_option("rdf_cull", 1)
         for k, v in opts.items():
@@ -1213,7 +1215,7 @@ def test_displaced_rows_reference_shape_and_random_relations(B):
             assert "<3," in res["auto_kernel"], res["auto_kernel"]
             assert "<5," in res["off_kernel"], res["off_kernel"]
         took_disp += ("<3," in res["auto_kernel"]) and ("<5," in res["off_kernel"])
-        for tag in ("off", "force", "f64"):
+        for tag in ("off", "force", "f64", "big"):
             msg = "case %d T=%d rel=%s %s vs auto (%s / %s)" % (k, T, rel.tolist(), tag, res[tag + "_kernel"], res["auto_kernel"])
             np.testing.assert_array_equal(res[tag][0], res["auto"][0], err_msg=msg)
             np.testing.assert_array_equal(res[tag][1], res["auto"][1], err_msg=msg)
@@ -1240,7 +1242,7 @@ def test_displaced_rows_reference_shape_and_random_relations(B):
     st = rng.integers(1, 6, m).astype(np.int32)
     rel = np.array([[9, 1], [9, 4], [2, 4], [7, 5]])
     parts = {tag: B.rdf_mol_loop(xyz, ty, sites, st, box, rel, r_cut, bin_size, nbins, ctx=c) for tag, c in ctxs.items()}
-    for tag in ("off", "force", "f64"):
+    for tag in ("off", "force", "f64", "big"):
         np.testing.assert_array_equal(parts[tag][0], parts["auto"][0], err_msg=tag)
     cp, _ = C.rdf_rect(xyz[0], ty, sites[0], st, rel, box[0], r_cut * r_cut, bin_size, nbins)
     np.testing.assert_array_equal(parts["auto"][0][0], cp)
@@ -1384,7 +1386,9 @@ def test_packed_class_rows_in_several_passes(B):
     xyz = rng.uniform(0, L, (F, 3, n))
     box = np.full((F, 3), L)
     ctxs = {}
-    for tag, opts in (("pk", {}), ("one", {"rdf_pk_passes": 0}), ("f64", {"rdf_pk": 0})):
+    # "big": the default since the same round — the 81 ordered rows of nine types in ONE 16-wave block per CU (the whole LDS
+    # for one histogram, `pair_hist_sj_kernel<3, ., false, true>`); twelve types (144 rows) do not fit that either
+    for tag, opts in (("pk", {"rdf_big": 0}), ("big", {}), ("one", {"rdf_pk_passes": 0, "rdf_big": 0}), ("f64", {"rdf_pk": 0})):
         c = ctxs[tag] = Context(0)
         c.set_option("rdf_cull", 1)
         for k, v in opts.items():
@@ -1398,7 +1402,12 @@ def test_packed_class_rows_in_several_passes(B):
             names = {tag: c.last_kernel_name() for tag, c in ctxs.items()}
             assert ("<5," in names["pk"] or "<6," in names["pk"]) and "<0," in names["one"] and "<0," in names["f64"], names
             assert ctxs["pk"].last_kernel_ms()[1] >= 2, ctxs["pk"].last_kernel_ms()  # launches of the pair kernel
-            for tag in ("one", "f64"):
+            if T == 9:
+                assert names["big"].endswith(", false, true>") and ("<3," in names["big"] or "<4," in names["big"]), names
+                assert ctxs["big"].last_kernel_ms()[1] == 1
+            else:
+                assert names["big"] == names["pk"], names
+            for tag in ("one", "f64", "big"):
                 np.testing.assert_array_equal(res[tag][0], res["pk"][0], err_msg=tag)
                 np.testing.assert_array_equal(res[tag][1], res["pk"][1], err_msg=tag)
                 assert res[tag][2] == res["pk"][2], (tag, res[tag][2], res["pk"][2])

@@ -27,6 +27,7 @@ for s in "$@"; do
     pmc_c2) timeout -k 10 900 bash tools/pmc.sh ${ROUND}_c2 C2 > $O/pmc_c2.log 2>&1; echo "pmc rc=$?"; tail -3 $O/pmc_c2.log ;;
     pmc_c1) timeout -k 10 900 bash tools/pmc.sh ${ROUND}_c1 C1 --shape C1 > $O/pmc_c1.log 2>&1; echo "pmc rc=$?"; tail -3 $O/pmc_c1.log ;;
     pmc_c1alt) timeout -k 10 900 bash tools/pmc.sh ${ROUND}_c1alt C1alt --shape C1alt > $O/pmc_c1alt.log 2>&1; echo "pmc rc=$?"; tail -3 $O/pmc_c1alt.log ;;
+    pmc_c1full) timeout -k 10 900 bash tools/pmc.sh ${ROUND}_c1full C1full --shape C1full > $O/pmc_c1full.log 2>&1; echo "pmc rc=$?"; tail -3 $O/pmc_c1full.log ;;
     pmc_c2_f64) timeout -k 10 900 bash tools/pmc.sh ${ROUND}_c2_f64 C2 --option rdf_pk=0 > $O/pmc_c2_f64.log 2>&1; echo "pmc rc=$?" ;;
     pmc_c3) timeout -k 10 900 bash tools/pmc.sh ${ROUND}_c3 C3 --scaling strong > $O/pmc_c3.log 2>&1; echo "pmc rc=$?" ;;
     pmc_c3_cn) timeout -k 10 900 bash tools/pmc.sh ${ROUND}_c3_cn C3/cn --scaling strong --op cn > $O/pmc_c3_cn.log 2>&1; echo "pmc rc=$?" ;;
