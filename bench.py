@@ -592,7 +592,9 @@ def leg_c1(B, ctx, torch, device, synth, sync, steps, c2_kernel_ns_per_kpair, al
             "kernel_ns_per_kpair": ns_per_kpair,
             "cost_per_pair_over_c2": None if not c2_kernel_ns_per_kpair else ns_per_kpair / c2_kernel_ns_per_kpair,
             "parity_checked": "frame 0 == oracle/cpu_ref.c; sum of 8 per-frame histograms == their frame-summed call",
-            "roofline": valu_roofline(kernel, tag, kdur, "mix bin 11/16", 6, pairs, 28.0 * n * F)}
+            # (the 16-wave instance runs 4 waves per SIMD: its roof is the mix's rate at that occupancy)
+            "roofline": valu_roofline(kernel, tag, kdur, "mix bin 11/16", 4 if kernel.count(",") == 3 and kernel.endswith(", true>") else 6,
+                                      pairs, 28.0 * n * F)}
 
 
 def leg_residence(B, ctx, torch, device, synth, sync):
