@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MDHIP_VERSION 500 /* 0.5.0: + mdhip_ticket_status / mdhip_fallbacks / MDHIP_EPENDING (a call's own completion status), mdhip_lag_msd_status_dev; 0.4.0: the *_async entry points with mdhip_sync / mdhip_wait / mdhip_call_stats, mdhip_green_kubo, mdhip_cumtrapz_dev */
+#define MDHIP_VERSION 600 /* 0.6.0: + mdhip_row_displacement, MDHIP_EUNKNOWN (mdhip_ticket_status of a forgotten ticket), mdhip_lag_msd* finishes on the device at every length; 0.5.0: + mdhip_ticket_status / mdhip_fallbacks / MDHIP_EPENDING (a call's own completion status), mdhip_lag_msd_status_dev; 0.4.0: the *_async entry points with mdhip_sync / mdhip_wait / mdhip_call_stats, mdhip_green_kubo, mdhip_cumtrapz_dev */
 
 #define MDHIP_OK 0
 #define MDHIP_EINVAL (-1)  /* bad argument (shape, NULL, unsupported size) */

@@ -859,7 +859,7 @@ static int lag_msd_impl(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const d
     if (variant >= 2 && variant <= 4) {
         // the spectral path: the fused kernels finish on the device (round 5: prefix sums of the squares, S1 - 2 S2, division
         // by the counts in double-double arithmetic, msd_fft.hip) and the means are on their way to `out` when this
-        // returns; only the batched path for long series still finishes on the host. The completion step decides
+        // returns (round 6: the batched path for long series as well). The completion step decides
         // whether the bound is good enough — if not, the exact-difference kernel answers, from inside the step
         auto res = std::make_shared<LagFftResult>();
         rc = mdhip_lag_msd_fft(cs, n_frames, n_ent, d_r, scale, max_lag, n_groups, group_off, res, out, out_on_device);

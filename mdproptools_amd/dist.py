@@ -845,7 +845,7 @@ def msd_step_sharded_async(r_f, r_e, n_frames_total, entity_range, group_off, ta
       full lag x origin average (superset)   ENTITIES dealt to the ranks, r_e [F,3,E_local]   -> means [F,G,4]
     Returns a handle: wait() -> (single, windows, lag) as host arrays, the same on every rank, plus the per-call kernel
     times. The library calls are ISSUED when this function returns (their kernels queued behind the all-gather); what
-    has to wait for them — the host finish of the spectral lag path, the all-reduce, the copy to the host — happens in
+    has to wait for them — the all-reduce and the copy to the host — is queued behind them and waited for in
     wait(). A pipeline issues step k + 1 before it waits for step k, so that the GPU never idles while the host works.
 
     What crosses between the ranks is coalesced into ONE collective before the kernels and ONE after them:
@@ -854,8 +854,9 @@ def msd_step_sharded_async(r_f, r_e, n_frames_total, entity_range, group_off, ta
       after   an all-reduce of ONE buffer: the single-origin rows at their global offsets in a zero array (a row is
               non-zero on exactly one rank: the sum IS the gather, exactly), the window sums, the lag sums.
     The three library calls are issued through their *_async entry points on the stream the collectives are ordered
-    with; the host waits twice per step: once for the calls to complete (the spectral lag path finishes on the host,
-    include/mdhip.h) and once for the reduced buffer. With one process it is three queued calls and one wait.
+    with; the host waits ONCE per step (round 5: the spectral lag path finishes on the device, every length since round 6;
+    the round-4 order — two waits — is MDHIP_STEP_ONE_WAIT=0), plus, with more than one rank, one summed word on which the
+    ranks agree about errors that only showed at completion. With one process it is three queued calls and one wait.
     `compute` (tests: the exchange logic on CPU over gloo, with the oracle as the stand-in): a dict of
     "origin"(r [f,3,E], r0 [3,E], goff, scale) -> [f,G,4], "windows"(r [f,3,E], tao, scale) -> [E,4] (windows between the
     frames 0, tao, 2 tao ... of r) and "lag"(x [F,3,e], max_lag, loc_off, scale) -> means [F,g,4] on numpy arrays.

@@ -33,12 +33,15 @@ def main():
         ctx.set_option("rdf_cull", 1)
         ctx.set_option("rdf_pk", v)
     engaged, pairs = 0, 0
+    layouts = {}
     for trial in range(trials):
         xyz, ty, box, rel, r_cut, bin_size, nbins = _pk_case(rng, trial)
         per_frame = bool(trial % 2)
         a = B.rdf_loop(xyz, ty, box, rel, r_cut, bin_size, nbins, per_frame=per_frame, ctx=f64)
         b = B.rdf_loop(xyz, ty, box, rel, r_cut, bin_size, nbins, per_frame=per_frame, ctx=pk)
         engaged += any(t in pk.last_kernel_name() for t in ("<3,", "<4,", "<5,", "<6,"))
+        key = (pk.last_kernel_name(), pk.last_kernel_ms()[1])  # (kernel instance, launches: > 1 = class rows in passes)
+        layouts[key] = layouts.get(key, 0) + 1
         n = xyz.shape[2]
         pairs += xyz.shape[0] * n * (n - 1) // 2
         if not (np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]):
@@ -56,6 +59,8 @@ def main():
         if trial % 50 == 49:
             print("trial %d ok (%d with the packed kernel, %.3g atom pairs so far)" % (trial + 1, engaged, pairs), flush=True)
     print("soak_pk: %d cases identical, packed kernel in %d, %.4g atom pairs" % (trials, engaged, pairs))
+    for (name, launches), cnt in sorted(layouts.items()):
+        print("   %5d x %s, %d launch(es)" % (cnt, name, launches))
 
 
 if __name__ == "__main__":

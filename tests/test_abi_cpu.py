@@ -19,7 +19,7 @@ def test_header_symbols_are_exported():
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]
     assert not missing, missing
     assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
-    assert lib.mdhip_version() == 500
+    assert lib.mdhip_version() == 600
 
 
 def _ref_bin(rsq, ddr):

@@ -1018,6 +1018,9 @@ def _pk_case(rng, trial):
     if trial % 5 == 4:  # many types, all of them named: the T^2 ordered rows do not fit LDS -> class rows + row table
         n_types = int(rng.integers(6, 10))
         rel = np.array([[a, b] for a in range(1, n_types + 1) for b in range(a, n_types + 1)])[::3][:14]
+        if trial % 10 == 9:  # (round 6) EVERY pair named: nothing for displaced rows to merge — the ordered rows in one
+            # 16-wave block per CU where they fit the whole LDS, else the packed class rows in several passes
+            rel = np.array([[a, b] for a in range(1, n_types + 1) for b in range(a, n_types + 1)])
     ty = rng.integers(1, n_types + 1, n).astype(np.int32)
     return xyz, ty, box, rel, r_cut, bin_size, nbins
 
