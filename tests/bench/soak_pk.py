@@ -58,9 +58,9 @@ def main():
                 sys.exit(1)
         if trial % 50 == 49:
             print("trial %d ok (%d with the packed kernel, %.3g atom pairs so far)" % (trial + 1, engaged, pairs), flush=True)
-    print("soak_pk: %d cases identical, packed kernel in %d, %.4g atom pairs" % (trials, engaged, pairs))
     for (name, launches), cnt in sorted(layouts.items()):
         print("   %5d x %s, %d launch(es)" % (cnt, name, launches))
+    print("soak_pk: %d cases identical, packed kernel in %d, %.4g atom pairs" % (trials, engaged, pairs))
 
 
 if __name__ == "__main__":
