@@ -1196,8 +1196,9 @@ def msd_sharded(torch, dist, D, B, ctx, device, synth, rank, world, backend, ste
                         "world_size": dist.get_world_size() if dist.is_initialized() else 1,
                         "per_step": "ONE all_gather before the kernels (origin frame + last kept frame of every rank, "
                                     "2 x 24 E B per rank) and ONE all_reduce after them ([F,G,4] single-origin rows at "
-                                    "their global offsets | [E,4] window sums | [F,G,4] lag sums, f64) — on device buffers; "
-                                    "two host waits per step"},
+                                    "their global offsets | [E,4] window sums | [F,G,4] lag sums | failure flag | lag status, f64) — on "
+                                    "device buffers; ONE host wait per step, then one summed word on which the ranks agree "
+                                    "about completion-time errors"},
         # the HBM-bound kernel of the step, this rank's launch: 24 E bytes per frame pair
         "roofline": dict(hbm_roofline("msd_pairs", 24.0 * E * (hi - lo), k_single), kernel="msd_pairs_kernel",
                          launch_ms=k_single * 1e3),
