@@ -601,8 +601,8 @@ def leg_residence(B, ctx, torch, device, synth, sync):
     """SURVEY 8f rank 4 (residence_time.py:70-148) at C3's size and density: 100 000 atoms in L = 104 A of which the
     example's share are central atoms (Mg: 315) and shell atoms (ether O: 11 280), unwrapped random walks (0.1 A per
     frame) over 1000 frames, shell (0, 2.325 A] — the example's Mg-O coordination cutoff. One call = every central x
-    shell pair of every frame through the exact f64 distance chain (the sweep is dense: n_i x n_j x F pairs), records
-    sorted by pair, presence masks correlated over all lags. The first frames' indicator against the oracle."""
+    shell pair of every frame through the exact f64 distance chain (the sweep is dense: n_i x n_j x F pairs), every hit
+    a bit in its pair's presence mask (a hash table: no record list, no sort), the masks correlated over all lags. The first frames' indicator against the oracle."""
     F, L, n_i, n_j = 1000, 104.0, 315, 11_280
     ri, rj = synth.residence_walk(F, n_i, n_j, L)
     r = np.concatenate([ri, rj], axis=2)
@@ -635,7 +635,7 @@ def leg_residence(B, ctx, torch, device, synth, sync):
             "roofline": {"bound": "fp64-valu (non-fused)", "achieved": pairs * 17.0 / kdur / 1e12,
                          "peak": FP64_NONFUSED_PEAK / 1e12, "unit": "T op/s", "frac": pairs * 17.0 / kdur / FP64_NONFUSED_PEAK,
                          "ops_per_pair": 17, "traffic": pmc_traffic("residence"),
-                         "hbm_algorithmic_bytes": 24.0 * F * (n_i + n_j) + 16.0 * float(nrec),
+                         "hbm_algorithmic_bytes": 24.0 * F * (n_i + n_j),
                          "note": "3 sub + 3 x (|a - L|, min) + 3 mul + 2 add + 2 compares per pair, exact chain (rdf_cn.py:44-57)"}}
 
 

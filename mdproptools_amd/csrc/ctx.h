@@ -179,7 +179,7 @@ struct mdhip_ctx {
                                // CU with the whole LDS (pair_hist_sj_kernel<., ., false, true>), 0 class rows in passes (A/B)
     int opt_rdf_pk_passes = 1; // packed class-row sweep in several passes when the classes do not fit LDS at once (round 6);
                                // 0: such calls take the all-f64 class-row kernel as before (A/B)
-    int opt_residence_cap = 0; // mdhip_shell_residence: > 0 = capacity of the first sweep's record list (tests: forces the re-sweep)
+    int opt_residence_cap = 0; // mdhip_shell_residence: > 0 = slots of the first sweep's pair table (tests: forces the re-sweep)
     int opt_rdf_pk = -1;      // scalar-j RDF with ordered rows: -1/1 packed-f32 classification sweep with the exact
                               // deferred resolver (MODE 3) when its error bound allows, 0 the all-f64 sweep (MODE 2)
     int opt_rdf_sort = -1;    // spatial sort: -1 auto, 1 one block per frame (LDS counters), 0 multi-block (global counters),

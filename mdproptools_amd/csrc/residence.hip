@@ -9,14 +9,16 @@
 //
 // and are computed exactly; the reference's FFT estimator returns them with ~1e-16 relative noise.
 //
-//  1. shell_pairs_kernel (twice: count, then fill): all central x shell atoms of every frame, the same
-//     exact single-wrap rsq as the pair histograms (rdf_cn.py:44-57, contraction off), shell atoms staged
-//     through LDS. Every hit appends one record (pair key << frame bits | frame).
-//  2. a 64-bit radix sort of the records (hipCUB) brings each pair's frames together, in time order.
-//  3. residence_lag_kernel: a wave per run of equal pair keys builds the pair's presence bit mask over the
-//     frames in LDS and adds popcount(mask & (mask >> k)) to its lag table for every lag k up to the run's
-//     span; tables are merged with 64-bit global atomics (integers: order-independent).
-#include <hipcub/hipcub.hpp>
+//  1. shell_pairs_kernel: all central x shell atoms of every frame, the same exact single-wrap rsq as the pair
+//     histograms (rdf_cn.py:44-57, contraction off), the smaller set staged through LDS. Every hit sets bit t of the
+//     PRESENCE MASK of its pair (i, j) — a row of ceil(F / 64) words in a hash table keyed by i * n_j + j (open
+//     addressing, linear probing; a slot is claimed with one compare-and-swap, a bit set with one atomic OR).
+//     Round 6: rounds 1-5 appended a record per hit and brought a pair's frames together with a 64-bit radix sort of
+//     the records (hipCUB — the one vendor-library call of the product); only the GROUPING was ever needed — the
+//     masks are sets — and the table gives it without a sort, a record list or a run search.
+//  2. residence_lag_kernel: a wave per occupied slot copies the pair's mask to LDS and adds
+//     popcount(mask & (mask >> k)) to its lag table for every lag k up to the pair's span; tables are merged with
+//     64-bit global atomics (integers: order-independent, so is the table's slot order).
 
 #include <algorithm>
 #include <cmath>
@@ -37,24 +39,45 @@ __device__ __forceinline__ double rt_wrap_abs(double d, double L)
     return __builtin_fmin(a, __builtin_fabs(a - L));
 }
 
+constexpr unsigned long long RT_EMPTY = ~0ull;  // (a pair key is < 2^63)
+constexpr unsigned RT_NONE = ~0u;
+
+__device__ __forceinline__ unsigned long long rt_mix(unsigned long long x)
+{
+    // splitmix64's finaliser: consecutive keys (neighbouring j of one i) land far apart
+    x ^= x >> 30;
+    x *= 0xbf58476d1ce4e5b9ull;
+    x ^= x >> 27;
+    x *= 0x94d049bb133111ebull;
+    return x ^ (x >> 31);
+}
+
+// the slot of `key` in the table (claimed if new); RT_NONE when `max_probe` slots in a row were other pairs' (the table
+// is too small: the host sweeps again with one sized from the hit count)
+__device__ __forceinline__ unsigned rt_slot(unsigned long long *__restrict__ keys, unsigned slot_mask, unsigned max_probe,
+                                            unsigned long long key)
+{
+    unsigned h = (unsigned)rt_mix(key) & slot_mask;
+    for (unsigned probe = 0; probe < max_probe; ++probe) {
+        const unsigned long long seen = atomicCAS(&keys[h], RT_EMPTY, key);
+        if (seen == RT_EMPTY || seen == key) return h;
+        h = (h + 1u) & slot_mask;
+    }
+    return RT_NONE;
+}
+
 // grid (ceil(n_lane / 256), F): a lane holds one atom of the LARGER set (round 6: with the central atoms always on the
 // lanes, 315 Mg against 11 280 O filled 315 of 512 lanes), the atoms of the other set are staged through LDS 256 at a time
-// and read as broadcasts. SWAP: the lanes hold the shell atoms j, the loop walks the central atoms i (the record key is
-// i * n_j + j either way). Records are appended to the list; a block collects its hits in LDS and reserves space in the
-// global list once per staged tile (one global atomic per flush instead of one per hit on a single counter, which
-// serialises: 10^7 hits took 100 ms that way). *n_rec counts every hit, also those beyond `cap` (the host sweeps again
-// with the exact size then).
-constexpr int RT_STAGE = 2048;
+// and read as broadcasts. SWAP: the lanes hold the shell atoms j, the loop walks the central atoms i (the pair key is
+// i * n_j + j either way). stat[0] += hits, stat[1] = 1 when a hit found no slot.
 template <bool SWAP>
 __global__ __launch_bounds__(RT_TILE) void shell_pairs_kernel(
     const double *__restrict__ xi, long long n_i, const double *__restrict__ xj, long long n_j,
-    const double *__restrict__ box, double lo2, double hi2, int exclude_diagonal, int frame_bits,
-    unsigned long long *__restrict__ n_rec, unsigned long long *__restrict__ rec, unsigned long long cap)
+    const double *__restrict__ box, double lo2, double hi2, int exclude_diagonal, int words,
+    unsigned long long *__restrict__ keys, unsigned long long *__restrict__ masks, unsigned slot_mask, unsigned max_probe,
+    unsigned long long *__restrict__ stat)
 {
     __shared__ double s_b[3][RT_TILE];
-    __shared__ unsigned long long s_rec[RT_STAGE];
-    __shared__ unsigned s_n;
-    __shared__ unsigned long long s_base;
     const int f = blockIdx.y, tid = threadIdx.x;
     // lane set a, looped set b
     const long long n_a = SWAP ? n_j : n_i, n_b = SWAP ? n_i : n_j;
@@ -67,7 +90,10 @@ __global__ __launch_bounds__(RT_TILE) void shell_pairs_kernel(
         y = pa[n_a + la];
         z = pa[2 * n_a + la];
     }
-    if (tid == 0) s_n = 0u;
+    const unsigned long long bit = 1ull << (f & 63);
+    const size_t word = (size_t)(f >> 6);
+    unsigned long long mine = 0;
+    bool lost = false;
     for (long long b0 = 0; b0 < n_b; b0 += RT_TILE) {
         __syncthreads();
         const long long bl = b0 + tid;
@@ -86,86 +112,43 @@ __global__ __launch_bounds__(RT_TILE) void shell_pairs_kernel(
                 const double rsq = (ax * ax + ay * ay) + az * az;
                 const long long i = SWAP ? b0 + bb : la, j = SWAP ? la : b0 + bb;
                 if (rsq > lo2 && rsq <= hi2 && !(exclude_diagonal && j == i)) {  // residence_time.py:102-104
-                    const unsigned long long r =
-                        (((unsigned long long)i * (unsigned long long)n_j + (unsigned long long)j) << frame_bits) |
-                        (unsigned long long)f;
-                    const unsigned k = atomicAdd(&s_n, 1u);
-                    if (k < (unsigned)RT_STAGE) {
-                        s_rec[k] = r;
-                    } else {  // stage full (a very dense shell): straight to the global list
-                        const unsigned long long pos = atomicAdd(n_rec, 1ull);
-                        if (pos < cap) rec[pos] = r;
-                    }
+                    ++mine;
+                    const unsigned slot = rt_slot(keys, slot_mask, max_probe, (unsigned long long)i * (unsigned long long)n_j + (unsigned long long)j);
+                    if (slot == RT_NONE) lost = true;
+                    else atomicOr(&masks[(size_t)slot * (size_t)words + word], bit);
                 }
             }
         }
-        // flush the stage
-        __syncthreads();
-        const unsigned staged = s_n < (unsigned)RT_STAGE ? s_n : (unsigned)RT_STAGE;
-        if (tid == 0 && staged) s_base = atomicAdd(n_rec, (unsigned long long)staged);
-        __syncthreads();
-        for (unsigned k = tid; k < staged; k += RT_TILE)
-            if (s_base + k < cap) rec[s_base + k] = s_rec[k];
-        __syncthreads();
-        if (tid == 0) s_n = 0u;
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
+    if ((tid & 63) == 0 && mine) atomicAdd(stat, mine);
+    if (lost) atomicOr(stat + 1, 1ull);
 }
 
-// starts[] = indices where a new pair key begins in the sorted records (any order); a block reserves its
-// slots with ONE global atomic
-__global__ __launch_bounds__(256) void run_starts_kernel(const unsigned long long *__restrict__ rec,
-                                                         unsigned long long n, int frame_bits,
-                                                         unsigned long long *__restrict__ n_runs,
-                                                         unsigned long long *__restrict__ starts)
-{
-    __shared__ unsigned s_wave[4];
-    __shared__ unsigned long long s_base;
-    const unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool is_start = k < n && (k == 0 || (rec[k] >> frame_bits) != (rec[k - 1] >> frame_bits));
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(is_start);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) s_wave[wave] = (unsigned)__builtin_popcountll(m);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned tot = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-        s_base = tot ? atomicAdd(n_runs, (unsigned long long)tot) : 0ull;
-    }
-    __syncthreads();
-    if (is_start) {
-        unsigned off = (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull));
-        for (int w = 0; w < wave; ++w) off += s_wave[w];
-        starts[s_base + off] = k;
-    }
-}
-
-// One wave per run (grid-stride over the runs). LDS: presence mask [words] + lag table [n_frames] (u64).
+// One wave per occupied slot (grid-stride over the table). LDS: presence mask [words + 1] + lag table [n_frames] (u64).
 __global__ __launch_bounds__(64) void residence_lag_kernel(
-    const unsigned long long *__restrict__ rec, unsigned long long n, int frame_bits,
-    const unsigned long long *__restrict__ starts, unsigned long long n_runs, int n_frames, int words,
-    unsigned long long *__restrict__ counts)
+    const unsigned long long *__restrict__ keys, const unsigned long long *__restrict__ masks, unsigned long long n_slots,
+    int n_frames, int words, unsigned long long *__restrict__ counts)
 {
     extern __shared__ unsigned long long s_mem[];
-    unsigned long long *mask = s_mem;            // [words + 1] (one zero word behind the end)
+    unsigned long long *mask = s_mem;               // [words + 1] (one zero word behind the end)
     unsigned long long *table = s_mem + words + 1;  // [n_frames]
     const int lane = threadIdx.x;
-    const unsigned long long fmask = (1ull << frame_bits) - 1ull;
     for (int k = lane; k < n_frames; k += 64) table[k] = 0ull;
-    for (unsigned long long r = blockIdx.x; r < n_runs; r += gridDim.x) {
-        for (int w = lane; w <= words; w += 64) mask[w] = 0ull;
-        __syncthreads();
-        const unsigned long long s0 = starts[r];
-        const unsigned long long key = rec[s0] >> frame_bits;
-        // records of a run are sorted by frame: walk them 64 at a time
+    if (lane == 0) mask[words] = 0ull;
+    for (unsigned long long r = blockIdx.x; r < n_slots; r += gridDim.x) {
+        if (keys[r] == RT_EMPTY) continue;  // (wave-uniform)
+        __syncthreads();  // (the previous pair's lags have read the mask)
         int t_first = n_frames, t_last = -1;
-        for (unsigned long long p = s0 + lane;; p += 64) {
-            const bool in = p < n && (rec[p] >> frame_bits) == key;
-            if (in) {
-                const int t = (int)(rec[p] & fmask);
-                atomicOr(&mask[t >> 6], 1ull << (t & 63));
-                t_first = t < t_first ? t : t_first;
-                t_last = t > t_last ? t : t_last;
+        for (int w = lane; w < words; w += 64) {
+            const unsigned long long m = masks[(size_t)r * (size_t)words + w];
+            mask[w] = m;
+            if (m) {
+                const int lo = 64 * w + __builtin_ctzll(m), hi = 64 * w + 63 - __builtin_clzll(m);
+                t_first = lo < t_first ? lo : t_first;
+                t_last = hi > t_last ? hi : t_last;
             }
-            if (!__builtin_amdgcn_ballot_w64(in) || __builtin_amdgcn_ballot_w64(!in)) break;  // run ended in this batch
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
@@ -186,8 +169,8 @@ __global__ __launch_bounds__(64) void residence_lag_kernel(
             }
             table[lag] += c;  // a lag belongs to one lane: no conflict
         }
-        __syncthreads();
     }
+    __syncthreads();
     for (int k = lane; k < n_frames; k += 64)
         if (table[k]) atomicAdd(&counts[k], table[k]);
 }
@@ -209,10 +192,7 @@ int mdhip_shell_residence(mdhip_ctx *ctx, int64_t n_frames, int64_t n_i, const d
     std::fill(counts, counts + n_frames, (uint64_t)0);
     if (n_frames == 0 || n_i == 0 || n_j == 0) return cs.end();
     MD_REQUIRE(xi && xj && box, "NULL input array");
-    int frame_bits = 1;
-    while ((1LL << frame_bits) < n_frames) ++frame_bits;
-    MD_REQUIRE(frame_bits <= 24, "at most 2^24 frames");
-    MD_REQUIRE((double)n_i * (double)n_j < (double)(1ull << (63 - frame_bits)), "pair key does not fit 64 bits");
+    MD_REQUIRE((double)n_i * (double)n_j < 9.0e18, "pair key does not fit 63 bits");
     MD_REQUIRE(n_frames <= 65535, "at most 65535 frames per call");
     const int words = (int)((n_frames + 63) / 64);
     const size_t lds_b = ((size_t)words + 1 + (size_t)n_frames) * 8;
@@ -231,7 +211,6 @@ int mdhip_shell_residence(mdhip_ctx *ctx, int64_t n_frames, int64_t n_i, const d
     memcpy(h_box, box, (size_t)n_frames * 3 * 8);
     MD_HIP(hipMemcpyAsync(d_box, h_box, (size_t)n_frames * 3 * 8, hipMemcpyHostToDevice, ctx->stream));
     MD_WS(d_misc, unsigned long long, WS_MISC, 64);
-    MD_HIP(hipMemsetAsync(d_misc, 0, 64, ctx->stream));
     MD_WS(d_counts, unsigned long long, WS_OUT, (size_t)n_frames * 8);
     MD_HIP(hipMemsetAsync(d_counts, 0, (size_t)n_frames * 8, ctx->stream));
     MD_PIN(h_out, unsigned long long, ((size_t)n_frames + 8) * 8);
@@ -240,71 +219,70 @@ int mdhip_shell_residence(mdhip_ctx *ctx, int64_t n_frames, int64_t n_i, const d
     const dim3 grid((unsigned)(((swap ? n_j : n_i) + RT_TILE - 1) / RT_TILE), (unsigned)n_frames);
     KernelTimer timer(ctx);
     ctx->last_kernel = "shell_pairs_kernel";
-    // ONE sweep over the pairs in the common case (round 6; rounds 1-5 swept twice, count then fill): the record list is
-    // sized from the shell's share of the box — expected records x 1.5 + slack — and the fill sweep counts every hit
-    // whether it fits or not; only a call whose shells are denser than that (a clustered system) sweeps again with
-    // the exact size. The sweep is the call's cost (n_i x n_j x F exact f64 distance chains), the list a few MB.
-    unsigned long long cap;
+    // The table: one slot per PAIR that is ever in the shell (key 8 B + a mask of `words` words), at most half full.
+    // ONE sweep in the common case: the slot count comes from the expected number of HITS (the shell's share of the box x
+    // pairs x frames x 1.5 + slack: far more than distinct pairs — a pair stays for many frames); only a call whose table
+    // fills up (a clustered system) sweeps again, with slots from the hit count the first sweep returned (>= its pairs).
+    const size_t slot_b = 8 + (size_t)words * 8;
+    const size_t mem_cap = (size_t)12 << 30;  // (the table's bytes; beyond that the call fails cleanly)
+    auto pow2_at_least = [](double v, unsigned long long lo = 1024) {
+        unsigned long long p = lo;
+        while ((double)p < v && p < (1ull << 31)) p <<= 1;
+        return p;
+    };
+    unsigned long long slots;
     {
         const double pi43 = 4.18879020478639;
         const double vol = box[0] * box[1] * box[2];
         const double r_hi = std::sqrt(std::max(r_hi_sq, 0.0)), r_lo = std::sqrt(std::max(r_lo_sq, 0.0));
         const double share = vol > 0.0 ? std::min(1.0, pi43 * (r_hi * r_hi * r_hi - r_lo * r_lo * r_lo) / vol) : 1.0;
         const double est = (double)n_i * (double)n_j * (double)n_frames * share * 1.5 + 262144.0;
-        cap = (unsigned long long)std::min(est, 2.5e8);  // (<= 4 GB for the list and its sorted copy)
-        if (ctx->opt_residence_cap > 0) cap = (unsigned long long)ctx->opt_residence_cap;  // (tests: force the second sweep)
+        slots = pow2_at_least(2.0 * std::min(est, (double)n_i * (double)n_j));  // (never more pairs than there are)
+        if (ctx->opt_residence_cap > 0) slots = pow2_at_least((double)ctx->opt_residence_cap, 4);  // (tests: force the re-sweep)
+        while (slots > 1024 && slots * slot_b > mem_cap) slots >>= 1;
     }
-    unsigned long long n_rec = 0;
-    unsigned long long *d_rec = nullptr;
+    unsigned long long n_hit = 0;
+    unsigned long long *d_keys = nullptr, *d_masks = nullptr;
     for (int sweep = 0; sweep < 2; ++sweep) {
-        d_rec = (unsigned long long *)mdhip_ws(ctx, WS_AUX0, (size_t)cap * 8);
-        if (!d_rec) return MDHIP_ENOMEM;
+        unsigned char *d_tab = (unsigned char *)mdhip_ws(ctx, WS_AUX0, (size_t)slots * slot_b);
+        if (!d_tab) return MDHIP_ENOMEM;
+        d_keys = reinterpret_cast<unsigned long long *>(d_tab);
+        d_masks = d_keys + slots;
+        MD_HIP(hipMemsetAsync(d_keys, 0xFF, (size_t)slots * 8, ctx->stream));
+        MD_HIP(hipMemsetAsync(d_masks, 0, (size_t)slots * (size_t)words * 8, ctx->stream));
+        MD_HIP(hipMemsetAsync(d_misc, 0, 64, ctx->stream));
+        // (the second sweep's table holds every pair at half load: its probes may walk as far as they must)
+        const unsigned max_probe = sweep == 0 ? 512u : (unsigned)std::min<unsigned long long>(slots, 0xFFFFFFFFull);
         if (swap)
             hipLaunchKernelGGL(shell_pairs_kernel<true>, grid, dim3(RT_TILE), 0, ctx->stream, d_xi, (long long)n_i, d_xj,
-                               (long long)n_j, d_box, r_lo_sq, r_hi_sq, exclude_diagonal, frame_bits, d_misc + sweep, d_rec, cap);
+                               (long long)n_j, d_box, r_lo_sq, r_hi_sq, exclude_diagonal, words, d_keys, d_masks,
+                               (unsigned)(slots - 1), max_probe, d_misc);
         else
             hipLaunchKernelGGL(shell_pairs_kernel<false>, grid, dim3(RT_TILE), 0, ctx->stream, d_xi, (long long)n_i, d_xj,
-                               (long long)n_j, d_box, r_lo_sq, r_hi_sq, exclude_diagonal, frame_bits, d_misc + sweep, d_rec, cap);
+                               (long long)n_j, d_box, r_lo_sq, r_hi_sq, exclude_diagonal, words, d_keys, d_masks,
+                               (unsigned)(slots - 1), max_probe, d_misc);
         MD_HIP(hipGetLastError());
-        MD_HIP(hipMemcpyAsync(h_out, d_misc + sweep, 8, hipMemcpyDeviceToHost, ctx->stream));
+        MD_HIP(hipMemcpyAsync(h_out, d_misc, 16, hipMemcpyDeviceToHost, ctx->stream));
         MD_HIP(mdhip_stream_wait(ctx));
-        n_rec = h_out[0];
-        if (n_rec <= cap) break;
-        MD_REQUIRE(sweep == 0, "residence: the record count changed between two sweeps of the same frames");
-        cap = n_rec;  // exact now
+        n_hit = h_out[0];
+        if (h_out[1] == 0) break;
+        MD_REQUIRE(sweep == 0, "residence: the pair table filled up although it was sized from the hit count");
+        slots = pow2_at_least(2.0 * (double)n_hit);
+        if (slots * slot_b > mem_cap)
+            return mdhip_fail(ctx, MDHIP_ELIMIT, "residence: %llu in-shell records over %lld frames need a pair table of %.1f GB",
+                              n_hit, (long long)n_frames, (double)(slots * slot_b) / 1073741824.0);
     }
-    if (n_records) *n_records = n_rec;
-    if (n_rec == 0) {
-        timer.stop();
-        MD_HIP(mdhip_stream_wait(ctx));
-        const double ms0 = timer.collect();
-        cs.defer([ctx, ms0]() {
-            ctx->last_ms = ms0;
-            return MDHIP_OK;
-        });
-        return cs.end();
+    if (n_records) *n_records = n_hit;
+    if (n_hit > 0) {
+        if (lds_b > 65536)
+            MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(residence_lag_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+        const unsigned lag_grid = (unsigned)std::min<unsigned long long>(slots, (unsigned long long)ctx->cu_count * 16);
+        hipLaunchKernelGGL(residence_lag_kernel, dim3(lag_grid), dim3(64), lds_b, ctx->stream, d_keys, d_masks, slots,
+                           (int)n_frames, words, d_counts);
+        MD_HIP(hipGetLastError());
     }
-    MD_WS(d_srt, unsigned long long, WS_AUX1, (size_t)n_rec * 8);
-    size_t tmp_b = 0;
-    MD_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_b, d_rec, d_srt, (size_t)n_rec, 0, 64, ctx->stream));
-    MD_WS(d_tmp, unsigned char, WS_AUX2, tmp_b + 256);
-    MD_HIP(hipcub::DeviceRadixSort::SortKeys(d_tmp, tmp_b, d_rec, d_srt, (size_t)n_rec, 0, 64, ctx->stream));
-    // run starts (unordered list) reuse the unsorted buffer
-    unsigned long long *d_starts = d_rec;
-    hipLaunchKernelGGL(run_starts_kernel, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, ctx->stream, d_srt,
-                       n_rec, frame_bits, d_misc + 2, d_starts);
-    MD_HIP(hipGetLastError());
-    MD_HIP(hipMemcpyAsync(h_out, d_misc + 2, 8, hipMemcpyDeviceToHost, ctx->stream));
-    MD_HIP(mdhip_stream_wait(ctx));
-    const unsigned long long n_runs = h_out[0];
-    if (lds_b > 65536)
-        MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(residence_lag_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
-    const unsigned lag_grid = (unsigned)std::min<unsigned long long>(n_runs, (unsigned long long)ctx->cu_count * 16);
-    hipLaunchKernelGGL(residence_lag_kernel, dim3(lag_grid), dim3(64), lds_b, ctx->stream, d_srt, n_rec, frame_bits,
-                       d_starts, n_runs, (int)n_frames, words, d_counts);
     timer.stop();
-    MD_HIP(hipGetLastError());
     MD_HIP(hipMemcpyAsync(h_out, d_counts, (size_t)n_frames * 8, hipMemcpyDeviceToHost, ctx->stream));
     MD_HIP(mdhip_stream_wait(ctx));
     const double ms = timer.collect();

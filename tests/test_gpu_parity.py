@@ -1624,8 +1624,12 @@ def test_shell_residence_vs_oracle(B):
     and without a lower bound, same-type relation (diagonal cleared), runs longer than 64 frames, an empty
     shell; integers must equal the oracle's."""
     rng = np.random.default_rng(41)
+    # (the last two, round 6: DENSE shells — half of all pairs inside, every pair of the table occupied, long probe chains —
+    # and more frames than one mask word, with the larger set on either side)
     for F, ni, nj, lo, hi, same in [(30, 12, 40, 0.0, 3.0, False), (150, 7, 25, 1.5, 4.0, False),
-                                     (70, 33, 33, 0.0, 3.5, True), (10, 5, 9, 0.0, 0.01, False)]:
+                                     (70, 33, 33, 0.0, 3.5, True), (10, 5, 9, 0.0, 0.01, False),
+                                     (200, 40, 300, 0.0, 6.0, False), (130, 310, 30, 1.0, 5.5, False),
+                                     (90, 260, 260, 0.0, 5.0, True)]:
         L = np.array([11.0, 12.0, 13.0])
         n = ni if same else ni + nj
         r = rng.uniform(0, 1, (1, 3, n)) * L[None, :, None] + np.cumsum(rng.normal(0, 0.15, (F, 3, n)), axis=0)
@@ -1637,8 +1641,8 @@ def test_shell_residence_vs_oracle(B):
         want = O.residence_counts(h)
         np.testing.assert_array_equal(counts.astype(np.int64), want)
         assert nrec == int(h.sum())
-        # the record list is sized from an estimate and filled in ONE sweep (round 6); a list that turns out too small is
-        # swept again with the exact size: forced here with a capacity of 5 records
+        # the pairs' presence masks live in a hash table sized from an estimate and filled in ONE sweep (round 6: no record
+        # list, no sort); a table that fills up is swept again with one sized from the hit count: forced here with 8 slots
         ctx = B.default_context()
         ctx.set_option("residence_cap", 5)
         try:
