@@ -423,6 +423,13 @@ def cpu_check_residence(r, n_i, L, lo2, hi2):
     return O.residence_counts(h), int(h.sum())
 
 
+def cpu_check_lag(rsub, lags, esub):
+    """The long-trajectory leg's checker: oracle/cpu_ref.c's lag x origin means of one group at the given lags."""
+    from oracle import cref
+
+    return cref.lag_msd(rsub, lags, [0, esub])
+
+
 def cpu_check_c3(x0, ty, rel, L, cfg, nb, cuts):
     """C3 frame 0 at full size: the whole frame on the host cores (head rows dealt to threads) as the parity oracle,
     and its first head rows on ONE core as the bounded single-core sample (RDF and CN)."""
@@ -786,6 +793,65 @@ def leg_c3(B, ctx, torch, device, synth, sync):
     return out
 
 
+def leg_lag_long(B, ctx, torch, device, synth, sync):
+    """Full lag x origin MSD of a trajectory TWICE as long as C4's (10 000 frames x 50k atoms, 12 GB resident): beyond the
+    fused kernels' 16 384 padded points the transforms run in HBM (csrc/msd_fft.hip, the batched path). Device result with
+    its status word; the small lags against the oracle on a 48-entity group; the exact-difference kernel on that group."""
+    E, F = 50_000, 10_000
+    g = torch.Generator(device=device)
+    g.manual_seed(synth.BASE_SEED + 14)
+    r = torch.empty((F, 3, E), dtype=torch.float64, device=device)
+    r[0] = torch.rand((3, E), generator=g, device=device, dtype=torch.float64) * 82.8
+    for f0 in range(1, F, 250):
+        f1 = min(F, f0 + 250)
+        st = torch.randn((f1 - f0, 3, E), generator=g, device=device, dtype=torch.float64) * 0.1
+        r[f0:f1] = r[f0 - 1] + torch.cumsum(st, dim=0)
+        del st
+    out = torch.empty((F, 1, 4), dtype=torch.float64, device=device)
+    status = torch.full((1,), -1.0, dtype=torch.float64, device=device)
+    km = []
+
+    def call():
+        B.lag_msd(r, F - 1, [0, E], scale=1.0, ctx=ctx, out=out, async_=True, status_out=status).wait()
+        km.append(ctx.last_kernel_ms()[0])
+
+    dt, _ = timed(call, sync, 3)
+    kernel, bound = ctx.last_kernel_name(), ctx.last_rel_bound()
+    if not (float(status.item()) == bound and 0.0 < bound <= 1e-10):
+        raise AssertionError(("lag_long: status word / bound", float(status.item()), bound))
+    esub = 48
+    rsub = r[:, :, :esub].contiguous()
+    ctx.set_option("lag_variant", 2)
+    try:
+        sub = B.lag_msd(rsub, F - 1, [0, esub], scale=1.0, ctx=ctx)
+        sub_bound = ctx.last_rel_bound()
+    finally:
+        ctx.set_option("lag_variant", -1)
+    ctx.set_option("lag_variant", 1)
+    try:
+        exact = B.lag_msd(rsub, F - 1, [0, esub], scale=1.0, ctx=ctx)
+    finally:
+        ctx.set_option("lag_variant", -1)
+    rel = float(np.max(np.abs(sub[1:] - exact[1:]) / exact[1:]))
+    if not rel <= max(sub_bound, 1e-12):
+        raise AssertionError(("lag_long: spectral vs difference kernel", rel, sub_bound))
+    lags = np.linspace(1, 2000, 25).astype(np.int32)
+    want = cpu_check_lag(rsub.cpu().numpy(), lags, esub)
+    np.testing.assert_allclose(sub[lags, 0, :], want[:, 0, :], rtol=1e-9)
+    fp = F * (F - 1) / 2
+    L = 1 << int(np.ceil(np.log2(2 * F - 1)))
+    kernel_s = float(np.median(km[1:])) * 1e-3
+    del r, rsub, out
+    torch.cuda.empty_cache()
+    return {"workload": "full-lag MSD, 10 000 frames x 50k atoms (12 GB resident), max_lag 9999: padded length %d, transforms in HBM" % L,
+            "wall_s": dt, "kernel_s": kernel_s, "kernel": kernel, "frame_pairs": fp, "value": fp / dt, "unit": "frame-pairs/s",
+            "reported_rel_bound": bound, "status_word_equals_bound": True,
+            "max_rel_diff_vs_difference_kernel_48_entities": rel,
+            "parity_checked": "48-entity group: spectral vs exact-difference kernel within the bound; 25 lags <= 2000 vs oracle (rtol 1e-9)",
+            # SURVEY 8d: compulsory bytes 24 E F; what the path moves is ~1.26 MB per series (DESIGN 9.1 item 4)
+            "roofline": dict(hbm_roofline("lag_long", 24.0 * E * F, kernel_s), kernel=kernel)}
+
+
 def leg_c4(B, ctx, torch, device, synth, sync):
     """BASELINE.json configs[3] at full size: 50k atoms x 5000 frames, MSD (single origin, fixed lag, COM, full lag)."""
     E, F = 50_000, 5000
@@ -1029,6 +1095,8 @@ def flat_scalars(out):
         "c5_cumtrapz_kernel_s": _get(out, "c5", "cumtrapz", "kernel_s"),
         "c5_green_kubo_chain_wall_s": _get(out, "c5", "green_kubo_chain", "wall_s"),
         "c1_pairs_per_s": _get(out, "c1", "value"), "c1_alt_pairs_per_s": _get(out, "c1_alt", "value"),
+        "lag_long_kernel_ms": None if _get(out, "lag_long", "kernel_s") is None else _get(out, "lag_long", "kernel_s") * 1e3,
+        "lag_long_frame_pairs_per_s": _get(out, "lag_long", "value"),
         "lag_diff_kernel_ms": None if _get(out, "c4", "lag_msd_difference_kernel", "kernel_s") is None
         else _get(out, "c4", "lag_msd_difference_kernel", "kernel_s") * 1e3,
         "lag_diff_fp64_fma_frac": _get(out, "c4", "lag_msd_difference_kernel", "roofline", "frac"),
@@ -1223,7 +1291,7 @@ def main():
     ap.add_argument("--msd-steps", type=int, default=5, help="timed steps of the `msd` object of the default line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="headline only (profiling runs)")
-    ap.add_argument("--legs", default="parity,f64,h2d,c1,residence,c3,c4,c5")
+    ap.add_argument("--legs", default="parity,f64,h2d,c1,residence,c3,c4,lag_long,c5")
     ap.add_argument("--cpu-frames", type=int, default=10)
     ap.add_argument("--variant", type=int, default=None, help="kernel variant knob (A/B only)")
     ap.add_argument("--option", action="append", default=[], help="library option key=value (A/B only)")
@@ -1512,6 +1580,8 @@ def main():
             run_leg("c3", lambda: leg_c3(B, ctx, torch, device, synth, sync))
         if "c4" in legs:
             run_leg("c4", lambda: leg_c4(B, ctx, torch, device, synth, sync))
+        if "lag_long" in legs:
+            run_leg("lag_long", lambda: leg_lag_long(B, ctx, torch, device, synth, sync))
         if "c5" in legs:
             run_leg("c5", lambda: leg_c5(B, ctx, torch, device, synth, sync))
         roof_flat, conf_flat = flat_scalars(out)
