@@ -206,11 +206,14 @@ struct mdhip_ctx {
     int opt_seg_frame = 1;    // mdhip_segment_com: one (run, frame) per block, nothing carried between frames (A/B: 0 =
                               // the software-pipelined staged kernel)
     int opt_xcorr_tile = 0;
+    int opt_lag_batch_mb = 4096;  // batched full-lag path: device memory of one batch of series (centred series + transform buffers), MB
     int opt_lag_w12_min_f = 1536;  // full-lag MSD with 2048 < F + max_lag <= 8192: from this many frames on the 12288-point
                                    // kernel (msd_fft_w12.h) instead of the 8192-point one; 0 = never, >= 1536
-    int opt_lag_batched_fuse = 1;  // full-lag MSD of series beyond the fused kernels: 1 (default, round 6) the first pass reads
+    int opt_lag_batched_fuse = 2;  // full-lag MSD of series beyond the fused kernels: 1 (round 6) the first pass reads
                                    // the centred series where they are (implicit padding) and |X|^2 is reduced straight
-                                   // from the packed transform; 0 the round-2 sequence (padded copy, half spectra) — A/B
+                                   // from the packed transform; 2 (default) as 1 in two passes, the second one fused with
+                                   // that reduction (the packed transform is never written); 0 the round-2 sequence
+                                   // (padded copy, half spectra) — A/B
     int opt_lag_variant = 3;  // full-lag MSD: 3 (default) = autocorrelation theorem (msd_fft.hip) when its error bound
                               // stays below 1e-10, else the exact-difference kernel; 1 = series-resident LDS
                               // difference kernel when it fits, 0 = staged difference kernel, 2 = always the
@@ -255,6 +258,11 @@ int mdhip_fft_c2r(mdhip_ctx *ctx, const double2 *d_spec, double2 *d_tmp, double 
 int mdhip_fft_r2c_packed(mdhip_ctx *ctx, const double *d_series, long long n, double2 *d_buf0, double2 *d_buf1, long long L,
                          int batch, const double2 **Z_out);
 int mdhip_fft_power_rows(mdhip_ctx *ctx, const double2 *Z, long long L, long long row0, long long row1, int splits,
+                         double *d_partial);
+// ... in two passes, the second one fused with the column sums (fft_power_pass_kernel): the packed transform is never written
+bool mdhip_fft_power2_plan(const mdhip_ctx *ctx, long long L);
+int mdhip_fft_first_perm(mdhip_ctx *ctx, const double *d_series, long long n, double2 *d_buf, long long L, int batch);
+int mdhip_fft_power_pass(mdhip_ctx *ctx, const double2 *d_buf, long long L, long long row0, long long row1, int splits,
                          double *d_partial);
 // the fused FFT estimator of xcorr.hip: series in, scaled lags out; buf0..3 hold batch * L/2 complex points each
 int mdhip_fft_xcorr(mdhip_ctx *ctx, const double *d_a, const double *d_b, long long n, long long L, int batch,

@@ -236,7 +236,7 @@ struct Net8Plan {
     int lf;  // log2 of the last round's transform (1 .. 4), without twiddles
 };
 
-__host__ __device__ inline Net8Plan net8_plan(int logR)
+__host__ __device__ constexpr inline Net8Plan net8_plan(int logR)
 {
     Net8Plan p{0, logR};
     while (p.lf > 4) {
@@ -759,6 +759,180 @@ __global__ __launch_bounds__(256) void r2c_power_rows_kernel(const double2 *__re
     if (H - k != k) p[H - k] = b0 + b1;  // (k = 0 -> X(H))
 }
 
+// Round 6, second step: the SECOND pass of a two-pass transform and the column sums of |X_k|^2 in one kernel — the packed
+// transform Z never exists in memory. H = Ra Rb; the first pass (radix Ra, IN_PAD, OUT_PERM) left in[Ra r + pair_phys(j)] =
+// output j of column r, as for fft_mid_acf_kernel, whose tile this kernel shares: C neighbouring positions x of every row
+// r < Rb = the columns c = pair_logical(x) of the second pass, so that the frequencies k = c + Ra j and H - k, which the
+// real spectrum combines, sit in the same tile. A workgroup owns ONE tile and walks the rows (series) of its split: load,
+// transform (the forward network of fft_pass8_kernel), the sums of its 4 pairs (k, H - k) per lane into registers; partial[split][k], k = 0..H, once at the end. Per series and pass over HBM: 16 H bytes read,
+// nothing written (the plain sequence: 16 H read + 16 H written by the pass, 16 H read by r2c_power_rows_kernel).
+// grid (Ra / C tiles, splits), EXACTLY Rb C / 8 lanes (64 .. 512); rows [row0, row1) of in [.][H]; LDS as fft_pass8_kernel
+// at radix Rb.
+template <int logR, int logC>
+__global__ __launch_bounds__(((1 << logR) << logC) >> 3, 3) void fft_power_pass_kernel(const double2 *__restrict__ in, long long H,
+                                                                                      int logRa, long long row0, long long row1,
+                                                                                      double *__restrict__ partial, TwTab tt)
+{
+    extern __shared__ double2 lds[];
+    constexpr int R = 1 << logR, C = 1 << logC, NT = (R * C) >> 3;
+    const int Ra = 1 << logRa;
+    constexpr Net8Plan pl = net8_plan(logR);
+    constexpr int lf = pl.lf;
+    double2 *buf = lds;
+    double2 *tw = lds + (R << logC) + ((R >> lf) << logC);
+#define NET8_P(k, cc) ((((k) + ((k) >> lf)) << logC) + (cc))
+    long long tile = blockIdx.x;
+    if ((gridDim.x & 15u) == 0u) {  // (half-line tiles: the two halves of a line to the same XCD, as fft_pass8_kernel)
+        const unsigned m = blockIdx.x >> 3, xc = blockIdx.x & 7u;
+        tile = (long long)((m & 1u) + 2u * xc) + 16LL * (m >> 1);
+    }
+    const int x0 = (int)(tile << logC);
+    const long long n_rows = row1 - row0;
+    const long long ra = row0 + n_rows * blockIdx.y / gridDim.y, rb = row0 + n_rows * (blockIdx.y + 1) / gridDim.y;
+    for (int t = threadIdx.x; t < (R >> 1); t += NT) tw[t] = tw_lookup(tt, (unsigned long long)t, logR);
+    // This lane's four pairs (item idx = lane + i NT < R/2 * C: column cc = idx mod C, output j = idx div C < R/2) and, for
+    // lane 0 of the tile that holds column 0, the point H/2 (c = 0, j = R/2: its own partner). The sums are the BILINEAR ones
+    // of the fused kernels (msd_fft.hip, msd_power_lds2_kernel): S = |Z_k|^2, S' = |Z_(H-k)|^2, T = Im(Z_k Z_(H-k)) per series —
+    // six fused multiply-adds per pair — and the frequencies are sorted out once, after the last series:
+    //   |X_k|^2 = (S + S')/2 + Im(w) (S - S')/2 + Re(w) T,  |X_(H-k)|^2 = (S + S')/2 - Im(w) (S - S')/2 - Re(w) T,  w = e^{-2 pi i k/L}
+    int pos[4], posp[4];
+    double sk[4], sh[4], tk[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = threadIdx.x + i * NT;
+        const int cc = idx & (C - 1), j = idx >> logC;
+        const int x = x0 + cc, c = pair_logical(x, Ra);
+        const int ccp = (x < 2 ? x : x ^ 1) - x0;
+        const int jp = c == 0 ? (R - j) & (R - 1) : R - 1 - j;
+        pos[i] = NET8_P(net8_row(j, logR, pl), cc);
+        posp[i] = NET8_P(net8_row(jp, logR, pl), ccp);
+        sk[i] = sh[i] = tk[i] = 0.0;
+    }
+    const bool has_mid = x0 == 0 && threadIdx.x == 0;
+    const int pos_mid = NET8_P(net8_row(R >> 1, logR, pl), 0);
+    double s_mid = 0.0;
+    double2 v[8];
+    // (`lane` = threadIdx.x through an opaque copy made inside the series loop: every address, LDS position and twiddle of
+    // the transform is the same for all series, and hoisted out of the loop they would fill the register budget — 100+
+    // spilled registers; recomputed per series they are a few integer operations)
+    auto fetch = [&](long long q, int lane) {
+        const double2 *row = in + (size_t)q * H + x0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {  // (R C = 8 NT points: all eight loads in flight)
+            const int idx = lane + i * NT;
+            typedef double d2_t __attribute__((ext_vector_type(2)));
+            const d2_t t = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(row + (idx & (C - 1)) + (long long)(idx >> logC) * Ra));
+            v[i] = make_double2(t[0], t[1]);
+        }
+    };
+    if (ra < rb) fetch(ra, threadIdx.x);
+    for (long long q = ra; q < rb; ++q) {
+        int lane = threadIdx.x;
+        asm volatile("" : "+v"(lane));
+        __syncthreads();  // (the previous series' pairs are read; the first trip: the twiddle table is written)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = lane + i * NT;
+            buf[NET8_P(idx >> logC, idx & (C - 1))] = v[i];
+        }
+        __syncthreads();
+        int logn = logR;
+        for (int r8 = 0; r8 < pl.n8; ++r8) {
+            const int lst = logn - 3;
+            {  // (R/8 * C butterflies = NT: one per lane)
+                const int b = lane;
+                const int cc = b & (C - 1), bf = b >> logC;
+                const int i = bf & ((1 << lst) - 1), blk = bf >> lst;
+                const int rw0 = (blk << logn) + i;
+                double2 a[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[e] = buf[NET8_P(rw0 + (e << lst), cc)];
+                net_dft8(a);
+                const int sft = logR - logn;
+                const double2 w1 = net8_root(tw, i << sft, R >> 1), w2 = net8_root(tw, (2 * i) << sft, R >> 1),
+                              w4 = net8_root(tw, (4 * i) << sft, R >> 1);
+                const double2 w3 = cmul(w1, w2), w5 = cmul(w4, w1), w6 = cmul(w4, w2), w7 = cmul(w4, w3);
+                a[1] = cmul(a[1], w1);
+                a[2] = cmul(a[2], w2);
+                a[3] = cmul(a[3], w3);
+                a[4] = cmul(a[4], w4);
+                a[5] = cmul(a[5], w5);
+                a[6] = cmul(a[6], w6);
+                a[7] = cmul(a[7], w7);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) buf[NET8_P(rw0 + (e << lst), cc)] = a[e];
+            }
+            __syncthreads();
+            logn -= 3;
+        }
+        for (int b = lane; b < (R >> lf << logC); b += NT) {
+            const int cc = b & (C - 1), rw0 = (b >> logC) << lf;
+            if (lf == 4) {
+                double2 x[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) x[e] = buf[NET8_P(rw0 + e, cc)];
+                net_dft16(x);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) buf[NET8_P(rw0 + e, cc)] = x[e];
+            } else if (lf == 3) {
+                double2 x[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = buf[NET8_P(rw0 + e, cc)];
+                net_dft8(x);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) buf[NET8_P(rw0 + e, cc)] = x[e];
+            } else if (lf == 2) {
+                double2 y0, y1, y2, y3;
+                net_dft4(buf[NET8_P(rw0, cc)], buf[NET8_P(rw0 + 1, cc)], buf[NET8_P(rw0 + 2, cc)], buf[NET8_P(rw0 + 3, cc)],
+                         y0, y1, y2, y3);
+                buf[NET8_P(rw0, cc)] = y0;
+                buf[NET8_P(rw0 + 1, cc)] = y1;
+                buf[NET8_P(rw0 + 2, cc)] = y2;
+                buf[NET8_P(rw0 + 3, cc)] = y3;
+            } else {
+                const double2 u = buf[NET8_P(rw0, cc)], w = buf[NET8_P(rw0 + 1, cc)];
+                buf[NET8_P(rw0, cc)] = cadd(u, w);
+                buf[NET8_P(rw0 + 1, cc)] = csub(u, w);
+            }
+        }
+        __syncthreads();
+        if (q + 1 < rb) fetch(q + 1, lane);  // (the next series' tile lands under the sums and the barrier)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const double2 zk = buf[pos[i]], zh = buf[posp[i]];
+            sk[i] = __builtin_fma(zk.x, zk.x, sk[i]);
+            sk[i] = __builtin_fma(zk.y, zk.y, sk[i]);
+            sh[i] = __builtin_fma(zh.x, zh.x, sh[i]);
+            sh[i] = __builtin_fma(zh.y, zh.y, sh[i]);
+            tk[i] = __builtin_fma(zk.x, zh.y, tk[i]);
+            tk[i] = __builtin_fma(zk.y, zh.x, tk[i]);
+        }
+        if (has_mid) {
+            const double2 z = buf[pos_mid];
+            s_mid = __builtin_fma(z.x, z.x, s_mid);
+            s_mid = __builtin_fma(z.y, z.y, s_mid);
+        }
+    }
+    double *p = partial + (size_t)blockIdx.y * (H + 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = threadIdx.x + i * NT;
+        const int cc = idx & (C - 1), j = idx >> logC;
+        const long long k = (long long)pair_logical(x0 + cc, Ra) + (long long)Ra * j;
+        const double2 w = tw_lookup(tt, (unsigned long long)k, tt.logL);  // e^{-2 pi i k/L}
+        if (k == 0) {  // Z_0 is its own partner: X_0 = Re + Im, X_H = Re - Im
+            p[0] = sk[i] + tk[i];
+            p[H] = sk[i] - tk[i];
+        } else {
+            const double m = 0.5 * (sk[i] + sh[i]), d = 0.5 * (sk[i] - sh[i]);
+            p[k] = m + w.y * d + w.x * tk[i];
+            p[H - k] = m - w.y * d - w.x * tk[i];
+        }
+    }
+    if (has_mid) p[H >> 1] = s_mid;  // X_(H/2) = conj Z_(H/2)
+#undef NET8_P
+}
+
 // W = conj Y (the input of the forward transform that stands for the inverse one) from the Hermitian half spectrum
 // S[b][0..H]. grid (ceil((H/2+1)/256), batch)
 __global__ void c2r_pre_kernel(const double2 *__restrict__ S, double2 *__restrict__ W, long long H, TwTab tt)
@@ -889,7 +1063,7 @@ bool net8_tile(const mdhip_ctx *ctx, long long H, int logR, int &logC, size_t &l
     const long long cols = H >> logR;
     const int lf = net8_plan(logR).lf;
     auto bytes = [&](int lc) {
-        return (((size_t)1 << logR) + ((size_t)1 << logR >> lf) << lc) * sizeof(double2) + ((size_t)1 << logR >> 1) * sizeof(double2);
+        return ((((size_t)1 << logR) + ((size_t)1 << logR >> lf)) << lc) * sizeof(double2) + ((size_t)1 << logR >> 1) * sizeof(double2);
     };
     // two workgroups per CU (their loads, transforms and stores overlap), i.e. <= 78 KB of LDS each
     const size_t cap = ctx->opt_fft_net8 == 2 ? ctx->lds_max : (size_t)78 * 1024;  // (2: one workgroup per CU, A/B)
@@ -1043,6 +1217,99 @@ int mdhip_fft_power_rows(mdhip_ctx *ctx, const double2 *Z, long long L, long lon
                        ctx->stream, Z, H, row0, row1, d_partial, tt);
     MD_HIP(hipGetLastError());
     return MDHIP_OK;
+}
+
+// The two-pass form of mdhip_fft_r2c_packed + mdhip_fft_power_rows (fft_power_pass_kernel): H = L/2 = Ra Rb.
+// mdhip_fft_power2_plan: false when this length does not take it (H < 2^10: the callers' lengths are far beyond).
+// mdhip_fft_first_perm: the first pass over `batch` zero-padded series d_series[b][0..n) into d_buf [batch][H].
+// mdhip_fft_power_pass: partial[split][0..L/2] = sum over the rows [row0, row1) of d_buf of |X_row(k)|^2 (`splits` parts).
+// (radix, tile width) pairs fft_power_pass_kernel is compiled for: what power2_plan's rule gives for H = 2^10 .. 2^22
+#define POWER2_INSTANCES(X) X(5, 4) X(6, 4) X(7, 4) X(8, 3) X(9, 2) X(10, 1) X(11, 1)
+namespace {
+struct Power2Plan {
+    int logRa, logRb, lc1, lc2;
+    size_t lds1, lds2;
+};
+
+bool power2_plan(const mdhip_ctx *ctx, long long H, Power2Plan &pp)
+{
+    int logH = 0;
+    while ((1LL << logH) < H) ++logH;
+    if (logH < 10 || logH > 22) return false;
+    pp.logRa = (logH + 1) / 2;
+    pp.logRb = logH - pp.logRa;
+    auto bytes = [](int logR, int lc) {
+        const int lf = net8_plan(logR).lf;
+        return ((((size_t)1 << logR) + ((size_t)1 << logR >> lf)) << lc) * sizeof(double2) + ((size_t)1 << logR >> 1) * sizeof(double2);
+    };
+    // tiles of <= 40 KB: four workgroups per CU, whose loads, transforms and sums overlap; 16 columns (256-byte runs) at most,
+    // R C / 8 lanes between 64 and 1024
+    auto pick = [&](int logR, int &lc, size_t &lds) {
+        lc = 4;
+        while (lc > 1 && (bytes(logR, lc) > (size_t)40 * 1024 || ((1 << logR << lc) >> 3) > 512)) --lc;
+        lds = bytes(logR, lc);
+        return lds <= ctx->lds_max && ((1 << logR << lc) >> 3) >= 64 && ((1 << logR << lc) >> 3) <= 512;
+    };
+    if (!pick(pp.logRa, pp.lc1, pp.lds1) || !pick(pp.logRb, pp.lc2, pp.lds2)) return false;
+    bool have = false;
+#define MD_HAVE(LR, LC) have = have || (pp.logRb == LR && pp.lc2 == LC);
+    POWER2_INSTANCES(MD_HAVE)
+#undef MD_HAVE
+    return have;
+}
+}  // namespace
+
+bool mdhip_fft_power2_plan(const mdhip_ctx *ctx, long long L)
+{
+    Power2Plan pp;
+    return L >= 512 && (L & (L - 1)) == 0 && power2_plan(ctx, L / 2, pp);
+}
+
+int mdhip_fft_first_perm(mdhip_ctx *ctx, const double *d_series, long long n, double2 *d_buf, long long L, int batch)
+{
+    const long long H = L / 2;
+    Power2Plan pp;
+    MD_REQUIRE((L & (L - 1)) == 0 && n <= L && power2_plan(ctx, H, pp), "no two-pass plan for the transform length %lld", L);
+    TwTab tt;
+    if (!fft_twiddle_table(ctx, H, tt)) return MDHIP_ENOMEM;
+    MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fft_pass8_kernel<IN_PAD, OUT_PERM>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp.lds1));
+    const long long cols = H >> pp.logRa;
+    const int threads = (1 << pp.logRa << pp.lc1) >> 3;
+    for (int b0 = 0; b0 < batch; b0 += FFT_MAX_BATCH) {  // (grid.y)
+        PassIo io{};
+        io.series = d_series + (size_t)b0 * n;
+        io.n = n;
+        hipLaunchKernelGGL((fft_pass8_kernel<IN_PAD, OUT_PERM>), dim3((unsigned)(cols >> pp.lc1), (unsigned)std::min(FFT_MAX_BATCH, batch - b0)),
+                           dim3((unsigned)threads), pp.lds1, ctx->stream, (const double2 *)nullptr, d_buf + (size_t)b0 * H, H,
+                           pp.logRa, pp.lc1, 0, H, io, tt);
+    }
+    MD_HIP(hipGetLastError());
+    return MDHIP_OK;
+}
+
+int mdhip_fft_power_pass(mdhip_ctx *ctx, const double2 *d_buf, long long L, long long row0, long long row1, int splits,
+                         double *d_partial)
+{
+    const long long H = L / 2;
+    Power2Plan pp;
+    MD_REQUIRE((L & (L - 1)) == 0 && power2_plan(ctx, H, pp), "no two-pass plan for the transform length %lld", L);
+    TwTab tt;
+    if (!fft_twiddle_table(ctx, H, tt)) return MDHIP_ENOMEM;
+    const int threads = (1 << pp.logRb << pp.lc2) >> 3;
+#define MD_POWER_PASS(LR, LC)                                                                                                 \
+    if (pp.logRb == LR && pp.lc2 == LC) {                                                                                     \
+        MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fft_power_pass_kernel<LR, LC>),                             \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp.lds2));                                \
+        hipLaunchKernelGGL((fft_power_pass_kernel<LR, LC>), dim3((unsigned)((1LL << pp.logRa) >> pp.lc2), (unsigned)splits),  \
+                           dim3((unsigned)threads), pp.lds2, ctx->stream, d_buf, H, pp.logRa, row0, row1, d_partial, tt);     \
+        MD_HIP(hipGetLastError());                                                                                            \
+        return MDHIP_OK;                                                                                                      \
+    }
+    POWER2_INSTANCES(MD_POWER_PASS)
+#undef MD_POWER_PASS
+    mdhip_fail(ctx, MDHIP_EHIP, "internal: no instance of the fused pass for radix 2^%d, 2^%d columns", pp.logRb, pp.lc2);
+    return MDHIP_EHIP;
 }
 
 // Unnormalised inverse: c[b][t] = sum_{k=0}^{L-1} S[b][k] e^{+2 pi i k t/L} (S Hermitian, given for k = 0..L/2) into

@@ -760,7 +760,9 @@ int mdhip_set_option(mdhip_ctx *ctx, const char *key, int value)
     else if (!strcmp(key, "rdf_pk"))
         ctx->opt_rdf_pk = value;
     else if (!strcmp(key, "lag_batched_fuse"))
-        ctx->opt_lag_batched_fuse = value < 0 ? 1 : value;
+        ctx->opt_lag_batched_fuse = value < 0 ? 2 : value;
+    else if (!strcmp(key, "lag_batch_mb"))
+        ctx->opt_lag_batch_mb = value <= 0 ? 4096 : std::min(value, 65536);
     else if (!strcmp(key, "lag_w12_min_f"))
         ctx->opt_lag_w12_min_f = value < 0 ? 1536 : value;  // -1 restores the default
     else if (!strcmp(key, "lag_variant"))

@@ -2329,10 +2329,14 @@ int mdhip_lag_msd_fft(CallScope &cs, int64_t n_frames, int64_t n_ent, const doub
     // left them (implicit zero padding: no padded copy is written or read) and the column sums of |X_k|^2 are taken straight
     // from the packed transform (r2c_power_rows_kernel: the half spectra are never written) — 2.1 -> 1.3 MB of HBM traffic per
     // series at F = 10 000 (profiles/r06_lag_long_kernel_stats.csv before, r06_lag_sizes.txt after). 0: the round-2 sequence.
+    // Second step (`lag_batched_fuse` 2, default): the transform in TWO passes, the second one fused with the column sums
+    // (fft_power_pass_kernel): the packed transform is never written either — 1.3 -> 0.9 MB per series (one transform buffer).
     const bool fuse = ctx->opt_lag_batched_fuse != 0;
+    const bool fuse2 = ctx->opt_lag_batched_fuse >= 2 && mdhip_fft_power2_plan(ctx, L);
+    constexpr int MF_SPLITS2 = 128;  // row splits of the fused pass (8-16 tiles of columns each: >= 4 workgroups per CU)
     // batches of whole series: (padded copy | centred series) + the transform buffers (+ spectrum) <= ~4 GiB
-    const long long per_series = fuse ? F * 8 + 2 * L * 8 : 2 * L * 8 + K * 16;
-    const long long nb_max = std::max<long long>(1, std::min<long long>((4LL << 30) / per_series, (1LL << 31) / K));
+    const long long per_series = fuse2 ? F * 8 + L * 8 : fuse ? F * 8 + 2 * L * 8 : 2 * L * 8 + K * 16;
+    const long long nb_max = std::max<long long>(1, std::min<long long>(((long long)ctx->opt_lag_batch_mb << 20) / per_series, (1LL << 31) / K));
     const long long n_batches = (cols + nb_max - 1) / nb_max;
     const long long nb0 = (cols + n_batches - 1) / n_batches;
 
@@ -2340,7 +2344,7 @@ int mdhip_lag_msd_fft(CallScope &cs, int64_t n_frames, int64_t n_ent, const doub
     double *d_msum = d_mean + cols;
     MD_WS(d_pad, double, WS_AUX1, (size_t)nb0 * (fuse ? F : L) * 8);                 // fuse: the centred series [nb][F]
     MD_WS(d_spec, double2, WS_AUX2, fuse ? (size_t)nb0 * L * 8 : (size_t)nb0 * K * 16);  // fuse: the first transform buffer
-    MD_WS(d_tmp, double2, WS_FFT_TMP, (size_t)std::max(nb0, S) * L * 8 + 64);
+    MD_WS(d_tmp, double2, WS_FFT_TMP, (size_t)(fuse2 ? S : std::max(nb0, S)) * L * 8 + 64);
     // Q [S][F] | P [S][K] | complex P [S][K] | correlations [S][L] | group offsets
     const size_t q_b = (size_t)S * F * 8, p_b = (size_t)S * K * 8, z_b = (size_t)S * K * 16, c_b = (size_t)S * L * 8;
     MD_WS(d_small, unsigned char, WS_AUX3, q_b + p_b + z_b + c_b + (size_t)(G + 1) * 8 + (size_t)G * 8 + 256);
@@ -2350,7 +2354,7 @@ int mdhip_lag_msd_fft(CallScope &cs, int64_t n_frames, int64_t n_ent, const doub
     double *d_corr = reinterpret_cast<double *>(d_small + q_b + p_b + z_b);
     long long *d_goff = reinterpret_cast<long long *>(d_small + q_b + p_b + z_b + c_b);
     double *d_ng = reinterpret_cast<double *>(d_goff + G + 1);  // entities per group (lag_finish_dd_kernel)
-    MD_WS(d_part, double, WS_PART, (size_t)MF_SPLITS * K * 8);
+    MD_WS(d_part, double, WS_PART, (size_t)(fuse2 ? MF_SPLITS2 : MF_SPLITS) * K * 8);
 
     {
         // group offsets | entities per group: one pinned block, one copy on the launch stream
@@ -2382,8 +2386,9 @@ int mdhip_lag_msd_fft(CallScope &cs, int64_t n_frames, int64_t n_ent, const doub
                                dim3(256), 0, ctx->stream, d_r, d_mean, F, cols, c_first, nb, L, scale, d_pad);
         MD_HIP(hipGetLastError());
         const double2 *d_Zp = nullptr;  // fuse: the packed transform of the batch
-        int rc = fuse ? mdhip_fft_r2c_packed(ctx, d_pad, F, d_spec, d_tmp, L, (int)nb, &d_Zp)
-                      : mdhip_fft_r2c(ctx, d_pad, d_tmp, d_spec, L, (int)nb);
+        int rc = fuse2  ? mdhip_fft_first_perm(ctx, d_pad, F, d_spec, L, (int)nb)
+                 : fuse ? mdhip_fft_r2c_packed(ctx, d_pad, F, d_spec, d_tmp, L, (int)nb, &d_Zp)
+                        : mdhip_fft_r2c(ctx, d_pad, d_tmp, d_spec, L, (int)nb);
         if (rc) return rc;
         // the (axis, group) segments this batch touches
         for (long long s = 0; s < S; ++s) {
@@ -2391,8 +2396,11 @@ int mdhip_lag_msd_fft(CallScope &cs, int64_t n_frames, int64_t n_ent, const doub
             const long long lo = std::max(c_first, a * E + (long long)group_off[g]);
             const long long hi = std::min(c_first + nb, a * E + (long long)group_off[g + 1]);
             if (lo >= hi) continue;
-            const int splits = (int)std::min<long long>(MF_SPLITS, hi - lo);
-            if (fuse) {
+            const int splits = (int)std::min<long long>(fuse2 ? MF_SPLITS2 : MF_SPLITS, hi - lo);
+            if (fuse2) {
+                const int rcp = mdhip_fft_power_pass(ctx, d_spec, L, lo - c_first, hi - c_first, splits, d_part);
+                if (rcp) return rcp;
+            } else if (fuse) {
                 const int rcp = mdhip_fft_power_rows(ctx, d_Zp, L, lo - c_first, hi - c_first, splits, d_part);
                 if (rcp) return rcp;
             } else {

@@ -550,14 +550,33 @@ def test_lag_msd_long_series_finish_on_the_device(B):
             assert float(st.item()) == bound
             again = B.lag_msd(r, max_lag, goff, scale=0.5, async_=True).wait()
             np.testing.assert_array_equal(again, fft)
-            # round 6: the first pass reads the series in place and |X|^2 is reduced from the packed transform — the same
-            # operations in the same order as the padded copy + half spectra of round 2 (`lag_batched_fuse` 0): identical bits
-            ctx.set_option("lag_batched_fuse", 0)
+            # round 6: the first pass reads the series in place and |X|^2 is reduced from the packed transform
+            # (`lag_batched_fuse` 1) — the same operations in the same order as the padded copy + half spectra of round 2
+            # (`lag_batched_fuse` 0): identical bits. The default (2: two passes, the second fused with the reduction) runs
+            # another butterfly network and adds the rows in another order: equal within the bounds.
             try:
+                ctx.set_option("lag_batched_fuse", 0)
                 old = B.lag_msd(r, max_lag, goff, scale=0.5)
-            finally:
                 ctx.set_option("lag_batched_fuse", 1)
-            np.testing.assert_array_equal(old, fft)
+                mid = B.lag_msd(r, max_lag, goff, scale=0.5)
+                mid_bound = ctx.last_rel_bound()
+            finally:
+                ctx.set_option("lag_batched_fuse", -1)
+            np.testing.assert_array_equal(old, mid)
+            assert (np.abs(mid[nz] - fft[nz]) / exact[nz]).max() <= bound + mid_bound
+            assert (np.abs(mid[nz] - exact[nz]) / exact[nz]).max() <= mid_bound
+        # more series than one batch of the fused pass holds rows per split: groups that straddle batches and splits
+        F, E = 8200, 700
+        goff = [0, 1, 130, 700]
+        r = np.cumsum(rng.normal(0, 0.1, (F, 3, E)), axis=0) + rng.uniform(-50, 50, (1, 3, E))
+        ctx.set_option("lag_variant", 1)
+        exact = B.lag_msd(r, F - 1, goff)
+        ctx.set_option("lag_variant", 2)
+        fft = B.lag_msd(r, F - 1, goff)
+        bound = ctx.last_rel_bound()
+        assert ctx.last_kernel_name() == "lag_msd_fft"
+        nz = exact > 0
+        assert (np.abs(fft[nz] - exact[nz]) / exact[nz]).max() <= bound, bound
     finally:
         ctx.set_option("lag_variant", 1)
 

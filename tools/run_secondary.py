@@ -47,6 +47,9 @@ def main():
     what = sys.argv[1]
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     ctx = default_context(0)
+    for kv in os.environ.get("MDHIP_OPTS", "").split():  # (A/B runs: "key=value ..." context options)
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
     dev = torch.device("cuda", 0)
     E, F = 50_000, 5000
     off = np.concatenate([np.arange(0, 40_000, 16), np.arange(40_000, 50_001, 4)]).astype(np.int64)
