@@ -22,7 +22,7 @@ OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libmdhip.so")
 SOURCES = ["mdhip_ctx.hip", "pair_hist.hip", "pair_dense.hip", "pair_cull.hip", "pair_sj.hip", "segment_com.hip", "msd.hip", "msd_fft.hip", "xcorr.hip", "fft_pow2.hip", "scan.hip", "residence.hip",
            "dump_reader.cpp"]
-HEADERS = [os.path.join(CSRC, "ctx.h"), os.path.join(CSRC, "pair_common.h"), os.path.join(CSRC, "msd_fft_w12.h"), os.path.join(os.path.dirname(HERE), "include", "mdhip.h")]
+HEADERS = [os.path.join(CSRC, "ctx.h"), os.path.join(CSRC, "pair_common.h"), os.path.join(CSRC, "msd_fft_w12.h"), os.path.join(CSRC, "msd_fft_w12r.h"), os.path.join(os.path.dirname(HERE), "include", "mdhip.h")]
 ARCH = "gfx950"
 CFLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "--offload-arch=" + ARCH,
           "-Wall", "-Wno-unused-function"]

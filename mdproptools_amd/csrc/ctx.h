@@ -206,6 +206,7 @@ struct mdhip_ctx {
     int opt_seg_frame = 1;    // mdhip_segment_com: one (run, frame) per block, nothing carried between frames (A/B: 0 =
                               // the software-pipelined staged kernel)
     int opt_xcorr_tile = 0;
+    int opt_lag_residue = 1;      // full-lag MSD with 16 384 < F + max_lag <= 24 576: 1 (default) the residue-class kernel (msd_fft_w12r.h), 0 the batched transforms
     int opt_lag_batch_mb = 4096;  // batched full-lag path: device memory of one batch of series (centred series + transform buffers), MB
     int opt_lag_w12_min_f = 1536;  // full-lag MSD with 2048 < F + max_lag <= 8192: from this many frames on the 12288-point
                                    // kernel (msd_fft_w12.h) instead of the 8192-point one; 0 = never, >= 1536

@@ -1661,6 +1661,7 @@ __global__ __launch_bounds__(FT_THREADS) void msd_power_lds3_kernel(
 }
 
 #include "msd_fft_w12.h"
+#include "msd_fft_w12r.h"
 
 // out[s][i] = sum over the items of segment s of part[item][i]
 __global__ void fold_items_kernel(const double *__restrict__ part, const int *__restrict__ seg_item_off,
@@ -2277,6 +2278,151 @@ int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r
     return MDHIP_OK;
 }
 
+// Round 6: series beyond the fused kernels through msd_power_w12r_kernel (msd_fft_w12r.h): padded length L' = 4 x 6144 = 24 576
+// >= F + max_lag, F <= 12 288. The trajectory is transposed and centred batch by batch (transpose_centre64_kernel, as the
+// batched path), every batch's series are dealt to one block per CU, the blocks' partial spectra are folded per segment, and
+// the correlations come from msd_residue_inverse_kernel; the finish is the fused kernels' (lag_finish_dd_kernel).
+int lag_msd_fft_residue(CallScope &cs, long long F, long long E, const double *d_r, double scale, int max_lag, long long G,
+                        const int64_t *group_off, const std::shared_ptr<LagFftResult> &res, double *out, int out_on_device)
+{
+    mdhip_ctx *ctx = cs.ctx;
+    constexpr int D = 4;
+    constexpr long long LP = (long long)D * W12_N, K = LP / 2 + 1;
+    const long long n_lags = (long long)max_lag + 1, cols = 3 * E, S = 3 * G;
+    res->delivered = true;
+    const long long nb_max = std::max<long long>(1, ((long long)ctx->opt_lag_batch_mb << 20) / (F * 8));
+    const long long n_batches = (cols + nb_max - 1) / nb_max;
+    const long long nb0 = (cols + n_batches - 1) / n_batches;
+    // work items, batch by batch: every (segment, batch) overlap gets its share of ~one block per CU
+    std::vector<FftItem> items;
+    struct Fold {
+        long long batch, seg;
+        int first, count;
+    };
+    std::vector<Fold> folds;
+    std::vector<int> batch_off((size_t)n_batches + 1, 0);
+    int max_items = 0;
+    for (long long b = 0; b < n_batches; ++b) {
+        const long long c_first = b * nb0, nb = std::min(nb0, cols - c_first);
+        batch_off[(size_t)b] = (int)items.size();
+        int row = 0;
+        for (long long s = 0; s < S; ++s) {
+            const long long a = s / G, g = s % G;
+            const long long lo = std::max(c_first, a * E + (long long)group_off[g]);
+            const long long hi = std::min(c_first + nb, a * E + (long long)group_off[g + 1]);
+            if (lo >= hi) continue;
+            const long long n = hi - lo;
+            long long k = (n * ctx->cu_count + nb / 2) / nb;
+            k = std::max<long long>(1, std::min(k, n));
+            folds.push_back({b, s, row, (int)k});
+            for (long long q = 0; q < k; ++q)
+                items.push_back({lo - c_first + n * q / k, lo - c_first + n * (q + 1) / k, 1, row++});
+        }
+        max_items = std::max(max_items, row);
+    }
+    batch_off[(size_t)n_batches] = (int)items.size();
+
+    // twiddle table of w_L': B[i] = w^i (i < 256), A[i] = w^(256 i)
+    const int n_tab = 256 + (int)(LP / 256);
+    std::vector<double> tab((size_t)2 * n_tab);
+    const long double step = -2.0L * 3.14159265358979323846264338327950288L / (long double)LP;
+    for (int i = 0; i < n_tab; ++i) {
+        const long long idx = i < 256 ? i : 256LL * (i - 256);
+        tab[2 * i] = (double)cosl(step * idx);
+        tab[2 * i + 1] = (double)sinl(step * idx);
+    }
+
+    MD_WS(d_mean, double, WS_AUX0, (size_t)(MF_SLABS + 1) * cols * 8);
+    double *d_msum = d_mean + cols;
+    MD_WS(d_pad, double, WS_AUX1, (size_t)nb0 * F * 8 + 256);
+    MD_WS(d_part, double, WS_PART, (size_t)max_items * K * 8);
+    const size_t q_b = (size_t)S * F * 8, p_b = (size_t)S * K * 8, c_b = (size_t)S * n_lags * 8;
+    const size_t tab_b = (size_t)n_tab * 16, it_b = (items.size() * sizeof(FftItem) + 15) / 16 * 16;
+    const size_t go_b = (size_t)(G + 1) * 8, ng_b = (size_t)G * 8;
+    MD_WS(d_small, unsigned char, WS_AUX3, q_b + p_b + c_b + tab_b + it_b + go_b + ng_b + 256);
+    double *d_Q = reinterpret_cast<double *>(d_small);
+    double *d_P = reinterpret_cast<double *>(d_small + q_b);
+    double *d_corr = reinterpret_cast<double *>(d_small + q_b + p_b);
+    double2 *d_tab = reinterpret_cast<double2 *>(d_small + q_b + p_b + c_b);
+    FftItem *d_items = reinterpret_cast<FftItem *>(d_small + q_b + p_b + c_b + tab_b);
+    long long *d_goff = reinterpret_cast<long long *>(d_small + q_b + p_b + c_b + tab_b + it_b);
+    double *d_ng = reinterpret_cast<double *>(d_small + q_b + p_b + c_b + tab_b + it_b + go_b);
+    {
+        MD_PIN(h_blk, unsigned char, tab_b + it_b + go_b + ng_b);
+        memcpy(h_blk, tab.data(), tab_b);
+        memcpy(h_blk + tab_b, items.data(), items.size() * sizeof(FftItem));
+        memcpy(h_blk + tab_b + it_b, group_off, go_b);
+        double *h_ng = reinterpret_cast<double *>(h_blk + tab_b + it_b + go_b);
+        for (long long g = 0; g < G; ++g) h_ng[g] = (double)(group_off[g + 1] - group_off[g]);
+        const int rcc = mdhip_copy_small(ctx, d_tab, h_blk, tab_b + it_b + go_b + ng_b, hipMemcpyHostToDevice);
+        if (rcc) return rcc;
+    }
+    MD_HIP(hipMemsetAsync(d_P, 0, p_b, ctx->stream));
+
+    KernelTimer timer(ctx);
+    hipLaunchKernelGGL(col_sum_kernel, dim3((unsigned)((cols + 255) / 256), MF_SLABS), dim3(256), 0, ctx->stream, d_r, F, cols,
+                       d_msum);
+    hipLaunchKernelGGL(col_mean_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, ctx->stream, d_msum, MF_SLABS, F,
+                       cols, scale, d_mean);
+    hipLaunchKernelGGL(frame_sq_kernel, dim3((unsigned)F, 3), dim3(256), 0, ctx->stream, d_r, d_mean, E, scale, d_goff, (int)G,
+                       F, d_Q);
+    MD_HIP(hipGetLastError());
+    const size_t ldsr = w12r_lds_bytes(D);
+    MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msd_power_w12r_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)ldsr));
+    size_t fold_i = 0;
+    for (long long b = 0; b < n_batches; ++b) {
+        const long long c_first = b * nb0, nb = std::min(nb0, cols - c_first);
+        hipLaunchKernelGGL(transpose_centre64_kernel, dim3((unsigned)((nb + 63) / 64), (unsigned)((F + 63) / 64)), dim3(256), 0,
+                           ctx->stream, d_r, d_mean, F, cols, c_first, nb, scale, d_pad);
+        const int n_it = batch_off[(size_t)b + 1] - batch_off[(size_t)b];
+        hipLaunchKernelGGL((msd_power_w12r_kernel<D>), dim3((unsigned)n_it), dim3(W12_THREADS), ldsr, ctx->stream, d_pad, (int)F,
+                           d_items + batch_off[(size_t)b], d_tab, d_part);
+        for (; fold_i < folds.size() && folds[fold_i].batch == b; ++fold_i)
+            hipLaunchKernelGGL(power_fold_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, ctx->stream,
+                               d_part + (size_t)folds[fold_i].first * K, folds[fold_i].count, K, d_P + (size_t)folds[fold_i].seg * K);
+        MD_HIP(hipGetLastError());
+    }
+    const size_t ldsi = (size_t)(LP / 4 + 1 + 4 * 64 * 2) * 8;
+    MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msd_residue_inverse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)ldsi));
+    hipLaunchKernelGGL(msd_residue_inverse_kernel, dim3((unsigned)((n_lags + 63) / 64), (unsigned)S), dim3(256), ldsi, ctx->stream,
+                       d_P, (int)LP, (int)n_lags, d_corr);
+    MD_HIP(hipGetLastError());
+    timer.stop();
+    ctx->last_kernel = "msd_power_w12r_kernel";
+
+    // the finish, on the device, as the fused kernels'
+    const size_t fin_b = (size_t)n_lags * G * 4 * 8;
+    MD_WS(d_fin_ws, unsigned char, WS_OUT3, fin_b + (size_t)(S + 2) * 8 + (size_t)S * (F + 1) * sizeof(DD) + 64);
+    double *d_fin = reinterpret_cast<double *>(d_fin_ws), *d_bound = d_fin + (size_t)n_lags * G * 4;
+    DD *d_pre = reinterpret_cast<DD *>(d_bound + S + 2);
+    const double eps_l = 4.0 * 2.220446049250313e-16 * std::log2((double)LP);
+    hipLaunchKernelGGL(lag_finish_dd_kernel, dim3((unsigned)S), dim3(256), 0, ctx->stream, d_Q, d_corr, n_lags, 1.0, F, n_lags,
+                       (int)G, d_ng, eps_l, d_pre, d_fin, d_bound);
+    hipLaunchKernelGGL(lag_total_kernel, dim3((unsigned)((n_lags * G + 255) / 256)), dim3(256), 0, ctx->stream, d_fin, n_lags * G,
+                       d_bound, (int)S, (const unsigned *)nullptr);
+    ctx->lag_status_dev = d_bound + S;
+    MD_HIP(hipGetLastError());
+    {
+        const int rcr = mdhip_result(cs, out, d_fin, fin_b, out_on_device);
+        if (rcr) return rcr;
+    }
+    MD_PIN(h_bound, double, (size_t)S * 8);
+    {
+        const int rcc = mdhip_copy_small(ctx, h_bound, d_bound, (size_t)S * 8, hipMemcpyDeviceToHost);
+        if (rcc) return rcc;
+    }
+    cs.defer([timer, res, h_bound, S]() {
+        timer.collect();
+        double worst = 0.0;
+        for (long long q = 0; q < S; ++q) worst = std::max(worst, h_bound[q]);
+        res->bound = worst;
+        return MDHIP_OK;
+    });
+    return MDHIP_OK;
+}
+
 }  // namespace
 
 // d_r: device [F][3][E]. out: host [max_lag+1][G][4] means as mdhip_lag_msd. *rel_bound: the largest
@@ -2316,6 +2462,10 @@ int mdhip_lag_msd_fft(CallScope &cs, int64_t n_frames, int64_t n_ent, const doub
             return lag_msd_fft_fused(cs, F, E, d_r, scale, max_lag, G, group_off, m, res, out, out_on_device);
         }
     }
+    // round 6: 16 384 < F + max_lag <= 24 576 (F <= 12 288) in residue classes of a 4 x 6144-point transform, no pass through HBM
+    if (ctx->opt_lag_variant != 4 && ctx->opt_lag_residue != 0 && F + max_lag <= 4LL * W12_N && F <= 2LL * W12_N &&
+        w12r_lds_bytes(4) <= ctx->lds_max)
+        return lag_msd_fft_residue(cs, F, E, d_r, scale, max_lag, G, group_off, res, out, out_on_device);
     const long long L = pow2_length(F + max_lag);
     MD_REQUIRE(L < (1LL << 30), "series too long for the FFT path (%lld)", L);
     // (round 6: this path finishes on the device as well — lag_finish_dd_kernel on Q and the correlations where they are —

@@ -1,0 +1,339 @@
+// msd_fft_w12r.h — included by msd_fft.hip inside its anonymous namespace, behind msd_fft_w12.h.
+//
+// Round 6: the power spectra of series LONGER than the fused kernels hold (F + max_lag > 16 384), without transform passes
+// through HBM. The padded length is L' = D x 6144 (D = 4: 24 576 >= F + max_lag, F <= 12 288 — BASELINE's C4 shape at 10 000
+// frames), and the spectrum is computed one RESIDUE CLASS of frequencies at a time:
+//     X[D j + r] = sum_{n < 6144} y_r[n] w_6144^(n j),     y_r[n] = w_L'^(r n) sum_q x[n + 6144 q] w_D^(r q)
+// — a 6144-point complex transform per class, exactly the size msd_power_w12_kernel's machinery (twelve register-resident
+// 512-point sub-transforms, one per wave) was built for. x is real, so |X[L' - k]|^2 = |X[k]|^2: the classes r = 0 .. D/2
+// cover every frequency 0 .. L'/2 (r = 0 and r = D/2 twice: their upper halves are dropped). Nothing is untangled and no
+// wave reads another's results: the sums are |Y_r[j]|^2 in the lane that holds Y_r[j].
+// Per series and class, three block barriers (msd_power_w12_kernel's structure):
+//   inputs     all 12 waves, 8 points per lane: y_r[n] from the lane's samples x[n + 6144 q], n = tid + 768 i (loaded once
+//              per series, coalesced from the time-major centred copy, kept in registers for every class), times the part of
+//              the class twiddle that depends on e = n div 512 (w_L'^(512 r e), a table of 12 D-th roots) -> region e, position j;
+//   -- barrier --
+//   head       waves 0 .. 7, lane = position j < 512: the radix-12 butterfly over the regions, in place;
+//   -- barrier --
+//   wave d     msd_power_w12_kernel's three register passes over its region; the twiddles of the head (w_6144^(j d)) AND the rest of
+//              the class twiddle (w_L'^(r j)) ride in its two factors: the per-register one from a table [class][d][n2], the
+//              per-lane one folded into the first pass's twiddle chain; |Y|^2 into the class's 8 accumulators;
+//   -- barrier --
+// The frequencies are sorted out once per block (Ppart [rows][L'/2 + 1]); msd_residue_inverse_kernel turns the folded spectra
+// into correlations by direct summation in double-double (a handful of segments: 12 288 terms per lag).
+
+#ifndef W12R_EXP
+#define W12R_EXP 0  // timing experiments only (WRONG results): 1 no input stage, 2 no head, 4 no register passes
+#endif
+
+template <int K, int DD>
+__device__ __forceinline__ Cx w12r_root_mul(double a)  // a * w_DD^K (a real), DD = 4 or 8
+{
+    constexpr int k = ((K % DD) + DD) % DD;
+    constexpr double H = 0.70710678118654752440;
+    if constexpr (DD == 4) {
+        if constexpr (k == 0) return {a, 0.0};
+        else if constexpr (k == 1) return {0.0, -a};
+        else if constexpr (k == 2) return {-a, 0.0};
+        else return {0.0, a};
+    } else {
+        if constexpr (k == 0) return {a, 0.0};
+        else if constexpr (k == 1) return {a * H, -a * H};
+        else if constexpr (k == 2) return {0.0, -a};
+        else if constexpr (k == 3) return {-a * H, -a * H};
+        else if constexpr (k == 4) return {-a, 0.0};
+        else if constexpr (k == 5) return {-a * H, a * H};
+        else if constexpr (k == 6) return {0.0, a};
+        else return {a * H, a * H};
+    }
+}
+
+// The 3-point DFT (w_3 = e^{-2 pi i / 3})
+__device__ __forceinline__ void w12r_dft3(Cx a, Cx b, Cx c, Cx &y0, Cx &y1, Cx &y2)
+{
+    constexpr double S60 = 0.86602540378443864676;
+    const Cx t1 = cx_add(b, c);
+    const Cx t2 = {a.x - 0.5 * t1.x, a.y - 0.5 * t1.y};
+    const Cx t3 = {S60 * (b.x - c.x), S60 * (b.y - c.y)};
+    y0 = cx_add(a, t1);
+    y1 = {t2.x + t3.y, t2.y - t3.x};
+    y2 = {t2.x - t3.y, t2.y + t3.x};
+}
+
+// The full 12-point DFT of position j over the regions, in place, by the prime-factor map 12 = 3 x 4 (no twiddles between the
+// two stages): input n = (4 n1 + 3 n2) mod 12, output k = (4 k1 + 9 k2) mod 12 — four 3-point and three 4-point transforms,
+// ~100 additions and 8 multiplications (the three pruned radix-12 butterflies of msd_power_w12_kernel's head, unpruned: ~300).
+__device__ __forceinline__ void w12r_dft12(double2 *col)  // col = R + j: element e at col[e * W12_RS]
+{
+    Cx t[3][4];
+    {
+        const Cx a = w12_ld(col), b = w12_ld(col + 4 * W12_RS), c = w12_ld(col + 8 * W12_RS);
+        w12r_dft3(a, b, c, t[0][0], t[1][0], t[2][0]);
+    }
+    {
+        const Cx a = w12_ld(col + 3 * W12_RS), b = w12_ld(col + 7 * W12_RS), c = w12_ld(col + 11 * W12_RS);
+        w12r_dft3(a, b, c, t[0][1], t[1][1], t[2][1]);
+    }
+    {
+        const Cx a = w12_ld(col + 6 * W12_RS), b = w12_ld(col + 10 * W12_RS), c = w12_ld(col + 2 * W12_RS);
+        w12r_dft3(a, b, c, t[0][2], t[1][2], t[2][2]);
+    }
+    {
+        const Cx a = w12_ld(col + 9 * W12_RS), b = w12_ld(col + 1 * W12_RS), c = w12_ld(col + 5 * W12_RS);
+        w12r_dft3(a, b, c, t[0][3], t[1][3], t[2][3]);
+    }
+    Cx o[4];
+    dft4(t[0][0], t[0][1], t[0][2], t[0][3], o[0], o[1], o[2], o[3]);  // k = 0, 9, 6, 3
+    w12_st(col, o[0]);
+    w12_st(col + 9 * W12_RS, o[1]);
+    w12_st(col + 6 * W12_RS, o[2]);
+    w12_st(col + 3 * W12_RS, o[3]);
+    dft4(t[1][0], t[1][1], t[1][2], t[1][3], o[0], o[1], o[2], o[3]);  // k = 4, 1, 10, 7
+    w12_st(col + 4 * W12_RS, o[0]);
+    w12_st(col + 1 * W12_RS, o[1]);
+    w12_st(col + 10 * W12_RS, o[2]);
+    w12_st(col + 7 * W12_RS, o[3]);
+    dft4(t[2][0], t[2][1], t[2][2], t[2][3], o[0], o[1], o[2], o[3]);  // k = 8, 5, 2, 11
+    w12_st(col + 8 * W12_RS, o[0]);
+    w12_st(col + 5 * W12_RS, o[1]);
+    w12_st(col + 2 * W12_RS, o[2]);
+    w12_st(col + 11 * W12_RS, o[3]);
+}
+
+// LDS: regions | two-level table of w_L' ([256] w^i, [L'/256] w^(256 i)) | class tables [NCLS][12][8] | w_512^lane [64] |
+// w_64^(n0 k1) [8][9] | head roots w_(12 D)^m [12 D] | the sums of class 0 [8][768] (the registers hold the other classes')
+inline size_t w12r_lds_bytes(int D)
+{
+    const int ncls = D / 2 + 1;
+    return (size_t)W12_NW * W12_RS * 16 + (size_t)(256 + D * W12_N / 256) * 16 + (size_t)ncls * W12_NW * 8 * 16 + (64 + 72) * 16 +
+           (size_t)12 * D * 16 + (size_t)8 * W12_THREADS * 8;
+}
+
+// x: the time-major centred copy [rows][F] of a batch of series (scaled); items: row ranges [c_lo, c_hi) of it, one block
+// each; tab2: [256] w_L'^i | [L'/256] w_L'^(256 i); Ppart [items][L'/2 + 1].
+template <int D>
+__global__ __launch_bounds__(W12_THREADS) void msd_power_w12r_kernel(const double *__restrict__ x, int F,
+                                                                     const FftItem *__restrict__ items,
+                                                                     const double2 *__restrict__ tab2,
+                                                                     double *__restrict__ Ppart)
+{
+    constexpr int N = W12_N, RS = W12_RS, NCLS = D / 2 + 1, NQ = D / 2, LP = D * N, NA = LP / 256;
+    extern __shared__ double ft_lds[];
+    double2 *R = reinterpret_cast<double2 *>(ft_lds);
+    double2 *tB = R + W12_NW * RS, *tA = tB + 256;
+    double2 *btab = tA + NA;                   // [cls][d][n2] = w_N^(64 d n2) w_L'^(64 cls n2)
+    double2 *t1tab = btab + NCLS * W12_NW * 8;  // [lane] = w_512^lane
+    double2 *t2tab = t1tab + 64;               // [9 n0 + k1] = w_64^(n0 k1)
+    double2 *ctab = t2tab + 72;                // [m] = w_(12 D)^m = w_L'^(512 m)
+    double *sacc0 = reinterpret_cast<double *>(ctab + 12 * D);  // [k0][tid]: class 0's sums (the kernel is short of registers)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int i = tid; i < 256 + NA; i += W12_THREADS) tB[i] = tab2[i];
+    const FftItem it = items[blockIdx.x];
+    __syncthreads();
+    auto tw2 = [&](int k) {  // w_L'^k, 0 <= k < L'
+        const double2 a = tA[k >> 8], b = tB[k & 255];
+        return Cx{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+    };
+    auto twn = [&](long long k) { return tw2((int)((k % (2 * N)) * (D / 2))); };  // w_(2 N)^k
+    for (int i = tid; i < NCLS * W12_NW * 8; i += W12_THREADS) {
+        const int cls = i / (W12_NW * 8), d = (i >> 3) % W12_NW, n2 = i & 7;
+        const Cx w = cx_mul(twn(128LL * d * n2), tw2(64 * cls * n2));
+        btab[i] = make_double2(w.x, w.y);
+    }
+    for (int i = tid; i < 64 + 72 + 12 * D; i += W12_THREADS) {
+        Cx w;
+        if (i < 64) w = twn(24LL * i);
+        else if (i < 64 + 72) w = twn(192LL * ((i - 64) / 9) * ((i - 64) % 9));
+        else w = tw2(512 * (i - 64 - 72));
+        t1tab[i] = make_double2(w.x, w.y);
+    }
+    // per-lane factor of the twiddles that sit between the head and the first register pass: w_N^(lane d); the class's
+    // w_L'^(cls lane) comes from the table where it is used (w_L'^i, i < 256)
+    const Cx tw_a = twn(2LL * lane * wv);
+    double sacc[NCLS - 1][8];  // classes 1 .. NCLS - 1
+#pragma unroll
+    for (int cls = 0; cls < NCLS - 1; ++cls)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sacc[cls][i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sacc0[i * W12_THREADS + tid] = 0.0;
+    // this lane's samples of the series: x[n + 6144 q], n = tid + 768 i (loaded once per series, used by every class)
+    double xs[8][NQ];
+    auto fetch = [&](long long c) {
+        const double *row = x + (size_t)c * F;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int t = tid + W12_THREADS * i + N * q;
+                xs[i][q] = t < F ? __builtin_nontemporal_load(row + t) : 0.0;
+            }
+    };
+    double2 *myR = R + wv * RS;
+    const int hj = (wv & 7) * 64 + lane;  // the head's position j (waves 0 .. 7)
+    __syncthreads();
+    if (it.c_lo < it.c_hi) fetch(it.c_lo);
+    for (long long c = it.c_lo; c < it.c_hi; ++c) {
+        const bool more = c + 1 < it.c_hi;
+        // (the tables' addresses through an opaque copy per series: their entries are the same for every series, and hoisted
+        // out of the loop they would take a hundred registers)
+        const double2 *ctab_s = ctab, *btab_s = btab, *tB_s = tB;
+        asm volatile("" : "+v"(ctab_s), "+v"(btab_s), "+v"(tB_s));
+        auto one_class = [&](auto ck) {
+            constexpr int cls = decltype(ck)::value;
+            // ---- the class's inputs y_cls[n] (but for the factor w_L'^(cls j), which rides in the register passes) ----
+#pragma unroll
+            for (int i = 0; i < ((W12R_EXP & 1) ? 1 : 8); ++i) {
+                const int n = tid + W12_THREADS * i, e = n >> 9, j = n & 511;
+                // sum_q x[n + 6144 q] w_D^(cls q)
+                Cx s = {xs[i][0], 0.0};
+                if constexpr (NQ > 1) s = cx_add(s, w12r_root_mul<cls, D>(xs[i][1]));
+                if constexpr (NQ > 2) s = cx_add(s, w12r_root_mul<2 * cls, D>(xs[i][2]));
+                if constexpr (NQ > 3) s = cx_add(s, w12r_root_mul<3 * cls, D>(xs[i][3]));
+                if constexpr (cls != 0) s = cx_mul(s, w12_ld(ctab_s + cls * e));
+                w12_st(R + e * RS + j, s);
+            }
+            if constexpr (cls == NCLS - 1) {
+                if (more) fetch(c + 1);  // (the samples are consumed: the next series' land under the passes)
+            }
+            __syncthreads();
+            // ---- head: waves 0 .. 7, the radix-12 butterfly of position j in place ----
+            if (wv < 8 && !(W12R_EXP & 2)) w12r_dft12(R + hj);
+            __syncthreads();
+            // ---- this wave's 512-point sub-transform, in registers (msd_power_w12_kernel) ----
+            Cx a[8];
+#pragma unroll
+            for (int n2 = 0; n2 < 8; ++n2) a[n2] = w12_ld(myR + lane + 64 * n2);
+            if (!(W12R_EXP & 4)) {
+            if (wv != 0 || cls != 0) {
+#pragma unroll
+                for (int n2 = 1; n2 < 8; ++n2) a[n2] = cx_mul(a[n2], w12_ld(btab_s + (cls * W12_NW + wv) * 8 + n2));
+            }
+            f2_bfly8(a, Cx{1.0, 0.0}, false);
+            {
+                const Cx tw_1 = w12_ld(t1tab + lane);
+                Cx t = tw_a;
+                if constexpr (cls != 0) t = cx_mul(t, w12_ld(tB_s + cls * lane));
+                a[0] = cx_mul(a[0], t);
+#pragma unroll
+                for (int k2 = 1; k2 < 8; ++k2) {
+                    t = cx_mul(t, tw_1);
+                    a[k2] = cx_mul(a[k2], t);
+                }
+            }
+            // exchange 1: (n0, n1 | k2) -> (n0, k2 | n1): point n0 + 8 k2 + 64 n1
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) w12_st(myR + (lane & 7) + 8 * k2 + 64 * (lane >> 3), a[k2]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int n1 = 0; n1 < 8; ++n1) a[n1] = w12_ld(myR + lane + 64 * n1);
+            f2_bfly8(a, Cx{1.0, 0.0}, false);
+            {
+                const double2 *t2 = t2tab + 9 * (lane & 7);
+#pragma unroll
+                for (int k1 = 1; k1 < 8; ++k1) a[k1] = cx_mul(a[k1], w12_ld(t2 + k1));
+            }
+            // exchange 2: (n0, k2 | k1) -> (k1, k2 | n0): point k1 + 8 k2 + 65 n0
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k1 = 0; k1 < 8; ++k1) w12_st(myR + k1 + 8 * (lane >> 3) + 65 * (lane & 7), a[k1]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int n0 = 0; n0 < 8; ++n0) a[n0] = w12_ld(myR + lane + 65 * n0);
+            f2_bfly8(a, Cx{1.0, 0.0}, false);
+            }
+            // a[k0] = Y_cls at j = d + 12 (k2 + 8 k1 + 64 k0), lane = k1 + 8 k2
+            if constexpr (cls == 0) {
+#pragma unroll
+                for (int k0 = 0; k0 < 8; ++k0) {
+                    double v = sacc0[k0 * W12_THREADS + tid];
+                    v = __builtin_fma(a[k0].x, a[k0].x, v);
+                    v = __builtin_fma(a[k0].y, a[k0].y, v);
+                    sacc0[k0 * W12_THREADS + tid] = v;
+                }
+            } else {
+#pragma unroll
+                for (int k0 = 0; k0 < 8; ++k0) {
+                    sacc[cls - 1][k0] = __builtin_fma(a[k0].x, a[k0].x, sacc[cls - 1][k0]);
+                    sacc[cls - 1][k0] = __builtin_fma(a[k0].y, a[k0].y, sacc[cls - 1][k0]);
+                }
+            }
+            __syncthreads();
+        };
+        one_class(std::integral_constant<int, 0>());
+        one_class(std::integral_constant<int, 1>());
+        one_class(std::integral_constant<int, 2>());
+        if constexpr (NCLS > 3) {
+            one_class(std::integral_constant<int, 3>());
+            one_class(std::integral_constant<int, (NCLS > 3 ? 4 : 0)>());
+        }
+    }
+    // frequencies: class r, j = d + 12 k' -> k = D j + r, or its mirror L' - k (r = 0 and r = D/2 hold both: the upper one is dropped)
+    double *pp = Ppart + (size_t)it.row * (LP / 2 + 1);
+#pragma unroll
+    for (int cls = 0; cls < NCLS; ++cls) {
+#pragma unroll
+        for (int k0 = 0; k0 < 8; ++k0) {
+            const int kp = (lane >> 3) + 8 * (lane & 7) + 64 * k0;  // k' = k2 + 8 k1 + 64 k0
+            const int k = D * (wv + W12_NW * kp) + cls;
+            const double v = cls == 0 ? sacc0[k0 * W12_THREADS + tid] : sacc[cls == 0 ? 0 : cls - 1][k0];
+            if (k <= LP / 2) pp[k] = v;
+            else if (cls != 0 && cls != D / 2) pp[LP - k] = v;
+        }
+    }
+}
+
+// corr[s][k] = (1 / L') sum_{f < L'} P_s[f] e^{2 pi i f k / L'}, P_s[L' - f] = P_s[f] given for f = 0 .. L'/2, k < n_lags — by direct
+// summation: lane = one lag, the four waves of a block take a quarter of the frequencies each; cos from a quarter-wave table
+// in LDS (L'/4 + 1 entries, cospi of 2 m / L'); products and sums in double-double (two_prod by fma, two_sum), so that the
+// 12 288 terms cost no accuracy against a transform's log2 L' stages. grid (ceil(n_lags / 64), S), 256 lanes.
+__global__ __launch_bounds__(256) void msd_residue_inverse_kernel(const double *__restrict__ P, int LP, int n_lags,
+                                                                  double *__restrict__ corr)
+{
+#pragma clang fp contract(off)  // (the two-sums below take a product: a fused multiply-add would break their error terms)
+    extern __shared__ double ft_lds[];
+    double *qt = ft_lds;                 // [LP / 4 + 1]
+    double *red = qt + LP / 4 + 1;       // [4][64][2]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, H = LP / 2, Q4 = LP / 4;
+    for (int m = tid; m <= Q4; m += 256) qt[m] = cospi(2.0 * (double)m / (double)LP);
+    __syncthreads();
+    const double *p = P + (size_t)blockIdx.y * (H + 1);
+    const int k = blockIdx.x * 64 + lane;
+    // frequencies f = 1 .. H - 1 in four parts
+    const int f0 = 1 + (H - 1) * wv / 4, f1 = 1 + (H - 1) * (wv + 1) / 4;
+    long long idx = ((long long)f0 * (long long)k) % LP;
+    double hi = 0.0, lo = 0.0;
+    for (int f = f0; f < f1; ++f) {
+        int m = (int)idx;
+        if (m > H) m = LP - m;
+        const double cv = m > Q4 ? -qt[H - m] : qt[m];
+        const double pv = p[f];
+        const double ph = pv * cv, pl = __builtin_fma(pv, cv, -ph);
+        const double s = hi + ph, bb = s - hi;
+        const double err = (hi - (s - bb)) + (ph - bb);
+        hi = s;
+        lo += err + pl;
+        idx += k;
+        if (idx >= LP) idx -= LP;
+    }
+    red[(wv * 64 + lane) * 2] = hi;
+    red[(wv * 64 + lane) * 2 + 1] = lo;
+    __syncthreads();
+    if (wv == 0 && k < n_lags) {
+        double sh = 0.0, sl = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const double ah = red[(w * 64 + lane) * 2], al = red[(w * 64 + lane) * 2 + 1];
+            const double s = sh + ah, bb = s - sh;
+            sl += ((sh - (s - bb)) + (ah - bb)) + al;
+            sh = s;
+        }
+        const double edge = p[0] + ((k & 1) ? -p[H] : p[H]);
+        corr[(size_t)blockIdx.y * n_lags + k] = (edge + 2.0 * (sh + sl)) / (double)LP;
+    }
+}

@@ -531,7 +531,9 @@ def test_lag_msd_long_series_finish_on_the_device(B):
             bound = ctx.last_rel_bound()
             # (the bound is relative to the SMALLEST |MSD sum| over the lags: with max_lag ~ F the last lags hold one or two
             # origins of two entities, so it is far looser here than at C4 — what is tested is that the result respects it)
-            assert ctx.last_kernel_name() == "lag_msd_fft" and 0.0 < bound < 1e-4, (ctx.last_kernel_name(), bound)
+            # (round 6: up to F + max_lag = 24 576 the residue-class kernel, beyond it the batched transforms)
+            want_kernel = "msd_power_w12r_kernel" if F + max_lag <= 24576 and F <= 12288 else "lag_msd_fft"
+            assert ctx.last_kernel_name() == want_kernel and 0.0 < bound < 1e-4, (ctx.last_kernel_name(), bound)
             assert (fft[0] == 0.0).all()
             nz = exact > 0
             rel = np.abs(fft[nz] - exact[nz]) / exact[nz]
@@ -555,6 +557,13 @@ def test_lag_msd_long_series_finish_on_the_device(B):
             # (`lag_batched_fuse` 0): identical bits. The default (2: two passes, the second fused with the reduction) runs
             # another butterfly network and adds the rows in another order: equal within the bounds.
             try:
+                ctx.set_option("lag_residue", 0)
+                ctx.set_option("lag_batched_fuse", 2)
+                two = B.lag_msd(r, max_lag, goff, scale=0.5)
+                two_bound = ctx.last_rel_bound()
+                assert ctx.last_kernel_name() == "lag_msd_fft"
+                assert (np.abs(two[nz] - fft[nz]) / exact[nz]).max() <= bound + two_bound
+                assert (np.abs(two[nz] - exact[nz]) / exact[nz]).max() <= two_bound
                 ctx.set_option("lag_batched_fuse", 0)
                 old = B.lag_msd(r, max_lag, goff, scale=0.5)
                 ctx.set_option("lag_batched_fuse", 1)
@@ -562,21 +571,31 @@ def test_lag_msd_long_series_finish_on_the_device(B):
                 mid_bound = ctx.last_rel_bound()
             finally:
                 ctx.set_option("lag_batched_fuse", -1)
+                ctx.set_option("lag_residue", -1)
             np.testing.assert_array_equal(old, mid)
             assert (np.abs(mid[nz] - fft[nz]) / exact[nz]).max() <= bound + mid_bound
             assert (np.abs(mid[nz] - exact[nz]) / exact[nz]).max() <= mid_bound
-        # more series than one batch of the fused pass holds rows per split: groups that straddle batches and splits
-        F, E = 8200, 700
-        goff = [0, 1, 130, 700]
-        r = np.cumsum(rng.normal(0, 0.1, (F, 3, E)), axis=0) + rng.uniform(-50, 50, (1, 3, E))
-        ctx.set_option("lag_variant", 1)
-        exact = B.lag_msd(r, F - 1, goff)
-        ctx.set_option("lag_variant", 2)
-        fft = B.lag_msd(r, F - 1, goff)
-        bound = ctx.last_rel_bound()
-        assert ctx.last_kernel_name() == "lag_msd_fft"
-        nz = exact > 0
-        assert (np.abs(fft[nz] - exact[nz]) / exact[nz]).max() <= bound, bound
+        # more series than one batch holds / than the fused pass has rows per split: groups that straddle batches, splits and
+        # blocks — both long-series paths (the residue-class kernel; the batched transforms), small batches forced
+        for F, E, goff, mb in ((8200, 700, [0, 1, 130, 700], -1), (8193, 300, [0, 300], 1), (12288, 40, [0, 7, 7, 40], 1),
+                               (11111, 130, [0, 64, 65, 130], 2)):
+            r = np.cumsum(rng.normal(0, 0.1, (F, 3, E)), axis=0) + rng.uniform(-50, 50, (1, 3, E))
+            ctx.set_option("lag_variant", 1)
+            exact = B.lag_msd(r, F - 1, goff)
+            nz = exact > 0
+            ctx.set_option("lag_variant", 2)
+            try:
+                ctx.set_option("lag_batch_mb", mb)
+                for residue, name in ((1, "msd_power_w12r_kernel"), (0, "lag_msd_fft")):
+                    ctx.set_option("lag_residue", residue)
+                    fft = B.lag_msd(r, F - 1, goff)
+                    bound = ctx.last_rel_bound()
+                    assert ctx.last_kernel_name() == name, (F, ctx.last_kernel_name())
+                    assert (np.abs(fft[nz] - exact[nz]) / exact[nz]).max() <= bound, (F, E, residue, bound)
+                    assert (fft[~nz] == 0.0).all()
+            finally:
+                ctx.set_option("lag_batch_mb", -1)
+                ctx.set_option("lag_residue", -1)
     finally:
         ctx.set_option("lag_variant", 1)
 
