@@ -144,6 +144,47 @@ __global__ __launch_bounds__(256) void transpose_centre64_kernel(const double *_
     }
 }
 
+// transpose_centre64_kernel for the columns [c_first, c_first + nb) of ONE (axis, group) segment, with the squares of the
+// centred values added per frame on the way: Qpart[tile][t] = sum over the tile's (at most 64) series of ser[.][t]^2, tile =
+// blockIdx.x = TSQ_TILES tiles of 64 columns (the residue-class path: frame_sq_kernel read the whole trajectory once more for the same sums).
+// ser row of column c: c - c_first + row0.
+constexpr int TSQ_TILES = 8;  // tiles of 64 columns per block
+__global__ __launch_bounds__(256) void transpose_centre64_sq_kernel(const double *__restrict__ r,
+                                                                    const double *__restrict__ mean, long long F,
+                                                                    long long cols, long long c_first, long long nb, long long row0,
+                                                                    double scale, double *__restrict__ ser,
+                                                                    double *__restrict__ Qpart)
+{
+    __shared__ double tile[64][65];
+    __shared__ double red[4][64];
+    const long long t0 = (long long)blockIdx.y * 64, c_end = c_first + nb;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+    double sq = 0.0;  // frame t0 + tx, series c0 + ty, + 4, ...: zeros beyond the segment and the trajectory
+    for (int ti = 0; ti < TSQ_TILES; ++ti) {  // (several tiles of columns per block: as many times fewer rows to fold)
+        const long long c0 = c_first + ((long long)blockIdx.x * TSQ_TILES + ti) * 64;
+        if (c0 >= c_end) break;
+        const long long cc_in = c0 + tx;
+        const double m = cc_in < c_end ? mean[cc_in] : 0.0;
+        if (ti) __syncthreads();
+#pragma unroll 4
+        for (int k = ty; k < 64; k += 4) {
+            const long long tt = t0 + k;
+            tile[k][tx] = (tt < F && cc_in < c_end) ? __builtin_nontemporal_load(r + tt * cols + cc_in) * scale - m : 0.0;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int k = ty; k < 64; k += 4) {
+            const long long cc = c0 + k, tt = t0 + tx;
+            const double v = tile[tx][k];
+            sq = __builtin_fma(v, v, sq);
+            if (tt < F && cc < c_end) __builtin_nontemporal_store(v, ser + (size_t)(cc - c_first + row0) * F + tt);
+        }
+    }
+    red[ty][tx] = sq;
+    __syncthreads();
+    if (ty == 0 && t0 + tx < F) Qpart[(size_t)blockIdx.x * F + t0 + tx] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+}
+
 // partial[split][k] = sum over the split's rows of |spec[row][k]|^2
 __global__ __launch_bounds__(256) void power_rows_kernel(const double2 *__restrict__ spec, long long K,
                                                          long long row0, long long row1,
@@ -2296,12 +2337,13 @@ int lag_msd_fft_residue(CallScope &cs, long long F, long long E, const double *d
     // work items, batch by batch: every (segment, batch) overlap gets its share of ~one block per CU
     std::vector<FftItem> items;
     struct Fold {
-        long long batch, seg;
-        int first, count;
+        long long batch, seg, c_lo, c_n;  // the segment's columns inside the batch
+        int first, count;                 // its rows of the blocks' partial spectra
     };
     std::vector<Fold> folds;
     std::vector<int> batch_off((size_t)n_batches + 1, 0);
     int max_items = 0;
+    long long max_tiles = 1;
     for (long long b = 0; b < n_batches; ++b) {
         const long long c_first = b * nb0, nb = std::min(nb0, cols - c_first);
         batch_off[(size_t)b] = (int)items.size();
@@ -2314,7 +2356,8 @@ int lag_msd_fft_residue(CallScope &cs, long long F, long long E, const double *d
             const long long n = hi - lo;
             long long k = (n * ctx->cu_count + nb / 2) / nb;
             k = std::max<long long>(1, std::min(k, n));
-            folds.push_back({b, s, row, (int)k});
+            folds.push_back({b, s, lo, n, row, (int)k});
+            max_tiles = std::max(max_tiles, (n + 64 * TSQ_TILES - 1) / (64 * TSQ_TILES));
             for (long long q = 0; q < k; ++q)
                 items.push_back({lo - c_first + n * q / k, lo - c_first + n * (q + 1) / k, 1, row++});
         }
@@ -2336,6 +2379,7 @@ int lag_msd_fft_residue(CallScope &cs, long long F, long long E, const double *d
     double *d_msum = d_mean + cols;
     MD_WS(d_pad, double, WS_AUX1, (size_t)nb0 * F * 8 + 256);
     MD_WS(d_part, double, WS_PART, (size_t)max_items * K * 8);
+    MD_WS(d_qpart, double, WS_AUX2, (size_t)max_tiles * F * 8);
     const size_t q_b = (size_t)S * F * 8, p_b = (size_t)S * K * 8, c_b = (size_t)S * n_lags * 8;
     const size_t tab_b = (size_t)n_tab * 16, it_b = (items.size() * sizeof(FftItem) + 15) / 16 * 16;
     const size_t go_b = (size_t)(G + 1) * 8, ng_b = (size_t)G * 8;
@@ -2347,6 +2391,7 @@ int lag_msd_fft_residue(CallScope &cs, long long F, long long E, const double *d
     FftItem *d_items = reinterpret_cast<FftItem *>(d_small + q_b + p_b + c_b + tab_b);
     long long *d_goff = reinterpret_cast<long long *>(d_small + q_b + p_b + c_b + tab_b + it_b);
     double *d_ng = reinterpret_cast<double *>(d_small + q_b + p_b + c_b + tab_b + it_b + go_b);
+    (void)d_goff;
     {
         MD_PIN(h_blk, unsigned char, tab_b + it_b + go_b + ng_b);
         memcpy(h_blk, tab.data(), tab_b);
@@ -2357,15 +2402,13 @@ int lag_msd_fft_residue(CallScope &cs, long long F, long long E, const double *d
         const int rcc = mdhip_copy_small(ctx, d_tab, h_blk, tab_b + it_b + go_b + ng_b, hipMemcpyHostToDevice);
         if (rcc) return rcc;
     }
-    MD_HIP(hipMemsetAsync(d_P, 0, p_b, ctx->stream));
+    MD_HIP(hipMemsetAsync(d_Q, 0, q_b + p_b, ctx->stream));  // (Q | P: both are added to, batch by batch)
 
     KernelTimer timer(ctx);
     hipLaunchKernelGGL(col_sum_kernel, dim3((unsigned)((cols + 255) / 256), MF_SLABS), dim3(256), 0, ctx->stream, d_r, F, cols,
                        d_msum);
     hipLaunchKernelGGL(col_mean_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, ctx->stream, d_msum, MF_SLABS, F,
                        cols, scale, d_mean);
-    hipLaunchKernelGGL(frame_sq_kernel, dim3((unsigned)F, 3), dim3(256), 0, ctx->stream, d_r, d_mean, E, scale, d_goff, (int)G,
-                       F, d_Q);
     MD_HIP(hipGetLastError());
     const size_t ldsr = w12r_lds_bytes(D);
     MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msd_power_w12r_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2373,8 +2416,15 @@ int lag_msd_fft_residue(CallScope &cs, long long F, long long E, const double *d
     size_t fold_i = 0;
     for (long long b = 0; b < n_batches; ++b) {
         const long long c_first = b * nb0, nb = std::min(nb0, cols - c_first);
-        hipLaunchKernelGGL(transpose_centre64_kernel, dim3((unsigned)((nb + 63) / 64), (unsigned)((F + 63) / 64)), dim3(256), 0,
-                           ctx->stream, d_r, d_mean, F, cols, c_first, nb, scale, d_pad);
+        // the batch's series, segment by segment (a tile's per-frame squares belong to one segment), and S1's terms with them
+        for (size_t fi = fold_i; fi < folds.size() && folds[fi].batch == b; ++fi) {
+            const long long lo = folds[fi].c_lo, n = folds[fi].c_n, tiles = (n + 64 * TSQ_TILES - 1) / (64 * TSQ_TILES);
+            hipLaunchKernelGGL(transpose_centre64_sq_kernel, dim3((unsigned)tiles, (unsigned)((F + 63) / 64)), dim3(256), 0,
+                               ctx->stream, d_r, d_mean, F, cols, lo, n, lo - c_first, scale, d_pad, d_qpart);
+            hipLaunchKernelGGL(power_fold_kernel, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, ctx->stream, d_qpart, (int)tiles,
+                               F, d_Q + (size_t)folds[fi].seg * F);
+        }
+        (void)nb;
         const int n_it = batch_off[(size_t)b + 1] - batch_off[(size_t)b];
         hipLaunchKernelGGL((msd_power_w12r_kernel<D>), dim3((unsigned)n_it), dim3(W12_THREADS), ldsr, ctx->stream, d_pad, (int)F,
                            d_items + batch_off[(size_t)b], d_tab, d_part);
@@ -2383,10 +2433,10 @@ int lag_msd_fft_residue(CallScope &cs, long long F, long long E, const double *d
                                d_part + (size_t)folds[fold_i].first * K, folds[fold_i].count, K, d_P + (size_t)folds[fold_i].seg * K);
         MD_HIP(hipGetLastError());
     }
-    const size_t ldsi = (size_t)(LP / 4 + 1 + 4 * 64 * 2) * 8;
+    const size_t ldsi = (size_t)(LP / 4 + 1 + RI_WAVES * 64 * 2) * 8;
     MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msd_residue_inverse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)ldsi));
-    hipLaunchKernelGGL(msd_residue_inverse_kernel, dim3((unsigned)((n_lags + 63) / 64), (unsigned)S), dim3(256), ldsi, ctx->stream,
+    hipLaunchKernelGGL(msd_residue_inverse_kernel, dim3((unsigned)((n_lags + 63) / 64), (unsigned)S), dim3(64 * RI_WAVES), ldsi, ctx->stream,
                        d_P, (int)LP, (int)n_lags, d_corr);
     MD_HIP(hipGetLastError());
     timer.stop();

@@ -289,48 +289,63 @@ __global__ __launch_bounds__(W12_THREADS) void msd_power_w12r_kernel(const doubl
 }
 
 // corr[s][k] = (1 / L') sum_{f < L'} P_s[f] e^{2 pi i f k / L'}, P_s[L' - f] = P_s[f] given for f = 0 .. L'/2, k < n_lags — by direct
-// summation: lane = one lag, the four waves of a block take a quarter of the frequencies each; cos from a quarter-wave table
-// in LDS (L'/4 + 1 entries, cospi of 2 m / L'); products and sums in double-double (two_prod by fma, two_sum), so that the
-// 12 288 terms cost no accuracy against a transform's log2 L' stages. grid (ceil(n_lags / 64), S), 256 lanes.
-__global__ __launch_bounds__(256) void msd_residue_inverse_kernel(const double *__restrict__ P, int LP, int n_lags,
-                                                                  double *__restrict__ corr)
+// summation: lane = one lag, the RI_WAVES waves of a block take a share of the frequencies each (two independent sums per
+// lane); cos from a quarter-wave table in LDS (L'/4 + 1 entries, cospi of 2 m / L'); products and sums in double-double
+// (two_prod by fma, two_sum), so that the 12 288 terms cost no accuracy against a transform's log2 L' stages.
+// grid (ceil(n_lags / 64), S), 64 RI_WAVES lanes.
+constexpr int RI_WAVES = 16;
+__global__ __launch_bounds__(64 * RI_WAVES) void msd_residue_inverse_kernel(const double *__restrict__ P, int LP, int n_lags,
+                                                                            double *__restrict__ corr)
 {
 #pragma clang fp contract(off)  // (the two-sums below take a product: a fused multiply-add would break their error terms)
     extern __shared__ double ft_lds[];
     double *qt = ft_lds;                 // [LP / 4 + 1]
-    double *red = qt + LP / 4 + 1;       // [4][64][2]
+    double *red = qt + LP / 4 + 1;       // [RI_WAVES][64][2]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, H = LP / 2, Q4 = LP / 4;
-    for (int m = tid; m <= Q4; m += 256) qt[m] = cospi(2.0 * (double)m / (double)LP);
+    for (int m = tid; m <= Q4; m += 64 * RI_WAVES) qt[m] = cospi(2.0 * (double)m / (double)LP);
     __syncthreads();
     const double *p = P + (size_t)blockIdx.y * (H + 1);
     const int k = blockIdx.x * 64 + lane;
-    // frequencies f = 1 .. H - 1 in four parts
-    const int f0 = 1 + (H - 1) * wv / 4, f1 = 1 + (H - 1) * (wv + 1) / 4;
-    long long idx = ((long long)f0 * (long long)k) % LP;
-    double hi = 0.0, lo = 0.0;
-    for (int f = f0; f < f1; ++f) {
+    // frequencies f = 1 .. H - 1 in RI_WAVES parts, each walked from both ends by two sums
+    const int f0 = 1 + (int)((long long)(H - 1) * wv / RI_WAVES), f1 = 1 + (int)((long long)(H - 1) * (wv + 1) / RI_WAVES);
+    const int fm = (f0 + f1) / 2;
+    auto cosv = [&](long long idx) {
         int m = (int)idx;
         if (m > H) m = LP - m;
-        const double cv = m > Q4 ? -qt[H - m] : qt[m];
-        const double pv = p[f];
+        return m > Q4 ? -qt[H - m] : qt[m];
+    };
+    auto dd_add = [&](double &hi, double &lo, double pv, double cv) {
         const double ph = pv * cv, pl = __builtin_fma(pv, cv, -ph);
         const double s = hi + ph, bb = s - hi;
-        const double err = (hi - (s - bb)) + (ph - bb);
+        lo += ((hi - (s - bb)) + (ph - bb)) + pl;
         hi = s;
-        lo += err + pl;
-        idx += k;
-        if (idx >= LP) idx -= LP;
+    };
+    long long ia = ((long long)f0 * (long long)k) % LP, ib = ((long long)fm * (long long)k) % LP;
+    double ah = 0.0, al = 0.0, bh = 0.0, bl = 0.0;
+    const int na = fm - f0, nbb = f1 - fm;  // (nbb = na or na + 1)
+    for (int i = 0; i < na; ++i) {
+        dd_add(ah, al, p[f0 + i], cosv(ia));
+        dd_add(bh, bl, p[fm + i], cosv(ib));
+        ia += k;
+        if (ia >= LP) ia -= LP;
+        ib += k;
+        if (ib >= LP) ib -= LP;
     }
-    red[(wv * 64 + lane) * 2] = hi;
-    red[(wv * 64 + lane) * 2 + 1] = lo;
+    if (nbb > na) dd_add(bh, bl, p[f1 - 1], cosv(ib));
+    {
+        const double s = ah + bh, bb = s - ah;
+        al += ((ah - (s - bb)) + (bh - bb)) + bl;
+        ah = s;
+    }
+    red[(wv * 64 + lane) * 2] = ah;
+    red[(wv * 64 + lane) * 2 + 1] = al;
     __syncthreads();
     if (wv == 0 && k < n_lags) {
         double sh = 0.0, sl = 0.0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const double ah = red[(w * 64 + lane) * 2], al = red[(w * 64 + lane) * 2 + 1];
-            const double s = sh + ah, bb = s - sh;
-            sl += ((sh - (s - bb)) + (ah - bb)) + al;
+        for (int w = 0; w < RI_WAVES; ++w) {
+            const double xh = red[(w * 64 + lane) * 2], xl = red[(w * 64 + lane) * 2 + 1];
+            const double s = sh + xh, bb = s - sh;
+            sl += ((sh - (s - bb)) + (xh - bb)) + xl;
             sh = s;
         }
         const double edge = p[0] + ((k & 1) ? -p[H] : p[H]);
