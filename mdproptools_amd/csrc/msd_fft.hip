@@ -2410,9 +2410,13 @@ int lag_msd_fft_residue(CallScope &cs, long long F, long long E, const double *d
     hipLaunchKernelGGL(col_mean_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, ctx->stream, d_msum, MF_SLABS, F,
                        cols, scale, d_mean);
     MD_HIP(hipGetLastError());
-    const size_t ldsr = w12r_lds_bytes(D);
-    MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msd_power_w12r_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)ldsr));
+    // lag_residue 1 (default): two transforms per series (the even frequencies packed, the odd ones as class 1); 2: three
+    // classes (0, 1, 2), nothing packed — the first form of the kernel, kept for A/B
+    const bool packed = ctx->opt_lag_residue != 2;
+    const size_t ldsr = packed ? w12p_lds_bytes() : w12r_lds_bytes(D);
+    MD_HIP(hipFuncSetAttribute(packed ? reinterpret_cast<const void *>(msd_power_w12p_kernel)
+                                      : reinterpret_cast<const void *>(msd_power_w12r_kernel<D>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr));
     size_t fold_i = 0;
     for (long long b = 0; b < n_batches; ++b) {
         const long long c_first = b * nb0, nb = std::min(nb0, cols - c_first);
@@ -2426,8 +2430,12 @@ int lag_msd_fft_residue(CallScope &cs, long long F, long long E, const double *d
         }
         (void)nb;
         const int n_it = batch_off[(size_t)b + 1] - batch_off[(size_t)b];
-        hipLaunchKernelGGL((msd_power_w12r_kernel<D>), dim3((unsigned)n_it), dim3(W12_THREADS), ldsr, ctx->stream, d_pad, (int)F,
-                           d_items + batch_off[(size_t)b], d_tab, d_part);
+        if (packed)
+            hipLaunchKernelGGL(msd_power_w12p_kernel, dim3((unsigned)n_it), dim3(W12_THREADS), ldsr, ctx->stream, d_pad, (int)F,
+                               d_items + batch_off[(size_t)b], d_tab, d_part);
+        else
+            hipLaunchKernelGGL((msd_power_w12r_kernel<D>), dim3((unsigned)n_it), dim3(W12_THREADS), ldsr, ctx->stream, d_pad, (int)F,
+                               d_items + batch_off[(size_t)b], d_tab, d_part);
         for (; fold_i < folds.size() && folds[fold_i].batch == b; ++fold_i)
             hipLaunchKernelGGL(power_fold_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, ctx->stream,
                                d_part + (size_t)folds[fold_i].first * K, folds[fold_i].count, K, d_P + (size_t)folds[fold_i].seg * K);
@@ -2440,7 +2448,7 @@ int lag_msd_fft_residue(CallScope &cs, long long F, long long E, const double *d
                        d_P, (int)LP, (int)n_lags, d_corr);
     MD_HIP(hipGetLastError());
     timer.stop();
-    ctx->last_kernel = "msd_power_w12r_kernel";
+    ctx->last_kernel = packed ? "msd_power_w12p_kernel" : "msd_power_w12r_kernel";
 
     // the finish, on the device, as the fused kernels'
     const size_t fin_b = (size_t)n_lags * G * 4 * 8;
@@ -2514,7 +2522,7 @@ int mdhip_lag_msd_fft(CallScope &cs, int64_t n_frames, int64_t n_ent, const doub
     }
     // round 6: 16 384 < F + max_lag <= 24 576 (F <= 12 288) in residue classes of a 4 x 6144-point transform, no pass through HBM
     if (ctx->opt_lag_variant != 4 && ctx->opt_lag_residue != 0 && F + max_lag <= 4LL * W12_N && F <= 2LL * W12_N &&
-        w12r_lds_bytes(4) <= ctx->lds_max)
+        std::max(w12r_lds_bytes(4), w12p_lds_bytes()) <= ctx->lds_max)
         return lag_msd_fft_residue(cs, F, E, d_r, scale, max_lag, G, group_off, res, out, out_on_device);
     const long long L = pow2_length(F + max_lag);
     MD_REQUIRE(L < (1LL << 30), "series too long for the FFT path (%lld)", L);

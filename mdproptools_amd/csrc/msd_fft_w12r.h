@@ -288,6 +288,248 @@ __global__ __launch_bounds__(W12_THREADS) void msd_power_w12r_kernel(const doubl
     }
 }
 
+// The three register passes of one wave over its region (msd_power_w12_kernel's, verbatim): a[k0] = the transform at
+// j = d + 12 (k2 + 8 k1 + 64 k0), lane = k1 + 8 k2. brow: the per-register factors [8] applied in front (nullptr: none);
+// t: the per-lane factor folded into the first pass's twiddle chain.
+__device__ __forceinline__ void w12r_passes(Cx *a, double2 *myR, int lane, const double2 *brow, Cx t, const double2 *t1tab,
+                                            const double2 *t2tab)
+{
+#pragma unroll
+    for (int n2 = 0; n2 < 8; ++n2) a[n2] = w12_ld(myR + lane + 64 * n2);
+    if (brow) {
+#pragma unroll
+        for (int n2 = 1; n2 < 8; ++n2) a[n2] = cx_mul(a[n2], w12_ld(brow + n2));
+    }
+    f2_bfly8(a, Cx{1.0, 0.0}, false);
+    {
+        const Cx tw_1 = w12_ld(t1tab + lane);
+        a[0] = cx_mul(a[0], t);
+#pragma unroll
+        for (int k2 = 1; k2 < 8; ++k2) {
+            t = cx_mul(t, tw_1);
+            a[k2] = cx_mul(a[k2], t);
+        }
+    }
+    // exchange 1: (n0, n1 | k2) -> (n0, k2 | n1): point n0 + 8 k2 + 64 n1
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) w12_st(myR + (lane & 7) + 8 * k2 + 64 * (lane >> 3), a[k2]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) a[n1] = w12_ld(myR + lane + 64 * n1);
+    f2_bfly8(a, Cx{1.0, 0.0}, false);
+    {
+        const double2 *t2 = t2tab + 9 * (lane & 7);
+#pragma unroll
+        for (int k1 = 1; k1 < 8; ++k1) a[k1] = cx_mul(a[k1], w12_ld(t2 + k1));
+    }
+    // exchange 2: (n0, k2 | k1) -> (k1, k2 | n0): point k1 + 8 k2 + 65 n0
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k1 = 0; k1 < 8; ++k1) w12_st(myR + k1 + 8 * (lane >> 3) + 65 * (lane & 7), a[k1]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int n0 = 0; n0 < 8; ++n0) a[n0] = w12_ld(myR + lane + 65 * n0);
+    f2_bfly8(a, Cx{1.0, 0.0}, false);
+}
+
+// Second form (the default): TWO transforms per series instead of three. The even frequencies k = 2 k'' are the real transform
+// of length 12 288 of the series itself (F <= 12 288: nothing folds), i.e. msd_power_w12_kernel's packed transform z[m] = x[2 m] +
+// i x[2 m + 1] with its bilinear sums S, S', T and partner phase; the odd ones are class r = 1 above (r = 3 is its mirror).
+// LDS: regions | w_L' tables | btab [2][12][8] | w_512^lane | w_64^(n0 k1) | w_L'^(512 e) [12] | the odd class's sums [8][768].
+inline size_t w12p_lds_bytes()
+{
+    return (size_t)W12_NW * W12_RS * 16 + (size_t)(256 + 4 * W12_N / 256) * 16 + (size_t)2 * W12_NW * 8 * 16 + (64 + 72) * 16 +
+           (size_t)12 * 16 + (size_t)8 * W12_THREADS * 8;
+}
+
+__global__ __launch_bounds__(W12_THREADS) void msd_power_w12p_kernel(const double *__restrict__ x, int F,
+                                                                     const FftItem *__restrict__ items,
+                                                                     const double2 *__restrict__ tab2,
+                                                                     double *__restrict__ Ppart)
+{
+    constexpr int D = 4, N = W12_N, RS = W12_RS, LP = D * N, NA = LP / 256;
+    extern __shared__ double ft_lds[];
+    double2 *R = reinterpret_cast<double2 *>(ft_lds);
+    double2 *tB = R + W12_NW * RS, *tA = tB + 256;
+    double2 *btab = tA + NA;                   // [cls][d][n2] = w_N^(64 d n2) w_L'^(64 cls n2), cls = 0 (packed), 1 (odd)
+    double2 *t1tab = btab + 2 * W12_NW * 8;    // [lane] = w_512^lane
+    double2 *t2tab = t1tab + 64;               // [9 n0 + k1] = w_64^(n0 k1)
+    double2 *ctab = t2tab + 72;                // [e] = w_L'^(512 e)
+    double *saccg = reinterpret_cast<double *>(ctab + 12);  // [k0][tid]: the odd class's sums
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int i = tid; i < 256 + NA; i += W12_THREADS) tB[i] = tab2[i];
+    const FftItem it = items[blockIdx.x];
+    __syncthreads();
+    auto tw2 = [&](int k) {  // w_L'^k, 0 <= k < L'
+        const double2 a = tA[k >> 8], b = tB[k & 255];
+        return Cx{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+    };
+    auto twn = [&](long long k) { return tw2((int)((k % (2 * N)) * (D / 2))); };  // w_(2 N)^k
+    for (int i = tid; i < 2 * W12_NW * 8; i += W12_THREADS) {
+        const int cls = i / (W12_NW * 8), d = (i >> 3) % W12_NW, n2 = i & 7;
+        const Cx w = cx_mul(twn(128LL * d * n2), tw2(64 * cls * n2));
+        btab[i] = make_double2(w.x, w.y);
+    }
+    for (int i = tid; i < 64 + 72 + 12; i += W12_THREADS) {
+        Cx w;
+        if (i < 64) w = twn(24LL * i);
+        else if (i < 64 + 72) w = twn(192LL * ((i - 64) / 9) * ((i - 64) % 9));
+        else w = tw2(512 * (i - 64 - 72));
+        t1tab[i] = make_double2(w.x, w.y);
+    }
+    const Cx tw_a = twn(2LL * lane * wv);  // w_N^(lane d)
+    // the partner of frequency j = d + 12 k' of the packed transform (msd_power_w12_kernel): wave 12 - d, lane 63 - lane,
+    // register 7 - k0 for d > 0; wave 0 pairs inside itself, lane 0 of it inside its own registers
+    const int pw = wv == 0 ? 0 : W12_NW - wv;
+    int plane = 63 - lane;
+    if (wv == 0) {
+        const int mneg = (64 - ((lane >> 3) + 8 * (lane & 7))) & 63;
+        plane = (mneg >> 3) + 8 * (mneg & 7);
+    }
+    const bool self0 = wv == 0 && lane == 0;
+    double sacc[8], tacc[5];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sacc[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) tacc[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) saccg[i * W12_THREADS + tid] = 0.0;
+    // this lane's samples, one set at a time: the packed transform's x[2 m], x[2 m + 1] (m = tid + 768 i), then the odd class's
+    // x[n], x[n + 6144] (n = tid + 768 i); each set is requested when the other has been consumed and lands under its passes
+    double xs[8][2];
+    auto fetch_packed = [&](long long c) {
+        const double *row = x + (size_t)c * F;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int t = 2 * (tid + W12_THREADS * i);
+            xs[i][0] = t < F ? __builtin_nontemporal_load(row + t) : 0.0;
+            xs[i][1] = t + 1 < F ? __builtin_nontemporal_load(row + t + 1) : 0.0;
+        }
+    };
+    auto fetch_odd = [&](long long c) {
+        const double *row = x + (size_t)c * F;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int t = tid + W12_THREADS * i;
+            xs[i][0] = t < F ? __builtin_nontemporal_load(row + t) : 0.0;
+            xs[i][1] = t + N < F ? __builtin_nontemporal_load(row + t + N) : 0.0;
+        }
+    };
+    double2 *myR = R + wv * RS;
+    const double2 *pR = R + pw * RS;
+    const int hj = (wv & 7) * 64 + lane;  // the head's position j (waves 0 .. 7)
+    __syncthreads();
+    if (it.c_lo < it.c_hi) fetch_packed(it.c_lo);
+    for (long long c = it.c_lo; c < it.c_hi; ++c) {
+        const bool more = c + 1 < it.c_hi;
+        // (the tables' addresses through an opaque copy per series: see msd_power_w12r_kernel)
+        const double2 *ctab_s = ctab, *btab_s = btab, *tB_s = tB;
+        asm volatile("" : "+v"(ctab_s), "+v"(btab_s), "+v"(tB_s));
+        // ======== the even frequencies: the packed transform ========
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = tid + W12_THREADS * i;
+            w12_st(R + (m >> 9) * RS + (m & 511), Cx{xs[i][0], xs[i][1]});
+        }
+        fetch_odd(c);
+        __syncthreads();
+        if (wv < 8) w12r_dft12(R + hj);
+        __syncthreads();
+        Cx a[8];
+        w12r_passes(a, myR, lane, wv != 0 ? btab_s + wv * 8 : nullptr, tw_a, t1tab, t2tab);
+#pragma unroll
+        for (int k0 = 0; k0 < 8; ++k0) {
+            sacc[k0] = __builtin_fma(a[k0].x, a[k0].x, sacc[k0]);
+            sacc[k0] = __builtin_fma(a[k0].y, a[k0].y, sacc[k0]);
+        }
+        // registers 4 .. 7 are what the partner reads (its registers 3 .. 0)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k0 = 4; k0 < 8; ++k0) w12_st(myR + lane + 64 * (k0 - 4), a[k0]);
+        if (self0) {
+            // lane 0 of wave 0: frequencies 12 * 64 k0, pairs (k0, 8 - k0): 0 and 4 with themselves
+            tacc[0] = __builtin_fma(2.0 * a[0].x, a[0].y, tacc[0]);
+            tacc[4] = __builtin_fma(2.0 * a[4].x, a[4].y, tacc[4]);
+#pragma unroll
+            for (int u = 1; u < 4; ++u) {
+                tacc[u] = __builtin_fma(a[u].x, a[8 - u].y, tacc[u]);
+                tacc[u] = __builtin_fma(a[u].y, a[8 - u].x, tacc[u]);
+            }
+        }
+        __syncthreads();
+        if (!self0) {
+            Cx pz[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) pz[u] = w12_ld(pR + plane + 64 * (3 - u));  // the partner's register 7 - u
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                tacc[u] = __builtin_fma(a[u].x, pz[u].y, tacc[u]);
+                tacc[u] = __builtin_fma(a[u].y, pz[u].x, tacc[u]);
+            }
+        }
+        __syncthreads();
+        // ======== the odd frequencies: class r = 1 ========
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int n = tid + W12_THREADS * i, e = n >> 9;
+            // x[n] + w_4 x[n + 6144] = x[n] - i x[n + 6144], times w_L'^(512 e) (w_L'^j rides in the register passes)
+            const Cx sv = cx_mul(Cx{xs[i][0], -xs[i][1]}, w12_ld(ctab_s + e));
+            w12_st(R + e * RS + (n & 511), sv);
+        }
+        if (more) fetch_packed(c + 1);
+        __syncthreads();
+        if (wv < 8) w12r_dft12(R + hj);
+        __syncthreads();
+        w12r_passes(a, myR, lane, btab_s + (W12_NW + wv) * 8, cx_mul(tw_a, w12_ld(tB_s + lane)), t1tab, t2tab);
+#pragma unroll
+        for (int k0 = 0; k0 < 8; ++k0) {
+            double v = saccg[k0 * W12_THREADS + tid];
+            v = __builtin_fma(a[k0].x, a[k0].x, v);
+            v = __builtin_fma(a[k0].y, a[k0].y, v);
+            saccg[k0 * W12_THREADS + tid] = v;
+        }
+        __syncthreads();
+    }
+    double *pp = Ppart + (size_t)it.row * (LP / 2 + 1);
+    // odd frequencies: j = d + 12 k' -> k = 4 j + 1, or its mirror L' - k
+#pragma unroll
+    for (int k0 = 0; k0 < 8; ++k0) {
+        const int kp = (lane >> 3) + 8 * (lane & 7) + 64 * k0;  // k' = k2 + 8 k1 + 64 k0
+        const int k = D * (wv + W12_NW * kp) + 1;
+        pp[k <= LP / 2 ? k : LP - k] = saccg[k0 * W12_THREADS + tid];
+    }
+    // even frequencies, as msd_power_w12_kernel sorts them out (the loop ended on a barrier): point lane + 64 k0 of the wave's
+    // region = {S, T}; |X_(2 k'')|^2 = (S + S')/2 + Im(w) (S - S')/2 + Re(w) T, w = e^{-2 pi i k''/12288}
+#pragma unroll
+    for (int k0 = 0; k0 < 8; ++k0) myR[lane + 64 * k0] = make_double2(sacc[k0], k0 < 4 ? tacc[k0] : 0.0);
+    __syncthreads();
+#pragma unroll
+    for (int k0 = 0; k0 < 8; ++k0) {
+        const int kp = (lane >> 3) + 8 * (lane & 7) + 64 * k0;
+        const int k = wv + W12_NW * kp;
+        double sn, tk;
+        if (self0) {
+            const int kq = (8 - k0) & 7;
+            sn = myR[64 * kq].x;  // (lane 0: its own registers, through the region)
+            tk = k0 == 0 ? tacc[0] : k0 == 4 ? tacc[4] : k0 < 4 ? tacc[k0] : tacc[8 - k0];
+        } else {
+            const double2 pv = pR[plane + 64 * (7 - k0)];
+            sn = pv.x;
+            tk = k0 < 4 ? tacc[k0] : pv.y;
+        }
+        const double sk = sacc[k0];
+        const Cx w = twn(k);  // (cos, -sin) of 2 pi k / 12288
+        pp[2 * k] = 0.5 * (sk + sn) + w.y * (0.5 * (sk - sn)) + w.x * tk;
+        if (k == 0) pp[2 * N] = sk - tk;
+    }
+}
+
 // corr[s][k] = (1 / L') sum_{f < L'} P_s[f] e^{2 pi i f k / L'}, P_s[L' - f] = P_s[f] given for f = 0 .. L'/2, k < n_lags — by direct
 // summation: lane = one lag, the RI_WAVES waves of a block take a share of the frequencies each (two independent sums per
 // lane); cos from a quarter-wave table in LDS (L'/4 + 1 entries, cospi of 2 m / L'); products and sums in double-double

@@ -532,7 +532,7 @@ def test_lag_msd_long_series_finish_on_the_device(B):
             # (the bound is relative to the SMALLEST |MSD sum| over the lags: with max_lag ~ F the last lags hold one or two
             # origins of two entities, so it is far looser here than at C4 — what is tested is that the result respects it)
             # (round 6: up to F + max_lag = 24 576 the residue-class kernel, beyond it the batched transforms)
-            want_kernel = "msd_power_w12r_kernel" if F + max_lag <= 24576 and F <= 12288 else "lag_msd_fft"
+            want_kernel = "msd_power_w12p_kernel" if F + max_lag <= 24576 and F <= 12288 else "lag_msd_fft"
             assert ctx.last_kernel_name() == want_kernel and 0.0 < bound < 1e-4, (ctx.last_kernel_name(), bound)
             assert (fft[0] == 0.0).all()
             nz = exact > 0
@@ -586,7 +586,7 @@ def test_lag_msd_long_series_finish_on_the_device(B):
             ctx.set_option("lag_variant", 2)
             try:
                 ctx.set_option("lag_batch_mb", mb)
-                for residue, name in ((1, "msd_power_w12r_kernel"), (0, "lag_msd_fft")):
+                for residue, name in ((1, "msd_power_w12p_kernel"), (2, "msd_power_w12r_kernel"), (0, "lag_msd_fft")):
                     ctx.set_option("lag_residue", residue)
                     fft = B.lag_msd(r, F - 1, goff)
                     bound = ctx.last_rel_bound()
