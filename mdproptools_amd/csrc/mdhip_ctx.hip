@@ -763,6 +763,8 @@ int mdhip_set_option(mdhip_ctx *ctx, const char *key, int value)
         ctx->opt_lag_batched_fuse = value < 0 ? 2 : value;
     else if (!strcmp(key, "lag_residue"))
         ctx->opt_lag_residue = value < 0 ? 1 : value;
+    else if (!strcmp(key, "lag_mean_sample"))
+        ctx->opt_lag_mean_sample = value;
     else if (!strcmp(key, "lag_batch_mb"))
         ctx->opt_lag_batch_mb = value <= 0 ? 4096 : std::min(value, 65536);
     else if (!strcmp(key, "lag_w12_min_f"))

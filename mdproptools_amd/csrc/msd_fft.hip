@@ -49,7 +49,50 @@ __global__ __launch_bounds__(256) void col_sum_kernel(const double *__restrict__
     partial[(size_t)blockIdx.y * cols + c] = (s0 + s1) + (s2 + s3);
 }
 
-// mean[c] = scale * sum_slabs partial / F
+// The same over a SAMPLE of the frames (round 6, the long-series paths): the MSD does not see a constant offset of a
+// series, so the series may be centred on any constant as long as S1 and the correlations are made of the same centred
+// values — the mean only keeps S1, and with it the error bound (which is computed from the values actually used), as small
+// as the data allow. The mean of one frame in `stride`, jittered inside its stride so that no periodic motion aliases,
+// does that as well as the mean of all frames, and costs 1/stride of a pass over the trajectory (2.0 of the 16 ms of a
+// 10 000-frame call at C4's size). Frame i of a slab: t0 + i stride + (hash(i, slab) mod stride), clipped to the slab.
+__device__ __forceinline__ long long sample_frame(long long t0, long long t1, long long i, long long stride, unsigned slab)
+{
+    unsigned h = (unsigned)i * 2654435761u + slab * 40503u + 12345u;
+    h ^= h >> 15;
+    h *= 2246822519u;
+    h ^= h >> 13;
+    const long long t = t0 + i * stride + (long long)(h % (unsigned)stride);
+    return t < t1 ? t : t1 - 1;
+}
+
+inline long long sample_count(long long F, int slabs, long long stride)
+{
+    long long n = 0;
+    for (int y = 0; y < slabs; ++y) {
+        const long long t0 = F * y / slabs, t1 = F * (y + 1) / slabs;
+        n += (t1 - t0 + stride - 1) / stride;
+    }
+    return n;
+}
+
+__global__ __launch_bounds__(256) void col_sum_sample_kernel(const double *__restrict__ r, long long F, long long cols,
+                                                             long long stride, double *__restrict__ partial)
+{
+    const long long c = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    const long long t0 = F * blockIdx.y / gridDim.y, t1 = F * (blockIdx.y + 1) / gridDim.y;
+    const long long n = (t1 - t0 + stride - 1) / stride;
+    double s0 = 0.0, s1 = 0.0;
+    long long i = 0;
+    for (; i + 2 <= n; i += 2) {
+        s0 += r[sample_frame(t0, t1, i, stride, blockIdx.y) * cols + c];
+        s1 += r[sample_frame(t0, t1, i + 1, stride, blockIdx.y) * cols + c];
+    }
+    if (i < n) s0 += r[sample_frame(t0, t1, i, stride, blockIdx.y) * cols + c];
+    partial[(size_t)blockIdx.y * cols + c] = s0 + s1;
+}
+
+// mean[c] = scale * sum_slabs partial / F   (F: the number of frames summed)
 __global__ void col_mean_kernel(const double *__restrict__ partial, int slabs, long long F, long long cols,
                                 double scale, double *__restrict__ mean)
 {
@@ -2323,6 +2366,15 @@ int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r
 // >= F + max_lag, F <= 12 288. The trajectory is transposed and centred batch by batch (transpose_centre64_kernel, as the
 // batched path), every batch's series are dealt to one block per CU, the blocks' partial spectra are folded per segment, and
 // the correlations come from msd_residue_inverse_kernel; the finish is the fused kernels' (lag_finish_dd_kernel).
+// frames between two samples of the series' means (col_sum_sample_kernel): ~512 samples of a long trajectory; option
+// `lag_mean_sample` 0 = every frame, n > 0 = about n samples
+inline long long lag_mean_stride(const mdhip_ctx *ctx, long long F)
+{
+    if (ctx->opt_lag_mean_sample == 0) return 1;
+    const long long want = ctx->opt_lag_mean_sample > 0 ? ctx->opt_lag_mean_sample : 512;
+    return std::max<long long>(1, F / want);
+}
+
 int lag_msd_fft_residue(CallScope &cs, long long F, long long E, const double *d_r, double scale, int max_lag, long long G,
                         const int64_t *group_off, const std::shared_ptr<LagFftResult> &res, double *out, int out_on_device)
 {
@@ -2405,10 +2457,15 @@ int lag_msd_fft_residue(CallScope &cs, long long F, long long E, const double *d
     MD_HIP(hipMemsetAsync(d_Q, 0, q_b + p_b, ctx->stream));  // (Q | P: both are added to, batch by batch)
 
     KernelTimer timer(ctx);
-    hipLaunchKernelGGL(col_sum_kernel, dim3((unsigned)((cols + 255) / 256), MF_SLABS), dim3(256), 0, ctx->stream, d_r, F, cols,
-                       d_msum);
-    hipLaunchKernelGGL(col_mean_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, ctx->stream, d_msum, MF_SLABS, F,
-                       cols, scale, d_mean);
+    const long long m_stride = lag_mean_stride(ctx, F);
+    if (m_stride > 1)
+        hipLaunchKernelGGL(col_sum_sample_kernel, dim3((unsigned)((cols + 255) / 256), MF_SLABS), dim3(256), 0, ctx->stream, d_r, F,
+                           cols, m_stride, d_msum);
+    else
+        hipLaunchKernelGGL(col_sum_kernel, dim3((unsigned)((cols + 255) / 256), MF_SLABS), dim3(256), 0, ctx->stream, d_r, F, cols,
+                           d_msum);
+    hipLaunchKernelGGL(col_mean_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, ctx->stream, d_msum, MF_SLABS,
+                       m_stride > 1 ? sample_count(F, MF_SLABS, m_stride) : F, cols, scale, d_mean);
     MD_HIP(hipGetLastError());
     // lag_residue 1 (default): two transforms per series (the even frequencies packed, the odd ones as class 1); 2: three
     // classes (0, 1, 2), nothing packed — the first form of the kernel, kept for A/B
@@ -2576,10 +2633,15 @@ int mdhip_lag_msd_fft(CallScope &cs, int64_t n_frames, int64_t n_ent, const doub
     MD_HIP(hipMemsetAsync(d_P, 0, p_b, ctx->stream));
 
     KernelTimer timer(ctx);
-    hipLaunchKernelGGL(col_sum_kernel, dim3((unsigned)((cols + 255) / 256), MF_SLABS), dim3(256), 0, ctx->stream,
-                       d_r, F, cols, d_msum);
-    hipLaunchKernelGGL(col_mean_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, ctx->stream, d_msum,
-                       MF_SLABS, F, cols, scale, d_mean);
+    const long long m_stride = lag_mean_stride(ctx, F);
+    if (m_stride > 1)
+        hipLaunchKernelGGL(col_sum_sample_kernel, dim3((unsigned)((cols + 255) / 256), MF_SLABS), dim3(256), 0, ctx->stream, d_r, F,
+                           cols, m_stride, d_msum);
+    else
+        hipLaunchKernelGGL(col_sum_kernel, dim3((unsigned)((cols + 255) / 256), MF_SLABS), dim3(256), 0, ctx->stream, d_r, F, cols,
+                           d_msum);
+    hipLaunchKernelGGL(col_mean_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, ctx->stream, d_msum, MF_SLABS,
+                       m_stride > 1 ? sample_count(F, MF_SLABS, m_stride) : F, cols, scale, d_mean);
     hipLaunchKernelGGL(frame_sq_kernel, dim3((unsigned)F, 3), dim3(256), 0, ctx->stream, d_r, d_mean, E, scale,
                        d_goff, (int)G, F, d_Q);
     MD_HIP(hipGetLastError());

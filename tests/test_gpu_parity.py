@@ -575,6 +575,26 @@ def test_lag_msd_long_series_finish_on_the_device(B):
             np.testing.assert_array_equal(old, mid)
             assert (np.abs(mid[nz] - fft[nz]) / exact[nz]).max() <= bound + mid_bound
             assert (np.abs(mid[nz] - exact[nz]) / exact[nz]).max() <= mid_bound
+        # the series are centred on the mean of ~512 SAMPLED frames (col_sum_sample_kernel): any constant is right as long as
+        # S1 and the correlations use the same one. A motion whose period is the sampling stride (F / 512 = 19 frames) must
+        # not alias into the offset (the samples are jittered), and the bound, made of the values actually used, holds.
+        F, E = 10000, 24
+        t = np.arange(F)[:, None, None]
+        r = 3.0 * np.sin(2 * np.pi * t / 19.0 + rng.uniform(0, 6.28, (1, 3, E))) + np.cumsum(rng.normal(0, 0.02, (F, 3, E)), axis=0)
+        ctx.set_option("lag_variant", 1)
+        exact = B.lag_msd(r, F - 1, [0, E])
+        nz = exact > 0
+        ctx.set_option("lag_variant", 2)
+        try:
+            bounds = {}
+            for sample in (-1, 0, 64):
+                ctx.set_option("lag_mean_sample", sample)
+                fft = B.lag_msd(r, F - 1, [0, E])
+                bounds[sample] = ctx.last_rel_bound()
+                assert (np.abs(fft[nz] - exact[nz]) / exact[nz]).max() <= bounds[sample], (sample, bounds)
+            assert bounds[-1] < 1.5 * bounds[0], bounds  # (the sampled mean costs the bound next to nothing)
+        finally:
+            ctx.set_option("lag_mean_sample", -1)
         # more series than one batch holds / than the fused pass has rows per split: groups that straddle batches, splits and
         # blocks — both long-series paths (the residue-class kernel; the batched transforms), small batches forced
         for F, E, goff, mb in ((8200, 700, [0, 1, 130, 700], -1), (8193, 300, [0, 300], 1), (12288, 40, [0, 7, 7, 40], 1),
