@@ -228,6 +228,63 @@ __global__ __launch_bounds__(256) void transpose_centre64_sq_kernel(const double
     if (ty == 0 && t0 + tx < F) Qpart[(size_t)blockIdx.x * F + t0 + tx] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
 }
 
+// The same for trajectories of 12 288 < F <= 24 576 frames, folded once on the way: frames t < 12 288 and t + 12 288 of the
+// centred series (zero beyond F) leave as their sum and difference, ser[row][t] = a + b, ser[row][12288 + t] = a - b (rows of
+// 24 576 doubles) — what the residue-class kernels of the padded length 49 152 read (msd_fft_w12r.h). The squares stay per
+// frame: Qpart[.][t] takes a^2, Qpart[.][t + 12288] b^2. grid (blocks of TSQ_TILES column tiles, 192 frame tiles).
+__global__ __launch_bounds__(256) void transpose_fold64_sq_kernel(const double *__restrict__ r, const double *__restrict__ mean,
+                                                                  long long F, long long cols, long long c_first, long long nb,
+                                                                  long long row0, double scale, double *__restrict__ ser,
+                                                                  double *__restrict__ Qpart)
+{
+    constexpr long long HF = 12288;
+    __shared__ double tile[64][65];
+    __shared__ double red[2][4][64];
+    const long long t0 = (long long)blockIdx.y * 64, c_end = c_first + nb;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+    double sqa = 0.0, sqb = 0.0;
+    for (int ti = 0; ti < TSQ_TILES; ++ti) {
+        const long long c0 = c_first + ((long long)blockIdx.x * TSQ_TILES + ti) * 64;
+        if (c0 >= c_end) break;
+        const long long cc_in = c0 + tx;
+        const double m = cc_in < c_end ? mean[cc_in] : 0.0;
+        double va[16];
+        for (int half = 0; half < 2; ++half) {
+            __syncthreads();  // (the previous readers of the tile are done)
+#pragma unroll 4
+            for (int k = ty; k < 64; k += 4) {
+                const long long tt = t0 + k + half * HF;
+                tile[k][tx] = (tt < F && cc_in < c_end) ? __builtin_nontemporal_load(r + tt * cols + cc_in) * scale - m : 0.0;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int k = ty + 4 * q;
+                const double v = tile[tx][k];
+                if (half == 0) {
+                    va[q] = v;
+                    sqa = __builtin_fma(v, v, sqa);
+                } else {
+                    sqb = __builtin_fma(v, v, sqb);
+                    const long long cc = c0 + k, tt = t0 + tx;
+                    if (cc < c_end) {
+                        double *row = ser + (size_t)(cc - c_first + row0) * (size_t)(2 * HF);
+                        __builtin_nontemporal_store(va[q] + v, row + tt);
+                        __builtin_nontemporal_store(va[q] - v, row + HF + tt);
+                    }
+                }
+            }
+        }
+    }
+    red[0][ty][tx] = sqa;
+    red[1][ty][tx] = sqb;
+    __syncthreads();
+    if (ty < 2) {
+        const long long tt = t0 + tx + ty * HF;
+        if (tt < F) Qpart[(size_t)blockIdx.x * F + tt] = (red[ty][0][tx] + red[ty][1][tx]) + (red[ty][2][tx] + red[ty][3][tx]);
+    }
+}
+
 // partial[split][k] = sum over the split's rows of |spec[row][k]|^2
 __global__ __launch_bounds__(256) void power_rows_kernel(const double2 *__restrict__ spec, long long K,
                                                          long long row0, long long row1,
@@ -2379,11 +2436,15 @@ int lag_msd_fft_residue(CallScope &cs, long long F, long long E, const double *d
                         const int64_t *group_off, const std::shared_ptr<LagFftResult> &res, double *out, int out_on_device)
 {
     mdhip_ctx *ctx = cs.ctx;
-    constexpr int D = 4;
-    constexpr long long LP = (long long)D * W12_N, K = LP / 2 + 1;
+    // D = 4: padded length 24 576, the series as they are; D = 8: 49 152, the series folded once by the transposition (rows
+    // [g | h] of 24 576 doubles): the even frequencies by the D = 4 kernel over those rows, the odd ones by msd_power_w12o_kernel
+    const int D = (F <= 2LL * W12_N && F + max_lag <= 4LL * W12_N) ? 4 : 8;
+    const long long LP = (long long)D * W12_N, K = LP / 2 + 1;
+    const long long LP4 = 4LL * W12_N;  // the length msd_power_w12p_kernel transforms at
     const long long n_lags = (long long)max_lag + 1, cols = 3 * E, S = 3 * G;
+    const long long row_len = D == 4 ? F : 4LL * W12_N;  // doubles per series of the time-major copy
     res->delivered = true;
-    const long long nb_max = std::max<long long>(1, ((long long)ctx->opt_lag_batch_mb << 20) / (F * 8));
+    const long long nb_max = std::max<long long>(1, ((long long)ctx->opt_lag_batch_mb << 20) / (row_len * 8));
     const long long n_batches = (cols + nb_max - 1) / nb_max;
     const long long nb0 = (cols + n_batches - 1) / n_batches;
     // work items, batch by batch: every (segment, batch) overlap gets its share of ~one block per CU
@@ -2417,19 +2478,23 @@ int lag_msd_fft_residue(CallScope &cs, long long F, long long E, const double *d
     }
     batch_off[(size_t)n_batches] = (int)items.size();
 
-    // twiddle table of w_L': B[i] = w^i (i < 256), A[i] = w^(256 i)
-    const int n_tab = 256 + (int)(LP / 256);
+    // twiddle tables: B[i] = w^i (i < 256), A[i] = w^(256 i) of w_24576 (msd_power_w12p_kernel / _w12r_), behind it of w_49152
+    const int n_tab4 = 256 + (int)(LP4 / 256), n_tab8 = D == 8 ? 256 + (int)(LP / 256) : 0, n_tab = n_tab4 + n_tab8;
     std::vector<double> tab((size_t)2 * n_tab);
-    const long double step = -2.0L * 3.14159265358979323846264338327950288L / (long double)LP;
-    for (int i = 0; i < n_tab; ++i) {
-        const long long idx = i < 256 ? i : 256LL * (i - 256);
-        tab[2 * i] = (double)cosl(step * idx);
-        tab[2 * i + 1] = (double)sinl(step * idx);
+    for (int part = 0; part < (D == 8 ? 2 : 1); ++part) {
+        const long long len = part == 0 ? LP4 : LP;
+        const long double step = -2.0L * 3.14159265358979323846264338327950288L / (long double)len;
+        const int base = part == 0 ? 0 : n_tab4, cnt = part == 0 ? n_tab4 : n_tab8;
+        for (int i = 0; i < cnt; ++i) {
+            const long long idx = i < 256 ? i : 256LL * (i - 256);
+            tab[2 * (base + i)] = (double)cosl(step * idx);
+            tab[2 * (base + i) + 1] = (double)sinl(step * idx);
+        }
     }
 
     MD_WS(d_mean, double, WS_AUX0, (size_t)(MF_SLABS + 1) * cols * 8);
     double *d_msum = d_mean + cols;
-    MD_WS(d_pad, double, WS_AUX1, (size_t)nb0 * F * 8 + 256);
+    MD_WS(d_pad, double, WS_AUX1, (size_t)nb0 * row_len * 8 + 256);
     MD_WS(d_part, double, WS_PART, (size_t)max_items * K * 8);
     MD_WS(d_qpart, double, WS_AUX2, (size_t)max_tiles * F * 8);
     const size_t q_b = (size_t)S * F * 8, p_b = (size_t)S * K * 8, c_b = (size_t)S * n_lags * 8;
@@ -2469,29 +2534,46 @@ int lag_msd_fft_residue(CallScope &cs, long long F, long long E, const double *d
     MD_HIP(hipGetLastError());
     // lag_residue 1 (default): two transforms per series (the even frequencies packed, the odd ones as class 1); 2: three
     // classes (0, 1, 2), nothing packed — the first form of the kernel, kept for A/B
-    const bool packed = ctx->opt_lag_residue != 2;
-    const size_t ldsr = packed ? w12p_lds_bytes() : w12r_lds_bytes(D);
+    const bool packed = ctx->opt_lag_residue != 2 || D == 8;
+    const size_t ldsr = packed ? w12p_lds_bytes() : w12r_lds_bytes(4);
     MD_HIP(hipFuncSetAttribute(packed ? reinterpret_cast<const void *>(msd_power_w12p_kernel)
-                                      : reinterpret_cast<const void *>(msd_power_w12r_kernel<D>),
+                                      : reinterpret_cast<const void *>(msd_power_w12r_kernel<4>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr));
+    if (D == 8) {
+        MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msd_power_w12o_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)w12o_lds_bytes()));
+        MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msd_power_w12o_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)w12o_lds_bytes()));
+    }
     size_t fold_i = 0;
     for (long long b = 0; b < n_batches; ++b) {
         const long long c_first = b * nb0, nb = std::min(nb0, cols - c_first);
         // the batch's series, segment by segment (a tile's per-frame squares belong to one segment), and S1's terms with them
         for (size_t fi = fold_i; fi < folds.size() && folds[fi].batch == b; ++fi) {
             const long long lo = folds[fi].c_lo, n = folds[fi].c_n, tiles = (n + 64 * TSQ_TILES - 1) / (64 * TSQ_TILES);
-            hipLaunchKernelGGL(transpose_centre64_sq_kernel, dim3((unsigned)tiles, (unsigned)((F + 63) / 64)), dim3(256), 0,
-                               ctx->stream, d_r, d_mean, F, cols, lo, n, lo - c_first, scale, d_pad, d_qpart);
+            if (D == 4)
+                hipLaunchKernelGGL(transpose_centre64_sq_kernel, dim3((unsigned)tiles, (unsigned)((F + 63) / 64)), dim3(256), 0,
+                                   ctx->stream, d_r, d_mean, F, cols, lo, n, lo - c_first, scale, d_pad, d_qpart);
+            else
+                hipLaunchKernelGGL(transpose_fold64_sq_kernel, dim3((unsigned)tiles, (unsigned)(2 * W12_N / 64)), dim3(256), 0,
+                                   ctx->stream, d_r, d_mean, F, cols, lo, n, lo - c_first, scale, d_pad, d_qpart);
             hipLaunchKernelGGL(power_fold_kernel, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, ctx->stream, d_qpart, (int)tiles,
                                F, d_Q + (size_t)folds[fi].seg * F);
         }
         (void)nb;
         const int n_it = batch_off[(size_t)b + 1] - batch_off[(size_t)b];
-        if (packed)
-            hipLaunchKernelGGL(msd_power_w12p_kernel, dim3((unsigned)n_it), dim3(W12_THREADS), ldsr, ctx->stream, d_pad, (int)F,
-                               d_items + batch_off[(size_t)b], d_tab, d_part);
+        if (D == 8) {
+            hipLaunchKernelGGL(msd_power_w12p_kernel, dim3((unsigned)n_it), dim3(W12_THREADS), ldsr, ctx->stream, d_pad, row_len,
+                               2 * W12_N, 2 * W12_N, 2 * W12_N, 2, (int)K, d_items + batch_off[(size_t)b], d_tab, d_part);
+            hipLaunchKernelGGL(msd_power_w12o_kernel<1>, dim3((unsigned)n_it), dim3(W12_THREADS), w12o_lds_bytes(), ctx->stream,
+                               d_pad, d_items + batch_off[(size_t)b], d_tab + n_tab4, d_part);
+            hipLaunchKernelGGL(msd_power_w12o_kernel<3>, dim3((unsigned)n_it), dim3(W12_THREADS), w12o_lds_bytes(), ctx->stream,
+                               d_pad, d_items + batch_off[(size_t)b], d_tab + n_tab4, d_part);
+        } else if (packed)
+            hipLaunchKernelGGL(msd_power_w12p_kernel, dim3((unsigned)n_it), dim3(W12_THREADS), ldsr, ctx->stream, d_pad, row_len,
+                               (int)F, 0, (int)F, 1, (int)K, d_items + batch_off[(size_t)b], d_tab, d_part);
         else
-            hipLaunchKernelGGL((msd_power_w12r_kernel<D>), dim3((unsigned)n_it), dim3(W12_THREADS), ldsr, ctx->stream, d_pad, (int)F,
+            hipLaunchKernelGGL((msd_power_w12r_kernel<4>), dim3((unsigned)n_it), dim3(W12_THREADS), ldsr, ctx->stream, d_pad, (int)F,
                                d_items + batch_off[(size_t)b], d_tab, d_part);
         for (; fold_i < folds.size() && folds[fold_i].batch == b; ++fold_i)
             hipLaunchKernelGGL(power_fold_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, ctx->stream,
@@ -2505,7 +2587,7 @@ int lag_msd_fft_residue(CallScope &cs, long long F, long long E, const double *d
                        d_P, (int)LP, (int)n_lags, d_corr);
     MD_HIP(hipGetLastError());
     timer.stop();
-    ctx->last_kernel = packed ? "msd_power_w12p_kernel" : "msd_power_w12r_kernel";
+    ctx->last_kernel = D == 8 ? "msd_power_w12p_kernel + msd_power_w12o_kernel" : packed ? "msd_power_w12p_kernel" : "msd_power_w12r_kernel";
 
     // the finish, on the device, as the fused kernels'
     const size_t fin_b = (size_t)n_lags * G * 4 * 8;
@@ -2577,9 +2659,10 @@ int mdhip_lag_msd_fft(CallScope &cs, int64_t n_frames, int64_t n_ent, const doub
             return lag_msd_fft_fused(cs, F, E, d_r, scale, max_lag, G, group_off, m, res, out, out_on_device);
         }
     }
-    // round 6: 16 384 < F + max_lag <= 24 576 (F <= 12 288) in residue classes of a 4 x 6144-point transform, no pass through HBM
-    if (ctx->opt_lag_variant != 4 && ctx->opt_lag_residue != 0 && F + max_lag <= 4LL * W12_N && F <= 2LL * W12_N &&
-        std::max(w12r_lds_bytes(4), w12p_lds_bytes()) <= ctx->lds_max)
+    // round 6: 16 384 < F + max_lag <= 24 576 (F <= 12 288) in residue classes of a 4 x 6144-point transform, F + max_lag <=
+    // 49 152 (F <= 24 576) of an 8 x 6144-point one: no transform pass through HBM
+    if (ctx->opt_lag_variant != 4 && ctx->opt_lag_residue != 0 && F + max_lag <= 8LL * W12_N && F <= 4LL * W12_N &&
+        std::max(std::max(w12r_lds_bytes(4), w12p_lds_bytes()), w12o_lds_bytes()) <= ctx->lds_max)
         return lag_msd_fft_residue(cs, F, E, d_r, scale, max_lag, G, group_off, res, out, out_on_device);
     const long long L = pow2_length(F + max_lag);
     MD_REQUIRE(L < (1LL << 30), "series too long for the FFT path (%lld)", L);

@@ -347,7 +347,13 @@ inline size_t w12p_lds_bytes()
            (size_t)12 * 16 + (size_t)8 * W12_THREADS * 8;
 }
 
-__global__ __launch_bounds__(W12_THREADS) void msd_power_w12p_kernel(const double *__restrict__ x, int F,
+// x: rows of `stride` doubles. Padded length 24 576 (F <= 12 288): the centred series itself, stride = Fp = Fo = F, off_odd = 0,
+// kmul = 1, prow = 12 289. Padded length 49 152 (F <= 24 576; the EVEN frequencies of that length, msd_power_w12o_kernel
+// makes the odd ones): rows [g | h] of 12 288 samples each, g[n] = x[n] + x[n + 12288], h[n] = x[n] - x[n + 12288]
+// (transpose_fold64_sq_kernel) — the 24 576-point transform of the series folded once is the packed transform of g and class
+// 1 of h —, stride = 24 576, Fp = Fo = off_odd = 12 288, kmul = 2, prow = 24 577.
+__global__ __launch_bounds__(W12_THREADS) void msd_power_w12p_kernel(const double *__restrict__ x, long long stride, int Fp,
+                                                                     int off_odd, int Fo, int kmul, int prow,
                                                                      const FftItem *__restrict__ items,
                                                                      const double2 *__restrict__ tab2,
                                                                      double *__restrict__ Ppart)
@@ -403,21 +409,21 @@ __global__ __launch_bounds__(W12_THREADS) void msd_power_w12p_kernel(const doubl
     // x[n], x[n + 6144] (n = tid + 768 i); each set is requested when the other has been consumed and lands under its passes
     double xs[8][2];
     auto fetch_packed = [&](long long c) {
-        const double *row = x + (size_t)c * F;
+        const double *row = x + (size_t)c * (size_t)stride;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int t = 2 * (tid + W12_THREADS * i);
-            xs[i][0] = t < F ? __builtin_nontemporal_load(row + t) : 0.0;
-            xs[i][1] = t + 1 < F ? __builtin_nontemporal_load(row + t + 1) : 0.0;
+            xs[i][0] = t < Fp ? __builtin_nontemporal_load(row + t) : 0.0;
+            xs[i][1] = t + 1 < Fp ? __builtin_nontemporal_load(row + t + 1) : 0.0;
         }
     };
     auto fetch_odd = [&](long long c) {
-        const double *row = x + (size_t)c * F;
+        const double *row = x + (size_t)c * (size_t)stride + off_odd;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int t = tid + W12_THREADS * i;
-            xs[i][0] = t < F ? __builtin_nontemporal_load(row + t) : 0.0;
-            xs[i][1] = t + N < F ? __builtin_nontemporal_load(row + t + N) : 0.0;
+            xs[i][0] = t < Fo ? __builtin_nontemporal_load(row + t) : 0.0;
+            xs[i][1] = t + N < Fo ? __builtin_nontemporal_load(row + t + N) : 0.0;
         }
     };
     double2 *myR = R + wv * RS;
@@ -496,13 +502,13 @@ __global__ __launch_bounds__(W12_THREADS) void msd_power_w12p_kernel(const doubl
         }
         __syncthreads();
     }
-    double *pp = Ppart + (size_t)it.row * (LP / 2 + 1);
+    double *pp = Ppart + (size_t)it.row * (size_t)prow;
     // odd frequencies: j = d + 12 k' -> k = 4 j + 1, or its mirror L' - k
 #pragma unroll
     for (int k0 = 0; k0 < 8; ++k0) {
         const int kp = (lane >> 3) + 8 * (lane & 7) + 64 * k0;  // k' = k2 + 8 k1 + 64 k0
         const int k = D * (wv + W12_NW * kp) + 1;
-        pp[k <= LP / 2 ? k : LP - k] = saccg[k0 * W12_THREADS + tid];
+        pp[kmul * (k <= LP / 2 ? k : LP - k)] = saccg[k0 * W12_THREADS + tid];
     }
     // even frequencies, as msd_power_w12_kernel sorts them out (the loop ended on a barrier): point lane + 64 k0 of the wave's
     // region = {S, T}; |X_(2 k'')|^2 = (S + S')/2 + Im(w) (S - S')/2 + Re(w) T, w = e^{-2 pi i k''/12288}
@@ -525,8 +531,116 @@ __global__ __launch_bounds__(W12_THREADS) void msd_power_w12p_kernel(const doubl
         }
         const double sk = sacc[k0];
         const Cx w = twn(k);  // (cos, -sin) of 2 pi k / 12288
-        pp[2 * k] = 0.5 * (sk + sn) + w.y * (0.5 * (sk - sn)) + w.x * tk;
-        if (k == 0) pp[2 * N] = sk - tk;
+        pp[kmul * 2 * k] = 0.5 * (sk + sn) + w.y * (0.5 * (sk - sn)) + w.x * tk;
+        if (k == 0) pp[kmul * 2 * N] = sk - tk;
+    }
+}
+
+// The ODD frequencies of the padded length L'' = 8 x 6144 = 49 152 (12 288 < F <= 24 576): class R = 1 or 3 (mod 8; 7 and 5 are
+// their mirrors) of the series x[n] = (g[n] + h[n]) / 2, x[n + 12288] = (g[n] - h[n]) / 2 that transpose_fold64_sq_kernel
+// left folded (rows [g | h], see msd_power_w12p_kernel, which makes the even frequencies from the same rows):
+//     y_R[n] = w_L''^(R n) sum_{q < 4} x[n + 6144 q] w_8^(R q),  n < 6144;   X[8 j + R] = FFT_6144(y_R)[j]
+// One class per launch: a lane's 8 points take 32 samples, which fill the registers the other kernels keep sums in — the
+// sums live in LDS here. LDS: regions | w_L'' tables | btab [12][8] | w_512^lane | w_64^(n0 k1) | w_L''^(512 R e) [12] | sums.
+inline size_t w12o_lds_bytes()
+{
+    return (size_t)W12_NW * W12_RS * 16 + (size_t)(256 + 8 * W12_N / 256) * 16 + (size_t)W12_NW * 8 * 16 + (64 + 72) * 16 +
+           (size_t)12 * 16 + (size_t)8 * W12_THREADS * 8;
+}
+
+template <int RC>
+__global__ __launch_bounds__(W12_THREADS) void msd_power_w12o_kernel(const double *__restrict__ x,
+                                                                     const FftItem *__restrict__ items,
+                                                                     const double2 *__restrict__ tab2,
+                                                                     double *__restrict__ Ppart)
+{
+    constexpr int D = 8, N = W12_N, RS = W12_RS, LP = D * N, NA = LP / 256, G2 = 2 * N;  // G2: samples of g (and of h) per row
+    extern __shared__ double ft_lds[];
+    double2 *R = reinterpret_cast<double2 *>(ft_lds);
+    double2 *tB = R + W12_NW * RS, *tA = tB + 256;
+    double2 *btab = tA + NA;              // [d][n2] = w_N^(64 d n2) w_L''^(64 RC n2)
+    double2 *t1tab = btab + W12_NW * 8;   // [lane] = w_512^lane
+    double2 *t2tab = t1tab + 64;          // [9 n0 + k1] = w_64^(n0 k1)
+    double2 *ctab = t2tab + 72;           // [e] = w_L''^(512 RC e)
+    double *saccg = reinterpret_cast<double *>(ctab + 12);  // [k0][tid]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int i = tid; i < 256 + NA; i += W12_THREADS) tB[i] = tab2[i];
+    const FftItem it = items[blockIdx.x];
+    __syncthreads();
+    auto tw2 = [&](int k) {  // w_L''^k, 0 <= k < L''
+        const double2 a = tA[k >> 8], b = tB[k & 255];
+        return Cx{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+    };
+    auto twn = [&](long long k) { return tw2((int)((k % (2 * N)) * (D / 2))); };  // w_(2 N)^k
+    for (int i = tid; i < W12_NW * 8; i += W12_THREADS) {
+        const int d = i >> 3, n2 = i & 7;
+        const Cx w = cx_mul(twn(128LL * d * n2), tw2(64 * RC * n2));
+        btab[i] = make_double2(w.x, w.y);
+    }
+    for (int i = tid; i < 64 + 72 + 12; i += W12_THREADS) {
+        Cx w;
+        if (i < 64) w = twn(24LL * i);
+        else if (i < 64 + 72) w = twn(192LL * ((i - 64) / 9) * ((i - 64) % 9));
+        else w = tw2(512 * RC * (i - 64 - 72));
+        t1tab[i] = make_double2(w.x, w.y);
+    }
+    __syncthreads();
+    const Cx tw_l = cx_mul(twn(2LL * lane * wv), w12_ld(tB + RC * lane));  // w_N^(lane d) w_L''^(RC lane)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) saccg[i * W12_THREADS + tid] = 0.0;
+    // the lane's samples: g[n], h[n], g[n + 6144], h[n + 6144], n = tid + 768 i
+    double xs[8][4];
+    auto fetch = [&](long long c) {
+        const double *row = x + (size_t)c * (size_t)(2 * G2);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int n = tid + W12_THREADS * i;
+            xs[i][0] = __builtin_nontemporal_load(row + n);
+            xs[i][1] = __builtin_nontemporal_load(row + G2 + n);
+            xs[i][2] = __builtin_nontemporal_load(row + n + N);
+            xs[i][3] = __builtin_nontemporal_load(row + G2 + n + N);
+        }
+    };
+    double2 *myR = R + wv * RS;
+    const int hj = (wv & 7) * 64 + lane;
+    if (it.c_lo < it.c_hi) fetch(it.c_lo);
+    for (long long c = it.c_lo; c < it.c_hi; ++c) {
+        const bool more = c + 1 < it.c_hi;
+        const double2 *ctab_s = ctab, *btab_s = btab;
+        asm volatile("" : "+v"(ctab_s), "+v"(btab_s));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int n = tid + W12_THREADS * i, e = n >> 9;
+            const double x0 = 0.5 * (xs[i][0] + xs[i][1]), x2 = 0.5 * (xs[i][0] - xs[i][1]);
+            const double x1 = 0.5 * (xs[i][2] + xs[i][3]), x3 = 0.5 * (xs[i][2] - xs[i][3]);
+            Cx sv = {x0, 0.0};
+            sv = cx_add(sv, w12r_root_mul<RC, 8>(x1));
+            sv = cx_add(sv, w12r_root_mul<2 * RC, 8>(x2));
+            sv = cx_add(sv, w12r_root_mul<3 * RC, 8>(x3));
+            sv = cx_mul(sv, w12_ld(ctab_s + e));
+            w12_st(R + e * RS + (n & 511), sv);
+        }
+        if (more) fetch(c + 1);
+        __syncthreads();
+        if (wv < 8) w12r_dft12(R + hj);
+        __syncthreads();
+        Cx a[8];
+        w12r_passes(a, myR, lane, btab_s + wv * 8, tw_l, t1tab, t2tab);
+#pragma unroll
+        for (int k0 = 0; k0 < 8; ++k0) {
+            double v = saccg[k0 * W12_THREADS + tid];
+            v = __builtin_fma(a[k0].x, a[k0].x, v);
+            v = __builtin_fma(a[k0].y, a[k0].y, v);
+            saccg[k0 * W12_THREADS + tid] = v;
+        }
+        __syncthreads();
+    }
+    double *pp = Ppart + (size_t)it.row * (LP / 2 + 1);
+#pragma unroll
+    for (int k0 = 0; k0 < 8; ++k0) {
+        const int kp = (lane >> 3) + 8 * (lane & 7) + 64 * k0;
+        const int k = D * (wv + W12_NW * kp) + RC;
+        pp[k <= LP / 2 ? k : LP - k] = saccg[k0 * W12_THREADS + tid];
     }
 }
 

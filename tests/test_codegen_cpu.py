@@ -212,3 +212,21 @@ def test_staging_stores_keep_their_data_registers_for_two_cycles():
     found = {k: wide_store_hazards(body) for k, (body, _) in kern.items()}
     found = {k: v for k, v in found.items() if v}
     assert found == {}, found
+
+
+def test_long_series_kernels_stay_inside_their_register_budgets():
+    """Round 6. msd_power_w12p_kernel (msd_fft_w12r.h) runs twelve waves per block — 168 registers each — and requests its
+    next samples a transform ahead: a spilled register's reload waits for those loads (scratch and global memory share a
+    counter), so the kernel is only as fast as measured while (almost) nothing spills: <= 12 registers (ROCm 7.2: 8), all in
+    its prologue and epilogue. The first form of the kernel hoisted every table entry out of the series loop and spilled
+    206. fft_power_pass_kernel (fft_pow2.hip) likewise: three waves per SIMD, <= 8 spilled registers (hoisted, it spilled
+    79-147 and ran at a quarter of the speed)."""
+    kern = _kernels(_asm("msd_fft.hip"))
+    _, meta = _find(kern, "msd_power_w12p_kernel")
+    assert int(meta["vgpr_count"]) <= 168 and int(meta["vgpr_spill_count"]) <= 12, meta
+    fft = _kernels(_asm("fft_pow2.hip"))
+    hits = [k for k in fft if "fft_power_pass_kernel" in k]
+    assert len(hits) >= 5
+    for k in hits:
+        meta = fft[k][1]
+        assert int(meta["vgpr_count"]) <= 168 and int(meta["vgpr_spill_count"]) <= 8, (k, meta)

@@ -532,7 +532,8 @@ def test_lag_msd_long_series_finish_on_the_device(B):
             # (the bound is relative to the SMALLEST |MSD sum| over the lags: with max_lag ~ F the last lags hold one or two
             # origins of two entities, so it is far looser here than at C4 — what is tested is that the result respects it)
             # (round 6: up to F + max_lag = 24 576 the residue-class kernel, beyond it the batched transforms)
-            want_kernel = "msd_power_w12p_kernel" if F + max_lag <= 24576 and F <= 12288 else "lag_msd_fft"
+            want_kernel = ("msd_power_w12p_kernel" if F + max_lag <= 24576 and F <= 12288 else
+                           "msd_power_w12p_kernel + msd_power_w12o_kernel" if F + max_lag <= 49152 and F <= 24576 else "lag_msd_fft")
             assert ctx.last_kernel_name() == want_kernel and 0.0 < bound < 1e-4, (ctx.last_kernel_name(), bound)
             assert (fft[0] == 0.0).all()
             nz = exact > 0
@@ -598,7 +599,8 @@ def test_lag_msd_long_series_finish_on_the_device(B):
         # more series than one batch holds / than the fused pass has rows per split: groups that straddle batches, splits and
         # blocks — both long-series paths (the residue-class kernel; the batched transforms), small batches forced
         for F, E, goff, mb in ((8200, 700, [0, 1, 130, 700], -1), (8193, 300, [0, 300], 1), (12288, 40, [0, 7, 7, 40], 1),
-                               (11111, 130, [0, 64, 65, 130], 2)):
+                               (11111, 130, [0, 64, 65, 130], 2), (12289, 70, [0, 3, 70], 1), (24576, 9, [0, 9], -1),
+                               (17001, 150, [0, 50, 150], 3)):
             r = np.cumsum(rng.normal(0, 0.1, (F, 3, E)), axis=0) + rng.uniform(-50, 50, (1, 3, E))
             ctx.set_option("lag_variant", 1)
             exact = B.lag_msd(r, F - 1, goff)
@@ -606,7 +608,10 @@ def test_lag_msd_long_series_finish_on_the_device(B):
             ctx.set_option("lag_variant", 2)
             try:
                 ctx.set_option("lag_batch_mb", mb)
+                long_form = "msd_power_w12p_kernel + msd_power_w12o_kernel"  # (padded length 49 152: F > 12 288)
                 for residue, name in ((1, "msd_power_w12p_kernel"), (2, "msd_power_w12r_kernel"), (0, "lag_msd_fft")):
+                    if F > 12288 and residue:
+                        name = long_form
                     ctx.set_option("lag_residue", residue)
                     fft = B.lag_msd(r, F - 1, goff)
                     bound = ctx.last_rel_bound()

@@ -10,7 +10,7 @@ TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/pmc2
 mkdir -p $OUT
-WL=${@:-"msd_pairs msd_windows com flux lag_fft lag_diff acf_fft acf_direct cumtrapz residence"}
+WL=${@:-"msd_pairs msd_windows com flux lag_fft lag_long lag_diff acf_fft acf_direct cumtrapz residence"}
 cd /tmp && export TMPDIR=/tmp
 P1="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"
 P2="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_SCA SQ_THREAD_CYCLES_VALU"
