@@ -128,7 +128,7 @@ def pmc_entry(kernel, workload):
     return e, None
 
 
-SECONDARY_SOURCES = ["msd.hip", "msd_fft.hip", "msd_fft_w12.h", "segment_com.hip", "xcorr.hip", "fft_pow2.hip", "scan.hip",
+SECONDARY_SOURCES = ["msd.hip", "msd_fft.hip", "msd_fft_w12.h", "msd_fft_w12r.h", "segment_com.hip", "xcorr.hip", "fft_pow2.hip", "scan.hip",
                      "residence.hip"]
 LDS_READ_PEAK = 150e12  # ds_read_b64 / b128 aggregate with every CU streaming, MI355X_MICROARCH.md (LDS section)
 

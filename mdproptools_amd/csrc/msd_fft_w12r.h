@@ -645,7 +645,7 @@ __global__ __launch_bounds__(W12_THREADS) void msd_power_w12o_kernel(const doubl
 }
 
 // corr[s][k] = (1 / L') sum_{f < L'} P_s[f] e^{2 pi i f k / L'}, P_s[L' - f] = P_s[f] given for f = 0 .. L'/2, k < n_lags — by direct
-// summation: lane = one lag, the RI_WAVES waves of a block take a share of the frequencies each (two independent sums per
+// summation: lane = one lag, the RI_WAVES waves of a block take a share of the frequencies each (four independent sums per
 // lane); cos from a quarter-wave table in LDS (L'/4 + 1 entries, cospi of 2 m / L'); products and sums in double-double
 // (two_prod by fma, two_sum), so that the 12 288 terms cost no accuracy against a transform's log2 L' stages.
 // grid (ceil(n_lags / 64), S), 64 RI_WAVES lanes.
@@ -662,9 +662,8 @@ __global__ __launch_bounds__(64 * RI_WAVES) void msd_residue_inverse_kernel(cons
     __syncthreads();
     const double *p = P + (size_t)blockIdx.y * (H + 1);
     const int k = blockIdx.x * 64 + lane;
-    // frequencies f = 1 .. H - 1 in RI_WAVES parts, each walked from both ends by two sums
+    // frequencies f = 1 .. H - 1 in RI_WAVES parts, each in four runs with a sum of its own (four independent chains per lane)
     const int f0 = 1 + (int)((long long)(H - 1) * wv / RI_WAVES), f1 = 1 + (int)((long long)(H - 1) * (wv + 1) / RI_WAVES);
-    const int fm = (f0 + f1) / 2;
     auto cosv = [&](long long idx) {
         int m = (int)idx;
         if (m > H) m = LP - m;
@@ -676,21 +675,32 @@ __global__ __launch_bounds__(64 * RI_WAVES) void msd_residue_inverse_kernel(cons
         lo += ((hi - (s - bb)) + (ph - bb)) + pl;
         hi = s;
     };
-    long long ia = ((long long)f0 * (long long)k) % LP, ib = ((long long)fm * (long long)k) % LP;
-    double ah = 0.0, al = 0.0, bh = 0.0, bl = 0.0;
-    const int na = fm - f0, nbb = f1 - fm;  // (nbb = na or na + 1)
-    for (int i = 0; i < na; ++i) {
-        dd_add(ah, al, p[f0 + i], cosv(ia));
-        dd_add(bh, bl, p[fm + i], cosv(ib));
-        ia += k;
-        if (ia >= LP) ia -= LP;
-        ib += k;
-        if (ib >= LP) ib -= LP;
+    const int nq = (f1 - f0) / 4;  // terms per run; the remainder (< 4 terms) goes to the first sum
+    double sh[4] = {0.0, 0.0, 0.0, 0.0}, sl[4] = {0.0, 0.0, 0.0, 0.0};
+    long long ix[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ix[u] = ((long long)(f0 + u * nq) * (long long)k) % LP;
+    for (int i = 0; i < nq; ++i) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            dd_add(sh[u], sl[u], p[f0 + u * nq + i], cosv(ix[u]));
+            ix[u] += k;
+            if (ix[u] >= LP) ix[u] -= LP;
+        }
     }
-    if (nbb > na) dd_add(bh, bl, p[f1 - 1], cosv(ib));
     {
-        const double s = ah + bh, bb = s - ah;
-        al += ((ah - (s - bb)) + (bh - bb)) + bl;
+        long long ir = ((long long)(f0 + 4 * nq) * (long long)k) % LP;
+        for (int f = f0 + 4 * nq; f < f1; ++f) {
+            dd_add(sh[0], sl[0], p[f], cosv(ir));
+            ir += k;
+            if (ir >= LP) ir -= LP;
+        }
+    }
+    double ah = sh[0], al = sl[0];
+#pragma unroll
+    for (int u = 1; u < 4; ++u) {
+        const double s = ah + sh[u], bb = s - ah;
+        al += ((ah - (s - bb)) + (sh[u] - bb)) + sl[u];
         ah = s;
     }
     red[(wv * 64 + lane) * 2] = ah;

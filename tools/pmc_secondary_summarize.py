@@ -26,7 +26,7 @@ KEEP = ("msd_", "segment_", "type_sum", "mol_flux", "fft_", "xcorr_", "lag_msd",
 
 
 HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SECONDARY_SOURCES = ["msd.hip", "msd_fft.hip", "msd_fft_w12.h", "segment_com.hip", "xcorr.hip", "fft_pow2.hip", "scan.hip",
+SECONDARY_SOURCES = ["msd.hip", "msd_fft.hip", "msd_fft_w12.h", "msd_fft_w12r.h", "segment_com.hip", "xcorr.hip", "fft_pow2.hip", "scan.hip",
                      "residence.hip"]
 
 

@@ -56,7 +56,7 @@ def main():
     mass = np.where(np.arange(E) < 40_000, 2.0, 3.0)
     M = len(off) - 1
     if what == "lag_long":
-        F = 10_000
+        F = int(os.environ.get("LAG_F", 10_000))
     if what in ("msd_pairs", "msd_windows", "com", "flux", "lag_fft", "lag_diff", "lag_long"):
         r = c4_walk(torch, dev, synth, E, F)
     if what == "msd_pairs":
