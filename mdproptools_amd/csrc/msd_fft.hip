@@ -2536,8 +2536,9 @@ int lag_msd_fft_residue(CallScope &cs, long long F, long long E, const double *d
     // classes (0, 1, 2), nothing packed — the first form of the kernel, kept for A/B
     const bool packed = ctx->opt_lag_residue != 2 || D == 8;
     const size_t ldsr = packed ? w12p_lds_bytes() : w12r_lds_bytes(4);
-    MD_HIP(hipFuncSetAttribute(packed ? reinterpret_cast<const void *>(msd_power_w12p_kernel)
-                                      : reinterpret_cast<const void *>(msd_power_w12r_kernel<4>),
+    MD_HIP(hipFuncSetAttribute(!packed  ? reinterpret_cast<const void *>(msd_power_w12r_kernel<4>)
+                               : D == 4 ? reinterpret_cast<const void *>(msd_power_w12p_kernel<true>)
+                                        : reinterpret_cast<const void *>(msd_power_w12p_kernel<false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr));
     if (D == 8) {
         MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msd_power_w12o_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2563,14 +2564,14 @@ int lag_msd_fft_residue(CallScope &cs, long long F, long long E, const double *d
         (void)nb;
         const int n_it = batch_off[(size_t)b + 1] - batch_off[(size_t)b];
         if (D == 8) {
-            hipLaunchKernelGGL(msd_power_w12p_kernel, dim3((unsigned)n_it), dim3(W12_THREADS), ldsr, ctx->stream, d_pad, row_len,
+            hipLaunchKernelGGL(msd_power_w12p_kernel<false>, dim3((unsigned)n_it), dim3(W12_THREADS), ldsr, ctx->stream, d_pad, row_len,
                                2 * W12_N, 2 * W12_N, 2 * W12_N, 2, (int)K, d_items + batch_off[(size_t)b], d_tab, d_part);
             hipLaunchKernelGGL(msd_power_w12o_kernel<1>, dim3((unsigned)n_it), dim3(W12_THREADS), w12o_lds_bytes(), ctx->stream,
                                d_pad, d_items + batch_off[(size_t)b], d_tab + n_tab4, d_part);
             hipLaunchKernelGGL(msd_power_w12o_kernel<3>, dim3((unsigned)n_it), dim3(W12_THREADS), w12o_lds_bytes(), ctx->stream,
                                d_pad, d_items + batch_off[(size_t)b], d_tab + n_tab4, d_part);
         } else if (packed)
-            hipLaunchKernelGGL(msd_power_w12p_kernel, dim3((unsigned)n_it), dim3(W12_THREADS), ldsr, ctx->stream, d_pad, row_len,
+            hipLaunchKernelGGL(msd_power_w12p_kernel<true>, dim3((unsigned)n_it), dim3(W12_THREADS), ldsr, ctx->stream, d_pad, row_len,
                                (int)F, 0, (int)F, 1, (int)K, d_items + batch_off[(size_t)b], d_tab, d_part);
         else
             hipLaunchKernelGGL((msd_power_w12r_kernel<4>), dim3((unsigned)n_it), dim3(W12_THREADS), ldsr, ctx->stream, d_pad, (int)F,

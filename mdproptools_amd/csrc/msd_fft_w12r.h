@@ -352,6 +352,10 @@ inline size_t w12p_lds_bytes()
 // makes the odd ones): rows [g | h] of 12 288 samples each, g[n] = x[n] + x[n + 12288], h[n] = x[n] - x[n + 12288]
 // (transpose_fold64_sq_kernel) — the 24 576-point transform of the series folded once is the packed transform of g and class
 // 1 of h —, stride = 24 576, Fp = Fo = off_odd = 12 288, kmul = 2, prow = 24 577.
+// SHARE (the D = 4 use): both transforms of a series from ONE set of samples. The packed transform's lane holds x[2 m],
+// x[2 m + 1] for m = tid + 768 i, i < 8 — and 6144 samples further is 4 i further in the same lane: the lane also holds the
+// odd class's pairs (x[n], x[n + 6144]) for its own 8 points n = 2 (tid + 768 i) + p, i < 4, p < 2. The series is read once.
+template <bool SHARE>
 __global__ __launch_bounds__(W12_THREADS) void msd_power_w12p_kernel(const double *__restrict__ x, long long stride, int Fp,
                                                                      int off_odd, int Fo, int kmul, int prow,
                                                                      const FftItem *__restrict__ items,
@@ -442,7 +446,7 @@ __global__ __launch_bounds__(W12_THREADS) void msd_power_w12p_kernel(const doubl
             const int m = tid + W12_THREADS * i;
             w12_st(R + (m >> 9) * RS + (m & 511), Cx{xs[i][0], xs[i][1]});
         }
-        fetch_odd(c);
+        if constexpr (!SHARE) fetch_odd(c);
         __syncthreads();
         if (wv < 8) w12r_dft12(R + hj);
         __syncthreads();
@@ -483,9 +487,10 @@ __global__ __launch_bounds__(W12_THREADS) void msd_power_w12p_kernel(const doubl
         // ======== the odd frequencies: class r = 1 ========
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int n = tid + W12_THREADS * i, e = n >> 9;
             // x[n] + w_4 x[n + 6144] = x[n] - i x[n + 6144], times w_L'^(512 e) (w_L'^j rides in the register passes)
-            const Cx sv = cx_mul(Cx{xs[i][0], -xs[i][1]}, w12_ld(ctab_s + e));
+            const int n = SHARE ? 2 * (tid + W12_THREADS * (i >> 1)) + (i & 1) : tid + W12_THREADS * i, e = n >> 9;
+            const Cx xv = SHARE ? Cx{xs[i >> 1][i & 1], -xs[(i >> 1) + 4][i & 1]} : Cx{xs[i][0], -xs[i][1]};
+            const Cx sv = cx_mul(xv, w12_ld(ctab_s + e));
             w12_st(R + e * RS + (n & 511), sv);
         }
         if (more) fetch_packed(c + 1);

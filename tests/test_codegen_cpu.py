@@ -222,8 +222,9 @@ def test_long_series_kernels_stay_inside_their_register_budgets():
     206. fft_power_pass_kernel (fft_pow2.hip) likewise: three waves per SIMD, <= 8 spilled registers (hoisted, it spilled
     79-147 and ran at a quarter of the speed)."""
     kern = _kernels(_asm("msd_fft.hip"))
-    _, meta = _find(kern, "msd_power_w12p_kernel")
-    assert int(meta["vgpr_count"]) <= 168 and int(meta["vgpr_spill_count"]) <= 12, meta
+    for inst in ("Lb1", "Lb0"):
+        _, meta = _find(kern, "msd_power_w12p_kernelI%sE" % inst)
+        assert int(meta["vgpr_count"]) <= 168 and int(meta["vgpr_spill_count"]) <= 12, meta
     fft = _kernels(_asm("fft_pow2.hip"))
     hits = [k for k in fft if "fft_power_pass_kernel" in k]
     assert len(hits) >= 5
