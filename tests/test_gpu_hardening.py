@@ -283,6 +283,18 @@ def test_soak_slice_full_lag_sources():
     assert r.returncode == 0 and "agree within their bounds" in tail, tail
 
 
+def test_soak_slice_long_trajectories():
+    """A slice of tests/bench/soak_lag_long.py inside `-m gpu` (round 6): six random shapes of 8193 .. 26 000 frames through
+    the residue-class kernels (padded length 24 576 / 49 152, both forms) against the batched transforms, batches of a few
+    MB so that batches, blocks and segments straddle — agreement within the reported bounds, reproducible bit for bit."""
+    import subprocess
+
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "bench", "soak_lag_long.py"), "6", "5"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    tail = "\n".join(r.stdout.splitlines()[-5:])
+    assert r.returncode == 0 and "agree with the batched transforms" in tail, tail
+
+
 def test_every_pair_ambiguous_fills_the_queues(B):
     """The deferred-pair queues at their limit (the push has no capacity test). Atoms sit on TWO points a
     whole number of bins apart: every pair is either at distance 0 or exactly on a bin edge, i.e. inside the guard band of
