@@ -208,6 +208,7 @@ struct mdhip_ctx {
     int opt_xcorr_tile = 0;
     int opt_lag_residue = 1;      // full-lag MSD with 16 384 < F + max_lag <= 24 576: 1 (default) the residue-class kernel (msd_fft_w12r.h), 0 the batched transforms
     int opt_lag_mean_sample = -1; // long-series paths: the series are centred on the mean of about this many sampled frames (-1: 512; 0: every frame)
+    int opt_lag_w1 = 1;           // full-lag MSD of F <= 1536 frames (F + max_lag <= 3072): 1 (default) one wave per series (msd_power_w1_kernel), 0 the block-wide kernels
     int opt_lag_batch_mb = 4096;  // batched full-lag path: device memory of one batch of series (centred series + transform buffers), MB
     int opt_lag_w12_min_f = 1536;  // full-lag MSD with 2048 < F + max_lag <= 8192: from this many frames on the 12288-point
                                    // kernel (msd_fft_w12.h) instead of the 8192-point one; 0 = never, >= 1536

@@ -765,6 +765,8 @@ int mdhip_set_option(mdhip_ctx *ctx, const char *key, int value)
         ctx->opt_lag_residue = value < 0 ? 1 : value;
     else if (!strcmp(key, "lag_mean_sample"))
         ctx->opt_lag_mean_sample = value;
+    else if (!strcmp(key, "lag_w1"))
+        ctx->opt_lag_w1 = value < 0 ? 1 : value;
     else if (!strcmp(key, "lag_batch_mb"))
         ctx->opt_lag_batch_mb = value <= 0 ? 4096 : std::min(value, 65536);
     else if (!strcmp(key, "lag_w12_min_f"))

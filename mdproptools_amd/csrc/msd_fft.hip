@@ -2423,24 +2423,29 @@ int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r
 // >= F + max_lag, F <= 12 288. The trajectory is transposed and centred batch by batch (transpose_centre64_kernel, as the
 // batched path), every batch's series are dealt to one block per CU, the blocks' partial spectra are folded per segment, and
 // the correlations come from msd_residue_inverse_kernel; the finish is the fused kernels' (lag_finish_dd_kernel).
-// frames between two samples of the series' means (col_sum_sample_kernel): ~512 samples of a long trajectory; option
+// frames between two samples of the series' means (col_sum_sample_kernel): ~512 samples of a long trajectory (128 of one of at
+// most 1536 frames); option
 // `lag_mean_sample` 0 = every frame, n > 0 = about n samples
-inline long long lag_mean_stride(const mdhip_ctx *ctx, long long F)
+inline long long lag_mean_stride(const mdhip_ctx *ctx, long long F, long long dflt = 512)
 {
     if (ctx->opt_lag_mean_sample == 0) return 1;
-    const long long want = ctx->opt_lag_mean_sample > 0 ? ctx->opt_lag_mean_sample : 512;
+    const long long want = ctx->opt_lag_mean_sample > 0 ? ctx->opt_lag_mean_sample : dflt;
     return std::max<long long>(1, F / want);
 }
 
+// short_d2 > 0: trajectories BELOW msd_power_w12_kernel's range (F + max_lag <= 3072, F <= 1536) through msd_power_w1_kernel<short_d2>
+// — padded length short_d2 x 1024, one wave per series; the same preparation, folds, inverse and finish.
 int lag_msd_fft_residue(CallScope &cs, long long F, long long E, const double *d_r, double scale, int max_lag, long long G,
-                        const int64_t *group_off, const std::shared_ptr<LagFftResult> &res, double *out, int out_on_device)
+                        const int64_t *group_off, const std::shared_ptr<LagFftResult> &res, double *out, int out_on_device,
+                        int short_d2 = 0)
 {
     mdhip_ctx *ctx = cs.ctx;
     // D = 4: padded length 24 576, the series as they are; D = 8: 49 152, the series folded once by the transposition (rows
     // [g | h] of 24 576 doubles): the even frequencies by the D = 4 kernel over those rows, the odd ones by msd_power_w12o_kernel
-    const int D = (F <= 2LL * W12_N && F + max_lag <= 4LL * W12_N) ? 4 : 8;
-    const long long LP = (long long)D * W12_N, K = LP / 2 + 1;
-    const long long LP4 = 4LL * W12_N;  // the length msd_power_w12p_kernel transforms at
+    const int D = short_d2 ? 4 : (F <= 2LL * W12_N && F + max_lag <= 4LL * W12_N) ? 4 : 8;  // (short: as D = 4 in what follows)
+    const long long LP = short_d2 ? 1024LL * short_d2 : (long long)D * W12_N, K = LP / 2 + 1;
+    const long long LP4 = short_d2 ? LP : 4LL * W12_N;  // the length of the first twiddle table (msd_power_w12p_kernel's)
+    const int rows_per_item = 1;                        // partial spectra a block writes
     const long long n_lags = (long long)max_lag + 1, cols = 3 * E, S = 3 * G;
     const long long row_len = D == 4 ? F : 4LL * W12_N;  // doubles per series of the time-major copy
     res->delivered = true;
@@ -2495,7 +2500,7 @@ int lag_msd_fft_residue(CallScope &cs, long long F, long long E, const double *d
     MD_WS(d_mean, double, WS_AUX0, (size_t)(MF_SLABS + 1) * cols * 8);
     double *d_msum = d_mean + cols;
     MD_WS(d_pad, double, WS_AUX1, (size_t)nb0 * row_len * 8 + 256);
-    MD_WS(d_part, double, WS_PART, (size_t)max_items * K * 8);
+    MD_WS(d_part, double, WS_PART, (size_t)max_items * rows_per_item * K * 8);
     MD_WS(d_qpart, double, WS_AUX2, (size_t)max_tiles * F * 8);
     const size_t q_b = (size_t)S * F * 8, p_b = (size_t)S * K * 8, c_b = (size_t)S * n_lags * 8;
     const size_t tab_b = (size_t)n_tab * 16, it_b = (items.size() * sizeof(FftItem) + 15) / 16 * 16;
@@ -2522,7 +2527,7 @@ int lag_msd_fft_residue(CallScope &cs, long long F, long long E, const double *d
     MD_HIP(hipMemsetAsync(d_Q, 0, q_b + p_b, ctx->stream));  // (Q | P: both are added to, batch by batch)
 
     KernelTimer timer(ctx);
-    const long long m_stride = lag_mean_stride(ctx, F);
+    const long long m_stride = lag_mean_stride(ctx, F, short_d2 ? 128 : 512);
     if (m_stride > 1)
         hipLaunchKernelGGL(col_sum_sample_kernel, dim3((unsigned)((cols + 255) / 256), MF_SLABS), dim3(256), 0, ctx->stream, d_r, F,
                            cols, m_stride, d_msum);
@@ -2535,10 +2540,13 @@ int lag_msd_fft_residue(CallScope &cs, long long F, long long E, const double *d
     // lag_residue 1 (default): two transforms per series (the even frequencies packed, the odd ones as class 1); 2: three
     // classes (0, 1, 2), nothing packed — the first form of the kernel, kept for A/B
     const bool packed = ctx->opt_lag_residue != 2 || D == 8;
-    const size_t ldsr = packed ? w12p_lds_bytes() : w12r_lds_bytes(4);
-    MD_HIP(hipFuncSetAttribute(!packed  ? reinterpret_cast<const void *>(msd_power_w12r_kernel<4>)
-                               : D == 4 ? reinterpret_cast<const void *>(msd_power_w12p_kernel<true>)
-                                        : reinterpret_cast<const void *>(msd_power_w12p_kernel<false>),
+    const size_t ldsr = short_d2 ? w1_lds_bytes(short_d2) : packed ? w12p_lds_bytes() : w12r_lds_bytes(4);
+    MD_HIP(hipFuncSetAttribute(short_d2 == 1   ? reinterpret_cast<const void *>(msd_power_w1_kernel<1>)
+                               : short_d2 == 2 ? reinterpret_cast<const void *>(msd_power_w1_kernel<2>)
+                               : short_d2 == 3 ? reinterpret_cast<const void *>(msd_power_w1_kernel<3>)
+                               : !packed       ? reinterpret_cast<const void *>(msd_power_w12r_kernel<4>)
+                               : D == 4        ? reinterpret_cast<const void *>(msd_power_w12p_kernel<true>)
+                                               : reinterpret_cast<const void *>(msd_power_w12p_kernel<false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr));
     if (D == 8) {
         MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msd_power_w12o_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2563,7 +2571,16 @@ int lag_msd_fft_residue(CallScope &cs, long long F, long long E, const double *d
         }
         (void)nb;
         const int n_it = batch_off[(size_t)b + 1] - batch_off[(size_t)b];
-        if (D == 8) {
+        if (short_d2 == 1)
+            hipLaunchKernelGGL(msd_power_w1_kernel<1>, dim3((unsigned)n_it), dim3(W12_THREADS), ldsr, ctx->stream, d_pad, (int)F,
+                               d_items + batch_off[(size_t)b], d_tab, d_part);
+        else if (short_d2 == 2)
+            hipLaunchKernelGGL(msd_power_w1_kernel<2>, dim3((unsigned)n_it), dim3(W12_THREADS), ldsr, ctx->stream, d_pad, (int)F,
+                               d_items + batch_off[(size_t)b], d_tab, d_part);
+        else if (short_d2 == 3)
+            hipLaunchKernelGGL(msd_power_w1_kernel<3>, dim3((unsigned)n_it), dim3(W12_THREADS), ldsr, ctx->stream, d_pad, (int)F,
+                               d_items + batch_off[(size_t)b], d_tab, d_part);
+        else if (D == 8) {
             hipLaunchKernelGGL(msd_power_w12p_kernel<false>, dim3((unsigned)n_it), dim3(W12_THREADS), ldsr, ctx->stream, d_pad, row_len,
                                2 * W12_N, 2 * W12_N, 2 * W12_N, 2, (int)K, d_items + batch_off[(size_t)b], d_tab, d_part);
             hipLaunchKernelGGL(msd_power_w12o_kernel<1>, dim3((unsigned)n_it), dim3(W12_THREADS), w12o_lds_bytes(), ctx->stream,
@@ -2578,7 +2595,8 @@ int lag_msd_fft_residue(CallScope &cs, long long F, long long E, const double *d
                                d_items + batch_off[(size_t)b], d_tab, d_part);
         for (; fold_i < folds.size() && folds[fold_i].batch == b; ++fold_i)
             hipLaunchKernelGGL(power_fold_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, ctx->stream,
-                               d_part + (size_t)folds[fold_i].first * K, folds[fold_i].count, K, d_P + (size_t)folds[fold_i].seg * K);
+                               d_part + (size_t)folds[fold_i].first * rows_per_item * K, folds[fold_i].count * rows_per_item, K,
+                               d_P + (size_t)folds[fold_i].seg * K);
         MD_HIP(hipGetLastError());
     }
     const size_t ldsi = (size_t)(LP / 4 + 1 + RI_WAVES * 64 * 2) * 8;
@@ -2588,7 +2606,10 @@ int lag_msd_fft_residue(CallScope &cs, long long F, long long E, const double *d
                        d_P, (int)LP, (int)n_lags, d_corr);
     MD_HIP(hipGetLastError());
     timer.stop();
-    ctx->last_kernel = D == 8 ? "msd_power_w12p_kernel + msd_power_w12o_kernel" : packed ? "msd_power_w12p_kernel" : "msd_power_w12r_kernel";
+    ctx->last_kernel = short_d2 ? "msd_power_w1_kernel"
+                       : D == 8 ? "msd_power_w12p_kernel + msd_power_w12o_kernel"
+                       : packed ? "msd_power_w12p_kernel"
+                                : "msd_power_w12r_kernel";
 
     // the finish, on the device, as the fused kernels'
     const size_t fin_b = (size_t)n_lags * G * 4 * 8;
@@ -2638,6 +2659,12 @@ int mdhip_lag_msd_fft(CallScope &cs, int64_t n_frames, int64_t n_ent, const doub
     res->bound = 0.0;
     const long long n_lags = (long long)max_lag + 1;
     const long long cols = 3 * E;
+    // round 6: trajectories below msd_power_w12_kernel's range, one wave per series (msd_fft_w12r.h): padded length 1024 / 2048 / 3072
+    if (ctx->opt_lag_variant != 4 && ctx->opt_lag_w1 != 0 && F + max_lag <= 3072 && F <= 1536 && F >= 2 &&
+        (F < std::max(3 * W12_SUB, ctx->opt_lag_w12_min_f) || ctx->opt_lag_w12_min_f <= 0 || F + max_lag <= 2048) &&
+        w1_lds_bytes(3) <= ctx->lds_max)
+        return lag_msd_fft_residue(cs, F, E, d_r, scale, max_lag, G, group_off, res, out, out_on_device,
+                                   (int)((F + max_lag + 1023) / 1024));
     if (ctx->opt_lag_variant != 4) {
         // fused LDS path when the padded series fits: L = power of two >= max(16, F + max_lag)
         int m = 3;

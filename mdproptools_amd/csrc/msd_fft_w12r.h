@@ -48,6 +48,23 @@ __device__ __forceinline__ Cx w12r_root_mul(double a)  // a * w_DD^K (a real), D
     }
 }
 
+template <int K, int DD>
+__device__ __forceinline__ Cx w12r_root_mul_d(double a)  // a * w_DD^K (a real), DD = 2, 4 or 6
+{
+    if constexpr (DD == 4) return w12r_root_mul<K, 4>(a);
+    else if constexpr (DD == 2) return (K & 1) ? Cx{-a, 0.0} : Cx{a, 0.0};
+    else {
+        constexpr int k = ((K % 6) + 6) % 6;
+        constexpr double S60 = 0.86602540378443864676;
+        if constexpr (k == 0) return {a, 0.0};
+        else if constexpr (k == 1) return {0.5 * a, -S60 * a};
+        else if constexpr (k == 2) return {-0.5 * a, -S60 * a};
+        else if constexpr (k == 3) return {-a, 0.0};
+        else if constexpr (k == 4) return {-0.5 * a, S60 * a};
+        else return {0.5 * a, S60 * a};
+    }
+}
+
 // The 3-point DFT (w_3 = e^{-2 pi i / 3})
 __device__ __forceinline__ void w12r_dft3(Cx a, Cx b, Cx c, Cx &y0, Cx &y1, Cx &y2)
 {
@@ -292,10 +309,12 @@ __global__ __launch_bounds__(W12_THREADS) void msd_power_w12r_kernel(const doubl
 // j = d + 12 (k2 + 8 k1 + 64 k0), lane = k1 + 8 k2. brow: the per-register factors [8] applied in front (nullptr: none);
 // t: the per-lane factor folded into the first pass's twiddle chain.
 __device__ __forceinline__ void w12r_passes(Cx *a, double2 *myR, int lane, const double2 *brow, Cx t, const double2 *t1tab,
-                                            const double2 *t2tab)
+                                            const double2 *t2tab, bool from_region = true)
 {
+    if (from_region) {  // (false: the caller has put point lane + 64 n2 into a[n2] itself)
 #pragma unroll
-    for (int n2 = 0; n2 < 8; ++n2) a[n2] = w12_ld(myR + lane + 64 * n2);
+        for (int n2 = 0; n2 < 8; ++n2) a[n2] = w12_ld(myR + lane + 64 * n2);
+    }
     if (brow) {
 #pragma unroll
         for (int n2 = 1; n2 < 8; ++n2) a[n2] = cx_mul(a[n2], w12_ld(brow + n2));
@@ -647,6 +666,212 @@ __global__ __launch_bounds__(W12_THREADS) void msd_power_w12o_kernel(const doubl
         const int k = D * (wv + W12_NW * kp) + RC;
         pp[k <= LP / 2 ? k : LP - k] = saccg[k0 * W12_THREADS + tid];
     }
+}
+
+// SHORT trajectories (F + max_lag <= 3072, F <= 1536 — below msd_power_w12_kernel's range, where rounds 2-5 ran block-wide
+// transforms through LDS at one 8-wave block per CU: 2.1-3.9 ms per call at E = 50 000 whatever F): the same residue classes with
+// the 512-point sub-transform as the WHOLE transform — padded length L' = D2 x 1024, D2 = 1 .. 3; the frequencies k = D2 k'' are
+// the real transform of length 1024 of the series folded at 1024 (packed, 512 complex points, bilinear sums, the partner of
+// k'' in the same wave: msd_power_w12_kernel's wave 0); the classes r = 1 .. D2 - 1 (mod D = 2 D2) are 512-point transforms of
+// y_r[n] = w_L'^(r n) sum_q x[n + 512 q] w_D^(r q). One WAVE per series, twelve independent waves per block, no block
+// barrier in the series loop; a wave's region (8.3 KB) is the medium of its exchanges only. Samples straight from the
+// time-major centred copy (a series is <= 12 KB: the classes' re-reads hit L1 / L2).
+// LDS: regions [12][520] | w_L' tables ([256] w^i, [L'/256] w^(256 i)) | class tables [D2][8] | w_512^lane | w_64^(n0 k1) | the
+// sums of the last class [12][8][64] (registers hold the others').
+inline size_t w1_lds_bytes(int D2)
+{
+    return (size_t)W12_NW * W12_RS * 16 + (size_t)(256 + D2 * 1024 / 256) * 16 + (size_t)D2 * 8 * 16 + (64 + 72) * 16 +
+           (D2 >= 3 ? (size_t)W12_NW * 8 * 64 * 8 : 0);
+}
+
+// x: rows of F doubles; items: row ranges, one block each (wave w takes rows c_lo + w, + 12, ...); Ppart row it.row, L'/2 + 1
+// doubles.
+template <int D2>
+__global__ __launch_bounds__(W12_THREADS) void msd_power_w1_kernel(const double *__restrict__ x, int F,
+                                                                   const FftItem *__restrict__ items,
+                                                                   const double2 *__restrict__ tab2,
+                                                                   double *__restrict__ Ppart)
+{
+    constexpr int D = 2 * D2, N = 512, RS = W12_RS, LP = D2 * 1024, NA = LP / 256;
+    extern __shared__ double ft_lds[];
+    double2 *R = reinterpret_cast<double2 *>(ft_lds);
+    double2 *tB = R + W12_NW * RS, *tA = tB + 256;
+    double2 *btab = tA + NA;            // [r][n2] = w_L'^(64 r n2)
+    double2 *t1tab = btab + D2 * 8;     // [lane] = w_512^lane
+    double2 *t2tab = t1tab + 64;        // [9 n0 + k1] = w_64^(n0 k1)
+    double *sacc_l = reinterpret_cast<double *>(t2tab + 72);  // D2 == 3: class 2's sums [wave][k0][lane]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int i = tid; i < 256 + NA; i += W12_THREADS) tB[i] = tab2[i];
+    const FftItem it = items[blockIdx.x];
+    __syncthreads();
+    auto tw2 = [&](int k) {  // w_L'^k, 0 <= k < L'
+        const double2 a = tA[k >> 8], b = tB[k & 255];
+        return Cx{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+    };
+    for (int i = tid; i < D2 * 8 + 64 + 72; i += W12_THREADS) {
+        Cx w;
+        if (i < D2 * 8) w = tw2((64 * (i >> 3) * (i & 7)) % LP);
+        else if (i < D2 * 8 + 64) w = tw2(((i - D2 * 8) * D) % LP);  // w_512^i = w_L'^(i D)
+        else w = tw2((((i - D2 * 8 - 64) / 9) * ((i - D2 * 8 - 64) % 9) * 8 * D) % LP);  // w_64^m = w_L'^(8 D m)
+        btab[i] = make_double2(w.x, w.y);
+    }
+    __syncthreads();
+    // the partner of frequency k'' = k2 + 8 k1 + 64 k0 of the packed transform: 512 - k'', register 7 - k0 of the lane that
+    // holds -(k2 + 8 k1) mod 64; lane 0 pairs inside its own registers (msd_power_w12_kernel's wave 0)
+    const int mneg = (64 - ((lane >> 3) + 8 * (lane & 7))) & 63;
+    const int plane = (mneg >> 3) + 8 * (mneg & 7);
+    const bool self0 = lane == 0;
+    double2 *myR = R + wv * RS;
+    double sacc[8], tacc[5], sacc1[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sacc[i] = sacc1[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) tacc[i] = 0.0;
+    double *my_l = sacc_l + (size_t)wv * 8 * 64;
+    if constexpr (D2 >= 3) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) my_l[i * 64 + lane] = 0.0;
+    }
+    Cx tw_c[D2 >= 2 ? D2 - 1 : 1];  // w_L'^(r lane): the per-lane factor of class r's twiddle
+#pragma unroll
+    for (int r = 1; r < D2; ++r) tw_c[r - 1] = tw2(r * lane);
+    for (long long c = it.c_lo + wv; c < it.c_hi; c += W12_NW) {
+        const double *row = x + (size_t)c * F;
+        // (the tables' addresses through an opaque copy per series: see msd_power_w12r_kernel)
+        const double2 *btab_s = btab;
+        asm volatile("" : "+v"(btab_s));
+        Cx a[8];
+        // ======== the frequencies k = D2 k'': the packed transform of the series folded at 1024 ========
+#pragma unroll
+        for (int n2 = 0; n2 < 8; ++n2) {
+            const int t = 2 * (lane + 64 * n2);
+            double re = t < F ? row[t] : 0.0, im = t + 1 < F ? row[t + 1] : 0.0;
+            if constexpr (D2 >= 2) {  // (F > 1024 only then)
+                if (t + 1024 < F) re += row[t + 1024];
+                if (t + 1025 < F) im += row[t + 1025];
+            }
+            a[n2] = {re, im};
+        }
+        w12r_passes(a, myR, lane, nullptr, Cx{1.0, 0.0}, t1tab, t2tab, false);
+#pragma unroll
+        for (int k0 = 0; k0 < 8; ++k0) {
+            sacc[k0] = __builtin_fma(a[k0].x, a[k0].x, sacc[k0]);
+            sacc[k0] = __builtin_fma(a[k0].y, a[k0].y, sacc[k0]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k0 = 4; k0 < 8; ++k0) w12_st(myR + lane + 64 * (k0 - 4), a[k0]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (self0) {
+            tacc[0] = __builtin_fma(2.0 * a[0].x, a[0].y, tacc[0]);
+            tacc[4] = __builtin_fma(2.0 * a[4].x, a[4].y, tacc[4]);
+#pragma unroll
+            for (int u = 1; u < 4; ++u) {
+                tacc[u] = __builtin_fma(a[u].x, a[8 - u].y, tacc[u]);
+                tacc[u] = __builtin_fma(a[u].y, a[8 - u].x, tacc[u]);
+            }
+        } else {
+            Cx pz[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) pz[u] = w12_ld(myR + plane + 64 * (3 - u));  // the partner's register 7 - u
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                tacc[u] = __builtin_fma(a[u].x, pz[u].y, tacc[u]);
+                tacc[u] = __builtin_fma(a[u].y, pz[u].x, tacc[u]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ======== the classes r = 1 .. D2 - 1 ========
+        auto one_class = [&](auto rk) {
+            constexpr int r = decltype(rk)::value;
+#pragma unroll
+            for (int n2 = 0; n2 < 8; ++n2) {
+                const int n = lane + 64 * n2;
+                Cx sv = {n < F ? row[n] : 0.0, 0.0};
+                if (n + 512 < F) sv = cx_add(sv, w12r_root_mul_d<r, D>(row[n + 512]));
+                if (n + 1024 < F) sv = cx_add(sv, w12r_root_mul_d<2 * r, D>(row[n + 1024]));
+                a[n2] = sv;
+            }
+            w12r_passes(a, myR, lane, btab_s + r * 8, tw_c[r - 1], t1tab, t2tab, false);
+            if constexpr (r == 1) {
+#pragma unroll
+                for (int k0 = 0; k0 < 8; ++k0) {
+                    sacc1[k0] = __builtin_fma(a[k0].x, a[k0].x, sacc1[k0]);
+                    sacc1[k0] = __builtin_fma(a[k0].y, a[k0].y, sacc1[k0]);
+                }
+            } else {
+#pragma unroll
+                for (int k0 = 0; k0 < 8; ++k0) {
+                    double v = my_l[k0 * 64 + lane];
+                    v = __builtin_fma(a[k0].x, a[k0].x, v);
+                    v = __builtin_fma(a[k0].y, a[k0].y, v);
+                    my_l[k0 * 64 + lane] = v;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        };
+        if constexpr (D2 >= 2) one_class(std::integral_constant<int, 1>());
+        if constexpr (D2 >= 3) one_class(std::integral_constant<int, 2>());
+    }
+    // The packed transform's frequencies first, as msd_power_w12_kernel sorts them out (the wave's own region: {S, T} at point
+    // lane + 64 k0): |X_(D2 k'')|^2 = (S + S')/2 + Im(w) (S - S')/2 + Re(w) T, w = e^{-2 pi i k''/1024} — into registers.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k0 = 0; k0 < 8; ++k0) myR[lane + 64 * k0] = make_double2(sacc[k0], k0 < 4 ? tacc[k0] : 0.0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    double pk[8], p_top = 0.0;
+#pragma unroll
+    for (int k0 = 0; k0 < 8; ++k0) {
+        const int k = (lane >> 3) + 8 * (lane & 7) + 64 * k0;
+        double sn, tk;
+        if (self0) {
+            const int kq = (8 - k0) & 7;
+            sn = myR[64 * kq].x;
+            tk = k0 == 0 ? tacc[0] : k0 == 4 ? tacc[4] : k0 < 4 ? tacc[k0] : tacc[8 - k0];
+        } else {
+            const double2 pv = myR[plane + 64 * (7 - k0)];
+            sn = pv.x;
+            tk = k0 < 4 ? tacc[k0] : pv.y;
+        }
+        const double sk = sacc[k0];
+        const Cx w = tw2(k * D2);  // (cos, -sin) of 2 pi k / 1024
+        pk[k0] = 0.5 * (sk + sn) + w.y * (0.5 * (sk - sn)) + w.x * tk;
+        if (k == 0) p_top = sk - tk;
+    }
+    // The twelve waves' spectra are added in LDS, wave after wave in a fixed order (the regions are free behind the barrier): ONE
+    // row of L'/2 + 1 sums per block goes to memory (twelve rows per block made the fold of the partial spectra the most
+    // expensive kernel of the call).
+    __syncthreads();
+    double *rowsum = reinterpret_cast<double *>(R);
+    for (int i = tid; i <= LP / 2; i += W12_THREADS) rowsum[i] = 0.0;
+    __syncthreads();
+    for (int w = 0; w < W12_NW; ++w) {
+        if (wv == w) {
+#pragma unroll
+            for (int k0 = 0; k0 < 8; ++k0) {
+                const int j = (lane >> 3) + 8 * (lane & 7) + 64 * k0;
+                rowsum[D2 * j] += pk[k0];
+                if (j == 0) rowsum[D2 * N] += p_top;
+                if constexpr (D2 >= 2) {  // classes r >= 1: k = D j + r, or its mirror L' - k
+                    const int k = D * j + 1;
+                    rowsum[k <= LP / 2 ? k : LP - k] += sacc1[k0];
+                }
+                if constexpr (D2 >= 3) {
+                    const int k = D * j + 2;
+                    rowsum[k <= LP / 2 ? k : LP - k] += my_l[k0 * 64 + lane];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    double *pp = Ppart + (size_t)it.row * (LP / 2 + 1);
+    for (int i = tid; i <= LP / 2; i += W12_THREADS) pp[i] = rowsum[i];
 }
 
 // corr[s][k] = (1 / L') sum_{f < L'} P_s[f] e^{2 pi i f k / L'}, P_s[L' - f] = P_s[f] given for f = 0 .. L'/2, k < n_lags — by direct

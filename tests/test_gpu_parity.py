@@ -437,7 +437,7 @@ def test_lag_msd_fft_variant(B):
                 fft = B.lag_msd(r, max_lag, goff, scale=0.5)
                 bound = ctx.last_rel_bound()
                 assert (ctx.last_kernel_name() == "lag_msd_fft") == (variant == 4)
-                assert ctx.last_kernel_name() in ("lag_msd_fft", "msd_power_lds_kernel", "msd_power_w12_kernel") and (bound > 0.0) == (max_lag > 0) and bound < 1e-9, (F, bound)
+                assert ctx.last_kernel_name() in ("lag_msd_fft", "msd_power_lds_kernel", "msd_power_w12_kernel", "msd_power_w1_kernel") and (bound > 0.0) == (max_lag > 0) and bound < 1e-9, (F, bound)
                 assert fft.shape == exact.shape and (fft[0] == 0.0).all()
                 nz = exact > 0
                 rel = np.abs(fft[nz] - exact[nz]) / exact[nz]
@@ -462,7 +462,7 @@ def test_lag_msd_fft_variant(B):
         r = np.cumsum(rng.normal(0, 0.1, (500, 3, 64)), axis=0)
         ctx.set_option("lag_variant", 3)
         B.lag_msd(r, 499, [0, 64])
-        assert ctx.last_kernel_name() == "msd_power_lds_kernel" and 0.0 < ctx.last_rel_bound() <= 1e-10
+        assert ctx.last_kernel_name() == "msd_power_w1_kernel" and 0.0 < ctx.last_rel_bound() <= 1e-10
     finally:
         ctx.set_option("lag_variant", 1)
 
@@ -491,6 +491,15 @@ def test_lag_msd_fft_every_transform_size(B):
             ctx.set_option("lag_variant", 2)
             nz = exact > 0
             outs = []
+            # round 6: one wave per series below the 12288-point kernel's range (F <= 1536, F + max_lag <= 3072; the fused
+            # block-wide kernels this test walks stay behind `lag_w1` 0)
+            ctx.set_option("lag_w1", 1)
+            w1 = B.lag_msd(r, max_lag, goff, scale=0.5)
+            w1_bound = ctx.last_rel_bound()
+            takes_w1 = F <= 1536 and F + max_lag <= 3072 and (F < 1536 or F + max_lag <= 2048)
+            assert (ctx.last_kernel_name() == "msd_power_w1_kernel") == takes_w1, (F, max_lag, ctx.last_kernel_name())
+            assert (np.abs(w1[nz] - exact[nz]) / exact[nz]).max() <= w1_bound and (w1[0] == 0.0).all(), (F, max_lag, w1_bound)
+            ctx.set_option("lag_w1", 0)
             for kern in (3, 2, 1, 0):
                 ctx.set_option("lag_fft_kernel", kern)
                 fft = B.lag_msd(r, max_lag, goff, scale=0.5)
@@ -508,6 +517,55 @@ def test_lag_msd_fft_every_transform_size(B):
     finally:
         ctx.set_option("lag_variant", 1)
         ctx.set_option("lag_fft_kernel", 3)
+        ctx.set_option("lag_w1", -1)
+
+
+def test_lag_msd_short_series_one_wave_per_series(B):
+    """Round 6: trajectories of at most 1536 frames (F + max_lag <= 3072) run msd_power_w1_kernel — padded length 1024, 2048 or
+    3072, one wave per series, residue classes of the spectrum. Every padded length on both sides of its limits,
+    full and truncated lags, tiny frame counts, groups that start mid-tile / are empty / hold one entity, more series than
+    one block's twelve waves, several batches: within the reported bound of the exact-difference kernel, equal to the C
+    oracle at rtol 1e-9, zero at lag 0, reproducible bit for bit, device result = host result."""
+    import torch
+
+    ctx = B.default_context()
+    rng = np.random.default_rng(41)
+    cases = [(2, 1, 3), (3, 2, 5), (17, 16, 40), (300, 299, 1000), (512, 511, 77), (513, 510, 30), (513, 512, 30), (700, 699, 13),
+             (1000, 999, 2500), (1024, 1023, 50), (1025, 1022, 50), (1025, 1024, 50), (1400, 1399, 130), (1535, 1534, 64),
+             (1536, 500, 20), (1200, 1847, 0), (1100, 900, 33), (1536, 1535, 9)]
+    try:
+        for F, max_lag, E in cases:
+            if max_lag >= F:  # (marks a truncated case written as (F, F + max_lag limit, .): keep it legal)
+                max_lag = F - 1
+            E = E or 25
+            cuts = sorted(rng.integers(0, E + 1, 2).tolist())
+            goff = [0, cuts[0], cuts[0], cuts[1], E]
+            r = np.cumsum(rng.normal(0, 0.1, (F, 3, E)), axis=0) + rng.uniform(-80, 80, (1, 3, E))
+            ctx.set_option("lag_variant", 1)
+            exact = B.lag_msd(r, max_lag, goff, scale=0.3)
+            ctx.set_option("lag_variant", 2)
+            ctx.set_option("lag_batch_mb", int(rng.choice([-1, 1])))
+            got = B.lag_msd(r, max_lag, goff, scale=0.3)
+            bound = ctx.last_rel_bound()
+            takes_w1 = F <= 1536 and F + max_lag <= 3072 and (F < 1536 or F + max_lag <= 2048)
+            assert (ctx.last_kernel_name() == "msd_power_w1_kernel") == takes_w1, (F, max_lag, ctx.last_kernel_name())
+            nz = exact > 0
+            if nz.any():
+                assert (np.abs(got[nz] - exact[nz]) / exact[nz]).max() <= bound, (F, max_lag, E, bound)
+            assert (got[~nz] == 0.0).all() and (got[0] == 0.0).all()
+            lags = np.unique(np.concatenate([np.arange(0, min(max_lag + 1, 30)), rng.integers(0, max_lag + 1, 20)]))
+            want = C.lag_msd(r * 0.3, lags, goff)
+            nzl = want > 0
+            if nzl.any():
+                assert (np.abs(got[lags][nzl] - want[nzl]) / want[nzl]).max() <= max(bound, 1e-11), (F, max_lag)
+            assert np.array_equal(B.lag_msd(r, max_lag, goff, scale=0.3), got)
+            out = torch.empty((max_lag + 1, 4, 4), dtype=torch.float64, device="cuda")
+            B.lag_msd(torch.from_numpy(r).cuda(), max_lag, goff, scale=0.3, out=out)
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(out.cpu().numpy(), got)
+    finally:
+        ctx.set_option("lag_variant", 1)
+        ctx.set_option("lag_batch_mb", -1)
 
 
 def test_lag_msd_long_series_finish_on_the_device(B):

@@ -20,7 +20,7 @@ if len(sys.argv) > 2:  # A/B: from how many frames on the 12288-point kernel tak
     ctx.set_option("lag_w12_min_f", int(sys.argv[2]))
     print("lag_w12_min_f =", sys.argv[2])
 rows = []
-for F in (1000, 1536, 1800, 2048, 2500, 3000, 4096, 5000, 6144, 8192, 8193, 10_000, 12_288, 12_289, 20_000, 24_576):
+for F in (300, 512, 700, 1000, 1400, 1535, 1536, 1800, 2048, 2500, 3000, 4096, 5000, 6144, 8192, 8193, 10_000, 12_288, 12_289, 20_000, 24_576):
     g = torch.Generator(device="cuda").manual_seed(100 + F)
     r = torch.empty((F, 3, E), dtype=torch.float64, device="cuda")
     for f0 in range(0, F, 500):
@@ -33,7 +33,7 @@ for F in (1000, 1536, 1800, 2048, 2500, 3000, 4096, 5000, 6144, 8192, 8193, 10_0
         ms.append(ctx.last_kernel_ms()[0])
     kernel = ctx.last_kernel_name()
     bound = ctx.last_rel_bound()
-    L = (49152 if "msd_power_w12o" in kernel else 24576 if kernel.startswith(("msd_power_w12p", "msd_power_w12r")) else 12288 if kernel.startswith("msd_power_w12")
+    L = (1024 * ((2 * F - 1 + 1023) // 1024) if kernel.startswith("msd_power_w1_") else 49152 if "msd_power_w12o" in kernel else 24576 if kernel.startswith(("msd_power_w12p", "msd_power_w12r")) else 12288 if kernel.startswith("msd_power_w12")
          else 1 << int(np.ceil(np.log2(2 * F - 1))))
     t = float(np.median(ms[1:]))
     rows.append((F, L, kernel, t, t / (E * F * np.log2(L)) * 1e9, bound, float(out[1, 0, 3].item())))
