@@ -225,6 +225,12 @@ def test_long_series_kernels_stay_inside_their_register_budgets():
     for inst in ("Lb1", "Lb0"):
         _, meta = _find(kern, "msd_power_w12p_kernelI%sE" % inst)
         assert int(meta["vgpr_count"]) <= 168 and int(meta["vgpr_spill_count"]) <= 12, meta
+    # msd_power_w1_kernel (one wave per series, F <= 1536): the one- and two-transform instances spill nothing; the
+    # three-transform one keeps 24 samples in flight per class next to three sets of sums and spills ~45 registers (ROCm 7.2:
+    # 43) — measured as it is; more would say something else got hoisted
+    for d2, cap in ((1, 0), (2, 0), (3, 48)):
+        _, meta = _find(kern, "msd_power_w1_kernelILi%dE" % d2)
+        assert int(meta["vgpr_count"]) <= 168 and int(meta["vgpr_spill_count"]) <= cap, (d2, meta)
     fft = _kernels(_asm("fft_pow2.hip"))
     hits = [k for k in fft if "fft_power_pass_kernel" in k]
     assert len(hits) >= 5
