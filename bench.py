@@ -793,6 +793,32 @@ def leg_c3(B, ctx, torch, device, synth, sync):
     return out
 
 
+def lag_long_power_kernel():
+    """The transform kernel of the long-trajectory call (msd_power_w12p_kernel: 8 of its 13 ms) priced as the C4 kernel is —
+    vector instructions per call from the committed PMC run (this source tree's) over ITS time in that run, against the issue
+    rate tools/ubench_valu.hip measures for its instruction mix at three waves per SIMD."""
+    e, why = secondary_pmc("lag_long")
+    if e is None:
+        return {"note": why}
+    name, k = next(((n, v) for n, v in e["kernels"].items() if n.startswith("msd_power_w12p")), (None, None))
+    if not k or "SQ_INSTS_VALU" not in k or not k.get("total_us_per_rep"):
+        return {"note": "no counters of msd_power_w12p_kernel in the PMC entry"}
+    calls = float(k.get("calls_per_rep", 1.0))
+    rate, waves, txt = shares_rate(k)
+    out = {"kernel": name, "launches_per_call": calls, "kernel_s_in_pmc_run": k["total_us_per_rep"] * 1e-6,
+           "instructions_per_call": float(k["SQ_INSTS_VALU"]) * calls,
+           "f64_share_of_valu": sum(float(k.get("SQ_INSTS_VALU_%s_F64" % t, 0.0)) for t in ("ADD", "MUL", "FMA")) / float(k["SQ_INSTS_VALU"]),
+           "bound": "valu-issue (f64, 3 waves/SIMD)", "unit": "G wave-instructions/s"}
+    out["achieved"] = out["instructions_per_call"] / out["kernel_s_in_pmc_run"] / 1e9
+    if rate:
+        out["peak"] = rate * N_SIMD
+        out["frac"] = out["achieved"] / out["peak"]
+        out["peak_source"] = txt
+    else:
+        out["note"] = txt
+    return out
+
+
 def leg_lag_long(B, ctx, torch, device, synth, sync):
     """Full lag x origin MSD of a trajectory TWICE as long as C4's (10 000 frames x 50k atoms, 12 GB resident): beyond the
     fused kernels' 16 384 padded points — round 6: in residue classes of a 4 x 6144-point transform (csrc/msd_fft_w12r.h), no
@@ -851,7 +877,8 @@ def leg_lag_long(B, ctx, torch, device, synth, sync):
             "parity_checked": "48-entity group: spectral vs exact-difference kernel within the bound; 25 lags <= 2000 vs oracle (rtol 1e-9)",
             # compulsory bytes 24 E F; the path reads the trajectory twice (means of sampled frames + transposition),
             # writes the centred time-major copy and reads it back
-            "roofline": dict(hbm_roofline("lag_long", 24.0 * E * F, kernel_s), kernel=kernel)}
+            "roofline": dict(hbm_roofline("lag_long", 24.0 * E * F, kernel_s), kernel=kernel,
+                             power_kernel=lag_long_power_kernel())}
 
 
 def leg_c4(B, ctx, torch, device, synth, sync):
@@ -1099,6 +1126,9 @@ def flat_scalars(out):
         "c1_pairs_per_s": _get(out, "c1", "value"), "c1_alt_pairs_per_s": _get(out, "c1_alt", "value"),
         "lag_long_kernel_ms": None if _get(out, "lag_long", "kernel_s") is None else _get(out, "lag_long", "kernel_s") * 1e3,
         "lag_long_frame_pairs_per_s": _get(out, "lag_long", "value"),
+        "lag_long_valu_issue_frac": _get(out, "lag_long", "roofline", "power_kernel", "frac"),
+        "lag_long_traffic_over_algorithmic": None if not _get(out, "lag_long", "roofline", "traffic") else
+        _get(out, "lag_long", "roofline", "traffic") / _get(out, "lag_long", "roofline", "algorithmic_bytes"),
         "lag_diff_kernel_ms": None if _get(out, "c4", "lag_msd_difference_kernel", "kernel_s") is None
         else _get(out, "c4", "lag_msd_difference_kernel", "kernel_s") * 1e3,
         "lag_diff_fp64_fma_frac": _get(out, "c4", "lag_msd_difference_kernel", "roofline", "frac"),
