@@ -126,6 +126,14 @@ struct mdhip_ctx {
                                     // for up to 100 ms, then block; 0 block at once (A/B)
     // host-resident pair inputs: the frames of batch k+1 are copied on this stream while batch k is swept (created on
     // first use); one event per batch in flight
+    // Round 6: two streams whose kernels run on DISJOINT sets of CUs (hipExtStreamCreateWithCUMask; mask bit i = CU i div 8 of
+    // XCD i mod 8): [0] three quarters of every XCD's CUs, for a compute-bound kernel with one workgroup per CU, [1] the other
+    // quarter, for a streaming kernel that would otherwise run in front of it with the compute units idle. Created on first
+    // use (mdhip_part_streams); part_state -1: not available on this device / driver.
+    hipStream_t part_stream[2] = {nullptr, nullptr};
+    hipEvent_t part_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // fork | ready[2] | free[2] | join
+    int part_state = 0;
+    int part_cus[2] = {0, 0};
     hipStream_t copy_stream = nullptr;
     hipEvent_t copy_ev[2] = {nullptr, nullptr};
     // asynchronous pair calls on host-resident frames: the whole trajectory of call k + 1 is copied (copy stream) into
@@ -209,6 +217,10 @@ struct mdhip_ctx {
     int opt_lag_residue = 1;      // full-lag MSD with 16 384 < F + max_lag <= 24 576: 1 (default) the residue-class kernel (msd_fft_w12r.h), 0 the batched transforms
     int opt_lag_mean_sample = -1; // long-series paths: the series are centred on the mean of about this many sampled frames (-1: 512; 0: every frame)
     int opt_lag_w1 = 1;           // full-lag MSD of F <= 1536 frames (F + max_lag <= 3072): 1 (default) one wave per series (msd_power_w1_kernel), 0 the block-wide kernels
+    int opt_lag_overlap = 0;      // long-series full-lag MSD: 1 = the transposition of batch k + 1 runs on a quarter of the CUs while the
+                                  // transform kernel of batch k runs on the others (CU-masked streams; 2: whatever the size, tests);
+                                  // 0 (default) one after the other — measured: 16.7 against 13.2 ms at F = 10 000, a quarter of the CUs
+                                  // moves 1.7 TB/s where the whole chip moves 4.8 (profiles/r06_ab_lag_overlap.txt)
     int opt_lag_batch_mb = 4096;  // batched full-lag path: device memory of one batch of series (centred series + transform buffers), MB
     int opt_lag_w12_min_f = 1536;  // full-lag MSD with 2048 < F + max_lag <= 8192: from this many frames on the 12288-point
                                    // kernel (msd_fft_w12.h) instead of the 8192-point one; 0 = never, >= 1536
@@ -252,6 +264,7 @@ int mdhip_fail(mdhip_ctx *ctx, int code, const char *fmt, ...);
 // threads copy them chunk by chunk (the host waits for that memcpy, ~40 GB/s), each chunk's DMA is queued as soon as
 // it is there. `slot` 0 / 1: which half of the ring (two calls' worth may be in flight). Returns when every byte of
 // `src` has been read.
+bool mdhip_part_streams(mdhip_ctx *ctx);  // the CU-partitioned streams exist (created on first use)
 int mdhip_h2d_any(mdhip_ctx *ctx, void *dst_dev, const void *src, size_t bytes, hipStream_t stream, int slot);
 // msd_fft.hip: full-lag MSD through batched FFTs; d_r device [F][3][E], out host [max_lag+1][G][4]
 // fft_pow2.hip: batched power-of-two FP64 real transforms (half spectra [batch][L/2+1]); d_tmp holds batch * L/2

@@ -1,5 +1,6 @@
 // mdhip_ctx.hip — lifecycle, workspace, options and the host-side bin-edge table.
 #include <algorithm>
+#include <vector>
 #include <cmath>
 #include <cstdlib>
 #include <ctime>
@@ -332,6 +333,35 @@ int mdhip_copy_small(mdhip_ctx *ctx, void *dst, const void *src, size_t bytes, h
     return MDHIP_OK;
 }
 
+bool mdhip_part_streams(mdhip_ctx *ctx)
+{
+    if (ctx->part_state) return ctx->part_state > 0;
+    ctx->part_state = -1;
+    const int n = ctx->cu_count;
+    if (n < 64 || n % 32 != 0) return false;  // (8 XCDs x a multiple of 4 CUs)
+    std::vector<uint32_t> mask[2] = {std::vector<uint32_t>((size_t)(n + 31) / 32, 0u), std::vector<uint32_t>((size_t)(n + 31) / 32, 0u)};
+    int cnt[2] = {0, 0};
+    for (int i = 0; i < n; ++i) {
+        const int part = ((i / 8) % 4 == 3) ? 1 : 0;  // every fourth CU of each XCD to the streaming side
+        mask[part][(size_t)i / 32] |= 1u << (i % 32);
+        ++cnt[part];
+    }
+    for (int k = 0; k < 2; ++k)
+        if (hipExtStreamCreateWithCUMask(&ctx->part_stream[k], (uint32_t)mask[k].size(), mask[k].data()) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+    for (auto &e : ctx->part_ev)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+    ctx->part_cus[0] = cnt[0];
+    ctx->part_cus[1] = cnt[1];
+    ctx->part_state = 1;
+    return true;
+}
+
 int mdhip_deliver_to_device(mdhip_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes)
 {
     if (bytes == 0) return MDHIP_OK;
@@ -567,6 +597,13 @@ void mdhip_destroy(mdhip_ctx *ctx)
         (void)hipStreamSynchronize(ctx->copy_stream);
         (void)hipStreamDestroy(ctx->copy_stream);
     }
+    for (auto &st : ctx->part_stream)
+        if (st) {
+            (void)hipStreamSynchronize(st);
+            (void)hipStreamDestroy(st);
+        }
+    for (auto &e : ctx->part_ev)
+        if (e) (void)hipEventDestroy(e);
     copy_pool_destroy(ctx);
     for (auto &e : ctx->copy_ev)
         if (e) (void)hipEventDestroy(e);
@@ -767,6 +804,8 @@ int mdhip_set_option(mdhip_ctx *ctx, const char *key, int value)
         ctx->opt_lag_mean_sample = value;
     else if (!strcmp(key, "lag_w1"))
         ctx->opt_lag_w1 = value < 0 ? 1 : value;
+    else if (!strcmp(key, "lag_overlap"))
+        ctx->opt_lag_overlap = value < 0 ? 0 : value;
     else if (!strcmp(key, "lag_batch_mb"))
         ctx->opt_lag_batch_mb = value <= 0 ? 4096 : std::min(value, 65536);
     else if (!strcmp(key, "lag_w12_min_f"))

@@ -2449,9 +2449,23 @@ int lag_msd_fft_residue(CallScope &cs, long long F, long long E, const double *d
     const long long n_lags = (long long)max_lag + 1, cols = 3 * E, S = 3 * G;
     const long long row_len = D == 4 ? F : 4LL * W12_N;  // doubles per series of the time-major copy
     res->delivered = true;
-    const long long nb_max = std::max<long long>(1, ((long long)ctx->opt_lag_batch_mb << 20) / (row_len * 8));
+    // Round 6, `lag_overlap` (an experiment that did not pay; off by default, kept behind its option and its test): the
+    // transposition of batch k + 1 on a quarter of the CUs WHILE the transform kernel of batch k (compute-bound, one workgroup
+    // per CU) runs on the other three quarters — two CU-masked streams (hipExtStreamCreateWithCUMask), two buffers, at least
+    // six batches, the first transposed and the last transformed on the whole chip. The masks work as advertised; what does
+    // not is the premise that a streaming kernel needs few CUs: the transposition moves 4.8 TB/s on 256 CUs and 1.7 TB/s on
+    // 64 (a CU cannot hold the ~160 KB in flight that a quarter of the chip would need to cover HBM's latency), so the call
+    // takes 16.7 ms instead of 13.2 (profiles/r06_ab_lag_overlap.txt).
+    const bool want_overlap = ctx->opt_lag_overlap != 0 && !short_d2 &&
+                              (cols * row_len * 8 >= (512LL << 20) || ctx->opt_lag_overlap >= 2 /* tests: whatever the size */) &&
+                              mdhip_part_streams(ctx);
+    long long nb_max = std::max<long long>(1, ((long long)ctx->opt_lag_batch_mb << 20) / (row_len * 8) / (want_overlap ? 2 : 1));
+    if (want_overlap) nb_max = std::min(nb_max, std::max<long long>(ctx->opt_lag_overlap >= 2 ? 1 : 4LL * ctx->cu_count, (cols + 5) / 6));
     const long long n_batches = (cols + nb_max - 1) / nb_max;
     const long long nb0 = (cols + n_batches - 1) / n_batches;
+    const bool overlap = want_overlap && n_batches >= 3;
+    // (CUs the transform kernel of batch b runs on: it is given one workgroup per CU)
+    auto batch_cus = [&](long long b) { return overlap && b + 1 < n_batches ? ctx->part_cus[0] : ctx->cu_count; };
     // work items, batch by batch: every (segment, batch) overlap gets its share of ~one block per CU
     std::vector<FftItem> items;
     struct Fold {
@@ -2472,7 +2486,7 @@ int lag_msd_fft_residue(CallScope &cs, long long F, long long E, const double *d
             const long long hi = std::min(c_first + nb, a * E + (long long)group_off[g + 1]);
             if (lo >= hi) continue;
             const long long n = hi - lo;
-            long long k = (n * ctx->cu_count + nb / 2) / nb;
+            long long k = (n * batch_cus(b) + nb / 2) / nb;
             k = std::max<long long>(1, std::min(k, n));
             folds.push_back({b, s, lo, n, row, (int)k});
             max_tiles = std::max(max_tiles, (n + 64 * TSQ_TILES - 1) / (64 * TSQ_TILES));
@@ -2499,7 +2513,8 @@ int lag_msd_fft_residue(CallScope &cs, long long F, long long E, const double *d
 
     MD_WS(d_mean, double, WS_AUX0, (size_t)(MF_SLABS + 1) * cols * 8);
     double *d_msum = d_mean + cols;
-    MD_WS(d_pad, double, WS_AUX1, (size_t)nb0 * row_len * 8 + 256);
+    MD_WS(d_pad0, double, WS_AUX1, (size_t)nb0 * row_len * 8 * (overlap ? 2 : 1) + 512);
+    double *d_pads[2] = {d_pad0, overlap ? d_pad0 + (((size_t)nb0 * row_len + 31) & ~(size_t)31) : d_pad0};
     MD_WS(d_part, double, WS_PART, (size_t)max_items * rows_per_item * K * 8);
     MD_WS(d_qpart, double, WS_AUX2, (size_t)max_tiles * F * 8);
     const size_t q_b = (size_t)S * F * 8, p_b = (size_t)S * K * 8, c_b = (size_t)S * n_lags * 8;
@@ -2554,49 +2569,84 @@ int lag_msd_fft_residue(CallScope &cs, long long F, long long E, const double *d
         MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msd_power_w12o_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)w12o_lds_bytes()));
     }
-    size_t fold_i = 0;
-    for (long long b = 0; b < n_batches; ++b) {
-        const long long c_first = b * nb0, nb = std::min(nb0, cols - c_first);
-        // the batch's series, segment by segment (a tile's per-frame squares belong to one segment), and S1's terms with them
-        for (size_t fi = fold_i; fi < folds.size() && folds[fi].batch == b; ++fi) {
+    // first fold record of every batch
+    std::vector<size_t> fold_first((size_t)n_batches + 1, folds.size());
+    for (size_t fi = folds.size(); fi-- > 0;) fold_first[(size_t)folds[fi].batch] = fi;
+    for (long long b = n_batches - 1; b >= 0; --b)
+        if (fold_first[(size_t)b] == folds.size()) fold_first[(size_t)b] = fold_first[(size_t)b + 1];
+    // the batch's series into `pad`, segment by segment (a tile's per-frame squares belong to one segment), S1's terms with them
+    auto transpose_batch = [&](long long b, hipStream_t st, double *pad) {
+        const long long c_first = b * nb0;
+        for (size_t fi = fold_first[(size_t)b]; fi < folds.size() && folds[fi].batch == b; ++fi) {
             const long long lo = folds[fi].c_lo, n = folds[fi].c_n, tiles = (n + 64 * TSQ_TILES - 1) / (64 * TSQ_TILES);
             if (D == 4)
-                hipLaunchKernelGGL(transpose_centre64_sq_kernel, dim3((unsigned)tiles, (unsigned)((F + 63) / 64)), dim3(256), 0,
-                                   ctx->stream, d_r, d_mean, F, cols, lo, n, lo - c_first, scale, d_pad, d_qpart);
+                hipLaunchKernelGGL(transpose_centre64_sq_kernel, dim3((unsigned)tiles, (unsigned)((F + 63) / 64)), dim3(256), 0, st,
+                                   d_r, d_mean, F, cols, lo, n, lo - c_first, scale, pad, d_qpart);
             else
-                hipLaunchKernelGGL(transpose_fold64_sq_kernel, dim3((unsigned)tiles, (unsigned)(2 * W12_N / 64)), dim3(256), 0,
-                                   ctx->stream, d_r, d_mean, F, cols, lo, n, lo - c_first, scale, d_pad, d_qpart);
-            hipLaunchKernelGGL(power_fold_kernel, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, ctx->stream, d_qpart, (int)tiles,
-                               F, d_Q + (size_t)folds[fi].seg * F);
+                hipLaunchKernelGGL(transpose_fold64_sq_kernel, dim3((unsigned)tiles, (unsigned)(2 * W12_N / 64)), dim3(256), 0, st,
+                                   d_r, d_mean, F, cols, lo, n, lo - c_first, scale, pad, d_qpart);
+            hipLaunchKernelGGL(power_fold_kernel, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, st, d_qpart, (int)tiles, F,
+                               d_Q + (size_t)folds[fi].seg * F);
         }
-        (void)nb;
+    };
+    // the batch's power spectra from `pad`, folded into the segments' sums
+    auto power_batch = [&](long long b, hipStream_t st, const double *pad) {
         const int n_it = batch_off[(size_t)b + 1] - batch_off[(size_t)b];
+        const FftItem *its = d_items + batch_off[(size_t)b];
         if (short_d2 == 1)
-            hipLaunchKernelGGL(msd_power_w1_kernel<1>, dim3((unsigned)n_it), dim3(W12_THREADS), ldsr, ctx->stream, d_pad, (int)F,
-                               d_items + batch_off[(size_t)b], d_tab, d_part);
+            hipLaunchKernelGGL(msd_power_w1_kernel<1>, dim3((unsigned)n_it), dim3(W12_THREADS), ldsr, st, pad, (int)F, its, d_tab, d_part);
         else if (short_d2 == 2)
-            hipLaunchKernelGGL(msd_power_w1_kernel<2>, dim3((unsigned)n_it), dim3(W12_THREADS), ldsr, ctx->stream, d_pad, (int)F,
-                               d_items + batch_off[(size_t)b], d_tab, d_part);
+            hipLaunchKernelGGL(msd_power_w1_kernel<2>, dim3((unsigned)n_it), dim3(W12_THREADS), ldsr, st, pad, (int)F, its, d_tab, d_part);
         else if (short_d2 == 3)
-            hipLaunchKernelGGL(msd_power_w1_kernel<3>, dim3((unsigned)n_it), dim3(W12_THREADS), ldsr, ctx->stream, d_pad, (int)F,
-                               d_items + batch_off[(size_t)b], d_tab, d_part);
+            hipLaunchKernelGGL(msd_power_w1_kernel<3>, dim3((unsigned)n_it), dim3(W12_THREADS), ldsr, st, pad, (int)F, its, d_tab, d_part);
         else if (D == 8) {
-            hipLaunchKernelGGL(msd_power_w12p_kernel<false>, dim3((unsigned)n_it), dim3(W12_THREADS), ldsr, ctx->stream, d_pad, row_len,
-                               2 * W12_N, 2 * W12_N, 2 * W12_N, 2, (int)K, d_items + batch_off[(size_t)b], d_tab, d_part);
-            hipLaunchKernelGGL(msd_power_w12o_kernel<1>, dim3((unsigned)n_it), dim3(W12_THREADS), w12o_lds_bytes(), ctx->stream,
-                               d_pad, d_items + batch_off[(size_t)b], d_tab + n_tab4, d_part);
-            hipLaunchKernelGGL(msd_power_w12o_kernel<3>, dim3((unsigned)n_it), dim3(W12_THREADS), w12o_lds_bytes(), ctx->stream,
-                               d_pad, d_items + batch_off[(size_t)b], d_tab + n_tab4, d_part);
+            hipLaunchKernelGGL(msd_power_w12p_kernel<false>, dim3((unsigned)n_it), dim3(W12_THREADS), ldsr, st, pad, row_len, 2 * W12_N,
+                               2 * W12_N, 2 * W12_N, 2, (int)K, its, d_tab, d_part);
+            hipLaunchKernelGGL(msd_power_w12o_kernel<1>, dim3((unsigned)n_it), dim3(W12_THREADS), w12o_lds_bytes(), st, pad, its,
+                               d_tab + n_tab4, d_part);
+            hipLaunchKernelGGL(msd_power_w12o_kernel<3>, dim3((unsigned)n_it), dim3(W12_THREADS), w12o_lds_bytes(), st, pad, its,
+                               d_tab + n_tab4, d_part);
         } else if (packed)
-            hipLaunchKernelGGL(msd_power_w12p_kernel<true>, dim3((unsigned)n_it), dim3(W12_THREADS), ldsr, ctx->stream, d_pad, row_len,
-                               (int)F, 0, (int)F, 1, (int)K, d_items + batch_off[(size_t)b], d_tab, d_part);
+            hipLaunchKernelGGL(msd_power_w12p_kernel<true>, dim3((unsigned)n_it), dim3(W12_THREADS), ldsr, st, pad, row_len, (int)F, 0,
+                               (int)F, 1, (int)K, its, d_tab, d_part);
         else
-            hipLaunchKernelGGL((msd_power_w12r_kernel<4>), dim3((unsigned)n_it), dim3(W12_THREADS), ldsr, ctx->stream, d_pad, (int)F,
-                               d_items + batch_off[(size_t)b], d_tab, d_part);
-        for (; fold_i < folds.size() && folds[fold_i].batch == b; ++fold_i)
-            hipLaunchKernelGGL(power_fold_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, ctx->stream,
-                               d_part + (size_t)folds[fold_i].first * rows_per_item * K, folds[fold_i].count * rows_per_item, K,
-                               d_P + (size_t)folds[fold_i].seg * K);
+            hipLaunchKernelGGL((msd_power_w12r_kernel<4>), dim3((unsigned)n_it), dim3(W12_THREADS), ldsr, st, pad, (int)F, its, d_tab,
+                               d_part);
+        for (size_t fi = fold_first[(size_t)b]; fi < folds.size() && folds[fi].batch == b; ++fi)
+            hipLaunchKernelGGL(power_fold_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, st,
+                               d_part + (size_t)folds[fi].first * rows_per_item * K, folds[fi].count * rows_per_item, K,
+                               d_P + (size_t)folds[fi].seg * K);
+    };
+    if (!overlap) {
+        for (long long b = 0; b < n_batches; ++b) {
+            transpose_batch(b, ctx->stream, d_pads[0]);
+            power_batch(b, ctx->stream, d_pads[0]);
+            MD_HIP(hipGetLastError());
+        }
+    } else {
+        // batch 0 is transposed on the whole chip; then stream A (3/4 of the CUs) transforms batch b while stream B (1/4)
+        // transposes batch b + 1 into the other buffer; the last batch is transformed on the whole chip again
+        hipStream_t sa = ctx->part_stream[0], sb = ctx->part_stream[1];
+        hipEvent_t ev_fork = ctx->part_ev[0], *ev_ready = ctx->part_ev + 1, *ev_free = ctx->part_ev + 3, ev_join = ctx->part_ev[5];
+        transpose_batch(0, ctx->stream, d_pads[0]);
+        MD_HIP(hipEventRecord(ev_fork, ctx->stream));
+        MD_HIP(hipStreamWaitEvent(sa, ev_fork, 0));
+        MD_HIP(hipStreamWaitEvent(sb, ev_fork, 0));
+        for (long long b = 0; b + 1 < n_batches; ++b) {
+            const int cur = (int)(b & 1), nxt = cur ^ 1;
+            if (b >= 1) MD_HIP(hipStreamWaitEvent(sb, ev_free[nxt], 0));  // (batch b - 1 has been transformed out of that buffer)
+            transpose_batch(b + 1, sb, d_pads[nxt]);
+            MD_HIP(hipEventRecord(ev_ready[nxt], sb));
+            if (b >= 1) MD_HIP(hipStreamWaitEvent(sa, ev_ready[cur], 0));
+            power_batch(b, sa, d_pads[cur]);
+            MD_HIP(hipEventRecord(ev_free[cur], sa));
+            MD_HIP(hipGetLastError());
+        }
+        const int last = (int)((n_batches - 1) & 1);
+        MD_HIP(hipEventRecord(ev_join, sa));
+        MD_HIP(hipStreamWaitEvent(ctx->stream, ev_join, 0));
+        MD_HIP(hipStreamWaitEvent(ctx->stream, ev_ready[last], 0));
+        power_batch(n_batches - 1, ctx->stream, d_pads[last]);
         MD_HIP(hipGetLastError());
     }
     const size_t ldsi = (size_t)(LP / 4 + 1 + RI_WAVES * 64 * 2) * 8;

@@ -671,14 +671,20 @@ def test_lag_msd_long_series_finish_on_the_device(B):
                     if F > 12288 and residue:
                         name = long_form
                     ctx.set_option("lag_residue", residue)
-                    fft = B.lag_msd(r, F - 1, goff)
-                    bound = ctx.last_rel_bound()
-                    assert ctx.last_kernel_name() == name, (F, ctx.last_kernel_name())
-                    assert (np.abs(fft[nz] - exact[nz]) / exact[nz]).max() <= bound, (F, E, residue, bound)
-                    assert (fft[~nz] == 0.0).all()
+                    # (`lag_overlap` 2: the CU-partitioned streams whatever the size — the transposition of batch k + 1 beside
+                    # the transform kernel of batch k, two buffers; 0: one stream)
+                    for overlap in (2, 0) if residue else (0,):
+                        ctx.set_option("lag_overlap", overlap)
+                        fft = B.lag_msd(r, F - 1, goff)
+                        bound = ctx.last_rel_bound()
+                        assert ctx.last_kernel_name() == name, (F, ctx.last_kernel_name())
+                        assert (np.abs(fft[nz] - exact[nz]) / exact[nz]).max() <= bound, (F, E, residue, overlap, bound)
+                        assert (fft[~nz] == 0.0).all()
+                        assert np.array_equal(B.lag_msd(r, F - 1, goff), fft), (F, E, residue, overlap)
             finally:
                 ctx.set_option("lag_batch_mb", -1)
                 ctx.set_option("lag_residue", -1)
+                ctx.set_option("lag_overlap", -1)
     finally:
         ctx.set_option("lag_variant", 1)
 
