@@ -2517,7 +2517,8 @@ int lag_msd_fft_residue(CallScope &cs, long long F, long long E, const double *d
     double *d_pads[2] = {d_pad0, overlap ? d_pad0 + (((size_t)nb0 * row_len + 31) & ~(size_t)31) : d_pad0};
     MD_WS(d_part, double, WS_PART, (size_t)max_items * rows_per_item * K * 8);
     MD_WS(d_qpart, double, WS_AUX2, (size_t)max_tiles * F * 8);
-    const size_t q_b = (size_t)S * F * 8, p_b = (size_t)S * K * 8, c_b = (size_t)S * n_lags * 8;
+    // (Q | P | correlations, the three together rounded up to 16 bytes: the twiddle table behind them is read as double2)
+    const size_t q_b = (size_t)S * F * 8, p_b = (size_t)S * K * 8, c_b = ((size_t)S * (F + K + n_lags) * 8 + 15) / 16 * 16 - q_b - p_b;
     const size_t tab_b = (size_t)n_tab * 16, it_b = (items.size() * sizeof(FftItem) + 15) / 16 * 16;
     const size_t go_b = (size_t)(G + 1) * 8, ng_b = (size_t)G * 8;
     MD_WS(d_small, unsigned char, WS_AUX3, q_b + p_b + c_b + tab_b + it_b + go_b + ng_b + 256);
