@@ -2711,7 +2711,9 @@ int mdhip_lag_msd_fft(CallScope &cs, int64_t n_frames, int64_t n_ent, const doub
     const long long n_lags = (long long)max_lag + 1;
     const long long cols = 3 * E;
     // round 6: trajectories below msd_power_w12_kernel's range, one wave per series (msd_fft_w12r.h): padded length 1024 / 2048 / 3072
-    if (ctx->opt_lag_variant != 4 && ctx->opt_lag_w1 != 0 && F + max_lag <= 3072 && F <= 1536 && F >= 2 &&
+    // (the residue-class host path launches its transposition and folds per (axis, group) segment: with many groups the
+    // block-wide kernels, which take every segment in one launch, stay the faster choice for calls of a millisecond)
+    if (ctx->opt_lag_variant != 4 && ctx->opt_lag_w1 != 0 && F + max_lag <= 3072 && F <= 1536 && F >= 2 && n_groups <= 16 &&
         (F < std::max(3 * W12_SUB, ctx->opt_lag_w12_min_f) || ctx->opt_lag_w12_min_f <= 0 || F + max_lag <= 2048) &&
         w1_lds_bytes(3) <= ctx->lds_max)
         return lag_msd_fft_residue(cs, F, E, d_r, scale, max_lag, G, group_off, res, out, out_on_device,

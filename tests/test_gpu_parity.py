@@ -563,6 +563,18 @@ def test_lag_msd_short_series_one_wave_per_series(B):
             B.lag_msd(torch.from_numpy(r).cuda(), max_lag, goff, scale=0.3, out=out)
             torch.cuda.synchronize()
             np.testing.assert_array_equal(out.cpu().numpy(), got)
+        # more than 16 groups: the block-wide kernels keep the call (they take every segment in ONE launch; this path
+        # launches per segment)
+        F, E = 600, 90
+        goff = list(range(0, 91, 5))  # 18 groups
+        r = np.cumsum(rng.normal(0, 0.1, (F, 3, E)), axis=0)
+        ctx.set_option("lag_variant", 1)
+        exact = B.lag_msd(r, F - 1, goff)
+        ctx.set_option("lag_variant", 2)
+        got = B.lag_msd(r, F - 1, goff)
+        assert ctx.last_kernel_name() == "msd_power_lds_kernel"
+        nz = exact > 0
+        assert (np.abs(got[nz] - exact[nz]) / exact[nz]).max() <= ctx.last_rel_bound()
     finally:
         ctx.set_option("lag_variant", 1)
         ctx.set_option("lag_batch_mb", -1)
