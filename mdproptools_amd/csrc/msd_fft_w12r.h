@@ -192,10 +192,13 @@ __global__ __launch_bounds__(W12_THREADS) void msd_power_w12r_kernel(const doubl
     if (it.c_lo < it.c_hi) fetch(it.c_lo);
     for (long long c = it.c_lo; c < it.c_hi; ++c) {
         const bool more = c + 1 < it.c_hi;
-        // (the tables' addresses through an opaque copy per series: their entries are the same for every series, and hoisted
-        // out of the loop they would take a hundred registers)
-        const double2 *ctab_s = ctab, *btab_s = btab, *tB_s = tB;
-        asm volatile("" : "+v"(ctab_s), "+v"(btab_s), "+v"(tB_s));
+        // (the tables' addresses opaque per series: their entries are the same for every series, and hoisted out of the loop
+        // they would take a hundred registers)
+        int opq = 0;  // (an opaque ZERO added to the tables' addresses — not the pointers themselves through the asm: that
+                      // loses their address space, and every table read becomes a flat load that waits for ALL memory counters,
+                      // the prefetched samples included)
+        asm volatile("" : "+v"(opq));
+        const double2 *ctab_s = ctab + opq, *btab_s = btab + opq, *tB_s = tB + opq;
         auto one_class = [&](auto ck) {
             constexpr int cls = decltype(ck)::value;
             // ---- the class's inputs y_cls[n] (but for the factor w_L'^(cls j), which rides in the register passes) ----
@@ -457,8 +460,11 @@ __global__ __launch_bounds__(W12_THREADS) void msd_power_w12p_kernel(const doubl
     for (long long c = it.c_lo; c < it.c_hi; ++c) {
         const bool more = c + 1 < it.c_hi;
         // (the tables' addresses through an opaque copy per series: see msd_power_w12r_kernel)
-        const double2 *ctab_s = ctab, *btab_s = btab, *tB_s = tB;
-        asm volatile("" : "+v"(ctab_s), "+v"(btab_s), "+v"(tB_s));
+        int opq = 0;  // (an opaque ZERO added to the tables' addresses — not the pointers themselves through the asm: that
+                      // loses their address space, and every table read becomes a flat load that waits for ALL memory counters,
+                      // the prefetched samples included)
+        asm volatile("" : "+v"(opq));
+        const double2 *ctab_s = ctab + opq, *btab_s = btab + opq, *tB_s = tB + opq;
         // ======== the even frequencies: the packed transform ========
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -630,8 +636,9 @@ __global__ __launch_bounds__(W12_THREADS) void msd_power_w12o_kernel(const doubl
     if (it.c_lo < it.c_hi) fetch(it.c_lo);
     for (long long c = it.c_lo; c < it.c_hi; ++c) {
         const bool more = c + 1 < it.c_hi;
-        const double2 *ctab_s = ctab, *btab_s = btab;
-        asm volatile("" : "+v"(ctab_s), "+v"(btab_s));
+        int opq = 0;  // (see msd_power_w12r_kernel)
+        asm volatile("" : "+v"(opq));
+        const double2 *ctab_s = ctab + opq, *btab_s = btab + opq;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int n = tid + W12_THREADS * i, e = n >> 9;
@@ -738,8 +745,9 @@ __global__ __launch_bounds__(W12_THREADS) void msd_power_w1_kernel(const double 
     for (long long c = it.c_lo + wv; c < it.c_hi; c += W12_NW) {
         const double *row = x + (size_t)c * F;
         // (the tables' addresses through an opaque copy per series: see msd_power_w12r_kernel)
-        const double2 *btab_s = btab;
-        asm volatile("" : "+v"(btab_s));
+        int opq = 0;  // (see msd_power_w12r_kernel)
+        asm volatile("" : "+v"(opq));
+        const double2 *btab_s = btab + opq;
         Cx a[8];
         // ======== the frequencies k = D2 k'': the packed transform of the series folded at 1024 ========
 #pragma unroll
