@@ -212,6 +212,62 @@ def test_c4_full_size_msd(B, c4):
     np.testing.assert_allclose(lag[1:, 1, 3] / theory, 1.0, atol=0.2)
 
 
+def test_full_lag_msd_at_twice_and_four_times_c4s_length(B):
+    """Round 6: trajectories beyond the fused kernels at C4's atom count — 10 000 frames (12 GB resident; padded length 24 576,
+    msd_power_w12p_kernel) and 20 000 frames x 20 000 atoms (9.6 GB; padded length 49 152, + msd_power_w12o_kernel): the
+    default path on the device with its status word, a 64-entity group of the SAME call against the exact-difference kernel
+    within the reported bound and against the C oracle on sampled lags, the diffusive slope of the whole system
+    (diffusion.py:207-238's quantity, every origin)."""
+    import torch
+
+    from mdproptools_amd import synth
+    from mdproptools_amd._lib import Context, default_context
+
+    for F, E, name in ((10_000, 50_000, "msd_power_w12p_kernel"), (20_000, 20_000, "msd_power_w12p_kernel + msd_power_w12o_kernel")):
+        g = torch.Generator(device="cuda")
+        g.manual_seed(synth.BASE_SEED + 40 + F)
+        r = torch.empty((F, 3, E), dtype=torch.float64, device="cuda")
+        r[0] = torch.rand((3, E), generator=g, device="cuda", dtype=torch.float64) * 82.8
+        for f0 in range(1, F, 250):
+            f1 = min(F, f0 + 250)
+            st = torch.randn((f1 - f0, 3, E), generator=g, device="cuda", dtype=torch.float64) * 0.1
+            r[f0:f1] = r[f0 - 1] + torch.cumsum(st, dim=0)
+            del st
+        goff = [0, 64, E]
+        out = torch.empty((F, 2, 4), dtype=torch.float64, device="cuda")
+        status = torch.full((1,), -1.0, dtype=torch.float64, device="cuda")
+        # (20 000 frames: the bound of a 64-entity group passes 1e-10 and the DEFAULT would hand the call to the difference
+        # kernel — seconds; the spectral path is asked for and held to the bound it reports)
+        ctx0 = default_context()
+        if F > 12288:
+            ctx0.set_option("lag_variant", 2)
+        try:
+            B.lag_msd(r, F - 1, goff, out=out, async_=True, status_out=status).wait()
+        finally:
+            ctx0.set_option("lag_variant", -1)
+        bound = ctx0.last_rel_bound()
+        assert ctx0.last_kernel_name() == name and float(status.item()) == bound, (F, ctx0.last_kernel_name(), bound)
+        assert 0.0 < bound <= (1e-10 if F <= 12288 else 1e-9), (F, bound)
+        lag = out.cpu().numpy()
+        rsub = r[:, :, :64].contiguous()
+        del r
+        torch.cuda.empty_cache()
+        ctx = Context(0)
+        ctx.set_option("lag_variant", 1)
+        lagd = B.lag_msd(rsub, F - 1, [0, 64], ctx=ctx)
+        assert ctx.last_kernel_name().startswith("lag_msd_")
+        ctx.close()
+        rel = np.max(np.abs(lag[1:, 0] - lagd[1:, 0]) / lagd[1:, 0])
+        assert rel <= max(bound, 1e-13), (F, rel, bound)
+        lags = np.unique(np.concatenate([[0, 1, 2, 3, 511, 512, 6143, 6144, 6145], np.linspace(10, F - 1, 20).astype(int)]))
+        refl = C.lag_msd(rsub.cpu().numpy(), lags, [0, 64])
+        np.testing.assert_allclose(lag[lags, 0, :], refl[:, 0, :], rtol=1e-9, atol=1e-300)
+        theory = 3 * 0.01 * np.arange(1, F // 2)
+        np.testing.assert_allclose(lag[1:F // 2, 1, 3] / theory, 1.0, atol=0.2)
+        del out, rsub
+        torch.cuda.empty_cache()
+
+
 def test_c5_full_size_acf(B):
     import torch
 
