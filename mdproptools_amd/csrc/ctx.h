@@ -221,6 +221,8 @@ struct mdhip_ctx {
                                   // transform kernel of batch k runs on the others (CU-masked streams; 2: whatever the size, tests);
                                   // 0 (default) one after the other — measured: 16.7 against 13.2 ms at F = 10 000, a quarter of the CUs
                                   // moves 1.7 TB/s where the whole chip moves 4.8 (profiles/r06_ab_lag_overlap.txt)
+    int opt_lag_ends = 1;         // lag_variant 3 with the bound missed at <= 8 lags per end of the lag range: 1 (default) those lags from the
+                                  // difference form, the rest of the spectral result stands; 0 the whole call to the difference kernel
     int opt_lag_batch_mb = 4096;  // batched full-lag path: device memory of one batch of series (centred series + transform buffers), MB
     int opt_lag_w12_min_f = 1536;  // full-lag MSD with 2048 < F + max_lag <= 8192: from this many frames on the 12288-point
                                    // kernel (msd_fft_w12.h) instead of the 8192-point one; 0 = never, >= 1536
@@ -368,6 +370,10 @@ struct LagFftResult {
     std::vector<int64_t> group_off;
     double bound = 0.0;
     bool delivered = false;        // the fused path: finished on the device and copied to the caller's buffer on the stream
+    // (round 6) which lags miss the 1e-10 bound: none beyond [1, k_lo] and [k_hi, max_lag]; the bound of all the others
+    bool ends_valid = false;
+    long long k_lo = 0, k_hi = 0;
+    double bound_ok = 0.0;
 };
 int mdhip_lag_msd_fft(CallScope &cs, int64_t n_frames, int64_t n_ent, const double *d_r, double scale, int max_lag,
                       int n_groups, const int64_t *group_off, const std::shared_ptr<LagFftResult> &res, double *out,

@@ -806,6 +806,8 @@ int mdhip_set_option(mdhip_ctx *ctx, const char *key, int value)
         ctx->opt_lag_w1 = value < 0 ? 1 : value;
     else if (!strcmp(key, "lag_overlap"))
         ctx->opt_lag_overlap = value < 0 ? 0 : value;
+    else if (!strcmp(key, "lag_ends"))
+        ctx->opt_lag_ends = value < 0 ? 1 : value;
     else if (!strcmp(key, "lag_batch_mb"))
         ctx->opt_lag_batch_mb = value <= 0 ? 4096 : std::min(value, 65536);
     else if (!strcmp(key, "lag_w12_min_f"))

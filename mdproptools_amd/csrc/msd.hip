@@ -794,6 +794,157 @@ static int deliver_host_values(mdhip_ctx *ctx, const double *src, size_t bytes, 
     return mdhip_deliver_to_device(ctx, dst, src, bytes);
 }
 
+// ---- Round 6: the exact difference form for a FEW lags at the two ends of the lag range -------------------------------
+// The spectral path's rounding error is the same absolute amount at every lag; relative to the MSD it is largest where
+// (origins x MSD) is smallest: the first lags (small displacement) and the last ones (few origins). A diffusive or ballistic
+// trajectory a little too long for the 1e-10 bound misses it at a handful of lags only — the whole call then used to go to
+// the difference kernel, O(F^2 E): seconds where the spectral path takes milliseconds. The completion step now asks
+// msd_fft.hip which lags miss the bound (lag_finish_dd_kernel: none beyond [1, k_lo] and [k_hi, max_lag]) and, when those
+// are at most LAG_ENDS_MAX per end, recomputes just them from the trajectory itself and writes them over the spectral
+// values: one pass over the trajectory for the low lags (a window of k_lo + 1 frames in registers per series), a few rows
+// for the high ones.
+constexpr int LAG_ENDS_MAX = 8;
+constexpr int LAG_ENDS_SLABS = 16;
+
+// part[(slab * kl + k - 1) * cols + c] = sum over the slab's origins t (t + k < F) of (r[t + k][c] - r[t][c])^2 * scale^2,
+// k = 1 .. kl; c = axis * E + entity. grid (ceil(cols / 256), LAG_ENDS_SLABS)
+__global__ __launch_bounds__(256) void lag_low_lags_kernel(const double *__restrict__ r, long long F, long long cols, double scale,
+                                                           int kl, double *__restrict__ part)
+{
+    const long long c = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    const long long t0 = F * blockIdx.y / gridDim.y, t1 = F * (blockIdx.y + 1) / gridDim.y;
+    double w[LAG_ENDS_MAX + 1], acc[LAG_ENDS_MAX];
+#pragma unroll
+    for (int k = 0; k < LAG_ENDS_MAX; ++k) acc[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k <= LAG_ENDS_MAX; ++k) w[k] = (k <= kl && t0 + k < F) ? r[(t0 + k) * cols + c] * scale : 0.0;
+    for (long long t = t0; t < t1; ++t) {
+#pragma unroll
+        for (int k = 1; k <= LAG_ENDS_MAX; ++k)
+            if (k <= kl && t + k < F) {
+                const double d = w[k] - w[0];
+                acc[k - 1] += d * d;
+            }
+#pragma unroll
+        for (int k = 0; k < LAG_ENDS_MAX; ++k) w[k] = w[k + 1];
+        // (the window's new last frame: t + 1 + kl; the slots above kl are never read)
+#pragma unroll
+        for (int k = 1; k <= LAG_ENDS_MAX; ++k)
+            if (k == kl) w[k] = t + 1 + kl < F ? r[(t + 1 + kl) * cols + c] * scale : 0.0;
+    }
+#pragma unroll
+    for (int k = 1; k <= LAG_ENDS_MAX; ++k)
+        if (k <= kl) part[((size_t)blockIdx.y * kl + (k - 1)) * cols + c] = acc[k - 1];
+}
+
+// part[j * cols + c] = sum over the F - k origins of lag k = k_hi + j (at most LAG_ENDS_MAX + ... origins each)
+__global__ __launch_bounds__(256) void lag_high_lags_kernel(const double *__restrict__ r, long long F, long long cols, double scale,
+                                                            long long k_hi, int n_hi, double *__restrict__ part)
+{
+    const long long c = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    for (int j = 0; j < n_hi; ++j) {
+        const long long k = k_hi + j;
+        double acc = 0.0;
+        for (long long t = 0; t + k < F; ++t) {
+            const double d = r[(t + k) * cols + c] * scale - r[t * cols + c] * scale;
+            acc += d * d;
+        }
+        part[(size_t)j * cols + c] = acc;
+    }
+}
+
+// rows[(i * G + g) * 4 + a] = (sum over the group's entities and the `slabs` partial rows of lag i) / ((F - k_i) n_g);
+// k_i = k0 + i. One block per (lag i, axis a, group g); the sum in a fixed order (per-lane strided, then a tree).
+__global__ __launch_bounds__(256) void lag_ends_fold_kernel(const double *__restrict__ part, int slabs, int n_rows, long long cols,
+                                                            long long E, const long long *__restrict__ goff, int G, long long F,
+                                                            long long k0, double *__restrict__ rows)
+{
+    __shared__ double red[256];
+    const int i = blockIdx.x, a = blockIdx.y, g = blockIdx.z;
+    const long long lo = goff[g], hi = goff[g + 1];
+    double s = 0.0;
+    for (int sl = 0; sl < slabs; ++sl) {
+        const double *p = part + ((size_t)sl * n_rows + i) * cols + (size_t)a * E;
+        for (long long e = lo + threadIdx.x; e < hi; e += 256) s += p[e];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double cnt = (double)(F - (k0 + i)) * (double)(hi - lo);
+        rows[((size_t)i * G + g) * 4 + a] = cnt > 0.0 ? red[0] / cnt : 0.0;
+    }
+}
+
+__global__ void lag_ends_total_kernel(double *__restrict__ rows, long long n)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) rows[4 * i + 3] = (rows[4 * i] + rows[4 * i + 1]) + rows[4 * i + 2];
+}
+
+// The lags 1 .. k_lo and k_hi .. max_lag of `out` [max_lag + 1][G][4] (host or device memory) from the difference form.
+// A synchronous call of its own (it runs inside the completion step of the spectral call, like the full fallback).
+static int lag_exact_ends(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r, int on_device, double scale,
+                          int max_lag, int n_groups, const int64_t *group_off, long long k_lo, long long k_hi, double *out,
+                          int out_on_device)
+{
+    CallScope cs(ctx);
+    const long long F = n_frames, E = n_ent, G = n_groups, cols = 3 * E;
+    const int kl = (int)k_lo, n_hi = (int)((long long)max_lag + 1 - k_hi);
+    MD_REQUIRE(kl >= 0 && kl <= LAG_ENDS_MAX && n_hi >= 0 && n_hi <= LAG_ENDS_MAX, "internal: %d + %d lags to recompute", kl, n_hi);
+    MD_HIP(hipSetDevice(ctx->device));
+    int rc = MDHIP_OK;
+    const size_t r_b = (size_t)F * 3 * E * 8;
+    const double *d_r = (const double *)mdhip_stage(ctx, WS_XYZ_I, r, r_b, on_device, &rc);
+    if (rc) return rc;
+    const size_t part_b = (size_t)std::max(kl * LAG_ENDS_SLABS, n_hi) * cols * 8, go_b = (size_t)(G + 1) * 8;
+    const size_t rows_b = (size_t)(kl + n_hi) * G * 4 * 8;
+    MD_WS(d_part, double, WS_PART, part_b + 256);
+    MD_WS(d_tab, unsigned char, WS_TABLES, go_b + rows_b + 64);
+    long long *d_goff = reinterpret_cast<long long *>(d_tab);
+    double *d_rows = reinterpret_cast<double *>(d_tab + go_b);
+    MD_PIN(h_goff, unsigned char, go_b);
+    memcpy(h_goff, group_off, go_b);
+    rc = mdhip_copy_small(ctx, d_goff, h_goff, go_b, hipMemcpyHostToDevice);
+    if (rc) return rc;
+    KernelTimer timer(ctx);
+    if (kl > 0) {
+        hipLaunchKernelGGL(lag_low_lags_kernel, dim3((unsigned)((cols + 255) / 256), LAG_ENDS_SLABS), dim3(256), 0, ctx->stream, d_r, F,
+                           cols, scale, kl, d_part);
+        hipLaunchKernelGGL(lag_ends_fold_kernel, dim3((unsigned)kl, 3, (unsigned)G), dim3(256), 0, ctx->stream, d_part,
+                           LAG_ENDS_SLABS, kl, cols, E, d_goff, (int)G, F, 1LL, d_rows);
+    }
+    if (n_hi > 0) {
+        hipLaunchKernelGGL(lag_high_lags_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, ctx->stream, d_r, F, cols, scale,
+                           k_hi, n_hi, d_part);
+        hipLaunchKernelGGL(lag_ends_fold_kernel, dim3((unsigned)n_hi, 3, (unsigned)G), dim3(256), 0, ctx->stream, d_part, 1, n_hi,
+                           cols, E, d_goff, (int)G, F, k_hi, d_rows + (size_t)kl * G * 4);
+    }
+    hipLaunchKernelGGL(lag_ends_total_kernel, dim3((unsigned)(((kl + n_hi) * G + 255) / 256)), dim3(256), 0, ctx->stream, d_rows,
+                       (long long)(kl + n_hi) * G);
+    MD_HIP(hipGetLastError());
+    timer.stop();
+    const size_t row_b = (size_t)G * 4 * 8;
+    if (kl > 0) {
+        rc = mdhip_result(cs, out + (size_t)1 * G * 4, d_rows, kl * row_b, out_on_device);
+        if (rc) return rc;
+    }
+    if (n_hi > 0) {
+        rc = mdhip_result(cs, out + (size_t)k_hi * G * 4, d_rows + (size_t)kl * G * 4, n_hi * row_b, out_on_device);
+        if (rc) return rc;
+    }
+    cs.defer([timer]() {
+        timer.collect();
+        return MDHIP_OK;
+    });
+    return cs.end();
+}
+
 // force_variant >= 0: that lag_variant instead of the context's option (the fallback of the spectral path)
 static int lag_msd_impl(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const double *r, int on_device,
                         double scale, int max_lag, int n_groups, const int64_t *group_off, double *out,
@@ -868,6 +1019,15 @@ static int lag_msd_impl(mdhip_ctx *ctx, int64_t n_frames, int64_t n_ent, const d
             ctx->last_rel_bound = res->bound;
             if (variant != 3 || res->bound <= 1e-10)
                 return res->delivered ? MDHIP_OK : deliver_host_values(ctx, res->out.data(), res_b, out, out_on_device);
+            // (round 6) too loose at a few lags of the two ends only: those from the difference form, the rest stands
+            if (ctx->opt_lag_ends != 0 && res->ends_valid && res->delivered && res->k_lo <= LAG_ENDS_MAX &&
+                (long long)max_lag + 1 - res->k_hi <= LAG_ENDS_MAX && res->bound_ok <= 1e-10) {
+                const int rc2 = lag_exact_ends(ctx, n_frames, n_ent, r, on_device, scale, max_lag, n_groups, res->group_off.data(),
+                                               res->k_lo, res->k_hi, out, out_on_device);
+                ctx->last_rel_bound = res->bound_ok;
+                ctx->last_kernel = "spectral + lag_low_lags_kernel (the lags that missed the bound from the difference form)";
+                return rc2;
+            }
             // bound too loose for this data (r and group_off are the caller's: valid until the call has completed)
             const int rc2 = lag_msd_impl(ctx, n_frames, n_ent, r, on_device, scale, max_lag, n_groups,
                                          res->group_off.data(), out, out_on_device, 1);

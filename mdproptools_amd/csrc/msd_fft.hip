@@ -1952,6 +1952,28 @@ __device__ __forceinline__ DD dd_neg(DD a) { return {-a.hi, -a.lo}; }
 // Q [3 G][F], corr [3 G][corr_row] (S2(k) = corr * corr_scale), n_g [G] entities per group -> out [n_lags][G][4] (device:
 // components 0..2 here, their total by lag_total_kernel), bound [3 G]; pre: workspace [3 G][F + 1] of DD.
 // One block per (axis, group) segment.
+// the relative bound a lag must keep for the spectral result to stand (lag_variant 3), and the words behind a call's
+// bounds: S bounds | 2 status words | per segment (lo_max, hi_min, the bound of the lags that keep LAG_BOUND_OK)
+constexpr double LAG_BOUND_OK = 1e-10;
+inline size_t lag_bound_words(long long S) { return (size_t)(4 * S + 2); }
+
+// what the completion step reads from the words a call copied back
+inline void lag_collect_bounds(LagFftResult *res, const double *h, long long S, long long n_lags)
+{
+    double worst = 0.0, lo = 0.0, hi = (double)n_lags, ok = 0.0;
+    for (long long q = 0; q < S; ++q) {
+        worst = std::max(worst, h[q]);
+        lo = std::max(lo, h[S + 2 + 3 * q]);
+        hi = std::min(hi, h[S + 2 + 3 * q + 1]);
+        ok = std::max(ok, h[S + 2 + 3 * q + 2]);
+    }
+    res->bound = worst;
+    res->k_lo = (long long)lo;
+    res->k_hi = (long long)hi;
+    res->bound_ok = ok;
+    res->ends_valid = true;
+}
+
 __global__ __launch_bounds__(256) void lag_finish_dd_kernel(const double *__restrict__ Q, const double *__restrict__ corr,
                                                            long long corr_row, double corr_scale, long long F, long long n_lags,
                                                            int G, const double *__restrict__ n_g, double eps_l,
@@ -1960,6 +1982,7 @@ __global__ __launch_bounds__(256) void lag_finish_dd_kernel(const double *__rest
 {
     __shared__ DD wtot[4];
     __shared__ double vmin_s[4];
+    __shared__ double ends_s[4][3];
     const int s = blockIdx.x, a = s / G, g = s % G, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const double ng = n_g[g];
     const long long chunk = (F + 255) / 256;
@@ -1995,6 +2018,13 @@ __global__ __launch_bounds__(256) void lag_finish_dd_kernel(const double *__rest
     __threadfence_block();
     __syncthreads();
     double vmin = 0.0;  // smallest non-zero |S1 - 2 S2| over the lags k > 0
+    // (round 6) which lags miss LAG_BOUND_OK: the transform's error is the same absolute amount at every lag, so a lag misses
+    // the bound iff its |S1 - 2 S2| lies below vthr. For diffusive and ballistic data those are the first few lags and the
+    // last few (few origins): lo_max = the largest such k in the lower half of the lag range, hi_min = the smallest one in the
+    // upper half, vok = the smallest |.| among the lags that keep the bound.
+    const double e2 = eps_l * (2.0 * (tot.hi + tot.lo)), vthr = e2 / LAG_BOUND_OK;
+    long long lo_max = 0, hi_min = n_lags;
+    double vok = 0.0;
     for (long long k = tid; k < n_lags; k += 256) {
         const DD s1 = dd_add(pre[F - k], dd_add(tot, dd_neg(pre[k])));
         const double s2 = corr[(size_t)s * corr_row + k] * corr_scale;
@@ -2005,17 +2035,45 @@ __global__ __launch_bounds__(256) void lag_finish_dd_kernel(const double *__rest
         out[((size_t)k * G + g) * 4 + a] = cnt > 0.0 ? v / cnt : 0.0;
         const double av = fabs(v);
         if (k > 0 && av != 0.0 && (vmin == 0.0 || av < vmin)) vmin = av;
+        if (k > 0 && av != 0.0) {
+            if (av < vthr) {
+                if (2 * k < n_lags) lo_max = k > lo_max ? k : lo_max;
+                else hi_min = k < hi_min ? k : hi_min;
+            } else if (vok == 0.0 || av < vok) {
+                vok = av;
+            }
+        }
     }
     for (int o = 32; o > 0; o >>= 1) {
         const double other = __shfl_down(vmin, o, 64);
         if (other != 0.0 && (vmin == 0.0 || other < vmin)) vmin = other;
     }
-    if (lane == 0) vmin_s[wv] = vmin;
+    for (int o = 32; o > 0; o >>= 1) {
+        const long long lo_o = __shfl_down(lo_max, o, 64), hi_o = __shfl_down(hi_min, o, 64);
+        const double vo = __shfl_down(vok, o, 64);
+        lo_max = lo_o > lo_max ? lo_o : lo_max;
+        hi_min = hi_o < hi_min ? hi_o : hi_min;
+        if (vo != 0.0 && (vok == 0.0 || vo < vok)) vok = vo;
+    }
+    if (lane == 0) {
+        vmin_s[wv] = vmin;
+        ends_s[wv][0] = (double)lo_max;
+        ends_s[wv][1] = (double)hi_min;
+        ends_s[wv][2] = vok;
+    }
     __syncthreads();
     if (tid == 0) {
-        double m = 0.0;
-        for (int w = 0; w < 4; ++w)
+        double m = 0.0, lo = 0.0, hi = (double)n_lags, ok = 0.0;
+        for (int w = 0; w < 4; ++w) {
             if (vmin_s[w] != 0.0 && (m == 0.0 || vmin_s[w] < m)) m = vmin_s[w];
+            lo = ends_s[w][0] > lo ? ends_s[w][0] : lo;
+            hi = ends_s[w][1] < hi ? ends_s[w][1] : hi;
+            if (ends_s[w][2] != 0.0 && (ok == 0.0 || ends_s[w][2] < ok)) ok = ends_s[w][2];
+        }
+        double *ends = bound + gridDim.x + 2 + 3 * s;  // (behind the S bounds and the two status words)
+        ends[0] = lo;
+        ends[1] = hi;
+        ends[2] = ok > 0.0 ? e2 / ok : 0.0;
         // the transform's rounding error in S2(k) scales with the energy of the WHOLE series at every lag: the worst
         // relative error is at the lag with the smallest |v| (2 pre[F] >= S1(k), equal at small lags)
         bound[s] = m > 0.0 ? eps_l * (2.0 * (tot.hi + tot.lo)) / m : 0.0;
@@ -2367,9 +2425,9 @@ int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r
     // the finish, on the device (lag_finish_dd_kernel): means into `d_fin`, from there to the caller's buffer on the
     // stream; only the bound of every group (and the ring's stall word) comes back for the completion step
     const size_t fin_b = (size_t)n_lags * G * 4 * 8;
-    MD_WS(d_fin_ws, unsigned char, WS_OUT3, fin_b + (size_t)(S + 2) * 8 + (size_t)S * (F + 1) * sizeof(DD) + 64);
+    MD_WS(d_fin_ws, unsigned char, WS_OUT3, fin_b + lag_bound_words(S) * 8 + (size_t)S * (F + 1) * sizeof(DD) + 64);
     double *d_fin = reinterpret_cast<double *>(d_fin_ws), *d_bound = d_fin + (size_t)n_lags * G * 4;
-    DD *d_pre = reinterpret_cast<DD *>(d_bound + S + 2);
+    DD *d_pre = reinterpret_cast<DD *>(d_bound + lag_bound_words(S));
     const double eps_l = 4.0 * 2.220446049250313e-16 * std::log2((double)L);
     hipLaunchKernelGGL(lag_finish_dd_kernel, dim3((unsigned)S), dim3(256), 0, ctx->stream, d_Q, d_corr, n_lags, 1.0, F, n_lags,
                        (int)G, d_ng, eps_l, d_pre, d_fin, d_bound);
@@ -2382,11 +2440,11 @@ int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r
         const int rcr = mdhip_result(cs, out, d_fin, fin_b, out_on_device);
         if (rcr) return rcr;
     }
-    MD_PIN(h_bound, double, (size_t)S * 8 + 8);
-    unsigned *h_stall = reinterpret_cast<unsigned *>(h_bound + S);
+    MD_PIN(h_bound, double, lag_bound_words(S) * 8 + 8);
+    unsigned *h_stall = reinterpret_cast<unsigned *>(h_bound + lag_bound_words(S));
     *h_stall = 0u;
     {
-        const int rcc = mdhip_copy_small(ctx, h_bound, d_bound, (size_t)S * 8, hipMemcpyDeviceToHost);
+        const int rcc = mdhip_copy_small(ctx, h_bound, d_bound, lag_bound_words(S) * 8, hipMemcpyDeviceToHost);
         if (rcc) return rcc;
     }
     if (staged) {
@@ -2411,9 +2469,7 @@ int lag_msd_fft_fused(CallScope &cs, long long F, long long E, const double *d_r
                                    : "msd_power_lds_kernel (repeated over the transposed copy: a cluster member did not run)";
             return rc3;
         }
-        double worst = 0.0;
-        for (long long q = 0; q < S; ++q) worst = std::max(worst, h_bound[q]);
-        res->bound = worst;
+        lag_collect_bounds(res.get(), h_bound, S, n_lags);
         return MDHIP_OK;
     });
     return MDHIP_OK;
@@ -2664,9 +2720,9 @@ int lag_msd_fft_residue(CallScope &cs, long long F, long long E, const double *d
 
     // the finish, on the device, as the fused kernels'
     const size_t fin_b = (size_t)n_lags * G * 4 * 8;
-    MD_WS(d_fin_ws, unsigned char, WS_OUT3, fin_b + (size_t)(S + 2) * 8 + (size_t)S * (F + 1) * sizeof(DD) + 64);
+    MD_WS(d_fin_ws, unsigned char, WS_OUT3, fin_b + lag_bound_words(S) * 8 + (size_t)S * (F + 1) * sizeof(DD) + 64);
     double *d_fin = reinterpret_cast<double *>(d_fin_ws), *d_bound = d_fin + (size_t)n_lags * G * 4;
-    DD *d_pre = reinterpret_cast<DD *>(d_bound + S + 2);
+    DD *d_pre = reinterpret_cast<DD *>(d_bound + lag_bound_words(S));
     const double eps_l = 4.0 * 2.220446049250313e-16 * std::log2((double)LP);
     hipLaunchKernelGGL(lag_finish_dd_kernel, dim3((unsigned)S), dim3(256), 0, ctx->stream, d_Q, d_corr, n_lags, 1.0, F, n_lags,
                        (int)G, d_ng, eps_l, d_pre, d_fin, d_bound);
@@ -2678,16 +2734,14 @@ int lag_msd_fft_residue(CallScope &cs, long long F, long long E, const double *d
         const int rcr = mdhip_result(cs, out, d_fin, fin_b, out_on_device);
         if (rcr) return rcr;
     }
-    MD_PIN(h_bound, double, (size_t)S * 8);
+    MD_PIN(h_bound, double, lag_bound_words(S) * 8);
     {
-        const int rcc = mdhip_copy_small(ctx, h_bound, d_bound, (size_t)S * 8, hipMemcpyDeviceToHost);
+        const int rcc = mdhip_copy_small(ctx, h_bound, d_bound, lag_bound_words(S) * 8, hipMemcpyDeviceToHost);
         if (rcc) return rcc;
     }
-    cs.defer([timer, res, h_bound, S]() {
+    cs.defer([timer, res, h_bound, S, n_lags]() {
         timer.collect();
-        double worst = 0.0;
-        for (long long q = 0; q < S; ++q) worst = std::max(worst, h_bound[q]);
-        res->bound = worst;
+        lag_collect_bounds(res.get(), h_bound, S, n_lags);
         return MDHIP_OK;
     });
     return MDHIP_OK;
@@ -2856,9 +2910,9 @@ int mdhip_lag_msd_fft(CallScope &cs, int64_t n_frames, int64_t n_ent, const doub
     // the finish, on the device: means into `d_fin`, from there to the caller's buffer on the stream; only the segments'
     // bounds come back for the completion step (as lag_msd_fft_fused)
     const size_t fin_b = (size_t)n_lags * G * 4 * 8;
-    MD_WS(d_fin_ws, unsigned char, WS_OUT3, fin_b + (size_t)(S + 2) * 8 + (size_t)S * (F + 1) * sizeof(DD) + 64);
+    MD_WS(d_fin_ws, unsigned char, WS_OUT3, fin_b + lag_bound_words(S) * 8 + (size_t)S * (F + 1) * sizeof(DD) + 64);
     double *d_fin = reinterpret_cast<double *>(d_fin_ws), *d_bound = d_fin + (size_t)n_lags * G * 4;
-    DD *d_pre = reinterpret_cast<DD *>(d_bound + S + 2);
+    DD *d_pre = reinterpret_cast<DD *>(d_bound + lag_bound_words(S));
     const double eps_l = 4.0 * 2.220446049250313e-16 * std::log2((double)L);
     hipLaunchKernelGGL(lag_finish_dd_kernel, dim3((unsigned)S), dim3(256), 0, ctx->stream, d_Q, d_corr, L, 1.0 / (double)L, F,
                        n_lags, (int)G, d_ng, eps_l, d_pre, d_fin, d_bound);
@@ -2870,16 +2924,14 @@ int mdhip_lag_msd_fft(CallScope &cs, int64_t n_frames, int64_t n_ent, const doub
         const int rcr = mdhip_result(cs, out, d_fin, fin_b, out_on_device);
         if (rcr) return rcr;
     }
-    MD_PIN(h_bound, double, (size_t)S * 8);
+    MD_PIN(h_bound, double, lag_bound_words(S) * 8);
     {
-        const int rcc = mdhip_copy_small(ctx, h_bound, d_bound, (size_t)S * 8, hipMemcpyDeviceToHost);
+        const int rcc = mdhip_copy_small(ctx, h_bound, d_bound, lag_bound_words(S) * 8, hipMemcpyDeviceToHost);
         if (rcc) return rcc;
     }
-    cs.defer([timer, res, h_bound, S]() {
+    cs.defer([timer, res, h_bound, S, n_lags]() {
         timer.collect();
-        double worst = 0.0;
-        for (long long q = 0; q < S; ++q) worst = std::max(worst, h_bound[q]);
-        res->bound = worst;
+        lag_collect_bounds(res.get(), h_bound, S, n_lags);
         return MDHIP_OK;
     });
     return MDHIP_OK;

@@ -1059,13 +1059,16 @@ def msd_step_sharded_async(r_f, r_e, n_frames_total, entity_range, group_off, ta
             status = flat[nS + nW + nL + 1]  # (the SUM of the ranks' bounds: at least the largest of them)
             if not (status <= 1e-10):
                 # some rank's spectral result is not good enough (or was rewritten at completion): every rank sees the same
-                # reduced status, so every rank repeats the lag part with the exact-difference kernel, together
+                # reduced status, so every rank repeats the lag part, together, under lag_variant 3 — the library's own
+                # decision per call (round 6): the spectral result stands where the rank's bound holds (the status is the SUM
+                # of the ranks' bounds: it can pass the tolerance with every rank inside it), the few lags that miss it are
+                # recomputed from the difference form, and only data that misses it broadly goes to the difference kernel
                 flat = flat.copy()
                 lag_part = torch.zeros(nL, dtype=torch.float64, device=dev)
                 with torch.cuda.stream(_step_stream(dev, ctx, post=True)):
                     if x is not None:
                         user_variant = ctx.get_option("lag_variant", -1)
-                        ctx.set_option("lag_variant", 1)
+                        ctx.set_option("lag_variant", 3)
                         try:
                             m2 = torch.empty((n_lags, len(held), 4), dtype=torch.float64, device=dev)
                             backend.lag_msd(x, max_lag, loc_off - loc_off[0], scale=lag_scale, out=m2, ctx=ctx)

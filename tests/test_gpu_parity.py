@@ -520,6 +520,63 @@ def test_lag_msd_fft_every_transform_size(B):
         ctx.set_option("lag_w1", -1)
 
 
+def test_lag_variant3_repairs_the_few_lags_that_miss_the_bound(B):
+    """Round 6: the spectral path's error is the same absolute amount at every lag, so relative to the MSD it is largest at
+    the first lags (small displacement) and the last ones (few origins). When the 1e-10 bound is missed at no more than 8
+    lags per end, the default (lag_variant 3) recomputes THOSE lags from the difference form (lag_low_lags_kernel /
+    lag_high_lags_kernel, csrc/msd.hip) and lets the rest of the spectral result stand, instead of handing the whole call
+    to the O(F^2) difference kernel: long random walks through the residue-class and the batched paths, a walk riding on a
+    slow oscillation through the fused kernel. The repaired rows equal the difference kernel's to 1e-12, every other row is
+    the spectral path's bit for bit, the reported bound is that of the rows that stood (<= 1e-10); host, device and
+    asynchronous results agree; `lag_ends` 0 restores the whole-call fallback; ballistic data still takes it."""
+    import torch
+
+    ctx = B.default_context()
+    rng = np.random.default_rng(91)
+    cases = []
+    for F, E, goff in ((24576, 30, [0, 10, 30]), (30000, 20, [0, 20])):
+        cases.append((np.cumsum(rng.normal(0, 0.1, (F, 3, E)), axis=0) + rng.uniform(-50, 50, (1, 3, E)), goff))
+    F, E = 5000, 60
+    t = np.arange(F)[:, None, None]
+    cases.append((np.cumsum(rng.normal(0, 0.1, (F, 3, E)), axis=0) + 9.0 * np.sin(2 * np.pi * t / F + rng.uniform(0, 6.28, (1, 3, E))),
+                  [0, 25, 60]))
+    try:
+        for r, goff in cases:
+            F = r.shape[0]
+            ctx.set_option("lag_variant", 1)
+            exact = B.lag_msd(r, F - 1, goff)
+            ctx.set_option("lag_variant", 2)
+            spec = B.lag_msd(r, F - 1, goff)
+            assert ctx.last_rel_bound() > 1e-10, (F, ctx.last_rel_bound())  # (else the case tests nothing)
+            ctx.set_option("lag_variant", 3)
+            got = B.lag_msd(r, F - 1, goff)
+            bound = ctx.last_rel_bound()
+            assert "lag_low_lags_kernel" in ctx.last_kernel_name() and 0.0 < bound <= 1e-10, (F, ctx.last_kernel_name(), bound)
+            changed = np.where(np.any(got != spec, axis=(1, 2)))[0]
+            assert len(changed) and all(k <= 8 or k >= F - 8 for k in changed), (F, changed)
+            np.testing.assert_allclose(got[changed], exact[changed], rtol=1e-12)
+            nz = exact > 0
+            assert (np.abs(got[nz] - exact[nz]) / exact[nz]).max() <= bound, (F, bound)
+            out = torch.empty((F, len(goff) - 1, 4), dtype=torch.float64, device="cuda")
+            B.lag_msd(torch.from_numpy(r).cuda(), F - 1, goff, out=out, async_=True).wait()
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(out.cpu().numpy(), got)
+            ctx.set_option("lag_ends", 0)
+            whole = B.lag_msd(r, F - 1, goff)
+            assert ctx.last_kernel_name().startswith("lag_msd_") and ctx.last_rel_bound() == 0.0
+            np.testing.assert_array_equal(whole, exact)
+            ctx.set_option("lag_ends", -1)
+        # ballistic motion: the bound fails over a long run of lags — the whole call goes to the difference kernel as before
+        F, E = 3000, 12
+        r = np.arange(F)[:, None, None] * rng.normal(0, 0.05, (1, 3, E)) + rng.uniform(-5, 5, (1, 3, E))
+        ctx.set_option("lag_variant", 3)
+        got = B.lag_msd(r, F - 1, [0, E])
+        assert ctx.last_kernel_name().startswith("lag_msd_") and ctx.last_rel_bound() == 0.0
+    finally:
+        ctx.set_option("lag_variant", 1)
+        ctx.set_option("lag_ends", -1)
+
+
 def test_lag_msd_short_series_one_wave_per_series(B):
     """Round 6: trajectories of at most 1536 frames (F + max_lag <= 3072) run msd_power_w1_kernel — padded length 1024, 2048 or
     3072, one wave per series, residue classes of the spectrum. Every padded length on both sides of its limits,
