@@ -192,10 +192,20 @@ def test_msd_step_async_equals_sync(env):
     t = torch.arange(F, device="cuda", dtype=torch.float64)[:, None, None]
     rb = (t * torch.rand((1, 3, E), generator=g, device="cuda", dtype=torch.float64) + 500.0).contiguous()
     ref_b = B.lag_msd(rb, F - 1, goff, scale=1.0, ctx=ctx)
-    assert ctx.last_rel_bound() == 0.0 and "lag_msd" in ctx.last_kernel_name()
+    # (round 6: the difference form answers — for the whole call, or, when only a few lags at the ends of the range miss
+    # the bound, for those lags: the reported bound is then that of the spectral rows that stood)
+    assert ctx.last_rel_bound() <= 1e-10 and ("lag_msd" in ctx.last_kernel_name() or "lag_low_lags" in ctx.last_kernel_name())
+    bound_b = ctx.last_rel_bound()
     got_b = B.lag_msd(rb, F - 1, goff, scale=1.0, ctx=ctx, async_=True).wait()
     np.testing.assert_array_equal(got_b, ref_b)
-    assert ctx.last_rel_bound() == 0.0
+    assert ctx.last_rel_bound() == bound_b
+    ctx.set_option("lag_variant", 1)
+    try:
+        exact_b = B.lag_msd(rb, F - 1, goff, scale=1.0, ctx=ctx)
+    finally:
+        ctx.set_option("lag_variant", -1)
+    nzb = exact_b > 0
+    assert (np.abs(ref_b[nzb] - exact_b[nzb]) / exact_b[nzb]).max() <= max(bound_b, 1e-13)
 
 
 def test_full_lag_in_kernel_transposition_pipelined(env):
@@ -481,7 +491,8 @@ def test_lag_status_word_on_the_device(env):
     B.lag_msd(r, F - 1, [0, E], out=out, ctx=ctx, async_=True, status_out=st).wait()
     assert float(st.cpu()[0]) == ctx.last_rel_bound() and 0.0 < ctx.last_rel_bound() <= 1e-10
     B.lag_msd(rb, F - 1, [0, E], out=out, ctx=ctx, async_=True, status_out=st).wait()
-    assert float(st.cpu()[0]) > 1e-10 and ctx.last_rel_bound() == 0.0  # (the exact kernel answered at completion)
+    assert float(st.cpu()[0]) > 1e-10 and ctx.last_rel_bound() <= 1e-10  # (the difference form answered at completion: for the
+    # whole call, or for the few lags that missed the bound)
     ctx.set_option("lag_variant", 1)
     try:
         B.lag_msd(r, F - 1, [0, E], out=out, ctx=ctx, async_=True, status_out=st).wait()
