@@ -221,7 +221,7 @@ struct mdhip_ctx {
                                   // transform kernel of batch k runs on the others (CU-masked streams; 2: whatever the size, tests);
                                   // 0 (default) one after the other — measured: 16.7 against 13.2 ms at F = 10 000, a quarter of the CUs
                                   // moves 1.7 TB/s where the whole chip moves 4.8 (profiles/r06_ab_lag_overlap.txt)
-    int opt_lag_ends = 1;         // lag_variant 3 with the bound missed at <= 8 lags per end of the lag range: 1 (default) those lags from the
+    int opt_lag_ends = 1;         // lag_variant 3 with the bound missed at <= 24 lags per end of the lag range: 1 (default) those lags from the
                                   // difference form, the rest of the spectral result stands; 0 the whole call to the difference kernel
     int opt_lag_batch_mb = 4096;  // batched full-lag path: device memory of one batch of series (centred series + transform buffers), MB
     int opt_lag_w12_min_f = 1536;  // full-lag MSD with 2048 < F + max_lag <= 8192: from this many frames on the 12288-point

@@ -800,10 +800,10 @@ static int deliver_host_values(mdhip_ctx *ctx, const double *src, size_t bytes, 
 // trajectory a little too long for the 1e-10 bound misses it at a handful of lags only — the whole call then used to go to
 // the difference kernel, O(F^2 E): seconds where the spectral path takes milliseconds. The completion step now asks
 // msd_fft.hip which lags miss the bound (lag_finish_dd_kernel: none beyond [1, k_lo] and [k_hi, max_lag]) and, when those
-// are at most LAG_ENDS_MAX per end, recomputes just them from the trajectory itself and writes them over the spectral
+// are at most LAG_ENDS_MAX (24) per end, recomputes just them from the trajectory itself and writes them over the spectral
 // values: one pass over the trajectory for the low lags (a window of k_lo + 1 frames in registers per series), a few rows
 // for the high ones.
-constexpr int LAG_ENDS_MAX = 8;
+constexpr int LAG_ENDS_MAX = 24;
 constexpr int LAG_ENDS_SLABS = 16;
 
 // part[(slab * kl + k - 1) * cols + c] = sum over the slab's origins t (t + k < F) of (r[t + k][c] - r[t][c])^2 * scale^2,
