@@ -33,7 +33,7 @@ for s in "$@"; do
     pmc_c3_cn) timeout -k 10 900 bash tools/pmc.sh ${ROUND}_c3_cn C3/cn --scaling strong --op cn > $O/pmc_c3_cn.log 2>&1; echo "pmc rc=$?" ;;
     pmc_c3_both) timeout -k 10 900 bash tools/pmc.sh ${ROUND}_c3_both C3/rdf_cn --scaling strong --op rdf_cn > $O/pmc_c3_both.log 2>&1; echo "pmc rc=$?" ;;
     pmc2) timeout -k 10 1150 bash tools/pmc_secondary.sh ${ROUND} > $O/pmc2.log 2>&1; echo "pmc2 rc=$?"; tail -3 $O/pmc2.log ;;
-    soaks) ( timeout -k 10 500 python tests/bench/soak_pk.py 2500 5 oracle 2>&1 | tail -2; timeout -k 10 400 python tests/bench/soak_cn.py 1000 2>&1 | tail -2; timeout -k 10 300 python tests/bench/soak_cull.py 1000 2>&1 | tail -2; timeout -k 10 400 python tests/bench/soak_lag.py 300 2>&1 | tail -2; timeout -k 10 600 python tests/bench/soak_lag_long.py 120 2>&1 | tail -3; timeout -k 10 600 python tests/bench/soak_lag_short.py 600 2>&1 | tail -2; timeout -k 10 200 python tests/bench/soak_fft.py 2>&1 | tail -2 ) > $O/${ROUND}_soaks.txt 2>&1; cat $O/${ROUND}_soaks.txt ;;
+    soaks) ( timeout -k 10 500 python tests/bench/soak_pk.py 2500 5 oracle 2>&1 | tail -2; timeout -k 10 400 python tests/bench/soak_cn.py 1000 2>&1 | tail -2; timeout -k 10 300 python tests/bench/soak_cull.py 1000 2>&1 | tail -2; timeout -k 10 400 python tests/bench/soak_lag.py 300 2>&1 | tail -2; timeout -k 10 600 python tests/bench/soak_lag_long.py 120 2>&1 | tail -3; timeout -k 10 600 python tests/bench/soak_lag_short.py 600 2>&1 | tail -2; timeout -k 10 600 python tests/bench/soak_lag_ends.py 150 2>&1 | tail -2; timeout -k 10 200 python tests/bench/soak_fft.py 2>&1 | tail -2 ) > $O/${ROUND}_soaks.txt 2>&1; cat $O/${ROUND}_soaks.txt ;;
     stats) (cd /tmp && export TMPDIR=/tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o ${ROUND}_bench -- python3 $R/bench.py --no-cpu-baseline --no-legs > $O/bench_line_rocprof.json 2> $O/rocprof_err.log); echo "stats rc=$?" ;;
     stats_legs) (cd /tmp && export TMPDIR=/tmp && timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o ${ROUND}_bench_legs -- python3 $R/bench.py --no-cpu-baseline > $O/bench_line_rocprof_legs.json 2> $O/rocprof_legs_err.log); echo "stats_legs rc=$?"; tail -2 $O/rocprof_legs_err.log ;;
     ab_lag) timeout -k 10 400 python tools/ab_libs_lag.py $LP $L 2>&1 | grep -v amdgpu > $O/${ROUND}_ab_lag_${TAG}.txt; cat $O/${ROUND}_ab_lag_${TAG}.txt ;;
