@@ -1949,9 +1949,6 @@ __device__ __forceinline__ DD dd_add_d(DD a, double b)
 }
 __device__ __forceinline__ DD dd_neg(DD a) { return {-a.hi, -a.lo}; }
 
-// Q [3 G][F], corr [3 G][corr_row] (S2(k) = corr * corr_scale), n_g [G] entities per group -> out [n_lags][G][4] (device:
-// components 0..2 here, their total by lag_total_kernel), bound [3 G]; pre: workspace [3 G][F + 1] of DD.
-// One block per (axis, group) segment.
 // the relative bound a lag must keep for the spectral result to stand (lag_variant 3), and the words behind a call's
 // bounds: S bounds | 2 status words | per segment (lo_max, hi_min, the bound of the lags that keep LAG_BOUND_OK)
 constexpr double LAG_BOUND_OK = 1e-10;
@@ -1974,6 +1971,10 @@ inline void lag_collect_bounds(LagFftResult *res, const double *h, long long S, 
     res->ends_valid = true;
 }
 
+// Q [3 G][F], corr [3 G][corr_row] (S2(k) = corr * corr_scale), n_g [G] entities per group -> out [n_lags][G][4] (device:
+// components 0..2 here, their total by lag_total_kernel), bound [lag_bound_words(3 G)]: the segments' bounds, two status
+// words (lag_total_kernel), and per segment which lags miss LAG_BOUND_OK; pre: workspace [3 G][F + 1] of DD.
+// One block per (axis, group) segment.
 __global__ __launch_bounds__(256) void lag_finish_dd_kernel(const double *__restrict__ Q, const double *__restrict__ corr,
                                                            long long corr_row, double corr_scale, long long F, long long n_lags,
                                                            int G, const double *__restrict__ n_g, double eps_l,

@@ -21,6 +21,15 @@
 //   -- barrier --
 // The frequencies are sorted out once per block (Ppart [rows][L'/2 + 1]); msd_residue_inverse_kernel turns the folded spectra
 // into correlations by direct summation in double-double (a handful of segments: 12 288 terms per lag).
+//
+// What this file holds, in the order of the text (DESIGN.md 4.4b has the measurements):
+//   msd_power_w12r_kernel<4>     the first form described above: classes 0, 1, 2 (option lag_residue 2, kept for A/B);
+//   msd_power_w12p_kernel<SHARE> the default for F <= 12 288: TWO transforms per series — the even frequencies as
+//                                msd_power_w12_kernel's packed transform (bilinear sums, partner phase), the odd ones as class 1;
+//   msd_power_w12o_kernel<R>     12 288 < F <= 24 576 (L' = 8 x 6144, the series folded once by the transposition): the odd
+//                                frequencies, classes 1 and 3 (mod 8); the even ones are msd_power_w12p_kernel<false> over the folded rows;
+//   msd_power_w1_kernel<D2>      F <= 1536: the 512-point sub-transform as the whole transform, one wave per series;
+//   msd_residue_inverse_kernel   the correlations of a non-power-of-two length, directly.
 
 #ifndef W12R_EXP
 #define W12R_EXP 0  // timing experiments only (WRONG results): 1 no input stage, 2 no head, 4 no register passes
